@@ -1,0 +1,123 @@
+/* gz_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C) of the Genozip entropy-coding hot path that genozip_amd implements in HIP.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+ * library (genozip_amd/csrc -> libgenozip_amd.so) never links or calls it.
+ *
+ * Every function cites the reference file:line whose behaviour it restates (paths relative to /root/reference).
+ * Parity status: the rANS-4x16 / arith codecs are PINNED byte-for-byte against the reference's own vendored
+ * htscodecs sources compiled in place (oracle/_ref, see oracle/Makefile and tests/golden/). The Genozip-authored
+ * pieces (b250 VARL, local transforms, section framing) are pinned only by the hand-derived KATs of SURVEY.md
+ * Appendix A -- beyond those: PARITY UNPINNED (the reference ships no fixtures and cannot be built here).
+ */
+#ifndef GZ_ORACLE_H
+#define GZ_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* htscodecs order-byte flags (src/htscodecs/arith_dynamic.h:43-50) */
+#define GZO_X_PACK   0x80
+#define GZO_X_RLE    0x40
+#define GZO_X_CAT    0x20
+#define GZO_X_NOSZ   0x10
+#define GZO_X_STRIPE 0x08
+#define GZO_X_EXT    0x04
+#define GZO_X_ORDER  0x03
+
+/* Genozip codec ids = file-format values (src/genozip.h:325-360) */
+enum { GZO_CODEC_UNKNOWN = 0, GZO_CODEC_NONE = 1, GZO_CODEC_RANB = 6, GZO_CODEC_RANW = 7, GZO_CODEC_RANb = 8,
+       GZO_CODEC_RANw = 9, GZO_CODEC_ARTB = 16, GZO_CODEC_ARTW = 17, GZO_CODEC_ARTb = 18, GZO_CODEC_ARTw = 19 };
+
+/* ---- htscodecs level (rows a12-a14) ---- */
+uint32_t gzo_rans_bound  (uint32_t size, int order);              /* rANS_static4x16pr.c:357 */
+uint32_t gzo_arith_bound (uint32_t size, int order);              /* arith_dynamic.c:74      */
+
+/* return compressed length, or -1 when out_cap < bound (the reference's NULL return) */
+long gzo_rans_compress   (const uint8_t *in, uint32_t in_size, uint8_t *out, uint32_t out_cap, int order); /* rANS_static4x16pr.c:1151 */
+long gzo_arith_compress  (const uint8_t *in, uint32_t in_size, uint8_t *out, uint32_t out_cap, int order); /* arith_dynamic.c:615      */
+/* return number of bytes decoded (== out_len on success) or -1 on malformed input */
+long gzo_rans_uncompress (const uint8_t *in, uint32_t in_size, uint8_t *out, uint32_t out_len);           /* rANS_static4x16pr.c:1358 */
+long gzo_arith_uncompress(const uint8_t *in, uint32_t in_size, uint8_t *out, uint32_t out_len);           /* arith_dynamic.c:860      */
+
+/* diagnostic: the e10/e12 ratio compute_shift() saw in the most recent order-1 rANS call of this thread
+ * (rANS_static4x16pr.c:681) -- tests use it to prove inputs are far from the 1.01 decision boundary */
+double gzo_last_shift_ratio (void);
+
+/* ---- codec plugin surface (rows a10/a11; src/codec.h:17-40, src/codec_htscodecs.c:17-33,77-123) ---- */
+uint32_t gzo_codec_est_size (int codec, uint64_t uncompressed_len);
+/* returns 1 on success; 0 if *out_len (capacity) < est_size and soft_fail; -1 on any other error */
+int gzo_codec_compress   (int codec, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t *out_len, int soft_fail);
+int gzo_codec_uncompress (int codec, const uint8_t *in, uint32_t in_len, uint8_t *out, uint64_t out_len);
+/* many independent streams on a pthread pool (the CPU baseline of bench.py): returns 0 if all succeeded */
+int gzo_codec_compress_many (int n, const int *codecs, const uint8_t *const *ins, const uint32_t *in_lens,
+                             uint8_t *const *outs, uint32_t *out_lens /* in: capacity, out: length */, int n_threads);
+
+/* deterministic stand-in for codec_assign_best_codec (src/codec.c:234-363): smallest framed size on
+ * the first min(len,99999) bytes, ties -> lower codec id; returns GZO_CODEC_UNKNOWN when len < 50 */
+int gzo_codec_assign_best (const uint8_t *in, uint32_t in_len, uint32_t *sizes_out /* [9] or NULL */);
+
+/* ---- b250 (rows a2, a5; src/b250.c:60-110,112-163,202-267) ---- */
+/* seg-time encoding of one entry (little endian, type tag in LAST byte); new nodes (>= ol_nodes_len) always 4 B.
+ * returns bytes written (1..4) */
+uint32_t gzo_b250_seg_put (uint8_t *dst, int32_t node_index, uint32_t ol_nodes_len);
+/* PIZ-format big-endian encoding of one word index (tag in first byte); returns bytes written */
+uint32_t gzo_b250_piz_put (uint8_t *dst, int32_t wi);
+/* b250_zip_generate: seg-format buffer -> PIZ VARL format. node2word[i] is the word_index of VB-local node
+ * (ol_nodes_len + i). out must hold seg_len bytes. Returns output length (<= seg_len), -1 on malformed input. */
+long gzo_b250_generate (const uint8_t *seg, uint32_t seg_len, uint32_t ol_nodes_len,
+                        const int32_t *node2word, uint32_t n_new_nodes, uint8_t *out);
+/* decode a PIZ VARL stream into word indices (ONE_UP resolved); returns count or -1 */
+long gzo_b250_piz_decode (const uint8_t *b, uint32_t len, int32_t *wi_out, uint32_t wi_cap);
+
+/* ---- local generation (rows a6, a7; src/zip.c:167-219, src/buffer.c:336-350, src/context.h:99-101,
+ *      src/dyn_int.c:45-132) ---- */
+enum { GZO_LT_INT8 = 1, GZO_LT_UINT8 = 2, GZO_LT_INT16 = 3, GZO_LT_UINT16 = 4, GZO_LT_INT32 = 5, GZO_LT_UINT32 = 6,
+       GZO_LT_INT64 = 7, GZO_LT_UINT64 = 8, GZO_LT_FLOAT32 = 9, GZO_LT_FLOAT64 = 10, GZO_LT_BLOB = 11,
+       GZO_LT_BITMAP = 12, GZO_LT_UINT8_TR = 14, GZO_LT_UINT16_TR = 15, GZO_LT_UINT32_TR = 16 };
+uint32_t gzo_lt_width (int ltype);
+/* in-place: native little-endian elements -> file byte order (BGEN, interlace). n = element count */
+int  gzo_local_to_file_order (int ltype, void *data, uint64_t n);
+/* rows x cols -> cols x rows of `width`-byte elements (element bytes untouched) */
+void gzo_transpose (const void *src, void *dst, uint32_t rows, uint32_t cols, uint32_t width);
+/* full zip_generate_local for integer ltypes: returns final ltype (e.g. LT_UINT8_TR when transposed) */
+int  gzo_local_generate (int ltype, void *data, uint64_t n, uint32_t transpose_cols /*0 = no transpose*/, void *scratch);
+uint8_t gzo_bitmap_param (uint64_t nbits); /* zip.c:181 */
+
+/* ---- section framing (rows a9, a10, a16; src/sections.h:146-167,342-369,419-435, src/compressor.c:55-58,
+ *      114-161, src/zfile.c:288-395,1108-1144) ---- */
+uint32_t gzo_adler32 (uint32_t adler, const uint8_t *buf, size_t len); /* == libdeflate_adler32, compressor.c:161 */
+
+typedef struct {
+    uint32_t vblock_i;       /* 1-based */
+    uint8_t  section_type;   /* 11 = SEC_B250, 12 = SEC_LOCAL (src/genozip.h:378-379) */
+    uint8_t  codec;          /* requested codec; < 50 B payload is rewritten to CODEC_NONE (compressor.c:56-58) */
+    uint8_t  sub_codec;
+    uint8_t  flags;          /* struct FlagsCtx packed LSB first (sections.h:99-118) */
+    uint8_t  ltype;
+    uint8_t  param;
+    uint8_t  b250_size_or_nothing_char;
+    uint8_t  dict_id[8];
+} GzoCtxSectionDesc;
+
+#define GZO_SECTION_HEADER_LEN     28
+#define GZO_CTX_SECTION_HEADER_LEN 40
+#define GZO_VB_HEADER_LEN          84
+#define GZO_MAGIC                  0x27052012u
+
+/* comp_compress for a SEC_B250 / SEC_LOCAL section: header(40) || payload appended at z; returns total bytes
+ * appended or -1. z_cap = remaining capacity. */
+long gzo_section_compress (const GzoCtxSectionDesc *d, const uint8_t *data, uint32_t data_len, uint8_t *z, uint64_t z_cap);
+/* 84-byte VB header (no payload): zfile_compress_vb_header; z_data_bytes patched later by gzo_vb_header_patch */
+void gzo_vb_header_write (uint8_t *z, uint32_t vblock_i, uint32_t recon_size, uint32_t longest_line_len,
+                          uint32_t longest_seq_len, const uint8_t digest[16], uint8_t flags);
+void gzo_vb_header_patch (uint8_t *z, uint32_t z_data_bytes); /* zfile.c:1139-1144 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

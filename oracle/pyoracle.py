@@ -1,0 +1,222 @@
+"""pyoracle.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes bindings for (a) oracle/liboracle.so, this repo's CPU restatement of the hot path, and (b), when present,
+oracle/_ref/libhtsref.so, the reference's own vendored htscodecs sources compiled in place (see oracle/Makefile).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; nothing under
+genozip_amd/ does.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(_HERE, "liboracle.so")
+REF_SO = os.path.join(_HERE, "_ref", "libhtsref.so")
+
+CODEC_NONE, CODEC_RANB, CODEC_RANW, CODEC_RANb, CODEC_RANw = 1, 6, 7, 8, 9
+CODEC_ARTB, CODEC_ARTW, CODEC_ARTb, CODEC_ARTw = 16, 17, 18, 19
+SIMPLE_CODECS = (CODEC_RANB, CODEC_RANW, CODEC_RANb, CODEC_RANw, CODEC_ARTB, CODEC_ARTW, CODEC_ARTb, CODEC_ARTw)
+CODEC_ORDER = {6: 0x01, 7: 0x19, 8: 0x81, 9: 0x99, 16: 0x01, 17: 0x19, 18: 0x81, 19: 0x99}
+CODEC_NAME = {1: "NONE", 6: "RANB", 7: "RANW", 8: "RANb", 9: "RANw", 16: "ARTB", 17: "ARTW", 18: "ARTb", 19: "ARTw"}
+
+
+def build(ref=True):
+    """make liboracle.so, and _ref/libhtsref.so when the reference sources are available (never at run time on
+    the GPU box, which only uses the prebuilt files)."""
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+    if ref and os.path.isdir("/root/reference/src/htscodecs"):
+        subprocess.run(["make", "-s", "-C", _HERE, "ref"], check=True)
+
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def _buf(b):
+    return (ctypes.c_uint8 * max(1, len(b))).from_buffer_copy(bytes(b) if len(b) else b"\0")
+
+
+class GzoCtxSectionDesc(ctypes.Structure):
+    _fields_ = [("vblock_i", ctypes.c_uint32), ("section_type", ctypes.c_uint8), ("codec", ctypes.c_uint8),
+                ("sub_codec", ctypes.c_uint8), ("flags", ctypes.c_uint8), ("ltype", ctypes.c_uint8),
+                ("param", ctypes.c_uint8), ("b250_size_or_nothing_char", ctypes.c_uint8),
+                ("dict_id", ctypes.c_uint8 * 8)]
+
+
+class Oracle:
+    """this repo's CPU restatement"""
+
+    def __init__(self, path=ORACLE_SO):
+        if not os.path.exists(path):
+            build(ref=False)
+        L = self.L = ctypes.CDLL(path)
+        for n in ("gzo_rans_compress", "gzo_arith_compress", "gzo_rans_uncompress", "gzo_arith_uncompress",
+                  "gzo_b250_generate", "gzo_b250_piz_decode", "gzo_section_compress"):
+            getattr(L, n).restype = ctypes.c_long
+        L.gzo_last_shift_ratio.restype = ctypes.c_double
+        for n in ("gzo_rans_bound", "gzo_arith_bound", "gzo_codec_est_size", "gzo_adler32", "gzo_b250_seg_put",
+                  "gzo_b250_piz_put", "gzo_lt_width"):
+            getattr(L, n).restype = ctypes.c_uint32
+        L.gzo_codec_est_size.argtypes = [ctypes.c_int, ctypes.c_uint64]
+        L.gzo_adler32.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
+
+    # ---- htscodecs level
+    def hts_compress(self, kind, data, order):
+        data = bytes(data)
+        bound = (self.L.gzo_rans_bound if kind == "rans" else self.L.gzo_arith_bound)(len(data), order) + 1024
+        out = ctypes.create_string_buffer(bound)
+        f = self.L.gzo_rans_compress if kind == "rans" else self.L.gzo_arith_compress
+        n = f(data, len(data), out, bound, order)
+        if n < 0:
+            raise RuntimeError("oracle %s compress failed" % kind)
+        return out.raw[:n]
+
+    def hts_uncompress(self, kind, comp, out_len):
+        comp = bytes(comp)
+        out = ctypes.create_string_buffer(max(1, out_len))
+        f = self.L.gzo_rans_uncompress if kind == "rans" else self.L.gzo_arith_uncompress
+        n = f(comp, len(comp), out, out_len)
+        if n != out_len:
+            raise RuntimeError("oracle %s uncompress failed (%d)" % (kind, n))
+        return out.raw[:out_len]
+
+    def last_shift_ratio(self):
+        return self.L.gzo_last_shift_ratio()
+
+    # ---- codec level
+    def est_size(self, codec, n):
+        return self.L.gzo_codec_est_size(codec, n)
+
+    def codec_compress(self, codec, data, cap=None, soft_fail=False):
+        data = bytes(data)
+        cap = self.est_size(codec, len(data)) if cap is None else cap
+        out = ctypes.create_string_buffer(max(1, cap))
+        ol = ctypes.c_uint32(cap)
+        rc = self.L.gzo_codec_compress(codec, data, len(data), out, ctypes.byref(ol), int(soft_fail))
+        if rc == 0:
+            return None
+        if rc != 1:
+            raise RuntimeError("oracle codec_compress failed")
+        return out.raw[:ol.value]
+
+    def codec_uncompress(self, codec, comp, out_len):
+        comp = bytes(comp)
+        out = ctypes.create_string_buffer(max(1, out_len))
+        if self.L.gzo_codec_uncompress(codec, comp, len(comp), out, ctypes.c_uint64(out_len)) != 1:
+            raise RuntimeError("oracle codec_uncompress failed")
+        return out.raw[:out_len]
+
+    def codec_compress_many(self, codecs, datas, n_threads):
+        n = len(datas)
+        ins = [bytes(d) for d in datas]
+        caps = [self.est_size(c, len(d)) for c, d in zip(codecs, ins)]
+        outs = [ctypes.create_string_buffer(max(1, c)) for c in caps]
+        a_codecs = (ctypes.c_int * n)(*codecs)
+        a_ins = (ctypes.c_char_p * n)(*ins)
+        a_lens = (ctypes.c_uint32 * n)(*[len(d) for d in ins])
+        a_outs = (ctypes.c_void_p * n)(*[ctypes.addressof(o) for o in outs])
+        a_olens = (ctypes.c_uint32 * n)(*caps)
+        if self.L.gzo_codec_compress_many(n, a_codecs, a_ins, a_lens, a_outs, a_olens, n_threads) != 0:
+            raise RuntimeError("oracle compress_many failed")
+        return [o.raw[:l] for o, l in zip(outs, a_olens)]
+
+    def assign_best(self, data):
+        data = bytes(data)
+        sizes = (ctypes.c_uint32 * 9)()
+        c = self.L.gzo_codec_assign_best(data, len(data), sizes)
+        return c, list(sizes)
+
+    # ---- b250
+    def b250_seg(self, node_indices, ol_nodes_len):
+        out = bytearray()
+        tmp = ctypes.create_string_buffer(4)
+        for ni in node_indices:
+            n = self.L.gzo_b250_seg_put(tmp, int(ni), ol_nodes_len)
+            assert n
+            out += tmp.raw[:n]
+        return bytes(out)
+
+    def b250_piz(self, wis):
+        out = bytearray()
+        tmp = ctypes.create_string_buffer(4)
+        for wi in wis:
+            n = self.L.gzo_b250_piz_put(tmp, int(wi))
+            out += tmp.raw[:n]
+        return bytes(out)
+
+    def b250_generate(self, seg, ol_nodes_len, node2word):
+        seg = bytes(seg)
+        n2w = (ctypes.c_int32 * max(1, len(node2word)))(*node2word)
+        out = ctypes.create_string_buffer(max(1, len(seg)))
+        n = self.L.gzo_b250_generate(seg, len(seg), ol_nodes_len, n2w, len(node2word), out)
+        if n < 0:
+            raise RuntimeError("oracle b250_generate failed")
+        return out.raw[:n]
+
+    def b250_decode(self, piz):
+        piz = bytes(piz)
+        wi = (ctypes.c_int32 * max(1, len(piz)))()
+        n = self.L.gzo_b250_piz_decode(piz, len(piz), wi, len(piz))
+        if n < 0:
+            raise RuntimeError("oracle b250 decode failed")
+        return list(wi[:n])
+
+    # ---- local
+    def local_generate(self, ltype, raw_native_le, transpose_cols=0):
+        w = self.L.gzo_lt_width(ltype)
+        buf = ctypes.create_string_buffer(bytes(raw_native_le), max(1, len(raw_native_le)))
+        scratch = ctypes.create_string_buffer(max(1, len(raw_native_le)))
+        lt = self.L.gzo_local_generate(ltype, buf, ctypes.c_uint64(len(raw_native_le) // w), transpose_cols, scratch)
+        return lt, buf.raw[:len(raw_native_le)]
+
+    # ---- sections
+    def adler32(self, data, start=1):
+        data = bytes(data)
+        return self.L.gzo_adler32(start, data, len(data))
+
+    def section_compress(self, desc, data):
+        data = bytes(data)
+        cap = 40 + self.est_size(desc.codec, len(data)) + 64
+        z = ctypes.create_string_buffer(cap)
+        n = self.L.gzo_section_compress(ctypes.byref(desc), data, len(data), z, ctypes.c_uint64(cap))
+        if n < 0:
+            raise RuntimeError("oracle section_compress failed")
+        return z.raw[:n]
+
+
+class Ref:
+    """the reference's vendored htscodecs, compiled in place (only where oracle/_ref was built)"""
+
+    def __init__(self, path=REF_SO):
+        self.L = ctypes.CDLL(path)
+        for n in ("htsref_rans_compress", "htsref_arith_compress", "htsref_rans_uncompress", "htsref_arith_uncompress"):
+            getattr(self.L, n).restype = ctypes.c_long
+        self.L.htsref_rans_bound.restype = ctypes.c_uint32
+        self.L.htsref_arith_bound.restype = ctypes.c_uint32
+
+    @staticmethod
+    def available():
+        return os.path.exists(REF_SO)
+
+    def hts_compress(self, kind, data, order, extra_cap=1024):
+        data = bytes(data)
+        bound = (self.L.htsref_rans_bound if kind == "rans" else self.L.htsref_arith_bound)(len(data), order) + extra_cap
+        out = ctypes.create_string_buffer(bound)
+        f = self.L.htsref_rans_compress if kind == "rans" else self.L.htsref_arith_compress
+        n = f(data, len(data), out, bound, order)
+        if n < 0:
+            raise RuntimeError("ref %s compress failed" % kind)
+        return out.raw[:n]
+
+    def hts_uncompress(self, kind, comp, out_len):
+        comp = bytes(comp)
+        out = ctypes.create_string_buffer(max(1, out_len))
+        f = self.L.htsref_rans_uncompress if kind == "rans" else self.L.htsref_arith_uncompress
+        n = f(comp, len(comp), out, out_len)
+        if n != out_len:
+            raise RuntimeError("ref %s uncompress failed (%d)" % (kind, n))
+        return out.raw[:out_len]
+
+    def codec_compress(self, codec, data):
+        kind = "rans" if codec < 16 else "arith"
+        return self.hts_compress(kind, data, CODEC_ORDER[codec])

@@ -1,0 +1,96 @@
+/* ref_shim.c -- TEST INFRASTRUCTURE ONLY (not shipped, not linked into the product library).
+ *
+ * Five-symbol shim that lets the reference's vendored htscodecs sources
+ * (/root/reference/src/htscodecs/{rANS_static4x16pr,arith_dynamic,pack,rle}.c, BSD licensed, compiled
+ * IN PLACE - never copied into this repo) link into oracle/_ref/libhtsref.so without the rest of Genozip.
+ *
+ * The reference routes its scratch allocations through codec_alloc()/codec_free() (src/codec.h:143-147,
+ * src/codec.c:30-63) and MALLOC/FREE (src/buf_struct.h:222-227) and its assertions through
+ * error_assert_failed() (src/genozip.h:747). Here they are plain malloc/free/abort.
+ *
+ * This file is authored for this repo; it contains no reference code.
+ */
+#include <stdint.h>
+#include <stdbool.h>
+#include <stdlib.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+
+void *codec_alloc_do (void *vb, uint64_t size, float grow_at_least_factor, unsigned *buf_i,
+                      const char *func, uint32_t code_line)
+{
+    (void)vb; (void)grow_at_least_factor; (void)func; (void)code_line;
+    if (buf_i) *buf_i = 0;
+    return malloc (size ? size : 1);
+}
+
+void codec_free_do (void *vb, void *addr, const char *func, uint32_t code_line)
+{
+    (void)vb; (void)func; (void)code_line;
+    free (addr);
+}
+
+void *buf_low_level_malloc (size_t size, bool zero, const char *func, uint32_t code_line)
+{
+    (void)func; (void)code_line;
+    return zero ? calloc (size ? size : 1, 1) : malloc (size ? size : 1);
+}
+
+void buf_low_level_free (void *p, const char *func, uint32_t code_line)
+{
+    (void)func; (void)code_line;
+    free (p);
+}
+
+void error_assert_failed (const char *func, uint32_t code_line, const char *format, ...)
+{
+    va_list ap;
+    va_start (ap, format);
+    fprintf (stderr, "htsref assertion failed in %s:%u: ", func, code_line);
+    vfprintf (stderr, format, ap);
+    fprintf (stderr, "\n");
+    va_end (ap);
+    abort ();
+}
+
+/* ---- flat entry points used by the python test harness (ctypes) and by bench.py's cpu_baseline ---- */
+
+extern unsigned char *rans_compress_to_4x16 (void *vb, unsigned char *in, unsigned int in_size,
+                                             unsigned char *out, unsigned int *out_size, int order);
+extern unsigned char *rans_uncompress_to_4x16 (void *vb, unsigned char *in, unsigned int in_size,
+                                               unsigned char *out, unsigned int *out_size);
+extern unsigned int rans_compress_bound_4x16 (unsigned int size, int order);
+extern unsigned char *arith_compress_to (void *vb, unsigned char *in, unsigned int in_size,
+                                         unsigned char *out, unsigned int *out_size, int order);
+extern unsigned char *arith_uncompress_to (void *vb, unsigned char *in, unsigned int in_size,
+                                           unsigned char *out, unsigned int *out_size);
+extern unsigned int arith_compress_bound (unsigned int size, int order);
+
+/* returns compressed length, or -1 if the reference signalled "output buffer too small" */
+long htsref_rans_compress (const unsigned char *in, unsigned in_size, unsigned char *out, unsigned out_cap, int order)
+{
+    unsigned out_size = out_cap;
+    return rans_compress_to_4x16 (NULL, (unsigned char *)in, in_size, out, &out_size, order) ? (long)out_size : -1;
+}
+
+long htsref_arith_compress (const unsigned char *in, unsigned in_size, unsigned char *out, unsigned out_cap, int order)
+{
+    unsigned out_size = out_cap;
+    return arith_compress_to (NULL, (unsigned char *)in, in_size, out, &out_size, order) ? (long)out_size : -1;
+}
+
+long htsref_rans_uncompress (const unsigned char *in, unsigned in_size, unsigned char *out, unsigned out_len)
+{
+    unsigned out_size = out_len;
+    return rans_uncompress_to_4x16 (NULL, (unsigned char *)in, in_size, out, &out_size) ? (long)out_size : -1;
+}
+
+long htsref_arith_uncompress (const unsigned char *in, unsigned in_size, unsigned char *out, unsigned out_len)
+{
+    unsigned out_size = out_len;
+    return arith_uncompress_to (NULL, (unsigned char *)in, in_size, out, &out_size) ? (long)out_size : -1;
+}
+
+unsigned htsref_rans_bound  (unsigned size, int order) { return rans_compress_bound_4x16 (size, order); }
+unsigned htsref_arith_bound (unsigned size, int order) { return arith_compress_bound (size, order); }
