@@ -1,0 +1,119 @@
+// gz_device.h -- structures shared by the host orchestrator and the gfx950 kernels of libgenozip_amd.so
+//
+// Vocabulary (follows the reference): a *stream* is one codec call == the payload of one b250/local section
+// (src/codec.h:17-27); a striped codec (RANW/RANw/ARTW/ARTw) splits it into 4 byte *planes*
+// (src/htscodecs/rANS_static4x16pr.c:1165-1227, arith_dynamic.c:636-753) and tries several methods per plane; each
+// (plane, method) pair - or the whole stream for the unstriped codecs - is a *leaf*: one independent entropy-coding
+// job. Leaves are the unit of GPU parallelism: the coders are serial per leaf, so throughput comes from running
+// thousands of leaves (VBlocks x contexts x planes x methods) at once.
+#pragma once
+#include <stdint.h>
+
+#define GZ_X_PACK   0x80
+#define GZ_X_RLE    0x40
+#define GZ_X_CAT    0x20
+#define GZ_X_NOSZ   0x10
+#define GZ_X_STRIPE 0x08
+
+#define GZ_ENG_NONE  0
+#define GZ_ENG_RANS  1
+#define GZ_ENG_ARITH 2
+
+#define GZ_TAB_CAP     (257 * 257 * 3 + 1024)   // order-1 frequency table bytes (rans_compress_bound_4x16)
+#define GZ_ROW_SLOT    768                      // serialised bytes of one order-1 row: <= 256 * (2 + zero-run)
+#define GZ_PREFIX_CAP  32
+
+// encoder-side description of one (context, symbol): x' = x + bias + ((x * rcp) >> rsh) * cmpl
+// (src/htscodecs/rANS_word.h:169-265; 16 bytes instead of the reference's 24)
+struct GzRansSym { uint32_t x_max, rcp, bias, cmpl_rsh; };   // cmpl_rsh = cmpl | (rsh - 32) << 16
+
+struct GzdStream {
+    const uint8_t  *in;
+    const uint32_t *in_len_dev;
+    uint8_t  *out;            // payload destination (batch mode) / scratch (vb mode: final copy goes to z_data)
+    uint8_t  *planes;         // n bytes, striped codecs only
+    uint32_t in_len;          // planning upper bound
+    uint32_t out_cap;
+    uint32_t n;               // resolved length
+    uint32_t out_len;         // result: payload bytes
+    int32_t  status;
+    int32_t  codec_req;
+    uint32_t first_leaf, n_leaves;
+    uint8_t  codec;           // effective codec (< 50 B -> NONE in section mode)
+    uint8_t  engine, order, striped;
+    uint8_t  best_leaf[4];    // index (relative to first_leaf) of the winning leaf of each plane
+    uint8_t  whole_leaf;      // index (relative to first_leaf) of the leaf that codes the unstriped stream
+    uint32_t plane_unit_len[4];
+    // section / VBlock mode
+    int32_t  vb;              // -1 in batch mode
+    uint32_t sec_in_vb;
+    uint64_t z_off;           // where the 40-byte header of this section starts inside the VB's z_data
+    uint8_t  hdr[40];         // SectionHeaderCtx template; lengths, codec and digest are patched on device
+};
+
+struct GzdLeaf {
+    uint32_t stream;
+    uint8_t  plane;           // 0..3, or 0xff = whole stream
+    uint8_t  method;          // htscodecs order byte of this leaf (without STRIPE)
+    uint8_t  engine;
+    // resolved by k_leaf_prep:
+    uint8_t  active;
+    uint8_t  flag;            // final first byte of the unit
+    uint8_t  o1, rle, packed_on, cat;
+    uint8_t  prefix_len;
+    uint8_t  shift_bits;      // rANS order-1: 10 or 12
+    uint8_t  prefix[GZ_PREFIX_CAP];    // flag [varint n] [pack meta] [varint packed n]
+    const uint8_t *src;  uint32_t n;
+    const uint8_t *coded; uint32_t coded_n;   // bytes the entropy coder sees (== packed or src)
+    uint32_t max_sym;         // arith: 1 + largest byte
+    uint32_t nsym;            // distinct coded byte values
+    uint8_t  symlist[256];    // ascending
+    uint16_t symrank[256];    // value -> rank, 0xffff if absent (rank 255 is a legal rank)
+    uint32_t tab_len, pay_len, unit_len;
+    int32_t  overflow;        // payload alone already > coded_n => CAT
+    // scratch owned by this leaf (device pointers; NULL when the method does not need it)
+    uint8_t   *packed;        // coded bytes after PACK (n + 1)
+    uint32_t  *F;             // histogram: 256 (order 0) or 256*256 (order 1) counters, + 256 row totals
+    GzRansSym *syms;          // 256 or 256*256 records
+    uint8_t   *rowbuf;        // order-1: GZ_ROW_SLOT bytes per context while serialising; also nested table coder scratch
+    uint8_t   *tab;           // serialised frequency table
+    uint8_t   *pay;           // entropy-coded payload area (rANS fills it from the end)
+    uint32_t  *models;        // arith: global-memory models when they do not fit the LDS
+    uint32_t  pay_cap;
+};
+
+struct GzdVB {
+    uint8_t *z_data; uint64_t z_cap; uint64_t z_len;
+    uint32_t first_stream, n_streams;
+    uint32_t vblock_i, recon_size, longest_line_len, longest_seq_len;
+    uint8_t  digest[16];
+    uint8_t  vb_flags;
+    int32_t  status;
+};
+
+// ---- decode side ----
+struct GzdDecStream {
+    const uint8_t  *in; uint32_t in_len;
+    uint8_t  *out; uint32_t out_len;   // exact expected length
+    uint8_t  *tmp_planes;              // out_len bytes: plane buffer (striped)
+    uint8_t  *tmp_packed;              // out_len bytes per leaf slot x4: packed intermediate
+    int32_t  codec, status;
+    uint32_t first_leaf;               // 4 decode leaves reserved per stream
+    uint8_t  striped, engine, n_leaves, pad;
+};
+
+struct GzdDecLeaf {
+    uint32_t stream;
+    uint8_t  active, engine, o1, rle, cat, packed_on, per, shift_bits;
+    uint8_t  map[16];
+    const uint8_t *body; uint32_t body_len;   // after the unit's prefix
+    uint8_t  *dst; uint32_t coded_n;          // entropy decoder output (packed tmp or final plane / out)
+    uint8_t  *final_dst; uint32_t n;          // after unpack
+    int32_t  status;
+    // scratch
+    uint8_t  *lut;        // rANS: o0: 4096 * 4 B {sym,freq,off}; o1: 256 << bits sym bytes
+    uint32_t *fc;         // rANS o1: 256*256 {freq | cum << 16}
+    uint8_t  *tabtmp;     // uncompressed order-1 table
+    uint32_t *models;
+    const uint8_t *pay; uint32_t pay_len;     // start of the 4 states
+};

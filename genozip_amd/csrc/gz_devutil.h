@@ -1,0 +1,113 @@
+// gz_devutil.h -- small device helpers shared by the encode and decode kernels
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gz_device.h"
+
+// status values kept in GzdStream.status while a batch is in flight
+#define GZ_ST_PENDING   2
+#define GZ_ST_OK        1
+#define GZ_ST_TOO_SMALL 0
+#define GZ_ST_CORRUPT   (-5)
+
+// All LDS scratch lives in the dynamic region (keeps its base 16-byte aligned; cdna_hip_programming.md G17)
+extern __shared__ __attribute__((aligned(16))) uint8_t gz_lds[];
+
+__host__ __device__ static inline int gz_codec_order (int codec)   // codec_htscodecs.c:17-20
+{
+    switch (codec) {
+        case 6: case 16: return 0x01;
+        case 7: case 17: return 0x19;
+        case 8: case 18: return 0x81;
+        case 9: case 19: return 0x99;
+        default: return -1;
+    }
+}
+
+// plane k of an n-byte stream holds bytes k, k+4, ... : len[k] = n/4 + (n%4 > k)   (rANS_static4x16pr.c:1178-1181)
+__host__ __device__ static inline void gz_plane_geometry (uint32_t n, uint32_t *len, uint32_t *off)
+{
+    uint32_t o = 0;
+    for (uint32_t k = 0; k < 4; k++) { len[k] = n / 4 + ((n % 4) > k); off[k] = o; o += len[k]; }
+}
+
+__host__ __device__ static inline uint32_t gz_vi_len (uint32_t v)
+{
+    return v < (1u << 7) ? 1 : v < (1u << 14) ? 2 : v < (1u << 21) ? 3 : v < (1u << 28) ? 4 : 5;
+}
+
+// 7-bit groups, most significant first (varint.h:206-240)
+__host__ __device__ static inline uint32_t gz_vi_put (uint8_t *dst, uint32_t v)
+{
+    uint32_t n = gz_vi_len (v);
+    for (uint32_t k = 0; k < n; k++) {
+        uint32_t sh = 7 * (n - 1 - k);
+        dst[k] = (uint8_t)(((v >> sh) & 0x7f) | (k + 1 < n ? 0x80 : 0));
+    }
+    return n;
+}
+
+// returns bytes consumed, 0 on truncation
+__host__ __device__ static inline uint32_t gz_vi_get (const uint8_t *src, uint32_t avail, uint32_t *v)
+{
+    uint32_t acc = 0, n = 0;
+    while (n < avail && n < 6) {
+        uint8_t c = src[n++];
+        acc = (acc << 7) | (c & 0x7f);
+        if (!(c & 0x80)) { *v = acc; return n; }
+    }
+    *v = acc;
+    return 0;
+}
+
+__host__ __device__ static inline uint32_t gz_pow2_ceil (uint32_t v)   // 0 -> 0
+{
+    v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16;
+    return v + 1;
+}
+
+__host__ __device__ static inline void gz_be32 (uint8_t *p, uint32_t v)
+{
+    p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v;
+}
+
+__host__ __device__ static inline uint32_t gz_rd_be32 (const uint8_t *p)
+{
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+}
+
+// adler32 (start value 1) of `len` bytes by a 256-thread workgroup. Thread t sums a contiguous slice:
+// A = sum d_j, B = sum (m-j) d_j ; slices combine as a' = a + A, b' = b + m*a + B (mod 65521).
+// Uses the first 2 KB + 8 bytes of gz_lds. Result valid in every thread.
+__device__ static inline uint32_t gz_adler32_wg (const uint8_t *data, uint32_t len, int tid)
+{
+    uint32_t *sA = (uint32_t *)gz_lds, *sB = sA + 256, *res = sA + 512;
+    uint32_t slice = (len + 255) / 256;
+    uint32_t lo = tid * slice, hi = lo + slice < len ? lo + slice : len;
+    uint64_t A = 0, B = 0;
+    if (lo < hi) {
+        uint32_t m = hi - lo;
+        for (uint32_t j = 0; j < m; j++) {
+            uint32_t d = data[lo + j];
+            A += d;
+            B += (uint64_t)(m - j) * d;
+        }
+    }
+    __syncthreads ();
+    sA[tid] = (uint32_t)(A % 65521u);
+    sB[tid] = (uint32_t)(B % 65521u);
+    __syncthreads ();
+    if (!tid) {
+        uint64_t a = 1, b = 0;
+        for (int t = 0; t < 256; t++) {
+            uint32_t l = t * slice, h = l + slice < len ? l + slice : len;
+            if (l >= h) break;
+            uint64_t m = h - l;
+            b = (b + (m % 65521u) * a + sB[t]) % 65521u;
+            a = (a + sA[t]) % 65521u;
+        }
+        res[0] = (uint32_t)((b << 16) | a);
+    }
+    __syncthreads ();
+    return res[0];
+}

@@ -1,0 +1,711 @@
+// gz_host.cpp -- host orchestrator + C-ABI of libgenozip_amd.so (compiled by hipcc together with the kernels).
+//
+// The reference runs one VBlock per pthread and calls codec_args[codec].compress once per section
+// (src/zip.c:510-601, src/compressor.c:18). Here the host only PLANS: it turns a table of streams (sections) into
+// a table of leaves (independent entropy-coding jobs), carves their scratch out of one HBM arena, uploads both
+// tables and queues ~10 kernels on one HIP stream; every kernel covers all leaves of the whole batch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <math.h>
+#include <vector>
+#include <string>
+
+#include "../../include/genozip_amd.h"
+#include "gz_device.h"
+#include "gz_devutil.h"
+#include "gz_kernels_enc.h"
+#include "gz_kernels_dec.h"
+#include "gz_kernels_ctx.h"
+
+#define GZ_VERSION "genozip_amd 0.1 (gfx950; format parity: genozip 15.0.86)"
+
+// ---------------------------------------------------------------------------------------------------------
+// handle, arena
+// ---------------------------------------------------------------------------------------------------------
+struct Pending {          // results to hand back at gz_sync()
+    int kind;             // 0 compress batch, 1 uncompress batch, 2 vb batch
+    void *user; int n;
+    void *dev_streams;    // GzdStream* / GzdDecStream*
+    void *dev_vbs;        // GzdVB*
+    size_t n_dev_streams;
+};
+
+struct ArenaBlock { uint8_t *base; size_t size, used; };
+
+struct GzHandle {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    std::vector<ArenaBlock> blocks;
+    std::vector<Pending> pending;
+    std::vector<void *> host_tmp;      // host staging to free at sync
+    GzLogTable *d_logs;
+    std::string err;
+    size_t arena_block_size;
+};
+
+#define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    (h)->err = std::string (#call) + ": " + hipGetErrorString (e_); return GZ_ERR_HIP; } } while (0)
+
+static const size_t ARENA_ALIGN = 256;
+
+static void *arena_alloc (GzHandle *h, size_t bytes)
+{
+    bytes = (bytes + ARENA_ALIGN - 1) & ~(ARENA_ALIGN - 1);
+    if (!bytes) bytes = ARENA_ALIGN;
+    for (auto &b : h->blocks)
+        if (b.size - b.used >= bytes) { void *p = b.base + b.used; b.used += bytes; return p; }
+    size_t sz = h->arena_block_size;
+    while (sz < bytes) sz *= 2;
+    ArenaBlock nb; nb.size = sz; nb.used = bytes;
+    if (hipMalloc ((void **)&nb.base, sz) != hipSuccess) {
+        // fall back to an exact-size block before giving up
+        nb.size = bytes;
+        if (hipMalloc ((void **)&nb.base, bytes) != hipSuccess) { h->err = "hipMalloc failed (arena)"; return NULL; }
+    }
+    h->blocks.push_back (nb);
+    return nb.base;
+}
+
+static void arena_reset (GzHandle *h)
+{
+    // keep the blocks (the steady state re-uses them), just rewind
+    for (auto &b : h->blocks) b.used = 0;
+}
+
+extern "C" const char *gz_version (void) { return GZ_VERSION; }
+
+extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount (&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        if (err) *err = GZ_ERR_NO_DEVICE;   // no CPU fallback: the caller must have a GPU
+        return NULL;
+    }
+    if (hipSetDevice (device) != hipSuccess) { if (err) *err = GZ_ERR_HIP; return NULL; }
+    GzHandle *h = new GzHandle ();
+    h->device = device;
+    h->arena_block_size = (size_t)256 << 20;
+    if (hip_stream) { h->stream = (hipStream_t)hip_stream; h->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags (&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; if (err) *err = GZ_ERR_HIP; return NULL; }
+        h->own_stream = true;
+    }
+    // log(1024+k), log(4096+k) from the host libm: what the reference's compute_shift() sees (rANS_static4x16pr.c:647)
+    GzLogTable lt;
+    for (int k = 0; k <= 256; k++) { lt.l10[k] = log (1024.0 + k); lt.l12[k] = log (4096.0 + k); }
+    if (hipMalloc ((void **)&h->d_logs, sizeof (lt)) != hipSuccess ||
+        hipMemcpy (h->d_logs, &lt, sizeof (lt), hipMemcpyHostToDevice) != hipSuccess) {
+        if (h->own_stream) hipStreamDestroy (h->stream);
+        delete h; if (err) *err = GZ_ERR_HIP; return NULL;
+    }
+    if (err) *err = GZ_OK;
+    return h;
+}
+
+extern "C" void gz_destroy (GzHandle *h)
+{
+    if (!h) return;
+    hipSetDevice (h->device);
+    hipStreamSynchronize (h->stream);
+    for (auto &b : h->blocks) hipFree (b.base);
+    for (auto p : h->host_tmp) free (p);
+    hipFree (h->d_logs);
+    if (h->own_stream) hipStreamDestroy (h->stream);
+    delete h;
+}
+
+extern "C" const char *gz_last_error (GzHandle *h) { return h ? h->err.c_str () : "no handle"; }
+extern "C" void *gz_stream (GzHandle *h) { return h ? (void *)h->stream : NULL; }
+
+// ---------------------------------------------------------------------------------------------------------
+// bounds (host copies of the reference's arithmetic: rANS_static4x16pr.c:357-369, arith_dynamic.c:74-80,
+// codec_htscodecs.c:26-33)
+// ---------------------------------------------------------------------------------------------------------
+static uint32_t rans_bound (uint32_t size, int order)
+{
+    int sz = (int)((order == 0 ? 1.05 * size + 257 * 3 + 4 : 1.05 * size + 257 * 257 * 3 + 4 + 257 * 3 + 4)
+                   + ((order & GZ_X_PACK) ? 1 : 0) + ((order & GZ_X_RLE) ? 1 + 257 * 3 + 4 : 0) + 20
+                   + ((order & GZ_X_STRIPE) ? 1 + 5 * 4 : 0));
+    return (uint32_t)(sz + (sz & 1) + 2);
+}
+
+static uint32_t arith_bound (uint32_t size, int order)
+{
+    return (uint32_t)((order == 0 ? 1.05 * size + 257 * 3 + 4 : 1.05 * size + 257 * 257 * 3 + 4 + 257 * 3 + 4)
+                      + ((order & GZ_X_PACK) ? 1 : 0) + ((order & GZ_X_RLE) ? 1 + 257 * 3 + 4 : 0) + 5);
+}
+
+static bool codec_is_rans  (int c) { return c >= 6 && c <= 9; }
+static bool codec_is_arith (int c) { return c >= 16 && c <= 19; }
+static bool codec_ok       (int c) { return c == GZ_CODEC_NONE || codec_is_rans (c) || codec_is_arith (c); }
+
+extern "C" uint32_t gz_codec_est_size (int codec, uint64_t len)
+{
+    if (codec == GZ_CODEC_NONE) return (uint32_t)len;
+    if (codec_is_rans (codec))  return 1024 + rans_bound  ((uint32_t)len, gz_codec_order (codec));
+    if (codec_is_arith (codec)) return 1024 + arith_bound ((uint32_t)len, gz_codec_order (codec));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// planning: streams -> leaves
+// ---------------------------------------------------------------------------------------------------------
+struct Plan {
+    std::vector<GzdStream> streams;
+    std::vector<GzdLeaf>   leaves;
+    bool any_striped = false, any_rans = false, any_arith = false;
+    uint32_t max_in = 0;
+};
+
+static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int plane, int method, uint32_t n_bound)
+{
+    GzdLeaf L;
+    memset (&L, 0, sizeof (L));
+    L.stream = stream; L.plane = (uint8_t)plane; L.method = (uint8_t)method; L.engine = (uint8_t)engine;
+    const bool o1 = method & 1, pack = method & GZ_X_PACK;
+    if (pack) { if (!(L.packed = (uint8_t *)arena_alloc (h, (size_t)n_bound + 16))) return false; }
+    L.pay_cap = n_bound + 64;
+    if (!(L.pay = (uint8_t *)arena_alloc (h, L.pay_cap))) return false;
+    if (engine == GZ_ENG_RANS) {
+        if (!(L.F    = (uint32_t *)arena_alloc (h, (o1 ? 256 * 256 + 256 : 256) * sizeof (uint32_t)))) return false;
+        if (!(L.syms = (GzRansSym *)arena_alloc (h, (o1 ? 256 * 256 : 256) * sizeof (GzRansSym)))) return false;
+        if (!(L.tab  = (uint8_t *)arena_alloc (h, o1 ? GZ_TAB_CAP : 1024))) return false;
+        if (o1 && !(L.rowbuf = (uint8_t *)arena_alloc (h, 256 * GZ_ROW_SLOT))) return false;
+    }
+    else {
+        const bool rle = method & GZ_X_RLE;
+        size_t words = (size_t)(o1 ? 256 : 1) * 257 + (rle ? GZ_ARITH_RUN_MODELS * GZ_ARITH_RUN_STRIDE : 0);
+        if (!(L.models = (uint32_t *)arena_alloc (h, words * 4))) return false;
+    }
+    P.leaves.push_back (L);
+    return true;
+}
+
+// leaves of one stream. Candidate methods per plane: rANS tries {O1, RLE, PACK, O0} masked by the caller's order
+// (rANS_static4x16pr.c:1203-1206); arith tries a fixed list per plane (arith_dynamic.c:684-687).
+static bool plan_stream_leaves (GzHandle *h, Plan &P, uint32_t si)
+{
+    GzdStream &S = P.streams[si];
+    const int codec = S.codec_req, order = gz_codec_order (codec);
+    S.first_leaf = (uint32_t)P.leaves.size ();
+    S.n_leaves = 0; S.whole_leaf = 0;
+    if (codec == GZ_CODEC_NONE) return true;
+    const int engine = codec_is_rans (codec) ? GZ_ENG_RANS : GZ_ENG_ARITH;
+    const uint32_t n = S.in_len;
+    (engine == GZ_ENG_RANS ? P.any_rans : P.any_arith) = true;
+
+    if (order & GZ_X_STRIPE) {
+        if (n > 20) {
+            P.any_striped = true;
+            if (!(S.planes = (uint8_t *)arena_alloc (h, (size_t)n + 16))) return false;
+            uint32_t plen = n / 4 + 1;
+            for (int k = 0; k < 4; k++) {
+                if (engine == GZ_ENG_RANS) {
+                    static const int m[4] = { 1, GZ_X_RLE, GZ_X_PACK, 0 };
+                    for (int j = 0; j < 4; j++)
+                        if ((order & m[j]) == m[j]) { if (!add_leaf (h, P, si, engine, k, m[j] | GZ_X_NOSZ, plen)) return false; S.n_leaves++; }
+                }
+                else {
+                    static const int m[4][4] = { { 3, 1, GZ_X_RLE, 0 }, { 2, 1, 0, 0 }, { 2, 1, GZ_X_PACK, 0 }, { 2, 1, GZ_X_PACK, 0 } };
+                    for (int j = 1; j <= m[k][0]; j++) {
+                        if ((order & 3) == 0 && (m[k][j] & 1)) continue;
+                        if (!add_leaf (h, P, si, engine, k, m[k][j] | GZ_X_NOSZ, plen)) return false;
+                        S.n_leaves++;
+                    }
+                }
+            }
+        }
+        // the actual length may be <= 20 (known only on the device when in_len_dev is given): unstriped fallback
+        if (n <= 20 || S.in_len_dev) {
+            S.whole_leaf = (uint8_t)S.n_leaves;
+            if (!add_leaf (h, P, si, engine, 0xff, order & ~GZ_X_STRIPE, n < 20 ? n : 20)) return false;
+            S.n_leaves++;
+        }
+    }
+    else {
+        S.whole_leaf = 0;
+        if (!add_leaf (h, P, si, engine, 0xff, order, n)) return false;
+        S.n_leaves = 1;
+    }
+    return true;
+}
+
+static int upload (GzHandle *h, const void *host, size_t bytes, void **dev)
+{
+    *dev = arena_alloc (h, bytes);
+    if (!*dev) return GZ_ERR_HIP;
+    if (bytes) {
+        // the source vectors die when the planning function returns: stage through a heap copy that lives until sync
+        void *stage = malloc (bytes);
+        if (!stage) return GZ_ERR;
+        memcpy (stage, host, bytes);
+        h->host_tmp.push_back (stage);
+        HIPCHK (h, hipMemcpyAsync (*dev, stage, bytes, hipMemcpyHostToDevice, h->stream));
+    }
+    return GZ_OK;
+}
+
+static const uint32_t ARITH_CLASS_WORDS[4] = { 0, 4096, 16384, 40000 };   // 16 KB, 64 KB, 156 KB of LDS
+
+static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d_leaves, GzdVB *d_vbs, uint32_t n_vbs, int section_mode)
+{
+    const uint32_t ns = (uint32_t)P.streams.size (), nl = (uint32_t)P.leaves.size ();
+    if (!ns) return GZ_OK;
+    hipLaunchKernelGGL (k_resolve, dim3 ((ns + 255) / 256), dim3 (256), 0, h->stream, d_streams, ns, section_mode);
+    if (P.any_striped) {
+        uint32_t chunks = (P.max_in / 16 + 255) / 256;
+        if (chunks < 1) chunks = 1;
+        if (chunks > 64) chunks = 64;
+        hipLaunchKernelGGL (k_stripe, dim3 (ns, chunks), dim3 (256), 0, h->stream, d_streams);
+    }
+    if (nl) {
+        hipLaunchKernelGGL (k_leaf_prep, dim3 (nl), dim3 (256), 4096, h->stream, d_streams, d_leaves);
+        if (P.any_rans) {
+            hipLaunchKernelGGL (k_hist, dim3 (nl, GZ_HIST_CHUNKS), dim3 (256), GZ_HIST_LDS + 1024, h->stream, d_leaves);
+            hipLaunchKernelGGL (k_rans_table, dim3 (nl), dim3 (256), 16384, h->stream, d_leaves, (const GzLogTable *)h->d_logs);
+            hipLaunchKernelGGL (k_rans_encode, dim3 (nl), dim3 (64), 0, h->stream, d_leaves);
+        }
+        if (P.any_arith) {
+            for (int c = 0; c < 3; c++)
+                hipLaunchKernelGGL (k_arith_encode, dim3 (nl), dim3 (64), ARITH_CLASS_WORDS[c + 1] * 4, h->stream,
+                                    d_leaves, ARITH_CLASS_WORDS[c], ARITH_CLASS_WORDS[c + 1], 0);
+            hipLaunchKernelGGL (k_arith_encode, dim3 (nl), dim3 (64), 0, h->stream, d_leaves, ARITH_CLASS_WORDS[3], 0xffffffffu, 1);
+        }
+    }
+    hipLaunchKernelGGL (k_select, dim3 ((ns + 255) / 256), dim3 (256), 0, h->stream, d_streams, d_leaves, ns);
+    if (n_vbs) hipLaunchKernelGGL (k_vb_layout, dim3 ((n_vbs + 63) / 64), dim3 (64), 0, h->stream, d_vbs, d_streams, n_vbs);
+    hipLaunchKernelGGL (k_emit, dim3 (ns), dim3 (256), 4096, h->stream, d_streams, d_leaves, d_vbs);
+    HIPCHK (h, hipGetLastError ());
+    return GZ_OK;
+}
+
+extern "C" int gz_codec_compress_batch (GzHandle *h, GzStream *streams, int n_streams)
+{
+    if (!h || (n_streams && !streams) || n_streams < 0) return GZ_ERR_ARG;
+    HIPCHK (h, hipSetDevice (h->device));
+    Plan P;
+    P.streams.resize (n_streams);
+    for (int i = 0; i < n_streams; i++) {
+        GzStream &u = streams[i];
+        GzdStream &S = P.streams[i];
+        memset (&S, 0, sizeof (S));
+        u.out_len = 0;
+        if (!codec_ok (u.codec)) { u.status = GZ_ERR_ARG; S.status = GZ_ERR_ARG; continue; }
+        S.in = u.in; S.in_len = u.in_len; S.in_len_dev = u.in_len_dev; S.out = u.out; S.out_cap = u.out_cap;
+        S.codec_req = u.codec; S.vb = -1;
+        // the reference's "output buffer too small" test (rANS_static4x16pr.c:1158) against Genozip's est_size
+        S.status = u.out_cap < gz_codec_est_size (u.codec, u.in_len) ? GZ_ST_TOO_SMALL : GZ_ST_PENDING;
+        u.status = S.status;
+        if (S.status != GZ_ST_PENDING) continue;
+        if (u.in_len > P.max_in) P.max_in = u.in_len;
+        if (!plan_stream_leaves (h, P, (uint32_t)i)) return GZ_ERR_HIP;
+    }
+    void *d_streams, *d_leaves;
+    int rc;
+    if ((rc = upload (h, P.streams.data (), P.streams.size () * sizeof (GzdStream), &d_streams)) != GZ_OK) return rc;
+    if ((rc = upload (h, P.leaves.data (), P.leaves.size () * sizeof (GzdLeaf), &d_leaves)) != GZ_OK) return rc;
+    if ((rc = launch_encode (h, P, (GzdStream *)d_streams, (GzdLeaf *)d_leaves, NULL, 0, 0)) != GZ_OK) return rc;
+    Pending pd; pd.kind = 0; pd.user = streams; pd.n = n_streams; pd.dev_streams = d_streams; pd.dev_vbs = NULL; pd.n_dev_streams = P.streams.size ();
+    h->pending.push_back (pd);
+    return GZ_OK;
+}
+
+extern "C" uint64_t gz_vb_z_bound (const GzSection *sections, uint32_t n_sections)
+{
+    uint64_t b = 84;
+    for (uint32_t i = 0; i < n_sections; i++) {
+        int codec = sections[i].codec ? sections[i].codec : GZ_CODEC_RANB;
+        uint64_t e = gz_codec_est_size (codec, sections[i].data_len);
+        if (e < sections[i].data_len) e = sections[i].data_len;
+        b += 40 + e;
+    }
+    return b;
+}
+
+extern "C" int gz_vb_compress_batch (GzHandle *h, GzVBlock *vbs, int n_vbs)
+{
+    if (!h || (n_vbs && !vbs) || n_vbs < 0) return GZ_ERR_ARG;
+    HIPCHK (h, hipSetDevice (h->device));
+    Plan P;
+    std::vector<GzdVB> V (n_vbs);
+    for (int v = 0; v < n_vbs; v++) {
+        GzVBlock &u = vbs[v];
+        GzdVB &D = V[v];
+        memset (&D, 0, sizeof (D));
+        D.z_data = u.z_data; D.z_cap = u.z_cap; D.first_stream = (uint32_t)P.streams.size (); D.n_streams = u.n_sections;
+        D.vblock_i = u.vblock_i; D.recon_size = u.recon_size; D.longest_line_len = u.longest_line_len; D.longest_seq_len = u.longest_seq_len;
+        memcpy (D.digest, u.digest, 16); D.vb_flags = u.vb_flags; D.status = GZ_ST_PENDING;
+        u.status = GZ_ST_PENDING; u.z_len = 0;
+        for (uint32_t k = 0; k < u.n_sections; k++) {
+            const GzSection &sec = u.sections[k];
+            GzdStream S;
+            memset (&S, 0, sizeof (S));
+            int codec = sec.codec ? sec.codec : GZ_CODEC_RANB;            // zfile.c:300,337
+            if (!codec_ok (codec)) { h->err = "unsupported codec in section"; return GZ_ERR_ARG; }
+            S.in = sec.data; S.in_len = sec.data_len; S.in_len_dev = sec.data_len_dev;
+            S.codec_req = codec; S.vb = v; S.sec_in_vb = k; S.status = GZ_ST_PENDING;
+            S.out_cap = 0xffffffffu;
+            uint8_t *hd = S.hdr;                                        // SectionHeaderCtx, sections.h:146-167,419-435
+            gz_be32 (hd + 0, 0x27052012u);
+            gz_be32 (hd + 20, u.vblock_i);
+            hd[24] = sec.section_type; hd[25] = (uint8_t)codec; hd[26] = sec.sub_codec; hd[27] = sec.flags;
+            hd[28] = sec.ltype; hd[29] = sec.param; hd[30] = sec.b250_size_or_nothing_char; hd[31] = 0;
+            memcpy (hd + 32, sec.dict_id, 8);
+            if (sec.data_len > P.max_in) P.max_in = sec.data_len;
+            P.streams.push_back (S);
+            // a section shorter than 50 bytes is stored raw; when the length is only known on the device we must
+            // still plan the leaves of the requested codec
+            if (sec.data_len < 50 && !sec.data_len_dev) { P.streams.back ().codec_req = GZ_CODEC_NONE; P.streams.back ().hdr[25] = GZ_CODEC_NONE; }
+            if (!plan_stream_leaves (h, P, (uint32_t)P.streams.size () - 1)) return GZ_ERR_HIP;
+        }
+    }
+    void *d_streams, *d_leaves, *d_vbs;
+    int rc;
+    if ((rc = upload (h, P.streams.data (), P.streams.size () * sizeof (GzdStream), &d_streams)) != GZ_OK) return rc;
+    if ((rc = upload (h, P.leaves.data (), P.leaves.size () * sizeof (GzdLeaf), &d_leaves)) != GZ_OK) return rc;
+    if ((rc = upload (h, V.data (), V.size () * sizeof (GzdVB), &d_vbs)) != GZ_OK) return rc;
+    if ((rc = launch_encode (h, P, (GzdStream *)d_streams, (GzdLeaf *)d_leaves, (GzdVB *)d_vbs, (uint32_t)n_vbs, 1)) != GZ_OK) return rc;
+    Pending pd; pd.kind = 2; pd.user = vbs; pd.n = n_vbs; pd.dev_streams = d_streams; pd.dev_vbs = d_vbs; pd.n_dev_streams = P.streams.size ();
+    h->pending.push_back (pd);
+    return GZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// decode batch
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int gz_codec_uncompress_batch (GzHandle *h, GzStream *streams, int n_streams)
+{
+    if (!h || (n_streams && !streams) || n_streams < 0) return GZ_ERR_ARG;
+    HIPCHK (h, hipSetDevice (h->device));
+    std::vector<GzdDecStream> DS (n_streams);
+    std::vector<GzdDecLeaf> DL ((size_t)n_streams * 4);
+    memset (DL.data (), 0, DL.size () * sizeof (GzdDecLeaf));
+    bool any = false;
+    for (int i = 0; i < n_streams; i++) {
+        GzStream &u = streams[i];
+        GzdDecStream &S = DS[i];
+        memset (&S, 0, sizeof (S));
+        u.out_len = 0;
+        if (!codec_ok (u.codec)) { u.status = S.status = GZ_ERR_ARG; continue; }
+        S.in = u.in; S.in_len = u.in_len; S.out = u.out; S.out_len = u.out_cap; S.codec = u.codec;
+        S.status = GZ_ST_PENDING; S.first_leaf = (uint32_t)i * 4;
+        u.status = GZ_ST_PENDING;
+        any = true;
+        if (u.codec == GZ_CODEC_NONE) continue;
+        const bool rans = codec_is_rans (u.codec);
+        size_t n = u.out_cap;
+        if (!(S.tmp_planes = (uint8_t *)arena_alloc (h, n + 16))) return GZ_ERR_HIP;
+        if (!(S.tmp_packed = (uint8_t *)arena_alloc (h, n + 64))) return GZ_ERR_HIP;
+        for (int k = 0; k < 4; k++) {
+            GzdDecLeaf &L = DL[(size_t)i * 4 + k];
+            L.stream = (uint32_t)i;
+            if (rans) {
+                if (!(L.lut = (uint8_t *)arena_alloc (h, (size_t)256 << 12))) return GZ_ERR_HIP;
+                if (!(L.fc  = (uint32_t *)arena_alloc (h, 256 * 256 * 4))) return GZ_ERR_HIP;
+                if (!(L.tabtmp = (uint8_t *)arena_alloc (h, GZ_TAB_CAP))) return GZ_ERR_HIP;
+            }
+            else if (!(L.models = (uint32_t *)arena_alloc (h, ((size_t)256 * 257 + GZ_ARITH_RUN_MODELS * GZ_ARITH_RUN_STRIDE) * 4))) return GZ_ERR_HIP;
+        }
+    }
+    void *d_streams, *d_leaves;
+    int rc;
+    if ((rc = upload (h, DS.data (), DS.size () * sizeof (GzdDecStream), &d_streams)) != GZ_OK) return rc;
+    if ((rc = upload (h, DL.data (), DL.size () * sizeof (GzdDecLeaf), &d_leaves)) != GZ_OK) return rc;
+    if (any) {
+        const uint32_t ns = (uint32_t)n_streams;
+        hipLaunchKernelGGL (k_dec_parse, dim3 ((ns + 63) / 64), dim3 (64), 0, h->stream, (GzdDecStream *)d_streams, (GzdDecLeaf *)d_leaves, ns);
+        hipLaunchKernelGGL (k_dec_table, dim3 (ns * 4), dim3 (256), 20480, h->stream, (GzdDecLeaf *)d_leaves);
+        hipLaunchKernelGGL (k_rans_decode, dim3 (ns * 4), dim3 (64), 0, h->stream, (GzdDecLeaf *)d_leaves);
+        for (int c = 0; c < 3; c++)
+            hipLaunchKernelGGL (k_arith_decode, dim3 (ns * 4), dim3 (64), ARITH_CLASS_WORDS[c + 1] * 4, h->stream,
+                                (GzdDecLeaf *)d_leaves, ARITH_CLASS_WORDS[c], ARITH_CLASS_WORDS[c + 1], 0);
+        hipLaunchKernelGGL (k_arith_decode, dim3 (ns * 4), dim3 (64), 0, h->stream, (GzdDecLeaf *)d_leaves, ARITH_CLASS_WORDS[3], 0xffffffffu, 1);
+        hipLaunchKernelGGL (k_dec_finish, dim3 (ns), dim3 (256), 0, h->stream, (GzdDecStream *)d_streams, (GzdDecLeaf *)d_leaves);
+        HIPCHK (h, hipGetLastError ());
+    }
+    Pending pd; pd.kind = 1; pd.user = streams; pd.n = n_streams; pd.dev_streams = d_streams; pd.dev_vbs = NULL; pd.n_dev_streams = DS.size ();
+    h->pending.push_back (pd);
+    return GZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// sync: wait, fetch results, recycle the arena
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int gz_sync (GzHandle *h)
+{
+    if (!h) return GZ_ERR_ARG;
+    HIPCHK (h, hipSetDevice (h->device));
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    int rc = GZ_OK;
+    for (auto &pd : h->pending) {
+        if (pd.kind == 0) {
+            std::vector<GzdStream> S (pd.n_dev_streams);
+            HIPCHK (h, hipMemcpy (S.data (), pd.dev_streams, S.size () * sizeof (GzdStream), hipMemcpyDeviceToHost));
+            GzStream *u = (GzStream *)pd.user;
+            for (int i = 0; i < pd.n; i++) {
+                if (u[i].status != GZ_ST_PENDING) continue;
+                u[i].status = S[i].status == GZ_ST_OK ? GZ_OK : S[i].status == GZ_ST_TOO_SMALL ? GZ_TOO_SMALL : GZ_ERR;
+                u[i].out_len = S[i].status == GZ_ST_OK ? S[i].out_len : 0;
+            }
+        }
+        else if (pd.kind == 1) {
+            std::vector<GzdDecStream> S (pd.n_dev_streams);
+            HIPCHK (h, hipMemcpy (S.data (), pd.dev_streams, S.size () * sizeof (GzdDecStream), hipMemcpyDeviceToHost));
+            GzStream *u = (GzStream *)pd.user;
+            for (int i = 0; i < pd.n; i++) {
+                if (u[i].status != GZ_ST_PENDING) continue;
+                u[i].status = S[i].status == GZ_ST_OK ? GZ_OK : GZ_ERR_CORRUPT;
+                u[i].out_len = S[i].status == GZ_ST_OK ? S[i].out_len : 0;
+            }
+        }
+        else {
+            std::vector<GzdVB> V (pd.n);
+            HIPCHK (h, hipMemcpy (V.data (), pd.dev_vbs, V.size () * sizeof (GzdVB), hipMemcpyDeviceToHost));
+            GzVBlock *u = (GzVBlock *)pd.user;
+            for (int i = 0; i < pd.n; i++) {
+                u[i].status = V[i].status == GZ_ST_OK ? GZ_OK : GZ_TOO_SMALL;
+                u[i].z_len  = V[i].z_len;
+                if (u[i].status != GZ_OK) rc = GZ_TOO_SMALL;
+            }
+        }
+    }
+    h->pending.clear ();
+    for (auto p : h->host_tmp) free (p);
+    h->host_tmp.clear ();
+    arena_reset (h);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host-pointer single-call forms == the reference's COMPRESS()/UNCOMPRESS() signatures
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int gz_codec_compress_host (GzHandle *h, int codec, const uint8_t *in, uint32_t in_len,
+                                       uint8_t *out, uint32_t *out_len, int soft_fail)
+{
+    if (!h || !out_len || (in_len && !in) || !out) return GZ_ERR_ARG;
+    if (!codec_ok (codec)) return GZ_ERR_ARG;
+    uint32_t est = gz_codec_est_size (codec, in_len);
+    if (*out_len < est) return soft_fail ? GZ_TOO_SMALL : GZ_ERR;
+    int rc;
+    if ((rc = gz_sync (h)) < 0) return rc;           // own the arena
+    uint8_t *d_in  = (uint8_t *)arena_alloc (h, (size_t)in_len + 16);
+    uint8_t *d_out = (uint8_t *)arena_alloc (h, (size_t)est + 16);
+    if (!d_in || !d_out) return GZ_ERR_HIP;
+    if (in_len) HIPCHK (h, hipMemcpyAsync (d_in, in, in_len, hipMemcpyHostToDevice, h->stream));
+    GzStream s; memset (&s, 0, sizeof (s));
+    s.in = d_in; s.in_len = in_len; s.out = d_out; s.out_cap = est; s.codec = codec;
+    if ((rc = gz_codec_compress_batch (h, &s, 1)) != GZ_OK) return rc;
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    // fetch the payload before gz_sync recycles the arena
+    if ((rc = gz_sync (h)) < 0) return rc;
+    if (s.status != GZ_OK) return s.status;
+    if (s.out_len) HIPCHK (h, hipMemcpy (out, d_out, s.out_len, hipMemcpyDeviceToHost));
+    *out_len = s.out_len;
+    return GZ_OK;
+}
+
+extern "C" int gz_codec_uncompress_host (GzHandle *h, int codec, const uint8_t *in, uint32_t in_len,
+                                         uint8_t *out, uint64_t out_len)
+{
+    if (!h || (in_len && !in) || (out_len && !out) || out_len > 0xffffffffull) return GZ_ERR_ARG;
+    if (!codec_ok (codec)) return GZ_ERR_ARG;
+    int rc;
+    if ((rc = gz_sync (h)) < 0) return rc;
+    uint8_t *d_in  = (uint8_t *)arena_alloc (h, (size_t)in_len + 16);
+    uint8_t *d_out = (uint8_t *)arena_alloc (h, (size_t)out_len + 16);
+    if (!d_in || !d_out) return GZ_ERR_HIP;
+    if (in_len) HIPCHK (h, hipMemcpyAsync (d_in, in, in_len, hipMemcpyHostToDevice, h->stream));
+    GzStream s; memset (&s, 0, sizeof (s));
+    s.in = d_in; s.in_len = in_len; s.out = d_out; s.out_cap = (uint32_t)out_len; s.codec = codec;
+    if ((rc = gz_codec_uncompress_batch (h, &s, 1)) != GZ_OK) return rc;
+    if ((rc = gz_sync (h)) < 0) return rc;
+    if (s.status != GZ_OK) return s.status;
+    if (out_len) HIPCHK (h, hipMemcpy (out, d_out, out_len, hipMemcpyDeviceToHost));
+    return GZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// codec_assign_best_codec, deterministic rule
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int gz_codec_assign_best (GzHandle *h, const uint8_t *in, uint32_t in_len, uint32_t *sizes_out)
+{
+    static const int cand[9] = { GZ_CODEC_NONE, GZ_CODEC_RANB, GZ_CODEC_RANW, GZ_CODEC_RANb, GZ_CODEC_RANw,
+                                 GZ_CODEC_ARTB, GZ_CODEC_ARTW, GZ_CODEC_ARTb, GZ_CODEC_ARTw };
+    if (!h || (in_len && !in)) return GZ_ERR_ARG;
+    uint32_t sample = in_len < 99999 ? in_len : 99999;                  // codec.c:309
+    if (sample < 50) return GZ_CODEC_UNKNOWN;                          // codec.c:311-312
+    int rc;
+    if ((rc = gz_sync (h)) < 0) return rc;
+    GzStream s[8]; memset (s, 0, sizeof (s));
+    for (int i = 0; i < 8; i++) {
+        s[i].in = in; s[i].in_len = sample; s[i].codec = cand[i + 1];
+        s[i].out_cap = gz_codec_est_size (cand[i + 1], sample);
+        if (!(s[i].out = (uint8_t *)arena_alloc (h, s[i].out_cap + 16))) return GZ_ERR_HIP;
+    }
+    if ((rc = gz_codec_compress_batch (h, s, 8)) != GZ_OK) return rc;
+    if ((rc = gz_sync (h)) < 0) return rc;
+    int best = GZ_CODEC_NONE;
+    uint32_t best_size = sample;                                       // NONE: bare length (codec.c:324)
+    if (sizes_out) sizes_out[0] = sample;
+    for (int i = 0; i < 8; i++) {
+        if (s[i].status != GZ_OK) return GZ_ERR;
+        uint32_t size = s[i].out_len + 28;                             // framed: + SectionHeader (codec.c:328-331)
+        if (sizes_out) sizes_out[i + 1] = size;
+        if (size < best_size) { best_size = size; best = cand[i + 1]; }
+    }
+    return best;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// context engine pieces
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int gz_b250_generate_batch (GzHandle *h, const GzB250Job *jobs, int n_jobs)
+{
+    if (!h || (n_jobs && !jobs) || n_jobs < 0) return GZ_ERR_ARG;
+    if (!n_jobs) return GZ_OK;
+    HIPCHK (h, hipSetDevice (h->device));
+    std::vector<GzdB250Job> J (n_jobs);
+    for (int i = 0; i < n_jobs; i++) {
+        const GzB250Job &u = jobs[i];
+        if (!u.out_len_dev || (u.seg_len && (!u.seg || !u.out))) return GZ_ERR_ARG;
+        GzdB250Job &d = J[i];
+        memset (&d, 0, sizeof (d));
+        d.seg = u.seg; d.seg_len = u.seg_len; d.seg_len_dev = u.seg_len_dev; d.ol_nodes_len = u.ol_nodes_len;
+        d.node2word = u.node2word; d.n_new_nodes = u.n_new_nodes; d.out = u.out; d.out_len_dev = u.out_len_dev;
+        d.status_dev = u.status_dev;
+        // scratch: one int32 per possible word (every word is at least one byte) + the chunk table
+        size_t nchunks = ((size_t)u.seg_len + GZ_B250_CHUNK - 1) / GZ_B250_CHUNK;
+        if (!(d.wi = (int32_t *)arena_alloc (h, ((size_t)u.seg_len + 1) * 4))) return GZ_ERR_HIP;
+        if (!(d.chunk_tab = (uint32_t *)arena_alloc (h, (nchunks + 1) * 7 * 4))) return GZ_ERR_HIP;
+    }
+    void *d_jobs;
+    int rc;
+    if ((rc = upload (h, J.data (), J.size () * sizeof (GzdB250Job), &d_jobs)) != GZ_OK) return rc;
+    hipLaunchKernelGGL (k_b250_generate, dim3 (n_jobs), dim3 (256), 4096, h->stream, (GzdB250Job *)d_jobs);
+    HIPCHK (h, hipGetLastError ());
+    return GZ_OK;
+}
+
+extern "C" int gz_b250_generate (GzHandle *h, const uint8_t *seg, uint32_t seg_len, uint32_t ol_nodes_len,
+                                 const int32_t *node2word, uint32_t n_new_nodes, uint8_t *out, uint32_t *out_len_dev)
+{
+    GzB250Job j; memset (&j, 0, sizeof (j));
+    j.seg = seg; j.seg_len = seg_len; j.ol_nodes_len = ol_nodes_len; j.node2word = node2word; j.n_new_nodes = n_new_nodes;
+    j.out = out; j.out_len_dev = out_len_dev;
+    return gz_b250_generate_batch (h, &j, 1);
+}
+
+static uint32_t lt_width (int lt)   // local_type.h:75-108
+{
+    switch (lt) {
+        case GZ_LT_INT16: case GZ_LT_UINT16: case GZ_LT_UINT16_TR: return 2;
+        case GZ_LT_INT32: case GZ_LT_UINT32: case GZ_LT_FLOAT32: case GZ_LT_UINT32_TR: return 4;
+        case GZ_LT_INT64: case GZ_LT_UINT64: case GZ_LT_FLOAT64: case GZ_LT_BITMAP: return 8;
+        default: return 1;
+    }
+}
+
+static int local_xform (GzHandle *h, int ltype, void *data, uint64_t n, uint32_t cols, void *scratch, int to_file)
+{
+    if (!h || (n && !data)) return GZ_ERR_ARG;
+    HIPCHK (h, hipSetDevice (h->device));
+    const uint32_t w = lt_width (ltype);
+    const bool is_signed = ltype == GZ_LT_INT8 || ltype == GZ_LT_INT16 || ltype == GZ_LT_INT32 || ltype == GZ_LT_INT64;
+    int base = ltype == GZ_LT_UINT8_TR ? GZ_LT_UINT8 : ltype == GZ_LT_UINT16_TR ? GZ_LT_UINT16 : ltype == GZ_LT_UINT32_TR ? GZ_LT_UINT32 : ltype;
+    const bool swap = (w > 1 || is_signed) && ltype != GZ_LT_BITMAP;
+    const uint32_t blocks = (uint32_t)((n + 1023) / 1024 > 4096 ? 4096 : (n + 1023) / 1024);
+    int result = ltype;
+
+    if (to_file) {
+        if (swap && n) hipLaunchKernelGGL (k_local_order, dim3 (blocks ? blocks : 1), dim3 (256), 0, h->stream, (uint8_t *)data, n, w, (int)is_signed, 1);
+        if (cols && n % cols == 0 && (base == GZ_LT_UINT8 || base == GZ_LT_UINT16 || base == GZ_LT_UINT32) && n) {
+            if (!scratch) return GZ_ERR_ARG;
+            uint32_t rows = (uint32_t)(n / cols);
+            hipLaunchKernelGGL (k_transpose, dim3 ((cols + 31) / 32, (rows + 31) / 32), dim3 (32, 8), 0, h->stream,
+                                (const uint8_t *)data, (uint8_t *)scratch, rows, cols, w);
+            HIPCHK (h, hipMemcpyAsync (data, scratch, n * w, hipMemcpyDeviceToDevice, h->stream));
+            result = base == GZ_LT_UINT8 ? GZ_LT_UINT8_TR : base == GZ_LT_UINT16 ? GZ_LT_UINT16_TR : GZ_LT_UINT32_TR;
+        }
+    }
+    else {
+        if (cols && (ltype == GZ_LT_UINT8_TR || ltype == GZ_LT_UINT16_TR || ltype == GZ_LT_UINT32_TR) && n) {
+            if (!scratch || n % cols) return GZ_ERR_ARG;
+            uint32_t rows = (uint32_t)(n / cols);           // file holds cols x rows; give back rows x cols
+            hipLaunchKernelGGL (k_transpose, dim3 ((rows + 31) / 32, (cols + 31) / 32), dim3 (32, 8), 0, h->stream,
+                                (const uint8_t *)data, (uint8_t *)scratch, cols, rows, w);
+            HIPCHK (h, hipMemcpyAsync (data, scratch, n * w, hipMemcpyDeviceToDevice, h->stream));
+            result = base;
+        }
+        if (swap && n) hipLaunchKernelGGL (k_local_order, dim3 (blocks ? blocks : 1), dim3 (256), 0, h->stream, (uint8_t *)data, n, w, (int)is_signed, 0);
+    }
+    HIPCHK (h, hipGetLastError ());
+    return result;
+}
+
+extern "C" int gz_local_generate (GzHandle *h, int ltype, void *data, uint64_t n, uint32_t cols, void *scratch)
+{ return local_xform (h, ltype, data, n, cols, scratch, 1); }
+
+extern "C" int gz_local_to_native (GzHandle *h, int ltype, void *data, uint64_t n, uint32_t cols, void *scratch)
+{ return local_xform (h, ltype, data, n, cols, scratch, 0); }
+
+extern "C" int gz_adler32 (GzHandle *h, const uint8_t *data, uint64_t len, uint32_t *adler_out)
+{
+    if (!h || !adler_out || (len && !data) || len > 0xffffffffull) return GZ_ERR_ARG;
+    int rc;
+    if ((rc = gz_sync (h)) < 0) return rc;
+    uint32_t *d = (uint32_t *)arena_alloc (h, 4);
+    if (!d) return GZ_ERR_HIP;
+    hipLaunchKernelGGL (k_adler32, dim3 (1), dim3 (256), 4096, h->stream, data, (uint32_t)len, d);
+    HIPCHK (h, hipGetLastError ());
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    HIPCHK (h, hipMemcpy (adler_out, d, 4, hipMemcpyDeviceToHost));
+    return GZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// VBlock decode (round trip proof): walk the sections on the host, decode payloads on the device
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int gz_vb_uncompress (GzHandle *h, const uint8_t *z_data, uint64_t z_len, uint8_t *out, uint64_t out_cap,
+                                 uint64_t *section_offsets_host, uint32_t max_sections, uint32_t *n_sections_out)
+{
+    if (!h || !z_data || !n_sections_out || z_len < 84) return GZ_ERR_ARG;
+    int rc;
+    if ((rc = gz_sync (h)) < 0) return rc;
+    std::vector<uint8_t> z (z_len);
+    HIPCHK (h, hipMemcpy (z.data (), z_data, z_len, hipMemcpyDeviceToHost));
+    if (gz_rd_be32 (&z[0]) != 0x27052012u || z[24] != GZ_SEC_VB_HEADER) { h->err = "bad VB header"; return GZ_ERR_CORRUPT; }
+    if (gz_rd_be32 (&z[40]) != z_len) { h->err = "z_data_bytes mismatch"; return GZ_ERR_CORRUPT; }
+    std::vector<GzStream> S;
+    uint64_t at = 84, o = 0;
+    std::vector<uint32_t> want_adler;
+    while (at < z_len) {
+        if (at + 40 > z_len || gz_rd_be32 (&z[at]) != 0x27052012u) { h->err = "bad section magic"; return GZ_ERR_CORRUPT; }
+        uint32_t clen = gz_rd_be32 (&z[at + 12]), ulen = gz_rd_be32 (&z[at + 16]);
+        if (at + 40 + clen > z_len || o + ulen > out_cap || S.size () >= max_sections) { h->err = "section overflow"; return GZ_ERR_CORRUPT; }
+        GzStream s; memset (&s, 0, sizeof (s));
+        s.in = z_data + at + 40; s.in_len = clen; s.out = out + o; s.out_cap = ulen; s.codec = z[at + 25];
+        S.push_back (s);
+        want_adler.push_back (gz_rd_be32 (&z[at + 4]));
+        if (section_offsets_host) section_offsets_host[S.size () - 1] = o;
+        o += ulen; at += 40 + clen;
+    }
+    if (section_offsets_host) section_offsets_host[S.size ()] = o;
+    *n_sections_out = (uint32_t)S.size ();
+    for (size_t i = 0; i < S.size (); i++) {                // z_digest check (zfile.c:212-218)
+        uint32_t a;
+        if ((rc = gz_adler32 (h, S[i].in, S[i].in_len, &a)) != GZ_OK) return rc;
+        if (a != want_adler[i]) { h->err = "section adler32 mismatch"; return GZ_ERR_CORRUPT; }
+    }
+    std::vector<GzStream> work;
+    for (auto &s : S) if (s.out_cap) work.push_back (s);
+    if (!work.empty ()) {
+        if ((rc = gz_codec_uncompress_batch (h, work.data (), (int)work.size ())) != GZ_OK) return rc;
+        if ((rc = gz_sync (h)) < 0) return rc;
+        for (auto &s : work) if (s.status != GZ_OK) { h->err = "section payload corrupt"; return GZ_ERR_CORRUPT; }
+    }
+    return GZ_OK;
+}

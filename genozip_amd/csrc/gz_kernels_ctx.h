@@ -1,0 +1,218 @@
+// gz_kernels_ctx.h -- context-engine kernels: b250 generation (src/b250.c:202-267), local byte-order / interlace
+// (src/buffer.c:336-350, src/context.h:99-101), matrix transpose (src/dyn_int.c:45-132) and adler32.
+#pragma once
+#include "gz_device.h"
+#include "gz_devutil.h"
+
+// ======================================================================================================
+// b250_zip_generate
+//
+// The seg-time b250 stream is a sequence of 1..4 byte little-endian VARL words whose length tag sits in the LAST
+// byte, so it can only be parsed backwards (the reference walks it backwards, serially). Parallel version: cut the
+// stream into 64-byte chunks counted from the end. Whatever the words look like, the backward chain of "last bytes"
+// enters a chunk at one of its top 4 positions; every thread walks its chunk for all 4 possible entries, recording
+// where it would leave and how many words it would see; one thread then threads the real chain through the chunk
+// table; finally every thread re-walks its chunk knowing the real entry and scatters converted word indices.
+// A second pass applies ONE_UP (it compares *converted* neighbours, b250.c:236,251) and re-encodes big-endian with
+// the tag first; output positions come from a workgroup prefix sum of the encoded lengths.
+// ======================================================================================================
+#define GZ_B250_CHUNK 64
+
+struct GzdB250Job {
+    const uint8_t *seg; uint32_t seg_len; const uint32_t *seg_len_dev;
+    uint32_t ol_nodes_len; const int32_t *node2word; uint32_t n_new_nodes;
+    uint8_t *out; uint32_t *out_len_dev;
+    int32_t *wi;             // scratch: seg_len + 1 words
+    uint32_t *chunk_tab;     // scratch: 5 words per chunk (count for entry 0..3, packed exits) + 2 per chunk (entry, base)
+    int32_t *status_dev;     // optional
+};
+
+__device__ static inline int d_varl_len (uint8_t tag) { return !(tag >> 7) ? 1 : (tag >> 6) == 2 ? 2 : (tag >> 5) == 6 ? 3 : 4; }
+
+// value of the seg-format word whose last byte is at index `last` (b250.c:60-79)
+__device__ static inline int32_t d_seg_value (const uint8_t *seg, int64_t last, int n)
+{
+    uint32_t v = 0;
+    for (int k = 0; k < n; k++) v = (v << 8) | seg[last - k];
+    switch (n) {
+        case 1:  return (int32_t)v;
+        case 2:  return v == 0xBFFE ? -3 : v == 0xBFFF ? -4 : (int32_t)(v & 0x3fff) + 127;
+        case 3:  return (int32_t)(v & 0x1fffff) + 16509;
+        default: return (int32_t)(v & 0x1fffffff);
+    }
+}
+
+// PIZ-format code of a word index (b250.c:82-107): returns length, *code holds the bytes big-endian in its low bytes
+__device__ static inline int d_varl_code (int32_t wi, uint32_t *code)
+{
+    if (wi == -2) { *code = 127;    return 1; }
+    if (wi == -3) { *code = 0xBFFE; return 2; }
+    if (wi == -4) { *code = 0xBFFF; return 2; }
+    if (wi <= 126)     { *code = (uint32_t)wi; return 1; }
+    if (wi <= 16508)   { *code = (2u << 14) | (uint32_t)(wi - 127); return 2; }
+    if (wi <= 2113660) { *code = (6u << 21) | (uint32_t)(wi - 16509); return 3; }
+    *code = (7u << 29) | (uint32_t)wi;
+    return 4;
+}
+
+__global__ void __launch_bounds__(256) k_b250_generate (GzdB250Job *jobs)
+{
+    GzdB250Job &J = jobs[blockIdx.x];
+    const int tid = threadIdx.x;
+    uint32_t *sh = (uint32_t *)gz_lds;              // [0..255] per-thread sums, [256..] misc
+    uint32_t seg_len = J.seg_len;
+    if (J.seg_len_dev) { uint32_t v = *J.seg_len_dev; if (v < seg_len) seg_len = v; }
+    if (!seg_len) { if (!tid) { *J.out_len_dev = 0; if (J.status_dev) *J.status_dev = GZ_ST_OK; } return; }
+    const uint8_t *seg = J.seg;
+    const uint32_t nchunks = (seg_len + GZ_B250_CHUNK - 1) / GZ_B250_CHUNK;
+    uint32_t *ctab = J.chunk_tab;                   // [c*7 + e] count, [c*7+4] exits (4 x 8 bit, 0xff = malformed), [c*7+5] entry, [c*7+6] base
+
+    // ---- A: speculative walks
+    for (uint32_t c = tid; c < nchunks; c += 256) {
+        int64_t hi = (int64_t)seg_len - (int64_t)c * GZ_B250_CHUNK, lo = hi - GZ_B250_CHUNK;
+        if (lo < 0) lo = 0;
+        uint32_t exits = 0;
+        for (int e = 0; e < 4; e++) {
+            int64_t p = hi - 1 - e;
+            uint32_t cnt = 0;
+            while (p >= lo) { cnt++; p -= d_varl_len (seg[p]); }
+            uint32_t ex = (uint32_t)(lo - 1 - p);    // 0..3 ; for the first chunk of the stream only 0 is well-formed
+            if (lo == 0 && ex != 0) ex = 0xff;
+            ctab[c * 7 + e] = cnt;
+            exits |= (ex & 0xff) << (8 * e);
+        }
+        ctab[c * 7 + 4] = exits;
+    }
+    __threadfence_block ();
+    __syncthreads ();
+
+    // ---- B: thread the real chain through the chunks
+    if (!tid) {
+        uint32_t state = 0, running = 0, ok = 1;
+        for (uint32_t c = 0; c < nchunks; c++) {
+            ctab[c * 7 + 5] = state;
+            ctab[c * 7 + 6] = running;
+            running += ctab[c * 7 + state];
+            state = (ctab[c * 7 + 4] >> (8 * state)) & 0xff;
+            if (state == 0xff) { ok = 0; break; }
+        }
+        sh[256] = running;       // number of words
+        sh[257] = ok;
+    }
+    __syncthreads ();
+    const uint32_t cnt = sh[256];
+    if (!sh[257]) { if (!tid) { *J.out_len_dev = 0; if (J.status_dev) *J.status_dev = GZ_ST_CORRUPT; } return; }
+
+    // ---- C: re-walk with the real entry, convert node -> word (context.h:109), store in reverse order
+    int32_t *wi = J.wi;
+    uint32_t bad = 0;
+    for (uint32_t c = tid; c < nchunks; c += 256) {
+        int64_t hi = (int64_t)seg_len - (int64_t)c * GZ_B250_CHUNK, lo = hi - GZ_B250_CHUNK;
+        if (lo < 0) lo = 0;
+        int64_t p = hi - 1 - ctab[c * 7 + 5];
+        uint32_t k = ctab[c * 7 + 6];
+        while (p >= lo) {
+            int n = d_varl_len (seg[p]);
+            if (p - n + 1 < 0) { bad = 1; break; }
+            int32_t v = d_seg_value (seg, p, n);
+            if (v >= 0 && (uint32_t)v >= J.ol_nodes_len) {
+                uint32_t local = (uint32_t)v - J.ol_nodes_len;
+                if (local >= J.n_new_nodes) { bad = 1; v = 0; }
+                else v = J.node2word[local];
+            }
+            wi[k++] = v;
+            p -= n;
+        }
+    }
+    __threadfence_block ();
+    __syncthreads ();
+
+    // ---- D: ONE_UP + re-encode. Thread t owns words [t*per, (t+1)*per) in forward order.
+    const bool one_up_ok = (uint64_t)J.n_new_nodes + J.ol_nodes_len > 1024;
+    const uint32_t per = (cnt + 255) / 256;
+    const uint32_t i0 = tid * per, i1 = i0 + per < cnt ? i0 + per : cnt;
+    uint32_t mylen = 0;
+    for (uint32_t i = i0; i < i1; i++) {
+        int32_t cur = wi[cnt - 1 - i];
+        if (one_up_ok && i && cur >= 0) { int32_t prev = wi[cnt - i]; if (prev >= 0 && cur == prev + 1) cur = -2; }
+        uint32_t code;
+        mylen += d_varl_code (cur, &code);
+    }
+    sh[tid] = mylen;
+    sh[258 + tid] = bad;
+    __syncthreads ();
+    if (!tid) {
+        uint32_t run = 0, anybad = 0;
+        for (int t = 0; t < 256; t++) { uint32_t l = sh[t]; sh[t] = run; run += l; anybad |= sh[258 + t]; }
+        sh[256] = run; sh[257] = anybad;
+    }
+    __syncthreads ();
+    uint32_t o = sh[tid];
+    for (uint32_t i = i0; i < i1; i++) {
+        int32_t cur = wi[cnt - 1 - i];
+        if (one_up_ok && i && cur >= 0) { int32_t prev = wi[cnt - i]; if (prev >= 0 && cur == prev + 1) cur = -2; }
+        uint32_t code; int n = d_varl_code (cur, &code);
+        for (int k = 0; k < n; k++) J.out[o + k] = (uint8_t)(code >> (8 * (n - 1 - k)));
+        o += n;
+    }
+    if (!tid) {
+        *J.out_len_dev = sh[257] ? 0 : sh[256];
+        if (J.status_dev) *J.status_dev = sh[257] ? GZ_ST_CORRUPT : GZ_ST_OK;
+    }
+}
+
+// ======================================================================================================
+// element byte order: little-endian native <-> big-endian file order, zig-zag "interlace" for signed types
+// ======================================================================================================
+__global__ void k_local_order (uint8_t *data, uint64_t n, uint32_t w, int is_signed, int to_file)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t mask = w == 8 ? ~0ull : ((1ull << (8 * w)) - 1), sign = 1ull << (8 * w - 1);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint8_t *p = data + i * w;
+        uint64_t v = 0;
+        if (to_file) {
+            for (uint32_t k = 0; k < w; k++) v |= (uint64_t)p[k] << (8 * k);
+            if (is_signed) v = (v & sign) ? ((((~v + 1) & mask) << 1) - 1) & mask : (v << 1) & mask;   // context.h:99-100
+            for (uint32_t k = 0; k < w; k++) p[k] = (uint8_t)(v >> (8 * (w - 1 - k)));
+        }
+        else {
+            for (uint32_t k = 0; k < w; k++) v = (v << 8) | p[k];
+            if (is_signed) v = (v & 1) ? (~(v >> 1)) & mask : (v >> 1);                              // context.h:101: -(u>>1)-1
+            for (uint32_t k = 0; k < w; k++) p[k] = (uint8_t)(v >> (8 * k));
+        }
+    }
+}
+
+// ======================================================================================================
+// dst[c*rows + r] = src[r*cols + c], elements of w bytes; 32x32 tiles through LDS, block = (32, 8)
+// ======================================================================================================
+__global__ void k_transpose (const uint8_t *src, uint8_t *dst, uint32_t rows, uint32_t cols, uint32_t w)
+{
+    uint32_t *tile = (uint32_t *)gz_lds;             // [32][33]
+    const uint32_t c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (uint32_t j = threadIdx.y; j < 32; j += 8) {
+        uint32_t r = r0 + j, c = c0 + threadIdx.x;
+        if (r < rows && c < cols) {
+            const uint8_t *p = src + ((uint64_t)r * cols + c) * w;
+            uint32_t v = 0;
+            for (uint32_t k = 0; k < w; k++) v |= (uint32_t)p[k] << (8 * k);
+            tile[j * 33 + threadIdx.x] = v;
+        }
+    }
+    __syncthreads ();
+    for (uint32_t j = threadIdx.y; j < 32; j += 8) {
+        uint32_t c = c0 + j, r = r0 + threadIdx.x;
+        if (r < rows && c < cols) {
+            uint32_t v = tile[threadIdx.x * 33 + j];
+            uint8_t *p = dst + ((uint64_t)c * rows + r) * w;
+            for (uint32_t k = 0; k < w; k++) p[k] = (uint8_t)(v >> (8 * k));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_adler32 (const uint8_t *data, uint32_t len, uint32_t *out)
+{
+    uint32_t a = gz_adler32_wg (data, len, threadIdx.x);
+    if (!threadIdx.x) *out = a;
+}

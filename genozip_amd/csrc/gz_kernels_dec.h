@@ -1,0 +1,465 @@
+// gz_kernels_dec.h -- gfx950 kernels of the decompression direction (codec_rans_uncompress / codec_arith_uncompress,
+// src/codec_htscodecs.c:100,116 -> rans_uncompress_to_4x16 rANS_static4x16pr.c:1358, arith_uncompress_to
+// arith_dynamic.c:860). Needed for the round-trip proof of the encoder.
+//
+//   k_dec_parse    one thread per stream: flags, sizes, stripe / pack meta -> up to 4 decode leaves
+//   k_dec_table    rANS: frequency tables -> reverse lookup tables (incl. the nested order-0 coded order-1 table)
+//   k_rans_decode  4 states on 4 lanes of one wave, shared forward read pointer
+//   k_arith_decode lane 0, models in LDS
+//   k_dec_finish   CAT copies, unpack (pack.c:214-351), unstripe (utils.h:41-73), status
+#pragma once
+#include "gz_device.h"
+#include "gz_devutil.h"
+
+__device__ static bool d_parse_unit (GzdDecStream &S, GzdDecLeaf &L, const uint8_t *u, uint32_t unit_len,
+                                     uint32_t expect_n, uint8_t *final_dst, uint8_t *packed_tmp, bool rans)
+{
+    if (!unit_len) return false;
+    uint32_t q = 1, v;
+    const uint8_t flag = u[0];
+    if (flag & GZ_X_STRIPE) return false;                            // no nested striping
+    if (!(flag & GZ_X_NOSZ)) {
+        uint32_t used = gz_vi_get (u + q, unit_len - q, &v);
+        if (!used || v != expect_n) return false;
+        q += used;
+    }
+    L.engine = rans ? GZ_ENG_RANS : GZ_ENG_ARITH;
+    L.o1  = rans ? (flag & 1) : ((flag & 3) == 1);
+    L.rle = (flag & GZ_X_RLE) ? 1 : 0;
+    L.cat = (flag & GZ_X_CAT) ? 1 : 0;
+    if (rans && L.rle) return false;                                 // rle.c streams are never written by Genozip
+    if (!rans && (flag & 4)) return false;                           // X_EXT
+    L.n = expect_n; L.final_dst = final_dst;
+    L.packed_on = 0; L.per = 1;
+    uint32_t coded_n = expect_n;
+    uint8_t *dst = final_dst;
+    if (flag & GZ_X_PACK) {
+        if (q >= unit_len) return false;
+        uint32_t ns = u[q] ? u[q] : 256;
+        L.packed_on = 1;
+        if (ns > 16) { L.per = 1; q += 1; }
+        else {
+            L.per = ns <= 1 ? 0 : ns <= 2 ? 8 : ns <= 4 ? 4 : 2;
+            if (q + 1 + ns > unit_len) return false;
+            for (uint32_t k = 0; k < ns; k++) L.map[k] = u[q + 1 + k];
+            q += 1 + ns;
+        }
+        uint32_t used = gz_vi_get (u + q, unit_len - q, &coded_n);
+        if (!used || coded_n > expect_n) return false;
+        q += used;
+        dst = packed_tmp;
+    }
+    L.dst = dst; L.coded_n = coded_n;
+    L.body = u + q; L.body_len = unit_len - q;
+    if (!L.body_len) L.coded_n = 0;                                  // "in_size == 0": nothing was coded (:1583-1601)
+    L.status = GZ_ST_PENDING;
+    L.active = 1;
+    return true;
+}
+
+__global__ void k_dec_parse (GzdDecStream *streams, GzdDecLeaf *leaves, uint32_t n_streams)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_streams) return;
+    GzdDecStream &S = streams[i];
+    if (S.status != GZ_ST_PENDING) return;
+    GzdDecLeaf *L = leaves + S.first_leaf;
+    for (int k = 0; k < 4; k++) L[k].active = 0;
+    S.striped = 0; S.n_leaves = 0;
+    if (S.codec == 1) { if (S.in_len != S.out_len) S.status = GZ_ST_CORRUPT; return; }
+    const bool rans = S.codec >= 6 && S.codec <= 9;
+    S.engine = rans ? GZ_ENG_RANS : GZ_ENG_ARITH;
+    if (!S.in_len) { S.status = GZ_ST_CORRUPT; return; }
+    const uint8_t *in = S.in;
+    bool ok = true;
+    if (in[0] & GZ_X_STRIPE) {
+        uint32_t p = 1, ulen, used, clen[4], len[4], off[4];
+        used = gz_vi_get (in + p, S.in_len - p, &ulen);
+        ok = used && ulen == S.out_len;
+        p += used;
+        ok = ok && p < S.in_len && in[p] == 4;
+        p++;
+        for (int k = 0; ok && k < 4; k++) { used = gz_vi_get (in + p, S.in_len - p, &clen[k]); ok = used && clen[k] >= 1; p += used; }
+        if (ok) {
+            gz_plane_geometry (ulen, len, off);
+            for (int k = 0; ok && k < 4; k++) {
+                ok = p + clen[k] <= S.in_len &&
+                     d_parse_unit (S, L[k], in + p, clen[k], len[k], S.tmp_planes + off[k], S.tmp_packed + off[k], rans);
+                p += clen[k];
+            }
+            S.striped = 1; S.n_leaves = 4;
+        }
+    }
+    else {
+        ok = d_parse_unit (S, L[0], in, S.in_len, S.out_len, S.out, S.tmp_packed, rans);
+        S.n_leaves = 1;
+    }
+    if (!ok) { S.status = GZ_ST_CORRUPT; for (int k = 0; k < 4; k++) L[k].active = 0; }
+}
+
+// ---- frequency table parsing -------------------------------------------------------------------------------
+
+// symbol list (rANS_static4x16pr.c:205-252) -> present[256]; returns bytes consumed or 0
+__device__ static uint32_t d_alphabet_get (const uint8_t *src, uint32_t avail, uint32_t *present)
+{
+    uint32_t p = 0;
+    if (!avail) return 0;
+    int run = 0, s = src[p++];
+    for (;;) {
+        present[s] = 1;
+        if (run) { run--; s++; if (s > 255) return 0; }
+        else {
+            if (p >= avail) return 0;
+            if (s + 1 == src[p]) { if (p + 1 >= avail) return 0; s = src[p++]; run = src[p++]; }
+            else s = src[p++];
+        }
+        if (!s) break;
+    }
+    return p;
+}
+
+// order-0 table at `src` -> 4096-entry lookup (sym | (freq-1) << 8 | offset << 20). One thread. Returns bytes
+// consumed or 0. F is a 256-word scratch.
+__device__ static uint32_t d_o0_lut (const uint8_t *src, uint32_t avail, uint32_t *F, uint32_t *lut)
+{
+    for (int s = 0; s < 256; s++) F[s] = 0;
+    uint32_t p = d_alphabet_get (src, avail, F), sum = 0;
+    if (!p) return 0;
+    for (int s = 0; s < 256; s++)
+        if (F[s]) {
+            uint32_t used = gz_vi_get (src + p, avail - p, &F[s]);
+            if (!used) return 0;
+            p += used; sum += F[s];
+        }
+    if (!sum || sum > 4096) return 0;
+    int sh = 0;
+    while ((sum << sh) < 4096) sh++;
+    if ((sum << sh) != 4096) return 0;
+    uint32_t c = 0;
+    for (int s = 0; s < 256; s++) {
+        uint32_t f = F[s] << sh;
+        for (uint32_t k = 0; k < f; k++) lut[c + k] = (uint32_t)s | ((f - 1) << 8) | (k << 20);
+        c += f;
+    }
+    return c == 4096 ? p : 0;
+}
+
+// The 4 decoder states on lanes 0..3; called by all 64 lanes. sym(k, r, x) consumes state x of lane k at its r-th
+// step and returns the new (un-renormalised) state after storing the decoded byte. Renormalisation reads 16-bit
+// words from one shared forward pointer in lane order (rANS_word.h:380-409).
+template <typename StepFn>
+__device__ static bool d_rans_decode_wave (const uint8_t *pay, uint32_t pay_len, uint32_t len_k, uint32_t rounds, StepFn step)
+{
+    const int lane = threadIdx.x & 63;
+    if (pay_len < 16) return false;
+    uint32_t x = 0;
+    if (lane < 4) {
+        const uint8_t *p = pay + 4 * lane;
+        x = p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24);
+    }
+    bool bad = lane < 4 && x < 0x8000u;
+    if (__ballot (bad)) return false;
+    uint32_t pos = 16;
+    for (uint32_t r = 0; r < rounds; r++) {
+        bool mine = lane < 4 && r < len_k;
+        if (mine) x = step (lane, r, x);
+        bool need = mine && x < 0x8000u;
+        uint64_t m = __ballot (need) & 0xfull;
+        if (need) {
+            uint32_t at = pos + 2 * __popcll (m & ((1ull << lane) - 1));
+            if (at + 1 < pay_len) x = (x << 16) | pay[at] | (pay[at + 1] << 8);
+        }
+        pos += 2 * __popcll (m);
+    }
+    return true;
+}
+
+// one 256-thread workgroup per decode leaf; 20 KB dynamic LDS
+__global__ void __launch_bounds__(256) k_dec_table (GzdDecLeaf *leaves)
+{
+    GzdDecLeaf &L = leaves[blockIdx.x];
+    if (!L.active || L.engine != GZ_ENG_RANS || L.cat || !L.coded_n) return;
+    const int tid = threadIdx.x;
+    uint32_t *lds = (uint32_t *)gz_lds;
+    uint32_t *F = lds;               // [256]
+    uint32_t *sh = lds + 256;        // [0] status/consumed ...
+    uint32_t *lut0 = lds + 512;      // [4096] nested / order-0 lookup
+
+    if (!L.o1) {
+        if (!tid) {
+            uint32_t used = d_o0_lut (L.body, L.body_len, F, (uint32_t *)L.lut);
+            if (!used) L.status = GZ_ST_CORRUPT;
+            else { L.pay = L.body + used; L.pay_len = L.body_len - used; }
+        }
+        return;
+    }
+
+    // ---- order 1 (rANS_static4x16pr.c:953-1016)
+    const uint8_t *tab; uint32_t tab_avail;
+    if (!tid) {
+        sh[0] = 1;
+        uint32_t bits = L.body_len ? L.body[0] >> 4 : 0;
+        if (bits != 10 && bits != 12) sh[0] = 0;
+        sh[1] = bits;
+    }
+    __syncthreads ();
+    if (!sh[0]) { if (!tid) L.status = GZ_ST_CORRUPT; return; }
+    const uint32_t bits = sh[1];
+    const bool nested = L.body[0] & 1;
+    if (nested) {
+        if (!tid) {
+            uint32_t p = 1, raw = 0, clen = 0, used;
+            bool ok = (used = gz_vi_get (L.body + p, L.body_len - p, &raw)) != 0;
+            p += used;
+            ok = ok && (used = gz_vi_get (L.body + p, L.body_len - p, &clen)) != 0;
+            p += used;
+            ok = ok && raw <= GZ_TAB_CAP && p + clen + 16 <= L.body_len && clen >= 16;
+            uint32_t tused = ok ? d_o0_lut (L.body + p, clen, F, lut0) : 0;
+            ok = ok && tused;
+            sh[0] = ok; sh[2] = raw; sh[3] = p + tused; sh[4] = clen - tused; sh[5] = p + clen;
+        }
+        __syncthreads ();
+        if (!sh[0]) { if (!tid) L.status = GZ_ST_CORRUPT; return; }
+        const uint32_t raw = sh[2];
+        const uint8_t *npay = L.body + sh[3];
+        uint8_t *dstt = L.tabtmp;
+        if (tid < 64) {
+            uint32_t len_k = (raw >> 2) + ((raw & 3) > (uint32_t)(tid & 3));
+            bool ok = d_rans_decode_wave (npay, sh[4], tid < 4 ? len_k : 0, (raw + 3) >> 2,
+                                          [&] (int k, uint32_t r, uint32_t x) {
+                                              uint32_t e = lut0[x & 4095];
+                                              dstt[4 * r + k] = (uint8_t)e;
+                                              return (((e >> 8) & 0xfff) + 1) * (x >> 12) + (e >> 20);
+                                          });
+            if (!tid && !ok) sh[0] = 0;
+        }
+        __syncthreads ();
+        if (!sh[0]) { if (!tid) L.status = GZ_ST_CORRUPT; return; }
+        tab = L.tabtmp; tab_avail = raw;
+    }
+    else { tab = L.body + 1; tab_avail = L.body_len - 1; }
+
+    // thread 0 walks the variable-length rows; the frequencies land in fc[c][s], then every thread expands its row
+    uint32_t *present = F;
+    present[tid] = 0;
+    __syncthreads ();
+    if (!tid) {
+        bool ok = true;
+        uint32_t p = d_alphabet_get (tab, tab_avail, present);
+        ok = p != 0;
+        for (int c = 0; ok && c < 256; c++) {
+            if (!present[c]) continue;
+            uint32_t *row = L.fc + c * 256, zeros = 0;
+            for (int s = 0; ok && s < 256; s++) {
+                row[s] = 0;
+                if (!present[s]) continue;
+                if (zeros) { zeros--; continue; }
+                uint32_t f, used = gz_vi_get (tab + p, tab_avail - p, &f);
+                if (!used) { ok = false; break; }
+                p += used;
+                if (!f) { if (p >= tab_avail) { ok = false; break; } zeros = tab[p++]; }
+                row[s] = f;
+            }
+        }
+        sh[0] = ok;
+        sh[6] = p;
+    }
+    __syncthreads ();
+    if (!sh[0]) { if (!tid) L.status = GZ_ST_CORRUPT; return; }
+    {
+        const int c = tid;
+        bool ok = true;
+        if (present[c]) {
+            uint32_t *row = L.fc + c * 256, sum = 0;
+            for (int s = 0; s < 256; s++) sum += row[s];
+            if (sum) {
+                int shf = 0;
+                while ((sum << shf) < (1u << bits)) shf++;
+                ok = (sum << shf) == (1u << bits);
+                uint32_t cum = 0;
+                uint8_t *lrow = L.lut + ((size_t)c << bits);
+                for (int s = 0; ok && s < 256; s++) {
+                    uint32_t f = row[s] << shf;
+                    if (!f) continue;
+                    for (uint32_t k = 0; k < f; k++) lrow[cum + k] = (uint8_t)s;
+                    row[s] = f | (cum << 16);
+                    cum += f;
+                }
+            }
+        }
+        if (!ok) L.status = GZ_ST_CORRUPT;
+    }
+    if (!tid) {
+        uint32_t consumed = nested ? sh[5] : 1 + sh[6];
+        L.pay = L.body + consumed; L.pay_len = L.body_len - consumed; L.shift_bits = (uint8_t)bits;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_rans_decode (GzdDecLeaf *leaves)
+{
+    GzdDecLeaf &L = leaves[blockIdx.x];
+    if (!L.active || L.engine != GZ_ENG_RANS || L.cat || !L.coded_n || L.status != GZ_ST_PENDING) return;
+    const int lane = threadIdx.x;
+    const uint32_t n = L.coded_n;
+    uint8_t *out = L.dst;
+    bool ok;
+    if (!L.o1) {
+        const uint32_t *lut = (const uint32_t *)L.lut;
+        uint32_t len_k = (n >> 2) + ((n & 3) > (uint32_t)(lane & 3));
+        ok = d_rans_decode_wave (L.pay, L.pay_len, lane < 4 ? len_k : 0, (n + 3) >> 2,
+                                 [&] (int k, uint32_t r, uint32_t x) {
+                                     uint32_t e = lut[x & 4095];
+                                     out[4 * r + k] = (uint8_t)e;
+                                     return (((e >> 8) & 0xfff) + 1) * (x >> 12) + (e >> 20);
+                                 });
+    }
+    else {
+        const uint32_t bits = L.shift_bits, mask = (1u << bits) - 1, q = n >> 2;
+        const uint8_t *lut = L.lut; const uint32_t *fc = L.fc;
+        uint32_t last = 0;
+        uint32_t len_k = lane == 3 ? n - 3 * q : q;
+        ok = d_rans_decode_wave (L.pay, L.pay_len, lane < 4 ? len_k : 0, n - 3 * q,
+                                 [&] (int k, uint32_t r, uint32_t x) {
+                                     uint32_t m = x & mask;
+                                     uint32_t s = lut[((size_t)last << bits) + m];
+                                     uint32_t e = fc[last * 256 + s];
+                                     out[k * q + r] = (uint8_t)s;
+                                     last = s;
+                                     return (e & 0xffff) * (x >> bits) + m - (e >> 16);
+                                 });
+    }
+    if (!lane) L.status = ok ? GZ_ST_OK : GZ_ST_CORRUPT;
+}
+
+// ---- adaptive arithmetic decoder (c_range_coder.h:55-68,111-127, c_simple_model.h:148-179) --------------------
+struct GzRcDec { uint32_t code, range; const uint8_t *in; uint32_t pos, len; };
+
+__device__ static inline uint32_t d_model_decode (uint32_t *m, uint32_t max_sym, GzRcDec &rc)
+{
+    uint32_t tot = m[0];
+    uint32_t target = (tot && rc.range >= tot) ? rc.code / (rc.range /= tot) : 0;
+    if (target > 65519) return 0;
+    uint32_t *slot = m + 1, cum = 0, at = 0, e = slot[0];
+    while (cum + (e & 0xffff) <= target) {
+        cum += e & 0xffff;
+        if (++at >= max_sym) return 0;                 // malformed
+        e = slot[at];
+    }
+    rc.code  -= cum * rc.range;
+    rc.range *= e & 0xffff;
+    while (rc.range < (1u << 24)) {
+        if (rc.pos >= rc.len) break;
+        rc.code = (rc.code << 8) + rc.in[rc.pos++];
+        rc.range <<= 8;
+    }
+    uint32_t sym = e >> 16;
+    e += 16;
+    uint32_t t2 = tot + 16;
+    slot[at] = e;
+    if (t2 > 65519) {
+        t2 = 0;
+        for (uint32_t i = 0; i < max_sym; i++) {
+            uint32_t v = slot[i], f = v & 0xffff;
+            f -= f >> 1;
+            slot[i] = (v & 0xffff0000u) | f;
+            t2 += f;
+        }
+        e = slot[at];
+    }
+    m[0] = t2;
+    if (at > 0) {
+        uint32_t left = slot[at - 1];
+        if ((e & 0xffff) > (left & 0xffff)) { slot[at - 1] = e; slot[at] = left; }
+    }
+    return sym;
+}
+
+__global__ void __launch_bounds__(64) k_arith_decode (GzdDecLeaf *leaves, uint32_t lds_words_lo, uint32_t lds_words_hi, int use_global)
+{
+    GzdDecLeaf &L = leaves[blockIdx.x];
+    if (!L.active || L.engine != GZ_ENG_ARITH || L.cat || !L.coded_n) return;
+    if (!L.body_len) return;
+    const uint32_t n = L.coded_n;
+    const uint32_t ms = L.body[0] ? L.body[0] : 256;
+    const bool o1 = L.o1, rle = L.rle;
+    const uint32_t words = (o1 ? ms : 1) * (ms + 1) + (rle ? 258 * 5 : 0);
+    if (words <= lds_words_lo || words > lds_words_hi) return;
+    uint32_t *models = use_global ? L.models : (uint32_t *)gz_lds;
+    const int lane = threadIdx.x;
+    const uint32_t nlit = o1 ? ms : 1, lit_stride = ms + 1;
+    for (uint32_t i = lane; i < nlit * lit_stride; i += 64) { uint32_t k = i % lit_stride; models[i] = k ? (1u | ((k - 1) << 16)) : ms; }
+    uint32_t *runm = models + nlit * lit_stride;
+    if (rle) for (uint32_t i = lane; i < 258 * 5; i += 64) { uint32_t k = i % 5; runm[i] = k ? (1u | ((k - 1) << 16)) : 4; }
+    __syncthreads ();
+    if (lane) return;
+
+    GzRcDec rc;
+    rc.code = 0; rc.range = 0xffffffffu; rc.in = L.body + 1; rc.pos = 0; rc.len = L.body_len - 1;
+    if (rc.len >= 5) for (int k = 0; k < 5; k++) rc.code = (rc.code << 8) | rc.in[rc.pos++];
+    else rc.pos = rc.len;
+    uint8_t *out = L.dst;
+    uint32_t last = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t s = d_model_decode (models + (o1 ? last * lit_stride : 0), ms, rc);
+        if (s >= ms) s = 0;
+        out[i] = (uint8_t)s;
+        last = s;
+        if (!rle) continue;
+        uint32_t run = 0, d, ctx = s;                            // arith_dynamic.c:476-487
+        do {
+            d = d_model_decode (runm + ctx * 5, 4, rc);
+            ctx = (ctx == s) ? 256 : ctx + (ctx < 257);
+            run += d;
+        } while (d == 3 && run < n);
+        while (run-- && i + 1 < n) out[++i] = (uint8_t)s;
+    }
+    L.status = GZ_ST_OK;
+}
+
+// one 256-thread workgroup per stream
+__global__ void __launch_bounds__(256) k_dec_finish (GzdDecStream *streams, GzdDecLeaf *leaves)
+{
+    GzdDecStream &S = streams[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (S.status != GZ_ST_PENDING) return;
+    if (S.codec == 1) {
+        for (uint32_t i = tid; i < S.out_len; i += 256) S.out[i] = S.in[i];
+        __syncthreads ();       // status is also this kernel's entry test: change it only once everybody is past it
+        if (!tid) S.status = GZ_ST_OK;
+        return;
+    }
+    bool ok = true;
+    for (uint32_t k = 0; k < S.n_leaves; k++) {
+        GzdDecLeaf &L = leaves[S.first_leaf + k];
+        if (!L.active) { ok = false; continue; }
+        if (L.coded_n) {
+            if (L.cat) {
+                if (L.body_len < L.coded_n) ok = false;
+                else for (uint32_t i = tid; i < L.coded_n; i += 256) L.dst[i] = L.body[i];
+            }
+            else if (L.status != GZ_ST_OK) ok = false;
+        }
+        __syncthreads ();
+        if (L.packed_on && ok) {                               // pack.c:214-351
+            const uint32_t per = L.per, n = L.n;
+            if (per == 1) { if (L.coded_n != n) ok = false; else for (uint32_t i = tid; i < n; i += 256) L.final_dst[i] = L.dst[i]; }
+            else if (per == 0) { for (uint32_t i = tid; i < n; i += 256) L.final_dst[i] = L.map[0]; }
+            else {
+                if ((n + per - 1) / per > L.coded_n) ok = false;
+                else {
+                    const uint32_t width = 8 / per, mask = (1u << width) - 1;
+                    for (uint32_t i = tid; i < n; i += 256) L.final_dst[i] = L.map[(L.dst[i / per] >> ((i % per) * width)) & mask];
+                }
+            }
+        }
+        else if (!L.packed_on && ok && L.coded_n != L.n) ok = false;
+        __syncthreads ();
+    }
+    if (ok && S.striped) {
+        uint32_t len[4], off[4];
+        gz_plane_geometry (S.out_len, len, off);
+        for (uint32_t i = tid; i < S.out_len; i += 256) S.out[i] = S.tmp_planes[off[i & 3] + (i >> 2)];
+    }
+    __syncthreads ();
+    if (!tid) S.status = ok ? GZ_ST_OK : GZ_ST_CORRUPT;
+}

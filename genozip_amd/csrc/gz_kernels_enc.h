@@ -1,0 +1,856 @@
+// gz_kernels_enc.h -- gfx950 kernels of the compression direction.
+//
+// Pipeline over a table of streams / leaves (see gz_device.h), one launch per phase, every phase covering ALL
+// leaves of ALL streams of ALL VBlocks in the batch:
+//   k_resolve      stream lengths, effective codec, striping decision          (codec rules: compressor.c:56-58,
+//                                                                                rANS_static4x16pr.c:1162)
+//   k_stripe       byte i -> plane i%4                                          (rANS_static4x16pr.c:1174-1190)
+//   k_leaf_prep    PACK (pack.c:58-154), unit prefix, alphabet of the coded bytes
+//   k_hist         order-0 / order-1 histograms (utils.h:81,137)
+//   k_rans_table   normalise, compute_shift, serialise + (optionally) order-0 code the table, build the encoder
+//                  records (rANS_static4x16pr.c:113-203,254-322,376-433,626-687,729-796)
+//   k_rans_encode  the 4 interleaved rANS states of a leaf on 4 lanes of one wave (rANS_word.h:280-320)
+//   k_arith_encode adaptive range coder, models in LDS (arith_dynamic.c:92-197,387-561, c_range_coder.h,
+//                  c_simple_model.h)
+//   k_select       CAT fallback, best method per plane, stream size
+//   k_vb_layout    section offsets inside each VBlock's z_data (zip.c:560-585 order, given by the caller)
+//   k_emit         final bytes: stripe meta + units; SectionHeaderCtx + adler32 in VBlock mode
+#pragma once
+#include "gz_device.h"
+#include "gz_devutil.h"
+
+// ======================================================================================================
+// k_resolve : one thread per stream
+// ======================================================================================================
+__global__ void k_resolve (GzdStream *streams, uint32_t n_streams, int section_mode)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_streams) return;
+    GzdStream &S = streams[i];
+    if (S.status != GZ_ST_PENDING) return;
+
+    uint32_t n = S.in_len;
+    if (S.in_len_dev) { uint32_t v = *S.in_len_dev; if (v < n) n = v; }
+    S.n = n;
+
+    int codec = S.codec_req;
+    if (section_mode && n < 50) codec = 1 /* CODEC_NONE: compressor.c:56-58 */;
+    S.codec = (uint8_t)codec;
+
+    int order = gz_codec_order (codec);
+    S.engine = (codec >= 6 && codec <= 9) ? GZ_ENG_RANS : (codec >= 16 && codec <= 19) ? GZ_ENG_ARITH : GZ_ENG_NONE;
+    if (order < 0) order = 0;
+    if (n <= 20) order &= ~GZ_X_STRIPE;       // rANS_static4x16pr.c:1162, arith_dynamic.c:626
+    S.order   = (uint8_t)order;
+    S.striped = (order & GZ_X_STRIPE) ? 1 : 0;
+}
+
+// ======================================================================================================
+// k_stripe : grid (n_streams, chunks)
+// ======================================================================================================
+__global__ void k_stripe (GzdStream *streams)
+{
+    const GzdStream &S = streams[blockIdx.x];
+    if (S.status != GZ_ST_PENDING || !S.striped) return;
+    uint32_t n = S.n, off[4], len[4];
+    gz_plane_geometry (n, len, off);
+    // each thread moves 4 consecutive bytes of one plane: plane k, positions x..x+3 <- in[4x+k], in[4(x+1)+k], ...
+    uint32_t quads = (n + 15) / 16;   // groups of 16 input bytes
+    for (uint32_t g = blockIdx.y * blockDim.x + threadIdx.x; g < quads; g += gridDim.y * blockDim.x) {
+        uint32_t base = g * 16;
+        uint8_t b[16];
+        #pragma unroll
+        for (int j = 0; j < 16; j++) b[j] = (base + j < n) ? S.in[base + j] : 0;
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t x = g * 4;
+            #pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (x + j < len[k]) S.planes[off[k] + x + j] = b[4 * j + k];
+        }
+    }
+}
+
+// ======================================================================================================
+// k_leaf_prep : one 256-thread workgroup per leaf
+// ======================================================================================================
+__global__ void __launch_bounds__(256) k_leaf_prep (GzdStream *streams, GzdLeaf *leaves)
+{
+    GzdLeaf &L = leaves[blockIdx.x];
+    const GzdStream &S = streams[L.stream];
+    const int tid = threadIdx.x;
+    uint32_t *flags = (uint32_t *)gz_lds;          // [256] presence -> rank
+    uint32_t *misc  = flags + 256;                 // [0] nsym  [1] max present  ; [16..] symbol list
+    const bool arith = L.engine == GZ_ENG_ARITH;
+
+    bool active = S.status == GZ_ST_PENDING && S.engine == L.engine &&
+                  ((L.plane == 0xff) ? !S.striped : S.striped);
+    if (!active) { if (!tid) { L.active = 0; L.unit_len = 0; } return; }
+
+    const uint8_t *src; uint32_t n;
+    if (L.plane == 0xff) { src = S.in; n = S.n; }
+    else { uint32_t len[4], off[4]; gz_plane_geometry (S.n, len, off); src = S.planes + off[L.plane]; n = len[L.plane]; }
+
+    uint8_t  flag = L.method;
+    bool     o1 = flag & 1, rle = arith && (flag & GZ_X_RLE), nosz = flag & GZ_X_NOSZ;
+    bool     packed_on = false;
+    const uint8_t *coded = src; uint32_t coded_n = n;
+    uint32_t nsym_pack = 0;
+
+    if (flag & GZ_X_PACK) {
+        if (!n) flag &= ~GZ_X_PACK;
+        else {
+            flags[tid] = 0;
+            __syncthreads ();
+            for (uint32_t i = tid; i < n; i += 256) flags[src[i]] = 1;
+            __syncthreads ();
+            if (!tid) {
+                uint32_t ns = 0;
+                for (int s = 0; s < 256; s++) if (flags[s]) { misc[16 + ns] = s; flags[s] = ns++; }
+                misc[0] = ns;
+            }
+            __syncthreads ();
+            nsym_pack = misc[0];
+            if (nsym_pack > 16 && nsym_pack < 256) flag &= ~GZ_X_PACK;            // rANS_static4x16pr.c:1260-1264
+            else {
+                packed_on = true;
+                if (nsym_pack <= 16) {
+                    uint32_t per = nsym_pack > 4 ? 2 : nsym_pack > 2 ? 4 : nsym_pack > 1 ? 8 : 0;
+                    coded = L.packed;
+                    coded_n = per ? (n + per - 1) / per : 0;
+                    uint32_t width = per ? 8 / per : 0;
+                    for (uint32_t j = tid; j < coded_n; j += 256) {
+                        uint32_t v = 0, base = j * per;
+                        for (uint32_t t = 0; t < per && base + t < n; t++) v |= flags[src[base + t]] << (t * width);
+                        L.packed[j] = (uint8_t)v;
+                    }
+                }
+                // 256 distinct symbols: the count byte wraps to 0, data passes through unchanged and stays "packed"
+            }
+            __syncthreads ();
+        }
+    }
+
+    if (o1 && coded_n < 8) { flag &= arith ? ~3 : ~1; o1 = false; }               // :1333-1336 / arith :803-806
+    if (rle && !n) flag &= ~GZ_X_RLE;                                             // arith :798-800 (coder still RLE)
+
+    if (!tid) {
+        uint32_t p = 0;
+        L.prefix[p++] = flag;
+        if (!nosz) p += gz_vi_put (L.prefix + p, n);
+        if (packed_on) {
+            L.prefix[p++] = (uint8_t)nsym_pack;
+            if (nsym_pack <= 16) for (uint32_t k = 0; k < nsym_pack; k++) L.prefix[p++] = (uint8_t)misc[16 + k];
+            p += gz_vi_put (L.prefix + p, coded_n);
+        }
+        L.prefix_len = (uint8_t)p;
+        L.active = 1; L.flag = flag; L.o1 = o1; L.rle = rle; L.packed_on = packed_on; L.cat = 0;
+        L.src = src; L.n = n; L.coded = coded; L.coded_n = coded_n;
+        L.tab_len = 0; L.pay_len = 0; L.overflow = 0; L.unit_len = 0; L.shift_bits = 0;
+    }
+    __syncthreads ();   // packed bytes written by all threads are read below
+
+    // alphabet of the coded bytes: rank map for the order-1 histogram, max symbol for the arith models
+    flags[tid] = 0;
+    __syncthreads ();
+    for (uint32_t i = tid; i < coded_n; i += 256) flags[coded[i]] = 1;
+    __syncthreads ();
+    if (!tid) {
+        uint32_t ns = 0, mx = 0;
+        for (int s = 0; s < 256; s++) {
+            if (flags[s]) { L.symlist[ns] = (uint8_t)s; L.symrank[s] = (uint16_t)ns; ns++; mx = s; }
+            else L.symrank[s] = 0xffff;
+        }
+        L.nsym = ns;
+        L.max_sym = mx + 1;
+    }
+
+    // clear the histogram of rANS leaves (256 order-0 counters, or 256 rows x 256 + 256 totals)
+    if (L.engine == GZ_ENG_RANS && L.F) {
+        uint32_t cnt = o1 ? 256 * 256 + 256 : 256;
+        for (uint32_t i = tid; i < cnt; i += 256) L.F[i] = 0;
+    }
+}
+
+// ======================================================================================================
+// k_hist : grid (n_leaves, GZ_HIST_CHUNKS), 256 threads, dynamic LDS = GZ_HIST_LDS bytes
+// ======================================================================================================
+#define GZ_HIST_CHUNKS 8
+#define GZ_HIST_RANKS  120                       // order-1 counters kept in LDS when the alphabet is this small
+#define GZ_HIST_LDS    (GZ_HIST_RANKS * GZ_HIST_RANKS * 4)
+
+__global__ void __launch_bounds__(256) k_hist (GzdLeaf *leaves)
+{
+    GzdLeaf &L = leaves[blockIdx.x];
+    if (!L.active || L.engine != GZ_ENG_RANS) return;
+    const int tid = threadIdx.x;
+    const uint32_t n = L.coded_n;
+    if (!n) return;
+    const uint8_t *in = L.coded;
+    uint32_t chunk = (n + gridDim.y - 1) / gridDim.y;
+    uint32_t lo = blockIdx.y * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    if (lo >= hi) return;
+    uint32_t *h = (uint32_t *)gz_lds;
+
+    if (!L.o1) {
+        h[tid] = 0;
+        __syncthreads ();
+        for (uint32_t i = lo + tid; i < hi; i += 256) atomicAdd (&h[in[i]], 1u);
+        __syncthreads ();
+        if (h[tid]) atomicAdd (&L.F[tid], h[tid]);
+        return;
+    }
+
+    const uint32_t ns = L.nsym;
+    const uint32_t q = n >> 2;
+    if (ns <= GZ_HIST_RANKS) {
+        // counters indexed by (rank of context, rank of symbol); context 0 may be absent from the data -> rank slot ns
+        const uint32_t w = ns + 1;     // one extra row for the "context 0" of stream / quarter heads if byte 0 is absent
+        for (uint32_t i = tid; i < w * ns; i += 256) h[i] = 0;
+        __syncthreads ();
+        const uint32_t r0 = L.symrank[0] != 0xffff ? L.symrank[0] : ns;
+        for (uint32_t i = lo + tid; i < hi; i += 256) {
+            uint32_t rc = i ? L.symrank[in[i - 1]] : r0;
+            atomicAdd (&h[rc * ns + L.symrank[in[i]]], 1u);
+        }
+        if (!blockIdx.y && !tid)
+            for (int k = 1; k < 4; k++) atomicAdd (&h[r0 * ns + L.symrank[in[k * q]]], 1u);  // quarter heads, :730-733
+        __syncthreads ();
+        for (uint32_t i = tid; i < w * ns; i += 256) {
+            uint32_t v = h[i];
+            if (!v) continue;
+            uint32_t rc = i / ns, rs = i % ns;
+            uint32_t c = rc == ns ? 0 : L.symlist[rc];
+            atomicAdd (&L.F[c * 256 + L.symlist[rs]], v);
+        }
+    }
+    else {
+        for (uint32_t i = lo + tid; i < hi; i += 256) atomicAdd (&L.F[(i ? in[i - 1] : 0) * 256 + in[i]], 1u);
+        if (!blockIdx.y && !tid)
+            for (int k = 1; k < 4; k++) atomicAdd (&L.F[in[k * q]], 1u);
+    }
+}
+
+// ======================================================================================================
+// rANS table construction
+// ======================================================================================================
+
+// rANS_static4x16pr.c:113-160 -- see oracle/gz_oracle.c freq_scale for the prose. F may live in LDS or global.
+__device__ static void d_freq_scale (uint32_t *F, uint32_t sum, uint32_t target)
+{
+    if (!sum) return;
+    for (int pass = 0; ; pass++) {
+        uint64_t mult = (((uint64_t)target) << 31) / sum + (uint32_t)((1u << 30) / sum);
+        uint32_t big = 0, new_sum = 0;
+        int big_at = 0;
+        for (int s = 0; s < 256; s++) {
+            uint32_t f = F[s];
+            if (!f) continue;
+            if (f > big) { big = f; big_at = s; }
+            uint32_t g = (uint32_t)((f * mult) >> 31);
+            if (!g) g = 1;
+            F[s] = g;
+            new_sum += g;
+        }
+        int32_t adjust = (int32_t)target - (int32_t)new_sum;
+        if (adjust > 0) F[big_at] += (uint32_t)adjust;
+        else if (adjust < 0) {
+            uint32_t need = (uint32_t)(-adjust), fb = F[big_at];
+            if (fb > need && (pass == 1 || fb / 2 >= need)) F[big_at] = fb - need;
+            else if (pass == 0) { sum = new_sum; continue; }
+            else {
+                adjust += (int32_t)fb - 1;
+                F[big_at] = 1;
+                for (int s = 0; adjust && s < 256; s++) {
+                    uint32_t f = F[s];
+                    if (f < 2) continue;
+                    int32_t step = (f > (uint32_t)(-adjust)) ? adjust : 1 - (int32_t)f;
+                    F[s] = (uint32_t)((int32_t)f + step);
+                    adjust -= step;
+                }
+            }
+        }
+        break;
+    }
+}
+
+__device__ static inline void d_freq_shift_up (uint32_t *F, uint32_t sum, uint32_t target)
+{
+    if (!sum || sum == target) return;
+    int sh = 0;
+    while (sum < target) { sum <<= 1; sh++; }
+    for (int s = 0; s < 256; s++) F[s] <<= sh;
+}
+
+// present[] as 0/1 words; writes the run-length coded symbol list (rANS_static4x16pr.c:179-203)
+__device__ static uint32_t d_alphabet_put (uint8_t *dst, const uint32_t *present)
+{
+    uint32_t p = 0;
+    int s = 0;
+    while (s < 256) {
+        if (!present[s]) { s++; continue; }
+        int e = s;
+        while (e + 1 < 256 && present[e + 1]) e++;
+        dst[p++] = (uint8_t)s;
+        if (e > s) { dst[p++] = (uint8_t)(s + 1); dst[p++] = (uint8_t)(e - (s + 1)); }
+        s = e + 1;
+    }
+    dst[p++] = 0;
+    return p;
+}
+
+__device__ static inline GzRansSym d_rans_sym (uint32_t start, uint32_t freq, uint32_t bits)   // rANS_word.h:189-265
+{
+    GzRansSym r;
+    r.x_max = ((0x8000u >> bits) << 16) * freq;
+    uint32_t cmpl = ((1u << bits) - freq) & 0xffff, rsh;
+    if (freq < 2) { r.rcp = ~0u; rsh = 0; r.bias = start + (1u << bits) - 1; }
+    else {
+        uint32_t lg = 0;
+        while (freq > (1u << lg)) lg++;
+        r.rcp  = (uint32_t)(((1ull << (lg + 31)) + freq - 1) / freq);
+        rsh    = lg - 1;
+        r.bias = start;
+    }
+    r.cmpl_rsh = cmpl | (rsh << 16);
+    return r;
+}
+
+// x -> x' and the renormalisation test for one symbol (rANS_word.h:280-320). q < 2^21 and cmpl <= 4096, so the
+// product fits the 24-bit multiplier.
+__device__ static inline uint32_t d_rans_advance (uint32_t x, const GzRansSym &r)
+{
+    uint32_t q = __umulhi (x, r.rcp) >> (r.cmpl_rsh >> 16);
+    return x + r.bias + q * (r.cmpl_rsh & 0xffff);
+}
+
+// The 4 interleaved states on lanes 0..3 of one wave. Lane k codes its own list of (record) steps, longest list
+// first: round r (counting down) is coded by every lane whose list is longer than r. Within a round state 3 emits
+// first, i.e. lands at the highest address of the backwards-growing stream. Called by ALL 64 lanes of the wave.
+//   rec(k, r) -> pointer to the encoder record of lane k's r-th step
+// Returns payload length (bytes, incl. the 16 state bytes) or 0xffffffff on overflow; payload ends at buf+cap.
+template <typename RecFn>
+__device__ static uint32_t d_rans_encode_wave (uint32_t len_k, uint32_t rounds, uint8_t *buf, uint32_t cap, RecFn rec)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t x = 0x8000u;
+    uint32_t used = 0;                 // bytes emitted so far (wave-uniform)
+    bool overflow = false;
+    for (uint32_t r = rounds; r-- > 0; ) {
+        bool mine = lane < 4 && r < len_k;
+        GzRansSym s;
+        s.x_max = 0xffffffffu; s.rcp = 0; s.bias = 0; s.cmpl_rsh = 0;
+        if (mine) s = *rec (lane, r);
+        bool emit = mine && x >= s.x_max;
+        uint64_t m = __ballot (emit) & 0xfull;
+        uint32_t cnt = __popcll (m);
+        if (used + 2 * cnt + 16 > cap) { overflow = true; break; }
+        used += 2 * cnt;
+        if (emit) {
+            uint32_t below = __popcll (m & ((1ull << lane) - 1));       // emitting states with a smaller index
+            uint8_t *p = buf + cap - used + 2 * below;
+            p[0] = (uint8_t)x; p[1] = (uint8_t)(x >> 8);
+            x >>= 16;
+        }
+        if (mine) x = d_rans_advance (x, s);
+    }
+    if (overflow) return 0xffffffffu;
+    used += 16;
+    if (lane < 4) {
+        uint8_t *p = buf + cap - used + 4 * lane;
+        p[0] = (uint8_t)x; p[1] = (uint8_t)(x >> 8); p[2] = (uint8_t)(x >> 16); p[3] = (uint8_t)(x >> 24);
+    }
+    return used;
+}
+
+// order-0 frequency table + encoder records for `n` bytes whose histogram is in F (256 counters, clobbered).
+// Serial (one thread). Returns table length. rANS_static4x16pr.c:405-432
+__device__ static uint32_t d_o0_table (uint32_t *F, uint32_t n, uint8_t *tab, GzRansSym *syms)
+{
+    uint32_t stored = gz_pow2_ceil (n);
+    if (stored > 4096) stored = 4096;
+    d_freq_scale (F, n, stored);
+    uint32_t p = d_alphabet_put (tab, F);
+    for (int s = 0; s < 256; s++) if (F[s]) p += gz_vi_put (tab + p, F[s]);
+    d_freq_scale (F, stored, 4096);
+    uint32_t cum = 0;
+    for (int s = 0; s < 256; s++) if (F[s]) { syms[s] = d_rans_sym (cum, F[s], 12); cum += F[s]; }
+    return p;
+}
+
+// 2 x 257 doubles: log(1024 + k), log(4096 + k) computed by the HOST libm at start-up (bit-identical to what the
+// reference's compute_shift gets from log(), rANS_static4x16pr.c:647-648)
+struct GzLogTable { double l10[257], l12[257]; };
+
+__device__ static inline double d_log_from_bits (int v)   // rANS_static4x16pr.c:617-620
+{
+    double a = (double)v;
+    long long bits = __double_as_longlong (a);
+    return (double)(bits - 4606921278410026770LL) * 1.539095918623324e-16;
+}
+
+// one 256-thread workgroup per rANS leaf
+__global__ void __launch_bounds__(256) k_rans_table (GzdLeaf *leaves, const GzLogTable *logs)
+{
+    GzdLeaf &L = leaves[blockIdx.x];
+    if (!L.active || L.engine != GZ_ENG_RANS) return;
+    const int tid = threadIdx.x;
+    const uint32_t n = L.coded_n;
+    if (!n) { if (!tid) L.tab_len = 0; return; }
+
+    uint32_t *lds = (uint32_t *)gz_lds;
+
+    if (!L.o1) {
+        lds[tid] = L.F[tid];
+        __syncthreads ();
+        if (!tid) L.tab_len = d_o0_table (lds, n, L.tab, L.syms);
+        return;
+    }
+
+    // ---------- order 1 ----------
+    uint32_t *present = lds;            // [256] 0/1, with [0] forced
+    uint32_t *T       = lds + 256;      // [256] row totals
+    uint32_t *target  = lds + 512;      // [256] stored total per row (S[] of compute_shift)
+    uint32_t *rowlen  = lds + 768;      // [256] serialised bytes per row, later exclusive offsets
+    uint32_t *shared  = lds + 1024;     // [0] bits  [1] tab cursor
+    uint32_t *F = L.F;
+
+    present[tid] = (L.symrank[tid] != 0xffff) || tid == 0;
+    {   // row total: one thread per row (only rows of present symbols can be non-empty)
+        uint32_t t = 0;
+        if (present[tid]) for (int s = 0; s < 256; s++) t += F[tid * 256 + s];
+        T[tid] = t;
+    }
+    __syncthreads ();
+
+    // ---- compute_shift (rANS_static4x16pr.c:626-687). The entropy sums must be accumulated in the reference's
+    //      order with the reference's roundings (fused e -= f*d, see oracle/gz_oracle.c o1_choose_bits), so one
+    //      thread walks the (present context, present symbol) pairs in order; only non-zero cells exist there.
+    if (!tid) {
+        double e10 = 0, e12 = 0;
+        uint32_t widest = 0;
+        const uint32_t ns = L.nsym;
+        for (int c = 0; c < 256; c++) {
+            if (!present[c]) continue;
+            const uint32_t tc = T[c];
+            uint32_t cap = gz_pow2_ceil (tc), b10 = 0, b12 = 0, cnt = 0;
+            for (uint32_t k = 0; k < ns; k++) {
+                uint32_t f = F[c * 256 + L.symlist[k]];
+                if (!f) continue;
+                uint32_t ratio = cap / f;
+                b10 += ratio > 1024; b12 += ratio > 4096;
+            }
+            const double l10 = logs->l10[b10], l12 = logs->l12[b12];
+            for (uint32_t k = 0; k < ns; k++) {
+                uint32_t f = F[c * 256 + L.symlist[k]];
+                if (!f) continue;
+                cnt++;
+                int x10 = (int)(1024.0 * (double)f / (double)tc), x12 = (int)(4096.0 * (double)f / (double)tc);
+                double d10 = d_log_from_bits (x10 > 1 ? x10 : 1) - l10;
+                double d12 = d_log_from_bits (x12 > 1 ? x12 : 1) - l12;
+                e10 = fma (-(double)f, d10, e10) + 4.0;
+                e12 = fma (-(double)f, d12, e12) + 6.0;
+            }
+            if (cnt < 64 && cap > 128) cap /= 2;
+            if (cap > 1024)            cap /= 2;
+            if (cap > 4096)            cap = 4096;
+            target[c] = cap;
+            if (cap > widest) widest = cap;
+        }
+        shared[0] = (e10 / e12 < 1.01 || widest <= 1024) ? 10 : 12;
+    }
+    __syncthreads ();
+    const uint32_t bits = shared[0];
+
+    // ---- per row: normalise to the stored total, serialise, scale to 1<<bits, build encoder records
+    {
+        const int c = tid;
+        uint32_t len = 0;
+        if (present[c]) {
+            uint32_t *row = F + c * 256;
+            uint32_t tot = target[c];
+            if (bits == 10 && tot > 1024) tot = 1024;
+            d_freq_scale (row, T[c], tot);
+            uint8_t *dst = L.rowbuf + c * GZ_ROW_SLOT;
+            uint32_t zeros = 0;
+            for (int s = 0; s <= 256; s++) {                       // :292-322 zero runs are "00, run-1"
+                if (s < 256 && !present[s]) continue;
+                if (s < 256 && !row[s]) { zeros++; continue; }
+                if (zeros) { dst[len++] = 0; dst[len++] = (uint8_t)(zeros - 1); zeros = 0; }
+                if (s < 256) len += gz_vi_put (dst + len, row[s]);
+            }
+            d_freq_shift_up (row, tot, 1u << bits);
+            uint32_t cum = 0;
+            GzRansSym *rs = L.syms + c * 256;
+            for (int s = 0; s < 256; s++) { rs[s] = d_rans_sym (cum, row[s], bits); cum += row[s]; }
+        }
+        rowlen[c] = len;
+    }
+    __syncthreads ();
+    if (!tid) {
+        uint32_t p = 0;
+        L.tab[p++] = (uint8_t)(bits << 4);
+        p += d_alphabet_put (L.tab + p, present);
+        for (int c = 0; c < 256; c++) { uint32_t l = rowlen[c]; rowlen[c] = p; p += l; }
+        shared[1] = p;
+    }
+    __syncthreads ();
+    {
+        uint32_t end = tid == 255 ? shared[1] : rowlen[tid + 1];
+        const uint8_t *srcb = L.rowbuf + tid * GZ_ROW_SLOT;
+        for (uint32_t o = rowlen[tid], k = 0; o < end; o++, k++) L.tab[o] = srcb[k];
+    }
+    __syncthreads ();
+    uint32_t tab_len = shared[1];
+
+    // ---- a table of more than 1000 bytes is itself order-0 coded if that saves at least 6 bytes (:779-792)
+    if (tab_len > 1000) {
+        const uint32_t raw = tab_len - 1;
+        const uint8_t *tin = L.tab + 1;
+        uint32_t *h = lds;                            // reuse: [256] histogram
+        GzRansSym *tsyms = (GzRansSym *)(lds + 2048); // [256] records (4 KB) in LDS
+        __syncthreads ();
+        h[tid] = 0;
+        __syncthreads ();
+        for (uint32_t i = tid; i < raw; i += 256) atomicAdd (&h[tin[i]], 1u);
+        __syncthreads ();
+        uint8_t *ttab = L.rowbuf;                     // nested table (< 1 KB), nested payload behind it
+        if (!tid) shared[2] = d_o0_table (h, raw, ttab, tsyms);
+        __syncthreads ();
+        const uint32_t ttab_len = shared[2];
+        uint8_t *tpay = L.rowbuf + 1024;
+        const uint32_t tpay_cap = 256 * GZ_ROW_SLOT - 1024;
+        if (tid < 64) {
+            uint32_t len_k = (raw >> 2) + ((raw & 3) > (uint32_t)(tid & 3));
+            uint32_t rounds = (raw + 3) >> 2;
+            uint32_t plen = d_rans_encode_wave (tid < 4 ? len_k : 0, rounds, tpay, tpay_cap,
+                                                [&] (int k, uint32_t r) { return &tsyms[tin[4 * r + k]]; });
+            if (!tid) shared[3] = plen;
+        }
+        __syncthreads ();
+        const uint32_t plen = shared[3];
+        if (plen != 0xffffffffu && ttab_len + plen + 6 < tab_len) {
+            const uint32_t packed = ttab_len + plen;
+            uint32_t p = 1;
+            if (!tid) {
+                L.tab[0] |= 1;
+                p += gz_vi_put (L.tab + p, raw);
+                p += gz_vi_put (L.tab + p, packed);
+                shared[4] = p;
+            }
+            __syncthreads ();     // everybody has finished reading the raw table (the encode above is complete)
+            p = shared[4];
+            for (uint32_t i = tid; i < ttab_len; i += 256) L.tab[p + i] = ttab[i];
+            for (uint32_t i = tid; i < plen; i += 256)     L.tab[p + ttab_len + i] = tpay[tpay_cap - plen + i];
+            tab_len = p + packed;
+        }
+    }
+    if (!tid) { L.tab_len = tab_len; L.shift_bits = (uint8_t)bits; }
+}
+
+// ======================================================================================================
+// k_rans_encode : one wave per leaf
+// ======================================================================================================
+__global__ void __launch_bounds__(64) k_rans_encode (GzdLeaf *leaves)
+{
+    GzdLeaf &L = leaves[blockIdx.x];
+    if (!L.active || L.engine != GZ_ENG_RANS) return;
+    const int lane = threadIdx.x;
+    const uint32_t n = L.coded_n;
+    if (!n) { if (!lane) L.pay_len = 0; return; }
+    const uint8_t *in = L.coded;
+    const GzRansSym *syms = L.syms;
+    uint32_t plen;
+
+    if (!L.o1) {
+        uint32_t len_k = (n >> 2) + ((n & 3) > (uint32_t)(lane & 3));
+        plen = d_rans_encode_wave (lane < 4 ? len_k : 0, (n + 3) >> 2, L.pay, L.pay_cap,
+                                   [&] (int k, uint32_t r) { return &syms[in[4 * r + k]]; });
+    }
+    else {
+        // quarter k = [k*q, (k+1)*q), the last one extends to n and codes its surplus first, alone (:817-823);
+        // the head of each quarter is coded in context 0 (:843-846)
+        const uint32_t q = n >> 2;
+        uint32_t len_k = lane == 3 ? n - 3 * q : q;
+        plen = d_rans_encode_wave (lane < 4 ? len_k : 0, n - 3 * q, L.pay, L.pay_cap,
+                                   [&] (int k, uint32_t r) {
+                                       uint32_t at = k * q + r;
+                                       return &syms[(r ? in[at - 1] : 0) * 256 + in[at]];
+                                   });
+    }
+    if (!lane) { if (plen == 0xffffffffu) { L.overflow = 1; L.pay_len = 0; } else L.pay_len = plen; }
+}
+
+// ======================================================================================================
+// k_arith_encode : adaptive range coder. One wave per leaf, lane 0 walks the stream; the models live in LDS.
+// ======================================================================================================
+
+// A model is [tot][slot 0 .. slot m-1], slot = freq | sym << 16 (c_simple_model.h:63-83). Only the first max_sym
+// slots can ever be non-zero, so that is all we keep; the sentinel that the reference keeps in front of slot 0 (it
+// can never be overtaken: no frequency exceeds 65519 after a bump) is the `at > 0` test.
+struct GzRc { uint32_t low, range, carry, cache, ff; uint8_t *out; uint32_t len, cap; int overflow; };
+
+__device__ static inline void d_rc_shift (GzRc &rc)    // c_range_coder.h:70-88
+{
+    if (rc.low < 0xff000000u || rc.carry) {
+        if (rc.len + 1 + rc.ff > rc.cap) { rc.overflow = 1; rc.ff = 0; }
+        else {
+            rc.out[rc.len++] = (uint8_t)(rc.cache + rc.carry);
+            for (; rc.ff; rc.ff--) rc.out[rc.len++] = (uint8_t)(rc.carry - 1);
+        }
+        rc.cache = rc.low >> 24;
+        rc.carry = 0;
+    }
+    else rc.ff++;
+    rc.low <<= 8;
+}
+
+__device__ static inline void d_rc_encode (GzRc &rc, uint32_t cum, uint32_t freq, uint32_t tot)   // :97-109
+{
+    uint32_t before = rc.low;
+    rc.range /= tot;
+    rc.low   += cum * rc.range;
+    rc.range *= freq;
+    rc.carry += rc.low < before;
+    while (rc.range < (1u << 24)) { rc.range <<= 8; d_rc_shift (rc); }
+}
+
+__device__ static inline void d_model_init (uint32_t *m, uint32_t max_sym)
+{
+    m[0] = max_sym;
+    for (uint32_t i = 0; i < max_sym; i++) m[1 + i] = 1u | (i << 16);
+}
+
+__device__ static inline void d_model_encode (uint32_t *m, uint32_t max_sym, GzRc &rc, uint32_t sym)   // c_simple_model.h:123-146
+{
+    uint32_t *slot = m + 1, cum = 0, at = 0, e;
+    while (((e = slot[at]) >> 16) != sym) { cum += e & 0xffff; at++; }
+    d_rc_encode (rc, cum, e & 0xffff, m[0]);
+    e += 16;
+    uint32_t tot = m[0] + 16;
+    slot[at] = e;
+    if (tot > 65519) {
+        tot = 0;
+        for (uint32_t i = 0; i < max_sym; i++) {
+            uint32_t v = slot[i], f = v & 0xffff;
+            f -= f >> 1;
+            slot[i] = (v & 0xffff0000u) | f;
+            tot += f;
+        }
+        e = slot[at];
+    }
+    m[0] = tot;
+    if (at > 0) {
+        uint32_t left = slot[at - 1];
+        if ((e & 0xffff) > (left & 0xffff)) { slot[at - 1] = e; slot[at] = left; }
+    }
+}
+
+#define GZ_ARITH_RUN_MODELS 258
+#define GZ_ARITH_RUN_STRIDE 5      // tot + 4 slots (MAX_RUN == 4, arith_dynamic.c:384)
+
+__device__ static inline uint32_t gz_arith_model_words (uint32_t max_sym, bool o1, bool rle)
+{
+    uint32_t w = (o1 ? max_sym : 1) * (max_sym + 1);
+    if (rle) w += GZ_ARITH_RUN_MODELS * GZ_ARITH_RUN_STRIDE;
+    return w;
+}
+
+// lds_words: dynamic LDS of this launch in 32-bit words. A leaf runs in the launch of the smallest class it fits;
+// models that fit no LDS class run from global memory (class 3).
+__global__ void __launch_bounds__(64) k_arith_encode (GzdLeaf *leaves, uint32_t lds_words_lo, uint32_t lds_words_hi, int use_global)
+{
+    GzdLeaf &L = leaves[blockIdx.x];
+    if (!L.active || L.engine != GZ_ENG_ARITH) return;
+    const uint32_t n = L.coded_n, max_sym = L.max_sym;
+    const bool o1 = L.o1, rle = L.rle;
+    const uint32_t words = gz_arith_model_words (n ? max_sym : 1, o1, rle);
+    if (words <= lds_words_lo || words > lds_words_hi) return;     // another size class handles this leaf
+    uint32_t *models = use_global ? L.models : (uint32_t *)gz_lds;
+    const int lane = threadIdx.x;
+
+    // initialise the models in parallel: literal models (contexts 0..max_sym-1), then the run models
+    const uint32_t ms = n ? max_sym : 1;
+    const uint32_t nlit = o1 ? ms : 1, lit_stride = ms + 1;
+    for (uint32_t i = lane; i < nlit * lit_stride; i += 64) {
+        uint32_t k = i % lit_stride;
+        models[i] = k ? (1u | ((k - 1) << 16)) : ms;
+    }
+    uint32_t *runm = models + nlit * lit_stride;
+    if (rle)
+        for (uint32_t i = lane; i < GZ_ARITH_RUN_MODELS * GZ_ARITH_RUN_STRIDE; i += 64) {
+            uint32_t k = i % GZ_ARITH_RUN_STRIDE;
+            runm[i] = k ? (1u | ((k - 1) << 16)) : 4;
+        }
+    __syncthreads ();
+    if (lane) return;
+
+    const uint8_t *in = L.coded;
+    GzRc rc;
+    rc.low = 0; rc.range = 0xffffffffu; rc.carry = rc.cache = rc.ff = 0;
+    rc.out = L.pay + 1; rc.len = 0; rc.cap = L.pay_cap - 1; rc.overflow = 0;
+    L.pay[0] = (uint8_t)ms;                                    // max_sym + 1 (256 wraps to 0), arith_dynamic.c:103-108
+
+    uint32_t last = 0;
+    if (!rle)
+        for (uint32_t i = 0; i < n && !rc.overflow; i++) {
+            uint32_t s = in[i];
+            d_model_encode (models + (o1 ? last * lit_stride : 0), ms, rc, s);
+            last = s;
+        }
+    else
+        for (uint32_t i = 0; i < n && !rc.overflow; ) {        // arith_dynamic.c:416-438
+            uint32_t s = in[i++];
+            d_model_encode (models + (o1 ? last * lit_stride : 0), ms, rc, s);
+            last = s;
+            uint32_t run = 0;
+            while (i < n && in[i] == s) run++, i++;
+            uint32_t ctx = s;
+            do {
+                uint32_t d = run < 4 ? run : 3;
+                d_model_encode (runm + ctx * GZ_ARITH_RUN_STRIDE, 4, rc, d);
+                run -= d;
+                ctx = (ctx == s) ? 256 : ctx + (ctx < 257);
+                if (d == 3 && !run) d_model_encode (runm + ctx * GZ_ARITH_RUN_STRIDE, 4, rc, 0);
+            } while (run);
+        }
+    for (int k = 0; k < 5; k++) d_rc_shift (rc);               // RC_FinishEncode
+    if (rc.overflow) { L.overflow = 1; L.pay_len = 0; }
+    else L.pay_len = rc.len + 1;
+    L.tab_len = 0;
+}
+
+// ======================================================================================================
+// k_select : one thread per stream -- CAT fallback per leaf, best method per plane, stream size
+// ======================================================================================================
+__global__ void k_select (GzdStream *streams, GzdLeaf *leaves, uint32_t n_streams)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_streams) return;
+    GzdStream &S = streams[i];
+    if (S.status != GZ_ST_PENDING) return;
+
+    if (S.engine == GZ_ENG_NONE) { S.out_len = S.n; return; }            // codec_none_compress
+
+    uint32_t best_len[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
+    uint32_t whole_len = 0;
+    for (uint32_t k = 0; k < S.n_leaves; k++) {
+        GzdLeaf &L = leaves[S.first_leaf + k];
+        if (!L.active) continue;
+        uint32_t body = L.tab_len + L.pay_len;
+        bool cat = L.overflow || body >= L.coded_n;                       // :1343-1348 / arith :845-850
+        if (cat) {
+            L.cat = 1;
+            uint8_t f = L.prefix[0];
+            f = (uint8_t)((f & ~3) | GZ_X_CAT);                           // PACK and NOSZ bits stay
+            L.prefix[0] = f;
+            body = L.coded_n;
+        }
+        L.unit_len = L.prefix_len + body;
+        if (L.plane == 0xff) whole_len = L.unit_len;
+        else if (L.unit_len < best_len[L.plane]) { best_len[L.plane] = L.unit_len; S.best_leaf[L.plane] = (uint8_t)k; }  // first smallest wins
+    }
+    if (!S.striped) { S.out_len = whole_len; S.best_leaf[0] = 0xff; return; }
+
+    uint32_t total = 1 + gz_vi_len (S.n) + 1;
+    for (int k = 0; k < 4; k++) { S.plane_unit_len[k] = best_len[k]; total += gz_vi_len (best_len[k]) + best_len[k]; }
+    S.out_len = total;
+}
+
+// ======================================================================================================
+// k_vb_layout : one thread per VBlock -- offsets of the sections inside z_data
+// ======================================================================================================
+__global__ void k_vb_layout (GzdVB *vbs, GzdStream *streams, uint32_t n_vbs)
+{
+    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_vbs) return;
+    GzdVB &V = vbs[v];
+    uint64_t off = 84;                                   // SectionHeaderVbHeader first (zip.c:560)
+    for (uint32_t k = 0; k < V.n_streams; k++) {
+        GzdStream &S = streams[V.first_stream + k];
+        S.z_off = off;
+        off += 40 + (uint64_t)S.out_len;
+    }
+    V.z_len = off;
+    V.status = off <= V.z_cap ? GZ_ST_OK : GZ_ST_TOO_SMALL;
+
+    uint8_t *z = V.z_data;                               // zfile_compress_vb_header + zfile_update_compressed_vb_header
+    if (V.status != GZ_ST_OK) return;
+    for (int k = 0; k < 84; k++) z[k] = 0;
+    gz_be32 (z + 0, 0x27052012u);
+    gz_be32 (z + 4, 1);                                  // adler32 of an empty payload
+    gz_be32 (z + 20, V.vblock_i);
+    z[24] = 9; z[25] = 1; z[27] = V.vb_flags;
+    gz_be32 (z + 36, V.recon_size);
+    gz_be32 (z + 40, (uint32_t)off);                     // z_data_bytes
+    gz_be32 (z + 44, V.longest_line_len);
+    for (int k = 0; k < 16; k++) z[48 + k] = V.digest[k];
+    gz_be32 (z + 80, V.longest_seq_len);
+}
+
+// ======================================================================================================
+// k_emit : one 256-thread workgroup per stream -- writes the payload (and, in VBlock mode, the section header)
+// ======================================================================================================
+__device__ static inline void d_copy (uint8_t *dst, const uint8_t *src, uint32_t n, int tid)
+{
+    for (uint32_t i = tid; i < n; i += 256) dst[i] = src[i];
+}
+
+__device__ static void d_emit_unit (uint8_t *dst, const GzdLeaf &L, int tid)
+{
+    d_copy (dst, L.prefix, L.prefix_len, tid);
+    dst += L.prefix_len;
+    if (L.cat) { d_copy (dst, L.coded, L.coded_n, tid); return; }
+    d_copy (dst, L.tab, L.tab_len, tid);
+    const uint8_t *pay = L.engine == GZ_ENG_RANS ? L.pay + L.pay_cap - L.pay_len : L.pay;
+    d_copy (dst + L.tab_len, pay, L.pay_len, tid);
+}
+
+__global__ void __launch_bounds__(256) k_emit (GzdStream *streams, GzdLeaf *leaves, GzdVB *vbs)
+{
+    GzdStream &S = streams[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (S.status != GZ_ST_PENDING) return;
+
+    uint8_t *dst = S.out;
+    if (S.vb >= 0) {
+        GzdVB &V = vbs[S.vb];
+        if (V.status != GZ_ST_OK) { if (!tid) S.status = GZ_ST_TOO_SMALL; return; }
+        dst = V.z_data + S.z_off + 40;
+    }
+    else if (S.out_len > S.out_cap) { if (!tid) S.status = GZ_ST_TOO_SMALL; return; }
+
+    if (S.engine == GZ_ENG_NONE) d_copy (dst, S.in, S.n, tid);
+    else if (!S.striped) d_emit_unit (dst, leaves[S.first_leaf + S.whole_leaf], tid);
+    else {
+        // [order & ~NOSZ][varint n][4][varint unit length x4][unit x4]   (rANS_static4x16pr.c:1194-1225)
+        uint8_t meta[32]; uint32_t p = 0;
+        meta[p++] = (uint8_t)(S.order & ~GZ_X_NOSZ);
+        p += gz_vi_put (meta + p, S.n);
+        meta[p++] = 4;
+        for (int k = 0; k < 4; k++) p += gz_vi_put (meta + p, S.plane_unit_len[k]);
+        if (tid < (int)p) dst[tid] = meta[tid];
+        uint32_t o = p;
+        for (int k = 0; k < 4; k++) {
+            d_emit_unit (dst + o, leaves[S.first_leaf + S.best_leaf[k]], tid);
+            o += S.plane_unit_len[k];
+        }
+    }
+
+    // NB: status doubles as the entry test of this kernel: every thread must be past it before it changes
+    if (S.vb < 0) { __syncthreads (); if (!tid) S.status = GZ_ST_OK; return; }
+
+    // ---- section header (comp_compress, compressor.c:114-161): adler32 of the payload by the whole workgroup
+    __threadfence_block ();
+    __syncthreads ();
+    uint32_t adler = gz_adler32_wg (dst, S.out_len, tid);
+    if (!tid) {
+        uint8_t *h = vbs[S.vb].z_data + S.z_off;
+        for (int k = 0; k < 40; k++) h[k] = S.hdr[k];
+        gz_be32 (h + 4,  adler);
+        gz_be32 (h + 12, S.out_len);
+        gz_be32 (h + 16, S.n);
+        h[25] = S.codec;
+        S.status = GZ_ST_OK;
+    }
+}

@@ -1,0 +1,95 @@
+"""ctypes binding of include/genozip_amd.h (libgenozip_amd.so).
+
+There is deliberately no fallback: if the HIP library is missing, or no GPU is visible, loading / creating a handle
+raises. (tests/emul builds the same sources against a CPU stand-in of the HIP runtime for logic tests; that library
+is only ever loaded by tests, through the explicit `path` argument.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libgenozip_amd.so")
+
+# codec ids == file format values (reference: src/genozip.h:325-360)
+CODEC_UNKNOWN, CODEC_NONE = 0, 1
+CODEC_RANB, CODEC_RANW, CODEC_RANb, CODEC_RANw = 6, 7, 8, 9
+CODEC_ARTB, CODEC_ARTW, CODEC_ARTb, CODEC_ARTw = 16, 17, 18, 19
+SIMPLE_CODECS = (CODEC_RANB, CODEC_RANW, CODEC_RANb, CODEC_RANw, CODEC_ARTB, CODEC_ARTW, CODEC_ARTb, CODEC_ARTw)
+CODEC_NAMES = {0: "UNKNOWN", 1: "NONE", 6: "RANB", 7: "RANW", 8: "RANb", 9: "RANw", 16: "ARTB", 17: "ARTW", 18: "ARTb", 19: "ARTw"}
+
+SEC_VB_HEADER, SEC_B250, SEC_LOCAL = 9, 11, 12
+
+LT_INT8, LT_UINT8, LT_INT16, LT_UINT16, LT_INT32, LT_UINT32, LT_INT64, LT_UINT64 = 1, 2, 3, 4, 5, 6, 7, 8
+LT_FLOAT32, LT_FLOAT64, LT_BLOB, LT_BITMAP = 9, 10, 11, 12
+LT_UINT8_TR, LT_UINT16_TR, LT_UINT32_TR = 14, 15, 16
+
+GZ_OK, GZ_TOO_SMALL, GZ_ERR, GZ_ERR_NO_DEVICE, GZ_ERR_ARG, GZ_ERR_HIP, GZ_ERR_CORRUPT = 1, 0, -1, -2, -3, -4, -5
+
+
+class GzStream(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("in_len", C.c_uint32), ("in_len_dev", C.c_void_p), ("out", C.c_void_p),
+                ("out_cap", C.c_uint32), ("codec", C.c_int32), ("out_len", C.c_uint32), ("status", C.c_int32)]
+
+
+class GzB250Job(C.Structure):
+    _fields_ = [("seg", C.c_void_p), ("seg_len", C.c_uint32), ("seg_len_dev", C.c_void_p), ("ol_nodes_len", C.c_uint32),
+                ("node2word", C.c_void_p), ("n_new_nodes", C.c_uint32), ("out", C.c_void_p), ("out_len_dev", C.c_void_p),
+                ("status_dev", C.c_void_p)]
+
+
+class GzSection(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("data_len", C.c_uint32), ("data_len_dev", C.c_void_p),
+                ("section_type", C.c_uint8), ("codec", C.c_uint8), ("sub_codec", C.c_uint8), ("flags", C.c_uint8),
+                ("ltype", C.c_uint8), ("param", C.c_uint8), ("b250_size_or_nothing_char", C.c_uint8),
+                ("dict_id", C.c_uint8 * 8)]
+
+
+class GzVBlock(C.Structure):
+    _fields_ = [("vblock_i", C.c_uint32), ("recon_size", C.c_uint32), ("longest_line_len", C.c_uint32),
+                ("longest_seq_len", C.c_uint32), ("digest", C.c_uint8 * 16), ("vb_flags", C.c_uint8),
+                ("sections", C.POINTER(GzSection)), ("n_sections", C.c_uint32), ("z_data", C.c_void_p),
+                ("z_cap", C.c_uint64), ("z_len", C.c_uint64), ("status", C.c_int32)]
+
+
+# every symbol include/genozip_amd.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = (
+    "gz_create", "gz_destroy", "gz_sync", "gz_last_error", "gz_version", "gz_stream",
+    "gz_codec_est_size", "gz_codec_compress_host", "gz_codec_uncompress_host",
+    "gz_codec_compress_batch", "gz_codec_uncompress_batch", "gz_codec_assign_best",
+    "gz_b250_generate", "gz_b250_generate_batch", "gz_local_generate", "gz_local_to_native",
+    "gz_vb_z_bound", "gz_vb_compress_batch", "gz_vb_uncompress", "gz_adler32",
+)
+
+
+def load(path=None):
+    path = path or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise RuntimeError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(genozip_amd has no CPU fallback)" % path)
+    L = C.CDLL(path)
+    L.gz_create.restype = C.c_void_p
+    L.gz_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+    L.gz_destroy.argtypes = [C.c_void_p]
+    L.gz_sync.argtypes = [C.c_void_p]
+    L.gz_last_error.restype = C.c_char_p
+    L.gz_last_error.argtypes = [C.c_void_p]
+    L.gz_version.restype = C.c_char_p
+    L.gz_stream.restype = C.c_void_p
+    L.gz_stream.argtypes = [C.c_void_p]
+    L.gz_codec_est_size.restype = C.c_uint32
+    L.gz_codec_est_size.argtypes = [C.c_int, C.c_uint64]
+    L.gz_codec_compress_host.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.POINTER(C.c_uint32), C.c_int]
+    L.gz_codec_uncompress_host.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint64]
+    L.gz_codec_compress_batch.argtypes = [C.c_void_p, C.POINTER(GzStream), C.c_int]
+    L.gz_codec_uncompress_batch.argtypes = [C.c_void_p, C.POINTER(GzStream), C.c_int]
+    L.gz_codec_assign_best.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.gz_b250_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.gz_b250_generate_batch.argtypes = [C.c_void_p, C.POINTER(GzB250Job), C.c_int]
+    L.gz_local_generate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+    L.gz_local_to_native.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+    L.gz_vb_z_bound.restype = C.c_uint64
+    L.gz_vb_z_bound.argtypes = [C.POINTER(GzSection), C.c_uint32]
+    L.gz_vb_compress_batch.argtypes = [C.c_void_p, C.POINTER(GzVBlock), C.c_int]
+    L.gz_vb_uncompress.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32)]
+    L.gz_adler32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32)]
+    return L

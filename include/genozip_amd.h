@@ -1,0 +1,188 @@
+/* genozip_amd.h -- C-ABI of libgenozip_amd.so: the MI355X (gfx950) implementation of Genozip's context
+ * entropy-coding hot path. Plain C, pointers and sizes only; no torch / C++ types.
+ *
+ * Every entry point names the interface of the reference (divonlan/genozip 15.0.86, paths relative to
+ * /root/reference) that it stands in for. INTEGRATION.md shows the reference-side stub that would bind them.
+ *
+ * Memory spaces: names ending in _host take host pointers (the library stages through HBM itself);
+ * everything else takes DEVICE pointers (hipMalloc'd, e.g. torch tensors' data_ptr()) and is asynchronous on the
+ * handle's HIP stream until gz_sync() / a *_host call.
+ *
+ * Determinism contract: for the simple codecs the payload is a pure function of
+ * (codec id, input bytes) and is byte-identical to the reference's, provided the output capacity is at least
+ * gz_codec_est_size() (below that the reference reports "too small"; so does this library).
+ */
+#ifndef GENOZIP_AMD_H
+#define GENOZIP_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Codec ids == file-format values, src/genozip.h:325-360 (also the index into the reference's codec_args[],
+ * src/codec.h:65-117) */
+typedef enum {
+    GZ_CODEC_UNKNOWN = 0, GZ_CODEC_NONE = 1,
+    GZ_CODEC_RANB = 6,  GZ_CODEC_RANW = 7,  GZ_CODEC_RANb = 8,  GZ_CODEC_RANw = 9,   /* rANS 4x16  */
+    GZ_CODEC_ARTB = 16, GZ_CODEC_ARTW = 17, GZ_CODEC_ARTb = 18, GZ_CODEC_ARTw = 19   /* arith_dynamic */
+} GzCodec;
+
+/* SectionType values used on this path, src/genozip.h:378-379 */
+enum { GZ_SEC_VB_HEADER = 9, GZ_SEC_B250 = 11, GZ_SEC_LOCAL = 12 };
+
+/* LocalType, src/local_type.h:14-57 (file-format values) */
+typedef enum {
+    GZ_LT_SINGLETON = 0, GZ_LT_INT8 = 1, GZ_LT_UINT8 = 2, GZ_LT_INT16 = 3, GZ_LT_UINT16 = 4, GZ_LT_INT32 = 5,
+    GZ_LT_UINT32 = 6, GZ_LT_INT64 = 7, GZ_LT_UINT64 = 8, GZ_LT_FLOAT32 = 9, GZ_LT_FLOAT64 = 10, GZ_LT_BLOB = 11,
+    GZ_LT_BITMAP = 12, GZ_LT_CODEC = 13, GZ_LT_UINT8_TR = 14, GZ_LT_UINT16_TR = 15, GZ_LT_UINT32_TR = 16,
+    GZ_LT_STRING = 26, GZ_LT_SUPP = 27
+} GzLocalType;
+
+/* return codes */
+enum { GZ_OK = 1, GZ_TOO_SMALL = 0, GZ_ERR = -1, GZ_ERR_NO_DEVICE = -2, GZ_ERR_ARG = -3, GZ_ERR_HIP = -4, GZ_ERR_CORRUPT = -5 };
+
+typedef struct GzHandle GzHandle;   /* stands in for VBlockP: owns the HIP stream and the scratch arena
+                                       (the reference's vb->codec_bufs[], src/codec.c:30-63) */
+
+/* ---- lifetime ------------------------------------------------------------------------------------------ */
+/* device = HIP device ordinal; hip_stream = a hipStream_t to run on, or NULL for a private stream.
+ * Fails (returns NULL, *err set) when no gfx950-capable device / runtime is present: there is NO CPU fallback. */
+GzHandle *gz_create (int device, void *hip_stream, int *err);
+void      gz_destroy (GzHandle *h);
+int       gz_sync (GzHandle *h);
+const char *gz_last_error (GzHandle *h);
+const char *gz_version (void);
+/* the HIP stream work is queued on (a hipStream_t) - for timing with HIP events on the right stream */
+void     *gz_stream (GzHandle *h);
+
+/* ---- codec plugin surface: codec_args[codec].est_size / .compress / .uncompress ---------------------------- */
+
+/* src/codec.h:40, src/codec_htscodecs.c:26-33, src/codec_none.c:44 */
+uint32_t gz_codec_est_size (int codec, uint64_t uncompressed_len);
+
+/* COMPRESS() src/codec.h:17-27 as implemented by codec_RANB_compress ... codec_ARTw_compress
+ * (src/codec_htscodecs.c:87-94) and codec_none_compress (src/codec_none.c:13).
+ * *compressed_len: in = capacity, out = payload length. Returns GZ_OK; GZ_TOO_SMALL iff capacity < est_size and
+ * soft_fail (the caller grows and retries, src/compressor.c:89-110); GZ_ERR* otherwise. Host pointers. */
+int gz_codec_compress_host (GzHandle *h, int codec, const uint8_t *uncompressed, uint32_t uncompressed_len,
+                            uint8_t *compressed, uint32_t *compressed_len, int soft_fail);
+
+/* UNCOMPRESS() src/codec.h:29-38: codec_rans_uncompress / codec_arith_uncompress (src/codec_htscodecs.c:100,116),
+ * codec_none_uncompress (src/codec_none.c:39). Host pointers. */
+int gz_codec_uncompress_host (GzHandle *h, int codec, const uint8_t *compressed, uint32_t compressed_len,
+                              uint8_t *uncompressed, uint64_t uncompressed_len);
+
+/* One entry of a stream table: an independent codec call. All pointers are DEVICE pointers.
+ * in_len_dev (optional): device address of a uint32 holding the actual length, for inputs produced on the GPU
+ * (then in_len is the upper bound used for planning). */
+typedef struct {
+    const uint8_t *in;            /* uncompressed (compress) / compressed (uncompress) bytes         */
+    uint32_t       in_len;
+    const uint32_t *in_len_dev;   /* NULL, or device-resident actual length (<= in_len)              */
+    uint8_t       *out;           /* destination                                                      */
+    uint32_t       out_cap;       /* compress: capacity >= gz_codec_est_size ; uncompress: exact length */
+    int32_t        codec;
+    /* results, valid after gz_sync(): */
+    uint32_t       out_len;
+    int32_t        status;        /* GZ_OK / GZ_TOO_SMALL / GZ_ERR_CORRUPT                            */
+} GzStream;
+
+/* Batched, asynchronous forms over a stream table (host array of descriptors of device buffers). Many streams
+ * are coded concurrently: stripes, trial methods and streams all become independent GPU work items.
+ * Results (out_len, status) are written back into the table by gz_sync(). */
+int gz_codec_compress_batch   (GzHandle *h, GzStream *streams, int n_streams);
+int gz_codec_uncompress_batch (GzHandle *h, GzStream *streams, int n_streams);
+
+/* codec_assign_best_codec (src/codec.c:234-363) with the deterministic rule of SURVEY.md A.8 (smallest framed size
+ * of the first min(len,99999) bytes; ties -> lower codec id; < 50 bytes -> GZ_CODEC_UNKNOWN). in = device pointer.
+ * sizes_out (host, 9 entries: NONE,RANB,RANW,RANb,RANw,ARTB,ARTW,ARTb,ARTw) may be NULL. Synchronous. */
+int gz_codec_assign_best (GzHandle *h, const uint8_t *in, uint32_t in_len, uint32_t *sizes_out);
+
+/* ---- context engine pieces -------------------------------------------------------------------------------- */
+
+/* b250_zip_generate (src/b250.c:202-267): seg-format b250 (little-endian VARL, tag in last byte; nodes new to the
+ * VB are 4-byte node indices) -> PIZ-format VARL (big endian, tag first, node->word converted, ONE_UP applied when
+ * the dictionary has > 1024 words). node2word[i] = word index of VB-local node (ol_nodes_len + i) after the merge
+ * (ctx->nodes after ctx_merge_in_vb_ctx, src/context.c:1032). out must hold seg_len bytes; *out_len_dev receives
+ * the length. All pointers device. */
+int gz_b250_generate (GzHandle *h, const uint8_t *seg, uint32_t seg_len, uint32_t ol_nodes_len,
+                      const int32_t *node2word, uint32_t n_new_nodes, uint8_t *out, uint32_t *out_len_dev);
+
+/* the same for many contexts (all VBlocks x contexts of a batch) in one launch; all pointers device */
+typedef struct {
+    const uint8_t  *seg; uint32_t seg_len;
+    const uint32_t *seg_len_dev;     /* optional device-resident actual length (<= seg_len) */
+    uint32_t        ol_nodes_len;
+    const int32_t  *node2word; uint32_t n_new_nodes;
+    uint8_t        *out;             /* seg_len bytes */
+    uint32_t       *out_len_dev;     /* receives the generated length */
+    int32_t        *status_dev;      /* optional: receives GZ_OK / GZ_ERR_CORRUPT */
+} GzB250Job;
+int gz_b250_generate_batch (GzHandle *h, const GzB250Job *jobs, int n_jobs);
+
+/* zip_generate_local (src/zip.c:167-219): native little-endian elements -> file order (big endian; signed types
+ * zig-zag "interlaced" first, src/context.h:99-101, src/buffer.c:336-350), then optional matrix transpose
+ * rows x cols -> cols x rows (dyn_int_transpose, src/dyn_int.c:45-132, full-matrix case). In place on `data`
+ * (device), `scratch` (device, same size) needed when transpose_cols != 0. Returns the resulting ltype
+ * (e.g. GZ_LT_UINT8_TR) or a negative error. n = element count. */
+int gz_local_generate (GzHandle *h, int ltype, void *data, uint64_t n, uint32_t transpose_cols, void *scratch);
+
+/* PIZ inverse (lt_desc[].file_to_native, src/local_type.h:75-108; BGEN_transpose_u##n##_buf src/buffer.c:364-391) */
+int gz_local_to_native (GzHandle *h, int ltype, void *data, uint64_t n, uint32_t transpose_cols, void *scratch);
+
+/* ---- section writer --------------------------------------------------------------------------------------- */
+
+/* One b250 / local section of one VBlock: the fields of SectionHeaderCtx (src/sections.h:146-167,419-435) that the
+ * caller decides, as zfile_compress_b250_data / zfile_compress_local_data fill them (src/zfile.c:288-364). */
+typedef struct {
+    const uint8_t  *data;         /* device: section payload before compression (ctx->b250.data / ctx->local.data) */
+    uint32_t        data_len;     /* bytes (upper bound if data_len_dev != NULL)                               */
+    const uint32_t *data_len_dev; /* device-resident actual length, or NULL                                    */
+    uint8_t  section_type;        /* GZ_SEC_B250 / GZ_SEC_LOCAL                                                */
+    uint8_t  codec;               /* ctx->bcodec / ctx->lcodec ; UNKNOWN -> RANB (zfile.c:300,337)             */
+    uint8_t  sub_codec;
+    uint8_t  flags;               /* struct FlagsCtx, LSB first: store:2 paired:1 store_delta:1 spl_custom:1
+                                     all_the_same:1 ctx_specific_flag:1 store_per_line:1 (sections.h:99-118) */
+    uint8_t  ltype;
+    uint8_t  param;
+    uint8_t  b250_size_or_nothing_char; /* byte 30: B250_VARL(4) for b250, nothing_char for integer locals   */
+    uint8_t  dict_id[8];
+} GzSection;
+
+typedef struct {
+    uint32_t vblock_i;            /* 1-based */
+    uint32_t recon_size, longest_line_len, longest_seq_len;
+    uint8_t  digest[16];
+    uint8_t  vb_flags;
+    const GzSection *sections;    /* in the order they must appear in z_data                   */
+    uint32_t n_sections;
+    uint8_t *z_data;              /* device: receives SEC_VB_HEADER (84 B) + every section (40 B header + payload) */
+    uint64_t z_cap;               /* >= gz_vb_z_bound()                                                        */
+    /* results after gz_sync(): */
+    uint64_t z_len;               /* == z_data_bytes patched into the VB header (zfile.c:1139-1144)            */
+    int32_t  status;
+} GzVBlock;
+
+uint64_t gz_vb_z_bound (const GzSection *sections, uint32_t n_sections);
+
+/* zip_compress_one_vb's codec phase for a batch of VBlocks (src/zip.c:560-585): zfile_compress_vb_header, then for
+ * every section comp_compress (src/compressor.c:18: < 50 B -> CODEC_NONE, payload, z_digest = adler32, big-endian
+ * lengths) appended to z_data. All VBlocks and all their sections run concurrently on the GPU. Asynchronous. */
+int gz_vb_compress_batch (GzHandle *h, GzVBlock *vbs, int n_vbs);
+
+/* section-level decode for the round trip: walks z_data (device), checks magic / adler32 (src/zfile.c:212-218),
+ * decodes every section payload into out (device, concatenated in order), writes per-section offsets (n+1 entries,
+ * host). Synchronous. */
+int gz_vb_uncompress (GzHandle *h, const uint8_t *z_data, uint64_t z_len, uint8_t *out, uint64_t out_cap,
+                      uint64_t *section_offsets_host, uint32_t max_sections, uint32_t *n_sections_out);
+
+/* adler32 of a device buffer (libdeflate_adler32 as used by src/compressor.c:161). Synchronous. */
+int gz_adler32 (GzHandle *h, const uint8_t *data, uint64_t len, uint32_t *adler_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENOZIP_AMD_H */

@@ -1,0 +1,74 @@
+"""shared parity cases: the same checks run against the CPU-emulated build (small sizes) and the GPU (full sizes)"""
+import hashlib
+import json
+import os
+
+import numpy as np
+
+from genozip_amd import synth
+from genozip_amd.lib import SIMPLE_CODECS, CODEC_NONE
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CODEC_OF = {("rans", 0x01): 6, ("rans", 0x19): 7, ("rans", 0x81): 8, ("rans", 0x99): 9,
+            ("arith", 0x01): 16, ("arith", 0x19): 17, ("arith", 0x81): 18, ("arith", 0x99): 19}
+
+
+def golden_cases():
+    with open(os.path.join(HERE, "golden", "hts_golden.json")) as f:
+        return json.load(f)["cases"]
+
+
+def golden_input(c):
+    if c["kind"] == "markov40_q":
+        data = synth.markov_bytes(c["seed"], c["n"], 40, 33).tobytes()
+    else:
+        data = synth.stream(c["kind"], c["seed"], c["n"], c["nsym"]).tobytes()
+    assert hashlib.sha1(data).hexdigest() == c["in_sha1"], "synthetic generator drifted from the committed fixture"
+    return data
+
+
+def check_golden(c, out):
+    assert len(out) == c["out_len"], (c["kind"], c["n"], c["nsym"], c["engine"], hex(c["order"]), len(out), c["out_len"])
+    if "out_hex" in c:
+        assert out.hex() == c["out_hex"], (c["kind"], c["n"], c["nsym"], c["engine"], hex(c["order"]))
+    assert hashlib.sha1(out).hexdigest() == c["out_sha1"], (c["kind"], c["n"], c["nsym"], c["engine"], hex(c["order"]))
+
+
+def edge_streams(max_n):
+    """(name, bytes): the edge cases the codecs branch on -- empty, < 8 (order-1 dropped), <= 20 (stripe dropped),
+    < 50 (stored raw by the section writer), 1 / 2 / 4 / 16 / 17 / 256 symbol alphabets (PACK widths and its
+    refusal, the 256-wraps-to-0 quirk), tables over 1000 bytes (nested order-0 coding), incompressible (CAT)"""
+    out = []
+    seed = 5000
+    for n in (0, 1, 2, 7, 8, 9, 19, 20, 21, 22, 23, 24, 49, 50, 51, 255, 256, 257, 1000, 1031, 4097, 6000, 20011, 65537, 300007):
+        if n > max_n:
+            continue
+        for kind, nsym in (("uniform", 1), ("uniform", 2), ("uniform", 4), ("skew", 5), ("uniform", 16), ("uniform", 17),
+                           ("markov", 40), ("uniform", 256), ("u32be", 256), ("runs", 8), ("highsym", 3), ("skew", 256)):
+            seed += 1
+            out.append(("%s%d_n%d" % (kind, nsym, n), synth.stream(kind, seed, n, nsym).tobytes()))
+    # all 256 byte values present exactly once / in order: PACK's count byte wraps to 0
+    if max_n >= 256:
+        out.append(("perm256", bytes(range(256))))
+        out.append(("perm256x3", bytes(range(256)) * 3))
+    return out
+
+
+def b250_case(seed, n_entries, ol_nodes, n_new, specials=True):
+    """random seg-format b250: node indices (old: VARL 1-4 bytes, new: always 4 bytes), some EMPTY/MISSING, plus a
+    node->word map for the new nodes. Consecutive runs are planted so that ONE_UP triggers."""
+    r = synth.u32(seed, n_entries * 3)
+    total = ol_nodes + n_new
+    ni = (r[:n_entries] % np.uint32(max(1, total))).astype(np.int64)
+    # plant increasing runs
+    runs = (r[n_entries:2 * n_entries] % np.uint32(7)) == 0
+    for i in range(1, n_entries):
+        if runs[i]:
+            ni[i] = min(total - 1, ni[i - 1] + 1)
+    if specials:
+        sp = r[2 * n_entries:] % np.uint32(50)
+        ni[sp == 0] = -3
+        ni[sp == 1] = -4
+    n2w = (synth.u32(seed + 1, max(1, n_new)) % np.uint32(max(1, total + 50))).astype(np.int64)
+    # make some new nodes map to "previous word + 1" so that converted neighbours trigger ONE_UP
+    return [int(x) for x in ni], [int(x) for x in n2w[:n_new]]

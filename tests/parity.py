@@ -1,0 +1,146 @@
+"""the parity checks proper, parametrised by an Engine (GPU or CPU-emulated) -- compared with the oracle"""
+import struct
+import zlib
+
+import numpy as np
+
+import cases
+from genozip_amd import synth
+from genozip_amd.codec import Section, VBlock
+from genozip_amd.lib import SIMPLE_CODECS, CODEC_NONE, SEC_B250, SEC_LOCAL
+
+ALL_CODECS = (CODEC_NONE,) + SIMPLE_CODECS
+
+
+def codec_edge_cases(E, oracle, max_n, decode=True):
+    """every codec x every edge stream, one batched launch per codec; byte parity + on-device round trip"""
+    streams = cases.edge_streams(max_n)
+    for codec in ALL_CODECS:
+        items = [(codec, d) for _, d in streams if (d or codec == CODEC_NONE or True)]
+        got = E.compress_many(items)
+        for (name, d), g in zip(streams, got):
+            want = oracle.codec_compress(codec, d)
+            assert g == want, "codec %d %s: %d vs %d bytes" % (codec, name, len(g), len(want))
+        if decode:
+            dec_items = [(codec, g, len(d)) for (name, d), g in zip(streams, got) if len(d)]
+            back = E.uncompress_many(dec_items)
+            for (name, d), b in zip([s for s in streams if len(s[1])], back):
+                assert b == d, "codec %d %s: round trip" % (codec, name)
+
+
+def host_call_surface(E, oracle):
+    """the COMPRESS()/UNCOMPRESS() shaped single calls incl. the soft-fail convention (compressor.c:89-110)"""
+    data = synth.markov_bytes(9, 3000, 40, 33).tobytes()
+    for codec in ALL_CODECS:
+        est = E.est_size(codec, len(data))
+        assert est == oracle.est_size(codec, len(data))
+        comp = E.compress(codec, data)
+        assert comp == oracle.codec_compress(codec, data)
+        assert E.uncompress(codec, comp, len(data)) == data
+        if codec != CODEC_NONE:
+            assert E.compress(codec, data, capacity=est - 1, soft_fail=True) is None
+            try:
+                E.compress(codec, data, capacity=est - 1, soft_fail=False)
+                raise AssertionError("hard failure expected")
+            except RuntimeError:
+                pass
+            assert E.compress(codec, data, capacity=est + 4096) == comp      # capacity independent (SURVEY 8b probe)
+    for n in (0, 1, 49):
+        assert E.est_size(6, n) == oracle.est_size(6, n) and E.est_size(19, n) == oracle.est_size(19, n)
+
+
+def golden(E, max_n):
+    """the committed reference vectors (tests/golden/hts_golden.json) through the device path"""
+    todo = [c for c in cases.golden_cases() if c["n"] <= max_n]
+    cache = {}
+    items, metas = [], []
+    for c in todo:
+        key = (c["kind"], c["seed"], c["n"], c["nsym"])
+        if key not in cache:
+            cache[key] = cases.golden_input(c)
+        items.append((cases.CODEC_OF[(c["engine"], c["order"])], cache[key]))
+        metas.append(c)
+    B = 256
+    for i in range(0, len(items), B):
+        got = E.compress_many(items[i:i + B])
+        for c, g in zip(metas[i:i + B], got):
+            cases.check_golden(c, g)
+    return len(items)
+
+
+def assign_best(E, oracle, n=60000):
+    for kind, nsym in (("markov", 40), ("uniform", 4), ("u32be", 256), ("skew", 5)):
+        d = synth.stream(kind, 321, n, nsym).tobytes()
+        c, sizes = E.assign_best(d)
+        oc, osizes = oracle.assign_best(d)
+        assert (c, sizes) == (oc, osizes), (kind, c, oc, sizes, osizes)
+    assert E.assign_best(b"x" * 49)[0] == 0
+
+
+def b250(E, oracle, n_entries):
+    jobs = []
+    for seed, (ne, ol, nn, sp) in enumerate([(1, 5, 0, False), (3, 2000, 2, False), (n_entries, 1500, 700, True), (n_entries, 100, 40, True),
+                                            (n_entries // 3, 0, 3000, False), (n_entries, 200000, 3000000, True), (67, 20000, 10, True)]):
+        ni, n2w = cases.b250_case(700 + seed, ne, ol, nn, sp)
+        if ol + nn == 0:
+            continue
+        jobs.append((oracle.b250_seg(ni, ol), ol, n2w))
+    jobs.append((b"", 10, []))
+    got = E.b250_generate_many(jobs)
+    for (seg, ol, n2w), g in zip(jobs, got):
+        assert g == oracle.b250_generate(seg, ol, n2w), (len(seg), ol, len(n2w))
+
+
+def local(E, oracle, rows, cols):
+    r = synth.u32(42, rows * cols)
+    for lt, dt in ((1, "<i1"), (2, "<u1"), (3, "<i2"), (4, "<u2"), (5, "<i4"), (6, "<u4"), (7, "<i8"), (8, "<u8"), (9, "<f4"), (11, "<u1")):
+        raw = (r.astype(np.int64) - (1 << 31)).astype(dt).tobytes() if lt != 9 else r.astype("<f4").tobytes()
+        got = E.local_generate(lt, raw)
+        assert got == oracle.local_generate(lt, raw), lt
+        if lt != 11:
+            assert E.local_to_native(lt, got[1]) == (lt, raw), lt
+    for lt, dt in ((2, "<u1"), (4, "<u2"), (6, "<u4")):
+        raw = r.astype(dt).tobytes()
+        got = E.local_generate(lt, raw, cols)
+        assert got == oracle.local_generate(lt, raw, cols), (lt, "transposed")
+        assert E.local_to_native(got[0], got[1], cols) == (lt, raw)
+    d = synth.uniform_bytes(8, rows * cols + 13).tobytes()
+    assert E.adler32(d) == zlib.adler32(d) and E.adler32(b"") == 1
+
+
+def vblocks(E, oracle, n_vb, qual_len):
+    """section writer: VB header + sections, byte for byte what oracle's comp_compress restatement gives"""
+    import pyoracle as po
+    vbs, want = [], []
+    for v in range(n_vb):
+        qual = synth.markov_bytes(50 + v, qual_len, 40, 33).tobytes()
+        ni, n2w = cases.b250_case(900 + v, qual_len // 100 + 5, 300, 900, False)
+        b250 = oracle.b250_generate(oracle.b250_seg(ni, 300), 300, n2w)
+        pos = oracle.local_generate(6, np.cumsum(synth.u32(v, qual_len // 50 + 1) % 1000).astype("<u4").tobytes())[1]
+        secs = [Section(qual, SEC_LOCAL, 7 + (v % 2) * 10, b"QUAL", ltype=11, flags=0x04 if v % 2 else 0),
+                Section(pos, SEC_LOCAL, 9, b"POS", ltype=6, byte30=0xff),
+                Section(b"tiny-section-stored-raw", SEC_LOCAL, 16, b"E1L", ltype=11),
+                Section(b250, SEC_B250, 0, b"Q0NAME", byte30=4),           # codec UNKNOWN -> RANB (zfile.c:300)
+                Section(b"", SEC_B250, 6, b"EMPTY", byte30=4)]
+        vbs.append(VBlock(v + 1, secs, recon_size=123456 + v, longest_line_len=151, longest_seq_len=150, digest=bytes(range(16)), vb_flags=0))
+        z = bytearray(84)
+        for s in secs:
+            d = po.GzoCtxSectionDesc(vblock_i=v + 1, section_type=s.section_type, codec=s.codec or 6, sub_codec=s.sub_codec,
+                                     flags=s.flags, ltype=s.ltype, param=s.param, b250_size_or_nothing_char=s.byte30)
+            d.dict_id[:] = list(s.dict_id)
+            z += oracle.section_compress(d, s.data)
+        hdr = bytearray(84)
+        hdr[0:4] = struct.pack(">I", 0x27052012); hdr[4:8] = struct.pack(">I", 1); hdr[20:24] = struct.pack(">I", v + 1)
+        hdr[24] = 9; hdr[25] = 1
+        hdr[36:40] = struct.pack(">I", 123456 + v); hdr[40:44] = struct.pack(">I", len(z)); hdr[44:48] = struct.pack(">I", 151)
+        hdr[48:64] = bytes(range(16)); hdr[80:84] = struct.pack(">I", 150)
+        z[:84] = hdr
+        want.append(bytes(z))
+    got = E.vb_compress(vbs)
+    for v, (g, w) in enumerate(zip(got, want)):
+        assert g == w, "vblock %d: %d vs %d bytes" % (v + 1, len(g), len(w))
+    # and back: walk + adler check + decode every section on the device
+    for v, g in enumerate(got):
+        total = sum(len(s.data) for s in vbs[v].sections)
+        secs = E.vb_uncompress(g, total)
+        assert secs == [bytes(s.data) for s in vbs[v].sections]

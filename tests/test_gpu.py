@@ -1,0 +1,77 @@
+"""GPU (-m gpu): the parity tests proper. Everything goes through the C-ABI of libgenozip_amd.so on cuda:0 and is
+compared byte for byte with the oracle / the committed golden vectors of the reference."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import cases
+import parity
+from genozip_amd import synth
+from genozip_amd.lib import SIMPLE_CODECS
+
+pytestmark = pytest.mark.gpu
+
+
+def test_native_library_is_the_one_running(gpu_engine):
+    import os
+    assert "gfx950" in gpu_engine.version()
+    maps = open("/proc/self/maps").read()
+    assert "libgenozip_amd.so" in maps and "libgenozip_amd_emul" not in maps.replace("libgenozip_amd.so", "")
+
+
+def test_codec_edge_cases(gpu_engine, oracle):
+    parity.codec_edge_cases(gpu_engine, oracle, max_n=300007)
+
+
+def test_host_call_surface(gpu_engine, oracle):
+    parity.host_call_surface(gpu_engine, oracle)
+
+
+def test_golden_vectors_all(gpu_engine):
+    """every committed reference vector incl. the 16 MiB VBlock-sized streams"""
+    assert parity.golden(gpu_engine, max_n=1 << 30) > 3000
+
+
+def test_assign_best(gpu_engine, oracle):
+    parity.assign_best(gpu_engine, oracle, n=150000)
+
+
+def test_b250(gpu_engine, oracle):
+    parity.b250(gpu_engine, oracle, 180000)
+
+
+def test_local_and_transpose(gpu_engine, oracle):
+    parity.local(gpu_engine, oracle, 1000, 250)
+    parity.local(gpu_engine, oracle, 33, 7)
+
+
+def test_vblocks(gpu_engine, oracle):
+    parity.vblocks(gpu_engine, oracle, 6, 300000)
+
+
+def test_full_size_round_trip_properties(gpu_engine):
+    """BASELINE-sized streams (a whole 16 MiB VBlock's QUAL) where the oracle would be slow: size-independent
+    properties instead - decode(encode(x)) == x on the device for every codec, and the batched call is deterministic"""
+    E = gpu_engine
+    q = synth.quality_diverse(11, 46000).tobytes()          # ~6.9 MB, the QUAL of one 16 MiB FASTQ VBlock
+    items = [(c, q) for c in SIMPLE_CODECS]
+    a = E.compress_many(items)
+    b = E.compress_many(items)
+    assert [hashlib.sha1(x).hexdigest() for x in a] == [hashlib.sha1(x).hexdigest() for x in b]
+    back = E.uncompress_many([(c, x, len(q)) for c, x in zip(SIMPLE_CODECS, a)])
+    assert all(y == q for y in back)
+    assert all(len(x) < len(q) // 2 for x in a)
+
+
+def test_many_vblocks_concurrently(gpu_engine, oracle):
+    """a batch shaped like the bench: many VBlocks x sections in one launch == one-at-a-time results"""
+    E = gpu_engine
+    items = []
+    for v in range(24):
+        items.append((7 + 10 * (v % 2), synth.quality_diverse(100 + v, 3000).tobytes()))
+        items.append((6, synth.markov_bytes(200 + v, 40000, 12, 48).tobytes()))
+        items.append((9, synth.u32be_increasing(300 + v, 50000).tobytes()))
+    got = E.compress_many(items)
+    for (c, d), g in zip(items, got):
+        assert g == oracle.codec_compress(c, d)

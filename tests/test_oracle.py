@@ -1,0 +1,135 @@
+"""CPU: the oracle (oracle/gz_oracle.c) against the committed golden vectors, the survey's KATs and - where it was
+built - the reference's own htscodecs (oracle/_ref)."""
+import numpy as np
+import pytest
+
+import cases
+from genozip_amd import synth
+
+# SURVEY.md 8c bootstrap vectors (hex of the full codec output incl. the order byte)
+K1 = b"ACGT" * 16
+K2 = bytes((ord(":") if i % 10 == 9 else ord(",") if i % 7 == 3 else ord("F")) for i in range(60))
+KATS = [
+    (K1, "rans", 0x01, "0140a0004143475400000004000200011000010002100000000310000010000200800000008000000080000000800000"),
+    (K1, "rans", 0x81, "a040044143475410e4e4e4e4e4e4e4e4e4e4e4e4e4e4e4e4"),
+    (K1, "rans", 0x99, "89400404040404b0014100b0014300b0014700b0015400"),
+    (K1, "arith", 0x01, "01405500c62b2fb6f969c8bc864b77fa2bcc50"),
+    (K1, "arith", 0x81, "8140044143475410e500fffffd03d855d19a00"),
+    (K1, "arith", 0x19, "09400409090404114200ffffaf108fdd114400ffffb6c366eab0014700b0015400"),
+    (K2, "rans", 0x01, "013ca0002c3a460000000100000300010107000001000007000009073030d3c817505eff7a309b871230ec3045"),
+    (K2, "rans", 0x81, "a03c032c3a460f2aaa86aa62aaa826aa4aaaa2a6a86a"),
+    (K2, "arith", 0x81, "a03c032c3a460f2aaa86aa62aaa826aa4aaaa2a6a86a"),
+    (K2, "arith", 0x01, "013c4700fffe6b806a74c88cb5228329f1d3ca04a6e14900"),
+    (K2, "rans", 0x99, "893c04070a070ab0022c4602bf5fb0032c3a46049a682a29b0022c4602fb7db0032c3a4604a829a61a"),
+]
+
+
+@pytest.mark.parametrize("data,engine,order,hexout", KATS)
+def test_survey_kats(oracle, data, engine, order, hexout):
+    assert oracle.hts_compress(engine, data, order).hex() == hexout
+    assert oracle.hts_uncompress(engine, bytes.fromhex(hexout), len(data)) == data
+
+
+def test_golden_vectors(oracle):
+    """every committed vector (made by tests/golden/make_golden.py from the reference's htscodecs)"""
+    n = 0
+    shift_margin = 1.0
+    for c in cases.golden_cases():
+        data = cases.golden_input(c)
+        out = oracle.hts_compress(c["engine"], data, c["order"])
+        cases.check_golden(c, out)
+        if c["engine"] == "rans" and len(data) >= 8:
+            r = oracle.last_shift_ratio()
+            if r == r:
+                shift_margin = min(shift_margin, abs(r - 1.01))
+        if len(data) <= 100000:
+            assert oracle.hts_uncompress(c["engine"], out, len(data)) == data
+        n += 1
+    assert n > 3000
+    # compute_shift (rANS_static4x16pr.c:681) compares e10/e12 with 1.01 in floating point: the corpus stays far
+    # enough from the boundary that a last-ulp difference between libm / FMA choices cannot flip a decision
+    assert shift_margin > 1e-6
+
+
+def test_against_reference_build(oracle, ref):
+    """oracle == the reference's own code on fresh inputs (only where oracle/_ref could be built)"""
+    for name, data in cases.edge_streams(70000):
+        for (engine, order) in cases.CODEC_OF:
+            a = oracle.hts_compress(engine, data, order)
+            b = ref.hts_compress(engine, data, order)
+            assert a == b, (name, engine, hex(order))
+            if data:
+                assert ref.hts_uncompress(engine, a, len(data)) == data
+                assert oracle.hts_uncompress(engine, b, len(data)) == data
+
+
+def test_codec_surface(oracle):
+    data = synth.markov_bytes(9, 5000, 40, 33).tobytes()
+    for codec in (1, 6, 7, 8, 9, 16, 17, 18, 19):
+        est = oracle.est_size(codec, len(data))
+        comp = oracle.codec_compress(codec, data)
+        assert oracle.codec_uncompress(codec, comp, len(data)) == data
+        if codec != 1:
+            assert oracle.codec_compress(codec, data, cap=est - 1, soft_fail=True) is None   # "too small" -> caller retries
+            assert oracle.codec_compress(codec, data, cap=2 * est) == comp                   # capacity independent
+    # est_size values: 1 KB + htscodecs bound (codec_htscodecs.c:26-33)
+    assert oracle.est_size(6, 0) == 1024 + 198948 and oracle.est_size(16, 0) == 1024 + 198931
+    many = oracle.codec_compress_many([6, 16, 9], [data, data, data], 3)
+    assert many == [oracle.codec_compress(c, data) for c in (6, 16, 9)]
+
+
+def test_b250_kats(oracle):
+    """SURVEY.md A.2 table (hand-derived from src/b250.c:29-43,82-110)"""
+    kat = {0: "00", 126: "7e", -2: "7f", 127: "8000", 16508: "bffd", -3: "bffe", -4: "bfff", 16509: "c00000",
+           2113660: "dfffff", 2113661: "e020407d"}
+    for wi, hx in kat.items():
+        assert oracle.b250_piz([wi]).hex() == hx
+    # seg format: little endian, tag last; new nodes (>= ol_nodes_len) always 4 bytes
+    assert oracle.b250_seg([5], 100).hex() == "05"
+    assert oracle.b250_seg([127], 1000).hex() == "0080"
+    assert oracle.b250_seg([5], 3).hex() == "050000e0"
+    # generate: node->word, ONE_UP only when the dictionary has > 1024 words and both neighbours are >= 0
+    seg = oracle.b250_seg([1, 2, 3, 10, 2000, 2001], 2000)
+    out = oracle.b250_generate(seg, 2000, [500, 501])
+    assert oracle.b250_decode(out) == [1, 2, 3, 10, 500, 501]
+    assert out.hex() == "017f7f0a8175" + "7f"
+    small = oracle.b250_generate(oracle.b250_seg([1, 2, 3], 100), 100, [])
+    assert small.hex() == "010203"          # dictionary <= 1024 words: no ONE_UP
+    for seed in range(5):
+        ni, n2w = cases.b250_case(100 + seed, 3000, 1500, 700)
+        seg = oracle.b250_seg(ni, 1500)
+        out = oracle.b250_generate(seg, 1500, n2w)
+        want = [(n2w[x - 1500] if x >= 1500 else x) for x in ni]
+        assert oracle.b250_decode(out) == want
+        assert len(out) <= len(seg)
+
+
+def test_local_and_sections(oracle):
+    import pyoracle as po
+    import struct
+    import zlib
+    # interlace KATs (src/context.h:99-100): 2,-5 -> 4,9 ; int8 extremes
+    lt, b = oracle.local_generate(1, struct.pack("<4b", 2, -5, -128, 127))
+    assert list(b) == [4, 9, 255, 254]
+    lt, b = oracle.local_generate(5, struct.pack("<2i", -1, 1))
+    assert b.hex() == "00000001" + "00000002"
+    lt, b = oracle.local_generate(6, struct.pack("<I", 0x11223344))
+    assert b.hex() == "11223344"
+    # transpose after BGEN (src/zip.c:185-219): 2 rows x 3 cols of u16
+    lt, b = oracle.local_generate(4, struct.pack("<6H", 1, 2, 3, 4, 5, 6), 3)
+    assert lt == 15 and b.hex() == "000100040002000500030006"
+    # adler32 == zlib's
+    d = synth.uniform_bytes(3, 100000).tobytes()
+    assert oracle.adler32(d) == zlib.adler32(d)
+    # section header layout
+    desc = po.GzoCtxSectionDesc(vblock_i=3, section_type=12, codec=6, sub_codec=0, flags=0x04, ltype=11, param=7,
+                                b250_size_or_nothing_char=0xff)
+    desc.dict_id[:] = list(b"QUAL\0\0\0\0")
+    payload = synth.markov_bytes(1, 4000, 40, 33).tobytes()
+    sec = oracle.section_compress(desc, payload)
+    comp = oracle.codec_compress(6, payload)
+    assert sec[:4].hex() == "27052012" and sec[40:] == comp
+    assert struct.unpack(">IIIII", sec[4:24]) == (zlib.adler32(comp), 0, len(comp), len(payload), 3)
+    assert list(sec[24:32]) == [12, 6, 0, 0x04, 11, 7, 0xff, 0] and sec[32:40] == b"QUAL\0\0\0\0"
+    tiny = oracle.section_compress(desc, b"x" * 49)          # < 50 bytes: stored raw, codec byte rewritten to NONE
+    assert tiny[25] == 1 and tiny[40:] == b"x" * 49
