@@ -102,6 +102,13 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
         if (h->own_stream) hipStreamDestroy (h->stream);
         delete h; if (err) *err = GZ_ERR_HIP; return NULL;
     }
+    // the largest LDS class of the arithmetic coder needs more than the default 64 KB of dynamic LDS
+    if (hipFuncSetAttribute ((const void *)k_arith_encode, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
+        hipFuncSetAttribute ((const void *)k_arith_decode, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
+        if (err) *err = GZ_ERR_HIP;
+        gz_destroy (h);
+        return NULL;
+    }
     if (err) *err = GZ_OK;
     return h;
 }
@@ -265,7 +272,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
     if (nl) {
         hipLaunchKernelGGL (k_leaf_prep, dim3 (nl), dim3 (256), 4096, h->stream, d_streams, d_leaves);
         if (P.any_rans) {
-            hipLaunchKernelGGL (k_hist, dim3 (nl, GZ_HIST_CHUNKS), dim3 (256), GZ_HIST_LDS + 1024, h->stream, d_leaves);
+            hipLaunchKernelGGL (k_hist, dim3 (nl, GZ_HIST_CHUNKS), dim3 (256), GZ_HIST_LDS, h->stream, d_leaves);
             hipLaunchKernelGGL (k_rans_table, dim3 (nl), dim3 (256), 16384, h->stream, d_leaves, (const GzLogTable *)h->d_logs);
             hipLaunchKernelGGL (k_rans_encode, dim3 (nl), dim3 (64), 0, h->stream, d_leaves);
         }
@@ -625,7 +632,7 @@ static int local_xform (GzHandle *h, int ltype, void *data, uint64_t n, uint32_t
         if (cols && n % cols == 0 && (base == GZ_LT_UINT8 || base == GZ_LT_UINT16 || base == GZ_LT_UINT32) && n) {
             if (!scratch) return GZ_ERR_ARG;
             uint32_t rows = (uint32_t)(n / cols);
-            hipLaunchKernelGGL (k_transpose, dim3 ((cols + 31) / 32, (rows + 31) / 32), dim3 (32, 8), 0, h->stream,
+            hipLaunchKernelGGL (k_transpose, dim3 ((cols + 31) / 32, (rows + 31) / 32), dim3 (32, 8), 32 * 33 * 4 + 128, h->stream,
                                 (const uint8_t *)data, (uint8_t *)scratch, rows, cols, w);
             HIPCHK (h, hipMemcpyAsync (data, scratch, n * w, hipMemcpyDeviceToDevice, h->stream));
             result = base == GZ_LT_UINT8 ? GZ_LT_UINT8_TR : base == GZ_LT_UINT16 ? GZ_LT_UINT16_TR : GZ_LT_UINT32_TR;
@@ -635,7 +642,7 @@ static int local_xform (GzHandle *h, int ltype, void *data, uint64_t n, uint32_t
         if (cols && (ltype == GZ_LT_UINT8_TR || ltype == GZ_LT_UINT16_TR || ltype == GZ_LT_UINT32_TR) && n) {
             if (!scratch || n % cols) return GZ_ERR_ARG;
             uint32_t rows = (uint32_t)(n / cols);           // file holds cols x rows; give back rows x cols
-            hipLaunchKernelGGL (k_transpose, dim3 ((rows + 31) / 32, (cols + 31) / 32), dim3 (32, 8), 0, h->stream,
+            hipLaunchKernelGGL (k_transpose, dim3 ((rows + 31) / 32, (cols + 31) / 32), dim3 (32, 8), 32 * 33 * 4 + 128, h->stream,
                                 (const uint8_t *)data, (uint8_t *)scratch, cols, rows, w);
             HIPCHK (h, hipMemcpyAsync (data, scratch, n * w, hipMemcpyDeviceToDevice, h->stream));
             result = base;

@@ -272,7 +272,8 @@ __global__ void __launch_bounds__(256) k_dec_table (GzdDecLeaf *leaves)
         if (present[c]) {
             uint32_t *row = L.fc + c * 256, sum = 0;
             for (int s = 0; s < 256; s++) sum += row[s];
-            if (sum) {
+            if (sum > (1u << bits)) ok = false;
+            else if (sum) {
                 int shf = 0;
                 while ((sum << shf) < (1u << bits)) shf++;
                 ok = (sum << shf) == (1u << bits);

@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256) k_leaf_prep (GzdStream *streams, GzdLeaf 
 // ======================================================================================================
 #define GZ_HIST_CHUNKS 8
 #define GZ_HIST_RANKS  120                       // order-1 counters kept in LDS when the alphabet is this small
-#define GZ_HIST_LDS    (GZ_HIST_RANKS * GZ_HIST_RANKS * 4)
+#define GZ_HIST_LDS    ((GZ_HIST_RANKS + 1) * GZ_HIST_RANKS * 4 + 64)
 
 __global__ void __launch_bounds__(256) k_hist (GzdLeaf *leaves)
 {

@@ -43,6 +43,8 @@ static inline hipError_t hipStreamCreateWithFlags (hipStream_t *s, int) { *s = (
 static inline hipError_t hipStreamDestroy (hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize (hipStream_t) { return hipSuccess; }
 static inline hipError_t hipGetLastError (void) { return hipSuccess; }
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute (const void *, int, int) { return hipSuccess; }
 static inline hipError_t hipMalloc (void **p, size_t n)
 {
     size_t sz = (n + 255) & ~(size_t)255;
