@@ -66,6 +66,15 @@ def load(path=None):
     if not os.path.exists(path):
         raise RuntimeError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(genozip_amd has no CPU fallback)" % path)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7). If it is
+    # already loaded, the dynamic linker resolves our DT_NEEDED libamdhip64.so.7 to that copy; loaded the other way
+    # round the process would hold two runtimes and the second one to initialise finds no device. So when torch
+    # is going to be used for the HBM buffers, it must come first.
+    if not os.path.basename(path).startswith("libgenozip_amd_emul"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(path)
     L.gz_create.restype = C.c_void_p
     L.gz_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_int)]
