@@ -79,6 +79,19 @@ class Engine:
     def sync(self):
         return self._check(self.L.gz_sync(self.h), "gz_sync")
 
+    def profile(self, enable=True, reset=False):
+        self.L.gz_profile(self.h, int(enable), int(reset))
+
+    def profile_results(self):
+        """{kernel name: (total ms, launches)} accumulated by gz_sync() since the last reset"""
+        out, i = {}, 0
+        name = C.create_string_buffer(64)
+        ms, n = C.c_double(0), C.c_int(0)
+        while self.L.gz_profile_get(self.h, i, name, 64, C.byref(ms), C.byref(n)):
+            out[name.value.decode()] = (ms.value, n.value)
+            i += 1
+        return out
+
     def hip_stream(self):
         return self.L.gz_stream(self.h)
 

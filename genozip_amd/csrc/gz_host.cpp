@@ -45,7 +45,20 @@ struct GzHandle {
     GzLogTable *d_logs;
     std::string err;
     size_t arena_block_size;
+    // optional per-kernel timing with HIP events on this handle's stream (bench.py's roofline object)
+    bool profiling = false;
+    struct ProfRec { const char *name; hipEvent_t a, b; };
+    std::vector<ProfRec> prof_open;
+    struct ProfAcc { std::string name; double ms; int launches; };
+    std::vector<ProfAcc> prof;
 };
+
+// KLAUNCH: hipLaunchKernelGGL bracketed by two events when profiling is on
+#define KLAUNCH(h, kern, grid, block, shmem, ...) do { \
+    GzHandle::ProfRec pr_; pr_.name = #kern; \
+    if ((h)->profiling) { hipEventCreate (&pr_.a); hipEventCreate (&pr_.b); hipEventRecord (pr_.a, (h)->stream); } \
+    hipLaunchKernelGGL (kern, grid, block, shmem, (h)->stream, __VA_ARGS__); \
+    if ((h)->profiling) { hipEventRecord (pr_.b, (h)->stream); (h)->prof_open.push_back (pr_); } } while (0)
 
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     (h)->err = std::string (#call) + ": " + hipGetErrorString (e_); return GZ_ERR_HIP; } } while (0)
@@ -123,6 +136,22 @@ extern "C" void gz_destroy (GzHandle *h)
     hipFree (h->d_logs);
     if (h->own_stream) hipStreamDestroy (h->stream);
     delete h;
+}
+
+extern "C" void gz_profile (GzHandle *h, int enable, int reset)
+{
+    if (!h) return;
+    h->profiling = enable != 0;
+    if (reset) h->prof.clear ();
+}
+
+extern "C" int gz_profile_get (GzHandle *h, int idx, char *name, int name_cap, double *total_ms, int *launches)
+{
+    if (!h || idx < 0 || idx >= (int)h->prof.size ()) return 0;
+    if (name && name_cap > 0) { strncpy (name, h->prof[idx].name.c_str (), name_cap - 1); name[name_cap - 1] = 0; }
+    if (total_ms) *total_ms = h->prof[idx].ms;
+    if (launches) *launches = h->prof[idx].launches;
+    return 1;
 }
 
 extern "C" const char *gz_last_error (GzHandle *h) { return h ? h->err.c_str () : "no handle"; }
@@ -262,30 +291,30 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
 {
     const uint32_t ns = (uint32_t)P.streams.size (), nl = (uint32_t)P.leaves.size ();
     if (!ns) return GZ_OK;
-    hipLaunchKernelGGL (k_resolve, dim3 ((ns + 255) / 256), dim3 (256), 0, h->stream, d_streams, ns, section_mode);
+    KLAUNCH (h, k_resolve, dim3 ((ns + 255) / 256), dim3 (256), 0, d_streams, ns, section_mode);
     if (P.any_striped) {
         uint32_t chunks = (P.max_in / 16 + 255) / 256;
         if (chunks < 1) chunks = 1;
         if (chunks > 64) chunks = 64;
-        hipLaunchKernelGGL (k_stripe, dim3 (ns, chunks), dim3 (256), 0, h->stream, d_streams);
+        KLAUNCH (h, k_stripe, dim3 (ns, chunks), dim3 (256), 0, d_streams);
     }
     if (nl) {
-        hipLaunchKernelGGL (k_leaf_prep, dim3 (nl), dim3 (256), 4096, h->stream, d_streams, d_leaves);
+        KLAUNCH (h, k_leaf_prep, dim3 (nl), dim3 (256), 4096, d_streams, d_leaves);
         if (P.any_rans) {
-            hipLaunchKernelGGL (k_hist, dim3 (nl, GZ_HIST_CHUNKS), dim3 (256), GZ_HIST_LDS, h->stream, d_leaves);
-            hipLaunchKernelGGL (k_rans_table, dim3 (nl), dim3 (256), 16384, h->stream, d_leaves, (const GzLogTable *)h->d_logs);
-            hipLaunchKernelGGL (k_rans_encode, dim3 (nl), dim3 (64), 0, h->stream, d_leaves);
+            KLAUNCH (h, k_hist, dim3 (nl, GZ_HIST_CHUNKS), dim3 (256), GZ_HIST_LDS, d_leaves);
+            KLAUNCH (h, k_rans_table, dim3 (nl), dim3 (256), 16384, d_leaves, (const GzLogTable *)h->d_logs);
+            KLAUNCH (h, k_rans_encode, dim3 (nl), dim3 (64), 0, d_leaves);
         }
         if (P.any_arith) {
             for (int c = 0; c < 3; c++)
-                hipLaunchKernelGGL (k_arith_encode, dim3 (nl), dim3 (64), ARITH_CLASS_WORDS[c + 1] * 4, h->stream,
+                KLAUNCH (h, k_arith_encode, dim3 (nl), dim3 (64), ARITH_CLASS_WORDS[c + 1] * 4,
                                     d_leaves, ARITH_CLASS_WORDS[c], ARITH_CLASS_WORDS[c + 1], 0);
-            hipLaunchKernelGGL (k_arith_encode, dim3 (nl), dim3 (64), 0, h->stream, d_leaves, ARITH_CLASS_WORDS[3], 0xffffffffu, 1);
+            KLAUNCH (h, k_arith_encode, dim3 (nl), dim3 (64), 0, d_leaves, ARITH_CLASS_WORDS[3], 0xffffffffu, 1);
         }
     }
-    hipLaunchKernelGGL (k_select, dim3 ((ns + 255) / 256), dim3 (256), 0, h->stream, d_streams, d_leaves, ns);
-    if (n_vbs) hipLaunchKernelGGL (k_vb_layout, dim3 ((n_vbs + 63) / 64), dim3 (64), 0, h->stream, d_vbs, d_streams, n_vbs);
-    hipLaunchKernelGGL (k_emit, dim3 (ns), dim3 (256), 4096, h->stream, d_streams, d_leaves, d_vbs);
+    KLAUNCH (h, k_select, dim3 ((ns + 255) / 256), dim3 (256), 0, d_streams, d_leaves, ns);
+    if (n_vbs) KLAUNCH (h, k_vb_layout, dim3 ((n_vbs + 63) / 64), dim3 (64), 0, d_vbs, d_streams, n_vbs);
+    KLAUNCH (h, k_emit, dim3 (ns), dim3 (256), 4096, d_streams, d_leaves, d_vbs);
     HIPCHK (h, hipGetLastError ());
     return GZ_OK;
 }
@@ -480,6 +509,16 @@ extern "C" int gz_sync (GzHandle *h)
             }
         }
     }
+    for (auto &pr : h->prof_open) {
+        float ms = 0;
+        if (hipEventElapsedTime (&ms, pr.a, pr.b) == hipSuccess) {
+            bool found = false;
+            for (auto &acc : h->prof) if (acc.name == pr.name) { acc.ms += ms; acc.launches++; found = true; break; }
+            if (!found) { GzHandle::ProfAcc acc; acc.name = pr.name; acc.ms = ms; acc.launches = 1; h->prof.push_back (acc); }
+        }
+        hipEventDestroy (pr.a); hipEventDestroy (pr.b);
+    }
+    h->prof_open.clear ();
     h->pending.clear ();
     for (auto p : h->host_tmp) free (p);
     h->host_tmp.clear ();
@@ -592,7 +631,7 @@ extern "C" int gz_b250_generate_batch (GzHandle *h, const GzB250Job *jobs, int n
     void *d_jobs;
     int rc;
     if ((rc = upload (h, J.data (), J.size () * sizeof (GzdB250Job), &d_jobs)) != GZ_OK) return rc;
-    hipLaunchKernelGGL (k_b250_generate, dim3 (n_jobs), dim3 (256), 4096, h->stream, (GzdB250Job *)d_jobs);
+    KLAUNCH (h, k_b250_generate, dim3 (n_jobs), dim3 (256), 4096, (GzdB250Job *)d_jobs);
     HIPCHK (h, hipGetLastError ());
     return GZ_OK;
 }

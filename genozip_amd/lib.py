@@ -53,7 +53,7 @@ class GzVBlock(C.Structure):
 
 # every symbol include/genozip_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
-    "gz_create", "gz_destroy", "gz_sync", "gz_last_error", "gz_version", "gz_stream",
+    "gz_create", "gz_destroy", "gz_sync", "gz_last_error", "gz_version", "gz_stream", "gz_profile", "gz_profile_get",
     "gz_codec_est_size", "gz_codec_compress_host", "gz_codec_uncompress_host",
     "gz_codec_compress_batch", "gz_codec_uncompress_batch", "gz_codec_assign_best",
     "gz_b250_generate", "gz_b250_generate_batch", "gz_local_generate", "gz_local_to_native",
@@ -85,6 +85,9 @@ def load(path=None):
     L.gz_version.restype = C.c_char_p
     L.gz_stream.restype = C.c_void_p
     L.gz_stream.argtypes = [C.c_void_p]
+    L.gz_profile.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.gz_profile.restype = None
+    L.gz_profile_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.gz_codec_est_size.restype = C.c_uint32
     L.gz_codec_est_size.argtypes = [C.c_int, C.c_uint64]
     L.gz_codec_compress_host.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.POINTER(C.c_uint32), C.c_int]

@@ -1,0 +1,151 @@
+"""Synthetic FASTQ-PE workload of BASELINE.json (configs[0..1]: 150 bp paired-end, 1 M read pairs) expressed as the
+per-VBlock context streams that enter the hot path.
+
+The text parser / field splitter is NOT on the path yet, so the workload is generated
+directly in the form the segmenter hands to the context engine: per VBlock
+    QUAL   local  LT_BLOB   n_reads x 150 quality bytes            (fastq_seg_QUAL  src/fastq_qual.c:24)
+    Q1NAME b250            lane  : tiny dictionary                  (qname tokens   src/qname.c:715-866)
+    Q2NAME b250            tile  : ~600 words, slowly varying, runs
+    Q3NAME local LT_UINT16 x coordinate
+    Q4NAME local LT_UINT32 y coordinate, increasing within a tile
+SEQ (NONREF -> CODEC_ACGT -> LZMA, src/fastq_seq.c:139-154) is outside the path and not generated.
+
+Everything is integer arithmetic on a counter-based hash, written once against a tiny array-namespace shim so that
+numpy (host; CPU baseline, tests) and torch (device; the full batch is generated in HBM) give identical bytes.
+"""
+import numpy as np
+
+READ_LEN = 150
+RECORD_BYTES = 62 + 1 + READ_LEN + 1 + 1 + 1 + READ_LEN + 1     # "@name\nSEQ\n+\nQUAL\n" of the synthetic Illumina read
+_C1, _C2, _C3 = 0x9E3779B97F4A7C15, 0xBF58476D1CE4E5B9, 0x94D049BB133111EB
+
+
+def _s64(v):
+    v &= 0xFFFFFFFFFFFFFFFF
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+class _NP:
+    int64 = np.int64
+
+    @staticmethod
+    def arange(a, b):
+        return np.arange(a, b, dtype=np.int64)
+
+    @staticmethod
+    def mul(x, c):
+        with np.errstate(over="ignore"):
+            return (x.astype(np.uint64) * np.uint64(c & 0xFFFFFFFFFFFFFFFF)).astype(np.int64)
+
+    @staticmethod
+    def add(x, c):
+        with np.errstate(over="ignore"):
+            return (x.astype(np.uint64) + np.uint64(c & 0xFFFFFFFFFFFFFFFF)).astype(np.int64)
+
+    @staticmethod
+    def lsr(x, k):
+        return (x.astype(np.uint64) >> np.uint64(k)).astype(np.int64)
+
+    cumsum = staticmethod(lambda x: np.cumsum(x, dtype=np.int64))
+    clip = staticmethod(lambda x, lo, hi: np.clip(x, lo, hi))
+    where = staticmethod(np.where)
+    repeat_rows = staticmethod(lambda v, k: np.repeat(v, k))
+    tile = staticmethod(lambda v, k: np.tile(v, k))
+    to_u8 = staticmethod(lambda x: x.astype(np.uint8))
+
+
+class _TH:
+    def __init__(self, device):
+        import torch
+        self.t, self.dev, self.int64 = torch, device, torch.int64
+
+    def arange(self, a, b):
+        return self.t.arange(a, b, dtype=self.t.int64, device=self.dev)
+
+    def mul(self, x, c):
+        return x * _s64(c)                      # int64 multiplication wraps
+
+    def add(self, x, c):
+        return x + _s64(c)
+
+    def lsr(self, x, k):
+        return (x >> k) & ((1 << (64 - k)) - 1)
+
+    def cumsum(self, x):
+        return self.t.cumsum(x, 0)
+
+    def clip(self, x, lo, hi):
+        return self.t.clamp(x, lo, hi)
+
+    def where(self, c, a, b):
+        if not self.t.is_tensor(a):
+            a = self.t.full_like(b if self.t.is_tensor(b) else c, a, dtype=self.t.int64)
+        if not self.t.is_tensor(b):
+            b = self.t.full_like(a, b)
+        return self.t.where(c, a, b)
+
+    def repeat_rows(self, v, k):
+        return self.t.repeat_interleave(v, k)
+
+    def tile(self, v, k):
+        return v.repeat(k)
+
+    def to_u8(self, x):
+        return x.to(self.t.uint8)
+
+
+def _hash(xp, seed, idx):
+    """splitmix64 of (seed, counter) -> non-negative 32-bit values in int64 (same stream as synth.splitmix64 >> 32)"""
+    z = xp.add(xp.mul(xp.add(idx, 1), _C1), seed)
+    z = xp.mul(z ^ xp.lsr(z, 30), _C2)
+    z = xp.mul(z ^ xp.lsr(z, 27), _C3)
+    z = z ^ xp.lsr(z, 31)
+    return xp.lsr(z, 32)
+
+
+def quality_rows(xp, seed, read0, n_reads, profile="div"):
+    """n_reads x 150 Phred+33 bytes for reads [read0, read0+n_reads) of the file with this seed.
+    profile "div": 40-level, position dependent decay + per-read random walk (SURVEY 8d Q-div);
+    profile "bin": NovaSeq 4-level F : , # with >= 85 % F (SURVEY 8d Q-bin)."""
+    L = READ_LEN
+    idx = xp.arange(read0 * L, (read0 + n_reads) * L)
+    pos = idx % L
+    h1, h2 = _hash(xp, seed, idx), _hash(xp, seed + 0x51ED, idx)
+    if profile == "bin":
+        dip = (h1 % 100) < 5
+        lvl = h2 % 100
+        q = xp.where(dip, xp.where(lvl < 55, 58, xp.where(lvl < 88, 44, 35)), 70)
+        prev_dip = (_hash(xp, seed, idx - 1) % 100) < 5
+        q = xp.where(prev_dip & ~dip & (pos > 0), 58, q)
+        return xp.to_u8(q)
+    steps = (h1 % 3) - 1
+    walk = xp.cumsum(steps)
+    row_start = xp.repeat_rows(walk[::L] - steps[::L], L)
+    walk = walk - row_start
+    noise = (h2 % 5) + (xp.lsr(h2, 8) % 5) + (xp.lsr(h2, 16) % 5) - 6
+    q = 38 - (12 * pos * pos) // (L * L) + (walk * 3) // 8 + noise
+    return xp.to_u8(xp.clip(q, 2, 41) + 33)
+
+
+def name_fields(seed, read0, n_reads):
+    """host side (numpy): lane / tile node indices and x / y coordinates of reads [read0, read0+n_reads).
+    Reads are emitted tile by tile (~4000 reads per tile), x random, y increasing inside a tile."""
+    xp = _NP
+    idx = xp.arange(read0, read0 + n_reads)
+    tile_no = idx // 4000
+    lane = (tile_no // 156) % 4                     # dictionary of 4 lanes
+    tile = tile_no % 624                            # dictionary of 624 tiles
+    h = _hash(xp, seed + 0x7A11, idx)
+    x = (1000 + h % 32000).astype(np.uint16)
+    y = (1000 + (idx % 4000) * 9 + xp.lsr(h, 16) % 9).astype(np.uint32)
+    return lane, tile, x, y
+
+
+def reads_per_vb(vb_bytes):
+    return max(1, vb_bytes // RECORD_BYTES)
+
+
+def vb_ranges(n_reads, vb_bytes):
+    """(read0, n_reads) of every VBlock of one mate file (txtfile_read_vblock cuts at record boundaries, src/txtfile.c:1228)"""
+    per = reads_per_vb(vb_bytes)
+    return [(r0, min(per, n_reads - r0)) for r0 in range(0, n_reads, per)]

@@ -55,6 +55,12 @@ void      gz_destroy (GzHandle *h);
 int       gz_sync (GzHandle *h);
 const char *gz_last_error (GzHandle *h);
 const char *gz_version (void);
+/* Per-kernel timing: when enabled, every kernel launch of the compression pipeline is bracketed by two HIP events on
+ * the handle's stream; gz_sync() folds them into per-kernel totals (this is the reference's --show-time /
+ * START_TIMER..COPY_TIMER instrumentation, src/profiler.h:96-166, re-expressed for a GPU stream).
+ * gz_profile_get(idx) enumerates the accumulated entries until it returns 0. */
+void gz_profile (GzHandle *h, int enable, int reset);
+int  gz_profile_get (GzHandle *h, int idx, char *name, int name_cap, double *total_ms, int *launches);
 /* the HIP stream work is queued on (a hipStream_t) - for timing with HIP events on the right stream */
 void     *gz_stream (GzHandle *h);
 

@@ -43,6 +43,11 @@ static inline hipError_t hipStreamCreateWithFlags (hipStream_t *s, int) { *s = (
 static inline hipError_t hipStreamDestroy (hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize (hipStream_t) { return hipSuccess; }
 static inline hipError_t hipGetLastError (void) { return hipSuccess; }
+typedef void *hipEvent_t;
+static inline hipError_t hipEventCreate (hipEvent_t *e) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventDestroy (hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord (hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime (float *ms, hipEvent_t, hipEvent_t) { *ms = 0; return hipSuccess; }
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute (const void *, int, int) { return hipSuccess; }
 static inline hipError_t hipMalloc (void **p, size_t n)
