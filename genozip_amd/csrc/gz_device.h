@@ -78,7 +78,8 @@ struct GzdLeaf {
     uint8_t   *rowbuf;        // order-1: GZ_ROW_SLOT bytes per context while serialising; also nested table coder scratch
     uint8_t   *tab;           // serialised frequency table
     uint8_t   *pay;           // entropy-coded payload area (rANS fills it from the end)
-    uint32_t  *models;        // arith: global-memory models when they do not fit the LDS
+    uint32_t  *models;        // arith (run-length variant): global-memory models when they do not fit the LDS
+    uint8_t   *triples;       // arith: 8 bytes per coded byte: cum | freq << 16, tot  (k_arith_model -> k_arith_chain)
     uint32_t  pay_cap;
 };
 

@@ -17,6 +17,7 @@
 #include "gz_device.h"
 #include "gz_devutil.h"
 #include "gz_kernels_enc.h"
+#include "gz_kernels_arith.h"
 #include "gz_kernels_dec.h"
 #include "gz_kernels_ctx.h"
 
@@ -43,6 +44,7 @@ struct GzHandle {
     std::vector<Pending> pending;
     std::vector<void *> host_tmp;      // host staging to free at sync
     GzLogTable *d_logs;
+    GzDivMagic *d_magic;      // division-by-multiplication constants for every possible model total
     std::string err;
     size_t arena_block_size;
     // optional per-kernel timing with HIP events on this handle's stream (bench.py's roofline object)
@@ -100,7 +102,7 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
     }
     if (hipSetDevice (device) != hipSuccess) { if (err) *err = GZ_ERR_HIP; return NULL; }
     GzHandle *h = new GzHandle ();
-    h->device = device;
+    h->device = device; h->d_logs = NULL; h->d_magic = NULL;
     h->arena_block_size = (size_t)256 << 20;
     if (hip_stream) { h->stream = (hipStream_t)hip_stream; h->own_stream = false; }
     else {
@@ -114,6 +116,30 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
         hipMemcpy (h->d_logs, &lt, sizeof (lt), hipMemcpyHostToDevice) != hipSuccess) {
         if (h->own_stream) hipStreamDestroy (h->stream);
         delete h; if (err) *err = GZ_ERR_HIP; return NULL;
+    }
+    // range / tot of the range coder (c_range_coder.h:100) as multiply + shifts: one "branch-free" magic number per
+    // divisor (Granlund & Montgomery; the libdivide u32 branchfree scheme), tot <= 65519 + 16
+    {
+        const uint32_t N = 65536 + 32;
+        std::vector<GzDivMagic> mt (N);
+        mt[0].magic = 0; mt[0].shift = 0xff;
+        mt[1].magic = 0; mt[1].shift = 0xff;                       // divisor 1: q = n
+        for (uint32_t dv = 2; dv < N; dv++) {
+            uint32_t L = 31 - __builtin_clz (dv);
+            if ((dv & (dv - 1)) == 0) { mt[dv].magic = 0; mt[dv].shift = L - 1; continue; }
+            uint64_t num = 1ull << (32 + L);
+            uint32_t m = (uint32_t)(num / dv), rem = (uint32_t)(num % dv);
+            m += m;
+            uint32_t twice = rem + rem;
+            if (twice >= dv || twice < rem) m += 1;
+            mt[dv].magic = m + 1; mt[dv].shift = L;
+        }
+        if (hipMalloc ((void **)&h->d_magic, N * sizeof (GzDivMagic)) != hipSuccess ||
+            hipMemcpy (h->d_magic, mt.data (), N * sizeof (GzDivMagic), hipMemcpyHostToDevice) != hipSuccess) {
+            if (err) *err = GZ_ERR_HIP;
+            gz_destroy (h);
+            return NULL;
+        }
     }
     // the largest LDS class of the arithmetic coder needs more than the default 64 KB of dynamic LDS
     if (hipFuncSetAttribute ((const void *)k_arith_encode, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
@@ -134,6 +160,7 @@ extern "C" void gz_destroy (GzHandle *h)
     for (auto &b : h->blocks) hipFree (b.base);
     for (auto p : h->host_tmp) free (p);
     hipFree (h->d_logs);
+    hipFree (h->d_magic);
     if (h->own_stream) hipStreamDestroy (h->stream);
     delete h;
 }
@@ -214,8 +241,11 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
     }
     else {
         const bool rle = method & GZ_X_RLE;
-        size_t words = (size_t)(o1 ? 256 : 1) * 257 + (rle ? GZ_ARITH_RUN_MODELS * GZ_ARITH_RUN_STRIDE : 0);
-        if (!(L.models = (uint32_t *)arena_alloc (h, words * 4))) return false;
+        if (rle) {
+            size_t words = (size_t)(o1 ? 256 : 1) * 257 + GZ_ARITH_RUN_MODELS * GZ_ARITH_RUN_STRIDE;
+            if (!(L.models = (uint32_t *)arena_alloc (h, words * 4))) return false;
+        }
+        else if (!(L.triples = (uint8_t *)arena_alloc (h, ((size_t)n_bound + 64) * 8))) return false;
     }
     P.leaves.push_back (L);
     return true;
@@ -306,6 +336,8 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
             KLAUNCH (h, k_rans_encode, dim3 (nl), dim3 (64), 0, d_leaves);
         }
         if (P.any_arith) {
+            KLAUNCH (h, k_arith_model, dim3 (nl, 256), dim3 (64), 0, d_leaves);
+            KLAUNCH (h, k_arith_chain, dim3 (nl), dim3 (64), 0, d_leaves, (const GzDivMagic *)h->d_magic);
             for (int c = 0; c < 3; c++)
                 KLAUNCH (h, k_arith_encode, dim3 (nl), dim3 (64), ARITH_CLASS_WORDS[c + 1] * 4,
                                     d_leaves, ARITH_CLASS_WORDS[c], ARITH_CLASS_WORDS[c + 1], 0);

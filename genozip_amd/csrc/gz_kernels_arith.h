@@ -1,0 +1,203 @@
+// gz_kernels_arith.h -- the adaptive arithmetic coder (arith_dynamic.c:92-197, c_simple_model.h, c_range_coder.h),
+// re-thought for a GPU.
+//
+// The reference walks a stream once, per symbol: search the context's frequency-sorted list for the symbol
+// (accumulating the cumulative frequency), divide the range by the model total, update low/range, renormalise,
+// bump the frequency, maybe halve all, maybe swap with the left neighbour. One lane doing that costs ~2000 cycles per
+// symbol. But the triple (cum, freq, tot) fed to the range coder depends only on the *model history*, never on the
+// coder state, and in order-1 mode the 256 models never interact. So:
+//
+//   k_arith_model  one WAVE per (leaf, context). The model lives in registers, entry e in lane e%64: finding a symbol
+//                  is one ballot, its cumulative frequency a register kept up to date incrementally (every entry after
+//                  the bumped one gains 16), the swap two writelanes. The wave scans the input for the positions that
+//                  belong to its context and writes the 8-byte triple of every such position. All contexts of all
+//                  leaves run concurrently.
+//   k_arith_chain  one wave per leaf replays the triples through the range coder. Only range -> range/tot*freq ->
+//                  renormalise is truly serial; it runs on wave-uniform values (the scalar unit), with the division
+//                  replaced by a multiply by a per-divisor magic number looked up from a table built once on the host.
+//                  64 triples are fetched per iteration with one coalesced load and handed to the chain by readlane.
+//
+// Leaves using the run-length variant (stripe plane 0 candidate of ARTW/ARTw) keep the serial kernel in
+// gz_kernels_enc.h for now.
+#pragma once
+#include "gz_device.h"
+#include "gz_devutil.h"
+
+#define GZ_MODEL_LIMIT 65519u          // MAX_FREQ (c_simple_model.h:63)
+#define GZ_MODEL_STEP  16u
+
+struct GzDivMagic { uint32_t magic, shift; };   // q = ((((n - t) >> 1) + t) >> shift, t = mulhi(magic, n); divisor 1: shift = 0xff
+
+__device__ static inline uint32_t d_readlane (uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane ((int)v, lane); }
+__device__ static inline uint32_t d_writelane (uint32_t val, int lane, uint32_t old) { return (uint32_t)__builtin_amdgcn_writelane ((int)val, lane, (int)old); }
+
+// J = registers per lane holding the model (entries e = j*64 + lane), J*64 >= max_sym
+template <int J>
+__device__ static void d_arith_model_wave (const uint8_t *in, uint32_t n, uint32_t ms, bool o1, uint32_t ctx, uint2 *triples)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t sym[J], freq[J], cum[J];
+    #pragma unroll
+    for (int j = 0; j < J; j++) {
+        uint32_t e = j * 64 + lane;
+        sym[j] = e; freq[j] = e < ms ? 1 : 0; cum[j] = e < ms ? e : ms;
+    }
+    uint32_t tot = ms;
+
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t pos = base + lane;
+        uint32_t s_v = 0;
+        bool mine = false;
+        if (pos < n) {
+            s_v = in[pos];
+            mine = !o1 || (pos ? in[pos - 1] : 0u) == ctx;
+        }
+        uint64_t todo = __ballot (mine);
+        uint32_t out_lo = 0, out_hi = 0;
+        while (todo) {
+            const int b = __ffsll ((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t s = d_readlane (s_v, b);
+            // ---- find the symbol: global position p = jj*64 + pl
+            int jj = 0, pl = 0;
+            #pragma unroll
+            for (int j = 0; j < J; j++) {
+                uint64_t hit = __ballot (sym[j] == s && (uint32_t)(j * 64 + lane) < ms);
+                if (hit) { jj = j; pl = __ffsll ((unsigned long long)hit) - 1; }
+            }
+            uint32_t f = 0, cu = 0;
+            #pragma unroll
+            for (int j = 0; j < J; j++) if (j == jj) { f = d_readlane (freq[j], pl); cu = d_readlane (cum[j], pl); }
+            // ---- hand (cum, freq, tot) to the lane that owns this position
+            out_lo = d_writelane (cu | (f << 16), b, out_lo);
+            out_hi = d_writelane (tot, b, out_hi);
+            // ---- bump (c_simple_model.h:133-134): the entry gains 16, so does the cumulative of everything after it
+            const uint32_t p = jj * 64 + pl;
+            uint32_t f16 = f + GZ_MODEL_STEP;
+            tot += GZ_MODEL_STEP;
+            #pragma unroll
+            for (int j = 0; j < J; j++) {
+                if (j == jj) freq[j] = d_writelane (f16, pl, freq[j]);
+                cum[j] += ((uint32_t)(j * 64 + lane) > p) ? GZ_MODEL_STEP : 0u;
+            }
+            // ---- halve everything when the total passes the limit (c_simple_model.h:106-115,136-137)
+            if (tot > GZ_MODEL_LIMIT) {
+                #pragma unroll
+                for (int j = 0; j < J; j++) freq[j] -= freq[j] >> 1;
+                uint32_t run = 0;
+                #pragma unroll
+                for (int j = 0; j < J; j++)
+                    for (int l = 0; l < 64; l++) {
+                        if ((uint32_t)(j * 64 + l) >= ms) break;
+                        cum[j] = d_writelane (run, l, cum[j]);
+                        run += d_readlane (freq[j], l);
+                    }
+                tot = run;
+                #pragma unroll
+                for (int j = 0; j < J; j++) {
+                    if (j == jj) f16 = d_readlane (freq[j], pl);
+                    cum[j] = ((uint32_t)(j * 64 + lane) < ms) ? cum[j] : run;
+                }
+            }
+            // ---- keep approximately sorted: one bubble step to the left (c_simple_model.h:139-145)
+            if (p > 0) {
+                const int jq = (int)((p - 1) >> 6), lq = (int)((p - 1) & 63);
+                uint32_t fl = 0, sl = 0, cl = 0;
+                #pragma unroll
+                for (int j = 0; j < J; j++) if (j == jq) { fl = d_readlane (freq[j], lq); sl = d_readlane (sym[j], lq); cl = d_readlane (cum[j], lq); }
+                if (f16 > fl) {
+                    #pragma unroll
+                    for (int j = 0; j < J; j++) {
+                        if (j == jq) { sym[j] = d_writelane (s, lq, sym[j]); freq[j] = d_writelane (f16, lq, freq[j]); }
+                        if (j == jj) { sym[j] = d_writelane (sl, pl, sym[j]); freq[j] = d_writelane (fl, pl, freq[j]); cum[j] = d_writelane (cl + f16, pl, cum[j]); }
+                    }
+                }
+            }
+        }
+        if (mine) triples[pos] = make_uint2 (out_lo, out_hi);
+    }
+}
+
+// grid (n_leaves, 256): block y serves context y of leaf x
+__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves)
+{
+    GzdLeaf &L = leaves[blockIdx.x];
+    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle || !L.coded_n) return;
+    const uint32_t ctx = blockIdx.y, ms = L.max_sym;
+    const bool o1 = L.o1;
+    if (o1 ? (ctx >= ms || (ctx && L.symrank[ctx] == 0xffff)) : ctx != 0) return;   // a byte that never occurs is never a context
+    uint2 *tr = (uint2 *)L.triples;
+    if (ms <= 64)       d_arith_model_wave<1> (L.coded, L.coded_n, ms, o1, ctx, tr);
+    else if (ms <= 128) d_arith_model_wave<2> (L.coded, L.coded_n, ms, o1, ctx, tr);
+    else                d_arith_model_wave<4> (L.coded, L.coded_n, ms, o1, ctx, tr);
+}
+
+// ---- range coder chain ------------------------------------------------------------------------------------------
+// All values below are wave-uniform (they come from readlane), so the compiler keeps the chain on the scalar unit.
+struct GzRcU { uint32_t low, range, carry, cache, ff, len, cap, overflow; uint32_t stage; uint8_t *out; };
+
+__device__ static inline void d_rcu_emit (GzRcU &rc, uint32_t byte, int lane)
+{
+    if (rc.len >= rc.cap) { rc.overflow = 1; return; }
+    rc.stage = d_writelane (byte, (int)(rc.len & 63), rc.stage);
+    rc.len++;
+    if (!(rc.len & 63)) rc.out[rc.len - 64 + lane] = (uint8_t)rc.stage;        // 64 staged bytes leave with one store
+}
+
+__device__ static inline void d_rcu_shift (GzRcU &rc, int lane)     // c_range_coder.h:70-88
+{
+    if (rc.low < 0xff000000u || rc.carry) {
+        d_rcu_emit (rc, (rc.cache + rc.carry) & 0xff, lane);
+        for (; rc.ff; rc.ff--) d_rcu_emit (rc, (rc.carry - 1) & 0xff, lane);
+        rc.cache = rc.low >> 24;
+        rc.carry = 0;
+    }
+    else rc.ff++;
+    rc.low <<= 8;
+}
+
+// one wave per leaf
+__global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves, const GzDivMagic *magic_tab)
+{
+    GzdLeaf &L = leaves[blockIdx.x];
+    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
+    const int lane = threadIdx.x;
+    const uint32_t n = L.coded_n;
+    const uint2 *tr = (const uint2 *)L.triples;
+
+    GzRcU rc;
+    rc.low = 0; rc.range = 0xffffffffu; rc.carry = rc.cache = rc.ff = 0;
+    rc.len = 0; rc.cap = L.pay_cap - 1; rc.overflow = 0; rc.stage = 0; rc.out = L.pay + 1;
+    if (!lane) L.pay[0] = (uint8_t)(n ? L.max_sym : 1);                  // max_sym + 1 (256 wraps to 0), arith_dynamic.c:103-108
+
+    for (uint32_t base = 0; base < n && !rc.overflow; base += 64) {
+        const uint32_t i = base + lane;
+        uint32_t v_lo = 0, v_tot = 1, v_magic = 0, v_shift = 0;
+        if (i < n) {
+            uint2 t = tr[i];
+            v_lo = t.x; v_tot = t.y;
+            GzDivMagic mg = magic_tab[t.y];
+            v_magic = mg.magic; v_shift = mg.shift;
+        }
+        const uint32_t cnt = n - base < 64 ? n - base : 64;
+        for (uint32_t k = 0; k < cnt; k++) {
+            const uint32_t lo = d_readlane (v_lo, (int)k), mg = d_readlane (v_magic, (int)k), sh = d_readlane (v_shift, (int)k);
+            const uint32_t cum = lo & 0xffff, freq = lo >> 16;
+            // r = range / tot                                         (c_range_coder.h:100)
+            const uint32_t t = __umulhi (mg, rc.range);
+            const uint32_t r = sh == 0xff ? rc.range : (((rc.range - t) >> 1) + t) >> sh;
+            const uint32_t before = rc.low;
+            rc.low  += cum * r;
+            rc.range = r * freq;
+            rc.carry += rc.low < before;
+            while (rc.range < (1u << 24)) { rc.range <<= 8; d_rcu_shift (rc, lane); }
+        }
+    }
+    for (int k = 0; k < 5; k++) d_rcu_shift (rc, lane);                  // RC_FinishEncode
+    if (rc.len & 63) { if ((uint32_t)lane < (rc.len & 63)) rc.out[(rc.len & ~63u) + lane] = (uint8_t)rc.stage; }
+    if (!lane) {
+        if (rc.overflow) { L.overflow = 1; L.pay_len = 0; }
+        else L.pay_len = rc.len + 1;
+        L.tab_len = 0;
+    }
+}

@@ -661,7 +661,7 @@ __device__ static inline uint32_t gz_arith_model_words (uint32_t max_sym, bool o
 __global__ void __launch_bounds__(64) k_arith_encode (GzdLeaf *leaves, uint32_t lds_words_lo, uint32_t lds_words_hi, int use_global)
 {
     GzdLeaf &L = leaves[blockIdx.x];
-    if (!L.active || L.engine != GZ_ENG_ARITH) return;
+    if (!L.active || L.engine != GZ_ENG_ARITH || !L.rle) return;     // plain order-0/1 leaves: gz_kernels_arith.h
     const uint32_t n = L.coded_n, max_sym = L.max_sym;
     const bool o1 = L.o1, rle = L.rle;
     const uint32_t words = gz_arith_model_words (n ? max_sym : 1, o1, rle);

@@ -191,6 +191,25 @@ static inline unsigned long long __ballot (int pred)
     return W.result;
 }
 
+// wave-wide exchange: every live lane deposits a value, then reads the source lane's
+static inline int emu_shfl (int v, int src)
+{
+    unsigned me = emu.cur, w = me / 64;
+    static int slots[EmuSched::MAXT];
+    slots[me] = v;
+    (void)__ballot (0);                     // all lanes have deposited
+    int r = slots[w * 64 + (src & 63)];
+    (void)__ballot (0);                     // all lanes have read
+    return r;
+}
+#define __builtin_amdgcn_readlane(v, lane) emu_shfl ((v), (lane))
+#define __builtin_amdgcn_readfirstlane(v) emu_shfl ((v), 0)
+static inline int emu_writelane (int val, int lane, int old) { return (int)(emu.cur % 64) == lane ? val : old; }
+#define __builtin_amdgcn_writelane(val, lane, old) emu_writelane ((val), (lane), (old))
+static inline int __ffsll (unsigned long long v) { return __builtin_ffsll ((long long)v); }
+struct uint2 { unsigned x, y; };
+static inline uint2 make_uint2 (unsigned x, unsigned y) { uint2 r; r.x = x; r.y = y; return r; }
+
 static inline int __popcll (unsigned long long v) { return __builtin_popcountll (v); }
 static inline unsigned __umulhi (unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline long long __double_as_longlong (double d) { long long v; memcpy (&v, &d, 8); return v; }
