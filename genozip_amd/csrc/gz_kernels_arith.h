@@ -29,7 +29,8 @@
 struct GzDivMagic { uint32_t magic, shift; };   // q = ((((n - t) >> 1) + t) >> shift, t = mulhi(magic, n); divisor 1: shift = 0xff
 
 __device__ static inline uint32_t d_readlane (uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane ((int)v, lane); }
-__device__ static inline uint32_t d_writelane (uint32_t val, int lane, uint32_t old) { return (uint32_t)__builtin_amdgcn_writelane ((int)val, lane, (int)old); }
+// (clang 22 / ROCm 7.2 has no __builtin_amdgcn_writelane; compare + select costs one more VALU op than v_writelane_b32)
+__device__ static inline uint32_t d_writelane (uint32_t val, int lane, uint32_t old) { return (int)(threadIdx.x & 63) == lane ? val : old; }
 
 // J = registers per lane holding the model (entries e = j*64 + lane), J*64 >= max_sym
 template <int J>

@@ -204,8 +204,6 @@ static inline int emu_shfl (int v, int src)
 }
 #define __builtin_amdgcn_readlane(v, lane) emu_shfl ((v), (lane))
 #define __builtin_amdgcn_readfirstlane(v) emu_shfl ((v), 0)
-static inline int emu_writelane (int val, int lane, int old) { return (int)(emu.cur % 64) == lane ? val : old; }
-#define __builtin_amdgcn_writelane(val, lane, old) emu_writelane ((val), (lane), (old))
 static inline int __ffsll (unsigned long long v) { return __builtin_ffsll ((long long)v); }
 struct uint2 { unsigned x, y; };
 static inline uint2 make_uint2 (unsigned x, unsigned y) { uint2 r; r.x = x; r.y = y; return r; }
