@@ -79,7 +79,7 @@ struct GzdLeaf {
     uint8_t   *tab;           // serialised frequency table
     uint8_t   *pay;           // entropy-coded payload area (rANS fills it from the end)
     uint32_t  *models;        // arith (run-length variant): global-memory models when they do not fit the LDS
-    uint8_t   *triples;       // arith: 8 bytes per coded byte: cum | freq << 16, tot  (k_arith_model -> k_arith_chain)
+    uint8_t   *triples;       // arith: 16 bytes per coded byte: cum | freq << 16, division magic, shift, tot  (k_arith_model -> k_arith_chain)
     uint32_t  pay_cap;
 };
 

@@ -34,7 +34,7 @@ __device__ static inline uint32_t d_writelane (uint32_t val, int lane, uint32_t 
 
 // J = registers per lane holding the model (entries e = j*64 + lane), J*64 >= max_sym
 template <int J>
-__device__ static void d_arith_model_wave (const uint8_t *in, uint32_t n, uint32_t ms, bool o1, uint32_t ctx, uint2 *triples)
+__device__ static void d_arith_model_wave (const uint8_t *in, uint32_t n, uint32_t ms, bool o1, uint32_t ctx, uint4 *recs, const GzDivMagic *magic_tab)
 {
     const int lane = threadIdx.x & 63;
     uint32_t sym[J], freq[J], cum[J];
@@ -115,22 +115,22 @@ __device__ static void d_arith_model_wave (const uint8_t *in, uint32_t n, uint32
                 }
             }
         }
-        if (mine) triples[pos] = make_uint2 (out_lo, out_hi);
+        if (mine) { GzDivMagic mg = magic_tab[out_hi]; recs[pos] = make_uint4 (out_lo, mg.magic, mg.shift, out_hi); }
     }
 }
 
 // grid (n_leaves, 256): block y serves context y of leaf x
-__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves)
+__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const GzDivMagic *magic_tab)
 {
     GzdLeaf &L = leaves[blockIdx.x];
     if (!L.active || L.engine != GZ_ENG_ARITH || L.rle || !L.coded_n) return;
     const uint32_t ctx = blockIdx.y, ms = L.max_sym;
     const bool o1 = L.o1;
     if (o1 ? (ctx >= ms || (ctx && L.symrank[ctx] == 0xffff)) : ctx != 0) return;   // a byte that never occurs is never a context
-    uint2 *tr = (uint2 *)L.triples;
-    if (ms <= 64)       d_arith_model_wave<1> (L.coded, L.coded_n, ms, o1, ctx, tr);
-    else if (ms <= 128) d_arith_model_wave<2> (L.coded, L.coded_n, ms, o1, ctx, tr);
-    else                d_arith_model_wave<4> (L.coded, L.coded_n, ms, o1, ctx, tr);
+    uint4 *tr = (uint4 *)L.triples;
+    if (ms <= 64)       d_arith_model_wave<1> (L.coded, L.coded_n, ms, o1, ctx, tr, magic_tab);
+    else if (ms <= 128) d_arith_model_wave<2> (L.coded, L.coded_n, ms, o1, ctx, tr, magic_tab);
+    else                d_arith_model_wave<4> (L.coded, L.coded_n, ms, o1, ctx, tr, magic_tab);
 }
 
 // ---- range coder chain ------------------------------------------------------------------------------------------
@@ -157,43 +157,54 @@ __device__ static inline void d_rcu_shift (GzRcU &rc, int lane)     // c_range_c
     rc.low <<= 8;
 }
 
+// One symbol of the chain: r = range / tot by multiplication, low += cum * r, range = r * freq, renormalise.
+__device__ static inline void d_rcu_step (GzRcU &rc, uint32_t lo, uint32_t mg, uint32_t sh, int lane)
+{
+    const uint32_t cum = lo & 0xffff, freq = lo >> 16;
+    const uint32_t t = __umulhi (mg, rc.range);
+    const uint32_t r = sh == 0xff ? rc.range : (((rc.range - t) >> 1) + t) >> sh;        // c_range_coder.h:100
+    const uint32_t before = rc.low;
+    rc.low  += cum * r;
+    rc.range = r * freq;
+    rc.carry += rc.low < before;
+    while (rc.range < (1u << 24)) { rc.range <<= 8; d_rcu_shift (rc, lane); }
+}
+
+// The records were written by the previous kernel and are read-only here: reading them through the constant address
+// space with a wave-uniform index turns the loads into scalar (SMEM) loads, so the whole chain - loads included - runs
+// on the scalar unit; the next 4 records are in flight while the current 4 are being coded.
+typedef uint32_t gz_u32x4 __attribute__((vector_size (16)));
+typedef const volatile __attribute__((address_space(4))) gz_u32x4 *GzConstRecP;   // volatile: keeps the prefetch a prefetch (no rematerialisation)
+
 // one wave per leaf
-__global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves, const GzDivMagic *magic_tab)
+__global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
 {
     GzdLeaf &L = leaves[blockIdx.x];
     if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
     const int lane = threadIdx.x;
     const uint32_t n = L.coded_n;
-    const uint2 *tr = (const uint2 *)L.triples;
+    GzConstRecP rec = (GzConstRecP)(uintptr_t)L.triples;
 
     GzRcU rc;
     rc.low = 0; rc.range = 0xffffffffu; rc.carry = rc.cache = rc.ff = 0;
     rc.len = 0; rc.cap = L.pay_cap - 1; rc.overflow = 0; rc.stage = 0; rc.out = L.pay + 1;
     if (!lane) L.pay[0] = (uint8_t)(n ? L.max_sym : 1);                  // max_sym + 1 (256 wraps to 0), arith_dynamic.c:103-108
 
-    for (uint32_t base = 0; base < n && !rc.overflow; base += 64) {
-        const uint32_t i = base + lane;
-        uint32_t v_lo = 0, v_tot = 1, v_magic = 0, v_shift = 0;
-        if (i < n) {
-            uint2 t = tr[i];
-            v_lo = t.x; v_tot = t.y;
-            GzDivMagic mg = magic_tab[t.y];
-            v_magic = mg.magic; v_shift = mg.shift;
-        }
-        const uint32_t cnt = n - base < 64 ? n - base : 64;
-        for (uint32_t k = 0; k < cnt; k++) {
-            const uint32_t lo = d_readlane (v_lo, (int)k), mg = d_readlane (v_magic, (int)k), sh = d_readlane (v_shift, (int)k);
-            const uint32_t cum = lo & 0xffff, freq = lo >> 16;
-            // r = range / tot                                         (c_range_coder.h:100)
-            const uint32_t t = __umulhi (mg, rc.range);
-            const uint32_t r = sh == 0xff ? rc.range : (((rc.range - t) >> 1) + t) >> sh;
-            const uint32_t before = rc.low;
-            rc.low  += cum * r;
-            rc.range = r * freq;
-            rc.carry += rc.low < before;
-            while (rc.range < (1u << 24)) { rc.range <<= 8; d_rcu_shift (rc, lane); }
+    const uint32_t n4 = n & ~3u;
+    if (n4) {
+        gz_u32x4 c0 = rec[0], c1 = rec[1], c2 = rec[2], c3 = rec[3];
+        for (uint32_t i = 0; i < n4 && !rc.overflow; i += 4) {
+            const uint32_t nx = i + 4 < n4 ? i + 4 : i;                  // the last block re-reads itself (harmless)
+            const gz_u32x4 p0 = rec[nx], p1 = rec[nx + 1], p2 = rec[nx + 2], p3 = rec[nx + 3];
+            d_rcu_step (rc, c0[0], c0[1], c0[2], lane);
+            d_rcu_step (rc, c1[0], c1[1], c1[2], lane);
+            d_rcu_step (rc, c2[0], c2[1], c2[2], lane);
+            d_rcu_step (rc, c3[0], c3[1], c3[2], lane);
+            c0 = p0; c1 = p1; c2 = p2; c3 = p3;
         }
     }
+    for (uint32_t i = n4; i < n && !rc.overflow; i++) { const gz_u32x4 c = rec[i]; d_rcu_step (rc, c[0], c[1], c[2], lane); }
+
     for (int k = 0; k < 5; k++) d_rcu_shift (rc, lane);                  // RC_FinishEncode
     if (rc.len & 63) { if ((uint32_t)lane < (rc.len & 63)) rc.out[(rc.len & ~63u) + lane] = (uint8_t)rc.stage; }
     if (!lane) {

@@ -207,6 +207,8 @@ static inline int emu_shfl (int v, int src)
 static inline int __ffsll (unsigned long long v) { return __builtin_ffsll ((long long)v); }
 struct uint2 { unsigned x, y; };
 static inline uint2 make_uint2 (unsigned x, unsigned y) { uint2 r; r.x = x; r.y = y; return r; }
+struct uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4 (unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 
 static inline int __popcll (unsigned long long v) { return __builtin_popcountll (v); }
 static inline unsigned __umulhi (unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
