@@ -231,7 +231,9 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
     L.stream = stream; L.plane = (uint8_t)plane; L.method = (uint8_t)method; L.engine = (uint8_t)engine;
     const bool o1 = method & 1, pack = method & GZ_X_PACK;
     if (pack) { if (!(L.packed = (uint8_t *)arena_alloc (h, (size_t)n_bound + 16))) return false; }
-    L.pay_cap = n_bound + 64;
+    // rANS stops (-> CAT) once the payload exceeds the input; the arithmetic coder's scalar chain carries no capacity
+    // checks, so its area holds the worst case of an adaptive model: 2 bytes per symbol (freq 1 of a total < 2^16)
+    L.pay_cap = (engine == GZ_ENG_ARITH && !(method & GZ_X_RLE)) ? 2 * n_bound + 64 : n_bound + 64;
     if (!(L.pay = (uint8_t *)arena_alloc (h, L.pay_cap))) return false;
     if (engine == GZ_ENG_RANS) {
         if (!(L.F    = (uint32_t *)arena_alloc (h, (o1 ? 256 * 256 + 256 : 256) * sizeof (uint32_t)))) return false;

@@ -70,7 +70,7 @@ __device__ static void d_arith_model_wave (const uint8_t *in, uint32_t n, uint32
             #pragma unroll
             for (int j = 0; j < J; j++) if (j == jj) { f = d_readlane (freq[j], pl); cu = d_readlane (cum[j], pl); }
             // ---- hand (cum, freq, tot) to the lane that owns this position
-            out_lo = d_writelane (cu | (f << 16), b, out_lo);
+            out_lo = d_writelane (cu | (f << 16), b, out_lo);      // cum and freq both fit 16 bits
             out_hi = d_writelane (tot, b, out_hi);
             // ---- bump (c_simple_model.h:133-134): the entry gains 16, so does the cumulative of everything after it
             const uint32_t p = jj * 64 + pl;
@@ -115,7 +115,7 @@ __device__ static void d_arith_model_wave (const uint8_t *in, uint32_t n, uint32
                 }
             }
         }
-        if (mine) { GzDivMagic mg = magic_tab[out_hi]; recs[pos] = make_uint4 (out_lo, mg.magic, mg.shift, out_hi); }
+        if (mine) { GzDivMagic mg = magic_tab[out_hi]; recs[pos] = make_uint4 (out_lo & 0xffff, out_lo >> 16, mg.magic, mg.shift); }
     }
 }
 
@@ -134,12 +134,14 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const GzDi
 }
 
 // ---- range coder chain ------------------------------------------------------------------------------------------
-// All values below are wave-uniform (they come from readlane), so the compiler keeps the chain on the scalar unit.
-struct GzRcU { uint32_t low, range, carry, cache, ff, len, cap, overflow; uint32_t stage; uint8_t *out; };
+// All values below are wave-uniform, so the compiler keeps the chain on the scalar unit. A single wave issues one
+// instruction every ~4.5 cycles, so the cost of a symbol is its instruction count: the loop is written for few
+// instructions (carry as the high half of a 64-bit low, no capacity checks - the payload area holds the 2 bytes per
+// symbol an adaptive model can cost at most - and no special case for a total of 1 in the fast path).
+struct GzRcU { uint64_t lowc; uint32_t range, cache, ff, len, stage; uint8_t *out; };   // lowc = carry:low
 
 __device__ static inline void d_rcu_emit (GzRcU &rc, uint32_t byte, int lane)
 {
-    if (rc.len >= rc.cap) { rc.overflow = 1; return; }
     rc.stage = d_writelane (byte, (int)(rc.len & 63), rc.stage);
     rc.len++;
     if (!(rc.len & 63)) rc.out[rc.len - 64 + lane] = (uint8_t)rc.stage;        // 64 staged bytes leave with one store
@@ -147,34 +149,32 @@ __device__ static inline void d_rcu_emit (GzRcU &rc, uint32_t byte, int lane)
 
 __device__ static inline void d_rcu_shift (GzRcU &rc, int lane)     // c_range_coder.h:70-88
 {
-    if (rc.low < 0xff000000u || rc.carry) {
-        d_rcu_emit (rc, (rc.cache + rc.carry) & 0xff, lane);
-        for (; rc.ff; rc.ff--) d_rcu_emit (rc, (rc.carry - 1) & 0xff, lane);
-        rc.cache = rc.low >> 24;
-        rc.carry = 0;
+    const uint32_t low = (uint32_t)rc.lowc, carry = (uint32_t)(rc.lowc >> 32);
+    if (low < 0xff000000u || carry) {
+        d_rcu_emit (rc, (rc.cache + carry) & 0xff, lane);
+        for (; rc.ff; rc.ff--) d_rcu_emit (rc, (carry - 1) & 0xff, lane);
+        rc.cache = low >> 24;
     }
     else rc.ff++;
-    rc.low <<= 8;
+    rc.lowc = (uint64_t)(low << 8);                                  // carry consumed (or impossible: low >= 0xff000000 with carry 0)
 }
 
-// One symbol of the chain: r = range / tot by multiplication, low += cum * r, range = r * freq, renormalise.
-__device__ static inline void d_rcu_step (GzRcU &rc, uint32_t lo, uint32_t mg, uint32_t sh, int lane)
+// One symbol: r = range / tot by multiplication (tot >= 2), low += cum * r, range = r * freq, renormalise.
+__device__ static inline void d_rcu_step (GzRcU &rc, uint32_t cum, uint32_t freq, uint32_t mg, uint32_t sh, int lane)
 {
-    const uint32_t cum = lo & 0xffff, freq = lo >> 16;
     const uint32_t t = __umulhi (mg, rc.range);
-    const uint32_t r = sh == 0xff ? rc.range : (((rc.range - t) >> 1) + t) >> sh;        // c_range_coder.h:100
-    const uint32_t before = rc.low;
-    rc.low  += cum * r;
+    const uint32_t r = (((rc.range - t) >> 1) + t) >> sh;            // c_range_coder.h:100
+    rc.lowc += (uint64_t)(cum * r);
     rc.range = r * freq;
-    rc.carry += rc.low < before;
     while (rc.range < (1u << 24)) { rc.range <<= 8; d_rcu_shift (rc, lane); }
 }
 
 // The records were written by the previous kernel and are read-only here: reading them through the constant address
 // space with a wave-uniform index turns the loads into scalar (SMEM) loads, so the whole chain - loads included - runs
-// on the scalar unit; the next 4 records are in flight while the current 4 are being coded.
+// on the scalar unit; the next 4 records are in flight while the current 4 are being coded (volatile keeps the
+// prefetch a prefetch: an invariant load would simply be rematerialised at its use).
 typedef uint32_t gz_u32x4 __attribute__((vector_size (16)));
-typedef const volatile __attribute__((address_space(4))) gz_u32x4 *GzConstRecP;   // volatile: keeps the prefetch a prefetch (no rematerialisation)
+typedef const volatile __attribute__((address_space(4))) gz_u32x4 *GzConstRecP;
 
 // one wave per leaf
 __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
@@ -186,29 +186,41 @@ __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
     GzConstRecP rec = (GzConstRecP)(uintptr_t)L.triples;
 
     GzRcU rc;
-    rc.low = 0; rc.range = 0xffffffffu; rc.carry = rc.cache = rc.ff = 0;
-    rc.len = 0; rc.cap = L.pay_cap - 1; rc.overflow = 0; rc.stage = 0; rc.out = L.pay + 1;
+    rc.lowc = 0; rc.range = 0xffffffffu; rc.cache = rc.ff = 0; rc.len = 0; rc.stage = 0; rc.out = L.pay + 1;
     if (!lane) L.pay[0] = (uint8_t)(n ? L.max_sym : 1);                  // max_sym + 1 (256 wraps to 0), arith_dynamic.c:103-108
 
-    const uint32_t n4 = n & ~3u;
-    if (n4) {
-        gz_u32x4 c0 = rec[0], c1 = rec[1], c2 = rec[2], c3 = rec[3];
-        for (uint32_t i = 0; i < n4 && !rc.overflow; i += 4) {
-            const uint32_t nx = i + 4 < n4 ? i + 4 : i;                  // the last block re-reads itself (harmless)
-            const gz_u32x4 p0 = rec[nx], p1 = rec[nx + 1], p2 = rec[nx + 2], p3 = rec[nx + 3];
-            d_rcu_step (rc, c0[0], c0[1], c0[2], lane);
-            d_rcu_step (rc, c1[0], c1[1], c1[2], lane);
-            d_rcu_step (rc, c2[0], c2[1], c2[2], lane);
-            d_rcu_step (rc, c3[0], c3[1], c3[2], lane);
-            c0 = p0; c1 = p1; c2 = p2; c3 = p3;
+    if (n && L.max_sym == 1) {
+        // a stream of zero bytes: the model total starts at 1, which the multiply-shift division cannot express
+        for (uint32_t i = 0; i < n; i++) {
+            const gz_u32x4 c = rec[i];
+            const uint32_t t = __umulhi (c[2], rc.range);
+            const uint32_t r = c[3] == 0xff ? rc.range : (((rc.range - t) >> 1) + t) >> c[3];
+            rc.lowc += (uint64_t)(c[0] * r);
+            rc.range = r * c[1];
+            while (rc.range < (1u << 24)) { rc.range <<= 8; d_rcu_shift (rc, lane); }
         }
     }
-    for (uint32_t i = n4; i < n && !rc.overflow; i++) { const gz_u32x4 c = rec[i]; d_rcu_step (rc, c[0], c[1], c[2], lane); }
+    else {
+        const uint32_t n4 = n & ~3u;
+        if (n4) {
+            gz_u32x4 c0 = rec[0], c1 = rec[1], c2 = rec[2], c3 = rec[3];
+            for (uint32_t i = 0; i < n4; i += 4) {
+                const uint32_t nx = i + 4 < n4 ? i + 4 : i;              // the last block re-reads itself (harmless)
+                const gz_u32x4 p0 = rec[nx], p1 = rec[nx + 1], p2 = rec[nx + 2], p3 = rec[nx + 3];
+                d_rcu_step (rc, c0[0], c0[1], c0[2], c0[3], lane);
+                d_rcu_step (rc, c1[0], c1[1], c1[2], c1[3], lane);
+                d_rcu_step (rc, c2[0], c2[1], c2[2], c2[3], lane);
+                d_rcu_step (rc, c3[0], c3[1], c3[2], c3[3], lane);
+                c0 = p0; c1 = p1; c2 = p2; c3 = p3;
+            }
+        }
+        for (uint32_t i = n4; i < n; i++) { const gz_u32x4 c = rec[i]; d_rcu_step (rc, c[0], c[1], c[2], c[3], lane); }
+    }
 
     for (int k = 0; k < 5; k++) d_rcu_shift (rc, lane);                  // RC_FinishEncode
     if (rc.len & 63) { if ((uint32_t)lane < (rc.len & 63)) rc.out[(rc.len & ~63u) + lane] = (uint8_t)rc.stage; }
     if (!lane) {
-        if (rc.overflow) { L.overflow = 1; L.pay_len = 0; }
+        if (rc.len + 1 > L.pay_cap) { L.overflow = 1; L.pay_len = 0; }     // cannot happen: pay_cap >= 2n + 64
         else L.pay_len = rc.len + 1;
         L.tab_len = 0;
     }
