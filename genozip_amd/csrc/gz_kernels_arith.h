@@ -45,14 +45,32 @@ __device__ static void d_arith_model_wave (const uint8_t *in, uint32_t n, uint32
     }
     uint32_t tot = ms;
 
-    for (uint32_t base = 0; base < n; base += 64) {
-        const uint32_t pos = base + lane;
-        uint32_t s_v = 0;
-        bool mine = false;
-        if (pos < n) {
-            s_v = in[pos];
-            mine = !o1 || (pos ? in[pos - 1] : 0u) == ctx;
+    // The wave scans the whole stream for "its" positions, 4 x 64 positions per iteration; the bytes of the next
+    // iteration are requested before the current ones are used, so the scan never waits for memory.
+    uint32_t nx_s[4], nx_p[4];
+    #pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t pos = k * 64 + lane;
+        nx_s[k] = pos < n ? in[pos] : 0;
+        nx_p[k] = (o1 && pos && pos < n) ? in[pos - 1] : 0;
+    }
+    for (uint32_t gbase = 0; gbase < n; gbase += 256) {
+        uint32_t cs[4], cp[4];
+        #pragma unroll
+        for (int k = 0; k < 4; k++) { cs[k] = nx_s[k]; cp[k] = nx_p[k]; }
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t pos = gbase + 256 + k * 64 + lane;
+            nx_s[k] = pos < n ? in[pos] : 0;
+            nx_p[k] = (o1 && pos < n) ? in[pos - 1] : 0;
         }
+      #pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t base = gbase + k * 64;
+        if (base >= n) break;
+        const uint32_t pos = base + lane;
+        const uint32_t s_v = cs[k];
+        const bool mine = pos < n && (!o1 || cp[k] == ctx);
         uint64_t todo = __ballot (mine);
         uint32_t out_lo = 0, out_hi = 0;
         while (todo) {
@@ -116,6 +134,7 @@ __device__ static void d_arith_model_wave (const uint8_t *in, uint32_t n, uint32
             }
         }
         if (mine) { GzDivMagic mg = magic_tab[out_hi]; recs[pos] = make_uint4 (out_lo & 0xffff, out_lo >> 16, mg.magic, mg.shift); }
+      }
     }
 }
 
