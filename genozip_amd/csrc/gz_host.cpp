@@ -247,7 +247,10 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
             size_t words = (size_t)(o1 ? 256 : 1) * 257 + GZ_ARITH_RUN_MODELS * GZ_ARITH_RUN_STRIDE;
             if (!(L.models = (uint32_t *)arena_alloc (h, words * 4))) return false;
         }
-        else if (!(L.triples = (uint8_t *)arena_alloc (h, ((size_t)n_bound + 64) * 16))) return false;
+        else {
+            if (!(L.triples = (uint8_t *)arena_alloc (h, ((size_t)n_bound + 64) * 16))) return false;
+            if (!(L.events  = (uint8_t *)arena_alloc (h, ((size_t)L.pay_cap + 128) * 2))) return false;
+        }
     }
     P.leaves.push_back (L);
     return true;
@@ -340,6 +343,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
         if (P.any_arith) {
             KLAUNCH (h, k_arith_model, dim3 (nl, 256), dim3 (64), 0, d_leaves, (const GzDivMagic *)h->d_magic);
             KLAUNCH (h, k_arith_chain, dim3 (nl), dim3 (64), 0, d_leaves);
+            KLAUNCH (h, k_arith_carry, dim3 (nl), dim3 (256), 4096, d_leaves);
             for (int c = 0; c < 3; c++)
                 KLAUNCH (h, k_arith_encode, dim3 (nl), dim3 (64), ARITH_CLASS_WORDS[c + 1] * 4,
                                     d_leaves, ARITH_CLASS_WORDS[c], ARITH_CLASS_WORDS[c + 1], 0);

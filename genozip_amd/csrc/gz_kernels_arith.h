@@ -154,28 +154,25 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const GzDi
 
 // ---- range coder chain ------------------------------------------------------------------------------------------
 // All values below are wave-uniform, so the compiler keeps the chain on the scalar unit. A single wave issues one
-// instruction every ~4.5 cycles, so the cost of a symbol is its instruction count: the loop is written for few
-// instructions (carry as the high half of a 64-bit low, no capacity checks - the payload area holds the 2 bytes per
-// symbol an adaptive model can cost at most - and no special case for a total of 1 in the fast path).
-struct GzRcU { uint64_t lowc; uint32_t range, cache, ff, len, stage; uint8_t *out; };   // lowc = carry:low
+// instruction every ~5 cycles, so the cost of a symbol is its instruction count, and the loop is written for few
+// instructions:
+//  * r = range / tot is a multiply-high and three shifts/adds with the per-record magic number;
+//  * carry is the high half of a 64-bit low;
+//  * the byte-output logic of the reference (RC_ShiftLow, c_range_coder.h:70-88: hold back a byte while later carries
+//    can still reach it, count pending 0xFF bytes) is NOT run here. That logic is a lazy big-number addition: the
+//    stream is [0, T1, T2, ...] (Tj = top byte of low at the j-th shift) plus, for every shift that saw the carry
+//    flag set, +1 at the byte before it. The chain just records (Tj, carry_j) per shift - no conditions - and
+//    k_arith_carry resolves all carries of all leaves in parallel afterwards.
+struct GzRcU { uint64_t lowc; uint32_t range, nev, stage; uint16_t *ev; };   // lowc = carry:low ; ev[j] = Tj | carry_j << 8
 
-__device__ static inline void d_rcu_emit (GzRcU &rc, uint32_t byte, int lane)
+__device__ static inline void d_rcu_shift (GzRcU &rc, int lane)
 {
-    rc.stage = d_writelane (byte, (int)(rc.len & 63), rc.stage);
-    rc.len++;
-    if (!(rc.len & 63)) rc.out[rc.len - 64 + lane] = (uint8_t)rc.stage;        // 64 staged bytes leave with one store
-}
-
-__device__ static inline void d_rcu_shift (GzRcU &rc, int lane)     // c_range_coder.h:70-88
-{
-    const uint32_t low = (uint32_t)rc.lowc, carry = (uint32_t)(rc.lowc >> 32);
-    if (low < 0xff000000u || carry) {
-        d_rcu_emit (rc, (rc.cache + carry) & 0xff, lane);
-        for (; rc.ff; rc.ff--) d_rcu_emit (rc, (carry - 1) & 0xff, lane);
-        rc.cache = low >> 24;
-    }
-    else rc.ff++;
-    rc.lowc = (uint64_t)(low << 8);                                  // carry consumed (or impossible: low >= 0xff000000 with carry 0)
+    const uint32_t low = (uint32_t)rc.lowc;
+    const uint32_t e = (low >> 24) | ((uint32_t)(rc.lowc >> 32) << 8);
+    rc.stage = d_writelane (e, (int)(rc.nev & 63), rc.stage);
+    rc.nev++;
+    if (!(rc.nev & 63)) rc.ev[rc.nev - 64 + lane] = (uint16_t)rc.stage;       // 64 staged events leave with one store
+    rc.lowc = (uint64_t)(low << 8);
 }
 
 // One symbol: r = range / tot by multiplication (tot >= 2), low += cum * r, range = r * freq, renormalise.
@@ -205,8 +202,7 @@ __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
     GzConstRecP rec = (GzConstRecP)(uintptr_t)L.triples;
 
     GzRcU rc;
-    rc.lowc = 0; rc.range = 0xffffffffu; rc.cache = rc.ff = 0; rc.len = 0; rc.stage = 0; rc.out = L.pay + 1;
-    if (!lane) L.pay[0] = (uint8_t)(n ? L.max_sym : 1);                  // max_sym + 1 (256 wraps to 0), arith_dynamic.c:103-108
+    rc.lowc = 0; rc.range = 0xffffffffu; rc.nev = 0; rc.stage = 0; rc.ev = (uint16_t *)L.events;
 
     if (n && L.max_sym == 1) {
         // a stream of zero bytes: the model total starts at 1, which the multiply-shift division cannot express
@@ -236,11 +232,55 @@ __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
         for (uint32_t i = n4; i < n; i++) { const gz_u32x4 c = rec[i]; d_rcu_step (rc, c[0], c[1], c[2], c[3], lane); }
     }
 
-    for (int k = 0; k < 5; k++) d_rcu_shift (rc, lane);                  // RC_FinishEncode
-    if (rc.len & 63) { if ((uint32_t)lane < (rc.len & 63)) rc.out[(rc.len & ~63u) + lane] = (uint8_t)rc.stage; }
-    if (!lane) {
-        if (rc.len + 1 > L.pay_cap) { L.overflow = 1; L.pay_len = 0; }     // cannot happen: pay_cap >= 2n + 64
-        else L.pay_len = rc.len + 1;
+    for (int k = 0; k < 5; k++) d_rcu_shift (rc, lane);                  // RC_FinishEncode: 5 more shifts
+    if (rc.nev & 63) { if ((uint32_t)lane < (rc.nev & 63)) rc.ev[(rc.nev & ~63u) + lane] = (uint16_t)rc.stage; }
+    if (!lane) L.n_events = rc.nev;
+}
+
+// Carry resolution, one 256-thread workgroup per leaf. With m shifts the output is m bytes: byte 0 is the coder's
+// initial cache (0), byte i is T_i; the carry flag seen at shift j adds 1 at byte j-1 and ripples left through 0xFF
+// bytes. Each thread owns a slice: it first finds whether a carry entering its slice from the right would leave it
+// on the left (only if every byte is 0xFF after its own carries) and what it emits on its own; thread 0 chains the
+// 256 slices; then every thread writes its bytes.
+__global__ void __launch_bounds__(256) k_arith_carry (GzdLeaf *leaves)
+{
+    GzdLeaf &L = leaves[blockIdx.x];
+    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
+    const int tid = threadIdx.x;
+    const uint32_t m = L.n_events;
+    const uint16_t *ev = (const uint16_t *)L.events;
+    uint8_t *out = L.pay + 1;
+    uint32_t *sh = (uint32_t *)gz_lds;          // [0..255] carry-out with carry-in 0, [256..511] with carry-in 1, [512..767] carry-in
+    if (!tid) L.pay[0] = (uint8_t)(L.coded_n ? L.max_sym : 1);            // max_sym + 1 (256 wraps to 0), arith_dynamic.c:103-108
+
+    const uint32_t per = (m + 255) / 256;
+    const uint32_t lo = tid * per, hi = lo + per < m ? lo + per : m;
+    // value of byte i before ripple: (i ? T_i : 0) + carry flag of shift i+1
+    uint32_t c0 = 0, c1 = 1;
+    for (uint32_t i = hi; i-- > lo; ) {
+        const uint32_t raw = i ? (ev[i - 1] & 0xffu) : 0u;
+        const uint32_t cin = ((uint32_t)ev[i] >> 8) & 1u;                 // carry flag recorded at shift i+1 == event index i
+        c0 = (raw + cin + c0) >> 8;
+        c1 = (raw + cin + c1) >> 8;
+    }
+    sh[tid] = c0; sh[256 + tid] = c1;
+    __syncthreads ();
+    if (!tid) {
+        uint32_t carry = 0;
+        for (int t = 255; t >= 0; t--) { sh[512 + t] = carry; carry = carry ? sh[256 + t] : sh[t]; }
+    }
+    __syncthreads ();
+    uint32_t carry = sh[512 + tid];
+    for (uint32_t i = hi; i-- > lo; ) {
+        const uint32_t raw = i ? (ev[i - 1] & 0xffu) : 0u;
+        const uint32_t cin = ((uint32_t)ev[i] >> 8) & 1u;
+        const uint32_t v = raw + cin + carry;
+        out[i] = (uint8_t)v;
+        carry = v >> 8;
+    }
+    if (!tid) {
+        if (m + 1 > L.pay_cap) { L.overflow = 1; L.pay_len = 0; }        // cannot happen: pay_cap >= 2n + 64
+        else L.pay_len = m + 1;
         L.tab_len = 0;
     }
 }
