@@ -185,12 +185,17 @@ __device__ static inline void d_rcu_step (GzRcU &rc, uint32_t cum, uint32_t freq
     while (rc.range < (1u << 24)) { rc.range <<= 8; d_rcu_shift (rc, lane); }
 }
 
-// The records were written by the previous kernel and are read-only here: reading them through the constant address
-// space with a wave-uniform index turns the loads into scalar (SMEM) loads, so the whole chain - loads included - runs
-// on the scalar unit; the next 4 records are in flight while the current 4 are being coded (volatile keeps the
-// prefetch a prefetch: an invariant load would simply be rematerialised at its use).
-typedef uint32_t gz_u32x4 __attribute__((vector_size (16)));
-typedef const volatile __attribute__((address_space(4))) gz_u32x4 *GzConstRecP;
+// Records reach the chain through vector loads: the 64 lanes fetch 64 consecutive records with one coalesced 1 KB
+// load, two such chunks are kept in flight ahead of the one being coded (vector loads complete in order, so the
+// compiler can wait for exactly the oldest), and the chain picks record k out of lane k with v_readlane.
+// (Scalar loads would keep even that off the vector unit, but they return out of order: the only safe wait is "all
+// of them", which exposes a full memory latency every few symbols - measured 100 ns per symbol.)
+__device__ static inline void d_rcu_chunk (GzRcU &rc, const uint4 &v, uint32_t cnt, int lane)
+{
+    #pragma unroll 8
+    for (uint32_t k = 0; k < cnt; k++)
+        d_rcu_step (rc, d_readlane (v.x, (int)k), d_readlane (v.y, (int)k), d_readlane (v.z, (int)k), d_readlane (v.w, (int)k), lane);
+}
 
 // one wave per leaf
 __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
@@ -199,7 +204,7 @@ __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
     if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
     const int lane = threadIdx.x;
     const uint32_t n = L.coded_n;
-    GzConstRecP rec = (GzConstRecP)(uintptr_t)L.triples;
+    const uint4 *rec = (const uint4 *)L.triples;          // the area is padded to a multiple of 64 records + 128
 
     GzRcU rc;
     rc.lowc = 0; rc.range = 0xffffffffu; rc.nev = 0; rc.stage = 0; rc.ev = (uint16_t *)L.events;
@@ -207,29 +212,21 @@ __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
     if (n && L.max_sym == 1) {
         // a stream of zero bytes: the model total starts at 1, which the multiply-shift division cannot express
         for (uint32_t i = 0; i < n; i++) {
-            const gz_u32x4 c = rec[i];
-            const uint32_t t = __umulhi (c[2], rc.range);
-            const uint32_t r = c[3] == 0xff ? rc.range : (((rc.range - t) >> 1) + t) >> c[3];
-            rc.lowc += (uint64_t)(c[0] * r);
-            rc.range = r * c[1];
+            const uint4 c = rec[i];
+            const uint32_t t = __umulhi (c.z, rc.range);
+            const uint32_t r = c.w == 0xff ? rc.range : (((rc.range - t) >> 1) + t) >> c.w;
+            rc.lowc += (uint64_t)(c.x * r);
+            rc.range = r * c.y;
             while (rc.range < (1u << 24)) { rc.range <<= 8; d_rcu_shift (rc, lane); }
         }
     }
-    else {
-        const uint32_t n4 = n & ~3u;
-        if (n4) {
-            gz_u32x4 c0 = rec[0], c1 = rec[1], c2 = rec[2], c3 = rec[3];
-            for (uint32_t i = 0; i < n4; i += 4) {
-                const uint32_t nx = i + 4 < n4 ? i + 4 : i;              // the last block re-reads itself (harmless)
-                const gz_u32x4 p0 = rec[nx], p1 = rec[nx + 1], p2 = rec[nx + 2], p3 = rec[nx + 3];
-                d_rcu_step (rc, c0[0], c0[1], c0[2], c0[3], lane);
-                d_rcu_step (rc, c1[0], c1[1], c1[2], c1[3], lane);
-                d_rcu_step (rc, c2[0], c2[1], c2[2], c2[3], lane);
-                d_rcu_step (rc, c3[0], c3[1], c3[2], c3[3], lane);
-                c0 = p0; c1 = p1; c2 = p2; c3 = p3;
-            }
+    else if (n) {
+        uint4 a = rec[lane], b = rec[64 + lane];
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint4 c = rec[base + 128 + lane];       // two chunks ahead (reads past n land in the padding)
+            d_rcu_chunk (rc, a, n - base < 64 ? n - base : 64, lane);
+            a = b; b = c;
         }
-        for (uint32_t i = n4; i < n; i++) { const gz_u32x4 c = rec[i]; d_rcu_step (rc, c[0], c[1], c[2], c[3], lane); }
     }
 
     for (int k = 0; k < 5; k++) d_rcu_shift (rc, lane);                  // RC_FinishEncode: 5 more shifts
