@@ -82,6 +82,7 @@ struct GzdLeaf {
     uint8_t   *triples;       // arith: 16 bytes per coded byte: cum | freq << 16, division magic, shift, tot  (k_arith_model -> k_arith_chain)
     uint8_t   *events;        // arith: 2 bytes per range-coder shift: top byte of low | carry flag << 8
     uint32_t  n_events;
+    uint32_t  touch_sink;     // keeps the L2 prefetch loads of k_arith_chain alive
     uint32_t  pay_cap;
 };
 

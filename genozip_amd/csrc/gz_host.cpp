@@ -248,7 +248,7 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
             if (!(L.models = (uint32_t *)arena_alloc (h, words * 4))) return false;
         }
         else {
-            if (!(L.triples = (uint8_t *)arena_alloc (h, ((size_t)n_bound + 256) * 16))) return false;
+            if (!(L.triples = (uint8_t *)arena_alloc (h, ((size_t)n_bound + 64) * 16 + 2 * GZ_CHAIN_TOUCH_AHEAD + 8192))) return false;
             if (!(L.events  = (uint8_t *)arena_alloc (h, ((size_t)L.pay_cap + 128) * 2))) return false;
         }
     }

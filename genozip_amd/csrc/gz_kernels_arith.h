@@ -153,49 +153,45 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const GzDi
 }
 
 // ---- range coder chain ------------------------------------------------------------------------------------------
-// All values below are wave-uniform, so the compiler keeps the chain on the scalar unit. A single wave issues one
-// instruction every ~5 cycles, so the cost of a symbol is its instruction count, and the loop is written for few
-// instructions:
+// Measured on MI355X (tools/ubench_chain.hip): ONE wave issues an instruction every ~3.2 ns (scalar) / 2.5 ns
+// (vector) whether or not it depends on the previous one, a vector->scalar hand-over (v_readlane feeding s_*) costs
+// ~12 ns, and nothing but the instruction count of the wave matters. So the chain is kept entirely on the scalar
+// unit and written for few instructions per symbol:
+//  * records arrive through scalar (SMEM) loads, 8 at a time, the next 8 in flight while 8 are coded. SMEM returns
+//    out of order, so the only wait is "all": the lines are therefore pulled into L2 well ahead by a cheap vector
+//    load whose result is never used, which turns the scalar loads into L2 hits;
 //  * r = range / tot is a multiply-high and three shifts/adds with the per-record magic number;
-//  * carry is the high half of a 64-bit low;
+//  * carry is the high half of a 64-bit low, so (carry:low) >> 24 is exactly "top byte | carry << 8";
 //  * the byte-output logic of the reference (RC_ShiftLow, c_range_coder.h:70-88: hold back a byte while later carries
 //    can still reach it, count pending 0xFF bytes) is NOT run here. That logic is a lazy big-number addition: the
 //    stream is [0, T1, T2, ...] (Tj = top byte of low at the j-th shift) plus, for every shift that saw the carry
-//    flag set, +1 at the byte before it. The chain just records (Tj, carry_j) per shift - no conditions - and
-//    k_arith_carry resolves all carries of all leaves in parallel afterwards.
-struct GzRcU { uint64_t lowc; uint32_t range, nev, stage; uint16_t *ev; };   // lowc = carry:low ; ev[j] = Tj | carry_j << 8
+//    flag set, +1 at the byte before it. The chain only records the 16-bit event (Tj | carry_j << 8) per shift, four
+//    events per 64-bit store, and k_arith_carry resolves all carries of all leaves in parallel afterwards.
+struct GzRcU { uint64_t lowc, acc; uint32_t range, nev; uint64_t *ev; int lane; };
 
-__device__ static inline void d_rcu_shift (GzRcU &rc, int lane)
+__device__ static inline void d_rcu_shift (GzRcU &rc)
 {
-    const uint32_t low = (uint32_t)rc.lowc;
-    const uint32_t e = (low >> 24) | ((uint32_t)(rc.lowc >> 32) << 8);
-    rc.stage = d_writelane (e, (int)(rc.nev & 63), rc.stage);
+    rc.acc = (rc.acc >> 16) | ((rc.lowc >> 24) << 48);               // event = (carry:low) >> 24, 9 significant bits
     rc.nev++;
-    if (!(rc.nev & 63)) rc.ev[rc.nev - 64 + lane] = (uint16_t)rc.stage;       // 64 staged events leave with one store
-    rc.lowc = (uint64_t)(low << 8);
+    if (!(rc.nev & 3)) { if (!rc.lane) rc.ev[(rc.nev >> 2) - 1] = rc.acc; }
+    rc.lowc = (uint64_t)((uint32_t)rc.lowc << 8);
 }
 
 // One symbol: r = range / tot by multiplication (tot >= 2), low += cum * r, range = r * freq, renormalise.
-__device__ static inline void d_rcu_step (GzRcU &rc, uint32_t cum, uint32_t freq, uint32_t mg, uint32_t sh, int lane)
+__device__ static inline void d_rcu_step (GzRcU &rc, uint32_t cum, uint32_t freq, uint32_t mg, uint32_t sh)
 {
     const uint32_t t = __umulhi (mg, rc.range);
     const uint32_t r = (((rc.range - t) >> 1) + t) >> sh;            // c_range_coder.h:100
     rc.lowc += (uint64_t)(cum * r);
     rc.range = r * freq;
-    while (rc.range < (1u << 24)) { rc.range <<= 8; d_rcu_shift (rc, lane); }
+    while (rc.range < (1u << 24)) { rc.range <<= 8; d_rcu_shift (rc); }
 }
 
-// Records reach the chain through vector loads: the 64 lanes fetch 64 consecutive records with one coalesced 1 KB
-// load, two such chunks are kept in flight ahead of the one being coded (vector loads complete in order, so the
-// compiler can wait for exactly the oldest), and the chain picks record k out of lane k with v_readlane.
-// (Scalar loads would keep even that off the vector unit, but they return out of order: the only safe wait is "all
-// of them", which exposes a full memory latency every few symbols - measured 100 ns per symbol.)
-__device__ static inline void d_rcu_chunk (GzRcU &rc, const uint4 &v, uint32_t cnt, int lane)
-{
-    #pragma unroll 8
-    for (uint32_t k = 0; k < cnt; k++)
-        d_rcu_step (rc, d_readlane (v.x, (int)k), d_readlane (v.y, (int)k), d_readlane (v.z, (int)k), d_readlane (v.w, (int)k), lane);
-}
+typedef uint32_t gz_u32x4 __attribute__((vector_size (16)));
+typedef const volatile __attribute__((address_space(4))) gz_u32x4 *GzConstRecP;   // volatile: keeps the prefetch a prefetch
+
+#define GZ_CHAIN_BLOCK 8
+#define GZ_CHAIN_TOUCH_AHEAD (16 * 1024)   // bytes: how far ahead of the scalar loads the vector unit pulls lines into L2
 
 // one wave per leaf
 __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
@@ -204,34 +200,51 @@ __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
     if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
     const int lane = threadIdx.x;
     const uint32_t n = L.coded_n;
-    const uint4 *rec = (const uint4 *)L.triples;          // the area is padded to a multiple of 64 records + 128
+    GzConstRecP rec = (GzConstRecP)(uintptr_t)L.triples;       // padded: reads up to 64 KB past n stay inside the area
+    const uint32_t *touch = (const uint32_t *)L.triples;
+    uint32_t sink = 0;
 
     GzRcU rc;
-    rc.lowc = 0; rc.range = 0xffffffffu; rc.nev = 0; rc.stage = 0; rc.ev = (uint16_t *)L.events;
+    rc.lowc = 0; rc.acc = 0; rc.range = 0xffffffffu; rc.nev = 0; rc.ev = (uint64_t *)L.events; rc.lane = lane;
 
     if (n && L.max_sym == 1) {
         // a stream of zero bytes: the model total starts at 1, which the multiply-shift division cannot express
         for (uint32_t i = 0; i < n; i++) {
-            const uint4 c = rec[i];
-            const uint32_t t = __umulhi (c.z, rc.range);
-            const uint32_t r = c.w == 0xff ? rc.range : (((rc.range - t) >> 1) + t) >> c.w;
-            rc.lowc += (uint64_t)(c.x * r);
-            rc.range = r * c.y;
-            while (rc.range < (1u << 24)) { rc.range <<= 8; d_rcu_shift (rc, lane); }
+            const gz_u32x4 c = rec[i];
+            const uint32_t t = __umulhi (c[2], rc.range);
+            const uint32_t r = c[3] == 0xff ? rc.range : (((rc.range - t) >> 1) + t) >> c[3];
+            rc.lowc += (uint64_t)(c[0] * r);
+            rc.range = r * c[1];
+            while (rc.range < (1u << 24)) { rc.range <<= 8; d_rcu_shift (rc); }
         }
     }
-    else if (n) {
-        uint4 a = rec[lane], b = rec[64 + lane];
-        for (uint32_t base = 0; base < n; base += 64) {
-            const uint4 c = rec[base + 128 + lane];       // two chunks ahead (reads past n land in the padding)
-            d_rcu_chunk (rc, a, n - base < 64 ? n - base : 64, lane);
-            a = b; b = c;
+    else {
+        const uint32_t nb = n & ~(uint32_t)(GZ_CHAIN_BLOCK - 1);
+        if (nb) {
+            for (uint32_t b = 0; b < GZ_CHAIN_TOUCH_AHEAD; b += 4096) sink += touch[(b >> 2) + lane * 16];   // 64 lanes x 64 B = 4 KB
+            gz_u32x4 c0 = rec[0], c1 = rec[1], c2 = rec[2], c3 = rec[3], c4 = rec[4], c5 = rec[5], c6 = rec[6], c7 = rec[7];
+            for (uint32_t i = 0; i < nb; i += GZ_CHAIN_BLOCK) {
+                const uint32_t nx = i + GZ_CHAIN_BLOCK < nb ? i + GZ_CHAIN_BLOCK : i;   // the last block re-reads itself
+                const gz_u32x4 p0 = rec[nx], p1 = rec[nx + 1], p2 = rec[nx + 2], p3 = rec[nx + 3],
+                               p4 = rec[nx + 4], p5 = rec[nx + 5], p6 = rec[nx + 6], p7 = rec[nx + 7];
+                if (!(i & 255)) sink += touch[((i * 16 + GZ_CHAIN_TOUCH_AHEAD) >> 2) + lane * 16];  // every 256 records = 4 KB
+                d_rcu_step (rc, c0[0], c0[1], c0[2], c0[3]);
+                d_rcu_step (rc, c1[0], c1[1], c1[2], c1[3]);
+                d_rcu_step (rc, c2[0], c2[1], c2[2], c2[3]);
+                d_rcu_step (rc, c3[0], c3[1], c3[2], c3[3]);
+                d_rcu_step (rc, c4[0], c4[1], c4[2], c4[3]);
+                d_rcu_step (rc, c5[0], c5[1], c5[2], c5[3]);
+                d_rcu_step (rc, c6[0], c6[1], c6[2], c6[3]);
+                d_rcu_step (rc, c7[0], c7[1], c7[2], c7[3]);
+                c0 = p0; c1 = p1; c2 = p2; c3 = p3; c4 = p4; c5 = p5; c6 = p6; c7 = p7;
+            }
         }
+        for (uint32_t i = nb; i < n; i++) { const gz_u32x4 c = rec[i]; d_rcu_step (rc, c[0], c[1], c[2], c[3]); }
     }
 
-    for (int k = 0; k < 5; k++) d_rcu_shift (rc, lane);                  // RC_FinishEncode: 5 more shifts
-    if (rc.nev & 63) { if ((uint32_t)lane < (rc.nev & 63)) rc.ev[(rc.nev & ~63u) + lane] = (uint16_t)rc.stage; }
-    if (!lane) L.n_events = rc.nev;
+    for (int k = 0; k < 5; k++) d_rcu_shift (rc);                        // RC_FinishEncode: 5 more shifts
+    if (rc.nev & 3) { if (!lane) rc.ev[rc.nev >> 2] = rc.acc >> (16 * (4 - (rc.nev & 3))); }
+    if (!lane) { L.n_events = rc.nev; L.touch_sink = sink; }
 }
 
 // Carry resolution, one 256-thread workgroup per leaf. With m shifts the output is m bytes: byte 0 is the coder's
