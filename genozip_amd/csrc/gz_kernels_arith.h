@@ -138,6 +138,104 @@ __device__ static void d_arith_model_wave (const uint8_t *in, uint32_t n, uint32
     }
 }
 
+// Compact variant for leaves with at most 64 distinct byte values (every quality / token stream): only the symbols
+// that occur are kept, one per lane, in list order. The max_sym - nsym entries of symbols that never occur all have
+// frequency 1 for ever (halving leaves 1 alone) and never start a swap, so they are interchangeable: each present
+// symbol just remembers how many of them sit directly in front of it (`gap`). Coding a symbol whose gap is > 0 swaps it
+// with such an entry (its frequency, >= 17, always beats 1): gap--, and the next present symbol's gap++. With gap 0
+// the left neighbour is the previous lane and the ordinary "swap if now larger" applies. cum includes the gaps.
+// The common case (no swap, no halving) is ~25 instructions with a single vector->scalar decision.
+__device__ static void d_arith_model_wave_compact (const uint8_t *in, uint32_t n, uint32_t ms, bool o1, uint32_t ctx,
+                                                   uint4 *recs, const GzDivMagic *magic_tab, const uint8_t *symlist, uint32_t nsym)
+{
+    const int lane = threadIdx.x & 63;
+    const bool live = (uint32_t)lane < nsym;
+    uint32_t sym = live ? symlist[lane] : 0xffffffffu;
+    uint32_t prev_sym = (live && lane) ? symlist[lane - 1] : 0xffffffffu;
+    uint32_t gap = live ? (lane ? sym - prev_sym - 1 : sym) : 0;
+    uint32_t freq = live ? 1 : 0;
+    uint32_t cum = live ? sym : ms;                       // lane entries + absent entries before it == its byte value
+    uint32_t tot = ms;
+    const uint32_t n_absent = ms - nsym;
+
+    uint32_t nx_s[4], nx_p[4];
+    #pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t pos = k * 64 + lane;
+        nx_s[k] = pos < n ? in[pos] : 0;
+        nx_p[k] = (o1 && pos && pos < n) ? in[pos - 1] : 0;
+    }
+    for (uint32_t gbase = 0; gbase < n; gbase += 256) {
+        uint32_t cs[4], cp[4];
+        #pragma unroll
+        for (int k = 0; k < 4; k++) { cs[k] = nx_s[k]; cp[k] = nx_p[k]; }
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t pos = gbase + 256 + k * 64 + lane;
+            nx_s[k] = pos < n ? in[pos] : 0;
+            nx_p[k] = (o1 && pos < n) ? in[pos - 1] : 0;
+        }
+      #pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t base = gbase + k * 64;
+        if (base >= n) break;
+        const uint32_t pos = base + lane;
+        const uint32_t s_v = cs[k];
+        const bool mine = pos < n && (!o1 || cp[k] == ctx);
+        uint64_t todo = __ballot (mine);
+        uint32_t out_cum = 0, out_freq = 0, out_tot = 0;
+        while (todo) {
+            const int b = __ffsll ((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t s = d_readlane (s_v, b);
+            const bool me = sym == s;                                    // exactly one lane
+            const int r = __ffsll ((unsigned long long)__ballot (me)) - 1;
+            const uint32_t f = d_readlane (freq, r), cu = d_readlane (cum, r);
+            const bool owner = lane == b;
+            out_cum = owner ? cu : out_cum; out_freq = owner ? f : out_freq; out_tot = owner ? tot : out_tot;
+            // bump
+            freq += me ? GZ_MODEL_STEP : 0u;
+            cum  += lane > r ? GZ_MODEL_STEP : 0u;
+            tot  += GZ_MODEL_STEP;
+            if (tot > GZ_MODEL_LIMIT) {                                  // rare: halve, rebuild tot and cum
+                freq -= freq >> 1;
+                uint32_t run = 0;
+                for (uint32_t l = 0; l < nsym; l++) {
+                    run += d_readlane (gap, (int)l);
+                    cum = d_writelane (run, (int)l, cum);
+                    run += d_readlane (freq, (int)l);
+                }
+                uint32_t fsum = 0;
+                for (uint32_t l = 0; l < nsym; l++) fsum += d_readlane (freq, (int)l);
+                tot = fsum + n_absent;                                   // every absent entry still weighs 1
+            }
+            // one bubble step to the left (c_simple_model.h:139-145)
+            const uint32_t f_now = d_readlane (freq, r);
+            const bool over_absent = me && gap > 0;
+            const bool over_left = (lane == r - 1) && freq < f_now;
+            const uint64_t chg = __ballot (over_absent || over_left);
+            if (chg) {
+                const uint32_t g = d_readlane (gap, r);
+                if (g > 0) {
+                    gap += me ? 0xffffffffu : (lane == r + 1 ? 1u : 0u);  // the absent entry hops over: mine - 1, next + 1
+                    cum += me ? 0xffffffffu : 0u;
+                }
+                else {
+                    const int q = r - 1;
+                    const uint32_t fl = d_readlane (freq, q), sl = d_readlane (sym, q), cl = d_readlane (cum, q), gl = d_readlane (gap, q);
+                    const bool at_q = lane == q;
+                    sym  = at_q ? s : (me ? sl : sym);
+                    freq = at_q ? f_now : (me ? fl : freq);
+                    gap  = at_q ? gl : (me ? 0u : gap);
+                    cum  = me ? cl + f_now : cum;                        // lane q keeps its cumulative
+                }
+            }
+        }
+        if (mine) { GzDivMagic mg = magic_tab[out_tot]; recs[pos] = make_uint4 (out_cum, out_freq, mg.magic, mg.shift); }
+      }
+    }
+}
+
 // grid (n_leaves, 256): block y serves context y of leaf x
 __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const GzDivMagic *magic_tab)
 {
@@ -147,7 +245,8 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const GzDi
     const bool o1 = L.o1;
     if (o1 ? (ctx >= ms || (ctx && L.symrank[ctx] == 0xffff)) : ctx != 0) return;   // a byte that never occurs is never a context
     uint4 *tr = (uint4 *)L.triples;
-    if (ms <= 64)       d_arith_model_wave<1> (L.coded, L.coded_n, ms, o1, ctx, tr, magic_tab);
+    if (L.nsym <= 64)   d_arith_model_wave_compact (L.coded, L.coded_n, ms, o1, ctx, tr, magic_tab, L.symlist, L.nsym);
+    else if (ms <= 64)  d_arith_model_wave<1> (L.coded, L.coded_n, ms, o1, ctx, tr, magic_tab);
     else if (ms <= 128) d_arith_model_wave<2> (L.coded, L.coded_n, ms, o1, ctx, tr, magic_tab);
     else                d_arith_model_wave<4> (L.coded, L.coded_n, ms, o1, ctx, tr, magic_tab);
 }
