@@ -203,6 +203,7 @@ def main():
     ap.add_argument("--vb-mb", type=int, default=4, help="VBlock size in MiB (reference: --vblock; its small-file rule floors at 4)")
     ap.add_argument("--qual", default="div", choices=("div", "bin"))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--pin-codecs", action="store_true", help="skip codec_assign_best and use the codecs it picks for this workload (profiling runs: every launch of a kernel is then a timed-region launch)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -217,7 +218,14 @@ def main():
 
     E = Engine(device=local_rank)
     wl = RankWorkload(E, a.pairs, a.vb_mb << 20, a.qual, seed_base=1 + 2 * rank, device=device)
-    codecs = wl.assign_codecs()
+    PINNED = {"div": {"QUAL": 16, "Q1NAME": 8, "Q2NAME": 16, "Q3NAME": 17, "Q4NAME": 17},
+              "bin": {"QUAL": 18, "Q1NAME": 8, "Q2NAME": 16, "Q3NAME": 17, "Q4NAME": 17}}
+    if a.pin_codecs:
+        wl.codecs = codecs = dict(PINNED[a.qual])
+        wl.step_prepare()
+        E.sync()
+    else:
+        codecs = wl.assign_codecs()
     wl.build_tables()
 
     def gather_to_rank0():
