@@ -168,16 +168,13 @@ def cpu_baseline(rank_wl, z_list, n_threads):
             if s.data_len_dev is not None:
                 n = int(s.data_len_dev.cpu().numpy()[0])
             tasks.append((s.codec, E.mem.download(s.data, n)))
-    def run(t):
-        codec, data = t
-        if len(data) < 50:
-            return data
-        return impl.codec_compress(codec, data)
-    run(tasks[0])
-    t0 = time.time()
-    with concurrent.futures.ThreadPoolExecutor(n_threads) as ex:
-        outs = list(ex.map(run, tasks, chunksize=1))
-    dt = time.time() - t0
+    if kind == "reference":
+        impl.codec_compress_many([t[0] for t in tasks[:8]], [t[1] for t in tasks[:8]], 8)            # warm up
+        outs, dt = impl.codec_compress_many([t[0] for t in tasks], [t[1] for t in tasks], n_threads)  # C pthread pool
+    else:
+        t0 = time.time()
+        outs = O.codec_compress_many([t[0] if len(t[1]) >= 50 else 1 for t in tasks], [t[1] for t in tasks], n_threads)
+        dt = time.time() - t0
     nbytes = sum(len(d) for _, d in tasks)
     # bit-exactness: every section payload produced on the GPU == the CPU reference's
     exact, k = True, 0
@@ -192,6 +189,16 @@ def cpu_baseline(rank_wl, z_list, n_threads):
     return {"value": round(nbytes / dt / 1e6, 1), "unit": "MB/s", "cores": n_threads, "kind": kind,
             "sample": "all %d sections of rank 0's %d VBlocks (%.0f MB), codec calls only, %d threads on %d logical CPUs" %
                       (len(tasks), len(rank_wl.vbs), nbytes / 1e6, n_threads, os.cpu_count())}, bool(exact)
+
+
+def pmc_traffic(kernel, a):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/round1_pmc.json, made by tools/summarize_prof.py); null for non-default workloads"""
+    p = os.path.join(ROOT, "profiles", "round1_pmc.json")
+    if not os.path.exists(p) or a.pairs != 1000000 or a.vb_mb != 4 or a.qual != "div":
+        return None
+    k = json.load(open(p))["kernels"].get(kernel)
+    return k["traffic_bytes"] if k else None
 
 
 def main():
@@ -232,16 +239,8 @@ def main():
         # the only exchange step of the path: compressed VBlocks go to the writer rank
         if world == 1:
             return
-        lens = torch.tensor([int(wl.vtab[i].z_len) for i in range(wl.n_vb)], dtype=torch.int64, device=device)
-        total = int(lens.sum())
-        flat = torch.cat([vb.z[:int(l)] for vb, l in zip(wl.vbs, lens.tolist())])
-        sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([total], dtype=torch.int64, device=device))
-        cap = int(max(int(s) for s in sizes))
-        pad = torch.zeros(cap, dtype=torch.uint8, device=device)
-        pad[:total] = flat
-        bufs = [torch.empty(cap, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
-        dist.gather(pad, bufs, dst=0)
+        from genozip_amd.shard import gather_blobs
+        gather_blobs(dist, [vb.z[:int(wl.vtab[i].z_len)] for i, vb in enumerate(wl.vbs)], rank, world, device)
 
     def barrier():
         if world > 1:
@@ -285,7 +284,7 @@ def main():
     alg_per_launch = alg_bytes_per_step / per_step_launches
     achieved = alg_per_launch / (avg_launch_ms / 1e3) / 1e9
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dom, a),
                 "avg_launch_ms": round(avg_launch_ms, 4), "launches_per_step": per_step_launches,
                 "alg_bytes_per_launch": int(alg_per_launch),
                 "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}

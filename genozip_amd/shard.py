@@ -1,0 +1,43 @@
+"""Multi-GPU plumbing of the path: VBlocks are independent, so they are dealt out to one process per
+GPU with no collective on the data path; the only exchange is the hand-over of the finished, variable-length z_data
+blobs to the writer rank -- torch.distributed (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU
+tests): an all_gather of the byte counts, then one gather of the padded payloads."""
+import torch
+
+
+def vblocks_of_rank(n_vblocks, rank, world, pair_size=1):
+    """VBlock i -> rank (i // pair_size) % world. pair_size=2 keeps the R1/R2 VBlocks of a FASTQ pair on one GPU
+    (R2 consults R1's sections, src/fastq.c:956-976)"""
+    return [i for i in range(n_vblocks) if (i // pair_size) % world == rank]
+
+
+def gather_blobs(dist, blobs, rank, world, device, dst=0):
+    """blobs: list of 1-D uint8 tensors on `device` (this rank's compressed VBlocks, in order).
+    Returns on dst: list (per rank) of lists of byte strings' tensors; elsewhere None."""
+    lens = torch.tensor([int(b.numel()) for b in blobs], dtype=torch.int64, device=device)
+    n_local = torch.tensor([len(blobs), int(lens.sum()) if len(blobs) else 0], dtype=torch.int64, device=device)
+    counts = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, n_local)
+    max_n = max(int(c[0]) for c in counts)
+    max_bytes = max(int(c[1]) for c in counts)
+    lens_pad = torch.zeros(max(1, max_n), dtype=torch.int64, device=device)
+    lens_pad[:len(blobs)] = lens
+    pay = torch.zeros(max(1, max_bytes), dtype=torch.uint8, device=device)
+    if len(blobs):
+        pay[:int(lens.sum())] = torch.cat(blobs)
+    len_bufs = [torch.empty_like(lens_pad) for _ in range(world)] if rank == dst else None
+    pay_bufs = [torch.empty_like(pay) for _ in range(world)] if rank == dst else None
+    dist.gather(lens_pad, len_bufs, dst=dst)
+    dist.gather(pay, pay_bufs, dst=dst)
+    if rank != dst:
+        return None
+    out = []
+    for r in range(world):
+        n = int(counts[r][0])
+        offs, cur = [], 0
+        for k in range(n):
+            ln = int(len_bufs[r][k])
+            offs.append(pay_bufs[r][cur:cur + ln])
+            cur += ln
+        out.append(offs)
+    return out

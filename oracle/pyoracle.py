@@ -220,3 +220,24 @@ class Ref:
     def codec_compress(self, codec, data):
         kind = "rans" if codec < 16 else "arith"
         return self.hts_compress(kind, data, CODEC_ORDER[codec])
+
+    def codec_compress_many(self, codecs, datas, n_threads):
+        """C pthread pool over independent codec calls (bench.py's multithreaded CPU baseline); returns (payloads, seconds)"""
+        import time
+        n = len(datas)
+        ins = [bytes(d) for d in datas]
+        caps = [(self.L.htsref_rans_bound if c < 16 else self.L.htsref_arith_bound)(len(d), CODEC_ORDER[c]) + 1024 for c, d in zip(codecs, ins)]
+        outs = [ctypes.create_string_buffer(c) for c in caps]
+        a_ar = (ctypes.c_int * n)(*[int(c >= 16) for c in codecs])
+        a_or = (ctypes.c_int * n)(*[CODEC_ORDER[c] for c in codecs])
+        a_in = (ctypes.c_char_p * n)(*ins)
+        a_il = (ctypes.c_uint * n)(*[len(d) for d in ins])
+        a_out = (ctypes.c_void_p * n)(*[ctypes.addressof(o) for o in outs])
+        a_cap = (ctypes.c_uint * n)(*caps)
+        a_ol = (ctypes.c_long * n)()
+        t0 = time.perf_counter()
+        rc = self.L.htsref_compress_many(n, a_ar, a_or, a_in, a_il, a_out, a_cap, a_ol, n_threads)
+        dt = time.perf_counter() - t0
+        if rc != 0:
+            raise RuntimeError("ref compress_many failed")
+        return [o.raw[:l] for o, l in zip(outs, a_ol)], dt

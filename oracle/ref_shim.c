@@ -94,3 +94,42 @@ long htsref_arith_uncompress (const unsigned char *in, unsigned in_size, unsigne
 
 unsigned htsref_rans_bound  (unsigned size, int order) { return rans_compress_bound_4x16 (size, order); }
 unsigned htsref_arith_bound (unsigned size, int order) { return arith_compress_bound (size, order); }
+
+/* ---- many independent streams on a pthread pool: the multithreaded CPU baseline of bench.py ("kind": "reference").
+ * Mirrors what Genozip's dispatcher does for this path: one compute thread per VBlock-sized unit of work
+ * (src/dispatcher.c:544-618), here one codec call per task. codecs use Genozip's order bytes
+ * (src/codec_htscodecs.c:17-20); streams shorter than 50 bytes are stored raw (src/compressor.c:56-58). ---- */
+#include <pthread.h>
+
+typedef struct {
+    int n; const int *is_arith; const int *orders; const unsigned char *const *ins; const unsigned *in_lens;
+    unsigned char *const *outs; const unsigned *out_caps; long *out_lens; int next; pthread_mutex_t mu;
+} HtsRefMany;
+
+static void *htsref_many_worker (void *arg)
+{
+    HtsRefMany *j = arg;
+    for (;;) {
+        pthread_mutex_lock (&j->mu);
+        int i = j->next++;
+        pthread_mutex_unlock (&j->mu);
+        if (i >= j->n) return NULL;
+        if (j->in_lens[i] < 50) { memcpy (j->outs[i], j->ins[i], j->in_lens[i]); j->out_lens[i] = j->in_lens[i]; }
+        else j->out_lens[i] = j->is_arith[i] ? htsref_arith_compress (j->ins[i], j->in_lens[i], j->outs[i], j->out_caps[i], j->orders[i])
+                                             : htsref_rans_compress  (j->ins[i], j->in_lens[i], j->outs[i], j->out_caps[i], j->orders[i]);
+    }
+}
+
+int htsref_compress_many (int n, const int *is_arith, const int *orders, const unsigned char *const *ins, const unsigned *in_lens,
+                          unsigned char *const *outs, const unsigned *out_caps, long *out_lens, int n_threads)
+{
+    HtsRefMany j = { n, is_arith, orders, ins, in_lens, outs, out_caps, out_lens, 0, PTHREAD_MUTEX_INITIALIZER };
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 1024) n_threads = 1024;
+    pthread_t th[1024];
+    for (int t = 1; t < n_threads; t++) pthread_create (&th[t], NULL, htsref_many_worker, &j);
+    htsref_many_worker (&j);
+    for (int t = 1; t < n_threads; t++) pthread_join (th[t], NULL);
+    for (int i = 0; i < n; i++) if (out_lens[i] < 0) return -1;
+    return 0;
+}

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 outputs a gpurun call left under gpurun_out/prof/ into the small summaries committed under
+profiles/: per-kernel stats (as rocprofv3 --stats wrote them), per-kernel HBM counters (FETCH_SIZE / WRITE_SIZE, from
+separate --pmc passes as MI355X_MICROARCH.md prescribes) and profiles/<tag>_pmc.json which bench.py reads to fill
+roofline.traffic."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "trace", "r1_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
+for f in ("bench_stats.json", "bench_fetch.json", "bench_write.json"):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, tag + "_" + f))
+
+
+def agg(path, cname):
+    out = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == cname and r["Kernel_Name"].startswith("k_"):
+            out[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+fetch = agg(os.path.join(src, "fetch", "r1_counter_collection.csv"), "FETCH_SIZE")
+write = agg(os.path.join(src, "write", "r1_counter_collection.csv"), "WRITE_SIZE")
+rows = []
+for k in sorted(set(fetch) | set(write)):
+    f, w = fetch.get(k, [0]), write.get(k, [0])
+    rows.append({"kernel": k, "dispatches": max(len(f), len(w)), "FETCH_SIZE_KB_per_dispatch_mean": sum(f) / len(f),
+                 "FETCH_SIZE_KB_max": max(f), "WRITE_SIZE_KB_per_dispatch_mean": sum(w) / len(w), "WRITE_SIZE_KB_max": max(w)})
+with open(os.path.join(dst, tag + "_pmc_hbm.csv"), "w", newline="") as fh:
+    wr = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+    wr.writeheader()
+    wr.writerows(rows)
+# per launch HBM traffic of each kernel in bytes: FETCH_SIZE counts 64 B per 128 B request on gfx950 (x2, calibrated
+# for wide coalesced reads only - MI355X_MICROARCH.md section HBM); WRITE_SIZE is taken as reported (uncalibrated)
+pmc = {r["kernel"].split("(")[0]: {"fetch_kb_reported": r["FETCH_SIZE_KB_per_dispatch_mean"], "write_kb_reported": r["WRITE_SIZE_KB_per_dispatch_mean"],
+                                    "traffic_bytes": int(2 * 1024 * r["FETCH_SIZE_KB_per_dispatch_mean"] + 1024 * r["WRITE_SIZE_KB_per_dispatch_mean"])} for r in rows}
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of: python bench.py --steps 2 --warmup 1 --no-cpu --pin-codecs",
+           "correction": "traffic = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 (gfx950 FETCH_SIZE half-count; WRITE_SIZE uncalibrated)", "kernels": pmc},
+          open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
+print(open(os.path.join(dst, tag + "_pmc_hbm.csv")).read())
