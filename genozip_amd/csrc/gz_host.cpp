@@ -39,6 +39,8 @@ struct ArenaBlock { uint8_t *base; size_t size, used; };
 struct GzHandle {
     int device;
     hipStream_t stream;
+    hipStream_t stream2;      // side stream: work that is independent of the arithmetic coder's long chain runs beside it
+    hipEvent_t ev_fork, ev_join;
     bool own_stream;
     std::vector<ArenaBlock> blocks;
     std::vector<Pending> pending;
@@ -56,11 +58,12 @@ struct GzHandle {
 };
 
 // KLAUNCH: hipLaunchKernelGGL bracketed by two events when profiling is on
-#define KLAUNCH(h, kern, grid, block, shmem, ...) do { \
+#define KLAUNCH_ON(h, strm, kern, grid, block, shmem, ...) do { \
     GzHandle::ProfRec pr_; pr_.name = #kern; \
-    if ((h)->profiling) { hipEventCreate (&pr_.a); hipEventCreate (&pr_.b); hipEventRecord (pr_.a, (h)->stream); } \
-    hipLaunchKernelGGL (kern, grid, block, shmem, (h)->stream, __VA_ARGS__); \
-    if ((h)->profiling) { hipEventRecord (pr_.b, (h)->stream); (h)->prof_open.push_back (pr_); } } while (0)
+    if ((h)->profiling) { hipEventCreate (&pr_.a); hipEventCreate (&pr_.b); hipEventRecord (pr_.a, (strm)); } \
+    hipLaunchKernelGGL (kern, grid, block, shmem, (strm), __VA_ARGS__); \
+    if ((h)->profiling) { hipEventRecord (pr_.b, (strm)); (h)->prof_open.push_back (pr_); } } while (0)
+#define KLAUNCH(h, kern, grid, block, shmem, ...) KLAUNCH_ON (h, (h)->stream, kern, grid, block, shmem, __VA_ARGS__)
 
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     (h)->err = std::string (#call) + ": " + hipGetErrorString (e_); return GZ_ERR_HIP; } } while (0)
@@ -109,6 +112,9 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
         if (hipStreamCreateWithFlags (&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; if (err) *err = GZ_ERR_HIP; return NULL; }
         h->own_stream = true;
     }
+    if (hipStreamCreateWithFlags (&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags (&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags (&h->ev_join, hipEventDisableTiming) != hipSuccess) { delete h; if (err) *err = GZ_ERR_HIP; return NULL; }
     // log(1024+k), log(4096+k) from the host libm: what the reference's compute_shift() sees (rANS_static4x16pr.c:647)
     GzLogTable lt;
     for (int k = 0; k <= 256; k++) { lt.l10[k] = log (1024.0 + k); lt.l12[k] = log (4096.0 + k); }
@@ -162,6 +168,8 @@ extern "C" void gz_destroy (GzHandle *h)
     hipFree (h->d_logs);
     hipFree (h->d_magic);
     if (h->own_stream) hipStreamDestroy (h->stream);
+    hipStreamDestroy (h->stream2);
+    hipEventDestroy (h->ev_fork); hipEventDestroy (h->ev_join);
     delete h;
 }
 
@@ -220,7 +228,7 @@ extern "C" uint32_t gz_codec_est_size (int codec, uint64_t len)
 struct Plan {
     std::vector<GzdStream> streams;
     std::vector<GzdLeaf>   leaves;
-    bool any_striped = false, any_rans = false, any_arith = false;
+    bool any_striped = false, any_rans = false, any_arith = false, any_arith_rle = false;
     uint32_t max_in = 0;
 };
 
@@ -244,6 +252,7 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
     else {
         const bool rle = method & GZ_X_RLE;
         if (rle) {
+            P.any_arith_rle = true;
             size_t words = (size_t)(o1 ? 256 : 1) * 257 + GZ_ARITH_RUN_MODELS * GZ_ARITH_RUN_STRIDE;
             if (!(L.models = (uint32_t *)arena_alloc (h, words * 4))) return false;
         }
@@ -335,20 +344,28 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
     }
     if (nl) {
         KLAUNCH (h, k_leaf_prep, dim3 (nl), dim3 (256), 4096, d_streams, d_leaves);
+        // fork: the rANS leaves and the run-length arith leaves do not depend on the long model/chain kernels of the
+        // plain arith leaves (which keep only one wave per leaf busy), so they run beside them on a second stream
+        const bool fork = P.any_arith;
+        hipStream_t side = fork ? h->stream2 : h->stream;
+        if (fork) { HIPCHK (h, hipEventRecord (h->ev_fork, h->stream)); HIPCHK (h, hipStreamWaitEvent (side, h->ev_fork, 0)); }
         if (P.any_rans) {
-            KLAUNCH (h, k_hist, dim3 (nl, GZ_HIST_CHUNKS), dim3 (256), GZ_HIST_LDS, d_leaves);
-            KLAUNCH (h, k_rans_table, dim3 (nl), dim3 (256), 16384, d_leaves, (const GzLogTable *)h->d_logs);
-            KLAUNCH (h, k_rans_encode, dim3 (nl), dim3 (64), 0, d_leaves);
+            KLAUNCH_ON (h, side, k_hist, dim3 (nl, GZ_HIST_CHUNKS), dim3 (256), GZ_HIST_LDS, d_leaves);
+            KLAUNCH_ON (h, side, k_rans_table, dim3 (nl), dim3 (256), 16384, d_leaves, (const GzLogTable *)h->d_logs);
+            KLAUNCH_ON (h, side, k_rans_encode, dim3 (nl), dim3 (64), 0, d_leaves);
         }
         if (P.any_arith) {
+            if (P.any_arith_rle) {
+                for (int c = 0; c < 3; c++)
+                    KLAUNCH_ON (h, side, k_arith_encode, dim3 (nl), dim3 (64), ARITH_CLASS_WORDS[c + 1] * 4,
+                                d_leaves, ARITH_CLASS_WORDS[c], ARITH_CLASS_WORDS[c + 1], 0);
+                KLAUNCH_ON (h, side, k_arith_encode, dim3 (nl), dim3 (64), 0, d_leaves, ARITH_CLASS_WORDS[3], 0xffffffffu, 1);
+            }
             KLAUNCH (h, k_arith_model, dim3 (nl, 256), dim3 (64), 0, d_leaves, (const GzDivMagic *)h->d_magic);
             KLAUNCH (h, k_arith_chain, dim3 (nl), dim3 (64), 0, d_leaves);
             KLAUNCH (h, k_arith_carry, dim3 (nl), dim3 (256), 4096, d_leaves);
-            for (int c = 0; c < 3; c++)
-                KLAUNCH (h, k_arith_encode, dim3 (nl), dim3 (64), ARITH_CLASS_WORDS[c + 1] * 4,
-                                    d_leaves, ARITH_CLASS_WORDS[c], ARITH_CLASS_WORDS[c + 1], 0);
-            KLAUNCH (h, k_arith_encode, dim3 (nl), dim3 (64), 0, d_leaves, ARITH_CLASS_WORDS[3], 0xffffffffu, 1);
         }
+        if (fork) { HIPCHK (h, hipEventRecord (h->ev_join, side)); HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_join, 0)); }
     }
     KLAUNCH (h, k_select, dim3 ((ns + 255) / 256), dim3 (256), 0, d_streams, d_leaves, ns);
     if (n_vbs) KLAUNCH (h, k_vb_layout, dim3 ((n_vbs + 63) / 64), dim3 (64), 0, d_vbs, d_streams, n_vbs);

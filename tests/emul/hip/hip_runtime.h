@@ -45,6 +45,9 @@ static inline hipError_t hipStreamSynchronize (hipStream_t) { return hipSuccess;
 static inline hipError_t hipGetLastError (void) { return hipSuccess; }
 typedef void *hipEvent_t;
 static inline hipError_t hipEventCreate (hipEvent_t *e) { *e = nullptr; return hipSuccess; }
+enum { hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags (hipEvent_t *e, int) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent (hipStream_t, hipEvent_t, int) { return hipSuccess; }
 static inline hipError_t hipEventDestroy (hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord (hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime (float *ms, hipEvent_t, hipEvent_t) { *ms = 0; return hipSuccess; }
