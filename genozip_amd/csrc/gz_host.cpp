@@ -258,7 +258,8 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
         }
         else {
             if (!(L.triples = (uint8_t *)arena_alloc (h, ((size_t)n_bound + 64) * 16 + 2 * GZ_CHAIN_TOUCH_AHEAD + 8192))) return false;
-            if (!(L.events  = (uint8_t *)arena_alloc (h, ((size_t)L.pay_cap + 128) * 2))) return false;
+            if (!(L.events  = (uint8_t *)arena_alloc (h, ((size_t)L.pay_cap + 128) * 4))) return false;
+            if (!(L.rvals   = (uint8_t *)arena_alloc (h, ((size_t)n_bound + 64) * 4))) return false;
         }
     }
     P.leaves.push_back (L);
@@ -363,7 +364,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
             }
             KLAUNCH (h, k_arith_model, dim3 (nl, 256), dim3 (64), 0, d_leaves, (const GzDivMagic *)h->d_magic);
             KLAUNCH (h, k_arith_chain, dim3 (nl), dim3 (64), 0, d_leaves);
-            KLAUNCH (h, k_arith_carry, dim3 (nl), dim3 (256), 4096, d_leaves);
+            KLAUNCH (h, k_arith_low, dim3 (nl), dim3 (256), 8192, d_leaves);
         }
         if (fork) { HIPCHK (h, hipEventRecord (h->ev_join, side)); HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_join, 0)); }
     }

@@ -254,43 +254,36 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const GzDi
 // ---- range coder chain ------------------------------------------------------------------------------------------
 // Measured on MI355X (tools/ubench_chain.hip): ONE wave issues an instruction every ~3.2 ns (scalar) / 2.5 ns
 // (vector) whether or not it depends on the previous one, a vector->scalar hand-over (v_readlane feeding s_*) costs
-// ~12 ns, and nothing but the instruction count of the wave matters. So the chain is kept entirely on the scalar
-// unit and written for few instructions per symbol:
-//  * records arrive through scalar (SMEM) loads, 8 at a time, the next 8 in flight while 8 are coded. SMEM returns
-//    out of order, so the only wait is "all": the lines are therefore pulled into L2 well ahead by a cheap vector
-//    load whose result is never used, which turns the scalar loads into L2 hits;
-//  * r = range / tot is a multiply-high and three shifts/adds with the per-record magic number;
-//  * carry is the high half of a 64-bit low, so (carry:low) >> 24 is exactly "top byte | carry << 8";
-//  * the byte-output logic of the reference (RC_ShiftLow, c_range_coder.h:70-88: hold back a byte while later carries
-//    can still reach it, count pending 0xFF bytes) is NOT run here. That logic is a lazy big-number addition: the
-//    stream is [0, T1, T2, ...] (Tj = top byte of low at the j-th shift) plus, for every shift that saw the carry
-//    flag set, +1 at the byte before it. The chain only records the 16-bit event (Tj | carry_j << 8) per shift, four
-//    events per 64-bit store, and k_arith_carry resolves all carries of all leaves in parallel afterwards.
-struct GzRcU { uint64_t lowc, acc; uint32_t range, nev; uint64_t *ev; int lane; };
-
-__device__ static inline void d_rcu_shift (GzRcU &rc)
-{
-    rc.acc = (rc.acc >> 16) | ((rc.lowc >> 24) << 48);               // event = (carry:low) >> 24, 9 significant bits
-    rc.nev++;
-    if (!(rc.nev & 3)) { if (!rc.lane) rc.ev[(rc.nev >> 2) - 1] = rc.acc; }
-    rc.lowc = (uint64_t)((uint32_t)rc.lowc << 8);
-}
-
-// One symbol: r = range / tot by multiplication (tot >= 2), low += cum * r, range = r * freq, renormalise.
-__device__ static inline void d_rcu_step (GzRcU &rc, uint32_t cum, uint32_t freq, uint32_t mg, uint32_t sh)
-{
-    const uint32_t t = __umulhi (mg, rc.range);
-    const uint32_t r = (((rc.range - t) >> 1) + t) >> sh;            // c_range_coder.h:100
-    rc.lowc += (uint64_t)(cum * r);
-    rc.range = r * freq;
-    while (rc.range < (1u << 24)) { rc.range <<= 8; d_rcu_shift (rc); }
-}
-
+// ~12 ns, and nothing but the instruction count of the wave matters. What is truly serial in the range coder
+// (c_range_coder.h:97-109) is only
+//        r = range / tot ;  range = (r * freq) << 8k      (k = bytes needed to bring range back above 2^24)
+// `low` is not: low += cum * r followed by shifts is a big-number addition, and addition is associative. So
+//   k_arith_chain  one wave per leaf, entirely on the scalar unit, ~12 instructions per symbol: SMEM record loads
+//                  (8 at a time, the next 8 in flight; the lines are pulled into L2 well ahead by a vector "touch"
+//                  load because SMEM returns out of order and can only be waited for as a whole), division by the
+//                  per-record magic number, renormalisation by count-leading-zeros instead of a loop, and r stored
+//                  four at a time. It never looks at cum or low.
+//   k_arith_low    one workgroup per leaf, all threads: every thread replays low += cum * r for its own slice of the
+//                  symbols from low = 0, emitting the byte that leaves the 32-bit window at every shift (plus the carry
+//                  out of the window as a 9th bit) at its absolute output position (a prefix sum of the k's), and adds
+//                  what is left in its window where the following slices' bytes go. Then the digits are normalised:
+//                  carries ripple left inside each slice and, very rarely, across slices.
+// This reproduces RC_ShiftLow's cache / pending-0xFF bookkeeping (c_range_coder.h:70-88) exactly: that logic is just
+// a lazy form of the same addition ("[0, T1, T2, ...] plus 1 at the byte before every shift that saw a carry").
 typedef uint32_t gz_u32x4 __attribute__((vector_size (16)));
 typedef const volatile __attribute__((address_space(4))) gz_u32x4 *GzConstRecP;   // volatile: keeps the prefetch a prefetch
 
 #define GZ_CHAIN_BLOCK 8
 #define GZ_CHAIN_TOUCH_AHEAD (16 * 1024)   // bytes: how far ahead of the scalar loads the vector unit pulls lines into L2
+
+__device__ static inline uint32_t d_chain_step (uint32_t &range, uint32_t freq, uint32_t mg, uint32_t sh)
+{
+    const uint32_t t = __umulhi (mg, range);
+    const uint32_t r = (((range - t) >> 1) + t) >> sh;               // range / tot, tot >= 2
+    const uint32_t x = r * freq;                                     // >= 256: r >= 2^24 / 65535
+    range = x << (__clz (x) & 0x18);                                 // 0, 1 or 2 bytes
+    return r;
+}
 
 // one wave per leaf
 __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
@@ -301,20 +294,18 @@ __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
     const uint32_t n = L.coded_n;
     GzConstRecP rec = (GzConstRecP)(uintptr_t)L.triples;       // padded: reads up to 64 KB past n stay inside the area
     const uint32_t *touch = (const uint32_t *)L.triples;
-    uint32_t sink = 0;
-
-    GzRcU rc;
-    rc.lowc = 0; rc.acc = 0; rc.range = 0xffffffffu; rc.nev = 0; rc.ev = (uint64_t *)L.events; rc.lane = lane;
+    uint32_t *rout = (uint32_t *)L.rvals;
+    uint32_t sink = 0, range = 0xffffffffu;
 
     if (n && L.max_sym == 1) {
         // a stream of zero bytes: the model total starts at 1, which the multiply-shift division cannot express
         for (uint32_t i = 0; i < n; i++) {
             const gz_u32x4 c = rec[i];
-            const uint32_t t = __umulhi (c[2], rc.range);
-            const uint32_t r = c[3] == 0xff ? rc.range : (((rc.range - t) >> 1) + t) >> c[3];
-            rc.lowc += (uint64_t)(c[0] * r);
-            rc.range = r * c[1];
-            while (rc.range < (1u << 24)) { rc.range <<= 8; d_rcu_shift (rc); }
+            const uint32_t t = __umulhi (c[2], range);
+            const uint32_t r = c[3] == 0xff ? range : (((range - t) >> 1) + t) >> c[3];
+            const uint32_t x = r * c[1];
+            range = x << (__clz (x) & 0x18);
+            if (!lane) rout[i] = r;
         }
     }
     else {
@@ -327,67 +318,113 @@ __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
                 const gz_u32x4 p0 = rec[nx], p1 = rec[nx + 1], p2 = rec[nx + 2], p3 = rec[nx + 3],
                                p4 = rec[nx + 4], p5 = rec[nx + 5], p6 = rec[nx + 6], p7 = rec[nx + 7];
                 if (!(i & 255)) sink += touch[((i * 16 + GZ_CHAIN_TOUCH_AHEAD) >> 2) + lane * 16];  // every 256 records = 4 KB
-                d_rcu_step (rc, c0[0], c0[1], c0[2], c0[3]);
-                d_rcu_step (rc, c1[0], c1[1], c1[2], c1[3]);
-                d_rcu_step (rc, c2[0], c2[1], c2[2], c2[3]);
-                d_rcu_step (rc, c3[0], c3[1], c3[2], c3[3]);
-                d_rcu_step (rc, c4[0], c4[1], c4[2], c4[3]);
-                d_rcu_step (rc, c5[0], c5[1], c5[2], c5[3]);
-                d_rcu_step (rc, c6[0], c6[1], c6[2], c6[3]);
-                d_rcu_step (rc, c7[0], c7[1], c7[2], c7[3]);
+                uint4 ra, rb;
+                ra.x = d_chain_step (range, c0[1], c0[2], c0[3]);
+                ra.y = d_chain_step (range, c1[1], c1[2], c1[3]);
+                ra.z = d_chain_step (range, c2[1], c2[2], c2[3]);
+                ra.w = d_chain_step (range, c3[1], c3[2], c3[3]);
+                rb.x = d_chain_step (range, c4[1], c4[2], c4[3]);
+                rb.y = d_chain_step (range, c5[1], c5[2], c5[3]);
+                rb.z = d_chain_step (range, c6[1], c6[2], c6[3]);
+                rb.w = d_chain_step (range, c7[1], c7[2], c7[3]);
+                if (!lane) { *(uint4 *)(rout + i) = ra; *(uint4 *)(rout + i + 4) = rb; }
                 c0 = p0; c1 = p1; c2 = p2; c3 = p3; c4 = p4; c5 = p5; c6 = p6; c7 = p7;
             }
         }
-        for (uint32_t i = nb; i < n; i++) { const gz_u32x4 c = rec[i]; d_rcu_step (rc, c[0], c[1], c[2], c[3]); }
+        for (uint32_t i = nb; i < n; i++) {
+            const gz_u32x4 c = rec[i];
+            const uint32_t r = d_chain_step (range, c[1], c[2], c[3]);
+            if (!lane) rout[i] = r;
+        }
     }
-
-    for (int k = 0; k < 5; k++) d_rcu_shift (rc);                        // RC_FinishEncode: 5 more shifts
-    if (rc.nev & 3) { if (!lane) rc.ev[rc.nev >> 2] = rc.acc >> (16 * (4 - (rc.nev & 3))); }
-    if (!lane) { L.n_events = rc.nev; L.touch_sink = sink; }
+    if (!lane) L.touch_sink = sink;
 }
 
-// Carry resolution, one 256-thread workgroup per leaf. With m shifts the output is m bytes: byte 0 is the coder's
-// initial cache (0), byte i is T_i; the carry flag seen at shift j adds 1 at byte j-1 and ripples left through 0xFF
-// bytes. Each thread owns a slice: it first finds whether a carry entering its slice from the right would leave it
-// on the left (only if every byte is 0xFF after its own carries) and what it emits on its own; thread 0 chains the
-// 256 slices; then every thread writes its bytes.
-__global__ void __launch_bounds__(256) k_arith_carry (GzdLeaf *leaves)
+// one 256-thread workgroup per leaf; 8 KB of dynamic LDS
+__global__ void __launch_bounds__(256) k_arith_low (GzdLeaf *leaves)
 {
     GzdLeaf &L = leaves[blockIdx.x];
     if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
     const int tid = threadIdx.x;
-    const uint32_t m = L.n_events;
-    const uint16_t *ev = (const uint16_t *)L.events;
+    const uint32_t n = L.coded_n;
+    const uint4 *rec = (const uint4 *)L.triples;
+    const uint32_t *rv = (const uint32_t *)L.rvals;
+    uint32_t *dig = (uint32_t *)L.events;          // one 32-bit digit per output byte (index 0 = the coder's initial cache byte)
     uint8_t *out = L.pay + 1;
-    uint32_t *sh = (uint32_t *)gz_lds;          // [0..255] carry-out with carry-in 0, [256..511] with carry-in 1, [512..767] carry-in
-    if (!tid) L.pay[0] = (uint8_t)(L.coded_n ? L.max_sym : 1);            // max_sym + 1 (256 wraps to 0), arith_dynamic.c:103-108
+    uint32_t *sh = (uint32_t *)gz_lds;             // [0..255] per-thread counts / carries, [256..] misc
 
-    const uint32_t per = (m + 255) / 256;
-    const uint32_t lo = tid * per, hi = lo + per < m ? lo + per : m;
-    // value of byte i before ripple: (i ? T_i : 0) + carry flag of shift i+1
-    uint32_t c0 = 0, c1 = 1;
-    for (uint32_t i = hi; i-- > lo; ) {
-        const uint32_t raw = i ? (ev[i - 1] & 0xffu) : 0u;
-        const uint32_t cin = ((uint32_t)ev[i] >> 8) & 1u;                 // carry flag recorded at shift i+1 == event index i
-        c0 = (raw + cin + c0) >> 8;
-        c1 = (raw + cin + c1) >> 8;
-    }
-    sh[tid] = c0; sh[256 + tid] = c1;
+    // ---- slice of symbols of this thread, number of shifts in it
+    const uint32_t per = (n + 255) / 256;
+    const uint32_t s0 = tid * per < n ? tid * per : n, s1 = s0 + per < n ? s0 + per : n;
+    uint32_t kcnt = 0;
+    for (uint32_t i = s0; i < s1; i++) kcnt += __clz (rv[i] * rec[i].y) >> 3;
+    sh[tid] = kcnt;
     __syncthreads ();
     if (!tid) {
-        uint32_t carry = 0;
-        for (int t = 255; t >= 0; t--) { sh[512 + t] = carry; carry = carry ? sh[256 + t] : sh[t]; }
+        uint32_t run = 0;
+        for (int t = 0; t < 256; t++) { uint32_t c = sh[t]; sh[t] = run; run += c; }
+        sh[256] = run + 5;                          // + RC_FinishEncode's 5 shifts
     }
     __syncthreads ();
-    uint32_t carry = sh[512 + tid];
-    for (uint32_t i = hi; i-- > lo; ) {
-        const uint32_t raw = i ? (ev[i - 1] & 0xffu) : 0u;
-        const uint32_t cin = ((uint32_t)ev[i] >> 8) & 1u;
-        const uint32_t v = raw + cin + carry;
-        out[i] = (uint8_t)v;
-        carry = v >> 8;
+    const uint32_t m = sh[256];                     // output bytes (before the max_sym byte)
+    uint32_t pos = sh[tid];                         // shifts before this slice == index of the digit its next shift produces, minus 1
+
+    // ---- zero the digits this slice owns (digit j+1 belongs to shift j; digit 0 to thread 0), then replay low
+    const uint32_t own0 = tid ? pos + 1 : 0, own1 = (tid == 255 ? m : sh[tid + 1] + 1);
+    for (uint32_t j = own0; j < own1 && j < m; j++) dig[j] = 0;
+    __syncthreads ();
+    uint64_t lowc = 0;
+    for (uint32_t i = s0; i < s1; i++) {
+        const uint4 c = rec[i];
+        const uint32_t r = rv[i];
+        lowc += (uint64_t)(c.x * r);
+        const uint32_t k = __clz (r * c.y) >> 3;
+        for (uint32_t q = 0; q < k; q++) { dig[++pos] = (uint32_t)(lowc >> 24); lowc = (uint64_t)((uint32_t)lowc << 8); }
+    }
+    if (tid == 255 || s1 == n) {
+        // the slice that ends the stream performs the 5 closing shifts (only one thread has s1 == n && s0 < n, or n == 0)
+        const bool closer = (n == 0) ? tid == 0 : (s0 < n && s1 == n);
+        if (closer) for (int q = 0; q < 5; q++) { dig[++pos] = (uint32_t)(lowc >> 24); lowc = (uint64_t)((uint32_t)lowc << 8); }
+    }
+    __threadfence_block ();
+    __syncthreads ();
+    // what is still inside this slice's window belongs to the next 4 output bytes (they are other slices' digits)
+    if (lowc) {
+        if (pos + 1 < m) atomicAdd (&dig[pos + 1], (uint32_t)(lowc >> 24));
+        if (pos + 2 < m) atomicAdd (&dig[pos + 2], (uint32_t)(lowc >> 16) & 0xff);
+        if (pos + 3 < m) atomicAdd (&dig[pos + 3], (uint32_t)(lowc >> 8) & 0xff);
+        if (pos + 4 < m) atomicAdd (&dig[pos + 4], (uint32_t)lowc & 0xff);
+    }
+    __threadfence_block ();
+    __syncthreads ();
+
+    // ---- normalise: thread t owns output bytes [b0, b1); ripple right to left, then pass carries between slices
+    const uint32_t bper = (m + 255) / 256;
+    const uint32_t b0 = tid * bper < m ? tid * bper : m, b1 = b0 + bper < m ? b0 + bper : m;
+    uint32_t carry = 0;
+    for (uint32_t j = b1; j-- > b0; ) { const uint32_t v = dig[j] + carry; out[j] = (uint8_t)v; carry = v >> 8; }
+    sh[tid] = carry;
+    __syncthreads ();
+    for (int round = 0; round < 256; round++) {
+        uint32_t cin = (tid < 255 && b1 < m + 0) ? sh[tid + 1] : 0;
+        if (b1 >= m) cin = 0;
+        __syncthreads ();
+        uint32_t cout = 0;
+        if (cin && b1 > b0) {
+            uint32_t c = cin;
+            for (uint32_t j = b1; c && j-- > b0; ) { const uint32_t v = out[j] + c; out[j] = (uint8_t)v; c = v >> 8; }
+            cout = c;
+        }
+        else if (cin) cout = cin;                     // empty slice: hand it on
+        sh[tid] = cout;
+        sh[300] = 0;
+        __syncthreads ();
+        if (cout) sh[300] = 1;
+        __syncthreads ();
+        if (!sh[300]) break;
     }
     if (!tid) {
+        L.pay[0] = (uint8_t)(n ? L.max_sym : 1);                          // max_sym + 1 (256 wraps to 0), arith_dynamic.c:103-108
         if (m + 1 > L.pay_cap) { L.overflow = 1; L.pay_len = 0; }        // cannot happen: pay_cap >= 2n + 64
         else L.pay_len = m + 1;
         L.tab_len = 0;
