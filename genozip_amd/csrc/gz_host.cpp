@@ -364,7 +364,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
             }
             KLAUNCH (h, k_arith_model, dim3 (nl, 256), dim3 (64), 0, d_leaves, (const GzDivMagic *)h->d_magic);
             KLAUNCH (h, k_arith_chain, dim3 (nl), dim3 (64), 0, d_leaves);
-            KLAUNCH (h, k_arith_low, dim3 (nl), dim3 (256), 8192, d_leaves);
+            KLAUNCH (h, k_arith_low, dim3 (nl), dim3 (GZ_LOW_NT), 8192, d_leaves);
         }
         if (fork) { HIPCHK (h, hipEventRecord (h->ev_join, side)); HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_join, 0)); }
     }

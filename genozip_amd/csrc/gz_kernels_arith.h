@@ -340,8 +340,10 @@ __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
     if (!lane) L.touch_sink = sink;
 }
 
-// one 256-thread workgroup per leaf; 8 KB of dynamic LDS
-__global__ void __launch_bounds__(256) k_arith_low (GzdLeaf *leaves)
+// one 1024-thread workgroup per leaf (many short slices: the replay of a slice is a dependent load-use loop, so its
+// cost is memory latency x slice length); 8 KB of dynamic LDS
+#define GZ_LOW_NT 1024
+__global__ void __launch_bounds__(GZ_LOW_NT) k_arith_low (GzdLeaf *leaves)
 {
     GzdLeaf &L = leaves[blockIdx.x];
     if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
@@ -351,37 +353,44 @@ __global__ void __launch_bounds__(256) k_arith_low (GzdLeaf *leaves)
     const uint32_t *rv = (const uint32_t *)L.rvals;
     uint32_t *dig = (uint32_t *)L.events;          // one 32-bit digit per output byte (index 0 = the coder's initial cache byte)
     uint8_t *out = L.pay + 1;
-    uint32_t *sh = (uint32_t *)gz_lds;             // [0..255] per-thread counts / carries, [256..] misc
+    uint32_t *sh = (uint32_t *)gz_lds;             // [0..NT-1] per-thread counts / carries, [NT..] misc
 
     // ---- slice of symbols of this thread, number of shifts in it
-    const uint32_t per = (n + 255) / 256;
+    const uint32_t per = (n + GZ_LOW_NT - 1) / GZ_LOW_NT;
     const uint32_t s0 = tid * per < n ? tid * per : n, s1 = s0 + per < n ? s0 + per : n;
     uint32_t kcnt = 0;
-    for (uint32_t i = s0; i < s1; i++) kcnt += __clz (rv[i] * rec[i].y) >> 3;
+    {   uint32_t i = s0;
+        for (; i + 4 <= s1; i += 4) {
+            const uint32_t x0 = rv[i] * rec[i].y, x1 = rv[i + 1] * rec[i + 1].y, x2 = rv[i + 2] * rec[i + 2].y, x3 = rv[i + 3] * rec[i + 3].y;
+            kcnt += (__clz (x0) >> 3) + (__clz (x1) >> 3) + (__clz (x2) >> 3) + (__clz (x3) >> 3);
+        }
+        for (; i < s1; i++) kcnt += __clz (rv[i] * rec[i].y) >> 3;
+    }
     sh[tid] = kcnt;
     __syncthreads ();
     if (!tid) {
         uint32_t run = 0;
-        for (int t = 0; t < 256; t++) { uint32_t c = sh[t]; sh[t] = run; run += c; }
-        sh[256] = run + 5;                          // + RC_FinishEncode's 5 shifts
+        for (int t = 0; t < GZ_LOW_NT; t++) { uint32_t c = sh[t]; sh[t] = run; run += c; }
+        sh[GZ_LOW_NT] = run + 5;                          // + RC_FinishEncode's 5 shifts
     }
     __syncthreads ();
-    const uint32_t m = sh[256];                     // output bytes (before the max_sym byte)
+    const uint32_t m = sh[GZ_LOW_NT];                     // output bytes (before the max_sym byte)
     uint32_t pos = sh[tid];                         // shifts before this slice == index of the digit its next shift produces, minus 1
 
     // ---- zero the digits this slice owns (digit j+1 belongs to shift j; digit 0 to thread 0), then replay low
-    const uint32_t own0 = tid ? pos + 1 : 0, own1 = (tid == 255 ? m : sh[tid + 1] + 1);
+    const uint32_t own0 = tid ? pos + 1 : 0, own1 = (tid == GZ_LOW_NT - 1 ? m : sh[tid + 1] + 1);
     for (uint32_t j = own0; j < own1 && j < m; j++) dig[j] = 0;
     __syncthreads ();
     uint64_t lowc = 0;
+    uint4 cn = rec[s0]; uint32_t rn = rv[s0];              // (the areas are padded, reading one past the slice is harmless)
     for (uint32_t i = s0; i < s1; i++) {
-        const uint4 c = rec[i];
-        const uint32_t r = rv[i];
+        const uint4 c = cn; const uint32_t r = rn;
+        cn = rec[i + 1]; rn = rv[i + 1];
         lowc += (uint64_t)(c.x * r);
         const uint32_t k = __clz (r * c.y) >> 3;
         for (uint32_t q = 0; q < k; q++) { dig[++pos] = (uint32_t)(lowc >> 24); lowc = (uint64_t)((uint32_t)lowc << 8); }
     }
-    if (tid == 255 || s1 == n) {
+    if (tid == GZ_LOW_NT - 1 || s1 == n) {
         // the slice that ends the stream performs the 5 closing shifts (only one thread has s1 == n && s0 < n, or n == 0)
         const bool closer = (n == 0) ? tid == 0 : (s0 < n && s1 == n);
         if (closer) for (int q = 0; q < 5; q++) { dig[++pos] = (uint32_t)(lowc >> 24); lowc = (uint64_t)((uint32_t)lowc << 8); }
@@ -399,14 +408,14 @@ __global__ void __launch_bounds__(256) k_arith_low (GzdLeaf *leaves)
     __syncthreads ();
 
     // ---- normalise: thread t owns output bytes [b0, b1); ripple right to left, then pass carries between slices
-    const uint32_t bper = (m + 255) / 256;
+    const uint32_t bper = (m + GZ_LOW_NT - 1) / GZ_LOW_NT;
     const uint32_t b0 = tid * bper < m ? tid * bper : m, b1 = b0 + bper < m ? b0 + bper : m;
     uint32_t carry = 0;
     for (uint32_t j = b1; j-- > b0; ) { const uint32_t v = dig[j] + carry; out[j] = (uint8_t)v; carry = v >> 8; }
     sh[tid] = carry;
     __syncthreads ();
-    for (int round = 0; round < 256; round++) {
-        uint32_t cin = (tid < 255 && b1 < m + 0) ? sh[tid + 1] : 0;
+    for (int round = 0; round < GZ_LOW_NT; round++) {
+        uint32_t cin = (tid < GZ_LOW_NT - 1) ? sh[tid + 1] : 0;
         if (b1 >= m) cin = 0;
         __syncthreads ();
         uint32_t cout = 0;
@@ -417,11 +426,11 @@ __global__ void __launch_bounds__(256) k_arith_low (GzdLeaf *leaves)
         }
         else if (cin) cout = cin;                     // empty slice: hand it on
         sh[tid] = cout;
-        sh[300] = 0;
+        sh[GZ_LOW_NT + 8] = 0;
         __syncthreads ();
-        if (cout) sh[300] = 1;
+        if (cout) sh[GZ_LOW_NT + 8] = 1;
         __syncthreads ();
-        if (!sh[300]) break;
+        if (!sh[GZ_LOW_NT + 8]) break;
     }
     if (!tid) {
         L.pay[0] = (uint8_t)(n ? L.max_sym : 1);                          // max_sym + 1 (256 wraps to 0), arith_dynamic.c:103-108

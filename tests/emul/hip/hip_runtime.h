@@ -85,8 +85,8 @@ enum { EMU_RUN = 0, EMU_WAIT_BLOCK = 1, EMU_WAIT_WAVE = 2, EMU_DONE = 3 };
 struct EmuFiber { void *sp; int state; };
 struct EmuWave { unsigned alive, arrived; unsigned long long result; uint8_t slot[64]; };
 struct EmuSched {
-    static const unsigned MAXT = 256;
-    static const size_t STACK = 256 << 10;
+    static const unsigned MAXT = 1024;
+    static const size_t STACK = 128 << 10;
     uint8_t *stacks = nullptr;
     EmuFiber f[MAXT];
     EmuWave wave[MAXT / 64];
