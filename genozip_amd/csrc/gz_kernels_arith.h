@@ -359,10 +359,15 @@ __global__ void __launch_bounds__(GZ_LOW_NT) k_arith_low (GzdLeaf *leaves)
     const uint32_t per = (n + GZ_LOW_NT - 1) / GZ_LOW_NT;
     const uint32_t s0 = tid * per < n ? tid * per : n, s1 = s0 + per < n ? s0 + per : n;
     uint32_t kcnt = 0;
+    // (a thread walks its slice 8 records = one 128-byte line at a time: the loads of a chunk are independent, so a
+    //  slice costs one memory latency per 8 symbols and every fetched line is used completely)
     {   uint32_t i = s0;
-        for (; i + 4 <= s1; i += 4) {
-            const uint32_t x0 = rv[i] * rec[i].y, x1 = rv[i + 1] * rec[i + 1].y, x2 = rv[i + 2] * rec[i + 2].y, x3 = rv[i + 3] * rec[i + 3].y;
-            kcnt += (__clz (x0) >> 3) + (__clz (x1) >> 3) + (__clz (x2) >> 3) + (__clz (x3) >> 3);
+        for (; i + 8 <= s1; i += 8) {
+            uint32_t f[8], r[8];
+            #pragma unroll
+            for (int q = 0; q < 8; q++) { f[q] = rec[i + q].y; r[q] = rv[i + q]; }
+            #pragma unroll
+            for (int q = 0; q < 8; q++) kcnt += __clz (r[q] * f[q]) >> 3;
         }
         for (; i < s1; i++) kcnt += __clz (rv[i] * rec[i].y) >> 3;
     }
@@ -382,13 +387,25 @@ __global__ void __launch_bounds__(GZ_LOW_NT) k_arith_low (GzdLeaf *leaves)
     for (uint32_t j = own0; j < own1 && j < m; j++) dig[j] = 0;
     __syncthreads ();
     uint64_t lowc = 0;
-    uint4 cn = rec[s0]; uint32_t rn = rv[s0];              // (the areas are padded, reading one past the slice is harmless)
-    for (uint32_t i = s0; i < s1; i++) {
-        const uint4 c = cn; const uint32_t r = rn;
-        cn = rec[i + 1]; rn = rv[i + 1];
-        lowc += (uint64_t)(c.x * r);
-        const uint32_t k = __clz (r * c.y) >> 3;
-        for (uint32_t q = 0; q < k; q++) { dig[++pos] = (uint32_t)(lowc >> 24); lowc = (uint64_t)((uint32_t)lowc << 8); }
+    {   uint32_t i = s0;
+        for (; i + 8 <= s1; i += 8) {
+            uint4 c[8]; uint32_t r[8];
+            #pragma unroll
+            for (int q = 0; q < 8; q++) { c[q] = rec[i + q]; r[q] = rv[i + q]; }
+            #pragma unroll
+            for (int q = 0; q < 8; q++) {
+                lowc += (uint64_t)(c[q].x * r[q]);
+                const uint32_t k = __clz (r[q] * c[q].y) >> 3;
+                for (uint32_t z = 0; z < k; z++) { dig[++pos] = (uint32_t)(lowc >> 24); lowc = (uint64_t)((uint32_t)lowc << 8); }
+            }
+        }
+        for (; i < s1; i++) {
+            const uint4 c = rec[i];
+            const uint32_t r = rv[i];
+            lowc += (uint64_t)(c.x * r);
+            const uint32_t k = __clz (r * c.y) >> 3;
+            for (uint32_t z = 0; z < k; z++) { dig[++pos] = (uint32_t)(lowc >> 24); lowc = (uint64_t)((uint32_t)lowc << 8); }
+        }
     }
     if (tid == GZ_LOW_NT - 1 || s1 == n) {
         // the slice that ends the stream performs the 5 closing shifts (only one thread has s1 == n && s0 < n, or n == 0)
