@@ -157,6 +157,7 @@ __device__ static void d_arith_model_wave_compact (const uint8_t *in, uint32_t n
     uint32_t cum = live ? sym : ms;                       // lane entries + absent entries before it == its byte value
     uint32_t tot = ms;
     const uint32_t n_absent = ms - nsym;
+    uint32_t seen = 0; bool boosted = false;
 
     uint32_t nx_s[4], nx_p[4];
     #pragma unroll
@@ -184,6 +185,10 @@ __device__ static void d_arith_model_wave_compact (const uint8_t *in, uint32_t n
         const bool mine = pos < n && (!o1 || cp[k] == ctx);
         uint64_t todo = __ballot (mine);
         uint32_t out_cum = 0, out_freq = 0, out_tot = 0;
+        // the leaf is as slow as its most frequent context: once a wave has proven to be one of those, it gets issue
+        // priority over the (many) waves of rare contexts that share its SIMD and scalar unit
+        if (!boosted && seen > 4096) { __builtin_amdgcn_s_setprio (3); boosted = true; }
+        seen += __popcll (todo);
         while (todo) {
             const int b = __ffsll ((unsigned long long)todo) - 1;
             todo &= todo - 1;
@@ -271,7 +276,9 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const GzDi
 // This reproduces RC_ShiftLow's cache / pending-0xFF bookkeeping (c_range_coder.h:70-88) exactly: that logic is just
 // a lazy form of the same addition ("[0, T1, T2, ...] plus 1 at the byte before every shift that saw a carry").
 typedef uint32_t gz_u32x4 __attribute__((vector_size (16)));
+typedef uint32_t gz_u32x16 __attribute__((vector_size (64)));
 typedef const volatile __attribute__((address_space(4))) gz_u32x4 *GzConstRecP;   // volatile: keeps the prefetch a prefetch
+typedef const volatile __attribute__((address_space(4))) gz_u32x16 *GzConstRec4P; // 4 records per load
 
 #define GZ_CHAIN_BLOCK 8
 #define GZ_CHAIN_TOUCH_AHEAD (16 * 1024)   // bytes: how far ahead of the scalar loads the vector unit pulls lines into L2
@@ -311,24 +318,24 @@ __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
     else {
         const uint32_t nb = n & ~(uint32_t)(GZ_CHAIN_BLOCK - 1);
         if (nb) {
+            GzConstRec4P rec4 = (GzConstRec4P)(uintptr_t)L.triples;
             for (uint32_t b = 0; b < GZ_CHAIN_TOUCH_AHEAD; b += 4096) sink += touch[(b >> 2) + lane * 16];   // 64 lanes x 64 B = 4 KB
-            gz_u32x4 c0 = rec[0], c1 = rec[1], c2 = rec[2], c3 = rec[3], c4 = rec[4], c5 = rec[5], c6 = rec[6], c7 = rec[7];
+            gz_u32x16 ca = rec4[0], cb = rec4[1];
             for (uint32_t i = 0; i < nb; i += GZ_CHAIN_BLOCK) {
-                const uint32_t nx = i + GZ_CHAIN_BLOCK < nb ? i + GZ_CHAIN_BLOCK : i;   // the last block re-reads itself
-                const gz_u32x4 p0 = rec[nx], p1 = rec[nx + 1], p2 = rec[nx + 2], p3 = rec[nx + 3],
-                               p4 = rec[nx + 4], p5 = rec[nx + 5], p6 = rec[nx + 6], p7 = rec[nx + 7];
+                const uint32_t nx = (i + GZ_CHAIN_BLOCK < nb ? i + GZ_CHAIN_BLOCK : i) >> 2;   // the last block re-reads itself
+                const gz_u32x16 pa = rec4[nx], pb = rec4[nx + 1];
                 if (!(i & 255)) sink += touch[((i * 16 + GZ_CHAIN_TOUCH_AHEAD) >> 2) + lane * 16];  // every 256 records = 4 KB
                 uint4 ra, rb;
-                ra.x = d_chain_step (range, c0[1], c0[2], c0[3]);
-                ra.y = d_chain_step (range, c1[1], c1[2], c1[3]);
-                ra.z = d_chain_step (range, c2[1], c2[2], c2[3]);
-                ra.w = d_chain_step (range, c3[1], c3[2], c3[3]);
-                rb.x = d_chain_step (range, c4[1], c4[2], c4[3]);
-                rb.y = d_chain_step (range, c5[1], c5[2], c5[3]);
-                rb.z = d_chain_step (range, c6[1], c6[2], c6[3]);
-                rb.w = d_chain_step (range, c7[1], c7[2], c7[3]);
+                ra.x = d_chain_step (range, ca[1],  ca[2],  ca[3]);
+                ra.y = d_chain_step (range, ca[5],  ca[6],  ca[7]);
+                ra.z = d_chain_step (range, ca[9],  ca[10], ca[11]);
+                ra.w = d_chain_step (range, ca[13], ca[14], ca[15]);
+                rb.x = d_chain_step (range, cb[1],  cb[2],  cb[3]);
+                rb.y = d_chain_step (range, cb[5],  cb[6],  cb[7]);
+                rb.z = d_chain_step (range, cb[9],  cb[10], cb[11]);
+                rb.w = d_chain_step (range, cb[13], cb[14], cb[15]);
                 if (!lane) { *(uint4 *)(rout + i) = ra; *(uint4 *)(rout + i + 4) = rb; }
-                c0 = p0; c1 = p1; c2 = p2; c3 = p3; c4 = p4; c5 = p5; c6 = p6; c7 = p7;
+                ca = pa; cb = pb;
             }
         }
         for (uint32_t i = nb; i < n; i++) {

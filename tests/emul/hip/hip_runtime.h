@@ -214,6 +214,7 @@ struct uint4 { unsigned x, y, z, w; };
 static inline uint4 make_uint4 (unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 
 static inline int __clz (unsigned v) { return v ? __builtin_clz (v) : 32; }
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
 static inline int __popcll (unsigned long long v) { return __builtin_popcountll (v); }
 static inline unsigned __umulhi (unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline long long __double_as_longlong (double d) { long long v; memcpy (&v, &d, 8); return v; }
