@@ -28,6 +28,16 @@
 
 struct GzDivMagic { uint32_t magic, shift; };   // q = ((((n - t) >> 1) + t) >> shift, t = mulhi(magic, n); divisor 1: shift = 0xff
 
+// Values loaded from the leaf table arrive through vector loads, so the compiler must assume they differ per lane and
+// turns every loop / branch on them into exec-mask code. They are wave-uniform: say so.
+__device__ static inline uint32_t d_uniform (uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane ((int)v); }
+template <typename T> __device__ static inline T *d_uniform_ptr (T *p)
+{
+    uint64_t a = (uint64_t)(uintptr_t)p;
+    uint32_t lo = d_uniform ((uint32_t)a), hi = d_uniform ((uint32_t)(a >> 32));
+    return (T *)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+
 __device__ static inline uint32_t d_readlane (uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane ((int)v, lane); }
 // (clang 22 / ROCm 7.2 has no __builtin_amdgcn_writelane; compare + select costs one more VALU op than v_writelane_b32)
 __device__ static inline uint32_t d_writelane (uint32_t val, int lane, uint32_t old) { return (int)(threadIdx.x & 63) == lane ? val : old; }
@@ -249,9 +259,12 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const GzDi
     const uint32_t ctx = blockIdx.y, ms = L.max_sym;
     const bool o1 = L.o1;
     if (o1 ? (ctx >= ms || (ctx && L.symrank[ctx] == 0xffff)) : ctx != 0) return;   // a byte that never occurs is never a context
-    uint4 *tr = (uint4 *)L.triples;
-    if (L.nsym <= 64)   d_arith_model_wave_compact (L.coded, L.coded_n, ms, o1, ctx, tr, magic_tab, L.symlist, L.nsym);
-    else if (ms <= 64)  d_arith_model_wave<1> (L.coded, L.coded_n, ms, o1, ctx, tr, magic_tab);
+    uint4 *tr = d_uniform_ptr ((uint4 *)L.triples);
+    const uint8_t *coded = d_uniform_ptr (L.coded);
+    const uint32_t n_u = d_uniform (L.coded_n), ms_u = d_uniform (ms), nsym_u = d_uniform (L.nsym);
+    const bool o1_u = d_uniform (o1 ? 1u : 0u) != 0;
+    if (nsym_u <= 64) { d_arith_model_wave_compact (coded, n_u, ms_u, o1_u, ctx, tr, magic_tab, L.symlist, nsym_u); return; }
+    if (ms <= 64)       d_arith_model_wave<1> (L.coded, L.coded_n, ms, o1, ctx, tr, magic_tab);
     else if (ms <= 128) d_arith_model_wave<2> (L.coded, L.coded_n, ms, o1, ctx, tr, magic_tab);
     else                d_arith_model_wave<4> (L.coded, L.coded_n, ms, o1, ctx, tr, magic_tab);
 }
