@@ -44,7 +44,7 @@ __device__ static inline uint32_t d_writelane (uint32_t val, int lane, uint32_t 
 
 // J = registers per lane holding the model (entries e = j*64 + lane), J*64 >= max_sym
 template <int J>
-__device__ static void d_arith_model_wave (const uint8_t *in, uint32_t n, uint32_t ms, bool o1, uint32_t ctx, uint4 *recs, const GzDivMagic *magic_tab)
+__device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, uint32_t n, uint32_t ms, bool o1, uint32_t ctx, uint4 *recs, const GzDivMagic *magic_tab)
 {
     const int lane = threadIdx.x & 63;
     uint32_t sym[J], freq[J], cum[J];
@@ -155,7 +155,9 @@ __device__ static void d_arith_model_wave (const uint8_t *in, uint32_t n, uint32
 // with such an entry (its frequency, >= 17, always beats 1): gap--, and the next present symbol's gap++. With gap 0
 // the left neighbour is the previous lane and the ordinary "swap if now larger" applies. cum includes the gaps.
 // The common case (no swap, no halving) is ~25 instructions with a single vector->scalar decision.
-__device__ static void d_arith_model_wave_compact (const uint8_t *in, uint32_t n, uint32_t ms, bool o1, uint32_t ctx,
+// (force-inlined: as a called function its arguments would arrive in vector registers and every loop on them would
+//  become exec-mask code)
+__device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t *in, uint32_t n, uint32_t ms, bool o1, uint32_t ctx,
                                                    uint4 *recs, const GzDivMagic *magic_tab, const uint8_t *symlist, uint32_t nsym)
 {
     const int lane = threadIdx.x & 63;
