@@ -80,8 +80,10 @@ struct GzdLeaf {
     uint8_t   *pay;           // entropy-coded payload area (rANS fills it from the end)
     uint32_t  *models;        // arith (run-length variant): global-memory models when they do not fit the LDS
     uint8_t   *triples;       // arith: 16 bytes per coded byte: cum | freq << 16, division magic, shift, tot  (k_arith_model -> k_arith_chain)
-    uint8_t   *events;        // arith: one 32-bit digit per output byte (k_arith_low)
-    uint8_t   *rvals;         // arith: r = range / tot of every symbol (k_arith_chain -> k_arith_low)
+    uint8_t   *events;        // arith: one 32-bit digit per output byte (k_low_replay / k_low_norm)
+    uint8_t   *rvals;         // arith: r = range / tot of every symbol (k_arith_chain -> k_low_*)
+    uint8_t   *kpos;          // arith: per 64-symbol slice: shifts in it, then (k_low_scan) shifts before it
+    uint8_t   *resid;         // arith: per slice: what is left in its 32-bit window (+ carry) after its last shift
     uint32_t  n_events;
     uint32_t  touch_sink;     // keeps the L2 prefetch loads of k_arith_chain alive
     uint32_t  pay_cap;

@@ -228,6 +228,7 @@ extern "C" uint32_t gz_codec_est_size (int codec, uint64_t len)
 struct Plan {
     std::vector<GzdStream> streams;
     std::vector<GzdLeaf>   leaves;
+    std::vector<GzdLowBlock> low_blocks;   // (leaf, first slice) of every 256-slice workgroup of the k_low_* kernels
     bool any_striped = false, any_rans = false, any_arith = false, any_arith_rle = false;
     uint32_t max_in = 0;
 };
@@ -260,6 +261,10 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
             if (!(L.triples = (uint8_t *)arena_alloc (h, ((size_t)n_bound + 64) * 16 + 2 * GZ_CHAIN_TOUCH_AHEAD + 8192))) return false;
             if (!(L.events  = (uint8_t *)arena_alloc (h, ((size_t)L.pay_cap + 128) * 4))) return false;
             if (!(L.rvals   = (uint8_t *)arena_alloc (h, ((size_t)n_bound + 64) * 4))) return false;
+            const uint32_t ns = n_bound ? (n_bound + GZ_LOW_SLICE - 1) / GZ_LOW_SLICE : 1;
+            if (!(L.kpos    = (uint8_t *)arena_alloc (h, ((size_t)ns + 2) * 4))) return false;
+            if (!(L.resid   = (uint8_t *)arena_alloc (h, ((size_t)ns + 1) * 8))) return false;
+            for (uint32_t s0 = 0; s0 < ns; s0 += GZ_LOW_WG) { GzdLowBlock b; b.leaf = (uint32_t)P.leaves.size (); b.first_slice = s0; P.low_blocks.push_back (b); }
         }
     }
     P.leaves.push_back (L);
@@ -364,7 +369,17 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
             }
             KLAUNCH (h, k_arith_model, dim3 (nl, 256), dim3 (64), 0, d_leaves, (const GzDivMagic *)h->d_magic);
             KLAUNCH (h, k_arith_chain, dim3 (nl), dim3 (64), 0, d_leaves);
-            KLAUNCH (h, k_arith_low, dim3 (nl), dim3 (GZ_LOW_NT), 8192, d_leaves);
+            if (!P.low_blocks.empty ()) {
+                void *d_lb;
+                int rc2 = upload (h, P.low_blocks.data (), P.low_blocks.size () * sizeof (GzdLowBlock), &d_lb);
+                if (rc2 != GZ_OK) return rc2;
+                const uint32_t nlb = (uint32_t)P.low_blocks.size ();
+                KLAUNCH (h, k_low_count, dim3 (nlb), dim3 (GZ_LOW_WG), 0, d_leaves, (const GzdLowBlock *)d_lb);
+                KLAUNCH (h, k_low_scan, dim3 (nl), dim3 (1024), 8192, d_leaves);
+                KLAUNCH (h, k_low_replay, dim3 (nlb), dim3 (GZ_LOW_WG), 0, d_leaves, (const GzdLowBlock *)d_lb);
+                KLAUNCH (h, k_low_resid, dim3 (nlb), dim3 (GZ_LOW_WG), 0, d_leaves, (const GzdLowBlock *)d_lb);
+                KLAUNCH (h, k_low_norm, dim3 (nl), dim3 (GZ_NORM_NT), 8192, d_leaves);
+            }
         }
         if (fork) { HIPCHK (h, hipEventRecord (h->ev_join, side)); HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_join, 0)); }
     }

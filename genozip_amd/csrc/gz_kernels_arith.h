@@ -362,117 +362,170 @@ __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
     if (!lane) L.touch_sink = sink;
 }
 
-// one 1024-thread workgroup per leaf (many short slices: the replay of a slice is a dependent load-use loop, so its
-// cost is memory latency x slice length); 8 KB of dynamic LDS
-#define GZ_LOW_NT 1024
-__global__ void __launch_bounds__(GZ_LOW_NT) k_arith_low (GzdLeaf *leaves)
+// ---- low: parallel replay over short slices ----------------------------------------------------------------------
+// A slice is 64 consecutive symbols (1 KB of records). Slices are dealt out one per thread, 256 consecutive slices of
+// one leaf per workgroup (table built by the host), so a wave walks a contiguous 64 KB window of records: every line
+// is fetched once and used completely. Five small kernels:
+//   k_low_count   shifts per slice
+//   k_low_scan    per leaf: exclusive prefix -> first output position of every slice; m = total + 5 closing shifts
+//   k_low_replay  low += cum * r from low = 0 inside the slice; every shift stores the 9-bit digit leaving the window
+//   k_low_resid   what is left in a slice's window is added onto the 4 digits that follow its last shift
+//   k_low_norm    per leaf: digits -> bytes, carries rippling left (16 digits per thread as one 128-bit add)
+#define GZ_LOW_SLICE 64
+#define GZ_LOW_WG    256
+struct GzdLowBlock { uint32_t leaf, first_slice; };
+
+__device__ static inline uint32_t d_low_nslices (uint32_t n) { return n ? (n + GZ_LOW_SLICE - 1) / GZ_LOW_SLICE : 1; }
+
+__global__ void __launch_bounds__(GZ_LOW_WG) k_low_count (GzdLeaf *leaves, const GzdLowBlock *blocks)
+{
+    const GzdLowBlock B = blocks[blockIdx.x];
+    GzdLeaf &L = leaves[B.leaf];
+    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
+    const uint32_t n = L.coded_n, slice = B.first_slice + threadIdx.x;
+    if (slice >= d_low_nslices (n)) return;
+    const uint4 *rec = (const uint4 *)L.triples;
+    const uint32_t *rv = (const uint32_t *)L.rvals;
+    const uint32_t s0 = slice * GZ_LOW_SLICE, s1 = s0 + GZ_LOW_SLICE < n ? s0 + GZ_LOW_SLICE : n;
+    uint32_t k = 0;
+    for (uint32_t i = s0; i < s1; i++) k += __clz (rv[i] * rec[i].y) >> 3;
+    ((uint32_t *)L.kpos)[slice] = k;
+}
+
+// one 1024-thread workgroup per leaf
+__global__ void __launch_bounds__(1024) k_low_scan (GzdLeaf *leaves)
 {
     GzdLeaf &L = leaves[blockIdx.x];
     if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
     const int tid = threadIdx.x;
-    const uint32_t n = L.coded_n;
-    const uint4 *rec = (const uint4 *)L.triples;
-    const uint32_t *rv = (const uint32_t *)L.rvals;
-    uint32_t *dig = (uint32_t *)L.events;          // one 32-bit digit per output byte (index 0 = the coder's initial cache byte)
-    uint8_t *out = L.pay + 1;
-    uint32_t *sh = (uint32_t *)gz_lds;             // [0..NT-1] per-thread counts / carries, [NT..] misc
-
-    // ---- slice of symbols of this thread, number of shifts in it
-    const uint32_t per = (n + GZ_LOW_NT - 1) / GZ_LOW_NT;
-    const uint32_t s0 = tid * per < n ? tid * per : n, s1 = s0 + per < n ? s0 + per : n;
-    uint32_t kcnt = 0;
-    // (a thread walks its slice 8 records = one 128-byte line at a time: the loads of a chunk are independent, so a
-    //  slice costs one memory latency per 8 symbols and every fetched line is used completely)
-    {   uint32_t i = s0;
-        for (; i + 8 <= s1; i += 8) {
-            uint32_t f[8], r[8];
-            #pragma unroll
-            for (int q = 0; q < 8; q++) { f[q] = rec[i + q].y; r[q] = rv[i + q]; }
-            #pragma unroll
-            for (int q = 0; q < 8; q++) kcnt += __clz (r[q] * f[q]) >> 3;
-        }
-        for (; i < s1; i++) kcnt += __clz (rv[i] * rec[i].y) >> 3;
-    }
-    sh[tid] = kcnt;
+    uint32_t *sh = (uint32_t *)gz_lds;
+    uint32_t *kpos = (uint32_t *)L.kpos;
+    const uint32_t ns = d_low_nslices (L.coded_n);
+    const uint32_t per = (ns + 1023) / 1024;
+    const uint32_t a = tid * per < ns ? tid * per : ns, b = a + per < ns ? a + per : ns;
+    uint32_t sum = 0;
+    for (uint32_t i = a; i < b; i++) sum += kpos[i];
+    sh[tid] = sum;
     __syncthreads ();
     if (!tid) {
         uint32_t run = 0;
-        for (int t = 0; t < GZ_LOW_NT; t++) { uint32_t c = sh[t]; sh[t] = run; run += c; }
-        sh[GZ_LOW_NT] = run + 5;                          // + RC_FinishEncode's 5 shifts
+        for (int t = 0; t < 1024; t++) { uint32_t c = sh[t]; sh[t] = run; run += c; }
+        sh[1024] = run;
     }
     __syncthreads ();
-    const uint32_t m = sh[GZ_LOW_NT];                     // output bytes (before the max_sym byte)
-    uint32_t pos = sh[tid];                         // shifts before this slice == index of the digit its next shift produces, minus 1
+    uint32_t run = sh[tid];
+    for (uint32_t i = a; i < b; i++) { uint32_t c = kpos[i]; kpos[i] = run; run += c; }
+    if (!tid) {
+        const uint32_t m = sh[1024] + 5;                      // + RC_FinishEncode's 5 shifts
+        kpos[ns] = sh[1024];
+        L.n_events = m;
+        ((uint32_t *)L.events)[0] = 0;                        // digit 0: the coder's initial cache byte
+    }
+}
 
-    // ---- zero the digits this slice owns (digit j+1 belongs to shift j; digit 0 to thread 0), then replay low
-    const uint32_t own0 = tid ? pos + 1 : 0, own1 = (tid == GZ_LOW_NT - 1 ? m : sh[tid + 1] + 1);
-    for (uint32_t j = own0; j < own1 && j < m; j++) dig[j] = 0;
-    __syncthreads ();
+__global__ void __launch_bounds__(GZ_LOW_WG) k_low_replay (GzdLeaf *leaves, const GzdLowBlock *blocks)
+{
+    const GzdLowBlock B = blocks[blockIdx.x];
+    GzdLeaf &L = leaves[B.leaf];
+    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
+    const uint32_t n = L.coded_n, slice = B.first_slice + threadIdx.x, ns = d_low_nslices (n);
+    if (slice >= ns) return;
+    const uint4 *rec = (const uint4 *)L.triples;
+    const uint32_t *rv = (const uint32_t *)L.rvals;
+    uint32_t *dig = (uint32_t *)L.events;
+    const uint32_t s0 = slice * GZ_LOW_SLICE, s1 = s0 + GZ_LOW_SLICE < n ? s0 + GZ_LOW_SLICE : n;
+    uint32_t pos = ((const uint32_t *)L.kpos)[slice];        // shifts before this slice: its next shift produces digit pos + 1
     uint64_t lowc = 0;
-    {   uint32_t i = s0;
-        for (; i + 8 <= s1; i += 8) {
-            uint4 c[8]; uint32_t r[8];
-            #pragma unroll
-            for (int q = 0; q < 8; q++) { c[q] = rec[i + q]; r[q] = rv[i + q]; }
-            #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                lowc += (uint64_t)(c[q].x * r[q]);
-                const uint32_t k = __clz (r[q] * c[q].y) >> 3;
-                for (uint32_t z = 0; z < k; z++) { dig[++pos] = (uint32_t)(lowc >> 24); lowc = (uint64_t)((uint32_t)lowc << 8); }
-            }
-        }
-        for (; i < s1; i++) {
-            const uint4 c = rec[i];
-            const uint32_t r = rv[i];
-            lowc += (uint64_t)(c.x * r);
-            const uint32_t k = __clz (r * c.y) >> 3;
-            for (uint32_t z = 0; z < k; z++) { dig[++pos] = (uint32_t)(lowc >> 24); lowc = (uint64_t)((uint32_t)lowc << 8); }
-        }
+    for (uint32_t i = s0; i < s1; i++) {
+        const uint4 c = rec[i];
+        const uint32_t r = rv[i];
+        lowc += (uint64_t)(c.x * r);
+        const uint32_t k = __clz (r * c.y) >> 3;
+        for (uint32_t z = 0; z < k; z++) { dig[++pos] = (uint32_t)(lowc >> 24); lowc = (uint64_t)((uint32_t)lowc << 8); }
     }
-    if (tid == GZ_LOW_NT - 1 || s1 == n) {
-        // the slice that ends the stream performs the 5 closing shifts (only one thread has s1 == n && s0 < n, or n == 0)
-        const bool closer = (n == 0) ? tid == 0 : (s0 < n && s1 == n);
-        if (closer) for (int q = 0; q < 5; q++) { dig[++pos] = (uint32_t)(lowc >> 24); lowc = (uint64_t)((uint32_t)lowc << 8); }
-    }
-    __threadfence_block ();
-    __syncthreads ();
-    // what is still inside this slice's window belongs to the next 4 output bytes (they are other slices' digits)
-    if (lowc) {
-        if (pos + 1 < m) atomicAdd (&dig[pos + 1], (uint32_t)(lowc >> 24));
-        if (pos + 2 < m) atomicAdd (&dig[pos + 2], (uint32_t)(lowc >> 16) & 0xff);
-        if (pos + 3 < m) atomicAdd (&dig[pos + 3], (uint32_t)(lowc >> 8) & 0xff);
-        if (pos + 4 < m) atomicAdd (&dig[pos + 4], (uint32_t)lowc & 0xff);
-    }
-    __threadfence_block ();
-    __syncthreads ();
+    if (slice == ns - 1)
+        for (int z = 0; z < 5; z++) { dig[++pos] = (uint32_t)(lowc >> 24); lowc = (uint64_t)((uint32_t)lowc << 8); }
+    ((uint64_t *)L.resid)[slice] = lowc;
+}
 
-    // ---- normalise: thread t owns output bytes [b0, b1); ripple right to left, then pass carries between slices
-    const uint32_t bper = (m + GZ_LOW_NT - 1) / GZ_LOW_NT;
-    const uint32_t b0 = tid * bper < m ? tid * bper : m, b1 = b0 + bper < m ? b0 + bper : m;
-    uint32_t carry = 0;
-    for (uint32_t j = b1; j-- > b0; ) { const uint32_t v = dig[j] + carry; out[j] = (uint8_t)v; carry = v >> 8; }
-    sh[tid] = carry;
+__global__ void __launch_bounds__(GZ_LOW_WG) k_low_resid (GzdLeaf *leaves, const GzdLowBlock *blocks)
+{
+    const GzdLowBlock B = blocks[blockIdx.x];
+    GzdLeaf &L = leaves[B.leaf];
+    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
+    const uint32_t slice = B.first_slice + threadIdx.x, ns = d_low_nslices (L.coded_n);
+    if (slice >= ns) return;
+    const uint64_t lowc = ((const uint64_t *)L.resid)[slice];
+    if (!lowc) return;
+    uint32_t *dig = (uint32_t *)L.events;
+    const uint32_t m = L.n_events;
+    const uint32_t pos = slice == ns - 1 ? m - 1 : ((const uint32_t *)L.kpos)[slice + 1];   // last digit this slice produced
+    if (pos + 1 < m) atomicAdd (&dig[pos + 1], (uint32_t)(lowc >> 24));
+    if (pos + 2 < m) atomicAdd (&dig[pos + 2], (uint32_t)(lowc >> 16) & 0xff);
+    if (pos + 3 < m) atomicAdd (&dig[pos + 3], (uint32_t)(lowc >> 8) & 0xff);
+    if (pos + 4 < m) atomicAdd (&dig[pos + 4], (uint32_t)lowc & 0xff);
+}
+
+// one 1024-thread workgroup per leaf. Tiles of 1024 x 16 digits are normalised from the end of the stream towards
+// its start; a thread turns its 16 digits into 16 bytes (a 128-bit big-endian number in 4 words) plus a carry-out,
+// carries then move one thread to the left per round as a 128-bit add until none is left (normally one round).
+#define GZ_NORM_NT 1024
+#define GZ_NORM_PER 16
+__global__ void __launch_bounds__(GZ_NORM_NT) k_low_norm (GzdLeaf *leaves)
+{
+    GzdLeaf &L = leaves[blockIdx.x];
+    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
+    const int tid = threadIdx.x;
+    const uint32_t m = L.n_events;
+    const uint32_t *dig = (const uint32_t *)L.events;
+    uint8_t *out = L.pay + 1;
+    uint32_t *sh = (uint32_t *)gz_lds;              // [0..NT] carries, [NT+8] "any carry left", [NT+9] carry into the next tile
+    const uint32_t tile = GZ_NORM_NT * GZ_NORM_PER;
+    const uint32_t ntiles = (m + tile - 1) / tile;
+    if (!tid) sh[GZ_NORM_NT + 9] = 0;
     __syncthreads ();
-    for (int round = 0; round < GZ_LOW_NT; round++) {
-        uint32_t cin = (tid < GZ_LOW_NT - 1) ? sh[tid + 1] : 0;
-        if (b1 >= m) cin = 0;
-        __syncthreads ();
-        uint32_t cout = 0;
-        if (cin && b1 > b0) {
-            uint32_t c = cin;
-            for (uint32_t j = b1; c && j-- > b0; ) { const uint32_t v = out[j] + c; out[j] = (uint8_t)v; c = v >> 8; }
-            cout = c;
+    for (uint32_t t = ntiles; t-- > 0; ) {
+        const uint32_t b0 = t * tile + tid * GZ_NORM_PER;
+        uint32_t w[4] = { 0, 0, 0, 0 };             // w[0] most significant: bytes b0..b0+3
+        uint32_t carry = 0;
+        #pragma unroll
+        for (int j = GZ_NORM_PER - 1; j >= 0; j--) {
+            const uint32_t idx = b0 + j;
+            const uint32_t v = (idx < m ? dig[idx] : 0u) + carry;
+            w[j >> 2] |= (v & 0xff) << (8 * (3 - (j & 3)));
+            carry = v >> 8;
         }
-        else if (cin) cout = cin;                     // empty slice: hand it on
-        sh[tid] = cout;
-        sh[GZ_LOW_NT + 8] = 0;
+        // carries move one thread to the left per round. sh[t] = carry out of thread t (read by thread t-1);
+        // sh[NT] = carry coming in from the tile to the right; thread 0's carries leave the tile (tile_out).
+        uint32_t tile_out = carry;                   // meaningful in thread 0 only
+        sh[tid] = carry;
+        if (!tid) sh[GZ_NORM_NT] = sh[GZ_NORM_NT + 9];
         __syncthreads ();
-        if (cout) sh[GZ_LOW_NT + 8] = 1;
+        for (int round = 0; round < GZ_NORM_NT + 1; round++) {
+            const uint32_t cin = sh[tid + 1];
+            __syncthreads ();
+            uint64_t a3 = (uint64_t)w[3] + cin;        w[3] = (uint32_t)a3;
+            uint64_t a2 = (uint64_t)w[2] + (a3 >> 32); w[2] = (uint32_t)a2;
+            uint64_t a1 = (uint64_t)w[1] + (a2 >> 32); w[1] = (uint32_t)a1;
+            uint64_t a0 = (uint64_t)w[0] + (a1 >> 32); w[0] = (uint32_t)a0;
+            const uint32_t cout = (uint32_t)(a0 >> 32);
+            sh[tid] = cout;
+            if (!tid) { tile_out += cout; sh[GZ_NORM_NT] = 0; sh[GZ_NORM_NT + 8] = 0; }
+            __syncthreads ();
+            if (tid && cout) sh[GZ_NORM_NT + 8] = 1;
+            __syncthreads ();
+            if (!sh[GZ_NORM_NT + 8]) break;
+        }
+        if (!tid) sh[GZ_NORM_NT + 9] = tile_out;
+        #pragma unroll
+        for (int j = 0; j < GZ_NORM_PER; j++) {
+            const uint32_t idx = b0 + j;
+            if (idx < m) out[idx] = (uint8_t)(w[j >> 2] >> (8 * (3 - (j & 3))));
+        }
         __syncthreads ();
-        if (!sh[GZ_LOW_NT + 8]) break;
     }
     if (!tid) {
-        L.pay[0] = (uint8_t)(n ? L.max_sym : 1);                          // max_sym + 1 (256 wraps to 0), arith_dynamic.c:103-108
+        L.pay[0] = (uint8_t)(L.coded_n ? L.max_sym : 1);                 // max_sym + 1 (256 wraps to 0), arith_dynamic.c:103-108
         if (m + 1 > L.pay_cap) { L.overflow = 1; L.pay_len = 0; }        // cannot happen: pay_cap >= 2n + 64
         else L.pay_len = m + 1;
         L.tab_len = 0;

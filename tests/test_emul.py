@@ -30,3 +30,14 @@ def test_emul_local(emul_engine, oracle):
 
 def test_emul_vblocks(emul_engine, oracle):
     parity.vblocks(emul_engine, oracle, 3, 6000)
+
+
+def test_emul_arith_long_streams(emul_engine, oracle):
+    """long enough for several 16384-byte normalisation tiles and thousands of 64-symbol replay slices"""
+    from genozip_amd import synth
+    items = [(16, synth.markov_bytes(3, 70000, 40, 33).tobytes()), (16, synth.uniform_bytes(4, 50000, 7).tobytes()),
+             (18, synth.skewed_bytes(5, 90000, 4, 0.3).tobytes()), (17, synth.u32be_increasing(6, 80000).tobytes()),
+             (16, bytes(60000)), (16, synth.skewed_bytes(7, 120000, 2, 0.02).tobytes())]
+    got = emul_engine.compress_many(items)
+    for (c, d), g in zip(items, got):
+        assert g == oracle.codec_compress(c, d), (c, len(d))
