@@ -154,22 +154,80 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
 // symbol just remembers how many of them sit directly in front of it (`gap`). Coding a symbol whose gap is > 0 swaps it
 // with such an entry (its frequency, >= 17, always beats 1): gap--, and the next present symbol's gap++. With gap 0
 // the left neighbour is the previous lane and the ordinary "swap if now larger" applies. cum includes the gaps.
-// The common case (no swap, no halving) is ~25 instructions with a single vector->scalar decision.
+//
+// Two ways through the occurrences of a 64-position chunk:
+//  * one at a time (d_model_serial_step) - ~45 instructions and two vector->scalar decisions per occurrence;
+//  * as a batch: as long as no occurrence causes a structural change (a swap, a halving), the triples of ALL the
+//    chunk's occurrences follow from the current model plus prefix counts inside the chunk:
+//        freq_j = F[p_j] + 16 * #{i < j : p_i == p_j}      cum_j = C[p_j] + 16 * #{i < j : p_i < p_j}
+//        tot_j  = tot + 16 * j                              (p = list position of the occurrence's symbol)
+//    and whether occurrence j would swap needs only the left neighbour's frequency at that time,
+//    FL[p_j] + 16 * #{i < j : p_i == p_j - 1}. The lanes that own the positions fetch F, C, gap, FL with cross-lane
+//    reads (the symbol -> list position map `where` is kept per static rank), a short loop over the occurrences
+//    accumulates the counts with pure vector instructions, the longest valid prefix is accepted in one go, and only
+//    the first occurrence that changes the structure (if any) takes the one-at-a-time path.
+struct GzModelLane { uint32_t sym, srank, freq, cum, gap, where; };
+
+__device__ static __forceinline__ void d_model_serial_step (GzModelLane &M, uint32_t &tot, int lane, int r, uint32_t nsym, uint32_t n_absent)
+{
+    const bool me = lane == r;
+    // bump
+    M.freq += me ? GZ_MODEL_STEP : 0u;
+    M.cum  += lane > r ? GZ_MODEL_STEP : 0u;
+    tot    += GZ_MODEL_STEP;
+    if (tot > GZ_MODEL_LIMIT) {                                  // rare: halve, rebuild tot and cum
+        M.freq -= M.freq >> 1;
+        uint32_t run = 0, fsum = 0;
+        for (uint32_t l = 0; l < nsym; l++) {
+            run += d_readlane (M.gap, (int)l);
+            M.cum = d_writelane (run, (int)l, M.cum);
+            const uint32_t fq = d_readlane (M.freq, (int)l);
+            run += fq; fsum += fq;
+        }
+        tot = fsum + n_absent;                                   // every absent entry still weighs 1
+    }
+    // one bubble step to the left (c_simple_model.h:139-145)
+    const uint32_t f_now = d_readlane (M.freq, r);
+    const bool over_absent = me && M.gap > 0;
+    const bool over_left = (lane == r - 1) && M.freq < f_now;
+    if (__ballot (over_absent || over_left)) {
+        const uint32_t g = d_readlane (M.gap, r);
+        if (g > 0) {
+            M.gap += me ? 0xffffffffu : (lane == r + 1 ? 1u : 0u);  // the absent entry hops over: mine - 1, next + 1
+            M.cum += me ? 0xffffffffu : 0u;
+        }
+        else {
+            const int q = r - 1;
+            const uint32_t fl = d_readlane (M.freq, q), sl = d_readlane (M.sym, q), cl = d_readlane (M.cum, q), gl = d_readlane (M.gap, q);
+            const uint32_t rs = d_readlane (M.srank, r), rl = d_readlane (M.srank, q), s = d_readlane (M.sym, r);
+            const bool at_q = lane == q;
+            M.sym   = at_q ? s : (me ? sl : M.sym);
+            M.srank = at_q ? rs : (me ? rl : M.srank);
+            M.freq  = at_q ? f_now : (me ? fl : M.freq);
+            M.gap   = at_q ? gl : (me ? 0u : M.gap);
+            M.cum   = me ? cl + f_now : M.cum;                   // lane q keeps its cumulative
+            M.where = lane == (int)rs ? (uint32_t)q : (lane == (int)rl ? (uint32_t)r : M.where);
+        }
+    }
+}
+
 // (force-inlined: as a called function its arguments would arrive in vector registers and every loop on them would
 //  become exec-mask code)
 __device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t *in, uint32_t n, uint32_t ms, bool o1, uint32_t ctx,
-                                                   uint4 *recs, const GzDivMagic *magic_tab, const uint8_t *symlist, uint32_t nsym)
+                                                   uint4 *recs, const GzDivMagic *magic_tab, const uint8_t *symlist,
+                                                   const uint16_t *symrank, uint32_t nsym)
 {
     const int lane = threadIdx.x & 63;
     const bool live = (uint32_t)lane < nsym;
-    uint32_t sym = live ? symlist[lane] : 0xffffffffu;
-    uint32_t prev_sym = (live && lane) ? symlist[lane - 1] : 0xffffffffu;
-    uint32_t gap = live ? (lane ? sym - prev_sym - 1 : sym) : 0;
-    uint32_t freq = live ? 1 : 0;
-    uint32_t cum = live ? sym : ms;                       // lane entries + absent entries before it == its byte value
+    GzModelLane M;
+    M.sym = live ? symlist[lane] : 0xffffffffu;
+    const uint32_t prev_sym = (live && lane) ? symlist[lane - 1] : 0xffffffffu;
+    M.gap = live ? (lane ? M.sym - prev_sym - 1 : M.sym) : 0;
+    M.freq = live ? 1 : 0;
+    M.cum = live ? M.sym : ms;                            // lane entries + absent entries before it == its byte value
+    M.srank = lane; M.where = lane;
     uint32_t tot = ms;
     const uint32_t n_absent = ms - nsym;
-    uint32_t seen = 0; bool boosted = false;
 
     uint32_t nx_s[4], nx_p[4];
     #pragma unroll
@@ -193,60 +251,57 @@ __device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t
         const uint32_t base = gbase + k * 64;
         if (base >= n) break;
         const uint32_t pos = base + lane;
-        const uint32_t s_v = cs[k];
         const bool mine = pos < n && (!o1 || cp[k] == ctx);
         uint64_t todo = __ballot (mine);
+        if (!todo) continue;
+        const uint32_t rk = mine ? symrank[cs[k]] : 0;             // static rank of my position's symbol
         uint32_t out_cum = 0, out_freq = 0, out_tot = 0;
-        // the leaf is as slow as its most frequent context: once a wave has proven to be one of those, it gets issue
-        // priority over the (many) waves of rare contexts that share its SIMD and scalar unit
-        if (!boosted && seen > 4096) { __builtin_amdgcn_s_setprio (3); boosted = true; }
-        seen += __popcll (todo);
         while (todo) {
+            if (__popcll (todo) >= 3) {
+                // ---- batch attempt over the pending occurrences
+                const bool occ = (todo >> lane) & 1;
+                const uint32_t p  = (uint32_t)__shfl ((int)M.where, (int)rk);
+                const uint32_t F  = (uint32_t)__shfl ((int)M.freq, (int)p), Cm = (uint32_t)__shfl ((int)M.cum, (int)p);
+                const uint32_t G  = (uint32_t)__shfl ((int)M.gap, (int)p);
+                const uint32_t FL = (uint32_t)__shfl ((int)M.freq, (int)(p ? p - 1 : 0));
+                uint32_t eq = 0, lt = 0, eql = 0;
+                for (uint64_t it = todo; it; it &= it - 1) {
+                    const int i = __ffsll ((unsigned long long)it) - 1;
+                    const uint32_t pi = d_readlane (p, i);
+                    const bool later = lane > i;
+                    eq  += (later && pi == p) ? 1u : 0u;
+                    lt  += (later && pi < p) ? 1u : 0u;
+                    eql += (later && pi + 1 == p) ? 1u : 0u;
+                }
+                const uint32_t idx = __popcll (todo & ((1ull << lane) - 1));
+                const uint32_t f = F + GZ_MODEL_STEP * eq, cu = Cm + GZ_MODEL_STEP * lt, fl = FL + GZ_MODEL_STEP * eql;
+                const uint32_t tj = tot + GZ_MODEL_STEP * idx;
+                const bool bad = occ && (G != 0 || (p > 0 && f + GZ_MODEL_STEP > fl) || tj + GZ_MODEL_STEP > GZ_MODEL_LIMIT);
+                const uint64_t badm = __ballot (bad);
+                const uint64_t acc = badm ? (todo & ((1ull << (__ffsll ((unsigned long long)badm) - 1)) - 1)) : todo;
+                if (acc) {
+                    if ((acc >> lane) & 1) { out_cum = cu; out_freq = f; out_tot = tj; }
+                    uint32_t ceq = 0, clt = 0;
+                    for (uint64_t it = acc; it; it &= it - 1) {
+                        const uint32_t pi = d_readlane (p, __ffsll ((unsigned long long)it) - 1);
+                        ceq += (pi == (uint32_t)lane) ? 1u : 0u;
+                        clt += (pi < (uint32_t)lane) ? 1u : 0u;
+                    }
+                    M.freq += GZ_MODEL_STEP * ceq;
+                    M.cum  += GZ_MODEL_STEP * clt;
+                    tot    += GZ_MODEL_STEP * (uint32_t)__popcll (acc);
+                    todo &= ~acc;
+                    if (!todo) break;
+                }
+            }
+            // ---- one occurrence the ordinary way: the first pending one
             const int b = __ffsll ((unsigned long long)todo) - 1;
             todo &= todo - 1;
-            const uint32_t s = d_readlane (s_v, b);
-            const bool me = sym == s;                                    // exactly one lane
-            const int r = __ffsll ((unsigned long long)__ballot (me)) - 1;
-            const uint32_t f = d_readlane (freq, r), cu = d_readlane (cum, r);
+            const int r = (int)d_readlane (M.where, (int)d_readlane (rk, b));
+            const uint32_t f = d_readlane (M.freq, r), cu = d_readlane (M.cum, r);
             const bool owner = lane == b;
             out_cum = owner ? cu : out_cum; out_freq = owner ? f : out_freq; out_tot = owner ? tot : out_tot;
-            // bump
-            freq += me ? GZ_MODEL_STEP : 0u;
-            cum  += lane > r ? GZ_MODEL_STEP : 0u;
-            tot  += GZ_MODEL_STEP;
-            if (tot > GZ_MODEL_LIMIT) {                                  // rare: halve, rebuild tot and cum
-                freq -= freq >> 1;
-                uint32_t run = 0;
-                for (uint32_t l = 0; l < nsym; l++) {
-                    run += d_readlane (gap, (int)l);
-                    cum = d_writelane (run, (int)l, cum);
-                    run += d_readlane (freq, (int)l);
-                }
-                uint32_t fsum = 0;
-                for (uint32_t l = 0; l < nsym; l++) fsum += d_readlane (freq, (int)l);
-                tot = fsum + n_absent;                                   // every absent entry still weighs 1
-            }
-            // one bubble step to the left (c_simple_model.h:139-145)
-            const uint32_t f_now = d_readlane (freq, r);
-            const bool over_absent = me && gap > 0;
-            const bool over_left = (lane == r - 1) && freq < f_now;
-            const uint64_t chg = __ballot (over_absent || over_left);
-            if (chg) {
-                const uint32_t g = d_readlane (gap, r);
-                if (g > 0) {
-                    gap += me ? 0xffffffffu : (lane == r + 1 ? 1u : 0u);  // the absent entry hops over: mine - 1, next + 1
-                    cum += me ? 0xffffffffu : 0u;
-                }
-                else {
-                    const int q = r - 1;
-                    const uint32_t fl = d_readlane (freq, q), sl = d_readlane (sym, q), cl = d_readlane (cum, q), gl = d_readlane (gap, q);
-                    const bool at_q = lane == q;
-                    sym  = at_q ? s : (me ? sl : sym);
-                    freq = at_q ? f_now : (me ? fl : freq);
-                    gap  = at_q ? gl : (me ? 0u : gap);
-                    cum  = me ? cl + f_now : cum;                        // lane q keeps its cumulative
-                }
-            }
+            d_model_serial_step (M, tot, lane, r, nsym, n_absent);
         }
         if (mine) { GzDivMagic mg = magic_tab[out_tot]; recs[pos] = make_uint4 (out_cum, out_freq, mg.magic, mg.shift); }
       }
@@ -265,7 +320,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const GzDi
     const uint8_t *coded = d_uniform_ptr (L.coded);
     const uint32_t n_u = d_uniform (L.coded_n), ms_u = d_uniform (ms), nsym_u = d_uniform (L.nsym);
     const bool o1_u = d_uniform (o1 ? 1u : 0u) != 0;
-    if (nsym_u <= 64) { d_arith_model_wave_compact (coded, n_u, ms_u, o1_u, ctx, tr, magic_tab, L.symlist, nsym_u); return; }
+    if (nsym_u <= 64) { d_arith_model_wave_compact (coded, n_u, ms_u, o1_u, ctx, tr, magic_tab, L.symlist, L.symrank, nsym_u); return; }
     if (ms <= 64)       d_arith_model_wave<1> (L.coded, L.coded_n, ms, o1, ctx, tr, magic_tab);
     else if (ms <= 128) d_arith_model_wave<2> (L.coded, L.coded_n, ms, o1, ctx, tr, magic_tab);
     else                d_arith_model_wave<4> (L.coded, L.coded_n, ms, o1, ctx, tr, magic_tab);

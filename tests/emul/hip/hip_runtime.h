@@ -206,6 +206,7 @@ static inline int emu_shfl (int v, int src)
     return r;
 }
 #define __builtin_amdgcn_readlane(v, lane) emu_shfl ((v), (lane))
+#define __shfl(v, lane) emu_shfl ((v), (lane))
 #define __builtin_amdgcn_readfirstlane(v) emu_shfl ((v), 0)
 static inline int __ffsll (unsigned long long v) { return __builtin_ffsll ((long long)v); }
 struct uint2 { unsigned x, y; };
