@@ -228,6 +228,7 @@ __device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t
     M.srank = lane; M.where = lane;
     uint32_t tot = ms;
     const uint32_t n_absent = ms - nsym;
+    uint32_t b_try = 0, b_acc = 0; bool batch_on = true;
 
     uint32_t nx_s[4], nx_p[4];
     #pragma unroll
@@ -257,8 +258,9 @@ __device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t
         const uint32_t rk = mine ? symrank[cs[k]] : 0;             // static rank of my position's symbol
         uint32_t out_cum = 0, out_freq = 0, out_tot = 0;
         while (todo) {
-            if (__popcll (todo) >= 3) {
+            if (batch_on && __popcll (todo) >= 3) {
                 // ---- batch attempt over the pending occurrences
+                b_try++;
                 const bool occ = (todo >> lane) & 1;
                 const uint32_t p  = (uint32_t)__shfl ((int)M.where, (int)rk);
                 const uint32_t F  = (uint32_t)__shfl ((int)M.freq, (int)p), Cm = (uint32_t)__shfl ((int)M.cum, (int)p);
@@ -290,9 +292,12 @@ __device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t
                     M.freq += GZ_MODEL_STEP * ceq;
                     M.cum  += GZ_MODEL_STEP * clt;
                     tot    += GZ_MODEL_STEP * (uint32_t)__popcll (acc);
+                    b_acc  += (uint32_t)__popcll (acc);
                     todo &= ~acc;
                     if (!todo) break;
                 }
+                // data whose neighbouring symbols keep overtaking each other (ties) defeats batching: stop trying
+                if (b_try >= 16 && b_acc < 2 * b_try) batch_on = false;
             }
             // ---- one occurrence the ordinary way: the first pending one
             const int b = __ffsll ((unsigned long long)todo) - 1;
