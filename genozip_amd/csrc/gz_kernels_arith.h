@@ -228,7 +228,7 @@ __device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t
     M.srank = lane; M.where = lane;
     uint32_t tot = ms;
     const uint32_t n_absent = ms - nsym;
-    uint32_t b_try = 0, b_acc = 0; bool batch_on = true;
+    uint32_t b_try = 0, b_acc = 0, cool = 0; bool batch_on = true;
 
     uint32_t nx_s[4], nx_p[4];
     #pragma unroll
@@ -297,9 +297,10 @@ __device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t
                     if (!todo) break;
                 }
                 // data whose neighbouring symbols keep overtaking each other (ties) defeats batching: stop trying
-                if (b_try >= 16 && b_acc < 2 * b_try) batch_on = false;
+                if (b_try >= 16) { if (b_acc < 2 * b_try) { batch_on = false; cool = 0; } b_try = b_acc = 0; }
             }
             // ---- one occurrence the ordinary way: the first pending one
+            if (!batch_on && ++cool >= 1024) batch_on = true;            // the model settles (warm-up swaps end): try again later
             const int b = __ffsll ((unsigned long long)todo) - 1;
             todo &= todo - 1;
             const int r = (int)d_readlane (M.where, (int)d_readlane (rk, b));
