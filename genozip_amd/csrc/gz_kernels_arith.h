@@ -266,14 +266,18 @@ __device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t
                 const uint32_t F  = (uint32_t)__shfl ((int)M.freq, (int)p), Cm = (uint32_t)__shfl ((int)M.cum, (int)p);
                 const uint32_t G  = (uint32_t)__shfl ((int)M.gap, (int)p);
                 const uint32_t FL = (uint32_t)__shfl ((int)M.freq, (int)(p ? p - 1 : 0));
+                // prefix counts, one round per DISTINCT list position among the pending occurrences (a run of equal
+                // symbols - the common case in binned qualities - costs one round, not one per occurrence)
                 uint32_t eq = 0, lt = 0, eql = 0;
-                for (uint64_t it = todo; it; it &= it - 1) {
-                    const int i = __ffsll ((unsigned long long)it) - 1;
-                    const uint32_t pi = d_readlane (p, i);
-                    const bool later = lane > i;
-                    eq  += (later && pi == p) ? 1u : 0u;
-                    lt  += (later && pi < p) ? 1u : 0u;
-                    eql += (later && pi + 1 == p) ? 1u : 0u;
+                const uint64_t below = (1ull << lane) - 1;
+                for (uint64_t rem = todo; rem; ) {
+                    const uint32_t q = d_readlane (p, __ffsll ((unsigned long long)rem) - 1);
+                    const uint64_t mb = __ballot (occ && p == q);           // occurrences of the symbol at position q
+                    rem &= ~mb;
+                    const uint32_t before = (uint32_t)__popcll (mb & below);   // ... that precede me
+                    eq  += (q == p) ? before : 0u;
+                    lt  += (q < p) ? before : 0u;
+                    eql += (q + 1 == p) ? before : 0u;
                 }
                 const uint32_t idx = __popcll (todo & ((1ull << lane) - 1));
                 const uint32_t f = F + GZ_MODEL_STEP * eq, cu = Cm + GZ_MODEL_STEP * lt, fl = FL + GZ_MODEL_STEP * eql;
@@ -284,10 +288,13 @@ __device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t
                 if (acc) {
                     if ((acc >> lane) & 1) { out_cum = cu; out_freq = f; out_tot = tj; }
                     uint32_t ceq = 0, clt = 0;
-                    for (uint64_t it = acc; it; it &= it - 1) {
-                        const uint32_t pi = d_readlane (p, __ffsll ((unsigned long long)it) - 1);
-                        ceq += (pi == (uint32_t)lane) ? 1u : 0u;
-                        clt += (pi < (uint32_t)lane) ? 1u : 0u;
+                    for (uint64_t rem = acc; rem; ) {
+                        const uint32_t q = d_readlane (p, __ffsll ((unsigned long long)rem) - 1);
+                        const uint64_t mb = __ballot (occ && p == q) & acc;
+                        rem &= ~mb;
+                        const uint32_t cnt = (uint32_t)__popcll (mb);
+                        ceq += (q == (uint32_t)lane) ? cnt : 0u;
+                        clt += (q < (uint32_t)lane) ? cnt : 0u;
                     }
                     M.freq += GZ_MODEL_STEP * ceq;
                     M.cum  += GZ_MODEL_STEP * clt;
