@@ -1,0 +1,21 @@
+// gz_intrin.h -- the few places where plain HIP C++ cannot express the instruction we want.
+// (tests/emul/gz_intrin.h provides the same functions in portable C++ for the CPU-emulated test build.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint32_t gz_sgpr4 __attribute__((ext_vector_type(4)));
+
+// four wave-uniform dwords to a wave-uniform, 16-byte aligned address with ONE scalar instruction (s_store_dwordx4)
+// instead of 4 v_mov + an exec-masked vector store. The values must be scalar (SALU results).
+__device__ static inline void gz_scalar_store4 (uint32_t *dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    gz_sgpr4 v = { a, b, c, d };
+    asm volatile ("s_store_dwordx4 %0, %1, 0x0" : : "s"(v), "s"(dst) : "memory");
+}
+
+// scalar stores sit in the scalar data cache: write it back before anybody else (a later kernel) reads the data
+__device__ static inline void gz_scalar_store_flush (void)
+{
+    asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" : : : "memory");
+}

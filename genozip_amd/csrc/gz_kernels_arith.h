@@ -22,6 +22,7 @@
 #pragma once
 #include "gz_device.h"
 #include "gz_devutil.h"
+#include <gz_intrin.h>
 
 #define GZ_MODEL_LIMIT 65519u          // MAX_FREQ (c_simple_model.h:63)
 #define GZ_MODEL_STEP  16u
@@ -408,16 +409,16 @@ __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
                 const uint32_t nx = (i + GZ_CHAIN_BLOCK < nb ? i + GZ_CHAIN_BLOCK : i) >> 2;   // the last block re-reads itself
                 const gz_u32x16 pa = rec4[nx], pb = rec4[nx + 1];
                 if (!(i & 255)) sink += touch[((i * 16 + GZ_CHAIN_TOUCH_AHEAD) >> 2) + lane * 16];  // every 256 records = 4 KB
-                uint4 ra, rb;
-                ra.x = d_chain_step (range, ca[1],  ca[2],  ca[3]);
-                ra.y = d_chain_step (range, ca[5],  ca[6],  ca[7]);
-                ra.z = d_chain_step (range, ca[9],  ca[10], ca[11]);
-                ra.w = d_chain_step (range, ca[13], ca[14], ca[15]);
-                rb.x = d_chain_step (range, cb[1],  cb[2],  cb[3]);
-                rb.y = d_chain_step (range, cb[5],  cb[6],  cb[7]);
-                rb.z = d_chain_step (range, cb[9],  cb[10], cb[11]);
-                rb.w = d_chain_step (range, cb[13], cb[14], cb[15]);
-                if (!lane) { *(uint4 *)(rout + i) = ra; *(uint4 *)(rout + i + 4) = rb; }
+                const uint32_t r0 = d_chain_step (range, ca[1],  ca[2],  ca[3]);
+                const uint32_t r1 = d_chain_step (range, ca[5],  ca[6],  ca[7]);
+                const uint32_t r2 = d_chain_step (range, ca[9],  ca[10], ca[11]);
+                const uint32_t r3 = d_chain_step (range, ca[13], ca[14], ca[15]);
+                gz_scalar_store4 (rout + i, r0, r1, r2, r3);             // the chain never touches the vector unit
+                const uint32_t r4 = d_chain_step (range, cb[1],  cb[2],  cb[3]);
+                const uint32_t r5 = d_chain_step (range, cb[5],  cb[6],  cb[7]);
+                const uint32_t r6 = d_chain_step (range, cb[9],  cb[10], cb[11]);
+                const uint32_t r7 = d_chain_step (range, cb[13], cb[14], cb[15]);
+                gz_scalar_store4 (rout + i + 4, r4, r5, r6, r7);
                 ca = pa; cb = pb;
             }
         }
@@ -427,6 +428,7 @@ __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
             if (!lane) rout[i] = r;
         }
     }
+    gz_scalar_store_flush ();
     if (!lane) L.touch_sink = sink;
 }
 

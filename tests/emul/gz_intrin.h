@@ -1,0 +1,9 @@
+// tests/emul/gz_intrin.h -- TEST INFRASTRUCTURE: portable stand-ins for genozip_amd/csrc/gz_intrin.h
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+static inline void gz_scalar_store4 (uint32_t *dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    if (emu.cur % 64 == 0) { dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d; }
+}
+static inline void gz_scalar_store_flush (void) {}
