@@ -263,8 +263,8 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
             if (!(L.rvals   = (uint8_t *)arena_alloc (h, ((size_t)n_bound + 64) * 4))) return false;
             const uint32_t ns = n_bound ? (n_bound + GZ_LOW_SLICE - 1) / GZ_LOW_SLICE : 1;
             if (!(L.kpos    = (uint8_t *)arena_alloc (h, ((size_t)ns + 2) * 4))) return false;
-            if (!(L.resid   = (uint8_t *)arena_alloc (h, ((size_t)ns + 1) * 8))) return false;
-            for (uint32_t s0 = 0; s0 < ns; s0 += GZ_LOW_WG) { GzdLowBlock b; b.leaf = (uint32_t)P.leaves.size (); b.first_slice = s0; P.low_blocks.push_back (b); }
+            if (!(L.resid   = (uint8_t *)arena_alloc (h, ((size_t)ns + 1) * 16))) return false;
+            for (uint32_t s0 = 0; s0 < ns; s0 += GZ_LOW_SLICES_PER_WG) { GzdLowBlock b; b.leaf = (uint32_t)P.leaves.size (); b.first_slice = s0; P.low_blocks.push_back (b); }
         }
     }
     P.leaves.push_back (L);
@@ -376,7 +376,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 const uint32_t nlb = (uint32_t)P.low_blocks.size ();
                 KLAUNCH (h, k_low_count, dim3 (nlb), dim3 (GZ_LOW_WG), 0, d_leaves, (const GzdLowBlock *)d_lb);
                 KLAUNCH (h, k_low_scan, dim3 (nl), dim3 (1024), 8192, d_leaves);
-                KLAUNCH (h, k_low_replay, dim3 (nlb), dim3 (GZ_LOW_WG), 0, d_leaves, (const GzdLowBlock *)d_lb);
+                KLAUNCH (h, k_low_scatter, dim3 (nlb), dim3 (GZ_LOW_WG), 4 * 144 * 4, d_leaves, (const GzdLowBlock *)d_lb);
                 KLAUNCH (h, k_low_resid, dim3 (nlb), dim3 (GZ_LOW_WG), 0, d_leaves, (const GzdLowBlock *)d_lb);
                 KLAUNCH (h, k_low_norm, dim3 (nl), dim3 (GZ_NORM_NT), 8192, d_leaves);
             }

@@ -432,17 +432,21 @@ __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
     if (!lane) L.touch_sink = sink;
 }
 
-// ---- low: parallel replay over short slices ----------------------------------------------------------------------
-// A slice is 64 consecutive symbols (1 KB of records). Slices are dealt out one per thread, 256 consecutive slices of
-// one leaf per workgroup (table built by the host), so a wave walks a contiguous 64 KB window of records: every line
-// is fetched once and used completely. Five small kernels:
-//   k_low_count   shifts per slice
-//   k_low_scan    per leaf: exclusive prefix -> first output position of every slice; m = total + 5 closing shifts
-//   k_low_replay  low += cum * r from low = 0 inside the slice; every shift stores the 9-bit digit leaving the window
-//   k_low_resid   what is left in a slice's window is added onto the 4 digits that follow its last shift
-//   k_low_norm    per leaf: digits -> bytes, carries rippling left (16 digits per thread as one 128-bit add)
+// ---- low: a big-number sum, one thread per symbol -----------------------------------------------------------------
+// Symbol i adds a_i = cum_i * r_i into the 32-bit window of `low` after P_i bytes have left it (P = prefix sum of the
+// per-symbol shift counts k_i = clz(r_i * freq_i) / 8). In the output stream (byte 0 = the coder's initial cache byte)
+// that is: the four bytes of a_i are added at bytes P_i+1 .. P_i+4. Nothing else happens to low, so the whole thing is
+//   k_low_count    one wave per 64-symbol slice (lane = symbol, coalesced): shifts in the slice = two ballots
+//   k_low_scan     per leaf: exclusive prefix over the slices; m = total + 5 closing shifts
+//   k_low_scatter  one wave per slice: P_i inside the slice again from two ballots; the lanes add their four bytes into
+//                  a small LDS accumulator; the digits the slice owns are stored, the (up to 4) that spill into the
+//                  following slices' digits are kept aside ...
+//   k_low_resid    ... and added there
+//   k_low_norm     per leaf: digits (which may exceed 255 by far: consecutive symbols without a shift pile up on the same
+//                  bytes) -> bytes, carries rippling left (16 digits per thread as one 128-bit add)
 #define GZ_LOW_SLICE 64
 #define GZ_LOW_WG    256
+#define GZ_LOW_SLICES_PER_WG 64          // each of the 4 waves of a workgroup walks 16 slices
 struct GzdLowBlock { uint32_t leaf, first_slice; };
 
 __device__ static inline uint32_t d_low_nslices (uint32_t n) { return n ? (n + GZ_LOW_SLICE - 1) / GZ_LOW_SLICE : 1; }
@@ -452,14 +456,18 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_count (GzdLeaf *leaves, const
     const GzdLowBlock B = blocks[blockIdx.x];
     GzdLeaf &L = leaves[B.leaf];
     if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
-    const uint32_t n = L.coded_n, slice = B.first_slice + threadIdx.x;
-    if (slice >= d_low_nslices (n)) return;
+    const uint32_t n = L.coded_n, ns = d_low_nslices (n);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint4 *rec = (const uint4 *)L.triples;
     const uint32_t *rv = (const uint32_t *)L.rvals;
-    const uint32_t s0 = slice * GZ_LOW_SLICE, s1 = s0 + GZ_LOW_SLICE < n ? s0 + GZ_LOW_SLICE : n;
-    uint32_t k = 0;
-    for (uint32_t i = s0; i < s1; i++) k += __clz (rv[i] * rec[i].y) >> 3;
-    ((uint32_t *)L.kpos)[slice] = k;
+    for (uint32_t q = 0; q < GZ_LOW_SLICES_PER_WG / 4; q++) {
+        const uint32_t slice = B.first_slice + wave * (GZ_LOW_SLICES_PER_WG / 4) + q;
+        if (slice >= ns) break;
+        const uint32_t i = slice * GZ_LOW_SLICE + lane;
+        const uint32_t k = i < n ? (uint32_t)__clz (rv[i] * rec[i].y) >> 3 : 0u;
+        const uint32_t cnt = (uint32_t)__popcll (__ballot (k >= 1)) + (uint32_t)__popcll (__ballot (k == 2));
+        if (!lane) ((uint32_t *)L.kpos)[slice] = cnt;
+    }
 }
 
 // one 1024-thread workgroup per leaf
@@ -493,29 +501,47 @@ __global__ void __launch_bounds__(1024) k_low_scan (GzdLeaf *leaves)
     }
 }
 
-__global__ void __launch_bounds__(GZ_LOW_WG) k_low_replay (GzdLeaf *leaves, const GzdLowBlock *blocks)
+// 4 waves, each with a 140-word LDS accumulator
+__global__ void __launch_bounds__(GZ_LOW_WG) k_low_scatter (GzdLeaf *leaves, const GzdLowBlock *blocks)
 {
     const GzdLowBlock B = blocks[blockIdx.x];
     GzdLeaf &L = leaves[B.leaf];
     if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
-    const uint32_t n = L.coded_n, slice = B.first_slice + threadIdx.x, ns = d_low_nslices (n);
-    if (slice >= ns) return;
+    const uint32_t n = L.coded_n, ns = d_low_nslices (n);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint4 *rec = (const uint4 *)L.triples;
     const uint32_t *rv = (const uint32_t *)L.rvals;
+    const uint32_t *kpos = (const uint32_t *)L.kpos;
     uint32_t *dig = (uint32_t *)L.events;
-    const uint32_t s0 = slice * GZ_LOW_SLICE, s1 = s0 + GZ_LOW_SLICE < n ? s0 + GZ_LOW_SLICE : n;
-    uint32_t pos = ((const uint32_t *)L.kpos)[slice];        // shifts before this slice: its next shift produces digit pos + 1
-    uint64_t lowc = 0;
-    for (uint32_t i = s0; i < s1; i++) {
-        const uint4 c = rec[i];
-        const uint32_t r = rv[i];
-        lowc += (uint64_t)(c.x * r);
-        const uint32_t k = __clz (r * c.y) >> 3;
-        for (uint32_t z = 0; z < k; z++) { dig[++pos] = (uint32_t)(lowc >> 24); lowc = (uint64_t)((uint32_t)lowc << 8); }
+    uint32_t *acc = (uint32_t *)gz_lds + wave * 144;          // up to 128 own digits + 5 closing / 4 spilling
+    const uint64_t below = (1ull << lane) - 1;
+    for (uint32_t q = 0; q < GZ_LOW_SLICES_PER_WG / 4; q++) {
+        const uint32_t slice = B.first_slice + wave * (GZ_LOW_SLICES_PER_WG / 4) + q;
+        const bool on = slice < ns;                            // (all waves keep hitting the barriers)
+        const uint32_t i = slice * GZ_LOW_SLICE + lane;
+        uint32_t k = 0, a = 0;
+        if (on && i < n) { const uint4 c = rec[i]; const uint32_t r = rv[i]; k = (uint32_t)__clz (r * c.y) >> 3; a = c.x * r; }
+        const uint64_t m1 = __ballot (k >= 1), m2 = __ballot (k == 2);
+        const uint32_t P = (uint32_t)__popcll (m1 & below) + (uint32_t)__popcll (m2 & below);   // shifts before me in the slice
+        const uint32_t K = (uint32_t)__popcll (m1) + (uint32_t)__popcll (m2);
+        const bool last = on && slice == ns - 1;
+        const uint32_t own = last ? K + 5 : K;                 // digits this slice owns: one per shift (+ the closing 5)
+        for (uint32_t j = lane; j < 144; j += 64) acc[j] = 0;
+        __syncthreads ();
+        if (on && a) {
+            atomicAdd (&acc[P],     a >> 24);
+            atomicAdd (&acc[P + 1], (a >> 16) & 0xff);
+            atomicAdd (&acc[P + 2], (a >> 8) & 0xff);
+            atomicAdd (&acc[P + 3], a & 0xff);
+        }
+        __syncthreads ();
+        if (on) {
+            const uint32_t base = kpos[slice] + 1;             // output byte of this slice's first shift
+            for (uint32_t j = lane; j < own; j += 64) dig[base + j] = acc[j];
+            if (lane < 4) ((uint32_t *)L.resid)[slice * 4 + lane] = last ? 0u : acc[own + lane];
+        }
+        __syncthreads ();
     }
-    if (slice == ns - 1)
-        for (int z = 0; z < 5; z++) { dig[++pos] = (uint32_t)(lowc >> 24); lowc = (uint64_t)((uint32_t)lowc << 8); }
-    ((uint64_t *)L.resid)[slice] = lowc;
 }
 
 __global__ void __launch_bounds__(GZ_LOW_WG) k_low_resid (GzdLeaf *leaves, const GzdLowBlock *blocks)
@@ -523,17 +549,18 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_resid (GzdLeaf *leaves, const
     const GzdLowBlock B = blocks[blockIdx.x];
     GzdLeaf &L = leaves[B.leaf];
     if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
-    const uint32_t slice = B.first_slice + threadIdx.x, ns = d_low_nslices (L.coded_n);
-    if (slice >= ns) return;
-    const uint64_t lowc = ((const uint64_t *)L.resid)[slice];
-    if (!lowc) return;
+    const uint32_t ns = d_low_nslices (L.coded_n), m = L.n_events;
+    if (threadIdx.x >= GZ_LOW_SLICES_PER_WG) return;
+    const uint32_t slice = B.first_slice + threadIdx.x;
+    if (slice + 1 >= ns) return;                               // the last slice owns everything it touches
+    const uint4 r = ((const uint4 *)L.resid)[slice];
+    if (!(r.x | r.y | r.z | r.w)) return;
     uint32_t *dig = (uint32_t *)L.events;
-    const uint32_t m = L.n_events;
-    const uint32_t pos = slice == ns - 1 ? m - 1 : ((const uint32_t *)L.kpos)[slice + 1];   // last digit this slice produced
-    if (pos + 1 < m) atomicAdd (&dig[pos + 1], (uint32_t)(lowc >> 24));
-    if (pos + 2 < m) atomicAdd (&dig[pos + 2], (uint32_t)(lowc >> 16) & 0xff);
-    if (pos + 3 < m) atomicAdd (&dig[pos + 3], (uint32_t)(lowc >> 8) & 0xff);
-    if (pos + 4 < m) atomicAdd (&dig[pos + 4], (uint32_t)lowc & 0xff);
+    const uint32_t at = ((const uint32_t *)L.kpos)[slice + 1] + 1;   // first digit of the next slice
+    if (r.x && at < m)     atomicAdd (&dig[at], r.x);
+    if (r.y && at + 1 < m) atomicAdd (&dig[at + 1], r.y);
+    if (r.z && at + 2 < m) atomicAdd (&dig[at + 2], r.z);
+    if (r.w && at + 3 < m) atomicAdd (&dig[at + 3], r.w);
 }
 
 // one 1024-thread workgroup per leaf. Tiles of 1024 x 16 digits are normalised from the end of the stream towards
