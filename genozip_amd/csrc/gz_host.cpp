@@ -123,22 +123,20 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
         if (h->own_stream) hipStreamDestroy (h->stream);
         delete h; if (err) *err = GZ_ERR_HIP; return NULL;
     }
-    // range / tot of the range coder (c_range_coder.h:100) as multiply + shifts: one "branch-free" magic number per
-    // divisor (Granlund & Montgomery; the libdivide u32 branchfree scheme), tot <= 65519 + 16
+    // range / tot of the range coder (c_range_coder.h:100) as q = mulhi (magic, n + inc) >> shift with a 32-bit magic:
+    // with L = floor (log2 d) and e = 2^(32+L) mod d, the rounded-up reciprocal is exact for every 32-bit n when
+    // d - e <= 2^L, otherwise the rounded-down one applied to n + 1 is (one of the two always holds; Granlund &
+    // Montgomery / "Labor of Division III"). tot <= 65519 + 16
     {
         const uint32_t N = 65536 + 32;
         std::vector<GzDivMagic> mt (N);
-        mt[0].magic = 0; mt[0].shift = 0xff;
-        mt[1].magic = 0; mt[1].shift = 0xff;                       // divisor 1: q = n
-        for (uint32_t dv = 2; dv < N; dv++) {
-            uint32_t L = 31 - __builtin_clz (dv);
-            if ((dv & (dv - 1)) == 0) { mt[dv].magic = 0; mt[dv].shift = L - 1; continue; }
-            uint64_t num = 1ull << (32 + L);
-            uint32_t m = (uint32_t)(num / dv), rem = (uint32_t)(num % dv);
-            m += m;
-            uint32_t twice = rem + rem;
-            if (twice >= dv || twice < rem) m += 1;
-            mt[dv].magic = m + 1; mt[dv].shift = L;
+        mt[0].magic = 0xffffffffu; mt[0].sh_inc = 1u << 8;
+        for (uint32_t dv = 1; dv < N; dv++) {
+            const uint32_t L = 31 - __builtin_clz (dv);
+            if ((dv & (dv - 1)) == 0) { mt[dv].magic = 0xffffffffu; mt[dv].sh_inc = L | (1u << 8); continue; }
+            const uint64_t num = 1ull << (32 + L), md = num / dv, e = num % dv;
+            if (dv - e <= (1ull << L)) { mt[dv].magic = (uint32_t)(md + 1); mt[dv].sh_inc = L; }
+            else                       { mt[dv].magic = (uint32_t)md;       mt[dv].sh_inc = L | (1u << 8); }
         }
         if (hipMalloc ((void **)&h->d_magic, N * sizeof (GzDivMagic)) != hipSuccess ||
             hipMemcpy (h->d_magic, mt.data (), N * sizeof (GzDivMagic), hipMemcpyHostToDevice) != hipSuccess) {
@@ -367,7 +365,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                                 d_leaves, ARITH_CLASS_WORDS[c], ARITH_CLASS_WORDS[c + 1], 0);
                 KLAUNCH_ON (h, side, k_arith_encode, dim3 (nl), dim3 (64), 0, d_leaves, ARITH_CLASS_WORDS[3], 0xffffffffu, 1);
             }
-            KLAUNCH (h, k_arith_model, dim3 (nl, 256), dim3 (64), 0, d_leaves, (const GzDivMagic *)h->d_magic);
+            KLAUNCH (h, k_arith_model, dim3 (nl, 256), dim3 (64), GZ_MODEL_LDS, d_leaves, (const GzDivMagic *)h->d_magic);
             KLAUNCH (h, k_arith_chain, dim3 (nl), dim3 (64), 0, d_leaves);
             if (!P.low_blocks.empty ()) {
                 void *d_lb;

@@ -14,8 +14,28 @@ __device__ static inline void gz_scalar_store4 (uint32_t *dst, uint32_t a, uint3
     asm volatile ("s_store_dwordx4 %0, %1, 0x0" : : "s"(v), "s"(dst) : "memory");
 }
 
+// the same with an immediate byte offset (one base pointer serves several stores)
+template <int OFF> __device__ static inline void gz_scalar_store4_at (uint32_t *dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    gz_sgpr4 v = { a, b, c, d };
+    asm volatile ("s_store_dwordx4 %0, %1, %2" : : "s"(v), "s"(dst), "n"(OFF) : "memory");
+}
+
+// wait for every outstanding scalar load (they return out of order, so "all" is the only wait there is) without
+// waiting for vector memory operations. A builtin, not inline asm: the compiler's own wait-count bookkeeping sees it.
+__device__ static inline void gz_wait_scalar_loads (void) { __builtin_amdgcn_s_waitcnt (0xC07F); }   // vmcnt 63, expcnt 7, lgkmcnt 0
+
+// keep the instruction scheduler from moving anything across this point (it likes to sink loads towards their use)
+__device__ static inline void gz_sched_fence (void) { __builtin_amdgcn_sched_barrier (0); }
+
 // scalar stores sit in the scalar data cache: write it back before anybody else (a later kernel) reads the data
 __device__ static inline void gz_scalar_store_flush (void)
 {
     asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" : : : "memory");
+}
+
+// number of set bits of a wave mask below my lane (v_mbcnt_lo + v_mbcnt_hi)
+__device__ static inline uint32_t gz_mbcnt (uint64_t m)
+{
+    return __builtin_amdgcn_mbcnt_hi ((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo ((uint32_t)m, 0u));
 }

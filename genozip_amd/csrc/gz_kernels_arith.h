@@ -27,7 +27,18 @@
 #define GZ_MODEL_LIMIT 65519u          // MAX_FREQ (c_simple_model.h:63)
 #define GZ_MODEL_STEP  16u
 
-struct GzDivMagic { uint32_t magic, shift; };   // q = ((((n - t) >> 1) + t) >> shift, t = mulhi(magic, n); divisor 1: shift = 0xff
+// range / tot without dividing: q = mulhi (magic, n + inc) >> shift with a 32-bit magic number. For every divisor either
+// the rounded-up reciprocal (inc 0) or the rounded-down one (inc 1) is exact for all 32-bit n ("Labor of Division,
+// episode III"); powers of two use magic 2^32-1, inc 1. sh_inc = shift | inc << 8. (n + 1 must not wrap: n = 2^32-1
+// only happens at the very first symbol, which the chain handles itself.)
+struct GzDivMagic { uint32_t magic, sh_inc; };
+
+// record of one symbol, written by the model for the chain and the low kernels: { freq, magic, shift | cum << 8, inc }
+// (the scalar shift instruction only looks at the low 5 bits of its count, so cum rides along for free)
+__device__ static inline uint4 d_model_record (uint32_t cum, uint32_t freq, GzDivMagic mg)
+{
+    return make_uint4 (freq, mg.magic, (mg.sh_inc & 0xffu) | (cum << 8), mg.sh_inc >> 8);
+}
 
 // Values loaded from the leaf table arrive through vector loads, so the compiler must assume they differ per lane and
 // turns every loop / branch on them into exec-mask code. They are wave-uniform: say so.
@@ -144,7 +155,7 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
                 }
             }
         }
-        if (mine) { GzDivMagic mg = magic_tab[out_hi]; recs[pos] = make_uint4 (out_lo & 0xffff, out_lo >> 16, mg.magic, mg.shift); }
+        if (mine) recs[pos] = d_model_record (out_lo & 0xffff, out_lo >> 16, magic_tab[out_hi]);
       }
     }
 }
@@ -156,18 +167,23 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
 // with such an entry (its frequency, >= 17, always beats 1): gap--, and the next present symbol's gap++. With gap 0
 // the left neighbour is the previous lane and the ordinary "swap if now larger" applies. cum includes the gaps.
 //
-// Two ways through the occurrences of a 64-position chunk:
+// The wave scans the stream, queues the occurrences of its context (position, static rank of the symbol) in a small LDS
+// ring and works them off 64 at a time, however sparse the context is. Two ways through a batch:
 //  * one at a time (d_model_serial_step) - ~45 instructions and two vector->scalar decisions per occurrence;
-//  * as a batch: as long as no occurrence causes a structural change (a swap, a halving), the triples of ALL the
-//    chunk's occurrences follow from the current model plus prefix counts inside the chunk:
+//  * all at once: as long as no occurrence causes a structural change (a swap, a halving), the triples of ALL the
+//    batch's occurrences follow from the current model plus prefix counts inside the batch:
 //        freq_j = F[p_j] + 16 * #{i < j : p_i == p_j}      cum_j = C[p_j] + 16 * #{i < j : p_i < p_j}
 //        tot_j  = tot + 16 * j                              (p = list position of the occurrence's symbol)
 //    and whether occurrence j would swap needs only the left neighbour's frequency at that time,
-//    FL[p_j] + 16 * #{i < j : p_i == p_j - 1}. The lanes that own the positions fetch F, C, gap, FL with cross-lane
-//    reads (the symbol -> list position map `where` is kept per static rank), a short loop over the occurrences
-//    accumulates the counts with pure vector instructions, the longest valid prefix is accepted in one go, and only
-//    the first occurrence that changes the structure (if any) takes the one-at-a-time path.
+//    FL[p_j] + 16 * #{i < j : p_i == p_j - 1}. The lanes fetch F, C, gap, FL with cross-lane reads (the symbol -> list
+//    position map `where` is kept per static rank); one round per DISTINCT list position in the batch accumulates the
+//    counts (and, speculatively, the model update) with ~20 instructions; the longest valid prefix is accepted in one
+//    go, and only the first occurrence that changes the structure (if any) takes the one-at-a-time path.
 struct GzModelLane { uint32_t sym, srank, freq, cum, gap, where; };
+struct GzModelCtl { uint32_t tot, b_try, b_acc, cool; bool batch_on; };
+
+#define GZ_MQ 128                          // ring of queued occurrences (entries), > 2 * 64 - 1
+#define GZ_MODEL_LDS (256 + GZ_MQ * 8)     // rank table + ring
 
 __device__ static __forceinline__ void d_model_serial_step (GzModelLane &M, uint32_t &tot, int lane, int r, uint32_t nsym, uint32_t n_absent)
 {
@@ -212,6 +228,78 @@ __device__ static __forceinline__ void d_model_serial_step (GzModelLane &M, uint
     }
 }
 
+// lanes 0 .. cnt-1 hold the next cnt occurrences of this context in stream order (rk = static rank of the symbol);
+// on return they hold the (cum, freq, tot) the coder must see for them
+__device__ static __forceinline__ void d_model_batch (GzModelLane &M, GzModelCtl &C, int lane, uint32_t cnt, uint32_t rk, uint32_t nsym,
+                                                      uint32_t n_absent, uint32_t &out_cum, uint32_t &out_freq, uint32_t &out_tot)
+{
+    uint64_t todo = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
+    while (todo) {
+        if (C.batch_on && __popcll (todo) >= 3) {
+            C.b_try++;
+            const bool occ = (todo >> lane) & 1;
+            const uint32_t p  = (uint32_t)__shfl ((int)M.where, (int)rk);
+            const uint32_t F  = (uint32_t)__shfl ((int)M.freq, (int)p), Cm = (uint32_t)__shfl ((int)M.cum, (int)p);
+            const uint32_t G  = (uint32_t)__shfl ((int)M.gap, (int)p);
+            const uint32_t FL = (uint32_t)__shfl ((int)M.freq, (int)(p ? p - 1 : 0));
+            // one round per distinct list position q among the pending occurrences. As an occurrence I count the
+            // earlier occurrences at my position / below it / at my left neighbour; as list position `lane` I count
+            // what the whole batch would add to my frequency and cumulative.
+            uint32_t eq = 0, lt = 0, eql = 0, ceq = 0, clt = 0;
+            for (uint64_t rem = todo; rem; ) {
+                const uint32_t q = d_readlane (p, __ffsll ((unsigned long long)rem) - 1);
+                const uint64_t mb = __ballot (p == q) & todo;
+                rem &= ~mb;
+                const uint32_t before = gz_mbcnt (mb), c = (uint32_t)__popcll (mb);
+                eq  += (q == p) ? before : 0u;
+                lt  += (q < p) ? before : 0u;
+                eql += (q + 1 == p) ? before : 0u;
+                ceq += (q == (uint32_t)lane) ? c : 0u;
+                clt += (q < (uint32_t)lane) ? c : 0u;
+            }
+            const uint32_t idx = gz_mbcnt (todo);
+            const uint32_t f = F + GZ_MODEL_STEP * eq, cu = Cm + GZ_MODEL_STEP * lt, fl = FL + GZ_MODEL_STEP * eql;
+            const uint32_t tj = C.tot + GZ_MODEL_STEP * idx;
+            const bool bad = occ && (G != 0 || (p > 0 && f + GZ_MODEL_STEP > fl) || tj + GZ_MODEL_STEP > GZ_MODEL_LIMIT);
+            const uint64_t badm = __ballot (bad);
+            uint64_t acc = todo;
+            if (badm) {
+                acc = todo & ((1ull << (__ffsll ((unsigned long long)badm) - 1)) - 1);
+                ceq = clt = 0;                                   // the update, restricted to the accepted prefix
+                for (uint64_t rem = acc; rem; ) {
+                    const uint32_t q = d_readlane (p, __ffsll ((unsigned long long)rem) - 1);
+                    const uint64_t mb = __ballot (p == q) & acc;
+                    rem &= ~mb;
+                    const uint32_t c = (uint32_t)__popcll (mb);
+                    ceq += (q == (uint32_t)lane) ? c : 0u;
+                    clt += (q < (uint32_t)lane) ? c : 0u;
+                }
+            }
+            if (acc) {
+                if ((acc >> lane) & 1) { out_cum = cu; out_freq = f; out_tot = tj; }
+                const uint32_t na = (uint32_t)__popcll (acc);
+                M.freq += GZ_MODEL_STEP * ceq;
+                M.cum  += GZ_MODEL_STEP * clt;
+                C.tot  += GZ_MODEL_STEP * na;
+                C.b_acc += na;
+                todo &= ~acc;
+            }
+            // data whose neighbouring symbols keep overtaking each other (ties) defeats batching: stop trying for a while
+            if (C.b_try >= 16) { if (C.b_acc < 4 * C.b_try) { C.batch_on = false; C.cool = 0; } C.b_try = C.b_acc = 0; }
+            if (!todo) break;
+        }
+        // ---- one occurrence the ordinary way: the first pending one
+        if (!C.batch_on && ++C.cool >= 1024) C.batch_on = true;      // the model settles (warm-up swaps end): try again later
+        const int b = __ffsll ((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const int r = (int)d_readlane (M.where, (int)d_readlane (rk, b));
+        const uint32_t f = d_readlane (M.freq, r), cu = d_readlane (M.cum, r);
+        const bool owner = lane == b;
+        out_cum = owner ? cu : out_cum; out_freq = owner ? f : out_freq; out_tot = owner ? C.tot : out_tot;
+        d_model_serial_step (M, C.tot, lane, r, nsym, n_absent);
+    }
+}
+
 // (force-inlined: as a called function its arguments would arrive in vector registers and every loop on them would
 //  become exec-mask code)
 __device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t *in, uint32_t n, uint32_t ms, bool o1, uint32_t ctx,
@@ -227,9 +315,31 @@ __device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t
     M.freq = live ? 1 : 0;
     M.cum = live ? M.sym : ms;                            // lane entries + absent entries before it == its byte value
     M.srank = lane; M.where = lane;
-    uint32_t tot = ms;
+    GzModelCtl C;
+    C.tot = ms; C.b_try = C.b_acc = C.cool = 0; C.batch_on = true;
     const uint32_t n_absent = ms - nsym;
-    uint32_t b_try = 0, b_acc = 0, cool = 0; bool batch_on = true;
+
+    uint8_t  *rank_of = gz_lds;                           // byte value -> static rank, a wave-private copy
+    uint32_t *q_pos = (uint32_t *)(gz_lds + 256), *q_rk = q_pos + GZ_MQ;
+    for (int e = lane; e < 256; e += 64) rank_of[e] = (uint8_t)symrank[e];
+    __syncthreads ();
+    uint32_t head = 0, tail = 0;                          // ring indices (not wrapped)
+    // the records of a batch are stored while the next batch is being worked on: the division constants they need come
+    // from a table in memory, and waiting for that load at the end of every batch would cost more than the batch
+    uint32_t p_pos = 0, p_cum = 0, p_freq = 0; GzDivMagic p_mg = { 0, 0 }; bool p_on = false;
+
+    auto flush = [&] (uint32_t cnt) {
+        __syncthreads ();                                 // (one wave: orders the ring writes before the reads)
+        const bool occ = (uint32_t)lane < cnt;
+        const uint32_t e = (head + (uint32_t)lane) & (GZ_MQ - 1);
+        const uint32_t b_pos = occ ? q_pos[e] : 0u, b_rk = occ ? q_rk[e] : 0u;
+        head += cnt;
+        uint32_t out_cum = 0, out_freq = 0, out_tot = 0;
+        d_model_batch (M, C, lane, cnt, b_rk, nsym, n_absent, out_cum, out_freq, out_tot);
+        if (p_on) recs[p_pos] = d_model_record (p_cum, p_freq, p_mg);
+        p_on = occ; p_pos = b_pos; p_cum = out_cum; p_freq = out_freq;
+        if (occ) p_mg = magic_tab[out_tot];
+    };
 
     uint32_t nx_s[4], nx_p[4];
     #pragma unroll
@@ -239,7 +349,7 @@ __device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t
         nx_p[k] = (o1 && pos && pos < n) ? in[pos - 1] : 0;
     }
     for (uint32_t gbase = 0; gbase < n; gbase += 256) {
-        uint32_t cs[4], cp[4];
+        uint32_t cs[4], cp[4], rk[4];
         #pragma unroll
         for (int k = 0; k < 4; k++) { cs[k] = nx_s[k]; cp[k] = nx_p[k]; }
         #pragma unroll
@@ -248,78 +358,24 @@ __device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t
             nx_s[k] = pos < n ? in[pos] : 0;
             nx_p[k] = (o1 && pos < n) ? in[pos - 1] : 0;
         }
-      #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t base = gbase + k * 64;
-        if (base >= n) break;
-        const uint32_t pos = base + lane;
-        const bool mine = pos < n && (!o1 || cp[k] == ctx);
-        uint64_t todo = __ballot (mine);
-        if (!todo) continue;
-        const uint32_t rk = mine ? symrank[cs[k]] : 0;             // static rank of my position's symbol
-        uint32_t out_cum = 0, out_freq = 0, out_tot = 0;
-        while (todo) {
-            if (batch_on && __popcll (todo) >= 3) {
-                // ---- batch attempt over the pending occurrences
-                b_try++;
-                const bool occ = (todo >> lane) & 1;
-                const uint32_t p  = (uint32_t)__shfl ((int)M.where, (int)rk);
-                const uint32_t F  = (uint32_t)__shfl ((int)M.freq, (int)p), Cm = (uint32_t)__shfl ((int)M.cum, (int)p);
-                const uint32_t G  = (uint32_t)__shfl ((int)M.gap, (int)p);
-                const uint32_t FL = (uint32_t)__shfl ((int)M.freq, (int)(p ? p - 1 : 0));
-                // prefix counts, one round per DISTINCT list position among the pending occurrences (a run of equal
-                // symbols - the common case in binned qualities - costs one round, not one per occurrence)
-                uint32_t eq = 0, lt = 0, eql = 0;
-                const uint64_t below = (1ull << lane) - 1;
-                for (uint64_t rem = todo; rem; ) {
-                    const uint32_t q = d_readlane (p, __ffsll ((unsigned long long)rem) - 1);
-                    const uint64_t mb = __ballot (occ && p == q);           // occurrences of the symbol at position q
-                    rem &= ~mb;
-                    const uint32_t before = (uint32_t)__popcll (mb & below);   // ... that precede me
-                    eq  += (q == p) ? before : 0u;
-                    lt  += (q < p) ? before : 0u;
-                    eql += (q + 1 == p) ? before : 0u;
-                }
-                const uint32_t idx = __popcll (todo & ((1ull << lane) - 1));
-                const uint32_t f = F + GZ_MODEL_STEP * eq, cu = Cm + GZ_MODEL_STEP * lt, fl = FL + GZ_MODEL_STEP * eql;
-                const uint32_t tj = tot + GZ_MODEL_STEP * idx;
-                const bool bad = occ && (G != 0 || (p > 0 && f + GZ_MODEL_STEP > fl) || tj + GZ_MODEL_STEP > GZ_MODEL_LIMIT);
-                const uint64_t badm = __ballot (bad);
-                const uint64_t acc = badm ? (todo & ((1ull << (__ffsll ((unsigned long long)badm) - 1)) - 1)) : todo;
-                if (acc) {
-                    if ((acc >> lane) & 1) { out_cum = cu; out_freq = f; out_tot = tj; }
-                    uint32_t ceq = 0, clt = 0;
-                    for (uint64_t rem = acc; rem; ) {
-                        const uint32_t q = d_readlane (p, __ffsll ((unsigned long long)rem) - 1);
-                        const uint64_t mb = __ballot (occ && p == q) & acc;
-                        rem &= ~mb;
-                        const uint32_t cnt = (uint32_t)__popcll (mb);
-                        ceq += (q == (uint32_t)lane) ? cnt : 0u;
-                        clt += (q < (uint32_t)lane) ? cnt : 0u;
-                    }
-                    M.freq += GZ_MODEL_STEP * ceq;
-                    M.cum  += GZ_MODEL_STEP * clt;
-                    tot    += GZ_MODEL_STEP * (uint32_t)__popcll (acc);
-                    b_acc  += (uint32_t)__popcll (acc);
-                    todo &= ~acc;
-                    if (!todo) break;
-                }
-                // data whose neighbouring symbols keep overtaking each other (ties) defeats batching: stop trying
-                if (b_try >= 16) { if (b_acc < 2 * b_try) { batch_on = false; cool = 0; } b_try = b_acc = 0; }
-            }
-            // ---- one occurrence the ordinary way: the first pending one
-            if (!batch_on && ++cool >= 1024) batch_on = true;            // the model settles (warm-up swaps end): try again later
-            const int b = __ffsll ((unsigned long long)todo) - 1;
-            todo &= todo - 1;
-            const int r = (int)d_readlane (M.where, (int)d_readlane (rk, b));
-            const uint32_t f = d_readlane (M.freq, r), cu = d_readlane (M.cum, r);
-            const bool owner = lane == b;
-            out_cum = owner ? cu : out_cum; out_freq = owner ? f : out_freq; out_tot = owner ? tot : out_tot;
-            d_model_serial_step (M, tot, lane, r, nsym, n_absent);
+        #pragma unroll
+        for (int k = 0; k < 4; k++) rk[k] = rank_of[cs[k]];
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t base = gbase + k * 64;
+            if (base >= n) break;
+            const uint32_t pos = base + lane;
+            const bool mine = pos < n && (!o1 || cp[k] == ctx);
+            const uint64_t mask = __ballot (mine);
+            if (!mask) continue;
+            const uint32_t slot = (tail + gz_mbcnt (mask)) & (GZ_MQ - 1);
+            if (mine) { q_pos[slot] = pos; q_rk[slot] = rk[k]; }
+            tail += (uint32_t)__popcll (mask);
+            if (tail - head >= 64) flush (64);
         }
-        if (mine) { GzDivMagic mg = magic_tab[out_tot]; recs[pos] = make_uint4 (out_cum, out_freq, mg.magic, mg.shift); }
-      }
     }
+    if (tail != head) flush (tail - head);
+    if (p_on) recs[p_pos] = d_model_record (p_cum, p_freq, p_mg);
 }
 
 // grid (n_leaves, 256): block y serves context y of leaf x
@@ -367,12 +423,11 @@ typedef const volatile __attribute__((address_space(4))) gz_u32x16 *GzConstRec4P
 #define GZ_CHAIN_BLOCK 8
 #define GZ_CHAIN_TOUCH_AHEAD (16 * 1024)   // bytes: how far ahead of the scalar loads the vector unit pulls lines into L2
 
-__device__ static inline uint32_t d_chain_step (uint32_t &range, uint32_t freq, uint32_t mg, uint32_t sh)
+__device__ static inline uint32_t d_chain_step (uint32_t &range, uint32_t freq, uint32_t mg, uint32_t shw, uint32_t inc)
 {
-    const uint32_t t = __umulhi (mg, range);
-    const uint32_t r = (((range - t) >> 1) + t) >> sh;               // range / tot, tot >= 2
+    const uint32_t r = __umulhi (mg, range + inc) >> (shw & 31);     // range / tot (the hardware masks the count itself)
     const uint32_t x = r * freq;                                     // >= 256: r >= 2^24 / 65535
-    range = x << (__clz (x) & 0x18);                                 // 0, 1 or 2 bytes
+    range = x << (__builtin_clz (x) & 0x18);                         // 0, 1 or 2 bytes (x is never 0)
     return r;
 }
 
@@ -386,50 +441,67 @@ __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
     GzConstRecP rec = (GzConstRecP)(uintptr_t)L.triples;       // padded: reads up to 64 KB past n stay inside the area
     const uint32_t *touch = (const uint32_t *)L.triples;
     uint32_t *rout = (uint32_t *)L.rvals;
-    uint32_t sink = 0, range = 0xffffffffu;
+    uint32_t sink = 0, touched = 0, range = 0xffffffffu;
 
     if (n && L.max_sym == 1) {
-        // a stream of zero bytes: the model total starts at 1, which the multiply-shift division cannot express
+        // a stream of zero bytes: the range stays 2^32-1 while the model total is 1 (and 17), which n + inc cannot take
         for (uint32_t i = 0; i < n; i++) {
             const gz_u32x4 c = rec[i];
-            const uint32_t t = __umulhi (c[2], range);
-            const uint32_t r = c[3] == 0xff ? range : (((range - t) >> 1) + t) >> c[3];
-            const uint32_t x = r * c[1];
+            const uint32_t r = (uint32_t)(((uint64_t)c[1] * ((uint64_t)range + c[3])) >> 32) >> (c[2] & 31);
+            const uint32_t x = r * c[0];
             range = x << (__clz (x) & 0x18);
             if (!lane) rout[i] = r;
         }
     }
-    else {
+    else if (n) {
+        // the first symbol sees range = 2^32-1 and total = max_sym: as a reciprocal for exactly that case,
+        // mulhi (q + 1, 2^32-1) = q
+        const uint32_t q0 = 0xffffffffu / d_uniform (L.max_sym);
+        // 16 records per iteration as two halves A and B of 8: while one half is being worked on, the loads of the
+        // other are in flight (issued right after an explicit wait, because the compiler would place the wait for the
+        // half it needs AFTER the issue of the next loads and so wait for those too)
         const uint32_t nb = n & ~(uint32_t)(GZ_CHAIN_BLOCK - 1);
         if (nb) {
-            GzConstRec4P rec4 = (GzConstRec4P)(uintptr_t)L.triples;
+            GzConstRec4P rec4 = (GzConstRec4P)(uintptr_t)L.triples;       // (padded: loads past nb stay inside the area)
             for (uint32_t b = 0; b < GZ_CHAIN_TOUCH_AHEAD; b += 4096) sink += touch[(b >> 2) + lane * 16];   // 64 lanes x 64 B = 4 KB
-            gz_u32x16 ca = rec4[0], cb = rec4[1];
-            for (uint32_t i = 0; i < nb; i += GZ_CHAIN_BLOCK) {
-                const uint32_t nx = (i + GZ_CHAIN_BLOCK < nb ? i + GZ_CHAIN_BLOCK : i) >> 2;   // the last block re-reads itself
-                const gz_u32x16 pa = rec4[nx], pb = rec4[nx + 1];
-                if (!(i & 255)) sink += touch[((i * 16 + GZ_CHAIN_TOUCH_AHEAD) >> 2) + lane * 16];  // every 256 records = 4 KB
-                const uint32_t r0 = d_chain_step (range, ca[1],  ca[2],  ca[3]);
-                const uint32_t r1 = d_chain_step (range, ca[5],  ca[6],  ca[7]);
-                const uint32_t r2 = d_chain_step (range, ca[9],  ca[10], ca[11]);
-                const uint32_t r3 = d_chain_step (range, ca[13], ca[14], ca[15]);
-                gz_scalar_store4 (rout + i, r0, r1, r2, r3);             // the chain never touches the vector unit
-                const uint32_t r4 = d_chain_step (range, cb[1],  cb[2],  cb[3]);
-                const uint32_t r5 = d_chain_step (range, cb[5],  cb[6],  cb[7]);
-                const uint32_t r6 = d_chain_step (range, cb[9],  cb[10], cb[11]);
-                const uint32_t r7 = d_chain_step (range, cb[13], cb[14], cb[15]);
-                gz_scalar_store4 (rout + i + 4, r4, r5, r6, r7);
-                ca = pa; cb = pb;
+            gz_u32x16 a0 = rec4[0], a1 = rec4[1];
+            a0[1] = q0 + 1; a0[2] = 0; a0[3] = 0;
+            gz_wait_scalar_loads ();
+            for (uint32_t i = 0; ; ) {
+                const gz_u32x16 b0 = rec4[(i >> 2) + 2], b1 = rec4[(i >> 2) + 3];
+                gz_sched_fence ();
+                // every 256 records = 4 KB (the loaded value is only looked at 256 records later: no wait here)
+                if (!(i & 255)) { sink += touched; touched = touch[((i * 16 + GZ_CHAIN_TOUCH_AHEAD) >> 2) + lane * 16]; }
+                uint32_t r0, r1, r2, r3;
+                r0 = d_chain_step (range, a0[0], a0[1], a0[2],  a0[3]);  r1 = d_chain_step (range, a0[4],  a0[5],  a0[6],  a0[7]);
+                r2 = d_chain_step (range, a0[8], a0[9], a0[10], a0[11]); r3 = d_chain_step (range, a0[12], a0[13], a0[14], a0[15]);
+                gz_scalar_store4_at<0> (rout + i, r0, r1, r2, r3);       // the chain never touches the vector unit
+                r0 = d_chain_step (range, a1[0], a1[1], a1[2],  a1[3]);  r1 = d_chain_step (range, a1[4],  a1[5],  a1[6],  a1[7]);
+                r2 = d_chain_step (range, a1[8], a1[9], a1[10], a1[11]); r3 = d_chain_step (range, a1[12], a1[13], a1[14], a1[15]);
+                gz_scalar_store4_at<16> (rout + i, r0, r1, r2, r3);
+                if (i + 8 >= nb) break;
+                gz_wait_scalar_loads ();
+                a0 = rec4[(i >> 2) + 4]; a1 = rec4[(i >> 2) + 5];
+                gz_sched_fence ();
+                r0 = d_chain_step (range, b0[0], b0[1], b0[2],  b0[3]);  r1 = d_chain_step (range, b0[4],  b0[5],  b0[6],  b0[7]);
+                r2 = d_chain_step (range, b0[8], b0[9], b0[10], b0[11]); r3 = d_chain_step (range, b0[12], b0[13], b0[14], b0[15]);
+                gz_scalar_store4_at<32> (rout + i, r0, r1, r2, r3);
+                r0 = d_chain_step (range, b1[0], b1[1], b1[2],  b1[3]);  r1 = d_chain_step (range, b1[4],  b1[5],  b1[6],  b1[7]);
+                r2 = d_chain_step (range, b1[8], b1[9], b1[10], b1[11]); r3 = d_chain_step (range, b1[12], b1[13], b1[14], b1[15]);
+                gz_scalar_store4_at<48> (rout + i, r0, r1, r2, r3);
+                i += 16;
+                if (i >= nb) break;
+                gz_wait_scalar_loads ();
             }
         }
         for (uint32_t i = nb; i < n; i++) {
             const gz_u32x4 c = rec[i];
-            const uint32_t r = d_chain_step (range, c[1], c[2], c[3]);
+            const uint32_t r = i ? d_chain_step (range, c[0], c[1], c[2], c[3]) : d_chain_step (range, c[0], q0 + 1, 0, 0);
             if (!lane) rout[i] = r;
         }
     }
     gz_scalar_store_flush ();
-    if (!lane) L.touch_sink = sink;
+    if (!lane) L.touch_sink = sink + touched;
 }
 
 // ---- low: a big-number sum, one thread per symbol -----------------------------------------------------------------
@@ -464,7 +536,7 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_count (GzdLeaf *leaves, const
         const uint32_t slice = B.first_slice + wave * (GZ_LOW_SLICES_PER_WG / 4) + q;
         if (slice >= ns) break;
         const uint32_t i = slice * GZ_LOW_SLICE + lane;
-        const uint32_t k = i < n ? (uint32_t)__clz (rv[i] * rec[i].y) >> 3 : 0u;
+        const uint32_t k = i < n ? (uint32_t)__clz (rv[i] * rec[i].x) >> 3 : 0u;
         const uint32_t cnt = (uint32_t)__popcll (__ballot (k >= 1)) + (uint32_t)__popcll (__ballot (k == 2));
         if (!lane) ((uint32_t *)L.kpos)[slice] = cnt;
     }
@@ -520,7 +592,7 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_scatter (GzdLeaf *leaves, con
         const bool on = slice < ns;                            // (all waves keep hitting the barriers)
         const uint32_t i = slice * GZ_LOW_SLICE + lane;
         uint32_t k = 0, a = 0;
-        if (on && i < n) { const uint4 c = rec[i]; const uint32_t r = rv[i]; k = (uint32_t)__clz (r * c.y) >> 3; a = c.x * r; }
+        if (on && i < n) { const uint4 c = rec[i]; const uint32_t r = rv[i]; k = (uint32_t)__clz (r * c.x) >> 3; a = (c.z >> 8) * r; }
         const uint64_t m1 = __ballot (k >= 1), m2 = __ballot (k == 2);
         const uint32_t P = (uint32_t)__popcll (m1 & below) + (uint32_t)__popcll (m2 & below);   // shifts before me in the slice
         const uint32_t K = (uint32_t)__popcll (m1) + (uint32_t)__popcll (m2);
