@@ -79,7 +79,12 @@ struct GzdLeaf {
     uint8_t   *tab;           // serialised frequency table
     uint8_t   *pay;           // entropy-coded payload area (rANS fills it from the end)
     uint32_t  *models;        // arith (run-length variant): global-memory models when they do not fit the LDS
-    uint8_t   *triples;       // arith: 16 bytes per coded byte: cum | freq << 16, division magic, shift, tot  (k_arith_model -> k_arith_chain)
+    uint8_t   *triples;       // arith: 16 bytes per coded byte: freq, division magic, shift | cum << 8, inc  (k_arith_model -> k_arith_chain)
+    uint32_t  *spos;          // arith order-1: positions grouped by context (the byte before), stream order inside a context
+    uint8_t   *srk;           // arith order-1: static rank of the symbol at spos[j]
+    uint32_t  *ctxoff;        // arith order-1: [tile][context] -> index into spos/srk of the first occurrence at or after the tile
+    uint32_t  *mstate;        // arith: the models' registers between two position chunks (GZ_MSTATE_WORDS x 64 lanes per context)
+    uint32_t  chain_range;    // arith: the coder's range between two position chunks
     uint8_t   *events;        // arith: one 32-bit digit per output byte (k_low_replay / k_low_norm)
     uint8_t   *rvals;         // arith: r = range / tot of every symbol (k_arith_chain -> k_low_*)
     uint8_t   *kpos;          // arith: per 64-symbol slice: shifts in it, then (k_low_scan) shifts before it

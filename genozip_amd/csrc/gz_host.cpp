@@ -41,6 +41,9 @@ struct GzHandle {
     hipStream_t stream;
     hipStream_t stream2;      // side stream: work that is independent of the arithmetic coder's long chain runs beside it
     hipEvent_t ev_fork, ev_join;
+    hipStream_t stream3;      // the range coder chain of position chunk k runs here, beside the models of chunk k+1
+    std::vector<hipEvent_t> ev_chunk;   // model chunk k done (recorded on stream); ev_chain = last chain chunk done
+    hipEvent_t ev_chain;
     bool own_stream;
     std::vector<ArenaBlock> blocks;
     std::vector<Pending> pending;
@@ -113,6 +116,8 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
         h->own_stream = true;
     }
     if (hipStreamCreateWithFlags (&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags (&h->stream3, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags (&h->ev_chain, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags (&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags (&h->ev_join, hipEventDisableTiming) != hipSuccess) { delete h; if (err) *err = GZ_ERR_HIP; return NULL; }
     // log(1024+k), log(4096+k) from the host libm: what the reference's compute_shift() sees (rANS_static4x16pr.c:647)
@@ -167,6 +172,9 @@ extern "C" void gz_destroy (GzHandle *h)
     hipFree (h->d_magic);
     if (h->own_stream) hipStreamDestroy (h->stream);
     hipStreamDestroy (h->stream2);
+    hipStreamDestroy (h->stream3);
+    hipEventDestroy (h->ev_chain);
+    for (hipEvent_t e : h->ev_chunk) hipEventDestroy (e);
     hipEventDestroy (h->ev_fork); hipEventDestroy (h->ev_join);
     delete h;
 }
@@ -229,6 +237,8 @@ struct Plan {
     std::vector<GzdLowBlock> low_blocks;   // (leaf, first slice) of every 256-slice workgroup of the k_low_* kernels
     bool any_striped = false, any_rans = false, any_arith = false, any_arith_rle = false;
     uint32_t max_in = 0;
+    uint32_t max_arith_n = 0;              // largest plain (model/chain) arith leaf
+    bool any_arith_o1 = false;
 };
 
 static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int plane, int method, uint32_t n_bound)
@@ -259,6 +269,15 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
             if (!(L.triples = (uint8_t *)arena_alloc (h, ((size_t)n_bound + 64) * 16 + 2 * GZ_CHAIN_TOUCH_AHEAD + 8192))) return false;
             if (!(L.events  = (uint8_t *)arena_alloc (h, ((size_t)L.pay_cap + 128) * 4))) return false;
             if (!(L.rvals   = (uint8_t *)arena_alloc (h, ((size_t)n_bound + 64) * 4))) return false;
+            if (o1) {
+                const size_t nt = ((size_t)n_bound + GZ_CTX_TILE - 1) / GZ_CTX_TILE;
+                if (!(L.spos   = (uint32_t *)arena_alloc (h, ((size_t)n_bound + 64) * 4))) return false;
+                if (!(L.srk    = (uint8_t *)arena_alloc (h, (size_t)n_bound + 64))) return false;
+                if (!(L.ctxoff = (uint32_t *)arena_alloc (h, (nt + 1) * 256 * 4))) return false;
+                P.any_arith_o1 = true;
+            }
+            if (n_bound > GZ_CHUNK_MIN && !(L.mstate = (uint32_t *)arena_alloc (h, (size_t)256 * GZ_MSTATE_WORDS * 64 * 4))) return false;
+            if (n_bound > P.max_arith_n) P.max_arith_n = n_bound;
             const uint32_t ns = n_bound ? (n_bound + GZ_LOW_SLICE - 1) / GZ_LOW_SLICE : 1;
             if (!(L.kpos    = (uint8_t *)arena_alloc (h, ((size_t)ns + 2) * 4))) return false;
             if (!(L.resid   = (uint8_t *)arena_alloc (h, ((size_t)ns + 1) * 16))) return false;
@@ -365,8 +384,29 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                                 d_leaves, ARITH_CLASS_WORDS[c], ARITH_CLASS_WORDS[c + 1], 0);
                 KLAUNCH_ON (h, side, k_arith_encode, dim3 (nl), dim3 (64), 0, d_leaves, ARITH_CLASS_WORDS[3], 0xffffffffu, 1);
             }
-            KLAUNCH (h, k_arith_model, dim3 (nl, 256), dim3 (64), GZ_MODEL_LDS, d_leaves, (const GzDivMagic *)h->d_magic);
-            KLAUNCH (h, k_arith_chain, dim3 (nl), dim3 (64), 0, d_leaves);
+            // position chunks (see gz_kernels_arith.h): at most 8 per leaf, none smaller than GZ_CHUNK_MIN
+            uint32_t chunk = ((P.max_arith_n + 7) / 8 + GZ_CTX_TILE - 1) & ~(GZ_CTX_TILE - 1);
+            if (chunk < GZ_CHUNK_MIN) chunk = GZ_CHUNK_MIN;
+            const uint32_t n_chunks = P.max_arith_n ? (P.max_arith_n + chunk - 1) / chunk : 1;
+            while (h->ev_chunk.size () < n_chunks) {
+                hipEvent_t e;
+                HIPCHK (h, hipEventCreateWithFlags (&e, hipEventDisableTiming));
+                h->ev_chunk.push_back (e);
+            }
+            if (P.any_arith_o1 && P.max_arith_n) {            // group the positions of order-1 leaves by context
+                const uint32_t max_tiles = (P.max_arith_n + GZ_CTX_TILE - 1) / GZ_CTX_TILE;
+                KLAUNCH (h, k_ctx_count, dim3 (nl, max_tiles), dim3 (64), 1024, d_leaves);
+                KLAUNCH (h, k_ctx_scan, dim3 (nl), dim3 (256), 1024, d_leaves);
+                KLAUNCH (h, k_ctx_scatter, dim3 (nl, max_tiles), dim3 (64), 1280, d_leaves);
+            }
+            for (uint32_t k = 0; k < n_chunks; k++) {
+                KLAUNCH (h, k_arith_model, dim3 (nl, 256), dim3 (64), 0, d_leaves, (const GzDivMagic *)h->d_magic, k * chunk, chunk);
+                if (n_chunks == 1) { KLAUNCH (h, k_arith_chain, dim3 (nl), dim3 (64), 0, d_leaves, 0u, chunk); break; }
+                HIPCHK (h, hipEventRecord (h->ev_chunk[k], h->stream));
+                HIPCHK (h, hipStreamWaitEvent (h->stream3, h->ev_chunk[k], 0));
+                KLAUNCH_ON (h, h->stream3, k_arith_chain, dim3 (nl), dim3 (64), 0, d_leaves, k * chunk, chunk);
+            }
+            if (n_chunks > 1) { HIPCHK (h, hipEventRecord (h->ev_chain, h->stream3)); HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_chain, 0)); }
             if (!P.low_blocks.empty ()) {
                 void *d_lb;
                 int rc2 = upload (h, P.low_blocks.data (), P.low_blocks.size () * sizeof (GzdLowBlock), &d_lb);

@@ -56,27 +56,35 @@ __device__ static inline uint32_t d_writelane (uint32_t val, int lane, uint32_t 
 
 // J = registers per lane holding the model (entries e = j*64 + lane), J*64 >= max_sym
 template <int J>
-__device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, uint32_t n, uint32_t ms, bool o1, uint32_t ctx, uint4 *recs, const GzDivMagic *magic_tab)
+__device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, uint32_t n, uint32_t ms, bool o1, uint32_t ctx, uint4 *recs, const GzDivMagic *magic_tab,
+                                                            uint32_t p0, uint32_t p1, uint32_t *st)
 {
     const int lane = threadIdx.x & 63;
     uint32_t sym[J], freq[J], cum[J];
-    #pragma unroll
-    for (int j = 0; j < J; j++) {
-        uint32_t e = j * 64 + lane;
-        sym[j] = e; freq[j] = e < ms ? 1 : 0; cum[j] = e < ms ? e : ms;
-    }
     uint32_t tot = ms;
+    if (p0 == 0) {
+        #pragma unroll
+        for (int j = 0; j < J; j++) {
+            uint32_t e = j * 64 + lane;
+            sym[j] = e; freq[j] = e < ms ? 1 : 0; cum[j] = e < ms ? e : ms;
+        }
+    }
+    else {                                                 // resume where the previous position chunk stopped
+        #pragma unroll
+        for (int j = 0; j < J; j++) { sym[j] = st[(3 * j) * 64 + lane]; freq[j] = st[(3 * j + 1) * 64 + lane]; cum[j] = st[(3 * j + 2) * 64 + lane]; }
+        tot = d_uniform (st[12 * 64]);
+    }
 
     // The wave scans the whole stream for "its" positions, 4 x 64 positions per iteration; the bytes of the next
     // iteration are requested before the current ones are used, so the scan never waits for memory.
     uint32_t nx_s[4], nx_p[4];
     #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const uint32_t pos = k * 64 + lane;
+        const uint32_t pos = p0 + k * 64 + lane;
         nx_s[k] = pos < n ? in[pos] : 0;
         nx_p[k] = (o1 && pos && pos < n) ? in[pos - 1] : 0;
     }
-    for (uint32_t gbase = 0; gbase < n; gbase += 256) {
+    for (uint32_t gbase = p0; gbase < p1; gbase += 256) {
         uint32_t cs[4], cp[4];
         #pragma unroll
         for (int k = 0; k < 4; k++) { cs[k] = nx_s[k]; cp[k] = nx_p[k]; }
@@ -89,10 +97,10 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
       #pragma unroll
       for (int k = 0; k < 4; k++) {
         const uint32_t base = gbase + k * 64;
-        if (base >= n) break;
+        if (base >= p1) break;
         const uint32_t pos = base + lane;
         const uint32_t s_v = cs[k];
-        const bool mine = pos < n && (!o1 || cp[k] == ctx);
+        const bool mine = pos < p1 && (!o1 || cp[k] == ctx);
         uint64_t todo = __ballot (mine);
         uint32_t out_lo = 0, out_hi = 0;
         while (todo) {
@@ -158,6 +166,11 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
         if (mine) recs[pos] = d_model_record (out_lo & 0xffff, out_lo >> 16, magic_tab[out_hi]);
       }
     }
+    if (p1 < n) {
+        #pragma unroll
+        for (int j = 0; j < J; j++) { st[(3 * j) * 64 + lane] = sym[j]; st[(3 * j + 1) * 64 + lane] = freq[j]; st[(3 * j + 2) * 64 + lane] = cum[j]; }
+        if (!lane) st[12 * 64] = tot;
+    }
 }
 
 // Compact variant for leaves with at most 64 distinct byte values (every quality / token stream): only the symbols
@@ -180,10 +193,7 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
 //    counts (and, speculatively, the model update) with ~20 instructions; the longest valid prefix is accepted in one
 //    go, and only the first occurrence that changes the structure (if any) takes the one-at-a-time path.
 struct GzModelLane { uint32_t sym, srank, freq, cum, gap, where; };
-struct GzModelCtl { uint32_t tot, b_try, b_acc, cool; bool batch_on; };
 
-#define GZ_MQ 128                          // ring of queued occurrences (entries), > 2 * 64 - 1
-#define GZ_MODEL_LDS (256 + GZ_MQ * 8)     // rank table + ring
 
 __device__ static __forceinline__ void d_model_serial_step (GzModelLane &M, uint32_t &tot, int lane, int r, uint32_t nsym, uint32_t n_absent)
 {
@@ -229,22 +239,34 @@ __device__ static __forceinline__ void d_model_serial_step (GzModelLane &M, uint
 }
 
 // lanes 0 .. cnt-1 hold the next cnt occurrences of this context in stream order (rk = static rank of the symbol);
-// on return they hold the (cum, freq, tot) the coder must see for them
-__device__ static __forceinline__ void d_model_batch (GzModelLane &M, GzModelCtl &C, int lane, uint32_t cnt, uint32_t rk, uint32_t nsym,
+// on return they hold the (cum, freq, tot) the coder must see for them.
+//
+// Per attempt: every pending occurrence fetches its symbol's list position p, frequency, cumulative, gap and left
+// neighbour's frequency from the model as it stands, and adds 16 x the number of earlier pending occurrences at the same /
+// a lower / the left neighbour's position (one round per DISTINCT position). That is exact up to the first occurrence
+// whose coding moves something. Those EVENTS are then taken in stream order, each one patching only the lanes it
+// concerns instead of starting over:
+//   hop   the symbol (at position r) has absent entries in front of it: one of them moves behind it. Later occurrences of
+//         the symbol: cum - 1, gap - 1; later occurrences of the symbol at r + 1: gap + 1.
+//   swap  the symbol a at r overtakes its left neighbour b at r - 1. Later occurrences of a: cum - freq_b(then), new left
+//         neighbour r - 2; of b: cum + freq_a(then), left neighbour a; of the symbol at r + 1: left neighbour b.
+//         (freq_x(then) = model frequency + 16 x earlier occurrences of x in the batch: a ballot and a mbcnt.)
+// The model registers follow the order changes immediately; the batch's counts (ceq, clt per list position) are added
+// at the end. Only a halving (once per ~2000 occurrences of a context) ends an attempt early: the prefix is committed,
+// that one occurrence goes through d_model_serial_step, and the rest starts a new attempt.
+__device__ static __forceinline__ void d_model_batch (GzModelLane &M, uint32_t &tot, int lane, uint32_t cnt, uint32_t rk, uint32_t nsym,
                                                       uint32_t n_absent, uint32_t &out_cum, uint32_t &out_freq, uint32_t &out_tot)
 {
     uint64_t todo = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
     while (todo) {
-        if (C.batch_on && __popcll (todo) >= 3) {
-            C.b_try++;
+        if (__popcll (todo) >= 3) {
             const bool occ = (todo >> lane) & 1;
-            const uint32_t p  = (uint32_t)__shfl ((int)M.where, (int)rk);
+            uint32_t p  = (uint32_t)__shfl ((int)M.where, (int)rk);
             const uint32_t F  = (uint32_t)__shfl ((int)M.freq, (int)p), Cm = (uint32_t)__shfl ((int)M.cum, (int)p);
-            const uint32_t G  = (uint32_t)__shfl ((int)M.gap, (int)p);
+            uint32_t G  = (uint32_t)__shfl ((int)M.gap, (int)p);
             const uint32_t FL = (uint32_t)__shfl ((int)M.freq, (int)(p ? p - 1 : 0));
-            // one round per distinct list position q among the pending occurrences. As an occurrence I count the
-            // earlier occurrences at my position / below it / at my left neighbour; as list position `lane` I count
-            // what the whole batch would add to my frequency and cumulative.
+            // as an occurrence I count the earlier occurrences at my position / below it / at my left neighbour; as
+            // list position `lane` I count what the whole batch adds to my frequency and cumulative
             uint32_t eq = 0, lt = 0, eql = 0, ceq = 0, clt = 0;
             for (uint64_t rem = todo; rem; ) {
                 const uint32_t q = d_readlane (p, __ffsll ((unsigned long long)rem) - 1);
@@ -257,15 +279,57 @@ __device__ static __forceinline__ void d_model_batch (GzModelLane &M, GzModelCtl
                 ceq += (q == (uint32_t)lane) ? c : 0u;
                 clt += (q < (uint32_t)lane) ? c : 0u;
             }
-            const uint32_t idx = gz_mbcnt (todo);
-            const uint32_t f = F + GZ_MODEL_STEP * eq, cu = Cm + GZ_MODEL_STEP * lt, fl = FL + GZ_MODEL_STEP * eql;
-            const uint32_t tj = C.tot + GZ_MODEL_STEP * idx;
-            const bool bad = occ && (G != 0 || (p > 0 && f + GZ_MODEL_STEP > fl) || tj + GZ_MODEL_STEP > GZ_MODEL_LIMIT);
-            const uint64_t badm = __ballot (bad);
-            uint64_t acc = todo;
-            if (badm) {
-                acc = todo & ((1ull << (__ffsll ((unsigned long long)badm) - 1)) - 1);
-                ceq = clt = 0;                                   // the update, restricted to the accepted prefix
+            const uint32_t f = F + GZ_MODEL_STEP * eq, tj = tot + GZ_MODEL_STEP * gz_mbcnt (todo);
+            uint32_t cu = Cm + GZ_MODEL_STEP * lt, fl = FL + GZ_MODEL_STEP * eql;
+            // the first occurrence that would push the total over the limit ends the attempt
+            const uint64_t halve_m = __ballot (occ && tj + GZ_MODEL_STEP > GZ_MODEL_LIMIT);
+            const uint64_t acc = halve_m ? todo & ((1ull << (__ffsll ((unsigned long long)halve_m) - 1)) - 1) : todo;
+            // ---- events, in stream order
+            for (uint64_t pend = acc; ; ) {
+                const uint64_t badm = __ballot (G != 0 || (p > 0 && f + GZ_MODEL_STEP > fl)) & pend;
+                if (!badm) break;
+                const int j = __ffsll ((unsigned long long)badm) - 1;
+                pend &= ~((2ull << j) - 1);
+                const bool later = lane > j;
+                const uint32_t r = d_readlane (p, j);
+                if (d_readlane (G, j)) {                                    // hop
+                    M.gap += lane == (int)r ? 0xffffffffu : (lane == (int)r + 1 ? 1u : 0u);
+                    M.cum += lane == (int)r ? 0xffffffffu : 0u;
+                    cu -= (later && p == r) ? 1u : 0u;
+                    G  += later ? (p == r ? 0xffffffffu : (p == r + 1 ? 1u : 0u)) : 0u;
+                }
+                else {                                                      // swap list positions q = r - 1 and r
+                    const uint32_t q = r - 1, q2 = q ? q - 1 : 0;
+                    const bool is_a = p == r, is_b = p == q, is_c = p == r + 1;
+                    const uint32_t Fa = d_readlane (M.freq, (int)r), Fb = d_readlane (M.freq, (int)q), F2 = d_readlane (M.freq, (int)q2);
+                    const uint32_t fa = Fa + GZ_MODEL_STEP * gz_mbcnt (__ballot (is_a) & todo);
+                    const uint32_t fb = Fb + GZ_MODEL_STEP * gz_mbcnt (__ballot (is_b) & todo);
+                    const uint32_t f2 = F2 + GZ_MODEL_STEP * gz_mbcnt (__ballot (q && p == q2) & todo);
+                    const uint32_t gl = d_readlane (M.gap, (int)q);
+                    if (later) {
+                        cu = is_a ? cu - fb : (is_b ? cu + fa : cu);
+                        fl = is_a ? f2 : (is_b ? fa : (is_c ? fb : fl));
+                        G  = is_a ? gl : (is_b ? 0u : G);
+                    }
+                    p = is_a ? q : (is_b ? r : p);                          // (all lanes: equal symbols keep equal positions)
+                    // the model registers
+                    const bool at_r = lane == (int)r, at_q = lane == (int)q;
+                    const uint32_t sb = d_readlane (M.sym, (int)q), cb = d_readlane (M.cum, (int)q);
+                    const uint32_t ra = d_readlane (M.srank, (int)r), rb = d_readlane (M.srank, (int)q), sa = d_readlane (M.sym, (int)r);
+                    M.sym   = at_q ? sa : (at_r ? sb : M.sym);
+                    M.srank = at_q ? ra : (at_r ? rb : M.srank);
+                    M.freq  = at_q ? Fa : (at_r ? Fb : M.freq);
+                    M.gap   = at_r ? 0u : M.gap;                            // (a takes over b's gap: lane q keeps it)
+                    M.cum   = at_r ? cb + Fa : M.cum;                       // (lane q keeps its cumulative)
+                    M.where = lane == (int)ra ? q : (lane == (int)rb ? r : M.where);
+                    // ... and the batch's counts per list position
+                    const uint32_t ea = d_readlane (ceq, (int)r), eb = d_readlane (ceq, (int)q), lq = d_readlane (clt, (int)q);
+                    ceq = at_q ? ea : (at_r ? eb : ceq);
+                    clt = at_r ? lq + ea : clt;
+                }
+            }
+            if (halve_m) {                                                  // commit the prefix only: recount it
+                ceq = clt = 0;
                 for (uint64_t rem = acc; rem; ) {
                     const uint32_t q = d_readlane (p, __ffsll ((unsigned long long)rem) - 1);
                     const uint64_t mb = __ballot (p == q) & acc;
@@ -275,114 +339,178 @@ __device__ static __forceinline__ void d_model_batch (GzModelLane &M, GzModelCtl
                     clt += (q < (uint32_t)lane) ? c : 0u;
                 }
             }
-            if (acc) {
-                if ((acc >> lane) & 1) { out_cum = cu; out_freq = f; out_tot = tj; }
-                const uint32_t na = (uint32_t)__popcll (acc);
-                M.freq += GZ_MODEL_STEP * ceq;
-                M.cum  += GZ_MODEL_STEP * clt;
-                C.tot  += GZ_MODEL_STEP * na;
-                C.b_acc += na;
-                todo &= ~acc;
-            }
-            // data whose neighbouring symbols keep overtaking each other (ties) defeats batching: stop trying for a while
-            if (C.b_try >= 16) { if (C.b_acc < 4 * C.b_try) { C.batch_on = false; C.cool = 0; } C.b_try = C.b_acc = 0; }
+            if ((acc >> lane) & 1) { out_cum = cu; out_freq = f; out_tot = tj; }
+            M.freq += GZ_MODEL_STEP * ceq;
+            M.cum  += GZ_MODEL_STEP * clt;
+            tot    += GZ_MODEL_STEP * (uint32_t)__popcll (acc);
+            todo &= ~acc;
             if (!todo) break;
         }
         // ---- one occurrence the ordinary way: the first pending one
-        if (!C.batch_on && ++C.cool >= 1024) C.batch_on = true;      // the model settles (warm-up swaps end): try again later
         const int b = __ffsll ((unsigned long long)todo) - 1;
         todo &= todo - 1;
         const int r = (int)d_readlane (M.where, (int)d_readlane (rk, b));
         const uint32_t f = d_readlane (M.freq, r), cu = d_readlane (M.cum, r);
         const bool owner = lane == b;
-        out_cum = owner ? cu : out_cum; out_freq = owner ? f : out_freq; out_tot = owner ? C.tot : out_tot;
-        d_model_serial_step (M, C.tot, lane, r, nsym, n_absent);
+        out_cum = owner ? cu : out_cum; out_freq = owner ? f : out_freq; out_tot = owner ? tot : out_tot;
+        d_model_serial_step (M, tot, lane, r, nsym, n_absent);
+    }
+}
+
+// ---- grouping the positions of an order-1 leaf by context ---------------------------------------------------------
+// Without it every context's wave has to scan the whole stream for its positions (with ~40 contexts in a quality
+// stream that scan was most of the instructions the model kernel executed). A stable counting sort by the context byte:
+//   k_ctx_count    per tile of 4096 positions: how many positions each context has in it (LDS counters)
+//   k_ctx_scan     per leaf: tile/context counts -> start index of every (tile, context) in the sorted order
+//   k_ctx_scatter  per tile, one wave walking it 64 positions at a time: index = running count of my context (an LDS
+//                  gather) + my rank among the lanes of this group with the same context (one ballot per distinct
+//                  context in the group)
+// The chunk size of the model / chain pipeline is a multiple of the tile size, so the occurrences of a context inside a
+// position chunk are one contiguous run of its list, delimited by ctxoff.
+#define GZ_CTX_TILE 4096u
+
+__device__ static inline bool d_ctx_sorted (const GzdLeaf &L) { return L.active && L.engine == GZ_ENG_ARITH && !L.rle && L.o1 && L.nsym <= 64 && L.coded_n; }
+__device__ static inline uint32_t d_ctx_ntiles (uint32_t n) { return (n + GZ_CTX_TILE - 1) / GZ_CTX_TILE; }
+
+// grid (n_leaves, max tiles), 64 threads
+__global__ void __launch_bounds__(64) k_ctx_count (GzdLeaf *leaves)
+{
+    GzdLeaf &L = leaves[blockIdx.x];
+    if (!d_ctx_sorted (L)) return;
+    const uint32_t n = L.coded_n, t0 = blockIdx.y * GZ_CTX_TILE;
+    if (t0 >= n) return;
+    const int lane = threadIdx.x;
+    uint32_t *cnt = (uint32_t *)gz_lds;
+    for (int e = lane; e < 256; e += 64) cnt[e] = 0;
+    __syncthreads ();
+    const uint8_t *in = L.coded;
+    for (uint32_t g = 0; g < GZ_CTX_TILE; g += 64) {
+        const uint32_t pos = t0 + g + lane;
+        if (pos < n) atomicAdd (&cnt[pos ? in[pos - 1] : 0], 1u);
+    }
+    __syncthreads ();
+    for (int e = lane; e < 256; e += 64) L.ctxoff[(size_t)blockIdx.y * 256 + e] = cnt[e];
+}
+
+// one 256-thread workgroup per leaf: thread c owns context c
+__global__ void __launch_bounds__(256) k_ctx_scan (GzdLeaf *leaves)
+{
+    GzdLeaf &L = leaves[blockIdx.x];
+    if (!d_ctx_sorted (L)) return;
+    const uint32_t nt = d_ctx_ntiles (L.coded_n), c = threadIdx.x;
+    uint32_t *off = L.ctxoff, *sh = (uint32_t *)gz_lds;
+    uint32_t run = 0;
+    for (uint32_t t = 0; t < nt; t++) { const uint32_t v = off[(size_t)t * 256 + c]; off[(size_t)t * 256 + c] = run; run += v; }
+    sh[c] = run;
+    __syncthreads ();
+    if (!c) { uint32_t b = 0; for (int e = 0; e < 256; e++) { const uint32_t v = sh[e]; sh[e] = b; b += v; } }
+    __syncthreads ();
+    const uint32_t base = sh[c];
+    for (uint32_t t = 0; t < nt; t++) off[(size_t)t * 256 + c] += base;
+    off[(size_t)nt * 256 + c] = base + run;
+}
+
+// grid (n_leaves, max tiles), 64 threads
+__global__ void __launch_bounds__(64) k_ctx_scatter (GzdLeaf *leaves)
+{
+    GzdLeaf &L = leaves[blockIdx.x];
+    if (!d_ctx_sorted (L)) return;
+    const uint32_t n = L.coded_n, t0 = blockIdx.y * GZ_CTX_TILE;
+    if (t0 >= n) return;
+    const int lane = threadIdx.x;
+    uint32_t *cnt = (uint32_t *)gz_lds;
+    uint8_t *rank_of = gz_lds + 1024;
+    for (int e = lane; e < 256; e += 64) { cnt[e] = L.ctxoff[(size_t)blockIdx.y * 256 + e]; rank_of[e] = (uint8_t)L.symrank[e]; }
+    __syncthreads ();
+    const uint8_t *in = L.coded;
+    uint32_t *spos = L.spos; uint8_t *srk = L.srk;
+    for (uint32_t g = 0; g < GZ_CTX_TILE && t0 + g < n; g += 64) {
+        const uint32_t pos = t0 + g + lane;
+        const bool valid = pos < n;
+        const uint32_t c = valid ? (pos ? in[pos - 1] : 0u) : 0xffffffffu, s = valid ? in[pos] : 0u;
+        const uint32_t base = valid ? cnt[c] : 0u;
+        uint32_t within = 0;
+        for (uint64_t rem = __ballot (valid); rem; ) {
+            const uint32_t q = d_readlane (c, __ffsll ((unsigned long long)rem) - 1);
+            const uint64_t mb = __ballot (c == q);
+            rem &= ~mb;
+            within = (c == q) ? gz_mbcnt (mb) : within;
+        }
+        if (valid) {
+            spos[base + within] = pos; srk[base + within] = rank_of[s];
+            atomicAdd (&cnt[c], 1u);
+        }
+        __syncthreads ();                                  // (one wave: the next group's gather sees this group's counts)
     }
 }
 
 // (force-inlined: as a called function its arguments would arrive in vector registers and every loop on them would
 //  become exec-mask code)
-__device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t *in, uint32_t n, uint32_t ms, bool o1, uint32_t ctx,
-                                                   uint4 *recs, const GzDivMagic *magic_tab, const uint8_t *symlist,
-                                                   const uint16_t *symrank, uint32_t nsym)
+// The occurrences of this wave's context inside the position chunk are entries [j0, j1) of the leaf's sorted lists
+// (order 1), or simply positions [j0, j1) of the stream (order 0: one context).
+__device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t *in, uint32_t n, uint32_t ms, bool o1, uint4 *recs,
+                                                   const GzDivMagic *magic_tab, const uint8_t *symlist, const uint16_t *symrank, uint32_t nsym,
+                                                   const uint32_t *spos, const uint8_t *srk, uint32_t j0, uint32_t j1, bool first, bool save, uint32_t *st)
 {
     const int lane = threadIdx.x & 63;
     const bool live = (uint32_t)lane < nsym;
     GzModelLane M;
-    M.sym = live ? symlist[lane] : 0xffffffffu;
-    const uint32_t prev_sym = (live && lane) ? symlist[lane - 1] : 0xffffffffu;
-    M.gap = live ? (lane ? M.sym - prev_sym - 1 : M.sym) : 0;
-    M.freq = live ? 1 : 0;
-    M.cum = live ? M.sym : ms;                            // lane entries + absent entries before it == its byte value
-    M.srank = lane; M.where = lane;
-    GzModelCtl C;
-    C.tot = ms; C.b_try = C.b_acc = C.cool = 0; C.batch_on = true;
+    uint32_t tot = ms;
+    if (first) {
+        M.sym = live ? symlist[lane] : 0xffffffffu;
+        const uint32_t prev_sym = (live && lane) ? symlist[lane - 1] : 0xffffffffu;
+        M.gap = live ? (lane ? M.sym - prev_sym - 1 : M.sym) : 0;
+        M.freq = live ? 1 : 0;
+        M.cum = live ? M.sym : ms;                        // lane entries + absent entries before it == its byte value
+        M.srank = lane; M.where = lane;
+    }
+    else {                                                // resume where the previous position chunk stopped
+        M.sym = st[lane]; M.srank = st[64 + lane]; M.freq = st[128 + lane]; M.cum = st[192 + lane]; M.gap = st[256 + lane]; M.where = st[320 + lane];
+        tot = d_uniform (st[384]);
+    }
     const uint32_t n_absent = ms - nsym;
 
-    uint8_t  *rank_of = gz_lds;                           // byte value -> static rank, a wave-private copy
-    uint32_t *q_pos = (uint32_t *)(gz_lds + 256), *q_rk = q_pos + GZ_MQ;
-    for (int e = lane; e < 256; e += 64) rank_of[e] = (uint8_t)symrank[e];
-    __syncthreads ();
-    uint32_t head = 0, tail = 0;                          // ring indices (not wrapped)
     // the records of a batch are stored while the next batch is being worked on: the division constants they need come
     // from a table in memory, and waiting for that load at the end of every batch would cost more than the batch
     uint32_t p_pos = 0, p_cum = 0, p_freq = 0; GzDivMagic p_mg = { 0, 0 }; bool p_on = false;
-
-    auto flush = [&] (uint32_t cnt) {
-        __syncthreads ();                                 // (one wave: orders the ring writes before the reads)
+    // ... and the occurrences of the next batch are fetched while this one is being worked on
+    uint32_t nx_pos = 0, nx_rk = 0;
+    if (j0 + lane < j1) {
+        if (o1) { nx_pos = spos[j0 + lane]; nx_rk = srk[j0 + lane]; }
+        else    { nx_pos = j0 + lane; nx_rk = symrank[in[nx_pos]]; }
+    }
+    for (uint32_t j = j0; j < j1; j += 64) {
+        const uint32_t cnt = j1 - j < 64 ? j1 - j : 64;
         const bool occ = (uint32_t)lane < cnt;
-        const uint32_t e = (head + (uint32_t)lane) & (GZ_MQ - 1);
-        const uint32_t b_pos = occ ? q_pos[e] : 0u, b_rk = occ ? q_rk[e] : 0u;
-        head += cnt;
+        const uint32_t b_pos = nx_pos, b_rk = nx_rk;
+        if (j + 64 + lane < j1) {
+            if (o1) { nx_pos = spos[j + 64 + lane]; nx_rk = srk[j + 64 + lane]; }
+            else    { nx_pos = j + 64 + lane; nx_rk = symrank[in[nx_pos]]; }
+        }
         uint32_t out_cum = 0, out_freq = 0, out_tot = 0;
-        d_model_batch (M, C, lane, cnt, b_rk, nsym, n_absent, out_cum, out_freq, out_tot);
+        d_model_batch (M, tot, lane, cnt, occ ? b_rk : 0u, nsym, n_absent, out_cum, out_freq, out_tot);
         if (p_on) recs[p_pos] = d_model_record (p_cum, p_freq, p_mg);
         p_on = occ; p_pos = b_pos; p_cum = out_cum; p_freq = out_freq;
         if (occ) p_mg = magic_tab[out_tot];
-    };
-
-    uint32_t nx_s[4], nx_p[4];
-    #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t pos = k * 64 + lane;
-        nx_s[k] = pos < n ? in[pos] : 0;
-        nx_p[k] = (o1 && pos && pos < n) ? in[pos - 1] : 0;
     }
-    for (uint32_t gbase = 0; gbase < n; gbase += 256) {
-        uint32_t cs[4], cp[4], rk[4];
-        #pragma unroll
-        for (int k = 0; k < 4; k++) { cs[k] = nx_s[k]; cp[k] = nx_p[k]; }
-        #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t pos = gbase + 256 + k * 64 + lane;
-            nx_s[k] = pos < n ? in[pos] : 0;
-            nx_p[k] = (o1 && pos < n) ? in[pos - 1] : 0;
-        }
-        #pragma unroll
-        for (int k = 0; k < 4; k++) rk[k] = rank_of[cs[k]];
-        #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t base = gbase + k * 64;
-            if (base >= n) break;
-            const uint32_t pos = base + lane;
-            const bool mine = pos < n && (!o1 || cp[k] == ctx);
-            const uint64_t mask = __ballot (mine);
-            if (!mask) continue;
-            const uint32_t slot = (tail + gz_mbcnt (mask)) & (GZ_MQ - 1);
-            if (mine) { q_pos[slot] = pos; q_rk[slot] = rk[k]; }
-            tail += (uint32_t)__popcll (mask);
-            if (tail - head >= 64) flush (64);
-        }
-    }
-    if (tail != head) flush (tail - head);
     if (p_on) recs[p_pos] = d_model_record (p_cum, p_freq, p_mg);
+    if (save) {
+        st[lane] = M.sym; st[64 + lane] = M.srank; st[128 + lane] = M.freq; st[192 + lane] = M.cum; st[256 + lane] = M.gap; st[320 + lane] = M.where;
+        if (!lane) st[384] = tot;
+    }
 }
 
+// Position chunks: the model of positions [k*C, (k+1)*C) of every leaf is one launch, the chain over the same positions
+// another one on a second HIP stream; chain chunk k runs beside model chunk k+1, so that only the first model chunk is
+// not hidden behind the (longer, strictly serial) chain. The models' registers travel between launches through mstate.
+#define GZ_MSTATE_WORDS 16                 // per lane and context: compact 6 (+ total), generic up to 12 (+ total)
+#define GZ_CHUNK_MIN    (64u * 1024u)      // positions; a multiple of GZ_CTX_TILE. Leaves up to this size are never split.
+
 // grid (n_leaves, 256): block y serves context y of leaf x
-__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const GzDivMagic *magic_tab)
+__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const GzDivMagic *magic_tab, uint32_t p0, uint32_t chunk)
 {
     GzdLeaf &L = leaves[blockIdx.x];
-    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle || !L.coded_n) return;
+    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle || L.coded_n <= p0) return;
     const uint32_t ctx = blockIdx.y, ms = L.max_sym;
     const bool o1 = L.o1;
     if (o1 ? (ctx >= ms || (ctx && L.symrank[ctx] == 0xffff)) : ctx != 0) return;   // a byte that never occurs is never a context
@@ -390,10 +518,22 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const GzDi
     const uint8_t *coded = d_uniform_ptr (L.coded);
     const uint32_t n_u = d_uniform (L.coded_n), ms_u = d_uniform (ms), nsym_u = d_uniform (L.nsym);
     const bool o1_u = d_uniform (o1 ? 1u : 0u) != 0;
-    if (nsym_u <= 64) { d_arith_model_wave_compact (coded, n_u, ms_u, o1_u, ctx, tr, magic_tab, L.symlist, L.symrank, nsym_u); return; }
-    if (ms <= 64)       d_arith_model_wave<1> (L.coded, L.coded_n, ms, o1, ctx, tr, magic_tab);
-    else if (ms <= 128) d_arith_model_wave<2> (L.coded, L.coded_n, ms, o1, ctx, tr, magic_tab);
-    else                d_arith_model_wave<4> (L.coded, L.coded_n, ms, o1, ctx, tr, magic_tab);
+    const uint32_t p1 = (n_u - p0 > chunk) ? p0 + chunk : n_u;
+    uint32_t *st = d_uniform_ptr (L.mstate) + (size_t)ctx * (GZ_MSTATE_WORDS * 64);   // (only touched when the leaf spans chunks)
+    if (nsym_u <= 64) {
+        uint32_t j0 = p0, j1 = p1;
+        if (o1_u) {                                            // my run of the sorted lists (chunks are whole tiles)
+            const uint32_t *off = d_uniform_ptr (L.ctxoff);
+            j0 = d_uniform (off[(size_t)(p0 / GZ_CTX_TILE) * 256 + ctx]);
+            j1 = d_uniform (off[(size_t)(p1 < n_u ? p1 / GZ_CTX_TILE : d_ctx_ntiles (n_u)) * 256 + ctx]);
+        }
+        d_arith_model_wave_compact (coded, n_u, ms_u, o1_u, tr, magic_tab, L.symlist, L.symrank, nsym_u,
+                                    d_uniform_ptr (L.spos), d_uniform_ptr (L.srk), j0, j1, p0 == 0, p1 < n_u, st);
+        return;
+    }
+    if (ms <= 64)       d_arith_model_wave<1> (coded, n_u, ms_u, o1_u, ctx, tr, magic_tab, p0, p1, st);
+    else if (ms <= 128) d_arith_model_wave<2> (coded, n_u, ms_u, o1_u, ctx, tr, magic_tab, p0, p1, st);
+    else                d_arith_model_wave<4> (coded, n_u, ms_u, o1_u, ctx, tr, magic_tab, p0, p1, st);
 }
 
 // ---- range coder chain ------------------------------------------------------------------------------------------
@@ -431,21 +571,24 @@ __device__ static inline uint32_t d_chain_step (uint32_t &range, uint32_t freq, 
     return r;
 }
 
-// one wave per leaf
-__global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
+// one wave per leaf; positions [p0, p0 + chunk) (p0 and chunk are multiples of 256)
+__global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves, uint32_t p0, uint32_t chunk)
 {
     GzdLeaf &L = leaves[blockIdx.x];
-    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
+    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle || L.coded_n <= p0) return;
+    __builtin_amdgcn_s_setprio (3);                            // the chain is the critical path: win every issue arbitration
     const int lane = threadIdx.x;
-    const uint32_t n = L.coded_n;
-    GzConstRecP rec = (GzConstRecP)(uintptr_t)L.triples;       // padded: reads up to 64 KB past n stay inside the area
-    const uint32_t *touch = (const uint32_t *)L.triples;
-    uint32_t *rout = (uint32_t *)L.rvals;
-    uint32_t sink = 0, touched = 0, range = 0xffffffffu;
+    const uint32_t n = d_uniform (L.coded_n);
+    const uint32_t p1 = (n - p0 > chunk) ? p0 + chunk : n;
+    uint8_t *triples = d_uniform_ptr (L.triples);              // (wave-uniform: keep them in scalar registers)
+    GzConstRecP rec = (GzConstRecP)(uintptr_t)triples;         // padded: reads up to 64 KB past n stay inside the area
+    const uint32_t *touch = (const uint32_t *)triples;
+    uint32_t *rout = d_uniform_ptr ((uint32_t *)L.rvals);
+    uint32_t sink = 0, touched = 0, range = p0 ? d_uniform (L.chain_range) : 0xffffffffu;
 
-    if (n && L.max_sym == 1) {
+    if (L.max_sym == 1) {
         // a stream of zero bytes: the range stays 2^32-1 while the model total is 1 (and 17), which n + inc cannot take
-        for (uint32_t i = 0; i < n; i++) {
+        for (uint32_t i = p0; i < p1; i++) {
             const gz_u32x4 c = rec[i];
             const uint32_t r = (uint32_t)(((uint64_t)c[1] * ((uint64_t)range + c[3])) >> 32) >> (c[2] & 31);
             const uint32_t x = r * c[0];
@@ -453,25 +596,30 @@ __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
             if (!lane) rout[i] = r;
         }
     }
-    else if (n) {
+    else {
         // the first symbol sees range = 2^32-1 and total = max_sym: as a reciprocal for exactly that case,
         // mulhi (q + 1, 2^32-1) = q
         const uint32_t q0 = 0xffffffffu / d_uniform (L.max_sym);
         // 16 records per iteration as two halves A and B of 8: while one half is being worked on, the loads of the
         // other are in flight (issued right after an explicit wait, because the compiler would place the wait for the
         // half it needs AFTER the issue of the next loads and so wait for those too)
-        const uint32_t nb = n & ~(uint32_t)(GZ_CHAIN_BLOCK - 1);
-        if (nb) {
-            GzConstRec4P rec4 = (GzConstRec4P)(uintptr_t)L.triples;       // (padded: loads past nb stay inside the area)
-            for (uint32_t b = 0; b < GZ_CHAIN_TOUCH_AHEAD; b += 4096) sink += touch[(b >> 2) + lane * 16];   // 64 lanes x 64 B = 4 KB
-            gz_u32x16 a0 = rec4[0], a1 = rec4[1];
-            a0[1] = q0 + 1; a0[2] = 0; a0[3] = 0;
+        // A chunk that is not the leaf's last one must not look past its end: those records are being written right now
+        // by the next model chunk, and a stale copy pulled into this XCD's L2 / scalar cache is not what the next chain
+        // launch should find. So the main loop (which loads 16 records ahead) stops 16 records early there.
+        const bool last = p1 == n;
+        const uint32_t nb = last ? p1 & ~(uint32_t)(GZ_CHAIN_BLOCK - 1) : p1 - 16;
+        const uint32_t touch_end = last ? 0xffffffffu : p1;                      // (in records)
+        if (nb > p0) {
+            GzConstRec4P rec4 = (GzConstRec4P)(uintptr_t)triples;         // (padded: loads past nb stay inside the area)
+            for (uint32_t b = 0; b < GZ_CHAIN_TOUCH_AHEAD; b += 4096) sink += touch[(size_t)p0 * 4 + (b >> 2) + lane * 16];   // 64 lanes x 64 B = 4 KB
+            gz_u32x16 a0 = rec4[p0 >> 2], a1 = rec4[(p0 >> 2) + 1];
+            if (!p0) { a0[1] = q0 + 1; a0[2] = 0; a0[3] = 0; }
             gz_wait_scalar_loads ();
-            for (uint32_t i = 0; ; ) {
+            for (uint32_t i = p0; ; ) {
                 const gz_u32x16 b0 = rec4[(i >> 2) + 2], b1 = rec4[(i >> 2) + 3];
                 gz_sched_fence ();
                 // every 256 records = 4 KB (the loaded value is only looked at 256 records later: no wait here)
-                if (!(i & 255)) { sink += touched; touched = touch[((i * 16 + GZ_CHAIN_TOUCH_AHEAD) >> 2) + lane * 16]; }
+                if (!(i & 255) && i + (GZ_CHAIN_TOUCH_AHEAD + 4096) / 16 <= touch_end) { sink += touched; touched = touch[(size_t)i * 4 + (GZ_CHAIN_TOUCH_AHEAD >> 2) + lane * 16]; }
                 uint32_t r0, r1, r2, r3;
                 r0 = d_chain_step (range, a0[0], a0[1], a0[2],  a0[3]);  r1 = d_chain_step (range, a0[4],  a0[5],  a0[6],  a0[7]);
                 r2 = d_chain_step (range, a0[8], a0[9], a0[10], a0[11]); r3 = d_chain_step (range, a0[12], a0[13], a0[14], a0[15]);
@@ -494,14 +642,14 @@ __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves)
                 gz_wait_scalar_loads ();
             }
         }
-        for (uint32_t i = nb; i < n; i++) {
+        for (uint32_t i = nb > p0 ? nb : p0; i < p1; i++) {
             const gz_u32x4 c = rec[i];
             const uint32_t r = i ? d_chain_step (range, c[0], c[1], c[2], c[3]) : d_chain_step (range, c[0], q0 + 1, 0, 0);
             if (!lane) rout[i] = r;
         }
     }
     gz_scalar_store_flush ();
-    if (!lane) L.touch_sink = sink + touched;
+    if (!lane) { L.touch_sink = sink + touched; L.chain_range = range; }
 }
 
 // ---- low: a big-number sum, one thread per symbol -----------------------------------------------------------------

@@ -37,7 +37,9 @@ def test_emul_arith_long_streams(emul_engine, oracle):
     from genozip_amd import synth
     items = [(16, synth.markov_bytes(3, 70000, 40, 33).tobytes()), (16, synth.uniform_bytes(4, 50000, 7).tobytes()),
              (18, synth.skewed_bytes(5, 90000, 4, 0.3).tobytes()), (17, synth.u32be_increasing(6, 80000).tobytes()),
-             (16, bytes(60000)), (16, synth.skewed_bytes(7, 120000, 2, 0.02).tobytes())]
+             (16, bytes(60000)), (16, synth.skewed_bytes(7, 120000, 2, 0.02).tobytes()),
+             # position chunks (> 64 K) through the wide-alphabet models and the all-zero special case
+             (16, synth.uniform_bytes(8, 140000, 200).tobytes()), (16, synth.markov_bytes(9, 70000, 100, 20).tobytes()), (16, bytes(70000))]
     got = emul_engine.compress_many(items)
     for (c, d), g in zip(items, got):
         assert g == oracle.codec_compress(c, d), (c, len(d))

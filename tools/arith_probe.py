@@ -16,7 +16,9 @@ kinds = {
     "skewed iid 8 symbols": synth.skewed_bytes(2, n, 8, 0.6, 48).tobytes(),
     "qual_bin (4 levels)": W.quality_rows(W._TH(torch.device("cuda", 0)), 5, 0, n // 150, "bin").cpu().numpy().tobytes(),
 }
+only = sys.argv[1] if len(sys.argv) > 1 else ""
 for name, d in kinds.items():
+    if only not in name: continue
     bufs = [E.mem.upload(d) for _ in range(copies)]
     tab, outs = E.make_stream_table([(16, b, len(d)) for b in bufs])
     E.compress_table(tab, copies); E.sync()
