@@ -42,6 +42,10 @@ struct GzHandle {
     hipStream_t stream2;      // side stream: work that is independent of the arithmetic coder's long chain runs beside it
     hipEvent_t ev_fork, ev_join;
     hipStream_t stream3;      // the range coder chain of position chunk k runs here, beside the models of chunk k+1
+    hipStream_t stream4;      // the models: like stream2 kept off the compute units reserved for the chain
+    hipEvent_t ev_model_fork;
+    hipStream_t stream5;      // model + chain of the leaves that fit one chunk
+    hipEvent_t ev_small;
     std::vector<hipEvent_t> ev_chunk;   // model chunk k done (recorded on stream); ev_chain = last chain chunk done
     hipEvent_t ev_chain;
     bool own_stream;
@@ -115,8 +119,17 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
         if (hipStreamCreateWithFlags (&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; if (err) *err = GZ_ERR_HIP; return NULL; }
         h->own_stream = true;
     }
-    if (hipStreamCreateWithFlags (&h->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags (&h->stream3, hipStreamNonBlocking) != hipSuccess ||
+    // The chain (one wave per leaf, strictly serial) is the critical path: its few workgroups must not queue behind
+    // the tens of thousands of the model kernel launched at the same moment, so its stream gets the highest priority and
+    // the streams of the kernels that run beside it the lowest.
+    int prio_lo = 0, prio_hi = 0;
+    if (hipDeviceGetStreamPriorityRange (&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
+    if (hipStreamCreateWithPriority (&h->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipStreamCreateWithPriority (&h->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority (&h->stream4, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipStreamCreateWithPriority (&h->stream5, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipEventCreateWithFlags (&h->ev_small, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags (&h->ev_model_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags (&h->ev_chain, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags (&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags (&h->ev_join, hipEventDisableTiming) != hipSuccess) { delete h; if (err) *err = GZ_ERR_HIP; return NULL; }
@@ -173,6 +186,10 @@ extern "C" void gz_destroy (GzHandle *h)
     if (h->own_stream) hipStreamDestroy (h->stream);
     hipStreamDestroy (h->stream2);
     hipStreamDestroy (h->stream3);
+    hipStreamDestroy (h->stream4);
+    hipStreamDestroy (h->stream5);
+    hipEventDestroy (h->ev_small);
+    hipEventDestroy (h->ev_model_fork);
     hipEventDestroy (h->ev_chain);
     for (hipEvent_t e : h->ev_chunk) hipEventDestroy (e);
     hipEventDestroy (h->ev_fork); hipEventDestroy (h->ev_join);
@@ -239,6 +256,7 @@ struct Plan {
     uint32_t max_in = 0;
     uint32_t max_arith_n = 0;              // largest plain (model/chain) arith leaf
     bool any_arith_o1 = false;
+    std::vector<uint32_t> plain_list, plain_nb, o1_list;   // plain (model/chain) arith leaves and their size bounds; those of them that are order-1
 };
 
 static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int plane, int method, uint32_t n_bound)
@@ -275,7 +293,10 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
                 if (!(L.srk    = (uint8_t *)arena_alloc (h, (size_t)n_bound + 64))) return false;
                 if (!(L.ctxoff = (uint32_t *)arena_alloc (h, (nt + 1) * 256 * 4))) return false;
                 P.any_arith_o1 = true;
+                P.o1_list.push_back ((uint32_t)P.leaves.size ());
             }
+            P.plain_list.push_back ((uint32_t)P.leaves.size ());
+            P.plain_nb.push_back (n_bound);
             if (n_bound > GZ_CHUNK_MIN && !(L.mstate = (uint32_t *)arena_alloc (h, (size_t)256 * GZ_MSTATE_WORDS * 64 * 4))) return false;
             if (n_bound > P.max_arith_n) P.max_arith_n = n_bound;
             const uint32_t ns = n_bound ? (n_bound + GZ_LOW_SLICE - 1) / GZ_LOW_SLICE : 1;
@@ -384,39 +405,66 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                                 d_leaves, ARITH_CLASS_WORDS[c], ARITH_CLASS_WORDS[c + 1], 0);
                 KLAUNCH_ON (h, side, k_arith_encode, dim3 (nl), dim3 (64), 0, d_leaves, ARITH_CLASS_WORDS[3], 0xffffffffu, 1);
             }
-            // position chunks (see gz_kernels_arith.h): at most 8 per leaf, none smaller than GZ_CHUNK_MIN
-            uint32_t chunk = ((P.max_arith_n + 7) / 8 + GZ_CTX_TILE - 1) & ~(GZ_CTX_TILE - 1);
-            if (chunk < GZ_CHUNK_MIN) chunk = GZ_CHUNK_MIN;
-            const uint32_t n_chunks = P.max_arith_n ? (P.max_arith_n + chunk - 1) / chunk : 1;
-            while (h->ev_chunk.size () < n_chunks) {
-                hipEvent_t e;
-                HIPCHK (h, hipEventCreateWithFlags (&e, hipEventDisableTiming));
-                h->ev_chunk.push_back (e);
-            }
-            if (P.any_arith_o1 && P.max_arith_n) {            // group the positions of order-1 leaves by context
-                const uint32_t max_tiles = (P.max_arith_n + GZ_CTX_TILE - 1) / GZ_CTX_TILE;
-                KLAUNCH (h, k_ctx_count, dim3 (nl, max_tiles), dim3 (64), 1024, d_leaves);
-                KLAUNCH (h, k_ctx_scan, dim3 (nl), dim3 (256), 1024, d_leaves);
-                KLAUNCH (h, k_ctx_scatter, dim3 (nl, max_tiles), dim3 (64), 1280, d_leaves);
-            }
-            for (uint32_t k = 0; k < n_chunks; k++) {
-                KLAUNCH (h, k_arith_model, dim3 (nl, 256), dim3 (64), 0, d_leaves, (const GzDivMagic *)h->d_magic, k * chunk, chunk);
-                if (n_chunks == 1) { KLAUNCH (h, k_arith_chain, dim3 (nl), dim3 (64), 0, d_leaves, 0u, chunk); break; }
-                HIPCHK (h, hipEventRecord (h->ev_chunk[k], h->stream));
-                HIPCHK (h, hipStreamWaitEvent (h->stream3, h->ev_chunk[k], 0));
-                KLAUNCH_ON (h, h->stream3, k_arith_chain, dim3 (nl), dim3 (64), 0, d_leaves, k * chunk, chunk);
-            }
-            if (n_chunks > 1) { HIPCHK (h, hipEventRecord (h->ev_chain, h->stream3)); HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_chain, 0)); }
-            if (!P.low_blocks.empty ()) {
-                void *d_lb;
-                int rc2 = upload (h, P.low_blocks.data (), P.low_blocks.size () * sizeof (GzdLowBlock), &d_lb);
+            if (!P.plain_list.empty ()) {
+                void *d_plain, *d_o1 = NULL, *d_lb;
+                int rc2 = upload (h, P.plain_list.data (), P.plain_list.size () * 4, &d_plain);
+                if (rc2 == GZ_OK && !P.o1_list.empty ()) rc2 = upload (h, P.o1_list.data (), P.o1_list.size () * 4, &d_o1);
+                if (rc2 == GZ_OK) rc2 = upload (h, P.low_blocks.data (), P.low_blocks.size () * sizeof (GzdLowBlock), &d_lb);
                 if (rc2 != GZ_OK) return rc2;
-                const uint32_t nlb = (uint32_t)P.low_blocks.size ();
+                const uint32_t np = (uint32_t)P.plain_list.size (), no1 = (uint32_t)P.o1_list.size (), nlb = (uint32_t)P.low_blocks.size ();
+                const uint32_t *pl = (const uint32_t *)d_plain;
+                // position chunks (see gz_kernels_arith.h): at most 8 per leaf, none smaller than GZ_CHUNK_MIN
+                uint32_t chunk = ((P.max_arith_n + 7) / 8 + GZ_CTX_TILE - 1) & ~(GZ_CTX_TILE - 1);
+                if (chunk < GZ_CHUNK_MIN) chunk = GZ_CHUNK_MIN;
+                const uint32_t n_chunks = P.max_arith_n ? (P.max_arith_n + chunk - 1) / chunk : 1;
+                while (h->ev_chunk.size () < n_chunks) {
+                    hipEvent_t e;
+                    HIPCHK (h, hipEventCreateWithFlags (&e, hipEventDisableTiming));
+                    h->ev_chunk.push_back (e);
+                }
+                if (no1 && P.max_arith_n) {                       // group the positions of order-1 leaves by context
+                    const uint32_t max_tiles = (P.max_arith_n + GZ_CTX_TILE - 1) / GZ_CTX_TILE;
+                    KLAUNCH (h, k_ctx_count, dim3 (no1, max_tiles), dim3 (64), 1024, d_leaves, (const uint32_t *)d_o1);
+                    KLAUNCH (h, k_ctx_scan, dim3 (no1), dim3 (256), 1024, d_leaves, (const uint32_t *)d_o1);
+                    KLAUNCH (h, k_ctx_scatter, dim3 (no1, max_tiles), dim3 (64), 1280, d_leaves, (const uint32_t *)d_o1);
+                }
+                // leaves that fit one chunk go through model and chain in one piece on the side stream; only the long ones
+                // take the pipeline (their first model chunk is the lead-in of the whole step: keep it free of other work)
+                std::vector<uint32_t> big, small;
+                for (size_t i = 0; i < P.plain_list.size (); i++) (P.plain_nb[i] > chunk ? big : small).push_back (P.plain_list[i]);
+                if (big.empty () || !fork) {
+                    KLAUNCH (h, k_arith_model, dim3 (np, GZ_MODEL_GRID_Y), dim3 (64), 0, d_leaves, pl, (const GzDivMagic *)h->d_magic, 0u, 0xffffffffu);
+                    KLAUNCH (h, k_arith_chain, dim3 (np), dim3 (64), 0, d_leaves, pl, 0u, 0xffffffffu);
+                }
+                else {
+                    void *d_big, *d_small = NULL;
+                    rc2 = upload (h, big.data (), big.size () * 4, &d_big);
+                    if (rc2 == GZ_OK && !small.empty ()) rc2 = upload (h, small.data (), small.size () * 4, &d_small);
+                    if (rc2 != GZ_OK) return rc2;
+                    const uint32_t nbig = (uint32_t)big.size (), nsmall = (uint32_t)small.size ();
+                    HIPCHK (h, hipEventRecord (h->ev_model_fork, h->stream));        // (after the uploads and the sort)
+                    HIPCHK (h, hipStreamWaitEvent (h->stream4, h->ev_model_fork, 0));
+                    for (uint32_t k = 0; k < n_chunks; k++) {
+                        KLAUNCH_ON (h, h->stream4, k_arith_model, dim3 (nbig, GZ_MODEL_GRID_Y), dim3 (64), 0, d_leaves, (const uint32_t *)d_big, (const GzDivMagic *)h->d_magic, k * chunk, chunk);
+                        HIPCHK (h, hipEventRecord (h->ev_chunk[k], h->stream4));
+                        HIPCHK (h, hipStreamWaitEvent (h->stream3, h->ev_chunk[k], 0));
+                        KLAUNCH_ON (h, h->stream3, k_arith_chain, dim3 (nbig), dim3 (64), 0, d_leaves, (const uint32_t *)d_big, k * chunk, chunk);
+                    }
+                    HIPCHK (h, hipEventRecord (h->ev_chain, h->stream3));
+                    if (nsmall) {
+                        HIPCHK (h, hipStreamWaitEvent (h->stream5, h->ev_model_fork, 0));
+                        KLAUNCH_ON (h, h->stream5, k_arith_model, dim3 (nsmall, GZ_MODEL_GRID_Y), dim3 (64), 0, d_leaves, (const uint32_t *)d_small, (const GzDivMagic *)h->d_magic, 0u, 0xffffffffu);
+                        KLAUNCH_ON (h, h->stream5, k_arith_chain, dim3 (nsmall), dim3 (64), 0, d_leaves, (const uint32_t *)d_small, 0u, 0xffffffffu);
+                        HIPCHK (h, hipEventRecord (h->ev_small, h->stream5));
+                        HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_small, 0));
+                    }
+                    HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_chain, 0));
+                }
                 KLAUNCH (h, k_low_count, dim3 (nlb), dim3 (GZ_LOW_WG), 0, d_leaves, (const GzdLowBlock *)d_lb);
-                KLAUNCH (h, k_low_scan, dim3 (nl), dim3 (1024), 8192, d_leaves);
+                KLAUNCH (h, k_low_scan, dim3 (np), dim3 (1024), 8192, d_leaves, pl);
                 KLAUNCH (h, k_low_scatter, dim3 (nlb), dim3 (GZ_LOW_WG), 4 * 144 * 4, d_leaves, (const GzdLowBlock *)d_lb);
                 KLAUNCH (h, k_low_resid, dim3 (nlb), dim3 (GZ_LOW_WG), 0, d_leaves, (const GzdLowBlock *)d_lb);
-                KLAUNCH (h, k_low_norm, dim3 (nl), dim3 (GZ_NORM_NT), 8192, d_leaves);
+                KLAUNCH (h, k_low_norm, dim3 (np), dim3 (GZ_NORM_NT), 8192, d_leaves, pl);
             }
         }
         if (fork) { HIPCHK (h, hipEventRecord (h->ev_join, side)); HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_join, 0)); }

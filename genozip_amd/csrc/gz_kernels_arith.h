@@ -373,9 +373,9 @@ __device__ static inline bool d_ctx_sorted (const GzdLeaf &L) { return L.active 
 __device__ static inline uint32_t d_ctx_ntiles (uint32_t n) { return (n + GZ_CTX_TILE - 1) / GZ_CTX_TILE; }
 
 // grid (n_leaves, max tiles), 64 threads
-__global__ void __launch_bounds__(64) k_ctx_count (GzdLeaf *leaves)
+__global__ void __launch_bounds__(64) k_ctx_count (GzdLeaf *leaves, const uint32_t *list)
 {
-    GzdLeaf &L = leaves[blockIdx.x];
+    GzdLeaf &L = leaves[list[blockIdx.x]];
     if (!d_ctx_sorted (L)) return;
     const uint32_t n = L.coded_n, t0 = blockIdx.y * GZ_CTX_TILE;
     if (t0 >= n) return;
@@ -393,9 +393,9 @@ __global__ void __launch_bounds__(64) k_ctx_count (GzdLeaf *leaves)
 }
 
 // one 256-thread workgroup per leaf: thread c owns context c
-__global__ void __launch_bounds__(256) k_ctx_scan (GzdLeaf *leaves)
+__global__ void __launch_bounds__(256) k_ctx_scan (GzdLeaf *leaves, const uint32_t *list)
 {
-    GzdLeaf &L = leaves[blockIdx.x];
+    GzdLeaf &L = leaves[list[blockIdx.x]];
     if (!d_ctx_sorted (L)) return;
     const uint32_t nt = d_ctx_ntiles (L.coded_n), c = threadIdx.x;
     uint32_t *off = L.ctxoff, *sh = (uint32_t *)gz_lds;
@@ -411,9 +411,9 @@ __global__ void __launch_bounds__(256) k_ctx_scan (GzdLeaf *leaves)
 }
 
 // grid (n_leaves, max tiles), 64 threads
-__global__ void __launch_bounds__(64) k_ctx_scatter (GzdLeaf *leaves)
+__global__ void __launch_bounds__(64) k_ctx_scatter (GzdLeaf *leaves, const uint32_t *list)
 {
-    GzdLeaf &L = leaves[blockIdx.x];
+    GzdLeaf &L = leaves[list[blockIdx.x]];
     if (!d_ctx_sorted (L)) return;
     const uint32_t n = L.coded_n, t0 = blockIdx.y * GZ_CTX_TILE;
     if (t0 >= n) return;
@@ -506,21 +506,31 @@ __device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t
 #define GZ_MSTATE_WORDS 16                 // per lane and context: compact 6 (+ total), generic up to 12 (+ total)
 #define GZ_CHUNK_MIN    (64u * 1024u)      // positions; a multiple of GZ_CTX_TILE. Leaves up to this size are never split.
 
-// grid (n_leaves, 256): block y serves context y of leaf x
-__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const GzDivMagic *magic_tab, uint32_t p0, uint32_t chunk)
+// The grids of these kernels run over a list of the plain arithmetic-coder leaves only (a VBlock's other leaves would
+// otherwise cost a million workgroups per launch that exit at once - and the dispatcher, not the work, set the pace).
+#define GZ_MODEL_GRID_Y 65                 // context 0 + one per present symbol of a compact leaf
+
+// grid (listed leaves, GZ_MODEL_GRID_Y)
+__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, const GzDivMagic *magic_tab, uint32_t p0, uint32_t chunk)
 {
-    GzdLeaf &L = leaves[blockIdx.x];
+    GzdLeaf &L = leaves[list[blockIdx.x]];
     if (!L.active || L.engine != GZ_ENG_ARITH || L.rle || L.coded_n <= p0) return;
-    const uint32_t ctx = blockIdx.y, ms = L.max_sym;
+    const uint32_t ms = L.max_sym;
     const bool o1 = L.o1;
-    if (o1 ? (ctx >= ms || (ctx && L.symrank[ctx] == 0xffff)) : ctx != 0) return;   // a byte that never occurs is never a context
     uint4 *tr = d_uniform_ptr ((uint4 *)L.triples);
     const uint8_t *coded = d_uniform_ptr (L.coded);
     const uint32_t n_u = d_uniform (L.coded_n), ms_u = d_uniform (ms), nsym_u = d_uniform (L.nsym);
     const bool o1_u = d_uniform (o1 ? 1u : 0u) != 0;
     const uint32_t p1 = (n_u - p0 > chunk) ? p0 + chunk : n_u;
-    uint32_t *st = d_uniform_ptr (L.mstate) + (size_t)ctx * (GZ_MSTATE_WORDS * 64);   // (only touched when the leaf spans chunks)
     if (nsym_u <= 64) {
+        // block 0: context 0 (the context of position 0, whether byte 0 occurs or not); block y: the y-th present symbol
+        uint32_t ctx = 0;
+        if (blockIdx.y) {
+            if (!o1_u || blockIdx.y > nsym_u) return;
+            ctx = d_uniform (L.symlist[blockIdx.y - 1]);
+            if (!ctx) return;                                  // (byte 0 is block 0's)
+        }
+        uint32_t *st = d_uniform_ptr (L.mstate) + (size_t)ctx * (GZ_MSTATE_WORDS * 64);   // (only touched when the leaf spans chunks)
         uint32_t j0 = p0, j1 = p1;
         if (o1_u) {                                            // my run of the sorted lists (chunks are whole tiles)
             const uint32_t *off = d_uniform_ptr (L.ctxoff);
@@ -531,9 +541,13 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const GzDi
                                     d_uniform_ptr (L.spos), d_uniform_ptr (L.srk), j0, j1, p0 == 0, p1 < n_u, st);
         return;
     }
-    if (ms <= 64)       d_arith_model_wave<1> (coded, n_u, ms_u, o1_u, ctx, tr, magic_tab, p0, p1, st);
-    else if (ms <= 128) d_arith_model_wave<2> (coded, n_u, ms_u, o1_u, ctx, tr, magic_tab, p0, p1, st);
-    else                d_arith_model_wave<4> (coded, n_u, ms_u, o1_u, ctx, tr, magic_tab, p0, p1, st);
+    // wide alphabets: the contexts are dealt out over the blocks of the column
+    for (uint32_t ctx = blockIdx.y; ctx < (o1_u ? ms_u : 1u); ctx += GZ_MODEL_GRID_Y) {
+        if (ctx && L.symrank[ctx] == 0xffff) continue;         // a byte that never occurs is never a context
+        uint32_t *st = d_uniform_ptr (L.mstate) + (size_t)ctx * (GZ_MSTATE_WORDS * 64);
+        if (ms <= 128) d_arith_model_wave<2> (coded, n_u, ms_u, o1_u, ctx, tr, magic_tab, p0, p1, st);
+        else           d_arith_model_wave<4> (coded, n_u, ms_u, o1_u, ctx, tr, magic_tab, p0, p1, st);
+    }
 }
 
 // ---- range coder chain ------------------------------------------------------------------------------------------
@@ -572,9 +586,9 @@ __device__ static inline uint32_t d_chain_step (uint32_t &range, uint32_t freq, 
 }
 
 // one wave per leaf; positions [p0, p0 + chunk) (p0 and chunk are multiples of 256)
-__global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves, uint32_t p0, uint32_t chunk)
+__global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t p0, uint32_t chunk)
 {
-    GzdLeaf &L = leaves[blockIdx.x];
+    GzdLeaf &L = leaves[list[blockIdx.x]];
     if (!L.active || L.engine != GZ_ENG_ARITH || L.rle || L.coded_n <= p0) return;
     __builtin_amdgcn_s_setprio (3);                            // the chain is the critical path: win every issue arbitration
     const int lane = threadIdx.x;
@@ -691,9 +705,9 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_count (GzdLeaf *leaves, const
 }
 
 // one 1024-thread workgroup per leaf
-__global__ void __launch_bounds__(1024) k_low_scan (GzdLeaf *leaves)
+__global__ void __launch_bounds__(1024) k_low_scan (GzdLeaf *leaves, const uint32_t *list)
 {
-    GzdLeaf &L = leaves[blockIdx.x];
+    GzdLeaf &L = leaves[list[blockIdx.x]];
     if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
     const int tid = threadIdx.x;
     uint32_t *sh = (uint32_t *)gz_lds;
@@ -788,9 +802,9 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_resid (GzdLeaf *leaves, const
 // carries then move one thread to the left per round as a 128-bit add until none is left (normally one round).
 #define GZ_NORM_NT 1024
 #define GZ_NORM_PER 16
-__global__ void __launch_bounds__(GZ_NORM_NT) k_low_norm (GzdLeaf *leaves)
+__global__ void __launch_bounds__(GZ_NORM_NT) k_low_norm (GzdLeaf *leaves, const uint32_t *list)
 {
-    GzdLeaf &L = leaves[blockIdx.x];
+    GzdLeaf &L = leaves[list[blockIdx.x]];
     if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
     const int tid = threadIdx.x;
     const uint32_t m = L.n_events;

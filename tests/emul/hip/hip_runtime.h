@@ -40,6 +40,8 @@ static inline const char *hipGetErrorString (hipError_t) { return "emulated"; }
 static inline hipError_t hipGetDeviceCount (int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice (int) { return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags (hipStream_t *s, int) { *s = (void *)1; return hipSuccess; }
+static inline hipError_t hipDeviceGetStreamPriorityRange (int *lo, int *hi) { *lo = 0; *hi = 0; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithPriority (hipStream_t *s, int, int) { *s = (void *)1; return hipSuccess; }
 static inline hipError_t hipStreamDestroy (hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize (hipStream_t) { return hipSuccess; }
 static inline hipError_t hipGetLastError (void) { return hipSuccess; }
