@@ -84,7 +84,6 @@ struct GzdLeaf {
     uint8_t   *srk;           // arith order-1: static rank of the symbol at spos[j]
     uint32_t  *ctxoff;        // arith order-1: [tile][context] -> index into spos/srk of the first occurrence at or after the tile
     uint32_t  *mstate;        // arith: the models' registers between two position chunks (GZ_MSTATE_WORDS x 64 lanes per context)
-    uint32_t  chain_range;    // arith: the coder's range between two position chunks
     uint8_t   *events;        // arith: one 32-bit digit per output byte (k_low_replay / k_low_norm)
     uint8_t   *rvals;         // arith: r = range / tot of every symbol (k_arith_chain -> k_low_*)
     uint8_t   *kpos;          // arith: per 64-symbol slice: shifts in it, then (k_low_scan) shifts before it

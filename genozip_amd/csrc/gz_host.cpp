@@ -46,8 +46,7 @@ struct GzHandle {
     hipEvent_t ev_model_fork;
     hipStream_t stream5;      // model + chain of the leaves that fit one chunk
     hipEvent_t ev_small;
-    std::vector<hipEvent_t> ev_chunk;   // model chunk k done (recorded on stream); ev_chain = last chain chunk done
-    hipEvent_t ev_chain;
+    hipEvent_t ev_chain_go, ev_chain;   // the persistent chain may start / has finished
     bool own_stream;
     std::vector<ArenaBlock> blocks;
     std::vector<Pending> pending;
@@ -131,6 +130,7 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
         hipEventCreateWithFlags (&h->ev_small, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags (&h->ev_model_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags (&h->ev_chain, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags (&h->ev_chain_go, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags (&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags (&h->ev_join, hipEventDisableTiming) != hipSuccess) { delete h; if (err) *err = GZ_ERR_HIP; return NULL; }
     // log(1024+k), log(4096+k) from the host libm: what the reference's compute_shift() sees (rANS_static4x16pr.c:647)
@@ -165,6 +165,7 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
     }
     // the largest LDS class of the arithmetic coder needs more than the default 64 KB of dynamic LDS
     if (hipFuncSetAttribute ((const void *)k_arith_encode, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
+        hipFuncSetAttribute ((const void *)k_arith_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
         hipFuncSetAttribute ((const void *)k_arith_decode, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
         if (err) *err = GZ_ERR_HIP;
         gz_destroy (h);
@@ -191,7 +192,7 @@ extern "C" void gz_destroy (GzHandle *h)
     hipEventDestroy (h->ev_small);
     hipEventDestroy (h->ev_model_fork);
     hipEventDestroy (h->ev_chain);
-    for (hipEvent_t e : h->ev_chunk) hipEventDestroy (e);
+    hipEventDestroy (h->ev_chain_go);
     hipEventDestroy (h->ev_fork); hipEventDestroy (h->ev_join);
     delete h;
 }
@@ -373,12 +374,68 @@ static int upload (GzHandle *h, const void *host, size_t bytes, void **dev)
     return GZ_OK;
 }
 
+// kernels that run beside the pipelined chain ask for this much LDS so that they never fit on a chain's compute unit
+#define GZ_KEEP_OFF_LDS 8192
 static const uint32_t ARITH_CLASS_WORDS[4] = { 0, 4096, 16384, 40000 };   // 16 KB, 64 KB, 156 KB of LDS
+
+// The arithmetic coder's pipeline of one batch (see gz_kernels_arith.h): which leaves, in how many position chunks
+struct ArithPipe {
+    uint32_t np = 0, no1 = 0, nlb = 0, nbig = 0, nsmall = 0, chunk = 0, n_chunks = 1;
+    const uint32_t *d_plain = NULL, *d_o1 = NULL, *d_big = NULL, *d_small = NULL;
+    const GzdLowBlock *d_lb = NULL;
+    uint32_t *d_progress = NULL;
+    bool pipelined = false;
+};
+
+static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
+{
+    A.np = (uint32_t)P.plain_list.size (); A.no1 = (uint32_t)P.o1_list.size (); A.nlb = (uint32_t)P.low_blocks.size ();
+    if (!A.np) return GZ_OK;
+    // position chunks: at most 8 per leaf, none smaller than GZ_CHUNK_MIN, whole sort tiles
+    A.chunk = ((P.max_arith_n + 7) / 8 + GZ_CTX_TILE - 1) & ~(GZ_CTX_TILE - 1);
+    if (A.chunk < GZ_CHUNK_MIN) A.chunk = GZ_CHUNK_MIN;
+    A.n_chunks = P.max_arith_n ? (P.max_arith_n + A.chunk - 1) / A.chunk : 1;
+    // leaves that fit one chunk go through model and chain in one piece on a stream of their own; only the long ones
+    // take the pipeline (their first model chunk is the lead-in of the whole step: keep it free of other work)
+    std::vector<uint32_t> big, small;
+    for (size_t i = 0; i < P.plain_list.size (); i++) (P.plain_nb[i] > A.chunk ? big : small).push_back (P.plain_list[i]);
+    A.nbig = (uint32_t)big.size (); A.nsmall = (uint32_t)small.size ();
+    A.pipelined = A.nbig != 0;
+    void *d;
+    int rc = upload (h, P.plain_list.data (), P.plain_list.size () * 4, &d); A.d_plain = (const uint32_t *)d;
+    if (rc == GZ_OK && A.no1)    { rc = upload (h, P.o1_list.data (), P.o1_list.size () * 4, &d); A.d_o1 = (const uint32_t *)d; }
+    if (rc == GZ_OK)             { rc = upload (h, P.low_blocks.data (), P.low_blocks.size () * sizeof (GzdLowBlock), &d); A.d_lb = (const GzdLowBlock *)d; }
+    if (rc == GZ_OK && A.nbig)   { rc = upload (h, big.data (), big.size () * 4, &d); A.d_big = (const uint32_t *)d; }
+    if (rc == GZ_OK && A.nsmall) { rc = upload (h, small.data (), small.size () * 4, &d); A.d_small = (const uint32_t *)d; }
+    if (rc != GZ_OK) return rc;
+    if (A.pipelined) {
+        if (!(A.d_progress = (uint32_t *)arena_alloc (h, 64))) return GZ_ERR_HIP;
+        HIPCHK (h, hipMemsetAsync (A.d_progress, 0, 64, h->stream));
+    }
+    return GZ_OK;
+}
+
+// the persistent chain of the long leaves: launched before everything else so that it finds free compute units
+static int arith_launch_chain (GzHandle *h, const ArithPipe &A, GzdLeaf *d_leaves)
+{
+    HIPCHK (h, hipEventRecord (h->ev_chain_go, h->stream));                     // (behind the uploads and the memset)
+    HIPCHK (h, hipStreamWaitEvent (h->stream3, h->ev_chain_go, 0));
+    KLAUNCH_ON (h, h->stream3, k_arith_chain, dim3 ((A.nbig + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), GZ_CHAIN_LDS,
+                d_leaves, A.d_big, A.nbig, (const uint32_t *)A.d_progress, A.chunk);
+    HIPCHK (h, hipEventRecord (h->ev_chain, h->stream3));
+    return GZ_OK;
+}
 
 static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d_leaves, GzdVB *d_vbs, uint32_t n_vbs, int section_mode)
 {
     const uint32_t ns = (uint32_t)P.streams.size (), nl = (uint32_t)P.leaves.size ();
     if (!ns) return GZ_OK;
+    ArithPipe A;
+    int rc = arith_pipe_setup (h, P, A);
+    if (rc != GZ_OK) return rc;
+#ifndef GZ_SEQUENTIAL_STREAMS
+    if (A.pipelined && (rc = arith_launch_chain (h, A, d_leaves)) != GZ_OK) return rc;
+#endif
     KLAUNCH (h, k_resolve, dim3 ((ns + 255) / 256), dim3 (256), 0, d_streams, ns, section_mode);
     if (P.any_striped) {
         uint32_t chunks = (P.max_in / 16 + 255) / 256;
@@ -388,8 +445,8 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
     }
     if (nl) {
         KLAUNCH (h, k_leaf_prep, dim3 (nl), dim3 (256), 4096, d_streams, d_leaves);
-        // fork: the rANS leaves and the run-length arith leaves do not depend on the long model/chain kernels of the
-        // plain arith leaves (which keep only one wave per leaf busy), so they run beside them on a second stream
+        // fork: the rANS leaves and the run-length arith leaves do not depend on the model/chain kernels of the plain
+        // arith leaves, so they run beside them on a second stream
         const bool fork = P.any_arith;
         hipStream_t side = fork ? h->stream2 : h->stream;
         if (fork) { HIPCHK (h, hipEventRecord (h->ev_fork, h->stream)); HIPCHK (h, hipStreamWaitEvent (side, h->ev_fork, 0)); }
@@ -398,74 +455,50 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
             KLAUNCH_ON (h, side, k_rans_table, dim3 (nl), dim3 (256), 16384, d_leaves, (const GzLogTable *)h->d_logs);
             KLAUNCH_ON (h, side, k_rans_encode, dim3 (nl), dim3 (64), 0, d_leaves);
         }
-        if (P.any_arith) {
-            if (P.any_arith_rle) {
-                for (int c = 0; c < 3; c++)
-                    KLAUNCH_ON (h, side, k_arith_encode, dim3 (nl), dim3 (64), ARITH_CLASS_WORDS[c + 1] * 4,
-                                d_leaves, ARITH_CLASS_WORDS[c], ARITH_CLASS_WORDS[c + 1], 0);
-                KLAUNCH_ON (h, side, k_arith_encode, dim3 (nl), dim3 (64), 0, d_leaves, ARITH_CLASS_WORDS[3], 0xffffffffu, 1);
+        if (P.any_arith_rle) {
+            for (int c = 0; c < 3; c++)
+                KLAUNCH_ON (h, side, k_arith_encode, dim3 (nl), dim3 (64), ARITH_CLASS_WORDS[c + 1] * 4,
+                            d_leaves, ARITH_CLASS_WORDS[c], ARITH_CLASS_WORDS[c + 1], 0);
+            KLAUNCH_ON (h, side, k_arith_encode, dim3 (nl), dim3 (64), 0, d_leaves, ARITH_CLASS_WORDS[3], 0xffffffffu, 1);
+        }
+        if (A.np) {
+            const GzDivMagic *magic = (const GzDivMagic *)h->d_magic;
+            if (A.no1 && P.max_arith_n) {                         // group the positions of order-1 leaves by context
+                const uint32_t max_tiles = (P.max_arith_n + GZ_CTX_TILE - 1) / GZ_CTX_TILE;
+                KLAUNCH (h, k_ctx_count, dim3 (A.no1, max_tiles), dim3 (64), 1024, d_leaves, A.d_o1);
+                KLAUNCH (h, k_ctx_scan, dim3 (A.no1), dim3 (256), 1024, d_leaves, A.d_o1);
+                KLAUNCH (h, k_ctx_scatter, dim3 (A.no1, max_tiles), dim3 (64), 1280, d_leaves, A.d_o1);
             }
-            if (!P.plain_list.empty ()) {
-                void *d_plain, *d_o1 = NULL, *d_lb;
-                int rc2 = upload (h, P.plain_list.data (), P.plain_list.size () * 4, &d_plain);
-                if (rc2 == GZ_OK && !P.o1_list.empty ()) rc2 = upload (h, P.o1_list.data (), P.o1_list.size () * 4, &d_o1);
-                if (rc2 == GZ_OK) rc2 = upload (h, P.low_blocks.data (), P.low_blocks.size () * sizeof (GzdLowBlock), &d_lb);
-                if (rc2 != GZ_OK) return rc2;
-                const uint32_t np = (uint32_t)P.plain_list.size (), no1 = (uint32_t)P.o1_list.size (), nlb = (uint32_t)P.low_blocks.size ();
-                const uint32_t *pl = (const uint32_t *)d_plain;
-                // position chunks (see gz_kernels_arith.h): at most 8 per leaf, none smaller than GZ_CHUNK_MIN
-                uint32_t chunk = ((P.max_arith_n + 7) / 8 + GZ_CTX_TILE - 1) & ~(GZ_CTX_TILE - 1);
-                if (chunk < GZ_CHUNK_MIN) chunk = GZ_CHUNK_MIN;
-                const uint32_t n_chunks = P.max_arith_n ? (P.max_arith_n + chunk - 1) / chunk : 1;
-                while (h->ev_chunk.size () < n_chunks) {
-                    hipEvent_t e;
-                    HIPCHK (h, hipEventCreateWithFlags (&e, hipEventDisableTiming));
-                    h->ev_chunk.push_back (e);
-                }
-                if (no1 && P.max_arith_n) {                       // group the positions of order-1 leaves by context
-                    const uint32_t max_tiles = (P.max_arith_n + GZ_CTX_TILE - 1) / GZ_CTX_TILE;
-                    KLAUNCH (h, k_ctx_count, dim3 (no1, max_tiles), dim3 (64), 1024, d_leaves, (const uint32_t *)d_o1);
-                    KLAUNCH (h, k_ctx_scan, dim3 (no1), dim3 (256), 1024, d_leaves, (const uint32_t *)d_o1);
-                    KLAUNCH (h, k_ctx_scatter, dim3 (no1, max_tiles), dim3 (64), 1280, d_leaves, (const uint32_t *)d_o1);
-                }
-                // leaves that fit one chunk go through model and chain in one piece on the side stream; only the long ones
-                // take the pipeline (their first model chunk is the lead-in of the whole step: keep it free of other work)
-                std::vector<uint32_t> big, small;
-                for (size_t i = 0; i < P.plain_list.size (); i++) (P.plain_nb[i] > chunk ? big : small).push_back (P.plain_list[i]);
-                if (big.empty () || !fork) {
-                    KLAUNCH (h, k_arith_model, dim3 (np, GZ_MODEL_GRID_Y), dim3 (64), 0, d_leaves, pl, (const GzDivMagic *)h->d_magic, 0u, 0xffffffffu);
-                    KLAUNCH (h, k_arith_chain, dim3 (np), dim3 (64), 0, d_leaves, pl, 0u, 0xffffffffu);
-                }
-                else {
-                    void *d_big, *d_small = NULL;
-                    rc2 = upload (h, big.data (), big.size () * 4, &d_big);
-                    if (rc2 == GZ_OK && !small.empty ()) rc2 = upload (h, small.data (), small.size () * 4, &d_small);
-                    if (rc2 != GZ_OK) return rc2;
-                    const uint32_t nbig = (uint32_t)big.size (), nsmall = (uint32_t)small.size ();
-                    HIPCHK (h, hipEventRecord (h->ev_model_fork, h->stream));        // (after the uploads and the sort)
-                    HIPCHK (h, hipStreamWaitEvent (h->stream4, h->ev_model_fork, 0));
-                    for (uint32_t k = 0; k < n_chunks; k++) {
-                        KLAUNCH_ON (h, h->stream4, k_arith_model, dim3 (nbig, GZ_MODEL_GRID_Y), dim3 (64), 0, d_leaves, (const uint32_t *)d_big, (const GzDivMagic *)h->d_magic, k * chunk, chunk);
-                        HIPCHK (h, hipEventRecord (h->ev_chunk[k], h->stream4));
-                        HIPCHK (h, hipStreamWaitEvent (h->stream3, h->ev_chunk[k], 0));
-                        KLAUNCH_ON (h, h->stream3, k_arith_chain, dim3 (nbig), dim3 (64), 0, d_leaves, (const uint32_t *)d_big, k * chunk, chunk);
-                    }
-                    HIPCHK (h, hipEventRecord (h->ev_chain, h->stream3));
-                    if (nsmall) {
-                        HIPCHK (h, hipStreamWaitEvent (h->stream5, h->ev_model_fork, 0));
-                        KLAUNCH_ON (h, h->stream5, k_arith_model, dim3 (nsmall, GZ_MODEL_GRID_Y), dim3 (64), 0, d_leaves, (const uint32_t *)d_small, (const GzDivMagic *)h->d_magic, 0u, 0xffffffffu);
-                        KLAUNCH_ON (h, h->stream5, k_arith_chain, dim3 (nsmall), dim3 (64), 0, d_leaves, (const uint32_t *)d_small, 0u, 0xffffffffu);
-                        HIPCHK (h, hipEventRecord (h->ev_small, h->stream5));
-                        HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_small, 0));
-                    }
-                    HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_chain, 0));
-                }
-                KLAUNCH (h, k_low_count, dim3 (nlb), dim3 (GZ_LOW_WG), 0, d_leaves, (const GzdLowBlock *)d_lb);
-                KLAUNCH (h, k_low_scan, dim3 (np), dim3 (1024), 8192, d_leaves, pl);
-                KLAUNCH (h, k_low_scatter, dim3 (nlb), dim3 (GZ_LOW_WG), 4 * 144 * 4, d_leaves, (const GzdLowBlock *)d_lb);
-                KLAUNCH (h, k_low_resid, dim3 (nlb), dim3 (GZ_LOW_WG), 0, d_leaves, (const GzdLowBlock *)d_lb);
-                KLAUNCH (h, k_low_norm, dim3 (np), dim3 (GZ_NORM_NT), 8192, d_leaves, pl);
+            if (!A.pipelined) {
+                KLAUNCH (h, k_arith_model, dim3 (A.np, GZ_MODEL_GRID_Y), dim3 (64), 0, d_leaves, A.d_plain, magic, 0u, 0xffffffffu);
+                KLAUNCH (h, k_arith_chain, dim3 ((A.np + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), 0,
+                         d_leaves, A.d_plain, A.np, (const uint32_t *)NULL, 0u);
             }
+            else {
+                HIPCHK (h, hipEventRecord (h->ev_model_fork, h->stream));        // (after the sort)
+                HIPCHK (h, hipStreamWaitEvent (h->stream4, h->ev_model_fork, 0));
+                for (uint32_t k = 0; k < A.n_chunks; k++) {
+                    KLAUNCH_ON (h, h->stream4, k_arith_model, dim3 (A.nbig, GZ_MODEL_GRID_Y), dim3 (64), GZ_KEEP_OFF_LDS, d_leaves, A.d_big, magic, k * A.chunk, A.chunk);
+                    hipLaunchKernelGGL (k_arith_progress, dim3 (1), dim3 (1), 0, h->stream4, A.d_progress, k + 1);
+                }
+#ifdef GZ_SEQUENTIAL_STREAMS
+                if ((rc = arith_launch_chain (h, A, d_leaves)) != GZ_OK) return rc;
+#endif
+                if (A.nsmall) {
+                    HIPCHK (h, hipStreamWaitEvent (h->stream5, h->ev_model_fork, 0));
+                    KLAUNCH_ON (h, h->stream5, k_arith_model, dim3 (A.nsmall, GZ_MODEL_GRID_Y), dim3 (64), GZ_KEEP_OFF_LDS, d_leaves, A.d_small, magic, 0u, 0xffffffffu);
+                    KLAUNCH_ON (h, h->stream5, k_arith_chain, dim3 ((A.nsmall + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), GZ_KEEP_OFF_LDS,
+                                d_leaves, A.d_small, A.nsmall, (const uint32_t *)NULL, 0u);
+                    HIPCHK (h, hipEventRecord (h->ev_small, h->stream5));
+                    HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_small, 0));
+                }
+                HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_chain, 0));
+            }
+            KLAUNCH (h, k_low_count, dim3 (A.nlb), dim3 (GZ_LOW_WG), 0, d_leaves, A.d_lb);
+            KLAUNCH (h, k_low_scan, dim3 (A.np), dim3 (1024), 8192, d_leaves, A.d_plain);
+            KLAUNCH (h, k_low_scatter, dim3 (A.nlb), dim3 (GZ_LOW_WG), 4 * 144 * 4, d_leaves, A.d_lb);
+            KLAUNCH (h, k_low_resid, dim3 (A.nlb), dim3 (GZ_LOW_WG), 0, d_leaves, A.d_lb);
+            KLAUNCH (h, k_low_norm, dim3 (A.np), dim3 (GZ_NORM_NT), 8192, d_leaves, A.d_plain);
         }
         if (fork) { HIPCHK (h, hipEventRecord (h->ev_join, side)); HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_join, 0)); }
     }

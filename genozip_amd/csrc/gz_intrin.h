@@ -39,3 +39,6 @@ __device__ static inline uint32_t gz_mbcnt (uint64_t m)
 {
     return __builtin_amdgcn_mbcnt_hi ((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo ((uint32_t)m, 0u));
 }
+
+// drop the scalar data cache (after an acquire, before scalar loads of data another kernel has just written)
+__device__ static inline void gz_scalar_cache_inv (void) { asm volatile ("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : : : "memory"); }

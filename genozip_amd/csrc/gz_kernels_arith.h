@@ -54,15 +54,17 @@ __device__ static inline uint32_t d_readlane (uint32_t v, int lane) { return (ui
 // (clang 22 / ROCm 7.2 has no __builtin_amdgcn_writelane; compare + select costs one more VALU op than v_writelane_b32)
 __device__ static inline uint32_t d_writelane (uint32_t val, int lane, uint32_t old) { return (int)(threadIdx.x & 63) == lane ? val : old; }
 
-// J = registers per lane holding the model (entries e = j*64 + lane), J*64 >= max_sym
+// J = registers per lane holding the model (entries e = j*64 + lane), J*64 >= max_sym. Wide alphabets (> 64 distinct
+// bytes: binary planes) - one occurrence at a time. The occurrences of this wave's context inside the position chunk
+// are entries [j0, j1) of the leaf's sorted lists (order 1; srk holds the byte itself), or positions [j0, j1) (order 0).
 template <int J>
-__device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, uint32_t n, uint32_t ms, bool o1, uint32_t ctx, uint4 *recs, const GzDivMagic *magic_tab,
-                                                            uint32_t p0, uint32_t p1, uint32_t *st)
+__device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, uint32_t ms, bool o1, uint4 *recs, const GzDivMagic *magic_tab,
+                                                            const uint32_t *spos, const uint8_t *srk, uint32_t j0, uint32_t j1, bool first, bool save, uint32_t *st)
 {
     const int lane = threadIdx.x & 63;
     uint32_t sym[J], freq[J], cum[J];
     uint32_t tot = ms;
-    if (p0 == 0) {
+    if (first) {
         #pragma unroll
         for (int j = 0; j < J; j++) {
             uint32_t e = j * 64 + lane;
@@ -75,33 +77,20 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
         tot = d_uniform (st[12 * 64]);
     }
 
-    // The wave scans the whole stream for "its" positions, 4 x 64 positions per iteration; the bytes of the next
-    // iteration are requested before the current ones are used, so the scan never waits for memory.
-    uint32_t nx_s[4], nx_p[4];
-    #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t pos = p0 + k * 64 + lane;
-        nx_s[k] = pos < n ? in[pos] : 0;
-        nx_p[k] = (o1 && pos && pos < n) ? in[pos - 1] : 0;
+    uint32_t nx_pos = 0, nx_s = 0;                         // the next 64 occurrences are fetched while these are worked on
+    if (j0 + lane < j1) {
+        if (o1) { nx_pos = spos[j0 + lane]; nx_s = srk[j0 + lane]; }
+        else    { nx_pos = j0 + lane; nx_s = in[nx_pos]; }
     }
-    for (uint32_t gbase = p0; gbase < p1; gbase += 256) {
-        uint32_t cs[4], cp[4];
-        #pragma unroll
-        for (int k = 0; k < 4; k++) { cs[k] = nx_s[k]; cp[k] = nx_p[k]; }
-        #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t pos = gbase + 256 + k * 64 + lane;
-            nx_s[k] = pos < n ? in[pos] : 0;
-            nx_p[k] = (o1 && pos < n) ? in[pos - 1] : 0;
+    for (uint32_t jb = j0; jb < j1; jb += 64) {
+        const uint32_t cnt = j1 - jb < 64 ? j1 - jb : 64;
+        const bool mine = (uint32_t)lane < cnt;
+        const uint32_t pos = nx_pos, s_v = nx_s;
+        if (jb + 64 + lane < j1) {
+            if (o1) { nx_pos = spos[jb + 64 + lane]; nx_s = srk[jb + 64 + lane]; }
+            else    { nx_pos = jb + 64 + lane; nx_s = in[nx_pos]; }
         }
-      #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t base = gbase + k * 64;
-        if (base >= p1) break;
-        const uint32_t pos = base + lane;
-        const uint32_t s_v = cs[k];
-        const bool mine = pos < p1 && (!o1 || cp[k] == ctx);
-        uint64_t todo = __ballot (mine);
+        uint64_t todo = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
         uint32_t out_lo = 0, out_hi = 0;
         while (todo) {
             const int b = __ffsll ((unsigned long long)todo) - 1;
@@ -117,7 +106,7 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
             uint32_t f = 0, cu = 0;
             #pragma unroll
             for (int j = 0; j < J; j++) if (j == jj) { f = d_readlane (freq[j], pl); cu = d_readlane (cum[j], pl); }
-            // ---- hand (cum, freq, tot) to the lane that owns this position
+            // ---- hand (cum, freq, tot) to the lane that owns this occurrence
             out_lo = d_writelane (cu | (f << 16), b, out_lo);      // cum and freq both fit 16 bits
             out_hi = d_writelane (tot, b, out_hi);
             // ---- bump (c_simple_model.h:133-134): the entry gains 16, so does the cumulative of everything after it
@@ -164,9 +153,8 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
             }
         }
         if (mine) recs[pos] = d_model_record (out_lo & 0xffff, out_lo >> 16, magic_tab[out_hi]);
-      }
     }
-    if (p1 < n) {
+    if (save) {
         #pragma unroll
         for (int j = 0; j < J; j++) { st[(3 * j) * 64 + lane] = sym[j]; st[(3 * j + 1) * 64 + lane] = freq[j]; st[(3 * j + 2) * 64 + lane] = cum[j]; }
         if (!lane) st[12 * 64] = tot;
@@ -369,7 +357,7 @@ __device__ static __forceinline__ void d_model_batch (GzModelLane &M, uint32_t &
 // position chunk are one contiguous run of its list, delimited by ctxoff.
 #define GZ_CTX_TILE 4096u
 
-__device__ static inline bool d_ctx_sorted (const GzdLeaf &L) { return L.active && L.engine == GZ_ENG_ARITH && !L.rle && L.o1 && L.nsym <= 64 && L.coded_n; }
+__device__ static inline bool d_ctx_sorted (const GzdLeaf &L) { return L.active && L.engine == GZ_ENG_ARITH && !L.rle && L.o1 && L.coded_n; }
 __device__ static inline uint32_t d_ctx_ntiles (uint32_t n) { return (n + GZ_CTX_TILE - 1) / GZ_CTX_TILE; }
 
 // grid (n_leaves, max tiles), 64 threads
@@ -420,14 +408,20 @@ __global__ void __launch_bounds__(64) k_ctx_scatter (GzdLeaf *leaves, const uint
     const int lane = threadIdx.x;
     uint32_t *cnt = (uint32_t *)gz_lds;
     uint8_t *rank_of = gz_lds + 1024;
-    for (int e = lane; e < 256; e += 64) { cnt[e] = L.ctxoff[(size_t)blockIdx.y * 256 + e]; rank_of[e] = (uint8_t)L.symrank[e]; }
+    const bool wide = L.nsym > 64;                          // wide alphabets keep the byte itself
+    for (int e = lane; e < 256; e += 64) { cnt[e] = L.ctxoff[(size_t)blockIdx.y * 256 + e]; rank_of[e] = wide ? (uint8_t)e : (uint8_t)L.symrank[e]; }
     __syncthreads ();
     const uint8_t *in = L.coded;
     uint32_t *spos = L.spos; uint8_t *srk = L.srk;
+    // (the bytes of the next group are requested before this group is worked on)
+    uint32_t nx_c = 0xffffffffu, nx_s = 0;
+    if (t0 + lane < n) { nx_c = (t0 + lane) ? in[t0 + lane - 1] : 0u; nx_s = in[t0 + lane]; }
     for (uint32_t g = 0; g < GZ_CTX_TILE && t0 + g < n; g += 64) {
         const uint32_t pos = t0 + g + lane;
         const bool valid = pos < n;
-        const uint32_t c = valid ? (pos ? in[pos - 1] : 0u) : 0xffffffffu, s = valid ? in[pos] : 0u;
+        const uint32_t c = nx_c, s = nx_s;
+        nx_c = 0xffffffffu;
+        if (g + 64 < GZ_CTX_TILE && pos + 64 < n) { nx_c = in[pos + 63]; nx_s = in[pos + 64]; }
         const uint32_t base = valid ? cnt[c] : 0u;
         uint32_t within = 0;
         for (uint64_t rem = __ballot (valid); rem; ) {
@@ -522,6 +516,9 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
     const uint32_t n_u = d_uniform (L.coded_n), ms_u = d_uniform (ms), nsym_u = d_uniform (L.nsym);
     const bool o1_u = d_uniform (o1 ? 1u : 0u) != 0;
     const uint32_t p1 = (n_u - p0 > chunk) ? p0 + chunk : n_u;
+    const uint32_t *off = d_uniform_ptr (L.ctxoff), *spos = d_uniform_ptr (L.spos);
+    const uint8_t *srk = d_uniform_ptr (L.srk);
+    const uint32_t t0 = p0 / GZ_CTX_TILE, t1 = p1 < n_u ? p1 / GZ_CTX_TILE : d_ctx_ntiles (n_u);   // (chunks are whole tiles)
     if (nsym_u <= 64) {
         // block 0: context 0 (the context of position 0, whether byte 0 occurs or not); block y: the y-th present symbol
         uint32_t ctx = 0;
@@ -532,21 +529,19 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
         }
         uint32_t *st = d_uniform_ptr (L.mstate) + (size_t)ctx * (GZ_MSTATE_WORDS * 64);   // (only touched when the leaf spans chunks)
         uint32_t j0 = p0, j1 = p1;
-        if (o1_u) {                                            // my run of the sorted lists (chunks are whole tiles)
-            const uint32_t *off = d_uniform_ptr (L.ctxoff);
-            j0 = d_uniform (off[(size_t)(p0 / GZ_CTX_TILE) * 256 + ctx]);
-            j1 = d_uniform (off[(size_t)(p1 < n_u ? p1 / GZ_CTX_TILE : d_ctx_ntiles (n_u)) * 256 + ctx]);
-        }
-        d_arith_model_wave_compact (coded, n_u, ms_u, o1_u, tr, magic_tab, L.symlist, L.symrank, nsym_u,
-                                    d_uniform_ptr (L.spos), d_uniform_ptr (L.srk), j0, j1, p0 == 0, p1 < n_u, st);
+        if (o1_u) { j0 = d_uniform (off[(size_t)t0 * 256 + ctx]); j1 = d_uniform (off[(size_t)t1 * 256 + ctx]); }   // my run of the sorted lists
+        d_arith_model_wave_compact (coded, n_u, ms_u, o1_u, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
         return;
     }
     // wide alphabets: the contexts are dealt out over the blocks of the column
     for (uint32_t ctx = blockIdx.y; ctx < (o1_u ? ms_u : 1u); ctx += GZ_MODEL_GRID_Y) {
         if (ctx && L.symrank[ctx] == 0xffff) continue;         // a byte that never occurs is never a context
         uint32_t *st = d_uniform_ptr (L.mstate) + (size_t)ctx * (GZ_MSTATE_WORDS * 64);
-        if (ms <= 128) d_arith_model_wave<2> (coded, n_u, ms_u, o1_u, ctx, tr, magic_tab, p0, p1, st);
-        else           d_arith_model_wave<4> (coded, n_u, ms_u, o1_u, ctx, tr, magic_tab, p0, p1, st);
+        uint32_t j0 = p0, j1 = p1;
+        if (o1_u) { j0 = d_uniform (off[(size_t)t0 * 256 + ctx]); j1 = d_uniform (off[(size_t)t1 * 256 + ctx]); }
+        if (j0 == j1 && p0) continue;                           // (nothing of mine in this chunk: the saved state stands)
+        if (ms <= 128) d_arith_model_wave<2> (coded, ms_u, o1_u, tr, magic_tab, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        else           d_arith_model_wave<4> (coded, ms_u, o1_u, tr, magic_tab, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
     }
 }
 
@@ -585,22 +580,39 @@ __device__ static inline uint32_t d_chain_step (uint32_t &range, uint32_t freq, 
     return r;
 }
 
-// one wave per leaf; positions [p0, p0 + chunk) (p0 and chunk are multiples of 256)
-__global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t p0, uint32_t chunk)
+// positions [p0, p0 + chunk) (p0 and chunk are multiples of 256)
+// Four leaves per workgroup, one per wave (= one per SIMD). For the long leaves the kernel is PERSISTENT: it is launched
+// at the start of the step, asks for (nearly) the whole LDS of a compute unit although it uses none - so that no
+// workgroup of another kernel that needs LDS fits beside it and the chain waves, the critical path of the whole step,
+// share instruction fetch and issue with nobody - and then follows the model kernels chunk by chunk: `progress` is the
+// number of position chunks whose records are complete (written by k_arith_progress, which the host queues behind every
+// model launch). Records are only ever read after their chunk was announced, and never before by this kernel (the
+// look-ahead stays inside the announced chunks), so no stale copy of them can sit in a cache on the way.
+#define GZ_CHAIN_WAVES 4
+#define GZ_CHAIN_LDS   (156 * 1024)
+
+__global__ void k_arith_progress (uint32_t *progress, uint32_t chunks_done) { *progress = chunks_done; }
+
+// (bounded: if the models never report - a failed launch - the chain gives up after a few seconds instead of hanging
+//  the device; the leaf is then flagged and its stream fails)
+__device__ static inline bool d_wait_progress (const uint32_t *progress, uint32_t want)
 {
-    GzdLeaf &L = leaves[list[blockIdx.x]];
-    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle || L.coded_n <= p0) return;
-    __builtin_amdgcn_s_setprio (3);                            // the chain is the critical path: win every issue arbitration
-    const int lane = threadIdx.x;
-    const uint32_t n = d_uniform (L.coded_n);
-    const uint32_t p1 = (n - p0 > chunk) ? p0 + chunk : n;
-    uint8_t *triples = d_uniform_ptr (L.triples);              // (wave-uniform: keep them in scalar registers)
+    for (uint32_t spins = 0; __atomic_load_n (progress, __ATOMIC_RELAXED) < want; spins++) {
+        if (spins > 8000000u) return false;
+        __builtin_amdgcn_s_sleep (16);
+    }
+    __atomic_thread_fence (__ATOMIC_ACQUIRE);
+    gz_scalar_cache_inv ();
+    return true;
+}
+
+// positions [p0, p1) of one leaf
+__device__ static __forceinline__ void d_chain_chunk (uint32_t &range, uint32_t &sink, uint32_t &touched, int lane, uint32_t p0, uint32_t p1, uint32_t n,
+                                                      uint8_t *triples, uint32_t *rout, uint32_t max_sym)
+{
     GzConstRecP rec = (GzConstRecP)(uintptr_t)triples;         // padded: reads up to 64 KB past n stay inside the area
     const uint32_t *touch = (const uint32_t *)triples;
-    uint32_t *rout = d_uniform_ptr ((uint32_t *)L.rvals);
-    uint32_t sink = 0, touched = 0, range = p0 ? d_uniform (L.chain_range) : 0xffffffffu;
-
-    if (L.max_sym == 1) {
+    if (max_sym == 1) {
         // a stream of zero bytes: the range stays 2^32-1 while the model total is 1 (and 17), which n + inc cannot take
         for (uint32_t i = p0; i < p1; i++) {
             const gz_u32x4 c = rec[i];
@@ -609,61 +621,81 @@ __global__ void __launch_bounds__(64) k_arith_chain (GzdLeaf *leaves, const uint
             range = x << (__clz (x) & 0x18);
             if (!lane) rout[i] = r;
         }
+        return;
     }
-    else {
-        // the first symbol sees range = 2^32-1 and total = max_sym: as a reciprocal for exactly that case,
-        // mulhi (q + 1, 2^32-1) = q
-        const uint32_t q0 = 0xffffffffu / d_uniform (L.max_sym);
-        // 16 records per iteration as two halves A and B of 8: while one half is being worked on, the loads of the
-        // other are in flight (issued right after an explicit wait, because the compiler would place the wait for the
-        // half it needs AFTER the issue of the next loads and so wait for those too)
-        // A chunk that is not the leaf's last one must not look past its end: those records are being written right now
-        // by the next model chunk, and a stale copy pulled into this XCD's L2 / scalar cache is not what the next chain
-        // launch should find. So the main loop (which loads 16 records ahead) stops 16 records early there.
-        const bool last = p1 == n;
-        const uint32_t nb = last ? p1 & ~(uint32_t)(GZ_CHAIN_BLOCK - 1) : p1 - 16;
-        const uint32_t touch_end = last ? 0xffffffffu : p1;                      // (in records)
-        if (nb > p0) {
-            GzConstRec4P rec4 = (GzConstRec4P)(uintptr_t)triples;         // (padded: loads past nb stay inside the area)
-            for (uint32_t b = 0; b < GZ_CHAIN_TOUCH_AHEAD; b += 4096) sink += touch[(size_t)p0 * 4 + (b >> 2) + lane * 16];   // 64 lanes x 64 B = 4 KB
-            gz_u32x16 a0 = rec4[p0 >> 2], a1 = rec4[(p0 >> 2) + 1];
-            if (!p0) { a0[1] = q0 + 1; a0[2] = 0; a0[3] = 0; }
+    // the first symbol sees range = 2^32-1 and total = max_sym: as a reciprocal for exactly that case,
+    // mulhi (q + 1, 2^32-1) = q
+    const uint32_t q0 = 0xffffffffu / max_sym;
+    // 16 records per iteration as two halves A and B of 8: while one half is being worked on, the loads of the
+    // other are in flight (issued right after an explicit wait, because the compiler would place the wait for the
+    // half it needs AFTER the issue of the next loads and so wait for those too)
+    // A chunk that is not the leaf's last one must not look past its end: those records are being written right now
+    // by the next model chunk. So the main loop (which loads 16 records ahead) stops 16 records early there.
+    const bool last = p1 == n;
+    const uint32_t nb = last ? p1 & ~(uint32_t)(GZ_CHAIN_BLOCK - 1) : p1 - 16;
+    const uint32_t touch_end = last ? 0xffffffffu : p1;                      // (in records)
+    if (nb > p0) {
+        GzConstRec4P rec4 = (GzConstRec4P)(uintptr_t)triples;         // (padded: loads past nb stay inside the area)
+        for (uint32_t b = 0; b < GZ_CHAIN_TOUCH_AHEAD; b += 4096) sink += touch[(size_t)p0 * 4 + (b >> 2) + lane * 16];   // 64 lanes x 64 B = 4 KB
+        gz_u32x16 a0 = rec4[p0 >> 2], a1 = rec4[(p0 >> 2) + 1];
+        if (!p0) { a0[1] = q0 + 1; a0[2] = 0; a0[3] = 0; }
+        gz_wait_scalar_loads ();
+        for (uint32_t i = p0; ; ) {
+            const gz_u32x16 b0 = rec4[(i >> 2) + 2], b1 = rec4[(i >> 2) + 3];
+            gz_sched_fence ();
+            // every 256 records = 4 KB (the loaded value is only looked at 256 records later: no wait here)
+            if (!(i & 255) && i + (GZ_CHAIN_TOUCH_AHEAD + 4096) / 16 <= touch_end) { sink += touched; touched = touch[(size_t)i * 4 + (GZ_CHAIN_TOUCH_AHEAD >> 2) + lane * 16]; }
+            uint32_t r0, r1, r2, r3;
+            r0 = d_chain_step (range, a0[0], a0[1], a0[2],  a0[3]);  r1 = d_chain_step (range, a0[4],  a0[5],  a0[6],  a0[7]);
+            r2 = d_chain_step (range, a0[8], a0[9], a0[10], a0[11]); r3 = d_chain_step (range, a0[12], a0[13], a0[14], a0[15]);
+            gz_scalar_store4_at<0> (rout + i, r0, r1, r2, r3);       // the chain never touches the vector unit
+            r0 = d_chain_step (range, a1[0], a1[1], a1[2],  a1[3]);  r1 = d_chain_step (range, a1[4],  a1[5],  a1[6],  a1[7]);
+            r2 = d_chain_step (range, a1[8], a1[9], a1[10], a1[11]); r3 = d_chain_step (range, a1[12], a1[13], a1[14], a1[15]);
+            gz_scalar_store4_at<16> (rout + i, r0, r1, r2, r3);
+            if (i + 8 >= nb) break;
             gz_wait_scalar_loads ();
-            for (uint32_t i = p0; ; ) {
-                const gz_u32x16 b0 = rec4[(i >> 2) + 2], b1 = rec4[(i >> 2) + 3];
-                gz_sched_fence ();
-                // every 256 records = 4 KB (the loaded value is only looked at 256 records later: no wait here)
-                if (!(i & 255) && i + (GZ_CHAIN_TOUCH_AHEAD + 4096) / 16 <= touch_end) { sink += touched; touched = touch[(size_t)i * 4 + (GZ_CHAIN_TOUCH_AHEAD >> 2) + lane * 16]; }
-                uint32_t r0, r1, r2, r3;
-                r0 = d_chain_step (range, a0[0], a0[1], a0[2],  a0[3]);  r1 = d_chain_step (range, a0[4],  a0[5],  a0[6],  a0[7]);
-                r2 = d_chain_step (range, a0[8], a0[9], a0[10], a0[11]); r3 = d_chain_step (range, a0[12], a0[13], a0[14], a0[15]);
-                gz_scalar_store4_at<0> (rout + i, r0, r1, r2, r3);       // the chain never touches the vector unit
-                r0 = d_chain_step (range, a1[0], a1[1], a1[2],  a1[3]);  r1 = d_chain_step (range, a1[4],  a1[5],  a1[6],  a1[7]);
-                r2 = d_chain_step (range, a1[8], a1[9], a1[10], a1[11]); r3 = d_chain_step (range, a1[12], a1[13], a1[14], a1[15]);
-                gz_scalar_store4_at<16> (rout + i, r0, r1, r2, r3);
-                if (i + 8 >= nb) break;
-                gz_wait_scalar_loads ();
-                a0 = rec4[(i >> 2) + 4]; a1 = rec4[(i >> 2) + 5];
-                gz_sched_fence ();
-                r0 = d_chain_step (range, b0[0], b0[1], b0[2],  b0[3]);  r1 = d_chain_step (range, b0[4],  b0[5],  b0[6],  b0[7]);
-                r2 = d_chain_step (range, b0[8], b0[9], b0[10], b0[11]); r3 = d_chain_step (range, b0[12], b0[13], b0[14], b0[15]);
-                gz_scalar_store4_at<32> (rout + i, r0, r1, r2, r3);
-                r0 = d_chain_step (range, b1[0], b1[1], b1[2],  b1[3]);  r1 = d_chain_step (range, b1[4],  b1[5],  b1[6],  b1[7]);
-                r2 = d_chain_step (range, b1[8], b1[9], b1[10], b1[11]); r3 = d_chain_step (range, b1[12], b1[13], b1[14], b1[15]);
-                gz_scalar_store4_at<48> (rout + i, r0, r1, r2, r3);
-                i += 16;
-                if (i >= nb) break;
-                gz_wait_scalar_loads ();
-            }
-        }
-        for (uint32_t i = nb > p0 ? nb : p0; i < p1; i++) {
-            const gz_u32x4 c = rec[i];
-            const uint32_t r = i ? d_chain_step (range, c[0], c[1], c[2], c[3]) : d_chain_step (range, c[0], q0 + 1, 0, 0);
-            if (!lane) rout[i] = r;
+            a0 = rec4[(i >> 2) + 4]; a1 = rec4[(i >> 2) + 5];
+            gz_sched_fence ();
+            r0 = d_chain_step (range, b0[0], b0[1], b0[2],  b0[3]);  r1 = d_chain_step (range, b0[4],  b0[5],  b0[6],  b0[7]);
+            r2 = d_chain_step (range, b0[8], b0[9], b0[10], b0[11]); r3 = d_chain_step (range, b0[12], b0[13], b0[14], b0[15]);
+            gz_scalar_store4_at<32> (rout + i, r0, r1, r2, r3);
+            r0 = d_chain_step (range, b1[0], b1[1], b1[2],  b1[3]);  r1 = d_chain_step (range, b1[4],  b1[5],  b1[6],  b1[7]);
+            r2 = d_chain_step (range, b1[8], b1[9], b1[10], b1[11]); r3 = d_chain_step (range, b1[12], b1[13], b1[14], b1[15]);
+            gz_scalar_store4_at<48> (rout + i, r0, r1, r2, r3);
+            i += 16;
+            if (i >= nb) break;
+            gz_wait_scalar_loads ();
         }
     }
+    for (uint32_t i = nb > p0 ? nb : p0; i < p1; i++) {
+        const gz_u32x4 c = rec[i];
+        const uint32_t r = i ? d_chain_step (range, c[0], c[1], c[2], c[3]) : d_chain_step (range, c[0], q0 + 1, 0, 0);
+        if (!lane) rout[i] = r;
+    }
+}
+
+// progress == NULL: everything is there already, one piece (chunk is ignored)
+__global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress, uint32_t chunk)
+{
+    const uint32_t li = blockIdx.x * GZ_CHAIN_WAVES + (threadIdx.x >> 6);
+    if (li >= n_list) return;
+    __builtin_amdgcn_s_setprio (3);
+    const int lane = threadIdx.x & 63;
+    if (progress && !d_wait_progress (progress, 1)) return;    // (the leaf table itself is only final once the models have started)
+    GzdLeaf &L = leaves[list[li]];
+    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle || !L.coded_n) return;
+    const uint32_t n = d_uniform (L.coded_n), max_sym = d_uniform (L.max_sym);
+    uint8_t *triples = d_uniform_ptr (L.triples);              // (wave-uniform: keep them in scalar registers)
+    uint32_t *rout = d_uniform_ptr ((uint32_t *)L.rvals);
+    uint32_t sink = 0, touched = 0, range = 0xffffffffu;
+    if (!progress) d_chain_chunk (range, sink, touched, lane, 0, n, n, triples, rout, max_sym);
+    else
+        for (uint32_t k = 0, p0 = 0; p0 < n; k++, p0 += chunk) {
+            if (k && !d_wait_progress (progress, k + 1)) { if (!lane) L.overflow = 1; break; }
+            d_chain_chunk (range, sink, touched, lane, p0, (n - p0 > chunk) ? p0 + chunk : n, n, triples, rout, max_sym);
+        }
     gz_scalar_store_flush ();
-    if (!lane) { L.touch_sink = sink + touched; L.chain_range = range; }
+    if (!lane) L.touch_sink = sink + touched;
 }
 
 // ---- low: a big-number sum, one thread per symbol -----------------------------------------------------------------

@@ -72,6 +72,25 @@ __global__ void k_stripe (GzdStream *streams)
 }
 
 // ======================================================================================================
+// presence flags of the byte values in p[0..n): 16 bytes per thread and load (a long leaf has one workgroup to itself)
+__device__ static inline void d_mark_present (uint32_t *flags, const uint8_t *p, uint32_t n, int tid)
+{
+    uint32_t head = (uint32_t)((16 - ((uintptr_t)p & 15)) & 15);
+    if (head > n) head = n;
+    for (uint32_t i = tid; i < head; i += 256) flags[p[i]] = 1;
+    const uint4 *q = (const uint4 *)(p + head);
+    const uint32_t nv = (n - head) / 16;
+    for (uint32_t i = tid; i < nv; i += 256) {
+        const uint4 v = q[i];
+        const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            flags[w[k] & 0xff] = 1; flags[(w[k] >> 8) & 0xff] = 1; flags[(w[k] >> 16) & 0xff] = 1; flags[w[k] >> 24] = 1;
+        }
+    }
+    for (uint32_t i = head + nv * 16 + tid; i < n; i += 256) flags[p[i]] = 1;
+}
+
 // k_leaf_prep : one 256-thread workgroup per leaf
 // ======================================================================================================
 __global__ void __launch_bounds__(256) k_leaf_prep (GzdStream *streams, GzdLeaf *leaves)
@@ -102,7 +121,7 @@ __global__ void __launch_bounds__(256) k_leaf_prep (GzdStream *streams, GzdLeaf 
         else {
             flags[tid] = 0;
             __syncthreads ();
-            for (uint32_t i = tid; i < n; i += 256) flags[src[i]] = 1;
+            d_mark_present (flags, src, n, tid);
             __syncthreads ();
             if (!tid) {
                 uint32_t ns = 0;
@@ -153,7 +172,7 @@ __global__ void __launch_bounds__(256) k_leaf_prep (GzdStream *streams, GzdLeaf 
     // alphabet of the coded bytes: rank map for the order-1 histogram, max symbol for the arith models
     flags[tid] = 0;
     __syncthreads ();
-    for (uint32_t i = tid; i < coded_n; i += 256) flags[coded[i]] = 1;
+    d_mark_present (flags, coded, coded_n, tid);
     __syncthreads ();
     if (!tid) {
         uint32_t ns = 0, mx = 0;

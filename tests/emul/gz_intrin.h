@@ -11,3 +11,4 @@ static inline uint32_t gz_mbcnt (uint64_t m) { return (uint32_t)__builtin_popcou
 template <int OFF> static inline void gz_scalar_store4_at (uint32_t *dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { gz_scalar_store4 (dst + OFF / 4, a, b, c, d); }
 static inline void gz_wait_scalar_loads (void) {}
 static inline void gz_sched_fence (void) {}
+static inline void gz_scalar_cache_inv (void) {}

@@ -218,6 +218,9 @@ static inline uint4 make_uint4 (unsigned x, unsigned y, unsigned z, unsigned w) 
 
 static inline int __clz (unsigned v) { return v ? __builtin_clz (v) : 32; }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
+// this runtime runs every launch to completion at enqueue time: a kernel that waits for a later launch must be queued after it
+#define GZ_SEQUENTIAL_STREAMS 1
 static inline int __popcll (unsigned long long v) { return __builtin_popcountll (v); }
 static inline unsigned __umulhi (unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline long long __double_as_longlong (double d) { long long v; memcpy (&v, &d, 8); return v; }
