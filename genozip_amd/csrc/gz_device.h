@@ -83,6 +83,7 @@ struct GzdLeaf {
     uint32_t  *spos;          // arith order-1: positions grouped by context (the byte before), stream order inside a context
     uint8_t   *srk;           // arith order-1: static rank of the symbol at spos[j]
     uint32_t  *ctxoff;        // arith order-1: [tile][context] -> index into spos/srk of the first occurrence at or after the tile
+    uint32_t  *ctxend;        // arith order-1: [context] -> end of the context's run in the position chunk sorted last
     uint32_t  *mstate;        // arith: the models' registers between two position chunks (GZ_MSTATE_WORDS x 64 lanes per context)
     uint8_t   *events;        // arith: one 32-bit digit per output byte (k_low_replay / k_low_norm)
     uint8_t   *rvals;         // arith: r = range / tot of every symbol (k_arith_chain -> k_low_*)

@@ -47,6 +47,7 @@ struct GzHandle {
     hipStream_t stream5;      // model + chain of the leaves that fit one chunk
     hipEvent_t ev_small;
     hipEvent_t ev_chain_go, ev_chain;   // the persistent chain may start / has finished
+    int n_cu = 0;             // compute units of the device
     bool own_stream;
     std::vector<ArenaBlock> blocks;
     std::vector<Pending> pending;
@@ -121,6 +122,7 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
     // The chain (one wave per leaf, strictly serial) is the critical path: its few workgroups must not queue behind
     // the tens of thousands of the model kernel launched at the same moment, so its stream gets the highest priority and
     // the streams of the kernels that run beside it the lowest.
+    if (hipDeviceGetAttribute (&h->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || h->n_cu <= 0) h->n_cu = 64;
     int prio_lo = 0, prio_hi = 0;
     if (hipDeviceGetStreamPriorityRange (&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
     if (hipStreamCreateWithPriority (&h->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
@@ -293,6 +295,7 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
                 if (!(L.spos   = (uint32_t *)arena_alloc (h, ((size_t)n_bound + 64) * 4))) return false;
                 if (!(L.srk    = (uint8_t *)arena_alloc (h, (size_t)n_bound + 64))) return false;
                 if (!(L.ctxoff = (uint32_t *)arena_alloc (h, (nt + 1) * 256 * 4))) return false;
+                if (!(L.ctxend = (uint32_t *)arena_alloc (h, 256 * 4))) return false;
                 P.any_arith_o1 = true;
                 P.o1_list.push_back ((uint32_t)P.leaves.size ());
             }
@@ -384,7 +387,7 @@ struct ArithPipe {
     const uint32_t *d_plain = NULL, *d_o1 = NULL, *d_big = NULL, *d_small = NULL;
     const GzdLowBlock *d_lb = NULL;
     uint32_t *d_progress = NULL;
-    bool pipelined = false;
+    bool pipelined = false, reserve_cu = false;
 };
 
 static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
@@ -400,10 +403,15 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
     std::vector<uint32_t> big, small;
     for (size_t i = 0; i < P.plain_list.size (); i++) (P.plain_nb[i] > A.chunk ? big : small).push_back (P.plain_list[i]);
     A.nbig = (uint32_t)big.size (); A.nsmall = (uint32_t)small.size ();
-    A.pipelined = A.nbig != 0;
+    // The persistent chain waits (on the device) for the models, so it must never keep them from running: all its
+    // workgroups are resident at once, and they may take at most half the wave slots of the device (4 waves each,
+    // 32 slots per compute unit). More long leaves than that: no pipeline, everything in one piece (correct, slower).
+    const uint32_t chain_wgs = (A.nbig + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES;
+    A.pipelined = A.nbig != 0 && chain_wgs <= (uint32_t)h->n_cu * 4;
+    A.reserve_cu = chain_wgs <= (uint32_t)h->n_cu / 4;        // a whole compute unit each only while that leaves 3/4 to the rest
+    if (!A.pipelined) { A.nbig = 0; small = P.plain_list; big.clear (); A.nsmall = (uint32_t)small.size (); }
     void *d;
     int rc = upload (h, P.plain_list.data (), P.plain_list.size () * 4, &d); A.d_plain = (const uint32_t *)d;
-    if (rc == GZ_OK && A.no1)    { rc = upload (h, P.o1_list.data (), P.o1_list.size () * 4, &d); A.d_o1 = (const uint32_t *)d; }
     if (rc == GZ_OK)             { rc = upload (h, P.low_blocks.data (), P.low_blocks.size () * sizeof (GzdLowBlock), &d); A.d_lb = (const GzdLowBlock *)d; }
     if (rc == GZ_OK && A.nbig)   { rc = upload (h, big.data (), big.size () * 4, &d); A.d_big = (const uint32_t *)d; }
     if (rc == GZ_OK && A.nsmall) { rc = upload (h, small.data (), small.size () * 4, &d); A.d_small = (const uint32_t *)d; }
@@ -420,7 +428,7 @@ static int arith_launch_chain (GzHandle *h, const ArithPipe &A, GzdLeaf *d_leave
 {
     HIPCHK (h, hipEventRecord (h->ev_chain_go, h->stream));                     // (behind the uploads and the memset)
     HIPCHK (h, hipStreamWaitEvent (h->stream3, h->ev_chain_go, 0));
-    KLAUNCH_ON (h, h->stream3, k_arith_chain, dim3 ((A.nbig + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), GZ_CHAIN_LDS,
+    KLAUNCH_ON (h, h->stream3, k_arith_chain, dim3 ((A.nbig + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), A.reserve_cu ? GZ_CHAIN_LDS : 64,
                 d_leaves, A.d_big, A.nbig, (const uint32_t *)A.d_progress, A.chunk);
     HIPCHK (h, hipEventRecord (h->ev_chain, h->stream3));
     return GZ_OK;
@@ -463,22 +471,28 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
         }
         if (A.np) {
             const GzDivMagic *magic = (const GzDivMagic *)h->d_magic;
-            if (A.no1 && P.max_arith_n) {                         // group the positions of order-1 leaves by context
-                const uint32_t max_tiles = (P.max_arith_n + GZ_CTX_TILE - 1) / GZ_CTX_TILE;
-                KLAUNCH (h, k_ctx_count, dim3 (A.no1, max_tiles), dim3 (64), 1024, d_leaves, A.d_o1);
-                KLAUNCH (h, k_ctx_scan, dim3 (A.no1), dim3 (256), 1024, d_leaves, A.d_o1);
-                KLAUNCH (h, k_ctx_scatter, dim3 (A.no1, max_tiles), dim3 (64), 1280, d_leaves, A.d_o1);
-            }
+            // sort (group the positions of the order-1 leaves by context), models, chain
+            auto sort_chunk = [&] (hipStream_t st, const uint32_t *list, uint32_t n_list, uint32_t p0, uint32_t chunk, uint32_t span) -> int {
+                if (!A.no1 || !span) return GZ_OK;
+                const uint32_t tiles = (span + GZ_CTX_TILE - 1) / GZ_CTX_TILE;
+                KLAUNCH_ON (h, st, k_ctx_count, dim3 (n_list, tiles), dim3 (64), 1024, d_leaves, list, p0, chunk);
+                KLAUNCH_ON (h, st, k_ctx_scan, dim3 (n_list), dim3 (256), 1024, d_leaves, list, p0, chunk);
+                KLAUNCH_ON (h, st, k_ctx_scatter, dim3 (n_list, tiles), dim3 (64), 1280, d_leaves, list, p0, chunk);
+                return GZ_OK;
+            };
             if (!A.pipelined) {
+                if ((rc = sort_chunk (h->stream, A.d_plain, A.np, 0u, 0xffffffffu, P.max_arith_n)) != GZ_OK) return rc;
                 KLAUNCH (h, k_arith_model, dim3 (A.np, GZ_MODEL_GRID_Y), dim3 (64), 0, d_leaves, A.d_plain, magic, 0u, 0xffffffffu);
-                KLAUNCH (h, k_arith_chain, dim3 ((A.np + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), 0,
+                KLAUNCH (h, k_arith_chain, dim3 ((A.np + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), 64,
                          d_leaves, A.d_plain, A.np, (const uint32_t *)NULL, 0u);
             }
             else {
-                HIPCHK (h, hipEventRecord (h->ev_model_fork, h->stream));        // (after the sort)
+                HIPCHK (h, hipEventRecord (h->ev_model_fork, h->stream));        // (after k_leaf_prep)
                 HIPCHK (h, hipStreamWaitEvent (h->stream4, h->ev_model_fork, 0));
                 for (uint32_t k = 0; k < A.n_chunks; k++) {
-                    KLAUNCH_ON (h, h->stream4, k_arith_model, dim3 (A.nbig, GZ_MODEL_GRID_Y), dim3 (64), GZ_KEEP_OFF_LDS, d_leaves, A.d_big, magic, k * A.chunk, A.chunk);
+                    const uint32_t p0 = k * A.chunk, span = P.max_arith_n - p0 < A.chunk ? P.max_arith_n - p0 : A.chunk;
+                    if ((rc = sort_chunk (h->stream4, A.d_big, A.nbig, p0, A.chunk, span)) != GZ_OK) return rc;
+                    KLAUNCH_ON (h, h->stream4, k_arith_model, dim3 (A.nbig, GZ_MODEL_GRID_Y), dim3 (64), GZ_KEEP_OFF_LDS, d_leaves, A.d_big, magic, p0, A.chunk);
                     hipLaunchKernelGGL (k_arith_progress, dim3 (1), dim3 (1), 0, h->stream4, A.d_progress, k + 1);
                 }
 #ifdef GZ_SEQUENTIAL_STREAMS
@@ -486,6 +500,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
 #endif
                 if (A.nsmall) {
                     HIPCHK (h, hipStreamWaitEvent (h->stream5, h->ev_model_fork, 0));
+                    if ((rc = sort_chunk (h->stream5, A.d_small, A.nsmall, 0u, 0xffffffffu, A.chunk)) != GZ_OK) return rc;
                     KLAUNCH_ON (h, h->stream5, k_arith_model, dim3 (A.nsmall, GZ_MODEL_GRID_Y), dim3 (64), GZ_KEEP_OFF_LDS, d_leaves, A.d_small, magic, 0u, 0xffffffffu);
                     KLAUNCH_ON (h, h->stream5, k_arith_chain, dim3 ((A.nsmall + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), GZ_KEEP_OFF_LDS,
                                 d_leaves, A.d_small, A.nsmall, (const uint32_t *)NULL, 0u);

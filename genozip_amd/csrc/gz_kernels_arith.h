@@ -353,20 +353,20 @@ __device__ static __forceinline__ void d_model_batch (GzModelLane &M, uint32_t &
 //   k_ctx_scatter  per tile, one wave walking it 64 positions at a time: index = running count of my context (an LDS
 //                  gather) + my rank among the lanes of this group with the same context (one ballot per distinct
 //                  context in the group)
-// The chunk size of the model / chain pipeline is a multiple of the tile size, so the occurrences of a context inside a
-// position chunk are one contiguous run of its list, delimited by ctxoff.
+// The chunk size of the model / chain pipeline is a multiple of the tile size, and every position chunk is sorted on its
+// own (into entries [p0, p1) of the lists) right before its models run: the sort of chunk k+1 hides behind the chain of chunk k.
 #define GZ_CTX_TILE 4096u
 
 __device__ static inline bool d_ctx_sorted (const GzdLeaf &L) { return L.active && L.engine == GZ_ENG_ARITH && !L.rle && L.o1 && L.coded_n; }
 __device__ static inline uint32_t d_ctx_ntiles (uint32_t n) { return (n + GZ_CTX_TILE - 1) / GZ_CTX_TILE; }
 
-// grid (n_leaves, max tiles), 64 threads
-__global__ void __launch_bounds__(64) k_ctx_count (GzdLeaf *leaves, const uint32_t *list)
+// grid (listed leaves, tiles per chunk), 64 threads; positions [p0, p0 + chunk)
+__global__ void __launch_bounds__(64) k_ctx_count (GzdLeaf *leaves, const uint32_t *list, uint32_t p0, uint32_t chunk)
 {
     GzdLeaf &L = leaves[list[blockIdx.x]];
     if (!d_ctx_sorted (L)) return;
-    const uint32_t n = L.coded_n, t0 = blockIdx.y * GZ_CTX_TILE;
-    if (t0 >= n) return;
+    const uint32_t n = L.coded_n, tile = p0 / GZ_CTX_TILE + blockIdx.y, t0 = tile * GZ_CTX_TILE;
+    if (t0 >= n || t0 - p0 >= chunk) return;
     const int lane = threadIdx.x;
     uint32_t *cnt = (uint32_t *)gz_lds;
     for (int e = lane; e < 256; e += 64) cnt[e] = 0;
@@ -377,39 +377,42 @@ __global__ void __launch_bounds__(64) k_ctx_count (GzdLeaf *leaves, const uint32
         if (pos < n) atomicAdd (&cnt[pos ? in[pos - 1] : 0], 1u);
     }
     __syncthreads ();
-    for (int e = lane; e < 256; e += 64) L.ctxoff[(size_t)blockIdx.y * 256 + e] = cnt[e];
+    for (int e = lane; e < 256; e += 64) L.ctxoff[(size_t)tile * 256 + e] = cnt[e];
 }
 
-// one 256-thread workgroup per leaf: thread c owns context c
-__global__ void __launch_bounds__(256) k_ctx_scan (GzdLeaf *leaves, const uint32_t *list)
+// one 256-thread workgroup per leaf: thread c owns context c. The occurrences of positions [p0, p0 + chunk) take
+// entries [p0, p1) of the sorted lists, grouped by context: every position chunk is sorted on its own, just before
+// its models run (ctxend = where each context's run of this chunk ends).
+__global__ void __launch_bounds__(256) k_ctx_scan (GzdLeaf *leaves, const uint32_t *list, uint32_t p0, uint32_t chunk)
 {
     GzdLeaf &L = leaves[list[blockIdx.x]];
-    if (!d_ctx_sorted (L)) return;
-    const uint32_t nt = d_ctx_ntiles (L.coded_n), c = threadIdx.x;
+    if (!d_ctx_sorted (L) || L.coded_n <= p0) return;
+    const uint32_t n = L.coded_n, p1 = (n - p0 > chunk) ? p0 + chunk : n;
+    const uint32_t t0 = p0 / GZ_CTX_TILE, t1 = d_ctx_ntiles (p1), c = threadIdx.x;
     uint32_t *off = L.ctxoff, *sh = (uint32_t *)gz_lds;
     uint32_t run = 0;
-    for (uint32_t t = 0; t < nt; t++) { const uint32_t v = off[(size_t)t * 256 + c]; off[(size_t)t * 256 + c] = run; run += v; }
+    for (uint32_t t = t0; t < t1; t++) { const uint32_t v = off[(size_t)t * 256 + c]; off[(size_t)t * 256 + c] = run; run += v; }
     sh[c] = run;
     __syncthreads ();
-    if (!c) { uint32_t b = 0; for (int e = 0; e < 256; e++) { const uint32_t v = sh[e]; sh[e] = b; b += v; } }
+    if (!c) { uint32_t b = p0; for (int e = 0; e < 256; e++) { const uint32_t v = sh[e]; sh[e] = b; b += v; } }
     __syncthreads ();
     const uint32_t base = sh[c];
-    for (uint32_t t = 0; t < nt; t++) off[(size_t)t * 256 + c] += base;
-    off[(size_t)nt * 256 + c] = base + run;
+    for (uint32_t t = t0; t < t1; t++) off[(size_t)t * 256 + c] += base;
+    L.ctxend[c] = base + run;
 }
 
-// grid (n_leaves, max tiles), 64 threads
-__global__ void __launch_bounds__(64) k_ctx_scatter (GzdLeaf *leaves, const uint32_t *list)
+// grid (listed leaves, tiles per chunk), 64 threads
+__global__ void __launch_bounds__(64) k_ctx_scatter (GzdLeaf *leaves, const uint32_t *list, uint32_t p0, uint32_t chunk)
 {
     GzdLeaf &L = leaves[list[blockIdx.x]];
     if (!d_ctx_sorted (L)) return;
-    const uint32_t n = L.coded_n, t0 = blockIdx.y * GZ_CTX_TILE;
-    if (t0 >= n) return;
+    const uint32_t n = L.coded_n, tile = p0 / GZ_CTX_TILE + blockIdx.y, t0 = tile * GZ_CTX_TILE;
+    if (t0 >= n || t0 - p0 >= chunk) return;
     const int lane = threadIdx.x;
     uint32_t *cnt = (uint32_t *)gz_lds;
     uint8_t *rank_of = gz_lds + 1024;
     const bool wide = L.nsym > 64;                          // wide alphabets keep the byte itself
-    for (int e = lane; e < 256; e += 64) { cnt[e] = L.ctxoff[(size_t)blockIdx.y * 256 + e]; rank_of[e] = wide ? (uint8_t)e : (uint8_t)L.symrank[e]; }
+    for (int e = lane; e < 256; e += 64) { cnt[e] = L.ctxoff[(size_t)tile * 256 + e]; rank_of[e] = wide ? (uint8_t)e : (uint8_t)L.symrank[e]; }
     __syncthreads ();
     const uint8_t *in = L.coded;
     uint32_t *spos = L.spos; uint8_t *srk = L.srk;
@@ -518,7 +521,8 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
     const uint32_t p1 = (n_u - p0 > chunk) ? p0 + chunk : n_u;
     const uint32_t *off = d_uniform_ptr (L.ctxoff), *spos = d_uniform_ptr (L.spos);
     const uint8_t *srk = d_uniform_ptr (L.srk);
-    const uint32_t t0 = p0 / GZ_CTX_TILE, t1 = p1 < n_u ? p1 / GZ_CTX_TILE : d_ctx_ntiles (n_u);   // (chunks are whole tiles)
+    const uint32_t *cend = d_uniform_ptr (L.ctxend);
+    const uint32_t t0 = p0 / GZ_CTX_TILE;                      // (chunks are whole tiles)
     if (nsym_u <= 64) {
         // block 0: context 0 (the context of position 0, whether byte 0 occurs or not); block y: the y-th present symbol
         uint32_t ctx = 0;
@@ -529,7 +533,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
         }
         uint32_t *st = d_uniform_ptr (L.mstate) + (size_t)ctx * (GZ_MSTATE_WORDS * 64);   // (only touched when the leaf spans chunks)
         uint32_t j0 = p0, j1 = p1;
-        if (o1_u) { j0 = d_uniform (off[(size_t)t0 * 256 + ctx]); j1 = d_uniform (off[(size_t)t1 * 256 + ctx]); }   // my run of the sorted lists
+        if (o1_u) { j0 = d_uniform (off[(size_t)t0 * 256 + ctx]); j1 = d_uniform (cend[ctx]); }   // my run of the sorted lists
         d_arith_model_wave_compact (coded, n_u, ms_u, o1_u, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
         return;
     }
@@ -538,7 +542,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
         if (ctx && L.symrank[ctx] == 0xffff) continue;         // a byte that never occurs is never a context
         uint32_t *st = d_uniform_ptr (L.mstate) + (size_t)ctx * (GZ_MSTATE_WORDS * 64);
         uint32_t j0 = p0, j1 = p1;
-        if (o1_u) { j0 = d_uniform (off[(size_t)t0 * 256 + ctx]); j1 = d_uniform (off[(size_t)t1 * 256 + ctx]); }
+        if (o1_u) { j0 = d_uniform (off[(size_t)t0 * 256 + ctx]); j1 = d_uniform (cend[ctx]); }
         if (j0 == j1 && p0) continue;                           // (nothing of mine in this chunk: the saved state stands)
         if (ms <= 128) d_arith_model_wave<2> (coded, ms_u, o1_u, tr, magic_tab, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
         else           d_arith_model_wave<4> (coded, ms_u, o1_u, tr, magic_tab, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
@@ -675,6 +679,9 @@ __device__ static __forceinline__ void d_chain_chunk (uint32_t &range, uint32_t 
 }
 
 // progress == NULL: everything is there already, one piece (chunk is ignored)
+// (Tried and measured without effect on the slow-down the chain suffers while other kernels run - ~15 %, with the clock
+//  unchanged -: wave priority, compute-unit masks, a helper wave pulling the records into the scalar cache ahead of
+//  the chain, dropping the stores of r.)
 __global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress, uint32_t chunk)
 {
     const uint32_t li = blockIdx.x * GZ_CHAIN_WAVES + (threadIdx.x >> 6);

@@ -40,6 +40,8 @@ static inline const char *hipGetErrorString (hipError_t) { return "emulated"; }
 static inline hipError_t hipGetDeviceCount (int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice (int) { return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags (hipStream_t *s, int) { *s = (void *)1; return hipSuccess; }
+enum { hipDeviceAttributeMultiprocessorCount = 1 };
+static inline hipError_t hipDeviceGetAttribute (int *v, int, int) { *v = 256; return hipSuccess; }
 static inline hipError_t hipDeviceGetStreamPriorityRange (int *lo, int *hi) { *lo = 0; *hi = 0; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithPriority (hipStream_t *s, int, int) { *s = (void *)1; return hipSuccess; }
 static inline hipError_t hipStreamDestroy (hipStream_t) { return hipSuccess; }
@@ -218,7 +220,7 @@ static inline uint4 make_uint4 (unsigned x, unsigned y, unsigned z, unsigned w) 
 
 static inline int __clz (unsigned v) { return v ? __builtin_clz (v) : 32; }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
-#define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) emu_yield ()          /* lets the other threads of the block run */
 // this runtime runs every launch to completion at enqueue time: a kernel that waits for a later launch must be queued after it
 #define GZ_SEQUENTIAL_STREAMS 1
 static inline int __popcll (unsigned long long v) { return __builtin_popcountll (v); }
