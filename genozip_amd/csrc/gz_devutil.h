@@ -79,34 +79,38 @@ __host__ __device__ static inline uint32_t gz_rd_be32 (const uint8_t *p)
 // adler32 (start value 1) of `len` bytes by a 256-thread workgroup. Thread t sums a contiguous slice:
 // A = sum d_j, B = sum (m-j) d_j ; slices combine as a' = a + A, b' = b + m*a + B (mod 65521).
 // Uses the first 2 KB + 8 bytes of gz_lds. Result valid in every thread.
+typedef uint32_t gz_u32x4_unaligned __attribute__((vector_size (16), aligned (1)));
+
+// adler32 = (b << 16 | a) with a = 1 + sum d_i, b = len + sum (len - i) d_i, both mod 65521: a weighted sum, so any
+// thread can take any bytes. Thread t takes bytes [4096 k + 16 t, + 16) for k = 0, 1, ... (coalesced 16-byte loads).
 __device__ static inline uint32_t gz_adler32_wg (const uint8_t *data, uint32_t len, int tid)
 {
     uint32_t *sA = (uint32_t *)gz_lds, *sB = sA + 256, *res = sA + 512;
-    uint32_t slice = (len + 255) / 256;
-    uint32_t lo = tid * slice, hi = lo + slice < len ? lo + slice : len;
-    uint64_t A = 0, B = 0;
-    if (lo < hi) {
-        uint32_t m = hi - lo;
-        for (uint32_t j = 0; j < m; j++) {
-            uint32_t d = data[lo + j];
-            A += d;
-            B += (uint64_t)(m - j) * d;
+    uint64_t A = 0, W = 0;
+    const uint32_t body = len & ~15u;
+    uint32_t rounds = 0;
+    for (uint32_t i = (uint32_t)tid * 16; i < body; i += 256 * 16) {
+        const gz_u32x4_unaligned v = *(const gz_u32x4_unaligned *)(data + i);
+        uint32_t S = 0, T = 0;                                 // sum d_j, sum j d_j over the 16 bytes
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t w = v[k], b0 = w & 0xff, b1 = (w >> 8) & 0xff, b2 = (w >> 16) & 0xff, b3 = w >> 24;
+            S += b0 + b1 + b2 + b3;
+            T += (4 * k) * b0 + (4 * k + 1) * b1 + (4 * k + 2) * b2 + (4 * k + 3) * b3;
         }
+        A += S;
+        W += (uint64_t)(len - i) * S - T;                      // < 2^44 each
+        if (++rounds == 65536) { W %= 65521u; rounds = 0; }
     }
+    for (uint32_t i = body + tid; i < len; i += 256) { const uint32_t d = data[i]; A += d; W += (uint64_t)(len - i) * d; }
     __syncthreads ();
     sA[tid] = (uint32_t)(A % 65521u);
-    sB[tid] = (uint32_t)(B % 65521u);
+    sB[tid] = (uint32_t)(W % 65521u);
     __syncthreads ();
     if (!tid) {
-        uint64_t a = 1, b = 0;
-        for (int t = 0; t < 256; t++) {
-            uint32_t l = t * slice, h = l + slice < len ? l + slice : len;
-            if (l >= h) break;
-            uint64_t m = h - l;
-            b = (b + (m % 65521u) * a + sB[t]) % 65521u;
-            a = (a + sA[t]) % 65521u;
-        }
-        res[0] = (uint32_t)((b << 16) | a);
+        uint64_t a = 1, b = len % 65521u;
+        for (int t = 0; t < 256; t++) { a += sA[t]; b += sB[t]; }
+        res[0] = (uint32_t)(((b % 65521u) << 16) | (a % 65521u));
     }
     __syncthreads ();
     return res[0];

@@ -42,3 +42,15 @@ __device__ static inline uint32_t gz_mbcnt (uint64_t m)
 
 // drop the scalar data cache (after an acquire, before scalar loads of data another kernel has just written)
 __device__ static inline void gz_scalar_cache_inv (void) { asm volatile ("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : : : "memory"); }
+
+// Pull the 64-byte line at p towards this wave's L2 without ever waiting for it: a plain global load whose result lands in
+// `pit`, a register the caller keeps alive (and untouched) until gz_touch_done. Written as inline asm because the
+// compiler would otherwise either wait for the value where it is consumed or move the load to where it is.
+__device__ static inline void gz_touch (const void *p, uint32_t &pit)
+{
+    asm volatile ("global_load_dword %0, %1, off" : "+v"(pit) : "v"(p) : "memory");
+}
+__device__ static inline void gz_touch_done (uint32_t &pit)
+{
+    asm volatile ("s_waitcnt vmcnt(0)" : "+v"(pit) : : "memory");
+}

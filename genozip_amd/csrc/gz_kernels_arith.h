@@ -572,6 +572,7 @@ typedef uint32_t gz_u32x4 __attribute__((vector_size (16)));
 typedef uint32_t gz_u32x16 __attribute__((vector_size (64)));
 typedef const volatile __attribute__((address_space(4))) gz_u32x4 *GzConstRecP;   // volatile: keeps the prefetch a prefetch
 typedef const volatile __attribute__((address_space(4))) gz_u32x16 *GzConstRec4P; // 4 records per load
+typedef const __attribute__((address_space(1))) uint32_t *GzGlobalU32P;
 
 #define GZ_CHAIN_BLOCK 8
 #define GZ_CHAIN_TOUCH_AHEAD (16 * 1024)   // bytes: how far ahead of the scalar loads the vector unit pulls lines into L2
@@ -615,7 +616,9 @@ __device__ static __forceinline__ void d_chain_chunk (uint32_t &range, uint32_t 
                                                       uint8_t *triples, uint32_t *rout, uint32_t max_sym)
 {
     GzConstRecP rec = (GzConstRecP)(uintptr_t)triples;         // padded: reads up to 64 KB past n stay inside the area
-    const uint32_t *touch = (const uint32_t *)triples;
+    // (a GLOBAL pointer: a load through a generic one is a flat load, which also counts as an LDS / scalar operation -
+    //  every wait for the scalar record loads would then wait for the touch's trip to memory as well)
+    const GzGlobalU32P touch = (GzGlobalU32P)(uintptr_t)triples;
     if (max_sym == 1) {
         // a stream of zero bytes: the range stays 2^32-1 while the model total is 1 (and 17), which n + inc cannot take
         for (uint32_t i = p0; i < p1; i++) {
@@ -647,8 +650,8 @@ __device__ static __forceinline__ void d_chain_chunk (uint32_t &range, uint32_t 
         for (uint32_t i = p0; ; ) {
             const gz_u32x16 b0 = rec4[(i >> 2) + 2], b1 = rec4[(i >> 2) + 3];
             gz_sched_fence ();
-            // every 256 records = 4 KB (the loaded value is only looked at 256 records later: no wait here)
-            if (!(i & 255) && i + (GZ_CHAIN_TOUCH_AHEAD + 4096) / 16 <= touch_end) { sink += touched; touched = touch[(size_t)i * 4 + (GZ_CHAIN_TOUCH_AHEAD >> 2) + lane * 16]; }
+            // every 256 records = 4 KB, never waited for (gz_touch)
+            if (!(i & 255) && i + (GZ_CHAIN_TOUCH_AHEAD + 4096) / 16 <= touch_end) gz_touch (triples + (size_t)i * 16 + GZ_CHAIN_TOUCH_AHEAD + lane * 64, touched);
             uint32_t r0, r1, r2, r3;
             r0 = d_chain_step (range, a0[0], a0[1], a0[2],  a0[3]);  r1 = d_chain_step (range, a0[4],  a0[5],  a0[6],  a0[7]);
             r2 = d_chain_step (range, a0[8], a0[9], a0[10], a0[11]); r3 = d_chain_step (range, a0[12], a0[13], a0[14], a0[15]);
@@ -670,6 +673,7 @@ __device__ static __forceinline__ void d_chain_chunk (uint32_t &range, uint32_t 
             if (i >= nb) break;
             gz_wait_scalar_loads ();
         }
+        gz_touch_done (touched);
     }
     for (uint32_t i = nb > p0 ? nb : p0; i < p1; i++) {
         const gz_u32x4 c = rec[i];

@@ -810,9 +810,12 @@ __global__ void k_vb_layout (GzdVB *vbs, GzdStream *streams, uint32_t n_vbs)
 // ======================================================================================================
 // k_emit : one 256-thread workgroup per stream -- writes the payload (and, in VBlock mode, the section header)
 // ======================================================================================================
+// 16 bytes per thread and access (neither side is aligned in general: the hardware takes unaligned vector accesses)
 __device__ static inline void d_copy (uint8_t *dst, const uint8_t *src, uint32_t n, int tid)
 {
-    for (uint32_t i = tid; i < n; i += 256) dst[i] = src[i];
+    const uint32_t body = n & ~15u;
+    for (uint32_t i = (uint32_t)tid * 16; i < body; i += 256 * 16) *(gz_u32x4_unaligned *)(dst + i) = *(const gz_u32x4_unaligned *)(src + i);
+    for (uint32_t i = body + tid; i < n; i += 256) dst[i] = src[i];
 }
 
 __device__ static void d_emit_unit (uint8_t *dst, const GzdLeaf &L, int tid)

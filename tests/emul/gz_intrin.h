@@ -12,3 +12,5 @@ template <int OFF> static inline void gz_scalar_store4_at (uint32_t *dst, uint32
 static inline void gz_wait_scalar_loads (void) {}
 static inline void gz_sched_fence (void) {}
 static inline void gz_scalar_cache_inv (void) {}
+static inline void gz_touch (const void *p, uint32_t &pit) { pit += *(const volatile uint8_t *)p; }
+static inline void gz_touch_done (uint32_t &) {}
