@@ -191,14 +191,18 @@ def cpu_baseline(rank_wl, z_list, n_threads):
                       (len(tasks), len(rank_wl.vbs), nbytes / 1e6, n_threads, os.cpu_count())}, bool(exact)
 
 
+def per_launch(per_step, launches_per_step):
+    return None if per_step is None else int(per_step / launches_per_step)
+
+
 def pmc_traffic(kernel, a):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    """HBM bytes per STEP of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/round1_pmc.json, made by tools/summarize_prof.py); null for non-default workloads"""
     p = os.path.join(ROOT, "profiles", "round1_pmc.json")
     if not os.path.exists(p) or a.pairs != 1000000 or a.vb_mb != 4 or a.qual != "div":
         return None
     k = json.load(open(p))["kernels"].get(kernel)
-    return k["traffic_bytes"] if k else None
+    return k.get("traffic_bytes_per_step", k["traffic_bytes"]) if k else None
 
 
 def main():
@@ -284,7 +288,7 @@ def main():
     alg_per_launch = alg_bytes_per_step / per_step_launches
     achieved = alg_per_launch / (avg_launch_ms / 1e3) / 1e9
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dom, a),
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": per_launch(pmc_traffic(dom, a), per_step_launches),
                 "avg_launch_ms": round(avg_launch_ms, 4), "launches_per_step": per_step_launches,
                 "alg_bytes_per_launch": int(alg_per_launch),
                 "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}

@@ -9,6 +9,7 @@
 #define GZ_ST_OK        1
 #define GZ_ST_TOO_SMALL 0
 #define GZ_ST_CORRUPT   (-5)
+#define GZ_ST_FAILED    (-1)          // internal failure (a kernel gave up): the stream / VBlock is reported as GZ_ERR
 
 // All LDS scratch lives in the dynamic region (keeps its base 16-byte aligned; cdna_hip_programming.md G17)
 extern __shared__ __attribute__((aligned(16))) uint8_t gz_lds[];

@@ -48,6 +48,8 @@ struct GzHandle {
     hipEvent_t ev_small;
     hipEvent_t ev_chain_go, ev_chain;   // the persistent chain may start / has finished
     int n_cu = 0;             // compute units of the device
+    uint32_t *d_fail = NULL;  // set by a kernel that gave up (the persistent chain when the models never report)
+    bool no_pipeline = false; // GZ_NO_PIPELINE=1: no persistent kernel (needed under tools that serialise kernels, e.g. rocprofv3 --pmc)
     bool own_stream;
     std::vector<ArenaBlock> blocks;
     std::vector<Pending> pending;
@@ -165,6 +167,8 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
             return NULL;
         }
     }
+    if (hipMalloc ((void **)&h->d_fail, 64) != hipSuccess || hipMemset (h->d_fail, 0, 64) != hipSuccess) { if (err) *err = GZ_ERR_HIP; gz_destroy (h); return NULL; }
+    { const char *e = getenv ("GZ_NO_PIPELINE"); h->no_pipeline = e && *e && *e != '0'; }
     // the largest LDS class of the arithmetic coder needs more than the default 64 KB of dynamic LDS
     if (hipFuncSetAttribute ((const void *)k_arith_encode, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
         hipFuncSetAttribute ((const void *)k_arith_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
@@ -186,6 +190,7 @@ extern "C" void gz_destroy (GzHandle *h)
     for (auto p : h->host_tmp) free (p);
     hipFree (h->d_logs);
     hipFree (h->d_magic);
+    hipFree (h->d_fail);
     if (h->own_stream) hipStreamDestroy (h->stream);
     hipStreamDestroy (h->stream2);
     hipStreamDestroy (h->stream3);
@@ -407,7 +412,7 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
     // workgroups are resident at once, and they may take at most half the wave slots of the device (4 waves each,
     // 32 slots per compute unit). More long leaves than that: no pipeline, everything in one piece (correct, slower).
     const uint32_t chain_wgs = (A.nbig + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES;
-    A.pipelined = A.nbig != 0 && chain_wgs <= (uint32_t)h->n_cu * 4;
+    A.pipelined = A.nbig != 0 && chain_wgs <= (uint32_t)h->n_cu * 4 && !h->no_pipeline;
     A.reserve_cu = chain_wgs <= (uint32_t)h->n_cu / 4;        // a whole compute unit each only while that leaves 3/4 to the rest
     if (!A.pipelined) { A.nbig = 0; small = P.plain_list; big.clear (); A.nsmall = (uint32_t)small.size (); }
     void *d;
@@ -429,7 +434,7 @@ static int arith_launch_chain (GzHandle *h, const ArithPipe &A, GzdLeaf *d_leave
     HIPCHK (h, hipEventRecord (h->ev_chain_go, h->stream));                     // (behind the uploads and the memset)
     HIPCHK (h, hipStreamWaitEvent (h->stream3, h->ev_chain_go, 0));
     KLAUNCH_ON (h, h->stream3, k_arith_chain, dim3 ((A.nbig + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), A.reserve_cu ? GZ_CHAIN_LDS : 64,
-                d_leaves, A.d_big, A.nbig, (const uint32_t *)A.d_progress, A.chunk);
+                d_leaves, A.d_big, A.nbig, (const uint32_t *)A.d_progress, A.chunk, h->d_fail);
     HIPCHK (h, hipEventRecord (h->ev_chain, h->stream3));
     return GZ_OK;
 }
@@ -484,7 +489,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 if ((rc = sort_chunk (h->stream, A.d_plain, A.np, 0u, 0xffffffffu, P.max_arith_n)) != GZ_OK) return rc;
                 KLAUNCH (h, k_arith_model, dim3 (A.np, GZ_MODEL_GRID_Y), dim3 (64), 0, d_leaves, A.d_plain, magic, 0u, 0xffffffffu);
                 KLAUNCH (h, k_arith_chain, dim3 ((A.np + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), 64,
-                         d_leaves, A.d_plain, A.np, (const uint32_t *)NULL, 0u);
+                         d_leaves, A.d_plain, A.np, (const uint32_t *)NULL, 0u, h->d_fail);
             }
             else {
                 HIPCHK (h, hipEventRecord (h->ev_model_fork, h->stream));        // (after k_leaf_prep)
@@ -503,7 +508,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                     if ((rc = sort_chunk (h->stream5, A.d_small, A.nsmall, 0u, 0xffffffffu, A.chunk)) != GZ_OK) return rc;
                     KLAUNCH_ON (h, h->stream5, k_arith_model, dim3 (A.nsmall, GZ_MODEL_GRID_Y), dim3 (64), GZ_KEEP_OFF_LDS, d_leaves, A.d_small, magic, 0u, 0xffffffffu);
                     KLAUNCH_ON (h, h->stream5, k_arith_chain, dim3 ((A.nsmall + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), GZ_KEEP_OFF_LDS,
-                                d_leaves, A.d_small, A.nsmall, (const uint32_t *)NULL, 0u);
+                                d_leaves, A.d_small, A.nsmall, (const uint32_t *)NULL, 0u, h->d_fail);
                     HIPCHK (h, hipEventRecord (h->ev_small, h->stream5));
                     HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_small, 0));
                 }
@@ -682,6 +687,12 @@ extern "C" int gz_sync (GzHandle *h)
     HIPCHK (h, hipSetDevice (h->device));
     HIPCHK (h, hipStreamSynchronize (h->stream));
     int rc = GZ_OK;
+    bool device_failed = false;
+    if (!h->pending.empty ()) {
+        uint32_t f = 0;
+        HIPCHK (h, hipMemcpy (&f, h->d_fail, 4, hipMemcpyDeviceToHost));
+        if (f) { device_failed = true; HIPCHK (h, hipMemset (h->d_fail, 0, 4)); }
+    }
     for (auto &pd : h->pending) {
         if (pd.kind == 0) {
             std::vector<GzdStream> S (pd.n_dev_streams);
@@ -708,9 +719,9 @@ extern "C" int gz_sync (GzHandle *h)
             HIPCHK (h, hipMemcpy (V.data (), pd.dev_vbs, V.size () * sizeof (GzdVB), hipMemcpyDeviceToHost));
             GzVBlock *u = (GzVBlock *)pd.user;
             for (int i = 0; i < pd.n; i++) {
-                u[i].status = V[i].status == GZ_ST_OK ? GZ_OK : GZ_TOO_SMALL;
+                u[i].status = V[i].status == GZ_ST_OK ? GZ_OK : V[i].status == GZ_ST_TOO_SMALL ? GZ_TOO_SMALL : GZ_ERR;
                 u[i].z_len  = V[i].z_len;
-                if (u[i].status != GZ_OK) rc = GZ_TOO_SMALL;
+                if (u[i].status == GZ_ERR) rc = GZ_ERR; else if (u[i].status != GZ_OK && rc != GZ_ERR) rc = GZ_TOO_SMALL;
             }
         }
     }
@@ -728,6 +739,12 @@ extern "C" int gz_sync (GzHandle *h)
     for (auto p : h->host_tmp) free (p);
     h->host_tmp.clear ();
     arena_reset (h);
+    if (device_failed) {
+        // (every stream / VBlock of this sync is suspect: their statuses say OK where the chain's leaf was not involved)
+        h->err = "the arithmetic coder's persistent chain kernel never heard from the model kernels (are kernels being "
+                 "serialised by a tool? set GZ_NO_PIPELINE=1)";
+        return GZ_ERR;
+    }
     return rc;
 }
 

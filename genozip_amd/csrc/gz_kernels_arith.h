@@ -686,13 +686,13 @@ __device__ static __forceinline__ void d_chain_chunk (uint32_t &range, uint32_t 
 // (Tried and measured without effect on the slow-down the chain suffers while other kernels run - ~15 %, with the clock
 //  unchanged -: wave priority, compute-unit masks, a helper wave pulling the records into the scalar cache ahead of
 //  the chain, dropping the stores of r.)
-__global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress, uint32_t chunk)
+__global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress, uint32_t chunk, uint32_t *fail)
 {
     const uint32_t li = blockIdx.x * GZ_CHAIN_WAVES + (threadIdx.x >> 6);
     if (li >= n_list) return;
     __builtin_amdgcn_s_setprio (3);
     const int lane = threadIdx.x & 63;
-    if (progress && !d_wait_progress (progress, 1)) return;    // (the leaf table itself is only final once the models have started)
+    if (progress && !d_wait_progress (progress, 1)) { if (!lane) *fail = 1; return; }   // (the leaf table itself is only final once the models have started)
     GzdLeaf &L = leaves[list[li]];
     if (!L.active || L.engine != GZ_ENG_ARITH || L.rle || !L.coded_n) return;
     const uint32_t n = d_uniform (L.coded_n), max_sym = d_uniform (L.max_sym);
@@ -702,7 +702,7 @@ __global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *l
     if (!progress) d_chain_chunk (range, sink, touched, lane, 0, n, n, triples, rout, max_sym);
     else
         for (uint32_t k = 0, p0 = 0; p0 < n; k++, p0 += chunk) {
-            if (k && !d_wait_progress (progress, k + 1)) { if (!lane) L.overflow = 1; break; }
+            if (k && !d_wait_progress (progress, k + 1)) { if (!lane) { L.overflow = 2; *fail = 1; } break; }
             d_chain_chunk (range, sink, touched, lane, p0, (n - p0 > chunk) ? p0 + chunk : n, n, triples, rout, max_sym);
         }
     gz_scalar_store_flush ();

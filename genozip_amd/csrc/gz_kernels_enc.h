@@ -756,6 +756,7 @@ __global__ void k_select (GzdStream *streams, GzdLeaf *leaves, uint32_t n_stream
     for (uint32_t k = 0; k < S.n_leaves; k++) {
         GzdLeaf &L = leaves[S.first_leaf + k];
         if (!L.active) continue;
+        if (L.overflow == 2) { S.status = GZ_ST_FAILED; S.out_len = 0; return; }   // (the chain never heard from the models)
         uint32_t body = L.tab_len + L.pay_len;
         bool cat = L.overflow || body >= L.coded_n;                       // :1343-1348 / arith :845-850
         if (cat) {
@@ -785,13 +786,15 @@ __global__ void k_vb_layout (GzdVB *vbs, GzdStream *streams, uint32_t n_vbs)
     if (v >= n_vbs) return;
     GzdVB &V = vbs[v];
     uint64_t off = 84;                                   // SectionHeaderVbHeader first (zip.c:560)
+    bool failed = false;
     for (uint32_t k = 0; k < V.n_streams; k++) {
         GzdStream &S = streams[V.first_stream + k];
+        if (S.status == GZ_ST_FAILED) failed = true;
         S.z_off = off;
         off += 40 + (uint64_t)S.out_len;
     }
     V.z_len = off;
-    V.status = off <= V.z_cap ? GZ_ST_OK : GZ_ST_TOO_SMALL;
+    V.status = failed ? GZ_ST_FAILED : off <= V.z_cap ? GZ_ST_OK : GZ_ST_TOO_SMALL;
 
     uint8_t *z = V.z_data;                               // zfile_compress_vb_header + zfile_update_compressed_vb_header
     if (V.status != GZ_ST_OK) return;

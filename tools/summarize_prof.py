@@ -39,9 +39,17 @@ with open(os.path.join(dst, tag + "_pmc_hbm.csv"), "w", newline="") as fh:
     wr.writerows(rows)
 # per launch HBM traffic of each kernel in bytes: FETCH_SIZE counts 64 B per 128 B request on gfx950 (x2, calibrated
 # for wide coalesced reads only - MI355X_MICROARCH.md section HBM); WRITE_SIZE is taken as reported (uncalibrated)
-pmc = {r["kernel"].split("(")[0]: {"fetch_kb_reported": r["FETCH_SIZE_KB_per_dispatch_mean"], "write_kb_reported": r["WRITE_SIZE_KB_per_dispatch_mean"],
-                                    "traffic_bytes": int(2 * 1024 * r["FETCH_SIZE_KB_per_dispatch_mean"] + 1024 * r["WRITE_SIZE_KB_per_dispatch_mean"])} for r in rows}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of: python bench.py --steps 2 --warmup 1 --no-cpu --pin-codecs",
+STEPS = 3   # the PMC passes run --steps 2 --warmup 1 with --pin-codecs: every dispatch belongs to one of 3 identical steps
+pmc = {}
+for r in rows:
+    per_dispatch = 2 * 1024 * r["FETCH_SIZE_KB_per_dispatch_mean"] + 1024 * r["WRITE_SIZE_KB_per_dispatch_mean"]
+    pmc[r["kernel"].split("(")[0]] = {"fetch_kb_reported": r["FETCH_SIZE_KB_per_dispatch_mean"], "write_kb_reported": r["WRITE_SIZE_KB_per_dispatch_mean"],
+                                      "dispatches_per_step": r["dispatches"] / STEPS, "traffic_bytes": int(per_dispatch),
+                                      "traffic_bytes_per_step": int(per_dispatch * r["dispatches"] / STEPS)}
+json.dump({"source": "GZ_NO_PIPELINE=1 rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of: python bench.py --steps 2 --warmup 1 --no-cpu "
+                     "--pin-codecs. (Counter collection serialises kernels, which the persistent chain kernel cannot live with: GZ_NO_PIPELINE runs the "
+                     "same kernels over the same data one after the other - per step the bytes are the same, only the number of launches they are "
+                     "spread over differs, hence traffic_bytes_per_step.)",
            "correction": "traffic = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 (gfx950 FETCH_SIZE half-count; WRITE_SIZE uncalibrated)", "kernels": pmc},
           open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
 print(open(os.path.join(dst, tag + "_pmc_hbm.csv")).read())
