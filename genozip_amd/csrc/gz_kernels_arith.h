@@ -441,13 +441,50 @@ __global__ void __launch_bounds__(64) k_ctx_scatter (GzdLeaf *leaves, const uint
     }
 }
 
+// A leaf with a wide alphabet (a binary plane: up to 256 byte values) usually still has contexts that are each followed
+// by few distinct bytes (a plane of 11 000 bytes has ~43 occurrences per context). Such a context's model runs in the
+// compact form with an alphabet of its own: the bytes that follow THIS context, found by a first pass over its
+// occurrences (presence flags in LDS -> four 64-bit masks; rank of a byte = set bits below it).
+struct GzLocalAlpha { uint64_t m[4]; };
+
+__device__ static inline uint32_t d_local_rank (const GzLocalAlpha &A, uint32_t s)
+{
+    const uint32_t j = s >> 6;
+    const uint32_t c0 = (uint32_t)__popcll (A.m[0]), c1 = c0 + (uint32_t)__popcll (A.m[1]), c2 = c1 + (uint32_t)__popcll (A.m[2]);
+    const uint32_t base = j == 0 ? 0u : (j == 1 ? c0 : (j == 2 ? c1 : c2));
+    const uint64_t mj = j == 0 ? A.m[0] : (j == 1 ? A.m[1] : (j == 2 ? A.m[2] : A.m[3]));
+    return base + (uint32_t)__popcll (mj & ((1ull << (s & 63)) - 1));
+}
+
+// Returns the number of distinct bytes among the context's occurrences [j0, j1) and, if there are at most 64, leaves
+// them (ascending) in lds_list[0..]. lds_flags: 256 bytes of LDS; one wave.
+__device__ static inline uint32_t d_local_alphabet (GzLocalAlpha &A, const uint8_t *in, bool o1, const uint32_t *spos, const uint8_t *srk,
+                                                    uint32_t j0, uint32_t j1, uint8_t *lds_flags, uint8_t *lds_list)
+{
+    const int lane = threadIdx.x & 63;
+    ((uint32_t *)lds_flags)[lane] = 0;
+    __syncthreads ();
+    for (uint32_t j = j0 + lane; j < j1; j += 64) lds_flags[o1 ? srk[j] : in[j]] = 1;
+    __syncthreads ();
+    uint32_t nd = 0;
+    #pragma unroll
+    for (int k = 0; k < 4; k++) { A.m[k] = __ballot (lds_flags[k * 64 + lane] != 0); nd += (uint32_t)__popcll (A.m[k]); }
+    if (nd <= 64) {
+        #pragma unroll
+        for (int k = 0; k < 4; k++) if ((A.m[k] >> lane) & 1) lds_list[d_local_rank (A, (uint32_t)(k * 64 + lane))] = (uint8_t)(k * 64 + lane);
+    }
+    __syncthreads ();
+    return nd;
+}
+
 // (force-inlined: as a called function its arguments would arrive in vector registers and every loop on them would
 //  become exec-mask code)
 // The occurrences of this wave's context inside the position chunk are entries [j0, j1) of the leaf's sorted lists
 // (order 1), or simply positions [j0, j1) of the stream (order 0: one context).
 __device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t *in, uint32_t n, uint32_t ms, bool o1, uint4 *recs,
                                                    const GzDivMagic *magic_tab, const uint8_t *symlist, const uint16_t *symrank, uint32_t nsym,
-                                                   const uint32_t *spos, const uint8_t *srk, uint32_t j0, uint32_t j1, bool first, bool save, uint32_t *st)
+                                                   const uint32_t *spos, const uint8_t *srk, uint32_t j0, uint32_t j1, bool first, bool save, uint32_t *st,
+                                                   const GzLocalAlpha *la = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const bool live = (uint32_t)lane < nsym;
@@ -474,7 +511,8 @@ __device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t
     uint32_t nx_pos = 0, nx_rk = 0;
     if (j0 + lane < j1) {
         if (o1) { nx_pos = spos[j0 + lane]; nx_rk = srk[j0 + lane]; }
-        else    { nx_pos = j0 + lane; nx_rk = symrank[in[nx_pos]]; }
+        else    { nx_pos = j0 + lane; nx_rk = la ? in[nx_pos] : symrank[in[nx_pos]]; }
+        if (la) nx_rk = d_local_rank (*la, nx_rk);
     }
     for (uint32_t j = j0; j < j1; j += 64) {
         const uint32_t cnt = j1 - j < 64 ? j1 - j : 64;
@@ -482,7 +520,8 @@ __device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t
         const uint32_t b_pos = nx_pos, b_rk = nx_rk;
         if (j + 64 + lane < j1) {
             if (o1) { nx_pos = spos[j + 64 + lane]; nx_rk = srk[j + 64 + lane]; }
-            else    { nx_pos = j + 64 + lane; nx_rk = symrank[in[nx_pos]]; }
+            else    { nx_pos = j + 64 + lane; nx_rk = la ? in[nx_pos] : symrank[in[nx_pos]]; }
+            if (la) nx_rk = d_local_rank (*la, nx_rk);
         }
         uint32_t out_cum = 0, out_freq = 0, out_tot = 0;
         d_model_batch (M, tot, lane, cnt, occ ? b_rk : 0u, nsym, n_absent, out_cum, out_freq, out_tot);
@@ -544,6 +583,15 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
         uint32_t j0 = p0, j1 = p1;
         if (o1_u) { j0 = d_uniform (off[(size_t)t0 * 256 + ctx]); j1 = d_uniform (cend[ctx]); }
         if (j0 == j1 && p0) continue;                           // (nothing of mine in this chunk: the saved state stands)
+        if (p0 == 0 && p1 == n_u && j1 > j0) {                  // a leaf in one piece: try the context's own alphabet
+            GzLocalAlpha la;
+            uint8_t *lds_flags = gz_lds, *lds_list = gz_lds + 256;
+            const uint32_t nd = d_local_alphabet (la, coded, o1_u, spos, srk, j0, j1, lds_flags, lds_list);
+            if (nd <= 64) {
+                d_arith_model_wave_compact (coded, n_u, ms_u, o1_u, tr, magic_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, true, false, st, &la);
+                continue;
+            }
+        }
         if (ms <= 128) d_arith_model_wave<2> (coded, ms_u, o1_u, tr, magic_tab, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
         else           d_arith_model_wave<4> (coded, ms_u, o1_u, tr, magic_tab, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
     }
