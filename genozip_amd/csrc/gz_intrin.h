@@ -54,3 +54,7 @@ __device__ static inline void gz_touch_done (uint32_t &pit)
 {
     asm volatile ("s_waitcnt vmcnt(0)" : "+v"(pit) : : "memory");
 }
+
+// all lanes of the wave have performed their LDS accesses so far before any lane performs a later one (one wave's LDS
+// operations execute in order; this only has to keep the compiler from reordering them)
+__device__ static inline void gz_wave_sync (void) { __builtin_amdgcn_fence (__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier (); }

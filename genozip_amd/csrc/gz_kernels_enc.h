@@ -18,6 +18,7 @@
 #pragma once
 #include "gz_device.h"
 #include "gz_devutil.h"
+#include <gz_intrin.h>
 
 // ======================================================================================================
 // k_resolve : one thread per stream
@@ -347,31 +348,55 @@ __device__ static inline uint32_t d_rans_advance (uint32_t x, const GzRansSym &r
 // first: round r (counting down) is coded by every lane whose list is longer than r. Within a round state 3 emits
 // first, i.e. lands at the highest address of the backwards-growing stream. Called by ALL 64 lanes of the wave.
 //   rec(k, r) -> pointer to the encoder record of lane k's r-th step
+// Only the state update x -> x' is serial. Which record a step needs is known from the input alone, so the records of 16
+// rounds are fetched by all 64 lanes at once (lane 4j+k: state k, j-th round of the batch), one batch ahead of their
+// use, and handed to the state lanes through LDS (lds: 2 KB of this wave's own, two buffers).
 // Returns payload length (bytes, incl. the 16 state bytes) or 0xffffffff on overflow; payload ends at buf+cap.
+#define GZ_RANS_ENC_LDS 2048
 template <typename RecFn>
-__device__ static uint32_t d_rans_encode_wave (uint32_t len_k, uint32_t rounds, uint8_t *buf, uint32_t cap, RecFn rec)
+__device__ static uint32_t d_rans_encode_wave (uint32_t len_k, uint32_t rounds, uint8_t *buf, uint32_t cap, uint8_t *lds, RecFn rec)
 {
     const int lane = threadIdx.x & 63;
+    const int k_of = lane & 3, j_of = lane >> 2;
+    const uint32_t len_mine = (uint32_t)__shfl ((int)len_k, k_of);      // list length of the state this lane fetches for
+    uint4 *slot = (uint4 *)lds;                                        // [2][64]
     uint32_t x = 0x8000u;
     uint32_t used = 0;                 // bytes emitted so far (wave-uniform)
     bool overflow = false;
-    for (uint32_t r = rounds; r-- > 0; ) {
-        bool mine = lane < 4 && r < len_k;
-        GzRansSym s;
-        s.x_max = 0xffffffffu; s.rcp = 0; s.bias = 0; s.cmpl_rsh = 0;
-        if (mine) s = *rec (lane, r);
-        bool emit = mine && x >= s.x_max;
-        uint64_t m = __ballot (emit) & 0xfull;
-        uint32_t cnt = __popcll (m);
-        if (used + 2 * cnt + 16 > cap) { overflow = true; break; }
-        used += 2 * cnt;
-        if (emit) {
-            uint32_t below = __popcll (m & ((1ull << lane) - 1));       // emitting states with a smaller index
-            uint8_t *p = buf + cap - used + 2 * below;
-            p[0] = (uint8_t)x; p[1] = (uint8_t)(x >> 8);
-            x >>= 16;
+    const uint4 idle = make_uint4 (0xffffffffu, 0, 0, 0);              // x_max that never triggers
+    auto fetch = [&] (uint32_t r_hi) -> uint4 {                        // records of rounds r_hi-1 ... r_hi-16
+        if (r_hi <= (uint32_t)j_of) return idle;
+        const uint32_t r = r_hi - 1 - (uint32_t)j_of;
+        if (r >= len_mine) return idle;
+        const GzRansSym *p = rec (k_of, r);
+        return make_uint4 (p->x_max, p->rcp, p->bias, p->cmpl_rsh);
+    };
+    uint4 nxt = fetch (rounds);
+    int b = 0;
+    for (uint32_t r_hi = rounds; r_hi > 0 && !overflow; b ^= 1) {
+        const uint32_t nb = r_hi < 16 ? r_hi : 16;
+        slot[b * 64 + lane] = nxt;
+        gz_wave_sync ();
+        nxt = fetch (r_hi - nb);                                       // in flight while this batch is coded
+        for (uint32_t j = 0; j < nb; j++) {
+            const uint32_t r = r_hi - 1 - j;
+            const bool mine = lane < 4 && r < len_k;
+            GzRansSym s;
+            { const uint4 v = slot[b * 64 + j * 4 + (lane & 3)]; s.x_max = v.x; s.rcp = v.y; s.bias = v.z; s.cmpl_rsh = v.w; }
+            bool emit = mine && x >= s.x_max;
+            uint64_t m = __ballot (emit) & 0xfull;
+            uint32_t cnt = __popcll (m);
+            if (used + 2 * cnt + 16 > cap) { overflow = true; break; }
+            used += 2 * cnt;
+            if (emit) {
+                uint32_t below = __popcll (m & ((1ull << lane) - 1));       // emitting states with a smaller index
+                uint8_t *p = buf + cap - used + 2 * below;
+                p[0] = (uint8_t)x; p[1] = (uint8_t)(x >> 8);
+                x >>= 16;
+            }
+            if (mine) x = d_rans_advance (x, s);
         }
-        if (mine) x = d_rans_advance (x, s);
+        r_hi -= nb;
     }
     if (overflow) return 0xffffffffu;
     used += 16;
@@ -542,7 +567,7 @@ __global__ void __launch_bounds__(256) k_rans_table (GzdLeaf *leaves, const GzLo
         if (tid < 64) {
             uint32_t len_k = (raw >> 2) + ((raw & 3) > (uint32_t)(tid & 3));
             uint32_t rounds = (raw + 3) >> 2;
-            uint32_t plen = d_rans_encode_wave (tid < 4 ? len_k : 0, rounds, tpay, tpay_cap,
+            uint32_t plen = d_rans_encode_wave (tid < 4 ? len_k : 0, rounds, tpay, tpay_cap, gz_lds + 16384,
                                                 [&] (int k, uint32_t r) { return &tsyms[tin[4 * r + k]]; });
             if (!tid) shared[3] = plen;
         }
@@ -583,7 +608,7 @@ __global__ void __launch_bounds__(64) k_rans_encode (GzdLeaf *leaves)
 
     if (!L.o1) {
         uint32_t len_k = (n >> 2) + ((n & 3) > (uint32_t)(lane & 3));
-        plen = d_rans_encode_wave (lane < 4 ? len_k : 0, (n + 3) >> 2, L.pay, L.pay_cap,
+        plen = d_rans_encode_wave (lane < 4 ? len_k : 0, (n + 3) >> 2, L.pay, L.pay_cap, gz_lds,
                                    [&] (int k, uint32_t r) { return &syms[in[4 * r + k]]; });
     }
     else {
@@ -591,7 +616,7 @@ __global__ void __launch_bounds__(64) k_rans_encode (GzdLeaf *leaves)
         // the head of each quarter is coded in context 0 (:843-846)
         const uint32_t q = n >> 2;
         uint32_t len_k = lane == 3 ? n - 3 * q : q;
-        plen = d_rans_encode_wave (lane < 4 ? len_k : 0, n - 3 * q, L.pay, L.pay_cap,
+        plen = d_rans_encode_wave (lane < 4 ? len_k : 0, n - 3 * q, L.pay, L.pay_cap, gz_lds,
                                    [&] (int k, uint32_t r) {
                                        uint32_t at = k * q + r;
                                        return &syms[(r ? in[at - 1] : 0) * 256 + in[at]];

@@ -1186,6 +1186,18 @@ uint32_t gzo_b250_seg_put (uint8_t *dst, int32_t node_index, uint32_t ol_nodes_l
     return (uint32_t)n;
 }
 
+/* test convenience: a whole array of node indices -> seg-format bytes; returns the length */
+uint64_t gzo_b250_seg_put_many (uint8_t *dst, const int32_t *node_index, uint64_t n, uint32_t ol_nodes_len)
+{
+    uint64_t at = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        uint32_t k = gzo_b250_seg_put (dst + at, node_index[i], ol_nodes_len);
+        if (!k) return 0;
+        at += k;
+    }
+    return at;
+}
+
 uint32_t gzo_b250_piz_put (uint8_t *dst, int32_t wi) /* b250.c:98-107 */
 {
     uint32_t code; int n = varl_code (wi, &code);

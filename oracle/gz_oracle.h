@@ -65,6 +65,7 @@ int gzo_codec_assign_best (const uint8_t *in, uint32_t in_len, uint32_t *sizes_o
 /* seg-time encoding of one entry (little endian, type tag in LAST byte); new nodes (>= ol_nodes_len) always 4 B.
  * returns bytes written (1..4) */
 uint32_t gzo_b250_seg_put (uint8_t *dst, int32_t node_index, uint32_t ol_nodes_len);
+uint64_t gzo_b250_seg_put_many (uint8_t *dst, const int32_t *node_index, uint64_t n, uint32_t ol_nodes_len);
 /* PIZ-format big-endian encoding of one word index (tag in first byte); returns bytes written */
 uint32_t gzo_b250_piz_put (uint8_t *dst, int32_t wi);
 /* b250_zip_generate: seg-format buffer -> PIZ VARL format. node2word[i] is the word_index of VB-local node

@@ -136,6 +136,16 @@ class Oracle:
             out += tmp.raw[:n]
         return bytes(out)
 
+    def b250_seg_array(self, node_indices, ol_nodes_len):
+        """numpy int32 array of node indices -> seg-format bytes (C loop; for the multi-million-entry cases)"""
+        import numpy as np
+        a = np.ascontiguousarray(node_indices, dtype=np.int32)
+        out = ctypes.create_string_buffer(4 * len(a) + 4)
+        self.L.gzo_b250_seg_put_many.restype = ctypes.c_uint64
+        n = self.L.gzo_b250_seg_put_many(out, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(len(a)), ol_nodes_len)
+        assert n or not len(a)
+        return out.raw[:n]
+
     def b250_piz(self, wis):
         out = bytearray()
         tmp = ctypes.create_string_buffer(4)

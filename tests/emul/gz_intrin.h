@@ -14,3 +14,4 @@ static inline void gz_sched_fence (void) {}
 static inline void gz_scalar_cache_inv (void) {}
 static inline void gz_touch (const void *p, uint32_t &pit) { pit += *(const volatile uint8_t *)p; }
 static inline void gz_touch_done (uint32_t &) {}
+static inline void gz_wave_sync (void) { (void)__ballot (1); }
