@@ -54,174 +54,96 @@ __device__ static inline uint32_t d_readlane (uint32_t v, int lane) { return (ui
 // (clang 22 / ROCm 7.2 has no __builtin_amdgcn_writelane; compare + select costs one more VALU op than v_writelane_b32)
 __device__ static inline uint32_t d_writelane (uint32_t val, int lane, uint32_t old) { return (int)(threadIdx.x & 63) == lane ? val : old; }
 
-// J = registers per lane holding the model (entries e = j*64 + lane), J*64 >= max_sym. Wide alphabets (> 64 distinct
-// bytes: binary planes) - one occurrence at a time. The occurrences of this wave's context inside the position chunk
-// are entries [j0, j1) of the leaf's sorted lists (order 1; srk holds the byte itself), or positions [j0, j1) (order 0).
-template <int J>
-__device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, uint32_t ms, bool o1, uint4 *recs, const GzDivMagic *magic_tab,
-                                                            const uint32_t *spos, const uint8_t *srk, uint32_t j0, uint32_t j1, bool first, bool save, uint32_t *st)
-{
-    const int lane = threadIdx.x & 63;
-    uint32_t sym[J], freq[J], cum[J];
-    uint32_t tot = ms;
-    if (first) {
-        #pragma unroll
-        for (int j = 0; j < J; j++) {
-            uint32_t e = j * 64 + lane;
-            sym[j] = e; freq[j] = e < ms ? 1 : 0; cum[j] = e < ms ? e : ms;
-        }
-    }
-    else {                                                 // resume where the previous position chunk stopped
-        #pragma unroll
-        for (int j = 0; j < J; j++) { sym[j] = st[(3 * j) * 64 + lane]; freq[j] = st[(3 * j + 1) * 64 + lane]; cum[j] = st[(3 * j + 2) * 64 + lane]; }
-        tot = d_uniform (st[12 * 64]);
-    }
-
-    uint32_t nx_pos = 0, nx_s = 0;                         // the next 64 occurrences are fetched while these are worked on
-    if (j0 + lane < j1) {
-        if (o1) { nx_pos = spos[j0 + lane]; nx_s = srk[j0 + lane]; }
-        else    { nx_pos = j0 + lane; nx_s = in[nx_pos]; }
-    }
-    for (uint32_t jb = j0; jb < j1; jb += 64) {
-        const uint32_t cnt = j1 - jb < 64 ? j1 - jb : 64;
-        const bool mine = (uint32_t)lane < cnt;
-        const uint32_t pos = nx_pos, s_v = nx_s;
-        if (jb + 64 + lane < j1) {
-            if (o1) { nx_pos = spos[jb + 64 + lane]; nx_s = srk[jb + 64 + lane]; }
-            else    { nx_pos = jb + 64 + lane; nx_s = in[nx_pos]; }
-        }
-        uint64_t todo = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
-        uint32_t out_lo = 0, out_hi = 0;
-        while (todo) {
-            const int b = __ffsll ((unsigned long long)todo) - 1;
-            todo &= todo - 1;
-            const uint32_t s = d_readlane (s_v, b);
-            // ---- find the symbol: global position p = jj*64 + pl
-            int jj = 0, pl = 0;
-            #pragma unroll
-            for (int j = 0; j < J; j++) {
-                uint64_t hit = __ballot (sym[j] == s && (uint32_t)(j * 64 + lane) < ms);
-                if (hit) { jj = j; pl = __ffsll ((unsigned long long)hit) - 1; }
-            }
-            uint32_t f = 0, cu = 0;
-            #pragma unroll
-            for (int j = 0; j < J; j++) if (j == jj) { f = d_readlane (freq[j], pl); cu = d_readlane (cum[j], pl); }
-            // ---- hand (cum, freq, tot) to the lane that owns this occurrence
-            out_lo = d_writelane (cu | (f << 16), b, out_lo);      // cum and freq both fit 16 bits
-            out_hi = d_writelane (tot, b, out_hi);
-            // ---- bump (c_simple_model.h:133-134): the entry gains 16, so does the cumulative of everything after it
-            const uint32_t p = jj * 64 + pl;
-            uint32_t f16 = f + GZ_MODEL_STEP;
-            tot += GZ_MODEL_STEP;
-            #pragma unroll
-            for (int j = 0; j < J; j++) {
-                if (j == jj) freq[j] = d_writelane (f16, pl, freq[j]);
-                cum[j] += ((uint32_t)(j * 64 + lane) > p) ? GZ_MODEL_STEP : 0u;
-            }
-            // ---- halve everything when the total passes the limit (c_simple_model.h:106-115,136-137)
-            if (tot > GZ_MODEL_LIMIT) {
-                #pragma unroll
-                for (int j = 0; j < J; j++) freq[j] -= freq[j] >> 1;
-                uint32_t run = 0;
-                #pragma unroll
-                for (int j = 0; j < J; j++)
-                    for (int l = 0; l < 64; l++) {
-                        if ((uint32_t)(j * 64 + l) >= ms) break;
-                        cum[j] = d_writelane (run, l, cum[j]);
-                        run += d_readlane (freq[j], l);
-                    }
-                tot = run;
-                #pragma unroll
-                for (int j = 0; j < J; j++) {
-                    if (j == jj) f16 = d_readlane (freq[j], pl);
-                    cum[j] = ((uint32_t)(j * 64 + lane) < ms) ? cum[j] : run;
-                }
-            }
-            // ---- keep approximately sorted: one bubble step to the left (c_simple_model.h:139-145)
-            if (p > 0) {
-                const int jq = (int)((p - 1) >> 6), lq = (int)((p - 1) & 63);
-                uint32_t fl = 0, sl = 0, cl = 0;
-                #pragma unroll
-                for (int j = 0; j < J; j++) if (j == jq) { fl = d_readlane (freq[j], lq); sl = d_readlane (sym[j], lq); cl = d_readlane (cum[j], lq); }
-                if (f16 > fl) {
-                    #pragma unroll
-                    for (int j = 0; j < J; j++) {
-                        if (j == jq) { sym[j] = d_writelane (s, lq, sym[j]); freq[j] = d_writelane (f16, lq, freq[j]); }
-                        if (j == jj) { sym[j] = d_writelane (sl, pl, sym[j]); freq[j] = d_writelane (fl, pl, freq[j]); cum[j] = d_writelane (cl + f16, pl, cum[j]); }
-                    }
-                }
-            }
-        }
-        if (mine) recs[pos] = d_model_record (out_lo & 0xffff, out_lo >> 16, magic_tab[out_hi]);
-    }
-    if (save) {
-        #pragma unroll
-        for (int j = 0; j < J; j++) { st[(3 * j) * 64 + lane] = sym[j]; st[(3 * j + 1) * 64 + lane] = freq[j]; st[(3 * j + 2) * 64 + lane] = cum[j]; }
-        if (!lane) st[12 * 64] = tot;
-    }
-}
-
-// Compact variant for leaves with at most 64 distinct byte values (every quality / token stream): only the symbols
-// that occur are kept, one per lane, in list order. The max_sym - nsym entries of symbols that never occur all have
-// frequency 1 for ever (halving leaves 1 alone) and never start a swap, so they are interchangeable: each present
-// symbol just remembers how many of them sit directly in front of it (`gap`). Coding a symbol whose gap is > 0 swaps it
-// with such an entry (its frequency, >= 17, always beats 1): gap--, and the next present symbol's gap++. With gap 0
-// the left neighbour is the previous lane and the ordinary "swap if now larger" applies. cum includes the gaps.
+// ---- the adaptive models ----------------------------------------------------------------------------------------------
+// Only the symbols that occur in the leaf are kept (nsym <= 256 of them), in list order, entry e in register plane
+// e / 64 of lane e % 64 (J = 1, 2 or 4 planes; every quality / token stream has J = 1). The max_sym - nsym entries of
+// symbols that never occur all have frequency 1 for ever (halving leaves 1 alone) and never start a swap, so they are
+// interchangeable: each present symbol just remembers how many of them sit directly in front of it (`gap`). Coding a
+// symbol whose gap is > 0 swaps it with such an entry (its frequency, >= 17, always beats 1): gap--, and the next present
+// symbol's gap++. With gap 0 the left neighbour is the previous entry and the ordinary "swap if now larger" applies.
+// cum includes the gaps. `where` maps a symbol's static rank (its index in the leaf's sorted alphabet) to its entry.
 //
-// The wave scans the stream, queues the occurrences of its context (position, static rank of the symbol) in a small LDS
-// ring and works them off 64 at a time, however sparse the context is. Two ways through a batch:
+// A wave works the occurrences of its context off 64 at a time. Two ways through a batch:
 //  * one at a time (d_model_serial_step) - ~45 instructions and two vector->scalar decisions per occurrence;
 //  * all at once: as long as no occurrence causes a structural change (a swap, a halving), the triples of ALL the
 //    batch's occurrences follow from the current model plus prefix counts inside the batch:
 //        freq_j = F[p_j] + 16 * #{i < j : p_i == p_j}      cum_j = C[p_j] + 16 * #{i < j : p_i < p_j}
 //        tot_j  = tot + 16 * j                              (p = list position of the occurrence's symbol)
 //    and whether occurrence j would swap needs only the left neighbour's frequency at that time,
-//    FL[p_j] + 16 * #{i < j : p_i == p_j - 1}. The lanes fetch F, C, gap, FL with cross-lane reads (the symbol -> list
-//    position map `where` is kept per static rank); one round per DISTINCT list position in the batch accumulates the
-//    counts (and, speculatively, the model update) with ~20 instructions; the longest valid prefix is accepted in one
-//    go, and only the first occurrence that changes the structure (if any) takes the one-at-a-time path.
-struct GzModelLane { uint32_t sym, srank, freq, cum, gap, where; };
+//    FL[p_j] + 16 * #{i < j : p_i == p_j - 1}. The lanes fetch F, C, gap, FL with cross-lane reads; one round per
+//    DISTINCT list position in the batch accumulates the counts (and, speculatively, the model update); events (below)
+//    are patched in place.
+template <int J> struct GzModel { uint32_t sym[J], srank[J], freq[J], cum[J], gap[J], where[J]; };
 
-
-__device__ static __forceinline__ void d_model_serial_step (GzModelLane &M, uint32_t &tot, int lane, int r, uint32_t nsym, uint32_t n_absent)
+// R[idx / 64] of lane idx % 64, idx per lane
+template <int J> __device__ static __forceinline__ uint32_t d_gather (const uint32_t (&R)[J], uint32_t idx)
 {
-    const bool me = lane == r;
+    uint32_t v = (uint32_t)__shfl ((int)R[0], (int)(idx & 63));
+    #pragma unroll
+    for (int j = 1; j < J; j++) { const uint32_t t = (uint32_t)__shfl ((int)R[j], (int)(idx & 63)); v = (idx >> 6) == (uint32_t)j ? t : v; }
+    return v;
+}
+// the same for a wave-uniform idx
+// (tried: running only the copy of the code for the plane concerned, picked by a uniform branch - measurably slower than
+//  doing every plane with a select)
+template <int J> __device__ static __forceinline__ uint32_t d_peek (const uint32_t (&R)[J], uint32_t idx)
+{
+    uint32_t v = d_readlane (R[0], (int)(idx & 63));
+    #pragma unroll
+    for (int j = 1; j < J; j++) if ((idx >> 6) == (uint32_t)j) v = d_readlane (R[j], (int)(idx & 63));
+    return v;
+}
+
+template <int J>
+__device__ static __forceinline__ void d_model_serial_step (GzModel<J> &M, uint32_t &tot, int lane, uint32_t r, uint32_t nsym, uint32_t n_absent)
+{
     // bump
-    M.freq += me ? GZ_MODEL_STEP : 0u;
-    M.cum  += lane > r ? GZ_MODEL_STEP : 0u;
-    tot    += GZ_MODEL_STEP;
+    #pragma unroll
+    for (int j = 0; j < J; j++) {
+        const uint32_t e = (uint32_t)(j * 64 + lane);
+        M.freq[j] += e == r ? GZ_MODEL_STEP : 0u;
+        M.cum[j]  += e > r ? GZ_MODEL_STEP : 0u;
+    }
+    tot += GZ_MODEL_STEP;
     if (tot > GZ_MODEL_LIMIT) {                                  // rare: halve, rebuild tot and cum
-        M.freq -= M.freq >> 1;
         uint32_t run = 0, fsum = 0;
-        for (uint32_t l = 0; l < nsym; l++) {
-            run += d_readlane (M.gap, (int)l);
-            M.cum = d_writelane (run, (int)l, M.cum);
-            const uint32_t fq = d_readlane (M.freq, (int)l);
-            run += fq; fsum += fq;
+        #pragma unroll
+        for (int j = 0; j < J; j++) {
+            M.freq[j] -= M.freq[j] >> 1;
+            for (uint32_t l = 0; l < 64 && (uint32_t)(j * 64) + l < nsym; l++) {
+                run += d_readlane (M.gap[j], (int)l);
+                M.cum[j] = d_writelane (run, (int)l, M.cum[j]);
+                const uint32_t fq = d_readlane (M.freq[j], (int)l);
+                run += fq; fsum += fq;
+            }
         }
         tot = fsum + n_absent;                                   // every absent entry still weighs 1
     }
     // one bubble step to the left (c_simple_model.h:139-145)
-    const uint32_t f_now = d_readlane (M.freq, r);
-    const bool over_absent = me && M.gap > 0;
-    const bool over_left = (lane == r - 1) && M.freq < f_now;
-    if (__ballot (over_absent || over_left)) {
-        const uint32_t g = d_readlane (M.gap, r);
-        if (g > 0) {
-            M.gap += me ? 0xffffffffu : (lane == r + 1 ? 1u : 0u);  // the absent entry hops over: mine - 1, next + 1
-            M.cum += me ? 0xffffffffu : 0u;
+    const uint32_t f_now = d_peek<J> (M.freq, r), g = d_peek<J> (M.gap, r);
+    const uint32_t q = r ? r - 1 : 0;
+    const uint32_t fl = d_peek<J> (M.freq, q);
+    if (g > 0) {                                                 // the absent entry hops over: mine - 1, next + 1
+        #pragma unroll
+        for (int j = 0; j < J; j++) {
+            const uint32_t e = (uint32_t)(j * 64 + lane);
+            M.gap[j] += e == r ? 0xffffffffu : (e == r + 1 ? 1u : 0u);
+            M.cum[j] += e == r ? 0xffffffffu : 0u;
         }
-        else {
-            const int q = r - 1;
-            const uint32_t fl = d_readlane (M.freq, q), sl = d_readlane (M.sym, q), cl = d_readlane (M.cum, q), gl = d_readlane (M.gap, q);
-            const uint32_t rs = d_readlane (M.srank, r), rl = d_readlane (M.srank, q), s = d_readlane (M.sym, r);
-            const bool at_q = lane == q;
-            M.sym   = at_q ? s : (me ? sl : M.sym);
-            M.srank = at_q ? rs : (me ? rl : M.srank);
-            M.freq  = at_q ? f_now : (me ? fl : M.freq);
-            M.gap   = at_q ? gl : (me ? 0u : M.gap);
-            M.cum   = me ? cl + f_now : M.cum;                   // lane q keeps its cumulative
-            M.where = lane == (int)rs ? (uint32_t)q : (lane == (int)rl ? (uint32_t)r : M.where);
+    }
+    else if (r > 0 && fl < f_now) {
+        const uint32_t sl = d_peek<J> (M.sym, q), cl = d_peek<J> (M.cum, q);
+        const uint32_t rs = d_peek<J> (M.srank, r), rl = d_peek<J> (M.srank, q), s = d_peek<J> (M.sym, r);
+        #pragma unroll
+        for (int j = 0; j < J; j++) {
+            const uint32_t e = (uint32_t)(j * 64 + lane);
+            const bool at_q = e == q, me = e == r;
+            M.sym[j]   = at_q ? s : (me ? sl : M.sym[j]);
+            M.srank[j] = at_q ? rs : (me ? rl : M.srank[j]);
+            M.freq[j]  = at_q ? f_now : (me ? fl : M.freq[j]);
+            M.gap[j]   = me ? 0u : M.gap[j];                     // (the promoted symbol takes over its neighbour's gap: entry q keeps it)
+            M.cum[j]   = me ? cl + f_now : M.cum[j];             // (entry q keeps its cumulative)
+            M.where[j] = e == rs ? q : (e == rl ? r : M.where[j]);
         }
     }
 }
@@ -242,20 +164,26 @@ __device__ static __forceinline__ void d_model_serial_step (GzModelLane &M, uint
 // The model registers follow the order changes immediately; the batch's counts (ceq, clt per list position) are added
 // at the end. Only a halving (once per ~2000 occurrences of a context) ends an attempt early: the prefix is committed,
 // that one occurrence goes through d_model_serial_step, and the rest starts a new attempt.
-__device__ static __forceinline__ void d_model_batch (GzModelLane &M, uint32_t &tot, int lane, uint32_t cnt, uint32_t rk, uint32_t nsym,
+template <int J>
+__device__ static __forceinline__ void d_model_batch (GzModel<J> &M, uint32_t &tot, int lane, uint32_t cnt, uint32_t rk, uint32_t nsym,
                                                       uint32_t n_absent, uint32_t &out_cum, uint32_t &out_freq, uint32_t &out_tot)
 {
     uint64_t todo = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
+    // (a model that has seen fewer than two occurrences per symbol is all ties: nearly every occurrence is an event, and
+    //  one at a time is the cheaper way through them)
+    const uint32_t settled = nsym + n_absent + 2 * GZ_MODEL_STEP * nsym;
     while (todo) {
-        if (__popcll (todo) >= 3) {
+        if (__popcll (todo) >= 3 && tot >= settled) {
             const bool occ = (todo >> lane) & 1;
-            uint32_t p  = (uint32_t)__shfl ((int)M.where, (int)rk);
-            const uint32_t F  = (uint32_t)__shfl ((int)M.freq, (int)p), Cm = (uint32_t)__shfl ((int)M.cum, (int)p);
-            uint32_t G  = (uint32_t)__shfl ((int)M.gap, (int)p);
-            const uint32_t FL = (uint32_t)__shfl ((int)M.freq, (int)(p ? p - 1 : 0));
+            uint32_t p  = d_gather<J> (M.where, rk);
+            const uint32_t F  = d_gather<J> (M.freq, p), Cm = d_gather<J> (M.cum, p);
+            uint32_t G  = d_gather<J> (M.gap, p);
+            const uint32_t FL = d_gather<J> (M.freq, p ? p - 1 : 0);
             // as an occurrence I count the earlier occurrences at my position / below it / at my left neighbour; as
-            // list position `lane` I count what the whole batch adds to my frequency and cumulative
-            uint32_t eq = 0, lt = 0, eql = 0, ceq = 0, clt = 0;
+            // list entries lane + 64 j I count what the whole batch adds to my frequency and cumulative
+            uint32_t eq = 0, lt = 0, eql = 0, ceq[J], clt[J];
+            #pragma unroll
+            for (int j = 0; j < J; j++) ceq[j] = clt[j] = 0;
             for (uint64_t rem = todo; rem; ) {
                 const uint32_t q = d_readlane (p, __ffsll ((unsigned long long)rem) - 1);
                 const uint64_t mb = __ballot (p == q) & todo;
@@ -264,8 +192,12 @@ __device__ static __forceinline__ void d_model_batch (GzModelLane &M, uint32_t &
                 eq  += (q == p) ? before : 0u;
                 lt  += (q < p) ? before : 0u;
                 eql += (q + 1 == p) ? before : 0u;
-                ceq += (q == (uint32_t)lane) ? c : 0u;
-                clt += (q < (uint32_t)lane) ? c : 0u;
+                #pragma unroll
+                for (int j = 0; j < J; j++) {
+                    const uint32_t e = (uint32_t)(j * 64 + lane);
+                    ceq[j] += (q == e) ? c : 0u;
+                    clt[j] += (q < e) ? c : 0u;
+                }
             }
             const uint32_t f = F + GZ_MODEL_STEP * eq, tj = tot + GZ_MODEL_STEP * gz_mbcnt (todo);
             uint32_t cu = Cm + GZ_MODEL_STEP * lt, fl = FL + GZ_MODEL_STEP * eql;
@@ -276,72 +208,85 @@ __device__ static __forceinline__ void d_model_batch (GzModelLane &M, uint32_t &
             for (uint64_t pend = acc; ; ) {
                 const uint64_t badm = __ballot (G != 0 || (p > 0 && f + GZ_MODEL_STEP > fl)) & pend;
                 if (!badm) break;
-                const int j = __ffsll ((unsigned long long)badm) - 1;
-                pend &= ~((2ull << j) - 1);
-                const bool later = lane > j;
-                const uint32_t r = d_readlane (p, j);
-                if (d_readlane (G, j)) {                                    // hop
-                    M.gap += lane == (int)r ? 0xffffffffu : (lane == (int)r + 1 ? 1u : 0u);
-                    M.cum += lane == (int)r ? 0xffffffffu : 0u;
+                const int jv = __ffsll ((unsigned long long)badm) - 1;
+                pend &= ~((2ull << jv) - 1);
+                const bool later = lane > jv;
+                const uint32_t r = d_readlane (p, jv);
+                if (d_readlane (G, jv)) {                                   // hop
+                    #pragma unroll
+                    for (int j = 0; j < J; j++) {
+                        const uint32_t e = (uint32_t)(j * 64 + lane);
+                        M.gap[j] += e == r ? 0xffffffffu : (e == r + 1 ? 1u : 0u);
+                        M.cum[j] += e == r ? 0xffffffffu : 0u;
+                    }
                     cu -= (later && p == r) ? 1u : 0u;
                     G  += later ? (p == r ? 0xffffffffu : (p == r + 1 ? 1u : 0u)) : 0u;
                 }
                 else {                                                      // swap list positions q = r - 1 and r
                     const uint32_t q = r - 1, q2 = q ? q - 1 : 0;
                     const bool is_a = p == r, is_b = p == q, is_c = p == r + 1;
-                    const uint32_t Fa = d_readlane (M.freq, (int)r), Fb = d_readlane (M.freq, (int)q), F2 = d_readlane (M.freq, (int)q2);
+                    const uint32_t Fa = d_peek<J> (M.freq, r), Fb = d_peek<J> (M.freq, q), F2 = d_peek<J> (M.freq, q2);
                     const uint32_t fa = Fa + GZ_MODEL_STEP * gz_mbcnt (__ballot (is_a) & todo);
                     const uint32_t fb = Fb + GZ_MODEL_STEP * gz_mbcnt (__ballot (is_b) & todo);
                     const uint32_t f2 = F2 + GZ_MODEL_STEP * gz_mbcnt (__ballot (q && p == q2) & todo);
-                    const uint32_t gl = d_readlane (M.gap, (int)q);
+                    const uint32_t gl = d_peek<J> (M.gap, q);
                     if (later) {
                         cu = is_a ? cu - fb : (is_b ? cu + fa : cu);
                         fl = is_a ? f2 : (is_b ? fa : (is_c ? fb : fl));
                         G  = is_a ? gl : (is_b ? 0u : G);
                     }
                     p = is_a ? q : (is_b ? r : p);                          // (all lanes: equal symbols keep equal positions)
-                    // the model registers
-                    const bool at_r = lane == (int)r, at_q = lane == (int)q;
-                    const uint32_t sb = d_readlane (M.sym, (int)q), cb = d_readlane (M.cum, (int)q);
-                    const uint32_t ra = d_readlane (M.srank, (int)r), rb = d_readlane (M.srank, (int)q), sa = d_readlane (M.sym, (int)r);
-                    M.sym   = at_q ? sa : (at_r ? sb : M.sym);
-                    M.srank = at_q ? ra : (at_r ? rb : M.srank);
-                    M.freq  = at_q ? Fa : (at_r ? Fb : M.freq);
-                    M.gap   = at_r ? 0u : M.gap;                            // (a takes over b's gap: lane q keeps it)
-                    M.cum   = at_r ? cb + Fa : M.cum;                       // (lane q keeps its cumulative)
-                    M.where = lane == (int)ra ? q : (lane == (int)rb ? r : M.where);
+                    // the model registers ...
+                    const uint32_t sb = d_peek<J> (M.sym, q), cb = d_peek<J> (M.cum, q);
+                    const uint32_t ra = d_peek<J> (M.srank, r), rb = d_peek<J> (M.srank, q), sa = d_peek<J> (M.sym, r);
                     // ... and the batch's counts per list position
-                    const uint32_t ea = d_readlane (ceq, (int)r), eb = d_readlane (ceq, (int)q), lq = d_readlane (clt, (int)q);
-                    ceq = at_q ? ea : (at_r ? eb : ceq);
-                    clt = at_r ? lq + ea : clt;
+                    const uint32_t ea = d_peek<J> (ceq, r), eb = d_peek<J> (ceq, q), lq = d_peek<J> (clt, q);
+                    #pragma unroll
+                    for (int j = 0; j < J; j++) {
+                        const uint32_t e = (uint32_t)(j * 64 + lane);
+                        const bool at_r = e == r, at_q = e == q;
+                        M.sym[j]   = at_q ? sa : (at_r ? sb : M.sym[j]);
+                        M.srank[j] = at_q ? ra : (at_r ? rb : M.srank[j]);
+                        M.freq[j]  = at_q ? Fa : (at_r ? Fb : M.freq[j]);
+                        M.gap[j]   = at_r ? 0u : M.gap[j];                  // (a takes over b's gap: entry q keeps it)
+                        M.cum[j]   = at_r ? cb + Fa : M.cum[j];             // (entry q keeps its cumulative)
+                        M.where[j] = e == ra ? q : (e == rb ? r : M.where[j]);
+                        ceq[j] = at_q ? ea : (at_r ? eb : ceq[j]);
+                        clt[j] = at_r ? lq + ea : clt[j];
+                    }
                 }
             }
             if (halve_m) {                                                  // commit the prefix only: recount it
-                ceq = clt = 0;
+                #pragma unroll
+                for (int j = 0; j < J; j++) ceq[j] = clt[j] = 0;
                 for (uint64_t rem = acc; rem; ) {
                     const uint32_t q = d_readlane (p, __ffsll ((unsigned long long)rem) - 1);
                     const uint64_t mb = __ballot (p == q) & acc;
                     rem &= ~mb;
                     const uint32_t c = (uint32_t)__popcll (mb);
-                    ceq += (q == (uint32_t)lane) ? c : 0u;
-                    clt += (q < (uint32_t)lane) ? c : 0u;
+                    #pragma unroll
+                    for (int j = 0; j < J; j++) {
+                        const uint32_t e = (uint32_t)(j * 64 + lane);
+                        ceq[j] += (q == e) ? c : 0u;
+                        clt[j] += (q < e) ? c : 0u;
+                    }
                 }
             }
             if ((acc >> lane) & 1) { out_cum = cu; out_freq = f; out_tot = tj; }
-            M.freq += GZ_MODEL_STEP * ceq;
-            M.cum  += GZ_MODEL_STEP * clt;
-            tot    += GZ_MODEL_STEP * (uint32_t)__popcll (acc);
+            #pragma unroll
+            for (int j = 0; j < J; j++) { M.freq[j] += GZ_MODEL_STEP * ceq[j]; M.cum[j] += GZ_MODEL_STEP * clt[j]; }
+            tot  += GZ_MODEL_STEP * (uint32_t)__popcll (acc);
             todo &= ~acc;
             if (!todo) break;
         }
         // ---- one occurrence the ordinary way: the first pending one
         const int b = __ffsll ((unsigned long long)todo) - 1;
         todo &= todo - 1;
-        const int r = (int)d_readlane (M.where, (int)d_readlane (rk, b));
-        const uint32_t f = d_readlane (M.freq, r), cu = d_readlane (M.cum, r);
+        const uint32_t r = d_peek<J> (M.where, d_readlane (rk, b));
+        const uint32_t f = d_peek<J> (M.freq, r), cu = d_peek<J> (M.cum, r);
         const bool owner = lane == b;
         out_cum = owner ? cu : out_cum; out_freq = owner ? f : out_freq; out_tot = owner ? tot : out_tot;
-        d_model_serial_step (M, tot, lane, r, nsym, n_absent);
+        d_model_serial_step<J> (M, tot, lane, r, nsym, n_absent);
     }
 }
 
@@ -411,8 +356,7 @@ __global__ void __launch_bounds__(64) k_ctx_scatter (GzdLeaf *leaves, const uint
     const int lane = threadIdx.x;
     uint32_t *cnt = (uint32_t *)gz_lds;
     uint8_t *rank_of = gz_lds + 1024;
-    const bool wide = L.nsym > 64;                          // wide alphabets keep the byte itself
-    for (int e = lane; e < 256; e += 64) { cnt[e] = L.ctxoff[(size_t)tile * 256 + e]; rank_of[e] = wide ? (uint8_t)e : (uint8_t)L.symrank[e]; }
+    for (int e = lane; e < 256; e += 64) { cnt[e] = L.ctxoff[(size_t)tile * 256 + e]; rank_of[e] = (uint8_t)L.symrank[e]; }
     __syncthreads ();
     const uint8_t *in = L.coded;
     uint32_t *spos = L.spos; uint8_t *srk = L.srk;
@@ -442,9 +386,10 @@ __global__ void __launch_bounds__(64) k_ctx_scatter (GzdLeaf *leaves, const uint
 }
 
 // A leaf with a wide alphabet (a binary plane: up to 256 byte values) usually still has contexts that are each followed
-// by few distinct bytes (a plane of 11 000 bytes has ~43 occurrences per context). Such a context's model runs in the
-// compact form with an alphabet of its own: the bytes that follow THIS context, found by a first pass over its
-// occurrences (presence flags in LDS -> four 64-bit masks; rank of a byte = set bits below it).
+// by few distinct bytes (a plane of 11 000 bytes has ~43 occurrences per context). When the leaf is coded in one piece,
+// such a context's model runs with one register plane and an alphabet of its own: the symbols that follow THIS context,
+// found by a first pass over its occurrences (presence flags of the leaf ranks in LDS -> four 64-bit masks; local rank
+// of a symbol = set bits below its leaf rank).
 struct GzLocalAlpha { uint64_t m[4]; };
 
 __device__ static inline uint32_t d_local_rank (const GzLocalAlpha &A, uint32_t s)
@@ -456,22 +401,22 @@ __device__ static inline uint32_t d_local_rank (const GzLocalAlpha &A, uint32_t 
     return base + (uint32_t)__popcll (mj & ((1ull << (s & 63)) - 1));
 }
 
-// Returns the number of distinct bytes among the context's occurrences [j0, j1) and, if there are at most 64, leaves
-// them (ascending) in lds_list[0..]. lds_flags: 256 bytes of LDS; one wave.
-__device__ static inline uint32_t d_local_alphabet (GzLocalAlpha &A, const uint8_t *in, bool o1, const uint32_t *spos, const uint8_t *srk,
-                                                    uint32_t j0, uint32_t j1, uint8_t *lds_flags, uint8_t *lds_list)
+// Returns the number of distinct symbols among the context's occurrences [j0, j1) and, if there are at most 64, leaves
+// their byte values (ascending) in lds_list[0..]. lds_flags: 256 bytes of LDS; one wave.
+__device__ static inline uint32_t d_local_alphabet (GzLocalAlpha &A, const uint8_t *in, bool o1, const uint8_t *srk, const uint16_t *symrank,
+                                                    const uint8_t *symlist, uint32_t j0, uint32_t j1, uint8_t *lds_flags, uint8_t *lds_list)
 {
     const int lane = threadIdx.x & 63;
     ((uint32_t *)lds_flags)[lane] = 0;
     __syncthreads ();
-    for (uint32_t j = j0 + lane; j < j1; j += 64) lds_flags[o1 ? srk[j] : in[j]] = 1;
+    for (uint32_t j = j0 + lane; j < j1; j += 64) lds_flags[o1 ? srk[j] : symrank[in[j]]] = 1;
     __syncthreads ();
     uint32_t nd = 0;
     #pragma unroll
     for (int k = 0; k < 4; k++) { A.m[k] = __ballot (lds_flags[k * 64 + lane] != 0); nd += (uint32_t)__popcll (A.m[k]); }
     if (nd <= 64) {
         #pragma unroll
-        for (int k = 0; k < 4; k++) if ((A.m[k] >> lane) & 1) lds_list[d_local_rank (A, (uint32_t)(k * 64 + lane))] = (uint8_t)(k * 64 + lane);
+        for (int k = 0; k < 4; k++) if ((A.m[k] >> lane) & 1) lds_list[d_local_rank (A, (uint32_t)(k * 64 + lane))] = symlist[k * 64 + lane];
     }
     __syncthreads ();
     return nd;
@@ -480,27 +425,36 @@ __device__ static inline uint32_t d_local_alphabet (GzLocalAlpha &A, const uint8
 // (force-inlined: as a called function its arguments would arrive in vector registers and every loop on them would
 //  become exec-mask code)
 // The occurrences of this wave's context inside the position chunk are entries [j0, j1) of the leaf's sorted lists
-// (order 1), or simply positions [j0, j1) of the stream (order 0: one context).
-__device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t *in, uint32_t n, uint32_t ms, bool o1, uint4 *recs,
+// (order 1; srk = the symbol's rank in the leaf's alphabet), or simply positions [j0, j1) of the stream (order 0).
+template <int J>
+__device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, uint32_t ms, bool o1, uint4 *recs,
                                                    const GzDivMagic *magic_tab, const uint8_t *symlist, const uint16_t *symrank, uint32_t nsym,
                                                    const uint32_t *spos, const uint8_t *srk, uint32_t j0, uint32_t j1, bool first, bool save, uint32_t *st,
                                                    const GzLocalAlpha *la = nullptr)
 {
     const int lane = threadIdx.x & 63;
-    const bool live = (uint32_t)lane < nsym;
-    GzModelLane M;
+    GzModel<J> M;
     uint32_t tot = ms;
     if (first) {
-        M.sym = live ? symlist[lane] : 0xffffffffu;
-        const uint32_t prev_sym = (live && lane) ? symlist[lane - 1] : 0xffffffffu;
-        M.gap = live ? (lane ? M.sym - prev_sym - 1 : M.sym) : 0;
-        M.freq = live ? 1 : 0;
-        M.cum = live ? M.sym : ms;                        // lane entries + absent entries before it == its byte value
-        M.srank = lane; M.where = lane;
+        #pragma unroll
+        for (int j = 0; j < J; j++) {
+            const uint32_t e = (uint32_t)(j * 64 + lane);
+            const bool live = e < nsym;
+            M.sym[j] = live ? symlist[e] : 0xffffffffu;
+            const uint32_t prev_sym = (live && e) ? symlist[e - 1] : 0xffffffffu;
+            M.gap[j] = live ? (e ? M.sym[j] - prev_sym - 1 : M.sym[j]) : 0;
+            M.freq[j] = live ? 1 : 0;
+            M.cum[j] = live ? M.sym[j] : ms;                  // present entries + absent entries before it == its byte value
+            M.srank[j] = e; M.where[j] = e;
+        }
     }
     else {                                                // resume where the previous position chunk stopped
-        M.sym = st[lane]; M.srank = st[64 + lane]; M.freq = st[128 + lane]; M.cum = st[192 + lane]; M.gap = st[256 + lane]; M.where = st[320 + lane];
-        tot = d_uniform (st[384]);
+        #pragma unroll
+        for (int j = 0; j < J; j++) {
+            uint32_t *s6 = st + (6 * j) * 64 + lane;
+            M.sym[j] = s6[0]; M.srank[j] = s6[64]; M.freq[j] = s6[128]; M.cum[j] = s6[192]; M.gap[j] = s6[256]; M.where[j] = s6[320];
+        }
+        tot = d_uniform (st[6 * J * 64]);
     }
     const uint32_t n_absent = ms - nsym;
 
@@ -511,7 +465,7 @@ __device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t
     uint32_t nx_pos = 0, nx_rk = 0;
     if (j0 + lane < j1) {
         if (o1) { nx_pos = spos[j0 + lane]; nx_rk = srk[j0 + lane]; }
-        else    { nx_pos = j0 + lane; nx_rk = la ? in[nx_pos] : symrank[in[nx_pos]]; }
+        else    { nx_pos = j0 + lane; nx_rk = symrank[in[nx_pos]]; }
         if (la) nx_rk = d_local_rank (*la, nx_rk);
     }
     for (uint32_t j = j0; j < j1; j += 64) {
@@ -520,31 +474,35 @@ __device__ static __forceinline__ void d_arith_model_wave_compact (const uint8_t
         const uint32_t b_pos = nx_pos, b_rk = nx_rk;
         if (j + 64 + lane < j1) {
             if (o1) { nx_pos = spos[j + 64 + lane]; nx_rk = srk[j + 64 + lane]; }
-            else    { nx_pos = j + 64 + lane; nx_rk = la ? in[nx_pos] : symrank[in[nx_pos]]; }
+            else    { nx_pos = j + 64 + lane; nx_rk = symrank[in[nx_pos]]; }
             if (la) nx_rk = d_local_rank (*la, nx_rk);
         }
         uint32_t out_cum = 0, out_freq = 0, out_tot = 0;
-        d_model_batch (M, tot, lane, cnt, occ ? b_rk : 0u, nsym, n_absent, out_cum, out_freq, out_tot);
+        d_model_batch<J> (M, tot, lane, cnt, occ ? b_rk : 0u, nsym, n_absent, out_cum, out_freq, out_tot);
         if (p_on) recs[p_pos] = d_model_record (p_cum, p_freq, p_mg);
         p_on = occ; p_pos = b_pos; p_cum = out_cum; p_freq = out_freq;
         if (occ) p_mg = magic_tab[out_tot];
     }
     if (p_on) recs[p_pos] = d_model_record (p_cum, p_freq, p_mg);
     if (save) {
-        st[lane] = M.sym; st[64 + lane] = M.srank; st[128 + lane] = M.freq; st[192 + lane] = M.cum; st[256 + lane] = M.gap; st[320 + lane] = M.where;
-        if (!lane) st[384] = tot;
+        #pragma unroll
+        for (int j = 0; j < J; j++) {
+            uint32_t *s6 = st + (6 * j) * 64 + lane;
+            s6[0] = M.sym[j]; s6[64] = M.srank[j]; s6[128] = M.freq[j]; s6[192] = M.cum[j]; s6[256] = M.gap[j]; s6[320] = M.where[j];
+        }
+        if (!lane) st[6 * J * 64] = tot;
     }
 }
 
-// Position chunks: the model of positions [k*C, (k+1)*C) of every leaf is one launch, the chain over the same positions
-// another one on a second HIP stream; chain chunk k runs beside model chunk k+1, so that only the first model chunk is
-// not hidden behind the (longer, strictly serial) chain. The models' registers travel between launches through mstate.
-#define GZ_MSTATE_WORDS 16                 // per lane and context: compact 6 (+ total), generic up to 12 (+ total)
+// Position chunks: the model of positions [k*C, (k+1)*C) of every leaf is one launch; the chain follows chunk by
+// chunk, so that only the first model chunk is not hidden behind the (longer, strictly serial) chain. The models'
+// registers travel between launches through mstate.
+#define GZ_MSTATE_WORDS 32                 // per lane and context: 6 per register plane (+ the total)
 #define GZ_CHUNK_MIN    (64u * 1024u)      // positions; a multiple of GZ_CTX_TILE. Leaves up to this size are never split.
 
 // The grids of these kernels run over a list of the plain arithmetic-coder leaves only (a VBlock's other leaves would
 // otherwise cost a million workgroups per launch that exit at once - and the dispatcher, not the work, set the pace).
-#define GZ_MODEL_GRID_Y 65                 // context 0 + one per present symbol of a compact leaf
+#define GZ_MODEL_GRID_Y 65                 // context 0 + one per present symbol of a leaf with up to 64 symbols
 
 // grid (listed leaves, GZ_MODEL_GRID_Y)
 __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, const GzDivMagic *magic_tab, uint32_t p0, uint32_t chunk)
@@ -573,7 +531,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
         uint32_t *st = d_uniform_ptr (L.mstate) + (size_t)ctx * (GZ_MSTATE_WORDS * 64);   // (only touched when the leaf spans chunks)
         uint32_t j0 = p0, j1 = p1;
         if (o1_u) { j0 = d_uniform (off[(size_t)t0 * 256 + ctx]); j1 = d_uniform (cend[ctx]); }   // my run of the sorted lists
-        d_arith_model_wave_compact (coded, n_u, ms_u, o1_u, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        d_arith_model_wave<1> (coded, ms_u, o1_u, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
         return;
     }
     // wide alphabets: the contexts are dealt out over the blocks of the column
@@ -586,14 +544,14 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
         if (p0 == 0 && p1 == n_u && j1 > j0) {                  // a leaf in one piece: try the context's own alphabet
             GzLocalAlpha la;
             uint8_t *lds_flags = gz_lds, *lds_list = gz_lds + 256;
-            const uint32_t nd = d_local_alphabet (la, coded, o1_u, spos, srk, j0, j1, lds_flags, lds_list);
+            const uint32_t nd = d_local_alphabet (la, coded, o1_u, srk, L.symrank, L.symlist, j0, j1, lds_flags, lds_list);
             if (nd <= 64) {
-                d_arith_model_wave_compact (coded, n_u, ms_u, o1_u, tr, magic_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, true, false, st, &la);
+                d_arith_model_wave<1> (coded, ms_u, o1_u, tr, magic_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, true, false, st, &la);
                 continue;
             }
         }
-        if (ms <= 128) d_arith_model_wave<2> (coded, ms_u, o1_u, tr, magic_tab, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
-        else           d_arith_model_wave<4> (coded, ms_u, o1_u, tr, magic_tab, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        if (nsym_u <= 128) d_arith_model_wave<2> (coded, ms_u, o1_u, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        else               d_arith_model_wave<4> (coded, ms_u, o1_u, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
     }
 }
 
