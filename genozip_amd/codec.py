@@ -238,6 +238,25 @@ class Engine:
         self._check(self.L.gz_adler32(self.h, self.mem.ptr(buf), len(data), C.byref(a)), "gz_adler32")
         return a.value
 
+    # ---- CODEC_ACGT pre-transform (codec_acgt.c) ----------------------------------------------------------
+    def acgt_pack(self, seq, in_place=False):
+        """SEQ bytes -> (2-bit packed bytes, exception stream, has_x)"""
+        n = len(seq)
+        sbuf = self.mem.upload(seq) if n else self.mem.alloc(16)
+        pl = self.L.gz_acgt_packed_len(n)
+        pbuf = self.mem.alloc(pl + 16)
+        xbuf = sbuf if in_place else self.mem.alloc(n + 16)
+        has_x = C.c_int(0)
+        self._check(self.L.gz_acgt_pack(self.h, self.mem.ptr(sbuf), n, self.mem.ptr(pbuf), self.mem.ptr(xbuf), C.byref(has_x)), "gz_acgt_pack")
+        return self.mem.download(pbuf, pl), self.mem.download(xbuf, n), bool(has_x.value)
+
+    def acgt_unpack(self, packed, x, n):
+        pbuf = self.mem.upload(packed) if len(packed) else self.mem.alloc(16)
+        xbuf = self.mem.upload(x) if x is not None and n else None
+        out = self.mem.alloc(n + 16)
+        self._check(self.L.gz_acgt_unpack(self.h, self.mem.ptr(pbuf), self.mem.ptr(xbuf) if xbuf is not None else None, n, self.mem.ptr(out)), "gz_acgt_unpack")
+        return self.mem.download(out, n)
+
     # ---- VBlock section writer ----------------------------------------------------------------------------
     def vb_table(self, vblocks):
         """builds the C tables for gz_vb_compress_batch; section.data may be bytes (uploaded here) or a device buffer"""

@@ -935,6 +935,46 @@ extern "C" int gz_adler32 (GzHandle *h, const uint8_t *data, uint64_t len, uint3
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// CODEC_ACGT pre-transform
+// ---------------------------------------------------------------------------------------------------------
+extern "C" uint64_t gz_acgt_packed_len (uint64_t n_bases) { return ((2 * n_bases + 63) / 64) * 8; }
+
+extern "C" int gz_acgt_pack (GzHandle *h, const uint8_t *seq, uint64_t n_bases, uint8_t *packed, uint8_t *x, int *has_x_host)
+{
+    if (!h || !has_x_host || (n_bases && (!seq || !packed || !x))) return GZ_ERR_ARG;
+    int rc;
+    if ((rc = gz_sync (h)) < 0) return rc;
+    uint32_t *d = (uint32_t *)arena_alloc (h, 4);
+    if (!d) return GZ_ERR_HIP;
+    HIPCHK (h, hipMemsetAsync (d, 0, 4, h->stream));
+    const uint64_t pb = gz_acgt_packed_len (n_bases);
+    if (pb) {
+        uint64_t blocks = (pb / 4 + 255) / 256;
+        if (blocks > 16384) blocks = 16384;              // (grid-stride: a few iterations amortise the table set-up)
+        KLAUNCH (h, k_acgt_pack, dim3 ((uint32_t)blocks), dim3 (256), 512, seq, n_bases, packed, pb, x, d);
+    }
+    HIPCHK (h, hipGetLastError ());
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    uint32_t f = 0;
+    HIPCHK (h, hipMemcpy (&f, d, 4, hipMemcpyDeviceToHost));
+    *has_x_host = f != 0;
+    return gz_sync (h) < 0 ? GZ_ERR : GZ_OK;
+}
+
+extern "C" int gz_acgt_unpack (GzHandle *h, const uint8_t *packed, const uint8_t *x, uint64_t n_bases, uint8_t *seq)
+{
+    if (!h || (n_bases && (!seq || !packed))) return GZ_ERR_ARG;
+    if (n_bases) {
+        uint64_t blocks = ((n_bases + 15) / 16 + 255) / 256;
+        if (blocks > 65536) blocks = 65536;
+        KLAUNCH (h, k_acgt_unpack, dim3 ((uint32_t)blocks), dim3 (256), 0, packed, x, n_bases, seq);
+    }
+    HIPCHK (h, hipGetLastError ());
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    return gz_sync (h) < 0 ? GZ_ERR : GZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // VBlock decode (round trip proof): walk the sections on the host, decode payloads on the device
 // ---------------------------------------------------------------------------------------------------------
 extern "C" int gz_vb_uncompress (GzHandle *h, const uint8_t *z_data, uint64_t z_len, uint8_t *out, uint64_t out_cap,

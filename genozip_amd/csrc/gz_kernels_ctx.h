@@ -216,3 +216,76 @@ __global__ void __launch_bounds__(256) k_adler32 (const uint8_t *data, uint32_t 
     uint32_t a = gz_adler32_wg (data, len, threadIdx.x);
     if (!threadIdx.x) *out = a;
 }
+
+// ======================================================================================================
+// CODEC_ACGT pre-transform: SEQ -> 2 bits per base + exception stream (codec_acgt.c:45-55,64-129;
+// the table of reference.c:45-58). HBM-bound: reads n, writes n / 4 + n. One thread per 16 bases = one 16-byte load,
+// one packed dword, one 16-byte store of exceptions (x may be the seq buffer itself, like the reference's overlay).
+// ======================================================================================================
+__device__ static inline uint32_t d_acgt_code (uint32_t c)          // IUPAC codes map to the lowest of their bases, the rest to 0
+{
+    c |= 0x20;
+    return (c == 'c' || c == 'y' || c == 's' || c == 'b') ? 1u : (c == 'g' || c == 'k') ? 2u : (c == 't' || c == 'u') ? 3u : 0u;
+}
+__device__ static inline uint32_t d_acgt_exception (uint32_t c)     // 0: ACGT, 1: acgt, else the character
+{
+    return (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? 0u : (c == 'a' || c == 'c' || c == 'g' || c == 't') ? 1u : c;
+}
+
+// grid-stride; packed_bytes = whole 64-bit words (the excess is cleared)
+__global__ void __launch_bounds__(256) k_acgt_pack (const uint8_t *seq, uint64_t n, uint8_t *packed, uint64_t packed_bytes, uint8_t *x, uint32_t *has_x)
+{
+    const uint64_t groups = (n + 15) / 16, words = packed_bytes / 4;
+    uint32_t any = 0;
+    uint16_t *tab = (uint16_t *)gz_lds;                            // byte -> code | exception << 8 (one LDS read per base)
+    tab[threadIdx.x] = (uint16_t)(d_acgt_code (threadIdx.x) | (d_acgt_exception (threadIdx.x) << 8));
+    __syncthreads ();
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < words; g += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t w = 0;
+        if (g < groups) {
+            const uint64_t base = g * 16;
+            const uint32_t m = base + 16 <= n ? 16u : (uint32_t)(n - base);          // bases of this group that exist
+            gz_u32x4_unaligned v = { 0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u };   // 'A': code 0, exception 0
+            if (m == 16) v = *(const gz_u32x4_unaligned *)(seq + base);
+            else for (uint32_t k = 0; k < m; k++) v[k >> 2] = (v[k >> 2] & ~(0xffu << (8 * (k & 3)))) | ((uint32_t)seq[base + k] << (8 * (k & 3)));
+            gz_u32x4_unaligned ev = { 0, 0, 0, 0 };
+            #pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t t = tab[(v[k >> 2] >> (8 * (k & 3))) & 0xff];
+                w |= (t & 3) << (2 * k);
+                ev[k >> 2] |= (t >> 8) << (8 * (k & 3));
+            }
+            any |= ev[0] | ev[1] | ev[2] | ev[3];
+            if (m == 16) *(gz_u32x4_unaligned *)(x + base) = ev;
+            else for (uint32_t k = 0; k < m; k++) x[base + k] = (uint8_t)(ev[k >> 2] >> (8 * (k & 3)));
+        }
+        ((uint32_t *)packed)[g] = w;                               // (the arena and torch allocations are 4-byte aligned)
+    }
+    // (one flag for the whole stream: only the first waves to see an exception touch it)
+    if (__ballot (any != 0) && (threadIdx.x & 63) == 0 && *(volatile uint32_t *)has_x == 0) atomicMax (has_x, 1u);
+}
+
+// x == NULL: no exceptions (flags.acgt_no_x). One thread per 16 bases.
+__global__ void __launch_bounds__(256) k_acgt_unpack (const uint8_t *packed, const uint8_t *x, uint64_t n, uint8_t *seq)
+{
+    const uint64_t groups = (n + 15) / 16;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t base = g * 16;
+        const uint32_t m = base + 16 <= n ? 16u : (uint32_t)(n - base);
+        const uint32_t w = ((const uint32_t *)packed)[g];
+        gz_u32x4_unaligned ev = { 0, 0, 0, 0 };
+        if (x) {
+            if (m == 16) ev = *(const gz_u32x4_unaligned *)(x + base);
+            else for (uint32_t k = 0; k < m; k++) ev[k >> 2] |= (uint32_t)x[base + k] << (8 * (k & 3));
+        }
+        gz_u32x4_unaligned out = { 0, 0, 0, 0 };
+        #pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t b = (0x54474341u >> (8 * ((w >> (2 * k)) & 3))) & 0xff;    // "ACGT"
+            const uint32_t e = (ev[k >> 2] >> (8 * (k & 3))) & 0xff;
+            out[k >> 2] |= (e == 0 ? b : e == 1 ? b + 32 : e) << (8 * (k & 3));
+        }
+        if (m == 16) *(gz_u32x4_unaligned *)(seq + base) = out;
+        else for (uint32_t k = 0; k < m; k++) seq[base + k] = (uint8_t)(out[k >> 2] >> (8 * (k & 3)));
+    }
+}

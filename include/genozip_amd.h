@@ -188,6 +188,18 @@ int gz_vb_uncompress (GzHandle *h, const uint8_t *z_data, uint64_t z_len, uint8_
 /* adler32 of a device buffer (libdeflate_adler32 as used by src/compressor.c:161). Synchronous. */
 int gz_adler32 (GzHandle *h, const uint8_t *data, uint64_t len, uint32_t *adler_out);
 
+/* ---- CODEC_ACGT pre-transform ------------------------------------------------------------------
+ * The part of codec_acgt_compress (src/codec_acgt.c:64-137) that is not the LZMA sub-codec: SEQ bases -> 2 bits each
+ * (codec_acgt_pack :45-55 with the table of src/reference.c:45-58; little-endian 64-bit words, excess bits clear) plus
+ * the NONREF_X exception stream (:66-70,108-110: 0 for ACGT, 1 for acgt, the character otherwise). x may be seq itself
+ * (the reference overlays NONREF_X.local on NONREF.local). *has_x_host = 0 means "no exceptions": the caller sets
+ * flags.acgt_no_x and drops NONREF_X (:133-137). The packed bytes then go to the sub-codec (LZMA, host) and x through
+ * the ordinary codec path (gz_codec_compress_*). Synchronous. */
+uint64_t gz_acgt_packed_len (uint64_t n_bases);
+int gz_acgt_pack (GzHandle *h, const uint8_t *seq, uint64_t n_bases, uint8_t *packed, uint8_t *x, int *has_x_host);
+/* codec_acgt_uncompress + codec_xcgt_uncompress (src/codec_acgt.c:177-199,218-246); x == NULL: flags.acgt_no_x */
+int gz_acgt_unpack (GzHandle *h, const uint8_t *packed, const uint8_t *x, uint64_t n_bases, uint8_t *seq);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1387,3 +1387,40 @@ void gzo_vb_header_write (uint8_t *z, uint32_t vblock_i, uint32_t recon_size, ui
 }
 
 void gzo_vb_header_patch (uint8_t *z, uint32_t z_data_bytes) { be32 (z + 40, z_data_bytes); }
+
+/* ---- CODEC_ACGT pre-transform ------------------------------------------------------------------------------------ */
+static uint8_t acgt_code (uint8_t c) /* reference.c:45-58: IUPAC codes map to the lowest of their bases, the rest to 0 */
+{
+    switch (c | 0x20) {
+        case 'c': case 'y': case 's': case 'b': return 1;
+        case 'g': case 'k':                     return 2;
+        case 't': case 'u':                     return 3;
+        default:                                return 0;
+    }
+}
+
+uint64_t gzo_acgt_packed_len (uint64_t n) { return ((2 * n + 63) / 64) * 8; }
+
+int gzo_acgt_pack (const uint8_t *seq, uint64_t n, uint8_t *packed, uint8_t *x)
+{
+    memset (packed, 0, gzo_acgt_packed_len (n));
+    int has_x = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint8_t c = seq[i];
+        packed[i >> 2] |= (uint8_t)(acgt_code (c) << (2 * (i & 3)));           /* codec_acgt.c:45-55, LTEN words */
+        /* codec_acgt.c:66-70,108-110: XOR with self (upper case), self^1 (lower case), 0 (anything else) */
+        const uint8_t e = (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? 0 : (c == 'a' || c == 'c' || c == 'g' || c == 't') ? 1 : c;
+        x[i] = e;
+        has_x |= e != 0;
+    }
+    return has_x;                                                              /* :133-137: all zero -> acgt_no_x */
+}
+
+void gzo_acgt_unpack (const uint8_t *packed, const uint8_t *x, uint64_t n, uint8_t *seq)
+{
+    static const char dec[4] = { 'A', 'C', 'G', 'T' };
+    for (uint64_t i = 0; i < n; i++) {
+        const char b = dec[(packed[i >> 2] >> (2 * (i & 3))) & 3];
+        seq[i] = (!x || x[i] == 0) ? (uint8_t)b : x[i] == 1 ? (uint8_t)(b + 32) : x[i];
+    }
+}

@@ -118,6 +118,13 @@ void gzo_vb_header_write (uint8_t *z, uint32_t vblock_i, uint32_t recon_size, ui
                           uint32_t longest_seq_len, const uint8_t digest[16], uint8_t flags);
 void gzo_vb_header_patch (uint8_t *z, uint32_t z_data_bytes); /* zfile.c:1139-1144 */
 
+/* ---- CODEC_ACGT pre-transform (codec_acgt.c:45-55,64-129, reference.c:45-58): SEQ -> 2 bits per base
+ * (little-endian 64-bit words, base i in bits 2i..2i+1, excess bits of the top word clear) + the exception stream
+ * NONREF_X (0 for ACGT, 1 for acgt, the character itself otherwise). The LZMA sub-codec stays outside the path. */
+uint64_t gzo_acgt_packed_len (uint64_t n);                     /* bytes: whole 64-bit words */
+int  gzo_acgt_pack (const uint8_t *seq, uint64_t n, uint8_t *packed, uint8_t *x);   /* x may be seq; returns has_x */
+void gzo_acgt_unpack (const uint8_t *packed, const uint8_t *x /* or NULL */, uint64_t n, uint8_t *seq);   /* codec_acgt.c:177-199,232-246 */
+
 #ifdef __cplusplus
 }
 #endif

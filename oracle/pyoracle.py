@@ -179,6 +179,21 @@ class Oracle:
         lt = self.L.gzo_local_generate(ltype, buf, ctypes.c_uint64(len(raw_native_le) // w), transpose_cols, scratch)
         return lt, buf.raw[:len(raw_native_le)]
 
+    # ---- CODEC_ACGT pre-transform
+    def acgt_pack(self, seq):
+        seq = bytes(seq)
+        self.L.gzo_acgt_packed_len.restype = ctypes.c_uint64
+        pl = self.L.gzo_acgt_packed_len(ctypes.c_uint64(len(seq)))
+        packed = ctypes.create_string_buffer(max(1, pl))
+        x = ctypes.create_string_buffer(max(1, len(seq)))
+        has_x = self.L.gzo_acgt_pack(seq, ctypes.c_uint64(len(seq)), packed, x)
+        return packed.raw[:pl], x.raw[:len(seq)], bool(has_x)
+
+    def acgt_unpack(self, packed, x, n):
+        out = ctypes.create_string_buffer(max(1, n))
+        self.L.gzo_acgt_unpack(bytes(packed), None if x is None else bytes(x), ctypes.c_uint64(n), out)
+        return out.raw[:n]
+
     # ---- sections
     def adler32(self, data, start=1):
         data = bytes(data)

@@ -144,3 +144,26 @@ def vblocks(E, oracle, n_vb, qual_len):
         total = sum(len(s.data) for s in vbs[v].sections)
         secs = E.vb_uncompress(g, total)
         assert secs == [bytes(s.data) for s in vbs[v].sections]
+
+
+def acgt(E, oracle, n):
+    """CODEC_ACGT pre-transform: pack + exceptions == oracle, unpack gives the bases back; edge lengths around the
+    16-base groups and the 32-base words; in place like the reference's overlay"""
+    r = synth.u32(4242, n + 64)
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[(r % np.uint32(4)).astype(np.int64)]
+    odd = np.frombuffer(b"NacgtRYKMSWBDHVUn-*.", dtype=np.uint8)
+    dirty = bases.copy()
+    hit = (r >> np.uint32(8)) % np.uint32(37) == 0
+    dirty[hit] = odd[((r >> np.uint32(16)) % np.uint32(len(odd))).astype(np.int64)][hit]
+    for name, arr in (("clean", bases), ("dirty", dirty)):
+        for m in sorted({0, 1, 3, 4, 15, 16, 17, 31, 32, 33, 63, 64, 65, 1000, n}):
+            if m > n:
+                continue
+            seq = arr[:m].tobytes()
+            want = oracle.acgt_pack(seq)
+            got = E.acgt_pack(seq)
+            assert got == want, (name, m)
+            assert E.acgt_pack(seq, in_place=True) == want, (name, m, "in place")
+            assert (name == "clean" or m < 40) or want[2]
+            x = want[1] if want[2] else None
+            assert E.acgt_unpack(want[0], x, m) == seq == oracle.acgt_unpack(want[0], x, m), (name, m)

@@ -43,3 +43,7 @@ def test_emul_arith_long_streams(emul_engine, oracle):
     got = emul_engine.compress_many(items)
     for (c, d), g in zip(items, got):
         assert g == oracle.codec_compress(c, d), (c, len(d))
+
+
+def test_emul_acgt(emul_engine, oracle):
+    parity.acgt(emul_engine, oracle, 5000)

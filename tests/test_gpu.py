@@ -75,3 +75,8 @@ def test_many_vblocks_concurrently(gpu_engine, oracle):
     got = E.compress_many(items)
     for (c, d), g in zip(items, got):
         assert g == oracle.codec_compress(c, d)
+
+
+def test_acgt_pack(gpu_engine, oracle):
+    """N2: a VBlock's worth of SEQ (46 000 reads x 150 bp)"""
+    parity.acgt(gpu_engine, oracle, 6900000)

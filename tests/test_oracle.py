@@ -133,3 +133,18 @@ def test_local_and_sections(oracle):
     assert list(sec[24:32]) == [12, 6, 0, 0x04, 11, 7, 0xff, 0] and sec[32:40] == b"QUAL\0\0\0\0"
     tiny = oracle.section_compress(desc, b"x" * 49)          # < 50 bytes: stored raw, codec byte rewritten to NONE
     assert tiny[25] == 1 and tiny[40:] == b"x" * 49
+
+
+def test_acgt_kats(oracle):
+    """hand-derived from codec_acgt.c:45-55,66-70 and reference.c:45-58 (parity unpinned beyond these: the reference ships
+    no fixture and cannot be run): base i sits in bits 2(i%4) of byte i/4, whole little-endian 64-bit words"""
+    p, x, has_x = oracle.acgt_pack(b"ACGT")
+    assert (p, x, has_x) == (bytes([0b11100100]) + bytes(7), bytes(4), False)
+    p, x, has_x = oracle.acgt_pack(b"ACGTacgtNNRYACGTA")
+    assert p.hex() == "e4e440e400000000" and x == b"\0\0\0\0\1\1\1\1NNRY\0\0\0\0\0" and has_x
+    assert oracle.acgt_unpack(p, x, 17) == b"ACGTacgtNNRYACGTA" and oracle.acgt_unpack(p, None, 17) == b"ACGTACGTAAACACGTA"
+    assert oracle.acgt_pack(b"") == (b"", b"", False) and len(oracle.acgt_pack(b"A" * 33)[0]) == 16
+    iupac = {"U": 3, "R": 0, "Y": 1, "S": 1, "W": 0, "K": 2, "M": 0, "B": 1, "D": 0, "H": 0, "V": 0, "N": 0, "-": 0, "*": 0}
+    for ch, code in iupac.items():
+        for c in (ch, ch.lower()):
+            assert oracle.acgt_pack(c.encode())[0][0] == code and oracle.acgt_pack(c.encode())[1] == c.encode()
