@@ -84,6 +84,10 @@ struct GzdLeaf {
     uint8_t   *srk;           // arith order-1: static rank of the symbol at spos[j]
     uint32_t  *ctxoff;        // arith order-1: [tile][context] -> index into spos/srk of the first occurrence at or after the tile
     uint32_t  *ctxend;        // arith order-1: [context] -> end of the context's run in the position chunk sorted last
+    uint16_t  *ev_ctx;        // arith run-length variant: model id of every coding event (0..255 literal models, 256 + 0..257 run models)
+    uint8_t   *ev_sym;        // arith run-length variant: its symbol (literal: rank in the leaf's alphabet; run digit: 0..3)
+    uint32_t  arith_n;        // arith: symbols the coder sees: coded_n, or the number of events of the run-length variant
+    uint32_t  nctx;           // arith: row length of ctxoff / ctxend: 256, or 768 for the run-length variant's 514 models
     uint32_t  *mstate;        // arith: the models' registers between two position chunks (GZ_MSTATE_WORDS x 64 lanes per context)
     uint8_t   *events;        // arith: one 32-bit digit per output byte (k_low_replay / k_low_norm)
     uint8_t   *rvals;         // arith: r = range / tot of every symbol (k_arith_chain -> k_low_*)

@@ -170,8 +170,7 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
     if (hipMalloc ((void **)&h->d_fail, 64) != hipSuccess || hipMemset (h->d_fail, 0, 64) != hipSuccess) { if (err) *err = GZ_ERR_HIP; gz_destroy (h); return NULL; }
     { const char *e = getenv ("GZ_NO_PIPELINE"); h->no_pipeline = e && *e && *e != '0'; }
     // the largest LDS class of the arithmetic coder needs more than the default 64 KB of dynamic LDS
-    if (hipFuncSetAttribute ((const void *)k_arith_encode, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
-        hipFuncSetAttribute ((const void *)k_arith_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
+    if (hipFuncSetAttribute ((const void *)k_arith_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
         hipFuncSetAttribute ((const void *)k_arith_decode, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
         if (err) *err = GZ_ERR_HIP;
         gz_destroy (h);
@@ -260,11 +259,11 @@ struct Plan {
     std::vector<GzdStream> streams;
     std::vector<GzdLeaf>   leaves;
     std::vector<GzdLowBlock> low_blocks;   // (leaf, first slice) of every 256-slice workgroup of the k_low_* kernels
-    bool any_striped = false, any_rans = false, any_arith = false, any_arith_rle = false;
+    bool any_striped = false, any_rans = false, any_arith = false;
     uint32_t max_in = 0;
     uint32_t max_arith_n = 0;              // largest plain (model/chain) arith leaf
     bool any_arith_o1 = false;
-    std::vector<uint32_t> plain_list, plain_nb, o1_list;   // plain (model/chain) arith leaves and their size bounds; those of them that are order-1
+    std::vector<uint32_t> plain_list, plain_nb, o1_list, rle_list;   // plain (model/chain) arith leaves and their size bounds; those of them that are order-1
 };
 
 static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int plane, int method, uint32_t n_bound)
@@ -276,7 +275,7 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
     if (pack) { if (!(L.packed = (uint8_t *)arena_alloc (h, (size_t)n_bound + 16))) return false; }
     // rANS stops (-> CAT) once the payload exceeds the input; the arithmetic coder's scalar chain carries no capacity
     // checks, so its area holds the worst case of an adaptive model: 2 bytes per symbol (freq 1 of a total < 2^16)
-    L.pay_cap = (engine == GZ_ENG_ARITH && !(method & GZ_X_RLE)) ? 2 * n_bound + 64 : n_bound + 64;
+    L.pay_cap = engine == GZ_ENG_ARITH ? ((method & GZ_X_RLE) ? 4 : 2) * n_bound + 64 : n_bound + 64;
     if (!(L.pay = (uint8_t *)arena_alloc (h, L.pay_cap))) return false;
     if (engine == GZ_ENG_RANS) {
         if (!(L.F    = (uint32_t *)arena_alloc (h, (o1 ? 256 * 256 + 256 : 256) * sizeof (uint32_t)))) return false;
@@ -286,33 +285,34 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
     }
     else {
         const bool rle = method & GZ_X_RLE;
+        // what the coder sees: the bytes, or (run-length variant) up to 2 coding events per byte
+        const uint32_t nb = rle ? 2 * n_bound : n_bound;
+        const uint32_t nctx = rle ? 768 : 256;
+        if (!(L.triples = (uint8_t *)arena_alloc (h, ((size_t)nb + 64) * 16 + 2 * GZ_CHAIN_TOUCH_AHEAD + 8192))) return false;
+        if (!(L.events  = (uint8_t *)arena_alloc (h, ((size_t)L.pay_cap + 128) * 4))) return false;
+        if (!(L.rvals   = (uint8_t *)arena_alloc (h, ((size_t)nb + 64) * 4))) return false;
+        const uint32_t ns = nb ? (nb + GZ_LOW_SLICE - 1) / GZ_LOW_SLICE : 1;
+        if (!(L.kpos    = (uint8_t *)arena_alloc (h, ((size_t)ns + 2) * 4))) return false;
+        if (!(L.resid   = (uint8_t *)arena_alloc (h, ((size_t)ns + 1) * 16))) return false;
+        for (uint32_t s0 = 0; s0 < ns; s0 += GZ_LOW_SLICES_PER_WG) { GzdLowBlock b; b.leaf = (uint32_t)P.leaves.size (); b.first_slice = s0; P.low_blocks.push_back (b); }
+        if (o1 || rle) {
+            const size_t nt = ((size_t)nb + GZ_CTX_TILE - 1) / GZ_CTX_TILE;
+            if (!(L.spos   = (uint32_t *)arena_alloc (h, ((size_t)nb + 64) * 4))) return false;
+            if (!(L.srk    = (uint8_t *)arena_alloc (h, (size_t)nb + 64))) return false;
+            if (!(L.ctxoff = (uint32_t *)arena_alloc (h, (nt + 1) * nctx * 4))) return false;
+            if (!(L.ctxend = (uint32_t *)arena_alloc (h, nctx * 4))) return false;
+            P.any_arith_o1 = true;
+            P.o1_list.push_back ((uint32_t)P.leaves.size ());
+        }
         if (rle) {
-            P.any_arith_rle = true;
-            size_t words = (size_t)(o1 ? 256 : 1) * 257 + GZ_ARITH_RUN_MODELS * GZ_ARITH_RUN_STRIDE;
-            if (!(L.models = (uint32_t *)arena_alloc (h, words * 4))) return false;
+            if (!(L.ev_ctx = (uint16_t *)arena_alloc (h, ((size_t)nb + 64) * 2))) return false;
+            if (!(L.ev_sym = (uint8_t *)arena_alloc (h, (size_t)nb + 64))) return false;
+            P.rle_list.push_back ((uint32_t)P.leaves.size ());
         }
-        else {
-            if (!(L.triples = (uint8_t *)arena_alloc (h, ((size_t)n_bound + 64) * 16 + 2 * GZ_CHAIN_TOUCH_AHEAD + 8192))) return false;
-            if (!(L.events  = (uint8_t *)arena_alloc (h, ((size_t)L.pay_cap + 128) * 4))) return false;
-            if (!(L.rvals   = (uint8_t *)arena_alloc (h, ((size_t)n_bound + 64) * 4))) return false;
-            if (o1) {
-                const size_t nt = ((size_t)n_bound + GZ_CTX_TILE - 1) / GZ_CTX_TILE;
-                if (!(L.spos   = (uint32_t *)arena_alloc (h, ((size_t)n_bound + 64) * 4))) return false;
-                if (!(L.srk    = (uint8_t *)arena_alloc (h, (size_t)n_bound + 64))) return false;
-                if (!(L.ctxoff = (uint32_t *)arena_alloc (h, (nt + 1) * 256 * 4))) return false;
-                if (!(L.ctxend = (uint32_t *)arena_alloc (h, 256 * 4))) return false;
-                P.any_arith_o1 = true;
-                P.o1_list.push_back ((uint32_t)P.leaves.size ());
-            }
-            P.plain_list.push_back ((uint32_t)P.leaves.size ());
-            P.plain_nb.push_back (n_bound);
-            if (n_bound > GZ_CHUNK_MIN && !(L.mstate = (uint32_t *)arena_alloc (h, (size_t)256 * GZ_MSTATE_WORDS * 64 * 4))) return false;
-            if (n_bound > P.max_arith_n) P.max_arith_n = n_bound;
-            const uint32_t ns = n_bound ? (n_bound + GZ_LOW_SLICE - 1) / GZ_LOW_SLICE : 1;
-            if (!(L.kpos    = (uint8_t *)arena_alloc (h, ((size_t)ns + 2) * 4))) return false;
-            if (!(L.resid   = (uint8_t *)arena_alloc (h, ((size_t)ns + 1) * 16))) return false;
-            for (uint32_t s0 = 0; s0 < ns; s0 += GZ_LOW_SLICES_PER_WG) { GzdLowBlock b; b.leaf = (uint32_t)P.leaves.size (); b.first_slice = s0; P.low_blocks.push_back (b); }
-        }
+        if (nb > GZ_CHUNK_MIN && !(L.mstate = (uint32_t *)arena_alloc (h, (size_t)(rle ? 514 : 256) * GZ_MSTATE_WORDS * 64 * 4))) return false;
+        if (nb > P.max_arith_n) P.max_arith_n = nb;
+        P.plain_list.push_back ((uint32_t)P.leaves.size ());
+        P.plain_nb.push_back (nb);
     }
     P.leaves.push_back (L);
     return true;
@@ -389,7 +389,7 @@ static const uint32_t ARITH_CLASS_WORDS[4] = { 0, 4096, 16384, 40000 };   // 16 
 // The arithmetic coder's pipeline of one batch (see gz_kernels_arith.h): which leaves, in how many position chunks
 struct ArithPipe {
     uint32_t np = 0, no1 = 0, nlb = 0, nbig = 0, nsmall = 0, chunk = 0, n_chunks = 1;
-    const uint32_t *d_plain = NULL, *d_o1 = NULL, *d_big = NULL, *d_small = NULL;
+    const uint32_t *d_plain = NULL, *d_o1 = NULL, *d_big = NULL, *d_small = NULL, *d_rle = NULL;
     const GzdLowBlock *d_lb = NULL;
     uint32_t *d_progress = NULL;
     bool pipelined = false, reserve_cu = false;
@@ -419,6 +419,7 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
     int rc = upload (h, P.plain_list.data (), P.plain_list.size () * 4, &d); A.d_plain = (const uint32_t *)d;
     if (rc == GZ_OK)             { rc = upload (h, P.low_blocks.data (), P.low_blocks.size () * sizeof (GzdLowBlock), &d); A.d_lb = (const GzdLowBlock *)d; }
     if (rc == GZ_OK && A.nbig)   { rc = upload (h, big.data (), big.size () * 4, &d); A.d_big = (const uint32_t *)d; }
+    if (rc == GZ_OK && !P.rle_list.empty ()) { rc = upload (h, P.rle_list.data (), P.rle_list.size () * 4, &d); A.d_rle = (const uint32_t *)d; }
     if (rc == GZ_OK && A.nsmall) { rc = upload (h, small.data (), small.size () * 4, &d); A.d_small = (const uint32_t *)d; }
     if (rc != GZ_OK) return rc;
     if (A.pipelined) {
@@ -468,26 +469,23 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
             KLAUNCH_ON (h, side, k_rans_table, dim3 (nl), dim3 (256), 16384 + GZ_RANS_ENC_LDS, d_leaves, (const GzLogTable *)h->d_logs);
             KLAUNCH_ON (h, side, k_rans_encode, dim3 (nl), dim3 (64), GZ_RANS_ENC_LDS, d_leaves);
         }
-        if (P.any_arith_rle) {
-            for (int c = 0; c < 3; c++)
-                KLAUNCH_ON (h, side, k_arith_encode, dim3 (nl), dim3 (64), ARITH_CLASS_WORDS[c + 1] * 4,
-                            d_leaves, ARITH_CLASS_WORDS[c], ARITH_CLASS_WORDS[c + 1], 0);
-            KLAUNCH_ON (h, side, k_arith_encode, dim3 (nl), dim3 (64), 0, d_leaves, ARITH_CLASS_WORDS[3], 0xffffffffu, 1);
-        }
         if (A.np) {
             const GzDivMagic *magic = (const GzDivMagic *)h->d_magic;
+            const uint32_t grid_y = GZ_MODEL_GRID_Y + (P.rle_list.empty () ? 0 : GZ_MODEL_GRID_RUN);
+            if (!P.rle_list.empty ())                              // the run-length variant's coding events (before anything looks at arith_n)
+                KLAUNCH (h, k_rle_events, dim3 ((uint32_t)P.rle_list.size ()), dim3 (1024), 256, d_leaves, A.d_rle);
             // sort (group the positions of the order-1 leaves by context), models, chain
             auto sort_chunk = [&] (hipStream_t st, const uint32_t *list, uint32_t n_list, uint32_t p0, uint32_t chunk, uint32_t span) -> int {
                 if (!A.no1 || !span) return GZ_OK;
                 const uint32_t tiles = (span + GZ_CTX_TILE - 1) / GZ_CTX_TILE;
-                KLAUNCH_ON (h, st, k_ctx_count, dim3 (n_list, tiles), dim3 (64), 1024, d_leaves, list, p0, chunk);
-                KLAUNCH_ON (h, st, k_ctx_scan, dim3 (n_list), dim3 (256), 1024, d_leaves, list, p0, chunk);
-                KLAUNCH_ON (h, st, k_ctx_scatter, dim3 (n_list, tiles), dim3 (64), 1280, d_leaves, list, p0, chunk);
+                KLAUNCH_ON (h, st, k_ctx_count, dim3 (n_list, tiles), dim3 (64), GZ_CTX_MAX * 4, d_leaves, list, p0, chunk);
+                KLAUNCH_ON (h, st, k_ctx_scan, dim3 (n_list), dim3 (256), GZ_CTX_MAX * 8, d_leaves, list, p0, chunk);
+                KLAUNCH_ON (h, st, k_ctx_scatter, dim3 (n_list, tiles), dim3 (64), GZ_CTX_MAX * 4 + 256, d_leaves, list, p0, chunk);
                 return GZ_OK;
             };
             if (!A.pipelined) {
                 if ((rc = sort_chunk (h->stream, A.d_plain, A.np, 0u, 0xffffffffu, P.max_arith_n)) != GZ_OK) return rc;
-                KLAUNCH (h, k_arith_model, dim3 (A.np, GZ_MODEL_GRID_Y), dim3 (64), 512, d_leaves, A.d_plain, magic, 0u, 0xffffffffu);
+                KLAUNCH (h, k_arith_model, dim3 (A.np, grid_y), dim3 (64), 512, d_leaves, A.d_plain, magic, 0u, 0xffffffffu);
                 KLAUNCH (h, k_arith_chain, dim3 ((A.np + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), 64,
                          d_leaves, A.d_plain, A.np, (const uint32_t *)NULL, 0u, h->d_fail);
             }
@@ -497,7 +495,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 for (uint32_t k = 0; k < A.n_chunks; k++) {
                     const uint32_t p0 = k * A.chunk, span = P.max_arith_n - p0 < A.chunk ? P.max_arith_n - p0 : A.chunk;
                     if ((rc = sort_chunk (h->stream4, A.d_big, A.nbig, p0, A.chunk, span)) != GZ_OK) return rc;
-                    KLAUNCH_ON (h, h->stream4, k_arith_model, dim3 (A.nbig, GZ_MODEL_GRID_Y), dim3 (64), GZ_KEEP_OFF_LDS, d_leaves, A.d_big, magic, p0, A.chunk);
+                    KLAUNCH_ON (h, h->stream4, k_arith_model, dim3 (A.nbig, grid_y), dim3 (64), GZ_KEEP_OFF_LDS, d_leaves, A.d_big, magic, p0, A.chunk);
                     hipLaunchKernelGGL (k_arith_progress, dim3 (1), dim3 (1), 0, h->stream4, A.d_progress, k + 1);
                 }
 #ifdef GZ_SEQUENTIAL_STREAMS
@@ -506,7 +504,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 if (A.nsmall) {
                     HIPCHK (h, hipStreamWaitEvent (h->stream5, h->ev_model_fork, 0));
                     if ((rc = sort_chunk (h->stream5, A.d_small, A.nsmall, 0u, 0xffffffffu, A.chunk)) != GZ_OK) return rc;
-                    KLAUNCH_ON (h, h->stream5, k_arith_model, dim3 (A.nsmall, GZ_MODEL_GRID_Y), dim3 (64), GZ_KEEP_OFF_LDS, d_leaves, A.d_small, magic, 0u, 0xffffffffu);
+                    KLAUNCH_ON (h, h->stream5, k_arith_model, dim3 (A.nsmall, grid_y), dim3 (64), GZ_KEEP_OFF_LDS, d_leaves, A.d_small, magic, 0u, 0xffffffffu);
                     KLAUNCH_ON (h, h->stream5, k_arith_chain, dim3 ((A.nsmall + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), GZ_KEEP_OFF_LDS,
                                 d_leaves, A.d_small, A.nsmall, (const uint32_t *)NULL, 0u, h->d_fail);
                     HIPCHK (h, hipEventRecord (h->ev_small, h->stream5));

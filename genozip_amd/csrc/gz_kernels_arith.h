@@ -302,48 +302,58 @@ __device__ static __forceinline__ void d_model_batch (GzModel<J> &M, uint32_t &t
 // own (into entries [p0, p1) of the lists) right before its models run: the sort of chunk k+1 hides behind the chain of chunk k.
 #define GZ_CTX_TILE 4096u
 
-__device__ static inline bool d_ctx_sorted (const GzdLeaf &L) { return L.active && L.engine == GZ_ENG_ARITH && !L.rle && L.o1 && L.coded_n; }
+__device__ static inline bool d_ctx_sorted (const GzdLeaf &L) { return L.active && L.engine == GZ_ENG_ARITH && (L.o1 || L.rle) && L.arith_n; }
 __device__ static inline uint32_t d_ctx_ntiles (uint32_t n) { return (n + GZ_CTX_TILE - 1) / GZ_CTX_TILE; }
+// context (model id) of coding event `pos`: the byte before it, or what k_rle_events wrote down
+__device__ static inline uint32_t d_ctx_of (const GzdLeaf &L, const uint8_t *in, const uint16_t *ev_ctx, uint32_t pos)
+{
+    return ev_ctx ? ev_ctx[pos] : (pos ? in[pos - 1] : 0u);
+}
+#define GZ_CTX_MAX 768                      // LDS counters: 256 contexts, or the 514 models of the run-length variant
 
 // grid (listed leaves, tiles per chunk), 64 threads; positions [p0, p0 + chunk)
 __global__ void __launch_bounds__(64) k_ctx_count (GzdLeaf *leaves, const uint32_t *list, uint32_t p0, uint32_t chunk)
 {
     GzdLeaf &L = leaves[list[blockIdx.x]];
     if (!d_ctx_sorted (L)) return;
-    const uint32_t n = L.coded_n, tile = p0 / GZ_CTX_TILE + blockIdx.y, t0 = tile * GZ_CTX_TILE;
+    const uint32_t n = L.arith_n, tile = p0 / GZ_CTX_TILE + blockIdx.y, t0 = tile * GZ_CTX_TILE, nctx = L.nctx;
     if (t0 >= n || t0 - p0 >= chunk) return;
     const int lane = threadIdx.x;
     uint32_t *cnt = (uint32_t *)gz_lds;
-    for (int e = lane; e < 256; e += 64) cnt[e] = 0;
+    for (uint32_t e = lane; e < nctx; e += 64) cnt[e] = 0;
     __syncthreads ();
-    const uint8_t *in = L.coded;
+    const uint8_t *in = L.coded; const uint16_t *ev_ctx = L.ev_ctx;
     for (uint32_t g = 0; g < GZ_CTX_TILE; g += 64) {
         const uint32_t pos = t0 + g + lane;
-        if (pos < n) atomicAdd (&cnt[pos ? in[pos - 1] : 0], 1u);
+        if (pos < n) atomicAdd (&cnt[d_ctx_of (L, in, ev_ctx, pos)], 1u);
     }
     __syncthreads ();
-    for (int e = lane; e < 256; e += 64) L.ctxoff[(size_t)tile * 256 + e] = cnt[e];
+    for (uint32_t e = lane; e < nctx; e += 64) L.ctxoff[(size_t)tile * nctx + e] = cnt[e];
 }
 
-// one 256-thread workgroup per leaf: thread c owns context c. The occurrences of positions [p0, p0 + chunk) take
-// entries [p0, p1) of the sorted lists, grouped by context: every position chunk is sorted on its own, just before
-// its models run (ctxend = where each context's run of this chunk ends).
+// one 256-thread workgroup per leaf: thread c owns contexts c, c + 256, c + 512. The occurrences of positions
+// [p0, p0 + chunk) take entries [p0, p1) of the sorted lists, grouped by context: every position chunk is sorted on
+// its own, just before its models run (ctxend = where each context's run of this chunk ends).
 __global__ void __launch_bounds__(256) k_ctx_scan (GzdLeaf *leaves, const uint32_t *list, uint32_t p0, uint32_t chunk)
 {
     GzdLeaf &L = leaves[list[blockIdx.x]];
-    if (!d_ctx_sorted (L) || L.coded_n <= p0) return;
-    const uint32_t n = L.coded_n, p1 = (n - p0 > chunk) ? p0 + chunk : n;
-    const uint32_t t0 = p0 / GZ_CTX_TILE, t1 = d_ctx_ntiles (p1), c = threadIdx.x;
+    if (!d_ctx_sorted (L) || L.arith_n <= p0) return;
+    const uint32_t n = L.arith_n, p1 = (n - p0 > chunk) ? p0 + chunk : n, nctx = L.nctx;
+    const uint32_t t0 = p0 / GZ_CTX_TILE, t1 = d_ctx_ntiles (p1);
     uint32_t *off = L.ctxoff, *sh = (uint32_t *)gz_lds;
-    uint32_t run = 0;
-    for (uint32_t t = t0; t < t1; t++) { const uint32_t v = off[(size_t)t * 256 + c]; off[(size_t)t * 256 + c] = run; run += v; }
-    sh[c] = run;
+    for (uint32_t c = threadIdx.x; c < nctx; c += 256) {
+        uint32_t run = 0;
+        for (uint32_t t = t0; t < t1; t++) { const uint32_t v = off[(size_t)t * nctx + c]; off[(size_t)t * nctx + c] = run; run += v; }
+        sh[c] = run;
+    }
     __syncthreads ();
-    if (!c) { uint32_t b = p0; for (int e = 0; e < 256; e++) { const uint32_t v = sh[e]; sh[e] = b; b += v; } }
+    if (!threadIdx.x) { uint32_t b = p0; for (uint32_t e = 0; e < nctx; e++) { const uint32_t v = sh[e]; sh[e] = b; b += v; sh[GZ_CTX_MAX + e] = v; } }
     __syncthreads ();
-    const uint32_t base = sh[c];
-    for (uint32_t t = t0; t < t1; t++) off[(size_t)t * 256 + c] += base;
-    L.ctxend[c] = base + run;
+    for (uint32_t c = threadIdx.x; c < nctx; c += 256) {
+        const uint32_t base = sh[c];
+        for (uint32_t t = t0; t < t1; t++) off[(size_t)t * nctx + c] += base;
+        L.ctxend[c] = base + sh[GZ_CTX_MAX + c];
+    }
 }
 
 // grid (listed leaves, tiles per chunk), 64 threads
@@ -351,24 +361,25 @@ __global__ void __launch_bounds__(64) k_ctx_scatter (GzdLeaf *leaves, const uint
 {
     GzdLeaf &L = leaves[list[blockIdx.x]];
     if (!d_ctx_sorted (L)) return;
-    const uint32_t n = L.coded_n, tile = p0 / GZ_CTX_TILE + blockIdx.y, t0 = tile * GZ_CTX_TILE;
+    const uint32_t n = L.arith_n, tile = p0 / GZ_CTX_TILE + blockIdx.y, t0 = tile * GZ_CTX_TILE, nctx = L.nctx;
     if (t0 >= n || t0 - p0 >= chunk) return;
     const int lane = threadIdx.x;
     uint32_t *cnt = (uint32_t *)gz_lds;
-    uint8_t *rank_of = gz_lds + 1024;
-    for (int e = lane; e < 256; e += 64) { cnt[e] = L.ctxoff[(size_t)tile * 256 + e]; rank_of[e] = (uint8_t)L.symrank[e]; }
+    uint8_t *rank_of = gz_lds + GZ_CTX_MAX * 4;
+    for (uint32_t e = lane; e < nctx; e += 64) cnt[e] = L.ctxoff[(size_t)tile * nctx + e];
+    for (int e = lane; e < 256; e += 64) rank_of[e] = (uint8_t)L.symrank[e];
     __syncthreads ();
-    const uint8_t *in = L.coded;
+    const uint8_t *in = L.coded, *ev_sym = L.ev_sym; const uint16_t *ev_ctx = L.ev_ctx;
     uint32_t *spos = L.spos; uint8_t *srk = L.srk;
     // (the bytes of the next group are requested before this group is worked on)
     uint32_t nx_c = 0xffffffffu, nx_s = 0;
-    if (t0 + lane < n) { nx_c = (t0 + lane) ? in[t0 + lane - 1] : 0u; nx_s = in[t0 + lane]; }
+    if (t0 + lane < n) { nx_c = d_ctx_of (L, in, ev_ctx, t0 + lane); nx_s = ev_sym ? ev_sym[t0 + lane] : in[t0 + lane]; }
     for (uint32_t g = 0; g < GZ_CTX_TILE && t0 + g < n; g += 64) {
         const uint32_t pos = t0 + g + lane;
         const bool valid = pos < n;
         const uint32_t c = nx_c, s = nx_s;
         nx_c = 0xffffffffu;
-        if (g + 64 < GZ_CTX_TILE && pos + 64 < n) { nx_c = in[pos + 63]; nx_s = in[pos + 64]; }
+        if (g + 64 < GZ_CTX_TILE && pos + 64 < n) { nx_c = d_ctx_of (L, in, ev_ctx, pos + 64); nx_s = ev_sym ? ev_sym[pos + 64] : in[pos + 64]; }
         const uint32_t base = valid ? cnt[c] : 0u;
         uint32_t within = 0;
         for (uint64_t rem = __ballot (valid); rem; ) {
@@ -378,11 +389,73 @@ __global__ void __launch_bounds__(64) k_ctx_scatter (GzdLeaf *leaves, const uint
             within = (c == q) ? gz_mbcnt (mb) : within;
         }
         if (valid) {
-            spos[base + within] = pos; srk[base + within] = rank_of[s];
+            spos[base + within] = pos; srk[base + within] = ev_sym ? (uint8_t)s : rank_of[s];
             atomicAdd (&cnt[c], 1u);
         }
         __syncthreads ();                                  // (one wave: the next group's gather sees this group's counts)
     }
+}
+
+// ---- the run-length variant's coding events (arith_dynamic.c:387-448,496-561) ---------------------------------------
+// A run of r + 1 equal bytes b is coded as: the literal b in the literal model of the previous literal (order 1) or model
+// 0, then r as "base-4-ish" digits, 3 meaning "more follows": floor (r / 3) threes and a final digit r % 3 - the first
+// digit in run model b, the second in run model 256, the rest in run model 257. Seen from the positions of the run
+// (offset j = 0 .. r): position 0 emits the literal, every position with j > 0 and j % 3 == 0 a three, the last position
+// the final digit. So every position emits 0 to 3 events and knows them from j and "am I the last": a segmented scan.
+// One 1024-thread workgroup per leaf walks it 1024 positions at a time (offset of the running run and number of events
+// so far carried along) and writes for every event its model id (run models: 256 +) and symbol.
+__global__ void __launch_bounds__(1024) k_rle_events (GzdLeaf *leaves, const uint32_t *list)
+{
+    GzdLeaf &L = leaves[list[blockIdx.x]];
+    if (!L.active || L.engine != GZ_ENG_ARITH || !L.rle) return;
+    const uint32_t n = L.coded_n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t *in = L.coded;
+    const bool o1 = L.o1;
+    uint16_t *ev_ctx = L.ev_ctx; uint8_t *ev_sym = L.ev_sym;
+    uint32_t *sh = (uint32_t *)gz_lds;                         // [0..15] wave aggregates (run start + 1)  [16..31] wave event counts
+    uint32_t start_carry = 0, ev_carry = 0;                    // start (+1) of the run reaching into this tile; events before it
+    uint32_t prev_lit_carry = 0;                               // the literal before that run
+    for (uint32_t t0 = 0; t0 < n; t0 += 1024) {
+        const uint32_t i = t0 + tid;
+        const bool valid = i < n;
+        const uint32_t b = valid ? in[i] : 0, bp = (valid && i) ? in[i - 1] : 0x100u, bn = (valid && i + 1 < n) ? in[i + 1] : 0x100u;
+        const bool is_start = valid && (i == 0 || bp != b), is_last = valid && bn != b;
+        // inclusive max-scan of (start position + 1) over the tile; 0 = none yet (the carried run continues)
+        uint32_t st = is_start ? i + 1 : 0;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl ((int)st, (int)(lane >= (uint32_t)d ? lane - d : lane)); st = (lane >= (uint32_t)d && o > st) ? o : st; }
+        if (lane == 63) sh[wave] = st;
+        __syncthreads ();
+        uint32_t before = start_carry;
+        for (uint32_t w = 0; w < wave; w++) before = sh[w] > before ? sh[w] : before;
+        st = st > before ? st : before;                        // start (+1) of my run
+        const uint32_t j = valid ? i - (st - 1) : 0;           // my offset inside it
+        // the literal before my run (context of my run's literal): the byte before the run start
+        const uint32_t s0 = st - 1;
+        const uint32_t lit_ctx = (o1 && valid && s0) ? in[s0 - 1] : 0u;
+        const uint32_t e_lit = (valid && j == 0) ? 1u : 0u, e_three = (valid && j > 0 && j % 3 == 0) ? 1u : 0u, e_fin = is_last ? 1u : 0u;
+        const uint32_t cnt = e_lit + e_three + e_fin;
+        // exclusive sum-scan of the event counts
+        uint32_t inc = cnt;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl ((int)inc, (int)(lane >= (uint32_t)d ? lane - d : lane)); inc += lane >= (uint32_t)d ? o : 0u; }
+        if (lane == 63) sh[16 + wave] = inc;
+        __syncthreads ();
+        uint32_t at = ev_carry + inc - cnt;
+        for (uint32_t w = 0; w < wave; w++) at += sh[16 + w];
+        if (valid) {
+            const uint32_t nth = j / 3;                        // digits of my run before this position's
+            if (e_lit)   { ev_ctx[at] = (uint16_t)lit_ctx; ev_sym[at] = (uint8_t)L.symrank[b]; at++; }
+            if (e_three) { const uint32_t k = nth - 1; ev_ctx[at] = (uint16_t)(256 + (k == 0 ? b : k == 1 ? 256u : 257u)); ev_sym[at] = 3; at++; }
+            if (e_fin)   { const uint32_t k = nth;     ev_ctx[at] = (uint16_t)(256 + (k == 0 ? b : k == 1 ? 256u : 257u)); ev_sym[at] = (uint8_t)(j % 3); }
+        }
+        __syncthreads ();
+        // carries for the next tile
+        if (tid == 1023) { sh[32] = st; uint32_t tot = at + (e_fin ? 1u : 0u); sh[33] = tot; }
+        __syncthreads ();
+        start_carry = sh[32]; ev_carry = sh[33];
+        (void)prev_lit_carry;
+        __syncthreads ();
+    }
+    if (!tid) L.arith_n = ev_carry;
 }
 
 // A leaf with a wide alphabet (a binary plane: up to 256 byte values) usually still has contexts that are each followed
@@ -504,22 +577,43 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
 // otherwise cost a million workgroups per launch that exit at once - and the dispatcher, not the work, set the pace).
 #define GZ_MODEL_GRID_Y 65                 // context 0 + one per present symbol of a leaf with up to 64 symbols
 
-// grid (listed leaves, GZ_MODEL_GRID_Y)
+// grid (listed leaves, GZ_MODEL_GRID_Y [+ GZ_MODEL_GRID_RUN for lists with run-length leaves])
+#define GZ_MODEL_GRID_RUN 66               // run models: one per present symbol, 256 and 257
 __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, const GzDivMagic *magic_tab, uint32_t p0, uint32_t chunk)
 {
     GzdLeaf &L = leaves[list[blockIdx.x]];
-    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle || L.coded_n <= p0) return;
+    if (!L.active || L.engine != GZ_ENG_ARITH || L.arith_n <= p0) return;
     const uint32_t ms = L.max_sym;
-    const bool o1 = L.o1;
+    const bool o1 = L.o1, rle = L.rle;
     uint4 *tr = d_uniform_ptr ((uint4 *)L.triples);
     const uint8_t *coded = d_uniform_ptr (L.coded);
-    const uint32_t n_u = d_uniform (L.coded_n), ms_u = d_uniform (ms), nsym_u = d_uniform (L.nsym);
-    const bool o1_u = d_uniform (o1 ? 1u : 0u) != 0;
+    const uint32_t n_u = d_uniform (L.arith_n), ms_u = d_uniform (ms), nsym_u = d_uniform (L.nsym), nctx = d_uniform (L.nctx);
+    const bool o1_u = d_uniform (o1 ? 1u : 0u) != 0, rle_u = d_uniform (rle ? 1u : 0u) != 0;
+    const bool sorted = o1_u || rle_u;                         // (the run-length variant always goes through the sorted lists)
     const uint32_t p1 = (n_u - p0 > chunk) ? p0 + chunk : n_u;
     const uint32_t *off = d_uniform_ptr (L.ctxoff), *spos = d_uniform_ptr (L.spos);
     const uint8_t *srk = d_uniform_ptr (L.srk);
     const uint32_t *cend = d_uniform_ptr (L.ctxend);
     const uint32_t t0 = p0 / GZ_CTX_TILE;                      // (chunks are whole tiles)
+    uint32_t *mstate = d_uniform_ptr (L.mstate);
+
+    // ---- the run models of the run-length variant: blocks GZ_MODEL_GRID_Y ... ; 4 symbols, all present from the start
+    if (blockIdx.y >= GZ_MODEL_GRID_Y) {
+        if (!rle_u) return;
+        uint8_t *digits = gz_lds;                              // the alphabet { 0, 1, 2, 3 }
+        if (threadIdx.x < 4) digits[threadIdx.x] = (uint8_t)threadIdx.x;
+        __syncthreads ();
+        for (uint32_t k = blockIdx.y - GZ_MODEL_GRID_Y; k < 258; k += GZ_MODEL_GRID_RUN) {
+            if (k < 256 && L.symrank[k] == 0xffff) continue;   // a byte that never occurs has no runs
+            const uint32_t ctx = 256 + k;
+            const uint32_t j0 = d_uniform (off[(size_t)t0 * nctx + ctx]), j1 = d_uniform (cend[ctx]);
+            if (j0 == j1 && p0) continue;
+            d_arith_model_wave<1> (coded, 4u, true, tr, magic_tab, digits, L.symrank, 4u, spos, srk, j0, j1, p0 == 0, p1 < n_u,
+                                   mstate + (size_t)ctx * (GZ_MSTATE_WORDS * 64));
+        }
+        return;
+    }
+    // ---- the literal models
     if (nsym_u <= 64) {
         // block 0: context 0 (the context of position 0, whether byte 0 occurs or not); block y: the y-th present symbol
         uint32_t ctx = 0;
@@ -528,30 +622,30 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
             ctx = d_uniform (L.symlist[blockIdx.y - 1]);
             if (!ctx) return;                                  // (byte 0 is block 0's)
         }
-        uint32_t *st = d_uniform_ptr (L.mstate) + (size_t)ctx * (GZ_MSTATE_WORDS * 64);   // (only touched when the leaf spans chunks)
+        uint32_t *st = mstate + (size_t)ctx * (GZ_MSTATE_WORDS * 64);   // (only touched when the leaf spans chunks)
         uint32_t j0 = p0, j1 = p1;
-        if (o1_u) { j0 = d_uniform (off[(size_t)t0 * 256 + ctx]); j1 = d_uniform (cend[ctx]); }   // my run of the sorted lists
-        d_arith_model_wave<1> (coded, ms_u, o1_u, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        if (sorted) { j0 = d_uniform (off[(size_t)t0 * nctx + ctx]); j1 = d_uniform (cend[ctx]); }   // my run of the sorted lists
+        d_arith_model_wave<1> (coded, ms_u, sorted, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
         return;
     }
     // wide alphabets: the contexts are dealt out over the blocks of the column
     for (uint32_t ctx = blockIdx.y; ctx < (o1_u ? ms_u : 1u); ctx += GZ_MODEL_GRID_Y) {
         if (ctx && L.symrank[ctx] == 0xffff) continue;         // a byte that never occurs is never a context
-        uint32_t *st = d_uniform_ptr (L.mstate) + (size_t)ctx * (GZ_MSTATE_WORDS * 64);
+        uint32_t *st = mstate + (size_t)ctx * (GZ_MSTATE_WORDS * 64);
         uint32_t j0 = p0, j1 = p1;
-        if (o1_u) { j0 = d_uniform (off[(size_t)t0 * 256 + ctx]); j1 = d_uniform (cend[ctx]); }
+        if (sorted) { j0 = d_uniform (off[(size_t)t0 * nctx + ctx]); j1 = d_uniform (cend[ctx]); }
         if (j0 == j1 && p0) continue;                           // (nothing of mine in this chunk: the saved state stands)
         if (p0 == 0 && p1 == n_u && j1 > j0) {                  // a leaf in one piece: try the context's own alphabet
             GzLocalAlpha la;
             uint8_t *lds_flags = gz_lds, *lds_list = gz_lds + 256;
-            const uint32_t nd = d_local_alphabet (la, coded, o1_u, srk, L.symrank, L.symlist, j0, j1, lds_flags, lds_list);
+            const uint32_t nd = d_local_alphabet (la, coded, sorted, srk, L.symrank, L.symlist, j0, j1, lds_flags, lds_list);
             if (nd <= 64) {
-                d_arith_model_wave<1> (coded, ms_u, o1_u, tr, magic_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, true, false, st, &la);
+                d_arith_model_wave<1> (coded, ms_u, sorted, tr, magic_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, true, false, st, &la);
                 continue;
             }
         }
-        if (nsym_u <= 128) d_arith_model_wave<2> (coded, ms_u, o1_u, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
-        else               d_arith_model_wave<4> (coded, ms_u, o1_u, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        if (nsym_u <= 128) d_arith_model_wave<2> (coded, ms_u, sorted, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        else               d_arith_model_wave<4> (coded, ms_u, sorted, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
     }
 }
 
@@ -700,8 +794,8 @@ __global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *l
     const int lane = threadIdx.x & 63;
     if (progress && !d_wait_progress (progress, 1)) { if (!lane) *fail = 1; return; }   // (the leaf table itself is only final once the models have started)
     GzdLeaf &L = leaves[list[li]];
-    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle || !L.coded_n) return;
-    const uint32_t n = d_uniform (L.coded_n), max_sym = d_uniform (L.max_sym);
+    if (!L.active || L.engine != GZ_ENG_ARITH || !L.arith_n) return;
+    const uint32_t n = d_uniform (L.arith_n), max_sym = d_uniform (L.max_sym);
     uint8_t *triples = d_uniform_ptr (L.triples);              // (wave-uniform: keep them in scalar registers)
     uint32_t *rout = d_uniform_ptr ((uint32_t *)L.rvals);
     uint32_t sink = 0, touched = 0, range = 0xffffffffu;
@@ -738,8 +832,8 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_count (GzdLeaf *leaves, const
 {
     const GzdLowBlock B = blocks[blockIdx.x];
     GzdLeaf &L = leaves[B.leaf];
-    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
-    const uint32_t n = L.coded_n, ns = d_low_nslices (n);
+    if (!L.active || L.engine != GZ_ENG_ARITH) return;
+    const uint32_t n = L.arith_n, ns = d_low_nslices (n);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint4 *rec = (const uint4 *)L.triples;
     const uint32_t *rv = (const uint32_t *)L.rvals;
@@ -757,11 +851,11 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_count (GzdLeaf *leaves, const
 __global__ void __launch_bounds__(1024) k_low_scan (GzdLeaf *leaves, const uint32_t *list)
 {
     GzdLeaf &L = leaves[list[blockIdx.x]];
-    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
+    if (!L.active || L.engine != GZ_ENG_ARITH) return;
     const int tid = threadIdx.x;
     uint32_t *sh = (uint32_t *)gz_lds;
     uint32_t *kpos = (uint32_t *)L.kpos;
-    const uint32_t ns = d_low_nslices (L.coded_n);
+    const uint32_t ns = d_low_nslices (L.arith_n);
     const uint32_t per = (ns + 1023) / 1024;
     const uint32_t a = tid * per < ns ? tid * per : ns, b = a + per < ns ? a + per : ns;
     uint32_t sum = 0;
@@ -789,8 +883,8 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_scatter (GzdLeaf *leaves, con
 {
     const GzdLowBlock B = blocks[blockIdx.x];
     GzdLeaf &L = leaves[B.leaf];
-    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
-    const uint32_t n = L.coded_n, ns = d_low_nslices (n);
+    if (!L.active || L.engine != GZ_ENG_ARITH) return;
+    const uint32_t n = L.arith_n, ns = d_low_nslices (n);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint4 *rec = (const uint4 *)L.triples;
     const uint32_t *rv = (const uint32_t *)L.rvals;
@@ -831,8 +925,8 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_resid (GzdLeaf *leaves, const
 {
     const GzdLowBlock B = blocks[blockIdx.x];
     GzdLeaf &L = leaves[B.leaf];
-    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
-    const uint32_t ns = d_low_nslices (L.coded_n), m = L.n_events;
+    if (!L.active || L.engine != GZ_ENG_ARITH) return;
+    const uint32_t ns = d_low_nslices (L.arith_n), m = L.n_events;
     if (threadIdx.x >= GZ_LOW_SLICES_PER_WG) return;
     const uint32_t slice = B.first_slice + threadIdx.x;
     if (slice + 1 >= ns) return;                               // the last slice owns everything it touches
@@ -854,7 +948,7 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_resid (GzdLeaf *leaves, const
 __global__ void __launch_bounds__(GZ_NORM_NT) k_low_norm (GzdLeaf *leaves, const uint32_t *list)
 {
     GzdLeaf &L = leaves[list[blockIdx.x]];
-    if (!L.active || L.engine != GZ_ENG_ARITH || L.rle) return;
+    if (!L.active || L.engine != GZ_ENG_ARITH) return;
     const int tid = threadIdx.x;
     const uint32_t m = L.n_events;
     const uint32_t *dig = (const uint32_t *)L.events;

@@ -10,7 +10,7 @@
 //   k_rans_table   normalise, compute_shift, serialise + (optionally) order-0 code the table, build the encoder
 //                  records (rANS_static4x16pr.c:113-203,254-322,376-433,626-687,729-796)
 //   k_rans_encode  the 4 interleaved rANS states of a leaf on 4 lanes of one wave (rANS_word.h:280-320)
-//   k_arith_encode adaptive range coder, models in LDS (arith_dynamic.c:92-197,387-561, c_range_coder.h,
+//   (arithmetic coder: gz_kernels_arith.h) (arith_dynamic.c:92-197,387-561, c_range_coder.h,
 //                  c_simple_model.h)
 //   k_select       CAT fallback, best method per plane, stream size
 //   k_vb_layout    section offsets inside each VBlock's z_data (zip.c:560-585 order, given by the caller)
@@ -166,6 +166,8 @@ __global__ void __launch_bounds__(256) k_leaf_prep (GzdStream *streams, GzdLeaf 
         L.prefix_len = (uint8_t)p;
         L.active = 1; L.flag = flag; L.o1 = o1; L.rle = rle; L.packed_on = packed_on; L.cat = 0;
         L.src = src; L.n = n; L.coded = coded; L.coded_n = coded_n;
+        L.arith_n = coded_n;                                  // (the run-length variant: k_rle_events puts its event count here)
+        L.nctx = rle ? 768 : 256;
         L.tab_len = 0; L.pay_len = 0; L.overflow = 0; L.unit_len = 0; L.shift_bits = 0;
     }
     __syncthreads ();   // packed bytes written by all threads are read below
@@ -625,71 +627,8 @@ __global__ void __launch_bounds__(64) k_rans_encode (GzdLeaf *leaves)
     if (!lane) { if (plen == 0xffffffffu) { L.overflow = 1; L.pay_len = 0; } else L.pay_len = plen; }
 }
 
-// ======================================================================================================
-// k_arith_encode : adaptive range coder. One wave per leaf, lane 0 walks the stream; the models live in LDS.
-// ======================================================================================================
-
-// A model is [tot][slot 0 .. slot m-1], slot = freq | sym << 16 (c_simple_model.h:63-83). Only the first max_sym
-// slots can ever be non-zero, so that is all we keep; the sentinel that the reference keeps in front of slot 0 (it
-// can never be overtaken: no frequency exceeds 65519 after a bump) is the `at > 0` test.
-struct GzRc { uint32_t low, range, carry, cache, ff; uint8_t *out; uint32_t len, cap; int overflow; };
-
-__device__ static inline void d_rc_shift (GzRc &rc)    // c_range_coder.h:70-88
-{
-    if (rc.low < 0xff000000u || rc.carry) {
-        if (rc.len + 1 + rc.ff > rc.cap) { rc.overflow = 1; rc.ff = 0; }
-        else {
-            rc.out[rc.len++] = (uint8_t)(rc.cache + rc.carry);
-            for (; rc.ff; rc.ff--) rc.out[rc.len++] = (uint8_t)(rc.carry - 1);
-        }
-        rc.cache = rc.low >> 24;
-        rc.carry = 0;
-    }
-    else rc.ff++;
-    rc.low <<= 8;
-}
-
-__device__ static inline void d_rc_encode (GzRc &rc, uint32_t cum, uint32_t freq, uint32_t tot)   // :97-109
-{
-    uint32_t before = rc.low;
-    rc.range /= tot;
-    rc.low   += cum * rc.range;
-    rc.range *= freq;
-    rc.carry += rc.low < before;
-    while (rc.range < (1u << 24)) { rc.range <<= 8; d_rc_shift (rc); }
-}
-
-__device__ static inline void d_model_init (uint32_t *m, uint32_t max_sym)
-{
-    m[0] = max_sym;
-    for (uint32_t i = 0; i < max_sym; i++) m[1 + i] = 1u | (i << 16);
-}
-
-__device__ static inline void d_model_encode (uint32_t *m, uint32_t max_sym, GzRc &rc, uint32_t sym)   // c_simple_model.h:123-146
-{
-    uint32_t *slot = m + 1, cum = 0, at = 0, e;
-    while (((e = slot[at]) >> 16) != sym) { cum += e & 0xffff; at++; }
-    d_rc_encode (rc, cum, e & 0xffff, m[0]);
-    e += 16;
-    uint32_t tot = m[0] + 16;
-    slot[at] = e;
-    if (tot > 65519) {
-        tot = 0;
-        for (uint32_t i = 0; i < max_sym; i++) {
-            uint32_t v = slot[i], f = v & 0xffff;
-            f -= f >> 1;
-            slot[i] = (v & 0xffff0000u) | f;
-            tot += f;
-        }
-        e = slot[at];
-    }
-    m[0] = tot;
-    if (at > 0) {
-        uint32_t left = slot[at - 1];
-        if ((e & 0xffff) > (left & 0xffff)) { slot[at - 1] = e; slot[at] = left; }
-    }
-}
-
+// (the arithmetic coder's encoder is gz_kernels_arith.h; what is left here is shared with the decoder, which keeps its
+//  models in LDS)
 #define GZ_ARITH_RUN_MODELS 258
 #define GZ_ARITH_RUN_STRIDE 5      // tot + 4 slots (MAX_RUN == 4, arith_dynamic.c:384)
 
@@ -698,70 +637,6 @@ __device__ static inline uint32_t gz_arith_model_words (uint32_t max_sym, bool o
     uint32_t w = (o1 ? max_sym : 1) * (max_sym + 1);
     if (rle) w += GZ_ARITH_RUN_MODELS * GZ_ARITH_RUN_STRIDE;
     return w;
-}
-
-// lds_words: dynamic LDS of this launch in 32-bit words. A leaf runs in the launch of the smallest class it fits;
-// models that fit no LDS class run from global memory (class 3).
-__global__ void __launch_bounds__(64) k_arith_encode (GzdLeaf *leaves, uint32_t lds_words_lo, uint32_t lds_words_hi, int use_global)
-{
-    GzdLeaf &L = leaves[blockIdx.x];
-    if (!L.active || L.engine != GZ_ENG_ARITH || !L.rle) return;     // plain order-0/1 leaves: gz_kernels_arith.h
-    const uint32_t n = L.coded_n, max_sym = L.max_sym;
-    const bool o1 = L.o1, rle = L.rle;
-    const uint32_t words = gz_arith_model_words (n ? max_sym : 1, o1, rle);
-    if (words <= lds_words_lo || words > lds_words_hi) return;     // another size class handles this leaf
-    uint32_t *models = use_global ? L.models : (uint32_t *)gz_lds;
-    const int lane = threadIdx.x;
-
-    // initialise the models in parallel: literal models (contexts 0..max_sym-1), then the run models
-    const uint32_t ms = n ? max_sym : 1;
-    const uint32_t nlit = o1 ? ms : 1, lit_stride = ms + 1;
-    for (uint32_t i = lane; i < nlit * lit_stride; i += 64) {
-        uint32_t k = i % lit_stride;
-        models[i] = k ? (1u | ((k - 1) << 16)) : ms;
-    }
-    uint32_t *runm = models + nlit * lit_stride;
-    if (rle)
-        for (uint32_t i = lane; i < GZ_ARITH_RUN_MODELS * GZ_ARITH_RUN_STRIDE; i += 64) {
-            uint32_t k = i % GZ_ARITH_RUN_STRIDE;
-            runm[i] = k ? (1u | ((k - 1) << 16)) : 4;
-        }
-    __syncthreads ();
-    if (lane) return;
-
-    const uint8_t *in = L.coded;
-    GzRc rc;
-    rc.low = 0; rc.range = 0xffffffffu; rc.carry = rc.cache = rc.ff = 0;
-    rc.out = L.pay + 1; rc.len = 0; rc.cap = L.pay_cap - 1; rc.overflow = 0;
-    L.pay[0] = (uint8_t)ms;                                    // max_sym + 1 (256 wraps to 0), arith_dynamic.c:103-108
-
-    uint32_t last = 0;
-    if (!rle)
-        for (uint32_t i = 0; i < n && !rc.overflow; i++) {
-            uint32_t s = in[i];
-            d_model_encode (models + (o1 ? last * lit_stride : 0), ms, rc, s);
-            last = s;
-        }
-    else
-        for (uint32_t i = 0; i < n && !rc.overflow; ) {        // arith_dynamic.c:416-438
-            uint32_t s = in[i++];
-            d_model_encode (models + (o1 ? last * lit_stride : 0), ms, rc, s);
-            last = s;
-            uint32_t run = 0;
-            while (i < n && in[i] == s) run++, i++;
-            uint32_t ctx = s;
-            do {
-                uint32_t d = run < 4 ? run : 3;
-                d_model_encode (runm + ctx * GZ_ARITH_RUN_STRIDE, 4, rc, d);
-                run -= d;
-                ctx = (ctx == s) ? 256 : ctx + (ctx < 257);
-                if (d == 3 && !run) d_model_encode (runm + ctx * GZ_ARITH_RUN_STRIDE, 4, rc, 0);
-            } while (run);
-        }
-    for (int k = 0; k < 5; k++) d_rc_shift (rc);               // RC_FinishEncode
-    if (rc.overflow) { L.overflow = 1; L.pay_len = 0; }
-    else L.pay_len = rc.len + 1;
-    L.tab_len = 0;
 }
 
 // ======================================================================================================
