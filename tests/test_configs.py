@@ -34,7 +34,7 @@ def test_vcf_vblock_streams(gpu_engine, oracle):
     assert lt == LT_UINT8_TR and tr == np.ascontiguousarray(dp.reshape(rows, cols).T).tobytes()
     assert (lt, tr) == oracle.local_generate(LT_UINT8, raw, cols)
     assert E.local_to_native(lt, tr, cols) == (LT_UINT8, raw)
-    _same_as_oracle(E, oracle, [(6, tr), (8, tr), (16, tr)])                                       # RANB, RANb, ARTB on 30 MB each
+    _same_as_oracle(E, oracle, [(6, tr), (8, tr), (16, tr), (17, tr)])                              # RANB, RANb, ARTB, ARTW (9 candidate leaves, one run-length) on 30 MB each
 
     n = 3 * 10 ** 7
     h = synth.u32(78, n)
