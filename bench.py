@@ -305,7 +305,7 @@ def main():
                       "codecs": {k: CODEC_NAMES[v] for k, v in codecs.items()}, "compressed_mb": round(z_bytes / 1e6, 2),
                       "parallelism": "vblocks sharded over %d GPU(s), no data-path collective; RCCL gather of z_data" % world},
            "roofline": roofline}
-    if not a.no_cpu:
+    if not a.no_cpu and world == 1:                # (the CPU pool is timed on rank 0 of the 1-GPU run only)
         cb, exact = cpu_baseline(wl, z_list, min(os.cpu_count() or 1, 256))
         out["cpu_baseline"] = cb
         out["bit_exact"] = exact
