@@ -288,7 +288,7 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
         // what the coder sees: the bytes, or (run-length variant) up to 2 coding events per byte
         const uint32_t nb = rle ? 2 * n_bound : n_bound;
         const uint32_t nctx = rle ? 768 : 256;
-        if (!(L.triples = (uint8_t *)arena_alloc (h, ((size_t)nb + 64) * 16 + 2 * GZ_CHAIN_TOUCH_AHEAD + 8192))) return false;
+        if (!(L.triples = (uint8_t *)arena_alloc (h, ((size_t)nb + 64) * 16 + 2 * GZ_CHAIN_TOUCH_AHEAD + 16384))) return false;
         if (!(L.events  = (uint8_t *)arena_alloc (h, ((size_t)L.pay_cap + 128) * 4))) return false;
         if (!(L.rvals   = (uint8_t *)arena_alloc (h, ((size_t)nb + 64) * 4))) return false;
         const uint32_t ns = nb ? (nb + GZ_LOW_SLICE - 1) / GZ_LOW_SLICE : 1;
@@ -515,7 +515,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
             KLAUNCH (h, k_low_count, dim3 (A.nlb), dim3 (GZ_LOW_WG), 0, d_leaves, A.d_lb);
             KLAUNCH (h, k_low_scan, dim3 (A.np), dim3 (1024), 8192, d_leaves, A.d_plain);
             KLAUNCH (h, k_low_scatter, dim3 (A.nlb), dim3 (GZ_LOW_WG), 4 * 144 * 4, d_leaves, A.d_lb);
-            KLAUNCH (h, k_low_resid, dim3 (A.nlb), dim3 (GZ_LOW_WG), 0, d_leaves, A.d_lb);
+            KLAUNCH (h, k_low_resid, dim3 (A.nlb), dim3 (GZ_LOW_SLICES_PER_WG), 0, d_leaves, A.d_lb);   // (one thread per slice)
             KLAUNCH (h, k_low_norm, dim3 (A.np), dim3 (GZ_NORM_NT), 8192, d_leaves, A.d_plain);
         }
         if (fork) { HIPCHK (h, hipEventRecord (h->ev_join, side)); HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_join, 0)); }
