@@ -46,6 +46,8 @@ struct GzHandle {
     hipEvent_t ev_model_fork;
     hipStream_t stream5;      // model + chain of the leaves that fit one chunk
     hipEvent_t ev_small;
+    hipStream_t stream6;      // the `low` kernels of the long leaves, following the chain chunk by chunk
+    hipEvent_t ev_low;
     hipEvent_t ev_chain_go, ev_chain;   // the persistent chain may start / has finished
     int n_cu = 0;             // compute units of the device
     uint32_t *d_fail = NULL;  // set by a kernel that gave up (the persistent chain when the models never report)
@@ -131,6 +133,8 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
         hipStreamCreateWithPriority (&h->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority (&h->stream4, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipStreamCreateWithPriority (&h->stream5, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipStreamCreateWithPriority (&h->stream6, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipEventCreateWithFlags (&h->ev_low, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags (&h->ev_small, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags (&h->ev_model_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags (&h->ev_chain, hipEventDisableTiming) != hipSuccess ||
@@ -195,6 +199,8 @@ extern "C" void gz_destroy (GzHandle *h)
     hipStreamDestroy (h->stream3);
     hipStreamDestroy (h->stream4);
     hipStreamDestroy (h->stream5);
+    hipStreamDestroy (h->stream6);
+    hipEventDestroy (h->ev_low);
     hipEventDestroy (h->ev_small);
     hipEventDestroy (h->ev_model_fork);
     hipEventDestroy (h->ev_chain);
@@ -388,10 +394,10 @@ static const uint32_t ARITH_CLASS_WORDS[4] = { 0, 4096, 16384, 40000 };   // 16 
 
 // The arithmetic coder's pipeline of one batch (see gz_kernels_arith.h): which leaves, in how many position chunks
 struct ArithPipe {
-    uint32_t np = 0, no1 = 0, nlb = 0, nbig = 0, nsmall = 0, chunk = 0, n_chunks = 1;
+    uint32_t np = 0, no1 = 0, nlb = 0, nlb_small = 0, nbig = 0, nsmall = 0, chunk = 0, n_chunks = 1;
     const uint32_t *d_plain = NULL, *d_o1 = NULL, *d_big = NULL, *d_small = NULL, *d_rle = NULL;
-    const GzdLowBlock *d_lb = NULL;
-    uint32_t *d_progress = NULL;
+    const GzdLowBlock *d_lb = NULL, *d_lb_small = NULL;
+    uint32_t *d_progress = NULL;      // [0] model chunks announced  [16 + k] leaves whose chain is through chunk k
     bool pipelined = false, reserve_cu = false;
 };
 
@@ -423,8 +429,18 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
     if (rc == GZ_OK && A.nsmall) { rc = upload (h, small.data (), small.size () * 4, &d); A.d_small = (const uint32_t *)d; }
     if (rc != GZ_OK) return rc;
     if (A.pipelined) {
-        if (!(A.d_progress = (uint32_t *)arena_alloc (h, 64))) return GZ_ERR_HIP;
-        HIPCHK (h, hipMemsetAsync (A.d_progress, 0, 64, h->stream));
+        if (A.n_chunks > 48) return GZ_ERR;                       // (cannot happen: at most 8 chunks)
+        if (!(A.d_progress = (uint32_t *)arena_alloc (h, 256))) return GZ_ERR_HIP;
+        HIPCHK (h, hipMemsetAsync (A.d_progress, 0, 256, h->stream));
+        if (A.nsmall) {                                           // the slices of the short leaves only
+            std::vector<uint8_t> is_small (P.leaves.size (), 0);
+            for (uint32_t l : small) is_small[l] = 1;
+            std::vector<GzdLowBlock> lbs;
+            for (const GzdLowBlock &b : P.low_blocks) if (is_small[b.leaf]) lbs.push_back (b);
+            A.nlb_small = (uint32_t)lbs.size ();
+            if (A.nlb_small) { rc = upload (h, lbs.data (), lbs.size () * sizeof (GzdLowBlock), &d); A.d_lb_small = (const GzdLowBlock *)d; }
+            if (rc != GZ_OK) return rc;
+        }
     }
     return GZ_OK;
 }
@@ -435,7 +451,7 @@ static int arith_launch_chain (GzHandle *h, const ArithPipe &A, GzdLeaf *d_leave
     HIPCHK (h, hipEventRecord (h->ev_chain_go, h->stream));                     // (behind the uploads and the memset)
     HIPCHK (h, hipStreamWaitEvent (h->stream3, h->ev_chain_go, 0));
     KLAUNCH_ON (h, h->stream3, k_arith_chain, dim3 ((A.nbig + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), A.reserve_cu ? GZ_CHAIN_LDS : 64,
-                d_leaves, A.d_big, A.nbig, (const uint32_t *)A.d_progress, A.chunk, h->d_fail);
+                d_leaves, A.d_big, A.nbig, (const uint32_t *)A.d_progress, A.chunk, h->d_fail, A.d_progress + 16, A.n_chunks);
     HIPCHK (h, hipEventRecord (h->ev_chain, h->stream3));
     return GZ_OK;
 }
@@ -487,7 +503,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 if ((rc = sort_chunk (h->stream, A.d_plain, A.np, 0u, 0xffffffffu, P.max_arith_n)) != GZ_OK) return rc;
                 KLAUNCH (h, k_arith_model, dim3 (A.np, grid_y), dim3 (64), 512, d_leaves, A.d_plain, magic, 0u, 0xffffffffu);
                 KLAUNCH (h, k_arith_chain, dim3 ((A.np + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), 64,
-                         d_leaves, A.d_plain, A.np, (const uint32_t *)NULL, 0u, h->d_fail);
+                         d_leaves, A.d_plain, A.np, (const uint32_t *)NULL, 0u, h->d_fail, (uint32_t *)NULL, 0u);
             }
             else {
                 HIPCHK (h, hipEventRecord (h->ev_model_fork, h->stream));        // (after k_leaf_prep)
@@ -501,20 +517,41 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
 #ifdef GZ_SEQUENTIAL_STREAMS
                 if ((rc = arith_launch_chain (h, A, d_leaves)) != GZ_OK) return rc;
 #endif
+                // the `low` kernels of the long leaves follow the chain: a one-thread gate holds their stream until every
+                // leaf is through chunk k; count / scan / scatter of that chunk then run beside the chain's next chunk
+                HIPCHK (h, hipStreamWaitEvent (h->stream6, h->ev_model_fork, 0));
+                for (uint32_t k = 0; k < A.n_chunks; k++) {
+                    const uint32_t p0 = k * A.chunk, span = P.max_arith_n - p0 < A.chunk ? P.max_arith_n - p0 : A.chunk;
+                    const uint32_t wgs = (span + GZ_LOW_SLICE * GZ_LOW_SLICES_PER_WG - 1) / (GZ_LOW_SLICE * GZ_LOW_SLICES_PER_WG);
+                    hipLaunchKernelGGL (k_low_gate, dim3 (1), dim3 (1), 0, h->stream6, (const uint32_t *)(A.d_progress + 16 + k), A.nbig, h->d_fail);
+                    KLAUNCH_ON (h, h->stream6, k_low_count, dim3 (A.nbig, wgs), dim3 (GZ_LOW_WG), GZ_KEEP_OFF_LDS, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0);
+                    KLAUNCH_ON (h, h->stream6, k_low_scan, dim3 (A.nbig), dim3 (1024), 8192, d_leaves, A.d_big, p0, A.chunk);
+                    KLAUNCH_ON (h, h->stream6, k_low_scatter, dim3 (A.nbig, wgs), dim3 (GZ_LOW_WG), GZ_KEEP_OFF_LDS, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0);
+                }
+                HIPCHK (h, hipEventRecord (h->ev_low, h->stream6));
                 if (A.nsmall) {
                     HIPCHK (h, hipStreamWaitEvent (h->stream5, h->ev_model_fork, 0));
                     if ((rc = sort_chunk (h->stream5, A.d_small, A.nsmall, 0u, 0xffffffffu, A.chunk)) != GZ_OK) return rc;
                     KLAUNCH_ON (h, h->stream5, k_arith_model, dim3 (A.nsmall, grid_y), dim3 (64), GZ_KEEP_OFF_LDS, d_leaves, A.d_small, magic, 0u, 0xffffffffu);
                     KLAUNCH_ON (h, h->stream5, k_arith_chain, dim3 ((A.nsmall + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), GZ_KEEP_OFF_LDS,
-                                d_leaves, A.d_small, A.nsmall, (const uint32_t *)NULL, 0u, h->d_fail);
+                                d_leaves, A.d_small, A.nsmall, (const uint32_t *)NULL, 0u, h->d_fail, (uint32_t *)NULL, 0u);
+                    if (A.nlb_small) {
+                        KLAUNCH_ON (h, h->stream5, k_low_count, dim3 (A.nlb_small), dim3 (GZ_LOW_WG), GZ_KEEP_OFF_LDS, d_leaves, A.d_lb_small, (const uint32_t *)NULL, 0u);
+                        KLAUNCH_ON (h, h->stream5, k_low_scan, dim3 (A.nsmall), dim3 (1024), 8192, d_leaves, A.d_small, 0u, 0xffffffffu);
+                        KLAUNCH_ON (h, h->stream5, k_low_scatter, dim3 (A.nlb_small), dim3 (GZ_LOW_WG), GZ_KEEP_OFF_LDS, d_leaves, A.d_lb_small, (const uint32_t *)NULL, 0u);
+                    }
                     HIPCHK (h, hipEventRecord (h->ev_small, h->stream5));
                     HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_small, 0));
                 }
                 HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_chain, 0));
+                HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_low, 0));
             }
-            KLAUNCH (h, k_low_count, dim3 (A.nlb), dim3 (GZ_LOW_WG), 0, d_leaves, A.d_lb);
-            KLAUNCH (h, k_low_scan, dim3 (A.np), dim3 (1024), 8192, d_leaves, A.d_plain);
-            KLAUNCH (h, k_low_scatter, dim3 (A.nlb), dim3 (GZ_LOW_WG), 4 * 144 * 4, d_leaves, A.d_lb);
+            if (!A.pipelined) {
+                KLAUNCH (h, k_low_count, dim3 (A.nlb), dim3 (GZ_LOW_WG), 0, d_leaves, A.d_lb, (const uint32_t *)NULL, 0u);
+                KLAUNCH (h, k_low_scan, dim3 (A.np), dim3 (1024), 8192, d_leaves, A.d_plain, 0u, 0xffffffffu);
+                KLAUNCH (h, k_low_scatter, dim3 (A.nlb), dim3 (GZ_LOW_WG), 4 * 144 * 4, d_leaves, A.d_lb, (const uint32_t *)NULL, 0u);
+            }
+            // spills into the following slices' digits (they can reach any distance: only once every digit is stored), then bytes
             KLAUNCH (h, k_low_resid, dim3 (A.nlb), dim3 (GZ_LOW_SLICES_PER_WG), 0, d_leaves, A.d_lb);   // (one thread per slice)
             KLAUNCH (h, k_low_norm, dim3 (A.np), dim3 (GZ_NORM_NT), 8192, d_leaves, A.d_plain);
         }

@@ -788,7 +788,8 @@ __device__ static __forceinline__ void d_chain_chunk (uint32_t &range, uint32_t 
 // (Tried and measured without effect on the slow-down the chain suffers while other kernels run - ~15 %, with the clock
 //  unchanged -: wave priority, compute-unit masks, a helper wave pulling the records into the scalar cache ahead of
 //  the chain, dropping the stores of r.)
-__global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress, uint32_t chunk, uint32_t *fail)
+__global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress, uint32_t chunk,
+                                                                      uint32_t *fail, uint32_t *done, uint32_t n_chunks)
 {
     const uint32_t li = blockIdx.x * GZ_CHAIN_WAVES + (threadIdx.x >> 6);
     if (li >= n_list) return;
@@ -796,7 +797,10 @@ __global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *l
     const int lane = threadIdx.x & 63;
     if (progress && !d_wait_progress (progress, 1)) { if (!lane) *fail = 1; return; }   // (the leaf table itself is only final once the models have started)
     GzdLeaf &L = leaves[list[li]];
-    if (!L.active || L.engine != GZ_ENG_ARITH || !L.arith_n) return;
+    if (!L.active || L.engine != GZ_ENG_ARITH || !L.arith_n) {
+        if (done && !lane) for (uint32_t k = 0; k < n_chunks; k++) atomicAdd (&done[k], 1u);   // (the low kernels count leaves per chunk)
+        return;
+    }
     const uint32_t n = d_uniform (L.arith_n), max_sym = d_uniform (L.max_sym);
     uint8_t *triples = d_uniform_ptr (L.triples);              // (wave-uniform: keep them in scalar registers)
     uint32_t *rout = d_uniform_ptr ((uint32_t *)L.rvals);
@@ -806,9 +810,28 @@ __global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *l
         for (uint32_t k = 0, p0 = 0; p0 < n; k++, p0 += chunk) {
             if (k && !d_wait_progress (progress, k + 1)) { if (!lane) { L.overflow = 2; *fail = 1; } break; }
             d_chain_chunk (range, sink, touched, lane, p0, (n - p0 > chunk) ? p0 + chunk : n, n, triples, rout, max_sym);
+            if (done) {                                        // this leaf's r values of chunk k are final: tell the low kernels
+                gz_scalar_store_flush ();
+                __threadfence ();
+                if (!lane) {
+                    atomicAdd (&done[k], 1u);
+                    if (n - p0 <= chunk) for (uint32_t k2 = k + 1; k2 < n_chunks; k2++) atomicAdd (&done[k2], 1u);   // (a short leaf has no later chunks)
+                }
+            }
         }
     gz_scalar_store_flush ();
     if (!lane) L.touch_sink = sink + touched;
+}
+
+// One thread: holds its stream until all `want` leaves of the persistent chain have finished a position chunk (the low
+// kernels of that chunk are queued behind it). Bounded like d_wait_progress.
+__global__ void k_low_gate (const uint32_t *done, uint32_t want, uint32_t *fail)
+{
+    for (uint32_t spins = 0; __atomic_load_n (done, __ATOMIC_RELAXED) < want; spins++) {
+        if (spins > 8000000u) { *fail = 1; return; }
+        __builtin_amdgcn_s_sleep (32);
+    }
+    __atomic_thread_fence (__ATOMIC_ACQUIRE);
 }
 
 // ---- low: a big-number sum, one thread per symbol -----------------------------------------------------------------
@@ -830,9 +853,19 @@ struct GzdLowBlock { uint32_t leaf, first_slice; };
 
 __device__ static inline uint32_t d_low_nslices (uint32_t n) { return n ? (n + GZ_LOW_SLICE - 1) / GZ_LOW_SLICE : 1; }
 
-__global__ void __launch_bounds__(GZ_LOW_WG) k_low_count (GzdLeaf *leaves, const GzdLowBlock *blocks)
+// a workgroup's 64 slices: from the table (whole leaves), or - following the chain chunk by chunk - grid (listed leaves,
+// chunk / 4096) over the position chunk that starts at p0
+__device__ static inline GzdLowBlock d_low_block (const GzdLowBlock *blocks, const uint32_t *list, uint32_t p0)
 {
-    const GzdLowBlock B = blocks[blockIdx.x];
+    if (blocks) return blocks[blockIdx.x];
+    GzdLowBlock b;
+    b.leaf = list[blockIdx.x]; b.first_slice = p0 / GZ_LOW_SLICE + blockIdx.y * GZ_LOW_SLICES_PER_WG;
+    return b;
+}
+
+__global__ void __launch_bounds__(GZ_LOW_WG) k_low_count (GzdLeaf *leaves, const GzdLowBlock *blocks, const uint32_t *list, uint32_t p0)
+{
+    const GzdLowBlock B = d_low_block (blocks, list, p0);
     GzdLeaf &L = leaves[B.leaf];
     if (!L.active || L.engine != GZ_ENG_ARITH) return;
     const uint32_t n = L.arith_n, ns = d_low_nslices (n);
@@ -849,23 +882,27 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_count (GzdLeaf *leaves, const
     }
 }
 
-// one 1024-thread workgroup per leaf
-__global__ void __launch_bounds__(1024) k_low_scan (GzdLeaf *leaves, const uint32_t *list)
+// one 1024-thread workgroup per leaf; the slices of positions [p0, p0 + chunk)
+__global__ void __launch_bounds__(1024) k_low_scan (GzdLeaf *leaves, const uint32_t *list, uint32_t p0, uint32_t chunk)
 {
     GzdLeaf &L = leaves[list[blockIdx.x]];
     if (!L.active || L.engine != GZ_ENG_ARITH) return;
+    const uint32_t n = L.arith_n;
+    if (p0 && n <= p0) return;
     const int tid = threadIdx.x;
     uint32_t *sh = (uint32_t *)gz_lds;
     uint32_t *kpos = (uint32_t *)L.kpos;
-    const uint32_t ns = d_low_nslices (L.arith_n);
-    const uint32_t per = (ns + 1023) / 1024;
-    const uint32_t a = tid * per < ns ? tid * per : ns, b = a + per < ns ? a + per : ns;
+    const uint32_t ns = d_low_nslices (n);
+    const uint32_t s0 = p0 / GZ_LOW_SLICE, s1 = (n - p0 > chunk) ? (p0 + chunk) / GZ_LOW_SLICE : ns;
+    const uint32_t base = p0 ? L.low_base : 0u;
+    const uint32_t per = (s1 - s0 + 1023) / 1024;
+    const uint32_t a = s0 + tid * per < s1 ? s0 + tid * per : s1, b = a + per < s1 ? a + per : s1;
     uint32_t sum = 0;
     for (uint32_t i = a; i < b; i++) sum += kpos[i];
     sh[tid] = sum;
     __syncthreads ();
     if (!tid) {
-        uint32_t run = 0;
+        uint32_t run = base;
         for (int t = 0; t < 1024; t++) { uint32_t c = sh[t]; sh[t] = run; run += c; }
         sh[1024] = run;
     }
@@ -873,17 +910,19 @@ __global__ void __launch_bounds__(1024) k_low_scan (GzdLeaf *leaves, const uint3
     uint32_t run = sh[tid];
     for (uint32_t i = a; i < b; i++) { uint32_t c = kpos[i]; kpos[i] = run; run += c; }
     if (!tid) {
-        const uint32_t m = sh[1024] + 5;                      // + RC_FinishEncode's 5 shifts
-        kpos[ns] = sh[1024];
-        L.n_events = m;
-        ((uint32_t *)L.events)[0] = 0;                        // digit 0: the coder's initial cache byte
+        L.low_base = sh[1024];
+        if (!p0) ((uint32_t *)L.events)[0] = 0;               // digit 0: the coder's initial cache byte
+        if (s1 == ns) {
+            kpos[ns] = sh[1024];
+            L.n_events = sh[1024] + 5;                        // + RC_FinishEncode's 5 shifts
+        }
     }
 }
 
 // 4 waves, each with a 140-word LDS accumulator
-__global__ void __launch_bounds__(GZ_LOW_WG) k_low_scatter (GzdLeaf *leaves, const GzdLowBlock *blocks)
+__global__ void __launch_bounds__(GZ_LOW_WG) k_low_scatter (GzdLeaf *leaves, const GzdLowBlock *blocks, const uint32_t *list, uint32_t p0)
 {
-    const GzdLowBlock B = blocks[blockIdx.x];
+    const GzdLowBlock B = d_low_block (blocks, list, p0);
     GzdLeaf &L = leaves[B.leaf];
     if (!L.active || L.engine != GZ_ENG_ARITH) return;
     const uint32_t n = L.arith_n, ns = d_low_nslices (n);
