@@ -1003,10 +1003,21 @@ __global__ void __launch_bounds__(GZ_NORM_NT) k_low_norm (GzdLeaf *leaves, const
         const uint32_t b0 = t * tile + tid * GZ_NORM_PER;
         uint32_t w[4] = { 0, 0, 0, 0 };             // w[0] most significant: bytes b0..b0+3
         uint32_t carry = 0;
+        uint32_t d16[GZ_NORM_PER];                   // (four 16-byte loads when the thread's digits all exist)
+        if (b0 + GZ_NORM_PER <= m) {
+            #pragma unroll
+            for (int q = 0; q < GZ_NORM_PER / 4; q++) {
+                const uint4 v4 = ((const uint4 *)(dig + b0))[q];
+                d16[4 * q] = v4.x; d16[4 * q + 1] = v4.y; d16[4 * q + 2] = v4.z; d16[4 * q + 3] = v4.w;
+            }
+        }
+        else {
+            #pragma unroll
+            for (int j = 0; j < GZ_NORM_PER; j++) d16[j] = b0 + j < m ? dig[b0 + j] : 0u;
+        }
         #pragma unroll
         for (int j = GZ_NORM_PER - 1; j >= 0; j--) {
-            const uint32_t idx = b0 + j;
-            const uint32_t v = (idx < m ? dig[idx] : 0u) + carry;
+            const uint32_t v = d16[j] + carry;
             w[j >> 2] |= (v & 0xff) << (8 * (3 - (j & 3)));
             carry = v >> 8;
         }
@@ -1032,10 +1043,16 @@ __global__ void __launch_bounds__(GZ_NORM_NT) k_low_norm (GzdLeaf *leaves, const
             if (!sh[GZ_NORM_NT + 8]) break;
         }
         if (!tid) sh[GZ_NORM_NT + 9] = tile_out;
-        #pragma unroll
-        for (int j = 0; j < GZ_NORM_PER; j++) {
-            const uint32_t idx = b0 + j;
-            if (idx < m) out[idx] = (uint8_t)(w[j >> 2] >> (8 * (3 - (j & 3))));
+        if (b0 + GZ_NORM_PER <= m) {                 // one 16-byte store (w[] is big-endian: byte b0 is the top of w[0])
+            gz_u32x4_unaligned o = { __builtin_bswap32 (w[0]), __builtin_bswap32 (w[1]), __builtin_bswap32 (w[2]), __builtin_bswap32 (w[3]) };
+            *(gz_u32x4_unaligned *)(out + b0) = o;
+        }
+        else {
+            #pragma unroll
+            for (int j = 0; j < GZ_NORM_PER; j++) {
+                const uint32_t idx = b0 + j;
+                if (idx < m) out[idx] = (uint8_t)(w[j >> 2] >> (8 * (3 - (j & 3))));
+            }
         }
         __syncthreads ();
     }
