@@ -552,7 +552,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 KLAUNCH (h, k_low_scatter, dim3 (A.nlb), dim3 (GZ_LOW_WG), 4 * 144 * 4, d_leaves, A.d_lb, (const uint32_t *)NULL, 0u);
             }
             // spills into the following slices' digits (they can reach any distance: only once every digit is stored), then bytes
-            KLAUNCH (h, k_low_resid, dim3 (A.nlb), dim3 (GZ_LOW_SLICES_PER_WG), 0, d_leaves, A.d_lb);   // (one thread per slice)
+            KLAUNCH (h, k_low_resid, dim3 ((A.nlb + 3) / 4), dim3 (GZ_LOW_WG), 0, d_leaves, A.d_lb, A.nlb);
             KLAUNCH (h, k_low_norm, dim3 (A.np), dim3 (GZ_NORM_NT), 8192, d_leaves, A.d_plain);
         }
         if (fork) { HIPCHK (h, hipEventRecord (h->ev_join, side)); HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_join, 0)); }

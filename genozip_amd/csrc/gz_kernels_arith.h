@@ -962,14 +962,16 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_scatter (GzdLeaf *leaves, con
     }
 }
 
-__global__ void __launch_bounds__(GZ_LOW_WG) k_low_resid (GzdLeaf *leaves, const GzdLowBlock *blocks)
+// one thread per slice: each wave of a workgroup takes one entry of the table (grid: entries / 4)
+__global__ void __launch_bounds__(GZ_LOW_WG) k_low_resid (GzdLeaf *leaves, const GzdLowBlock *blocks, uint32_t n_blocks)
 {
-    const GzdLowBlock B = blocks[blockIdx.x];
+    const uint32_t bi = blockIdx.x * (GZ_LOW_WG / 64) + (threadIdx.x >> 6);
+    if (bi >= n_blocks) return;
+    const GzdLowBlock B = blocks[bi];
     GzdLeaf &L = leaves[B.leaf];
     if (!L.active || L.engine != GZ_ENG_ARITH) return;
     const uint32_t ns = d_low_nslices (L.arith_n), m = L.n_events;
-    if (threadIdx.x >= GZ_LOW_SLICES_PER_WG) return;
-    const uint32_t slice = B.first_slice + threadIdx.x;
+    const uint32_t slice = B.first_slice + (threadIdx.x & 63);
     if (slice + 1 >= ns) return;                               // the last slice owns everything it touches
     const uint4 r = ((const uint4 *)L.resid)[slice];
     if (!(r.x | r.y | r.z | r.w)) return;
