@@ -10,6 +10,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <math.h>
+#include <atomic>
 #include <vector>
 #include <string>
 
@@ -36,6 +37,9 @@ struct Pending {          // results to hand back at gz_sync()
 
 struct ArenaBlock { uint8_t *base; size_t size, used; };
 
+// workgroups of persistent chain kernels in flight in this process / those of them that hold a whole compute unit
+static std::atomic<int> g_chain_wgs (0), g_chain_cus (0);
+
 struct GzHandle {
     int device;
     hipStream_t stream;
@@ -50,6 +54,7 @@ struct GzHandle {
     hipEvent_t ev_low;
     hipEvent_t ev_chain_go, ev_chain;   // the persistent chain may start / has finished
     int n_cu = 0;             // compute units of the device
+    int chain_wgs_held = 0, chain_cus_held = 0;   // this handle's share of g_chain_wgs / g_chain_cus, returned at gz_sync
     uint32_t *d_fail = NULL;  // set by a kernel that gave up (the persistent chain when the models never report)
     bool no_pipeline = false; // GZ_NO_PIPELINE=1: no persistent kernel (needed under tools that serialise kernels, e.g. rocprofv3 --pmc)
     bool own_stream;
@@ -186,6 +191,7 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
 
 extern "C" void gz_destroy (GzHandle *h)
 {
+    if (h) { g_chain_wgs.fetch_sub (h->chain_wgs_held); g_chain_cus.fetch_sub (h->chain_cus_held); h->chain_wgs_held = h->chain_cus_held = 0; }
     if (!h) return;
     hipSetDevice (h->device);
     hipStreamSynchronize (h->stream);
@@ -418,8 +424,17 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
     // workgroups are resident at once, and they may take at most half the wave slots of the device (4 waves each,
     // 32 slots per compute unit). More long leaves than that: no pipeline, everything in one piece (correct, slower).
     const uint32_t chain_wgs = (A.nbig + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES;
-    A.pipelined = A.nbig != 0 && chain_wgs <= (uint32_t)h->n_cu * 4 && !h->no_pipeline;
-    A.reserve_cu = chain_wgs <= (uint32_t)h->n_cu / 4;        // a whole compute unit each only while that leaves 3/4 to the rest
+    // (the budget is per process: several handles - one per host thread, INTEGRATION.md - share the device)
+    A.pipelined = false; A.reserve_cu = false;
+    if (A.nbig && !h->no_pipeline) {
+        const int wgs = (int)chain_wgs;
+        if (g_chain_wgs.fetch_add (wgs) + wgs <= h->n_cu * 4) {
+            A.pipelined = true; h->chain_wgs_held += wgs;
+            if (g_chain_cus.fetch_add (wgs) + wgs <= h->n_cu / 4) { A.reserve_cu = true; h->chain_cus_held += wgs; }   // a whole compute unit each only while that leaves 3/4 to the rest
+            else g_chain_cus.fetch_sub (wgs);
+        }
+        else g_chain_wgs.fetch_sub (wgs);
+    }
     if (!A.pipelined) { A.nbig = 0; small = P.plain_list; big.clear (); A.nsmall = (uint32_t)small.size (); }
     void *d;
     int rc = upload (h, P.plain_list.data (), P.plain_list.size () * 4, &d); A.d_plain = (const uint32_t *)d;
@@ -720,7 +735,10 @@ extern "C" int gz_sync (GzHandle *h)
 {
     if (!h) return GZ_ERR_ARG;
     HIPCHK (h, hipSetDevice (h->device));
-    HIPCHK (h, hipStreamSynchronize (h->stream));
+    const hipError_t sync_err = hipStreamSynchronize (h->stream);
+    g_chain_wgs.fetch_sub (h->chain_wgs_held); g_chain_cus.fetch_sub (h->chain_cus_held);
+    h->chain_wgs_held = h->chain_cus_held = 0;
+    HIPCHK (h, sync_err);
     int rc = GZ_OK;
     bool device_failed = false;
     if (!h->pending.empty ()) {

@@ -80,3 +80,22 @@ def test_many_vblocks_concurrently(gpu_engine, oracle):
 def test_acgt_pack(gpu_engine, oracle):
     """N2: a VBlock's worth of SEQ (46 000 reads x 150 bp)"""
     parity.acgt(gpu_engine, oracle, 6900000)
+
+
+def test_two_handles_in_flight(gpu_engine, oracle):
+    """two GzHandles (two host threads in the reference's threading model) with batches in flight at the same time: the
+    persistent chain kernels of both must get along (process-wide budget in gz_host.cpp)"""
+    from genozip_amd.codec import Engine
+    E1, E2 = gpu_engine, Engine(device=0)
+    d1 = [synth.quality_diverse(900 + k, 2000).tobytes() for k in range(6)]      # 300 KB each: several position chunks
+    d2 = [synth.markov_bytes(950 + k, 250000, 30, 40).tobytes() for k in range(6)]
+    b1 = [E1.mem.upload(d) for d in d1]; b2 = [E2.mem.upload(d) for d in d2]
+    t1, o1 = E1.make_stream_table([(16, b, len(d)) for b, d in zip(b1, d1)])
+    t2, o2 = E2.make_stream_table([(17, b, len(d)) for b, d in zip(b2, d2)])
+    for _ in range(3):
+        E1.compress_table(t1, len(d1)); E2.compress_table(t2, len(d2))
+        E1.sync(); E2.sync()
+    for k, d in enumerate(d1):
+        assert E1.mem.download(o1[k], t1[k].out_len) == oracle.codec_compress(16, d)
+    for k, d in enumerate(d2):
+        assert E2.mem.download(o2[k], t2[k].out_len) == oracle.codec_compress(17, d)
