@@ -69,14 +69,23 @@ struct GzHandle {
     bool profiling = false;
     struct ProfRec { const char *name; hipEvent_t a, b; };
     std::vector<ProfRec> prof_open;
+    std::vector<hipEvent_t> event_pool;            // (creating and destroying two events per launch costs more than the launch)
     struct ProfAcc { std::string name; double ms; int launches; };
     std::vector<ProfAcc> prof;
 };
 
+static inline hipEvent_t gz_event_get (GzHandle *h)
+{
+    if (!h->event_pool.empty ()) { hipEvent_t e = h->event_pool.back (); h->event_pool.pop_back (); return e; }
+    hipEvent_t e = NULL;
+    hipEventCreate (&e);
+    return e;
+}
+
 // KLAUNCH: hipLaunchKernelGGL bracketed by two events when profiling is on
 #define KLAUNCH_ON(h, strm, kern, grid, block, shmem, ...) do { \
     GzHandle::ProfRec pr_; pr_.name = #kern; \
-    if ((h)->profiling) { hipEventCreate (&pr_.a); hipEventCreate (&pr_.b); hipEventRecord (pr_.a, (strm)); } \
+    if ((h)->profiling) { pr_.a = gz_event_get (h); pr_.b = gz_event_get (h); hipEventRecord (pr_.a, (strm)); } \
     hipLaunchKernelGGL (kern, grid, block, shmem, (strm), __VA_ARGS__); \
     if ((h)->profiling) { hipEventRecord (pr_.b, (strm)); (h)->prof_open.push_back (pr_); } } while (0)
 #define KLAUNCH(h, kern, grid, block, shmem, ...) KLAUNCH_ON (h, (h)->stream, kern, grid, block, shmem, __VA_ARGS__)
@@ -195,6 +204,7 @@ extern "C" void gz_destroy (GzHandle *h)
     if (!h) return;
     hipSetDevice (h->device);
     hipStreamSynchronize (h->stream);
+    for (auto e : h->event_pool) hipEventDestroy (e);
     for (auto &b : h->blocks) hipFree (b.base);
     for (auto p : h->host_tmp) free (p);
     hipFree (h->d_logs);
@@ -385,6 +395,7 @@ static int upload (GzHandle *h, const void *host, size_t bytes, void **dev)
     if (!*dev) return GZ_ERR_HIP;
     if (bytes) {
         // the source vectors die when the planning function returns: stage through a heap copy that lives until sync
+        // (page-locked staging was tried: no faster end to end)
         void *stage = malloc (bytes);
         if (!stage) return GZ_ERR;
         memcpy (stage, host, bytes);
@@ -785,7 +796,7 @@ extern "C" int gz_sync (GzHandle *h)
             for (auto &acc : h->prof) if (acc.name == pr.name) { acc.ms += ms; acc.launches++; found = true; break; }
             if (!found) { GzHandle::ProfAcc acc; acc.name = pr.name; acc.ms = ms; acc.launches = 1; h->prof.push_back (acc); }
         }
-        hipEventDestroy (pr.a); hipEventDestroy (pr.b);
+        h->event_pool.push_back (pr.a); h->event_pool.push_back (pr.b);
     }
     h->prof_open.clear ();
     h->pending.clear ();

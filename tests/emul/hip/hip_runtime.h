@@ -69,6 +69,9 @@ static inline hipError_t hipMemcpy (void *d, const void *s, size_t n, hipMemcpyK
 static inline hipError_t hipMemcpyAsync (void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memmove (d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync (void *d, int v, size_t n, hipStream_t) { memset (d, v, n); return hipSuccess; }
 static inline hipError_t hipMemset (void *d, int v, size_t n) { memset (d, v, n); return hipSuccess; }
+enum { hipHostMallocDefault = 0 };
+static inline hipError_t hipHostMalloc (void **p, size_t n, unsigned) { *p = malloc (n); return *p ? hipSuccess : (hipError_t)2; }
+static inline hipError_t hipHostFree (void *p) { free (p); return hipSuccess; }
 
 // ---- execution context: the threads of a block are cooperative fibers on the calling OS thread ----
 // (hand-rolled x86-64 context switch: a wave ballot costs 64 switches of a few ns, where OS threads + barriers cost
