@@ -748,33 +748,38 @@ __device__ static __forceinline__ void d_chain_chunk (uint32_t &range, uint32_t 
         gz_u32x16 a0 = rec4[p0 >> 2], a1 = rec4[(p0 >> 2) + 1];
         if (!p0) { a0[1] = q0 + 1; a0[2] = 0; a0[3] = 0; }
         gz_wait_scalar_loads ();
-        for (uint32_t i = p0; ; ) {
-            const gz_u32x16 b0 = rec4[(i >> 2) + 2], b1 = rec4[(i >> 2) + 3];
-            gz_sched_fence ();
-            // every PERIOD records the PERIOD records that start AHEAD bytes further on, never waited for (gz_touch)
-            if (!(i & (GZ_CHAIN_TOUCH_PERIOD - 1)) && i + GZ_CHAIN_TOUCH_AHEAD / 16 + GZ_CHAIN_TOUCH_PERIOD <= touch_end)
+        // 8 records of buffer (C0, C1) through the chain while the next 8 arrive in (N0, N1); K = which eighth of the 64
+#define GZ_CHAIN_HALF(C0, C1, N0, N1, K) do { \
+            gz_wait_scalar_loads (); \
+            N0 = rec4[(i >> 2) + 2 * (K) + 2]; N1 = rec4[(i >> 2) + 2 * (K) + 3]; \
+            gz_sched_fence (); \
+            uint32_t r0, r1, r2, r3; \
+            r0 = d_chain_step (range, C0[0], C0[1], C0[2],  C0[3]);  r1 = d_chain_step (range, C0[4],  C0[5],  C0[6],  C0[7]); \
+            r2 = d_chain_step (range, C0[8], C0[9], C0[10], C0[11]); r3 = d_chain_step (range, C0[12], C0[13], C0[14], C0[15]); \
+            gz_scalar_store4_at<32 * (K)> (rout + i, r0, r1, r2, r3);       /* the chain never touches the vector unit */ \
+            r0 = d_chain_step (range, C1[0], C1[1], C1[2],  C1[3]);  r1 = d_chain_step (range, C1[4],  C1[5],  C1[6],  C1[7]); \
+            r2 = d_chain_step (range, C1[8], C1[9], C1[10], C1[11]); r3 = d_chain_step (range, C1[12], C1[13], C1[14], C1[15]); \
+            gz_scalar_store4_at<32 * (K) + 16> (rout + i, r0, r1, r2, r3); \
+        } while (0)
+        uint32_t i = p0;
+        gz_u32x16 b0, b1;
+        // 64 records per iteration (loop control, address arithmetic and the touch are paid once per 64: every instruction
+        // of this wave is 4 clocks of the step's critical path)
+        for (; i + 64 <= nb; i += 64) {
+            // every 64 records the 64 records that start AHEAD bytes further on, never waited for (gz_touch)
+            if (i + GZ_CHAIN_TOUCH_AHEAD / 16 + GZ_CHAIN_TOUCH_PERIOD <= touch_end)
                 gz_touch (triples + (size_t)i * 16 + GZ_CHAIN_TOUCH_AHEAD + lane * (GZ_CHAIN_TOUCH_PERIOD / 4), touched);
-            uint32_t r0, r1, r2, r3;
-            r0 = d_chain_step (range, a0[0], a0[1], a0[2],  a0[3]);  r1 = d_chain_step (range, a0[4],  a0[5],  a0[6],  a0[7]);
-            r2 = d_chain_step (range, a0[8], a0[9], a0[10], a0[11]); r3 = d_chain_step (range, a0[12], a0[13], a0[14], a0[15]);
-            gz_scalar_store4_at<0> (rout + i, r0, r1, r2, r3);       // the chain never touches the vector unit
-            r0 = d_chain_step (range, a1[0], a1[1], a1[2],  a1[3]);  r1 = d_chain_step (range, a1[4],  a1[5],  a1[6],  a1[7]);
-            r2 = d_chain_step (range, a1[8], a1[9], a1[10], a1[11]); r3 = d_chain_step (range, a1[12], a1[13], a1[14], a1[15]);
-            gz_scalar_store4_at<16> (rout + i, r0, r1, r2, r3);
-            if (i + 8 >= nb) break;
-            gz_wait_scalar_loads ();
-            a0 = rec4[(i >> 2) + 4]; a1 = rec4[(i >> 2) + 5];
-            gz_sched_fence ();
-            r0 = d_chain_step (range, b0[0], b0[1], b0[2],  b0[3]);  r1 = d_chain_step (range, b0[4],  b0[5],  b0[6],  b0[7]);
-            r2 = d_chain_step (range, b0[8], b0[9], b0[10], b0[11]); r3 = d_chain_step (range, b0[12], b0[13], b0[14], b0[15]);
-            gz_scalar_store4_at<32> (rout + i, r0, r1, r2, r3);
-            r0 = d_chain_step (range, b1[0], b1[1], b1[2],  b1[3]);  r1 = d_chain_step (range, b1[4],  b1[5],  b1[6],  b1[7]);
-            r2 = d_chain_step (range, b1[8], b1[9], b1[10], b1[11]); r3 = d_chain_step (range, b1[12], b1[13], b1[14], b1[15]);
-            gz_scalar_store4_at<48> (rout + i, r0, r1, r2, r3);
-            i += 16;
-            if (i >= nb) break;
-            gz_wait_scalar_loads ();
+            GZ_CHAIN_HALF (a0, a1, b0, b1, 0); GZ_CHAIN_HALF (b0, b1, a0, a1, 1); GZ_CHAIN_HALF (a0, a1, b0, b1, 2); GZ_CHAIN_HALF (b0, b1, a0, a1, 3);
+            GZ_CHAIN_HALF (a0, a1, b0, b1, 4); GZ_CHAIN_HALF (b0, b1, a0, a1, 5); GZ_CHAIN_HALF (a0, a1, b0, b1, 6); GZ_CHAIN_HALF (b0, b1, a0, a1, 7);
         }
+        gz_wait_scalar_loads ();
+        // what is left of the chunk (< 64 records): 8 at a time, (a0, a1) holds the next 8
+        for (; i < nb; i += 8) {
+            GZ_CHAIN_HALF (a0, a1, b0, b1, 0);
+            gz_wait_scalar_loads ();
+            a0 = b0; a1 = b1;
+        }
+#undef GZ_CHAIN_HALF
         gz_touch_done (touched);
     }
     for (uint32_t i = nb > p0 ? nb : p0; i < p1; i++) {
