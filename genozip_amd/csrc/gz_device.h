@@ -67,8 +67,9 @@ struct GzdLeaf {
     const uint8_t *coded; uint32_t coded_n;   // bytes the entropy coder sees (== packed or src)
     uint32_t max_sym;         // arith: 1 + largest byte
     uint32_t nsym;            // distinct coded byte values
-    uint8_t  symlist[256];    // ascending
-    uint16_t symrank[256];    // value -> rank, 0xffff if absent (rank 255 is a legal rank)
+    // (two small device-only tables, written by k_leaf_prep: kept out of this struct, which is uploaded for every leaf)
+    uint8_t  *symlist;        // [256] the distinct coded byte values, ascending
+    uint16_t *symrank;        // [256] value -> rank, 0xffff if absent (rank 255 is a legal rank)
     uint32_t tab_len, pay_len, unit_len;
     int32_t  overflow;        // payload alone already > coded_n => CAT
     // scratch owned by this leaf (device pointers; NULL when the method does not need it)

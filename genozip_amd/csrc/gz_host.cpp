@@ -298,6 +298,7 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
     // rANS stops (-> CAT) once the payload exceeds the input; the arithmetic coder's scalar chain carries no capacity
     // checks, so its area holds the worst case of an adaptive model: 2 bytes per symbol (freq 1 of a total < 2^16)
     L.pay_cap = engine == GZ_ENG_ARITH ? ((method & GZ_X_RLE) ? 4 : 2) * n_bound + 64 : n_bound + 64;
+    if (!(L.symlist = (uint8_t *)arena_alloc (h, 256)) || !(L.symrank = (uint16_t *)arena_alloc (h, 512))) return false;
     if (!(L.pay = (uint8_t *)arena_alloc (h, L.pay_cap))) return false;
     if (engine == GZ_ENG_RANS) {
         if (!(L.F    = (uint32_t *)arena_alloc (h, (o1 ? 256 * 256 + 256 : 256) * sizeof (uint32_t)))) return false;
