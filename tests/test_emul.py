@@ -5,7 +5,7 @@ import parity
 
 
 def test_emul_codec_edge_cases(emul_engine, oracle):
-    parity.codec_edge_cases(emul_engine, oracle, max_n=4097)
+    parity.codec_edge_cases(emul_engine, oracle, max_n=1031)
 
 
 def test_emul_host_call_surface(emul_engine, oracle):
@@ -13,7 +13,7 @@ def test_emul_host_call_surface(emul_engine, oracle):
 
 
 def test_emul_golden_small(emul_engine):
-    assert parity.golden(emul_engine, max_n=1000) > 1500
+    assert parity.golden(emul_engine, max_n=260) > 1000
 
 
 def test_emul_assign_best(emul_engine, oracle):
