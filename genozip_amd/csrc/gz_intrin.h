@@ -58,3 +58,18 @@ __device__ static inline void gz_touch_done (uint32_t &pit)
 // all lanes of the wave have performed their LDS accesses so far before any lane performs a later one (one wave's LDS
 // operations execute in order; this only has to keep the compiler from reordering them)
 __device__ static inline void gz_wave_sync (void) { __builtin_amdgcn_fence (__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier (); }
+
+// loads through a GLOBAL pointer: a load through a generic one is a flat load, which also counts as an LDS operation -
+// every wait for an LDS read would then wait for its trip to memory as well
+__device__ static inline uint32_t gz_ldg_u8 (const uint8_t *p) { return *(const __attribute__((address_space(1))) uint8_t *)(uintptr_t)p; }
+__device__ static inline uint4 gz_ldg_u32x4 (const void *p)
+{
+    typedef uint32_t gz_v4 __attribute__((ext_vector_type(4)));
+    const gz_v4 v = *(const __attribute__((address_space(1))) gz_v4 *)(uintptr_t)p;
+    return make_uint4 (v.x, v.y, v.z, v.w);
+}
+__device__ static inline void gz_stg_u16 (uint8_t *p, uint32_t v)     // 2 bytes, any alignment, through a GLOBAL pointer
+{
+    typedef uint16_t __attribute__((aligned(1))) gz_u16_unaligned;
+    *(__attribute__((address_space(1))) gz_u16_unaligned *)(uintptr_t)p = (uint16_t)v;
+}

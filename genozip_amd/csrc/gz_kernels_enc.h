@@ -346,17 +346,19 @@ __device__ static inline uint32_t d_rans_advance (uint32_t x, const GzRansSym &r
     return x + r.bias + q * (r.cmpl_rsh & 0xffff);
 }
 
+__device__ static inline uint32_t d_uniform_u32 (uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane ((int)v); }
+
 // The 4 interleaved states on lanes 0..3 of one wave. Lane k codes its own list of (record) steps, longest list
 // first: round r (counting down) is coded by every lane whose list is longer than r. Within a round state 3 emits
 // first, i.e. lands at the highest address of the backwards-growing stream. Called by ALL 64 lanes of the wave.
-//   rec(k, r) -> pointer to the encoder record of lane k's r-th step
-// Only the state update x -> x' is serial. Which record a step needs is known from the input alone, so the records of 16
-// rounds are fetched by all 64 lanes at once (lane 4j+k: state k, j-th round of the batch), one batch ahead of their
-// use, and handed to the state lanes through LDS (lds: 2 KB of this wave's own, two buffers).
+//   idx(k, r, hi, lo) loads the bytes that select the record of lane k's r-th step: record = syms[hi * 256 + lo]
+// Only the state update x -> x' is serial. Which record a step needs is known from the input alone, so all 64 lanes work
+// ahead for the four state lanes (lane 4j+k: state k, j-th round of a batch of 16), in three stages one batch apart: the
+// input bytes -> the record they select -> hand-over through LDS (lds: 2 KB of this wave's own, two buffers).
 // Returns payload length (bytes, incl. the 16 state bytes) or 0xffffffff on overflow; payload ends at buf+cap.
 #define GZ_RANS_ENC_LDS 2048
-template <typename RecFn>
-__device__ static uint32_t d_rans_encode_wave (uint32_t len_k, uint32_t rounds, uint8_t *buf, uint32_t cap, uint8_t *lds, RecFn rec)
+template <typename IdxFn>
+__device__ static uint32_t d_rans_encode_wave (uint32_t len_k, uint32_t rounds, uint8_t *buf, uint32_t cap, uint8_t *lds, const GzRansSym *syms, IdxFn idx)
 {
     const int lane = threadIdx.x & 63;
     const int k_of = lane & 3, j_of = lane >> 2;
@@ -366,25 +368,59 @@ __device__ static uint32_t d_rans_encode_wave (uint32_t len_k, uint32_t rounds, 
     uint32_t used = 0;                 // bytes emitted so far (wave-uniform)
     bool overflow = false;
     const uint4 idle = make_uint4 (0xffffffffu, 0, 0, 0);              // x_max that never triggers
-    auto fetch = [&] (uint32_t r_hi) -> uint4 {                        // records of rounds r_hi-1 ... r_hi-16
-        if (r_hi <= (uint32_t)j_of) return idle;
+    const uint32_t NONE = 0xffffffffu;
+    // (stage 1 only LOADS the bytes - hi = context byte or 0, lo = symbol, both untouched until stage 2 turns them into
+    //  a table index: any arithmetic on them here would make the compiler wait for the loads on the spot)
+    uint32_t nxt_hi = 0, nxt_lo = NONE;
+    auto fetch_idx = [&] (uint32_t r_hi, uint32_t &hi, uint32_t &lo) {  // of rounds r_hi-1 ... r_hi-16
+        hi = 0; lo = NONE;
+        if (r_hi <= (uint32_t)j_of) return;
         const uint32_t r = r_hi - 1 - (uint32_t)j_of;
-        if (r >= len_mine) return idle;
-        const GzRansSym *p = rec (k_of, r);
-        return make_uint4 (p->x_max, p->rcp, p->bias, p->cmpl_rsh);
+        if (r < len_mine) idx (k_of, r, hi, lo);
     };
-    uint4 nxt = fetch (rounds);
+    auto fetch_rec = [&] (uint32_t hi, uint32_t lo) -> uint4 { return lo == NONE ? idle : gz_ldg_u32x4 (syms + hi * 256 + lo); };
+    fetch_idx (rounds, nxt_hi, nxt_lo);
+    uint4 nxt = fetch_rec (nxt_hi, nxt_lo);
+    fetch_idx (rounds > 16 ? rounds - 16 : 0, nxt_hi, nxt_lo);
     int b = 0;
     for (uint32_t r_hi = rounds; r_hi > 0 && !overflow; b ^= 1) {
         const uint32_t nb = r_hi < 16 ? r_hi : 16;
         slot[b * 64 + lane] = nxt;
         gz_wave_sync ();
-        nxt = fetch (r_hi - nb);                                       // in flight while this batch is coded
+        nxt = fetch_rec (nxt_hi, nxt_lo);                              // (its bytes were requested one batch ago)
+        fetch_idx (r_hi - nb > 16 ? r_hi - nb - 16 : 0, nxt_hi, nxt_lo);   // in flight while this batch is coded
+        uint4 cur = slot[b * 64 + (lane & 3)];                         // (the next round's record is read while this round works)
+        if (used + 8 * nb + 16 + 8 <= cap) {
+            // the usual case - no capacity test inside the batch, and nothing that makes the scalar unit wait for the
+            // vector unit (a ballot feeding scalar arithmetic costs ~12 ns each time): counts by v_mbcnt / v_bcnt on the
+            // ballot mask, "emit or not" as a select between the real address and a dump slot at the unused front of buf
+            uint32_t used_v = used;
+            for (uint32_t j = 0; j < nb; j++) {
+                const uint32_t r = r_hi - 1 - j;
+                const bool mine = lane < 4 && r < len_k;
+                GzRansSym s;
+                s.x_max = cur.x; s.rcp = cur.y; s.bias = cur.z; s.cmpl_rsh = cur.w;
+                cur = slot[b * 64 + ((j + 1) & 15) * 4 + (lane & 3)];
+                const bool emit = mine && x >= s.x_max;
+                const uint32_t mlo = (uint32_t)__ballot (emit);          // (only lanes 0..3 can be set)
+                const uint32_t below = gz_mbcnt ((uint64_t)mlo);
+                used_v += 2 * (below + (uint32_t)__popcll ((unsigned long long)(mlo >> lane)));   // every lane: the whole count
+                const uint32_t off = emit ? cap - used_v + 2 * below : 2u * (uint32_t)(lane & 3);
+                if (lane < 4) gz_stg_u16 (buf + off, x);
+                x = emit ? x >> 16 : x;
+                const uint32_t xn = d_rans_advance (x, s);
+                x = mine ? xn : x;
+            }
+            used = d_uniform_u32 (used_v);
+            r_hi -= nb;
+            continue;
+        }
         for (uint32_t j = 0; j < nb; j++) {
             const uint32_t r = r_hi - 1 - j;
             const bool mine = lane < 4 && r < len_k;
             GzRansSym s;
-            { const uint4 v = slot[b * 64 + j * 4 + (lane & 3)]; s.x_max = v.x; s.rcp = v.y; s.bias = v.z; s.cmpl_rsh = v.w; }
+            s.x_max = cur.x; s.rcp = cur.y; s.bias = cur.z; s.cmpl_rsh = cur.w;
+            cur = slot[b * 64 + ((j + 1) & 15) * 4 + (lane & 3)];
             bool emit = mine && x >= s.x_max;
             uint64_t m = __ballot (emit) & 0xfull;
             uint32_t cnt = __popcll (m);
@@ -392,13 +428,45 @@ __device__ static uint32_t d_rans_encode_wave (uint32_t len_k, uint32_t rounds, 
             used += 2 * cnt;
             if (emit) {
                 uint32_t below = __popcll (m & ((1ull << lane) - 1));       // emitting states with a smaller index
-                uint8_t *p = buf + cap - used + 2 * below;
-                p[0] = (uint8_t)x; p[1] = (uint8_t)(x >> 8);
+                gz_stg_u16 (buf + cap - used + 2 * below, x);
                 x >>= 16;
             }
             if (mine) x = d_rans_advance (x, s);
         }
         r_hi -= nb;
+    }
+    if (overflow) return 0xffffffffu;
+    used += 16;
+    if (lane < 4) {
+        uint8_t *p = buf + cap - used + 4 * lane;
+        p[0] = (uint8_t)x; p[1] = (uint8_t)(x >> 8); p[2] = (uint8_t)(x >> 16); p[3] = (uint8_t)(x >> 24);
+    }
+    return used;
+}
+
+// the same coder for the (small, order-0) nested coding of a frequency table: records in LDS, no pipelining needed
+__device__ static uint32_t d_rans_encode_wave_lds (uint32_t len_k, uint32_t rounds, uint8_t *buf, uint32_t cap, const GzRansSym *tsyms, const uint8_t *tin)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t x = 0x8000u, used = 0;
+    bool overflow = false;
+    for (uint32_t r = rounds; r-- > 0; ) {
+        const bool mine = lane < 4 && r < len_k;
+        GzRansSym s;
+        s.x_max = 0xffffffffu; s.rcp = 0; s.bias = 0; s.cmpl_rsh = 0;
+        if (mine) s = tsyms[tin[4 * r + lane]];
+        bool emit = mine && x >= s.x_max;
+        uint64_t m = __ballot (emit) & 0xfull;
+        uint32_t cnt = __popcll (m);
+        if (used + 2 * cnt + 16 > cap) { overflow = true; break; }
+        used += 2 * cnt;
+        if (emit) {
+            uint32_t below = __popcll (m & ((1ull << lane) - 1));
+            uint8_t *p = buf + cap - used + 2 * below;
+            p[0] = (uint8_t)x; p[1] = (uint8_t)(x >> 8);
+            x >>= 16;
+        }
+        if (mine) x = d_rans_advance (x, s);
     }
     if (overflow) return 0xffffffffu;
     used += 16;
@@ -569,8 +637,8 @@ __global__ void __launch_bounds__(256) k_rans_table (GzdLeaf *leaves, const GzLo
         if (tid < 64) {
             uint32_t len_k = (raw >> 2) + ((raw & 3) > (uint32_t)(tid & 3));
             uint32_t rounds = (raw + 3) >> 2;
-            uint32_t plen = d_rans_encode_wave (tid < 4 ? len_k : 0, rounds, tpay, tpay_cap, gz_lds + 16384,
-                                                [&] (int k, uint32_t r) { return &tsyms[tin[4 * r + k]]; });
+            // (the records of the nested coder live in LDS: copy them out for the wave's global-memory fetch path)
+            uint32_t plen = d_rans_encode_wave_lds (tid < 4 ? len_k : 0, rounds, tpay, tpay_cap, tsyms, tin);
             if (!tid) shared[3] = plen;
         }
         __syncthreads ();
@@ -610,18 +678,18 @@ __global__ void __launch_bounds__(64) k_rans_encode (GzdLeaf *leaves)
 
     if (!L.o1) {
         uint32_t len_k = (n >> 2) + ((n & 3) > (uint32_t)(lane & 3));
-        plen = d_rans_encode_wave (lane < 4 ? len_k : 0, (n + 3) >> 2, L.pay, L.pay_cap, gz_lds,
-                                   [&] (int k, uint32_t r) { return &syms[in[4 * r + k]]; });
+        plen = d_rans_encode_wave (lane < 4 ? len_k : 0, (n + 3) >> 2, L.pay, L.pay_cap, gz_lds, syms,
+                                   [&] (int k, uint32_t r, uint32_t &hi, uint32_t &lo) { hi = 0; lo = gz_ldg_u8 (in + 4 * r + k); });
     }
     else {
         // quarter k = [k*q, (k+1)*q), the last one extends to n and codes its surplus first, alone (:817-823);
         // the head of each quarter is coded in context 0 (:843-846)
         const uint32_t q = n >> 2;
         uint32_t len_k = lane == 3 ? n - 3 * q : q;
-        plen = d_rans_encode_wave (lane < 4 ? len_k : 0, n - 3 * q, L.pay, L.pay_cap, gz_lds,
-                                   [&] (int k, uint32_t r) {
+        plen = d_rans_encode_wave (lane < 4 ? len_k : 0, n - 3 * q, L.pay, L.pay_cap, gz_lds, syms,
+                                   [&] (int k, uint32_t r, uint32_t &hi, uint32_t &lo) {
                                        uint32_t at = k * q + r;
-                                       return &syms[(r ? in[at - 1] : 0) * 256 + in[at]];
+                                       hi = r ? gz_ldg_u8 (in + at - 1) : 0u; lo = gz_ldg_u8 (in + at);
                                    });
     }
     if (!lane) { if (plen == 0xffffffffu) { L.overflow = 1; L.pay_len = 0; } else L.pay_len = plen; }

@@ -24,3 +24,8 @@ seg = T("oracle seg array", lambda: oracle.b250_seg_array(ni, 3000))
 n2w = [int(x) for x in (synth.u32(79, 1200) % np.uint32(4240))]
 piz = T("gpu b250_generate 1e7", lambda: E.b250_generate(seg, 3000, n2w))
 T("oracle b250_generate", lambda: oracle.b250_generate(seg, 3000, n2w))
+for c in (6, 8):
+    E.profile(True, reset=True)
+    E.compress_many([(c, tr)])
+    E.profile(False)
+    print("codec %d kernels:" % c, "  ".join("%s %.1f ms" % (k.replace("k_", ""), v[0]) for k, v in sorted(E.profile_results().items(), key=lambda kv: -kv[1][0])[:6]), flush=True)
