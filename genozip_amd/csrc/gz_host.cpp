@@ -198,12 +198,15 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
     return h;
 }
 
+static void prof_collect (GzHandle *h);
+
 extern "C" void gz_destroy (GzHandle *h)
 {
     if (h) { g_chain_wgs.fetch_sub (h->chain_wgs_held); g_chain_cus.fetch_sub (h->chain_cus_held); h->chain_wgs_held = h->chain_cus_held = 0; }
     if (!h) return;
     hipSetDevice (h->device);
     hipStreamSynchronize (h->stream);
+    prof_collect (h);
     for (auto e : h->event_pool) hipEventDestroy (e);
     for (auto &b : h->blocks) hipFree (b.base);
     for (auto p : h->host_tmp) free (p);
@@ -225,15 +228,33 @@ extern "C" void gz_destroy (GzHandle *h)
     delete h;
 }
 
+// turn the recorded event pairs into per-kernel totals (the kernels have completed: called after a sync). Not done inside
+// every gz_sync: ~100 elapsed-time queries per step are measurement work, not part of the step
+static void prof_collect (GzHandle *h)
+{
+    for (auto &pr : h->prof_open) {
+        float ms = 0;
+        if (hipEventElapsedTime (&ms, pr.a, pr.b) == hipSuccess) {
+            bool found = false;
+            for (auto &acc : h->prof) if (acc.name == pr.name) { acc.ms += ms; acc.launches++; found = true; break; }
+            if (!found) { GzHandle::ProfAcc acc; acc.name = pr.name; acc.ms = ms; acc.launches = 1; h->prof.push_back (acc); }
+        }
+        h->event_pool.push_back (pr.a); h->event_pool.push_back (pr.b);
+    }
+    h->prof_open.clear ();
+}
+
 extern "C" void gz_profile (GzHandle *h, int enable, int reset)
 {
     if (!h) return;
+    if (h->pending.empty ()) prof_collect (h);          // (everything recorded so far has been synchronised)
     h->profiling = enable != 0;
     if (reset) h->prof.clear ();
 }
 
 extern "C" int gz_profile_get (GzHandle *h, int idx, char *name, int name_cap, double *total_ms, int *launches)
 {
+    if (h && h->pending.empty ()) prof_collect (h);
     if (!h || idx < 0 || idx >= (int)h->prof.size ()) return 0;
     if (name && name_cap > 0) { strncpy (name, h->prof[idx].name.c_str (), name_cap - 1); name[name_cap - 1] = 0; }
     if (total_ms) *total_ms = h->prof[idx].ms;
@@ -790,16 +811,7 @@ extern "C" int gz_sync (GzHandle *h)
             }
         }
     }
-    for (auto &pr : h->prof_open) {
-        float ms = 0;
-        if (hipEventElapsedTime (&ms, pr.a, pr.b) == hipSuccess) {
-            bool found = false;
-            for (auto &acc : h->prof) if (acc.name == pr.name) { acc.ms += ms; acc.launches++; found = true; break; }
-            if (!found) { GzHandle::ProfAcc acc; acc.name = pr.name; acc.ms = ms; acc.launches = 1; h->prof.push_back (acc); }
-        }
-        h->event_pool.push_back (pr.a); h->event_pool.push_back (pr.b);
-    }
-    h->prof_open.clear ();
+    if (!h->profiling || h->prof_open.size () > 4096) prof_collect (h);
     h->pending.clear ();
     for (auto p : h->host_tmp) free (p);
     h->host_tmp.clear ();
