@@ -1,24 +1,21 @@
-// gz_kernels_arith.h -- the adaptive arithmetic coder (arith_dynamic.c:92-197, c_simple_model.h, c_range_coder.h),
-// re-thought for a GPU.
+// gz_kernels_arith.h -- the adaptive arithmetic coder (arith_dynamic.c:92-197,387-561, c_simple_model.h,
+// c_range_coder.h), re-thought for a GPU. (DESIGN.md section 3 has the measurements behind every choice.)
 //
 // The reference walks a stream once, per symbol: search the context's frequency-sorted list for the symbol
 // (accumulating the cumulative frequency), divide the range by the model total, update low/range, renormalise,
 // bump the frequency, maybe halve all, maybe swap with the left neighbour. One lane doing that costs ~2000 cycles per
-// symbol. But the triple (cum, freq, tot) fed to the range coder depends only on the *model history*, never on the
-// coder state, and in order-1 mode the 256 models never interact. So:
+// symbol. The loop is taken apart by what depends on what:
 //
-//   k_arith_model  one WAVE per (leaf, context). The model lives in registers, entry e in lane e%64: finding a symbol
-//                  is one ballot, its cumulative frequency a register kept up to date incrementally (every entry after
-//                  the bumped one gains 16), the swap two writelanes. The wave scans the input for the positions that
-//                  belong to its context and writes the 8-byte triple of every such position. All contexts of all
-//                  leaves run concurrently.
-//   k_arith_chain  one wave per leaf replays the triples through the range coder. Only range -> range/tot*freq ->
-//                  renormalise is truly serial; it runs on wave-uniform values (the scalar unit), with the division
-//                  replaced by a multiply by a per-divisor magic number looked up from a table built once on the host.
-//                  64 triples are fetched per iteration with one coalesced load and handed to the chain by readlane.
-//
-// Leaves using the run-length variant (stripe plane 0 candidate of ARTW/ARTw) keep the serial kernel in
-// gz_kernels_enc.h for now.
+//   k_rle_events   (run-length variant only) bytes -> coding events (model id, symbol): a segmented scan
+//   k_ctx_*        a stable counting sort of the positions by context, so that a context's wave reads only its own
+//   k_arith_model  the triple (cum, freq, tot) fed to the coder depends only on MODEL history, and the models never
+//                  interact: one wave per (leaf, context), the model in registers (1, 2 or 4 planes of one entry per
+//                  lane), 64 occurrences at a time, order changes (swaps, hops) patched in as events. Writes a 16-byte
+//                  record per position: freq, reciprocal of tot, shift | cum << 8, inc.
+//   k_arith_chain  what is truly serial: range -> range / tot * freq -> renormalise. One wave per leaf, entirely on the
+//                  scalar unit, 7 instructions per symbol; persistent, following the models position chunk by chunk.
+//   k_low_*        low += cum * r is a big-number addition and addition is associative: one thread per symbol adds its
+//                  bytes at the output position given by a prefix sum of the shift counts; then carries.
 #pragma once
 #include "gz_device.h"
 #include "gz_devutil.h"

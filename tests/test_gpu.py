@@ -99,3 +99,19 @@ def test_two_handles_in_flight(gpu_engine, oracle):
         assert E1.mem.download(o1[k], t1[k].out_len) == oracle.codec_compress(16, d)
     for k, d in enumerate(d2):
         assert E2.mem.download(o2[k], t2[k].out_len) == oracle.codec_compress(17, d)
+
+
+def test_unpipelined_mode(oracle):
+    """GZ_NO_PIPELINE=1 (what the PMC profiling passes use): the same kernels one after the other, same bytes"""
+    import os
+    from genozip_amd.codec import Engine
+    os.environ["GZ_NO_PIPELINE"] = "1"
+    try:
+        E = Engine(device=0)
+    finally:
+        del os.environ["GZ_NO_PIPELINE"]
+    items = [(16, synth.quality_diverse(77, 2500).tobytes()), (17, synth.u32be_increasing(78, 120000).tobytes()),
+             (18, synth.markov_bytes(79, 300000, 4, 33).tobytes()), (19, synth.uniform_bytes(80, 200000, 200).tobytes())]
+    got = E.compress_many(items)
+    for (c, d), g in zip(items, got):
+        assert g == oracle.codec_compress(c, d), (c, len(d))
