@@ -115,3 +115,22 @@ def test_unpipelined_mode(oracle):
     got = E.compress_many(items)
     for (c, d), g in zip(items, got):
         assert g == oracle.codec_compress(c, d), (c, len(d))
+
+
+def test_chunk_and_tile_boundaries(gpu_engine, oracle):
+    """sizes around the 64 K chunking threshold, whole / broken 4096-position sort tiles, 16 chunks + 1 byte; data that
+    exercises the run-length events (long runs, runs of exactly 3k), wide alphabets and tiny ones - all arith codecs"""
+    E = gpu_engine
+    items = []
+    seed = 31000
+    for n in (65535, 65536, 65537, 69632, 69633, 131071, 262145, 1048577):
+        for kind, nsym in (("runs", 8), ("uniform", 256), ("markov", 40), ("skew", 3)):
+            seed += 1
+            d = synth.stream(kind, seed, n, nsym).tobytes()
+            for c in ((16, 17) if n > 300000 else (16, 17, 18, 19)):
+                items.append((c, d))
+    three = (bytes([7]) * 4 + bytes([9]) * 7 + bytes([11]) * 10 + bytes([13])) * 9000      # runs of r = 3, 6, 9, 0
+    items += [(17, three), (19, three), (17, bytes(200000)), (19, bytes([5]) * 70001)]
+    got = E.compress_many(items)
+    for (c, d), g in zip(items, got):
+        assert g == oracle.codec_compress(c, d), (c, len(d))
