@@ -394,22 +394,24 @@ __device__ static uint32_t d_rans_encode_wave (uint32_t len_k, uint32_t rounds, 
             // the usual case - no capacity test inside the batch, and nothing that makes the scalar unit wait for the
             // vector unit (a ballot feeding scalar arithmetic costs ~12 ns each time): counts by v_mbcnt / v_bcnt on the
             // ballot mask, "emit or not" as a select between the real address and a dump slot at the unused front of buf
+            // (no predicate is ever combined on the scalar unit: lanes 4.. have list length 0 and a state that never
+            //  reaches any x_max - the smallest is 8 << 16 -, records past the end of a list are `idle`)
             uint32_t used_v = used;
+            const uint32_t len_eff = lane < 4 ? len_k : 0u, hi_bits = lane < 4 ? 0xfu >> lane : 0u;
             for (uint32_t j = 0; j < nb; j++) {
                 const uint32_t r = r_hi - 1 - j;
-                const bool mine = lane < 4 && r < len_k;
                 GzRansSym s;
                 s.x_max = cur.x; s.rcp = cur.y; s.bias = cur.z; s.cmpl_rsh = cur.w;
                 cur = slot[b * 64 + ((j + 1) & 15) * 4 + (lane & 3)];
-                const bool emit = mine && x >= s.x_max;
+                const bool emit = x >= s.x_max;
                 const uint32_t mlo = (uint32_t)__ballot (emit);          // (only lanes 0..3 can be set)
                 const uint32_t below = gz_mbcnt ((uint64_t)mlo);
-                used_v += 2 * (below + (uint32_t)__popcll ((unsigned long long)(mlo >> lane)));   // every lane: the whole count
+                used_v += 2 * (below + (uint32_t)__popcll ((unsigned long long)((mlo >> (lane & 31)) & hi_bits)));   // every lane 0..3: the whole count
                 const uint32_t off = emit ? cap - used_v + 2 * below : 2u * (uint32_t)(lane & 3);
                 if (lane < 4) gz_stg_u16 (buf + off, x);
                 x = emit ? x >> 16 : x;
                 const uint32_t xn = d_rans_advance (x, s);
-                x = mine ? xn : x;
+                x = r < len_eff ? xn : x;
             }
             used = d_uniform_u32 (used_v);
             r_hi -= nb;
