@@ -78,16 +78,16 @@ static inline hipEvent_t gz_event_get (GzHandle *h)
 {
     if (!h->event_pool.empty ()) { hipEvent_t e = h->event_pool.back (); h->event_pool.pop_back (); return e; }
     hipEvent_t e = NULL;
-    hipEventCreate (&e);
+    (void)hipEventCreate (&e);
     return e;
 }
 
 // KLAUNCH: hipLaunchKernelGGL bracketed by two events when profiling is on
 #define KLAUNCH_ON(h, strm, kern, grid, block, shmem, ...) do { \
     GzHandle::ProfRec pr_; pr_.name = #kern; \
-    if ((h)->profiling) { pr_.a = gz_event_get (h); pr_.b = gz_event_get (h); hipEventRecord (pr_.a, (strm)); } \
+    if ((h)->profiling) { pr_.a = gz_event_get (h); pr_.b = gz_event_get (h); (void)hipEventRecord (pr_.a, (strm)); } \
     hipLaunchKernelGGL (kern, grid, block, shmem, (strm), __VA_ARGS__); \
-    if ((h)->profiling) { hipEventRecord (pr_.b, (strm)); (h)->prof_open.push_back (pr_); } } while (0)
+    if ((h)->profiling) { (void)hipEventRecord (pr_.b, (strm)); (h)->prof_open.push_back (pr_); } } while (0)
 #define KLAUNCH(h, kern, grid, block, shmem, ...) KLAUNCH_ON (h, (h)->stream, kern, grid, block, shmem, __VA_ARGS__)
 
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
@@ -160,7 +160,7 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
     for (int k = 0; k <= 256; k++) { lt.l10[k] = log (1024.0 + k); lt.l12[k] = log (4096.0 + k); }
     if (hipMalloc ((void **)&h->d_logs, sizeof (lt)) != hipSuccess ||
         hipMemcpy (h->d_logs, &lt, sizeof (lt), hipMemcpyHostToDevice) != hipSuccess) {
-        if (h->own_stream) hipStreamDestroy (h->stream);
+        if (h->own_stream) (void)hipStreamDestroy (h->stream);
         delete h; if (err) *err = GZ_ERR_HIP; return NULL;
     }
     // range / tot of the range coder (c_range_coder.h:100) as q = mulhi (magic, n + inc) >> shift with a 32-bit magic:
@@ -204,27 +204,27 @@ extern "C" void gz_destroy (GzHandle *h)
 {
     if (h) { g_chain_wgs.fetch_sub (h->chain_wgs_held); g_chain_cus.fetch_sub (h->chain_cus_held); h->chain_wgs_held = h->chain_cus_held = 0; }
     if (!h) return;
-    hipSetDevice (h->device);
-    hipStreamSynchronize (h->stream);
+    (void)hipSetDevice (h->device);
+    (void)hipStreamSynchronize (h->stream);
     prof_collect (h);
-    for (auto e : h->event_pool) hipEventDestroy (e);
-    for (auto &b : h->blocks) hipFree (b.base);
+    for (auto e : h->event_pool) (void)hipEventDestroy (e);
+    for (auto &b : h->blocks) (void)hipFree (b.base);
     for (auto p : h->host_tmp) free (p);
-    hipFree (h->d_logs);
-    hipFree (h->d_magic);
-    hipFree (h->d_fail);
-    if (h->own_stream) hipStreamDestroy (h->stream);
-    hipStreamDestroy (h->stream2);
-    hipStreamDestroy (h->stream3);
-    hipStreamDestroy (h->stream4);
-    hipStreamDestroy (h->stream5);
-    hipStreamDestroy (h->stream6);
-    hipEventDestroy (h->ev_low);
-    hipEventDestroy (h->ev_small);
-    hipEventDestroy (h->ev_model_fork);
-    hipEventDestroy (h->ev_chain);
-    hipEventDestroy (h->ev_chain_go);
-    hipEventDestroy (h->ev_fork); hipEventDestroy (h->ev_join);
+    (void)hipFree (h->d_logs);
+    (void)hipFree (h->d_magic);
+    (void)hipFree (h->d_fail);
+    if (h->own_stream) (void)hipStreamDestroy (h->stream);
+    (void)hipStreamDestroy (h->stream2);
+    (void)hipStreamDestroy (h->stream3);
+    (void)hipStreamDestroy (h->stream4);
+    (void)hipStreamDestroy (h->stream5);
+    (void)hipStreamDestroy (h->stream6);
+    (void)hipEventDestroy (h->ev_low);
+    (void)hipEventDestroy (h->ev_small);
+    (void)hipEventDestroy (h->ev_model_fork);
+    (void)hipEventDestroy (h->ev_chain);
+    (void)hipEventDestroy (h->ev_chain_go);
+    (void)hipEventDestroy (h->ev_fork); (void)hipEventDestroy (h->ev_join);
     delete h;
 }
 
