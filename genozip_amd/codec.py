@@ -238,6 +238,168 @@ class Engine:
         self._check(self.L.gz_adler32(self.h, self.mem.ptr(buf), len(data), C.byref(a)), "gz_adler32")
         return a.value
 
+    # ---- seg-side appends, a column at a time (rows a1-a3) ------------------------------------------------
+    def ctx_seg_columns(self, columns, keep_on_device=False):
+        """columns: list of (text bytes | device buffer, off u32[n], len u32[n], ol_snips) -> list of dicts with the
+        keys node_index, dict, node_char_index, node_snip_len, counts, b250, b250_count, all_the_same
+        (ctx_create_node_do + b250_seg_append over the whole column)"""
+        import numpy as np
+        from .lib import GzColumnJob, GzColumnResult
+        nj = len(columns)
+        tab = (GzColumnJob * max(1, nj))()
+        keep, outs = [], []
+        texts = {}
+        for i, (text, off, length, ol_snips) in enumerate(columns):
+            off = np.ascontiguousarray(off, dtype=np.uint32); length = np.ascontiguousarray(length, dtype=np.uint32)
+            n, n_ol = len(off), len(ol_snips)
+            if isinstance(text, (bytes, bytearray)):
+                if id(text) not in texts:
+                    texts[id(text)] = self.mem.upload(text)
+                tbuf = texts[id(text)]
+            else:
+                tbuf = text
+            ol_dict = b"".join(bytes(w) + b"\0" for w in ol_snips)
+            ol_len = np.array([len(w) for w in ol_snips], dtype=np.uint32)
+            ol_ci = np.zeros(n_ol, dtype=np.uint64)
+            if n_ol > 1:
+                ol_ci[1:] = np.cumsum(ol_len[:-1].astype(np.uint64) + 1)
+            dict_cap = int(length.astype(np.uint64).sum()) + n
+            b = dict(off=self.mem.upload(off), len=self.mem.upload(length), ol_dict=self.mem.upload(ol_dict),
+                     ol_ci=self.mem.upload(ol_ci), ol_len=self.mem.upload(ol_len), ni=self.mem.alloc(4 * n + 16),
+                     dict=self.mem.alloc(dict_cap + 16), nci=self.mem.alloc(8 * n + 16), nsl=self.mem.alloc(4 * n + 16),
+                     counts=self.mem.alloc(4 * (n + n_ol) + 16), b250=self.mem.alloc(4 * n + 16), res=self.mem.alloc(C.sizeof(GzColumnResult)))
+            keep.append((tbuf, b))
+            j = tab[i]
+            j.text = self.mem.ptr(tbuf); j.off = self.mem.ptr(b["off"]); j.len = self.mem.ptr(b["len"]); j.n = n
+            j.ol_dict = self.mem.ptr(b["ol_dict"]); j.ol_char_index = self.mem.ptr(b["ol_ci"]); j.ol_snip_len = self.mem.ptr(b["ol_len"]); j.n_ol = n_ol
+            j.node_index = self.mem.ptr(b["ni"]); j.dict = self.mem.ptr(b["dict"]); j.dict_cap = dict_cap
+            j.node_char_index = self.mem.ptr(b["nci"]); j.node_snip_len = self.mem.ptr(b["nsl"]); j.counts = self.mem.ptr(b["counts"])
+            j.b250 = self.mem.ptr(b["b250"]); j.result_dev = self.mem.ptr(b["res"])
+            outs.append((n, n_ol, b))
+        self._check(self.L.gz_ctx_seg_columns(self.h, tab, nj), "gz_ctx_seg_columns")
+        self.sync()
+        if keep_on_device:
+            return outs
+        res = []
+        for n, n_ol, b in outs:
+            r = GzColumnResult.from_buffer_copy(self.mem.download(b["res"], C.sizeof(GzColumnResult)))
+            if r.status != 1:
+                raise GenozipAMDError("gz_ctx_seg_columns: dict capacity too small")
+            res.append(dict(node_index=np.frombuffer(self.mem.download(b["ni"], 4 * n), dtype=np.int32),
+                            dict=self.mem.download(b["dict"], r.dict_len),
+                            node_char_index=np.frombuffer(self.mem.download(b["nci"], 8 * r.n_new), dtype=np.uint64),
+                            node_snip_len=np.frombuffer(self.mem.download(b["nsl"], 4 * r.n_new), dtype=np.uint32),
+                            counts=np.frombuffer(self.mem.download(b["counts"], 4 * (n_ol + r.n_new)), dtype=np.uint32),
+                            b250=self.mem.download(b["b250"], r.b250_len), b250_count=int(r.b250_count),
+                            all_the_same=bool(r.all_the_same)))
+        return res
+
+    def ctx_seg_column(self, text, off, length, ol_snips=()):
+        return self.ctx_seg_columns([(bytes(text), off, length, list(ol_snips))])[0]
+
+    def dyn_int_columns(self, columns):
+        """columns: list of (int64 values, is_nothing | None, nothing_char) -> list of (ltype, native LE bytes)"""
+        import numpy as np
+        from .lib import GzDynIntJob, GzDynIntResult
+        nj = len(columns)
+        tab = (GzDynIntJob * max(1, nj))()
+        keep = []
+        for i, (values, is_nothing, nothing_char) in enumerate(columns):
+            v = np.ascontiguousarray(values, dtype=np.int64)
+            vb = self.mem.upload(v)
+            mb = None if is_nothing is None else self.mem.upload(np.ascontiguousarray(is_nothing, dtype=np.uint8))
+            ob = self.mem.alloc(8 * len(v) + 16); rb = self.mem.alloc(C.sizeof(GzDynIntResult))
+            keep.append((vb, mb, ob, rb))
+            j = tab[i]
+            j.values = self.mem.ptr(vb); j.is_nothing = self.mem.ptr(mb) if mb is not None else None; j.n = len(v)
+            j.nothing_char = int(nothing_char); j.out = self.mem.ptr(ob); j.result_dev = self.mem.ptr(rb)
+        self._check(self.L.gz_dyn_int_columns(self.h, tab, nj), "gz_dyn_int_columns")
+        self.sync()
+        res = []
+        for vb, mb, ob, rb in keep:
+            r = GzDynIntResult.from_buffer_copy(self.mem.download(rb, C.sizeof(GzDynIntResult)))
+            res.append((r.ltype, self.mem.download(ob, r.len)))
+        return res
+
+    def dyn_int_column(self, values, is_nothing=None, nothing_char=0):
+        return self.dyn_int_columns([(values, is_nothing, nothing_char)])[0]
+
+    def local_blob_columns(self, columns):
+        """columns: list of (text bytes | device buffer, off, len, add_nul) -> list of bytes"""
+        import numpy as np
+        from .lib import GzBlobJob
+        nj = len(columns)
+        tab = (GzBlobJob * max(1, nj))()
+        keep, texts = [], {}
+        for i, (text, off, length, add_nul) in enumerate(columns):
+            off = np.ascontiguousarray(off, dtype=np.uint32); length = np.ascontiguousarray(length, dtype=np.uint32)
+            if isinstance(text, (bytes, bytearray)):
+                if id(text) not in texts:
+                    texts[id(text)] = self.mem.upload(text)
+                tbuf = texts[id(text)]
+            else:
+                tbuf = text
+            cap = int(length.astype(np.uint64).sum()) + len(off)
+            ofb, lb, ob, rb = self.mem.upload(off), self.mem.upload(length), self.mem.alloc(cap + 16), self.mem.alloc(8)
+            keep.append((tbuf, ofb, lb, ob, rb))
+            j = tab[i]
+            j.text = self.mem.ptr(tbuf); j.off = self.mem.ptr(ofb); j.len = self.mem.ptr(lb); j.n = len(off)
+            j.add_nul = int(bool(add_nul)); j.out = self.mem.ptr(ob); j.out_len_dev = self.mem.ptr(rb)
+        self._check(self.L.gz_local_blob_columns(self.h, tab, nj), "gz_local_blob_columns")
+        self.sync()
+        return [self.mem.download(ob, int(np.frombuffer(self.mem.download(rb, 8), dtype=np.uint64)[0])) for _, _, _, ob, rb in keep]
+
+    # ---- N1 (first part): lines, FASTQ records, tokens ----------------------------------------------------
+    def text_lines(self, text, cap=None, on_device=False):
+        """seg_get_next_line over the whole buffer -> (line_off, line_len) numpy arrays (or device buffers + count)"""
+        import numpy as np
+        tbuf = self.mem.upload(text) if isinstance(text, (bytes, bytearray)) else text
+        n = len(text) if isinstance(text, (bytes, bytearray)) else int(tbuf.numel() if hasattr(tbuf, "numel") else tbuf.size)
+        if cap is None:
+            cap = (bytes(text).count(b"\n") + 1) if isinstance(text, (bytes, bytearray)) else n // 2 + 1
+        ob, lb, rb = self.mem.alloc(4 * cap + 16), self.mem.alloc(4 * cap + 16), self.mem.alloc(16)
+        self._check(self.L.gz_text_lines(self.h, self.mem.ptr(tbuf), n, self.mem.ptr(ob), self.mem.ptr(lb), cap, self.mem.ptr(rb)), "gz_text_lines")
+        self.sync()
+        res = np.frombuffer(self.mem.download(rb, 16), dtype=np.uint64)
+        n_lines, status = int(res[0]), int(np.frombuffer(self.mem.download(rb, 16), dtype=np.int32)[2])
+        if status != 1:
+            raise GenozipAMDError("gz_text_lines: %d lines do not fit cap=%d" % (n_lines, cap))
+        if on_device:
+            return tbuf, ob, lb, rb, n_lines
+        return (np.frombuffer(self.mem.download(ob, 4 * n_lines), dtype=np.uint32), np.frombuffer(self.mem.download(lb, 4 * n_lines), dtype=np.uint32))
+
+    def fastq_records(self, text):
+        """-> (first_bad or None, [(off, len)] for line 1, SEQ, line 3, QUAL) from the text of whole reads"""
+        import numpy as np
+        tbuf, ob, lb, rb, n_lines = self.text_lines(text, on_device=True)
+        nr = n_lines // 4
+        cols = [self.mem.alloc(4 * nr + 16) for _ in range(8)]
+        fb = self.mem.alloc(16)
+        self._check(self.L.gz_fastq_records(self.h, self.mem.ptr(tbuf), self.mem.ptr(ob), self.mem.ptr(lb), self.mem.ptr(rb), nr,
+                                            *[self.mem.ptr(c) for c in cols], self.mem.ptr(fb)), "gz_fastq_records")
+        self.sync()
+        raw = self.mem.download(fb, 16)
+        n_reads, first_bad = int(np.frombuffer(raw, dtype=np.uint64)[0]), int(np.frombuffer(raw, dtype=np.uint32)[2])
+        assert n_reads == nr
+        arr = [np.frombuffer(self.mem.download(c, 4 * nr), dtype=np.uint32) for c in cols]
+        return (None if first_bad == 0xffffffff else first_bad), [(arr[2 * i], arr[2 * i + 1]) for i in range(4)]
+
+    def tokenize_column(self, text, off, length, seps):
+        """-> (n_bad, item_off[n_items, n], item_len[n_items, n])"""
+        import numpy as np
+        seps = bytes(seps)
+        off = np.ascontiguousarray(off, dtype=np.uint32); length = np.ascontiguousarray(length, dtype=np.uint32)
+        n, ni = len(off), len(seps) + 1
+        tbuf = self.mem.upload(text) if isinstance(text, (bytes, bytearray)) else text
+        ofb, lb = self.mem.upload(off), self.mem.upload(length)
+        io, il, nb = self.mem.alloc(4 * ni * n + 16), self.mem.alloc(4 * ni * n + 16), self.mem.alloc(16)
+        self._check(self.L.gz_tokenize_column(self.h, self.mem.ptr(tbuf), self.mem.ptr(ofb), self.mem.ptr(lb), n, seps, len(seps),
+                                              self.mem.ptr(io), self.mem.ptr(il), self.mem.ptr(nb)), "gz_tokenize_column")
+        self.sync()
+        return (int(np.frombuffer(self.mem.download(nb, 4), dtype=np.uint32)[0]),
+                np.frombuffer(self.mem.download(io, 4 * ni * n), dtype=np.uint32).reshape(ni, n),
+                np.frombuffer(self.mem.download(il, 4 * ni * n), dtype=np.uint32).reshape(ni, n))
+
     # ---- CODEC_ACGT pre-transform (codec_acgt.c) ----------------------------------------------------------
     def acgt_pack(self, seq, in_place=False):
         """SEQ bytes -> (2-bit packed bytes, exception stream, has_x)"""

@@ -21,6 +21,7 @@
 #include "gz_kernels_arith.h"
 #include "gz_kernels_dec.h"
 #include "gz_kernels_ctx.h"
+#include "gz_kernels_seg.h"
 
 #define GZ_VERSION "genozip_amd 0.1 (gfx950; format parity: genozip 15.0.86)"
 
@@ -428,7 +429,7 @@ static int upload (GzHandle *h, const void *host, size_t bytes, void **dev)
 }
 
 // kernels that run beside the pipelined chain ask for this much LDS so that they never fit on a chain's compute unit
-#define GZ_KEEP_OFF_LDS 8192
+#define GZ_KEEP_OFF_LDS 4608                  // (the chain leaves 4096 bytes of a compute unit free)
 static const uint32_t ARITH_CLASS_WORDS[4] = { 0, 4096, 16384, 40000 };   // 16 KB, 64 KB, 156 KB of LDS
 
 // The arithmetic coder's pipeline of one batch (see gz_kernels_arith.h): which leaves, in how many position chunks
@@ -1049,6 +1050,174 @@ extern "C" int gz_acgt_unpack (GzHandle *h, const uint8_t *packed, const uint8_t
     HIPCHK (h, hipGetLastError ());
     HIPCHK (h, hipStreamSynchronize (h->stream));
     return gz_sync (h) < 0 ? GZ_ERR : GZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// seg-side appends, a column at a time (rows a1-a3; gz_kernels_seg.h)
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int gz_ctx_seg_columns (GzHandle *h, const GzColumnJob *jobs, int n_jobs)
+{
+    if (!h || (n_jobs && !jobs) || n_jobs < 0) return GZ_ERR_ARG;
+    if (!n_jobs) return GZ_OK;
+    HIPCHK (h, hipSetDevice (h->device));
+    std::vector<GzdColumn> J (n_jobs);
+    uint32_t max_n = 0, max_ol = 0, max_all = 0;
+    // one allocation for all the tables: a single memset clears them
+    std::vector<size_t> table_at (n_jobs);
+    size_t table_words = 0;
+    for (int i = 0; i < n_jobs; i++) {
+        const GzColumnJob &u = jobs[i];
+        if (!u.result_dev || u.n >= (1u << 30) || u.n_ol >= (1u << 30)) return GZ_ERR_ARG;
+        if (u.n && (!u.off || !u.len || !u.node_index || !u.node_char_index || !u.node_snip_len || !u.counts || !u.b250)) return GZ_ERR_ARG;
+        if (u.n_ol && (!u.ol_dict || !u.ol_char_index || !u.ol_snip_len || !u.counts)) return GZ_ERR_ARG;
+        GzdColumn &d = J[i];
+        memset (&d, 0, sizeof (d));
+        d.text = u.text; d.off = u.off; d.len = u.len; d.n = u.n;
+        d.ol_dict = u.ol_dict; d.ol_char_index = u.ol_char_index; d.ol_snip_len = u.ol_snip_len; d.n_ol = u.n_ol;
+        d.node_index = u.node_index; d.dict = u.dict; d.dict_cap = u.dict ? u.dict_cap : 0;
+        d.node_char_index = u.node_char_index; d.node_snip_len = u.node_snip_len; d.counts = u.counts; d.b250 = u.b250;
+        d.result = u.result_dev;
+        uint32_t bits = 4;                                         // at most half full
+        while ((1ull << bits) < 2ull * ((uint64_t)u.n + u.n_ol)) bits++;
+        d.table_bits = bits;
+        table_at[i] = table_words; table_words += (size_t)1 << bits;
+        const size_t tiles = ((size_t)u.n + GZ_COL_TILE - 1) / GZ_COL_TILE + 1;
+        if (!(d.rep = (uint32_t *)arena_alloc (h, ((size_t)u.n + 1) * 4))) return GZ_ERR_HIP;
+        if (!(d.rank = (uint32_t *)arena_alloc (h, ((size_t)u.n + 1) * 4))) return GZ_ERR_HIP;
+        if (!(d.tile_a = (uint64_t *)arena_alloc (h, tiles * 8))) return GZ_ERR_HIP;
+        if (!(d.tile_b = (uint64_t *)arena_alloc (h, tiles * 8))) return GZ_ERR_HIP;
+        if (!(d.not_same = (uint32_t *)arena_alloc (h, 4))) return GZ_ERR_HIP;
+        if (u.n > max_n) max_n = u.n;
+        if (u.n_ol > max_ol) max_ol = u.n_ol;
+        if (u.n + u.n_ol > max_all) max_all = u.n + u.n_ol;
+    }
+    uint32_t *tables = (uint32_t *)arena_alloc (h, table_words * 4);
+    if (!tables) return GZ_ERR_HIP;
+    for (int i = 0; i < n_jobs; i++) J[i].table = tables + table_at[i];
+    HIPCHK (h, hipMemsetAsync (tables, 0xff, table_words * 4, h->stream));
+    void *dj;
+    int rc;
+    if ((rc = upload (h, J.data (), J.size () * sizeof (GzdColumn), &dj)) != GZ_OK) return rc;
+    GzdColumn *d_cols = (GzdColumn *)dj;
+    const uint32_t t_n = (max_n + GZ_COL_TILE - 1) / GZ_COL_TILE, t_ol = (max_ol + 255) / 256, t_all = (max_all + 255) / 256;
+    const dim3 g_n (t_n ? t_n : 1, n_jobs), g_jobs (n_jobs);
+    KLAUNCH (h, k_col_clear, dim3 (t_all ? t_all : 1, n_jobs), dim3 (256), 0, d_cols);
+    if (t_ol) KLAUNCH (h, k_col_insert_ol, dim3 (t_ol, n_jobs), dim3 (256), 0, d_cols);
+    if (t_n) {
+        KLAUNCH (h, k_col_insert, g_n, dim3 (256), 0, d_cols);
+        KLAUNCH (h, k_col_first, g_n, dim3 (256), 2048, d_cols);
+        KLAUNCH (h, k_col_scan_a, g_jobs, dim3 (256), 2048, d_cols);
+        KLAUNCH (h, k_col_assign, g_n, dim3 (256), 2048, d_cols);
+        KLAUNCH (h, k_col_node, g_n, dim3 (256), 2048, d_cols);
+        KLAUNCH (h, k_col_scan_b, g_jobs, dim3 (256), 2048, d_cols);
+        KLAUNCH (h, k_col_b250, g_n, dim3 (256), 2048, d_cols);
+    }
+    HIPCHK (h, hipGetLastError ());
+    return GZ_OK;
+}
+
+extern "C" int gz_dyn_int_columns (GzHandle *h, const GzDynIntJob *jobs, int n_jobs)
+{
+    if (!h || (n_jobs && !jobs) || n_jobs < 0) return GZ_ERR_ARG;
+    if (!n_jobs) return GZ_OK;
+    HIPCHK (h, hipSetDevice (h->device));
+    std::vector<GzdDynInt> J (n_jobs);
+    uint64_t max_tiles = 1;
+    for (int i = 0; i < n_jobs; i++) {
+        const GzDynIntJob &u = jobs[i];
+        if (!u.result_dev || (u.n && (!u.values || !u.out)) || ((uintptr_t)u.out & 7) || u.n >= (1ull << 40)) return GZ_ERR_ARG;
+        GzdDynInt &d = J[i];
+        d.values = u.values; d.is_nothing = u.is_nothing; d.n = u.n; d.nothing_char = u.nothing_char; d.out = u.out; d.result = u.result_dev;
+        const uint64_t tiles = (u.n + GZ_DYN_TILE - 1) / GZ_DYN_TILE;
+        if (!(d.tile_min = (int64_t *)arena_alloc (h, (tiles + 1) * 8))) return GZ_ERR_HIP;
+        if (!(d.tile_max = (int64_t *)arena_alloc (h, (tiles + 1) * 8))) return GZ_ERR_HIP;
+        if (tiles > max_tiles) max_tiles = tiles;
+    }
+    void *dj;
+    int rc;
+    if ((rc = upload (h, J.data (), J.size () * sizeof (GzdDynInt), &dj)) != GZ_OK) return rc;
+    KLAUNCH (h, k_dyn_minmax, dim3 ((uint32_t)max_tiles, n_jobs), dim3 (256), 4096, (GzdDynInt *)dj);
+    KLAUNCH (h, k_dyn_decide, dim3 (n_jobs), dim3 (256), 4096, (GzdDynInt *)dj);
+    KLAUNCH (h, k_dyn_write, dim3 ((uint32_t)max_tiles, n_jobs), dim3 (256), 0, (GzdDynInt *)dj);
+    HIPCHK (h, hipGetLastError ());
+    return GZ_OK;
+}
+
+extern "C" int gz_local_blob_columns (GzHandle *h, const GzBlobJob *jobs, int n_jobs)
+{
+    if (!h || (n_jobs && !jobs) || n_jobs < 0) return GZ_ERR_ARG;
+    if (!n_jobs) return GZ_OK;
+    HIPCHK (h, hipSetDevice (h->device));
+    std::vector<GzdBlob> J (n_jobs);
+    uint32_t max_tiles = 1;
+    for (int i = 0; i < n_jobs; i++) {
+        const GzBlobJob &u = jobs[i];
+        if (!u.out_len_dev || (u.n && (!u.text || !u.off || !u.len || !u.out))) return GZ_ERR_ARG;
+        GzdBlob &d = J[i];
+        d.text = u.text; d.off = u.off; d.len = u.len; d.n = u.n; d.add_nul = u.add_nul ? 1 : 0; d.out = u.out; d.out_len = u.out_len_dev;
+        const uint32_t tiles = (u.n + GZ_COL_TILE - 1) / GZ_COL_TILE;
+        if (!(d.tile = (uint64_t *)arena_alloc (h, ((size_t)tiles + 1) * 8))) return GZ_ERR_HIP;
+        if (tiles > max_tiles) max_tiles = tiles;
+    }
+    void *dj;
+    int rc;
+    if ((rc = upload (h, J.data (), J.size () * sizeof (GzdBlob), &dj)) != GZ_OK) return rc;
+    KLAUNCH (h, k_blob_sum, dim3 (max_tiles, n_jobs), dim3 (256), 2048, (GzdBlob *)dj);
+    KLAUNCH (h, k_blob_scan, dim3 (n_jobs), dim3 (256), 2048, (GzdBlob *)dj);
+    KLAUNCH (h, k_blob_copy, dim3 (max_tiles, n_jobs), dim3 (256), 2048, (GzdBlob *)dj);
+    HIPCHK (h, hipGetLastError ());
+    return GZ_OK;
+}
+
+extern "C" int gz_text_lines (GzHandle *h, const uint8_t *text, uint64_t n_bytes, uint32_t *line_off, uint32_t *line_len, uint32_t cap,
+                              GzLinesResult *result_dev)
+{
+    if (!h || !result_dev || (n_bytes && !text) || (cap && (!line_off || !line_len)) || n_bytes >= 0xffffffffull) return GZ_ERR_ARG;
+    HIPCHK (h, hipSetDevice (h->device));
+    GzdLines L;
+    L.text = text; L.n = n_bytes; L.off = line_off; L.len = line_len; L.cap = cap; L.result = result_dev;
+    const uint32_t tiles = (uint32_t)((n_bytes + GZ_NL_TILE - 1) / GZ_NL_TILE);
+    if (!(L.start = (uint32_t *)arena_alloc (h, ((size_t)cap + 2) * 4))) return GZ_ERR_HIP;
+    if (!(L.tile = (uint64_t *)arena_alloc (h, ((size_t)tiles + 1) * 8))) return GZ_ERR_HIP;
+    if (tiles) KLAUNCH (h, k_nl_count, dim3 (tiles), dim3 (256), 2048, L);
+    KLAUNCH (h, k_nl_scan, dim3 (1), dim3 (256), 2048, L);
+    if (tiles) KLAUNCH (h, k_nl_write, dim3 (tiles), dim3 (256), 2048, L);
+    if (cap) KLAUNCH (h, k_lines_finish, dim3 ((cap + 255) / 256), dim3 (256), 0, L);
+    HIPCHK (h, hipGetLastError ());
+    return GZ_OK;
+}
+
+extern "C" int gz_fastq_records (GzHandle *h, const uint8_t *text, const uint32_t *line_off, const uint32_t *line_len,
+                                 const GzLinesResult *lines_dev, uint32_t max_reads,
+                                 uint32_t *l1_off, uint32_t *l1_len, uint32_t *seq_off, uint32_t *seq_len,
+                                 uint32_t *l3_off, uint32_t *l3_len, uint32_t *qual_off, uint32_t *qual_len, GzFastqResult *result_dev)
+{
+    if (!h || !result_dev || !lines_dev) return GZ_ERR_ARG;
+    if (max_reads && (!text || !line_off || !line_len || !l1_off || !l1_len || !seq_off || !seq_len || !l3_off || !l3_len || !qual_off || !qual_len)) return GZ_ERR_ARG;
+    HIPCHK (h, hipSetDevice (h->device));
+    GzdFastq F;
+    F.text = text; F.line_off = line_off; F.line_len = line_len; F.lines = lines_dev; F.max_reads = max_reads; F.result = result_dev;
+    uint32_t *cols[8] = { l1_off, l1_len, seq_off, seq_len, l3_off, l3_len, qual_off, qual_len };
+    for (int i = 0; i < 8; i++) F.col[i] = cols[i];
+    HIPCHK (h, hipMemsetAsync (result_dev, 0xff, sizeof (GzFastqResult), h->stream));   // first_bad = none (the kernel sets the rest)
+    KLAUNCH (h, k_fastq_records, dim3 (max_reads ? (max_reads + 255) / 256 : 1), dim3 (256), 0, F);
+    HIPCHK (h, hipGetLastError ());
+    return GZ_OK;
+}
+
+extern "C" int gz_tokenize_column (GzHandle *h, const uint8_t *text, const uint32_t *off, const uint32_t *len, uint32_t n,
+                                   const char *seps, uint32_t n_seps, uint32_t *item_off, uint32_t *item_len, uint32_t *n_bad_dev)
+{
+    if (!h || !n_bad_dev || n_seps > GZ_TOK_MAX_SEPS || (n_seps && !seps) || (n && (!text || !off || !len || !item_off || !item_len))) return GZ_ERR_ARG;
+    HIPCHK (h, hipSetDevice (h->device));
+    GzdTokens T;
+    memset (&T, 0, sizeof (T));
+    T.text = text; T.off = off; T.len = len; T.n = n; T.n_seps = n_seps; T.item_off = item_off; T.item_len = item_len; T.n_bad = n_bad_dev;
+    for (uint32_t i = 0; i < n_seps; i++) T.seps[i] = (uint8_t)seps[i];
+    HIPCHK (h, hipMemsetAsync (n_bad_dev, 0, 4, h->stream));
+    if (n) KLAUNCH (h, k_tokenize, dim3 ((n + 255) / 256), dim3 (256), 0, T);
+    HIPCHK (h, hipGetLastError ());
+    return GZ_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------

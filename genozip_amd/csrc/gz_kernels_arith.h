@@ -576,6 +576,9 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
 
 // grid (listed leaves, GZ_MODEL_GRID_Y [+ GZ_MODEL_GRID_RUN for lists with run-length leaves])
 #define GZ_MODEL_GRID_RUN 66               // run models: one per present symbol, 256 and 257
+// (tried: a build of its own for the alphabets of up to 64 symbols - 42 instead of 87 vector registers, 8 instead of 5
+//  waves per SIMD - launched beside one for the wide alphabets: no faster (4 M read pairs: 84.0 -> 86.8 ms per step).
+//  With every SIMD holding several of these waves it is the issue slots, not the waves in flight, that run out.)
 __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, const GzDivMagic *magic_tab, uint32_t p0, uint32_t chunk)
 {
     GzdLeaf &L = leaves[list[blockIdx.x]];

@@ -37,6 +37,33 @@ class GzB250Job(C.Structure):
                 ("status_dev", C.c_void_p)]
 
 
+class GzColumnResult(C.Structure):
+    _fields_ = [("dict_len", C.c_uint64), ("b250_len", C.c_uint64), ("b250_count", C.c_uint64), ("n_new", C.c_uint32),
+                ("all_the_same", C.c_uint32), ("status", C.c_int32), ("reserved", C.c_uint32)]
+
+
+class GzColumnJob(C.Structure):
+    _fields_ = [("text", C.c_void_p), ("off", C.c_void_p), ("len", C.c_void_p), ("n", C.c_uint32),
+                ("ol_dict", C.c_void_p), ("ol_char_index", C.c_void_p), ("ol_snip_len", C.c_void_p), ("n_ol", C.c_uint32),
+                ("node_index", C.c_void_p), ("dict", C.c_void_p), ("dict_cap", C.c_uint64),
+                ("node_char_index", C.c_void_p), ("node_snip_len", C.c_void_p), ("counts", C.c_void_p),
+                ("b250", C.c_void_p), ("result_dev", C.c_void_p)]
+
+
+class GzDynIntResult(C.Structure):
+    _fields_ = [("len", C.c_uint64), ("ltype", C.c_int32), ("width", C.c_uint32), ("order", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class GzDynIntJob(C.Structure):
+    _fields_ = [("values", C.c_void_p), ("is_nothing", C.c_void_p), ("n", C.c_uint64), ("nothing_char", C.c_uint32),
+                ("out", C.c_void_p), ("result_dev", C.c_void_p)]
+
+
+class GzBlobJob(C.Structure):
+    _fields_ = [("text", C.c_void_p), ("off", C.c_void_p), ("len", C.c_void_p), ("n", C.c_uint32), ("add_nul", C.c_uint32),
+                ("out", C.c_void_p), ("out_len_dev", C.c_void_p)]
+
+
 class GzSection(C.Structure):
     _fields_ = [("data", C.c_void_p), ("data_len", C.c_uint32), ("data_len_dev", C.c_void_p),
                 ("section_type", C.c_uint8), ("codec", C.c_uint8), ("sub_codec", C.c_uint8), ("flags", C.c_uint8),
@@ -59,6 +86,8 @@ ABI_SYMBOLS = (
     "gz_b250_generate", "gz_b250_generate_batch", "gz_local_generate", "gz_local_to_native",
     "gz_vb_z_bound", "gz_vb_compress_batch", "gz_vb_uncompress", "gz_adler32",
     "gz_acgt_packed_len", "gz_acgt_pack", "gz_acgt_unpack",
+    "gz_ctx_seg_columns", "gz_dyn_int_columns", "gz_local_blob_columns",
+    "gz_text_lines", "gz_fastq_records", "gz_tokenize_column",
 )
 
 
@@ -109,4 +138,11 @@ def load(path=None):
     L.gz_acgt_packed_len.argtypes = [C.c_uint64]
     L.gz_acgt_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
     L.gz_acgt_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.gz_ctx_seg_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.gz_dyn_int_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.gz_local_blob_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.gz_text_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.gz_fastq_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 9
+    L.gz_tokenize_column.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]
     return L

@@ -200,6 +200,84 @@ int gz_acgt_pack (GzHandle *h, const uint8_t *seq, uint64_t n_bases, uint8_t *pa
 /* codec_acgt_uncompress + codec_xcgt_uncompress (src/codec_acgt.c:177-199,218-246); x == NULL: flags.acgt_no_x */
 int gz_acgt_unpack (GzHandle *h, const uint8_t *packed, const uint8_t *x, uint64_t n_bases, uint8_t *seq);
 
+/* ---- seg-side appends, a column at a time -------------------------------------------------
+ * What the segmenter leaves in a context after evaluating the snips of one field of every line: node indices, the
+ * VBlock's new dictionary words and nodes, counts and the seg-format b250 (ctx_create_node_do src/context.c:320-404
+ * with hash_get_entry_for_seg src/hash.c:530-576 and ctx_insert_to_dict src/context.c:50-71; b250_seg_append
+ * src/b250.c:112-163) - computed for the whole column at once: a snip's node index is its index in ol_nodes (the
+ * dictionary cloned from the file-level context, ctx_clone) or ol_nodes.len + the rank of its first occurrence in the
+ * VBlock. All pointers device; asynchronous on the handle's stream (results valid after gz_sync).
+ *   snip k = text[off[k] .. off[k]+len[k]); len 0 = WORD_INDEX_EMPTY, or WORD_INDEX_MISSING if off[k] == GZ_SNIP_MISSING
+ *   (the reference's snip == NULL, context.c:331-335). Limits: n < 2^30, the VBlock's dictionary < 4 GB.
+ * The b250 produced here is the input of gz_b250_generate once the host has merged the new words (a4) and knows
+ * node2word[]. */
+#define GZ_SNIP_MISSING 0xffffffffu
+typedef struct {
+    uint64_t dict_len;            /* bytes of `dict` (every new snip + its NUL)                                   */
+    uint64_t b250_len;            /* bytes of `b250`: ONE entry while the column is all-the-same (b250.c:117-141)  */
+    uint64_t b250_count;          /* entries appended (ctx->b250.count)                                            */
+    uint32_t n_new;               /* nodes new to the VBlock (ctx->nodes.len)                                      */
+    uint32_t all_the_same;        /* ctx->flags.all_the_same                                                       */
+    int32_t  status;              /* 1 ok; 0: dict_cap too small (dict not written, everything else is valid)      */
+    uint32_t reserved;
+} GzColumnResult;
+typedef struct {
+    const uint8_t  *text; const uint32_t *off, *len; uint32_t n;
+    const uint8_t  *ol_dict; const uint64_t *ol_char_index; const uint32_t *ol_snip_len; uint32_t n_ol;   /* CtxNode.char_index / .snip_len of ol_nodes */
+    int32_t  *node_index;         /* [n]                                                                           */
+    uint8_t  *dict; uint64_t dict_cap;
+    uint64_t *node_char_index; uint32_t *node_snip_len;      /* [n]: the CtxNode fields of the new nodes           */
+    uint32_t *counts;             /* [n_ol + n]: occurrences in this VBlock per node (vctx->counts)                */
+    uint8_t  *b250;               /* [4 n]                                                                         */
+    GzColumnResult *result_dev;
+} GzColumnJob;
+int gz_ctx_seg_columns (GzHandle *h, const GzColumnJob *jobs, int n_jobs);
+
+/* dyn_int_append over a column (src/dyn_int.c:232-320; final type dyn_int_get_ltype :27-43 with lt_order :17): the
+ * values at the narrowest of UINT8, INT8, UINT16, INT16, UINT32, INT32, INT64 that holds them all (one less at the top
+ * when the context has a nothing_char; entries flagged in is_nothing are stored as the type's maximum, :322-345),
+ * native little endian - gz_local_generate then puts them in file order. out: 8 n bytes, 8-byte aligned. */
+typedef struct { uint64_t len; int32_t ltype; uint32_t width; uint32_t order; uint32_t reserved; } GzDynIntResult;
+typedef struct {
+    const int64_t *values; const uint8_t *is_nothing /* or NULL */; uint64_t n; uint32_t nothing_char;
+    uint8_t *out; GzDynIntResult *result_dev;
+} GzDynIntJob;
+int gz_dyn_int_columns (GzHandle *h, const GzDynIntJob *jobs, int n_jobs);
+
+/* seg_add_to_local_fixed_do over a column (src/seg.c:1268-1287): the field of every line gathered into the context's
+ * local, each followed by a NUL if add_nul - e.g. SEQ of every read -> NONREF.local, QUAL -> QUAL.local. */
+typedef struct {
+    const uint8_t *text; const uint32_t *off, *len; uint32_t n; uint32_t add_nul;
+    uint8_t *out; uint64_t *out_len_dev;
+} GzBlobJob;
+int gz_local_blob_columns (GzHandle *h, const GzBlobJob *jobs, int n_jobs);
+
+/* ---- N1 (first part): the line buffer -> lines -> FASTQ records -> tokens -------------------------
+ * What the segmenter's line loop does before any context is touched, for the whole buffer at once. All pointers
+ * device, asynchronous, text < 4 GB per call.
+ * gz_text_lines: seg_get_next_line (src/seg.c:200-236) - offset and length of every line (length without the newline
+ *   and without a '\r' before it; a last line without a newline counts). off/len hold `cap` entries; n_lines is the
+ *   true count, status 0 if it exceeds cap (then only the first cap lines are written).
+ * gz_fastq_records: fastq_seg_get_lines (src/fastq.c:1002-1135) - every 4 lines are a read; the 8 output arrays of
+ *   max_reads entries are (offset, length) of line 1 without its '@', SEQ, line 3 without its '+', QUAL. first_bad =
+ *   the first read that is not '@'.. / SEQ / '+'.. / QUAL with len(QUAL) == len(SEQ) (the reference aborts there,
+ *   :1008-1010,1076,1121), 0xffffffff if none.
+ * gz_tokenize_column: the items of a container whose separators are known - the QNAME flavors (src/qname_flavors.h:21-49,
+ *   src/qname.c:715-866; seg_get_next_item src/seg.c:153-198): item i of a snip ends at the first seps[i] after item
+ *   i-1, the last item is the rest; item-major output [i * n + k], ready to be columns of gz_ctx_seg_columns /
+ *   gz_dyn_int_columns. A snip lacking a separator counts in *n_bad_dev and stays whole in item 0 (the reference
+ *   segs such a qname as one snip). n_seps <= 15. */
+typedef struct { uint64_t n_lines; int32_t status; uint32_t reserved; } GzLinesResult;
+int gz_text_lines (GzHandle *h, const uint8_t *text, uint64_t n_bytes, uint32_t *line_off, uint32_t *line_len, uint32_t cap,
+                   GzLinesResult *result_dev);
+typedef struct { uint64_t n_reads; uint32_t first_bad; uint32_t reserved; } GzFastqResult;
+int gz_fastq_records (GzHandle *h, const uint8_t *text, const uint32_t *line_off, const uint32_t *line_len,
+                      const GzLinesResult *lines_dev, uint32_t max_reads,
+                      uint32_t *l1_off, uint32_t *l1_len, uint32_t *seq_off, uint32_t *seq_len,
+                      uint32_t *l3_off, uint32_t *l3_len, uint32_t *qual_off, uint32_t *qual_len, GzFastqResult *result_dev);
+int gz_tokenize_column (GzHandle *h, const uint8_t *text, const uint32_t *off, const uint32_t *len, uint32_t n,
+                        const char *seps, uint32_t n_seps, uint32_t *item_off, uint32_t *item_len, uint32_t *n_bad_dev);
+
 #ifdef __cplusplus
 }
 #endif

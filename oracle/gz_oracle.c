@@ -1424,3 +1424,174 @@ void gzo_acgt_unpack (const uint8_t *packed, const uint8_t *x, uint64_t n, uint8
         seq[i] = (!x || x[i] == 0) ? (uint8_t)b : x[i] == 1 ? (uint8_t)(b + 32) : x[i];
     }
 }
+
+/* ================================================================================================================
+ * seg-side appends, a column at a time (rows a1-a3)
+ * ================================================================================================================ */
+
+/* hash.h:30-52: rotate-xor over the snip's bytes, then modulo the table length */
+static uint32_t o_hash_do (uint32_t hash_len, const uint8_t *snip, uint32_t snip_len)
+{
+    uint64_t result = 0;
+    for (uint32_t i = 0; i < snip_len; i++) result = ((result << 23) | (result >> 41)) ^ (uint64_t)snip[i];
+    return (uint32_t)(result % hash_len);
+}
+
+int gzo_ctx_seg_column (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n,
+                        const uint8_t *ol_dict, const uint64_t *ol_char_index, const uint32_t *ol_snip_len, uint32_t n_ol,
+                        GzoColumn *out)
+{
+    /* one chained table for both node arrays (the reference keeps two, hash.c:530-576: ol_nodes are looked up first
+     * and a snip found there is never added to the VBlock's own nodes - the same thing) */
+    uint32_t hash_len = 65521;
+    while (hash_len < 2 * (n + n_ol) && hash_len < 0x7fffffffu / 2) hash_len = hash_len * 2 + 1;
+    uint32_t *head = malloc ((size_t)hash_len * 4), *next = malloc ((size_t)(n_ol + n + 1) * 4);
+    if (!head || !next) { free (head); free (next); return -1; }
+    memset (head, 0xff, (size_t)hash_len * 4);
+    for (uint32_t i = 0; i < n_ol; i++) {
+        const uint32_t hv = o_hash_do (hash_len, ol_dict + ol_char_index[i], ol_snip_len[i]);
+        next[i] = head[hv]; head[hv] = i;
+    }
+    memset (out->counts, 0, (size_t)(n_ol + n) * 4);
+    out->dict_len = 0; out->n_new = 0; out->b250_len = 0; out->b250_count = 0; out->all_the_same = 0;
+    int32_t first_ni = 0;
+    for (uint64_t k = 0; k < n; k++) {
+        int32_t ni;
+        const uint8_t *snip = off[k] == GZO_SNIP_MISSING ? NULL : text + off[k];
+        if (!len[k]) ni = snip ? -3 : -4;                                   /* context.c:331-335 */
+        else {
+            const uint32_t hv = o_hash_do (hash_len, snip, len[k]);
+            uint32_t e = head[hv];
+            for (; e != 0xffffffffu; e = next[e]) {
+                const uint8_t *d = e < n_ol ? ol_dict + ol_char_index[e] : out->dict + out->node_char_index[e - n_ol];
+                const uint32_t dl = e < n_ol ? ol_snip_len[e] : out->node_snip_len[e - n_ol];
+                if (dl == len[k] && !memcmp (d, snip, dl)) break;
+            }
+            if (e == 0xffffffffu) {                                         /* a new node: context.c:364-384 */
+                e = n_ol + out->n_new;
+                out->node_char_index[out->n_new] = out->dict_len;
+                out->node_snip_len[out->n_new] = len[k];
+                memcpy (out->dict + out->dict_len, snip, len[k]);
+                out->dict[out->dict_len + len[k]] = 0;                      /* context.c:62-65 */
+                out->dict_len += (uint64_t)len[k] + 1;
+                out->n_new++;
+                next[e] = head[hv]; head[hv] = e;
+            }
+            out->counts[e]++;
+            ni = (int32_t)e;
+        }
+        out->node_index[k] = ni;
+        /* b250_seg_append, b250.c:112-163 */
+        if (!out->b250_count) { out->all_the_same = 1; first_ni = ni; out->b250_len = gzo_b250_seg_put (out->b250, ni, n_ol); }
+        else if (out->all_the_same && ni == first_ni) { /* only the count goes up */ }
+        else {
+            if (out->all_the_same) {                                        /* no longer: write out the copies held back */
+                const uint32_t wl = (uint32_t)out->b250_len;
+                for (uint64_t c = 1; c < out->b250_count; c++) memcpy (out->b250 + c * wl, out->b250, wl);
+                out->b250_len = out->b250_count * wl;
+                out->all_the_same = 0;
+            }
+            out->b250_len += gzo_b250_seg_put (out->b250 + out->b250_len, ni, n_ol);
+        }
+        out->b250_count++;
+    }
+    free (head); free (next);
+    return 0;
+}
+
+int gzo_dyn_int_column (const int64_t *values, const uint8_t *is_nothing, uint64_t n, int nothing_char, uint8_t *out)
+{
+    /* lt_order, dyn_int.c:17 (GZ_LT_* numbering: INT8 1, UINT8 2, INT16 3, UINT16 4, INT32 5, UINT32 6, INT64 7) */
+    static const int     order_lt[8]  = { 0, 2, 1, 4, 3, 6, 5, 7 };
+    static const int64_t order_min[8] = { 0, 0, -128, 0, -32768, 0, -2147483648LL, INT64_MIN };
+    static const int64_t order_max[8] = { 0, 255, 127, 65535, 32767, 4294967295LL, 2147483647LL, INT64_MAX };
+    const int nc = nothing_char != 0;
+    /* the walk of dyn_init_prepare (dyn_int.c:232-282), value by value */
+    int order = 0; int64_t mn = 0, mx = 0;
+    for (uint64_t k = 0; k < n; k++) {
+        if (is_nothing && is_nothing[k]) {
+            if (!order) { order = 1; mn = mx = 0xff; }                      /* dyn_int_append_nothing_char :327-328 */
+            continue;
+        }
+        const int64_t v = values[k];
+        if (!order) { order = 1; mn = mx = v; }
+        if (v < mn) mn = v; else if (v > mx) mx = v;
+        if (v < order_min[order] || v > order_max[order] - nc)
+            for (int i = order + 1; i < 8; i++)
+                if (mn >= order_min[i] && mx <= order_max[i] - nc) { order = i; break; }
+    }
+    if (!order) order = 1;                                                  /* (never appended to: nothing to write either) */
+    const int lt = order_lt[order];
+    const int w = order <= 2 ? 1 : order <= 4 ? 2 : order <= 6 ? 4 : 8;
+    for (uint64_t k = 0; k < n; k++) {
+        const int64_t v = (is_nothing && is_nothing[k]) ? order_max[order] : values[k];
+        memcpy (out + k * w, &v, w);                                        /* little endian host: the low bytes */
+    }
+    return lt;
+}
+
+uint64_t gzo_local_blob_column (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n, int add_nul, uint8_t *out)
+{
+    uint64_t at = 0;
+    for (uint64_t k = 0; k < n; k++) {
+        if (len[k]) memcpy (out + at, text + off[k], len[k]);
+        at += len[k];
+        if (add_nul) out[at++] = 0;
+    }
+    return at;
+}
+
+/* ---- N1 (first part): lines, FASTQ records, tokens ---------------------------------------------------------------- */
+uint64_t gzo_text_lines (const uint8_t *text, uint64_t n, uint32_t *off, uint32_t *len, uint64_t cap)
+{
+    uint64_t k = 0, start = 0;
+    for (uint64_t i = 0; i < n; i++)
+        if (text[i] == '\n') {                                                 /* seg.c:208-220 */
+            if (k < cap) { off[k] = (uint32_t)start; len[k] = (uint32_t)(i - start - (i > start && text[i - 1] == '\r')); }
+            k++; start = i + 1;
+        }
+    if (start < n) {                                                           /* seg.c:227-230 */
+        if (k < cap) { off[k] = (uint32_t)start; len[k] = (uint32_t)(n - start - (text[n - 1] == '\r')); }
+        k++;
+    }
+    return k;
+}
+
+long gzo_fastq_records (const uint8_t *text, const uint32_t *line_off, const uint32_t *line_len, uint64_t n_lines,
+                        uint32_t *l1_off, uint32_t *l1_len, uint32_t *seq_off, uint32_t *seq_len,
+                        uint32_t *l3_off, uint32_t *l3_len, uint32_t *qual_off, uint32_t *qual_len)
+{
+    long bad = 0;
+    for (uint64_t r = 0; r < n_lines / 4; r++) {
+        const uint32_t *o = line_off + 4 * r, *l = line_len + 4 * r;
+        const int ok = l[0] >= 1 && text[o[0]] == '@' && l[2] >= 1 && text[o[2]] == '+' && l[1] == l[3];
+        if (!ok && !bad) bad = -1 - (long)r;
+        l1_off[r] = o[0] + 1; l1_len[r] = l[0] ? l[0] - 1 : 0;
+        seq_off[r] = o[1];    seq_len[r] = l[1];
+        l3_off[r] = o[2] + 1; l3_len[r] = l[2] ? l[2] - 1 : 0;
+        qual_off[r] = o[3];   qual_len[r] = l[3];
+    }
+    return bad;
+}
+
+uint64_t gzo_tokenize_column (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n,
+                              const uint8_t *seps, uint32_t n_seps, uint32_t *item_off, uint32_t *item_len)
+{
+    uint64_t n_bad = 0;
+    for (uint64_t k = 0; k < n; k++) {
+        uint32_t at = 0, i = 0;
+        for (; i < n_seps; i++) {
+            uint32_t e = at;
+            while (e < len[k] && text[off[k] + e] != seps[i]) e++;
+            if (e == len[k]) break;                                            /* separator missing */
+            item_off[(uint64_t)i * n + k] = off[k] + at; item_len[(uint64_t)i * n + k] = e - at;
+            at = e + 1;
+        }
+        if (i < n_seps) {
+            n_bad++;
+            for (uint32_t j = 0; j <= n_seps; j++) { item_off[(uint64_t)j * n + k] = off[k]; item_len[(uint64_t)j * n + k] = j ? 0 : len[k]; }
+        }
+        else { item_off[(uint64_t)n_seps * n + k] = off[k] + at; item_len[(uint64_t)n_seps * n + k] = len[k] - at; }
+    }
+    return n_bad;
+}

@@ -125,6 +125,65 @@ uint64_t gzo_acgt_packed_len (uint64_t n);                     /* bytes: whole 6
 int  gzo_acgt_pack (const uint8_t *seq, uint64_t n, uint8_t *packed, uint8_t *x);   /* x may be seq; returns has_x */
 void gzo_acgt_unpack (const uint8_t *packed, const uint8_t *x /* or NULL */, uint64_t n, uint8_t *seq);   /* codec_acgt.c:177-199,232-246 */
 
+/* ---- seg-side appends (rows a1-a3): a whole column of one context at once ---------------------------------------
+ * Test infrastructure like the rest of this file. What the segmenter leaves behind in a context after evaluating a
+ * column of snips one by one (ctx_create_node_do context.c:320-404, hash_get_entry_for_seg hash.c:530-576,
+ * ctx_insert_to_dict context.c:50-71, b250_seg_append b250.c:112-163): for every snip its node index - the index in
+ * ol_nodes when the snip is in the dictionary cloned from the file-level context, else ol_nodes_len + the rank of
+ * its first occurrence in this VBlock; the VBlock's own dictionary (new snips in order of first occurrence, each
+ * followed by a NUL) and nodes (char_index, snip_len); counts[] (one per node, occurrences in this VBlock; empty and
+ * missing snips are not counted, context.c:331-335); and the seg-format b250 with its all-the-same collapse (while
+ * every entry is the same node only ONE entry is stored and `count` goes up).
+ * A snip with len 0 is WORD_INDEX_EMPTY (-3), or WORD_INDEX_MISSING (-4) when off == GZO_SNIP_MISSING (the reference's
+ * snip == NULL). The hash table itself (hash.h:30-52) never reaches the file; only its effect does. */
+#define GZO_SNIP_MISSING 0xffffffffu
+typedef struct {
+    int32_t  *node_index;        /* [n] */
+    uint8_t  *dict;              /* [sum of (len+1) over the snips] */
+    uint64_t  dict_len;
+    uint64_t *node_char_index;   /* [n] */
+    uint32_t *node_snip_len;     /* [n] */
+    uint32_t  n_new;
+    uint32_t *counts;            /* [n_ol + n] */
+    uint8_t  *b250;              /* [4 n] */
+    uint64_t  b250_len;
+    uint64_t  b250_count;
+    int       all_the_same;
+} GzoColumn;
+int gzo_ctx_seg_column (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n,
+                        const uint8_t *ol_dict, const uint64_t *ol_char_index, const uint32_t *ol_snip_len, uint32_t n_ol,
+                        GzoColumn *out);
+
+/* dyn_int_append over a whole column (dyn_int.c:17,232-320, dyn_int_get_ltype :27-43): the final local type is the
+ * first of UINT8, INT8, UINT16, INT16, UINT32, INT32, INT64 that holds every value (one less at the top when the
+ * context has a nothing_char, whose entries are stored as the type's maximum, :322-345); out = the values in that
+ * width, native little endian (zip_generate_local then orders them). Returns the ltype (GZ_LT_* numbering). */
+int gzo_dyn_int_column (const int64_t *values, const uint8_t *is_nothing /* or NULL */, uint64_t n, int nothing_char,
+                        uint8_t *out /* 8 n */);
+
+/* seg_add_to_local_fixed_do over a column (seg.c:1268-1287): the snips one after the other, each followed by a NUL
+ * if add_nul. Returns the length. */
+uint64_t gzo_local_blob_column (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n, int add_nul, uint8_t *out);
+
+/* ---- N1 (first part): the line buffer -> per-field (offset, length) columns -----------------------------------------
+ * seg_get_next_line (seg.c:200-236) over a whole buffer: start and length of every line, the length without the
+ * newline and without a '\r' before it; a last line without a newline counts. Returns the number of lines
+ * (all of them, even beyond cap; only the first cap are written). */
+uint64_t gzo_text_lines (const uint8_t *text, uint64_t n, uint32_t *off, uint32_t *len, uint64_t cap);
+/* fastq_seg_get_lines (fastq.c:1002-1135): every 4 lines are a read: '@' + line 1, SEQ, '+' + line 3, QUAL. The
+ * columns hold line 1 without its '@', SEQ, line 3 without its '+', QUAL. Returns 0, or -1 - k where read k is the
+ * first that is malformed (line 1 not starting with '@', line 3 not with '+', QUAL and SEQ of different lengths;
+ * :1008-1010,1076,1121). Lines beyond the last whole read are ignored. */
+long gzo_fastq_records (const uint8_t *text, const uint32_t *line_off, const uint32_t *line_len, uint64_t n_lines,
+                        uint32_t *l1_off, uint32_t *l1_len, uint32_t *seq_off, uint32_t *seq_len,
+                        uint32_t *l3_off, uint32_t *l3_len, uint32_t *qual_off, uint32_t *qual_len);
+/* The items of a container whose separators are known (the QNAME flavors, qname_flavors.h:21-49 with qname.c:715-866;
+ * seg_get_next_item seg.c:153-198): item i of snip k ends at the first seps[i] after item i-1, the last item is the
+ * rest. item_off / item_len are item-major: [i * n + k]. A snip that lacks a separator is "bad" (the reference then
+ * segs it whole): item 0 = the whole snip, the others empty. Returns the number of bad snips. */
+uint64_t gzo_tokenize_column (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n,
+                              const uint8_t *seps, uint32_t n_seps, uint32_t *item_off, uint32_t *item_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -194,6 +194,96 @@ class Oracle:
         self.L.gzo_acgt_unpack(bytes(packed), None if x is None else bytes(x), ctypes.c_uint64(n), out)
         return out.raw[:n]
 
+    # ---- seg-side appends, a column at a time (rows a1-a3)
+    def ctx_seg_column(self, text, off, length, ol_snips=()):
+        """-> dict(node_index, dict, node_char_index, node_snip_len, counts, b250, b250_count, all_the_same)"""
+        import numpy as np
+        text = bytes(text)
+        off = np.ascontiguousarray(off, dtype=np.uint32); length = np.ascontiguousarray(length, dtype=np.uint32)
+        n = len(off)
+        ol_dict = b"".join(bytes(w) + b"\0" for w in ol_snips)
+        ol_len = np.array([len(w) for w in ol_snips], dtype=np.uint32)
+        ol_ci = np.zeros(len(ol_snips), dtype=np.uint64)
+        if len(ol_snips) > 1:
+            ol_ci[1:] = np.cumsum(ol_len[:-1].astype(np.uint64) + 1)
+        n_ol = len(ol_snips)
+
+        class Col(ctypes.Structure):
+            _fields_ = [("node_index", ctypes.c_void_p), ("dict", ctypes.c_void_p), ("dict_len", ctypes.c_uint64),
+                        ("node_char_index", ctypes.c_void_p), ("node_snip_len", ctypes.c_void_p), ("n_new", ctypes.c_uint32),
+                        ("counts", ctypes.c_void_p), ("b250", ctypes.c_void_p), ("b250_len", ctypes.c_uint64),
+                        ("b250_count", ctypes.c_uint64), ("all_the_same", ctypes.c_int)]
+        ni = np.zeros(max(1, n), dtype=np.int32)
+        dic = np.zeros(int(length.astype(np.uint64).sum()) + n + 1, dtype=np.uint8)
+        nci = np.zeros(max(1, n), dtype=np.uint64); nsl = np.zeros(max(1, n), dtype=np.uint32)
+        counts = np.zeros(n_ol + n + 1, dtype=np.uint32)
+        b250 = np.zeros(4 * n + 4, dtype=np.uint8)
+        c = Col(ni.ctypes.data, dic.ctypes.data, 0, nci.ctypes.data, nsl.ctypes.data, 0, counts.ctypes.data, b250.ctypes.data, 0, 0, 0)
+        rc = self.L.gzo_ctx_seg_column(text, off.ctypes.data_as(ctypes.c_void_p), length.ctypes.data_as(ctypes.c_void_p),
+                                       ctypes.c_uint64(n), ol_dict, ol_ci.ctypes.data_as(ctypes.c_void_p),
+                                       ol_len.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(n_ol), ctypes.byref(c))
+        assert rc == 0
+        return dict(node_index=ni[:n].copy(), dict=dic[:c.dict_len].tobytes(), node_char_index=nci[:c.n_new].copy(),
+                    node_snip_len=nsl[:c.n_new].copy(), counts=counts[:n_ol + c.n_new].copy(),
+                    b250=b250[:c.b250_len].tobytes(), b250_count=int(c.b250_count), all_the_same=bool(c.all_the_same))
+
+    def dyn_int_column(self, values, is_nothing=None, nothing_char=0):
+        """-> (ltype, native little-endian bytes at the final width)"""
+        import numpy as np
+        v = np.ascontiguousarray(values, dtype=np.int64)
+        m = None if is_nothing is None else np.ascontiguousarray(is_nothing, dtype=np.uint8)
+        out = np.zeros(8 * len(v) + 8, dtype=np.uint8)
+        lt = self.L.gzo_dyn_int_column(v.ctypes.data_as(ctypes.c_void_p), None if m is None else m.ctypes.data_as(ctypes.c_void_p),
+                                       ctypes.c_uint64(len(v)), int(nothing_char), out.ctypes.data_as(ctypes.c_void_p))
+        w = {1: 1, 2: 1, 3: 2, 4: 2, 5: 4, 6: 4, 7: 8}[lt]
+        return lt, out[:w * len(v)].tobytes()
+
+    def local_blob_column(self, text, off, length, add_nul=False):
+        import numpy as np
+        text = bytes(text)
+        off = np.ascontiguousarray(off, dtype=np.uint32); length = np.ascontiguousarray(length, dtype=np.uint32)
+        out = np.zeros(int(length.astype(np.uint64).sum()) + len(off) + 1, dtype=np.uint8)
+        self.L.gzo_local_blob_column.restype = ctypes.c_uint64
+        n = self.L.gzo_local_blob_column(text, off.ctypes.data_as(ctypes.c_void_p), length.ctypes.data_as(ctypes.c_void_p),
+                                         ctypes.c_uint64(len(off)), int(bool(add_nul)), out.ctypes.data_as(ctypes.c_void_p))
+        return out[:n].tobytes()
+
+    # ---- N1 (first part): lines, FASTQ records, tokens
+    def text_lines(self, text):
+        import numpy as np
+        text = bytes(text)
+        cap = text.count(b"\n") + 1
+        off = np.zeros(cap, dtype=np.uint32); ln = np.zeros(cap, dtype=np.uint32)
+        self.L.gzo_text_lines.restype = ctypes.c_uint64
+        n = self.L.gzo_text_lines(text, ctypes.c_uint64(len(text)), off.ctypes.data_as(ctypes.c_void_p), ln.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(cap))
+        return off[:n].copy(), ln[:n].copy()
+
+    def fastq_records(self, text, line_off, line_len):
+        """-> (rc, [(off, len)] for line 1, SEQ, line 3, QUAL)"""
+        import numpy as np
+        text = bytes(text)
+        lo = np.ascontiguousarray(line_off, dtype=np.uint32); ll = np.ascontiguousarray(line_len, dtype=np.uint32)
+        nr = len(lo) // 4
+        cols = [np.zeros(max(1, nr), dtype=np.uint32) for _ in range(8)]
+        self.L.gzo_fastq_records.restype = ctypes.c_long
+        rc = self.L.gzo_fastq_records(text, lo.ctypes.data_as(ctypes.c_void_p), ll.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(len(lo)),
+                                      *[c.ctypes.data_as(ctypes.c_void_p) for c in cols])
+        return rc, [(cols[2 * i][:nr], cols[2 * i + 1][:nr]) for i in range(4)]
+
+    def tokenize_column(self, text, off, length, seps):
+        """-> (n_bad, item_off[n_items, n], item_len[n_items, n])"""
+        import numpy as np
+        text = bytes(text); seps = bytes(seps)
+        off = np.ascontiguousarray(off, dtype=np.uint32); length = np.ascontiguousarray(length, dtype=np.uint32)
+        n, ni = len(off), len(seps) + 1
+        io = np.zeros((ni, max(1, n)), dtype=np.uint32); il = np.zeros((ni, max(1, n)), dtype=np.uint32)
+        if n == 0:
+            return 0, io[:, :0], il[:, :0]
+        self.L.gzo_tokenize_column.restype = ctypes.c_uint64
+        nb = self.L.gzo_tokenize_column(text, off.ctypes.data_as(ctypes.c_void_p), length.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(n),
+                                        seps, len(seps), io.ctypes.data_as(ctypes.c_void_p), il.ctypes.data_as(ctypes.c_void_p))
+        return int(nb), io, il
+
     # ---- sections
     def adler32(self, data, start=1):
         data = bytes(data)

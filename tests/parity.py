@@ -167,3 +167,135 @@ def acgt(E, oracle, n):
             assert (name == "clean" or m < 40) or want[2]
             x = want[1] if want[2] else None
             assert E.acgt_unpack(want[0], x, m) == seq == oracle.acgt_unpack(want[0], x, m), (name, m)
+
+
+def _column_cases(n):
+    """(name, text, off, len, ol_snips): the shapes a context's column takes"""
+    r = synth.u32(777, 4 * n + 64).astype(np.int64)
+    cases = []
+
+    def build(words, picks, name, ol=(), holes=None):
+        text = b"".join(words)
+        starts = np.concatenate([[0], np.cumsum([len(w) for w in words])[:-1]]).astype(np.uint32) if words else np.zeros(0, np.uint32)
+        lens = np.array([len(w) for w in words], dtype=np.uint32)
+        off, ln = starts[picks].copy(), lens[picks].copy()
+        if holes is not None:
+            ln[holes == 1] = 0                                  # empty
+            ln[holes == 2] = 0; off[holes == 2] = 0xffffffff    # missing
+        cases.append((name, text, off, ln, list(ol)))
+
+    few = [b"PASS", b".", b"q10", b"LowQual;q10", b"x" * 70, b"y" * 200]
+    build(few, r[:n] % 6, "few words", ol=[b".", b"nope", b"PASS"])
+    build(few, r[:n] % 6, "few words, holes", ol=[b"q10"], holes=(r[n:2 * n] % 11 == 0) * 1 + (r[n:2 * n] % 13 == 0) * 1)
+    build(few, np.zeros(n, dtype=np.int64) + 3, "all the same, new")
+    build(few, np.zeros(n, dtype=np.int64) + 1, "all the same, ol", ol=[b"a", b"."])
+    build(few, np.zeros(n, dtype=np.int64), "all empty", holes=np.ones(n, dtype=np.int64))
+    uniq = [b"read%d:%d" % (i, (i * 7919) % 1000) for i in range(n)]
+    build(uniq, np.arange(n), "all distinct")
+    build(uniq, (r[:n] % max(1, n // 3)), "a third distinct, shuffled", ol=uniq[5:n:7])
+    big_ol = [b"w%d" % i for i in range(17000)]
+    build(big_ol, r[:n] % 17000, "large cloned dictionary (1, 2 and 3 byte words)", ol=big_ol)
+    build(big_ol, np.sort(r[:n] % 17000), "half cloned, sorted", ol=big_ol[::2])
+    build(few, np.zeros(0, dtype=np.int64), "no entries")
+    build(few, np.zeros(1, dtype=np.int64) + 4, "one entry")
+    build(few, np.array([4, 4, 5], dtype=np.int64), "same same different")
+    return cases
+
+
+def seg_columns(E, oracle, n):
+    """rows a1-a3: node indices, dict, nodes, counts and seg-format b250 of whole columns == the oracle's one-by-one
+    evaluation; then through gz_b250_generate (the identity merge) like the reference's flow"""
+    cases = _column_cases(n)
+    got = E.ctx_seg_columns([(t, o, l, ol) for _, t, o, l, ol in cases])
+    for (name, t, o, l, ol), g in zip(cases, got):
+        w = oracle.ctx_seg_column(t, o, l, ol)
+        for key in ("node_index", "node_char_index", "node_snip_len", "counts"):
+            assert np.array_equal(g[key], w[key]), (name, key)
+        for key in ("dict", "b250", "b250_count", "all_the_same"):
+            assert g[key] == w[key], (name, key)
+        n_new = len(w["node_snip_len"])
+        n2w = list(range(len(ol), len(ol) + n_new))
+        if w["b250"]:
+            assert E.b250_generate(g["b250"], len(ol), n2w) == oracle.b250_generate(w["b250"], len(ol), n2w), (name, "generate")
+    # one column on its own == the same column in a batch
+    name, t, o, l, ol = cases[1]
+    assert E.ctx_seg_column(t, o, l, ol)["b250"] == got[1]["b250"]
+
+    # dyn_int_append over columns
+    r = synth.u32(778, n + 8).astype(np.int64)
+    cols = [(r[:n] % 200, None, 0), (r[:n] % 256, None, 0), (r[:n] % 256, None, 46), (r[:n] % 300 - 20, None, 0),
+            (r[:n] % 100 - 50, None, 0), (r[:n] % 70000, None, 0), (r[:n] % 70000 - 5, None, 0),
+            ((r[:n] << 3), None, 0), ((r[:n] << 3) - (1 << 34), None, 0), (r[:n] * 123456789 - (1 << 50), None, 0),
+            (r[:n] % 255, (r[:n] % 7 == 0).astype(np.uint8), 46),
+            (np.concatenate([[5], r[1:n] % 100 - 1]), np.concatenate([[1], np.zeros(n - 1)]).astype(np.uint8), 46),
+            (np.concatenate([[5], r[1:n] % 100]), np.concatenate([[1], np.zeros(n - 1)]).astype(np.uint8), 46),
+            (np.zeros(n), np.ones(n, dtype=np.uint8), 46), (np.zeros(0), None, 0), (np.array([65535]), None, 46)]
+    got = E.dyn_int_columns(cols)
+    for i, (c, g) in enumerate(zip(cols, got)):
+        assert g == oracle.dyn_int_column(*c), ("dyn_int", i)
+    # ... and on into file order
+    lt, raw = got[3]
+    assert E.local_generate(lt, raw) == oracle.local_generate(lt, raw)
+
+    # the gather of a field into its context's local
+    name, t, o, l, ol = cases[1]
+    blobs = E.local_blob_columns([(t, np.where(l == 0, 0, o), l, False), (t, np.where(l == 0, 0, o), l, True),
+                                  (t, o[:0], l[:0], True), (cases[5][1], cases[5][2], cases[5][3], False)])
+    oo = np.where(l == 0, 0, o)
+    assert blobs[0] == oracle.local_blob_column(t, oo, l, False)
+    assert blobs[1] == oracle.local_blob_column(t, oo, l, True)
+    assert blobs[2] == b""
+    assert blobs[3] == oracle.local_blob_column(cases[5][1], cases[5][2], cases[5][3], False) == cases[5][1]
+
+
+def fastq_text(n_reads, seed=11, crlf_every=0, read_len=150):
+    """a small FASTQ text in the shape of SURVEY 8d config 1 (Illumina-7 names, 40-level qualities)"""
+    r = synth.u32(seed, 4 * n_reads + 8).astype(np.int64)
+    seqs = np.frombuffer(b"ACGT", dtype=np.uint8)[synth.uniform_bytes(seed + 1, n_reads * read_len, 4)].reshape(n_reads, read_len)
+    quals = (synth.uniform_bytes(seed + 2, n_reads * read_len, 40) + 33).astype(np.uint8).reshape(n_reads, read_len)
+    out = []
+    for i in range(n_reads):
+        eol = b"\r\n" if crlf_every and i % crlf_every == 0 else b"\n"
+        ln = read_len - (r[i] % 3 == 0) * int(r[i] % 7)
+        out.append(b"@A00123:45:HXXXXXXXX:%d:%d:%d:%d 1:N:0:ACGTACGT+TGCATGCA" % (1 + i * 4 // max(1, n_reads), 1101 + i % 70, 1000 + r[i] % 30000, 1000 + (i * 37) % 36000) + eol)
+        out.append(seqs[i, :ln].tobytes() + eol + (b"+" if i % 5 else b"+x%d" % i) + eol + quals[i, :ln].tobytes() + eol)
+    return b"".join(out)
+
+
+def fastq_front(E, oracle, n_reads):
+    """N1 (first part) + a1-a3 chained the way the segmenter's line loop uses them: text -> lines -> reads -> qname
+    tokens -> per-token columns (b250 / dyn-int local) and the SEQ / QUAL gather; every stage == the oracle's"""
+    for text in (fastq_text(n_reads), fastq_text(min(n_reads, 300), seed=12, crlf_every=3), fastq_text(5)[:-1], b"", b"\n", b"no newline", b"a\n\nb\r\n"):
+        lo, ll = E.text_lines(text)
+        wo, wl = oracle.text_lines(text)
+        assert np.array_equal(lo, wo) and np.array_equal(ll, wl), text[:40]
+    text = fastq_text(n_reads, crlf_every=7)
+    bad, cols = E.fastq_records(text)
+    wo, wl = oracle.text_lines(text)
+    wrc, wcols = oracle.fastq_records(text, wo, wl)
+    assert bad is None and wrc == 0
+    for (go, gl), (o, l) in zip(cols, wcols):
+        assert np.array_equal(go, o) and np.array_equal(gl, l)
+    # a malformed read is found (the reference aborts on it)
+    broken = text.replace(b"\n+", b"\n-", 3)
+    assert E.fastq_records(broken)[0] == -1 - oracle.fastq_records(broken, *oracle.text_lines(broken))[0]
+    # qname tokens: Illumina-7 (qname_flavors.h) - six ':' then ' ' ; the rest of line 1 is the last item
+    (qo, ql), (so, sl), _, (uo, ul) = cols
+    nb, io, il = E.tokenize_column(text, qo, ql, b":::::: ")
+    wnb, wio, wil = oracle.tokenize_column(text, qo, ql, b":::::: ")
+    assert nb == wnb == 0 and np.array_equal(io, wio) and np.array_equal(il, wil)
+    nb, io2, il2 = E.tokenize_column(text, qo, ql, b"::::::: ")               # one ':' too many: every snip is bad
+    wnb, wio2, wil2 = oracle.tokenize_column(text, qo, ql, b"::::::: ")
+    assert nb == wnb == len(qo) and np.array_equal(io2, wio2) and np.array_equal(il2, wil2)
+    # token columns -> contexts
+    got = E.ctx_seg_columns([(text, io[i], il[i], []) for i in range(io.shape[0])])
+    for i, g in enumerate(got):
+        w = oracle.ctx_seg_column(text, io[i], il[i])
+        assert g["b250"] == w["b250"] and g["dict"] == w["dict"] and np.array_equal(g["counts"], w["counts"]), i
+    # a numeric token (x coordinate) as a dyn-int local
+    xs = np.array([int(text[o:o + l]) for o, l in zip(io[5], il[5])], dtype=np.int64)
+    assert E.dyn_int_column(xs) == oracle.dyn_int_column(xs)
+    # SEQ -> NONREF.local, QUAL -> QUAL.local
+    blobs = E.local_blob_columns([(text, so, sl, False), (text, uo, ul, False)])
+    assert blobs[0] == oracle.local_blob_column(text, so, sl) and blobs[1] == oracle.local_blob_column(text, uo, ul)
+    assert len(blobs[0]) == int(sl.sum())

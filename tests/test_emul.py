@@ -47,3 +47,11 @@ def test_emul_arith_long_streams(emul_engine, oracle):
 
 def test_emul_acgt(emul_engine, oracle):
     parity.acgt(emul_engine, oracle, 5000)
+
+
+def test_emul_seg_columns(emul_engine, oracle):
+    parity.seg_columns(emul_engine, oracle, 3000)
+
+
+def test_emul_fastq_front(emul_engine, oracle):
+    parity.fastq_front(emul_engine, oracle, 700)

@@ -82,6 +82,35 @@ def test_acgt_pack(gpu_engine, oracle):
     parity.acgt(gpu_engine, oracle, 6900000)
 
 
+def test_seg_columns(gpu_engine, oracle):
+    """rows a1-a3 at a VBlock's size: 46 000 entries per column (FASTQ), every column shape of parity._column_cases"""
+    parity.seg_columns(gpu_engine, oracle, 46000)
+
+
+def test_fastq_front(gpu_engine, oracle):
+    """N1 (first part) chained into a1-a3 on a VBlock's worth of FASTQ text (23 000 reads, ~7 MB)"""
+    parity.fastq_front(gpu_engine, oracle, 23000)
+
+
+def test_seg_column_vcf_sized(gpu_engine, oracle):
+    """a FORMAT/PL-like column: 3 million snips, ~2 000 distinct, half of them already in the cloned dictionary"""
+    import numpy as np
+    from genozip_amd import synth
+    n = 3000000
+    words = [b"%d,%d,%d" % (i % 97, (i * 7) % 255, (i * 13) % 255) for i in range(2000)]
+    text = b"".join(words)
+    lens = np.array([len(w) for w in words], dtype=np.uint32)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint32)
+    r = synth.u32(99, n).astype(np.int64)
+    pick = np.minimum(r % 2000, (r >> 11) % 2000)                    # skewed towards the low indices
+    got = gpu_engine.ctx_seg_column(text, starts[pick], lens[pick], words[::2])
+    want = oracle.ctx_seg_column(text, starts[pick], lens[pick], words[::2])
+    for key in ("node_index", "node_char_index", "node_snip_len", "counts"):
+        assert np.array_equal(got[key], want[key]), key
+    for key in ("dict", "b250", "b250_count", "all_the_same"):
+        assert got[key] == want[key], key
+
+
 def test_two_handles_in_flight(gpu_engine, oracle):
     """two GzHandles (two host threads in the reference's threading model) with batches in flight at the same time: the
     persistent chain kernels of both must get along (process-wide budget in gz_host.cpp)"""
