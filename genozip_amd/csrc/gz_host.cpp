@@ -1109,6 +1109,7 @@ extern "C" int gz_ctx_seg_columns (GzHandle *h, const GzColumnJob *jobs, int n_j
         KLAUNCH (h, k_col_scan_a, g_jobs, dim3 (256), 2048, d_cols);
         KLAUNCH (h, k_col_assign, g_n, dim3 (256), 2048, d_cols);
         KLAUNCH (h, k_col_node, g_n, dim3 (256), 2048, d_cols);
+        KLAUNCH (h, k_col_counts, dim3 ((t_n + GZ_COUNT_TILES - 1) / GZ_COUNT_TILES, n_jobs), dim3 (256), GZ_COUNT_SLOTS * 8, d_cols);
         KLAUNCH (h, k_col_scan_b, g_jobs, dim3 (256), 2048, d_cols);
         KLAUNCH (h, k_col_b250, g_n, dim3 (256), 2048, d_cols);
     }

@@ -14,7 +14,8 @@
 //   k_col_first      representative of every snip; first occurrences flagged; per-tile (count, dict bytes)
 //   k_col_scan_a     per column: exclusive scan of the tile sums -> n_new, dict_len
 //   k_col_assign     rank and dict offset of every first occurrence (workgroup prefix sum); nodes; dict bytes + NUL
-//   k_col_node       node index of every snip; counts (wave-aggregated atomics); all-the-same; per-tile b250 bytes
+//   k_col_node       node index of every snip; all-the-same; per-tile b250 bytes
+//   k_col_counts     occurrences per node (LDS table per 16 K snips, then global atomics)
 //   k_col_scan_b     per column: scan -> b250_len (or the single entry of an all-the-same column)
 //   k_col_b250       seg-format words: little endian, type tag in the LAST byte, nodes new to the VBlock always 4 bytes
 // The table is this library's own (never written to the file); the snip mixing function is the reference's rotate-xor,
@@ -92,11 +93,11 @@ __device__ static inline void d_wave_copy (uint8_t *dst, const uint8_t *src, uin
 
 // ---- rows a1 + a2 ---------------------------------------------------------------------------------------------------
 // hash.h:36-46: rotate-xor of the snip's bytes through a 64-bit word
-__device__ static inline uint32_t d_snip_slot (const uint8_t *s, uint32_t len, uint32_t bits)
+__device__ static inline uint64_t d_snip_hash (const uint8_t *s, uint32_t len)
 {
     uint64_t r = 0;
     for (uint32_t i = 0; i < len; i++) r = ((r << 23) | (r >> 41)) ^ (uint64_t)s[i];
-    return (uint32_t)((r * 0x9E3779B97F4A7C15ull) >> (64 - bits));
+    return r;
 }
 
 __device__ static inline const uint8_t *d_col_snip (const GzdColumn &C, uint32_t id, uint32_t *len)
@@ -115,10 +116,10 @@ __device__ static inline bool d_same_bytes (const uint8_t *a, const uint8_t *b, 
 
 // Equal strings walk the same probe sequence and slots are never vacated, so they all end in ONE slot; every id a slot
 // ever holds names the same string, which makes the comparison below independent of the races on the id.
-__device__ static inline uint32_t d_col_insert (const GzdColumn &C, uint32_t id, const uint8_t *s, uint32_t len)
+__device__ static inline uint32_t d_col_insert (const GzdColumn &C, uint32_t id, const uint8_t *s, uint32_t len, uint64_t hash)
 {
     const uint32_t mask = (1u << C.table_bits) - 1;
-    uint32_t slot = d_snip_slot (s, len, C.table_bits);
+    uint32_t slot = (uint32_t)((hash * 0x9E3779B97F4A7C15ull) >> (64 - C.table_bits));
     for (;;) {
         // a plain look first: whatever id it finds - however stale - names the slot's string for good, and a column
         // that is one word ten thousand times over would otherwise be ten thousand atomics on one address
@@ -155,17 +156,39 @@ __global__ void __launch_bounds__(256) k_col_insert_ol (GzdColumn *cols)
     if (i >= C.n_ol) return;
     uint32_t len;
     const uint8_t *s = d_col_snip (C, i, &len);
-    (void)d_col_insert (C, i, s, len);
+    (void)d_col_insert (C, i, s, len, d_snip_hash (s, len));
 }
 
 // grid (tiles over n, columns), and so are the following
 __global__ void __launch_bounds__(256) k_col_insert (GzdColumn *cols)
 {
     const GzdColumn &C = cols[blockIdx.y];
+    if (blockIdx.x * 256 >= C.n) return;
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= C.n) return;
-    const uint32_t len = C.len[k];
-    C.rep[k] = len ? d_col_insert (C, C.n_ol + k, C.text + C.off[k], len) : 0xffffffffu;
+    const uint32_t len = k < C.n ? C.len[k] : 0, off = len ? C.off[k] : 0;
+    // Columns of few distinct words (most of them) would put a wave's 64 lanes on the same slot: the first lane of every
+    // group of equal snips inserts for the group - like the reference's "same as the previous snip" short cut
+    // (context.c:338-342). Four groups per wave, whoever is left goes on its own.
+    const int lane = threadIdx.x & 63;
+    const uint64_t hv = d_snip_hash (C.text + off, len);
+    uint32_t slot = 0xffffffffu;
+    uint64_t todo = __ballot (len != 0);
+    for (int round = 0; round < 4 && todo; round++) {
+        const int src = __ffsll ((unsigned long long)todo) - 1;
+        const uint32_t lh_lo = (uint32_t)__shfl ((int)(uint32_t)hv, src), lh_hi = (uint32_t)__shfl ((int)(uint32_t)(hv >> 32), src);
+        const uint32_t lo = (uint32_t)__shfl ((int)off, src), ll = (uint32_t)__shfl ((int)len, src);
+        const bool same = len && slot == 0xffffffffu && (uint32_t)hv == lh_lo && (uint32_t)(hv >> 32) == lh_hi && len == ll
+                          && d_same_bytes (C.text + off, C.text + lo, len);
+        uint32_t ls = 0;
+        if (lane == src) ls = d_col_insert (C, C.n_ol + k, C.text + off, len, hv);
+        ls = (uint32_t)__shfl ((int)ls, src);
+        if (same) slot = ls;
+        const uint64_t group = __ballot (same);
+        todo &= ~group;
+        if (__popcll (group) < 4) break;                   // (a column of mostly distinct words: the rounds would be wasted)
+    }
+    if (len && slot == 0xffffffffu) slot = d_col_insert (C, C.n_ol + k, C.text + off, len, hv);
+    if (k < C.n) C.rep[k] = slot;
 }
 
 __global__ void __launch_bounds__(256) k_col_first (GzdColumn *cols)
@@ -262,20 +285,40 @@ __global__ void __launch_bounds__(256) k_col_node (GzdColumn *cols)
         uint32_t code;
         bytes = d_seg_word (node, C.n_ol, &code);
     }
-    // counts: one atomic per distinct node of the wave for the first few, the stragglers on their own
-    uint64_t todo = __ballot (on && node >= 0);
-    for (int round = 0; round < 4 && todo; round++) {
-        const int src = __ffsll ((unsigned long long)todo) - 1;
-        const int32_t v = __shfl (node, src);
-        const uint64_t same = __ballot (node == v) & todo;
-        if ((tid & 63) == src) atomicAdd (&C.counts[v], (uint32_t)__popcll (same));
-        todo &= ~same;
-    }
-    if ((todo >> (tid & 63)) & 1) atomicAdd (&C.counts[node], 1u);
-    if (__ballot (node != node0) && !(tid & 63)) atomicMax (C.not_same, 1u);
+    if (__ballot (node != node0) && !(tid & 63) && !*C.not_same) atomicMax (C.not_same, 1u);   // (half a million waves on one address otherwise)
     uint64_t total;
     (void)d_wg_scan_u64 (bytes, tid, &total);
     if (!tid) C.tile_b[blockIdx.x] = total;
+}
+
+// counts (vctx->counts, context.c:355,383): a workgroup takes GZ_COUNT_TILES tiles and collects them in a small
+// direct-mapped table in LDS first - a 30-million-entry column of 2 000 words is otherwise 30 million global atomics
+// on 2 000 addresses (6.1 ms; 1.5 ms this way). What does not find its place in the table goes to memory directly.
+#define GZ_COUNT_TILES 64
+#define GZ_COUNT_SLOTS 2048
+// grid (tiles / GZ_COUNT_TILES, columns)
+__global__ void __launch_bounds__(256) k_col_counts (GzdColumn *cols)
+{
+    const GzdColumn &C = cols[blockIdx.y];
+    const uint32_t k0 = blockIdx.x * (GZ_COUNT_TILES * 256);
+    if (k0 >= C.n) return;
+    uint32_t *key = (uint32_t *)gz_lds, *cnt = key + GZ_COUNT_SLOTS;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < GZ_COUNT_SLOTS; i += 256) { key[i] = 0xffffffffu; cnt[i] = 0; }
+    __syncthreads ();
+    for (int t = 0; t < GZ_COUNT_TILES; t++) {
+        const uint32_t k = k0 + (uint32_t)t * 256 + tid;
+        if (k >= C.n) break;
+        const int32_t node = C.node_index[k];
+        if (node < 0) continue;                                                // empty / missing are not counted (context.c:331-335)
+        const uint32_t h = ((uint32_t)node * 0x9E3779B1u) >> 21;              // 11 bits
+        uint32_t cur = key[h];
+        if (cur == 0xffffffffu) { cur = atomicCAS (&key[h], 0xffffffffu, (uint32_t)node); if (cur == 0xffffffffu) cur = (uint32_t)node; }
+        if (cur == (uint32_t)node) atomicAdd (&cnt[h], 1u);
+        else atomicAdd (&C.counts[node], 1u);
+    }
+    __syncthreads ();
+    for (int i = tid; i < GZ_COUNT_SLOTS; i += 256) if (cnt[i]) atomicAdd (&C.counts[key[i]], cnt[i]);
 }
 
 // grid (columns)
@@ -438,12 +481,32 @@ __global__ void __launch_bounds__(256) k_blob_copy (GzdBlob *cols)
     // the wave's bytes are one contiguous stretch of the output starting at lane 0's offset
     const uint64_t wave_at = ((uint64_t)(uint32_t)__shfl ((int)(uint32_t)(at >> 32), 0) << 32) | (uint32_t)__shfl ((int)(uint32_t)at, 0);
     const uint32_t rel = (uint32_t)(at - wave_at);
-    for (uint64_t m = __ballot (on); m; m &= m - 1) {
-        const int src = __ffsll ((unsigned long long)m) - 1;
-        const uint32_t o = (uint32_t)__shfl ((int)off, src), l = (uint32_t)__shfl ((int)len, src), r = (uint32_t)__shfl ((int)rel, src);
-        uint8_t *dst = B.out + wave_at + r;
-        d_wave_copy (dst, B.text + o, l, lane);
-        if (B.add_nul && !lane) dst[l] = 0;
+    // four snips per round: their loads are all in flight before the first store (one snip at a time the wave just sat
+    // out a memory round trip per snip - 1.1 ms for the 600 MB of SEQ + QUAL of FASTQ-PE-1M)
+    uint64_t m = __ballot (on);
+    while (m) {
+        uint32_t o[4], l[4], r[4], v[4];
+        #pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int src = m ? __ffsll ((unsigned long long)m) - 1 : 0;
+            const bool live = m != 0;
+            m &= m - 1;
+            o[q] = (uint32_t)__shfl ((int)off, src); l[q] = live ? (uint32_t)__shfl ((int)len, src) : 0; r[q] = (uint32_t)__shfl ((int)rel, src);
+            if (!live) r[q] = 0xffffffffu;
+        }
+        #pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = (uint32_t)lane * 4 < (l[q] & ~3u) ? *(const gz_u32_unaligned *)(B.text + o[q] + lane * 4) : 0;
+        #pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (r[q] == 0xffffffffu) continue;
+            uint8_t *dst = B.out + wave_at + r[q];
+            const uint8_t *src = B.text + o[q];
+            const uint32_t whole = l[q] & ~3u;
+            if ((uint32_t)lane * 4 < whole) *(gz_u32_unaligned *)(dst + lane * 4) = v[q];
+            for (uint32_t b = 256 + (uint32_t)lane * 4; b < whole; b += 256) *(gz_u32_unaligned *)(dst + b) = *(const gz_u32_unaligned *)(src + b);
+            if ((uint32_t)lane < l[q] - whole) dst[whole + lane] = src[whole + lane];
+            if (B.add_nul && !lane) dst[l[q]] = 0;
+        }
     }
 }
 
