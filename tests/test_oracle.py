@@ -148,3 +148,37 @@ def test_acgt_kats(oracle):
     for ch, code in iupac.items():
         for c in (ch, ch.lower()):
             assert oracle.acgt_pack(c.encode())[0][0] == code and oracle.acgt_pack(c.encode())[1] == c.encode()
+
+
+def test_seg_column_kats(oracle):
+    """hand-derived known answers for the seg-side restatements (rows a1-a3, N1): the reference holds no fixtures"""
+    import numpy as np
+    text = b"chr1chr2chr1chrXchr2"
+    r = oracle.ctx_seg_column(text, [0, 4, 8, 12, 16, 0xffffffff, 0], [4, 4, 4, 4, 4, 0, 0], ol_snips=[b"chr2"])
+    # chr2 is node 0 (cloned); chr1 and chrX are new in order of first occurrence; then MISSING (-4) and EMPTY (-3)
+    assert r["node_index"].tolist() == [1, 0, 1, 2, 0, -4, -3]
+    assert r["dict"] == b"chr1\0chrX\0" and r["node_char_index"].tolist() == [0, 5] and r["node_snip_len"].tolist() == [4, 4]
+    assert r["counts"].tolist() == [2, 2, 1]
+    # new nodes: 4 bytes 111|node little endian; the cloned node 0: one byte; MISSING bf ff / EMPTY bf fe stored tag-last
+    assert r["b250"].hex() == "010000e0" "00" "010000e0" "020000e0" "00" "ffbf" "febf"
+    assert r["b250_count"] == 7 and not r["all_the_same"]
+    # all the same: ONE entry however often it was appended (b250.c:117-141)
+    r = oracle.ctx_seg_column(text, [0, 8], [4, 4])
+    assert r["b250"].hex() == "000000e0" and r["b250_count"] == 2 and r["all_the_same"] and r["counts"].tolist() == [2]
+    # dyn-int: first of UINT8 INT8 UINT16 INT16 UINT32 INT32 INT64 that holds all values (GZ_LT numbering)
+    assert oracle.dyn_int_column([0, 200, -1]) == (3, bytes([0, 0, 200, 0, 255, 255]))              # INT16
+    assert oracle.dyn_int_column([1, 2, 254], [0, 0, 0], nothing_char=46) == (2, bytes([1, 2, 254]))  # UINT8: 254 is the top with a nothing_char
+    assert oracle.dyn_int_column([1, 2, 255], [0, 0, 0], nothing_char=46)[0] == 4                    # ... 255 needs UINT16
+    assert oracle.dyn_int_column([5, 255], [1, 0], 46) == (4, bytes([255, 255, 255, 0]))             # nothing first; stored as the type's maximum
+    assert oracle.dyn_int_column([-129])[0] == 3 and oracle.dyn_int_column([1 << 31])[0] == 6 and oracle.dyn_int_column([-(1 << 31) - 1])[0] == 7
+    assert oracle.local_blob_column(text, [0, 4], [4, 4], True) == b"chr1\0chr2\0"
+    # lines (a '\r' before the newline is not part of the line; a last line without newline counts), reads, tokens
+    t = b"@r1:2 x\r\nACGT\n+\nFFFF\n@r2:3 y\nAC\n+r2\nF#"
+    lo, ll = oracle.text_lines(t)
+    assert lo.tolist() == [0, 9, 14, 16, 21, 29, 32, 36] and ll.tolist() == [7, 4, 1, 4, 7, 2, 3, 2]
+    rc, cols = oracle.fastq_records(t, lo, ll)
+    assert rc == 0 and [c[0].tolist() for c in cols] == [[1, 22], [9, 29], [15, 33], [16, 36]]
+    assert [c[1].tolist() for c in cols] == [[6, 6], [4, 2], [0, 2], [4, 2]]
+    nb, io, il = oracle.tokenize_column(t, cols[0][0], cols[0][1], b": ")
+    assert nb == 0 and io.tolist() == [[1, 22], [4, 25], [6, 27]] and il.tolist() == [[2, 2], [1, 1], [1, 1]]
+    assert oracle.fastq_records(t.replace(b"\n+r2", b"\n-r2"), lo, ll)[0] == -2
