@@ -400,6 +400,21 @@ class Engine:
                 np.frombuffer(self.mem.download(io, 4 * ni * n), dtype=np.uint32).reshape(ni, n),
                 np.frombuffer(self.mem.download(il, 4 * ni * n), dtype=np.uint32).reshape(ni, n))
 
+    def seg_integer_or_not(self, text, off, length, nothing_char=0, lookup_off=0):
+        """-> (snip_off, snip_len, values, is_nothing): seg_integer_or_not over a column"""
+        import numpy as np
+        off = np.ascontiguousarray(off, dtype=np.uint32); length = np.ascontiguousarray(length, dtype=np.uint32)
+        n = len(off)
+        tbuf = self.mem.upload(text) if isinstance(text, (bytes, bytearray)) else text
+        ofb, lb = self.mem.upload(off), self.mem.upload(length)
+        so, sl, vb, mb, nb = self.mem.alloc(4 * n + 16), self.mem.alloc(4 * n + 16), self.mem.alloc(8 * n + 16), self.mem.alloc(n + 16), self.mem.alloc(16)
+        self._check(self.L.gz_seg_integer_or_not(self.h, self.mem.ptr(tbuf), self.mem.ptr(ofb), self.mem.ptr(lb), n, int(nothing_char), int(lookup_off),
+                                                 self.mem.ptr(so), self.mem.ptr(sl), self.mem.ptr(vb), self.mem.ptr(mb), self.mem.ptr(nb)), "gz_seg_integer_or_not")
+        self.sync()
+        nv = int(np.frombuffer(self.mem.download(nb, 8), dtype=np.uint64)[0])
+        return (np.frombuffer(self.mem.download(so, 4 * n), dtype=np.uint32), np.frombuffer(self.mem.download(sl, 4 * n), dtype=np.uint32),
+                np.frombuffer(self.mem.download(vb, 8 * nv), dtype=np.int64), np.frombuffer(self.mem.download(mb, nv), dtype=np.uint8))
+
     # ---- CODEC_ACGT pre-transform (codec_acgt.c) ----------------------------------------------------------
     def acgt_pack(self, seq, in_place=False):
         """SEQ bytes -> (2-bit packed bytes, exception stream, has_x)"""

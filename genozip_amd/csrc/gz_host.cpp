@@ -1221,6 +1221,24 @@ extern "C" int gz_tokenize_column (GzHandle *h, const uint8_t *text, const uint3
     return GZ_OK;
 }
 
+extern "C" int gz_seg_integer_or_not (GzHandle *h, const uint8_t *text, const uint32_t *off, const uint32_t *len, uint32_t n,
+                                      uint32_t nothing_char, uint32_t lookup_off, uint32_t *snip_off, uint32_t *snip_len,
+                                      int64_t *values, uint8_t *is_nothing, uint64_t *n_values_dev)
+{
+    if (!h || !n_values_dev || (n && (!text || !off || !len || !snip_off || !snip_len || !values || !is_nothing))) return GZ_ERR_ARG;
+    HIPCHK (h, hipSetDevice (h->device));
+    GzdIntSplit S;
+    S.text = text; S.off = off; S.len = len; S.n = n; S.nothing_char = nothing_char; S.lookup_off = lookup_off;
+    S.snip_off = snip_off; S.snip_len = snip_len; S.values = values; S.is_nothing = is_nothing; S.n_values = n_values_dev;
+    const uint32_t tiles = (n + 255) / 256;
+    if (!(S.tile = (uint64_t *)arena_alloc (h, ((size_t)tiles + 1) * 8))) return GZ_ERR_HIP;
+    if (tiles) KLAUNCH (h, k_int_count, dim3 (tiles), dim3 (256), 2048, S);
+    KLAUNCH (h, k_int_scan, dim3 (1), dim3 (256), 2048, S);
+    if (tiles) KLAUNCH (h, k_int_write, dim3 (tiles), dim3 (256), 2048, S);
+    HIPCHK (h, hipGetLastError ());
+    return GZ_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // VBlock decode (round trip proof): walk the sections on the host, decode payloads on the device
 // ---------------------------------------------------------------------------------------------------------

@@ -647,3 +647,61 @@ __global__ void __launch_bounds__(256) k_tokenize (GzdTokens T)
     }
     else { T.item_off[(uint64_t)T.n_seps * T.n + k] = off + at; T.item_len[(uint64_t)T.n_seps * T.n + k] = len - at; }
 }
+
+// seg_integer_or_not over a column (src/seg.c:531-560, str_get_int src/strings.c:315-341): integers (and the context's
+// nothing_char) leave the one-character snip SNIP_LOOKUP in the column and go, compacted, to the dyn-int column.
+struct GzdIntSplit {
+    const uint8_t *text; const uint32_t *off, *len; uint32_t n; uint32_t nothing_char; uint32_t lookup_off;
+    uint32_t *snip_off, *snip_len; int64_t *values; uint8_t *is_nothing; uint64_t *n_values;
+    uint64_t *tile;           // scratch [tiles]
+};
+
+// 0: a snip, 1: an integer (*v), 2: the nothing_char
+__device__ static inline int d_int_or_not (const GzdIntSplit &S, uint32_t k, int64_t *v)
+{
+    const uint32_t len = S.len[k];
+    if (!len) return 0;
+    const uint8_t *s = S.text + S.off[k];
+    if (S.nothing_char && len == 1 && s[0] == (uint8_t)S.nothing_char) { *v = 0; return 2; }
+    if ((len == 1 && s[0] == '-') || (len >= 2 && s[0] == '0') || (len >= 2 && s[0] == '-' && s[1] == '0')) return 0;
+    const uint32_t negative = s[0] == '-';
+    uint64_t out = 0;
+    for (uint32_t i = negative; i < len; i++) {
+        const uint32_t d = (uint32_t)s[i] - '0';
+        if (d > 9 || out > (uint64_t)INT64_MAX / 10) return 0;
+        out = out * 10 + d;
+        if (out > (uint64_t)INT64_MAX) return 0;
+    }
+    *v = negative ? -(int64_t)out : (int64_t)out;
+    return 1;
+}
+
+// grid (tiles)
+__global__ void __launch_bounds__(256) k_int_count (GzdIntSplit S)
+{
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    int64_t v;
+    uint64_t total;
+    (void)d_wg_scan_u64 (k < S.n && d_int_or_not (S, k, &v) ? 1 : 0, threadIdx.x, &total);
+    if (!threadIdx.x) S.tile[blockIdx.x] = total;
+}
+
+// grid (1)
+__global__ void __launch_bounds__(256) k_int_scan (GzdIntSplit S)
+{
+    const uint64_t total = d_wg_scan_array (S.tile, (S.n + 255) / 256, threadIdx.x);
+    if (!threadIdx.x) *S.n_values = total;
+}
+
+// grid (tiles)
+__global__ void __launch_bounds__(256) k_int_write (GzdIntSplit S)
+{
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    int64_t v = 0;
+    const int kind = k < S.n ? d_int_or_not (S, k, &v) : 0;
+    uint64_t total;
+    const uint64_t at = S.tile[blockIdx.x] + d_wg_scan_u64 (kind ? 1 : 0, threadIdx.x, &total);
+    if (k >= S.n) return;
+    if (kind) { S.values[at] = v; S.is_nothing[at] = kind == 2; S.snip_off[k] = S.lookup_off; S.snip_len[k] = 1; }
+    else      { S.snip_off[k] = S.off[k]; S.snip_len[k] = S.len[k]; }
+}

@@ -278,6 +278,16 @@ int gz_fastq_records (GzHandle *h, const uint8_t *text, const uint32_t *line_off
 int gz_tokenize_column (GzHandle *h, const uint8_t *text, const uint32_t *off, const uint32_t *len, uint32_t n,
                         const char *seps, uint32_t n_seps, uint32_t *item_off, uint32_t *item_len, uint32_t *n_bad_dev);
 
+/* seg_integer_or_not over a column (src/seg.c:531-560; str_get_int src/strings.c:315-341): a snip that is a decimal
+ * integer the text can be rebuilt from goes to the context's dyn-int local and leaves the one-character snip
+ * SNIP_LOOKUP in the b250; so does the context's nothing_char on its own (as a "nothing" entry); everything else stays a
+ * snip. Outputs: snip_off/snip_len [n] = the column for gz_ctx_seg_columns (lookup_off = offset in `text` of a byte
+ * holding SNIP_LOOKUP); values/is_nothing [n] = the compacted column for gz_dyn_int_columns, *n_values_dev entries.
+ * Numbers beyond int64 stay snips. All pointers device, asynchronous. */
+int gz_seg_integer_or_not (GzHandle *h, const uint8_t *text, const uint32_t *off, const uint32_t *len, uint32_t n,
+                           uint32_t nothing_char, uint32_t lookup_off, uint32_t *snip_off, uint32_t *snip_len,
+                           int64_t *values, uint8_t *is_nothing, uint64_t *n_values_dev);
+
 #ifdef __cplusplus
 }
 #endif

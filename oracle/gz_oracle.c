@@ -1595,3 +1595,37 @@ uint64_t gzo_tokenize_column (const uint8_t *text, const uint32_t *off, const ui
     }
     return n_bad;
 }
+
+/* strings.c:315-341 */
+static int o_str_get_int (const uint8_t *str, uint32_t str_len, int64_t *value)
+{
+    if (!str_len || (str_len == 1 && str[0] == '-') || (str_len >= 2 && str[0] == '0') || (str_len >= 2 && str[0] == '-' && str[1] == '0')) return 0;
+    const uint32_t negative = str[0] == '-';
+    uint64_t out = 0;
+    for (uint32_t i = negative; i < str_len; i++) {
+        if (str[i] < '0' || str[i] > '9') return 0;
+        if (out > (uint64_t)INT64_MAX / 10) return 0;
+        out = out * 10 + (uint64_t)(str[i] - '0');
+        if (out > (uint64_t)INT64_MAX) return 0;
+    }
+    *value = negative ? -(int64_t)out : (int64_t)out;
+    return 1;
+}
+
+uint64_t gzo_seg_integer_or_not (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n,
+                                 int nothing_char, uint32_t lookup_off, uint32_t *snip_off, uint32_t *snip_len,
+                                 int64_t *values, uint8_t *is_nothing)
+{
+    uint64_t nv = 0;
+    for (uint64_t k = 0; k < n; k++) {
+        int64_t v = 0;
+        const uint8_t *s = len[k] ? text + off[k] : (const uint8_t *)"";
+        const int nothing = nothing_char && len[k] == 1 && s[0] == (uint8_t)nothing_char;       /* seg.c:537-542 */
+        if (nothing || o_str_get_int (s, len[k], &v)) {
+            values[nv] = nothing ? 0 : v; is_nothing[nv] = (uint8_t)nothing; nv++;
+            snip_off[k] = lookup_off; snip_len[k] = 1;                                          /* seg_integer (..., with_lookup) */
+        }
+        else { snip_off[k] = off[k]; snip_len[k] = len[k]; }
+    }
+    return nv;
+}

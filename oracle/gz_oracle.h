@@ -184,6 +184,16 @@ long gzo_fastq_records (const uint8_t *text, const uint32_t *line_off, const uin
 uint64_t gzo_tokenize_column (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n,
                               const uint8_t *seps, uint32_t n_seps, uint32_t *item_off, uint32_t *item_len);
 
+/* seg_integer_or_not over a column (seg.c:531-560 with str_get_int strings.c:315-341): a snip that is a decimal integer
+ * the text can be rebuilt from ("" "-" "030" "-0" are not) goes to the context's dyn-int local and leaves the
+ * one-character snip SNIP_LOOKUP in the b250; the context's nothing_char alone does the same with a "nothing" entry;
+ * anything else stays a snip. snip_off/snip_len = the column for gzo_ctx_seg_column (lookup_off = where a SNIP_LOOKUP
+ * byte lives in text), values/is_nothing = the compacted column for gzo_dyn_int_column. Returns the number of values.
+ * Numbers beyond int64 are "not an integer" (the reference's overflow test there relies on signed wrap-around). */
+uint64_t gzo_seg_integer_or_not (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n,
+                                 int nothing_char, uint32_t lookup_off, uint32_t *snip_off, uint32_t *snip_len,
+                                 int64_t *values, uint8_t *is_nothing);
+
 #ifdef __cplusplus
 }
 #endif

@@ -284,6 +284,20 @@ class Oracle:
                                         seps, len(seps), io.ctypes.data_as(ctypes.c_void_p), il.ctypes.data_as(ctypes.c_void_p))
         return int(nb), io, il
 
+    def seg_integer_or_not(self, text, off, length, nothing_char=0, lookup_off=0):
+        """-> (snip_off, snip_len, values, is_nothing)"""
+        import numpy as np
+        text = bytes(text)
+        off = np.ascontiguousarray(off, dtype=np.uint32); length = np.ascontiguousarray(length, dtype=np.uint32)
+        n = len(off)
+        so = np.zeros(max(1, n), dtype=np.uint32); sl = np.zeros(max(1, n), dtype=np.uint32)
+        v = np.zeros(max(1, n), dtype=np.int64); m = np.zeros(max(1, n), dtype=np.uint8)
+        self.L.gzo_seg_integer_or_not.restype = ctypes.c_uint64
+        nv = self.L.gzo_seg_integer_or_not(text, off.ctypes.data_as(ctypes.c_void_p), length.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(n),
+                                           int(nothing_char), ctypes.c_uint32(lookup_off), so.ctypes.data_as(ctypes.c_void_p),
+                                           sl.ctypes.data_as(ctypes.c_void_p), v.ctypes.data_as(ctypes.c_void_p), m.ctypes.data_as(ctypes.c_void_p))
+        return so[:n].copy(), sl[:n].copy(), v[:nv].copy(), m[:nv].copy()
+
     # ---- sections
     def adler32(self, data, start=1):
         data = bytes(data)

@@ -292,9 +292,23 @@ def fastq_front(E, oracle, n_reads):
     for i, g in enumerate(got):
         w = oracle.ctx_seg_column(text, io[i], il[i])
         assert g["b250"] == w["b250"] and g["dict"] == w["dict"] and np.array_equal(g["counts"], w["counts"]), i
-    # a numeric token (x coordinate) as a dyn-int local
-    xs = np.array([int(text[o:o + l]) for o, l in zip(io[5], il[5])], dtype=np.int64)
-    assert E.dyn_int_column(xs) == oracle.dyn_int_column(xs)
+    # a numeric token (x coordinate): seg_integer_or_not -> dyn-int local + SNIP_LOOKUP entries in the b250
+    ltext = text + b"\x01"                                                    # SNIP_LOOKUP lives behind the text
+    got = E.seg_integer_or_not(ltext, io[5], il[5], 0, len(text))
+    want = oracle.seg_integer_or_not(ltext, io[5], il[5], 0, len(text))
+    assert all(np.array_equal(g, w) for g, w in zip(got, want)) and len(want[2]) == len(qo)
+    assert E.dyn_int_column(got[2]) == oracle.dyn_int_column(want[2])
+    assert E.ctx_seg_column(ltext, got[0], got[1])["all_the_same"]
+    # ... and the shapes that are not integers (strings.c:320-324), the nothing_char, the int64 edge
+    words = [b"0", b"-", b"030", b"-0", b"-030", b"7", b"-7", b"12a", b"", b".", b"9223372036854775807", b"9223372036854775808",
+             b"-9223372036854775807", b"99999999999999999999", b"+5", b" 5", b"1000000"]
+    wt = b"".join(words) + b"\x01"
+    wo = np.concatenate([[0], np.cumsum([len(w) for w in words])[:-1]]).astype(np.uint32); wl = np.array([len(w) for w in words], dtype=np.uint32)
+    for nc in (0, ord(".")):
+        got = E.seg_integer_or_not(wt, wo, wl, nc, len(wt) - 1)
+        want = oracle.seg_integer_or_not(wt, wo, wl, nc, len(wt) - 1)
+        assert all(np.array_equal(g, w) for g, w in zip(got, want)), nc
+        assert want[2].tolist() == [0, 7, -7] + ([0] if nc else []) + [9223372036854775807, -9223372036854775807, 1000000]
     # SEQ -> NONREF.local, QUAL -> QUAL.local
     blobs = E.local_blob_columns([(text, so, sl, False), (text, uo, ul, False)])
     assert blobs[0] == oracle.local_blob_column(text, so, sl) and blobs[1] == oracle.local_blob_column(text, uo, ul)
