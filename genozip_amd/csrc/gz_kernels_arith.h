@@ -650,22 +650,23 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
 }
 
 // ---- range coder chain ------------------------------------------------------------------------------------------
-// Measured on MI355X (tools/ubench_chain.hip): ONE wave issues an instruction every ~3.2 ns (scalar) / 2.5 ns
-// (vector) whether or not it depends on the previous one, a vector->scalar hand-over (v_readlane feeding s_*) costs
+// Measured on MI355X (tools/ubench_chain.hip): ONE wave issues at most one instruction every 4 clocks (1.67 ns at
+// 2.4 GHz) whether or not it depends on the previous one, a vector->scalar hand-over (v_readlane feeding s_*) costs
 // ~12 ns, and nothing but the instruction count of the wave matters. What is truly serial in the range coder
 // (c_range_coder.h:97-109) is only
 //        r = range / tot ;  range = (r * freq) << 8k      (k = bytes needed to bring range back above 2^24)
 // `low` is not: low += cum * r followed by shifts is a big-number addition, and addition is associative. So
-//   k_arith_chain  one wave per leaf, entirely on the scalar unit, ~12 instructions per symbol: SMEM record loads
-//                  (8 at a time, the next 8 in flight; the lines are pulled into L2 well ahead by a vector "touch"
-//                  load because SMEM returns out of order and can only be waited for as a whole), division by the
-//                  per-record magic number, renormalisation by count-leading-zeros instead of a loop, and r stored
-//                  four at a time. It never looks at cum or low.
-//   k_arith_low    one workgroup per leaf, all threads: every thread replays low += cum * r for its own slice of the
-//                  symbols from low = 0, emitting the byte that leaves the 32-bit window at every shift (plus the carry
-//                  out of the window as a 9th bit) at its absolute output position (a prefix sum of the k's), and adds
-//                  what is left in its window where the following slices' bytes go. Then the digits are normalised:
-//                  carries ripple left inside each slice and, very rarely, across slices.
+//   k_arith_chain  one wave per leaf, entirely on the scalar unit, 7 operations per symbol (d_chain_step) + the record
+//                  loads: SMEM, 64 records per loop iteration in two 32-register buffers, the next buffer in flight
+//                  (the lines are pulled into L2 1 KB ahead by a vector "touch" load because SMEM returns out of order
+//                  and can only be waited for as a whole), division by the per-record magic number, renormalisation
+//                  by count-leading-zeros instead of a loop, and r stored four at a time. It never looks at cum or low.
+//   k_low_*        all threads: every thread replays low += cum * r for its own slice of 64 symbols from low = 0,
+//                  emitting the byte that leaves the 32-bit window at every shift (plus the carry out of the window as
+//                  a 9th bit) at its absolute output position (k_low_count / k_low_scan: a prefix sum of the k's;
+//                  k_low_scatter), k_low_resid adds what is left in each window where the following slices' bytes
+//                  go, and k_low_norm normalises the digits: carries ripple left inside a tile and, very rarely, across.
+//                  The first three follow the chain chunk by chunk (k_low_gate), the last two run once at the end.
 // This reproduces RC_ShiftLow's cache / pending-0xFF bookkeeping (c_range_coder.h:70-88) exactly: that logic is just
 // a lazy form of the same addition ("[0, T1, T2, ...] plus 1 at the byte before every shift that saw a carry").
 typedef uint32_t gz_u32x4 __attribute__((vector_size (16)));
