@@ -578,7 +578,9 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
 #define GZ_MODEL_GRID_RUN 66               // run models: one per present symbol, 256 and 257
 // (tried: a build of its own for the alphabets of up to 64 symbols - 42 instead of 87 vector registers, 8 instead of 5
 //  waves per SIMD - launched beside one for the wide alphabets: no faster (4 M read pairs: 84.0 -> 86.8 ms per step).
-//  With every SIMD holding several of these waves it is the issue slots, not the waves in flight, that run out.)
+//  With every SIMD holding several of these waves it is the issue slots, not the waves in flight, that run out.
+//  Also tried: starting the busiest contexts of a chunk first (an order computed in k_ctx_scan) instead of in symbol
+//  order - the launch is not waiting for its longest wave either: 84.0 -> 84.2 ms, 1 M pairs 33.95 -> 33.87.)
 __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, const GzDivMagic *magic_tab, uint32_t p0, uint32_t chunk)
 {
     GzdLeaf &L = leaves[list[blockIdx.x]];
