@@ -914,11 +914,13 @@ extern "C" int gz_b250_generate_batch (GzHandle *h, const GzB250Job *jobs, int n
     if (!h || (n_jobs && !jobs) || n_jobs < 0) return GZ_ERR_ARG;
     if (!n_jobs) return GZ_OK;
     HIPCHK (h, hipSetDevice (h->device));
-    std::vector<GzdB250Job> J (n_jobs);
+    std::vector<GzdB250Job> J;                     // one workgroup each
+    std::vector<GzdB250Big> B;                     // the long ones: kernels over all chunks (gz_kernels_ctx.h)
+    uint32_t max_super = 0, max_tiles = 0;
     for (int i = 0; i < n_jobs; i++) {
         const GzB250Job &u = jobs[i];
         if (!u.out_len_dev || (u.seg_len && (!u.seg || !u.out))) return GZ_ERR_ARG;
-        GzdB250Job &d = J[i];
+        GzdB250Job d;
         memset (&d, 0, sizeof (d));
         d.seg = u.seg; d.seg_len = u.seg_len; d.seg_len_dev = u.seg_len_dev; d.ol_nodes_len = u.ol_nodes_len;
         d.node2word = u.node2word; d.n_new_nodes = u.n_new_nodes; d.out = u.out; d.out_len_dev = u.out_len_dev;
@@ -927,11 +929,34 @@ extern "C" int gz_b250_generate_batch (GzHandle *h, const GzB250Job *jobs, int n
         size_t nchunks = ((size_t)u.seg_len + GZ_B250_CHUNK - 1) / GZ_B250_CHUNK;
         if (!(d.wi = (int32_t *)arena_alloc (h, ((size_t)u.seg_len + 1) * 4))) return GZ_ERR_HIP;
         if (!(d.chunk_tab = (uint32_t *)arena_alloc (h, (nchunks + 1) * 7 * 4))) return GZ_ERR_HIP;
+        if (u.seg_len < GZ_B250_BIG) { J.push_back (d); continue; }
+        GzdB250Big b;
+        b.j = d;
+        const uint32_t nsuper = (uint32_t)((nchunks + GZ_B250_SUPER - 1) / GZ_B250_SUPER), tiles = (u.seg_len + 255) / 256;
+        if (!(b.stab = (uint32_t *)arena_alloc (h, ((size_t)nsuper + 1) * 7 * 4))) return GZ_ERR_HIP;
+        if (!(b.tile = (uint64_t *)arena_alloc (h, ((size_t)tiles + 1) * 8))) return GZ_ERR_HIP;
+        if (!(b.info = (uint32_t *)arena_alloc (h, 16))) return GZ_ERR_HIP;
+        if (nsuper > max_super) max_super = nsuper;
+        if (tiles > max_tiles) max_tiles = tiles;
+        B.push_back (b);
     }
     void *d_jobs;
     int rc;
-    if ((rc = upload (h, J.data (), J.size () * sizeof (GzdB250Job), &d_jobs)) != GZ_OK) return rc;
-    KLAUNCH (h, k_b250_generate, dim3 (n_jobs), dim3 (256), 4096, (GzdB250Job *)d_jobs);
+    if (!J.empty ()) {
+        if ((rc = upload (h, J.data (), J.size () * sizeof (GzdB250Job), &d_jobs)) != GZ_OK) return rc;
+        KLAUNCH (h, k_b250_generate, dim3 ((uint32_t)J.size ()), dim3 (256), 4096, (GzdB250Job *)d_jobs);
+    }
+    if (!B.empty ()) {
+        if ((rc = upload (h, B.data (), B.size () * sizeof (GzdB250Big), &d_jobs)) != GZ_OK) return rc;
+        GzdB250Big *db = (GzdB250Big *)d_jobs;
+        const uint32_t nb = (uint32_t)B.size ();
+        KLAUNCH (h, k_b250_walk, dim3 (max_super, nb), dim3 (256), (GZ_B250_SUPER * 5 + 4) * 4, db);
+        KLAUNCH (h, k_b250_chain, dim3 (nb), dim3 (1), 0, db);
+        KLAUNCH (h, k_b250_convert, dim3 (max_super, nb), dim3 (256), GZ_B250_SUPER * 8, db);
+        KLAUNCH (h, k_b250_len, dim3 (max_tiles, nb), dim3 (256), 1024, db);
+        KLAUNCH (h, k_b250_scan, dim3 (nb), dim3 (256), 2048, db);
+        KLAUNCH (h, k_b250_emit, dim3 (max_tiles, nb), dim3 (256), 1024, db);
+    }
     HIPCHK (h, hipGetLastError ());
     return GZ_OK;
 }

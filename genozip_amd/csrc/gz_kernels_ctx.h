@@ -161,6 +161,203 @@ __global__ void __launch_bounds__(256) k_b250_generate (GzdB250Job *jobs)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The same for LONG b250s (a FORMAT/PL column of a VCF VBlock is 3 x 10^7 entries, 30-40 MB: 134 ms in one workgroup):
+// the phases become kernels over all chunks. What made it one workgroup was the backward chain through the chunk
+// table - but a chunk is a map {entry 0..3} -> (exit, words), and maps compose: every workgroup composes its 256
+// chunks into one map of a "super chunk" (k_b250_walk), one thread chains the few thousand super chunks
+// (k_b250_chain), every workgroup then chains its own 256 chunks from its known entry and converts (k_b250_convert);
+// lengths, a scan over tiles of 256 words and the emission follow (k_b250_len / k_b250_scan / k_b250_emit).
+// grid (super chunks, jobs) unless noted; jobs = the long ones only.
+#define GZ_B250_SUPER 256                  // chunks per workgroup
+#define GZ_B250_BIG   (128u * 1024u)       // seg bytes from which a b250 takes this path
+
+struct GzdB250Big {
+    GzdB250Job j;
+    uint32_t *stab;          // per super chunk: [0..3] words for entry e, [4] exits (4 x 8 bit), [5] entry, [6] base
+    uint64_t *tile;          // per 256 words: encoded bytes, then their exclusive scan
+    uint32_t *info;          // [0] words, [1] ok, [2] bad node index seen
+};
+
+__device__ static inline uint32_t d_b250_seg_len (const GzdB250Job &J)
+{
+    uint32_t seg_len = J.seg_len;
+    if (J.seg_len_dev) { const uint32_t v = *J.seg_len_dev; if (v < seg_len) seg_len = v; }
+    return seg_len;
+}
+
+__global__ void __launch_bounds__(256) k_b250_walk (GzdB250Big *jobs)
+{
+    const GzdB250Big &B = jobs[blockIdx.y];
+    const uint32_t seg_len = d_b250_seg_len (B.j);
+    const uint32_t nchunks = (seg_len + GZ_B250_CHUNK - 1) / GZ_B250_CHUNK;
+    const uint32_t c0 = blockIdx.x * GZ_B250_SUPER;
+    if (c0 >= nchunks) return;
+    const uint8_t *seg = B.j.seg;
+    uint32_t *ctab = B.j.chunk_tab;
+    uint32_t *sh = (uint32_t *)gz_lds;               // [c * 5 + e] words, [c * 5 + 4] exits of the workgroup's chunks
+    const uint32_t c = c0 + threadIdx.x;
+    if (c < nchunks) {
+        int64_t hi = (int64_t)seg_len - (int64_t)c * GZ_B250_CHUNK, lo = hi - GZ_B250_CHUNK;
+        if (lo < 0) lo = 0;
+        uint32_t exits = 0;
+        for (int e = 0; e < 4; e++) {
+            int64_t p = hi - 1 - e;
+            uint32_t cnt = 0;
+            while (p >= lo) { cnt++; p -= d_varl_len (seg[p]); }
+            uint32_t ex = (uint32_t)(lo - 1 - p);
+            if (lo == 0 && ex != 0) ex = 0xff;
+            ctab[c * 7 + e] = cnt; sh[threadIdx.x * 5 + e] = cnt;
+            exits |= (ex & 0xff) << (8 * e);
+        }
+        ctab[c * 7 + 4] = exits; sh[threadIdx.x * 5 + 4] = exits;
+    }
+    __syncthreads ();
+    if (threadIdx.x < 4) {                           // the super chunk's map for entry state e
+        const uint32_t last = nchunks - c0 < GZ_B250_SUPER ? nchunks - c0 : GZ_B250_SUPER;
+        uint32_t state = threadIdx.x, words = 0;
+        for (uint32_t k = 0; k < last && state != 0xff; k++) { words += sh[k * 5 + state]; state = (sh[k * 5 + 4] >> (8 * state)) & 0xff; }
+        B.stab[blockIdx.x * 7 + threadIdx.x] = words;
+        sh[GZ_B250_SUPER * 5 + threadIdx.x] = state;
+    }
+    __syncthreads ();
+    if (!threadIdx.x) B.stab[blockIdx.x * 7 + 4] = sh[GZ_B250_SUPER * 5] | (sh[GZ_B250_SUPER * 5 + 1] << 8) | (sh[GZ_B250_SUPER * 5 + 2] << 16) | (sh[GZ_B250_SUPER * 5 + 3] << 24);
+}
+
+// grid (jobs), one thread
+__global__ void k_b250_chain (GzdB250Big *jobs)
+{
+    const GzdB250Big &B = jobs[blockIdx.x];
+    const uint32_t seg_len = d_b250_seg_len (B.j);
+    const uint32_t nchunks = (seg_len + GZ_B250_CHUNK - 1) / GZ_B250_CHUNK, nsuper = (nchunks + GZ_B250_SUPER - 1) / GZ_B250_SUPER;
+    uint32_t state = 0, running = 0, ok = 1;
+    for (uint32_t s = 0; s < nsuper; s++) {
+        B.stab[s * 7 + 5] = state; B.stab[s * 7 + 6] = running;
+        running += B.stab[s * 7 + state];
+        state = (B.stab[s * 7 + 4] >> (8 * state)) & 0xff;
+        if (state == 0xff) { ok = 0; break; }
+    }
+    B.info[0] = ok ? running : 0; B.info[1] = ok; B.info[2] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_b250_convert (GzdB250Big *jobs)
+{
+    const GzdB250Big &B = jobs[blockIdx.y];
+    const GzdB250Job &J = B.j;
+    const uint32_t seg_len = d_b250_seg_len (J);
+    const uint32_t nchunks = (seg_len + GZ_B250_CHUNK - 1) / GZ_B250_CHUNK;
+    const uint32_t c0 = blockIdx.x * GZ_B250_SUPER;
+    if (c0 >= nchunks || !B.info[1]) return;
+    uint32_t *ctab = J.chunk_tab;
+    uint32_t *sh = (uint32_t *)gz_lds;               // [k * 2] entry, [k * 2 + 1] base of the workgroup's chunks
+    if (!threadIdx.x) {
+        const uint32_t last = nchunks - c0 < GZ_B250_SUPER ? nchunks - c0 : GZ_B250_SUPER;
+        uint32_t state = B.stab[blockIdx.x * 7 + 5], running = B.stab[blockIdx.x * 7 + 6];
+        for (uint32_t k = 0; k < last; k++) {
+            sh[k * 2] = state; sh[k * 2 + 1] = running;
+            running += ctab[(c0 + k) * 7 + state];
+            state = (ctab[(c0 + k) * 7 + 4] >> (8 * state)) & 0xff;
+        }
+    }
+    __syncthreads ();
+    const uint32_t c = c0 + threadIdx.x;
+    if (c >= nchunks) return;
+    const uint8_t *seg = J.seg;
+    int32_t *wi = J.wi;
+    int64_t hi = (int64_t)seg_len - (int64_t)c * GZ_B250_CHUNK, lo = hi - GZ_B250_CHUNK;
+    if (lo < 0) lo = 0;
+    int64_t p = hi - 1 - sh[threadIdx.x * 2];
+    uint32_t k = sh[threadIdx.x * 2 + 1], bad = 0;
+    while (p >= lo) {
+        const int n = d_varl_len (seg[p]);
+        if (p - n + 1 < 0) { bad = 1; break; }
+        int32_t v = d_seg_value (seg, p, n);
+        if (v >= 0 && (uint32_t)v >= J.ol_nodes_len) {       // node -> word (context.h:109)
+            const uint32_t local = (uint32_t)v - J.ol_nodes_len;
+            if (local >= J.n_new_nodes) { bad = 1; v = 0; }
+            else v = J.node2word[local];
+        }
+        wi[k++] = v;
+        p -= n;
+    }
+    if (bad) atomicMax (&B.info[2], 1u);
+}
+
+// forward word i of the stream, ONE_UP applied (b250.c:236,251): its code and length
+__device__ static inline int d_b250_word (const GzdB250Job &J, const int32_t *wi, uint32_t cnt, uint32_t i, bool one_up_ok, uint32_t *code)
+{
+    int32_t cur = wi[cnt - 1 - i];
+    if (one_up_ok && i && cur >= 0) { const int32_t prev = wi[cnt - i]; if (prev >= 0 && cur == prev + 1) cur = -2; }
+    return d_varl_code (cur, code);
+}
+
+// grid (tiles of 256 words over seg_len - every word is at least a byte, jobs)
+__global__ void __launch_bounds__(256) k_b250_len (GzdB250Big *jobs)
+{
+    const GzdB250Big &B = jobs[blockIdx.y];
+    const uint32_t cnt = B.info[0], i = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= cnt) return;
+    const bool one_up_ok = (uint64_t)B.j.n_new_nodes + B.j.ol_nodes_len > 1024;
+    uint32_t code, len = 0;
+    if (i < cnt) len = (uint32_t)d_b250_word (B.j, B.j.wi, cnt, i, one_up_ok, &code);
+    uint32_t *sh = (uint32_t *)gz_lds;
+    sh[threadIdx.x] = len;
+    __syncthreads ();
+    for (int d = 128; d; d >>= 1) { if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d]; __syncthreads (); }
+    if (!threadIdx.x) B.tile[blockIdx.x] = sh[0];
+}
+
+// grid (jobs)
+__global__ void __launch_bounds__(256) k_b250_scan (GzdB250Big *jobs)
+{
+    const GzdB250Big &B = jobs[blockIdx.x];
+    const uint32_t cnt = B.info[0], n_tiles = (cnt + 255) / 256, tid = threadIdx.x;
+    uint64_t *sh = (uint64_t *)gz_lds;
+    uint64_t carry = 0;
+    for (uint32_t base = 0; base < n_tiles; base += 256) {
+        const uint32_t t = base + tid;
+        const uint64_t v = t < n_tiles ? B.tile[t] : 0;
+        __syncthreads ();
+        sh[tid] = v;
+        __syncthreads ();
+        for (int d = 1; d < 256; d <<= 1) {
+            const uint64_t add = (int)tid >= d ? sh[tid - d] : 0;
+            __syncthreads ();
+            sh[tid] += add;
+            __syncthreads ();
+        }
+        if (t < n_tiles) B.tile[t] = carry + sh[tid] - v;
+        carry += sh[255];
+    }
+    if (!tid) {
+        const bool ok = B.info[1] && !B.info[2];
+        *B.j.out_len_dev = ok ? (uint32_t)carry : 0;
+        if (B.j.status_dev) *B.j.status_dev = ok ? GZ_ST_OK : GZ_ST_CORRUPT;
+    }
+}
+
+// grid like k_b250_len
+__global__ void __launch_bounds__(256) k_b250_emit (GzdB250Big *jobs)
+{
+    const GzdB250Big &B = jobs[blockIdx.y];
+    const uint32_t cnt = B.info[0], i = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= cnt || !B.info[1] || B.info[2]) return;
+    const bool one_up_ok = (uint64_t)B.j.n_new_nodes + B.j.ol_nodes_len > 1024;
+    uint32_t code = 0, len = 0;
+    if (i < cnt) len = (uint32_t)d_b250_word (B.j, B.j.wi, cnt, i, one_up_ok, &code);
+    uint32_t *sh = (uint32_t *)gz_lds;
+    sh[threadIdx.x] = len;
+    __syncthreads ();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t add = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+        __syncthreads ();
+        sh[threadIdx.x] += add;
+        __syncthreads ();
+    }
+    uint8_t *o = B.j.out + B.tile[blockIdx.x] + (sh[threadIdx.x] - len);
+    for (uint32_t k = 0; k < len; k++) o[k] = (uint8_t)(code >> (8 * (len - 1 - k)));
+}
+
 // ======================================================================================================
 // element byte order: little-endian native <-> big-endian file order, zig-zag "interlace" for signed types
 // ======================================================================================================
