@@ -84,7 +84,7 @@ struct GzdLeaf {
     uint32_t  *spos;          // arith order-1: positions grouped by context (the byte before), stream order inside a context
     uint8_t   *srk;           // arith order-1: static rank of the symbol at spos[j]
     uint32_t  *ctxoff;        // arith order-1: [tile][context] -> index into spos/srk of the first occurrence at or after the tile
-    uint32_t  *ctxend;        // arith order-1: [context] -> end of the context's run in the position chunk sorted last
+    uint32_t  *ctxend;        // arith order-1: [position chunk][context] -> end of the context's run in that chunk's part of the sorted lists
     uint16_t  *ev_ctx;        // arith run-length variant: model id of every coding event (0..255 literal models, 256 + 0..257 run models)
     uint8_t   *ev_sym;        // arith run-length variant: its symbol (literal: rank in the leaf's alphabet; run digit: 0..3)
     uint32_t  arith_n;        // arith: symbols the coder sees: coded_n, or the number of events of the run-length variant

@@ -41,6 +41,7 @@ struct ArenaBlock { uint8_t *base; size_t size, used; };
 // workgroups of persistent chain kernels in flight in this process / those of them that hold a whole compute unit
 static std::atomic<int> g_chain_wgs (0), g_chain_cus (0);
 
+#define GZ_MAX_CHUNKS 17     // position chunks of the arithmetic coder's pipeline: at most 16 (arith_pipe_setup) + a partial one
 struct GzHandle {
     int device;
     hipStream_t stream;
@@ -53,6 +54,8 @@ struct GzHandle {
     hipEvent_t ev_small;
     hipStream_t stream6;      // the `low` kernels of the long leaves, following the chain chunk by chunk
     hipEvent_t ev_low;
+    hipStream_t stream7;      // the context sort of position chunk k+1, beside the models of chunk k
+    hipEvent_t ev_sort[GZ_MAX_CHUNKS];
     hipEvent_t ev_chain_go, ev_chain;   // the persistent chain may start / has finished
     int n_cu = 0;             // compute units of the device
     int chain_wgs_held = 0, chain_cus_held = 0;   // this handle's share of g_chain_wgs / g_chain_cus, returned at gz_sync
@@ -149,6 +152,7 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
         hipStreamCreateWithPriority (&h->stream4, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipStreamCreateWithPriority (&h->stream5, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipStreamCreateWithPriority (&h->stream6, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipStreamCreateWithPriority (&h->stream7, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipEventCreateWithFlags (&h->ev_low, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags (&h->ev_small, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags (&h->ev_model_fork, hipEventDisableTiming) != hipSuccess ||
@@ -156,6 +160,8 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
         hipEventCreateWithFlags (&h->ev_chain_go, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags (&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags (&h->ev_join, hipEventDisableTiming) != hipSuccess) { delete h; if (err) *err = GZ_ERR_HIP; return NULL; }
+    for (int k = 0; k < GZ_MAX_CHUNKS; k++)
+        if (hipEventCreateWithFlags (&h->ev_sort[k], hipEventDisableTiming) != hipSuccess) { delete h; if (err) *err = GZ_ERR_HIP; return NULL; }
     // log(1024+k), log(4096+k) from the host libm: what the reference's compute_shift() sees (rANS_static4x16pr.c:647)
     GzLogTable lt;
     for (int k = 0; k <= 256; k++) { lt.l10[k] = log (1024.0 + k); lt.l12[k] = log (4096.0 + k); }
@@ -220,6 +226,8 @@ extern "C" void gz_destroy (GzHandle *h)
     (void)hipStreamDestroy (h->stream4);
     (void)hipStreamDestroy (h->stream5);
     (void)hipStreamDestroy (h->stream6);
+    (void)hipStreamDestroy (h->stream7);
+    for (int k = 0; k < GZ_MAX_CHUNKS; k++) (void)hipEventDestroy (h->ev_sort[k]);
     (void)hipEventDestroy (h->ev_low);
     (void)hipEventDestroy (h->ev_small);
     (void)hipEventDestroy (h->ev_model_fork);
@@ -345,7 +353,7 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
             if (!(L.spos   = (uint32_t *)arena_alloc (h, ((size_t)nb + 64) * 4))) return false;
             if (!(L.srk    = (uint8_t *)arena_alloc (h, (size_t)nb + 64))) return false;
             if (!(L.ctxoff = (uint32_t *)arena_alloc (h, (nt + 1) * nctx * 4))) return false;
-            if (!(L.ctxend = (uint32_t *)arena_alloc (h, nctx * 4))) return false;
+            if (!(L.ctxend = (uint32_t *)arena_alloc (h, (size_t)GZ_MAX_CHUNKS * nctx * 4))) return false;   // one row per position chunk
             P.any_arith_o1 = true;
             P.o1_list.push_back ((uint32_t)P.leaves.size ());
         }
@@ -557,9 +565,15 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
             else {
                 HIPCHK (h, hipEventRecord (h->ev_model_fork, h->stream));        // (after k_leaf_prep)
                 HIPCHK (h, hipStreamWaitEvent (h->stream4, h->ev_model_fork, 0));
+                HIPCHK (h, hipStreamWaitEvent (h->stream7, h->ev_model_fork, 0));
+                // the sort of a chunk needs nothing from the models: it runs ahead on its own stream (one after the other on
+                // the models' stream, sort + model of 16 chunks WAS the length of the whole step - the chain kept waiting)
+                if (A.n_chunks > GZ_MAX_CHUNKS) return GZ_ERR;
                 for (uint32_t k = 0; k < A.n_chunks; k++) {
                     const uint32_t p0 = k * A.chunk, span = P.max_arith_n - p0 < A.chunk ? P.max_arith_n - p0 : A.chunk;
-                    if ((rc = sort_chunk (h->stream4, A.d_big, A.nbig, p0, A.chunk, span)) != GZ_OK) return rc;
+                    if ((rc = sort_chunk (h->stream7, A.d_big, A.nbig, p0, A.chunk, span)) != GZ_OK) return rc;
+                    HIPCHK (h, hipEventRecord (h->ev_sort[k], h->stream7));
+                    HIPCHK (h, hipStreamWaitEvent (h->stream4, h->ev_sort[k], 0));
                     KLAUNCH_ON (h, h->stream4, k_arith_model, dim3 (A.nbig, grid_y), dim3 (64), GZ_KEEP_OFF_LDS, d_leaves, A.d_big, magic, p0, A.chunk);
                     hipLaunchKernelGGL (k_arith_progress, dim3 (1), dim3 (1), 0, h->stream4, A.d_progress, k + 1);
                 }

@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(256) k_ctx_scan (GzdLeaf *leaves, const uint32
     for (uint32_t c = threadIdx.x; c < nctx; c += 256) {
         const uint32_t base = sh[c];
         for (uint32_t t = t0; t < t1; t++) off[(size_t)t * nctx + c] += base;
-        L.ctxend[c] = base + sh[GZ_CTX_MAX + c];
+        L.ctxend[(size_t)(chunk == 0xffffffffu ? 0 : p0 / chunk) * nctx + c] = base + sh[GZ_CTX_MAX + c];   // (a row per chunk: the sort runs ahead of the models)
     }
 }
 
@@ -595,7 +595,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
     const uint32_t p1 = (n_u - p0 > chunk) ? p0 + chunk : n_u;
     const uint32_t *off = d_uniform_ptr (L.ctxoff), *spos = d_uniform_ptr (L.spos);
     const uint8_t *srk = d_uniform_ptr (L.srk);
-    const uint32_t *cend = d_uniform_ptr (L.ctxend);
+    const uint32_t *cend = d_uniform_ptr (L.ctxend + (size_t)(chunk == 0xffffffffu ? 0 : p0 / chunk) * L.nctx);
     const uint32_t t0 = p0 / GZ_CTX_TILE;                      // (chunks are whole tiles)
     uint32_t *mstate = d_uniform_ptr (L.mstate);
 
