@@ -1096,7 +1096,7 @@ extern "C" int gz_acgt_unpack (GzHandle *h, const uint8_t *packed, const uint8_t
 // ---------------------------------------------------------------------------------------------------------
 extern "C" int gz_ctx_seg_columns (GzHandle *h, const GzColumnJob *jobs, int n_jobs)
 {
-    if (!h || (n_jobs && !jobs) || n_jobs < 0) return GZ_ERR_ARG;
+    if (!h || (n_jobs && !jobs) || n_jobs < 0 || n_jobs > 65535) return GZ_ERR_ARG;   // (one grid row per column)
     if (!n_jobs) return GZ_OK;
     HIPCHK (h, hipSetDevice (h->device));
     std::vector<GzdColumn> J (n_jobs);
@@ -1158,7 +1158,7 @@ extern "C" int gz_ctx_seg_columns (GzHandle *h, const GzColumnJob *jobs, int n_j
 
 extern "C" int gz_dyn_int_columns (GzHandle *h, const GzDynIntJob *jobs, int n_jobs)
 {
-    if (!h || (n_jobs && !jobs) || n_jobs < 0) return GZ_ERR_ARG;
+    if (!h || (n_jobs && !jobs) || n_jobs < 0 || n_jobs > 65535) return GZ_ERR_ARG;   // (one grid row per column)
     if (!n_jobs) return GZ_OK;
     HIPCHK (h, hipSetDevice (h->device));
     std::vector<GzdDynInt> J (n_jobs);
@@ -1185,7 +1185,7 @@ extern "C" int gz_dyn_int_columns (GzHandle *h, const GzDynIntJob *jobs, int n_j
 
 extern "C" int gz_local_blob_columns (GzHandle *h, const GzBlobJob *jobs, int n_jobs)
 {
-    if (!h || (n_jobs && !jobs) || n_jobs < 0) return GZ_ERR_ARG;
+    if (!h || (n_jobs && !jobs) || n_jobs < 0 || n_jobs > 65535) return GZ_ERR_ARG;   // (one grid row per column)
     if (!n_jobs) return GZ_OK;
     HIPCHK (h, hipSetDevice (h->device));
     std::vector<GzdBlob> J (n_jobs);

@@ -208,7 +208,8 @@ int gz_acgt_unpack (GzHandle *h, const uint8_t *packed, const uint8_t *x, uint64
  * dictionary cloned from the file-level context, ctx_clone) or ol_nodes.len + the rank of its first occurrence in the
  * VBlock. All pointers device; asynchronous on the handle's stream (results valid after gz_sync).
  *   snip k = text[off[k] .. off[k]+len[k]); len 0 = WORD_INDEX_EMPTY, or WORD_INDEX_MISSING if off[k] == GZ_SNIP_MISSING
- *   (the reference's snip == NULL, context.c:331-335). Limits: n < 2^30, the VBlock's dictionary < 4 GB.
+ *   (the reference's snip == NULL, context.c:331-335). Limits: n < 2^30, the VBlock's dictionary < 4 GB, at most 65 535
+ *   columns per call.
  * The b250 produced here is the input of gz_b250_generate once the host has merged the new words (a4) and knows
  * node2word[]. */
 #define GZ_SNIP_MISSING 0xffffffffu
