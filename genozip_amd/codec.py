@@ -205,12 +205,15 @@ class Engine:
             tab[i].n_new_nodes = len(n2w)
             tab[i].out = self.mem.ptr(ob)
             tab[i].out_len_dev = self.mem.ptr(lb)
+            tab[i].status_dev = self.mem.ptr(lb) + 4
         self._check(self.L.gz_b250_generate_batch(self.h, tab, n), "gz_b250_generate_batch")
         self.sync()
         res = []
         for i in range(n):
-            ln = int(np.frombuffer(self.mem.download(lens[i], 4), dtype=np.uint32)[0])
-            res.append(self.mem.download(outs[i], ln))
+            ln, st = np.frombuffer(self.mem.download(lens[i], 8), dtype=np.int32)
+            if st != 1:
+                raise GenozipAMDError("b250 %d: malformed seg-format stream or node index out of range (status %d)" % (i, st))
+            res.append(self.mem.download(outs[i], int(ln)))
         return res
 
     def b250_generate(self, seg, ol_nodes_len, node2word):
@@ -239,7 +242,7 @@ class Engine:
         return a.value
 
     # ---- seg-side appends, a column at a time (rows a1-a3) ------------------------------------------------
-    def ctx_seg_columns(self, columns, keep_on_device=False):
+    def ctx_seg_columns(self, columns, keep_on_device=False, dict_cap=None):
         """columns: list of (text bytes | device buffer, off u32[n], len u32[n], ol_snips) -> list of dicts with the
         keys node_index, dict, node_char_index, node_snip_len, counts, b250, b250_count, all_the_same
         (ctx_create_node_do + b250_seg_append over the whole column)"""
@@ -263,16 +266,16 @@ class Engine:
             ol_ci = np.zeros(n_ol, dtype=np.uint64)
             if n_ol > 1:
                 ol_ci[1:] = np.cumsum(ol_len[:-1].astype(np.uint64) + 1)
-            dict_cap = int(length.astype(np.uint64).sum()) + n
+            dict_cap_i = int(length.astype(np.uint64).sum()) + n if dict_cap is None else int(dict_cap)
             b = dict(off=self.mem.upload(off), len=self.mem.upload(length), ol_dict=self.mem.upload(ol_dict),
                      ol_ci=self.mem.upload(ol_ci), ol_len=self.mem.upload(ol_len), ni=self.mem.alloc(4 * n + 16),
-                     dict=self.mem.alloc(dict_cap + 16), nci=self.mem.alloc(8 * n + 16), nsl=self.mem.alloc(4 * n + 16),
+                     dict=self.mem.alloc(dict_cap_i + 16), nci=self.mem.alloc(8 * n + 16), nsl=self.mem.alloc(4 * n + 16),
                      counts=self.mem.alloc(4 * (n + n_ol) + 16), b250=self.mem.alloc(4 * n + 16), res=self.mem.alloc(C.sizeof(GzColumnResult)))
             keep.append((tbuf, b))
             j = tab[i]
             j.text = self.mem.ptr(tbuf); j.off = self.mem.ptr(b["off"]); j.len = self.mem.ptr(b["len"]); j.n = n
             j.ol_dict = self.mem.ptr(b["ol_dict"]); j.ol_char_index = self.mem.ptr(b["ol_ci"]); j.ol_snip_len = self.mem.ptr(b["ol_len"]); j.n_ol = n_ol
-            j.node_index = self.mem.ptr(b["ni"]); j.dict = self.mem.ptr(b["dict"]); j.dict_cap = dict_cap
+            j.node_index = self.mem.ptr(b["ni"]); j.dict = self.mem.ptr(b["dict"]); j.dict_cap = dict_cap_i
             j.node_char_index = self.mem.ptr(b["nci"]); j.node_snip_len = self.mem.ptr(b["nsl"]); j.counts = self.mem.ptr(b["counts"])
             j.b250 = self.mem.ptr(b["b250"]); j.result_dev = self.mem.ptr(b["res"])
             outs.append((n, n_ol, b))
@@ -294,8 +297,8 @@ class Engine:
                             all_the_same=bool(r.all_the_same)))
         return res
 
-    def ctx_seg_column(self, text, off, length, ol_snips=()):
-        return self.ctx_seg_columns([(bytes(text), off, length, list(ol_snips))])[0]
+    def ctx_seg_column(self, text, off, length, ol_snips=(), dict_cap=None):
+        return self.ctx_seg_columns([(bytes(text), off, length, list(ol_snips))], dict_cap=dict_cap)[0]
 
     def dyn_int_columns(self, columns):
         """columns: list of (int64 values, is_nothing | None, nothing_char) -> list of (ltype, native LE bytes)"""

@@ -91,6 +91,21 @@ def b250(E, oracle, n_entries):
         assert g == oracle.b250_generate(seg, ol, n2w), (len(seg), ol, len(n2w))
 
 
+def b250_malformed(E, oracle, n_entries):
+    """what the reference would ASSERT on: a truncated word at the start of the stream, a node index beyond the VBlock's
+    nodes - reported as an error (never as output), on the one-workgroup and on the multi-workgroup path alike"""
+    import pytest
+    for ne in (200, n_entries):
+        ni, n2w = cases.b250_case(31, ne, 1500, 700, True)
+        seg = oracle.b250_seg(ni, 1500)
+        assert E.b250_generate(seg, 1500, n2w) == oracle.b250_generate(seg, 1500, n2w)
+        for bad, n2 in ((b"\xe0" + seg, n2w), (seg, n2w[:3])):
+            with pytest.raises(RuntimeError):
+                oracle.b250_generate(bad, 1500, n2)
+            with pytest.raises(RuntimeError):
+                E.b250_generate(bad, 1500, n2)
+
+
 def local(E, oracle, rows, cols):
     r = synth.u32(42, rows * cols)
     for lt, dt in ((1, "<i1"), (2, "<u1"), (3, "<i2"), (4, "<u2"), (5, "<i4"), (6, "<u4"), (7, "<i8"), (8, "<u8"), (9, "<f4"), (11, "<u1")):
@@ -220,6 +235,11 @@ def seg_columns(E, oracle, n):
     # one column on its own == the same column in a batch
     name, t, o, l, ol = cases[1]
     assert E.ctx_seg_column(t, o, l, ol)["b250"] == got[1]["b250"]
+    # a dictionary buffer that is too small is reported, not overrun
+    import pytest
+    from genozip_amd.codec import GenozipAMDError
+    with pytest.raises(GenozipAMDError):
+        E.ctx_seg_column(t, o, l, ol, dict_cap=3)
 
     # dyn_int_append over columns
     r = synth.u32(778, n + 8).astype(np.int64)

@@ -60,3 +60,7 @@ def test_emul_fastq_front(emul_engine, oracle):
 def test_emul_b250_long(emul_engine, oracle):
     """b250s beyond GZ_B250_BIG take the multi-workgroup path (super chunks of 256 x 64 bytes)"""
     parity.b250(emul_engine, oracle, 90000)
+
+
+def test_emul_b250_malformed(emul_engine, oracle):
+    parity.b250_malformed(emul_engine, oracle, 60000)
