@@ -64,3 +64,12 @@ def test_emul_b250_long(emul_engine, oracle):
 
 def test_emul_b250_malformed(emul_engine, oracle):
     parity.b250_malformed(emul_engine, oracle, 60000)
+
+
+def test_emul_arith_many_long_leaves(emul_engine, oracle):
+    """nine leaves that all span position chunks (three chain workgroups, the last one partly filled)"""
+    from genozip_amd import synth
+    items = [(16, synth.markov_bytes(40 + i, 66000 + 997 * i, 30 + i, 33).tobytes()) for i in range(9)]
+    got = emul_engine.compress_many(items)
+    for (c, d), g in zip(items, got):
+        assert g == oracle.codec_compress(c, d), (c, len(d))
