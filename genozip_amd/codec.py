@@ -418,6 +418,17 @@ class Engine:
         return (np.frombuffer(self.mem.download(so, 4 * n), dtype=np.uint32), np.frombuffer(self.mem.download(sl, 4 * n), dtype=np.uint32),
                 np.frombuffer(self.mem.download(vb, 8 * nv), dtype=np.int64), np.frombuffer(self.mem.download(mb, nv), dtype=np.uint8))
 
+    def local_generate_partial(self, ltype, raw_native_le, rows, cols, missing, to_file=True):
+        """dyn_int_transpose's partial case: present elements row-major -> file order, column-major (and back)"""
+        import numpy as np
+        buf = self.mem.upload(raw_native_le)
+        scratch = self.mem.alloc(len(raw_native_le) + 16)
+        mb = self.mem.upload(np.ascontiguousarray(missing, dtype=np.uint8))
+        w = {2: 1, 4: 2, 6: 4, 28: 1, 29: 2, 30: 4}[ltype]
+        f = self.L.gz_local_generate_partial if to_file else self.L.gz_local_partial_to_native
+        lt = self._check(f(self.h, ltype, self.mem.ptr(buf), len(raw_native_le) // w, rows, cols, self.mem.ptr(mb), self.mem.ptr(scratch)), "gz_local_generate_partial")
+        return lt, self.mem.download(buf, len(raw_native_le))
+
     # ---- CODEC_ACGT pre-transform (codec_acgt.c) ----------------------------------------------------------
     def acgt_pack(self, seq, in_place=False):
         """SEQ bytes -> (2-bit packed bytes, exception stream, has_x)"""

@@ -1040,6 +1040,61 @@ extern "C" int gz_local_generate (GzHandle *h, int ltype, void *data, uint64_t n
 extern "C" int gz_local_to_native (GzHandle *h, int ltype, void *data, uint64_t n, uint32_t cols, void *scratch)
 { return local_xform (h, ltype, data, n, cols, scratch, 0); }
 
+static int local_partial (GzHandle *h, int ltype, void *data, uint64_t n_present, uint32_t rows, uint32_t cols,
+                          const uint8_t *missing, void *scratch, int to_file)
+{
+    const int base = to_file ? ltype : ltype == GZ_LT_UINT8_PTR ? GZ_LT_UINT8 : ltype == GZ_LT_UINT16_PTR ? GZ_LT_UINT16 : ltype == GZ_LT_UINT32_PTR ? GZ_LT_UINT32 : -1;
+    if (!h || (base != GZ_LT_UINT8 && base != GZ_LT_UINT16 && base != GZ_LT_UINT32) || !rows || !cols || !missing) return GZ_ERR_ARG;
+    if (n_present && (!data || !scratch)) return GZ_ERR_ARG;
+    const uint64_t cells = (uint64_t)rows * cols;
+    if (cells >= (1ull << 32) || n_present > cells) return GZ_ERR_ARG;
+    int rc;
+    if ((rc = gz_sync (h)) < 0) return rc;
+    HIPCHK (h, hipSetDevice (h->device));
+    const uint32_t w = lt_width (base);
+    if (to_file && w > 1 && n_present) {
+        const uint32_t blocks = (uint32_t)((n_present + 1023) / 1024 > 4096 ? 4096 : (n_present + 1023) / 1024);
+        hipLaunchKernelGGL (k_local_order, dim3 (blocks), dim3 (256), 0, h->stream, (uint8_t *)data, n_present, w, 0, 1);
+    }
+    GzdPartial P;
+    memset (&P, 0, sizeof (P));
+    const uint32_t tiles = (uint32_t)((cells + 255) / 256);
+    uint8_t *miss_t = (uint8_t *)arena_alloc (h, cells);
+    P.rank_a = (uint32_t *)arena_alloc (h, cells * 4);
+    P.tile_a = (uint64_t *)arena_alloc (h, ((size_t)tiles + 1) * 8);
+    P.tile_b = (uint64_t *)arena_alloc (h, ((size_t)tiles + 1) * 8);
+    P.status = (int32_t *)arena_alloc (h, 4);
+    if (!miss_t || !P.rank_a || !P.tile_a || !P.tile_b || !P.status) return GZ_ERR_HIP;
+    P.missing = missing; P.miss_t = miss_t; P.cells = cells; P.rows = rows; P.cols = cols; P.w = w; P.n_present = n_present;
+    P.in = (const uint8_t *)data; P.out = (uint8_t *)scratch; P.to_file = to_file ? 1 : 0;
+    const int32_t ok = GZ_ST_OK;
+    HIPCHK (h, hipMemcpy (P.status, &ok, 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL (k_transpose, dim3 ((cols + 31) / 32, (rows + 31) / 32), dim3 (32, 8), 32 * 33 * 4 + 128, h->stream, missing, miss_t, rows, cols, 1u);
+    KLAUNCH (h, k_ptr_count, dim3 (tiles, 2), dim3 (256), 2048, P);
+    KLAUNCH (h, k_ptr_scan, dim3 (2), dim3 (256), 2048, P);
+    KLAUNCH (h, k_ptr_rank, dim3 (tiles), dim3 (256), 2048, P);
+    KLAUNCH (h, k_ptr_gather, dim3 (tiles), dim3 (256), 2048, P);
+    if (n_present) HIPCHK (h, hipMemcpyAsync (data, scratch, n_present * w, hipMemcpyDeviceToDevice, h->stream));
+    if (!to_file && w > 1 && n_present) {
+        const uint32_t blocks = (uint32_t)((n_present + 1023) / 1024 > 4096 ? 4096 : (n_present + 1023) / 1024);
+        hipLaunchKernelGGL (k_local_order, dim3 (blocks), dim3 (256), 0, h->stream, (uint8_t *)data, n_present, w, 0, 0);
+    }
+    HIPCHK (h, hipGetLastError ());
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    int32_t st = 0;
+    HIPCHK (h, hipMemcpy (&st, P.status, 4, hipMemcpyDeviceToHost));
+    if ((rc = gz_sync (h)) < 0) return rc;
+    if (st != GZ_ST_OK) { h->err = "partial transpose: the mask does not leave n_present elements"; return GZ_ERR_CORRUPT; }
+    if (!to_file) return base;
+    return base == GZ_LT_UINT8 ? GZ_LT_UINT8_PTR : base == GZ_LT_UINT16 ? GZ_LT_UINT16_PTR : GZ_LT_UINT32_PTR;
+}
+
+extern "C" int gz_local_generate_partial (GzHandle *h, int ltype, void *data, uint64_t n_present, uint32_t rows, uint32_t cols, const uint8_t *missing, void *scratch)
+{ return local_partial (h, ltype, data, n_present, rows, cols, missing, scratch, 1); }
+
+extern "C" int gz_local_partial_to_native (GzHandle *h, int ltype, void *data, uint64_t n_present, uint32_t rows, uint32_t cols, const uint8_t *missing, void *scratch)
+{ return local_partial (h, ltype, data, n_present, rows, cols, missing, scratch, 0); }
+
 extern "C" int gz_adler32 (GzHandle *h, const uint8_t *data, uint64_t len, uint32_t *adler_out)
 {
     if (!h || !adler_out || (len && !data) || len > 0xffffffffull) return GZ_ERR_ARG;

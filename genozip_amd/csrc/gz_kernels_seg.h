@@ -705,3 +705,57 @@ __global__ void __launch_bounds__(256) k_int_write (GzdIntSplit S)
     if (kind) { S.values[at] = v; S.is_nothing[at] = kind == 2; S.snip_off[k] = S.lookup_off; S.snip_len[k] = 1; }
     else      { S.snip_off[k] = S.off[k]; S.snip_len[k] = S.len[k]; }
 }
+
+// ---- row a7, partial case: dyn_int_transpose with a `missing` mask (src/dyn_int.c:64-72,89-96,104-129) --------------
+// local holds only the present elements of a rows x cols matrix, in row-major order; the file wants them in
+// column-major order. An element's source index is its rank among the present cells in row-major order, its destination
+// the rank in column-major order: two prefix sums over the mask (the second over the transposed mask, so that both run
+// along memory), then a gather.
+struct GzdPartial {
+    const uint8_t *missing, *miss_t; uint64_t cells; uint32_t rows, cols, w; uint64_t n_present;
+    const uint8_t *in; uint8_t *out;
+    uint32_t *rank_a;         // scratch [cells]: row-major rank of every present cell
+    uint64_t *tile_a, *tile_b;
+    int32_t *status; uint32_t to_file;
+};
+
+// grid (tiles of 256 cells, 2): y = 0 the mask, y = 1 the transposed mask
+__global__ void __launch_bounds__(256) k_ptr_count (GzdPartial P)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint8_t *m = blockIdx.y ? P.miss_t : P.missing;
+    uint64_t total;
+    (void)d_wg_scan_u64 (i < P.cells && !m[i] ? 1 : 0, threadIdx.x, &total);
+    if (!threadIdx.x) (blockIdx.y ? P.tile_b : P.tile_a)[blockIdx.x] = total;
+}
+
+// grid (2)
+__global__ void __launch_bounds__(256) k_ptr_scan (GzdPartial P)
+{
+    const uint64_t total = d_wg_scan_array (blockIdx.x ? P.tile_b : P.tile_a, (uint32_t)((P.cells + 255) / 256), threadIdx.x);
+    if (!threadIdx.x && total != P.n_present) *P.status = GZ_ST_CORRUPT;      // the mask and the element count disagree
+}
+
+// grid (tiles)
+__global__ void __launch_bounds__(256) k_ptr_rank (GzdPartial P)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool on = i < P.cells && !P.missing[i];
+    uint64_t total;
+    const uint64_t at = P.tile_a[blockIdx.x] + d_wg_scan_u64 (on ? 1 : 0, threadIdx.x, &total);
+    if (on) P.rank_a[i] = (uint32_t)at;
+}
+
+// grid (tiles), over the transposed mask: cell i = c * rows + r
+__global__ void __launch_bounds__(256) k_ptr_gather (GzdPartial P)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool on = i < P.cells && !P.miss_t[i];
+    uint64_t total;
+    const uint64_t d = P.tile_b[blockIdx.x] + d_wg_scan_u64 (on ? 1 : 0, threadIdx.x, &total);
+    if (!on || *P.status != GZ_ST_OK) return;
+    const uint64_t c = i / P.rows, r = i % P.rows;
+    const uint64_t a = P.rank_a[r * P.cols + c];
+    const uint64_t src = (P.to_file ? a : d) * P.w, dst = (P.to_file ? d : a) * P.w;
+    for (uint32_t k = 0; k < P.w; k++) P.out[dst + k] = P.in[src + k];
+}

@@ -88,6 +88,7 @@ ABI_SYMBOLS = (
     "gz_acgt_packed_len", "gz_acgt_pack", "gz_acgt_unpack",
     "gz_ctx_seg_columns", "gz_dyn_int_columns", "gz_local_blob_columns",
     "gz_text_lines", "gz_fastq_records", "gz_tokenize_column", "gz_seg_integer_or_not",
+    "gz_local_generate_partial", "gz_local_partial_to_native",
 )
 
 
@@ -144,6 +145,8 @@ def load(path=None):
     L.gz_text_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.gz_fastq_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 9
     L.gz_seg_integer_or_not.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32] + [C.c_void_p] * 5
+    for f in (L.gz_local_generate_partial, L.gz_local_partial_to_native):
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     L.gz_tokenize_column.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
     return L

@@ -289,6 +289,19 @@ int gz_seg_integer_or_not (GzHandle *h, const uint8_t *text, const uint32_t *off
                            uint32_t nothing_char, uint32_t lookup_off, uint32_t *snip_off, uint32_t *snip_len,
                            int64_t *values, uint8_t *is_nothing, uint64_t *n_values_dev);
 
+/* dyn_int_transpose, partial case (src/dyn_int.c:64-72,89-96,104-129): a VCF FORMAT field some of whose samples were
+ * copied by VCF_COPY_SAMPLE has only the remaining elements in local - those whose missing[r * cols + c] is 0, in
+ * row-major order. gz_local_generate_partial puts them in file byte order and then in COLUMN-major order; returns
+ * GZ_LT_UINT{8,16,32}_PTR (28..30). gz_local_partial_to_native is the PIZ inverse (takes the _PTR type, returns the
+ * base type). ltype: GZ_LT_UINT8/16/32; data: n_present elements, in place; scratch: as large as data; missing:
+ * rows * cols bytes. All device. A mask that does not leave n_present elements -> GZ_ERR at the next gz_sync-ing call
+ * is avoided by checking here: these two calls synchronise and return GZ_ERR_CORRUPT. */
+enum { GZ_LT_UINT8_PTR = 28, GZ_LT_UINT16_PTR = 29, GZ_LT_UINT32_PTR = 30 };
+int gz_local_generate_partial (GzHandle *h, int ltype, void *data, uint64_t n_present, uint32_t rows, uint32_t cols,
+                               const uint8_t *missing, void *scratch);
+int gz_local_partial_to_native (GzHandle *h, int ltype, void *data, uint64_t n_present, uint32_t rows, uint32_t cols,
+                                const uint8_t *missing, void *scratch);
+
 #ifdef __cplusplus
 }
 #endif

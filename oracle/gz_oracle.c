@@ -1629,3 +1629,26 @@ uint64_t gzo_seg_integer_or_not (const uint8_t *text, const uint32_t *off, const
     }
     return nv;
 }
+
+long gzo_transpose_partial (const uint8_t *in, uint64_t n_present, uint32_t rows, uint32_t cols, uint32_t w,
+                            const uint8_t *missing, uint8_t *out, int to_file)
+{
+    /* the reference goes through a full rows x cols scratch matrix (dyn_int.c:89-96) and copies the available elements
+     * back column by column (:113-121); the same with an index matrix */
+    const uint64_t cells = (uint64_t)rows * cols;
+    uint64_t *at = malloc ((cells + 1) * 8), k = 0;
+    if (!at) return -1;
+    for (uint64_t i = 0; i < cells; i++) at[i] = missing[i] ? UINT64_MAX : k++;     /* row-major rank */
+    if (k != n_present) { free (at); return -1; }
+    uint64_t d = 0;
+    for (uint32_t c = 0; c < cols; c++)
+        for (uint32_t r = 0; r < rows; r++) {
+            const uint64_t a = at[(uint64_t)r * cols + c];
+            if (a == UINT64_MAX) continue;
+            if (to_file) memcpy (out + d * w, in + a * w, w);
+            else         memcpy (out + a * w, in + d * w, w);
+            d++;
+        }
+    free (at);
+    return (long)d;
+}

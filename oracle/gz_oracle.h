@@ -194,6 +194,14 @@ uint64_t gzo_seg_integer_or_not (const uint8_t *text, const uint32_t *off, const
                                  int nothing_char, uint32_t lookup_off, uint32_t *snip_off, uint32_t *snip_len,
                                  int64_t *values, uint8_t *is_nothing);
 
+/* dyn_int_transpose, partial case (dyn_int.c:64-72,89-96,104-129; VCF samples copied by VCF_COPY_SAMPLE are absent from
+ * local): `in` holds, in row-major order, only the elements of the rows x cols matrix whose missing[r*cols+c] is 0;
+ * `out` receives the same elements in column-major order (to_file) - or the other way round (PIZ). Elements are w bytes
+ * (already in file byte order: BGEN comes first, zip.c:185-219). Returns the number of elements, -1 if it is not
+ * n_present. */
+long gzo_transpose_partial (const uint8_t *in, uint64_t n_present, uint32_t rows, uint32_t cols, uint32_t w,
+                            const uint8_t *missing, uint8_t *out, int to_file);
+
 #ifdef __cplusplus
 }
 #endif

@@ -298,6 +298,17 @@ class Oracle:
                                            sl.ctypes.data_as(ctypes.c_void_p), v.ctypes.data_as(ctypes.c_void_p), m.ctypes.data_as(ctypes.c_void_p))
         return so[:n].copy(), sl[:n].copy(), v[:nv].copy(), m[:nv].copy()
 
+    def transpose_partial(self, data, rows, cols, w, missing, to_file=True):
+        import numpy as np
+        data = bytes(data); missing = np.ascontiguousarray(missing, dtype=np.uint8)
+        n = len(data) // w
+        out = ctypes.create_string_buffer(max(1, len(data)))
+        self.L.gzo_transpose_partial.restype = ctypes.c_long
+        rc = self.L.gzo_transpose_partial(data, ctypes.c_uint64(n), rows, cols, w, missing.ctypes.data_as(ctypes.c_void_p), out, int(to_file))
+        if rc != n:
+            raise RuntimeError("oracle transpose_partial: the mask does not leave %d elements" % n)
+        return out.raw[:len(data)]
+
     # ---- sections
     def adler32(self, data, start=1):
         data = bytes(data)

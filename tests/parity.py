@@ -333,3 +333,28 @@ def fastq_front(E, oracle, n_reads):
     blobs = E.local_blob_columns([(text, so, sl, False), (text, uo, ul, False)])
     assert blobs[0] == oracle.local_blob_column(text, so, sl) and blobs[1] == oracle.local_blob_column(text, uo, ul)
     assert len(blobs[0]) == int(sl.sum())
+
+
+def transpose_partial(E, oracle, rows, cols):
+    """a7, partial case: the present elements of a rows x cols matrix, row-major -> file byte order, column-major ==
+    the oracle's walk through the full scratch matrix; back again; a mask that does not fit the element count is an error"""
+    import pytest
+    r = synth.u32(4711, rows * cols)
+    for frac in (0, 3, 50, 100):
+        missing = ((r >> np.uint32(7)) % np.uint32(100) < np.uint32(frac)).astype(np.uint8)
+        n = int((missing == 0).sum())
+        for lt, dt, w in ((2, "<u1", 1), (4, "<u2", 2), (6, "<u4", 4)):
+            vals = (r[:n] % np.uint32(1 << (8 * w) if w < 4 else 0xffffffff)).astype(dt)
+            raw = vals.tobytes()
+            be = oracle.local_generate(lt, raw)[1]                                      # BGEN first (zip.c:185-219)
+            want = oracle.transpose_partial(be, rows, cols, w, missing)
+            got_lt, got = E.local_generate_partial(lt, raw, rows, cols, missing)
+            assert (got_lt, got) == (lt // 2 + 27, want), (frac, lt)
+            # the same thing said with numpy: column-major order of the present cells
+            full = np.zeros(rows * cols, dtype=dt); full[missing == 0] = vals
+            keep = (missing.reshape(rows, cols).T == 0).reshape(-1)
+            assert got == full.reshape(rows, cols).T.reshape(-1)[keep].astype(dt.replace("<", ">")).tobytes()
+            assert E.local_generate_partial(got_lt, got, rows, cols, missing, to_file=False) == (lt, raw)
+            assert oracle.transpose_partial(want, rows, cols, w, missing, to_file=False) == be
+    with pytest.raises(RuntimeError):
+        E.local_generate_partial(2, bytes(10), rows, cols, np.zeros(rows * cols, dtype=np.uint8))

@@ -73,3 +73,9 @@ def test_emul_arith_many_long_leaves(emul_engine, oracle):
     got = emul_engine.compress_many(items)
     for (c, d), g in zip(items, got):
         assert g == oracle.codec_compress(c, d), (c, len(d))
+
+
+def test_emul_transpose_partial(emul_engine, oracle):
+    parity.transpose_partial(emul_engine, oracle, 37, 23)
+    parity.transpose_partial(emul_engine, oracle, 1, 300)
+    parity.transpose_partial(emul_engine, oracle, 300, 1)

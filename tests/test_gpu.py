@@ -87,6 +87,12 @@ def test_seg_columns(gpu_engine, oracle):
     parity.seg_columns(gpu_engine, oracle, 46000)
 
 
+def test_transpose_partial(gpu_engine, oracle):
+    """a7's partial case at odd shapes and at 1 000 x 3 000 cells"""
+    parity.transpose_partial(gpu_engine, oracle, 37, 23)
+    parity.transpose_partial(gpu_engine, oracle, 1000, 3000)
+
+
 def test_b250_malformed(gpu_engine, oracle):
     parity.b250_malformed(gpu_engine, oracle, 300000)
 
