@@ -184,8 +184,9 @@ class Engine:
         return c, list(sizes)
 
     # ---- context engine -------------------------------------------------------------------------------------
-    def b250_generate_many(self, jobs):
-        """jobs: list of (seg bytes, ol_nodes_len, node2word list) -> list of PIZ-format bytes"""
+    def b250_generate_many(self, jobs, r1=None):
+        """jobs: list of (seg bytes, ol_nodes_len, node2word list) -> list of PIZ-format bytes; r1: optional list of the
+        generated b250 of the same contexts in R1's VBlock (bytes or None) - an identical one gives None (dropped)"""
         import numpy as np
         n = len(jobs)
         tab = (GzB250Job * max(1, n))()
@@ -206,11 +207,18 @@ class Engine:
             tab[i].out = self.mem.ptr(ob)
             tab[i].out_len_dev = self.mem.ptr(lb)
             tab[i].status_dev = self.mem.ptr(lb) + 4
+            if r1 is not None and r1[i] is not None:
+                rb = self.mem.upload(r1[i]); rl = self.mem.upload(np.array([len(r1[i])], dtype=np.uint32))
+                keep += [rb, rl]
+                tab[i].r1 = self.mem.ptr(rb); tab[i].r1_len_dev = self.mem.ptr(rl)
         self._check(self.L.gz_b250_generate_batch(self.h, tab, n), "gz_b250_generate_batch")
         self.sync()
         res = []
         for i in range(n):
             ln, st = np.frombuffer(self.mem.download(lens[i], 8), dtype=np.int32)
+            if st == 3:
+                res.append(None)                         # identical to R1: no section
+                continue
             if st != 1:
                 raise GenozipAMDError("b250 %d: malformed seg-format stream or node index out of range (status %d)" % (i, st))
             res.append(self.mem.download(outs[i], int(ln)))

@@ -7,6 +7,7 @@
 // status values kept in GzdStream.status while a batch is in flight
 #define GZ_ST_PENDING   2
 #define GZ_ST_OK        1
+#define GZ_ST_DROPPED   3             // a b250 identical to its R1 counterpart: no section (b250.c:270-277)
 #define GZ_ST_TOO_SMALL 0
 #define GZ_ST_CORRUPT   (-5)
 #define GZ_ST_FAILED    (-1)          // internal failure (a kernel gave up): the stream / VBlock is reported as GZ_ERR

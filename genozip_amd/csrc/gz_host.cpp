@@ -934,6 +934,7 @@ extern "C" int gz_b250_generate_batch (GzHandle *h, const GzB250Job *jobs, int n
     std::vector<GzdB250Job> J;                     // one workgroup each
     std::vector<GzdB250Big> B;                     // the long ones: kernels over all chunks (gz_kernels_ctx.h)
     uint32_t max_super = 0, max_tiles = 0;
+    bool any_r1 = false;
     for (int i = 0; i < n_jobs; i++) {
         const GzB250Job &u = jobs[i];
         if (!u.out_len_dev || (u.seg_len && (!u.seg || !u.out))) return GZ_ERR_ARG;
@@ -941,7 +942,8 @@ extern "C" int gz_b250_generate_batch (GzHandle *h, const GzB250Job *jobs, int n
         memset (&d, 0, sizeof (d));
         d.seg = u.seg; d.seg_len = u.seg_len; d.seg_len_dev = u.seg_len_dev; d.ol_nodes_len = u.ol_nodes_len;
         d.node2word = u.node2word; d.n_new_nodes = u.n_new_nodes; d.out = u.out; d.out_len_dev = u.out_len_dev;
-        d.status_dev = u.status_dev;
+        d.status_dev = u.status_dev; d.r1 = u.r1; d.r1_len_dev = u.r1_len_dev;
+        if (u.r1) any_r1 = true;
         // scratch: one int32 per possible word (every word is at least one byte) + the chunk table
         size_t nchunks = ((size_t)u.seg_len + GZ_B250_CHUNK - 1) / GZ_B250_CHUNK;
         if (!(d.wi = (int32_t *)arena_alloc (h, ((size_t)u.seg_len + 1) * 4))) return GZ_ERR_HIP;
@@ -962,6 +964,7 @@ extern "C" int gz_b250_generate_batch (GzHandle *h, const GzB250Job *jobs, int n
     if (!J.empty ()) {
         if ((rc = upload (h, J.data (), J.size () * sizeof (GzdB250Job), &d_jobs)) != GZ_OK) return rc;
         KLAUNCH (h, k_b250_generate, dim3 ((uint32_t)J.size ()), dim3 (256), 4096, (GzdB250Job *)d_jobs);
+        if (any_r1) KLAUNCH (h, k_b250_pair_identical, dim3 ((uint32_t)J.size ()), dim3 (256), 64, (GzdB250Job *)d_jobs);
     }
     if (!B.empty ()) {
         if ((rc = upload (h, B.data (), B.size () * sizeof (GzdB250Big), &d_jobs)) != GZ_OK) return rc;
@@ -973,6 +976,12 @@ extern "C" int gz_b250_generate_batch (GzHandle *h, const GzB250Job *jobs, int n
         KLAUNCH (h, k_b250_len, dim3 (max_tiles, nb), dim3 (256), 1024, db);
         KLAUNCH (h, k_b250_scan, dim3 (nb), dim3 (256), 2048, db);
         KLAUNCH (h, k_b250_emit, dim3 (max_tiles, nb), dim3 (256), 1024, db);
+        if (any_r1) {                                  // (GzdB250Big starts with its GzdB250Job: a table of the jobs alone)
+            std::vector<GzdB250Job> bj (B.size ());
+            for (size_t i = 0; i < B.size (); i++) bj[i] = B[i].j;
+            if ((rc = upload (h, bj.data (), bj.size () * sizeof (GzdB250Job), &d_jobs)) != GZ_OK) return rc;
+            KLAUNCH (h, k_b250_pair_identical, dim3 (nb), dim3 (256), 64, (GzdB250Job *)d_jobs);
+        }
     }
     HIPCHK (h, hipGetLastError ());
     return GZ_OK;

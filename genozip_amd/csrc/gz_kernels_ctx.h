@@ -25,6 +25,7 @@ struct GzdB250Job {
     int32_t *wi;             // scratch: seg_len + 1 words
     uint32_t *chunk_tab;     // scratch: 5 words per chunk (count for entry 0..3, packed exits) + 2 per chunk (entry, base)
     int32_t *status_dev;     // optional
+    const uint8_t *r1; const uint32_t *r1_len_dev;   // optional: R1's b250 of the same context
 };
 
 __device__ static inline int d_varl_len (uint8_t tag) { return !(tag >> 7) ? 1 : (tag >> 6) == 2 ? 2 : (tag >> 5) == 6 ? 3 : 4; }
@@ -356,6 +357,24 @@ __global__ void __launch_bounds__(256) k_b250_emit (GzdB250Big *jobs)
     }
     uint8_t *o = B.j.out + B.tile[blockIdx.x] + (sh[threadIdx.x] - len);
     for (uint32_t k = 0; k < len; k++) o[k] = (uint8_t)(code >> (8 * (len - 1 - k)));
+}
+
+// paired FASTQ: an R2 b250 that came out identical to its R1 counterpart is dropped (b250.c:270-277). grid (jobs)
+__global__ void __launch_bounds__(256) k_b250_pair_identical (GzdB250Job *jobs)
+{
+    GzdB250Job &J = jobs[blockIdx.x];
+    if (!J.r1 || !J.r1_len_dev) return;
+    const uint32_t n = *J.out_len_dev;
+    uint32_t *sh = (uint32_t *)gz_lds;
+    if (!threadIdx.x) sh[0] = (n && n == *J.r1_len_dev) ? 1u : 0u;
+    __syncthreads ();
+    if (!sh[0]) return;
+    __syncthreads ();
+    uint32_t diff = 0;
+    for (uint32_t i = threadIdx.x; i < n && !diff; i += 256) diff = J.out[i] != J.r1[i];
+    if (diff) sh[0] = 0;                                        // (benign race: every writer writes 0)
+    __syncthreads ();
+    if (!threadIdx.x && sh[0]) { *J.out_len_dev = 0; if (J.status_dev) *J.status_dev = GZ_ST_DROPPED; }
 }
 
 // ======================================================================================================

@@ -761,6 +761,7 @@ __global__ void k_vb_layout (GzdVB *vbs, GzdStream *streams, uint32_t n_vbs)
         GzdStream &S = streams[V.first_stream + k];
         if (S.status == GZ_ST_FAILED) failed = true;
         S.z_off = off;
+        if (!S.n && S.in_len_dev) continue;              // generated on the device and dropped there (b250.c:270-277): no section
         off += 40 + (uint64_t)S.out_len;
     }
     V.z_len = off;
@@ -811,6 +812,7 @@ __global__ void __launch_bounds__(256) k_emit (GzdStream *streams, GzdLeaf *leav
     if (S.vb >= 0) {
         GzdVB &V = vbs[S.vb];
         if (V.status != GZ_ST_OK) { if (!tid) S.status = GZ_ST_TOO_SMALL; return; }
+        if (!S.n && S.in_len_dev) { if (!tid) S.status = GZ_ST_OK; return; }     // dropped: k_vb_layout left no room for it
         dst = V.z_data + S.z_off + 40;
     }
     else if (S.out_len > S.out_cap) { if (!tid) S.status = GZ_ST_TOO_SMALL; return; }

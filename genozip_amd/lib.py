@@ -34,7 +34,7 @@ class GzStream(C.Structure):
 class GzB250Job(C.Structure):
     _fields_ = [("seg", C.c_void_p), ("seg_len", C.c_uint32), ("seg_len_dev", C.c_void_p), ("ol_nodes_len", C.c_uint32),
                 ("node2word", C.c_void_p), ("n_new_nodes", C.c_uint32), ("out", C.c_void_p), ("out_len_dev", C.c_void_p),
-                ("status_dev", C.c_void_p)]
+                ("status_dev", C.c_void_p), ("r1", C.c_void_p), ("r1_len_dev", C.c_void_p)]
 
 
 class GzColumnResult(C.Structure):

@@ -125,7 +125,10 @@ typedef struct {
     const int32_t  *node2word; uint32_t n_new_nodes;
     uint8_t        *out;             /* seg_len bytes */
     uint32_t       *out_len_dev;     /* receives the generated length */
-    int32_t        *status_dev;      /* optional: receives GZ_OK / GZ_ERR_CORRUPT */
+    int32_t        *status_dev;      /* optional: receives 1 ok / -5 malformed input / 3 dropped (see r1)           */
+    const uint8_t  *r1; const uint32_t *r1_len_dev;   /* optional (paired FASTQ, R2's VBlock): the generated b250 of the same
+                                      * context in R1's VBlock; an identical R2 b250 is dropped (src/b250.c:270-277):
+                                      * *out_len_dev = 0, status 3, no section is written                              */
 } GzB250Job;
 int gz_b250_generate_batch (GzHandle *h, const GzB250Job *jobs, int n_jobs);
 
@@ -146,7 +149,8 @@ int gz_local_to_native (GzHandle *h, int ltype, void *data, uint64_t n, uint32_t
 typedef struct {
     const uint8_t  *data;         /* device: section payload before compression (ctx->b250.data / ctx->local.data) */
     uint32_t        data_len;     /* bytes (upper bound if data_len_dev != NULL)                               */
-    const uint32_t *data_len_dev; /* device-resident actual length, or NULL                                    */
+    const uint32_t *data_len_dev; /* device-resident actual length, or NULL. 0 there = dropped on the device   */
+                                  /* (an R2 b250 identical to R1's, src/b250.c:270-277): no section is written  */
     uint8_t  section_type;        /* GZ_SEC_B250 / GZ_SEC_LOCAL                                                */
     uint8_t  codec;               /* ctx->bcodec / ctx->lcodec ; UNKNOWN -> RANB (zfile.c:300,337)             */
     uint8_t  sub_codec;

@@ -106,6 +106,28 @@ def b250_malformed(E, oracle, n_entries):
                 E.b250_generate(bad, 1500, n2)
 
 
+def b250_pair_identical(E, oracle, n_entries):
+    """paired FASTQ: an R2 b250 identical to R1's is dropped (b250.c:270-277), one that differs in its last byte or in
+    its length is kept - on both generation paths"""
+    for ne in (300, n_entries):
+        ni, n2w = cases.b250_case(77, ne, 1500, 700, True)
+        seg = oracle.b250_seg(ni, 1500)
+        piz = oracle.b250_generate(seg, 1500, n2w)
+        other = piz[:-1] + bytes([piz[-1] ^ 1])
+        got = E.b250_generate_many([(seg, 1500, n2w)] * 4, r1=[piz, other, piz + b"\0", None])
+        assert got == [None, piz, piz, piz], ne
+    # ... and the section writer leaves a dropped b250 out (zip.c:266-267): a VBlock with a zero device-side length
+    import pyoracle as po
+    zero = E.mem.upload(np.zeros(1, dtype=np.uint32))
+    qual = synth.markov_bytes(5, 3000, 40, 33).tobytes()
+    vb = VBlock(1, [Section(qual, SEC_LOCAL, 16, b"QUAL", ltype=11),
+                    Section(E.mem.upload(piz), SEC_B250, 16, b"Q1NAME", byte30=4, data_len=len(piz), data_len_dev=zero),
+                    Section(piz, SEC_B250, 16, b"Q2NAME", byte30=4)])
+    z = E.vb_compress([vb])[0]
+    want = E.vb_compress([VBlock(1, [vb.sections[0], vb.sections[2]])])[0]
+    assert z == want
+
+
 def local(E, oracle, rows, cols):
     r = synth.u32(42, rows * cols)
     for lt, dt in ((1, "<i1"), (2, "<u1"), (3, "<i2"), (4, "<u2"), (5, "<i4"), (6, "<u4"), (7, "<i8"), (8, "<u8"), (9, "<f4"), (11, "<u1")):

@@ -79,3 +79,7 @@ def test_emul_transpose_partial(emul_engine, oracle):
     parity.transpose_partial(emul_engine, oracle, 37, 23)
     parity.transpose_partial(emul_engine, oracle, 1, 300)
     parity.transpose_partial(emul_engine, oracle, 300, 1)
+
+
+def test_emul_b250_pair_identical(emul_engine, oracle):
+    parity.b250_pair_identical(emul_engine, oracle, 60000)
