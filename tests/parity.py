@@ -117,7 +117,8 @@ def b250_pair_identical(E, oracle, n_entries):
         got = E.b250_generate_many([(seg, 1500, n2w)] * 4, r1=[piz, other, piz + b"\0", None])
         assert got == [None, piz, piz, piz], ne
     # ... and the section writer leaves a dropped b250 out (zip.c:266-267): a VBlock with a zero device-side length
-    import pyoracle as po
+    ni, n2w = cases.b250_case(77, 300, 1500, 700, True)
+    piz = oracle.b250_generate(oracle.b250_seg(ni, 1500), 1500, n2w)
     zero = E.mem.upload(np.zeros(1, dtype=np.uint32))
     qual = synth.markov_bytes(5, 3000, 40, 33).tobytes()
     vb = VBlock(1, [Section(qual, SEC_LOCAL, 16, b"QUAL", ltype=11),
