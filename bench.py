@@ -191,6 +191,36 @@ def cpu_baseline(rank_wl, z_list, n_threads):
                       (len(tasks), len(rank_wl.vbs), nbytes / 1e6, n_threads, os.cpu_count())}, bool(exact)
 
 
+def seg_front_probe(E, device, target_mb=1536):
+    """SURVEY 8f N1 + rows a1-a3 on FASTQ text resident in HBM - NOT part of `value` (the metric is quoted on the context
+    streams); reported beside it because these kernels, unlike the coders, are bandwidth-bound: lines -> reads -> qname
+    tokens -> per-token columns (node indices, dict, b250) + SEQ / QUAL gathered into their locals. HIP events of the
+    library; `nl_scan` is the newline count over the whole text against the HBM roof."""
+    n_reads = 20000
+    text, rec = W.fastq_text(1, 0, n_reads)
+    reps = max(1, (target_mb << 20) // len(text))
+    block = torch.from_numpy(np.frombuffer(text, dtype=np.uint8).copy()).to(device)
+    big = block.repeat(reps)
+    E.sync()
+    E.profile(True, reset=True)
+    tb, ob, lb, rb, n_lines = E.text_lines(big, cap=4 * n_reads * reps + 8, on_device=True)      # the whole text
+    bad, cols = E.fastq_records(text)                                                             # one VBlock's worth: reads,
+    (qo, ql), (so, sl), _, (uo, ul) = cols
+    nb, io, il = E.tokenize_column(block, qo, ql, b":::::: ")                                     # tokens,
+    n_vb = 64
+    E.ctx_seg_columns([(block, io[i], il[i], []) for i in range(io.shape[0])] * n_vb, keep_on_device=True)   # columns of 64 VBlocks in one call,
+    E.local_blob_columns([(block, so, sl, False), (block, uo, ul, False)] * n_vb)                 # SEQ / QUAL -> locals
+    E.profile(False)
+    pr = E.profile_results()
+    ms = {k: round(v[0], 3) for k, v in sorted(pr.items(), key=lambda kv: -kv[1][0])}
+    nl = pr.get("k_nl_count", (0, 0))[0]
+    gbs = big.numel() / (nl / 1e3) / 1e9 if nl else None
+    assert n_lines == 4 * n_reads * reps and bad is None and nb == 0
+    return {"text_mb": round(big.numel() / 1e6, 1), "columns": io.shape[0] * n_vb, "snips_per_column": n_reads,
+            "kernels_ms": ms, "nl_scan": {"bound": "hbm", "achieved": round(gbs, 1) if gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": round(gbs / HBM_PEAK_GBS, 4) if gbs else None}}
+
+
 def per_launch(per_step, launches_per_step):
     return None if per_step is None else int(per_step / launches_per_step)
 
@@ -214,6 +244,7 @@ def main():
     ap.add_argument("--vb-mb", type=int, default=4, help="VBlock size in MiB (reference: --vblock; its small-file rule floors at 4)")
     ap.add_argument("--qual", default="div", choices=("div", "bin"))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-seg-front", action="store_true", help="skip the (untimed) probe of the seg-side kernels")
     ap.add_argument("--pin-codecs", action="store_true", help="skip codec_assign_best and use the codecs it picks for this workload (profiling runs: every launch of a kernel is then a timed-region launch)")
     a = ap.parse_args()
 
@@ -305,6 +336,8 @@ def main():
                       "codecs": {k: CODEC_NAMES[v] for k, v in codecs.items()}, "compressed_mb": round(z_bytes / 1e6, 2),
                       "parallelism": "vblocks sharded over %d GPU(s), no data-path collective; RCCL gather of z_data" % world},
            "roofline": roofline}
+    if world == 1 and not a.no_seg_front:
+        out["seg_front"] = seg_front_probe(E, device)
     if not a.no_cpu and world == 1:                # (the CPU pool is timed on rank 0 of the 1-GPU run only)
         cb, exact = cpu_baseline(wl, z_list, min(os.cpu_count() or 1, 256))
         out["cpu_baseline"] = cb

@@ -149,3 +149,37 @@ def vb_ranges(n_reads, vb_bytes):
     """(read0, n_reads) of every VBlock of one mate file (txtfile_read_vblock cuts at record boundaries, src/txtfile.c:1228)"""
     per = reads_per_vb(vb_bytes)
     return [(r0, min(per, n_reads - r0)) for r0 in range(0, n_reads, per)]
+
+
+def fastq_text(seed, read0, n_reads):
+    """the FASTQ text of reads [read0, read0 + n_reads) of the file with this seed (numpy, host): the lines the
+    segmenter's front end splits - `@A00123:45:HXXXXXXXX:<lane>:<tile>:<x>:<y> 1:N:0:ACGTACGT+TGCATGCA`, SEQ, `+`, QUAL.
+    Fixed-width numeric fields (no leading zeros) keep every record the same length, so it is assembled as a matrix.
+    Returns (text, bytes per record)."""
+    lane, tile, x, y = name_fields(seed, read0, n_reads)
+    head, tail = b"@A00123:45:HXXXXXXXX:", b" 1:N:0:ACGTACGT+TGCATGCA\n"
+    rec = np.zeros((n_reads, RECORD_BYTES + 16), dtype=np.uint8)
+    at = 0
+
+    def put(b):
+        nonlocal at
+        rec[:, at:at + len(b)] = np.frombuffer(b, dtype=np.uint8)
+        at += len(b)
+
+    def digits(v, width):
+        nonlocal at
+        v = v.astype(np.int64)
+        for k in range(width):
+            rec[:, at + k] = 48 + (v // 10 ** (width - 1 - k)) % 10
+        at += width
+
+    put(head); digits(lane + 1, 1); put(b":"); digits(1101 + tile, 4); put(b":"); digits(10000 + x.astype(np.int64) % 20000, 5); put(b":")
+    digits(10000 + y.astype(np.int64) % 80000, 5); put(tail)
+    h = _hash(_NP, seed + 0x5E9, _NP.arange(read0 * READ_LEN, (read0 + n_reads) * READ_LEN))
+    rec[:, at:at + READ_LEN] = np.frombuffer(b"ACGT", dtype=np.uint8)[(h % 4).astype(np.int64)].reshape(n_reads, READ_LEN)
+    at += READ_LEN
+    put(b"\n+\n")
+    rec[:, at:at + READ_LEN] = quality_rows(_NP, seed, read0, n_reads).reshape(n_reads, READ_LEN)
+    at += READ_LEN
+    put(b"\n")
+    return rec[:, :at].tobytes(), at
