@@ -630,8 +630,8 @@ __global__ void __launch_bounds__(256) k_tokenize (GzdTokens T)
 {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= T.n) return;
-    const uint32_t len = T.len[k], off = len ? T.off[k] : 0;
-    const uint8_t *s = T.text + off;
+    const uint32_t len = T.len[k], off = T.off[k];
+    const uint8_t *s = T.text + off;                      // (never read when len is 0)
     uint32_t at = 0, i = 0;
     for (; i < T.n_seps; i++) {
         uint32_t e = at;

@@ -381,3 +381,63 @@ def transpose_partial(E, oracle, rows, cols):
             assert oracle.transpose_partial(want, rows, cols, w, missing, to_file=False) == be
     with pytest.raises(RuntimeError):
         E.local_generate_partial(2, bytes(10), rows, cols, np.zeros(rows * cols, dtype=np.uint8))
+
+
+def seg_random(E, oracle, rounds, seed=2024):
+    """randomised cross-check of the seg-side kernels against the oracle: random words (lengths 1..90, shared
+    prefixes, duplicates), random cloned dictionaries (subsets of the words and strangers), holes; random integers of
+    every magnitude with and without nothing-chars; random texts with CR LF / LF / empty lines / no final newline"""
+    rng = np.random.RandomState(seed)
+    cols = []
+    for _ in range(rounds):
+        nw = int(rng.randint(1, 60))
+        words = [bytes(rng.randint(33, 127, size=int(rng.randint(1, 1 + (90 if rng.rand() < 0.2 else 9)))).astype(np.uint8)) for _ in range(nw)]
+        words += [w + b"x" for w in words[: nw // 3]]                     # shared prefixes
+        text = b"".join(words)
+        starts = np.concatenate([[0], np.cumsum([len(w) for w in words])[:-1]]).astype(np.uint32)
+        lens = np.array([len(w) for w in words], dtype=np.uint32)
+        n = int(rng.randint(0, 700))
+        pick = rng.randint(0, len(words), size=n) if rng.rand() < 0.7 else np.sort(rng.randint(0, len(words), size=n))
+        off, ln = starts[pick].copy(), lens[pick].copy()
+        holes = rng.rand(n)
+        ln[holes < 0.05] = 0
+        off[holes < 0.02] = 0xffffffff
+        ol = [w for w in words if rng.rand() < 0.4] + [b"stranger%d" % i for i in range(int(rng.randint(0, 4)))]
+        ol = list(dict.fromkeys(ol))                                      # a dictionary has no duplicates
+        rng.shuffle(ol)
+        cols.append((text, off, ln, ol))
+    got = E.ctx_seg_columns(cols)
+    for i, ((t, o, l, ol), g) in enumerate(zip(cols, got)):
+        w = oracle.ctx_seg_column(t, o, l, ol)
+        for key in ("node_index", "node_char_index", "node_snip_len", "counts"):
+            assert np.array_equal(g[key], w[key]), (i, key)
+        for key in ("dict", "b250", "b250_count", "all_the_same"):
+            assert g[key] == w[key], (i, key)
+    ints = []
+    for _ in range(rounds):
+        n = int(rng.randint(0, 500))
+        mag = int(rng.choice([7, 8, 9, 15, 16, 17, 31, 32, 33, 62]))
+        v = rng.randint(0, 2 ** 62, size=n, dtype=np.int64) >> (62 - mag)
+        if rng.rand() < 0.5:
+            v = v - (int(v.max()) // 2 if n else 0)
+        nc = 46 if rng.rand() < 0.5 else 0
+        m = (rng.rand(n) < 0.1).astype(np.uint8) if nc and rng.rand() < 0.7 else None
+        ints.append((v, m, nc))
+    for i, (c, g) in enumerate(zip(ints, E.dyn_int_columns(ints))):
+        assert g == oracle.dyn_int_column(*c), ("dyn_int", i)
+    for _ in range(rounds):
+        parts = []
+        for _ in range(int(rng.randint(0, 40))):
+            parts.append(bytes(rng.randint(32, 127, size=int(rng.randint(0, 100))).astype(np.uint8)) + (b"\r\n" if rng.rand() < 0.3 else b"\n"))
+        text = b"".join(parts) + (b"tail" if rng.rand() < 0.3 else b"")
+        lo, ll = E.text_lines(text)
+        wo, wl = oracle.text_lines(text)
+        assert np.array_equal(lo, wo) and np.array_equal(ll, wl)
+        if len(wo):
+            seps = bytes(rng.choice([58, 32, 47, 95], size=int(rng.randint(0, 5))).astype(np.uint8))
+            g = E.tokenize_column(text, wo, wl, seps)
+            w = oracle.tokenize_column(text, wo, wl, seps)
+            assert g[0] == w[0] and np.array_equal(g[1], w[1]) and np.array_equal(g[2], w[2]), seps
+            g = E.seg_integer_or_not(text + b"\x01", wo, wl, 46, len(text))
+            w = oracle.seg_integer_or_not(text + b"\x01", wo, wl, 46, len(text))
+            assert all(np.array_equal(a, b) for a, b in zip(g, w))

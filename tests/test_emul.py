@@ -83,3 +83,7 @@ def test_emul_transpose_partial(emul_engine, oracle):
 
 def test_emul_b250_pair_identical(emul_engine, oracle):
     parity.b250_pair_identical(emul_engine, oracle, 60000)
+
+
+def test_emul_seg_random(emul_engine, oracle):
+    parity.seg_random(emul_engine, oracle, 25)

@@ -106,6 +106,10 @@ def test_fastq_front(gpu_engine, oracle):
     parity.fastq_front(gpu_engine, oracle, 23000)
 
 
+def test_seg_random(gpu_engine, oracle):
+    parity.seg_random(gpu_engine, oracle, 60, seed=77)
+
+
 def test_seg_column_vcf_sized(gpu_engine, oracle):
     """a FORMAT/PL-like column: 3 million snips, ~2 000 distinct, half of them already in the cloned dictionary"""
     import numpy as np
