@@ -66,16 +66,20 @@ __device__ static inline uint64_t d_wg_scan_u64 (uint64_t v, int tid, uint64_t *
     return incl - v;
 }
 
-// in-place exclusive scan of tiles[0 .. n_tiles) by one workgroup; returns the total
+// in-place exclusive scan of tiles[0 .. n_tiles) by one workgroup; returns the total. Every thread takes 16 consecutive
+// entries (one 128-byte line) per round, so a round covers 4096 entries with ONE workgroup scan (the newline tiles of
+// a 1.6 GB text are 98 000 entries: 24 rounds instead of 383).
+#define GZ_SCAN_PER 16
 __device__ static inline uint64_t d_wg_scan_array (uint64_t *tiles, uint32_t n_tiles, int tid)
 {
     uint64_t carry = 0;
-    for (uint32_t base = 0; base < n_tiles; base += 256) {
-        const uint32_t i = base + (uint32_t)tid;
-        const uint64_t v = i < n_tiles ? tiles[i] : 0;
+    for (uint32_t base = 0; base < n_tiles; base += 256 * GZ_SCAN_PER) {
+        const uint32_t i0 = base + (uint32_t)tid * GZ_SCAN_PER;
+        uint64_t mine = 0;
+        for (uint32_t k = 0; k < GZ_SCAN_PER && i0 + k < n_tiles; k++) mine += tiles[i0 + k];
         uint64_t total;
-        const uint64_t ex = d_wg_scan_u64 (v, tid, &total);
-        if (i < n_tiles) tiles[i] = carry + ex;
+        uint64_t run = carry + d_wg_scan_u64 (mine, tid, &total);
+        for (uint32_t k = 0; k < GZ_SCAN_PER && i0 + k < n_tiles; k++) { const uint64_t v = tiles[i0 + k]; tiles[i0 + k] = run; run += v; }
         carry += total;
     }
     return carry;
