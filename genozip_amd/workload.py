@@ -1,8 +1,9 @@
 """Synthetic FASTQ-PE workload of BASELINE.json (configs[0..1]: 150 bp paired-end, 1 M read pairs) expressed as the
 per-VBlock context streams that enter the hot path.
 
-The text parser / field splitter is NOT on the path yet, so the workload is generated
-directly in the form the segmenter hands to the context engine: per VBlock
+The metric is quoted on the context streams (the per-data-type rules that turn tokens into snips stay with the caller,
+SURVEY.md 8f row N1), so the workload is generated directly in the form the segmenter hands to the context engine
+(fastq_text() below gives the matching FASTQ text for the seg-side kernels' probe): per VBlock
     QUAL   local  LT_BLOB   n_reads x 150 quality bytes            (fastq_seg_QUAL  src/fastq_qual.c:24)
     Q1NAME b250            lane  : tiny dictionary                  (qname tokens   src/qname.c:715-866)
     Q2NAME b250            tile  : ~600 words, slowly varying, runs
