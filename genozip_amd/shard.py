@@ -14,30 +14,28 @@ def vblocks_of_rank(n_vblocks, rank, world, pair_size=1):
 def gather_blobs(dist, blobs, rank, world, device, dst=0):
     """blobs: list of 1-D uint8 tensors on `device` (this rank's compressed VBlocks, in order).
     Returns on dst: list (per rank) of lists of byte strings' tensors; elsewhere None."""
-    lens = torch.tensor([int(b.numel()) for b in blobs], dtype=torch.int64, device=device)
-    n_local = torch.tensor([len(blobs), int(lens.sum()) if len(blobs) else 0], dtype=torch.int64, device=device)
+    lens_host = [int(b.numel()) for b in blobs]
+    lens = torch.tensor(lens_host, dtype=torch.int64, device=device)
+    n_local = torch.tensor([len(blobs), sum(lens_host)], dtype=torch.int64, device=device)
     counts = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(counts, n_local)
-    max_n = max(int(c[0]) for c in counts)
-    max_bytes = max(int(c[1]) for c in counts)
+    counts_host = torch.stack(counts).cpu().numpy()                 # ONE read-back, not one per element
+    max_n, max_bytes = int(counts_host[:, 0].max()), int(counts_host[:, 1].max())
     lens_pad = torch.zeros(max(1, max_n), dtype=torch.int64, device=device)
     lens_pad[:len(blobs)] = lens
     pay = torch.zeros(max(1, max_bytes), dtype=torch.uint8, device=device)
     if len(blobs):
-        pay[:int(lens.sum())] = torch.cat(blobs)
+        torch.cat(blobs, out=pay[:sum(lens_host)])
     len_bufs = [torch.empty_like(lens_pad) for _ in range(world)] if rank == dst else None
     pay_bufs = [torch.empty_like(pay) for _ in range(world)] if rank == dst else None
     dist.gather(lens_pad, len_bufs, dst=dst)
     dist.gather(pay, pay_bufs, dst=dst)
     if rank != dst:
         return None
+    lens_all = torch.stack(len_bufs).cpu().numpy()                  # (the writer needs the lengths on the host anyway)
     out = []
     for r in range(world):
-        n = int(counts[r][0])
-        offs, cur = [], 0
-        for k in range(n):
-            ln = int(len_bufs[r][k])
-            offs.append(pay_bufs[r][cur:cur + ln])
-            cur += ln
-        out.append(offs)
+        n = int(counts_host[r, 0])
+        ends = lens_all[r, :n].cumsum()
+        out.append([pay_bufs[r][int(e - ln):int(e)] for e, ln in zip(ends, lens_all[r, :n])])
     return out
