@@ -270,12 +270,26 @@ def main():
         codecs = wl.assign_codecs()
     wl.build_tables()
 
+    pending = [None]
+
+    def gather_wait():
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
+
     def gather_to_rank0():
-        # the only exchange step of the path: compressed VBlocks go to the writer rank
+        # the only exchange step of the path: compressed VBlocks go to the writer rank. The payload is
+        # packed into a staging buffer and the gather only STARTED: the transfer over xGMI runs beside the next step's
+        # kernels; every gather is complete before the timed region ends (gather_wait below).
         if world == 1:
             return
         from genozip_amd.shard import gather_blobs
-        gather_blobs(dist, [vb.z[:int(wl.vtab[i].z_len)] for i, vb in enumerate(wl.vbs)], rank, world, device)
+        gather_wait()
+        blobs = [vb.z[:int(wl.vtab[i].z_len)] for i, vb in enumerate(wl.vbs)]
+        if os.environ.get("GZ_SYNC_GATHER"):
+            gather_blobs(dist, blobs, rank, world, device)
+        else:
+            pending[0] = gather_blobs(dist, blobs, rank, world, device, async_op=True)
 
     def barrier():
         if world > 1:
@@ -285,12 +299,14 @@ def main():
     for _ in range(a.warmup):
         wl.step()
         gather_to_rank0()
+    gather_wait()
     E.profile(True, reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         wl.step()
         gather_to_rank0()
+    gather_wait()
     barrier()
     dt = time.perf_counter() - t0
     E.profile(False)

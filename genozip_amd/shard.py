@@ -11,9 +11,28 @@ def vblocks_of_rank(n_vblocks, rank, world, pair_size=1):
     return [i for i in range(n_vblocks) if (i // pair_size) % world == rank]
 
 
-def gather_blobs(dist, blobs, rank, world, device, dst=0):
+class PendingGather:
+    """a gather in flight: wait() completes it and (on dst) returns the per-rank lists of blob tensors"""
+
+    def __init__(self, works, keep, finish):
+        self.works, self.keep, self.finish = works, keep, finish
+
+    def wait(self):
+        for w in self.works:
+            if w is not None:
+                w.wait()
+        self.works = []
+        out = self.finish() if self.finish else None
+        self.keep, self.finish = None, None          # the staging buffers may go now
+        return out
+
+
+def gather_blobs(dist, blobs, rank, world, device, dst=0, async_op=False):
     """blobs: list of 1-D uint8 tensors on `device` (this rank's compressed VBlocks, in order).
-    Returns on dst: list (per rank) of lists of byte strings' tensors; elsewhere None."""
+    Returns on dst: list (per rank) of lists of byte strings' tensors; elsewhere None.
+    async_op: the payload is first packed into a staging buffer of its own (the blobs may be overwritten as soon as this
+    returns), the gather is only started, and a PendingGather is returned: the transfer over xGMI then runs beside the
+    next batch's kernels - wait() before starting the next gather."""
     lens_host = [int(b.numel()) for b in blobs]
     lens = torch.tensor(lens_host, dtype=torch.int64, device=device)
     n_local = torch.tensor([len(blobs), sum(lens_host)], dtype=torch.int64, device=device)
@@ -28,14 +47,20 @@ def gather_blobs(dist, blobs, rank, world, device, dst=0):
         torch.cat(blobs, out=pay[:sum(lens_host)])
     len_bufs = [torch.empty_like(lens_pad) for _ in range(world)] if rank == dst else None
     pay_bufs = [torch.empty_like(pay) for _ in range(world)] if rank == dst else None
-    dist.gather(lens_pad, len_bufs, dst=dst)
-    dist.gather(pay, pay_bufs, dst=dst)
-    if rank != dst:
-        return None
-    lens_all = torch.stack(len_bufs).cpu().numpy()                  # (the writer needs the lengths on the host anyway)
-    out = []
-    for r in range(world):
-        n = int(counts_host[r, 0])
-        ends = lens_all[r, :n].cumsum()
-        out.append([pay_bufs[r][int(e - ln):int(e)] for e, ln in zip(ends, lens_all[r, :n])])
-    return out
+    w1 = dist.gather(lens_pad, len_bufs, dst=dst, async_op=async_op)
+    w2 = dist.gather(pay, pay_bufs, dst=dst, async_op=async_op)
+
+    def finish():
+        if rank != dst:
+            return None
+        lens_all = torch.stack(len_bufs).cpu().numpy()              # (the writer needs the lengths on the host anyway)
+        out = []
+        for r in range(world):
+            n = int(counts_host[r, 0])
+            ends = lens_all[r, :n].cumsum()
+            out.append([pay_bufs[r][int(e - ln):int(e)] for e, ln in zip(ends, lens_all[r, :n])])
+        return out
+
+    if async_op:
+        return PendingGather([w1, w2], (lens_pad, pay, len_bufs, pay_bufs), finish)
+    return finish()

@@ -22,14 +22,20 @@ def _worker(rank, world, port, n_vb, q):
     mine = vblocks_of_rank(n_vb, rank, world, pair_size=2)
     blobs = [torch.frombuffer(bytearray(_blob(v)), dtype=torch.uint8) for v in mine]
     got = gather_blobs(dist, blobs, rank, world, torch.device("cpu"))
+    # the overlapped form bench.py uses: start, overwrite the blobs (the next batch's output), wait
+    pending = gather_blobs(dist, blobs, rank, world, torch.device("cpu"), async_op=True)
+    for b in blobs:
+        b.zero_()
+    got2 = pending.wait()
     if rank == 0:
         ok = True
         for r in range(world):
             want = [_blob(v) for v in vblocks_of_rank(n_vb, r, world, pair_size=2)]
             ok &= [bytes(t.numpy().tobytes()) for t in got[r]] == want
+            ok &= [bytes(t.numpy().tobytes()) for t in got2[r]] == want
         q.put(ok)
     else:
-        assert got is None
+        assert got is None and got2 is None
     dist.barrier()
     dist.destroy_process_group()
 
