@@ -27,12 +27,23 @@ def _worker(rank, world, port, n_vb, q):
     for b in blobs:
         b.zero_()
     got2 = pending.wait()
+    # bench.py's loop: step k's gather is waited for only when step k+1 wants to start its own
+    pend, last = None, None
+    for step in range(3):
+        for i, v in enumerate(mine):
+            blobs[i].copy_(torch.frombuffer(bytearray(_blob(v)), dtype=torch.uint8))
+            blobs[i][0] = step                                   # "this step's output"
+        if pend is not None:
+            pend.wait()
+        pend = gather_blobs(dist, blobs, rank, world, torch.device("cpu"), async_op=True)
+    last = pend.wait()
     if rank == 0:
         ok = True
         for r in range(world):
             want = [_blob(v) for v in vblocks_of_rank(n_vb, r, world, pair_size=2)]
             ok &= [bytes(t.numpy().tobytes()) for t in got[r]] == want
             ok &= [bytes(t.numpy().tobytes()) for t in got2[r]] == want
+            ok &= [bytes(t.numpy().tobytes()) for t in last[r]] == [bytes([2]) + w[1:] for w in want]
         q.put(ok)
     else:
         assert got is None and got2 is None
