@@ -296,6 +296,15 @@ static bool codec_is_rans  (int c) { return c >= 6 && c <= 9; }
 static bool codec_is_arith (int c) { return c >= 16 && c <= 19; }
 static bool codec_ok       (int c) { return c == GZ_CODEC_NONE || codec_is_rans (c) || codec_is_arith (c); }
 
+// what the coders themselves compare the capacity with (rANS_static4x16pr.c:1158, arith_dynamic.c:622): Genozip's est_size
+// is this + 1 KB (codec_htscodecs.c:26-33), so capacities in [bound, est_size) still succeed in the reference
+static uint32_t codec_min_cap (int codec, uint32_t len)
+{
+    if (codec_is_rans (codec))  return rans_bound  (len, gz_codec_order (codec));
+    if (codec_is_arith (codec)) return arith_bound (len, gz_codec_order (codec));
+    return len;
+}
+
 extern "C" uint32_t gz_codec_est_size (int codec, uint64_t len)
 {
     if (codec == GZ_CODEC_NONE) return (uint32_t)len;
@@ -644,8 +653,8 @@ extern "C" int gz_codec_compress_batch (GzHandle *h, GzStream *streams, int n_st
         if (!codec_ok (u.codec)) { u.status = GZ_ERR_ARG; S.status = GZ_ERR_ARG; continue; }
         S.in = u.in; S.in_len = u.in_len; S.in_len_dev = u.in_len_dev; S.out = u.out; S.out_cap = u.out_cap;
         S.codec_req = u.codec; S.vb = -1;
-        // the reference's "output buffer too small" test (rANS_static4x16pr.c:1158) against Genozip's est_size
-        S.status = u.out_cap < gz_codec_est_size (u.codec, u.in_len) ? GZ_ST_TOO_SMALL : GZ_ST_PENDING;
+        // the reference's "output buffer too small" test (rANS_static4x16pr.c:1158, arith_dynamic.c:622)
+        S.status = u.out_cap < codec_min_cap (u.codec, u.in_len) ? GZ_ST_TOO_SMALL : GZ_ST_PENDING;
         u.status = S.status;
         if (S.status != GZ_ST_PENDING) continue;
         if (u.in_len > P.max_in) P.max_in = u.in_len;
@@ -782,9 +791,25 @@ extern "C" int gz_codec_uncompress_batch (GzHandle *h, GzStream *streams, int n_
 // ---------------------------------------------------------------------------------------------------------
 // sync: wait, fetch results, recycle the arena
 // ---------------------------------------------------------------------------------------------------------
+static int gz_sync_do (GzHandle *h);
+
 extern "C" int gz_sync (GzHandle *h)
 {
     if (!h) return GZ_ERR_ARG;
+    const int rc = gz_sync_do (h);
+    if (rc == GZ_ERR_HIP) {
+        // a failed wait / read-back: nothing of this batch may be handed out later (the tables of the callers may be gone
+        // by the next sync) - drop the bookkeeping; the statuses in the callers' tables stay "pending"
+        h->pending.clear ();
+        for (auto p : h->host_tmp) free (p);
+        h->host_tmp.clear ();
+        arena_reset (h);
+    }
+    return rc;
+}
+
+static int gz_sync_do (GzHandle *h)
+{
     HIPCHK (h, hipSetDevice (h->device));
     const hipError_t sync_err = hipStreamSynchronize (h->stream);
     g_chain_wgs.fetch_sub (h->chain_wgs_held); g_chain_cus.fetch_sub (h->chain_cus_held);
@@ -851,24 +876,28 @@ extern "C" int gz_codec_compress_host (GzHandle *h, int codec, const uint8_t *in
 {
     if (!h || !out_len || (in_len && !in) || !out) return GZ_ERR_ARG;
     if (!codec_ok (codec)) return GZ_ERR_ARG;
-    uint32_t est = gz_codec_est_size (codec, in_len);
-    if (*out_len < est) return soft_fail ? GZ_TOO_SMALL : GZ_ERR;
+    const uint32_t est = gz_codec_est_size (codec, in_len);
+    if (*out_len < codec_min_cap (codec, in_len)) return soft_fail ? GZ_TOO_SMALL : GZ_ERR;
     int rc;
     if ((rc = gz_sync (h)) < 0) return rc;           // own the arena
-    uint8_t *d_in  = (uint8_t *)arena_alloc (h, (size_t)in_len + 16);
-    uint8_t *d_out = (uint8_t *)arena_alloc (h, (size_t)est + 16);
-    if (!d_in || !d_out) return GZ_ERR_HIP;
-    if (in_len) HIPCHK (h, hipMemcpyAsync (d_in, in, in_len, hipMemcpyHostToDevice, h->stream));
+    // the staging buffers are NOT arena memory: gz_sync below recycles the arena before the payload is copied out
+    uint8_t *d_buf = NULL;
+    HIPCHK (h, hipMalloc ((void **)&d_buf, (size_t)in_len + 256 + (size_t)est + 16));
+    uint8_t *d_in = d_buf, *d_out = d_buf + (((size_t)in_len + 255) & ~(size_t)255);
     GzStream s; memset (&s, 0, sizeof (s));
     s.in = d_in; s.in_len = in_len; s.out = d_out; s.out_cap = est; s.codec = codec;
-    if ((rc = gz_codec_compress_batch (h, &s, 1)) != GZ_OK) return rc;
-    HIPCHK (h, hipStreamSynchronize (h->stream));
-    // fetch the payload before gz_sync recycles the arena
-    if ((rc = gz_sync (h)) < 0) return rc;
-    if (s.status != GZ_OK) return s.status;
-    if (s.out_len) HIPCHK (h, hipMemcpy (out, d_out, s.out_len, hipMemcpyDeviceToHost));
-    *out_len = s.out_len;
-    return GZ_OK;
+    hipError_t e = in_len ? hipMemcpyAsync (d_in, in, in_len, hipMemcpyHostToDevice, h->stream) : hipSuccess;
+    if (e != hipSuccess) { (void)hipFree (d_buf); h->err = std::string ("hipMemcpyAsync: ") + hipGetErrorString (e); return GZ_ERR_HIP; }
+    rc = gz_codec_compress_batch (h, &s, 1);
+    const int rc2 = gz_sync (h);                      // (also when the batch call failed: nothing stays pending)
+    if (rc == GZ_OK && rc2 < 0) rc = rc2;
+    if (rc == GZ_OK && s.status != GZ_OK) rc = s.status;
+    if (rc == GZ_OK && s.out_len && (e = hipMemcpy (out, d_out, s.out_len, hipMemcpyDeviceToHost)) != hipSuccess) {
+        h->err = std::string ("hipMemcpy: ") + hipGetErrorString (e); rc = GZ_ERR_HIP;
+    }
+    (void)hipFree (d_buf);
+    if (rc == GZ_OK) *out_len = s.out_len;
+    return rc;
 }
 
 extern "C" int gz_codec_uncompress_host (GzHandle *h, int codec, const uint8_t *in, uint32_t in_len,

@@ -83,7 +83,8 @@ __global__ void k_dec_parse (GzdDecStream *streams, GzdDecLeaf *leaves, uint32_t
         if (ok) {
             gz_plane_geometry (ulen, len, off);
             for (int k = 0; ok && k < 4; k++) {
-                ok = p + clen[k] <= S.in_len &&
+                // (p <= in_len holds here; compared without the addition: a crafted 5-byte varint must not wrap)
+                ok = clen[k] <= S.in_len - p &&
                      d_parse_unit (S, L[k], in + p, clen[k], len[k], S.tmp_planes + off[k], S.tmp_packed + off[k], rans);
                 p += clen[k];
             }

@@ -30,9 +30,11 @@ class PendingGather:
 def gather_blobs(dist, blobs, rank, world, device, dst=0, async_op=False):
     """blobs: list of 1-D uint8 tensors on `device` (this rank's compressed VBlocks, in order).
     Returns on dst: list (per rank) of lists of byte strings' tensors; elsewhere None.
-    async_op: the payload is first packed into a staging buffer of its own (the blobs may be overwritten as soon as this
-    returns), the gather is only started, and a PendingGather is returned: the transfer over xGMI then runs beside the
-    next batch's kernels - wait() before starting the next gather."""
+    async_op: the payload is first packed into a staging buffer of its own, the gather is only started, and a
+    PendingGather is returned: the transfer over xGMI then runs beside the next batch's kernels - wait() before starting
+    the next gather. The packing copy runs on torch's current stream, the library writes z_data on its own stream and the
+    two are not ordered with each other: this function therefore waits for the copy before it returns, so that the blobs
+    really may be overwritten (by any stream) as soon as it has returned."""
     lens_host = [int(b.numel()) for b in blobs]
     lens = torch.tensor(lens_host, dtype=torch.int64, device=device)
     n_local = torch.tensor([len(blobs), sum(lens_host)], dtype=torch.int64, device=device)
@@ -45,6 +47,8 @@ def gather_blobs(dist, blobs, rank, world, device, dst=0, async_op=False):
     pay = torch.zeros(max(1, max_bytes), dtype=torch.uint8, device=device)
     if len(blobs):
         torch.cat(blobs, out=pay[:sum(lens_host)])
+        if pay.is_cuda:
+            torch.cuda.current_stream(pay.device).synchronize()      # the staging copy has read the blobs
     len_bufs = [torch.empty_like(lens_pad) for _ in range(world)] if rank == dst else None
     pay_bufs = [torch.empty_like(pay) for _ in range(world)] if rank == dst else None
     w1 = dist.gather(lens_pad, len_bufs, dst=dst, async_op=async_op)

@@ -9,8 +9,10 @@
  * handle's HIP stream until gz_sync() / a *_host call.
  *
  * Determinism contract: for the simple codecs the payload is a pure function of
- * (codec id, input bytes) and is byte-identical to the reference's, provided the output capacity is at least
- * gz_codec_est_size() (below that the reference reports "too small"; so does this library).
+ * (codec id, input bytes) and is byte-identical to the reference's, provided the output capacity is at least the
+ * coder's own bound (rans_compress_bound_4x16 / arith_compress_bound = gz_codec_est_size() - 1 KB; below that the
+ * reference's coders report "too small", src/htscodecs/rANS_static4x16pr.c:1158, arith_dynamic.c:622 - so does this
+ * library). Genozip itself always hands over gz_codec_est_size() bytes (src/compressor.c:63-67).
  */
 #ifndef GENOZIP_AMD_H
 #define GENOZIP_AMD_H
@@ -71,7 +73,7 @@ uint32_t gz_codec_est_size (int codec, uint64_t uncompressed_len);
 
 /* COMPRESS() src/codec.h:17-27 as implemented by codec_RANB_compress ... codec_ARTw_compress
  * (src/codec_htscodecs.c:87-94) and codec_none_compress (src/codec_none.c:13).
- * *compressed_len: in = capacity, out = payload length. Returns GZ_OK; GZ_TOO_SMALL iff capacity < est_size and
+ * *compressed_len: in = capacity, out = payload length. Returns GZ_OK; GZ_TOO_SMALL iff capacity < est_size - 1 KB and
  * soft_fail (the caller grows and retries, src/compressor.c:89-110); GZ_ERR* otherwise. Host pointers. */
 int gz_codec_compress_host (GzHandle *h, int codec, const uint8_t *uncompressed, uint32_t uncompressed_len,
                             uint8_t *compressed, uint32_t *compressed_len, int soft_fail);
@@ -89,7 +91,7 @@ typedef struct {
     uint32_t       in_len;
     const uint32_t *in_len_dev;   /* NULL, or device-resident actual length (<= in_len)              */
     uint8_t       *out;           /* destination                                                      */
-    uint32_t       out_cap;       /* compress: capacity >= gz_codec_est_size ; uncompress: exact length */
+    uint32_t       out_cap;       /* compress: capacity, normally gz_codec_est_size ; uncompress: exact length */
     int32_t        codec;
     /* results, valid after gz_sync(): */
     uint32_t       out_len;

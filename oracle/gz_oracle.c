@@ -1074,9 +1074,11 @@ uint32_t gzo_codec_est_size (int codec, uint64_t len) /* codec_htscodecs.c:26-33
 int gzo_codec_compress (int codec, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t *out_len, int soft_fail)
 {
     if (codec != GZO_CODEC_NONE && codec_order (codec) < 0) return -1;
-    /* the reference's own "too small" test is against the htscodecs bound; Genozip always hands over >= est_size
-     * (compressor.c:63-67), which is the contract this library (and the HIP one) states */
-    if (*out_len < gzo_codec_est_size (codec, in_len)) return soft_fail ? 0 : -1;
+    /* the reference's "too small" test is the coder's own, against the htscodecs bound (rANS_static4x16pr.c:1158,
+     * arith_dynamic.c:622; codec_none.c: capacity < length) - not against est_size, which is that bound + 1 KB */
+    uint32_t min_cap = codec == GZO_CODEC_NONE ? in_len : codec_is_rans (codec) ? gzo_rans_bound (in_len, codec_order (codec))
+                                                                              : gzo_arith_bound (in_len, codec_order (codec));
+    if (*out_len < min_cap) return soft_fail ? 0 : -1;
 
     long l;
     if (codec == GZO_CODEC_NONE) { memcpy (out, in, in_len); l = in_len; }

@@ -38,12 +38,14 @@ def host_call_surface(E, oracle):
         assert comp == oracle.codec_compress(codec, data)
         assert E.uncompress(codec, comp, len(data)) == data
         if codec != CODEC_NONE:
-            assert E.compress(codec, data, capacity=est - 1, soft_fail=True) is None
+            bound = est - 1024          # the coder's own bound (rANS_static4x16pr.c:1158): est_size is that + 1 KB
+            assert E.compress(codec, data, capacity=bound - 1, soft_fail=True) is None
             try:
-                E.compress(codec, data, capacity=est - 1, soft_fail=False)
+                E.compress(codec, data, capacity=bound - 1, soft_fail=False)
                 raise AssertionError("hard failure expected")
             except RuntimeError:
                 pass
+            assert E.compress(codec, data, capacity=bound, soft_fail=True) == comp   # [bound, est_size) succeeds in the reference
             assert E.compress(codec, data, capacity=est + 4096) == comp      # capacity independent (SURVEY 8b probe)
     for n in (0, 1, 49):
         assert E.est_size(6, n) == oracle.est_size(6, n) and E.est_size(19, n) == oracle.est_size(19, n)
@@ -104,6 +106,46 @@ def b250_malformed(E, oracle, n_entries):
                 oracle.b250_generate(bad, 1500, n2)
             with pytest.raises(RuntimeError):
                 E.b250_generate(bad, 1500, n2)
+
+
+def decode_malformed(E, oracle):
+    """untrusted .genozip bytes: a striped stream whose unit length was rewritten to a 5-byte varint near 2^32 (so that
+    offset + length wraps in 32 bits) and whose tail was cut off must be reported as corrupt, never decoded from beyond the
+    input; so must plainly truncated streams"""
+    import pytest
+
+    def vi_get(b, p):
+        v = 0
+        while True:
+            c = b[p]; p += 1
+            v = (v << 7) | (c & 0x7f)
+            if not c & 0x80:
+                return v, p
+
+    data = synth.u32be_increasing(11, 4000).tobytes()
+    for codec in (7, 9, 17, 19):
+        comp = oracle.codec_compress(codec, data)
+        assert E.uncompress(codec, comp, len(data)) == data
+        assert comp[0] & 8, "a striped stream is expected here"
+        ulen, p = vi_get(comp, 1)
+        assert comp[p] == 4
+        p += 1
+        starts, clen = [], []
+        for k in range(4):
+            starts.append(p)
+            v, p = vi_get(comp, p)
+            clen.append(v)
+        head = comp[:starts[3]]
+        new_p = starts[3] + 5                       # where the units start once clen[3] takes 5 bytes
+        at3 = new_p + clen[0] + clen[1] + clen[2]   # offset of unit 3
+        cut = len(comp) + 5 - (p - starts[3]) - clen[3] // 2          # half of unit 3 is missing
+        v = (cut - at3) + (1 << 32) - 0             # wraps to "ends exactly at the cut"
+        v &= 0xffffffff
+        wrap = bytes([0x80 | ((v >> 28) & 0x7f), 0x80 | ((v >> 21) & 0x7f), 0x80 | ((v >> 14) & 0x7f), 0x80 | ((v >> 7) & 0x7f), v & 0x7f])
+        bad = (head + wrap + comp[p:])[:cut]
+        for b in (bad, comp[:len(comp) // 2], comp[:starts[1]]):
+            with pytest.raises(RuntimeError):
+                E.uncompress(codec, b, len(data))
 
 
 def b250_pair_identical(E, oracle, n_entries):

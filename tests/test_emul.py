@@ -87,3 +87,7 @@ def test_emul_b250_pair_identical(emul_engine, oracle):
 
 def test_emul_seg_random(emul_engine, oracle):
     parity.seg_random(emul_engine, oracle, 25)
+
+
+def test_emul_decode_malformed(emul_engine, oracle):
+    parity.decode_malformed(emul_engine, oracle)

@@ -97,6 +97,10 @@ def test_b250_malformed(gpu_engine, oracle):
     parity.b250_malformed(gpu_engine, oracle, 300000)
 
 
+def test_decode_malformed(gpu_engine, oracle):
+    parity.decode_malformed(gpu_engine, oracle)
+
+
 def test_b250_pair_identical(gpu_engine, oracle):
     parity.b250_pair_identical(gpu_engine, oracle, 300000)
 
