@@ -45,6 +45,61 @@ class VBlock:
         self.z_len = 0
 
 
+class Zctx:
+    """a file-level context (zctx): the host side of the dictionary merge, row a4 (ctx_merge_in_one_vctx,
+    src/context.c:938-1079). merge() takes one VBlock context as ctx_seg_columns returns it."""
+
+    def __init__(self, L, estimated_entries=0):
+        self.L = L
+        self.z = L.gz_zctx_create(estimated_entries)
+
+    def close(self):
+        if getattr(self, "z", None):
+            self.L.gz_zctx_destroy(self.z)
+            self.z = None
+
+    __del__ = close
+
+    def merge(self, vblock_i, n_ol, col, can_have_singletons=False, flags=0, local_len=0, no_drop_b250=False,
+              pair2_identical=False, b250_r1_len=0, local_r1_len=0):
+        """-> dict(node2word, ston_local, n_stons, dropped_b250)"""
+        import numpy as np
+        from .lib import GzMergeJob
+        n_new = len(col["node_snip_len"])
+        d = np.frombuffer(bytes(col["dict"]) + b"\0", dtype=np.uint8).copy()
+        nci = np.ascontiguousarray(col["node_char_index"], dtype=np.uint64); nsl = np.ascontiguousarray(col["node_snip_len"], dtype=np.uint32)
+        cnt = np.ascontiguousarray(col["counts"], dtype=np.uint32)
+        n2w = np.zeros(max(1, n_new), dtype=np.int32); ston = np.zeros(len(d) + 8, dtype=np.uint8)
+        ats = bool(col["all_the_same"])
+        j = GzMergeJob()
+        j.vblock_i, j.n_ol, j.n_new = vblock_i, n_ol, n_new
+        j.dict, j.node_char_index, j.node_snip_len, j.counts = d.ctypes.data, nci.ctypes.data, nsl.ctypes.data, cnt.ctypes.data
+        j.can_have_singletons = int(can_have_singletons and not ats)
+        j.flags = flags | (0x20 if ats else 0)
+        j.no_drop_b250, j.pair2_identical = int(no_drop_b250), int(pair2_identical)
+        j.b250_len, j.local_len, j.b250_r1_len, j.local_r1_len = len(col["b250"]), local_len, b250_r1_len, local_r1_len
+        j.ats_node_index = int(col["node_index"][0]) if ats and len(col["node_index"]) else -1
+        j.node2word, j.ston_local, j.ston_cap = n2w.ctypes.data, ston.ctypes.data, len(ston)
+        rc = self.L.gz_ctx_merge(self.z, C.byref(j))
+        if rc != GZ_OK:
+            raise GenozipAMDError("gz_ctx_merge failed (%d)" % rc)
+        return dict(node2word=n2w[:n_new].copy(), ston_local=ston[:j.ston_len].tobytes(), n_stons=int(j.n_stons), dropped_b250=bool(j.dropped_b250))
+
+    def view(self):
+        import numpy as np
+        from .lib import GzZctxView
+        v = GzZctxView()
+        self.L.gz_zctx_view(self.z, C.byref(v))
+        d = C.string_at(v.dict, v.dict_len) if v.dict_len else b""
+        c = np.frombuffer(C.string_at(v.counts, 8 * v.n_words), dtype=np.uint64).copy() if v.n_words else np.zeros(0, np.uint64)
+        return dict(dict=d, n_words=v.n_words, counts=c, n_failed_singletons=v.n_failed_singletons,
+                    rm_dict=bool(v.rm_dict_all_the_same), hash_len=v.hash_len)
+
+    def words(self):
+        d = self.view()["dict"]
+        return d[:-1].split(b"\0") if d else []
+
+
 class Engine:
     def __init__(self, device=0, lib_path=None, mem=None, hip_stream=None):
         self.L = _lib.load(lib_path)
@@ -248,6 +303,9 @@ class Engine:
         a = C.c_uint32(0)
         self._check(self.L.gz_adler32(self.h, self.mem.ptr(buf), len(data), C.byref(a)), "gz_adler32")
         return a.value
+
+    def zctx(self, estimated_entries=0):
+        return Zctx(self.L, estimated_entries)
 
     # ---- seg-side appends, a column at a time (rows a1-a3) ------------------------------------------------
     def ctx_seg_columns(self, columns, keep_on_device=False, dict_cap=None):

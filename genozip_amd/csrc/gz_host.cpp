@@ -22,6 +22,7 @@
 #include "gz_kernels_dec.h"
 #include "gz_kernels_ctx.h"
 #include "gz_kernels_seg.h"
+#include "gz_merge.h"
 
 #define GZ_VERSION "genozip_amd 0.1 (gfx950; format parity: genozip 15.0.86)"
 

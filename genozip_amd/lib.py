@@ -78,6 +78,21 @@ class GzVBlock(C.Structure):
                 ("z_cap", C.c_uint64), ("z_len", C.c_uint64), ("status", C.c_int32)]
 
 
+class GzMergeJob(C.Structure):
+    _fields_ = [("vblock_i", C.c_uint32), ("n_ol", C.c_uint32), ("n_new", C.c_uint32),
+                ("dict", C.c_void_p), ("node_char_index", C.c_void_p), ("node_snip_len", C.c_void_p), ("counts", C.c_void_p),
+                ("can_have_singletons", C.c_uint8), ("flags", C.c_uint8), ("no_drop_b250", C.c_uint8), ("pair2_identical", C.c_uint8),
+                ("b250_len", C.c_uint64), ("local_len", C.c_uint64), ("b250_r1_len", C.c_uint64), ("local_r1_len", C.c_uint64),
+                ("ats_node_index", C.c_int32), ("lcodec", C.c_uint8), ("bcodec", C.c_uint8), ("dropped_b250", C.c_uint8), ("reserved", C.c_uint8),
+                ("node2word", C.c_void_p), ("ston_local", C.c_void_p), ("ston_cap", C.c_uint64), ("ston_len", C.c_uint64), ("n_stons", C.c_uint32)]
+
+
+class GzZctxView(C.Structure):
+    _fields_ = [("dict", C.c_void_p), ("dict_len", C.c_uint64), ("char_index", C.c_void_p), ("snip_len", C.c_void_p), ("counts", C.c_void_p),
+                ("n_words", C.c_uint32), ("hash_len", C.c_uint32), ("n_singletons", C.c_uint64), ("n_failed_singletons", C.c_uint64),
+                ("flags", C.c_uint8), ("rm_dict_all_the_same", C.c_uint8), ("lcodec", C.c_uint8), ("bcodec", C.c_uint8), ("all_the_same_wi", C.c_int32)]
+
+
 # every symbol include/genozip_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "gz_create", "gz_destroy", "gz_sync", "gz_last_error", "gz_version", "gz_stream", "gz_profile", "gz_profile_get",
@@ -89,6 +104,7 @@ ABI_SYMBOLS = (
     "gz_ctx_seg_columns", "gz_dyn_int_columns", "gz_local_blob_columns",
     "gz_text_lines", "gz_fastq_records", "gz_tokenize_column", "gz_seg_integer_or_not",
     "gz_local_generate_partial", "gz_local_partial_to_native",
+    "gz_zctx_create", "gz_zctx_destroy", "gz_hash_next_size_up", "gz_ctx_merge", "gz_zctx_view", "gz_zctx_commit_codec",
 )
 
 
@@ -149,4 +165,12 @@ def load(path=None):
         f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     L.gz_tokenize_column.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gz_zctx_create.restype = C.c_void_p
+    L.gz_zctx_create.argtypes = [C.c_uint32]
+    L.gz_zctx_destroy.argtypes = [C.c_void_p]
+    L.gz_hash_next_size_up.restype = C.c_uint32
+    L.gz_hash_next_size_up.argtypes = [C.c_uint64]
+    L.gz_ctx_merge.argtypes = [C.c_void_p, C.POINTER(GzMergeJob)]
+    L.gz_zctx_view.argtypes = [C.c_void_p, C.POINTER(GzZctxView)]
+    L.gz_zctx_commit_codec.argtypes = [C.c_void_p, C.c_int, C.c_int]
     return L

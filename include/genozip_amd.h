@@ -308,6 +308,62 @@ int gz_local_generate_partial (GzHandle *h, int ltype, void *data, uint64_t n_pr
 int gz_local_partial_to_native (GzHandle *h, int ltype, void *data, uint64_t n_present, uint32_t rows, uint32_t cols,
                                 const uint8_t *missing, void *scratch);
 
+/* ---- a4: the ordered dictionary merge (HOST) -------------------------------------------------------
+ * ctx_merge_in_one_vctx (src/context.c:938-1079) with ctx_commit_node (:269-316), hash_global_get_entry (src/hash.c:444-482),
+ * the singleton tables (src/hash.c:280-366) and ctx_drop_all_the_same (src/context.c:795-871): the words a VBlock added to
+ * its copy of a context go into the file-level context (zctx) in VBlock order and get their word indices; a word seen
+ * exactly once so far (count 1 in this VBlock, not yet in the dictionary, not a known singleton) is diverted to the
+ * VBlock's `local` and its node then points at the SNIP_LOOKUP word. Host pointers throughout, no GPU work: this is the
+ * serial step between gz_ctx_seg_columns (which produces dict / node_char_index / node_snip_len / counts / n_new of every
+ * VBlock context) and gz_b250_generate (which consumes node2word). One GzZctx per context of the file; a context must see
+ * its VBlocks in order (vb_i = 1 first, context.c:944), different contexts may be merged on different host threads. */
+typedef struct GzZctx GzZctx;
+/* hash_alloc_global (src/hash.c:227-239): global_hash.len = gz_hash_next_size_up (3 x estimated_entries), where
+ * estimated_entries is hash_get_estimated_entries' figure (src/hash.c:109-225; 0 -> 1000). The size never reaches the file
+ * but decides which singletons share a bucket. */
+GzZctx  *gz_zctx_create (uint32_t estimated_entries);
+void     gz_zctx_destroy (GzZctx *z);
+uint32_t gz_hash_next_size_up (uint64_t size);                              /* src/hash.c:26-48 */
+typedef struct {
+    /* in: the VBlock's context */
+    uint32_t vblock_i;               /* 1-based */
+    uint32_t n_ol;                   /* vctx->ol_nodes.len: words of the zctx at the time this VBlock cloned it         */
+    uint32_t n_new;                  /* vctx->nodes.len                                                               */
+    const uint8_t  *dict;            /* vctx->dict, node_char_index / node_snip_len [n_new], counts [n_ol + n_new]    */
+    const uint64_t *node_char_index;
+    const uint32_t *node_snip_len;
+    const uint32_t *counts;
+    uint8_t  can_have_singletons;    /* ctx_can_have_singletons (src/context.h:263-265): ltype == LT_SINGLETON, !no_stons,
+                                        store != STORE_INDEX, !all_the_same                                           */
+    uint8_t  flags;                  /* vctx->flags (struct FlagsCtx as in GzSection.flags)                           */
+    uint8_t  no_drop_b250;           /* vctx->no_drop_b250                                                            */
+    uint8_t  pair2_identical;        /* is_fastq_pair_2 && fastq_zip_use_pair_identical (dict_id) (context.c:810)     */
+    uint64_t b250_len, local_len;    /* vctx->b250.len / local.len before the merge                                   */
+    uint64_t b250_r1_len, local_r1_len;
+    int32_t  ats_node_index;         /* the one b250 entry of an all-the-same context (b250_seg_get_last)             */
+    /* in / out */
+    uint8_t  lcodec, bcodec;         /* 0 -> inherited from the zctx (context.c:980-981)                              */
+    /* out */
+    uint8_t  dropped_b250;           /* ctx_drop_all_the_same freed the b250: no B250 section for this VBlock         */
+    uint8_t  reserved;
+    int32_t *node2word;              /* [n_new] word index of every VBlock node (vctx->nodes after the merge, :1032)  */
+    uint8_t *ston_local; uint64_t ston_cap;   /* singletons' text, each followed by NUL, appended to vctx->local (:297) */
+    uint64_t ston_len; uint32_t n_stons;      /* ston_cap >= the VBlock's dict length always suffices                   */
+} GzMergeJob;
+/* Returns GZ_OK; GZ_TOO_SMALL when ston_local cannot hold the singletons; GZ_ERR_ARG (n_ol beyond the zctx's words, ...) */
+int gz_ctx_merge (GzZctx *z, GzMergeJob *job);
+typedef struct {
+    const uint8_t *dict; uint64_t dict_len;            /* zctx->dict: every word + NUL, in word-index order (-> SEC_DICT)  */
+    const uint64_t *char_index; const uint32_t *snip_len; const uint64_t *counts;   /* [n_words]                          */
+    uint32_t n_words, hash_len;
+    uint64_t n_singletons, n_failed_singletons;
+    uint8_t  flags; uint8_t rm_dict_all_the_same; uint8_t lcodec, bcodec; int32_t all_the_same_wi;
+} GzZctxView;
+/* what ctx_clone (src/zip.c:528) overlays into the next VBlock - pointers stay valid until the next gz_ctx_merge */
+int gz_zctx_view (const GzZctx *z, GzZctxView *view);
+/* codec_assign_best_codec's commit to the file-level context (src/codec.c:352-363) */
+int gz_zctx_commit_codec (GzZctx *z, int is_local, int codec);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1654,3 +1654,191 @@ long gzo_transpose_partial (const uint8_t *in, uint64_t n_present, uint32_t rows
     free (at);
     return (long)d;
 }
+
+/* =====================================================================================================
+ * row a4: the ordered dictionary merge, stated the reference's way (chained prime-sized hash, nodes with `next`,
+ * singleton digests in per-bucket linked lists with a recycling list) - src/context.c:269-316,938-1079,
+ * src/hash.c:227-239,241-366,368-482. PARITY UNPINNED (the reference cannot be run); the product uses different
+ * structures (gz_merge.h) and must produce the same word indices, dictionary, counts, singletons and drop decisions.
+ * ===================================================================================================== */
+#define O_NO_NEXT 0xffffffffu
+typedef struct { uint64_t char_index; uint32_t snip_len, next; } OZNode;
+typedef struct { uint32_t next, digest; } OSton;
+struct GzoZctx {
+    uint8_t *dict; uint64_t dict_len, dict_cap;
+    OZNode *nodes; uint32_t n_nodes, nodes_cap;
+    uint64_t *counts;
+    uint32_t *global_hash, hash_len;
+    uint32_t *ston_hash;                       /* hash_len + 1 heads: the last one heads the decommissioned entries */
+    OSton *ston_ents; uint32_t n_ston_ents, ston_cap;
+    uint64_t n_failed;
+    uint8_t flags; int32_t ats_wi; int rm_dict, override_rm;
+};
+
+uint32_t gzo_hash_next_size_up (uint64_t size)
+{
+    static const uint32_t sizes[] = { 65521, 92681, 131071, 185363, 262139, 370723, 524287, 741431, 1048573, 1482907, 2097143,
+                                      2965819, 4194301, 5931641, 8388593, 11863279, 16777213, 19951579, 23726561, 28215799,
+                                      33554393, 39903161, 47453111, 56431601, 67108859 };           /* hash.c:34-40, regular sizes */
+    if (size > 16000000) size = 16000000;                                                            /* hash.c:29 at vb_size <= 16 MB */
+    for (unsigned i = 0; i < sizeof (sizes) / sizeof (sizes[0]); i++) if (size < sizes[i]) return sizes[i];
+    return sizes[sizeof (sizes) / sizeof (sizes[0]) - 1];
+}
+
+GzoZctx *gzo_zctx_create (uint32_t estimated_entries)
+{
+    GzoZctx *z = calloc (1, sizeof (*z));
+    if (!z) return NULL;
+    if (!estimated_entries) estimated_entries = 1000;                                                /* hash.c:229 */
+    z->hash_len = gzo_hash_next_size_up ((uint64_t)estimated_entries * 3);
+    z->global_hash = malloc ((size_t)z->hash_len * 4);
+    memset (z->global_hash, 0xff, (size_t)z->hash_len * 4);
+    z->ats_wi = -1;
+    return z;
+}
+
+void gzo_zctx_destroy (GzoZctx *z)
+{
+    if (!z) return;
+    free (z->dict); free (z->nodes); free (z->counts); free (z->global_hash); free (z->ston_hash); free (z->ston_ents); free (z);
+}
+
+static uint32_t o_crc32c (const uint8_t *s, uint32_t n)     /* hash.c:241-272 */
+{
+    uint32_t crc = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        crc ^= s[i];
+        for (int k = 0; k < 8; k++) crc = (crc >> 1) ^ (0x82F63B78u & (0u - (crc & 1)));
+    }
+    return crc;
+}
+
+static int o_stons_remove (GzoZctx *z, uint32_t hash, const uint8_t *s, uint32_t n)    /* hash.c:280-326 */
+{
+    if (!z->n_ston_ents) return 0;
+    uint32_t *prevs_next = &z->ston_hash[hash];
+    const uint32_t digest = o_crc32c (s, n);
+    uint32_t cur = *prevs_next;
+    while (cur != O_NO_NEXT) {
+        OSton *e = &z->ston_ents[cur];
+        if (e->digest == digest) {
+            *prevs_next = e->next;
+            uint32_t *head = &z->ston_hash[z->hash_len];
+            e->next = *head; *head = cur;
+            z->n_failed++;
+            return 1;
+        }
+        prevs_next = &e->next; cur = e->next;
+    }
+    return 0;
+}
+
+static void o_stons_add (GzoZctx *z, uint32_t hash, const uint8_t *s, uint32_t n)      /* hash.c:329-366 */
+{
+    if (!z->ston_hash) { z->ston_hash = malloc (((size_t)z->hash_len + 1) * 4); memset (z->ston_hash, 0xff, ((size_t)z->hash_len + 1) * 4); }
+    const uint32_t digest = o_crc32c (s, n);
+    uint32_t *dec = &z->ston_hash[z->hash_len];
+    if (*dec != O_NO_NEXT) {
+        const uint32_t i = *dec;
+        *dec = z->ston_ents[i].next;
+        z->ston_ents[i].next = z->ston_hash[hash]; z->ston_ents[i].digest = digest;
+        z->ston_hash[hash] = i;
+    }
+    else {
+        if (z->n_ston_ents == z->ston_cap) { z->ston_cap = z->ston_cap ? 2 * z->ston_cap : 1024; z->ston_ents = realloc (z->ston_ents, (size_t)z->ston_cap * sizeof (OSton)); }
+        z->ston_ents[z->n_ston_ents].next = z->ston_hash[hash]; z->ston_ents[z->n_ston_ents].digest = digest;
+        z->ston_hash[hash] = z->n_ston_ents++;
+    }
+}
+
+/* hash_global_get_entry (hash.c:444-482) + the dictionary insert of ctx_commit_node (context.c:290-291); returns the word
+ * index or -1 for "singleton" */
+static int64_t o_global_get_entry (GzoZctx *z, const uint8_t *s, uint32_t n, int allow_singleton)
+{
+    const uint32_t hash = o_hash_do (z->hash_len, s, n);
+    uint32_t prev = O_NO_NEXT, cur = z->global_hash[hash];
+    while (cur != O_NO_NEXT) {                                                          /* hash.c:369-397 */
+        const OZNode *nd = &z->nodes[cur];
+        if (nd->snip_len == n && !memcmp (s, z->dict + nd->char_index, n)) return cur;
+        prev = cur; cur = nd->next;
+    }
+    const int was_ston = o_stons_remove (z, hash, s, n);
+    if (!was_ston && allow_singleton) { o_stons_add (z, hash, s, n); return -1; }
+    if (z->n_nodes == z->nodes_cap) {                                                   /* hash.c:400-441 */
+        z->nodes_cap = z->nodes_cap ? 2 * z->nodes_cap : 1024;
+        z->nodes = realloc (z->nodes, (size_t)z->nodes_cap * sizeof (OZNode));
+        z->counts = realloc (z->counts, (size_t)z->nodes_cap * 8);
+    }
+    if (z->dict_len + n + 1 > z->dict_cap) { z->dict_cap = 2 * (z->dict_len + n + 1) + 1024; z->dict = realloc (z->dict, z->dict_cap); }
+    OZNode *nn = &z->nodes[z->n_nodes];
+    nn->snip_len = n; nn->next = O_NO_NEXT; nn->char_index = z->dict_len;               /* context.c:50-71 */
+    memcpy (z->dict + z->dict_len, s, n); z->dict[z->dict_len + n] = 0; z->dict_len += (uint64_t)n + 1;
+    z->counts[z->n_nodes] = 0;
+    if (prev == O_NO_NEXT) z->global_hash[hash] = z->n_nodes; else z->nodes[prev].next = z->n_nodes;
+    return z->n_nodes++;
+}
+
+static int64_t o_commit_node (GzoZctx *z, GzoMerge *j, const uint8_t *s, uint32_t n, int allow_singletons)   /* context.c:269-316 */
+{
+    const int64_t wi = o_global_get_entry (z, s, n, allow_singletons && j->can_have_singletons);
+    if (wi >= 0) return wi;
+    memcpy (j->ston_local + j->ston_len, s, n); j->ston_local[j->ston_len + n] = 0;     /* seg_add_to_local_fixed_do, add_nul */
+    j->ston_len += (uint64_t)n + 1; j->n_stons++;
+    static const uint8_t lookup[1] = { 1 };                                             /* SNIP_LOOKUP */
+    return o_commit_node (z, j, lookup, 1, 0);
+}
+
+static void o_add_count (uint64_t *counter, uint32_t inc)                              /* context.c:925-934 */
+{
+    if (inc & 0x80000000u) { *counter += inc & ~0x80000000u; *counter |= 0x8000000000000000ull; }
+    else *counter += inc;
+}
+
+int gzo_ctx_merge (GzoZctx *z, GzoMerge *j)
+{
+    if (j->n_ol > z->n_nodes) return -1;
+    j->ston_len = 0; j->n_stons = 0; j->dropped_b250 = 0;
+    if (j->vblock_i == 1 && (j->b250_len || j->local_len)) z->flags = j->flags;         /* context.c:962-963 */
+    for (uint32_t i = 0; i < j->n_new; i++) {                                           /* context.c:1004-1033 */
+        const uint32_t count = j->counts[j->n_ol + i];
+        const int64_t wi = o_commit_node (z, j, j->dict + j->node_char_index[i], j->node_snip_len[i], count == 1);
+        o_add_count (&z->counts[wi], count);
+        j->node2word[i] = (int32_t)wi;
+    }
+    for (uint32_t ni = 0; ni < j->n_ol; ni++) o_add_count (&z->counts[ni], j->counts[ni]);   /* context.c:1059-1060 */
+
+    /* ctx_drop_all_the_same, context.c:795-871 */
+    const uint64_t local_len = j->local_len + j->ston_len;
+    if (!(j->flags & 0x20)) { z->override_rm = 1; return 0; }
+    if (j->no_drop_b250) goto no_drop;
+    if (j->pair2_identical) {
+        if (j->b250_r1_len) goto no_drop;
+        if (j->local_r1_len && !local_len) goto no_drop;
+    }
+    {
+        const int32_t ni = j->ats_node_index;
+        const int64_t wi = ni < 0 ? ni : (uint32_t)ni < j->n_ol ? ni : j->node2word[(uint32_t)ni - j->n_ol];   /* node_index_to_word_index */
+        if (wi > 15 || wi < 0) goto no_drop;
+        const uint8_t *d = z->dict + z->nodes[wi].char_index;
+        if (d[0] == 5) goto no_drop;
+        const int is_simple_lookup = d[0] == 1 && !d[1];
+        if (local_len && !is_simple_lookup) goto no_drop;
+        const uint8_t my_flags = j->flags & ~0x20, vb_1_flags = (j->vblock_i == 1 ? 0 : z->flags) & ~0x20;
+        if (my_flags != vb_1_flags) goto no_drop;
+        if (z->ats_wi < 0) z->ats_wi = (int32_t)wi;
+        else if (wi != z->ats_wi) goto no_drop;
+        j->dropped_b250 = 1;
+        if (is_simple_lookup) z->rm_dict = 1;
+        return 0;
+    }
+no_drop:
+    z->override_rm = 1;
+    return 0;
+}
+
+void gzo_zctx_view (const GzoZctx *z, const uint8_t **dict, uint64_t *dict_len, uint32_t *n_words, const uint64_t **counts,
+                    uint64_t *n_failed, int *rm_dict)
+{
+    *dict = z->dict; *dict_len = z->dict_len; *n_words = z->n_nodes; *counts = z->counts; *n_failed = z->n_failed;
+    *rm_dict = z->rm_dict && !z->override_rm;
+}

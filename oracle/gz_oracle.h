@@ -202,6 +202,27 @@ uint64_t gzo_seg_integer_or_not (const uint8_t *text, const uint32_t *off, const
 long gzo_transpose_partial (const uint8_t *in, uint64_t n_present, uint32_t rows, uint32_t cols, uint32_t w,
                             const uint8_t *missing, uint8_t *out, int to_file);
 
+
+/* ---- row a4: the ordered dictionary merge (context.c:269-316,938-1079; hash.c:227-482), the reference's structures ----
+ * PARITY UNPINNED. One GzoZctx per file-level context; gzo_ctx_merge = ctx_merge_in_one_vctx for one VBlock context. */
+typedef struct GzoZctx GzoZctx;
+typedef struct {
+    uint32_t vblock_i, n_ol, n_new;
+    const uint8_t *dict; const uint64_t *node_char_index; const uint32_t *node_snip_len; const uint32_t *counts;
+    uint8_t can_have_singletons, flags, no_drop_b250, pair2_identical;
+    uint64_t b250_len, local_len, b250_r1_len, local_r1_len;
+    int32_t ats_node_index;
+    uint8_t dropped_b250;                          /* out */
+    int32_t *node2word;                            /* out [n_new] */
+    uint8_t *ston_local; uint64_t ston_len; uint32_t n_stons;   /* out: must hold the VBlock's dict length */
+} GzoMerge;
+uint32_t gzo_hash_next_size_up (uint64_t size);
+GzoZctx *gzo_zctx_create (uint32_t estimated_entries);
+void gzo_zctx_destroy (GzoZctx *z);
+int gzo_ctx_merge (GzoZctx *z, GzoMerge *j);
+void gzo_zctx_view (const GzoZctx *z, const uint8_t **dict, uint64_t *dict_len, uint32_t *n_words, const uint64_t **counts,
+                    uint64_t *n_failed, int *rm_dict);
+
 #ifdef __cplusplus
 }
 #endif

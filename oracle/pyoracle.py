@@ -324,6 +324,67 @@ class Oracle:
         return z.raw[:n]
 
 
+class GzoMerge(ctypes.Structure):
+    _fields_ = [("vblock_i", ctypes.c_uint32), ("n_ol", ctypes.c_uint32), ("n_new", ctypes.c_uint32),
+                ("dict", ctypes.c_void_p), ("node_char_index", ctypes.c_void_p), ("node_snip_len", ctypes.c_void_p), ("counts", ctypes.c_void_p),
+                ("can_have_singletons", ctypes.c_uint8), ("flags", ctypes.c_uint8), ("no_drop_b250", ctypes.c_uint8), ("pair2_identical", ctypes.c_uint8),
+                ("b250_len", ctypes.c_uint64), ("local_len", ctypes.c_uint64), ("b250_r1_len", ctypes.c_uint64), ("local_r1_len", ctypes.c_uint64),
+                ("ats_node_index", ctypes.c_int32), ("dropped_b250", ctypes.c_uint8),
+                ("node2word", ctypes.c_void_p), ("ston_local", ctypes.c_void_p), ("ston_len", ctypes.c_uint64), ("n_stons", ctypes.c_uint32)]
+
+
+class OracleZctx:
+    """row a4 the reference's way (gz_oracle.c): one file-level context; merge(col, ...) = ctx_merge_in_one_vctx of one
+    VBlock context given as the dict ctx_seg_column returns. Same call shape as genozip_amd.codec.Zctx."""
+
+    def __init__(self, oracle, estimated_entries=0):
+        self.L = oracle.L
+        self.L.gzo_zctx_create.restype = ctypes.c_void_p
+        self.L.gzo_zctx_destroy.argtypes = [ctypes.c_void_p]
+        self.L.gzo_ctx_merge.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self.L.gzo_zctx_view.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 6
+        self.z = self.L.gzo_zctx_create(ctypes.c_uint32(estimated_entries))
+
+    def __del__(self):
+        if getattr(self, "z", None):
+            self.L.gzo_zctx_destroy(self.z)
+            self.z = None
+
+    def merge(self, vblock_i, n_ol, col, can_have_singletons=False, flags=0, local_len=0, no_drop_b250=False,
+              pair2_identical=False, b250_r1_len=0, local_r1_len=0):
+        """-> dict(node2word, ston_local, n_stons, dropped_b250)"""
+        import numpy as np
+        n_new = len(col["node_snip_len"])
+        d = np.frombuffer(bytes(col["dict"]) + b"\0", dtype=np.uint8).copy()
+        nci = np.ascontiguousarray(col["node_char_index"], dtype=np.uint64); nsl = np.ascontiguousarray(col["node_snip_len"], dtype=np.uint32)
+        cnt = np.ascontiguousarray(col["counts"], dtype=np.uint32)
+        n2w = np.zeros(max(1, n_new), dtype=np.int32); ston = np.zeros(len(d) + 8, dtype=np.uint8)
+        ats = bool(col["all_the_same"])
+        j = GzoMerge(vblock_i, n_ol, n_new, d.ctypes.data, nci.ctypes.data, nsl.ctypes.data, cnt.ctypes.data,
+                     int(can_have_singletons and not ats), flags | (0x20 if ats else 0), int(no_drop_b250), int(pair2_identical),
+                     len(col["b250"]), local_len, b250_r1_len, local_r1_len,
+                     int(col["node_index"][0]) if ats and len(col["node_index"]) else -1, 0, n2w.ctypes.data, ston.ctypes.data, 0, 0)
+        rc = self.L.gzo_ctx_merge(self.z, ctypes.byref(j))
+        if rc != 0:
+            raise RuntimeError("oracle ctx_merge failed")
+        return dict(node2word=n2w[:n_new].copy(), ston_local=ston[:j.ston_len].tobytes(), n_stons=int(j.n_stons), dropped_b250=bool(j.dropped_b250))
+
+    def view(self):
+        """-> dict(dict bytes, n_words, counts, n_failed_singletons, rm_dict)"""
+        import numpy as np
+        dp, cp = ctypes.c_void_p(), ctypes.c_void_p()
+        dl, nf = ctypes.c_uint64(), ctypes.c_uint64()
+        nw, rm = ctypes.c_uint32(), ctypes.c_int()
+        self.L.gzo_zctx_view(self.z, ctypes.byref(dp), ctypes.byref(dl), ctypes.byref(nw), ctypes.byref(cp), ctypes.byref(nf), ctypes.byref(rm))
+        d = ctypes.string_at(dp.value, dl.value) if dl.value else b""
+        c = np.frombuffer(ctypes.string_at(cp.value, 8 * nw.value), dtype=np.uint64).copy() if nw.value else np.zeros(0, np.uint64)
+        return dict(dict=d, n_words=nw.value, counts=c, n_failed_singletons=nf.value, rm_dict=bool(rm.value))
+
+    def words(self):
+        d = self.view()["dict"]
+        return d[:-1].split(b"\0") if d else []
+
+
 class Ref:
     """the reference's vendored htscodecs, compiled in place (only where oracle/_ref was built)"""
 

@@ -333,6 +333,93 @@ def seg_columns(E, oracle, n):
     assert blobs[3] == oracle.local_blob_column(cases[5][1], cases[5][2], cases[5][3], False) == cases[5][1]
 
 
+def _snip_column(snips):
+    """list of bytes (None = missing) -> (text, off, len) of a column"""
+    text, off, ln = bytearray(b"#"), [], []
+    for w in snips:
+        if w is None:
+            off.append(0xffffffff); ln.append(0)
+        else:
+            off.append(len(text)); ln.append(len(w)); text += w
+    return bytes(text), np.array(off, dtype=np.uint32), np.array(ln, dtype=np.uint32)
+
+
+def merge_chain(E, oracle, n):
+    """rows a1/a2 -> a4 -> a5 chained over VBlocks that share dictionaries: every VBlock's column is evaluated against the
+    dictionary as cloned when it started (gz_ctx_seg_columns), merged in VBlock order on the host (gz_ctx_merge:
+    word indices, singletons into local, failed singletons, counts, the all-the-same drop), and its b250 generated with
+    the merged word indices (gz_b250_generate). Checked against the oracle's restatement of the reference's structures
+    AND by reconstructing every snip from (b250, dictionary, local) - the property genounzip relies on."""
+    import pyoracle
+    r = synth.u32(4242, 8 * n + 64).astype(np.int64)
+
+    def ids(lo, hi):            # read-name like: mostly unique, a few repeats
+        return [b"id%07d" % (i if r[i] % 9 else i - 1) for i in range(lo, hi)]
+
+    scenarios = {
+        # name: (can_have_singletons, [(clone after VBlock k merged (0 = empty dictionary), snips)])
+        "ids":    (True, [(0, ids(0, n)), (1, ids(n // 2, n + n // 2)), (2, ids(0, 2 * n)), (3, ids(0, n // 3))]),
+        "tiles":  (False, [(0, [b"%d" % (1101 + (i * 7 // n)) for i in range(n)]),
+                           (1, [b"%d" % (1104 + (i * 9 // n)) for i in range(n)]),
+                           (1, [b"%d" % (1101 + (r[i] % 40)) for i in range(n)]),      # cloned before VBlock 2 merged (a batch)
+                           (3, [b"%d" % (1090 + (r[i] % 80)) for i in range(n)])]),
+        "big":    (False, [(0, [b"w%d" % (r[i] % 3000) for i in range(n)]), (1, [b"w%d" % (r[n + i] % 5000) for i in range(n)]),
+                           (2, [b"w%d" % (i % 4000) for i in range(n)])]),               # > 1024 words: ONE_UP in the generated b250
+        "same":   (False, [(0, [b"+"] * n), (1, [b"+"] * n), (2, [b"+"] * (n - 1) + [b"x"]), (3, [b"+"] * n)]),
+        "ston1":  (True, [(0, [b"only-once"] + [b"rep"] * 5), (1, [b"only-once", b"rep", b"new2", b"new2"]), (2, [b"only-once", b"new3"]),
+                          (2, [b"new3", b"", None, b"rep"]), (4, [b"new3", b"new4"])]),
+    }
+    for name, (can_ston, vbs) in scenarios.items():
+        Z, OZ = E.zctx(), pyoracle.OracleZctx(oracle)
+        words_after = [[]]                                    # dictionary after k VBlocks were merged
+        for k, (clone_at, snips) in enumerate(vbs):
+            ol = words_after[clone_at]
+            t, o, l = _snip_column(snips)
+            col = E.ctx_seg_column(t, o, l, ol)
+            ocol = oracle.ctx_seg_column(t, o, l, ol)
+            assert col["b250"] == ocol["b250"] and col["dict"] == ocol["dict"], (name, k)
+            m = Z.merge(k + 1, len(ol), col, can_have_singletons=can_ston)
+            om = OZ.merge(k + 1, len(ol), ocol, can_have_singletons=can_ston)
+            assert np.array_equal(m["node2word"], om["node2word"]), (name, k, m["node2word"][:8], om["node2word"][:8])
+            for key in ("ston_local", "n_stons", "dropped_b250"):
+                assert m[key] == om[key], (name, k, key)
+            v, ov = Z.view(), OZ.view()
+            assert v["dict"] == ov["dict"] and np.array_equal(v["counts"], ov["counts"]) and v["n_failed_singletons"] == ov["n_failed_singletons"], (name, k)
+            assert v["rm_dict"] == ov["rm_dict"], (name, k)
+            words = Z.words()
+            words_after.append(words)
+            # a5 with the merged indices, and the reconstruction property
+            n2w = [int(x) for x in m["node2word"]]
+            piz = E.b250_generate(col["b250"], len(ol), n2w)
+            assert piz == oracle.b250_generate(ocol["b250"], len(ol), n2w), (name, k)
+            wis = oracle.b250_decode(piz)
+            if col["all_the_same"]:
+                assert len(wis) == 1 and col["b250_count"] == len(snips)
+                wis = wis * len(snips)
+            stons = m["ston_local"][:-1].split(b"\0") if m["ston_local"] else []
+            back, si = [], 0
+            for wi in wis:
+                if wi == -3:
+                    back.append(b"")
+                elif wi == -4:
+                    back.append(None)
+                elif words[wi] == b"\x01" and can_ston:
+                    back.append(stons[si]); si += 1
+                else:
+                    back.append(words[wi])
+            assert back == list(snips), (name, k)
+            assert si == m["n_stons"], (name, k)
+        # what the scenarios are there for
+        if name == "ids":
+            assert Z.view()["n_failed_singletons"] > 0 and b"\x01" in Z.words()
+        if name == "ston1":
+            assert Z.words() == [b"\x01", b"rep", b"only-once", b"new2", b"new3"], Z.words()   # only-once: singleton, then a failed one; new4: singleton
+        if name == "same":
+            assert Z.words() == [b"+", b"x"]
+        Z.close()
+    assert E.L.gz_hash_next_size_up(3000) == 65521 and E.L.gz_hash_next_size_up(65521) == 92681 and E.L.gz_hash_next_size_up(10 ** 9) == 16777213
+
+
 def fastq_text(n_reads, seed=11, crlf_every=0, read_len=150):
     """a small FASTQ text in the shape of SURVEY 8d config 1 (Illumina-7 names, 40-level qualities)"""
     r = synth.u32(seed, 4 * n_reads + 8).astype(np.int64)

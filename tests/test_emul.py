@@ -91,3 +91,7 @@ def test_emul_seg_random(emul_engine, oracle):
 
 def test_emul_decode_malformed(emul_engine, oracle):
     parity.decode_malformed(emul_engine, oracle)
+
+
+def test_emul_merge_chain(emul_engine, oracle):
+    parity.merge_chain(emul_engine, oracle, 900)

@@ -97,6 +97,11 @@ def test_b250_malformed(gpu_engine, oracle):
     parity.b250_malformed(gpu_engine, oracle, 300000)
 
 
+def test_merge_chain(gpu_engine, oracle):
+    """seg columns -> host dictionary merge (a4) -> b250 generation over VBlocks that share dictionaries"""
+    parity.merge_chain(gpu_engine, oracle, 46000)
+
+
 def test_decode_malformed(gpu_engine, oracle):
     parity.decode_malformed(gpu_engine, oracle)
 
