@@ -100,6 +100,66 @@ class Zctx:
         return d[:-1].split(b"\0") if d else []
 
 
+class ZipFile:
+    """z_file for the hot path: gz_zip_open / gz_fastq_zip_vblocks / gz_zip_close"""
+
+    def __init__(self, E, plan):
+        from .fastq import c_plan
+        self.E, self.plan = E, plan
+        self._cplan, self._keep = c_plan(plan)
+        self.f = E.L.gz_zip_open(E.h, C.byref(self._cplan))
+        if not self.f:
+            raise GenozipAMDError("gz_zip_open failed: bad plan")
+
+    def close(self):
+        if getattr(self, "f", None):
+            self.E.L.gz_zip_close(self.f)
+            self.f = None
+
+    __del__ = close
+
+    def vb_table(self, vbs):
+        """vbs: list of (text_off, text_len, vblock_i, r1 index or -1)"""
+        from .lib import GzFastqVB
+        tab = (GzFastqVB * len(vbs))()
+        for i, (off, ln, vi, r1) in enumerate(vbs):
+            tab[i].text_off, tab[i].text_len, tab[i].vblock_i, tab[i].r1 = off, ln, vi, r1
+        return tab
+
+    def zip_table(self, text_buf, text_len, tab, n):
+        rc = self.E.L.gz_fastq_zip_vblocks(self.f, self.E.mem.ptr(text_buf), text_len, tab, n)
+        if rc != GZ_OK:
+            raise GenozipAMDError("gz_fastq_zip_vblocks failed (%d): %s" % (rc, self.E.L.gz_last_error(self.E.h).decode()))
+
+    def zip_vblocks(self, text, vbs):
+        """text: bytes; vbs as for vb_table -> list of dict(z=bytes, seq_packed=bytes, n_bases, seq_has_x, n_reads)"""
+        import numpy as np
+        buf = self.E.mem.upload(bytes(text) + b"\0" * 32)
+        tab = self.vb_table(vbs)
+        self.zip_table(buf, len(text), tab, len(vbs))
+        out = []
+        for t in tab:
+            z = self._download(t.z_data, t.z_len)
+            out.append(dict(z=z, seq_packed=self._download(t.seq_packed, t.seq_packed_len), n_bases=t.n_bases, seq_has_x=bool(t.seq_has_x),
+                            n_reads=t.n_reads, n_sections=t.n_sections))
+        return out
+
+    def _download(self, ptr, n):
+        """bytes at a raw device pointer of the library's workspace"""
+        if not n:
+            return b""
+        out = C.create_string_buffer(n)
+        self.E._check(self.E.L.gz_download(self.E.h, out, ptr, n), "gz_download")
+        return out.raw
+
+    def zctx_words(self, ctx_i):
+        from .lib import GzZctxView
+        v = GzZctxView()
+        self.E.L.gz_zctx_view(self.E.L.gz_zip_zctx(self.f, ctx_i), C.byref(v))
+        d = C.string_at(v.dict, v.dict_len) if v.dict_len else b""
+        return d[:-1].split(b"\0") if d else []
+
+
 class Engine:
     def __init__(self, device=0, lib_path=None, mem=None, hip_stream=None):
         self.L = _lib.load(lib_path)
@@ -513,6 +573,11 @@ class Engine:
         out = self.mem.alloc(n + 16)
         self._check(self.L.gz_acgt_unpack(self.h, self.mem.ptr(pbuf), self.mem.ptr(xbuf) if xbuf is not None else None, n, self.mem.ptr(out)), "gz_acgt_unpack")
         return self.mem.download(out, n)
+
+    # ---- the VBlock compute driver (zip_compress_one_vb for a batch of FASTQ VBlocks) ------------------------
+    def zip_open(self, plan):
+        """plan: dict as genozip_amd.fastq.illumina_plan() returns -> ZipFile"""
+        return ZipFile(self, plan)
 
     # ---- VBlock section writer ----------------------------------------------------------------------------
     def vb_table(self, vblocks):

@@ -23,6 +23,7 @@
 #include "gz_kernels_ctx.h"
 #include "gz_kernels_seg.h"
 #include "gz_merge.h"
+#include "gz_kernels_zip.h"
 
 #define GZ_VERSION "genozip_amd 0.1 (gfx950; format parity: genozip 15.0.86)"
 
@@ -271,6 +272,33 @@ extern "C" int gz_profile_get (GzHandle *h, int idx, char *name, int name_cap, d
     if (launches) *launches = h->prof[idx].launches;
     return 1;
 }
+
+extern "C" int gz_download (GzHandle *h, void *dst, const void *src, uint64_t n)
+{
+    if (!h || (n && (!dst || !src))) return GZ_ERR_ARG;
+    HIPCHK (h, hipSetDevice (h->device));
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    if (n) HIPCHK (h, hipMemcpy (dst, src, n, hipMemcpyDeviceToHost));
+    return GZ_OK;
+}
+
+extern "C" int gz_upload (GzHandle *h, void *dst, const void *src, uint64_t n)
+{
+    if (!h || (n && (!dst || !src))) return GZ_ERR_ARG;
+    HIPCHK (h, hipSetDevice (h->device));
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    if (n) HIPCHK (h, hipMemcpy (dst, src, n, hipMemcpyHostToDevice));
+    return GZ_OK;
+}
+
+extern "C" void *gz_dev_alloc (GzHandle *h, uint64_t n)
+{
+    void *p = NULL;
+    if (!h || hipSetDevice (h->device) != hipSuccess || hipMalloc (&p, n ? n : 1) != hipSuccess) return NULL;
+    return p;
+}
+
+extern "C" void gz_dev_free (GzHandle *h, void *p) { if (h && p && hipSetDevice (h->device) == hipSuccess) (void)hipFree (p); }
 
 extern "C" const char *gz_last_error (GzHandle *h) { return h ? h->err.c_str () : "no handle"; }
 extern "C" void *gz_stream (GzHandle *h) { return h ? (void *)h->stream : NULL; }
@@ -1265,6 +1293,7 @@ extern "C" int gz_dyn_int_columns (GzHandle *h, const GzDynIntJob *jobs, int n_j
         if (!u.result_dev || (u.n && (!u.values || !u.out)) || ((uintptr_t)u.out & 7) || u.n >= (1ull << 40)) return GZ_ERR_ARG;
         GzdDynInt &d = J[i];
         d.values = u.values; d.is_nothing = u.is_nothing; d.n = u.n; d.nothing_char = u.nothing_char; d.out = u.out; d.result = u.result_dev;
+        d.n_dev = u.n_dev;
         const uint64_t tiles = (u.n + GZ_DYN_TILE - 1) / GZ_DYN_TILE;
         if (!(d.tile_min = (int64_t *)arena_alloc (h, (tiles + 1) * 8))) return GZ_ERR_HIP;
         if (!(d.tile_max = (int64_t *)arena_alloc (h, (tiles + 1) * 8))) return GZ_ERR_HIP;
@@ -1418,3 +1447,5 @@ extern "C" int gz_vb_uncompress (GzHandle *h, const uint8_t *z_data, uint64_t z_
     }
     return GZ_OK;
 }
+
+#include "gz_zip.h"

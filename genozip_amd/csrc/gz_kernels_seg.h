@@ -359,7 +359,9 @@ struct GzdDynInt {
     const int64_t *values; const uint8_t *is_nothing; uint64_t n; uint32_t nothing_char;
     uint8_t *out; GzDynIntResult *result;
     int64_t *tile_min, *tile_max;          // scratch [tiles]
+    const uint64_t *n_dev;                 // optional: the actual count (<= n) lives on the device
 };
+__device__ static inline uint64_t d_dyn_n (const GzdDynInt &D) { return D.n_dev ? (*D.n_dev < D.n ? *D.n_dev : D.n) : D.n; }
 
 #define GZ_DYN_TILE 1024                   // values per workgroup
 
@@ -368,12 +370,13 @@ __global__ void __launch_bounds__(256) k_dyn_minmax (GzdDynInt *cols)
 {
     const GzdDynInt &D = cols[blockIdx.y];
     const uint64_t base = (uint64_t)blockIdx.x * GZ_DYN_TILE;
-    if (base >= D.n) return;
+    if (base >= D.n) return;                                  // (tiles beyond the planning bound do not exist)
+    const uint64_t Dn = d_dyn_n (D);
     const int tid = threadIdx.x;
     int64_t mn = INT64_MAX, mx = INT64_MIN;
     for (int j = 0; j < GZ_DYN_TILE / 256; j++) {
         const uint64_t k = base + (uint64_t)j * 256 + tid;
-        if (k < D.n && !(D.is_nothing && D.is_nothing[k])) { const int64_t v = D.values[k]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+        if (k < Dn && !(D.is_nothing && D.is_nothing[k])) { const int64_t v = D.values[k]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
     }
     int64_t *sh = (int64_t *)gz_lds;
     sh[tid] = mn; sh[256 + tid] = mx;
@@ -403,7 +406,8 @@ __global__ void __launch_bounds__(256) k_dyn_decide (GzdDynInt *cols)
 {
     const GzdDynInt &D = cols[blockIdx.x];
     const int tid = threadIdx.x;
-    const uint32_t n_tiles = (uint32_t)((D.n + GZ_DYN_TILE - 1) / GZ_DYN_TILE);
+    const uint64_t Dn = d_dyn_n (D);
+    const uint32_t n_tiles = (uint32_t)((D.n + GZ_DYN_TILE - 1) / GZ_DYN_TILE);   // (tiles past Dn hold the neutral elements)
     int64_t mn = INT64_MAX, mx = INT64_MIN;
     for (uint32_t i = tid; i < n_tiles; i += 256) { if (D.tile_min[i] < mn) mn = D.tile_min[i]; if (D.tile_max[i] > mx) mx = D.tile_max[i]; }
     int64_t *sh = (int64_t *)gz_lds;
@@ -414,13 +418,13 @@ __global__ void __launch_bounds__(256) k_dyn_decide (GzdDynInt *cols)
     const int nc = D.nothing_char != 0;
     int order = 1;
     if (mn <= mx && (mn < 0 || mx > 255 - nc)) {                                // some value does not fit UINT8
-        if (D.n && D.is_nothing && D.is_nothing[0]) { if (mn > 0xff) mn = 0xff; if (mx < 0xff) mx = 0xff; }
+        if (Dn && D.is_nothing && D.is_nothing[0]) { if (mn > 0xff) mn = 0xff; if (mx < 0xff) mx = 0xff; }
         for (order = 2; order < 7; order++) if (mn >= d_order_min (order) && mx <= d_order_max (order) - nc) break;
     }
     const int lt[8] = { 0, GZ_LT_UINT8, GZ_LT_INT8, GZ_LT_UINT16, GZ_LT_INT16, GZ_LT_UINT32, GZ_LT_INT32, GZ_LT_INT64 };
     D.result->ltype = lt[order];
     D.result->width = order <= 2 ? 1 : order <= 4 ? 2 : order <= 6 ? 4 : 8;
-    D.result->len = D.n * D.result->width;
+    D.result->len = Dn * D.result->width;
     D.result->order = (uint32_t)order;
 }
 
@@ -429,12 +433,13 @@ __global__ void __launch_bounds__(256) k_dyn_write (GzdDynInt *cols)
 {
     const GzdDynInt &D = cols[blockIdx.y];
     const uint64_t base = (uint64_t)blockIdx.x * GZ_DYN_TILE;
-    if (base >= D.n) return;
+    const uint64_t Dn = d_dyn_n (D);
+    if (base >= Dn) return;
     const uint32_t w = D.result->width;
     const int64_t top = d_order_max ((int)D.result->order);                    // a nothing_char is the type's maximum (dyn_int.c:334-341)
     for (int j = 0; j < GZ_DYN_TILE / 256; j++) {
         const uint64_t k = base + (uint64_t)j * 256 + threadIdx.x;
-        if (k >= D.n) break;
+        if (k >= Dn) break;
         const int64_t v = (D.is_nothing && D.is_nothing[k]) ? top : D.values[k];
         switch (w) {
             case 1:  D.out[k] = (uint8_t)v; break;

@@ -1,0 +1,282 @@
+// gz_kernels_zip.h -- gfx950 kernels of the VBlock compute driver (gz_zip.h): the batched forms the driver needs so that
+// one launch covers every (VBlock, context) of a batch.
+//
+//   k_vb_bounds        first line of every VBlock from its text offset (txtfile_read_vblock cuts at record boundaries,
+//                      src/txtfile.c:1228: a VBlock starts where a line starts)
+//   k_tokenize_n       items of a container whose separators may be "the n-th occurrence" (CI0_COLONn, qname_flavors.h:40-49)
+//   k_icol_*           seg_integer_or_not (src/seg.c:531-560) / seg_self_delta (src/seg.c:688-718) over a table of columns
+//   k_local_order_jobs zip_generate_local's byte order step (src/zip.c:185-216) over a table of locals whose type was decided
+//                      on the device (dyn_int_get_ltype)
+//   k_bufs_identical   "pair identical": an R2 local that equals its R1 counterpart is dropped (src/zip.c:224-234)
+//   k_acgt_pack_jobs   codec_acgt_pack (src/codec_acgt.c:45-55) over a table of NONREF locals
+#pragma once
+#include "gz_device.h"
+#include "gz_devutil.h"
+#include "gz_kernels_seg.h"
+#include "gz_kernels_ctx.h"
+
+// ---- VBlock boundaries ------------------------------------------------------------------------------------------------
+// one thread per boundary: the index of the first line that starts at or after vb_off[v] (binary search over the line
+// starts); first_line[n_vb] = n_lines. A boundary that is not a line start is reported in *bad.
+__global__ void k_vb_bounds (const uint32_t *line_off, const GzLinesResult *lines, const uint64_t *vb_off, uint32_t n_vb, uint32_t *first_line, uint32_t *bad)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > n_vb) return;
+    const uint64_t n_lines = lines->n_lines;
+    if (v == n_vb) { first_line[v] = (uint32_t)n_lines; return; }
+    const uint64_t want = vb_off[v];
+    uint64_t lo = 0, hi = n_lines;
+    while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (line_off[mid] < want) lo = mid + 1; else hi = mid; }
+    first_line[v] = (uint32_t)lo;
+    if (lo < n_lines ? line_off[lo] != want : false) atomicMax (bad, 1u);
+}
+
+// ---- tokenizer with n-th occurrence separators --------------------------------------------------------------------------
+struct GzdTokensN {
+    const uint8_t *text; const uint32_t *off, *len; uint32_t n;
+    uint8_t seps[GZ_TOK_MAX_SEPS + 1], counts[GZ_TOK_MAX_SEPS + 1]; uint32_t n_seps;
+    uint32_t *item_off, *item_len; uint32_t *n_bad;
+};
+
+// grid (tiles of 256 snips): item i ends at the counts[i]-th seps[i] after item i-1; the last item is the rest
+__global__ void __launch_bounds__(256) k_tokenize_n (GzdTokensN T)
+{
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= T.n) return;
+    const uint32_t len = T.len[k], off = T.off[k];
+    const uint8_t *s = T.text + off;
+    uint32_t at = 0, i = 0;
+    for (; i < T.n_seps; i++) {
+        uint32_t e = at, left = T.counts[i];
+        const uint8_t sep = T.seps[i];
+        for (; e < len; e++) if (s[e] == sep && !--left) break;
+        if (e == len) break;
+        T.item_off[(uint64_t)i * T.n + k] = off + at; T.item_len[(uint64_t)i * T.n + k] = e - at;
+        at = e + 1;
+    }
+    if (i < T.n_seps) {
+        atomicAdd (T.n_bad, 1u);
+        for (uint32_t j = 0; j <= T.n_seps; j++) { T.item_off[(uint64_t)j * T.n + k] = off; T.item_len[(uint64_t)j * T.n + k] = j ? 0 : len; }
+    }
+    else { T.item_off[(uint64_t)T.n_seps * T.n + k] = off + at; T.item_len[(uint64_t)T.n_seps * T.n + k] = len - at; }
+}
+
+// ---- integer columns -------------------------------------------------------------------------------------------------
+// mode 0: seg_integer_or_not - integers (and the nothing_char) go, compacted, to `values`, their snip becomes SNIP_LOOKUP
+// mode 1: seg_self_delta - every snip must be an integer; values[k] = v[k] - v[k-1] with v[-1] = 0 (ctx->last_value starts
+//         at 0 in every VBlock); a snip that is not an integer sets status to GZ_ST_CORRUPT (the reference would seg such a
+//         line through another branch, src/qname.c:750-756: the caller then has to fall back to mode 0 for the column)
+struct GzdIntCol {
+    const uint8_t *text; const uint32_t *off, *len; uint32_t n; uint32_t nothing_char; uint32_t lookup_off; uint32_t mode;
+    uint32_t *snip_off, *snip_len; int64_t *values; uint8_t *is_nothing; uint64_t *n_values; int32_t *status;
+    uint64_t *tile;
+};
+
+__device__ static inline int d_icol_kind (const GzdIntCol &C, uint32_t k, int64_t *v)
+{
+    GzdIntSplit S;
+    S.text = C.text; S.off = C.off; S.len = C.len; S.n = C.n; S.nothing_char = C.nothing_char; S.lookup_off = C.lookup_off;
+    return d_int_or_not (S, k, v);
+}
+
+// grid (tiles, columns)
+__global__ void __launch_bounds__(256) k_icol_count (GzdIntCol *cols)
+{
+    const GzdIntCol &C = cols[blockIdx.y];
+    if (blockIdx.x * 256 >= C.n) return;
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    int64_t v;
+    const int kind = k < C.n ? d_icol_kind (C, k, &v) : 0;
+    if (C.mode == 1 && k < C.n && kind != 1) *C.status = GZ_ST_CORRUPT;
+    uint64_t total;
+    (void)d_wg_scan_u64 (kind ? 1 : 0, threadIdx.x, &total);
+    if (!threadIdx.x) C.tile[blockIdx.x] = total;
+}
+
+// grid (columns)
+__global__ void __launch_bounds__(256) k_icol_scan (GzdIntCol *cols)
+{
+    const GzdIntCol &C = cols[blockIdx.x];
+    const uint64_t total = d_wg_scan_array (C.tile, (C.n + 255) / 256, threadIdx.x);
+    if (!threadIdx.x) *C.n_values = C.mode == 1 ? C.n : total;
+}
+
+// grid (tiles, columns)
+__global__ void __launch_bounds__(256) k_icol_write (GzdIntCol *cols)
+{
+    const GzdIntCol &C = cols[blockIdx.y];
+    if (blockIdx.x * 256 >= C.n) return;
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    int64_t v = 0;
+    const int kind = k < C.n ? d_icol_kind (C, k, &v) : 0;
+    if (C.mode == 1) {
+        if (k >= C.n) return;
+        int64_t prev = 0;
+        if (k) (void)d_icol_kind (C, k - 1, &prev);
+        C.values[k] = kind == 1 ? v - prev : 0;
+        if (C.is_nothing) C.is_nothing[k] = 0;
+        return;
+    }
+    uint64_t total;
+    const uint64_t at = C.tile[blockIdx.x] + d_wg_scan_u64 (kind ? 1 : 0, threadIdx.x, &total);
+    if (k >= C.n) return;
+    if (kind) { C.values[at] = v; C.is_nothing[at] = kind == 2; C.snip_off[k] = C.lookup_off; C.snip_len[k] = 1; }
+    else      { C.snip_off[k] = C.off[k]; C.snip_len[k] = C.len[k]; }
+}
+
+// ---- byte order of many locals ---------------------------------------------------------------------------------------
+struct GzdLocalJob {
+    uint8_t *data; uint64_t n;                 // elements (upper bound when dyn != NULL)
+    const GzDynIntResult *dyn;                 // type / width / length decided on the device, or NULL
+    int32_t ltype;                             // used when dyn == NULL
+    uint32_t *len_dev;                         // optional: receives the byte length
+};
+
+// grid (tiles of 1024 elements, jobs)
+__global__ void __launch_bounds__(256) k_local_order_jobs (const GzdLocalJob *jobs)
+{
+    const GzdLocalJob &J = jobs[blockIdx.y];
+    const int lt = J.dyn ? J.dyn->ltype : J.ltype;
+    const uint32_t w = J.dyn ? J.dyn->width : (lt == GZ_LT_INT16 || lt == GZ_LT_UINT16) ? 2 : (lt == GZ_LT_INT32 || lt == GZ_LT_UINT32 || lt == GZ_LT_FLOAT32) ? 4
+                                             : (lt == GZ_LT_INT64 || lt == GZ_LT_UINT64 || lt == GZ_LT_FLOAT64) ? 8 : 1;
+    const uint64_t n = J.dyn ? J.dyn->len / (w ? w : 1) : J.n;
+    if (!blockIdx.x && !threadIdx.x && J.len_dev) *J.len_dev = (uint32_t)(n * w);
+    const bool is_signed = lt == GZ_LT_INT8 || lt == GZ_LT_INT16 || lt == GZ_LT_INT32 || lt == GZ_LT_INT64;
+    if (w == 1 && !is_signed) return;
+    const uint64_t mask = w == 8 ? ~0ull : ((1ull << (8 * w)) - 1), sign = 1ull << (8 * w - 1);
+    for (int q = 0; q < 4; q++) {
+        const uint64_t i = (uint64_t)blockIdx.x * 1024 + (uint64_t)q * 256 + threadIdx.x;
+        if (i >= n) return;
+        uint8_t *p = J.data + i * w;
+        uint64_t v = 0;
+        for (uint32_t k = 0; k < w; k++) v |= (uint64_t)p[k] << (8 * k);
+        if (is_signed) v = (v & sign) ? ((((~v + 1) & mask) << 1) - 1) & mask : (v << 1) & mask;   // context.h:99-100
+        for (uint32_t k = 0; k < w; k++) p[k] = (uint8_t)(v >> (8 * (w - 1 - k)));
+    }
+}
+
+// ---- pair identical ---------------------------------------------------------------------------------------------------
+struct GzdSameJob {
+    const uint8_t *a; const uint32_t *a_len;   // R2's section payload and its device-resident length
+    const uint8_t *b; const uint32_t *b_len;   // R1's
+    uint32_t *drop_len;                        // set to 0 when identical (the section writer then leaves the section out)
+    uint32_t *flag;                            // scratch, 1 = differs
+};
+
+// grid (jobs): one workgroup per pair
+__global__ void __launch_bounds__(256) k_bufs_identical (const GzdSameJob *jobs)
+{
+    const GzdSameJob &J = jobs[blockIdx.x];
+    const uint32_t n = *J.a_len;
+    __shared__ uint32_t differs;
+    if (!threadIdx.x) differs = n != *J.b_len;
+    __syncthreads ();
+    if (differs) return;
+    uint32_t d = 0;
+    for (uint32_t i = threadIdx.x; i < n && !d; i += 256) d |= J.a[i] != J.b[i];
+    if (d) differs = 1;
+    __syncthreads ();
+    if (!threadIdx.x && !differs) *J.drop_len = 0;
+}
+
+// ---- CODEC_ACGT pack over many NONREF locals -----------------------------------------------------------------------------
+struct GzdAcgtJob { const uint8_t *seq; const uint64_t *n_dev; uint64_t n_max; uint8_t *packed; uint8_t *x; uint32_t *has_x; uint64_t *packed_len; };
+
+// grid (tiles of 256 x 16 bases, jobs)
+__global__ void __launch_bounds__(256) k_acgt_pack_jobs (const GzdAcgtJob *jobs)
+{
+    const GzdAcgtJob &J = jobs[blockIdx.y];
+    const uint64_t n = J.n_dev ? *J.n_dev : J.n_max;
+    const uint64_t packed_bytes = ((2 * n + 63) / 64) * 8, groups = (n + 15) / 16, words = packed_bytes / 4;
+    if (!blockIdx.x && !threadIdx.x && J.packed_len) *J.packed_len = packed_bytes;
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint16_t *tab = (uint16_t *)gz_lds;
+    tab[threadIdx.x] = (uint16_t)(d_acgt_code (threadIdx.x) | (d_acgt_exception (threadIdx.x) << 8));
+    __syncthreads ();
+    uint32_t any = 0;
+    if (g < words) {
+        uint32_t w = 0;
+        if (g < groups) {
+            const uint64_t base = g * 16;
+            const uint32_t m = base + 16 <= n ? 16u : (uint32_t)(n - base);
+            gz_u32x4_unaligned v = { 0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u };
+            if (m == 16) v = *(const gz_u32x4_unaligned *)(J.seq + base);
+            else for (uint32_t k = 0; k < m; k++) v[k >> 2] = (v[k >> 2] & ~(0xffu << (8 * (k & 3)))) | ((uint32_t)J.seq[base + k] << (8 * (k & 3)));
+            gz_u32x4_unaligned ev = { 0, 0, 0, 0 };
+            #pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t t = tab[(v[k >> 2] >> (8 * (k & 3))) & 0xff];
+                w |= (t & 3) << (2 * k);
+                ev[k >> 2] |= (t >> 8) << (8 * (k & 3));
+            }
+            any = ev[0] | ev[1] | ev[2] | ev[3];
+            if (m == 16) *(gz_u32x4_unaligned *)(J.x + base) = ev;
+            else for (uint32_t k = 0; k < m; k++) J.x[base + k] = (uint8_t)(ev[k >> 2] >> (8 * (k & 3)));
+        }
+        ((uint32_t *)J.packed)[g] = w;
+    }
+    if (__ballot (any != 0) && (threadIdx.x & 63) == 0 && *(volatile uint32_t *)J.has_x == 0) atomicMax (J.has_x, 1u);
+}
+
+// ---- what the host needs for the merge, packed into one staging buffer -----------------------------------------------
+// Per column: dict [dict_len], node_char_index [n_new], node_snip_len [n_new], counts [n_ol + n_new] - variable sizes that
+// only the device knows. k_pack_sizes lays them out one after the other (8-byte aligned), k_pack_copy copies; the host then
+// reads the layout and ONE stretch of memory instead of four small copies per column.
+struct GzdPackJob {
+    const uint8_t *dict; const uint64_t *nci; const uint32_t *nsl; const uint32_t *counts; uint32_t n_ol;
+    const GzColumnResult *res;
+    uint64_t at[4];            // out: offsets of the four parts in the staging buffer
+};
+
+// grid (1): a serial walk over the jobs (a few thousand at most)
+__global__ void k_pack_sizes (GzdPackJob *jobs, uint32_t n_jobs, uint64_t cap, uint64_t *total_out)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    uint64_t at = 0;
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        GzdPackJob &J = jobs[j];
+        const uint64_t n_new = J.res->n_new, sz[4] = { J.res->status == 1 ? J.res->dict_len : 0, 8 * n_new, 4 * n_new, 4 * ((uint64_t)J.n_ol + n_new) };
+        for (int k = 0; k < 4; k++) { J.at[k] = at; at += (sz[k] + 7) & ~7ull; }
+    }
+    total_out[0] = at;
+    total_out[1] = at <= cap;
+}
+
+// grid (jobs)
+__global__ void __launch_bounds__(256) k_pack_copy (const GzdPackJob *jobs, uint8_t *staging, const uint64_t *total)
+{
+    if (!total[1]) return;
+    const GzdPackJob &J = jobs[blockIdx.x];
+    const uint64_t n_new = J.res->n_new;
+    const uint8_t *src[4] = { J.dict, (const uint8_t *)J.nci, (const uint8_t *)J.nsl, (const uint8_t *)J.counts };
+    const uint64_t sz[4] = { J.res->status == 1 ? J.res->dict_len : 0, 8 * n_new, 4 * n_new, 4 * ((uint64_t)J.n_ol + n_new) };
+    for (int k = 0; k < 4; k++)
+        for (uint64_t i = threadIdx.x; i < sz[k]; i += 256) staging[J.at[k] + i] = src[k][i];
+}
+
+// ---- VB header statistics: longest record (vb->longest_line_len, seg.c: a FASTQ "line" is the 4-line read) and longest SEQ ----
+// grid (VBlocks)
+__global__ void __launch_bounds__(256) k_vb_stats (const uint32_t *line_off, const uint32_t *seq_len, const uint32_t *first_line, const uint64_t *vb_end,
+                                                    uint32_t *out /* [n_vb][2] */)
+{
+    const uint32_t v = blockIdx.x;
+    const uint32_t r0 = first_line[v] / 4, r1 = first_line[v + 1] / 4;
+    uint32_t longest = 0, longest_seq = 0;
+    for (uint32_t r = r0 + threadIdx.x; r < r1; r += 256) {
+        const uint64_t end = r + 1 < r1 ? line_off[4 * (r + 1)] : vb_end[v];
+        const uint32_t len = (uint32_t)(end - line_off[4 * r]);
+        longest = len > longest ? len : longest;
+        longest_seq = seq_len[r] > longest_seq ? seq_len[r] : longest_seq;
+    }
+    uint32_t *sh = (uint32_t *)gz_lds;
+    sh[threadIdx.x] = longest; sh[256 + threadIdx.x] = longest_seq;
+    __syncthreads ();
+    for (int d = 128; d; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            if (sh[threadIdx.x + d] > sh[threadIdx.x]) sh[threadIdx.x] = sh[threadIdx.x + d];
+            if (sh[256 + threadIdx.x + d] > sh[256 + threadIdx.x]) sh[256 + threadIdx.x] = sh[256 + threadIdx.x + d];
+        }
+        __syncthreads ();
+    }
+    if (!threadIdx.x) { out[2 * v] = sh[0]; out[2 * v + 1] = sh[256]; }
+}

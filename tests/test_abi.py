@@ -13,8 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def real_lib():
     import __graft_entry__ as g
     so = os.path.join(ROOT, "genozip_amd", "libgenozip_amd.so")
-    if not os.path.exists(so):
-        g.build()
+    if os.path.isdir("/opt/rocm/bin") and os.path.exists("/opt/rocm/bin/hipcc"):
+        g.build()                      # (rebuilds only when a source is newer than the library)
     from genozip_amd import lib
     return lib.load(so)
 
@@ -55,3 +55,21 @@ def test_oracle_is_not_linked_into_the_product():
         if f.endswith(".py"):
             src = open(os.path.join(ROOT, "genozip_amd", f)).read()
             assert "oracle" not in src.replace("no oracle", ""), f
+
+
+def _build_c_program(lib_dir, lib_name, out):
+    import subprocess
+    src = os.path.join(ROOT, "tests", "c", "zip_fastq.c")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", out,
+                    "-L", lib_dir, "-l:" + lib_name, "-Wl,-rpath," + lib_dir], check=True)
+    return out
+
+
+def test_c_host_program_against_the_header(emul_engine, tmp_path):
+    """a plain C11 program (tests/c/zip_fastq.c) compiled against include/genozip_amd.h drives the whole path - text ->
+    seg -> merge -> generate -> compress -> decode - without Python; here linked with the CPU-emulated build of the product
+    sources, on the GPU box with the real library (tests/test_gpu.py)"""
+    import subprocess
+    exe = _build_c_program(os.path.join(ROOT, "tests", "emul"), "libgenozip_amd_emul.so", str(tmp_path / "zip_fastq_emul"))
+    r = subprocess.run([exe, "600"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr

@@ -95,3 +95,7 @@ def test_emul_decode_malformed(emul_engine, oracle):
 
 def test_emul_merge_chain(emul_engine, oracle):
     parity.merge_chain(emul_engine, oracle, 900)
+
+
+def test_emul_fastq_zip(emul_engine, oracle):
+    parity.fastq_zip(emul_engine, oracle, 400)

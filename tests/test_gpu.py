@@ -97,6 +97,24 @@ def test_b250_malformed(gpu_engine, oracle):
     parity.b250_malformed(gpu_engine, oracle, 300000)
 
 
+def test_fastq_zip_driver(gpu_engine, oracle):
+    """FASTQ text -> z_data through gz_fastq_zip_vblocks (a1-a16 + N1 in one call, paired VBlocks, two calls sharing the
+    file's dictionaries) == the oracle's step-by-step composition"""
+    parity.fastq_zip(gpu_engine, oracle, 6000)
+
+
+def test_c_host_program():
+    """tests/c/zip_fastq.c: plain C11 against include/genozip_amd.h and the real library, no Python in the loop"""
+    import os
+    import subprocess
+    import tempfile
+    import test_abi
+    with tempfile.TemporaryDirectory() as d:
+        exe = test_abi._build_c_program(os.path.join(test_abi.ROOT, "genozip_amd"), "libgenozip_amd.so", os.path.join(d, "zip_fastq"))
+        r = subprocess.run([exe, "46000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
 def test_merge_chain(gpu_engine, oracle):
     """seg columns -> host dictionary merge (a4) -> b250 generation over VBlocks that share dictionaries"""
     parity.merge_chain(gpu_engine, oracle, 46000)
