@@ -110,10 +110,13 @@ class ZipFile:
         self.f = E.L.gz_zip_open(E.h, C.byref(self._cplan))
         if not self.f:
             raise GenozipAMDError("gz_zip_open failed: bad plan")
+        import weakref
+        E._zip_files.append(weakref.ref(self))          # (the handle must outlive the files opened on it)
 
     def close(self):
         if getattr(self, "f", None):
-            self.E.L.gz_zip_close(self.f)
+            if getattr(self.E, "h", None):
+                self.E.L.gz_zip_close(self.f)
             self.f = None
 
     __del__ = close
@@ -130,6 +133,42 @@ class ZipFile:
         rc = self.E.L.gz_fastq_zip_vblocks(self.f, self.E.mem.ptr(text_buf), text_len, tab, n)
         if rc != GZ_OK:
             raise GenozipAMDError("gz_fastq_zip_vblocks failed (%d): %s" % (rc, self.E.L.gz_last_error(self.E.h).decode()))
+
+    # the three phases (a file dealt out over several processes; see genozip_amd/shard.py)
+    def seg(self, text_buf, text_len, tab, n):
+        """-> this process' merge blob (bytes)"""
+        bp, bl = C.c_void_p(), C.c_uint64()
+        rc = self.E.L.gz_fastq_zip_seg(self.f, self.E.mem.ptr(text_buf) if n else None, text_len, tab, n, C.byref(bp), C.byref(bl))
+        if rc != GZ_OK:
+            raise GenozipAMDError("gz_fastq_zip_seg failed (%d): %s" % (rc, self.E.L.gz_last_error(self.E.h).decode()))
+        return C.string_at(bp.value, bl.value) if bl.value else b""
+
+    @staticmethod
+    def _blob_table(blobs):
+        blobs = [bytes(b) for b in blobs if len(b)]
+        n = len(blobs)
+        ptrs = (C.c_void_p * max(1, n))(*[C.cast(C.c_char_p(b), C.c_void_p) for b in blobs])
+        lens = (C.c_uint64 * max(1, n))(*[len(b) for b in blobs])
+        return blobs, ptrs, lens, n
+
+    def merge(self, blobs):
+        """blobs: the merge blobs of ALL processes -> this process' codec votes (bytes)"""
+        keep, ptrs, lens, n = self._blob_table(blobs)
+        vp, vl = C.c_void_p(), C.c_uint64()
+        rc = self.E.L.gz_fastq_zip_merge(self.f, ptrs, lens, n, C.byref(vp), C.byref(vl))
+        if rc != GZ_OK:
+            raise GenozipAMDError("gz_fastq_zip_merge failed (%d): %s" % (rc, self.E.L.gz_last_error(self.E.h).decode()))
+        return C.string_at(vp.value, vl.value) if vl.value else b""
+
+    def finish(self, votes):
+        keep, ptrs, lens, n = self._blob_table(votes)
+        rc = self.E.L.gz_fastq_zip_finish(self.f, ptrs, lens, n)
+        if rc != GZ_OK:
+            raise GenozipAMDError("gz_fastq_zip_finish failed (%d): %s" % (rc, self.E.L.gz_last_error(self.E.h).decode()))
+
+    def results(self, tab):
+        return [dict(z=self._download(t.z_data, t.z_len), seq_packed=self._download(t.seq_packed, t.seq_packed_len), n_bases=t.n_bases,
+                     seq_has_x=bool(t.seq_has_x), n_reads=t.n_reads, n_sections=t.n_sections, vblock_i=t.vblock_i) for t in tab]
 
     def zip_vblocks(self, text, vbs):
         """text: bytes; vbs as for vb_table -> list of dict(z=bytes, seq_packed=bytes, n_bases, seq_has_x, n_reads)"""
@@ -167,6 +206,7 @@ class Engine:
             from .mem import TorchMem
             mem = TorchMem(device)
         self.mem = mem
+        self._zip_files = []
         err = C.c_int(0)
         self.h = self.L.gz_create(device, hip_stream, C.byref(err))
         if not self.h:
@@ -174,6 +214,10 @@ class Engine:
 
     def close(self):
         if getattr(self, "h", None):
+            for r in getattr(self, "_zip_files", []):
+                zf = r()
+                if zf is not None:
+                    zf.close()
             self.L.gz_destroy(self.h)
             self.h = None
 

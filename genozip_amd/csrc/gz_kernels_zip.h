@@ -16,19 +16,18 @@
 #include "gz_kernels_ctx.h"
 
 // ---- VBlock boundaries ------------------------------------------------------------------------------------------------
-// one thread per boundary: the index of the first line that starts at or after vb_off[v] (binary search over the line
-// starts); first_line[n_vb] = n_lines. A boundary that is not a line start is reported in *bad.
-__global__ void k_vb_bounds (const uint32_t *line_off, const GzLinesResult *lines, const uint64_t *vb_off, uint32_t n_vb, uint32_t *first_line, uint32_t *bad)
+// one thread per boundary (the start and the end of every VBlock: the VBlocks of a call need not be adjacent): the index of
+// the first line that starts at or after the offset (binary search over the line starts; the end of the text -> n_lines).
+// A boundary inside a line is reported in *bad.
+__global__ void k_vb_bounds (const uint32_t *line_off, const GzLinesResult *lines, const uint64_t *offs, uint32_t n, uint64_t text_len, uint32_t *first_line, uint32_t *bad)
 {
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v > n_vb) return;
-    const uint64_t n_lines = lines->n_lines;
-    if (v == n_vb) { first_line[v] = (uint32_t)n_lines; return; }
-    const uint64_t want = vb_off[v];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t n_lines = lines->n_lines, want = offs[i];
     uint64_t lo = 0, hi = n_lines;
     while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (line_off[mid] < want) lo = mid + 1; else hi = mid; }
-    first_line[v] = (uint32_t)lo;
-    if (lo < n_lines ? line_off[lo] != want : false) atomicMax (bad, 1u);
+    first_line[i] = (uint32_t)lo;
+    if (lo < n_lines ? line_off[lo] != want : want != text_len) atomicMax (bad, 1u);
 }
 
 // ---- tokenizer with n-th occurrence separators --------------------------------------------------------------------------
@@ -255,12 +254,12 @@ __global__ void __launch_bounds__(256) k_pack_copy (const GzdPackJob *jobs, uint
 }
 
 // ---- VB header statistics: longest record (vb->longest_line_len, seg.c: a FASTQ "line" is the 4-line read) and longest SEQ ----
-// grid (VBlocks)
-__global__ void __launch_bounds__(256) k_vb_stats (const uint32_t *line_off, const uint32_t *seq_len, const uint32_t *first_line, const uint64_t *vb_end,
+// grid (VBlocks); first_line = [starts (n_vb) | ends (n_vb)]
+__global__ void __launch_bounds__(256) k_vb_stats (const uint32_t *line_off, const uint32_t *seq_len, const uint32_t *first_line, const uint64_t *vb_end, uint32_t n_vb,
                                                     uint32_t *out /* [n_vb][2] */)
 {
     const uint32_t v = blockIdx.x;
-    const uint32_t r0 = first_line[v] / 4, r1 = first_line[v + 1] / 4;
+    const uint32_t r0 = first_line[v] / 4, r1 = first_line[n_vb + v] / 4;
     uint32_t longest = 0, longest_seq = 0;
     for (uint32_t r = r0 + threadIdx.x; r < r1; r += 256) {
         const uint64_t end = r + 1 < r1 ? line_off[4 * (r + 1)] : vb_end[v];

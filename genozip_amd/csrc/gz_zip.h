@@ -8,6 +8,7 @@
 // VBlock reproduces the single-thread order of SURVEY A.6.
 #pragma once
 #include <algorithm>
+#include <map>
 
 // ---------------------------------------------------------------------------------------------------------
 // a15: order of the sections of one VBlock (zip_compress_all_contexts_local src/zip.c:291-342 called at :566 for
@@ -34,6 +35,52 @@ extern "C" uint32_t gz_section_order (const GzSecOrderIn *c, uint32_t n, uint32_
     return k;
 }
 
+struct ZipCol {                    // one (VBlock, context) of this process
+    uint32_t n = 0;                // snips (reads of the VBlock)
+    int col_job = -1, dyn_job = -1, blob_job = -1, icol_job = -1;
+    uint8_t *b250_seg = NULL, *b250_out = NULL;
+    uint8_t *local = NULL; uint64_t local_cap = 0; uint32_t *sec_len_dev = NULL;
+    // host side after the read-back / the merge
+    uint32_t n_ol = 0, n_new = 0; bool all_the_same = false; uint64_t seg_b250_len = 0, b250_count = 0;
+    uint64_t local_len = 0; int ltype = 0;
+    bool has_b250 = false, has_local = false, ston_only_local = false;
+    std::vector<uint8_t> host_b250;            // constant-snip contexts: the generated b250, written by the host
+    const uint8_t *sec_b250 = NULL; uint32_t sec_b250_len = 0;
+    std::vector<uint8_t> ston_local;
+    size_t n2w_at = 0;
+    uint8_t lcodec = 0, bcodec = 0;
+};
+
+// One (VBlock, context) as the merge sees it - what a process has to tell the others when the VBlocks of a file are dealt out
+// to several processes (the ordered dictionary merge is the one exchange step of the path): fixed part + the
+// VBlock's new words. Serialised into the "merge blob" of gz_fastq_zip_seg.
+struct ZipMergeRec {
+    uint32_t state;                // 0: nothing to merge; 1: a device column; 2: constant snip
+    uint32_t n, n_ol, n_new;
+    uint64_t dict_len, seg_b250_len, b250_count, local_len;
+    int32_t  ats_node; uint32_t all_the_same;
+    // followed (state 1) by dict [dict_len], node_char_index [n_new], node_snip_len [n_new], counts [n_ol + n_new], each padded to 8 bytes
+};
+struct ZipBlobVB { uint32_t vblock_i, r1_vblock_i, n_ctx, reserved; };   // then n_ctx x (ZipMergeRec + payload)
+struct ZipVote { uint32_t ctx, is_local, vblock_i, codec; };
+
+struct ZipVBState { std::vector<uint8_t> has_b250, has_local; std::vector<std::vector<uint8_t>> host_b250; };
+
+struct ZipCall {                   // what lives between the phases of one call
+    int phase = 0;
+    uint8_t *text = NULL; uint64_t text_len = 0; GzFastqVB *vbs = NULL; uint32_t NV = 0;
+    std::vector<uint32_t> r0;
+    std::vector<ZipCol> col;
+    std::vector<GzColumnJob> col_jobs;
+    std::vector<GzColumnResult> colres; std::vector<GzDynIntResult> dynres; std::vector<uint64_t> blobres, acgtres; std::vector<uint32_t> vbstat;
+    std::vector<int> acgt_of_vb;
+    GzDynIntResult *d_dynres = NULL; uint32_t *d_seclen = NULL; int32_t *d_b250st = NULL;
+    std::vector<uint8_t> blob;      // this process' merge blob
+    std::vector<ZipVote> votes;
+    std::vector<int32_t> n2w_host;
+    std::map<uint32_t, ZipVBState> vbstate;   // by vblock_i: every VBlock of the call, own or not
+};
+
 // ---------------------------------------------------------------------------------------------------------
 struct GzZipFile {
     GzHandle *h;
@@ -44,6 +91,7 @@ struct GzZipFile {
     std::vector<ArenaBlock> ws;            // device workspace of one call (bump allocated, reused by the next call)
     std::vector<uint8_t> stage;            // host staging
     uint32_t last_vblock_i = 0;
+    ZipCall call;
 };
 
 static void *ws_alloc (GzZipFile *f, size_t bytes)
@@ -231,37 +279,37 @@ static int zip_assign_best_many (GzHandle *h, GzZipFile *f, const std::vector<co
     return GZ_OK;
 }
 
-struct ZipCol {                    // one (VBlock, context) on the device
-    uint32_t n = 0;                // snips (reads of the VBlock)
-    // column job outputs (ITEM_TEXT / ITEM_INT)
-    int col_job = -1;              // index into the column job table
-    uint8_t *b250_seg = NULL, *b250_out = NULL; uint32_t *b250_len_dev = NULL; int32_t *b250_status_dev = NULL;
-    int32_t *node2word_dev = NULL;
-    // local
-    uint8_t *local = NULL; uint64_t local_cap = 0; int dyn_job = -1; int blob_job = -1; uint32_t *sec_len_dev = NULL;
-    int icol_job = -1;
-    // host side after the read-back
-    uint32_t n_ol = 0, n_new = 0; bool all_the_same = false; uint64_t seg_b250_len = 0, b250_count = 0;
-    uint64_t local_len = 0; int ltype = 0;
-    bool has_b250 = false, has_local = false, ston_only_local = false, dropped_by_r1_host = false;
-    std::vector<uint8_t> host_b250;            // CONST contexts: the generated b250 written by the host
-    const uint8_t *sec_b250 = NULL; uint32_t sec_b250_len = 0;
-    std::vector<uint8_t> ston_local;
-    uint8_t lcodec = 0, bcodec = 0;
-    int32_t ats_node = -1;
-};
-
 #define ZCHK(call) do { int rc_ = (call); if (rc_ != GZ_OK) return rc_ < 0 ? rc_ : GZ_ERR; } while (0)
 #define WS(var, type, count) type *var = (type *)ws_alloc (f, (size_t)(count) * sizeof (type)); if (!var) return GZ_ERR_HIP
 
-extern "C" int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_len, GzFastqVB *vbs, int n_vbs)
+static inline void blob_put (std::vector<uint8_t> &b, const void *p, size_t n)
 {
-    if (!f || !text || !vbs || n_vbs <= 0 || n_vbs > 16384 || text_len >= 0xfffffff0ull) return GZ_ERR_ARG;
+    const size_t at = b.size ();
+    b.resize (at + ((n + 7) & ~(size_t)7), 0);
+    if (n) memcpy (b.data () + at, p, n);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// phase 1: text -> the columns of every (VBlock, context) of THIS process; returns the merge blob
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len, GzFastqVB *vbs, int n_vbs, const void **blob_out, uint64_t *blob_len_out)
+{
+    if (!f || !blob_out || !blob_len_out) return GZ_ERR_ARG;
+    if (n_vbs == 0) {                                      // a process without VBlocks in this call still takes part in the merge
+        int rc0 = gz_sync (f->h);
+        if (rc0 < 0) return rc0;
+        for (auto &b : f->ws) b.used = 0;
+        f->call = ZipCall ();
+        f->call.phase = 1;
+        *blob_out = NULL; *blob_len_out = 0;
+        return GZ_OK;
+    }
+    if (!text || !vbs || n_vbs < 0 || n_vbs > 16384 || text_len >= 0xfffffff0ull) return GZ_ERR_ARG;
     GzHandle *h = f->h;
     const uint32_t NC = (uint32_t)f->ctxs.size (), NV = (uint32_t)n_vbs;
     if ((uint64_t)NC * NV > 60000) { h->err = "too many (VBlock, context) pairs for one call"; return GZ_ERR_ARG; }
     for (uint32_t v = 0; v < NV; v++) {
-        if (vbs[v].text_off + vbs[v].text_len > text_len || (v && vbs[v].vblock_i <= vbs[v - 1].vblock_i) || vbs[v].vblock_i <= f->last_vblock_i ||
+        if (vbs[v].text_off + vbs[v].text_len > text_len || (v && vbs[v].vblock_i <= vbs[v - 1].vblock_i) || !vbs[v].vblock_i ||
             vbs[v].r1 >= (int32_t)v || (v && vbs[v].text_off < vbs[v - 1].text_off + vbs[v - 1].text_len)) { h->err = "VBlock table: offsets / order / r1"; return GZ_ERR_ARG; }
         vbs[v].status = GZ_ERR; vbs[v].z_data = NULL; vbs[v].z_len = 0; vbs[v].n_reads = 0; vbs[v].seq_packed = NULL; vbs[v].seq_packed_len = 0;
         vbs[v].n_bases = 0; vbs[v].seq_has_x = 0; vbs[v].n_sections = 0;
@@ -270,8 +318,11 @@ extern "C" int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_
     int rc;
     if ((rc = gz_sync (h)) < 0) return rc;
     for (auto &b : f->ws) b.used = 0;
+    f->call = ZipCall ();
+    ZipCall &K = f->call;
+    K.text = text; K.text_len = text_len; K.vbs = vbs; K.NV = NV;
 
-    // ---- phase A: lines of the whole text, first line of every VBlock (seg_get_next_line, src/seg.c:200-236) -------------
+    // ---- lines of the whole text, first line of every VBlock (seg_get_next_line, src/seg.c:200-236) -------------------------
     const uint8_t lookup_byte[16] = { 1 };                                  // SNIP_LOOKUP parked behind the text
     HIPCHK (h, hipMemcpyAsync (text + text_len, lookup_byte, 16, hipMemcpyHostToDevice, h->stream));
     const uint32_t lookup_off = (uint32_t)text_len;
@@ -280,40 +331,40 @@ extern "C" int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_
     struct ABlock { GzLinesResult lines; uint32_t bad_bound, n_bad_items; GzFastqResult fq; } ;
     WS (d_a, ABlock, 1);
     WS (d_vb_off, uint64_t, 2 * NV + 2);
-    WS (d_first_line, uint32_t, NV + 2);
-    std::vector<uint64_t> vb_off (2 * NV + 2);
-    for (uint32_t v = 0; v < NV; v++) { vb_off[v] = vbs[v].text_off; vb_off[NV + 1 + v] = vbs[v].text_off + vbs[v].text_len; }
+    WS (d_first_line, uint32_t, 2 * NV + 2);
+    std::vector<uint64_t> vb_off (2 * NV + 2);                              // starts, then ends
+    for (uint32_t v = 0; v < NV; v++) { vb_off[v] = vbs[v].text_off; vb_off[NV + v] = vbs[v].text_off + vbs[v].text_len; }
     HIPCHK (h, hipMemcpyAsync (d_vb_off, vb_off.data (), vb_off.size () * 8, hipMemcpyHostToDevice, h->stream));
     ABlock a;
-    std::vector<uint32_t> first_line (NV + 2);
+    std::vector<uint32_t> first_line (2 * NV + 2);
     for (int attempt = 0;; attempt++) {
         line_off = (uint32_t *)ws_alloc (f, ((size_t)line_cap + 8) * 4); line_len = (uint32_t *)ws_alloc (f, ((size_t)line_cap + 8) * 4);
         if (!line_off || !line_len) return GZ_ERR_HIP;
         HIPCHK (h, hipMemsetAsync (d_a, 0, sizeof (ABlock), h->stream));
         ZCHK (gz_text_lines (h, text, text_len, line_off, line_len, line_cap, &d_a->lines));
-        hipLaunchKernelGGL (k_vb_bounds, dim3 ((NV + 64) / 64), dim3 (64), 0, h->stream, (const uint32_t *)line_off, (const GzLinesResult *)&d_a->lines,
-                            (const uint64_t *)d_vb_off, NV, d_first_line, &d_a->bad_bound);
+        hipLaunchKernelGGL (k_vb_bounds, dim3 ((2 * NV + 63) / 64), dim3 (64), 0, h->stream, (const uint32_t *)line_off, (const GzLinesResult *)&d_a->lines,
+                            (const uint64_t *)d_vb_off, 2 * NV, text_len, d_first_line, &d_a->bad_bound);
         HIPCHK (h, hipMemcpyAsync (&a, d_a, sizeof (a), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK (h, hipMemcpyAsync (first_line.data (), d_first_line, (NV + 1) * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK (h, hipMemcpyAsync (first_line.data (), d_first_line, 2 * (size_t)NV * 4, hipMemcpyDeviceToHost, h->stream));
         if ((rc = gz_sync (h)) < 0) return rc;
         if (a.lines.status == GZ_ST_OK) break;
         if (attempt || a.lines.n_lines > 0xfffffff0ull) { h->err = "line index does not fit"; return GZ_ERR; }
         line_cap = (uint32_t)a.lines.n_lines + 8;                          // (short lines: once more with the exact count)
     }
-    if (a.bad_bound) { h->err = "a VBlock does not start at the start of a line"; return GZ_ERR_CORRUPT; }
+    if (a.bad_bound) { h->err = "a VBlock does not start / end at the start of a line"; return GZ_ERR_CORRUPT; }
     const uint64_t n_lines = a.lines.n_lines;
-    const uint32_t R = (uint32_t)(n_lines / 4);                            // reads of the whole text
-    std::vector<uint32_t> r0 (NV + 1);
-    for (uint32_t v = 0; v <= NV; v++) {
-        if (first_line[v] % 4) { h->err = "a VBlock does not hold whole reads (4 lines each)"; return GZ_ERR_CORRUPT; }
-        r0[v] = first_line[v] / 4;
-    }
+    if (n_lines % 4) { h->err = "the text does not hold whole reads (4 lines each)"; return GZ_ERR_CORRUPT; }
+    const uint32_t R = (uint32_t)(n_lines / 4);                            // reads of the whole text (every 4 lines: VBlocks hold whole reads)
+    K.r0.resize (NV + 1);
+    std::vector<uint32_t> &r0 = K.r0;
+    std::vector<uint32_t> r_end (NV);
     for (uint32_t v = 0; v < NV; v++) {
-        // lines between the VBlocks (text the table leaves out) must not exist: VBlock v ends where v+1 starts or the text ends
-        vbs[v].n_reads = r0[v + 1] - r0[v];
+        if (first_line[v] % 4 || first_line[NV + v] % 4) { h->err = "a VBlock does not hold whole reads (4 lines each)"; return GZ_ERR_CORRUPT; }
+        r0[v] = first_line[v] / 4; r_end[v] = first_line[NV + v] / 4;
+        vbs[v].n_reads = r_end[v] - r0[v];
     }
 
-    // ---- phase B: reads, items, the columns of every (VBlock, context) -----------------------------------------------------
+    // ---- reads, items, the columns of every (VBlock, context) ---------------------------------------------------------------
     const uint32_t NI = f->plan.n_seps + 1;
     WS (rec, uint32_t, (size_t)8 * (R + 8));
     uint32_t *l1_off = rec, *l1_len = rec + (R + 8), *seq_off = rec + 2 * (size_t)(R + 8), *seq_len = rec + 3 * (size_t)(R + 8),
@@ -324,7 +375,7 @@ extern "C" int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_
     ZCHK (gz_tokenize_column_n (h, text, l1_off, l1_len, R, f->plan.seps, f->plan.sep_counts, f->plan.n_seps, item_off, item_len, &d_a->n_bad_items));
     WS (d_vbstat, uint32_t, 2 * (size_t)NV + 2);
     hipLaunchKernelGGL (k_vb_stats, dim3 (NV), dim3 (256), 2048, h->stream, (const uint32_t *)line_off, (const uint32_t *)seq_len, (const uint32_t *)d_first_line,
-                        (const uint64_t *)(d_vb_off + NV + 1), d_vbstat);
+                        (const uint64_t *)(d_vb_off + NV), NV, d_vbstat);
 
     // the dictionaries as every VBlock of this call clones them (ctx_clone)
     struct OlDev { const uint8_t *dict = NULL; const uint64_t *ci = NULL; const uint32_t *sl = NULL; uint32_t n = 0; };
@@ -343,11 +394,11 @@ extern "C" int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_
         ol[c].dict = d; ol[c].ci = ci; ol[c].sl = sl;
     }
 
-    std::vector<ZipCol> col ((size_t)NV * NC);
-    auto COL = [&] (uint32_t v, uint32_t c) -> ZipCol & { return col[(size_t)v * NC + c]; };
-    std::vector<GzIntColJob> icol_jobs; std::vector<GzColumnJob> col_jobs; std::vector<GzDynIntJob> dyn_jobs; std::vector<GzBlobJob> blob_jobs; std::vector<GzAcgtJob> acgt_jobs;
-    std::vector<int> acgt_of_vb (NV, -1);
-    // result block: everything the host reads back in one copy
+    K.col.assign ((size_t)NV * NC, ZipCol ());
+    auto COL = [&] (uint32_t v, uint32_t c) -> ZipCol & { return K.col[(size_t)v * NC + c]; };
+    std::vector<GzIntColJob> icol_jobs; std::vector<GzDynIntJob> dyn_jobs; std::vector<GzBlobJob> blob_jobs; std::vector<GzAcgtJob> acgt_jobs;
+    std::vector<GzColumnJob> &col_jobs = K.col_jobs;
+    K.acgt_of_vb.assign (NV, -1);
     const size_t max_jobs = (size_t)NV * NC + 1;
     WS (d_colres, GzColumnResult, max_jobs);
     WS (d_dynres, GzDynIntResult, max_jobs);
@@ -356,8 +407,10 @@ extern "C" int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_
     WS (d_acgtres, uint64_t, 2 * max_jobs);          // has_x (u32) | pad, packed_len
     WS (d_seclen, uint32_t, 2 * max_jobs);           // device-resident payload length of every (VBlock, context) local / b250 section
     WS (d_b250st, int32_t, max_jobs);
+    K.d_dynres = d_dynres; K.d_seclen = d_seclen; K.d_b250st = d_b250st;
     HIPCHK (h, hipMemsetAsync (d_icolres, 0, 2 * max_jobs * 8, h->stream));
     HIPCHK (h, hipMemsetAsync (d_seclen, 0, 2 * max_jobs * 4, h->stream));
+    HIPCHK (h, hipMemsetAsync (d_b250st, 0, max_jobs * 4, h->stream));
 
     for (uint32_t v = 0; v < NV; v++) {
         const uint32_t n = vbs[v].n_reads, rr = r0[v];
@@ -416,8 +469,8 @@ extern "C" int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_
                     aj.packed = (uint8_t *)ws_alloc (f, gz_acgt_packed_len (Z.local_cap) + 64);
                     aj.x = Z.local;                                         // NONREF_X overlays NONREF (codec_acgt.c:66-70)
                     if (!aj.packed) return GZ_ERR_HIP;
-                    acgt_of_vb[v] = (int)acgt_jobs.size ();
-                    aj.has_x_dev = (uint32_t *)(d_acgtres + 2 * (size_t)acgt_of_vb[v]); aj.packed_len_dev = d_acgtres + 2 * (size_t)acgt_of_vb[v] + 1;
+                    K.acgt_of_vb[v] = (int)acgt_jobs.size ();
+                    aj.has_x_dev = (uint32_t *)(d_acgtres + 2 * (size_t)K.acgt_of_vb[v]); aj.packed_len_dev = d_acgtres + 2 * (size_t)K.acgt_of_vb[v] + 1;
                     vbs[v].seq_packed = aj.packed;
                     acgt_jobs.push_back (aj);
                 }
@@ -441,7 +494,7 @@ extern "C" int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_
         pack_cap += j.dict_cap + 16ull * j.n + 4ull * j.n_ol + 64;
     }
     // (worst case = every snip a new word; the usual case is a few hundred bytes per column)
-    const uint64_t pack_cap_used = std::min<uint64_t> (pack_cap, (uint64_t)64 << 20);
+    const uint64_t pack_cap_used = std::min<uint64_t> (pack_cap, (uint64_t)256 << 20);
     WS (d_pack, GzdPackJob, NCJ + 1);
     WS (d_pack_total, uint64_t, 2);
     uint8_t *d_staging = (uint8_t *)ws_alloc (f, pack_cap_used);
@@ -452,125 +505,223 @@ extern "C" int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_
         hipLaunchKernelGGL (k_pack_copy, dim3 ((uint32_t)NCJ), dim3 (256), 0, h->stream, (const GzdPackJob *)d_pack, d_staging, (const uint64_t *)d_pack_total);
     }
     // ---- read back (second wait)
-    std::vector<GzColumnResult> colres (NCJ + 1); std::vector<GzDynIntResult> dynres (dyn_jobs.size () + 1);
-    std::vector<uint64_t> icolres (2 * icol_jobs.size () + 2), blobres (blob_jobs.size () + 1), acgtres (2 * acgt_jobs.size () + 2);
-    std::vector<uint32_t> vbstat (2 * (size_t)NV + 2);
+    K.colres.resize (NCJ + 1); K.dynres.resize (dyn_jobs.size () + 1);
+    std::vector<uint64_t> icolres (2 * icol_jobs.size () + 2);
+    K.blobres.resize (blob_jobs.size () + 1); K.acgtres.resize (2 * acgt_jobs.size () + 2); K.vbstat.resize (2 * (size_t)NV + 2);
     uint64_t pack_total[2] = { 0, 1 };
     if (NCJ) {
-        HIPCHK (h, hipMemcpyAsync (colres.data (), d_colres, NCJ * sizeof (GzColumnResult), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK (h, hipMemcpyAsync (K.colres.data (), d_colres, NCJ * sizeof (GzColumnResult), hipMemcpyDeviceToHost, h->stream));
         HIPCHK (h, hipMemcpyAsync (pack.data (), d_pack, NCJ * sizeof (GzdPackJob), hipMemcpyDeviceToHost, h->stream));
         HIPCHK (h, hipMemcpyAsync (pack_total, d_pack_total, 16, hipMemcpyDeviceToHost, h->stream));
     }
-    if (!dyn_jobs.empty ())  HIPCHK (h, hipMemcpyAsync (dynres.data (), d_dynres, dyn_jobs.size () * sizeof (GzDynIntResult), hipMemcpyDeviceToHost, h->stream));
+    if (!dyn_jobs.empty ())  HIPCHK (h, hipMemcpyAsync (K.dynres.data (), d_dynres, dyn_jobs.size () * sizeof (GzDynIntResult), hipMemcpyDeviceToHost, h->stream));
     if (!icol_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (icolres.data (), d_icolres, icol_jobs.size () * 16, hipMemcpyDeviceToHost, h->stream));
-    if (!blob_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (blobres.data (), d_blobres, blob_jobs.size () * 8, hipMemcpyDeviceToHost, h->stream));
-    if (!acgt_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (acgtres.data (), d_acgtres, acgt_jobs.size () * 16, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK (h, hipMemcpyAsync (vbstat.data (), d_vbstat, 2 * (size_t)NV * 4, hipMemcpyDeviceToHost, h->stream));
+    if (!blob_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (K.blobres.data (), d_blobres, blob_jobs.size () * 8, hipMemcpyDeviceToHost, h->stream));
+    if (!acgt_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (K.acgtres.data (), d_acgtres, acgt_jobs.size () * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK (h, hipMemcpyAsync (K.vbstat.data (), d_vbstat, 2 * (size_t)NV * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK (h, hipMemcpyAsync (&a, d_a, sizeof (a), hipMemcpyDeviceToHost, h->stream));
     if ((rc = gz_sync (h)) < 0) return rc;
     if (a.fq.first_bad != 0xffffffffu) {
-        for (uint32_t v = 0; v < NV; v++) if (a.fq.first_bad >= r0[v] && a.fq.first_bad < r0[v + 1]) vbs[v].status = GZ_ERR_CORRUPT;
+        for (uint32_t v = 0; v < NV; v++) if (a.fq.first_bad >= r0[v] && a.fq.first_bad < r_end[v]) vbs[v].status = GZ_ERR_CORRUPT;
         h->err = "not FASTQ: a read is not '@'.. / SEQ / '+'.. / QUAL of SEQ's length (fastq.c:1008-1010,1076,1121)"; return GZ_ERR_CORRUPT;
     }
     if (a.n_bad_items) { h->err = "a line 1 does not fit the container of the plan (the reference would re-discover the flavor, qname.c:823-826)"; return GZ_ERR_CORRUPT; }
     for (size_t k = 0; k < icol_jobs.size (); k++)
         if ((int32_t)icolres[2 * k + 1] == GZ_ST_CORRUPT) { h->err = "an ordered item is not an integer (qname.c:750-756)"; return GZ_ERR_CORRUPT; }
-    for (size_t k = 0; k < NCJ; k++) if (colres[k].status != 1) { h->err = "column dictionary capacity"; return GZ_ERR; }
+    for (size_t k = 0; k < NCJ; k++) if (K.colres[k].status != 1) { h->err = "column dictionary capacity"; return GZ_ERR; }
     if (!pack_total[1]) { h->err = "merge staging buffer too small"; return GZ_ERR; }
     f->stage.resize (pack_total[0] + 16);
     if (pack_total[0]) HIPCHK (h, hipMemcpy (f->stage.data (), d_staging, pack_total[0], hipMemcpyDeviceToHost));
 
-    // ---- a4: the merge, context by context, VBlocks in order (ctx_merge_in_vb_ctx, src/zip.c:578) ---------------------------
-    const uint8_t ATS = 0x20, PAIRED = 0x04;
-    std::vector<int32_t> n2w_host;                      // all node2word arrays, uploaded in one copy
-    std::vector<size_t> n2w_at ((size_t)NV * NC, 0);
-    for (uint32_t c = 0; c < NC; c++) {
-        const GzFastqCtx &X = f->ctxs[c];
-        GzZctx *z = f->zctx[c];
-        for (uint32_t v = 0; v < NV; v++) {
+    // ---- the merge blob: per VBlock, per context, what ctx_merge_in_one_vctx reads of the VBlock's context ------------------
+    K.blob.clear ();
+    for (uint32_t v = 0; v < NV; v++) {
+        ZipBlobVB hv = { vbs[v].vblock_i, vbs[v].r1 >= 0 ? vbs[vbs[v].r1].vblock_i : 0, NC, 0 };
+        blob_put (K.blob, &hv, sizeof (hv));
+        for (uint32_t c = 0; c < NC; c++) {
+            const GzFastqCtx &X = f->ctxs[c];
             ZipCol &Z = COL (v, c);
-            const bool is_r2 = vbs[v].r1 >= 0;
-            GzMergeJob m; memset (&m, 0, sizeof (m));
-            m.vblock_i = vbs[v].vblock_i;
-            if (Z.dyn_job >= 0) { Z.local_len = dynres[Z.dyn_job].len; Z.ltype = dynres[Z.dyn_job].ltype; Z.has_local = Z.local_len != 0; }
-            if (Z.blob_job >= 0) { Z.local_len = blobres[Z.blob_job]; Z.ltype = GZ_LT_BLOB; Z.has_local = Z.local_len != 0; }
+            ZipMergeRec r; memset (&r, 0, sizeof (r));
+            if (Z.dyn_job >= 0) { Z.local_len = K.dynres[Z.dyn_job].len; Z.ltype = K.dynres[Z.dyn_job].ltype; Z.has_local = Z.local_len != 0; }
+            if (Z.blob_job >= 0) { Z.local_len = K.blobres[Z.blob_job]; Z.ltype = GZ_LT_BLOB; Z.has_local = Z.local_len != 0; }
             if (X.kind == GZ_FQ_SEQ) {                                     // NONREF itself leaves the path 2-bit packed; what stays is NONREF_X
-                const int aj = acgt_of_vb[v];
-                vbs[v].n_bases = Z.local_len; vbs[v].seq_packed_len = acgtres[2 * aj + 1]; vbs[v].seq_has_x = (uint32_t)acgtres[2 * aj] != 0;
+                const int aj = K.acgt_of_vb[v];
+                vbs[v].n_bases = Z.local_len; vbs[v].seq_packed_len = K.acgtres[2 * aj + 1]; vbs[v].seq_has_x = (uint32_t)K.acgtres[2 * aj] != 0;
                 Z.has_local = vbs[v].seq_has_x != 0; Z.ltype = GZ_LT_UINT8;  // NONREF_X.ltype (codec_acgt.c:34-35)
-                continue;
             }
-            if (X.kind == GZ_FQ_QUAL) continue;                            // no b250, nothing to merge
-            if (!Z.n) continue;                                            // an empty VBlock segs nothing
-            if (Z.col_job >= 0) {
-                const GzColumnResult &r = colres[Z.col_job];
-                const GzdPackJob &p = pack[Z.col_job];
-                Z.n_new = r.n_new; Z.all_the_same = r.all_the_same != 0; Z.seg_b250_len = r.b250_len; Z.b250_count = r.b250_count;
-                m.n_ol = Z.n_ol; m.n_new = r.n_new;
-                m.dict = f->stage.data () + p.at[0]; m.node_char_index = (const uint64_t *)(f->stage.data () + p.at[1]);
-                m.node_snip_len = (const uint32_t *)(f->stage.data () + p.at[2]); m.counts = (const uint32_t *)(f->stage.data () + p.at[3]);
-                m.b250_len = r.b250_len;
-                if (Z.all_the_same) {
-                    // the one node of the column: an ol word (index with a count) or the VBlock's first new node
-                    int32_t node = -1;
-                    for (uint32_t k = 0; k < Z.n_ol && node < 0; k++) if (m.counts[k]) node = (int32_t)k;
-                    if (node < 0 && r.n_new) node = (int32_t)Z.n_ol;
-                    Z.ats_node = node;                                     // (-1: every snip was empty / missing: not droppable)
-                }
+            r.n = Z.n; r.local_len = Z.local_len; r.ats_node = -1;
+            if (X.kind == GZ_FQ_SEQ || X.kind == GZ_FQ_QUAL || !Z.n) { blob_put (K.blob, &r, sizeof (r)); continue; }
+            if (Z.col_job < 0) { r.state = 2; blob_put (K.blob, &r, sizeof (r)); continue; }
+            const GzColumnResult &cr = K.colres[Z.col_job];
+            const GzdPackJob &p = pack[Z.col_job];
+            const uint32_t *counts = (const uint32_t *)(f->stage.data () + p.at[3]);
+            r.state = 1; r.n_ol = Z.n_ol; r.n_new = cr.n_new; r.dict_len = cr.dict_len; r.seg_b250_len = cr.b250_len; r.b250_count = cr.b250_count;
+            r.all_the_same = cr.all_the_same != 0;
+            if (r.all_the_same) {
+                // the one node of the column: an ol word (the index with a count) or the VBlock's first new node
+                for (uint32_t k = 0; k < Z.n_ol && r.ats_node < 0; k++) if (counts[k]) r.ats_node = (int32_t)k;
+                if (r.ats_node < 0 && cr.n_new) r.ats_node = (int32_t)Z.n_ol;    // (-1: every snip was empty / missing: not droppable)
             }
-            else {
+            blob_put (K.blob, &r, sizeof (r));
+            blob_put (K.blob, f->stage.data () + p.at[0], cr.dict_len);
+            blob_put (K.blob, f->stage.data () + p.at[1], 8 * (size_t)cr.n_new);
+            blob_put (K.blob, f->stage.data () + p.at[2], 4 * (size_t)cr.n_new);
+            blob_put (K.blob, counts, 4 * ((size_t)Z.n_ol + cr.n_new));
+        }
+    }
+    *blob_out = K.blob.data (); *blob_len_out = K.blob.size ();
+    K.phase = 1;
+    return GZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// phase 2: the merge over ALL VBlocks of the call in vblock_i order (this process' and, when the file is dealt out over
+// several processes, everybody else's), then b250 generation, locals into file order, R2 == R1 drops, and the trial
+// compressions of contexts whose codec the file does not know yet -> votes
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const uint64_t *blob_lens, int n_blobs, const void **votes_out, uint64_t *votes_len_out)
+{
+    if (!f || f->call.phase != 1 || n_blobs < 0 || (n_blobs && (!blobs || !blob_lens)) || !votes_out || !votes_len_out) return GZ_ERR_ARG;
+    GzHandle *h = f->h;
+    ZipCall &K = f->call;
+    GzFastqVB *vbs = K.vbs;
+    const uint32_t NC = (uint32_t)f->ctxs.size (), NV = K.NV;
+    auto COL = [&] (uint32_t v, uint32_t c) -> ZipCol & { return K.col[(size_t)v * NC + c]; };
+    HIPCHK (h, hipSetDevice (h->device));
+    int rc;
+    const uint8_t ATS = 0x20;
+
+    // every VBlock of every blob, in vblock_i order
+    struct Ent { uint32_t vblock_i; const uint8_t *p; };
+    std::vector<Ent> ents;
+    for (int b = 0; b < n_blobs; b++) {
+        const uint8_t *p = (const uint8_t *)blobs[b], *end = p + blob_lens[b];
+        while (p < end) {
+            if ((size_t)(end - p) < sizeof (ZipBlobVB)) { h->err = "merge blob: truncated"; return GZ_ERR_CORRUPT; }
+            const ZipBlobVB *hv = (const ZipBlobVB *)p;
+            if (hv->n_ctx != NC) { h->err = "merge blob: made with another plan"; return GZ_ERR_CORRUPT; }
+            ents.push_back ({ hv->vblock_i, p });
+            p += sizeof (ZipBlobVB);
+            for (uint32_t c = 0; c < NC; c++) {
+                if ((size_t)(end - p) < sizeof (ZipMergeRec)) { h->err = "merge blob: truncated"; return GZ_ERR_CORRUPT; }
+                const ZipMergeRec *r = (const ZipMergeRec *)p;
+                p += sizeof (ZipMergeRec);
+                if (r->state == 1) p += ((r->dict_len + 7) & ~7ull) + 8ull * r->n_new + ((4ull * r->n_new + 7) & ~7ull) + ((4ull * ((uint64_t)r->n_ol + r->n_new) + 7) & ~7ull);
+                if (p > end) { h->err = "merge blob: truncated"; return GZ_ERR_CORRUPT; }
+            }
+        }
+    }
+    std::stable_sort (ents.begin (), ents.end (), [] (const Ent &a, const Ent &b) { return a.vblock_i < b.vblock_i; });
+    for (size_t i = 0; i < ents.size (); i++)
+        if ((i && ents[i].vblock_i == ents[i - 1].vblock_i) || ents[i].vblock_i <= f->last_vblock_i) { h->err = "merge: a vblock_i twice, or not after the previous call's"; return GZ_ERR_ARG; }
+    std::map<uint32_t, uint32_t> own;                       // vblock_i -> index in vbs
+    for (uint32_t v = 0; v < NV; v++) own[vbs[v].vblock_i] = v;
+
+    K.n2w_host.clear ();
+    for (const Ent &e : ents) {
+        const ZipBlobVB *hv = (const ZipBlobVB *)e.p;
+        const uint8_t *p = e.p + sizeof (ZipBlobVB);
+        const auto it = own.find (hv->vblock_i);
+        const bool mine = it != own.end ();
+        const uint32_t v = mine ? it->second : 0;
+        const bool is_r2 = hv->r1_vblock_i != 0;
+        const ZipVBState *R1 = NULL;
+        if (is_r2) {
+            const auto r = K.vbstate.find (hv->r1_vblock_i);
+            if (r == K.vbstate.end ()) { h->err = "merge: an R2 VBlock whose R1 VBlock is not part of the call"; return GZ_ERR_ARG; }
+            R1 = &r->second;
+        }
+        ZipVBState &VS = K.vbstate[hv->vblock_i];
+        VS.has_b250.assign (NC, 0); VS.has_local.assign (NC, 0); VS.host_b250.assign (NC, std::vector<uint8_t> ());
+        for (uint32_t c = 0; c < NC; c++) {
+            const GzFastqCtx &X = f->ctxs[c];
+            GzZctx *z = f->zctx[c];
+            const ZipMergeRec *r = (const ZipMergeRec *)p;
+            p += sizeof (ZipMergeRec);
+            ZipCol scratch;
+            ZipCol &Z = mine ? COL (v, c) : scratch;
+            bool has_local = r->local_len != 0;
+            if (X.kind == GZ_FQ_SEQ) has_local = mine ? Z.has_local : false;    // (NONREF_X takes no part in any pair rule)
+            VS.has_local[c] = has_local;
+            if (r->state == 0) continue;
+            GzMergeJob m; memset (&m, 0, sizeof (m));
+            m.vblock_i = hv->vblock_i;
+            m.local_len = r->local_len;
+            m.pair2_identical = is_r2 && X.pair_identical;
+            if (is_r2) { m.b250_r1_len = R1->has_b250[c]; m.local_r1_len = R1->has_local[c]; }
+            if (r->state == 2) {
                 // GZ_FQ_CONST / GZ_FQ_ITEM_DELTA: every line segs `snip` - one node, count = lines (b250_seg_append's
                 // all-the-same collapse, b250.c:117-141); evaluated here, no device work. The snip is looked up in the
                 // dictionary as it is NOW: a word added by an earlier VBlock of this call then counts as cloned, which
                 // changes no byte (the node of a new word and the index of a cloned one convert to the same word index)
                 const uint32_t found = zctx_find (z, gz_snip_mix (X.snip, X.snip_len), X.snip, X.snip_len);
                 const uint32_t n_words = (uint32_t)z->snip_len.size ();
-                Z.n_ol = n_words; Z.all_the_same = true; Z.b250_count = Z.n;
-                Z.seg_b250_len = found == GZ_NO_WORD ? 4 : found <= 126 ? 1 : found <= 16508 ? 2 : found <= 2113660 ? 3 : 4;
-                Z.n_new = found == GZ_NO_WORD; Z.ats_node = found == GZ_NO_WORD ? (int32_t)n_words : (int32_t)found;
+                const uint64_t seg_len = found == GZ_NO_WORD ? 4 : found <= 126 ? 1 : found <= 16508 ? 2 : found <= 2113660 ? 3 : 4;
                 std::vector<uint32_t> cnt ((size_t)n_words + 1, 0);
-                cnt[(size_t)Z.ats_node] = Z.n;
+                const int32_t node = found == GZ_NO_WORD ? (int32_t)n_words : (int32_t)found;
+                cnt[(size_t)node] = r->n;
                 const uint64_t one_ci = 0; const uint32_t one_sl = X.snip_len;
                 int32_t w1 = -1; uint8_t no_ston[8];
-                m.n_ol = n_words; m.n_new = Z.n_new; m.dict = X.snip; m.node_char_index = &one_ci; m.node_snip_len = &one_sl; m.counts = cnt.data ();
-                m.b250_len = Z.seg_b250_len; m.local_len = Z.local_len;
-                m.flags = X.flags | ATS; m.pair2_identical = is_r2 && X.pair_identical; m.ats_node_index = Z.ats_node;
-                if (is_r2) { const ZipCol &R1 = COL ((uint32_t)vbs[v].r1, c); m.b250_r1_len = R1.has_b250 ? 1 : 0; m.local_r1_len = R1.has_local ? 1 : 0; }
+                m.n_ol = n_words; m.n_new = found == GZ_NO_WORD; m.dict = X.snip; m.node_char_index = &one_ci; m.node_snip_len = &one_sl; m.counts = cnt.data ();
+                m.b250_len = seg_len; m.flags = X.flags | ATS; m.ats_node_index = node;
                 m.node2word = &w1; m.ston_local = no_ston; m.ston_cap = 0;
                 if ((rc = gz_ctx_merge (z, &m)) != GZ_OK) { h->err = "gz_ctx_merge (constant snip)"; return rc < 0 ? rc : GZ_ERR; }
-                Z.lcodec = m.lcodec; Z.bcodec = m.bcodec;
-                Z.has_b250 = !m.dropped_b250;
-                if (Z.has_b250) { Z.host_b250.resize (4); Z.host_b250.resize (zip_piz_put (Z.host_b250.data (), found == GZ_NO_WORD ? w1 : (int64_t)found)); }
+                VS.has_b250[c] = !m.dropped_b250;
+                if (VS.has_b250[c]) { VS.host_b250[c].resize (4); VS.host_b250[c].resize (zip_piz_put (VS.host_b250[c].data (), found == GZ_NO_WORD ? w1 : (int64_t)found)); }
+                // (b250.c:270-277) an R2 b250 identical to its R1 counterpart is dropped
+                if (VS.has_b250[c] && is_r2 && X.pair_identical && R1->has_b250[c] && R1->host_b250[c] == VS.host_b250[c]) { /* kept in VS for later R2's; no section */ if (mine) Z.has_b250 = false; }
+                else if (mine) Z.has_b250 = VS.has_b250[c];
+                if (mine) { Z.n_ol = n_words; Z.all_the_same = true; Z.b250_count = r->n; Z.seg_b250_len = seg_len; Z.n_new = m.n_new; Z.lcodec = m.lcodec; Z.bcodec = m.bcodec;
+                            if (Z.has_b250) Z.host_b250 = VS.host_b250[c]; }
                 continue;
             }
+            // a device column
+            const uint8_t *dict = p; p += (r->dict_len + 7) & ~7ull;
+            const uint64_t *nci = (const uint64_t *)p; p += 8ull * r->n_new;
+            const uint32_t *nsl = (const uint32_t *)p; p += (4ull * r->n_new + 7) & ~7ull;
+            const uint32_t *counts = (const uint32_t *)p; p += (4ull * ((uint64_t)r->n_ol + r->n_new) + 7) & ~7ull;
+            if (mine) { Z.n_new = r->n_new; Z.all_the_same = r->all_the_same != 0; Z.seg_b250_len = r->seg_b250_len; Z.b250_count = r->b250_count; }
             // zip_handle_unique_words_ctxs (src/zip.c:136-166): a context without local whose every entry is a word new to the
             // VBlock (a unique ID) hands its whole dictionary to local; nodes and b250 are gone, nothing is merged
-            if (!Z.local_len && !X.no_stons && (X.flags & 3) != 3 && !Z.all_the_same && Z.n_new && Z.n_new == Z.b250_count && Z.n_new >= Z.n / 5 && Z.b250_count != 1) {
-                Z.has_b250 = false; Z.has_local = true; Z.ltype = GZ_LT_SINGLETON;
-                Z.local = col_jobs[Z.col_job].dict; Z.local_len = colres[Z.col_job].dict_len; Z.local_cap = Z.local_len;
-                GzZctxView zv; gz_zctx_view (z, &zv);
-                Z.lcodec = zv.lcodec; Z.bcodec = zv.bcodec;
+            if (!r->local_len && !X.no_stons && (X.flags & 3) != 3 && !r->all_the_same && r->n_new && r->n_new == r->b250_count && r->n_new >= r->n / 5 && r->b250_count != 1) {
+                VS.has_local[c] = 1;
+                if (mine) {
+                    Z.has_b250 = false; Z.has_local = true; Z.ltype = GZ_LT_SINGLETON;
+                    Z.local = K.col_jobs[Z.col_job].dict; Z.local_len = r->dict_len; Z.local_cap = Z.local_len;
+                    GzZctxView zv; gz_zctx_view (z, &zv);
+                    Z.lcodec = zv.lcodec; Z.bcodec = zv.bcodec;
+                }
                 continue;
             }
-            // device columns: flags, singleton rule (zip_handle_unique_words_ctxs src/zip.c:136-166 makes a context without
-            // local an LT_SINGLETON one; ctx_can_have_singletons src/context.h:263-265)
-            m.flags = X.flags | (Z.all_the_same ? ATS : 0);
-            m.pair2_identical = is_r2 && X.pair_identical;
-            m.local_len = Z.local_len;
-            m.ats_node_index = Z.ats_node;
-            if (is_r2) { const ZipCol &R1 = COL ((uint32_t)vbs[v].r1, c); m.b250_r1_len = R1.has_b250 ? 1 : 0; m.local_r1_len = R1.has_local ? 1 : 0; }
-            m.can_have_singletons = !Z.local_len && !X.no_stons && (X.flags & 3) != 3 && !Z.all_the_same;
-            if (Z.all_the_same && Z.ats_node < 0) m.no_drop_b250 = 1;
-            n2w_at[(size_t)v * NC + c] = n2w_host.size ();
-            n2w_host.resize (n2w_host.size () + Z.n_new + 1);
-            m.node2word = n2w_host.data () + n2w_at[(size_t)v * NC + c];
-            Z.ston_local.resize ((size_t)(colres[Z.col_job].dict_len) + 8);
-            m.ston_local = Z.ston_local.data (); m.ston_cap = Z.ston_local.size ();
+            // flags, singleton rule (zip_handle_unique_words_ctxs makes a context without local an LT_SINGLETON one;
+            // ctx_can_have_singletons src/context.h:263-265)
+            m.n_ol = r->n_ol; m.n_new = r->n_new; m.dict = dict; m.node_char_index = nci; m.node_snip_len = nsl; m.counts = counts;
+            m.b250_len = r->seg_b250_len;
+            m.flags = X.flags | (r->all_the_same ? ATS : 0);
+            m.ats_node_index = r->ats_node;
+            m.can_have_singletons = !r->local_len && !X.no_stons && (X.flags & 3) != 3 && !r->all_the_same;
+            if (r->all_the_same && r->ats_node < 0) m.no_drop_b250 = 1;
+            std::vector<int32_t> n2w_foreign; std::vector<uint8_t> ston_foreign;
+            if (mine) {
+                Z.n2w_at = K.n2w_host.size ();
+                K.n2w_host.resize (K.n2w_host.size () + r->n_new + 1);
+                m.node2word = K.n2w_host.data () + Z.n2w_at;
+                Z.ston_local.resize ((size_t)r->dict_len + 8);
+                m.ston_local = Z.ston_local.data (); m.ston_cap = Z.ston_local.size ();
+            }
+            else {
+                n2w_foreign.resize ((size_t)r->n_new + 1); ston_foreign.resize ((size_t)r->dict_len + 8);
+                m.node2word = n2w_foreign.data (); m.ston_local = ston_foreign.data (); m.ston_cap = ston_foreign.size ();
+            }
             if ((rc = gz_ctx_merge (z, &m)) != GZ_OK) { h->err = "gz_ctx_merge"; return rc < 0 ? rc : GZ_ERR; }
-            Z.ston_local.resize (m.ston_len);
-            Z.lcodec = m.lcodec; Z.bcodec = m.bcodec;
-            Z.has_b250 = !m.dropped_b250 && Z.seg_b250_len != 0;
-            if (m.ston_len) { Z.has_local = true; Z.ston_only_local = true; Z.ltype = GZ_LT_SINGLETON; Z.local_len = m.ston_len; }
+            VS.has_b250[c] = !m.dropped_b250 && r->seg_b250_len != 0;
+            if (m.ston_len) VS.has_local[c] = 1;
+            if (mine) {
+                Z.ston_local.resize (m.ston_len);
+                Z.lcodec = m.lcodec; Z.bcodec = m.bcodec;
+                Z.has_b250 = VS.has_b250[c];
+                if (m.ston_len) { Z.has_local = true; Z.ston_only_local = true; Z.ltype = GZ_LT_SINGLETON; Z.local_len = m.ston_len; }
+            }
         }
     }
     // locals of contexts without a b250 merge still inherit the committed codec (context.c:980-981)
@@ -578,20 +729,24 @@ extern "C" int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_
         GzZctxView zv; gz_zctx_view (f->zctx[c], &zv);
         for (uint32_t v = 0; v < NV; v++) { ZipCol &Z = COL (v, c); if (!Z.lcodec) Z.lcodec = zv.lcodec; if (!Z.bcodec) Z.bcodec = zv.bcodec; }
     }
+    if (!ents.empty ()) f->last_vblock_i = ents.back ().vblock_i;
 
-    // ---- phase C: b250 generation, locals into file order, R2 == R1 drops --------------------------------------------------
-    int32_t *d_n2w = (int32_t *)ws_alloc (f, (n2w_host.size () + 1) * 4);
+    // ---- b250 generation, locals into file order, R2 == R1 drops --------------------------------------------------------------
+    int32_t *d_n2w = (int32_t *)ws_alloc (f, (K.n2w_host.size () + 1) * 4);
     if (!d_n2w) return GZ_ERR_HIP;
-    if (!n2w_host.empty ()) HIPCHK (h, hipMemcpyAsync (d_n2w, n2w_host.data (), n2w_host.size () * 4, hipMemcpyHostToDevice, h->stream));
+    if (!K.n2w_host.empty ()) HIPCHK (h, hipMemcpyAsync (d_n2w, K.n2w_host.data (), K.n2w_host.size () * 4, hipMemcpyHostToDevice, h->stream));
     // small host-made payloads (constant b250s, singletons) go up in one copy
     std::vector<uint8_t> small; std::vector<std::pair<ZipCol *, std::pair<int, size_t>>> small_ref;
-    for (auto &Z : col) {
+    for (auto &Z : K.col) {
         if (Z.has_b250 && !Z.host_b250.empty ()) { small_ref.push_back ({ &Z, { 0, small.size () } }); small.insert (small.end (), Z.host_b250.begin (), Z.host_b250.end ()); small.resize ((small.size () + 15) & ~(size_t)15); }
         if (Z.ston_only_local && !Z.ston_local.empty ()) { small_ref.push_back ({ &Z, { 1, small.size () } }); small.insert (small.end (), Z.ston_local.begin (), Z.ston_local.end ()); small.resize ((small.size () + 15) & ~(size_t)15); }
     }
     uint8_t *d_small = (uint8_t *)ws_alloc (f, small.size () + 16);
     if (!d_small) return GZ_ERR_HIP;
-    if (!small.empty ()) HIPCHK (h, hipMemcpyAsync (d_small, small.data (), small.size (), hipMemcpyHostToDevice, h->stream));
+    if (!small.empty ()) {
+        f->stage.assign (small.begin (), small.end ());                     // (lives until the copy has run)
+        HIPCHK (h, hipMemcpyAsync (d_small, f->stage.data (), small.size (), hipMemcpyHostToDevice, h->stream));
+    }
     for (auto &sr : small_ref) {
         if (sr.second.first == 0) { sr.first->sec_b250 = d_small + sr.second.second; sr.first->sec_b250_len = (uint32_t)sr.first->host_b250.size (); }
         else sr.first->local = d_small + sr.second.second;
@@ -606,9 +761,9 @@ extern "C" int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_
             if (Z.has_b250 && Z.col_job >= 0) {
                 GzB250Job j; memset (&j, 0, sizeof (j));
                 j.seg = Z.b250_seg; j.seg_len = (uint32_t)Z.seg_b250_len; j.ol_nodes_len = Z.n_ol;
-                j.node2word = d_n2w + n2w_at[(size_t)v * NC + c]; j.n_new_nodes = Z.n_new;
+                j.node2word = d_n2w + Z.n2w_at; j.n_new_nodes = Z.n_new;
                 if (!(Z.b250_out = (uint8_t *)ws_alloc (f, Z.seg_b250_len + 16))) return GZ_ERR_HIP;
-                j.out = Z.b250_out; j.out_len_dev = Z.sec_len_dev + 1; j.status_dev = d_b250st + ((size_t)v * NC + c);
+                j.out = Z.b250_out; j.out_len_dev = Z.sec_len_dev + 1; j.status_dev = K.d_b250st + ((size_t)v * NC + c);
                 if (is_r2 && X.pair_identical) {
                     const ZipCol &R1 = COL ((uint32_t)vbs[v].r1, c);
                     if (R1.has_b250 && R1.b250_out) { j.r1 = R1.b250_out; j.r1_len_dev = R1.sec_len_dev + 1; }
@@ -616,13 +771,9 @@ extern "C" int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_
                 Z.sec_b250 = Z.b250_out; Z.sec_b250_len = (uint32_t)Z.seg_b250_len;
                 bjobs.push_back (j);
             }
-            if (Z.has_b250 && Z.col_job < 0 && is_r2 && X.pair_identical) {            // host-made b250s: compared here (b250.c:270-277)
-                const ZipCol &R1 = COL ((uint32_t)vbs[v].r1, c);
-                if (R1.has_b250 && R1.host_b250 == Z.host_b250) Z.has_b250 = false;
-            }
             if (Z.has_local && Z.dyn_job >= 0) {
                 GzLocalJob j; memset (&j, 0, sizeof (j));
-                j.data = Z.local; j.n = Z.n; j.dyn_dev = d_dynres + Z.dyn_job; j.len_dev = Z.sec_len_dev;
+                j.data = Z.local; j.n = Z.n; j.dyn_dev = K.d_dynres + Z.dyn_job; j.len_dev = Z.sec_len_dev;
                 ljobs.push_back (j);
                 if (is_r2 && X.pair_identical) {
                     const ZipCol &R1 = COL ((uint32_t)vbs[v].r1, c);
@@ -641,43 +792,74 @@ extern "C" int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_
         KLAUNCH (h, k_bufs_identical, dim3 ((uint32_t)same.size ()), dim3 (256), 0, (const GzdSameJob *)ds);
     }
 
-    // ---- a8: contexts whose codec the file does not know yet: trial compressions on the first VBlock that has >= 50 bytes of
-    // the stream, committed to the file-level context (codec.c:309-312,352-363); until then the section writer's RANB fallback
+    // ---- a8: contexts whose codec the file does not know yet: trial compressions on the first VBlock (of this process) that
+    // has >= 50 bytes of the stream (codec.c:309-312); the lowest vblock_i of all processes' votes is committed in phase 3
+    K.votes.clear ();
     {
-        std::vector<const uint8_t *> ptr; std::vector<uint32_t> len; std::vector<std::pair<uint32_t, int>> who;   // (context, is_local)
-        bool need_lens = false;
-        for (uint32_t c = 0; c < NC; c++) {
-            GzZctxView zv; gz_zctx_view (f->zctx[c], &zv);
-            if (!zv.lcodec || !zv.bcodec) need_lens = true;
-        }
-        if (need_lens) {
+        std::vector<const uint8_t *> ptr; std::vector<uint32_t> len; std::vector<ZipVote> who;
+        bool need = false;
+        for (uint32_t c = 0; c < NC; c++) { GzZctxView zv; gz_zctx_view (f->zctx[c], &zv); if (!zv.lcodec || !zv.bcodec) need = true; }
+        if (need) {
             std::vector<uint32_t> seclen (2 * (size_t)NV * NC);
-            HIPCHK (h, hipMemcpyAsync (seclen.data (), d_seclen, seclen.size () * 4, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK (h, hipMemcpyAsync (seclen.data (), K.d_seclen, seclen.size () * 4, hipMemcpyDeviceToHost, h->stream));
             if ((rc = gz_sync (h)) < 0) return rc;
             for (uint32_t c = 0; c < NC; c++) {
                 GzZctxView zv; gz_zctx_view (f->zctx[c], &zv);
-                for (int is_local = 0; is_local < 2; is_local++) {
+                for (uint32_t is_local = 0; is_local < 2; is_local++) {
                     if (is_local ? zv.lcodec : zv.bcodec) continue;
                     for (uint32_t v = 0; v < NV; v++) {
                         ZipCol &Z = COL (v, c);
                         uint32_t L = 0; const uint8_t *p = NULL;
                         if (is_local && Z.has_local) { p = Z.local; L = Z.dyn_job >= 0 ? seclen[2 * ((size_t)v * NC + c)] : (uint32_t)Z.local_len; }
                         if (!is_local && Z.has_b250) { p = Z.sec_b250; L = Z.col_job >= 0 ? seclen[2 * ((size_t)v * NC + c) + 1] : Z.sec_b250_len; }
-                        if (L >= 50) { ptr.push_back (p); len.push_back (L); who.push_back ({ c, is_local }); break; }
+                        if (L >= 50) { ptr.push_back (p); len.push_back (L); who.push_back ({ c, is_local, vbs[v].vblock_i, 0 }); break; }
                     }
                 }
             }
             std::vector<int> best;
             if ((rc = zip_assign_best_many (h, f, ptr, len, best)) != GZ_OK) return rc;
-            for (size_t k = 0; k < who.size (); k++) {
-                if (!best[k]) continue;
-                gz_zctx_commit_codec (f->zctx[who[k].first], who[k].second, best[k]);
-                for (uint32_t v = 0; v < NV; v++) { ZipCol &Z = COL (v, who[k].first); if (who[k].second) { if (!Z.lcodec) Z.lcodec = (uint8_t)best[k]; } else if (!Z.bcodec) Z.bcodec = (uint8_t)best[k]; }
-            }
+            for (size_t k = 0; k < who.size (); k++) if (best[k]) { who[k].codec = (uint32_t)best[k]; K.votes.push_back (who[k]); }
         }
     }
+    *votes_out = K.votes.data (); *votes_len_out = K.votes.size () * sizeof (ZipVote);
+    K.phase = 2;
+    return GZ_OK;
+}
 
-    // ---- a15 + a9-a13 + a16: sections in the reference's order, compressed, framed -------------------------------------------
+// ---------------------------------------------------------------------------------------------------------
+// phase 3: commit the codecs (lowest vblock_i wins, as in a serial run: codec.c:352-363), then the sections of this process'
+// VBlocks in the reference's order (a15), compressed and framed (a9-a13, a16)
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int gz_fastq_zip_finish (GzZipFile *f, const void *const *votes, const uint64_t *votes_lens, int n_votes)
+{
+    if (!f || f->call.phase != 2 || n_votes < 0 || (n_votes && (!votes || !votes_lens))) return GZ_ERR_ARG;
+    GzHandle *h = f->h;
+    ZipCall &K = f->call;
+    GzFastqVB *vbs = K.vbs;
+    const uint32_t NC = (uint32_t)f->ctxs.size (), NV = K.NV;
+    auto COL = [&] (uint32_t v, uint32_t c) -> ZipCol & { return K.col[(size_t)v * NC + c]; };
+    HIPCHK (h, hipSetDevice (h->device));
+    const uint8_t ATS = 0x20, PAIRED = 0x04;
+    int rc;
+    {
+        std::map<std::pair<uint32_t, uint32_t>, ZipVote> win;
+        for (int b = 0; b < n_votes; b++) {
+            if (votes_lens[b] % sizeof (ZipVote)) { h->err = "votes: size"; return GZ_ERR_ARG; }
+            const ZipVote *vt = (const ZipVote *)votes[b];
+            for (size_t k = 0; k < votes_lens[b] / sizeof (ZipVote); k++) {
+                if (vt[k].ctx >= NC || vt[k].is_local > 1) { h->err = "votes: context"; return GZ_ERR_ARG; }
+                auto key = std::make_pair (vt[k].ctx, vt[k].is_local);
+                auto it = win.find (key);
+                if (it == win.end () || vt[k].vblock_i < it->second.vblock_i) win[key] = vt[k];
+            }
+        }
+        for (auto &w : win) {
+            GzZctxView zv; gz_zctx_view (f->zctx[w.first.first], &zv);
+            if (w.first.second ? zv.lcodec : zv.bcodec) continue;
+            gz_zctx_commit_codec (f->zctx[w.first.first], (int)w.first.second, (int)w.second.codec);
+            for (uint32_t v = 0; v < NV; v++) { ZipCol &Z = COL (v, w.first.first); if (w.first.second) { if (!Z.lcodec) Z.lcodec = (uint8_t)w.second.codec; } else if (!Z.bcodec) Z.bcodec = (uint8_t)w.second.codec; }
+        }
+    }
     std::vector<GzVBlock> V (NV);
     std::vector<std::vector<GzSection>> secs (NV);
     for (uint32_t v = 0; v < NV; v++) {
@@ -703,7 +885,7 @@ extern "C" int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_
                 if ((is_r1 && X.pair_identical) || (is_r2 && X.pair_assisted_b250)) s.flags |= PAIRED;    // zfile.c:292-294
             }
             else {
-                s.section_type = GZ_SEC_LOCAL; s.data = Z.local; s.data_len = (uint32_t)std::min<uint64_t> (Z.local_len, Z.local_cap ? Z.local_cap : Z.local_len);
+                s.section_type = GZ_SEC_LOCAL; s.data = Z.local; s.data_len = (uint32_t)Z.local_len;
                 if (Z.dyn_job >= 0) { s.data_len = (uint32_t)Z.local_cap; s.data_len_dev = Z.sec_len_dev; }
                 s.codec = Z.lcodec; s.ltype = (uint8_t)Z.ltype;
                 const bool int_lt = Z.ltype >= GZ_LT_INT8 && Z.ltype <= GZ_LT_UINT64;
@@ -713,21 +895,31 @@ extern "C" int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_
             secs[v].push_back (s);
         }
         GzVBlock &B = V[v]; memset (&B, 0, sizeof (B));
-        B.vblock_i = vbs[v].vblock_i; B.recon_size = (uint32_t)vbs[v].text_len; B.longest_line_len = vbstat[2 * v]; B.longest_seq_len = vbstat[2 * v + 1];
+        B.vblock_i = vbs[v].vblock_i; B.recon_size = (uint32_t)vbs[v].text_len; B.longest_line_len = K.vbstat[2 * v]; B.longest_seq_len = K.vbstat[2 * v + 1];
         B.sections = secs[v].data (); B.n_sections = (uint32_t)secs[v].size ();
         B.z_cap = gz_vb_z_bound (B.sections, B.n_sections);
         if (!(B.z_data = (uint8_t *)ws_alloc (f, B.z_cap + 64))) return GZ_ERR_HIP;
     }
     ZCHK (gz_vb_compress_batch (h, V.data (), (int)NV));
     std::vector<int32_t> b250st ((size_t)NV * NC, 1);
-    HIPCHK (h, hipMemcpyAsync (b250st.data (), d_b250st, b250st.size () * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK (h, hipMemcpyAsync (b250st.data (), K.d_b250st, b250st.size () * 4, hipMemcpyDeviceToHost, h->stream));
     rc = gz_sync (h);
+    K.phase = 0;
     if (rc < 0) return rc;
     for (uint32_t v = 0; v < NV; v++) {
         for (uint32_t c = 0; c < NC; c++) { const ZipCol &Z = COL (v, c); if (Z.has_b250 && Z.col_job >= 0 && b250st[(size_t)v * NC + c] == -5) { h->err = "b250 generation: malformed stream"; return GZ_ERR; } }
         vbs[v].status = V[v].status; vbs[v].z_data = V[v].z_data; vbs[v].z_len = V[v].z_len; vbs[v].n_sections = V[v].n_sections;
         if (V[v].status != GZ_OK) rc = GZ_ERR;
     }
-    f->last_vblock_i = vbs[NV - 1].vblock_i;
     return rc == GZ_ERR ? GZ_ERR : GZ_OK;
+}
+
+// all three phases in one process
+extern "C" int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_len, GzFastqVB *vbs, int n_vbs)
+{
+    const void *blob, *votes; uint64_t blob_len, votes_len;
+    int rc;
+    if ((rc = gz_fastq_zip_seg (f, text, text_len, vbs, n_vbs, &blob, &blob_len)) != GZ_OK) return rc;
+    if ((rc = gz_fastq_zip_merge (f, &blob, &blob_len, 1, &votes, &votes_len)) != GZ_OK) return rc;
+    return gz_fastq_zip_finish (f, &votes, &votes_len, 1);
 }

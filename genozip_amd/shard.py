@@ -68,3 +68,29 @@ def gather_blobs(dist, blobs, rank, world, device, dst=0, async_op=False):
     if async_op:
         return PendingGather([w1, w2], (lens_pad, pay, len_bufs, pay_bufs), finish)
     return finish()
+
+
+def pairs_of_rank(n_pairs, rank, world):
+    """VBlock pair k (R1 VBlock k and R2 VBlock k of a paired FASTQ; a single VBlock for an unpaired file) -> rank k % world:
+    the dealing of ONE file over the GPUs (strong scaling). R2 consults R1's sections, so the two stay together
+    (src/fastq.c:956-976, src/zip.c:613-620)."""
+    return [k for k in range(n_pairs) if k % world == rank]
+
+
+def zip_vblocks_sharded(zf, dist, text_buf, text_len, tab, n):
+    """gz_fastq_zip_vblocks for a file whose VBlocks are dealt out over the ranks of `dist` (None: one process): the ordered
+    dictionary merge is the one exchange step on the way - every rank contributes the new words of its VBlocks
+    (a few KB), all ranks replay the merge of the whole call in vblock_i order and so hold identical dictionaries; codec
+    choices for contexts the file has none for yet are exchanged the same way (lowest vblock_i wins, as in a serial run).
+    The payload bytes never leave their GPU before the final gather (gather_blobs)."""
+    blob = zf.seg(text_buf, text_len, tab, n)
+    if dist is None or dist.get_world_size() == 1:
+        zf.finish([zf.merge([blob])])
+        return
+    world = dist.get_world_size()
+    blobs = [None] * world
+    dist.all_gather_object(blobs, blob)
+    votes = zf.merge(blobs)
+    all_votes = [None] * world
+    dist.all_gather_object(all_votes, votes)
+    zf.finish(all_votes)

@@ -433,6 +433,19 @@ void       gz_zip_close (GzZipFile *f);
 /* text: device, text_len bytes, with at least 16 writable bytes of slack behind them (a SNIP_LOOKUP byte is parked there);
  * < 4 GB per call. Synchronous (three waits inside: line index, seg results for the merge, z lengths). */
 int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_len, GzFastqVB *vbs, int n_vbs);
+/* The same in three phases, for a file whose VBlocks are dealt out to several processes (one per GPU): the ordered
+ * dictionary merge is the path's one exchange step. Every process calls gz_fastq_zip_seg on ITS VBlocks and gets a "merge
+ * blob" (host memory owned by f: per VBlock and context the new words, counts and the handful of facts
+ * ctx_merge_in_one_vctx reads); the processes exchange blobs (tiny: new words only) and every one of them hands ALL blobs to
+ * gz_fastq_zip_merge, which replays the merge of the whole call in vblock_i order - so all processes end up with identical
+ * dictionaries and each with the word indices of its own VBlocks - generates b250s / locals and returns this process'
+ * codec "votes" (context, local / b250, vblock_i, codec) for contexts the file has no codec for yet; after exchanging the
+ * votes, gz_fastq_zip_finish commits for every such context the vote with the lowest vblock_i (what a serial run commits,
+ * src/codec.c:352-363) and writes the sections. vblock_i are global: unique and ascending over all processes and calls; an R2
+ * VBlock and its R1 VBlock belong to the same process. gz_fastq_zip_vblocks == the three phases with the own blob only. */
+int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len, GzFastqVB *vbs, int n_vbs, const void **blob_out, uint64_t *blob_len_out);
+int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const uint64_t *blob_lens, int n_blobs, const void **votes_out, uint64_t *votes_len_out);
+int gz_fastq_zip_finish (GzZipFile *f, const void *const *votes, const uint64_t *votes_lens, int n_votes);
 /* the file-level context of plan context i (for the global area writer / inspection) */
 GzZctx *gz_zip_zctx (GzZipFile *f, uint32_t ctx_i);
 /* section order of one VBlock (a15): given n contexts' (did_i, local_dep, has_local, local_is_ston_only, has_b250) returns the

@@ -791,14 +791,14 @@ def fastq_zip(E, oracle, n_reads, n_calls=2):
         r1 = fastq_text(nr, seed=100 + call, dirty_seq=(call == 1))
         r2 = fastq_text(nr, seed=100 + call, dirty_seq=(call == 1), mate=2, qual_seed=300 + call)
         # two VBlocks per mate (the second shorter), R2's name their R1 counterparts
-        recs1, recs2 = r1.split(b"\n@"), r2.split(b"\n@")
         cut = (2 * nr) // 3
 
-        def parts(recs):
-            a = b"\n@".join(recs[:cut]) + b"\n"
-            return a, b"@" + b"\n@".join(recs[cut:])
-        a1, b1 = parts(recs1)
-        a2, b2 = parts(recs2)
+        def parts(t):                     # (a quality line may start with '@': cut by counting lines)
+            nl = np.flatnonzero(np.frombuffer(t, dtype=np.uint8) == 10)
+            at = int(nl[4 * cut - 1]) + 1
+            return t[:at], t[at:]
+        a1, b1 = parts(r1)
+        a2, b2 = parts(r2)
         text = a1 + b1 + a2 + b2
         offs = [0, len(a1), len(a1) + len(b1), len(a1) + len(b1) + len(a2)]
         lens = [len(a1), len(b1), len(a2), len(b2)]

@@ -76,3 +76,90 @@ def test_gather_to_writer_rank_gloo_world2():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+# ---- real VBlocks under a process group: the file of test_emul_fastq_zip dealt out over 2 ranks -----------------------------
+def _pair_file(n_reads, n_pairs):
+    """-> (text, [(text_off, text_len, vblock_i, r1 index)]) of a paired FASTQ in the reference's VBlock order: R1's VBlocks
+    1..n_pairs, then R2's n_pairs+1..2 n_pairs, R2 VBlock k pairing R1 VBlock k"""
+    import numpy as np
+    import parity
+    r1 = parity.fastq_text(n_reads, seed=500, mate=1)
+    r2 = parity.fastq_text(n_reads, seed=500, mate=2, qual_seed=900)
+    vbs, text = [], r1 + r2
+    for m, t in enumerate((r1, r2)):
+        nl = np.flatnonzero(np.frombuffer(t, dtype=np.uint8) == 10)
+        cuts = [0] + [int(nl[4 * (n_reads * k // n_pairs) - 1]) + 1 for k in range(1, n_pairs)] + [len(t)]
+        for k in range(n_pairs):
+            vbs.append((m * len(r1) + cuts[k], cuts[k + 1] - cuts[k], m * n_pairs + k + 1, k if m else -1))
+    return text, vbs
+
+
+def _zip_worker(rank, world, port, n_reads, n_pairs, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), here, os.path.join(here, "emul")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hostmem import HostMem
+    from genozip_amd.codec import Engine
+    from genozip_amd import fastq as fq
+    from genozip_amd.shard import pairs_of_rank, zip_vblocks_sharded
+    E = Engine(lib_path=os.path.join(here, "emul", "libgenozip_amd_emul.so"), mem=HostMem())
+    text, vbs = _pair_file(n_reads, n_pairs)
+    F = E.zip_open(fq.illumina_plan(paired=True))
+    mine = pairs_of_rank(n_pairs, rank, world)
+    # this rank's VBlocks in ascending vblock_i: its R1 VBlocks, then its R2 VBlocks naming them
+    own = [vbs[k] for k in mine] + [vbs[n_pairs + k] for k in mine]
+    own = [(o, l, vi, (mine.index(r1) if r1 >= 0 else -1)) for (o, l, vi, r1) in own]
+    buf = E.mem.upload(text + b"\0" * 32)
+    tab = F.vb_table(own)
+    zip_vblocks_sharded(F, dist, buf, len(text), tab, len(own))
+    res = {r["vblock_i"]: r["z"] for r in F.results(tab)}
+    words = F.zctx_words(3)
+    allres = [None] * world
+    dist.all_gather_object(allres, (res, words))
+    if rank == 0:
+        q.put(allres)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_file_dealt_out_over_2_ranks_equals_one_rank(emul_engine):
+    """the N>1 form of the whole path (strong scaling: ONE file, its VBlock pairs dealt out): every rank segs and compresses its
+    own VBlocks through the emulated build, the dictionary merge and the codec choices are exchanged - and every VBlock's z_data
+    is byte-identical to what a single process makes of the same file"""
+    from genozip_amd import fastq as fq
+    n_reads, n_pairs = 360, 3
+    text, vbs = _pair_file(n_reads, n_pairs)
+    F = emul_engine.zip_open(fq.illumina_plan(paired=True))
+    one = {r["vblock_i"]: r["z"] for r in F.zip_vblocks(text, vbs)} if False else None
+    buf = emul_engine.mem.upload(text + b"\0" * 32)
+    tab = F.vb_table(vbs)
+    F.zip_table(buf, len(text), tab, len(vbs))
+    one = {r["vblock_i"]: r["z"] for r in F.results(tab)}
+    words_one = F.zctx_words(3)
+    F.close()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_zip_worker, args=(r, 2, port, n_reads, n_pairs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    allres = q.get(timeout=300)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = {}
+    for res, words in allres:
+        assert words == words_one                       # identical dictionaries on every rank
+        got.update(res)
+    assert sorted(got) == sorted(one) == list(range(1, 2 * n_pairs + 1))
+    for vi in one:
+        assert got[vi] == one[vi], "VBlock %d differs between the 2-rank and the 1-rank run" % vi
