@@ -1,252 +1,235 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json metric on MI355X: input MB/s of the Genozip context entropy-coding hot path
-(b250_zip_generate + zip_generate_local + codec_compress + section writer) over the synthetic FASTQ-PE-1M workload.
+"""bench.py -- BASELINE.json metric on MI355X: input MB/s of Genozip's context entropy-coding hot path, from FASTQ text
+resident in HBM to finished VBlock z_data, over the synthetic paired-end FASTQ workload (BASELINE configs[1]).
 
-    python bench.py [--gpus N --steps K --warmup W]      (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N --steps K --warmup W]      N > 1: this script re-launches itself under torch.distributed.run,
+                                                         one rank per GPU (or is launched that way by the driver)
 
-A "step" is one pass of the hot path over the whole batch of VBlocks of this rank's FASTQ pair (inputs resident in
-HBM when the timed region starts; outputs stay in HBM, N>1 additionally gathers the compressed VBlocks to rank 0 over
-RCCL). Prints ONE JSON line (rank 0). See DESIGN.md section "Measurement".
+A "step" is ONE PASS OVER THE WHOLE FILE PAIR through the library's VBlock compute driver (gz_fastq_zip_vblocks /
+its three phases): text -> lines -> reads -> line-1 items -> seg-side columns (a1-a3) -> dictionary merge on the host in C
+(a4) -> b250 generation (a5) -> local byte order (a6) -> R2 == R1 drops -> codec assignment on the first VBlock (a8) ->
+sections in the reference's order (a15) -> rANS / arithmetic coders and section framing (a9-a13) -> VB headers (a16), a
+new file (fresh dictionaries and codecs) every step. Inputs are resident in HBM when the timed region starts; outputs
+stay in HBM (N > 1: + the RCCL gather of the compressed VBlocks to the writer rank).
+
+What is NOT in the path: LZMA of the 2-bit packed SEQ - the pack itself (CODEC_ACGT's front) is in the step, the
+packed bytes are handed back for the host's LZMA. `value` therefore counts the text WITHOUT the SEQ lines (the bytes this
+path compresses to finished sections); text_mb_s (all of the text, SEQ leaving 2-bit packed) and stream_mb_s (bytes entering
+the entropy coders) are printed beside it.
+
+--scaling weak (default): every rank compresses its own file pair. --scaling strong: ONE file pair, its VBlock pairs dealt out
+over the ranks (genozip_amd/shard.py): the dictionary merge and the codec choices are exchanged, z_data is what one process
+would have written. --stream-reads R: BASELINE configs[4] at reduced scale - R read pairs per rank streamed through the same
+file in calls of --batch-pairs VBlock pairs (dictionaries carried from call to call).
+
+Prints ONE JSON line (rank 0). See DESIGN.md section "Measurement".
 """
 import argparse
-import concurrent.futures
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np   # noqa: E402
-import torch         # noqa: E402  (first: one HIP runtime per process, see genozip_amd/lib.py)
-
-from genozip_amd import workload as W                                   # noqa: E402
-from genozip_amd.codec import Engine, Section, VBlock                   # noqa: E402
-from genozip_amd.lib import (SEC_B250, SEC_LOCAL, LT_BLOB, LT_UINT16, LT_UINT32, CODEC_NAMES, CODEC_RANB)  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+METRIC = "input MB/s compressed (bit-exact .genozip) at 1/2/4/8 GPUs vs CPU ref"
 
 
-def varl_seg(nodes, ol_nodes_len):
-    """seg-time b250 (src/b250.c:112-163): little-endian VARL, tag in the last byte; nodes new to the VB are 4 bytes"""
-    nodes = np.asarray(nodes, dtype=np.int64)
-    out = bytearray()
-    for v in nodes.tolist():
-        if v >= ol_nodes_len:
-            out += int((7 << 29) | v).to_bytes(4, "little")
-        elif v <= 126:
-            out.append(v)
-        elif v <= 16508:
-            out += int((2 << 14) | (v - 127)).to_bytes(2, "little")
-        else:
-            out += int((6 << 21) | (v - 16509)).to_bytes(3, "little")
-    return bytes(out)
-
-
-class RankWorkload:
-    """the VBlocks of one FASTQ pair, resident in HBM, plus the C tables of one step"""
-
-    def __init__(self, E, n_pairs, vb_bytes, profile, seed_base, device):
-        self.E = E
-        th = W._TH(device)
-        ranges = W.vb_ranges(n_pairs, vb_bytes)
-        self.n_vb = 2 * len(ranges)
-        self.qual = []          # per mate: one tensor with all qualities, VBlocks are slices
-        self.text_bytes = 2 * n_pairs * W.RECORD_BYTES
-        self.vb_meta = []       # (mate, read0, n_reads)
-        TILE_OL = 600           # tiles >= 600 are "new to the VB": exercised node -> word conversion
-        b250_jobs, self.sections_src = [], []
-        xs, ys = [], []
-        for mate in (0, 1):
-            seed = seed_base + mate
-            q = torch.empty(n_pairs * W.READ_LEN, dtype=torch.uint8, device=device)
-            CH = 200000
-            for r0 in range(0, n_pairs, CH):
-                n = min(CH, n_pairs - r0)
-                q[r0 * W.READ_LEN:(r0 + n) * W.READ_LEN] = W.quality_rows(th, seed, r0, n, profile)
-            self.qual.append(q)
-            lane, tile, x, y = W.name_fields(seed, 0, n_pairs)
-            for (r0, n) in ranges:
-                self.vb_meta.append((mate, r0, n))
-                b250_jobs.append((varl_seg(lane[r0:r0 + n], 4), 4, []))
-                b250_jobs.append((varl_seg(tile[r0:r0 + n], TILE_OL), TILE_OL, list(range(TILE_OL, 624))))
-                xs.append(x[r0:r0 + n])
-                ys.append(y[r0:r0 + n])
-        mem = E.mem
-        # b250: seg-format inputs, node2word maps, outputs and device-resident lengths
-        self.b250_in = [mem.upload(j[0]) for j in b250_jobs]
-        self.b250_n2w = [mem.upload(np.asarray(j[2] or [0], dtype=np.int32)) for j in b250_jobs]
-        self.b250_out = [mem.alloc(len(j[0]) + 16) for j in b250_jobs]
-        self.b250_len = torch.zeros(len(b250_jobs), dtype=torch.int32, device=device)
-        from genozip_amd.lib import GzB250Job
-        self.b250_tab = (GzB250Job * len(b250_jobs))()
-        for i, j in enumerate(b250_jobs):
-            t = self.b250_tab[i]
-            t.seg, t.seg_len, t.ol_nodes_len = mem.ptr(self.b250_in[i]), len(j[0]), j[1]
-            t.node2word, t.n_new_nodes = mem.ptr(self.b250_n2w[i]), len(j[2])
-            t.out, t.out_len_dev = mem.ptr(self.b250_out[i]), self.b250_len.data_ptr() + 4 * i
-        self.b250_jobs = b250_jobs
-        # x / y locals: raw native copies + working buffers (zip_generate_local works in place)
-        self.x_raw = mem.upload(np.concatenate(xs).astype("<u2"))
-        self.y_raw = mem.upload(np.concatenate(ys).astype("<u4"))
-        self.x_work, self.y_work = torch.empty_like(self.x_raw), torch.empty_like(self.y_raw)
-        self.x_off = np.concatenate([[0], np.cumsum([2 * len(a) for a in xs])])
-        self.y_off = np.concatenate([[0], np.cumsum([4 * len(a) for a in ys])])
-        self.n_x, self.n_y = sum(len(a) for a in xs), sum(len(a) for a in ys)
-        self.codecs = None
-        self.vtab = None
-
-    def assign_codecs(self):
-        """codec_assign_best_codec on the first VBlock's streams, committed for all later VBlocks (src/codec.c:352-363)"""
-        E = self.E
-        mate, r0, n = self.vb_meta[0]
-        q = self.qual[mate][r0 * W.READ_LEN:(r0 + n) * W.READ_LEN]
-        self.step_prepare()
-        E.sync()
-        lens = self.b250_len.cpu().numpy()
-        res = {}
-        for name, ptr, ln in (("QUAL", q.data_ptr(), q.numel()), ("Q1NAME", E.mem.ptr(self.b250_out[0]), int(lens[0])),
-                              ("Q2NAME", E.mem.ptr(self.b250_out[1]), int(lens[1])),
-                              ("Q3NAME", self.x_work.data_ptr(), int(self.x_off[1])), ("Q4NAME", self.y_work.data_ptr(), int(self.y_off[1]))):
-            c = E._check(E.L.gz_codec_assign_best(E.h, ptr, ln, None), "assign_best")
-            res[name] = c or CODEC_RANB      # UNKNOWN (< 50 bytes) -> RANB fallback of the section writer
-        self.codecs = res
-        return res
-
-    def build_tables(self):
-        E = self.E
-        vbs = []
-        for v, (mate, r0, n) in enumerate(self.vb_meta):
-            q = self.qual[mate][r0 * W.READ_LEN:(r0 + n) * W.READ_LEN]
-            paired = 0x04
-            secs = [Section(q, SEC_LOCAL, self.codecs["QUAL"], b"QUAL", ltype=LT_BLOB, flags=paired, data_len=q.numel()),
-                    Section(self.x_work[int(self.x_off[v]):int(self.x_off[v + 1])], SEC_LOCAL, self.codecs["Q3NAME"], b"Q3NAME", ltype=LT_UINT16,
-                            byte30=0xff, data_len=int(self.x_off[v + 1] - self.x_off[v])),
-                    Section(self.y_work[int(self.y_off[v]):int(self.y_off[v + 1])], SEC_LOCAL, self.codecs["Q4NAME"], b"Q4NAME", ltype=LT_UINT32,
-                            byte30=0xff, data_len=int(self.y_off[v + 1] - self.y_off[v])),
-                    Section(self.b250_out[2 * v], SEC_B250, self.codecs["Q1NAME"], b"Q1NAME", byte30=4, flags=paired,
-                            data_len=len(self.b250_jobs[2 * v][0]), data_len_dev=self.b250_len[2 * v:2 * v + 1]),
-                    Section(self.b250_out[2 * v + 1], SEC_B250, self.codecs["Q2NAME"], b"Q2NAME", byte30=4, flags=paired,
-                            data_len=len(self.b250_jobs[2 * v + 1][0]), data_len_dev=self.b250_len[2 * v + 1:2 * v + 2])]
-            vbs.append(VBlock(v + 1, secs, recon_size=n * W.RECORD_BYTES, longest_line_len=W.READ_LEN + 1, longest_seq_len=W.READ_LEN))
-        self.vbs = vbs
-        self.vtab, self._keep = E.vb_table(vbs)
-        # bytes entering the path: every local as handed over by seg + every b250 in its seg-time form
-        self.stream_bytes = sum(s.data_len for vb in vbs for s in vb.sections if s.section_type == SEC_LOCAL) \
-            + sum(len(j[0]) for j in self.b250_jobs)
-
-    def step_prepare(self):
-        """b250_zip_generate for every b250 context + zip_generate_local for every integer local, whole batch at once"""
-        E = self.E
-        E._check(E.L.gz_b250_generate_batch(E.h, self.b250_tab, len(self.b250_jobs)), "b250_generate_batch")
-        self.x_work.copy_(self.x_raw, non_blocking=True)
-        self.y_work.copy_(self.y_raw, non_blocking=True)
-        torch.cuda.current_stream().synchronize()       # the copies run on torch's stream, the library on its own
-        E._check(E.L.gz_local_generate(E.h, LT_UINT16, self.x_work.data_ptr(), self.n_x, 0, None), "local_generate")
-        E._check(E.L.gz_local_generate(E.h, LT_UINT32, self.y_work.data_ptr(), self.n_y, 0, None), "local_generate")
-
-    def step(self):
-        self.step_prepare()
-        self.E.vb_compress_table(self.vtab, len(self.vbs))
-        self.E.sync()
-
-
-def cpu_baseline(rank_wl, z_list, n_threads):
-    """the reference's own rANS/arith code (oracle/_ref: src/htscodecs compiled in place) - or, where that was not
-    built, this repo's C restatement - over the SAME section payloads on the host cores; also the bit-exactness check"""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import pyoracle
-    kind = "reference" if pyoracle.Ref.available() else "port"
-    impl = pyoracle.Ref() if kind == "reference" else pyoracle.Oracle()
-    O = pyoracle.Oracle()
-    E = rank_wl.E
-    tasks = []
-    for vb in rank_wl.vbs:
-        for s in vb.sections:
-            n = s.data_len
-            if s.data_len_dev is not None:
-                n = int(s.data_len_dev.cpu().numpy()[0])
-            tasks.append((s.codec, E.mem.download(s.data, n)))
-    if kind == "reference":
-        impl.codec_compress_many([t[0] for t in tasks[:8]], [t[1] for t in tasks[:8]], 8)            # warm up
-        outs, dt = impl.codec_compress_many([t[0] for t in tasks], [t[1] for t in tasks], n_threads)  # C pthread pool
-    else:
-        t0 = time.time()
-        outs = O.codec_compress_many([t[0] if len(t[1]) >= 50 else 1 for t in tasks], [t[1] for t in tasks], n_threads)
-        dt = time.time() - t0
-    nbytes = sum(len(d) for _, d in tasks)
-    # bit-exactness: every section payload produced on the GPU == the CPU reference's
-    exact, k = True, 0
-    for z in z_list:
-        at = 84
-        while at < len(z):
-            clen = int.from_bytes(z[at + 12:at + 16], "big")
-            exact &= z[at + 40:at + 40 + clen] == outs[k]
-            k += 1
-            at += 40 + clen
-    exact &= k == len(outs)
-    return {"value": round(nbytes / dt / 1e6, 1), "unit": "MB/s", "cores": n_threads, "kind": kind,
-            "sample": "all %d sections of rank 0's %d VBlocks (%.0f MB), codec calls only, %d threads on %d logical CPUs" %
-                      (len(tasks), len(rank_wl.vbs), nbytes / 1e6, n_threads, os.cpu_count())}, bool(exact)
-
-
-def seg_front_probe(E, device, target_mb=1536):
-    """SURVEY 8f N1 + rows a1-a3 on FASTQ text resident in HBM - NOT part of `value` (the metric is quoted on the context
-    streams); reported beside it because these kernels, unlike the coders, are bandwidth-bound: lines -> reads -> qname
-    tokens -> per-token columns (node indices, dict, b250) + SEQ / QUAL gathered into their locals. HIP events of the
-    library; `nl_scan` is the newline count over the whole text against the HBM roof."""
-    n_reads = 20000
-    text, rec = W.fastq_text(1, 0, n_reads)
-    reps = max(1, (target_mb << 20) // len(text))
-    block = torch.from_numpy(np.frombuffer(text, dtype=np.uint8).copy()).to(device)
-    big = block.repeat(reps)
-    E.sync()
-    E.profile(True, reset=True)
-    tb, ob, lb, rb, n_lines = E.text_lines(big, cap=4 * n_reads * reps + 8, on_device=True)      # the whole text
-    bad, cols = E.fastq_records(text)                                                             # one VBlock's worth: reads,
-    (qo, ql), (so, sl), _, (uo, ul) = cols
-    nb, io, il = E.tokenize_column(block, qo, ql, b":::::: ")                                     # tokens,
-    n_vb = 64
-    E.ctx_seg_columns([(block, io[i], il[i], []) for i in range(io.shape[0])] * n_vb, keep_on_device=True)   # columns of 64 VBlocks in one call,
-    E.local_blob_columns([(block, so, sl, False), (block, uo, ul, False)] * n_vb)                 # SEQ / QUAL -> locals
-    E.profile(False)
-    pr = E.profile_results()
-    ms = {k: round(v[0], 3) for k, v in sorted(pr.items(), key=lambda kv: -kv[1][0])}
-    nl = pr.get("k_nl_count", (0, 0))[0]
-    gbs = big.numel() / (nl / 1e3) / 1e9 if nl else None
-    assert n_lines == 4 * n_reads * reps and bad is None and nb == 0
-    return {"text_mb": round(big.numel() / 1e6, 1), "columns": io.shape[0] * n_vb, "snips_per_column": n_reads,
-            "kernels_ms": ms, "nl_scan": {"bound": "hbm", "achieved": round(gbs, 1) if gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": round(gbs / HBM_PEAK_GBS, 4) if gbs else None}}
-
-
-def per_launch(per_step, launches_per_step):
-    return None if per_step is None else int(per_step / launches_per_step)
-
-
-def pmc_traffic(kernel, a):
-    """HBM bytes per STEP of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/round1_pmc.json, made by tools/summarize_prof.py); null for non-default workloads"""
-    p = os.path.join(ROOT, "profiles", "round1_pmc.json")
-    if not os.path.exists(p) or a.pairs != 1000000 or a.vb_mb != 4 or a.qual != "div":
-        return None
-    k = json.load(open(p))["kernels"].get(kernel)
-    return k.get("traffic_bytes_per_step", k["traffic_bytes"]) if k else None
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=1000000, help="read pairs per rank (BASELINE configs[1]: 1 M)")
-    ap.add_argument("--vb-mb", type=int, default=4, help="VBlock size in MiB (reference: --vblock; its small-file rule floors at 4)")
+    ap.add_argument("--pairs", type=int, default=1000000, help="read pairs of the file (BASELINE configs[1]: 1 M)")
+    ap.add_argument("--vb-mb", type=int, default=16, help="VBlock size in MiB (the reference's --vblock; its own rule gives ~14.7 MB for this file: "
+                    "src/segconf.c:186-203 with est_max_threads capped at 30 for plain text, SURVEY 8: 16 MiB)")
     ap.add_argument("--qual", default="div", choices=("div", "bin"))
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    ap.add_argument("--stream-reads", type=int, default=0, help="stream this many read pairs per rank through one file (configs[4] at reduced scale)")
+    ap.add_argument("--batch-pairs", type=int, default=64, help="VBlock pairs per call in --stream-reads mode")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-seg-front", action="store_true", help="skip the (untimed) probe of the seg-side kernels")
-    ap.add_argument("--pin-codecs", action="store_true", help="skip codec_assign_best and use the codecs it picks for this workload (profiling runs: every launch of a kernel is then a timed-region launch)")
-    a = ap.parse_args()
+    ap.add_argument("--pin-codecs", action="store_true", help="hard-code the codecs codec_assign_best_codec picks for this workload (profiling runs: no trial compressions in the step)")
+    return ap.parse_args()
+
+
+def relaunch_under_torchrun(a):
+    """`python bench.py --gpus N` on its own: start N ranks (one per GPU) with torch.distributed.run"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def walk_sections(z):
+    """[(section_type, codec, dict_id, uncompressed_len, payload)] of one VBlock's z_data (SectionHeaderCtx, sections.h:146-167,419-435)"""
+    out, at = [], 84
+    while at < len(z):
+        clen = int.from_bytes(z[at + 12:at + 16], "big")
+        out.append((z[at + 24], z[at + 25], bytes(z[at + 32:at + 40]), int.from_bytes(z[at + 16:at + 20], "big"), z[at + 40:at + 40 + clen]))
+        at += 40 + clen
+    return out
+
+
+class Workload:
+    """this rank's share of the file pair: the text of its VBlocks in HBM and the VBlock table of one call"""
+
+    def __init__(self, E, a, rank, world, device):
+        import torch
+        from genozip_amd import workload as W
+        from genozip_amd import fastq as fq
+        from genozip_amd.shard import pairs_of_rank
+        self.E, self.a, self.W = E, a, W
+        strong = a.scaling == "strong" and world > 1
+        seed = 1 if strong else 1 + 2 * rank                     # strong: the one file; weak: a file pair of its own per rank
+        n_reads = a.stream_reads or a.pairs
+        ranges = W.vb_ranges(n_reads, a.vb_mb << 20)
+        if a.stream_reads:
+            ranges = ranges[:a.batch_pairs]                       # one call's worth of text, streamed over and over with new vblock_i
+        self.n_pairs_file = len(W.vb_ranges(n_reads, a.vb_mb << 20))
+        mine = pairs_of_rank(len(ranges), rank, world) if strong else list(range(len(ranges)))
+        self.mine, self.ranges = mine, ranges
+        th = W._TH(device)
+        n_own = sum(ranges[k][1] for k in mine)
+        self.n_reads_own = 2 * n_own
+        self.text_len = 2 * n_own * W.RECORD_BYTES
+        assert self.text_len < (1 << 32) - 64, "one call takes < 4 GB of text: use --stream-reads / fewer pairs per rank"
+        self.text = torch.empty(self.text_len + 64, dtype=torch.uint8, device=device)
+        at, self.vb = 0, []
+        for mate in (1, 2):
+            for i, k in enumerate(mine):
+                r0, n = ranges[k]
+                CH = 100000
+                for c0 in range(0, n, CH):
+                    m = min(CH, n - c0)
+                    self.text[at + c0 * W.RECORD_BYTES: at + (c0 + m) * W.RECORD_BYTES] = W.fastq_text(seed, r0 + c0, m, mate=mate, profile=a.qual, xp=th)
+                vblock_i = (k + 1) if mate == 1 else (self.n_pairs_file + k + 1)
+                self.vb.append((at, n * W.RECORD_BYTES, vblock_i, -1 if mate == 1 else i))
+                at += n * W.RECORD_BYTES
+        torch.cuda.synchronize()
+        PIN = {"div": {"QUAL": 16, "Q1NAME": (8, 0), "Q2NAME": (0, 16), "Q3NAME": (17, 0), "Q4NAME": (17, 0)},
+               "bin": {"QUAL": 18, "Q1NAME": (8, 0), "Q2NAME": (0, 16), "Q3NAME": (17, 0), "Q4NAME": (17, 0)}}
+        self.plan = fq.illumina_plan(paired=True)
+        if a.pin_codecs:
+            for c in self.plan["ctxs"]:
+                p = PIN[a.qual].get(c["tag"])
+                if isinstance(p, int):
+                    c["lcodec"] = p
+                elif p:
+                    c["lcodec"], c["bcodec"] = p
+        self.F = E.zip_open(self.plan)
+        self.tab = self.F.vb_table(self.vb)
+        self.zbuf = None
+        self.offs = None
+        self.calls_per_step = 1 if not a.stream_reads else max(1, -(-self.n_pairs_file // len(ranges)))
+
+    def step(self, dist):
+        from genozip_amd.shard import zip_vblocks_sharded
+        F, n = self.F, len(self.vb)
+        F.reset()
+        for call in range(self.calls_per_step):
+            if call:
+                for t in self.tab:                                 # the next stretch of the stream: same text, later VBlocks
+                    t.vblock_i += 2 * self.n_pairs_file
+            zip_vblocks_sharded(F, dist if self.a.scaling == "strong" else None, self.text, self.text_len, self.tab, n)
+        if self.calls_per_step > 1:
+            for t, v in zip(self.tab, self.vb):
+                t.vblock_i = v[2]
+        total = sum(t.z_len for t in self.tab)
+        if self.zbuf is None or self.zbuf.numel() < total + 64:
+            import torch
+            self.zbuf = torch.empty(int(total * 1.05) + 4096, dtype=torch.uint8, device=self.text.device)
+        self.offs = F.collect(self.tab, n, self.zbuf, self.zbuf.numel())
+        return self.offs[-1]
+
+
+def cpu_leg(wl, z_all, n_threads):
+    """the reference's own rANS / arith code (oracle/_ref: src/htscodecs compiled in place) - or, where that was not built,
+    this repo's C restatement - over the SAME section payloads on the host cores: (a) decodes every section the GPU wrote with
+    the reference's decoder, (b) re-encodes with the reference's encoder on a C pthread pool (timed) and compares with the
+    GPU's payload byte for byte, (c) checks the decoded QUAL against the text's quality lines"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    kind = "reference" if pyoracle.Ref.available() else "port"
+    R = pyoracle.Ref() if kind == "reference" else pyoracle.Oracle()
+    O = pyoracle.Oracle()
+    tasks, payloads, task_vb, qual_ok = [], [], [], True
+    text = wl.text[:wl.text_len].cpu().numpy()
+    RB, L = wl.W.RECORD_BYTES, wl.W.READ_LEN
+    qual_id = next(c["dict_id"] for c in wl.plan["ctxs"] if c["tag"] == "QUAL")
+    for v, ((off, ln, vi, r1), z) in enumerate(zip(wl.vb, z_all)):
+        for st, codec, did, ulen, pay in walk_sections(z):
+            data = bytes(pay) if codec == 1 else (R.codec_uncompress(codec, pay, ulen) if kind == "port" else R.hts_uncompress("rans" if codec < 16 else "arith", pay, ulen))
+            if did == qual_id:
+                want = text[off:off + ln].reshape(-1, RB)[:, RB - L - 1:RB - 1]
+                qual_ok &= data == want.tobytes()
+            if codec != 1:
+                tasks.append((codec, data)); payloads.append(bytes(pay)); task_vb.append(v)
+    if not tasks:
+        return None, False
+    codecs, datas = [t[0] for t in tasks], [t[1] for t in tasks]
+    nbytes = sum(len(d) for d in datas)
+
+    def pool(nt, idx=None):
+        cs = codecs if idx is None else [codecs[i] for i in idx]
+        ds = datas if idx is None else [datas[i] for i in idx]
+        if kind == "reference":
+            outs, dt = R.codec_compress_many(cs, ds, nt)
+        else:
+            t0 = time.time(); outs = O.codec_compress_many(cs, ds, nt); dt = time.time() - t0
+        return outs, dt, sum(len(d) for d in ds)
+    pool(8, list(range(min(8, len(tasks)))))                                    # warm up
+    outs, dt_all, _ = pool(n_threads)
+    exact = all(o == p for o, p in zip(outs, payloads)) and qual_ok
+    # steady state: as many threads as keep every one of them busy with >= 4 of the long streams
+    long_ix = [i for i, d in enumerate(datas) if len(d) >= max(len(x) for x in datas) // 2]
+    nt_ss = max(1, min(n_threads, len(long_ix) // 4))
+    _, dt_ss, nb_ss = pool(nt_ss)
+    per_thread = nb_ss / dt_ss / nt_ss
+    # one thread (BASELINE configs[0]) on a bounded sample: the sections of the first VBlock pair
+    first = [i for i, v in enumerate(task_vb) if v in (0, len(wl.vb) // 2)]
+    _, dt_1, nb_1 = pool(1, first)
+    scale = wl.value_bytes / nbytes                                             # same unit as `value`: text without SEQ per second
+    return {"value": round(nbytes / dt_all / 1e6 * scale, 1), "unit": "MB/s", "cores": n_threads, "kind": kind,
+            "sample": "codec calls only (no seg / merge / generate on the CPU side): all %d coded sections of rank 0's %d VBlocks (%.0f MB of streams), %d threads on %d logical CPUs; "
+                      "in the unit of `value` (text without SEQ lines: x %.3f)" % (len(tasks), len(wl.vb), nbytes / 1e6, n_threads, os.cpu_count(), scale),
+            "stream_mb_s": round(nbytes / dt_all / 1e6, 1),
+            "steady_state": {"threads": nt_ss, "stream_mb_s_per_thread": round(per_thread / 1e6, 1),
+                             "stream_mb_s_all_cores_est": round(per_thread * n_threads / 1e6, 1),
+                             "note": "every thread busy with >= 4 long streams; x threads = what a file with tasks >> threads would reach"},
+            "one_thread": {"stream_mb_s": round(nb_1 / dt_1 / 1e6, 1), "sample": "sections of the first VBlock pair (%.1f MB)" % (nb_1 / 1e6)}}, bool(exact)
+
+
+def pmc_traffic(kernel, a):
+    """HBM bytes per STEP of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/round2_pmc.json, made by tools/summarize_prof.py); null for other workloads"""
+    p = os.path.join(ROOT, "profiles", "round2_pmc.json")
+    if not os.path.exists(p):
+        return None
+    d = json.load(open(p))
+    if d.get("workload") != {"pairs": a.pairs, "vb_mb": a.vb_mb, "qual": a.qual}:
+        return None
+    k = d["kernels"].get(kernel)
+    return k.get("traffic_bytes_per_step") if k else None
+
+
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(a)
+    import numpy as np   # noqa: F401
+    import torch
+    from genozip_amd.codec import Engine
+    from genozip_amd.lib import CODEC_NAMES
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -259,16 +242,11 @@ def main():
     device = torch.device("cuda", local_rank)
 
     E = Engine(device=local_rank)
-    wl = RankWorkload(E, a.pairs, a.vb_mb << 20, a.qual, seed_base=1 + 2 * rank, device=device)
-    PINNED = {"div": {"QUAL": 16, "Q1NAME": 8, "Q2NAME": 16, "Q3NAME": 17, "Q4NAME": 17},
-              "bin": {"QUAL": 18, "Q1NAME": 8, "Q2NAME": 16, "Q3NAME": 17, "Q4NAME": 17}}
-    if a.pin_codecs:
-        wl.codecs = codecs = dict(PINNED[a.qual])
-        wl.step_prepare()
-        E.sync()
-    else:
-        codecs = wl.assign_codecs()
-    wl.build_tables()
+    wl = Workload(E, a, rank, world, device)
+    RB, L = wl.W.RECORD_BYTES, wl.W.READ_LEN
+    per_call_text = wl.text_len
+    wl.text_bytes = per_call_text * wl.calls_per_step
+    wl.value_bytes = wl.text_bytes - wl.n_reads_own * wl.calls_per_step * (L + 1)          # the text without its SEQ lines
 
     pending = [None]
 
@@ -277,15 +255,14 @@ def main():
             pending[0].wait()
             pending[0] = None
 
-    def gather_to_rank0():
-        # the only exchange step of the path: compressed VBlocks go to the writer rank. The payload is
-        # packed into a staging buffer and the gather only STARTED: the transfer over xGMI runs beside the next step's
-        # kernels; every gather is complete before the timed region ends (gather_wait below).
+    def gather_to_rank0(total):
+        # the final exchange of the path: compressed VBlocks go to the writer rank. The gather is only STARTED:
+        # the transfer over xGMI runs beside the next step's kernels; every gather is complete before the timed region ends
         if world == 1:
             return
         from genozip_amd.shard import gather_blobs
         gather_wait()
-        blobs = [vb.z[:int(wl.vtab[i].z_len)] for i, vb in enumerate(wl.vbs)]
+        blobs = [wl.zbuf[:total]]
         if os.environ.get("GZ_SYNC_GATHER"):
             gather_blobs(dist, blobs, rank, world, device)
         else:
@@ -297,65 +274,76 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        wl.step()
-        gather_to_rank0()
+        gather_to_rank0(wl.step(dist))
     gather_wait()
     E.profile(True, reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        wl.step()
-        gather_to_rank0()
+        gather_to_rank0(wl.step(dist))
     gather_wait()
     barrier()
     dt = time.perf_counter() - t0
     E.profile(False)
+
+    # per-rank byte counts -> whole-job sums
+    z_total = wl.offs[-1]
+    zhost = wl.zbuf[:z_total].cpu().numpy().tobytes()
+    z_all = [zhost[wl.offs[i]:wl.offs[i + 1]] for i in range(len(wl.vb))]
+    stream_bytes = sum(s[3] for z in z_all for s in walk_sections(z)) * wl.calls_per_step
+    sums = torch.tensor([dt, wl.text_bytes, wl.value_bytes, stream_bytes, z_total * wl.calls_per_step], dtype=torch.float64, device=device)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+        mx = sums[:1].clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        sums[0] = mx[0]
+    dt, text_b, value_b, stream_b, z_b = [float(x) for x in sums.cpu()]
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
     ms_per_step = dt / a.steps * 1e3
-    stream_mb = wl.stream_bytes / 1e6
-    value = world * stream_mb / (ms_per_step / 1e3)
-    z_list = [E.mem.download(vb.z, int(wl.vtab[i].z_len)) for i, vb in enumerate(wl.vbs)]
-    z_bytes = sum(len(z) for z in z_list)
+    value = value_b / 1e6 / (ms_per_step / 1e3)
 
-    # ---- roofline of the dominant kernel, from HIP events on the library's stream
+    # ---- roofline of the dominant kernel, from HIP events on the library's streams (gz_profile)
     prof = E.profile_results()
     dom = max(prof, key=lambda k: prof[k][0])
     dom_ms, dom_launches = prof[dom]
     per_step_launches = dom_launches / a.steps
     avg_launch_ms = dom_ms / dom_launches
-    alg_bytes_per_step = wl.stream_bytes + z_bytes - 84 * wl.n_vb       # N_in + N_out of every stream
+    alg_bytes_per_step = (stream_bytes + z_total * wl.calls_per_step)             # rank 0: N_in + N_out of every stream
     alg_per_launch = alg_bytes_per_step / per_step_launches
-    achieved = alg_per_launch / (avg_launch_ms / 1e3) / 1e9
+    achieved = alg_per_launch / (max(avg_launch_ms, 1e-6) / 1e3) / 1e9
+    tr = pmc_traffic(dom, a)
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": per_launch(pmc_traffic(dom, a), per_step_launches),
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None if tr is None else int(tr / per_step_launches),
                 "avg_launch_ms": round(avg_launch_ms, 4), "launches_per_step": per_step_launches,
                 "alg_bytes_per_launch": int(alg_per_launch),
-                "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}
+                "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:24]}}
 
-    out = {"metric": "input MB/s compressed (bit-exact .genozip) at 1/2/4/8 GPUs vs CPU ref", "value": round(value, 1), "unit": "MB/s",
-           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-           "config": {"workload": "FASTQ-PE-1M per GPU (2 x %d reads x 150 bp): context streams of %d VBlocks of %d MiB "
-                                  "(QUAL local + 2 QNAME-token b250 + 2 QNAME-token int locals) through b250_generate / "
-                                  "local_generate / codec_compress / section writer; MB counted = bytes entering the path "
-                                  "(%.1f MB per GPU; the FASTQ text they come from is %.0f MB); SEQ (ACGT pack + host LZMA) and the "
-                                  "seg-side kernels (measured apart: seg_front) are outside the timed region" % (a.pairs, wl.n_vb, a.vb_mb, stream_mb, wl.text_bytes / 1e6),
-                      "qual_profile": a.qual, "vb_mib": a.vb_mb,
-                      "codecs": {k: CODEC_NAMES[v] for k, v in codecs.items()}, "compressed_mb": round(z_bytes / 1e6, 2),
-                      "parallelism": "vblocks sharded over %d GPU(s), no data-path collective; RCCL gather of z_data" % world},
+    codecs = {}
+    for z in z_all[:1] + z_all[len(z_all) // 2:len(z_all) // 2 + 1]:
+        for st, codec, did, ulen, pay in walk_sections(z):
+            tag = next((c["tag"] for c in wl.plan["ctxs"] if c["dict_id"] == did), did.hex())
+            codecs.setdefault(("b250:" if st == 11 else "local:") + tag, CODEC_NAMES.get(codec, str(codec)))
+    mode = ("stream of %d read pairs per GPU in calls of %d VBlock pairs" % (a.stream_reads, len(wl.ranges))) if a.stream_reads else \
+           ("FASTQ-PE-1M: ONE file pair (2 x %d reads x 150 bp), its %d VBlock pairs dealt out over the GPUs" % (a.pairs, wl.n_pairs_file)) if (a.scaling == "strong" and world > 1) else \
+           ("FASTQ-PE-1M per GPU (2 x %d reads x 150 bp), %d VBlock pairs" % (a.pairs, wl.n_pairs_file))
+    out = {"metric": METRIC, "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": a.scaling if world > 1 else "weak", "vs_baseline": None,
+           "dtype": "u8", "data": "synthetic",
+           "config": {"workload": mode + ", VBlocks of %d MiB; the WHOLE path per step from FASTQ text in HBM: lines / reads / line-1 items -> seg columns (a1-a3) -> "
+                                   "host dictionary merge in C (a4) -> b250 / local generation (a5-a7) -> codec assignment (a8) -> sections in DEP / did_i order (a15) -> "
+                                   "rANS / arith + framing (a9-a13, a16); a new file every step. MB counted in `value` = text WITHOUT the SEQ lines "
+                                   "(SEQ is 2-bit packed in the step and handed to the host's LZMA, which is outside the path, SURVEY F8)" % a.vb_mb,
+                      "qual_profile": a.qual, "vb_mib": a.vb_mb, "codecs": codecs,
+                      "text_mb_per_step": round(text_b / 1e6, 1), "stream_mb_per_step": round(stream_b / 1e6, 1), "compressed_mb_per_step": round(z_b / 1e6, 2),
+                      "parallelism": "vblocks sharded over %d GPU(s), no data-path collective; host exchange of new dictionary words (strong scaling only); RCCL gather of z_data" % world},
+           "text_mb_s": round(text_b / 1e6 / (ms_per_step / 1e3), 1), "stream_mb_s": round(stream_b / 1e6 / (ms_per_step / 1e3), 1),
            "roofline": roofline}
-    if world == 1 and not a.no_seg_front:
-        out["seg_front"] = seg_front_probe(E, device)
     if not a.no_cpu and world == 1:                # (the CPU pool is timed on rank 0 of the 1-GPU run only)
-        cb, exact = cpu_baseline(wl, z_list, min(os.cpu_count() or 1, 256))
+        cb, exact = cpu_leg(wl, z_all, min(os.cpu_count() or 1, 256))
         out["cpu_baseline"] = cb
         out["bit_exact"] = exact
     print(json.dumps(out))

@@ -134,6 +134,17 @@ class ZipFile:
         if rc != GZ_OK:
             raise GenozipAMDError("gz_fastq_zip_vblocks failed (%d): %s" % (rc, self.E.L.gz_last_error(self.E.h).decode()))
 
+    def reset(self):
+        self.E._check(self.E.L.gz_zip_reset(self.f), "gz_zip_reset")
+
+    def collect(self, tab, n, dst_buf, cap):
+        """the last call's z_data, VBlock after VBlock, into dst_buf (device) -> offsets (n + 1)"""
+        offs = (C.c_uint64 * (n + 1))()
+        rc = self.E.L.gz_fastq_zip_collect(self.f, tab, n, self.E.mem.ptr(dst_buf), cap, offs)
+        if rc != GZ_OK:
+            raise GenozipAMDError("gz_fastq_zip_collect failed (%d)" % rc)
+        return list(offs)
+
     # the three phases (a file dealt out over several processes; see genozip_amd/shard.py)
     def seg(self, text_buf, text_len, tab, n):
         """-> this process' merge blob (bytes)"""

@@ -141,6 +141,42 @@ extern "C" void gz_zip_close (GzZipFile *f)
     delete f;
 }
 
+// a new file with the same plan: fresh dictionaries and codecs, the device workspace is kept
+extern "C" int gz_zip_reset (GzZipFile *f)
+{
+    if (!f) return GZ_ERR_ARG;
+    int rc = gz_sync (f->h);
+    if (rc < 0) return rc;
+    for (size_t i = 0; i < f->zctx.size (); i++) {
+        gz_zctx_destroy (f->zctx[i]);
+        f->zctx[i] = gz_zctx_create (f->plan.estimated_entries);
+        if (f->ctxs[i].lcodec) gz_zctx_commit_codec (f->zctx[i], 1, f->ctxs[i].lcodec);
+        if (f->ctxs[i].bcodec) gz_zctx_commit_codec (f->zctx[i], 0, f->ctxs[i].bcodec);
+    }
+    f->last_vblock_i = 0;
+    f->call = ZipCall ();
+    return GZ_OK;
+}
+
+// the z_data of the VBlocks of the last call, one after the other, into a buffer of the caller (device): what goes to the
+// writer (zfile_output_processed_vb_ext, src/zfile.c:1160) - or into the gather to the writer rank. offsets_host: n + 1 entries
+extern "C" int gz_fastq_zip_collect (GzZipFile *f, const GzFastqVB *vbs, int n_vbs, uint8_t *dst, uint64_t cap, uint64_t *offsets_host)
+{
+    if (!f || n_vbs < 0 || (n_vbs && (!vbs || !dst)) || !offsets_host) return GZ_ERR_ARG;
+    GzHandle *h = f->h;
+    HIPCHK (h, hipSetDevice (h->device));
+    uint64_t at = 0;
+    for (int v = 0; v < n_vbs; v++) {
+        offsets_host[v] = at;
+        if (at + vbs[v].z_len > cap) return GZ_TOO_SMALL;
+        if (vbs[v].z_len) HIPCHK (h, hipMemcpyAsync (dst + at, vbs[v].z_data, vbs[v].z_len, hipMemcpyDeviceToDevice, h->stream));
+        at += vbs[v].z_len;
+    }
+    offsets_host[n_vbs] = at;
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    return GZ_OK;
+}
+
 extern "C" GzZctx *gz_zip_zctx (GzZipFile *f, uint32_t i) { return f && i < f->zctx.size () ? f->zctx[i] : NULL; }
 
 // ---- the batched forms --------------------------------------------------------------------------------------------------

@@ -130,6 +130,7 @@ ABI_SYMBOLS = (
     "gz_local_generate_partial", "gz_local_partial_to_native",
     "gz_zctx_create", "gz_zctx_destroy", "gz_hash_next_size_up", "gz_ctx_merge", "gz_zctx_view", "gz_zctx_commit_codec",
     "gz_zip_open", "gz_zip_close", "gz_fastq_zip_vblocks", "gz_fastq_zip_seg", "gz_fastq_zip_merge", "gz_fastq_zip_finish", "gz_zip_zctx", "gz_section_order",
+    "gz_zip_reset", "gz_fastq_zip_collect",
     "gz_tokenize_column_n", "gz_int_columns", "gz_local_generate_batch", "gz_acgt_pack_batch",
 )
 
@@ -211,6 +212,8 @@ def load(path=None):
     L.gz_fastq_zip_seg.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(GzFastqVB), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.gz_fastq_zip_merge.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.gz_fastq_zip_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int]
+    L.gz_zip_reset.argtypes = [C.c_void_p]
+    L.gz_fastq_zip_collect.argtypes = [C.c_void_p, C.POINTER(GzFastqVB), C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.gz_zip_zctx.restype = C.c_void_p
     L.gz_zip_zctx.argtypes = [C.c_void_p, C.c_uint32]
     L.gz_section_order.restype = C.c_uint32

@@ -17,7 +17,7 @@ numpy (host; CPU baseline, tests) and torch (device; the full batch is generated
 import numpy as np
 
 READ_LEN = 150
-RECORD_BYTES = 62 + 1 + READ_LEN + 1 + 1 + 1 + READ_LEN + 1     # "@name\nSEQ\n+\nQUAL\n" of the synthetic Illumina read
+RECORD_BYTES = 63 + 1 + READ_LEN + 1 + 1 + 1 + READ_LEN + 1     # "@name\nSEQ\n+\nQUAL\n" of the synthetic Illumina read
 _C1, _C2, _C3 = 0x9E3779B97F4A7C15, 0xBF58476D1CE4E5B9, 0x94D049BB133111EB
 
 
@@ -128,17 +128,21 @@ def quality_rows(xp, seed, read0, n_reads, profile="div"):
     return xp.to_u8(xp.clip(q, 2, 41) + 33)
 
 
-def name_fields(seed, read0, n_reads):
-    """host side (numpy): lane / tile node indices and x / y coordinates of reads [read0, read0+n_reads).
-    Reads are emitted tile by tile (~4000 reads per tile), x random, y increasing inside a tile."""
-    xp = _NP
+def name_fields(seed, read0, n_reads, xp=None):
+    """lane / tile node indices and x / y coordinates of reads [read0, read0+n_reads) (numpy on the host by default, or
+    the torch shim on the device). Reads are emitted tile by tile (~4000 reads per tile), x random, y increasing inside
+    a tile. Both mates of a pair share the names: `seed` is the pair's."""
+    host = xp is None
+    xp = xp or _NP
     idx = xp.arange(read0, read0 + n_reads)
     tile_no = idx // 4000
     lane = (tile_no // 156) % 4                     # dictionary of 4 lanes
     tile = tile_no % 624                            # dictionary of 624 tiles
     h = _hash(xp, seed + 0x7A11, idx)
-    x = (1000 + h % 32000).astype(np.uint16)
-    y = (1000 + (idx % 4000) * 9 + xp.lsr(h, 16) % 9).astype(np.uint32)
+    x = 1000 + h % 32000
+    y = 1000 + (idx % 4000) * 9 + xp.lsr(h, 16) % 9
+    if host:
+        x, y = x.astype(np.uint16), y.astype(np.uint32)
     return lane, tile, x, y
 
 
@@ -152,35 +156,56 @@ def vb_ranges(n_reads, vb_bytes):
     return [(r0, min(per, n_reads - r0)) for r0 in range(0, n_reads, per)]
 
 
-def fastq_text(seed, read0, n_reads):
-    """the FASTQ text of reads [read0, read0 + n_reads) of the file with this seed (numpy, host): the lines the
-    segmenter's front end splits - `@A00123:45:HXXXXXXXX:<lane>:<tile>:<x>:<y> 1:N:0:ACGTACGT+TGCATGCA`, SEQ, `+`, QUAL.
-    Fixed-width numeric fields (no leading zeros) keep every record the same length, so it is assembled as a matrix.
-    Returns (text, bytes per record)."""
-    lane, tile, x, y = name_fields(seed, read0, n_reads)
-    head, tail = b"@A00123:45:HXXXXXXXX:", b" 1:N:0:ACGTACGT+TGCATGCA\n"
-    rec = np.zeros((n_reads, RECORD_BYTES + 16), dtype=np.uint8)
+_HEAD, _TAIL = b"@A00123:45:HXXXXXXXX:", b":N:0:ACGTACGT+TGCATGCA\n"
+
+
+def fastq_text(seed, read0, n_reads, mate=1, profile="div", xp=None, n_rate=0):
+    """the FASTQ text of reads [read0, read0 + n_reads) of mate `mate` (1 / 2) of the pair with this seed - the lines the
+    segmenter's front end splits: `@A00123:45:HXXXXXXXX:<lane>:<tile>:<x>:<y> <mate>:N:0:ACGTACGT+TGCATGCA`, SEQ, `+`, QUAL.
+    Fixed-width numeric fields (no leading zeros) keep every record RECORD_BYTES long, so the text is assembled as a
+    matrix - with numpy on the host (returns bytes) or, xp = _TH(device), with torch in HBM (returns a uint8 tensor):
+    identical bytes. The names are the pair's; SEQ and QUAL are the mate's own. n_rate: one base in n_rate is 'N'."""
+    host = xp is None
+    xp = xp or _NP
+    lane, tile, x, y = name_fields(seed, read0, n_reads, xp)
+    mseed = seed + 0x100000 * mate
+    if host:
+        rec = np.zeros((n_reads, RECORD_BYTES), dtype=np.uint8)
+        const = lambda b: np.frombuffer(b, dtype=np.uint8)                         # noqa: E731
+        to_u8 = lambda v: v.astype(np.uint8)                                       # noqa: E731
+        table = lambda b, i: np.frombuffer(b, dtype=np.uint8)[i.astype(np.int64)]  # noqa: E731
+    else:
+        t = xp.t
+        rec = t.zeros((n_reads, RECORD_BYTES), dtype=t.uint8, device=xp.dev)
+        const = lambda b: t.tensor(list(b), dtype=t.uint8, device=xp.dev)          # noqa: E731
+        to_u8 = lambda v: v.to(t.uint8)                                            # noqa: E731
+        table = lambda b, i: t.tensor(list(b), dtype=t.uint8, device=xp.dev)[i]    # noqa: E731
     at = 0
 
     def put(b):
         nonlocal at
-        rec[:, at:at + len(b)] = np.frombuffer(b, dtype=np.uint8)
+        rec[:, at:at + len(b)] = const(b)
         at += len(b)
 
     def digits(v, width):
         nonlocal at
-        v = v.astype(np.int64)
         for k in range(width):
-            rec[:, at + k] = 48 + (v // 10 ** (width - 1 - k)) % 10
+            rec[:, at + k] = to_u8(48 + (v // 10 ** (width - 1 - k)) % 10)
         at += width
 
-    put(head); digits(lane + 1, 1); put(b":"); digits(1101 + tile, 4); put(b":"); digits(10000 + x.astype(np.int64) % 20000, 5); put(b":")
-    digits(10000 + y.astype(np.int64) % 80000, 5); put(tail)
-    h = _hash(_NP, seed + 0x5E9, _NP.arange(read0 * READ_LEN, (read0 + n_reads) * READ_LEN))
-    rec[:, at:at + READ_LEN] = np.frombuffer(b"ACGT", dtype=np.uint8)[(h % 4).astype(np.int64)].reshape(n_reads, READ_LEN)
+    put(_HEAD); digits(lane + 1, 1); put(b":"); digits(1101 + tile, 4); put(b":"); digits(10000 + (x if not host else x.astype(np.int64)) % 20000, 5); put(b":")
+    digits(10000 + (y if not host else y.astype(np.int64)) % 80000, 5); put(b" "); digits(lane * 0 + mate, 1); put(_TAIL)
+    idx = xp.arange(read0 * READ_LEN, (read0 + n_reads) * READ_LEN)
+    h = _hash(xp, mseed + 0x5E9, idx)
+    bases = table(b"ACGT", h % 4)
+    if n_rate:
+        bases = xp.where((xp.lsr(h, 8) % n_rate) == 0, 78, bases.astype(np.int64) if host else bases.to(xp.int64))
+        bases = to_u8(bases)
+    rec[:, at:at + READ_LEN] = bases.reshape(n_reads, READ_LEN)
     at += READ_LEN
     put(b"\n+\n")
-    rec[:, at:at + READ_LEN] = quality_rows(_NP, seed, read0, n_reads).reshape(n_reads, READ_LEN)
+    rec[:, at:at + READ_LEN] = quality_rows(xp, mseed, read0, n_reads, profile).reshape(n_reads, READ_LEN)
     at += READ_LEN
     put(b"\n")
-    return rec[:, :at].tobytes(), at
+    assert at == RECORD_BYTES
+    return rec.tobytes() if host else rec.reshape(-1)

@@ -446,6 +446,11 @@ int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_len, GzFast
 int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len, GzFastqVB *vbs, int n_vbs, const void **blob_out, uint64_t *blob_len_out);
 int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const uint64_t *blob_lens, int n_blobs, const void **votes_out, uint64_t *votes_len_out);
 int gz_fastq_zip_finish (GzZipFile *f, const void *const *votes, const uint64_t *votes_lens, int n_votes);
+/* a new file with the same plan (fresh dictionaries and codecs; the device workspace is kept) */
+int gz_zip_reset (GzZipFile *f);
+/* the z_data of the last call's VBlocks one after the other into dst (device) - what is handed to the writer
+ * (zfile_output_processed_vb_ext, src/zfile.c:1160) or to the gather to the writer rank; offsets_host: n_vbs + 1 entries */
+int gz_fastq_zip_collect (GzZipFile *f, const GzFastqVB *vbs, int n_vbs, uint8_t *dst, uint64_t cap, uint64_t *offsets_host);
 /* the file-level context of plan context i (for the global area writer / inspection) */
 GzZctx *gz_zip_zctx (GzZipFile *f, uint32_t ctx_i);
 /* section order of one VBlock (a15): given n contexts' (did_i, local_dep, has_local, local_is_ston_only, has_b250) returns the
