@@ -577,7 +577,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
         if (fork) { HIPCHK (h, hipEventRecord (h->ev_fork, h->stream)); HIPCHK (h, hipStreamWaitEvent (side, h->ev_fork, 0)); }
         if (P.any_rans) {
             KLAUNCH_ON (h, side, k_hist, dim3 (nl, GZ_HIST_CHUNKS), dim3 (256), GZ_HIST_LDS, d_leaves);
-            KLAUNCH_ON (h, side, k_rans_table, dim3 (nl), dim3 (256), 16384, d_leaves, (const GzLogTable *)h->d_logs);
+            KLAUNCH_ON (h, side, k_rans_table, dim3 (nl), dim3 (256), 20480, d_leaves, (const GzLogTable *)h->d_logs);
             KLAUNCH_ON (h, side, k_rans_encode, dim3 (nl), dim3 (64), GZ_RANS_ENC_LDS, d_leaves);
         }
         if (A.np) {

@@ -524,83 +524,163 @@ __global__ void __launch_bounds__(256) k_rans_table (GzdLeaf *leaves, const GzLo
     }
 
     // ---------- order 1 ----------
+    // Everything that is elementwise or a reduction runs wave-parallel (a wave per context row, lanes over the symbols);
+    // what the reference's arithmetic makes order-dependent - the entropy sums of compute_shift, whose roundings depend
+    // on the order of accumulation, and the zero-run serialisation of a row - is done by one lane, from LDS.
     uint32_t *present = lds;            // [256] 0/1, with [0] forced
     uint32_t *T       = lds + 256;      // [256] row totals
     uint32_t *target  = lds + 512;      // [256] stored total per row (S[] of compute_shift)
     uint32_t *rowlen  = lds + 768;      // [256] serialised bytes per row, later exclusive offsets
-    uint32_t *shared  = lds + 1024;     // [0] bits  [1] tab cursor
+    uint32_t *shared  = lds + 1024;     // [0] bits  [1] tab cursor  [8..16) per-wave partial counts
+    uint32_t *cellF   = lds + 1088;     // [256] the row's counts of the present symbols (compute_shift)
+    double   *cellD   = (double *)(lds + 1088 + 256);            // [256][2] d10, d12
+    const int wave = tid >> 6, lane = tid & 63;
+    uint32_t *wrow    = lds + 1088 + 256 + 1024 + wave * 448;    // this wave's row: 256 counts + 768 serialised bytes
+    uint8_t  *wbytes  = (uint8_t *)(wrow + 256);
     uint32_t *F = L.F;
+    const uint32_t ns = L.nsym;
 
     present[tid] = (L.symrank[tid] != 0xffff) || tid == 0;
-    {   // row total: one thread per row (only rows of present symbols can be non-empty)
-        uint32_t t = 0;
-        if (present[tid]) for (int s = 0; s < 256; s++) t += F[tid * 256 + s];
-        T[tid] = t;
+    T[tid] = 0; target[tid] = 0; rowlen[tid] = 0;
+    __syncthreads ();
+    // row totals: a wave per row, coalesced (only rows of present symbols can be non-empty)
+    for (int c = wave; c < 256; c += 4) {
+        if (!present[c]) continue;
+        uint32_t t = F[c * 256 + lane] + F[c * 256 + 64 + lane] + F[c * 256 + 128 + lane] + F[c * 256 + 192 + lane];
+        for (int m = 32; m; m >>= 1) t += (uint32_t)__shfl ((int)t, lane ^ m);
+        if (!lane) T[c] = t;
     }
     __syncthreads ();
 
     // ---- compute_shift (rANS_static4x16pr.c:626-687). The entropy sums must be accumulated in the reference's
-    //      order with the reference's roundings (fused e -= f*d, see oracle/gz_oracle.c o1_choose_bits), so one
-    //      thread walks the (present context, present symbol) pairs in order; only non-zero cells exist there.
-    if (!tid) {
+    //      order with the reference's roundings (fused e -= f*d, see oracle/gz_oracle.c o1_choose_bits): per row, thread k
+    //      prepares the terms of present symbol k, then thread 0 adds them up in symbol order.
+    {
         double e10 = 0, e12 = 0;
         uint32_t widest = 0;
-        const uint32_t ns = L.nsym;
         for (int c = 0; c < 256; c++) {
-            if (!present[c]) continue;
+            if (!present[c]) continue;                                   // (uniform: present[] is shared)
             const uint32_t tc = T[c];
-            uint32_t cap = gz_pow2_ceil (tc), b10 = 0, b12 = 0, cnt = 0;
-            for (uint32_t k = 0; k < ns; k++) {
-                uint32_t f = F[c * 256 + L.symlist[k]];
-                if (!f) continue;
-                uint32_t ratio = cap / f;
-                b10 += ratio > 1024; b12 += ratio > 4096;
-            }
-            const double l10 = logs->l10[b10], l12 = logs->l12[b12];
-            for (uint32_t k = 0; k < ns; k++) {
-                uint32_t f = F[c * 256 + L.symlist[k]];
-                if (!f) continue;
-                cnt++;
+            uint32_t cap = gz_pow2_ceil (tc);
+            const uint32_t f = (uint32_t)tid < ns ? F[c * 256 + L.symlist[tid]] : 0;
+            const uint32_t ratio = f ? cap / f : 0;
+            const uint64_t m10 = __ballot (f && ratio > 1024), m12 = __ballot (f && ratio > 4096), mc = __ballot (f != 0);
+            if (!lane) { shared[8 + wave] = (uint32_t)__popcll (m10) | ((uint32_t)__popcll (m12) << 10) | ((uint32_t)__popcll (mc) << 20); }
+            __syncthreads ();
+            uint32_t b10 = 0, b12 = 0, cnt = 0;
+            for (int w = 0; w < 4; w++) { const uint32_t v = shared[8 + w]; b10 += v & 1023; b12 += (v >> 10) & 1023; cnt += v >> 20; }
+            cellF[tid] = f;
+            if (f) {
+                const double l10 = logs->l10[b10], l12 = logs->l12[b12];
                 int x10 = (int)(1024.0 * (double)f / (double)tc), x12 = (int)(4096.0 * (double)f / (double)tc);
-                double d10 = d_log_from_bits (x10 > 1 ? x10 : 1) - l10;
-                double d12 = d_log_from_bits (x12 > 1 ? x12 : 1) - l12;
-                e10 = fma (-(double)f, d10, e10) + 4.0;
-                e12 = fma (-(double)f, d12, e12) + 6.0;
+                cellD[2 * tid]     = d_log_from_bits (x10 > 1 ? x10 : 1) - l10;
+                cellD[2 * tid + 1] = d_log_from_bits (x12 > 1 ? x12 : 1) - l12;
             }
-            if (cnt < 64 && cap > 128) cap /= 2;
-            if (cap > 1024)            cap /= 2;
-            if (cap > 4096)            cap = 4096;
-            target[c] = cap;
-            if (cap > widest) widest = cap;
+            __syncthreads ();
+            if (!tid) {
+                for (uint32_t k = 0; k < ns; k++) {
+                    const uint32_t fk = cellF[k];
+                    if (!fk) continue;
+                    e10 = fma (-(double)fk, cellD[2 * k], e10) + 4.0;
+                    e12 = fma (-(double)fk, cellD[2 * k + 1], e12) + 6.0;
+                }
+                if (cnt < 64 && cap > 128) cap /= 2;
+                if (cap > 1024)            cap /= 2;
+                if (cap > 4096)            cap = 4096;
+                target[c] = cap;
+                if (cap > widest) widest = cap;
+            }
+            __syncthreads ();
         }
-        shared[0] = (e10 / e12 < 1.01 || widest <= 1024) ? 10 : 12;
+        if (!tid) shared[0] = (e10 / e12 < 1.01 || widest <= 1024) ? 10 : 12;
     }
     __syncthreads ();
     const uint32_t bits = shared[0];
 
-    // ---- per row: normalise to the stored total, serialise, scale to 1<<bits, build encoder records
-    {
-        const int c = tid;
-        uint32_t len = 0;
-        if (present[c]) {
-            uint32_t *row = F + c * 256;
-            uint32_t tot = target[c];
-            if (bits == 10 && tot > 1024) tot = 1024;
-            d_freq_scale (row, T[c], tot);
-            uint8_t *dst = L.rowbuf + c * GZ_ROW_SLOT;
-            uint32_t zeros = 0;
-            for (int s = 0; s <= 256; s++) {                       // :292-322 zero runs are "00, run-1"
-                if (s < 256 && !present[s]) continue;
-                if (s < 256 && !row[s]) { zeros++; continue; }
-                if (zeros) { dst[len++] = 0; dst[len++] = (uint8_t)(zeros - 1); zeros = 0; }
-                if (s < 256) len += gz_vi_put (dst + len, row[s]);
-            }
-            d_freq_shift_up (row, tot, 1u << bits);
-            uint32_t cum = 0;
-            GzRansSym *rs = L.syms + c * 256;
-            for (int s = 0; s < 256; s++) { rs[s] = d_rans_sym (cum, row[s], bits); cum += row[s]; }
+    // ---- per row (a wave each; lane l owns symbols 4l..4l+3): normalise to the stored total (normalise_freq :113-160),
+    //      serialise (:292-322), scale to 1 << bits, build the encoder records
+    for (int c = wave; c < 256; c += 4) {
+        if (!present[c]) continue;
+        uint32_t fr[4];
+        {
+            const uint4 v = *(const uint4 *)(F + c * 256 + 4 * lane);
+            fr[0] = v.x; fr[1] = v.y; fr[2] = v.z; fr[3] = v.w;
         }
-        rowlen[c] = len;
+        uint32_t tot = target[c];
+        if (bits == 10 && tot > 1024) tot = 1024;
+        uint32_t sum = T[c];
+        for (int pass = 0; sum; pass++) {
+            const uint64_t mult = (((uint64_t)tot) << 31) / sum + (uint32_t)((1u << 30) / sum);
+            uint32_t big = 0, big_at = 0, new_sum = 0;
+            #pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t f = fr[j];
+                if (!f) continue;
+                if (f > big) { big = f; big_at = 4 * lane + j; }
+                uint32_t g = (uint32_t)((f * mult) >> 31);
+                if (!g) g = 1;
+                fr[j] = g; new_sum += g;
+            }
+            for (int m = 32; m; m >>= 1) {
+                new_sum += (uint32_t)__shfl ((int)new_sum, lane ^ m);
+                const uint32_t ob = (uint32_t)__shfl ((int)big, lane ^ m), oa = (uint32_t)__shfl ((int)big_at, lane ^ m);
+                if (ob > big || (ob == big && oa < big_at)) { big = ob; big_at = oa; }     // the FIRST of the largest (strict > in the reference)
+            }
+            int32_t adjust = (int32_t)tot - (int32_t)new_sum;
+            const bool mine = (uint32_t)lane == big_at / 4;
+            uint32_t fb = (uint32_t)__shfl ((int)fr[big_at & 3], (int)(big_at / 4));
+            if (adjust > 0) { if (mine) fr[big_at & 3] += (uint32_t)adjust; break; }
+            if (adjust == 0) break;
+            const uint32_t need = (uint32_t)(-adjust);
+            if (fb > need && (pass == 1 || fb / 2 >= need)) { if (mine) fr[big_at & 3] = fb - need; break; }
+            if (pass == 0) { sum = new_sum; continue; }
+            // the rare last resort: take it off the other symbols one by one, in symbol order - one lane, through LDS
+            wrow[4 * lane] = fr[0]; wrow[4 * lane + 1] = fr[1]; wrow[4 * lane + 2] = fr[2]; wrow[4 * lane + 3] = fr[3];
+            gz_wave_sync ();
+            if (!lane) {
+                adjust += (int32_t)fb - 1;
+                wrow[big_at] = 1;
+                for (int s2 = 0; adjust && s2 < 256; s2++) {
+                    const uint32_t f = wrow[s2];
+                    if (f < 2) continue;
+                    const int32_t step = (f > (uint32_t)(-adjust)) ? adjust : 1 - (int32_t)f;
+                    wrow[s2] = (uint32_t)((int32_t)f + step);
+                    adjust -= step;
+                }
+            }
+            gz_wave_sync ();
+            fr[0] = wrow[4 * lane]; fr[1] = wrow[4 * lane + 1]; fr[2] = wrow[4 * lane + 2]; fr[3] = wrow[4 * lane + 3];
+            break;
+        }
+        // serialise: zero runs are "00, run-1" (:292-322); one lane walks the row in LDS
+        wrow[4 * lane] = fr[0]; wrow[4 * lane + 1] = fr[1]; wrow[4 * lane + 2] = fr[2]; wrow[4 * lane + 3] = fr[3];
+        gz_wave_sync ();
+        uint32_t len = 0;
+        if (!lane) {
+            uint32_t zeros = 0;
+            for (int s2 = 0; s2 <= 256; s2++) {
+                if (s2 < 256 && !present[s2]) continue;
+                if (s2 < 256 && !wrow[s2]) { zeros++; continue; }
+                if (zeros) { wbytes[len++] = 0; wbytes[len++] = (uint8_t)(zeros - 1); zeros = 0; }
+                if (s2 < 256) len += gz_vi_put (wbytes + len, wrow[s2]);
+            }
+            rowlen[c] = len;
+        }
+        gz_wave_sync ();
+        len = (uint32_t)__shfl ((int)len, 0);
+        for (uint32_t i = lane; i < len; i += 64) L.rowbuf[c * GZ_ROW_SLOT + i] = wbytes[i];
+        // scale up to 1 << bits (normalise_freq_shift :165-177), cumulative starts, encoder records
+        int sh = 0;
+        { uint32_t t2 = tot; while (t2 && t2 < (1u << bits)) { t2 <<= 1; sh++; } }
+        uint32_t lsum = 0;
+        #pragma unroll
+        for (int j = 0; j < 4; j++) { fr[j] <<= sh; lsum += fr[j]; }
+        uint32_t incl = lsum;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl ((int)incl, lane - d < 0 ? 0 : lane - d); if (lane >= d) incl += o; }
+        uint32_t cum = incl - lsum;
+        GzRansSym *rs = L.syms + c * 256 + 4 * lane;
+        #pragma unroll
+        for (int j = 0; j < 4; j++) { rs[j] = d_rans_sym (cum, fr[j], bits); cum += fr[j]; }
     }
     __syncthreads ();
     if (!tid) {

@@ -9,6 +9,7 @@
 #pragma once
 #include <algorithm>
 #include <map>
+#include <chrono>
 
 // ---------------------------------------------------------------------------------------------------------
 // a15: order of the sections of one VBlock (zip_compress_all_contexts_local src/zip.c:291-342 called at :566 for
@@ -315,6 +316,22 @@ static int zip_assign_best_many (GzHandle *h, GzZipFile *f, const std::vector<co
     return GZ_OK;
 }
 
+// GZ_ZIP_TIMING=1: wall-clock milliseconds between the marks of a call, to stderr (where the host side of a step goes)
+struct ZipTimer {
+    bool on; std::chrono::steady_clock::time_point t0, last; std::string line;
+    ZipTimer () { const char *e = getenv ("GZ_ZIP_TIMING"); on = e && *e && *e != '0'; t0 = last = std::chrono::steady_clock::now (); }
+    void mark (const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now ();
+        char b[96]; snprintf (b, sizeof (b), " %s %.2f", what, std::chrono::duration<double, std::milli> (now - last).count ());
+        line += b; last = now;
+    }
+    void done (const char *phase) {
+        if (!on) return;
+        fprintf (stderr, "[gz_zip %s %.2f ms]%s\n", phase, std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t0).count (), line.c_str ());
+    }
+};
+
 #define ZCHK(call) do { int rc_ = (call); if (rc_ != GZ_OK) return rc_ < 0 ? rc_ : GZ_ERR; } while (0)
 #define WS(var, type, count) type *var = (type *)ws_alloc (f, (size_t)(count) * sizeof (type)); if (!var) return GZ_ERR_HIP
 
@@ -352,6 +369,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     }
     HIPCHK (h, hipSetDevice (h->device));
     int rc;
+    ZipTimer T;
     if ((rc = gz_sync (h)) < 0) return rc;
     for (auto &b : f->ws) b.used = 0;
     f->call = ZipCall ();
@@ -387,6 +405,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         if (attempt || a.lines.n_lines > 0xfffffff0ull) { h->err = "line index does not fit"; return GZ_ERR; }
         line_cap = (uint32_t)a.lines.n_lines + 8;                          // (short lines: once more with the exact count)
     }
+    T.mark ("lines+sync");
     if (a.bad_bound) { h->err = "a VBlock does not start / end at the start of a line"; return GZ_ERR_CORRUPT; }
     const uint64_t n_lines = a.lines.n_lines;
     if (n_lines % 4) { h->err = "the text does not hold whole reads (4 lines each)"; return GZ_ERR_CORRUPT; }
@@ -513,6 +532,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
             }
         }
     }
+    T.mark ("plan");
     ZCHK (gz_int_columns (h, icol_jobs.data (), (int)icol_jobs.size ()));
     // (column tables hold at most 65 535 rows per call)
     for (size_t at = 0; at < col_jobs.size (); at += 32768) ZCHK (gz_ctx_seg_columns (h, col_jobs.data () + at, (int)std::min<size_t> (32768, col_jobs.size () - at)));
@@ -540,6 +560,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         hipLaunchKernelGGL (k_pack_sizes, dim3 (1), dim3 (1), 0, h->stream, d_pack, (uint32_t)NCJ, pack_cap_used, d_pack_total);
         hipLaunchKernelGGL (k_pack_copy, dim3 ((uint32_t)NCJ), dim3 (256), 0, h->stream, (const GzdPackJob *)d_pack, d_staging, (const uint64_t *)d_pack_total);
     }
+    T.mark ("queue");
     // ---- read back (second wait)
     K.colres.resize (NCJ + 1); K.dynres.resize (dyn_jobs.size () + 1);
     std::vector<uint64_t> icolres (2 * icol_jobs.size () + 2);
@@ -557,6 +578,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     HIPCHK (h, hipMemcpyAsync (K.vbstat.data (), d_vbstat, 2 * (size_t)NV * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK (h, hipMemcpyAsync (&a, d_a, sizeof (a), hipMemcpyDeviceToHost, h->stream));
     if ((rc = gz_sync (h)) < 0) return rc;
+    T.mark ("seg-sync");
     if (a.fq.first_bad != 0xffffffffu) {
         for (uint32_t v = 0; v < NV; v++) if (a.fq.first_bad >= r0[v] && a.fq.first_bad < r_end[v]) vbs[v].status = GZ_ERR_CORRUPT;
         h->err = "not FASTQ: a read is not '@'.. / SEQ / '+'.. / QUAL of SEQ's length (fastq.c:1008-1010,1076,1121)"; return GZ_ERR_CORRUPT;
@@ -607,6 +629,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     }
     *blob_out = K.blob.data (); *blob_len_out = K.blob.size ();
     K.phase = 1;
+    T.mark ("staging+blob"); T.done ("seg");
     return GZ_OK;
 }
 
@@ -626,6 +649,7 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
     HIPCHK (h, hipSetDevice (h->device));
     int rc;
     const uint8_t ATS = 0x20;
+    ZipTimer T;
 
     // every VBlock of every blob, in vblock_i order
     struct Ent { uint32_t vblock_i; const uint8_t *p; };
@@ -767,6 +791,7 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
     }
     if (!ents.empty ()) f->last_vblock_i = ents.back ().vblock_i;
 
+    T.mark ("merge");
     // ---- b250 generation, locals into file order, R2 == R1 drops --------------------------------------------------------------
     int32_t *d_n2w = (int32_t *)ws_alloc (f, (K.n2w_host.size () + 1) * 4);
     if (!d_n2w) return GZ_ERR_HIP;
@@ -828,6 +853,7 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
         KLAUNCH (h, k_bufs_identical, dim3 ((uint32_t)same.size ()), dim3 (256), 0, (const GzdSameJob *)ds);
     }
 
+    T.mark ("generate-queue");
     // ---- a8: contexts whose codec the file does not know yet: trial compressions on the first VBlock (of this process) that
     // has >= 50 bytes of the stream (codec.c:309-312); the lowest vblock_i of all processes' votes is committed in phase 3
     K.votes.clear ();
@@ -839,6 +865,7 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
             std::vector<uint32_t> seclen (2 * (size_t)NV * NC);
             HIPCHK (h, hipMemcpyAsync (seclen.data (), K.d_seclen, seclen.size () * 4, hipMemcpyDeviceToHost, h->stream));
             if ((rc = gz_sync (h)) < 0) return rc;
+            T.mark ("generate-sync");
             for (uint32_t c = 0; c < NC; c++) {
                 GzZctxView zv; gz_zctx_view (f->zctx[c], &zv);
                 for (uint32_t is_local = 0; is_local < 2; is_local++) {
@@ -859,6 +886,7 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
     }
     *votes_out = K.votes.data (); *votes_len_out = K.votes.size () * sizeof (ZipVote);
     K.phase = 2;
+    T.mark ("assign"); T.done ("merge");
     return GZ_OK;
 }
 
@@ -877,6 +905,7 @@ extern "C" int gz_fastq_zip_finish (GzZipFile *f, const void *const *votes, cons
     HIPCHK (h, hipSetDevice (h->device));
     const uint8_t ATS = 0x20, PAIRED = 0x04;
     int rc;
+    ZipTimer T;
     {
         std::map<std::pair<uint32_t, uint32_t>, ZipVote> win;
         for (int b = 0; b < n_votes; b++) {
@@ -936,11 +965,14 @@ extern "C" int gz_fastq_zip_finish (GzZipFile *f, const void *const *votes, cons
         B.z_cap = gz_vb_z_bound (B.sections, B.n_sections);
         if (!(B.z_data = (uint8_t *)ws_alloc (f, B.z_cap + 64))) return GZ_ERR_HIP;
     }
+    T.mark ("sections");
     ZCHK (gz_vb_compress_batch (h, V.data (), (int)NV));
+    T.mark ("compress-queue");
     std::vector<int32_t> b250st ((size_t)NV * NC, 1);
     HIPCHK (h, hipMemcpyAsync (b250st.data (), K.d_b250st, b250st.size () * 4, hipMemcpyDeviceToHost, h->stream));
     rc = gz_sync (h);
     K.phase = 0;
+    T.mark ("compress-sync"); T.done ("finish");
     if (rc < 0) return rc;
     for (uint32_t v = 0; v < NV; v++) {
         for (uint32_t c = 0; c < NC; c++) { const ZipCol &Z = COL (v, c); if (Z.has_b250 && Z.col_job >= 0 && b250st[(size_t)v * NC + c] == -5) { h->err = "b250 generation: malformed stream"; return GZ_ERR; } }
