@@ -202,6 +202,37 @@ class ZipFile:
         self.E._check(self.E.L.gz_download(self.E.h, out, ptr, n), "gz_download")
         return out.raw
 
+    def write_file(self, vb_results, num_lines, counts_ctxs=(), created=b"genozip_amd"):
+        """the VBlocks (dicts of zip_vblocks / results, in the order they are written) + the global area (N4) -> the whole file's
+        bytes: zfile_output_processed_vb for every VBlock, then zip_write_global_area"""
+        L, E = self.E.L, self.E
+        zf = L.gz_zfile_create(3, 16 << 20)                    # DT_FASTQ
+        try:
+            body = b""
+            for r, nl in zip(vb_results, num_lines):
+                E._check(L.gz_zfile_add_vblock(zf, r["z"], len(r["z"]), len(body), 0, nl), "gz_zfile_add_vblock")
+                body += r["z"]
+            n = len(self.plan["ctxs"])
+            zc = (C.c_void_p * n)(*[L.gz_zip_zctx(self.f, i) for i in range(n)])
+            ids = b"".join(c["dict_id"] for c in self.plan["ctxs"])
+            cs = bytes(int(i in counts_ctxs) for i in range(n))
+            cap = 1 << 20
+            while True:
+                out, ol = C.create_string_buffer(cap), C.c_uint64(0)
+                rc = L.gz_zfile_write_global_area(zf, E.h, zc, ids, cs, n, len(body), sum(len(r["z"]) for r in vb_results), sum(num_lines), created, out, cap, C.byref(ol))
+                if rc == GZ_TOO_SMALL:
+                    cap = ol.value + 64
+                    L.gz_zfile_destroy(zf)
+                    zf = L.gz_zfile_create(3, 16 << 20)
+                    at = 0
+                    for r, nl in zip(vb_results, num_lines):
+                        L.gz_zfile_add_vblock(zf, r["z"], len(r["z"]), at, 0, nl); at += len(r["z"])
+                    continue
+                E._check(rc, "gz_zfile_write_global_area")
+                return body + out.raw[:ol.value]
+        finally:
+            L.gz_zfile_destroy(zf)
+
     def zctx_words(self, ctx_i):
         from .lib import GzZctxView
         v = GzZctxView()

@@ -981,6 +981,19 @@ extern "C" int gz_codec_assign_best (GzHandle *h, const uint8_t *in, uint32_t in
     return best;
 }
 
+// the same for host memory (global-area sections: dictionaries, counts)
+extern "C" int gz_codec_assign_best_host (GzHandle *h, const uint8_t *in, uint32_t in_len)
+{
+    if (!h || (in_len && !in)) return GZ_ERR_ARG;
+    if (in_len < 50) return GZ_CODEC_UNKNOWN;
+    uint8_t *d = NULL;
+    HIPCHK (h, hipSetDevice (h->device));
+    HIPCHK (h, hipMalloc ((void **)&d, (size_t)in_len + 16));
+    int rc = hipMemcpy (d, in, in_len, hipMemcpyHostToDevice) == hipSuccess ? gz_codec_assign_best (h, d, in_len, NULL) : GZ_ERR_HIP;
+    (void)hipFree (d);
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // context engine pieces
 // ---------------------------------------------------------------------------------------------------------
@@ -1449,3 +1462,4 @@ extern "C" int gz_vb_uncompress (GzHandle *h, const uint8_t *z_data, uint64_t z_
 }
 
 #include "gz_zip.h"
+#include "gz_global.h"

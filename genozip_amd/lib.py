@@ -131,6 +131,7 @@ ABI_SYMBOLS = (
     "gz_zctx_create", "gz_zctx_destroy", "gz_hash_next_size_up", "gz_ctx_merge", "gz_zctx_view", "gz_zctx_commit_codec",
     "gz_zip_open", "gz_zip_close", "gz_fastq_zip_vblocks", "gz_fastq_zip_seg", "gz_fastq_zip_merge", "gz_fastq_zip_finish", "gz_zip_zctx", "gz_section_order",
     "gz_zip_reset", "gz_fastq_zip_collect",
+    "gz_zfile_create", "gz_zfile_destroy", "gz_zfile_add_vblock", "gz_zfile_write_global_area", "gz_codec_assign_best_host",
     "gz_tokenize_column_n", "gz_int_columns", "gz_local_generate_batch", "gz_acgt_pack_batch",
 )
 
@@ -212,6 +213,13 @@ def load(path=None):
     L.gz_fastq_zip_seg.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(GzFastqVB), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.gz_fastq_zip_merge.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.gz_fastq_zip_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int]
+    L.gz_zfile_create.restype = C.c_void_p
+    L.gz_zfile_create.argtypes = [C.c_uint16, C.c_uint32]
+    L.gz_zfile_destroy.argtypes = [C.c_void_p]
+    L.gz_zfile_add_vblock.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint8, C.c_uint32]
+    L.gz_zfile_write_global_area.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64,
+                                             C.c_char_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.gz_codec_assign_best_host.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
     L.gz_zip_reset.argtypes = [C.c_void_p]
     L.gz_fastq_zip_collect.argtypes = [C.c_void_p, C.POINTER(GzFastqVB), C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.gz_zip_zctx.restype = C.c_void_p

@@ -821,6 +821,33 @@ def fastq_zip(E, oracle, n_reads, n_calls=2):
     # the dictionaries the file ends up with: tiles in order of first appearance
     tiles = F.zctx_words(3)
     assert tiles and tiles == zstate["z"][3].words()
+    # N4: VBlocks + global area, read back by the independent reader of tests/gz_reader.py
+    import gz_reader
+    blob = F.write_file(got, [g["n_reads"] for g in got], counts_ctxs=(3,))
+    R = gz_reader.read_file(blob, lambda codec, pay, ulen: bytes(pay) if codec == 1 else oracle.codec_uncompress(codec, pay, ulen))
+    assert R["version"] == (15, 86) and R["data_type"] == 3 and R["num_lines"] == sum(g["n_reads"] for g in got) and R["created"] == b"genozip_amd"
+    for i, c in enumerate(plan["ctxs"]):
+        want = zstate["z"][i].view()
+        if want["n_words"] and not want["rm_dict"]:
+            assert R["dicts"][c["dict_id"]] == zstate["z"][i].words(), c["tag"]
+        else:
+            assert c["dict_id"] not in R["dicts"], c["tag"]
+    assert R["counts"][plan["ctxs"][3]["dict_id"]] == [int(x) for x in zstate["z"][3].view()["counts"]]
+    # every section the list names is where the list says it is, VBlock by VBlock
+    at = 0
+    vb_secs = [s for s in R["sections"] if s["st"] in (9, 11, 12)]
+    k = 0
+    for g in got:
+        z = g["z"]
+        assert vb_secs[k]["st"] == 9 and vb_secs[k]["offset"] == at and vb_secs[k]["num_lines"] == g["n_reads"]
+        k += 1
+        p = 84
+        while p < len(z):
+            clen = int.from_bytes(z[p + 12:p + 16], "big")
+            assert vb_secs[k]["offset"] == at + p and vb_secs[k]["size"] == 40 + clen and vb_secs[k]["dict_id"] == z[p + 32:p + 40] and vb_secs[k]["st"] == z[p + 24]
+            p += 40 + clen; k += 1
+        at += len(z)
+    assert k == len(vb_secs) and R["sections"][-1]["st"] == 6
     F.close()
 
 
