@@ -49,6 +49,9 @@ struct GzdStream {
     uint32_t sec_in_vb;
     uint64_t z_off;           // where the 40-byte header of this section starts inside the VB's z_data
     uint8_t  hdr[40];         // SectionHeaderCtx template; lengths, codec and digest are patched on device
+    uint32_t *out_len_dev;    // batch mode, optional: the payload length for a later section writer
+    uint32_t raw_len;         // precompressed section: data_uncompressed_len of the header
+    uint8_t  pre;             // precompressed section: `in` already is the payload of codec hdr[25]
 };
 
 struct GzdLeaf {

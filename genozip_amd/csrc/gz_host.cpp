@@ -62,6 +62,8 @@ struct GzHandle {
     int n_cu = 0;             // compute units of the device
     int chain_wgs_held = 0, chain_cus_held = 0;   // this handle's share of g_chain_wgs / g_chain_cus, returned at gz_sync
     uint32_t *d_fail = NULL;  // set by a kernel that gave up (the persistent chain when the models never report)
+    GzHandle *emit_after = NULL;   // the next VBlock batch's section writer waits for this handle's queued work (gz_emit_after)
+    hipEvent_t ev_other = NULL;
     bool no_pipeline = false; // GZ_NO_PIPELINE=1: no persistent kernel (needed under tools that serialise kernels, e.g. rocprofv3 --pmc)
     bool own_stream;
     std::vector<ArenaBlock> blocks;
@@ -236,6 +238,7 @@ extern "C" void gz_destroy (GzHandle *h)
     (void)hipEventDestroy (h->ev_chain);
     (void)hipEventDestroy (h->ev_chain_go);
     (void)hipEventDestroy (h->ev_fork); (void)hipEventDestroy (h->ev_join);
+    if (h->ev_other) (void)hipEventDestroy (h->ev_other);
     delete h;
 }
 
@@ -271,6 +274,13 @@ extern "C" int gz_profile_get (GzHandle *h, int idx, char *name, int name_cap, d
     if (total_ms) *total_ms = h->prof[idx].ms;
     if (launches) *launches = h->prof[idx].launches;
     return 1;
+}
+
+extern "C" int gz_emit_after (GzHandle *h, GzHandle *other)
+{
+    if (!h || !other || h == other || h->device != other->device) return GZ_ERR_ARG;
+    h->emit_after = other;
+    return GZ_OK;
 }
 
 extern "C" int gz_download (GzHandle *h, void *dst, const void *src, uint64_t n)
@@ -661,6 +671,12 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
         }
         if (fork) { HIPCHK (h, hipEventRecord (h->ev_join, side)); HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_join, 0)); }
     }
+    if (n_vbs && h->emit_after) {                    // precompressed sections coded on another handle: only the writer waits for them
+        if (!h->ev_other) HIPCHK (h, hipEventCreateWithFlags (&h->ev_other, hipEventDisableTiming));
+        HIPCHK (h, hipEventRecord (h->ev_other, h->emit_after->stream));
+        HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_other, 0));
+        h->emit_after = NULL;
+    }
     KLAUNCH (h, k_select, dim3 ((ns + 255) / 256), dim3 (256), 0, d_streams, d_leaves, ns);
     if (n_vbs) KLAUNCH (h, k_vb_layout, dim3 ((n_vbs + 63) / 64), dim3 (64), 0, d_vbs, d_streams, n_vbs);
     KLAUNCH (h, k_emit, dim3 (ns), dim3 (256), 4096, d_streams, d_leaves, d_vbs);
@@ -681,7 +697,7 @@ extern "C" int gz_codec_compress_batch (GzHandle *h, GzStream *streams, int n_st
         u.out_len = 0;
         if (!codec_ok (u.codec)) { u.status = GZ_ERR_ARG; S.status = GZ_ERR_ARG; continue; }
         S.in = u.in; S.in_len = u.in_len; S.in_len_dev = u.in_len_dev; S.out = u.out; S.out_cap = u.out_cap;
-        S.codec_req = u.codec; S.vb = -1;
+        S.codec_req = u.codec; S.vb = -1; S.out_len_dev = u.out_len_dev;
         // the reference's "output buffer too small" test (rANS_static4x16pr.c:1158, arith_dynamic.c:622)
         S.status = u.out_cap < codec_min_cap (u.codec, u.in_len) ? GZ_ST_TOO_SMALL : GZ_ST_PENDING;
         u.status = S.status;
@@ -704,7 +720,7 @@ extern "C" uint64_t gz_vb_z_bound (const GzSection *sections, uint32_t n_section
     uint64_t b = 84;
     for (uint32_t i = 0; i < n_sections; i++) {
         int codec = sections[i].codec ? sections[i].codec : GZ_CODEC_RANB;
-        uint64_t e = gz_codec_est_size (codec, sections[i].data_len);
+        uint64_t e = sections[i].precompressed ? sections[i].data_len : gz_codec_est_size (codec, sections[i].data_len);
         if (e < sections[i].data_len) e = sections[i].data_len;
         b += 40 + e;
     }
@@ -740,6 +756,7 @@ extern "C" int gz_vb_compress_batch (GzHandle *h, GzVBlock *vbs, int n_vbs)
             hd[24] = sec.section_type; hd[25] = (uint8_t)codec; hd[26] = sec.sub_codec; hd[27] = sec.flags;
             hd[28] = sec.ltype; hd[29] = sec.param; hd[30] = sec.b250_size_or_nothing_char; hd[31] = 0;
             memcpy (hd + 32, sec.dict_id, 8);
+            if (sec.precompressed) { S.pre = 1; S.raw_len = sec.raw_len; S.codec_req = GZ_CODEC_NONE; P.streams.push_back (S); P.streams.back ().first_leaf = (uint32_t)P.leaves.size (); continue; }
             if (sec.data_len > P.max_in) P.max_in = sec.data_len;
             P.streams.push_back (S);
             // a section shorter than 50 bytes is stored raw; when the length is only known on the device we must

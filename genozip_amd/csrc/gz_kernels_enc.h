@@ -35,6 +35,7 @@ __global__ void k_resolve (GzdStream *streams, uint32_t n_streams, int section_m
     S.n = n;
 
     int codec = S.codec_req;
+    if (S.pre) { S.codec = S.hdr[25]; S.engine = GZ_ENG_NONE; S.order = 0; S.striped = 0; return; }   // already coded: only framed
     if (section_mode && n < 50) codec = 1 /* CODEC_NONE: compressor.c:56-58 */;
     S.codec = (uint8_t)codec;
 
@@ -915,7 +916,7 @@ __global__ void __launch_bounds__(256) k_emit (GzdStream *streams, GzdLeaf *leav
     }
 
     // NB: status doubles as the entry test of this kernel: every thread must be past it before it changes
-    if (S.vb < 0) { __syncthreads (); if (!tid) S.status = GZ_ST_OK; return; }
+    if (S.vb < 0) { __syncthreads (); if (!tid) { if (S.out_len_dev) *S.out_len_dev = S.out_len; S.status = GZ_ST_OK; } return; }
 
     // ---- section header (comp_compress, compressor.c:114-161): adler32 of the payload by the whole workgroup
     __threadfence_block ();
@@ -926,7 +927,7 @@ __global__ void __launch_bounds__(256) k_emit (GzdStream *streams, GzdLeaf *leav
         for (int k = 0; k < 40; k++) h[k] = S.hdr[k];
         gz_be32 (h + 4,  adler);
         gz_be32 (h + 12, S.out_len);
-        gz_be32 (h + 16, S.n);
+        gz_be32 (h + 16, S.pre ? S.raw_len : S.n);
         h[25] = S.codec;
         S.status = GZ_ST_OK;
     }

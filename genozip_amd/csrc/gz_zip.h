@@ -50,6 +50,7 @@ struct ZipCol {                    // one (VBlock, context) of this process
     std::vector<uint8_t> ston_local;
     size_t n2w_at = 0;
     uint8_t lcodec = 0, bcodec = 0;
+    int early = -1;                            // index of this local's stream in the batch coded ahead on the second handle
 };
 
 // One (VBlock, context) as the merge sees it - what a process has to tell the others when the VBlocks of a file are dealt out
@@ -78,6 +79,8 @@ struct ZipCall {                   // what lives between the phases of one call
     GzDynIntResult *d_dynres = NULL; uint32_t *d_seclen = NULL; int32_t *d_b250st = NULL;
     std::vector<uint8_t> blob;      // this process' merge blob
     std::vector<ZipVote> votes;
+    std::vector<GzStream> early;               // the streams coded ahead (results arrive when the second handle is synchronised)
+    uint32_t *d_early_len = NULL;
     std::vector<int32_t> n2w_host;
     std::map<uint32_t, ZipVBState> vbstate;   // by vblock_i: every VBlock of the call, own or not
 };
@@ -85,6 +88,7 @@ struct ZipCall {                   // what lives between the phases of one call
 // ---------------------------------------------------------------------------------------------------------
 struct GzZipFile {
     GzHandle *h;
+    GzHandle *h2 = NULL;                   // the long streams (QUAL) are coded here, ahead of and beside everything else
     GzFastqPlan plan;
     std::vector<GzFastqCtx> ctxs;
     std::vector<std::vector<uint8_t>> snips;
@@ -129,6 +133,7 @@ extern "C" GzZipFile *gz_zip_open (GzHandle *h, const GzFastqPlan *plan)
         if (c.bcodec) gz_zctx_commit_codec (f->zctx.back (), 0, c.bcodec);
     }
     f->plan.ctxs = f->ctxs.data ();
+    { const char *e = getenv ("GZ_ZIP_NO_OVERLAP"); int err = 0; if (!(e && *e && *e != '0')) f->h2 = gz_create (h->device, NULL, &err); }
     return f;
 }
 
@@ -137,6 +142,7 @@ extern "C" void gz_zip_close (GzZipFile *f)
     if (!f) return;
     (void)hipSetDevice (f->h->device);
     (void)gz_sync (f->h);
+    if (f->h2) gz_destroy (f->h2);
     for (auto z : f->zctx) gz_zctx_destroy (z);
     for (auto &b : f->ws) (void)hipFree (b.base);
     delete f;
@@ -678,6 +684,7 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
     for (uint32_t v = 0; v < NV; v++) own[vbs[v].vblock_i] = v;
 
     K.n2w_host.clear ();
+    K.votes.clear ();
     for (const Ent &e : ents) {
         const ZipBlobVB *hv = (const ZipBlobVB *)e.p;
         const uint8_t *p = e.p + sizeof (ZipBlobVB);
@@ -854,9 +861,50 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
     }
 
     T.mark ("generate-queue");
+    // ---- the long streams go first, on a handle of their own: QUAL locals (length known on the host, no dependence on the merge)
+    // are handed to the coders NOW, so that their strictly serial chains run beside the trial compressions and the short
+    // sections instead of after them. Their codec must be known for that: committed in the file, or decided here by trial on
+    // the call's first VBlock - which only the process that owns that VBlock may do (a serial run commits VBlock 1's choice).
+    K.early.clear ();
+    if (f->h2 && NV) {
+        const bool own_first = ents.empty () || ents.front ().vblock_i == vbs[0].vblock_i;
+        for (uint32_t c = 0; c < NC; c++) {
+            if (f->ctxs[c].kind != GZ_FQ_QUAL) continue;
+            GzZctxView zv; gz_zctx_view (f->zctx[c], &zv);
+            int codec = zv.lcodec;
+            if (!codec && own_first) {
+                std::vector<const uint8_t *> ptr; std::vector<uint32_t> len; std::vector<int> best;
+                uint32_t v0 = NV;
+                for (uint32_t v = 0; v < NV && v0 == NV; v++) if (COL (v, c).has_local && COL (v, c).local_len >= 50) v0 = v;
+                if (v0 < NV) {
+                    ptr.push_back (COL (v0, c).local); len.push_back ((uint32_t)COL (v0, c).local_len);
+                    if ((rc = zip_assign_best_many (h, f, ptr, len, best)) != GZ_OK) return rc;
+                    codec = best[0];
+                    if (codec) K.votes.push_back ({ c, 1, vbs[v0].vblock_i, (uint32_t)codec });
+                }
+            }
+            if (!codec) continue;                                     // (not decided here: coded with the rest, below)
+            for (uint32_t v = 0; v < NV; v++) {
+                ZipCol &Z = COL (v, c);
+                if (!Z.has_local || Z.local_len < 50 || Z.local_len > 0xffffffffull) continue;
+                GzStream st; memset (&st, 0, sizeof (st));
+                st.in = Z.local; st.in_len = (uint32_t)Z.local_len; st.codec = codec; st.out_cap = gz_codec_est_size (codec, Z.local_len);
+                if (!(st.out = (uint8_t *)ws_alloc (f, (size_t)st.out_cap + 64))) return GZ_ERR_HIP;
+                Z.early = (int)K.early.size (); Z.lcodec = (uint8_t)codec;
+                K.early.push_back (st);
+            }
+        }
+        if (!K.early.empty ()) {
+            if (!(K.d_early_len = (uint32_t *)ws_alloc (f, K.early.size () * 4))) return GZ_ERR_HIP;
+            for (size_t k = 0; k < K.early.size (); k++) K.early[k].out_len_dev = K.d_early_len + k;
+            HIPCHK (h, hipStreamSynchronize (h->stream));             // (their inputs were gathered on this handle's stream)
+            GzHandle *h2 = f->h2;
+            if ((rc = gz_codec_compress_batch (h2, K.early.data (), (int)K.early.size ())) != GZ_OK) { h->err = h2->err; return rc; }
+        }
+    }
+    T.mark ("early-launch");
     // ---- a8: contexts whose codec the file does not know yet: trial compressions on the first VBlock (of this process) that
     // has >= 50 bytes of the stream (codec.c:309-312); the lowest vblock_i of all processes' votes is committed in phase 3
-    K.votes.clear ();
     {
         std::vector<const uint8_t *> ptr; std::vector<uint32_t> len; std::vector<ZipVote> who;
         bool need = false;
@@ -870,6 +918,9 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
                 GzZctxView zv; gz_zctx_view (f->zctx[c], &zv);
                 for (uint32_t is_local = 0; is_local < 2; is_local++) {
                     if (is_local ? zv.lcodec : zv.bcodec) continue;
+                    bool voted = false;
+                    for (const ZipVote &vt : K.votes) if (vt.ctx == c && vt.is_local == is_local) voted = true;
+                    if (voted) continue;                                  // (decided above for the streams that were coded ahead)
                     for (uint32_t v = 0; v < NV; v++) {
                         ZipCol &Z = COL (v, c);
                         uint32_t L = 0; const uint8_t *p = NULL;
@@ -952,6 +1003,10 @@ extern "C" int gz_fastq_zip_finish (GzZipFile *f, const void *const *votes, cons
             else {
                 s.section_type = GZ_SEC_LOCAL; s.data = Z.local; s.data_len = (uint32_t)Z.local_len;
                 if (Z.dyn_job >= 0) { s.data_len = (uint32_t)Z.local_cap; s.data_len_dev = Z.sec_len_dev; }
+                if (Z.early >= 0) {                                                                    // coded ahead on the second handle: only framed here
+                    const GzStream &es = K.early[Z.early];
+                    s.precompressed = 1; s.raw_len = es.in_len; s.data = es.out; s.data_len = es.out_cap; s.data_len_dev = es.out_len_dev;
+                }
                 s.codec = Z.lcodec; s.ltype = (uint8_t)Z.ltype;
                 const bool int_lt = Z.ltype >= GZ_LT_INT8 && Z.ltype <= GZ_LT_UINT64;
                 if (int_lt) s.b250_size_or_nothing_char = X.nothing_char ? X.nothing_char : 0xff;    // zfile.c:344-345
@@ -966,12 +1021,18 @@ extern "C" int gz_fastq_zip_finish (GzZipFile *f, const void *const *votes, cons
         if (!(B.z_data = (uint8_t *)ws_alloc (f, B.z_cap + 64))) return GZ_ERR_HIP;
     }
     T.mark ("sections");
+    if (!K.early.empty ()) ZCHK (gz_emit_after (h, f->h2));
     ZCHK (gz_vb_compress_batch (h, V.data (), (int)NV));
     T.mark ("compress-queue");
     std::vector<int32_t> b250st ((size_t)NV * NC, 1);
     HIPCHK (h, hipMemcpyAsync (b250st.data (), K.d_b250st, b250st.size () * 4, hipMemcpyDeviceToHost, h->stream));
     rc = gz_sync (h);
     K.phase = 0;
+    if (!K.early.empty ()) {
+        const int rc2 = gz_sync (f->h2);
+        if (rc2 < 0) { h->err = f->h2->err; return rc2; }
+        for (const GzStream &es : K.early) if (es.status != GZ_OK) { h->err = "a stream coded ahead failed"; return GZ_ERR; }
+    }
     T.mark ("compress-sync"); T.done ("finish");
     if (rc < 0) return rc;
     for (uint32_t v = 0; v < NV; v++) {

@@ -28,7 +28,7 @@ GZ_OK, GZ_TOO_SMALL, GZ_ERR, GZ_ERR_NO_DEVICE, GZ_ERR_ARG, GZ_ERR_HIP, GZ_ERR_CO
 
 class GzStream(C.Structure):
     _fields_ = [("in_", C.c_void_p), ("in_len", C.c_uint32), ("in_len_dev", C.c_void_p), ("out", C.c_void_p),
-                ("out_cap", C.c_uint32), ("codec", C.c_int32), ("out_len", C.c_uint32), ("status", C.c_int32)]
+                ("out_cap", C.c_uint32), ("codec", C.c_int32), ("out_len", C.c_uint32), ("status", C.c_int32), ("out_len_dev", C.c_void_p)]
 
 
 class GzB250Job(C.Structure):
@@ -68,7 +68,7 @@ class GzSection(C.Structure):
     _fields_ = [("data", C.c_void_p), ("data_len", C.c_uint32), ("data_len_dev", C.c_void_p),
                 ("section_type", C.c_uint8), ("codec", C.c_uint8), ("sub_codec", C.c_uint8), ("flags", C.c_uint8),
                 ("ltype", C.c_uint8), ("param", C.c_uint8), ("b250_size_or_nothing_char", C.c_uint8),
-                ("dict_id", C.c_uint8 * 8)]
+                ("dict_id", C.c_uint8 * 8), ("precompressed", C.c_uint8), ("raw_len", C.c_uint32)]
 
 
 class GzVBlock(C.Structure):
@@ -119,7 +119,7 @@ GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ
 # every symbol include/genozip_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "gz_create", "gz_destroy", "gz_sync", "gz_last_error", "gz_version", "gz_stream", "gz_profile", "gz_profile_get",
-    "gz_download", "gz_upload", "gz_dev_alloc", "gz_dev_free",
+    "gz_download", "gz_upload", "gz_dev_alloc", "gz_dev_free", "gz_emit_after",
     "gz_codec_est_size", "gz_codec_compress_host", "gz_codec_uncompress_host",
     "gz_codec_compress_batch", "gz_codec_uncompress_batch", "gz_codec_assign_best",
     "gz_b250_generate", "gz_b250_generate_batch", "gz_local_generate", "gz_local_to_native",
@@ -193,6 +193,7 @@ def load(path=None):
         f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     L.gz_tokenize_column.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gz_emit_after.argtypes = [C.c_void_p, C.c_void_p]
     L.gz_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.gz_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.gz_dev_alloc.restype = C.c_void_p

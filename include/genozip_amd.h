@@ -65,6 +65,9 @@ void gz_profile (GzHandle *h, int enable, int reset);
 int  gz_profile_get (GzHandle *h, int idx, char *name, int name_cap, double *total_ms, int *launches);
 /* the HIP stream work is queued on (a hipStream_t) - for timing with HIP events on the right stream */
 void     *gz_stream (GzHandle *h);
+/* The section-writing kernels of h's NEXT gz_vb_compress_batch (layout, emit, adler32) wait until everything queued on `other`
+ * so far has completed - for sections precompressed on another handle while this one's own coders run (no host wait). */
+int gz_emit_after (GzHandle *h, GzHandle *other);
 /* plain copies between host memory and HBM for callers that have no HIP runtime of their own in reach (a C host program;
  * results that live in the library's workspace, e.g. GzFastqVB.z_data). Synchronous; they wait for the handle's stream first. */
 int gz_download (GzHandle *h, void *host_dst, const void *dev_src, uint64_t n);
@@ -102,6 +105,8 @@ typedef struct {
     /* results, valid after gz_sync(): */
     uint32_t       out_len;
     int32_t        status;        /* GZ_OK / GZ_TOO_SMALL / GZ_ERR_CORRUPT                            */
+    uint32_t      *out_len_dev;   /* optional (compress): the payload length is also left on the device, for a
+                                     section writer that runs before the host has seen it (GzSection.precompressed) */
 } GzStream;
 
 /* Batched, asynchronous forms over a stream table (host array of descriptors of device buffers). Many streams
@@ -168,6 +173,10 @@ typedef struct {
     uint8_t  param;
     uint8_t  b250_size_or_nothing_char; /* byte 30: B250_VARL(4) for b250, nothing_char for integer locals   */
     uint8_t  dict_id[8];
+    uint8_t  precompressed;       /* data / data_len(_dev) already ARE the codec's payload (gz_codec_compress_batch ran ahead,
+                                     possibly on another handle: gz_emit_after): only framed here; `codec` = the effective
+                                     codec, raw_len = data_uncompressed_len of the header                           */
+    uint32_t raw_len;
 } GzSection;
 
 typedef struct {
