@@ -129,7 +129,13 @@ static void arena_reset (GzHandle *h)
 
 extern "C" const char *gz_version (void) { return GZ_VERSION; }
 
-extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
+static GzHandle *gz_create_do (int device, void *hip_stream, int *err, bool background);
+extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err) { return gz_create_do (device, hip_stream, err, false); }
+// a handle for long-running work that must not hold up another handle's short kernels: all its streams but the chain's at the
+// lowest priority (the VBlock compute driver codes the long QUAL streams on such a handle)
+extern "C" GzHandle *gz_create_background (int device, int *err) { return gz_create_do (device, NULL, err, true); }
+
+static GzHandle *gz_create_do (int device, void *hip_stream, int *err, bool background)
 {
     int ndev = 0;
     if (hipGetDeviceCount (&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
@@ -140,9 +146,11 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
     GzHandle *h = new GzHandle ();
     h->device = device; h->d_logs = NULL; h->d_magic = NULL;
     h->arena_block_size = (size_t)256 << 20;
+    int prio_lo0 = 0, prio_hi0 = 0;
+    if (hipDeviceGetStreamPriorityRange (&prio_lo0, &prio_hi0) != hipSuccess) prio_lo0 = prio_hi0 = 0;
     if (hip_stream) { h->stream = (hipStream_t)hip_stream; h->own_stream = false; }
     else {
-        if (hipStreamCreateWithFlags (&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; if (err) *err = GZ_ERR_HIP; return NULL; }
+        if (hipStreamCreateWithPriority (&h->stream, hipStreamNonBlocking, background ? prio_lo0 : (prio_lo0 + prio_hi0) / 2) != hipSuccess) { delete h; if (err) *err = GZ_ERR_HIP; return NULL; }
         h->own_stream = true;
     }
     // The chain (one wave per leaf, strictly serial) is the critical path: its few workgroups must not queue behind
@@ -151,6 +159,7 @@ extern "C" GzHandle *gz_create (int device, void *hip_stream, int *err)
     if (hipDeviceGetAttribute (&h->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || h->n_cu <= 0) h->n_cu = 64;
     int prio_lo = 0, prio_hi = 0;
     if (hipDeviceGetStreamPriorityRange (&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
+    if (!background) prio_lo = (prio_lo + prio_hi) / 2;      // an ordinary handle's side streams: the middle; a background handle's: the lowest
     if (hipStreamCreateWithPriority (&h->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipStreamCreateWithPriority (&h->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority (&h->stream4, hipStreamNonBlocking, prio_lo) != hipSuccess ||
@@ -274,6 +283,17 @@ extern "C" int gz_profile_get (GzHandle *h, int idx, char *name, int name_cap, d
     if (total_ms) *total_ms = h->prof[idx].ms;
     if (launches) *launches = h->prof[idx].launches;
     return 1;
+}
+
+// everything queued on h from now on waits until what is queued on `other` so far has completed (no host wait)
+extern "C" int gz_wait_for (GzHandle *h, GzHandle *other)
+{
+    if (!h || !other || h == other || h->device != other->device) return GZ_ERR_ARG;
+    HIPCHK (h, hipSetDevice (h->device));
+    if (!h->ev_other) HIPCHK (h, hipEventCreateWithFlags (&h->ev_other, hipEventDisableTiming));
+    HIPCHK (h, hipEventRecord (h->ev_other, other->stream));
+    HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_other, 0));
+    return GZ_OK;
 }
 
 extern "C" int gz_emit_after (GzHandle *h, GzHandle *other)

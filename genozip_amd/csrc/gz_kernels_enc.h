@@ -800,6 +800,12 @@ __global__ void k_select (GzdStream *streams, GzdLeaf *leaves, uint32_t n_stream
     GzdStream &S = streams[i];
     if (S.status != GZ_ST_PENDING) return;
 
+    if (S.pre) {                                                         // coded ahead, possibly on another handle: its length exists only now
+        uint32_t n = S.in_len;
+        if (S.in_len_dev) { const uint32_t v = *(volatile const uint32_t *)S.in_len_dev; if (v < n) n = v; }
+        S.n = n; S.out_len = n;
+        return;
+    }
     if (S.engine == GZ_ENG_NONE) { S.out_len = S.n; return; }            // codec_none_compress
 
     uint32_t best_len[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };

@@ -133,7 +133,7 @@ extern "C" GzZipFile *gz_zip_open (GzHandle *h, const GzFastqPlan *plan)
         if (c.bcodec) gz_zctx_commit_codec (f->zctx.back (), 0, c.bcodec);
     }
     f->plan.ctxs = f->ctxs.data ();
-    { const char *e = getenv ("GZ_ZIP_NO_OVERLAP"); int err = 0; if (!(e && *e && *e != '0')) f->h2 = gz_create (h->device, NULL, &err); }
+    { const char *e = getenv ("GZ_ZIP_NO_OVERLAP"); int err = 0; if (!(e && *e && *e != '0')) f->h2 = gz_create_background (h->device, &err); }
     return f;
 }
 
@@ -381,6 +381,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     f->call = ZipCall ();
     ZipCall &K = f->call;
     K.text = text; K.text_len = text_len; K.vbs = vbs; K.NV = NV;
+    K.votes.clear ();
 
     // ---- lines of the whole text, first line of every VBlock (seg_get_next_line, src/seg.c:200-236) -------------------------
     const uint8_t lookup_byte[16] = { 1 };                                  // SNIP_LOOKUP parked behind the text
@@ -539,11 +540,36 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         }
     }
     T.mark ("plan");
+    // SEQ / QUAL are gathered first: the QUAL streams are the long pole of the whole call, and when the file has no codec for
+    // them yet, the trial compressions (a8) of the first VBlock's QUAL start on the second handle while the columns are evaluated
+    for (size_t at = 0; at < blob_jobs.size (); at += 32768) ZCHK (gz_local_blob_columns (h, blob_jobs.data () + at, (int)std::min<size_t> (32768, blob_jobs.size () - at)));
+    static const int trial_codecs[8] = { GZ_CODEC_RANB, GZ_CODEC_RANW, GZ_CODEC_RANb, GZ_CODEC_RANw, GZ_CODEC_ARTB, GZ_CODEC_ARTW, GZ_CODEC_ARTb, GZ_CODEC_ARTw };
+    std::vector<GzStream> trial;                          // 8 per QUAL-kind context that needs a codec
+    std::vector<uint32_t> trial_ctx;
+    const bool own_first = vbs[0].vblock_i == f->last_vblock_i + 1;   // (vblock_i are consecutive over the processes: this one opens the call)
+    if (f->h2 && own_first)
+        for (uint32_t c = 0; c < NC; c++) {
+            if (f->ctxs[c].kind != GZ_FQ_QUAL || !vbs[0].n_reads) continue;
+            GzZctxView zv; gz_zctx_view (f->zctx[c], &zv);
+            if (zv.lcodec) continue;
+            const ZipCol &Z = COL (0, c);
+            for (int k = 0; k < 8; k++) {
+                GzStream st; memset (&st, 0, sizeof (st));
+                st.in = Z.local; st.in_len = 99999; st.in_len_dev = (const uint32_t *)(d_blobres + Z.blob_job);   // codec.c:309 (low half of the 64-bit length)
+                st.codec = trial_codecs[k]; st.out_cap = gz_codec_est_size (st.codec, 99999);
+                if (!(st.out = (uint8_t *)ws_alloc (f, (size_t)st.out_cap + 64))) return GZ_ERR_HIP;
+                trial.push_back (st);
+            }
+            trial_ctx.push_back (c);
+        }
+    if (!trial.empty ()) {
+        ZCHK (gz_wait_for (f->h2, h));
+        if ((rc = gz_codec_compress_batch (f->h2, trial.data (), (int)trial.size ())) != GZ_OK) { h->err = f->h2->err; return rc; }
+    }
     ZCHK (gz_int_columns (h, icol_jobs.data (), (int)icol_jobs.size ()));
     // (column tables hold at most 65 535 rows per call)
     for (size_t at = 0; at < col_jobs.size (); at += 32768) ZCHK (gz_ctx_seg_columns (h, col_jobs.data () + at, (int)std::min<size_t> (32768, col_jobs.size () - at)));
     for (size_t at = 0; at < dyn_jobs.size (); at += 32768) ZCHK (gz_dyn_int_columns (h, dyn_jobs.data () + at, (int)std::min<size_t> (32768, dyn_jobs.size () - at)));
-    for (size_t at = 0; at < blob_jobs.size (); at += 32768) ZCHK (gz_local_blob_columns (h, blob_jobs.data () + at, (int)std::min<size_t> (32768, blob_jobs.size () - at)));
     ZCHK (gz_acgt_pack_batch (h, acgt_jobs.data (), (int)acgt_jobs.size ()));
 
     // what the merge needs from every column, packed into one stretch
@@ -633,9 +659,50 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
             blob_put (K.blob, counts, 4 * ((size_t)Z.n_ol + cr.n_new));
         }
     }
+    // ---- the long streams go first, on a handle of their own: QUAL locals (length known on the host, no dependence on the merge)
+    // are handed to the coders as soon as they are gathered, so that their strictly serial chains run beside the trial compressions and the short
+    // sections instead of after them. Their codec must be known for that: committed in the file, or decided here by trial on
+    // the call's first VBlock - which only the process that owns that VBlock may do (a serial run commits VBlock 1's choice).
+    K.early.clear ();
+    if (f->h2 && NV) {
+        if (!trial.empty () && (rc = gz_sync (f->h2)) < 0) { h->err = f->h2->err; return rc; }
+        for (uint32_t c = 0; c < NC; c++) {
+            if (f->ctxs[c].kind != GZ_FQ_QUAL) continue;
+            GzZctxView zv; gz_zctx_view (f->zctx[c], &zv);
+            int codec = zv.lcodec;
+            for (size_t t = 0; !codec && t < trial_ctx.size (); t++) {
+                if (trial_ctx[t] != c || COL (0, c).local_len < 50) continue;            // codec.c:311-312: too small a sample decides nothing
+                const uint32_t sample = (uint32_t)std::min<uint64_t> (COL (0, c).local_len, 99999);
+                uint32_t best_size = sample; codec = GZ_CODEC_NONE;                     // NONE: the bare length (codec.c:324)
+                for (int k = 0; k < 8; k++) {
+                    const GzStream &st = trial[8 * t + k];
+                    if (st.status != GZ_OK) { h->err = "trial compression failed"; return GZ_ERR; }
+                    if (st.out_len + 28 < best_size) { best_size = st.out_len + 28; codec = st.codec; }   // framed (codec.c:328-331), ties -> first
+                }
+                K.votes.push_back ({ c, 1, vbs[0].vblock_i, (uint32_t)codec });
+            }
+            if (!codec) continue;                                     // (not decided here: coded with the rest, below)
+            for (uint32_t v = 0; v < NV; v++) {
+                ZipCol &Z = COL (v, c);
+                if (!Z.has_local || Z.local_len < 50 || Z.local_len > 0xffffffffull) continue;
+                GzStream st; memset (&st, 0, sizeof (st));
+                st.in = Z.local; st.in_len = (uint32_t)Z.local_len; st.codec = codec; st.out_cap = gz_codec_est_size (codec, Z.local_len);
+                if (!(st.out = (uint8_t *)ws_alloc (f, (size_t)st.out_cap + 64))) return GZ_ERR_HIP;
+                Z.early = (int)K.early.size (); Z.lcodec = (uint8_t)codec;
+                K.early.push_back (st);
+            }
+        }
+        if (!K.early.empty ()) {
+            if (!(K.d_early_len = (uint32_t *)ws_alloc (f, K.early.size () * 4))) return GZ_ERR_HIP;
+            for (size_t k = 0; k < K.early.size (); k++) K.early[k].out_len_dev = K.d_early_len + k;
+            HIPCHK (h, hipStreamSynchronize (h->stream));             // (their inputs were gathered on this handle's stream)
+            GzHandle *h2 = f->h2;
+            if ((rc = gz_codec_compress_batch (h2, K.early.data (), (int)K.early.size ())) != GZ_OK) { h->err = h2->err; return rc; }
+        }
+    }
     *blob_out = K.blob.data (); *blob_len_out = K.blob.size ();
     K.phase = 1;
-    T.mark ("staging+blob"); T.done ("seg");
+    T.mark ("staging+blob+early"); T.done ("seg");
     return GZ_OK;
 }
 
@@ -684,7 +751,6 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
     for (uint32_t v = 0; v < NV; v++) own[vbs[v].vblock_i] = v;
 
     K.n2w_host.clear ();
-    K.votes.clear ();
     for (const Ent &e : ents) {
         const ZipBlobVB *hv = (const ZipBlobVB *)e.p;
         const uint8_t *p = e.p + sizeof (ZipBlobVB);
@@ -861,48 +927,6 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
     }
 
     T.mark ("generate-queue");
-    // ---- the long streams go first, on a handle of their own: QUAL locals (length known on the host, no dependence on the merge)
-    // are handed to the coders NOW, so that their strictly serial chains run beside the trial compressions and the short
-    // sections instead of after them. Their codec must be known for that: committed in the file, or decided here by trial on
-    // the call's first VBlock - which only the process that owns that VBlock may do (a serial run commits VBlock 1's choice).
-    K.early.clear ();
-    if (f->h2 && NV) {
-        const bool own_first = ents.empty () || ents.front ().vblock_i == vbs[0].vblock_i;
-        for (uint32_t c = 0; c < NC; c++) {
-            if (f->ctxs[c].kind != GZ_FQ_QUAL) continue;
-            GzZctxView zv; gz_zctx_view (f->zctx[c], &zv);
-            int codec = zv.lcodec;
-            if (!codec && own_first) {
-                std::vector<const uint8_t *> ptr; std::vector<uint32_t> len; std::vector<int> best;
-                uint32_t v0 = NV;
-                for (uint32_t v = 0; v < NV && v0 == NV; v++) if (COL (v, c).has_local && COL (v, c).local_len >= 50) v0 = v;
-                if (v0 < NV) {
-                    ptr.push_back (COL (v0, c).local); len.push_back ((uint32_t)COL (v0, c).local_len);
-                    if ((rc = zip_assign_best_many (h, f, ptr, len, best)) != GZ_OK) return rc;
-                    codec = best[0];
-                    if (codec) K.votes.push_back ({ c, 1, vbs[v0].vblock_i, (uint32_t)codec });
-                }
-            }
-            if (!codec) continue;                                     // (not decided here: coded with the rest, below)
-            for (uint32_t v = 0; v < NV; v++) {
-                ZipCol &Z = COL (v, c);
-                if (!Z.has_local || Z.local_len < 50 || Z.local_len > 0xffffffffull) continue;
-                GzStream st; memset (&st, 0, sizeof (st));
-                st.in = Z.local; st.in_len = (uint32_t)Z.local_len; st.codec = codec; st.out_cap = gz_codec_est_size (codec, Z.local_len);
-                if (!(st.out = (uint8_t *)ws_alloc (f, (size_t)st.out_cap + 64))) return GZ_ERR_HIP;
-                Z.early = (int)K.early.size (); Z.lcodec = (uint8_t)codec;
-                K.early.push_back (st);
-            }
-        }
-        if (!K.early.empty ()) {
-            if (!(K.d_early_len = (uint32_t *)ws_alloc (f, K.early.size () * 4))) return GZ_ERR_HIP;
-            for (size_t k = 0; k < K.early.size (); k++) K.early[k].out_len_dev = K.d_early_len + k;
-            HIPCHK (h, hipStreamSynchronize (h->stream));             // (their inputs were gathered on this handle's stream)
-            GzHandle *h2 = f->h2;
-            if ((rc = gz_codec_compress_batch (h2, K.early.data (), (int)K.early.size ())) != GZ_OK) { h->err = h2->err; return rc; }
-        }
-    }
-    T.mark ("early-launch");
     // ---- a8: contexts whose codec the file does not know yet: trial compressions on the first VBlock (of this process) that
     // has >= 50 bytes of the stream (codec.c:309-312); the lowest vblock_i of all processes' votes is committed in phase 3
     {

@@ -118,8 +118,8 @@ GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ
 
 # every symbol include/genozip_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
-    "gz_create", "gz_destroy", "gz_sync", "gz_last_error", "gz_version", "gz_stream", "gz_profile", "gz_profile_get",
-    "gz_download", "gz_upload", "gz_dev_alloc", "gz_dev_free", "gz_emit_after",
+    "gz_create", "gz_create_background", "gz_destroy", "gz_sync", "gz_last_error", "gz_version", "gz_stream", "gz_profile", "gz_profile_get",
+    "gz_download", "gz_upload", "gz_dev_alloc", "gz_dev_free", "gz_emit_after", "gz_wait_for",
     "gz_codec_est_size", "gz_codec_compress_host", "gz_codec_uncompress_host",
     "gz_codec_compress_batch", "gz_codec_uncompress_batch", "gz_codec_assign_best",
     "gz_b250_generate", "gz_b250_generate_batch", "gz_local_generate", "gz_local_to_native",
@@ -194,6 +194,7 @@ def load(path=None):
     L.gz_tokenize_column.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
     L.gz_emit_after.argtypes = [C.c_void_p, C.c_void_p]
+    L.gz_wait_for.argtypes = [C.c_void_p, C.c_void_p]
     L.gz_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.gz_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.gz_dev_alloc.restype = C.c_void_p

@@ -53,6 +53,9 @@ typedef struct GzHandle GzHandle;   /* stands in for VBlockP: owns the HIP strea
 /* device = HIP device ordinal; hip_stream = a hipStream_t to run on, or NULL for a private stream.
  * Fails (returns NULL, *err set) when no gfx950-capable device / runtime is present: there is NO CPU fallback. */
 GzHandle *gz_create (int device, void *hip_stream, int *err);
+/* the same with all streams (but the range coder chain's) at the lowest priority: for long-running batches that run beside another
+ * handle's short ones (the VBlock compute driver codes the long QUAL streams on such a handle) */
+GzHandle *gz_create_background (int device, int *err);
 void      gz_destroy (GzHandle *h);
 int       gz_sync (GzHandle *h);
 const char *gz_last_error (GzHandle *h);
@@ -68,6 +71,8 @@ void     *gz_stream (GzHandle *h);
 /* The section-writing kernels of h's NEXT gz_vb_compress_batch (layout, emit, adler32) wait until everything queued on `other`
  * so far has completed - for sections precompressed on another handle while this one's own coders run (no host wait). */
 int gz_emit_after (GzHandle *h, GzHandle *other);
+/* everything queued on h from now on waits (on the device) for what is queued on `other` so far */
+int gz_wait_for (GzHandle *h, GzHandle *other);
 /* plain copies between host memory and HBM for callers that have no HIP runtime of their own in reach (a C host program;
  * results that live in the library's workspace, e.g. GzFastqVB.z_data). Synchronous; they wait for the handle's stream first. */
 int gz_download (GzHandle *h, void *host_dst, const void *dev_src, uint64_t n);
