@@ -13,6 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(_HERE, "liboracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libhtsref.so")
+CTXREF_SO = os.path.join(_HERE, "_ref", "libctxref.so")
 
 CODEC_NONE, CODEC_RANB, CODEC_RANW, CODEC_RANb, CODEC_RANw = 1, 6, 7, 8, 9
 CODEC_ARTB, CODEC_ARTW, CODEC_ARTb, CODEC_ARTw = 16, 17, 18, 19
@@ -442,3 +443,53 @@ class Ref:
         if rc != 0:
             raise RuntimeError("ref compress_many failed")
         return [o.raw[:l] for o, l in zip(outs, a_ol)], dt
+
+
+class CtxRef:
+    """the reference's OWN src/b250.c and src/dyn_int.c, compiled in place (oracle/Makefile target `ref`, oracle/ref_ctx_shim.c):
+    rows a2 / a5 / a3 / a7 of SURVEY 8(a) as the reference computes them. Exists only where /root/reference does."""
+
+    def __init__(self, path=CTXREF_SO):
+        L = self.L = ctypes.CDLL(path)
+        vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
+        L.ctxref_b250_seg.restype = ctypes.c_long
+        L.ctxref_b250_seg.argtypes = [vp, u32, u32, vp, ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_int)]
+        L.ctxref_b250_generate.restype = ctypes.c_long
+        L.ctxref_b250_generate.argtypes = [ctypes.c_char_p, u32, u64, ctypes.c_int, u32, vp, u32, vp]
+        L.ctxref_dyn_int_column.argtypes = [vp, vp, u64, ctypes.c_int, vp, ctypes.POINTER(u64)]
+        L.ctxref_dyn_int_transpose.argtypes = [ctypes.c_int, ctypes.c_char_p, u64, u32, vp]
+
+    @staticmethod
+    def available():
+        return os.path.exists(CTXREF_SO)
+
+    def b250_seg(self, node_indices, ol_nodes_len):
+        """-> (seg-format bytes, count, all_the_same) after b250_seg_append of every node index"""
+        import numpy as np
+        ni = np.ascontiguousarray(node_indices, dtype=np.int32)
+        out = np.zeros(4 * len(ni) + 16, dtype=np.uint8)
+        cnt, ats = ctypes.c_uint64(), ctypes.c_int()
+        n = self.L.ctxref_b250_seg(ni.ctypes.data, len(ni), ol_nodes_len, out.ctypes.data, ctypes.byref(cnt), ctypes.byref(ats))
+        return out[:n].tobytes(), cnt.value, bool(ats.value)
+
+    def b250_generate(self, seg, count, all_the_same, ol_nodes_len, node2word):
+        import numpy as np
+        n2w = np.ascontiguousarray(list(node2word) or [0], dtype=np.int32)
+        out = np.zeros(len(seg) + 16, dtype=np.uint8)
+        n = self.L.ctxref_b250_generate(bytes(seg), len(seg), count, int(all_the_same), ol_nodes_len, n2w.ctypes.data, len(node2word), out.ctypes.data)
+        return out[:n].tobytes()
+
+    def dyn_int_column(self, values, is_nothing=None, nothing_char=0):
+        import numpy as np
+        v = np.ascontiguousarray(values, dtype=np.int64)
+        m = None if is_nothing is None else np.ascontiguousarray(is_nothing, dtype=np.uint8)
+        out = np.zeros(8 * len(v) + 16, dtype=np.uint8)
+        ln = ctypes.c_uint64()
+        lt = self.L.ctxref_dyn_int_column(v.ctypes.data, m.ctypes.data if m is not None else None, len(v), nothing_char, out.ctypes.data, ctypes.byref(ln))
+        return lt, out[:ln.value].tobytes()
+
+    def dyn_int_transpose(self, ltype, data_file_order, n_elems, cols):
+        import numpy as np
+        out = np.zeros(len(data_file_order) + 16, dtype=np.uint8)
+        lt = self.L.ctxref_dyn_int_transpose(ltype, bytes(data_file_order), n_elems, cols, out.ctypes.data)
+        return lt, out[:len(data_file_order)].tobytes()

@@ -1,0 +1,164 @@
+/* oracle/ref_ctx_shim.c -- TEST INFRASTRUCTURE ONLY (see oracle/Makefile, target "ref").
+ *
+ * Compiled together with the reference's own src/b250.c and src/dyn_int.c WHERE THEY LIE under /root/reference (never
+ * copied) into oracle/_ref/libctxref.so, against the reference's own headers (-iquote): what b250_seg_append,
+ * b250_zip_generate, dyn_int_append and dyn_int_transpose (rows a3, a7) do to a Context is then the
+ * reference's own code running, and tests/golden/ctx_golden.json is generated from it (tests/golden/make_ctx_golden.py).
+ *
+ * This file supplies (a) the ~25 symbols those two objects import from the rest of the reference - allocation of a Buffer,
+ * the global option structs (all zero = defaults), diagnostics - as plain stand-ins written here, and (b) small entry
+ * points with plain-C signatures that build a VBlock / Context by hand (zeroed, the few fields the functions read set
+ * explicitly), call the reference's functions and hand the buffers back. Nothing here is product code.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdarg.h>
+#include <string.h>
+#include "genozip.h"
+#include "vblock.h"
+#include "context.h"
+#include "buffer.h"
+#include "flags.h"
+#include "segconf.h"
+#include "file.h"
+#include "b250.h"
+#include "dyn_int.h"
+#include "local_type.h"
+#include "data_types.h"
+#include "seg.h"
+#include "strings.h"
+#include "profiler.h"
+
+/* ---- (a) what b250.o / dyn_int.o import -------------------------------------------------------------------------------- */
+Flags flag;
+SegConf segconf;
+FileP txt_file, z_file;
+FILE *info_stream;
+CommandType primary_command = ZIP;
+FileMode READ = "rb", WRITE = "wb", WRITEREAD = "wb+";
+/* the PIZ-side converters the local-type table points at are never called here */
+#define NEVER(f) void f (BufferP buf, LocalType *lt) { abort (); }
+NEVER (BGEN_u8_buf) NEVER (BGEN_u16_buf) NEVER (BGEN_u32_buf) NEVER (BGEN_u64_buf)
+NEVER (BGEN_deinterlace_d8_buf) NEVER (BGEN_deinterlace_d16_buf) NEVER (BGEN_deinterlace_d32_buf) NEVER (BGEN_deinterlace_d64_buf)
+NEVER (BGEN_transpose_u8_buf) NEVER (BGEN_transpose_u16_buf) NEVER (BGEN_transpose_u32_buf)
+NEVER (BGEN_ptranspose_u8_buf) NEVER (BGEN_ptranspose_u16_buf) NEVER (BGEN_ptranspose_u32_buf)
+const LocalTypeDesc lt_desc[NUM_LOCAL_TYPES] = LOCALTYPE_DESC;
+DataTypeProperties dt_props[NUM_DATATYPES], dt_props_def;
+static uint32_t shim_num_samples;
+__attribute__((constructor)) static void shim_defaults (void) { flag.show_time_comp_i = COMP_NONE; flag.command = ZIP; }   /* --show-time off (flags.c default); we are genozip, not genounzip */
+
+void buf_alloc_do (VBlockP vb, BufferP buf, uint64_t requested_size, float grow_at_least_factor, rom name, FUNCLINE)
+{
+    if (buf->size >= requested_size && buf->data) return;
+    uint64_t sz = requested_size * (grow_at_least_factor > 1 ? grow_at_least_factor : 1) + 64;
+    char *m = realloc (buf->memory, sz + 16);
+    if (!m) abort ();
+    buf->memory = m; buf->data = m + 8; buf->size = sz; buf->vb = vb; buf->name = name; buf->type = BUF_REGULAR;
+}
+void buf_free_do (BufferP buf, FUNCLINE) { buf->len = 0; buf->param = 0; }
+void buf_copy_do (VBlockP dst_vb, BufferP dst, ConstBufferP src, uint64_t bytes_per_entry, uint64_t src_start_entry, uint64_t max_entries, FUNCLINE, rom dst_name)
+{
+    if (!bytes_per_entry) bytes_per_entry = 1;
+    uint64_t n = src->len - src_start_entry;
+    if (max_entries && n > max_entries) n = max_entries;
+    buf_alloc_do (dst_vb, dst, n * bytes_per_entry, 1, dst_name, func, code_line);
+    memcpy (dst->data, src->data + src_start_entry * bytes_per_entry, n * bytes_per_entry);
+    dst->len = n;
+}
+const BufDescType buf_desc (ConstBufferP buf) { BufDescType d = {}; return d; }
+void error_assert_failed (rom func, uint32_t line, rom fmt, ...) { va_list a; va_start (a, fmt); fprintf (stderr, "reference ASSERT in %s:%u: ", func, line); vfprintf (stderr, fmt, a); fprintf (stderr, "\n"); va_end (a); abort (); }
+void error_assertinp_failed (rom fmt, ...) { va_list a; va_start (a, fmt); vfprintf (stderr, fmt, a); va_end (a); abort (); }
+Codec codec_assign_best_codec (VBlockP vb, ContextP ctx, BufferP data, SectionType st) { return CODEC_UNKNOWN; }
+void ctx_decrement_count (VBlockP vb, ContextP ctx, WordIndex node_index) {}
+bool fastq_zip_use_pair_identical (DictId dict_id) { return false; }
+bool is_fastq_pair_2 (VBlockP vb) { return false; }
+StrText vb_name (VBlockP vb) { StrText s = { "shim" }; return s; }
+StrText line_name (VBlockP vb) { StrText s = { "shim" }; return s; }
+rom lt_name (LocalType lt) { return "lt"; }
+rom store_type_name (StoreType st) { return "store"; }
+StrText1K str_time (void) { StrText1K s = {}; return s; }
+StrText1K str_str_s_ (rom label, STRp(str)) { StrText1K s = {}; return s; }
+StrText1K seg_error (VBlockP vb) { StrText1K s = {}; return s; }
+StrText char_to_printable (char c) { StrText s = {}; s.s[0] = c; return s; }
+void show_time_one (VBlockP vb, rom res, uint64_t delta) {}
+uint32_t vcf_header_get_num_samples (void) { return shim_num_samples; }
+
+/* ---- (b) entry points --------------------------------------------------------------------------------------------------- */
+static VBlockP new_vb (void)
+{
+    VBlockP vb = calloc (1, sizeof (VBlock));
+    vb->data_type = DT_FASTQ; vb->vblock_i = 2;
+    return vb;
+}
+static void free_ctx (ContextP c) { free (c->b250.memory); free (c->local.memory); free (c->nodes.memory); free (c); }
+
+/* b250_seg_append (src/b250.c:112) for every node index in turn. Returns the byte length; *count / *all_the_same as the context holds them */
+long ctxref_b250_seg (const int32_t *node_index, uint32_t n, uint32_t ol_len, uint8_t *out, uint64_t *count, int *all_the_same)
+{
+    VBlockP vb = new_vb ();
+    ContextP ctx = calloc (1, sizeof (Context));
+    ctx->dict_id.num = 0x1234; ctx->ol_nodes.len32 = ol_len; ctx->flags.all_the_same = false;
+    for (uint32_t i = 0; i < n; i++) b250_seg_append (vb, ctx, node_index[i]);
+    const long len = (long)ctx->b250.len;
+    if (len) memcpy (out, ctx->b250.data, len);
+    *count = ctx->b250.count; *all_the_same = ctx->flags.all_the_same;
+    free_ctx (ctx); free (vb);
+    return len;
+}
+
+/* b250_zip_generate (src/b250.c:202) on a seg-format buffer. nodes = the VBlock's nodes after the merge (word indices). Returns the length */
+long ctxref_b250_generate (const uint8_t *seg, uint32_t seg_len, uint64_t count, int all_the_same, uint32_t ol_len,
+                           const int32_t *node2word, uint32_t n_new, uint8_t *out)
+{
+    VBlockP vb = new_vb ();
+    ContextP ctx = calloc (1, sizeof (Context));
+    ctx->dict_id.num = 0x1234; ctx->ol_nodes.len32 = ol_len; ctx->nodes_converted = true; ctx->flags.all_the_same = all_the_same;
+    buf_alloc_do (vb, &ctx->b250, seg_len + 8, 1, "b250", __FUNCTION__, __LINE__);
+    memcpy (ctx->b250.data, seg, seg_len); ctx->b250.len = seg_len; ctx->b250.count = count;
+    buf_alloc_do (vb, &ctx->nodes, (uint64_t)(n_new + 1) * sizeof (CtxNode), 1, "nodes", __FUNCTION__, __LINE__);
+    memcpy (ctx->nodes.data, node2word, (size_t)n_new * 4); ctx->nodes.len = n_new;
+    (void)b250_zip_generate (vb, ctx);
+    const long len = (long)ctx->b250.len;
+    if (len) memcpy (out, ctx->b250.data, len);
+    ctx->b250.data = ctx->b250.memory + 8;            /* (the function shifts the start of the buffer) */
+    free_ctx (ctx); free (vb);
+    return len;
+}
+
+/* dyn_int_append (src/dyn_int.c:304) / dyn_int_append_nothing_char (:324) for a column, then the final type (dyn_int_get_ltype :27).
+ * Returns the ltype; *len = bytes in out (native little endian) */
+int ctxref_dyn_int_column (const int64_t *values, const uint8_t *is_nothing, uint64_t n, int nothing_char, uint8_t *out, uint64_t *len)
+{
+    VBlockP vb = new_vb ();
+    ContextP ctx = calloc (1, sizeof (Context));
+    ctx->dict_id.num = 0x1234; ctx->ltype = LT_DYN_INT; ctx->nothing_char = (char)nothing_char;
+    for (uint64_t i = 0; i < n; i++)
+        if (is_nothing && is_nothing[i]) dyn_int_append_nothing_char (vb, ctx, 0);
+        else dyn_int_append (vb, ctx, values[i], 0);
+    const LocalType lt = n ? dyn_int_get_ltype (ctx) : LT_UINT8;
+    *len = ctx->local.len * lt_width (ctx) * 0 + ctx->local.len * lt_desc[lt].width;
+    if (*len) memcpy (out, ctx->local.data, *len);
+    free_ctx (ctx); free (vb);
+    return (int)lt;
+}
+
+/* dyn_int_transpose (src/dyn_int.c:45), full matrix: data = rows x cols elements of `ltype` (LT_UINT8/16/32) already in file byte
+ * order (zip_generate_local orders before it transposes, src/zip.c:185-219). Returns the resulting ltype */
+int ctxref_dyn_int_transpose (int ltype, const uint8_t *data, uint64_t n_elems, uint32_t cols, uint8_t *out)
+{
+    VBlockP vb = new_vb ();
+    vb->data_type = DT_VCF;
+    ContextP ctxs = calloc (MAX_DICTS, sizeof (Context));      /* (the function looks at CTX(VCF_COPY_SAMPLE)) */
+    memcpy (&vb->ca.contexts, &ctxs, 0);                        /* no-op: contexts live inside the VBlock */
+    ContextP ctx = &vb->ca.contexts[200];
+    ctx->dict_id.num = 0x1234; ctx->ltype = (LocalType)ltype; ctx->dyn_transposed = true;
+    const unsigned w = lt_desc[ltype].width;
+    buf_alloc_do (vb, &ctx->local, n_elems * w + 8, 1, "local", __FUNCTION__, __LINE__);
+    memcpy (ctx->local.data, data, n_elems * w); ctx->local.len = n_elems;
+    if (cols <= 255) ctx->local.n_cols = cols; else { ctx->local.n_cols = 0; shim_num_samples = cols; }
+    dyn_int_transpose (vb, ctx);
+    memcpy (out, ctx->local.data, n_elems * w);
+    const int lt = ctx->ltype;
+    free (ctx->local.memory); free (vb->scratch.memory); free (ctxs); free (vb);
+    return lt;
+}

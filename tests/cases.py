@@ -72,3 +72,40 @@ def b250_case(seed, n_entries, ol_nodes, n_new, specials=True):
     n2w = (synth.u32(seed + 1, max(1, n_new)) % np.uint32(max(1, total + 50))).astype(np.int64)
     # make some new nodes map to "previous word + 1" so that converted neighbours trigger ONE_UP
     return [int(x) for x in ni], [int(x) for x in n2w[:n_new]]
+
+
+# ---- cases of tests/golden/ctx_golden.json (generated from the reference's own b250.c / dyn_int.c) ------------------------
+def b250_ctx_case(seed, n_entries, ol_nodes, n_new, all_the_same):
+    """node indices of a column (old: < ol_nodes, new: ol_nodes .. ol_nodes + n_new - 1, some EMPTY / MISSING, planted runs) and
+    the word index every new node gets in the merge"""
+    ni, n2w = b250_case(seed, n_entries, ol_nodes, n_new, True)
+    if all_the_same:
+        ni = [ni[0]] * n_entries
+    n2w = [int(x) % (ol_nodes + n_new + 40) for x in n2w]
+    return ni, n2w
+
+
+def dyn_int_cases():
+    r = synth.u32(5, 4000).astype(np.int64)
+    return [(r[:1000] % 200, None, 0), (r[:1000] % 256, None, 0), (r[:1000] % 256, None, 46), (r[:1000] % 300 - 20, None, 0), (r[:1000] % 100 - 50, None, 0),
+            (r[:1000] % 70000, None, 0), (r[:1000] % 70000 - 5, None, 0), ((r[:777] << 3), None, 0), ((r[:500] << 3) - (1 << 34), None, 0),
+            (r[:100] * 123456789 - (1 << 50), None, 0), (r[:1000] % 255, (r[:1000] % 7 == 0).astype(np.uint8), 46),
+            (np.concatenate([[5], r[1:300] % 100 - 1]), np.concatenate([[1], np.zeros(299)]).astype(np.uint8), 46),
+            (np.concatenate([[5], r[1:300] % 100]), np.concatenate([[1], np.zeros(299)]).astype(np.uint8), 46),
+            (np.zeros(50, dtype=np.int64), np.ones(50, dtype=np.uint8), 46), (np.array([65535]), None, 46), (np.array([127, -128]), None, 0),
+            (np.array([0, 4294967295]), None, 0), (np.array([0, 4294967295]), None, 46), (np.array([-1, 2147483647]), None, 0)]
+
+
+TRANSPOSE_CASES = [(2, 1, 37, 50), (4, 2, 64, 255), (6, 4, 31, 300), (2, 1, 300, 1000), (2, 1, 1, 7), (4, 2, 9, 1)]
+
+
+def ctx_golden():
+    with open(os.path.join(HERE, "golden", "ctx_golden.json")) as f:
+        return json.load(f)
+
+
+def check_enc(got, want, what):
+    if "hex" in want:
+        assert got.hex() == want["hex"], what
+    else:
+        assert len(got) == want["len"] and hashlib.sha1(got).hexdigest() == want["sha1"], what

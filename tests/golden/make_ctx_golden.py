@@ -1,0 +1,52 @@
+"""TEST INFRASTRUCTURE: generates tests/golden/ctx_golden.json from the REFERENCE'S OWN src/b250.c and src/dyn_int.c, compiled in
+place by `make -C oracle ref` (oracle/_ref/libctxref.so, oracle/ref_ctx_shim.c) - rows a2 / a5 (b250_seg_append,
+b250_zip_generate) and a3 / a7 (dyn_int_append, dyn_int_transpose) of SURVEY 8(a). Only runs where /root/reference exists; the
+vectors (generator parameters + outputs as hex or sha1) are committed, the reference is not.
+
+    python tests/golden/make_ctx_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import cases          # noqa: E402
+import pyoracle       # noqa: E402
+from genozip_amd import synth   # noqa: E402
+
+
+def enc(b):
+    return {"hex": b.hex()} if len(b) <= 96 else {"sha1": hashlib.sha1(b).hexdigest(), "len": len(b)}
+
+
+def main():
+    R = pyoracle.CtxRef()
+    out = {"b250": [], "dyn_int": [], "transpose": []}
+    for seed in range(60):
+        ne = [1, 2, 7, 300, 5000, 40000][seed % 6]
+        ol, nn = [(0, 5), (4, 0), (1500, 700), (17000, 300), (2200000, 10), (900, 200)][seed // 10]
+        ats = seed % 7 == 0
+        ni, n2w = cases.b250_ctx_case(seed, ne, ol, nn, ats)
+        seg, cnt, flag = R.b250_seg(ni, ol)
+        gen = R.b250_generate(seg, cnt, flag, ol, n2w)
+        out["b250"].append({"seed": seed, "n": ne, "ol": ol, "n_new": nn, "ats": ats, "seg": enc(seg), "count": cnt, "all_the_same": flag, "piz": enc(gen)})
+    for i, (vals, isn, nc) in enumerate(cases.dyn_int_cases()):
+        lt, raw = R.dyn_int_column(vals, isn, nc)
+        out["dyn_int"].append({"case": i, "ltype": lt, "raw": enc(raw)})
+    for (lt, w, rows, cols) in cases.TRANSPOSE_CASES:
+        raw = synth.uniform_bytes(9 + rows, rows * cols * w, 256).tobytes()
+        lt2, tr = R.dyn_int_transpose(lt, raw, rows * cols, cols)
+        out["transpose"].append({"ltype": lt, "w": w, "rows": rows, "cols": cols, "ltype_out": lt2, "out": enc(tr)})
+    with open(os.path.join(HERE, "ctx_golden.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("wrote", {k: len(v) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -857,3 +857,64 @@ def _first_diff(a, b):
         if a[i] != b[i]:
             return i
     return n
+
+
+def ctx_golden(E, oracle):
+    """rows a2 / a5 / a3 / a7 against the vectors generated from the REFERENCE'S OWN src/b250.c and src/dyn_int.c
+    (tests/golden/ctx_golden.json, made by tests/golden/make_ctx_golden.py from oracle/_ref/libctxref.so): E = the product
+    (GPU or emulated) or None for the oracle alone"""
+    G = cases.ctx_golden()
+    for c in G["b250"]:
+        ni, n2w = cases.b250_ctx_case(c["seed"], c["n"], c["ol"], c["n_new"], c["ats"])
+        what = ("b250", c["seed"])
+        # a2: b250_seg_append over the column - the oracle's seg-format bytes with the all-the-same collapse
+        seg = oracle.b250_seg(ni[:1] if c["all_the_same"] else ni, c["ol"])
+        cases.check_enc(seg, c["seg"], what)
+        assert c["count"] == len(ni)
+        cases.check_enc(oracle.b250_generate(seg, c["ol"], n2w), c["piz"], what)
+        if E is not None:
+            cases.check_enc(E.b250_generate(seg, c["ol"], n2w), c["piz"], what)
+    if E is not None:        # the product's seg side on the same node sequences: snips "w<node>" against a cloned dictionary
+        for c in G["b250"][:40]:
+            ni, _ = cases.b250_ctx_case(c["seed"], c["n"], c["ol"], c["n_new"], c["ats"])
+            if c["ol"] > 20000 or any(v >= c["ol"] for v in ni if v >= 0) and not _first_occurrence_order(ni, c["ol"]):
+                continue
+            snips = [None if v == -4 else b"" if v == -3 else b"w%d" % v for v in ni]
+            t, o, l = _snip_column(snips)
+            col = E.ctx_seg_column(t, o, l, [b"w%d" % k for k in range(c["ol"])])
+            cases.check_enc(col["b250"], c["seg"], ("seg", c["seed"]))
+            assert col["b250_count"] == c["count"] and col["all_the_same"] == c["all_the_same"]
+    for c, (vals, isn, nc) in zip(G["dyn_int"], cases.dyn_int_cases()):
+        lt, raw = oracle.dyn_int_column(vals, isn, nc)
+        assert lt == c["ltype"], ("dyn", c["case"])
+        cases.check_enc(raw, c["raw"], ("dyn", c["case"]))
+        if E is not None:
+            glt, graw = E.dyn_int_column(vals, isn, nc)
+            assert glt == c["ltype"]
+            cases.check_enc(graw, c["raw"], ("dyn gpu", c["case"]))
+    for c in G["transpose"]:
+        raw = synth.uniform_bytes(9 + c["rows"], c["rows"] * c["cols"] * c["w"], 256).tobytes()
+        # the vectors were made from bytes already in file order: feed 1-byte elements so that no byte order step applies
+        tr = np.frombuffer(raw, dtype="V%d" % c["w"]).reshape(c["rows"], c["cols"]).T.tobytes()
+        cases.check_enc(tr, c["out"], ("transpose numpy", c["rows"]))
+        assert c["ltype_out"] == {2: 14, 4: 15, 6: 16}[c["ltype"]]
+        be = np.frombuffer(raw, dtype=">u%d" % c["w"]).astype("<u%d" % c["w"]).tobytes()      # native values whose file order is `raw`
+        lt, got = oracle.local_generate(c["ltype"], be, c["cols"])
+        assert lt == c["ltype_out"]
+        cases.check_enc(got, c["out"], ("transpose oracle", c["rows"]))
+        if E is not None:
+            lt, got = E.local_generate(c["ltype"], be, c["cols"])
+            assert lt == c["ltype_out"]
+            cases.check_enc(got, c["out"], ("transpose gpu", c["rows"]))
+
+
+def _first_occurrence_order(ni, ol):
+    """new nodes must appear in order ol, ol+1, ... for a column of snips to reproduce the node sequence"""
+    nxt = ol
+    for v in ni:
+        if v >= ol:
+            if v > nxt:
+                return False
+            if v == nxt:
+                nxt += 1
+    return True

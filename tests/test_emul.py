@@ -99,3 +99,7 @@ def test_emul_merge_chain(emul_engine, oracle):
 
 def test_emul_fastq_zip(emul_engine, oracle):
     parity.fastq_zip(emul_engine, oracle, 400)
+
+
+def test_emul_ctx_golden(emul_engine, oracle):
+    parity.ctx_golden(emul_engine, oracle)

@@ -115,6 +115,12 @@ def test_c_host_program():
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
 
 
+def test_ctx_golden_vectors(gpu_engine, oracle):
+    """b250 seg append / generation, dyn-int columns and the matrix transpose against vectors made from the reference's own
+    src/b250.c and src/dyn_int.c (tests/golden/ctx_golden.json)"""
+    parity.ctx_golden(gpu_engine, oracle)
+
+
 def test_merge_chain(gpu_engine, oracle):
     """seg columns -> host dictionary merge (a4) -> b250 generation over VBlocks that share dictionaries"""
     parity.merge_chain(gpu_engine, oracle, 46000)

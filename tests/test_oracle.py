@@ -182,3 +182,41 @@ def test_seg_column_kats(oracle):
     nb, io, il = oracle.tokenize_column(t, cols[0][0], cols[0][1], b": ")
     assert nb == 0 and io.tolist() == [[1, 22], [4, 25], [6, 27]] and il.tolist() == [[2, 2], [1, 1], [1, 1]]
     assert oracle.fastq_records(t.replace(b"\n+r2", b"\n-r2"), lo, ll)[0] == -2
+
+
+def test_ctx_golden_vectors(oracle):
+    """the oracle's b250_seg_append / b250_zip_generate / dyn_int_append / dyn_int_transpose == the vectors generated from
+    the reference's own src/b250.c and src/dyn_int.c (tests/golden/ctx_golden.json): rows a2, a3, a5, a7 PINNED"""
+    import parity
+    parity.ctx_golden(None, oracle)
+
+
+def test_against_ctx_reference_build(oracle):
+    """where /root/reference exists: the oracle against the reference's own b250.c / dyn_int.c compiled in place, on fresh
+    random cases beyond the committed vectors"""
+    import os
+    import numpy as np
+    import pytest
+    import cases
+    import pyoracle
+    from genozip_amd import synth
+    if not pyoracle.CtxRef.available():
+        if os.path.isfile("/root/reference/src/b250.c"):
+            pyoracle.build(ref=True)
+        else:
+            pytest.skip("oracle/_ref/libctxref.so not built (reference sources absent)")
+    R = pyoracle.CtxRef()
+    for seed in range(1000, 1120):
+        ne = [1, 3, 50, 2000, 20000][seed % 5]
+        ol, nn = [(0, 9), (100, 0), (1500, 700), (17000, 300), (2200000, 10), (1000, 30)][seed % 6]
+        ni, n2w = cases.b250_ctx_case(seed, ne, ol, nn, seed % 11 == 0)
+        seg, cnt, ats = R.b250_seg(ni, ol)
+        assert seg == oracle.b250_seg(ni[:1] if ats else ni, ol) and cnt == len(ni), seed
+        assert R.b250_generate(seg, cnt, ats, ol, n2w) == oracle.b250_generate(seg, ol, n2w), seed
+    r = synth.u32(77, 30000).astype(np.int64)
+    for k in range(60):
+        n = [1, 2, 50, 400][k % 4]
+        v = (r[k * 400:k * 400 + n] % [200, 300, 70000, 1 << 33, 1 << 40][k % 5]) - [0, 0, 100, 40000, 1 << 35][(k // 5) % 5]
+        isn = (r[k * 400 + 1:k * 400 + 1 + n] % 5 == 0).astype(np.uint8) if k % 3 == 0 else None
+        nc = 46 if k % 3 == 0 else 0
+        assert R.dyn_int_column(v, isn, nc) == oracle.dyn_int_column(v, isn, nc), k
