@@ -458,6 +458,8 @@ class CtxRef:
         L.ctxref_b250_generate.argtypes = [ctypes.c_char_p, u32, u64, ctypes.c_int, u32, vp, u32, vp]
         L.ctxref_dyn_int_column.argtypes = [vp, vp, u64, ctypes.c_int, vp, ctypes.POINTER(u64)]
         L.ctxref_dyn_int_transpose.argtypes = [ctypes.c_int, ctypes.c_char_p, u64, u32, vp]
+        L.ctxref_local_to_file_order.argtypes = [ctypes.c_int, vp, u64]
+        L.ctxref_local_to_native.argtypes = [ctypes.c_int, vp, u64, u32]
 
     @staticmethod
     def available():
@@ -493,3 +495,17 @@ class CtxRef:
         out = np.zeros(len(data_file_order) + 16, dtype=np.uint8)
         lt = self.L.ctxref_dyn_int_transpose(ltype, bytes(data_file_order), n_elems, cols, out.ctypes.data)
         return lt, out[:len(data_file_order)].tobytes()
+
+    def local_to_file_order(self, ltype, raw_native_le, width):
+        """zip_generate_local's byte-order step with the reference's own converters (src/buffer.c:336-350)"""
+        import numpy as np
+        a = np.frombuffer(bytes(raw_native_le), dtype=np.uint8).copy()
+        self.L.ctxref_local_to_file_order(ltype, a.ctypes.data, len(a) // width)
+        return a.tobytes()
+
+    def local_to_native(self, ltype, file_bytes, width, cols=0):
+        """lt_desc[ltype].file_to_native (src/local_type.h:75-108) -> (resulting ltype, native bytes)"""
+        import numpy as np
+        a = np.frombuffer(bytes(file_bytes), dtype=np.uint8).copy()
+        lt = self.L.ctxref_local_to_native(ltype, a.ctypes.data, len(a) // width, cols)
+        return lt, a.tobytes()

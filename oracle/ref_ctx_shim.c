@@ -28,6 +28,7 @@
 #include "seg.h"
 #include "strings.h"
 #include "profiler.h"
+#include "bits.h"
 
 /* ---- (a) what b250.o / dyn_int.o import -------------------------------------------------------------------------------- */
 Flags flag;
@@ -36,16 +37,10 @@ FileP txt_file, z_file;
 FILE *info_stream;
 CommandType primary_command = ZIP;
 FileMode READ = "rb", WRITE = "wb", WRITEREAD = "wb+";
-/* the PIZ-side converters the local-type table points at are never called here */
-#define NEVER(f) void f (BufferP buf, LocalType *lt) { abort (); }
-NEVER (BGEN_u8_buf) NEVER (BGEN_u16_buf) NEVER (BGEN_u32_buf) NEVER (BGEN_u64_buf)
-NEVER (BGEN_deinterlace_d8_buf) NEVER (BGEN_deinterlace_d16_buf) NEVER (BGEN_deinterlace_d32_buf) NEVER (BGEN_deinterlace_d64_buf)
-NEVER (BGEN_transpose_u8_buf) NEVER (BGEN_transpose_u16_buf) NEVER (BGEN_transpose_u32_buf)
-NEVER (BGEN_ptranspose_u8_buf) NEVER (BGEN_ptranspose_u16_buf) NEVER (BGEN_ptranspose_u32_buf)
 const LocalTypeDesc lt_desc[NUM_LOCAL_TYPES] = LOCALTYPE_DESC;
 DataTypeProperties dt_props[NUM_DATATYPES], dt_props_def;
 static uint32_t shim_num_samples;
-__attribute__((constructor)) static void shim_defaults (void) { flag.show_time_comp_i = COMP_NONE; flag.command = ZIP; }   /* --show-time off (flags.c default); we are genozip, not genounzip */
+__attribute__((constructor)) static void shim_defaults (void) { flag.show_time_comp_i = COMP_NONE; flag.command = ZIP; flag.is_lten = true; }   /* --show-time off (flags.c default); we are genozip, not genounzip */
 
 void buf_alloc_do (VBlockP vb, BufferP buf, uint64_t requested_size, float grow_at_least_factor, rom name, FUNCLINE)
 {
@@ -56,15 +51,17 @@ void buf_alloc_do (VBlockP vb, BufferP buf, uint64_t requested_size, float grow_
     buf->memory = m; buf->data = m + 8; buf->size = sz; buf->vb = vb; buf->name = name; buf->type = BUF_REGULAR;
 }
 void buf_free_do (BufferP buf, FUNCLINE) { buf->len = 0; buf->param = 0; }
-void buf_copy_do (VBlockP dst_vb, BufferP dst, ConstBufferP src, uint64_t bytes_per_entry, uint64_t src_start_entry, uint64_t max_entries, FUNCLINE, rom dst_name)
-{
-    if (!bytes_per_entry) bytes_per_entry = 1;
-    uint64_t n = src->len - src_start_entry;
-    if (max_entries && n > max_entries) n = max_entries;
-    buf_alloc_do (dst_vb, dst, n * bytes_per_entry, 1, dst_name, func, code_line);
-    memcpy (dst->data, src->data + src_start_entry * bytes_per_entry, n * bytes_per_entry);
-    dst->len = n;
-}
+/* src/buffer.c (compiled in place for its byte order / interlace / transpose functions) imports a few more */
+VBlockP evb;
+uint64_t buf_mem_size (ConstBufferP buf) { return buf->size; }
+void buf_overlay_do (VBlockP vb, BufferP top_buf, BufferP bottom_buf, uint64_t start_in_bottom, bool copy_len, FUNCLINE, rom name) { abort (); }
+rom buf_type_name (ConstBufferP buf) { return "buf"; }
+void bits_clear_region_do (BitsP bits, uint64_t start, uint64_t len, FUNCLINE) { abort (); }
+void bits_set_region (BitsP bits, uint64_t start, uint64_t len) { abort (); }
+bool file_put_data (rom filename, const void *data, uint64_t len, mode_t mode) { return false; }
+void file_gzip (char *filename) {}
+void warn (rom fmt, ...) {}
+/* (buf_copy_do is the reference's own: src/buffer.c) */
 const BufDescType buf_desc (ConstBufferP buf) { BufDescType d = {}; return d; }
 void error_assert_failed (rom func, uint32_t line, rom fmt, ...) { va_list a; va_start (a, fmt); fprintf (stderr, "reference ASSERT in %s:%u: ", func, line); vfprintf (stderr, fmt, a); fprintf (stderr, "\n"); va_end (a); abort (); }
 void error_assertinp_failed (rom fmt, ...) { va_list a; va_start (a, fmt); vfprintf (stderr, fmt, a); va_end (a); abort (); }
@@ -161,4 +158,37 @@ int ctxref_dyn_int_transpose (int ltype, const uint8_t *data, uint64_t n_elems, 
     const int lt = ctx->ltype;
     free (ctx->local.memory); free (vb->scratch.memory); free (ctxs); free (vb);
     return lt;
+}
+
+/* zip_generate_local's byte-order step (src/zip.c:178-216) with the reference's own converters (src/buffer.c:336-350): in place,
+ * n elements of `ltype`, native little endian -> file order */
+void ctxref_local_to_file_order (int ltype, uint8_t *data, uint64_t n)
+{
+    Buffer b = {}; b.data = (char *)data; b.len = n; b.size = n * 8;
+    switch (ltype) {
+        case LT_UINT32 : case LT_FLOAT32 : BGEN_u32_buf (&b, NULL); break;
+        case LT_UINT16 : BGEN_u16_buf (&b, NULL); break;
+        case LT_UINT64 : case LT_FLOAT64 : BGEN_u64_buf (&b, NULL); break;
+        case LT_INT8   : interlace_d8_buf (&b, NULL); break;
+        case LT_INT16  : BGEN_interlace_d16_buf (&b, NULL); break;
+        case LT_INT32  : BGEN_interlace_d32_buf (&b, NULL); break;
+        case LT_INT64  : BGEN_interlace_d64_buf (&b, NULL); break;
+        default : break;
+    }
+}
+
+/* the PIZ side of a local type (lt_desc[ltype].file_to_native, src/local_type.h:75-108 as piz_adjust_one_local applies it,
+ * src/piz.c:219-245): in place; cols for the transposed types. Returns the resulting ltype */
+int ctxref_local_to_native (int ltype, uint8_t *data, uint64_t n, uint32_t cols)
+{
+    VBlockP vb = new_vb ();
+    Buffer b = {}; 
+    buf_alloc_do (vb, &b, n * 8 + 8, 1, "local", __FUNCTION__, __LINE__);
+    memcpy (b.data, data, n * lt_desc[ltype].width); b.len = n; b.vb = vb;
+    if (cols <= 255) b.n_cols = cols; else { b.n_cols = 0; shim_num_samples = cols; }
+    LocalType lt = (LocalType)ltype;
+    if (lt_desc[ltype].file_to_native) lt_desc[ltype].file_to_native (&b, &lt);
+    memcpy (data, b.data, n * lt_desc[ltype].width);
+    free (b.memory); free (vb->scratch.memory); free (vb);
+    return (int)lt;
 }

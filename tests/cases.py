@@ -99,6 +99,9 @@ def dyn_int_cases():
 TRANSPOSE_CASES = [(2, 1, 37, 50), (4, 2, 64, 255), (6, 4, 31, 300), (2, 1, 300, 1000), (2, 1, 1, 7), (4, 2, 9, 1)]
 
 
+LOCAL_ORDER_CASES = [(1, 1), (2, 1), (3, 2), (4, 2), (5, 4), (6, 4), (7, 8), (8, 8), (9, 4), (10, 8)]
+
+
 def ctx_golden():
     with open(os.path.join(HERE, "golden", "ctx_golden.json")) as f:
         return json.load(f)

@@ -27,7 +27,13 @@ def enc(b):
 
 def main():
     R = pyoracle.CtxRef()
-    out = {"b250": [], "dyn_int": [], "transpose": []}
+    out = {"b250": [], "dyn_int": [], "transpose": [], "local_order": []}
+    for lt, w in cases.LOCAL_ORDER_CASES:
+        raw = synth.uniform_bytes(40 + lt, 500 * w, 256).tobytes()
+        fo = R.local_to_file_order(lt, raw, w)
+        lt2, back = R.local_to_native(lt, fo, w)
+        assert back == raw and lt2 == lt
+        out["local_order"].append({"ltype": lt, "w": w, "file": enc(fo)})
     for seed in range(60):
         ne = [1, 2, 7, 300, 5000, 40000][seed % 6]
         ol, nn = [(0, 5), (4, 0), (1500, 700), (17000, 300), (2200000, 10), (900, 200)][seed // 10]

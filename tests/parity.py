@@ -892,6 +892,13 @@ def ctx_golden(E, oracle):
             glt, graw = E.dyn_int_column(vals, isn, nc)
             assert glt == c["ltype"]
             cases.check_enc(graw, c["raw"], ("dyn gpu", c["case"]))
+    for c in G["local_order"]:                       # a6: byte order / interlace of every integer and float type
+        raw = synth.uniform_bytes(40 + c["ltype"], 500 * c["w"], 256).tobytes()
+        cases.check_enc(oracle.local_generate(c["ltype"], raw)[1], c["file"], ("order oracle", c["ltype"]))
+        if E is not None:
+            lt, fo = E.local_generate(c["ltype"], raw)
+            cases.check_enc(fo, c["file"], ("order gpu", c["ltype"]))
+            assert E.local_to_native(c["ltype"], fo)[1] == raw
     for c in G["transpose"]:
         raw = synth.uniform_bytes(9 + c["rows"], c["rows"] * c["cols"] * c["w"], 256).tobytes()
         # the vectors were made from bytes already in file order: feed 1-byte elements so that no byte order step applies
