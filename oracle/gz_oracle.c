@@ -1842,3 +1842,6 @@ void gzo_zctx_view (const GzoZctx *z, const uint8_t **dict, uint64_t *dict_len, 
     *dict = z->dict; *dict_len = z->dict_len; *n_words = z->n_nodes; *counts = z->counts; *n_failed = z->n_failed;
     *rm_dict = z->rm_dict && !z->override_rm;
 }
+
+/* exposed for the pinning tests: hash.h:30-52 */
+uint32_t gzo_hash_do (uint32_t hash_len, const uint8_t *snip, uint32_t snip_len) { return o_hash_do (hash_len, snip, snip_len); }

@@ -217,6 +217,7 @@ typedef struct {
     uint8_t *ston_local; uint64_t ston_len; uint32_t n_stons;   /* out: must hold the VBlock's dict length */
 } GzoMerge;
 uint32_t gzo_hash_next_size_up (uint64_t size);
+uint32_t gzo_hash_do (uint32_t hash_len, const uint8_t *snip, uint32_t snip_len);   /* hash.h:30-52 */
 GzoZctx *gzo_zctx_create (uint32_t estimated_entries);
 void gzo_zctx_destroy (GzoZctx *z);
 int gzo_ctx_merge (GzoZctx *z, GzoMerge *j);

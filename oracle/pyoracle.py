@@ -458,6 +458,8 @@ class CtxRef:
         L.ctxref_b250_generate.argtypes = [ctypes.c_char_p, u32, u64, ctypes.c_int, u32, vp, u32, vp]
         L.ctxref_dyn_int_column.argtypes = [vp, vp, u64, ctypes.c_int, vp, ctypes.POINTER(u64)]
         L.ctxref_dyn_int_transpose.argtypes = [ctypes.c_int, ctypes.c_char_p, u64, u32, vp]
+        L.ctxref_hash_do.restype = u32
+        L.ctxref_hash_do.argtypes = [u32, ctypes.c_char_p, u32]
         L.ctxref_local_to_file_order.argtypes = [ctypes.c_int, vp, u64]
         L.ctxref_local_to_native.argtypes = [ctypes.c_int, vp, u64, u32]
 
@@ -509,3 +511,6 @@ class CtxRef:
         a = np.frombuffer(bytes(file_bytes), dtype=np.uint8).copy()
         lt = self.L.ctxref_local_to_native(ltype, a.ctypes.data, len(a) // width, cols)
         return lt, a.tobytes()
+
+    def hash_do(self, hash_len, snip):
+        return self.L.ctxref_hash_do(hash_len, bytes(snip), len(snip))

@@ -29,6 +29,7 @@
 #include "strings.h"
 #include "profiler.h"
 #include "bits.h"
+#include "hash.h"
 
 /* ---- (a) what b250.o / dyn_int.o import -------------------------------------------------------------------------------- */
 Flags flag;
@@ -192,3 +193,6 @@ int ctxref_local_to_native (int ltype, uint8_t *data, uint64_t n, uint32_t cols)
     free (b.memory); free (vb->scratch.memory); free (vb);
     return (int)lt;
 }
+
+/* hash_do (src/hash.h:30-52, a static inline of the reference's header): the bucket of a snip */
+uint32_t ctxref_hash_do (uint32_t hash_len, const char *snip, uint32_t snip_len) { return hash_do (hash_len, snip, snip_len); }

@@ -99,6 +99,12 @@ def dyn_int_cases():
 TRANSPOSE_CASES = [(2, 1, 37, 50), (4, 2, 64, 255), (6, 4, 31, 300), (2, 1, 300, 1000), (2, 1, 1, 7), (4, 2, 9, 1)]
 
 
+def hash_cases():
+    r = synth.u32(91, 64)
+    snips = [b"", b"A", b"1101", b"A00123:45:HXXXXXXXX", b"\x01", b"x" * 300] + [synth.uniform_bytes(int(k), 1 + int(k) % 40, 256).tobytes() for k in r[:40]]
+    return [(hl, sn) for hl in (65521, 92681, 8388593) for sn in snips]
+
+
 LOCAL_ORDER_CASES = [(1, 1), (2, 1), (3, 2), (4, 2), (5, 4), (6, 4), (7, 8), (8, 8), (9, 4), (10, 8)]
 
 

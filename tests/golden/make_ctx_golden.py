@@ -28,6 +28,7 @@ def enc(b):
 def main():
     R = pyoracle.CtxRef()
     out = {"b250": [], "dyn_int": [], "transpose": [], "local_order": []}
+    out["hash_do"] = [{"hash_len": hl, "snip_hex": sn.hex(), "hash": R.hash_do(hl, sn)} for hl, sn in cases.hash_cases()]
     for lt, w in cases.LOCAL_ORDER_CASES:
         raw = synth.uniform_bytes(40 + lt, 500 * w, 256).tobytes()
         fo = R.local_to_file_order(lt, raw, w)

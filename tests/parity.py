@@ -892,6 +892,10 @@ def ctx_golden(E, oracle):
             glt, graw = E.dyn_int_column(vals, isn, nc)
             assert glt == c["ltype"]
             cases.check_enc(graw, c["raw"], ("dyn gpu", c["case"]))
+    for c in G["hash_do"]:                           # a1's hash: the bucket a snip falls in (it decides which singletons can meet)
+        sn = bytes.fromhex(c["snip_hex"])
+        oracle.L.gzo_hash_do.restype = __import__("ctypes").c_uint32
+        assert oracle.L.gzo_hash_do(c["hash_len"], sn, len(sn)) == c["hash"], ("hash_do", c["hash_len"], sn)
     for c in G["local_order"]:                       # a6: byte order / interlace of every integer and float type
         raw = synth.uniform_bytes(40 + c["ltype"], 500 * c["w"], 256).tobytes()
         cases.check_enc(oracle.local_generate(c["ltype"], raw)[1], c["file"], ("order oracle", c["ltype"]))
