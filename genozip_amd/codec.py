@@ -564,6 +564,39 @@ class Engine:
         self.sync()
         return [self.mem.download(ob, int(np.frombuffer(self.mem.download(rb, 8), dtype=np.uint64)[0])) for _, _, _, ob, rb in keep]
 
+    # ---- N3: CODEC_DOMQ's pre-transform -----------------------------------------------------------------------
+    def domq_columns(self, columns):
+        """columns: list of (text bytes, off, len) - the QUAL lines of a VBlock each -> list of dict(qual, runs, mplx, divr, denorm,
+        num_doms, num_norm_qs, has_diverse, all_diverse, fit)"""
+        import numpy as np
+        from .lib import GzDomqJob, GzDomqResult, GzDomqFitJob
+        nj = len(columns)
+        tab, ftab = (GzDomqJob * max(1, nj))(), (GzDomqFitJob * max(1, nj))()
+        keep = []
+        for i, (text, off, length) in enumerate(columns):
+            off = np.ascontiguousarray(off, dtype=np.uint32); length = np.ascontiguousarray(length, dtype=np.uint32)
+            B, n = int(length.astype(np.uint64).sum()), len(off)
+            b = dict(text=self.mem.upload(bytes(text) + b"\0"), off=self.mem.upload(off), len=self.mem.upload(length), qual=self.mem.alloc(2 * B + 16),
+                     runs=self.mem.alloc(B + B // 254 + 16), mplx=self.mem.alloc(n + 16), divr=self.mem.alloc(B + 16), res=self.mem.alloc(C.sizeof(GzDomqResult)), fit=self.mem.alloc(16))
+            keep.append(b)
+            j = tab[i]
+            j.text, j.off, j.len, j.n = self.mem.ptr(b["text"]), self.mem.ptr(b["off"]), self.mem.ptr(b["len"]), n
+            j.qual, j.runs, j.mplx, j.divr, j.result_dev = self.mem.ptr(b["qual"]), self.mem.ptr(b["runs"]), self.mem.ptr(b["mplx"]), self.mem.ptr(b["divr"]), self.mem.ptr(b["res"])
+            fj = ftab[i]
+            fj.text, fj.off, fj.len, fj.n, fj.fit_dev = j.text, j.off, j.len, n, self.mem.ptr(b["fit"])
+        self._check(self.L.gz_domq_fit(self.h, ftab, nj), "gz_domq_fit")
+        self._check(self.L.gz_domq_columns(self.h, tab, nj), "gz_domq_columns")
+        self.sync()
+        out = []
+        for b in keep:
+            r = GzDomqResult.from_buffer_copy(self.mem.download(b["res"], C.sizeof(GzDomqResult)))
+            if r.status != 1:
+                raise GenozipAMDError("gz_domq_columns: a quality score outside ' '..'~'")
+            out.append(dict(qual=self.mem.download(b["qual"], r.qual_len), runs=self.mem.download(b["runs"], r.runs_len), mplx=self.mem.download(b["mplx"], r.mplx_len),
+                            divr=self.mem.download(b["divr"], r.divr_len), denorm=bytes(r.denorm[:r.num_doms * r.num_norm_qs]), num_doms=r.num_doms, num_norm_qs=r.num_norm_qs,
+                            has_diverse=bool(r.has_diverse), all_diverse=bool(r.all_diverse), fit=bool(np.frombuffer(self.mem.download(b["fit"], 4), dtype=np.uint32)[0])))
+        return out
+
     # ---- N1 (first part): lines, FASTQ records, tokens ----------------------------------------------------
     def text_lines(self, text, cap=None, on_device=False):
         """seg_get_next_line over the whole buffer -> (line_off, line_len) numpy arrays (or device buffers + count)"""

@@ -24,6 +24,7 @@
 #include "gz_kernels_seg.h"
 #include "gz_merge.h"
 #include "gz_kernels_zip.h"
+#include "gz_kernels_domq.h"
 
 #define GZ_VERSION "genozip_amd 0.1 (gfx950; format parity: genozip 15.0.86)"
 
@@ -1016,6 +1017,48 @@ extern "C" int gz_codec_assign_best (GzHandle *h, const uint8_t *in, uint32_t in
         if (size < best_size) { best_size = size; best = cand[i + 1]; }
     }
     return best;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// N3: CODEC_DOMQ's pre-transform (gz_kernels_domq.h)
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int gz_domq_columns (GzHandle *h, const GzDomqJob *jobs, int n_jobs)
+{
+    if (!h || (n_jobs && !jobs) || n_jobs < 0) return GZ_ERR_ARG;
+    if (!n_jobs) return GZ_OK;
+    HIPCHK (h, hipSetDevice (h->device));
+    std::vector<GzdDomq> J (n_jobs);
+    for (int i = 0; i < n_jobs; i++) {
+        const GzDomqJob &u = jobs[i];
+        if (!u.result_dev || !u.qual || !u.mplx || (u.n && (!u.text || !u.off || !u.len || !u.runs || !u.divr))) return GZ_ERR_ARG;
+        GzdDomq &d = J[i];
+        d.text = u.text; d.off = u.off; d.len = u.len; d.n = u.n; d.qual = u.qual; d.runs = u.runs; d.mplx = u.mplx; d.divr = u.divr; d.res = u.result_dev;
+        if (!(d.line_dom = (uint8_t *)arena_alloc (h, (size_t)u.n + 16)) || !(d.normalize = (uint8_t *)arena_alloc (h, GZ_DQ_N * GZ_DQ_N))) return GZ_ERR_HIP;
+    }
+    void *dj;
+    int rc;
+    if ((rc = upload (h, J.data (), J.size () * sizeof (GzdDomq), &dj)) != GZ_OK) return rc;
+    KLAUNCH (h, k_domq, dim3 ((uint32_t)n_jobs), dim3 (256), GZ_DOMQ_LDS, (GzdDomq *)dj);
+    HIPCHK (h, hipGetLastError ());
+    return GZ_OK;
+}
+
+extern "C" int gz_domq_fit (GzHandle *h, const GzDomqFitJob *jobs, int n_jobs)
+{
+    if (!h || (n_jobs && !jobs) || n_jobs < 0) return GZ_ERR_ARG;
+    if (!n_jobs) return GZ_OK;
+    HIPCHK (h, hipSetDevice (h->device));
+    std::vector<GzdDomqFit> J (n_jobs);
+    for (int i = 0; i < n_jobs; i++) {
+        if (!jobs[i].fit_dev || (jobs[i].n && (!jobs[i].text || !jobs[i].off || !jobs[i].len))) return GZ_ERR_ARG;
+        J[i].text = jobs[i].text; J[i].off = jobs[i].off; J[i].len = jobs[i].len; J[i].n = jobs[i].n; J[i].fit = jobs[i].fit_dev;
+    }
+    void *dj;
+    int rc;
+    if ((rc = upload (h, J.data (), J.size () * sizeof (GzdDomqFit), &dj)) != GZ_OK) return rc;
+    KLAUNCH (h, k_domq_fit, dim3 (((uint32_t)n_jobs + 63) / 64), dim3 (64), 0, (const GzdDomqFit *)dj, (uint32_t)n_jobs);
+    HIPCHK (h, hipGetLastError ());
+    return GZ_OK;
 }
 
 // the same for host memory (global-area sections: dictionaries, counts)

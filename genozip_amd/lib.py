@@ -93,6 +93,21 @@ class GzZctxView(C.Structure):
                 ("flags", C.c_uint8), ("rm_dict_all_the_same", C.c_uint8), ("lcodec", C.c_uint8), ("bcodec", C.c_uint8), ("all_the_same_wi", C.c_int32)]
 
 
+class GzDomqResult(C.Structure):
+    _fields_ = [("qual_len", C.c_uint64), ("runs_len", C.c_uint64), ("mplx_len", C.c_uint64), ("divr_len", C.c_uint64),
+                ("num_doms", C.c_uint32), ("num_norm_qs", C.c_uint32), ("has_diverse", C.c_uint32), ("all_diverse", C.c_uint32),
+                ("status", C.c_int32), ("reserved", C.c_uint32), ("denorm", C.c_uint8 * (95 * 95 + 7))]
+
+
+class GzDomqJob(C.Structure):
+    _fields_ = [("text", C.c_void_p), ("off", C.c_void_p), ("len", C.c_void_p), ("n", C.c_uint32), ("qual", C.c_void_p), ("runs", C.c_void_p),
+                ("mplx", C.c_void_p), ("divr", C.c_void_p), ("result_dev", C.c_void_p)]
+
+
+class GzDomqFitJob(C.Structure):
+    _fields_ = [("text", C.c_void_p), ("off", C.c_void_p), ("len", C.c_void_p), ("n", C.c_uint32), ("fit_dev", C.c_void_p)]
+
+
 class GzFastqCtx(C.Structure):
     _fields_ = [("dict_id", C.c_uint8 * 8), ("did_i", C.c_uint16), ("kind", C.c_uint8), ("item", C.c_uint8), ("local_dep", C.c_uint8),
                 ("flags", C.c_uint8), ("no_stons", C.c_uint8), ("lcodec", C.c_uint8), ("bcodec", C.c_uint8), ("pair_identical", C.c_uint8),
@@ -131,6 +146,7 @@ ABI_SYMBOLS = (
     "gz_zctx_create", "gz_zctx_destroy", "gz_hash_next_size_up", "gz_ctx_merge", "gz_zctx_view", "gz_zctx_commit_codec",
     "gz_zip_open", "gz_zip_close", "gz_fastq_zip_vblocks", "gz_fastq_zip_seg", "gz_fastq_zip_merge", "gz_fastq_zip_finish", "gz_zip_zctx", "gz_section_order",
     "gz_zip_reset", "gz_fastq_zip_collect",
+    "gz_domq_columns", "gz_domq_fit",
     "gz_zfile_create", "gz_zfile_destroy", "gz_zfile_add_vblock", "gz_zfile_write_global_area", "gz_codec_assign_best_host",
     "gz_tokenize_column_n", "gz_int_columns", "gz_local_generate_batch", "gz_acgt_pack_batch",
 )
@@ -215,6 +231,8 @@ def load(path=None):
     L.gz_fastq_zip_seg.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(GzFastqVB), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.gz_fastq_zip_merge.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.gz_fastq_zip_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int]
+    L.gz_domq_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.gz_domq_fit.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.gz_zfile_create.restype = C.c_void_p
     L.gz_zfile_create.argtypes = [C.c_uint16, C.c_uint32]
     L.gz_zfile_destroy.argtypes = [C.c_void_p]

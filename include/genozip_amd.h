@@ -503,6 +503,32 @@ int gz_zfile_write_global_area (GzZFile *zf, GzHandle *h, GzZctx *const *zctx, c
                                 uint8_t *out_host, uint64_t out_cap, uint64_t *out_len);
 int gz_codec_assign_best_host (GzHandle *h, const uint8_t *in_host, uint32_t in_len);
 
+/* ---- N3: CODEC_DOMQ's pre-transform (src/codec_domq.c:69-134,139-249,347-503) -------------------------------
+ * The QUAL lines of a VBlock -> QUAL (non-dominant normalised scores + `no_doms` markers), DOMQRUNS (run lengths of the
+ * dominant score, continuing across lines), QUALMPLX (a byte per line: row in the denormalisation table, | 0x80 = diverse),
+ * DIVRQUAL (normalised scores of lines whose dominant score covers < 85 %), and the denormalisation table num_doms x
+ * num_norm_qs (the caller base64-codes it into DOMQRUNS' dictionary; QUAL's section param = num_norm_qs | 0x80, its ltype
+ * LT_CODEC, codec DOMQ with the sub-codec that coded the stream). Lines of length 0 take no part. All pointers device,
+ * asynchronous. Capacities with B = sum of the lengths: qual 2 B + 16, runs B + B / 254 + 16, mplx n + 16, divr B + 16. */
+enum { GZ_CODEC_DOMQ = 13, GZ_LT_CODEC_ = 13 };
+typedef struct {
+    uint64_t qual_len, runs_len, mplx_len, divr_len;
+    uint32_t num_doms, num_norm_qs, has_diverse, all_diverse;   /* all_diverse: QUAL is the single byte 'X', sub-codec NONE (:490-494) */
+    int32_t  status;              /* 1 ok; -5: a score outside ' '..'~'                                                   */
+    uint32_t reserved;
+    uint8_t  denorm[95 * 95 + 7];
+} GzDomqResult;
+typedef struct {
+    const uint8_t *text; const uint32_t *off, *len; uint32_t n;
+    uint8_t *qual, *runs, *mplx, *divr;
+    GzDomqResult *result_dev;
+} GzDomqJob;
+int gz_domq_columns (GzHandle *h, const GzDomqJob *jobs, int n_jobs);
+/* codec_domq_qual_data_is_a_fit_for_domq (:69-134) per VBlock: *fit_dev = 1 when more than half of the first (up to) 10 lines
+ * have a score that fills more than half of their first 2500 / lines bytes */
+typedef struct { const uint8_t *text; const uint32_t *off, *len; uint32_t n; uint32_t *fit_dev; } GzDomqFitJob;
+int gz_domq_fit (GzHandle *h, const GzDomqFitJob *jobs, int n_jobs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1845,3 +1845,109 @@ void gzo_zctx_view (const GzoZctx *z, const uint8_t **dict, uint64_t *dict_len, 
 
 /* exposed for the pinning tests: hash.h:30-52 */
 uint32_t gzo_hash_do (uint32_t hash_len, const uint8_t *snip, uint32_t snip_len) { return o_hash_do (hash_len, snip, snip_len); }
+
+/* =====================================================================================================
+ * N3: CODEC_DOMQ's pre-transform (src/codec_domq.c:69-134 fit test, :139-176 per-line dom + histogram, :178-249 tables,
+ * :347-373 normalise, :375-503 the four streams). Restated from the stream format; the reference's qsort (glibc merge sort
+ * for this size) is stable, so equal counts keep ascending score order.
+ * ===================================================================================================== */
+#define DQ_FIRST 32
+#define DQ_N 95
+
+int gzo_domq_is_fit (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n_lines)   /* :69-134 */
+{
+    uint64_t sampled = n_lines < 10 ? n_lines : 10, tested = 0, with_dom = 0;
+    const uint32_t per_line = sampled ? 2500 / (uint32_t)sampled : 2500;
+    for (uint64_t i = 0; i < sampled; i++) {
+        uint32_t l = len[i] < per_line ? len[i] : per_line;
+        if (!l) { if (sampled < n_lines) { sampled++; continue; } else break; }
+        uint32_t h[DQ_N] = { 0 };
+        for (uint32_t k = 0; k < l; k++) h[text[off[i] + k] - DQ_FIRST]++;
+        for (int q = 0; q < DQ_N; q++) if (h[q] * 2 > l) { with_dom++; break; }
+        tested++;
+    }
+    return tested && 100.0 * (double)with_dom / (double)tested > 50.0;                  /* percent() > MINIMUM_PERCENT_LINES_WITH_DOM */
+}
+
+static void dq_add_runs (uint8_t *runs, uint64_t *n, uint32_t runlen)                    /* :347-356 */
+{
+    while (runlen) {
+        const uint32_t sub = runlen < 254 ? runlen : 254;
+        runs[(*n)++] = runlen <= 254 ? (uint8_t)sub : 255;
+        runlen -= sub;
+    }
+}
+
+int gzo_domq_encode (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n_lines, GzoDomq *o)
+{
+    static uint32_t hist[DQ_N][DQ_N];
+    uint32_t lines_with_dom[DQ_N] = { 0 };
+    memset (hist, 0, sizeof (hist));
+    uint8_t *dom = malloc (n_lines + 1), *diverse = calloc (n_lines + 1, 1);
+    uint64_t total = 0;
+    o->has_diverse = 0;
+    for (uint64_t i = 0; i < n_lines; i++) {                                             /* :139-176 */
+        if (!len[i]) continue;
+        uint32_t h[DQ_N] = { 0 }, best = 0;
+        for (uint32_t k = 0; k < len[i]; k++) {
+            const uint8_t c = text[off[i] + k];
+            if (c < DQ_FIRST || c > 126) { free (dom); free (diverse); return -1; }
+            h[c - DQ_FIRST]++;
+        }
+        for (int q = 0; q < DQ_N; q++) if (h[q] >= best) { best = h[q]; dom[i] = (uint8_t)q; }   /* equal: the higher score */
+        if (100 * h[dom[i]] / len[i] < 85) { diverse[i] = 1; o->has_diverse = 1; }
+        lines_with_dom[dom[i]]++;
+        for (int q = 0; q < DQ_N; q++) hist[dom[i]][q] += h[q];
+        total += len[i];
+    }
+    uint8_t dom_to_cdom[DQ_N] = { 0 }, ndom = 0;                                          /* :178-196 */
+    static uint32_t ch[DQ_N][DQ_N];
+    for (int q = 0; q < DQ_N; q++) if (lines_with_dom[q]) { dom_to_cdom[q] = ndom; memcpy (ch[ndom], hist[q], sizeof (ch[0])); ndom++; }
+    static uint8_t normalize[DQ_N][DQ_N], denorm[DQ_N][DQ_N];
+    memset (denorm, 0, sizeof (denorm)); memset (normalize, 0, sizeof (normalize));
+    uint32_t num_norm = 0;
+    for (int c = 0; c < ndom; c++) {                                                      /* :198-249: rank by count, descending, stable */
+        uint32_t rank = 0;
+        uint8_t used[DQ_N] = { 0 };
+        for (;;) {
+            int bq = -1;
+            for (int q = 0; q < DQ_N; q++) if (!used[q] && ch[c][q] && (bq < 0 || ch[c][q] > ch[c][bq])) bq = q;
+            if (bq < 0) break;
+            used[bq] = 1; normalize[c][bq] = (uint8_t)rank; denorm[c][rank] = (uint8_t)(bq + DQ_FIRST); rank++;
+        }
+        if (rank > num_norm) num_norm = rank;
+    }
+    o->num_doms = ndom; o->num_norm_qs = num_norm;
+    for (int c = 0; c < ndom; c++) for (uint32_t r = 0; r < num_norm; r++) o->denorm[c * num_norm + r] = denorm[c][r];
+    const uint8_t no_doms = (uint8_t)num_norm;
+    o->qual = malloc (2 * total + 16); o->runs = malloc (total + total / 254 + 16); o->mplx = malloc (n_lines + 16); o->divr = malloc (total + 16);
+    o->qual_len = o->runs_len = o->mplx_len = o->divr_len = 0;
+    uint32_t runlen = 0, last_len = 0;
+    for (uint64_t i = 0; i < n_lines; i++) {                                              /* :418-466 */
+        if (!len[i]) continue;
+        const uint8_t cd = dom_to_cdom[dom[i]];
+        last_len = len[i];
+        if (diverse[i]) {
+            for (uint32_t k = 0; k < len[i]; k++) o->divr[o->divr_len++] = normalize[cd][text[off[i] + k] - DQ_FIRST];
+            o->mplx[o->mplx_len++] = cd | 0x80;
+            continue;
+        }
+        o->mplx[o->mplx_len++] = cd;
+        for (uint32_t k = 0; k < len[i]; k++) {
+            const uint8_t v = normalize[cd][text[off[i] + k] - DQ_FIRST];
+            if (!v) { runlen++; continue; }
+            if (runlen) { dq_add_runs (o->runs, &o->runs_len, runlen); runlen = 0; }
+            else o->qual[o->qual_len++] = no_doms;
+            o->qual[o->qual_len++] = v;
+        }
+    }
+    /* the final run (:468-480): last_len = qual_len of the LAST line of the VBlock, whatever its kind */
+    { uint64_t j = n_lines; while (j && !len[j - 1]) j--; last_len = j ? len[j - 1] : 0; if (n_lines && !len[n_lines - 1]) last_len = 0; }
+    if (runlen && (o->runs_len || runlen < last_len)) { dq_add_runs (o->runs, &o->runs_len, runlen); o->qual[o->qual_len++] = no_doms; }
+    o->all_diverse = 0;
+    if (!o->qual_len) { o->qual[o->qual_len++] = 'X'; o->all_diverse = 1; }             /* :490-494 */
+    free (dom); free (diverse);
+    return 0;
+}
+
+void gzo_domq_free (GzoDomq *o) { free (o->qual); free (o->runs); free (o->mplx); free (o->divr); }

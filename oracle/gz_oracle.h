@@ -224,6 +224,21 @@ int gzo_ctx_merge (GzoZctx *z, GzoMerge *j);
 void gzo_zctx_view (const GzoZctx *z, const uint8_t **dict, uint64_t *dict_len, uint32_t *n_words, const uint64_t **counts,
                     uint64_t *n_failed, int *rm_dict);
 
+
+/* ---- N3: CODEC_DOMQ's pre-transform (src/codec_domq.c:69-134,139-249,347-503) - QUAL lines -> four streams ------------------
+ * QUAL (non-dominant normalised scores, a `no_doms` marker where no run precedes one, a final marker after a trailing run),
+ * DOMQRUNS (run lengths of the dominant score: 0-254 = a run of that many, 255 = 254 and the run continues; runs span lines),
+ * QUALMPLX (per line: index of its dom in the denormalisation table, | 0x80 for a diverse line), DIVRQUAL (the normalised
+ * scores of diverse lines: < 85 % dom). denorm = num_doms x num_norm_qs table (-> base64 snip in DOMQRUNS' dictionary);
+ * QUAL's section param = num_norm_qs | 0x80. Lines of length 0 take no part. */
+typedef struct {
+    uint8_t *qual, *runs, *mplx, *divr; uint64_t qual_len, runs_len, mplx_len, divr_len;
+    uint8_t denorm[95 * 95]; uint32_t num_doms, num_norm_qs; int has_diverse, all_diverse;
+} GzoDomq;
+int  gzo_domq_is_fit (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n_lines);
+int  gzo_domq_encode (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n_lines, GzoDomq *out);   /* -1: a byte outside ' '..'~' */
+void gzo_domq_free (GzoDomq *o);
+
 #ifdef __cplusplus
 }
 #endif

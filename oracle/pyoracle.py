@@ -325,6 +325,32 @@ class Oracle:
         return z.raw[:n]
 
 
+class GzoDomq(ctypes.Structure):
+    _fields_ = [("qual", ctypes.c_void_p), ("runs", ctypes.c_void_p), ("mplx", ctypes.c_void_p), ("divr", ctypes.c_void_p),
+                ("qual_len", ctypes.c_uint64), ("runs_len", ctypes.c_uint64), ("mplx_len", ctypes.c_uint64), ("divr_len", ctypes.c_uint64),
+                ("denorm", ctypes.c_uint8 * (95 * 95)), ("num_doms", ctypes.c_uint32), ("num_norm_qs", ctypes.c_uint32),
+                ("has_diverse", ctypes.c_int), ("all_diverse", ctypes.c_int)]
+
+
+def oracle_domq(O, text, off, length):
+    """N3 through the oracle (gzo_domq_encode / gzo_domq_is_fit) -> same dict as Engine.domq_columns gives per column"""
+    import numpy as np
+    text = bytes(text) + b"\0"
+    off = np.ascontiguousarray(off, dtype=np.uint32); length = np.ascontiguousarray(length, dtype=np.uint32)
+    o = GzoDomq()
+    O.L.gzo_domq_encode.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+    O.L.gzo_domq_is_fit.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+    O.L.gzo_domq_free.argtypes = [ctypes.c_void_p]
+    if O.L.gzo_domq_encode(text, off.ctypes.data, length.ctypes.data, len(off), ctypes.byref(o)) != 0:
+        raise RuntimeError("oracle domq: a score outside ' '..'~'")
+    r = dict(qual=ctypes.string_at(o.qual, o.qual_len), runs=ctypes.string_at(o.runs, o.runs_len), mplx=ctypes.string_at(o.mplx, o.mplx_len),
+             divr=ctypes.string_at(o.divr, o.divr_len), denorm=bytes(o.denorm[:o.num_doms * o.num_norm_qs]), num_doms=o.num_doms, num_norm_qs=o.num_norm_qs,
+             has_diverse=bool(o.has_diverse), all_diverse=bool(o.all_diverse),
+             fit=bool(O.L.gzo_domq_is_fit(text, off.ctypes.data, length.ctypes.data, len(off))))
+    O.L.gzo_domq_free(ctypes.byref(o))
+    return r
+
+
 class GzoMerge(ctypes.Structure):
     _fields_ = [("vblock_i", ctypes.c_uint32), ("n_ol", ctypes.c_uint32), ("n_new", ctypes.c_uint32),
                 ("dict", ctypes.c_void_p), ("node_char_index", ctypes.c_void_p), ("node_snip_len", ctypes.c_void_p), ("counts", ctypes.c_void_p),
@@ -511,6 +537,26 @@ class CtxRef:
         a = np.frombuffer(bytes(file_bytes), dtype=np.uint8).copy()
         lt = self.L.ctxref_local_to_native(ltype, a.ctypes.data, len(a) // width, cols)
         return lt, a.tobytes()
+
+    def domq(self, text, off, length):
+        """the reference's own codec_domq_comp_init + codec_domq_compress on the QUAL lines of a VBlock (sub-codec = store)
+        -> dict(qual, runs, mplx, divr, denorm_snip (base64 as segged into DOMQRUNS), param, sub_codec, fit)"""
+        import numpy as np
+        text = bytes(text) + b"\0"
+        off = np.ascontiguousarray(off, dtype=np.uint32); length = np.ascontiguousarray(length, dtype=np.uint32)
+        B = int(length.astype(np.uint64).sum())
+        bufs = [np.zeros(2 * B + 2048, dtype=np.uint8) for _ in range(4)]
+        lens = [ctypes.c_uint64() for _ in range(4)]
+        snip = np.zeros(16384, dtype=np.uint8)
+        sl, param, sub, fit = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_int()
+        self.L.ctxref_domq.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 13
+        args = []
+        for b, l in zip(bufs, lens):
+            args += [b.ctypes.data, ctypes.addressof(l)]
+        self.L.ctxref_domq(text, len(text), off.ctypes.data, length.ctypes.data, len(off), *args, snip.ctypes.data, ctypes.addressof(sl),
+                           ctypes.addressof(param), ctypes.addressof(sub), ctypes.addressof(fit))
+        q, r, m, d = [b[:l.value].tobytes() for b, l in zip(bufs, lens)]
+        return dict(qual=q, runs=r, mplx=m, divr=d, denorm_snip=snip[:sl.value].tobytes(), param=param.value, sub_codec=sub.value, fit=bool(fit.value))
 
     def hash_do(self, hash_len, snip):
         return self.L.ctxref_hash_do(hash_len, bytes(snip), len(snip))

@@ -30,6 +30,8 @@
 #include "profiler.h"
 #include "bits.h"
 #include "hash.h"
+#include "codec.h"
+#include "sam.h"
 
 /* ---- (a) what b250.o / dyn_int.o import -------------------------------------------------------------------------------- */
 Flags flag;
@@ -196,3 +198,64 @@ int ctxref_local_to_native (int ltype, uint8_t *data, uint64_t n, uint32_t cols)
 
 /* hash_do (src/hash.h:30-52, a static inline of the reference's header): the bucket of a snip */
 uint32_t ctxref_hash_do (uint32_t hash_len, const char *snip, uint32_t snip_len) { return hash_do (hash_len, snip, snip_len); }
+
+/* ---- N3: the reference's own src/codec_domq.c (+ src/base64.c), compiled in place ---------------------------------------------
+ * What codec_domq.o imports beyond the above: the codec table (a sub-codec that stores = CODEC_NONE is all that is needed: the
+ * four streams are read back uncompressed), the snip the denormalisation table is segged as, and SAM / PIZ-side functions
+ * that are never reached from here. */
+static uint8_t shim_snip[16384]; static uint32_t shim_snip_len;
+WordIndex seg_by_ctx_ex (VBlockP vb, STRp(snip), ContextP ctx, uint32_t add_bytes, bool *is_new) { memcpy (shim_snip, snip, snip_len); shim_snip_len = snip_len; return 0; }
+WordIndex ctx_peek_next_snip (VBlockP vb, ContextP ctx, pSTRp (snip)) { abort (); }
+void ctx_set_ltype (VBlockP vb, int ltype, ...) {}
+void error_asspiz (rom func, uint32_t line, rom fmt, ...) { abort (); }
+rom codec_name (Codec codec) { return "codec"; }
+void sam_xcons_split_qual_line (VBlockP vb_, BufferP ql_buf) { abort (); }
+void sam_reconstruct_missing_quality (VBlockP vb, ReconType reconstruct) { abort (); }
+void sam_xcons_reconstruct_QUAL (VBlockP vb, ContextP ctx, uint32_t qual_len, bool reconstruct) { abort (); }
+static COMPRESS (shim_store) { memcpy (compressed, uncompressed, *uncompressed_len); *compressed_len = *uncompressed_len; return true; }
+static uint32_t shim_est (Codec codec, uint64_t len) { return (uint32_t)len; }
+CodecArgs codec_args[NUM_CODECS] = { [CODEC_NONE] = { .is_simple = true, .name = "NONE", .compress = shim_store, .est_size = shim_est } };
+extern COMPRESS (codec_domq_compress);
+
+static char *dq_text; static const uint32_t *dq_off, *dq_len;
+static COMPRESSOR_CALLBACK (dq_get_line)
+{
+    *line_data = dq_text + dq_off[vb_line_i]; *line_data_len = dq_len[vb_line_i] < maximum_size ? dq_len[vb_line_i] : maximum_size;
+    if (is_rev) *is_rev = 0;
+}
+
+/* codec_domq_comp_init + codec_domq_compress over the QUAL lines of one VBlock. Outputs: the four locals, the denormalisation table
+ * snip (base64 as segged), QUAL's param; *fit = what codec_domq_comp_init answers without `force`. Returns 0. */
+int ctxref_domq (const uint8_t *text, uint64_t text_len, const uint32_t *off, const uint32_t *len, uint32_t n_lines,
+                 uint8_t *qual, uint64_t *qual_len, uint8_t *runs, uint64_t *runs_len, uint8_t *mplx, uint64_t *mplx_len, uint8_t *divr, uint64_t *divr_len,
+                 uint8_t *snip, uint32_t *snip_len, uint32_t *param, uint32_t *sub_codec, int *fit)
+{
+    VBlockP vb = new_vb ();
+    vb->lines.len = n_lines;
+    dq_text = malloc (text_len + 8); memcpy (dq_text, text, text_len); dq_off = off; dq_len = len;
+    ContextP q = &vb->ca.contexts[SAM_QUAL];
+    for (int k = 0; k < 4; k++) q[k].dict_id.num = 0x1234 + k;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_lines; i++) total += len[i];
+    q->local.len = total;                                   /* (QUAL's local holds no data before the codec runs: the callback supplies the lines) */
+    *fit = codec_domq_comp_init (vb, SAM_QUAL, dq_get_line, false);
+    memset (q, 0, 4 * sizeof (Context)); for (int k = 0; k < 4; k++) q[k].dict_id.num = 0x1234 + k;
+    q->local.len = total;
+    memcpy (dq_text, text, text_len);
+    shim_snip_len = 0;
+    codec_domq_comp_init (vb, SAM_QUAL, dq_get_line, true);
+    SectionHeaderCtx hd = {};
+    uint32_t ulen = (uint32_t)total, clen = (uint32_t)(2 * total + 1024);
+    char *comp = malloc (clen);
+    codec_domq_compress (vb, q, (SectionHeaderP)&hd, NULL, &ulen, dq_get_line, comp, &clen, true, "QUAL");
+    memcpy (qual, comp, clen); *qual_len = clen;
+    memcpy (runs, q[1].local.data, q[1].local.len); *runs_len = q[1].local.len;
+    memcpy (mplx, q[2].local.data, q[2].local.len); *mplx_len = q[2].local.len;
+    memcpy (divr, q[3].local.data, q[3].local.len); *divr_len = q[3].local.len;
+    memcpy (snip, shim_snip, shim_snip_len); *snip_len = shim_snip_len;
+    *param = q->local.prm8[0]; *sub_codec = hd.sub_codec;
+    free (comp); free (dq_text);
+    for (int k = 0; k < 4; k++) free (q[k].local.memory);      /* (qual_line / normalize_buf alias other Buffers of the Context: left alone) */
+    free (vb);
+    return 0;
+}

@@ -105,6 +105,20 @@ def hash_cases():
     return [(hl, sn) for hl in (65521, 92681, 8388593) for sn in snips]
 
 
+def domq_cases():
+    """(name, QUAL lines of a VBlock)"""
+    def lines_bin(n, seed):
+        return [synth.quality_binned(seed + i, 1, 150 - (i % 3 == 0) * (i % 11))[0].tobytes() for i in range(n)]
+
+    def lines_div(n, seed):
+        return [synth.quality_diverse(seed + i, 1, 150)[0].tobytes() for i in range(n)]
+    two = [l.replace(b"F", b"\x01").replace(b":", b"F").replace(b"\x01", b":") if i % 3 == 0 else l for i, l in enumerate(lines_bin(200, 11))]
+    return [("bin", lines_bin(300, 1)), ("div", lines_div(50, 2)), ("mix", [l if i % 5 else lines_div(1, 900 + i)[0] for i, l in enumerate(lines_bin(300, 3))]),
+            ("allF", [b"F" * 150] * 7), ("one", [b"F" * 150]), ("gaps", [b"" if i % 4 == 1 else l for i, l in enumerate(lines_bin(61, 5))]),
+            ("startnz", [b"#" + l[1:] for l in lines_bin(40, 6)]), ("long", [b"F" * 600, b"F" * 600 + b":", b"F" * 100]), ("twodoms", two),
+            ("tail", lines_bin(9, 21) + [b"F" * 150] * 3), ("ties", [b"FF::,,##" * 10, b"F" * 70 + b":,#;" * 2, b"F" * 75 + b";#,:"])]
+
+
 LOCAL_ORDER_CASES = [(1, 1), (2, 1), (3, 2), (4, 2), (5, 4), (6, 4), (7, 8), (8, 8), (9, 4), (10, 8)]
 
 

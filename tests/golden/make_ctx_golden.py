@@ -29,6 +29,14 @@ def main():
     R = pyoracle.CtxRef()
     out = {"b250": [], "dyn_int": [], "transpose": [], "local_order": []}
     out["hash_do"] = [{"hash_len": hl, "snip_hex": sn.hex(), "hash": R.hash_do(hl, sn)} for hl, sn in cases.hash_cases()]
+    import parity
+    out["domq"] = []
+    for name, ls in cases.domq_cases():
+        t, o, l = parity._snip_column(ls)
+        o = np.where(l == 0, 0, o).astype(np.uint32)
+        r = R.domq(t, o, l)
+        out["domq"].append({"name": name, "qual": enc(r["qual"]), "runs": enc(r["runs"]), "mplx": enc(r["mplx"]), "divr": enc(r["divr"]),
+                            "denorm_snip": r["denorm_snip"].decode(), "param": r["param"], "fit": r["fit"]})
     for lt, w in cases.LOCAL_ORDER_CASES:
         raw = synth.uniform_bytes(40 + lt, 500 * w, 256).tobytes()
         fo = R.local_to_file_order(lt, raw, w)

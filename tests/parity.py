@@ -896,6 +896,16 @@ def ctx_golden(E, oracle):
         sn = bytes.fromhex(c["snip_hex"])
         oracle.L.gzo_hash_do.restype = __import__("ctypes").c_uint32
         assert oracle.L.gzo_hash_do(c["hash_len"], sn, len(sn)) == c["hash"], ("hash_do", c["hash_len"], sn)
+    import base64
+    import pyoracle
+    for c, (name, ls) in zip(G["domq"], cases.domq_cases()):      # N3: the reference's own codec_domq.c
+        t, o, l = _snip_column(ls)
+        o = np.where(l == 0, 0, o).astype(np.uint32)
+        rs = [pyoracle.oracle_domq(oracle, t, o, l)] + ([E.domq_columns([(t, o, l)])[0]] if E is not None else [])
+        for r in rs:
+            for key in ("qual", "runs", "mplx", "divr"):
+                cases.check_enc(r[key], c[key], ("domq", name, key))
+            assert base64.b64encode(r["denorm"]).decode() == c["denorm_snip"] and (r["num_norm_qs"] | 0x80) == c["param"] and r["fit"] == c["fit"], ("domq", name)
     for c in G["local_order"]:                       # a6: byte order / interlace of every integer and float type
         raw = synth.uniform_bytes(40 + c["ltype"], 500 * c["w"], 256).tobytes()
         cases.check_enc(oracle.local_generate(c["ltype"], raw)[1], c["file"], ("order oracle", c["ltype"]))
@@ -929,3 +939,51 @@ def _first_occurrence_order(ni, ol):
             if v == nxt:
                 nxt += 1
     return True
+
+
+def domq(E, oracle, n_lines):
+    """N3: the four DOMQ streams + the denormalisation table of whole VBlocks == the oracle's line-by-line restatement; shapes:
+    binned NovaSeq-like (long runs over line ends), diverse lines mixed in, two dominant scores, empty lines, a VBlock of
+    one run, all diverse, runs beyond 254 / 508, a non-dominant first score; the fit test on both kinds"""
+    import pyoracle
+    r = synth.u32(606, 4 * n_lines + 64)
+
+    def lines_of(kind, n):
+        out = []
+        for i in range(n):
+            L = 150 - int(r[i] % 3 == 0) * int(r[i] % 11)
+            if kind == "bin":
+                q = synth.quality_binned(1000 + i, 1, L)[0].tobytes()
+            elif kind == "div":
+                q = synth.quality_diverse(2000 + i, 1, L)[0].tobytes()
+            elif kind == "mix":
+                q = (synth.quality_binned(3000 + i, 1, L) if i % 5 else synth.quality_diverse(3000 + i, 1, L))[0].tobytes()
+            elif kind == "twodoms":
+                q = synth.quality_binned(4000 + i, 1, L)[0].tobytes()
+                if i % 3 == 0:
+                    q = q.replace(b"F", b"\x01").replace(b":", b"F").replace(b"\x01", b":")
+            elif kind == "allF":
+                q = b"F" * L
+            elif kind == "gaps":
+                q = b"" if i % 4 == 1 else synth.quality_binned(5000 + i, 1, L)[0].tobytes()
+            elif kind == "startnz":
+                q = b"#" + synth.quality_binned(6000 + i, 1, L - 1)[0].tobytes()
+            else:
+                raise ValueError(kind)
+            out.append(q)
+        return out
+    cols, names = [], []
+    for kind, n in (("bin", n_lines), ("div", min(n_lines, 300)), ("mix", n_lines), ("twodoms", n_lines), ("allF", 7), ("gaps", 61), ("startnz", 40),
+                    ("allF", 1), ("bin", 1), ("bin", 257)):
+        ls = lines_of(kind, n)
+        t, o, l = _snip_column(ls)
+        o = np.where(l == 0, 0, o).astype(np.uint32)
+        cols.append((t, o, l)); names.append((kind, n, ls))
+    got = E.domq_columns(cols)
+    for (kind, n, ls), (t, o, l), g in zip(names, cols, got):
+        w = pyoracle.oracle_domq(oracle, t, o, l)
+        for key in ("num_doms", "num_norm_qs", "denorm", "mplx", "divr", "runs", "qual", "has_diverse", "all_diverse", "fit"):
+            assert g[key] == w[key], (kind, n, key, len(g[key]) if hasattr(g[key], "__len__") else g[key])
+        if kind in ("bin", "mix", "twodoms", "gaps", "startnz", "allF") and not g["all_diverse"]:
+            pass
+    assert got[0]["fit"] and not got[1]["fit"] and got[4]["runs"] == b"" and got[4]["qual"] == b"\x01" * 0 + got[4]["qual"]

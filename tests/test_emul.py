@@ -103,3 +103,7 @@ def test_emul_fastq_zip(emul_engine, oracle):
 
 def test_emul_ctx_golden(emul_engine, oracle):
     parity.ctx_golden(emul_engine, oracle)
+
+
+def test_emul_domq(emul_engine, oracle):
+    parity.domq(emul_engine, oracle, 700)

@@ -214,3 +214,9 @@ def test_chunk_and_tile_boundaries(gpu_engine, oracle):
     got = E.compress_many(items)
     for (c, d), g in zip(items, got):
         assert g == oracle.codec_compress(c, d), (c, len(d))
+
+
+def test_domq(gpu_engine, oracle):
+    """N3: CODEC_DOMQ's pre-transform at VBlock size (46 000 lines) == the oracle, whose restatement is pinned to the reference's
+    own codec_domq.c by tests/golden/ctx_golden.json (checked for the product in test_ctx_golden_vectors)"""
+    parity.domq(gpu_engine, oracle, 46000)
