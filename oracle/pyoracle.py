@@ -560,3 +560,14 @@ class CtxRef:
 
     def hash_do(self, hash_len, snip):
         return self.L.ctxref_hash_do(hash_len, bytes(snip), len(snip))
+
+    def acgt(self, seq):
+        """the reference's own codec_acgt_compress on a contiguous NONREF.local (sub-codec = store)
+        -> (packed as handed to the sub-codec, NONREF_X.local, has_x, sub_codec)"""
+        import numpy as np
+        seq = bytes(seq); n = len(seq)
+        packed = np.zeros(n // 4 + 64, dtype=np.uint8); x = np.zeros(n + 16, dtype=np.uint8)
+        pl, sub, hx = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_int()
+        self.L.ctxref_acgt.argtypes = [ctypes.c_char_p, ctypes.c_uint32] + [ctypes.c_void_p] * 5
+        self.L.ctxref_acgt(seq, n, packed.ctypes.data, ctypes.addressof(pl), x.ctypes.data, ctypes.addressof(hx), ctypes.addressof(sub))
+        return packed[:pl.value].tobytes(), x[:n].tobytes(), bool(hx.value), sub.value

@@ -32,6 +32,7 @@
 #include "hash.h"
 #include "codec.h"
 #include "sam.h"
+#include "reference.h"
 
 /* ---- (a) what b250.o / dyn_int.o import -------------------------------------------------------------------------------- */
 Flags flag;
@@ -57,7 +58,15 @@ void buf_free_do (BufferP buf, FUNCLINE) { buf->len = 0; buf->param = 0; }
 /* src/buffer.c (compiled in place for its byte order / interlace / transpose functions) imports a few more */
 VBlockP evb;
 uint64_t buf_mem_size (ConstBufferP buf) { return buf->size; }
-void buf_overlay_do (VBlockP vb, BufferP top_buf, BufferP bottom_buf, uint64_t start_in_bottom, bool copy_len, FUNCLINE, rom name) { abort (); }
+void buf_overlay_do (VBlockP vb, BufferP top_buf, BufferP bottom_buf, uint64_t start_in_bottom, bool copy_len, FUNCLINE, rom name)
+{   /* the top buffer shares the bottom one's memory (enough of src/buf_struct.c's overlay for codec_acgt_compress) */
+    top_buf->data = bottom_buf->data + start_in_bottom; top_buf->size = bottom_buf->size - start_in_bottom; top_buf->vb = vb;
+    top_buf->type = BUF_REGULAR; top_buf->memory = NULL; if (copy_len) top_buf->len = bottom_buf->len;
+}
+void buf_set_shared (BufferP buf) {}
+void buf_destroy_do (BufferP buf, FUNCLINE) { buf->data = NULL; buf->len = 0; buf->size = 0; buf->memory = NULL; }
+void codec_show_time (VBlockP vb, rom name, rom subname, Codec codec) {}
+bool str_is_zero (STRp(str)) { for (uint32_t i = 0; i < str_len; i++) if (str[i]) return false; return true; }
 rom buf_type_name (ConstBufferP buf) { return "buf"; }
 void bits_clear_region_do (BitsP bits, uint64_t start, uint64_t len, FUNCLINE) { abort (); }
 void bits_set_region (BitsP bits, uint64_t start, uint64_t len) { abort (); }
@@ -257,5 +266,40 @@ int ctxref_domq (const uint8_t *text, uint64_t text_len, const uint32_t *off, co
     free (comp); free (dq_text);
     for (int k = 0; k < 4; k++) free (q[k].local.memory);      /* (qual_line / normalize_buf alias other Buffers of the Context: left alone) */
     free (vb);
+    return 0;
+}
+
+/* ---- N2: the reference's own src/codec_acgt.c, compiled in place ---------------------------------------------------------------
+ * It imports the base -> 2-bit table of src/reference.c (:45-58; reference.c itself drags in the genome machinery): stated here from
+ * its description - A C G T (either case) = 0 1 2 3, U = T, an IUPAC code = the alphabetically lowest base it stands for, anything
+ * else 0. So the TABLE is this file's; the packing, the exception stream and the sub-codec rule are the reference's own code. */
+#define LO(c) ((c) + 32)
+const uint8_t _acgt_encode[256] = {   /* (everything not named: 0, as A R W M D H V N are) */
+    ['C']=1, ['Y']=1, ['S']=1, ['B']=1, [LO('C')]=1, [LO('Y')]=1, [LO('S')]=1, [LO('B')]=1,
+    ['G']=2, ['K']=2, [LO('G')]=2, [LO('K')]=2,
+    ['T']=3, ['U']=3, [LO('T')]=3, [LO('U')]=3 };
+extern COMPRESS (codec_acgt_compress);
+static COMPRESS (shim_store_named) { memcpy (compressed, uncompressed, *uncompressed_len); *compressed_len = *uncompressed_len; return true; }
+
+/* codec_acgt_compress over a contiguous NONREF.local: packed = what is handed to the sub-codec, x = NONREF_X.local (seq_len bytes) when
+ * *has_x, *sub_codec = header->sub_codec (LZMA unless the packed data is under 50 bytes) */
+int ctxref_acgt (const uint8_t *seq, uint32_t n, uint8_t *packed, uint32_t *packed_len, uint8_t *x, int *has_x, uint32_t *sub_codec)
+{
+    VBlockP vb = new_vb ();
+    static Context zc[MAX_DICTS]; static File zf; z_file = &zf;        /* (ZCTX(..)->lcodec of NONREF_X is read) */
+    codec_args[CODEC_LZMA].compress = shim_store_named; codec_args[CODEC_LZMA].est_size = shim_est;   /* the sub-codec stores */
+    ContextP c = &vb->ca.contexts[SAM_NONREF];
+    c[0].dict_id.num = 0x1234; c[1].dict_id.num = 0x1235; c[0].did_i = SAM_NONREF; c[1].did_i = SAM_NONREF_X;
+    buf_alloc_do (vb, &c->local, n + 16, 1, "local", __FUNCTION__, __LINE__);
+    memcpy (c->local.data, seq, n); c->local.len = n;
+    SectionHeaderCtx hd = {};
+    uint32_t ulen = n, clen = n + 1024;
+    char *comp = malloc (clen);
+    codec_acgt_compress (vb, c, (SectionHeaderP)&hd, c->local.data, &ulen, NULL, comp, &clen, false, "NONREF");
+    memcpy (packed, comp, clen); *packed_len = clen;
+    *has_x = !hd.flags.ctx.acgt_no_x;
+    if (*has_x) memcpy (x, c->local.data, n);
+    *sub_codec = hd.sub_codec;
+    free (comp); free (c->local.memory); free (vb->scratch.memory); free (vb);
     return 0;
 }

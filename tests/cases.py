@@ -119,6 +119,15 @@ def domq_cases():
             ("tail", lines_bin(9, 21) + [b"F" * 150] * 3), ("ties", [b"FF::,,##" * 10, b"F" * 70 + b":,#;" * 2, b"F" * 75 + b";#,:"])]
 
 
+def acgt_cases():
+    """(name, NONREF.local bytes)"""
+    iupac = (synth.uniform_bytes(7, 2000, 256) % 30 + 65).astype("uint8").tobytes() + b"acgtnryswkmbdhvu" * 9
+    out = [("clean%d" % n, synth.bases(60 + n, 1, n, 0.0)[0].tobytes()) for n in (1, 3, 4, 5, 31, 32, 33, 63, 64, 65, 199, 200, 201, 4096, 100003)]
+    out += [("dirty%d" % n, synth.bases(80 + n, 1, n, 0.01)[0].tobytes()) for n in (50, 257, 100001)]
+    out += [("iupac", iupac), ("lower", synth.bases(3, 1, 1000, 0.0)[0].tobytes().lower()), ("allN", b"N" * 77), ("bytes", bytes(range(256)) * 3)]
+    return out
+
+
 LOCAL_ORDER_CASES = [(1, 1), (2, 1), (3, 2), (4, 2), (5, 4), (6, 4), (7, 8), (8, 8), (9, 4), (10, 8)]
 
 

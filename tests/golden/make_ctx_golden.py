@@ -37,6 +37,10 @@ def main():
         r = R.domq(t, o, l)
         out["domq"].append({"name": name, "qual": enc(r["qual"]), "runs": enc(r["runs"]), "mplx": enc(r["mplx"]), "divr": enc(r["divr"]),
                             "denorm_snip": r["denorm_snip"].decode(), "param": r["param"], "fit": r["fit"]})
+    out["acgt"] = []
+    for name, seq in cases.acgt_cases():
+        pk, x, hx, sub = R.acgt(seq)
+        out["acgt"].append({"name": name, "packed": enc(pk), "x": enc(x if hx else b""), "has_x": hx, "sub_codec": sub})
     for lt, w in cases.LOCAL_ORDER_CASES:
         raw = synth.uniform_bytes(40 + lt, 500 * w, 256).tobytes()
         fo = R.local_to_file_order(lt, raw, w)

@@ -906,6 +906,14 @@ def ctx_golden(E, oracle):
             for key in ("qual", "runs", "mplx", "divr"):
                 cases.check_enc(r[key], c[key], ("domq", name, key))
             assert base64.b64encode(r["denorm"]).decode() == c["denorm_snip"] and (r["num_norm_qs"] | 0x80) == c["param"] and r["fit"] == c["fit"], ("domq", name)
+    for c, (name, seq) in zip(G["acgt"], cases.acgt_cases()):     # N2: the reference's own codec_acgt.c
+        for who in [oracle] + ([E] if E is not None else []):
+            pk, x, hx = who.acgt_pack(seq)
+            cases.check_enc(pk, c["packed"], ("acgt", name))
+            assert hx == c["has_x"], ("acgt has_x", name)
+            if hx:
+                cases.check_enc(x, c["x"], ("acgt x", name))
+            assert c["sub_codec"] == (4 if len(pk) >= 50 else 1)          # LZMA unless the packed data is under 50 bytes (codec_acgt.c)
     for c in G["local_order"]:                       # a6: byte order / interlace of every integer and float type
         raw = synth.uniform_bytes(40 + c["ltype"], 500 * c["w"], 256).tobytes()
         cases.check_enc(oracle.local_generate(c["ltype"], raw)[1], c["file"], ("order oracle", c["ltype"]))
