@@ -70,11 +70,13 @@ def relaunch_under_torchrun(a):
 
 
 def walk_sections(z):
-    """[(section_type, codec, dict_id, uncompressed_len, payload)] of one VBlock's z_data (SectionHeaderCtx, sections.h:146-167,419-435)"""
+    """[(section_type, codec, dict_id, uncompressed_len, payload, through DOMQ)] of one VBlock's z_data (SectionHeaderCtx,
+    sections.h:146-167,419-435); codec = the coder of the payload: a CODEC_DOMQ section names it in sub_codec"""
     out, at = [], 84
     while at < len(z):
         clen = int.from_bytes(z[at + 12:at + 16], "big")
-        out.append((z[at + 24], z[at + 25], bytes(z[at + 32:at + 40]), int.from_bytes(z[at + 16:at + 20], "big"), z[at + 40:at + 40 + clen]))
+        domq = z[at + 25] == 13
+        out.append((z[at + 24], z[at + 26] if domq else z[at + 25], bytes(z[at + 32:at + 40]), int.from_bytes(z[at + 16:at + 20], "big"), z[at + 40:at + 40 + clen], domq))
         at += 40 + clen
     return out
 
@@ -167,11 +169,16 @@ def cpu_leg(wl, z_all, n_threads):
     RB, L = wl.W.RECORD_BYTES, wl.W.READ_LEN
     qual_id = next(c["dict_id"] for c in wl.plan["ctxs"] if c["tag"] == "QUAL")
     for v, ((off, ln, vi, r1), z) in enumerate(zip(wl.vb, z_all)):
-        for st, codec, did, ulen, pay in walk_sections(z):
+        for st, codec, did, ulen, pay, domq in walk_sections(z):
             data = bytes(pay) if codec == 1 else (R.codec_uncompress(codec, pay, ulen) if kind == "port" else R.hts_uncompress("rans" if codec < 16 else "arith", pay, ulen))
             if did == qual_id:
                 want = text[off:off + ln].reshape(-1, RB)[:, RB - L - 1:RB - 1]
-                qual_ok &= data == want.tobytes()
+                if domq:                       # the stream CODEC_DOMQ leaves of these quality lines, by the CPU restatement of codec_domq.c
+                    n = ln // RB
+                    qo = (np.arange(n, dtype=np.int64) * RB + RB - L - 1).astype(np.uint32)
+                    qual_ok &= data == pyoracle.oracle_domq(O, text[off:off + ln].tobytes(), qo, np.full(n, L, dtype=np.uint32))["qual"]
+                else:
+                    qual_ok &= data == want.tobytes()
             if codec != 1:
                 tasks.append((codec, data)); payloads.append(bytes(pay)); task_vb.append(v)
     if not tasks:
@@ -324,7 +331,7 @@ def main():
 
     codecs = {}
     for z in z_all[:1] + z_all[len(z_all) // 2:len(z_all) // 2 + 1]:
-        for st, codec, did, ulen, pay in walk_sections(z):
+        for st, codec, did, ulen, pay, _domq in walk_sections(z):
             tag = next((c["tag"] for c in wl.plan["ctxs"] if c["dict_id"] == did), did.hex())
             codecs.setdefault(("b250:" if st == 11 else "local:") + tag, CODEC_NAMES.get(codec, str(codec)))
     mode = ("stream of %d read pairs per GPU in calls of %d VBlock pairs" % (a.stream_reads, len(wl.ranges))) if a.stream_reads else \

@@ -51,7 +51,8 @@ struct GzdStream {
     uint8_t  hdr[40];         // SectionHeaderCtx template; lengths, codec and digest are patched on device
     uint32_t *out_len_dev;    // batch mode, optional: the payload length for a later section writer
     uint32_t raw_len;         // precompressed section: data_uncompressed_len of the header
-    uint8_t  pre;             // precompressed section: `in` already is the payload of codec hdr[25]
+    uint8_t  pre;             // precompressed section: `in` already is the payload of codec hdr[25] (hdr[26] when hdr_codec)
+    uint8_t  hdr_codec;       // a complex codec (DOMQ) names the section: the coder of the stream goes to sub_codec
 };
 
 struct GzdLeaf {

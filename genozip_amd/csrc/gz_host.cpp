@@ -775,6 +775,7 @@ extern "C" int gz_vb_compress_batch (GzHandle *h, GzVBlock *vbs, int n_vbs)
             gz_be32 (hd + 0, 0x27052012u);
             gz_be32 (hd + 20, u.vblock_i);
             hd[24] = sec.section_type; hd[25] = (uint8_t)codec; hd[26] = sec.sub_codec; hd[27] = sec.flags;
+            if (sec.hdr_codec) { S.hdr_codec = sec.hdr_codec; hd[25] = sec.hdr_codec; hd[26] = (uint8_t)codec; }
             hd[28] = sec.ltype; hd[29] = sec.param; hd[30] = sec.b250_size_or_nothing_char; hd[31] = 0;
             memcpy (hd + 32, sec.dict_id, 8);
             if (sec.precompressed) { S.pre = 1; S.raw_len = sec.raw_len; S.codec_req = GZ_CODEC_NONE; P.streams.push_back (S); P.streams.back ().first_leaf = (uint32_t)P.leaves.size (); continue; }
@@ -782,7 +783,7 @@ extern "C" int gz_vb_compress_batch (GzHandle *h, GzVBlock *vbs, int n_vbs)
             P.streams.push_back (S);
             // a section shorter than 50 bytes is stored raw; when the length is only known on the device we must
             // still plan the leaves of the requested codec
-            if (sec.data_len < 50 && !sec.data_len_dev) { P.streams.back ().codec_req = GZ_CODEC_NONE; P.streams.back ().hdr[25] = GZ_CODEC_NONE; }
+            if (sec.data_len < 50 && !sec.data_len_dev && !sec.hdr_codec) { P.streams.back ().codec_req = GZ_CODEC_NONE; P.streams.back ().hdr[25] = GZ_CODEC_NONE; }
             if (!plan_stream_leaves (h, P, (uint32_t)P.streams.size () - 1)) return GZ_ERR_HIP;
         }
     }
@@ -1519,6 +1520,7 @@ extern "C" int gz_vb_uncompress (GzHandle *h, const uint8_t *z_data, uint64_t z_
         if (at + 40 + clen > z_len || o + ulen > out_cap || S.size () >= max_sections) { h->err = "section overflow"; return GZ_ERR_CORRUPT; }
         GzStream s; memset (&s, 0, sizeof (s));
         s.in = z_data + at + 40; s.in_len = clen; s.out = out + o; s.out_cap = ulen; s.codec = z[at + 25];
+        if (s.codec == GZ_CODEC_DOMQ) s.codec = z[at + 26];            // USE_SUBCODEC (compressor.c:60-61, codec.c codec_args[CODEC_DOMQ])
         S.push_back (s);
         want_adler.push_back (gz_rd_be32 (&z[at + 4]));
         if (section_offsets_host) section_offsets_host[S.size () - 1] = o;

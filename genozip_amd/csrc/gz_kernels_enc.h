@@ -35,8 +35,8 @@ __global__ void k_resolve (GzdStream *streams, uint32_t n_streams, int section_m
     S.n = n;
 
     int codec = S.codec_req;
-    if (S.pre) { S.codec = S.hdr[25]; S.engine = GZ_ENG_NONE; S.order = 0; S.striped = 0; return; }   // already coded: only framed
-    if (section_mode && n < 50) codec = 1 /* CODEC_NONE: compressor.c:56-58 */;
+    if (S.pre) { S.codec = S.hdr_codec ? S.hdr[26] : S.hdr[25]; S.engine = GZ_ENG_NONE; S.order = 0; S.striped = 0; return; }   // already coded: only framed
+    if (section_mode && n < 50 && !S.hdr_codec) codec = 1 /* CODEC_NONE: compressor.c:56-58 (simple codecs) */;
     S.codec = (uint8_t)codec;
 
     int order = gz_codec_order (codec);
@@ -934,7 +934,8 @@ __global__ void __launch_bounds__(256) k_emit (GzdStream *streams, GzdLeaf *leav
         gz_be32 (h + 4,  adler);
         gz_be32 (h + 12, S.out_len);
         gz_be32 (h + 16, S.pre ? S.raw_len : S.n);
-        h[25] = S.codec;
+        if (S.hdr_codec) { h[25] = S.hdr_codec; h[26] = S.codec; }          // codec_domq.c:487-500: header->sub_codec
+        else h[25] = S.codec;
         S.status = GZ_ST_OK;
     }
 }

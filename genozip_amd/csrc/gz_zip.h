@@ -57,16 +57,20 @@ struct ZipCol {                    // one (VBlock, context) of this process
 // to several processes (the ordered dictionary merge is the one exchange step of the path): fixed part + the
 // VBlock's new words. Serialised into the "merge blob" of gz_fastq_zip_seg.
 struct ZipMergeRec {
-    uint32_t state;                // 0: nothing to merge; 1: a device column; 2: constant snip
+    uint32_t state;                // 0: nothing to merge; 1: a device column; 2: constant snip; 3: one snip of the VBlock's own (DOMQRUNS)
     uint32_t n, n_ol, n_new;
     uint64_t dict_len, seg_b250_len, b250_count, local_len;
+    uint64_t domq_local_len;       // QUAL and its three: the length of the local if the file's QUAL goes through CODEC_DOMQ (local_len: if not)
     int32_t  ats_node; uint32_t all_the_same;
-    // followed (state 1) by dict [dict_len], node_char_index [n_new], node_snip_len [n_new], counts [n_ol + n_new], each padded to 8 bytes
+    // followed (state 1) by dict [dict_len], node_char_index [n_new], node_snip_len [n_new], counts [n_ol + n_new], each padded to 8 bytes;
+    // (state 3) by the snip [dict_len], padded to 8 bytes
 };
-struct ZipBlobVB { uint32_t vblock_i, r1_vblock_i, n_ctx, reserved; };   // then n_ctx x (ZipMergeRec + payload)
+// qual: bit 0 the VBlock's QUAL was tested, bit 1 it is a fit for DOMQ (codec_domq.c:69-134), bit 2 a score outside ' '..'~'
+struct ZipBlobVB { uint32_t vblock_i, r1_vblock_i, n_ctx, qual; };   // then n_ctx x (ZipMergeRec + payload)
 struct ZipVote { uint32_t ctx, is_local, vblock_i, codec; };
 
 struct ZipVBState { std::vector<uint8_t> has_b250, has_local; std::vector<std::vector<uint8_t>> host_b250; };
+struct ZipDomq { uint8_t *out[4] = { NULL, NULL, NULL, NULL }; GzDomqResult res; uint32_t fit = 0; std::vector<uint8_t> snip; };   // one VBlock's QUAL through k_domq
 
 struct ZipCall {                   // what lives between the phases of one call
     int phase = 0;
@@ -79,6 +83,8 @@ struct ZipCall {                   // what lives between the phases of one call
     GzDynIntResult *d_dynres = NULL; uint32_t *d_seclen = NULL; int32_t *d_b250st = NULL;
     std::vector<uint8_t> blob;      // this process' merge blob
     std::vector<ZipVote> votes;
+    std::vector<ZipDomq> domq;                 // per VBlock, when the file's QUAL may go / goes through CODEC_DOMQ
+    int qual_mode_applied = -1;
     std::vector<GzStream> early;               // the streams coded ahead (results arrive when the second handle is synchronised)
     uint32_t *d_early_len = NULL;
     std::vector<int32_t> n2w_host;
@@ -96,8 +102,29 @@ struct GzZipFile {
     std::vector<ArenaBlock> ws;            // device workspace of one call (bump allocated, reused by the next call)
     std::vector<uint8_t> stage;            // host staging
     uint32_t last_vblock_i = 0;
+    // zctx->qual_codec of the QUAL context (codec.c:403-407,445): -1 not decided yet (the file's first VBlock will), 0 a plain
+    // LT_BLOB local, GZ_CODEC_DOMQ
+    int qual_ctx = -1, aux[3] = { -1, -1, -1 }, qual_mode = 0;
     ZipCall call;
 };
+
+static void zip_init_qual_mode (GzZipFile *f)
+{
+    const bool possible = f->qual_ctx >= 0 && f->aux[0] >= 0 && f->aux[1] >= 0 && f->aux[2] >= 0;
+    f->qual_mode = !possible || f->plan.qual_codec == GZ_CODEC_NONE ? 0 : f->plan.qual_codec == GZ_CODEC_DOMQ ? GZ_CODEC_DOMQ : -1;
+}
+
+// base64_encode (src/base64.c: the standard alphabet, '=' padded) of the denormalisation table -> the snip segged into DOMQRUNS
+static void zip_base64 (const uint8_t *in, size_t n, std::vector<uint8_t> &out)
+{
+    static const char A[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    out.clear ();
+    for (size_t i = 0; i < n; i += 3) {
+        const uint32_t b0 = in[i], b1 = i + 1 < n ? in[i + 1] : 0, b2 = i + 2 < n ? in[i + 2] : 0, w = b0 << 16 | b1 << 8 | b2;
+        out.push_back (A[w >> 18]); out.push_back (A[(w >> 12) & 63]);
+        out.push_back (i + 1 < n ? A[(w >> 6) & 63] : '='); out.push_back (i + 2 < n ? A[w & 63] : '=');
+    }
+}
 
 static void *ws_alloc (GzZipFile *f, size_t bytes)
 {
@@ -128,11 +155,14 @@ extern "C" GzZipFile *gz_zip_open (GzHandle *h, const GzFastqPlan *plan)
         c.snip = f->snips[i].data ();
         if ((c.kind == GZ_FQ_ITEM_TEXT || c.kind == GZ_FQ_ITEM_INT || c.kind == GZ_FQ_ITEM_DELTA) && c.item > plan->n_seps) { delete f; return NULL; }
         if ((c.kind == GZ_FQ_CONST || c.kind == GZ_FQ_ITEM_DELTA) && !c.snip_len) { delete f; return NULL; }
+        if (c.kind == GZ_FQ_QUAL) { if (f->qual_ctx >= 0) { delete f; return NULL; } f->qual_ctx = (int)i; }     // (one QUAL per plan)
+        if (c.kind == GZ_FQ_QUAL_AUX) { if (c.item > 2 || f->aux[c.item] >= 0) { delete f; return NULL; } f->aux[c.item] = (int)i; }
         f->zctx.push_back (gz_zctx_create (plan->estimated_entries));
         if (c.lcodec) gz_zctx_commit_codec (f->zctx.back (), 1, c.lcodec);
         if (c.bcodec) gz_zctx_commit_codec (f->zctx.back (), 0, c.bcodec);
     }
     f->plan.ctxs = f->ctxs.data ();
+    zip_init_qual_mode (f);
     { const char *e = getenv ("GZ_ZIP_NO_OVERLAP"); int err = 0; if (!(e && *e && *e != '0')) f->h2 = gz_create_background (h->device, &err); }
     return f;
 }
@@ -162,6 +192,7 @@ extern "C" int gz_zip_reset (GzZipFile *f)
     }
     f->last_vblock_i = 0;
     f->call = ZipCall ();
+    zip_init_qual_mode (f);
     return GZ_OK;
 }
 
@@ -341,6 +372,7 @@ struct ZipTimer {
 #define ZCHK(call) do { int rc_ = (call); if (rc_ != GZ_OK) return rc_ < 0 ? rc_ : GZ_ERR; } while (0)
 #define WS(var, type, count) type *var = (type *)ws_alloc (f, (size_t)(count) * sizeof (type)); if (!var) return GZ_ERR_HIP
 
+static void zip_apply_qual_mode (GzZipFile *f, int mode);
 static inline void blob_put (std::vector<uint8_t> &b, const void *p, size_t n)
 {
     const size_t at = b.size ();
@@ -459,6 +491,15 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     K.col.assign ((size_t)NV * NC, ZipCol ());
     auto COL = [&] (uint32_t v, uint32_t c) -> ZipCol & { return K.col[(size_t)v * NC + c]; };
     std::vector<GzIntColJob> icol_jobs; std::vector<GzDynIntJob> dyn_jobs; std::vector<GzBlobJob> blob_jobs; std::vector<GzAcgtJob> acgt_jobs;
+    std::vector<GzDomqJob> domq_jobs; std::vector<GzDomqFitJob> fit_jobs;
+    const int qmode0 = f->qual_mode;                       // as the call finds it
+    K.domq.clear (); K.qual_mode_applied = -1;
+    GzDomqResult *d_domqres = NULL; uint32_t *d_fit = NULL;
+    if (qmode0) {
+        K.domq.resize (NV);
+        if (!(d_domqres = (GzDomqResult *)ws_alloc (f, (size_t)NV * sizeof (GzDomqResult) + 16)) || !(d_fit = (uint32_t *)ws_alloc (f, (size_t)NV * 4 + 16))) return GZ_ERR_HIP;
+        HIPCHK (h, hipMemsetAsync (d_fit, 0, (size_t)NV * 4 + 16, h->stream));
+    }
     std::vector<GzColumnJob> &col_jobs = K.col_jobs;
     K.acgt_of_vb.assign (NV, -1);
     const size_t max_jobs = (size_t)NV * NC + 1;
@@ -518,7 +559,19 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
                 Z.b250_seg = j.b250; Z.n_ol = ol[c].n;
                 col_jobs.push_back (j);
             }
-            if (X.kind == GZ_FQ_SEQ || X.kind == GZ_FQ_QUAL) {
+            if (X.kind == GZ_FQ_QUAL && qmode0 && n) {
+                // N3: the four streams of CODEC_DOMQ (capacities: include/genozip_amd.h at gz_domq_columns)
+                const uint64_t B = vbs[v].text_len;
+                const size_t cap[4] = { (size_t)(2 * B + 64), (size_t)(B + B / 254 + 64), (size_t)n + 64, (size_t)B + 64 };
+                ZipDomq &D = K.domq[v];
+                for (int k = 0; k < 4; k++) if (!(D.out[k] = (uint8_t *)ws_alloc (f, cap[k]))) return GZ_ERR_HIP;
+                GzDomqJob dj; memset (&dj, 0, sizeof (dj));
+                dj.text = text; dj.off = qual_off + rr; dj.len = qual_len + rr; dj.n = n;
+                dj.qual = D.out[0]; dj.runs = D.out[1]; dj.mplx = D.out[2]; dj.divr = D.out[3]; dj.result_dev = d_domqres + v;
+                domq_jobs.push_back (dj);
+                if (qmode0 < 0) { GzDomqFitJob fj; memset (&fj, 0, sizeof (fj)); fj.text = text; fj.off = dj.off; fj.len = dj.len; fj.n = n; fj.fit_dev = d_fit + v; fit_jobs.push_back (fj); }
+            }
+            if (X.kind == GZ_FQ_SEQ || (X.kind == GZ_FQ_QUAL && qmode0 <= 0)) {
                 GzBlobJob j; memset (&j, 0, sizeof (j));
                 j.text = text; j.off = (X.kind == GZ_FQ_SEQ ? seq_off : qual_off) + rr; j.len = (X.kind == GZ_FQ_SEQ ? seq_len : qual_len) + rr; j.n = n;
                 Z.local_cap = vbs[v].text_len + 64;
@@ -543,9 +596,11 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     // SEQ / QUAL are gathered first: the QUAL streams are the long pole of the whole call, and when the file has no codec for
     // them yet, the trial compressions (a8) of the first VBlock's QUAL start on the second handle while the columns are evaluated
     for (size_t at = 0; at < blob_jobs.size (); at += 32768) ZCHK (gz_local_blob_columns (h, blob_jobs.data () + at, (int)std::min<size_t> (32768, blob_jobs.size () - at)));
+    ZCHK (gz_domq_fit (h, fit_jobs.data (), (int)fit_jobs.size ()));
+    ZCHK (gz_domq_columns (h, domq_jobs.data (), (int)domq_jobs.size ()));
     static const int trial_codecs[8] = { GZ_CODEC_RANB, GZ_CODEC_RANW, GZ_CODEC_RANb, GZ_CODEC_RANw, GZ_CODEC_ARTB, GZ_CODEC_ARTW, GZ_CODEC_ARTb, GZ_CODEC_ARTw };
     std::vector<GzStream> trial;                          // 8 per QUAL-kind context that needs a codec
-    std::vector<uint32_t> trial_ctx;
+    std::vector<uint32_t> trial_ctx; std::vector<int> trial_domq;
     const bool own_first = vbs[0].vblock_i == f->last_vblock_i + 1;   // (vblock_i are consecutive over the processes: this one opens the call)
     if (f->h2 && own_first)
         for (uint32_t c = 0; c < NC; c++) {
@@ -553,14 +608,19 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
             GzZctxView zv; gz_zctx_view (f->zctx[c], &zv);
             if (zv.lcodec) continue;
             const ZipCol &Z = COL (0, c);
-            for (int k = 0; k < 8; k++) {
-                GzStream st; memset (&st, 0, sizeof (st));
-                st.in = Z.local; st.in_len = 99999; st.in_len_dev = (const uint32_t *)(d_blobres + Z.blob_job);   // codec.c:309 (low half of the 64-bit length)
-                st.codec = trial_codecs[k]; st.out_cap = gz_codec_est_size (st.codec, 99999);
-                if (!(st.out = (uint8_t *)ws_alloc (f, (size_t)st.out_cap + 64))) return GZ_ERR_HIP;
-                trial.push_back (st);
+            // (not decided yet whether QUAL goes through DOMQ: both candidates are tried, the read-back below says which one counts)
+            for (int as_domq = 0; as_domq < 2; as_domq++) {
+                if (as_domq ? !qmode0 : qmode0 > 0) continue;
+                for (int k = 0; k < 8; k++) {
+                    GzStream st; memset (&st, 0, sizeof (st));
+                    st.in = as_domq ? K.domq[0].out[0] : Z.local; st.in_len = 99999;                          // codec.c:309 (low half of the 64-bit length)
+                    st.in_len_dev = as_domq ? (const uint32_t *)&d_domqres[0].qual_len : (const uint32_t *)(d_blobres + Z.blob_job);
+                    st.codec = trial_codecs[k]; st.out_cap = gz_codec_est_size (st.codec, 99999);
+                    if (!(st.out = (uint8_t *)ws_alloc (f, (size_t)st.out_cap + 64))) return GZ_ERR_HIP;
+                    trial.push_back (st);
+                }
+                trial_ctx.push_back (c); trial_domq.push_back (as_domq);
             }
-            trial_ctx.push_back (c);
         }
     if (!trial.empty ()) {
         ZCHK (gz_wait_for (f->h2, h));
@@ -609,8 +669,24 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     if (!acgt_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (K.acgtres.data (), d_acgtres, acgt_jobs.size () * 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK (h, hipMemcpyAsync (K.vbstat.data (), d_vbstat, 2 * (size_t)NV * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK (h, hipMemcpyAsync (&a, d_a, sizeof (a), hipMemcpyDeviceToHost, h->stream));
+    std::vector<GzDomqResult> domqres (qmode0 ? NV : 0); std::vector<uint32_t> fits (qmode0 ? NV : 0);
+    if (qmode0 && NV) {
+        HIPCHK (h, hipMemcpyAsync (domqres.data (), d_domqres, (size_t)NV * sizeof (GzDomqResult), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK (h, hipMemcpyAsync (fits.data (), d_fit, (size_t)NV * 4, hipMemcpyDeviceToHost, h->stream));
+    }
     if ((rc = gz_sync (h)) < 0) return rc;
     T.mark ("seg-sync");
+    for (uint32_t v = 0; qmode0 && v < NV; v++) {
+        ZipDomq &D = K.domq[v];
+        D.fit = fits[v];
+        if (!vbs[v].n_reads) { memset (&D.res, 0, sizeof (D.res)); D.res.status = 1; continue; }
+        D.res = domqres[v];
+        if (D.res.status == 1) zip_base64 (D.res.denorm, (size_t)D.res.num_doms * D.res.num_norm_qs, D.snip);      // codec_domq.c:232-244
+    }
+    // this process holds the call's first VBlock and the file has not decided yet: that VBlock decides (codec.c:403-445), so the
+    // long streams can be handed to the coders below; every process arrives at the same in the merge (from the blobs)
+    int qmode = qmode0;
+    if (qmode0 < 0 && own_first && NV) qmode = K.domq[0].fit ? GZ_CODEC_DOMQ : 0;
     if (a.fq.first_bad != 0xffffffffu) {
         for (uint32_t v = 0; v < NV; v++) if (a.fq.first_bad >= r0[v] && a.fq.first_bad < r_end[v]) vbs[v].status = GZ_ERR_CORRUPT;
         h->err = "not FASTQ: a read is not '@'.. / SEQ / '+'.. / QUAL of SEQ's length (fastq.c:1008-1010,1076,1121)"; return GZ_ERR_CORRUPT;
@@ -627,6 +703,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     K.blob.clear ();
     for (uint32_t v = 0; v < NV; v++) {
         ZipBlobVB hv = { vbs[v].vblock_i, vbs[v].r1 >= 0 ? vbs[vbs[v].r1].vblock_i : 0, NC, 0 };
+        if (qmode0) hv.qual = (qmode0 < 0 ? 1u : 0u) | (K.domq[v].fit ? 2u : 0u) | (K.domq[v].res.status != 1 ? 4u : 0u);
         blob_put (K.blob, &hv, sizeof (hv));
         for (uint32_t c = 0; c < NC; c++) {
             const GzFastqCtx &X = f->ctxs[c];
@@ -640,7 +717,16 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
                 Z.has_local = vbs[v].seq_has_x != 0; Z.ltype = GZ_LT_UINT8;  // NONREF_X.ltype (codec_acgt.c:34-35)
             }
             r.n = Z.n; r.local_len = Z.local_len; r.ats_node = -1;
-            if (X.kind == GZ_FQ_SEQ || X.kind == GZ_FQ_QUAL || !Z.n) { blob_put (K.blob, &r, sizeof (r)); continue; }
+            if (qmode0 && Z.n && (X.kind == GZ_FQ_QUAL || X.kind == GZ_FQ_QUAL_AUX)) {
+                const ZipDomq &D = K.domq[v];
+                r.domq_local_len = X.kind == GZ_FQ_QUAL ? D.res.qual_len : X.item == 0 ? D.res.runs_len : X.item == 1 ? D.res.mplx_len : D.res.divr_len;
+                if (X.kind == GZ_FQ_QUAL_AUX && X.item == 0 && !D.snip.empty ()) {          // seg_by_ctx (denorm_snip) (codec_domq.c:244): one b250 entry
+                    r.state = 3; r.n = 1; r.dict_len = D.snip.size ();
+                    blob_put (K.blob, &r, sizeof (r)); blob_put (K.blob, D.snip.data (), D.snip.size ());
+                    continue;
+                }
+            }
+            if (X.kind == GZ_FQ_SEQ || X.kind == GZ_FQ_QUAL || X.kind == GZ_FQ_QUAL_AUX || !Z.n) { blob_put (K.blob, &r, sizeof (r)); continue; }
             if (Z.col_job < 0) { r.state = 2; blob_put (K.blob, &r, sizeof (r)); continue; }
             const GzColumnResult &cr = K.colres[Z.col_job];
             const GzdPackJob &p = pack[Z.col_job];
@@ -664,14 +750,19 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     // sections instead of after them. Their codec must be known for that: committed in the file, or decided here by trial on
     // the call's first VBlock - which only the process that owns that VBlock may do (a serial run commits VBlock 1's choice).
     K.early.clear ();
+    if (qmode >= 0) {
+        if (qmode == GZ_CODEC_DOMQ) for (uint32_t v = 0; v < NV; v++) if (K.domq[v].res.status != 1) {
+            vbs[v].status = GZ_ERR_CORRUPT; h->err = "QUAL: a score outside ' '..'~' (codec_domq.c:150-153)"; return GZ_ERR_CORRUPT; }
+        zip_apply_qual_mode (f, qmode);
+    }
     if (f->h2 && NV) {
         if (!trial.empty () && (rc = gz_sync (f->h2)) < 0) { h->err = f->h2->err; return rc; }
         for (uint32_t c = 0; c < NC; c++) {
-            if (f->ctxs[c].kind != GZ_FQ_QUAL) continue;
+            if (f->ctxs[c].kind != GZ_FQ_QUAL || qmode < 0) continue;
             GzZctxView zv; gz_zctx_view (f->zctx[c], &zv);
             int codec = zv.lcodec;
             for (size_t t = 0; !codec && t < trial_ctx.size (); t++) {
-                if (trial_ctx[t] != c || COL (0, c).local_len < 50) continue;            // codec.c:311-312: too small a sample decides nothing
+                if (trial_ctx[t] != c || trial_domq[t] != (qmode == GZ_CODEC_DOMQ) || COL (0, c).local_len < 50) continue;            // codec.c:311-312: too small a sample decides nothing
                 const uint32_t sample = (uint32_t)std::min<uint64_t> (COL (0, c).local_len, 99999);
                 uint32_t best_size = sample; codec = GZ_CODEC_NONE;                     // NONE: the bare length (codec.c:324)
                 for (int k = 0; k < 8; k++) {
@@ -704,6 +795,25 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     K.phase = 1;
     T.mark ("staging+blob+early"); T.done ("seg");
     return GZ_OK;
+}
+
+// QUAL and its three contexts of this process' VBlocks, once the file's QUAL codec is known (codec_domq_comp_init, codec_domq.c:299-323)
+static void zip_apply_qual_mode (GzZipFile *f, int mode)
+{
+    ZipCall &K = f->call;
+    if (K.qual_mode_applied == mode || f->qual_ctx < 0) return;
+    K.qual_mode_applied = mode;
+    const uint32_t NC = (uint32_t)f->ctxs.size ();
+    for (uint32_t v = 0; v < K.NV; v++) {
+        if (mode != GZ_CODEC_DOMQ || !K.vbs[v].n_reads) continue;          // (a plain local: as gathered; the three stay empty)
+        const ZipDomq &D = K.domq[v];
+        const uint64_t len[4] = { D.res.qual_len, D.res.runs_len, D.res.mplx_len, D.res.divr_len };
+        for (int k = 0; k < 4; k++) {
+            ZipCol &Z = K.col[(size_t)v * NC + (k ? f->aux[k - 1] : f->qual_ctx)];
+            Z.local = D.out[k]; Z.local_len = len[k]; Z.local_cap = len[k]; Z.has_local = len[k] != 0;
+            Z.ltype = k ? GZ_LT_SUPP : GZ_LT_CODEC;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -740,6 +850,7 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
                 const ZipMergeRec *r = (const ZipMergeRec *)p;
                 p += sizeof (ZipMergeRec);
                 if (r->state == 1) p += ((r->dict_len + 7) & ~7ull) + 8ull * r->n_new + ((4ull * r->n_new + 7) & ~7ull) + ((4ull * ((uint64_t)r->n_ol + r->n_new) + 7) & ~7ull);
+                if (r->state == 3) p += (r->dict_len + 7) & ~7ull;
                 if (p > end) { h->err = "merge blob: truncated"; return GZ_ERR_CORRUPT; }
             }
         }
@@ -747,6 +858,17 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
     std::stable_sort (ents.begin (), ents.end (), [] (const Ent &a, const Ent &b) { return a.vblock_i < b.vblock_i; });
     for (size_t i = 0; i < ents.size (); i++)
         if ((i && ents[i].vblock_i == ents[i - 1].vblock_i) || ents[i].vblock_i <= f->last_vblock_i) { h->err = "merge: a vblock_i twice, or not after the previous call's"; return GZ_ERR_ARG; }
+    // codec_assign_best_qual_codec (codec.c:391-450): the first VBlock of the file to get there decides for the file - in a serial
+    // run VBlock 1. FASTQ has no SEQ-dependent QUAL codec, so it is DOMQ if that VBlock's lines are a fit, else a plain local
+    if (f->qual_mode < 0 && !ents.empty ()) {
+        const uint32_t q = ((const ZipBlobVB *)ents[0].p)->qual;
+        if (!(q & 1)) { h->err = "merge blob: the first VBlock's QUAL was not tested"; return GZ_ERR_CORRUPT; }
+        f->qual_mode = (q & 2) ? GZ_CODEC_DOMQ : 0;
+    }
+    const int qmode = f->qual_mode;
+    if (qmode == GZ_CODEC_DOMQ)
+        for (const Ent &e : ents) if (((const ZipBlobVB *)e.p)->qual & 4) { h->err = "QUAL: a score outside ' '..'~' (codec_domq.c:150-153)"; return GZ_ERR_CORRUPT; }
+    zip_apply_qual_mode (f, qmode);
     std::map<uint32_t, uint32_t> own;                       // vblock_i -> index in vbs
     for (uint32_t v = 0; v < NV; v++) own[vbs[v].vblock_i] = v;
 
@@ -773,29 +895,34 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
             p += sizeof (ZipMergeRec);
             ZipCol scratch;
             ZipCol &Z = mine ? COL (v, c) : scratch;
-            bool has_local = r->local_len != 0;
+            const bool qual_kind = X.kind == GZ_FQ_QUAL || X.kind == GZ_FQ_QUAL_AUX;
+            const uint64_t local_len = qual_kind ? (qmode == GZ_CODEC_DOMQ ? r->domq_local_len : X.kind == GZ_FQ_QUAL ? r->local_len : 0) : r->local_len;
+            const uint8_t *payload3 = NULL;
+            if (r->state == 3) { payload3 = p; p += (r->dict_len + 7) & ~7ull; }
+            bool has_local = local_len != 0;
             if (X.kind == GZ_FQ_SEQ) has_local = mine ? Z.has_local : false;    // (NONREF_X takes no part in any pair rule)
             VS.has_local[c] = has_local;
-            if (r->state == 0) continue;
+            if (r->state == 0 || (r->state == 3 && qmode != GZ_CODEC_DOMQ)) continue;
             GzMergeJob m; memset (&m, 0, sizeof (m));
             m.vblock_i = hv->vblock_i;
-            m.local_len = r->local_len;
+            m.local_len = local_len;
             m.pair2_identical = is_r2 && X.pair_identical;
             if (is_r2) { m.b250_r1_len = R1->has_b250[c]; m.local_r1_len = R1->has_local[c]; }
-            if (r->state == 2) {
+            if (r->state == 2 || r->state == 3) {
+                const uint8_t *snip = r->state == 3 ? payload3 : X.snip; const uint32_t snip_len = r->state == 3 ? (uint32_t)r->dict_len : X.snip_len;
                 // GZ_FQ_CONST / GZ_FQ_ITEM_DELTA: every line segs `snip` - one node, count = lines (b250_seg_append's
                 // all-the-same collapse, b250.c:117-141); evaluated here, no device work. The snip is looked up in the
                 // dictionary as it is NOW: a word added by an earlier VBlock of this call then counts as cloned, which
                 // changes no byte (the node of a new word and the index of a cloned one convert to the same word index)
-                const uint32_t found = zctx_find (z, gz_snip_mix (X.snip, X.snip_len), X.snip, X.snip_len);
+                const uint32_t found = zctx_find (z, gz_snip_mix (snip, snip_len), snip, snip_len);
                 const uint32_t n_words = (uint32_t)z->snip_len.size ();
                 const uint64_t seg_len = found == GZ_NO_WORD ? 4 : found <= 126 ? 1 : found <= 16508 ? 2 : found <= 2113660 ? 3 : 4;
                 std::vector<uint32_t> cnt ((size_t)n_words + 1, 0);
                 const int32_t node = found == GZ_NO_WORD ? (int32_t)n_words : (int32_t)found;
                 cnt[(size_t)node] = r->n;
-                const uint64_t one_ci = 0; const uint32_t one_sl = X.snip_len;
+                const uint64_t one_ci = 0; const uint32_t one_sl = snip_len;
                 int32_t w1 = -1; uint8_t no_ston[8];
-                m.n_ol = n_words; m.n_new = found == GZ_NO_WORD; m.dict = X.snip; m.node_char_index = &one_ci; m.node_snip_len = &one_sl; m.counts = cnt.data ();
+                m.n_ol = n_words; m.n_new = found == GZ_NO_WORD; m.dict = snip; m.node_char_index = &one_ci; m.node_snip_len = &one_sl; m.counts = cnt.data ();
                 m.b250_len = seg_len; m.flags = X.flags | ATS; m.ats_node_index = node;
                 m.node2word = &w1; m.ston_local = no_ston; m.ston_cap = 0;
                 if ((rc = gz_ctx_merge (z, &m)) != GZ_OK) { h->err = "gz_ctx_merge (constant snip)"; return rc < 0 ? rc : GZ_ERR; }
@@ -981,6 +1108,8 @@ extern "C" int gz_fastq_zip_finish (GzZipFile *f, const void *const *votes, cons
     const uint8_t ATS = 0x20, PAIRED = 0x04;
     int rc;
     ZipTimer T;
+    uint32_t qual_lcodec_voter = 0xffffffffu;      // the VBlock whose vote gave QUAL's stream its coder in this call
+    if (f->qual_ctx >= 0) { GzZctxView zv; gz_zctx_view (f->zctx[f->qual_ctx], &zv); if (zv.lcodec) qual_lcodec_voter = 0; }   // (known before the call)
     {
         std::map<std::pair<uint32_t, uint32_t>, ZipVote> win;
         for (int b = 0; b < n_votes; b++) {
@@ -996,6 +1125,7 @@ extern "C" int gz_fastq_zip_finish (GzZipFile *f, const void *const *votes, cons
         for (auto &w : win) {
             GzZctxView zv; gz_zctx_view (f->zctx[w.first.first], &zv);
             if (w.first.second ? zv.lcodec : zv.bcodec) continue;
+            if ((int)w.first.first == f->qual_ctx && w.first.second) qual_lcodec_voter = w.second.vblock_i;
             gz_zctx_commit_codec (f->zctx[w.first.first], (int)w.first.second, (int)w.second.codec);
             for (uint32_t v = 0; v < NV; v++) { ZipCol &Z = COL (v, w.first.first); if (w.first.second) { if (!Z.lcodec) Z.lcodec = (uint8_t)w.second.codec; } else if (!Z.bcodec) Z.bcodec = (uint8_t)w.second.codec; }
         }
@@ -1007,7 +1137,9 @@ extern "C" int gz_fastq_zip_finish (GzZipFile *f, const void *const *votes, cons
         std::vector<GzSecOrderIn> in (NC);
         for (uint32_t c = 0; c < NC; c++) {
             const ZipCol &Z = COL (v, c);
-            in[c].did_i = f->ctxs[c].did_i; in[c].local_dep = f->ctxs[c].local_dep; in[c].has_local = Z.has_local; in[c].ston_only_local = Z.ston_only_local; in[c].has_b250 = Z.has_b250;
+            in[c].did_i = f->ctxs[c].did_i; in[c].local_dep = f->ctxs[c].local_dep;
+            if ((int)c == f->qual_ctx && f->qual_mode == GZ_CODEC_DOMQ) in[c].local_dep = 1;           // DEP_L1 (codec_domq.c:310)
+            in[c].has_local = Z.has_local; in[c].ston_only_local = Z.ston_only_local; in[c].has_b250 = Z.has_b250;
         }
         std::vector<uint32_t> order (2 * NC);
         const uint32_t ns = gz_section_order (in.data (), NC, vbs[v].vblock_i, order.data ());
@@ -1032,6 +1164,12 @@ extern "C" int gz_fastq_zip_finish (GzZipFile *f, const void *const *votes, cons
                     s.precompressed = 1; s.raw_len = es.in_len; s.data = es.out; s.data_len = es.out_cap; s.data_len_dev = es.out_len_dev;
                 }
                 s.codec = Z.lcodec; s.ltype = (uint8_t)Z.ltype;
+                if (Z.ltype == GZ_LT_CODEC) {                                                          // QUAL through CODEC_DOMQ (codec_domq.c:221,308-309,487-500)
+                    // the stream's coder: the file's, as VBlock v would find it in a serial run (codec.c:280-281) - however short the
+                    // stream; none known yet -> NONE; all lines diverse -> the single byte 'X', NONE (codec_domq.c:490-500)
+                    s.hdr_codec = GZ_CODEC_DOMQ; s.param = (uint8_t)(K.domq[v].res.num_norm_qs | 0x80);
+                    if (K.domq[v].res.all_diverse || !s.codec || vbs[v].vblock_i < qual_lcodec_voter) s.codec = GZ_CODEC_NONE;
+                }
                 const bool int_lt = Z.ltype >= GZ_LT_INT8 && Z.ltype <= GZ_LT_UINT64;
                 if (int_lt) s.b250_size_or_nothing_char = X.nothing_char ? X.nothing_char : 0xff;    // zfile.c:344-345
                 if (is_r1 && X.pair_identical) s.flags |= PAIRED;                                     // zfile.c:323-325

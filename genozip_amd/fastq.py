@@ -12,7 +12,7 @@ of the reference's segmenter, SURVEY 2 OUT OF SCOPE) - every line segs the same 
 """
 import ctypes as C
 
-from .lib import (GzFastqCtx, GzFastqPlan, GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL)
+from .lib import (GzFastqCtx, GzFastqPlan, GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL, GZ_FQ_QUAL_AUX)
 
 DTYPE_FIELD, DTYPE_1, DTYPE_2 = 0, 1, 2
 STORE_INT = 1
@@ -28,8 +28,10 @@ def dict_id(tag, dtype=DTYPE_FIELD):
 
 # did_i follow the order of the #pragma GENDICT lines of src/sam.h:19-86 (FASTQ shares SAM's Dids, src/fastq.h:13-60);
 # only their relative order matters here (sections appear in ascending did_i)
-def illumina_plan(paired=True, qual_codec=0, estimated_entries=0):
-    """-> list of dict(tag, dict_id, did_i, kind, item, flags, snip, ...) for GzFastqPlan"""
+def illumina_plan(paired=True, qual_codec=0, estimated_entries=0, domq=0):
+    """-> list of dict(tag, dict_id, did_i, kind, item, flags, snip, ...) for GzFastqPlan.
+    qual_codec: hard-coded coder of the QUAL stream (0: codec_assign_best_codec); domq: 0 the reference's own rule (the file's first
+    VBlock decides, codec.c:391-450), 1 (CODEC_NONE) --no-domqual, 13 (CODEC_DOMQ) --force-domq"""
     P = []
 
     def ctx(tag, did_i, kind, dtype=DTYPE_FIELD, item=0, flags=0, snip=b"", pair_identical=False, no_stons=False, lcodec=0, bcodec=0,
@@ -52,12 +54,14 @@ def illumina_plan(paired=True, qual_codec=0, estimated_entries=0):
     ctx("SQBITMAP", 40, GZ_FQ_CONST, snip=bytes([SNIP_SPECIAL]) + b"<unaligned SEQ>", pair_assisted_b250=True)
     ctx("NONREF_X", 42, GZ_FQ_SEQ, local_dep=1)
     ctx("QUAL", 80, GZ_FQ_QUAL, lcodec=qual_codec)
+    for k, tag in enumerate(("DOMQRUNS", "QUALMPLX", "DIVRQUAL")):     # "these 3 must be right after SAM_QUAL" (src/sam.h:108-110)
+        ctx(tag, 81 + k, GZ_FQ_QUAL_AUX, item=k, local_dep=2)
     ctx("TOPLEVEL", 90, GZ_FQ_CONST, snip=bytes([SNIP_CONTAINER]) + b"<fastq toplevel>", pair_identical=pi)
     ctx("E1L", 96, GZ_FQ_CONST, snip=b"\n", pair_identical=pi)
     ctx("E2L", 97, GZ_FQ_CONST, snip=b"\n", pair_identical=pi)
     ctx("LINE3", 98, GZ_FQ_CONST, snip=b"", pair_identical=pi)        # replaced below: an empty line 3 is the snip ""
     P[-1]["snip"] = bytes([SNIP_SPECIAL]) + b"<line3 = empty>"
-    return dict(ctxs=P, seps=b":::: :+", sep_counts=[3, 1, 1, 1, 1, 3, 1], paired=paired, estimated_entries=estimated_entries)
+    return dict(ctxs=P, seps=b":::: :+", sep_counts=[3, 1, 1, 1, 1, 3, 1], paired=paired, estimated_entries=estimated_entries, qual_codec=domq)
 
 
 def c_plan(plan):
@@ -78,4 +82,5 @@ def c_plan(plan):
     p.seps = plan["seps"]
     p.sep_counts = (C.c_uint8 * 16)(*(list(plan["sep_counts"]) + [0] * (16 - len(plan["sep_counts"]))))
     p.n_seps, p.paired, p.estimated_entries = len(plan["seps"]), int(plan["paired"]), plan["estimated_entries"]
+    p.qual_codec = plan.get("qual_codec", 0)
     return p, keep

@@ -68,7 +68,7 @@ class GzSection(C.Structure):
     _fields_ = [("data", C.c_void_p), ("data_len", C.c_uint32), ("data_len_dev", C.c_void_p),
                 ("section_type", C.c_uint8), ("codec", C.c_uint8), ("sub_codec", C.c_uint8), ("flags", C.c_uint8),
                 ("ltype", C.c_uint8), ("param", C.c_uint8), ("b250_size_or_nothing_char", C.c_uint8),
-                ("dict_id", C.c_uint8 * 8), ("precompressed", C.c_uint8), ("raw_len", C.c_uint32)]
+                ("dict_id", C.c_uint8 * 8), ("precompressed", C.c_uint8), ("raw_len", C.c_uint32), ("hdr_codec", C.c_uint8)]
 
 
 class GzVBlock(C.Structure):
@@ -116,7 +116,7 @@ class GzFastqCtx(C.Structure):
 
 class GzFastqPlan(C.Structure):
     _fields_ = [("ctxs", C.POINTER(GzFastqCtx)), ("n_ctxs", C.c_uint32), ("seps", C.c_char * 16), ("sep_counts", C.c_uint8 * 16),
-                ("n_seps", C.c_uint32), ("paired", C.c_uint8), ("estimated_entries", C.c_uint32)]
+                ("n_seps", C.c_uint32), ("paired", C.c_uint8), ("estimated_entries", C.c_uint32), ("qual_codec", C.c_uint8)]
 
 
 class GzFastqVB(C.Structure):
@@ -129,7 +129,7 @@ class GzSecOrderIn(C.Structure):
     _fields_ = [("did_i", C.c_uint16), ("local_dep", C.c_uint8), ("has_local", C.c_uint8), ("ston_only_local", C.c_uint8), ("has_b250", C.c_uint8)]
 
 
-GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL = 1, 2, 3, 4, 5, 6
+GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL, GZ_FQ_QUAL_AUX = 1, 2, 3, 4, 5, 6, 7
 
 # every symbol include/genozip_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (

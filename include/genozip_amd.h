@@ -182,6 +182,9 @@ typedef struct {
                                      possibly on another handle: gz_emit_after): only framed here; `codec` = the effective
                                      codec, raw_len = data_uncompressed_len of the header                           */
     uint32_t raw_len;
+    uint8_t  hdr_codec;           /* nonzero: a complex codec whose primary stream this is (GZ_CODEC_DOMQ): it goes to the header's
+                                     codec byte and the coder of the stream (`codec`, as given: the 50-byte rule is for simple codecs)
+                                     to sub_codec, as codec_domq_compress sets them (src/codec_domq.c:487-500)                */
 } GzSection;
 
 typedef struct {
@@ -408,7 +411,12 @@ enum {
     GZ_FQ_SEQ        = 5,  /* SEQ of every read -> NONREF.local, then CODEC_ACGT's 2-bit pack (fastq_seq.c:139-154,
                               codec_acgt.c:64-137): the packed bytes are handed back for the LZMA sub-codec (host, out of
                               scope); dict_id names the NONREF_X exception stream, written when there are any    */
-    GZ_FQ_QUAL       = 6   /* QUAL of every read -> QUAL.local (fastq_qual.c:24-60 through the get_line callback)           */
+    GZ_FQ_QUAL       = 6,  /* QUAL of every read -> QUAL.local (fastq_qual.c:24-60 through the get_line callback). When the plan
+                              also holds its three GZ_FQ_QUAL_AUX contexts, codec_assign_best_qual_codec (src/codec.c:391-450) is
+                              followed as far as FASTQ can go: the file's first VBlock decides between CODEC_DOMQ (N3: its QUAL
+                              lines pass codec_domq_qual_data_is_a_fit_for_domq) and a plain LT_BLOB local, for the whole file     */
+    GZ_FQ_QUAL_AUX   = 7   /* DOMQRUNS / QUALMPLX / DIVRQUAL (item 0 / 1 / 2) of the plan's QUAL context: LT_SUPP locals at DEP_L2
+                              (codec_domq.c:308-313); DOMQRUNS' dictionary takes the denormalisation table (:240-244)              */
 };
 typedef struct {
     uint8_t  dict_id[8];
@@ -430,6 +438,7 @@ typedef struct {
                                    sep_counts[i]-th seps[i] (CI0_COLONn, src/qname_flavors.h:40-49); n_seps + 1 items        */
     uint8_t  paired;              /* --pair: R2 VBlocks name their R1 VBlock                                              */
     uint32_t estimated_entries;   /* hash_get_estimated_entries' figure for the dictionaries (0: default)                  */
+    uint8_t  qual_codec;          /* 0: as the reference decides (above); GZ_CODEC_NONE: --no-domqual; GZ_CODEC_DOMQ: --force-domq    */
 } GzFastqPlan;
 typedef struct {
     uint64_t text_off, text_len;  /* in: the VBlock's slice of the text: whole reads                                      */

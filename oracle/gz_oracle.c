@@ -1350,8 +1350,15 @@ static void be32 (uint8_t *p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (u
 
 long gzo_section_compress (const GzoCtxSectionDesc *d, const uint8_t *data, uint32_t data_len, uint8_t *z, uint64_t z_cap)
 {
-    int codec = d->codec;
-    if (data_len < 50) codec = GZO_CODEC_NONE;                           /* compressor.c:56-58 */
+    int codec = d->codec, complex_codec = 0;
+    if (codec == 13 /* CODEC_DOMQ */) {
+        /* the primary stream of a complex codec: the header keeps its name, the stream is coded by the sub-codec that
+         * codec_assign_best_codec gave (the file's, however short the stream; a stream under 50 bytes assigns none) - NONE when it
+         * gave none ("really small") (codec_domq.c:487-510, compressor.c:60-61; the 50-byte rule of :56-58 is for simple codecs) */
+        complex_codec = codec;
+        codec = d->sub_codec ? d->sub_codec : GZO_CODEC_NONE;
+    }
+    else if (data_len < 50) codec = GZO_CODEC_NONE;                      /* compressor.c:56-58: simple codecs only */
     uint32_t est = gzo_codec_est_size (codec, data_len);
     if (z_cap < (uint64_t)GZO_CTX_SECTION_HEADER_LEN + est) return -1;
 
@@ -1369,6 +1376,7 @@ long gzo_section_compress (const GzoCtxSectionDesc *d, const uint8_t *data, uint
     be32 (h + 16, data_len);
     be32 (h + 20, d->vblock_i);
     h[24] = d->section_type; h[25] = (uint8_t)codec; h[26] = d->sub_codec; h[27] = d->flags;
+    if (complex_codec) { h[25] = (uint8_t)complex_codec; h[26] = (uint8_t)codec; }
     h[28] = d->ltype; h[29] = d->param; h[30] = d->b250_size_or_nothing_char; h[31] = 0;
     memcpy (h + 32, d->dict_id, 8);
     return (long)GZO_CTX_SECTION_HEADER_LEN + clen;

@@ -48,7 +48,7 @@ def read_file(blob, decode):
         assert struct.unpack(">I", hd[:4])[0] == MAGIC and hd[24] == s["st"], (s, hd[:28])
         if s["st"] == SEC_DICT:
             clen, ulen = struct.unpack(">II", hd[12:20])
-            data = decode(hd[25], blob[s["offset"] + 40:s["offset"] + 40 + clen], ulen)
+            data = decode(hd[26] if hd[25] == 13 else hd[25], blob[s["offset"] + 40:s["offset"] + 40 + clen], ulen)   # (CODEC_DOMQ: its sub-codec)
             words = data[:-1].split(b"\0")
             assert len(words) == struct.unpack(">I", hd[28:32])[0] and hd[32:40] == s["dict_id"]
             out["dicts"].setdefault(s["dict_id"], []).extend(words)

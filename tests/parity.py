@@ -420,7 +420,7 @@ def merge_chain(E, oracle, n):
     assert E.L.gz_hash_next_size_up(3000) == 65521 and E.L.gz_hash_next_size_up(65521) == 92681 and E.L.gz_hash_next_size_up(10 ** 9) == 16777213
 
 
-def fastq_text(n_reads, seed=11, crlf_every=0, read_len=150, mate=None, qual_seed=None, dirty_seq=False):
+def fastq_text(n_reads, seed=11, crlf_every=0, read_len=150, mate=None, qual_seed=None, dirty_seq=False, qual="uniform"):
     """a small FASTQ text in the shape of SURVEY 8d config 1 (Illumina-7 names, 40-level qualities). mate = 1 / 2: the
     paired form - plain '+' third lines, names that differ between the mates in the read number only (own SEQ / QUAL)"""
     r = synth.u32(seed, 4 * n_reads + 8).astype(np.int64)
@@ -429,6 +429,10 @@ def fastq_text(n_reads, seed=11, crlf_every=0, read_len=150, mate=None, qual_see
     if dirty_seq:
         seqs[synth.u32(sq + 5, n_reads * read_len).reshape(n_reads, read_len) % 97 == 0] = ord("N")
     quals = (synth.uniform_bytes(seed + 2 if qual_seed is None else qual_seed, n_reads * read_len, 40) + 33).astype(np.uint8).reshape(n_reads, read_len)
+    if qual == "bin":                          # Illumina-binned scores, mostly 'F': a fit for CODEC_DOMQ; every 9th line stays diverse
+        qb = synth.quality_binned(seed + 2 if qual_seed is None else qual_seed, n_reads, read_len)
+        keep = np.arange(n_reads) % 9 == 4
+        quals = np.where(keep[:, None], quals, qb).astype(np.uint8)
     out = []
     for i in range(n_reads):
         eol = b"\r\n" if crlf_every and i % crlf_every == 0 else b"\n"
@@ -609,11 +613,14 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
     functions, VBlock by VBlock. zstate carries the file-level contexts and codecs from call to call.
     -> (list of dict(z, seq_packed, n_bases, seq_has_x), zstate)"""
     import pyoracle as po
-    from genozip_amd.lib import (GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL)
+    from genozip_amd.lib import (GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL, GZ_FQ_QUAL_AUX)
+    import base64
     C = plan["ctxs"]
     NC = len(C)
+    aux = {X["item"]: c for c, X in enumerate(C) if X["kind"] == GZ_FQ_QUAL_AUX}
     if zstate is None:
-        zstate = dict(z=[po.OracleZctx(oracle, plan["estimated_entries"]) for _ in C], lcodec=[c["lcodec"] for c in C], bcodec=[c["bcodec"] for c in C], flags_vb1=[0] * NC)
+        zstate = dict(z=[po.OracleZctx(oracle, plan["estimated_entries"]) for _ in C], lcodec=[c["lcodec"] for c in C], bcodec=[c["bcodec"] for c in C], flags_vb1=[0] * NC,
+                      qual_mode=0 if len(aux) != 3 or plan.get("qual_codec") == 1 else 13 if plan.get("qual_codec") == 13 else None)
     lo, ll = oracle.text_lines(text)
     bad, cols = oracle.fastq_records(text, lo, ll)
     assert bad == 0
@@ -634,6 +641,10 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
         a = lo_list.index(off) // 4
         b = (lo_list.index(off + ln) // 4) if off + ln < len(text) else len(l1o)
         rng.append((a, b))
+    # codec_assign_best_qual_codec (codec.c:391-450): the file's first VBlock decides whether QUAL goes through CODEC_DOMQ
+    if zstate["qual_mode"] is None and vbs:
+        a, b = rng[0]
+        zstate["qual_mode"] = 13 if po.oracle_domq(oracle, text, qo[a:b], ql[a:b])["fit"] else 0
     # seg
     for v, (off, ln, vi, r1) in enumerate(vbs):
         a, b = rng[v]
@@ -661,15 +672,23 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
                 seq = oracle.local_blob_column(text, so[a:b], sl[a:b], False)
                 packed, x, has_x = oracle.acgt_pack(seq)
                 st.update(seq_packed=packed, n_bases=len(seq), seq_has_x=has_x, local=x, ltype=2, has_local=has_x)
+            elif k == GZ_FQ_QUAL and zstate["qual_mode"] == 13 and n:
+                dq = po.oracle_domq(oracle, text, qo[a:b], ql[a:b])
+                st.update(local=dq["qual"], ltype=13, has_local=len(dq["qual"]) > 0, param=dq["num_norm_qs"] | 0x80, domq=dq)
             elif k == GZ_FQ_QUAL:
                 q = oracle.local_blob_column(text, qo[a:b], ql[a:b], False)
                 st.update(local=q, ltype=11, has_local=len(q) > 0)
+        if zstate["qual_mode"] == 13 and n:                           # codec_domq.c:308-313,240-244
+            dq = next(S[v][c] for c, X in enumerate(C) if X["kind"] == GZ_FQ_QUAL)["domq"]
+            for item, key in enumerate(("runs", "mplx", "divr")):
+                S[v][aux[item]].update(local=dq[key], ltype=27, has_local=len(dq[key]) > 0)
+            S[v][aux[0]]["own_snip"] = base64.b64encode(dq["denorm"])
     # merge, context by context, VBlocks in order
     for c, X in enumerate(C):
         OZ = zstate["z"][c]
         for v, (off, ln, vi, r1) in enumerate(vbs):
             st = S[v][c]
-            if X["kind"] in (GZ_FQ_SEQ, GZ_FQ_QUAL) or not st["n"]:
+            if X["kind"] in (GZ_FQ_SEQ, GZ_FQ_QUAL) or not st["n"] or (X["kind"] == GZ_FQ_QUAL_AUX and "own_snip" not in st):
                 continue
             is_r2 = r1 >= 0
             kw = dict(flags=X["flags"], local_len=len(st["local"]), pair2_identical=is_r2 and X["pair_identical"])
@@ -677,14 +696,14 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
                 kw.update(b250_r1_len=int(S[r1][c]["has_b250"]), local_r1_len=int(S[r1][c]["has_local"]))
             if st["col"] is None:                                     # constant snip
                 words = OZ.words()
-                snip = X["snip"]
+                snip, n_seg = (st["own_snip"], 1) if "own_snip" in st else (X["snip"], st["n"])
                 found = words.index(snip) if snip in words else -1
                 node = found if found >= 0 else len(words)
-                cnt = np.zeros(len(words) + 1, dtype=np.uint32); cnt[node] = st["n"]
+                cnt = np.zeros(len(words) + 1, dtype=np.uint32); cnt[node] = n_seg
                 col = dict(node_index=np.array([node], dtype=np.int32), dict=b"" if found >= 0 else snip + b"\0",
                            node_char_index=np.zeros(0 if found >= 0 else 1, dtype=np.uint64),
                            node_snip_len=np.array([] if found >= 0 else [len(snip)], dtype=np.uint32), counts=cnt[:len(words) + (found < 0)],
-                           b250=oracle.b250_seg([node], len(words)), b250_count=st["n"], all_the_same=True)
+                           b250=oracle.b250_seg([node], len(words)), b250_count=n_seg, all_the_same=True)
                 m = OZ.merge(vi, len(words), col, can_have_singletons=False, **kw)
                 wi = found if found >= 0 else int(m["node2word"][0])
                 st.update(ats=True, has_b250=not m["dropped_b250"], b250=oracle.b250_piz([wi]))
@@ -732,6 +751,7 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
             st, R1 = S[v][c], S[r1][c]
             if X["pair_identical"] and st["has_b250"] and R1["b250_kept"] is not None and st["b250"] == R1["b250_kept"]:
                 st["drop_b250_section"] = True
+    voter = {}                                             # (context, is_local) -> the VBlock of this call that assigned the codec
     for c, X in enumerate(C):
         for is_local in (1, 0):
             key = "lcodec" if is_local else "bcodec"
@@ -742,12 +762,13 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
                 data = st["local"] if is_local else st.get("b250", b"")
                 if (st["has_local"] if is_local else st["has_b250"]) and len(data) >= 50:
                     zstate[key][c] = oracle.assign_best(data)[0]
+                    voter[(c, is_local)] = v
                     break
     out = []
     for v, (off, ln, vi, r1) in enumerate(vbs):
         a, b = rng[v]
         is_r2, is_r1 = r1 >= 0, plan["paired"] and r1 < 0
-        order = _section_order_ref([(X["did_i"], X["local_dep"], S[v][c]["has_local"], S[v][c]["ston_only"], S[v][c]["has_b250"]) for c, X in enumerate(C)], vi)
+        order = _section_order_ref([(X["did_i"], 1 if S[v][c]["ltype"] == 13 else X["local_dep"], S[v][c]["has_local"], S[v][c]["ston_only"], S[v][c]["has_b250"]) for c, X in enumerate(C)], vi)
         z = bytearray(84)
         for c, kind in order:
             X, st = C[c], S[v][c]
@@ -765,8 +786,11 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
                 if is_r1 and X["pair_identical"]:
                     flags |= 4
                 int_lt = 1 <= st["ltype"] <= 8
-                d = po.GzoCtxSectionDesc(vblock_i=vi, section_type=SEC_LOCAL, codec=zstate["lcodec"][c] or 6, sub_codec=0, flags=flags, ltype=st["ltype"], param=0,
+                d = po.GzoCtxSectionDesc(vblock_i=vi, section_type=SEC_LOCAL, codec=zstate["lcodec"][c] or 6, sub_codec=0, flags=flags, ltype=st["ltype"], param=st.get("param", 0),
                                          b250_size_or_nothing_char=(X["nothing_char"] or 0xff) if int_lt else 0)
+                if st["ltype"] == 13:                                  # LT_CODEC: QUAL through CODEC_DOMQ; the file's coder as VBlock v finds it (codec.c:280-281)
+                    known = zstate["lcodec"][c] if v >= voter.get((c, 1), -1) else 0
+                    d.codec, d.sub_codec = 13, 0 if st["domq"]["all_diverse"] else known
                 data = st["local"]
             d.dict_id[:] = list(X["dict_id"])
             z += oracle.section_compress(d, data)
@@ -777,19 +801,19 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
     return out, zstate
 
 
-def fastq_zip(E, oracle, n_reads, n_calls=2):
+def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0):
     """the whole a1-a16 path from FASTQ text: gz_fastq_zip_vblocks over paired VBlocks (R1/R2 of a file pair in one call,
     dictionaries carried from call to call) == the oracle's step-by-step composition, byte for byte; every VBlock's z_data
     decodes again on the device (adler32 of every section, payloads) and the packed SEQ unpacks to the reads' bases"""
     from genozip_amd import fastq as fq
-    plan = fq.illumina_plan(paired=True)
+    plan = fq.illumina_plan(paired=True, domq=domq)
     F = E.zip_open(plan)
     zstate = None
     vb_i = 0
     for call in range(n_calls):
         nr = n_reads if call == 0 else max(8, n_reads // 3)
-        r1 = fastq_text(nr, seed=100 + call, dirty_seq=(call == 1))
-        r2 = fastq_text(nr, seed=100 + call, dirty_seq=(call == 1), mate=2, qual_seed=300 + call)
+        r1 = fastq_text(nr, seed=100 + call, dirty_seq=(call == 1), qual=qual[call])
+        r2 = fastq_text(nr, seed=100 + call, dirty_seq=(call == 1), mate=2, qual_seed=300 + call, qual=qual[call])
         # two VBlocks per mate (the second shorter), R2's name their R1 counterparts
         cut = (2 * nr) // 3
 

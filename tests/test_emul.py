@@ -101,6 +101,15 @@ def test_emul_fastq_zip(emul_engine, oracle):
     parity.fastq_zip(emul_engine, oracle, 400)
 
 
+def test_emul_fastq_zip_domq(emul_engine, oracle):
+    """QUAL through CODEC_DOMQ inside the driver: the file's first VBlock decides (binned scores: a fit), later calls follow even
+    with scores that would not fit; forced (--force-domq) on scores that do not fit; refused (--no-domqual) on scores that do"""
+    parity.fastq_zip(emul_engine, oracle, 300, qual=("bin", "uniform"))
+    parity.fastq_zip(emul_engine, oracle, 200, qual=("uniform", "bin"))
+    parity.fastq_zip(emul_engine, oracle, 120, n_calls=1, qual=("uniform",), domq=13)
+    parity.fastq_zip(emul_engine, oracle, 120, n_calls=1, qual=("bin",), domq=1)
+
+
 def test_emul_ctx_golden(emul_engine, oracle):
     parity.ctx_golden(emul_engine, oracle)
 

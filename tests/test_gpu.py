@@ -101,6 +101,8 @@ def test_fastq_zip_driver(gpu_engine, oracle):
     """FASTQ text -> z_data through gz_fastq_zip_vblocks (a1-a16 + N1 in one call, paired VBlocks, two calls sharing the
     file's dictionaries) == the oracle's step-by-step composition"""
     parity.fastq_zip(gpu_engine, oracle, 6000)
+    parity.fastq_zip(gpu_engine, oracle, 3000, qual=("bin", "uniform"))          # QUAL through CODEC_DOMQ (decided by the first VBlock)
+    parity.fastq_zip(gpu_engine, oracle, 1000, n_calls=1, qual=("uniform",), domq=13)
 
 
 def test_c_host_program():
