@@ -1029,17 +1029,31 @@ extern "C" int gz_domq_columns (GzHandle *h, const GzDomqJob *jobs, int n_jobs)
     if (!n_jobs) return GZ_OK;
     HIPCHK (h, hipSetDevice (h->device));
     std::vector<GzdDomq> J (n_jobs);
+    uint32_t max_n = 1;
+    size_t hist_words = 0;
+    for (int i = 0; i < n_jobs; i++) hist_words += GZ_DQ_HIST + GZ_DQ_MISC;
+    uint32_t *hist = (uint32_t *)arena_alloc (h, hist_words * 4);
+    if (!hist) return GZ_ERR_HIP;
+    HIPCHK (h, hipMemsetAsync (hist, 0, hist_words * 4, h->stream));
     for (int i = 0; i < n_jobs; i++) {
         const GzDomqJob &u = jobs[i];
         if (!u.result_dev || !u.qual || !u.mplx || (u.n && (!u.text || !u.off || !u.len || !u.runs || !u.divr))) return GZ_ERR_ARG;
         GzdDomq &d = J[i];
         d.text = u.text; d.off = u.off; d.len = u.len; d.n = u.n; d.qual = u.qual; d.runs = u.runs; d.mplx = u.mplx; d.divr = u.divr; d.res = u.result_dev;
-        if (!(d.line_dom = (uint8_t *)arena_alloc (h, (size_t)u.n + 16)) || !(d.normalize = (uint8_t *)arena_alloc (h, GZ_DQ_N * GZ_DQ_N))) return GZ_ERR_HIP;
+        d.hist = hist + (size_t)i * (GZ_DQ_HIST + GZ_DQ_MISC);
+        if (!(d.line_dom = (uint8_t *)arena_alloc (h, (size_t)u.n + 16)) || !(d.normalize = (uint8_t *)arena_alloc (h, GZ_DQ_HIST))
+            || !(d.rec = (uint32_t *)arena_alloc (h, ((size_t)6 * u.n + 4) * 4)) || !(d.lo = (uint32_t *)arena_alloc (h, ((size_t)5 * u.n + 4) * 4))) return GZ_ERR_HIP;
+        if (u.n > max_n) max_n = u.n;
     }
     void *dj;
     int rc;
     if ((rc = upload (h, J.data (), J.size () * sizeof (GzdDomq), &dj)) != GZ_OK) return rc;
-    KLAUNCH (h, k_domq, dim3 ((uint32_t)n_jobs), dim3 (256), GZ_DOMQ_LDS, (GzdDomq *)dj);
+    const dim3 by_line ((max_n + GZ_DQ_LINES_PER_WG - 1) / GZ_DQ_LINES_PER_WG, (uint32_t)n_jobs);
+    KLAUNCH (h, k_domq_lines, by_line, dim3 (256), GZ_DOMQ_LDS, (const GzdDomq *)dj);
+    KLAUNCH (h, k_domq_tables, dim3 ((uint32_t)n_jobs), dim3 (128), 64, (const GzdDomq *)dj);
+    KLAUNCH (h, k_domq_measure, by_line, dim3 (256), 0, (const GzdDomq *)dj);
+    KLAUNCH (h, k_domq_scan, dim3 ((uint32_t)n_jobs), dim3 (256), 4096, (const GzdDomq *)dj);
+    KLAUNCH (h, k_domq_write, by_line, dim3 (256), 0, (const GzdDomq *)dj);
     HIPCHK (h, hipGetLastError ());
     return GZ_OK;
 }

@@ -11,9 +11,16 @@
 //   DIVRQUAL  the normalised scores of "diverse" lines (dominant score < 85 % of the line, :157-158)
 // and the denormalisation table (num_doms x num_norm_qs), which the host base64-codes into DOMQRUNS' dictionary (:231-236).
 //
-// One 256-thread workgroup per VBlock walks its lines in rounds of 256; everything that the reference does line after line
-// with carried state (the run counter, the output cursors) is a workgroup scan per round plus a carry: the run before a
-// line's first non-dominant score is (its position) - (position of the last non-dominant score before it) - 1, a max-scan.
+// Everything the reference does line after line with carried state (the run counter that only a non-dominant score resets,
+// the output cursors) is restated as per-line facts + scans over the lines, so that all lines of all VBlocks of a call are
+// worked on at once:
+//   k_domq_lines    a wave per line: histogram, dominant score, diverse?  -> per-VBlock histograms (LDS per workgroup, then atomics)
+//   k_domq_tables   a workgroup per VBlock: compacted dominant scores, rank tables, the denormalisation table
+//   k_domq_measure  a wave per line: normalised; number of non-dominant scores, leading / trailing run, bytes of the runs and
+//                   markers inside the line
+//   k_domq_scan     a workgroup per VBlock: positions, the run before every line's first non-dominant score (its position minus
+//                   the position of the last one before it: a max-scan), output offsets of every line; the VBlock's last run
+//   k_domq_write    a wave per line: the four streams
 #pragma once
 #include "gz_device.h"
 #include "gz_devutil.h"
@@ -21,13 +28,19 @@
 
 #define GZ_DQ_FIRST 32
 #define GZ_DQ_N     95
-#define GZ_DOMQ_LDS (4096 + GZ_DQ_N * GZ_DQ_N * 4 + 4 * GZ_DQ_N * 4 + 1024)
+#define GZ_DQ_HIST  (GZ_DQ_N * GZ_DQ_N)
+#define GZ_DQ_MISC  128                              // u32 behind the histograms: [0..95) lines_with_dom [96] bad [97] has_diverse [98] num_norm [99] num_doms [100..124) dom_to_cdom bytes
+#define GZ_DQ_LINES_PER_WG 256
+#define GZ_DOMQ_LDS (4096 + GZ_DQ_HIST * 4 + 4 * GZ_DQ_N * 4 + GZ_DQ_MISC * 4)
 
 struct GzdDomq {
     const uint8_t *text; const uint32_t *off, *len; uint32_t n;
     uint8_t *qual, *runs, *mplx, *divr;            // outputs: capacities 2 * bytes + 16, bytes + bytes / 254 + 16, n + 16, bytes + 16
     uint8_t *line_dom;                             // scratch [n]
     uint8_t *normalize;                            // scratch [95][95], indexed by the (uncompacted) dominant score
+    uint32_t *hist;                                // scratch [95 * 95 + GZ_DQ_MISC], zero on entry
+    uint32_t *rec;                                 // scratch [6][n]: L (length if not diverse), trail, lead, nnz, inner qual bytes, inner run bytes
+    uint32_t *lo;                                  // scratch [5][n]: offsets of the line in qual / runs / divr / mplx, the run before its first non-dominant score
     GzDomqResult *res;
 };
 
@@ -56,19 +69,42 @@ __device__ static inline void d_dq_put_run (uint8_t *dst, uint64_t r)           
     while (r) { const uint32_t sub = r < 254 ? (uint32_t)r : 254; *dst++ = r <= 254 ? (uint8_t)sub : 255; r -= sub; }
 }
 
-// grid (VBlocks), 256 threads, GZ_DOMQ_LDS bytes
-__global__ void __launch_bounds__(256) k_domq (GzdDomq *jobs)
+// sum / exclusive prefix sum of a 64-bit value over the wave
+__device__ static inline uint64_t d_wave_sum_u64 (uint64_t v, int lane)
 {
-    const GzdDomq &J = jobs[blockIdx.x];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    uint32_t *hist  = (uint32_t *)(gz_lds + 4096);            // [95][95] per dominant score
-    uint32_t *whist = hist + GZ_DQ_N * GZ_DQ_N;               // [4][95] the line a wave is looking at
-    uint32_t *misc  = whist + 4 * GZ_DQ_N;                    // [0..95) lines_with_dom  [96] bad  [97] has_diverse  [98] num_norm  [99] num_doms
-    for (int i = tid; i < GZ_DQ_N * GZ_DQ_N + 4 * GZ_DQ_N + 128; i += 256) hist[i] = 0;
-    __syncthreads ();
+    for (int m = 32; m; m >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl ((int)(uint32_t)v, lane ^ m), hi = (uint32_t)__shfl ((int)(uint32_t)(v >> 32), lane ^ m);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+__device__ static inline uint64_t d_wave_excl_u64 (uint64_t v, int lane, uint64_t *total)
+{
+    uint64_t inc = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int src = lane >= d ? lane - d : lane;
+        const uint32_t lo = (uint32_t)__shfl ((int)(uint32_t)inc, src), hi = (uint32_t)__shfl ((int)(uint32_t)(inc >> 32), src);
+        if (lane >= d) inc += ((uint64_t)hi << 32) | lo;
+    }
+    *total = ((uint64_t)(uint32_t)__shfl ((int)(uint32_t)(inc >> 32), 63) << 32) | (uint32_t)__shfl ((int)(uint32_t)inc, 63);
+    return inc - v;
+}
 
-    // ---- 1. every line's dominant score and the histograms per dominant score (codec_domq.c:139-176): a wave per line
-    for (uint32_t i = wave; i < J.n; i += 4) {
+// ---- 1. every line's dominant score and the histograms per dominant score (codec_domq.c:139-176)
+// grid (lines / 256, VBlocks), 256 threads, GZ_DOMQ_LDS bytes: a wave per line, 64 lines per wave
+__global__ void __launch_bounds__(256) k_domq_lines (const GzdDomq *jobs)
+{
+    const GzdDomq &J = jobs[blockIdx.y];
+    const uint32_t base = blockIdx.x * GZ_DQ_LINES_PER_WG;
+    if (base >= J.n) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    uint32_t *hist  = (uint32_t *)(gz_lds + 4096);            // [95][95] per dominant score, this workgroup's lines
+    uint32_t *whist = hist + GZ_DQ_HIST;                      // [4][95] the line a wave is looking at
+    uint32_t *misc  = whist + 4 * GZ_DQ_N;
+    for (int i = tid; i < GZ_DQ_HIST + 4 * GZ_DQ_N + GZ_DQ_MISC; i += 256) hist[i] = 0;
+    __syncthreads ();
+    const uint32_t end = base + GZ_DQ_LINES_PER_WG < J.n ? base + GZ_DQ_LINES_PER_WG : J.n;
+    for (uint32_t i = base + wave; i < end; i += 4) {
         const uint32_t len = J.len[i];
         if (!len) continue;                                                     // (wave-uniform)
         const uint8_t *s = J.text + J.off[i];
@@ -86,19 +122,29 @@ __global__ void __launch_bounds__(256) k_domq (GzdDomq *jobs)
             if (ob > best || (ob == best && oq > bq)) { best = ob; bq = oq; }
         }
         const bool diverse = 100u * best / len < 85u;                           // DOMQ_THRESHOLD
-        atomicAdd (&hist[bq * GZ_DQ_N + lane], c0);
-        if (lane + 64 < GZ_DQ_N) atomicAdd (&hist[bq * GZ_DQ_N + lane + 64], c1);
+        if (c0) atomicAdd (&hist[bq * GZ_DQ_N + lane], c0);
+        if (c1) atomicAdd (&hist[bq * GZ_DQ_N + lane + 64], c1);
         if (!lane) { J.line_dom[i] = (uint8_t)(bq | (diverse ? 0x80 : 0)); atomicAdd (&misc[bq], 1u); if (diverse) misc[97] = 1; }
         gz_wave_sync ();
         h[lane] = 0; if (lane + 64 < GZ_DQ_N) h[lane + 64] = 0;
         gz_wave_sync ();
     }
     __syncthreads ();
+    for (int i = tid; i < GZ_DQ_HIST; i += 256) { const uint32_t v = hist[i]; if (v) atomicAdd (&J.hist[i], v); }
+    if (tid < 98) { const uint32_t v = misc[tid]; if (v) { if (tid < GZ_DQ_N) atomicAdd (&J.hist[GZ_DQ_HIST + tid], v); else J.hist[GZ_DQ_HIST + tid] = 1; } }
+}
 
-    // ---- 2. tables (:178-249): compact the dominant scores in ascending order; within one, rank the scores by count,
-    //         descending, equal counts in ascending score order (the reference's qsort is glibc's stable merge sort at this size)
-    uint8_t *dom_to_cdom = (uint8_t *)(misc + 100);           // [95] (+ room)
-    if (!tid) { uint32_t nd = 0; for (int q = 0; q < GZ_DQ_N; q++) if (misc[q]) dom_to_cdom[q] = (uint8_t)nd++; misc[99] = nd; misc[98] = 0; }
+// ---- 2. tables (:178-249): compact the dominant scores in ascending order; within one, rank the scores by count,
+//         descending, equal counts in ascending score order (the reference's qsort is glibc's stable merge sort at this size)
+// grid (VBlocks), 128 threads, 64 bytes of LDS
+__global__ void __launch_bounds__(128) k_domq_tables (const GzdDomq *jobs)
+{
+    const GzdDomq &J = jobs[blockIdx.x];
+    const int tid = threadIdx.x;
+    const uint32_t *hist = J.hist; uint32_t *misc = J.hist + GZ_DQ_HIST;
+    uint8_t *dom_to_cdom = (uint8_t *)(misc + 100);
+    uint32_t &s_norm = *(uint32_t *)gz_lds;
+    if (!tid) { uint32_t nd = 0; for (int q = 0; q < GZ_DQ_N; q++) if (misc[q]) dom_to_cdom[q] = (uint8_t)nd++; misc[99] = nd; s_norm = 0; }
     __syncthreads ();
     for (int d = 0; d < GZ_DQ_N; d++) {
         if (!misc[d]) continue;                                                 // (uniform)
@@ -111,89 +157,169 @@ __global__ void __launch_bounds__(256) k_domq (GzdDomq *jobs)
                 rank += o > mine || (o == mine && q < tid && o);
             }
             J.normalize[d * GZ_DQ_N + tid] = mine ? (uint8_t)rank : 0;
-            if (!tid) atomicMax (&misc[98], nz);
+            if (!tid) atomicMax (&s_norm, nz);
         }
     }
+    __threadfence_block ();
     __syncthreads ();
-    const uint32_t num_norm = misc[98], num_doms = misc[99], no_doms = num_norm;
+    const uint32_t num_norm = s_norm;
+    if (!tid) misc[98] = num_norm;
     if (tid < GZ_DQ_N && misc[tid]) {                         // denormalisation rows, compacted to num_norm columns
         const uint32_t cd = dom_to_cdom[tid];
         for (uint32_t r = 0; r < num_norm; r++) J.res->denorm[cd * num_norm + r] = 0;
         for (int q = 0; q < GZ_DQ_N; q++) if (hist[tid * GZ_DQ_N + q]) J.res->denorm[cd * num_norm + J.normalize[tid * GZ_DQ_N + q]] = (uint8_t)(q + GZ_DQ_FIRST);
     }
-    __threadfence_block ();
-    __syncthreads ();
+}
 
-    // ---- 3. the four streams, 256 lines a round; carried from round to round: positions, cursors, the last non-dominant score
-    uint64_t pos = 0, at_qual = 0, at_runs = 0, at_divr = 0, at_mplx = 0;
-    int64_t last_nz = -1;
-    uint32_t last_len = 0;
-    for (uint32_t base = 0; base < J.n; base += 256) {
-        const uint32_t i = base + tid;
-        const uint32_t len = i < J.n ? J.len[i] : 0;
+// ---- 3a. a line on its own. grid (lines / 256, VBlocks), 256 threads: a wave per line, 64 scores a step
+__global__ void __launch_bounds__(256) k_domq_measure (const GzdDomq *jobs)
+{
+    const GzdDomq &J = jobs[blockIdx.y];
+    const uint32_t base = blockIdx.x * GZ_DQ_LINES_PER_WG;
+    if (base >= J.n) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t end = base + GZ_DQ_LINES_PER_WG < J.n ? base + GZ_DQ_LINES_PER_WG : J.n;
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0;
+    for (uint32_t i = base + wave; i < end; i += 4) {
+        const uint32_t len = J.len[i];
         const uint8_t ld = len ? J.line_dom[i] : 0;
-        const bool diverse = ld & 0x80;
-        const uint8_t *nrm = J.normalize + (ld & 0x7f) * GZ_DQ_N;
-        const uint8_t *s = J.text + (len ? J.off[i] : 0);
-        // pass 1: the line on its own
-        uint32_t lead = 0, trail = 0, nnz = 0, inner_marks = 0, inner_run_bytes = 0;
-        if (len && !diverse) {
-            uint32_t run = 0;
-            for (uint32_t k = 0; k < len; k++) {
-                const uint32_t v = nrm[s[k] - GZ_DQ_FIRST];
-                if (!v) { run++; continue; }
-                if (!nnz) lead = run;
-                else if (run) inner_run_bytes += d_dq_run_bytes (run);
-                else inner_marks++;
-                nnz++; run = 0;
+        uint32_t L = 0, trail = 0, lead = 0, nnz = 0, inner_q = 0, inner_r = 0;
+        if (len && !(ld & 0x80)) {
+            const uint8_t *nrm = J.normalize + (ld & 0x7f) * GZ_DQ_N;
+            const uint8_t *s = J.text + J.off[i];
+            int64_t last = -1;                                                  // (wave-uniform) position of the last non-dominant score so far
+            uint64_t acc = 0;                                                   // per lane: markers << 32 | run bytes
+            for (uint32_t c0 = 0; c0 < len; c0 += 64) {
+                const uint32_t k = c0 + lane;
+                const uint32_t v = k < len ? nrm[s[k] - GZ_DQ_FIRST] : 0;
+                const uint64_t mask = __ballot (v != 0);
+                if (v) {
+                    const uint64_t mb = mask & below;
+                    const int64_t prev = mb ? (int64_t)c0 + 63 - __builtin_clzll (mb) : last;
+                    if (prev >= 0) { const uint32_t run = (uint32_t)((int64_t)k - prev - 1); acc += run ? d_dq_run_bytes (run) : (1ull << 32); }
+                }
+                if (mask) {
+                    if (last < 0) lead = c0 + (uint32_t)__builtin_ctzll (mask);
+                    last = (int64_t)c0 + 63 - __builtin_clzll (mask);
+                    nnz += (uint32_t)__popcll (mask);
+                }
             }
-            trail = run;
+            acc = d_wave_sum_u64 (acc, lane);
+            L = len; trail = nnz ? len - 1 - (uint32_t)last : len;
+            inner_q = nnz + (uint32_t)(acc >> 32); inner_r = (uint32_t)acc;
         }
-        uint64_t tot;
-        const uint64_t L = len && !diverse ? len : 0;
-        const uint64_t my_pos = pos + d_wg_scan_u64 (L, tid, &tot);
-        int64_t mx;
-        int64_t before = d_wg_scan_max (nnz ? (int64_t)(my_pos + L - 1 - trail) : -1, tid, &mx);
-        if (last_nz > before) before = last_nz;
-        const uint64_t run_before = nnz ? (my_pos + lead) - (uint64_t)(before + 1) : 0;
-        const uint32_t q_bytes = nnz + inner_marks + (nnz && !run_before ? 1 : 0);
-        const uint32_t r_bytes = inner_run_bytes + (nnz ? d_dq_run_bytes (run_before) : 0);
-        uint64_t t2, t3;
-        const uint64_t e2 = d_wg_scan_u64 (((uint64_t)q_bytes << 32) | r_bytes, tid, &t2);
-        const uint64_t e3 = d_wg_scan_u64 (((uint64_t)(diverse ? len : 0) << 32) | (len ? 1u : 0u), tid, &t3);
-        // pass 2: write
-        if (len) J.mplx[at_mplx + (uint32_t)e3] = (uint8_t)(dom_to_cdom[ld & 0x7f] | (diverse ? 0x80 : 0));
-        if (len && diverse) {
-            uint8_t *d = J.divr + at_divr + (e3 >> 32);
-            for (uint32_t k = 0; k < len; k++) d[k] = nrm[s[k] - GZ_DQ_FIRST];
+        if (!lane) {
+            uint32_t *r = J.rec + i; const size_t n = J.n;
+            r[0] = L; r[n] = trail; r[2 * n] = lead; r[3 * n] = nnz; r[4 * n] = inner_q; r[5 * n] = inner_r;
         }
-        else if (nnz) {
-            uint8_t *q = J.qual + at_qual + (e2 >> 32), *r = J.runs + at_runs + (uint32_t)e2;
-            uint64_t run = run_before;
-            bool first = true;
-            for (uint32_t k = 0; k < len; k++) {
-                const uint32_t v = nrm[s[k] - GZ_DQ_FIRST];
-                if (!v) { if (!first) run++; continue; }
-                if (first) { run = run_before; first = false; }
-                if (run) { d_dq_put_run (r, run); r += d_dq_run_bytes (run); }
-                else *q++ = (uint8_t)no_doms;
-                *q++ = (uint8_t)v;
-                run = 0;
+    }
+}
+
+// ---- 3b. the lines in order. grid (VBlocks), 256 threads: thread t walks lines [t T, (t + 1) T)
+__global__ void __launch_bounds__(256) k_domq_scan (const GzdDomq *jobs)
+{
+    const GzdDomq &J = jobs[blockIdx.x];
+    const int tid = threadIdx.x;
+    const size_t n = J.n;
+    const uint32_t T = (J.n + 255) / 256, i0 = (uint32_t)tid * T < J.n ? (uint32_t)tid * T : J.n, i1 = i0 + T < J.n ? i0 + T : J.n;
+    const uint32_t *rL = J.rec, *rT = J.rec + n, *rLead = J.rec + 2 * n, *rN = J.rec + 3 * n, *rQ = J.rec + 4 * n, *rR = J.rec + 5 * n;
+    const uint32_t *misc = J.hist + GZ_DQ_HIST;
+    // positions (in the concatenation of the lines that are not diverse)
+    uint64_t sumL = 0, tot_pos;
+    for (uint32_t i = i0; i < i1; i++) sumL += rL[i];
+    const uint64_t pos0 = d_wg_scan_u64 (sumL, tid, &tot_pos);
+    // the last non-dominant score before my stretch
+    int64_t mine = -1, last_nz;
+    { uint64_t pos = pos0; for (uint32_t i = i0; i < i1; i++) { if (rN[i]) mine = (int64_t)(pos + rL[i] - 1 - rT[i]); pos += rL[i]; } }
+    const int64_t before0 = d_wg_scan_max (mine, tid, &last_nz);
+    // bytes of every line in the four streams
+    uint64_t qr = 0, dm = 0, tot_qr, tot_dm;
+    for (int pass = 0; pass < 2; pass++) {
+        uint64_t pos = pos0; int64_t before = before0;
+        uint64_t at_qr = 0, at_dm = 0;
+        if (pass) { at_qr = d_wg_scan_u64 (qr, tid, &tot_qr); at_dm = d_wg_scan_u64 (dm, tid, &tot_dm); }
+        for (uint32_t i = i0; i < i1; i++) {
+            const uint32_t len = J.len[i], nnz = rN[i];
+            const bool diverse = len && (J.line_dom[i] & 0x80);
+            const uint64_t run_before = nnz ? pos + rLead[i] - (uint64_t)(before + 1) : 0;
+            const uint64_t q_bytes = rQ[i] + (nnz && !run_before ? 1 : 0), r_bytes = rR[i] + (nnz ? d_dq_run_bytes (run_before) : 0);
+            if (pass) {
+                uint32_t *o = J.lo + i;
+                o[0] = (uint32_t)(at_qr >> 32); o[n] = (uint32_t)at_qr; o[2 * n] = (uint32_t)(at_dm >> 32); o[3 * n] = (uint32_t)at_dm; o[4 * n] = (uint32_t)run_before;
+                at_qr += (q_bytes << 32) | r_bytes; at_dm += ((uint64_t)(diverse ? len : 0) << 32) | (len ? 1u : 0u);
             }
+            else { qr += (q_bytes << 32) | r_bytes; dm += ((uint64_t)(diverse ? len : 0) << 32) | (len ? 1u : 0u); }
+            if (nnz) before = (int64_t)(pos + rL[i] - 1 - rT[i]);
+            pos += rL[i];
         }
-        pos += tot; if (mx > last_nz) last_nz = mx;
-        at_qual += t2 >> 32; at_runs += (uint32_t)t2; at_divr += t3 >> 32; at_mplx += (uint32_t)t3;
-        if (base + 256 >= J.n) { uint32_t *sh = (uint32_t *)gz_lds; __syncthreads (); if (J.n - 1 - base == (uint32_t)tid) sh[600] = len; __syncthreads (); last_len = sh[600]; }
     }
     // ---- the run the VBlock ends with (:468-480), "all diverse" (:490-494), results
     if (!tid) {
-        const uint64_t runlen = pos - (uint64_t)(last_nz + 1);
+        uint64_t at_qual = tot_qr >> 32, at_runs = (uint32_t)tot_qr;
+        const uint32_t no_doms = misc[98], last_len = J.n ? J.len[J.n - 1] : 0;
+        const uint64_t runlen = tot_pos - (uint64_t)(last_nz + 1);
         if (runlen && (at_runs || runlen < last_len)) { d_dq_put_run (J.runs + at_runs, runlen); at_runs += d_dq_run_bytes (runlen); J.qual[at_qual++] = (uint8_t)no_doms; }
         uint32_t all_diverse = 0;
         if (!at_qual) { J.qual[at_qual++] = 'X'; all_diverse = 1; }
-        J.res->qual_len = at_qual; J.res->runs_len = at_runs; J.res->mplx_len = at_mplx; J.res->divr_len = at_divr;
-        J.res->num_doms = num_doms; J.res->num_norm_qs = num_norm; J.res->has_diverse = misc[97]; J.res->all_diverse = all_diverse;
+        J.res->qual_len = at_qual; J.res->runs_len = at_runs; J.res->mplx_len = (uint32_t)tot_dm; J.res->divr_len = tot_dm >> 32;
+        J.res->num_doms = misc[99]; J.res->num_norm_qs = no_doms; J.res->has_diverse = misc[97]; J.res->all_diverse = all_diverse;
         J.res->status = misc[96] ? GZ_ST_CORRUPT : GZ_ST_OK;
+    }
+}
+
+// ---- 3c. the streams. grid (lines / 256, VBlocks), 256 threads: a wave per line
+__global__ void __launch_bounds__(256) k_domq_write (const GzdDomq *jobs)
+{
+    const GzdDomq &J = jobs[blockIdx.y];
+    const uint32_t base = blockIdx.x * GZ_DQ_LINES_PER_WG;
+    if (base >= J.n) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t end = base + GZ_DQ_LINES_PER_WG < J.n ? base + GZ_DQ_LINES_PER_WG : J.n;
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0;
+    const size_t n = J.n;
+    const uint32_t *misc = J.hist + GZ_DQ_HIST;
+    const uint8_t *dom_to_cdom = (const uint8_t *)(misc + 100);
+    const uint32_t no_doms = misc[98];
+    for (uint32_t i = base + wave; i < end; i += 4) {
+        const uint32_t len = J.len[i];
+        if (!len) continue;
+        const uint8_t ld = J.line_dom[i];
+        const bool diverse = ld & 0x80;
+        const uint8_t *nrm = J.normalize + (ld & 0x7f) * GZ_DQ_N;
+        const uint8_t *s = J.text + J.off[i];
+        const uint32_t *o = J.lo + i;
+        if (!lane) J.mplx[o[3 * n]] = (uint8_t)(dom_to_cdom[ld & 0x7f] | (diverse ? 0x80 : 0));
+        if (diverse) {
+            uint8_t *d = J.divr + o[2 * n];
+            for (uint32_t k = lane; k < len; k += 64) d[k] = nrm[s[k] - GZ_DQ_FIRST];
+            continue;
+        }
+        if (!J.rec[3 * n + i]) continue;                                        // only the dominant score: the run goes on
+        uint8_t *q = J.qual + o[0], *r = J.runs + o[n];
+        const uint64_t run_before = o[4 * n];
+        int64_t last = -1;
+        for (uint32_t c0 = 0; c0 < len; c0 += 64) {
+            const uint32_t k = c0 + lane;
+            const uint32_t v = k < len ? nrm[s[k] - GZ_DQ_FIRST] : 0;
+            const uint64_t mask = __ballot (v != 0);
+            if (!mask) continue;                                                // (wave-uniform)
+            uint64_t run = 0;
+            if (v) {
+                const uint64_t mb = mask & below;
+                const int64_t prev = mb ? (int64_t)c0 + 63 - __builtin_clzll (mb) : last;
+                run = prev >= 0 ? (uint64_t)((int64_t)k - prev - 1) : run_before;
+            }
+            const uint64_t mine = v ? ((uint64_t)(run ? 1u : 2u) << 32) | d_dq_run_bytes (run) : 0;
+            uint64_t tot;
+            const uint64_t ex = d_wave_excl_u64 (mine, lane, &tot);
+            if (v) {
+                uint8_t *qq = q + (ex >> 32);
+                if (run) d_dq_put_run (r + (uint32_t)ex, run); else *qq++ = (uint8_t)no_doms;
+                *qq = (uint8_t)v;
+            }
+            q += tot >> 32; r += (uint32_t)tot;
+            last = (int64_t)c0 + 63 - __builtin_clzll (mask);
+        }
     }
 }
 
