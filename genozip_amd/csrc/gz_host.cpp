@@ -1039,7 +1039,7 @@ extern "C" int gz_domq_columns (GzHandle *h, const GzDomqJob *jobs, int n_jobs)
         const GzDomqJob &u = jobs[i];
         if (!u.result_dev || !u.qual || !u.mplx || (u.n && (!u.text || !u.off || !u.len || !u.runs || !u.divr))) return GZ_ERR_ARG;
         GzdDomq &d = J[i];
-        d.text = u.text; d.off = u.off; d.len = u.len; d.n = u.n; d.qual = u.qual; d.runs = u.runs; d.mplx = u.mplx; d.divr = u.divr; d.res = u.result_dev;
+        d.text = u.text; d.off = u.off; d.len = u.len; d.n = u.n; d.qual = u.qual; d.runs = u.runs; d.mplx = u.mplx; d.divr = u.divr; d.res = u.result_dev; d.only_if = u.only_if_dev;
         d.hist = hist + (size_t)i * (GZ_DQ_HIST + GZ_DQ_MISC);
         if (!(d.line_dom = (uint8_t *)arena_alloc (h, (size_t)u.n + 16)) || !(d.normalize = (uint8_t *)arena_alloc (h, GZ_DQ_HIST))
             || !(d.rec = (uint32_t *)arena_alloc (h, ((size_t)6 * u.n + 4) * 4)) || !(d.lo = (uint32_t *)arena_alloc (h, ((size_t)5 * u.n + 4) * 4))) return GZ_ERR_HIP;

@@ -42,6 +42,7 @@ struct GzdDomq {
     uint32_t *rec;                                 // scratch [6][n]: L (length if not diverse), trail, lead, nnz, inner qual bytes, inner run bytes
     uint32_t *lo;                                  // scratch [5][n]: offsets of the line in qual / runs / divr / mplx, the run before its first non-dominant score
     GzDomqResult *res;
+    const uint32_t *only_if;                       // optional: nothing is done (and res is left alone) when this device word is 0
 };
 
 // inclusive -> exclusive max scan over the workgroup (identity -1); *total = max over all threads
@@ -95,6 +96,7 @@ __device__ static inline uint64_t d_wave_excl_u64 (uint64_t v, int lane, uint64_
 __global__ void __launch_bounds__(256) k_domq_lines (const GzdDomq *jobs)
 {
     const GzdDomq &J = jobs[blockIdx.y];
+    if (J.only_if && !*J.only_if) return;
     const uint32_t base = blockIdx.x * GZ_DQ_LINES_PER_WG;
     if (base >= J.n) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -140,6 +142,7 @@ __global__ void __launch_bounds__(256) k_domq_lines (const GzdDomq *jobs)
 __global__ void __launch_bounds__(128) k_domq_tables (const GzdDomq *jobs)
 {
     const GzdDomq &J = jobs[blockIdx.x];
+    if (J.only_if && !*J.only_if) return;
     const int tid = threadIdx.x;
     const uint32_t *hist = J.hist; uint32_t *misc = J.hist + GZ_DQ_HIST;
     uint8_t *dom_to_cdom = (uint8_t *)(misc + 100);
@@ -175,6 +178,7 @@ __global__ void __launch_bounds__(128) k_domq_tables (const GzdDomq *jobs)
 __global__ void __launch_bounds__(256) k_domq_measure (const GzdDomq *jobs)
 {
     const GzdDomq &J = jobs[blockIdx.y];
+    if (J.only_if && !*J.only_if) return;
     const uint32_t base = blockIdx.x * GZ_DQ_LINES_PER_WG;
     if (base >= J.n) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -219,6 +223,7 @@ __global__ void __launch_bounds__(256) k_domq_measure (const GzdDomq *jobs)
 __global__ void __launch_bounds__(256) k_domq_scan (const GzdDomq *jobs)
 {
     const GzdDomq &J = jobs[blockIdx.x];
+    if (J.only_if && !*J.only_if) return;
     const int tid = threadIdx.x;
     const size_t n = J.n;
     const uint32_t T = (J.n + 255) / 256, i0 = (uint32_t)tid * T < J.n ? (uint32_t)tid * T : J.n, i1 = i0 + T < J.n ? i0 + T : J.n;
@@ -271,6 +276,7 @@ __global__ void __launch_bounds__(256) k_domq_scan (const GzdDomq *jobs)
 __global__ void __launch_bounds__(256) k_domq_write (const GzdDomq *jobs)
 {
     const GzdDomq &J = jobs[blockIdx.y];
+    if (J.only_if && !*J.only_if) return;
     const uint32_t base = blockIdx.x * GZ_DQ_LINES_PER_WG;
     if (base >= J.n) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;

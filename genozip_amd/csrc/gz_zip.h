@@ -105,8 +105,20 @@ struct GzZipFile {
     // zctx->qual_codec of the QUAL context (codec.c:403-407,445): -1 not decided yet (the file's first VBlock will), 0 a plain
     // LT_BLOB local, GZ_CODEC_DOMQ
     int qual_ctx = -1, aux[3] = { -1, -1, -1 }, qual_mode = 0;
+    hipEvent_t ev_early = NULL;
+    uint8_t *pinned = NULL; size_t pinned_size = 0;      // host memory the device can write while the host does something else
     ZipCall call;
 };
+
+static uint8_t *zip_pinned (GzZipFile *f, size_t bytes)
+{
+    if (f->pinned_size >= bytes) return f->pinned;
+    if (f->pinned) (void)hipHostFree (f->pinned);
+    f->pinned = NULL; f->pinned_size = 0;
+    if (hipHostMalloc ((void **)&f->pinned, bytes + bytes / 2, hipHostMallocDefault) != hipSuccess) { f->h->err = "hipHostMalloc failed"; return NULL; }
+    f->pinned_size = bytes + bytes / 2;
+    return f->pinned;
+}
 
 static void zip_init_qual_mode (GzZipFile *f)
 {
@@ -173,6 +185,8 @@ extern "C" void gz_zip_close (GzZipFile *f)
     (void)hipSetDevice (f->h->device);
     (void)gz_sync (f->h);
     if (f->h2) gz_destroy (f->h2);
+    if (f->pinned) (void)hipHostFree (f->pinned);
+    if (f->ev_early) (void)hipEventDestroy (f->ev_early);
     for (auto z : f->zctx) gz_zctx_destroy (z);
     for (auto &b : f->ws) (void)hipFree (b.base);
     delete f;
@@ -499,6 +513,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         K.domq.resize (NV);
         if (!(d_domqres = (GzDomqResult *)ws_alloc (f, (size_t)NV * sizeof (GzDomqResult) + 16)) || !(d_fit = (uint32_t *)ws_alloc (f, (size_t)NV * 4 + 16))) return GZ_ERR_HIP;
         HIPCHK (h, hipMemsetAsync (d_fit, 0, (size_t)NV * 4 + 16, h->stream));
+        HIPCHK (h, hipMemsetAsync (d_domqres, 0, (size_t)NV * sizeof (GzDomqResult), h->stream));
     }
     std::vector<GzColumnJob> &col_jobs = K.col_jobs;
     K.acgt_of_vb.assign (NV, -1);
@@ -568,6 +583,8 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
                 GzDomqJob dj; memset (&dj, 0, sizeof (dj));
                 dj.text = text; dj.off = qual_off + rr; dj.len = qual_len + rr; dj.n = n;
                 dj.qual = D.out[0]; dj.runs = D.out[1]; dj.mplx = D.out[2]; dj.divr = D.out[3]; dj.result_dev = d_domqres + v;
+                // (this process holds the file's first VBlock: nobody needs the streams if that one is not a fit)
+                if (qmode0 < 0 && vbs[0].vblock_i == f->last_vblock_i + 1 && vbs[0].n_reads) dj.only_if_dev = d_fit;
                 domq_jobs.push_back (dj);
                 if (qmode0 < 0) { GzDomqFitJob fj; memset (&fj, 0, sizeof (fj)); fj.text = text; fj.off = dj.off; fj.len = dj.len; fj.n = n; fj.fit_dev = d_fit + v; fit_jobs.push_back (fj); }
             }
@@ -598,6 +615,17 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     for (size_t at = 0; at < blob_jobs.size (); at += 32768) ZCHK (gz_local_blob_columns (h, blob_jobs.data () + at, (int)std::min<size_t> (32768, blob_jobs.size () - at)));
     ZCHK (gz_domq_fit (h, fit_jobs.data (), (int)fit_jobs.size ()));
     ZCHK (gz_domq_columns (h, domq_jobs.data (), (int)domq_jobs.size ()));
+    // the few numbers the launch of the long streams needs come back on their own, ahead of the columns' results (pinned memory)
+    const size_t eb_blob = blob_jobs.size () * 8, eb_fit = qmode0 ? (size_t)NV * 4 + 8 : 0, eb_res = qmode0 ? (size_t)NV * sizeof (GzDomqResult) : 0;
+    uint8_t *eb = zip_pinned (f, eb_blob + eb_fit + eb_res + 64);
+    if (!eb) return GZ_ERR_HIP;
+    if (eb_blob) HIPCHK (h, hipMemcpyAsync (eb, d_blobres, eb_blob, hipMemcpyDeviceToHost, h->stream));
+    if (qmode0 && NV) {
+        HIPCHK (h, hipMemcpyAsync (eb + eb_blob, d_fit, (size_t)NV * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK (h, hipMemcpyAsync (eb + eb_blob + eb_fit, d_domqres, eb_res, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (!f->ev_early) HIPCHK (h, hipEventCreateWithFlags (&f->ev_early, hipEventDisableTiming));
+    HIPCHK (h, hipEventRecord (f->ev_early, h->stream));
     static const int trial_codecs[8] = { GZ_CODEC_RANB, GZ_CODEC_RANW, GZ_CODEC_RANb, GZ_CODEC_RANw, GZ_CODEC_ARTB, GZ_CODEC_ARTW, GZ_CODEC_ARTb, GZ_CODEC_ARTw };
     std::vector<GzStream> trial;                          // 8 per QUAL-kind context that needs a codec
     std::vector<uint32_t> trial_ctx; std::vector<int> trial_domq;
@@ -665,85 +693,28 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     }
     if (!dyn_jobs.empty ())  HIPCHK (h, hipMemcpyAsync (K.dynres.data (), d_dynres, dyn_jobs.size () * sizeof (GzDynIntResult), hipMemcpyDeviceToHost, h->stream));
     if (!icol_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (icolres.data (), d_icolres, icol_jobs.size () * 16, hipMemcpyDeviceToHost, h->stream));
-    if (!blob_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (K.blobres.data (), d_blobres, blob_jobs.size () * 8, hipMemcpyDeviceToHost, h->stream));
     if (!acgt_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (K.acgtres.data (), d_acgtres, acgt_jobs.size () * 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK (h, hipMemcpyAsync (K.vbstat.data (), d_vbstat, 2 * (size_t)NV * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK (h, hipMemcpyAsync (&a, d_a, sizeof (a), hipMemcpyDeviceToHost, h->stream));
-    std::vector<GzDomqResult> domqres (qmode0 ? NV : 0); std::vector<uint32_t> fits (qmode0 ? NV : 0);
-    if (qmode0 && NV) {
-        HIPCHK (h, hipMemcpyAsync (domqres.data (), d_domqres, (size_t)NV * sizeof (GzDomqResult), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK (h, hipMemcpyAsync (fits.data (), d_fit, (size_t)NV * 4, hipMemcpyDeviceToHost, h->stream));
-    }
-    if ((rc = gz_sync (h)) < 0) return rc;
-    T.mark ("seg-sync");
+    // ---- as soon as the gathered QUAL (and what CODEC_DOMQ makes of it) is there - the columns are still being evaluated:
+    HIPCHK (h, hipEventSynchronize (f->ev_early));
+    if (eb_blob) memcpy (K.blobres.data (), eb, eb_blob);
+    const uint32_t *fits = (const uint32_t *)(eb + eb_blob); const GzDomqResult *domqres = (const GzDomqResult *)(eb + eb_blob + eb_fit);
     for (uint32_t v = 0; qmode0 && v < NV; v++) {
         ZipDomq &D = K.domq[v];
         D.fit = fits[v];
         if (!vbs[v].n_reads) { memset (&D.res, 0, sizeof (D.res)); D.res.status = 1; continue; }
-        D.res = domqres[v];
+        memcpy (&D.res, &domqres[v], sizeof (D.res));
+        if (qmode0 < 0 && vbs[0].vblock_i == f->last_vblock_i + 1 && vbs[0].n_reads && !fits[0]) { memset (&D.res, 0, sizeof (D.res)); D.res.status = 1; }   // (skipped)
         if (D.res.status == 1) zip_base64 (D.res.denorm, (size_t)D.res.num_doms * D.res.num_norm_qs, D.snip);      // codec_domq.c:232-244
     }
     // this process holds the call's first VBlock and the file has not decided yet: that VBlock decides (codec.c:403-445), so the
     // long streams can be handed to the coders below; every process arrives at the same in the merge (from the blobs)
     int qmode = qmode0;
     if (qmode0 < 0 && own_first && NV) qmode = K.domq[0].fit ? GZ_CODEC_DOMQ : 0;
-    if (a.fq.first_bad != 0xffffffffu) {
-        for (uint32_t v = 0; v < NV; v++) if (a.fq.first_bad >= r0[v] && a.fq.first_bad < r_end[v]) vbs[v].status = GZ_ERR_CORRUPT;
-        h->err = "not FASTQ: a read is not '@'.. / SEQ / '+'.. / QUAL of SEQ's length (fastq.c:1008-1010,1076,1121)"; return GZ_ERR_CORRUPT;
-    }
-    if (a.n_bad_items) { h->err = "a line 1 does not fit the container of the plan (the reference would re-discover the flavor, qname.c:823-826)"; return GZ_ERR_CORRUPT; }
-    for (size_t k = 0; k < icol_jobs.size (); k++)
-        if ((int32_t)icolres[2 * k + 1] == GZ_ST_CORRUPT) { h->err = "an ordered item is not an integer (qname.c:750-756)"; return GZ_ERR_CORRUPT; }
-    for (size_t k = 0; k < NCJ; k++) if (K.colres[k].status != 1) { h->err = "column dictionary capacity"; return GZ_ERR; }
-    if (!pack_total[1]) { h->err = "merge staging buffer too small"; return GZ_ERR; }
-    f->stage.resize (pack_total[0] + 16);
-    if (pack_total[0]) HIPCHK (h, hipMemcpy (f->stage.data (), d_staging, pack_total[0], hipMemcpyDeviceToHost));
-
-    // ---- the merge blob: per VBlock, per context, what ctx_merge_in_one_vctx reads of the VBlock's context ------------------
-    K.blob.clear ();
-    for (uint32_t v = 0; v < NV; v++) {
-        ZipBlobVB hv = { vbs[v].vblock_i, vbs[v].r1 >= 0 ? vbs[vbs[v].r1].vblock_i : 0, NC, 0 };
-        if (qmode0) hv.qual = (qmode0 < 0 ? 1u : 0u) | (K.domq[v].fit ? 2u : 0u) | (K.domq[v].res.status != 1 ? 4u : 0u);
-        blob_put (K.blob, &hv, sizeof (hv));
-        for (uint32_t c = 0; c < NC; c++) {
-            const GzFastqCtx &X = f->ctxs[c];
-            ZipCol &Z = COL (v, c);
-            ZipMergeRec r; memset (&r, 0, sizeof (r));
-            if (Z.dyn_job >= 0) { Z.local_len = K.dynres[Z.dyn_job].len; Z.ltype = K.dynres[Z.dyn_job].ltype; Z.has_local = Z.local_len != 0; }
-            if (Z.blob_job >= 0) { Z.local_len = K.blobres[Z.blob_job]; Z.ltype = GZ_LT_BLOB; Z.has_local = Z.local_len != 0; }
-            if (X.kind == GZ_FQ_SEQ) {                                     // NONREF itself leaves the path 2-bit packed; what stays is NONREF_X
-                const int aj = K.acgt_of_vb[v];
-                vbs[v].n_bases = Z.local_len; vbs[v].seq_packed_len = K.acgtres[2 * aj + 1]; vbs[v].seq_has_x = (uint32_t)K.acgtres[2 * aj] != 0;
-                Z.has_local = vbs[v].seq_has_x != 0; Z.ltype = GZ_LT_UINT8;  // NONREF_X.ltype (codec_acgt.c:34-35)
-            }
-            r.n = Z.n; r.local_len = Z.local_len; r.ats_node = -1;
-            if (qmode0 && Z.n && (X.kind == GZ_FQ_QUAL || X.kind == GZ_FQ_QUAL_AUX)) {
-                const ZipDomq &D = K.domq[v];
-                r.domq_local_len = X.kind == GZ_FQ_QUAL ? D.res.qual_len : X.item == 0 ? D.res.runs_len : X.item == 1 ? D.res.mplx_len : D.res.divr_len;
-                if (X.kind == GZ_FQ_QUAL_AUX && X.item == 0 && !D.snip.empty ()) {          // seg_by_ctx (denorm_snip) (codec_domq.c:244): one b250 entry
-                    r.state = 3; r.n = 1; r.dict_len = D.snip.size ();
-                    blob_put (K.blob, &r, sizeof (r)); blob_put (K.blob, D.snip.data (), D.snip.size ());
-                    continue;
-                }
-            }
-            if (X.kind == GZ_FQ_SEQ || X.kind == GZ_FQ_QUAL || X.kind == GZ_FQ_QUAL_AUX || !Z.n) { blob_put (K.blob, &r, sizeof (r)); continue; }
-            if (Z.col_job < 0) { r.state = 2; blob_put (K.blob, &r, sizeof (r)); continue; }
-            const GzColumnResult &cr = K.colres[Z.col_job];
-            const GzdPackJob &p = pack[Z.col_job];
-            const uint32_t *counts = (const uint32_t *)(f->stage.data () + p.at[3]);
-            r.state = 1; r.n_ol = Z.n_ol; r.n_new = cr.n_new; r.dict_len = cr.dict_len; r.seg_b250_len = cr.b250_len; r.b250_count = cr.b250_count;
-            r.all_the_same = cr.all_the_same != 0;
-            if (r.all_the_same) {
-                // the one node of the column: an ol word (the index with a count) or the VBlock's first new node
-                for (uint32_t k = 0; k < Z.n_ol && r.ats_node < 0; k++) if (counts[k]) r.ats_node = (int32_t)k;
-                if (r.ats_node < 0 && cr.n_new) r.ats_node = (int32_t)Z.n_ol;    // (-1: every snip was empty / missing: not droppable)
-            }
-            blob_put (K.blob, &r, sizeof (r));
-            blob_put (K.blob, f->stage.data () + p.at[0], cr.dict_len);
-            blob_put (K.blob, f->stage.data () + p.at[1], 8 * (size_t)cr.n_new);
-            blob_put (K.blob, f->stage.data () + p.at[2], 4 * (size_t)cr.n_new);
-            blob_put (K.blob, counts, 4 * ((size_t)Z.n_ol + cr.n_new));
-        }
+    if (f->qual_ctx >= 0) for (uint32_t v = 0; v < NV; v++) {
+        ZipCol &Z = COL (v, (uint32_t)f->qual_ctx);
+        if (Z.blob_job >= 0) { Z.local_len = K.blobres[Z.blob_job]; Z.ltype = GZ_LT_BLOB; Z.has_local = Z.local_len != 0; }
     }
     // ---- the long streams go first, on a handle of their own: QUAL locals (length known on the host, no dependence on the merge)
     // are handed to the coders as soon as they are gathered, so that their strictly serial chains run beside the trial compressions and the short
@@ -786,9 +757,73 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         if (!K.early.empty ()) {
             if (!(K.d_early_len = (uint32_t *)ws_alloc (f, K.early.size () * 4))) return GZ_ERR_HIP;
             for (size_t k = 0; k < K.early.size (); k++) K.early[k].out_len_dev = K.d_early_len + k;
-            HIPCHK (h, hipStreamSynchronize (h->stream));             // (their inputs were gathered on this handle's stream)
+            // (their inputs were gathered on this handle's stream: complete, the event above was waited for)
             GzHandle *h2 = f->h2;
             if ((rc = gz_codec_compress_batch (h2, K.early.data (), (int)K.early.size ())) != GZ_OK) { h->err = h2->err; return rc; }
+        }
+    }
+    T.mark ("early");
+    rc = gz_sync (h);
+    // (from here on the second handle may be at work on this call's buffers: it is waited for before an error is returned)
+#define ZIP_FAIL(code) do { if (f->h2) (void)gz_sync (f->h2); return (code); } while (0)
+    if (rc < 0) ZIP_FAIL (rc);
+    T.mark ("seg-sync");
+    if (a.fq.first_bad != 0xffffffffu) {
+        for (uint32_t v = 0; v < NV; v++) if (a.fq.first_bad >= r0[v] && a.fq.first_bad < r_end[v]) vbs[v].status = GZ_ERR_CORRUPT;
+        h->err = "not FASTQ: a read is not '@'.. / SEQ / '+'.. / QUAL of SEQ's length (fastq.c:1008-1010,1076,1121)"; return GZ_ERR_CORRUPT;
+    }
+    if (a.n_bad_items) { h->err = "a line 1 does not fit the container of the plan (the reference would re-discover the flavor, qname.c:823-826)"; ZIP_FAIL (GZ_ERR_CORRUPT); }
+    for (size_t k = 0; k < icol_jobs.size (); k++)
+        if ((int32_t)icolres[2 * k + 1] == GZ_ST_CORRUPT) { h->err = "an ordered item is not an integer (qname.c:750-756)"; ZIP_FAIL (GZ_ERR_CORRUPT); }
+    for (size_t k = 0; k < NCJ; k++) if (K.colres[k].status != 1) { h->err = "column dictionary capacity"; ZIP_FAIL (GZ_ERR); }
+    if (!pack_total[1]) { h->err = "merge staging buffer too small"; ZIP_FAIL (GZ_ERR); }
+    f->stage.resize (pack_total[0] + 16);
+    if (pack_total[0] && hipMemcpy (f->stage.data (), d_staging, pack_total[0], hipMemcpyDeviceToHost) != hipSuccess) { h->err = "hipMemcpy (merge staging)"; ZIP_FAIL (GZ_ERR_HIP); }
+
+    // ---- the merge blob: per VBlock, per context, what ctx_merge_in_one_vctx reads of the VBlock's context ------------------
+    K.blob.clear ();
+    for (uint32_t v = 0; v < NV; v++) {
+        ZipBlobVB hv = { vbs[v].vblock_i, vbs[v].r1 >= 0 ? vbs[vbs[v].r1].vblock_i : 0, NC, 0 };
+        if (qmode0) hv.qual = (qmode0 < 0 ? 1u : 0u) | (K.domq[v].fit ? 2u : 0u) | (K.domq[v].res.status != 1 ? 4u : 0u);
+        blob_put (K.blob, &hv, sizeof (hv));
+        for (uint32_t c = 0; c < NC; c++) {
+            const GzFastqCtx &X = f->ctxs[c];
+            ZipCol &Z = COL (v, c);
+            ZipMergeRec r; memset (&r, 0, sizeof (r));
+            if (Z.dyn_job >= 0) { Z.local_len = K.dynres[Z.dyn_job].len; Z.ltype = K.dynres[Z.dyn_job].ltype; Z.has_local = Z.local_len != 0; }
+            if (Z.blob_job >= 0 && X.kind == GZ_FQ_SEQ) { Z.local_len = K.blobres[Z.blob_job]; Z.ltype = GZ_LT_BLOB; Z.has_local = Z.local_len != 0; }   // (QUAL: above)
+            if (X.kind == GZ_FQ_SEQ) {                                     // NONREF itself leaves the path 2-bit packed; what stays is NONREF_X
+                const int aj = K.acgt_of_vb[v];
+                vbs[v].n_bases = Z.local_len; vbs[v].seq_packed_len = K.acgtres[2 * aj + 1]; vbs[v].seq_has_x = (uint32_t)K.acgtres[2 * aj] != 0;
+                Z.has_local = vbs[v].seq_has_x != 0; Z.ltype = GZ_LT_UINT8;  // NONREF_X.ltype (codec_acgt.c:34-35)
+            }
+            r.n = Z.n; r.local_len = X.kind == GZ_FQ_QUAL ? (Z.blob_job >= 0 ? K.blobres[Z.blob_job] : 0) : Z.local_len; r.ats_node = -1;
+            if (qmode0 && Z.n && (X.kind == GZ_FQ_QUAL || X.kind == GZ_FQ_QUAL_AUX)) {
+                const ZipDomq &D = K.domq[v];
+                r.domq_local_len = X.kind == GZ_FQ_QUAL ? D.res.qual_len : X.item == 0 ? D.res.runs_len : X.item == 1 ? D.res.mplx_len : D.res.divr_len;
+                if (X.kind == GZ_FQ_QUAL_AUX && X.item == 0 && !D.snip.empty ()) {          // seg_by_ctx (denorm_snip) (codec_domq.c:244): one b250 entry
+                    r.state = 3; r.n = 1; r.dict_len = D.snip.size ();
+                    blob_put (K.blob, &r, sizeof (r)); blob_put (K.blob, D.snip.data (), D.snip.size ());
+                    continue;
+                }
+            }
+            if (X.kind == GZ_FQ_SEQ || X.kind == GZ_FQ_QUAL || X.kind == GZ_FQ_QUAL_AUX || !Z.n) { blob_put (K.blob, &r, sizeof (r)); continue; }
+            if (Z.col_job < 0) { r.state = 2; blob_put (K.blob, &r, sizeof (r)); continue; }
+            const GzColumnResult &cr = K.colres[Z.col_job];
+            const GzdPackJob &p = pack[Z.col_job];
+            const uint32_t *counts = (const uint32_t *)(f->stage.data () + p.at[3]);
+            r.state = 1; r.n_ol = Z.n_ol; r.n_new = cr.n_new; r.dict_len = cr.dict_len; r.seg_b250_len = cr.b250_len; r.b250_count = cr.b250_count;
+            r.all_the_same = cr.all_the_same != 0;
+            if (r.all_the_same) {
+                // the one node of the column: an ol word (the index with a count) or the VBlock's first new node
+                for (uint32_t k = 0; k < Z.n_ol && r.ats_node < 0; k++) if (counts[k]) r.ats_node = (int32_t)k;
+                if (r.ats_node < 0 && cr.n_new) r.ats_node = (int32_t)Z.n_ol;    // (-1: every snip was empty / missing: not droppable)
+            }
+            blob_put (K.blob, &r, sizeof (r));
+            blob_put (K.blob, f->stage.data () + p.at[0], cr.dict_len);
+            blob_put (K.blob, f->stage.data () + p.at[1], 8 * (size_t)cr.n_new);
+            blob_put (K.blob, f->stage.data () + p.at[2], 4 * (size_t)cr.n_new);
+            blob_put (K.blob, counts, 4 * ((size_t)Z.n_ol + cr.n_new));
         }
     }
     *blob_out = K.blob.data (); *blob_len_out = K.blob.size ();

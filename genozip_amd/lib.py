@@ -101,7 +101,7 @@ class GzDomqResult(C.Structure):
 
 class GzDomqJob(C.Structure):
     _fields_ = [("text", C.c_void_p), ("off", C.c_void_p), ("len", C.c_void_p), ("n", C.c_uint32), ("qual", C.c_void_p), ("runs", C.c_void_p),
-                ("mplx", C.c_void_p), ("divr", C.c_void_p), ("result_dev", C.c_void_p)]
+                ("mplx", C.c_void_p), ("divr", C.c_void_p), ("result_dev", C.c_void_p), ("only_if_dev", C.c_void_p)]
 
 
 class GzDomqFitJob(C.Structure):

@@ -531,6 +531,8 @@ typedef struct {
     const uint8_t *text; const uint32_t *off, *len; uint32_t n;
     uint8_t *qual, *runs, *mplx, *divr;
     GzDomqResult *result_dev;
+    const uint32_t *only_if_dev;  /* optional: the job is skipped (nothing written, *result_dev included) when this device word is 0 -
+                                     e.g. the fit flag gz_domq_fit left for the VBlock that decides for the file                  */
 } GzDomqJob;
 int gz_domq_columns (GzHandle *h, const GzDomqJob *jobs, int n_jobs);
 /* codec_domq_qual_data_is_a_fit_for_domq (:69-134) per VBlock: *fit_dev = 1 when more than half of the first (up to) 10 lines

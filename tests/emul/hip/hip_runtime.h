@@ -54,6 +54,7 @@ static inline hipError_t hipEventCreateWithFlags (hipEvent_t *e, int) { *e = nul
 static inline hipError_t hipStreamWaitEvent (hipStream_t, hipEvent_t, int) { return hipSuccess; }
 static inline hipError_t hipEventDestroy (hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord (hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize (hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime (float *ms, hipEvent_t, hipEvent_t) { *ms = 0; return hipSuccess; }
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute (const void *, int, int) { return hipSuccess; }

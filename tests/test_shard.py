@@ -79,13 +79,13 @@ def test_gather_to_writer_rank_gloo_world2():
 
 
 # ---- real VBlocks under a process group: the file of test_emul_fastq_zip dealt out over 2 ranks -----------------------------
-def _pair_file(n_reads, n_pairs):
+def _pair_file(n_reads, n_pairs, qual="uniform"):
     """-> (text, [(text_off, text_len, vblock_i, r1 index)]) of a paired FASTQ in the reference's VBlock order: R1's VBlocks
     1..n_pairs, then R2's n_pairs+1..2 n_pairs, R2 VBlock k pairing R1 VBlock k"""
     import numpy as np
     import parity
-    r1 = parity.fastq_text(n_reads, seed=500, mate=1)
-    r2 = parity.fastq_text(n_reads, seed=500, mate=2, qual_seed=900)
+    r1 = parity.fastq_text(n_reads, seed=500, mate=1, qual=qual)
+    r2 = parity.fastq_text(n_reads, seed=500, mate=2, qual_seed=900, qual=qual)
     vbs, text = [], r1 + r2
     for m, t in enumerate((r1, r2)):
         nl = np.flatnonzero(np.frombuffer(t, dtype=np.uint8) == 10)
@@ -95,7 +95,7 @@ def _pair_file(n_reads, n_pairs):
     return text, vbs
 
 
-def _zip_worker(rank, world, port, n_reads, n_pairs, q):
+def _zip_worker(rank, world, port, n_reads, n_pairs, q, qual="uniform"):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), here, os.path.join(here, "emul")):
@@ -109,7 +109,7 @@ def _zip_worker(rank, world, port, n_reads, n_pairs, q):
     from genozip_amd import fastq as fq
     from genozip_amd.shard import pairs_of_rank, zip_vblocks_sharded
     E = Engine(lib_path=os.path.join(here, "emul", "libgenozip_amd_emul.so"), mem=HostMem())
-    text, vbs = _pair_file(n_reads, n_pairs)
+    text, vbs = _pair_file(n_reads, n_pairs, qual)
     F = E.zip_open(fq.illumina_plan(paired=True))
     mine = pairs_of_rank(n_pairs, rank, world)
     # this rank's VBlocks in ascending vblock_i: its R1 VBlocks, then its R2 VBlocks naming them
@@ -128,15 +128,19 @@ def _zip_worker(rank, world, port, n_reads, n_pairs, q):
     dist.destroy_process_group()
 
 
-def test_file_dealt_out_over_2_ranks_equals_one_rank(emul_engine):
+import pytest
+
+
+@pytest.mark.parametrize("qual", ["uniform", "bin"])
+def test_file_dealt_out_over_2_ranks_equals_one_rank(emul_engine, qual):
     """the N>1 form of the whole path (strong scaling: ONE file, its VBlock pairs dealt out): every rank segs and compresses its
     own VBlocks through the emulated build, the dictionary merge and the codec choices are exchanged - and every VBlock's z_data
-    is byte-identical to what a single process makes of the same file"""
+    is byte-identical to what a single process makes of the same file. qual = "bin": the file's first VBlock (rank 0's) makes QUAL go
+    through CODEC_DOMQ - rank 1 learns that in the merge, from rank 0's blob"""
     from genozip_amd import fastq as fq
     n_reads, n_pairs = 360, 3
-    text, vbs = _pair_file(n_reads, n_pairs)
+    text, vbs = _pair_file(n_reads, n_pairs, qual)
     F = emul_engine.zip_open(fq.illumina_plan(paired=True))
-    one = {r["vblock_i"]: r["z"] for r in F.zip_vblocks(text, vbs)} if False else None
     buf = emul_engine.mem.upload(text + b"\0" * 32)
     tab = F.vb_table(vbs)
     F.zip_table(buf, len(text), tab, len(vbs))
@@ -149,7 +153,7 @@ def test_file_dealt_out_over_2_ranks_equals_one_rank(emul_engine):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_zip_worker, args=(r, 2, port, n_reads, n_pairs, q)) for r in range(2)]
+    procs = [ctx.Process(target=_zip_worker, args=(r, 2, port, n_reads, n_pairs, q, qual)) for r in range(2)]
     for p in procs:
         p.start()
     allres = q.get(timeout=300)
