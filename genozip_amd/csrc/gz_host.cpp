@@ -81,6 +81,8 @@ struct GzHandle {
     std::vector<hipEvent_t> event_pool;            // (creating and destroying two events per launch costs more than the launch)
     struct ProfAcc { std::string name; double ms; int launches; };
     std::vector<ProfAcc> prof;
+    std::vector<GzHandle *> helpers;       // handles that work for this one (the VBlock driver's second handle): profiled with it
+    std::vector<ProfAcc> prof_view;        // gz_profile_get: this handle's totals + its helpers'
 };
 
 static inline hipEvent_t gz_event_get (GzHandle *h)
@@ -274,15 +276,29 @@ extern "C" void gz_profile (GzHandle *h, int enable, int reset)
     if (h->pending.empty ()) prof_collect (h);          // (everything recorded so far has been synchronised)
     h->profiling = enable != 0;
     if (reset) h->prof.clear ();
+    for (GzHandle *o : h->helpers) gz_profile (o, enable, reset);
 }
 
 extern "C" int gz_profile_get (GzHandle *h, int idx, char *name, int name_cap, double *total_ms, int *launches)
 {
-    if (h && h->pending.empty ()) prof_collect (h);
-    if (!h || idx < 0 || idx >= (int)h->prof.size ()) return 0;
-    if (name && name_cap > 0) { strncpy (name, h->prof[idx].name.c_str (), name_cap - 1); name[name_cap - 1] = 0; }
-    if (total_ms) *total_ms = h->prof[idx].ms;
-    if (launches) *launches = h->prof[idx].launches;
+    if (!h || idx < 0) return 0;
+    if (idx == 0) {                                         // (a walk starts at 0: gather this handle's and its helpers' totals)
+        h->prof_view.clear ();
+        std::vector<GzHandle *> all (1, h);
+        all.insert (all.end (), h->helpers.begin (), h->helpers.end ());
+        for (GzHandle *o : all) {
+            if (o->pending.empty ()) prof_collect (o);
+            for (auto &p : o->prof) {
+                bool found = false;
+                for (auto &acc : h->prof_view) if (acc.name == p.name) { acc.ms += p.ms; acc.launches += p.launches; found = true; break; }
+                if (!found) h->prof_view.push_back (p);
+            }
+        }
+    }
+    if (idx >= (int)h->prof_view.size ()) return 0;
+    if (name && name_cap > 0) { strncpy (name, h->prof_view[idx].name.c_str (), name_cap - 1); name[name_cap - 1] = 0; }
+    if (total_ms) *total_ms = h->prof_view[idx].ms;
+    if (launches) *launches = h->prof_view[idx].launches;
     return 1;
 }
 

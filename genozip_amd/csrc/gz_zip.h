@@ -176,6 +176,7 @@ extern "C" GzZipFile *gz_zip_open (GzHandle *h, const GzFastqPlan *plan)
     f->plan.ctxs = f->ctxs.data ();
     zip_init_qual_mode (f);
     { const char *e = getenv ("GZ_ZIP_NO_OVERLAP"); int err = 0; if (!(e && *e && *e != '0')) f->h2 = gz_create_background (h->device, &err); }
+    if (f->h2) { f->h2->profiling = h->profiling; h->helpers.push_back (f->h2); }
     return f;
 }
 
@@ -184,7 +185,11 @@ extern "C" void gz_zip_close (GzZipFile *f)
     if (!f) return;
     (void)hipSetDevice (f->h->device);
     (void)gz_sync (f->h);
-    if (f->h2) gz_destroy (f->h2);
+    if (f->h2) {
+        auto &hl = f->h->helpers;
+        hl.erase (std::remove (hl.begin (), hl.end (), f->h2), hl.end ());
+        gz_destroy (f->h2);
+    }
     if (f->pinned) (void)hipHostFree (f->pinned);
     if (f->ev_early) (void)hipEventDestroy (f->ev_early);
     for (auto z : f->zctx) gz_zctx_destroy (z);
@@ -480,10 +485,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     ZCHK (gz_fastq_records (h, text, line_off, line_len, &d_a->lines, R, l1_off, l1_len, seq_off, seq_len, l3_off, l3_len, qual_off, qual_len, &d_a->fq));
     WS (item_off, uint32_t, (size_t)NI * R + 8);
     WS (item_len, uint32_t, (size_t)NI * R + 8);
-    ZCHK (gz_tokenize_column_n (h, text, l1_off, l1_len, R, f->plan.seps, f->plan.sep_counts, f->plan.n_seps, item_off, item_len, &d_a->n_bad_items));
     WS (d_vbstat, uint32_t, 2 * (size_t)NV + 2);
-    hipLaunchKernelGGL (k_vb_stats, dim3 (NV), dim3 (256), 2048, h->stream, (const uint32_t *)line_off, (const uint32_t *)seq_len, (const uint32_t *)d_first_line,
-                        (const uint64_t *)(d_vb_off + NV), NV, d_vbstat);
 
     // the dictionaries as every VBlock of this call clones them (ctx_clone)
     struct OlDev { const uint8_t *dict = NULL; const uint64_t *ci = NULL; const uint32_t *sl = NULL; uint32_t n = 0; };
@@ -654,6 +656,10 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         ZCHK (gz_wait_for (f->h2, h));
         if ((rc = gz_codec_compress_batch (f->h2, trial.data (), (int)trial.size ())) != GZ_OK) { h->err = f->h2->err; return rc; }
     }
+    // (the items of line 1 and the VBlock statistics are only needed from here on: queued behind the QUAL gather, which the long pole waits for)
+    ZCHK (gz_tokenize_column_n (h, text, l1_off, l1_len, R, f->plan.seps, f->plan.sep_counts, f->plan.n_seps, item_off, item_len, &d_a->n_bad_items));
+    hipLaunchKernelGGL (k_vb_stats, dim3 (NV), dim3 (256), 2048, h->stream, (const uint32_t *)line_off, (const uint32_t *)seq_len, (const uint32_t *)d_first_line,
+                        (const uint64_t *)(d_vb_off + NV), NV, d_vbstat);
     ZCHK (gz_int_columns (h, icol_jobs.data (), (int)icol_jobs.size ()));
     // (column tables hold at most 65 535 rows per call)
     for (size_t at = 0; at < col_jobs.size (); at += 32768) ZCHK (gz_ctx_seg_columns (h, col_jobs.data () + at, (int)std::min<size_t> (32768, col_jobs.size () - at)));

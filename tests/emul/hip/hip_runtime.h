@@ -176,8 +176,26 @@ static inline void emu_launch (dim3 grid, dim3 block, size_t shmem, const std::f
     }
 }
 
+// EMU_PROFILE=1: seconds per kernel name on stderr when the process ends (where does an emulated test spend its time?)
+#include <map>
+#include <string>
+#include <chrono>
+struct EmuProfile {
+    std::map<std::string, std::pair<double, unsigned long>> t; bool on;
+    EmuProfile () { const char *e = getenv ("EMU_PROFILE"); on = e && *e && *e != '0'; }
+    ~EmuProfile () { if (on) for (auto &k : t) fprintf (stderr, "[emu] %-28s %9.3f s  %8lu launches\n", k.first.c_str (), k.second.first, k.second.second); }
+};
+static EmuProfile emu_profile;
+static inline void emu_launch_named (const char *name, dim3 grid, dim3 block, size_t shmem, const std::function<void ()> &body)
+{
+    if (!emu_profile.on) { emu_launch (grid, block, shmem, body); return; }
+    const auto t0 = std::chrono::steady_clock::now ();
+    emu_launch (grid, block, shmem, body);
+    auto &e = emu_profile.t[name];
+    e.first += std::chrono::duration<double> (std::chrono::steady_clock::now () - t0).count (); e.second++;
+}
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
-    emu_launch ((grid), (block), (shmem), [=] () { kern (__VA_ARGS__); })
+    emu_launch_named (#kern, (grid), (block), (shmem), [=] () { kern (__VA_ARGS__); })
 
 // ---- device intrinsics ----
 static inline void __syncthreads (void)

@@ -102,7 +102,9 @@ def test_fastq_zip_driver(gpu_engine, oracle):
     file's dictionaries) == the oracle's step-by-step composition"""
     parity.fastq_zip(gpu_engine, oracle, 6000)
     parity.fastq_zip(gpu_engine, oracle, 3000, qual=("bin", "uniform"))          # QUAL through CODEC_DOMQ (decided by the first VBlock)
+    parity.fastq_zip(gpu_engine, oracle, 2000, qual=("uniform", "bin"))          # ... or not, also for later VBlocks that would fit
     parity.fastq_zip(gpu_engine, oracle, 1000, n_calls=1, qual=("uniform",), domq=13)
+    parity.fastq_zip(gpu_engine, oracle, 1000, n_calls=1, qual=("bin",), domq=1)
 
 
 def test_c_host_program():

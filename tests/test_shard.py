@@ -138,7 +138,7 @@ def test_file_dealt_out_over_2_ranks_equals_one_rank(emul_engine, qual):
     is byte-identical to what a single process makes of the same file. qual = "bin": the file's first VBlock (rank 0's) makes QUAL go
     through CODEC_DOMQ - rank 1 learns that in the merge, from rank 0's blob"""
     from genozip_amd import fastq as fq
-    n_reads, n_pairs = 360, 3
+    n_reads, n_pairs = 96, 3
     text, vbs = _pair_file(n_reads, n_pairs, qual)
     F = emul_engine.zip_open(fq.illumina_plan(paired=True))
     buf = emul_engine.mem.upload(text + b"\0" * 32)

@@ -11,8 +11,10 @@ import shutil
 import sys
 
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+pre = sys.argv[4] if len(sys.argv) > 4 else "r1"                     # the -o name the rocprofv3 runs were given
+workload = json.loads(sys.argv[5]) if len(sys.argv) > 5 else None       # what bench.py was run on (it only takes traffic for the same)
 os.makedirs(dst, exist_ok=True)
-shutil.copy(os.path.join(src, "trace", "r1_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "trace", pre + "_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
 for f in ("bench_stats.json", "bench_fetch.json", "bench_write.json"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, tag + "_" + f))
@@ -26,8 +28,8 @@ def agg(path, cname):
     return out
 
 
-fetch = agg(os.path.join(src, "fetch", "r1_counter_collection.csv"), "FETCH_SIZE")
-write = agg(os.path.join(src, "write", "r1_counter_collection.csv"), "WRITE_SIZE")
+fetch = agg(os.path.join(src, "fetch", pre + "_counter_collection.csv"), "FETCH_SIZE")
+write = agg(os.path.join(src, "write", pre + "_counter_collection.csv"), "WRITE_SIZE")
 rows = []
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, [0]), write.get(k, [0])
@@ -46,7 +48,7 @@ for r in rows:
     pmc[r["kernel"].split("(")[0]] = {"fetch_kb_reported": r["FETCH_SIZE_KB_per_dispatch_mean"], "write_kb_reported": r["WRITE_SIZE_KB_per_dispatch_mean"],
                                       "dispatches_per_step": r["dispatches"] / STEPS, "traffic_bytes": int(per_dispatch),
                                       "traffic_bytes_per_step": int(per_dispatch * r["dispatches"] / STEPS)}
-json.dump({"source": "GZ_NO_PIPELINE=1 rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of: python bench.py --steps 2 --warmup 1 --no-cpu "
+json.dump({"workload": workload, "source": "GZ_NO_PIPELINE=1 GZ_ZIP_NO_OVERLAP=1 rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of: python bench.py --steps 2 --warmup 1 --no-cpu "
                      "--pin-codecs. (Counter collection serialises kernels, which the persistent chain kernel cannot live with: GZ_NO_PIPELINE runs the "
                      "same kernels over the same data one after the other - per step the bytes are the same, only the number of launches they are "
                      "spread over differs, hence traffic_bytes_per_step.)",
