@@ -115,3 +115,26 @@ def test_emul_ctx_golden(emul_engine, oracle):
 
 def test_emul_domq(emul_engine, oracle):
     parity.domq(emul_engine, oracle, 700)
+
+
+def test_section_order_contexts_out_of_order(emul_engine):
+    """a15 is computed in the library (gz_section_order, src/zip.c:247-342,565-585), whatever order the caller's context table is
+    in: random tables of contexts (did_i shuffled, every DEP level, merge-made locals, vb_i = 1 and later) == SURVEY A.7 restated"""
+    import ctypes as C
+    import numpy as np
+    from genozip_amd.lib import GzSecOrderIn
+    from genozip_amd import synth
+    L = emul_engine.L
+    for seed in range(40):
+        r = synth.u32(7000 + seed, 200)
+        n = 1 + int(r[0] % 30)
+        dids = np.argsort(r[1:1 + n], kind="stable")                    # a permutation: the table is NOT in did_i order
+        ctxs = [(int(dids[i]) * 3 + 1, int(r[40 + i] % 3), bool(r[80 + i] % 4), bool(r[120 + i] % 5 == 0), bool(r[160 + i] % 3)) for i in range(n)]
+        arr = (GzSecOrderIn * n)()
+        for i, (did, dep, hl, so, hb) in enumerate(ctxs):
+            arr[i].did_i, arr[i].local_dep, arr[i].has_local, arr[i].ston_only_local, arr[i].has_b250 = did, dep, int(hl), int(so), int(hb)
+        for vb_i in (1, 2, 7):
+            out = (C.c_uint32 * (2 * n))()
+            k = L.gz_section_order(arr, n, vb_i, out)
+            got = [(out[j] // 2, "B" if out[j] & 1 else "L") for j in range(k)]
+            assert got == parity._section_order_ref(ctxs, vb_i), (seed, vb_i)
