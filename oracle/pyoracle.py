@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(_HERE, "liboracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libhtsref.so")
 CTXREF_SO = os.path.join(_HERE, "_ref", "libctxref.so")
+COMPREF_SO = os.path.join(_HERE, "_ref", "libcompref.so")
 
 CODEC_NONE, CODEC_RANB, CODEC_RANW, CODEC_RANb, CODEC_RANw = 1, 6, 7, 8, 9
 CODEC_ARTB, CODEC_ARTW, CODEC_ARTb, CODEC_ARTw = 16, 17, 18, 19
@@ -561,6 +562,26 @@ class CtxRef:
     def hash_do(self, hash_len, snip):
         return self.L.ctxref_hash_do(hash_len, bytes(snip), len(snip))
 
+    def merge_hash(self, estimated_entries, vbs):
+        """the reference's own hash.c under the merge loop: vbs = [(can_have_singletons, [(snip, count), ...new nodes])]
+        -> dict(word=[per VBlock list], ston=[per VBlock list], dict, n_failed, hash_len)"""
+        import numpy as np
+        flat = [(s, c) for _, nodes in vbs for s, c in nodes]
+        n = len(flat)
+        snips = b"".join(bytes(s) + b"\0" for s, _ in flat) + b"\0"
+        sl = np.array([len(s) for s, _ in flat], dtype=np.uint32); cnt = np.array([c for _, c in flat], dtype=np.uint32)
+        nn = np.array([len(nodes) for _, nodes in vbs], dtype=np.uint32); cs = np.array([int(c) for c, _ in vbs], dtype=np.uint8)
+        word = np.zeros(max(1, n), dtype=np.int32); ston = np.zeros(max(1, n), dtype=np.uint8)
+        dic = np.zeros(len(snips) + 64, dtype=np.uint8)
+        dl, nf, hl = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint32()
+        self.L.ctxref_merge_hash.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p] + [ctypes.c_void_p] * 8
+        self.L.ctxref_merge_hash(estimated_entries, len(vbs), nn.ctypes.data, cs.ctypes.data, snips, sl.ctypes.data, cnt.ctypes.data, word.ctypes.data, ston.ctypes.data,
+                                 dic.ctypes.data, ctypes.addressof(dl), ctypes.addressof(nf), ctypes.addressof(hl))
+        out_w, out_s, at = [], [], 0
+        for _, nodes in vbs:
+            out_w.append([int(x) for x in word[at:at + len(nodes)]]); out_s.append([int(x) for x in ston[at:at + len(nodes)]]); at += len(nodes)
+        return dict(word=out_w, ston=out_s, dict=dic[:dl.value].tobytes(), n_failed=nf.value, hash_len=hl.value)
+
     def acgt(self, seq):
         """the reference's own codec_acgt_compress on a contiguous NONREF.local (sub-codec = store)
         -> (packed as handed to the sub-codec, NONREF_X.local, has_x, sub_codec)"""
@@ -571,3 +592,28 @@ class CtxRef:
         self.L.ctxref_acgt.argtypes = [ctypes.c_char_p, ctypes.c_uint32] + [ctypes.c_void_p] * 5
         self.L.ctxref_acgt(seq, n, packed.ctypes.data, ctypes.addressof(pl), x.ctypes.data, ctypes.addressof(hx), ctypes.addressof(sub))
         return packed[:pl.value].tobytes(), x[:n].tobytes(), bool(hx.value), sub.value
+
+
+class CompRef:
+    """the reference's OWN src/compressor.c (comp_compress, row a10) with its codec_none.c, the vendored libdeflate adler32 and the
+    vendored htscodecs, compiled in place (oracle/Makefile target `ref`, oracle/ref_comp_shim.c). Exists only where /root/reference does."""
+
+    def __init__(self, path=COMPREF_SO):
+        self.L = ctypes.CDLL(path)
+        self.L.compref_section.restype = ctypes.c_long
+        self.L.compref_section.argtypes = [ctypes.c_int] * 7 + [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64]
+
+    @staticmethod
+    def available():
+        return os.path.exists(COMPREF_SO)
+
+    def section(self, desc, data):
+        """desc: GzoCtxSectionDesc -> header + payload as comp_compress appends them to z_data"""
+        data = bytes(data)
+        cap = 2 * len(data) + 300000
+        out = ctypes.create_string_buffer(cap)
+        n = self.L.compref_section(desc.section_type, desc.codec, desc.sub_codec, desc.flags, desc.ltype, desc.param, desc.b250_size_or_nothing_char,
+                                   bytes(desc.dict_id), desc.vblock_i, data, len(data), out, cap)
+        if n < 0:
+            raise RuntimeError("compref_section failed")
+        return out.raw[:n]

@@ -303,3 +303,57 @@ int ctxref_acgt (const uint8_t *seq, uint32_t n, uint8_t *packed, uint32_t *pack
     free (comp); free (c->local.memory); free (vb->scratch.memory); free (vb);
     return 0;
 }
+
+/* ---- a4 (its hash): the reference's own src/hash.c, compiled in place ----------------------------------------------------------
+ * hash_alloc_global + hash_global_get_entry with the singleton tables (src/hash.c:229-240,280-482) decide, for every new node of
+ * a VBlock context, whether it is a word the file already has, a new word, a singleton (diverted to local) or a failed singleton.
+ * The loop around them is ctx_merge_in_one_vctx / ctx_commit_node (src/context.c:1000-1034,269-316; context.c does not build
+ * outside the reference's tree), stated here in its essentials: count == 1 in a context that can have singletons allows a
+ * singleton; a singleton's node gets the word index of the SNIP_LOOKUP snip; a new word is appended to the dictionary + NUL. */
+#include "hash.h"
+rom report_support_if_unexpected (void) { return ""; }
+#include "dict_io.h"
+StrText16K str_snip_ex (DataType dt, STRp(snip), bool add_quote) { static StrText16K s; return s; }
+StrText str_int_commas (int64_t n) { StrText s = {}; return s; }
+
+static WordIndex shim_commit (ContextP zctx, STRp(snip), bool allow_singleton, int *was_singleton)
+{
+    CtxNode *upd;
+    WordIndex wi = hash_global_get_entry (zctx, STRa(snip), allow_singleton, false, &upd);
+    if (wi != WORD_INDEX_NONE && !upd) return wi;                       /* an existing word */
+    if (upd) {                                                          /* a new word: ctx_insert_to_dict (context.c:50-71) */
+        buf_alloc_do (NULL, &zctx->dict, zctx->dict.len + snip_len + 1, 2, "dict", __FUNCTION__, __LINE__);
+        upd->char_index = zctx->dict.len;
+        memcpy (zctx->dict.data + zctx->dict.len, snip, snip_len); zctx->dict.data[zctx->dict.len + snip_len] = 0;
+        zctx->dict.len += snip_len + 1;
+        return wi;
+    }
+    *was_singleton = 1;                                                 /* a singleton: its node points at the SNIP_LOOKUP word */
+    char lookup[1] = { SNIP_LOOKUP };
+    int dummy = 0;
+    return shim_commit (zctx, lookup, 1, false, &dummy);
+}
+
+/* VBlock contexts merging one after the other into one file context. Per VBlock: its new nodes (snips NUL-separated, with their
+ * lengths and counts) and whether the context can have singletons. Out: per node the word index and whether it went to local;
+ * the dictionary, the number of failed singletons, the prime the hash was given */
+int ctxref_merge_hash (uint32_t estimated_entries, uint32_t n_vb, const uint32_t *n_nodes, const uint8_t *can_ston, const char *snips,
+                       const uint32_t *snip_len, const uint32_t *count, int32_t *word_out, uint8_t *ston_out,
+                       uint8_t *dict_out, uint64_t *dict_len_out, uint64_t *n_failed_out, uint32_t *hash_len_out)
+{
+    Context *zctx = calloc (1, sizeof (Context));
+    strcpy (zctx->tag_name, "CTX");
+    hash_alloc_global (zctx, estimated_entries);
+    uint64_t at = 0, k = 0;
+    for (uint32_t v = 0; v < n_vb; v++)
+        for (uint32_t i = 0; i < n_nodes[v]; i++, k++) {
+            int ston = 0;
+            word_out[k] = shim_commit (zctx, snips + at, snip_len[k], can_ston[v] && count[k] == 1, &ston);
+            ston_out[k] = (uint8_t)ston;
+            at += snip_len[k] + 1;
+        }
+    memcpy (dict_out, zctx->dict.data, zctx->dict.len); *dict_len_out = zctx->dict.len;
+    *n_failed_out = zctx->num_failed_singletons; *hash_len_out = zctx->global_hash.len32;
+    free (zctx->dict.memory); free (zctx->nodes.memory); free (zctx->global_hash.memory); free (zctx->ston_hash.memory); free (zctx->ston_ents.memory); free (zctx);
+    return 0;
+}

@@ -128,6 +128,36 @@ def acgt_cases():
     return out
 
 
+def merge_hash_cases():
+    """(name, estimated_entries, [(can_have_singletons, [(snip, count)] = the new nodes of one VBlock context)]): VBlocks that all cloned
+    an empty dictionary (a batch) merging one after the other - words met again, new words, singletons, singletons met again (failed),
+    the same snip a singleton twice, contexts that cannot have singletons, long chains in a small hash"""
+    r = synth.u32(777, 4000).astype(np.int64)
+    out = []
+    ids = lambda lo, hi, rep: [(b"read%06d" % i, 1 + (r[i] % rep == 0)) for i in range(lo, hi)]   # noqa: E731
+    out.append(("ids", 0, [(True, ids(0, 300, 7)), (True, ids(200, 500, 5)), (True, ids(0, 500, 11)), (False, ids(450, 600, 3)), (True, ids(0, 100, 1))]))
+    out.append(("tiles", 0, [(False, [(b"%d" % (1101 + i), 40) for i in range(30)]), (False, [(b"%d" % (1110 + i), 3) for i in range(40)]), (True, [(b"%d" % (1100 + i), 1) for i in range(60)])]))
+    out.append(("small_hash", 5, [(True, [(b"w%d" % (r[i] % 900), 1 + (r[i] % 3 == 0)) for i in range(v * 150, v * 150 + 400)]) for v in range(6)]))
+    out.append(("twice", 100, [(True, [(b"a", 1), (b"b", 2)]), (True, [(b"a", 1)]), (True, [(b"a", 1), (b"c", 1)]), (True, [(b"c", 1), (b"c2", 1)]), (True, [(b"\x01", 1), (b"", 1)])]))
+    out.append(("big", 60000, [(True, [(b"k%d_%d" % (r[(i * 7 + v) % 4000] % 5000, i % 3), 1 + (i % 4 == 0)) for i in range(1500)]) for v in range(4)]))
+    return out
+
+
+def section_cases():
+    """(GzoCtxSectionDesc fields, payload bytes): context sections as zfile_compress_local_data / _b250_data hand them to comp_compress"""
+    out = []
+    k = 0
+    for codec in (1, 6, 7, 8, 9, 16, 17, 18, 19):
+        for n in (0, 1, 49, 50, 51, 700, 5000):
+            k += 1
+            is_local = k % 3 != 0
+            data = synth.stream(("markov", "skew", "uniform", "runs")[k % 4], 8000 + k, n, (40, 5, 200, 8)[k % 4]).tobytes()
+            out.append((dict(vblock_i=1 + k % 5, section_type=12 if is_local else 11, codec=codec, sub_codec=0, flags=(0, 0x20, 0x04, 0x01)[k % 4],
+                             ltype=(11, 2, 6, 0)[k % 4] if is_local else 0, param=(0, 0, 7)[k % 3], b250_size_or_nothing_char=0xff if is_local and k % 4 in (1, 2) else 0 if is_local else 4,
+                             dict_id=(b"Q%dNAME" % (k % 7) + b"\0" * 8)[:8]), data))
+    return out
+
+
 LOCAL_ORDER_CASES = [(1, 1), (2, 1), (3, 2), (4, 2), (5, 4), (6, 4), (7, 8), (8, 8), (9, 4), (10, 8)]
 
 

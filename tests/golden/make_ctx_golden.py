@@ -1,6 +1,7 @@
-"""TEST INFRASTRUCTURE: generates tests/golden/ctx_golden.json from the REFERENCE'S OWN src/b250.c and src/dyn_int.c, compiled in
-place by `make -C oracle ref` (oracle/_ref/libctxref.so, oracle/ref_ctx_shim.c) - rows a2 / a5 (b250_seg_append,
-b250_zip_generate) and a3 / a7 (dyn_int_append, dyn_int_transpose) of SURVEY 8(a). Only runs where /root/reference exists; the
+"""TEST INFRASTRUCTURE: generates tests/golden/ctx_golden.json from the REFERENCE'S OWN sources compiled in place by
+`make -C oracle ref` (oracle/_ref/libctxref.so + oracle/ref_ctx_shim.c: b250.c, dyn_int.c, buffer.c, codec_domq.c, base64.c,
+codec_acgt.c, hash.c; oracle/_ref/libcompref.so + oracle/ref_comp_shim.c: compressor.c, codec_none.c, libdeflate adler32,
+htscodecs) - rows a2 / a5, a3 / a7, a6, a1's and a4's hash, a10, N2, N3 of SURVEY 8(a) / 8(f). Only runs where /root/reference exists; the
 vectors (generator parameters + outputs as hex or sha1) are committed, the reference is not.
 
     python tests/golden/make_ctx_golden.py
@@ -37,6 +38,17 @@ def main():
         r = R.domq(t, o, l)
         out["domq"].append({"name": name, "qual": enc(r["qual"]), "runs": enc(r["runs"]), "mplx": enc(r["mplx"]), "divr": enc(r["divr"]),
                             "denorm_snip": r["denorm_snip"].decode(), "param": r["param"], "fit": r["fit"]})
+    if pyoracle.CompRef.available():        # a10: the reference's own comp_compress
+        CR = pyoracle.CompRef()
+        out["sections"] = []
+        for f, data in cases.section_cases():
+            d = pyoracle.GzoCtxSectionDesc(**{k: v for k, v in f.items() if k != "dict_id"})
+            d.dict_id[:] = list(f["dict_id"])
+            out["sections"].append({"codec": f["codec"], "n": len(data), "z": enc(CR.section(d, data))})
+    out["merge_hash"] = []                  # a4's hash and singleton tables: the reference's own hash.c
+    for name, est, vbs in cases.merge_hash_cases():
+        m = R.merge_hash(est, vbs)
+        out["merge_hash"].append({"name": name, "word": m["word"], "ston": m["ston"], "dict": enc(m["dict"]), "n_failed": m["n_failed"], "hash_len": m["hash_len"]})
     out["acgt"] = []
     for name, seq in cases.acgt_cases():
         pk, x, hx, sub = R.acgt(seq)

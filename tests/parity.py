@@ -932,6 +932,35 @@ def ctx_golden(E, oracle):
             for key in ("qual", "runs", "mplx", "divr"):
                 cases.check_enc(r[key], c[key], ("domq", name, key))
             assert base64.b64encode(r["denorm"]).decode() == c["denorm_snip"] and (r["num_norm_qs"] | 0x80) == c["param"] and r["fit"] == c["fit"], ("domq", name)
+    for c, (name, est, vbs) in zip(G["merge_hash"], cases.merge_hash_cases()):     # a4: the reference's own hash.c under the merge loop
+        for Z in [pyoracle.OracleZctx(oracle, est)] + ([E.zctx(est)] if E is not None else []):
+            for v, (can_ston, nodes) in enumerate(vbs):
+                sl = [len(s) for s, _ in nodes]
+                col = dict(dict=b"".join(s + b"\0" for s, _ in nodes), node_char_index=np.cumsum([0] + [x + 1 for x in sl[:-1]]).astype(np.uint64) if nodes else np.zeros(0, np.uint64),
+                           node_snip_len=np.array(sl, dtype=np.uint32), counts=np.array([k for _, k in nodes], dtype=np.uint32), b250=b"\0" * 8, all_the_same=False, node_index=[])
+                m = Z.merge(v + 1, 0, col, can_have_singletons=can_ston)
+                assert [int(x) for x in m["node2word"]] == c["word"][v], ("merge_hash", name, v)
+                assert m["n_stons"] == sum(c["ston"][v]), ("merge_hash stons", name, v)
+                want_local = b"".join(s + b"\0" for (s, _), f in zip(nodes, c["ston"][v]) if f)
+                assert m["ston_local"] == want_local, ("merge_hash local", name, v)
+            vw = Z.view()
+            cases.check_enc(vw["dict"], c["dict"], ("merge_hash dict", name))
+            assert vw["n_failed_singletons"] == c["n_failed"], ("merge_hash failed", name)
+            if "hash_len" in vw:
+                assert vw["hash_len"] == c["hash_len"], ("merge_hash prime", name)
+    if "sections" in G:                                # a10: the reference's own comp_compress (compressor.c)
+        vbs = []
+        for c, (f, data) in zip(G["sections"], cases.section_cases()):
+            d = pyoracle.GzoCtxSectionDesc(**{k: v for k, v in f.items() if k != "dict_id"})
+            d.dict_id[:] = list(f["dict_id"])
+            cases.check_enc(oracle.section_compress(d, data), c["z"], ("section oracle", f["codec"], len(data)))
+            if E is not None:
+                from genozip_amd.codec import Section, VBlock
+                vbs.append(VBlock(f["vblock_i"], [Section(data, f["section_type"], f["codec"], f["dict_id"], ltype=f["ltype"], flags=f["flags"], param=f["param"],
+                                                           byte30=f["b250_size_or_nothing_char"], sub_codec=f["sub_codec"])]))
+        if E is not None:
+            for z, c, (f, data) in zip(E.vb_compress(vbs), G["sections"], cases.section_cases()):
+                cases.check_enc(z[84:], c["z"], ("section gpu", f["codec"], len(data)))
     for c, (name, seq) in zip(G["acgt"], cases.acgt_cases()):     # N2: the reference's own codec_acgt.c
         for who in [oracle] + ([E] if E is not None else []):
             pk, x, hx = who.acgt_pack(seq)
