@@ -582,6 +582,16 @@ class CtxRef:
             out_w.append([int(x) for x in word[at:at + len(nodes)]]); out_s.append([int(x) for x in ston[at:at + len(nodes)]]); at += len(nodes)
         return dict(word=out_w, ston=out_s, dict=dic[:dl.value].tobytes(), n_failed=nf.value, hash_len=hl.value)
 
+    def seg_nodes(self, ol_words, snips):
+        """the reference's own hash_get_entry_for_seg under ctx_create_node_do's add-a-node lines -> node index of every snip"""
+        import numpy as np
+        ol = b"".join(bytes(w) + b"\0" for w in ol_words) + b"\0"; sn = b"".join(bytes(w) + b"\0" for w in snips) + b"\0"
+        oll = np.array([len(w) for w in ol_words], dtype=np.uint32); snl = np.array([len(w) for w in snips], dtype=np.uint32)
+        out = np.zeros(max(1, len(snips)), dtype=np.int32)
+        self.L.ctxref_seg_nodes.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
+        assert self.L.ctxref_seg_nodes(len(ol_words), ol, oll.ctypes.data, len(snips), sn, snl.ctypes.data, out.ctypes.data) == 0
+        return [int(x) for x in out[:len(snips)]]
+
     def acgt(self, seq):
         """the reference's own codec_acgt_compress on a contiguous NONREF.local (sub-codec = store)
         -> (packed as handed to the sub-codec, NONREF_X.local, has_x, sub_codec)"""

@@ -357,3 +357,37 @@ int ctxref_merge_hash (uint32_t estimated_entries, uint32_t n_vb, const uint32_t
     free (zctx->dict.memory); free (zctx->nodes.memory); free (zctx->global_hash.memory); free (zctx->ston_hash.memory); free (zctx->ston_ents.memory); free (zctx);
     return 0;
 }
+
+/* ---- a1 (its hash): snip -> node index through hash_get_entry_for_seg (src/hash.c:529-576: the dictionary cloned from the file,
+ * then the VBlock's own hash), under the few lines of ctx_create_node_do (src/context.c:320-404) that add a node when there is none:
+ * the node index of a snip = its index among the cloned words, or the number of cloned words + its rank among the VBlock's new ones */
+int ctxref_seg_nodes (uint32_t n_ol, const char *ol_snips, const uint32_t *ol_len, uint32_t n, const char *snips, const uint32_t *snip_len, int32_t *node_index_out)
+{
+    Context *zctx = calloc (1, sizeof (Context)), *vctx = calloc (1, sizeof (Context));
+    VBlockP vb = new_vb ();
+    strcpy (zctx->tag_name, "CTX"); strcpy (vctx->tag_name, "CTX");
+    hash_alloc_global (zctx, n_ol + 1000);
+    uint64_t at = 0;
+    for (uint32_t i = 0; i < n_ol; i++) { int s = 0; if (shim_commit (zctx, ol_snips + at, ol_len[i], false, &s) != (WordIndex)i) return -1; at += ol_len[i] + 1; }
+    vctx->global_hash = zctx->global_hash; vctx->ol_nodes = zctx->nodes; vctx->ol_dict = zctx->dict;        /* ctx_clone: overlays */
+    vctx->num_new_entries_prev_merged_vb = 1000;                                                             /* (sizes the VBlock's hash: hash.c:76-78) */
+    at = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        rom in_dict;
+        WordIndex wi = hash_get_entry_for_seg (vb, vctx, snips + at, snip_len[i], &in_dict);
+        if (wi == WORD_INDEX_NONE) {                                                                         /* a new node (context.c:372-398) */
+            buf_alloc_do (vb, &vctx->nodes, (vctx->nodes.len + 1) * sizeof (CtxNode), 2, "nodes", __FUNCTION__, __LINE__);
+            buf_alloc_do (vb, &vctx->dict, vctx->dict.len + snip_len[i] + 1, 2, "dict", __FUNCTION__, __LINE__);
+            CtxNode *nd = &((CtxNode *)vctx->nodes.data)[vctx->nodes.len++];
+            *nd = (CtxNode){ .char_index = vctx->dict.len, .snip_len = snip_len[i], .next = NO_NEXT };
+            memcpy (vctx->dict.data + vctx->dict.len, snips + at, snip_len[i]); vctx->dict.data[vctx->dict.len + snip_len[i]] = 0;
+            vctx->dict.len += snip_len[i] + 1;
+            wi = n_ol + vctx->nodes.len32 - 1;
+        }
+        node_index_out[i] = wi;
+        at += snip_len[i] + 1;
+    }
+    free (vctx->nodes.memory); free (vctx->dict.memory); free (vctx->local_hash.memory);
+    free (zctx->dict.memory); free (zctx->nodes.memory); free (zctx->global_hash.memory); free (zctx); free (vctx); free (vb);
+    return 0;
+}

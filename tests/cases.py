@@ -128,6 +128,18 @@ def acgt_cases():
     return out
 
 
+def seg_node_cases():
+    """(cloned words, snips of the column): none cloned / thousands cloned, all new / all known / mixed, long repeats, similar strings"""
+    r = synth.u32(901, 40000).astype(np.int64)
+    ol_a = [b"w%d" % i for i in range(17000)]
+    return [([], [b"x%d" % (r[i] % 50) for i in range(3000)]),
+            (ol_a, [b"w%d" % (r[i] % 20000) for i in range(8000)]),
+            (ol_a[:300], [b"w%d" % (r[i] % 300) for i in range(2000)]),
+            ([b"1101", b"1102"], [b"%d" % (1101 + i * 9 // 5000) for i in range(5000)]),
+            ([b"a", b"aa", b"aaa"], [b"a" * (1 + r[i] % 9) for i in range(1000)] + [b"A00123:45:HXXXXXXXX"] * 20 + [b"\x01", b"\x05$", b"a\tb"]),
+            ([], [b"id%07d" % i for i in range(6000)])]
+
+
 def merge_hash_cases():
     """(name, estimated_entries, [(can_have_singletons, [(snip, count)] = the new nodes of one VBlock context)]): VBlocks that all cloned
     an empty dictionary (a batch) merging one after the other - words met again, new words, singletons, singletons met again (failed),

@@ -45,6 +45,8 @@ def main():
             d = pyoracle.GzoCtxSectionDesc(**{k: v for k, v in f.items() if k != "dict_id"})
             d.dict_id[:] = list(f["dict_id"])
             out["sections"].append({"codec": f["codec"], "n": len(data), "z": enc(CR.section(d, data))})
+    out["seg_nodes"] = [{"node_index_sha1": hashlib.sha1(np.array(R.seg_nodes(ol, sn), dtype=np.int32).tobytes()).hexdigest(), "n": len(sn)}
+                        for ol, sn in cases.seg_node_cases()]       # a1: hash_get_entry_for_seg
     out["merge_hash"] = []                  # a4's hash and singleton tables: the reference's own hash.c
     for name, est, vbs in cases.merge_hash_cases():
         m = R.merge_hash(est, vbs)

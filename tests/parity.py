@@ -932,6 +932,12 @@ def ctx_golden(E, oracle):
             for key in ("qual", "runs", "mplx", "divr"):
                 cases.check_enc(r[key], c[key], ("domq", name, key))
             assert base64.b64encode(r["denorm"]).decode() == c["denorm_snip"] and (r["num_norm_qs"] | 0x80) == c["param"] and r["fit"] == c["fit"], ("domq", name)
+    import hashlib
+    for c, (ol, sn) in zip(G["seg_nodes"], cases.seg_node_cases()):      # a1: the reference's own hash_get_entry_for_seg
+        t, o, l = _snip_column(sn)
+        for who in [oracle] + ([E] if E is not None else []):
+            ni = who.ctx_seg_column(t, o, l, ol)["node_index"]
+            assert hashlib.sha1(np.asarray(ni, dtype=np.int32).tobytes()).hexdigest() == c["node_index_sha1"], ("seg_nodes", len(ol), len(sn))
     for c, (name, est, vbs) in zip(G["merge_hash"], cases.merge_hash_cases()):     # a4: the reference's own hash.c under the merge loop
         for Z in [pyoracle.OracleZctx(oracle, est)] + ([E.zctx(est)] if E is not None else []):
             for v, (can_ston, nodes) in enumerate(vbs):
