@@ -592,6 +592,16 @@ class CtxRef:
         assert self.L.ctxref_seg_nodes(len(ol_words), ol, oll.ctypes.data, len(snips), sn, snl.ctypes.data, out.ctypes.data) == 0
         return [int(x) for x in out[:len(snips)]]
 
+    def str_get_int(self, snips):
+        """the reference's own str_get_int -> ([is_int], [value])"""
+        import numpy as np
+        sn = b"".join(bytes(w) + b"\0" for w in snips) + b"\0"
+        snl = np.array([len(w) for w in snips], dtype=np.uint32)
+        f = np.zeros(max(1, len(snips)), dtype=np.uint8); v = np.zeros(max(1, len(snips)), dtype=np.int64)
+        self.L.ctxref_str_get_int.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self.L.ctxref_str_get_int(len(snips), sn, snl.ctypes.data, f.ctypes.data, v.ctypes.data)
+        return [int(x) for x in f[:len(snips)]], [int(x) for x in v[:len(snips)]]
+
     def acgt(self, seq):
         """the reference's own codec_acgt_compress on a contiguous NONREF.local (sub-codec = store)
         -> (packed as handed to the sub-codec, NONREF_X.local, has_x, sub_codec)"""

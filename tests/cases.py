@@ -128,6 +128,14 @@ def acgt_cases():
     return out
 
 
+def int_snip_cases():
+    """snips of a numeric column: what str_get_int takes for an integer and what it leaves as text"""
+    r = synth.u32(55, 600).astype(np.int64)
+    fixed = [b"0", b"1", b"-1", b"-", b"-0", b"00", b"030", b"-030", b"+5", b"5 ", b" 5", b"12a", b"9223372036854775807", b"9223372036854775808", b"-9223372036854775808",
+             b"-9223372036854775807", b"99999999999999999999", b"18446744073709551616", b"1e5", b"0x10", b".", b"1.0", b"2147483648", b"-2147483649", b"4294967295", b"4294967296", b"65535", b"65536", b"255", b"256", b"-128", b"-129"]
+    return fixed + [b"%d" % (r[i] * (1 if i % 3 else -1) * (10 ** (i % 9))) for i in range(300)] + [b"1%02d" % (r[i] % 100) for i in range(50)]
+
+
 def seg_node_cases():
     """(cloned words, snips of the column): none cloned / thousands cloned, all new / all known / mixed, long repeats, similar strings"""
     r = synth.u32(901, 40000).astype(np.int64)

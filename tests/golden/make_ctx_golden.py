@@ -47,6 +47,8 @@ def main():
             out["sections"].append({"codec": f["codec"], "n": len(data), "z": enc(CR.section(d, data))})
     out["seg_nodes"] = [{"node_index_sha1": hashlib.sha1(np.array(R.seg_nodes(ol, sn), dtype=np.int32).tobytes()).hexdigest(), "n": len(sn)}
                         for ol, sn in cases.seg_node_cases()]       # a1: hash_get_entry_for_seg
+    f, v = R.str_get_int(cases.int_snip_cases())                 # a3: str_get_int
+    out["str_get_int"] = {"is_int": "".join(str(x) for x in f), "values_sha1": hashlib.sha1(np.array([y for x, y in zip(f, v) if x], dtype=np.int64).tobytes()).hexdigest()}
     out["merge_hash"] = []                  # a4's hash and singleton tables: the reference's own hash.c
     for name, est, vbs in cases.merge_hash_cases():
         m = R.merge_hash(est, vbs)

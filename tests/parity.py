@@ -933,6 +933,13 @@ def ctx_golden(E, oracle):
                 cases.check_enc(r[key], c[key], ("domq", name, key))
             assert base64.b64encode(r["denorm"]).decode() == c["denorm_snip"] and (r["num_norm_qs"] | 0x80) == c["param"] and r["fit"] == c["fit"], ("domq", name)
     import hashlib
+    sn = cases.int_snip_cases()                                          # a3: the reference's own str_get_int under seg_integer_or_not
+    t, o, l = _snip_column(sn)
+    for who in [oracle] + ([E] if E is not None else []):
+        so, sl, vals, isn = who.seg_integer_or_not(bytes(t) + b"\x01", o, l, 0, len(t))
+        is_int = "".join("1" if (int(a) == len(t) and int(b) == 1) else "0" for a, b in zip(so, sl))
+        assert is_int == G["str_get_int"]["is_int"], ("str_get_int", [s for s, x, y in zip(sn, is_int, G["str_get_int"]["is_int"]) if x != y][:5])
+        assert hashlib.sha1(np.asarray(vals, dtype=np.int64).tobytes()).hexdigest() == G["str_get_int"]["values_sha1"]
     for c, (ol, sn) in zip(G["seg_nodes"], cases.seg_node_cases()):      # a1: the reference's own hash_get_entry_for_seg
         t, o, l = _snip_column(sn)
         for who in [oracle] + ([E] if E is not None else []):
