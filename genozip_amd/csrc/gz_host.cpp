@@ -1087,7 +1087,7 @@ extern "C" int gz_domq_fit (GzHandle *h, const GzDomqFitJob *jobs, int n_jobs)
     void *dj;
     int rc;
     if ((rc = upload (h, J.data (), J.size () * sizeof (GzdDomqFit), &dj)) != GZ_OK) return rc;
-    KLAUNCH (h, k_domq_fit, dim3 (((uint32_t)n_jobs + 63) / 64), dim3 (64), 0, (const GzdDomqFit *)dj, (uint32_t)n_jobs);
+    KLAUNCH (h, k_domq_fit, dim3 ((uint32_t)n_jobs), dim3 (64), 512, (const GzdDomqFit *)dj, (uint32_t)n_jobs);
     HIPCHK (h, hipGetLastError ());
     return GZ_OK;
 }

@@ -330,24 +330,29 @@ __global__ void __launch_bounds__(256) k_domq_write (const GzdDomq *jobs)
 }
 
 // codec_domq_qual_data_is_a_fit_for_domq (:69-134): the first (up to) 10 lines, 2500 / lines bytes of each: more than half of
-// them must have a score that fills more than half of the sample. One thread per VBlock (the sample is 2.5 KB).
+// them must have a score that fills more than half of the sample. A wave per VBlock (it sits in front of the long streams' launch):
+// 64 bytes of a line a step into an LDS histogram, then "is any count past half" over the 95 scores.
+// grid (VBlocks), 64 threads, 512 bytes of LDS
 struct GzdDomqFit { const uint8_t *text; const uint32_t *off, *len; uint32_t n; uint32_t *fit; };
-__global__ void k_domq_fit (const GzdDomqFit *jobs, uint32_t n_jobs)
+__global__ void __launch_bounds__(64) k_domq_fit (const GzdDomqFit *jobs, uint32_t n_jobs)
 {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_jobs) return;
-    const GzdDomqFit &J = jobs[j];
+    if (blockIdx.x >= n_jobs) return;
+    const GzdDomqFit &J = jobs[blockIdx.x];
+    const int lane = threadIdx.x;
+    uint32_t *h = (uint32_t *)gz_lds;                                           // [95] (+ room)
     uint32_t sampled = J.n < 10 ? J.n : 10, tested = 0, with_dom = 0;
     const uint32_t per_line = sampled ? 2500 / sampled : 2500;
     for (uint32_t i = 0; i < sampled; i++) {
         const uint32_t l = J.len[i] < per_line ? J.len[i] : per_line;
-        if (!l) { if (sampled < J.n) { sampled++; continue; } else break; }
-        uint16_t h[GZ_DQ_N];
-        for (int q = 0; q < GZ_DQ_N; q++) h[q] = 0;
+        if (!l) { if (sampled < J.n) { sampled++; continue; } else break; }     // (an empty line is not sampled: the next one is, :84-86)
+        h[lane] = 0; h[lane + 64] = 0;
+        gz_wave_sync ();
         const uint8_t *s = J.text + J.off[i];
-        bool dom = false;
-        for (uint32_t k = 0; k < l; k++) { const uint32_t c = s[k] - GZ_DQ_FIRST; if (c < GZ_DQ_N && ++h[c] * 2u > l) dom = true; }   // (a count only grows: once past half, it stays past half)
-        with_dom += dom; tested++;
+        for (uint32_t k = lane; k < l; k += 64) { const uint32_t c = (uint32_t)s[k] - GZ_DQ_FIRST; if (c < GZ_DQ_N) atomicAdd (&h[c], 1u); }
+        gz_wave_sync ();
+        const bool mine = h[lane] * 2u > l || (lane + 64 < GZ_DQ_N && h[lane + 64] * 2u > l);
+        with_dom += __ballot (mine) != 0; tested++;
+        gz_wave_sync ();
     }
-    *J.fit = tested && 100.0 * (double)with_dom / (double)tested > 50.0;
+    if (!lane) *J.fit = tested && 100.0 * (double)with_dom / (double)tested > 50.0;
 }

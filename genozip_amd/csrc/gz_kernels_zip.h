@@ -37,27 +37,36 @@ struct GzdTokensN {
     uint32_t *item_off, *item_len; uint32_t *n_bad;
 };
 
-// grid (tiles of 256 snips): item i ends at the counts[i]-th seps[i] after item i-1; the last item is the rest
+// grid (tiles of 256 snips), 64 bytes of LDS: item i ends at the counts[i]-th seps[i] after item i-1; the last item is the rest.
+// A thread per snip, 16 bytes a load (a line 1 is ~60 bytes: 4 requests instead of 60 - with half a million snips in flight their
+// lines do not stay in L2, so every request goes out to the fabric); the text has 16 bytes of slack behind it.
 __global__ void __launch_bounds__(256) k_tokenize_n (GzdTokensN T)
 {
+    uint8_t *sh = gz_lds;                                                        // [0..32) separators, [32..64) counts
+    if (threadIdx.x <= GZ_TOK_MAX_SEPS) { sh[threadIdx.x] = T.seps[threadIdx.x]; sh[32 + threadIdx.x] = T.counts[threadIdx.x]; }
+    __syncthreads ();
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= T.n) return;
-    const uint32_t len = T.len[k], off = T.off[k];
+    const uint32_t len = T.len[k], off = T.off[k], n_seps = T.n_seps;
     const uint8_t *s = T.text + off;
-    uint32_t at = 0, i = 0;
-    for (; i < T.n_seps; i++) {
-        uint32_t e = at, left = T.counts[i];
-        const uint8_t sep = T.seps[i];
-        for (; e < len; e++) if (s[e] == sep && !--left) break;
-        if (e == len) break;
-        T.item_off[(uint64_t)i * T.n + k] = off + at; T.item_len[(uint64_t)i * T.n + k] = e - at;
-        at = e + 1;
+    uint32_t at = 0, i = 0, left = n_seps ? sh[32] : 0, sep = n_seps ? sh[0] : 0x100;
+    for (uint32_t base = 0; base < len && i < n_seps; base += 16) {
+        const gz_u32x4_unaligned v = *(const gz_u32x4_unaligned *)(s + base);
+        #pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t c = (v[j >> 2] >> ((j & 3) * 8)) & 0xff, e = base + j;
+            if (e < len && c == sep && !--left) {
+                T.item_off[(uint64_t)i * T.n + k] = off + at; T.item_len[(uint64_t)i * T.n + k] = e - at;
+                at = e + 1; i++;
+                if (i < n_seps) { sep = sh[i]; left = sh[32 + i]; } else sep = 0x100;
+            }
+        }
     }
-    if (i < T.n_seps) {
+    if (i < n_seps) {
         atomicAdd (T.n_bad, 1u);
-        for (uint32_t j = 0; j <= T.n_seps; j++) { T.item_off[(uint64_t)j * T.n + k] = off; T.item_len[(uint64_t)j * T.n + k] = j ? 0 : len; }
+        for (uint32_t j = 0; j <= n_seps; j++) { T.item_off[(uint64_t)j * T.n + k] = off; T.item_len[(uint64_t)j * T.n + k] = j ? 0 : len; }
     }
-    else { T.item_off[(uint64_t)T.n_seps * T.n + k] = off + at; T.item_len[(uint64_t)T.n_seps * T.n + k] = len - at; }
+    else { T.item_off[(uint64_t)n_seps * T.n + k] = off + at; T.item_len[(uint64_t)n_seps * T.n + k] = len - at; }
 }
 
 // ---- integer columns -------------------------------------------------------------------------------------------------

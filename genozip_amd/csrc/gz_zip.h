@@ -247,7 +247,7 @@ extern "C" int gz_tokenize_column_n (GzHandle *h, const uint8_t *text, const uin
     T.text = text; T.off = off; T.len = len; T.n = n; T.n_seps = n_seps; T.item_off = item_off; T.item_len = item_len; T.n_bad = n_bad_dev;
     for (uint32_t i = 0; i < n_seps; i++) { T.seps[i] = (uint8_t)seps[i]; T.counts[i] = counts && counts[i] ? counts[i] : 1; }
     HIPCHK (h, hipMemsetAsync (n_bad_dev, 0, 4, h->stream));
-    if (n) KLAUNCH (h, k_tokenize_n, dim3 ((n + 255) / 256), dim3 (256), 0, T);
+    if (n) KLAUNCH (h, k_tokenize_n, dim3 ((n + 255) / 256), dim3 (256), 64, T);
     HIPCHK (h, hipGetLastError ());
     return GZ_OK;
 }

@@ -482,6 +482,7 @@ typedef struct { uint16_t did_i; uint8_t local_dep, has_local, ston_only_local, 
 uint32_t gz_section_order (const GzSecOrderIn *ctxs, uint32_t n, uint32_t vblock_i, uint32_t *order_out);
 
 /* batched / asynchronous forms used by the driver (all pointers device unless noted) */
+/* (gz_tokenize_column_n reads the snips 16 bytes at a time: 15 readable bytes are needed behind the last snip of the text) */
 int gz_tokenize_column_n (GzHandle *h, const uint8_t *text, const uint32_t *off, const uint32_t *len, uint32_t n,
                           const char *seps, const uint8_t *sep_counts, uint32_t n_seps, uint32_t *item_off, uint32_t *item_len, uint32_t *n_bad_dev);
 typedef struct {

@@ -224,3 +224,86 @@ def test_domq(gpu_engine, oracle):
     """N3: CODEC_DOMQ's pre-transform at VBlock size (46 000 lines) == the oracle, whose restatement is pinned to the reference's
     own codec_domq.c by tests/golden/ctx_golden.json (checked for the product in test_ctx_golden_vectors)"""
     parity.domq(gpu_engine, oracle, 46000)
+
+
+def _bench_workload(gpu_engine, **kw):
+    import argparse
+    import torch
+    import bench
+    a = argparse.Namespace(pairs=1000000, vb_mb=16, qual="div", scaling="weak", stream_reads=0, batch_pairs=64, pin_codecs=False)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return bench, bench.Workload(gpu_engine, a, 0, 1, torch.device("cuda", 0))
+
+
+def _check_vblocks(gpu_engine, oracle, bench, wl, z_all, decode_vbs):
+    """size-independent properties of finished VBlocks: the VB header names its own length, every section's adler32 holds (checked
+    by gz_vb_uncompress on the device), sections come in ascending (DEP level, did_i) order with the b250s last, and the QUAL
+    section decodes to the text's quality lines"""
+    import numpy as np
+    RB, L = wl.W.RECORD_BYTES, wl.W.READ_LEN
+    qual_id = next(c["dict_id"] for c in wl.plan["ctxs"] if c["tag"] == "QUAL")
+    text = wl.text[:wl.text_len]
+    for v, ((off, ln, vi, r1), z) in enumerate(zip(wl.vb, z_all)):
+        assert int.from_bytes(z[40:44], "big") == len(z) and int.from_bytes(z[20:24], "big") == vi
+        secs = bench.walk_sections(z)
+        kinds = [s[0] for s in secs]
+        assert kinds == sorted(kinds, reverse=True), "locals (12) before b250s (11)"
+        if v in decode_vbs:
+            total = sum(s[3] for s in secs)
+            dec = gpu_engine.vb_uncompress(z, total)
+            assert len(dec) == len(secs)
+            q = next(d for d, s in zip(dec, secs) if s[2] == qual_id and s[0] == 12)
+            want = text[off:off + ln].cpu().numpy().reshape(-1, RB)[:, RB - L - 1:RB - 1]
+            assert q == want.tobytes(), "QUAL of VBlock %d" % vi
+
+
+def test_full_size_fastq_file(gpu_engine, oracle):
+    """BASELINE configs[1] at full size (2 x 1 M reads, 16 MiB VBlocks) through the driver, as bench.py runs it: properties that do not
+    need the oracle at this size - framing, order, adler32 and QUAL round trip of the first / a middle / the last VBlock, the same
+    bytes when the file is compressed again, every read accounted for - plus the oracle's own coder on one QUAL section"""
+    bench, wl = _bench_workload(gpu_engine)
+    total = wl.step(None)
+    z1 = wl.zbuf[:total].cpu().numpy().tobytes()
+    offs = list(wl.offs)
+    z_all = [z1[offs[i]:offs[i + 1]] for i in range(len(wl.vb))]
+    assert sum(t.n_reads for t in wl.tab) == 2 * 1000000
+    _check_vblocks(gpu_engine, oracle, bench, wl, z_all, {0, len(z_all) // 2, len(z_all) - 1})
+    total2 = wl.step(None)                                   # a new file with the same text: the same bytes
+    assert total2 == total and wl.zbuf[:total].cpu().numpy().tobytes() == z1
+    # one QUAL payload against the CPU restatement of the coder (6.9 MB: a few seconds)
+    st, codec, did, ulen, pay, _ = next(s for s in bench.walk_sections(z_all[3]) if s[3] > 1000000)
+    off, ln = wl.vb[3][0], wl.vb[3][1]
+    RB, L = wl.W.RECORD_BYTES, wl.W.READ_LEN
+    raw = wl.text[off:off + ln].cpu().numpy().reshape(-1, RB)[:, RB - L - 1:RB - 1].tobytes()
+    assert oracle.codec_compress(codec, raw) == bytes(pay)
+
+
+def test_streamed_file(gpu_engine, oracle):
+    """BASELINE configs[4] in small: ONE file streamed through the driver in several calls (dictionaries and codecs carried from call to
+    call, vblock_i continuing): every call's VBlocks hold the properties above; the codecs chosen in the first call are the ones
+    every later call uses; the dictionaries only grow"""
+    bench, wl = _bench_workload(gpu_engine, pairs=0, stream_reads=400000, batch_pairs=3, vb_mb=4)
+    from genozip_amd.shard import zip_vblocks_sharded
+    F, n = wl.F, len(wl.vb)
+    F.reset()
+    codecs_first, words = None, 0
+    for call in range(3):
+        if call:
+            for t in wl.tab:
+                t.vblock_i += 2 * wl.n_pairs_file
+        zip_vblocks_sharded(F, None, wl.text, wl.text_len, wl.tab, n)
+        z_all = [r["z"] for r in F.results(wl.tab)]
+        vb_now = [(o, l, int(t.vblock_i), r1) for (o, l, _, r1), t in zip(wl.vb, wl.tab)]
+        wl_view = type("V", (), dict(W=wl.W, plan=wl.plan, text=wl.text, text_len=wl.text_len, vb=vb_now))
+        _check_vblocks(gpu_engine, oracle, bench, wl_view, z_all, {0, n - 1})
+        codecs = {(s[0], s[2]): s[1] for z in z_all for s in bench.walk_sections(z) if s[3] >= 50}
+        if codecs_first is None:
+            codecs_first = codecs
+        else:
+            assert all(codecs_first.get(k, c) == c for k, c in codecs.items()), "a committed codec changed between calls"
+        w = len(F.zctx_words(3))
+        assert w >= words
+        words = w
+    for t, v in zip(wl.tab, wl.vb):
+        t.vblock_i = v[2]
