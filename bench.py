@@ -45,8 +45,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=1000000, help="read pairs of the file (BASELINE configs[1]: 1 M)")
-    ap.add_argument("--vb-mb", type=int, default=16, help="VBlock size in MiB (the reference's --vblock; its own rule gives ~14.7 MB for this file: "
-                    "src/segconf.c:186-203 with est_max_threads capped at 30 for plain text, SURVEY 8: 16 MiB)")
+    ap.add_argument("--vb-mb", type=float, default=0, help="VBlock size in MiB (the reference's --vblock). Default 0: the reference's own rule for the file "
+                    "(src/segconf.c:152-206, see vb_bytes below): 14.72 MB for a 1 M-read mate file; 16 MiB for --stream-reads")
     ap.add_argument("--qual", default="div", choices=("div", "bin"))
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
     ap.add_argument("--stream-reads", type=int, default=0, help="stream this many read pairs per rank through one file (configs[4] at reduced scale)")
@@ -67,6 +67,20 @@ def relaunch_under_torchrun(a):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def vb_bytes(a):
+    """segconf_set_vb_size (src/segconf.c:152-206) for a plain-text FASTQ mate file on a host with more than 36 threads:
+    min (what the number of used contexts gives: 1 MB each, at least 16 MB, doubled for > 36 threads,
+         max (4 MB, est_seggable_size * 1.2 / min (est_max_threads = 30 for uncompressed text, threads)))"""
+    if a.vb_mb:
+        return int(a.vb_mb * (1 << 20))
+    if a.stream_reads:
+        return 16 << 20
+    from genozip_amd import workload as W
+    file_bytes = a.pairs * W.RECORD_BYTES                       # txt_file->est_seggable_size of one mate file
+    by_contexts = 2 * max(20 << 20, 16 << 20)                   # ~20 contexts with data (the plan's), x 2: global_max_threads > 36
+    return min(by_contexts, max(4 << 20, int(file_bytes * 1.2 / 30)))
 
 
 def walk_sections(z):
@@ -93,10 +107,10 @@ class Workload:
         strong = a.scaling == "strong" and world > 1
         seed = 1 if strong else 1 + 2 * rank                     # strong: the one file; weak: a file pair of its own per rank
         n_reads = a.stream_reads or a.pairs
-        ranges = W.vb_ranges(n_reads, a.vb_mb << 20)
+        ranges = W.vb_ranges(n_reads, vb_bytes(a))
         if a.stream_reads:
             ranges = ranges[:a.batch_pairs]                       # one call's worth of text, streamed over and over with new vblock_i
-        self.n_pairs_file = len(W.vb_ranges(n_reads, a.vb_mb << 20))
+        self.n_pairs_file = len(W.vb_ranges(n_reads, vb_bytes(a)))
         mine = pairs_of_rank(len(ranges), rank, world) if strong else list(range(len(ranges)))
         self.mine, self.ranges = mine, ranges
         th = W._TH(device)
@@ -223,7 +237,7 @@ def pmc_traffic(kernel, a):
     if not os.path.exists(p):
         return None
     d = json.load(open(p))
-    if d.get("workload") != {"pairs": a.pairs, "vb_mb": a.vb_mb, "qual": a.qual}:
+    if d.get("workload") != {"pairs": a.pairs, "vb_bytes": vb_bytes(a), "qual": a.qual}:
         return None
     k = d["kernels"].get(kernel)
     return k.get("traffic_bytes_per_step") if k else None
@@ -340,11 +354,11 @@ def main():
     out = {"metric": METRIC, "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": a.scaling if world > 1 else "weak", "vs_baseline": None,
            "dtype": "u8", "data": "synthetic",
-           "config": {"workload": mode + ", VBlocks of %d MiB; the WHOLE path per step from FASTQ text in HBM: lines / reads / line-1 items -> seg columns (a1-a3) -> "
+           "config": {"workload": mode + ", VBlocks of %.2f MB (%s); the WHOLE path per step from FASTQ text in HBM: lines / reads / line-1 items -> seg columns (a1-a3) -> "
                                    "host dictionary merge in C (a4) -> b250 / local generation (a5-a7) -> codec assignment (a8) -> sections in DEP / did_i order (a15) -> "
                                    "rANS / arith + framing (a9-a13, a16); a new file every step. MB counted in `value` = text WITHOUT the SEQ lines "
-                                   "(SEQ is 2-bit packed in the step and handed to the host's LZMA, which is outside the path, SURVEY F8)" % a.vb_mb,
-                      "qual_profile": a.qual, "vb_mib": a.vb_mb, "codecs": codecs,
+                                   "(SEQ is 2-bit packed in the step and handed to the host's LZMA, which is outside the path, SURVEY F8)" % (vb_bytes(a) / 1e6, "--vb-mb" if a.vb_mb else "the reference's own rule for this file, src/segconf.c:152-206"),
+                      "qual_profile": a.qual, "vb_bytes": vb_bytes(a), "codecs": codecs,
                       "text_mb_per_step": round(text_b / 1e6, 1), "stream_mb_per_step": round(stream_b / 1e6, 1), "compressed_mb_per_step": round(z_b / 1e6, 2),
                       "parallelism": "vblocks sharded over %d GPU(s), no data-path collective; host exchange of new dictionary words (strong scaling only); RCCL gather of z_data" % world},
            "text_mb_s": round(text_b / 1e6 / (ms_per_step / 1e3), 1), "stream_mb_s": round(stream_b / 1e6 / (ms_per_step / 1e3), 1),
