@@ -283,6 +283,24 @@ class Engine:
     def profile(self, enable=True, reset=False):
         self.L.gz_profile(self.h, int(enable), int(reset))
 
+    def compress_lines(self, codec, lines, capacity=None, soft_fail=False):
+        """COMPRESS() with a get_line callback (src/codec.h:23, codec_htscodecs.c:51-64): lines = list of bytes"""
+        from .lib import GzGetLineCB
+        keep = [C.create_string_buffer(bytes(l), max(1, len(l))) for l in lines]
+        total = sum(len(l) for l in lines)
+
+        def cb(user, i, line_p, len_p):
+            line_p[0] = C.cast(keep[i], C.c_void_p).value
+            len_p[0] = len(lines[i])
+        cap = self.est_size(codec, total) if capacity is None else capacity
+        out = C.create_string_buffer(max(1, cap))
+        ol = C.c_uint32(cap)
+        rc = self.L.gz_codec_compress_lines_host(self.h, codec, GzGetLineCB(cb), None, len(lines), total, out, C.byref(ol), int(soft_fail))
+        if rc == 0 and soft_fail:                  # GZ_TOO_SMALL
+            return None
+        self._check(rc, "gz_codec_compress_lines_host")
+        return out.raw[:ol.value]
+
     def profile_results(self):
         """{kernel name: (total ms, launches)} accumulated by gz_sync() since the last reset"""
         out, i = {}, 0

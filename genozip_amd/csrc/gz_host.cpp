@@ -984,6 +984,29 @@ extern "C" int gz_codec_compress_host (GzHandle *h, int codec, const uint8_t *in
     return rc;
 }
 
+extern "C" int gz_codec_compress_lines_host (GzHandle *h, int codec, GzGetLineCB get_line, void *user, uint32_t n_lines, uint32_t in_len,
+                                             uint8_t *out, uint32_t *out_len, int soft_fail)
+{
+    if (!h || !out_len || !out || (n_lines && !get_line)) return GZ_ERR_ARG;
+    if (!codec_ok (codec)) return GZ_ERR_ARG;
+    if (*out_len < codec_min_cap (codec, in_len)) return soft_fail ? GZ_TOO_SMALL : GZ_ERR;
+    HIPCHK (h, hipSetDevice (h->device));
+    uint8_t *stage = NULL;
+    HIPCHK (h, hipHostMalloc ((void **)&stage, (size_t)in_len + 64, hipHostMallocDefault));
+    uint64_t at = 0;
+    for (uint32_t i = 0; i < n_lines; i++) {
+        const uint8_t *line = NULL; uint32_t len = 0;
+        get_line (user, i, &line, &len);
+        if (at + len > in_len || (len && !line)) { (void)hipHostFree (stage); h->err = "get_line: more bytes than uncompressed_len"; return GZ_ERR_CORRUPT; }
+        if (len) memcpy (stage + at, line, len);
+        at += len;
+    }
+    if (at != in_len) { (void)hipHostFree (stage); h->err = "get_line: total length != uncompressed_len (codec_htscodecs.c:61)"; return GZ_ERR_CORRUPT; }
+    const int rc = gz_codec_compress_host (h, codec, stage, in_len, out, out_len, soft_fail);
+    (void)hipHostFree (stage);
+    return rc;
+}
+
 extern "C" int gz_codec_uncompress_host (GzHandle *h, int codec, const uint8_t *in, uint32_t in_len,
                                          uint8_t *out, uint64_t out_len)
 {

@@ -92,6 +92,16 @@ uint32_t gz_codec_est_size (int codec, uint64_t uncompressed_len);
 int gz_codec_compress_host (GzHandle *h, int codec, const uint8_t *uncompressed, uint32_t uncompressed_len,
                             uint8_t *compressed, uint32_t *compressed_len, int soft_fail);
 
+/* The same for data the caller only has line by line - COMPRESS()'s second input option, `LocalGetLineCB get_line_cb`
+ * (src/codec.h:23, as codec_hts_compress uses it: src/codec_htscodecs.c:51-64): get_line (user, line_i, &line, &line_len) is called
+ * for line_i = 0 .. n_lines - 1 (for_line) and what it returns is concatenated - straight into pinned staging memory, from where
+ * it goes to the device in one copy - and compressed as one stream. uncompressed_len: the total the caller expects (what
+ * *uncompressed_len holds in the reference); a different total from the callbacks is GZ_ERR_CORRUPT (the reference's ASSERT :61).
+ * (With the text resident on the device the gather is gz_local_blob_columns and the data never leaves HBM.) */
+typedef void (*GzGetLineCB) (void *user, uint32_t line_i, const uint8_t **line, uint32_t *line_len);
+int gz_codec_compress_lines_host (GzHandle *h, int codec, GzGetLineCB get_line, void *user, uint32_t n_lines, uint32_t uncompressed_len,
+                                  uint8_t *compressed, uint32_t *compressed_len, int soft_fail);
+
 /* UNCOMPRESS() src/codec.h:29-38: codec_rans_uncompress / codec_arith_uncompress (src/codec_htscodecs.c:100,116),
  * codec_none_uncompress (src/codec_none.c:39). Host pointers. */
 int gz_codec_uncompress_host (GzHandle *h, int codec, const uint8_t *compressed, uint32_t compressed_len,

@@ -52,6 +52,14 @@ def host_call_surface(E, oracle):
         assert E.est_size(6, n) == oracle.est_size(6, n) and E.est_size(19, n) == oracle.est_size(19, n)
 
 
+def compress_lines(E, oracle):
+    """COMPRESS() fed line by line (the get_line_cb form) == the same bytes compressed as one buffer"""
+    ls = [synth.quality_binned(77 + i, 1, 150 - (i % 4))[0].tobytes() for i in range(200)] + [b"", b"x"]
+    for codec in (1, 6, 9, 16, 18):
+        assert E.compress_lines(codec, ls) == oracle.codec_compress(codec, b"".join(ls)), codec
+    assert E.compress_lines(16, []) == oracle.codec_compress(16, b"")
+
+
 def golden(E, max_n, stride=1):
     """the committed reference vectors (tests/golden/hts_golden.json) through the device path (stride: every n-th one only - the
     emulated build is slow; the oracle test and the GPU run take them all)"""

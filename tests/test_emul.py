@@ -10,6 +10,7 @@ def test_emul_codec_edge_cases(emul_engine, oracle):
 
 def test_emul_host_call_surface(emul_engine, oracle):
     parity.host_call_surface(emul_engine, oracle)
+    parity.compress_lines(emul_engine, oracle)
 
 
 def test_emul_golden_small(emul_engine):

@@ -26,6 +26,7 @@ def test_codec_edge_cases(gpu_engine, oracle):
 
 def test_host_call_surface(gpu_engine, oracle):
     parity.host_call_surface(gpu_engine, oracle)
+    parity.compress_lines(gpu_engine, oracle)
 
 
 def test_golden_vectors_all(gpu_engine):
