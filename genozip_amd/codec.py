@@ -634,6 +634,40 @@ class Engine:
             return tbuf, ob, lb, rb, n_lines
         return (np.frombuffer(self.mem.download(ob, 4 * n_lines), dtype=np.uint32), np.frombuffer(self.mem.download(lb, 4 * n_lines), dtype=np.uint32))
 
+    def vcf_sample_columns(self, text, line_off, line_len, n_samples, n_sub):
+        """the FORMAT subfields of every sample of the given data lines -> (n_bad, item_off [n_sub][lines * samples], item_len, missing)"""
+        import numpy as np
+        text = bytes(text)
+        tbuf = self.mem.upload(text + b"\0" * 16)
+        cap = text.count(b"\t") + 1
+        ab, rb = self.mem.alloc(4 * (cap + 2) + 16), self.mem.alloc(16)
+        self._check(self.L.gz_byte_index(self.h, self.mem.ptr(tbuf), len(text), 9, self.mem.ptr(ab), cap, self.mem.ptr(rb)), "gz_byte_index")
+        lo = np.ascontiguousarray(line_off, dtype=np.uint32); ll = np.ascontiguousarray(line_len, dtype=np.uint32)
+        n = len(lo)
+        lob, llb = self.mem.upload(lo), self.mem.upload(ll)
+        tot = max(1, n * n_samples * n_sub)
+        io, il, mi, nb = self.mem.alloc(4 * tot + 16), self.mem.alloc(4 * tot + 16), self.mem.alloc(tot + 16), self.mem.alloc(16)
+        self._check(self.L.gz_vcf_sample_columns(self.h, self.mem.ptr(tbuf), self.mem.ptr(lob), self.mem.ptr(llb), n, self.mem.ptr(ab), self.mem.ptr(rb), n_samples, n_sub,
+                                                 self.mem.ptr(io), self.mem.ptr(il), self.mem.ptr(mi), self.mem.ptr(nb)), "gz_vcf_sample_columns")
+        self.sync()
+        k = n * n_samples
+        return (int(np.frombuffer(self.mem.download(nb, 4), dtype=np.uint32)[0]),
+                np.frombuffer(self.mem.download(io, 4 * k * n_sub), dtype=np.uint32).reshape(n_sub, k),
+                np.frombuffer(self.mem.download(il, 4 * k * n_sub), dtype=np.uint32).reshape(n_sub, k),
+                np.frombuffer(self.mem.download(mi, k * n_sub), dtype=np.uint8).reshape(n_sub, k))
+
+    def byte_index(self, text, byte):
+        """-> positions behind every occurrence of `byte` (numpy)"""
+        import numpy as np
+        text = bytes(text)
+        tbuf = self.mem.upload(text + b"\0" * 16)
+        cap = text.count(bytes([byte])) + 1
+        ab, rb = self.mem.alloc(4 * (cap + 2) + 16), self.mem.alloc(16)
+        self._check(self.L.gz_byte_index(self.h, self.mem.ptr(tbuf), len(text), byte, self.mem.ptr(ab), cap, self.mem.ptr(rb)), "gz_byte_index")
+        self.sync()
+        n = int(np.frombuffer(self.mem.download(rb, 8), dtype=np.uint64)[0])
+        return np.frombuffer(self.mem.download(ab, 4 * (n + 1)), dtype=np.uint32)[1:].copy()
+
     def fastq_records(self, text):
         """-> (first_bad or None, [(off, len)] for line 1, SEQ, line 3, QUAL) from the text of whole reads"""
         import numpy as np

@@ -1488,7 +1488,7 @@ extern "C" int gz_text_lines (GzHandle *h, const uint8_t *text, uint64_t n_bytes
     if (!h || !result_dev || (n_bytes && !text) || (cap && (!line_off || !line_len)) || n_bytes >= 0xffffffffull) return GZ_ERR_ARG;
     HIPCHK (h, hipSetDevice (h->device));
     GzdLines L;
-    L.text = text; L.n = n_bytes; L.off = line_off; L.len = line_len; L.cap = cap; L.result = result_dev;
+    L.text = text; L.n = n_bytes; L.off = line_off; L.len = line_len; L.cap = cap; L.result = result_dev; L.byte4 = 0x0a0a0a0au; L.raw = 0;
     const uint32_t tiles = (uint32_t)((n_bytes + GZ_NL_TILE - 1) / GZ_NL_TILE);
     if (!(L.start = (uint32_t *)arena_alloc (h, ((size_t)cap + 2) * 4))) return GZ_ERR_HIP;
     if (!(L.tile = (uint64_t *)arena_alloc (h, ((size_t)tiles + 1) * 8))) return GZ_ERR_HIP;
@@ -1496,6 +1496,22 @@ extern "C" int gz_text_lines (GzHandle *h, const uint8_t *text, uint64_t n_bytes
     KLAUNCH (h, k_nl_scan, dim3 (1), dim3 (256), 2048, L);
     if (tiles) KLAUNCH (h, k_nl_write, dim3 (tiles), dim3 (256), 2048, L);
     if (cap) KLAUNCH (h, k_lines_finish, dim3 ((cap + 255) / 256), dim3 (256), 0, L);
+    HIPCHK (h, hipGetLastError ());
+    return GZ_OK;
+}
+
+// positions of one separator byte (N1 for tab-separated data types): the newline machinery with another byte and no line rules
+extern "C" int gz_byte_index (GzHandle *h, const uint8_t *text, uint64_t n_bytes, uint8_t byte, uint32_t *after, uint32_t cap, GzLinesResult *result_dev)
+{
+    if (!h || !result_dev || !after || (n_bytes && !text) || n_bytes >= 0xffffffffull) return GZ_ERR_ARG;
+    HIPCHK (h, hipSetDevice (h->device));
+    GzdLines L; memset (&L, 0, sizeof (L));
+    L.text = text; L.n = n_bytes; L.cap = cap; L.result = result_dev; L.byte4 = 0x01010101u * byte; L.raw = 1; L.start = after;
+    const uint32_t tiles = (uint32_t)((n_bytes + GZ_NL_TILE - 1) / GZ_NL_TILE);
+    if (!(L.tile = (uint64_t *)arena_alloc (h, ((size_t)tiles + 1) * 8))) return GZ_ERR_HIP;
+    if (tiles) KLAUNCH (h, k_nl_count, dim3 (tiles), dim3 (256), 2048, L);
+    KLAUNCH (h, k_nl_scan, dim3 (1), dim3 (256), 2048, L);
+    if (tiles) KLAUNCH (h, k_nl_write, dim3 (tiles), dim3 (256), 2048, L);
     HIPCHK (h, hipGetLastError ());
     return GZ_OK;
 }

@@ -532,10 +532,12 @@ struct GzdLines {
     GzLinesResult *result;
     uint32_t *start;          // scratch [cap + 2]: start[j] = offset of line j
     uint64_t *tile;           // scratch [tiles]
+    uint32_t byte4;           // the byte looked for, in every byte of the word ('\n': 0x0a0a0a0a)
+    uint32_t raw;             // gz_byte_index: just the positions after every occurrence (no "last line without a newline")
 };
 
 // bit i set: byte i of the thread's 64 bytes is a newline (bytes beyond n: never)
-__device__ static inline uint64_t d_newline_mask (const uint8_t *text, uint64_t n, uint64_t at)
+__device__ static inline uint64_t d_newline_mask (const uint8_t *text, uint64_t n, uint64_t at, uint32_t byte4 = 0x0a0a0a0au)
 {
     uint64_t mask = 0;
     if (at + GZ_NL_PER_THREAD <= n) {
@@ -544,7 +546,7 @@ __device__ static inline uint64_t d_newline_mask (const uint8_t *text, uint64_t 
             const gz_u32x4_unaligned v = *(const gz_u32x4_unaligned *)(text + at + 16 * q);
             #pragma unroll
             for (int w = 0; w < 4; w++) {
-                const uint32_t t = v[w] ^ 0x0a0a0a0au;
+                const uint32_t t = v[w] ^ byte4;
                 const uint32_t z = ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t | 0x7f7f7f7fu);     // 0x80 in every byte that was '\n'
                 const uint32_t bits = ((z >> 7) & 1) | ((z >> 14) & 2) | ((z >> 21) & 4) | ((z >> 28) & 8);
                 mask |= (uint64_t)bits << (16 * q + 4 * w);
@@ -552,7 +554,7 @@ __device__ static inline uint64_t d_newline_mask (const uint8_t *text, uint64_t 
         }
     }
     else
-        for (uint32_t i = 0; at + i < n && i < GZ_NL_PER_THREAD; i++) if (text[at + i] == '\n') mask |= 1ull << i;
+        for (uint32_t i = 0; at + i < n && i < GZ_NL_PER_THREAD; i++) if (text[at + i] == (byte4 & 0xff)) mask |= 1ull << i;
     return mask;
 }
 
@@ -560,7 +562,7 @@ __device__ static inline uint64_t d_newline_mask (const uint8_t *text, uint64_t 
 __global__ void __launch_bounds__(256) k_nl_count (GzdLines L)
 {
     const uint64_t at = (uint64_t)blockIdx.x * GZ_NL_TILE + (uint64_t)threadIdx.x * GZ_NL_PER_THREAD;
-    const uint64_t mask = at < L.n ? d_newline_mask (L.text, L.n, at) : 0;
+    const uint64_t mask = at < L.n ? d_newline_mask (L.text, L.n, at, L.byte4) : 0;
     uint64_t total;
     (void)d_wg_scan_u64 ((uint64_t)__popcll (mask), threadIdx.x, &total);
     if (!threadIdx.x) L.tile[blockIdx.x] = total;
@@ -572,7 +574,7 @@ __global__ void __launch_bounds__(256) k_nl_scan (GzdLines L)
     const uint32_t n_tiles = (uint32_t)((L.n + GZ_NL_TILE - 1) / GZ_NL_TILE);
     const uint64_t newlines = d_wg_scan_array (L.tile, n_tiles, threadIdx.x);
     if (threadIdx.x) return;
-    const uint64_t lines = newlines + ((L.n && L.text[L.n - 1] != '\n') ? 1 : 0);   // a last line without newline counts (seg.c:227-230)
+    const uint64_t lines = newlines + ((!L.raw && L.n && L.text[L.n - 1] != '\n') ? 1 : 0);   // a last line without newline counts (seg.c:227-230)
     L.result->n_lines = lines;
     L.result->status = lines <= L.cap ? GZ_ST_OK : GZ_ST_TOO_SMALL;
     L.start[0] = 0;
@@ -582,7 +584,7 @@ __global__ void __launch_bounds__(256) k_nl_scan (GzdLines L)
 __global__ void __launch_bounds__(256) k_nl_write (GzdLines L)
 {
     const uint64_t at = (uint64_t)blockIdx.x * GZ_NL_TILE + (uint64_t)threadIdx.x * GZ_NL_PER_THREAD;
-    uint64_t mask = at < L.n ? d_newline_mask (L.text, L.n, at) : 0;
+    uint64_t mask = at < L.n ? d_newline_mask (L.text, L.n, at, L.byte4) : 0;
     uint64_t total;
     uint64_t j = L.tile[blockIdx.x] + d_wg_scan_u64 ((uint64_t)__popcll (mask), threadIdx.x, &total);
     for (; mask; mask &= mask - 1, j++)

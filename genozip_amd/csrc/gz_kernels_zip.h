@@ -288,3 +288,54 @@ __global__ void __launch_bounds__(256) k_vb_stats (const uint32_t *line_off, con
     }
     if (!threadIdx.x) { out[2 * v] = sh[0]; out[2 * v + 1] = sh[256]; }
 }
+
+// ---- N1 for VCF: the FORMAT subfields of every sample of every data line as columns (vcf_seg_samples, src/vcf_samples.c:1601) -----
+// A data line is CHROM POS ID REF ALT QUAL FILTER INFO FORMAT sample ... sample, tab separated; a sample is its subfields in FORMAT's
+// order, ':' separated, trailing ones may be left out. With the positions of all tabs of the text known (gz_byte_index), sample s of
+// a line starts behind the line's (9 + s)-th tab: k_vcf_line_tabs finds every line's first tab (binary search) and checks the tab
+// count; k_vcf_samples, a thread per (line, sample), cuts the sample at its colons. Items are subfield-major:
+// [j][line * n_samples + s] - columns for gz_ctx_seg_columns / gz_int_columns, matrices of lines x samples for the transposes.
+struct GzdVcf {
+    const uint8_t *text; const uint32_t *line_off, *line_len; uint32_t n_lines;
+    const uint32_t *tab_after; const GzLinesResult *tabs;    // tab_after[k + 1] = position behind the k-th tab of the text
+    uint32_t n_samples, n_sub;
+    uint32_t *item_off, *item_len; uint8_t *missing;         // [n_sub][n_lines * n_samples]; missing may be NULL
+    uint32_t *first_tab;                                     // scratch [n_lines]
+    uint32_t *n_bad;                                         // lines whose tab count is not 8 + n_samples; samples with more than n_sub subfields
+};
+
+__global__ void __launch_bounds__(256) k_vcf_line_tabs (GzdVcf V)
+{
+    const uint32_t l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= V.n_lines) return;
+    const uint64_t n_tabs = V.tabs->n_lines;
+    const uint32_t off = V.line_off[l], end = off + V.line_len[l];
+    uint64_t lo = 0, hi = n_tabs;                            // first tab at or behind the start of the line
+    while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (V.tab_after[mid + 1] - 1 < off) lo = mid + 1; else hi = mid; }
+    V.first_tab[l] = (uint32_t)lo;
+    const uint64_t want = 8ull + V.n_samples, last = lo + want - 1;           // the line's last tab / the first one that must not be its
+    const bool ok = V.n_samples && last < n_tabs && V.tab_after[last + 1] - 1 < end && (last + 1 >= n_tabs || V.tab_after[last + 2] - 1 >= end);
+    if (!ok) atomicAdd (V.n_bad, 1u);
+}
+
+__global__ void __launch_bounds__(256) k_vcf_samples (GzdVcf V)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x, total = (uint64_t)V.n_lines * V.n_samples;
+    if (k >= total) return;
+    const uint32_t l = (uint32_t)(k / V.n_samples), s = (uint32_t)(k % V.n_samples);
+    const uint64_t t = (uint64_t)V.first_tab[l] + 8 + s, n_tabs = V.tabs->n_lines;
+    const uint32_t line_end = V.line_off[l] + V.line_len[l];
+    uint32_t a = t < n_tabs ? V.tab_after[t + 1] : line_end;
+    uint32_t e = (s + 1 < V.n_samples && t + 1 < n_tabs) ? V.tab_after[t + 2] - 1 : line_end;
+    if (a > line_end) a = line_end;
+    if (e > line_end) e = line_end;
+    if (e < a) e = a;
+    uint32_t j = 0, at = a;
+    for (uint32_t i = a; i <= e; i++) {
+        if (i < e && V.text[i] != ':') continue;
+        if (j < V.n_sub) { V.item_off[(uint64_t)j * total + k] = at; V.item_len[(uint64_t)j * total + k] = i - at; if (V.missing) V.missing[(uint64_t)j * total + k] = 0; }
+        else if (j == V.n_sub) atomicAdd (V.n_bad, 1u);
+        j++; at = i + 1;
+    }
+    for (; j < V.n_sub; j++) { V.item_off[(uint64_t)j * total + k] = 0; V.item_len[(uint64_t)j * total + k] = 0; if (V.missing) V.missing[(uint64_t)j * total + k] = 1; }
+}

@@ -1255,3 +1255,25 @@ extern "C" int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_
     if ((rc = gz_fastq_zip_merge (f, &blob, &blob_len, 1, &votes, &votes_len)) != GZ_OK) return rc;
     return gz_fastq_zip_finish (f, &votes, &votes_len, 1);
 }
+
+// ---- N1 for VCF ----------------------------------------------------------------------------------------------------------------
+extern "C" int gz_vcf_sample_columns (GzHandle *h, const uint8_t *text, const uint32_t *line_off, const uint32_t *line_len, uint32_t n_lines,
+                                      const uint32_t *tab_after, const GzLinesResult *tabs_dev, uint32_t n_samples, uint32_t n_subfields,
+                                      uint32_t *item_off, uint32_t *item_len, uint8_t *missing, uint32_t *n_bad_dev)
+{
+    if (!h || !n_bad_dev || !tabs_dev || !tab_after || (n_lines && (!text || !line_off || !line_len)) || !n_samples || !n_subfields
+        || (uint64_t)n_lines * n_samples > 0xfffffff0ull || (n_lines && (!item_off || !item_len))) return GZ_ERR_ARG;
+    HIPCHK (h, hipSetDevice (h->device));
+    GzdVcf V; memset (&V, 0, sizeof (V));
+    V.text = text; V.line_off = line_off; V.line_len = line_len; V.n_lines = n_lines; V.tab_after = tab_after; V.tabs = tabs_dev;
+    V.n_samples = n_samples; V.n_sub = n_subfields; V.item_off = item_off; V.item_len = item_len; V.missing = missing; V.n_bad = n_bad_dev;
+    if (!(V.first_tab = (uint32_t *)arena_alloc (h, ((size_t)n_lines + 1) * 4))) return GZ_ERR_HIP;
+    HIPCHK (h, hipMemsetAsync (n_bad_dev, 0, 4, h->stream));
+    if (n_lines) {
+        KLAUNCH (h, k_vcf_line_tabs, dim3 ((n_lines + 255) / 256), dim3 (256), 0, V);
+        const uint64_t total = (uint64_t)n_lines * n_samples;
+        KLAUNCH (h, k_vcf_samples, dim3 ((uint32_t)((total + 255) / 256)), dim3 (256), 0, V);
+    }
+    HIPCHK (h, hipGetLastError ());
+    return GZ_OK;
+}

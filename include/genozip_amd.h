@@ -501,6 +501,18 @@ typedef struct {
     uint32_t *snip_off, *snip_len; int64_t *values; uint8_t *is_nothing; uint64_t *n_values_dev; int32_t *status_dev;
 } GzIntColJob;
 int gz_int_columns (GzHandle *h, const GzIntColJob *jobs, int n_jobs);
+/* N1 for tab-separated data types (VCF, SAM). gz_byte_index: after[0] = 0, after[k + 1] = the position behind the k-th occurrence
+ * of `byte` in the text (cap + 2 entries), result_dev->n_lines = the number of occurrences (status 0 if > cap): the newline index of
+ * gz_text_lines for any byte. A SAM line's fields are then gz_tokenize_column_n with eleven tabs (the twelfth item: the optional
+ * fields). gz_vcf_sample_columns: vcf_seg_samples' split (src/vcf_samples.c:1601) - for the data lines given (not the header), the
+ * FORMAT subfields of every sample by position: item [j][line * n_samples + s] = subfield j of sample s (':' separated; a sample that
+ * leaves trailing subfields out has them `missing`: length 0 and, if `missing` is given, a 1 there - the mask
+ * gz_local_generate_partial takes). Which context a position feeds is the line's FORMAT field (item 8 of the line, for the caller to
+ * group lines by). *n_bad_dev counts lines that do not have 9 + n_samples fields and samples with more than n_subfields. */
+int gz_byte_index (GzHandle *h, const uint8_t *text, uint64_t n_bytes, uint8_t byte, uint32_t *after, uint32_t cap, GzLinesResult *result_dev);
+int gz_vcf_sample_columns (GzHandle *h, const uint8_t *text, const uint32_t *line_off, const uint32_t *line_len, uint32_t n_lines,
+                           const uint32_t *tab_after, const GzLinesResult *tabs_dev, uint32_t n_samples, uint32_t n_subfields,
+                           uint32_t *item_off, uint32_t *item_len, uint8_t *missing, uint32_t *n_bad_dev);
 typedef struct { void *data; uint64_t n; const GzDynIntResult *dyn_dev; int32_t ltype; uint32_t *len_dev; } GzLocalJob;
 int gz_local_generate_batch (GzHandle *h, const GzLocalJob *jobs, int n_jobs);
 typedef struct { const uint8_t *seq; const uint64_t *n_dev; uint64_t n_max; uint8_t *packed; uint8_t *x; uint32_t *has_x_dev; uint64_t *packed_len_dev; } GzAcgtJob;

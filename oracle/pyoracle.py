@@ -637,3 +637,37 @@ class CompRef:
         if n < 0:
             raise RuntimeError("compref_section failed")
         return out.raw[:n]
+
+
+def vcf_sample_items(text, line_off, line_len, n_samples, n_sub):
+    """N1 for VCF, restated: the split vcf_seg_samples does (src/vcf_samples.c:1601 with seg_get_next_item, src/seg.c:153-198) - a data
+    line is 9 tab-separated fields + n_samples samples, a sample its FORMAT subfields ':' separated, trailing ones may be left out.
+    -> (n_bad, item_off [n_sub][lines * samples], item_len, missing) like Engine.vcf_sample_columns"""
+    import numpy as np
+    text = bytes(text)
+    n = len(line_off)
+    k = n * n_samples
+    io = np.zeros((n_sub, max(1, k)), dtype=np.uint32); il = np.zeros((n_sub, max(1, k)), dtype=np.uint32); mi = np.ones((n_sub, max(1, k)), dtype=np.uint8)
+    bad = 0
+    for l in range(n):
+        a, b = int(line_off[l]), int(line_off[l]) + int(line_len[l])
+        fields, at = [], a
+        for part in text[a:b].split(b"\t"):
+            fields.append((at, len(part))); at += len(part) + 1
+        if len(fields) != 9 + n_samples:
+            bad += 1
+        for s in range(n_samples):
+            if 9 + s >= len(fields):
+                continue
+            o, ln = fields[9 + s]
+            if s == n_samples - 1 and len(fields) > 9 + n_samples:          # (too many fields: the last sample runs to the end of the line)
+                ln = b - o
+            at = o
+            for j, sub in enumerate(text[o:o + ln].split(b":")):
+                if j < n_sub:
+                    io[j, l * n_samples + s], il[j, l * n_samples + s], mi[j, l * n_samples + s] = at, len(sub), 0
+                elif j == n_sub:
+                    bad += 1
+                at += len(sub) + 1
+    io[mi == 1] = 0
+    return bad, io[:, :k], il[:, :k], mi[:, :k]

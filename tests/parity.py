@@ -1071,3 +1071,100 @@ def domq(E, oracle, n_lines):
         if kind in ("bin", "mix", "twodoms", "gaps", "startnz", "allF") and not g["all_diverse"]:
             pass
     assert got[0]["fit"] and not got[1]["fit"] and got[4]["runs"] == b"" and got[4]["qual"] == b"\x01" * 0 + got[4]["qual"]
+
+
+def vcf_text(n_lines, n_samples, seed=3):
+    """a small multi-sample VCF in the shape of BASELINE configs[3]: FORMAT GT:DP:PL, some samples cut short (./.), an INFO with a ':'"""
+    r = synth.u32(seed, n_lines * (n_samples + 4) + 16).astype(np.int64)
+    hdr = b"##fileformat=VCFv4.2\n##source=synthetic\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT" + b"".join(b"\tS%d" % i for i in range(n_samples)) + b"\n"
+    lines, pos, k = [], 10000, 0
+    for l in range(n_lines):
+        pos += 1 + int(r[k] % 300); k += 1
+        fixed = b"chr1\t%d\t.\t%s\t%s\t%d\tPASS\tDP=%d;AF=0.%d;X=a:b\tGT:DP:PL" % (pos, b"ACGT"[r[k] % 4:r[k] % 4 + 1], b"TGCA"[r[k + 1] % 4:r[k + 1] % 4 + 1], 30 + r[k + 2] % 60, r[k] % 500, r[k + 1] % 99)
+        k += 3
+        samples = []
+        for s in range(n_samples):
+            v = int(r[k]); k += 1
+            if v % 17 == 0:
+                samples.append(b"./.")                                        # trailing subfields left out
+            elif v % 29 == 0:
+                samples.append(b"0/0:%d" % (v % 70))
+            else:
+                dp = v % 70
+                samples.append(b"%s:%d:%d,%d,%d" % ((b"0/0", b"0/1", b"1/1", b"0|1")[v % 4], dp, 0 if v % 4 == 0 else 3 * dp, 3 * dp if v % 4 == 0 else 0, 40 * (v % 9)))
+        lines.append(fixed + b"\t" + b"\t".join(samples) + b"\n")
+    return hdr + b"".join(lines)
+
+
+def vcf_front(E, oracle, n_lines, n_samples):
+    """N1 for VCF chained into the rows it feeds: text -> lines -> data lines -> tabs -> FORMAT subfields of every sample as columns
+    (gz_byte_index, gz_vcf_sample_columns) == the restated split; then GT and PL through the column appends (a1 / a2), DP through
+    seg_integer_or_not + dyn-int (a3) and the lines x samples transpose (a7) - each == the oracle on the oracle's items"""
+    import pyoracle
+    text = vcf_text(n_lines, n_samples)
+    lo, ll = E.text_lines(text)
+    data = [i for i in range(len(lo)) if text[int(lo[i]):int(lo[i]) + 1] != b"#"]
+    dlo, dll = lo[data], ll[data]
+    assert np.array_equal(E.byte_index(text, 9), np.flatnonzero(np.frombuffer(text, dtype=np.uint8) == 9).astype(np.uint32) + 1)
+    bad, io, il, mi = E.vcf_sample_columns(text, dlo, dll, n_samples, 3)
+    wbad, wio, wil, wmi = pyoracle.vcf_sample_items(text, dlo, dll, n_samples, 3)
+    assert bad == wbad == 0 and np.array_equal(mi, wmi) and np.array_equal(il, wil) and np.array_equal(io, wio)
+    assert mi[1].sum() > 0 and mi[2].sum() > mi[1].sum()                       # (the cut-short samples are there)
+    # a line with a field too few / too many, a sample with a subfield too many: counted
+    broken = text.replace(b"\tPASS\t", b"\tPASS", 1)
+    blo, bll = E.text_lines(broken)
+    bd = [i for i in range(len(blo)) if broken[int(blo[i]):int(blo[i]) + 1] != b"#"]
+    assert E.vcf_sample_columns(broken, blo[bd], bll[bd], n_samples, 3)[0] == pyoracle.vcf_sample_items(broken, blo[bd], bll[bd], n_samples, 3)[0] > 0
+    assert E.vcf_sample_columns(text, dlo, dll, n_samples, 2)[0] == pyoracle.vcf_sample_items(text, dlo, dll, n_samples, 2)[0] > 0
+    # the columns: a missing subfield is a missing snip (WORD_INDEX_MISSING)
+    tx = bytes(text) + b"\x01"
+    for j in (0, 2):                                                             # GT, PL: dictionary + b250
+        o = np.where(mi[j] == 1, 0xffffffff, io[j]).astype(np.uint32)
+        g, w = E.ctx_seg_column(tx, o, il[j], []), oracle.ctx_seg_column(tx, o, il[j], [])
+        assert g["b250"] == w["b250"] and g["dict"] == w["dict"] and np.array_equal(g["counts"], w["counts"]), ("vcf column", j)
+    present = mi[1] == 0                                                         # DP: integers into a dyn-int local, lines x samples, transposed
+    so, sl, vals, isn = E.seg_integer_or_not(tx, io[1][present], il[1][present], 0, len(text))
+    wso, wsl, wvals, wisn = oracle.seg_integer_or_not(tx, io[1][present], il[1][present], 0, len(text))
+    assert np.array_equal(vals, wvals) and np.array_equal(so, wso)
+    if present.all():
+        lt, raw = E.dyn_int_column(vals, isn, 0)
+        wlt, wraw = oracle.dyn_int_column(wvals, wisn, 0)
+        assert (lt, raw) == (wlt, wraw)
+
+
+def sam_text(n, seed=8):
+    r = synth.u32(seed, 6 * n + 8).astype(np.int64)
+    out, pos = [b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:248956422\n"], 10000
+    for i in range(n):
+        pos += int(r[6 * i] % 200)
+        ln = 100 + int(r[6 * i + 1] % 51)
+        seq = np.frombuffer(b"ACGT", dtype=np.uint8)[synth.uniform_bytes(seed + i, ln, 4)].tobytes()
+        qual = synth.quality_binned(seed + 7 * i, 1, ln)[0].tobytes()
+        cigar = b"%dM" % ln if r[6 * i + 2] % 5 else b"%dM2I%dM" % (ln // 2, ln - ln // 2 - 2)
+        out.append(b"r%07d\t%d\tchr1\t%d\t%d\t%s\t=\t%d\t%d\t%s\t%s\tNM:i:%d\tAS:i:%d\n" % (i, (99, 147, 83, 163, 0, 16)[r[6 * i + 3] % 6], pos, (60, 60, 60, 0, 23)[r[6 * i + 4] % 5], cigar,
+                                                                                                   pos + 150, 250 + int(r[6 * i + 5] % 100), seq, qual, r[6 * i + 2] % 4, ln - r[6 * i + 5] % 9))
+    return b"".join(out)
+
+
+def sam_front(E, oracle, n):
+    """N1 for SAM: lines -> alignment lines -> the eleven mandatory fields + the optional ones by tab (gz_tokenize_column_n's job, here
+    through gz_tokenize_column with eleven tabs) -> FLAG / MAPQ / CIGAR as columns, POS through seg_integer_or_not, QUAL gathered"""
+    text = sam_text(n)
+    lo, ll = E.text_lines(text)
+    keep = [i for i in range(len(lo)) if text[int(lo[i]):int(lo[i]) + 1] != b"@"]
+    alo, all_ = lo[keep], ll[keep]
+    nb, io, il = E.tokenize_column(text, alo, all_, b"\t" * 11)
+    wnb, wio, wil = oracle.tokenize_column(text, alo, all_, b"\t" * 11)
+    assert nb == wnb == 0 and np.array_equal(io, wio) and np.array_equal(il, wil)
+    rows = [text[int(a):int(a) + int(b)].split(b"\t") for a, b in zip(alo, all_)]
+    for f in (1, 4, 5):                                                          # FLAG, MAPQ, CIGAR
+        got = [text[int(o):int(o) + int(l)] for o, l in zip(io[f], il[f])]
+        assert got == [r[f] for r in rows]
+        tx = bytes(text) + b"\x01"
+        g, w = E.ctx_seg_column(tx, io[f], il[f], []), oracle.ctx_seg_column(tx, io[f], il[f], [])
+        assert g["b250"] == w["b250"] and g["dict"] == w["dict"]
+    assert [text[int(o):int(o) + int(l)] for o, l in zip(io[11], il[11])] == [b"\t".join(r[11:]) for r in rows]
+    so, sl, vals, isn = E.seg_integer_or_not(bytes(text) + b"\x01", io[3], il[3], 0, len(text))      # POS
+    assert [int(v) for v in vals] == [int(r[3]) for r in rows]
+    q = E.local_blob_columns([(text, io[10], il[10], False)])[0]                  # QUAL -> local
+    assert q == b"".join(r[10] for r in rows) == oracle.local_blob_column(text, io[10], il[10], False)

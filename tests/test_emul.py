@@ -54,6 +54,11 @@ def test_emul_seg_columns(emul_engine, oracle):
     parity.seg_columns(emul_engine, oracle, 3000)
 
 
+def test_emul_vcf_and_sam_front(emul_engine, oracle):
+    parity.vcf_front(emul_engine, oracle, 40, 25)
+    parity.sam_front(emul_engine, oracle, 200)
+
+
 def test_emul_fastq_front(emul_engine, oracle):
     parity.fastq_front(emul_engine, oracle, 700)
 

@@ -139,6 +139,11 @@ def test_b250_pair_identical(gpu_engine, oracle):
     parity.b250_pair_identical(gpu_engine, oracle, 300000)
 
 
+def test_vcf_and_sam_front(gpu_engine, oracle):
+    parity.vcf_front(gpu_engine, oracle, 300, 400)
+    parity.sam_front(gpu_engine, oracle, 20000)
+
+
 def test_fastq_front(gpu_engine, oracle):
     """N1 (first part) chained into a1-a3 on a VBlock's worth of FASTQ text (23 000 reads, ~7 MB)"""
     parity.fastq_front(gpu_engine, oracle, 23000)
