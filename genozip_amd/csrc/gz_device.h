@@ -95,7 +95,8 @@ struct GzdLeaf {
     uint32_t  nctx;           // arith: row length of ctxoff / ctxend: 256, or 768 for the run-length variant's 514 models
     uint32_t  *mstate;        // arith: the models' registers between two position chunks (GZ_MSTATE_WORDS x 64 lanes per context)
     uint8_t   *events;        // arith: one 32-bit digit per output byte (k_low_replay / k_low_norm)
-    uint8_t   *rvals;         // arith: r = range / tot of every symbol (k_arith_chain -> k_low_*)
+    uint8_t   *rvals;         // arith: r = range / tot of every symbol (k_chain_expand -> k_low_*)
+    uint8_t   *ckpt;          // arith: the range before every 64th symbol (k_arith_chain -> k_chain_expand)
     uint8_t   *kpos;          // arith: per 64-symbol slice: shifts in it, then (k_low_scan) shifts before it
     uint8_t   *resid;         // arith: per slice: what is left in its 32-bit window (+ carry) after its last shift
     uint32_t  n_events;

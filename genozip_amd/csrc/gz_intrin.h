@@ -14,6 +14,12 @@ __device__ static inline void gz_scalar_store4 (uint32_t *dst, uint32_t a, uint3
     asm volatile ("s_store_dwordx4 %0, %1, 0x0" : : "s"(v), "s"(dst) : "memory");
 }
 
+// one wave-uniform dword to a wave-uniform address (s_store_dword)
+__device__ static inline void gz_scalar_store1 (uint32_t *dst, uint32_t a)
+{
+    asm volatile ("s_store_dword %0, %1, 0x0" : : "s"(a), "s"(dst) : "memory");
+}
+
 // the same with an immediate byte offset (one base pointer serves several stores)
 template <int OFF> __device__ static inline void gz_scalar_store4_at (uint32_t *dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 {

@@ -716,8 +716,12 @@ __device__ static inline bool d_wait_progress (const uint32_t *progress, uint32_
 }
 
 // positions [p0, p1) of one leaf
+// What leaves the chain is the range BEFORE every 64th symbol (ck[i / 64]) - one scalar store per 64 symbols. The r of every symbol,
+// which the low kernels need, is recomputed from those checkpoints by k_chain_expand (all slices of 64 symbols at once): storing
+// r from here (an s_store_dwordx4 per 4 symbols) cost the chain 12 % - every wait for the next records also waited for the
+// write acknowledgements (scalar loads and stores share one counter): 92.7 -> 81.6 ms for 6.0 M symbols, measured alone.
 __device__ static __forceinline__ void d_chain_chunk (uint32_t &range, uint32_t &sink, uint32_t &touched, int lane, uint32_t p0, uint32_t p1, uint32_t n,
-                                                      uint8_t *triples, uint32_t *rout, uint32_t max_sym)
+                                                      uint8_t *triples, uint32_t *ck, uint32_t max_sym)
 {
     GzConstRecP rec = (GzConstRecP)(uintptr_t)triples;         // padded: reads up to 64 KB past n stay inside the area
     // (a GLOBAL pointer: a load through a generic one is a flat load, which also counts as an LDS / scalar operation -
@@ -726,11 +730,11 @@ __device__ static __forceinline__ void d_chain_chunk (uint32_t &range, uint32_t 
     if (max_sym == 1) {
         // a stream of zero bytes: the range stays 2^32-1 while the model total is 1 (and 17), which n + inc cannot take
         for (uint32_t i = p0; i < p1; i++) {
+            if (!lane && !(i & 63)) ck[i >> 6] = range;
             const gz_u32x4 c = rec[i];
             const uint32_t r = (uint32_t)(((uint64_t)c[1] * ((uint64_t)range + c[3])) >> 32) >> (c[2] & 31);
             const uint32_t x = r * c[0];
             range = x << (__clz (x) & 0x18);
-            if (!lane) rout[i] = r;
         }
         return;
     }
@@ -756,19 +760,17 @@ __device__ static __forceinline__ void d_chain_chunk (uint32_t &range, uint32_t 
             gz_wait_scalar_loads (); \
             N0 = rec4[(i >> 2) + 2 * (K) + 2]; N1 = rec4[(i >> 2) + 2 * (K) + 3]; \
             gz_sched_fence (); \
-            uint32_t r0, r1, r2, r3; \
-            r0 = d_chain_step (range, C0[0], C0[1], C0[2],  C0[3]);  r1 = d_chain_step (range, C0[4],  C0[5],  C0[6],  C0[7]); \
-            r2 = d_chain_step (range, C0[8], C0[9], C0[10], C0[11]); r3 = d_chain_step (range, C0[12], C0[13], C0[14], C0[15]); \
-            gz_scalar_store4_at<32 * (K)> (rout + i, r0, r1, r2, r3);       /* the chain never touches the vector unit */ \
-            r0 = d_chain_step (range, C1[0], C1[1], C1[2],  C1[3]);  r1 = d_chain_step (range, C1[4],  C1[5],  C1[6],  C1[7]); \
-            r2 = d_chain_step (range, C1[8], C1[9], C1[10], C1[11]); r3 = d_chain_step (range, C1[12], C1[13], C1[14], C1[15]); \
-            gz_scalar_store4_at<32 * (K) + 16> (rout + i, r0, r1, r2, r3); \
+            (void)d_chain_step (range, C0[0], C0[1], C0[2],  C0[3]);  (void)d_chain_step (range, C0[4],  C0[5],  C0[6],  C0[7]); \
+            (void)d_chain_step (range, C0[8], C0[9], C0[10], C0[11]); (void)d_chain_step (range, C0[12], C0[13], C0[14], C0[15]); \
+            (void)d_chain_step (range, C1[0], C1[1], C1[2],  C1[3]);  (void)d_chain_step (range, C1[4],  C1[5],  C1[6],  C1[7]); \
+            (void)d_chain_step (range, C1[8], C1[9], C1[10], C1[11]); (void)d_chain_step (range, C1[12], C1[13], C1[14], C1[15]); \
         } while (0)
         uint32_t i = p0;
         gz_u32x16 b0, b1;
         // 64 records per iteration (loop control, address arithmetic and the touch are paid once per 64: every instruction
         // of this wave is 4 clocks of the step's critical path)
         for (; i + 64 <= nb; i += 64) {
+            gz_scalar_store1 (ck + (i >> 6), range);                       // (i is a multiple of 64 here: p0 is one of 256)
             // every 64 records the 64 records that start AHEAD bytes further on, never waited for (gz_touch)
             if (i + GZ_CHAIN_TOUCH_AHEAD / 16 + GZ_CHAIN_TOUCH_PERIOD <= touch_end)
                 gz_touch (triples + (size_t)i * 16 + GZ_CHAIN_TOUCH_AHEAD + lane * (GZ_CHAIN_TOUCH_PERIOD / 4), touched);
@@ -778,6 +780,7 @@ __device__ static __forceinline__ void d_chain_chunk (uint32_t &range, uint32_t 
         gz_wait_scalar_loads ();
         // what is left of the chunk (< 64 records): 8 at a time, (a0, a1) holds the next 8
         for (; i < nb; i += 8) {
+            if (!(i & 63)) gz_scalar_store1 (ck + (i >> 6), range);
             GZ_CHAIN_HALF (a0, a1, b0, b1, 0);
             gz_wait_scalar_loads ();
             a0 = b0; a1 = b1;
@@ -786,9 +789,9 @@ __device__ static __forceinline__ void d_chain_chunk (uint32_t &range, uint32_t 
         gz_touch_done (touched);
     }
     for (uint32_t i = nb > p0 ? nb : p0; i < p1; i++) {
+        if (!(i & 63)) gz_scalar_store1 (ck + (i >> 6), range);
         const gz_u32x4 c = rec[i];
-        const uint32_t r = i ? d_chain_step (range, c[0], c[1], c[2], c[3]) : d_chain_step (range, c[0], q0 + 1, 0, 0);
-        if (!lane) rout[i] = r;
+        if (i) (void)d_chain_step (range, c[0], c[1], c[2], c[3]); else (void)d_chain_step (range, c[0], q0 + 1, 0, 0);
     }
 }
 
@@ -811,7 +814,7 @@ __global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *l
     }
     const uint32_t n = d_uniform (L.arith_n), max_sym = d_uniform (L.max_sym);
     uint8_t *triples = d_uniform_ptr (L.triples);              // (wave-uniform: keep them in scalar registers)
-    uint32_t *rout = d_uniform_ptr ((uint32_t *)L.rvals);
+    uint32_t *rout = d_uniform_ptr ((uint32_t *)L.ckpt);        // (checkpoints: the range before every 64th symbol)
     uint32_t sink = 0, touched = 0, range = 0xffffffffu;
     if (!progress) d_chain_chunk (range, sink, touched, lane, 0, n, n, triples, rout, max_sym);
     else
@@ -869,6 +872,41 @@ __device__ static inline GzdLowBlock d_low_block (const GzdLowBlock *blocks, con
     GzdLowBlock b;
     b.leaf = list[blockIdx.x]; b.first_slice = p0 / GZ_LOW_SLICE + blockIdx.y * GZ_LOW_SLICES_PER_WG;
     return b;
+}
+
+// r = range / tot of every symbol, from the chain's checkpoints: a lane per 64-symbol slice replays the chain's arithmetic over its
+// slice (the same exact division by multiplication; in 64 bits, which also covers the total of 1 that a stream of one symbol keeps
+// and the first symbol's range of 2^32-1), the wave's 64 x 64 results go through LDS so that they are written row by row.
+// Same grid as the low kernels that follow it (one workgroup = 64 slices), 64 threads, 64 * 65 * 4 bytes of LDS.
+__global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const GzdLowBlock *blocks, const uint32_t *list, uint32_t p0)
+{
+    const GzdLowBlock B = d_low_block (blocks, list, p0);
+    GzdLeaf &L = leaves[B.leaf];
+    if (!L.active || L.engine != GZ_ENG_ARITH) return;
+    const uint32_t n = L.arith_n, ns = d_low_nslices (n);
+    if (!n || B.first_slice >= ns) return;
+    const int lane = threadIdx.x;
+    const uint4 *rec = (const uint4 *)L.triples;
+    uint32_t *rv = (uint32_t *)L.rvals;
+    uint32_t *tile = (uint32_t *)gz_lds;                        // [64 slices][65]
+    const uint32_t slice = B.first_slice + lane, i0 = slice * GZ_LOW_SLICE;
+    if (slice < ns) {
+        uint32_t range = ((const uint32_t *)L.ckpt)[slice];
+        const uint32_t q0 = 0xffffffffu / (L.max_sym ? L.max_sym : 1u), m = i0 + 64 <= n ? 64 : n - i0;
+        for (uint32_t j = 0; j < m; j++) {
+            uint4 c = rec[i0 + j];
+            if (!(i0 + j) && L.max_sym != 1) { c.y = q0 + 1; c.z = 0; c.w = 0; }          // (d_chain_chunk: the first symbol's reciprocal)
+            const uint32_t r = (uint32_t)(((uint64_t)c.y * ((uint64_t)range + c.w)) >> 32) >> (c.z & 31);
+            const uint32_t x = r * c.x;
+            range = x << (__clz (x) & 0x18);
+            tile[lane * 65 + j] = r;
+        }
+    }
+    gz_wave_sync ();
+    for (uint32_t s = 0; s < 64; s++) {
+        const uint32_t i = (B.first_slice + s) * GZ_LOW_SLICE + lane;
+        if (B.first_slice + s < ns && i < n) rv[i] = tile[s * 65 + lane];
+    }
 }
 
 __global__ void __launch_bounds__(GZ_LOW_WG) k_low_count (GzdLeaf *leaves, const GzdLowBlock *blocks, const uint32_t *list, uint32_t p0)

@@ -6,6 +6,7 @@ static inline void gz_scalar_store4 (uint32_t *dst, uint32_t a, uint32_t b, uint
 {
     if (emu.cur % 64 == 0) { dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d; }
 }
+static inline void gz_scalar_store1 (uint32_t *dst, uint32_t a) { if (emu.cur % 64 == 0) dst[0] = a; }
 static inline void gz_scalar_store_flush (void) {}
 static inline uint32_t gz_mbcnt (uint64_t m) { return (uint32_t)__builtin_popcountll (m & ((1ull << (emu.cur % 64)) - 1)); }
 template <int OFF> static inline void gz_scalar_store4_at (uint32_t *dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { gz_scalar_store4 (dst + OFF / 4, a, b, c, d); }
