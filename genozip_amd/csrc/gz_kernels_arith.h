@@ -662,7 +662,8 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
 //                  loads: SMEM, 64 records per loop iteration in two 32-register buffers, the next buffer in flight
 //                  (the lines are pulled into L2 1 KB ahead by a vector "touch" load because SMEM returns out of order
 //                  and can only be waited for as a whole), division by the per-record magic number, renormalisation
-//                  by count-leading-zeros instead of a loop, and r stored four at a time. It never looks at cum or low.
+//                  by count-leading-zeros instead of a loop. It never looks at cum or low, and stores only the range before
+//                  every 64th symbol: k_chain_expand recomputes r = range / tot of every symbol from those for the low kernels.
 //   k_low_*        all threads: every thread replays low += cum * r for its own slice of 64 symbols from low = 0,
 //                  emitting the byte that leaves the 32-bit window at every shift (plus the carry out of the window as
 //                  a 9th bit) at its absolute output position (k_low_count / k_low_scan: a prefix sum of the k's;
@@ -798,7 +799,7 @@ __device__ static __forceinline__ void d_chain_chunk (uint32_t &range, uint32_t 
 // progress == NULL: everything is there already, one piece (chunk is ignored)
 // (Tried and measured without effect on the slow-down the chain suffers while other kernels run - ~15 %, with the clock
 //  unchanged -: wave priority, compute-unit masks, a helper wave pulling the records into the scalar cache ahead of
-//  the chain, dropping the stores of r.)
+//  the chain. Dropping the stores of r, tried then with no effect on THAT slow-down, is worth 12 % of the chain itself: d_chain_chunk.)
 __global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress, uint32_t chunk,
                                                                       uint32_t *fail, uint32_t *done, uint32_t n_chunks)
 {
