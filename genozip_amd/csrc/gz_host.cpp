@@ -81,6 +81,7 @@ struct GzHandle {
     std::vector<hipEvent_t> event_pool;            // (creating and destroying two events per launch costs more than the launch)
     struct ProfAcc { std::string name; double ms; int launches; };
     std::vector<ProfAcc> prof;
+    bool background = false;               // gz_create_background
     std::vector<GzHandle *> helpers;       // handles that work for this one (the VBlock driver's second handle): profiled with it
     std::vector<ProfAcc> prof_view;        // gz_profile_get: this handle's totals + its helpers'
 };
@@ -147,7 +148,7 @@ static GzHandle *gz_create_do (int device, void *hip_stream, int *err, bool back
     }
     if (hipSetDevice (device) != hipSuccess) { if (err) *err = GZ_ERR_HIP; return NULL; }
     GzHandle *h = new GzHandle ();
-    h->device = device; h->d_logs = NULL; h->d_magic = NULL;
+    h->device = device; h->d_logs = NULL; h->d_magic = NULL; h->background = background;
     h->arena_block_size = (size_t)256 << 20;
     int prio_lo0 = 0, prio_hi0 = 0;
     if (hipDeviceGetStreamPriorityRange (&prio_lo0, &prio_hi0) != hipSuccess) prio_lo0 = prio_hi0 = 0;
@@ -554,7 +555,10 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
     const uint32_t chain_wgs = (A.nbig + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES;
     // (the budget is per process: several handles - one per host thread, INTEGRATION.md - share the device)
     A.pipelined = false; A.reserve_cu = false;
-    if (A.nbig && !h->no_pipeline) {
+    // (on a background handle a batch whose longest leaf is under two chunks - the 99 999-byte sample of the QUAL trial, which sits in
+    //  front of the long pole - goes in one piece: 6.5 -> 4.5 ms, it gains nothing from the pipeline and pays for its gates. The same
+    //  rule on the main handle made the step 9 ms SLOWER: its trial batches then hold up the sections that run beside the long pole)
+    if (A.nbig && !h->no_pipeline && (!h->background || P.max_arith_n > 2 * GZ_CHUNK_MIN)) {
         const int wgs = (int)chain_wgs;
         if (g_chain_wgs.fetch_add (wgs) + wgs <= h->n_cu * 4) {
             A.pipelined = true; h->chain_wgs_held += wgs;
