@@ -154,6 +154,8 @@ static void *ws_alloc (GzZipFile *f, size_t bytes)
     return nb.base;
 }
 
+static GzZipFile *zip_open_failed (GzZipFile *f) { for (auto z : f->zctx) gz_zctx_destroy (z); delete f; return NULL; }
+
 extern "C" GzZipFile *gz_zip_open (GzHandle *h, const GzFastqPlan *plan)
 {
     if (!h || !plan || !plan->ctxs || !plan->n_ctxs || plan->n_seps > GZ_TOK_MAX_SEPS) return NULL;
@@ -165,10 +167,10 @@ extern "C" GzZipFile *gz_zip_open (GzHandle *h, const GzFastqPlan *plan)
         GzFastqCtx &c = f->ctxs[i];
         if (c.snip && c.snip_len) f->snips[i].assign (c.snip, c.snip + c.snip_len);
         c.snip = f->snips[i].data ();
-        if ((c.kind == GZ_FQ_ITEM_TEXT || c.kind == GZ_FQ_ITEM_INT || c.kind == GZ_FQ_ITEM_DELTA) && c.item > plan->n_seps) { delete f; return NULL; }
-        if ((c.kind == GZ_FQ_CONST || c.kind == GZ_FQ_ITEM_DELTA) && !c.snip_len) { delete f; return NULL; }
-        if (c.kind == GZ_FQ_QUAL) { if (f->qual_ctx >= 0) { delete f; return NULL; } f->qual_ctx = (int)i; }     // (one QUAL per plan)
-        if (c.kind == GZ_FQ_QUAL_AUX) { if (c.item > 2 || f->aux[c.item] >= 0) { delete f; return NULL; } f->aux[c.item] = (int)i; }
+        if ((c.kind == GZ_FQ_ITEM_TEXT || c.kind == GZ_FQ_ITEM_INT || c.kind == GZ_FQ_ITEM_DELTA) && c.item > plan->n_seps) return zip_open_failed (f);
+        if ((c.kind == GZ_FQ_CONST || c.kind == GZ_FQ_ITEM_DELTA) && !c.snip_len) return zip_open_failed (f);
+        if (c.kind == GZ_FQ_QUAL) { if (f->qual_ctx >= 0) return zip_open_failed (f); f->qual_ctx = (int)i; }     // (one QUAL per plan)
+        if (c.kind == GZ_FQ_QUAL_AUX) { if (c.item > 2 || f->aux[c.item] >= 0) return zip_open_failed (f); f->aux[c.item] = (int)i; }
         f->zctx.push_back (gz_zctx_create (plan->estimated_entries));
         if (c.lcodec) gz_zctx_commit_codec (f->zctx.back (), 1, c.lcodec);
         if (c.bcodec) gz_zctx_commit_codec (f->zctx.back (), 0, c.bcodec);
@@ -186,6 +188,7 @@ extern "C" void gz_zip_close (GzZipFile *f)
     (void)hipSetDevice (f->h->device);
     (void)gz_sync (f->h);
     if (f->h2) {
+        (void)gz_sync (f->h2);
         auto &hl = f->h->helpers;
         hl.erase (std::remove (hl.begin (), hl.end (), f->h2), hl.end ());
         gz_destroy (f->h2);
@@ -202,6 +205,7 @@ extern "C" int gz_zip_reset (GzZipFile *f)
 {
     if (!f) return GZ_ERR_ARG;
     int rc = gz_sync (f->h);
+    if (f->h2) { const int rc2 = gz_sync (f->h2); if (rc >= 0 && rc2 < 0) rc = rc2; }   // (a call that failed half way may have left work there)
     if (rc < 0) return rc;
     for (size_t i = 0; i < f->zctx.size (); i++) {
         gz_zctx_destroy (f->zctx[i]);
@@ -405,6 +409,7 @@ static inline void blob_put (std::vector<uint8_t> &b, const void *p, size_t n)
 extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len, GzFastqVB *vbs, int n_vbs, const void **blob_out, uint64_t *blob_len_out)
 {
     if (!f || !blob_out || !blob_len_out) return GZ_ERR_ARG;
+    if (f->call.phase != 0 && f->h2) (void)gz_sync (f->h2);   // (the previous call was given up half way: its long streams may still be running in the workspace)
     if (n_vbs == 0) {                                      // a process without VBlocks in this call still takes part in the merge
         int rc0 = gz_sync (f->h);
         if (rc0 < 0) return rc0;
@@ -776,7 +781,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     T.mark ("seg-sync");
     if (a.fq.first_bad != 0xffffffffu) {
         for (uint32_t v = 0; v < NV; v++) if (a.fq.first_bad >= r0[v] && a.fq.first_bad < r_end[v]) vbs[v].status = GZ_ERR_CORRUPT;
-        h->err = "not FASTQ: a read is not '@'.. / SEQ / '+'.. / QUAL of SEQ's length (fastq.c:1008-1010,1076,1121)"; return GZ_ERR_CORRUPT;
+        h->err = "not FASTQ: a read is not '@'.. / SEQ / '+'.. / QUAL of SEQ's length (fastq.c:1008-1010,1076,1121)"; ZIP_FAIL (GZ_ERR_CORRUPT);
     }
     if (a.n_bad_items) { h->err = "a line 1 does not fit the container of the plan (the reference would re-discover the flavor, qname.c:823-826)"; ZIP_FAIL (GZ_ERR_CORRUPT); }
     for (size_t k = 0; k < icol_jobs.size (); k++)
