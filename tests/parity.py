@@ -1168,3 +1168,37 @@ def sam_front(E, oracle, n):
     assert [int(v) for v in vals] == [int(r[3]) for r in rows]
     q = E.local_blob_columns([(text, io[10], il[10], False)])[0]                  # QUAL -> local
     assert q == b"".join(r[10] for r in rows) == oracle.local_blob_column(text, io[10], il[10], False)
+
+
+def fastq_zip_errors(E, oracle):
+    """what the reference aborts on, the driver reports - and the file object is usable again after a reset: text that is not FASTQ,
+    a VBlock that does not start at a line, a line 1 that does not fit the plan's container, a quality score outside ' '..'~' under
+    --force-domq"""
+    from genozip_amd import fastq as fq
+    from genozip_amd.codec import GenozipAMDError
+    good = fastq_text(120, seed=9, mate=1)
+    F = E.zip_open(fq.illumina_plan(paired=False))
+    cases = {"not fastq": good.replace(b"\n+\n", b"\n-\n", 1), "cut inside a line": None, "other flavor": good.replace(b":N:0:", b"_N_0_", 1)}
+    for name, text in cases.items():
+        try:
+            if text is None:
+                F.zip_vblocks(good, [(5, len(good) - 5, 1, -1)])
+            else:
+                F.zip_vblocks(text, [(0, len(text), 1, -1)])
+            raise AssertionError("no error: " + name)
+        except GenozipAMDError:
+            pass
+        F.reset()
+    ok = F.zip_vblocks(good, [(0, len(good), 1, -1)])
+    want, _ = fastq_zip_expected(oracle, fq.illumina_plan(paired=False), good, [(0, len(good), 1, -1)])
+    assert ok[0]["z"] == want[0]["z"]
+    F.close()
+    F = E.zip_open(fq.illumina_plan(paired=False, domq=13))
+    lines = good.split(b"\n")
+    lines[3] = b"\x7f" + lines[3][1:]
+    try:
+        F.zip_vblocks(b"\n".join(lines), [(0, len(good), 1, -1)])
+        raise AssertionError("no error: bad score")
+    except GenozipAMDError:
+        pass
+    F.close()

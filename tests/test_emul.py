@@ -107,6 +107,10 @@ def test_emul_fastq_zip(emul_engine, oracle):
     parity.fastq_zip(emul_engine, oracle, 200)
 
 
+def test_emul_fastq_zip_errors(emul_engine, oracle):
+    parity.fastq_zip_errors(emul_engine, oracle)
+
+
 def test_emul_fastq_zip_domq(emul_engine, oracle):
     """QUAL through CODEC_DOMQ inside the driver: the file's first VBlock decides (binned scores: a fit), later calls follow even
     with scores that would not fit; forced (--force-domq) on scores that do not fit; refused (--no-domqual) on scores that do"""

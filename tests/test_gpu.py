@@ -108,6 +108,10 @@ def test_fastq_zip_driver(gpu_engine, oracle):
     parity.fastq_zip(gpu_engine, oracle, 1000, n_calls=1, qual=("bin",), domq=1)
 
 
+def test_fastq_zip_errors(gpu_engine, oracle):
+    parity.fastq_zip_errors(gpu_engine, oracle)
+
+
 def test_c_host_program():
     """tests/c/zip_fastq.c: plain C11 against include/genozip_amd.h and the real library, no Python in the loop"""
     import os
