@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(256) k_nl_scan (GzdLines L)
     const uint64_t newlines = d_wg_scan_array (L.tile, n_tiles, threadIdx.x);
     if (threadIdx.x) return;
     const uint64_t lines = newlines + ((!L.raw && L.n && L.text[L.n - 1] != '\n') ? 1 : 0);   // a last line without newline counts (seg.c:227-230)
-    L.result->n_lines = lines;
+    L.result->n_lines = lines; L.result->reserved = 0;
     L.result->status = lines <= L.cap ? GZ_ST_OK : GZ_ST_TOO_SMALL;
     L.start[0] = 0;
 }
@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(256) k_lines_finish (GzdLines L)
     const uint64_t start = L.start[j];
     const bool whole = !(j + 1 == lines && L.text[L.n - 1] != '\n');           // ends with a newline
     uint64_t end = whole ? (uint64_t)L.start[j + 1] - 1 : L.n;                  // one past the line's last byte
-    if (end > start && L.text[end - 1] == '\r') end--;
+    if (end > start && L.text[end - 1] == '\r') { end--; L.result->reserved = 1; }   // (any line ended \r\n: result->reserved, see genozip_amd.h)
     L.off[j] = (uint32_t)start;
     L.len[j] = (uint32_t)(end - start);
 }

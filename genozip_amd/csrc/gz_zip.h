@@ -470,6 +470,9 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     }
     T.mark ("lines+sync");
     if (a.bad_bound) { h->err = "a VBlock does not start / end at the start of a line"; return GZ_ERR_CORRUPT; }
+    // (the reference segs every line's end into E1L / E2L: "\n" or "\r\n", fastq.c:1191-1203; the plans this driver takes make those
+    //  contexts one constant snip, so a text with \r\n lines must not get through silently)
+    if (a.lines.reserved) { h->err = "lines end in \\r\\n: not expressible with a constant end-of-line snip"; return GZ_ERR_CORRUPT; }
     const uint64_t n_lines = a.lines.n_lines;
     if (n_lines % 4) { h->err = "the text does not hold whole reads (4 lines each)"; return GZ_ERR_CORRUPT; }
     const uint32_t R = (uint32_t)(n_lines / 4);                            // reads of the whole text (every 4 lines: VBlocks hold whole reads)

@@ -308,7 +308,7 @@ int gz_local_blob_columns (GzHandle *h, const GzBlobJob *jobs, int n_jobs);
  *   i-1, the last item is the rest; item-major output [i * n + k], ready to be columns of gz_ctx_seg_columns /
  *   gz_dyn_int_columns. A snip lacking a separator counts in *n_bad_dev and stays whole in item 0 (the reference
  *   segs such a qname as one snip). n_seps <= 15. */
-typedef struct { uint64_t n_lines; int32_t status; uint32_t reserved; } GzLinesResult;
+typedef struct { uint64_t n_lines; int32_t status; uint32_t reserved; /* gz_text_lines: 1 if a line ended in \r\n (the \r is not part of its length) */ } GzLinesResult;
 int gz_text_lines (GzHandle *h, const uint8_t *text, uint64_t n_bytes, uint32_t *line_off, uint32_t *line_len, uint32_t cap,
                    GzLinesResult *result_dev);
 typedef struct { uint64_t n_reads; uint32_t first_bad; uint32_t reserved; } GzFastqResult;
