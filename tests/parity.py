@@ -1176,7 +1176,7 @@ def fastq_zip_errors(E, oracle):
     --force-domq"""
     from genozip_amd import fastq as fq
     from genozip_amd.codec import GenozipAMDError
-    good = fastq_text(120, seed=9, mate=1)
+    good = fastq_text(48, seed=9, mate=1)
     F = E.zip_open(fq.illumina_plan(paired=False))
     cases = {"not fastq": good.replace(b"\n+\n", b"\n-\n", 1), "cut inside a line": None, "other flavor": good.replace(b":N:0:", b"_N_0_", 1),
              "crlf": good.replace(b"\n", b"\r\n", 8)}

@@ -5,7 +5,7 @@ import parity
 
 
 def test_emul_codec_edge_cases(emul_engine, oracle):
-    parity.codec_edge_cases(emul_engine, oracle, max_n=1031, thin_from=50)
+    parity.codec_edge_cases(emul_engine, oracle, max_n=1031, thin_from=24)
 
 
 def test_emul_host_call_surface(emul_engine, oracle):
