@@ -620,8 +620,39 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         }
     }
     T.mark ("plan");
-    // SEQ / QUAL are gathered first: the QUAL streams are the long pole of the whole call, and when the file has no codec for
-    // them yet, the trial compressions (a8) of the first VBlock's QUAL start on the second handle while the columns are evaluated
+    // SEQ / QUAL are gathered first: the QUAL streams are the long pole of the whole call. When the file has no codec for them yet,
+    // the trial compressions (a8) of the first VBlock's QUAL sit in front of that pole: their input - the first 99 999 bytes of
+    // QUAL.local (codec.c:309) - is gathered on its own, ahead of everything, and they start on the second handle right away
+    static const int trial_codecs[8] = { GZ_CODEC_RANB, GZ_CODEC_RANW, GZ_CODEC_RANb, GZ_CODEC_RANw, GZ_CODEC_ARTB, GZ_CODEC_ARTW, GZ_CODEC_ARTb, GZ_CODEC_ARTw };
+    std::vector<GzStream> trial;                          // 8 per candidate form of QUAL (plain / through DOMQ) that needs a codec
+    trial.reserve (16);                                   // (the coder keeps pointers into it until the second handle is synchronised)
+    std::vector<uint32_t> trial_ctx; std::vector<int> trial_domq;
+    const bool own_first = vbs[0].vblock_i == f->last_vblock_i + 1;   // (vblock_i are consecutive over the processes: this one opens the call)
+    bool want_trial = false;
+    if (f->h2 && own_first && f->qual_ctx >= 0 && vbs[0].n_reads) { GzZctxView zv; gz_zctx_view (f->zctx[f->qual_ctx], &zv); want_trial = !zv.lcodec; }
+    auto add_trials = [&] (const uint8_t *in, const uint32_t *len_dev, int as_domq) -> int {
+        const size_t first = trial.size ();
+        for (int k = 0; k < 8; k++) {
+            GzStream st; memset (&st, 0, sizeof (st));
+            st.in = in; st.in_len = 99999; st.in_len_dev = len_dev;                                          // (low half of a 64-bit length)
+            st.codec = trial_codecs[k]; st.out_cap = gz_codec_est_size (st.codec, 99999);
+            if (!(st.out = (uint8_t *)ws_alloc (f, (size_t)st.out_cap + 64))) return GZ_ERR_HIP;
+            trial.push_back (st);
+        }
+        trial_ctx.push_back ((uint32_t)f->qual_ctx); trial_domq.push_back (as_domq);
+        int r = gz_wait_for (f->h2, h);
+        if (r == GZ_OK && (r = gz_codec_compress_batch (f->h2, trial.data () + first, 8)) != GZ_OK) h->err = f->h2->err;
+        return r;
+    };
+    if (want_trial && qmode0 <= 0) {                      // the plain form: enough of VBlock 0's reads to hold 99 999 bytes
+        GzBlobJob tj; memset (&tj, 0, sizeof (tj));
+        tj.text = text; tj.off = qual_off + r0[0]; tj.len = qual_len + r0[0]; tj.n = std::min<uint32_t> (vbs[0].n_reads, 100000);
+        WS (d_trial_len, uint64_t, 2);
+        if (!(tj.out = (uint8_t *)ws_alloc (f, vbs[0].text_len + 128))) return GZ_ERR_HIP;
+        tj.out_len_dev = d_trial_len;
+        ZCHK (gz_local_blob_columns (h, &tj, 1));
+        ZCHK (add_trials (tj.out, (const uint32_t *)d_trial_len, 0));
+    }
     for (size_t at = 0; at < blob_jobs.size (); at += 32768) ZCHK (gz_local_blob_columns (h, blob_jobs.data () + at, (int)std::min<size_t> (32768, blob_jobs.size () - at)));
     ZCHK (gz_domq_fit (h, fit_jobs.data (), (int)fit_jobs.size ()));
     ZCHK (gz_domq_columns (h, domq_jobs.data (), (int)domq_jobs.size ()));
@@ -636,34 +667,8 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     }
     if (!f->ev_early) HIPCHK (h, hipEventCreateWithFlags (&f->ev_early, hipEventDisableTiming));
     HIPCHK (h, hipEventRecord (f->ev_early, h->stream));
-    static const int trial_codecs[8] = { GZ_CODEC_RANB, GZ_CODEC_RANW, GZ_CODEC_RANb, GZ_CODEC_RANw, GZ_CODEC_ARTB, GZ_CODEC_ARTW, GZ_CODEC_ARTb, GZ_CODEC_ARTw };
-    std::vector<GzStream> trial;                          // 8 per QUAL-kind context that needs a codec
-    std::vector<uint32_t> trial_ctx; std::vector<int> trial_domq;
-    const bool own_first = vbs[0].vblock_i == f->last_vblock_i + 1;   // (vblock_i are consecutive over the processes: this one opens the call)
-    if (f->h2 && own_first)
-        for (uint32_t c = 0; c < NC; c++) {
-            if (f->ctxs[c].kind != GZ_FQ_QUAL || !vbs[0].n_reads) continue;
-            GzZctxView zv; gz_zctx_view (f->zctx[c], &zv);
-            if (zv.lcodec) continue;
-            const ZipCol &Z = COL (0, c);
-            // (not decided yet whether QUAL goes through DOMQ: both candidates are tried, the read-back below says which one counts)
-            for (int as_domq = 0; as_domq < 2; as_domq++) {
-                if (as_domq ? !qmode0 : qmode0 > 0) continue;
-                for (int k = 0; k < 8; k++) {
-                    GzStream st; memset (&st, 0, sizeof (st));
-                    st.in = as_domq ? K.domq[0].out[0] : Z.local; st.in_len = 99999;                          // codec.c:309 (low half of the 64-bit length)
-                    st.in_len_dev = as_domq ? (const uint32_t *)&d_domqres[0].qual_len : (const uint32_t *)(d_blobres + Z.blob_job);
-                    st.codec = trial_codecs[k]; st.out_cap = gz_codec_est_size (st.codec, 99999);
-                    if (!(st.out = (uint8_t *)ws_alloc (f, (size_t)st.out_cap + 64))) return GZ_ERR_HIP;
-                    trial.push_back (st);
-                }
-                trial_ctx.push_back (c); trial_domq.push_back (as_domq);
-            }
-        }
-    if (!trial.empty ()) {
-        ZCHK (gz_wait_for (f->h2, h));
-        if ((rc = gz_codec_compress_batch (f->h2, trial.data (), (int)trial.size ())) != GZ_OK) { h->err = f->h2->err; return rc; }
-    }
+    // (not decided yet whether QUAL goes through DOMQ: both forms are tried, the read-back says which one counts)
+    if (want_trial && qmode0) ZCHK (add_trials (K.domq[0].out[0], (const uint32_t *)&d_domqres[0].qual_len, 1));
     // (the items of line 1 and the VBlock statistics are only needed from here on: queued behind the QUAL gather, which the long pole waits for)
     ZCHK (gz_tokenize_column_n (h, text, l1_off, l1_len, R, f->plan.seps, f->plan.sep_counts, f->plan.n_seps, item_off, item_len, &d_a->n_bad_items));
     hipLaunchKernelGGL (k_vb_stats, dim3 (NV), dim3 (256), 2048, h->stream, (const uint32_t *)line_off, (const uint32_t *)seq_len, (const uint32_t *)d_first_line,
