@@ -293,8 +293,8 @@ __device__ static __forceinline__ void d_model_batch (GzModel<J> &M, uint32_t &t
 //   k_ctx_count    per tile of 4096 positions: how many positions each context has in it (LDS counters)
 //   k_ctx_scan     per leaf: tile/context counts -> start index of every (tile, context) in the sorted order
 //   k_ctx_scatter  per tile, one wave walking it 64 positions at a time: index = running count of my context (an LDS
-//                  gather) + my rank among the lanes of this group with the same context (one ballot per distinct
-//                  context in the group)
+//                  gather) + my rank among the lanes of this group with the same context (a ballot per bit of the
+//                  context number: the lanes that agree with me on all of them)
 // The chunk size of the model / chain pipeline is a multiple of the tile size, and every position chunk is sorted on its
 // own (into entries [p0, p1) of the lists) right before its models run: the sort of chunk k+1 hides behind the chain of chunk k.
 #define GZ_CTX_TILE 4096u
@@ -368,6 +368,8 @@ __global__ void __launch_bounds__(64) k_ctx_scatter (GzdLeaf *leaves, const uint
     __syncthreads ();
     const uint8_t *in = L.coded, *ev_sym = L.ev_sym; const uint16_t *ev_ctx = L.ev_ctx;
     uint32_t *spos = L.spos; uint8_t *srk = L.srk;
+    const uint32_t cbits = nctx > 256 ? 10 : 8;
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0;
     // (the bytes of the next group are requested before this group is worked on)
     uint32_t nx_c = 0xffffffffu, nx_s = 0;
     if (t0 + lane < n) { nx_c = d_ctx_of (L, in, ev_ctx, t0 + lane); nx_s = ev_sym ? ev_sym[t0 + lane] : in[t0 + lane]; }
@@ -378,13 +380,16 @@ __global__ void __launch_bounds__(64) k_ctx_scatter (GzdLeaf *leaves, const uint
         nx_c = 0xffffffffu;
         if (g + 64 < GZ_CTX_TILE && pos + 64 < n) { nx_c = d_ctx_of (L, in, ev_ctx, pos + 64); nx_s = ev_sym ? ev_sym[pos + 64] : in[pos + 64]; }
         const uint32_t base = valid ? cnt[c] : 0u;
-        uint32_t within = 0;
-        for (uint64_t rem = __ballot (valid); rem; ) {
-            const uint32_t q = d_readlane (c, __ffsll ((unsigned long long)rem) - 1);
-            const uint64_t mb = __ballot (c == q);
-            rem &= ~mb;
-            within = (c == q) ? gz_mbcnt (mb) : within;
+        // my rank among the lanes of this group with my context: the lanes that agree with me on every bit of the context number
+        // (a ballot per BIT - 8, or 10 for the run-length variant's 514 models - where the first version took one per DISTINCT
+        //  context of the group, ~30 in a quality stream)
+        uint64_t same = __ballot (valid);
+        for (uint32_t b = 0; b < cbits; b++) {
+            const bool one = (c >> b) & 1;
+            const uint64_t B = __ballot (one);
+            same &= one ? B : ~B;
         }
+        const uint32_t within = (uint32_t)__popcll (same & below);
         if (valid) {
             spos[base + within] = pos; srk[base + within] = ev_sym ? (uint8_t)s : rank_of[s];
             atomicAdd (&cnt[c], 1u);
