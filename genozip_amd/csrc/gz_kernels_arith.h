@@ -145,6 +145,45 @@ __device__ static __forceinline__ void d_model_serial_step (GzModel<J> &M, uint3
     }
 }
 
+// What a batch's occurrences add, from the list positions p of the pending ones (lanes of T): as an occurrence I need the number of
+// EARLIER pending occurrences at my position (eq), at a lower one (lt) and at my left neighbour's (eql); as list entries lane + 64 j I
+// need the number of ALL pending occurrences at my position (ceq[j]) and below it (clt[j]). One ballot per BIT of the position,
+// most significant first: the lanes that agree with a value on all higher bits and have a 0 where it has a 1 are the smaller ones;
+// the lanes left at the end are the equal ones. (The first version took one round per DISTINCT position of the batch - 20 in a
+// quality stream, 35 with a wide alphabet - at about the cost of one bit here.)
+template <int J>
+__device__ static __forceinline__ void d_batch_counts (uint32_t p, uint64_t T, uint32_t nbits, int lane, uint64_t below,
+                                                       uint32_t &eq, uint32_t &lt, uint32_t &eql, uint32_t (&ceq)[J], uint32_t (&clt)[J])
+{
+    const uint32_t q = p - 1;                                   // (p == 0: no left neighbour, the result is dropped)
+    uint64_t P = T, Q = T, Pe[J];
+    uint32_t l = 0;
+    #pragma unroll
+    for (int j = 0; j < J; j++) { Pe[j] = T; clt[j] = 0; }
+    for (int b = (int)nbits - 1; b >= 0; b--) {
+        const bool mine = (p >> b) & 1;
+        const uint64_t B = __ballot (mine), nB = ~B;
+        l += mine ? (uint32_t)__popcll (P & nB & below) : 0u;
+        P &= mine ? B : nB;
+        Q &= ((q >> b) & 1) ? B : nB;
+        #pragma unroll
+        for (int j = 0; j < J; j++) {
+            const bool em = ((uint32_t)(j * 64 + lane) >> b) & 1;
+            clt[j] += em ? (uint32_t)__popcll (Pe[j] & nB) : 0u;
+            Pe[j] &= em ? B : nB;
+        }
+    }
+    eq = (uint32_t)__popcll (P & below); lt = l; eql = p ? (uint32_t)__popcll (Q & below) : 0u;
+    #pragma unroll
+    for (int j = 0; j < J; j++) {
+        // (entries beyond the highest position a batch can hold agree with nobody only if their upper bits are looked at too)
+        const uint32_t e = (uint32_t)(j * 64 + lane);
+        const bool in_range = nbits >= 32 || (e >> nbits) == 0;
+        ceq[j] = in_range ? (uint32_t)__popcll (Pe[j]) : 0u;
+        clt[j] = in_range ? clt[j] : (uint32_t)__popcll (T);
+    }
+}
+
 // lanes 0 .. cnt-1 hold the next cnt occurrences of this context in stream order (rk = static rank of the symbol);
 // on return they hold the (cum, freq, tot) the coder must see for them.
 //
@@ -166,6 +205,8 @@ __device__ static __forceinline__ void d_model_batch (GzModel<J> &M, uint32_t &t
                                                       uint32_t n_absent, uint32_t &out_cum, uint32_t &out_freq, uint32_t &out_tot)
 {
     uint64_t todo = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
+    const uint32_t nbits = nsym > 1 ? 32u - (uint32_t)__builtin_clz (nsym - 1) : 0u;   // list positions are < nsym
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0;
     // (a model that has seen fewer than two occurrences per symbol is all ties: nearly every occurrence is an event, and
     //  one at a time is the cheaper way through them)
     const uint32_t settled = nsym + n_absent + 2 * GZ_MODEL_STEP * nsym;
@@ -179,21 +220,26 @@ __device__ static __forceinline__ void d_model_batch (GzModel<J> &M, uint32_t &t
             // as an occurrence I count the earlier occurrences at my position / below it / at my left neighbour; as
             // list entries lane + 64 j I count what the whole batch adds to my frequency and cumulative
             uint32_t eq = 0, lt = 0, eql = 0, ceq[J], clt[J];
-            #pragma unroll
-            for (int j = 0; j < J; j++) ceq[j] = clt[j] = 0;
-            for (uint64_t rem = todo; rem; ) {
-                const uint32_t q = d_readlane (p, __ffsll ((unsigned long long)rem) - 1);
-                const uint64_t mb = __ballot (p == q) & todo;
-                rem &= ~mb;
-                const uint32_t before = gz_mbcnt (mb), c = (uint32_t)__popcll (mb);
-                eq  += (q == p) ? before : 0u;
-                lt  += (q < p) ? before : 0u;
-                eql += (q + 1 == p) ? before : 0u;
+            if (J <= 2) d_batch_counts<J> (p, todo, nbits, lane, below, eq, lt, eql, ceq, clt);
+            else {
+                // (four planes: 8 bits x 62 operations cost more than a round per distinct position - measured on BAM's packed
+                //  qualities, whose batches hold ~10 distinct positions: 124 -> 134 ms per step with the ballots per bit)
                 #pragma unroll
-                for (int j = 0; j < J; j++) {
-                    const uint32_t e = (uint32_t)(j * 64 + lane);
-                    ceq[j] += (q == e) ? c : 0u;
-                    clt[j] += (q < e) ? c : 0u;
+                for (int j = 0; j < J; j++) ceq[j] = clt[j] = 0;
+                for (uint64_t rem = todo; rem; ) {
+                    const uint32_t q = d_readlane (p, __ffsll ((unsigned long long)rem) - 1);
+                    const uint64_t mb = __ballot (p == q) & todo;
+                    rem &= ~mb;
+                    const uint32_t before = gz_mbcnt (mb), c = (uint32_t)__popcll (mb);
+                    eq  += (q == p) ? before : 0u;
+                    lt  += (q < p) ? before : 0u;
+                    eql += (q + 1 == p) ? before : 0u;
+                    #pragma unroll
+                    for (int j = 0; j < J; j++) {
+                        const uint32_t e = (uint32_t)(j * 64 + lane);
+                        ceq[j] += (q == e) ? c : 0u;
+                        clt[j] += (q < e) ? c : 0u;
+                    }
                 }
             }
             const uint32_t f = F + GZ_MODEL_STEP * eq, tj = tot + GZ_MODEL_STEP * gz_mbcnt (todo);
@@ -254,20 +300,8 @@ __device__ static __forceinline__ void d_model_batch (GzModel<J> &M, uint32_t &t
                 }
             }
             if (halve_m) {                                                  // commit the prefix only: recount it
-                #pragma unroll
-                for (int j = 0; j < J; j++) ceq[j] = clt[j] = 0;
-                for (uint64_t rem = acc; rem; ) {
-                    const uint32_t q = d_readlane (p, __ffsll ((unsigned long long)rem) - 1);
-                    const uint64_t mb = __ballot (p == q) & acc;
-                    rem &= ~mb;
-                    const uint32_t c = (uint32_t)__popcll (mb);
-                    #pragma unroll
-                    for (int j = 0; j < J; j++) {
-                        const uint32_t e = (uint32_t)(j * 64 + lane);
-                        ceq[j] += (q == e) ? c : 0u;
-                        clt[j] += (q < e) ? c : 0u;
-                    }
-                }
+                uint32_t d0, d1, d2;
+                d_batch_counts<J> (p, acc, nbits, lane, below, d0, d1, d2, ceq, clt);
             }
             if ((acc >> lane) & 1) { out_cum = cu; out_freq = f; out_tot = tj; }
             #pragma unroll
