@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--stream-reads", type=int, default=0, help="stream this many read pairs per rank through one file (configs[4] at reduced scale)")
     ap.add_argument("--batch-pairs", type=int, default=112, help="VBlock pairs per call in --stream-reads mode (112 x 2 x 16 MiB = 3.76 GB: a call takes < 4 GB of text; "
                     "the more VBlocks a call holds, the better the long chains are hidden: 32 -> 5.6 GB/s, 64 -> 10.2, 112 -> 15.5)")
+    ap.add_argument("--two-in-flight", action="store_true", help="--stream-reads: two calls in flight (gz_fastq_zip_begin / _end) instead of one at a time. Measured: no gain at 112 pairs "
+                    "per call (15.5 -> 14.0 GB/s) - with 224 long streams per call the model kernels already fill the device; it helps small calls")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--pin-codecs", action="store_true", help="hard-code the codecs codec_assign_best_codec picks for this workload (profiling runs: no trial compressions in the step)")
     return ap.parse_args()
@@ -144,6 +146,7 @@ class Workload:
                     c["lcodec"], c["bcodec"] = p
         self.F = E.zip_open(self.plan)
         self.tab = self.F.vb_table(self.vb)
+        self.tab2 = None
         self.zbuf = None
         self.offs = None
         self.calls_per_step = 1 if not a.stream_reads else max(1, -(-self.n_pairs_file // len(ranges)))
@@ -152,19 +155,38 @@ class Workload:
         from genozip_amd.shard import zip_vblocks_sharded
         F, n = self.F, len(self.vb)
         F.reset()
-        for call in range(self.calls_per_step):
-            if call:
-                for t in self.tab:                                 # the next stretch of the stream: same text, later VBlocks
-                    t.vblock_i += 2 * self.n_pairs_file
-            zip_vblocks_sharded(F, dist if self.a.scaling == "strong" else None, self.text, self.text_len, self.tab, n)
-        if self.calls_per_step > 1:
-            for t, v in zip(self.tab, self.vb):
-                t.vblock_i = v[2]
-        total = sum(t.z_len for t in self.tab)
+        if self.calls_per_step > 1 and not (self.a.scaling == "strong" and dist is not None) and self.a.two_in_flight:
+            # the stream: two calls in flight (gz_fastq_zip_begin / _end) - the next call's seg / merge and coders run beside the
+            # previous call's long chains; the same text stands for the next stretch of the file, with later vblock_i
+            if self.tab2 is None:
+                self.tab2 = F.vb_table(self.vb)
+            tabs, in_flight = (self.tab, self.tab2), 0
+            for call in range(self.calls_per_step):
+                t = tabs[call % 2]
+                if in_flight == 2:
+                    F.end(); in_flight -= 1
+                for e, v in zip(t, self.vb):
+                    e.vblock_i = v[2] + 2 * self.n_pairs_file * call
+                F.begin(self.text, self.text_len, t, n); in_flight += 1
+            while in_flight:
+                F.end(); in_flight -= 1
+            last = tabs[(self.calls_per_step - 1) % 2]
+        else:
+            for call in range(self.calls_per_step):
+                if call:
+                    for t in self.tab:                             # the next stretch of the stream: same text, later VBlocks
+                        t.vblock_i += 2 * self.n_pairs_file
+                zip_vblocks_sharded(F, dist if self.a.scaling == "strong" else None, self.text, self.text_len, self.tab, n)
+            last = self.tab
+            if self.calls_per_step > 1:
+                for t, v in zip(self.tab, self.vb):
+                    t.vblock_i = v[2]
+        self.last_tab = last
+        total = sum(t.z_len for t in last)
         if self.zbuf is None or self.zbuf.numel() < total + 64:
             import torch
             self.zbuf = torch.empty(int(total * 1.05) + 4096, dtype=torch.uint8, device=self.text.device)
-        self.offs = F.collect(self.tab, n, self.zbuf, self.zbuf.numel())
+        self.offs = F.collect(last, n, self.zbuf, self.zbuf.numel())
         return self.offs[-1]
 
 

@@ -134,6 +134,18 @@ class ZipFile:
         if rc != GZ_OK:
             raise GenozipAMDError("gz_fastq_zip_vblocks failed (%d): %s" % (rc, self.E.L.gz_last_error(self.E.h).decode()))
 
+    def begin(self, text_buf, text_len, tab, n):
+        """gz_fastq_zip_vblocks without its last wait (up to two calls in flight; text_buf and tab must stay alive until end())"""
+        rc = self.E.L.gz_fastq_zip_begin(self.f, self.E.mem.ptr(text_buf), text_len, tab, n)
+        if rc != GZ_OK:
+            raise GenozipAMDError("gz_fastq_zip_begin failed (%d): %s" % (rc, self.E.L.gz_last_error(self.E.h).decode()))
+
+    def end(self):
+        """waits for the oldest call begun; its table holds the results"""
+        rc = self.E.L.gz_fastq_zip_end(self.f)
+        if rc != GZ_OK:
+            raise GenozipAMDError("gz_fastq_zip_end failed (%d): %s" % (rc, self.E.L.gz_last_error(self.E.h).decode()))
+
     def reset(self):
         self.E._check(self.E.L.gz_zip_reset(self.f), "gz_zip_reset")
 

@@ -83,6 +83,7 @@ struct ZipCall {                   // what lives between the phases of one call
     GzDynIntResult *d_dynres = NULL; uint32_t *d_seclen = NULL; int32_t *d_b250st = NULL;
     std::vector<uint8_t> blob;      // this process' merge blob
     std::vector<ZipVote> votes;
+    std::vector<GzVBlock> V; std::vector<std::vector<GzSection>> secs; std::vector<int32_t> b250st;   // phase 3, between launch and wait
     std::vector<ZipDomq> domq;                 // per VBlock, when the file's QUAL may go / goes through CODEC_DOMQ
     int qual_mode_applied = -1;
     std::vector<GzStream> early;               // the streams coded ahead (results arrive when the second handle is synchronised)
@@ -108,7 +109,21 @@ struct GzZipFile {
     hipEvent_t ev_early = NULL;
     uint8_t *pinned = NULL; size_t pinned_size = 0;      // host memory the device can write while the host does something else
     ZipCall call;
+    // ---- two calls in flight (gz_fastq_zip_begin / _end): everything above that belongs to ONE call - the handles its work is
+    // queued on, its workspace, its staging memory, its state - exists twice; `other` holds the set that is not the current one
+    // (the older call while two are in flight). The file-level state (dictionaries, codecs, vblock_i) is one.
+    struct Lane { GzHandle *h = NULL, *h2 = NULL; std::vector<ArenaBlock> ws; std::vector<uint8_t> stage; hipEvent_t ev_early = NULL;
+                  uint8_t *pinned = NULL; size_t pinned_size = 0; ZipCall call; bool busy = false; } other;
+    bool busy = false, other_made = false;
+    GzHandle *h_user = NULL;                             // the handle the file was opened on (owns the profile of all of them)
 };
+
+static void zip_swap_lanes (GzZipFile *f)
+{
+    std::swap (f->h, f->other.h); std::swap (f->h2, f->other.h2); f->ws.swap (f->other.ws); f->stage.swap (f->other.stage);
+    std::swap (f->ev_early, f->other.ev_early); std::swap (f->pinned, f->other.pinned); std::swap (f->pinned_size, f->other.pinned_size);
+    std::swap (f->call, f->other.call); std::swap (f->busy, f->other.busy);
+}
 
 static uint8_t *zip_pinned (GzZipFile *f, size_t bytes)
 {
@@ -160,7 +175,7 @@ extern "C" GzZipFile *gz_zip_open (GzHandle *h, const GzFastqPlan *plan)
 {
     if (!h || !plan || !plan->ctxs || !plan->n_ctxs || plan->n_seps > GZ_TOK_MAX_SEPS) return NULL;
     GzZipFile *f = new GzZipFile ();
-    f->h = h; f->plan = *plan;
+    f->h = h; f->h_user = h; f->plan = *plan;
     f->ctxs.assign (plan->ctxs, plan->ctxs + plan->n_ctxs);
     f->snips.resize (plan->n_ctxs);
     for (uint32_t i = 0; i < plan->n_ctxs; i++) {
@@ -185,18 +200,22 @@ extern "C" GzZipFile *gz_zip_open (GzHandle *h, const GzFastqPlan *plan)
 extern "C" void gz_zip_close (GzZipFile *f)
 {
     if (!f) return;
-    (void)hipSetDevice (f->h->device);
-    (void)gz_sync (f->h);
-    if (f->h2) {
-        (void)gz_sync (f->h2);
-        auto &hl = f->h->helpers;
-        hl.erase (std::remove (hl.begin (), hl.end (), f->h2), hl.end ());
-        gz_destroy (f->h2);
+    (void)hipSetDevice (f->h_user->device);
+    for (int lane = 0; lane < 2; lane++) {
+        if (f->h) {
+            (void)gz_sync (f->h);
+            if (f->h2) (void)gz_sync (f->h2);
+            auto &hl = f->h_user->helpers;
+            for (GzHandle *o : { f->h2, f->h == f->h_user ? (GzHandle *)NULL : f->h })
+                if (o) { hl.erase (std::remove (hl.begin (), hl.end (), o), hl.end ()); gz_destroy (o); }
+            if (f->pinned) (void)hipHostFree (f->pinned);
+            if (f->ev_early) (void)hipEventDestroy (f->ev_early);
+            for (auto &b : f->ws) (void)hipFree (b.base);
+            f->h = f->h2 = NULL; f->pinned = NULL; f->ev_early = NULL; f->ws.clear ();
+        }
+        zip_swap_lanes (f);
     }
-    if (f->pinned) (void)hipHostFree (f->pinned);
-    if (f->ev_early) (void)hipEventDestroy (f->ev_early);
     for (auto z : f->zctx) gz_zctx_destroy (z);
-    for (auto &b : f->ws) (void)hipFree (b.base);
     delete f;
 }
 
@@ -204,8 +223,14 @@ extern "C" void gz_zip_close (GzZipFile *f)
 extern "C" int gz_zip_reset (GzZipFile *f)
 {
     if (!f) return GZ_ERR_ARG;
-    int rc = gz_sync (f->h);
-    if (f->h2) { const int rc2 = gz_sync (f->h2); if (rc >= 0 && rc2 < 0) rc = rc2; }   // (a call that failed half way may have left work there)
+    int rc = GZ_OK;
+    for (int lane = 0; lane < 2; lane++) {                 // (a call that failed half way, or was never ended, may have left work anywhere)
+        if (f->h) { const int r1 = gz_sync (f->h); if (rc >= 0 && r1 < 0) rc = r1; }
+        if (f->h2) { const int r2 = gz_sync (f->h2); if (rc >= 0 && r2 < 0) rc = r2; }
+        f->call = ZipCall (); f->busy = false;
+        zip_swap_lanes (f);
+    }
+    if (f->h != f->h_user) zip_swap_lanes (f);             // (start again on the caller's handle)
     if (rc < 0) return rc;
     for (size_t i = 0; i < f->zctx.size (); i++) {
         gz_zctx_destroy (f->zctx[i]);
@@ -1150,7 +1175,16 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
 // phase 3: commit the codecs (lowest vblock_i wins, as in a serial run: codec.c:352-363), then the sections of this process'
 // VBlocks in the reference's order (a15), compressed and framed (a9-a13, a16)
 // ---------------------------------------------------------------------------------------------------------
+static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint64_t *votes_lens, int n_votes);
+static int zip_finish_wait (GzZipFile *f);
 extern "C" int gz_fastq_zip_finish (GzZipFile *f, const void *const *votes, const uint64_t *votes_lens, int n_votes)
+{
+    const int rc = zip_finish_launch (f, votes, votes_lens, n_votes);
+    if (rc != GZ_OK) return rc;
+    return zip_finish_wait (f);
+}
+
+static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint64_t *votes_lens, int n_votes)
 {
     if (!f || f->call.phase != 2 || n_votes < 0 || (n_votes && (!votes || !votes_lens))) return GZ_ERR_ARG;
     GzHandle *h = f->h;
@@ -1184,8 +1218,9 @@ extern "C" int gz_fastq_zip_finish (GzZipFile *f, const void *const *votes, cons
             for (uint32_t v = 0; v < NV; v++) { ZipCol &Z = COL (v, w.first.first); if (w.first.second) { if (!Z.lcodec) Z.lcodec = (uint8_t)w.second.codec; } else if (!Z.bcodec) Z.bcodec = (uint8_t)w.second.codec; }
         }
     }
-    std::vector<GzVBlock> V (NV);
-    std::vector<std::vector<GzSection>> secs (NV);
+    K.V.assign (NV, GzVBlock ()); K.secs.assign (NV, std::vector<GzSection> ());
+    std::vector<GzVBlock> &V = K.V;
+    std::vector<std::vector<GzSection>> &secs = K.secs;
     for (uint32_t v = 0; v < NV; v++) {
         const bool is_r2 = vbs[v].r1 >= 0, is_r1 = f->plan.paired && !is_r2;
         std::vector<GzSecOrderIn> in (NC);
@@ -1240,9 +1275,27 @@ extern "C" int gz_fastq_zip_finish (GzZipFile *f, const void *const *votes, cons
     if (!K.early.empty ()) ZCHK (gz_emit_after (h, f->h2));
     ZCHK (gz_vb_compress_batch (h, V.data (), (int)NV));
     T.mark ("compress-queue");
-    std::vector<int32_t> b250st ((size_t)NV * NC, 1);
-    HIPCHK (h, hipMemcpyAsync (b250st.data (), K.d_b250st, b250st.size () * 4, hipMemcpyDeviceToHost, h->stream));
-    rc = gz_sync (h);
+    K.b250st.assign ((size_t)NV * NC, 1);
+    HIPCHK (h, hipMemcpyAsync (K.b250st.data (), K.d_b250st, K.b250st.size () * 4, hipMemcpyDeviceToHost, h->stream));
+    K.phase = 3;
+    T.done ("finish (queued)");
+    (void)rc;
+    return GZ_OK;
+}
+
+// the rest of phase 3: wait for the coders, results into the caller's VBlock table
+static int zip_finish_wait (GzZipFile *f)
+{
+    if (!f || f->call.phase != 3) return GZ_ERR_ARG;
+    GzHandle *h = f->h;
+    ZipCall &K = f->call;
+    GzFastqVB *vbs = K.vbs;
+    const uint32_t NC = (uint32_t)f->ctxs.size (), NV = K.NV;
+    auto COL = [&] (uint32_t v, uint32_t c) -> ZipCol & { return K.col[(size_t)v * NC + c]; };
+    std::vector<GzVBlock> &V = K.V;
+    const std::vector<int32_t> &b250st = K.b250st;
+    ZipTimer T;
+    int rc = gz_sync (h);
     K.phase = 0;
     if (!K.early.empty ()) {
         const int rc2 = gz_sync (f->h2);
@@ -1267,6 +1320,58 @@ extern "C" int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_
     if ((rc = gz_fastq_zip_seg (f, text, text_len, vbs, n_vbs, &blob, &blob_len)) != GZ_OK) return rc;
     if ((rc = gz_fastq_zip_merge (f, &blob, &blob_len, 1, &votes, &votes_len)) != GZ_OK) return rc;
     return gz_fastq_zip_finish (f, &votes, &votes_len, 1);
+}
+
+// ---- two calls in flight ---------------------------------------------------------------------------------------------------------
+// A stream of calls on one file (BASELINE configs[4]): the next call's seg and merge phases - and its coders - run while the
+// previous call's long chains are still at work. What the reference gets from its pool of compute threads (VBlocks of different
+// ages in flight, merging in order) is here two sets of handles / workspace taking turns. The order of the merges, and with it
+// every dictionary and every byte written, is the same as with one call at a time.
+static int zip_make_other_lane (GzZipFile *f)
+{
+    if (f->other_made) return GZ_OK;
+    int err = 0;
+    GzHandle *hb = gz_create (f->h_user->device, NULL, &err);
+    if (!hb) { f->h_user->err = "gz_create failed (second lane)"; return err < 0 ? err : GZ_ERR_HIP; }
+    hb->profiling = f->h_user->profiling; f->h_user->helpers.push_back (hb);
+    f->other.h = hb;
+    if (f->h2) {                                           // (no second handle with GZ_ZIP_NO_OVERLAP)
+        f->other.h2 = gz_create_background (f->h_user->device, &err);
+        if (f->other.h2) { f->other.h2->profiling = f->h_user->profiling; f->h_user->helpers.push_back (f->other.h2); }
+    }
+    f->other_made = true;
+    return GZ_OK;
+}
+
+extern "C" int gz_fastq_zip_begin (GzZipFile *f, uint8_t *text, uint64_t text_len, GzFastqVB *vbs, int n_vbs)
+{
+    if (!f) return GZ_ERR_ARG;
+    if (f->busy) { f->h->err = "two calls are in flight already: gz_fastq_zip_end first"; return GZ_ERR_ARG; }
+    const void *blob, *votes; uint64_t blob_len, votes_len;
+    int rc;
+    if ((rc = gz_fastq_zip_seg (f, text, text_len, vbs, n_vbs, &blob, &blob_len)) != GZ_OK
+        || (rc = gz_fastq_zip_merge (f, &blob, &blob_len, 1, &votes, &votes_len)) != GZ_OK
+        || (rc = zip_finish_launch (f, &votes, &votes_len, 1)) != GZ_OK) {
+        if (f->h != f->h_user) f->h_user->err = f->h->err;       // (gz_last_error is asked of the handle the file was opened on)
+        return rc;
+    }
+    f->busy = true;
+    if (!f->other.busy) {                                  // the other set is free: the next call is built there
+        if ((rc = zip_make_other_lane (f)) != GZ_OK) return GZ_OK;     // (no second set: the next begin will ask for an end first)
+        zip_swap_lanes (f);
+    }
+    return GZ_OK;
+}
+
+extern "C" int gz_fastq_zip_end (GzZipFile *f)
+{
+    if (!f) return GZ_ERR_ARG;
+    if (f->other.busy) zip_swap_lanes (f);                 // the older call
+    if (!f->busy) { f->h->err = "no call in flight"; return GZ_ERR_ARG; }
+    const int rc = zip_finish_wait (f);
+    f->busy = false;
+    if (rc != GZ_OK && f->h != f->h_user) f->h_user->err = f->h->err;
+    return rc;
 }
 
 // ---- N1 for VCF ----------------------------------------------------------------------------------------------------------------

@@ -479,6 +479,13 @@ int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_len, GzFast
 int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len, GzFastqVB *vbs, int n_vbs, const void **blob_out, uint64_t *blob_len_out);
 int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const uint64_t *blob_lens, int n_blobs, const void **votes_out, uint64_t *votes_len_out);
 int gz_fastq_zip_finish (GzZipFile *f, const void *const *votes, const uint64_t *votes_lens, int n_votes);
+/* The same with up to TWO calls in flight, for a stream of calls on one file: _begin = gz_fastq_zip_vblocks without its last wait
+ * (text, vbs and what vbs points at must stay as they are until the call has been ended); _end waits for the OLDEST call begun and
+ * fills in its vbs[] (z_data valid until that set of buffers is used again: two calls later). The next call's seg and merge phases
+ * and its coders run while the previous call's long streams are still being coded - the reference's VBlocks of different ages in
+ * flight on its compute threads. Merges happen in the order of the begins: the bytes are those of one call at a time. */
+int gz_fastq_zip_begin (GzZipFile *f, uint8_t *text, uint64_t text_len, GzFastqVB *vbs, int n_vbs);
+int gz_fastq_zip_end (GzZipFile *f);
 /* a new file with the same plan (fresh dictionaries and codecs; the device workspace is kept) */
 int gz_zip_reset (GzZipFile *f);
 /* the z_data of the last call's VBlocks one after the other into dst (device) - what is handed to the writer

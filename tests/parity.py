@@ -1203,3 +1203,39 @@ def fastq_zip_errors(E, oracle):
     except GenozipAMDError:
         pass
     F.close()
+
+
+def fastq_zip_two_in_flight(E, oracle, n_reads, n_calls=5):
+    """a stream of calls on one file with two of them in flight (gz_fastq_zip_begin / _end) == the same calls one at a time, byte
+    for byte, dictionaries included: the merges happen in the order of the begins"""
+    from genozip_amd import fastq as fq
+    texts, tabs_vbs, vb_i = [], [], 0
+    for call in range(n_calls):
+        nr = n_reads if call % 2 == 0 else max(8, n_reads // 2)
+        r1 = fastq_text(nr, seed=700 + call, mate=1, qual="bin" if call == 3 else "uniform")
+        r2 = fastq_text(nr, seed=700 + call, mate=2, qual_seed=800 + call, qual="bin" if call == 3 else "uniform")
+        texts.append(r1 + r2)
+        tabs_vbs.append([(0, len(r1), vb_i + 1, -1), (len(r1), len(r2), vb_i + 2, 0)])
+        vb_i += 2
+    F = E.zip_open(fq.illumina_plan(paired=True))
+    one = [[r["z"] for r in F.zip_vblocks(t, v)] for t, v in zip(texts, tabs_vbs)]
+    words_one = [F.zctx_words(c) for c in range(len(F.plan["ctxs"]))]
+    F.close()
+    F = E.zip_open(fq.illumina_plan(paired=True))
+    bufs = [E.mem.upload(t + b"\0" * 32) for t in texts]
+    tabs = [F.vb_table(v) for v in tabs_vbs]
+    got, in_flight = [None] * n_calls, []
+    for k in range(n_calls):
+        if len(in_flight) == 2:
+            j = in_flight.pop(0); F.end(); got[j] = [r["z"] for r in F.results(tabs[j])]
+        F.begin(bufs[k], len(texts[k]), tabs[k], len(tabs_vbs[k])); in_flight.append(k)
+    while in_flight:
+        j = in_flight.pop(0); F.end(); got[j] = [r["z"] for r in F.results(tabs[j])]
+    assert got == one
+    assert [F.zctx_words(c) for c in range(len(F.plan["ctxs"]))] == words_one
+    # the ordinary call still works on the same object, and a reset with a call in flight leaves a usable object
+    F.reset()
+    F.begin(bufs[0], len(texts[0]), tabs[0], 2)
+    F.reset()
+    assert [r["z"] for r in F.zip_vblocks(texts[0], tabs_vbs[0])] == one[0]
+    F.close()

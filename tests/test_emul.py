@@ -107,6 +107,10 @@ def test_emul_fastq_zip(emul_engine, oracle):
     parity.fastq_zip(emul_engine, oracle, 200)
 
 
+def test_emul_fastq_zip_two_in_flight(emul_engine, oracle):
+    parity.fastq_zip_two_in_flight(emul_engine, oracle, 60)
+
+
 def test_emul_fastq_zip_errors(emul_engine, oracle):
     parity.fastq_zip_errors(emul_engine, oracle)
 

@@ -108,6 +108,10 @@ def test_fastq_zip_driver(gpu_engine, oracle):
     parity.fastq_zip(gpu_engine, oracle, 1000, n_calls=1, qual=("bin",), domq=1)
 
 
+def test_fastq_zip_two_in_flight(gpu_engine, oracle):
+    parity.fastq_zip_two_in_flight(gpu_engine, oracle, 4000)
+
+
 def test_fastq_zip_errors(gpu_engine, oracle):
     parity.fastq_zip_errors(gpu_engine, oracle)
 
@@ -240,7 +244,7 @@ def _bench_workload(gpu_engine, **kw):
     import argparse
     import torch
     import bench
-    a = argparse.Namespace(pairs=1000000, vb_mb=16, qual="div", scaling="weak", stream_reads=0, batch_pairs=64, pin_codecs=False)
+    a = argparse.Namespace(pairs=1000000, vb_mb=16, qual="div", scaling="weak", stream_reads=0, batch_pairs=64, pin_codecs=False, two_in_flight=False)
     for k, v in kw.items():
         setattr(a, k, v)
     return bench, bench.Workload(gpu_engine, a, 0, 1, torch.device("cuda", 0))
