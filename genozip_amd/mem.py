@@ -19,7 +19,10 @@ class TorchMem:
         arr = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data.view(np.uint8).reshape(-1)
         if arr.size == 0:
             return self.alloc(1)
-        return self.torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+        arr = np.ascontiguousarray(arr)
+        if not arr.flags.writeable:                      # (bytes objects give read-only views; torch wants to own a writable array)
+            arr = arr.copy()
+        return self.torch.from_numpy(arr).to(self.device)
 
     @staticmethod
     def ptr(buf):
