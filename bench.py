@@ -136,7 +136,7 @@ class Workload:
         torch.cuda.synchronize()
         PIN = {"div": {"QUAL": 16, "Q1NAME": (8, 0), "Q2NAME": (0, 16), "Q3NAME": (17, 0), "Q4NAME": (17, 0)},
                "bin": {"QUAL": 18, "Q1NAME": (8, 0), "Q2NAME": (0, 16), "Q3NAME": (17, 0), "Q4NAME": (17, 0)}}
-        self.plan = fq.illumina_plan(paired=True)
+        self.plan = fq.illumina_plan(paired=True, vb_size=vb_bytes(a))       # (a file's last, short VBlock does not set codecs: codec.c:352)
         if a.pin_codecs:
             for c in self.plan["ctxs"]:
                 p = PIN[a.qual].get(c["tag"])

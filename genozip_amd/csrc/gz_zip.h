@@ -67,7 +67,12 @@ struct ZipMergeRec {
 };
 // qual: bit 0 the VBlock's QUAL was tested, bit 1 it is a fit for DOMQ (codec_domq.c:69-134), bit 2 a score outside ' '..'~'
 struct ZipBlobVB { uint32_t vblock_i, r1_vblock_i, n_ctx, qual; };   // then n_ctx x (ZipMergeRec + payload)
+// is_local: 0 b250, 1 local; | 2: the VBlock is too small to set the file's codec (codec.c:352) - its choice holds for itself only
 struct ZipVote { uint32_t ctx, is_local, vblock_i, codec; };
+static inline bool zip_vb_commits (const GzFastqPlan &plan, const GzFastqVB &vb)
+{
+    return !plan.vb_size || vb.text_len > std::min<uint64_t> ((uint64_t)4 << 20, plan.vb_size / 2);
+}
 
 struct ZipVBState { std::vector<uint8_t> has_b250, has_local; std::vector<std::vector<uint8_t>> host_b250; };
 struct ZipDomq { uint8_t *out[4] = { NULL, NULL, NULL, NULL }; GzDomqResult res; uint32_t fit = 0; std::vector<uint8_t> snip; };   // one VBlock's QUAL through k_domq
@@ -654,7 +659,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     std::vector<uint32_t> trial_ctx; std::vector<int> trial_domq;
     const bool own_first = vbs[0].vblock_i == f->last_vblock_i + 1;   // (vblock_i are consecutive over the processes: this one opens the call)
     bool want_trial = false;
-    if (f->h2 && own_first && f->qual_ctx >= 0 && vbs[0].n_reads) { GzZctxView zv; gz_zctx_view (f->zctx[f->qual_ctx], &zv); want_trial = !zv.lcodec; }
+    if (f->h2 && own_first && f->qual_ctx >= 0 && vbs[0].n_reads && zip_vb_commits (f->plan, vbs[0])) { GzZctxView zv; gz_zctx_view (f->zctx[f->qual_ctx], &zv); want_trial = !zv.lcodec; }
     auto add_trials = [&] (const uint8_t *in, const uint32_t *len_dev, int as_domq) -> int {
         const size_t first = trial.size ();
         for (int k = 0; k < 8; k++) {
@@ -1156,7 +1161,11 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
                         uint32_t L = 0; const uint8_t *p = NULL;
                         if (is_local && Z.has_local) { p = Z.local; L = Z.dyn_job >= 0 ? seclen[2 * ((size_t)v * NC + c)] : (uint32_t)Z.local_len; }
                         if (!is_local && Z.has_b250) { p = Z.sec_b250; L = Z.col_job >= 0 ? seclen[2 * ((size_t)v * NC + c) + 1] : Z.sec_b250_len; }
-                        if (L >= 50) { ptr.push_back (p); len.push_back (L); who.push_back ({ c, is_local, vbs[v].vblock_i, 0 }); break; }
+                        if (L < 50) continue;
+                        // a VBlock too small to speak for the file keeps its choice to itself, and the next one tests again (codec.c:352)
+                        const bool commits = zip_vb_commits (f->plan, vbs[v]);
+                        ptr.push_back (p); len.push_back (L); who.push_back ({ c, is_local | (commits ? 0u : 2u), vbs[v].vblock_i, 0 });
+                        if (commits) break;
                     }
                 }
             }
@@ -1196,15 +1205,14 @@ static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint
     const uint8_t ATS = 0x20, PAIRED = 0x04;
     int rc;
     ZipTimer T;
-    uint32_t qual_lcodec_voter = 0xffffffffu;      // the VBlock whose vote gave QUAL's stream its coder in this call
-    if (f->qual_ctx >= 0) { GzZctxView zv; gz_zctx_view (f->zctx[f->qual_ctx], &zv); if (zv.lcodec) qual_lcodec_voter = 0; }   // (known before the call)
     {
         std::map<std::pair<uint32_t, uint32_t>, ZipVote> win;
         for (int b = 0; b < n_votes; b++) {
             if (votes_lens[b] % sizeof (ZipVote)) { h->err = "votes: size"; return GZ_ERR_ARG; }
             const ZipVote *vt = (const ZipVote *)votes[b];
             for (size_t k = 0; k < votes_lens[b] / sizeof (ZipVote); k++) {
-                if (vt[k].ctx >= NC || vt[k].is_local > 1) { h->err = "votes: context"; return GZ_ERR_ARG; }
+                if (vt[k].ctx >= NC || vt[k].is_local > 3) { h->err = "votes: context"; return GZ_ERR_ARG; }
+                if (vt[k].is_local & 2) continue;                         // (a small VBlock's own choice: below)
                 auto key = std::make_pair (vt[k].ctx, vt[k].is_local);
                 auto it = win.find (key);
                 if (it == win.end () || vt[k].vblock_i < it->second.vblock_i) win[key] = vt[k];
@@ -1213,9 +1221,16 @@ static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint
         for (auto &w : win) {
             GzZctxView zv; gz_zctx_view (f->zctx[w.first.first], &zv);
             if (w.first.second ? zv.lcodec : zv.bcodec) continue;
-            if ((int)w.first.first == f->qual_ctx && w.first.second) qual_lcodec_voter = w.second.vblock_i;
             gz_zctx_commit_codec (f->zctx[w.first.first], (int)w.first.second, (int)w.second.codec);
-            for (uint32_t v = 0; v < NV; v++) { ZipCol &Z = COL (v, w.first.first); if (w.first.second) { if (!Z.lcodec) Z.lcodec = (uint8_t)w.second.codec; } else if (!Z.bcodec) Z.bcodec = (uint8_t)w.second.codec; }
+            // (a VBlock in front of the one that assigned finds nothing in the file, as in a serial run: it had < 50 bytes, or is small)
+            for (uint32_t v = 0; v < NV; v++) if (vbs[v].vblock_i >= w.second.vblock_i) {
+                ZipCol &Z = COL (v, w.first.first); if (w.first.second) { if (!Z.lcodec) Z.lcodec = (uint8_t)w.second.codec; } else if (!Z.bcodec) Z.bcodec = (uint8_t)w.second.codec; }
+        }
+        for (int b = 0; b < n_votes; b++) {
+            const ZipVote *vt = (const ZipVote *)votes[b];
+            for (size_t k = 0; k < votes_lens[b] / sizeof (ZipVote); k++) if (vt[k].is_local & 2)
+                for (uint32_t v = 0; v < NV; v++) if (vbs[v].vblock_i == vt[k].vblock_i) {
+                    ZipCol &Z = COL (v, vt[k].ctx); if (vt[k].is_local & 1) { if (!Z.lcodec) Z.lcodec = (uint8_t)vt[k].codec; } else if (!Z.bcodec) Z.bcodec = (uint8_t)vt[k].codec; }
         }
     }
     K.V.assign (NV, GzVBlock ()); K.secs.assign (NV, std::vector<GzSection> ());
@@ -1257,7 +1272,7 @@ static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint
                     // the stream's coder: the file's, as VBlock v would find it in a serial run (codec.c:280-281) - however short the
                     // stream; none known yet -> NONE; all lines diverse -> the single byte 'X', NONE (codec_domq.c:490-500)
                     s.hdr_codec = GZ_CODEC_DOMQ; s.param = (uint8_t)(K.domq[v].res.num_norm_qs | 0x80);
-                    if (K.domq[v].res.all_diverse || !s.codec || vbs[v].vblock_i < qual_lcodec_voter) s.codec = GZ_CODEC_NONE;
+                    if (K.domq[v].res.all_diverse || !s.codec) s.codec = GZ_CODEC_NONE;
                 }
                 const bool int_lt = Z.ltype >= GZ_LT_INT8 && Z.ltype <= GZ_LT_UINT64;
                 if (int_lt) s.b250_size_or_nothing_char = X.nothing_char ? X.nothing_char : 0xff;    // zfile.c:344-345

@@ -28,10 +28,11 @@ def dict_id(tag, dtype=DTYPE_FIELD):
 
 # did_i follow the order of the #pragma GENDICT lines of src/sam.h:19-86 (FASTQ shares SAM's Dids, src/fastq.h:13-60);
 # only their relative order matters here (sections appear in ascending did_i)
-def illumina_plan(paired=True, qual_codec=0, estimated_entries=0, domq=0):
+def illumina_plan(paired=True, qual_codec=0, estimated_entries=0, domq=0, vb_size=0):
     """-> list of dict(tag, dict_id, did_i, kind, item, flags, snip, ...) for GzFastqPlan.
     qual_codec: hard-coded coder of the QUAL stream (0: codec_assign_best_codec); domq: 0 the reference's own rule (the file's first
-    VBlock decides, codec.c:391-450), 1 (CODEC_NONE) --no-domqual, 13 (CODEC_DOMQ) --force-domq"""
+    VBlock decides, codec.c:391-450), 1 (CODEC_NONE) --no-domqual, 13 (CODEC_DOMQ) --force-domq; vb_size: segconf.vb_size (VBlocks
+    of at most MIN (4 MB, vb_size / 2) of text do not set codecs for the file, codec.c:352; 0: every VBlock may)"""
     P = []
 
     def ctx(tag, did_i, kind, dtype=DTYPE_FIELD, item=0, flags=0, snip=b"", pair_identical=False, no_stons=False, lcodec=0, bcodec=0,
@@ -61,7 +62,7 @@ def illumina_plan(paired=True, qual_codec=0, estimated_entries=0, domq=0):
     ctx("E2L", 97, GZ_FQ_CONST, snip=b"\n", pair_identical=pi)
     ctx("LINE3", 98, GZ_FQ_CONST, snip=b"", pair_identical=pi)        # replaced below: an empty line 3 is the snip ""
     P[-1]["snip"] = bytes([SNIP_SPECIAL]) + b"<line3 = empty>"
-    return dict(ctxs=P, seps=b":::: :+", sep_counts=[3, 1, 1, 1, 1, 3, 1], paired=paired, estimated_entries=estimated_entries, qual_codec=domq)
+    return dict(ctxs=P, seps=b":::: :+", sep_counts=[3, 1, 1, 1, 1, 3, 1], paired=paired, estimated_entries=estimated_entries, qual_codec=domq, vb_size=vb_size)
 
 
 def c_plan(plan):
@@ -83,4 +84,5 @@ def c_plan(plan):
     p.sep_counts = (C.c_uint8 * 16)(*(list(plan["sep_counts"]) + [0] * (16 - len(plan["sep_counts"]))))
     p.n_seps, p.paired, p.estimated_entries = len(plan["seps"]), int(plan["paired"]), plan["estimated_entries"]
     p.qual_codec = plan.get("qual_codec", 0)
+    p.vb_size = plan.get("vb_size", 0)
     return p, keep

@@ -449,6 +449,9 @@ typedef struct {
     uint8_t  paired;              /* --pair: R2 VBlocks name their R1 VBlock                                              */
     uint32_t estimated_entries;   /* hash_get_estimated_entries' figure for the dictionaries (0: default)                  */
     uint8_t  qual_codec;          /* 0: as the reference decides (above); GZ_CODEC_NONE: --no-domqual; GZ_CODEC_DOMQ: --force-domq    */
+    uint64_t vb_size;             /* segconf.vb_size, the size the caller cuts VBlocks to (src/segconf.c:152-206). A VBlock whose text is
+                                     not longer than MIN (4 MB, vb_size / 2) tests codecs for itself but does not set them for the
+                                     file (src/codec.c:352: "don't let tiny VBs set the codec for everyone"). 0: every VBlock may    */
 } GzFastqPlan;
 typedef struct {
     uint64_t text_off, text_len;  /* in: the VBlock's slice of the text: whole reads                                      */

@@ -761,19 +761,25 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
             st, R1 = S[v][c], S[r1][c]
             if X["pair_identical"] and st["has_b250"] and R1["b250_kept"] is not None and st["b250"] == R1["b250_kept"]:
                 st["drop_b250_section"] = True
-    voter = {}                                             # (context, is_local) -> the VBlock of this call that assigned the codec
+    # codec_assign_best_codec as the VBlocks of the call meet it one after the other (codec.c:280-281, 309-312, 352-363): the file's
+    # codec if there is one; else the VBlock's own test when it has >= 50 bytes - which it sets for the file unless it is a small
+    # VBlock ("don't let tiny VBs set the codec for everyone"); else nothing (-> RANB in the header, zfile.c:300,337)
+    vb_size = plan.get("vb_size", 0)
+    vcodec = {}                                            # (VBlock, context, is_local) -> codec
     for c, X in enumerate(C):
         for is_local in (1, 0):
             key = "lcodec" if is_local else "bcodec"
-            if zstate[key][c]:
-                continue
-            for v in range(n_vb):
+            for v, (off, ln, vi, r1) in enumerate(vbs):
                 st = S[v][c]
                 data = st["local"] if is_local else st.get("b250", b"")
-                if (st["has_local"] if is_local else st["has_b250"]) and len(data) >= 50:
-                    zstate[key][c] = oracle.assign_best(data)[0]
-                    voter[(c, is_local)] = v
-                    break
+                if zstate[key][c]:
+                    vcodec[(v, c, is_local)] = zstate[key][c]
+                elif (st["has_local"] if is_local else st["has_b250"]) and len(data) >= 50:
+                    vcodec[(v, c, is_local)] = oracle.assign_best(data)[0]
+                    if not vb_size or ln > min(4 << 20, vb_size // 2):
+                        zstate[key][c] = vcodec[(v, c, is_local)]
+                else:
+                    vcodec[(v, c, is_local)] = 0
     out = []
     for v, (off, ln, vi, r1) in enumerate(vbs):
         a, b = rng[v]
@@ -788,7 +794,7 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
                     continue
                 if (is_r1 and X["pair_identical"]) or (is_r2 and X["pair_assisted_b250"]):
                     flags |= 4
-                d = po.GzoCtxSectionDesc(vblock_i=vi, section_type=SEC_B250, codec=zstate["bcodec"][c] or 6, sub_codec=0, flags=flags, ltype=0, param=0, b250_size_or_nothing_char=4)
+                d = po.GzoCtxSectionDesc(vblock_i=vi, section_type=SEC_B250, codec=vcodec[(v, c, 0)] or 6, sub_codec=0, flags=flags, ltype=0, param=0, b250_size_or_nothing_char=4)
                 data = st["b250"]
             else:
                 if st.get("drop_local_section"):
@@ -796,11 +802,10 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
                 if is_r1 and X["pair_identical"]:
                     flags |= 4
                 int_lt = 1 <= st["ltype"] <= 8
-                d = po.GzoCtxSectionDesc(vblock_i=vi, section_type=SEC_LOCAL, codec=zstate["lcodec"][c] or 6, sub_codec=0, flags=flags, ltype=st["ltype"], param=st.get("param", 0),
+                d = po.GzoCtxSectionDesc(vblock_i=vi, section_type=SEC_LOCAL, codec=vcodec[(v, c, 1)] or 6, sub_codec=0, flags=flags, ltype=st["ltype"], param=st.get("param", 0),
                                          b250_size_or_nothing_char=(X["nothing_char"] or 0xff) if int_lt else 0)
                 if st["ltype"] == 13:                                  # LT_CODEC: QUAL through CODEC_DOMQ; the file's coder as VBlock v finds it (codec.c:280-281)
-                    known = zstate["lcodec"][c] if v >= voter.get((c, 1), -1) else 0
-                    d.codec, d.sub_codec = 13, 0 if st["domq"]["all_diverse"] else known
+                    d.codec, d.sub_codec = 13, 0 if st["domq"]["all_diverse"] else vcodec[(v, c, 1)]
                 data = st["local"]
             d.dict_id[:] = list(X["dict_id"])
             z += oracle.section_compress(d, data)
@@ -811,12 +816,15 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
     return out, zstate
 
 
-def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0):
+def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0, small_first=False):
     """the whole a1-a16 path from FASTQ text: gz_fastq_zip_vblocks over paired VBlocks (R1/R2 of a file pair in one call,
     dictionaries carried from call to call) == the oracle's step-by-step composition, byte for byte; every VBlock's z_data
-    decodes again on the device (adler32 of every section, payloads) and the packed SEQ unpacks to the reads' bases"""
+    decodes again on the device (adler32 of every section, payloads) and the packed SEQ unpacks to the reads' bases.
+    small_first: the shorter VBlock of each mate comes first and is "tiny" by the plan's vb_size (codec.c:352): it tests codecs for
+    itself without setting them for the file; in the second call every VBlock is tiny"""
     from genozip_amd import fastq as fq
-    plan = fq.illumina_plan(paired=True, domq=domq)
+    vb_size = len(fastq_text(n_reads, seed=100, qual=qual[0])) if small_first else 0
+    plan = fq.illumina_plan(paired=True, domq=domq, vb_size=vb_size)
     F = E.zip_open(plan)
     zstate = None
     vb_i = 0
@@ -825,7 +833,7 @@ def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0
         r1 = fastq_text(nr, seed=100 + call, dirty_seq=(call == 1), qual=qual[call])
         r2 = fastq_text(nr, seed=100 + call, dirty_seq=(call == 1), mate=2, qual_seed=300 + call, qual=qual[call])
         # two VBlocks per mate (the second shorter), R2's name their R1 counterparts
-        cut = (2 * nr) // 3
+        cut = nr // 3 if small_first else (2 * nr) // 3
 
         def parts(t):                     # (a quality line may start with '@': cut by counting lines)
             nl = np.flatnonzero(np.frombuffer(t, dtype=np.uint8) == 10)

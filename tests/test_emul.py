@@ -105,6 +105,7 @@ def test_emul_merge_chain(emul_engine, oracle):
 
 def test_emul_fastq_zip(emul_engine, oracle):
     parity.fastq_zip(emul_engine, oracle, 200)
+    parity.fastq_zip(emul_engine, oracle, 90, small_first=True)                         # VBlocks too small to set the file's codecs
 
 
 def test_emul_fastq_zip_two_in_flight(emul_engine, oracle):
@@ -121,6 +122,7 @@ def test_emul_fastq_zip_domq(emul_engine, oracle):
     parity.fastq_zip(emul_engine, oracle, 150, qual=("bin", "uniform"))
     parity.fastq_zip(emul_engine, oracle, 60, n_calls=1, qual=("uniform",), domq=13)
     parity.fastq_zip(emul_engine, oracle, 60, n_calls=1, qual=("bin",), domq=1)
+    parity.fastq_zip(emul_engine, oracle, 90, qual=("bin", "bin"), small_first=True)
 
 
 def test_emul_ctx_golden(emul_engine, oracle):

@@ -106,6 +106,8 @@ def test_fastq_zip_driver(gpu_engine, oracle):
     parity.fastq_zip(gpu_engine, oracle, 2000, qual=("uniform", "bin"))          # ... or not, also for later VBlocks that would fit
     parity.fastq_zip(gpu_engine, oracle, 1000, n_calls=1, qual=("uniform",), domq=13)
     parity.fastq_zip(gpu_engine, oracle, 1000, n_calls=1, qual=("bin",), domq=1)
+    parity.fastq_zip(gpu_engine, oracle, 1500, small_first=True)                         # VBlocks too small to set the file's codecs (codec.c:352)
+    parity.fastq_zip(gpu_engine, oracle, 1500, qual=("bin", "bin"), small_first=True)
 
 
 def test_fastq_zip_two_in_flight(gpu_engine, oracle):

@@ -79,9 +79,10 @@ def test_gather_to_writer_rank_gloo_world2():
 
 
 # ---- real VBlocks under a process group: the file of test_emul_fastq_zip dealt out over 2 ranks -----------------------------
-def _pair_file(n_reads, n_pairs, qual="uniform"):
-    """-> (text, [(text_off, text_len, vblock_i, r1 index)]) of a paired FASTQ in the reference's VBlock order: R1's VBlocks
-    1..n_pairs, then R2's n_pairs+1..2 n_pairs, R2 VBlock k pairing R1 VBlock k"""
+def _pair_file(n_reads, n_pairs, qual="uniform", tiny=False):
+    """-> (text, [(text_off, text_len, vblock_i, r1 index)], vb_size) of a paired FASTQ in the reference's VBlock order: R1's VBlocks
+    1..n_pairs, then R2's n_pairs+1..2 n_pairs, R2 VBlock k pairing R1 VBlock k. tiny: VBlocks of growing size (1 : 2 : 3 ...) and a
+    vb_size by which the first of each mate is too small to set the file's codecs (codec.c:352)"""
     import numpy as np
     import parity
     r1 = parity.fastq_text(n_reads, seed=500, mate=1, qual=qual)
@@ -89,13 +90,15 @@ def _pair_file(n_reads, n_pairs, qual="uniform"):
     vbs, text = [], r1 + r2
     for m, t in enumerate((r1, r2)):
         nl = np.flatnonzero(np.frombuffer(t, dtype=np.uint8) == 10)
-        cuts = [0] + [int(nl[4 * (n_reads * k // n_pairs) - 1]) + 1 for k in range(1, n_pairs)] + [len(t)]
+        tri = n_pairs * (n_pairs + 1) // 2
+        at = [n_reads * (k * (k + 1) // 2) // tri if tiny else n_reads * k // n_pairs for k in range(1, n_pairs)]
+        cuts = [0] + [int(nl[4 * a - 1]) + 1 for a in at] + [len(t)]
         for k in range(n_pairs):
             vbs.append((m * len(r1) + cuts[k], cuts[k + 1] - cuts[k], m * n_pairs + k + 1, k if m else -1))
-    return text, vbs
+    return text, vbs, (len(r1) // 2 if tiny else 0)
 
 
-def _zip_worker(rank, world, port, n_reads, n_pairs, q, qual="uniform"):
+def _zip_worker(rank, world, port, n_reads, n_pairs, q, qual="uniform", tiny=False):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), here, os.path.join(here, "emul")):
@@ -109,8 +112,8 @@ def _zip_worker(rank, world, port, n_reads, n_pairs, q, qual="uniform"):
     from genozip_amd import fastq as fq
     from genozip_amd.shard import pairs_of_rank, zip_vblocks_sharded
     E = Engine(lib_path=os.path.join(here, "emul", "libgenozip_amd_emul.so"), mem=HostMem())
-    text, vbs = _pair_file(n_reads, n_pairs, qual)
-    F = E.zip_open(fq.illumina_plan(paired=True))
+    text, vbs, vb_size = _pair_file(n_reads, n_pairs, qual, tiny)
+    F = E.zip_open(fq.illumina_plan(paired=True, vb_size=vb_size))
     mine = pairs_of_rank(n_pairs, rank, world)
     # this rank's VBlocks in ascending vblock_i: its R1 VBlocks, then its R2 VBlocks naming them
     own = [vbs[k] for k in mine] + [vbs[n_pairs + k] for k in mine]
@@ -131,16 +134,17 @@ def _zip_worker(rank, world, port, n_reads, n_pairs, q, qual="uniform"):
 import pytest
 
 
-@pytest.mark.parametrize("qual", ["uniform", "bin"])
-def test_file_dealt_out_over_2_ranks_equals_one_rank(emul_engine, qual):
+@pytest.mark.parametrize("qual,tiny", [("uniform", False), ("bin", False), ("uniform", True)], ids=["uniform", "bin", "tiny"])
+def test_file_dealt_out_over_2_ranks_equals_one_rank(emul_engine, qual, tiny):
     """the N>1 form of the whole path (strong scaling: ONE file, its VBlock pairs dealt out): every rank segs and compresses its
     own VBlocks through the emulated build, the dictionary merge and the codec choices are exchanged - and every VBlock's z_data
     is byte-identical to what a single process makes of the same file. qual = "bin": the file's first VBlock (rank 0's) makes QUAL go
-    through CODEC_DOMQ - rank 1 learns that in the merge, from rank 0's blob"""
+    through CODEC_DOMQ - rank 1 learns that in the merge, from rank 0's blob. tiny: VBlock 1 (rank 0's) is too small to set codecs
+    for the file: it keeps its own, VBlock 2 (rank 1's) sets them for VBlock 3 (rank 0's) and the rest"""
     from genozip_amd import fastq as fq
     n_reads, n_pairs = 96, 3
-    text, vbs = _pair_file(n_reads, n_pairs, qual)
-    F = emul_engine.zip_open(fq.illumina_plan(paired=True))
+    text, vbs, vb_size = _pair_file(n_reads, n_pairs, qual, tiny)
+    F = emul_engine.zip_open(fq.illumina_plan(paired=True, vb_size=vb_size))
     buf = emul_engine.mem.upload(text + b"\0" * 32)
     tab = F.vb_table(vbs)
     F.zip_table(buf, len(text), tab, len(vbs))
@@ -153,7 +157,7 @@ def test_file_dealt_out_over_2_ranks_equals_one_rank(emul_engine, qual):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_zip_worker, args=(r, 2, port, n_reads, n_pairs, q, qual)) for r in range(2)]
+    procs = [ctx.Process(target=_zip_worker, args=(r, 2, port, n_reads, n_pairs, q, qual, tiny)) for r in range(2)]
     for p in procs:
         p.start()
     allres = q.get(timeout=300)
