@@ -104,12 +104,12 @@ def test_emul_merge_chain(emul_engine, oracle):
 
 
 def test_emul_fastq_zip(emul_engine, oracle):
-    parity.fastq_zip(emul_engine, oracle, 200)
-    parity.fastq_zip(emul_engine, oracle, 90, small_first=True)                         # VBlocks too small to set the file's codecs
+    parity.fastq_zip(emul_engine, oracle, 140)
+    parity.fastq_zip(emul_engine, oracle, 66, small_first=True)                         # VBlocks too small to set the file's codecs
 
 
 def test_emul_fastq_zip_two_in_flight(emul_engine, oracle):
-    parity.fastq_zip_two_in_flight(emul_engine, oracle, 60)
+    parity.fastq_zip_two_in_flight(emul_engine, oracle, 40, n_calls=4)
 
 
 def test_emul_fastq_zip_errors(emul_engine, oracle):
@@ -119,10 +119,10 @@ def test_emul_fastq_zip_errors(emul_engine, oracle):
 def test_emul_fastq_zip_domq(emul_engine, oracle):
     """QUAL through CODEC_DOMQ inside the driver: the file's first VBlock decides (binned scores: a fit), later calls follow even
     with scores that would not fit; forced (--force-domq) on scores that do not fit; refused (--no-domqual) on scores that do"""
-    parity.fastq_zip(emul_engine, oracle, 150, qual=("bin", "uniform"))
-    parity.fastq_zip(emul_engine, oracle, 60, n_calls=1, qual=("uniform",), domq=13)
-    parity.fastq_zip(emul_engine, oracle, 60, n_calls=1, qual=("bin",), domq=1)
-    parity.fastq_zip(emul_engine, oracle, 90, qual=("bin", "bin"), small_first=True)
+    parity.fastq_zip(emul_engine, oracle, 100, qual=("bin", "uniform"))
+    parity.fastq_zip(emul_engine, oracle, 45, n_calls=1, qual=("uniform",), domq=13)
+    parity.fastq_zip(emul_engine, oracle, 45, n_calls=1, qual=("bin",), domq=1)
+    parity.fastq_zip(emul_engine, oracle, 66, qual=("bin", "bin"), small_first=True)
 
 
 def test_emul_ctx_golden(emul_engine, oracle):
