@@ -146,6 +146,12 @@ class ZipFile:
         if rc != GZ_OK:
             raise GenozipAMDError("gz_fastq_zip_end failed (%d): %s" % (rc, self.E.L.gz_last_error(self.E.h).decode()))
 
+    def speculation(self):
+        """-> (hits, misses) of the handle: QUAL streams coded ahead with the previous file's codec, confirmed / refuted by the file's own trial"""
+        h, m = C.c_uint32(0), C.c_uint32(0)
+        self.E.L.gz_zip_speculation(self.f, C.byref(h), C.byref(m))
+        return h.value, m.value
+
     def reset(self):
         self.E._check(self.E.L.gz_zip_reset(self.f), "gz_zip_reset")
 

@@ -12,6 +12,7 @@
 #include <math.h>
 #include <atomic>
 #include <vector>
+#include <chrono>
 #include <string>
 
 #include "../../include/genozip_amd.h"
@@ -83,6 +84,8 @@ struct GzHandle {
     std::vector<ProfAcc> prof;
     bool background = false;               // gz_create_background
     std::vector<GzHandle *> helpers;       // handles that work for this one (the VBlock driver's second handle): profiled with it
+    uint32_t zip_spec_hits = 0, zip_spec_misses = 0;
+    int zip_qual_guess[2] = { 0, 0 };      // the VBlock driver: the coder the last file's QUAL stream got (plain / through CODEC_DOMQ) - gz_zip.h, "speculation"
     std::vector<ProfAcc> prof_view;        // gz_profile_get: this handle's totals + its helpers'
 };
 
@@ -568,6 +571,12 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
         else g_chain_wgs.fetch_sub (wgs);
     }
     if (!A.pipelined) { A.nbig = 0; small = P.plain_list; big.clear (); A.nsmall = (uint32_t)small.size (); }
+    if (getenv ("GZ_DEBUG_PIPE")) {
+        uint64_t sum_big = 0; uint32_t mx = 0, mn = 0xffffffffu;
+        for (size_t i = 0; i < P.plain_list.size (); i++) if (P.plain_nb[i] > A.chunk) { sum_big += P.plain_nb[i]; mx = std::max (mx, P.plain_nb[i]); mn = std::min (mn, P.plain_nb[i]); }
+        fprintf (stderr, "[pipe] bg %d np %u nbig %u nsmall %u max_arith_n %u chunk %u n_chunks %u pipelined %d reserve %d big: min %u max %u sum %llu\n", (int)h->background, A.np, A.nbig, A.nsmall,
+                 P.max_arith_n, A.chunk, A.n_chunks, (int)A.pipelined, (int)A.reserve_cu, mn, mx, (unsigned long long)sum_big);
+    }
     void *d;
     int rc = upload (h, P.plain_list.data (), P.plain_list.size () * 4, &d); A.d_plain = (const uint32_t *)d;
     if (rc == GZ_OK)             { rc = upload (h, P.low_blocks.data (), P.low_blocks.size () * sizeof (GzdLowBlock), &d); A.d_lb = (const GzdLowBlock *)d; }
@@ -752,9 +761,14 @@ extern "C" int gz_codec_compress_batch (GzHandle *h, GzStream *streams, int n_st
     }
     void *d_streams, *d_leaves;
     int rc;
+    static const bool timing = getenv ("GZ_ZIP_TIMING") != NULL;
+    const auto tm0 = std::chrono::steady_clock::now ();
     if ((rc = upload (h, P.streams.data (), P.streams.size () * sizeof (GzdStream), &d_streams)) != GZ_OK) return rc;
     if ((rc = upload (h, P.leaves.data (), P.leaves.size () * sizeof (GzdLeaf), &d_leaves)) != GZ_OK) return rc;
+    const auto tm1 = std::chrono::steady_clock::now ();
     if ((rc = launch_encode (h, P, (GzdStream *)d_streams, (GzdLeaf *)d_leaves, NULL, 0, 0)) != GZ_OK) return rc;
+    if (timing) fprintf (stderr, "[compress_batch bg %d n %d: upload %.2f launch %.2f ms]\n", (int)h->background, n_streams,
+                         std::chrono::duration<double, std::milli> (tm1 - tm0).count (), std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - tm1).count ());
     Pending pd; pd.kind = 0; pd.user = streams; pd.n = n_streams; pd.dev_streams = d_streams; pd.dev_vbs = NULL; pd.n_dev_streams = P.streams.size ();
     h->pending.push_back (pd);
     return GZ_OK;

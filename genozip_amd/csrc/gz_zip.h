@@ -93,6 +93,9 @@ struct ZipCall {                   // what lives between the phases of one call
     int qual_mode_applied = -1;
     std::vector<GzStream> early;               // the streams coded ahead (results arrive when the second handle is synchronised)
     uint32_t *d_early_len = NULL;
+    // speculation: the long streams were handed to the coders with the codec the handle's previous file ended up with, before this
+    // file's own trial (a8) was through; the trial (queued on the main handle once the seg phase has its results) confirms or refutes
+    std::vector<GzStream> spec_trial; int spec_codec = 0; size_t spec_t = 0; bool spec = false, spec_pending = false;
     std::vector<int32_t> n2w_host;
     std::map<uint32_t, ZipVBState> vbstate;   // by vblock_i: every VBlock of the call, own or not
 };
@@ -660,20 +663,29 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     const bool own_first = vbs[0].vblock_i == f->last_vblock_i + 1;   // (vblock_i are consecutive over the processes: this one opens the call)
     bool want_trial = false;
     if (f->h2 && own_first && f->qual_ctx >= 0 && vbs[0].n_reads && zip_vb_commits (f->plan, vbs[0])) { GzZctxView zv; gz_zctx_view (f->zctx[f->qual_ctx], &zv); want_trial = !zv.lcodec; }
+    // Speculation. The handle remembers which coder the QUAL stream of its previous file ended up with. If it does, the long streams
+    // are handed to the coders with THAT codec as soon as they are gathered, and this file's own trial - which decides, as always -
+    // runs afterwards on the main handle, while the host merges: 4-5 ms of trial compressions no longer sit in front of the long
+    // pole. A trial that chooses otherwise throws the work away (the streams are then coded with the rest: one call of one file pays).
+    const int *guess = f->h_user->zip_qual_guess;
+    const bool may_spec = want_trial && !getenv ("GZ_ZIP_NO_SPECULATION") && (qmode0 == 0 ? guess[0] : qmode0 > 0 ? guess[1] : (guess[0] || guess[1]));
     auto add_trials = [&] (const uint8_t *in, const uint32_t *len_dev, int as_domq) -> int {
-        const size_t first = trial.size ();
+        std::vector<GzStream> &T8 = may_spec ? K.spec_trial : trial;
+        const size_t first = T8.size ();
         for (int k = 0; k < 8; k++) {
             GzStream st; memset (&st, 0, sizeof (st));
             st.in = in; st.in_len = 99999; st.in_len_dev = len_dev;                                          // (low half of a 64-bit length)
             st.codec = trial_codecs[k]; st.out_cap = gz_codec_est_size (st.codec, 99999);
             if (!(st.out = (uint8_t *)ws_alloc (f, (size_t)st.out_cap + 64))) return GZ_ERR_HIP;
-            trial.push_back (st);
+            T8.push_back (st);
         }
         trial_ctx.push_back ((uint32_t)f->qual_ctx); trial_domq.push_back (as_domq);
+        if (may_spec) return GZ_OK;                        // (launched once the seg phase has its results)
         int r = gz_wait_for (f->h2, h);
         if (r == GZ_OK && (r = gz_codec_compress_batch (f->h2, trial.data () + first, 8)) != GZ_OK) h->err = f->h2->err;
         return r;
     };
+    K.spec_trial.reserve (16);
     if (want_trial && qmode0 <= 0) {                      // the plain form: enough of VBlock 0's reads to hold 99 999 bytes
         GzBlobJob tj; memset (&tj, 0, sizeof (tj));
         tj.text = text; tj.off = qual_off + r0[0]; tj.len = qual_len + r0[0]; tj.n = std::min<uint32_t> (vbs[0].n_reads, 100000);
@@ -730,23 +742,10 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         hipLaunchKernelGGL (k_pack_copy, dim3 ((uint32_t)NCJ), dim3 (256), 0, h->stream, (const GzdPackJob *)d_pack, d_staging, (const uint64_t *)d_pack_total);
     }
     T.mark ("queue");
-    // ---- read back (second wait)
-    K.colres.resize (NCJ + 1); K.dynres.resize (dyn_jobs.size () + 1);
-    std::vector<uint64_t> icolres (2 * icol_jobs.size () + 2);
-    K.blobres.resize (blob_jobs.size () + 1); K.acgtres.resize (2 * acgt_jobs.size () + 2); K.vbstat.resize (2 * (size_t)NV + 2);
-    uint64_t pack_total[2] = { 0, 1 };
-    if (NCJ) {
-        HIPCHK (h, hipMemcpyAsync (K.colres.data (), d_colres, NCJ * sizeof (GzColumnResult), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK (h, hipMemcpyAsync (pack.data (), d_pack, NCJ * sizeof (GzdPackJob), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK (h, hipMemcpyAsync (pack_total, d_pack_total, 16, hipMemcpyDeviceToHost, h->stream));
-    }
-    if (!dyn_jobs.empty ())  HIPCHK (h, hipMemcpyAsync (K.dynres.data (), d_dynres, dyn_jobs.size () * sizeof (GzDynIntResult), hipMemcpyDeviceToHost, h->stream));
-    if (!icol_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (icolres.data (), d_icolres, icol_jobs.size () * 16, hipMemcpyDeviceToHost, h->stream));
-    if (!acgt_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (K.acgtres.data (), d_acgtres, acgt_jobs.size () * 16, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK (h, hipMemcpyAsync (K.vbstat.data (), d_vbstat, 2 * (size_t)NV * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK (h, hipMemcpyAsync (&a, d_a, sizeof (a), hipMemcpyDeviceToHost, h->stream));
+    K.blobres.resize (blob_jobs.size () + 1);
     // ---- as soon as the gathered QUAL (and what CODEC_DOMQ makes of it) is there - the columns are still being evaluated:
     HIPCHK (h, hipEventSynchronize (f->ev_early));
+    T.mark ("early-wait");
     if (eb_blob) memcpy (K.blobres.data (), eb, eb_blob);
     const uint32_t *fits = (const uint32_t *)(eb + eb_blob); const GzDomqResult *domqres = (const GzDomqResult *)(eb + eb_blob + eb_fit);
     for (uint32_t v = 0; qmode0 && v < NV; v++) {
@@ -781,7 +780,11 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
             if (f->ctxs[c].kind != GZ_FQ_QUAL || qmode < 0) continue;
             GzZctxView zv; gz_zctx_view (f->zctx[c], &zv);
             int codec = zv.lcodec;
-            for (size_t t = 0; !codec && t < trial_ctx.size (); t++) {
+            if (!codec && may_spec) {                                  // speculation: the previous file's coder for this form of QUAL
+                const int g = guess[qmode == GZ_CODEC_DOMQ];
+                if (g && COL (0, c).local_len >= 50) { codec = g; K.spec = true; K.spec_codec = g; }
+            }
+            for (size_t t = 0; !codec && !may_spec && t < trial_ctx.size (); t++) {
                 if (trial_ctx[t] != c || trial_domq[t] != (qmode == GZ_CODEC_DOMQ) || COL (0, c).local_len < 50) continue;            // codec.c:311-312: too small a sample decides nothing
                 const uint32_t sample = (uint32_t)std::min<uint64_t> (COL (0, c).local_len, 99999);
                 uint32_t best_size = sample; codec = GZ_CODEC_NONE;                     // NONE: the bare length (codec.c:324)
@@ -803,6 +806,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
                 K.early.push_back (st);
             }
         }
+        T.mark ("early-plan");
         if (!K.early.empty ()) {
             if (!(K.d_early_len = (uint32_t *)ws_alloc (f, K.early.size () * 4))) return GZ_ERR_HIP;
             for (size_t k = 0; k < K.early.size (); k++) K.early[k].out_len_dev = K.d_early_len + k;
@@ -812,6 +816,22 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         }
     }
     T.mark ("early");
+    // ---- read back (second wait). (Into pageable memory: each of these copies waits for the stream - which is why the long streams were
+    //      launched first)
+    K.colres.resize (NCJ + 1); K.dynres.resize (dyn_jobs.size () + 1);
+    std::vector<uint64_t> icolres (2 * icol_jobs.size () + 2);
+    K.acgtres.resize (2 * acgt_jobs.size () + 2); K.vbstat.resize (2 * (size_t)NV + 2);
+    uint64_t pack_total[2] = { 0, 1 };
+    if (NCJ) {
+        HIPCHK (h, hipMemcpyAsync (K.colres.data (), d_colres, NCJ * sizeof (GzColumnResult), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK (h, hipMemcpyAsync (pack.data (), d_pack, NCJ * sizeof (GzdPackJob), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK (h, hipMemcpyAsync (pack_total, d_pack_total, 16, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (!dyn_jobs.empty ())  HIPCHK (h, hipMemcpyAsync (K.dynres.data (), d_dynres, dyn_jobs.size () * sizeof (GzDynIntResult), hipMemcpyDeviceToHost, h->stream));
+    if (!icol_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (icolres.data (), d_icolres, icol_jobs.size () * 16, hipMemcpyDeviceToHost, h->stream));
+    if (!acgt_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (K.acgtres.data (), d_acgtres, acgt_jobs.size () * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK (h, hipMemcpyAsync (K.vbstat.data (), d_vbstat, 2 * (size_t)NV * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK (h, hipMemcpyAsync (&a, d_a, sizeof (a), hipMemcpyDeviceToHost, h->stream));
     rc = gz_sync (h);
     // (from here on the second handle may be at work on this call's buffers: it is waited for before an error is returned)
 #define ZIP_FAIL(code) do { if (f->h2) (void)gz_sync (f->h2); return (code); } while (0)
@@ -826,6 +846,14 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         if ((int32_t)icolres[2 * k + 1] == GZ_ST_CORRUPT) { h->err = "an ordered item is not an integer (qname.c:750-756)"; ZIP_FAIL (GZ_ERR_CORRUPT); }
     for (size_t k = 0; k < NCJ; k++) if (K.colres[k].status != 1) { h->err = "column dictionary capacity"; ZIP_FAIL (GZ_ERR); }
     if (!pack_total[1]) { h->err = "merge staging buffer too small"; ZIP_FAIL (GZ_ERR); }
+    // speculation: this file's own trial, on the main handle - idle now until the merge (host) has the dictionaries - and only of
+    // the form of QUAL the file uses; its sizes are read in the merge phase, with the other trial compressions'
+    if (!K.spec_trial.empty () && qmode >= 0 && COL (0, (uint32_t)f->qual_ctx).local_len >= 50) {     // (codec.c:311-312: too small a sample decides nothing)
+        for (size_t t = 0; t < trial_domq.size () && !K.spec_pending; t++) if (trial_domq[t] == (qmode == GZ_CODEC_DOMQ)) {
+            if ((rc = gz_codec_compress_batch (h, K.spec_trial.data () + 8 * t, 8)) != GZ_OK) ZIP_FAIL (rc);
+            K.spec_pending = true; K.spec_t = t;
+        }
+    }
     f->stage.resize (pack_total[0] + 16);
     if (pack_total[0] && hipMemcpy (f->stage.data (), d_staging, pack_total[0], hipMemcpyDeviceToHost) != hipSuccess) { h->err = "hipMemcpy (merge staging)"; ZIP_FAIL (GZ_ERR_HIP); }
 
@@ -1144,11 +1172,30 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
         std::vector<const uint8_t *> ptr; std::vector<uint32_t> len; std::vector<ZipVote> who;
         bool need = false;
         for (uint32_t c = 0; c < NC; c++) { GzZctxView zv; gz_zctx_view (f->zctx[c], &zv); if (!zv.lcodec || !zv.bcodec) need = true; }
-        if (need) {
+        if (need || K.spec_pending) {
             std::vector<uint32_t> seclen (2 * (size_t)NV * NC);
             HIPCHK (h, hipMemcpyAsync (seclen.data (), K.d_seclen, seclen.size () * 4, hipMemcpyDeviceToHost, h->stream));
             if ((rc = gz_sync (h)) < 0) return rc;
             T.mark ("generate-sync");
+            if (K.spec_pending) {                                         // the trial behind a speculation (seg phase): what does the file itself say?
+                K.spec_pending = false;
+                const uint32_t c = (uint32_t)f->qual_ctx;
+                const uint32_t sample = (uint32_t)std::min<uint64_t> (COL (0, c).local_len, 99999);
+                uint32_t best_size = sample; int codec = GZ_CODEC_NONE;                         // NONE: the bare length (codec.c:324)
+                for (int k = 0; k < 8; k++) {
+                    const GzStream &st = K.spec_trial[8 * K.spec_t + k];
+                    if (st.status != GZ_OK) { h->err = "trial compression failed"; if (f->h2) (void)gz_sync (f->h2); return GZ_ERR; }
+                    if (st.out_len + 28 < best_size) { best_size = st.out_len + 28; codec = st.codec; }   // framed (codec.c:328-331), ties -> first
+                }
+                K.votes.push_back ({ c, 1, vbs[0].vblock_i, (uint32_t)codec });
+                if (K.spec && codec == K.spec_codec) f->h_user->zip_spec_hits++;
+                else if (K.spec) {                                        // refuted: let the streams run out, then code them with the rest
+                    f->h_user->zip_spec_misses++;
+                    (void)gz_sync (f->h2);
+                    for (uint32_t v = 0; v < NV; v++) { ZipCol &Z = COL (v, c); if (Z.early >= 0) { Z.early = -1; Z.lcodec = 0; } }
+                    K.early.clear (); K.spec = false;
+                }
+            }
             for (uint32_t c = 0; c < NC; c++) {
                 GzZctxView zv; gz_zctx_view (f->zctx[c], &zv);
                 for (uint32_t is_local = 0; is_local < 2; is_local++) {
@@ -1222,6 +1269,7 @@ static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint
             GzZctxView zv; gz_zctx_view (f->zctx[w.first.first], &zv);
             if (w.first.second ? zv.lcodec : zv.bcodec) continue;
             gz_zctx_commit_codec (f->zctx[w.first.first], (int)w.first.second, (int)w.second.codec);
+            if ((int)w.first.first == f->qual_ctx && w.first.second) f->h_user->zip_qual_guess[f->qual_mode == GZ_CODEC_DOMQ] = (int)w.second.codec;   // (next file: speculation)
             // (a VBlock in front of the one that assigned finds nothing in the file, as in a serial run: it had < 50 bytes, or is small)
             for (uint32_t v = 0; v < NV; v++) if (vbs[v].vblock_i >= w.second.vblock_i) {
                 ZipCol &Z = COL (v, w.first.first); if (w.first.second) { if (!Z.lcodec) Z.lcodec = (uint8_t)w.second.codec; } else if (!Z.bcodec) Z.bcodec = (uint8_t)w.second.codec; }
@@ -1387,6 +1435,12 @@ extern "C" int gz_fastq_zip_end (GzZipFile *f)
     f->busy = false;
     if (rc != GZ_OK && f->h != f->h_user) f->h_user->err = f->h->err;
     return rc;
+}
+
+extern "C" void gz_zip_speculation (const GzZipFile *f, uint32_t *hits, uint32_t *misses)
+{
+    if (hits)   *hits   = f ? f->h_user->zip_spec_hits : 0;
+    if (misses) *misses = f ? f->h_user->zip_spec_misses : 0;
 }
 
 // ---- N1 for VCF ----------------------------------------------------------------------------------------------------------------

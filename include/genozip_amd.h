@@ -489,6 +489,11 @@ int gz_fastq_zip_finish (GzZipFile *f, const void *const *votes, const uint64_t 
  * flight on its compute threads. Merges happen in the order of the begins: the bytes are those of one call at a time. */
 int gz_fastq_zip_begin (GzZipFile *f, uint8_t *text, uint64_t text_len, GzFastqVB *vbs, int n_vbs);
 int gz_fastq_zip_end (GzZipFile *f);
+/* Speculation (no counterpart in the reference; results are the same with and without): a handle remembers which coder the QUAL
+ * stream of its previous file was given by codec_assign_best_codec. The next file's long QUAL streams are handed to that coder as soon
+ * as they are gathered - before the new file's own trial compressions (which still decide) are through. A trial that chooses otherwise
+ * discards that work. hits / misses of the handle the file was opened on; GZ_ZIP_NO_SPECULATION=1 in the environment turns it off. */
+void gz_zip_speculation (const GzZipFile *f, uint32_t *hits, uint32_t *misses);
 /* a new file with the same plan (fresh dictionaries and codecs; the device workspace is kept) */
 int gz_zip_reset (GzZipFile *f);
 /* the z_data of the last call's VBlocks one after the other into dst (device) - what is handed to the writer

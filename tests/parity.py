@@ -890,7 +890,29 @@ def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0
             p += 40 + clen; k += 1
         at += len(z)
     assert k == len(vb_secs) and R["sections"][-1]["st"] == 6
+    spec = F.speculation()
     F.close()
+    qc = next(i for i, c in enumerate(plan["ctxs"]) if c["tag"] == "QUAL")
+    return dict(qual_lcodec=zstate["lcodec"][qc], qual_mode=zstate["qual_mode"], speculation=spec)
+
+
+def fastq_zip_speculation(E, oracle, n_reads):
+    """the driver hands a file's long QUAL streams to the coder its handle's PREVIOUS file ended up with before the file's own trial
+    compressions are through (gz_zip_speculation): same bytes whether the trial then confirms (a second file of the same kind) or
+    refutes (a file whose trial chooses another coder) - every run below is compared with the oracle inside fastq_zip"""
+    a = fastq_zip(E, oracle, n_reads, n_calls=1, qual=("uniform",))
+    b = fastq_zip(E, oracle, n_reads, n_calls=1, qual=("uniform",))
+    assert b["qual_lcodec"] == a["qual_lcodec"] and b["speculation"][0] == a["speculation"][0] + 1 and b["speculation"][1] == a["speculation"][1]
+    c = fastq_zip(E, oracle, n_reads, n_calls=1, qual=("bin",), domq=1)           # plain QUAL again, other scores
+    assert c["qual_mode"] == 0
+    if c["qual_lcodec"] != a["qual_lcodec"]:
+        assert c["speculation"] == (b["speculation"][0], b["speculation"][1] + 1), "a refuted speculation"
+    else:
+        assert c["speculation"] == (b["speculation"][0] + 1, b["speculation"][1])
+    d = fastq_zip(E, oracle, n_reads, n_calls=1, qual=("bin",))                   # through CODEC_DOMQ: a guess of its own
+    e = fastq_zip(E, oracle, n_reads, n_calls=1, qual=("bin",))
+    assert d["qual_mode"] == 13 and e["speculation"][0] == d["speculation"][0] + 1
+    return a, c, d
 
 
 def _first_diff(a, b):

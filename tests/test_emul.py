@@ -108,6 +108,10 @@ def test_emul_fastq_zip(emul_engine, oracle):
     parity.fastq_zip(emul_engine, oracle, 66, small_first=True)                         # VBlocks too small to set the file's codecs
 
 
+def test_emul_fastq_zip_speculation(emul_engine, oracle):
+    parity.fastq_zip_speculation(emul_engine, oracle, 60)
+
+
 def test_emul_fastq_zip_two_in_flight(emul_engine, oracle):
     parity.fastq_zip_two_in_flight(emul_engine, oracle, 40, n_calls=4)
 

@@ -110,6 +110,13 @@ def test_fastq_zip_driver(gpu_engine, oracle):
     parity.fastq_zip(gpu_engine, oracle, 1500, qual=("bin", "bin"), small_first=True)
 
 
+@pytest.mark.gpu
+def test_fastq_zip_speculation(gpu_engine, oracle):
+    a, c, d = parity.fastq_zip_speculation(gpu_engine, oracle, 2500)
+    assert a["qual_lcodec"] and d["qual_mode"] == 13
+
+
+@pytest.mark.gpu
 def test_fastq_zip_two_in_flight(gpu_engine, oracle):
     parity.fastq_zip_two_in_flight(gpu_engine, oracle, 4000)
 
