@@ -453,6 +453,7 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
             P.rle_list.push_back ((uint32_t)P.leaves.size ());
         }
         if (nb > GZ_CHUNK_MIN && !(L.mstate = (uint32_t *)arena_alloc (h, (size_t)(rle ? 514 : 256) * GZ_MSTATE_WORDS * 64 * 4))) return false;
+        if (nb > GZ_CHUNK_MIN && o1 && !rle && !(L.succ = (uint64_t *)arena_alloc (h, 8192))) return false;
         if (nb > P.max_arith_n) P.max_arith_n = nb;
         P.plain_list.push_back ((uint32_t)P.leaves.size ());
         P.plain_nb.push_back (nb);
@@ -670,6 +671,8 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 //  launch fills the tail of the other's - no gain (33.8 vs 33.9 ms; 4 M pairs 84.9 vs 80.6): the model kernels
                 //  are short of issue slots, not of waves.)
                 if (A.n_chunks > GZ_MAX_CHUNKS) return GZ_ERR;
+                // (wide alphabets: the symbols that follow each context byte anywhere in the leaf, before the first chunk's models)
+                if (A.no1) KLAUNCH_ON (h, (A.nbig > 256 ? h->stream7 : h->stream4), k_ctx_succ, dim3 (A.nbig, (P.max_arith_n + GZ_SUCC_SPAN - 1) / GZ_SUCC_SPAN), dim3 (256), 8192, d_leaves, A.d_big);
                 for (uint32_t k = 0; k < A.n_chunks; k++) {
                     const uint32_t p0 = k * A.chunk, span = P.max_arith_n - p0 < A.chunk ? P.max_arith_n - p0 : A.chunk;
                     hipStream_t sort_stream = A.nbig > 256 ? h->stream7 : h->stream4;   // (measured: 702 leaves 84.0 -> 80.6 ms; 176 leaves 33.9 -> 34.2: the sort then only takes compute units from the models)

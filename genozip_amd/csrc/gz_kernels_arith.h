@@ -47,6 +47,7 @@ template <typename T> __device__ static inline T *d_uniform_ptr (T *p)
     return (T *)(uintptr_t)(((uint64_t)hi << 32) | lo);
 }
 
+__device__ static inline uint64_t d_uniform64 (uint64_t v) { return ((uint64_t)d_uniform ((uint32_t)(v >> 32)) << 32) | d_uniform ((uint32_t)v); }
 __device__ static inline uint32_t d_readlane (uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane ((int)v, lane); }
 // (clang 22 / ROCm 7.2 has no __builtin_amdgcn_writelane; compare + select costs one more VALU op than v_writelane_b32)
 __device__ static inline uint32_t d_writelane (uint32_t val, int lane, uint32_t old) { return (int)(threadIdx.x & 63) == lane ? val : old; }
@@ -523,12 +524,38 @@ __device__ static inline uint32_t d_local_alphabet (GzLocalAlpha &A, const uint8
     uint32_t nd = 0;
     #pragma unroll
     for (int k = 0; k < 4; k++) { A.m[k] = __ballot (lds_flags[k * 64 + lane] != 0); nd += (uint32_t)__popcll (A.m[k]); }
-    if (nd <= 64) {
+    if (nd <= 128) {
         #pragma unroll
         for (int k = 0; k < 4; k++) if ((A.m[k] >> lane) & 1) lds_list[d_local_rank (A, (uint32_t)(k * 64 + lane))] = symlist[k * 64 + lane];
     }
     __syncthreads ();
     return nd;
+}
+
+// The same for a leaf that spans position chunks, where a context's wave only ever sees one chunk's occurrences: which symbols follow
+// which context byte anywhere in the leaf is found by one pass over the whole leaf before its first chunk (k_ctx_succ; a 256 x 256 bit
+// matrix, 8 KB per leaf), so that a context keeps ONE alphabet - and with it one register layout in mstate - through all chunks.
+// grid (listed leaves, ceil (longest leaf / 16384)), 256 threads, 8 KB of LDS
+#define GZ_SUCC_SPAN 16384u
+__global__ void __launch_bounds__(256) k_ctx_succ (GzdLeaf *leaves, const uint32_t *list)
+{
+    GzdLeaf &L = leaves[list[blockIdx.x]];
+    if (!L.active || L.engine != GZ_ENG_ARITH || !L.succ || !L.o1 || L.rle || L.nsym <= 64) return;
+    const uint32_t n = L.arith_n, p0 = blockIdx.y * GZ_SUCC_SPAN;
+    if (p0 >= n) return;
+    const uint32_t p1 = n - p0 > GZ_SUCC_SPAN ? p0 + GZ_SUCC_SPAN : n;
+    uint32_t *m = (uint32_t *)gz_lds;                          // [256][8]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2048; i += 256) m[i] = 0;
+    __syncthreads ();
+    const uint8_t *in = L.coded; const uint16_t *symrank = L.symrank;
+    for (uint32_t pos = p0 + tid; pos < p1; pos += 256) {
+        const uint32_t c = pos ? in[pos - 1] : 0u, s = symrank[in[pos]];
+        atomicOr (&m[c * 8 + (s >> 5)], 1u << (s & 31));
+    }
+    __syncthreads ();
+    uint32_t *g = (uint32_t *)L.succ;                          // (word s >> 6 of a row, bit s & 63: the same bytes as 32-bit words)
+    for (int i = tid; i < 2048; i += 256) if (m[i]) atomicOr (&g[i], m[i]);
 }
 
 // (force-inlined: as a called function its arguments would arrive in vector registers and every loop on them would
@@ -637,6 +664,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
     const uint32_t *cend = d_uniform_ptr (L.ctxend + (size_t)(chunk == 0xffffffffu ? 0 : p0 / chunk) * L.nctx);
     const uint32_t t0 = p0 / GZ_CTX_TILE;                      // (chunks are whole tiles)
     uint32_t *mstate = d_uniform_ptr (L.mstate);
+    const uint64_t *succ = d_uniform_ptr (L.succ);
 
     // ---- the run models of the run-length variant: blocks GZ_MODEL_GRID_Y ... ; 4 symbols, all present from the start
     if (blockIdx.y >= GZ_MODEL_GRID_Y) {
@@ -682,6 +710,26 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
             const uint32_t nd = d_local_alphabet (la, coded, sorted, srk, L.symrank, L.symlist, j0, j1, lds_flags, lds_list);
             if (nd <= 64) {
                 d_arith_model_wave<1> (coded, ms_u, sorted, tr, magic_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, true, false, st, &la);
+                continue;
+            }
+            if (nd <= 128 && nsym_u > 128) {
+                d_arith_model_wave<2> (coded, ms_u, sorted, tr, magic_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, true, false, st, &la);
+                continue;
+            }
+        }
+        else if (succ && o1_u && !rle_u) {                      // a leaf in position chunks: the context's alphabet over the whole leaf (k_ctx_succ)
+            GzLocalAlpha la;
+            uint32_t nd = 0;
+            #pragma unroll
+            for (int k = 0; k < 4; k++) { la.m[k] = d_uniform64 (succ[ctx * 4 + k]); nd += (uint32_t)__popcll (la.m[k]); }
+            if (nd && (nd <= 64 || (nd <= 128 && nsym_u > 128))) {
+                uint8_t *lds_list = gz_lds + 256;
+                __syncthreads ();                              // (the previous context of this block is done with the list)
+                #pragma unroll
+                for (int k = 0; k < 4; k++) if ((la.m[k] >> (threadIdx.x & 63)) & 1) lds_list[d_local_rank (la, (uint32_t)(k * 64 + (threadIdx.x & 63)))] = L.symlist[k * 64 + (threadIdx.x & 63)];
+                __syncthreads ();
+                if (nd <= 64) d_arith_model_wave<1> (coded, ms_u, sorted, tr, magic_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, &la);
+                else          d_arith_model_wave<2> (coded, ms_u, sorted, tr, magic_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, &la);
                 continue;
             }
         }

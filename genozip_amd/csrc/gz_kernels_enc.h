@@ -107,6 +107,7 @@ __global__ void __launch_bounds__(256) k_leaf_prep (GzdStream *streams, GzdLeaf 
     bool active = S.status == GZ_ST_PENDING && S.engine == L.engine &&
                   ((L.plane == 0xff) ? !S.striped : S.striped);
     if (!active) { if (!tid) { L.active = 0; L.unit_len = 0; } return; }
+    if (L.succ) for (int i = tid; i < 1024; i += 256) L.succ[i] = 0;        // (k_ctx_succ fills it in)
 
     const uint8_t *src; uint32_t n;
     if (L.plane == 0xff) { src = S.in; n = S.n; }

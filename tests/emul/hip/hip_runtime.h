@@ -250,6 +250,7 @@ static inline int __popcll (unsigned long long v) { return __builtin_popcountll 
 static inline unsigned __umulhi (unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline long long __double_as_longlong (double d) { long long v; memcpy (&v, &d, 8); return v; }
 static inline unsigned atomicAdd (unsigned *p, unsigned v) { return __atomic_fetch_add (p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicOr (unsigned *p, unsigned v) { return __atomic_fetch_or (p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicCAS (unsigned *p, unsigned expect, unsigned v)
 {
     __atomic_compare_exchange_n (p, &expect, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);

@@ -41,6 +41,12 @@ def test_emul_arith_long_streams(emul_engine, oracle):
              (16, bytes(60000)), (16, synth.skewed_bytes(7, 120000, 2, 0.02).tobytes()),
              # position chunks (> 64 K) through the wide-alphabet models and the all-zero special case
              (16, synth.uniform_bytes(8, 140000, 200).tobytes()), (16, synth.markov_bytes(9, 70000, 100, 20).tobytes()), (16, bytes(70000))]
+    # wide alphabet (200 symbols), but every context byte is followed by only 100 / 40 of them: over position chunks such a context
+    # runs with its own alphabet (k_ctx_succ: two register planes / one instead of four)
+    import numpy as np
+    for seed, width in ((10, 100), (11, 40)):
+        r = np.frombuffer(synth.uniform_bytes(seed, 150000, width).tobytes(), dtype=np.uint8).astype(np.int64)
+        items.append((16, (np.cumsum(r) % 200).astype(np.uint8).tobytes()))
     got = emul_engine.compress_many(items)
     for (c, d), g in zip(items, got):
         assert g == oracle.codec_compress(c, d), (c, len(d))
