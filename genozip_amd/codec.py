@@ -210,6 +210,11 @@ class ZipFile:
             z = self._download(t.z_data, t.z_len)
             out.append(dict(z=z, seq_packed=self._download(t.seq_packed, t.seq_packed_len), n_bases=t.n_bases, seq_has_x=bool(t.seq_has_x),
                             n_reads=t.n_reads, n_sections=t.n_sections))
+        # what goes to the writer: the same bytes, VBlock after VBlock, in one buffer (gz_fastq_zip_collect)
+        total = sum(len(o["z"]) for o in out)
+        dst = self.E.mem.upload(b"\xee" * (total + 64))
+        offs = self.collect(tab, len(vbs), dst, total)
+        assert offs[-1] == total and self.E.mem.download(dst, total + 64) == b"".join(o["z"] for o in out) + b"\xee" * 64, "gz_fastq_zip_collect"
         return out
 
     def _download(self, ptr, n):

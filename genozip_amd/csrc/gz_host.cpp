@@ -12,6 +12,7 @@
 #include <math.h>
 #include <atomic>
 #include <vector>
+#include <map>
 #include <chrono>
 #include <string>
 
@@ -575,6 +576,20 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
     if (getenv ("GZ_DEBUG_PIPE")) {
         uint64_t sum_big = 0; uint32_t mx = 0, mn = 0xffffffffu;
         for (size_t i = 0; i < P.plain_list.size (); i++) if (P.plain_nb[i] > A.chunk) { sum_big += P.plain_nb[i]; mx = std::max (mx, P.plain_nb[i]); mn = std::min (mn, P.plain_nb[i]); }
+        std::map<uint32_t, std::pair<uint32_t, uint32_t>> kinds;      // (codec, method, plane) -> count, max nb
+        for (size_t i = 0; i < P.plain_list.size (); i++) {
+            const GzdLeaf &L = P.leaves[P.plain_list[i]];
+            auto &k = kinds[((uint32_t)P.streams[L.stream].codec_req << 16) | ((uint32_t)L.method << 8) | L.plane];
+            k.first++; k.second = std::max (k.second, P.plain_nb[i]);
+        }
+        for (auto &k : kinds) fprintf (stderr, "[pipe]   codec %u method 0x%02x plane %u: %u leaves, nb <= %u\n", k.first >> 16, (k.first >> 8) & 0xff, k.first & 0xff, k.second.first, k.second.second);
+#ifdef GZ_MODEL_DEBUG
+        for (int pass = 0; pass < 2; pass++) {
+            const std::vector<uint32_t> &lst = pass ? small : big;
+            for (size_t i = 0; i < lst.size (); i++) { const GzdLeaf &L = P.leaves[lst[i]];
+                fprintf (stderr, "[list] %s %zu: codec %u method 0x%02x plane %u stream %u in_len %u\n", pass ? "small" : "big", i, P.streams[L.stream].codec_req, L.method, L.plane, L.stream, P.streams[L.stream].in_len); }
+        }
+#endif
         fprintf (stderr, "[pipe] bg %d np %u nbig %u nsmall %u max_arith_n %u chunk %u n_chunks %u pipelined %d reserve %d big: min %u max %u sum %llu\n", (int)h->background, A.np, A.nbig, A.nsmall,
                  P.max_arith_n, A.chunk, A.n_chunks, (int)A.pipelined, (int)A.reserve_cu, mn, mx, (unsigned long long)sum_big);
     }
@@ -924,6 +939,15 @@ static int gz_sync_do (GzHandle *h)
     g_chain_wgs.fetch_sub (h->chain_wgs_held); g_chain_cus.fetch_sub (h->chain_cus_held);
     h->chain_wgs_held = h->chain_cus_held = 0;
     HIPCHK (h, sync_err);
+#ifdef GZ_MODEL_DEBUG
+    if (!h->pending.empty ()) {
+        unsigned long long v = 0, z = 0;
+        (void)hipMemcpyFromSymbol (&v, HIP_SYMBOL (g_model_slowest), 8);
+        (void)hipMemcpyToSymbol (HIP_SYMBOL (g_model_slowest), &z, 8);
+        if (v) fprintf (stderr, "[model] bg %d slowest wave %.3f ms: %s list index %llu context %llu occurrences ~%llu\n", (int)h->background, (double)(v >> 40) / 1e5,
+                        ((v >> 39) & 1) ? "small" : "big", (v >> 28) & 0x7ff, (v >> 18) & 0x3ff, (v & 0x3ffff) * 64);
+    }
+#endif
     int rc = GZ_OK;
     bool device_failed = false;
     if (!h->pending.empty ()) {

@@ -647,6 +647,15 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
 //  With every SIMD holding several of these waves it is the issue slots, not the waves in flight, that run out.
 //  Also tried: starting the busiest contexts of a chunk first (an order computed in k_ctx_scan) instead of in symbol
 //  order - the launch is not waiting for its longest wave either: 84.0 -> 84.2 ms, 1 M pairs 33.95 -> 33.87.)
+#ifdef GZ_MODEL_DEBUG
+__device__ unsigned long long g_model_slowest;     // (10 ns ticks << 40) | (list index << 28) | (context << 18) | occurrences / 64
+#define GZ_MODEL_T0 const unsigned long long t_dbg0 = wall_clock64 ()
+#define GZ_MODEL_T1(ctx, occ) do { if (!(threadIdx.x & 63)) atomicMax (&g_model_slowest, ((wall_clock64 () - t_dbg0) << 40) | ((unsigned long long)((blockIdx.x & 0x7ff) | (chunk == 0xffffffffu ? 0x800 : 0)) << 28) | \
+                                   ((unsigned long long)((ctx) & 0x3ff) << 18) | (unsigned long long)((occ) >> 6 > 0x3ffff ? 0x3ffff : (occ) >> 6)); } while (0)
+#else
+#define GZ_MODEL_T0 do {} while (0)
+#define GZ_MODEL_T1(ctx, occ) do {} while (0)
+#endif
 __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, const GzDivMagic *magic_tab, uint32_t p0, uint32_t chunk)
 {
     GzdLeaf &L = leaves[list[blockIdx.x]];
@@ -694,7 +703,9 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
         uint32_t *st = mstate + (size_t)ctx * (GZ_MSTATE_WORDS * 64);   // (only touched when the leaf spans chunks)
         uint32_t j0 = p0, j1 = p1;
         if (sorted) { j0 = d_uniform (off[(size_t)t0 * nctx + ctx]); j1 = d_uniform (cend[ctx]); }   // my run of the sorted lists
+        GZ_MODEL_T0;
         d_arith_model_wave<1> (coded, ms_u, sorted, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        GZ_MODEL_T1 (ctx, j1 - j0);
         return;
     }
     // wide alphabets: the contexts are dealt out over the blocks of the column
@@ -704,16 +715,19 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
         uint32_t j0 = p0, j1 = p1;
         if (sorted) { j0 = d_uniform (off[(size_t)t0 * nctx + ctx]); j1 = d_uniform (cend[ctx]); }
         if (j0 == j1 && p0) continue;                           // (nothing of mine in this chunk: the saved state stands)
+        GZ_MODEL_T0;
         if (p0 == 0 && p1 == n_u && j1 > j0) {                  // a leaf in one piece: try the context's own alphabet
             GzLocalAlpha la;
             uint8_t *lds_flags = gz_lds, *lds_list = gz_lds + 256;
             const uint32_t nd = d_local_alphabet (la, coded, sorted, srk, L.symrank, L.symlist, j0, j1, lds_flags, lds_list);
             if (nd <= 64) {
                 d_arith_model_wave<1> (coded, ms_u, sorted, tr, magic_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, true, false, st, &la);
+                GZ_MODEL_T1 (ctx, j1 - j0);
                 continue;
             }
             if (nd <= 128 && nsym_u > 128) {
                 d_arith_model_wave<2> (coded, ms_u, sorted, tr, magic_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, true, false, st, &la);
+                GZ_MODEL_T1 (ctx, j1 - j0);
                 continue;
             }
         }
@@ -730,11 +744,13 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
                 __syncthreads ();
                 if (nd <= 64) d_arith_model_wave<1> (coded, ms_u, sorted, tr, magic_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, &la);
                 else          d_arith_model_wave<2> (coded, ms_u, sorted, tr, magic_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, &la);
+                GZ_MODEL_T1 (ctx, j1 - j0);
                 continue;
             }
         }
         if (nsym_u <= 128) d_arith_model_wave<2> (coded, ms_u, sorted, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
         else               d_arith_model_wave<4> (coded, ms_u, sorted, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        GZ_MODEL_T1 (ctx, j1 - j0);
     }
 }
 

@@ -339,3 +339,38 @@ __global__ void __launch_bounds__(256) k_vcf_samples (GzdVcf V)
     }
     for (; j < V.n_sub; j++) { V.item_off[(uint64_t)j * total + k] = 0; V.item_len[(uint64_t)j * total + k] = 0; if (V.missing) V.missing[(uint64_t)j * total + k] = 1; }
 }
+
+// ---- the z_data of many VBlocks, one after the other (gz_fastq_zip_collect) ---------------------------------------------------------
+// One launch instead of a hipMemcpyAsync per VBlock (448 of them per call in the streamed form). The destinations are packed -
+// arbitrary alignment against their sources: every thread assembles 16 destination-aligned bytes from five aligned words of the
+// source (head and tail of a piece byte by byte).
+struct GzdPiece { const uint8_t *src; uint8_t *dst; uint64_t len; };
+
+// grid (pieces, slices), 256 threads
+__global__ void __launch_bounds__(256) k_pieces_copy (const GzdPiece *pieces)
+{
+    const GzdPiece P = pieces[blockIdx.x];
+    if (!P.len) return;
+    const uint64_t head = P.len < 16 ? P.len : ((16 - ((uintptr_t)P.dst & 15)) & 15);      // bytes up to the first aligned destination
+    const uint64_t n16 = (P.len - head) / 16;
+    const uint64_t per = (n16 + gridDim.y - 1) / gridDim.y;
+    const uint64_t c0 = (uint64_t)blockIdx.y * per, c1 = c0 + per < n16 ? c0 + per : n16;
+    for (uint64_t c = c0 + threadIdx.x; c < c1; c += 256) {
+        const uint8_t *sp = P.src + head + c * 16;
+        const uint32_t sh = (uint32_t)((uintptr_t)sp & 3) * 8;
+        const uint32_t *w = (const uint32_t *)((uintptr_t)sp & ~(uintptr_t)3);
+        uint4 o;
+        if (!sh) { o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3]; }
+        else {
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];     // (w[4] holds the chunk's last bytes: inside the source)
+            o.x = (uint32_t)((((uint64_t)w1 << 32) | w0) >> sh); o.y = (uint32_t)((((uint64_t)w2 << 32) | w1) >> sh);
+            o.z = (uint32_t)((((uint64_t)w3 << 32) | w2) >> sh); o.w = (uint32_t)((((uint64_t)w4 << 32) | w3) >> sh);
+        }
+        *(uint4 *)(P.dst + head + c * 16) = o;
+    }
+    if (blockIdx.y == 0) {
+        const uint64_t tail0 = head + n16 * 16;
+        for (uint64_t i = threadIdx.x; i < head; i += 256) P.dst[i] = P.src[i];
+        for (uint64_t i = tail0 + threadIdx.x; i < P.len; i += 256) P.dst[i] = P.src[i];
+    }
+}

@@ -259,14 +259,23 @@ extern "C" int gz_fastq_zip_collect (GzZipFile *f, const GzFastqVB *vbs, int n_v
     if (!f || n_vbs < 0 || (n_vbs && (!vbs || !dst)) || !offsets_host) return GZ_ERR_ARG;
     GzHandle *h = f->h;
     HIPCHK (h, hipSetDevice (h->device));
-    uint64_t at = 0;
+    uint64_t at = 0, longest = 0;
+    std::vector<GzdPiece> pieces (n_vbs);
     for (int v = 0; v < n_vbs; v++) {
         offsets_host[v] = at;
         if (at + vbs[v].z_len > cap) return GZ_TOO_SMALL;
-        if (vbs[v].z_len) HIPCHK (h, hipMemcpyAsync (dst + at, vbs[v].z_data, vbs[v].z_len, hipMemcpyDeviceToDevice, h->stream));
+        pieces[v].src = vbs[v].z_data; pieces[v].dst = dst + at; pieces[v].len = vbs[v].z_len;
+        longest = std::max<uint64_t> (longest, vbs[v].z_len);
         at += vbs[v].z_len;
     }
     offsets_host[n_vbs] = at;
+    if (n_vbs && longest) {                                    // one launch for all of them
+        void *d;
+        int rc = upload (h, pieces.data (), pieces.size () * sizeof (GzdPiece), &d);
+        if (rc != GZ_OK) return rc;
+        const uint32_t slices = (uint32_t)std::min<uint64_t> (64, std::max<uint64_t> (1, longest / 65536));
+        KLAUNCH (h, k_pieces_copy, dim3 ((uint32_t)n_vbs, slices), dim3 (256), 0, (const GzdPiece *)d);
+    }
     HIPCHK (h, hipStreamSynchronize (h->stream));
     return GZ_OK;
 }
