@@ -454,7 +454,8 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
             P.rle_list.push_back ((uint32_t)P.leaves.size ());
         }
         if (nb > GZ_CHUNK_MIN && !(L.mstate = (uint32_t *)arena_alloc (h, (size_t)(rle ? 514 : 256) * GZ_MSTATE_WORDS * 64 * 4))) return false;
-        if (nb > GZ_CHUNK_MIN && o1 && !rle && !(L.succ = (uint64_t *)arena_alloc (h, 8192))) return false;
+        static const bool no_succ = getenv ("GZ_NO_SUCC") != NULL;       // (experiments: the leaf's alphabet for every context, as before)
+        if (nb > GZ_CHUNK_MIN && o1 && !rle && !no_succ && !(L.succ = (uint64_t *)arena_alloc (h, 8192))) return false;
         if (nb > P.max_arith_n) P.max_arith_n = nb;
         P.plain_list.push_back ((uint32_t)P.leaves.size ());
         P.plain_nb.push_back (nb);

@@ -524,7 +524,7 @@ __device__ static inline uint32_t d_local_alphabet (GzLocalAlpha &A, const uint8
     uint32_t nd = 0;
     #pragma unroll
     for (int k = 0; k < 4; k++) { A.m[k] = __ballot (lds_flags[k * 64 + lane] != 0); nd += (uint32_t)__popcll (A.m[k]); }
-    if (nd <= 128) {
+    if (nd <= 64) {
         #pragma unroll
         for (int k = 0; k < 4; k++) if ((A.m[k] >> lane) & 1) lds_list[d_local_rank (A, (uint32_t)(k * 64 + lane))] = symlist[k * 64 + lane];
     }
@@ -725,11 +725,8 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
                 GZ_MODEL_T1 (ctx, j1 - j0);
                 continue;
             }
-            if (nd <= 128 && nsym_u > 128) {
-                d_arith_model_wave<2> (coded, ms_u, sorted, tr, magic_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, true, false, st, &la);
-                GZ_MODEL_T1 (ctx, j1 - j0);
-                continue;
-            }
+            // (65 - 128 successors on two register planes instead of the leaf's four: measured slower here - binned-quality FASTQ 104.5 -> 109 ms
+            //  per step - although it pays for leaves in position chunks, below)
         }
         else if (succ && o1_u && !rle_u) {                      // a leaf in position chunks: the context's alphabet over the whole leaf (k_ctx_succ)
             GzLocalAlpha la;

@@ -676,8 +676,17 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     // are handed to the coders with THAT codec as soon as they are gathered, and this file's own trial - which decides, as always -
     // runs afterwards on the main handle, while the host merges: 4-5 ms of trial compressions no longer sit in front of the long
     // pole. A trial that chooses otherwise throws the work away (the streams are then coded with the rest: one call of one file pays).
+    // It pays where the long streams are the long pole of the call - few VBlocks, of the reference's usual size (measured, ms per step
+    // without / with: one file pair of 1 M reads in 14.7 MB VBlocks 98.7 / 96.0; in 4 MB VBlocks 42.0 / 47.3; 112 pairs per call
+    // 286 / 297: there the trial only gets in the way of the rest) - so: at most 64 VBlocks, the longest with >= 5 M scores.
     const int *guess = f->h_user->zip_qual_guess;
-    const bool may_spec = want_trial && !getenv ("GZ_ZIP_NO_SPECULATION") && (qmode0 == 0 ? guess[0] : qmode0 > 0 ? guess[1] : (guess[0] || guess[1]));
+    uint64_t longest_text = 0;
+    for (uint32_t v = 0; v < NV; v++) longest_text = std::max<uint64_t> (longest_text, vbs[v].text_len);
+    const char *spec_env = getenv ("GZ_ZIP_SPECULATION");                  // "always": whatever the sizes (tests)
+    const bool spec_always = spec_env && !strcmp (spec_env, "always");
+    // QUAL through CODEC_DOMQ (binned scores, 104.3 / 110.3): not by itself either.
+    bool may_spec = want_trial && !getenv ("GZ_ZIP_NO_SPECULATION") && (qmode0 == 0 ? guess[0] : qmode0 > 0 ? (spec_always && guess[1]) : (guess[0] || (spec_always && guess[1]))) &&
+                    (spec_always || (NV <= 64 && longest_text >= 10000000));
     auto add_trials = [&] (const uint8_t *in, const uint32_t *len_dev, int as_domq) -> int {
         std::vector<GzStream> &T8 = may_spec ? K.spec_trial : trial;
         const size_t first = T8.size ();
@@ -709,7 +718,14 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     ZCHK (gz_domq_columns (h, domq_jobs.data (), (int)domq_jobs.size ()));
     // the few numbers the launch of the long streams needs come back on their own, ahead of the columns' results (pinned memory)
     const size_t eb_blob = blob_jobs.size () * 8, eb_fit = qmode0 ? (size_t)NV * 4 + 8 : 0, eb_res = qmode0 ? (size_t)NV * sizeof (GzDomqResult) : 0;
-    uint8_t *eb = zip_pinned (f, eb_blob + eb_fit + eb_res + 64);
+    // (... and, further on in the same stretch, everything else the seg kernels report)
+    auto up64 = [] (size_t x) { return (x + 63) & ~(size_t)63; };
+    const size_t n_col_jobs = col_jobs.size ();
+    const size_t rb0 = up64 (eb_blob + eb_fit + eb_res + 64);
+    const size_t rb_col = rb0, rb_pack = rb_col + up64 (n_col_jobs * sizeof (GzColumnResult)), rb_tot = rb_pack + up64 (n_col_jobs * sizeof (GzdPackJob)), rb_dyn = rb_tot + 64,
+                 rb_icol = rb_dyn + up64 (dyn_jobs.size () * sizeof (GzDynIntResult)), rb_acgt = rb_icol + up64 (icol_jobs.size () * 16), rb_stat = rb_acgt + up64 (acgt_jobs.size () * 16),
+                 rb_a = rb_stat + up64 (2 * (size_t)NV * 4), rb_end = rb_a + up64 (sizeof (ABlock));
+    uint8_t *eb = zip_pinned (f, rb_end + 64);
     if (!eb) return GZ_ERR_HIP;
     if (eb_blob) HIPCHK (h, hipMemcpyAsync (eb, d_blobres, eb_blob, hipMemcpyDeviceToHost, h->stream));
     if (qmode0 && NV) {
@@ -752,6 +768,23 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     }
     T.mark ("queue");
     K.blobres.resize (blob_jobs.size () + 1);
+    // ---- read back (second wait): queued behind the seg kernels now, into page-locked memory - a copy into pageable memory would
+    // hold the host until the stream gets there, and the host has the long streams to launch in the meantime
+    K.colres.resize (NCJ + 1); K.dynres.resize (dyn_jobs.size () + 1);
+    std::vector<uint64_t> icolres (2 * icol_jobs.size () + 2);
+    K.acgtres.resize (2 * acgt_jobs.size () + 2); K.vbstat.resize (2 * (size_t)NV + 2);
+    uint64_t pack_total[2] = { 0, 1 };
+    uint8_t *rb = eb;                                      // (one page-locked stretch for both read-backs)
+    if (NCJ) {
+        HIPCHK (h, hipMemcpyAsync (rb + rb_col, d_colres, NCJ * sizeof (GzColumnResult), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK (h, hipMemcpyAsync (rb + rb_pack, d_pack, NCJ * sizeof (GzdPackJob), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK (h, hipMemcpyAsync (rb + rb_tot, d_pack_total, 16, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (!dyn_jobs.empty ())  HIPCHK (h, hipMemcpyAsync (rb + rb_dyn, d_dynres, dyn_jobs.size () * sizeof (GzDynIntResult), hipMemcpyDeviceToHost, h->stream));
+    if (!icol_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (rb + rb_icol, d_icolres, icol_jobs.size () * 16, hipMemcpyDeviceToHost, h->stream));
+    if (!acgt_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (rb + rb_acgt, d_acgtres, acgt_jobs.size () * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK (h, hipMemcpyAsync (rb + rb_stat, d_vbstat, 2 * (size_t)NV * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK (h, hipMemcpyAsync (rb + rb_a, d_a, sizeof (a), hipMemcpyDeviceToHost, h->stream));
     // ---- as soon as the gathered QUAL (and what CODEC_DOMQ makes of it) is there - the columns are still being evaluated:
     HIPCHK (h, hipEventSynchronize (f->ev_early));
     T.mark ("early-wait");
@@ -782,6 +815,19 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         if (qmode == GZ_CODEC_DOMQ) for (uint32_t v = 0; v < NV; v++) if (K.domq[v].res.status != 1) {
             vbs[v].status = GZ_ERR_CORRUPT; h->err = "QUAL: a score outside ' '..'~' (codec_domq.c:150-153)"; return GZ_ERR_CORRUPT; }
         zip_apply_qual_mode (f, qmode);
+    }
+    if (may_spec) {                                        // now that the lengths are known: is it worth it?
+        uint64_t longest = 0;
+        for (uint32_t v = 0; v < NV; v++) longest = std::max<uint64_t> (longest, COL (v, (uint32_t)f->qual_ctx).local_len);
+        if (qmode < 0 || !guess[qmode == GZ_CODEC_DOMQ] || ((longest < 5000000 || qmode == GZ_CODEC_DOMQ) && !spec_always)) {
+            // no: the trial after all, on the second handle, and the long streams wait for it (as without speculation, a little later)
+            may_spec = false;
+            trial.swap (K.spec_trial);
+            int r = gz_wait_for (f->h2, h);
+            for (size_t t = 0; r == GZ_OK && t < trial_domq.size (); t++)
+                if ((r = gz_codec_compress_batch (f->h2, trial.data () + 8 * t, 8)) != GZ_OK) h->err = f->h2->err;
+            if (r != GZ_OK) { (void)gz_sync (f->h2); return r; }
+        }
     }
     if (f->h2 && NV) {
         if (!trial.empty () && (rc = gz_sync (f->h2)) < 0) { h->err = f->h2->err; return rc; }
@@ -825,23 +871,14 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         }
     }
     T.mark ("early");
-    // ---- read back (second wait). (Into pageable memory: each of these copies waits for the stream - which is why the long streams were
-    //      launched first)
-    K.colres.resize (NCJ + 1); K.dynres.resize (dyn_jobs.size () + 1);
-    std::vector<uint64_t> icolres (2 * icol_jobs.size () + 2);
-    K.acgtres.resize (2 * acgt_jobs.size () + 2); K.vbstat.resize (2 * (size_t)NV + 2);
-    uint64_t pack_total[2] = { 0, 1 };
-    if (NCJ) {
-        HIPCHK (h, hipMemcpyAsync (K.colres.data (), d_colres, NCJ * sizeof (GzColumnResult), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK (h, hipMemcpyAsync (pack.data (), d_pack, NCJ * sizeof (GzdPackJob), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK (h, hipMemcpyAsync (pack_total, d_pack_total, 16, hipMemcpyDeviceToHost, h->stream));
-    }
-    if (!dyn_jobs.empty ())  HIPCHK (h, hipMemcpyAsync (K.dynres.data (), d_dynres, dyn_jobs.size () * sizeof (GzDynIntResult), hipMemcpyDeviceToHost, h->stream));
-    if (!icol_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (icolres.data (), d_icolres, icol_jobs.size () * 16, hipMemcpyDeviceToHost, h->stream));
-    if (!acgt_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (K.acgtres.data (), d_acgtres, acgt_jobs.size () * 16, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK (h, hipMemcpyAsync (K.vbstat.data (), d_vbstat, 2 * (size_t)NV * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK (h, hipMemcpyAsync (&a, d_a, sizeof (a), hipMemcpyDeviceToHost, h->stream));
     rc = gz_sync (h);
+    // (the results of the seg kernels were copied to page-locked memory behind them, see above: into their places)
+    if (NCJ) { memcpy (K.colres.data (), rb + rb_col, NCJ * sizeof (GzColumnResult)); memcpy (pack.data (), rb + rb_pack, NCJ * sizeof (GzdPackJob)); memcpy (pack_total, rb + rb_tot, 16); }
+    if (!dyn_jobs.empty ())  memcpy (K.dynres.data (), rb + rb_dyn, dyn_jobs.size () * sizeof (GzDynIntResult));
+    if (!icol_jobs.empty ()) memcpy (icolres.data (), rb + rb_icol, icol_jobs.size () * 16);
+    if (!acgt_jobs.empty ()) memcpy (K.acgtres.data (), rb + rb_acgt, acgt_jobs.size () * 16);
+    memcpy (K.vbstat.data (), rb + rb_stat, 2 * (size_t)NV * 4);
+    memcpy (&a, rb + rb_a, sizeof (a));
     // (from here on the second handle may be at work on this call's buffers: it is waited for before an error is returned)
 #define ZIP_FAIL(code) do { if (f->h2) (void)gz_sync (f->h2); return (code); } while (0)
     if (rc < 0) ZIP_FAIL (rc);

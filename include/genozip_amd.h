@@ -492,7 +492,9 @@ int gz_fastq_zip_end (GzZipFile *f);
 /* Speculation (no counterpart in the reference; results are the same with and without): a handle remembers which coder the QUAL
  * stream of its previous file was given by codec_assign_best_codec. The next file's long QUAL streams are handed to that coder as soon
  * as they are gathered - before the new file's own trial compressions (which still decide) are through. A trial that chooses otherwise
- * discards that work. hits / misses of the handle the file was opened on; GZ_ZIP_NO_SPECULATION=1 in the environment turns it off. */
+ * discards that work. Done by itself only where it pays: calls of at most 64 VBlocks whose plain (not CODEC_DOMQ) QUAL streams reach 5 M
+ * scores (the long pole of such a call). hits / misses of the handle the file was opened on; environment: GZ_ZIP_NO_SPECULATION=1 never,
+ * GZ_ZIP_SPECULATION=always whatever the sizes. */
 void gz_zip_speculation (const GzZipFile *f, uint32_t *hits, uint32_t *misses);
 /* a new file with the same plan (fresh dictionaries and codecs; the device workspace is kept) */
 int gz_zip_reset (GzZipFile *f);

@@ -900,6 +900,15 @@ def fastq_zip_speculation(E, oracle, n_reads):
     """the driver hands a file's long QUAL streams to the coder its handle's PREVIOUS file ended up with before the file's own trial
     compressions are through (gz_zip_speculation): same bytes whether the trial then confirms (a second file of the same kind) or
     refutes (a file whose trial chooses another coder) - every run below is compared with the oracle inside fastq_zip"""
+    import os
+    os.environ["GZ_ZIP_SPECULATION"] = "always"                      # (by itself the driver only does it for few, long VBlocks)
+    try:
+        return _fastq_zip_speculation(E, oracle, n_reads)
+    finally:
+        del os.environ["GZ_ZIP_SPECULATION"]
+
+
+def _fastq_zip_speculation(E, oracle, n_reads):
     a = fastq_zip(E, oracle, n_reads, n_calls=1, qual=("uniform",))
     b = fastq_zip(E, oracle, n_reads, n_calls=1, qual=("uniform",))
     assert b["qual_lcodec"] == a["qual_lcodec"] and b["speculation"][0] == a["speculation"][0] + 1 and b["speculation"][1] == a["speculation"][1]
