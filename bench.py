@@ -382,6 +382,8 @@ def main():
                                    "rANS / arith + framing (a9-a13, a16); a new file every step. MB counted in `value` = text WITHOUT the SEQ lines "
                                    "(SEQ is 2-bit packed in the step and handed to the host's LZMA, which is outside the path, SURVEY F8)" % (vb_bytes(a) / 1e6, "--vb-mb" if a.vb_mb else "the reference's own rule for this file, src/segconf.c:152-206"),
                       "qual_profile": a.qual, "vb_bytes": vb_bytes(a), "codecs": codecs,
+                      "qual_codec_speculation": "hits %d, misses %d since the handle was made (warm-up included): the long QUAL streams of a new file start with the codec "
+                                                "the handle's previous file got; the file's own trial compressions still run in the step and decide (gz_zip_speculation)" % wl.F.speculation(),
                       "text_mb_per_step": round(text_b / 1e6, 1), "stream_mb_per_step": round(stream_b / 1e6, 1), "compressed_mb_per_step": round(z_b / 1e6, 2),
                       "parallelism": "vblocks sharded over %d GPU(s), no data-path collective; host exchange of new dictionary words (strong scaling only); RCCL gather of z_data" % world},
            "text_mb_s": round(text_b / 1e6 / (ms_per_step / 1e3), 1), "stream_mb_s": round(stream_b / 1e6 / (ms_per_step / 1e3), 1),

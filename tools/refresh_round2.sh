@@ -13,4 +13,4 @@ timeout 200 python tools/model_probe.py > $OUT/model_probe.txt 2>&1
 bash tools/prof_round2.sh > $OUT/prof.log 2>&1
 bash tools/prof_round2_sq.sh > $OUT/prof_sq.log 2>&1
 bash tools/prof_timeline.sh > $OUT/tl.log 2>&1
-find /root/repo/gpurun_out -size +6M -delete; du -sh /root/repo/gpurun_out
+find /root/repo/gpurun_out -size +25M -delete; du -sh /root/repo/gpurun_out
