@@ -674,7 +674,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
             };
             if (!A.pipelined) {
                 if ((rc = sort_chunk (h->stream, A.d_plain, A.np, 0u, 0xffffffffu, P.max_arith_n)) != GZ_OK) return rc;
-                KLAUNCH (h, k_arith_model, dim3 (A.np, grid_y), dim3 (64), 512, d_leaves, A.d_plain, magic, 0u, 0xffffffffu);
+                KLAUNCH (h, k_arith_model, dim3 (A.np, grid_y), dim3 (64), GZ_MLDS_OFF + GZ_MLDS_BYTES, d_leaves, A.d_plain, magic, 0u, 0xffffffffu);
                 KLAUNCH (h, k_arith_chain, dim3 ((A.np + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), 64,
                          d_leaves, A.d_plain, A.np, (const uint32_t *)NULL, 0u, h->d_fail, (uint32_t *)NULL, 0u);
             }

@@ -203,7 +203,7 @@ __device__ static __forceinline__ void d_batch_counts (uint32_t p, uint64_t T, u
 // that one occurrence goes through d_model_serial_step, and the rest starts a new attempt.
 template <int J>
 __device__ static __forceinline__ void d_model_batch (GzModel<J> &M, uint32_t &tot, int lane, uint32_t cnt, uint32_t rk, uint32_t nsym,
-                                                      uint32_t n_absent, uint32_t &out_cum, uint32_t &out_freq, uint32_t &out_tot)
+                                                      uint32_t n_absent, uint32_t &out_cum, uint32_t &out_freq, uint32_t &out_tot, uint32_t &n_events)
 {
     uint64_t todo = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
     const uint32_t nbits = nsym > 1 ? 32u - (uint32_t)__builtin_clz (nsym - 1) : 0u;   // list positions are < nsym
@@ -254,6 +254,7 @@ __device__ static __forceinline__ void d_model_batch (GzModel<J> &M, uint32_t &t
                 if (!badm) break;
                 const int jv = __ffsll ((unsigned long long)badm) - 1;
                 pend &= ~((2ull << jv) - 1);
+                n_events++;
                 const bool later = lane > jv;
                 const uint32_t r = d_readlane (p, jv);
                 if (d_readlane (G, jv)) {                                   // hop
@@ -320,6 +321,107 @@ __device__ static __forceinline__ void d_model_batch (GzModel<J> &M, uint32_t &t
         out_cum = owner ? cu : out_cum; out_freq = owner ? f : out_freq; out_tot = owner ? tot : out_tot;
         d_model_serial_step<J> (M, tot, lane, r, nsym, n_absent);
     }
+}
+
+// ---- contexts whose symbols keep overtaking each other -------------------------------------------------------------------------------
+// Near-uniform frequencies (the low and high bytes of coordinates, hashes ...) make nearly every occurrence an event, and an event costs
+// the batch path ~2 000 clocks of vector -> scalar round trips (measured: 850 ns per symbol on such a context). For these the list
+// moves to LDS for a batch at a time and the occurrences are taken one by one the way the reference does (c_simple_model.h:119-146) -
+// but with every look-up a broadcast LDS read of a wave-uniform address, so that nothing leaves the vector unit: position of the
+// symbol, its frequency, its left neighbour's, bump, (halve,) hop or swap. Only the cumulative frequencies stay in the lanes'
+// registers (entry lane + 64 j): "every entry behind p gains 16" is one compare-and-add per plane there, and a swap needs no other
+// lane's value: cum'[p] = cum[p] - freq[p-1] + freq'[p]. gz_wave_sync between reads and writes: all lanes touch the same words.
+// LDS: bytes 512 .. 3391 of the workgroup's (one wave's) dynamic LDS.
+#define GZ_MLDS_OFF 512
+#define GZ_MLDS_BYTES 2880
+#ifndef GZ_MODEL_EVENTS_IN
+#define GZ_MODEL_EVENTS_IN  12            // events in a batch of 64 from which on the next batch goes through LDS ...
+#define GZ_MODEL_EVENTS_OUT 8             // ... and order changes in such a batch below which the next one is a register batch again
+#endif
+
+__device__ static __forceinline__ uint32_t d_wave_incl_scan (uint32_t v, int lane)
+{
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl ((int)v, lane >= d ? lane - d : lane); v += lane >= d ? o : 0u; }
+    return v;
+}
+
+// (tried as a real function - not inlined - because inside the kernel its scalars push the register batches' own into spills, 74 -> 116
+//  spilled SGPRs: far worse, the kernel then needs scratch memory and every wave pays for it: binned FASTQ 93 -> 158 ms per step)
+template <int J>
+__device__ static __forceinline__ void d_model_batch_lds (GzModel<J> &M, uint32_t &tot, int lane, uint32_t cnt, uint32_t rk, uint32_t nsym, uint32_t n_absent,
+                                                          const uint8_t *symlist, uint32_t &out_cum, uint32_t &out_freq, uint32_t &out_tot, uint32_t &n_changes)
+{
+    uint32_t *s_freq = (uint32_t *)(gz_lds + GZ_MLDS_OFF);                  // [256] by list position
+    uint16_t *s_gap  = (uint16_t *)(gz_lds + GZ_MLDS_OFF + 1024);           // [256] by list position
+    uint8_t  *s_rank = gz_lds + GZ_MLDS_OFF + 1536;                         // [256] list position -> static rank
+    uint8_t  *s_pos  = gz_lds + GZ_MLDS_OFF + 1792;                         // [256] static rank -> list position
+    uint8_t  *s_rk   = gz_lds + GZ_MLDS_OFF + 2048;                         // [64]  the batch's occurrences
+    uint32_t *s_out  = (uint32_t *)(gz_lds + GZ_MLDS_OFF + 2112);           // [3][64] cum, freq, total
+    #pragma unroll
+    for (int j = 0; j < J; j++) {
+        const uint32_t e = (uint32_t)(j * 64 + lane);
+        if (e < nsym) { s_freq[e] = M.freq[j]; s_gap[e] = (uint16_t)M.gap[j]; s_rank[e] = (uint8_t)M.srank[j]; s_pos[e] = (uint8_t)M.where[j]; }
+    }
+    s_rk[lane] = (uint8_t)rk;
+    gz_wave_sync ();
+    uint32_t t = tot;
+    for (uint32_t b = 0; b < cnt; b++) {
+        const uint32_t s = s_rk[b];
+        const uint32_t p = s_pos[s], q = p ? p - 1 : 0;
+        const uint32_t f = s_freq[p], g = s_gap[p], rb = s_rank[q];
+        uint32_t fl = s_freq[q];
+        gz_wave_sync ();                                           // (everybody has read)
+        #pragma unroll
+        for (int j = 0; j < J; j++) {
+            const uint32_t e = (uint32_t)(j * 64 + lane);
+            if (e == p) s_out[b] = M.cum[j];
+            M.cum[j] += e > p ? GZ_MODEL_STEP : 0u;
+        }
+        if (!lane) { s_out[64 + b] = f; s_out[128 + b] = t; }
+        uint32_t fn = f + GZ_MODEL_STEP;
+        t += GZ_MODEL_STEP;
+        if (t > GZ_MODEL_LIMIT) {                                  // rare: halve, rebuild the cumulatives and the total
+            if (!lane) s_freq[p] = fn;
+            gz_wave_sync ();
+            uint32_t run = 0, fsum = 0;
+            #pragma unroll
+            for (int j = 0; j < J; j++) {
+                const uint32_t e = (uint32_t)(j * 64 + lane);
+                uint32_t x = 0, gp = 0;
+                if (e < nsym) { x = s_freq[e]; x -= x >> 1; s_freq[e] = x; gp = s_gap[e]; }
+                const uint32_t incl = d_wave_incl_scan (x + gp, lane);
+                M.cum[j] = e < nsym ? run + incl - x : M.cum[j];   // everything in front of me + my own gap
+                run += (uint32_t)__shfl ((int)incl, 63);
+                fsum += (uint32_t)__shfl ((int)d_wave_incl_scan (x, lane), 63);
+            }
+            t = fsum + n_absent;
+            gz_wave_sync ();
+            fn = s_freq[p]; fl = s_freq[q];
+            gz_wave_sync ();
+        }
+        else if (!lane) s_freq[p] = fn;
+        if (g > 0) {                                               // an absent entry hops over (see d_model_serial_step)
+            if (!lane) { s_gap[p] = (uint16_t)(g - 1); if (p + 1 < nsym) s_gap[p + 1] = (uint16_t)(s_gap[p + 1] + 1); }
+            #pragma unroll
+            for (int j = 0; j < J; j++) M.cum[j] -= (uint32_t)(j * 64 + lane) == p ? 1u : 0u;
+            n_changes++;
+        }
+        else if (p > 0 && fl < fn) {                               // one bubble step to the left
+            if (!lane) { s_freq[q] = fn; s_freq[p] = fl; s_rank[q] = (uint8_t)s; s_rank[p] = (uint8_t)rb; s_pos[s] = (uint8_t)q; s_pos[rb] = (uint8_t)p; }
+            #pragma unroll
+            for (int j = 0; j < J; j++) M.cum[j] = (uint32_t)(j * 64 + lane) == p ? M.cum[j] - fl + fn : M.cum[j];
+            n_changes++;
+        }
+        gz_wave_sync ();                                           // (written before the next occurrence reads)
+    }
+    #pragma unroll
+    for (int j = 0; j < J; j++) {
+        const uint32_t e = (uint32_t)(j * 64 + lane);
+        if (e < nsym) { M.freq[j] = s_freq[e]; M.gap[j] = s_gap[e]; M.srank[j] = s_rank[e]; M.where[j] = s_pos[e]; M.sym[j] = symlist[M.srank[j]]; }
+    }
+    if ((uint32_t)lane < cnt) { out_cum = s_out[lane]; out_freq = s_out[64 + lane]; out_tot = s_out[128 + lane]; }
+    tot = t;
+    gz_wave_sync ();
 }
 
 // ---- grouping the positions of an order-1 leaf by context ---------------------------------------------------------
@@ -562,7 +664,10 @@ __global__ void __launch_bounds__(256) k_ctx_succ (GzdLeaf *leaves, const uint32
 //  become exec-mask code)
 // The occurrences of this wave's context inside the position chunk are entries [j0, j1) of the leaf's sorted lists
 // (order 1; srk = the symbol's rank in the leaf's alphabet), or simply positions [j0, j1) of the stream (order 0).
-template <int J>
+// LDSM: with the LDS way through eventful batches (d_model_batch_lds). Only the two instantiations that run the leaf's own (wide)
+// alphabet have it: compiled into all of them its scalars cost the others theirs (spills) - 19 -> 21 ns per symbol on a quality
+// stream, 82 -> 118 ms on BAM's packed qualities - and the contexts it is for are the near-uniform planes of integers, which are wide.
+template <int J, bool LDSM = false>
 __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, uint32_t ms, bool o1, uint4 *recs,
                                                    const GzDivMagic *magic_tab, const uint8_t *symlist, const uint16_t *symrank, uint32_t nsym,
                                                    const uint32_t *spos, const uint8_t *srk, uint32_t j0, uint32_t j1, bool first, bool save, uint32_t *st,
@@ -599,26 +704,46 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
     uint32_t p_pos = 0, p_cum = 0, p_freq = 0; GzDivMagic p_mg = { 0, 0 }; bool p_on = false;
     // ... and the occurrences of the next batch are fetched while this one is being worked on
     uint32_t nx_pos = 0, nx_rk = 0;
+    bool through_lds = false;                             // (see d_model_batch_lds)
     if (j0 + lane < j1) {
         if (o1) { nx_pos = spos[j0 + lane]; nx_rk = srk[j0 + lane]; }
         else    { nx_pos = j0 + lane; nx_rk = symrank[in[nx_pos]]; }
         if (la) nx_rk = d_local_rank (*la, nx_rk);
     }
-    for (uint32_t j = j0; j < j1; j += 64) {
-        const uint32_t cnt = j1 - j < 64 ? j1 - j : 64;
-        const bool occ = (uint32_t)lane < cnt;
-        const uint32_t b_pos = nx_pos, b_rk = nx_rk;
-        if (j + 64 + lane < j1) {
-            if (o1) { nx_pos = spos[j + 64 + lane]; nx_rk = srk[j + 64 + lane]; }
-            else    { nx_pos = j + 64 + lane; nx_rk = symrank[in[nx_pos]]; }
-            if (la) nx_rk = d_local_rank (*la, nx_rk);
-        }
-        uint32_t out_cum = 0, out_freq = 0, out_tot = 0;
-        d_model_batch<J> (M, tot, lane, cnt, occ ? b_rk : 0u, nsym, n_absent, out_cum, out_freq, out_tot);
-        if (p_on) recs[p_pos] = d_model_record (p_cum, p_freq, p_mg);
-        p_on = occ; p_pos = b_pos; p_cum = out_cum; p_freq = out_freq;
+    // (two loops taking turns rather than one loop with a branch: with both ways through a batch in one loop body the register batches
+    //  paid for the LDS way's registers - BAM's packed qualities 82 -> 120 ms of model)
+#define GZ_WAVE_BATCH_HEAD \
+        const uint32_t cnt = j1 - j < 64 ? j1 - j : 64; \
+        const bool occ = (uint32_t)lane < cnt; \
+        const uint32_t b_pos = nx_pos, b_rk = nx_rk; \
+        if (j + 64 + lane < j1) { \
+            if (o1) { nx_pos = spos[j + 64 + lane]; nx_rk = srk[j + 64 + lane]; } \
+            else    { nx_pos = j + 64 + lane; nx_rk = symrank[in[nx_pos]]; } \
+            if (la) nx_rk = d_local_rank (*la, nx_rk); \
+        } \
+        uint32_t out_cum = 0, out_freq = 0, out_tot = 0, n_ev = 0;
+#define GZ_WAVE_BATCH_TAIL \
+        if (p_on) recs[p_pos] = d_model_record (p_cum, p_freq, p_mg); \
+        p_on = occ; p_pos = b_pos; p_cum = out_cum; p_freq = out_freq; \
         if (occ) p_mg = magic_tab[out_tot];
+    for (uint32_t j = j0; j < j1; ) {
+        for (; j < j1 && !through_lds; j += 64) {
+            GZ_WAVE_BATCH_HEAD
+            d_model_batch<J> (M, tot, lane, cnt, occ ? b_rk : 0u, nsym, n_absent, out_cum, out_freq, out_tot, n_ev);
+            if constexpr (LDSM) through_lds = n_ev >= GZ_MODEL_EVENTS_IN;
+            GZ_WAVE_BATCH_TAIL
+        }
+        if constexpr (LDSM) {
+            for (; j < j1 && through_lds; j += 64) {
+                GZ_WAVE_BATCH_HEAD
+                d_model_batch_lds<J> (M, tot, lane, cnt, occ ? b_rk : 0u, nsym, n_absent, symlist, out_cum, out_freq, out_tot, n_ev);
+                through_lds = n_ev >= GZ_MODEL_EVENTS_OUT;
+                GZ_WAVE_BATCH_TAIL
+            }
+        }
     }
+#undef GZ_WAVE_BATCH_HEAD
+#undef GZ_WAVE_BATCH_TAIL
     if (p_on) recs[p_pos] = d_model_record (p_cum, p_freq, p_mg);
     if (save) {
         #pragma unroll
@@ -733,7 +858,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
             uint32_t nd = 0;
             #pragma unroll
             for (int k = 0; k < 4; k++) { la.m[k] = d_uniform64 (succ[ctx * 4 + k]); nd += (uint32_t)__popcll (la.m[k]); }
-            if (nd && (nd <= 64 || (nd <= 128 && nsym_u > 128))) {
+            if (nd && nd <= 128) {
                 uint8_t *lds_list = gz_lds + 256;
                 __syncthreads ();                              // (the previous context of this block is done with the list)
                 #pragma unroll
@@ -745,8 +870,8 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
                 continue;
             }
         }
-        if (nsym_u <= 128) d_arith_model_wave<2> (coded, ms_u, sorted, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
-        else               d_arith_model_wave<4> (coded, ms_u, sorted, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        if (nsym_u <= 128) d_arith_model_wave<2, true> (coded, ms_u, sorted, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        else               d_arith_model_wave<4, true> (coded, ms_u, sorted, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
         GZ_MODEL_T1 (ctx, j1 - j0);
     }
 }
