@@ -40,12 +40,12 @@ def test_emul_arith_long_streams(emul_engine, oracle):
              (18, synth.skewed_bytes(5, 90000, 4, 0.3).tobytes()), (17, synth.u32be_increasing(6, 80000).tobytes()),
              (16, bytes(60000)), (16, synth.skewed_bytes(7, 120000, 2, 0.02).tobytes()),
              # position chunks (> 64 K) through the wide-alphabet models and the all-zero special case
-             (16, synth.uniform_bytes(8, 140000, 200).tobytes()), (16, synth.markov_bytes(9, 70000, 100, 20).tobytes()), (16, bytes(70000))]
+             (16, synth.uniform_bytes(8, 100000, 200).tobytes()), (16, synth.markov_bytes(9, 70000, 100, 20).tobytes()), (16, bytes(70000))]
     # wide alphabet (200 symbols), but every context byte is followed by only 100 / 40 of them: over position chunks such a context
     # runs with its own alphabet (k_ctx_succ: two register planes / one instead of four)
     import numpy as np
     for seed, width in ((10, 100), (11, 40)):
-        r = np.frombuffer(synth.uniform_bytes(seed, 150000, width).tobytes(), dtype=np.uint8).astype(np.int64)
+        r = np.frombuffer(synth.uniform_bytes(seed, 110000, width).tobytes(), dtype=np.uint8).astype(np.int64)
         items.append((16, (np.cumsum(r) % 200).astype(np.uint8).tobytes()))
     got = emul_engine.compress_many(items)
     for (c, d), g in zip(items, got):
@@ -110,16 +110,16 @@ def test_emul_merge_chain(emul_engine, oracle):
 
 
 def test_emul_fastq_zip(emul_engine, oracle):
-    parity.fastq_zip(emul_engine, oracle, 140)
-    parity.fastq_zip(emul_engine, oracle, 66, small_first=True)                         # VBlocks too small to set the file's codecs
+    parity.fastq_zip(emul_engine, oracle, 100)
+    parity.fastq_zip(emul_engine, oracle, 54, small_first=True)                         # VBlocks too small to set the file's codecs
 
 
 def test_emul_fastq_zip_speculation(emul_engine, oracle):
-    parity.fastq_zip_speculation(emul_engine, oracle, 60)
+    parity.fastq_zip_speculation(emul_engine, oracle, 42)
 
 
 def test_emul_fastq_zip_two_in_flight(emul_engine, oracle):
-    parity.fastq_zip_two_in_flight(emul_engine, oracle, 40, n_calls=4)
+    parity.fastq_zip_two_in_flight(emul_engine, oracle, 30, n_calls=4)
 
 
 def test_emul_fastq_zip_errors(emul_engine, oracle):
@@ -129,10 +129,10 @@ def test_emul_fastq_zip_errors(emul_engine, oracle):
 def test_emul_fastq_zip_domq(emul_engine, oracle):
     """QUAL through CODEC_DOMQ inside the driver: the file's first VBlock decides (binned scores: a fit), later calls follow even
     with scores that would not fit; forced (--force-domq) on scores that do not fit; refused (--no-domqual) on scores that do"""
-    parity.fastq_zip(emul_engine, oracle, 100, qual=("bin", "uniform"))
-    parity.fastq_zip(emul_engine, oracle, 45, n_calls=1, qual=("uniform",), domq=13)
-    parity.fastq_zip(emul_engine, oracle, 45, n_calls=1, qual=("bin",), domq=1)
-    parity.fastq_zip(emul_engine, oracle, 66, qual=("bin", "bin"), small_first=True)
+    parity.fastq_zip(emul_engine, oracle, 72, qual=("bin", "uniform"))
+    parity.fastq_zip(emul_engine, oracle, 36, n_calls=1, qual=("uniform",), domq=13)
+    parity.fastq_zip(emul_engine, oracle, 36, n_calls=1, qual=("bin",), domq=1)
+    parity.fastq_zip(emul_engine, oracle, 54, qual=("bin", "bin"), small_first=True)
 
 
 def test_emul_ctx_golden(emul_engine, oracle):

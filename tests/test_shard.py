@@ -142,7 +142,7 @@ def test_file_dealt_out_over_2_ranks_equals_one_rank(emul_engine, qual, tiny):
     through CODEC_DOMQ - rank 1 learns that in the merge, from rank 0's blob. tiny: VBlock 1 (rank 0's) is too small to set codecs
     for the file: it keeps its own, VBlock 2 (rank 1's) sets them for VBlock 3 (rank 0's) and the rest"""
     from genozip_amd import fastq as fq
-    n_reads, n_pairs = 96, 3
+    n_reads, n_pairs = 72, 3
     text, vbs, vb_size = _pair_file(n_reads, n_pairs, qual, tiny)
     F = emul_engine.zip_open(fq.illumina_plan(paired=True, vb_size=vb_size))
     buf = emul_engine.mem.upload(text + b"\0" * 32)
