@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """TEST INFRASTRUCTURE (not collected by pytest): open-ended random cross-checks of the CPU-emulated product build
-(tests/emul) against the oracle.   python tests/fuzz_emul.py codecs|b250 [seed] [seconds]
+(tests/emul) against the oracle.   python tests/fuzz_emul.py codecs|b250|wide [seed] [seconds]
 Round 1: 4 224 codec cases (8 codecs x random structure x sizes around every threshold, with round trips) and 57 120
-b250 columns (both generation paths, dictionary sizes around every VARL boundary, ONE_UP runs) - no mismatch."""
+b250 columns (both generation paths, dictionary sizes around every VARL boundary, ONE_UP runs) - no mismatch.
+Round 2: `wide` - 608 streams of 5 000 - 70 000 bytes over alphabets of 66 - 256 byte values with holes, uniform / few successors /
+mixed / skewed, also as the bytes of 16-bit integers, through the arithmetic coders: the eventful batches of the models' LDS way
+(d_model_batch_lds) incl. halvings and position chunks - no mismatch."""
 import os
 import sys
 import time
@@ -90,8 +93,35 @@ def fuzz_b250(seed, seconds):
     print("cases", cases, "bad", bad)
 
 
+def fuzz_wide(seed, seconds):
+    E, O = engine()
+    rng = np.random.RandomState(seed)
+    t0 = time.time(); cases = bad = 0
+    while time.time() - t0 < seconds:
+        items = []
+        for _ in range(4):
+            n = int(rng.choice([5000, 9000, 17000, 30000, 70000]))
+            nsym = int(rng.choice([66, 98, 128, 129, 200, 256]))
+            alpha = np.sort(rng.choice(256, nsym, replace=False))              # holes in the alphabet
+            kind = rng.randint(0, 4)
+            if kind == 0: idx = rng.randint(0, nsym, n)                           # uniform: every symbol an event
+            elif kind == 1: idx = np.cumsum(rng.randint(0, 5, n)) % nsym         # order-1 structure, few successors
+            elif kind == 2: idx = np.where(rng.rand(n) < 0.5, rng.randint(0, nsym, n), rng.randint(0, 8, n))
+            else: idx = np.minimum(rng.geometric(0.02, n), nsym - 1)            # skewed, wide
+            d = alpha[idx].astype(np.uint8)
+            if rng.rand() < 0.3:                                                 # as the bytes of 16-bit integers
+                d = np.stack([d, (idx % 7).astype(np.uint8)], axis=1).reshape(-1)[:n]
+            items.append((int(rng.choice([16, 17, 18, 19])), d.tobytes()))
+        got = E.compress_many(items)
+        for (c, d), g in zip(items, got):
+            cases += 1
+            if g != O.codec_compress(c, d):
+                bad += 1; print("MISMATCH codec", c, "len", len(d))
+    print("cases", cases, "bad", bad)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "codecs"
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     seconds = float(sys.argv[3]) if len(sys.argv) > 3 else 60
-    (fuzz_codecs if which == "codecs" else fuzz_b250)(seed, seconds)
+    {"codecs": fuzz_codecs, "b250": fuzz_b250, "wide": fuzz_wide}[which](seed, seconds)
