@@ -94,6 +94,7 @@ struct GzdLeaf {
     uint32_t  arith_n;        // arith: symbols the coder sees: coded_n, or the number of events of the run-length variant
     uint32_t  nctx;           // arith: row length of ctxoff / ctxend: 256, or 768 for the run-length variant's 514 models
     uint32_t  *mstate;        // arith: the models' registers between two position chunks (GZ_MSTATE_WORDS x 64 lanes per context)
+    uint32_t   pres[8];       // which byte values occur in the leaf's source bytes (k_presence, many workgroups; k_leaf_prep is one)
     uint64_t  *succ;          // arith, order 1, leaves that span position chunks: 256 rows x 4 words - which symbols (leaf ranks) follow each context byte anywhere in the leaf
     uint8_t   *events;        // arith: one 32-bit digit per output byte (k_low_replay / k_low_norm)
     uint8_t   *rvals;         // arith: r = range / tot of every symbol (k_chain_expand -> k_low_*)

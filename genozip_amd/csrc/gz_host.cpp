@@ -647,6 +647,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
         KLAUNCH (h, k_stripe, dim3 (ns, chunks), dim3 (256), 0, d_streams);
     }
     if (nl) {
+        KLAUNCH (h, k_presence, dim3 (nl, GZ_PRES_SLICES), dim3 (256), 1024, d_streams, d_leaves);
         KLAUNCH (h, k_leaf_prep, dim3 (nl), dim3 (256), 4096, d_streams, d_leaves);
         // fork: the rANS leaves and the run-length arith leaves do not depend on the model/chain kernels of the plain
         // arith leaves, so they run beside them on a second stream
