@@ -637,8 +637,8 @@ __device__ static inline uint32_t d_local_alphabet (GzLocalAlpha &A, const uint8
 // The same for a leaf that spans position chunks, where a context's wave only ever sees one chunk's occurrences: which symbols follow
 // which context byte anywhere in the leaf is found by one pass over the whole leaf before its first chunk (k_ctx_succ; a 256 x 256 bit
 // matrix, 8 KB per leaf), so that a context keeps ONE alphabet - and with it one register layout in mstate - through all chunks.
-// grid (listed leaves, ceil (longest leaf / 16384)), 256 threads, 8 KB of LDS
-#define GZ_SUCC_SPAN 16384u
+// grid (listed leaves, ceil (longest leaf / 131072)), 256 threads, 8 KB of LDS (few workgroups: a leaf with a small alphabet leaves at once, and this launch sits in front of the first chunk of every long stream)
+#define GZ_SUCC_SPAN 131072u
 __global__ void __launch_bounds__(256) k_ctx_succ (GzdLeaf *leaves, const uint32_t *list)
 {
     GzdLeaf &L = leaves[list[blockIdx.x]];
