@@ -476,29 +476,50 @@ __device__ static uint32_t d_rans_encode_wave (uint32_t len_k, uint32_t rounds, 
     return used;
 }
 
-// the same coder for the (small, order-0) nested coding of a frequency table: records in LDS, no pipelining needed
-__device__ static uint32_t d_rans_encode_wave_lds (uint32_t len_k, uint32_t rounds, uint8_t *buf, uint32_t cap, const GzRansSym *tsyms, const uint8_t *tin)
+// the same coder for the order-0 nested coding of a frequency table: records in LDS. The table's bytes are fetched 64 rounds (256
+// bytes) at a time, one round's four bytes per lane, the next block while this one is coded - with a global byte load inside every
+// round (as it was) a 50 KB table of a wide order-1 stream took 12 500 x 0.9 us: k_rans_table's 12 ms in the trials of a file's first call
+__device__ static uint32_t d_rans_encode_wave_lds (uint32_t len_k, uint32_t rounds, uint8_t *buf, uint32_t cap, const GzRansSym *tsyms, const uint8_t *tin, uint32_t n_in)
 {
     const int lane = threadIdx.x & 63;
     uint32_t x = 0x8000u, used = 0;
     bool overflow = false;
-    for (uint32_t r = rounds; r-- > 0; ) {
-        const bool mine = lane < 4 && r < len_k;
-        GzRansSym s;
-        s.x_max = 0xffffffffu; s.rcp = 0; s.bias = 0; s.cmpl_rsh = 0;
-        if (mine) s = tsyms[tin[4 * r + lane]];
-        bool emit = mine && x >= s.x_max;
-        uint64_t m = __ballot (emit) & 0xfull;
-        uint32_t cnt = __popcll (m);
-        if (used + 2 * cnt + 16 > cap) { overflow = true; break; }
-        used += 2 * cnt;
-        if (emit) {
-            uint32_t below = __popcll (m & ((1ull << lane) - 1));
-            uint8_t *p = buf + cap - used + 2 * below;
-            p[0] = (uint8_t)x; p[1] = (uint8_t)(x >> 8);
-            x >>= 16;
+    // the four bytes of round rb + lane as one word (the last round may be partial: nothing past the stream is read)
+    auto fetch = [&] (int32_t rb) -> uint32_t {
+        uint32_t w = 0;
+        if (rb >= 0) {
+            const uint32_t at = 4 * ((uint32_t)rb + (uint32_t)lane);
+            #pragma unroll
+            for (uint32_t k = 0; k < 4; k++) if (at + k < n_in) w |= (uint32_t)gz_ldg_u8 (tin + at + k) << (8 * k);
         }
-        if (mine) x = d_rans_advance (x, s);
+        return w;
+    };
+    int32_t rb = rounds ? (int32_t)((rounds - 1) & ~63u) : -64;
+    uint32_t w_next = fetch (rb);
+    for (; rb >= 0 && !overflow; rb -= 64) {
+        const uint32_t w_cur = w_next;
+        w_next = fetch (rb - 64);
+        const int32_t top = (int32_t)(rounds - 1 - (uint32_t)rb) < 63 ? (int32_t)(rounds - 1 - (uint32_t)rb) : 63;
+        for (int32_t i = top; i >= 0; i--) {
+            const uint32_t r = (uint32_t)rb + (uint32_t)i;
+            const bool mine = lane < 4 && r < len_k;
+            const uint32_t v = (uint32_t)__shfl ((int)w_cur, i);
+            GzRansSym s;
+            s.x_max = 0xffffffffu; s.rcp = 0; s.bias = 0; s.cmpl_rsh = 0;
+            if (mine) s = tsyms[(v >> (8 * (lane & 3))) & 0xff];
+            bool emit = mine && x >= s.x_max;
+            uint64_t m = __ballot (emit) & 0xfull;
+            uint32_t cnt = __popcll (m);
+            if (used + 2 * cnt + 16 > cap) { overflow = true; break; }
+            used += 2 * cnt;
+            if (emit) {
+                uint32_t below = __popcll (m & ((1ull << lane) - 1));
+                uint8_t *p = buf + cap - used + 2 * below;
+                p[0] = (uint8_t)x; p[1] = (uint8_t)(x >> 8);
+                x >>= 16;
+            }
+            if (mine) x = d_rans_advance (x, s);
+        }
     }
     if (overflow) return 0xffffffffu;
     used += 16;
@@ -608,11 +629,15 @@ __global__ void __launch_bounds__(256) k_rans_table (GzdLeaf *leaves, const GzLo
             }
             __syncthreads ();
             if (!tid) {
+                // (selects instead of a branch per symbol, eight symbols' terms fetched at a time: this loop is one thread's, 65 536 times
+                //  round for a wide order-1 stream, and the only thing in flight)
+                #pragma unroll 8
                 for (uint32_t k = 0; k < ns; k++) {
                     const uint32_t fk = cellF[k];
-                    if (!fk) continue;
-                    e10 = fma (-(double)fk, cellD[2 * k], e10) + 4.0;
-                    e12 = fma (-(double)fk, cellD[2 * k + 1], e12) + 6.0;
+                    const double d10 = cellD[2 * k], d12 = cellD[2 * k + 1];
+                    const double n10 = fma (-(double)fk, d10, e10) + 4.0, n12 = fma (-(double)fk, d12, e12) + 6.0;
+                    e10 = fk ? n10 : e10;
+                    e12 = fk ? n12 : e12;
                 }
                 if (cnt < 64 && cap > 128) cap /= 2;
                 if (cap > 1024)            cap /= 2;
@@ -750,7 +775,7 @@ __global__ void __launch_bounds__(256) k_rans_table (GzdLeaf *leaves, const GzLo
             uint32_t len_k = (raw >> 2) + ((raw & 3) > (uint32_t)(tid & 3));
             uint32_t rounds = (raw + 3) >> 2;
             // (the records of the nested coder live in LDS: copy them out for the wave's global-memory fetch path)
-            uint32_t plen = d_rans_encode_wave_lds (tid < 4 ? len_k : 0, rounds, tpay, tpay_cap, tsyms, tin);
+            uint32_t plen = d_rans_encode_wave_lds (tid < 4 ? len_k : 0, rounds, tpay, tpay_cap, tsyms, tin, raw);
             if (!tid) shared[3] = plen;
         }
         __syncthreads ();
