@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """TEST INFRASTRUCTURE (not collected by pytest): open-ended random cross-checks of the CPU-emulated product build
-(tests/emul) against the oracle.   python tests/fuzz_emul.py codecs|b250|wide [seed] [seconds]
+(tests/emul) against the oracle.   python tests/fuzz_emul.py codecs|b250|wide|driver [seed] [seconds]
 Round 1: 4 224 codec cases (8 codecs x random structure x sizes around every threshold, with round trips) and 57 120
 b250 columns (both generation paths, dictionary sizes around every VARL boundary, ONE_UP runs) - no mismatch.
 Round 2: `wide` - 608 streams of 5 000 - 70 000 bytes over alphabets of 66 - 256 byte values with holes, uniform / few successors /
 mixed / skewed, also as the bytes of 16-bit integers, through the arithmetic coders: the eventful batches of the models' LDS way
-(d_model_batch_lds) incl. halvings and position chunks - no mismatch."""
+(d_model_batch_lds) incl. halvings and position chunks - no mismatch. `driver` - 164 runs of the whole VBlock driver (tests/parity.py::
+fastq_zip: 9 - 120 reads per mate, 1 - 2 calls, uniform / binned scores, the three DOMQ modes, small VBlocks first, speculation forced or
+not) against the oracle's composition - no mismatch."""
 import os
 import sys
 import time
@@ -120,8 +122,29 @@ def fuzz_wide(seed, seconds):
     print("cases", cases, "bad", bad)
 
 
+def fuzz_driver(seed, seconds):
+    import random
+    import parity
+    E, O = engine()
+    rnd = random.Random(seed)
+    t0 = time.time(); runs = bad = 0
+    while time.time() - t0 < seconds:
+        nr = rnd.choice([9, 17, 33, 50, 77, 120])
+        q = tuple(rnd.choice(["uniform", "bin"]) for _ in range(2))
+        domq, sf = rnd.choice([0, 0, 0, 1, 13]), rnd.random() < 0.4
+        if rnd.random() < 0.5: os.environ["GZ_ZIP_SPECULATION"] = "always"
+        else: os.environ.pop("GZ_ZIP_SPECULATION", None)
+        try:
+            parity.fastq_zip(E, O, nr, n_calls=rnd.choice([1, 2]), qual=q, domq=domq, small_first=sf)
+        except Exception as e:                      # noqa: BLE001
+            bad += 1; print("FAIL", nr, q, domq, sf, os.environ.get("GZ_ZIP_SPECULATION"), repr(e)[:300])
+        runs += 1
+    os.environ.pop("GZ_ZIP_SPECULATION", None)
+    print("runs", runs, "bad", bad)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "codecs"
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     seconds = float(sys.argv[3]) if len(sys.argv) > 3 else 60
-    {"codecs": fuzz_codecs, "b250": fuzz_b250, "wide": fuzz_wide}[which](seed, seconds)
+    {"codecs": fuzz_codecs, "b250": fuzz_b250, "wide": fuzz_wide, "driver": fuzz_driver}[which](seed, seconds)
