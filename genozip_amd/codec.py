@@ -197,7 +197,8 @@ class ZipFile:
 
     def results(self, tab):
         return [dict(z=self._download(t.z_data, t.z_len), seq_packed=self._download(t.seq_packed, t.seq_packed_len), n_bases=t.n_bases,
-                     seq_has_x=bool(t.seq_has_x), n_reads=t.n_reads, n_sections=t.n_sections, vblock_i=t.vblock_i) for t in tab]
+                     seq_has_x=bool(t.seq_has_x), n_reads=t.n_reads, n_sections=t.n_sections, vblock_i=t.vblock_i, text_len=t.text_len,
+                     seq_section_index=t.seq_section_index) for t in tab]
 
     def zip_vblocks(self, text, vbs):
         """text: bytes; vbs as for vb_table -> list of dict(z=bytes, seq_packed=bytes, n_bases, seq_has_x, n_reads)"""
@@ -209,7 +210,7 @@ class ZipFile:
         for t in tab:
             z = self._download(t.z_data, t.z_len)
             out.append(dict(z=z, seq_packed=self._download(t.seq_packed, t.seq_packed_len), n_bases=t.n_bases, seq_has_x=bool(t.seq_has_x),
-                            n_reads=t.n_reads, n_sections=t.n_sections))
+                            n_reads=t.n_reads, n_sections=t.n_sections, vblock_i=t.vblock_i, text_len=t.text_len, seq_section_index=t.seq_section_index))
         # what goes to the writer: the same bytes, VBlock after VBlock, in one buffer (gz_fastq_zip_collect)
         total = sum(len(o["z"]) for o in out)
         dst = self.E.mem.upload(b"\xee" * (total + 64))
@@ -225,31 +226,56 @@ class ZipFile:
         self.E._check(self.E.L.gz_download(self.E.h, out, ptr, n), "gz_download")
         return out.raw
 
-    def write_file(self, vb_results, num_lines, counts_ctxs=(), created=b"genozip_amd"):
-        """the VBlocks (dicts of zip_vblocks / results, in the order they are written) + the global area (N4) -> the whole file's
-        bytes: zfile_output_processed_vb for every VBlock, then zip_write_global_area"""
+    def insert_section(self, z, index, dict_id, codec, sub_codec, flags, ltype, param, payload, uncompressed_len):
+        """gz_vb_insert_section: a section made on the host (NONREF: CODEC_ACGT's sub-codec is the host's) into a VBlock's z_data -> bytes"""
+        L = self.E.L
+        out, ol = C.create_string_buffer(len(z) + 40 + len(payload)), C.c_uint64(0)
+        self.E._check(L.gz_vb_insert_section(z, len(z), index, dict_id, codec, sub_codec, flags, ltype, param, payload, len(payload), uncompressed_len,
+                                             out, len(out), C.byref(ol)), "gz_vb_insert_section")
+        return out.raw[:ol.value]
+
+    def with_nonref(self, r, sub_compress, vb_size=16 << 20):
+        """r: a VBlock result of zip_vblocks; sub_compress (packed bytes, vb_size) -> the LZMA stream of CODEC_ACGT's sub-codec (host work,
+        SURVEY F8: the caller's encoder). -> z with the NONREF local section where it belongs (codec_acgt_compress, src/codec_acgt.c:64-177:
+        codec ACGT, sub_codec LZMA - NONE under 50 packed bytes -, ltype LT_BLOB, flags.acgt_no_x when the VBlock has no NONREF_X,
+        data_uncompressed_len = the number of bases: the reader sizes the packed words from it, :222-226)"""
+        if not r["n_bases"]:
+            return r["z"]
+        from .fastq import dict_id
+        packed = r["seq_packed"]
+        sub = 4 if len(packed) >= 50 else 1
+        payload = sub_compress(packed, vb_size) if sub == 4 else packed
+        return self.insert_section(r["z"], r["seq_section_index"], dict_id("NONREF"), 10, sub, 0 if r["seq_has_x"] else 0x40, 11, 0, payload, r["n_bases"])
+
+    def write_file(self, components, counts_ctxs=(), created=b"genozip_amd", vb_size=16 << 20, std_seq_len=0, std_seq_len_r2=0):
+        """components: [dict(name=bytes, pair=0 | 1 | 2, vbs=[VBlock results in the order they are written, each with z, n_reads, text_len])]
+        -> the whole file: per component SEC_TXT_HEADER + its VBlocks (zfile_output_processed_vb), then zip_write_global_area (N4)"""
         L, E = self.E.L, self.E
-        zf = L.gz_zfile_create(3, 16 << 20)                    # DT_FASTQ
+        zf = L.gz_zfile_create(3, vb_size)                     # DT_FASTQ
         try:
+            E._check(L.gz_zfile_set_fastq(zf, len(components), int(any(c.get("pair") for c in components)), std_seq_len, std_seq_len_r2), "gz_zfile_set_fastq")
             body = b""
-            for r, nl in zip(vb_results, num_lines):
-                E._check(L.gz_zfile_add_vblock(zf, r["z"], len(r["z"]), len(body), 0, nl), "gz_zfile_add_vblock")
-                body += r["z"]
+            flav = bytes(8)                                    # QnameFlavorProp x NUM_QTYPES: no seq_len item, not mated, no cnn (Illumina-7, Illum-2bc)
+            for ci, comp in enumerate(components):
+                hdr = C.create_string_buffer(400)
+                E._check(L.gz_zfile_add_txt_header(zf, ci, comp.get("pair", 0), comp["name"], sum(r["text_len"] for r in comp["vbs"]), sum(r["n_reads"] for r in comp["vbs"]),
+                                                   max([r["n_reads"] for r in comp["vbs"]] + [0]), flav, 4, len(body), hdr), "gz_zfile_add_txt_header")
+                body += hdr.raw
+                for r in comp["vbs"]:
+                    E._check(L.gz_zfile_add_vblock(zf, r["z"], len(r["z"]), len(body), ci, r["n_reads"]), "gz_zfile_add_vblock")
+                    body += r["z"]
             n = len(self.plan["ctxs"])
             zc = (C.c_void_p * n)(*[L.gz_zip_zctx(self.f, i) for i in range(n)])
             ids = b"".join(c["dict_id"] for c in self.plan["ctxs"])
             cs = bytes(int(i in counts_ctxs) for i in range(n))
+            recon = sum(r["text_len"] for comp in components for r in comp["vbs"])
+            lines = sum(r["n_reads"] for comp in components for r in comp["vbs"])
             cap = 1 << 20
             while True:
                 out, ol = C.create_string_buffer(cap), C.c_uint64(0)
-                rc = L.gz_zfile_write_global_area(zf, E.h, zc, ids, cs, n, len(body), sum(len(r["z"]) for r in vb_results), sum(num_lines), created, out, cap, C.byref(ol))
-                if rc == GZ_TOO_SMALL:
+                rc = L.gz_zfile_write_global_area(zf, E.h, zc, ids, cs, n, len(body), recon, lines, created, out, cap, C.byref(ol))
+                if rc == GZ_TOO_SMALL:                         # (the entries of a failed attempt are taken back: the same GzZFile again)
                     cap = ol.value + 64
-                    L.gz_zfile_destroy(zf)
-                    zf = L.gz_zfile_create(3, 16 << 20)
-                    at = 0
-                    for r, nl in zip(vb_results, num_lines):
-                        L.gz_zfile_add_vblock(zf, r["z"], len(r["z"]), at, 0, nl); at += len(r["z"])
                     continue
                 E._check(rc, "gz_zfile_write_global_area")
                 return body + out.raw[:ol.value]

@@ -114,6 +114,7 @@ struct GzdVB {
     uint8_t  digest[16];
     uint8_t  vb_flags;
     int32_t  status;
+    uint32_t mark_stream, mark_index;  // in: a position in the VBlock's stream list; out: how many sections were written in front of it
 };
 
 // ---- decode side ----

@@ -7,12 +7,11 @@
 // entries, offsets and vblock_i as deltas, a dict_id only at its first appearance), SEC_GENOZIP_HEADER + footer
 // src/sections.h:169-307 (layout: offsets probed from the reference's headers).
 //
-// What is NOT known: the reference's own writer of SEC_GENOZIP_HEADER (zfile_compress_genozip_header, declared in
-// src/zfile.h:19) is not among the shipped sources - it lives in the closed licence module together with
-// license_piz_prepare_genozip_header, through which the reader passes the header before it trusts the section list
-// (src/zfile.c:986). The header written here fills the documented fields (magic, version, data type, sizes, section
-// count, vb_size, "created") and leaves the licence fields zero: it is readable by this repo's own reader
-// (tests/gz_reader.py) and follows the published layout, but acceptance by the reference's genounzip cannot be claimed.
+// The reference's own writer of SEC_GENOZIP_HEADER (zfile_compress_genozip_header, declared in src/zfile.h:19) is not among the shipped
+// sources - it lives in the closed licence module. The header written here follows the struct (src/sections.h:169-300; every offset
+// below is pinned to the reference's own headers by oracle/ref_hdr_shim.c -> tests/golden/hdr_golden.json) and what the reader does
+// with it (zfile_read_genozip_header, src/zfile.c:889-1060); the licence fields (license_hash, lic_type) stay zero. The reference's
+// shipped genounzip (15.0.86) accepts it and reconstructs the FASTQ text from files written here: tests/test_e2e_genounzip.py.
 #pragma once
 #include <stdint.h>
 #include <string.h>
@@ -22,10 +21,11 @@
 struct GzSecEnt { uint64_t offset; uint32_t size; uint32_t vblock_i; uint32_t num_lines; uint8_t st, comp_i, flags; uint8_t dict_id[8]; };   // SectionEnt, sections.h:584-604
 struct GzZFile {
     uint16_t data_type; uint32_t vb_size; uint8_t num_txt_files = 1;
+    uint8_t paired = 0; uint32_t std_seq_len = 0, std_seq_len_r2 = 0;
     std::vector<GzSecEnt> list;
 };
 
-enum { GZ_SEC_GENOZIP_HEADER = 6, GZ_SEC_DICT = 10, GZ_SEC_COUNTS = 17, GZ_COMP_NONE = 255 };
+enum { GZ_SEC_GENOZIP_HEADER = 6, GZ_SEC_TXT_HEADER = 8, GZ_SEC_DICT = 10, GZ_SEC_COUNTS = 17, GZ_COMP_NONE = 255 };
 
 extern "C" GzZFile *gz_zfile_create (uint16_t data_type, uint32_t vb_size_bytes)
 {
@@ -58,6 +58,68 @@ extern "C" int gz_zfile_add_vblock (GzZFile *zf, const uint8_t *z, uint64_t z_le
 }
 
 static inline void gz_be64 (uint8_t *p, uint64_t v) { gz_be32 (p, (uint32_t)(v >> 32)); gz_be32 (p + 4, (uint32_t)v); }
+static inline uint32_t gz_host_adler32 (const uint8_t *p, size_t n)
+{
+    uint32_t a = 1, b = 0;
+    for (size_t i = 0; i < n; i++) { a = (a + p[i]) % 65521u; b = (b + a) % 65521u; }
+    return (b << 16) | a;
+}
+
+extern "C" int gz_zfile_set_fastq (GzZFile *zf, uint8_t num_txt_files, uint8_t paired, uint32_t std_seq_len, uint32_t std_seq_len_r2)
+{
+    if (!zf || !num_txt_files) return GZ_ERR_ARG;
+    zf->num_txt_files = num_txt_files; zf->paired = paired; zf->std_seq_len = std_seq_len; zf->std_seq_len_r2 = std_seq_len_r2;
+    return GZ_OK;
+}
+
+// SEC_TXT_HEADER of a component without header text (FASTQ): txtheader_compress (src/txtheader.c:65-111: one fragment, vblock_i = 1, written
+// even when empty :40-41; the codec of < 50 bytes is NONE) with the fields zfile_update_txt_header_section_header fills in when the component
+// is through (src/zfile.c:1068-1105). 400 bytes (src/sections.h:308-327)
+extern "C" int gz_zfile_add_txt_header (GzZFile *zf, uint8_t comp_i, uint8_t pair, const char *txt_filename, uint64_t txt_data_size, uint64_t txt_num_lines,
+                                        uint32_t max_lines_per_vb, const uint8_t *flav_prop, uint32_t n_flav_prop, uint64_t file_offset, uint8_t *out)
+{
+    if (!zf || !out || pair > 2 || n_flav_prop > 4 || (n_flav_prop && !flav_prop)) return GZ_ERR_ARG;
+    memset (out, 0, GZ_TXT_HEADER_LEN);
+    gz_be32 (out, 0x27052012u); gz_be32 (out + 4, 1 /* adler32 of no payload */); gz_be32 (out + 20, 1);
+    out[24] = GZ_SEC_TXT_HEADER; out[25] = GZ_CODEC_NONE; out[27] = pair;                          // FlagsTxtHeader.pair (fastq_zip_set_txt_header_flags)
+    gz_be64 (out + 28, txt_data_size); gz_be64 (out + 36, txt_num_lines); gz_be32 (out + 44, max_lines_per_vb);
+    out[48] = GZ_CODEC_NONE;                                                                       // src_codec: plain text
+    if (txt_filename) strncpy ((char *)out + 84, txt_filename, 255);
+    for (uint32_t q = 0; q < n_flav_prop; q++) { out[348 + 2 * q] = flav_prop[2 * q]; out[349 + 2 * q] = flav_prop[2 * q + 1]; }
+    GzSecEnt e; memset (&e, 0, sizeof (e));
+    e.offset = file_offset; e.size = GZ_TXT_HEADER_LEN; e.vblock_i = 1; e.st = GZ_SEC_TXT_HEADER; e.comp_i = comp_i; e.flags = pair;
+    zf->list.push_back (e);
+    return GZ_OK;
+}
+
+// a section made on the host (NONREF: the sub-codec of CODEC_ACGT is the host's) into a finished VBlock
+extern "C" int gz_vb_insert_section (const uint8_t *z, uint64_t z_len, uint32_t index, const uint8_t dict_id[8], uint8_t codec, uint8_t sub_codec,
+                                     uint8_t flags, uint8_t ltype, uint8_t param, const uint8_t *payload, uint32_t payload_len, uint32_t uncompressed_len,
+                                     uint8_t *out, uint64_t out_cap, uint64_t *out_len)
+{
+    if (!z || !dict_id || (payload_len && !payload) || !out_len || z_len < 84 || gz_rd_be32 (z) != 0x27052012u || z[24] != GZ_SEC_VB_HEADER || gz_rd_be32 (z + 40) != z_len) return GZ_ERR_ARG;
+    uint64_t at = 84;
+    for (uint32_t k = 0; k < index; k++) {
+        if (at + 40 > z_len || gz_rd_be32 (z + at) != 0x27052012u) return GZ_ERR_ARG;            // (fewer sections than `index`)
+        at += 40 + (uint64_t)gz_rd_be32 (z + at + 12);
+    }
+    if (at > z_len) return GZ_ERR_CORRUPT;
+    const uint64_t total = z_len + 40 + payload_len;
+    *out_len = total;
+    if (total > 0xffffffffull) return GZ_ERR_ARG;
+    if (!out || out_cap < total) return GZ_TOO_SMALL;
+    memcpy (out, z, at);
+    uint8_t *h = out + at;
+    memset (h, 0, 40);
+    gz_be32 (h, 0x27052012u); gz_be32 (h + 4, gz_host_adler32 (payload, payload_len)); gz_be32 (h + 12, payload_len); gz_be32 (h + 16, uncompressed_len);
+    memcpy (h + 20, z + 20, 4);                                                                    // vblock_i
+    h[24] = GZ_SEC_LOCAL; h[25] = codec; h[26] = sub_codec; h[27] = flags; h[28] = ltype; h[29] = param;
+    memcpy (h + 32, dict_id, 8);
+    if (payload_len) memcpy (h + 40, payload, payload_len);
+    memcpy (h + 40 + payload_len, z + at, z_len - at);
+    gz_be32 (out + 40, (uint32_t)total);                                                           // z_data_bytes (zfile.c:1144)
+    return GZ_OK;
+}
 static inline uint32_t gz_zigzag32 (int32_t n) { return n < 0 ? ((uint32_t)(-(int64_t)n) << 1) - 1 : (uint32_t)n << 1; }   // INTERLACE, context.h:99-100
 
 // comp_compress for a global section whose header is hdr_len bytes (28 common + specific): payload through the codec (host form)
@@ -69,9 +131,7 @@ static int global_section (GzHandle *h, std::vector<uint8_t> &out, uint8_t *hdr,
     if (codec == GZ_CODEC_NONE) { if (len) memcpy (pay.data (), data, len); plen = len; }
     else { const int rc = gz_codec_compress_host (h, codec, data, len, pay.data (), &plen, 0); if (rc != GZ_OK) return rc; }
     gz_be32 (hdr + 0, 0x27052012u);
-    uint32_t a = 1, b = 0;                                                 // z_digest = adler32 (1, payload) (compressor.c:161)
-    for (uint32_t i = 0; i < plen; i++) { a = (a + pay[i]) % 65521u; b = (b + a) % 65521u; }
-    gz_be32 (hdr + 4, (b << 16) | a);
+    gz_be32 (hdr + 4, gz_host_adler32 (pay.data (), plen));                // z_digest = adler32 (1, payload) (compressor.c:161)
     gz_be32 (hdr + 8, 0); gz_be32 (hdr + 12, plen); gz_be32 (hdr + 16, len);
     hdr[25] = (uint8_t)codec;
     out.insert (out.end (), hdr, hdr + hdr_len);
@@ -88,7 +148,11 @@ extern "C" int gz_zfile_write_global_area (GzZFile *zf, GzHandle *h, GzZctx *con
     if (!zf || !h || (n_ctx && (!zctx || !dict_ids)) || !out_host || !out_len) return GZ_ERR_ARG;
     std::vector<uint8_t> out;
     int rc;
+    // (the entries of the global area join zf->list as they are written: taken back on every return that is not GZ_OK, so that the call
+    //  can be repeated - e.g. with a larger buffer after GZ_TOO_SMALL - on the same GzZFile)
+    struct Undo { std::vector<GzSecEnt> &l; size_t n; bool keep; ~Undo () { if (!keep) l.resize (n); } } undo { zf->list, zf->list.size (), false };
     // ---- SEC_DICT (dict_io.c:45-193): contexts in order, fragments of whole words below 1 MB (or twice the longest word)
+    uint32_t frag_i = 0;
     for (uint32_t c = 0; c < n_ctx; c++) {
         GzZctxView v;
         if ((rc = gz_zctx_view (zctx[c], &v)) != GZ_OK) return rc;
@@ -102,8 +166,13 @@ extern "C" int gz_zfile_write_global_area (GzZFile *zf, GzHandle *h, GzZctx *con
             if (w == w0) return GZ_ERR;
             uint8_t hd[40]; memset (hd, 0, sizeof (hd));
             hd[24] = GZ_SEC_DICT; gz_be32 (hd + 28, w - w0); memcpy (hd + 32, dict_ids + 8 * (size_t)c, 8);
+            // vblock_i: the fragment's place in the fan-out over all dictionaries (dict_io.c:146); flags: zctx->dict_flags - the word
+            // every VBlock that dropped its all-the-same b250 reconstructs (FlagsDict.all_the_same_wi, bits 2-5; context.c:846-849)
+            gz_be32 (hd + 20, ++frag_i);
+            hd[27] = v.all_the_same_wi >= 0 ? (uint8_t)((v.all_the_same_wi & 15) << 2) : 0;
             GzSecEnt e; memset (&e, 0, sizeof (e));
             e.offset = file_offset + out.size (); e.st = GZ_SEC_DICT; e.comp_i = GZ_COMP_NONE; memcpy (e.dict_id, dict_ids + 8 * (size_t)c, 8);
+            e.vblock_i = frag_i; e.flags = hd[27];
             if ((rc = global_section (h, out, hd, 40, codec ? codec : GZ_CODEC_ARTB, v.dict + v.char_index[w0], len)) != GZ_OK) return rc;
             e.size = (uint32_t)(file_offset + out.size () - e.offset);
             zf->list.push_back (e);
@@ -157,13 +226,19 @@ extern "C" int gz_zfile_write_global_area (GzZFile *zf, GzHandle *h, GzZctx *con
     // ---- SEC_GENOZIP_HEADER (720-byte header, sections.h:169-300) + payload + footer (sections.h:303-307)
     uint8_t gh[720]; memset (gh, 0, sizeof (gh));
     gh[24] = GZ_SEC_GENOZIP_HEADER;
+    gh[27] = zf->paired ? 1 : 0;                                          // FlagsGenozipHeader: dt_specific = the file holds an R1 / R2 pair; no digest, no aligner
     gh[28] = 15;                                                          // genozip_version (format parity: 15.0.86)
     gh[30] = (uint8_t)(zf->data_type >> 8); gh[31] = (uint8_t)zf->data_type;
     gz_be64 (gh + 32, recon_size);
-    { const uint64_t bits = (86ull & 0x3fff) | ((num_lines & 0xffffffffffffull) << 16); memcpy (gh + 40, &bits, 8); }   // minor version : 14, flags : 2, num_lines_bound : 48 - little endian (sections.h:174-177)
+    // minor version : 14, is_modified : 1, private_file : 1, num_lines_bound : 48 - one little-endian 64-bit word (sections.h:174-177). The
+    // reader takes BGEN64 of the 48-bit field (zfile.c:965, sections_show.c:389), so what the field holds is the low 48 bits of the byte-
+    // swapped count: counts below 65 536 read back as 0 (only progress display uses the number)
+    { const uint64_t sw = __builtin_bswap64 (num_lines) & 0xffffffffffffull;
+      const uint64_t bits = (86ull & 0x3fff) | (sw << 16); memcpy (gh + 40, &bits, 8); }
     gz_be32 (gh + 48, (uint32_t)zf->list.size ());
     gh[55] = zf->num_txt_files;
     if (created) strncpy ((char *)gh + 88, created, 71);
+    gz_be32 (gh + 460, zf->std_seq_len); gz_be32 (gh + 464, zf->std_seq_len_r2);   // fastq.segconf_std_seq_len / _lR2 (sections.h:248-257)
     gz_be32 (gh + 715, zf->vb_size);
     if ((rc = global_section (h, out, gh, 720, GZ_CODEC_NONE, fl.data (), (uint32_t)fl.size ())) != GZ_OK) return rc;
     zf->list.back ().size = (uint32_t)(file_offset + out.size () - g.offset);
@@ -173,5 +248,6 @@ extern "C" int gz_zfile_write_global_area (GzZFile *zf, GzHandle *h, GzZctx *con
     *out_len = out.size ();
     if (out.size () > out_cap) return GZ_TOO_SMALL;
     memcpy (out_host, out.data (), out.size ());
+    undo.keep = true;
     return GZ_OK;
 }

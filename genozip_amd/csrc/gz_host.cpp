@@ -818,7 +818,7 @@ extern "C" int gz_vb_compress_batch (GzHandle *h, GzVBlock *vbs, int n_vbs)
         memset (&D, 0, sizeof (D));
         D.z_data = u.z_data; D.z_cap = u.z_cap; D.first_stream = (uint32_t)P.streams.size (); D.n_streams = u.n_sections;
         D.vblock_i = u.vblock_i; D.recon_size = u.recon_size; D.longest_line_len = u.longest_line_len; D.longest_seq_len = u.longest_seq_len;
-        memcpy (D.digest, u.digest, 16); D.vb_flags = u.vb_flags; D.status = GZ_ST_PENDING;
+        memcpy (D.digest, u.digest, 16); D.vb_flags = u.vb_flags; D.status = GZ_ST_PENDING; D.mark_stream = u.mark_section;
         u.status = GZ_ST_PENDING; u.z_len = 0;
         for (uint32_t k = 0; k < u.n_sections; k++) {
             const GzSection &sec = u.sections[k];
@@ -984,7 +984,7 @@ static int gz_sync_do (GzHandle *h)
             GzVBlock *u = (GzVBlock *)pd.user;
             for (int i = 0; i < pd.n; i++) {
                 u[i].status = V[i].status == GZ_ST_OK ? GZ_OK : V[i].status == GZ_ST_TOO_SMALL ? GZ_TOO_SMALL : GZ_ERR;
-                u[i].z_len  = V[i].z_len;
+                u[i].z_len  = V[i].z_len; u[i].mark_index = V[i].mark_index;
                 if (u[i].status == GZ_ERR) rc = GZ_ERR; else if (u[i].status != GZ_OK && rc != GZ_ERR) rc = GZ_TOO_SMALL;
             }
         }

@@ -898,13 +898,16 @@ __global__ void k_vb_layout (GzdVB *vbs, GzdStream *streams, uint32_t n_vbs)
     GzdVB &V = vbs[v];
     uint64_t off = 84;                                   // SectionHeaderVbHeader first (zip.c:560)
     bool failed = false;
+    uint32_t written_before_mark = 0;
     for (uint32_t k = 0; k < V.n_streams; k++) {
         GzdStream &S = streams[V.first_stream + k];
         if (S.status == GZ_ST_FAILED) failed = true;
         S.z_off = off;
         if (!S.n && S.in_len_dev) continue;              // generated on the device and dropped there (b250.c:270-277): no section
         off += 40 + (uint64_t)S.out_len;
+        if (k < V.mark_stream) written_before_mark++;
     }
+    V.mark_index = written_before_mark;
     V.z_len = off;
     V.status = failed ? GZ_ST_FAILED : off <= V.z_cap ? GZ_ST_OK : GZ_ST_TOO_SMALL;
 

@@ -374,3 +374,45 @@ __global__ void __launch_bounds__(256) k_pieces_copy (const GzdPiece *pieces)
         for (uint64_t i = tail0 + threadIdx.x; i < P.len; i += 256) P.dst[i] = P.src[i];
     }
 }
+
+// ---- SQBITMAP: the snip of every read (fastq_seg_SEQ, src/fastq_seq.c:45-154, the branches a file without reference / aligner takes) ------
+// A read's bases go to NONREF.local verbatim and SQBITMAP gets { SNIP_SPECIAL, FASTQ_SPECIAL_unaligned_SEQ, ' ', decimal seq_len } (:139-146);
+// a read that is one base repeated is not stored: the base takes the place of the ' ' (:120-126, dl->monochar = str_is_monochar, fastq.c:1267);
+// an empty read is '*' without a length (:113-117). One thread per read: 16-byte slot of snip text (prefix <= 4 bytes + <= 10 digits), its
+// (offset, length) for the column kernels, and the length the NONREF gather is to take (0 for a repeated base). The 150 bases of a read
+// are compared with the first 16 bytes at a time.
+struct GzdSeqSnip {
+    const uint8_t *text; const uint32_t *seq_off, *seq_len, *l3_len; uint32_t n;
+    uint8_t prefix[4]; uint32_t prefix_len;      // { SNIP_SPECIAL, code, ' ' }: the last byte is the one a repeated base / '*' replaces
+    uint8_t *slots; uint32_t *snip_off, *snip_len, *nonref_len; uint32_t *n_line3;   // n_line3: reads whose line 3 is more than "+" (the plan says L3_EMPTY)
+};
+
+__global__ void __launch_bounds__(256) k_seq_snips (GzdSeqSnip S)
+{
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= S.n) return;
+    const uint32_t len = S.seq_len[r];
+    const uint8_t *p = S.text + S.seq_off[r];
+    bool mono = len != 0;
+    if (len) {
+        const uint8_t c = p[0];
+        const uint64_t pat = 0x0101010101010101ull * c;
+        uint32_t i = 0;
+        for (; mono && i < len && ((uintptr_t)(p + i) & 7); i++) mono = p[i] == c;
+        for (; mono && i + 8 <= len; i += 8) mono = *(const uint64_t *)(p + i) == pat;
+        for (; mono && i < len; i++) mono = p[i] == c;
+    }
+    uint8_t *s = S.slots + (size_t)r * 16;
+    uint32_t k = 0;
+    for (; k + 1 < S.prefix_len; k++) s[k] = S.prefix[k];
+    s[k++] = !len ? '*' : mono ? p[0] : S.prefix[S.prefix_len - 1];
+    if (len) {
+        char d[10]; int nd = 0;
+        for (uint32_t v = len; v; v /= 10) d[nd++] = (char)('0' + v % 10);
+        while (nd) s[k++] = (uint8_t)d[--nd];
+    }
+    for (uint32_t z = k; z < 16; z++) s[z] = 0;
+    S.snip_off[r] = r * 16; S.snip_len[r] = k;
+    S.nonref_len[r] = mono ? 0 : len;
+    if (S.l3_len[r]) atomicAdd (S.n_line3, 1u);
+}

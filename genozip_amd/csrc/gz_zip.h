@@ -88,14 +88,17 @@ struct ZipCall {                   // what lives between the phases of one call
     GzDynIntResult *d_dynres = NULL; uint32_t *d_seclen = NULL; int32_t *d_b250st = NULL;
     std::vector<uint8_t> blob;      // this process' merge blob
     std::vector<ZipVote> votes;
-    std::vector<GzVBlock> V; std::vector<std::vector<GzSection>> secs; std::vector<int32_t> b250st;   // phase 3, between launch and wait
+    std::vector<GzVBlock> V; std::vector<std::vector<GzSection>> secs; std::vector<int32_t> b250st; int32_t *b250st_pinned = NULL;   // phase 3, between launch and wait
     std::vector<ZipDomq> domq;                 // per VBlock, when the file's QUAL may go / goes through CODEC_DOMQ
     int qual_mode_applied = -1;
+    std::vector<std::vector<uint8_t>> own_snip; // per (VBlock, context): the snip a GZ_FQ_TOPLEVEL context segs in this VBlock
     std::vector<GzStream> early;               // the streams coded ahead (results arrive when the second handle is synchronised)
     uint32_t *d_early_len = NULL;
     // speculation: the long streams were handed to the coders with the codec the handle's previous file ended up with, before this
     // file's own trial (a8) was through; the trial (queued on the main handle once the seg phase has its results) confirms or refutes
     std::vector<GzStream> spec_trial; int spec_codec = 0; size_t spec_t = 0; bool spec = false, spec_pending = false;
+    std::vector<GzStream> trial;               // the trial compressions queued on the second handle in the seg phase: the coder keeps pointers into
+                                               // it (GzStream.status / out_len) until that handle is synchronised, so it lives as long as the call
     std::vector<int32_t> n2w_host;
     std::map<uint32_t, ZipVBState> vbstate;   // by vblock_i: every VBlock of the call, own or not
 };
@@ -114,6 +117,7 @@ struct GzZipFile {
     // zctx->qual_codec of the QUAL context (codec.c:403-407,445): -1 not decided yet (the file's first VBlock will), 0 a plain
     // LT_BLOB local, GZ_CODEC_DOMQ
     int qual_ctx = -1, aux[3] = { -1, -1, -1 }, qual_mode = 0;
+    int seq_snip_ctx = -1;                 // the plan's GZ_FQ_SEQ_SNIP context (SQBITMAP)
     hipEvent_t ev_early = NULL;
     uint8_t *pinned = NULL; size_t pinned_size = 0;      // host memory the device can write while the host does something else
     ZipCall call;
@@ -192,6 +196,8 @@ extern "C" GzZipFile *gz_zip_open (GzHandle *h, const GzFastqPlan *plan)
         c.snip = f->snips[i].data ();
         if ((c.kind == GZ_FQ_ITEM_TEXT || c.kind == GZ_FQ_ITEM_INT || c.kind == GZ_FQ_ITEM_DELTA) && c.item > plan->n_seps) return zip_open_failed (f);
         if ((c.kind == GZ_FQ_CONST || c.kind == GZ_FQ_ITEM_DELTA) && !c.snip_len) return zip_open_failed (f);
+        if (c.kind == GZ_FQ_TOPLEVEL && (c.con_len < 8 || c.con_len > c.snip_len || (c.con_len - 8) % 12)) return zip_open_failed (f);   // Container_0 + n ContainerItem
+        if (c.kind == GZ_FQ_SEQ_SNIP) { if (!c.snip_len || c.snip_len > 4 || f->seq_snip_ctx >= 0) return zip_open_failed (f); f->seq_snip_ctx = (int)i; }
         if (c.kind == GZ_FQ_QUAL) { if (f->qual_ctx >= 0) return zip_open_failed (f); f->qual_ctx = (int)i; }     // (one QUAL per plan)
         if (c.kind == GZ_FQ_QUAL_AUX) { if (c.item > 2 || f->aux[c.item] >= 0) return zip_open_failed (f); f->aux[c.item] = (int)i; }
         f->zctx.push_back (gz_zctx_create (plan->estimated_entries));
@@ -451,7 +457,9 @@ static inline void blob_put (std::vector<uint8_t> &b, const void *p, size_t n)
 extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len, GzFastqVB *vbs, int n_vbs, const void **blob_out, uint64_t *blob_len_out)
 {
     if (!f || !blob_out || !blob_len_out) return GZ_ERR_ARG;
-    if (f->call.phase != 0 && f->h2) (void)gz_sync (f->h2);   // (the previous call was given up half way: its long streams may still be running in the workspace)
+    // (a previous call that was given up half way - in any phase, also inside its seg phase with f->call.phase still 0 - may have left
+    //  trial or long streams running on the second handle: in the workspace that is about to be reused, with results going to f->call)
+    if (f->h2) (void)gz_sync (f->h2);
     if (n_vbs == 0) {                                      // a process without VBlocks in this call still takes part in the merge
         int rc0 = gz_sync (f->h);
         if (rc0 < 0) return rc0;
@@ -487,7 +495,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     const uint32_t lookup_off = (uint32_t)text_len;
     uint32_t line_cap = (uint32_t)(text_len / 16 + 1024);
     uint32_t *line_off = NULL, *line_len = NULL;
-    struct ABlock { GzLinesResult lines; uint32_t bad_bound, n_bad_items; GzFastqResult fq; } ;
+    struct ABlock { GzLinesResult lines; uint32_t bad_bound, n_bad_items; GzFastqResult fq; uint32_t n_line3, pad; } ;
     WS (d_a, ABlock, 1);
     WS (d_vb_off, uint64_t, 2 * NV + 2);
     WS (d_first_line, uint32_t, 2 * NV + 2);
@@ -533,6 +541,19 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     uint32_t *l1_off = rec, *l1_len = rec + (R + 8), *seq_off = rec + 2 * (size_t)(R + 8), *seq_len = rec + 3 * (size_t)(R + 8),
              *l3_off = rec + 4 * (size_t)(R + 8), *l3_len = rec + 5 * (size_t)(R + 8), *qual_off = rec + 6 * (size_t)(R + 8), *qual_len = rec + 7 * (size_t)(R + 8);
     ZCHK (gz_fastq_records (h, text, line_off, line_len, &d_a->lines, R, l1_off, l1_len, seq_off, seq_len, l3_off, l3_len, qual_off, qual_len, &d_a->fq));
+    // SQBITMAP's snip of every read, and what NONREF takes of it (fastq_seg_SEQ): a read of one repeated base is not stored
+    uint8_t *sq_slots = NULL; uint32_t *sq_off = NULL, *sq_len = NULL, *nonref_len = NULL;
+    if (f->seq_snip_ctx >= 0 || f->plan.line3_empty) {
+        const GzFastqCtx *X = f->seq_snip_ctx >= 0 ? &f->ctxs[f->seq_snip_ctx] : NULL;
+        if (!(sq_slots = (uint8_t *)ws_alloc (f, (size_t)R * 16 + 64)) || !(sq_off = (uint32_t *)ws_alloc (f, ((size_t)R + 8) * 4)) ||
+            !(sq_len = (uint32_t *)ws_alloc (f, ((size_t)R + 8) * 4)) || !(nonref_len = (uint32_t *)ws_alloc (f, ((size_t)R + 8) * 4))) return GZ_ERR_HIP;
+        GzdSeqSnip S; memset (&S, 0, sizeof (S));
+        S.text = text; S.seq_off = seq_off; S.seq_len = seq_len; S.l3_len = l3_len; S.n = R;
+        S.prefix_len = X ? X->snip_len : 1; if (X) memcpy (S.prefix, X->snip, X->snip_len); else S.prefix[0] = ' ';
+        S.slots = sq_slots; S.snip_off = sq_off; S.snip_len = sq_len; S.nonref_len = nonref_len; S.n_line3 = &d_a->n_line3;
+        if (R) KLAUNCH (h, k_seq_snips, dim3 ((R + 255) / 256), dim3 (256), 0, S);
+        if (f->seq_snip_ctx < 0) nonref_len = NULL;                        // (only the line-3 check was wanted: SEQ as the plan without SQBITMAP has it)
+    }
     WS (item_off, uint32_t, (size_t)NI * R + 8);
     WS (item_len, uint32_t, (size_t)NI * R + 8);
     WS (d_vbstat, uint32_t, 2 * (size_t)NV + 2);
@@ -542,7 +563,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     std::vector<OlDev> ol (NC);
     for (uint32_t c = 0; c < NC; c++) {
         const uint8_t k = f->ctxs[c].kind;
-        if (k != GZ_FQ_ITEM_TEXT && k != GZ_FQ_ITEM_INT) continue;
+        if (k != GZ_FQ_ITEM_TEXT && k != GZ_FQ_ITEM_INT && k != GZ_FQ_SEQ_SNIP) continue;
         GzZctxView zv; gz_zctx_view (f->zctx[c], &zv);
         ol[c].n = zv.n_words;
         if (!zv.n_words) continue;
@@ -612,12 +633,13 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
                 dj.out = Z.local; Z.dyn_job = (int)dyn_jobs.size (); dj.result_dev = d_dynres + Z.dyn_job;
                 dyn_jobs.push_back (dj);
             }
-            if (X.kind == GZ_FQ_ITEM_TEXT || X.kind == GZ_FQ_ITEM_INT) {
+            if (X.kind == GZ_FQ_ITEM_TEXT || X.kind == GZ_FQ_ITEM_INT || X.kind == GZ_FQ_SEQ_SNIP) {
                 GzColumnJob j; memset (&j, 0, sizeof (j));
                 j.text = text; j.off = coff; j.len = clen; j.n = n;
+                if (X.kind == GZ_FQ_SEQ_SNIP) { j.text = sq_slots; j.off = sq_off + rr; j.len = sq_len + rr; }   // (generated text: 16-byte slots)
                 j.ol_dict = ol[c].dict; j.ol_char_index = ol[c].ci; j.ol_snip_len = ol[c].sl; j.n_ol = ol[c].n;
                 // the dictionary of a column cannot exceed its snips + a NUL each; an item is at most the line
-                const uint64_t dict_cap = X.kind == GZ_FQ_ITEM_INT ? (uint64_t)n * 24 + 64 : vbs[v].text_len + n + 64;
+                const uint64_t dict_cap = X.kind == GZ_FQ_ITEM_INT ? (uint64_t)n * 24 + 64 : X.kind == GZ_FQ_SEQ_SNIP ? (uint64_t)n * 17 + 64 : vbs[v].text_len + n + 64;
                 j.node_index = (int32_t *)ws_alloc (f, ((size_t)n + 1) * 4); j.dict = (uint8_t *)ws_alloc (f, dict_cap); j.dict_cap = dict_cap;
                 j.node_char_index = (uint64_t *)ws_alloc (f, ((size_t)n + 1) * 8); j.node_snip_len = (uint32_t *)ws_alloc (f, ((size_t)n + 1) * 4);
                 j.counts = (uint32_t *)ws_alloc (f, ((size_t)n + ol[c].n + 1) * 4); j.b250 = (uint8_t *)ws_alloc (f, (size_t)n * 4 + 16);
@@ -642,7 +664,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
             }
             if (X.kind == GZ_FQ_SEQ || (X.kind == GZ_FQ_QUAL && qmode0 <= 0)) {
                 GzBlobJob j; memset (&j, 0, sizeof (j));
-                j.text = text; j.off = (X.kind == GZ_FQ_SEQ ? seq_off : qual_off) + rr; j.len = (X.kind == GZ_FQ_SEQ ? seq_len : qual_len) + rr; j.n = n;
+                j.text = text; j.off = (X.kind == GZ_FQ_SEQ ? seq_off : qual_off) + rr; j.len = (X.kind == GZ_FQ_SEQ ? (nonref_len ? nonref_len : seq_len) : qual_len) + rr; j.n = n;
                 Z.local_cap = vbs[v].text_len + 64;
                 if (!(Z.local = (uint8_t *)ws_alloc (f, Z.local_cap + 64))) return GZ_ERR_HIP;
                 j.out = Z.local; Z.blob_job = (int)blob_jobs.size (); j.out_len_dev = d_blobres + Z.blob_job;
@@ -666,8 +688,8 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     // the trial compressions (a8) of the first VBlock's QUAL sit in front of that pole: their input - the first 99 999 bytes of
     // QUAL.local (codec.c:309) - is gathered on its own, ahead of everything, and they start on the second handle right away
     static const int trial_codecs[8] = { GZ_CODEC_RANB, GZ_CODEC_RANW, GZ_CODEC_RANb, GZ_CODEC_RANw, GZ_CODEC_ARTB, GZ_CODEC_ARTW, GZ_CODEC_ARTb, GZ_CODEC_ARTw };
-    std::vector<GzStream> trial;                          // 8 per candidate form of QUAL (plain / through DOMQ) that needs a codec
-    trial.reserve (16);                                   // (the coder keeps pointers into it until the second handle is synchronised)
+    std::vector<GzStream> &trial = K.trial;               // 8 per candidate form of QUAL (plain / through DOMQ) that needs a codec
+    trial.clear (); trial.reserve (16);                   // (the coder keeps pointers into it until the second handle is synchronised: never reallocated)
     std::vector<uint32_t> trial_ctx; std::vector<int> trial_domq;
     const bool own_first = vbs[0].vblock_i == f->last_vblock_i + 1;   // (vblock_i are consecutive over the processes: this one opens the call)
     bool want_trial = false;
@@ -887,6 +909,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         for (uint32_t v = 0; v < NV; v++) if (a.fq.first_bad >= r0[v] && a.fq.first_bad < r_end[v]) vbs[v].status = GZ_ERR_CORRUPT;
         h->err = "not FASTQ: a read is not '@'.. / SEQ / '+'.. / QUAL of SEQ's length (fastq.c:1008-1010,1076,1121)"; ZIP_FAIL (GZ_ERR_CORRUPT);
     }
+    if (f->plan.line3_empty && a.n_line3) { h->err = "line 3 of a read is more than '+' (the plan says L3_EMPTY; fastq_desc.c:35-37)"; ZIP_FAIL (GZ_ERR_CORRUPT); }
     if (a.n_bad_items) { h->err = "a line 1 does not fit the container of the plan (the reference would re-discover the flavor, qname.c:823-826)"; ZIP_FAIL (GZ_ERR_CORRUPT); }
     for (size_t k = 0; k < icol_jobs.size (); k++)
         if ((int32_t)icolres[2 * k + 1] == GZ_ST_CORRUPT) { h->err = "an ordered item is not an integer (qname.c:750-756)"; ZIP_FAIL (GZ_ERR_CORRUPT); }
@@ -905,6 +928,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
 
     // ---- the merge blob: per VBlock, per context, what ctx_merge_in_one_vctx reads of the VBlock's context ------------------
     K.blob.clear ();
+    K.own_snip.assign ((size_t)NV * NC, std::vector<uint8_t> ());
     for (uint32_t v = 0; v < NV; v++) {
         ZipBlobVB hv = { vbs[v].vblock_i, vbs[v].r1 >= 0 ? vbs[vbs[v].r1].vblock_i : 0, NC, 0 };
         if (qmode0) hv.qual = (qmode0 < 0 ? 1u : 0u) | (K.domq[v].fit ? 2u : 0u) | (K.domq[v].res.status != 1 ? 4u : 0u);
@@ -918,7 +942,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
             if (X.kind == GZ_FQ_SEQ) {                                     // NONREF itself leaves the path 2-bit packed; what stays is NONREF_X
                 const int aj = K.acgt_of_vb[v];
                 vbs[v].n_bases = Z.local_len; vbs[v].seq_packed_len = K.acgtres[2 * aj + 1]; vbs[v].seq_has_x = (uint32_t)K.acgtres[2 * aj] != 0;
-                Z.has_local = vbs[v].seq_has_x != 0; Z.ltype = GZ_LT_UINT8;  // NONREF_X.ltype (codec_acgt.c:34-35)
+                Z.has_local = vbs[v].seq_has_x != 0; Z.ltype = GZ_LT_SUPP;   // NONREF_X.ltype (codec_acgt.c:36-41)
             }
             r.n = Z.n; r.local_len = X.kind == GZ_FQ_QUAL ? (Z.blob_job >= 0 ? K.blobres[Z.blob_job] : 0) : Z.local_len; r.ats_node = -1;
             if (qmode0 && Z.n && (X.kind == GZ_FQ_QUAL || X.kind == GZ_FQ_QUAL_AUX)) {
@@ -931,7 +955,21 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
                 }
             }
             if (X.kind == GZ_FQ_SEQ || X.kind == GZ_FQ_QUAL || X.kind == GZ_FQ_QUAL_AUX || !Z.n) { blob_put (K.blob, &r, sizeof (r)); continue; }
-            if (Z.col_job < 0) { r.state = 2; blob_put (K.blob, &r, sizeof (r)); continue; }
+            if (X.kind == GZ_FQ_TOPLEVEL) {
+                // container_seg of the VBlock's TOPLEVEL (fastq.c:845-943): repeats = the VBlock's reads (Container.repeats: bits 8-31 of the
+                // first little-endian word, container.h:74-80; written little endian since 15.0.84, container.c:48-55), then
+                // SNIP_CONTAINER + base64 of the struct + the prefixes (container.c:35-64). One b250 entry.
+                std::vector<uint8_t> con (X.snip, X.snip + X.con_len), b64;
+                if (Z.n > 0xfffff0u) { h->err = "more reads in a VBlock than a container can repeat (CONTAINER_MAX_REPEATS)"; ZIP_FAIL (GZ_ERR_ARG); }
+                con[1] = (uint8_t)Z.n; con[2] = (uint8_t)(Z.n >> 8); con[3] = (uint8_t)(Z.n >> 16);
+                zip_base64 (con.data (), con.size (), b64);
+                std::vector<uint8_t> &own = K.own_snip[(size_t)v * NC + c];
+                own.assign (1, 4 /* SNIP_CONTAINER */); own.insert (own.end (), b64.begin (), b64.end ()); own.insert (own.end (), X.snip + X.con_len, X.snip + X.snip_len);
+                r.state = 3; r.n = 1; r.dict_len = own.size ();
+                blob_put (K.blob, &r, sizeof (r)); blob_put (K.blob, own.data (), own.size ());
+                continue;
+            }
+            if (Z.col_job < 0) { r.state = 2; r.n = Z.n * (X.segs_per_line ? X.segs_per_line : 1); blob_put (K.blob, &r, sizeof (r)); continue; }
             const GzColumnResult &cr = K.colres[Z.col_job];
             const GzdPackJob &p = pack[Z.col_job];
             const uint32_t *counts = (const uint32_t *)(f->stage.data () + p.at[3]);
@@ -1007,9 +1045,14 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
                 if ((size_t)(end - p) < sizeof (ZipMergeRec)) { h->err = "merge blob: truncated"; return GZ_ERR_CORRUPT; }
                 const ZipMergeRec *r = (const ZipMergeRec *)p;
                 p += sizeof (ZipMergeRec);
-                if (r->state == 1) p += ((r->dict_len + 7) & ~7ull) + 8ull * r->n_new + ((4ull * r->n_new + 7) & ~7ull) + ((4ull * ((uint64_t)r->n_ol + r->n_new) + 7) & ~7ull);
-                if (r->state == 3) p += (r->dict_len + 7) & ~7ull;
-                if (p > end) { h->err = "merge blob: truncated"; return GZ_ERR_CORRUPT; }
+                // (lengths come from a peer's blob: sized in 64 bits and compared with what is left BEFORE the pointer moves)
+                if (r->state > 3 || r->dict_len > (uint64_t)(end - p)) { h->err = "merge blob: corrupt record"; return GZ_ERR_CORRUPT; }
+                uint64_t need = 0;
+                if (r->state == 1) need = ((r->dict_len + 7) & ~7ull) + 8ull * r->n_new + ((4ull * r->n_new + 7) & ~7ull) + ((4ull * ((uint64_t)r->n_ol + r->n_new) + 7) & ~7ull);
+                if (r->state == 3) need = (r->dict_len + 7) & ~7ull;
+                if (need > (uint64_t)(end - p)) { h->err = "merge blob: truncated"; return GZ_ERR_CORRUPT; }
+                if (r->state == 1 && r->n_ol > f->zctx[c]->snip_len.size ()) { h->err = "merge blob: more cloned words than the dictionary has"; return GZ_ERR_CORRUPT; }
+                p += need;
             }
         }
     }
@@ -1060,7 +1103,7 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
             bool has_local = local_len != 0;
             if (X.kind == GZ_FQ_SEQ) has_local = mine ? Z.has_local : false;    // (NONREF_X takes no part in any pair rule)
             VS.has_local[c] = has_local;
-            if (r->state == 0 || (r->state == 3 && qmode != GZ_CODEC_DOMQ)) continue;
+            if (r->state == 0 || (r->state == 3 && X.kind == GZ_FQ_QUAL_AUX && qmode != GZ_CODEC_DOMQ)) continue;
             GzMergeJob m; memset (&m, 0, sizeof (m));
             m.vblock_i = hv->vblock_i;
             m.local_len = local_len;
@@ -1332,17 +1375,22 @@ static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint
     std::vector<std::vector<GzSection>> &secs = K.secs;
     for (uint32_t v = 0; v < NV; v++) {
         const bool is_r2 = vbs[v].r1 >= 0, is_r1 = f->plan.paired && !is_r2;
-        std::vector<GzSecOrderIn> in (NC);
+        std::vector<GzSecOrderIn> in (NC + 1);
         for (uint32_t c = 0; c < NC; c++) {
             const ZipCol &Z = COL (v, c);
             in[c].did_i = f->ctxs[c].did_i; in[c].local_dep = f->ctxs[c].local_dep;
             if ((int)c == f->qual_ctx && f->qual_mode == GZ_CODEC_DOMQ) in[c].local_dep = 1;           // DEP_L1 (codec_domq.c:310)
             in[c].has_local = Z.has_local; in[c].ston_only_local = Z.ston_only_local; in[c].has_b250 = Z.has_b250;
+            // NONREF itself - the context in front of NONREF_X (sam.h:77-79), DEP_L0 - leaves the path 2-bit packed for the host's
+            // sub-codec; where its local section belongs among the VBlock's sections is reported (GzFastqVB.seq_section_index)
+            if (f->ctxs[c].kind == GZ_FQ_SEQ) { memset (&in[NC], 0, sizeof (in[NC])); in[NC].did_i = f->ctxs[c].did_i - 1; in[NC].has_local = vbs[v].n_bases != 0; }
         }
-        std::vector<uint32_t> order (2 * NC);
-        const uint32_t ns = gz_section_order (in.data (), NC, vbs[v].vblock_i, order.data ());
+        std::vector<uint32_t> order (2 * NC + 2);
+        const uint32_t ns = gz_section_order (in.data (), NC + 1, vbs[v].vblock_i, order.data ());
+        uint32_t mark = 0;
         for (uint32_t k = 0; k < ns; k++) {
             const uint32_t c = order[k] / 2; const bool is_b250 = order[k] & 1;
+            if (c == NC) { mark = (uint32_t)secs[v].size (); continue; }
             const ZipCol &Z = COL (v, c);
             const GzFastqCtx &X = f->ctxs[c];
             GzSection s; memset (&s, 0, sizeof (s));
@@ -1368,6 +1416,12 @@ static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint
                     s.hdr_codec = GZ_CODEC_DOMQ; s.param = (uint8_t)(K.domq[v].res.num_norm_qs | 0x80);
                     if (K.domq[v].res.all_diverse || !s.codec) s.codec = GZ_CODEC_NONE;
                 }
+                if (X.kind == GZ_FQ_SEQ) {
+                    // NONREF_X: lcodec CODEC_XCGT names the section, the stream is coded by what codec_assign_best_codec gave (the file's; NONE
+                    // while a sample under 50 bytes assigns none) and that goes to sub_codec (codec_acgt.c:142-153, USE_SUBCODEC: codec.h:109)
+                    s.hdr_codec = GZ_CODEC_XCGT;
+                    if (!s.codec) s.codec = GZ_CODEC_NONE;
+                }
                 const bool int_lt = Z.ltype >= GZ_LT_INT8 && Z.ltype <= GZ_LT_UINT64;
                 if (int_lt) s.b250_size_or_nothing_char = X.nothing_char ? X.nothing_char : 0xff;    // zfile.c:344-345
                 if (is_r1 && X.pair_identical) s.flags |= PAIRED;                                     // zfile.c:323-325
@@ -1376,7 +1430,7 @@ static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint
         }
         GzVBlock &B = V[v]; memset (&B, 0, sizeof (B));
         B.vblock_i = vbs[v].vblock_i; B.recon_size = (uint32_t)vbs[v].text_len; B.longest_line_len = K.vbstat[2 * v]; B.longest_seq_len = K.vbstat[2 * v + 1];
-        B.sections = secs[v].data (); B.n_sections = (uint32_t)secs[v].size ();
+        B.sections = secs[v].data (); B.n_sections = (uint32_t)secs[v].size (); B.mark_section = mark;
         B.z_cap = gz_vb_z_bound (B.sections, B.n_sections);
         if (!(B.z_data = (uint8_t *)ws_alloc (f, B.z_cap + 64))) return GZ_ERR_HIP;
     }
@@ -1385,7 +1439,10 @@ static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint
     ZCHK (gz_vb_compress_batch (h, V.data (), (int)NV));
     T.mark ("compress-queue");
     K.b250st.assign ((size_t)NV * NC, 1);
-    HIPCHK (h, hipMemcpyAsync (K.b250st.data (), K.d_b250st, K.b250st.size () * 4, hipMemcpyDeviceToHost, h->stream));
+    // (into page-locked memory - the seg phase's read-backs in it have been consumed: a copy into pageable memory would hold the host until
+    //  the stream gets there, i.e. until this call's coders are through, and with it the next call of gz_fastq_zip_begin)
+    if (!(K.b250st_pinned = (int32_t *)zip_pinned (f, K.b250st.size () * 4 + 64))) return GZ_ERR_HIP;
+    HIPCHK (h, hipMemcpyAsync (K.b250st_pinned, K.d_b250st, K.b250st.size () * 4, hipMemcpyDeviceToHost, h->stream));
     K.phase = 3;
     T.done ("finish (queued)");
     (void)rc;
@@ -1402,9 +1459,10 @@ static int zip_finish_wait (GzZipFile *f)
     const uint32_t NC = (uint32_t)f->ctxs.size (), NV = K.NV;
     auto COL = [&] (uint32_t v, uint32_t c) -> ZipCol & { return K.col[(size_t)v * NC + c]; };
     std::vector<GzVBlock> &V = K.V;
-    const std::vector<int32_t> &b250st = K.b250st;
+    std::vector<int32_t> &b250st = K.b250st;
     ZipTimer T;
     int rc = gz_sync (h);
+    if (K.b250st_pinned && !b250st.empty ()) memcpy (b250st.data (), K.b250st_pinned, b250st.size () * 4);
     K.phase = 0;
     if (!K.early.empty ()) {
         const int rc2 = gz_sync (f->h2);
@@ -1416,6 +1474,7 @@ static int zip_finish_wait (GzZipFile *f)
     for (uint32_t v = 0; v < NV; v++) {
         for (uint32_t c = 0; c < NC; c++) { const ZipCol &Z = COL (v, c); if (Z.has_b250 && Z.col_job >= 0 && b250st[(size_t)v * NC + c] == -5) { h->err = "b250 generation: malformed stream"; return GZ_ERR; } }
         vbs[v].status = V[v].status; vbs[v].z_data = V[v].z_data; vbs[v].z_len = V[v].z_len; vbs[v].n_sections = V[v].n_sections;
+        vbs[v].seq_section_index = V[v].mark_index;
         if (V[v].status != GZ_OK) rc = GZ_ERR;
     }
     return rc == GZ_ERR ? GZ_ERR : GZ_OK;

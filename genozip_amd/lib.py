@@ -75,7 +75,7 @@ class GzVBlock(C.Structure):
     _fields_ = [("vblock_i", C.c_uint32), ("recon_size", C.c_uint32), ("longest_line_len", C.c_uint32),
                 ("longest_seq_len", C.c_uint32), ("digest", C.c_uint8 * 16), ("vb_flags", C.c_uint8),
                 ("sections", C.POINTER(GzSection)), ("n_sections", C.c_uint32), ("z_data", C.c_void_p),
-                ("z_cap", C.c_uint64), ("z_len", C.c_uint64), ("status", C.c_int32)]
+                ("z_cap", C.c_uint64), ("z_len", C.c_uint64), ("status", C.c_int32), ("mark_section", C.c_uint32), ("mark_index", C.c_uint32)]
 
 
 class GzMergeJob(C.Structure):
@@ -111,25 +111,27 @@ class GzDomqFitJob(C.Structure):
 class GzFastqCtx(C.Structure):
     _fields_ = [("dict_id", C.c_uint8 * 8), ("did_i", C.c_uint16), ("kind", C.c_uint8), ("item", C.c_uint8), ("local_dep", C.c_uint8),
                 ("flags", C.c_uint8), ("no_stons", C.c_uint8), ("lcodec", C.c_uint8), ("bcodec", C.c_uint8), ("pair_identical", C.c_uint8),
-                ("pair_assisted_b250", C.c_uint8), ("nothing_char", C.c_uint8), ("snip", C.c_char_p), ("snip_len", C.c_uint32)]
+                ("pair_assisted_b250", C.c_uint8), ("nothing_char", C.c_uint8), ("snip", C.c_char_p), ("snip_len", C.c_uint32),
+                ("con_len", C.c_uint32), ("segs_per_line", C.c_uint8)]
 
 
 class GzFastqPlan(C.Structure):
     _fields_ = [("ctxs", C.POINTER(GzFastqCtx)), ("n_ctxs", C.c_uint32), ("seps", C.c_char * 16), ("sep_counts", C.c_uint8 * 16),
-                ("n_seps", C.c_uint32), ("paired", C.c_uint8), ("estimated_entries", C.c_uint32), ("qual_codec", C.c_uint8), ("vb_size", C.c_uint64)]
+                ("n_seps", C.c_uint32), ("paired", C.c_uint8), ("estimated_entries", C.c_uint32), ("qual_codec", C.c_uint8), ("vb_size", C.c_uint64),
+                ("line3_empty", C.c_uint8)]
 
 
 class GzFastqVB(C.Structure):
     _fields_ = [("text_off", C.c_uint64), ("text_len", C.c_uint64), ("vblock_i", C.c_uint32), ("r1", C.c_int32), ("n_reads", C.c_uint32),
                 ("status", C.c_int32), ("z_data", C.c_void_p), ("z_len", C.c_uint64), ("seq_packed", C.c_void_p), ("seq_packed_len", C.c_uint64),
-                ("n_bases", C.c_uint64), ("seq_has_x", C.c_uint32), ("n_sections", C.c_uint32)]
+                ("n_bases", C.c_uint64), ("seq_has_x", C.c_uint32), ("n_sections", C.c_uint32), ("seq_section_index", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class GzSecOrderIn(C.Structure):
     _fields_ = [("did_i", C.c_uint16), ("local_dep", C.c_uint8), ("has_local", C.c_uint8), ("ston_only_local", C.c_uint8), ("has_b250", C.c_uint8)]
 
 
-GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL, GZ_FQ_QUAL_AUX = 1, 2, 3, 4, 5, 6, 7
+GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL, GZ_FQ_QUAL_AUX, GZ_FQ_TOPLEVEL, GZ_FQ_SEQ_SNIP = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 # every symbol include/genozip_amd.h declares (checked by tests/test_abi.py)
 GzGetLineCB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32))
@@ -150,6 +152,7 @@ ABI_SYMBOLS = (
     "gz_zip_reset", "gz_fastq_zip_collect",
     "gz_domq_columns", "gz_domq_fit", "gz_codec_compress_lines_host", "gz_byte_index", "gz_vcf_sample_columns", "gz_fastq_zip_begin", "gz_fastq_zip_end", "gz_zip_speculation",
     "gz_zfile_create", "gz_zfile_destroy", "gz_zfile_add_vblock", "gz_zfile_write_global_area", "gz_codec_assign_best_host",
+    "gz_zfile_add_txt_header", "gz_zfile_set_fastq", "gz_vb_insert_section",
     "gz_tokenize_column_n", "gz_int_columns", "gz_local_generate_batch", "gz_acgt_pack_batch",
 )
 
@@ -251,6 +254,10 @@ def load(path=None):
     L.gz_zfile_write_global_area.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64,
                                              C.c_char_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.gz_codec_assign_best_host.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
+    L.gz_zfile_add_txt_header.argtypes = [C.c_void_p, C.c_uint8, C.c_uint8, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint64, C.c_char_p]
+    L.gz_zfile_set_fastq.argtypes = [C.c_void_p, C.c_uint8, C.c_uint8, C.c_uint32, C.c_uint32]
+    L.gz_vb_insert_section.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_char_p, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint8, C.c_char_p, C.c_uint32,
+                                       C.c_uint32, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.gz_zip_reset.argtypes = [C.c_void_p]
     L.gz_fastq_zip_collect.argtypes = [C.c_void_p, C.POINTER(GzFastqVB), C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.gz_zip_zctx.restype = C.c_void_p

@@ -209,6 +209,9 @@ typedef struct {
     /* results after gz_sync(): */
     uint64_t z_len;               /* == z_data_bytes patched into the VB header (zfile.c:1139-1144)            */
     int32_t  status;
+    uint32_t mark_section;        /* in: an index into `sections` (or n_sections)                                       */
+    uint32_t mark_index;          /* out: how many sections were WRITTEN in front of it (a section generated on the device can be
+                                     dropped there, src/b250.c:270-277): where a section made by the host afterwards goes in    */
 } GzVBlock;
 
 uint64_t gz_vb_z_bound (const GzSection *sections, uint32_t n_sections);
@@ -425,8 +428,18 @@ enum {
                               also holds its three GZ_FQ_QUAL_AUX contexts, codec_assign_best_qual_codec (src/codec.c:391-450) is
                               followed as far as FASTQ can go: the file's first VBlock decides between CODEC_DOMQ (N3: its QUAL
                               lines pass codec_domq_qual_data_is_a_fit_for_domq) and a plain LT_BLOB local, for the whole file     */
-    GZ_FQ_QUAL_AUX   = 7   /* DOMQRUNS / QUALMPLX / DIVRQUAL (item 0 / 1 / 2) of the plan's QUAL context: LT_SUPP locals at DEP_L2
+    GZ_FQ_QUAL_AUX   = 7,  /* DOMQRUNS / QUALMPLX / DIVRQUAL (item 0 / 1 / 2) of the plan's QUAL context: LT_SUPP locals at DEP_L2
                               (codec_domq.c:308-313); DOMQRUNS' dictionary takes the denormalisation table (:240-244)              */
+    GZ_FQ_TOPLEVEL   = 8,  /* the TOPLEVEL container, segged ONCE per VBlock with repeats = the VBlock's reads (fastq_seg_finalize,
+                              src/fastq.c:845-943 -> container_seg): `snip` holds the binary Container (its first con_len bytes: 8 +
+                              12 per item, src/container.h:74-92, the 24 repeat bits zero) followed by its prefixes; the driver sets
+                              the repeats of every VBlock and segs SNIP_CONTAINER + base64 (Container) + prefixes
+                              (container_prepare_snip, src/container.c:35-64): one b250 entry                                      */
+    GZ_FQ_SEQ_SNIP   = 9   /* SQBITMAP: the snip fastq_seg_SEQ segs for every read, which carries the read's length
+                              (src/fastq_seq.c:45-154: `snip` + decimal seq_len, `snip` being SNIP_SPECIAL, FASTQ_SPECIAL_unaligned_SEQ,
+                              ' '); a read of one repeated base takes that base in the place of ' ' and is left out of NONREF
+                              (:120-126), an empty read is `snip` with '*' and no length (:113-117). Generated and evaluated on the
+                              device like a textual item. Must come before the plan's GZ_FQ_SEQ context                          */
 };
 typedef struct {
     uint8_t  dict_id[8];
@@ -440,7 +453,10 @@ typedef struct {
     uint8_t  pair_identical;      /* fastq_zip_use_pair_identical (src/fastq.c:238-243)                                    */
     uint8_t  pair_assisted_b250;  /* fastq_zip_use_pair_assisted (.., SEC_B250) (src/fastq.c:224-234)                      */
     uint8_t  nothing_char;        /* GZ_FQ_ITEM_INT                                                                       */
-    const uint8_t *snip; uint32_t snip_len;   /* GZ_FQ_CONST / GZ_FQ_ITEM_DELTA: the snip (host pointer)                   */
+    const uint8_t *snip; uint32_t snip_len;   /* GZ_FQ_CONST / GZ_FQ_ITEM_DELTA / GZ_FQ_TOPLEVEL / GZ_FQ_SEQ_SNIP: the snip (host pointer) */
+    uint32_t con_len;             /* GZ_FQ_TOPLEVEL: bytes of the binary Container at the start of `snip`                  */
+    uint8_t  segs_per_line;       /* GZ_FQ_CONST: how many times a read segs the snip (E2L: 3, src/fastq.c:1300-1304); 0 = once.
+                                     Only the word's count depends on it                                                    */
 } GzFastqCtx;
 typedef struct {
     const GzFastqCtx *ctxs; uint32_t n_ctxs;
@@ -452,6 +468,8 @@ typedef struct {
     uint64_t vb_size;             /* segconf.vb_size, the size the caller cuts VBlocks to (src/segconf.c:152-206). A VBlock whose text is
                                      not longer than MIN (4 MB, vb_size / 2) tests codecs for itself but does not set them for the
                                      file (src/codec.c:352: "don't let tiny VBs set the codec for everyone"). 0: every VBlock may    */
+    uint8_t  line3_empty;         /* segconf.line3 == L3_EMPTY: line 3 is "+" alone, takes no context (the '+' is a prefix of the TOPLEVEL
+                                     container) and anything else there is an error (fastq_seg_LINE3, src/fastq_desc.c:33-37)          */
 } GzFastqPlan;
 typedef struct {
     uint64_t text_off, text_len;  /* in: the VBlock's slice of the text: whole reads                                      */
@@ -462,6 +480,9 @@ typedef struct {
     uint8_t *z_data; uint64_t z_len;                     /* out, device: SEC_VB_HEADER + sections; valid until the next call */
     uint8_t *seq_packed; uint64_t seq_packed_len;        /* out, device: NONREF 2 bits per base                             */
     uint64_t n_bases; uint32_t seq_has_x; uint32_t n_sections;
+    uint32_t seq_section_index;   /* out: where among the VBlock's sections (0 = right behind the VB header) the NONREF local section
+                                     belongs (a15) once the host's sub-codec has made it: gz_vb_insert_section                      */
+    uint32_t reserved;
 } GzFastqVB;
 typedef struct GzZipFile GzZipFile;   /* z_file for this path: the file-level contexts and committed codecs */
 GzZipFile *gz_zip_open (GzHandle *h, const GzFastqPlan *plan);
@@ -551,6 +572,25 @@ int gz_zfile_write_global_area (GzZFile *zf, GzHandle *h, GzZctx *const *zctx, c
                                 uint64_t recon_size, uint64_t num_lines, const char *created,
                                 uint8_t *out_host, uint64_t out_cap, uint64_t *out_len);
 int gz_codec_assign_best_host (GzHandle *h, const uint8_t *in_host, uint32_t in_len);
+/* SEC_TXT_HEADER of one component (txtheader_compress + zfile_update_txt_header_section_header, src/txtheader.c:46-111,
+ * src/zfile.c:1068-1105; layout src/sections.h:308-327): FASTQ has no header text, the section is its 400-byte header alone and is
+ * written in front of the component's VBlocks. pair: 0 not paired, 1 R1, 2 R2 (FlagsTxtHeader.pair); flav_prop: NUM_QTYPES x 2 bytes
+ * (QnameFlavorProp, src/sections.h:296-305) or NULL. out_host: 400 bytes. The section joins zf's list at file_offset. */
+#define GZ_TXT_HEADER_LEN 400
+int gz_zfile_add_txt_header (GzZFile *zf, uint8_t comp_i, uint8_t pair, const char *txt_filename, uint64_t txt_data_size, uint64_t txt_num_lines,
+                             uint32_t max_lines_per_vb, const uint8_t *flav_prop, uint32_t n_flav_prop, uint64_t file_offset, uint8_t *out_host);
+/* What the reader needs of the file as a whole that is not in the sections (SectionHeaderGenozipHeader, src/sections.h:169-300):
+ * set before gz_zfile_write_global_area. paired: the file holds an R1 / R2 pair (z_flags.dt_specific, v14_is_paired);
+ * std_seq_len / std_seq_len_r2: segconf.std_seq_len, std_seq_lR2 (longest SEQ of the sampled reads, src/fastq.c:711) */
+int gz_zfile_set_fastq (GzZFile *zf, uint8_t num_txt_files, uint8_t paired, uint32_t std_seq_len, uint32_t std_seq_len_r2);
+/* A section made on the host into a finished VBlock's z_data (host copies): the 40-byte SectionHeaderCtx is built here (lengths,
+ * adler32 of the payload, vblock_i of the VBlock), the section goes in front of the VBlock's section number `index` (GzFastqVB.
+ * seq_section_index for NONREF, whose payload is the host's CODEC_ACGT sub-codec output: codec = GZ_CODEC_ACGT, sub_codec = LZMA 4 /
+ * NONE 1, src/codec_acgt.c:157-169) and z_data_bytes of the VB header is patched (zfile_update_compressed_vb_header, src/zfile.c:1139).
+ * out_host may not overlap z. Returns GZ_TOO_SMALL with *out_len = the size needed. */
+int gz_vb_insert_section (const uint8_t *z, uint64_t z_len, uint32_t index, const uint8_t dict_id[8], uint8_t codec, uint8_t sub_codec,
+                          uint8_t flags, uint8_t ltype, uint8_t param, const uint8_t *payload, uint32_t payload_len, uint32_t uncompressed_len,
+                          uint8_t *out_host, uint64_t out_cap, uint64_t *out_len);
 
 /* ---- N3: CODEC_DOMQ's pre-transform (src/codec_domq.c:69-134,139-249,347-503) -------------------------------
  * The QUAL lines of a VBlock -> QUAL (non-dominant normalised scores + `no_doms` markers), DOMQRUNS (run lengths of the
@@ -560,6 +600,9 @@ int gz_codec_assign_best_host (GzHandle *h, const uint8_t *in_host, uint32_t in_
  * LT_CODEC, codec DOMQ with the sub-codec that coded the stream). Lines of length 0 take no part. All pointers device,
  * asynchronous. Capacities with B = sum of the lengths: qual 2 B + 16, runs B + B / 254 + 16, mplx n + 16, divr B + 16. */
 enum { GZ_CODEC_DOMQ = 13, GZ_LT_CODEC_ = 13 };
+/* codecs that only ever appear in section headers of this path: CODEC_ACGT (NONREF: the host's sub-codec makes the payload), CODEC_XCGT
+ * (NONREF_X: the name of the section, its stream coded by the sub-codec), LZMA (src/genozip.h:325-360) */
+enum { GZ_CODEC_LZMA = 4, GZ_CODEC_ACGT = 10, GZ_CODEC_XCGT = 11 };
 typedef struct {
     uint64_t qual_len, runs_len, mplx_len, divr_len;
     uint32_t num_doms, num_norm_qs, has_diverse, all_diverse;   /* all_diverse: QUAL is the single byte 'X', sub-codec NONE (:490-494) */

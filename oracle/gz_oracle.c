@@ -1351,7 +1351,7 @@ static void be32 (uint8_t *p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (u
 long gzo_section_compress (const GzoCtxSectionDesc *d, const uint8_t *data, uint32_t data_len, uint8_t *z, uint64_t z_cap)
 {
     int codec = d->codec, complex_codec = 0;
-    if (codec == 13 /* CODEC_DOMQ */) {
+    if (codec == 13 /* CODEC_DOMQ */ || codec == 11 /* CODEC_XCGT: USE_SUBCODEC, not simple (codec.h:109, compressor.c:56-61) */) {
         /* the primary stream of a complex codec: the header keeps its name, the stream is coded by the sub-codec that
          * codec_assign_best_codec gave (the file's, however short the stream; a stream under 50 bytes assigns none) - NONE when it
          * gave none ("really small") (codec_domq.c:487-510, compressor.c:60-61; the 50-byte rule of :56-58 is for simple codecs) */

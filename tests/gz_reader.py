@@ -4,7 +4,7 @@ Written from the format description (sections.h:146-307), not from the product's
 import struct
 
 MAGIC = 0x27052012
-SEC_GENOZIP_HEADER, SEC_VB_HEADER, SEC_DICT, SEC_B250, SEC_LOCAL, SEC_COUNTS = 6, 9, 10, 11, 12, 17
+SEC_GENOZIP_HEADER, SEC_TXT_HEADER, SEC_VB_HEADER, SEC_DICT, SEC_B250, SEC_LOCAL, SEC_COUNTS = 6, 8, 9, 10, 11, 12, 17
 
 
 def _unzig(u):
@@ -23,7 +23,8 @@ def read_file(blob, decode):
     assert len(payload) == 19 * num_sections
     bits = int.from_bytes(h[40:48], "little")
     out = dict(version=(h[28], bits & 0x3fff), data_type=struct.unpack(">H", h[30:32])[0], recon_size=struct.unpack(">Q", h[32:40])[0],
-               num_lines=bits >> 16, vb_size=struct.unpack(">I", h[715:719])[0], created=h[88:160].split(b"\0")[0], sections=[])
+               num_lines=int.from_bytes((bits >> 16).to_bytes(8, "little"), "big"),   # zfile.c:965: BGEN64 of the 48-bit field
+               vb_size=struct.unpack(">I", h[715:719])[0], created=h[88:160].split(b"\0")[0], sections=[])
     prev_off = prev_vb = prev_lines = 0
     prev_comp = None
     for i in range(num_sections):
@@ -42,10 +43,14 @@ def read_file(blob, decode):
     for a, b in zip(out["sections"], out["sections"][1:]):
         a["size"] = b["offset"] - a["offset"]
     out["sections"][-1]["size"] = len(blob) - 12 - out["sections"][-1]["offset"]
-    out["dicts"], out["counts"] = {}, {}
+    out["dicts"], out["counts"], out["txt_headers"] = {}, {}, []
     for s in out["sections"]:
         hd = blob[s["offset"]:s["offset"] + 44]
         assert struct.unpack(">I", hd[:4])[0] == MAGIC and hd[24] == s["st"], (s, hd[:28])
+        if s["st"] == SEC_TXT_HEADER:                                       # src/sections.h:308-327
+            th = blob[s["offset"]:s["offset"] + 400]
+            out["txt_headers"].append(dict(pair=th[27] & 3, txt_data_size=struct.unpack(">Q", th[28:36])[0], txt_num_lines=struct.unpack(">Q", th[36:44])[0],
+                                           max_lines_per_vb=struct.unpack(">I", th[44:48])[0], txt_filename=th[84:340].split(b"\0")[0], comp_i=s["comp_i"]))
         if s["st"] == SEC_DICT:
             clen, ulen = struct.unpack(">II", hd[12:20])
             data = decode(hd[26] if hd[25] == 13 else hd[25], blob[s["offset"] + 40:s["offset"] + 40 + clen], ulen)   # (CODEC_DOMQ: its sub-codec)

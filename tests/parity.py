@@ -623,7 +623,7 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
     functions, VBlock by VBlock. zstate carries the file-level contexts and codecs from call to call.
     -> (list of dict(z, seq_packed, n_bases, seq_has_x), zstate)"""
     import pyoracle as po
-    from genozip_amd.lib import (GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL, GZ_FQ_QUAL_AUX)
+    from genozip_amd.lib import (GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL, GZ_FQ_QUAL_AUX, GZ_FQ_TOPLEVEL, GZ_FQ_SEQ_SNIP)
     import base64
     C = plan["ctxs"]
     NC = len(C)
@@ -634,7 +634,21 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
     lo, ll = oracle.text_lines(text)
     bad, cols = oracle.fastq_records(text, lo, ll)
     assert bad == 0
-    (l1o, l1l), (so, sl), _, (qo, ql) = cols
+    (l1o, l1l), (so, sl), (l3o, l3l), (qo, ql) = cols
+    assert not plan.get("line3_empty") or not l3l.any()
+    # SQBITMAP's snip of every read and what NONREF takes of it (fastq_seg_SEQ, src/fastq_seq.c:113-146): stated here in plain Python
+    sq = next((X for X in C if X["kind"] == GZ_FQ_SEQ_SNIP), None)
+    sl_nonref = sl
+    if sq is not None:
+        slots, sq_len, sl_nonref = bytearray(16 * len(sl)), np.zeros(len(sl), dtype=np.uint32), sl.copy()
+        for r in range(len(sl)):
+            seq = text[int(so[r]):int(so[r]) + int(sl[r])]
+            mono = len(seq) > 0 and seq == seq[:1] * len(seq)
+            snip = sq["snip"][:-1] + (b"*" if not seq else seq[:1] + b"%d" % len(seq) if mono else sq["snip"][-1:] + b"%d" % len(seq))
+            slots[16 * r:16 * r + len(snip)] = snip; sq_len[r] = len(snip)
+            if mono:
+                sl_nonref[r] = 0
+        sq_text, sq_off = bytes(slots) + b"\0" * 64, (16 * np.arange(len(sl))).astype(np.uint32)
     # line-1 items: single-occurrence tokens, then joined per sep_counts
     flat = b"".join(bytes([s]) * k for s, k in zip(plan["seps"], plan["sep_counts"]))
     nb, fo, fl = oracle.tokenize_column(text, l1o, l1l, flat)
@@ -678,10 +692,16 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
                 d = np.diff(np.concatenate([[0], vals])) if n else vals
                 lt, raw = oracle.dyn_int_column(d, None, 0)
                 st.update(local=oracle.local_generate(lt, raw)[1], ltype=lt, has_local=len(raw) > 0)
+            elif k == GZ_FQ_SEQ_SNIP:
+                st["col"] = oracle.ctx_seg_column(sq_text, sq_off[a:b], sq_len[a:b], ol_words[c])
+                st["n_ol"] = len(ol_words[c])
+            elif k == GZ_FQ_TOPLEVEL and n:                              # container_seg with repeats = the VBlock's reads (fastq.c:845-943, container.c:35-64)
+                con = bytearray(X["snip"][:X["con_len"]]); con[1:4] = n.to_bytes(3, "little")
+                st["own_snip"] = b"\x04" + base64.b64encode(bytes(con)) + X["snip"][X["con_len"]:]
             elif k == GZ_FQ_SEQ:
-                seq = oracle.local_blob_column(text, so[a:b], sl[a:b], False)
+                seq = oracle.local_blob_column(text, so[a:b], sl_nonref[a:b], False)
                 packed, x, has_x = oracle.acgt_pack(seq)
-                st.update(seq_packed=packed, n_bases=len(seq), seq_has_x=has_x, local=x, ltype=2, has_local=has_x)
+                st.update(seq_packed=packed, n_bases=len(seq), seq_has_x=has_x, local=x, ltype=27, has_local=has_x)
             elif k == GZ_FQ_QUAL and zstate["qual_mode"] == 13 and n:
                 dq = po.oracle_domq(oracle, text, qo[a:b], ql[a:b])
                 st.update(local=dq["qual"], ltype=13, has_local=len(dq["qual"]) > 0, param=dq["num_norm_qs"] | 0x80, domq=dq)
@@ -706,7 +726,7 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
                 kw.update(b250_r1_len=int(S[r1][c]["has_b250"]), local_r1_len=int(S[r1][c]["has_local"]))
             if st["col"] is None:                                     # constant snip
                 words = OZ.words()
-                snip, n_seg = (st["own_snip"], 1) if "own_snip" in st else (X["snip"], st["n"])
+                snip, n_seg = (st["own_snip"], 1) if "own_snip" in st else (X["snip"], st["n"] * (X.get("segs_per_line") or 1))
                 found = words.index(snip) if snip in words else -1
                 node = found if found >= 0 else len(words)
                 cnt = np.zeros(len(words) + 1, dtype=np.uint32); cnt[node] = n_seg
@@ -785,8 +805,17 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
         a, b = rng[v]
         is_r2, is_r1 = r1 >= 0, plan["paired"] and r1 < 0
         order = _section_order_ref([(X["did_i"], 1 if S[v][c]["ltype"] == 13 else X["local_dep"], S[v][c]["has_local"], S[v][c]["ston_only"], S[v][c]["has_b250"]) for c, X in enumerate(C)], vi)
+        # (NONREF itself - the context in front of NONREF_X, DEP_L0 - is the host's: where its section belongs among the written ones)
+        sx = next((c for c, X in enumerate(C) if X["kind"] == GZ_FQ_SEQ), None)
+        if sx is not None:
+            order = _section_order_ref([(X["did_i"], 1 if S[v][c]["ltype"] == 13 else X["local_dep"], S[v][c]["has_local"], S[v][c]["ston_only"], S[v][c]["has_b250"]) for c, X in enumerate(C)]
+                                       + [(C[sx]["did_i"] - 1, 0, S[v][sx]["n_bases"] > 0, False, False)], vi)
         z = bytearray(84)
+        nonref_at, n_written = 0, 0
         for c, kind in order:
+            if c == NC:
+                nonref_at = n_written
+                continue
             X, st = C[c], S[v][c]
             flags = X["flags"] | (0x20 if st["ats"] else 0)
             if kind == "B":
@@ -806,13 +835,16 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
                                          b250_size_or_nothing_char=(X["nothing_char"] or 0xff) if int_lt else 0)
                 if st["ltype"] == 13:                                  # LT_CODEC: QUAL through CODEC_DOMQ; the file's coder as VBlock v finds it (codec.c:280-281)
                     d.codec, d.sub_codec = 13, 0 if st["domq"]["all_diverse"] else vcodec[(v, c, 1)]
+                if X["kind"] == GZ_FQ_SEQ:                              # NONREF_X: CODEC_XCGT, the stream's coder (NONE if none was assigned) as sub_codec (codec_acgt.c:142-153)
+                    d.codec, d.sub_codec = 11, vcodec[(v, c, 1)] or 1
                 data = st["local"]
             d.dict_id[:] = list(X["dict_id"])
             z += oracle.section_compress(d, data)
+            n_written += 1
         rec_len = [int(lo[4 * (r + 1)] if r + 1 < b else off + ln) - int(lo[4 * r]) for r in range(a, b)]
         z[:84] = _vb_header(vi, ln, len(z), max(rec_len) if rec_len else 0, int(sl[a:b].max()) if b > a else 0)
         seq = next(S[v][c] for c, X in enumerate(C) if X["kind"] == GZ_FQ_SEQ)
-        out.append(dict(z=bytes(z), seq_packed=seq["seq_packed"], n_bases=seq["n_bases"], seq_has_x=seq["seq_has_x"]))
+        out.append(dict(z=bytes(z), seq_packed=seq["seq_packed"], n_bases=seq["n_bases"], seq_has_x=seq["seq_has_x"], seq_section_index=nonref_at))
     return out, zstate
 
 
@@ -830,7 +862,7 @@ def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0
     vb_i = 0
     for call in range(n_calls):
         nr = n_reads if call == 0 else max(8, n_reads // 3)
-        r1 = fastq_text(nr, seed=100 + call, dirty_seq=(call == 1), qual=qual[call])
+        r1 = fastq_text(nr, seed=100 + call, dirty_seq=(call == 1), mate=1, qual=qual[call])
         r2 = fastq_text(nr, seed=100 + call, dirty_seq=(call == 1), mate=2, qual_seed=300 + call, qual=qual[call])
         # two VBlocks per mate (the second shorter), R2's name their R1 counterparts
         cut = nr // 3 if small_first else (2 * nr) // 3
@@ -852,6 +884,7 @@ def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0
             assert g["n_bases"] == w["n_bases"] and g["seq_has_x"] == w["seq_has_x"], (call, v)
             assert g["seq_packed"] == w["seq_packed"], (call, v, "packed SEQ")
             assert g["z"] == w["z"], (call, v, len(g["z"]), len(w["z"]), _first_diff(g["z"], w["z"]))
+            assert g["seq_section_index"] == w["seq_section_index"], (call, v, g["seq_section_index"], w["seq_section_index"])
         # round trip of what was written
         for v, g in enumerate(got):
             z = g["z"]
@@ -865,9 +898,15 @@ def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0
     assert tiles and tiles == zstate["z"][3].words()
     # N4: VBlocks + global area, read back by the independent reader of tests/gz_reader.py
     import gz_reader
-    blob = F.write_file(got, [g["n_reads"] for g in got], counts_ctxs=(3,))
+    blob = F.write_file([dict(name=b"reads.fq", pair=0, vbs=got)], counts_ctxs=(3,))
     R = gz_reader.read_file(blob, lambda codec, pay, ulen: bytes(pay) if codec == 1 else oracle.codec_uncompress(codec, pay, ulen))
-    assert R["version"] == (15, 86) and R["data_type"] == 3 and R["num_lines"] == sum(g["n_reads"] for g in got) and R["created"] == b"genozip_amd"
+    n_lines = sum(g["n_reads"] for g in got)
+    # (the reader byte-swaps the 48-bit field as if it were 64 bits wide, src/zfile.c:965: counts lose their low 16 bits)
+    assert R["version"] == (15, 86) and R["data_type"] == 3 and R["num_lines"] == (n_lines & ~0xffff) and R["created"] == b"genozip_amd"
+    assert R["recon_size"] == sum(g["text_len"] for g in got)
+    th = R["sections"][0]
+    assert th["st"] == 8 and th["offset"] == 0 and th["size"] == 400 and th["comp_i"] == 0 and R["txt_headers"][0]["txt_num_lines"] == n_lines \
+        and R["txt_headers"][0]["txt_data_size"] == R["recon_size"] and R["txt_headers"][0]["txt_filename"] == b"reads.fq"
     for i, c in enumerate(plan["ctxs"]):
         want = zstate["z"][i].view()
         if want["n_words"] and not want["rm_dict"]:
@@ -876,7 +915,7 @@ def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0
             assert c["dict_id"] not in R["dicts"], c["tag"]
     assert R["counts"][plan["ctxs"][3]["dict_id"]] == [int(x) for x in zstate["z"][3].view()["counts"]]
     # every section the list names is where the list says it is, VBlock by VBlock
-    at = 0
+    at = 400                                                   # (behind the component's SEC_TXT_HEADER)
     vb_secs = [s for s in R["sections"] if s["st"] in (9, 11, 12)]
     k = 0
     for g in got:

@@ -1,0 +1,97 @@
+"""End to end against the REFERENCE'S OWN DECODER (build container only): FASTQ text -> the product's VBlock driver (the unmodified
+sources on the CPU stand-in of tests/emul) + global area -> a .genozip file -> the reference's shipped `genounzip` (15.0.86, untarred from
+/root/reference/installers into a temporary directory: never into the repo, never to the GPU box) -> the text again, byte for byte.
+
+This is what pins the rows no reference source builds for outside its tree: a1's special snips, the a4 merge loop and
+word indices, a8's codec ids in the headers, a9 / a16 header fields, a15 section order as far as the reader depends on it, N1 (the
+FASTQ segmenter's snips and containers) and N4 (SEC_TXT_HEADER, SEC_DICT, section list, SEC_GENOZIP_HEADER, footer): the reference
+itself reads all of them back into the original text. NONREF's payload (CODEC_ACGT's sub-codec, LZMA: host work outside the path,
+SURVEY F8) is made by the reference's vendored LZMA SDK compiled in place (oracle/_ref/liblzmaref.so).
+
+The decoder ends every run in this container with a segmentation fault AFTER the output is complete ("Done"): its exit path walks the
+System V shared memory segments of the machine (ref_cache_iterator, src/ref_cache.c:337-347) and the sandbox has a foreign one. The
+tests compare the output files; the exit code is not asserted.
+"""
+import ctypes as C
+import os
+import subprocess
+import tarfile
+
+import pytest
+
+import parity
+
+TAR = "/root/reference/installers/genozip-linux-x86_64.tar"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not os.path.exists(TAR), reason="the reference's installers are not here (GPU box)")
+
+
+@pytest.fixture(scope="module")
+def genounzip(tmp_path_factory):
+    d = tmp_path_factory.mktemp("ref_bin")
+    with tarfile.open(TAR) as t:
+        t.extractall(d)
+    exe = os.path.join(d, "genozip-linux-x86_64", "genounzip")
+    assert os.path.exists(exe)
+    return exe
+
+
+@pytest.fixture(scope="module")
+def lzma_sub():
+    so = os.path.join(ROOT, "oracle", "_ref", "liblzmaref.so")
+    if not os.path.exists(so):
+        import pyoracle
+        pyoracle.build(ref=True)
+    L = C.CDLL(so)
+    L.lzmaref_compress.restype = C.c_long
+    L.lzmaref_compress.argtypes = [C.c_char_p, C.c_uint32, C.c_uint64, C.c_char_p, C.c_uint32]
+
+    def compress(data, vb_size):
+        out = C.create_string_buffer(len(data) + len(data) // 2 + 10000)
+        n = L.lzmaref_compress(data, len(data), vb_size, out, len(out))
+        assert n > 0
+        return out.raw[:n]
+    return compress
+
+
+def _run(exe, args, cwd):
+    p = subprocess.run([exe] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    return p.stdout.decode(errors="replace")
+
+
+def _zip(E, plan, calls, lzma_sub):
+    """calls: list of (text, vbs) -> VBlock results (with NONREF spliced in) in vblock_i order, and the open file"""
+    F = E.zip_open(plan)
+    out = []
+    for text, vbs in calls:
+        got = F.zip_vblocks(text, vbs)
+        for g in got:
+            g["z"] = F.with_nonref(g, lzma_sub)
+        out += got
+    return F, out
+
+
+def _cut(text, n_parts):
+    """whole reads: -> [(offset, length)]"""
+    import numpy as np
+    nl = np.flatnonzero(np.frombuffer(text, dtype=np.uint8) == 10)
+    n_reads = len(nl) // 4
+    cuts = [0] + [int(nl[4 * (n_reads * k // n_parts) - 1]) + 1 for k in range(1, n_parts)] + [len(text)]
+    return [(a, b - a) for a, b in zip(cuts, cuts[1:])]
+
+
+@pytest.mark.parametrize("qual,dirty", [("uniform", False), ("uniform", True), ("bin", False)])
+def test_single_file_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, qual, dirty):
+    """one FASTQ file, 3 VBlocks in 2 calls (the second clones the first's dictionaries): reads of different lengths, N bases
+    (NONREF_X), binned scores (the file goes through CODEC_DOMQ)"""
+    from genozip_amd import fastq as fq
+    text = parity.fastq_text(900, seed=41, mate=1, qual=qual, dirty_seq=dirty)
+    parts = _cut(text, 3)
+    plan = fq.illumina_plan(paired=False)
+    F, vbs = _zip(emul_engine, plan, [(text, [(parts[0][0], parts[0][1], 1, -1)]), (text, [(parts[1][0], parts[1][1], 2, -1), (parts[2][0], parts[2][1], 3, -1)])], lzma_sub)
+    blob = F.write_file([dict(name=b"reads.fq", pair=0, vbs=vbs)], std_seq_len=150)
+    F.close()
+    (tmp_path / "reads.fq.genozip").write_bytes(blob)
+    log = _run(genounzip, ["-f", "-o", "out.fq", "reads.fq.genozip"], tmp_path)
+    out = (tmp_path / "out.fq").read_bytes() if (tmp_path / "out.fq").exists() else b""
+    assert out == text, log[:3000]
