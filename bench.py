@@ -48,7 +48,8 @@ def parse_args():
     ap.add_argument("--vb-mb", type=float, default=0, help="VBlock size in MiB (the reference's --vblock). Default 0: the reference's own rule for the file "
                     "(src/segconf.c:152-206, see vb_bytes below): 14.72 MB for a 1 M-read mate file; 16 MiB for --stream-reads")
     ap.add_argument("--qual", default="div", choices=("div", "bin"))
-    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    ap.add_argument("--scaling", default="strong", choices=("weak", "strong"),
+                    help="N > 1. strong (default: BASELINE's target is strong scaling of configs[1]): ONE file pair, its VBlock pairs dealt out over the GPUs; weak: a file pair per GPU")
     ap.add_argument("--stream-reads", type=int, default=0, help="stream this many read pairs per rank through one file (configs[4] at reduced scale)")
     ap.add_argument("--batch-pairs", type=int, default=112, help="VBlock pairs per call in --stream-reads mode (112 x 2 x 16 MiB = 3.76 GB: a call takes < 4 GB of text; "
                     "the more VBlocks a call holds, the better the long chains are hidden: 32 -> 5.6 GB/s, 64 -> 10.2, 112 -> 15.5)")
@@ -56,6 +57,9 @@ def parse_args():
                     "per call (15.5 -> 14.0 GB/s) - with 224 long streams per call the model kernels already fill the device; it helps small calls")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--pin-codecs", action="store_true", help="hard-code the codecs codec_assign_best_codec picks for this workload (profiling runs: no trial compressions in the step)")
+    ap.add_argument("--config", default="fastq", choices=("fastq", "bam", "vcf"), help="fastq: BASELINE configs[1] (the headline, from text). bam / vcf: configs[2] / configs[3] on one "
+                    "GPU at the context-stream level (their segmenters are not built: the streams of SURVEY 8(0) enter generated), same record layout, cpu_baseline beside it")
+    ap.add_argument("--warm-steps", type=int, default=3, help="extra steps with the handle's codec speculation ON, reported beside the (cold) headline; 0: none")
     return ap.parse_args()
 
 
@@ -93,7 +97,8 @@ def walk_sections(z):
     while at < len(z):
         clen = int.from_bytes(z[at + 12:at + 16], "big")
         domq = z[at + 25] == 13
-        out.append((z[at + 24], z[at + 26] if domq else z[at + 25], bytes(z[at + 32:at + 40]), int.from_bytes(z[at + 16:at + 20], "big"), z[at + 40:at + 40 + clen], domq))
+        named = domq or z[at + 25] == 11                         # CODEC_DOMQ / CODEC_XCGT name the section, the stream's coder is in sub_codec
+        out.append((z[at + 24], z[at + 26] if named else z[at + 25], bytes(z[at + 32:at + 40]), int.from_bytes(z[at + 16:at + 20], "big"), z[at + 40:at + 40 + clen], domq))
         at += 40 + clen
     return out
 
@@ -255,8 +260,9 @@ def cpu_leg(wl, z_all, n_threads):
 
 def pmc_traffic(kernel, a):
     """HBM bytes per STEP of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/round2_pmc.json, made by tools/summarize_prof.py); null for other workloads"""
-    p = os.path.join(ROOT, "profiles", "round2_pmc.json")
+    (profiles/round3_pmc.json, made by tools/summarize_prof.py: counter collection serialises kernels, so it cannot happen inside a timed
+    run); null when there is no such file for this workload"""
+    p = os.path.join(ROOT, "profiles", "round3_pmc.json")
     if not os.path.exists(p):
         return None
     d = json.load(open(p))
@@ -266,8 +272,64 @@ def pmc_traffic(kernel, a):
     return k.get("traffic_bytes_per_step") if k else None
 
 
+def config_leg(a):
+    """BASELINE configs[2] (BAM-1M) / configs[3] (VCF 10 k samples, one GPU's share) on ONE GPU in this record's layout. Their segmenters
+    (SURVEY 8f N1 for SAM / BAM / VCF) are not built: the context streams of SURVEY 8(0) enter generated, at the sizes the reference would
+    give them; a step = b250 generation + local byte order / transposes + codecs + section framing of every VBlock (tools/config_bench.py)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import torch
+    import config_bench as cb
+    from genozip_amd.codec import Engine
+    from genozip_amd.lib import CODEC_NAMES
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    E = Engine(device=0)
+    vbs, text_bytes = cb.bam_vblocks(1000000) if a.config == "bam" else cb.vcf_vblocks(4)
+    wl = cb.Workload(E, vbs, device)
+    codecs = wl.assign()
+    wl.build()
+    for _ in range(max(1, a.warmup)):
+        wl.generate(); wl.compress(); E.sync()
+    E.profile(True, reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        wl.generate(); wl.compress(); E.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    E.profile(False)
+    prof = E.profile_results()
+    prof_max = dict(E.profile_max)
+    ms = dt / a.steps * 1e3
+    z_list = [E.mem.download(vb.z, int(wl.vtab[i].z_len)) for i, vb in enumerate(wl.vbs)]
+    z_total = sum(len(z) for z in z_list)
+    dom = max(prof, key=lambda k: prof[k][0])
+    dom_ms, dom_n = prof[dom]
+    alg = wl.stream_bytes + z_total
+    per_launch = alg / (dom_n / a.steps)
+    ach = per_launch / (dom_ms / dom_n / 1e3) / 1e9
+    out = {"metric": METRIC, "value": round(wl.stream_bytes / 1e6 / (ms / 1e3), 1), "unit": "MB/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": ("BAM-1M (BASELINE configs[2]): 22 VBlocks of 46 000 aligned reads - CIGAR / FLAG / MAPQ b250, binned QUAL local, POS u32 local" if a.config == "bam" else
+                                   "VCF 10 k samples (BASELINE configs[3]), one GPU's share at 8 GPUs: 4 VBlocks of 3 000 lines x 10 000 samples - FORMAT/DP u8 matrix (transposed), FORMAT/PL b250")
+                                  + "; entered at the CONTEXT-STREAM level (the SAM / BAM / VCF segmenters are not built): MB counted = bytes of context streams",
+                      "n_vblocks": wl.n_vb, "stream_mb_per_step": round(wl.stream_bytes / 1e6, 1), "text_mb_approx": round(text_bytes / 1e6), "compressed_mb_per_step": round(z_total / 1e6, 2),
+                      "codecs": {k: CODEC_NAMES[v] for k, v in codecs.items()}},
+           "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                        "avg_launch_ms": round(dom_ms / dom_n, 4), "launches_per_step": dom_n / a.steps, "longest_launch_ms": round(prof_max.get(dom, 0), 3),
+                        "kernel_ms_per_step_summed_over_concurrent_launches": {k: round(v[0] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]}}}
+    if not a.no_cpu:
+        c, exact = cb.cpu_baseline(z_list, min(os.cpu_count() or 1, 256))
+        c["unit"] = "MB/s"
+        out["cpu_baseline"] = c
+        out["bit_exact"] = exact
+    print(json.dumps(out))
+
+
 def main():
     a = parse_args()
+    if a.config != "fastq":
+        return config_leg(a)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(a)
     import numpy as np   # noqa: F401
@@ -317,6 +379,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The headline is the COLD file: every step compresses a new file that knows nothing of the previous one - the handle's memory of
+    # the previous file's QUAL coder (gz_zip_speculation) is switched off for the timed region. The warm figure (a service compressing
+    # file after file of the same kind) is measured afterwards and reported beside it.
+    os.environ["GZ_ZIP_NO_SPECULATION"] = "1"
     for _ in range(a.warmup):
         gather_to_rank0(wl.step(dist))
     gather_wait()
@@ -329,19 +395,31 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     E.profile(False)
+    prof = E.profile_results()
+    prof_max = dict(E.profile_max)
+    warm_ms = None
+    del os.environ["GZ_ZIP_NO_SPECULATION"]
+    if a.warm_steps and not a.stream_reads:
+        gather_to_rank0(wl.step(dist))                       # (the step that teaches the handle the coder)
+        gather_wait(); barrier()
+        t1 = time.perf_counter()
+        for _ in range(a.warm_steps):
+            gather_to_rank0(wl.step(dist))
+        gather_wait(); barrier()
+        warm_ms = (time.perf_counter() - t1) / a.warm_steps * 1e3
 
     # per-rank byte counts -> whole-job sums
     z_total = wl.offs[-1]
     zhost = wl.zbuf[:z_total].cpu().numpy().tobytes()
     z_all = [zhost[wl.offs[i]:wl.offs[i + 1]] for i in range(len(wl.vb))]
     stream_bytes = sum(s[3] for z in z_all for s in walk_sections(z)) * wl.calls_per_step
-    sums = torch.tensor([dt, wl.text_bytes, wl.value_bytes, stream_bytes, z_total * wl.calls_per_step], dtype=torch.float64, device=device)
+    sums = torch.tensor([dt, wl.text_bytes, wl.value_bytes, stream_bytes, z_total * wl.calls_per_step, warm_ms or 0.0], dtype=torch.float64, device=device)
     if world > 1:
-        mx = sums[:1].clone()
+        mx = torch.stack([sums[0], sums[5]])
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        sums[0] = mx[0]
-    dt, text_b, value_b, stream_b, z_b = [float(x) for x in sums.cpu()]
+        sums[0] = mx[0]; sums[5] = mx[1]
+    dt, text_b, value_b, stream_b, z_b, warm_ms_all = [float(x) for x in sums.cpu()]
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -351,7 +429,6 @@ def main():
     value = value_b / 1e6 / (ms_per_step / 1e3)
 
     # ---- roofline of the dominant kernel, from HIP events on the library's streams (gz_profile)
-    prof = E.profile_results()
     dom = max(prof, key=lambda k: prof[k][0])
     dom_ms, dom_launches = prof[dom]
     per_step_launches = dom_launches / a.steps
@@ -360,11 +437,32 @@ def main():
     alg_per_launch = alg_bytes_per_step / per_step_launches
     achieved = alg_per_launch / (max(avg_launch_ms, 1e-6) / 1e3) / 1e9
     tr = pmc_traffic(dom, a)
+    # The critical path. The dominant kernel is launched several times per step on different streams (the persistent launch over the long
+    # QUAL streams + the short-leaf launches of trials and section writer): its launches overlap, their sum is NOT time on the step's
+    # critical path - the LONGEST launch is. That launch codes the long streams (sections of >= 1 MB); what bounds it is the issue rate
+    # of one wave per stream on the scalar unit (7.6 instructions x 4 clocks per symbol at 2.4 GHz = 12.7 ns), not HBM.
+    secs_all = [s for z in z_all for s in walk_sections(z)]
+    long_secs = [s for s in secs_all if s[3] >= (1 << 20) and s[1] in (16, 17, 18, 19)]
+    longest_ms = prof_max.get(dom, avg_launch_ms)
+    crit = None
+    if long_secs:
+        sym = max(s[3] for s in long_secs)
+        bytes_long = sum(s[3] + len(s[4]) for s in long_secs) * wl.calls_per_step
+        crit = {"kernel": dom, "longest_launch_ms": round(longest_ms, 3), "streams_in_it": len(long_secs), "symbols_of_longest_stream": sym,
+                "ns_per_symbol": round(longest_ms * 1e6 / sym, 2), "issue_rate_floor_ns_per_symbol": 12.7,
+                "issue_rate_frac": round(12.7 / (longest_ms * 1e6 / sym), 3),
+                "alg_bytes_in_it": bytes_long, "hbm_achieved_gbs": round(bytes_long / (longest_ms / 1e3) / 1e9, 3),
+                "hbm_frac": round(bytes_long / (longest_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 6),
+                "share_of_step": round(longest_ms / ms_per_step, 3)}
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None if tr is None else int(tr / per_step_launches),
                 "avg_launch_ms": round(avg_launch_ms, 4), "launches_per_step": per_step_launches,
                 "alg_bytes_per_launch": int(alg_per_launch),
-                "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:24]}}
+                "critical_path": crit,
+                "whole_step": {"alg_bytes": int(text_b / world + z_total * wl.calls_per_step), "achieved_gbs": round((text_b / world + z_total * wl.calls_per_step) / (ms_per_step / 1e3) / 1e9, 2),
+                               "frac": round((text_b / world + z_total * wl.calls_per_step) / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS, 6), "note": "T + Z of one step / step time (SURVEY 8d, per pipeline unit)"},
+                "kernel_ms_per_step_summed_over_concurrent_launches": {k: round(v[0] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:24]},
+                "note": "kernel_ms_per_step_summed_over_concurrent_launches adds up launches that run side by side on different streams: a sum of device time, not a critical path"}
 
     codecs = {}
     for z in z_all[:1] + z_all[len(z_all) // 2:len(z_all) // 2 + 1]:
@@ -375,7 +473,7 @@ def main():
            ("FASTQ-PE-1M: ONE file pair (2 x %d reads x 150 bp), its %d VBlock pairs dealt out over the GPUs" % (a.pairs, wl.n_pairs_file)) if (a.scaling == "strong" and world > 1) else \
            ("FASTQ-PE-1M per GPU (2 x %d reads x 150 bp), %d VBlock pairs" % (a.pairs, wl.n_pairs_file))
     out = {"metric": METRIC, "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-           "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": a.scaling if world > 1 else "weak", "vs_baseline": None,
+           "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
            "dtype": "u8", "data": "synthetic",
            "config": {"workload": mode + ", VBlocks of %.2f MB (%s); the WHOLE path per step from FASTQ text in HBM: lines / reads / line-1 items -> seg columns (a1-a3) -> "
                                    "host dictionary merge in C (a4) -> b250 / local generation (a5-a7) -> codec assignment (a8) -> sections in DEP / did_i order (a15) -> "
@@ -387,6 +485,9 @@ def main():
                       "text_mb_per_step": round(text_b / 1e6, 1), "stream_mb_per_step": round(stream_b / 1e6, 1), "compressed_mb_per_step": round(z_b / 1e6, 2),
                       "parallelism": "vblocks sharded over %d GPU(s), no data-path collective; host exchange of new dictionary words (strong scaling only); RCCL gather of z_data" % world},
            "text_mb_s": round(text_b / 1e6 / (ms_per_step / 1e3), 1), "stream_mb_s": round(stream_b / 1e6 / (ms_per_step / 1e3), 1),
+           "headline": "cold: a new file every step, no memory of the previous file (GZ_ZIP_NO_SPECULATION)",
+           "warm": None if not warm_ms_all else {"ms_per_step": round(warm_ms_all, 3), "value": round(value_b / 1e6 / (warm_ms_all / 1e3), 1), "steps": a.warm_steps,
+                                                 "note": "the handle remembers the previous file's QUAL coder and starts the long streams with it (gz_zip_speculation)"},
            "roofline": roofline}
     if not a.no_cpu and world == 1:                # (the CPU pool is timed on rank 0 of the 1-GPU run only)
         cb, exact = cpu_leg(wl, z_all, min(os.cpu_count() or 1, 256))

@@ -289,6 +289,13 @@ class ZipFile:
         d = C.string_at(v.dict, v.dict_len) if v.dict_len else b""
         return d[:-1].split(b"\0") if d else []
 
+    def zctx_view(self, ctx_i):
+        """-> dict(n_words, all_the_same_wi (-1: not set), rm_dict, lcodec, bcodec) of the file-level context"""
+        from .lib import GzZctxView
+        v = GzZctxView()
+        self.E.L.gz_zctx_view(self.E.L.gz_zip_zctx(self.f, ctx_i), C.byref(v))
+        return dict(n_words=v.n_words, all_the_same_wi=v.all_the_same_wi, rm_dict=bool(v.rm_dict_all_the_same), lcodec=v.lcodec, bcodec=v.bcodec)
+
 
 class Engine:
     def __init__(self, device=0, lib_path=None, mem=None, hip_stream=None):
@@ -355,8 +362,12 @@ class Engine:
         out, i = {}, 0
         name = C.create_string_buffer(64)
         ms, n = C.c_double(0), C.c_int(0)
+        mx = C.c_double(0)
+        self.profile_max = {}
         while self.L.gz_profile_get(self.h, i, name, 64, C.byref(ms), C.byref(n)):
             out[name.value.decode()] = (ms.value, n.value)
+            if self.L.gz_profile_get_max(self.h, i, C.byref(mx)):
+                self.profile_max[name.value.decode()] = mx.value       # the longest single launch
             i += 1
         return out
 

@@ -81,7 +81,7 @@ struct GzHandle {
     struct ProfRec { const char *name; hipEvent_t a, b; };
     std::vector<ProfRec> prof_open;
     std::vector<hipEvent_t> event_pool;            // (creating and destroying two events per launch costs more than the launch)
-    struct ProfAcc { std::string name; double ms; int launches; };
+    struct ProfAcc { std::string name; double ms; int launches; double max_ms; };
     std::vector<ProfAcc> prof;
     bool background = false;               // gz_create_background
     std::vector<GzHandle *> helpers;       // handles that work for this one (the VBlock driver's second handle): profiled with it
@@ -267,8 +267,8 @@ static void prof_collect (GzHandle *h)
         float ms = 0;
         if (hipEventElapsedTime (&ms, pr.a, pr.b) == hipSuccess) {
             bool found = false;
-            for (auto &acc : h->prof) if (acc.name == pr.name) { acc.ms += ms; acc.launches++; found = true; break; }
-            if (!found) { GzHandle::ProfAcc acc; acc.name = pr.name; acc.ms = ms; acc.launches = 1; h->prof.push_back (acc); }
+            for (auto &acc : h->prof) if (acc.name == pr.name) { acc.ms += ms; acc.launches++; if (ms > acc.max_ms) acc.max_ms = ms; found = true; break; }
+            if (!found) { GzHandle::ProfAcc acc; acc.name = pr.name; acc.ms = ms; acc.launches = 1; acc.max_ms = ms; h->prof.push_back (acc); }
         }
         h->event_pool.push_back (pr.a); h->event_pool.push_back (pr.b);
     }
@@ -295,7 +295,7 @@ extern "C" int gz_profile_get (GzHandle *h, int idx, char *name, int name_cap, d
             if (o->pending.empty ()) prof_collect (o);
             for (auto &p : o->prof) {
                 bool found = false;
-                for (auto &acc : h->prof_view) if (acc.name == p.name) { acc.ms += p.ms; acc.launches += p.launches; found = true; break; }
+                for (auto &acc : h->prof_view) if (acc.name == p.name) { acc.ms += p.ms; acc.launches += p.launches; if (p.max_ms > acc.max_ms) acc.max_ms = p.max_ms; found = true; break; }
                 if (!found) h->prof_view.push_back (p);
             }
         }
@@ -304,6 +304,15 @@ extern "C" int gz_profile_get (GzHandle *h, int idx, char *name, int name_cap, d
     if (name && name_cap > 0) { strncpy (name, h->prof_view[idx].name.c_str (), name_cap - 1); name[name_cap - 1] = 0; }
     if (total_ms) *total_ms = h->prof_view[idx].ms;
     if (launches) *launches = h->prof_view[idx].launches;
+    return 1;
+}
+
+// the longest single launch of entry idx of the last walk (gz_profile_get from 0): the critical path of a kernel that is launched
+// several times side by side on different streams is its longest launch, not the sum
+extern "C" int gz_profile_get_max (GzHandle *h, int idx, double *max_ms)
+{
+    if (!h || idx < 0 || idx >= (int)h->prof_view.size () || !max_ms) return 0;
+    *max_ms = h->prof_view[idx].max_ms;
     return 1;
 }
 
@@ -1640,7 +1649,7 @@ extern "C" int gz_vb_uncompress (GzHandle *h, const uint8_t *z_data, uint64_t z_
         if (at + 40 + clen > z_len || o + ulen > out_cap || S.size () >= max_sections) { h->err = "section overflow"; return GZ_ERR_CORRUPT; }
         GzStream s; memset (&s, 0, sizeof (s));
         s.in = z_data + at + 40; s.in_len = clen; s.out = out + o; s.out_cap = ulen; s.codec = z[at + 25];
-        if (s.codec == GZ_CODEC_DOMQ) s.codec = z[at + 26];            // USE_SUBCODEC (compressor.c:60-61, codec.c codec_args[CODEC_DOMQ])
+        if (s.codec == GZ_CODEC_DOMQ || s.codec == GZ_CODEC_XCGT) s.codec = z[at + 26];            // USE_SUBCODEC (compressor.c:60-61, codec.c codec_args[CODEC_DOMQ])
         S.push_back (s);
         want_adler.push_back (gz_rd_be32 (&z[at + 4]));
         if (section_offsets_host) section_offsets_host[S.size () - 1] = o;

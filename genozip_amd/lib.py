@@ -137,7 +137,7 @@ GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ
 GzGetLineCB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32))
 
 ABI_SYMBOLS = (
-    "gz_create", "gz_create_background", "gz_destroy", "gz_sync", "gz_last_error", "gz_version", "gz_stream", "gz_profile", "gz_profile_get",
+    "gz_create", "gz_create_background", "gz_destroy", "gz_sync", "gz_last_error", "gz_version", "gz_stream", "gz_profile", "gz_profile_get", "gz_profile_get_max",
     "gz_download", "gz_upload", "gz_dev_alloc", "gz_dev_free", "gz_emit_after", "gz_wait_for",
     "gz_codec_est_size", "gz_codec_compress_host", "gz_codec_uncompress_host",
     "gz_codec_compress_batch", "gz_codec_uncompress_batch", "gz_codec_assign_best",
@@ -184,6 +184,7 @@ def load(path=None):
     L.gz_profile.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.gz_profile.restype = None
     L.gz_profile_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.gz_profile_get_max.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
     L.gz_codec_est_size.restype = C.c_uint32
     L.gz_codec_est_size.argtypes = [C.c_int, C.c_uint64]
     L.gz_codec_compress_host.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_uint32, C.c_char_p, C.POINTER(C.c_uint32), C.c_int]

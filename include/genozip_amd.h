@@ -66,6 +66,8 @@ const char *gz_version (void);
  * gz_profile_get(idx) enumerates the accumulated entries until it returns 0. */
 void gz_profile (GzHandle *h, int enable, int reset);
 int  gz_profile_get (GzHandle *h, int idx, char *name, int name_cap, double *total_ms, int *launches);
+/* the longest single launch of entry idx of the walk begun with gz_profile_get (h, 0, ...) */
+int  gz_profile_get_max (GzHandle *h, int idx, double *max_ms);
 /* the HIP stream work is queued on (a hipStream_t) - for timing with HIP events on the right stream */
 void     *gz_stream (GzHandle *h);
 /* The section-writing kernels of h's NEXT gz_vb_compress_batch (layout, emit, adler32) wait until everything queued on `other`

@@ -318,7 +318,7 @@ class Oracle:
 
     def section_compress(self, desc, data):
         data = bytes(data)
-        cap = 40 + self.est_size(desc.sub_codec if desc.codec == 13 and desc.sub_codec else desc.codec, len(data)) + 64 + len(data)
+        cap = 40 + self.est_size((desc.sub_codec or 1) if desc.codec in (13, 11) else desc.codec, len(data)) + 64 + len(data)
         z = ctypes.create_string_buffer(cap)
         n = self.L.gzo_section_compress(ctypes.byref(desc), data, len(data), z, ctypes.c_uint64(cap))
         if n < 0:

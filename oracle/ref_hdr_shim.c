@@ -34,6 +34,7 @@ int hdrref_vb (uint32_t vblock_i, uint32_t recon_size, uint32_t z_data_bytes, ui
 {
     SectionHeaderVbHeader h; memset (&h, 0, sizeof (h));
     h.magic = BGEN32 (GENOZIP_MAGIC); h.section_type = SEC_VB_HEADER; h.vblock_i = BGEN32 (vblock_i); h.codec = CODEC_NONE; h.flags.flags = (uint8_t)flags;
+    h.z_digest = BGEN32 (1);                         /* comp_compress: adler32 of the (empty) payload (compressor.c:161) */
     h.recon_size = BGEN32 (recon_size); h.z_data_bytes = BGEN32 (z_data_bytes); h.longest_line_len = BGEN32 (longest_line_len); h.longest_seq_len = BGEN32 (longest_seq_len);
     OUT (h);
 }

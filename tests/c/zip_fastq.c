@@ -20,7 +20,7 @@ static void did (uint8_t id[8], const char *tag, int dtype)
 {
     memset (id, 0, 8);
     memcpy (id, tag, strlen (tag) > 8 ? 8 : strlen (tag));
-    id[0] = dtype == 0 ? (id[0] & 0x3f) : (id[0] | 0x80);             /* dict_id_make, src/dict_id.h:17-19 */
+    id[0] = dtype == 0 ? (id[0] & 0x3f) : (id[0] | 0xc0);             /* dict_id_make, src/dict_id.c:34-36 */
 }
 
 static uint32_t slen (const uint8_t *s) { return s ? (uint32_t)strlen ((const char *)s) : 0; }

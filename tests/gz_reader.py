@@ -1,10 +1,34 @@
-"""TEST INFRASTRUCTURE: an independent reader of what genozip_amd writes after the VBlocks - footer ->
-SEC_GENOZIP_HEADER -> section list (file format, src/sections.h:496-515: 19-byte entries, deltas) -> SEC_DICT / SEC_COUNTS.
-Written from the format description (sections.h:146-307), not from the product's writer."""
+"""TEST INFRASTRUCTURE: an independent reader of what genozip_amd writes around the VBlocks - footer ->
+SEC_GENOZIP_HEADER -> section list (file format, src/sections.h:496-515: 19-byte entries, deltas) -> SEC_TXT_HEADER / SEC_DICT /
+SEC_COUNTS. Every field is located through tests/golden/hdr_golden.json - offsets, widths and byte order taken from the REFERENCE'S
+OWN struct definitions (oracle/ref_hdr_shim.c compiled against src/sections.h; tests/golden/make_hdr_golden.py) - not through numbers
+written down here: a field the product puts elsewhere, or in the other byte order, does not read back."""
+import json
+import os
 import struct
 
 MAGIC = 0x27052012
-SEC_GENOZIP_HEADER, SEC_TXT_HEADER, SEC_VB_HEADER, SEC_DICT, SEC_B250, SEC_LOCAL, SEC_COUNTS = 6, 8, 9, 10, 11, 12, 17
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hdr_golden.json")) as _f:
+    GOLD = json.load(_f)
+K = GOLD["constants"]
+SEC_GENOZIP_HEADER, SEC_TXT_HEADER, SEC_VB_HEADER, SEC_DICT, SEC_B250, SEC_LOCAL, SEC_COUNTS = (K["SEC_GENOZIP_HEADER"], K["SEC_TXT_HEADER"], K["SEC_VB_HEADER"], K["SEC_DICT"],
+                                                                                                K["SEC_B250"], K["SEC_LOCAL"], K["SEC_COUNTS"])
+
+
+def field(struct_name, name, blob, at=0):
+    """the value of a field of one of the reference's structs, located by the golden layout"""
+    f = GOLD["layout"][struct_name]["fields"][name]
+    raw = blob[at + f[0]:at + f[0] + f[1]]
+    assert len(raw) == f[1], (struct_name, name, "truncated")
+    if f[2] == "bytes":
+        return bytes(raw)
+    if f[2] == "bits":
+        return (raw[0] >> f[3]) & ((1 << f[4]) - 1)
+    return int.from_bytes(raw, "big" if f[2] == "be" else "little")
+
+
+def size(struct_name):
+    return GOLD["layout"][struct_name]["size"]
 
 
 def _unzig(u):
@@ -13,52 +37,63 @@ def _unzig(u):
 
 def read_file(blob, decode):
     """blob: the whole file; decode(codec, payload, ulen) -> bytes. -> dict(header fields, sections=[dict], dicts={dict_id: [words]}, counts={})"""
-    off, magic = struct.unpack(">QI", blob[-12:])
-    assert magic == MAGIC, "footer"
-    h = blob[off:off + 720]
-    assert struct.unpack(">I", h[:4])[0] == MAGIC and h[24] == SEC_GENOZIP_HEADER
-    clen, ulen = struct.unpack(">II", h[12:20])
-    payload = decode(h[25], blob[off + 720:off + 720 + clen], ulen)
-    num_sections = struct.unpack(">I", h[48:52])[0]
-    assert len(payload) == 19 * num_sections
-    bits = int.from_bytes(h[40:48], "little")
-    out = dict(version=(h[28], bits & 0x3fff), data_type=struct.unpack(">H", h[30:32])[0], recon_size=struct.unpack(">Q", h[32:40])[0],
-               num_lines=int.from_bytes((bits >> 16).to_bytes(8, "little"), "big"),   # zfile.c:965: BGEN64 of the 48-bit field
-               vb_size=struct.unpack(">I", h[715:719])[0], created=h[88:160].split(b"\0")[0], sections=[])
+    foot = blob[-size("footer"):]
+    assert field("footer", "magic", foot) == MAGIC, "footer"
+    off = field("footer", "genozip_header_offset", foot)
+    GH = size("genozip")
+    h = blob[off:off + GH]
+    assert field("ctx", "magic", h) == MAGIC and field("ctx", "section_type", h) == SEC_GENOZIP_HEADER
+    clen, ulen = field("ctx", "data_compressed_len", h), field("ctx", "data_uncompressed_len", h)
+    payload = decode(field("ctx", "codec", h), blob[off + GH:off + GH + clen], ulen)
+    num_sections = field("genozip", "num_sections", h)
+    SE = size("secent")
+    assert len(payload) == SE * num_sections
+    word = field("genozip", "minor_and_num_lines_word", h)         # { minor : 14, is_modified : 1, private : 1, num_lines_bound : 48 } little endian
+    out = dict(version=(field("genozip", "version", h), word & 0x3fff), data_type=field("genozip", "data_type", h), recon_size=field("genozip", "recon_size", h),
+               num_lines=int.from_bytes((word >> 16).to_bytes(8, "little"), "big"),   # zfile.c:965: BGEN64 of the 48-bit field
+               vb_size=field("genozip", "segconf_vb_size", h), created=field("genozip", "created", h).split(b"\0")[0], flags=field("genozip", "flags", h),
+               num_txt_files=field("genozip", "num_txt_files", h), std_seq_len=field("genozip", "std_seq_len", h), std_seq_lR2=field("genozip", "std_seq_lR2", h), sections=[])
     prev_off = prev_vb = prev_lines = 0
     prev_comp = None
     for i in range(num_sections):
-        f = payload[19 * i:19 * i + 19]
-        prev_off += struct.unpack(">I", f[0:4])[0]
-        prev_vb += _unzig(struct.unpack(">I", f[4:8])[0])
-        comp = prev_comp if (i and f[8] == 0) else (255 if f[8] == 255 else f[8] - 1)
+        f = payload[SE * i:SE * i + SE]
+        prev_off += field("secent", "offset_delta", f)
+        prev_vb += _unzig(field("secent", "vblock_i_delta", f))
+        c1 = field("secent", "comp_i_plus_1", f)
+        comp = prev_comp if (i and c1 == 0) else (255 if c1 == 255 else c1 - 1)
         prev_comp = comp
-        s = dict(offset=prev_off, vblock_i=prev_vb, comp_i=comp, st=f[9], flags=f[18])
-        if f[9] in (SEC_DICT, SEC_B250, SEC_LOCAL, SEC_COUNTS):
-            s["dict_id"] = bytes(f[10:18]) if f[10] else out["sections"][struct.unpack(">I", f[14:18])[0]]["dict_id"]
-        elif f[9] == SEC_VB_HEADER:
-            prev_lines += _unzig(struct.unpack(">I", f[10:14])[0])
+        st = field("secent", "st", f)
+        s = dict(offset=prev_off, vblock_i=prev_vb, comp_i=comp, st=st, flags=field("secent", "flags", f))
+        if st in (SEC_DICT, SEC_B250, SEC_LOCAL, SEC_COUNTS):
+            s["dict_id"] = field("secent", "dict_id", f) if field("secent", "is_dict_id", f) else out["sections"][field("secent", "dict_sec_i", f)]["dict_id"]
+        elif st == SEC_VB_HEADER:
+            prev_lines += _unzig(field("secent", "num_lines", f))
             s["num_lines"] = prev_lines
         out["sections"].append(s)
     for a, b in zip(out["sections"], out["sections"][1:]):
         a["size"] = b["offset"] - a["offset"]
-    out["sections"][-1]["size"] = len(blob) - 12 - out["sections"][-1]["offset"]
-    out["dicts"], out["counts"], out["txt_headers"] = {}, {}, []
+    out["sections"][-1]["size"] = len(blob) - size("footer") - out["sections"][-1]["offset"]
+    out["dicts"], out["counts"], out["txt_headers"], out["dict_flags"] = {}, {}, [], {}
     for s in out["sections"]:
-        hd = blob[s["offset"]:s["offset"] + 44]
-        assert struct.unpack(">I", hd[:4])[0] == MAGIC and hd[24] == s["st"], (s, hd[:28])
-        if s["st"] == SEC_TXT_HEADER:                                       # src/sections.h:308-327
-            th = blob[s["offset"]:s["offset"] + 400]
-            out["txt_headers"].append(dict(pair=th[27] & 3, txt_data_size=struct.unpack(">Q", th[28:36])[0], txt_num_lines=struct.unpack(">Q", th[36:44])[0],
-                                           max_lines_per_vb=struct.unpack(">I", th[44:48])[0], txt_filename=th[84:340].split(b"\0")[0], comp_i=s["comp_i"]))
-        if s["st"] == SEC_DICT:
-            clen, ulen = struct.unpack(">II", hd[12:20])
-            data = decode(hd[26] if hd[25] == 13 else hd[25], blob[s["offset"] + 40:s["offset"] + 40 + clen], ulen)   # (CODEC_DOMQ: its sub-codec)
+        hd = blob[s["offset"]:s["offset"] + 400]
+        assert field("ctx", "magic", hd) == MAGIC and field("ctx", "section_type", hd) == s["st"], (s, hd[:28])
+        assert field("ctx", "vblock_i", hd) == s["vblock_i"] and field("ctx", "flags", hd) == s["flags"], ("section list vs header", s)
+        clen, ulen, codec = field("ctx", "data_compressed_len", hd), field("ctx", "data_uncompressed_len", hd), field("ctx", "codec", hd)
+        if s["st"] == SEC_TXT_HEADER:
+            assert s["size"] == size("txt") + clen
+            out["txt_headers"].append(dict(pair=field("txt", "pair", hd), txt_data_size=field("txt", "txt_data_size", hd), txt_num_lines=field("txt", "txt_num_lines", hd),
+                                           max_lines_per_vb=field("txt", "max_lines_per_vb", hd), txt_filename=field("txt", "txt_filename", hd).split(b"\0")[0],
+                                           comp_i=s["comp_i"], flav_prop=field("txt", "flav_prop", hd), src_codec=field("txt", "src_codec", hd)))
+        elif s["st"] == SEC_DICT:
+            D = size("dict")
+            data = decode(codec, blob[s["offset"] + D:s["offset"] + D + clen], ulen)
             words = data[:-1].split(b"\0")
-            assert len(words) == struct.unpack(">I", hd[28:32])[0] and hd[32:40] == s["dict_id"]
+            assert len(words) == field("dict", "num_snips", hd) and field("dict", "dict_id", hd) == s["dict_id"]
             out["dicts"].setdefault(s["dict_id"], []).extend(words)
+            out["dict_flags"][s["dict_id"]] = dict(all_the_same_wi=field("dict", "all_the_same_wi", hd))
         elif s["st"] == SEC_COUNTS:
-            clen, ulen = struct.unpack(">II", hd[12:20])
-            data = decode(hd[25], blob[s["offset"] + 44:s["offset"] + 44 + clen], ulen)
+            Cn = size("counts")
+            data = decode(codec, blob[s["offset"] + Cn:s["offset"] + Cn + clen], ulen)
+            assert field("counts", "dict_id", hd) == s["dict_id"]
             out["counts"][s["dict_id"]] = list(struct.unpack(">%dQ" % (ulen // 8), data))
     return out

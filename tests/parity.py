@@ -885,6 +885,8 @@ def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0
             assert g["seq_packed"] == w["seq_packed"], (call, v, "packed SEQ")
             assert g["z"] == w["z"], (call, v, len(g["z"]), len(w["z"]), _first_diff(g["z"], w["z"]))
             assert g["seq_section_index"] == w["seq_section_index"], (call, v, g["seq_section_index"], w["seq_section_index"])
+        # every read name, reconstructed from the item contexts' sections and the dictionaries alone
+        assert check_qnames(F, plan, text, vbs, got, lambda codec, pay, ulen: bytes(pay) if codec == 1 else oracle.codec_uncompress(codec, pay, ulen)) == sum(g["n_reads"] for g in got)
         # round trip of what was written
         for v, g in enumerate(got):
             z = g["z"]
@@ -1317,3 +1319,172 @@ def fastq_zip_two_in_flight(E, oracle, n_reads, n_calls=5):
     F.reset()
     assert [r["z"] for r in F.zip_vblocks(texts[0], tabs_vbs[0])] == one[0]
     F.close()
+
+
+def header_kats(E):
+    """rows a9 / a16 / N4: what the product writes into SectionHeaderCtx, SectionHeaderVbHeader, SectionHeaderTxtHeader and the containers of the
+    FASTQ plan == the reference's own structs filled through their members (tests/golden/hdr_golden.json, made by oracle/ref_hdr_shim.c
+    compiled against src/sections.h / src/container.h). The data-dependent fields of a section (z_digest, lengths) are taken from the
+    product's bytes at the golden layout's offsets; everything else must match byte for byte."""
+    import json, os, ctypes as C
+    import gz_reader
+    from genozip_amd import fastq as fq
+    G = gz_reader.GOLD
+    n = 0
+    for k in G["kat"]:
+        a, want = k["args"], bytearray.fromhex(k["hex"])
+        if k["kind"] == "ctx":
+            data = bytes(range(97, 97 + 26)) * 3                        # 78 bytes: compressed by the codec asked for
+            sec = Section(data, a["st"], a["codec"], bytes.fromhex(a["dict_id"]), ltype=a["ltype"], flags=a["flags"], param=a["param"], byte30=a["b250"], sub_codec=a["sub_codec"])
+            z = E.vb_compress([VBlock(a["vblock_i"], [sec])])[0]
+            got = bytearray(z[84:84 + 40])
+            for f in ("z_digest", "data_compressed_len", "data_uncompressed_len"):          # data dependent: where the layout says they are
+                o, w, _ = G["layout"]["ctx"]["fields"][f]
+                want[o:o + w] = got[o:o + w]
+            assert gz_reader.field("ctx", "data_uncompressed_len", got) == len(data) and gz_reader.field("ctx", "data_compressed_len", got) == len(z) - 124
+            assert got == want, ("SectionHeaderCtx", a, got.hex(), want.hex())
+        elif k["kind"] == "vb":
+            z = E.vb_compress([VBlock(a["vblock_i"], [Section(b"x" * 10, SEC_LOCAL, 1, b"E1L", ltype=11)], recon_size=a["recon_size"], longest_line_len=a["longest_line_len"],
+                                      longest_seq_len=a["longest_seq_len"])])[0]
+            o, w, _ = G["layout"]["vb"]["fields"]["z_data_bytes"]
+            assert gz_reader.field("vb", "z_data_bytes", z) == len(z)
+            want[o:o + w] = z[o:o + w]
+            assert bytes(z[:84]) == bytes(want), ("SectionHeaderVbHeader", a)
+        elif k["kind"] == "txt":
+            zf = E.L.gz_zfile_create(3, 1 << 20)
+            out = C.create_string_buffer(400)
+            E._check(E.L.gz_zfile_add_txt_header(zf, 0, a["pair"], a["txt_filename"].encode(), a["txt_data_size"], a["txt_num_lines"], a["max_lines_per_vb"], bytes(8), 4, 0, out), "txt header")
+            E.L.gz_zfile_destroy(zf)
+            assert out.raw == bytes(want), ("SectionHeaderTxtHeader", a)
+        elif k["kind"] == "container":
+            if a["name"] == "illumina-7":
+                got = fq.container([(fq.dict_id("Q%dNAME" % i, 1), s) for i, s in enumerate((bytes([8, 3]), b":", b":", b":", b""))], repeats=1)
+            else:
+                con, px = fq.fastq_toplevel(has_qname2=True)
+                got = bytearray(con); got[1:4] = a["repeats"].to_bytes(3, "little")
+            assert bytes(got) == bytes(want), ("Container", a["name"])
+        else:
+            continue                                                    # (footer / section list entries: through gz_reader's layout in the file tests)
+        n += 1
+    return n
+
+
+# ---- a reader of the QNAME contexts (test infrastructure): what reconstruct_one_snip does for the snips the FASTQ plan segs --------
+def _b250_words(data):
+    """PIZ-format b250 (src/b250.c:29-43,299-327) -> word indices (int64; ONE_UP resolved, EMPTY -3 / MISSING -4 kept)"""
+    a = np.frombuffer(bytes(data), dtype=np.uint8)
+    if len(a) and a.max() < 0x7f:                                  # every entry one byte, no ONE_UP: the usual case of a small dictionary
+        return a.astype(np.int64)
+    out, i, prev, n = [], 0, -1, len(a)
+    while i < n:
+        b = int(a[i])
+        if b < 0x7f: wi, i = b, i + 1
+        elif b == 0x7f: wi, i = prev + 1, i + 1
+        elif b < 0xc0:
+            v = ((b & 0x3f) << 8) | int(a[i + 1]); i += 2
+            wi = -3 if v == 0x3ffe else -4 if v == 0x3fff else v + 127
+        elif b < 0xe0: wi, i = (((b & 0x1f) << 16) | (int(a[i + 1]) << 8) | int(a[i + 2])) + 16509, i + 3
+        else: wi, i = ((b & 0x1f) << 24) | (int(a[i + 1]) << 16) | (int(a[i + 2]) << 8) | int(a[i + 3]), i + 4
+        out.append(wi); prev = wi
+    return np.array(out, dtype=np.int64)
+
+
+def _local_ints(data, ltype):
+    """a local of an integer type in file order (big endian; signed types interlaced, src/context.h:99-101) -> int64"""
+    width = {1: 1, 2: 1, 3: 2, 4: 2, 5: 4, 6: 4, 7: 8, 8: 8}[ltype]
+    u = np.frombuffer(bytes(data), dtype=">u%d" % width).astype(np.uint64)
+    if ltype in (1, 3, 5, 7):                                       # LT_INT8 / 16 / 32 / 64: 2n for n >= 0, 2|n| - 1 for n < 0
+        return np.where(u & np.uint64(1), -((u + np.uint64(1)) >> np.uint64(1)).astype(np.int64), (u >> np.uint64(1)).astype(np.int64))
+    return u.astype(np.int64)
+
+
+def qnames_of_vblock(plan, words, ats_wi, secs, r1_secs, n_reads, decode):
+    """line 1 (without '@') of every read of a VBlock from its QNAME / QNAME2 item contexts alone: b250 word indices -> dictionary
+    snips -> text; SNIP_LOOKUP -> the next integer of the local; SNIP_SELF_DELTA -> the previous value + the next integer (src/reconstruct.c).
+    plan: the FASTQ plan; words[c]: the file's dictionary of context c; ats_wi[c]: the word every VBlock without a b250 section
+    reconstructs (FlagsDict.all_the_same_wi); secs / r1_secs: {(section_type, dict_id): (flags, ltype, payload bytes, codec, ulen)} of the
+    VBlock and of its R1 VBlock (an R2 VBlock without a section of a pair-identical context takes R1's, src/sections.h:98-99);
+    decode (codec, payload, ulen) -> bytes. -> numpy array of bytes objects"""
+    from genozip_amd.lib import GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA
+    cols = {}
+    for c, X in enumerate(plan["ctxs"]):
+        if X["kind"] not in (GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA):
+            continue
+
+        def sec(st):
+            s = secs.get((st, X["dict_id"]))
+            if s is None and r1_secs is not None and X["pair_identical"]:
+                s = r1_secs.get((st, X["dict_id"]))
+            return s
+        b, l = sec(11), sec(12)
+        if b is not None:
+            wi = _b250_words(decode(b[3], b[2], b[4]))
+            if b[0] & 0x20:                                         # flags.all_the_same: one entry stands for every line
+                wi = np.full(n_reads, wi[0], dtype=np.int64)
+        else:
+            wi = np.full(n_reads, ats_wi[c] if ats_wi[c] >= 0 else 0, dtype=np.int64)
+        assert len(wi) == n_reads, (X["tag"], len(wi), n_reads)
+        ints = _local_ints(decode(l[3], l[2], l[4]), l[1]) if l is not None and 1 <= l[1] <= 8 else None
+        W = words[c]
+        uniq = np.unique(wi)
+        kinds = {int(u): W[int(u)][:1] for u in uniq}
+        if all(k == b"\x05" for k in kinds.values()):               # SNIP_SELF_DELTA: value = previous + delta (the first against 0)
+            assert ints is not None and len(ints) == n_reads, X["tag"]
+            cols[X["item"]] = np.cumsum(ints).astype("S")
+        elif all(k == b"\x01" for k in kinds.values()):             # SNIP_LOOKUP: the next integer of the local
+            assert ints is not None and len(ints) == n_reads, X["tag"]
+            cols[X["item"]] = ints.astype("S")
+        else:                                                       # textual snips (a lookup among them takes the local's next integer)
+            arr = np.array([W[int(u)] for u in uniq], dtype=object)
+            col = arr[np.searchsorted(uniq, wi)]
+            look = np.array([kinds[int(u)] == b"\x01" for u in uniq])[np.searchsorted(uniq, wi)]
+            if look.any():
+                col = col.copy(); col[look] = [b"%d" % v for v in ints[:int(look.sum())]]
+            cols[X["item"]] = col.astype("S")
+    seps = []
+    for s, k in zip(plan["seps"], plan["sep_counts"]):
+        seps.append(bytes([s]))
+    out = cols[0]
+    for i, s in enumerate(seps):
+        out = np.char.add(np.char.add(out, s), cols[i + 1])
+    return out
+
+
+def check_qnames(F, plan, text, vbs, got, decode):
+    """every read name of every VBlock of a call, reconstructed from the item contexts' sections + the file's dictionaries, == line 1 of the
+    text. vbs: (offset, length, vblock_i, r1 index within the call or -1); got: the VBlocks' results (z); decode (codec, payload, ulen)"""
+    NC = len(plan["ctxs"])
+    words = [F.zctx_words(c) for c in range(NC)]
+    ats = [F.zctx_view(c)["all_the_same_wi"] for c in range(NC)]
+    all_secs = []
+    for g in got:
+        z, at, S = g["z"], 84, {}
+        while at < len(z):
+            clen = int.from_bytes(z[at + 12:at + 16], "big")
+            named = z[at + 25] in (13, 11)
+            S[(z[at + 24], bytes(z[at + 32:at + 40]))] = (z[at + 27], z[at + 28], z[at + 40:at + 40 + clen], z[at + 26] if named else z[at + 25], int.from_bytes(z[at + 16:at + 20], "big"))
+            at += 40 + clen
+        all_secs.append(S)
+    t = np.frombuffer(bytes(text), dtype=np.uint8) if not isinstance(text, np.ndarray) else text
+    n_checked = 0
+    for v, ((off, ln, vi, r1), g) in enumerate(zip(vbs, got)):
+        names = qnames_of_vblock(plan, words, ats, all_secs[v], all_secs[r1] if r1 >= 0 else None, g["n_reads"], decode)
+        seg = t[off:off + ln]
+        nl = np.flatnonzero(seg == 10)
+        starts = np.concatenate([[0], nl[3::4][:-1] + 1]) if len(nl) else np.zeros(0, dtype=np.int64)
+        ends = nl[0::4]
+        assert len(starts) == len(names) == g["n_reads"]
+        # compare as one byte string: the names joined by '\n' (so neither lengths nor contents can drift)
+        want = b"\n".join(bytes(seg[int(a) + 1:int(b)]) for a, b in zip(starts, ends)) if g["n_reads"] <= 5000 else None
+        if want is not None:
+            assert b"\n".join(names.tolist()) == want, ("read names of VBlock", vi)
+        else:                                                       # fixed-width records (the bench workload): a matrix compare
+            W = int(ends[0] - starts[0] - 1)
+            assert (ends - starts - 1 == W).all()
+            rb = int(starts[1] - starts[0])
+            mat = seg[:rb * len(starts)].reshape(-1, rb)[:, 1:1 + W]
+            lens = np.char.str_len(names)                          # (np.char.add widens the dtype to the sum of its operands' widths)
+            assert lens.min() == lens.max() == W, ("read names of VBlock", vi, int(lens.min()), int(lens.max()), W)
+            assert (np.frombuffer(names.astype("S%d" % W).tobytes(), dtype=np.uint8).reshape(-1, W) == mat).all(), ("read names of VBlock", vi)
+        n_checked += g["n_reads"]
+    return n_checked

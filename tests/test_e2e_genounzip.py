@@ -95,3 +95,24 @@ def test_single_file_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, qual
     log = _run(genounzip, ["-f", "-o", "out.fq", "reads.fq.genozip"], tmp_path)
     out = (tmp_path / "out.fq").read_bytes() if (tmp_path / "out.fq").exists() else b""
     assert out == text, log[:3000]
+
+
+@pytest.mark.parametrize("qual", ["uniform", "bin"])
+def test_paired_files_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, qual):
+    """--pair: R1 and R2 as two components of one file (R1's VBlocks 1..n, R2's n+1..2n: the reader pairs vblock_i with vblock_i - n,
+    src/writer.c:318-322); R2 sections identical to R1's are left out, R1's carry flags.paired (zfile.c:292-294,323-325)"""
+    from genozip_amd import fastq as fq
+    r1 = parity.fastq_text(700, seed=51, mate=1, qual=qual)
+    r2 = parity.fastq_text(700, seed=51, mate=2, qual_seed=333, qual=qual, dirty_seq=True)
+    p1, p2 = _cut(r1, 2), _cut(r2, 2)
+    text = r1 + r2
+    vbs = [(p1[0][0], p1[0][1], 1, -1), (p1[1][0], p1[1][1], 2, -1), (len(r1) + p2[0][0], p2[0][1], 3, 0), (len(r1) + p2[1][0], p2[1][1], 4, 1)]
+    plan = fq.illumina_plan(paired=True)
+    F, res = _zip(emul_engine, plan, [(text, vbs)], lzma_sub)
+    blob = F.write_file([dict(name=b"reads_R1.fq", pair=1, vbs=res[:2]), dict(name=b"reads_R2.fq", pair=2, vbs=res[2:])], std_seq_len=150, std_seq_len_r2=150)
+    F.close()
+    (tmp_path / "pair.genozip").write_bytes(blob)
+    log = _run(genounzip, ["-f", "pair.genozip"], tmp_path)
+    got1 = (tmp_path / "reads_R1.fq").read_bytes() if (tmp_path / "reads_R1.fq").exists() else b""
+    got2 = (tmp_path / "reads_R2.fq").read_bytes() if (tmp_path / "reads_R2.fq").exists() else b""
+    assert got1 == r1 and got2 == r2, (sorted(os.listdir(tmp_path)), log[:3000])

@@ -164,3 +164,8 @@ def test_section_order_contexts_out_of_order(emul_engine):
             k = L.gz_section_order(arr, n, vb_i, out)
             got = [(out[j] // 2, "B" if out[j] & 1 else "L") for j in range(k)]
             assert got == parity._section_order_ref(ctxs, vb_i), (seed, vb_i)
+
+
+def test_emul_header_layouts(emul_engine):
+    """SectionHeaderCtx / VbHeader / TxtHeader and the plan's containers, byte for byte against the reference's own struct definitions"""
+    assert parity.header_kats(emul_engine) >= 6

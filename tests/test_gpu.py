@@ -243,6 +243,12 @@ def test_chunk_and_tile_boundaries(gpu_engine, oracle):
         assert g == oracle.codec_compress(c, d), (c, len(d))
 
 
+def test_header_layouts(gpu_engine):
+    """a9 / a16 / N4: SectionHeaderCtx, SectionHeaderVbHeader, SectionHeaderTxtHeader and the plan's containers as the product writes them
+    == the reference's own structs filled through their members (tests/golden/hdr_golden.json from oracle/ref_hdr_shim.c)"""
+    assert parity.header_kats(gpu_engine) >= 6
+
+
 def test_domq(gpu_engine, oracle):
     """N3: CODEC_DOMQ's pre-transform at VBlock size (46 000 lines) == the oracle, whose restatement is pinned to the reference's
     own codec_domq.c by tests/golden/ctx_golden.json (checked for the product in test_ctx_golden_vectors)"""
@@ -292,6 +298,12 @@ def test_full_size_fastq_file(gpu_engine, oracle):
     z_all = [z1[offs[i]:offs[i + 1]] for i in range(len(wl.vb))]
     assert sum(t.n_reads for t in wl.tab) == 2 * 1000000
     _check_vblocks(gpu_engine, oracle, bench, wl, z_all, {0, len(z_all) // 2, len(z_all) - 1})
+    # every one of the 2 M read names, rebuilt from the six QNAME and three QNAME2 item contexts' sections + the file's dictionaries
+    # (b250 word indices -> snips; lookups and self-deltas through the locals), == line 1 of the text
+    got = [dict(z=z, n_reads=int(t.n_reads)) for z, t in zip(z_all, wl.tab)]
+    text_host = wl.text[:wl.text_len].cpu().numpy()
+    dec = lambda codec, pay, ulen: bytes(pay) if codec == 1 else oracle.codec_uncompress(codec, pay, ulen)   # noqa: E731
+    assert parity.check_qnames(wl.F, wl.plan, text_host, wl.vb, got, dec) == 2 * 1000000
     total2 = wl.step(None)                                   # a new file with the same text: the same bytes
     assert total2 == total and wl.zbuf[:total].cpu().numpy().tobytes() == z1
     # one QUAL payload against the CPU restatement of the coder (6.9 MB: a few seconds)
