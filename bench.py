@@ -379,10 +379,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The headline is the COLD file: every step compresses a new file that knows nothing of the previous one - the handle's memory of
-    # the previous file's QUAL coder (gz_zip_speculation) is switched off for the timed region. The warm figure (a service compressing
-    # file after file of the same kind) is measured afterwards and reported beside it.
-    os.environ["GZ_ZIP_NO_SPECULATION"] = "1"
+    # The headline is the COLD file: every step compresses a new file that knows nothing of the previous one - what the handle learned
+    # from its previous file (the coder its QUAL streams got, gz_zip_speculation) is not used in the timed region: the long streams
+    # start with the library's built-in prior (an order-1 adaptive coder), as the first file on a fresh handle does, and the file's own
+    # trial compressions confirm or refute it. The warm figure (a service compressing file after file of the same kind) is measured
+    # afterwards and reported beside it.
+    os.environ["GZ_ZIP_PRIOR_ONLY"] = "1"
     for _ in range(a.warmup):
         gather_to_rank0(wl.step(dist))
     gather_wait()
@@ -398,7 +400,7 @@ def main():
     prof = E.profile_results()
     prof_max = dict(E.profile_max)
     warm_ms = None
-    del os.environ["GZ_ZIP_NO_SPECULATION"]
+    del os.environ["GZ_ZIP_PRIOR_ONLY"]
     if a.warm_steps and not a.stream_reads:
         gather_to_rank0(wl.step(dist))                       # (the step that teaches the handle the coder)
         gather_wait(); barrier()
@@ -485,7 +487,7 @@ def main():
                       "text_mb_per_step": round(text_b / 1e6, 1), "stream_mb_per_step": round(stream_b / 1e6, 1), "compressed_mb_per_step": round(z_b / 1e6, 2),
                       "parallelism": "vblocks sharded over %d GPU(s), no data-path collective; host exchange of new dictionary words (strong scaling only); RCCL gather of z_data" % world},
            "text_mb_s": round(text_b / 1e6 / (ms_per_step / 1e3), 1), "stream_mb_s": round(stream_b / 1e6 / (ms_per_step / 1e3), 1),
-           "headline": "cold: a new file every step, no memory of the previous file (GZ_ZIP_NO_SPECULATION)",
+           "headline": "cold: a new file every step, nothing learned from the previous file is used (GZ_ZIP_PRIOR_ONLY: the long QUAL streams start with the built-in prior coder, the file's own trial decides)",
            "warm": None if not warm_ms_all else {"ms_per_step": round(warm_ms_all, 3), "value": round(value_b / 1e6 / (warm_ms_all / 1e3), 1), "steps": a.warm_steps,
                                                  "note": "the handle remembers the previous file's QUAL coder and starts the long streams with it (gz_zip_speculation)"},
            "roofline": roofline}

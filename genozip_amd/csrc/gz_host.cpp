@@ -86,7 +86,10 @@ struct GzHandle {
     bool background = false;               // gz_create_background
     std::vector<GzHandle *> helpers;       // handles that work for this one (the VBlock driver's second handle): profiled with it
     uint32_t zip_spec_hits = 0, zip_spec_misses = 0;
-    int zip_qual_guess[2] = { 0, 0 };      // the VBlock driver: the coder the last file's QUAL stream got (plain / through CODEC_DOMQ) - gz_zip.h, "speculation"
+    // the VBlock driver: the coder the long QUAL streams are started with before the file's own trial compressions are through
+    // (plain / through CODEC_DOMQ) - gz_zip.h, "speculation". Starts as a built-in prior - an order-1 adaptive coder is what
+    // codec_assign_best_codec's size rule gives quality strings - and follows what the handle's files actually got
+    int zip_qual_guess[2] = { GZ_CODEC_ARTB, 0 };
     std::vector<ProfAcc> prof_view;        // gz_profile_get: this handle's totals + its helpers'
 };
 

@@ -701,7 +701,11 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     // It pays where the long streams are the long pole of the call - few VBlocks, of the reference's usual size (measured, ms per step
     // without / with: one file pair of 1 M reads in 14.7 MB VBlocks 98.7 / 96.0; in 4 MB VBlocks 42.0 / 47.3; 112 pairs per call
     // 286 / 297: there the trial only gets in the way of the rest) - so: at most 64 VBlocks, the longest with >= 5 M scores.
-    const int *guess = f->h_user->zip_qual_guess;
+    // (GZ_ZIP_PRIOR_ONLY=1: what the handle has learned from its previous files is not used - every file starts from the built-in prior,
+    //  as the first file on a fresh handle does: the "cold" figure of bench.py)
+    static const int prior_guess[2] = { GZ_CODEC_ARTB, 0 };
+    const char *prior_env = getenv ("GZ_ZIP_PRIOR_ONLY");
+    const int *guess = (prior_env && *prior_env && *prior_env != '0') ? prior_guess : f->h_user->zip_qual_guess;
     uint64_t longest_text = 0;
     for (uint32_t v = 0; v < NV; v++) longest_text = std::max<uint64_t> (longest_text, vbs[v].text_len);
     const char *spec_env = getenv ("GZ_ZIP_SPECULATION");                  // "always": whatever the sizes (tests)

@@ -171,3 +171,30 @@ def test_file_dealt_out_over_2_ranks_equals_one_rank(emul_engine, qual, tiny):
     assert sorted(got) == sorted(one) == list(range(1, 2 * n_pairs + 1))
     for vi in one:
         assert got[vi] == one[vi], "VBlock %d differs between the 2-rank and the 1-rank run" % vi
+
+
+def test_strong_scaling_at_one_rank_equals_weak(emul_engine):
+    """N = 1: the strong-scaling form (three phases + the exchanges of merge blobs and codec votes, here within a process group of ONE
+    rank) writes the bytes of the plain one-process call (the weak form's step): the curve bench.py --scaling strong starts from is
+    the same work as its N = 1 weak point"""
+    from genozip_amd import fastq as fq
+    n_reads, n_pairs = 60, 2
+    text, vbs, vb_size = _pair_file(n_reads, n_pairs)
+    F = emul_engine.zip_open(fq.illumina_plan(paired=True, vb_size=vb_size))
+    buf = emul_engine.mem.upload(text + b"\0" * 32)
+    tab = F.vb_table(vbs)
+    F.zip_table(buf, len(text), tab, len(vbs))
+    one = {r["vblock_i"]: r["z"] for r in F.results(tab)}
+    F.close()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_zip_worker, args=(0, 1, port, n_reads, n_pairs, q))
+    p.start()
+    allres = q.get(timeout=300)
+    p.join(120)
+    assert p.exitcode == 0 and len(allres) == 1
+    assert allres[0][0] == one
