@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--pairs", type=int, default=1000000, help="read pairs of the file (BASELINE configs[1]: 1 M)")
     ap.add_argument("--vb-mb", type=float, default=0, help="VBlock size in MiB (the reference's --vblock). Default 0: the reference's own rule for the file "
                     "(src/segconf.c:152-206, see vb_bytes below): 14.72 MB for a 1 M-read mate file; 16 MiB for --stream-reads")
-    ap.add_argument("--qual", default="div", choices=("div", "bin"))
+    ap.add_argument("--qual", default=None, choices=("div", "bin"), help="quality profile (SURVEY 8d): 40-level (default for fastq) or Illumina-binned (default for bam)")
     ap.add_argument("--scaling", default="strong", choices=("weak", "strong"),
                     help="N > 1. strong (default: BASELINE's target is strong scaling of configs[1]): ONE file pair, its VBlock pairs dealt out over the GPUs; weak: a file pair per GPU")
     ap.add_argument("--stream-reads", type=int, default=0, help="stream this many read pairs per rank through one file (configs[4] at reduced scale)")
@@ -57,8 +57,9 @@ def parse_args():
                     "per call (15.5 -> 14.0 GB/s) - with 224 long streams per call the model kernels already fill the device; it helps small calls")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--pin-codecs", action="store_true", help="hard-code the codecs codec_assign_best_codec picks for this workload (profiling runs: no trial compressions in the step)")
-    ap.add_argument("--config", default="fastq", choices=("fastq", "bam", "vcf"), help="fastq: BASELINE configs[1] (the headline, from text). bam / vcf: configs[2] / configs[3] on one "
-                    "GPU at the context-stream level (their segmenters are not built: the streams of SURVEY 8(0) enter generated), same record layout, cpu_baseline beside it")
+    ap.add_argument("--config", default="fastq", choices=("fastq", "bam", "vcf"), help="fastq: BASELINE configs[1] (the headline, from text). bam: configs[2] from SAM text (genozip_amd/sam.py). vcf: configs[3], one GPU's share, at the "
+                    "context-stream level (no VCF segmenter: the streams of SURVEY 8(0) enter generated). Same record layout, cpu_baseline beside it")
+    ap.add_argument("--stream-level", action="store_true", help="--config bam: enter at the context-stream level (generated streams) instead of from SAM text")
     ap.add_argument("--warm-steps", type=int, default=3, help="extra steps with the handle's codec speculation ON, reported beside the (cold) headline; 0: none")
     return ap.parse_args()
 
@@ -156,6 +157,11 @@ class Workload:
         self.offs = None
         self.calls_per_step = 1 if not a.stream_reads else max(1, -(-self.n_pairs_file // len(ranges)))
 
+    def qual_offsets(self, tv):
+        import numpy as np
+        RB, L = self.W.RECORD_BYTES, self.W.READ_LEN
+        return np.arange(len(tv) // RB, dtype=np.int64) * RB + RB - L - 1
+
     def step(self, dist):
         from genozip_amd.shard import zip_vblocks_sharded
         F, n = self.F, len(self.vb)
@@ -208,19 +214,18 @@ def cpu_leg(wl, z_all, n_threads):
     O = pyoracle.Oracle()
     tasks, payloads, task_vb, qual_ok = [], [], [], True
     text = wl.text[:wl.text_len].cpu().numpy()
-    RB, L = wl.W.RECORD_BYTES, wl.W.READ_LEN
+    L = wl.W.READ_LEN
     qual_id = next(c["dict_id"] for c in wl.plan["ctxs"] if c["tag"] == "QUAL")
     for v, ((off, ln, vi, r1), z) in enumerate(zip(wl.vb, z_all)):
         for st, codec, did, ulen, pay, domq in walk_sections(z):
             data = bytes(pay) if codec == 1 else (R.codec_uncompress(codec, pay, ulen) if kind == "port" else R.hts_uncompress("rans" if codec < 16 else "arith", pay, ulen))
-            if did == qual_id:
-                want = text[off:off + ln].reshape(-1, RB)[:, RB - L - 1:RB - 1]
+            if did == qual_id and st == 12:
+                tv = text[off:off + ln]
+                qo = wl.qual_offsets(tv)                                                   # where every record's QUAL (L scores) starts in the VBlock's text
                 if domq:                       # the stream CODEC_DOMQ leaves of these quality lines, by the CPU restatement of codec_domq.c
-                    n = ln // RB
-                    qo = (np.arange(n, dtype=np.int64) * RB + RB - L - 1).astype(np.uint32)
-                    qual_ok &= data == pyoracle.oracle_domq(O, text[off:off + ln].tobytes(), qo, np.full(n, L, dtype=np.uint32))["qual"]
+                    qual_ok &= data == pyoracle.oracle_domq(O, tv.tobytes(), qo.astype(np.uint32), np.full(len(qo), L, dtype=np.uint32))["qual"]
                 else:
-                    qual_ok &= data == want.tobytes()
+                    qual_ok &= data == tv[qo[:, None] + np.arange(L)].tobytes()
             if codec != 1:
                 tasks.append((codec, data)); payloads.append(bytes(pay)); task_vb.append(v)
     if not tasks:
@@ -270,6 +275,116 @@ def pmc_traffic(kernel, a):
         return None
     k = d["kernels"].get(kernel)
     return k.get("traffic_bytes_per_step") if k else None
+
+
+class SamWorkload:
+    """BASELINE configs[2] FROM TEXT: 1 M aligned 150 bp reads as SAM alignment lines in HBM (genozip_amd/workload.py::sam_text), VBlocks by
+    the reference's rule, through the VBlock compute driver with the one-line-record plan of genozip_amd/sam.py"""
+
+    def __init__(self, E, a, device):
+        import torch
+        from genozip_amd import workload as W, sam as sm
+        self.E, self.a, self.W = E, a, W
+        n = a.pairs
+        th = W._TH(device)
+        CH = 100000
+        parts = [W.sam_text(3, r0, min(CH, n - r0), profile="bin" if a.qual == "bin" else "div", xp=th) for r0 in range(0, n, CH)]
+        self.text_len = int(sum(p.numel() for p in parts))
+        self.text = torch.empty(self.text_len + 64, dtype=torch.uint8, device=device)
+        at = 0
+        for p in parts:
+            self.text[at:at + p.numel()] = p; at += p.numel()
+        del parts
+        # VBlocks: segconf_set_vb_size's figure for the file (as vb_bytes for FASTQ), cut at line ends
+        vbb = int(a.vb_mb * (1 << 20)) if a.vb_mb else min(2 * (20 << 20), max(4 << 20, int(self.text_len * 1.2 / 30)))
+        self.vb_bytes = vbb
+        nl = torch.nonzero(self.text[:self.text_len] == 10).reshape(-1)
+        ends = (nl + 1).cpu().numpy()
+        import numpy as np
+        cuts, at = [0], 0
+        while at < self.text_len:
+            k = int(np.searchsorted(ends, at + vbb, side="right")) - 1
+            nxt = int(ends[k]) if k >= 0 and ends[k] > at else int(ends[np.searchsorted(ends, at, side="right")])
+            cuts.append(min(nxt, self.text_len)); at = cuts[-1]
+        self.vb = [(cuts[i], cuts[i + 1] - cuts[i], i + 1, -1) for i in range(len(cuts) - 1)]
+        self.n_reads_own = n
+        self.plan = sm.sam_plan(has_aux=True, vb_size=vbb)
+        self.F = E.zip_open(self.plan)
+        self.tab = self.F.vb_table(self.vb)
+        self.zbuf, self.offs, self.calls_per_step = None, None, 1
+
+    def qual_offsets(self, tv):
+        import numpy as np
+        tabs = np.flatnonzero(tv == 9).reshape(-1, 12)                      # 12 tabs a line: QUAL sits behind the 10th
+        return tabs[:, 9].astype(np.int64) + 1
+
+    def step(self, dist):
+        import torch
+        F, n = self.F, len(self.vb)
+        F.reset()
+        F.zip_table(self.text, self.text_len, self.tab, n)
+        total = sum(t.z_len for t in self.tab)
+        if self.zbuf is None or self.zbuf.numel() < total + 64:
+            self.zbuf = torch.empty(int(total * 1.05) + 4096, dtype=torch.uint8, device=self.text.device)
+        self.offs = F.collect(self.tab, n, self.zbuf, self.zbuf.numel())
+        return self.offs[-1]
+
+
+def sam_leg(a):
+    """BASELINE configs[2] on one GPU, from SAM text resident in HBM (N1 for SAM, genozip_amd/sam.py) to finished VBlocks"""
+    import torch
+    from genozip_amd.codec import Engine
+    from genozip_amd.lib import CODEC_NAMES
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    E = Engine(device=0)
+    wl = SamWorkload(E, a, device)
+    os.environ["GZ_ZIP_PRIOR_ONLY"] = "1"
+    for _ in range(max(1, a.warmup)):
+        wl.step(None)
+    E.profile(True, reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        wl.step(None)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    E.profile(False)
+    prof = E.profile_results()
+    prof_max = dict(E.profile_max)
+    ms = dt / a.steps * 1e3
+    z_total = wl.offs[-1]
+    zhost = wl.zbuf[:z_total].cpu().numpy().tobytes()
+    z_all = [zhost[wl.offs[i]:wl.offs[i + 1]] for i in range(len(wl.vb))]
+    secs = [s_ for z in z_all for s_ in walk_sections(z)]
+    stream_bytes = sum(s_[3] for s_ in secs)
+    n_bases = sum(int(t.n_bases) for t in wl.tab)
+    wl.value_bytes = wl.text_len - n_bases                      # the text without its SEQ fields (2-bit packed in the step, LZMA outside the path: as for FASTQ)
+    dom = max(prof, key=lambda k: prof[k][0])
+    dom_ms, dom_n = prof[dom]
+    alg = stream_bytes + z_total
+    ach = alg / (dom_n / a.steps) / (dom_ms / dom_n / 1e3) / 1e9
+    long_secs = [s_ for s_ in secs if s_[3] >= (1 << 20) and s_[1] in (16, 17, 18, 19)]
+    codecs = {}
+    for st, codec, did, ulen, pay, _d in walk_sections(z_all[0]):
+        tag = next((c["tag"] for c in wl.plan["ctxs"] if c["dict_id"] == did), did.hex())
+        codecs[("b250:" if st == 11 else "local:") + tag] = CODEC_NAMES.get(codec, str(codec))
+    out = {"metric": METRIC, "value": round(wl.value_bytes / 1e6 / (ms / 1e3), 1), "unit": "MB/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "BAM-1M (BASELINE configs[2]) FROM TEXT: %d aligned 150 bp reads as SAM alignment lines (coordinate-sorted, CIGAR 90 %% 150M, QUAL profile %s), %d VBlocks of %.2f MB; "
+                                  "the whole path per step from text in HBM through the one-line-record plan of genozip_amd/sam.py (N1 for SAM: fields by tab, QNAME by flavor -> a1-a16); "
+                                  "a new file every step. MB counted in `value` = text WITHOUT the SEQ fields (2-bit packed in the step, LZMA outside the path)" % (a.pairs, a.qual, len(wl.vb), wl.vb_bytes / 1e6),
+                      "text_mb_per_step": round(wl.text_len / 1e6, 1), "stream_mb_per_step": round(stream_bytes / 1e6, 1), "compressed_mb_per_step": round(z_total / 1e6, 2), "codecs": codecs},
+           "text_mb_s": round(wl.text_len / 1e6 / (ms / 1e3), 1), "stream_mb_s": round(stream_bytes / 1e6 / (ms / 1e3), 1),
+           "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                        "avg_launch_ms": round(dom_ms / dom_n, 4), "launches_per_step": dom_n / a.steps, "longest_launch_ms": round(prof_max.get(dom, 0), 3),
+                        "long_streams": len(long_secs), "symbols_of_longest_stream": max([s_[3] for s_ in long_secs] + [0]),
+                        "kernel_ms_per_step_summed_over_concurrent_launches": {k: round(v[0] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]}}}
+    if not a.no_cpu:
+        cb, exact = cpu_leg(wl, z_all, min(os.cpu_count() or 1, 256))
+        out["cpu_baseline"] = cb
+        out["bit_exact"] = exact
+    print(json.dumps(out))
 
 
 def config_leg(a):
@@ -328,6 +443,10 @@ def config_leg(a):
 
 def main():
     a = parse_args()
+    if a.qual is None:
+        a.qual = "bin" if a.config == "bam" else "div"
+    if a.config == "bam" and not a.stream_level:
+        return sam_leg(a)
     if a.config != "fastq":
         return config_leg(a)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -265,14 +265,14 @@ __global__ void __launch_bounds__(256) k_pack_copy (const GzdPackJob *jobs, uint
 // ---- VB header statistics: longest record (vb->longest_line_len, seg.c: a FASTQ "line" is the 4-line read) and longest SEQ ----
 // grid (VBlocks); first_line = [starts (n_vb) | ends (n_vb)]
 __global__ void __launch_bounds__(256) k_vb_stats (const uint32_t *line_off, const uint32_t *seq_len, const uint32_t *first_line, const uint64_t *vb_end, uint32_t n_vb,
-                                                    uint32_t *out /* [n_vb][2] */)
+                                                    uint32_t RL /* lines per record: 4 FASTQ, 1 SAM */, uint32_t *out /* [n_vb][2] */)
 {
     const uint32_t v = blockIdx.x;
-    const uint32_t r0 = first_line[v] / 4, r1 = first_line[n_vb + v] / 4;
+    const uint32_t r0 = first_line[v] / RL, r1 = first_line[n_vb + v] / RL;
     uint32_t longest = 0, longest_seq = 0;
     for (uint32_t r = r0 + threadIdx.x; r < r1; r += 256) {
-        const uint64_t end = r + 1 < r1 ? line_off[4 * (r + 1)] : vb_end[v];
-        const uint32_t len = (uint32_t)(end - line_off[4 * r]);
+        const uint64_t end = r + 1 < r1 ? line_off[RL * (r + 1)] : vb_end[v];
+        const uint32_t len = (uint32_t)(end - line_off[RL * r]);
         longest = len > longest ? len : longest;
         longest_seq = seq_len[r] > longest_seq ? seq_len[r] : longest_seq;
     }

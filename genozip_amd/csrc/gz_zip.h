@@ -524,14 +524,16 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     //  contexts one constant snip, so a text with \r\n lines must not get through silently)
     if (a.lines.reserved) { h->err = "lines end in \\r\\n: not expressible with a constant end-of-line snip"; return GZ_ERR_CORRUPT; }
     const uint64_t n_lines = a.lines.n_lines;
-    if (n_lines % 4) { h->err = "the text does not hold whole reads (4 lines each)"; return GZ_ERR_CORRUPT; }
-    const uint32_t R = (uint32_t)(n_lines / 4);                            // reads of the whole text (every 4 lines: VBlocks hold whole reads)
+    // a record is 4 lines (FASTQ) or - plan.record_lines == 1 - one line whose SEQ and QUAL are two of its items (SAM)
+    const uint32_t RL = f->plan.record_lines == 1 ? 1 : 4;
+    if (n_lines % RL) { h->err = "the text does not hold whole reads (4 lines each)"; return GZ_ERR_CORRUPT; }
+    const uint32_t R = (uint32_t)(n_lines / RL);                           // records of the whole text (VBlocks hold whole records)
     K.r0.resize (NV + 1);
     std::vector<uint32_t> &r0 = K.r0;
     std::vector<uint32_t> r_end (NV);
     for (uint32_t v = 0; v < NV; v++) {
-        if (first_line[v] % 4 || first_line[NV + v] % 4) { h->err = "a VBlock does not hold whole reads (4 lines each)"; return GZ_ERR_CORRUPT; }
-        r0[v] = first_line[v] / 4; r_end[v] = first_line[NV + v] / 4;
+        if (first_line[v] % RL || first_line[NV + v] % RL) { h->err = "a VBlock does not hold whole reads (4 lines each)"; return GZ_ERR_CORRUPT; }
+        r0[v] = first_line[v] / RL; r_end[v] = first_line[NV + v] / RL;
         vbs[v].n_reads = r_end[v] - r0[v];
     }
 
@@ -540,7 +542,23 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     WS (rec, uint32_t, (size_t)8 * (R + 8));
     uint32_t *l1_off = rec, *l1_len = rec + (R + 8), *seq_off = rec + 2 * (size_t)(R + 8), *seq_len = rec + 3 * (size_t)(R + 8),
              *l3_off = rec + 4 * (size_t)(R + 8), *l3_len = rec + 5 * (size_t)(R + 8), *qual_off = rec + 6 * (size_t)(R + 8), *qual_len = rec + 7 * (size_t)(R + 8);
-    ZCHK (gz_fastq_records (h, text, line_off, line_len, &d_a->lines, R, l1_off, l1_len, seq_off, seq_len, l3_off, l3_len, qual_off, qual_len, &d_a->fq));
+    WS (item_off, uint32_t, (size_t)NI * R + 8);
+    WS (item_len, uint32_t, (size_t)NI * R + 8);
+    bool tokenized = false;
+    if (RL == 4) ZCHK (gz_fastq_records (h, text, line_off, line_len, &d_a->lines, R, l1_off, l1_len, seq_off, seq_len, l3_off, l3_len, qual_off, qual_len, &d_a->fq));
+    else {
+        // one-line records (sam_seg_txt_line's split of a line into its tab-separated fields, src/sam_seg.c; QNAME further by its
+        // flavor): the whole line is the container; SEQ and QUAL are the items the plan names. The items are needed before anything
+        // else can be queued, so the tokenizer runs first here.
+        if (f->plan.seq_item > f->plan.n_seps || f->plan.qual_item > f->plan.n_seps) { h->err = "plan: seq_item / qual_item"; return GZ_ERR_ARG; }
+        l1_off = line_off; l1_len = line_len;
+        HIPCHK (h, hipMemsetAsync (&d_a->fq, 0xff, sizeof (GzFastqResult), h->stream));          // (first_bad = none)
+        HIPCHK (h, hipMemsetAsync (l3_len, 0, ((size_t)R + 8) * 4, h->stream));
+        ZCHK (gz_tokenize_column_n (h, text, l1_off, l1_len, R, f->plan.seps, f->plan.sep_counts, f->plan.n_seps, item_off, item_len, &d_a->n_bad_items));
+        tokenized = true;
+        seq_off = item_off + (size_t)f->plan.seq_item * R; seq_len = item_len + (size_t)f->plan.seq_item * R;
+        qual_off = item_off + (size_t)f->plan.qual_item * R; qual_len = item_len + (size_t)f->plan.qual_item * R;
+    }
     // SQBITMAP's snip of every read, and what NONREF takes of it (fastq_seg_SEQ): a read of one repeated base is not stored
     uint8_t *sq_slots = NULL; uint32_t *sq_off = NULL, *sq_len = NULL, *nonref_len = NULL;
     if (f->seq_snip_ctx >= 0 || f->plan.line3_empty) {
@@ -554,8 +572,6 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         if (R) KLAUNCH (h, k_seq_snips, dim3 ((R + 255) / 256), dim3 (256), 0, S);
         if (f->seq_snip_ctx < 0) nonref_len = NULL;                        // (only the line-3 check was wanted: SEQ as the plan without SQBITMAP has it)
     }
-    WS (item_off, uint32_t, (size_t)NI * R + 8);
-    WS (item_len, uint32_t, (size_t)NI * R + 8);
     WS (d_vbstat, uint32_t, 2 * (size_t)NV + 2);
 
     // the dictionaries as every VBlock of this call clones them (ctx_clone)
@@ -763,9 +779,9 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     // (not decided yet whether QUAL goes through DOMQ: both forms are tried, the read-back says which one counts)
     if (want_trial && qmode0) ZCHK (add_trials (K.domq[0].out[0], (const uint32_t *)&d_domqres[0].qual_len, 1));
     // (the items of line 1 and the VBlock statistics are only needed from here on: queued behind the QUAL gather, which the long pole waits for)
-    ZCHK (gz_tokenize_column_n (h, text, l1_off, l1_len, R, f->plan.seps, f->plan.sep_counts, f->plan.n_seps, item_off, item_len, &d_a->n_bad_items));
+    if (!tokenized) ZCHK (gz_tokenize_column_n (h, text, l1_off, l1_len, R, f->plan.seps, f->plan.sep_counts, f->plan.n_seps, item_off, item_len, &d_a->n_bad_items));
     hipLaunchKernelGGL (k_vb_stats, dim3 (NV), dim3 (256), 2048, h->stream, (const uint32_t *)line_off, (const uint32_t *)seq_len, (const uint32_t *)d_first_line,
-                        (const uint64_t *)(d_vb_off + NV), NV, d_vbstat);
+                        (const uint64_t *)(d_vb_off + NV), NV, RL, d_vbstat);
     ZCHK (gz_int_columns (h, icol_jobs.data (), (int)icol_jobs.size ()));
     // (column tables hold at most 65 535 rows per call)
     for (size_t at = 0; at < col_jobs.size (); at += 32768) ZCHK (gz_ctx_seg_columns (h, col_jobs.data () + at, (int)std::min<size_t> (32768, col_jobs.size () - at)));

@@ -130,4 +130,5 @@ def c_plan(plan):
     p.qual_codec = plan.get("qual_codec", 0)
     p.vb_size = plan.get("vb_size", 0)
     p.line3_empty = plan.get("line3_empty", 0)
+    p.record_lines, p.seq_item, p.qual_item = plan.get("record_lines", 0), plan.get("seq_item", 0), plan.get("qual_item", 0)
     return p, keep

@@ -118,7 +118,7 @@ class GzFastqCtx(C.Structure):
 class GzFastqPlan(C.Structure):
     _fields_ = [("ctxs", C.POINTER(GzFastqCtx)), ("n_ctxs", C.c_uint32), ("seps", C.c_char * 16), ("sep_counts", C.c_uint8 * 16),
                 ("n_seps", C.c_uint32), ("paired", C.c_uint8), ("estimated_entries", C.c_uint32), ("qual_codec", C.c_uint8), ("vb_size", C.c_uint64),
-                ("line3_empty", C.c_uint8)]
+                ("record_lines", C.c_uint8), ("seq_item", C.c_uint8), ("qual_item", C.c_uint8), ("line3_empty", C.c_uint8)]
 
 
 class GzFastqVB(C.Structure):

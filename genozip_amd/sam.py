@@ -1,0 +1,63 @@
+"""Host-side set-up of the VBlock compute driver for SAM text (BASELINE configs[2]: aligned reads; SURVEY 8f N1 for SAM / BAM), as DATA:
+a GzFastqPlan with record_lines = 1 - a record is one line, its items the eleven mandatory tab-separated fields (sam_seg_txt_line,
+src/sam_seg.c; the reference's bam_seg_txt_line, src/bam_seg.c:425, walks the same fields in their binary form) with QNAME split further
+by its flavor (Illumina-7, src/qname_flavors.h:40-49), and the optional fields as one last item.
+
+    A00123:45:HXXXXXXXX:1:1101:10000:10000 <tab> FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL [<tab> optional fields]
+
+How each field reaches its context follows the reference's segmenter where the driver has the means (SURVEY 8(0), row configs[2]):
+  QNAME items   as in FASTQ (qname_seg_qf, src/qname.c:715-806): textual / integer in local / self-delta
+  FLAG MAPQ RNAME RNEXT CIGAR   snips -> dictionary + b250 (sam_seg_FLAG, seg_by_did; sam_seg_CIGAR segs the CIGAR text as a snip,
+                src/sam_cigar.c:708-760 - the reference puts { SNIP_SPECIAL, SAM_SPECIAL_CIGAR } in front of it, this plan does not)
+  POS           delta against the previous line in a dyn-int local (sam_seg_POS -> seg_pos_field: a delta snip per line in the b250 in
+                the reference; here the same deltas as integers in local, the form seg_self_delta gives ordered QNAME items)
+  PNEXT TLEN    seg_integer_or_not: dyn-int local ('*' / non-numbers as snips)
+  SEQ           no reference genome: NONREF.local -> CODEC_ACGT's 2-bit pack + NONREF_X, SQBITMAP's special snip with the length
+                (sam_seg_SEQ's verbatim branch; the same contexts FASTQ uses, src/fastq.h:13-60)
+  QUAL          QUAL.local; CODEC_DOMQ when the file's first VBlock is a fit (codec_assign_best_qual_codec, src/codec.c:391-450; the
+                reference also considers CODEC_NORMQ for SAM, which is not built)
+  optional      one textual item (the reference segs every tag into a context of its own: not built)
+What is NOT the reference's: the TOPLEVEL / QNAME containers of this plan are built in the reference's container FORMAT but are this
+repo's own choice of items (the reference's SAM reconstruction logic - sam_piz.c, buddies, MD / NM prediction - is out of scope), so a
+file made with this plan is not offered to genounzip; parity for this plan = the oracle's composition (tests/parity.py)."""
+from .fastq import (dict_id, container, container_snip, DTYPE_FIELD, DTYPE_1, STORE_INT, SNIP_SELF_DELTA, SNIP_SPECIAL, FASTQ_SPECIAL_unaligned_SEQ, CON_PX_SEP, CI0_COLONn,
+                    CON_FILTER_REPEATS, CON_FILTER_ITEMS, CON_IS_TOPLEVEL, CON_CALLBACK)
+from .lib import (GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL, GZ_FQ_QUAL_AUX, GZ_FQ_TOPLEVEL, GZ_FQ_SEQ_SNIP)
+
+
+def sam_plan(has_aux=True, qual_codec=0, estimated_entries=0, domq=0, vb_size=0):
+    P = []
+
+    def ctx(tag, did_i, kind, dtype=DTYPE_FIELD, item=0, flags=0, snip=b"", local_dep=0, con_len=0, lcodec=0):
+        P.append(dict(tag=tag, dict_id=dict_id(tag, dtype), did_i=did_i, kind=kind, item=item, flags=flags, snip=snip, pair_identical=False, no_stons=False,
+                      lcodec=lcodec, bcodec=0, pair_assisted_b250=False, local_dep=local_dep, nothing_char=0, con_len=con_len, segs_per_line=0))
+
+    q1 = container([(dict_id("Q0NAME", DTYPE_1), bytes([CI0_COLONn, 3])), (dict_id("Q1NAME", DTYPE_1), b":"), (dict_id("Q2NAME", DTYPE_1), b":"),
+                    (dict_id("Q3NAME", DTYPE_1), b":"), (dict_id("Q4NAME", DTYPE_1), b"")], repeats=1)
+    # did_i in the order of the GENDICT lines of src/sam.h (only the relative order matters)
+    ctx("QNAME", 1, GZ_FQ_CONST, snip=container_snip(q1))
+    ctx("Q0NAME", 2, GZ_FQ_ITEM_TEXT, DTYPE_1, item=0)
+    ctx("Q1NAME", 3, GZ_FQ_ITEM_INT, DTYPE_1, item=1)
+    ctx("Q2NAME", 4, GZ_FQ_ITEM_TEXT, DTYPE_1, item=2)
+    ctx("Q3NAME", 5, GZ_FQ_ITEM_DELTA, DTYPE_1, item=3, flags=STORE_INT, snip=bytes([SNIP_SELF_DELTA]) + b"$")
+    ctx("Q4NAME", 6, GZ_FQ_ITEM_DELTA, DTYPE_1, item=4, flags=STORE_INT, snip=bytes([SNIP_SELF_DELTA]) + b"$")
+    ctx("AUX", 53, GZ_FQ_ITEM_TEXT, item=15) if has_aux else None
+    ctx("SQBITMAP", 54, GZ_FQ_SEQ_SNIP, snip=bytes([SNIP_SPECIAL, FASTQ_SPECIAL_unaligned_SEQ]) + b" ")
+    ctx("NONREF_X", 56, GZ_FQ_SEQ, local_dep=1)
+    ctx("QUAL", 80, GZ_FQ_QUAL, lcodec=qual_codec)
+    for k, tag in enumerate(("DOMQRUNS", "QUALMPLX", "DIVRQUAL")):
+        ctx(tag, 81 + k, GZ_FQ_QUAL_AUX, item=k, local_dep=2)
+    fields = [("FLAG", 100, GZ_FQ_ITEM_TEXT, 5), ("RNAME", 0, GZ_FQ_ITEM_TEXT, 6), ("POS", 101, GZ_FQ_ITEM_DELTA, 7), ("MAPQ", 102, GZ_FQ_ITEM_TEXT, 8),
+              ("CIGAR", 103, GZ_FQ_ITEM_TEXT, 9), ("RNEXT", 104, GZ_FQ_ITEM_TEXT, 10), ("PNEXT", 105, GZ_FQ_ITEM_INT, 11), ("TLEN", 106, GZ_FQ_ITEM_INT, 12)]
+    for tag, did, kind, item in fields:
+        ctx(tag, did, kind, item=item, flags=STORE_INT if kind == GZ_FQ_ITEM_DELTA else 0, snip=(bytes([SNIP_SELF_DELTA]) + b"$") if kind == GZ_FQ_ITEM_DELTA else b"")
+    order = ["QNAME", "FLAG", "RNAME", "POS", "MAPQ", "CIGAR", "RNEXT", "PNEXT", "TLEN", "SQBITMAP", "QUAL"] + (["AUX"] if has_aux else [])
+    top = container([(dict_id(t), b"\t" if i + 1 < len(order) else b"") for i, t in enumerate(order)] + [(dict_id("EOL"), b"")],
+                    flags=CON_FILTER_REPEATS | CON_FILTER_ITEMS | CON_IS_TOPLEVEL | CON_CALLBACK)
+    ctx("TOPLEVEL", 120, GZ_FQ_TOPLEVEL, snip=top, con_len=len(top))
+    ctx("EOL", 121, GZ_FQ_CONST, snip=b"\n")
+    P.sort(key=lambda c: c["did_i"])
+    seps = b"::::" + b"\t" * (11 if has_aux else 10)
+    counts = [3, 1, 1, 1] + [1] * (11 if has_aux else 10)
+    return dict(ctxs=P, seps=seps, sep_counts=counts, paired=False, estimated_entries=estimated_entries, qual_codec=domq, vb_size=vb_size, line3_empty=0,
+                record_lines=1, seq_item=13, qual_item=14)

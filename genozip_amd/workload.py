@@ -209,3 +209,84 @@ def fastq_text(seed, read0, n_reads, mate=1, profile="div", xp=None, n_rate=0):
     put(b"\n")
     assert at == RECORD_BYTES
     return rec.tobytes() if host else rec.reshape(-1)
+
+
+# ---- BASELINE configs[2]: aligned reads as SAM text ---------------------------------------------------------------------
+SAM_MAX_RECORD = 44 + 4 + 5 + 10 + 3 + 9 + 2 + 10 + 4 + READ_LEN + 1 + READ_LEN + 1 + 20        # widest line: every variable field at its widest
+
+
+def sam_text(seed, read0, n_reads, profile="bin", xp=None):
+    """alignment lines [read0, read0 + n_reads) of a coordinate-sorted SAM file of 150 bp reads on one 100 Mb contig (no header lines):
+        A00123:45:HXXXXXXXX:<lane>:<tile>:<x>:<y> FLAG chr1 POS MAPQ CIGAR = PNEXT TLEN SEQ QUAL NM:i:<n> AS:i:<n>
+    CIGAR 90 % 150M, 8 % with one insertion / deletion, 2 % soft-clipped; FLAG of properly paired reads; MAPQ mostly 60; QUAL binned
+    (profile "bin") or 40-level ("div"). Lines differ in width (CIGAR, FLAG, MAPQ, TLEN), so a record is laid out in a matrix as wide as
+    the widest line with 0 bytes where a field is shorter, and the text is the matrix without its 0 bytes - numpy on the host or, xp =
+    _TH (device), torch in HBM: identical bytes. Returns (bytes | uint8 tensor)."""
+    host = xp is None
+    xp = xp or _NP
+    lane, tile, x, y = name_fields(seed, read0, n_reads, xp)
+    idx = xp.arange(read0, read0 + n_reads)
+    h1, h2, h3 = _hash(xp, seed + 0x5A11, idx), _hash(xp, seed + 0x5A12, idx), _hash(xp, seed + 0x5A13, idx)
+    if host:
+        rec = np.zeros((n_reads, SAM_MAX_RECORD), dtype=np.uint8)
+        const = lambda b: np.frombuffer(b, dtype=np.uint8)                         # noqa: E731
+        to_u8 = lambda v: v.astype(np.uint8)                                       # noqa: E731
+        i64 = lambda v: v.astype(np.int64)                                         # noqa: E731
+    else:
+        t = xp.t
+        rec = t.zeros((n_reads, SAM_MAX_RECORD), dtype=t.uint8, device=xp.dev)
+        const = lambda b: t.tensor(list(b), dtype=t.uint8, device=xp.dev)          # noqa: E731
+        to_u8 = lambda v: v.to(t.uint8)                                            # noqa: E731
+        i64 = lambda v: v.to(t.int64)                                              # noqa: E731
+    at = 0
+
+    def put(b):
+        nonlocal at
+        rec[:, at:at + len(b)] = const(b)
+        at += len(b)
+
+    def digits(v, width, fixed=True):
+        """decimal, right-aligned in `width` columns; not fixed: leading zeros become 0 bytes (dropped from the text)"""
+        nonlocal at
+        v = i64(v)
+        for k in range(width):
+            p = 10 ** (width - 1 - k)
+            d = 48 + (v // p) % 10
+            if not fixed and k < width - 1:
+                d = xp.where(v >= p, d, 0)
+            rec[:, at + k] = to_u8(d)
+        at += width
+
+    def choice(table, sel):
+        """one of the byte strings of `table` per row (sel: int64 index), left-aligned in the widest one's columns"""
+        nonlocal at
+        w = max(len(b) for b in table)
+        m = np.zeros((len(table), w), dtype=np.uint8)
+        for i, b in enumerate(table):
+            m[i, :len(b)] = np.frombuffer(b, dtype=np.uint8)
+        rec[:, at:at + w] = (m if host else xp.t.tensor(m, device=xp.dev))[sel]
+        at += w
+
+    put(b"A00123:45:HXXXXXXXX:"); digits(lane + 1, 1); put(b":"); digits(1101 + tile, 4); put(b":"); digits(10000 + i64(x) % 20000, 5); put(b":")
+    digits(10000 + i64(y) % 80000, 5); put(b"\t")
+    choice([b"99", b"147", b"83", b"163"], h1 % 4); put(b"\tchr1\t")
+    pos = 100000 + idx * 97 + h2 % 60                                                  # increasing: coordinate-sorted
+    digits(pos, 9, fixed=False); put(b"\t")
+    choice([b"60", b"60", b"60", b"0", b"23", b"60", b"40", b"60"], xp.lsr(h1, 8) % 8); put(b"\t")
+    k = xp.lsr(h1, 16) % 100
+    cig = xp.where(k < 90, 0, xp.where(k < 98, 1 + k % 4, 5))
+    choice([b"150M", b"70M2D80M", b"40M1I109M", b"100M3D50M", b"75M2I73M", b"20S130M"], cig); put(b"\t=\t")
+    digits(pos + 150 + xp.lsr(h2, 8) % 100, 9, fixed=False); put(b"\t")
+    digits(300 + xp.lsr(h2, 8) % 100, 3); put(b"\t")
+    bidx = xp.arange(read0 * READ_LEN, (read0 + n_reads) * READ_LEN)
+    hb = _hash(xp, seed + 0x5E9, bidx)
+    tab = np.frombuffer(b"ACGT", dtype=np.uint8)
+    bases = (tab[(hb % 4).astype(np.int64)] if host else xp.t.tensor(list(b"ACGT"), dtype=xp.t.uint8, device=xp.dev)[hb % 4])
+    rec[:, at:at + READ_LEN] = bases.reshape(n_reads, READ_LEN); at += READ_LEN
+    put(b"\t")
+    rec[:, at:at + READ_LEN] = quality_rows(xp, seed + 0x100000, read0, n_reads, profile).reshape(n_reads, READ_LEN); at += READ_LEN
+    put(b"\tNM:i:"); digits(h3 % 4, 1); put(b"\tAS:i:"); digits(150 - xp.lsr(h3, 8) % 9, 3); put(b"\n")
+    assert at <= SAM_MAX_RECORD
+    flat = rec.reshape(-1)
+    out = flat[flat != 0]
+    return out.tobytes() if host else out

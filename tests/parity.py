@@ -632,10 +632,23 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
         zstate = dict(z=[po.OracleZctx(oracle, plan["estimated_entries"]) for _ in C], lcodec=[c["lcodec"] for c in C], bcodec=[c["bcodec"] for c in C], flags_vb1=[0] * NC,
                       qual_mode=0 if len(aux) != 3 or plan.get("qual_codec") == 1 else 13 if plan.get("qual_codec") == 13 else None)
     lo, ll = oracle.text_lines(text)
-    bad, cols = oracle.fastq_records(text, lo, ll)
-    assert bad == 0
-    (l1o, l1l), (so, sl), (l3o, l3l), (qo, ql) = cols
-    assert not plan.get("line3_empty") or not l3l.any()
+    RL = 1 if plan.get("record_lines") == 1 else 4
+    if RL == 4:
+        bad, cols = oracle.fastq_records(text, lo, ll)
+        assert bad == 0
+        (l1o, l1l), (so, sl), (l3o, l3l), (qo, ql) = cols
+        assert not plan.get("line3_empty") or not l3l.any()
+    else:                                                  # one-line records (SAM): the line is the container, SEQ / QUAL two of its items (below)
+        l1o, l1l = lo, ll
+    # line-1 items: single-occurrence tokens, then joined per sep_counts
+    flat = b"".join(bytes([s]) * k for s, k in zip(plan["seps"], plan["sep_counts"]))
+    nb, fo, fl = oracle.tokenize_column(text, l1o, l1l, flat)
+    assert nb == 0
+    io, il, at = [], [], 0
+    for k in list(plan["sep_counts"]) + [1]:
+        io.append(fo[at]); il.append(fo[at + k - 1] + fl[at + k - 1] - fo[at]); at += k
+    if RL == 1:
+        so, sl, qo, ql = io[plan["seq_item"]], il[plan["seq_item"]], io[plan["qual_item"]], il[plan["qual_item"]]
     # SQBITMAP's snip of every read and what NONREF takes of it (fastq_seg_SEQ, src/fastq_seq.c:113-146): stated here in plain Python
     sq = next((X for X in C if X["kind"] == GZ_FQ_SEQ_SNIP), None)
     sl_nonref = sl
@@ -649,21 +662,14 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
             if mono:
                 sl_nonref[r] = 0
         sq_text, sq_off = bytes(slots) + b"\0" * 64, (16 * np.arange(len(sl))).astype(np.uint32)
-    # line-1 items: single-occurrence tokens, then joined per sep_counts
-    flat = b"".join(bytes([s]) * k for s, k in zip(plan["seps"], plan["sep_counts"]))
-    nb, fo, fl = oracle.tokenize_column(text, l1o, l1l, flat)
-    assert nb == 0
-    io, il, at = [], [], 0
-    for k in list(plan["sep_counts"]) + [1]:
-        io.append(fo[at]); il.append(fo[at + k - 1] + fl[at + k - 1] - fo[at]); at += k
     lo_list = lo.tolist()
     ol_words = [z.words() for z in zstate["z"]]                    # cloned when the call starts
     n_vb = len(vbs)
     S = [[dict() for _ in range(NC)] for _ in range(n_vb)]          # per (VBlock, context) state
     rng = []
     for (off, ln, vi, r1) in vbs:
-        a = lo_list.index(off) // 4
-        b = (lo_list.index(off + ln) // 4) if off + ln < len(text) else len(l1o)
+        a = lo_list.index(off) // RL
+        b = (lo_list.index(off + ln) // RL) if off + ln < len(text) else len(l1o)
         rng.append((a, b))
     # codec_assign_best_qual_codec (codec.c:391-450): the file's first VBlock decides whether QUAL goes through CODEC_DOMQ
     if zstate["qual_mode"] is None and vbs:
@@ -841,7 +847,7 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
             d.dict_id[:] = list(X["dict_id"])
             z += oracle.section_compress(d, data)
             n_written += 1
-        rec_len = [int(lo[4 * (r + 1)] if r + 1 < b else off + ln) - int(lo[4 * r]) for r in range(a, b)]
+        rec_len = [int(lo[RL * (r + 1)] if r + 1 < b else off + ln) - int(lo[RL * r]) for r in range(a, b)]
         z[:84] = _vb_header(vi, ln, len(z), max(rec_len) if rec_len else 0, int(sl[a:b].max()) if b > a else 0)
         seq = next(S[v][c] for c, X in enumerate(C) if X["kind"] == GZ_FQ_SEQ)
         out.append(dict(z=bytes(z), seq_packed=seq["seq_packed"], n_bases=seq["n_bases"], seq_has_x=seq["seq_has_x"], seq_section_index=nonref_at))
@@ -1488,3 +1494,56 @@ def check_qnames(F, plan, text, vbs, got, decode):
             assert (np.frombuffer(names.astype("S%d" % W).tobytes(), dtype=np.uint8).reshape(-1, W) == mat).all(), ("read names of VBlock", vi)
         n_checked += g["n_reads"]
     return n_checked
+
+
+def sam_aligned_text(n, seed=21, qual="bin", aux=True):
+    """alignment lines in the shape of BASELINE configs[2]: coordinate-sorted 150 bp reads on one contig, Illumina-7 names,
+    CIGAR mostly 150M / some with an indel or soft clips, binned or 40-level qualities, an NM / AS tag pair. No header lines: a VBlock
+    starts at the first alignment (the header is the component's SEC_TXT_HEADER in the reference)"""
+    r = synth.u32(seed, 8 * n + 8).astype(np.int64)
+    quals = synth.quality_binned(seed + 2, n, 150) if qual == "bin" else (synth.uniform_bytes(seed + 2, n * 150, 40) + 33).astype(np.uint8).reshape(n, 150)
+    seqs = np.frombuffer(b"ACGT", dtype=np.uint8)[synth.uniform_bytes(seed + 1, n * 150, 4)].reshape(n, 150)
+    out, pos = [], 10000
+    for i in range(n):
+        pos += int(r[8 * i] % 60)
+        k = int(r[8 * i + 1] % 100)
+        cigar = b"150M" if k < 90 else (b"70M2D80M", b"40M1I109M", b"100M3D50M", b"75M2I73M")[k % 4] if k < 98 else b"20S130M"
+        ln = 150
+        aux_s = b"\tNM:i:%d\tAS:i:%d" % (r[8 * i + 2] % 4, 150 - r[8 * i + 3] % 9) if aux else b""
+        out.append(b"A00123:45:HXXXXXXXX:%d:%d:%d:%d\t%d\tchr1\t%d\t%d\t%s\t=\t%d\t%d\t%s\t%s%s\n" % (
+            1 + i * 4 // max(1, n), 1101 + i * 70 // max(1, n), 1000 + r[8 * i + 4] % 30000, 1000 + (i * 37) % 36000,
+            (99, 147, 83, 163, 0, 16)[r[8 * i + 5] % 6], pos, (60, 60, 60, 0, 23)[r[8 * i + 6] % 5], cigar, pos + 150 + int(r[8 * i + 7] % 100),
+            300 + int(r[8 * i + 7] % 100), seqs[i, :ln].tobytes(), quals[i, :ln].tobytes(), aux_s))
+    return b"".join(out)
+
+
+def sam_zip(E, oracle, n_reads, n_calls=2, qual="bin", aux=True):
+    """N1 for SAM (BASELINE configs[2] from TEXT): alignment lines through the VBlock compute driver with a one-line-record plan
+    (genozip_amd/sam.py) == the oracle's step-by-step composition, byte for byte, over several VBlocks and calls (dictionaries carried);
+    every section decodes again on the device"""
+    from genozip_amd import sam as sm
+    plan = sm.sam_plan(has_aux=aux)
+    F = E.zip_open(plan)
+    zstate, vb_i, n_vb = None, 0, 0
+    for call in range(n_calls):
+        nr = n_reads if call == 0 else max(8, n_reads // 2)
+        text = sam_aligned_text(nr, seed=21 + call, qual=qual, aux=aux)
+        nl = np.flatnonzero(np.frombuffer(text, dtype=np.uint8) == 10)
+        cut = int(nl[(2 * nr) // 3 - 1]) + 1
+        vbs = [(0, cut, vb_i + 1, -1), (cut, len(text) - cut, vb_i + 2, -1)]
+        vb_i += 2
+        got = F.zip_vblocks(text, vbs)
+        want, zstate = fastq_zip_expected(oracle, plan, text, vbs, zstate)
+        for v, (g, w) in enumerate(zip(got, want)):
+            assert g["n_bases"] == w["n_bases"] and g["seq_has_x"] == w["seq_has_x"] and g["seq_packed"] == w["seq_packed"], (call, v)
+            assert g["z"] == w["z"], (call, v, len(g["z"]), len(w["z"]), _first_diff(g["z"], w["z"]))
+            total, at = 0, 84
+            z = g["z"]
+            while at < len(z):
+                total += int.from_bytes(z[at + 16:at + 20], "big"); at += 40 + int.from_bytes(z[at + 12:at + 16], "big")
+            E.vb_uncompress(z, total)
+            n_vb += 1
+    words = {c["tag"]: F.zctx_words(i) for i, c in enumerate(plan["ctxs"])}
+    assert b"150M" in words["CIGAR"] and b"chr1" in words["RNAME"] and words["FLAG"]
+    F.close()
+    return n_vb

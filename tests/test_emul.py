@@ -169,3 +169,9 @@ def test_section_order_contexts_out_of_order(emul_engine):
 def test_emul_header_layouts(emul_engine):
     """SectionHeaderCtx / VbHeader / TxtHeader and the plan's containers, byte for byte against the reference's own struct definitions"""
     assert parity.header_kats(emul_engine) >= 6
+
+
+def test_emul_sam_zip(emul_engine, oracle):
+    """N1 for SAM: configs[2] from text - 4 VBlocks over 2 calls through the one-line-record plan == the oracle's composition"""
+    assert parity.sam_zip(emul_engine, oracle, 500) == 4
+    assert parity.sam_zip(emul_engine, oracle, 300, n_calls=1, qual="uniform", aux=False) == 2

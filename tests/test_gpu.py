@@ -243,6 +243,13 @@ def test_chunk_and_tile_boundaries(gpu_engine, oracle):
         assert g == oracle.codec_compress(c, d), (c, len(d))
 
 
+def test_sam_zip_driver(gpu_engine, oracle):
+    """N1 for SAM (BASELINE configs[2] from text): alignment lines through the driver's one-line-record plan == the oracle's composition,
+    4 VBlocks over 2 calls, with and without optional fields, binned (CODEC_DOMQ) and 40-level qualities"""
+    assert parity.sam_zip(gpu_engine, oracle, 3000) == 4
+    assert parity.sam_zip(gpu_engine, oracle, 1500, n_calls=1, qual="uniform", aux=False) == 2
+
+
 def test_header_layouts(gpu_engine):
     """a9 / a16 / N4: SectionHeaderCtx, SectionHeaderVbHeader, SectionHeaderTxtHeader and the plan's containers as the product writes them
     == the reference's own structs filled through their members (tests/golden/hdr_golden.json from oracle/ref_hdr_shim.c)"""
