@@ -59,7 +59,10 @@ def parse_args():
     ap.add_argument("--pin-codecs", action="store_true", help="hard-code the codecs codec_assign_best_codec picks for this workload (profiling runs: no trial compressions in the step)")
     ap.add_argument("--config", default="fastq", choices=("fastq", "bam", "vcf"), help="fastq: BASELINE configs[1] (the headline, from text). bam: configs[2] from SAM text (genozip_amd/sam.py). vcf: configs[3], one GPU's share, at the "
                     "context-stream level (no VCF segmenter: the streams of SURVEY 8(0) enter generated). Same record layout, cpu_baseline beside it")
-    ap.add_argument("--stream-level", action="store_true", help="--config bam: enter at the context-stream level (generated streams) instead of from SAM text")
+    ap.add_argument("--stream-level", action="store_true", help="--config bam / vcf: enter at the context-stream level (generated streams, tools/config_bench.py) instead of from text")
+    ap.add_argument("--vcf-samples", type=int, default=10000)
+    ap.add_argument("--vcf-lines", type=int, default=3000, help="data lines per VBlock")
+    ap.add_argument("--vcf-vbs", type=int, default=4, help="VBlocks of this GPU (the file's 33 over 8 GPUs)")
     ap.add_argument("--warm-steps", type=int, default=3, help="extra steps with the handle's codec speculation ON, reported beside the (cold) headline; 0: none")
     return ap.parse_args()
 
@@ -215,7 +218,7 @@ def cpu_leg(wl, z_all, n_threads):
     tasks, payloads, task_vb, qual_ok = [], [], [], True
     text = wl.text[:wl.text_len].cpu().numpy()
     L = wl.W.READ_LEN
-    qual_id = next(c["dict_id"] for c in wl.plan["ctxs"] if c["tag"] == "QUAL")
+    qual_id = next((c["dict_id"] for c in wl.plan["ctxs"] if c["tag"] == "QUAL" and c["kind"] == 6), None)     # (GZ_FQ_QUAL; a VCF plan has none)
     for v, ((off, ln, vi, r1), z) in enumerate(zip(wl.vb, z_all)):
         for st, codec, did, ulen, pay, domq in walk_sections(z):
             data = bytes(pay) if codec == 1 else (R.codec_uncompress(codec, pay, ulen) if kind == "port" else R.hts_uncompress("rans" if codec < 16 else "arith", pay, ulen))
@@ -330,7 +333,48 @@ class SamWorkload:
         return self.offs[-1]
 
 
+class VcfWorkload:
+    """BASELINE configs[3] FROM TEXT, one GPU's share at 8 GPUs: VBlocks of 3 000 data lines x 10 000 samples (the 512 MB the reference's rule
+    clamps a VBlock of this file to, src/segconf.c:102,160-175) as VCF text in HBM (genozip_amd/workload.py::vcf_text), through the VBlock
+    compute driver with the per-sample plan of genozip_amd/vcf.py"""
+
+    def __init__(self, E, a, device):
+        import torch
+        from genozip_amd import workload as W, vcf as vc
+        self.E, self.a, self.W = E, a, W
+        self.n_samples, self.lines_per_vb, n_vb = a.vcf_samples, a.vcf_lines, a.vcf_vbs
+        th = W._TH(device)
+        parts, self.vb, at = [], [], 0
+        for v in range(n_vb):
+            ln = 0
+            for l0 in range(0, self.lines_per_vb, 250):
+                p = W.vcf_text(4, v * self.lines_per_vb + l0, min(250, self.lines_per_vb - l0), self.n_samples, xp=th)
+                parts.append(p); ln += p.numel()
+            self.vb.append((at, ln, v + 1, -1)); at += ln
+        self.text_len = at
+        assert self.text_len < (1 << 32) - 64, "one call takes < 4 GB of text"
+        self.text = torch.empty(self.text_len + 64, dtype=torch.uint8, device=device)
+        at = 0
+        for p in parts:
+            self.text[at:at + p.numel()] = p; at += p.numel()
+        del parts
+        self.plan = vc.vcf_plan(self.n_samples, vb_size=512 << 20)
+        self.F = E.zip_open(self.plan)
+        self.tab = self.F.vb_table(self.vb)
+        self.zbuf, self.offs, self.calls_per_step, self.value_bytes = None, None, 1, self.text_len
+
+    step = SamWorkload.step
+
+
 def sam_leg(a):
+    return text_leg(a, SamWorkload)
+
+
+def vcf_leg(a):
+    return text_leg(a, VcfWorkload)
+
+
+def text_leg(a, WL):
     """BASELINE configs[2] on one GPU, from SAM text resident in HBM (N1 for SAM, genozip_amd/sam.py) to finished VBlocks"""
     import torch
     from genozip_amd.codec import Engine
@@ -338,7 +382,8 @@ def sam_leg(a):
     torch.cuda.set_device(0)
     device = torch.device("cuda", 0)
     E = Engine(device=0)
-    wl = SamWorkload(E, a, device)
+    wl = WL(E, a, device)
+    is_sam = WL is SamWorkload
     os.environ["GZ_ZIP_PRIOR_ONLY"] = "1"
     for _ in range(max(1, a.warmup)):
         wl.step(None)
@@ -359,7 +404,7 @@ def sam_leg(a):
     secs = [s_ for z in z_all for s_ in walk_sections(z)]
     stream_bytes = sum(s_[3] for s_ in secs)
     n_bases = sum(int(t.n_bases) for t in wl.tab)
-    wl.value_bytes = wl.text_len - n_bases                      # the text without its SEQ fields (2-bit packed in the step, LZMA outside the path: as for FASTQ)
+    wl.value_bytes = wl.text_len - n_bases                      # the text without its SEQ fields (2-bit packed in the step, LZMA outside the path: as for FASTQ); VCF: all of it
     dom = max(prof, key=lambda k: prof[k][0])
     dom_ms, dom_n = prof[dom]
     alg = stream_bytes + z_total
@@ -371,9 +416,14 @@ def sam_leg(a):
         codecs[("b250:" if st == 11 else "local:") + tag] = CODEC_NAMES.get(codec, str(codec))
     out = {"metric": METRIC, "value": round(wl.value_bytes / 1e6 / (ms / 1e3), 1), "unit": "MB/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-           "config": {"workload": "BAM-1M (BASELINE configs[2]) FROM TEXT: %d aligned 150 bp reads as SAM alignment lines (coordinate-sorted, CIGAR 90 %% 150M, QUAL profile %s), %d VBlocks of %.2f MB; "
-                                  "the whole path per step from text in HBM through the one-line-record plan of genozip_amd/sam.py (N1 for SAM: fields by tab, QNAME by flavor -> a1-a16); "
-                                  "a new file every step. MB counted in `value` = text WITHOUT the SEQ fields (2-bit packed in the step, LZMA outside the path)" % (a.pairs, a.qual, len(wl.vb), wl.vb_bytes / 1e6),
+           "config": {"workload": ("BAM-1M (BASELINE configs[2]) FROM TEXT: %d aligned 150 bp reads as SAM alignment lines (coordinate-sorted, CIGAR 90 %% 150M, QUAL profile %s), %d VBlocks of %.2f MB; "
+                                   "the whole path per step from text in HBM through the one-line-record plan of genozip_amd/sam.py (N1 for SAM: fields by tab, QNAME by flavor -> a1-a16); "
+                                   "a new file every step. MB counted in `value` = text WITHOUT the SEQ fields (2-bit packed in the step, LZMA outside the path)" % (a.pairs, a.qual, len(wl.vb), wl.vb_bytes / 1e6))
+                                  if is_sam else
+                                  ("VCF %d samples (BASELINE configs[3]) FROM TEXT, one GPU's share at 8 GPUs: %d VBlocks of %d data lines x %d samples (FORMAT GT:DP:PL), %.0f MB of text; the whole path per "
+                                   "step from text in HBM through the per-sample plan of genozip_amd/vcf.py (N1 for VCF: fixed fields by tab, FORMAT subfields of every sample -> GT / PL b250 columns "
+                                   "of lines x samples entries, DP a dyn-int matrix written transposed, a1-a16); a new file every step. MB counted in `value` = the text"
+                                   % (wl.n_samples, len(wl.vb), wl.lines_per_vb, wl.n_samples, wl.text_len / 1e6)),
                       "text_mb_per_step": round(wl.text_len / 1e6, 1), "stream_mb_per_step": round(stream_bytes / 1e6, 1), "compressed_mb_per_step": round(z_total / 1e6, 2), "codecs": codecs},
            "text_mb_s": round(wl.text_len / 1e6 / (ms / 1e3), 1), "stream_mb_s": round(stream_bytes / 1e6 / (ms / 1e3), 1),
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
@@ -447,6 +497,8 @@ def main():
         a.qual = "bin" if a.config == "bam" else "div"
     if a.config == "bam" and not a.stream_level:
         return sam_leg(a)
+    if a.config == "vcf" and not a.stream_level:
+        return vcf_leg(a)
     if a.config != "fastq":
         return config_leg(a)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:

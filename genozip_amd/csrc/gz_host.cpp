@@ -902,7 +902,7 @@ extern "C" int gz_codec_uncompress_batch (GzHandle *h, GzStream *streams, int n_
                 if (!(L.fc  = (uint32_t *)arena_alloc (h, 256 * 256 * 4))) return GZ_ERR_HIP;
                 if (!(L.tabtmp = (uint8_t *)arena_alloc (h, GZ_TAB_CAP))) return GZ_ERR_HIP;
             }
-            else if (!(L.models = (uint32_t *)arena_alloc (h, ((size_t)256 * 257 + GZ_ARITH_RUN_MODELS * GZ_ARITH_RUN_STRIDE) * 4))) return GZ_ERR_HIP;
+            else if (!(L.models = (uint32_t *)arena_alloc (h, ((size_t)256 * GZ_DEC_ROW (256) + 258 * GZ_DEC_RUN_ROW) * 4))) return GZ_ERR_HIP;   // (models beyond the LDS classes live here)
         }
     }
     void *d_streams, *d_leaves;

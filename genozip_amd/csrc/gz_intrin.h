@@ -65,6 +65,9 @@ __device__ static inline void gz_touch_done (uint32_t &pit)
 // operations execute in order; this only has to keep the compiler from reordering them)
 __device__ static inline void gz_wave_sync (void) { __builtin_amdgcn_fence (__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier (); }
 
+// v_rcp_f64: the reciprocal to about one ulp (not the IEEE division sequence)
+__device__ static inline double gz_rcp_f64 (double x) { return __builtin_amdgcn_rcp (x); }
+
 // loads through a GLOBAL pointer: a load through a generic one is a flat load, which also counts as an LDS operation -
 // every wait for an LDS read would then wait for its trip to memory as well
 __device__ static inline uint32_t gz_ldg_u8 (const uint8_t *p) { return *(const __attribute__((address_space(1))) uint8_t *)(uintptr_t)p; }

@@ -334,46 +334,170 @@ __global__ void __launch_bounds__(64) k_rans_decode (GzdDecLeaf *leaves)
 }
 
 // ---- adaptive arithmetic decoder (c_range_coder.h:55-68,111-127, c_simple_model.h:148-179) --------------------
-struct GzRcDec { uint32_t code, range; const uint8_t *in; uint32_t pos, len; };
+// The decoder cannot be taken apart the way the encoder is (models / chain / low): which symbol comes next depends on the coder's
+// state. What CAN be spread over the wave is the model: every lane holds list entries (lane, lane + 64, ...) and a symbol is found
+// by all lanes at once - entry e carries its frequency AND its cumulative frequency, so "cum <= target < cum + freq" is one compare
+// per lane and a ballot, where the reference (and this kernel's first form, one lane walking the list in LDS) searches linearly.
+// Coding a symbol then costs every lane one LDS read and one LDS write of its entry (cum += 16 behind the symbol), the halving every
+// ~2000 symbols of a context rebuilds the cumulatives. A model = [tot, -, (freq | sym << 16, cum) x max_sym] in LDS (order 1 with up
+// to 140 symbols: 156 KB) or, beyond that, in global memory. The coded bytes are read 64 at a time (one per lane) and handed out by
+// v_readlane. Measured ... see DESIGN.md (decode).
+#define GZ_DEC_BAD 0xffffffffu
+struct GzRcDec { uint32_t code, range; const uint8_t *in; uint32_t pos, len; uint32_t win, base; };   // win: byte base + lane of the coded stream
 
-__device__ static inline uint32_t d_model_decode (uint32_t *m, uint32_t max_sym, GzRcDec &rc)
+__device__ static __forceinline__ uint32_t d_dec_byte (GzRcDec &rc, int lane)
 {
-    uint32_t tot = m[0];
-    uint32_t target = (tot && rc.range >= tot) ? rc.code / (rc.range /= tot) : 0;
+    if (rc.pos - rc.base >= 64) { rc.base = rc.pos & ~63u; rc.win = rc.base + lane < rc.len ? rc.in[rc.base + lane] : 0u; }
+    return d_readlane (rc.win, (int)(rc.pos++ - rc.base));
+}
+
+// a / b for a < 2^32, 0 < b < 2^32: the hardware's reciprocal seed (v_rcp_f64) + one Newton step is good to ~2^-46, so the truncated
+// product is off by at most one - corrected with one 64-bit product (instead of the ~40 instructions of the generic 32-bit division)
+__device__ static __forceinline__ uint32_t d_udiv (uint32_t a, uint32_t b)
+{
+    const double d = (double)b;
+    double r = gz_rcp_f64 (d);                                   // (v_rcp_f64 is a seed of about single precision: the division sequence refines it)
+    r = __builtin_fma (__builtin_fma (-d, r, 1.0), r, r);        // one Newton step: ~2^-46
+    uint32_t q = (uint32_t)((double)a * r);
+    const uint64_t p = (uint64_t)q * b;
+    q = p > a ? q - 1 : (a - p >= b ? q + 1 : q);
+    return q;
+}
+
+// one symbol of model m (row layout above) by the whole wave; returns the symbol, or 0 as the reference's search does when the
+// target lies beyond the model (a malformed stream: the caller's length / adler checks catch it).
+// Per symbol ONE round trip to the LDS: every lane reads its entry (and the total) once, the neighbour a swap needs comes from the
+// lane beside it (v_readlane), and every lane then writes its own entry back - lane 0 the total. A lane only ever writes entries it
+// owns, so nothing has to be waited for between two symbols but the hardware's in-order LDS.
+// MP: a pointer into the LDS (address space 3: ds_read / ds_write) or a generic one (models in global memory). Through a generic pointer
+// an LDS access is a FLAT instruction, and every wait for it also waits for the global stores in flight - measured: 760 ns per symbol.
+typedef __attribute__((address_space(3))) uint32_t *GzLdsU32P;
+template <typename MP>
+__device__ static inline uint32_t d_model_decode (MP m, uint32_t max_sym, GzRcDec &rc, int lane)
+{
+    const uint32_t tot = m[0];
+    uint32_t x = 0, c = 0;
+    if ((uint32_t)lane < max_sym) { x = m[2 + 2 * lane]; c = m[3 + 2 * lane]; }
+    uint32_t target = 0;
+    if (tot && rc.range >= tot) { rc.range = d_udiv (rc.range, tot); target = d_udiv (rc.code, rc.range); }
     if (target > 65519) return 0;
-    uint32_t *slot = m + 1, cum = 0, at = 0, e = slot[0];
-    while (cum + (e & 0xffff) <= target) {
-        cum += e & 0xffff;
-        if (++at >= max_sym) return 0;                 // malformed
-        e = slot[at];
+    uint32_t plane = 0;
+    uint64_t hit = __ballot ((uint32_t)lane < max_sym && c <= target && target - c < (x & 0xffff));
+    while (!hit) {                                              // (alphabets beyond 64 symbols: the next 64 entries)
+        if (++plane * 64 >= max_sym) return 0;
+        const uint32_t e = plane * 64 + lane;
+        x = 0; c = 0;
+        if (e < max_sym) { x = m[2 + 2 * e]; c = m[3 + 2 * e]; }
+        hit = __ballot (e < max_sym && c <= target && target - c < (x & 0xffff));
     }
-    rc.code  -= cum * rc.range;
-    rc.range *= e & 0xffff;
+    const int l = __ffsll ((unsigned long long)hit) - 1;
+    const uint32_t at = plane * 64 + l, ex = d_readlane (x, l), ec = d_readlane (c, l);
+    rc.code  -= ec * rc.range;
+    rc.range *= ex & 0xffff;
     while (rc.range < (1u << 24)) {
         if (rc.pos >= rc.len) break;
-        rc.code = (rc.code << 8) + rc.in[rc.pos++];
+        rc.code = (rc.code << 8) + d_dec_byte (rc, lane);
         rc.range <<= 8;
     }
-    uint32_t sym = e >> 16;
-    e += 16;
-    uint32_t t2 = tot + 16;
-    slot[at] = e;
-    if (t2 > 65519) {
-        t2 = 0;
-        for (uint32_t i = 0; i < max_sym; i++) {
-            uint32_t v = slot[i], f = v & 0xffff;
-            f -= f >> 1;
-            slot[i] = (v & 0xffff0000u) | f;
-            t2 += f;
+    const uint32_t sym = ex >> 16, e_new = ex + 16, t2 = tot + 16;
+    if (t2 <= 65519) {
+        // the neighbour to the left: the lane beside the symbol's (across a plane boundary: from the LDS)
+        uint32_t left = 0xffffu, cl = 0;
+        if (l > 0) { left = d_readlane (x, l - 1); cl = d_readlane (c, l - 1); }
+        else if (at) { left = m[2 + 2 * (at - 1)]; cl = m[3 + 2 * (at - 1)]; }
+        const bool swap = at && (e_new & 0xffff) > (left & 0xffff);      // one bubble step to the left (c_simple_model.h:139-145)
+        const uint32_t e = plane * 64 + lane;
+        if (e < max_sym) {
+            if (e == at) { m[2 + 2 * e] = swap ? left : e_new; m[3 + 2 * e] = swap ? cl + (e_new & 0xffff) : ec; }
+            else if (e + 1 == at) { if (swap) m[2 + 2 * e] = e_new; }                                    // (keeps its cumulative)
+            else if (e > at) m[3 + 2 * e] = c + 16;
         }
-        e = slot[at];
+        if (swap && l == 0 && !lane) m[2 + 2 * (at - 1)] = e_new;                                          // (the neighbour lives in the plane before)
+        for (uint32_t j = plane + 1; j * 64 < max_sym; j++) {        // the planes behind: cum + 16
+            const uint32_t e2 = j * 64 + lane;
+            if (e2 < max_sym) m[3 + 2 * e2] += 16;
+        }
+        if (!lane) m[0] = t2;
+        gz_wave_sync ();
+        return sym;
     }
-    m[0] = t2;
-    if (at > 0) {
-        uint32_t left = slot[at - 1];
-        if ((e & 0xffff) > (left & 0xffff)) { slot[at - 1] = e; slot[at] = left; }
+    // halve every frequency, rebuild total and cumulatives (every ~2000 symbols of a context: lane 0 walks the list)
+    if (!lane) {
+        m[2 + 2 * at] = e_new;
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < max_sym; i++) {
+            uint32_t v = m[2 + 2 * i], f = v & 0xffff;
+            f -= f >> 1;
+            m[2 + 2 * i] = (v & 0xffff0000u) | f; m[3 + 2 * i] = run;
+            run += f;
+        }
+        m[0] = run;
+    }
+    gz_wave_sync ();
+    if (at) {
+        const uint32_t mine = m[2 + 2 * at], left = m[2 + 2 * (at - 1)], cl = m[3 + 2 * (at - 1)];
+        gz_wave_sync ();
+        if ((mine & 0xffff) > (left & 0xffff)) {
+            if (!lane) { m[2 + 2 * (at - 1)] = mine; m[2 + 2 * at] = left; m[3 + 2 * at] = cl + (mine & 0xffff); }
+            gz_wave_sync ();
+        }
     }
     return sym;
+}
+
+#define GZ_DEC_ROW(ms) (2 * (ms) + 2)
+#define GZ_DEC_RUN_ROW 10
+
+template <typename MP>
+__device__ static __forceinline__ void d_arith_decode_leaf (GzdDecLeaf &L, MP models, uint32_t ms, uint32_t n, int lane)
+{
+    const bool o1 = L.o1, rle = L.rle;
+    const uint32_t nlit = o1 ? ms : 1, lit_stride = GZ_DEC_ROW (ms);
+    for (uint32_t i = lane; i < nlit * lit_stride; i += 64) {
+        const uint32_t k = i % lit_stride;
+        models[i] = k == 0 ? ms : k == 1 ? 0u : (k & 1) ? (k - 2) / 2 /* cum: every frequency is 1 */ : (1u | (((k - 2) / 2) << 16));
+    }
+    MP runm = models + nlit * lit_stride;
+    if (rle) for (uint32_t i = lane; i < 258 * GZ_DEC_RUN_ROW; i += 64) {
+        const uint32_t k = i % GZ_DEC_RUN_ROW;
+        runm[i] = k == 0 ? 4u : k == 1 ? 0u : (k & 1) ? (k - 2) / 2 : (1u | (((k - 2) / 2) << 16));
+    }
+    __syncthreads ();
+
+    GzRcDec rc;
+    rc.code = 0; rc.range = 0xffffffffu; rc.in = L.body + 1; rc.pos = 0; rc.len = L.body_len - 1; rc.base = 0xffffff00u; rc.win = 0;
+    if (rc.len >= 5) for (int k = 0; k < 5; k++) rc.code = (rc.code << 8) | d_dec_byte (rc, lane);
+    else rc.pos = rc.len;
+    uint8_t *out = L.dst;
+    uint32_t last = 0, obuf = 0;                                 // obuf: symbol i of the current 64 in lane i % 64, stored 64 at a time
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t s = d_model_decode<MP> (models + (o1 ? last * lit_stride : 0), ms, rc, lane);
+        if (s >= ms) s = 0;
+        obuf = (uint32_t)lane == (i & 63) ? s : obuf;
+        if ((i & 63) == 63) out[(i & ~63u) + lane] = (uint8_t)obuf;
+        last = s;
+        if (!rle) continue;
+        uint32_t run = 0, d, ctx = s;                            // arith_dynamic.c:476-487
+        do {
+            d = d_model_decode<MP> (runm + ctx * GZ_DEC_RUN_ROW, 4, rc, lane);
+            ctx = (ctx == s) ? 256 : ctx + (ctx < 257);
+            run += d;
+        } while (d == 3 && run < n);
+        // (a run: flush what is buffered, then the wave writes the run 64 bytes at a time)
+        const uint32_t r = run < n - 1 - i ? run : n - 1 - i;
+        if (r) {
+            if ((i & 63) != 63 && (uint32_t)lane <= (i & 63)) out[(i & ~63u) + lane] = (uint8_t)obuf;
+            for (uint32_t k = lane; k < r; k += 64) out[i + 1 + k] = (uint8_t)s;
+            const uint32_t first = i + 1;
+            i += r;
+            // (the buffer mirrors the 64-block the run ends in: its positions first .. i hold the run's symbol)
+            const uint32_t pos = (i & ~63u) + lane;
+            obuf = pos >= first && pos <= i ? s : obuf;
+            if ((i & 63) == 63) out[(i & ~63u) + lane] = (uint8_t)obuf;
+        }
+    }
+    if ((n & 63) && (uint32_t)lane < (n & 63)) out[(n & ~63u) + lane] = (uint8_t)obuf;
+    if (!lane) L.status = GZ_ST_OK;
 }
 
 __global__ void __launch_bounds__(64) k_arith_decode (GzdDecLeaf *leaves, uint32_t lds_words_lo, uint32_t lds_words_hi, int use_global)
@@ -383,39 +507,10 @@ __global__ void __launch_bounds__(64) k_arith_decode (GzdDecLeaf *leaves, uint32
     if (!L.body_len) return;
     const uint32_t n = L.coded_n;
     const uint32_t ms = L.body[0] ? L.body[0] : 256;
-    const bool o1 = L.o1, rle = L.rle;
-    const uint32_t words = (o1 ? ms : 1) * (ms + 1) + (rle ? 258 * 5 : 0);
+    const uint32_t words = (L.o1 ? ms : 1) * GZ_DEC_ROW (ms) + (L.rle ? 258 * GZ_DEC_RUN_ROW : 0);
     if (words <= lds_words_lo || words > lds_words_hi) return;
-    uint32_t *models = use_global ? L.models : (uint32_t *)gz_lds;
-    const int lane = threadIdx.x;
-    const uint32_t nlit = o1 ? ms : 1, lit_stride = ms + 1;
-    for (uint32_t i = lane; i < nlit * lit_stride; i += 64) { uint32_t k = i % lit_stride; models[i] = k ? (1u | ((k - 1) << 16)) : ms; }
-    uint32_t *runm = models + nlit * lit_stride;
-    if (rle) for (uint32_t i = lane; i < 258 * 5; i += 64) { uint32_t k = i % 5; runm[i] = k ? (1u | ((k - 1) << 16)) : 4; }
-    __syncthreads ();
-    if (lane) return;
-
-    GzRcDec rc;
-    rc.code = 0; rc.range = 0xffffffffu; rc.in = L.body + 1; rc.pos = 0; rc.len = L.body_len - 1;
-    if (rc.len >= 5) for (int k = 0; k < 5; k++) rc.code = (rc.code << 8) | rc.in[rc.pos++];
-    else rc.pos = rc.len;
-    uint8_t *out = L.dst;
-    uint32_t last = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        uint32_t s = d_model_decode (models + (o1 ? last * lit_stride : 0), ms, rc);
-        if (s >= ms) s = 0;
-        out[i] = (uint8_t)s;
-        last = s;
-        if (!rle) continue;
-        uint32_t run = 0, d, ctx = s;                            // arith_dynamic.c:476-487
-        do {
-            d = d_model_decode (runm + ctx * 5, 4, rc);
-            ctx = (ctx == s) ? 256 : ctx + (ctx < 257);
-            run += d;
-        } while (d == 3 && run < n);
-        while (run-- && i + 1 < n) out[++i] = (uint8_t)s;
-    }
-    L.status = GZ_ST_OK;
+    if (use_global) d_arith_decode_leaf<uint32_t *> (L, L.models, ms, n, (int)threadIdx.x);
+    else d_arith_decode_leaf<GzLdsU32P> (L, (GzLdsU32P)gz_lds, ms, n, (int)threadIdx.x);
 }
 
 // one 256-thread workgroup per stream

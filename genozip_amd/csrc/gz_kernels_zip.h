@@ -416,3 +416,12 @@ __global__ void __launch_bounds__(256) k_seq_snips (GzdSeqSnip S)
     S.nonref_len[r] = mono ? 0 : len;
     if (S.l3_len[r]) atomicAdd (S.n_line3, 1u);
 }
+
+// any byte set? (the `missing` mask of gz_vcf_sample_columns: a sample that leaves trailing subfields out) - grid (tiles of 256 x 16 bytes)
+__global__ void __launch_bounds__(256) k_any_set (const uint8_t *p, uint64_t n, uint32_t *count)
+{
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    uint32_t c = 0;
+    for (uint64_t i = i0; i < i0 + 16 && i < n; i++) c += p[i] != 0;
+    if (c) atomicAdd (count, c);
+}

@@ -51,6 +51,7 @@ struct ZipCol {                    // one (VBlock, context) of this process
     size_t n2w_at = 0;
     uint8_t lcodec = 0, bcodec = 0;
     int early = -1;                            // index of this local's stream in the batch coded ahead on the second handle
+    bool host_len = false;                     // a dyn-int local whose final byte length the host knows (transposed here, not by the batch of local jobs)
 };
 
 // One (VBlock, context) as the merge sees it - what a process has to tell the others when the VBlocks of a file are dealt out
@@ -495,7 +496,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     const uint32_t lookup_off = (uint32_t)text_len;
     uint32_t line_cap = (uint32_t)(text_len / 16 + 1024);
     uint32_t *line_off = NULL, *line_len = NULL;
-    struct ABlock { GzLinesResult lines; uint32_t bad_bound, n_bad_items; GzFastqResult fq; uint32_t n_line3, pad; } ;
+    struct ABlock { GzLinesResult lines; uint32_t bad_bound, n_bad_items; GzFastqResult fq; uint32_t n_line3, n_bad_samples, n_missing, pad; GzLinesResult tabs; } ;
     WS (d_a, ABlock, 1);
     WS (d_vb_off, uint64_t, 2 * NV + 2);
     WS (d_first_line, uint32_t, 2 * NV + 2);
@@ -558,6 +559,30 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         tokenized = true;
         seq_off = item_off + (size_t)f->plan.seq_item * R; seq_len = item_len + (size_t)f->plan.seq_item * R;
         qual_off = item_off + (size_t)f->plan.qual_item * R; qual_len = item_len + (size_t)f->plan.qual_item * R;
+    }
+    // VCF: the FORMAT subfields of every sample of every line as columns of lines x samples entries (vcf_seg_samples' split)
+    const uint32_t NS = f->plan.n_samples, NSUB = f->plan.n_subfields;
+    uint32_t *s_off = NULL, *s_len = NULL;
+    const uint64_t cells = (uint64_t)R * NS;
+    if (NS) {
+        if (RL != 1 || !NSUB || cells * NSUB > 0xfffffff0ull) { h->err = "plan: samples need one-line records; at most 2^32 sample subfields per call"; return GZ_ERR_ARG; }
+        uint32_t tab_cap = (uint32_t)std::min<uint64_t> (text_len, cells + 16ull * R + 1024);
+        uint32_t *tab_after = NULL;
+        for (int attempt = 0;; attempt++) {
+            if (!(tab_after = (uint32_t *)ws_alloc (f, ((size_t)tab_cap + 8) * 4))) return GZ_ERR_HIP;
+            ZCHK (gz_byte_index (h, text, text_len, '\t', tab_after, tab_cap, &d_a->tabs));
+            GzLinesResult tr;
+            HIPCHK (h, hipMemcpyAsync (&tr, &d_a->tabs, sizeof (tr), hipMemcpyDeviceToHost, h->stream));
+            if ((rc = gz_sync (h)) < 0) return rc;
+            if (tr.status == GZ_ST_OK) break;
+            if (attempt || tr.n_lines > 0xfffffff0ull) { h->err = "tab index does not fit"; return GZ_ERR; }
+            tab_cap = (uint32_t)tr.n_lines + 8;
+        }
+        uint8_t *missing = (uint8_t *)ws_alloc (f, cells * NSUB + 64);
+        if (!(s_off = (uint32_t *)ws_alloc (f, (cells * NSUB + 8) * 4)) || !(s_len = (uint32_t *)ws_alloc (f, (cells * NSUB + 8) * 4)) || !missing) return GZ_ERR_HIP;
+        HIPCHK (h, hipMemsetAsync (missing, 0, cells * NSUB, h->stream));
+        ZCHK (gz_vcf_sample_columns (h, text, line_off, line_len, R, tab_after, &d_a->tabs, NS, NSUB, s_off, s_len, missing, &d_a->n_bad_samples));
+        if (cells) KLAUNCH (h, k_any_set, dim3 ((uint32_t)((cells * NSUB + 4095) / 4096)), dim3 (256), 0, (const uint8_t *)missing, cells * NSUB, &d_a->n_missing);
     }
     // SQBITMAP's snip of every read, and what NONREF takes of it (fastq_seg_SEQ): a read of one repeated base is not stored
     uint8_t *sq_slots = NULL; uint32_t *sq_off = NULL, *sq_len = NULL, *nonref_len = NULL;
@@ -624,18 +649,22 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         for (uint32_t c = 0; c < NC; c++) {
             const GzFastqCtx &X = f->ctxs[c];
             ZipCol &Z = COL (v, c);
-            Z.n = n;
+            const bool ps = X.per_sample && NS;                            // a FORMAT subfield of every sample: lines x samples entries
+            if (X.per_sample && (!NS || X.item >= NSUB)) { h->err = "plan: a per-sample context without samples / beyond n_subfields"; return GZ_ERR_ARG; }
+            const uint32_t nn = ps ? n * NS : n;
+            Z.n = nn;
             Z.sec_len_dev = d_seclen + 2 * ((size_t)v * NC + c);
-            const uint32_t *io = item_off + (size_t)X.item * R + rr, *il = item_len + (size_t)X.item * R + rr;
+            const uint32_t *io = ps ? s_off + (size_t)X.item * cells + (size_t)rr * NS : item_off + (size_t)X.item * R + rr,
+                           *il = ps ? s_len + (size_t)X.item * cells + (size_t)rr * NS : item_len + (size_t)X.item * R + rr;
             const uint32_t *coff = io, *clen = il;
             if (X.kind == GZ_FQ_ITEM_INT || X.kind == GZ_FQ_ITEM_DELTA) {
                 GzIntColJob j; memset (&j, 0, sizeof (j));
-                j.text = text; j.off = io; j.len = il; j.n = n; j.nothing_char = X.nothing_char; j.lookup_off = lookup_off; j.mode = X.kind == GZ_FQ_ITEM_DELTA;
-                int64_t *vals = (int64_t *)ws_alloc (f, ((size_t)n + 1) * 8); uint8_t *isn = (uint8_t *)ws_alloc (f, (size_t)n + 16);
+                j.text = text; j.off = io; j.len = il; j.n = nn; j.nothing_char = X.nothing_char; j.lookup_off = lookup_off; j.mode = X.kind == GZ_FQ_ITEM_DELTA;
+                int64_t *vals = (int64_t *)ws_alloc (f, ((size_t)nn + 1) * 8); uint8_t *isn = (uint8_t *)ws_alloc (f, (size_t)nn + 16);
                 if (!vals || !isn) return GZ_ERR_HIP;
                 j.values = vals; j.is_nothing = isn;
                 if (X.kind == GZ_FQ_ITEM_INT) {
-                    uint32_t *so = (uint32_t *)ws_alloc (f, ((size_t)n + 1) * 4), *sl = (uint32_t *)ws_alloc (f, ((size_t)n + 1) * 4);
+                    uint32_t *so = (uint32_t *)ws_alloc (f, ((size_t)nn + 1) * 4), *sl = (uint32_t *)ws_alloc (f, ((size_t)nn + 1) * 4);
                     if (!so || !sl) return GZ_ERR_HIP;
                     j.snip_off = so; j.snip_len = sl; coff = so; clen = sl;
                 }
@@ -643,22 +672,22 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
                 j.n_values_dev = d_icolres + 2 * (size_t)Z.icol_job; j.status_dev = (int32_t *)(d_icolres + 2 * (size_t)Z.icol_job + 1);
                 icol_jobs.push_back (j);
                 GzDynIntJob dj; memset (&dj, 0, sizeof (dj));
-                dj.values = vals; dj.is_nothing = isn; dj.n = n; dj.nothing_char = X.nothing_char; dj.n_dev = j.n_values_dev;
-                if (!(Z.local = (uint8_t *)ws_alloc (f, ((size_t)n + 1) * 8))) return GZ_ERR_HIP;
-                Z.local_cap = (uint64_t)n * 8;
+                dj.values = vals; dj.is_nothing = isn; dj.n = nn; dj.nothing_char = X.nothing_char; dj.n_dev = j.n_values_dev;
+                if (!(Z.local = (uint8_t *)ws_alloc (f, ((size_t)nn + 1) * 8))) return GZ_ERR_HIP;
+                Z.local_cap = (uint64_t)nn * 8;
                 dj.out = Z.local; Z.dyn_job = (int)dyn_jobs.size (); dj.result_dev = d_dynres + Z.dyn_job;
                 dyn_jobs.push_back (dj);
             }
             if (X.kind == GZ_FQ_ITEM_TEXT || X.kind == GZ_FQ_ITEM_INT || X.kind == GZ_FQ_SEQ_SNIP) {
                 GzColumnJob j; memset (&j, 0, sizeof (j));
-                j.text = text; j.off = coff; j.len = clen; j.n = n;
+                j.text = text; j.off = coff; j.len = clen; j.n = nn;
                 if (X.kind == GZ_FQ_SEQ_SNIP) { j.text = sq_slots; j.off = sq_off + rr; j.len = sq_len + rr; }   // (generated text: 16-byte slots)
                 j.ol_dict = ol[c].dict; j.ol_char_index = ol[c].ci; j.ol_snip_len = ol[c].sl; j.n_ol = ol[c].n;
                 // the dictionary of a column cannot exceed its snips + a NUL each; an item is at most the line
-                const uint64_t dict_cap = X.kind == GZ_FQ_ITEM_INT ? (uint64_t)n * 24 + 64 : X.kind == GZ_FQ_SEQ_SNIP ? (uint64_t)n * 17 + 64 : vbs[v].text_len + n + 64;
-                j.node_index = (int32_t *)ws_alloc (f, ((size_t)n + 1) * 4); j.dict = (uint8_t *)ws_alloc (f, dict_cap); j.dict_cap = dict_cap;
-                j.node_char_index = (uint64_t *)ws_alloc (f, ((size_t)n + 1) * 8); j.node_snip_len = (uint32_t *)ws_alloc (f, ((size_t)n + 1) * 4);
-                j.counts = (uint32_t *)ws_alloc (f, ((size_t)n + ol[c].n + 1) * 4); j.b250 = (uint8_t *)ws_alloc (f, (size_t)n * 4 + 16);
+                const uint64_t dict_cap = X.kind == GZ_FQ_ITEM_INT ? (uint64_t)nn * 24 + 64 : X.kind == GZ_FQ_SEQ_SNIP ? (uint64_t)nn * 17 + 64 : vbs[v].text_len + nn + 64;
+                j.node_index = (int32_t *)ws_alloc (f, ((size_t)nn + 1) * 4); j.dict = (uint8_t *)ws_alloc (f, dict_cap); j.dict_cap = dict_cap;
+                j.node_char_index = (uint64_t *)ws_alloc (f, ((size_t)nn + 1) * 8); j.node_snip_len = (uint32_t *)ws_alloc (f, ((size_t)nn + 1) * 4);
+                j.counts = (uint32_t *)ws_alloc (f, ((size_t)nn + ol[c].n + 1) * 4); j.b250 = (uint8_t *)ws_alloc (f, (size_t)nn * 4 + 16);
                 if (!j.node_index || !j.dict || !j.node_char_index || !j.node_snip_len || !j.counts || !j.b250) return GZ_ERR_HIP;
                 Z.col_job = (int)col_jobs.size (); j.result_dev = d_colres + Z.col_job;
                 Z.b250_seg = j.b250; Z.n_ol = ol[c].n;
@@ -930,6 +959,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         h->err = "not FASTQ: a read is not '@'.. / SEQ / '+'.. / QUAL of SEQ's length (fastq.c:1008-1010,1076,1121)"; ZIP_FAIL (GZ_ERR_CORRUPT);
     }
     if (f->plan.line3_empty && a.n_line3) { h->err = "line 3 of a read is more than '+' (the plan says L3_EMPTY; fastq_desc.c:35-37)"; ZIP_FAIL (GZ_ERR_CORRUPT); }
+    if (NS && (a.n_bad_samples || a.n_missing)) { h->err = "VCF: a line without 9 + n_samples fields, a sample with more subfields than the plan's, or one that leaves subfields out (not supported by this driver)"; ZIP_FAIL (GZ_ERR_CORRUPT); }
     if (a.n_bad_items) { h->err = "a line 1 does not fit the container of the plan (the reference would re-discover the flavor, qname.c:823-826)"; ZIP_FAIL (GZ_ERR_CORRUPT); }
     for (size_t k = 0; k < icol_jobs.size (); k++)
         if ((int32_t)icolres[2 * k + 1] == GZ_ST_CORRUPT) { h->err = "an ordered item is not an integer (qname.c:750-756)"; ZIP_FAIL (GZ_ERR_CORRUPT); }
@@ -1253,6 +1283,21 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
                 Z.sec_b250 = Z.b250_out; Z.sec_b250_len = (uint32_t)Z.seg_b250_len;
                 bjobs.push_back (j);
             }
+            if (Z.has_local && Z.dyn_job >= 0 && X.transposed && X.per_sample && f->plan.n_samples) {
+                // zip_generate_local for a dyn_transposed context (zip.c:185-219: byte order first, then dyn_int_transpose): the unsigned
+                // lines x samples matrix goes out samples x lines as LT_UINTn_TR; a column that turned out signed (or with entries that are
+                // not integers) stays as it is, like in the reference (dyn_int.c:52-56)
+                const int lt = Z.ltype;
+                const uint32_t w = lt == GZ_LT_UINT8 ? 1 : lt == GZ_LT_UINT16 ? 2 : lt == GZ_LT_UINT32 ? 4 : 0;
+                if (w && Z.local_len == (uint64_t)Z.n * w) {
+                    void *scratch = ws_alloc (f, Z.local_len + 64);
+                    if (!scratch) return GZ_ERR_HIP;
+                    const int r = gz_local_generate (h, lt, Z.local, Z.n, f->plan.n_samples, scratch);
+                    if (r < 0) return r;
+                    Z.ltype = r; Z.host_len = true;
+                    continue;
+                }
+            }
             if (Z.has_local && Z.dyn_job >= 0) {
                 GzLocalJob j; memset (&j, 0, sizeof (j));
                 j.data = Z.local; j.n = Z.n; j.dyn_dev = K.d_dynres + Z.dyn_job; j.len_dev = Z.sec_len_dev;
@@ -1315,7 +1360,7 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
                     for (uint32_t v = 0; v < NV; v++) {
                         ZipCol &Z = COL (v, c);
                         uint32_t L = 0; const uint8_t *p = NULL;
-                        if (is_local && Z.has_local) { p = Z.local; L = Z.dyn_job >= 0 ? seclen[2 * ((size_t)v * NC + c)] : (uint32_t)Z.local_len; }
+                        if (is_local && Z.has_local) { p = Z.local; L = Z.dyn_job >= 0 && !Z.host_len ? seclen[2 * ((size_t)v * NC + c)] : (uint32_t)Z.local_len; }
                         if (!is_local && Z.has_b250) { p = Z.sec_b250; L = Z.col_job >= 0 ? seclen[2 * ((size_t)v * NC + c) + 1] : Z.sec_b250_len; }
                         if (L < 50) continue;
                         // a VBlock too small to speak for the file keeps its choice to itself, and the next one tests again (codec.c:352)
@@ -1424,7 +1469,7 @@ static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint
             }
             else {
                 s.section_type = GZ_SEC_LOCAL; s.data = Z.local; s.data_len = (uint32_t)Z.local_len;
-                if (Z.dyn_job >= 0) { s.data_len = (uint32_t)Z.local_cap; s.data_len_dev = Z.sec_len_dev; }
+                if (Z.dyn_job >= 0 && !Z.host_len) { s.data_len = (uint32_t)Z.local_cap; s.data_len_dev = Z.sec_len_dev; }
                 if (Z.early >= 0) {                                                                    // coded ahead on the second handle: only framed here
                     const GzStream &es = K.early[Z.early];
                     s.precompressed = 1; s.raw_len = es.in_len; s.data = es.out; s.data_len = es.out_cap; s.data_len_dev = es.out_len_dev;
@@ -1442,7 +1487,7 @@ static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint
                     s.hdr_codec = GZ_CODEC_XCGT;
                     if (!s.codec) s.codec = GZ_CODEC_NONE;
                 }
-                const bool int_lt = Z.ltype >= GZ_LT_INT8 && Z.ltype <= GZ_LT_UINT64;
+                const bool int_lt = (Z.ltype >= GZ_LT_INT8 && Z.ltype <= GZ_LT_UINT64) || (Z.ltype >= GZ_LT_UINT8_TR && Z.ltype <= GZ_LT_UINT32_TR);   // lt_max (ltype) != 0
                 if (int_lt) s.b250_size_or_nothing_char = X.nothing_char ? X.nothing_char : 0xff;    // zfile.c:344-345
                 if (is_r1 && X.pair_identical) s.flags |= PAIRED;                                     // zfile.c:323-325
             }

@@ -121,6 +121,7 @@ def c_plan(plan):
         a.pair_identical, a.pair_assisted_b250, a.nothing_char = int(c["pair_identical"]), int(c["pair_assisted_b250"]), c["nothing_char"]
         a.snip, a.snip_len = c["snip"], len(c["snip"])
         a.con_len, a.segs_per_line = c.get("con_len", 0), c.get("segs_per_line", 0)
+        a.per_sample, a.transposed = int(c.get("per_sample", 0)), int(c.get("transposed", 0))
         keep.append(c["snip"])
     p = GzFastqPlan()
     p.ctxs, p.n_ctxs = arr, n
@@ -131,4 +132,5 @@ def c_plan(plan):
     p.vb_size = plan.get("vb_size", 0)
     p.line3_empty = plan.get("line3_empty", 0)
     p.record_lines, p.seq_item, p.qual_item = plan.get("record_lines", 0), plan.get("seq_item", 0), plan.get("qual_item", 0)
+    p.n_samples, p.n_subfields = plan.get("n_samples", 0), plan.get("n_subfields", 0)
     return p, keep

@@ -112,13 +112,13 @@ class GzFastqCtx(C.Structure):
     _fields_ = [("dict_id", C.c_uint8 * 8), ("did_i", C.c_uint16), ("kind", C.c_uint8), ("item", C.c_uint8), ("local_dep", C.c_uint8),
                 ("flags", C.c_uint8), ("no_stons", C.c_uint8), ("lcodec", C.c_uint8), ("bcodec", C.c_uint8), ("pair_identical", C.c_uint8),
                 ("pair_assisted_b250", C.c_uint8), ("nothing_char", C.c_uint8), ("snip", C.c_char_p), ("snip_len", C.c_uint32),
-                ("con_len", C.c_uint32), ("segs_per_line", C.c_uint8)]
+                ("con_len", C.c_uint32), ("per_sample", C.c_uint8), ("transposed", C.c_uint8), ("segs_per_line", C.c_uint8)]
 
 
 class GzFastqPlan(C.Structure):
     _fields_ = [("ctxs", C.POINTER(GzFastqCtx)), ("n_ctxs", C.c_uint32), ("seps", C.c_char * 16), ("sep_counts", C.c_uint8 * 16),
                 ("n_seps", C.c_uint32), ("paired", C.c_uint8), ("estimated_entries", C.c_uint32), ("qual_codec", C.c_uint8), ("vb_size", C.c_uint64),
-                ("record_lines", C.c_uint8), ("seq_item", C.c_uint8), ("qual_item", C.c_uint8), ("line3_empty", C.c_uint8)]
+                ("record_lines", C.c_uint8), ("seq_item", C.c_uint8), ("qual_item", C.c_uint8), ("n_samples", C.c_uint32), ("n_subfields", C.c_uint8), ("line3_empty", C.c_uint8)]
 
 
 class GzFastqVB(C.Structure):

@@ -290,3 +290,88 @@ def sam_text(seed, read0, n_reads, profile="bin", xp=None):
     flat = rec.reshape(-1)
     out = flat[flat != 0]
     return out.tobytes() if host else out
+
+
+# ---- BASELINE configs[3]: a multi-sample VCF as text ---------------------------------------------------------------------
+def vcf_text(seed, line0, n_lines, n_samples, xp=None):
+    """data lines [line0, line0 + n_lines) of a VCF with n_samples samples, FORMAT GT:DP:PL (no header lines):
+        chr1 POS ID REF ALT QUAL PASS DP=<n>;AF=0.<nn> GT:DP:PL  <GT>:<DP>:<PL0>,<PL1>,<PL2> x n_samples
+    GT 0/0, 0/1, 1/1 with a per-site allele frequency (most sites rare), DP 10-59, PL consistent with GT (0 at the called genotype). Cells
+    differ in width (the PL numbers), so a line is laid out in a matrix as wide as the widest with 0 bytes where a number is shorter and the
+    text is the matrix without its 0 bytes - numpy on the host or torch in HBM (xp = _TH (device)): identical bytes."""
+    host = xp is None
+    xp = xp or _NP
+    li = xp.arange(line0, line0 + n_lines)
+    hl, hl2 = _hash(xp, seed + 0x7C1, li), _hash(xp, seed + 0x7C2, li)
+    FIX = 96                                                                           # columns of the fixed fields at their widest (asserted below)
+    CELL = 1 + 3 + 1 + 2 + 1 + 3 + 1 + 3 + 1 + 3                                       # tab GT : DP : PL0 , PL1 , PL2
+    W_ = FIX + n_samples * CELL
+    if host:
+        rec = np.zeros((n_lines, W_), dtype=np.uint8)
+        const = lambda b: np.frombuffer(b, dtype=np.uint8)                         # noqa: E731
+        to_u8 = lambda v: v.astype(np.uint8)                                       # noqa: E731
+        tab = lambda m: m                                                          # noqa: E731
+    else:
+        t = xp.t
+        rec = t.zeros((n_lines, W_), dtype=t.uint8, device=xp.dev)
+        const = lambda b: t.tensor(list(b), dtype=t.uint8, device=xp.dev)          # noqa: E731
+        to_u8 = lambda v: v.to(t.uint8)                                            # noqa: E731
+        tab = lambda m: t.tensor(m, device=xp.dev)                                 # noqa: E731
+    at = 0
+
+    def put(b):
+        nonlocal at
+        rec[:, at:at + len(b)] = const(b)
+        at += len(b)
+
+    def digits(dst, col, v, width, fixed):
+        for k in range(width):
+            p = 10 ** (width - 1 - k)
+            d = 48 + (v // p) % 10
+            if not fixed and k < width - 1:
+                d = xp.where(v >= p, d, 0)
+            dst[..., col + k] = to_u8(d)
+
+    put(b"chr1\t")
+    digits(rec, at, 1000000 + li * 211 + hl % 200, 9, False); at += 9
+    put(b"\t")
+    has_id = (hl2 % 3) == 0                                                           # a third of the sites carry an rs id, the others '.'
+    rs = 1000000 + xp.lsr(hl2, 4) % 9000000
+    rec[:, at] = to_u8(xp.where(has_id, 114, 46)); rec[:, at + 1] = to_u8(xp.where(has_id, 115, 0))
+    for k in range(7):
+        rec[:, at + 2 + k] = to_u8(xp.where(has_id, 48 + (rs // 10 ** (6 - k)) % 10, 0))
+    at += 9
+    put(b"\t")
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    rec[:, at] = (acgt[(hl % 4).astype(np.int64)] if host else tab(acgt)[hl % 4]); at += 1
+    put(b"\t")
+    rec[:, at] = (acgt[((hl + 1 + xp.lsr(hl, 8) % 3) % 4).astype(np.int64)] if host else tab(acgt)[(hl + 1 + xp.lsr(hl, 8) % 3) % 4]); at += 1
+    put(b"\t"); digits(rec, at, 30 + xp.lsr(hl, 12) % 60, 2, True); at += 2
+    put(b"\tPASS\tDP="); digits(rec, at, 20 * n_samples + hl2 % (10 * n_samples), 7, False); at += 7
+    put(b";AF=0."); digits(rec, at, xp.lsr(hl2, 8) % 100, 2, True); at += 2
+    put(b"\tGT:DP:PL")
+    assert at <= FIX
+    # the samples: an n_lines x n_samples x CELL block
+    cidx = (li * n_samples).reshape(-1, 1) + xp.arange(0, n_samples).reshape(1, -1)
+    hc = _hash(xp, seed + 0x7C3, cidx.reshape(-1)).reshape(n_lines, n_samples)
+    af = (xp.lsr(hl2, 16) % 100).reshape(-1, 1)                                      # per-site alt allele frequency in percent-ish: most sites rare
+    af = xp.where(af < 70, af % 5, af % 60)
+    u = hc % 100
+    g = xp.where(u < af, 1, 0) + xp.where(xp.lsr(hc, 8) % 100 < af, 1, 0)              # 0, 1, 2 alt alleles
+    dp = 10 + xp.lsr(hc, 16) % 50
+    cell = (np.zeros((n_lines, n_samples, CELL), dtype=np.uint8) if host else xp.t.zeros((n_lines, n_samples, CELL), dtype=xp.t.uint8, device=xp.dev))
+    cell[..., 0] = 9                                                                   # the tab in front of the sample
+    cell[..., 1] = to_u8(48 + xp.where(g == 2, 1, 0)); cell[..., 2] = 47; cell[..., 3] = to_u8(48 + xp.where(g >= 1, 1, 0)); cell[..., 4] = 58
+    digits(cell, 5, dp, 2, True); cell[..., 7] = 58
+    pl0 = xp.where(g == 0, 0, xp.where(g == 1, 3 * dp, 9 * dp)); pl1 = xp.where(g == 1, 0, 3 * dp); pl2 = xp.where(g == 2, 0, xp.where(g == 1, 3 * dp, 9 * dp))
+    cap = lambda v: xp.where(v > 255, 255, v)                                          # noqa: E731
+    digits(cell, 8, cap(pl0), 3, False); cell[..., 11] = 44
+    digits(cell, 12, cap(pl1), 3, False); cell[..., 15] = 44
+    digits(cell, 16, cap(pl2), 3, False)
+    rec[:, FIX:] = cell.reshape(n_lines, n_samples * CELL)
+    # the end of line: one more column behind the last cell
+    nlcol = (np.full((n_lines, 1), 10, dtype=np.uint8) if host else xp.t.full((n_lines, 1), 10, dtype=xp.t.uint8, device=xp.dev))
+    rec = (np.concatenate([rec, nlcol], axis=1) if host else xp.t.cat([rec, nlcol], dim=1))
+    flat = rec.reshape(-1)
+    out = flat[flat != 0]
+    return out.tobytes() if host else out

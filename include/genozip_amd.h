@@ -457,6 +457,11 @@ typedef struct {
     uint8_t  nothing_char;        /* GZ_FQ_ITEM_INT                                                                       */
     const uint8_t *snip; uint32_t snip_len;   /* GZ_FQ_CONST / GZ_FQ_ITEM_DELTA / GZ_FQ_TOPLEVEL / GZ_FQ_SEQ_SNIP: the snip (host pointer) */
     uint32_t con_len;             /* GZ_FQ_TOPLEVEL: bytes of the binary Container at the start of `snip`                  */
+    uint8_t  per_sample;          /* VCF (plan.n_samples): the item is FORMAT subfield `item` of EVERY sample of every line (vcf_seg_samples,
+                                     src/vcf_samples.c:1601): the column has lines x samples entries, line by line                         */
+    uint8_t  transposed;          /* per_sample GZ_FQ_ITEM_INT: ctx->dyn_transposed (src/vcf_samples.c:121-130) - the lines x samples matrix of
+                                     an unsigned dyn-int local is written samples x lines, LT_UINTn_TR, param 0 = "as many columns as the
+                                     file has samples" (dyn_int_transpose, src/dyn_int.c:45-132)                              */
     uint8_t  segs_per_line;       /* GZ_FQ_CONST: how many times a read segs the snip (E2L: 3, src/fastq.c:1300-1304); 0 = once.
                                      Only the word's count depends on it                                                    */
 } GzFastqCtx;
@@ -474,6 +479,9 @@ typedef struct {
                                      src/sam_seg.c) - the items are the line's (tab-separated fields; QNAME further by its flavor) and SEQ /
                                      QUAL are the items seq_item / qual_item                                                          */
     uint8_t  seq_item, qual_item;
+    uint32_t n_samples;           /* VCF: every record carries this many samples behind its 9 fixed fields (items 0-8 of the line; the plan's
+                                     separators are the 9 tabs), each n_subfields ':'-separated FORMAT subfields (0: no samples)           */
+    uint8_t  n_subfields;
     uint8_t  line3_empty;         /* segconf.line3 == L3_EMPTY: line 3 is "+" alone, takes no context (the '+' is a prefix of the TOPLEVEL
                                      container) and anything else there is an error (fastq_seg_LINE3, src/fastq_desc.c:33-37)          */
 } GzFastqPlan;

@@ -175,3 +175,8 @@ def test_emul_sam_zip(emul_engine, oracle):
     """N1 for SAM: configs[2] from text - 4 VBlocks over 2 calls through the one-line-record plan == the oracle's composition"""
     assert parity.sam_zip(emul_engine, oracle, 500) == 4
     assert parity.sam_zip(emul_engine, oracle, 300, n_calls=1, qual="uniform", aux=False) == 2
+
+
+def test_emul_vcf_zip(emul_engine, oracle):
+    """N1 for VCF: configs[3] from text - 4 VBlocks over 2 calls through the per-sample plan == the oracle's composition"""
+    assert parity.vcf_zip(emul_engine, oracle, 12, 40) == 4

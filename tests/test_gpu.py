@@ -250,6 +250,12 @@ def test_sam_zip_driver(gpu_engine, oracle):
     assert parity.sam_zip(gpu_engine, oracle, 1500, n_calls=1, qual="uniform", aux=False) == 2
 
 
+def test_vcf_zip_driver(gpu_engine, oracle):
+    """N1 for VCF (BASELINE configs[3] from text): data lines through the driver's per-sample plan == the oracle's composition, 4 VBlocks
+    over 2 calls: fixed fields, GT / PL b250 columns of lines x samples entries, DP transposed (LT_UINT8_TR)"""
+    assert parity.vcf_zip(gpu_engine, oracle, 60, 300) == 4
+
+
 def test_header_layouts(gpu_engine):
     """a9 / a16 / N4: SectionHeaderCtx, SectionHeaderVbHeader, SectionHeaderTxtHeader and the plan's containers as the product writes them
     == the reference's own structs filled through their members (tests/golden/hdr_golden.json from oracle/ref_hdr_shim.c)"""
