@@ -123,6 +123,8 @@ class Workload:
         if a.stream_reads:
             ranges = ranges[:a.batch_pairs]                       # one call's worth of text, streamed over and over with new vblock_i
         self.n_pairs_file = len(W.vb_ranges(n_reads, vb_bytes(a)))
+        if a.stream_reads:                                        # R1 = 1..N, R2 = N+1..2N (writer.c:318-322), N = whole calls; call c holds R1 c*B+1.. and R2 N+c*B+1..
+            self.n_pairs_file = -(-self.n_pairs_file // len(ranges)) * len(ranges)
         mine = pairs_of_rank(len(ranges), rank, world) if strong else list(range(len(ranges)))
         self.mine, self.ranges = mine, ranges
         th = W._TH(device)
@@ -180,7 +182,7 @@ class Workload:
                 if in_flight == 2:
                     F.end(); in_flight -= 1
                 for e, v in zip(t, self.vb):
-                    e.vblock_i = v[2] + 2 * self.n_pairs_file * call
+                    e.vblock_i = v[2] + len(self.ranges) * call
                 F.begin(self.text, self.text_len, t, n); in_flight += 1
             while in_flight:
                 F.end(); in_flight -= 1
@@ -189,7 +191,7 @@ class Workload:
             for call in range(self.calls_per_step):
                 if call:
                     for t in self.tab:                             # the next stretch of the stream: same text, later VBlocks
-                        t.vblock_i += 2 * self.n_pairs_file
+                        t.vblock_i += len(self.ranges)
                 zip_vblocks_sharded(F, dist if self.a.scaling == "strong" else None, self.text, self.text_len, self.tab, n)
             last = self.tab
             if self.calls_per_step > 1:

@@ -247,9 +247,11 @@ class ZipFile:
         payload = sub_compress(packed, vb_size) if sub == 4 else packed
         return self.insert_section(r["z"], r["seq_section_index"], dict_id("NONREF"), 10, sub, 0 if r["seq_has_x"] else 0x40, 11, 0, payload, r["n_bases"])
 
-    def write_file(self, components, counts_ctxs=(), created=b"genozip_amd", vb_size=16 << 20, std_seq_len=0, std_seq_len_r2=0):
+    def write_file(self, components, counts_ctxs=(), created=b"genozip_amd", vb_size=16 << 20, std_seq_len=0, std_seq_len_r2=0, vb_order=None):
         """components: [dict(name=bytes, pair=0 | 1 | 2, vbs=[VBlock results in the order they are written, each with z, n_reads, text_len])]
-        -> the whole file: per component SEC_TXT_HEADER + its VBlocks (zfile_output_processed_vb), then zip_write_global_area (N4)"""
+        -> the whole file: per component SEC_TXT_HEADER + its VBlocks (zfile_output_processed_vb), then zip_write_global_area (N4).
+        vb_order = [(component, index into its vbs)]: the streamed form - both SEC_TXT_HEADERs first, then the VBlocks in the order the calls
+        produced them (R1 and R2 VBlocks of a call next to each other)"""
         L, E = self.E.L, self.E
         zf = L.gz_zfile_create(3, vb_size)                     # DT_FASTQ
         try:
@@ -261,9 +263,13 @@ class ZipFile:
                 E._check(L.gz_zfile_add_txt_header(zf, ci, comp.get("pair", 0), comp["name"], sum(r["text_len"] for r in comp["vbs"]), sum(r["n_reads"] for r in comp["vbs"]),
                                                    max([r["n_reads"] for r in comp["vbs"]] + [0]), flav, 4, len(body), hdr), "gz_zfile_add_txt_header")
                 body += hdr.raw
-                for r in comp["vbs"]:
+                for r in comp["vbs"] if vb_order is None else ():
                     E._check(L.gz_zfile_add_vblock(zf, r["z"], len(r["z"]), len(body), ci, r["n_reads"]), "gz_zfile_add_vblock")
                     body += r["z"]
+            for ci, k in vb_order or ():
+                r = components[ci]["vbs"][k]
+                E._check(L.gz_zfile_add_vblock(zf, r["z"], len(r["z"]), len(body), ci, r["n_reads"]), "gz_zfile_add_vblock")
+                body += r["z"]
             n = len(self.plan["ctxs"])
             zc = (C.c_void_p * n)(*[L.gz_zip_zctx(self.f, i) for i in range(n)])
             ids = b"".join(c["dict_id"] for c in self.plan["ctxs"])

@@ -114,7 +114,17 @@ struct GzZipFile {
     std::vector<GzZctx *> zctx;
     std::vector<ArenaBlock> ws;            // device workspace of one call (bump allocated, reused by the next call)
     std::vector<uint8_t> stage;            // host staging
-    uint32_t last_vblock_i = 0;
+    // the vblock_i merged so far, as disjoint ascending ranges: calls number their VBlocks freely as long as none comes twice (a
+    // streamed pair of files is R1 = 1..N, R2 = N+1..2N, writer.c:318-322, while each call holds some VBlocks of both)
+    std::vector<std::pair<uint32_t, uint32_t>> merged;
+    uint32_t next_vblock_i () const { return (merged.empty () || merged[0].first > 1) ? 1 : merged[0].second + 1; }   // the lowest not merged yet
+    bool was_merged (uint32_t i) const { for (auto &r : merged) if (i >= r.first && i <= r.second) return true; return false; }
+    void add_merged (uint32_t i) {
+        size_t k = 0; while (k < merged.size () && merged[k].second + 1 < i) k++;
+        if (k < merged.size () && merged[k].first <= i + 1) { if (i < merged[k].first) merged[k].first = i; if (i > merged[k].second) merged[k].second = i; }
+        else merged.insert (merged.begin () + k, std::make_pair (i, i));
+        if (k + 1 < merged.size () && merged[k].second + 1 >= merged[k + 1].first) { merged[k].second = merged[k + 1].second; merged.erase (merged.begin () + k + 1); }
+    }
     // zctx->qual_codec of the QUAL context (codec.c:403-407,445): -1 not decided yet (the file's first VBlock will), 0 a plain
     // LT_BLOB local, GZ_CODEC_DOMQ
     int qual_ctx = -1, aux[3] = { -1, -1, -1 }, qual_mode = 0;
@@ -253,7 +263,7 @@ extern "C" int gz_zip_reset (GzZipFile *f)
         if (f->ctxs[i].lcodec) gz_zctx_commit_codec (f->zctx[i], 1, f->ctxs[i].lcodec);
         if (f->ctxs[i].bcodec) gz_zctx_commit_codec (f->zctx[i], 0, f->ctxs[i].bcodec);
     }
-    f->last_vblock_i = 0;
+    f->merged.clear ();
     f->call = ZipCall ();
     zip_init_qual_mode (f);
     return GZ_OK;
@@ -703,7 +713,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
                 dj.text = text; dj.off = qual_off + rr; dj.len = qual_len + rr; dj.n = n;
                 dj.qual = D.out[0]; dj.runs = D.out[1]; dj.mplx = D.out[2]; dj.divr = D.out[3]; dj.result_dev = d_domqres + v;
                 // (this process holds the file's first VBlock: nobody needs the streams if that one is not a fit)
-                if (qmode0 < 0 && vbs[0].vblock_i == f->last_vblock_i + 1 && vbs[0].n_reads) dj.only_if_dev = d_fit;
+                if (qmode0 < 0 && vbs[0].vblock_i == f->next_vblock_i () && vbs[0].n_reads) dj.only_if_dev = d_fit;
                 domq_jobs.push_back (dj);
                 if (qmode0 < 0) { GzDomqFitJob fj; memset (&fj, 0, sizeof (fj)); fj.text = text; fj.off = dj.off; fj.len = dj.len; fj.n = n; fj.fit_dev = d_fit + v; fit_jobs.push_back (fj); }
             }
@@ -736,7 +746,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     std::vector<GzStream> &trial = K.trial;               // 8 per candidate form of QUAL (plain / through DOMQ) that needs a codec
     trial.clear (); trial.reserve (16);                   // (the coder keeps pointers into it until the second handle is synchronised: never reallocated)
     std::vector<uint32_t> trial_ctx; std::vector<int> trial_domq;
-    const bool own_first = vbs[0].vblock_i == f->last_vblock_i + 1;   // (vblock_i are consecutive over the processes: this one opens the call)
+    const bool own_first = vbs[0].vblock_i == f->next_vblock_i ();   // (vblock_i are consecutive over the processes: this one opens the call)
     bool want_trial = false;
     if (f->h2 && own_first && f->qual_ctx >= 0 && vbs[0].n_reads && zip_vb_commits (f->plan, vbs[0])) { GzZctxView zv; gz_zctx_view (f->zctx[f->qual_ctx], &zv); want_trial = !zv.lcodec; }
     // Speculation. The handle remembers which coder the QUAL stream of its previous file ended up with. If it does, the long streams
@@ -866,7 +876,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         D.fit = fits[v];
         if (!vbs[v].n_reads) { memset (&D.res, 0, sizeof (D.res)); D.res.status = 1; continue; }
         memcpy (&D.res, &domqres[v], sizeof (D.res));
-        if (qmode0 < 0 && vbs[0].vblock_i == f->last_vblock_i + 1 && vbs[0].n_reads && !fits[0]) { memset (&D.res, 0, sizeof (D.res)); D.res.status = 1; }   // (skipped)
+        if (qmode0 < 0 && vbs[0].vblock_i == f->next_vblock_i () && vbs[0].n_reads && !fits[0]) { memset (&D.res, 0, sizeof (D.res)); D.res.status = 1; }   // (skipped)
         if (D.res.status == 1) zip_base64 (D.res.denorm, (size_t)D.res.num_doms * D.res.num_norm_qs, D.snip);      // codec_domq.c:232-244
     }
     // this process holds the call's first VBlock and the file has not decided yet: that VBlock decides (codec.c:403-445), so the
@@ -1108,7 +1118,7 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
     }
     std::stable_sort (ents.begin (), ents.end (), [] (const Ent &a, const Ent &b) { return a.vblock_i < b.vblock_i; });
     for (size_t i = 0; i < ents.size (); i++)
-        if ((i && ents[i].vblock_i == ents[i - 1].vblock_i) || ents[i].vblock_i <= f->last_vblock_i) { h->err = "merge: a vblock_i twice, or not after the previous call's"; return GZ_ERR_ARG; }
+        if ((i && ents[i].vblock_i == ents[i - 1].vblock_i) || f->was_merged (ents[i].vblock_i)) { h->err = "merge: a vblock_i twice (in this call, or in an earlier one)"; return GZ_ERR_ARG; }
     // codec_assign_best_qual_codec (codec.c:391-450): the first VBlock of the file to get there decides for the file - in a serial
     // run VBlock 1. FASTQ has no SEQ-dependent QUAL codec, so it is DOMQ if that VBlock's lines are a fit, else a plain local
     if (f->qual_mode < 0 && !ents.empty ()) {
@@ -1240,7 +1250,7 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
         GzZctxView zv; gz_zctx_view (f->zctx[c], &zv);
         for (uint32_t v = 0; v < NV; v++) { ZipCol &Z = COL (v, c); if (!Z.lcodec) Z.lcodec = zv.lcodec; if (!Z.bcodec) Z.bcodec = zv.bcodec; }
     }
-    if (!ents.empty ()) f->last_vblock_i = ents.back ().vblock_i;
+    for (size_t i = 0; i < ents.size (); i++) f->add_merged (ents[i].vblock_i);
 
     T.mark ("merge");
     // ---- b250 generation, locals into file order, R2 == R1 drops --------------------------------------------------------------

@@ -296,7 +296,7 @@ def sam_text(seed, read0, n_reads, profile="bin", xp=None):
 def vcf_text(seed, line0, n_lines, n_samples, xp=None):
     """data lines [line0, line0 + n_lines) of a VCF with n_samples samples, FORMAT GT:DP:PL (no header lines):
         chr1 POS ID REF ALT QUAL PASS DP=<n>;AF=0.<nn> GT:DP:PL  <GT>:<DP>:<PL0>,<PL1>,<PL2> x n_samples
-    GT 0/0, 0/1, 1/1 with a per-site allele frequency (most sites rare), DP 10-59, PL consistent with GT (0 at the called genotype). Cells
+    GT 0/0, 0/1, 1/1 with a per-site allele frequency (most sites rare), DP ~ Poisson (30) (18-42, peaked), PL consistent with GT (0 at the called genotype). Cells
     differ in width (the PL numbers), so a line is laid out in a matrix as wide as the widest with 0 bytes where a number is shorter and the
     text is the matrix without its 0 bytes - numpy on the host or torch in HBM (xp = _TH (device)): identical bytes."""
     host = xp is None
@@ -358,7 +358,7 @@ def vcf_text(seed, line0, n_lines, n_samples, xp=None):
     af = xp.where(af < 70, af % 5, af % 60)
     u = hc % 100
     g = xp.where(u < af, 1, 0) + xp.where(xp.lsr(hc, 8) % 100 < af, 1, 0)              # 0, 1, 2 alt alleles
-    dp = 10 + xp.lsr(hc, 16) % 50
+    dp = 18 + xp.lsr(hc, 16) % 13 + xp.lsr(hc, 24) % 13                               # ~ Poisson (30): peaked around 30, 18 .. 42
     cell = (np.zeros((n_lines, n_samples, CELL), dtype=np.uint8) if host else xp.t.zeros((n_lines, n_samples, CELL), dtype=xp.t.uint8, device=xp.dev))
     cell[..., 0] = 9                                                                   # the tab in front of the sample
     cell[..., 1] = to_u8(48 + xp.where(g == 2, 1, 0)); cell[..., 2] = 47; cell[..., 3] = to_u8(48 + xp.where(g >= 1, 1, 0)); cell[..., 4] = 58

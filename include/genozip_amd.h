@@ -512,8 +512,10 @@ int gz_fastq_zip_vblocks (GzZipFile *f, uint8_t *text, uint64_t text_len, GzFast
  * dictionaries and each with the word indices of its own VBlocks - generates b250s / locals and returns this process'
  * codec "votes" (context, local / b250, vblock_i, codec) for contexts the file has no codec for yet; after exchanging the
  * votes, gz_fastq_zip_finish commits for every such context the vote with the lowest vblock_i (what a serial run commits,
- * src/codec.c:352-363) and writes the sections. vblock_i are global: unique and ascending over all processes and calls; an R2
- * VBlock and its R1 VBlock belong to the same process. gz_fastq_zip_vblocks == the three phases with the own blob only. */
+ * src/codec.c:352-363) and writes the sections. vblock_i are global: unique over all processes and calls and ascending within a
+ * call (a later call may fill numbers an earlier one left out: a streamed pair of files numbers R1 1..N and R2 N+1..2N,
+ * src/writer.c:318-322, and each call holds some VBlocks of both; the call that holds the lowest number not merged yet is the
+ * one that decides what the file's first VBlock decides); an R2 VBlock and its R1 VBlock belong to the same process. gz_fastq_zip_vblocks == the three phases with the own blob only. */
 int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len, GzFastqVB *vbs, int n_vbs, const void **blob_out, uint64_t *blob_len_out);
 int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const uint64_t *blob_lens, int n_blobs, const void **votes_out, uint64_t *votes_len_out);
 int gz_fastq_zip_finish (GzZipFile *f, const void *const *votes, const uint64_t *votes_lens, int n_votes);

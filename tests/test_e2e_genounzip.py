@@ -116,3 +116,33 @@ def test_paired_files_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, qua
     got1 = (tmp_path / "reads_R1.fq").read_bytes() if (tmp_path / "reads_R1.fq").exists() else b""
     got2 = (tmp_path / "reads_R2.fq").read_bytes() if (tmp_path / "reads_R2.fq").exists() else b""
     assert got1 == r1 and got2 == r2, (sorted(os.listdir(tmp_path)), log[:3000])
+
+
+@pytest.mark.parametrize("interleaved", [False, True])
+def test_streamed_pairs_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, interleaved):
+    """the streamed form (BASELINE configs[4]: one file object, several calls, dictionaries and codecs carried from call to call). A v15 FASTQ
+    pair has exactly two components (sections.c:832-835) and R2's VBlock is R1's + the number of R1 VBlocks (writer.c:318-322), so the caller
+    numbers R1 1..N and R2 N+1..2N with N known up front, and every call holds some VBlocks of both; the reference's decoder reconstructs both
+    texts - whether the file holds R1 whole in front of R2, or the VBlocks in the order the calls made them"""
+    from genozip_amd import fastq as fq
+    plan = fq.illumina_plan(paired=True)
+    K, per = 2, 2
+    N = K * per
+    r1s = [parity.fastq_text(400, seed=61 + k, mate=1) for k in range(K)]
+    r2s = [parity.fastq_text(400, seed=61 + k, mate=2, qual_seed=444 + k) for k in range(K)]
+    calls = []
+    for k in range(K):
+        p1, p2 = _cut(r1s[k], per), _cut(r2s[k], per)
+        vbs = [(p1[j][0], p1[j][1], k * per + j + 1, -1) for j in range(per)] + [(len(r1s[k]) + p2[j][0], p2[j][1], N + k * per + j + 1, j) for j in range(per)]
+        calls.append((r1s[k] + r2s[k], vbs))
+    F, res = _zip(emul_engine, plan, calls, lzma_sub)
+    R1 = [r for k in range(K) for r in res[2 * per * k:2 * per * k + per]]
+    R2 = [r for k in range(K) for r in res[2 * per * k + per:2 * per * (k + 1)]]
+    order = [(m, k * per + j) for k in range(K) for m in (0, 1) for j in range(per)] if interleaved else None
+    blob = F.write_file([dict(name=b"reads_R1.fq", pair=1, vbs=R1), dict(name=b"reads_R2.fq", pair=2, vbs=R2)], std_seq_len=150, std_seq_len_r2=150, vb_order=order)
+    F.close()
+    (tmp_path / "stream.genozip").write_bytes(blob)
+    log = _run(genounzip, ["-f", "stream.genozip"], tmp_path)
+    for name, want in ((b"reads_R1.fq", b"".join(r1s)), (b"reads_R2.fq", b"".join(r2s))):
+        p = tmp_path / name.decode()
+        assert p.exists() and p.read_bytes() == want, (name, sorted(os.listdir(tmp_path)), log[:2000])
