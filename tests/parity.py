@@ -1290,6 +1290,16 @@ def fastq_zip_errors(E, oracle):
     ok = F.zip_vblocks(good, [(0, len(good), 1, -1)])
     want, _ = fastq_zip_expected(oracle, fq.illumina_plan(paired=False), good, [(0, len(good), 1, -1)])
     assert ok[0]["z"] == want[0]["z"]
+    # vblock_i: a later call may fill a number an earlier call left out (streamed pairs: R1 1..N, R2 N+1..2N), none comes twice
+    F.zip_vblocks(good, [(0, len(good), 5, -1)])
+    F.zip_vblocks(good, [(0, len(good), 2, -1)])
+    for again in (1, 2, 5):
+        try:
+            F.zip_vblocks(good, [(0, len(good), again, -1)])
+            raise AssertionError("no error: vblock_i %d twice" % again)
+        except GenozipAMDError:
+            pass
+    F.zip_vblocks(good, [(0, len(good), 3, -1)])
     F.close()
     F = E.zip_open(fq.illumina_plan(paired=False, domq=13))
     lines = good.split(b"\n")
