@@ -436,7 +436,7 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
         if (!(L.F    = (uint32_t *)arena_alloc (h, (o1 ? 256 * 256 + 256 : 256) * sizeof (uint32_t)))) return false;
         if (!(L.syms = (GzRansSym *)arena_alloc (h, (o1 ? 256 * 256 : 256) * sizeof (GzRansSym)))) return false;
         if (!(L.tab  = (uint8_t *)arena_alloc (h, o1 ? GZ_TAB_CAP : 1024))) return false;
-        if (o1 && !(L.rowbuf = (uint8_t *)arena_alloc (h, 256 * GZ_ROW_SLOT))) return false;
+        if (o1 && !(L.rowbuf = (uint8_t *)arena_alloc (h, 256 * GZ_ROW_SLOT + 256 * sizeof (GzRansSym)))) return false;
     }
     else {
         const bool rle = method & GZ_X_RLE;
@@ -960,6 +960,20 @@ static int gz_sync_do (GzHandle *h)
         (void)hipMemcpyToSymbol (HIP_SYMBOL (g_model_slowest), &z, 8);
         if (v) fprintf (stderr, "[model] bg %d slowest wave %.3f ms: %s list index %llu context %llu occurrences ~%llu\n", (int)h->background, (double)(v >> 40) / 1e5,
                         ((v >> 39) & 1) ? "small" : "big", (v >> 28) & 0x7ff, (v >> 18) & 0x3ff, (v & 0x3ffff) * 64);
+    }
+#endif
+#ifdef GZ_TABLE_DEBUG
+    if (!h->pending.empty ()) {
+        unsigned long long sm[9], mx[9], z[9] = { 0 };
+        (void)hipMemcpyFromSymbol (sm, HIP_SYMBOL (g_tab_sum), sizeof (sm));
+        (void)hipMemcpyFromSymbol (mx, HIP_SYMBOL (g_tab_max), sizeof (mx));
+        (void)hipMemcpyToSymbol (HIP_SYMBOL (g_tab_sum), z, sizeof (z));
+        (void)hipMemcpyToSymbol (HIP_SYMBOL (g_tab_max), z, sizeof (z));
+        if (sm[8]) {
+            fprintf (stderr, "[table] bg %d: %llu order-1 workgroups, the slowest %.3f ms; per phase mean / max in us:", (int)h->background, sm[8], (double)mx[8] / 1e5);
+            for (int k = 0; k < 8; k++) fprintf (stderr, " %d: %.1f / %.1f", k, (double)sm[k] / (double)sm[8] / 100.0, (double)mx[k] / 100.0);
+            fprintf (stderr, "\n");
+        }
     }
 #endif
     int rc = GZ_OK;

@@ -351,6 +351,12 @@ __device__ static uint32_t d_alphabet_put (uint8_t *dst, const uint32_t *present
     return p;
 }
 
+// floor (n / d) for n < 2^52, d > 0 through ONE double-precision division instead of the 64-bit integer division's ~150 instructions.
+// Both operands are exact doubles and IEEE division rounds the true quotient q correctly: |fl (q) - q| <= q x 2^-53 = n / (d x 2^53)
+// < 1 / d. A q that is not an integer is at least 1 / d below the next integer, so rounding cannot reach it; rounding is monotonic and
+// integers < 2^53 are representable, so it cannot fall below floor (q) either: the truncated double IS the integer quotient
+__device__ static inline uint64_t d_div_u52 (uint64_t n, uint32_t d) { return (uint64_t)((double)n / (double)d); }
+
 __device__ static inline GzRansSym d_rans_sym (uint32_t start, uint32_t freq, uint32_t bits)   // rANS_word.h:189-265
 {
     GzRansSym r;
@@ -358,9 +364,8 @@ __device__ static inline GzRansSym d_rans_sym (uint32_t start, uint32_t freq, ui
     uint32_t cmpl = ((1u << bits) - freq) & 0xffff, rsh;
     if (freq < 2) { r.rcp = ~0u; rsh = 0; r.bias = start + (1u << bits) - 1; }
     else {
-        uint32_t lg = 0;
-        while (freq > (1u << lg)) lg++;
-        r.rcp  = (uint32_t)(((1ull << (lg + 31)) + freq - 1) / freq);
+        const uint32_t lg = 32u - (uint32_t)__clz ((int)(freq - 1));        // the smallest lg with freq <= 1 << lg
+        r.rcp  = (uint32_t)d_div_u52 ((1ull << (lg + 31)) + freq - 1, freq);
         rsh    = lg - 1;
         r.bias = start;
     }
@@ -476,60 +481,6 @@ __device__ static uint32_t d_rans_encode_wave (uint32_t len_k, uint32_t rounds, 
     return used;
 }
 
-// the same coder for the order-0 nested coding of a frequency table: records in LDS. The table's bytes are fetched 64 rounds (256
-// bytes) at a time, one round's four bytes per lane, the next block while this one is coded - with a global byte load inside every
-// round (as it was) a 50 KB table of a wide order-1 stream took 12 500 x 0.9 us: k_rans_table's 12 ms in the trials of a file's first call
-__device__ static uint32_t d_rans_encode_wave_lds (uint32_t len_k, uint32_t rounds, uint8_t *buf, uint32_t cap, const GzRansSym *tsyms, const uint8_t *tin, uint32_t n_in)
-{
-    const int lane = threadIdx.x & 63;
-    uint32_t x = 0x8000u, used = 0;
-    bool overflow = false;
-    // the four bytes of round rb + lane as one word (the last round may be partial: nothing past the stream is read)
-    auto fetch = [&] (int32_t rb) -> uint32_t {
-        uint32_t w = 0;
-        if (rb >= 0) {
-            const uint32_t at = 4 * ((uint32_t)rb + (uint32_t)lane);
-            #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) if (at + k < n_in) w |= (uint32_t)gz_ldg_u8 (tin + at + k) << (8 * k);
-        }
-        return w;
-    };
-    int32_t rb = rounds ? (int32_t)((rounds - 1) & ~63u) : -64;
-    uint32_t w_next = fetch (rb);
-    for (; rb >= 0 && !overflow; rb -= 64) {
-        const uint32_t w_cur = w_next;
-        w_next = fetch (rb - 64);
-        const int32_t top = (int32_t)(rounds - 1 - (uint32_t)rb) < 63 ? (int32_t)(rounds - 1 - (uint32_t)rb) : 63;
-        for (int32_t i = top; i >= 0; i--) {
-            const uint32_t r = (uint32_t)rb + (uint32_t)i;
-            const bool mine = lane < 4 && r < len_k;
-            const uint32_t v = (uint32_t)__shfl ((int)w_cur, i);
-            GzRansSym s;
-            s.x_max = 0xffffffffu; s.rcp = 0; s.bias = 0; s.cmpl_rsh = 0;
-            if (mine) s = tsyms[(v >> (8 * (lane & 3))) & 0xff];
-            bool emit = mine && x >= s.x_max;
-            uint64_t m = __ballot (emit) & 0xfull;
-            uint32_t cnt = __popcll (m);
-            if (used + 2 * cnt + 16 > cap) { overflow = true; break; }
-            used += 2 * cnt;
-            if (emit) {
-                uint32_t below = __popcll (m & ((1ull << lane) - 1));
-                uint8_t *p = buf + cap - used + 2 * below;
-                p[0] = (uint8_t)x; p[1] = (uint8_t)(x >> 8);
-                x >>= 16;
-            }
-            if (mine) x = d_rans_advance (x, s);
-        }
-    }
-    if (overflow) return 0xffffffffu;
-    used += 16;
-    if (lane < 4) {
-        uint8_t *p = buf + cap - used + 4 * lane;
-        p[0] = (uint8_t)x; p[1] = (uint8_t)(x >> 8); p[2] = (uint8_t)(x >> 16); p[3] = (uint8_t)(x >> 24);
-    }
-    return used;
-}
-
 // order-0 frequency table + encoder records for `n` bytes whose histogram is in F (256 counters, clobbered).
 // Serial (one thread). Returns table length. rANS_static4x16pr.c:405-432
 __device__ static uint32_t d_o0_table (uint32_t *F, uint32_t n, uint8_t *tab, GzRansSym *syms)
@@ -556,6 +507,16 @@ __device__ static inline double d_log_from_bits (int v)   // rANS_static4x16pr.c
     return (double)(bits - 4606921278410026770LL) * 1.539095918623324e-16;
 }
 
+// -DGZ_TABLE_DEBUG: where a workgroup's time goes (thread 0's 100 MHz clock at the phase boundaries; sums and maxima over the launch's
+// order-1 workgroups, printed by gz_wait): 0 row totals, 1 compute_shift without 2, 2 its serial entropy sum, 3 rows (normalise,
+// serialise, records), 4 table assembly, 5 nested histogram + table, 6 nested coding, 7 the rest
+#ifdef GZ_TABLE_DEBUG
+__device__ unsigned long long g_tab_sum[9], g_tab_max[9];
+#define TAB_T(k) do { if (!tid) { const unsigned long long now_ = wall_clock64 (); ph_[k] += now_ - t_; t_ = now_; } } while (0)
+#else
+#define TAB_T(k) do { } while (0)
+#endif
+
 // one 256-thread workgroup per rANS leaf
 __global__ void __launch_bounds__(256) k_rans_table (GzdLeaf *leaves, const GzLogTable *logs)
 {
@@ -566,6 +527,9 @@ __global__ void __launch_bounds__(256) k_rans_table (GzdLeaf *leaves, const GzLo
     if (!n) { if (!tid) L.tab_len = 0; return; }
 
     uint32_t *lds = (uint32_t *)gz_lds;
+#ifdef GZ_TABLE_DEBUG
+    unsigned long long ph_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t_ = wall_clock64 ();
+#endif
 
     if (!L.o1) {
         lds[tid] = L.F[tid];
@@ -602,6 +566,7 @@ __global__ void __launch_bounds__(256) k_rans_table (GzdLeaf *leaves, const GzLo
         if (!lane) T[c] = t;
     }
     __syncthreads ();
+    TAB_T (0);
 
     // ---- compute_shift (rANS_static4x16pr.c:626-687). The entropy sums must be accumulated in the reference's
     //      order with the reference's roundings (fused e -= f*d, see oracle/gz_oracle.c o1_choose_bits): per row, thread k
@@ -618,26 +583,26 @@ __global__ void __launch_bounds__(256) k_rans_table (GzdLeaf *leaves, const GzLo
             const uint64_t m10 = __ballot (f && ratio > 1024), m12 = __ballot (f && ratio > 4096), mc = __ballot (f != 0);
             if (!lane) { shared[8 + wave] = (uint32_t)__popcll (m10) | ((uint32_t)__popcll (m12) << 10) | ((uint32_t)__popcll (mc) << 20); }
             __syncthreads ();
-            uint32_t b10 = 0, b12 = 0, cnt = 0;
-            for (int w = 0; w < 4; w++) { const uint32_t v = shared[8 + w]; b10 += v & 1023; b12 += (v >> 10) & 1023; cnt += v >> 20; }
-            cellF[tid] = f;
+            uint32_t b10 = 0, b12 = 0, cnt = 0, slot = 0;
+            for (int w = 0; w < 4; w++) { const uint32_t v = shared[8 + w]; b10 += v & 1023; b12 += (v >> 10) & 1023; if (w == wave) slot = cnt; cnt += v >> 20; }
             if (f) {
+                // (the row's non-empty cells close together, in symbol order: the sum below is one thread's, and the rows of a wide
+                //  order-1 table are mostly empty)
+                slot += (uint32_t)__popcll (mc & ((1ull << lane) - 1));
                 const double l10 = logs->l10[b10], l12 = logs->l12[b12];
                 int x10 = (int)(1024.0 * (double)f / (double)tc), x12 = (int)(4096.0 * (double)f / (double)tc);
-                cellD[2 * tid]     = d_log_from_bits (x10 > 1 ? x10 : 1) - l10;
-                cellD[2 * tid + 1] = d_log_from_bits (x12 > 1 ? x12 : 1) - l12;
+                cellF[slot] = f;
+                cellD[2 * slot]     = d_log_from_bits (x10 > 1 ? x10 : 1) - l10;
+                cellD[2 * slot + 1] = d_log_from_bits (x12 > 1 ? x12 : 1) - l12;
             }
             __syncthreads ();
+            TAB_T (1);
             if (!tid) {
-                // (selects instead of a branch per symbol, eight symbols' terms fetched at a time: this loop is one thread's, 65 536 times
-                //  round for a wide order-1 stream, and the only thing in flight)
-                #pragma unroll 8
-                for (uint32_t k = 0; k < ns; k++) {
-                    const uint32_t fk = cellF[k];
-                    const double d10 = cellD[2 * k], d12 = cellD[2 * k + 1];
-                    const double n10 = fma (-(double)fk, d10, e10) + 4.0, n12 = fma (-(double)fk, d12, e12) + 6.0;
-                    e10 = fk ? n10 : e10;
-                    e12 = fk ? n12 : e12;
+                #pragma unroll 4
+                for (uint32_t k = 0; k < cnt; k++) {
+                    const double fk = (double)cellF[k];
+                    e10 = fma (-fk, cellD[2 * k], e10) + 4.0;
+                    e12 = fma (-fk, cellD[2 * k + 1], e12) + 6.0;
                 }
                 if (cnt < 64 && cap > 128) cap /= 2;
                 if (cap > 1024)            cap /= 2;
@@ -645,11 +610,13 @@ __global__ void __launch_bounds__(256) k_rans_table (GzdLeaf *leaves, const GzLo
                 target[c] = cap;
                 if (cap > widest) widest = cap;
             }
+            TAB_T (2);
             __syncthreads ();
         }
         if (!tid) shared[0] = (e10 / e12 < 1.01 || widest <= 1024) ? 10 : 12;
     }
     __syncthreads ();
+    TAB_T (1);
     const uint32_t bits = shared[0];
 
     // ---- per row (a wave each; lane l owns symbols 4l..4l+3): normalise to the stored total (normalise_freq :113-160),
@@ -665,7 +632,7 @@ __global__ void __launch_bounds__(256) k_rans_table (GzdLeaf *leaves, const GzLo
         if (bits == 10 && tot > 1024) tot = 1024;
         uint32_t sum = T[c];
         for (int pass = 0; sum; pass++) {
-            const uint64_t mult = (((uint64_t)tot) << 31) / sum + (uint32_t)((1u << 30) / sum);
+            const uint64_t mult = d_div_u52 (((uint64_t)tot) << 31, sum) + (uint32_t)((1u << 30) / sum);
             uint32_t big = 0, big_at = 0, new_sum = 0;
             #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -707,22 +674,49 @@ __global__ void __launch_bounds__(256) k_rans_table (GzdLeaf *leaves, const GzLo
             fr[0] = wrow[4 * lane]; fr[1] = wrow[4 * lane + 1]; fr[2] = wrow[4 * lane + 2]; fr[3] = wrow[4 * lane + 3];
             break;
         }
-        // serialise: zero runs are "00, run-1" (:292-322); one lane walks the row in LDS
-        wrow[4 * lane] = fr[0]; wrow[4 * lane + 1] = fr[1]; wrow[4 * lane + 2] = fr[2]; wrow[4 * lane + 3] = fr[3];
-        gz_wave_sync ();
-        uint32_t len = 0;
-        if (!lane) {
-            uint32_t zeros = 0;
-            for (int s2 = 0; s2 <= 256; s2++) {
-                if (s2 < 256 && !present[s2]) continue;
-                if (s2 < 256 && !wrow[s2]) { zeros++; continue; }
-                if (zeros) { wbytes[len++] = 0; wbytes[len++] = (uint8_t)(zeros - 1); zeros = 0; }
-                if (s2 < 256) len += gz_vi_put (wbytes + len, wrow[s2]);
+        // serialise (:292-322): the counts of the present symbols in symbol order, a run of zero counts as "00, run-1" in front of the
+        // next non-zero one (or at the end of the row). Every lane places its own four symbols: Z = the number of zero counts (of present
+        // symbols) in front of a symbol is a prefix sum over the lanes, the Z of the last non-zero symbol before a lane a prefix maximum
+        // (Z never decreases), and the byte offsets a third prefix sum
+        uint32_t len;
+        {
+            uint32_t pz[4], zc = 0;
+            #pragma unroll
+            for (int j = 0; j < 4; j++) { pz[j] = (!fr[j] && present[4 * lane + j]) ? 1u : 0u; zc += pz[j]; }
+            uint32_t zin = zc;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl ((int)zin, lane - d < 0 ? 0 : lane - d); if (lane >= d) zin += o; }
+            const uint32_t z_all = (uint32_t)__shfl ((int)zin, 63);
+            uint32_t z = zin - zc, last = 0;              // z: zero counts in front of my first symbol; last: Z of my last non-zero symbol + 1 (0: none)
+            uint32_t zs[4];
+            #pragma unroll
+            for (int j = 0; j < 4; j++) { zs[j] = z; if (fr[j]) last = z + 1; z += pz[j]; }
+            uint32_t lin = last;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl ((int)lin, lane - d < 0 ? 0 : lane - d); if (lane >= d && o > lin) lin = o; }
+            const uint32_t last_all = (uint32_t)__shfl ((int)lin, 63);
+            uint32_t prev = (uint32_t)__shfl ((int)lin, lane ? lane - 1 : 0);
+            if (!lane) prev = 0;
+            prev = prev ? prev - 1 : 0;                   // Z of the last non-zero symbol in front of this lane (none: no zero counted yet)
+            uint32_t nb[4], run[4], mine = 0;
+            #pragma unroll
+            for (int j = 0; j < 4; j++) {
+                run[j] = 0; nb[j] = 0;
+                if (fr[j]) { run[j] = zs[j] - prev; prev = zs[j]; nb[j] = (run[j] ? 2u : 0u) + gz_vi_len (fr[j]); }
+                mine += nb[j];
             }
-            rowlen[c] = len;
+            uint32_t oin = mine;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl ((int)oin, lane - d < 0 ? 0 : lane - d); if (lane >= d) oin += o; }
+            len = (uint32_t)__shfl ((int)oin, 63);
+            uint32_t at = oin - mine;
+            #pragma unroll
+            for (int j = 0; j < 4; j++) if (fr[j]) {
+                if (run[j]) { wbytes[at++] = 0; wbytes[at++] = (uint8_t)(run[j] - 1); }
+                at += gz_vi_put (wbytes + at, fr[j]);
+            }
+            const uint32_t tail = z_all - (last_all ? last_all - 1 : 0);     // zero counts behind the row's last non-zero symbol
+            if (tail) { if (!lane) { wbytes[len] = 0; wbytes[len + 1] = (uint8_t)(tail - 1); } len += 2; }
+            if (!lane) rowlen[c] = len;
         }
         gz_wave_sync ();
-        len = (uint32_t)__shfl ((int)len, 0);
         for (uint32_t i = lane; i < len; i += 64) L.rowbuf[c * GZ_ROW_SLOT + i] = wbytes[i];
         // scale up to 1 << bits (normalise_freq_shift :165-177), cumulative starts, encoder records
         int sh = 0;
@@ -738,6 +732,7 @@ __global__ void __launch_bounds__(256) k_rans_table (GzdLeaf *leaves, const GzLo
         for (int j = 0; j < 4; j++) { rs[j] = d_rans_sym (cum, fr[j], bits); cum += fr[j]; }
     }
     __syncthreads ();
+    TAB_T (3);
     if (!tid) {
         uint32_t p = 0;
         L.tab[p++] = (uint8_t)(bits << 4);
@@ -752,6 +747,7 @@ __global__ void __launch_bounds__(256) k_rans_table (GzdLeaf *leaves, const GzLo
         for (uint32_t o = rowlen[tid], k = 0; o < end; o++, k++) L.tab[o] = srcb[k];
     }
     __syncthreads ();
+    TAB_T (4);
     uint32_t tab_len = shared[1];
 
     // ---- a table of more than 1000 bytes is itself order-0 coded if that saves at least 6 bytes (:779-792)
@@ -759,7 +755,7 @@ __global__ void __launch_bounds__(256) k_rans_table (GzdLeaf *leaves, const GzLo
         const uint32_t raw = tab_len - 1;
         const uint8_t *tin = L.tab + 1;
         uint32_t *h = lds;                            // reuse: [256] histogram
-        GzRansSym *tsyms = (GzRansSym *)(lds + 2048); // [256] records (4 KB) in LDS
+        GzRansSym *tsyms = (GzRansSym *)(lds + 2048); // [256] records (4 KB) in LDS while thread 0 builds them
         __syncthreads ();
         h[tid] = 0;
         __syncthreads ();
@@ -769,16 +765,25 @@ __global__ void __launch_bounds__(256) k_rans_table (GzdLeaf *leaves, const GzLo
         if (!tid) shared[2] = d_o0_table (h, raw, ttab, tsyms);
         __syncthreads ();
         const uint32_t ttab_len = shared[2];
+        TAB_T (5);
         uint8_t *tpay = L.rowbuf + 1024;
         const uint32_t tpay_cap = 256 * GZ_ROW_SLOT - 1024;
+        // (coded by the stream coder itself, d_rans_encode_wave with its look-ahead: its records come from global memory, so the 256
+        //  records go behind the row slots of rowbuf; a coder of its own with the records in LDS took 0.2 us per round - 2.6 of the 9 ms
+        //  of the slowest workgroup of a file's first call, measured inside the kernel)
+        GzRansSym *gsyms = (GzRansSym *)(L.rowbuf + 256 * GZ_ROW_SLOT);
+        gsyms[tid] = tsyms[tid];
+        __threadfence_block ();
+        __syncthreads ();
         if (tid < 64) {
             uint32_t len_k = (raw >> 2) + ((raw & 3) > (uint32_t)(tid & 3));
             uint32_t rounds = (raw + 3) >> 2;
-            // (the records of the nested coder live in LDS: copy them out for the wave's global-memory fetch path)
-            uint32_t plen = d_rans_encode_wave_lds (tid < 4 ? len_k : 0, rounds, tpay, tpay_cap, tsyms, tin, raw);
+            uint32_t plen = d_rans_encode_wave (tid < 4 ? len_k : 0, rounds, tpay, tpay_cap, (uint8_t *)(lds + 3072), gsyms,
+                                                [&] (int k, uint32_t r, uint32_t &hi, uint32_t &lo) { hi = 0; lo = gz_ldg_u8 (tin + 4 * r + k); });
             if (!tid) shared[3] = plen;
         }
         __syncthreads ();
+        TAB_T (6);
         const uint32_t plen = shared[3];
         if (plen != 0xffffffffu && ttab_len + plen + 6 < tab_len) {
             const uint32_t packed = ttab_len + plen;
@@ -797,6 +802,14 @@ __global__ void __launch_bounds__(256) k_rans_table (GzdLeaf *leaves, const GzLo
         }
     }
     if (!tid) { L.tab_len = tab_len; L.shift_bits = (uint8_t)bits; }
+    TAB_T (7);
+#ifdef GZ_TABLE_DEBUG
+    if (!tid) {
+        unsigned long long tot = 0;
+        for (int k = 0; k < 8; k++) { tot += ph_[k]; atomicAdd (&g_tab_sum[k], ph_[k]); atomicMax (&g_tab_max[k], ph_[k]); }
+        atomicAdd (&g_tab_sum[8], 1ull); atomicMax (&g_tab_max[8], tot);
+    }
+#endif
 }
 
 // ======================================================================================================

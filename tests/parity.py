@@ -1620,3 +1620,22 @@ def vcf_zip(E, oracle, n_lines, n_samples, n_calls=2):
             n_vb += 1
     F.close()
     return n_vb
+
+
+def rans_tables(E, oracle, scale=1.0):
+    """k_rans_table's rows: dense, sparse (Markov) and skewed order-1 tables of narrow to full alphabets - tables that are nested-coded
+    (> 1000 bytes, rANS_static4x16pr.c:779-792) and ones that are not, zero runs inside and at the end of a row, both shifts"""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    cases = []
+    for nsym, n in ((200, 300000), (256, 400000), (90, 120000), (17, 50000), (255, 70000), (3, 5000)):
+        n = max(64, int(n * scale))
+        cases.append(rng.integers(0, nsym, n).astype(np.uint8).tobytes())
+        cases.append((np.cumsum(rng.integers(0, 4, n)) % nsym).astype(np.uint8).tobytes())
+        cases.append(np.minimum(rng.geometric(0.05, n), nsym - 1).astype(np.uint8).tobytes())
+    for codec in (6, 7, 8, 9):
+        got = E.compress_many([(codec, d) for d in cases])
+        for i, (g, d) in enumerate(zip(got, cases)):
+            assert g == oracle.codec_compress(codec, d), (codec, i)
+        back = E.uncompress_many([(codec, g, len(d)) for g, d in zip(got, cases)])
+        assert all(b == d for b, d in zip(back, cases))

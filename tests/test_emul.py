@@ -180,3 +180,7 @@ def test_emul_sam_zip(emul_engine, oracle):
 def test_emul_vcf_zip(emul_engine, oracle):
     """N1 for VCF: configs[3] from text - 4 VBlocks over 2 calls through the per-sample plan == the oracle's composition"""
     assert parity.vcf_zip(emul_engine, oracle, 12, 40) == 4
+
+
+def test_emul_rans_tables(emul_engine, oracle):
+    parity.rans_tables(emul_engine, oracle, scale=0.25)

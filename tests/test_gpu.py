@@ -339,7 +339,7 @@ def test_streamed_file(gpu_engine, oracle):
     for call in range(3):
         if call:
             for t in wl.tab:
-                t.vblock_i += 2 * wl.n_pairs_file
+                t.vblock_i += len(wl.ranges)                # (R1 c*B+1.., R2 N+c*B+1..: the numbering bench.py streams with)
         zip_vblocks_sharded(F, None, wl.text, wl.text_len, wl.tab, n)
         z_all = [r["z"] for r in F.results(wl.tab)]
         vb_now = [(o, l, int(t.vblock_i), r1) for (o, l, _, r1), t in zip(wl.vb, wl.tab)]
@@ -355,3 +355,7 @@ def test_streamed_file(gpu_engine, oracle):
         words = w
     for t, v in zip(wl.tab, wl.vb):
         t.vblock_i = v[2]
+
+
+def test_rans_tables(gpu_engine, oracle):
+    parity.rans_tables(gpu_engine, oracle)
