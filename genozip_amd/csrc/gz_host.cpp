@@ -714,19 +714,9 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
 #ifdef GZ_SEQUENTIAL_STREAMS
                 if ((rc = arith_launch_chain (h, A, d_leaves)) != GZ_OK) return rc;
 #endif
-                // the `low` kernels of the long leaves follow the chain: a one-thread gate holds their stream until every
-                // leaf is through chunk k; count / scan / scatter of that chunk then run beside the chain's next chunk
-                HIPCHK (h, hipStreamWaitEvent (h->stream6, h->ev_model_fork, 0));
-                for (uint32_t k = 0; k < A.n_chunks; k++) {
-                    const uint32_t p0 = k * A.chunk, span = P.max_arith_n - p0 < A.chunk ? P.max_arith_n - p0 : A.chunk;
-                    const uint32_t wgs = (span + GZ_LOW_SLICE * GZ_LOW_SLICES_PER_WG - 1) / (GZ_LOW_SLICE * GZ_LOW_SLICES_PER_WG);
-                    hipLaunchKernelGGL (k_low_gate, dim3 (1), dim3 (1), 0, h->stream6, (const uint32_t *)(A.d_progress + 16 + k), A.nbig, h->d_fail);
-                    KLAUNCH_ON (h, h->stream6, k_chain_expand, dim3 (A.nbig, wgs), dim3 (64), 64 * 65 * 4, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0);
-                    KLAUNCH_ON (h, h->stream6, k_low_count, dim3 (A.nbig, wgs), dim3 (GZ_LOW_WG), GZ_KEEP_OFF_LDS, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0);
-                    KLAUNCH_ON (h, h->stream6, k_low_scan, dim3 (A.nbig), dim3 (1024), 8192, d_leaves, A.d_big, p0, A.chunk);
-                    KLAUNCH_ON (h, h->stream6, k_low_scatter, dim3 (A.nbig, wgs), dim3 (GZ_LOW_WG), GZ_KEEP_OFF_LDS, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0);
-                }
-                HIPCHK (h, hipEventRecord (h->ev_low, h->stream6));
+                // (the short leaves are queued BEFORE the gates below: streams share hardware queues, a gate spins until the chain is through
+                //  its chunk, and whatever is queued behind a gate in the same hardware queue waits with it - one VCF VBlock's 7.5 M-symbol
+                //  stripe planes, "short" next to a 30 M-entry b250, started 2.8 s late, after the long chain had finished)
                 if (A.nsmall) {
                     HIPCHK (h, hipStreamWaitEvent (h->stream5, h->ev_model_fork, 0));
                     if ((rc = sort_chunk (h->stream5, A.d_small, A.nsmall, 0u, 0xffffffffu, A.chunk)) != GZ_OK) return rc;
@@ -742,6 +732,19 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                     HIPCHK (h, hipEventRecord (h->ev_small, h->stream5));
                     HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_small, 0));
                 }
+                // the `low` kernels of the long leaves follow the chain: a one-thread gate holds their stream until every
+                // leaf is through chunk k; count / scan / scatter of that chunk then run beside the chain's next chunk
+                HIPCHK (h, hipStreamWaitEvent (h->stream6, h->ev_model_fork, 0));
+                for (uint32_t k = 0; k < A.n_chunks; k++) {
+                    const uint32_t p0 = k * A.chunk, span = P.max_arith_n - p0 < A.chunk ? P.max_arith_n - p0 : A.chunk;
+                    const uint32_t wgs = (span + GZ_LOW_SLICE * GZ_LOW_SLICES_PER_WG - 1) / (GZ_LOW_SLICE * GZ_LOW_SLICES_PER_WG);
+                    hipLaunchKernelGGL (k_low_gate, dim3 (1), dim3 (1), 0, h->stream6, (const uint32_t *)(A.d_progress + 16 + k), A.nbig, h->d_fail);
+                    KLAUNCH_ON (h, h->stream6, k_chain_expand, dim3 (A.nbig, wgs), dim3 (64), 64 * 65 * 4, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0);
+                    KLAUNCH_ON (h, h->stream6, k_low_count, dim3 (A.nbig, wgs), dim3 (GZ_LOW_WG), GZ_KEEP_OFF_LDS, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0);
+                    KLAUNCH_ON (h, h->stream6, k_low_scan, dim3 (A.nbig), dim3 (1024), 8192, d_leaves, A.d_big, p0, A.chunk);
+                    KLAUNCH_ON (h, h->stream6, k_low_scatter, dim3 (A.nbig, wgs), dim3 (GZ_LOW_WG), GZ_KEEP_OFF_LDS, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0);
+                }
+                HIPCHK (h, hipEventRecord (h->ev_low, h->stream6));
                 HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_chain, 0));
                 HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_low, 0));
             }
