@@ -122,11 +122,12 @@ class ZipFile:
     __del__ = close
 
     def vb_table(self, vbs):
-        """vbs: list of (text_off, text_len, vblock_i, r1 index or -1)"""
+        """vbs: list of (text_off, text_len, vblock_i, r1 index or -1[, flags: GZ_VB_LAST_OF_FILE = 1])"""
         from .lib import GzFastqVB
         tab = (GzFastqVB * len(vbs))()
-        for i, (off, ln, vi, r1) in enumerate(vbs):
-            tab[i].text_off, tab[i].text_len, tab[i].vblock_i, tab[i].r1 = off, ln, vi, r1
+        for i, t in enumerate(vbs):
+            tab[i].text_off, tab[i].text_len, tab[i].vblock_i, tab[i].r1 = t[:4]
+            tab[i].flags = t[4] if len(t) > 4 else 0
         return tab
 
     def zip_table(self, text_buf, text_len, tab, n):
@@ -247,22 +248,24 @@ class ZipFile:
         payload = sub_compress(packed, vb_size) if sub == 4 else packed
         return self.insert_section(r["z"], r["seq_section_index"], dict_id("NONREF"), 10, sub, 0 if r["seq_has_x"] else 0x40, 11, 0, payload, r["n_bases"])
 
-    def write_file(self, components, counts_ctxs=(), created=b"genozip_amd", vb_size=16 << 20, std_seq_len=0, std_seq_len_r2=0, vb_order=None):
-        """components: [dict(name=bytes, pair=0 | 1 | 2, vbs=[VBlock results in the order they are written, each with z, n_reads, text_len])]
+    def write_file(self, components, counts_ctxs=(), created=b"genozip_amd", vb_size=16 << 20, std_seq_len=0, std_seq_len_r2=0, vb_order=None, data_type=3):
+        """components: [dict(name=bytes, pair=0 | 1 | 2, vbs=[VBlock results in the order they are written, each with z, n_reads, text_len]
+        [, header=bytes: the component's header text (VCF / SAM), stored in its SEC_TXT_HEADER])]; data_type: DT_VCF 1, DT_SAM 2, DT_FASTQ 3
         -> the whole file: per component SEC_TXT_HEADER + its VBlocks (zfile_output_processed_vb), then zip_write_global_area (N4).
         vb_order = [(component, index into its vbs)]: the streamed form - both SEC_TXT_HEADERs first, then the VBlocks in the order the calls
         produced them (R1 and R2 VBlocks of a call next to each other)"""
         L, E = self.E.L, self.E
-        zf = L.gz_zfile_create(3, vb_size)                     # DT_FASTQ
+        zf = L.gz_zfile_create(data_type, vb_size)
         try:
             E._check(L.gz_zfile_set_fastq(zf, len(components), int(any(c.get("pair") for c in components)), std_seq_len, std_seq_len_r2), "gz_zfile_set_fastq")
             body = b""
             flav = bytes(8)                                    # QnameFlavorProp x NUM_QTYPES: no seq_len item, not mated, no cnn (Illumina-7, Illum-2bc)
             for ci, comp in enumerate(components):
-                hdr = C.create_string_buffer(400)
-                E._check(L.gz_zfile_add_txt_header(zf, ci, comp.get("pair", 0), comp["name"], sum(r["text_len"] for r in comp["vbs"]), sum(r["n_reads"] for r in comp["vbs"]),
-                                                   max([r["n_reads"] for r in comp["vbs"]] + [0]), flav, 4, len(body), hdr), "gz_zfile_add_txt_header")
-                body += hdr.raw
+                text = comp.get("header", b"")
+                hdr, hl = C.create_string_buffer(400 + len(text)), C.c_uint64(0)
+                E._check(L.gz_zfile_add_txt_header_text(zf, ci, comp.get("pair", 0), comp["name"], len(text) + sum(r["text_len"] for r in comp["vbs"]), sum(r["n_reads"] for r in comp["vbs"]),
+                                                        max([r["n_reads"] for r in comp["vbs"]] + [0]), flav, 4, len(body), text, len(text), hdr, len(hdr), C.byref(hl)), "gz_zfile_add_txt_header_text")
+                body += hdr.raw[:hl.value]
                 for r in comp["vbs"] if vb_order is None else ():
                     E._check(L.gz_zfile_add_vblock(zf, r["z"], len(r["z"]), len(body), ci, r["n_reads"]), "gz_zfile_add_vblock")
                     body += r["z"]
@@ -274,7 +277,7 @@ class ZipFile:
             zc = (C.c_void_p * n)(*[L.gz_zip_zctx(self.f, i) for i in range(n)])
             ids = b"".join(c["dict_id"] for c in self.plan["ctxs"])
             cs = bytes(int(i in counts_ctxs) for i in range(n))
-            recon = sum(r["text_len"] for comp in components for r in comp["vbs"])
+            recon = sum(r["text_len"] for comp in components for r in comp["vbs"]) + sum(len(comp.get("header", b"")) for comp in components)
             lines = sum(r["n_reads"] for comp in components for r in comp["vbs"])
             cap = 1 << 20
             while True:

@@ -75,21 +75,34 @@ extern "C" int gz_zfile_set_fastq (GzZFile *zf, uint8_t num_txt_files, uint8_t p
 // SEC_TXT_HEADER of a component without header text (FASTQ): txtheader_compress (src/txtheader.c:65-111: one fragment, vblock_i = 1, written
 // even when empty :40-41; the codec of < 50 bytes is NONE) with the fields zfile_update_txt_header_section_header fills in when the component
 // is through (src/zfile.c:1068-1105). 400 bytes (src/sections.h:308-327)
-extern "C" int gz_zfile_add_txt_header (GzZFile *zf, uint8_t comp_i, uint8_t pair, const char *txt_filename, uint64_t txt_data_size, uint64_t txt_num_lines,
-                                        uint32_t max_lines_per_vb, const uint8_t *flav_prop, uint32_t n_flav_prop, uint64_t file_offset, uint8_t *out)
+// with the component's header text (VCF: the ## lines and #CHROM; SAM: the @ lines) as the section's payload, stored (CODEC_NONE): the
+// reference compresses it with whatever codec_assign_best_codec finds (txtheader_compress, src/txtheader.c:46-111); the reader takes any
+extern "C" int gz_zfile_add_txt_header_text (GzZFile *zf, uint8_t comp_i, uint8_t pair, const char *txt_filename, uint64_t txt_data_size, uint64_t txt_num_lines,
+                                             uint32_t max_lines_per_vb, const uint8_t *flav_prop, uint32_t n_flav_prop, uint64_t file_offset,
+                                             const uint8_t *header_text, uint32_t header_len, uint8_t *out, uint64_t out_cap, uint64_t *out_len)
 {
-    if (!zf || !out || pair > 2 || n_flav_prop > 4 || (n_flav_prop && !flav_prop)) return GZ_ERR_ARG;
+    if (!zf || !out_len || pair > 2 || n_flav_prop > 4 || (n_flav_prop && !flav_prop) || (header_len && !header_text)) return GZ_ERR_ARG;
+    *out_len = (uint64_t)GZ_TXT_HEADER_LEN + header_len;
+    if (!out || out_cap < *out_len) return GZ_TOO_SMALL;
     memset (out, 0, GZ_TXT_HEADER_LEN);
-    gz_be32 (out, 0x27052012u); gz_be32 (out + 4, 1 /* adler32 of no payload */); gz_be32 (out + 20, 1);
+    gz_be32 (out, 0x27052012u); gz_be32 (out + 4, gz_host_adler32 (header_text, header_len)); gz_be32 (out + 12, header_len); gz_be32 (out + 16, header_len); gz_be32 (out + 20, 1);
     out[24] = GZ_SEC_TXT_HEADER; out[25] = GZ_CODEC_NONE; out[27] = pair;                          // FlagsTxtHeader.pair (fastq_zip_set_txt_header_flags)
     gz_be64 (out + 28, txt_data_size); gz_be64 (out + 36, txt_num_lines); gz_be32 (out + 44, max_lines_per_vb);
     out[48] = GZ_CODEC_NONE;                                                                       // src_codec: plain text
     if (txt_filename) strncpy ((char *)out + 84, txt_filename, 255);
+    gz_be64 (out + 340, header_len);                                                               // txt_header_size
     for (uint32_t q = 0; q < n_flav_prop; q++) { out[348 + 2 * q] = flav_prop[2 * q]; out[349 + 2 * q] = flav_prop[2 * q + 1]; }
+    if (header_len) memcpy (out + GZ_TXT_HEADER_LEN, header_text, header_len);
     GzSecEnt e; memset (&e, 0, sizeof (e));
-    e.offset = file_offset; e.size = GZ_TXT_HEADER_LEN; e.vblock_i = 1; e.st = GZ_SEC_TXT_HEADER; e.comp_i = comp_i; e.flags = pair;
+    e.offset = file_offset; e.size = (uint32_t)*out_len; e.vblock_i = 1; e.st = GZ_SEC_TXT_HEADER; e.comp_i = comp_i; e.flags = pair;
     zf->list.push_back (e);
     return GZ_OK;
+}
+extern "C" int gz_zfile_add_txt_header (GzZFile *zf, uint8_t comp_i, uint8_t pair, const char *txt_filename, uint64_t txt_data_size, uint64_t txt_num_lines,
+                                        uint32_t max_lines_per_vb, const uint8_t *flav_prop, uint32_t n_flav_prop, uint64_t file_offset, uint8_t *out)
+{
+    uint64_t n = 0;
+    return gz_zfile_add_txt_header_text (zf, comp_i, pair, txt_filename, txt_data_size, txt_num_lines, max_lines_per_vb, flav_prop, n_flav_prop, file_offset, NULL, 0, out, out ? GZ_TXT_HEADER_LEN : 0, &n);
 }
 
 // a section made on the host (NONREF: the sub-codec of CODEC_ACGT is the host's) into a finished VBlock

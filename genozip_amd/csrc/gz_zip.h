@@ -68,12 +68,22 @@ struct ZipMergeRec {
 };
 // qual: bit 0 the VBlock's QUAL was tested, bit 1 it is a fit for DOMQ (codec_domq.c:69-134), bit 2 a score outside ' '..'~'
 struct ZipBlobVB { uint32_t vblock_i, r1_vblock_i, n_ctx, qual; };   // then n_ctx x (ZipMergeRec + payload)
-// is_local: 0 b250, 1 local; | 2: the VBlock is too small to set the file's codec (codec.c:352) - its choice holds for itself only
+// is_local: 0 b250, 1 local; | 2: the VBlock does not set the file's codec (too small, codec.c:352; VBlock 1 of a context whose beginning
+// may not be representative, :358-362) - its choice holds for itself only; | 4: VBlock 10's second look (RETEST_VB_I, :274-277), which
+// replaces the file's codec from that VBlock on
 struct ZipVote { uint32_t ctx, is_local, vblock_i, codec; };
 static inline bool zip_vb_commits (const GzFastqPlan &plan, const GzFastqVB &vb)
 {
     return !plan.vb_size || vb.text_len > std::min<uint64_t> ((uint64_t)4 << 20, plan.vb_size / 2);
 }
+
+// src/codec.c:199-209 for a context of this plan
+static inline bool zip_not_representative (const GzFastqPlan &plan, const GzFastqCtx &X)
+{
+    const uint32_t t = X.dict_id[0] >> 6;                                 // 0 field, 1 DTYPE_2, 2 / 3 DTYPE_1 (src/dict_id.h:15-17)
+    return (plan.vb_1_not_representative >> (t == 0 ? 0 : t == 1 ? 2 : 1)) & 1;
+}
+#define ZIP_RETEST_VB_I 10u            // src/codec.c:22
 
 struct ZipVBState { std::vector<uint8_t> has_b250, has_local; std::vector<std::vector<uint8_t>> host_b250; };
 struct ZipDomq { uint8_t *out[4] = { NULL, NULL, NULL, NULL }; GzDomqResult res; uint32_t fit = 0; std::vector<uint8_t> snip; };   // one VBlock's QUAL through k_domq
@@ -1336,6 +1346,7 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
         std::vector<const uint8_t *> ptr; std::vector<uint32_t> len; std::vector<ZipVote> who;
         bool need = false;
         for (uint32_t c = 0; c < NC; c++) { GzZctxView zv; gz_zctx_view (f->zctx[c], &zv); if (!zv.lcodec || !zv.bcodec) need = true; }
+        if (f->plan.vb_1_not_representative) for (uint32_t v = 0; v < NV; v++) if (vbs[v].vblock_i == ZIP_RETEST_VB_I) need = true;
         if (need || K.spec_pending) {
             std::vector<uint32_t> seclen (2 * (size_t)NV * NC);
             HIPCHK (h, hipMemcpyAsync (seclen.data (), K.d_seclen, seclen.size () * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1373,13 +1384,32 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
                         if (is_local && Z.has_local) { p = Z.local; L = Z.dyn_job >= 0 && !Z.host_len ? seclen[2 * ((size_t)v * NC + c)] : (uint32_t)Z.local_len; }
                         if (!is_local && Z.has_b250) { p = Z.sec_b250; L = Z.col_job >= 0 ? seclen[2 * ((size_t)v * NC + c) + 1] : Z.sec_b250_len; }
                         if (L < 50) continue;
-                        // a VBlock too small to speak for the file keeps its choice to itself, and the next one tests again (codec.c:352)
-                        const bool commits = zip_vb_commits (f->plan, vbs[v]);
+                        // a VBlock too small to speak for the file keeps its choice to itself, and the next one tests again (codec.c:352); so
+                        // does VBlock 1 for the local of a context whose beginning may not be representative (:358-362)
+                        const bool commits = zip_vb_commits (f->plan, vbs[v]) &&
+                                             (!is_local || !zip_not_representative (f->plan, f->ctxs[c]) || vbs[v].vblock_i > 1 || (vbs[v].flags & GZ_VB_LAST_OF_FILE));
                         ptr.push_back (p); len.push_back (L); who.push_back ({ c, is_local | (commits ? 0u : 2u), vbs[v].vblock_i, 0 });
                         if (commits) break;
                     }
                 }
             }
+            // RETEST_VB_I (codec.c:274-277): VBlock 10 looks again at the contexts whose first VBlocks may not have been representative
+            if (f->plan.vb_1_not_representative)
+                for (uint32_t v = 0; v < NV; v++) if (vbs[v].vblock_i == ZIP_RETEST_VB_I)
+                    for (uint32_t c = 0; c < NC; c++) if (zip_not_representative (f->plan, f->ctxs[c]))
+                        for (uint32_t is_local = 0; is_local < 2; is_local++) {
+                            if (is_local ? f->ctxs[c].lcodec : f->ctxs[c].bcodec) continue;              // (hard-coded)
+                            bool tested = false;                                                         // (nothing in the file yet: tested above)
+                            for (const ZipVote &w : who) if (w.ctx == c && (w.is_local & 1) == is_local && w.vblock_i == ZIP_RETEST_VB_I) tested = true;
+                            for (const ZipVote &w : K.votes) if (w.ctx == c && (w.is_local & 1) == is_local && w.vblock_i == ZIP_RETEST_VB_I) tested = true;
+                            if (tested) continue;
+                            ZipCol &Z = COL (v, c);
+                            uint32_t L = 0; const uint8_t *p = NULL;
+                            if (is_local && Z.has_local) { p = Z.local; L = Z.dyn_job >= 0 && !Z.host_len ? seclen[2 * ((size_t)v * NC + c)] : (uint32_t)Z.local_len; }
+                            if (!is_local && Z.has_b250) { p = Z.sec_b250; L = Z.col_job >= 0 ? seclen[2 * ((size_t)v * NC + c) + 1] : Z.sec_b250_len; }
+                            if (L < 50) continue;                                                        // (too short to test: :309-312, the file's codec stays)
+                            ptr.push_back (p); len.push_back (L); who.push_back ({ c, is_local | 4u | (zip_vb_commits (f->plan, vbs[v]) ? 0u : 2u), vbs[v].vblock_i, 0 });
+                        }
             std::vector<int> best;
             if ((rc = zip_assign_best_many (h, f, ptr, len, best)) != GZ_OK) return rc;
             for (size_t k = 0; k < who.size (); k++) if (best[k]) { who[k].codec = (uint32_t)best[k]; K.votes.push_back (who[k]); }
@@ -1422,8 +1452,8 @@ static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint
             if (votes_lens[b] % sizeof (ZipVote)) { h->err = "votes: size"; return GZ_ERR_ARG; }
             const ZipVote *vt = (const ZipVote *)votes[b];
             for (size_t k = 0; k < votes_lens[b] / sizeof (ZipVote); k++) {
-                if (vt[k].ctx >= NC || vt[k].is_local > 3) { h->err = "votes: context"; return GZ_ERR_ARG; }
-                if (vt[k].is_local & 2) continue;                         // (a small VBlock's own choice: below)
+                if (vt[k].ctx >= NC || vt[k].is_local > 7) { h->err = "votes: context"; return GZ_ERR_ARG; }
+                if (vt[k].is_local & 6) continue;                         // (a VBlock's own choice, VBlock 10's second look: below)
                 auto key = std::make_pair (vt[k].ctx, vt[k].is_local);
                 auto it = win.find (key);
                 if (it == win.end () || vt[k].vblock_i < it->second.vblock_i) win[key] = vt[k];
@@ -1440,9 +1470,19 @@ static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint
         }
         for (int b = 0; b < n_votes; b++) {
             const ZipVote *vt = (const ZipVote *)votes[b];
-            for (size_t k = 0; k < votes_lens[b] / sizeof (ZipVote); k++) if (vt[k].is_local & 2)
+            for (size_t k = 0; k < votes_lens[b] / sizeof (ZipVote); k++) if ((vt[k].is_local & 6) == 2)
                 for (uint32_t v = 0; v < NV; v++) if (vbs[v].vblock_i == vt[k].vblock_i) {
                     ZipCol &Z = COL (v, vt[k].ctx); if (vt[k].is_local & 1) { if (!Z.lcodec) Z.lcodec = (uint8_t)vt[k].codec; } else if (!Z.bcodec) Z.bcodec = (uint8_t)vt[k].codec; }
+        }
+        // VBlock 10's second look replaces whatever the file had, for itself and - unless it is a small VBlock - for everything behind it
+        for (int b = 0; b < n_votes; b++) {
+            const ZipVote *vt = (const ZipVote *)votes[b];
+            for (size_t k = 0; k < votes_lens[b] / sizeof (ZipVote); k++) if (vt[k].is_local & 4) {
+                const bool sets = !(vt[k].is_local & 2), loc = vt[k].is_local & 1;
+                if (sets) gz_zctx_commit_codec (f->zctx[vt[k].ctx], (int)loc, (int)vt[k].codec);
+                for (uint32_t v = 0; v < NV; v++) if (sets ? vbs[v].vblock_i >= vt[k].vblock_i : vbs[v].vblock_i == vt[k].vblock_i) {
+                    ZipCol &Z = COL (v, vt[k].ctx); (loc ? Z.lcodec : Z.bcodec) = (uint8_t)vt[k].codec; }
+            }
         }
     }
     K.V.assign (NV, GzVBlock ()); K.secs.assign (NV, std::vector<GzSection> ());

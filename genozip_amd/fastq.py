@@ -27,6 +27,7 @@ CON_PX_SEP = 4                                                                  
 CI0_COLONn = 8                                                                          # src/container.h:41
 # Container flag bits (src/container.h:81-90, the byte behind nitems_lo)
 CON_FILTER_REPEATS, CON_FILTER_ITEMS, CON_IS_TOPLEVEL, CON_CALLBACK = 1 << 2, 1 << 3, 1 << 4, 1 << 6
+CON_DROP_FINAL_REPSEP = 1 << 1
 
 
 def dict_id(tag, dtype=DTYPE_FIELD):
@@ -131,6 +132,7 @@ def c_plan(plan):
     p.qual_codec = plan.get("qual_codec", 0)
     p.vb_size = plan.get("vb_size", 0)
     p.line3_empty = plan.get("line3_empty", 0)
+    p.vb_1_not_representative = plan.get("vb_1_not_representative", 0)
     p.record_lines, p.seq_item, p.qual_item = plan.get("record_lines", 0), plan.get("seq_item", 0), plan.get("qual_item", 0)
     p.n_samples, p.n_subfields = plan.get("n_samples", 0), plan.get("n_subfields", 0)
     return p, keep

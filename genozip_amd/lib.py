@@ -118,13 +118,14 @@ class GzFastqCtx(C.Structure):
 class GzFastqPlan(C.Structure):
     _fields_ = [("ctxs", C.POINTER(GzFastqCtx)), ("n_ctxs", C.c_uint32), ("seps", C.c_char * 16), ("sep_counts", C.c_uint8 * 16),
                 ("n_seps", C.c_uint32), ("paired", C.c_uint8), ("estimated_entries", C.c_uint32), ("qual_codec", C.c_uint8), ("vb_size", C.c_uint64),
-                ("record_lines", C.c_uint8), ("seq_item", C.c_uint8), ("qual_item", C.c_uint8), ("n_samples", C.c_uint32), ("n_subfields", C.c_uint8), ("line3_empty", C.c_uint8)]
+                ("record_lines", C.c_uint8), ("seq_item", C.c_uint8), ("qual_item", C.c_uint8), ("n_samples", C.c_uint32), ("n_subfields", C.c_uint8), ("line3_empty", C.c_uint8),
+                ("vb_1_not_representative", C.c_uint8)]
 
 
 class GzFastqVB(C.Structure):
     _fields_ = [("text_off", C.c_uint64), ("text_len", C.c_uint64), ("vblock_i", C.c_uint32), ("r1", C.c_int32), ("n_reads", C.c_uint32),
                 ("status", C.c_int32), ("z_data", C.c_void_p), ("z_len", C.c_uint64), ("seq_packed", C.c_void_p), ("seq_packed_len", C.c_uint64),
-                ("n_bases", C.c_uint64), ("seq_has_x", C.c_uint32), ("n_sections", C.c_uint32), ("seq_section_index", C.c_uint32), ("reserved", C.c_uint32)]
+                ("n_bases", C.c_uint64), ("seq_has_x", C.c_uint32), ("n_sections", C.c_uint32), ("seq_section_index", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class GzSecOrderIn(C.Structure):
@@ -152,7 +153,7 @@ ABI_SYMBOLS = (
     "gz_zip_reset", "gz_fastq_zip_collect",
     "gz_domq_columns", "gz_domq_fit", "gz_codec_compress_lines_host", "gz_byte_index", "gz_vcf_sample_columns", "gz_fastq_zip_begin", "gz_fastq_zip_end", "gz_zip_speculation",
     "gz_zfile_create", "gz_zfile_destroy", "gz_zfile_add_vblock", "gz_zfile_write_global_area", "gz_codec_assign_best_host",
-    "gz_zfile_add_txt_header", "gz_zfile_set_fastq", "gz_vb_insert_section",
+    "gz_zfile_add_txt_header", "gz_zfile_add_txt_header_text", "gz_zfile_set_fastq", "gz_vb_insert_section",
     "gz_tokenize_column_n", "gz_int_columns", "gz_local_generate_batch", "gz_acgt_pack_batch",
 )
 
@@ -256,6 +257,8 @@ def load(path=None):
                                              C.c_char_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.gz_codec_assign_best_host.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
     L.gz_zfile_add_txt_header.argtypes = [C.c_void_p, C.c_uint8, C.c_uint8, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint64, C.c_char_p]
+    L.gz_zfile_add_txt_header_text.argtypes = [C.c_void_p, C.c_uint8, C.c_uint8, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint64,
+                                               C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.gz_zfile_set_fastq.argtypes = [C.c_void_p, C.c_uint8, C.c_uint8, C.c_uint32, C.c_uint32]
     L.gz_vb_insert_section.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_char_p, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint8, C.c_char_p, C.c_uint32,
                                        C.c_uint32, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]

@@ -19,7 +19,7 @@ How each field reaches its context follows the reference's segmenter where the d
   optional      one textual item (the reference segs every tag into a context of its own: not built)
 What is NOT the reference's: the TOPLEVEL / QNAME containers of this plan are built in the reference's container FORMAT but are this
 repo's own choice of items (the reference's SAM reconstruction logic - sam_piz.c, buddies, MD / NM prediction - is out of scope), so a
-file made with this plan is not offered to genounzip; parity for this plan = the oracle's composition (tests/parity.py)."""
+file made with this plan is not offered to genounzip; parity for this plan: the CPU restatement's composition in tests/parity.py."""
 from .fastq import (dict_id, container, container_snip, DTYPE_FIELD, DTYPE_1, STORE_INT, SNIP_SELF_DELTA, SNIP_SPECIAL, FASTQ_SPECIAL_unaligned_SEQ, CON_PX_SEP, CI0_COLONn,
                     CON_FILTER_REPEATS, CON_FILTER_ITEMS, CON_IS_TOPLEVEL, CON_CALLBACK)
 from .lib import (GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL, GZ_FQ_QUAL_AUX, GZ_FQ_TOPLEVEL, GZ_FQ_SEQ_SNIP)
@@ -59,5 +59,5 @@ def sam_plan(has_aux=True, qual_codec=0, estimated_entries=0, domq=0, vb_size=0)
     P.sort(key=lambda c: c["did_i"])
     seps = b"::::" + b"\t" * (11 if has_aux else 10)
     counts = [3, 1, 1, 1] + [1] * (11 if has_aux else 10)
-    return dict(ctxs=P, seps=seps, sep_counts=counts, paired=False, estimated_entries=estimated_entries, qual_codec=domq, vb_size=vb_size, line3_empty=0,
+    return dict(ctxs=P, seps=seps, sep_counts=counts, paired=False, estimated_entries=estimated_entries, qual_codec=domq, vb_size=vb_size, line3_empty=0, vb_1_not_representative=0b100,
                 record_lines=1, seq_item=13, qual_item=14)

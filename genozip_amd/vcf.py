@@ -18,8 +18,8 @@ How each field reaches its context (SURVEY 8(0), row configs[3], as far as the d
                 snips over two dictionaries by the sample's dosage: not built - one dictionary here)
 The TOPLEVEL / samples containers are built in the reference's container FORMAT but are this repo's own choice of items (the reference's
 VCF reconstruction - vcf_piz.c, FORMAT-driven sample containers - is out of scope): a file made with this plan is not offered to
-genounzip; parity = the oracle's composition (tests/parity.py::vcf_zip)."""
-from .fastq import (dict_id, container, DTYPE_FIELD, DTYPE_2, STORE_INT, SNIP_SELF_DELTA, CON_FILTER_REPEATS, CON_FILTER_ITEMS, CON_IS_TOPLEVEL, CON_CALLBACK)
+genounzip; parity: the CPU restatement's composition, tests/parity.py::vcf_zip."""
+from .fastq import (dict_id, container, DTYPE_FIELD, DTYPE_2, STORE_INT, SNIP_SELF_DELTA, CON_FILTER_REPEATS, CON_FILTER_ITEMS, CON_IS_TOPLEVEL, CON_CALLBACK, CON_DROP_FINAL_REPSEP)
 from .lib import (GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_TOPLEVEL)
 
 
@@ -37,11 +37,11 @@ def vcf_plan(n_samples, estimated_entries=0, vb_size=0):
     ctx("GT", 20, GZ_FQ_ITEM_TEXT, DTYPE_2, item=0, per_sample=1)
     ctx("DP", 21, GZ_FQ_ITEM_INT, DTYPE_2, item=1, per_sample=1, transposed=1)
     ctx("PL", 22, GZ_FQ_ITEM_TEXT, DTYPE_2, item=2, per_sample=1)
-    smp = container([(dict_id("GT", DTYPE_2), b":"), (dict_id("DP", DTYPE_2), b":"), (dict_id("PL", DTYPE_2), b"")], repeats=n_samples, repsep=b"\t\0")
+    smp = container([(dict_id("GT", DTYPE_2), b":"), (dict_id("DP", DTYPE_2), b":"), (dict_id("PL", DTYPE_2), b"")], repeats=n_samples, repsep=b"\t\0", flags=CON_DROP_FINAL_REPSEP)   # (vcf_samples.c:1267)
     ctx("SAMPLES", 30, GZ_FQ_CONST, snip=b"\x04" + __import__("base64").b64encode(smp))
     top = container([(dict_id(t), b"\t") for t, _ in fixed] + [(dict_id("SAMPLES"), b""), (dict_id("EOL"), b"")],
                     flags=CON_FILTER_REPEATS | CON_FILTER_ITEMS | CON_IS_TOPLEVEL | CON_CALLBACK)
     ctx("TOPLEVEL", 40, GZ_FQ_TOPLEVEL, snip=top, con_len=len(top))
     ctx("EOL", 41, GZ_FQ_CONST, snip=b"\n")
-    return dict(ctxs=P, seps=b"\t" * 9, sep_counts=[1] * 9, paired=False, estimated_entries=estimated_entries, qual_codec=0, vb_size=vb_size, line3_empty=0,
+    return dict(ctxs=P, seps=b"\t" * 9, sep_counts=[1] * 9, paired=False, estimated_entries=estimated_entries, qual_codec=0, vb_size=vb_size, line3_empty=0, vb_1_not_representative=0b110,
                 record_lines=1, seq_item=0, qual_item=0, n_samples=n_samples, n_subfields=3)

@@ -484,6 +484,12 @@ typedef struct {
     uint8_t  n_subfields;
     uint8_t  line3_empty;         /* segconf.line3 == L3_EMPTY: line 3 is "+" alone, takes no context (the '+' is a prefix of the TOPLEVEL
                                      container) and anything else there is an error (fastq_seg_LINE3, src/fastq_desc.c:33-37)          */
+    uint8_t  vb_1_not_representative;   /* DTP (vb_1_not_representative) of the data type (src/data_types.h:57,148-152: VCF 0b110, SAM / BAM 0b100,
+                                     FASTQ 0): bit 0 field contexts, bit 1 DTYPE_1, bit 2 DTYPE_2 (dict_id[0] >> 6: 0, 2 or 3, 1; src/dict_id.h:
+                                     15-17). The beginning of such a file may not speak for the rest (src/codec.c:199-209), so for these contexts
+                                     VBlock 1 does not set the file's LOCAL codec unless it is its file's last (:358-362), and VBlock 10 tests
+                                     local and b250 again and sets what it finds (RETEST_VB_I, :22,274-277) - contexts with a codec given
+                                     in the plan excepted                                                                              */
 } GzFastqPlan;
 typedef struct {
     uint64_t text_off, text_len;  /* in: the VBlock's slice of the text: whole reads                                      */
@@ -496,8 +502,9 @@ typedef struct {
     uint64_t n_bases; uint32_t seq_has_x; uint32_t n_sections;
     uint32_t seq_section_index;   /* out: where among the VBlock's sections (0 = right behind the VB header) the NONREF local section
                                      belongs (a15) once the host's sub-codec has made it: gz_vb_insert_section                      */
-    uint32_t reserved;
+    uint32_t flags;               /* in: GZ_VB_LAST_OF_FILE                                                                */
 } GzFastqVB;
+#define GZ_VB_LAST_OF_FILE 1u     /* vb->is_last_vb_in_txt_file (src/codec.c:361; only looked at with vb_1_not_representative)         */
 typedef struct GzZipFile GzZipFile;   /* z_file for this path: the file-level contexts and committed codecs */
 GzZipFile *gz_zip_open (GzHandle *h, const GzFastqPlan *plan);
 void       gz_zip_close (GzZipFile *f);
@@ -596,6 +603,11 @@ int gz_codec_assign_best_host (GzHandle *h, const uint8_t *in_host, uint32_t in_
 #define GZ_TXT_HEADER_LEN 400
 int gz_zfile_add_txt_header (GzZFile *zf, uint8_t comp_i, uint8_t pair, const char *txt_filename, uint64_t txt_data_size, uint64_t txt_num_lines,
                              uint32_t max_lines_per_vb, const uint8_t *flav_prop, uint32_t n_flav_prop, uint64_t file_offset, uint8_t *out_host);
+/* the same for a component WITH header text (VCF: ## lines and #CHROM, SAM: @ lines): the text is the section's payload, stored (CODEC_NONE);
+ * txt_data_size counts it. out_host: GZ_TXT_HEADER_LEN + header_len bytes (GZ_TOO_SMALL: *out_len says how many) */
+int gz_zfile_add_txt_header_text (GzZFile *zf, uint8_t comp_i, uint8_t pair, const char *txt_filename, uint64_t txt_data_size, uint64_t txt_num_lines,
+                                  uint32_t max_lines_per_vb, const uint8_t *flav_prop, uint32_t n_flav_prop, uint64_t file_offset,
+                                  const uint8_t *header_text, uint32_t header_len, uint8_t *out_host, uint64_t out_cap, uint64_t *out_len);
 /* What the reader needs of the file as a whole that is not in the sections (SectionHeaderGenozipHeader, src/sections.h:169-300):
  * set before gz_zfile_write_global_area. paired: the file holds an R1 / R2 pair (z_flags.dt_specific, v14_is_paired);
  * std_seq_len / std_seq_len_r2: segconf.std_seq_len, std_seq_lR2 (longest SEQ of the sampled reads, src/fastq.c:711) */

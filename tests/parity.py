@@ -627,6 +627,8 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
     import base64
     C = plan["ctxs"]
     NC = len(C)
+    vb_flags = [t[4] if len(t) > 4 else 0 for t in vbs]     # GZ_VB_LAST_OF_FILE
+    vbs = [tuple(t[:4]) for t in vbs]
     aux = {X["item"]: c for c, X in enumerate(C) if X["kind"] == GZ_FQ_QUAL_AUX}
     if zstate is None:
         zstate = dict(z=[po.OracleZctx(oracle, plan["estimated_entries"]) for _ in C], lcodec=[c["lcodec"] for c in C], bcodec=[c["bcodec"] for c in C], flags_vb1=[0] * NC,
@@ -803,17 +805,32 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
     # VBlock ("don't let tiny VBs set the codec for everyone"); else nothing (-> RANB in the header, zfile.c:300,337)
     vb_size = plan.get("vb_size", 0)
     vcodec = {}                                            # (VBlock, context, is_local) -> codec
+    nr_bits = plan.get("vb_1_not_representative", 0)       # codec.c:199-209: bit 0 fields, bit 1 DTYPE_1, bit 2 DTYPE_2 (dict_id.h:15-17)
     for c, X in enumerate(C):
+        t = X["dict_id"][0] >> 6
+        nr = (nr_bits >> (0 if t == 0 else 2 if t == 1 else 1)) & 1
         for is_local in (1, 0):
             key = "lcodec" if is_local else "bcodec"
+            hard = X["lcodec"] if is_local else X["bcodec"]
             for v, (off, ln, vi, r1) in enumerate(vbs):
                 st = S[v][c]
                 data = st["local"] if is_local else st.get("b250", b"")
-                if zstate[key][c]:
+                testable = (st["has_local"] if is_local else st["has_b250"]) and len(data) >= 50
+                sets = not vb_size or ln > min(4 << 20, vb_size // 2)
+                if vi == 10 and nr and not hard:           # RETEST_VB_I (codec.c:22,274-277): a second look, whatever the file has
+                    if testable:
+                        vcodec[(v, c, is_local)] = oracle.assign_best(data)[0]
+                        if sets:
+                            zstate[key][c] = vcodec[(v, c, is_local)]
+                    else:                                  # (too short to test: NONE for this section, the file keeps what it has)
+                        vcodec[(v, c, is_local)] = zstate[key][c]
+                elif zstate[key][c]:
                     vcodec[(v, c, is_local)] = zstate[key][c]
-                elif (st["has_local"] if is_local else st["has_b250"]) and len(data) >= 50:
+                elif testable:
                     vcodec[(v, c, is_local)] = oracle.assign_best(data)[0]
-                    if not vb_size or ln > min(4 << 20, vb_size // 2):
+                    # (VBlock 1 does not set the LOCAL codec of a context whose beginning may not be representative, unless it is the
+                    #  file's last: codec.c:358-362)
+                    if sets and (not is_local or vi > nr or vb_flags[v] & 1):
                         zstate[key][c] = vcodec[(v, c, is_local)]
                 else:
                     vcodec[(v, c, is_local)] = 0
@@ -1570,8 +1587,9 @@ def sam_zip(E, oracle, n_reads, n_calls=2, qual="bin", aux=True):
     return n_vb
 
 
-def vcf_full_text(n_lines, n_samples, seed=5):
-    """data lines of a multi-sample VCF in the shape of BASELINE configs[3] (FORMAT GT:DP:PL, every sample complete; no header lines)"""
+def vcf_full_text(n_lines, n_samples, seed=5, flat=False):
+    """data lines of a multi-sample VCF in the shape of BASELINE configs[3] (FORMAT GT:DP:PL, every sample complete; no header lines).
+    flat: nearly constant depths and genotypes - other statistics than the default, for the codec re-test of VBlock 10"""
     r = synth.u32(seed, n_lines * (n_samples + 6) + 16).astype(np.int64)
     lines, pos, k = [], 10000, 0
     for l in range(n_lines):
@@ -1584,6 +1602,8 @@ def vcf_full_text(n_lines, n_samples, seed=5):
             v = int(r[k]); k += 1
             dp = 10 + v % 50
             g = (0, 0, 0, 1, 2, 1)[v % 6]
+            if flat:
+                dp, g = 30, int(v % 61 == 0)
             samples.append(b"%s:%d:%d,%d,%d" % ((b"0/0", b"0/1", b"1/1")[g], dp, (0, 3 * dp, 9 * dp)[g] % 256, (3 * dp, 0, 3 * dp)[g] % 256, (9 * dp, 3 * dp, 0)[g] % 256))
         lines.append(fixed + b"\t" + b"\t".join(samples) + b"\n")
     return b"".join(lines)
@@ -1620,6 +1640,45 @@ def vcf_zip(E, oracle, n_lines, n_samples, n_calls=2):
             n_vb += 1
     F.close()
     return n_vb
+
+
+def vcf_retest(E, oracle, n_lines, n_samples):
+    """codec_assign_best_codec's two rules for data types whose first VBlocks may not be representative (VCF: INFO / FORMAT contexts,
+    data_types.h:148; codec.c:199-209): VBlock 1 does not set the file's LOCAL codec (:358-362: VBlock 2 tests again) unless it is the
+    file's last, and VBlock 10 tests local and b250 again and sets what it finds (RETEST_VB_I, :274-277) - here on text with other
+    statistics, so that the second look does choose differently. The driver == the oracle's serial composition, byte for byte"""
+    from genozip_amd import vcf as vc
+    plan = vc.vcf_plan(n_samples)
+    F = E.zip_open(plan)
+    zstate, codecs = None, {}
+    for call, (numbers, flat) in enumerate((((1, 2), False), ((9, 10, 11), True))):
+        text = vcf_full_text(n_lines * len(numbers), n_samples, seed=15 + call, flat=flat)
+        nl = np.flatnonzero(np.frombuffer(text, dtype=np.uint8) == 10)
+        cuts = [0] + [int(nl[n_lines * k - 1]) + 1 for k in range(1, len(numbers))] + [len(text)]
+        vbs = [(a, b - a, vi, -1) for a, b, vi in zip(cuts, cuts[1:], numbers)]
+        got = F.zip_vblocks(text, vbs)
+        want, zstate = fastq_zip_expected(oracle, plan, text, vbs, zstate)
+        for v, (g, w) in enumerate(zip(got, want)):
+            assert g["z"] == w["z"], (call, v, len(g["z"]), len(w["z"]), _first_diff(g["z"], w["z"]))
+            z, at = g["z"], 84
+            while at < len(z):
+                if int.from_bytes(z[at + 16:at + 20], "big") >= 50:
+                    codecs[(numbers[v], z[at + 24], bytes(z[at + 32:at + 40]))] = z[at + 25]
+                at += 40 + int.from_bytes(z[at + 12:at + 16], "big")
+    F.close()
+    fmt = [k[1:] for k in codecs if k[0] == 10 and k[2][0] >> 6 == 1]                   # FORMAT contexts' sections of VBlock 10
+    assert fmt and any(codecs.get((9,) + k) not in (None, codecs[(10,) + k]) for k in fmt), "VBlock 10 chose as VBlock 9 had: the test text is not telling"
+    assert all(codecs.get((11,) + k, codecs[(10,) + k]) == codecs[(10,) + k] for k in fmt)
+    # the same file's last VBlock as its first: it does set the local codec
+    F = E.zip_open(plan)
+    text = vcf_full_text(n_lines, n_samples, seed=15)
+    for vbs in ([(0, len(text), 1, -1, 1)], [(0, len(text), 2, -1)]):
+        got = F.zip_vblocks(text, vbs)
+        want, zstate = fastq_zip_expected(oracle, plan, text, vbs, None if vbs[0][2] == 1 else zstate)
+        assert got[0]["z"] == want[0]["z"]
+    dp = next(i for i, c in enumerate(plan["ctxs"]) if c["tag"] == "DP")
+    assert F.zctx_view(dp)["lcodec"] and zstate["lcodec"][dp] == F.zctx_view(dp)["lcodec"]
+    F.close()
 
 
 def rans_tables(E, oracle, scale=1.0):

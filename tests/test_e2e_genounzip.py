@@ -146,3 +146,37 @@ def test_streamed_pairs_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, i
     for name, want in ((b"reads_R1.fq", b"".join(r1s)), (b"reads_R2.fq", b"".join(r2s))):
         p = tmp_path / name.decode()
         assert p.exists() and p.read_bytes() == want, (name, sorted(os.listdir(tmp_path)), log[:2000])
+
+
+VCF_HEADER = (b"##fileformat=VCFv4.2\n##contig=<ID=chr1,length=248956422>\n##INFO=<ID=DP,Number=1,Type=Integer,Description=\"d\">\n"
+              b"##INFO=<ID=AF,Number=A,Type=Float,Description=\"a\">\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"g\">\n"
+              b"##FORMAT=<ID=DP,Number=1,Type=Integer,Description=\"d\">\n##FORMAT=<ID=PL,Number=G,Type=Integer,Description=\"p\">\n"
+              b"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t")
+
+
+def test_vcf_round_trip(emul_engine, genounzip, tmp_path):
+    """a multi-sample VCF (BASELINE configs[3]'s shape: GT:DP:PL per sample) through the VCF plan of genozip_amd/vcf.py - 4 VBlocks over 2 calls,
+    VBlock 1 not setting the FORMAT locals' codec - + its header text in SEC_TXT_HEADER: the reference's decoder gives the file back byte for
+    byte. What that pins beyond the FASTQ tests: the per-sample columns (lines x samples entries per FORMAT context), the nested SAMPLES
+    container (repeats = samples, drop_final_repsep), a7's transposed matrix (FORMAT/DP: LT_UINT8_TR with param 0 = "the file's samples",
+    which the reader un-transposes, dyn_int.c / piz side), the integer / delta rules of the fixed fields, a header component"""
+    import numpy as np
+    from genozip_amd import vcf as vc
+    NS = 24
+    header = VCF_HEADER + b"\t".join(b"S%d" % i for i in range(NS)) + b"\n"
+    plan = vc.vcf_plan(NS)
+    F = emul_engine.zip_open(plan)
+    res, texts, vb_i = [], [], 0
+    for call, nl_ in enumerate((40, 30)):
+        text = parity.vcf_full_text(nl_, NS, seed=5 + call)
+        nl = np.flatnonzero(np.frombuffer(text, dtype=np.uint8) == 10)
+        cut = int(nl[(2 * nl_) // 3 - 1]) + 1
+        res += F.zip_vblocks(text, [(0, cut, vb_i + 1, -1), (cut, len(text) - cut, vb_i + 2, -1)])
+        vb_i += 2
+        texts.append(text)
+    blob = F.write_file([dict(name=b"cohort.vcf", pair=0, vbs=res, header=header)], data_type=1)
+    F.close()
+    (tmp_path / "cohort.vcf.genozip").write_bytes(blob)
+    log = _run(genounzip, ["-f", "-o", "out.vcf", "cohort.vcf.genozip"], tmp_path)
+    out = (tmp_path / "out.vcf").read_bytes() if (tmp_path / "out.vcf").exists() else b""
+    assert out == header + b"".join(texts), log[:3000]

@@ -184,3 +184,7 @@ def test_emul_vcf_zip(emul_engine, oracle):
 
 def test_emul_rans_tables(emul_engine, oracle):
     parity.rans_tables(emul_engine, oracle, scale=0.25)
+
+
+def test_emul_vcf_retest(emul_engine, oracle):
+    parity.vcf_retest(emul_engine, oracle, 12, 40)

@@ -359,3 +359,7 @@ def test_streamed_file(gpu_engine, oracle):
 
 def test_rans_tables(gpu_engine, oracle):
     parity.rans_tables(gpu_engine, oracle)
+
+
+def test_vcf_retest(gpu_engine, oracle):
+    parity.vcf_retest(gpu_engine, oracle, 40, 100)
