@@ -16,9 +16,10 @@ How each field reaches its context (SURVEY 8(0), row configs[3], as far as the d
                 917-919; dyn_int_transpose src/dyn_int.c:45-132): LT_UINT8_TR, param 0 = the file's number of samples
   FORMAT/PL     one snip per sample per line -> b250 of lines x samples entries (src/vcf_samples.c:1134-1156; the reference multiplexes the
                 snips over two dictionaries by the sample's dosage: not built - one dictionary here)
-The TOPLEVEL / samples containers are built in the reference's container FORMAT but are this repo's own choice of items (the reference's
-VCF reconstruction - vcf_piz.c, FORMAT-driven sample containers - is out of scope): a file made with this plan is not offered to
-genounzip; parity: the CPU restatement's composition, tests/parity.py::vcf_zip."""
+The TOPLEVEL / samples containers are built in the reference's container FORMAT with this repo's own (simpler) choice of items - every
+subfield a plain snip or integer. That is a valid encoding: the reference's own genounzip gives the VCF back byte for byte
+(tests/test_e2e_genounzip.py::test_vcf_round_trip); byte-level parity of the sections: the CPU restatement's composition,
+tests/parity.py::vcf_zip."""
 from .fastq import (dict_id, container, DTYPE_FIELD, DTYPE_2, STORE_INT, SNIP_SELF_DELTA, CON_FILTER_REPEATS, CON_FILTER_ITEMS, CON_IS_TOPLEVEL, CON_CALLBACK, CON_DROP_FINAL_REPSEP)
 from .lib import (GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_TOPLEVEL)
 
