@@ -965,6 +965,16 @@ static int gz_sync_do (GzHandle *h)
                         ((v >> 39) & 1) ? "small" : "big", (v >> 28) & 0x7ff, (v >> 18) & 0x3ff, (v & 0x3ffff) * 64);
     }
 #endif
+#ifdef GZ_MODEL_PHASES
+    if (!h->pending.empty ()) {
+        unsigned long long v[8], z[8] = { 0 };
+        (void)hipMemcpyFromSymbol (v, HIP_SYMBOL (g_mph), sizeof (v));
+        (void)hipMemcpyToSymbol (HIP_SYMBOL (g_mph), z, sizeof (z));
+        if (v[7]) fprintf (stderr, "[phases] bg %d: %llu hot waves, %llu batches (%llu through LDS), %.2f events per batch; us per batch: head %.3f register batches %.3f LDS batches %.3f tail %.3f\n",
+                           (int)h->background, v[7], v[4], v[5], (double)v[6] / (double)v[4], (double)v[0] / 100.0 / (double)v[4],
+                           v[4] > v[5] ? (double)v[1] / 100.0 / (double)(v[4] - v[5]) : 0.0, v[5] ? (double)v[2] / 100.0 / (double)v[5] : 0.0, (double)v[3] / 100.0 / (double)v[4]);
+    }
+#endif
 #ifdef GZ_TABLE_DEBUG
     if (!h->pending.empty ()) {
         unsigned long long sm[9], mx[9], z[9] = { 0 };

@@ -355,29 +355,41 @@ __device__ static __forceinline__ void d_model_batch_lds (GzModel<J> &M, uint32_
     uint16_t *s_gap  = (uint16_t *)(gz_lds + GZ_MLDS_OFF + 1024);           // [256] by list position
     uint8_t  *s_rank = gz_lds + GZ_MLDS_OFF + 1536;                         // [256] list position -> static rank
     uint8_t  *s_pos  = gz_lds + GZ_MLDS_OFF + 1792;                         // [256] static rank -> list position
-    uint8_t  *s_rk   = gz_lds + GZ_MLDS_OFF + 2048;                         // [64]  the batch's occurrences
-    uint32_t *s_out  = (uint32_t *)(gz_lds + GZ_MLDS_OFF + 2112);           // [3][64] cum, freq, total
     #pragma unroll
     for (int j = 0; j < J; j++) {
         const uint32_t e = (uint32_t)(j * 64 + lane);
         if (e < nsym) { s_freq[e] = M.freq[j]; s_gap[e] = (uint16_t)M.gap[j]; s_rank[e] = (uint8_t)M.srank[j]; s_pos[e] = (uint8_t)M.where[j]; }
     }
-    s_rk[lane] = (uint8_t)rk;
     gz_wave_sync ();
     uint32_t t = tot;
-    for (uint32_t b = 0; b < cnt; b++) {
-        const uint32_t s = s_rk[b];
-        const uint32_t p = s_pos[s], q = p ? p - 1 : 0;
-        const uint32_t f = s_freq[p], g = s_gap[p], rb = s_rank[q];
-        uint32_t fl = s_freq[q];
+    // One trip to the LDS per occurrence instead of three dependent ones (symbol -> its list position -> the entries there): the symbol
+    // comes out of the lanes' registers (v_readlane with a scalar lane number), and the NEXT occurrence's list position is read together
+    // with this occurrence's entries - only a swap can move it, and then only if it is one of the two symbols swapped: patched below.
+    // What comes back is wave-uniform and is moved to the scalar unit at once (v_readfirstlane): every decision below is then scalar
+    // arithmetic and a scalar branch instead of a vector compare whose result has to travel to the branch unit. The occurrence's
+    // (cum, freq, total) go straight into the register of the lane that owns it - nothing is written to the LDS but the model itself.
+    // (cnt, the total and the positions are said to be uniform explicitly: the compiler cannot know, and treats a branch on them as one
+    //  that lanes may disagree on - exec-mask bookkeeping around every if)
+    const uint32_t cnt_u = d_uniform (cnt);
+    t = d_uniform (t);
+    uint32_t s = d_readlane (rk, 0), p = d_uniform (s_pos[s]);
+    uint32_t o_cum = 0, o_freq = 0, o_tot = 0;
+    for (uint32_t b = 0; b < cnt_u; b++) {
+        const uint32_t q = p ? p - 1 : 0;
+        const uint32_t s_nx = d_readlane (rk, (int)(b + 1 < cnt_u ? b + 1 : b));
+        uint32_t f_v = s_freq[p], g_v = s_gap[p], rb_v = s_rank[q], fl_v = s_freq[q], pn_v = s_pos[s_nx];
+        const uint32_t f = d_uniform (f_v), g = d_uniform (g_v), rb = d_uniform (rb_v);
+        uint32_t fl = d_uniform (fl_v), p_nx = d_uniform (pn_v);
         gz_wave_sync ();                                           // (everybody has read)
+        // my cumulative if I am the occurrence's list entry: plane p / 64, lane p % 64
+        uint32_t cp = M.cum[0];
         #pragma unroll
-        for (int j = 0; j < J; j++) {
-            const uint32_t e = (uint32_t)(j * 64 + lane);
-            if (e == p) s_out[b] = M.cum[j];
-            M.cum[j] += e > p ? GZ_MODEL_STEP : 0u;
-        }
-        if (!lane) { s_out[64 + b] = f; s_out[128 + b] = t; }
+        for (int j = 1; j < J; j++) cp = (p >> 6) == (uint32_t)j ? M.cum[j] : cp;
+        const uint32_t c_out = d_readlane (cp, (int)(p & 63));
+        const bool mine = (uint32_t)lane == b;
+        o_cum = mine ? c_out : o_cum; o_freq = mine ? f : o_freq; o_tot = mine ? t : o_tot;
+        #pragma unroll
+        for (int j = 0; j < J; j++) M.cum[j] += (uint32_t)(j * 64 + lane) > p ? GZ_MODEL_STEP : 0u;
         uint32_t fn = f + GZ_MODEL_STEP;
         t += GZ_MODEL_STEP;
         if (t > GZ_MODEL_LIMIT) {                                  // rare: halve, rebuild the cumulatives and the total
@@ -394,14 +406,26 @@ __device__ static __forceinline__ void d_model_batch_lds (GzModel<J> &M, uint32_
                 run += (uint32_t)__shfl ((int)incl, 63);
                 fsum += (uint32_t)__shfl ((int)d_wave_incl_scan (x, lane), 63);
             }
-            t = fsum + n_absent;
+            t = d_uniform (fsum + n_absent);
             gz_wave_sync ();
-            fn = s_freq[p]; fl = s_freq[q];
+            fn = d_uniform (s_freq[p]); fl = d_uniform (s_freq[q]);
             gz_wave_sync ();
+            if (g > 0) {
+                if (!lane) { s_gap[p] = (uint16_t)(g - 1); if (p + 1 < nsym) s_gap[p + 1] = (uint16_t)(s_gap[p + 1] + 1); }
+                #pragma unroll
+                for (int j = 0; j < J; j++) M.cum[j] -= (uint32_t)(j * 64 + lane) == p ? 1u : 0u;
+                n_changes++;
+            }
+            else if (p > 0 && fl < fn) {
+                if (!lane) { s_freq[q] = fn; s_freq[p] = fl; s_rank[q] = (uint8_t)s; s_rank[p] = (uint8_t)rb; s_pos[s] = (uint8_t)q; s_pos[rb] = (uint8_t)p; }
+                #pragma unroll
+                for (int j = 0; j < J; j++) M.cum[j] = (uint32_t)(j * 64 + lane) == p ? M.cum[j] - fl + fn : M.cum[j];
+                n_changes++;
+                p_nx = s_nx == s ? q : (s_nx == rb ? p : p_nx);
+            }
         }
-        else if (!lane) s_freq[p] = fn;
-        if (g > 0) {                                               // an absent entry hops over (see d_model_serial_step)
-            if (!lane) { s_gap[p] = (uint16_t)(g - 1); if (p + 1 < nsym) s_gap[p + 1] = (uint16_t)(s_gap[p + 1] + 1); }
+        else if (g > 0) {                                          // an absent entry hops over (see d_model_serial_step)
+            if (!lane) { s_freq[p] = fn; s_gap[p] = (uint16_t)(g - 1); if (p + 1 < nsym) s_gap[p + 1] = (uint16_t)(s_gap[p + 1] + 1); }
             #pragma unroll
             for (int j = 0; j < J; j++) M.cum[j] -= (uint32_t)(j * 64 + lane) == p ? 1u : 0u;
             n_changes++;
@@ -411,15 +435,18 @@ __device__ static __forceinline__ void d_model_batch_lds (GzModel<J> &M, uint32_
             #pragma unroll
             for (int j = 0; j < J; j++) M.cum[j] = (uint32_t)(j * 64 + lane) == p ? M.cum[j] - fl + fn : M.cum[j];
             n_changes++;
+            p_nx = s_nx == s ? q : (s_nx == rb ? p : p_nx);
         }
+        else if (!lane) s_freq[p] = fn;
         gz_wave_sync ();                                           // (written before the next occurrence reads)
+        s = s_nx; p = d_uniform (p_nx);
     }
     #pragma unroll
     for (int j = 0; j < J; j++) {
         const uint32_t e = (uint32_t)(j * 64 + lane);
         if (e < nsym) { M.freq[j] = s_freq[e]; M.gap[j] = s_gap[e]; M.srank[j] = s_rank[e]; M.where[j] = s_pos[e]; M.sym[j] = symlist[M.srank[j]]; }
     }
-    if ((uint32_t)lane < cnt) { out_cum = s_out[lane]; out_freq = s_out[64 + lane]; out_tot = s_out[128 + lane]; }
+    if ((uint32_t)lane < cnt) { out_cum = o_cum; out_freq = o_freq; out_tot = o_tot; }
     tot = t;
     gz_wave_sync ();
 }
@@ -667,6 +694,15 @@ __global__ void __launch_bounds__(256) k_ctx_succ (GzdLeaf *leaves, const uint32
 // LDSM: with the LDS way through eventful batches (d_model_batch_lds). Only the two instantiations that run the leaf's own (wide)
 // alphabet have it: compiled into all of them its scalars cost the others theirs (spills) - 19 -> 21 ns per symbol on a quality
 // stream, 82 -> 118 ms on BAM's packed qualities - and the contexts it is for are the near-uniform planes of integers, which are wide.
+// -DGZ_MODEL_PHASES: where the waves of the hot contexts (>= 1 M occurrences in the launch) spend their time - lane 0's 100 MHz clock around
+// the head of a batch (waits for the prefetched occurrences), the batch itself and its tail (record store, reciprocal fetch); sums over
+// such waves, printed by gz_wait: 0 head, 1 register batches, 2 LDS batches, 3 tail, 4 batches, 5 LDS batches (count), 6 events, 7 waves
+#ifdef GZ_MODEL_PHASES
+__device__ unsigned long long g_mph[8];
+#define MPH_T(k) do { const unsigned long long now_ = wall_clock64 (); mph_[k] += now_ - mt_; mt_ = now_; } while (0)
+#else
+#define MPH_T(k) do { } while (0)
+#endif
 template <int J, bool LDSM = false>
 __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, uint32_t ms, bool o1, uint4 *recs,
                                                    const GzDivMagic *magic_tab, const uint8_t *symlist, const uint16_t *symrank, uint32_t nsym,
@@ -698,28 +734,56 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
         tot = d_uniform (st[6 * J * 64]);
     }
     const uint32_t n_absent = ms - nsym;
+#ifdef GZ_MODEL_PHASES
+    unsigned long long mph_[7] = { 0, 0, 0, 0, 0, 0, 0 }, mt_ = wall_clock64 ();
+#endif
 
     // the records of a batch are stored while the next batch is being worked on: the division constants they need come
     // from a table in memory, and waiting for that load at the end of every batch would cost more than the batch
     uint32_t p_pos = 0, p_cum = 0, p_freq = 0; GzDivMagic p_mg = { 0, 0 }; bool p_on = false;
-    // ... and the occurrences of the next batch are fetched while this one is being worked on
+    // ... and the occurrences of the following batches are fetched while this one is being worked on. The raw loads (sorted position +
+    // rank byte, or the input byte of an order-0 leaf) run FOUR TO EIGHT batches ahead: a batch without events is ~300 ns of work, a trip
+    // to memory 1-2 us, so one batch ahead (as it was) left a context whose order is stable waiting for its next occurrences most of the
+    // time (1.2 us per batch measured on a 25 M-occurrence genotype context). Two groups of four batches: A is being used up (picked by
+    // a select - a register that a load still owes cannot even be MOVED without waiting for it, so no shifting ring), B is in flight
+    // and becomes A once every four batches, when its loads are four batches old. What depends on a loaded value (the rank table of an
+    // order-0 leaf, the context's own alphabet) is done one batch ahead, from A
     uint32_t nx_pos = 0, nx_rk = 0;
+    uint32_t A_pos[4] = { 0, 0, 0, 0 }, A_raw[4] = { 0, 0, 0, 0 }, B_pos[4] = { 0, 0, 0, 0 }, B_raw[4] = { 0, 0, 0, 0 };
+    uint32_t bi = 0, grp = j0;                            // bi: which batch of group A is being worked on; grp: position of A's first batch
     bool through_lds = false;                             // (see d_model_batch_lds)
-    if (j0 + lane < j1) {
-        if (o1) { nx_pos = spos[j0 + lane]; nx_rk = srk[j0 + lane]; }
-        else    { nx_pos = j0 + lane; nx_rk = symrank[in[nx_pos]]; }
-        if (la) nx_rk = d_local_rank (*la, nx_rk);
-    }
+    auto fetch_raw = [&] (uint32_t at, uint32_t &pos, uint32_t &raw) {
+        if (at < j1) {
+            if (o1) { pos = spos[at]; raw = srk[at]; }
+            else    { pos = at; raw = in[at]; }
+        }
+    };
+    auto to_rank = [&] (uint32_t raw) -> uint32_t {
+        uint32_t rk = o1 ? raw : (uint32_t)symrank[raw & 0xff];
+        if (la) rk = d_local_rank (*la, rk);
+        return rk;
+    };
+    #pragma unroll
+    for (int k = 0; k < 4; k++) fetch_raw (j0 + 64 * k + lane, A_pos[k], A_raw[k]);
+    #pragma unroll
+    for (int k = 0; k < 4; k++) fetch_raw (j0 + 64 * (k + 4) + lane, B_pos[k], B_raw[k]);
+    nx_pos = A_pos[0];
+    if (j0 + lane < j1) nx_rk = to_rank (A_raw[0]);
     // (two loops taking turns rather than one loop with a branch: with both ways through a batch in one loop body the register batches
     //  paid for the LDS way's registers - BAM's packed qualities 82 -> 120 ms of model)
 #define GZ_WAVE_BATCH_HEAD \
         const uint32_t cnt = j1 - j < 64 ? j1 - j : 64; \
         const bool occ = (uint32_t)lane < cnt; \
         const uint32_t b_pos = nx_pos, b_rk = nx_rk; \
-        if (j + 64 + lane < j1) { \
-            if (o1) { nx_pos = spos[j + 64 + lane]; nx_rk = srk[j + 64 + lane]; } \
-            else    { nx_pos = j + 64 + lane; nx_rk = symrank[in[nx_pos]]; } \
-            if (la) nx_rk = d_local_rank (*la, nx_rk); \
+        if (++bi == 4) { \
+            bi = 0; grp += 256; \
+            _Pragma ("unroll") for (int k = 0; k < 4; k++) { A_pos[k] = B_pos[k]; A_raw[k] = B_raw[k]; } \
+            _Pragma ("unroll") for (int k = 0; k < 4; k++) fetch_raw (grp + 64 * (k + 4) + lane, B_pos[k], B_raw[k]); \
+        } \
+        { \
+            const uint32_t rp = bi == 0 ? A_pos[0] : bi == 1 ? A_pos[1] : bi == 2 ? A_pos[2] : A_pos[3]; \
+            const uint32_t rr = bi == 0 ? A_raw[0] : bi == 1 ? A_raw[1] : bi == 2 ? A_raw[2] : A_raw[3]; \
+            nx_pos = rp; nx_rk = (j + 64 + lane < j1) ? to_rank (rr) : 0u; \
         } \
         uint32_t out_cum = 0, out_freq = 0, out_tot = 0, n_ev = 0;
 #define GZ_WAVE_BATCH_TAIL \
@@ -729,22 +793,37 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
     for (uint32_t j = j0; j < j1; ) {
         for (; j < j1 && !through_lds; j += 64) {
             GZ_WAVE_BATCH_HEAD
+            MPH_T (0);
             d_model_batch<J> (M, tot, lane, cnt, occ ? b_rk : 0u, nsym, n_absent, out_cum, out_freq, out_tot, n_ev);
             if constexpr (LDSM) through_lds = n_ev >= GZ_MODEL_EVENTS_IN;
+            MPH_T (1);
             GZ_WAVE_BATCH_TAIL
+            MPH_T (3);
+#ifdef GZ_MODEL_PHASES
+            mph_[4]++; mph_[6] += n_ev;
+#endif
         }
         if constexpr (LDSM) {
             for (; j < j1 && through_lds; j += 64) {
                 GZ_WAVE_BATCH_HEAD
+                MPH_T (0);
                 d_model_batch_lds<J> (M, tot, lane, cnt, occ ? b_rk : 0u, nsym, n_absent, symlist, out_cum, out_freq, out_tot, n_ev);
                 through_lds = n_ev >= GZ_MODEL_EVENTS_OUT;
+                MPH_T (2);
                 GZ_WAVE_BATCH_TAIL
+                MPH_T (3);
+#ifdef GZ_MODEL_PHASES
+                mph_[4]++; mph_[5]++; mph_[6] += n_ev;
+#endif
             }
         }
     }
 #undef GZ_WAVE_BATCH_HEAD
 #undef GZ_WAVE_BATCH_TAIL
     if (p_on) recs[p_pos] = d_model_record (p_cum, p_freq, p_mg);
+#ifdef GZ_MODEL_PHASES
+    if (!lane && j1 - j0 >= 1000000u) { for (int k = 0; k < 7; k++) atomicAdd (&g_mph[k], mph_[k]); atomicAdd (&g_mph[7], 1ull); }
+#endif
     if (save) {
         #pragma unroll
         for (int j = 0; j < J; j++) {
