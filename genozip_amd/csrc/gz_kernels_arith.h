@@ -334,10 +334,17 @@ __device__ static __forceinline__ void d_model_batch (GzModel<J> &M, uint32_t &t
 // LDS: bytes 512 .. 3391 of the workgroup's (one wave's) dynamic LDS.
 #define GZ_MLDS_OFF 512
 #define GZ_MLDS_BYTES 2880
-#ifndef GZ_MODEL_EVENTS_IN
-#define GZ_MODEL_EVENTS_IN  12            // events in a batch of 64 from which on the next batch goes through LDS ...
-#define GZ_MODEL_EVENTS_OUT 8             // ... and order changes in such a batch below which the next one is a register batch again
-#endif
+// Which way an eventful batch goes is decided by the CLOCK. Both ways give the same records, so the choice is free: a register batch with
+// >= GZ_MODEL_EVENTS_IN events and every LDS batch are timed (s_memrealtime at the end of every batch - issued, not waited for: only an
+// eventful batch reads it), and the next eventful batch takes the way that was faster the last time it was taken; every
+// GZ_MODEL_REPROBE-th such batch tries the other one again. An LDS batch costs the same whatever happens in it, but more the more register
+// planes the model has; a register batch costs by its events, by its distinct list positions (4 planes) ... - fixed thresholds that suit
+// one kind of stream cost another 10-25 %: measured with IN / OUT = 12 / 8 (round 2's), 24 / 16, 40 / 28 and "never LDS" - one VCF VBlock
+// (4-plane models of near-uniform b250 planes) 2500 / 2000 / 1955 / 1955 ms, BAM from text 72.5 / 73.0 / 75.4 / 88.9 ms, binned FASTQ 69.4 /
+// 72.0 / 75.2 / 85.5 ms; thresholds by the number of planes (12 / 24 / 40): VCF 2030 but BAM 76.5, binned FASTQ 78.5.
+#define GZ_MODEL_EVENTS_IN  12            // events in a register batch of 64 from which on it counts as eventful ...
+#define GZ_MODEL_EVENTS_OUT 8             // ... and order changes in an LDS batch below which the next one is a register batch again
+#define GZ_MODEL_REPROBE    128
 
 __device__ static __forceinline__ uint32_t d_wave_incl_scan (uint32_t v, int lane)
 {
@@ -752,6 +759,7 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
     uint32_t A_pos[4] = { 0, 0, 0, 0 }, A_raw[4] = { 0, 0, 0, 0 }, B_pos[4] = { 0, 0, 0, 0 }, B_raw[4] = { 0, 0, 0, 0 };
     uint32_t bi = 0, grp = j0;                            // bi: which batch of group A is being worked on; grp: position of A's first batch
     bool through_lds = false;                             // (see d_model_batch_lds)
+    uint32_t stamp = LDSM ? (uint32_t)wall_clock64 () : 0u, reg_cost = 0, lds_cost = 0, probe = 0;   // (10 ns ticks)
     auto fetch_raw = [&] (uint32_t at, uint32_t &pos, uint32_t &raw) {
         if (at < j1) {
             if (o1) { pos = spos[at]; raw = srk[at]; }
@@ -795,7 +803,15 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
             GZ_WAVE_BATCH_HEAD
             MPH_T (0);
             d_model_batch<J> (M, tot, lane, cnt, occ ? b_rk : 0u, nsym, n_absent, out_cum, out_freq, out_tot, n_ev);
-            if constexpr (LDSM) through_lds = n_ev >= GZ_MODEL_EVENTS_IN;
+            if constexpr (LDSM) {
+                const uint32_t now = (uint32_t)wall_clock64 ();
+                if (n_ev >= GZ_MODEL_EVENTS_IN) {
+                    reg_cost = now - stamp;
+                    through_lds = !lds_cost || lds_cost <= reg_cost || ++probe >= GZ_MODEL_REPROBE;
+                    if (through_lds) probe = 0;
+                }
+                stamp = now;
+            }
             MPH_T (1);
             GZ_WAVE_BATCH_TAIL
             MPH_T (3);
@@ -808,7 +824,10 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
                 GZ_WAVE_BATCH_HEAD
                 MPH_T (0);
                 d_model_batch_lds<J> (M, tot, lane, cnt, occ ? b_rk : 0u, nsym, n_absent, symlist, out_cum, out_freq, out_tot, n_ev);
-                through_lds = n_ev >= GZ_MODEL_EVENTS_OUT;
+                const uint32_t now = (uint32_t)wall_clock64 ();
+                lds_cost = now - stamp; stamp = now;
+                through_lds = n_ev >= GZ_MODEL_EVENTS_OUT && (lds_cost <= reg_cost || !reg_cost) && ++probe < GZ_MODEL_REPROBE;
+                if (!through_lds) probe = 0;
                 MPH_T (2);
                 GZ_WAVE_BATCH_TAIL
                 MPH_T (3);

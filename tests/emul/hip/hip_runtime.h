@@ -207,6 +207,9 @@ static inline void __syncthreads (void)
     emu_set_tid (me);
 }
 static inline void __threadfence_block (void) {}
+// (the same value in every lane of a wave at the same point of the program, as on the device: the clock only ever picks between ways that
+//  give the same result - k_arith_model's eventful batches)
+static inline long long wall_clock64 (void) { return 0; }
 static inline void __threadfence (void) {}
 
 static inline unsigned long long __ballot (int pred)

@@ -8,7 +8,7 @@ import torch
 import bench
 from genozip_amd.codec import Engine
 a = argparse.Namespace(vcf_samples=10000, vcf_lines=int(sys.argv[1]) if len(sys.argv) > 1 else 3000, vcf_vbs=1)
-E = Engine(device=0, lib_path=os.path.join(ROOT, "genozip_amd", "libgenozip_amd_dbg.so") if os.environ.get("GZ_DBG_LIB") else None)
+E = Engine(device=0, lib_path=os.environ.get("GZ_LIB_PATH") or (os.path.join(ROOT, "genozip_amd", "libgenozip_amd_dbg.so") if os.environ.get("GZ_DBG_LIB") else None))
 wl = bench.VcfWorkload(E, a, torch.device("cuda", 0))
 for _ in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
