@@ -71,6 +71,8 @@ __device__ static inline double gz_rcp_f64 (double x) { return __builtin_amdgcn_
 // loads through a GLOBAL pointer: a load through a generic one is a flat load, which also counts as an LDS operation -
 // every wait for an LDS read would then wait for its trip to memory as well
 __device__ static inline uint32_t gz_ldg_u8 (const uint8_t *p) { return *(const __attribute__((address_space(1))) uint8_t *)(uintptr_t)p; }
+__device__ static inline uint32_t gz_ldg_u16 (const uint16_t *p) { return *(const __attribute__((address_space(1))) uint16_t *)(uintptr_t)p; }
+__device__ static inline uint32_t gz_ldg_u32 (const uint32_t *p) { return *(const __attribute__((address_space(1))) uint32_t *)(uintptr_t)p; }
 __device__ static inline uint4 gz_ldg_u32x4 (const void *p)
 {
     typedef uint32_t gz_v4 __attribute__((ext_vector_type(4)));

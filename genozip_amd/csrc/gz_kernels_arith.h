@@ -701,10 +701,13 @@ __global__ void __launch_bounds__(256) k_ctx_succ (GzdLeaf *leaves, const uint32
 // LDSM: with the LDS way through eventful batches (d_model_batch_lds). Only the two instantiations that run the leaf's own (wide)
 // alphabet have it: compiled into all of them its scalars cost the others theirs (spills) - 19 -> 21 ns per symbol on a quality
 // stream, 82 -> 118 ms on BAM's packed qualities - and the contexts it is for are the near-uniform planes of integers, which are wide.
-// -DGZ_MODEL_PHASES: where the waves of the hot contexts (>= 1 M occurrences in the launch) spend their time - lane 0's 100 MHz clock around
+// -DGZ_MODEL_PHASES: where the waves of the hot contexts (>= GZ_MODEL_HOT occurrences in the launch, default 1 M) spend their time - lane 0's 100 MHz clock around
 // the head of a batch (waits for the prefetched occurrences), the batch itself and its tail (record store, reciprocal fetch); sums over
 // such waves, printed by gz_wait: 0 head, 1 register batches, 2 LDS batches, 3 tail, 4 batches, 5 LDS batches (count), 6 events, 7 waves
 #ifdef GZ_MODEL_PHASES
+#ifndef GZ_MODEL_HOT
+#define GZ_MODEL_HOT 1000000u
+#endif
 __device__ unsigned long long g_mph[8];
 #define MPH_T(k) do { const unsigned long long now_ = wall_clock64 (); mph_[k] += now_ - mt_; mt_ = now_; } while (0)
 #else
@@ -760,14 +763,17 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
     uint32_t bi = 0, grp = j0;                            // bi: which batch of group A is being worked on; grp: position of A's first batch
     bool through_lds = false;                             // (see d_model_batch_lds)
     uint32_t stamp = LDSM ? (uint32_t)wall_clock64 () : 0u, reg_cost = 0, lds_cost = 0, probe = 0;   // (10 ns ticks)
+    // (always loads - past the end the context's last occurrence again, which nobody looks at - and through GLOBAL pointers: a load
+    //  under a condition leaves the compiler merging old and new value through a copy that has to wait for the load on the spot, and a
+    //  load through a generic pointer is a FLAT one, for which it waits with vmcnt (0): measured inside the kernel, 0.5 of the 1.5 us of
+    //  a quiet batch were that wait, once every four batches for the whole trip to memory)
     auto fetch_raw = [&] (uint32_t at, uint32_t &pos, uint32_t &raw) {
-        if (at < j1) {
-            if (o1) { pos = spos[at]; raw = srk[at]; }
-            else    { pos = at; raw = in[at]; }
-        }
+        const uint32_t a = at < j1 ? at : (j1 ? j1 - 1 : 0u);
+        if (o1) { pos = gz_ldg_u32 (spos + a); raw = gz_ldg_u8 (srk + a); }
+        else    { pos = a; raw = gz_ldg_u8 (in + a); }
     };
     auto to_rank = [&] (uint32_t raw) -> uint32_t {
-        uint32_t rk = o1 ? raw : (uint32_t)symrank[raw & 0xff];
+        uint32_t rk = o1 ? raw : gz_ldg_u16 (symrank + (raw & 0xff));
         if (la) rk = d_local_rank (*la, rk);
         return rk;
     };
@@ -841,7 +847,7 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
 #undef GZ_WAVE_BATCH_TAIL
     if (p_on) recs[p_pos] = d_model_record (p_cum, p_freq, p_mg);
 #ifdef GZ_MODEL_PHASES
-    if (!lane && j1 - j0 >= 1000000u) { for (int k = 0; k < 7; k++) atomicAdd (&g_mph[k], mph_[k]); atomicAdd (&g_mph[7], 1ull); }
+    if (!lane && j1 - j0 >= GZ_MODEL_HOT) { for (int k = 0; k < 7; k++) atomicAdd (&g_mph[k], mph_[k]); atomicAdd (&g_mph[7], 1ull); }
 #endif
     if (save) {
         #pragma unroll

@@ -10,7 +10,7 @@ import numpy as np                      # noqa: E402
 from genozip_amd import workload as W   # noqa: E402
 from genozip_amd.codec import Engine    # noqa: E402
 
-E = Engine(device=0)
+E = Engine(device=0, lib_path=os.environ.get("GZ_LIB_PATH"))
 n_reads = 46000
 qbin = W.quality_rows(W._NP, 4000, 0, n_reads, "bin").reshape(-1).astype(np.uint8).tobytes()
 qdiv = W.quality_rows(W._NP, 4000, 0, n_reads, "div").reshape(-1).astype(np.uint8).tobytes()
