@@ -626,14 +626,17 @@ class Engine:
     def dyn_int_column(self, values, is_nothing=None, nothing_char=0):
         return self.dyn_int_columns([(values, is_nothing, nothing_char)])[0]
 
-    def local_blob_columns(self, columns):
-        """columns: list of (text bytes | device buffer, off, len, add_nul) -> list of bytes"""
+    def local_blob_columns(self, columns, want_off=False):
+        """columns: list of (text bytes | device buffer, off, len, add_nul[, pre bytes, pad_to, pad_byte]) -> list of bytes
+        (want_off: list of (bytes, item offsets))"""
         import numpy as np
         from .lib import GzBlobJob
         nj = len(columns)
         tab = (GzBlobJob * max(1, nj))()
-        keep, texts = [], {}
-        for i, (text, off, length, add_nul) in enumerate(columns):
+        keep, texts, offs = [], {}, []
+        for i, col in enumerate(columns):
+            text, off, length, add_nul = col[:4]
+            pre, pad_to, pad_byte = (tuple(col[4:]) + (b"", 0, 0))[:3] if len(col) > 4 else (b"", 0, 0)
             off = np.ascontiguousarray(off, dtype=np.uint32); length = np.ascontiguousarray(length, dtype=np.uint32)
             if isinstance(text, (bytes, bytearray)):
                 if id(text) not in texts:
@@ -641,15 +644,22 @@ class Engine:
                 tbuf = texts[id(text)]
             else:
                 tbuf = text
-            cap = int(length.astype(np.uint64).sum()) + len(off)
+            cap = int(length.astype(np.uint64).sum()) + len(off) * (1 + len(pre) + pad_to)
             ofb, lb, ob, rb = self.mem.upload(off), self.mem.upload(length), self.mem.alloc(cap + 16), self.mem.alloc(8)
+            iob = self.mem.alloc(4 * len(off) + 16) if want_off else None
             keep.append((tbuf, ofb, lb, ob, rb))
+            offs.append((iob, len(off)))
             j = tab[i]
             j.text = self.mem.ptr(tbuf); j.off = self.mem.ptr(ofb); j.len = self.mem.ptr(lb); j.n = len(off)
             j.add_nul = int(bool(add_nul)); j.out = self.mem.ptr(ob); j.out_len_dev = self.mem.ptr(rb)
+            j.pre = (C.c_uint8 * 4)(*(bytes(pre) + b"\0" * 4)[:4]); j.pre_len = len(pre); j.pad_to = int(pad_to); j.pad_byte = int(pad_byte)
+            j.item_off = self.mem.ptr(iob) if want_off else None
         self._check(self.L.gz_local_blob_columns(self.h, tab, nj), "gz_local_blob_columns")
         self.sync()
-        return [self.mem.download(ob, int(np.frombuffer(self.mem.download(rb, 8), dtype=np.uint64)[0])) for _, _, _, ob, rb in keep]
+        blobs = [self.mem.download(ob, int(np.frombuffer(self.mem.download(rb, 8), dtype=np.uint64)[0])) for _, _, _, ob, rb in keep]
+        if not want_off:
+            return blobs
+        return [(b, np.frombuffer(self.mem.download(iob, 4 * n), dtype=np.uint32).copy() if n else np.zeros(0, dtype=np.uint32)) for b, (iob, n) in zip(blobs, offs)]
 
     # ---- N3: CODEC_DOMQ's pre-transform -----------------------------------------------------------------------
     def domq_columns(self, columns):

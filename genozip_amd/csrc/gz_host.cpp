@@ -1557,7 +1557,10 @@ extern "C" int gz_local_blob_columns (GzHandle *h, const GzBlobJob *jobs, int n_
         const GzBlobJob &u = jobs[i];
         if (!u.out_len_dev || (u.n && (!u.text || !u.off || !u.len || !u.out))) return GZ_ERR_ARG;
         GzdBlob &d = J[i];
+        if (u.pre_len > 4 || (u.pad_to & (u.pad_to - 1)) || u.pad_to > 64) return GZ_ERR_ARG;
         d.text = u.text; d.off = u.off; d.len = u.len; d.n = u.n; d.add_nul = u.add_nul ? 1 : 0; d.out = u.out; d.out_len = u.out_len_dev;
+        d.pre = (uint32_t)u.pre[0] | (uint32_t)u.pre[1] << 8 | (uint32_t)u.pre[2] << 16 | (uint32_t)u.pre[3] << 24; d.pre_len = u.pre_len;
+        d.pad_mask = u.pad_to ? u.pad_to - 1 : 0; d.pad_byte = u.pad_byte; d.item_off = u.item_off; d.item_len = u.item_len;
         const uint32_t tiles = (u.n + GZ_COL_TILE - 1) / GZ_COL_TILE;
         if (!(d.tile = (uint64_t *)arena_alloc (h, ((size_t)tiles + 1) * 8))) return GZ_ERR_HIP;
         if (tiles > max_tiles) max_tiles = tiles;

@@ -455,7 +455,17 @@ struct GzdBlob {
     const uint8_t *text; const uint32_t *off, *len; uint32_t n; uint32_t add_nul;
     uint8_t *out; uint64_t *out_len;
     uint64_t *tile;           // scratch [tiles]
+    uint32_t pre, pre_len;    // up to 4 bytes in front of every item (little endian in `pre`)
+    uint32_t pad_mask, pad_byte;   // pad_to - 1 (0: none): pad_byte's after every item up to the next multiple of pad_to
+    uint32_t *item_off, *item_len;   // optional: where every item starts in out; its length with the lead-in
 };
+
+// bytes an item of `len` bytes takes in the output
+__device__ static inline uint64_t d_blob_item_bytes (const GzdBlob &B, uint32_t len)
+{
+    const uint64_t raw = (uint64_t)B.pre_len + len + B.add_nul;
+    return (raw + B.pad_mask) & ~(uint64_t)B.pad_mask;
+}
 
 // grid (tiles, columns)
 __global__ void __launch_bounds__(256) k_blob_sum (GzdBlob *cols)
@@ -464,7 +474,7 @@ __global__ void __launch_bounds__(256) k_blob_sum (GzdBlob *cols)
     if (blockIdx.x * 256 >= B.n) return;
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     uint64_t total;
-    (void)d_wg_scan_u64 (k < B.n ? (uint64_t)B.len[k] + B.add_nul : 0, threadIdx.x, &total);
+    (void)d_wg_scan_u64 (k < B.n ? d_blob_item_bytes (B, B.len[k]) : 0, threadIdx.x, &total);
     if (!threadIdx.x) B.tile[blockIdx.x] = total;
 }
 
@@ -486,7 +496,9 @@ __global__ void __launch_bounds__(256) k_blob_copy (GzdBlob *cols)
     const bool on = k < B.n;
     const uint32_t len = on ? B.len[k] : 0, off = (on && len) ? B.off[k] : 0;
     uint64_t total;
-    const uint64_t at = B.tile[blockIdx.x] + d_wg_scan_u64 (on ? (uint64_t)len + B.add_nul : 0, tid, &total);
+    const uint64_t at = B.tile[blockIdx.x] + d_wg_scan_u64 (on ? d_blob_item_bytes (B, len) : 0, tid, &total);
+    if (on && B.item_off) B.item_off[k] = (uint32_t)at;
+    if (on && B.item_len) B.item_len[k] = len + B.pre_len;
     // the wave's bytes are one contiguous stretch of the output starting at lane 0's offset
     const uint64_t wave_at = ((uint64_t)(uint32_t)__shfl ((int)(uint32_t)(at >> 32), 0) << 32) | (uint32_t)__shfl ((int)(uint32_t)at, 0);
     const uint32_t rel = (uint32_t)(at - wave_at);
@@ -510,6 +522,12 @@ __global__ void __launch_bounds__(256) k_blob_copy (GzdBlob *cols)
             if (r[q] == 0xffffffffu) continue;
             uint8_t *dst = B.out + wave_at + r[q];
             const uint8_t *src = B.text + o[q];
+            if ((uint32_t)lane < B.pre_len) dst[lane] = (uint8_t)(B.pre >> (8 * lane));
+            dst += B.pre_len;
+            if (B.pad_mask) {                                  // (at most pad_to - 1 bytes)
+                const uint32_t raw = B.pre_len + l[q] + B.add_nul, padded = (raw + B.pad_mask) & ~B.pad_mask;
+                if ((uint32_t)lane < padded - raw) dst[l[q] + B.add_nul + lane] = (uint8_t)B.pad_byte;
+            }
             const uint32_t whole = l[q] & ~3u;
             if ((uint32_t)lane * 4 < whole) *(gz_u32_unaligned *)(dst + lane * 4) = v[q];
             for (uint32_t b = 256 + (uint32_t)lane * 4; b < whole; b += 256) *(gz_u32_unaligned *)(dst + b) = *(const gz_u32_unaligned *)(src + b);

@@ -207,6 +207,7 @@ static GzZipFile *zip_open_failed (GzZipFile *f) { for (auto z : f->zctx) gz_zct
 extern "C" GzZipFile *gz_zip_open (GzHandle *h, const GzFastqPlan *plan)
 {
     if (!h || !plan || !plan->ctxs || !plan->n_ctxs || plan->n_seps > GZ_TOK_MAX_SEPS) return NULL;
+    if (plan->seq_pad & (plan->seq_pad - 1) || plan->seq_pad > 64) return NULL;
     GzZipFile *f = new GzZipFile ();
     f->h = h; f->h_user = h; f->plan = *plan;
     f->ctxs.assign (plan->ctxs, plan->ctxs + plan->n_ctxs);
@@ -217,6 +218,7 @@ extern "C" GzZipFile *gz_zip_open (GzHandle *h, const GzFastqPlan *plan)
         c.snip = f->snips[i].data ();
         if ((c.kind == GZ_FQ_ITEM_TEXT || c.kind == GZ_FQ_ITEM_INT || c.kind == GZ_FQ_ITEM_DELTA) && c.item > plan->n_seps) return zip_open_failed (f);
         if ((c.kind == GZ_FQ_CONST || c.kind == GZ_FQ_ITEM_DELTA) && !c.snip_len) return zip_open_failed (f);
+        if (c.kind == GZ_FQ_ITEM_TEXT && c.snip_len > 4) return zip_open_failed (f);                 // (a lead-in of every snip: at most 4 bytes)
         if (c.kind == GZ_FQ_TOPLEVEL && (c.con_len < 8 || c.con_len > c.snip_len || (c.con_len - 8) % 12)) return zip_open_failed (f);   // Container_0 + n ContainerItem
         if (c.kind == GZ_FQ_SEQ_SNIP) { if (!c.snip_len || c.snip_len > 4 || f->seq_snip_ctx >= 0) return zip_open_failed (f); f->seq_snip_ctx = (int)i; }
         if (c.kind == GZ_FQ_QUAL) { if (f->qual_ctx >= 0) return zip_open_failed (f); f->qual_ctx = (int)i; }     // (one QUAL per plan)
@@ -638,7 +640,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
 
     K.col.assign ((size_t)NV * NC, ZipCol ());
     auto COL = [&] (uint32_t v, uint32_t c) -> ZipCol & { return K.col[(size_t)v * NC + c]; };
-    std::vector<GzIntColJob> icol_jobs; std::vector<GzDynIntJob> dyn_jobs; std::vector<GzBlobJob> blob_jobs; std::vector<GzAcgtJob> acgt_jobs;
+    std::vector<GzIntColJob> icol_jobs; std::vector<GzDynIntJob> dyn_jobs; std::vector<GzBlobJob> blob_jobs, pre_jobs; std::vector<GzAcgtJob> acgt_jobs;
     std::vector<GzDomqJob> domq_jobs; std::vector<GzDomqFitJob> fit_jobs;
     const int qmode0 = f->qual_mode;                       // as the call finds it
     K.domq.clear (); K.qual_mode_applied = -1;
@@ -702,9 +704,22 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
                 GzColumnJob j; memset (&j, 0, sizeof (j));
                 j.text = text; j.off = coff; j.len = clen; j.n = nn;
                 if (X.kind == GZ_FQ_SEQ_SNIP) { j.text = sq_slots; j.off = sq_off + rr; j.len = sq_len + rr; }   // (generated text: 16-byte slots)
+                uint64_t lead_bytes = 0;
+                if (X.kind == GZ_FQ_ITEM_TEXT && X.snip_len) {
+                    // every snip is `snip` + the item (sam_seg_CIGAR, src/sam_cigar.c:717-720): the column is gathered into a text of its own
+                    GzBlobJob pj; memset (&pj, 0, sizeof (pj));
+                    pj.text = text; pj.off = coff; pj.len = clen; pj.n = nn; pj.pre_len = X.snip_len; memcpy (pj.pre, X.snip, X.snip_len);
+                    lead_bytes = (uint64_t)nn * X.snip_len;
+                    pj.out = (uint8_t *)ws_alloc (f, vbs[v].text_len + lead_bytes + 64);
+                    pj.item_off = (uint32_t *)ws_alloc (f, ((size_t)nn + 1) * 4); pj.item_len = (uint32_t *)ws_alloc (f, ((size_t)nn + 1) * 4);
+                    pj.out_len_dev = (uint64_t *)ws_alloc (f, 8);
+                    if (!pj.out || !pj.item_off || !pj.item_len || !pj.out_len_dev) return GZ_ERR_HIP;
+                    pre_jobs.push_back (pj);
+                    j.text = pj.out; j.off = pj.item_off; j.len = pj.item_len;
+                }
                 j.ol_dict = ol[c].dict; j.ol_char_index = ol[c].ci; j.ol_snip_len = ol[c].sl; j.n_ol = ol[c].n;
                 // the dictionary of a column cannot exceed its snips + a NUL each; an item is at most the line
-                const uint64_t dict_cap = X.kind == GZ_FQ_ITEM_INT ? (uint64_t)nn * 24 + 64 : X.kind == GZ_FQ_SEQ_SNIP ? (uint64_t)nn * 17 + 64 : vbs[v].text_len + nn + 64;
+                const uint64_t dict_cap = X.kind == GZ_FQ_ITEM_INT ? (uint64_t)nn * 24 + 64 : X.kind == GZ_FQ_SEQ_SNIP ? (uint64_t)nn * 17 + 64 : vbs[v].text_len + nn + lead_bytes + 64;
                 j.node_index = (int32_t *)ws_alloc (f, ((size_t)nn + 1) * 4); j.dict = (uint8_t *)ws_alloc (f, dict_cap); j.dict_cap = dict_cap;
                 j.node_char_index = (uint64_t *)ws_alloc (f, ((size_t)nn + 1) * 8); j.node_snip_len = (uint32_t *)ws_alloc (f, ((size_t)nn + 1) * 4);
                 j.counts = (uint32_t *)ws_alloc (f, ((size_t)nn + ol[c].n + 1) * 4); j.b250 = (uint8_t *)ws_alloc (f, (size_t)nn * 4 + 16);
@@ -730,9 +745,10 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
             if (X.kind == GZ_FQ_SEQ || (X.kind == GZ_FQ_QUAL && qmode0 <= 0)) {
                 GzBlobJob j; memset (&j, 0, sizeof (j));
                 j.text = text; j.off = (X.kind == GZ_FQ_SEQ ? seq_off : qual_off) + rr; j.len = (X.kind == GZ_FQ_SEQ ? (nonref_len ? nonref_len : seq_len) : qual_len) + rr; j.n = n;
-                Z.local_cap = vbs[v].text_len + 64;
+                Z.local_cap = vbs[v].text_len + 64 + (X.kind == GZ_FQ_SEQ ? (uint64_t)f->plan.seq_pad * n : 0);
                 if (!(Z.local = (uint8_t *)ws_alloc (f, Z.local_cap + 64))) return GZ_ERR_HIP;
                 j.out = Z.local; Z.blob_job = (int)blob_jobs.size (); j.out_len_dev = d_blobres + Z.blob_job;
+                if (X.kind == GZ_FQ_SEQ && f->plan.seq_pad) { j.pad_to = f->plan.seq_pad; j.pad_byte = 'A'; }   // (sam_seg_SEQ_pad_nonref, src/sam_seq.c:224-229)
                 blob_jobs.push_back (j);
                 if (X.kind == GZ_FQ_SEQ) {
                     GzAcgtJob aj; memset (&aj, 0, sizeof (aj));
@@ -833,6 +849,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
                         (const uint64_t *)(d_vb_off + NV), NV, RL, d_vbstat);
     ZCHK (gz_int_columns (h, icol_jobs.data (), (int)icol_jobs.size ()));
     // (column tables hold at most 65 535 rows per call)
+    for (size_t at = 0; at < pre_jobs.size (); at += 32768) ZCHK (gz_local_blob_columns (h, pre_jobs.data () + at, (int)std::min<size_t> (32768, pre_jobs.size () - at)));
     for (size_t at = 0; at < col_jobs.size (); at += 32768) ZCHK (gz_ctx_seg_columns (h, col_jobs.data () + at, (int)std::min<size_t> (32768, col_jobs.size () - at)));
     for (size_t at = 0; at < dyn_jobs.size (); at += 32768) ZCHK (gz_dyn_int_columns (h, dyn_jobs.data () + at, (int)std::min<size_t> (32768, dyn_jobs.size () - at)));
     ZCHK (gz_acgt_pack_batch (h, acgt_jobs.data (), (int)acgt_jobs.size ()));

@@ -133,6 +133,7 @@ def c_plan(plan):
     p.vb_size = plan.get("vb_size", 0)
     p.line3_empty = plan.get("line3_empty", 0)
     p.vb_1_not_representative = plan.get("vb_1_not_representative", 0)
+    p.seq_pad = plan.get("seq_pad", 0)
     p.record_lines, p.seq_item, p.qual_item = plan.get("record_lines", 0), plan.get("seq_item", 0), plan.get("qual_item", 0)
     p.n_samples, p.n_subfields = plan.get("n_samples", 0), plan.get("n_subfields", 0)
     return p, keep

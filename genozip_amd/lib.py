@@ -61,7 +61,8 @@ class GzDynIntJob(C.Structure):
 
 class GzBlobJob(C.Structure):
     _fields_ = [("text", C.c_void_p), ("off", C.c_void_p), ("len", C.c_void_p), ("n", C.c_uint32), ("add_nul", C.c_uint32),
-                ("out", C.c_void_p), ("out_len_dev", C.c_void_p)]
+                ("out", C.c_void_p), ("out_len_dev", C.c_void_p),
+                ("pre", C.c_uint8 * 4), ("pre_len", C.c_uint32), ("pad_to", C.c_uint32), ("pad_byte", C.c_uint32), ("item_off", C.c_void_p), ("item_len", C.c_void_p)]
 
 
 class GzSection(C.Structure):
@@ -119,7 +120,7 @@ class GzFastqPlan(C.Structure):
     _fields_ = [("ctxs", C.POINTER(GzFastqCtx)), ("n_ctxs", C.c_uint32), ("seps", C.c_char * 16), ("sep_counts", C.c_uint8 * 16),
                 ("n_seps", C.c_uint32), ("paired", C.c_uint8), ("estimated_entries", C.c_uint32), ("qual_codec", C.c_uint8), ("vb_size", C.c_uint64),
                 ("record_lines", C.c_uint8), ("seq_item", C.c_uint8), ("qual_item", C.c_uint8), ("n_samples", C.c_uint32), ("n_subfields", C.c_uint8), ("line3_empty", C.c_uint8),
-                ("vb_1_not_representative", C.c_uint8)]
+                ("seq_pad", C.c_uint8), ("vb_1_not_representative", C.c_uint8)]
 
 
 class GzFastqVB(C.Structure):

@@ -5,24 +5,32 @@ by its flavor (Illumina-7, src/qname_flavors.h:40-49), and the optional fields a
 
     A00123:45:HXXXXXXXX:1:1101:10000:10000 <tab> FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL [<tab> optional fields]
 
-How each field reaches its context follows the reference's segmenter where the driver has the means (SURVEY 8(0), row configs[2]):
+How each field reaches its context follows the reference's segmenter where the driver has the means (SURVEY 8(0), row configs[2]), and
+the snips are the reference's own encodings - **the reference's genounzip reconstructs the SAM text from a file made with this plan**
+(tests/test_e2e_genounzip.py::test_sam_round_trip):
   QNAME items   as in FASTQ (qname_seg_qf, src/qname.c:715-806): textual / integer in local / self-delta
-  FLAG MAPQ RNAME RNEXT CIGAR   snips -> dictionary + b250 (sam_seg_FLAG, seg_by_did; sam_seg_CIGAR segs the CIGAR text as a snip,
-                src/sam_cigar.c:708-760 - the reference puts { SNIP_SPECIAL, SAM_SPECIAL_CIGAR } in front of it, this plan does not)
+  FLAG          snips -> dictionary + b250, the context storing the value (sam_seg_FLAG; the reader's last_flags, src/sam_private.h)
+  MAPQ RNAME RNEXT   snips -> dictionary + b250 (seg_by_did)
+  CIGAR         { SNIP_SPECIAL, SAM_SPECIAL_CIGAR } + the CIGAR text as the snip (sam_seg_CIGAR, src/sam_cigar.c:708-760: the reader's
+                sam_cigar_special_CIGAR analyses it - seq_len, reference consumed - for SEQ and QUAL, :940-1033)
   POS           delta against the previous line in a dyn-int local (sam_seg_POS -> seg_pos_field: a delta snip per line in the b250 in
-                the reference; here the same deltas as integers in local, the form seg_self_delta gives ordered QNAME items)
+                the reference; here the same deltas as integers in local, the form seg_self_delta gives ordered QNAME items), value stored
   PNEXT TLEN    seg_integer_or_not: dyn-int local ('*' / non-numbers as snips)
-  SEQ           no reference genome: NONREF.local -> CODEC_ACGT's 2-bit pack + NONREF_X, SQBITMAP's special snip with the length
-                (sam_seg_SEQ's verbatim branch; the same contexts FASTQ uses, src/fastq.h:13-60)
-  QUAL          QUAL.local; CODEC_DOMQ when the file's first VBlock is a fit (codec_assign_best_qual_codec, src/codec.c:391-450; the
-                reference also considers CODEC_NORMQ for SAM, which is not built)
-  optional      one textual item (the reference segs every tag into a context of its own: not built)
-What is NOT the reference's: the TOPLEVEL / QNAME containers of this plan are built in the reference's container FORMAT but are this
-repo's own choice of items (the reference's SAM reconstruction logic - sam_piz.c, buddies, MD / NM prediction - is out of scope), so a
-file made with this plan is not offered to genounzip; parity for this plan: the CPU restatement's composition in tests/parity.py."""
-from .fastq import (dict_id, container, container_snip, DTYPE_FIELD, DTYPE_1, STORE_INT, SNIP_SELF_DELTA, SNIP_SPECIAL, FASTQ_SPECIAL_unaligned_SEQ, CON_PX_SEP, CI0_COLONn,
-                    CON_FILTER_REPEATS, CON_FILTER_ITEMS, CON_IS_TOPLEVEL, CON_CALLBACK)
-from .lib import (GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL, GZ_FQ_QUAL_AUX, GZ_FQ_TOPLEVEL, GZ_FQ_SEQ_SNIP)
+  SEQ           no reference genome: sam_seg_SEQ's verbatim branch (src/sam_seq.c:744-757) - the bases into NONREF.local, 'A's after
+                every read up to a multiple of 4 (sam_seg_SEQ_pad_nonref, :224-229) -> CODEC_ACGT's 2-bit pack + NONREF_X; SQBITMAP's
+                snip { SNIP_SPECIAL, SAM_SPECIAL_SEQ, '0','0','0','0','0','1' }: the last flag is force_verbatim (:806-821,1064,1101-1113)
+  QUAL          QUAL.local (LT_BLOB, or LT_CODEC through CODEC_DOMQ when the file's first VBlock is a fit, codec_assign_best_qual_codec,
+                src/codec.c:391-450; the reference also considers CODEC_NORMQ for SAM, which is not built), seq_len scores per line
+  optional      one textual item (the reference segs every tag into a context of its own behind an AUX container: not built)
+The TOPLEVEL container has the reference's items in the reference's order (sam_seg_finalize, src/sam_seg.c:572-593) less BUDDY (mates are
+not looked up) and with the optional fields as one item. What is NOT the reference's: which fields the reference would predict from
+mates, MD / NM from the sequence, the reference-based SEQ - its alignment analysis is out of scope. Parity for this plan: the
+CPU restatement's composition in tests/parity.py + the reference's own reader."""
+from .fastq import (dict_id, container, container_snip, DTYPE_FIELD, DTYPE_1, STORE_INT, SNIP_SELF_DELTA, SNIP_SPECIAL, CI0_COLONn,
+                    CON_FILTER_ITEMS, CON_IS_TOPLEVEL, CON_CALLBACK)
+from .lib import (GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL, GZ_FQ_QUAL_AUX, GZ_FQ_TOPLEVEL)
+
+SAM_SPECIAL_CIGAR, SAM_SPECIAL_QUAL, SAM_SPECIAL_SEQ = 32 + 0, 32 + 16, 32 + 18          # src/sam.h:858,874,876 (+32: seg.h:33)
 
 
 def sam_plan(has_aux=True, qual_codec=0, estimated_entries=0, domq=0, vb_size=0):
@@ -42,22 +50,24 @@ def sam_plan(has_aux=True, qual_codec=0, estimated_entries=0, domq=0, vb_size=0)
     ctx("Q3NAME", 5, GZ_FQ_ITEM_DELTA, DTYPE_1, item=3, flags=STORE_INT, snip=bytes([SNIP_SELF_DELTA]) + b"$")
     ctx("Q4NAME", 6, GZ_FQ_ITEM_DELTA, DTYPE_1, item=4, flags=STORE_INT, snip=bytes([SNIP_SELF_DELTA]) + b"$")
     ctx("AUX", 53, GZ_FQ_ITEM_TEXT, item=15) if has_aux else None
-    ctx("SQBITMAP", 54, GZ_FQ_SEQ_SNIP, snip=bytes([SNIP_SPECIAL, FASTQ_SPECIAL_unaligned_SEQ]) + b" ")
+    ctx("SQBITMAP", 54, GZ_FQ_CONST, snip=bytes([SNIP_SPECIAL, SAM_SPECIAL_SEQ]) + b"000001")       # (src/sam_seq.c:806-821)
     ctx("NONREF_X", 56, GZ_FQ_SEQ, local_dep=1)
     ctx("QUAL", 80, GZ_FQ_QUAL, lcodec=qual_codec)
     for k, tag in enumerate(("DOMQRUNS", "QUALMPLX", "DIVRQUAL")):
         ctx(tag, 81 + k, GZ_FQ_QUAL_AUX, item=k, local_dep=2)
-    fields = [("FLAG", 100, GZ_FQ_ITEM_TEXT, 5), ("RNAME", 0, GZ_FQ_ITEM_TEXT, 6), ("POS", 101, GZ_FQ_ITEM_DELTA, 7), ("MAPQ", 102, GZ_FQ_ITEM_TEXT, 8),
-              ("CIGAR", 103, GZ_FQ_ITEM_TEXT, 9), ("RNEXT", 104, GZ_FQ_ITEM_TEXT, 10), ("PNEXT", 105, GZ_FQ_ITEM_INT, 11), ("TLEN", 106, GZ_FQ_ITEM_INT, 12)]
-    for tag, did, kind, item in fields:
-        ctx(tag, did, kind, item=item, flags=STORE_INT if kind == GZ_FQ_ITEM_DELTA else 0, snip=(bytes([SNIP_SELF_DELTA]) + b"$") if kind == GZ_FQ_ITEM_DELTA else b"")
+    cigar_lead = bytes([SNIP_SPECIAL, SAM_SPECIAL_CIGAR])
+    fields = [("FLAG", 100, GZ_FQ_ITEM_TEXT, 5, STORE_INT, b""), ("RNAME", 0, GZ_FQ_ITEM_TEXT, 6, 0, b""), ("POS", 101, GZ_FQ_ITEM_DELTA, 7, STORE_INT, b""),
+              ("MAPQ", 102, GZ_FQ_ITEM_TEXT, 8, 0, b""), ("CIGAR", 103, GZ_FQ_ITEM_TEXT, 9, 0, cigar_lead), ("RNEXT", 104, GZ_FQ_ITEM_TEXT, 10, 0, b""),
+              ("PNEXT", 105, GZ_FQ_ITEM_INT, 11, 0, b""), ("TLEN", 106, GZ_FQ_ITEM_INT, 12, 0, b"")]
+    for tag, did, kind, item, flags, lead in fields:
+        ctx(tag, did, kind, item=item, flags=flags, snip=(bytes([SNIP_SELF_DELTA]) + b"$") if kind == GZ_FQ_ITEM_DELTA else lead)
     order = ["QNAME", "FLAG", "RNAME", "POS", "MAPQ", "CIGAR", "RNEXT", "PNEXT", "TLEN", "SQBITMAP", "QUAL"] + (["AUX"] if has_aux else [])
     top = container([(dict_id(t), b"\t" if i + 1 < len(order) else b"") for i, t in enumerate(order)] + [(dict_id("EOL"), b"")],
-                    flags=CON_FILTER_REPEATS | CON_FILTER_ITEMS | CON_IS_TOPLEVEL | CON_CALLBACK)
+                    flags=CON_FILTER_ITEMS | CON_IS_TOPLEVEL | CON_CALLBACK)             # (src/sam_seg.c:572-577)
     ctx("TOPLEVEL", 120, GZ_FQ_TOPLEVEL, snip=top, con_len=len(top))
     ctx("EOL", 121, GZ_FQ_CONST, snip=b"\n")
     P.sort(key=lambda c: c["did_i"])
     seps = b"::::" + b"\t" * (11 if has_aux else 10)
     counts = [3, 1, 1, 1] + [1] * (11 if has_aux else 10)
     return dict(ctxs=P, seps=seps, sep_counts=counts, paired=False, estimated_entries=estimated_entries, qual_codec=domq, vb_size=vb_size, line3_empty=0, vb_1_not_representative=0b100,
-                record_lines=1, seq_item=13, qual_item=14)
+                record_lines=1, seq_item=13, qual_item=14, seq_pad=4)

@@ -291,10 +291,18 @@ typedef struct {
 int gz_dyn_int_columns (GzHandle *h, const GzDynIntJob *jobs, int n_jobs);
 
 /* seg_add_to_local_fixed_do over a column (src/seg.c:1268-1287): the field of every line gathered into the context's
- * local, each followed by a NUL if add_nul - e.g. SEQ of every read -> NONREF.local, QUAL -> QUAL.local. */
+ * local, each followed by a NUL if add_nul - e.g. SEQ of every read -> NONREF.local, QUAL -> QUAL.local.
+ * pre_len (<= 4) bytes `pre` in front of every item: a field whose snips carry a constant lead-in, e.g. sam_seg_CIGAR's
+ *   { SNIP_SPECIAL, SAM_SPECIAL_CIGAR } (src/sam_cigar.c:717-720); with item_off (device, n entries, or NULL) = where each item
+ *   starts in `out`, the gathered items are the column gz_ctx_seg_columns then segs (length = len + pre_len).
+ * pad_to (0 or a power of two) / pad_byte: every item is followed by pad_byte's up to the next multiple of pad_to - SAM's
+ *   verbatim SEQ in NONREF.local: sam_seg_SEQ_pad_nonref adds 'A's so that every read starts a new byte of the 2-bit packing
+ *   (src/sam_seq.c:224-229). `out` needs n * (pre_len + add_nul + pad_to) bytes beyond the items. */
 typedef struct {
     const uint8_t *text; const uint32_t *off, *len; uint32_t n; uint32_t add_nul;
     uint8_t *out; uint64_t *out_len_dev;
+    uint8_t pre[4]; uint32_t pre_len; uint32_t pad_to; uint32_t pad_byte;
+    uint32_t *item_off, *item_len;    /* (item_len: len + pre_len of every item - the lengths of that column) */
 } GzBlobJob;
 int gz_local_blob_columns (GzHandle *h, const GzBlobJob *jobs, int n_jobs);
 
@@ -419,7 +427,9 @@ int gz_zctx_commit_codec (GzZctx *z, int is_local, int codec);
 enum {
     GZ_FQ_CONST      = 1,  /* every line segs the same snip (a container, SEQ's special snip, line 3, an EOL ...): the b250
                               is all-the-same; nothing is computed per line                                                */
-    GZ_FQ_ITEM_TEXT  = 2,  /* seg_by_ctx of a line-1 item (qname.c:790): dictionary + b250                                */
+    GZ_FQ_ITEM_TEXT  = 2,  /* seg_by_ctx of a line-1 item (qname.c:790): dictionary + b250. With a `snip` (<= 4 bytes): every snip is
+                              `snip` + the item - a field the reference segs behind a constant lead-in, e.g. sam_seg_CIGAR's
+                              { SNIP_SPECIAL, SAM_SPECIAL_CIGAR } + the CIGAR text (src/sam_cigar.c:717-720)                       */
     GZ_FQ_ITEM_INT   = 3,  /* seg_integer_or_not of a line-1 item (qname.c:773-775): dyn-int local + SNIP_LOOKUP b250     */
     GZ_FQ_ITEM_DELTA = 4,  /* seg_self_delta of a line-1 item (qname.c:750-759, sorted_by_qname): the delta against the
                               previous line in a dyn-int local, the constant snip `snip` (SNIP_SELF_DELTA '$') in the b250  */
@@ -484,6 +494,8 @@ typedef struct {
     uint8_t  n_subfields;
     uint8_t  line3_empty;         /* segconf.line3 == L3_EMPTY: line 3 is "+" alone, takes no context (the '+' is a prefix of the TOPLEVEL
                                      container) and anything else there is an error (fastq_seg_LINE3, src/fastq_desc.c:33-37)          */
+    uint8_t  seq_pad;             /* 0 (FASTQ) or 4: SAM's verbatim SEQ - every read's bases in NONREF.local are followed by 'A's up to a multiple of
+                                     4, so that every read starts a new byte of the 2-bit packing (sam_seg_SEQ_pad_nonref, src/sam_seq.c:224-229,746-751) */
     uint8_t  vb_1_not_representative;   /* DTP (vb_1_not_representative) of the data type (src/data_types.h:57,148-152: VCF 0b110, SAM / BAM 0b100,
                                      FASTQ 0): bit 0 field contexts, bit 1 DTYPE_1, bit 2 DTYPE_2 (dict_id[0] >> 6: 0, 2 or 3, 1; src/dict_id.h:
                                      15-17). The beginning of such a file may not speak for the rest (src/codec.c:199-209), so for these contexts

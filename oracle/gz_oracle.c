@@ -1551,6 +1551,25 @@ uint64_t gzo_local_blob_column (const uint8_t *text, const uint32_t *off, const 
     return at;
 }
 
+/* the same with what the SAM segmenter adds around a field: a constant lead-in in front of every item (sam_seg_CIGAR's
+ * { SNIP_SPECIAL, SAM_SPECIAL_CIGAR } in front of the CIGAR text, src/sam_cigar.c:717-720) and / or padding after it up to a
+ * multiple of pad_to (sam_seg_SEQ_pad_nonref: 'A's until NONREF.local's length is a multiple of 4, src/sam_seq.c:224-229).
+ * item_off (or NULL): where every item starts. */
+uint64_t gzo_local_blob_column_ex (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n, int add_nul,
+                                   const uint8_t *pre, uint32_t pre_len, uint32_t pad_to, uint8_t pad_byte, uint8_t *out, uint32_t *item_off)
+{
+    uint64_t at = 0;
+    for (uint64_t k = 0; k < n; k++) {
+        if (item_off) item_off[k] = (uint32_t)at;
+        if (pre_len) { memcpy (out + at, pre, pre_len); at += pre_len; }
+        if (len[k]) memcpy (out + at, text + off[k], len[k]);
+        at += len[k];
+        if (add_nul) out[at++] = 0;
+        if (pad_to) while (at % pad_to) out[at++] = pad_byte;
+    }
+    return at;
+}
+
 /* ---- N1 (first part): lines, FASTQ records, tokens ---------------------------------------------------------------- */
 uint64_t gzo_text_lines (const uint8_t *text, uint64_t n, uint32_t *off, uint32_t *len, uint64_t cap)
 {

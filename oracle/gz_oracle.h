@@ -164,6 +164,8 @@ int gzo_dyn_int_column (const int64_t *values, const uint8_t *is_nothing /* or N
 /* seg_add_to_local_fixed_do over a column (seg.c:1268-1287): the snips one after the other, each followed by a NUL
  * if add_nul. Returns the length. */
 uint64_t gzo_local_blob_column (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n, int add_nul, uint8_t *out);
+uint64_t gzo_local_blob_column_ex (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n, int add_nul,
+                                   const uint8_t *pre, uint32_t pre_len, uint32_t pad_to, uint8_t pad_byte, uint8_t *out, uint32_t *item_off);
 
 /* ---- N1 (first part): the line buffer -> per-field (offset, length) columns -----------------------------------------
  * seg_get_next_line (seg.c:200-236) over a whole buffer: start and length of every line, the length without the

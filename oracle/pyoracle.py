@@ -240,10 +240,18 @@ class Oracle:
         w = {1: 1, 2: 1, 3: 2, 4: 2, 5: 4, 6: 4, 7: 8}[lt]
         return lt, out[:w * len(v)].tobytes()
 
-    def local_blob_column(self, text, off, length, add_nul=False):
+    def local_blob_column(self, text, off, length, add_nul=False, pre=b"", pad_to=0, pad_byte=0, want_off=False):
         import numpy as np
         text = bytes(text)
         off = np.ascontiguousarray(off, dtype=np.uint32); length = np.ascontiguousarray(length, dtype=np.uint32)
+        if pre or pad_to or want_off:
+            out = np.zeros(int(length.astype(np.uint64).sum()) + len(off) * (1 + len(pre) + pad_to) + 1, dtype=np.uint8)
+            io = np.zeros(len(off) + 1, dtype=np.uint32)
+            self.L.gzo_local_blob_column_ex.restype = ctypes.c_uint64
+            n = self.L.gzo_local_blob_column_ex(text, off.ctypes.data_as(ctypes.c_void_p), length.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(len(off)),
+                                                int(bool(add_nul)), bytes(pre), len(pre), int(pad_to), int(pad_byte), out.ctypes.data_as(ctypes.c_void_p),
+                                                io.ctypes.data_as(ctypes.c_void_p))
+            return (out[:n].tobytes(), io[:len(off)]) if want_off else out[:n].tobytes()
         out = np.zeros(int(length.astype(np.uint64).sum()) + len(off) + 1, dtype=np.uint8)
         self.L.gzo_local_blob_column.restype = ctypes.c_uint64
         n = self.L.gzo_local_blob_column(text, off.ctypes.data_as(ctypes.c_void_p), length.ctypes.data_as(ctypes.c_void_p),

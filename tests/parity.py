@@ -341,6 +341,15 @@ def seg_columns(E, oracle, n):
     assert blobs[1] == oracle.local_blob_column(t, oo, l, True)
     assert blobs[2] == b""
     assert blobs[3] == oracle.local_blob_column(cases[5][1], cases[5][2], cases[5][3], False) == cases[5][1]
+    # ... with the SAM segmenter's additions: a lead-in in front of every item (sam_cigar.c:717-720) with the items' offsets, padding
+    # after every item (sam_seq.c:224-229), both, a NUL inside the padding
+    variants = [(b"\x08\x20", 0, 0, False), (b"", 4, 65, False), (b"\x08", 8, 0x41, True), (b"abcd", 2, 0, False), (b"", 64, 1, True)]
+    got = E.local_blob_columns([(t, oo, l, nul, pre, pad, pb) for pre, pad, pb, nul in variants] + [(t, o[:0], l[:0], False, b"\x08\x20", 4, 65)], want_off=True)
+    for (pre, pad, pb, nul), (g, gio) in zip(variants, got):
+        want, wio = oracle.local_blob_column(t, oo, l, nul, pre=pre, pad_to=pad, pad_byte=pb, want_off=True)
+        assert g == want and np.array_equal(gio, wio), ("blob", pre, pad)
+        assert not pad or len(g) % pad == 0
+    assert got[-1][0] == b"" and len(got[-1][1]) == 0
 
 
 def _snip_column(snips):
@@ -703,7 +712,11 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
                         st.update(local=loc, ltype=lt2, has_local=len(raw) > 0)
                     else:
                         st.update(local=oracle.local_generate(lt, raw)[1], ltype=lt, has_local=len(raw) > 0)
-                st["col"] = oracle.ctx_seg_column(text + b"\x01", o, l, ol_words[c])
+                if k == GZ_FQ_ITEM_TEXT and X["snip"]:                  # a lead-in in front of every snip (sam_seg_CIGAR, sam_cigar.c:717-720)
+                    lead_text, lead_off = oracle.local_blob_column(text, o, l, False, pre=X["snip"], want_off=True)
+                    st["col"] = oracle.ctx_seg_column(lead_text + b"\x01", lead_off, (np.asarray(l, dtype=np.uint32) + len(X["snip"])).astype(np.uint32), ol_words[c])
+                else:
+                    st["col"] = oracle.ctx_seg_column(text + b"\x01", o, l, ol_words[c])
                 st["n_ol"] = len(ol_words[c])
             elif k == GZ_FQ_ITEM_DELTA:
                 o, l = io[X["item"]][a:b], il[X["item"]][a:b]
@@ -718,7 +731,7 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
                 con = bytearray(X["snip"][:X["con_len"]]); con[1:4] = n.to_bytes(3, "little")
                 st["own_snip"] = b"\x04" + base64.b64encode(bytes(con)) + X["snip"][X["con_len"]:]
             elif k == GZ_FQ_SEQ:
-                seq = oracle.local_blob_column(text, so[a:b], sl_nonref[a:b], False)
+                seq = oracle.local_blob_column(text, so[a:b], sl_nonref[a:b], False, pad_to=plan.get("seq_pad", 0), pad_byte=65)   # (sam_seq.c:224-229)
                 packed, x, has_x = oracle.acgt_pack(seq)
                 st.update(seq_packed=packed, n_bases=len(seq), seq_has_x=has_x, local=x, ltype=27, has_local=has_x)
             elif k == GZ_FQ_QUAL and zstate["qual_mode"] == 13 and n:
@@ -1582,7 +1595,7 @@ def sam_zip(E, oracle, n_reads, n_calls=2, qual="bin", aux=True):
             E.vb_uncompress(z, total)
             n_vb += 1
     words = {c["tag"]: F.zctx_words(i) for i, c in enumerate(plan["ctxs"])}
-    assert b"150M" in words["CIGAR"] and b"chr1" in words["RNAME"] and words["FLAG"]
+    assert b"\x08\x20150M" in words["CIGAR"] and b"chr1" in words["RNAME"] and words["FLAG"]      # (CIGAR: SNIP_SPECIAL, SAM_SPECIAL_CIGAR + text)
     F.close()
     return n_vb
 

@@ -180,3 +180,48 @@ def test_vcf_round_trip(emul_engine, genounzip, tmp_path):
     log = _run(genounzip, ["-f", "-o", "out.vcf", "cohort.vcf.genozip"], tmp_path)
     out = (tmp_path / "out.vcf").read_bytes() if (tmp_path / "out.vcf").exists() else b""
     assert out == header + b"".join(texts), log[:3000]
+
+
+SAM_HEADER = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:248956422\n@PG\tID:bwa\tPN:bwa\tVN:0.7.17\n"
+
+
+@pytest.mark.parametrize("qual,aux,dirty,header", [("uniform", False, False, b""), ("bin", True, True, SAM_HEADER), ("uniform", True, True, SAM_HEADER)])
+def test_sam_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, qual, aux, dirty, header):
+    """aligned reads as SAM text (BASELINE configs[2]'s shape) through the SAM plan of genozip_amd/sam.py - 4 VBlocks over 2 calls - and the
+    reference's decoder gives the text back byte for byte. What that pins beyond the FASTQ / VCF tests: the one-line-record plan's items
+    (the eleven mandatory fields by tab, QNAME by its flavor, the optional fields), CIGAR's snips { SNIP_SPECIAL, SAM_SPECIAL_CIGAR } + text
+    (src/sam_cigar.c:717-720) which the reader analyses for the lengths of SEQ and QUAL, SQBITMAP's verbatim special (src/sam_seq.c:806-821),
+    NONREF with every read padded to whole bytes of the 2-bit packing (:224-229) incl. NONREF_X for bases that are not ACGT, QUAL as LT_BLOB
+    and through CODEC_DOMQ with seq_len taken from the CIGAR, FLAG / POS as value-storing contexts, a header component for SAM"""
+    import random
+    import numpy as np
+    from genozip_amd import sam as sm
+    plan = sm.sam_plan(has_aux=aux)
+    F = emul_engine.zip_open(plan)
+    res, texts, vb_i = [], [], 0
+    for call, nr in enumerate((240, 150)):
+        text = parity.sam_aligned_text(nr, seed=21 + call, qual=qual, aux=aux)
+        if dirty:                                              # bases that are not ACGT -> NONREF_X (CODEC_XCGT)
+            rnd, lines = random.Random(7 + call), []
+            for ln in text.split(b"\n")[:-1]:
+                fl = ln.split(b"\t")
+                sq = bytearray(fl[9])
+                for _ in range(rnd.randrange(4)):
+                    sq[rnd.randrange(len(sq))] = ord("N")
+                fl[9] = bytes(sq)
+                lines.append(b"\t".join(fl))
+            text = b"\n".join(lines) + b"\n"
+        nl = np.flatnonzero(np.frombuffer(text, dtype=np.uint8) == 10)
+        cut = int(nl[(2 * nr) // 3 - 1]) + 1
+        got = F.zip_vblocks(text, [(0, cut, vb_i + 1, -1), (cut, len(text) - cut, vb_i + 2, -1)])
+        for g in got:
+            g["z"] = F.with_nonref(g, lzma_sub)
+        res += got
+        vb_i += 2
+        texts.append(text)
+    blob = F.write_file([dict(name=b"reads.sam", pair=0, vbs=res, header=header)], data_type=2)
+    F.close()
+    (tmp_path / "reads.sam.genozip").write_bytes(blob)
+    log = _run(genounzip, ["-f", "-o", "out.sam", "reads.sam.genozip"], tmp_path)
+    out = (tmp_path / "out.sam").read_bytes() if (tmp_path / "out.sam").exists() else b""
+    assert out == header + b"".join(texts), log[:3000]
