@@ -713,6 +713,58 @@ class Engine:
             return tbuf, ob, lb, rb, n_lines
         return (np.frombuffer(self.mem.download(ob, 4 * n_lines), dtype=np.uint32), np.frombuffer(self.mem.download(lb, 4 * n_lines), dtype=np.uint32))
 
+    # ---- N1 for BAM: alignment records -> alignment lines ----------------------------------------------------
+    def _bam_result(self, rb):
+        from .lib import GzBamResult
+        return GzBamResult.from_buffer_copy(self.mem.download(rb, C.sizeof(GzBamResult)))
+
+    def bam_records(self, bam, n_ref, cap=None, on_device=False):
+        """bam: the alignment records (bytes | device buffer) -> record offsets (numpy, or (device buffer, count) with on_device);
+        raises on a chain that does not fit the stream. self.last_bam = the GzBamResult"""
+        import numpy as np
+        host = isinstance(bam, (bytes, bytearray))
+        bbuf = self.mem.upload(bytes(bam) + b"\0" * 16) if host else bam
+        n = len(bam) if host else int(bbuf.numel() if hasattr(bbuf, "numel") else bbuf.size)
+        if cap is None:
+            cap = n // 36 + 1
+        ob, rb = self.mem.alloc(4 * cap + 16), self.mem.alloc(64)
+        self._check(self.L.gz_bam_records(self.h, self.mem.ptr(bbuf), n, n_ref, self.mem.ptr(ob), cap, self.mem.ptr(rb)), "gz_bam_records")
+        self.sync()
+        r = self.last_bam = self._bam_result(rb)
+        if r.status != 1:
+            raise GenozipAMDError("gz_bam_records: status %d, record %d, %d records" % (r.status, r.first_bad, r.n_records))
+        if on_device:
+            return bbuf, ob, int(r.n_records)
+        return np.frombuffer(self.mem.download(ob, 4 * int(r.n_records)), dtype=np.uint32).copy()
+
+    def bam_to_sam(self, bam, rec_off, ref_names, text_cap=None, on_device=False, n_rec=None):
+        """records -> the text of their alignment lines. ref_names: list of bytes (the header's reference names, in id order).
+        -> (text bytes, line_off numpy [n + 1]); on_device: (device text buffer, text_len, device line_off buffer)"""
+        import numpy as np
+        host = isinstance(bam, (bytes, bytearray))
+        bbuf = self.mem.upload(bytes(bam) + b"\0" * 16) if host else bam
+        n = len(bam) if host else int(bbuf.numel() if hasattr(bbuf, "numel") else bbuf.size)
+        if isinstance(rec_off, np.ndarray):
+            n_rec = len(rec_off)
+            robuf = self.mem.upload(np.ascontiguousarray(rec_off, dtype=np.uint32).tobytes() + b"\0" * 16)
+        else:
+            robuf = rec_off
+        names = b"".join(ref_names)
+        noff = np.concatenate([[0], np.cumsum([len(x) for x in ref_names])]).astype(np.uint32)
+        nbuf, nobuf = self.mem.upload(names + b"\0" * 16), self.mem.upload(noff.tobytes() + b"\0" * 16)
+        if text_cap is None:
+            text_cap = 6 * n + 64 * n_rec + 1024                                      # (an int8 array element: 1 byte -> up to 5 characters)
+        tb, lb, rb = self.mem.alloc(text_cap + 64), self.mem.alloc(4 * (n_rec + 1) + 16), self.mem.alloc(64)
+        self._check(self.L.gz_bam_to_sam(self.h, self.mem.ptr(bbuf), n, self.mem.ptr(robuf), n_rec, self.mem.ptr(nbuf), self.mem.ptr(nobuf), len(ref_names),
+                                         self.mem.ptr(tb), text_cap, self.mem.ptr(lb), self.mem.ptr(rb)), "gz_bam_to_sam")
+        self.sync()
+        r = self.last_bam = self._bam_result(rb)
+        if r.status != 1:
+            raise GenozipAMDError("gz_bam_to_sam: status %d, record %d, text %d bytes (cap %d)" % (r.status, r.first_bad, r.text_len, text_cap))
+        if on_device:
+            return tb, int(r.text_len), lb
+        return self.mem.download(tb, int(r.text_len)), np.frombuffer(self.mem.download(lb, 4 * (n_rec + 1)), dtype=np.uint32).copy()
+
     def vcf_sample_columns(self, text, line_off, line_len, n_samples, n_sub):
         """the FORMAT subfields of every sample of the given data lines -> (n_bad, item_off [n_sub][lines * samples], item_len, missing)"""
         import numpy as np

@@ -27,6 +27,7 @@
 #include "gz_merge.h"
 #include "gz_kernels_zip.h"
 #include "gz_kernels_domq.h"
+#include "gz_kernels_bam.h"
 
 #define GZ_VERSION "genozip_amd 0.1 (gfx950; format parity: genozip 15.0.86)"
 
@@ -1571,6 +1572,51 @@ extern "C" int gz_local_blob_columns (GzHandle *h, const GzBlobJob *jobs, int n_
     KLAUNCH (h, k_blob_sum, dim3 (max_tiles, n_jobs), dim3 (256), 2048, (GzdBlob *)dj);
     KLAUNCH (h, k_blob_scan, dim3 (n_jobs), dim3 (256), 2048, (GzdBlob *)dj);
     KLAUNCH (h, k_blob_copy, dim3 (max_tiles, n_jobs), dim3 (256), 2048, (GzdBlob *)dj);
+    HIPCHK (h, hipGetLastError ());
+    return GZ_OK;
+}
+
+extern "C" int gz_bam_records (GzHandle *h, const uint8_t *bam, uint64_t n_bytes, int32_t n_ref, uint32_t *rec_off, uint32_t cap, GzBamResult *result_dev)
+{
+    if (!h || !result_dev || (n_bytes && !bam) || (cap && !rec_off) || n_bytes >= 0xfffffff0ull || n_ref < 0) return GZ_ERR_ARG;
+    HIPCHK (h, hipSetDevice (h->device));
+    const uint32_t n_chunks = (uint32_t)((n_bytes + GZ_BAM_CHUNK - 1) / GZ_BAM_CHUNK);
+    GzdBamChain B;
+    B.bam = bam; B.n = n_bytes; B.rec_off = rec_off; B.cap = cap; B.result = result_dev; B.n_ref = n_ref;
+    uint32_t *scr = (uint32_t *)arena_alloc (h, ((size_t)3 * (n_chunks + 1) + 4) * 4);
+    B.tile = (uint64_t *)arena_alloc (h, ((size_t)n_chunks + 2) * 8);
+    if (!scr || !B.tile) return GZ_ERR_HIP;
+    B.entry = scr; B.exit_ = scr + (n_chunks + 1); B.count = scr + 2 * (size_t)(n_chunks + 1);
+    uint32_t *first_wrong = scr + 3 * (size_t)(n_chunks + 1);
+    HIPCHK (h, hipMemsetAsync (first_wrong, 0xff, 4, h->stream));
+    if (n_chunks) {
+        KLAUNCH (h, k_bam_entry, dim3 (n_chunks), dim3 (64), 0, B);
+        KLAUNCH (h, k_bam_walk_count, dim3 ((n_chunks + 63) / 64), dim3 (64), 0, B, n_chunks);
+        KLAUNCH (h, k_bam_check, dim3 ((n_chunks + 63) / 64), dim3 (64), 0, B, n_chunks, first_wrong);
+    }
+    KLAUNCH (h, k_bam_fix, dim3 (1), dim3 (256), 8192, B, n_chunks, (const uint32_t *)first_wrong);
+    if (n_chunks) KLAUNCH (h, k_bam_walk_write, dim3 ((n_chunks + 63) / 64), dim3 (64), 0, B, n_chunks);
+    HIPCHK (h, hipGetLastError ());
+    return GZ_OK;
+}
+
+extern "C" int gz_bam_to_sam (GzHandle *h, const uint8_t *bam, uint64_t n_bytes, const uint32_t *rec_off, uint32_t n_rec,
+                              const uint8_t *ref_names, const uint32_t *ref_name_off, int32_t n_ref,
+                              uint8_t *text, uint64_t text_cap, uint32_t *line_off, GzBamResult *result_dev)
+{
+    if (!h || !result_dev || (n_rec && (!bam || !rec_off)) || (text_cap && !text) || n_ref < 0 || (n_ref && (!ref_names || !ref_name_off)) || n_bytes >= 0xfffffff0ull) return GZ_ERR_ARG;
+    HIPCHK (h, hipSetDevice (h->device));
+    GzdBamText T;
+    T.bam = bam; T.n = n_bytes; T.rec_off = rec_off; T.n_rec = n_rec; T.ref_names = ref_names; T.ref_name_off = ref_name_off; T.n_ref = n_ref;
+    T.text = text; T.text_cap = text_cap; T.line_off = line_off; T.result = result_dev;
+    const uint32_t tiles = (n_rec + 255) / 256;
+    T.len = (uint32_t *)arena_alloc (h, ((size_t)n_rec + 1) * 4);
+    T.tile = (uint64_t *)arena_alloc (h, ((size_t)tiles + 1) * 8);
+    if (!T.len || !T.tile) return GZ_ERR_HIP;
+    HIPCHK (h, hipMemsetAsync (result_dev, 0xff, sizeof (GzBamResult), h->stream));     // (first_bad = none)
+    if (tiles) KLAUNCH (h, k_bam_len, dim3 (tiles), dim3 (256), 2048, T);
+    KLAUNCH (h, k_bam_scan, dim3 (1), dim3 (256), 2048, T);
+    if (tiles) KLAUNCH (h, k_bam_write, dim3 (tiles), dim3 (256), 2048, T);
     HIPCHK (h, hipGetLastError ());
     return GZ_OK;
 }

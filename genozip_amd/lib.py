@@ -65,6 +65,10 @@ class GzBlobJob(C.Structure):
                 ("pre", C.c_uint8 * 4), ("pre_len", C.c_uint32), ("pad_to", C.c_uint32), ("pad_byte", C.c_uint32), ("item_off", C.c_void_p), ("item_len", C.c_void_p)]
 
 
+class GzBamResult(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("text_len", C.c_uint64), ("status", C.c_int32), ("first_bad", C.c_uint32), ("n_rewalked", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class GzSection(C.Structure):
     _fields_ = [("data", C.c_void_p), ("data_len", C.c_uint32), ("data_len_dev", C.c_void_p),
                 ("section_type", C.c_uint8), ("codec", C.c_uint8), ("sub_codec", C.c_uint8), ("flags", C.c_uint8),
@@ -156,6 +160,7 @@ ABI_SYMBOLS = (
     "gz_zfile_create", "gz_zfile_destroy", "gz_zfile_add_vblock", "gz_zfile_write_global_area", "gz_codec_assign_best_host",
     "gz_zfile_add_txt_header", "gz_zfile_add_txt_header_text", "gz_zfile_set_fastq", "gz_vb_insert_section",
     "gz_tokenize_column_n", "gz_int_columns", "gz_local_generate_batch", "gz_acgt_pack_batch",
+    "gz_bam_records", "gz_bam_to_sam",
 )
 
 
@@ -211,6 +216,8 @@ def load(path=None):
     L.gz_dyn_int_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.gz_local_blob_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.gz_text_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.gz_bam_records.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.gz_bam_to_sam.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     L.gz_fastq_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 9
     L.gz_seg_integer_or_not.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32] + [C.c_void_p] * 5
     for f in (L.gz_local_generate_partial, L.gz_local_partial_to_native):

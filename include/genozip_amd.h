@@ -411,6 +411,29 @@ int gz_zctx_view (const GzZctx *z, GzZctxView *view);
 /* codec_assign_best_codec's commit to the file-level context (src/codec.c:352-363) */
 int gz_zctx_commit_codec (GzZctx *z, int is_local, int codec);
 
+/* ---- N1 for BAM: the alignment records of an uncompressed BAM stream -> alignment lines (SURVEY 8(0) configs[2]) ----------------
+ * bam_seg_txt_line (src/bam_seg.c:425-520) reads a record's fields in their binary form, converts SEQ / CIGAR / QUAL to their textual
+ * forms (bam_seq_to_sam src/bam_seq.c:58-103, sam_cigar_binary_to_textual src/sam_cigar.c:155-206, bam_rewrite_qual src/bam_seg.c:
+ * 276-284) and segs them with the functions SAM uses; the contexts of a BAM file are SAM's. Here: records -> the text of their
+ * alignment lines in HBM, which the one-line-record plan of the VBlock driver (genozip_amd/sam.py) then segs.
+ * `bam` (device) points at the FIRST ALIGNMENT (the caller has read magic, header text and reference names - the txt-header component,
+ * host work) and holds whole records; < 4 GB per call. The BGZF layer in front of it is I/O and not part of this library.
+ * gz_bam_records: the offsets of the records (every record names the next by its block_size, bam_unconsumed_scan_forwards
+ *   src/bam_seg.c:49-67). status GZ_ST_CORRUPT: a block_size that does not fit (first_bad = index of that record; bam_seg.c:444-447) or
+ *   a last record that does not end with the stream; GZ_ST_TOO_SMALL: more than cap records (n_records is the true count).
+ *   n_rewalked: 64 KB chunks whose first record was not where the heuristic of bam_unconsumed_scan_backwards (:76-130) found one.
+ * gz_bam_to_sam: QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL [TAG:TYPE:VALUE ..] '\n' per record (RNAME / RNEXT through
+ *   the header's reference names: ref_names is their concatenation, ref_name_off their n_ref + 1 offsets; '*' for -1, '=' for
+ *   RNEXT == RNAME), integers of every width as TYPE i, Z / H / A, B arrays of integers. line_off: n_rec + 1 entries or NULL.
+ *   status GZ_ST_CORRUPT (first_bad): fields that do not fit their record, a reference id outside the header, a malformed optional
+ *   field, or a float (f, B:f: kept binary by the reference behind bam_piz_special_FLOAT, src/sam.h:863 - not built);
+ *   GZ_ST_TOO_SMALL: the text needs text_len > text_cap bytes (nothing is written). */
+typedef struct { uint64_t n_records, text_len; int32_t status; uint32_t first_bad, n_rewalked, reserved; } GzBamResult;
+int gz_bam_records (GzHandle *h, const uint8_t *bam, uint64_t n_bytes, int32_t n_ref, uint32_t *rec_off, uint32_t cap, GzBamResult *result_dev);
+int gz_bam_to_sam (GzHandle *h, const uint8_t *bam, uint64_t n_bytes, const uint32_t *rec_off, uint32_t n_rec,
+                   const uint8_t *ref_names, const uint32_t *ref_name_off, int32_t n_ref,
+                   uint8_t *text, uint64_t text_cap, uint32_t *line_off, GzBamResult *result_dev);
+
 /* ---- the VBlock compute driver: zip_compress_one_vb for a batch of FASTQ VBlocks (SURVEY 8(a) a15 + 8(f) N1) ----------------
  * What zip_compress_one_vb (src/zip.c:510-601) does between "text of a VBlock in memory" and "z_data ready to be written",
  * for a whole batch of VBlocks at once and with the per-field rules of fastq_seg_txt_line (src/fastq.c:1249-1309) and

@@ -8,6 +8,7 @@
 #define _GNU_SOURCE
 #include "gz_oracle.h"
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 #include <math.h>
 #include <pthread.h>
@@ -1568,6 +1569,110 @@ uint64_t gzo_local_blob_column_ex (const uint8_t *text, const uint32_t *off, con
         if (pad_to) while (at % pad_to) out[at++] = pad_byte;
     }
     return at;
+}
+
+/* ---- N1 for BAM: alignment records -> alignment lines ----------------------------------------------------------------
+ * What bam_seg_txt_line does to a record before the SAM functions seg its fields (src/bam_seg.c:425-520), restated serially:
+ * the walk over block_size (bam_unconsumed_scan_forwards :49-67, the range check of :444-447), and per record the textual forms
+ * of its fields: bam_seq_to_sam (src/bam_seq.c:58-103, table :15), sam_cigar_binary_to_textual (src/sam_cigar.c:155-206, table :23),
+ * bam_rewrite_qual (src/bam_seg.c:276-284), bam_split_aux (:187-224) with the SAM spelling of every optional field. */
+static uint32_t le32 (const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+static uint32_t le16 (const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8; }
+
+/* -> number of records, or -1 - index of the record whose block_size does not fit / after which the stream does not end */
+int64_t gzo_bam_records (const uint8_t *bam, uint64_t n, uint32_t *rec_off, uint64_t cap)
+{
+    uint64_t p = 0, k = 0;
+    while (p < n) {
+        if (p + 36 > n) return -1 - (int64_t)k;
+        const uint32_t bs = le32 (bam + p);
+        if (bs < 32 || (uint64_t)bs + 4 > n - p) return -1 - (int64_t)k;
+        if (k < cap) rec_off[k] = (uint32_t)p;
+        k++;
+        p += 4 + (uint64_t)bs;
+    }
+    return (int64_t)k;
+}
+
+static char *put_i64 (char *o, int64_t v) { return o + sprintf (o, "%lld", (long long)v); }
+
+/* -> length of the text (written if it fits cap), or -1 - index of the first record that cannot be written */
+int64_t gzo_bam_to_sam (const uint8_t *bam, const uint32_t *rec_off, uint64_t n_rec, const uint8_t *ref_names, const uint32_t *ref_name_off, int32_t n_ref,
+                        uint8_t *text, uint64_t cap, uint32_t *line_off)
+{
+    static const char bases[] = "=ACMGRSVTWYHKDBN", ops[] = "MIDNSHP=Xabcdefg";
+    uint64_t at = 0;
+    size_t buf_cap = 1 << 16;
+    char *buf = malloc (buf_cap);
+    for (uint64_t r = 0; r < n_rec; r++) {
+        const uint8_t *a = bam + rec_off[r];
+        const uint32_t bs = le32 (a);
+        const uint8_t *after = a + 4 + bs;
+        const int32_t ref_id = (int32_t)le32 (a + 4), pos = (int32_t)le32 (a + 8), next_ref = (int32_t)le32 (a + 24), next_pos = (int32_t)le32 (a + 28), tlen = (int32_t)le32 (a + 32);
+        const uint32_t l_read_name = a[12], mapq = a[13], n_cigar = le16 (a + 16), flag = le16 (a + 18), l_seq = le32 (a + 20);
+        if (l_read_name < 1 || l_seq > bs || (uint64_t)32 + l_read_name + 4ull * n_cigar + (l_seq + 1) / 2 + l_seq > bs ||
+            ref_id < -1 || ref_id >= n_ref || next_ref < -1 || next_ref >= n_ref) { free (buf); return -1 - (int64_t)r; }
+        const uint8_t *name = a + 36, *cigar = name + l_read_name, *seq = cigar + 4 * (size_t)n_cigar, *qual = seq + (l_seq + 1) / 2, *aux = qual + l_seq;
+        const size_t need = (size_t)bs * 12 + 4096;                     /* (an array of int8 takes up to 5 characters per byte) */
+        if (need > buf_cap) { buf_cap = need; buf = realloc (buf, buf_cap); }
+        char *o = buf;
+        memcpy (o, name, l_read_name - 1); o += l_read_name - 1; *o++ = '\t';
+        o = put_i64 (o, flag); *o++ = '\t';
+        if (ref_id < 0) *o++ = '*'; else { const uint32_t k = ref_name_off[ref_id + 1] - ref_name_off[ref_id]; memcpy (o, ref_names + ref_name_off[ref_id], k); o += k; }
+        *o++ = '\t'; o = put_i64 (o, (int64_t)pos + 1); *o++ = '\t'; o = put_i64 (o, mapq); *o++ = '\t';
+        if (!n_cigar) *o++ = '*';
+        else for (uint32_t i = 0; i < n_cigar; i++) { const uint32_t op = le32 (cigar + 4 * (size_t)i); o = put_i64 (o, op >> 4); *o++ = ops[op & 15]; }
+        *o++ = '\t';
+        if (next_ref < 0) *o++ = '*'; else if (next_ref == ref_id) *o++ = '=';
+        else { const uint32_t k = ref_name_off[next_ref + 1] - ref_name_off[next_ref]; memcpy (o, ref_names + ref_name_off[next_ref], k); o += k; }
+        *o++ = '\t'; o = put_i64 (o, (int64_t)next_pos + 1); *o++ = '\t'; o = put_i64 (o, tlen); *o++ = '\t';
+        if (!l_seq) *o++ = '*'; else for (uint32_t i = 0; i < l_seq; i++) *o++ = bases[(seq[i >> 1] >> ((i & 1) ? 0 : 4)) & 15];
+        *o++ = '\t';
+        if (!l_seq || qual[0] == 0xff) *o++ = '*'; else for (uint32_t i = 0; i < l_seq; i++) *o++ = (char)(qual[i] + 33);
+        int bad = 0;
+        while (aux < after && !bad) {
+            if (after - aux < 4) { bad = 1; break; }
+            const uint8_t t = aux[2];
+            *o++ = '\t'; *o++ = (char)aux[0]; *o++ = (char)aux[1]; *o++ = ':';
+            if (t == 'Z' || t == 'H') {
+                const uint8_t *e = memchr (aux + 3, 0, (size_t)(after - aux - 3));
+                if (!e) { bad = 1; break; }
+                *o++ = (char)t; *o++ = ':'; memcpy (o, aux + 3, (size_t)(e - aux - 3)); o += e - aux - 3;
+                aux = e + 1;
+            }
+            else if (t == 'B') {
+                if (after - aux < 8) { bad = 1; break; }
+                const uint8_t st = aux[3];
+                const uint32_t w = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I') ? 4 : 0, cnt = le32 (aux + 4);
+                if (!w || (uint64_t)cnt * w > (uint64_t)(after - aux - 8)) { bad = 1; break; }
+                *o++ = 'B'; *o++ = ':'; *o++ = (char)st;
+                for (uint32_t i = 0; i < cnt; i++) {
+                    const uint8_t *v = aux + 8 + (size_t)i * w;
+                    *o++ = ',';
+                    o = put_i64 (o, st == 'c' ? (int8_t)v[0] : st == 'C' ? v[0] : st == 's' ? (int16_t)le16 (v) : st == 'S' ? (int64_t)le16 (v) : st == 'i' ? (int32_t)le32 (v) : (int64_t)le32 (v));
+                }
+                aux += 8 + (size_t)cnt * w;
+            }
+            else if (t == 'A') { *o++ = 'A'; *o++ = ':'; *o++ = (char)aux[3]; aux += 4; }
+            else {
+                const uint32_t w = (t == 'c' || t == 'C') ? 1 : (t == 's' || t == 'S') ? 2 : (t == 'i' || t == 'I') ? 4 : 0;
+                if (!w || (uint32_t)(after - aux) < 3 + w) { bad = 1; break; }
+                const uint8_t *v = aux + 3;
+                *o++ = 'i'; *o++ = ':';
+                o = put_i64 (o, t == 'c' ? (int8_t)v[0] : t == 'C' ? v[0] : t == 's' ? (int16_t)le16 (v) : t == 'S' ? (int64_t)le16 (v) : t == 'i' ? (int32_t)le32 (v) : (int64_t)le32 (v));
+                aux += 3 + w;
+            }
+        }
+        if (bad) { free (buf); return -1 - (int64_t)r; }
+        *o++ = '\n';
+        const uint64_t len = (uint64_t)(o - buf);
+        if (line_off) line_off[r] = (uint32_t)at;
+        if (at + len <= cap) memcpy (text + at, buf, len);
+        at += len;
+    }
+    if (line_off) line_off[n_rec] = (uint32_t)at;
+    free (buf);
+    return (int64_t)at;
 }
 
 /* ---- N1 (first part): lines, FASTQ records, tokens ---------------------------------------------------------------- */

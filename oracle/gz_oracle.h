@@ -171,6 +171,9 @@ uint64_t gzo_local_blob_column_ex (const uint8_t *text, const uint32_t *off, con
  * seg_get_next_line (seg.c:200-236) over a whole buffer: start and length of every line, the length without the
  * newline and without a '\r' before it; a last line without a newline counts. Returns the number of lines
  * (all of them, even beyond cap; only the first cap are written). */
+int64_t gzo_bam_records (const uint8_t *bam, uint64_t n, uint32_t *rec_off, uint64_t cap);
+int64_t gzo_bam_to_sam (const uint8_t *bam, const uint32_t *rec_off, uint64_t n_rec, const uint8_t *ref_names, const uint32_t *ref_name_off, int32_t n_ref,
+                        uint8_t *text, uint64_t cap, uint32_t *line_off);
 uint64_t gzo_text_lines (const uint8_t *text, uint64_t n, uint32_t *off, uint32_t *len, uint64_t cap);
 /* fastq_seg_get_lines (fastq.c:1002-1135): every 4 lines are a read: '@' + line 1, SEQ, '+' + line 3, QUAL. The
  * columns hold line 1 without its '@', SEQ, line 3 without its '+', QUAL. Returns 0, or -1 - k where read k is the

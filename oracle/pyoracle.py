@@ -258,6 +258,34 @@ class Oracle:
                                          ctypes.c_uint64(len(off)), int(bool(add_nul)), out.ctypes.data_as(ctypes.c_void_p))
         return out[:n].tobytes()
 
+    # ---- N1 for BAM
+    def bam_records(self, bam):
+        """-> record offsets, or raises ValueError(index of the bad record)"""
+        import numpy as np
+        bam = bytes(bam)
+        out = np.zeros(len(bam) // 36 + 1, dtype=np.uint32)
+        self.L.gzo_bam_records.restype = ctypes.c_int64
+        n = self.L.gzo_bam_records(bam, ctypes.c_uint64(len(bam)), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(len(out)))
+        if n < 0:
+            raise ValueError(-1 - n)
+        return out[:n].copy()
+
+    def bam_to_sam(self, bam, rec_off, ref_names):
+        """-> (text, line_off [n + 1]), or raises ValueError(index of the bad record)"""
+        import numpy as np
+        bam = bytes(bam)
+        rec_off = np.ascontiguousarray(rec_off, dtype=np.uint32)
+        names = b"".join(ref_names)
+        noff = np.concatenate([[0], np.cumsum([len(x) for x in ref_names])]).astype(np.uint32)
+        cap = 6 * len(bam) + 64 * len(rec_off) + 1024
+        text, lo = np.zeros(cap, dtype=np.uint8), np.zeros(len(rec_off) + 1, dtype=np.uint32)
+        self.L.gzo_bam_to_sam.restype = ctypes.c_int64
+        n = self.L.gzo_bam_to_sam(bam, rec_off.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(len(rec_off)), names, noff.ctypes.data_as(ctypes.c_void_p), len(ref_names),
+                                  text.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(cap), lo.ctypes.data_as(ctypes.c_void_p))
+        if n < 0:
+            raise ValueError(-1 - n)
+        return text[:n].tobytes(), lo
+
     # ---- N1 (first part): lines, FASTQ records, tokens
     def text_lines(self, text):
         import numpy as np

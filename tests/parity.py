@@ -1711,3 +1711,99 @@ def rans_tables(E, oracle, scale=1.0):
             assert g == oracle.codec_compress(codec, d), (codec, i)
         back = E.uncompress_many([(codec, g, len(d)) for g, d in zip(got, cases)])
         assert all(b == d for b, d in zip(back, cases))
+
+
+# ---- N1 for BAM: alignment records -> alignment lines ------------------------------------------------------------------------------
+def bam_stream(n, seed=31, exotic=True):
+    """-> (SAM text, BAM records, reference names): the aligned reads of sam_aligned_text as BAM records (genozip_amd/bam.py's encoder:
+    samtools' rules), some of them edited into the corners of the format: unmapped reads without CIGAR / SEQ / QUAL, a mate on another
+    reference, SEQ without QUAL, odd lengths, every base code, negative TLEN, optional fields of every integer width, Z / H / A and B
+    arrays, records without optional fields, a record far longer than a 64 KB chunk of the record chain"""
+    from genozip_amd import bam as gb
+    refs = [b"chr1", b"chr2", b"chrUn_KI270742v1"]
+    lines = sam_aligned_text(n, seed=seed, qual="bin", aux=True).split(b"\n")[:-1]
+    r = synth.u32(seed + 5, n + 8)
+    for i in range(len(lines) if exotic else 0):
+        f = lines[i].split(b"\t")
+        k = int(r[i] % 23)
+        if k == 0:
+            f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8], f[9], f[10] = b"77", b"*", b"0", b"0", b"*", b"*", b"0", b"0", b"*", b"*"
+        elif k == 1:
+            f[6], f[7], f[8] = b"chr2", b"12345", b"0"
+        elif k == 2:
+            f[10] = b"*"
+        elif k == 3:
+            f[5], f[9], f[10] = b"7M", b"ACGTNRY", b"IIIIII#"
+        elif k == 4:
+            f[5], f[9], f[10] = b"17M", b"=ACMGRSVTWYHKDBNA", b"!\"#$%&'()*+,-./01"
+        elif k == 5:
+            f[8] = b"-" + f[8]
+        elif k == 6:
+            f[11:] = [b"XA:A:q", b"X0:i:-1", b"X1:i:200", b"X2:i:-300", b"X3:i:40000", b"X4:i:-70000", b"X5:i:3000000000", b"RG:Z:grp 1", b"XH:H:1AE301",
+                      b"XB:B:c,-1,2,-128", b"XC:B:C,0,255", b"XS:B:s,-32768,5", b"XT:B:S,65535", b"XI:B:i,-2147483648,7", b"XJ:B:I,4294967295", b"XE:Z:"]
+        elif k == 7:
+            f = f[:11]
+        elif k == 8:
+            f[2], f[6] = b"chrUn_KI270742v1", b"="
+        elif k == 9 and i % 5 == 0:
+            ln = 90000 + i                                  # longer than a chunk of the record chain
+            f[5], f[9], f[10] = b"%dM" % ln, b"ACGT" * (ln // 4) + b"A" * (ln % 4), b"F" * ln
+        lines[i] = b"\t".join(f)
+    text = b"\n".join(lines) + b"\n"
+    return text, gb.sam_to_bam(text, refs), refs
+
+
+def bam_front(E, oracle, n, seed=31):
+    """gz_bam_records / gz_bam_to_sam == the oracle's serial restatement == the SAM text the records were made from; malformed streams
+    are refused at the same record"""
+    import pytest
+    text, bam, refs = bam_stream(n, seed)
+    want_off = oracle.bam_records(bam)
+    got_off = E.bam_records(bam, len(refs))
+    assert np.array_equal(got_off, want_off) and len(got_off) == text.count(b"\n")
+    want_text, want_lo = oracle.bam_to_sam(bam, want_off, refs)
+    got_text, got_lo = E.bam_to_sam(bam, got_off, refs)
+    assert want_text == text, _first_diff(want_text, text)
+    assert got_text == text, _first_diff(got_text, text)
+    assert np.array_equal(got_lo, want_lo)
+    # the empty stream, one record
+    assert len(E.bam_records(b"", 1)) == 0 and E.bam_to_sam(b"", np.zeros(0, dtype=np.uint32), refs)[0] == b""
+    one = bam[:int(want_off[1])]
+    assert E.bam_to_sam(one, E.bam_records(one, len(refs)), refs)[0] == text[:text.index(b"\n") + 1]
+    # a text buffer that is too small: refused, with the size it takes
+    with pytest.raises(Exception, match="status 0"):
+        E.bam_to_sam(bam, got_off, refs, text_cap=len(text) - 1)
+    assert E.last_bam.text_len == len(text)
+    # malformed: a block_size that runs past the end / a stream cut inside a record / a record smaller than its fixed part
+    k = len(want_off) // 2
+    for broken in (bam[:int(want_off[k])] + (2 ** 31).to_bytes(4, "little") + bam[int(want_off[k]) + 4:], bam[:-7], bam[:int(want_off[k])] + (20).to_bytes(4, "little") + bam[int(want_off[k]) + 4:]):
+        with pytest.raises(ValueError) as ev:
+            oracle.bam_records(broken)
+        with pytest.raises(Exception, match="gz_bam_records"):
+            E.bam_records(broken, len(refs))
+        assert E.last_bam.status == -5 and E.last_bam.first_bad == ev.value.args[0], (E.last_bam.first_bad, ev.value.args[0])
+    # the chunks' guesses misled: an optional field (a B array of bytes) that holds copies of whole records over three chunks of the chain -
+    # the first thing in those chunks that looks like an alignment followed by an alignment is not one. Same records as the serial walk
+    k0, k1 = int(want_off[3]), int(want_off[6])
+    inner = bam[k0:k1] * (200000 // (k1 - k0) + 1)
+    first = bam[:int(want_off[1])]
+    body = first[4:] + b"XB" + b"B" + b"C" + len(inner).to_bytes(4, "little") + inner
+    decoy = len(body).to_bytes(4, "little") + body + bam[int(want_off[1]):]
+    d_want = oracle.bam_records(decoy)
+    d_got = E.bam_records(decoy, len(refs))
+    assert np.array_equal(d_got, d_want) and len(d_got) == len(want_off) and E.last_bam.n_rewalked >= 1, E.last_bam.n_rewalked
+    assert E.bam_to_sam(decoy, d_got, refs)[0] == oracle.bam_to_sam(decoy, d_want, refs)[0]
+    # a reference id outside the header, an optional field cut short, a float: refused at that record
+    def edit(i, at, data):
+        p = int(want_off[i]) + at
+        return bam[:p] + data + bam[p + len(data):]
+    j = next(i for i in range(len(want_off) - 1) if int(want_off[i + 1]) - int(want_off[i]) > 60 and text.split(b"\n")[i].count(b"\t") > 11)
+    end_j = int(want_off[j + 1]) - int(want_off[j])
+    for broken in (edit(j, 4, (7).to_bytes(4, "little")), edit(j, end_j - 2, b"Z"), edit(j, end_j - 2 - 4, b"f")):
+        off = oracle.bam_records(broken)
+        with pytest.raises(ValueError) as ev:
+            oracle.bam_to_sam(broken, off, refs)
+        with pytest.raises(Exception, match="gz_bam_to_sam"):
+            E.bam_to_sam(broken, off, refs)
+        assert E.last_bam.status == -5 and E.last_bam.first_bad == ev.value.args[0] == j, (E.last_bam.first_bad, ev.value.args[0], j)
+    return len(got_off)

@@ -65,6 +65,11 @@ def test_emul_vcf_and_sam_front(emul_engine, oracle):
     parity.sam_front(emul_engine, oracle, 200)
 
 
+def test_emul_bam_front(emul_engine, oracle):
+    """N1 for BAM: the record chain and the records' alignment lines (the kernels on the CPU stand-in) == the serial restatement"""
+    assert parity.bam_front(emul_engine, oracle, 600) == 600
+
+
 def test_emul_fastq_front(emul_engine, oracle):
     parity.fastq_front(emul_engine, oracle, 700)
 

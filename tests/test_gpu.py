@@ -161,6 +161,13 @@ def test_vcf_and_sam_front(gpu_engine, oracle):
     parity.sam_front(gpu_engine, oracle, 20000)
 
 
+def test_bam_front(gpu_engine, oracle):
+    """N1 for BAM (bam_seg_txt_line, src/bam_seg.c:425-520): the records of an uncompressed BAM stream found chunk-parallel and turned
+    into alignment lines == the oracle's serial walk and conversion == the SAM text they were encoded from (30 000 records, ~12 MB:
+    ~190 chunks of the record chain), incl. records longer than a chunk, every optional-field type, malformed streams"""
+    assert parity.bam_front(gpu_engine, oracle, 30000) == 30000
+
+
 def test_fastq_front(gpu_engine, oracle):
     """N1 (first part) chained into a1-a3 on a VBlock's worth of FASTQ text (23 000 reads, ~7 MB)"""
     parity.fastq_front(gpu_engine, oracle, 23000)
