@@ -59,6 +59,8 @@ def parse_args():
     ap.add_argument("--pin-codecs", action="store_true", help="hard-code the codecs codec_assign_best_codec picks for this workload (profiling runs: no trial compressions in the step)")
     ap.add_argument("--config", default="fastq", choices=("fastq", "bam", "vcf"), help="fastq: BASELINE configs[1] (the headline, from text). bam: configs[2] from SAM text (genozip_amd/sam.py). vcf: configs[3], one GPU's share, at the "
                     "context-stream level (no VCF segmenter: the streams of SURVEY 8(0) enter generated). Same record layout, cpu_baseline beside it")
+    ap.add_argument("--bam-binary", action="store_true", help="--config bam: start from the alignment RECORDS of an uncompressed BAM stream in HBM (N1 for BAM: gz_bam_records + gz_bam_to_sam "
+                    "in every step, in front of the SAM plan) instead of from SAM text")
     ap.add_argument("--stream-level", action="store_true", help="--config bam / vcf: enter at the context-stream level (generated streams, tools/config_bench.py) instead of from text")
     ap.add_argument("--vcf-samples", type=int, default=10000)
     ap.add_argument("--vcf-lines", type=int, default=3000, help="data lines per VBlock")
@@ -300,17 +302,48 @@ class SamWorkload:
         for p in parts:
             self.text[at:at + p.numel()] = p; at += p.numel()
         del parts
-        # VBlocks: segconf_set_vb_size's figure for the file (as vb_bytes for FASTQ), cut at line ends
-        vbb = int(a.vb_mb * (1 << 20)) if a.vb_mb else min(2 * (20 << 20), max(4 << 20, int(self.text_len * 1.2 / 30)))
-        self.vb_bytes = vbb
-        nl = torch.nonzero(self.text[:self.text_len] == 10).reshape(-1)
-        ends = (nl + 1).cpu().numpy()
         import numpy as np
-        cuts, at = [0], 0
-        while at < self.text_len:
-            k = int(np.searchsorted(ends, at + vbb, side="right")) - 1
-            nxt = int(ends[k]) if k >= 0 and ends[k] > at else int(ends[np.searchsorted(ends, at, side="right")])
-            cuts.append(min(nxt, self.text_len)); at = cuts[-1]
+        self.bam = None
+        if a.bam_binary:
+            # the same alignments as the records of an uncompressed BAM stream (workload.py::bam_records): every step finds the records
+            # (gz_bam_records) and writes their alignment lines (gz_bam_to_sam) in front of the SAM plan; the text generated above is
+            # only what that conversion is compared with, once, here
+            parts = [W.bam_records(3, r0, min(CH, n - r0), profile="bin" if a.qual == "bin" else "div", xp=th) for r0 in range(0, n, CH)]
+            self.bam_len = int(sum(p.numel() for p in parts))
+            self.bam = torch.empty(self.bam_len + 64, dtype=torch.uint8, device=device)
+            at = 0
+            for p in parts:
+                self.bam[at:at + p.numel()] = p; at += p.numel()
+            del parts
+            self.ref_names = W.SAM_REF_NAMES
+            want = self.text
+            _, rob, nrec = E.bam_records(self.bam[:self.bam_len], len(self.ref_names), cap=n + 16, on_device=True)
+            tb, tl, lb = E.bam_to_sam(self.bam[:self.bam_len], rob, self.ref_names, text_cap=self.text_len + 4096, on_device=True, n_rec=nrec)
+            assert nrec == n and tl == self.text_len and bool(torch.equal(tb[:tl], want[:tl])), "BAM records -> alignment lines differ from the SAM text generator"
+            self.text = tb
+            rec_off = np.frombuffer(E.mem.download(rob, 4 * nrec), dtype=np.uint32).astype(np.int64)
+            line_off = np.frombuffer(E.mem.download(lb, 4 * (nrec + 1)), dtype=np.uint32).astype(np.int64)
+            # VBlocks of BAM bytes: segconf_set_vb_size with est_max_threads = 60 for a BGZF / BAM source (src/segconf.c:186-203), cut at records
+            vbb = int(a.vb_mb * (1 << 20)) if a.vb_mb else min(2 * (20 << 20), max(4 << 20, int(self.bam_len * 1.2 / 60)))
+            rcuts, at = [0], 0
+            while at < nrec:
+                k = int(np.searchsorted(rec_off, rec_off[at] + vbb, side="right")) - 1      # the last record that starts within vb_size of the VBlock's first
+                k = max(at + 1, min(nrec, k))
+                rcuts.append(k); at = k
+            self.rec_cuts = rcuts
+            cuts = [int(line_off[k]) for k in rcuts]
+            self.vb_bytes = vbb
+        else:
+            # VBlocks: segconf_set_vb_size's figure for the file (as vb_bytes for FASTQ), cut at line ends
+            vbb = int(a.vb_mb * (1 << 20)) if a.vb_mb else min(2 * (20 << 20), max(4 << 20, int(self.text_len * 1.2 / 30)))
+            self.vb_bytes = vbb
+            nl = torch.nonzero(self.text[:self.text_len] == 10).reshape(-1)
+            ends = (nl + 1).cpu().numpy()
+            cuts, at = [0], 0
+            while at < self.text_len:
+                k = int(np.searchsorted(ends, at + vbb, side="right")) - 1
+                nxt = int(ends[k]) if k >= 0 and ends[k] > at else int(ends[np.searchsorted(ends, at, side="right")])
+                cuts.append(min(nxt, self.text_len)); at = cuts[-1]
         self.vb = [(cuts[i], cuts[i + 1] - cuts[i], i + 1, -1) for i in range(len(cuts) - 1)]
         self.n_reads_own = n
         self.plan = sm.sam_plan(has_aux=True, vb_size=vbb)
@@ -327,6 +360,10 @@ class SamWorkload:
         import torch
         F, n = self.F, len(self.vb)
         F.reset()
+        if self.bam is not None:                               # N1 for BAM: records -> alignment lines, in the step
+            _, rob, nrec = self.E.bam_records(self.bam[:self.bam_len], len(self.ref_names), cap=self.n_reads_own + 16, on_device=True)
+            self.text, tl, _lb = self.E.bam_to_sam(self.bam[:self.bam_len], rob, self.ref_names, text_cap=self.text_len + 4096, on_device=True, n_rec=nrec)
+            assert tl == self.text_len
         F.zip_table(self.text, self.text_len, self.tab, n)
         total = sum(t.z_len for t in self.tab)
         if self.zbuf is None or self.zbuf.numel() < total + 64:
@@ -418,9 +455,14 @@ def text_leg(a, WL):
         codecs[("b250:" if st == 11 else "local:") + tag] = CODEC_NAMES.get(codec, str(codec))
     out = {"metric": METRIC, "value": round(wl.value_bytes / 1e6 / (ms / 1e3), 1), "unit": "MB/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-           "config": {"workload": ("BAM-1M (BASELINE configs[2]) FROM TEXT: %d aligned 150 bp reads as SAM alignment lines (coordinate-sorted, CIGAR 90 %% 150M, QUAL profile %s), %d VBlocks of %.2f MB; "
+           "config": {"workload": (("BAM-1M (BASELINE configs[2]) FROM BAM RECORDS: %d aligned 150 bp reads as the records of an uncompressed BAM stream in HBM (%.1f MB; coordinate-sorted, CIGAR 90 %% 150M, "
+                                    "QUAL profile %s), %d VBlocks of %.2f MB of BAM (segconf_set_vb_size for a BGZF source); per step: the record chain (gz_bam_records) and the records' alignment "
+                                    "lines (gz_bam_to_sam: N1 for BAM, bam_seg_txt_line's conversions) -> the one-line-record plan of genozip_amd/sam.py -> a1-a16; a new file every step. MB counted in "
+                                    "`value` = the alignment lines WITHOUT their SEQ fields (as for SAM text), so that the figure compares with the SAM leg" % (a.pairs, wl.bam_len / 1e6, a.qual, len(wl.vb), wl.vb_bytes / 1e6))
+                                   if getattr(wl, "bam", None) is not None else
+                                   ("BAM-1M (BASELINE configs[2]) FROM TEXT: %d aligned 150 bp reads as SAM alignment lines (coordinate-sorted, CIGAR 90 %% 150M, QUAL profile %s), %d VBlocks of %.2f MB; "
                                    "the whole path per step from text in HBM through the one-line-record plan of genozip_amd/sam.py (N1 for SAM: fields by tab, QNAME by flavor -> a1-a16); "
-                                   "a new file every step. MB counted in `value` = text WITHOUT the SEQ fields (2-bit packed in the step, LZMA outside the path)" % (a.pairs, a.qual, len(wl.vb), wl.vb_bytes / 1e6))
+                                   "a new file every step. MB counted in `value` = text WITHOUT the SEQ fields (2-bit packed in the step, LZMA outside the path)" % (a.pairs, a.qual, len(wl.vb), wl.vb_bytes / 1e6)))
                                   if is_sam else
                                   ("VCF %d samples (BASELINE configs[3]) FROM TEXT, one GPU's share at 8 GPUs: %d VBlocks of %d data lines x %d samples (FORMAT GT:DP:PL), %.0f MB of text; the whole path per "
                                    "step from text in HBM through the per-sample plan of genozip_amd/vcf.py (N1 for VCF: fixed fields by tab, FORMAT subfields of every sample -> GT / PL b250 columns "

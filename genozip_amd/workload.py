@@ -292,6 +292,95 @@ def sam_text(seed, read0, n_reads, profile="bin", xp=None):
     return out.tobytes() if host else out
 
 
+SAM_REF_NAMES = [b"chr1"]
+BAM_MAX_RECORD = 4 + 32 + 39 + 12 + READ_LEN // 2 + READ_LEN + 8
+
+
+def bam_records(seed, read0, n_reads, profile="bin", xp=None):
+    """the same alignments as sam_text (seed, read0, n_reads, profile) as the RECORDS of an uncompressed BAM stream (SAMv1 4.2; reference
+    names SAM_REF_NAMES): block_size, the fixed fields, read_name, 1-3 CIGAR operations, 4-bit bases, Phred scores, NM / AS as uint8
+    (samtools' smallest type). Records differ in length only by their CIGAR, so a record is laid out in a matrix as wide as the longest
+    with a mask over the CIGAR columns a record does not have; the stream is the matrix under its mask. numpy on the host or, xp = _TH
+    (device), torch in HBM: identical bytes. gz_bam_to_sam of these records is sam_text's text (tests)."""
+    host = xp is None
+    xp = xp or _NP
+    lane, tile, x, y = name_fields(seed, read0, n_reads, xp)
+    idx = xp.arange(read0, read0 + n_reads)
+    h1, h2, h3 = _hash(xp, seed + 0x5A11, idx), _hash(xp, seed + 0x5A12, idx), _hash(xp, seed + 0x5A13, idx)
+    if host:
+        rec = np.zeros((n_reads, BAM_MAX_RECORD), dtype=np.uint8)
+        keep = np.ones((n_reads, BAM_MAX_RECORD), dtype=bool)
+        const = lambda b: np.frombuffer(b, dtype=np.uint8)                         # noqa: E731
+        to_u8 = lambda v: v.astype(np.uint8)                                       # noqa: E731
+        i64 = lambda v: v.astype(np.int64)                                         # noqa: E731
+        table = lambda v: np.array(v, dtype=np.int64)                              # noqa: E731
+    else:
+        t = xp.t
+        rec = t.zeros((n_reads, BAM_MAX_RECORD), dtype=t.uint8, device=xp.dev)
+        keep = t.ones((n_reads, BAM_MAX_RECORD), dtype=t.bool, device=xp.dev)
+        const = lambda b: t.tensor(list(b), dtype=t.uint8, device=xp.dev)          # noqa: E731
+        to_u8 = lambda v: v.to(t.uint8)                                            # noqa: E731
+        i64 = lambda v: v.to(t.int64)                                              # noqa: E731
+        table = lambda v: t.tensor(v, dtype=t.int64, device=xp.dev)                # noqa: E731
+    at = 0
+
+    def put(b):
+        nonlocal at
+        rec[:, at:at + len(b)] = const(b)
+        at += len(b)
+
+    def le(v, nbytes):
+        nonlocal at
+        v = i64(v)
+        for k in range(nbytes):
+            rec[:, at + k] = to_u8(xp.lsr(v, 8 * k) % 256)
+        at += nbytes
+
+    def digits(v, width):
+        nonlocal at
+        v = i64(v)
+        for k in range(width):
+            rec[:, at + k] = to_u8(48 + (v // 10 ** (width - 1 - k)) % 10)
+        at += width
+
+    k100 = xp.lsr(h1, 16) % 100
+    cig = xp.where(k100 < 90, 0, xp.where(k100 < 98, 1 + k100 % 4, 5))
+    M, I, D, S = 0, 1, 2, 4
+    ops = [[150 << 4 | M, 0, 0], [70 << 4 | M, 2 << 4 | D, 80 << 4 | M], [40 << 4 | M, 1 << 4 | I, 109 << 4 | M], [100 << 4 | M, 3 << 4 | D, 50 << 4 | M],
+           [75 << 4 | M, 2 << 4 | I, 73 << 4 | M], [20 << 4 | S, 130 << 4 | M, 0]]
+    n_ops = table([1, 3, 3, 3, 3, 2])[cig]
+    ref_len = table([150, 152, 149, 153, 148, 130])[cig]
+    pos = 100000 + idx * 97 + h2 % 60                                                  # (1-based, as in sam_text)
+    beg, end = pos - 1, pos - 1 + ref_len - 1                                          # reg2bin (SAMv1 5.3) on [beg, end]
+    bin_ = xp.where(xp.lsr(beg, 14) == xp.lsr(end, 14), 4681 + xp.lsr(beg, 14), xp.where(xp.lsr(beg, 17) == xp.lsr(end, 17), 585 + xp.lsr(beg, 17),
+           xp.where(xp.lsr(beg, 20) == xp.lsr(end, 20), 73 + xp.lsr(beg, 20), xp.where(xp.lsr(beg, 23) == xp.lsr(end, 23), 9 + xp.lsr(beg, 23),
+           xp.where(xp.lsr(beg, 26) == xp.lsr(end, 26), 1 + xp.lsr(beg, 26), 0)))))
+    le(32 + 39 + 4 * n_ops + READ_LEN // 2 + READ_LEN + 8, 4)                          # block_size
+    le(idx * 0, 4); le(pos - 1, 4)                                                     # refID, pos
+    le(idx * 0 + 39, 1)                                                                # l_read_name
+    le(table([60, 60, 60, 0, 23, 60, 40, 60])[xp.lsr(h1, 8) % 8], 1)                   # mapq
+    le(bin_, 2); le(n_ops, 2)
+    le(table([99, 147, 83, 163])[h1 % 4], 2)                                           # flag
+    le(idx * 0 + READ_LEN, 4); le(idx * 0, 4)                                          # l_seq, next_refID
+    le(pos + 150 + xp.lsr(h2, 8) % 100 - 1, 4)                                         # next_pos
+    le(300 + xp.lsr(h2, 8) % 100, 4)                                                   # tlen
+    put(b"A00123:45:HXXXXXXXX:"); digits(lane + 1, 1); put(b":"); digits(1101 + tile, 4); put(b":"); digits(10000 + i64(x) % 20000, 5); put(b":")
+    digits(10000 + i64(y) % 80000, 5); put(b"\0")
+    opt = table(ops)[cig]                                                              # [n, 3]
+    for j in range(3):
+        if j:
+            keep[:, at:at + 4] = (n_ops > j).reshape(-1, 1)
+        le(opt[:, j], 4)
+    bidx = xp.arange(read0 * READ_LEN, (read0 + n_reads) * READ_LEN)
+    code = table([1, 2, 4, 8])[_hash(xp, seed + 0x5E9, bidx) % 4].reshape(n_reads, READ_LEN)
+    rec[:, at:at + READ_LEN // 2] = to_u8(code[:, 0::2] * 16 + code[:, 1::2]); at += READ_LEN // 2
+    rec[:, at:at + READ_LEN] = (quality_rows(xp, seed + 0x100000, read0, n_reads, profile) - 33).reshape(n_reads, READ_LEN); at += READ_LEN
+    put(b"NMC"); le(h3 % 4, 1); put(b"ASC"); le(150 - xp.lsr(h3, 8) % 9, 1)
+    assert at == BAM_MAX_RECORD and READ_LEN % 2 == 0
+    out = rec.reshape(-1)[keep.reshape(-1)]
+    return out.tobytes() if host else out
+
+
 # ---- BASELINE configs[3]: a multi-sample VCF as text (SURVEY 8d-3) ---------------------------------------------------------------------
 def vcf_text(seed, line0, n_lines, n_samples, xp=None):
     """data lines [line0, line0 + n_lines) of a VCF with n_samples samples, FORMAT GT:DP:PL (no header lines):

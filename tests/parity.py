@@ -1568,7 +1568,7 @@ def sam_aligned_text(n, seed=21, qual="bin", aux=True):
     return b"".join(out)
 
 
-def sam_zip(E, oracle, n_reads, n_calls=2, qual="bin", aux=True):
+def sam_zip(E, oracle, n_reads, n_calls=2, qual="bin", aux=True, via_bam=False):
     """N1 for SAM (BASELINE configs[2] from TEXT): alignment lines through the VBlock compute driver with a one-line-record plan
     (genozip_amd/sam.py) == the oracle's step-by-step composition, byte for byte, over several VBlocks and calls (dictionaries carried);
     every section decodes again on the device"""
@@ -1579,6 +1579,12 @@ def sam_zip(E, oracle, n_reads, n_calls=2, qual="bin", aux=True):
     for call in range(n_calls):
         nr = n_reads if call == 0 else max(8, n_reads // 2)
         text = sam_aligned_text(nr, seed=21 + call, qual=qual, aux=aux)
+        if via_bam:                                            # N1 for BAM: the records of a BAM stream -> the text the plan segs (configs[2] from BAM)
+            from genozip_amd import bam as gb
+            records = gb.sam_to_bam(text, [b"chr1"])
+            made, _lo = E.bam_to_sam(records, E.bam_records(records, 1), [b"chr1"])
+            assert made == text
+            text = made
         nl = np.flatnonzero(np.frombuffer(text, dtype=np.uint8) == 10)
         cut = int(nl[(2 * nr) // 3 - 1]) + 1
         vbs = [(0, cut, vb_i + 1, -1), (cut, len(text) - cut, vb_i + 2, -1)]
