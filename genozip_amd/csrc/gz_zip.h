@@ -924,9 +924,22 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
             vbs[v].status = GZ_ERR_CORRUPT; h->err = "QUAL: a score outside ' '..'~' (codec_domq.c:150-153)"; return GZ_ERR_CORRUPT; }
         zip_apply_qual_mode (f, qmode);
     }
+    // Coding the QUAL streams ahead of everything else costs the seg phase a wait for their trial compressions (~10 ms: one serial model
+    // + chain over a 100 KB sample) and the launch itself. That buys the strictly serial chains of LONG streams a head start of the whole
+    // merge phase - and nothing when the streams are short (QUAL through CODEC_DOMQ in 16 MB VBlocks: ~0.5 M symbols, 8 ms of chain): then
+    // QUAL is a context like any other - tested in the merge phase with the rest, coded in the finish phase (BAM from text: 70.7 -> see
+    // DESIGN section 4). Same bytes either way: the same sample, the same rule.
+    uint64_t longest = 0;
+    if (f->qual_ctx >= 0) for (uint32_t v = 0; v < NV; v++) longest = std::max<uint64_t> (longest, COL (v, (uint32_t)f->qual_ctx).local_len);
+    const char *early_env = getenv ("GZ_ZIP_EARLY_MIN");
+    const uint64_t early_min = early_env ? strtoull (early_env, NULL, 10) : 1500000ull;
+    bool early_worth = longest >= early_min || spec_always;
+    if (!early_worth && f->h2 && NV && qmode >= 0 && f->qual_ctx >= 0) {
+        GzZctxView zv; gz_zctx_view (f->zctx[f->qual_ctx], &zv);
+        if (zv.lcodec) early_worth = true;                 // (the file knows its codec: nothing to wait for, the streams may as well start now)
+    }
+    if (!early_worth) { may_spec = false; K.spec_trial.clear (); }
     if (may_spec) {                                        // now that the lengths are known: is it worth it?
-        uint64_t longest = 0;
-        for (uint32_t v = 0; v < NV; v++) longest = std::max<uint64_t> (longest, COL (v, (uint32_t)f->qual_ctx).local_len);
         if (qmode < 0 || !guess[qmode == GZ_CODEC_DOMQ] || ((longest < 5000000 || qmode == GZ_CODEC_DOMQ) && !spec_always)) {
             // no: the trial after all, on the second handle, and the long streams wait for it (as without speculation, a little later)
             may_spec = false;
@@ -937,7 +950,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
             if (r != GZ_OK) { (void)gz_sync (f->h2); return r; }
         }
     }
-    if (f->h2 && NV) {
+    if (f->h2 && NV && early_worth) {
         if (!trial.empty () && (rc = gz_sync (f->h2)) < 0) { h->err = f->h2->err; return rc; }
         for (uint32_t c = 0; c < NC; c++) {
             if (f->ctxs[c].kind != GZ_FQ_QUAL || qmode < 0) continue;

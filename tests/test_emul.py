@@ -119,6 +119,16 @@ def test_emul_fastq_zip(emul_engine, oracle):
     parity.fastq_zip(emul_engine, oracle, 54, small_first=True)                         # VBlocks too small to set the file's codecs
 
 
+def test_emul_fastq_zip_early_path(emul_engine, oracle, monkeypatch):
+    """the QUAL streams coded ahead of the merge (what the driver does for LONG streams, >= GZ_ZIP_EARLY_MIN scores: their trial is waited for in
+    the seg phase, the streams start on the second handle) - forced here for streams of test size: the same bytes as the ordinary way"""
+    monkeypatch.setenv("GZ_ZIP_EARLY_MIN", "0")
+    parity.fastq_zip(emul_engine, oracle, 100)
+    parity.fastq_zip(emul_engine, oracle, 72, qual=("bin", "uniform"))
+    parity.fastq_zip(emul_engine, oracle, 54, small_first=True)
+    assert parity.sam_zip(emul_engine, oracle, 300, n_calls=1) == 2
+
+
 def test_emul_fastq_zip_speculation(emul_engine, oracle):
     parity.fastq_zip_speculation(emul_engine, oracle, 42)
 

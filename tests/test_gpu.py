@@ -111,6 +111,17 @@ def test_fastq_zip_driver(gpu_engine, oracle):
 
 
 @pytest.mark.gpu
+def test_fastq_zip_early_path(gpu_engine, oracle, monkeypatch):
+    """the QUAL streams coded ahead of the merge on the second handle (the driver's way for long streams, >= GZ_ZIP_EARLY_MIN scores),
+    forced for streams of test size: the same bytes as when QUAL is coded with the rest"""
+    monkeypatch.setenv("GZ_ZIP_EARLY_MIN", "0")
+    parity.fastq_zip(gpu_engine, oracle, 6000)
+    parity.fastq_zip(gpu_engine, oracle, 3000, qual=("bin", "uniform"))
+    parity.fastq_zip(gpu_engine, oracle, 1500, small_first=True)
+    assert parity.sam_zip(gpu_engine, oracle, 3000, n_calls=1) == 2
+
+
+@pytest.mark.gpu
 def test_fastq_zip_speculation(gpu_engine, oracle):
     a, c, d = parity.fastq_zip_speculation(gpu_engine, oracle, 2500)
     assert a["qual_lcodec"] and d["qual_mode"] == 13
