@@ -346,7 +346,7 @@ class SamWorkload:
                 cuts.append(min(nxt, self.text_len)); at = cuts[-1]
         self.vb = [(cuts[i], cuts[i + 1] - cuts[i], i + 1, -1) for i in range(len(cuts) - 1)]
         self.n_reads_own = n
-        self.plan = sm.sam_plan(has_aux=True, vb_size=vbb)
+        self.plan = sm.sam_plan(vb_size=vbb, aux_tags=[("NM", "i"), ("AS", "i")])       # (a context per optional field behind the AUX container, sam_seg_aux_all)
         self.F = E.zip_open(self.plan)
         self.tab = self.F.vb_table(self.vb)
         self.zbuf, self.offs, self.calls_per_step = None, None, 1

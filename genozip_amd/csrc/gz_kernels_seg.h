@@ -648,7 +648,7 @@ __global__ void __launch_bounds__(256) k_fastq_records (GzdFastq F)
 
 // items of a container with known separators (qname_flavors.h:21-49, seg_get_next_item src/seg.c:153-198).
 // grid (tiles of 256 snips)
-#define GZ_TOK_MAX_SEPS 15
+#define GZ_TOK_MAX_SEPS 31
 struct GzdTokens {
     const uint8_t *text; const uint32_t *off, *len; uint32_t n;
     uint8_t seps[GZ_TOK_MAX_SEPS + 1]; uint32_t n_seps;

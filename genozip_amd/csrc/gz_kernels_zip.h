@@ -417,6 +417,18 @@ __global__ void __launch_bounds__(256) k_seq_snips (GzdSeqSnip S)
     if (S.l3_len[r]) atomicAdd (S.n_line3, 1u);
 }
 
+// GZ_FQ_ITEM_EXPECT: the item of every record must be exactly `want` (<= 16 bytes) - grid (tiles of 256 records)
+struct GzdExpect { const uint8_t *text; const uint32_t *off, *len; uint32_t n; uint8_t want[16]; uint32_t want_len; uint32_t *n_bad; };
+__global__ void __launch_bounds__(256) k_item_expect (GzdExpect X)
+{
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= X.n) return;
+    bool same = X.len[r] == X.want_len;
+    const uint8_t *p = X.text + X.off[r];
+    for (uint32_t i = 0; same && i < X.want_len; i++) same = p[i] == X.want[i];
+    if (!same) atomicAdd (X.n_bad, 1u);
+}
+
 // any byte set? (the `missing` mask of gz_vcf_sample_columns: a sample that leaves trailing subfields out) - grid (tiles of 256 x 16 bytes)
 __global__ void __launch_bounds__(256) k_any_set (const uint8_t *p, uint64_t n, uint32_t *count)
 {

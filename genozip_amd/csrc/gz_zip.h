@@ -218,7 +218,8 @@ extern "C" GzZipFile *gz_zip_open (GzHandle *h, const GzFastqPlan *plan)
         c.snip = f->snips[i].data ();
         if ((c.kind == GZ_FQ_ITEM_TEXT || c.kind == GZ_FQ_ITEM_INT || c.kind == GZ_FQ_ITEM_DELTA) && c.item > plan->n_seps) return zip_open_failed (f);
         if ((c.kind == GZ_FQ_CONST || c.kind == GZ_FQ_ITEM_DELTA) && !c.snip_len) return zip_open_failed (f);
-        if (c.kind == GZ_FQ_ITEM_TEXT && c.snip_len > 4) return zip_open_failed (f);                 // (a lead-in of every snip: at most 4 bytes)
+        if (c.kind == GZ_FQ_ITEM_TEXT && c.snip_len > 4) return zip_open_failed (f);
+        if (c.kind == GZ_FQ_ITEM_EXPECT && (c.snip_len > 16 || c.item > plan->n_seps)) return zip_open_failed (f);                 // (a lead-in of every snip: at most 4 bytes)
         if (c.kind == GZ_FQ_TOPLEVEL && (c.con_len < 8 || c.con_len > c.snip_len || (c.con_len - 8) % 12)) return zip_open_failed (f);   // Container_0 + n ContainerItem
         if (c.kind == GZ_FQ_SEQ_SNIP) { if (!c.snip_len || c.snip_len > 4 || f->seq_snip_ctx >= 0) return zip_open_failed (f); f->seq_snip_ctx = (int)i; }
         if (c.kind == GZ_FQ_QUAL) { if (f->qual_ctx >= 0) return zip_open_failed (f); f->qual_ctx = (int)i; }     // (one QUAL per plan)
@@ -518,7 +519,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     const uint32_t lookup_off = (uint32_t)text_len;
     uint32_t line_cap = (uint32_t)(text_len / 16 + 1024);
     uint32_t *line_off = NULL, *line_len = NULL;
-    struct ABlock { GzLinesResult lines; uint32_t bad_bound, n_bad_items; GzFastqResult fq; uint32_t n_line3, n_bad_samples, n_missing, pad; GzLinesResult tabs; } ;
+    struct ABlock { GzLinesResult lines; uint32_t bad_bound, n_bad_items; GzFastqResult fq; uint32_t n_line3, n_bad_samples, n_missing, n_unexpected; GzLinesResult tabs; } ;
     WS (d_a, ABlock, 1);
     WS (d_vb_off, uint64_t, 2 * NV + 2);
     WS (d_first_line, uint32_t, 2 * NV + 2);
@@ -674,6 +675,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
             const bool ps = X.per_sample && NS;                            // a FORMAT subfield of every sample: lines x samples entries
             if (X.per_sample && (!NS || X.item >= NSUB)) { h->err = "plan: a per-sample context without samples / beyond n_subfields"; return GZ_ERR_ARG; }
             const uint32_t nn = ps ? n * NS : n;
+            if (X.kind == GZ_FQ_ITEM_EXPECT) { Z.n = 0; continue; }             // (no context: checked below, once for the whole call)
             Z.n = nn;
             Z.sec_len_dev = d_seclen + 2 * ((size_t)v * NC + c);
             const uint32_t *io = ps ? s_off + (size_t)X.item * cells + (size_t)rr * NS : item_off + (size_t)X.item * R + rr,
@@ -849,6 +851,14 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
                         (const uint64_t *)(d_vb_off + NV), NV, RL, d_vbstat);
     ZCHK (gz_int_columns (h, icol_jobs.data (), (int)icol_jobs.size ()));
     // (column tables hold at most 65 535 rows per call)
+    for (uint32_t c = 0; c < NC && R; c++) {                                     // text the plan's containers carry as prefixes must be there, in every record
+        const GzFastqCtx &X = f->ctxs[c];
+        if (X.kind != GZ_FQ_ITEM_EXPECT) continue;
+        GzdExpect E; memset (&E, 0, sizeof (E));
+        E.text = text; E.off = item_off + (size_t)X.item * R; E.len = item_len + (size_t)X.item * R; E.n = R; E.want_len = X.snip_len; memcpy (E.want, X.snip, X.snip_len);
+        E.n_bad = &d_a->n_unexpected;
+        KLAUNCH (h, k_item_expect, dim3 ((R + 255) / 256), dim3 (256), 0, E);
+    }
     for (size_t at = 0; at < pre_jobs.size (); at += 32768) ZCHK (gz_local_blob_columns (h, pre_jobs.data () + at, (int)std::min<size_t> (32768, pre_jobs.size () - at)));
     for (size_t at = 0; at < col_jobs.size (); at += 32768) ZCHK (gz_ctx_seg_columns (h, col_jobs.data () + at, (int)std::min<size_t> (32768, col_jobs.size () - at)));
     for (size_t at = 0; at < dyn_jobs.size (); at += 32768) ZCHK (gz_dyn_int_columns (h, dyn_jobs.data () + at, (int)std::min<size_t> (32768, dyn_jobs.size () - at)));
@@ -1010,6 +1020,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     }
     if (f->plan.line3_empty && a.n_line3) { h->err = "line 3 of a read is more than '+' (the plan says L3_EMPTY; fastq_desc.c:35-37)"; ZIP_FAIL (GZ_ERR_CORRUPT); }
     if (NS && (a.n_bad_samples || a.n_missing)) { h->err = "VCF: a line without 9 + n_samples fields, a sample with more subfields than the plan's, or one that leaves subfields out (not supported by this driver)"; ZIP_FAIL (GZ_ERR_CORRUPT); }
+    if (a.n_unexpected) { h->err = "an item the plan expects to be constant (GZ_FQ_ITEM_EXPECT: a tag name its container carries as a prefix) is something else in some record"; ZIP_FAIL (GZ_ERR_CORRUPT); }
     if (a.n_bad_items) { h->err = "a line 1 does not fit the container of the plan (the reference would re-discover the flavor, qname.c:823-826)"; ZIP_FAIL (GZ_ERR_CORRUPT); }
     for (size_t k = 0; k < icol_jobs.size (); k++)
         if ((int32_t)icolres[2 * k + 1] == GZ_ST_CORRUPT) { h->err = "an ordered item is not an integer (qname.c:750-756)"; ZIP_FAIL (GZ_ERR_CORRUPT); }
@@ -1375,7 +1386,7 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
     {
         std::vector<const uint8_t *> ptr; std::vector<uint32_t> len; std::vector<ZipVote> who;
         bool need = false;
-        for (uint32_t c = 0; c < NC; c++) { GzZctxView zv; gz_zctx_view (f->zctx[c], &zv); if (!zv.lcodec || !zv.bcodec) need = true; }
+        for (uint32_t c = 0; c < NC; c++) { if (f->ctxs[c].kind == GZ_FQ_ITEM_EXPECT) continue; GzZctxView zv; gz_zctx_view (f->zctx[c], &zv); if (!zv.lcodec || !zv.bcodec) need = true; }
         if (f->plan.vb_1_not_representative) for (uint32_t v = 0; v < NV; v++) if (vbs[v].vblock_i == ZIP_RETEST_VB_I) need = true;
         if (need || K.spec_pending) {
             std::vector<uint32_t> seclen (2 * (size_t)NV * NC);

@@ -127,7 +127,7 @@ def c_plan(plan):
     p = GzFastqPlan()
     p.ctxs, p.n_ctxs = arr, n
     p.seps = plan["seps"]
-    p.sep_counts = (C.c_uint8 * 16)(*(list(plan["sep_counts"]) + [0] * (16 - len(plan["sep_counts"]))))
+    p.sep_counts = (C.c_uint8 * 32)(*(list(plan["sep_counts"]) + [0] * (32 - len(plan["sep_counts"]))))
     p.n_seps, p.paired, p.estimated_entries = len(plan["seps"]), int(plan["paired"]), plan["estimated_entries"]
     p.qual_codec = plan.get("qual_codec", 0)
     p.vb_size = plan.get("vb_size", 0)

@@ -121,7 +121,7 @@ class GzFastqCtx(C.Structure):
 
 
 class GzFastqPlan(C.Structure):
-    _fields_ = [("ctxs", C.POINTER(GzFastqCtx)), ("n_ctxs", C.c_uint32), ("seps", C.c_char * 16), ("sep_counts", C.c_uint8 * 16),
+    _fields_ = [("ctxs", C.POINTER(GzFastqCtx)), ("n_ctxs", C.c_uint32), ("seps", C.c_char * 32), ("sep_counts", C.c_uint8 * 32),
                 ("n_seps", C.c_uint32), ("paired", C.c_uint8), ("estimated_entries", C.c_uint32), ("qual_codec", C.c_uint8), ("vb_size", C.c_uint64),
                 ("record_lines", C.c_uint8), ("seq_item", C.c_uint8), ("qual_item", C.c_uint8), ("n_samples", C.c_uint32), ("n_subfields", C.c_uint8), ("line3_empty", C.c_uint8),
                 ("seq_pad", C.c_uint8), ("vb_1_not_representative", C.c_uint8)]
@@ -137,7 +137,7 @@ class GzSecOrderIn(C.Structure):
     _fields_ = [("did_i", C.c_uint16), ("local_dep", C.c_uint8), ("has_local", C.c_uint8), ("ston_only_local", C.c_uint8), ("has_b250", C.c_uint8)]
 
 
-GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL, GZ_FQ_QUAL_AUX, GZ_FQ_TOPLEVEL, GZ_FQ_SEQ_SNIP = 1, 2, 3, 4, 5, 6, 7, 8, 9
+GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL, GZ_FQ_QUAL_AUX, GZ_FQ_TOPLEVEL, GZ_FQ_SEQ_SNIP, GZ_FQ_ITEM_EXPECT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 
 # every symbol include/genozip_amd.h declares (checked by tests/test_abi.py)
 GzGetLineCB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32))

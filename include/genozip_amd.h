@@ -320,7 +320,7 @@ int gz_local_blob_columns (GzHandle *h, const GzBlobJob *jobs, int n_jobs);
  *   src/qname.c:715-866; seg_get_next_item src/seg.c:153-198): item i of a snip ends at the first seps[i] after item
  *   i-1, the last item is the rest; item-major output [i * n + k], ready to be columns of gz_ctx_seg_columns /
  *   gz_dyn_int_columns. A snip lacking a separator counts in *n_bad_dev and stays whole in item 0 (the reference
- *   segs such a qname as one snip). n_seps <= 15. */
+ *   segs such a qname as one snip). n_seps <= 31. */
 typedef struct { uint64_t n_lines; int32_t status; uint32_t reserved; /* gz_text_lines: 1 if a line ended in \r\n (the \r is not part of its length) */ } GzLinesResult;
 int gz_text_lines (GzHandle *h, const uint8_t *text, uint64_t n_bytes, uint32_t *line_off, uint32_t *line_len, uint32_t cap,
                    GzLinesResult *result_dev);
@@ -470,11 +470,15 @@ enum {
                               12 per item, src/container.h:74-92, the 24 repeat bits zero) followed by its prefixes; the driver sets
                               the repeats of every VBlock and segs SNIP_CONTAINER + base64 (Container) + prefixes
                               (container_prepare_snip, src/container.c:35-64): one b250 entry                                      */
-    GZ_FQ_SEQ_SNIP   = 9   /* SQBITMAP: the snip fastq_seg_SEQ segs for every read, which carries the read's length
+    GZ_FQ_SEQ_SNIP   = 9,  /* SQBITMAP: the snip fastq_seg_SEQ segs for every read, which carries the read's length
                               (src/fastq_seq.c:45-154: `snip` + decimal seq_len, `snip` being SNIP_SPECIAL, FASTQ_SPECIAL_unaligned_SEQ,
                               ' '); a read of one repeated base takes that base in the place of ' ' and is left out of NONREF
                               (:120-126), an empty read is `snip` with '*' and no length (:113-117). Generated and evaluated on the
                               device like a textual item. Must come before the plan's GZ_FQ_SEQ context                          */
+    GZ_FQ_ITEM_EXPECT = 10 /* no context: the item must be exactly `snip` in every record - text the plan's containers carry as a PREFIX
+                              (the "NM:i" of an optional field whose value is the next item: the AUX container's prefixes, sam_seg_aux_all
+                              src/sam_seg.c:1363-1433). A record where it is not makes the call fail with GZ_ERR_CORRUPT: the plan does not
+                              describe this file (flavor / tag-layout discovery is segconf's job, host). dict_id / did_i are ignored     */
 };
 typedef struct {
     uint8_t  dict_id[8];
@@ -500,7 +504,7 @@ typedef struct {
 } GzFastqCtx;
 typedef struct {
     const GzFastqCtx *ctxs; uint32_t n_ctxs;
-    char     seps[16]; uint8_t sep_counts[16]; uint32_t n_seps;   /* line 1 (without '@') as one container: item i ends at the
+    char     seps[32]; uint8_t sep_counts[32]; uint32_t n_seps;   /* line 1 (without '@') as one container: item i ends at the
                                    sep_counts[i]-th seps[i] (CI0_COLONn, src/qname_flavors.h:40-49); n_seps + 1 items        */
     uint8_t  paired;              /* --pair: R2 VBlocks name their R1 VBlock                                              */
     uint32_t estimated_entries;   /* hash_get_estimated_entries' figure for the dictionaries (0: default)                  */

@@ -632,7 +632,7 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
     functions, VBlock by VBlock. zstate carries the file-level contexts and codecs from call to call.
     -> (list of dict(z, seq_packed, n_bases, seq_has_x), zstate)"""
     import pyoracle as po
-    from genozip_amd.lib import (GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL, GZ_FQ_QUAL_AUX, GZ_FQ_TOPLEVEL, GZ_FQ_SEQ_SNIP)
+    from genozip_amd.lib import (GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ_QUAL, GZ_FQ_QUAL_AUX, GZ_FQ_TOPLEVEL, GZ_FQ_SEQ_SNIP, GZ_FQ_ITEM_EXPECT)
     import base64
     C = plan["ctxs"]
     NC = len(C)
@@ -698,6 +698,11 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
             st = S[v][c]
             st.update(n=n, has_b250=False, has_local=False, ston_only=False, local=b"", ltype=0, col=None, ats=False)
             k = X["kind"]
+            if k == GZ_FQ_ITEM_EXPECT:                                  # no context: a prefix of the plan's container, the same in every record
+                o, l = io[X["item"]][a:b], il[X["item"]][a:b]
+                assert all(text[int(p):int(p) + int(q)] == X["snip"] for p, q in zip(o, l)), "the plan does not describe this text"
+                st["n"] = 0
+                continue
             ps = bool(X.get("per_sample")) and NS
             if ps:
                 st["n"] = n * NS
@@ -1568,12 +1573,12 @@ def sam_aligned_text(n, seed=21, qual="bin", aux=True):
     return b"".join(out)
 
 
-def sam_zip(E, oracle, n_reads, n_calls=2, qual="bin", aux=True, via_bam=False):
+def sam_zip(E, oracle, n_reads, n_calls=2, qual="bin", aux=True, via_bam=False, tags=False):
     """N1 for SAM (BASELINE configs[2] from TEXT): alignment lines through the VBlock compute driver with a one-line-record plan
     (genozip_amd/sam.py) == the oracle's step-by-step composition, byte for byte, over several VBlocks and calls (dictionaries carried);
     every section decodes again on the device"""
     from genozip_amd import sam as sm
-    plan = sm.sam_plan(has_aux=aux)
+    plan = sm.sam_plan(has_aux=aux, aux_tags=[("NM", "i"), ("AS", "i")] if tags else None)     # tags: a context per optional field behind the AUX container
     F = E.zip_open(plan)
     zstate, vb_i, n_vb = None, 0, 0
     for call in range(n_calls):
@@ -1602,6 +1607,12 @@ def sam_zip(E, oracle, n_reads, n_calls=2, qual="bin", aux=True, via_bam=False):
             n_vb += 1
     words = {c["tag"]: F.zctx_words(i) for i, c in enumerate(plan["ctxs"])}
     assert b"\x08\x20150M" in words["CIGAR"] and b"chr1" in words["RNAME"] and words["FLAG"]      # (CIGAR: SNIP_SPECIAL, SAM_SPECIAL_CIGAR + text)
+    if tags:                                                   # a record whose optional fields are not the plan's: refused, not mis-segged
+        import pytest
+        from genozip_amd.codec import GenozipAMDError
+        bad = sam_aligned_text(40, seed=77, qual=qual, aux=True).replace(b"\tAS:i:", b"\tXS:i:", 1)
+        with pytest.raises(GenozipAMDError, match="GZ_FQ_ITEM_EXPECT"):
+            F.zip_vblocks(bad, [(0, len(bad), vb_i + 1, -1)])
     F.close()
     return n_vb
 

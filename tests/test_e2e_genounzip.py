@@ -185,18 +185,20 @@ def test_vcf_round_trip(emul_engine, genounzip, tmp_path):
 SAM_HEADER = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:248956422\n@PG\tID:bwa\tPN:bwa\tVN:0.7.17\n"
 
 
-@pytest.mark.parametrize("qual,aux,dirty,header", [("uniform", False, False, b""), ("bin", True, True, SAM_HEADER), ("uniform", True, True, SAM_HEADER)])
-def test_sam_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, qual, aux, dirty, header):
+@pytest.mark.parametrize("qual,aux,dirty,header,tags", [("uniform", False, False, b"", False), ("bin", True, True, SAM_HEADER, False), ("uniform", True, True, SAM_HEADER, True)])
+def test_sam_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, qual, aux, dirty, header, tags):
     """aligned reads as SAM text (BASELINE configs[2]'s shape) through the SAM plan of genozip_amd/sam.py - 4 VBlocks over 2 calls - and the
     reference's decoder gives the text back byte for byte. What that pins beyond the FASTQ / VCF tests: the one-line-record plan's items
     (the eleven mandatory fields by tab, QNAME by its flavor, the optional fields), CIGAR's snips { SNIP_SPECIAL, SAM_SPECIAL_CIGAR } + text
     (src/sam_cigar.c:717-720) which the reader analyses for the lengths of SEQ and QUAL, SQBITMAP's verbatim special (src/sam_seq.c:806-821),
     NONREF with every read padded to whole bytes of the 2-bit packing (:224-229) incl. NONREF_X for bases that are not ACGT, QUAL as LT_BLOB
-    and through CODEC_DOMQ with seq_len taken from the CIGAR, FLAG / POS as value-storing contexts, a header component for SAM"""
+    and through CODEC_DOMQ with seq_len taken from the CIGAR, FLAG / POS as value-storing contexts, a header component for SAM; tags: the
+    optional fields behind the AUX container of sam_seg_aux_all (src/sam_seg.c:1363-1433: "NM:i:" / "AS:i:" as item prefixes) with a context
+    per tag instead of one textual item"""
     import random
     import numpy as np
     from genozip_amd import sam as sm
-    plan = sm.sam_plan(has_aux=aux)
+    plan = sm.sam_plan(has_aux=aux, aux_tags=[("NM", "i"), ("AS", "i")] if tags else None)
     F = emul_engine.zip_open(plan)
     res, texts, vb_i = [], [], 0
     for call, nr in enumerate((240, 150)):

@@ -189,6 +189,7 @@ def test_emul_header_layouts(emul_engine):
 def test_emul_sam_zip(emul_engine, oracle):
     """N1 for SAM: configs[2] from text - 4 VBlocks over 2 calls through the one-line-record plan == the oracle's composition"""
     assert parity.sam_zip(emul_engine, oracle, 500) == 4
+    assert parity.sam_zip(emul_engine, oracle, 400, tags=True) == 4                                                      # (a context per optional field)
     assert parity.sam_zip(emul_engine, oracle, 300, n_calls=1, qual="uniform", aux=False, via_bam=True) == 2      # (from BAM records)
 
 

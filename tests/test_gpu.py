@@ -265,6 +265,7 @@ def test_sam_zip_driver(gpu_engine, oracle):
     """N1 for SAM (BASELINE configs[2] from text): alignment lines through the driver's one-line-record plan == the oracle's composition,
     4 VBlocks over 2 calls, with and without optional fields, binned (CODEC_DOMQ) and 40-level qualities"""
     assert parity.sam_zip(gpu_engine, oracle, 3000) == 4
+    assert parity.sam_zip(gpu_engine, oracle, 3000, tags=True) == 4                                                        # (a context per optional field behind the AUX container)
     assert parity.sam_zip(gpu_engine, oracle, 1500, n_calls=1, qual="uniform", aux=False, via_bam=True) == 2        # (from BAM records: N1 for BAM in front)
 
 
