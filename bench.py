@@ -250,7 +250,13 @@ def cpu_leg(wl, z_all, n_threads):
         return outs, dt, sum(len(d) for d in ds)
     pool(8, list(range(min(8, len(tasks)))))                                    # warm up
     outs, dt_all, _ = pool(n_threads)
-    exact = all(o == p for o, p in zip(outs, payloads)) and qual_ok
+    n_diff = sum(o != p for o, p in zip(outs, payloads))
+    exact = n_diff == 0 and qual_ok
+    if not exact:
+        bad = next((i for i, (o, p) in enumerate(zip(outs, payloads)) if o != p), None)
+        sys.stderr.write("bit_exact: %d of %d payloads differ from the reference coder's, decoded QUAL %s%s\n" % (n_diff, len(payloads), "matches" if qual_ok else "DIFFERS from the text",
+                         "" if bad is None else "; first: task %d of VBlock %d, codec %d, %d bytes in%s" % (bad, task_vb[bad] + 1, codecs[bad], len(datas[bad]),
+                         (": data %s library %s reference %s" % (datas[bad].hex(), payloads[bad].hex(), outs[bad].hex())) if len(datas[bad]) <= 256 else "")))
     # steady state: as many threads as keep every one of them busy with >= 4 of the long streams
     long_ix = [i for i, d in enumerate(datas) if len(d) >= max(len(x) for x in datas) // 2]
     nt_ss = max(1, min(n_threads, len(long_ix) // 4))
@@ -360,7 +366,7 @@ class SamWorkload:
         import torch
         F, n = self.F, len(self.vb)
         F.reset()
-        if self.bam is not None:                               # N1 for BAM: records -> alignment lines, in the step
+        if getattr(self, "bam", None) is not None:           # N1 for BAM: records -> alignment lines, in the step
             _, rob, nrec = self.E.bam_records(self.bam[:self.bam_len], len(self.ref_names), cap=self.n_reads_own + 16, on_device=True)
             self.text, tl, _lb = self.E.bam_to_sam(self.bam[:self.bam_len], rob, self.ref_names, text_cap=self.text_len + 4096, on_device=True, n_rec=nrec)
             assert tl == self.text_len

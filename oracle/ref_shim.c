@@ -98,7 +98,9 @@ unsigned htsref_arith_bound (unsigned size, int order) { return arith_compress_b
 /* ---- many independent streams on a pthread pool: the multithreaded CPU baseline of bench.py ("kind": "reference").
  * Mirrors what Genozip's dispatcher does for this path: one compute thread per VBlock-sized unit of work
  * (src/dispatcher.c:544-618), here one codec call per task. codecs use Genozip's order bytes
- * (src/codec_htscodecs.c:17-20); streams shorter than 50 bytes are stored raw (src/compressor.c:56-58). ---- */
+ * (src/codec_htscodecs.c:17-20). Every task is a codec call: the caller leaves out the sections comp_compress stores raw (simple
+ * codecs under 50 bytes, src/compressor.c:56-58) - the sub-codec stream of a complex codec (CODEC_DOMQ's QUAL) is coded whatever
+ * its length (codec_domq.c:508-520 calls the sub-codec directly). ---- */
 #include <pthread.h>
 
 typedef struct {
@@ -114,8 +116,7 @@ static void *htsref_many_worker (void *arg)
         int i = j->next++;
         pthread_mutex_unlock (&j->mu);
         if (i >= j->n) return NULL;
-        if (j->in_lens[i] < 50) { memcpy (j->outs[i], j->ins[i], j->in_lens[i]); j->out_lens[i] = j->in_lens[i]; }
-        else j->out_lens[i] = j->is_arith[i] ? htsref_arith_compress (j->ins[i], j->in_lens[i], j->outs[i], j->out_caps[i], j->orders[i])
+        j->out_lens[i] = j->is_arith[i] ? htsref_arith_compress (j->ins[i], j->in_lens[i], j->outs[i], j->out_caps[i], j->orders[i])
                                              : htsref_rans_compress  (j->ins[i], j->in_lens[i], j->outs[i], j->out_caps[i], j->orders[i]);
     }
 }
