@@ -40,8 +40,14 @@ def emul_engine():
     so = os.path.join(ROOT, "tests", "emul", "libgenozip_amd_emul.so")
     srcs = [os.path.join(ROOT, "genozip_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "genozip_amd", "csrc"))]
     srcs.append(os.path.join(ROOT, "tests", "emul", "hip", "hip_runtime.h"))
-    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.run(["sh", os.path.join(ROOT, "tests", "emul", "build_emul.sh")], check=True)
+    def stale():
+        return not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if stale():
+        import fcntl                                   # (pytest-xdist: one worker builds, the others wait for it)
+        with open(so + ".lock", "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if stale():
+                subprocess.run(["sh", os.path.join(ROOT, "tests", "emul", "build_emul.sh")], check=True)
     from hostmem import HostMem
     from genozip_amd.codec import Engine
     return Engine(lib_path=so, mem=HostMem())
