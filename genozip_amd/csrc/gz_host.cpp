@@ -47,7 +47,7 @@ struct ArenaBlock { uint8_t *base; size_t size, used; };
 // workgroups of persistent chain kernels in flight in this process / those of them that hold a whole compute unit
 static std::atomic<int> g_chain_wgs (0), g_chain_cus (0);
 
-#define GZ_MAX_CHUNKS 17     // position chunks of the arithmetic coder's pipeline: at most 16 (arith_pipe_setup) + a partial one
+#define GZ_MAX_CHUNKS 129    // position chunks of the arithmetic coder's pipeline: at most 16 - or GZ_ARITH_CHUNKS - (arith_pipe_setup) + a partial one
 struct GzHandle {
     int device;
     hipStream_t stream;
@@ -457,7 +457,9 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
             if (!(L.spos   = (uint32_t *)arena_alloc (h, ((size_t)nb + 64) * 4))) return false;
             if (!(L.srk    = (uint8_t *)arena_alloc (h, (size_t)nb + 64))) return false;
             if (!(L.ctxoff = (uint32_t *)arena_alloc (h, (nt + 1) * nctx * 4))) return false;
-            if (!(L.ctxend = (uint32_t *)arena_alloc (h, (size_t)GZ_MAX_CHUNKS * nctx * 4))) return false;   // one row per position chunk
+            // one row per position chunk (no chunk is smaller than GZ_CHUNK_MIN: a short leaf has few)
+            const size_t rows = std::min<size_t> (GZ_MAX_CHUNKS, (size_t)nb / GZ_CHUNK_MIN + 2);
+            if (!(L.ctxend = (uint32_t *)arena_alloc (h, rows * nctx * 4))) return false;
             P.any_arith_o1 = true;
             P.o1_list.push_back ((uint32_t)P.leaves.size ());
         }
@@ -560,7 +562,9 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
     A.np = (uint32_t)P.plain_list.size (); A.no1 = (uint32_t)P.o1_list.size (); A.nlb = (uint32_t)P.low_blocks.size ();
     if (!A.np) return GZ_OK;
     // position chunks: at most 16 per leaf (8: 38.0 ms, 12: 37.7, 16: 37.6), none smaller than GZ_CHUNK_MIN, whole sort tiles
-    A.chunk = ((P.max_arith_n + 15) / 16 + GZ_CTX_TILE - 1) & ~(GZ_CTX_TILE - 1);
+    uint32_t want_chunks = 16;
+    if (const char *e = getenv ("GZ_ARITH_CHUNKS")) { const int v = atoi (e); if (v >= 1 && v <= GZ_MAX_CHUNKS - 1) want_chunks = (uint32_t)v; }   // (experiments)
+    A.chunk = ((P.max_arith_n + want_chunks - 1) / want_chunks + GZ_CTX_TILE - 1) & ~(GZ_CTX_TILE - 1);
     if (A.chunk < GZ_CHUNK_MIN) A.chunk = GZ_CHUNK_MIN;
     A.n_chunks = P.max_arith_n ? (P.max_arith_n + A.chunk - 1) / A.chunk : 1;
     // leaves that fit one chunk go through model and chain in one piece on a stream of their own; only the long ones
@@ -615,9 +619,9 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
     if (rc == GZ_OK && A.nsmall) { rc = upload (h, small.data (), small.size () * 4, &d); A.d_small = (const uint32_t *)d; }
     if (rc != GZ_OK) return rc;
     if (A.pipelined) {
-        if (A.n_chunks > 48) return GZ_ERR;                       // (cannot happen: at most 16 chunks)
-        if (!(A.d_progress = (uint32_t *)arena_alloc (h, 256))) return GZ_ERR_HIP;
-        HIPCHK (h, hipMemsetAsync (A.d_progress, 0, 256, h->stream));
+        if (A.n_chunks > GZ_MAX_CHUNKS) return GZ_ERR;            // (cannot happen: at most 16 / GZ_ARITH_CHUNKS chunks)
+        if (!(A.d_progress = (uint32_t *)arena_alloc (h, 1024))) return GZ_ERR_HIP;
+        HIPCHK (h, hipMemsetAsync (A.d_progress, 0, 1024, h->stream));
         if (A.nsmall) {                                           // the slices of the short leaves only
             std::vector<uint8_t> is_small (P.leaves.size (), 0);
             for (uint32_t l : small) is_small[l] = 1;
@@ -1181,9 +1185,9 @@ extern "C" int gz_domq_columns (GzHandle *h, const GzDomqJob *jobs, int n_jobs)
     const dim3 by_line ((max_n + GZ_DQ_LINES_PER_WG - 1) / GZ_DQ_LINES_PER_WG, (uint32_t)n_jobs);
     KLAUNCH (h, k_domq_lines, by_line, dim3 (256), GZ_DOMQ_LDS, (const GzdDomq *)dj);
     KLAUNCH (h, k_domq_tables, dim3 ((uint32_t)n_jobs), dim3 (128), 64, (const GzdDomq *)dj);
-    KLAUNCH (h, k_domq_measure, by_line, dim3 (256), 0, (const GzdDomq *)dj);
+    KLAUNCH (h, k_domq_measure, by_line, dim3 (256), GZ_DQ_NORM_LDS, (const GzdDomq *)dj);
     KLAUNCH (h, k_domq_scan, dim3 ((uint32_t)n_jobs), dim3 (256), 4096, (const GzdDomq *)dj);
-    KLAUNCH (h, k_domq_write, by_line, dim3 (256), 0, (const GzdDomq *)dj);
+    KLAUNCH (h, k_domq_write, by_line, dim3 (256), GZ_DQ_NORM_LDS, (const GzdDomq *)dj);
     HIPCHK (h, hipGetLastError ());
     return GZ_OK;
 }

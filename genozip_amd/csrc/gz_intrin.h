@@ -31,6 +31,10 @@ template <int OFF> __device__ static inline void gz_scalar_store4_at (uint32_t *
 // waiting for vector memory operations. A builtin, not inline asm: the compiler's own wait-count bookkeeping sees it.
 __device__ static inline void gz_wait_scalar_loads (void) { __builtin_amdgcn_s_waitcnt (0xC07F); }   // vmcnt 63, expcnt 7, lgkmcnt 0
 
+// wait for every outstanding vector memory operation, said through the builtin so that the compiler's bookkeeping knows: loaded values
+// that are stored again behind branches otherwise get a vmcnt(0) in front of every store - which also waits for the stores before it
+__device__ static inline void gz_wait_vector_mem (void) { __builtin_amdgcn_s_waitcnt (0x0F70); }   // vmcnt 0, expcnt 7, lgkmcnt 15
+
 // keep the instruction scheduler from moving anything across this point (it likes to sink loads towards their use)
 __device__ static inline void gz_sched_fence (void) { __builtin_amdgcn_sched_barrier (0); }
 
@@ -79,6 +83,8 @@ __device__ static inline uint4 gz_ldg_u32x4 (const void *p)
     const gz_v4 v = *(const __attribute__((address_space(1))) gz_v4 *)(uintptr_t)p;
     return make_uint4 (v.x, v.y, v.z, v.w);
 }
+__device__ static inline void gz_stg_u8 (uint8_t *p, uint32_t v) { *(__attribute__((address_space(1))) uint8_t *)(uintptr_t)p = (uint8_t)v; }
+__device__ static inline void gz_stg_u32 (uint32_t *p, uint32_t v) { *(__attribute__((address_space(1))) uint32_t *)(uintptr_t)p = v; }
 __device__ static inline void gz_stg_u16 (uint8_t *p, uint32_t v)     // 2 bytes, any alignment, through a GLOBAL pointer
 {
     typedef uint16_t __attribute__((aligned(1))) gz_u16_unaligned;

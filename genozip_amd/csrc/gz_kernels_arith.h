@@ -37,6 +37,18 @@ __device__ static inline uint4 d_model_record (uint32_t cum, uint32_t freq, GzDi
     return make_uint4 (freq, mg.magic, (mg.sh_inc & 0xffu) | (cum << 8), mg.sh_inc >> 8);
 }
 
+// (-DGZ_NT_RECORDS: the records leave as non-temporal stores - an experiment)
+typedef uint32_t gz_rec_u32x4 __attribute__((ext_vector_type (4)));
+__device__ static __forceinline__ void d_record_store (uint4 *at, uint4 v)
+{
+#ifdef GZ_NT_RECORDS
+    gz_rec_u32x4 x = { v.x, v.y, v.z, v.w };
+    __builtin_nontemporal_store (x, (gz_rec_u32x4 *)at);
+#else
+    *at = v;
+#endif
+}
+
 // Values loaded from the leaf table arrive through vector loads, so the compiler must assume they differ per lane and
 // turns every loop / branch on them into exec-mask code. They are wave-uniform: say so.
 __device__ static inline uint32_t d_uniform (uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane ((int)v); }
@@ -801,7 +813,7 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
         } \
         uint32_t out_cum = 0, out_freq = 0, out_tot = 0, n_ev = 0;
 #define GZ_WAVE_BATCH_TAIL \
-        if (p_on) recs[p_pos] = d_model_record (p_cum, p_freq, p_mg); \
+        if (p_on) d_record_store (recs + p_pos, d_model_record (p_cum, p_freq, p_mg)); \
         p_on = occ; p_pos = b_pos; p_cum = out_cum; p_freq = out_freq; \
         if (occ) p_mg = magic_tab[out_tot];
     for (uint32_t j = j0; j < j1; ) {
@@ -845,7 +857,7 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
     }
 #undef GZ_WAVE_BATCH_HEAD
 #undef GZ_WAVE_BATCH_TAIL
-    if (p_on) recs[p_pos] = d_model_record (p_cum, p_freq, p_mg);
+    if (p_on) d_record_store (recs + p_pos, d_model_record (p_cum, p_freq, p_mg));
 #ifdef GZ_MODEL_PHASES
     if (!lane && j1 - j0 >= GZ_MODEL_HOT) { for (int k = 0; k < 7; k++) atomicAdd (&g_mph[k], mph_[k]); atomicAdd (&g_mph[7], 1ull); }
 #endif

@@ -70,6 +70,11 @@ __device__ static inline void d_dq_put_run (uint8_t *dst, uint64_t r)           
     while (r) { const uint32_t sub = r < 254 ? (uint32_t)r : 254; *dst++ = r <= 254 ? (uint8_t)sub : 255; r -= sub; }
 }
 
+__device__ static inline void d_dq_put_run_g (uint8_t *dst, uint64_t r)               // (the same through a GLOBAL pointer)
+{
+    while (r) { const uint32_t sub = r < 254 ? (uint32_t)r : 254; gz_stg_u8 (dst++, r <= 254 ? sub : 255u); r -= sub; }
+}
+
 // sum / exclusive prefix sum of a 64-bit value over the wave
 __device__ static inline uint64_t d_wave_sum_u64 (uint64_t v, int lane)
 {
@@ -91,11 +96,70 @@ __device__ static inline uint64_t d_wave_excl_u64 (uint64_t v, int lane, uint64_
     return inc - v;
 }
 
+// The three per-line kernels below work a wave through 64 lines, one after the other, and everything a line needs is a chain of trips
+// to memory: its length and offset, then its bytes, then (measure / write) a table look-up per byte. Left like that a wave spends
+// 4-5 us per line waiting (1.2 + 0.95 + 0.9 ms for the 150 MB of QUAL of a 1 M-read file, 5-10 % of what HBM allows, in front of the
+// launch of the long QUAL streams). So: the NEXT line's first 256 bytes are requested before this line is worked on and the length /
+// offset of the line after that (two register sets taking turns: a loaded value cannot even be moved without waiting for it), and the
+// normalisation tables are read from LDS.
+// (Loads always happen, from a clamped index, and through GLOBAL pointers: a load under a condition comes with an exec-mask branch and
+//  a wait for everything before it, and a load through a generic pointer is a flat one that every LDS wait waits for as well.)
+struct GzdDqMeta { uint32_t len, off, ld, x[6]; };     // (ld, x: what measure / write need from the per-line tables - KIND 1 / 2)
+template <int KIND> __device__ static __forceinline__ GzdDqMeta d_dq_meta (const GzdDomq &J, uint32_t i, uint32_t end)
+{
+    const uint32_t ic = i < end ? i : end - 1;                                  // (end >= 1)
+    GzdDqMeta m; m.len = gz_ldg_u32 (J.len + ic); m.off = gz_ldg_u32 (J.off + ic);
+    if (KIND >= 1) m.ld = gz_ldg_u8 (J.line_dom + ic);                          // (an empty line's is never written: only looked at if the line has bytes)
+    if (KIND >= 2) {
+        const size_t n = J.n; const uint32_t *o = J.lo + ic;
+        m.x[0] = gz_ldg_u32 (o); m.x[1] = gz_ldg_u32 (o + n); m.x[2] = gz_ldg_u32 (o + 2 * n); m.x[3] = gz_ldg_u32 (o + 3 * n); m.x[4] = gz_ldg_u32 (o + 4 * n);
+        m.x[5] = gz_ldg_u32 (J.rec + 3 * n + ic);
+    }
+    return m;
+}
+__device__ static __forceinline__ void d_dq_fetch (const uint8_t *text, const GzdDqMeta &m, int lane, uint32_t (&b)[4])
+{
+    #pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t k = (uint32_t)(q * 64 + lane);
+        b[q] = gz_ldg_u8 (text + (m.len ? m.off + (k < m.len ? k : m.len - 1) : 0u));   // (beyond the line: its last byte again, nobody looks)
+    }
+}
+// column of a score in the normalisation tables (a score outside '!' .. '~' - k_domq_lines has flagged the VBlock - stays inside the table)
+__device__ static __forceinline__ uint32_t d_dq_index (uint32_t c) { return c - GZ_DQ_FIRST < GZ_DQ_N ? c - GZ_DQ_FIRST : 0u; }
+
+// CHUNK (c0, byte of position c0 + lane - garbage beyond the line) over the line's 64-byte chunks: the first four from the registers in
+// straight-line code - a load anywhere in there and its wait would also wait for the NEXT line's bytes, which are requested after this
+// line's and return in order -, what a line has beyond 256 bytes from memory, in a loop of its own
+#define GZ_DQ_FOR_CHUNKS(s, len, lane, b, CHUNK) do { \
+        if ((len) > 0)   CHUNK (0u,   (b)[0]); \
+        if ((len) > 64)  CHUNK (64u,  (b)[1]); \
+        if ((len) > 128) CHUNK (128u, (b)[2]); \
+        if ((len) > 192) CHUNK (192u, (b)[3]); \
+        for (uint32_t c0_ = 256; c0_ < (len); c0_ += 64) { const uint32_t k_ = c0_ + (uint32_t)(lane); CHUNK (c0_, gz_ldg_u8 ((s) + (k_ < (len) ? k_ : (len) - 1))); } \
+    } while (0)
+// runs LINE (i, meta, bytes) over lines base + wave, + 4, ... < end with the look-ahead described above
+#define GZ_DQ_FOR_LINES(KIND, J, base, wave, end, lane, LINE) do { \
+        uint32_t i_ = (base) + (wave); \
+        GzdDqMeta m0_ = d_dq_meta<KIND> (J, i_, end), m1_ = d_dq_meta<KIND> (J, i_ + 4, end), m2_, m3_; \
+        uint32_t bA_[4], bB_[4]; \
+        d_dq_fetch (J.text, m0_, lane, bA_); \
+        while (i_ < (end)) { \
+            d_dq_fetch (J.text, m1_, lane, bB_); m2_ = d_dq_meta<KIND> (J, i_ + 8, end); \
+            LINE (i_, m0_, bA_); \
+            i_ += 4; if (i_ >= (end)) break; \
+            d_dq_fetch (J.text, m2_, lane, bA_); m3_ = d_dq_meta<KIND> (J, i_ + 8, end); \
+            LINE (i_, m1_, bB_); \
+            i_ += 4; \
+            m0_ = m2_; m1_ = m3_; \
+        } \
+    } while (0)
+
 // ---- 1. every line's dominant score and the histograms per dominant score (codec_domq.c:139-176)
 // grid (lines / 256, VBlocks), 256 threads, GZ_DOMQ_LDS bytes: a wave per line, 64 lines per wave
 __global__ void __launch_bounds__(256) k_domq_lines (const GzdDomq *jobs)
 {
-    const GzdDomq &J = jobs[blockIdx.y];
+    const GzdDomq J = jobs[blockIdx.y];
     if (J.only_if && !*J.only_if) return;
     const uint32_t base = blockIdx.x * GZ_DQ_LINES_PER_WG;
     if (base >= J.n) return;
@@ -106,31 +170,32 @@ __global__ void __launch_bounds__(256) k_domq_lines (const GzdDomq *jobs)
     for (int i = tid; i < GZ_DQ_HIST + 4 * GZ_DQ_N + GZ_DQ_MISC; i += 256) hist[i] = 0;
     __syncthreads ();
     const uint32_t end = base + GZ_DQ_LINES_PER_WG < J.n ? base + GZ_DQ_LINES_PER_WG : J.n;
-    for (uint32_t i = base + wave; i < end; i += 4) {
-        const uint32_t len = J.len[i];
-        if (!len) continue;                                                     // (wave-uniform)
-        const uint8_t *s = J.text + J.off[i];
-        uint32_t *h = whist + wave * GZ_DQ_N;
-        for (uint32_t k = lane; k < len; k += 64) {
-            const uint32_t c = s[k];
-            if (c < GZ_DQ_FIRST || c > 126) misc[96] = 1; else atomicAdd (&h[c - GZ_DQ_FIRST], 1u);
-        }
+    uint32_t *h = whist + wave * GZ_DQ_N;
+    auto line = [&] (uint32_t i, const GzdDqMeta &m, const uint32_t (&b)[4]) {
+        const uint32_t len = m.len;
+        if (!len) return;                                                       // (wave-uniform)
+        const uint8_t *s = J.text + m.off;
+        auto chunk = [&] (uint32_t c0, uint32_t c) {
+            if (c0 + lane < len) { if (c < GZ_DQ_FIRST || c > 126) misc[96] = 1; else atomicAdd (&h[c - GZ_DQ_FIRST], 1u); }
+        };
+        GZ_DQ_FOR_CHUNKS (s, len, lane, b, chunk);
         gz_wave_sync ();
         // the largest count, the higher score among equals (:152-157): lanes hold scores lane and lane + 64
         const uint32_t c0 = h[lane], c1 = lane + 64 < GZ_DQ_N ? h[lane + 64] : 0;
         uint32_t best = c1 >= c0 && lane + 64 < GZ_DQ_N ? c1 : c0, bq = c1 >= c0 && lane + 64 < GZ_DQ_N ? (uint32_t)lane + 64 : (uint32_t)lane;
-        for (int m = 32; m; m >>= 1) {
-            const uint32_t ob = (uint32_t)__shfl ((int)best, lane ^ m), oq = (uint32_t)__shfl ((int)bq, lane ^ m);
+        for (int mm = 32; mm; mm >>= 1) {
+            const uint32_t ob = (uint32_t)__shfl ((int)best, lane ^ mm), oq = (uint32_t)__shfl ((int)bq, lane ^ mm);
             if (ob > best || (ob == best && oq > bq)) { best = ob; bq = oq; }
         }
         const bool diverse = 100u * best / len < 85u;                           // DOMQ_THRESHOLD
         if (c0) atomicAdd (&hist[bq * GZ_DQ_N + lane], c0);
         if (c1) atomicAdd (&hist[bq * GZ_DQ_N + lane + 64], c1);
-        if (!lane) { J.line_dom[i] = (uint8_t)(bq | (diverse ? 0x80 : 0)); atomicAdd (&misc[bq], 1u); if (diverse) misc[97] = 1; }
+        if (!lane) { gz_stg_u8 (J.line_dom + i, bq | (diverse ? 0x80u : 0u)); atomicAdd (&misc[bq], 1u); if (diverse) misc[97] = 1; }
         gz_wave_sync ();
         h[lane] = 0; if (lane + 64 < GZ_DQ_N) h[lane + 64] = 0;
         gz_wave_sync ();
-    }
+    };
+    GZ_DQ_FOR_LINES (0, J, base, wave, end, lane, line);
     __syncthreads ();
     for (int i = tid; i < GZ_DQ_HIST; i += 256) { const uint32_t v = hist[i]; if (v) atomicAdd (&J.hist[i], v); }
     if (tid < 98) { const uint32_t v = misc[tid]; if (v) { if (tid < GZ_DQ_N) atomicAdd (&J.hist[GZ_DQ_HIST + tid], v); else J.hist[GZ_DQ_HIST + tid] = 1; } }
@@ -141,7 +206,7 @@ __global__ void __launch_bounds__(256) k_domq_lines (const GzdDomq *jobs)
 // grid (VBlocks), 128 threads, 64 bytes of LDS
 __global__ void __launch_bounds__(128) k_domq_tables (const GzdDomq *jobs)
 {
-    const GzdDomq &J = jobs[blockIdx.x];
+    const GzdDomq J = jobs[blockIdx.x];
     if (J.only_if && !*J.only_if) return;
     const int tid = threadIdx.x;
     const uint32_t *hist = J.hist; uint32_t *misc = J.hist + GZ_DQ_HIST;
@@ -174,28 +239,37 @@ __global__ void __launch_bounds__(128) k_domq_tables (const GzdDomq *jobs)
     }
 }
 
-// ---- 3a. a line on its own. grid (lines / 256, VBlocks), 256 threads: a wave per line, 64 scores a step
+// ---- 3a. a line on its own. grid (lines / 256, VBlocks), 256 threads, GZ_DQ_NORM_LDS bytes: a wave per line, 64 scores a step
+#define GZ_DQ_NORM_LDS (GZ_DQ_HIST + 64)
+__device__ static __forceinline__ const uint8_t *d_dq_norm_to_lds (const GzdDomq &J, int tid)
+{
+    uint8_t *t = gz_lds;
+    for (int i = tid; i < GZ_DQ_HIST; i += 256) t[i] = J.normalize[i];
+    __syncthreads ();
+    return t;
+}
 __global__ void __launch_bounds__(256) k_domq_measure (const GzdDomq *jobs)
 {
-    const GzdDomq &J = jobs[blockIdx.y];
+    const GzdDomq J = jobs[blockIdx.y];
     if (J.only_if && !*J.only_if) return;
     const uint32_t base = blockIdx.x * GZ_DQ_LINES_PER_WG;
     if (base >= J.n) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint8_t *norm = d_dq_norm_to_lds (J, tid);
     const uint32_t end = base + GZ_DQ_LINES_PER_WG < J.n ? base + GZ_DQ_LINES_PER_WG : J.n;
     const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0;
-    for (uint32_t i = base + wave; i < end; i += 4) {
-        const uint32_t len = J.len[i];
-        const uint8_t ld = len ? J.line_dom[i] : 0;
+    auto line = [&] (uint32_t i, const GzdDqMeta &m, const uint32_t (&b)[4]) {
+        const uint32_t len = m.len;
+        const uint32_t ld = m.ld;
         uint32_t L = 0, trail = 0, lead = 0, nnz = 0, inner_q = 0, inner_r = 0;
         if (len && !(ld & 0x80)) {
-            const uint8_t *nrm = J.normalize + (ld & 0x7f) * GZ_DQ_N;
-            const uint8_t *s = J.text + J.off[i];
+            const uint8_t *nrm = norm + (ld & 0x7f) * GZ_DQ_N;
+            const uint8_t *s = J.text + m.off;
             int64_t last = -1;                                                  // (wave-uniform) position of the last non-dominant score so far
             uint64_t acc = 0;                                                   // per lane: markers << 32 | run bytes
-            for (uint32_t c0 = 0; c0 < len; c0 += 64) {
+            auto chunk = [&] (uint32_t c0, uint32_t c) {
                 const uint32_t k = c0 + lane;
-                const uint32_t v = k < len ? nrm[s[k] - GZ_DQ_FIRST] : 0;
+                const uint32_t v = k < len ? nrm[d_dq_index (c)] : 0;
                 const uint64_t mask = __ballot (v != 0);
                 if (v) {
                     const uint64_t mb = mask & below;
@@ -207,22 +281,24 @@ __global__ void __launch_bounds__(256) k_domq_measure (const GzdDomq *jobs)
                     last = (int64_t)c0 + 63 - __builtin_clzll (mask);
                     nnz += (uint32_t)__popcll (mask);
                 }
-            }
+            };
+            GZ_DQ_FOR_CHUNKS (s, len, lane, b, chunk);
             acc = d_wave_sum_u64 (acc, lane);
             L = len; trail = nnz ? len - 1 - (uint32_t)last : len;
             inner_q = nnz + (uint32_t)(acc >> 32); inner_r = (uint32_t)acc;
         }
         if (!lane) {
             uint32_t *r = J.rec + i; const size_t n = J.n;
-            r[0] = L; r[n] = trail; r[2 * n] = lead; r[3 * n] = nnz; r[4 * n] = inner_q; r[5 * n] = inner_r;
+            gz_stg_u32 (r, L); gz_stg_u32 (r + n, trail); gz_stg_u32 (r + 2 * n, lead); gz_stg_u32 (r + 3 * n, nnz); gz_stg_u32 (r + 4 * n, inner_q); gz_stg_u32 (r + 5 * n, inner_r);
         }
-    }
+    };
+    GZ_DQ_FOR_LINES (1, J, base, wave, end, lane, line);
 }
 
 // ---- 3b. the lines in order. grid (VBlocks), 256 threads: thread t walks lines [t T, (t + 1) T)
 __global__ void __launch_bounds__(256) k_domq_scan (const GzdDomq *jobs)
 {
-    const GzdDomq &J = jobs[blockIdx.x];
+    const GzdDomq J = jobs[blockIdx.x];
     if (J.only_if && !*J.only_if) return;
     const int tid = threadIdx.x;
     const size_t n = J.n;
@@ -230,12 +306,25 @@ __global__ void __launch_bounds__(256) k_domq_scan (const GzdDomq *jobs)
     const uint32_t *rL = J.rec, *rT = J.rec + n, *rLead = J.rec + 2 * n, *rN = J.rec + 3 * n, *rQ = J.rec + 4 * n, *rR = J.rec + 5 * n;
     const uint32_t *misc = J.hist + GZ_DQ_HIST;
     // positions (in the concatenation of the lines that are not diverse)
+    // (every loop below takes its lines four at a time with all their loads ahead of the arithmetic: a thread walks ~150 lines, one
+    //  after the other, and a trip to memory per line and table - the stores of the second pass keep the compiler from reading ahead
+    //  by itself - was what this kernel's time went into)
     uint64_t sumL = 0, tot_pos;
+    #pragma unroll 8
     for (uint32_t i = i0; i < i1; i++) sumL += rL[i];
     const uint64_t pos0 = d_wg_scan_u64 (sumL, tid, &tot_pos);
     // the last non-dominant score before my stretch
     int64_t mine = -1, last_nz;
-    { uint64_t pos = pos0; for (uint32_t i = i0; i < i1; i++) { if (rN[i]) mine = (int64_t)(pos + rL[i] - 1 - rT[i]); pos += rL[i]; } }
+    {
+        uint64_t pos = pos0;
+        for (uint32_t i = i0; i < i1; i += 4) {
+            uint32_t vL[4], vN[4], vT[4];
+            #pragma unroll
+            for (int u = 0; u < 4; u++) { const bool in = i + u < i1; vL[u] = in ? rL[i + u] : 0; vN[u] = in ? rN[i + u] : 0; vT[u] = in ? rT[i + u] : 0; }
+            #pragma unroll
+            for (int u = 0; u < 4; u++) { if (vN[u]) mine = (int64_t)(pos + vL[u] - 1 - vT[u]); pos += vL[u]; }
+        }
+    }
     const int64_t before0 = d_wg_scan_max (mine, tid, &last_nz);
     // bytes of every line in the four streams
     uint64_t qr = 0, dm = 0, tot_qr, tot_dm;
@@ -243,19 +332,30 @@ __global__ void __launch_bounds__(256) k_domq_scan (const GzdDomq *jobs)
         uint64_t pos = pos0; int64_t before = before0;
         uint64_t at_qr = 0, at_dm = 0;
         if (pass) { at_qr = d_wg_scan_u64 (qr, tid, &tot_qr); at_dm = d_wg_scan_u64 (dm, tid, &tot_dm); }
-        for (uint32_t i = i0; i < i1; i++) {
-            const uint32_t len = J.len[i], nnz = rN[i];
-            const bool diverse = len && (J.line_dom[i] & 0x80);
-            const uint64_t run_before = nnz ? pos + rLead[i] - (uint64_t)(before + 1) : 0;
-            const uint64_t q_bytes = rQ[i] + (nnz && !run_before ? 1 : 0), r_bytes = rR[i] + (nnz ? d_dq_run_bytes (run_before) : 0);
-            if (pass) {
-                uint32_t *o = J.lo + i;
-                o[0] = (uint32_t)(at_qr >> 32); o[n] = (uint32_t)at_qr; o[2 * n] = (uint32_t)(at_dm >> 32); o[3 * n] = (uint32_t)at_dm; o[4 * n] = (uint32_t)run_before;
-                at_qr += (q_bytes << 32) | r_bytes; at_dm += ((uint64_t)(diverse ? len : 0) << 32) | (len ? 1u : 0u);
+        for (uint32_t i4 = i0; i4 < i1; i4 += 4) {
+            uint32_t vLen[4], vN[4], vDom[4], vLead[4], vQ[4], vR[4], vL[4], vT[4];
+            #pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool in = i4 + u < i1; const uint32_t i = in ? i4 + u : i0;
+                vLen[u] = J.len[i]; vN[u] = rN[i]; vDom[u] = J.line_dom[i]; vLead[u] = rLead[i]; vQ[u] = rQ[i]; vR[u] = rR[i]; vL[u] = rL[i]; vT[u] = rT[i];
             }
-            else { qr += (q_bytes << 32) | r_bytes; dm += ((uint64_t)(diverse ? len : 0) << 32) | (len ? 1u : 0u); }
-            if (nnz) before = (int64_t)(pos + rL[i] - 1 - rT[i]);
-            pos += rL[i];
+            #pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = i4 + u;
+                if (i >= i1) break;
+                const uint32_t len = vLen[u], nnz = vN[u];
+                const bool diverse = len && (vDom[u] & 0x80);
+                const uint64_t run_before = nnz ? pos + vLead[u] - (uint64_t)(before + 1) : 0;
+                const uint64_t q_bytes = vQ[u] + (nnz && !run_before ? 1 : 0), r_bytes = vR[u] + (nnz ? d_dq_run_bytes (run_before) : 0);
+                if (pass) {
+                    uint32_t *o = J.lo + i;
+                    o[0] = (uint32_t)(at_qr >> 32); o[n] = (uint32_t)at_qr; o[2 * n] = (uint32_t)(at_dm >> 32); o[3 * n] = (uint32_t)at_dm; o[4 * n] = (uint32_t)run_before;
+                    at_qr += (q_bytes << 32) | r_bytes; at_dm += ((uint64_t)(diverse ? len : 0) << 32) | (len ? 1u : 0u);
+                }
+                else { qr += (q_bytes << 32) | r_bytes; dm += ((uint64_t)(diverse ? len : 0) << 32) | (len ? 1u : 0u); }
+                if (nnz) before = (int64_t)(pos + vL[u] - 1 - vT[u]);
+                pos += vL[u];
+            }
         }
     }
     // ---- the run the VBlock ends with (:468-480), "all diverse" (:490-494), results
@@ -272,43 +372,45 @@ __global__ void __launch_bounds__(256) k_domq_scan (const GzdDomq *jobs)
     }
 }
 
-// ---- 3c. the streams. grid (lines / 256, VBlocks), 256 threads: a wave per line
+// ---- 3c. the streams. grid (lines / 256, VBlocks), 256 threads, GZ_DQ_NORM_LDS bytes: a wave per line
 __global__ void __launch_bounds__(256) k_domq_write (const GzdDomq *jobs)
 {
-    const GzdDomq &J = jobs[blockIdx.y];
+    const GzdDomq J = jobs[blockIdx.y];
     if (J.only_if && !*J.only_if) return;
     const uint32_t base = blockIdx.x * GZ_DQ_LINES_PER_WG;
     if (base >= J.n) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint8_t *norm = d_dq_norm_to_lds (J, tid);
     const uint32_t end = base + GZ_DQ_LINES_PER_WG < J.n ? base + GZ_DQ_LINES_PER_WG : J.n;
     const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0;
     const size_t n = J.n;
     const uint32_t *misc = J.hist + GZ_DQ_HIST;
     const uint8_t *dom_to_cdom = (const uint8_t *)(misc + 100);
     const uint32_t no_doms = misc[98];
-    for (uint32_t i = base + wave; i < end; i += 4) {
-        const uint32_t len = J.len[i];
-        if (!len) continue;
-        const uint8_t ld = J.line_dom[i];
+    auto line = [&] (uint32_t i, const GzdDqMeta &m, const uint32_t (&b)[4]) {
+        const uint32_t len = m.len;
+        if (!len) return;
+        // (everything the line needs from the per-line tables at once: five offsets, the count of non-dominant scores)
+        const uint32_t o_q = m.x[0], o_r = m.x[1], o_d = m.x[2], o_m = m.x[3], o_run = m.x[4], nnz = m.x[5], ld = m.ld;
         const bool diverse = ld & 0x80;
-        const uint8_t *nrm = J.normalize + (ld & 0x7f) * GZ_DQ_N;
-        const uint8_t *s = J.text + J.off[i];
-        const uint32_t *o = J.lo + i;
-        if (!lane) J.mplx[o[3 * n]] = (uint8_t)(dom_to_cdom[ld & 0x7f] | (diverse ? 0x80 : 0));
+        const uint8_t *nrm = norm + (ld & 0x7f) * GZ_DQ_N;
+        const uint8_t *s = J.text + m.off;
+        if (!lane) gz_stg_u8 (J.mplx + o_m, dom_to_cdom[ld & 0x7f] | (diverse ? 0x80u : 0u));
         if (diverse) {
-            uint8_t *d = J.divr + o[2 * n];
-            for (uint32_t k = lane; k < len; k += 64) d[k] = nrm[s[k] - GZ_DQ_FIRST];
-            continue;
+            uint8_t *d = J.divr + o_d;
+            auto chunk = [&] (uint32_t c0, uint32_t c) { const uint32_t k = c0 + lane; if (k < len) gz_stg_u8 (d + k, nrm[d_dq_index (c)]); };
+            GZ_DQ_FOR_CHUNKS (s, len, lane, b, chunk);
+            return;
         }
-        if (!J.rec[3 * n + i]) continue;                                        // only the dominant score: the run goes on
-        uint8_t *q = J.qual + o[0], *r = J.runs + o[n];
-        const uint64_t run_before = o[4 * n];
+        if (!nnz) return;                                                       // only the dominant score: the run goes on
+        uint8_t *q = J.qual + o_q, *r = J.runs + o_r;
+        const uint64_t run_before = o_run;
         int64_t last = -1;
-        for (uint32_t c0 = 0; c0 < len; c0 += 64) {
+        auto chunk = [&] (uint32_t c0, uint32_t c) {
             const uint32_t k = c0 + lane;
-            const uint32_t v = k < len ? nrm[s[k] - GZ_DQ_FIRST] : 0;
+            const uint32_t v = k < len ? nrm[d_dq_index (c)] : 0;
             const uint64_t mask = __ballot (v != 0);
-            if (!mask) continue;                                                // (wave-uniform)
+            if (!mask) return;                                                  // (wave-uniform)
             uint64_t run = 0;
             if (v) {
                 const uint64_t mb = mask & below;
@@ -320,13 +422,15 @@ __global__ void __launch_bounds__(256) k_domq_write (const GzdDomq *jobs)
             const uint64_t ex = d_wave_excl_u64 (mine, lane, &tot);
             if (v) {
                 uint8_t *qq = q + (ex >> 32);
-                if (run) d_dq_put_run (r + (uint32_t)ex, run); else *qq++ = (uint8_t)no_doms;
-                *qq = (uint8_t)v;
+                if (run) d_dq_put_run_g (r + (uint32_t)ex, run); else gz_stg_u8 (qq++, no_doms);
+                gz_stg_u8 (qq, v);
             }
             q += tot >> 32; r += (uint32_t)tot;
             last = (int64_t)c0 + 63 - __builtin_clzll (mask);
-        }
-    }
+        };
+        GZ_DQ_FOR_CHUNKS (s, len, lane, b, chunk);
+    };
+    GZ_DQ_FOR_LINES (2, J, base, wave, end, lane, line);
 }
 
 // codec_domq_qual_data_is_a_fit_for_domq (:69-134): the first (up to) 10 lines, 2500 / lines bytes of each: more than half of
@@ -337,7 +441,7 @@ struct GzdDomqFit { const uint8_t *text; const uint32_t *off, *len; uint32_t n; 
 __global__ void __launch_bounds__(64) k_domq_fit (const GzdDomqFit *jobs, uint32_t n_jobs)
 {
     if (blockIdx.x >= n_jobs) return;
-    const GzdDomqFit &J = jobs[blockIdx.x];
+    const GzdDomqFit J = jobs[blockIdx.x];
     const int lane = threadIdx.x;
     uint32_t *h = (uint32_t *)gz_lds;                                           // [95] (+ room)
     uint32_t sampled = J.n < 10 ? J.n : 10, tested = 0, with_dom = 0;

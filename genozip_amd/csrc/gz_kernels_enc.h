@@ -52,7 +52,7 @@ __global__ void k_resolve (GzdStream *streams, uint32_t n_streams, int section_m
 // ======================================================================================================
 __global__ void k_stripe (GzdStream *streams)
 {
-    const GzdStream &S = streams[blockIdx.x];
+    const GzdStream S = streams[blockIdx.x];
     if (S.status != GZ_ST_PENDING || !S.striped) return;
     uint32_t n = S.n, off[4], len[4];
     gz_plane_geometry (n, len, off);

@@ -88,6 +88,11 @@ __device__ static inline uint64_t d_wg_scan_array (uint64_t *tiles, uint32_t n_t
 // all lanes of the wave copy len bytes (the arguments are wave-uniform): 4 bytes per lane and step, whatever the
 // alignment (256 bytes per step: a 150-byte read or quality string is one step), the last 1..3 bytes one by one
 typedef uint32_t gz_u32_unaligned __attribute__((aligned (1)));
+// the same bytes through GLOBAL pointers (a load / store through a generic one is a flat instruction: it also counts as an LDS operation)
+typedef const __attribute__((address_space(1))) uint8_t *GzGlobalCU8P;
+typedef __attribute__((address_space(1))) uint8_t *GzGlobalU8P;
+typedef const __attribute__((address_space(1))) gz_u32_unaligned *GzGlobalCU32UP;
+typedef __attribute__((address_space(1))) gz_u32_unaligned *GzGlobalU32UP;
 __device__ static inline void d_wave_copy (uint8_t *dst, const uint8_t *src, uint32_t len, int lane)
 {
     const uint32_t whole = len & ~3u;
@@ -142,7 +147,7 @@ __device__ static inline uint32_t d_col_insert (const GzdColumn &C, uint32_t id,
 // grid (tiles over n_ol + n, columns)
 __global__ void __launch_bounds__(256) k_col_clear (GzdColumn *cols)
 {
-    const GzdColumn &C = cols[blockIdx.y];
+    const GzdColumn C = cols[blockIdx.y];
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < (uint64_t)C.n_ol + C.n) C.counts[i] = 0;
     if (!i) {
@@ -155,7 +160,7 @@ __global__ void __launch_bounds__(256) k_col_clear (GzdColumn *cols)
 // grid (tiles over n_ol, columns)
 __global__ void __launch_bounds__(256) k_col_insert_ol (GzdColumn *cols)
 {
-    const GzdColumn &C = cols[blockIdx.y];
+    const GzdColumn C = cols[blockIdx.y];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= C.n_ol) return;
     uint32_t len;
@@ -166,7 +171,7 @@ __global__ void __launch_bounds__(256) k_col_insert_ol (GzdColumn *cols)
 // grid (tiles over n, columns), and so are the following
 __global__ void __launch_bounds__(256) k_col_insert (GzdColumn *cols)
 {
-    const GzdColumn &C = cols[blockIdx.y];
+    const GzdColumn C = cols[blockIdx.y];
     if (blockIdx.x * 256 >= C.n) return;
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     const uint32_t len = k < C.n ? C.len[k] : 0, off = len ? C.off[k] : 0;
@@ -197,7 +202,7 @@ __global__ void __launch_bounds__(256) k_col_insert (GzdColumn *cols)
 
 __global__ void __launch_bounds__(256) k_col_first (GzdColumn *cols)
 {
-    const GzdColumn &C = cols[blockIdx.y];
+    const GzdColumn C = cols[blockIdx.y];
     if (blockIdx.x * 256 >= C.n) return;
     const int tid = threadIdx.x;
     const uint32_t k = blockIdx.x * 256 + tid;
@@ -219,7 +224,7 @@ __global__ void __launch_bounds__(256) k_col_first (GzdColumn *cols)
 // grid (columns)
 __global__ void __launch_bounds__(256) k_col_scan_a (GzdColumn *cols)
 {
-    const GzdColumn &C = cols[blockIdx.x];
+    const GzdColumn C = cols[blockIdx.x];
     const uint32_t n_tiles = (C.n + GZ_COL_TILE - 1) / GZ_COL_TILE;
     const uint64_t total = d_wg_scan_array (C.tile_a, n_tiles, threadIdx.x);
     if (!threadIdx.x) {
@@ -231,7 +236,7 @@ __global__ void __launch_bounds__(256) k_col_scan_a (GzdColumn *cols)
 
 __global__ void __launch_bounds__(256) k_col_assign (GzdColumn *cols)
 {
-    const GzdColumn &C = cols[blockIdx.y];
+    const GzdColumn C = cols[blockIdx.y];
     if (blockIdx.x * 256 >= C.n) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t k = blockIdx.x * 256 + tid;
@@ -275,7 +280,7 @@ __device__ static inline int32_t d_col_node_of (const GzdColumn &C, uint32_t k)
 
 __global__ void __launch_bounds__(256) k_col_node (GzdColumn *cols)
 {
-    const GzdColumn &C = cols[blockIdx.y];
+    const GzdColumn C = cols[blockIdx.y];
     if (blockIdx.x * 256 >= C.n) return;
     const int tid = threadIdx.x;
     const uint32_t k = blockIdx.x * 256 + tid;
@@ -303,7 +308,7 @@ __global__ void __launch_bounds__(256) k_col_node (GzdColumn *cols)
 // grid (tiles / GZ_COUNT_TILES, columns)
 __global__ void __launch_bounds__(256) k_col_counts (GzdColumn *cols)
 {
-    const GzdColumn &C = cols[blockIdx.y];
+    const GzdColumn C = cols[blockIdx.y];
     const uint32_t k0 = blockIdx.x * (GZ_COUNT_TILES * 256);
     if (k0 >= C.n) return;
     uint32_t *key = (uint32_t *)gz_lds, *cnt = key + GZ_COUNT_SLOTS;
@@ -328,7 +333,7 @@ __global__ void __launch_bounds__(256) k_col_counts (GzdColumn *cols)
 // grid (columns)
 __global__ void __launch_bounds__(256) k_col_scan_b (GzdColumn *cols)
 {
-    const GzdColumn &C = cols[blockIdx.x];
+    const GzdColumn C = cols[blockIdx.x];
     const uint32_t n_tiles = (C.n + GZ_COL_TILE - 1) / GZ_COL_TILE;
     const uint64_t total = d_wg_scan_array (C.tile_b, n_tiles, threadIdx.x);
     if (threadIdx.x || !C.n) return;
@@ -343,7 +348,7 @@ __global__ void __launch_bounds__(256) k_col_scan_b (GzdColumn *cols)
 
 __global__ void __launch_bounds__(256) k_col_b250 (GzdColumn *cols)
 {
-    const GzdColumn &C = cols[blockIdx.y];
+    const GzdColumn C = cols[blockIdx.y];
     if (blockIdx.x * 256 >= C.n || !*C.not_same) return;
     const int tid = threadIdx.x;
     const uint32_t k = blockIdx.x * 256 + tid;
@@ -368,7 +373,7 @@ __device__ static inline uint64_t d_dyn_n (const GzdDynInt &D) { return D.n_dev 
 // grid (tiles, columns)
 __global__ void __launch_bounds__(256) k_dyn_minmax (GzdDynInt *cols)
 {
-    const GzdDynInt &D = cols[blockIdx.y];
+    const GzdDynInt D = cols[blockIdx.y];
     const uint64_t base = (uint64_t)blockIdx.x * GZ_DYN_TILE;
     if (base >= D.n) return;                                  // (tiles beyond the planning bound do not exist)
     const uint64_t Dn = d_dyn_n (D);
@@ -404,7 +409,7 @@ __device__ static inline int64_t d_order_max (int o)
 // (but cannot cause one).
 __global__ void __launch_bounds__(256) k_dyn_decide (GzdDynInt *cols)
 {
-    const GzdDynInt &D = cols[blockIdx.x];
+    const GzdDynInt D = cols[blockIdx.x];
     const int tid = threadIdx.x;
     const uint64_t Dn = d_dyn_n (D);
     const uint32_t n_tiles = (uint32_t)((D.n + GZ_DYN_TILE - 1) / GZ_DYN_TILE);   // (tiles past Dn hold the neutral elements)
@@ -431,7 +436,7 @@ __global__ void __launch_bounds__(256) k_dyn_decide (GzdDynInt *cols)
 // grid (tiles, columns)
 __global__ void __launch_bounds__(256) k_dyn_write (GzdDynInt *cols)
 {
-    const GzdDynInt &D = cols[blockIdx.y];
+    const GzdDynInt D = cols[blockIdx.y];
     const uint64_t base = (uint64_t)blockIdx.x * GZ_DYN_TILE;
     const uint64_t Dn = d_dyn_n (D);
     if (base >= Dn) return;
@@ -470,7 +475,7 @@ __device__ static inline uint64_t d_blob_item_bytes (const GzdBlob &B, uint32_t 
 // grid (tiles, columns)
 __global__ void __launch_bounds__(256) k_blob_sum (GzdBlob *cols)
 {
-    const GzdBlob &B = cols[blockIdx.y];
+    const GzdBlob B = cols[blockIdx.y];
     if (blockIdx.x * 256 >= B.n) return;
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     uint64_t total;
@@ -481,15 +486,18 @@ __global__ void __launch_bounds__(256) k_blob_sum (GzdBlob *cols)
 // grid (columns)
 __global__ void __launch_bounds__(256) k_blob_scan (GzdBlob *cols)
 {
-    const GzdBlob &B = cols[blockIdx.x];
+    const GzdBlob B = cols[blockIdx.x];
     const uint64_t total = d_wg_scan_array (B.tile, (B.n + GZ_COL_TILE - 1) / GZ_COL_TILE, threadIdx.x);
     if (!threadIdx.x) *B.out_len = total;
 }
 
+#ifndef GZ_BLOB_Q
+#define GZ_BLOB_Q 4
+#endif
 // grid (tiles, columns): the wave copies its 64 snips one after the other, 64 bytes at a time
 __global__ void __launch_bounds__(256) k_blob_copy (GzdBlob *cols)
 {
-    const GzdBlob &B = cols[blockIdx.y];
+    const GzdBlob B = cols[blockIdx.y];
     if (blockIdx.x * 256 >= B.n) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t k = blockIdx.x * 256 + tid;
@@ -502,13 +510,18 @@ __global__ void __launch_bounds__(256) k_blob_copy (GzdBlob *cols)
     // the wave's bytes are one contiguous stretch of the output starting at lane 0's offset
     const uint64_t wave_at = ((uint64_t)(uint32_t)__shfl ((int)(uint32_t)(at >> 32), 0) << 32) | (uint32_t)__shfl ((int)(uint32_t)at, 0);
     const uint32_t rel = (uint32_t)(at - wave_at);
-    // four snips per round: their loads are all in flight before the first store (one snip at a time the wave just sat
+    // (The job's fields in registers and the bytes through global pointers: read through a reference into the job table, every field was
+    //  fetched again - and waited for - after each store, the text pointer in front of every single load; the kernel was a chain of
+    //  trips to the L2 with nothing in flight.)
+    const GzGlobalCU8P text = (GzGlobalCU8P)(uintptr_t)B.text; const GzGlobalU8P out = (GzGlobalU8P)(uintptr_t)B.out;
+    const uint32_t pre = B.pre, pre_len = B.pre_len, pad_mask = B.pad_mask, pad_byte = B.pad_byte, add_nul = B.add_nul;
+    // GZ_BLOB_Q snips per round: their loads are all in flight before the first store (one snip at a time the wave just sat
     // out a memory round trip per snip - 1.1 ms for the 600 MB of SEQ + QUAL of FASTQ-PE-1M)
     uint64_t m = __ballot (on);
     while (m) {
-        uint32_t o[4], l[4], r[4], v[4];
+        uint32_t o[GZ_BLOB_Q], l[GZ_BLOB_Q], r[GZ_BLOB_Q], v[GZ_BLOB_Q];
         #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < GZ_BLOB_Q; q++) {
             const int src = m ? __ffsll ((unsigned long long)m) - 1 : 0;
             const bool live = m != 0;
             m &= m - 1;
@@ -516,23 +529,28 @@ __global__ void __launch_bounds__(256) k_blob_copy (GzdBlob *cols)
             if (!live) r[q] = 0xffffffffu;
         }
         #pragma unroll
-        for (int q = 0; q < 4; q++) v[q] = (uint32_t)lane * 4 < (l[q] & ~3u) ? *(const gz_u32_unaligned *)(B.text + o[q] + lane * 4) : 0;
+        for (int q = 0; q < GZ_BLOB_Q; q++) v[q] = (uint32_t)lane * 4 < (l[q] & ~3u) ? *(GzGlobalCU32UP)(text + o[q] + lane * 4) : 0;
+        // (the 1-3 bytes after a snip's last whole word as well: loaded in the store loop they would cost a trip to memory per snip)
+        uint32_t tb[GZ_BLOB_Q];
         #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < GZ_BLOB_Q; q++) tb[q] = (uint32_t)lane < (l[q] & 3u) ? (uint32_t)text[o[q] + (l[q] & ~3u) + lane] : 0u;
+        gz_wait_vector_mem ();                                 // (once, here: not in front of every store, where it would also wait for the stores so far)
+        #pragma unroll
+        for (int q = 0; q < GZ_BLOB_Q; q++) {
             if (r[q] == 0xffffffffu) continue;
-            uint8_t *dst = B.out + wave_at + r[q];
-            const uint8_t *src = B.text + o[q];
-            if ((uint32_t)lane < B.pre_len) dst[lane] = (uint8_t)(B.pre >> (8 * lane));
-            dst += B.pre_len;
-            if (B.pad_mask) {                                  // (at most pad_to - 1 bytes)
-                const uint32_t raw = B.pre_len + l[q] + B.add_nul, padded = (raw + B.pad_mask) & ~B.pad_mask;
-                if ((uint32_t)lane < padded - raw) dst[l[q] + B.add_nul + lane] = (uint8_t)B.pad_byte;
+            GzGlobalU8P dst = out + wave_at + r[q];
+            GzGlobalCU8P src = text + o[q];
+            if ((uint32_t)lane < pre_len) dst[lane] = (uint8_t)(pre >> (8 * lane));
+            dst += pre_len;
+            if (pad_mask) {                                    // (at most pad_to - 1 bytes)
+                const uint32_t raw = pre_len + l[q] + add_nul, padded = (raw + pad_mask) & ~pad_mask;
+                if ((uint32_t)lane < padded - raw) dst[l[q] + add_nul + lane] = (uint8_t)pad_byte;
             }
             const uint32_t whole = l[q] & ~3u;
-            if ((uint32_t)lane * 4 < whole) *(gz_u32_unaligned *)(dst + lane * 4) = v[q];
-            for (uint32_t b = 256 + (uint32_t)lane * 4; b < whole; b += 256) *(gz_u32_unaligned *)(dst + b) = *(const gz_u32_unaligned *)(src + b);
-            if ((uint32_t)lane < l[q] - whole) dst[whole + lane] = src[whole + lane];
-            if (B.add_nul && !lane) dst[l[q]] = 0;
+            if ((uint32_t)lane * 4 < whole) *(GzGlobalU32UP)(dst + lane * 4) = v[q];
+            for (uint32_t b = 256 + (uint32_t)lane * 4; b < whole; b += 256) *(GzGlobalU32UP)(dst + b) = *(GzGlobalCU32UP)(src + b);
+            if ((uint32_t)lane < l[q] - whole) dst[whole + lane] = (uint8_t)tb[q];
+            if (add_nul && !lane) dst[l[q]] = 0;
         }
     }
 }

@@ -90,7 +90,7 @@ __device__ static inline int d_icol_kind (const GzdIntCol &C, uint32_t k, int64_
 // grid (tiles, columns)
 __global__ void __launch_bounds__(256) k_icol_count (GzdIntCol *cols)
 {
-    const GzdIntCol &C = cols[blockIdx.y];
+    const GzdIntCol C = cols[blockIdx.y];
     if (blockIdx.x * 256 >= C.n) return;
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     int64_t v;
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256) k_icol_count (GzdIntCol *cols)
 // grid (columns)
 __global__ void __launch_bounds__(256) k_icol_scan (GzdIntCol *cols)
 {
-    const GzdIntCol &C = cols[blockIdx.x];
+    const GzdIntCol C = cols[blockIdx.x];
     const uint64_t total = d_wg_scan_array (C.tile, (C.n + 255) / 256, threadIdx.x);
     if (!threadIdx.x) *C.n_values = C.mode == 1 ? C.n : total;
 }
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) k_icol_scan (GzdIntCol *cols)
 // grid (tiles, columns)
 __global__ void __launch_bounds__(256) k_icol_write (GzdIntCol *cols)
 {
-    const GzdIntCol &C = cols[blockIdx.y];
+    const GzdIntCol C = cols[blockIdx.y];
     if (blockIdx.x * 256 >= C.n) return;
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     int64_t v = 0;
@@ -143,7 +143,7 @@ struct GzdLocalJob {
 // grid (tiles of 1024 elements, jobs)
 __global__ void __launch_bounds__(256) k_local_order_jobs (const GzdLocalJob *jobs)
 {
-    const GzdLocalJob &J = jobs[blockIdx.y];
+    const GzdLocalJob J = jobs[blockIdx.y];
     const int lt = J.dyn ? J.dyn->ltype : J.ltype;
     const uint32_t w = J.dyn ? J.dyn->width : (lt == GZ_LT_INT16 || lt == GZ_LT_UINT16) ? 2 : (lt == GZ_LT_INT32 || lt == GZ_LT_UINT32 || lt == GZ_LT_FLOAT32) ? 4
                                              : (lt == GZ_LT_INT64 || lt == GZ_LT_UINT64 || lt == GZ_LT_FLOAT64) ? 8 : 1;
@@ -174,7 +174,7 @@ struct GzdSameJob {
 // grid (jobs): one workgroup per pair
 __global__ void __launch_bounds__(256) k_bufs_identical (const GzdSameJob *jobs)
 {
-    const GzdSameJob &J = jobs[blockIdx.x];
+    const GzdSameJob J = jobs[blockIdx.x];
     const uint32_t n = *J.a_len;
     __shared__ uint32_t differs;
     if (!threadIdx.x) differs = n != *J.b_len;
@@ -193,7 +193,7 @@ struct GzdAcgtJob { const uint8_t *seq; const uint64_t *n_dev; uint64_t n_max; u
 // grid (tiles of 256 x 16 bases, jobs)
 __global__ void __launch_bounds__(256) k_acgt_pack_jobs (const GzdAcgtJob *jobs)
 {
-    const GzdAcgtJob &J = jobs[blockIdx.y];
+    const GzdAcgtJob J = jobs[blockIdx.y];
     const uint64_t n = J.n_dev ? *J.n_dev : J.n_max;
     const uint64_t packed_bytes = ((2 * n + 63) / 64) * 8, groups = (n + 15) / 16, words = packed_bytes / 4;
     if (!blockIdx.x && !threadIdx.x && J.packed_len) *J.packed_len = packed_bytes;
@@ -254,7 +254,7 @@ __global__ void k_pack_sizes (GzdPackJob *jobs, uint32_t n_jobs, uint64_t cap, u
 __global__ void __launch_bounds__(256) k_pack_copy (const GzdPackJob *jobs, uint8_t *staging, const uint64_t *total)
 {
     if (!total[1]) return;
-    const GzdPackJob &J = jobs[blockIdx.x];
+    const GzdPackJob J = jobs[blockIdx.x];
     const uint64_t n_new = J.res->n_new;
     const uint8_t *src[4] = { J.dict, (const uint8_t *)J.nci, (const uint8_t *)J.nsl, (const uint8_t *)J.counts };
     const uint64_t sz[4] = { J.res->status == 1 ? J.res->dict_len : 0, 8 * n_new, 4 * n_new, 4 * ((uint64_t)J.n_ol + n_new) };

@@ -16,9 +16,12 @@ static inline void gz_scalar_cache_inv (void) {}
 static inline void gz_touch (const void *p, uint32_t &pit) { pit += *(const volatile uint8_t *)p; }
 static inline void gz_touch_done (uint32_t &) {}
 static inline void gz_wave_sync (void) { (void)__ballot (1); }
+static inline void gz_wait_vector_mem (void) {}
 static inline uint32_t gz_ldg_u8 (const uint8_t *p) { return *p; }
 static inline uint32_t gz_ldg_u16 (const uint16_t *p) { return *p; }
 static inline uint32_t gz_ldg_u32 (const uint32_t *p) { return *p; }
 static inline uint4 gz_ldg_u32x4 (const void *p) { return *(const uint4 *)p; }
+static inline void gz_stg_u8 (uint8_t *p, uint32_t v) { *p = (uint8_t)v; }
+static inline void gz_stg_u32 (uint32_t *p, uint32_t v) { *p = v; }
 static inline void gz_stg_u16 (uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
 static inline double gz_rcp_f64 (double x) { return (double)(1.0f / (float)x) * (1.0 - 3e-8); }   // (a SEED of single precision, like v_rcp_f64: the caller's refinement and correction must hold)
