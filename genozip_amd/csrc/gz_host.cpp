@@ -561,8 +561,8 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
 {
     A.np = (uint32_t)P.plain_list.size (); A.no1 = (uint32_t)P.o1_list.size (); A.nlb = (uint32_t)P.low_blocks.size ();
     if (!A.np) return GZ_OK;
-    // position chunks: at most 16 per leaf (8: 38.0 ms, 12: 37.7, 16: 37.6), none smaller than GZ_CHUNK_MIN, whole sort tiles
-    uint32_t want_chunks = 16;
+    // position chunks: at most 32 per leaf (4 MB VBlocks - 8: 38.0 ms, 12: 37.7, 16: 37.6), none smaller than GZ_CHUNK_MIN, whole sort tiles
+    uint32_t want_chunks = 32;                                  // (16 -> 32: the first chunk's models are the lead-in of the long streams; default step 96.2 -> 95.1 ms, streamed 280.8 -> 277.1)
     if (const char *e = getenv ("GZ_ARITH_CHUNKS")) { const int v = atoi (e); if (v >= 1 && v <= GZ_MAX_CHUNKS - 1) want_chunks = (uint32_t)v; }   // (experiments)
     A.chunk = ((P.max_arith_n + want_chunks - 1) / want_chunks + GZ_CTX_TILE - 1) & ~(GZ_CTX_TILE - 1);
     if (A.chunk < GZ_CHUNK_MIN) A.chunk = GZ_CHUNK_MIN;
@@ -760,8 +760,12 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 KLAUNCH (h, k_low_scatter, dim3 (A.nlb), dim3 (GZ_LOW_WG), 4 * 144 * 4, d_leaves, A.d_lb, (const uint32_t *)NULL, 0u);
             }
             // spills into the following slices' digits (they can reach any distance: only once every digit is stored), then bytes
-            KLAUNCH (h, k_low_resid, dim3 ((A.nlb + 3) / 4), dim3 (GZ_LOW_WG), 0, d_leaves, A.d_lb, A.nlb);
-            KLAUNCH (h, k_low_norm, dim3 (A.np), dim3 (GZ_NORM_NT), 8192, d_leaves, A.d_plain);
+            KLAUNCH (h, k_low_resid, dim3 ((A.nlb + 63) / 64), dim3 (GZ_LOW_WG), 0, d_leaves, A.d_lb, A.nlb);
+            {   // (the digits of a leaf are at most 2 per coded byte + the closing ones: pay_cap)
+                const uint32_t tile = GZ_NORM_NT * GZ_NORM_PER, ranges = (uint32_t)(((uint64_t)2 * P.max_arith_n + 64 + (uint64_t)tile * GZ_NORM_RANGE - 1) / ((uint64_t)tile * GZ_NORM_RANGE));
+                KLAUNCH (h, k_low_norm, dim3 (A.np, ranges ? ranges : 1), dim3 (GZ_NORM_NT), 8192, d_leaves, A.d_plain);
+                KLAUNCH (h, k_low_carry, dim3 (A.np), dim3 (64), 0, d_leaves, A.d_plain);
+            }
         }
         if (fork) { HIPCHK (h, hipEventRecord (h->ev_join, side)); HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_join, 0)); }
     }

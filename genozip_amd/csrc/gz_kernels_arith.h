@@ -1202,6 +1202,7 @@ __global__ void k_low_gate (const uint32_t *done, uint32_t want, uint32_t *fail)
 #define GZ_LOW_SLICE 64
 #define GZ_LOW_WG    256
 #define GZ_LOW_SLICES_PER_WG 64          // each of the 4 waves of a workgroup walks 16 slices
+#define GZ_LOW_RUN (GZ_LOW_SLICES_PER_WG / 4)
 struct GzdLowBlock { uint32_t leaf, first_slice; };
 
 __device__ static inline uint32_t d_low_nslices (uint32_t n) { return n ? (n + GZ_LOW_SLICE - 1) / GZ_LOW_SLICE : 1; }
@@ -1321,8 +1322,14 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_scatter (GzdLeaf *leaves, con
     uint32_t *dig = (uint32_t *)L.events;
     uint32_t *acc = (uint32_t *)gz_lds + wave * 144;          // up to 128 own digits + 5 closing / 4 spilling
     const uint64_t below = (1ull << lane) - 1;
-    for (uint32_t q = 0; q < GZ_LOW_SLICES_PER_WG / 4; q++) {
-        const uint32_t slice = B.first_slice + wave * (GZ_LOW_SLICES_PER_WG / 4) + q;
+    uint32_t *resid = (uint32_t *)L.resid;
+    // What a slice adds beyond the digits it owns (up to 4) belongs to the following slices' digits. A wave walks GZ_LOW_RUN consecutive
+    // slices, so it carries them into its next slice's accumulator itself (lanes 0..3 hold them); only what the last slice of a run leaves
+    // goes through memory (resid, added by k_low_resid once every digit is stored: 1 slice in 16 instead of every one - that kernel was
+    // 0.6 ms at the tail of the step).
+    uint32_t carry_in = 0;
+    for (uint32_t q = 0; q < GZ_LOW_RUN; q++) {
+        const uint32_t slice = B.first_slice + wave * GZ_LOW_RUN + q;
         const bool on = slice < ns;                            // (all waves keep hitting the barriers)
         const uint32_t i = slice * GZ_LOW_SLICE + lane;
         uint32_t k = 0, a = 0;
@@ -1332,7 +1339,7 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_scatter (GzdLeaf *leaves, con
         const uint32_t K = (uint32_t)__popcll (m1) + (uint32_t)__popcll (m2);
         const bool last = on && slice == ns - 1;
         const uint32_t own = last ? K + 5 : K;                 // digits this slice owns: one per shift (+ the closing 5)
-        for (uint32_t j = lane; j < 144; j += 64) acc[j] = 0;
+        for (uint32_t j = lane; j < 144; j += 64) acc[j] = j < 4 ? carry_in : 0u;
         __syncthreads ();
         if (on && a) {
             atomicAdd (&acc[P],     a >> 24);
@@ -1341,27 +1348,31 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_scatter (GzdLeaf *leaves, con
             atomicAdd (&acc[P + 3], a & 0xff);
         }
         __syncthreads ();
+        carry_in = 0;
         if (on) {
             const uint32_t base = kpos[slice] + 1;             // output byte of this slice's first shift
             for (uint32_t j = lane; j < own; j += 64) dig[base + j] = acc[j];
-            if (lane < 4) ((uint32_t *)L.resid)[slice * 4 + lane] = last ? 0u : acc[own + lane];
+            if (lane < 4) {
+                const uint32_t left = last ? 0u : acc[own + lane];
+                if (q == GZ_LOW_RUN - 1) resid[(slice / GZ_LOW_RUN) * 4 + lane] = left; else carry_in = left;
+            }
         }
         __syncthreads ();
     }
 }
 
-// one thread per slice: each wave of a workgroup takes one entry of the table (grid: entries / 4)
+// what the last slice of every run of GZ_LOW_RUN leaves for the slices after it: one thread per run, 16 table entries (of 4 runs) per wave
 __global__ void __launch_bounds__(GZ_LOW_WG) k_low_resid (GzdLeaf *leaves, const GzdLowBlock *blocks, uint32_t n_blocks)
 {
-    const uint32_t bi = blockIdx.x * (GZ_LOW_WG / 64) + (threadIdx.x >> 6);
+    const uint32_t bi = (blockIdx.x * (GZ_LOW_WG / 64) + (threadIdx.x >> 6)) * 16 + ((threadIdx.x & 63) >> 2);
     if (bi >= n_blocks) return;
     const GzdLowBlock B = blocks[bi];
     GzdLeaf &L = leaves[B.leaf];
     if (!L.active || L.engine != GZ_ENG_ARITH) return;
     const uint32_t ns = d_low_nslices (L.arith_n), m = L.n_events;
-    const uint32_t slice = B.first_slice + (threadIdx.x & 63);
+    const uint32_t slice = B.first_slice + (threadIdx.x & 3) * GZ_LOW_RUN + GZ_LOW_RUN - 1;
     if (slice + 1 >= ns) return;                               // the last slice owns everything it touches
-    const uint4 r = ((const uint4 *)L.resid)[slice];
+    const uint4 r = ((const uint4 *)L.resid)[slice / GZ_LOW_RUN];
     if (!(r.x | r.y | r.z | r.w)) return;
     uint32_t *dig = (uint32_t *)L.events;
     const uint32_t at = ((const uint32_t *)L.kpos)[slice + 1] + 1;   // first digit of the next slice
@@ -1371,11 +1382,14 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_resid (GzdLeaf *leaves, const
     if (r.w && at + 3 < m) atomicAdd (&dig[at + 3], r.w);
 }
 
-// one 1024-thread workgroup per leaf. Tiles of 1024 x 16 digits are normalised from the end of the stream towards
+// grid (leaves, ranges): a 1024-thread workgroup per GZ_NORM_RANGE tiles of a leaf's digits (one workgroup per leaf took 0.44 ms at the
+// tail of the step for the 2.7 MB of a quality stream). Tiles of 1024 x 16 digits are normalised from the end of the range towards
 // its start; a thread turns its 16 digits into 16 bytes (a 128-bit big-endian number in 4 words) plus a carry-out,
-// carries then move one thread to the left per round as a 128-bit add until none is left (normally one round).
+// carries then move one thread to the left per round as a 128-bit add until none is left (normally one round). What leaves a range
+// on its left is added to the bytes before it by k_low_carry (addition is associative: the range before was normalised as if nothing came).
 #define GZ_NORM_NT 1024
 #define GZ_NORM_PER 16
+#define GZ_NORM_RANGE 8
 __global__ void __launch_bounds__(GZ_NORM_NT) k_low_norm (GzdLeaf *leaves, const uint32_t *list)
 {
     GzdLeaf &L = leaves[list[blockIdx.x]];
@@ -1384,12 +1398,15 @@ __global__ void __launch_bounds__(GZ_NORM_NT) k_low_norm (GzdLeaf *leaves, const
     const uint32_t m = L.n_events;
     const uint32_t *dig = (const uint32_t *)L.events;
     uint8_t *out = L.pay + 1;
+    uint32_t *range_out = (uint32_t *)L.resid;      // (k_low_resid is through with it) [range]: what leaves the range on its left
     uint32_t *sh = (uint32_t *)gz_lds;              // [0..NT] carries, [NT+8] "any carry left", [NT+9] carry into the next tile
     const uint32_t tile = GZ_NORM_NT * GZ_NORM_PER;
     const uint32_t ntiles = (m + tile - 1) / tile;
+    const uint32_t t_lo = blockIdx.y * GZ_NORM_RANGE, t_hi = t_lo + GZ_NORM_RANGE < ntiles ? t_lo + GZ_NORM_RANGE : ntiles;
+    if (t_lo >= ntiles) return;
     if (!tid) sh[GZ_NORM_NT + 9] = 0;
     __syncthreads ();
-    for (uint32_t t = ntiles; t-- > 0; ) {
+    for (uint32_t t = t_hi; t-- > t_lo; ) {
         const uint32_t b0 = t * tile + tid * GZ_NORM_PER;
         uint32_t w[4] = { 0, 0, 0, 0 };             // w[0] most significant: bytes b0..b0+3
         uint32_t carry = 0;
@@ -1446,10 +1463,25 @@ __global__ void __launch_bounds__(GZ_NORM_NT) k_low_norm (GzdLeaf *leaves, const
         }
         __syncthreads ();
     }
-    if (!tid) {
-        L.pay[0] = (uint8_t)(L.coded_n ? L.max_sym : 1);                 // max_sym + 1 (256 wraps to 0), arith_dynamic.c:103-108
-        if (m + 1 > L.pay_cap) { L.overflow = 1; L.pay_len = 0; }        // cannot happen: pay_cap >= 2n + 64
-        else L.pay_len = m + 1;
-        L.tab_len = 0;
+    if (!tid) range_out[blockIdx.y] = sh[GZ_NORM_NT + 9];
+}
+
+// grid (leaves), 64 threads: what left every range of k_low_norm on its left goes into the bytes before it (it ripples on while a byte
+// overflows: rarely beyond one); then the stream's first byte and length
+__global__ void __launch_bounds__(64) k_low_carry (GzdLeaf *leaves, const uint32_t *list)
+{
+    GzdLeaf &L = leaves[list[blockIdx.x]];
+    if (!L.active || L.engine != GZ_ENG_ARITH || threadIdx.x) return;
+    const uint32_t m = L.n_events;
+    const uint32_t tile = GZ_NORM_NT * GZ_NORM_PER, ntiles = (m + tile - 1) / tile, nranges = (ntiles + GZ_NORM_RANGE - 1) / GZ_NORM_RANGE;
+    const uint32_t *range_out = (const uint32_t *)L.resid;
+    uint8_t *out = L.pay + 1;
+    for (uint32_t y = nranges; y-- > 1; ) {
+        uint32_t c = range_out[y];
+        for (uint32_t idx = y * GZ_NORM_RANGE * tile; c && idx-- > 0; ) { const uint32_t v = out[idx] + c; out[idx] = (uint8_t)v; c = v >> 8; }
     }
+    L.pay[0] = (uint8_t)(L.coded_n ? L.max_sym : 1);                     // max_sym + 1 (256 wraps to 0), arith_dynamic.c:103-108
+    if (m + 1 > L.pay_cap) { L.overflow = 1; L.pay_len = 0; }            // cannot happen: pay_cap >= 2n + 64
+    else L.pay_len = m + 1;
+    L.tab_len = 0;
 }
