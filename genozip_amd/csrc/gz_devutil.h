@@ -91,8 +91,7 @@ __device__ static inline uint32_t gz_adler32_wg (const uint8_t *data, uint32_t l
     uint64_t A = 0, W = 0;
     const uint32_t body = len & ~15u;
     uint32_t rounds = 0;
-    for (uint32_t i = (uint32_t)tid * 16; i < body; i += 256 * 16) {
-        const gz_u32x4_unaligned v = *(const gz_u32x4_unaligned *)(data + i);
+    auto take = [&] (const gz_u32x4_unaligned &v, uint32_t i) {
         uint32_t S = 0, T = 0;                                 // sum d_j, sum j d_j over the 16 bytes
         #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -103,7 +102,15 @@ __device__ static inline uint32_t gz_adler32_wg (const uint8_t *data, uint32_t l
         A += S;
         W += (uint64_t)(len - i) * S - T;                      // < 2^44 each
         if (++rounds == 65536) { W %= 65521u; rounds = 0; }
+    };
+    const uint32_t step = 256 * 16;
+    uint32_t i = (uint32_t)tid * 16;
+    for (; i + 3 * step < body; i += 4 * step) {               // (four loads in flight)
+        const gz_u32x4_unaligned v0 = *(const gz_u32x4_unaligned *)(data + i), v1 = *(const gz_u32x4_unaligned *)(data + i + step),
+                                 v2 = *(const gz_u32x4_unaligned *)(data + i + 2 * step), v3 = *(const gz_u32x4_unaligned *)(data + i + 3 * step);
+        take (v0, i); take (v1, i + step); take (v2, i + 2 * step); take (v3, i + 3 * step);
     }
+    for (; i < body; i += step) { const gz_u32x4_unaligned v = *(const gz_u32x4_unaligned *)(data + i); take (v, i); }
     for (uint32_t i = body + tid; i < len; i += 256) { const uint32_t d = data[i]; A += d; W += (uint64_t)(len - i) * d; }
     __syncthreads ();
     sA[tid] = (uint32_t)(A % 65521u);
