@@ -838,6 +838,8 @@ extern "C" int gz_vb_compress_batch (GzHandle *h, GzVBlock *vbs, int n_vbs)
 {
     if (!h || (n_vbs && !vbs) || n_vbs < 0) return GZ_ERR_ARG;
     HIPCHK (h, hipSetDevice (h->device));
+    static const bool timing = getenv ("GZ_ZIP_TIMING") != NULL;
+    const auto tm0 = std::chrono::steady_clock::now ();
     Plan P;
     std::vector<GzdVB> V (n_vbs);
     for (int v = 0; v < n_vbs; v++) {
@@ -875,10 +877,15 @@ extern "C" int gz_vb_compress_batch (GzHandle *h, GzVBlock *vbs, int n_vbs)
     }
     void *d_streams, *d_leaves, *d_vbs;
     int rc;
+    const auto tm1 = std::chrono::steady_clock::now ();
     if ((rc = upload (h, P.streams.data (), P.streams.size () * sizeof (GzdStream), &d_streams)) != GZ_OK) return rc;
     if ((rc = upload (h, P.leaves.data (), P.leaves.size () * sizeof (GzdLeaf), &d_leaves)) != GZ_OK) return rc;
     if ((rc = upload (h, V.data (), V.size () * sizeof (GzdVB), &d_vbs)) != GZ_OK) return rc;
+    const auto tm2 = std::chrono::steady_clock::now ();
     if ((rc = launch_encode (h, P, (GzdStream *)d_streams, (GzdLeaf *)d_leaves, (GzdVB *)d_vbs, (uint32_t)n_vbs, 1)) != GZ_OK) return rc;
+    if (timing) fprintf (stderr, "[vb_compress_batch bg %d vbs %d streams %zu leaves %zu (%zu B each): plan %.2f upload %.2f launch %.2f ms]\n", (int)h->background, n_vbs, P.streams.size (), P.leaves.size (),
+                         sizeof (GzdLeaf), std::chrono::duration<double, std::milli> (tm1 - tm0).count (), std::chrono::duration<double, std::milli> (tm2 - tm1).count (),
+                         std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - tm2).count ());
     Pending pd; pd.kind = 2; pd.user = vbs; pd.n = n_vbs; pd.dev_streams = d_streams; pd.dev_vbs = d_vbs; pd.n_dev_streams = P.streams.size ();
     h->pending.push_back (pd);
     return GZ_OK;
