@@ -1201,7 +1201,7 @@ extern "C" int gz_domq_columns (GzHandle *h, const GzDomqJob *jobs, int n_jobs)
     KLAUNCH (h, k_domq_lines, by_line, dim3 (256), GZ_DOMQ_LDS, (const GzdDomq *)dj);
     KLAUNCH (h, k_domq_tables, dim3 ((uint32_t)n_jobs), dim3 (128), 64, (const GzdDomq *)dj);
     KLAUNCH (h, k_domq_measure, by_line, dim3 (256), GZ_DQ_NORM_LDS, (const GzdDomq *)dj);
-    KLAUNCH (h, k_domq_scan, dim3 ((uint32_t)n_jobs), dim3 (256), 4096, (const GzdDomq *)dj);
+    KLAUNCH (h, k_domq_scan, dim3 ((uint32_t)n_jobs), dim3 (GZ_DQ_SCAN_NT), 4096, (const GzdDomq *)dj);
     KLAUNCH (h, k_domq_write, by_line, dim3 (256), GZ_DQ_NORM_LDS, (const GzdDomq *)dj);
     HIPCHK (h, hipGetLastError ());
     return GZ_OK;

@@ -295,66 +295,92 @@ __global__ void __launch_bounds__(256) k_domq_measure (const GzdDomq *jobs)
     GZ_DQ_FOR_LINES (1, J, base, wave, end, lane, line);
 }
 
-// ---- 3b. the lines in order. grid (VBlocks), 256 threads: thread t walks lines [t T, (t + 1) T)
-__global__ void __launch_bounds__(256) k_domq_scan (const GzdDomq *jobs)
+// ---- 3b. the lines in order. grid (VBlocks), 1024 threads: each of the 16 waves owns a contiguous sixteenth of the VBlock's lines and
+// walks it 64 lines at a time, lane = line (every table read and written in whole lines of memory; the first version had thread t walk
+// lines [t T, (t + 1) T) on its own - 256 threads each touching a different line of memory per load, 0.95 ms for a 38 000-line VBlock).
+// What runs through the lines - the position in the concatenation of the non-diverse lines, the position of the last non-dominant
+// score so far, the output offsets - is a scan: inside the 64 lines by shuffles, from tile to tile in wave-uniform registers, from
+// wave to wave through LDS (three passes: totals per wave; bytes per wave; the offsets).
+#define GZ_DQ_SCAN_NT 1024
+__device__ static __forceinline__ int64_t d_wave_shfl_i64 (int64_t v, int src)
+{
+    const uint32_t lo = (uint32_t)__shfl ((int)(uint32_t)(uint64_t)v, src), hi = (uint32_t)__shfl ((int)(uint32_t)((uint64_t)v >> 32), src);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+// exclusive max-scan over the wave (identity -1); *total = the maximum over all lanes
+__device__ static __forceinline__ int64_t d_wave_exclmax_i64 (int64_t v, int lane, int64_t *total)
+{
+    int64_t inc = v;
+    for (int d = 1; d < 64; d <<= 1) { const int64_t o = d_wave_shfl_i64 (inc, lane >= d ? lane - d : lane); if (lane >= d && o > inc) inc = o; }
+    *total = d_wave_shfl_i64 (inc, 63);
+    const int64_t left = d_wave_shfl_i64 (inc, lane ? lane - 1 : 0);
+    return lane ? left : -1;
+}
+__global__ void __launch_bounds__(GZ_DQ_SCAN_NT) k_domq_scan (const GzdDomq *jobs)
 {
     const GzdDomq J = jobs[blockIdx.x];
     if (J.only_if && !*J.only_if) return;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = GZ_DQ_SCAN_NT / 64;
     const size_t n = J.n;
-    const uint32_t T = (J.n + 255) / 256, i0 = (uint32_t)tid * T < J.n ? (uint32_t)tid * T : J.n, i1 = i0 + T < J.n ? i0 + T : J.n;
     const uint32_t *rL = J.rec, *rT = J.rec + n, *rLead = J.rec + 2 * n, *rN = J.rec + 3 * n, *rQ = J.rec + 4 * n, *rR = J.rec + 5 * n;
     const uint32_t *misc = J.hist + GZ_DQ_HIST;
-    // positions (in the concatenation of the lines that are not diverse)
-    // (every loop below takes its lines four at a time with all their loads ahead of the arithmetic: a thread walks ~150 lines, one
-    //  after the other, and a trip to memory per line and table - the stores of the second pass keep the compiler from reading ahead
-    //  by itself - was what this kernel's time went into)
-    uint64_t sumL = 0, tot_pos;
-    #pragma unroll 8
-    for (uint32_t i = i0; i < i1; i++) sumL += rL[i];
-    const uint64_t pos0 = d_wg_scan_u64 (sumL, tid, &tot_pos);
-    // the last non-dominant score before my stretch
-    int64_t mine = -1, last_nz;
-    {
-        uint64_t pos = pos0;
-        for (uint32_t i = i0; i < i1; i += 4) {
-            uint32_t vL[4], vN[4], vT[4];
-            #pragma unroll
-            for (int u = 0; u < 4; u++) { const bool in = i + u < i1; vL[u] = in ? rL[i + u] : 0; vN[u] = in ? rN[i + u] : 0; vT[u] = in ? rT[i + u] : 0; }
-            #pragma unroll
-            for (int u = 0; u < 4; u++) { if (vN[u]) mine = (int64_t)(pos + vL[u] - 1 - vT[u]); pos += vL[u]; }
-        }
+    uint64_t *shA = (uint64_t *)gz_lds, *shB = shA + NW;      // per wave: two sums
+    int64_t *shM = (int64_t *)(shB + NW);                     // per wave: a maximum
+    const uint32_t tiles = (J.n + 63) / 64, tpw = (tiles + NW - 1) / NW;
+    const uint32_t w0 = (uint64_t)wave * tpw * 64 < J.n ? wave * tpw * 64 : J.n, w1 = (uint64_t)w0 + tpw * 64 < J.n ? w0 + tpw * 64 : J.n;
+    // ---- pass 1: the length and the last non-dominant score of every wave's stretch
+    uint64_t sumL = 0; int64_t lastnz = -1;                    // (relative to the start of the stretch)
+    for (uint32_t t0 = w0; t0 < w1; t0 += 64) {
+        const bool in = t0 + lane < w1; const uint32_t i = in ? t0 + lane : w1 - 1;
+        uint32_t L = gz_ldg_u32 (rL + i), N = gz_ldg_u32 (rN + i); const uint32_t T = gz_ldg_u32 (rT + i);
+        if (!in) { L = 0; N = 0; }
+        uint64_t tot; const uint64_t ex = d_wave_excl_u64 (L, lane, &tot);
+        int64_t mx; (void)d_wave_exclmax_i64 (N ? (int64_t)(sumL + ex + L - 1 - T) : -1, lane, &mx);
+        if (mx > lastnz) lastnz = mx;
+        sumL += tot;
     }
-    const int64_t before0 = d_wg_scan_max (mine, tid, &last_nz);
-    // bytes of every line in the four streams
-    uint64_t qr = 0, dm = 0, tot_qr, tot_dm;
+    if (!lane) { shA[wave] = sumL; shM[wave] = lastnz; }
+    __syncthreads ();
+    uint64_t pos0 = 0, tot_pos = 0; int64_t before0 = -1, last_nz = -1;
+    for (int w = 0; w < NW; w++) {
+        if (w == wave) { pos0 = tot_pos; before0 = last_nz; }
+        if (shM[w] >= 0) last_nz = (int64_t)tot_pos + shM[w];
+        tot_pos += shA[w];
+    }
+    __syncthreads ();
+    // ---- passes 2 and 3: the bytes of every line in the four streams; their sums per wave, then every line's offsets
+    uint64_t at_qr0 = 0, at_dm0 = 0, tot_qr = 0, tot_dm = 0;
     for (int pass = 0; pass < 2; pass++) {
-        uint64_t pos = pos0; int64_t before = before0;
-        uint64_t at_qr = 0, at_dm = 0;
-        if (pass) { at_qr = d_wg_scan_u64 (qr, tid, &tot_qr); at_dm = d_wg_scan_u64 (dm, tid, &tot_dm); }
-        for (uint32_t i4 = i0; i4 < i1; i4 += 4) {
-            uint32_t vLen[4], vN[4], vDom[4], vLead[4], vQ[4], vR[4], vL[4], vT[4];
-            #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const bool in = i4 + u < i1; const uint32_t i = in ? i4 + u : i0;
-                vLen[u] = J.len[i]; vN[u] = rN[i]; vDom[u] = J.line_dom[i]; vLead[u] = rLead[i]; vQ[u] = rQ[i]; vR[u] = rR[i]; vL[u] = rL[i]; vT[u] = rT[i];
+        uint64_t pos = pos0, at_qr = at_qr0, at_dm = at_dm0; int64_t before = before0;
+        for (uint32_t t0 = w0; t0 < w1; t0 += 64) {
+            const bool in = t0 + lane < w1; const uint32_t i = in ? t0 + lane : w1 - 1;
+            uint32_t L = gz_ldg_u32 (rL + i), N = gz_ldg_u32 (rN + i), len = gz_ldg_u32 (J.len + i);
+            const uint32_t T = gz_ldg_u32 (rT + i), lead = gz_ldg_u32 (rLead + i), Q = gz_ldg_u32 (rQ + i), R = gz_ldg_u32 (rR + i), dom = gz_ldg_u8 (J.line_dom + i);
+            if (!in) { L = 0; N = 0; len = 0; }
+            const bool diverse = len && (dom & 0x80);
+            uint64_t totL; const uint64_t exL = d_wave_excl_u64 (L, lane, &totL);
+            const uint64_t my_pos = pos + exL;
+            int64_t mx; const int64_t exm = d_wave_exclmax_i64 (N ? (int64_t)(my_pos + L - 1 - T) : -1, lane, &mx);
+            const int64_t my_before = exm > before ? exm : before;
+            const uint64_t run_before = N ? my_pos + lead - (uint64_t)(my_before + 1) : 0;
+            const uint64_t q_bytes = in ? Q + (N && !run_before ? 1 : 0) : 0, r_bytes = in ? R + (N ? d_dq_run_bytes (run_before) : 0) : 0;
+            const uint64_t qr = (q_bytes << 32) | r_bytes, dm = ((uint64_t)(diverse ? len : 0) << 32) | (len ? 1u : 0u);
+            uint64_t tqr, tdm; const uint64_t eqr = d_wave_excl_u64 (qr, lane, &tqr), edm = d_wave_excl_u64 (dm, lane, &tdm);
+            if (pass && in) {
+                uint32_t *o = J.lo + i; const uint64_t a = at_qr + eqr, d = at_dm + edm;
+                gz_stg_u32 (o, (uint32_t)(a >> 32)); gz_stg_u32 (o + n, (uint32_t)a); gz_stg_u32 (o + 2 * n, (uint32_t)(d >> 32)); gz_stg_u32 (o + 3 * n, (uint32_t)d);
+                gz_stg_u32 (o + 4 * n, (uint32_t)run_before);
             }
-            #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t i = i4 + u;
-                if (i >= i1) break;
-                const uint32_t len = vLen[u], nnz = vN[u];
-                const bool diverse = len && (vDom[u] & 0x80);
-                const uint64_t run_before = nnz ? pos + vLead[u] - (uint64_t)(before + 1) : 0;
-                const uint64_t q_bytes = vQ[u] + (nnz && !run_before ? 1 : 0), r_bytes = vR[u] + (nnz ? d_dq_run_bytes (run_before) : 0);
-                if (pass) {
-                    uint32_t *o = J.lo + i;
-                    o[0] = (uint32_t)(at_qr >> 32); o[n] = (uint32_t)at_qr; o[2 * n] = (uint32_t)(at_dm >> 32); o[3 * n] = (uint32_t)at_dm; o[4 * n] = (uint32_t)run_before;
-                    at_qr += (q_bytes << 32) | r_bytes; at_dm += ((uint64_t)(diverse ? len : 0) << 32) | (len ? 1u : 0u);
-                }
-                else { qr += (q_bytes << 32) | r_bytes; dm += ((uint64_t)(diverse ? len : 0) << 32) | (len ? 1u : 0u); }
-                if (nnz) before = (int64_t)(pos + vL[u] - 1 - vT[u]);
-                pos += vL[u];
+            at_qr += tqr; at_dm += tdm; pos += totL;
+            if (mx > before) before = mx;
+        }
+        if (!pass) {
+            if (!lane) { shA[wave] = at_qr; shB[wave] = at_dm; }
+            __syncthreads ();
+            for (int w = 0; w < NW; w++) {
+                if (w == wave) { at_qr0 = tot_qr; at_dm0 = tot_dm; }
+                tot_qr += shA[w]; tot_dm += shB[w];
             }
         }
     }
