@@ -1021,7 +1021,9 @@ typedef const __attribute__((address_space(1))) uint32_t *GzGlobalU32P;
 
 #define GZ_CHAIN_BLOCK 8
 #define GZ_CHAIN_TOUCH_PERIOD 64          // records between two touches; one touch covers that many records (PERIOD * 16 bytes)
+#ifndef GZ_CHAIN_TOUCH_AHEAD
 #define GZ_CHAIN_TOUCH_AHEAD (1 * 1024)    // bytes: how far ahead of the scalar loads the vector unit pulls lines into L2 (measured: 1 KB 40.8 ms/step, 4 KB 42.9, 16 KB 44.9, 64 KB 61 - lines touched too early are gone again by the time they are needed)
+#endif
 
 __device__ static inline uint32_t d_chain_step (uint32_t &range, uint32_t freq, uint32_t mg, uint32_t shw, uint32_t inc)
 {

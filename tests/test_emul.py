@@ -40,7 +40,9 @@ def test_emul_arith_long_streams(emul_engine, oracle):
              (18, synth.skewed_bytes(5, 90000, 4, 0.3).tobytes()), (17, synth.u32be_increasing(6, 80000).tobytes()),
              (16, bytes(60000)), (16, synth.skewed_bytes(7, 120000, 2, 0.02).tobytes()),
              # position chunks (> 64 K) through the wide-alphabet models and the all-zero special case
-             (16, synth.uniform_bytes(8, 100000, 200).tobytes()), (16, synth.markov_bytes(9, 70000, 100, 20).tobytes()), (16, bytes(70000))]
+             (16, synth.uniform_bytes(8, 100000, 200).tobytes()), (16, synth.markov_bytes(9, 70000, 100, 20).tobytes()), (16, bytes(70000)),
+             # more than 131 072 output bytes: two ranges of k_low_norm, what leaves the second one goes through k_low_carry
+             (16, synth.uniform_bytes(12, 300000, 40).tobytes())]
     # wide alphabet (200 symbols), but every context byte is followed by only 100 / 40 of them: over position chunks such a context
     # runs with its own alphabet (k_ctx_succ: two register planes / one instead of four)
     import numpy as np
@@ -156,6 +158,12 @@ def test_emul_ctx_golden(emul_engine, oracle):
 
 def test_emul_domq(emul_engine, oracle):
     parity.domq(emul_engine, oracle, 700)
+
+
+def test_emul_domq_many_lines(emul_engine, oracle):
+    """more than 1024 lines per VBlock: every wave of k_domq_scan walks several 64-line tiles, the running position / last
+    non-dominant score / offsets pass from tile to tile and from wave to wave"""
+    parity.domq(emul_engine, oracle, 2600)
 
 
 def test_section_order_contexts_out_of_order(emul_engine):
