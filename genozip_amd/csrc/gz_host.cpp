@@ -78,7 +78,7 @@ struct GzHandle {
     std::vector<Pending> pending;
     std::vector<void *> host_tmp;      // host staging to free at sync
     GzLogTable *d_logs;
-    GzDivMagic *d_magic;      // division-by-multiplication constants for every possible model total
+    GzDivInv *d_magic;        // the reciprocal of every possible model total (division by multiplication in the chain)
     std::string err;
     size_t arena_block_size;
     // optional per-kernel timing with HIP events on this handle's stream (bench.py's roofline object)
@@ -199,23 +199,21 @@ static GzHandle *gz_create_do (int device, void *hip_stream, int *err, bool back
         if (h->own_stream) (void)hipStreamDestroy (h->stream);
         delete h; if (err) *err = GZ_ERR_HIP; return NULL;
     }
-    // range / tot of the range coder (c_range_coder.h:100) as q = mulhi (magic, n + inc) >> shift with a 32-bit magic:
-    // with L = floor (log2 d) and e = 2^(32+L) mod d, the rounded-up reciprocal is exact for every 32-bit n when
-    // d - e <= 2^L, otherwise the rounded-down one applied to n + 1 is (one of the two always holds; Granlund &
-    // Montgomery / "Labor of Division III"). tot <= 65519 + 16
+    // range / tot of the range coder (c_range_coder.h:100) as the low word of fma (range * 2^-7, inv, 2^52) rounded toward zero
+    // (gz_kernels_arith.h): inv = 2^7 / tot rounded UP to a double - the quotient of the two doubles rounded to nearest, one step up
+    // if that fell below (the fma gives the sign of inv * tot - 2^7 exactly). tot <= 65519 + 16
     {
         const uint32_t N = 65536 + 32;
-        std::vector<GzDivMagic> mt (N);
-        mt[0].magic = 0xffffffffu; mt[0].sh_inc = 1u << 8;
+        std::vector<GzDivInv> mt (N);
+        mt[0].lo = 0; mt[0].hi = 0x40600000u;                   // (128.0: never used)
         for (uint32_t dv = 1; dv < N; dv++) {
-            const uint32_t L = 31 - __builtin_clz (dv);
-            if ((dv & (dv - 1)) == 0) { mt[dv].magic = 0xffffffffu; mt[dv].sh_inc = L | (1u << 8); continue; }
-            const uint64_t num = 1ull << (32 + L), md = num / dv, e = num % dv;
-            if (dv - e <= (1ull << L)) { mt[dv].magic = (uint32_t)(md + 1); mt[dv].sh_inc = L; }
-            else                       { mt[dv].magic = (uint32_t)md;       mt[dv].sh_inc = L | (1u << 8); }
+            double inv = 128.0 / (double)dv;
+            if (fma (inv, (double)dv, -128.0) < 0.0) inv = nextafter (inv, 1e300);
+            uint64_t bits; memcpy (&bits, &inv, 8);
+            mt[dv].lo = (uint32_t)bits; mt[dv].hi = (uint32_t)(bits >> 32);
         }
-        if (hipMalloc ((void **)&h->d_magic, N * sizeof (GzDivMagic)) != hipSuccess ||
-            hipMemcpy (h->d_magic, mt.data (), N * sizeof (GzDivMagic), hipMemcpyHostToDevice) != hipSuccess) {
+        if (hipMalloc ((void **)&h->d_magic, N * sizeof (GzDivInv)) != hipSuccess ||
+            hipMemcpy (h->d_magic, mt.data (), N * sizeof (GzDivInv), hipMemcpyHostToDevice) != hipSuccess) {
             if (err) *err = GZ_ERR_HIP;
             gz_destroy (h);
             return NULL;
@@ -448,12 +446,12 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
         // what the coder sees: the bytes, or (run-length variant) up to 2 coding events per byte
         const uint32_t nb = rle ? 2 * n_bound : n_bound;
         const uint32_t nctx = rle ? 768 : 256;
-        if (!(L.triples = (uint8_t *)arena_alloc (h, ((size_t)nb + 64) * 16 + 2 * GZ_CHAIN_TOUCH_AHEAD + 16384))) return false;
+        if (!(L.triples = (uint8_t *)arena_alloc (h, ((size_t)nb + 64) * 16 + 16384))) return false;
         if (!(L.events  = (uint8_t *)arena_alloc (h, ((size_t)L.pay_cap + 128) * 4))) return false;
         if (!(L.rvals   = (uint8_t *)arena_alloc (h, ((size_t)nb + 64) * 4))) return false;
         const uint32_t ns = nb ? (nb + GZ_LOW_SLICE - 1) / GZ_LOW_SLICE : 1;
         if (!(L.kpos    = (uint8_t *)arena_alloc (h, ((size_t)ns + 2) * 4))) return false;
-        if (!(L.ckpt    = (uint8_t *)arena_alloc (h, ((size_t)ns + 2) * 4))) return false;
+        if (!(L.ckpt    = (uint8_t *)arena_alloc (h, ((size_t)ns + 2) * 8))) return false;
         if (!(L.resid   = (uint8_t *)arena_alloc (h, ((size_t)ns + 1) * 16))) return false;
         for (uint32_t s0 = 0; s0 < ns; s0 += GZ_LOW_SLICES_PER_WG) { GzdLowBlock b; b.leaf = (uint32_t)P.leaves.size (); b.first_slice = s0; P.low_blocks.push_back (b); }
         if (o1 || rle) {
@@ -681,7 +679,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
             KLAUNCH_ON (h, side, k_rans_encode, dim3 (nl), dim3 (64), GZ_RANS_ENC_LDS, d_leaves);
         }
         if (A.np) {
-            const GzDivMagic *magic = (const GzDivMagic *)h->d_magic;
+            const GzDivInv *magic = (const GzDivInv *)h->d_magic;
             const uint32_t grid_y = GZ_MODEL_GRID_Y + (P.rle_list.empty () ? 0 : GZ_MODEL_GRID_RUN);
             if (!P.rle_list.empty ())                              // the run-length variant's coding events (before anything looks at arith_n)
                 KLAUNCH (h, k_rle_events, dim3 ((uint32_t)P.rle_list.size ()), dim3 (1024), 256, d_leaves, A.d_rle);

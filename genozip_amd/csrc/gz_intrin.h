@@ -90,3 +90,35 @@ __device__ static inline void gz_stg_u16 (uint8_t *p, uint32_t v)     // 2 bytes
     typedef uint16_t __attribute__((aligned(1))) gz_u16_unaligned;
     *(__attribute__((address_space(1))) gz_u16_unaligned *)(uintptr_t)p = (uint16_t)v;
 }
+
+// ---- double precision with truncation: the range coder chain (gz_kernels_arith.h) ----------------------------------------
+// MODE.FP_ROUND[3:2] = 3: double precision rounds toward zero in this wave from here on. (Inline asm: a mode change the
+// compiler knows about is undone by it in front of the next floating point instruction.)
+__device__ static inline void gz_f64_round_toward_zero (void) { asm volatile ("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3" : : : "memory"); }
+// a * b + c in a wave that has called gz_f64_round_toward_zero
+__device__ static inline double gz_fma_rtz (double a, double b, double c) { return __builtin_fma (a, b, c); }
+
+#include "gz_chain_asm.h"
+// Whole 64-symbol blocks of one leaf's chain (tools/gen_chain_asm.py explains the loop). (rlo, rhi) = the state, a double
+// (range * 2^-7), wave-uniform in and out; recs = the records of the first block; ck = where the first block's checkpoint
+// goes (8 bytes per block, scalar stores). Returns the number of blocks NOT done: 0, or the first of them holds a total below
+// 256 - its checkpoint is written, the caller takes it symbol by symbol.
+__device__ static inline uint32_t gz_chain_blocks (uint32_t &rlo, uint32_t &rhi, const uint8_t *recs, uint32_t nblk, uint32_t *ck)
+{
+    const uint64_t b = (uint64_t)(uintptr_t)recs, c = (uint64_t)(uintptr_t)ck;
+    const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)b), b_hi = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)(b >> 32));
+    const uint32_t c_lo = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)c), c_hi = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)(c >> 32));
+    const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane ((int)nblk);
+    uint32_t left;
+    asm volatile (GZ_CHAIN_F64_ASM : [rlo] "+v"(rlo), [rhi] "+v"(rhi), [left] "=s"(left)
+                                   : [blo] "s"(b_lo), [bhi] "s"(b_hi), [nblk] "s"(nb), [clo] "s"(c_lo), [chi] "s"(c_hi) : GZ_CHAIN_F64_CLOBBERS);
+    rlo = (uint32_t)__builtin_amdgcn_readfirstlane ((int)rlo); rhi = (uint32_t)__builtin_amdgcn_readfirstlane ((int)rhi);   // (the state ends in lane 0)
+    return left;
+}
+// one 8-byte checkpoint through the scalar unit
+__device__ static inline void gz_scalar_store2 (uint32_t *dst, uint32_t a, uint32_t b)
+{
+    const uint32_t sa = (uint32_t)__builtin_amdgcn_readfirstlane ((int)a), sb = (uint32_t)__builtin_amdgcn_readfirstlane ((int)b);   // (wave-uniform values that live in vector registers)
+    asm volatile ("s_store_dwordx2 %0, %1, 0x0" : : "s"((uint64_t)sa | (uint64_t)sb << 32), "s"(dst) : "memory");
+}
+

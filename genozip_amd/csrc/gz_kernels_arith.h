@@ -11,9 +11,10 @@
 //   k_arith_model  the triple (cum, freq, tot) fed to the coder depends only on MODEL history, and the models never
 //                  interact: one wave per (leaf, context), the model in registers (1, 2 or 4 planes of one entry per
 //                  lane), 64 occurrences at a time, order changes (swaps, hops) patched in as events. Writes a 16-byte
-//                  record per position: freq, reciprocal of tot, shift | cum << 8, inc.
-//   k_arith_chain  what is truly serial: range -> range / tot * freq -> renormalise. One wave per leaf, entirely on the
-//                  scalar unit, 7 instructions per symbol; persistent, following the models position chunk by chunk.
+//                  record per position: the reciprocal of tot as a double, freq, cum.
+//   k_arith_chain  what is truly serial: range -> range / tot * freq -> renormalise. One wave per leaf, four vector
+//                  instructions per symbol in double precision, the state hopping a lane per symbol (gz_chain_asm.h);
+//                  persistent, following the models position chunk by chunk.
 //   k_low_*        low += cum * r is a big-number addition and addition is associative: one thread per symbol adds its
 //                  bytes at the output position given by a prefix sum of the shift counts; then carries.
 #pragma once
@@ -24,17 +25,17 @@
 #define GZ_MODEL_LIMIT 65519u          // MAX_FREQ (c_simple_model.h:63)
 #define GZ_MODEL_STEP  16u
 
-// range / tot without dividing: q = mulhi (magic, n + inc) >> shift with a 32-bit magic number. For every divisor either
-// the rounded-up reciprocal (inc 0) or the rounded-down one (inc 1) is exact for all 32-bit n ("Labor of Division,
-// episode III"); powers of two use magic 2^32-1, inc 1. sh_inc = shift | inc << 8. (n + 1 must not wrap: n = 2^32-1
-// only happens at the very first symbol, which the chain handles itself.)
-struct GzDivMagic { uint32_t magic, sh_inc; };
+// range / tot without dividing and without the integer unit: in double precision, rounding toward zero,
+//      fma (range * 2^-7, inv, 2^52) = 2^52 + floor (range / tot)        with inv = 2^7 / tot rounded UP to a double
+// (the product inside the fma is exact; inv errs by < 2^-52 relative, range / tot < 2^32, so the product errs by < 2^-20 - far less
+// than the 1 / tot by which a quotient that is not an integer stays below the next one - and never falls below an exact quotient).
+// The low half of the result IS the quotient as an integer. The table of inv for every model total is built by the host (gz_create).
+struct GzDivInv { uint32_t lo, hi; };
 
-// record of one symbol, written by the model for the chain and the low kernels: { freq, magic, shift | cum << 8, inc }
-// (the scalar shift instruction only looks at the low 5 bits of its count, so cum rides along for free)
-__device__ static inline uint4 d_model_record (uint32_t cum, uint32_t freq, GzDivMagic mg)
+// record of one symbol, written by the model for the chain and the low kernels: { inv (a double, two words), freq, cum }
+__device__ static inline uint4 d_model_record (uint32_t cum, uint32_t freq, GzDivInv iv)
 {
-    return make_uint4 (freq, mg.magic, (mg.sh_inc & 0xffu) | (cum << 8), mg.sh_inc >> 8);
+    return make_uint4 (iv.lo, iv.hi, freq, cum);
 }
 
 // (-DGZ_NT_RECORDS: the records leave as non-temporal stores - an experiment)
@@ -727,7 +728,7 @@ __device__ unsigned long long g_mph[8];
 #endif
 template <int J, bool LDSM = false>
 __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, uint32_t ms, bool o1, uint4 *recs,
-                                                   const GzDivMagic *magic_tab, const uint8_t *symlist, const uint16_t *symrank, uint32_t nsym,
+                                                   const GzDivInv *magic_tab, const uint8_t *symlist, const uint16_t *symrank, uint32_t nsym,
                                                    const uint32_t *spos, const uint8_t *srk, uint32_t j0, uint32_t j1, bool first, bool save, uint32_t *st,
                                                    const GzLocalAlpha *la = nullptr)
 {
@@ -762,7 +763,7 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
 
     // the records of a batch are stored while the next batch is being worked on: the division constants they need come
     // from a table in memory, and waiting for that load at the end of every batch would cost more than the batch
-    uint32_t p_pos = 0, p_cum = 0, p_freq = 0; GzDivMagic p_mg = { 0, 0 }; bool p_on = false;
+    uint32_t p_pos = 0, p_cum = 0, p_freq = 0; GzDivInv p_mg = { 0, 0 }; bool p_on = false;
     // ... and the occurrences of the following batches are fetched while this one is being worked on. The raw loads (sorted position +
     // rank byte, or the input byte of an order-0 leaf) run FOUR TO EIGHT batches ahead: a batch without events is ~300 ns of work, a trip
     // to memory 1-2 us, so one batch ahead (as it was) left a context whose order is stable waiting for its next occurrences most of the
@@ -897,7 +898,7 @@ __device__ unsigned long long g_model_slowest;     // (10 ns ticks << 40) | (lis
 #define GZ_MODEL_T0 do {} while (0)
 #define GZ_MODEL_T1(ctx, occ) do {} while (0)
 #endif
-__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, const GzDivMagic *magic_tab, uint32_t p0, uint32_t chunk)
+__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, const GzDivInv *magic_tab, uint32_t p0, uint32_t chunk)
 {
     GzdLeaf &L = leaves[list[blockIdx.x]];
     if (!L.active || L.engine != GZ_ENG_ARITH || L.arith_n <= p0) return;
@@ -993,18 +994,28 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
 }
 
 // ---- range coder chain ------------------------------------------------------------------------------------------
-// Measured on MI355X (tools/ubench_chain.hip): ONE wave issues at most one instruction every 4 clocks (1.67 ns at
-// 2.4 GHz) whether or not it depends on the previous one, a vector->scalar hand-over (v_readlane feeding s_*) costs
-// ~12 ns, and nothing but the instruction count of the wave matters. What is truly serial in the range coder
-// (c_range_coder.h:97-109) is only
+// Measured on MI355X (tools/ubench_issue.hip, tools/ubench_chain_f64.hip): ONE wave issues an instruction every 4.25 clocks
+// (5.25 for the 8-byte encodings) whether or not it depends on the previous one, a vector->scalar hand-over costs ~12 ns, scalar
+// loads return out of order (only "wait for all" exists), a vector load in the loop costs 9+ clocks - nothing but the instruction
+// count of the serial wave and the waits in it matter. What is truly serial in the range coder (c_range_coder.h:97-109) is only
 //        r = range / tot ;  range = (r * freq) << 8k      (k = bytes needed to bring range back above 2^24)
 // `low` is not: low += cum * r followed by shifts is a big-number addition, and addition is associative. So
-//   k_arith_chain  one wave per leaf, entirely on the scalar unit, 7 operations per symbol (d_chain_step) + the record
-//                  loads: SMEM, 64 records per loop iteration in two 32-register buffers, the next buffer in flight
-//                  (the lines are pulled into L2 1 KB ahead by a vector "touch" load because SMEM returns out of order
-//                  and can only be waited for as a whole), division by the per-record magic number, renormalisation
-//                  by count-leading-zeros instead of a loop. It never looks at cum or low, and stores only the range before
-//                  every 64th symbol: k_chain_expand recomputes r = range / tot of every symbol from those for the low kernels.
+//   k_arith_chain  one wave per leaf. Rounds 1-2 ran the recurrence on the scalar unit, seven integer instructions per symbol
+//                  (+ inc, mulhi by a magic number, >> shift, * freq, clz, & 0x18, <<) fed by scalar loads: 30.5 clocks per
+//                  symbol + the waits for those loads (13.6 ns alone on the device, 14.9 beside the other kernels of a step).
+//                  Now FOUR vector instructions in double precision (the state is range * 2^-7 as a double):
+//                      fma (R, 2^7 / tot, 2^52)   rounding toward zero: 2^52 + floor (range / tot) - the low word IS r
+//                      r * freq                   24-bit integer multiply (r < 2^24 when tot >= 256)
+//                      {P, 0x42c00000} - 2^45     the integer as a double, scaled by 2^-7, exact
+//                      hi = hi & 0x7fffff | 0x41000000    the exponent's low three bits stay, the others become those of
+//                                                 [2^24, 2^32): exactly "shift left by whole bytes until >= 2^24"
+//                  and NO operand fetch in the loop: lane j holds the record of symbol base + j (one coalesced load per 64
+//                  symbols, a block ahead), all lanes execute every step, the state hops one lane per symbol through a DPP
+//                  read (gz_chain_asm.h, written by tools/gen_chain_asm.py): 25.8 clocks = 10.8 ns per symbol, the same with 1
+//                  or 64 chains on the device and whatever else runs. It never looks at cum or low, and stores only the state
+//                  before every 64th symbol: k_chain_expand recomputes r = range / tot of every symbol from those for the low
+//                  kernels - with the plain formulation of the same arithmetic, and checks that it arrives at the chain's next
+//                  checkpoint: the two check each other on every 64 symbols of every stream.
 //   k_low_*        all threads: every thread replays low += cum * r for its own slice of 64 symbols from low = 0,
 //                  emitting the byte that leaves the 32-bit window at every shift (plus the carry out of the window as
 //                  a 9th bit) at its absolute output position (k_low_count / k_low_scan: a prefix sum of the k's;
@@ -1014,22 +1025,20 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
 // This reproduces RC_ShiftLow's cache / pending-0xFF bookkeeping (c_range_coder.h:70-88) exactly: that logic is just
 // a lazy form of the same addition ("[0, T1, T2, ...] plus 1 at the byte before every shift that saw a carry").
 typedef uint32_t gz_u32x4 __attribute__((vector_size (16)));
-typedef uint32_t gz_u32x16 __attribute__((vector_size (64)));
-typedef const volatile __attribute__((address_space(4))) gz_u32x4 *GzConstRecP;   // volatile: keeps the prefetch a prefetch
-typedef const volatile __attribute__((address_space(4))) gz_u32x16 *GzConstRec4P; // 4 records per load
-typedef const __attribute__((address_space(1))) uint32_t *GzGlobalU32P;
+typedef const volatile __attribute__((address_space(4))) gz_u32x4 *GzConstRecP;   // (scalar loads of single records: the slow way)
 
-#define GZ_CHAIN_BLOCK 8
-#define GZ_CHAIN_TOUCH_PERIOD 64          // records between two touches; one touch covers that many records (PERIOD * 16 bytes)
-#ifndef GZ_CHAIN_TOUCH_AHEAD
-#define GZ_CHAIN_TOUCH_AHEAD (1 * 1024)    // bytes: how far ahead of the scalar loads the vector unit pulls lines into L2 (measured: 1 KB 40.8 ms/step, 4 KB 42.9, 16 KB 44.9, 64 KB 61 - lines touched too early are gone again by the time they are needed)
-#endif
+#define GZ_CHAIN_R0_LO 0xffe00000u        // the coder's first range, 2^32 - 1, as the double (2^32 - 1) * 2^-7
+#define GZ_CHAIN_R0_HI 0x417fffffu
 
-__device__ static inline uint32_t d_chain_step (uint32_t &range, uint32_t freq, uint32_t mg, uint32_t shw, uint32_t inc)
+// One symbol, any total - the plain formulation (k_chain_expand; in the chain: blocks that hold a total below 256 and the
+// rest of a leaf that does not fill a block). The wave must have called gz_f64_round_toward_zero. Returns r = range / tot.
+__device__ static inline uint32_t d_chain_step (uint32_t &rlo, uint32_t &rhi, uint32_t inv_lo, uint32_t inv_hi, uint32_t freq)
 {
-    const uint32_t r = __umulhi (mg, range + inc) >> (shw & 31);     // range / tot (the hardware masks the count itself)
-    const uint32_t x = r * freq;                                     // >= 256: r >= 2^24 / 65535
-    range = x << (__builtin_clz (x) & 0x18);                         // 0, 1 or 2 bytes (x is never 0)
+    const double t = gz_fma_rtz (__hiloint2double ((int)rhi, (int)rlo), __hiloint2double ((int)inv_hi, (int)inv_lo), 4503599627370496.0);
+    const uint32_t r = (uint32_t)__double2loint (t);             // 2^52 + r: the integer sits in the low word
+    const double x = (double)(r * freq) * 0.0078125;             // r * freq <= range < 2^32 (>= 256: r >= 2^24 / 65535); * 2^-7: exact
+    rlo = (uint32_t)__double2loint (x);
+    rhi = ((uint32_t)__double2hiint (x) & 0x007fffffu) | 0x41000000u;    // 0, 1 or 2 bytes up
     return r;
 }
 
@@ -1040,7 +1049,7 @@ __device__ static inline uint32_t d_chain_step (uint32_t &range, uint32_t freq, 
 // share instruction fetch and issue with nobody - and then follows the model kernels chunk by chunk: `progress` is the
 // number of position chunks whose records are complete (written by k_arith_progress, which the host queues behind every
 // model launch). Records are only ever read after their chunk was announced, and never before by this kernel (the
-// look-ahead stays inside the announced chunks), so no stale copy of them can sit in a cache on the way.
+// block requested ahead stays inside the announced chunks), so no stale copy of them can sit in a cache on the way.
 #define GZ_CHAIN_WAVES 4
 #define GZ_CHAIN_LDS   (156 * 1024)
 
@@ -1059,96 +1068,37 @@ __device__ static inline bool d_wait_progress (const uint32_t *progress, uint32_
     return true;
 }
 
-// positions [p0, p1) of one leaf
-// What leaves the chain is the range BEFORE every 64th symbol (ck[i / 64]) - one scalar store per 64 symbols. The r of every symbol,
-// which the low kernels need, is recomputed from those checkpoints by k_chain_expand (all slices of 64 symbols at once): storing
-// r from here (an s_store_dwordx4 per 4 symbols) cost the chain 12 % - every wait for the next records also waited for the
-// write acknowledgements (scalar loads and stores share one counter): 92.7 -> 81.6 ms for 6.0 M symbols, measured alone.
-__device__ static __forceinline__ void d_chain_chunk (uint32_t &range, uint32_t &sink, uint32_t &touched, int lane, uint32_t p0, uint32_t p1, uint32_t n,
-                                                      uint8_t *triples, uint32_t *ck, uint32_t max_sym)
+// positions [p0, p1) of one leaf (p0 a multiple of 64; p1 one too unless it is the leaf's end)
+// What leaves the chain is the state BEFORE every 64th symbol (8 bytes at ck + 2 * (i / 64)) and the state after the last symbol
+// of the call (the next call's first checkpoint, or the leaf's closing one): one scalar store per 64 symbols.
+__device__ static __forceinline__ void d_chain_chunk (uint32_t &rlo, uint32_t &rhi, uint32_t p0, uint32_t p1, const uint8_t *triples, uint32_t *ck)
 {
-    GzConstRecP rec = (GzConstRecP)(uintptr_t)triples;         // padded: reads up to 64 KB past n stay inside the area
-    // (a GLOBAL pointer: a load through a generic one is a flat load, which also counts as an LDS / scalar operation -
-    //  every wait for the scalar record loads would then wait for the touch's trip to memory as well)
-    const GzGlobalU32P touch = (GzGlobalU32P)(uintptr_t)triples;
-    if (max_sym == 1) {
-        // a stream of zero bytes: the range stays 2^32-1 while the model total is 1 (and 17), which n + inc cannot take
-        for (uint32_t i = p0; i < p1; i++) {
-            if (!lane && !(i & 63)) ck[i >> 6] = range;
-            const gz_u32x4 c = rec[i];
-            const uint32_t r = (uint32_t)(((uint64_t)c[1] * ((uint64_t)range + c[3])) >> 32) >> (c[2] & 31);
-            const uint32_t x = r * c[0];
-            range = x << (__clz (x) & 0x18);
+    GzConstRecP rec = (GzConstRecP)(uintptr_t)triples;
+    const uint32_t whole = p1 & ~63u;
+    uint32_t i = p0;
+    while (i < whole) {
+        const uint32_t left = gz_chain_blocks (rlo, rhi, triples + (size_t)i * 16, (whole - i) >> 6, ck + 2 * (i >> 6));
+        i = whole - (left << 6);
+        if (left) {                                             // a block with a total below 256 (the first occurrences of a context): one symbol at a time
+            for (uint32_t j = 0; j < 64; j++) { const gz_u32x4 c = rec[i + j]; (void)d_chain_step (rlo, rhi, c[0], c[1], c[2]); }
+            i += 64;
         }
-        return;
     }
-    // the first symbol sees range = 2^32-1 and total = max_sym: as a reciprocal for exactly that case,
-    // mulhi (q + 1, 2^32-1) = q
-    const uint32_t q0 = 0xffffffffu / max_sym;
-    // 16 records per iteration as two halves A and B of 8: while one half is being worked on, the loads of the
-    // other are in flight (issued right after an explicit wait, because the compiler would place the wait for the
-    // half it needs AFTER the issue of the next loads and so wait for those too)
-    // A chunk that is not the leaf's last one must not look past its end: those records are being written right now
-    // by the next model chunk. So the main loop (which loads 16 records ahead) stops 16 records early there.
-    const bool last = p1 == n;
-    const uint32_t nb = last ? p1 & ~(uint32_t)(GZ_CHAIN_BLOCK - 1) : p1 - 16;
-    const uint32_t touch_end = last ? 0xffffffffu : p1;                      // (in records)
-    if (nb > p0) {
-        GzConstRec4P rec4 = (GzConstRec4P)(uintptr_t)triples;         // (padded: loads past nb stay inside the area)
-        for (uint32_t b = 0; b < GZ_CHAIN_TOUCH_AHEAD + GZ_CHAIN_TOUCH_PERIOD * 16; b += 4096) sink += touch[(size_t)p0 * 4 + (b >> 2) + lane * 16];   // 64 lanes x 64 B = 4 KB
-        gz_u32x16 a0 = rec4[p0 >> 2], a1 = rec4[(p0 >> 2) + 1];
-        if (!p0) { a0[1] = q0 + 1; a0[2] = 0; a0[3] = 0; }
-        gz_wait_scalar_loads ();
-        // 8 records of buffer (C0, C1) through the chain while the next 8 arrive in (N0, N1); K = which eighth of the 64
-#define GZ_CHAIN_HALF(C0, C1, N0, N1, K) do { \
-            gz_wait_scalar_loads (); \
-            N0 = rec4[(i >> 2) + 2 * (K) + 2]; N1 = rec4[(i >> 2) + 2 * (K) + 3]; \
-            gz_sched_fence (); \
-            (void)d_chain_step (range, C0[0], C0[1], C0[2],  C0[3]);  (void)d_chain_step (range, C0[4],  C0[5],  C0[6],  C0[7]); \
-            (void)d_chain_step (range, C0[8], C0[9], C0[10], C0[11]); (void)d_chain_step (range, C0[12], C0[13], C0[14], C0[15]); \
-            (void)d_chain_step (range, C1[0], C1[1], C1[2],  C1[3]);  (void)d_chain_step (range, C1[4],  C1[5],  C1[6],  C1[7]); \
-            (void)d_chain_step (range, C1[8], C1[9], C1[10], C1[11]); (void)d_chain_step (range, C1[12], C1[13], C1[14], C1[15]); \
-        } while (0)
-        uint32_t i = p0;
-        gz_u32x16 b0, b1;
-        // 64 records per iteration (loop control, address arithmetic and the touch are paid once per 64: every instruction
-        // of this wave is 4 clocks of the step's critical path)
-        for (; i + 64 <= nb; i += 64) {
-            gz_scalar_store1 (ck + (i >> 6), range);                       // (i is a multiple of 64 here: p0 is one of 256)
-            // every 64 records the 64 records that start AHEAD bytes further on, never waited for (gz_touch)
-            if (i + GZ_CHAIN_TOUCH_AHEAD / 16 + GZ_CHAIN_TOUCH_PERIOD <= touch_end)
-                gz_touch (triples + (size_t)i * 16 + GZ_CHAIN_TOUCH_AHEAD + lane * (GZ_CHAIN_TOUCH_PERIOD / 4), touched);
-            GZ_CHAIN_HALF (a0, a1, b0, b1, 0); GZ_CHAIN_HALF (b0, b1, a0, a1, 1); GZ_CHAIN_HALF (a0, a1, b0, b1, 2); GZ_CHAIN_HALF (b0, b1, a0, a1, 3);
-            GZ_CHAIN_HALF (a0, a1, b0, b1, 4); GZ_CHAIN_HALF (b0, b1, a0, a1, 5); GZ_CHAIN_HALF (a0, a1, b0, b1, 6); GZ_CHAIN_HALF (b0, b1, a0, a1, 7);
-        }
-        gz_wait_scalar_loads ();
-        // what is left of the chunk (< 64 records): 8 at a time, (a0, a1) holds the next 8
-        for (; i < nb; i += 8) {
-            if (!(i & 63)) gz_scalar_store1 (ck + (i >> 6), range);
-            GZ_CHAIN_HALF (a0, a1, b0, b1, 0);
-            gz_wait_scalar_loads ();
-            a0 = b0; a1 = b1;
-        }
-#undef GZ_CHAIN_HALF
-        gz_touch_done (touched);
+    if (i < p1) {                                               // the end of the leaf
+        gz_scalar_store2 (ck + 2 * (i >> 6), rlo, rhi);
+        for (; i < p1; i++) { const gz_u32x4 c = rec[i]; (void)d_chain_step (rlo, rhi, c[0], c[1], c[2]); }
     }
-    for (uint32_t i = nb > p0 ? nb : p0; i < p1; i++) {
-        if (!(i & 63)) gz_scalar_store1 (ck + (i >> 6), range);
-        const gz_u32x4 c = rec[i];
-        if (i) (void)d_chain_step (range, c[0], c[1], c[2], c[3]); else (void)d_chain_step (range, c[0], q0 + 1, 0, 0);
-    }
+    gz_scalar_store2 (ck + 2 * ((p1 + 63) >> 6), rlo, rhi);
 }
 
 // progress == NULL: everything is there already, one piece (chunk is ignored)
-// (Tried and measured without effect on the slow-down the chain suffers while other kernels run - ~15 %, with the clock
-//  unchanged -: wave priority, compute-unit masks, a helper wave pulling the records into the scalar cache ahead of
-//  the chain. Dropping the stores of r, tried then with no effect on THAT slow-down, is worth 12 % of the chain itself: d_chain_chunk.)
 __global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress, uint32_t chunk,
                                                                       uint32_t *fail, uint32_t *done, uint32_t n_chunks)
 {
     const uint32_t li = blockIdx.x * GZ_CHAIN_WAVES + (threadIdx.x >> 6);
     if (li >= n_list) return;
     __builtin_amdgcn_s_setprio (3);
+    gz_f64_round_toward_zero ();
     const int lane = threadIdx.x & 63;
     if (progress && !d_wait_progress (progress, 1)) { if (!lane) *fail = 1; return; }   // (the leaf table itself is only final once the models have started)
     GzdLeaf &L = leaves[list[li]];
@@ -1156,16 +1106,16 @@ __global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *l
         if (done && !lane) for (uint32_t k = 0; k < n_chunks; k++) atomicAdd (&done[k], 1u);   // (the low kernels count leaves per chunk)
         return;
     }
-    const uint32_t n = d_uniform (L.arith_n), max_sym = d_uniform (L.max_sym);
-    uint8_t *triples = d_uniform_ptr (L.triples);              // (wave-uniform: keep them in scalar registers)
-    uint32_t *rout = d_uniform_ptr ((uint32_t *)L.ckpt);        // (checkpoints: the range before every 64th symbol)
-    uint32_t sink = 0, touched = 0, range = 0xffffffffu;
-    if (!progress) d_chain_chunk (range, sink, touched, lane, 0, n, n, triples, rout, max_sym);
+    const uint32_t n = d_uniform (L.arith_n);
+    const uint8_t *triples = d_uniform_ptr (L.triples);        // (wave-uniform: keep them in scalar registers)
+    uint32_t *ck = d_uniform_ptr ((uint32_t *)L.ckpt);          // (checkpoints: the state before every 64th symbol, 8 bytes each)
+    uint32_t rlo = GZ_CHAIN_R0_LO, rhi = GZ_CHAIN_R0_HI;
+    if (!progress) d_chain_chunk (rlo, rhi, 0, n, triples, ck);
     else
         for (uint32_t k = 0, p0 = 0; p0 < n; k++, p0 += chunk) {
             if (k && !d_wait_progress (progress, k + 1)) { if (!lane) { L.overflow = 2; *fail = 1; } break; }
-            d_chain_chunk (range, sink, touched, lane, p0, (n - p0 > chunk) ? p0 + chunk : n, n, triples, rout, max_sym);
-            if (done) {                                        // this leaf's r values of chunk k are final: tell the low kernels
+            d_chain_chunk (rlo, rhi, p0, (n - p0 > chunk) ? p0 + chunk : n, triples, ck);
+            if (done) {                                        // this leaf's checkpoints of chunk k are final: tell the low kernels
                 gz_scalar_store_flush ();
                 __threadfence ();
                 if (!lane) {
@@ -1175,7 +1125,6 @@ __global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *l
             }
         }
     gz_scalar_store_flush ();
-    if (!lane) L.touch_sink = sink + touched;
 }
 
 // One thread: holds its stream until all `want` leaves of the persistent chain have finished a position chunk (the low
@@ -1219,9 +1168,10 @@ __device__ static inline GzdLowBlock d_low_block (const GzdLowBlock *blocks, con
     return b;
 }
 
-// r = range / tot of every symbol, from the chain's checkpoints: a lane per 64-symbol slice replays the chain's arithmetic over its
-// slice (the same exact division by multiplication; in 64 bits, which also covers the total of 1 that a stream of one symbol keeps
-// and the first symbol's range of 2^32-1), the wave's 64 x 64 results go through LDS so that they are written row by row.
+// r = range / tot of every symbol, from the chain's checkpoints: a lane per 64-symbol slice replays the recurrence over its
+// slice in the plain formulation (d_chain_step: any total, an ordinary multiply) and must arrive at the chain's NEXT checkpoint -
+// the chain got there through its 24-bit multiply and 64 hops from lane to lane; a slice that does not fails the stream (it never
+// has; the check costs one comparison per 64 symbols). The wave's 64 x 64 results go through LDS so that they are written row by row.
 // Same grid as the low kernels that follow it (one workgroup = 64 slices), 64 threads, 64 * 65 * 4 bytes of LDS.
 __global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const GzdLowBlock *blocks, const uint32_t *list, uint32_t p0)
 {
@@ -1230,22 +1180,21 @@ __global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const Gzd
     if (!L.active || L.engine != GZ_ENG_ARITH) return;
     const uint32_t n = L.arith_n, ns = d_low_nslices (n);
     if (!n || B.first_slice >= ns) return;
+    gz_f64_round_toward_zero ();
     const int lane = threadIdx.x;
     const uint4 *rec = (const uint4 *)L.triples;
     uint32_t *rv = (uint32_t *)L.rvals;
     uint32_t *tile = (uint32_t *)gz_lds;                        // [64 slices][65]
     const uint32_t slice = B.first_slice + lane, i0 = slice * GZ_LOW_SLICE;
     if (slice < ns) {
-        uint32_t range = ((const uint32_t *)L.ckpt)[slice];
-        const uint32_t q0 = 0xffffffffu / (L.max_sym ? L.max_sym : 1u), m = i0 + 64 <= n ? 64 : n - i0;
+        const uint32_t *ck = (const uint32_t *)L.ckpt + 2 * (size_t)slice;
+        uint32_t rlo = ck[0], rhi = ck[1];
+        const uint32_t m = i0 + 64 <= n ? 64 : n - i0;
         for (uint32_t j = 0; j < m; j++) {
-            uint4 c = rec[i0 + j];
-            if (!(i0 + j) && L.max_sym != 1) { c.y = q0 + 1; c.z = 0; c.w = 0; }          // (d_chain_chunk: the first symbol's reciprocal)
-            const uint32_t r = (uint32_t)(((uint64_t)c.y * ((uint64_t)range + c.w)) >> 32) >> (c.z & 31);
-            const uint32_t x = r * c.x;
-            range = x << (__clz (x) & 0x18);
-            tile[lane * 65 + j] = r;
+            const uint4 c = rec[i0 + j];
+            tile[lane * 65 + j] = d_chain_step (rlo, rhi, c.x, c.y, c.z);
         }
+        if (rlo != ck[2] || rhi != ck[3]) L.overflow = 2;
     }
     gz_wave_sync ();
     for (uint32_t s = 0; s < 64; s++) {
@@ -1267,7 +1216,7 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_count (GzdLeaf *leaves, const
         const uint32_t slice = B.first_slice + wave * (GZ_LOW_SLICES_PER_WG / 4) + q;
         if (slice >= ns) break;
         const uint32_t i = slice * GZ_LOW_SLICE + lane;
-        const uint32_t k = i < n ? (uint32_t)__clz (rv[i] * rec[i].x) >> 3 : 0u;
+        const uint32_t k = i < n ? (uint32_t)__clz (rv[i] * rec[i].z) >> 3 : 0u;
         const uint32_t cnt = (uint32_t)__popcll (__ballot (k >= 1)) + (uint32_t)__popcll (__ballot (k == 2));
         if (!lane) ((uint32_t *)L.kpos)[slice] = cnt;
     }
@@ -1335,7 +1284,7 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_scatter (GzdLeaf *leaves, con
         const bool on = slice < ns;                            // (all waves keep hitting the barriers)
         const uint32_t i = slice * GZ_LOW_SLICE + lane;
         uint32_t k = 0, a = 0;
-        if (on && i < n) { const uint4 c = rec[i]; const uint32_t r = rv[i]; k = (uint32_t)__clz (r * c.x) >> 3; a = (c.z >> 8) * r; }
+        if (on && i < n) { const uint4 c = rec[i]; const uint32_t r = rv[i]; k = (uint32_t)__clz (r * c.z) >> 3; a = c.w * r; }
         const uint64_t m1 = __ballot (k >= 1), m2 = __ballot (k == 2);
         const uint32_t P = (uint32_t)__popcll (m1 & below) + (uint32_t)__popcll (m2 & below);   // shifts before me in the slice
         const uint32_t K = (uint32_t)__popcll (m1) + (uint32_t)__popcll (m2);

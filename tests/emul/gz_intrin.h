@@ -25,3 +25,36 @@ static inline void gz_stg_u8 (uint8_t *p, uint32_t v) { *p = (uint8_t)v; }
 static inline void gz_stg_u32 (uint32_t *p, uint32_t v) { *p = v; }
 static inline void gz_stg_u16 (uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
 static inline double gz_rcp_f64 (double x) { return (double)(1.0f / (float)x) * (1.0 - 3e-8); }   // (a SEED of single precision, like v_rcp_f64: the caller's refinement and correction must hold)
+// ---- the range coder chain in double precision (product: rounding mode register + an inline-asm loop over 64-symbol blocks) ----
+#include <fenv.h>
+#include <math.h>
+#include <string.h>
+static inline void gz_f64_round_toward_zero (void) {}
+static inline double gz_fma_rtz (double a, double b, double c)
+{
+    const int was = fegetround (); fesetround (FE_TOWARDZERO);
+    volatile double va = a, vb = b, vc = c; const double r = fma (va, vb, vc);
+    fesetround (was); return r;
+}
+static inline void gz_scalar_store2 (uint32_t *dst, uint32_t a, uint32_t b) { if (emu.cur % 64 == 0) { dst[0] = a; dst[1] = b; } }
+// the same contract as the product's loop, one symbol at a time: records { inv (double), freq, cum }
+static inline uint32_t gz_chain_blocks (uint32_t &rlo, uint32_t &rhi, const uint8_t *recs, uint32_t nblk, uint32_t *ck)
+{
+    for (uint32_t b = 0; b < nblk; b++) {
+        const uint32_t *rec = (const uint32_t *)(recs + (size_t)b * 1024);
+        gz_scalar_store2 (ck + 2 * b, rlo, rhi);
+        for (int j = 0; j < 64; j++) { double inv; memcpy (&inv, rec + 4 * j, 8); if (inv > 0.5) return nblk - b; }
+        for (int j = 0; j < 64; j++) {
+            double inv, R; memcpy (&inv, rec + 4 * j, 8);
+            uint64_t rb = (uint64_t)rlo | (uint64_t)rhi << 32; memcpy (&R, &rb, 8);
+            const double t = gz_fma_rtz (R, inv, 4503599627370496.0);
+            uint64_t tb; memcpy (&tb, &t, 8);
+            const uint32_t P = ((uint32_t)tb & 0xffffffu) * (rec[4 * j + 2] & 0xffffffu);        // (v_mul_u32_u24)
+            const double Pd = (double)P * 0.0078125;
+            uint64_t pb; memcpy (&pb, &Pd, 8);
+            rlo = (uint32_t)pb; rhi = ((uint32_t)(pb >> 32) & 0x007fffffu) | 0x41000000u;
+        }
+    }
+    return 0;
+}
+

@@ -210,6 +210,10 @@ static inline void __threadfence_block (void) {}
 // (the same value in every lane of a wave at the same point of the program, as on the device: the clock only ever picks between ways that
 //  give the same result - k_arith_model's eventful batches)
 static inline long long wall_clock64 (void) { return 0; }
+// doubles by their two words
+static inline double __hiloint2double (int hi, int lo) { uint64_t b = (uint64_t)(uint32_t)hi << 32 | (uint32_t)lo; double d; memcpy (&d, &b, 8); return d; }
+static inline int __double2hiint (double d) { uint64_t b; memcpy (&b, &d, 8); return (int)(uint32_t)(b >> 32); }
+static inline int __double2loint (double d) { uint64_t b; memcpy (&b, &d, 8); return (int)(uint32_t)b; }
 static inline void __threadfence (void) {}
 
 static inline unsigned long long __ballot (int pred)

@@ -1,33 +1,58 @@
-"""The arithmetic coder's chain divides by multiplying (gz_host.cpp builds the table, gz_kernels_arith.h:d_chain_step uses it):
-    range / tot == mulhi (magic, range + inc) >> shift          with a 32-bit magic per divisor.
-This restates the table construction in numpy and checks the identity for every divisor the model total can take, on the
-numerators where a reciprocal scheme breaks first (multiples of the divisor and their neighbours, the top of the
-32-bit range). The product's own table is exercised end to end by the parity tests."""
-import numpy as np
+"""The arithmetic coder's chain divides by multiplying, in double precision with truncation (gz_host.cpp builds the table,
+gz_kernels_arith.h:d_chain_step and the loop of gz_chain_asm.h use it):
+    range / tot == low word of fma (range * 2^-7, inv, 2^52) rounded toward zero,   inv = 2^7 / tot rounded UP to a double
+The fma forms range * 2^-7 * inv exactly, adds 2^52 and truncates to the 53 bits of a double, i.e. to an integer: the result is
+2^52 + floor (range * inv / 2^7) computed without error. This restates the table construction and checks the identity in exact
+integer arithmetic for every divisor the model total can take, on the numerators where a reciprocal scheme breaks first (multiples
+of the divisor and the numbers just below them, up to the top of the 32-bit range). The product's own table and kernels are
+exercised end to end by the parity tests; the renormalisation by exponent bits is checked here as well."""
+import math
+import random
+import struct
+from fractions import Fraction
 
 
-def build(dmax):
-    d = np.arange(1, dmax, dtype=np.uint64)
-    L = np.floor(np.log2(d.astype(np.float64))).astype(np.uint64)
-    L = np.where((np.uint64(1) << L) > d, L - np.uint64(1), L)
-    L = np.where((np.uint64(1) << (L + np.uint64(1))) <= d, L + np.uint64(1), L)
-    pow2 = (d & (d - np.uint64(1))) == 0
-    num = np.uint64(1) << (np.uint64(32) + L)
-    md, e = num // d, num % d
-    up = (d - e) <= (np.uint64(1) << L)
-    magic = np.where(pow2, np.uint64(0xffffffff), np.where(up, md + np.uint64(1), md))
-    inc = np.where(pow2, np.uint64(1), np.where(up, np.uint64(0), np.uint64(1)))
-    return d, magic, L, inc
+def inv_of(d):
+    inv = 128.0 / d
+    if Fraction(inv) * d < 128:                                  # (the host asks fma (inv, d, -128) for the sign)
+        inv = math.nextafter(inv, math.inf)
+    return inv
+
+
+def quotient(n, inv):
+    m, e = math.frexp(inv)                                       # inv = m * 2^e exactly, m * 2^53 an integer
+    M = int(m * (1 << 53))
+    s = 53 - e + 7                                               # n * 2^-7 * inv = n * M / 2^s
+    return (n * M) >> s if s >= 0 else (n * M) << -s
 
 
 def test_reciprocal_is_exact_for_every_model_total():
-    d, magic, shift, inc = build(65536 + 32)
-    assert magic.max() <= 0xffffffff
-    top = np.uint64(0xffffffff)
-    for k in range(0, 400):
-        q = top // d - np.uint64(k % 200)                       # multiples of d near the top ...
-        for n in (q * d, q * d - np.uint64(1), q * d + (d - np.uint64(1)), top - np.uint64(k + 1),
-                  np.uint64(1 << 24) + np.uint64(k) * d, (np.uint64(k) * np.uint64(2654435761)) & top):
-            n = np.minimum(n, top - inc)                        # (range + inc must not wrap: the chain treats range = 2^32-1 itself)
-            got = ((magic * (n + inc)) >> np.uint64(32)) >> shift
-            assert np.array_equal(got, n // d), k
+    rnd = random.Random(1)
+    top = 0xffffffff
+    for d in range(1, 65536 + 32):
+        inv = inv_of(d)
+        assert Fraction(inv) * d >= 128 and Fraction(math.nextafter(inv, 0.0)) * d < 128 or Fraction(inv) * d == 128
+        q = top // d
+        ns = [top, q * d, q * d - 1, (q - 1) * d, (q - 1) * d + d - 1, 1 << 24, ((1 << 24) // d + 1) * d - 1, ((1 << 24) // d + 1) * d]
+        for _ in range(12):
+            k = rnd.randrange((1 << 24) // d + 1, q + 1)
+            ns += [k * d, k * d - 1, min(top, k * d + rnd.randrange(d))]
+        for n in ns:
+            assert quotient(n, inv) == n // d, (d, n)
+
+
+def test_renormalisation_by_exponent_bits():
+    """x * 2^-7 as a double with the high word's exponent forced to 0x410 | (its low 3 bits) == x shifted left by whole bytes until
+    it is >= 2^24 (x >= 2^8), times 2^-7"""
+    rnd = random.Random(2)
+    for _ in range(200000):
+        x = rnd.randrange(1 << rnd.randrange(9, 33))
+        if x < 256:
+            x += 256
+        want = x
+        while want < (1 << 24):
+            want <<= 8
+        bits = struct.unpack("<Q", struct.pack("<d", x / 128.0))[0]
+        hi = ((bits >> 32) & 0x007fffff) | 0x41000000
+        got = struct.unpack("<d", struct.pack("<Q", hi << 32 | (bits & 0xffffffff)))[0]
+        assert got * 128.0 == want, x
