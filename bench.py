@@ -37,6 +37,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")    # (genozip_amd/lib.py: must 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+CHAIN_FLOOR_NS = 10.75          # k_arith_chain's loop alone on the device: 25.8 clocks per symbol at 2.4 GHz (profiles/round4_ubench_chain_f64.txt)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 METRIC = "input MB/s compressed (bit-exact .genozip) at 1/2/4/8 GPUs vs CPU ref"
 
@@ -665,7 +666,9 @@ def main():
     # The critical path. The dominant kernel is launched several times per step on different streams (the persistent launch over the long
     # QUAL streams + the short-leaf launches of trials and section writer): its launches overlap, their sum is NOT time on the step's
     # critical path - the LONGEST launch is. That launch codes the long streams (sections of >= 1 MB); what bounds it is the issue rate
-    # of one wave per stream on the scalar unit (7.6 instructions x 4 clocks per symbol at 2.4 GHz = 12.7 ns), not HBM.
+    # of one wave per stream, not HBM: four dependent vector instructions + the two wait states of the lane hop per symbol = 25.8 clocks
+    # at 2.4 GHz = 10.75 ns, measured with the loop alone on the device (tools/ubench_chain_f64.hip; rounds 1-3: seven scalar integer
+    # instructions, 12.7 ns).
     secs_all = [s for z in z_all for s in walk_sections(z)]
     long_secs = [s for s in secs_all if s[3] >= (1 << 20) and s[1] in (16, 17, 18, 19)]
     longest_ms = prof_max.get(dom, avg_launch_ms)
@@ -674,8 +677,8 @@ def main():
         sym = max(s[3] for s in long_secs)
         bytes_long = sum(s[3] + len(s[4]) for s in long_secs) * wl.calls_per_step
         crit = {"kernel": dom, "longest_launch_ms": round(longest_ms, 3), "streams_in_it": len(long_secs), "symbols_of_longest_stream": sym,
-                "ns_per_symbol": round(longest_ms * 1e6 / sym, 2), "issue_rate_floor_ns_per_symbol": 12.7,
-                "issue_rate_frac": round(12.7 / (longest_ms * 1e6 / sym), 3),
+                "ns_per_symbol": round(longest_ms * 1e6 / sym, 2), "issue_rate_floor_ns_per_symbol": CHAIN_FLOOR_NS,
+                "issue_rate_frac": round(CHAIN_FLOOR_NS / (longest_ms * 1e6 / sym), 3),
                 "alg_bytes_in_it": bytes_long, "hbm_achieved_gbs": round(bytes_long / (longest_ms / 1e3) / 1e9, 3),
                 "hbm_frac": round(bytes_long / (longest_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 6),
                 "share_of_step": round(longest_ms / ms_per_step, 3)}

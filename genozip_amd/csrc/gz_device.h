@@ -103,7 +103,7 @@ struct GzdLeaf {
     uint8_t   *resid;         // arith: per slice: what is left in its 32-bit window (+ carry) after its last shift
     uint32_t  n_events;
     uint32_t  low_base;       // arith: shifts in the position chunks the low kernels have been through
-    uint32_t  touch_sink;     // keeps the L2 prefetch loads of k_arith_chain alive
+    uint32_t  touch_sink;     // k_arith_chain: blocks of 64 symbols that went the slow way (a total below 256 in them) - diagnostics
     uint32_t  pay_cap;
 };
 

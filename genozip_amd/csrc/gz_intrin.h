@@ -121,4 +121,3 @@ __device__ static inline void gz_scalar_store2 (uint32_t *dst, uint32_t a, uint3
     const uint32_t sa = (uint32_t)__builtin_amdgcn_readfirstlane ((int)a), sb = (uint32_t)__builtin_amdgcn_readfirstlane ((int)b);   // (wave-uniform values that live in vector registers)
     asm volatile ("s_store_dwordx2 %0, %1, 0x0" : : "s"((uint64_t)sa | (uint64_t)sb << 32), "s"(dst) : "memory");
 }
-

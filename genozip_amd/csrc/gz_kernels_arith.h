@@ -1071,7 +1071,7 @@ __device__ static inline bool d_wait_progress (const uint32_t *progress, uint32_
 // positions [p0, p1) of one leaf (p0 a multiple of 64; p1 one too unless it is the leaf's end)
 // What leaves the chain is the state BEFORE every 64th symbol (8 bytes at ck + 2 * (i / 64)) and the state after the last symbol
 // of the call (the next call's first checkpoint, or the leaf's closing one): one scalar store per 64 symbols.
-__device__ static __forceinline__ void d_chain_chunk (uint32_t &rlo, uint32_t &rhi, uint32_t p0, uint32_t p1, const uint8_t *triples, uint32_t *ck)
+__device__ static __forceinline__ void d_chain_chunk (uint32_t &rlo, uint32_t &rhi, uint32_t &nslow, int lane, uint32_t p0, uint32_t p1, const uint8_t *triples, uint32_t *ck)
 {
     GzConstRecP rec = (GzConstRecP)(uintptr_t)triples;
     const uint32_t whole = p1 & ~63u;
@@ -1079,9 +1079,10 @@ __device__ static __forceinline__ void d_chain_chunk (uint32_t &rlo, uint32_t &r
     while (i < whole) {
         const uint32_t left = gz_chain_blocks (rlo, rhi, triples + (size_t)i * 16, (whole - i) >> 6, ck + 2 * (i >> 6));
         i = whole - (left << 6);
-        if (left) {                                             // a block with a total below 256 (the first occurrences of a context): one symbol at a time
-            for (uint32_t j = 0; j < 64; j++) { const gz_u32x4 c = rec[i + j]; (void)d_chain_step (rlo, rhi, c[0], c[1], c[2]); }
-            i += 64;
+        if (left) {                                             // a block with a total below 256 (the first occurrences of a context): one symbol at a time,
+            const uint4 mine = ((const uint4 *)triples)[i + lane]; // the records fetched by the lanes (one trip to memory, not 64)
+            for (int j = 0; j < 64; j++) (void)d_chain_step (rlo, rhi, d_readlane (mine.x, j), d_readlane (mine.y, j), d_readlane (mine.z, j));
+            i += 64; nslow++;
         }
     }
     if (i < p1) {                                               // the end of the leaf
@@ -1092,8 +1093,8 @@ __device__ static __forceinline__ void d_chain_chunk (uint32_t &rlo, uint32_t &r
 }
 
 // progress == NULL: everything is there already, one piece (chunk is ignored)
-__global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress, uint32_t chunk,
-                                                                      uint32_t *fail, uint32_t *done, uint32_t n_chunks)
+__device__ static __forceinline__ void d_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress, uint32_t chunk,
+                                                      uint32_t *fail, uint32_t *done, uint32_t n_chunks)
 {
     const uint32_t li = blockIdx.x * GZ_CHAIN_WAVES + (threadIdx.x >> 6);
     if (li >= n_list) return;
@@ -1109,12 +1110,12 @@ __global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *l
     const uint32_t n = d_uniform (L.arith_n);
     const uint8_t *triples = d_uniform_ptr (L.triples);        // (wave-uniform: keep them in scalar registers)
     uint32_t *ck = d_uniform_ptr ((uint32_t *)L.ckpt);          // (checkpoints: the state before every 64th symbol, 8 bytes each)
-    uint32_t rlo = GZ_CHAIN_R0_LO, rhi = GZ_CHAIN_R0_HI;
-    if (!progress) d_chain_chunk (rlo, rhi, 0, n, triples, ck);
+    uint32_t rlo = GZ_CHAIN_R0_LO, rhi = GZ_CHAIN_R0_HI, nslow = 0;
+    if (!progress) d_chain_chunk (rlo, rhi, nslow, lane, 0, n, triples, ck);
     else
         for (uint32_t k = 0, p0 = 0; p0 < n; k++, p0 += chunk) {
             if (k && !d_wait_progress (progress, k + 1)) { if (!lane) { L.overflow = 2; *fail = 1; } break; }
-            d_chain_chunk (rlo, rhi, p0, (n - p0 > chunk) ? p0 + chunk : n, triples, ck);
+            d_chain_chunk (rlo, rhi, nslow, lane, p0, (n - p0 > chunk) ? p0 + chunk : n, triples, ck);
             if (done) {                                        // this leaf's checkpoints of chunk k are final: tell the low kernels
                 gz_scalar_store_flush ();
                 __threadfence ();
@@ -1125,6 +1126,13 @@ __global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *l
             }
         }
     gz_scalar_store_flush ();
+    if (!lane) L.touch_sink = nslow;                           // (diagnostics: blocks that went the slow way)
+}
+
+__global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress, uint32_t chunk,
+                                                                      uint32_t *fail, uint32_t *done, uint32_t n_chunks)
+{
+    d_arith_chain (leaves, list, n_list, progress, chunk, fail, done, n_chunks);
 }
 
 // One thread: holds its stream until all `want` leaves of the persistent chain have finished a position chunk (the low

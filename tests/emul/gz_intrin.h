@@ -57,4 +57,3 @@ static inline uint32_t gz_chain_blocks (uint32_t &rlo, uint32_t &rhi, const uint
     }
     return 0;
 }
-
