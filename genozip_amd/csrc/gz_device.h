@@ -84,7 +84,7 @@ struct GzdLeaf {
     uint8_t   *tab;           // serialised frequency table
     uint8_t   *pay;           // entropy-coded payload area (rANS fills it from the end)
     uint32_t  *models;        // arith (run-length variant): global-memory models when they do not fit the LDS
-    uint8_t   *triples;       // arith: 16 bytes per coded byte: freq, division magic, shift | cum << 8, inc  (k_arith_model -> k_arith_chain)
+    uint8_t   *triples;       // arith: 16 bytes per coded byte: 2^7 / tot as a double, freq, cum  (k_arith_model -> k_arith_chain, k_chain_expand)
     uint32_t  *spos;          // arith order-1: positions grouped by context (the byte before), stream order inside a context
     uint8_t   *srk;           // arith order-1: static rank of the symbol at spos[j]
     uint32_t  *ctxoff;        // arith order-1: [tile][context] -> index into spos/srk of the first occurrence at or after the tile
@@ -97,8 +97,9 @@ struct GzdLeaf {
     uint32_t   pres[8];       // which byte values occur in the leaf's source bytes (k_presence, many workgroups; k_leaf_prep is one)
     uint64_t  *succ;          // arith, order 1, leaves that span position chunks: 256 rows x 4 words - which symbols (leaf ranks) follow each context byte anywhere in the leaf
     uint8_t   *events;        // arith: one 32-bit digit per output byte (k_low_replay / k_low_norm)
-    uint8_t   *rvals;         // arith: r = range / tot of every symbol (k_chain_expand -> k_low_*)
-    uint8_t   *ckpt;          // arith: the range before every 64th symbol (k_arith_chain -> k_chain_expand)
+    uint8_t   *rvals;         // arith: a = cum * r of every symbol, what it adds to low (k_chain_expand -> k_low_scatter)
+    uint8_t   *kbits;         // arith: per 64-symbol slice 16 bytes: two bits per symbol, the bytes low moves up after it (k_chain_expand -> k_low_scatter)
+    uint8_t   *ckpt;          // arith: the chain's state (range * 2^-7 as a double) before every 64th symbol and after the last (k_arith_chain -> k_chain_expand)
     uint8_t   *kpos;          // arith: per 64-symbol slice: shifts in it, then (k_low_scan) shifts before it
     uint8_t   *resid;         // arith: per slice: what is left in its 32-bit window (+ carry) after its last shift
     uint32_t  n_events;

@@ -451,6 +451,7 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
         if (!(L.rvals   = (uint8_t *)arena_alloc (h, ((size_t)nb + 64) * 4))) return false;
         const uint32_t ns = nb ? (nb + GZ_LOW_SLICE - 1) / GZ_LOW_SLICE : 1;
         if (!(L.kpos    = (uint8_t *)arena_alloc (h, ((size_t)ns + 2) * 4))) return false;
+        if (!(L.kbits   = (uint8_t *)arena_alloc (h, ((size_t)ns + 2) * 16))) return false;
         if (!(L.ckpt    = (uint8_t *)arena_alloc (h, ((size_t)ns + 2) * 8))) return false;
         if (!(L.resid   = (uint8_t *)arena_alloc (h, ((size_t)ns + 1) * 16))) return false;
         for (uint32_t s0 = 0; s0 < ns; s0 += GZ_LOW_SLICES_PER_WG) { GzdLowBlock b; b.leaf = (uint32_t)P.leaves.size (); b.first_slice = s0; P.low_blocks.push_back (b); }
@@ -732,7 +733,6 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                                 d_leaves, A.d_small, A.nsmall, (const uint32_t *)NULL, 0u, h->d_fail, (uint32_t *)NULL, 0u);
                     if (A.nlb_small) {
                         KLAUNCH_ON (h, h->stream5, k_chain_expand, dim3 (A.nlb_small), dim3 (64), 64 * 65 * 4, d_leaves, A.d_lb_small, (const uint32_t *)NULL, 0u);
-                        KLAUNCH_ON (h, h->stream5, k_low_count, dim3 (A.nlb_small), dim3 (GZ_LOW_WG), GZ_KEEP_OFF_LDS, d_leaves, A.d_lb_small, (const uint32_t *)NULL, 0u);
                         KLAUNCH_ON (h, h->stream5, k_low_scan, dim3 (A.nsmall), dim3 (1024), 8192, d_leaves, A.d_small, 0u, 0xffffffffu);
                         KLAUNCH_ON (h, h->stream5, k_low_scatter, dim3 (A.nlb_small), dim3 (GZ_LOW_WG), GZ_KEEP_OFF_LDS, d_leaves, A.d_lb_small, (const uint32_t *)NULL, 0u);
                     }
@@ -747,7 +747,6 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                     const uint32_t wgs = (span + GZ_LOW_SLICE * GZ_LOW_SLICES_PER_WG - 1) / (GZ_LOW_SLICE * GZ_LOW_SLICES_PER_WG);
                     hipLaunchKernelGGL (k_low_gate, dim3 (1), dim3 (1), 0, h->stream6, (const uint32_t *)(A.d_progress + 16 + k), A.nbig, h->d_fail);
                     KLAUNCH_ON (h, h->stream6, k_chain_expand, dim3 (A.nbig, wgs), dim3 (64), 64 * 65 * 4, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0);
-                    KLAUNCH_ON (h, h->stream6, k_low_count, dim3 (A.nbig, wgs), dim3 (GZ_LOW_WG), GZ_KEEP_OFF_LDS, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0);
                     KLAUNCH_ON (h, h->stream6, k_low_scan, dim3 (A.nbig), dim3 (1024), 8192, d_leaves, A.d_big, p0, A.chunk);
                     KLAUNCH_ON (h, h->stream6, k_low_scatter, dim3 (A.nbig, wgs), dim3 (GZ_LOW_WG), GZ_KEEP_OFF_LDS, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0);
                 }
@@ -757,7 +756,6 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
             }
             if (!A.pipelined) {
                 KLAUNCH (h, k_chain_expand, dim3 (A.nlb), dim3 (64), 64 * 65 * 4, d_leaves, A.d_lb, (const uint32_t *)NULL, 0u);
-                KLAUNCH (h, k_low_count, dim3 (A.nlb), dim3 (GZ_LOW_WG), 0, d_leaves, A.d_lb, (const uint32_t *)NULL, 0u);
                 KLAUNCH (h, k_low_scan, dim3 (A.np), dim3 (1024), 8192, d_leaves, A.d_plain, 0u, 0xffffffffu);
                 KLAUNCH (h, k_low_scatter, dim3 (A.nlb), dim3 (GZ_LOW_WG), 4 * 144 * 4, d_leaves, A.d_lb, (const uint32_t *)NULL, 0u);
             }

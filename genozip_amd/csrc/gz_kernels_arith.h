@@ -1018,7 +1018,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
 //                  checkpoint: the two check each other on every 64 symbols of every stream.
 //   k_low_*        all threads: every thread replays low += cum * r for its own slice of 64 symbols from low = 0,
 //                  emitting the byte that leaves the 32-bit window at every shift (plus the carry out of the window as
-//                  a 9th bit) at its absolute output position (k_low_count / k_low_scan: a prefix sum of the k's;
+//                  a 9th bit) at its absolute output position (k_chain_expand / k_low_scan: a prefix sum of the k's;
 //                  k_low_scatter), k_low_resid adds what is left in each window where the following slices' bytes
 //                  go, and k_low_norm normalises the digits: carries ripple left inside a tile and, very rarely, across.
 //                  The first three follow the chain chunk by chunk (k_low_gate), the last two run once at the end.
@@ -1032,13 +1032,15 @@ typedef const volatile __attribute__((address_space(4))) gz_u32x4 *GzConstRecP; 
 
 // One symbol, any total - the plain formulation (k_chain_expand; in the chain: blocks that hold a total below 256 and the
 // rest of a leaf that does not fill a block). The wave must have called gz_f64_round_toward_zero. Returns r = range / tot.
-__device__ static inline uint32_t d_chain_step (uint32_t &rlo, uint32_t &rhi, uint32_t inv_lo, uint32_t inv_hi, uint32_t freq)
+__device__ static inline uint32_t d_chain_step (uint32_t &rlo, uint32_t &rhi, uint32_t inv_lo, uint32_t inv_hi, uint32_t freq, uint32_t *shift_bytes = NULL)
 {
     const double t = gz_fma_rtz (__hiloint2double ((int)rhi, (int)rlo), __hiloint2double ((int)inv_hi, (int)inv_lo), 4503599627370496.0);
     const uint32_t r = (uint32_t)__double2loint (t);             // 2^52 + r: the integer sits in the low word
-    const double x = (double)(r * freq) * 0.0078125;             // r * freq <= range < 2^32 (>= 256: r >= 2^24 / 65535); * 2^-7: exact
+    const uint32_t rf = r * freq;                                // <= range < 2^32 (>= 256: r >= 2^24 / 65535)
+    const double x = (double)rf * 0.0078125;                     // * 2^-7: exact
     rlo = (uint32_t)__double2loint (x);
     rhi = ((uint32_t)__double2hiint (x) & 0x007fffffu) | 0x41000000u;    // 0, 1 or 2 bytes up
+    if (shift_bytes) *shift_bytes = (uint32_t)__clz (rf) >> 3;  // how many
     return r;
 }
 
@@ -1150,7 +1152,7 @@ __global__ void k_low_gate (const uint32_t *done, uint32_t want, uint32_t *fail)
 // Symbol i adds a_i = cum_i * r_i into the 32-bit window of `low` after P_i bytes have left it (P = prefix sum of the
 // per-symbol shift counts k_i = clz(r_i * freq_i) / 8). In the output stream (byte 0 = the coder's initial cache byte)
 // that is: the four bytes of a_i are added at bytes P_i+1 .. P_i+4. Nothing else happens to low, so the whole thing is
-//   k_low_count    one wave per 64-symbol slice (lane = symbol, coalesced): shifts in the slice = two ballots
+//   k_chain_expand (above) a = cum * r and the shift count k of every symbol, the shifts per slice
 //   k_low_scan     per leaf: exclusive prefix over the slices; m = total + 5 closing shifts
 //   k_low_scatter  one wave per slice: P_i inside the slice again from two ballots; the lanes add their four bytes into
 //                  a small LDS accumulator; the digits the slice owns are stored, the (up to 4) that spill into the
@@ -1176,10 +1178,14 @@ __device__ static inline GzdLowBlock d_low_block (const GzdLowBlock *blocks, con
     return b;
 }
 
-// r = range / tot of every symbol, from the chain's checkpoints: a lane per 64-symbol slice replays the recurrence over its
+// What the low kernels need of every symbol, from the chain's checkpoints: a lane per 64-symbol slice replays the recurrence over its
 // slice in the plain formulation (d_chain_step: any total, an ordinary multiply) and must arrive at the chain's NEXT checkpoint -
 // the chain got there through its 24-bit multiply and 64 hops from lane to lane; a slice that does not fails the stream (it never
-// has; the check costs one comparison per 64 symbols). The wave's 64 x 64 results go through LDS so that they are written row by row.
+// has; the check costs one comparison per 64 symbols). Per symbol: a = cum * r, what it adds to low (the wave's 64 x 64 values go
+// through LDS so that they are written row by row), and k = the bytes low and range move up after it - two bits, the slice's 64 of
+// them are 16 bytes written by its lane, and their sum is the slice's entry in the prefix sum of output positions (k_low_scan).
+// (Until round 4 this kernel wrote r, and k_low_count / k_low_scatter each read every symbol's 16-byte record again for freq and cum:
+// 60 bytes of traffic per symbol between the three, now 25.)
 // Same grid as the low kernels that follow it (one workgroup = 64 slices), 64 threads, 64 * 65 * 4 bytes of LDS.
 __global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const GzdLowBlock *blocks, const uint32_t *list, uint32_t p0)
 {
@@ -1187,46 +1193,32 @@ __global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const Gzd
     GzdLeaf &L = leaves[B.leaf];
     if (!L.active || L.engine != GZ_ENG_ARITH) return;
     const uint32_t n = L.arith_n, ns = d_low_nslices (n);
-    if (!n || B.first_slice >= ns) return;
+    if (B.first_slice >= ns) return;
     gz_f64_round_toward_zero ();
     const int lane = threadIdx.x;
     const uint4 *rec = (const uint4 *)L.triples;
-    uint32_t *rv = (uint32_t *)L.rvals;
+    uint32_t *av = (uint32_t *)L.rvals;
     uint32_t *tile = (uint32_t *)gz_lds;                        // [64 slices][65]
     const uint32_t slice = B.first_slice + lane, i0 = slice * GZ_LOW_SLICE;
     if (slice < ns) {
         const uint32_t *ck = (const uint32_t *)L.ckpt + 2 * (size_t)slice;
-        uint32_t rlo = ck[0], rhi = ck[1];
-        const uint32_t m = i0 + 64 <= n ? 64 : n - i0;
+        uint32_t rlo = ck[0], rhi = ck[1], kb[4] = { 0, 0, 0, 0 }, ksum = 0;
+        const uint32_t m = i0 >= n ? 0u : (i0 + 64 <= n ? 64u : n - i0);      // (an empty leaf has one empty slice)
         for (uint32_t j = 0; j < m; j++) {
             const uint4 c = rec[i0 + j];
-            tile[lane * 65 + j] = d_chain_step (rlo, rhi, c.x, c.y, c.z);
+            uint32_t k;
+            const uint32_t r = d_chain_step (rlo, rhi, c.x, c.y, c.z, &k);
+            tile[lane * 65 + j] = c.w * r;
+            kb[j >> 4] |= k << (2 * (j & 15)); ksum += k;
         }
-        if (rlo != ck[2] || rhi != ck[3]) L.overflow = 2;
+        if (m && (rlo != ck[2] || rhi != ck[3])) L.overflow = 2;
+        ((uint32_t *)L.kpos)[slice] = ksum;
+        ((uint4 *)L.kbits)[slice] = make_uint4 (kb[0], kb[1], kb[2], kb[3]);
     }
     gz_wave_sync ();
     for (uint32_t s = 0; s < 64; s++) {
         const uint32_t i = (B.first_slice + s) * GZ_LOW_SLICE + lane;
-        if (B.first_slice + s < ns && i < n) rv[i] = tile[s * 65 + lane];
-    }
-}
-
-__global__ void __launch_bounds__(GZ_LOW_WG) k_low_count (GzdLeaf *leaves, const GzdLowBlock *blocks, const uint32_t *list, uint32_t p0)
-{
-    const GzdLowBlock B = d_low_block (blocks, list, p0);
-    GzdLeaf &L = leaves[B.leaf];
-    if (!L.active || L.engine != GZ_ENG_ARITH) return;
-    const uint32_t n = L.arith_n, ns = d_low_nslices (n);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint4 *rec = (const uint4 *)L.triples;
-    const uint32_t *rv = (const uint32_t *)L.rvals;
-    for (uint32_t q = 0; q < GZ_LOW_SLICES_PER_WG / 4; q++) {
-        const uint32_t slice = B.first_slice + wave * (GZ_LOW_SLICES_PER_WG / 4) + q;
-        if (slice >= ns) break;
-        const uint32_t i = slice * GZ_LOW_SLICE + lane;
-        const uint32_t k = i < n ? (uint32_t)__clz (rv[i] * rec[i].z) >> 3 : 0u;
-        const uint32_t cnt = (uint32_t)__popcll (__ballot (k >= 1)) + (uint32_t)__popcll (__ballot (k == 2));
-        if (!lane) ((uint32_t *)L.kpos)[slice] = cnt;
+        if (B.first_slice + s < ns && i < n) av[i] = tile[s * 65 + lane];
     }
 }
 
@@ -1275,8 +1267,7 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_scatter (GzdLeaf *leaves, con
     if (!L.active || L.engine != GZ_ENG_ARITH) return;
     const uint32_t n = L.arith_n, ns = d_low_nslices (n);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint4 *rec = (const uint4 *)L.triples;
-    const uint32_t *rv = (const uint32_t *)L.rvals;
+    const uint32_t *av = (const uint32_t *)L.rvals, *kbits = (const uint32_t *)L.kbits;
     const uint32_t *kpos = (const uint32_t *)L.kpos;
     uint32_t *dig = (uint32_t *)L.events;
     uint32_t *acc = (uint32_t *)gz_lds + wave * 144;          // up to 128 own digits + 5 closing / 4 spilling
@@ -1292,7 +1283,7 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_scatter (GzdLeaf *leaves, con
         const bool on = slice < ns;                            // (all waves keep hitting the barriers)
         const uint32_t i = slice * GZ_LOW_SLICE + lane;
         uint32_t k = 0, a = 0;
-        if (on && i < n) { const uint4 c = rec[i]; const uint32_t r = rv[i]; k = (uint32_t)__clz (r * c.z) >> 3; a = c.w * r; }
+        if (on && i < n) { a = av[i]; k = (kbits[slice * 4 + (lane >> 4)] >> (2 * (lane & 15))) & 3u; }
         const uint64_t m1 = __ballot (k >= 1), m2 = __ballot (k == 2);
         const uint32_t P = (uint32_t)__popcll (m1 & below) + (uint32_t)__popcll (m2 & below);   // shifts before me in the slice
         const uint32_t K = (uint32_t)__popcll (m1) + (uint32_t)__popcll (m2);
