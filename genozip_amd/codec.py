@@ -121,6 +121,46 @@ class ZipFile:
 
     __del__ = close
 
+    def set_host_codecs(self, trial=None, compress=None, clock_ns_per_byte=None, mode=0):
+        """gz_zip_set_host_codecs: the host's candidates of codec_assign_best_codec (BZ2 3 / LZMA 4 / BSC 5).
+        trial (dict_id bytes, is_local, sample bytes) -> [(codec, payload size, clock_us)]; compress (codec, data bytes) -> payload bytes"""
+        from .lib import GzHostCodecs, GZ_HOST_TRIAL_FN, GZ_HOST_COMPRESS_FN
+        if trial is None:
+            self.E._check(self.E.L.gz_zip_set_host_codecs(self.f, None), "gz_zip_set_host_codecs")
+            self._hostc = None
+            return
+
+        def c_trial(user, dict_id, is_local, sample, n, rows, max_rows):
+            try:
+                got = trial(bytes(dict_id[:8]), int(is_local), bytes(sample[:n]))[:max_rows]
+                for i, (c, sz, ck) in enumerate(got):
+                    rows[i].codec, rows[i].size, rows[i].clock_us = int(c), float(sz), float(ck)
+                return len(got)
+            except Exception:                                   # (an exception must not cross the C frames)
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        def c_compress(user, codec, data, n, out, out_len):
+            try:
+                pay = compress(int(codec), bytes(data[:n]))
+                if len(pay) > out_len[0]:
+                    return 1
+                C.memmove(out, pay, len(pay))
+                out_len[0] = len(pay)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 2
+
+        hc = GzHostCodecs()
+        hc.trial, hc.compress, hc.user, hc.mode = GZ_HOST_TRIAL_FN(c_trial), GZ_HOST_COMPRESS_FN(c_compress), None, mode
+        clk = (C.c_float * 32)(*clock_ns_per_byte) if clock_ns_per_byte is not None else None
+        hc.clock_ns_per_byte = C.cast(clk, C.POINTER(C.c_float)) if clk is not None else None
+        self._hostc = (hc, clk)                                  # (the callbacks must outlive the file's use of them)
+        self.E._check(self.E.L.gz_zip_set_host_codecs(self.f, C.byref(hc)), "gz_zip_set_host_codecs")
+
     def vb_table(self, vbs):
         """vbs: list of (text_off, text_len, vblock_i, r1 index or -1[, flags: GZ_VB_LAST_OF_FILE = 1])"""
         from .lib import GzFastqVB
@@ -470,6 +510,24 @@ class Engine:
         sizes = (C.c_uint32 * 9)()
         c = self._check(self.L.gz_codec_assign_best(self.h, self.mem.ptr(buf), len(data), sizes), "gz_codec_assign_best")
         return c, list(sizes)
+
+    def assign_sort(self, tests, mode=0):
+        """gz_codec_assign_sort: tests = [(codec, size, clock_us)] in trial order -> (winner, sorted list). Host only."""
+        from .lib import GzCodecTest
+        n = len(tests)
+        tab = (GzCodecTest * max(1, n))(*[GzCodecTest(int(c), float(sz), float(ck)) for c, sz, ck in tests])
+        w = self._check(self.L.gz_codec_assign_sort(tab, n, mode), "gz_codec_assign_sort")
+        return w, [(t.codec, t.size, t.clock_us) for t in tab[:n]]
+
+    def assign_best_ex(self, data, extra=(), clock_ns_per_byte=None, mode=0):
+        """gz_codec_assign_best_ex: the nine device candidates + the caller's rows [(codec, framed size, clock_us)] -> (codec, sorted table)"""
+        from .lib import GzCodecTest
+        buf = self.mem.upload(data)
+        ex = (GzCodecTest * max(1, len(extra)))(*[GzCodecTest(int(c), float(sz), float(ck)) for c, sz, ck in extra])
+        out = (GzCodecTest * (9 + len(extra)))()
+        clk = (C.c_float * 32)(*clock_ns_per_byte) if clock_ns_per_byte is not None else None
+        c = self._check(self.L.gz_codec_assign_best_ex(self.h, self.mem.ptr(buf), len(data), ex, len(extra), clk, mode, out), "gz_codec_assign_best_ex")
+        return c, [(t.codec, t.size, t.clock_us) for t in out] if c else []
 
     # ---- context engine -------------------------------------------------------------------------------------
     def b250_generate_many(self, jobs, r1=None):

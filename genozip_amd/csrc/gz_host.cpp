@@ -12,6 +12,7 @@
 #include <math.h>
 #include <atomic>
 #include <vector>
+#include <algorithm>
 #include <map>
 #include <chrono>
 #include <string>
@@ -851,7 +852,8 @@ extern "C" int gz_vb_compress_batch (GzHandle *h, GzVBlock *vbs, int n_vbs)
             GzdStream S;
             memset (&S, 0, sizeof (S));
             int codec = sec.codec ? sec.codec : GZ_CODEC_RANB;            // zfile.c:300,337
-            if (!codec_ok (codec)) { h->err = "unsupported codec in section"; return GZ_ERR_ARG; }
+            // (BZ2 / LZMA / BSC: only as payloads the host's coder has made - the section is framed here)
+            if (!codec_ok (codec) && !(sec.precompressed && (codec == GZ_CODEC_BZ2 || codec == GZ_CODEC_LZMA || codec == GZ_CODEC_BSC))) { h->err = "unsupported codec in section"; return GZ_ERR_ARG; }
             S.in = sec.data; S.in_len = sec.data_len; S.in_len_dev = sec.data_len_dev;
             S.codec_req = codec; S.vb = v; S.sec_in_vb = k; S.status = GZ_ST_PENDING;
             S.out_cap = 0xffffffffu;
@@ -1163,6 +1165,80 @@ extern "C" int gz_codec_assign_best (GzHandle *h, const uint8_t *in, uint32_t in
         if (size < best_size) { best_size = size; best = cand[i + 1]; }
     }
     return best;
+}
+
+// codec_assign_sorter (src/codec.c:128-173), restated: < 0 when a goes first
+static int gz_assign_cmp (const GzCodecTest &a, const GzCodecTest &b, int mode)
+{
+    if (mode == GZ_ASSIGN_FAST) {                                      // much faster at a modest cost in size
+        if (a.clock_us < b.clock_us * 0.80f && a.size < b.size * 1.3f) return -1;
+        if (b.clock_us < a.clock_us * 0.80f && b.size < a.size * 1.3f) return 1;
+    }
+    if (mode == GZ_ASSIGN_BEST || (a.clock_us <= 5000 && b.clock_us <= 5000)) {     // both fast enough: size, then time
+        if (a.size != b.size) return a.size < b.size ? -1 : 1;
+        return a.clock_us < b.clock_us ? -1 : a.clock_us > b.clock_us ? 1 : 0;
+    }
+    if (a.size < 100 && b.size < 100 && a.clock_us != b.clock_us) return a.clock_us < b.clock_us ? -1 : 1;   // both tiny: the faster
+    static const float level[5][2] = { { 0.96f, 0.20f }, { 0.97f, 0.33f }, { 0.98f, 0.50f }, { 0.985f, 0.67f }, { 0.99f, 0.85f } };
+    for (int l = 0; l < 5; l++) {
+        if (a.size < b.size * level[l][0]) return -1;                  // significantly smaller
+        if (b.size < a.size * level[l][0]) return 1;
+        if (a.clock_us < b.clock_us * level[l][1]) return -1;          // similar size: significantly faster
+        if (b.clock_us < a.clock_us * level[l][1]) return 1;
+    }
+    if (a.size == b.size) return a.codec < b.codec ? -1 : a.codec > b.codec ? 1 : 0;     // the lower codec id (the form without PACK)
+    return a.size < b.size ? -1 : 1;
+}
+
+// qsort (tests, n, ..., codec_assign_sorter) (src/codec.c:338) as the C library of the reference's Linux builds runs it: glibc's
+// qsort is a top-down merge sort for arrays this small (halves of n / 2 and n - n / 2 elements, the left element first unless the
+// comparator says it is larger). The comparator is not a strict order - the outcome depends on the algorithm, so it is stated.
+static void gz_assign_msort (GzCodecTest *b, int n, GzCodecTest *tmp, int mode)
+{
+    if (n <= 1) return;
+    const int n1 = n / 2, n2 = n - n1;
+    gz_assign_msort (b, n1, tmp, mode); gz_assign_msort (b + n1, n2, tmp, mode);
+    int i = 0, j = n1, k = 0;
+    while (i < n1 && j < n) tmp[k++] = gz_assign_cmp (b[i], b[j], mode) <= 0 ? b[i++] : b[j++];
+    while (i < n1) tmp[k++] = b[i++];
+    for (int x = 0; x < k; x++) b[x] = tmp[x];                          // (what is left of the right half is in place already)
+}
+
+extern "C" int gz_codec_assign_sort (GzCodecTest *tests, int n, int mode)
+{
+    if (!tests || n <= 0 || mode < 0 || mode > 2) return GZ_ERR_ARG;
+    std::vector<GzCodecTest> tmp (n);
+    gz_assign_msort (tests, n, tmp.data (), mode);
+    return tests[0].codec;
+}
+
+// the rows of the nine device candidates from their trial results (payload lengths), in the reference's order, + the caller's; sorted
+static int gz_assign_pick (uint32_t sample, const uint32_t payload[8], const GzCodecTest *extra, int n_extra, const float *ns_per_byte, int mode, GzCodecTest *tests_out)
+{
+    static const int cand[9] = { GZ_CODEC_NONE, GZ_CODEC_RANB, GZ_CODEC_RANW, GZ_CODEC_RANb, GZ_CODEC_RANw,
+                                 GZ_CODEC_ARTB, GZ_CODEC_ARTW, GZ_CODEC_ARTb, GZ_CODEC_ARTw };
+    std::vector<GzCodecTest> t (9 + (n_extra > 0 ? n_extra : 0));
+    for (int i = 0; i < 9; i++) {
+        t[i].codec = cand[i];
+        t[i].size = i ? (float)(payload[i - 1] + 28) : (float)sample;   // framed (codec.c:328-331); NONE: the bare length (:324)
+        t[i].clock_us = i && ns_per_byte ? (float)sample * ns_per_byte[cand[i]] / 1000.0f : 0.0f;
+    }
+    for (int i = 0; i < n_extra; i++) t[9 + i] = extra[i];
+    const int codec = gz_codec_assign_sort (t.data (), (int)t.size (), mode);
+    if (tests_out) memcpy (tests_out, t.data (), t.size () * sizeof (GzCodecTest));
+    return codec;
+}
+
+extern "C" int gz_codec_assign_best_ex (GzHandle *h, const uint8_t *in, uint32_t in_len, const GzCodecTest *extra, int n_extra,
+                                        const float *clock_ns_per_byte, int mode, GzCodecTest *tests_out)
+{
+    if (n_extra < 0 || (n_extra && !extra) || mode < 0 || mode > 2) return GZ_ERR_ARG;
+    uint32_t sizes[9];
+    const int rc = gz_codec_assign_best (h, in, in_len, sizes);
+    if (rc < 0 || rc == GZ_CODEC_UNKNOWN) return rc;
+    uint32_t payload[8];
+    for (int i = 0; i < 8; i++) payload[i] = sizes[i + 1] - 28;
+    return gz_assign_pick (sizes[0], payload, extra, n_extra, clock_ns_per_byte, mode, tests_out);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -149,7 +149,19 @@ struct GzZipFile {
                   uint8_t *pinned = NULL; size_t pinned_size = 0; ZipCall call; bool busy = false; } other;
     bool busy = false, other_made = false;
     GzHandle *h_user = NULL;                             // the handle the file was opened on (owns the profile of all of them)
+    // a8 in full: the host's candidates (BZ2 / BSC / LZMA) and the reference's sorter (gz_zip_set_host_codecs)
+    GzHostCodecs hostc = { NULL, NULL, NULL, NULL, 0 };
+    std::vector<float> hostc_clock;
 };
+
+extern "C" int gz_zip_set_host_codecs (GzZipFile *f, const GzHostCodecs *hc)
+{
+    if (!f || (hc && (hc->mode < 0 || hc->mode > 2))) return GZ_ERR_ARG;
+    if (!hc) { f->hostc = GzHostCodecs { NULL, NULL, NULL, NULL, 0 }; f->hostc_clock.clear (); return GZ_OK; }
+    f->hostc = *hc;
+    if (hc->clock_ns_per_byte) { f->hostc_clock.assign (hc->clock_ns_per_byte, hc->clock_ns_per_byte + 32); f->hostc.clock_ns_per_byte = f->hostc_clock.data (); }
+    return GZ_OK;
+}
 
 static void zip_swap_lanes (GzZipFile *f)
 {
@@ -412,8 +424,30 @@ static uint32_t zip_piz_put (uint8_t *d, int64_t wi)
     return 4;
 }
 
-// codec_assign_best_codec (codec.c:234-363, rule of SURVEY A.8) for several streams in ONE batch of trial compressions
-static int zip_assign_best_many (GzHandle *h, GzZipFile *f, const std::vector<const uint8_t *> &ptr, const std::vector<uint32_t> &len, std::vector<int> &best)
+static inline bool zip_is_host_codec (int c) { return c == GZ_CODEC_BZ2 || c == GZ_CODEC_LZMA || c == GZ_CODEC_BSC; }
+
+// The winner among the nine device candidates (payload sizes of their trials on the sample at `in`) and, if the file has them, the
+// host's: the reference's sorter (gz_assign_pick). Without host candidates and clocks this is "the smallest framed size, the first
+// of equals"  - the device trials all count as fast enough (codec.c:140-143).
+static int zip_pick_codec (GzHandle *h, GzZipFile *f, const uint8_t dict_id[8], int is_local, const uint8_t *in, uint32_t sample, const uint32_t payload[8], int *codec)
+{
+    GzCodecTest extra[8]; int n_extra = 0;
+    if (f->hostc.trial) {
+        std::vector<uint8_t> host (sample);
+        HIPCHK (h, hipMemcpy (host.data (), in, sample, hipMemcpyDeviceToHost));
+        n_extra = f->hostc.trial (f->hostc.user, dict_id, is_local, host.data (), sample, extra, 8);
+        if (n_extra < 0 || n_extra > 8) { h->err = "host codec trial"; return GZ_ERR; }
+        for (int i = 0; i < n_extra; i++) {
+            if (!zip_is_host_codec (extra[i].codec)) { h->err = "host codec trial: not a host codec"; return GZ_ERR_ARG; }
+            extra[i].size += 28;                                                         // framed (codec.c:328-331)
+        }
+    }
+    *codec = gz_assign_pick (sample, payload, extra, n_extra, f->hostc.clock_ns_per_byte, f->hostc.mode, NULL);
+    return GZ_OK;
+}
+
+// codec_assign_best_codec (codec.c:234-363) for several streams in ONE batch of trial compressions; who[i] = whose stream i is
+static int zip_assign_best_many (GzHandle *h, GzZipFile *f, const std::vector<const uint8_t *> &ptr, const std::vector<uint32_t> &len, const std::vector<ZipVote> &who, std::vector<int> &best)
 {
     static const int cand[8] = { GZ_CODEC_RANB, GZ_CODEC_RANW, GZ_CODEC_RANb, GZ_CODEC_RANw, GZ_CODEC_ARTB, GZ_CODEC_ARTW, GZ_CODEC_ARTb, GZ_CODEC_ARTw };
     const size_t n = ptr.size ();
@@ -436,14 +470,9 @@ static int zip_assign_best_many (GzHandle *h, GzZipFile *f, const std::vector<co
     if ((rc = gz_sync (h)) < 0) return rc;
     for (size_t k = 0; k < S.size (); k += 8) {
         const size_t i = owner[k];
-        uint32_t best_size = len[i] < 99999 ? len[i] : 99999;                            // NONE: the bare length (codec.c:324)
-        int b = GZ_CODEC_NONE;
-        for (int c = 0; c < 8; c++) {
-            if (S[k + c].status != GZ_OK) return GZ_ERR;
-            const uint32_t size = S[k + c].out_len + 28;                                 // framed (codec.c:328-331)
-            if (size < best_size) { best_size = size; b = cand[c]; }
-        }
-        best[i] = b;
+        uint32_t payload[8];
+        for (int c = 0; c < 8; c++) { if (S[k + c].status != GZ_OK) return GZ_ERR; payload[c] = S[k + c].out_len; }
+        if ((rc = zip_pick_codec (h, f, f->ctxs[who[i].ctx].dict_id, (int)(who[i].is_local & 1), ptr[i], len[i] < 99999 ? len[i] : 99999, payload, &best[i])) != GZ_OK) return rc;
     }
     return GZ_OK;
 }
@@ -776,7 +805,8 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     std::vector<uint32_t> trial_ctx; std::vector<int> trial_domq;
     const bool own_first = vbs[0].vblock_i == f->next_vblock_i ();   // (vblock_i are consecutive over the processes: this one opens the call)
     bool want_trial = false;
-    if (f->h2 && own_first && f->qual_ctx >= 0 && vbs[0].n_reads && zip_vb_commits (f->plan, vbs[0])) { GzZctxView zv; gz_zctx_view (f->zctx[f->qual_ctx], &zv); want_trial = !zv.lcodec; }
+    // (with the host's candidates in the race QUAL is tested in the merge phase like every other context: its trial needs the host's rows)
+    if (f->h2 && !f->hostc.trial && own_first && f->qual_ctx >= 0 && vbs[0].n_reads && zip_vb_commits (f->plan, vbs[0])) { GzZctxView zv; gz_zctx_view (f->zctx[f->qual_ctx], &zv); want_trial = !zv.lcodec; }
     // Speculation. The handle remembers which coder the QUAL stream of its previous file ended up with. If it does, the long streams
     // are handed to the coders with THAT codec as soon as they are gathered, and this file's own trial - which decides, as always -
     // runs afterwards on the main handle, while the host merges: 4-5 ms of trial compressions no longer sit in front of the long
@@ -944,9 +974,10 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     const char *early_env = getenv ("GZ_ZIP_EARLY_MIN");
     const uint64_t early_min = early_env ? strtoull (early_env, NULL, 10) : 1500000ull;
     bool early_worth = longest >= early_min || spec_always;
+    { GzZctxView zq; if (f->qual_ctx >= 0) { gz_zctx_view (f->zctx[f->qual_ctx], &zq); if (f->hostc.trial && (!zq.lcodec || zip_is_host_codec (zq.lcodec))) early_worth = false; } }   // (nothing to code ahead on the device)
     if (!early_worth && f->h2 && NV && qmode >= 0 && f->qual_ctx >= 0) {
         GzZctxView zv; gz_zctx_view (f->zctx[f->qual_ctx], &zv);
-        if (zv.lcodec) early_worth = true;                 // (the file knows its codec: nothing to wait for, the streams may as well start now)
+        if (zv.lcodec && !zip_is_host_codec (zv.lcodec)) early_worth = true;                 // (the file knows its codec: nothing to wait for, the streams may as well start now)
     }
     if (!early_worth) { may_spec = false; K.spec_trial.clear (); }
     if (may_spec) {                                        // now that the lengths are known: is it worth it?
@@ -1452,7 +1483,7 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
                             ptr.push_back (p); len.push_back (L); who.push_back ({ c, is_local | 4u | (zip_vb_commits (f->plan, vbs[v]) ? 0u : 2u), vbs[v].vblock_i, 0 });
                         }
             std::vector<int> best;
-            if ((rc = zip_assign_best_many (h, f, ptr, len, best)) != GZ_OK) return rc;
+            if ((rc = zip_assign_best_many (h, f, ptr, len, who, best)) != GZ_OK) return rc;
             for (size_t k = 0; k < who.size (); k++) if (best[k]) { who[k].codec = (uint32_t)best[k]; K.votes.push_back (who[k]); }
         }
     }
@@ -1581,6 +1612,25 @@ static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint
                 const bool int_lt = (Z.ltype >= GZ_LT_INT8 && Z.ltype <= GZ_LT_UINT64) || (Z.ltype >= GZ_LT_UINT8_TR && Z.ltype <= GZ_LT_UINT32_TR);   // lt_max (ltype) != 0
                 if (int_lt) s.b250_size_or_nothing_char = X.nothing_char ? X.nothing_char : 0xff;    // zfile.c:344-345
                 if (is_r1 && X.pair_identical) s.flags |= PAIRED;                                     // zfile.c:323-325
+            }
+            if (zip_is_host_codec (s.codec) && !s.precompressed) {
+                // a codec of the host's (a8: its candidate won the context): the stream goes to the host, its coder's payload comes back
+                // and is framed with the rest. Under 50 bytes a simple codec's section is stored (compressor.c:56-58)
+                if (!f->hostc.compress) { h->err = "a context has a host codec (BZ2 / LZMA / BSC) and the file no host coder: gz_zip_set_host_codecs"; return GZ_ERR_ARG; }
+                uint32_t L = s.data_len;
+                if (s.data_len_dev) { HIPCHK (h, hipMemcpyAsync (&L, s.data_len_dev, 4, hipMemcpyDeviceToHost, h->stream)); HIPCHK (h, hipStreamSynchronize (h->stream)); }
+                s.data_len = L; s.data_len_dev = NULL;
+                if (L < 50 && !s.hdr_codec) s.codec = GZ_CODEC_NONE;
+                else {
+                    std::vector<uint8_t> raw (L), pay ((size_t)L + L / 2 + 65536);
+                    HIPCHK (h, hipMemcpyAsync (raw.data (), s.data, L, hipMemcpyDeviceToHost, h->stream)); HIPCHK (h, hipStreamSynchronize (h->stream));
+                    uint32_t pl = (uint32_t)pay.size ();
+                    if (f->hostc.compress (f->hostc.user, s.codec, raw.data (), L, pay.data (), &pl) != 0 || pl > pay.size ()) { h->err = "host codec: compress failed"; return GZ_ERR; }
+                    uint8_t *d = (uint8_t *)ws_alloc (f, (size_t)pl + 64);
+                    if (!d) return GZ_ERR_HIP;
+                    HIPCHK (h, hipMemcpyAsync (d, pay.data (), pl, hipMemcpyHostToDevice, h->stream)); HIPCHK (h, hipStreamSynchronize (h->stream));
+                    s.precompressed = 1; s.raw_len = L; s.data = d; s.data_len = pl;
+                }
             }
             secs[v].push_back (s);
         }

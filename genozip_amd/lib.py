@@ -148,6 +148,19 @@ GZ_FQ_CONST, GZ_FQ_ITEM_TEXT, GZ_FQ_ITEM_INT, GZ_FQ_ITEM_DELTA, GZ_FQ_SEQ, GZ_FQ
 # every symbol include/genozip_amd.h declares (checked by tests/test_abi.py)
 GzGetLineCB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32))
 
+class GzCodecTest(C.Structure):
+    """CodecTest (src/codec.c:122-126): one candidate's trial"""
+    _fields_ = [("codec", C.c_int32), ("size", C.c_float), ("clock_us", C.c_float)]
+
+
+GZ_HOST_TRIAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(GzCodecTest), C.c_int)
+GZ_HOST_COMPRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32))
+
+
+class GzHostCodecs(C.Structure):
+    _fields_ = [("trial", GZ_HOST_TRIAL_FN), ("compress", GZ_HOST_COMPRESS_FN), ("user", C.c_void_p), ("clock_ns_per_byte", C.POINTER(C.c_float)), ("mode", C.c_int)]
+
+
 ABI_SYMBOLS = (
     "gz_create", "gz_create_background", "gz_destroy", "gz_sync", "gz_last_error", "gz_version", "gz_stream", "gz_profile", "gz_profile_get", "gz_profile_get_max",
     "gz_download", "gz_upload", "gz_dev_alloc", "gz_dev_free", "gz_emit_after", "gz_wait_for",
@@ -167,6 +180,7 @@ ABI_SYMBOLS = (
     "gz_zfile_add_txt_header", "gz_zfile_add_txt_header_text", "gz_zfile_set_fastq", "gz_vb_insert_section",
     "gz_tokenize_column_n", "gz_int_columns", "gz_local_generate_batch", "gz_acgt_pack_batch",
     "gz_bam_records", "gz_bam_to_sam",
+    "gz_codec_assign_sort", "gz_codec_assign_best_ex", "gz_zip_set_host_codecs",
 )
 
 
@@ -270,6 +284,9 @@ def load(path=None):
     L.gz_zfile_write_global_area.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64,
                                              C.c_char_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.gz_codec_assign_best_host.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
+    L.gz_codec_assign_sort.argtypes = [C.POINTER(GzCodecTest), C.c_int, C.c_int]
+    L.gz_codec_assign_best_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(GzCodecTest), C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(GzCodecTest)]
+    L.gz_zip_set_host_codecs.argtypes = [C.c_void_p, C.POINTER(GzHostCodecs)]
     L.gz_zfile_add_txt_header.argtypes = [C.c_void_p, C.c_uint8, C.c_uint8, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint64, C.c_char_p]
     L.gz_zfile_add_txt_header_text.argtypes = [C.c_void_p, C.c_uint8, C.c_uint8, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint64,
                                                C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]

@@ -137,6 +137,28 @@ int gz_codec_uncompress_batch (GzHandle *h, GzStream *streams, int n_streams);
  * sizes_out (host, 9 entries: NONE,RANB,RANW,RANb,RANw,ARTB,ARTW,ARTb,ARTw) may be NULL. Synchronous. */
 int gz_codec_assign_best (GzHandle *h, const uint8_t *in, uint32_t in_len, uint32_t *sizes_out);
 
+/* codec_assign_best_codec in full. The reference tries TWELVE candidates on the sample - NONE, the eight htscodecs forms, BZ2, BSC,
+ * LZMA (src/codec.c:286-295) - measures size (framed: + the 28-byte header, :328-331; NONE: the bare sample, :324) and the CPU time
+ * of every trial (clock(), :322-334), and sorts them with codec_assign_sorter (:128-173): the smaller size when both took <= 5 ms
+ * (or --best), otherwise a five-level trade-off of size against time, exact ties to the lower codec id. The first of the sorted
+ * table is the context's codec. BZ2 / BSC / LZMA are sequential LZ / BWT coders that stay on the host: their trials
+ * come from the caller (GzCodecTest rows it fills from its own codec_bz2_compress / codec_bsc_compress / codec_lzma_compress,
+ * sizes framed), the nine others run here. */
+typedef struct { int32_t codec; float size; float clock_us; } GzCodecTest;         /* CodecTest, src/codec.c:122-126 */
+enum { GZ_ASSIGN_NORMAL = 0, GZ_ASSIGN_BEST = 1, GZ_ASSIGN_FAST = 2 };              /* flag.best / flag.fast                  */
+enum { GZ_CODEC_BZ2 = 3, GZ_CODEC_LZMA = 4, GZ_CODEC_BSC = 5 };                      /* src/genozip.h:325-360                  */
+/* The sorter: tests[0..n) in the order the reference tries them (:286-289) -> sorted in place, returns tests[0].codec. The
+ * reference's comparator is not a strict order, so what qsort makes of it depends on the C library: this is glibc's top-down
+ * merge sort, what the reference's Linux builds run. */
+int gz_codec_assign_sort (GzCodecTest *tests, int n, int mode);
+/* The nine device candidates on the first min (in_len, 99 999) bytes of `in` (device) + the caller's `extra` rows, sorted.
+ * clock_ns_per_byte (32 entries, by codec id): NULL - every device trial counts as "fast enough" (<= 5 ms: what the reference sees for samples of 100 KB on
+ * any current CPU except with ARTW / ARTw on wide alphabets), so that among the device candidates the smaller size wins and the
+ * result does not depend on a clock; or a table by codec id of nominal costs from which clock_us = sample x cost / 1000 is made.
+ * tests_out: 9 + n_extra rows, sorted (may be NULL). Returns the codec, GZ_CODEC_UNKNOWN under 50 bytes (:311-312). Synchronous. */
+int gz_codec_assign_best_ex (GzHandle *h, const uint8_t *in, uint32_t in_len, const GzCodecTest *extra, int n_extra,
+                             const float *clock_ns_per_byte, int mode, GzCodecTest *tests_out);
+
 /* ---- context engine pieces -------------------------------------------------------------------------------- */
 
 /* b250_zip_generate (src/b250.c:202-267): seg-format b250 (little-endian VARL, tag in last byte; nodes new to the
@@ -546,6 +568,21 @@ typedef struct {
 #define GZ_VB_LAST_OF_FILE 1u     /* vb->is_last_vb_in_txt_file (src/codec.c:361; only looked at with vb_1_not_representative)         */
 typedef struct GzZipFile GzZipFile;   /* z_file for this path: the file-level contexts and committed codecs */
 GzZipFile *gz_zip_open (GzHandle *h, const GzFastqPlan *plan);
+/* The host's candidates in the driver's codec assignment (a8 in full, see gz_codec_assign_best_ex). With these set, every trial the
+ * driver makes (the first VBlock with >= 50 bytes of a context's stream, VBlock 10's second look ...) hands the SAME sample to
+ * `trial` (host memory), which appends rows for the candidates it ran - codec id, PAYLOAD size (the 28-byte header is added here),
+ * clock_us - and returns how many; a context whose winner is one of them has its sections compressed by `compress` (host in, host
+ * out, *out_len in: capacity, out: payload bytes; return 0 on success) and framed like any other. Both run on the calling thread.
+ * mode / clock_ns_per_byte as in gz_codec_assign_best_ex. NULL: back to the device candidates alone. While host candidates are set
+ * the QUAL streams are not coded ahead of the merge (their trial needs the host's rows). */
+typedef struct {
+    int  (*trial) (void *user, const uint8_t dict_id[8], int is_local, const uint8_t *sample, uint32_t sample_len, GzCodecTest *rows, int max_rows);
+    int  (*compress) (void *user, int codec, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t *out_len);
+    void  *user;
+    const float *clock_ns_per_byte;
+    int    mode;
+} GzHostCodecs;
+int gz_zip_set_host_codecs (GzZipFile *f, const GzHostCodecs *hc);
 void       gz_zip_close (GzZipFile *f);
 /* text: device, text_len bytes, with at least 16 writable bytes of slack behind them (a SNIP_LOOKUP byte is parked there);
  * < 4 GB per call. Synchronous (three waits inside: line index, seg results for the merge, z lengths). */
@@ -670,7 +707,7 @@ int gz_vb_insert_section (const uint8_t *z, uint64_t z_len, uint32_t index, cons
 enum { GZ_CODEC_DOMQ = 13, GZ_LT_CODEC_ = 13 };
 /* codecs that only ever appear in section headers of this path: CODEC_ACGT (NONREF: the host's sub-codec makes the payload), CODEC_XCGT
  * (NONREF_X: the name of the section, its stream coded by the sub-codec), LZMA (src/genozip.h:325-360) */
-enum { GZ_CODEC_LZMA = 4, GZ_CODEC_ACGT = 10, GZ_CODEC_XCGT = 11 };
+enum { GZ_CODEC_ACGT = 10, GZ_CODEC_XCGT = 11 };                  /* (GZ_CODEC_LZMA = 4: with the host codecs above) */
 typedef struct {
     uint64_t qual_len, runs_len, mplx_len, divr_len;
     uint32_t num_doms, num_norm_qs, has_diverse, all_diverse;   /* all_diverse: QUAL is the single byte 'X', sub-codec NONE (:490-494) */

@@ -1383,6 +1383,67 @@ long gzo_section_compress (const GzoCtxSectionDesc *d, const uint8_t *data, uint
     return (long)GZO_CTX_SECTION_HEADER_LEN + clen;
 }
 
+/* A section whose payload was made elsewhere (a host codec's: BZ2 / LZMA / BSC): header + payload, like comp_compress leaves it
+ * (compressor.c:114-133,161). d->codec names the coder (or d->sub_codec under a complex codec's name, as above) */
+long gzo_section_frame (const GzoCtxSectionDesc *d, const uint8_t *payload, uint32_t payload_len, uint32_t raw_len, uint8_t *z, uint64_t z_cap)
+{
+    if (z_cap < (uint64_t)GZO_CTX_SECTION_HEADER_LEN + payload_len) return -1;
+    uint8_t *h = z;
+    memset (h, 0, GZO_CTX_SECTION_HEADER_LEN);
+    memcpy (z + GZO_CTX_SECTION_HEADER_LEN, payload, payload_len);
+    be32 (h + 0,  GZO_MAGIC);
+    be32 (h + 4,  gzo_adler32 (1, payload, payload_len));
+    be32 (h + 12, payload_len);
+    be32 (h + 16, raw_len);
+    be32 (h + 20, d->vblock_i);
+    h[24] = d->section_type; h[25] = (uint8_t)d->codec; h[26] = d->sub_codec; h[27] = d->flags;
+    h[28] = d->ltype; h[29] = d->param; h[30] = d->b250_size_or_nothing_char;
+    memcpy (h + 32, d->dict_id, 8);
+    return (long)GZO_CTX_SECTION_HEADER_LEN + payload_len;
+}
+
+/* codec_assign_sorter (codec.c:128-173) and the qsort around it (:338), as glibc runs it for a dozen elements: merge sort, halves
+ * of n / 2 and n - n / 2, the left element first unless the comparator calls it larger. mode 0 normal, 1 --best, 2 --fast */
+static int o_assign_before (const GzoCodecTest *x, const GzoCodecTest *y, int mode)   /* > 0: y goes first */
+{
+    if (mode == 2) {
+        if (x->clock < y->clock * 0.80f && x->size < y->size * 1.3f) return -1;
+        if (y->clock < x->clock * 0.80f && y->size < x->size * 1.3f) return 1;
+    }
+    if (mode == 1 || (x->clock <= 5000 && y->clock <= 5000)) {
+        if (x->size != y->size) return x->size < y->size ? -1 : 1;
+        return (x->clock > y->clock) - (x->clock < y->clock);
+    }
+    if (x->size < 100 && y->size < 100 && x->clock != y->clock) return (x->clock > y->clock) - (x->clock < y->clock);
+    static const float sz[5] = { 0.96f, 0.97f, 0.98f, 0.985f, 0.99f }, tm[5] = { 0.20f, 0.33f, 0.50f, 0.67f, 0.85f };
+    for (int l = 0; l < 5; l++) {
+        if (x->size < y->size * sz[l]) return -1;
+        if (y->size < x->size * sz[l]) return 1;
+        if (x->clock < y->clock * tm[l]) return -1;
+        if (y->clock < x->clock * tm[l]) return 1;
+    }
+    if (x->size == y->size) return (x->codec > y->codec) - (x->codec < y->codec);
+    return x->size < y->size ? -1 : 1;
+}
+static void o_assign_sort (GzoCodecTest *t, int n, int mode)
+{
+    if (n < 2) return;
+    int nl = n / 2;
+    o_assign_sort (t, nl, mode); o_assign_sort (t + nl, n - nl, mode);
+    GzoCodecTest m[64];
+    int a = 0, b = nl, k = 0;
+    while (a < nl && b < n) { if (o_assign_before (t + a, t + b, mode) > 0) m[k++] = t[b++]; else m[k++] = t[a++]; }
+    while (a < nl) m[k++] = t[a++];
+    while (b < n) m[k++] = t[b++];
+    memcpy (t, m, (size_t)n * sizeof (GzoCodecTest));
+}
+int gzo_assign_sort (GzoCodecTest *t, int n, int mode)
+{
+    if (!t || n < 1 || n > 64) return -1;
+    o_assign_sort (t, n, mode);
+    return t[0].codec;
+}
+
 void gzo_vb_header_write (uint8_t *z, uint32_t vblock_i, uint32_t recon_size, uint32_t longest_line_len,
                           uint32_t longest_seq_len, const uint8_t digest[16], uint8_t flags) /* zfile.c:1108-1134 */
 {

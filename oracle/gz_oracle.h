@@ -244,6 +244,12 @@ int  gzo_domq_is_fit (const uint8_t *text, const uint32_t *off, const uint32_t *
 int  gzo_domq_encode (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n_lines, GzoDomq *out);   /* -1: a byte outside ' '..'~' */
 void gzo_domq_free (GzoDomq *o);
 
+/* ---- a8 in full: the sorter of the twelve candidates' trials (src/codec.c:122-173,338) and a section around a payload made by a
+ * codec that is not restated here (the host's BZ2 / LZMA / BSC) */
+typedef struct { int32_t codec; float size; float clock; } GzoCodecTest;
+int  gzo_assign_sort (GzoCodecTest *tests, int n, int mode);       /* sorted in place, returns tests[0].codec; n <= 64 */
+long gzo_section_frame (const GzoCtxSectionDesc *d, const uint8_t *payload, uint32_t payload_len, uint32_t raw_len, uint8_t *z, uint64_t z_cap);
+
 #ifdef __cplusplus
 }
 #endif

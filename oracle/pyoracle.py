@@ -53,7 +53,7 @@ class Oracle:
             build(ref=False)
         L = self.L = ctypes.CDLL(path)
         for n in ("gzo_rans_compress", "gzo_arith_compress", "gzo_rans_uncompress", "gzo_arith_uncompress",
-                  "gzo_b250_generate", "gzo_b250_piz_decode", "gzo_section_compress"):
+                  "gzo_b250_generate", "gzo_b250_piz_decode", "gzo_section_compress", "gzo_section_frame"):
             getattr(L, n).restype = ctypes.c_long
         L.gzo_last_shift_ratio.restype = ctypes.c_double
         for n in ("gzo_rans_bound", "gzo_arith_bound", "gzo_codec_est_size", "gzo_adler32", "gzo_b250_seg_put",
@@ -352,6 +352,34 @@ class Oracle:
         data = bytes(data)
         return self.L.gzo_adler32(start, data, len(data))
 
+    def assign_sort(self, tests, mode=0):
+        """gzo_assign_sort: [(codec, size, clock)] in trial order -> (winner, sorted)"""
+        n = len(tests)
+        tab = (GzoCodecTest * max(1, n))(*[GzoCodecTest(int(c), float(sz), float(ck)) for c, sz, ck in tests])
+        w = self.L.gzo_assign_sort(tab, n, mode)
+        if w < 0:
+            raise RuntimeError("oracle assign_sort failed")
+        return w, [(t.codec, t.size, t.clock) for t in tab[:n]]
+
+    def assign_best_with(self, data, rows=(), clock_ns_per_byte=None, mode=0):
+        """codec_assign_best_codec over the nine restated candidates + rows [(codec, PAYLOAD size, clock_us)] of the host's (a8 in full)"""
+        c0, sizes = self.assign_best(data)
+        if not c0:
+            return 0
+        cand = (1, 6, 7, 8, 9, 16, 17, 18, 19)
+        sample = min(len(data), 99999)
+        tests = [(cd, sizes[i], (sample * clock_ns_per_byte[cd] / 1000.0) if (i and clock_ns_per_byte is not None) else 0.0) for i, cd in enumerate(cand)]
+        tests += [(c, sz + 28, ck) for c, sz, ck in rows]
+        return self.assign_sort(tests, mode)[0]
+
+    def section_frame(self, desc, payload, raw_len):
+        payload = bytes(payload)
+        z = ctypes.create_string_buffer(40 + len(payload) + 8)
+        n = self.L.gzo_section_frame(ctypes.byref(desc), payload, len(payload), raw_len, z, ctypes.c_uint64(len(z)))
+        if n < 0:
+            raise RuntimeError("oracle section_frame failed")
+        return z.raw[:n]
+
     def section_compress(self, desc, data):
         data = bytes(data)
         cap = 40 + self.est_size((desc.sub_codec or 1) if desc.codec in (13, 11) else desc.codec, len(data)) + 64 + len(data)
@@ -360,6 +388,10 @@ class Oracle:
         if n < 0:
             raise RuntimeError("oracle section_compress failed")
         return z.raw[:n]
+
+
+class GzoCodecTest(ctypes.Structure):
+    _fields_ = [("codec", ctypes.c_int32), ("size", ctypes.c_float), ("clock", ctypes.c_float)]
 
 
 class GzoDomq(ctypes.Structure):

@@ -627,7 +627,7 @@ def _section_order_ref(ctxs, vblock_i):
     return out
 
 
-def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
+def fastq_zip_expected(oracle, plan, text, vbs, zstate=None, host=None):
     """what gz_fastq_zip_vblocks must produce for these VBlocks: every step with the oracle's per-column / per-section
     functions, VBlock by VBlock. zstate carries the file-level contexts and codecs from call to call.
     -> (list of dict(z, seq_packed, n_bases, seq_has_x), zstate)"""
@@ -823,6 +823,13 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
     # VBlock ("don't let tiny VBs set the codec for everyone"); else nothing (-> RANB in the header, zfile.c:300,337)
     vb_size = plan.get("vb_size", 0)
     vcodec = {}                                            # (VBlock, context, is_local) -> codec
+
+    def pick(data, X, is_local):
+        """codec_assign_best_codec's choice on this stream; with the host's candidates (a8 in full): their rows join the sorter's table"""
+        if host is None:
+            return oracle.assign_best(data)[0]
+        rows = host["trial"](bytes(X["dict_id"]), is_local, bytes(data[:99999])) if len(data) >= 50 else []
+        return oracle.assign_best_with(data, rows, host.get("clock"), host.get("mode", 0))
     nr_bits = plan.get("vb_1_not_representative", 0)       # codec.c:199-209: bit 0 fields, bit 1 DTYPE_1, bit 2 DTYPE_2 (dict_id.h:15-17)
     for c, X in enumerate(C):
         t = X["dict_id"][0] >> 6
@@ -837,7 +844,7 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
                 sets = not vb_size or ln > min(4 << 20, vb_size // 2)
                 if vi == 10 and nr and not hard:           # RETEST_VB_I (codec.c:22,274-277): a second look, whatever the file has
                     if testable:
-                        vcodec[(v, c, is_local)] = oracle.assign_best(data)[0]
+                        vcodec[(v, c, is_local)] = pick(data, X, is_local)
                         if sets:
                             zstate[key][c] = vcodec[(v, c, is_local)]
                     else:                                  # (too short to test: NONE for this section, the file keeps what it has)
@@ -845,7 +852,7 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
                 elif zstate[key][c]:
                     vcodec[(v, c, is_local)] = zstate[key][c]
                 elif testable:
-                    vcodec[(v, c, is_local)] = oracle.assign_best(data)[0]
+                    vcodec[(v, c, is_local)] = pick(data, X, is_local)
                     # (VBlock 1 does not set the LOCAL codec of a context whose beginning may not be representative, unless it is the
                     #  file's last: codec.c:358-362)
                     if sets and (not is_local or vi > nr or vb_flags[v] & 1):
@@ -891,7 +898,13 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None):
                     d.codec, d.sub_codec = 11, vcodec[(v, c, 1)] or 1
                 data = st["local"]
             d.dict_id[:] = list(X["dict_id"])
-            z += oracle.section_compress(d, data)
+            coder = d.sub_codec if d.codec in (13, 11) else d.codec
+            if coder in (3, 4, 5) and (len(data) >= 50 or d.codec in (13, 11)):     # the host's coder made the payload (under 50 bytes a simple codec's section is stored)
+                z += oracle.section_frame(d, host["compress"](coder, bytes(data)), len(data))
+            else:
+                if coder in (3, 4, 5):
+                    d.codec = 1
+                z += oracle.section_compress(d, data)
             n_written += 1
         rec_len = [int(lo[RL * (r + 1)] if r + 1 < b else off + ln) - int(lo[RL * r]) for r in range(a, b)]
         z[:84] = _vb_header(vi, ln, len(z), max(rec_len) if rec_len else 0, int(sl[a:b].max()) if b > a else 0)
@@ -987,6 +1000,84 @@ def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0
     F.close()
     qc = next(i for i, c in enumerate(plan["ctxs"]) if c["tag"] == "QUAL")
     return dict(qual_lcodec=zstate["lcodec"][qc], qual_mode=zstate["qual_mode"], speculation=spec)
+
+
+def host_codecs_for_tests(clock_bz2=300.0, clock_lzma=9000.0):
+    """stand-ins for the reference's host coders in the a8 tests: BZ2 = bzip2 -9, LZMA = an .lzma stream; what matters to the path
+    is who wins and that the payload is framed as it came"""
+    import bz2
+    import lzma
+
+    def compress(codec, data):
+        return bz2.compress(data, 9) if codec == 3 else lzma.compress(data, format=lzma.FORMAT_ALONE, preset=5)
+
+    def trial(dict_id, is_local, sample):
+        return [(3, len(compress(3, sample)), clock_bz2), (4, len(compress(4, sample)), clock_lzma)]
+    return dict(trial=trial, compress=compress, clock=None, mode=0)
+
+
+def assign_sort(E, oracle, rounds=4000, seed=5):
+    """gz_codec_assign_sort == the oracle's restatement of codec_assign_sorter + qsort (codec.c:128-173,338) on random tables of the
+    twelve candidates (sizes and clocks around every threshold of the comparator), in all three modes; and what the comparator says
+    in cases worked out by hand"""
+    rnd = np.random.default_rng(seed)
+    cand = [1, 6, 7, 8, 9, 16, 17, 18, 19, 3, 5, 4]
+    for r in range(rounds):
+        n = int(rnd.integers(2, 13))
+        base = float(rnd.choice([60, 90, 5000, 40000]))
+        tests = []
+        for c in cand[:n]:
+            size = float(int(base * rnd.choice([1.0, 0.995, 0.99, 0.985, 0.975, 0.965, 0.95, 0.7, 1.3, 1.31])))
+            clock = float(int(rnd.choice([0, 100, 900, 4999, 5000, 5001, 8000, 20000, 100000]) * rnd.choice([1.0, 0.19, 0.34, 0.66, 0.8, 0.86])))
+            tests.append((c, size, clock))
+        for mode in (0, 1, 2):
+            assert E.assign_sort(tests, mode) == oracle.assign_sort(tests, mode), (r, mode, tests)
+    # by hand (normal mode): both under 5 ms -> the smaller, whatever the time; equal sizes -> the faster, then the first
+    assert E.assign_sort([(6, 1000, 4000), (16, 999, 4999)])[0] == 16
+    assert E.assign_sort([(6, 1000, 10), (7, 1000, 5)])[0] == 7
+    assert E.assign_sort([(1, 1000, 0), (6, 1000, 0), (16, 1000, 0)])[0] == 1
+    # one of them slow: 4 % smaller wins however slow; 1.2 % smaller does not against a coder 5 x faster, but does against one 1.1 x faster
+    assert E.assign_sort([(6, 1000, 1000), (4, 950, 90000)])[0] == 4
+    assert E.assign_sort([(6, 1000, 1000), (3, 988, 6000)])[0] == 6
+    assert E.assign_sort([(16, 1000, 5500), (3, 988, 6000)])[0] == 3
+    # both tiny: the faster; --best: the smaller whatever it costs; --fast: 20 % faster at up to 30 % more bytes
+    assert E.assign_sort([(6, 90, 6000), (3, 80, 7000)])[0] == 6
+    assert E.assign_sort([(6, 1000, 10), (4, 999, 900000)], 1)[0] == 4
+    assert E.assign_sort([(6, 1290, 700), (16, 1000, 1000)], 2)[0] == 6
+
+
+def fastq_zip_host_codecs(E, oracle, n_reads=900):
+    """a8 with all twelve candidates inside the driver: the host's BZ2 / LZMA rows (gz_zip_set_host_codecs) join every trial, a
+    context they win has its sections coded by the host's coder and framed with the rest == the oracle's composition with the same
+    candidates. The quality lines repeat (a coder with a memory wins QUAL by far), LZMA is "slow" (9 ms: it must be > 4 % smaller)"""
+    from genozip_amd import fastq as fq
+    plan = fq.illumina_plan(paired=False, domq=0)
+    host = host_codecs_for_tests()
+    F = E.zip_open(plan)
+    F.set_host_codecs(host["trial"], host["compress"])
+    zstate, vb_i, used = None, 0, set()
+    for call in range(2):
+        t = bytearray(fastq_text(n_reads, seed=400 + call, mate=1))
+        lines = bytes(t).split(b"\n")
+        base = [(lines[3 + 4 * k] * 2)[:200] for k in range(3)]
+        for r in range(0, n_reads):                              # every read carries (the start of) one of three quality strings
+            lines[4 * r + 3] = base[r % 3][:len(lines[4 * r + 1])]
+        text = b"\n".join(lines)
+        nl = np.flatnonzero(np.frombuffer(text, dtype=np.uint8) == 10)
+        at = int(nl[4 * (n_reads // 2) - 1]) + 1
+        vbs = [(0, at, vb_i + 1, -1), (at, len(text) - at, vb_i + 2, -1)]
+        vb_i += 2
+        got = F.zip_vblocks(text, vbs)
+        want, zstate = fastq_zip_expected(oracle, plan, text, vbs, zstate, host=host)
+        for v, (g, w) in enumerate(zip(got, want)):
+            assert g["z"] == w["z"], (call, v, len(g["z"]), len(w["z"]), _first_diff(g["z"], w["z"]))
+            z, p = g["z"], 84
+            while p < len(z):
+                used.add(z[p + 25]); p += 40 + int.from_bytes(z[p + 12:p + 16], "big")
+    F.set_host_codecs(None)
+    F.close()
+    assert used & {3, 4}, used                                   # a host coder did win something
+    return used
 
 
 def fastq_zip_speculation(E, oracle, n_reads):

@@ -35,6 +35,23 @@ def test_est_size_matches_reference_arithmetic(real_lib, oracle):
             assert real_lib.gz_codec_est_size(codec, n) == oracle.est_size(codec, n)
 
 
+def test_assign_sorter_of_the_real_library(real_lib, oracle):
+    """gz_codec_assign_sort is host code of the library (the reference's codec_assign_sorter + qsort, src/codec.c:128-173,338): the
+    real build's against the oracle's restatement, no GPU involved"""
+    import random
+    from genozip_amd.lib import GzCodecTest
+    rnd = random.Random(9)
+    cand = [1, 6, 7, 8, 9, 16, 17, 18, 19, 3, 5, 4]
+    for _ in range(3000):
+        base = rnd.choice([70, 4000, 60000])
+        tests = [(c, float(int(base * rnd.choice([1, 0.99, 0.985, 0.97, 0.95, 0.5, 1.29, 1.31]))), float(rnd.choice([0, 300, 4999, 5001, 9000, 60000]) * rnd.choice([1, 0.2, 0.5, 0.8])))
+                 for c in cand[:rnd.randrange(2, 13)]]
+        for mode in (0, 1, 2):
+            tab = (GzCodecTest * len(tests))(*[GzCodecTest(c, s, k) for c, s, k in tests])
+            w = real_lib.gz_codec_assign_sort(tab, len(tests), mode)
+            assert (w, [(t.codec, t.size, t.clock_us) for t in tab]) == oracle.assign_sort(tests, mode), (mode, tests)
+
+
 def test_no_cpu_fallback(real_lib):
     import torch
     if torch.cuda.is_available():

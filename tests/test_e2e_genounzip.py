@@ -227,3 +227,43 @@ def test_sam_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, qual, aux, d
     log = _run(genounzip, ["-f", "-o", "out.sam", "reads.sam.genozip"], tmp_path)
     out = (tmp_path / "out.sam").read_bytes() if (tmp_path / "out.sam").exists() else b""
     assert out == header + b"".join(texts), log[:3000]
+
+
+def test_host_codecs_round_trip(emul_engine, genounzip, lzma_sub, tmp_path):
+    """a8 with the host's candidates (gz_zip_set_host_codecs): BZ2 (bzip2 -9) and LZMA (the reference's own LZMA SDK, compiled in place)
+    join every trial of the driver; the quality lines repeat, so a coder with a memory wins QUAL (and whatever else it wins): those
+    sections are coded on the host, framed by the library - and the reference's genounzip reads the file back, byte for byte"""
+    import bz2
+    from genozip_amd import fastq as fq
+    text0 = parity.fastq_text(900, seed=61, mate=1)
+    lines = text0.split(b"\n")
+    base = [(lines[3 + 4 * k] * 2)[:200] for k in range(3)]
+    for r in range(900):
+        lines[4 * r + 3] = base[r % 3][:len(lines[4 * r + 1])]
+    text = b"\n".join(lines)
+    parts = _cut(text, 3)
+
+    def compress(codec, data):
+        return bz2.compress(data, 9) if codec == 3 else lzma_sub(data, 16 << 20)
+
+    def trial(dict_id, is_local, sample):
+        return [(3, len(compress(3, sample)), 300.0), (4, len(compress(4, sample)), 9000.0)]
+    plan = fq.illumina_plan(paired=False)
+    F = emul_engine.zip_open(plan)
+    F.set_host_codecs(trial, compress)
+    vbs, used = [], set()
+    for call in ([(parts[0][0], parts[0][1], 1, -1)], [(parts[1][0], parts[1][1], 2, -1), (parts[2][0], parts[2][1], 3, -1)]):
+        got = F.zip_vblocks(text, call)
+        for g in got:
+            z, p = g["z"], 84
+            while p < len(z):
+                used.add(z[p + 25]); p += 40 + int.from_bytes(z[p + 12:p + 16], "big")
+            g["z"] = F.with_nonref(g, lzma_sub)
+        vbs += got
+    assert used & {3, 4}, used
+    blob = F.write_file([dict(name=b"reads.fq", pair=0, vbs=vbs)], std_seq_len=150)
+    F.close()
+    (tmp_path / "reads.fq.genozip").write_bytes(blob)
+    log = _run(genounzip, ["-f", "-o", "out.fq", "reads.fq.genozip"], tmp_path)
+    out = (tmp_path / "out.fq").read_bytes() if (tmp_path / "out.fq").exists() else b""
+    assert out == text, (used, log[:3000])

@@ -135,6 +135,14 @@ def test_emul_fastq_zip_speculation(emul_engine, oracle):
     parity.fastq_zip_speculation(emul_engine, oracle, 42)
 
 
+def test_emul_assign_sort(emul_engine, oracle):
+    parity.assign_sort(emul_engine, oracle, rounds=1500)
+
+
+def test_emul_fastq_zip_host_codecs(emul_engine, oracle):
+    parity.fastq_zip_host_codecs(emul_engine, oracle, 240)
+
+
 def test_emul_fastq_zip_two_in_flight(emul_engine, oracle):
     parity.fastq_zip_two_in_flight(emul_engine, oracle, 30, n_calls=4)
 

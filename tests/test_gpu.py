@@ -128,6 +128,18 @@ def test_fastq_zip_speculation(gpu_engine, oracle):
 
 
 @pytest.mark.gpu
+def test_assign_sort_and_host_codecs(gpu_engine, oracle):
+    """a8 in full: the reference's sorter over all twelve candidates, the host's BZ2 / LZMA rows inside the driver's trials, sections
+    coded by the host's coder framed with the rest"""
+    parity.assign_sort(gpu_engine, oracle)
+    used = parity.fastq_zip_host_codecs(gpu_engine, oracle, 3000)
+    assert 3 in used or 4 in used
+    data = bytes(range(256)) * 40 + b"ACGT" * 20000
+    c, table = gpu_engine.assign_best_ex(data, extra=[(3, 600.0, 200.0), (4, 500.0, 40000.0)])
+    oc = oracle.assign_best_with(data, [(3, 600.0 - 28, 200.0), (4, 500.0 - 28, 40000.0)])
+    assert c == oc and table[0][0] == c and len(table) == 11
+
+
 def test_fastq_zip_two_in_flight(gpu_engine, oracle):
     parity.fastq_zip_two_in_flight(gpu_engine, oracle, 4000)
 
