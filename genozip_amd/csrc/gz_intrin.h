@@ -99,10 +99,10 @@ __device__ static inline void gz_f64_round_toward_zero (void) { asm volatile ("s
 __device__ static inline double gz_fma_rtz (double a, double b, double c) { return __builtin_fma (a, b, c); }
 
 #include "gz_chain_asm.h"
-// Whole 64-symbol blocks of one leaf's chain (tools/gen_chain_asm.py explains the loop). (rlo, rhi) = the state, a double
-// (range * 2^-7), wave-uniform in and out; recs = the records of the first block; ck = where the first block's checkpoint
-// goes (8 bytes per block, scalar stores). Returns the number of blocks NOT done: 0, or the first of them holds a total below
-// 256 - its checkpoint is written, the caller takes it symbol by symbol.
+// Whole blocks of GZ_CHAIN_BLOCK symbols of one leaf's chain (tools/gen_chain_asm.py explains the loop). (rlo, rhi) = the state,
+// a double (range * 2^-7), wave-uniform in and out; recs = the records of the first block; ck = where the first block's first
+// checkpoint goes (8 bytes per 64 symbols, scalar stores). Returns the number of blocks NOT done: 0, or the first of them holds a
+// total below 256 - the caller takes it symbol by symbol (checkpoints included).
 __device__ static inline uint32_t gz_chain_blocks (uint32_t &rlo, uint32_t &rhi, const uint8_t *recs, uint32_t nblk, uint32_t *ck)
 {
     const uint64_t b = (uint64_t)(uintptr_t)recs, c = (uint64_t)(uintptr_t)ck;

@@ -1009,10 +1009,10 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
 //                      {P, 0x42c00000} - 2^45     the integer as a double, scaled by 2^-7, exact
 //                      hi = hi & 0x7fffff | 0x41000000    the exponent's low three bits stay, the others become those of
 //                                                 [2^24, 2^32): exactly "shift left by whole bytes until >= 2^24"
-//                  and NO operand fetch in the loop: lane j holds the record of symbol base + j (one coalesced load per 64
-//                  symbols, a block ahead), all lanes execute every step, the state hops one lane per symbol through a DPP
-//                  read (gz_chain_asm.h, written by tools/gen_chain_asm.py): 25.8 clocks = 10.8 ns per symbol, the same with 1
-//                  or 64 chains on the device and whatever else runs. It never looks at cum or low, and stores only the state
+//                  and NO operand fetch in the loop: lane j holds the records of symbols base + 8 j .. + 7 (coalesced loads, a
+//                  block of 512 symbols ahead), all lanes execute every step, the state hops to the next lane through a DPP
+//                  read - after the 8 symbols a lane holds, because the DPP read costs two wait states (gz_chain_asm.h, written by
+//                  tools/gen_chain_asm.py): 18.2 clocks = 7.6 ns per symbol, the same with 1 or 64 chains on the device. It never looks at cum or low, and stores only the state
 //                  before every 64th symbol: k_chain_expand recomputes r = range / tot of every symbol from those for the low
 //                  kernels - with the plain formulation of the same arithmetic, and checks that it arrives at the chain's next
 //                  checkpoint: the two check each other on every 64 symbols of every stream.
@@ -1025,7 +1025,6 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
 // This reproduces RC_ShiftLow's cache / pending-0xFF bookkeeping (c_range_coder.h:70-88) exactly: that logic is just
 // a lazy form of the same addition ("[0, T1, T2, ...] plus 1 at the byte before every shift that saw a carry").
 typedef uint32_t gz_u32x4 __attribute__((vector_size (16)));
-typedef const volatile __attribute__((address_space(4))) gz_u32x4 *GzConstRecP;   // (scalar loads of single records: the slow way)
 
 #define GZ_CHAIN_R0_LO 0xffe00000u        // the coder's first range, 2^32 - 1, as the double (2^32 - 1) * 2^-7
 #define GZ_CHAIN_R0_HI 0x417fffffu
@@ -1070,27 +1069,34 @@ __device__ static inline bool d_wait_progress (const uint32_t *progress, uint32_
     return true;
 }
 
-// positions [p0, p1) of one leaf (p0 a multiple of 64; p1 one too unless it is the leaf's end)
+// positions [i0, i1) one symbol at a time, any total (i0 a multiple of 64): 64 records per trip to memory, fetched by the lanes and
+// handed out by readlane; the state before every 64th symbol goes out as in the loop
+__device__ static inline void d_chain_slow (uint32_t &rlo, uint32_t &rhi, int lane, uint32_t i0, uint32_t i1, const uint8_t *triples, uint32_t *ck)
+{
+    for (uint32_t g = i0; g < i1; g += 64) {
+        gz_scalar_store2 (ck + 2 * (g >> 6), rlo, rhi);
+        const uint4 mine = ((const uint4 *)triples)[g + lane];  // (beyond i1: inside the padded area, not looked at)
+        const int m = i1 - g < 64 ? (int)(i1 - g) : 64;
+        for (int j = 0; j < m; j++) (void)d_chain_step (rlo, rhi, d_readlane (mine.x, j), d_readlane (mine.y, j), d_readlane (mine.z, j));
+    }
+}
+
+// positions [p0, p1) of one leaf (p0 a multiple of 64; p1 - p0 one of GZ_CHAIN_BLOCK unless p1 is the leaf's end)
 // What leaves the chain is the state BEFORE every 64th symbol (8 bytes at ck + 2 * (i / 64)) and the state after the last symbol
 // of the call (the next call's first checkpoint, or the leaf's closing one): one scalar store per 64 symbols.
 __device__ static __forceinline__ void d_chain_chunk (uint32_t &rlo, uint32_t &rhi, uint32_t &nslow, int lane, uint32_t p0, uint32_t p1, const uint8_t *triples, uint32_t *ck)
 {
-    GzConstRecP rec = (GzConstRecP)(uintptr_t)triples;
-    const uint32_t whole = p1 & ~63u;
+    const uint32_t whole = p0 + (p1 - p0) / GZ_CHAIN_BLOCK * GZ_CHAIN_BLOCK;
     uint32_t i = p0;
     while (i < whole) {
-        const uint32_t left = gz_chain_blocks (rlo, rhi, triples + (size_t)i * 16, (whole - i) >> 6, ck + 2 * (i >> 6));
-        i = whole - (left << 6);
-        if (left) {                                             // a block with a total below 256 (the first occurrences of a context): one symbol at a time,
-            const uint4 mine = ((const uint4 *)triples)[i + lane]; // the records fetched by the lanes (one trip to memory, not 64)
-            for (int j = 0; j < 64; j++) (void)d_chain_step (rlo, rhi, d_readlane (mine.x, j), d_readlane (mine.y, j), d_readlane (mine.z, j));
-            i += 64; nslow++;
+        const uint32_t left = gz_chain_blocks (rlo, rhi, triples + (size_t)i * 16, (whole - i) / GZ_CHAIN_BLOCK, ck + 2 * (i >> 6));
+        i = whole - left * GZ_CHAIN_BLOCK;
+        if (left) {                                             // a block with a total below 256 in it (the first occurrences of a context)
+            d_chain_slow (rlo, rhi, lane, i, i + GZ_CHAIN_BLOCK, triples, ck);
+            i += GZ_CHAIN_BLOCK; nslow++;
         }
     }
-    if (i < p1) {                                               // the end of the leaf
-        gz_scalar_store2 (ck + 2 * (i >> 6), rlo, rhi);
-        for (; i < p1; i++) { const gz_u32x4 c = rec[i]; (void)d_chain_step (rlo, rhi, c[0], c[1], c[2]); }
-    }
+    if (i < p1) d_chain_slow (rlo, rhi, lane, i, p1, triples, ck);     // the end of the leaf
     gz_scalar_store2 (ck + 2 * ((p1 + 63) >> 6), rlo, rhi);
 }
 

@@ -37,14 +37,15 @@ static inline double gz_fma_rtz (double a, double b, double c)
     fesetround (was); return r;
 }
 static inline void gz_scalar_store2 (uint32_t *dst, uint32_t a, uint32_t b) { if (emu.cur % 64 == 0) { dst[0] = a; dst[1] = b; } }
+#include "gz_chain_asm.h"                                       // (GZ_CHAIN_BLOCK; the loop itself is not for this compiler)
 // the same contract as the product's loop, one symbol at a time: records { inv (double), freq, cum }
 static inline uint32_t gz_chain_blocks (uint32_t &rlo, uint32_t &rhi, const uint8_t *recs, uint32_t nblk, uint32_t *ck)
 {
     for (uint32_t b = 0; b < nblk; b++) {
-        const uint32_t *rec = (const uint32_t *)(recs + (size_t)b * 1024);
-        gz_scalar_store2 (ck + 2 * b, rlo, rhi);
-        for (int j = 0; j < 64; j++) { double inv; memcpy (&inv, rec + 4 * j, 8); if (inv > 0.5) return nblk - b; }
-        for (int j = 0; j < 64; j++) {
+        const uint32_t *rec = (const uint32_t *)(recs + (size_t)b * GZ_CHAIN_BLOCK * 16);
+        for (int j = 0; j < GZ_CHAIN_BLOCK; j++) { double inv; memcpy (&inv, rec + 4 * j, 8); if (inv > 0.5) return nblk - b; }
+        for (int j = 0; j < GZ_CHAIN_BLOCK; j++) {
+            if (!(j & 63)) gz_scalar_store2 (ck + 2 * (b * (GZ_CHAIN_BLOCK / 64) + j / 64), rlo, rhi);
             double inv, R; memcpy (&inv, rec + 4 * j, 8);
             uint64_t rb = (uint64_t)rlo | (uint64_t)rhi << 32; memcpy (&R, &rb, 8);
             const double t = gz_fma_rtz (R, inv, 4503599627370496.0);
