@@ -37,7 +37,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")    # (genozip_amd/lib.py: must 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CHAIN_FLOOR_NS = 7.6            # k_arith_chain's loop alone on the device: 18.2 clocks per symbol at 2.4 GHz (profiles/round4_ubench_chain_f64.txt)
+CHAIN_FLOOR_NS = 6.6            # k_arith_chain's loop alone on the device: 15.8 clocks per symbol at 2.4 GHz (profiles/round4_ubench_chain_f64.txt)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 METRIC = "input MB/s compressed (bit-exact .genozip) at 1/2/4/8 GPUs vs CPU ref"
 
@@ -666,8 +666,8 @@ def main():
     # The critical path. The dominant kernel is launched several times per step on different streams (the persistent launch over the long
     # QUAL streams + the short-leaf launches of trials and section writer): its launches overlap, their sum is NOT time on the step's
     # critical path - the LONGEST launch is. That launch codes the long streams (sections of >= 1 MB); what bounds it is the issue rate
-    # of one wave per stream, not HBM: four dependent vector instructions per symbol + a lane hop every 8 symbols = 18.2 clocks at
-    # 2.4 GHz = 7.6 ns, measured with the loop alone on the device (tools/ubench_chain_f64.hip; rounds 1-3: seven scalar integer
+    # of one wave per stream, not HBM: three dependent vector instructions per symbol + a lane hop every 8 symbols = 15.8 clocks at
+    # 2.4 GHz = 6.6 ns, measured with the loop alone on the device (tools/ubench_chain_f64.hip; rounds 1-3: seven scalar integer
     # instructions, 12.7 ns).
     secs_all = [s for z in z_all for s in walk_sections(z)]
     long_secs = [s for s in secs_all if s[3] >= (1 << 20) and s[1] in (16, 17, 18, 19)]

@@ -101,19 +101,16 @@ __device__ static inline double gz_fma_rtz (double a, double b, double c) { retu
 #include "gz_chain_asm.h"
 // Whole blocks of GZ_CHAIN_BLOCK symbols of one leaf's chain (tools/gen_chain_asm.py explains the loop). (rlo, rhi) = the state,
 // a double (range * 2^-7), wave-uniform in and out; recs = the records of the first block; ck = where the first block's first
-// checkpoint goes (8 bytes per 64 symbols, scalar stores). Returns the number of blocks NOT done: 0, or the first of them holds a
-// total below 256 - the caller takes it symbol by symbol (checkpoints included).
-__device__ static inline uint32_t gz_chain_blocks (uint32_t &rlo, uint32_t &rhi, const uint8_t *recs, uint32_t nblk, uint32_t *ck)
+// checkpoint goes (8 bytes per 64 symbols, scalar stores).
+__device__ static inline void gz_chain_blocks (uint32_t &rlo, uint32_t &rhi, const uint8_t *recs, uint32_t nblk, uint32_t *ck)
 {
     const uint64_t b = (uint64_t)(uintptr_t)recs, c = (uint64_t)(uintptr_t)ck;
     const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)b), b_hi = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)(b >> 32));
     const uint32_t c_lo = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)c), c_hi = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)(c >> 32));
     const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane ((int)nblk);
-    uint32_t left;
-    asm volatile (GZ_CHAIN_F64_ASM : [rlo] "+v"(rlo), [rhi] "+v"(rhi), [left] "=s"(left)
+    asm volatile (GZ_CHAIN_F64_ASM : [rlo] "+v"(rlo), [rhi] "+v"(rhi)
                                    : [blo] "s"(b_lo), [bhi] "s"(b_hi), [nblk] "s"(nb), [clo] "s"(c_lo), [chi] "s"(c_hi) : GZ_CHAIN_F64_CLOBBERS);
     rlo = (uint32_t)__builtin_amdgcn_readfirstlane ((int)rlo); rhi = (uint32_t)__builtin_amdgcn_readfirstlane ((int)rhi);   // (the state ends in lane 0)
-    return left;
 }
 // one 8-byte checkpoint through the scalar unit
 __device__ static inline void gz_scalar_store2 (uint32_t *dst, uint32_t a, uint32_t b)

@@ -1003,19 +1003,19 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
 //   k_arith_chain  one wave per leaf. Rounds 1-2 ran the recurrence on the scalar unit, seven integer instructions per symbol
 //                  (+ inc, mulhi by a magic number, >> shift, * freq, clz, & 0x18, <<) fed by scalar loads: 30.5 clocks per
 //                  symbol + the waits for those loads (13.6 ns alone on the device, 14.9 beside the other kernels of a step).
-//                  Now FOUR vector instructions in double precision (the state is range * 2^-7 as a double):
-//                      fma (R, 2^7 / tot, 2^52)   rounding toward zero: 2^52 + floor (range / tot) - the low word IS r
-//                      r * freq                   24-bit integer multiply (r < 2^24 when tot >= 256)
-//                      {P, 0x42c00000} - 2^45     the integer as a double, scaled by 2^-7, exact
-//                      hi = hi & 0x7fffff | 0x41000000    the exponent's low three bits stay, the others become those of
-//                                                 [2^24, 2^32): exactly "shift left by whole bytes until >= 2^24"
+//                  Now THREE vector instructions in double precision (the state R is range * 2^-7 as a double):
+//                      T = fma (R, 2^7 / tot, 2^52)      rounding toward zero: 2^52 + floor (range / tot) - the low word IS r
+//                      R = fma (T, F, G)                 F = freq * 2^-7, G = -2^52 * F: r * freq * 2^-7, exact
+//                      R.hi = R.hi & 0x7fffff | 0x41000000     the exponent's low three bits stay, the others become those of
+//                                                        [2^24, 2^32): exactly "shift left by whole bytes until >= 2^24"
 //                  and NO operand fetch in the loop: lane j holds the records of symbols base + 8 j .. + 7 (coalesced loads, a
-//                  block of 512 symbols ahead), all lanes execute every step, the state hops to the next lane through a DPP
-//                  read - after the 8 symbols a lane holds, because the DPP read costs two wait states (gz_chain_asm.h, written by
-//                  tools/gen_chain_asm.py): 18.2 clocks = 7.6 ns per symbol, the same with 1 or 64 chains on the device. It never looks at cum or low, and stores only the state
+//                  block of 512 symbols ahead; F and G made from freq by all lanes at once), all lanes execute every step, the
+//                  state hops to the next lane through a DPP read of r - after the 8 symbols a lane holds, because a DPP read of
+//                  a fresh result costs two wait states (gz_chain_asm.h, written by tools/gen_chain_asm.py): 15.8 clocks = 6.6 ns
+//                  per symbol, the same with 1 or 64 chains on the device. It never looks at cum or low, and stores only the state
 //                  before every 64th symbol: k_chain_expand recomputes r = range / tot of every symbol from those for the low
-//                  kernels - with the plain formulation of the same arithmetic, and checks that it arrives at the chain's next
-//                  checkpoint: the two check each other on every 64 symbols of every stream.
+//                  kernels - with the plain formulation of the same arithmetic (an integer multiply), and checks that it arrives
+//                  at the chain's next checkpoint: the two check each other on every 64 symbols of every stream.
 //   k_low_*        all threads: every thread replays low += cum * r for its own slice of 64 symbols from low = 0,
 //                  emitting the byte that leaves the 32-bit window at every shift (plus the carry out of the window as
 //                  a 9th bit) at its absolute output position (k_chain_expand / k_low_scan: a prefix sum of the k's;
@@ -1029,8 +1029,7 @@ typedef uint32_t gz_u32x4 __attribute__((vector_size (16)));
 #define GZ_CHAIN_R0_LO 0xffe00000u        // the coder's first range, 2^32 - 1, as the double (2^32 - 1) * 2^-7
 #define GZ_CHAIN_R0_HI 0x417fffffu
 
-// One symbol, any total - the plain formulation (k_chain_expand; in the chain: blocks that hold a total below 256 and the
-// rest of a leaf that does not fill a block). The wave must have called gz_f64_round_toward_zero. Returns r = range / tot.
+// One symbol - the plain formulation (k_chain_expand; in the chain: the rest of a leaf that does not fill a block of the loop). The wave must have called gz_f64_round_toward_zero. Returns r = range / tot.
 __device__ static inline uint32_t d_chain_step (uint32_t &rlo, uint32_t &rhi, uint32_t inv_lo, uint32_t inv_hi, uint32_t freq, uint32_t *shift_bytes = NULL)
 {
     const double t = gz_fma_rtz (__hiloint2double ((int)rhi, (int)rlo), __hiloint2double ((int)inv_hi, (int)inv_lo), 4503599627370496.0);
@@ -1069,8 +1068,9 @@ __device__ static inline bool d_wait_progress (const uint32_t *progress, uint32_
     return true;
 }
 
-// positions [i0, i1) one symbol at a time, any total (i0 a multiple of 64): 64 records per trip to memory, fetched by the lanes and
-// handed out by readlane; the state before every 64th symbol goes out as in the loop
+// positions [i0, i1) one symbol at a time in the plain formulation (the end of a leaf that does not fill a block of the loop; i0 a
+// multiple of 64): 64 records per trip to memory, fetched by the lanes and handed out by readlane; the state before every 64th
+// symbol goes out as in the loop
 __device__ static inline void d_chain_slow (uint32_t &rlo, uint32_t &rhi, int lane, uint32_t i0, uint32_t i1, const uint8_t *triples, uint32_t *ck)
 {
     for (uint32_t g = i0; g < i1; g += 64) {
@@ -1084,18 +1084,11 @@ __device__ static inline void d_chain_slow (uint32_t &rlo, uint32_t &rhi, int la
 // positions [p0, p1) of one leaf (p0 a multiple of 64; p1 - p0 one of GZ_CHAIN_BLOCK unless p1 is the leaf's end)
 // What leaves the chain is the state BEFORE every 64th symbol (8 bytes at ck + 2 * (i / 64)) and the state after the last symbol
 // of the call (the next call's first checkpoint, or the leaf's closing one): one scalar store per 64 symbols.
-__device__ static __forceinline__ void d_chain_chunk (uint32_t &rlo, uint32_t &rhi, uint32_t &nslow, int lane, uint32_t p0, uint32_t p1, const uint8_t *triples, uint32_t *ck)
+__device__ static __forceinline__ void d_chain_chunk (uint32_t &rlo, uint32_t &rhi, int lane, uint32_t p0, uint32_t p1, const uint8_t *triples, uint32_t *ck)
 {
     const uint32_t whole = p0 + (p1 - p0) / GZ_CHAIN_BLOCK * GZ_CHAIN_BLOCK;
     uint32_t i = p0;
-    while (i < whole) {
-        const uint32_t left = gz_chain_blocks (rlo, rhi, triples + (size_t)i * 16, (whole - i) / GZ_CHAIN_BLOCK, ck + 2 * (i >> 6));
-        i = whole - left * GZ_CHAIN_BLOCK;
-        if (left) {                                             // a block with a total below 256 in it (the first occurrences of a context)
-            d_chain_slow (rlo, rhi, lane, i, i + GZ_CHAIN_BLOCK, triples, ck);
-            i += GZ_CHAIN_BLOCK; nslow++;
-        }
-    }
+    if (whole > p0) { gz_chain_blocks (rlo, rhi, triples + (size_t)p0 * 16, (whole - p0) / GZ_CHAIN_BLOCK, ck + 2 * (p0 >> 6)); i = whole; }
     if (i < p1) d_chain_slow (rlo, rhi, lane, i, p1, triples, ck);     // the end of the leaf
     gz_scalar_store2 (ck + 2 * ((p1 + 63) >> 6), rlo, rhi);
 }
@@ -1118,12 +1111,12 @@ __device__ static __forceinline__ void d_arith_chain (GzdLeaf *leaves, const uin
     const uint32_t n = d_uniform (L.arith_n);
     const uint8_t *triples = d_uniform_ptr (L.triples);        // (wave-uniform: keep them in scalar registers)
     uint32_t *ck = d_uniform_ptr ((uint32_t *)L.ckpt);          // (checkpoints: the state before every 64th symbol, 8 bytes each)
-    uint32_t rlo = GZ_CHAIN_R0_LO, rhi = GZ_CHAIN_R0_HI, nslow = 0;
-    if (!progress) d_chain_chunk (rlo, rhi, nslow, lane, 0, n, triples, ck);
+    uint32_t rlo = GZ_CHAIN_R0_LO, rhi = GZ_CHAIN_R0_HI;
+    if (!progress) d_chain_chunk (rlo, rhi, lane, 0, n, triples, ck);
     else
         for (uint32_t k = 0, p0 = 0; p0 < n; k++, p0 += chunk) {
             if (k && !d_wait_progress (progress, k + 1)) { if (!lane) { L.overflow = 2; *fail = 1; } break; }
-            d_chain_chunk (rlo, rhi, nslow, lane, p0, (n - p0 > chunk) ? p0 + chunk : n, triples, ck);
+            d_chain_chunk (rlo, rhi, lane, p0, (n - p0 > chunk) ? p0 + chunk : n, triples, ck);
             if (done) {                                        // this leaf's checkpoints of chunk k are final: tell the low kernels
                 gz_scalar_store_flush ();
                 __threadfence ();
@@ -1134,7 +1127,6 @@ __device__ static __forceinline__ void d_arith_chain (GzdLeaf *leaves, const uin
             }
         }
     gz_scalar_store_flush ();
-    if (!lane) L.touch_sink = nslow;                           // (diagnostics: blocks that went the slow way)
 }
 
 __global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress, uint32_t chunk,

@@ -38,23 +38,21 @@ static inline double gz_fma_rtz (double a, double b, double c)
 }
 static inline void gz_scalar_store2 (uint32_t *dst, uint32_t a, uint32_t b) { if (emu.cur % 64 == 0) { dst[0] = a; dst[1] = b; } }
 #include "gz_chain_asm.h"                                       // (GZ_CHAIN_BLOCK; the loop itself is not for this compiler)
-// the same contract as the product's loop, one symbol at a time: records { inv (double), freq, cum }
-static inline uint32_t gz_chain_blocks (uint32_t &rlo, uint32_t &rhi, const uint8_t *recs, uint32_t nblk, uint32_t *ck)
+// the same contract as the product's loop, one symbol at a time, in the loop's own arithmetic: records { inv (double), freq, cum },
+// T = fma (R, inv, 2^52) truncated, R' = fma (T, F, G) with F = freq * 2^-7, G = -2^52 * F, then the exponent bits
+static inline void gz_chain_blocks (uint32_t &rlo, uint32_t &rhi, const uint8_t *recs, uint32_t nblk, uint32_t *ck)
 {
     for (uint32_t b = 0; b < nblk; b++) {
         const uint32_t *rec = (const uint32_t *)(recs + (size_t)b * GZ_CHAIN_BLOCK * 16);
-        for (int j = 0; j < GZ_CHAIN_BLOCK; j++) { double inv; memcpy (&inv, rec + 4 * j, 8); if (inv > 0.5) return nblk - b; }
         for (int j = 0; j < GZ_CHAIN_BLOCK; j++) {
             if (!(j & 63)) gz_scalar_store2 (ck + 2 * (b * (GZ_CHAIN_BLOCK / 64) + j / 64), rlo, rhi);
             double inv, R; memcpy (&inv, rec + 4 * j, 8);
             uint64_t rb = (uint64_t)rlo | (uint64_t)rhi << 32; memcpy (&R, &rb, 8);
             const double t = gz_fma_rtz (R, inv, 4503599627370496.0);
-            uint64_t tb; memcpy (&tb, &t, 8);
-            const uint32_t P = ((uint32_t)tb & 0xffffffu) * (rec[4 * j + 2] & 0xffffffu);        // (v_mul_u32_u24)
-            const double Pd = (double)P * 0.0078125;
+            const double F = (double)rec[4 * j + 2] * 0.0078125, G = -4503599627370496.0 * F;
+            const double Pd = gz_fma_rtz (t, F, G);
             uint64_t pb; memcpy (&pb, &Pd, 8);
             rlo = (uint32_t)pb; rhi = ((uint32_t)(pb >> 32) & 0x007fffffu) | 0x41000000u;
         }
     }
-    return 0;
 }

@@ -1,27 +1,27 @@
 #!/usr/bin/env python3
 """Writes genozip_amd/csrc/gz_chain_asm.h: the inner loop of the range-coder chain (k_arith_chain) as ONE inline-asm statement.
 
-What is serial in the range coder (c_range_coder.h:97-109) is  r = range / tot ; range = (r * freq) << 8k.  Here, per symbol:
+What is serial in the range coder (c_range_coder.h:97-109) is  r = range / tot ; range = (r * freq) << 8k.  Here, per symbol, THREE
+dependent vector instructions in double precision (the state R is range * 2^-7 as a double, rounding is toward zero):
 
-    v_fma_f64      T, R, inv, 2^52            round toward zero: T = 2^52 + floor (R * inv); inv = RU (2^7 / tot), R = range * 2^-7.
-                                              The low half of T IS r as an integer.
-    v_mul_u32_u24  P, T.lo, freq              r * freq (r < 2^24 when tot >= 256)
-    v_add_f64      R, {P, 0x42c00000}, -2^45  the pair is the double 2^45 + P * 2^-7: R = P * 2^-7, exact
+    v_fma_f64      T, R, inv, 2^52            T = 2^52 + floor (R * inv) = 2^52 + r;  inv = 2^7 / tot rounded up
+    v_fma_f64      R, T, F, G                 F = freq * 2^-7, G = -2^52 * F:  (2^52 + r) * F - 2^52 * F = r * freq * 2^-7, exact
     v_and_or_b32   R.hi, R.hi, mask, exp      the exponent's low 3 bits stay, the others become "2^24 <= range < 2^32": that IS
-                                              "shift left by whole bytes until >= 2^24" (P >= 2^8 always)
+                                              "shift left by whole bytes until >= 2^24" (r * freq >= 2^8 always)
 
 No operand goes through a scalar register and no load sits in the loop: lane L of the wave holds the records of the PER symbols
-base + PER * L .. + PER - 1 (PER coalesced 16-byte loads per 64 * PER symbols, requested a block ahead), every lane executes every
-step, and the state walks through a lane's PER symbols and then HOPS to the next lane: the multiply of a lane's first symbol reads
-r from the lane before through DPP (wave_ror:1) and multiplies it by that lane's last frequency, which it holds as "the frequency
-before mine". A DPP read of a register a vector instruction has just written needs two wait states (s_nop 1: measured - without
-them the result is wrong, and they cost 6 clocks), which is why a lane takes PER symbols in a row and not one. Only the diagonal
-carries meaning; what the other lanes compute is never looked at.
-Clocks per symbol, alone on the device (tools/ubench_chain_f64.hip): PER = 1: 25.8, PER = 4: see profiles/; the seven-instruction
-integer form on the scalar unit (rounds 1-3): 30.5 + the waits for its scalar loads.
+base + PER * L .. + PER - 1 (PER coalesced 16-byte loads per block of 64 * PER symbols, requested a block ahead; F and G are made
+from the record's freq by all lanes at once: three instructions per record, 0.05 per symbol), every lane executes every step, and
+the state walks through a lane's PER symbols and then HOPS to the next lane: the low word of T - r, the only word of T that is not a
+constant - is read from the lane before through DPP (wave_ror:1), and multiplied by that lane's last F / G, which the lane holds as
+"the F and G before mine". A DPP read of a register a vector instruction has just written needs two wait states (s_nop 1: measured -
+without them the result is wrong), which is why a lane takes PER symbols in a row and not one. Only the diagonal carries meaning;
+what the other lanes compute is never looked at.
+Clocks per symbol, alone on the device (tools/ubench_chain_f64.hip; profiles/round4_ubench_chain_f64.txt): see there; the
+seven-instruction integer form on the scalar unit (rounds 1-3): 30.5 + the waits for its scalar loads.
 
-A block in which some total is below 256 (r may then need more than 24 bits) is left to the caller, as is the rest of a leaf that
-does not fill a block. Everything between the labels is written here, loop control included: the compiler schedules nothing in it.
+Everything between the labels is written here, loop control included: the compiler schedules nothing in it. The rest of a leaf that
+does not fill a block is the caller's.
 """
 import sys
 
@@ -29,24 +29,27 @@ PER = 8                         # symbols a lane takes in a row
 BLOCK = 64 * PER
 
 # registers
-R, T = "v[60:61]", "v[62:63]"
-RLO, RHI, TLO = "v60", "v61", "v62"
-P, PLO = "v[52:53]", "v52"      # v53 = 0x42c00000
-C45 = "v[54:55]"                # 2^45
+R, T, T2 = "v[60:61]", "v[62:63]", "v[52:53]"      # T2 = { r read from the lane before, 0x43300000 }
+RLO, RHI, TLO, T2LO = "v60", "v61", "v62", "v52"
 C52 = "v[56:57]"                # 2^52
 MASK, EXPO, OFF = "v58", "v59", "v50"
-VCMP = "v51"
+FIRST = 64
 
 
 def regset(base):
-    """PER records of 4 registers each + the frequency before mine"""
-    return dict(rec=[f"v[{base + 4 * k}:{base + 4 * k + 3}]" for k in range(PER)], inv=[f"v[{base + 4 * k}:{base + 4 * k + 1}]" for k in range(PER)],
-                fq=[f"v{base + 4 * k + 2}" for k in range(PER)], fp=f"v{base + 4 * PER}", first=base, last=base + 4 * PER)
+    """per symbol 8 registers: inv.lo inv.hi freq cum | F.lo (0) F.hi | G.lo (0) G.hi; then the F and G before mine (2 pairs)"""
+    sym = [base + 8 * k for k in range(PER)]
+    tail = base + 8 * PER
+    return dict(rec=[f"v[{b}:{b + 3}]" for b in sym], inv=[f"v[{b}:{b + 1}]" for b in sym], fq=[f"v{b + 2}" for b in sym],
+                F=[f"v[{b + 4}:{b + 5}]" for b in sym], Flo=[f"v{b + 4}" for b in sym], Fhi=[f"v{b + 5}" for b in sym],
+                G=[f"v[{b + 6}:{b + 7}]" for b in sym], Glo=[f"v{b + 6}" for b in sym], Ghi=[f"v{b + 7}" for b in sym],
+                Fp=f"v[{tail}:{tail + 1}]", Fplo=f"v{tail}", Fphi=f"v{tail + 1}", Gp=f"v[{tail + 2}:{tail + 3}]", Gplo=f"v{tail + 2}", Gphi=f"v{tail + 3}",
+                first=base, last=tail + 3)
 
 
-SETS = [regset(64), regset(64 + 4 * PER + 2)]
-CLOB_V = [50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63] + [r for s in SETS for r in range(s["first"], s["last"] + 1)]
-CLOB_S = [36, 37, 40, 41, 42, 44, 45, 46, 47, 48, 49]
+SETS = [regset(FIRST), regset(FIRST + 8 * PER + 4)]
+CLOB_V = [50, 52, 53, 56, 57, 58, 59, 60, 61, 62, 63] + [r for s in SETS for r in range(s["first"], s["last"] + 1)]
+CLOB_S = [36, 37, 40, 41, 42, 44, 45, 46, 47]
 BASE, NEXT, CK, TMP = "s[40:41]", "s[36:37]", "s[44:45]", "s[46:47]"     # NEXT = BASE + a block (beyond the 13-bit offset of a load)
 DPP = "wave_ror:1 row_mask:0xf bank_mask:0xf"
 
@@ -63,14 +66,15 @@ def block(a, cur, nxt, tag):
     a(f"s_cbranch_scc1 2{tag}f")
     loads(a, nxt, NEXT)
     a(f"2{tag}:")
-    a(f"v_mov_b32_dpp {cur['fp']}, {cur['fq'][PER - 1]} {DPP}")   # the frequency before mine: the last of the lane before
-    # a total below 256 somewhere in the block? (inv > 0.5)
-    a(f"v_cmp_lt_f64 vcc, 0.5, {cur['inv'][0]}")
-    for k in range(1, PER):
-        a(f"v_cmp_lt_f64 s[48:49], 0.5, {cur['inv'][k]}")
-        a("s_or_b64 vcc, vcc, s[48:49]")
+    for k in range(PER):                                     # F = freq * 2^-7, G = -2^52 * F (the low words are and stay 0)
+        a(f"v_cvt_f64_u32 {cur['F'][k]}, {cur['fq'][k]}")
+    for k in range(PER):
+        a(f"v_add_u32 {cur['Fhi'][k]}, 0xff900000, {cur['Fhi'][k]}")       # exponent - 7
+    for k in range(PER):
+        a(f"v_add_u32 {cur['Ghi'][k]}, 0x83400000, {cur['Fhi'][k]}")       # exponent + 52, sign
     a("s_nop 1")
-    a("s_cbranch_vccnz 9f")
+    a(f"v_mov_b32_dpp {cur['Fphi']}, {cur['Fhi'][PER - 1]} {DPP}")          # the F and G before mine: the last of the lane before
+    a(f"v_mov_b32_dpp {cur['Gphi']}, {cur['Ghi'][PER - 1]} {DPP}")
     for j in range(BLOCK):
         lane, k = divmod(j, PER)
         if j % 64 == 0:                                      # the state before every 64th symbol goes out: it sits in lane j / PER
@@ -81,15 +85,11 @@ def block(a, cur, nxt, tag):
             a(f"s_store_dwordx2 {TMP}, {CK}, 0x{8 * (j // 64):x}")
         a(f"v_fma_f64 {T}, {R}, {cur['inv'][k]}, {C52}")
         if k < PER - 1:                                      # the lane's next symbol: in place
-            a(f"v_mul_u32_u24 {PLO}, {TLO}, {cur['fq'][k]}")
-        elif j < BLOCK - 1:                                  # the next lane's first symbol
+            a(f"v_fma_f64 {R}, {T}, {cur['F'][k]}, {cur['G'][k]}")
+        else:                                                # the next lane's first symbol (lane 0: the next block's)
             a("s_nop 1")
-            a(f"v_mul_u32_u24_dpp {PLO}, {TLO}, {cur['fp']} {DPP}")
-        else:                                                # lane 0, which holds the next block's first records
-            a(f"v_mul_u32_u24 {PLO}, {TLO}, {cur['fq'][k]}")
-            a("s_nop 1")
-            a(f"v_mov_b32_dpp {PLO}, {PLO} {DPP}")
-        a(f"v_add_f64 {R}, {P}, -{C45}")
+            a(f"v_mov_b32_dpp {T2LO}, {TLO} {DPP}")
+            a(f"v_fma_f64 {R}, {T2}, {cur['Fp']}, {cur['Gp']}")
         a(f"v_and_or_b32 {RHI}, {RHI}, {MASK}, {EXPO}")
     a(f"s_add_u32 s44, s44, {8 * (BLOCK // 64)}")
     a("s_addc_u32 s45, s45, 0")
@@ -105,7 +105,6 @@ def body():
     a = L.append
     # operands: [rlo] [rhi] (v, in/out): the state - in: the same in every lane; out: valid in lane 0
     #           [blo] [bhi] (s): the records of the first block; [nblk] (s): blocks, >= 1; [clo] [chi] (s): where the first checkpoint goes
-    #           [left] (s, out): 0, or the number of blocks not done: the first of them holds a total below 256 (NO checkpoint of it is written)
     a("v_mov_b32 v60, %[rlo]")
     a("v_mov_b32 v61, %[rhi]")
     a("s_mov_b32 s40, %[blo]")
@@ -118,13 +117,16 @@ def body():
     a("v_mbcnt_lo_u32_b32 v50, -1, 0")
     a("v_mbcnt_hi_u32_b32 v50, -1, v50")
     a(f"v_mul_u32_u24 v50, {16 * PER}, v50")                 # lane * 16 * PER: my records
-    a("v_mov_b32 v53, 0x42c00000")
-    a("v_mov_b32 v54, 0")
-    a("v_mov_b32 v55, 0x42c00000")
+    a("v_mov_b32 v53, 0x43300000")                           # the high word of 2^52 + r
     a("v_mov_b32 v56, 0")
     a("v_mov_b32 v57, 0x43300000")
     a("v_mov_b32 v58, 0x7fffff")
     a("v_mov_b32 v59, 0x41000000")
+    for s in SETS:                                           # the low words of every F and G: 0, never written again (v_cvt_f64_u32 rewrites F's with 0)
+        for k in range(PER):
+            a(f"v_mov_b32 {s['Glo'][k]}, 0")
+        a(f"v_mov_b32 {s['Fplo']}, 0")
+        a(f"v_mov_b32 {s['Gplo']}, 0")
     a("s_nop 4")
     loads(a, SETS[0], BASE)
     a("1:")
@@ -136,7 +138,6 @@ def body():
     a("s_cbranch_scc1 1b")
     a("9:")
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    a("s_mov_b32 %[left], s42")
     a("s_nop 1")
     a("v_mov_b32 %[rlo], v60")
     a("v_mov_b32 %[rhi], v61")
