@@ -281,9 +281,9 @@ def cpu_leg(wl, z_all, n_threads):
 
 def pmc_traffic(kernel, a):
     """HBM bytes per STEP of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/round3_pmc.json, made by tools/summarize_prof.py: counter collection serialises kernels, so it cannot happen inside a timed
+    (profiles/round4_pmc.json, made by tools/summarize_prof.py: counter collection serialises kernels, so it cannot happen inside a timed
     run); null when there is no such file for this workload"""
-    p = os.path.join(ROOT, "profiles", "round3_pmc.json")
+    p = os.path.join(ROOT, "profiles", "round4_pmc.json")
     if not os.path.exists(p):
         return None
     d = json.load(open(p))

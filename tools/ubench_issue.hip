@@ -73,6 +73,14 @@ KERNEL_LD (k_step_16, "s_mov_b64 exec, 0xffff\n", STEP4, "s_nop 0\n")
 KERNEL_LD (k_step_32, "s_mov_b64 exec, 0xffffffff\n", STEP4, "s_nop 0\n")
 KERNEL_LD (k_step_1, "s_mov_b64 exec, 1\n", STEP4, "s_nop 0\n")
 KERNEL_LD (k_step_64, "", STEP4, "s_nop 0\n")
+#define STEP3 "v_fma_f64 v[12:13], v[10:11], v[20:21], v[24:25]\n v_fma_f64 v[10:11], v[12:13], v[22:23], v[30:31]\n v_and_or_b32 v11, v11, v26, v27\n"
+#define STEP3M "v_mov_b32 v13, v25\n v_fmac_f64 v[12:13], v[10:11], v[20:21]\n v_fmac_f64 v[10:11], v[12:13], v[22:23]\n v_and_or_b32 v11, v11, v26, v27\n"
+#define STEP2M "v_fmac_f64 v[12:13], v[10:11], v[20:21]\n v_fmac_f64 v[10:11], v[12:13], v[22:23]\n v_and_or_b32 v11, v11, v26, v27\n"
+KERNEL_LD (k_step3_64, "v_mov_b32 v30, 0\n v_mov_b32 v31, 0xc3300000\n", STEP3, "s_nop 0\n")
+KERNEL_LD (k_step3_1, "v_mov_b32 v30, 0\n v_mov_b32 v31, 0xc3300000\n s_mov_b64 exec, 1\n", STEP3, "s_nop 0\n")
+KERNEL_LD (k_step3_2, "v_mov_b32 v30, 0\n v_mov_b32 v31, 0xc3300000\n s_mov_b64 exec, 3\n", STEP3, "s_nop 0\n")
+KERNEL_LD (k_step2m_64, "", STEP2M, "s_nop 0\n")
+KERNEL_LD (k_step2m_1, "s_mov_b64 exec, 1\n", STEP2M, "s_nop 0\n")
 KERNEL_LD (k_hop_u24_nonop, "v_mov_b32 v15, 0x42c00000\n", "v_fma_f64 v[12:13], v[10:11], v[20:21], v[24:25]\n v_mul_u32_u24_dpp v14, v12, v22 row_ror:1 row_mask:0xf bank_mask:0xf\n v_add_f64 v[10:11], v[14:15], -v[24:25]\n v_and_or_b32 v11, v11, v26, v27\n", "s_nop 0\n")
 
 int main ()
@@ -94,6 +102,8 @@ int main ()
     RUNLD (k_hop_u24, 1, "step (fma, nop, mul_u24 dpp wave_ror, add, and_or)"); RUNLD (k_hop_u24_rowshr, 1, "the same with row_ror"); RUNLD (k_hop_u24_nonop, 1, "row_ror without the nop (wrong results, timing only)");
     RUNLD (k_hop_16, 1, "hop step, 16 lanes active"); RUNLD (k_hop_32, 1, "hop step, 32 lanes active"); RUNLD (k_hop_2, 1, "hop step, 2 lanes active");
     RUNLD (k_step_1, 1, "plain step, 1 lane"); RUNLD (k_step_16, 1, "plain step, 16 lanes"); RUNLD (k_step_32, 1, "plain step, 32 lanes"); RUNLD (k_step_64, 1, "plain step, 64 lanes");
+    RUNLD (k_step3_64, 1, "3-instruction step (fma, fma, and_or), 64 lanes"); RUNLD (k_step3_1, 1, "3-instruction step, 1 lane"); RUNLD (k_step3_2, 1, "3-instruction step, 2 lanes");
+    RUNLD (k_step2m_64, 1, "3-instruction step with v_fmac_f64 (timing only), 64 lanes"); RUNLD (k_step2m_1, 1, "the same, 1 lane");
     RUNLD (k_step_1, 1, "plain step, 1 lane (again)"); RUNLD (k_hop_16, 1, "hop step, 16 lanes active (again)");
     return 0;
 }
