@@ -388,6 +388,59 @@ def test_streamed_file(gpu_engine, oracle):
         t.vblock_i = v[2]
 
 
+def test_streamed_wgs_share(gpu_engine, oracle):
+    """BASELINE configs[4] at ONE GPU's full share: 600 M reads over 8 GPUs = 75 M read pairs = 55 GB of FASTQ text per GPU, streamed
+    through ONE file object in calls of 112 VBlock pairs (3.76 GB of NEW text per call - the generator continues the read numbering,
+    nothing is re-used), vblock_i as the reader wants them (R1 1..N, R2 N+1..2N). Per call: every VBlock's header names its own length
+    and number, sections in (DEP level, did_i) order, every section's adler32 and the QUAL round trip of the first and last VBlock;
+    over the calls: the codecs of the first call hold, the dictionaries only grow, every read is accounted for.
+    GZ_TEST_WGS_CALLS: fewer calls (default: the whole share)"""
+    import os
+    import torch
+    bench, wl = _bench_workload(gpu_engine, pairs=0, stream_reads=75000000, batch_pairs=112, vb_mb=0)
+    from genozip_amd.shard import zip_vblocks_sharded
+    W, F, n = wl.W, wl.F, len(wl.vb)
+    n_calls = int(os.environ.get("GZ_TEST_WGS_CALLS", wl.calls_per_step))
+    assert wl.calls_per_step >= 15 and n == 224
+    reads_per_call = sum(r[1] for r in wl.ranges)
+    th = W._TH(wl.text.device)
+    F.reset()
+    codecs_first, words, reads, text_bytes, z_bytes = None, 0, 0, 0, 0
+    for call in range(n_calls):
+        if call:                                            # the next stretch of the two files: new reads, later VBlocks
+            at = 0
+            for mate in (1, 2):
+                for r0, m_reads in wl.ranges:
+                    for c0 in range(0, m_reads, 100000):
+                        m = min(100000, m_reads - c0)
+                        wl.text[at + c0 * W.RECORD_BYTES: at + (c0 + m) * W.RECORD_BYTES] = W.fastq_text(1, call * reads_per_call + r0 + c0, m, mate=mate, profile="div", xp=th)
+                    at += m_reads * W.RECORD_BYTES
+            torch.cuda.synchronize()
+            for t in wl.tab:
+                t.vblock_i += len(wl.ranges)
+        zip_vblocks_sharded(F, None, wl.text, wl.text_len, wl.tab, n)
+        res = F.results(wl.tab)
+        z_all = [r["z"] for r in res]
+        vb_now = [(o, l, int(t.vblock_i), r1) for (o, l, _, r1), t in zip(wl.vb, wl.tab)]
+        assert [v[2] for v in vb_now[:2]] == [call * 112 + 1, call * 112 + 2] and vb_now[112][2] == wl.n_pairs_file + call * 112 + 1
+        wl_view = type("V", (), dict(W=W, plan=wl.plan, text=wl.text, text_len=wl.text_len, vb=vb_now))
+        _check_vblocks(gpu_engine, oracle, bench, wl_view, z_all, {0, n - 1})
+        codecs = {(s[0], s[2]): s[1] for z in z_all for s in bench.walk_sections(z) if s[3] >= 50}
+        if codecs_first is None:
+            codecs_first = codecs
+        else:
+            assert all(codecs_first.get(k, c) == c for k, c in codecs.items()), "a committed codec changed between calls"
+        w = len(F.zctx_words(3))
+        assert w >= words
+        words = w
+        reads += sum(r["n_reads"] for r in res); text_bytes += wl.text_len; z_bytes += sum(len(z) for z in z_all)
+    assert reads == 2 * reads_per_call * n_calls and text_bytes == reads * W.RECORD_BYTES
+    if n_calls == wl.calls_per_step:
+        assert reads >= 2 * 75000000 and text_bytes > 54e9
+    for t, v in zip(wl.tab, wl.vb):
+        t.vblock_i = v[2]
+
+
 def test_rans_tables(gpu_engine, oracle):
     parity.rans_tables(gpu_engine, oracle)
 
