@@ -1619,8 +1619,10 @@ static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint
                 if (!f->hostc.compress) { h->err = "a context has a host codec (BZ2 / LZMA / BSC) and the file no host coder: gz_zip_set_host_codecs"; return GZ_ERR_ARG; }
                 uint32_t L = s.data_len;
                 if (s.data_len_dev) { HIPCHK (h, hipMemcpyAsync (&L, s.data_len_dev, 4, hipMemcpyDeviceToHost, h->stream)); HIPCHK (h, hipStreamSynchronize (h->stream)); }
-                s.data_len = L; s.data_len_dev = NULL;
-                if (L < 50 && !s.hdr_codec) s.codec = GZ_CODEC_NONE;
+                if (s.data_len_dev && !L) s.codec = GZ_CODEC_NONE;           // generated on the device and dropped there (an R2 b250 identical to R1's): the writer leaves it out
+                else { s.data_len = L; s.data_len_dev = NULL; }
+                if (s.codec == GZ_CODEC_NONE) ;
+                else if (L < 50 && !s.hdr_codec) s.codec = GZ_CODEC_NONE;
                 else {
                     std::vector<uint8_t> raw (L), pay ((size_t)L + L / 2 + 65536);
                     HIPCHK (h, hipMemcpyAsync (raw.data (), s.data, L, hipMemcpyDeviceToHost, h->stream)); HIPCHK (h, hipStreamSynchronize (h->stream));

@@ -913,7 +913,7 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None, host=None):
     return out, zstate
 
 
-def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0, small_first=False):
+def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0, small_first=False, host=None):
     """the whole a1-a16 path from FASTQ text: gz_fastq_zip_vblocks over paired VBlocks (R1/R2 of a file pair in one call,
     dictionaries carried from call to call) == the oracle's step-by-step composition, byte for byte; every VBlock's z_data
     decodes again on the device (adler32 of every section, payloads) and the packed SEQ unpacks to the reads' bases.
@@ -923,8 +923,19 @@ def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0
     vb_size = len(fastq_text(n_reads, seed=100, qual=qual[0])) if small_first else 0
     plan = fq.illumina_plan(paired=True, domq=domq, vb_size=vb_size)
     F = E.zip_open(plan)
+    if host:                                                   # a8 in full: the host's candidates in every trial (paired files: R2 sections identical to R1's are still dropped)
+        F.set_host_codecs(host["trial"], host["compress"], host.get("clock"), host.get("mode", 0))
     zstate = None
     vb_i = 0
+
+    def dec(codec, pay, ulen):
+        if codec == 1:
+            return bytes(pay)
+        if host and codec in (3, 4):
+            import bz2
+            import lzma
+            return bz2.decompress(bytes(pay)) if codec == 3 else lzma.decompress(bytes(pay), format=lzma.FORMAT_ALONE)
+        return oracle.codec_uncompress(codec, pay, ulen)
     for call in range(n_calls):
         nr = n_reads if call == 0 else max(8, n_reads // 3)
         r1 = fastq_text(nr, seed=100 + call, dirty_seq=(call == 1), mate=1, qual=qual[call])
@@ -944,16 +955,16 @@ def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0
         vbs = [(offs[0], lens[0], vb_i + 1, -1), (offs[1], lens[1], vb_i + 2, -1), (offs[2], lens[2], vb_i + 3, 0), (offs[3], lens[3], vb_i + 4, 1)]
         vb_i += 4
         got = F.zip_vblocks(text, vbs)
-        want, zstate = fastq_zip_expected(oracle, plan, text, vbs, zstate)
+        want, zstate = fastq_zip_expected(oracle, plan, text, vbs, zstate, host=host)
         for v, (g, w) in enumerate(zip(got, want)):
             assert g["n_bases"] == w["n_bases"] and g["seq_has_x"] == w["seq_has_x"], (call, v)
             assert g["seq_packed"] == w["seq_packed"], (call, v, "packed SEQ")
             assert g["z"] == w["z"], (call, v, len(g["z"]), len(w["z"]), _first_diff(g["z"], w["z"]))
             assert g["seq_section_index"] == w["seq_section_index"], (call, v, g["seq_section_index"], w["seq_section_index"])
         # every read name, reconstructed from the item contexts' sections and the dictionaries alone
-        assert check_qnames(F, plan, text, vbs, got, lambda codec, pay, ulen: bytes(pay) if codec == 1 else oracle.codec_uncompress(codec, pay, ulen)) == sum(g["n_reads"] for g in got)
-        # round trip of what was written
-        for v, g in enumerate(got):
+        assert check_qnames(F, plan, text, vbs, got, dec) == sum(g["n_reads"] for g in got)
+        # round trip of what was written (the device does not decode the host's codecs)
+        for v, g in enumerate(got if not host else []):
             z = g["z"]
             total, at = 0, 84
             while at < len(z):
@@ -966,7 +977,7 @@ def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0
     # N4: VBlocks + global area, read back by the independent reader of tests/gz_reader.py
     import gz_reader
     blob = F.write_file([dict(name=b"reads.fq", pair=0, vbs=got)], counts_ctxs=(3,))
-    R = gz_reader.read_file(blob, lambda codec, pay, ulen: bytes(pay) if codec == 1 else oracle.codec_uncompress(codec, pay, ulen))
+    R = gz_reader.read_file(blob, dec)
     n_lines = sum(g["n_reads"] for g in got)
     # (the reader byte-swaps the 48-bit field as if it were 64 bits wide, src/zfile.c:965: counts lose their low 16 bits)
     assert R["version"] == (15, 86) and R["data_type"] == 3 and R["num_lines"] == (n_lines & ~0xffff) and R["created"] == b"genozip_amd"
@@ -1686,7 +1697,7 @@ def sam_zip(E, oracle, n_reads, n_calls=2, qual="bin", aux=True, via_bam=False, 
         vbs = [(0, cut, vb_i + 1, -1), (cut, len(text) - cut, vb_i + 2, -1)]
         vb_i += 2
         got = F.zip_vblocks(text, vbs)
-        want, zstate = fastq_zip_expected(oracle, plan, text, vbs, zstate)
+        want, zstate = fastq_zip_expected(oracle, plan, text, vbs, zstate, host=host)
         for v, (g, w) in enumerate(zip(got, want)):
             assert g["n_bases"] == w["n_bases"] and g["seq_has_x"] == w["seq_has_x"] and g["seq_packed"] == w["seq_packed"], (call, v)
             assert g["z"] == w["z"], (call, v, len(g["z"]), len(w["z"]), _first_diff(g["z"], w["z"]))

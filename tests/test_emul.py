@@ -141,6 +141,8 @@ def test_emul_assign_sort(emul_engine, oracle):
 
 def test_emul_fastq_zip_host_codecs(emul_engine, oracle):
     parity.fastq_zip_host_codecs(emul_engine, oracle, 240)
+    # a paired file: R2 sections identical to R1's are dropped whatever their codec; BZ2 cheap, LZMA dear
+    parity.fastq_zip(emul_engine, oracle, 60, host=parity.host_codecs_for_tests(clock_bz2=100.0, clock_lzma=20000.0))
 
 
 def test_emul_fastq_zip_two_in_flight(emul_engine, oracle):

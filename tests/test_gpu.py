@@ -134,6 +134,7 @@ def test_assign_sort_and_host_codecs(gpu_engine, oracle):
     parity.assign_sort(gpu_engine, oracle)
     used = parity.fastq_zip_host_codecs(gpu_engine, oracle, 3000)
     assert 3 in used or 4 in used
+    parity.fastq_zip(gpu_engine, oracle, 2500, host=parity.host_codecs_for_tests(clock_bz2=100.0, clock_lzma=20000.0))
     data = bytes(range(256)) * 40 + b"ACGT" * 20000
     c, table = gpu_engine.assign_best_ex(data, extra=[(3, 600.0, 200.0), (4, 500.0, 40000.0)])
     oc = oracle.assign_best_with(data, [(3, 600.0 - 28, 200.0), (4, 500.0 - 28, 40000.0)])
