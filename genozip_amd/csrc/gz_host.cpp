@@ -79,7 +79,7 @@ struct GzHandle {
     std::vector<Pending> pending;
     std::vector<void *> host_tmp;      // host staging to free at sync
     GzLogTable *d_logs;
-    GzDivInv *d_magic;        // the reciprocal of every possible model total (division by multiplication in the chain)
+    GzDivInv *d_inv_tab;        // the reciprocal of every possible model total (division by multiplication in the chain)
     std::string err;
     size_t arena_block_size;
     // optional per-kernel timing with HIP events on this handle's stream (bench.py's roofline object)
@@ -161,7 +161,7 @@ static GzHandle *gz_create_do (int device, void *hip_stream, int *err, bool back
     }
     if (hipSetDevice (device) != hipSuccess) { if (err) *err = GZ_ERR_HIP; return NULL; }
     GzHandle *h = new GzHandle ();
-    h->device = device; h->d_logs = NULL; h->d_magic = NULL; h->background = background;
+    h->device = device; h->d_logs = NULL; h->d_inv_tab = NULL; h->background = background;
     h->arena_block_size = (size_t)256 << 20;
     int prio_lo0 = 0, prio_hi0 = 0;
     if (hipDeviceGetStreamPriorityRange (&prio_lo0, &prio_hi0) != hipSuccess) prio_lo0 = prio_hi0 = 0;
@@ -213,8 +213,8 @@ static GzHandle *gz_create_do (int device, void *hip_stream, int *err, bool back
             uint64_t bits; memcpy (&bits, &inv, 8);
             mt[dv].lo = (uint32_t)bits; mt[dv].hi = (uint32_t)(bits >> 32);
         }
-        if (hipMalloc ((void **)&h->d_magic, N * sizeof (GzDivInv)) != hipSuccess ||
-            hipMemcpy (h->d_magic, mt.data (), N * sizeof (GzDivInv), hipMemcpyHostToDevice) != hipSuccess) {
+        if (hipMalloc ((void **)&h->d_inv_tab, N * sizeof (GzDivInv)) != hipSuccess ||
+            hipMemcpy (h->d_inv_tab, mt.data (), N * sizeof (GzDivInv), hipMemcpyHostToDevice) != hipSuccess) {
             if (err) *err = GZ_ERR_HIP;
             gz_destroy (h);
             return NULL;
@@ -246,7 +246,7 @@ extern "C" void gz_destroy (GzHandle *h)
     for (auto &b : h->blocks) (void)hipFree (b.base);
     for (auto p : h->host_tmp) free (p);
     (void)hipFree (h->d_logs);
-    (void)hipFree (h->d_magic);
+    (void)hipFree (h->d_inv_tab);
     (void)hipFree (h->d_fail);
     if (h->own_stream) (void)hipStreamDestroy (h->stream);
     (void)hipStreamDestroy (h->stream2);
@@ -681,7 +681,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
             KLAUNCH_ON (h, side, k_rans_encode, dim3 (nl), dim3 (64), GZ_RANS_ENC_LDS, d_leaves);
         }
         if (A.np) {
-            const GzDivInv *magic = (const GzDivInv *)h->d_magic;
+            const GzDivInv *inv_tab = (const GzDivInv *)h->d_inv_tab;
             const uint32_t grid_y = GZ_MODEL_GRID_Y + (P.rle_list.empty () ? 0 : GZ_MODEL_GRID_RUN);
             if (!P.rle_list.empty ())                              // the run-length variant's coding events (before anything looks at arith_n)
                 KLAUNCH (h, k_rle_events, dim3 ((uint32_t)P.rle_list.size ()), dim3 (1024), 256, d_leaves, A.d_rle);
@@ -696,7 +696,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
             };
             if (!A.pipelined) {
                 if ((rc = sort_chunk (h->stream, A.d_plain, A.np, 0u, 0xffffffffu, P.max_arith_n)) != GZ_OK) return rc;
-                KLAUNCH (h, k_arith_model, dim3 (A.np, grid_y), dim3 (64), GZ_MLDS_OFF + GZ_MLDS_BYTES, d_leaves, A.d_plain, magic, 0u, 0xffffffffu);
+                KLAUNCH (h, k_arith_model, dim3 (A.np, grid_y), dim3 (64), GZ_MLDS_OFF + GZ_MLDS_BYTES, d_leaves, A.d_plain, inv_tab, 0u, 0xffffffffu);
                 KLAUNCH (h, k_arith_chain, dim3 ((A.np + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), 64,
                          d_leaves, A.d_plain, A.np, (const uint32_t *)NULL, 0u, h->d_fail, (uint32_t *)NULL, 0u);
             }
@@ -717,7 +717,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                     if ((rc = sort_chunk (sort_stream, A.d_big, A.nbig, p0, A.chunk, span)) != GZ_OK) return rc;
                     HIPCHK (h, hipEventRecord (h->ev_sort[k], sort_stream));
                     HIPCHK (h, hipStreamWaitEvent (h->stream4, h->ev_sort[k], 0));
-                    KLAUNCH_ON (h, h->stream4, k_arith_model, dim3 (A.nbig, grid_y), dim3 (64), GZ_KEEP_OFF_LDS, d_leaves, A.d_big, magic, p0, A.chunk);
+                    KLAUNCH_ON (h, h->stream4, k_arith_model, dim3 (A.nbig, grid_y), dim3 (64), GZ_KEEP_OFF_LDS, d_leaves, A.d_big, inv_tab, p0, A.chunk);
                     hipLaunchKernelGGL (k_arith_progress, dim3 (1), dim3 (1), 0, h->stream4, A.d_progress, k + 1);
                 }
 #ifdef GZ_SEQUENTIAL_STREAMS
@@ -729,7 +729,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 if (A.nsmall) {
                     HIPCHK (h, hipStreamWaitEvent (h->stream5, h->ev_model_fork, 0));
                     if ((rc = sort_chunk (h->stream5, A.d_small, A.nsmall, 0u, 0xffffffffu, A.chunk)) != GZ_OK) return rc;
-                    KLAUNCH_ON (h, h->stream5, k_arith_model, dim3 (A.nsmall, grid_y), dim3 (64), GZ_KEEP_OFF_LDS, d_leaves, A.d_small, magic, 0u, 0xffffffffu);
+                    KLAUNCH_ON (h, h->stream5, k_arith_model, dim3 (A.nsmall, grid_y), dim3 (64), GZ_KEEP_OFF_LDS, d_leaves, A.d_small, inv_tab, 0u, 0xffffffffu);
                     KLAUNCH_ON (h, h->stream5, k_arith_chain, dim3 ((A.nsmall + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), GZ_KEEP_OFF_LDS,
                                 d_leaves, A.d_small, A.nsmall, (const uint32_t *)NULL, 0u, h->d_fail, (uint32_t *)NULL, 0u);
                     if (A.nlb_small) {

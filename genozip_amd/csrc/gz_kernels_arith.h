@@ -728,7 +728,7 @@ __device__ unsigned long long g_mph[8];
 #endif
 template <int J, bool LDSM = false>
 __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, uint32_t ms, bool o1, uint4 *recs,
-                                                   const GzDivInv *magic_tab, const uint8_t *symlist, const uint16_t *symrank, uint32_t nsym,
+                                                   const GzDivInv *inv_tab, const uint8_t *symlist, const uint16_t *symrank, uint32_t nsym,
                                                    const uint32_t *spos, const uint8_t *srk, uint32_t j0, uint32_t j1, bool first, bool save, uint32_t *st,
                                                    const GzLocalAlpha *la = nullptr)
 {
@@ -763,7 +763,7 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
 
     // the records of a batch are stored while the next batch is being worked on: the division constants they need come
     // from a table in memory, and waiting for that load at the end of every batch would cost more than the batch
-    uint32_t p_pos = 0, p_cum = 0, p_freq = 0; GzDivInv p_mg = { 0, 0 }; bool p_on = false;
+    uint32_t p_pos = 0, p_cum = 0, p_freq = 0; GzDivInv p_inv = { 0, 0 }; bool p_on = false;
     // ... and the occurrences of the following batches are fetched while this one is being worked on. The raw loads (sorted position +
     // rank byte, or the input byte of an order-0 leaf) run FOUR TO EIGHT batches ahead: a batch without events is ~300 ns of work, a trip
     // to memory 1-2 us, so one batch ahead (as it was) left a context whose order is stable waiting for its next occurrences most of the
@@ -814,9 +814,9 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
         } \
         uint32_t out_cum = 0, out_freq = 0, out_tot = 0, n_ev = 0;
 #define GZ_WAVE_BATCH_TAIL \
-        if (p_on) d_record_store (recs + p_pos, d_model_record (p_cum, p_freq, p_mg)); \
+        if (p_on) d_record_store (recs + p_pos, d_model_record (p_cum, p_freq, p_inv)); \
         p_on = occ; p_pos = b_pos; p_cum = out_cum; p_freq = out_freq; \
-        if (occ) p_mg = magic_tab[out_tot];
+        if (occ) p_inv = inv_tab[out_tot];
     for (uint32_t j = j0; j < j1; ) {
         for (; j < j1 && !through_lds; j += 64) {
             GZ_WAVE_BATCH_HEAD
@@ -858,7 +858,7 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
     }
 #undef GZ_WAVE_BATCH_HEAD
 #undef GZ_WAVE_BATCH_TAIL
-    if (p_on) d_record_store (recs + p_pos, d_model_record (p_cum, p_freq, p_mg));
+    if (p_on) d_record_store (recs + p_pos, d_model_record (p_cum, p_freq, p_inv));
 #ifdef GZ_MODEL_PHASES
     if (!lane && j1 - j0 >= GZ_MODEL_HOT) { for (int k = 0; k < 7; k++) atomicAdd (&g_mph[k], mph_[k]); atomicAdd (&g_mph[7], 1ull); }
 #endif
@@ -898,7 +898,7 @@ __device__ unsigned long long g_model_slowest;     // (10 ns ticks << 40) | (lis
 #define GZ_MODEL_T0 do {} while (0)
 #define GZ_MODEL_T1(ctx, occ) do {} while (0)
 #endif
-__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, const GzDivInv *magic_tab, uint32_t p0, uint32_t chunk)
+__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, const GzDivInv *inv_tab, uint32_t p0, uint32_t chunk)
 {
     GzdLeaf &L = leaves[list[blockIdx.x]];
     if (!L.active || L.engine != GZ_ENG_ARITH || L.arith_n <= p0) return;
@@ -928,7 +928,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
             const uint32_t ctx = 256 + k;
             const uint32_t j0 = d_uniform (off[(size_t)t0 * nctx + ctx]), j1 = d_uniform (cend[ctx]);
             if (j0 == j1 && p0) continue;
-            d_arith_model_wave<1> (coded, 4u, true, tr, magic_tab, digits, L.symrank, 4u, spos, srk, j0, j1, p0 == 0, p1 < n_u,
+            d_arith_model_wave<1> (coded, 4u, true, tr, inv_tab, digits, L.symrank, 4u, spos, srk, j0, j1, p0 == 0, p1 < n_u,
                                    mstate + (size_t)ctx * (GZ_MSTATE_WORDS * 64));
         }
         return;
@@ -946,7 +946,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
         uint32_t j0 = p0, j1 = p1;
         if (sorted) { j0 = d_uniform (off[(size_t)t0 * nctx + ctx]); j1 = d_uniform (cend[ctx]); }   // my run of the sorted lists
         GZ_MODEL_T0;
-        d_arith_model_wave<1> (coded, ms_u, sorted, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        d_arith_model_wave<1> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
         GZ_MODEL_T1 (ctx, j1 - j0);
         return;
     }
@@ -963,7 +963,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
             uint8_t *lds_flags = gz_lds, *lds_list = gz_lds + 256;
             const uint32_t nd = d_local_alphabet (la, coded, sorted, srk, L.symrank, L.symlist, j0, j1, lds_flags, lds_list);
             if (nd <= 64) {
-                d_arith_model_wave<1> (coded, ms_u, sorted, tr, magic_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, true, false, st, &la);
+                d_arith_model_wave<1> (coded, ms_u, sorted, tr, inv_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, true, false, st, &la);
                 GZ_MODEL_T1 (ctx, j1 - j0);
                 continue;
             }
@@ -981,14 +981,14 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
                 #pragma unroll
                 for (int k = 0; k < 4; k++) if ((la.m[k] >> (threadIdx.x & 63)) & 1) lds_list[d_local_rank (la, (uint32_t)(k * 64 + (threadIdx.x & 63)))] = L.symlist[k * 64 + (threadIdx.x & 63)];
                 __syncthreads ();
-                if (nd <= 64) d_arith_model_wave<1> (coded, ms_u, sorted, tr, magic_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, &la);
-                else          d_arith_model_wave<2> (coded, ms_u, sorted, tr, magic_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, &la);
+                if (nd <= 64) d_arith_model_wave<1> (coded, ms_u, sorted, tr, inv_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, &la);
+                else          d_arith_model_wave<2> (coded, ms_u, sorted, tr, inv_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, &la);
                 GZ_MODEL_T1 (ctx, j1 - j0);
                 continue;
             }
         }
-        if (nsym_u <= 128) d_arith_model_wave<2, true> (coded, ms_u, sorted, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
-        else               d_arith_model_wave<4, true> (coded, ms_u, sorted, tr, magic_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        if (nsym_u <= 128) d_arith_model_wave<2, true> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        else               d_arith_model_wave<4, true> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
         GZ_MODEL_T1 (ctx, j1 - j0);
     }
 }
