@@ -52,6 +52,16 @@ def test_assign_sorter_of_the_real_library(real_lib, oracle):
             assert (w, [(t.codec, t.size, t.clock_us) for t in tab]) == oracle.assign_sort(tests, mode), (mode, tests)
 
 
+def test_chain_loop_header_is_what_its_generator_writes(tmp_path):
+    """genozip_amd/csrc/gz_chain_asm.h (the range coder chain's inner loop, one inline-asm statement) is generated: the committed file
+    must be what tools/gen_chain_asm.py writes today"""
+    import subprocess
+    import sys
+    out = tmp_path / "gz_chain_asm.h"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_chain_asm.py"), str(out)], check=True)
+    assert out.read_text() == open(os.path.join(ROOT, "genozip_amd", "csrc", "gz_chain_asm.h")).read()
+
+
 def test_no_cpu_fallback(real_lib):
     import torch
     if torch.cuda.is_available():

@@ -1,13 +1,14 @@
 // micro-benchmark + exactness check: the range coder's serial recurrence
 //      r = range / tot ;  range = (r * freq) << 8k
-// as FOUR dependent vector instructions in double precision instead of seven scalar integer ones:
-//      t  = fma (R, inv, 2^52)          round toward zero: t = 2^52 + floor (R * inv), inv = RU (2^7 / tot), R = range * 2^-7
-//      rd = t - 2^52                    exact: r as a double
-//      P  = rd * F                      F = freq * 2^-7 (exact: P = r * freq * 2^-7 < 2^25)
-//      hi(P) = (hi(P) & 0x007fffff) | 0x41000000     the exponent's low 3 bits stay, the rest becomes 2^(24..31) * 2^-7:
-//                                                    that IS "shift left by whole bytes until >= 2^24" (P >= 2^8 always)
-// Operands arrive in scalar registers (s_load of 16-byte records {inv, F}) like the chain kernel's.
-// build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/ubench_chain_f64.hip -o /tmp/ubench_f64
+// in double precision instead of seven scalar integer instructions. What is measured here (profiles/round4_ubench_chain_f64.txt):
+//   * k_chain_hop    the product's loop (genozip_amd/csrc/gz_chain_asm.h, written by tools/gen_chain_asm.py): three dependent vector
+//                    instructions per symbol, operands held by the lanes, the state hopping from lane to lane - its checkpoints and final
+//                    range against the integer recurrence computed on the host (two data sets: one with 2 % of the totals below 256),
+//                    clocks per symbol with 1 / 50 / 64 chains on the device
+//   * k_chain_f64    a compiler-scheduled four-instruction form with scalar-register operands (how it started: exact, but its
+//                    scalar loads cannot be waited for one at a time)
+//   * k_chain_int    rounds 1-3's integer form, scalar operands, without the L2 touch of the product's old loop
+// build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -I tools tools/ubench_chain_f64.hip -o tools/ubench_f64.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
