@@ -29,6 +29,29 @@ def codec_edge_cases(E, oracle, max_n, decode=True, thin_from=None):
                 assert b == d, "codec %d %s: round trip" % (codec, name)
 
 
+def chain_block_boundaries(E, oracle, big=True):
+    """the arithmetic coders around the sizes the range coder chain branches on: its loop takes blocks of 512 symbols (the rest of a
+    leaf goes symbol by symbol), position chunks are multiples of 4096 and at least 65536, striped codecs cut a stream into four
+    planes, PACK into a quarter or half of the bytes; small totals (a context's first occurrences) anywhere"""
+    ns = [511, 512, 513, 1024, 1025, 4095, 4096, 4097, 8703]                  # (the emulated build is slow: the GPU run takes more)
+    if big:
+        ns += [1023, 1536, 2047, 2048, 2049, 8191, 8192, 65535, 65536, 65537, 66048, 131071, 131072, 131073, 131584, 196608 + 511, 262144 + 512 * 3 + 1, (1 << 20) + 300]
+    items, names = [], []
+    seed = 9100
+    for n in ns:
+        for kind, nsym in (("markov", 40), ("uniform", 256), ("skew", 5), ("u32be", 256), ("runs", 8)) if big else (("markov", 40), ("u32be", 256), ("skew", 5)):
+            seed += 1
+            d = synth.stream(kind, seed, n, nsym).tobytes()
+            for codec in (16, 17, 18, 19):
+                if n > 200000 and (codec, kind) not in ((16, "markov"), (17, "u32be"), (18, "skew"), (19, "runs"), (16, "uniform")):
+                    continue
+                items.append((codec, d)); names.append((codec, kind, n))
+    got = E.compress_many(items)
+    for (codec, d), g, nm in zip(items, got, names):
+        assert g == oracle.codec_compress(codec, d), nm
+    return len(items)
+
+
 def host_call_surface(E, oracle):
     """the COMPRESS()/UNCOMPRESS() shaped single calls incl. the soft-fail convention (compressor.c:89-110)"""
     data = synth.markov_bytes(9, 3000, 40, 33).tobytes()

@@ -135,6 +135,10 @@ def test_emul_fastq_zip_speculation(emul_engine, oracle):
     parity.fastq_zip_speculation(emul_engine, oracle, 42)
 
 
+def test_emul_chain_block_boundaries(emul_engine, oracle):
+    parity.chain_block_boundaries(emul_engine, oracle, big=False)
+
+
 def test_emul_assign_sort(emul_engine, oracle):
     parity.assign_sort(emul_engine, oracle, rounds=1500)
 

@@ -20,6 +20,10 @@ def test_native_library_is_the_one_running(gpu_engine):
     assert "libgenozip_amd.so" in maps and "libgenozip_amd_emul" not in maps.replace("libgenozip_amd.so", "")
 
 
+def test_chain_block_boundaries(gpu_engine, oracle):
+    assert parity.chain_block_boundaries(gpu_engine, oracle) > 300
+
+
 def test_codec_edge_cases(gpu_engine, oracle):
     parity.codec_edge_cases(gpu_engine, oracle, max_n=300007)
 
