@@ -1720,7 +1720,7 @@ def sam_zip(E, oracle, n_reads, n_calls=2, qual="bin", aux=True, via_bam=False, 
         vbs = [(0, cut, vb_i + 1, -1), (cut, len(text) - cut, vb_i + 2, -1)]
         vb_i += 2
         got = F.zip_vblocks(text, vbs)
-        want, zstate = fastq_zip_expected(oracle, plan, text, vbs, zstate, host=host)
+        want, zstate = fastq_zip_expected(oracle, plan, text, vbs, zstate)
         for v, (g, w) in enumerate(zip(got, want)):
             assert g["n_bases"] == w["n_bases"] and g["seq_has_x"] == w["seq_has_x"] and g["seq_packed"] == w["seq_packed"], (call, v)
             assert g["z"] == w["z"], (call, v, len(g["z"]), len(w["z"]), _first_diff(g["z"], w["z"]))
