@@ -397,7 +397,8 @@ def test_streamed_wgs_share(gpu_engine, oracle):
     """BASELINE configs[4] at ONE GPU's full share: 600 M reads over 8 GPUs = 75 M read pairs = 55 GB of FASTQ text per GPU, streamed
     through ONE file object in calls of 112 VBlock pairs (3.76 GB of NEW text per call - the generator continues the read numbering,
     nothing is re-used), vblock_i as the reader wants them (R1 1..N, R2 N+1..2N). Per call: every VBlock's header names its own length
-    and number, sections in (DEP level, did_i) order, every section's adler32 and the QUAL round trip of the first and last VBlock;
+    and number, sections in (DEP level, did_i) order (16 of the 224 VBlocks read back, the others counted), every section's adler32
+    and - in the first and the last call - the QUAL round trip of the first and last VBlock;
     over the calls: the codecs of the first call hold, the dictionaries only grow, every read is accounted for.
     GZ_TEST_WGS_CALLS: fewer calls (default: the whole share)"""
     import os
@@ -416,20 +417,25 @@ def test_streamed_wgs_share(gpu_engine, oracle):
             at = 0
             for mate in (1, 2):
                 for r0, m_reads in wl.ranges:
-                    for c0 in range(0, m_reads, 100000):
-                        m = min(100000, m_reads - c0)
+                    for c0 in range(0, m_reads, 1000000):           # (whole VBlocks at a time)
+                        m = min(1000000, m_reads - c0)
                         wl.text[at + c0 * W.RECORD_BYTES: at + (c0 + m) * W.RECORD_BYTES] = W.fastq_text(1, call * reads_per_call + r0 + c0, m, mate=mate, profile="div", xp=th)
                     at += m_reads * W.RECORD_BYTES
             torch.cuda.synchronize()
             for t in wl.tab:
                 t.vblock_i += len(wl.ranges)
         zip_vblocks_sharded(F, None, wl.text, wl.text_len, wl.tab, n)
-        res = F.results(wl.tab)
-        z_all = [r["z"] for r in res]
+        # 16 of the call's 224 VBlocks are read back and taken apart (all of them: 1.4 GB per call through the host - the test's time),
+        # the others are counted
+        pick = sorted({0, 1, n // 2 - 1, n // 2, n - 2, n - 1} | {(7 * call + 13 * k) % n for k in range(10)})
         vb_now = [(o, l, int(t.vblock_i), r1) for (o, l, _, r1), t in zip(wl.vb, wl.tab)]
         assert [v[2] for v in vb_now[:2]] == [call * 112 + 1, call * 112 + 2] and vb_now[112][2] == wl.n_pairs_file + call * 112 + 1
-        wl_view = type("V", (), dict(W=W, plan=wl.plan, text=wl.text, text_len=wl.text_len, vb=vb_now))
-        _check_vblocks(gpu_engine, oracle, bench, wl_view, z_all, {0, n - 1})
+        assert all(t.status == 1 and t.z_len > 84 for t in wl.tab)          # (GZ_OK)
+        z_all = [F._download(wl.tab[v].z_data, wl.tab[v].z_len) for v in pick]
+        res = [dict(n_reads=int(t.n_reads)) for t in wl.tab]
+        wl_view = type("V", (), dict(W=W, plan=wl.plan, text=wl.text, text_len=wl.text_len, vb=[vb_now[v] for v in pick]))
+        # (the device decodes a 6.8 M-symbol QUAL section in ~5 s - one wave, section 3 of DESIGN.md: the round trip in the first and the last call)
+        _check_vblocks(gpu_engine, oracle, bench, wl_view, z_all, {0, len(pick) - 1} if call in (0, n_calls - 1) else set())
         codecs = {(s[0], s[2]): s[1] for z in z_all for s in bench.walk_sections(z) if s[3] >= 50}
         if codecs_first is None:
             codecs_first = codecs
@@ -438,7 +444,7 @@ def test_streamed_wgs_share(gpu_engine, oracle):
         w = len(F.zctx_words(3))
         assert w >= words
         words = w
-        reads += sum(r["n_reads"] for r in res); text_bytes += wl.text_len; z_bytes += sum(len(z) for z in z_all)
+        reads += sum(r["n_reads"] for r in res); text_bytes += wl.text_len; z_bytes += sum(int(t.z_len) for t in wl.tab)
     assert reads == 2 * reads_per_call * n_calls and text_bytes == reads * W.RECORD_BYTES
     if n_calls == wl.calls_per_step:
         assert reads >= 2 * 75000000 and text_bytes > 54e9
