@@ -902,6 +902,10 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
 {
     GzdLeaf &L = leaves[list[blockIdx.x]];
     if (!L.active || L.engine != GZ_ENG_ARITH || L.arith_n <= p0) return;
+    // (the blocks of the column that have no model to run - most of them, for a leaf of order 0 or with a small alphabet - leave before
+    //  anything is made wave-uniform: the same tests as below)
+    if (blockIdx.y >= GZ_MODEL_GRID_Y) { if (!L.rle) return; }
+    else if (L.nsym <= 64 && blockIdx.y && (!L.o1 || blockIdx.y > L.nsym)) return;
     const uint32_t ms = L.max_sym;
     const bool o1 = L.o1, rle = L.rle;
     uint4 *tr = d_uniform_ptr ((uint4 *)L.triples);

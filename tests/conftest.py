@@ -13,6 +13,17 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.pa
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running CPU test")
+    config.addinivalue_line("markers", "thorough: a further variant of a CPU-emulated check that the default run leaves out to stay within "
+                                       "minutes (GZ_TEST_THOROUGH=1 runs them; the GPU suite runs the same checks at full size anyway)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("GZ_TEST_THOROUGH"):
+        return
+    skip = pytest.mark.skip(reason="thorough variant: GZ_TEST_THOROUGH=1")
+    for it in items:
+        if "thorough" in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

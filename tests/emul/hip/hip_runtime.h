@@ -91,7 +91,7 @@ __asm__ (
     ".size emu_switch,.-emu_switch\n");
 
 enum { EMU_RUN = 0, EMU_WAIT_BLOCK = 1, EMU_WAIT_WAVE = 2, EMU_DONE = 3 };
-struct EmuFiber { void *sp; int state; };
+struct EmuFiber { void *sp; int state; unsigned shfl_parity; };
 struct EmuWave { unsigned alive, arrived; unsigned long long result; uint8_t slot[64]; };
 struct EmuSched {
     static const unsigned MAXT = 1024;
@@ -159,7 +159,7 @@ static inline void emu_launch (dim3 grid, dim3 block, size_t shmem, const std::f
             top[-2] = (void *)emu_fiber_entry;          // `ret` of the first switch lands here
             for (int k = 3; k <= 8; k++) top[-k] = nullptr;   // rbp rbx r12 r13 r14 r15
             emu.f[t].sp = (void *)(top - 8);
-            emu.f[t].state = EMU_RUN;
+            emu.f[t].state = EMU_RUN; emu.f[t].shfl_parity = 0;
         }
         memset (gz_lds, 0x5A, shmem + 64 < sizeof (gz_lds) ? shmem + 64 : sizeof (gz_lds));   // LDS is not zeroed
         for (;;) {
@@ -181,9 +181,9 @@ static inline void emu_launch (dim3 grid, dim3 block, size_t shmem, const std::f
 #include <string>
 #include <chrono>
 struct EmuProfile {
-    std::map<std::string, std::pair<double, unsigned long>> t; bool on;
+    std::map<std::string, std::pair<double, unsigned long>> t; std::map<std::string, unsigned long long> thr; bool on;
     EmuProfile () { const char *e = getenv ("EMU_PROFILE"); on = e && *e && *e != '0'; }
-    ~EmuProfile () { if (on) for (auto &k : t) fprintf (stderr, "[emu] %-28s %9.3f s  %8lu launches\n", k.first.c_str (), k.second.first, k.second.second); }
+    ~EmuProfile () { if (on) for (auto &k : t) fprintf (stderr, "[emu] %-28s %9.3f s  %8lu launches %12llu threads\n", k.first.c_str (), k.second.first, k.second.second, thr[k.first]); }
 };
 static EmuProfile emu_profile;
 static inline void emu_launch_named (const char *name, dim3 grid, dim3 block, size_t shmem, const std::function<void ()> &body)
@@ -193,6 +193,7 @@ static inline void emu_launch_named (const char *name, dim3 grid, dim3 block, si
     emu_launch (grid, block, shmem, body);
     auto &e = emu_profile.t[name];
     e.first += std::chrono::duration<double> (std::chrono::steady_clock::now () - t0).count (); e.second++;
+    emu_profile.thr[name] += (unsigned long long)grid.x * grid.y * grid.z * block.x * block.y * block.z;
 }
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
     emu_launch_named (#kern, (grid), (block), (shmem), [=] () { kern (__VA_ARGS__); })
@@ -229,15 +230,16 @@ static inline unsigned long long __ballot (int pred)
 }
 
 // wave-wide exchange: every live lane deposits a value, then reads the source lane's
+// (two sets of slots taking turns: a lane that is through one exchange deposits for the next in the other set, and cannot get to the
+//  one after that - the first set again - before every lane has arrived at the next, i.e. has read this one: ONE barrier per exchange)
 static inline int emu_shfl (int v, int src)
 {
     unsigned me = emu.cur, w = me / 64;
-    static int slots[EmuSched::MAXT];
-    slots[me] = v;
+    static int slots[2][EmuSched::MAXT];
+    const unsigned par = emu.f[me].shfl_parity; emu.f[me].shfl_parity ^= 1;
+    slots[par][me] = v;
     (void)__ballot (0);                     // all lanes have deposited
-    int r = slots[w * 64 + (src & 63)];
-    (void)__ballot (0);                     // all lanes have read
-    return r;
+    return slots[par][w * 64 + (src & 63)];
 }
 #define __builtin_amdgcn_readlane(v, lane) emu_shfl ((v), (lane))
 #define __shfl(v, lane) emu_shfl ((v), (lane))

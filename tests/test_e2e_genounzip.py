@@ -80,12 +80,12 @@ def _cut(text, n_parts):
     return [(a, b - a) for a, b in zip(cuts, cuts[1:])]
 
 
-@pytest.mark.parametrize("qual,dirty", [("uniform", False), ("uniform", True), ("bin", False)])
+@pytest.mark.parametrize("qual,dirty", [pytest.param("uniform", False, marks=pytest.mark.thorough), ("uniform", True), ("bin", False)])
 def test_single_file_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, qual, dirty):
     """one FASTQ file, 3 VBlocks in 2 calls (the second clones the first's dictionaries): reads of different lengths, N bases
     (NONREF_X), binned scores (the file goes through CODEC_DOMQ)"""
     from genozip_amd import fastq as fq
-    text = parity.fastq_text(900, seed=41, mate=1, qual=qual, dirty_seq=dirty)
+    text = parity.fastq_text(450, seed=41, mate=1, qual=qual, dirty_seq=dirty)
     parts = _cut(text, 3)
     plan = fq.illumina_plan(paired=False)
     F, vbs = _zip(emul_engine, plan, [(text, [(parts[0][0], parts[0][1], 1, -1)]), (text, [(parts[1][0], parts[1][1], 2, -1), (parts[2][0], parts[2][1], 3, -1)])], lzma_sub)
@@ -102,8 +102,8 @@ def test_paired_files_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, qua
     """--pair: R1 and R2 as two components of one file (R1's VBlocks 1..n, R2's n+1..2n: the reader pairs vblock_i with vblock_i - n,
     src/writer.c:318-322); R2 sections identical to R1's are left out, R1's carry flags.paired (zfile.c:292-294,323-325)"""
     from genozip_amd import fastq as fq
-    r1 = parity.fastq_text(700, seed=51, mate=1, qual=qual)
-    r2 = parity.fastq_text(700, seed=51, mate=2, qual_seed=333, qual=qual, dirty_seq=True)
+    r1 = parity.fastq_text(360, seed=51, mate=1, qual=qual)
+    r2 = parity.fastq_text(360, seed=51, mate=2, qual_seed=333, qual=qual, dirty_seq=True)
     p1, p2 = _cut(r1, 2), _cut(r2, 2)
     text = r1 + r2
     vbs = [(p1[0][0], p1[0][1], 1, -1), (p1[1][0], p1[1][1], 2, -1), (len(r1) + p2[0][0], p2[0][1], 3, 0), (len(r1) + p2[1][0], p2[1][1], 4, 1)]
@@ -118,7 +118,7 @@ def test_paired_files_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, qua
     assert got1 == r1 and got2 == r2, (sorted(os.listdir(tmp_path)), log[:3000])
 
 
-@pytest.mark.parametrize("interleaved", [False, True])
+@pytest.mark.parametrize("interleaved", [False, pytest.param(True, marks=pytest.mark.thorough)])
 def test_streamed_pairs_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, interleaved):
     """the streamed form (BASELINE configs[4]: one file object, several calls, dictionaries and codecs carried from call to call). A v15 FASTQ
     pair has exactly two components (sections.c:832-835) and R2's VBlock is R1's + the number of R1 VBlocks (writer.c:318-322), so the caller
@@ -128,8 +128,8 @@ def test_streamed_pairs_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, i
     plan = fq.illumina_plan(paired=True)
     K, per = 2, 2
     N = K * per
-    r1s = [parity.fastq_text(400, seed=61 + k, mate=1) for k in range(K)]
-    r2s = [parity.fastq_text(400, seed=61 + k, mate=2, qual_seed=444 + k) for k in range(K)]
+    r1s = [parity.fastq_text(200, seed=61 + k, mate=1) for k in range(K)]
+    r2s = [parity.fastq_text(200, seed=61 + k, mate=2, qual_seed=444 + k) for k in range(K)]
     calls = []
     for k in range(K):
         p1, p2 = _cut(r1s[k], per), _cut(r2s[k], per)
@@ -185,7 +185,7 @@ def test_vcf_round_trip(emul_engine, genounzip, tmp_path):
 SAM_HEADER = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:248956422\n@PG\tID:bwa\tPN:bwa\tVN:0.7.17\n"
 
 
-@pytest.mark.parametrize("qual,aux,dirty,header,tags", [("uniform", False, False, b"", False), ("bin", True, True, SAM_HEADER, False), ("uniform", True, True, SAM_HEADER, True)])
+@pytest.mark.parametrize("qual,aux,dirty,header,tags", [pytest.param("uniform", False, False, b"", False, marks=pytest.mark.thorough), ("bin", True, True, SAM_HEADER, False), ("uniform", True, True, SAM_HEADER, True)])
 def test_sam_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, qual, aux, dirty, header, tags):
     """aligned reads as SAM text (BASELINE configs[2]'s shape) through the SAM plan of genozip_amd/sam.py - 4 VBlocks over 2 calls - and the
     reference's decoder gives the text back byte for byte. What that pins beyond the FASTQ / VCF tests: the one-line-record plan's items
@@ -235,10 +235,10 @@ def test_host_codecs_round_trip(emul_engine, genounzip, lzma_sub, tmp_path):
     sections are coded on the host, framed by the library - and the reference's genounzip reads the file back, byte for byte"""
     import bz2
     from genozip_amd import fastq as fq
-    text0 = parity.fastq_text(900, seed=61, mate=1)
+    text0 = parity.fastq_text(450, seed=61, mate=1)
     lines = text0.split(b"\n")
     base = [(lines[3 + 4 * k] * 2)[:200] for k in range(3)]
-    for r in range(900):
+    for r in range(450):
         lines[4 * r + 3] = base[r % 3][:len(lines[4 * r + 1])]
     text = b"\n".join(lines)
     parts = _cut(text, 3)

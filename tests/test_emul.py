@@ -1,6 +1,10 @@
 """CPU: the UNMODIFIED product sources (host orchestrator + kernels), compiled against the CPU stand-in of the HIP
 runtime in tests/emul, checked against the oracle on small inputs. Catches logic errors without a GPU; the same
 checks run at full size on the GPU in tests/test_gpu.py."""
+import os
+
+import pytest
+
 import parity
 
 
@@ -149,6 +153,7 @@ def test_emul_fastq_zip_host_codecs(emul_engine, oracle):
     parity.fastq_zip(emul_engine, oracle, 60, host=parity.host_codecs_for_tests(clock_bz2=100.0, clock_lzma=20000.0))
 
 
+@pytest.mark.thorough
 def test_emul_fastq_zip_two_in_flight(emul_engine, oracle):
     parity.fastq_zip_two_in_flight(emul_engine, oracle, 30, n_calls=4)
 
@@ -159,8 +164,13 @@ def test_emul_fastq_zip_errors(emul_engine, oracle):
 
 def test_emul_fastq_zip_domq(emul_engine, oracle):
     """QUAL through CODEC_DOMQ inside the driver: the file's first VBlock decides (binned scores: a fit), later calls follow even
-    with scores that would not fit; forced (--force-domq) on scores that do not fit; refused (--no-domqual) on scores that do"""
+    with scores that would not fit"""
     parity.fastq_zip(emul_engine, oracle, 72, qual=("bin", "uniform"))
+
+
+@pytest.mark.thorough
+def test_emul_fastq_zip_domq_modes(emul_engine, oracle):
+    """forced (--force-domq) on scores that do not fit; refused (--no-domqual) on scores that do; small VBlocks first"""
     parity.fastq_zip(emul_engine, oracle, 36, n_calls=1, qual=("uniform",), domq=13)
     parity.fastq_zip(emul_engine, oracle, 36, n_calls=1, qual=("bin",), domq=1)
     parity.fastq_zip(emul_engine, oracle, 54, qual=("bin", "bin"), small_first=True)
@@ -210,9 +220,13 @@ def test_emul_header_layouts(emul_engine):
 
 def test_emul_sam_zip(emul_engine, oracle):
     """N1 for SAM: configs[2] from text - 4 VBlocks over 2 calls through the one-line-record plan == the oracle's composition"""
-    assert parity.sam_zip(emul_engine, oracle, 500) == 4
+    assert parity.sam_zip(emul_engine, oracle, 200) == 4
+    assert parity.sam_zip(emul_engine, oracle, 120, n_calls=1, qual="uniform", aux=False, via_bam=True) == 2      # (from BAM records)
+
+
+@pytest.mark.thorough
+def test_emul_sam_zip_tags(emul_engine, oracle):
     assert parity.sam_zip(emul_engine, oracle, 400, tags=True) == 4                                                      # (a context per optional field)
-    assert parity.sam_zip(emul_engine, oracle, 300, n_calls=1, qual="uniform", aux=False, via_bam=True) == 2      # (from BAM records)
 
 
 def test_emul_vcf_zip(emul_engine, oracle):

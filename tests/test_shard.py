@@ -134,7 +134,7 @@ def _zip_worker(rank, world, port, n_reads, n_pairs, q, qual="uniform", tiny=Fal
 import pytest
 
 
-@pytest.mark.parametrize("qual,tiny", [("uniform", False), ("bin", False), ("uniform", True)], ids=["uniform", "bin", "tiny"])
+@pytest.mark.parametrize("qual,tiny", [("uniform", False), pytest.param("bin", False, marks=pytest.mark.thorough), ("uniform", True)], ids=["uniform", "bin", "tiny"])
 def test_file_dealt_out_over_2_ranks_equals_one_rank(emul_engine, qual, tiny):
     """the N>1 form of the whole path (strong scaling: ONE file, its VBlock pairs dealt out): every rank segs and compresses its
     own VBlocks through the emulated build, the dictionary merge and the codec choices are exchanged - and every VBlock's z_data
