@@ -689,14 +689,14 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
             auto sort_chunk = [&] (hipStream_t st, const uint32_t *list, uint32_t n_list, uint32_t p0, uint32_t chunk, uint32_t span) -> int {
                 if (!A.no1 || !span) return GZ_OK;
                 const uint32_t tiles = (span + GZ_CTX_TILE - 1) / GZ_CTX_TILE;
-                KLAUNCH_ON (h, st, k_ctx_count, dim3 (n_list, tiles), dim3 (64), GZ_CTX_MAX * 4, d_leaves, list, p0, chunk);
+                KLAUNCH_ON (h, st, k_ctx_count, GZ_XCD_DIM (n_list, tiles), dim3 (64), GZ_CTX_MAX * 4, d_leaves, list, n_list, p0, chunk);
                 KLAUNCH_ON (h, st, k_ctx_scan, dim3 (n_list), dim3 (256), GZ_CTX_MAX * 8, d_leaves, list, p0, chunk);
-                KLAUNCH_ON (h, st, k_ctx_scatter, dim3 (n_list, tiles), dim3 (64), GZ_CTX_MAX * 4 + 256, d_leaves, list, p0, chunk);
+                KLAUNCH_ON (h, st, k_ctx_scatter, GZ_XCD_DIM (n_list, tiles), dim3 (64), GZ_CTX_MAX * 4 + 256, d_leaves, list, n_list, p0, chunk);
                 return GZ_OK;
             };
             if (!A.pipelined) {
                 if ((rc = sort_chunk (h->stream, A.d_plain, A.np, 0u, 0xffffffffu, P.max_arith_n)) != GZ_OK) return rc;
-                KLAUNCH (h, k_arith_model, dim3 (A.np, grid_y), dim3 (64), GZ_MLDS_OFF + GZ_MLDS_BYTES, d_leaves, A.d_plain, inv_tab, 0u, 0xffffffffu);
+                KLAUNCH (h, k_arith_model, GZ_XCD_DIM (A.np, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_plain, A.np, inv_tab, 0u, 0xffffffffu);
                 KLAUNCH (h, k_arith_chain, dim3 ((A.np + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), 64,
                          d_leaves, A.d_plain, A.np, (const uint32_t *)NULL, 0u, h->d_fail, (uint32_t *)NULL, 0u);
             }
@@ -710,14 +710,15 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 //  are short of issue slots, not of waves.)
                 if (A.n_chunks > GZ_MAX_CHUNKS) return GZ_ERR;
                 // (wide alphabets: the symbols that follow each context byte anywhere in the leaf, before the first chunk's models)
-                if (A.no1) KLAUNCH_ON (h, (A.nbig > 256 ? h->stream7 : h->stream4), k_ctx_succ, dim3 (A.nbig, (P.max_arith_n + GZ_SUCC_SPAN - 1) / GZ_SUCC_SPAN), dim3 (256), 8192, d_leaves, A.d_big);
+                static const uint32_t sort_ahead_min = getenv ("GZ_SORT_AHEAD_MIN") ? (uint32_t)atoi (getenv ("GZ_SORT_AHEAD_MIN")) : 256u;
+                hipStream_t sort_stream = A.nbig > sort_ahead_min ? h->stream7 : h->stream4;   // (measured: 702 leaves 84.0 -> 80.6 ms; 176 leaves 33.9 -> 34.2: the sort then only takes compute units from the models)
+                if (A.no1) KLAUNCH_ON (h, sort_stream, k_ctx_succ, dim3 (A.nbig, (P.max_arith_n + GZ_SUCC_SPAN - 1) / GZ_SUCC_SPAN), dim3 (256), 8192, d_leaves, A.d_big);
                 for (uint32_t k = 0; k < A.n_chunks; k++) {
                     const uint32_t p0 = k * A.chunk, span = P.max_arith_n - p0 < A.chunk ? P.max_arith_n - p0 : A.chunk;
-                    hipStream_t sort_stream = A.nbig > 256 ? h->stream7 : h->stream4;   // (measured: 702 leaves 84.0 -> 80.6 ms; 176 leaves 33.9 -> 34.2: the sort then only takes compute units from the models)
                     if ((rc = sort_chunk (sort_stream, A.d_big, A.nbig, p0, A.chunk, span)) != GZ_OK) return rc;
                     HIPCHK (h, hipEventRecord (h->ev_sort[k], sort_stream));
                     HIPCHK (h, hipStreamWaitEvent (h->stream4, h->ev_sort[k], 0));
-                    KLAUNCH_ON (h, h->stream4, k_arith_model, dim3 (A.nbig, grid_y), dim3 (64), GZ_KEEP_OFF_LDS, d_leaves, A.d_big, inv_tab, p0, A.chunk);
+                    KLAUNCH_ON (h, h->stream4, k_arith_model, GZ_XCD_DIM (A.nbig, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_big, A.nbig, inv_tab, p0, A.chunk);
                     hipLaunchKernelGGL (k_arith_progress, dim3 (1), dim3 (1), 0, h->stream4, A.d_progress, k + 1);
                 }
 #ifdef GZ_SEQUENTIAL_STREAMS
@@ -729,7 +730,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 if (A.nsmall) {
                     HIPCHK (h, hipStreamWaitEvent (h->stream5, h->ev_model_fork, 0));
                     if ((rc = sort_chunk (h->stream5, A.d_small, A.nsmall, 0u, 0xffffffffu, A.chunk)) != GZ_OK) return rc;
-                    KLAUNCH_ON (h, h->stream5, k_arith_model, dim3 (A.nsmall, grid_y), dim3 (64), GZ_KEEP_OFF_LDS, d_leaves, A.d_small, inv_tab, 0u, 0xffffffffu);
+                    KLAUNCH_ON (h, h->stream5, k_arith_model, GZ_XCD_DIM (A.nsmall, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_small, A.nsmall, inv_tab, 0u, 0xffffffffu);
                     KLAUNCH_ON (h, h->stream5, k_arith_chain, dim3 ((A.nsmall + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), GZ_KEEP_OFF_LDS,
                                 d_leaves, A.d_small, A.nsmall, (const uint32_t *)NULL, 0u, h->d_fail, (uint32_t *)NULL, 0u);
                     if (A.nlb_small) {

@@ -50,6 +50,19 @@ __device__ static inline uint32_t gz_mbcnt (uint64_t m)
     return __builtin_amdgcn_mbcnt_hi ((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo ((uint32_t)m, 0u));
 }
 
+// inclusive OR over the lanes up to mine, one 32-bit word per lane: shifts inside the rows of 16 lanes (zeros come in at a row's
+// start), then the last lane of row 0 / 2 into row 1 / 3 and lane 31 into rows 2 and 3 (DPP row_shr, row_bcast:15, row_bcast:31)
+__device__ static inline uint32_t gz_wave_or_scan (uint32_t v)
+{
+    v |= (uint32_t)__builtin_amdgcn_update_dpp (0, (int)v, 0x111, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp (0, (int)v, 0x112, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp (0, (int)v, 0x114, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp (0, (int)v, 0x118, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp (0, (int)v, 0x142, 0xa, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp (0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 // drop the scalar data cache (after an acquire, before scalar loads of data another kernel has just written)
 __device__ static inline void gz_scalar_cache_inv (void) { asm volatile ("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : : : "memory"); }
 

@@ -198,6 +198,46 @@ __device__ static __forceinline__ void d_batch_counts (uint32_t p, uint64_t T, u
     }
 }
 
+// The same counts through the LDS: 35 vector instructions per bit of the position went into the ballots above (the per-lane sets P, Q, Pe
+// are 64-bit values: every and / select / popcount is two instructions) - 210 of the ~560 a batch of a quality context costs. Here every
+// pending occurrence ORs its lane bit into the word of its position (one ds_or_b64); a list entry then reads the set of ITS occurrences,
+// an OR-scan over the entries (DPP, gz_wave_or_scan) makes the set of occurrences BELOW every entry, and an occurrence reads the sets of
+// its position, of its left neighbour's and of everything below: the counts are popcounts of those under the mask of the earlier
+// lanes. ~45 vector instructions and three trips to the LDS whatever the alphabet.
+// LDS: s_mask [1 + 64 J] (word 0 stands for "the position left of position 0": nobody), s_low [64 J]
+#define GZ_MLDS_OFF 512                   // (d_model_batch_lds, below)
+#define GZ_MLDS_BYTES 2880
+#define GZ_CNT_OFF   (GZ_MLDS_OFF + GZ_MLDS_BYTES)
+#define GZ_CNT_BYTES (257 * 8 + 256 * 8)
+#define GZ_MODEL_LDS (GZ_CNT_OFF + GZ_CNT_BYTES)
+template <int J>
+__device__ static __forceinline__ void d_batch_counts_lds (uint32_t p, uint64_t T, int lane, uint64_t below,
+                                                           uint32_t &eq, uint32_t &lt, uint32_t &eql, uint32_t (&ceq)[J], uint32_t (&clt)[J])
+{
+    unsigned long long *s_mask = (unsigned long long *)(gz_lds + GZ_CNT_OFF), *s_low = s_mask + 257;
+    #pragma unroll
+    for (int j = 0; j < J; j++) s_mask[1 + j * 64 + lane] = 0;
+    if (!lane) s_mask[0] = 0;
+    gz_wave_sync ();
+    if ((T >> lane) & 1) atomicOr (&s_mask[1 + p], 1ull << lane);
+    gz_wave_sync ();
+    uint32_t run_lo = 0, run_hi = 0;                            // the occurrences at the planes before this one
+    #pragma unroll
+    for (int j = 0; j < J; j++) {
+        const unsigned long long m = s_mask[1 + j * 64 + lane];
+        const uint32_t m_lo = (uint32_t)m, m_hi = (uint32_t)(m >> 32);
+        const uint32_t i_lo = gz_wave_or_scan (m_lo), i_hi = gz_wave_or_scan (m_hi);
+        const uint32_t x_lo = (i_lo ^ m_lo) | run_lo, x_hi = (i_hi ^ m_hi) | run_hi;     // (the sets are disjoint: without mine)
+        ceq[j] = (uint32_t)__popc (m_lo) + (uint32_t)__popc (m_hi);
+        clt[j] = (uint32_t)__popc (x_lo) + (uint32_t)__popc (x_hi);
+        s_low[j * 64 + lane] = ((unsigned long long)x_hi << 32) | x_lo;
+        if (j + 1 < J) { run_lo |= d_readlane (i_lo, 63); run_hi |= d_readlane (i_hi, 63); }
+    }
+    gz_wave_sync ();
+    const unsigned long long me = s_mask[1 + p], lf = s_mask[p], lo = s_low[p];
+    eq = (uint32_t)__popcll (me & below); eql = (uint32_t)__popcll (lf & below); lt = (uint32_t)__popcll (lo & below);
+}
+
 // lanes 0 .. cnt-1 hold the next cnt occurrences of this context in stream order (rk = static rank of the symbol);
 // on return they hold the (cum, freq, tot) the coder must see for them.
 //
@@ -234,7 +274,11 @@ __device__ static __forceinline__ void d_model_batch (GzModel<J> &M, uint32_t &t
             // as an occurrence I count the earlier occurrences at my position / below it / at my left neighbour; as
             // list entries lane + 64 j I count what the whole batch adds to my frequency and cumulative
             uint32_t eq = 0, lt = 0, eql = 0, ceq[J], clt[J];
-            if (J <= 2) d_batch_counts<J> (p, todo, nbits, lane, below, eq, lt, eql, ceq, clt);
+#ifndef GZ_COUNTS_LDS_MAXJ
+#define GZ_COUNTS_LDS_MAXJ 2
+#endif
+            if (J <= GZ_COUNTS_LDS_MAXJ) d_batch_counts_lds<J> (p, todo, lane, below, eq, lt, eql, ceq, clt);
+            else if (J <= 2) d_batch_counts<J> (p, todo, nbits, lane, below, eq, lt, eql, ceq, clt);
             else {
                 // (four planes: 8 bits x 62 operations cost more than a round per distinct position - measured on BAM's packed
                 //  qualities, whose batches hold ~10 distinct positions: 124 -> 134 ms per step with the ballots per bit)
@@ -316,7 +360,7 @@ __device__ static __forceinline__ void d_model_batch (GzModel<J> &M, uint32_t &t
             }
             if (halve_m) {                                                  // commit the prefix only: recount it
                 uint32_t d0, d1, d2;
-                d_batch_counts<J> (p, acc, nbits, lane, below, d0, d1, d2, ceq, clt);
+                d_batch_counts_lds<J> (p, acc, lane, below, d0, d1, d2, ceq, clt);
             }
             if ((acc >> lane) & 1) { out_cum = cu; out_freq = f; out_tot = tj; }
             #pragma unroll
@@ -345,8 +389,6 @@ __device__ static __forceinline__ void d_model_batch (GzModel<J> &M, uint32_t &t
 // registers (entry lane + 64 j): "every entry behind p gains 16" is one compare-and-add per plane there, and a swap needs no other
 // lane's value: cum'[p] = cum[p] - freq[p-1] + freq'[p]. gz_wave_sync between reads and writes: all lanes touch the same words.
 // LDS: bytes 512 .. 3391 of the workgroup's (one wave's) dynamic LDS.
-#define GZ_MLDS_OFF 512
-#define GZ_MLDS_BYTES 2880
 // Which way an eventful batch goes is decided by the CLOCK. Both ways give the same records, so the choice is free: a register batch with
 // >= GZ_MODEL_EVENTS_IN events and every LDS batch are timed (s_memrealtime at the end of every batch - issued, not waited for: only an
 // eventful batch reads it), and the next eventful batch takes the way that was faster the last time it was taken; every
@@ -483,6 +525,17 @@ __device__ static __forceinline__ void d_model_batch_lds (GzModel<J> &M, uint32_
 // own (into entries [p0, p1) of the lists) right before its models run: the sort of chunk k+1 hides behind the chain of chunk k.
 #define GZ_CTX_TILE 4096u
 
+// Workgroups go to the 8 XCDs of the device round robin by their linear id, and every XCD has an L2 of its own. The workgroups of ONE
+// leaf store into the same cache lines - the contexts' waves of the model kernel the 16-byte records of neighbouring positions, the tiles
+// of the sort the ends of the same runs - and partial lines written through different L2s cost both time and traffic (tools/
+// ubench_scatter.hip: records at stride 4 .. 40 - 0.9 TB/s and 2 x the bytes when the neighbours come from other XCDs, 2.9 - 3.4 TB/s
+// and 1.0 - 1.2 x when they share one). So the x extent of a (leaf, y) grid is padded to a multiple of 8: the linear id y * extent +
+// leaf is then congruent to the leaf's index modulo 8 for every y - all workgroups of a leaf sit on one XCD. (The order stays
+// row by row: y = 0 of every leaf first - the busiest contexts are the low ones, and a long pole that starts late is a late step.
+// Tried: 8 leaves x all y as consecutive ids - binned FASTQ 44.1 -> 52.3 ms, BAM 52.7 -> 55.6.)
+#define GZ_XCD_GRID(li, by, n_list) const uint32_t li = blockIdx.x, by = blockIdx.y; if (li >= (n_list)) return
+#define GZ_XCD_DIM(n_list, Y) dim3 ((((uint32_t)(n_list) + 7u) / 8u) * 8u, (uint32_t)(Y))
+
 __device__ static inline bool d_ctx_sorted (const GzdLeaf &L) { return L.active && L.engine == GZ_ENG_ARITH && (L.o1 || L.rle) && L.arith_n; }
 __device__ static inline uint32_t d_ctx_ntiles (uint32_t n) { return (n + GZ_CTX_TILE - 1) / GZ_CTX_TILE; }
 // context (model id) of coding event `pos`: the byte before it, or what k_rle_events wrote down
@@ -492,12 +545,13 @@ __device__ static inline uint32_t d_ctx_of (const GzdLeaf &L, const uint8_t *in,
 }
 #define GZ_CTX_MAX 768                      // LDS counters: 256 contexts, or the 514 models of the run-length variant
 
-// grid (listed leaves, tiles per chunk), 64 threads; positions [p0, p0 + chunk)
-__global__ void __launch_bounds__(64) k_ctx_count (GzdLeaf *leaves, const uint32_t *list, uint32_t p0, uint32_t chunk)
+// grid: GZ_XCD_GRID over (listed leaves, tiles per chunk), 64 threads; positions [p0, p0 + chunk)
+__global__ void __launch_bounds__(64) k_ctx_count (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, uint32_t p0, uint32_t chunk)
 {
-    GzdLeaf &L = leaves[list[blockIdx.x]];
+    GZ_XCD_GRID (li, by, n_list);
+    GzdLeaf &L = leaves[list[li]];
     if (!d_ctx_sorted (L)) return;
-    const uint32_t n = L.arith_n, tile = p0 / GZ_CTX_TILE + blockIdx.y, t0 = tile * GZ_CTX_TILE, nctx = L.nctx;
+    const uint32_t n = L.arith_n, tile = p0 / GZ_CTX_TILE + by, t0 = tile * GZ_CTX_TILE, nctx = L.nctx;
     if (t0 >= n || t0 - p0 >= chunk) return;
     const int lane = threadIdx.x;
     uint32_t *cnt = (uint32_t *)gz_lds;
@@ -537,12 +591,13 @@ __global__ void __launch_bounds__(256) k_ctx_scan (GzdLeaf *leaves, const uint32
     }
 }
 
-// grid (listed leaves, tiles per chunk), 64 threads
-__global__ void __launch_bounds__(64) k_ctx_scatter (GzdLeaf *leaves, const uint32_t *list, uint32_t p0, uint32_t chunk)
+// grid: GZ_XCD_GRID over (listed leaves, tiles per chunk), 64 threads
+__global__ void __launch_bounds__(64) k_ctx_scatter (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, uint32_t p0, uint32_t chunk)
 {
-    GzdLeaf &L = leaves[list[blockIdx.x]];
+    GZ_XCD_GRID (li, by, n_list);
+    GzdLeaf &L = leaves[list[li]];
     if (!d_ctx_sorted (L)) return;
-    const uint32_t n = L.arith_n, tile = p0 / GZ_CTX_TILE + blockIdx.y, t0 = tile * GZ_CTX_TILE, nctx = L.nctx;
+    const uint32_t n = L.arith_n, tile = p0 / GZ_CTX_TILE + by, t0 = tile * GZ_CTX_TILE, nctx = L.nctx;
     if (t0 >= n || t0 - p0 >= chunk) return;
     const int lane = threadIdx.x;
     uint32_t *cnt = (uint32_t *)gz_lds;
@@ -882,7 +937,7 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
 // otherwise cost a million workgroups per launch that exit at once - and the dispatcher, not the work, set the pace).
 #define GZ_MODEL_GRID_Y 65                 // context 0 + one per present symbol of a leaf with up to 64 symbols
 
-// grid (listed leaves, GZ_MODEL_GRID_Y [+ GZ_MODEL_GRID_RUN for lists with run-length leaves])
+// grid: GZ_XCD_GRID over (listed leaves, GZ_MODEL_GRID_Y [+ GZ_MODEL_GRID_RUN for lists with run-length leaves])
 #define GZ_MODEL_GRID_RUN 66               // run models: one per present symbol, 256 and 257
 // (tried: a build of its own for the alphabets of up to 64 symbols - 42 instead of 87 vector registers, 8 instead of 5
 //  waves per SIMD - launched beside one for the wide alphabets: no faster (4 M read pairs: 84.0 -> 86.8 ms per step).
@@ -892,20 +947,21 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
 #ifdef GZ_MODEL_DEBUG
 __device__ unsigned long long g_model_slowest;     // (10 ns ticks << 40) | (list index << 28) | (context << 18) | occurrences / 64
 #define GZ_MODEL_T0 const unsigned long long t_dbg0 = wall_clock64 ()
-#define GZ_MODEL_T1(ctx, occ) do { if (!(threadIdx.x & 63)) atomicMax (&g_model_slowest, ((wall_clock64 () - t_dbg0) << 40) | ((unsigned long long)((blockIdx.x & 0x7ff) | (chunk == 0xffffffffu ? 0x800 : 0)) << 28) | \
+#define GZ_MODEL_T1(ctx, occ) do { if (!(threadIdx.x & 63)) atomicMax (&g_model_slowest, ((wall_clock64 () - t_dbg0) << 40) | ((unsigned long long)((li & 0x7ff) | (chunk == 0xffffffffu ? 0x800 : 0)) << 28) | \
                                    ((unsigned long long)((ctx) & 0x3ff) << 18) | (unsigned long long)((occ) >> 6 > 0x3ffff ? 0x3ffff : (occ) >> 6)); } while (0)
 #else
 #define GZ_MODEL_T0 do {} while (0)
 #define GZ_MODEL_T1(ctx, occ) do {} while (0)
 #endif
-__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, const GzDivInv *inv_tab, uint32_t p0, uint32_t chunk)
+__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const GzDivInv *inv_tab, uint32_t p0, uint32_t chunk)
 {
-    GzdLeaf &L = leaves[list[blockIdx.x]];
+    GZ_XCD_GRID (li, by, n_list);
+    GzdLeaf &L = leaves[list[li]];
     if (!L.active || L.engine != GZ_ENG_ARITH || L.arith_n <= p0) return;
     // (the blocks of the column that have no model to run - most of them, for a leaf of order 0 or with a small alphabet - leave before
     //  anything is made wave-uniform: the same tests as below)
-    if (blockIdx.y >= GZ_MODEL_GRID_Y) { if (!L.rle) return; }
-    else if (L.nsym <= 64 && blockIdx.y && (!L.o1 || blockIdx.y > L.nsym)) return;
+    if (by >= GZ_MODEL_GRID_Y) { if (!L.rle) return; }
+    else if (L.nsym <= 64 && by && (!L.o1 || by > L.nsym)) return;
     const uint32_t ms = L.max_sym;
     const bool o1 = L.o1, rle = L.rle;
     uint4 *tr = d_uniform_ptr ((uint4 *)L.triples);
@@ -922,12 +978,12 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
     const uint64_t *succ = d_uniform_ptr (L.succ);
 
     // ---- the run models of the run-length variant: blocks GZ_MODEL_GRID_Y ... ; 4 symbols, all present from the start
-    if (blockIdx.y >= GZ_MODEL_GRID_Y) {
+    if (by >= GZ_MODEL_GRID_Y) {
         if (!rle_u) return;
         uint8_t *digits = gz_lds;                              // the alphabet { 0, 1, 2, 3 }
         if (threadIdx.x < 4) digits[threadIdx.x] = (uint8_t)threadIdx.x;
         __syncthreads ();
-        for (uint32_t k = blockIdx.y - GZ_MODEL_GRID_Y; k < 258; k += GZ_MODEL_GRID_RUN) {
+        for (uint32_t k = by - GZ_MODEL_GRID_Y; k < 258; k += GZ_MODEL_GRID_RUN) {
             if (k < 256 && L.symrank[k] == 0xffff) continue;   // a byte that never occurs has no runs
             const uint32_t ctx = 256 + k;
             const uint32_t j0 = d_uniform (off[(size_t)t0 * nctx + ctx]), j1 = d_uniform (cend[ctx]);
@@ -941,9 +997,9 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
     if (nsym_u <= 64) {
         // block 0: context 0 (the context of position 0, whether byte 0 occurs or not); block y: the y-th present symbol
         uint32_t ctx = 0;
-        if (blockIdx.y) {
-            if (!o1_u || blockIdx.y > nsym_u) return;
-            ctx = d_uniform (L.symlist[blockIdx.y - 1]);
+        if (by) {
+            if (!o1_u || by > nsym_u) return;
+            ctx = d_uniform (L.symlist[by - 1]);
             if (!ctx) return;                                  // (byte 0 is block 0's)
         }
         uint32_t *st = mstate + (size_t)ctx * (GZ_MSTATE_WORDS * 64);   // (only touched when the leaf spans chunks)
@@ -955,7 +1011,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
         return;
     }
     // wide alphabets: the contexts are dealt out over the blocks of the column
-    for (uint32_t ctx = blockIdx.y; ctx < (o1_u ? ms_u : 1u); ctx += GZ_MODEL_GRID_Y) {
+    for (uint32_t ctx = by; ctx < (o1_u ? ms_u : 1u); ctx += GZ_MODEL_GRID_Y) {
         if (ctx && L.symrank[ctx] == 0xffff) continue;         // a byte that never occurs is never a context
         uint32_t *st = mstate + (size_t)ctx * (GZ_MSTATE_WORDS * 64);
         uint32_t j0 = p0, j1 = p1;

@@ -15,6 +15,12 @@ static inline void gz_sched_fence (void) {}
 static inline void gz_scalar_cache_inv (void) {}
 static inline void gz_touch (const void *p, uint32_t &pit) { pit += *(const volatile uint8_t *)p; }
 static inline void gz_touch_done (uint32_t &) {}
+static inline uint32_t gz_wave_or_scan (uint32_t v)
+{
+    const int lane = (int)(emu.cur % 64);
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl ((int)v, lane >= d ? lane - d : lane); if (lane >= d) v |= o; }
+    return v;
+}
 static inline void gz_wave_sync (void) { (void)__ballot (1); }
 static inline void gz_wait_vector_mem (void) {}
 static inline uint32_t gz_ldg_u8 (const uint8_t *p) { return *p; }

@@ -256,10 +256,12 @@ static inline int __clz (unsigned v) { return v ? __builtin_clz (v) : 32; }
 // this runtime runs every launch to completion at enqueue time: a kernel that waits for a later launch must be queued after it
 #define GZ_SEQUENTIAL_STREAMS 1
 static inline int __popcll (unsigned long long v) { return __builtin_popcountll (v); }
+static inline int __popc (unsigned v) { return __builtin_popcount (v); }
 static inline unsigned __umulhi (unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline long long __double_as_longlong (double d) { long long v; memcpy (&v, &d, 8); return v; }
 static inline unsigned atomicAdd (unsigned *p, unsigned v) { return __atomic_fetch_add (p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicOr (unsigned *p, unsigned v) { return __atomic_fetch_or (p, v, __ATOMIC_RELAXED); }
+static inline unsigned long long atomicOr (unsigned long long *p, unsigned long long v) { return __atomic_fetch_or (p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicCAS (unsigned *p, unsigned expect, unsigned v)
 {
     __atomic_compare_exchange_n (p, &expect, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
