@@ -204,17 +204,17 @@ __device__ static __forceinline__ void d_batch_counts (uint32_t p, uint64_t T, u
 // an OR-scan over the entries (DPP, gz_wave_or_scan) makes the set of occurrences BELOW every entry, and an occurrence reads the sets of
 // its position, of its left neighbour's and of everything below: the counts are popcounts of those under the mask of the earlier
 // lanes. ~45 vector instructions and three trips to the LDS whatever the alphabet.
-// LDS: s_mask [1 + 64 J] (word 0 stands for "the position left of position 0": nobody), s_low [64 J]
-#define GZ_MLDS_OFF 512                   // (d_model_batch_lds, below)
-#define GZ_MLDS_BYTES 2880
+// LDS: s_mask [2 + 64 J] (word 0 stands for "the position left of position 0": nobody; the last one for the position behind the last), s_low [64 J]
+#define GZ_MLDS_OFF 512                   // (the model's tables: d_model_batch_rounds / d_model_batch_lds, below)
+#define GZ_MLDS_BYTES 3072
 #define GZ_CNT_OFF   (GZ_MLDS_OFF + GZ_MLDS_BYTES)
-#define GZ_CNT_BYTES (257 * 8 + 256 * 8)
+#define GZ_CNT_BYTES (258 * 8 + 256 * 8)
 #define GZ_MODEL_LDS (GZ_CNT_OFF + GZ_CNT_BYTES)
 template <int J>
 __device__ static __forceinline__ void d_batch_counts_lds (uint32_t p, uint64_t T, int lane, uint64_t below,
                                                            uint32_t &eq, uint32_t &lt, uint32_t &eql, uint32_t (&ceq)[J], uint32_t (&clt)[J])
 {
-    unsigned long long *s_mask = (unsigned long long *)(gz_lds + GZ_CNT_OFF), *s_low = s_mask + 257;
+    unsigned long long *s_mask = (unsigned long long *)(gz_lds + GZ_CNT_OFF), *s_low = s_mask + 258;
     #pragma unroll
     for (int j = 0; j < J; j++) s_mask[1 + j * 64 + lane] = 0;
     if (!lane) s_mask[0] = 0;
@@ -513,6 +513,139 @@ __device__ static __forceinline__ void d_model_batch_lds (GzModel<J> &M, uint32_
     gz_wave_sync ();
 }
 
+// ---- the same, all occurrences that do not get in each other's way at once ("rounds") -----------------------------------------------
+// One occurrence at a time is what the reference does, but what one occurrence's order change can touch is small: a swap of list positions
+// r - 1 and r matters to later occurrences of the symbols at r - 1, r and r + 1 (the last one's left neighbour changes), a hop at r to those
+// at r and r + 1 - and to nobody else: their frequencies, cumulatives (a swap leaves the sum in front of everything behind it alone) and
+// neighbours are what the batch formulas of d_model_batch say. So the model lives in the LDS for the batch (tables by list position:
+// frequency, cumulative, gap, symbol rank; by symbol rank: position), and a ROUND takes every pending occurrence through the formulas at
+// once - positions and entries gathered from the tables, prefix counts through the masks of d_batch_counts_lds - finds the occurrences
+// that change the order ("events"), and commits the occurrences in front of the first one that has an EARLIER event at its own position
+// or a neighbouring one: for all of those the formulas are exact, and their events do not touch each other, so each event's lane writes
+// its own swap (or hop) into the tables. The rest is the next round's, gathered afresh from the tables - no patching of later lanes.
+// Simulated on the model (tools/rounds_sim.py): a near-uniform 256-symbol context has 39 events per batch of 64 and needs 4.9 rounds, a
+// 90-symbol geometric one 16 events and 5.7 rounds, 16 hot + 240 rare symbols 30 events and 9.6 rounds. A round costs ~0.6 us whatever
+// happens in it (J = 4), one occurrence at a time 0.32 us per occurrence, an event of the register batch 0.45 us.
+// The occurrence that pushes the total over the limit (once per ~4 000 occurrences) ends a round in front of it and is taken on its own.
+#define GZ_RT_FREQ (GZ_MLDS_OFF)           // uint32_t [256] by list position
+#define GZ_RT_CUM  (GZ_MLDS_OFF + 1024)    // uint32_t [256] by list position
+#define GZ_RT_GAP  (GZ_MLDS_OFF + 2048)    // uint16_t [256] by list position
+#define GZ_RT_RANK (GZ_MLDS_OFF + 2560)    // uint8_t  [256] list position -> symbol rank
+#define GZ_RT_POS  (GZ_MLDS_OFF + 2816)    // uint8_t  [256] symbol rank -> list position
+template <int J>
+__device__ static __forceinline__ void d_model_batch_rounds (GzModel<J> &M, uint32_t &tot, int lane, uint32_t cnt, uint32_t rk, uint32_t nsym, uint32_t n_absent,
+                                                             const uint8_t *symlist, uint32_t &out_cum, uint32_t &out_freq, uint32_t &out_tot, uint32_t &n_changes)
+{
+    uint32_t *t_freq = (uint32_t *)(gz_lds + GZ_RT_FREQ), *t_cum = (uint32_t *)(gz_lds + GZ_RT_CUM);
+    uint16_t *t_gap = (uint16_t *)(gz_lds + GZ_RT_GAP);
+    uint8_t *t_rank = gz_lds + GZ_RT_RANK, *t_pos = gz_lds + GZ_RT_POS;
+    unsigned long long *s_mask = (unsigned long long *)(gz_lds + GZ_CNT_OFF), *s_low = s_mask + 258;
+    #pragma unroll
+    for (int j = 0; j < J; j++) {
+        const uint32_t e = (uint32_t)(j * 64 + lane);
+        if (e < nsym) { t_freq[e] = M.freq[j]; t_cum[e] = M.cum[j]; t_gap[e] = (uint16_t)M.gap[j]; t_rank[e] = (uint8_t)M.srank[j]; t_pos[e] = (uint8_t)M.where[j]; }
+    }
+    gz_wave_sync ();
+    uint64_t todo = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0, self = 1ull << lane;
+    uint32_t t = d_uniform (tot), changes = 0;
+    while (todo) {
+        if (t + GZ_MODEL_STEP > GZ_MODEL_LIMIT) {
+            // ---- the occurrence that halves the model, on its own (c_simple_model.h:124-146): bump, halve, rebuild, one bubble step
+            const int b = __ffsll ((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t s = d_readlane (rk, b);
+            const uint32_t p = d_uniform (t_pos[s]), q = p ? p - 1 : 0;
+            const uint32_t f = d_uniform (t_freq[p]), g = d_uniform (t_gap[p]), c = d_uniform (t_cum[p]), rb = d_uniform (t_rank[q]);
+            if (lane == b) { out_cum = c; out_freq = f; out_tot = t; }
+            gz_wave_sync ();                                       // (everybody has read)
+            uint32_t run = 0, fsum = 0;
+            #pragma unroll
+            for (int j = 0; j < J; j++) {
+                const uint32_t e = (uint32_t)(j * 64 + lane);
+                uint32_t x = 0, gp = 0;
+                if (e < nsym) { x = t_freq[e] + (e == p ? GZ_MODEL_STEP : 0u); x -= x >> 1; t_freq[e] = x; gp = t_gap[e]; }
+                const uint32_t incl = d_wave_incl_scan (x + gp, lane);
+                if (e < nsym) t_cum[e] = run + incl - x;           // everything in front of me + my own gap
+                run += (uint32_t)__shfl ((int)incl, 63);
+                fsum += (uint32_t)__shfl ((int)d_wave_incl_scan (x, lane), 63);
+            }
+            t = d_uniform (fsum + n_absent);
+            gz_wave_sync ();
+            const uint32_t fn = d_uniform (t_freq[p]), fl = d_uniform (t_freq[q]);
+            gz_wave_sync ();
+            if (g > 0) {
+                if (!lane) { t_gap[p] = (uint16_t)(g - 1); if (p + 1 < nsym) t_gap[p + 1] = (uint16_t)(t_gap[p + 1] + 1); t_cum[p] -= 1; }
+                changes++;
+            }
+            else if (p > 0 && fl < fn) {
+                if (!lane) { t_freq[q] = fn; t_freq[p] = fl; t_rank[q] = (uint8_t)s; t_rank[p] = (uint8_t)rb; t_pos[s] = (uint8_t)q; t_pos[rb] = (uint8_t)p; t_cum[p] = t_cum[p] - fl + fn; }
+                changes++;
+            }
+            gz_wave_sync ();
+            continue;
+        }
+        const bool pend = (todo >> lane) & 1;
+        const uint32_t p = t_pos[rk], q = p ? p - 1 : 0;
+        const uint32_t f = t_freq[p], fl = t_freq[q], g = t_gap[p], c = t_cum[p], rb = t_rank[q];
+        #pragma unroll
+        for (int j = 0; j < J; j++) s_mask[1 + j * 64 + lane] = 0;
+        if (lane < 2) s_mask[lane ? 1 + 64 * J : 0] = 0;
+        gz_wave_sync ();
+        if (pend) atomicOr (&s_mask[1 + p], (unsigned long long)self);
+        gz_wave_sync ();
+        uint32_t x_lo[J], x_hi[J], run_lo = 0, run_hi = 0;
+        #pragma unroll
+        for (int j = 0; j < J; j++) {
+            const unsigned long long m = s_mask[1 + j * 64 + lane];
+            const uint32_t m_lo = (uint32_t)m, m_hi = (uint32_t)(m >> 32);
+            const uint32_t i_lo = gz_wave_or_scan (m_lo), i_hi = gz_wave_or_scan (m_hi);
+            x_lo[j] = (i_lo ^ m_lo) | run_lo; x_hi[j] = (i_hi ^ m_hi) | run_hi;           // the pending occurrences at positions below entry lane + 64 j
+            s_low[j * 64 + lane] = ((unsigned long long)x_hi[j] << 32) | x_lo[j];
+            if (j + 1 < J) { run_lo |= d_readlane (i_lo, 63); run_hi |= d_readlane (i_hi, 63); }
+        }
+        gz_wave_sync ();
+        const unsigned long long me = s_mask[1 + p], lf = s_mask[p], rt = s_mask[2 + p], lo = s_low[p];
+        const uint32_t fj = f + GZ_MODEL_STEP * (uint32_t)__popcll (me & below), flj = fl + GZ_MODEL_STEP * (uint32_t)__popcll (lf & below);
+        const uint32_t cj = c + GZ_MODEL_STEP * (uint32_t)__popcll (lo & below), tj = t + GZ_MODEL_STEP * gz_mbcnt (todo);
+        const bool bad = pend && (g != 0 || (p > 0 && fj + GZ_MODEL_STEP > flj));
+        const uint64_t badm = __ballot (bad);
+        const bool dirty = pend && ((me | lf | rt) & badm & below) != 0;
+        const uint64_t stop = __ballot (dirty || (pend && tj + GZ_MODEL_STEP > GZ_MODEL_LIMIT));
+        const uint64_t C = stop ? todo & ((1ull << (__ffsll ((unsigned long long)stop) - 1)) - 1) : todo;   // (never empty: the first pending occurrence has nobody in front of it)
+        const bool com = (C >> lane) & 1;
+        if (com) { out_cum = cj; out_freq = fj; out_tot = tj; }
+        // the tables: what the committed occurrences add (the last one at a position writes its frequency; every entry gains 16 per occurrence below it) ...
+        if (com && (me & C & ~below & ~self) == 0) t_freq[p] = fj + GZ_MODEL_STEP;
+        #pragma unroll
+        for (int j = 0; j < J; j++) {
+            const uint32_t e = (uint32_t)(j * 64 + lane);
+            if (e < nsym) t_cum[e] += GZ_MODEL_STEP * ((uint32_t)__popc (x_lo[j] & (uint32_t)C) + (uint32_t)__popc (x_hi[j] & (uint32_t)(C >> 32)));
+        }
+        gz_wave_sync ();
+        // ... then their order changes, every one by its own lane: none of them touches what another one does
+        if (com && bad) {
+            if (g) { t_gap[p] = (uint16_t)(g - 1); if (p + 1 < nsym) t_gap[p + 1] = (uint16_t)(t_gap[p + 1] + 1); t_cum[p] -= 1; }
+            else {
+                t_freq[q] = fj + GZ_MODEL_STEP; t_freq[p] = flj;
+                t_rank[q] = (uint8_t)rk; t_rank[p] = (uint8_t)rb; t_pos[rk] = (uint8_t)q; t_pos[rb] = (uint8_t)p;
+                t_cum[p] = t_cum[p] - flj + fj + GZ_MODEL_STEP;
+            }
+        }
+        changes += (uint32_t)__popcll (badm & C);
+        gz_wave_sync ();
+        t += GZ_MODEL_STEP * (uint32_t)__popcll (C);
+        todo &= ~C;
+    }
+    #pragma unroll
+    for (int j = 0; j < J; j++) {
+        const uint32_t e = (uint32_t)(j * 64 + lane);
+        if (e < nsym) { M.freq[j] = t_freq[e]; M.cum[j] = t_cum[e]; M.gap[j] = t_gap[e]; M.srank[j] = t_rank[e]; M.where[j] = t_pos[e]; M.sym[j] = symlist[M.srank[j]]; }
+    }
+    tot = t; n_changes = changes;
+    gz_wave_sync ();
+}
+
 // ---- grouping the positions of an order-1 leaf by context ---------------------------------------------------------
 // Without it every context's wave has to scan the whole stream for its positions (with ~40 contexts in a quality
 // stream that scan was most of the instructions the model kernel executed). A stable counting sort by the context byte:
@@ -785,7 +918,7 @@ template <int J, bool LDSM = false>
 __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, uint32_t ms, bool o1, uint4 *recs,
                                                    const GzDivInv *inv_tab, const uint8_t *symlist, const uint16_t *symrank, uint32_t nsym,
                                                    const uint32_t *spos, const uint8_t *srk, uint32_t j0, uint32_t j1, bool first, bool save, uint32_t *st,
-                                                   const GzLocalAlpha *la = nullptr)
+                                                   const GzLocalAlpha *la = nullptr, bool force_lds = false)
 {
     const int lane = threadIdx.x & 63;
     GzModel<J> M;
@@ -829,7 +962,7 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
     uint32_t nx_pos = 0, nx_rk = 0;
     uint32_t A_pos[4] = { 0, 0, 0, 0 }, A_raw[4] = { 0, 0, 0, 0 }, B_pos[4] = { 0, 0, 0, 0 }, B_raw[4] = { 0, 0, 0, 0 };
     uint32_t bi = 0, grp = j0;                            // bi: which batch of group A is being worked on; grp: position of A's first batch
-    bool through_lds = false;                             // (see d_model_batch_lds)
+    bool through_lds = LDSM && force_lds;                 // (see d_model_batch_rounds; force_lds: GZ_MODEL_FORCE_ROUNDS, for the tests)
     uint32_t stamp = LDSM ? (uint32_t)wall_clock64 () : 0u, reg_cost = 0, lds_cost = 0, probe = 0;   // (10 ns ticks)
     // (always loads - past the end the context's last occurrence again, which nobody looks at - and through GLOBAL pointers: a load
     //  under a condition leaves the compiler merging old and new value through a copy that has to wait for the load on the spot, and a
@@ -872,7 +1005,14 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
         if (p_on) d_record_store (recs + p_pos, d_model_record (p_cum, p_freq, p_inv)); \
         p_on = occ; p_pos = b_pos; p_cum = out_cum; p_freq = out_freq; \
         if (occ) p_inv = inv_tab[out_tot];
+    // wide alphabets (two and four register planes) always go in rounds: measured against the register batches + clock-picked serial LDS
+    // batches they replace - binned FASTQ 44.7 -> 27.5 ms per step, BAM 53.4 -> 37.8, one VCF VBlock 1981 -> 1050
+#ifndef GZ_ROUNDS_MINJ
+#define GZ_ROUNDS_MINJ 2
+#endif
+    constexpr bool kRounds = J >= GZ_ROUNDS_MINJ;
     for (uint32_t j = j0; j < j1; ) {
+        if constexpr (!kRounds)
         for (; j < j1 && !through_lds; j += 64) {
             GZ_WAVE_BATCH_HEAD
             MPH_T (0);
@@ -893,15 +1033,21 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
             mph_[4]++; mph_[6] += n_ev;
 #endif
         }
-        if constexpr (LDSM) {
-            for (; j < j1 && through_lds; j += 64) {
+        if constexpr (LDSM || kRounds) {
+            for (; j < j1 && (kRounds || through_lds); j += 64) {
                 GZ_WAVE_BATCH_HEAD
                 MPH_T (0);
+#ifdef GZ_MODEL_SERIAL_LDS
                 d_model_batch_lds<J> (M, tot, lane, cnt, occ ? b_rk : 0u, nsym, n_absent, symlist, out_cum, out_freq, out_tot, n_ev);
-                const uint32_t now = (uint32_t)wall_clock64 ();
-                lds_cost = now - stamp; stamp = now;
-                through_lds = n_ev >= GZ_MODEL_EVENTS_OUT && (lds_cost <= reg_cost || !reg_cost) && ++probe < GZ_MODEL_REPROBE;
-                if (!through_lds) probe = 0;
+#else
+                d_model_batch_rounds<J> (M, tot, lane, cnt, occ ? b_rk : 0u, nsym, n_absent, symlist, out_cum, out_freq, out_tot, n_ev);
+#endif
+                if constexpr (!kRounds) {
+                    const uint32_t now = (uint32_t)wall_clock64 ();
+                    lds_cost = now - stamp; stamp = now;
+                    through_lds = force_lds || (n_ev >= GZ_MODEL_EVENTS_OUT && (lds_cost <= reg_cost || !reg_cost) && ++probe < GZ_MODEL_REPROBE);
+                    if (!through_lds) probe = 0;
+                }
                 MPH_T (2);
                 GZ_WAVE_BATCH_TAIL
                 MPH_T (3);
@@ -953,7 +1099,7 @@ __device__ unsigned long long g_model_slowest;     // (10 ns ticks << 40) | (lis
 #define GZ_MODEL_T0 do {} while (0)
 #define GZ_MODEL_T1(ctx, occ) do {} while (0)
 #endif
-__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const GzDivInv *inv_tab, uint32_t p0, uint32_t chunk)
+__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const GzDivInv *inv_tab, uint32_t p0, uint32_t chunk, uint32_t force_rounds)
 {
     GZ_XCD_GRID (li, by, n_list);
     GzdLeaf &L = leaves[list[li]];
@@ -1047,8 +1193,8 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
                 continue;
             }
         }
-        if (nsym_u <= 128) d_arith_model_wave<2, true> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
-        else               d_arith_model_wave<4, true> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        if (nsym_u <= 128) d_arith_model_wave<2, true> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, nullptr, force_rounds != 0);
+        else               d_arith_model_wave<4, true> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, nullptr, force_rounds != 0);
         GZ_MODEL_T1 (ctx, j1 - j0);
     }
 }
