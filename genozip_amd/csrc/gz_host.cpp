@@ -682,7 +682,6 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
         }
         if (A.np) {
             const GzDivInv *inv_tab = (const GzDivInv *)h->d_inv_tab;
-            static const uint32_t force_rounds = getenv ("GZ_MODEL_FORCE_ROUNDS") ? 1u : 0u;   // (tests: every batch of a wide context through d_model_batch_rounds)
             const uint32_t grid_y = GZ_MODEL_GRID_Y + (P.rle_list.empty () ? 0 : GZ_MODEL_GRID_RUN);
             if (!P.rle_list.empty ())                              // the run-length variant's coding events (before anything looks at arith_n)
                 KLAUNCH (h, k_rle_events, dim3 ((uint32_t)P.rle_list.size ()), dim3 (1024), 256, d_leaves, A.d_rle);
@@ -697,7 +696,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
             };
             if (!A.pipelined) {
                 if ((rc = sort_chunk (h->stream, A.d_plain, A.np, 0u, 0xffffffffu, P.max_arith_n)) != GZ_OK) return rc;
-                KLAUNCH (h, k_arith_model, GZ_XCD_DIM (A.np, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_plain, A.np, inv_tab, 0u, 0xffffffffu, force_rounds);
+                KLAUNCH (h, k_arith_model, GZ_XCD_DIM (A.np, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_plain, A.np, inv_tab, 0u, 0xffffffffu);
                 KLAUNCH (h, k_arith_chain, dim3 ((A.np + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), 64,
                          d_leaves, A.d_plain, A.np, (const uint32_t *)NULL, 0u, h->d_fail, (uint32_t *)NULL, 0u);
             }
@@ -719,7 +718,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                     if ((rc = sort_chunk (sort_stream, A.d_big, A.nbig, p0, A.chunk, span)) != GZ_OK) return rc;
                     HIPCHK (h, hipEventRecord (h->ev_sort[k], sort_stream));
                     HIPCHK (h, hipStreamWaitEvent (h->stream4, h->ev_sort[k], 0));
-                    KLAUNCH_ON (h, h->stream4, k_arith_model, GZ_XCD_DIM (A.nbig, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_big, A.nbig, inv_tab, p0, A.chunk, force_rounds);
+                    KLAUNCH_ON (h, h->stream4, k_arith_model, GZ_XCD_DIM (A.nbig, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_big, A.nbig, inv_tab, p0, A.chunk);
                     hipLaunchKernelGGL (k_arith_progress, dim3 (1), dim3 (1), 0, h->stream4, A.d_progress, k + 1);
                 }
 #ifdef GZ_SEQUENTIAL_STREAMS
@@ -731,7 +730,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 if (A.nsmall) {
                     HIPCHK (h, hipStreamWaitEvent (h->stream5, h->ev_model_fork, 0));
                     if ((rc = sort_chunk (h->stream5, A.d_small, A.nsmall, 0u, 0xffffffffu, A.chunk)) != GZ_OK) return rc;
-                    KLAUNCH_ON (h, h->stream5, k_arith_model, GZ_XCD_DIM (A.nsmall, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_small, A.nsmall, inv_tab, 0u, 0xffffffffu, force_rounds);
+                    KLAUNCH_ON (h, h->stream5, k_arith_model, GZ_XCD_DIM (A.nsmall, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_small, A.nsmall, inv_tab, 0u, 0xffffffffu);
                     KLAUNCH_ON (h, h->stream5, k_arith_chain, dim3 ((A.nsmall + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), GZ_KEEP_OFF_LDS,
                                 d_leaves, A.d_small, A.nsmall, (const uint32_t *)NULL, 0u, h->d_fail, (uint32_t *)NULL, 0u);
                     if (A.nlb_small) {

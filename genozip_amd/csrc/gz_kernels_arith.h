@@ -205,7 +205,7 @@ __device__ static __forceinline__ void d_batch_counts (uint32_t p, uint64_t T, u
 // its position, of its left neighbour's and of everything below: the counts are popcounts of those under the mask of the earlier
 // lanes. ~45 vector instructions and three trips to the LDS whatever the alphabet.
 // LDS: s_mask [2 + 64 J] (word 0 stands for "the position left of position 0": nobody; the last one for the position behind the last), s_low [64 J]
-#define GZ_MLDS_OFF 512                   // (the model's tables: d_model_batch_rounds / d_model_batch_lds, below)
+#define GZ_MLDS_OFF 512                   // (the model's tables: d_model_batch_rounds, below)
 #define GZ_MLDS_BYTES 3072
 #define GZ_CNT_OFF   (GZ_MLDS_OFF + GZ_MLDS_BYTES)
 #define GZ_CNT_BYTES (258 * 8 + 256 * 8)
@@ -380,172 +380,79 @@ __device__ static __forceinline__ void d_model_batch (GzModel<J> &M, uint32_t &t
     }
 }
 
-// ---- contexts whose symbols keep overtaking each other -------------------------------------------------------------------------------
-// Near-uniform frequencies (the low and high bytes of coordinates, hashes ...) make nearly every occurrence an event, and an event costs
-// the batch path ~2 000 clocks of vector -> scalar round trips (measured: 850 ns per symbol on such a context). For these the list
-// moves to LDS for a batch at a time and the occurrences are taken one by one the way the reference does (c_simple_model.h:119-146) -
-// but with every look-up a broadcast LDS read of a wave-uniform address, so that nothing leaves the vector unit: position of the
-// symbol, its frequency, its left neighbour's, bump, (halve,) hop or swap. Only the cumulative frequencies stay in the lanes'
-// registers (entry lane + 64 j): "every entry behind p gains 16" is one compare-and-add per plane there, and a swap needs no other
-// lane's value: cum'[p] = cum[p] - freq[p-1] + freq'[p]. gz_wave_sync between reads and writes: all lanes touch the same words.
-// LDS: bytes 512 .. 3391 of the workgroup's (one wave's) dynamic LDS.
-// Which way an eventful batch goes is decided by the CLOCK. Both ways give the same records, so the choice is free: a register batch with
-// >= GZ_MODEL_EVENTS_IN events and every LDS batch are timed (s_memrealtime at the end of every batch - issued, not waited for: only an
-// eventful batch reads it), and the next eventful batch takes the way that was faster the last time it was taken; every
-// GZ_MODEL_REPROBE-th such batch tries the other one again. An LDS batch costs the same whatever happens in it, but more the more register
-// planes the model has; a register batch costs by its events, by its distinct list positions (4 planes) ... - fixed thresholds that suit
-// one kind of stream cost another 10-25 %: measured with IN / OUT = 12 / 8 (round 2's), 24 / 16, 40 / 28 and "never LDS" - one VCF VBlock
-// (4-plane models of near-uniform b250 planes) 2500 / 2000 / 1955 / 1955 ms, BAM from text 72.5 / 73.0 / 75.4 / 88.9 ms, binned FASTQ 69.4 /
-// 72.0 / 75.2 / 85.5 ms; thresholds by the number of planes (12 / 24 / 40): VCF 2030 but BAM 76.5, binned FASTQ 78.5.
-#define GZ_MODEL_EVENTS_IN  12            // events in a register batch of 64 from which on it counts as eventful ...
-#define GZ_MODEL_EVENTS_OUT 8             // ... and order changes in an LDS batch below which the next one is a register batch again
-#define GZ_MODEL_REPROBE    128
-
 __device__ static __forceinline__ uint32_t d_wave_incl_scan (uint32_t v, int lane)
 {
     for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl ((int)v, lane >= d ? lane - d : lane); v += lane >= d ? o : 0u; }
     return v;
 }
 
-// (tried as a real function - not inlined - because inside the kernel its scalars push the register batches' own into spills, 74 -> 116
-//  spilled SGPRs: far worse, the kernel then needs scratch memory and every wave pays for it: binned FASTQ 93 -> 158 ms per step)
-template <int J>
-__device__ static __forceinline__ void d_model_batch_lds (GzModel<J> &M, uint32_t &tot, int lane, uint32_t cnt, uint32_t rk, uint32_t nsym, uint32_t n_absent,
-                                                          const uint8_t *symlist, uint32_t &out_cum, uint32_t &out_freq, uint32_t &out_tot, uint32_t &n_changes)
-{
-    uint32_t *s_freq = (uint32_t *)(gz_lds + GZ_MLDS_OFF);                  // [256] by list position
-    uint16_t *s_gap  = (uint16_t *)(gz_lds + GZ_MLDS_OFF + 1024);           // [256] by list position
-    uint8_t  *s_rank = gz_lds + GZ_MLDS_OFF + 1536;                         // [256] list position -> static rank
-    uint8_t  *s_pos  = gz_lds + GZ_MLDS_OFF + 1792;                         // [256] static rank -> list position
-    #pragma unroll
-    for (int j = 0; j < J; j++) {
-        const uint32_t e = (uint32_t)(j * 64 + lane);
-        if (e < nsym) { s_freq[e] = M.freq[j]; s_gap[e] = (uint16_t)M.gap[j]; s_rank[e] = (uint8_t)M.srank[j]; s_pos[e] = (uint8_t)M.where[j]; }
-    }
-    gz_wave_sync ();
-    uint32_t t = tot;
-    // One trip to the LDS per occurrence instead of three dependent ones (symbol -> its list position -> the entries there): the symbol
-    // comes out of the lanes' registers (v_readlane with a scalar lane number), and the NEXT occurrence's list position is read together
-    // with this occurrence's entries - only a swap can move it, and then only if it is one of the two symbols swapped: patched below.
-    // What comes back is wave-uniform and is moved to the scalar unit at once (v_readfirstlane): every decision below is then scalar
-    // arithmetic and a scalar branch instead of a vector compare whose result has to travel to the branch unit. The occurrence's
-    // (cum, freq, total) go straight into the register of the lane that owns it - nothing is written to the LDS but the model itself.
-    // (cnt, the total and the positions are said to be uniform explicitly: the compiler cannot know, and treats a branch on them as one
-    //  that lanes may disagree on - exec-mask bookkeeping around every if)
-    const uint32_t cnt_u = d_uniform (cnt);
-    t = d_uniform (t);
-    uint32_t s = d_readlane (rk, 0), p = d_uniform (s_pos[s]);
-    uint32_t o_cum = 0, o_freq = 0, o_tot = 0;
-    for (uint32_t b = 0; b < cnt_u; b++) {
-        const uint32_t q = p ? p - 1 : 0;
-        const uint32_t s_nx = d_readlane (rk, (int)(b + 1 < cnt_u ? b + 1 : b));
-        uint32_t f_v = s_freq[p], g_v = s_gap[p], rb_v = s_rank[q], fl_v = s_freq[q], pn_v = s_pos[s_nx];
-        const uint32_t f = d_uniform (f_v), g = d_uniform (g_v), rb = d_uniform (rb_v);
-        uint32_t fl = d_uniform (fl_v), p_nx = d_uniform (pn_v);
-        gz_wave_sync ();                                           // (everybody has read)
-        // my cumulative if I am the occurrence's list entry: plane p / 64, lane p % 64
-        uint32_t cp = M.cum[0];
-        #pragma unroll
-        for (int j = 1; j < J; j++) cp = (p >> 6) == (uint32_t)j ? M.cum[j] : cp;
-        const uint32_t c_out = d_readlane (cp, (int)(p & 63));
-        const bool mine = (uint32_t)lane == b;
-        o_cum = mine ? c_out : o_cum; o_freq = mine ? f : o_freq; o_tot = mine ? t : o_tot;
-        #pragma unroll
-        for (int j = 0; j < J; j++) M.cum[j] += (uint32_t)(j * 64 + lane) > p ? GZ_MODEL_STEP : 0u;
-        uint32_t fn = f + GZ_MODEL_STEP;
-        t += GZ_MODEL_STEP;
-        if (t > GZ_MODEL_LIMIT) {                                  // rare: halve, rebuild the cumulatives and the total
-            if (!lane) s_freq[p] = fn;
-            gz_wave_sync ();
-            uint32_t run = 0, fsum = 0;
-            #pragma unroll
-            for (int j = 0; j < J; j++) {
-                const uint32_t e = (uint32_t)(j * 64 + lane);
-                uint32_t x = 0, gp = 0;
-                if (e < nsym) { x = s_freq[e]; x -= x >> 1; s_freq[e] = x; gp = s_gap[e]; }
-                const uint32_t incl = d_wave_incl_scan (x + gp, lane);
-                M.cum[j] = e < nsym ? run + incl - x : M.cum[j];   // everything in front of me + my own gap
-                run += (uint32_t)__shfl ((int)incl, 63);
-                fsum += (uint32_t)__shfl ((int)d_wave_incl_scan (x, lane), 63);
-            }
-            t = d_uniform (fsum + n_absent);
-            gz_wave_sync ();
-            fn = d_uniform (s_freq[p]); fl = d_uniform (s_freq[q]);
-            gz_wave_sync ();
-            if (g > 0) {
-                if (!lane) { s_gap[p] = (uint16_t)(g - 1); if (p + 1 < nsym) s_gap[p + 1] = (uint16_t)(s_gap[p + 1] + 1); }
-                #pragma unroll
-                for (int j = 0; j < J; j++) M.cum[j] -= (uint32_t)(j * 64 + lane) == p ? 1u : 0u;
-                n_changes++;
-            }
-            else if (p > 0 && fl < fn) {
-                if (!lane) { s_freq[q] = fn; s_freq[p] = fl; s_rank[q] = (uint8_t)s; s_rank[p] = (uint8_t)rb; s_pos[s] = (uint8_t)q; s_pos[rb] = (uint8_t)p; }
-                #pragma unroll
-                for (int j = 0; j < J; j++) M.cum[j] = (uint32_t)(j * 64 + lane) == p ? M.cum[j] - fl + fn : M.cum[j];
-                n_changes++;
-                p_nx = s_nx == s ? q : (s_nx == rb ? p : p_nx);
-            }
-        }
-        else if (g > 0) {                                          // an absent entry hops over (see d_model_serial_step)
-            if (!lane) { s_freq[p] = fn; s_gap[p] = (uint16_t)(g - 1); if (p + 1 < nsym) s_gap[p + 1] = (uint16_t)(s_gap[p + 1] + 1); }
-            #pragma unroll
-            for (int j = 0; j < J; j++) M.cum[j] -= (uint32_t)(j * 64 + lane) == p ? 1u : 0u;
-            n_changes++;
-        }
-        else if (p > 0 && fl < fn) {                               // one bubble step to the left
-            if (!lane) { s_freq[q] = fn; s_freq[p] = fl; s_rank[q] = (uint8_t)s; s_rank[p] = (uint8_t)rb; s_pos[s] = (uint8_t)q; s_pos[rb] = (uint8_t)p; }
-            #pragma unroll
-            for (int j = 0; j < J; j++) M.cum[j] = (uint32_t)(j * 64 + lane) == p ? M.cum[j] - fl + fn : M.cum[j];
-            n_changes++;
-            p_nx = s_nx == s ? q : (s_nx == rb ? p : p_nx);
-        }
-        else if (!lane) s_freq[p] = fn;
-        gz_wave_sync ();                                           // (written before the next occurrence reads)
-        s = s_nx; p = d_uniform (p_nx);
-    }
-    #pragma unroll
-    for (int j = 0; j < J; j++) {
-        const uint32_t e = (uint32_t)(j * 64 + lane);
-        if (e < nsym) { M.freq[j] = s_freq[e]; M.gap[j] = s_gap[e]; M.srank[j] = s_rank[e]; M.where[j] = s_pos[e]; M.sym[j] = symlist[M.srank[j]]; }
-    }
-    if ((uint32_t)lane < cnt) { out_cum = o_cum; out_freq = o_freq; out_tot = o_tot; }
-    tot = t;
-    gz_wave_sync ();
-}
-
-// ---- the same, all occurrences that do not get in each other's way at once ("rounds") -----------------------------------------------
-// One occurrence at a time is what the reference does, but what one occurrence's order change can touch is small: a swap of list positions
-// r - 1 and r matters to later occurrences of the symbols at r - 1, r and r + 1 (the last one's left neighbour changes), a hop at r to those
-// at r and r + 1 - and to nobody else: their frequencies, cumulatives (a swap leaves the sum in front of everything behind it alone) and
-// neighbours are what the batch formulas of d_model_batch say. So the model lives in the LDS for the batch (tables by list position:
-// frequency, cumulative, gap, symbol rank; by symbol rank: position), and a ROUND takes every pending occurrence through the formulas at
-// once - positions and entries gathered from the tables, prefix counts through the masks of d_batch_counts_lds - finds the occurrences
-// that change the order ("events"), and commits the occurrences in front of the first one that has an EARLIER event at its own position
-// or a neighbouring one: for all of those the formulas are exact, and their events do not touch each other, so each event's lane writes
-// its own swap (or hop) into the tables. The rest is the next round's, gathered afresh from the tables - no patching of later lanes.
+// ---- contexts whose symbols keep overtaking each other: ROUNDS ------------------------------------------------------------------------
+// Near-uniform frequencies (the low and high bytes of coordinates, hashes, packed qualities ...) make every other occurrence an order
+// change, and the register batch above takes those one at a time, patching the batch's later lanes after each (~0.45 us per event on a
+// 4-plane model: 850 ns per symbol on such a context; the first remedy - the model in the LDS and the occurrences one by one the way the
+// reference does it, every look-up a broadcast read - still cost 0.32 us per occurrence). But what one occurrence's order change can touch
+// is small: a swap of list positions r - 1 and r matters to later occurrences of the symbols at r - 1, r and r + 1 (the last one's left
+// neighbour changes), a hop at r to those at r and r + 1 - and to nobody else: their frequencies, cumulatives (a swap leaves the sum in
+// front of everything behind it alone) and neighbours are what the batch formulas of d_model_batch say. So the model of a WIDE alphabet
+// (more than 64 symbols: two or four register planes otherwise) lives in the LDS for as long as its wave works on it (tables by list
+// position: frequency, cumulative, gap, symbol rank; by symbol rank: position), and a ROUND takes every pending occurrence of a batch
+// through the formulas at once - positions and entries gathered from the tables, prefix counts through the masks of d_batch_counts_lds -
+// finds the occurrences that change the order ("events"), and commits the occurrences in front of the first one that has an EARLIER event
+// at its own position or a neighbouring one: for all of those the formulas are exact, and their events do not touch each other, so each
+// event's lane writes its own swap (or hop) into the tables. The rest is the next round's, gathered afresh - no patching of later lanes.
 // Simulated on the model (tools/rounds_sim.py): a near-uniform 256-symbol context has 39 events per batch of 64 and needs 4.9 rounds, a
-// 90-symbol geometric one 16 events and 5.7 rounds, 16 hot + 240 rare symbols 30 events and 9.6 rounds. A round costs ~0.6 us whatever
-// happens in it (J = 4), one occurrence at a time 0.32 us per occurrence, an event of the register batch 0.45 us.
+// 90-symbol geometric one 16 events and 5.7 rounds, 16 hot + 240 rare symbols 30 events and 9.6 rounds.
+// Measured against what it replaced (register batches, and - picked by the clock, batch by batch - the serial LDS batches): binned FASTQ
+// 44.7 -> 27.4 ms per step, BAM from text 53.4 -> 30.6, from records 41.8 -> 31.6, one VCF VBlock 1981 -> 1024 ms. One-plane models (a
+// quality stream's contexts) are as fast either way (-DGZ_ROUNDS_MINJ=1: default step 46.0 -> 46.3 ms, streamed 175.0 -> 177.5) and stay
+// in registers.
 // The occurrence that pushes the total over the limit (once per ~4 000 occurrences) ends a round in front of it and is taken on its own.
+// LDS: bytes GZ_MLDS_OFF .. of the workgroup's (one wave's) dynamic LDS, the masks behind them (GZ_CNT_OFF).
 #define GZ_RT_FREQ (GZ_MLDS_OFF)           // uint32_t [256] by list position
 #define GZ_RT_CUM  (GZ_MLDS_OFF + 1024)    // uint32_t [256] by list position
 #define GZ_RT_GAP  (GZ_MLDS_OFF + 2048)    // uint16_t [256] by list position
 #define GZ_RT_RANK (GZ_MLDS_OFF + 2560)    // uint8_t  [256] list position -> symbol rank
 #define GZ_RT_POS  (GZ_MLDS_OFF + 2816)    // uint8_t  [256] symbol rank -> list position
+// the model's registers (entry lane + 64 j of plane j) -> the tables, once per wave and context
 template <int J>
-__device__ static __forceinline__ void d_model_batch_rounds (GzModel<J> &M, uint32_t &tot, int lane, uint32_t cnt, uint32_t rk, uint32_t nsym, uint32_t n_absent,
-                                                             const uint8_t *symlist, uint32_t &out_cum, uint32_t &out_freq, uint32_t &out_tot, uint32_t &n_changes)
+__device__ static __forceinline__ void d_rounds_tables_in (const GzModel<J> &M, int lane, uint32_t nsym)
 {
     uint32_t *t_freq = (uint32_t *)(gz_lds + GZ_RT_FREQ), *t_cum = (uint32_t *)(gz_lds + GZ_RT_CUM);
     uint16_t *t_gap = (uint16_t *)(gz_lds + GZ_RT_GAP);
     uint8_t *t_rank = gz_lds + GZ_RT_RANK, *t_pos = gz_lds + GZ_RT_POS;
-    unsigned long long *s_mask = (unsigned long long *)(gz_lds + GZ_CNT_OFF), *s_low = s_mask + 258;
+    gz_wave_sync ();                                               // (the previous context of this workgroup is done with them)
     #pragma unroll
     for (int j = 0; j < J; j++) {
         const uint32_t e = (uint32_t)(j * 64 + lane);
         if (e < nsym) { t_freq[e] = M.freq[j]; t_cum[e] = M.cum[j]; t_gap[e] = (uint16_t)M.gap[j]; t_rank[e] = (uint8_t)M.srank[j]; t_pos[e] = (uint8_t)M.where[j]; }
     }
     gz_wave_sync ();
+}
+// ... and back, for the state that travels to the next position chunk
+template <int J>
+__device__ static __forceinline__ void d_rounds_tables_out (GzModel<J> &M, int lane, uint32_t nsym, const uint8_t *symlist)
+{
+    const uint32_t *t_freq = (const uint32_t *)(gz_lds + GZ_RT_FREQ), *t_cum = (const uint32_t *)(gz_lds + GZ_RT_CUM);
+    const uint16_t *t_gap = (const uint16_t *)(gz_lds + GZ_RT_GAP);
+    const uint8_t *t_rank = gz_lds + GZ_RT_RANK, *t_pos = gz_lds + GZ_RT_POS;
+    gz_wave_sync ();
+    #pragma unroll
+    for (int j = 0; j < J; j++) {
+        const uint32_t e = (uint32_t)(j * 64 + lane);
+        if (e < nsym) { M.freq[j] = t_freq[e]; M.cum[j] = t_cum[e]; M.gap[j] = t_gap[e]; M.srank[j] = t_rank[e]; M.where[j] = t_pos[e]; M.sym[j] = symlist[M.srank[j]]; }
+    }
+}
+
+// lanes 0 .. cnt-1 hold the next cnt occurrences of this context in stream order (rk = rank of the symbol in the context's alphabet);
+// on return they hold the (cum, freq, tot) the coder must see for them, and the tables have moved on
+template <int J>
+__device__ static __forceinline__ void d_model_batch_rounds (uint32_t &tot, int lane, uint32_t cnt, uint32_t rk, uint32_t nsym, uint32_t n_absent,
+                                                             uint32_t &out_cum, uint32_t &out_freq, uint32_t &out_tot, uint32_t &n_changes)
+{
+    uint32_t *t_freq = (uint32_t *)(gz_lds + GZ_RT_FREQ), *t_cum = (uint32_t *)(gz_lds + GZ_RT_CUM);
+    uint16_t *t_gap = (uint16_t *)(gz_lds + GZ_RT_GAP);
+    uint8_t *t_rank = gz_lds + GZ_RT_RANK, *t_pos = gz_lds + GZ_RT_POS;
+    unsigned long long *s_mask = (unsigned long long *)(gz_lds + GZ_CNT_OFF), *s_low = s_mask + 258;
     uint64_t todo = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
     const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0, self = 1ull << lane;
     uint32_t t = d_uniform (tot), changes = 0;
@@ -637,13 +544,7 @@ __device__ static __forceinline__ void d_model_batch_rounds (GzModel<J> &M, uint
         t += GZ_MODEL_STEP * (uint32_t)__popcll (C);
         todo &= ~C;
     }
-    #pragma unroll
-    for (int j = 0; j < J; j++) {
-        const uint32_t e = (uint32_t)(j * 64 + lane);
-        if (e < nsym) { M.freq[j] = t_freq[e]; M.cum[j] = t_cum[e]; M.gap[j] = t_gap[e]; M.srank[j] = t_rank[e]; M.where[j] = t_pos[e]; M.sym[j] = symlist[M.srank[j]]; }
-    }
     tot = t; n_changes = changes;
-    gz_wave_sync ();
 }
 
 // ---- grouping the positions of an order-1 leaf by context ---------------------------------------------------------
@@ -899,12 +800,11 @@ __global__ void __launch_bounds__(256) k_ctx_succ (GzdLeaf *leaves, const uint32
 //  become exec-mask code)
 // The occurrences of this wave's context inside the position chunk are entries [j0, j1) of the leaf's sorted lists
 // (order 1; srk = the symbol's rank in the leaf's alphabet), or simply positions [j0, j1) of the stream (order 0).
-// LDSM: with the LDS way through eventful batches (d_model_batch_lds). Only the two instantiations that run the leaf's own (wide)
-// alphabet have it: compiled into all of them its scalars cost the others theirs (spills) - 19 -> 21 ns per symbol on a quality
-// stream, 82 -> 118 ms on BAM's packed qualities - and the contexts it is for are the near-uniform planes of integers, which are wide.
+// J = 1: the model in registers (d_model_batch); J = 2, 4 (more than 64 symbols): the model in the LDS, the batches in rounds
+// (d_model_batch_rounds) - the registers only carry it in and out (the state that travels between position chunks has one layout).
 // -DGZ_MODEL_PHASES: where the waves of the hot contexts (>= GZ_MODEL_HOT occurrences in the launch, default 1 M) spend their time - lane 0's 100 MHz clock around
 // the head of a batch (waits for the prefetched occurrences), the batch itself and its tail (record store, reciprocal fetch); sums over
-// such waves, printed by gz_wait: 0 head, 1 register batches, 2 LDS batches, 3 tail, 4 batches, 5 LDS batches (count), 6 events, 7 waves
+// such waves, printed by gz_wait: 0 head, 1 register batches, 2 batches in rounds, 3 tail, 4 batches, 5 batches in rounds (count), 6 events, 7 waves
 #ifdef GZ_MODEL_PHASES
 #ifndef GZ_MODEL_HOT
 #define GZ_MODEL_HOT 1000000u
@@ -914,12 +814,16 @@ __device__ unsigned long long g_mph[8];
 #else
 #define MPH_T(k) do { } while (0)
 #endif
-template <int J, bool LDSM = false>
+#ifndef GZ_ROUNDS_MINJ
+#define GZ_ROUNDS_MINJ 2                   // (-DGZ_ROUNDS_MINJ=1: the one-plane models in rounds as well)
+#endif
+template <int J>
 __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, uint32_t ms, bool o1, uint4 *recs,
                                                    const GzDivInv *inv_tab, const uint8_t *symlist, const uint16_t *symrank, uint32_t nsym,
                                                    const uint32_t *spos, const uint8_t *srk, uint32_t j0, uint32_t j1, bool first, bool save, uint32_t *st,
-                                                   const GzLocalAlpha *la = nullptr, bool force_lds = false)
+                                                   const GzLocalAlpha *la = nullptr)
 {
+    constexpr bool kRounds = J >= GZ_ROUNDS_MINJ;
     const int lane = threadIdx.x & 63;
     GzModel<J> M;
     uint32_t tot = ms;
@@ -945,6 +849,7 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
         tot = d_uniform (st[6 * J * 64]);
     }
     const uint32_t n_absent = ms - nsym;
+    if constexpr (kRounds) d_rounds_tables_in<J> (M, lane, nsym);
 #ifdef GZ_MODEL_PHASES
     unsigned long long mph_[7] = { 0, 0, 0, 0, 0, 0, 0 }, mt_ = wall_clock64 ();
 #endif
@@ -962,8 +867,6 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
     uint32_t nx_pos = 0, nx_rk = 0;
     uint32_t A_pos[4] = { 0, 0, 0, 0 }, A_raw[4] = { 0, 0, 0, 0 }, B_pos[4] = { 0, 0, 0, 0 }, B_raw[4] = { 0, 0, 0, 0 };
     uint32_t bi = 0, grp = j0;                            // bi: which batch of group A is being worked on; grp: position of A's first batch
-    bool through_lds = LDSM && force_lds;                 // (see d_model_batch_rounds; force_lds: GZ_MODEL_FORCE_ROUNDS, for the tests)
-    uint32_t stamp = LDSM ? (uint32_t)wall_clock64 () : 0u, reg_cost = 0, lds_cost = 0, probe = 0;   // (10 ns ticks)
     // (always loads - past the end the context's last occurrence again, which nobody looks at - and through GLOBAL pointers: a load
     //  under a condition leaves the compiler merging old and new value through a copy that has to wait for the load on the spot, and a
     //  load through a generic pointer is a FLAT one, for which it waits with vmcnt (0): measured inside the kernel, 0.5 of the 1.5 us of
@@ -984,8 +887,6 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
     for (int k = 0; k < 4; k++) fetch_raw (j0 + 64 * (k + 4) + lane, B_pos[k], B_raw[k]);
     nx_pos = A_pos[0];
     if (j0 + lane < j1) nx_rk = to_rank (A_raw[0]);
-    // (two loops taking turns rather than one loop with a branch: with both ways through a batch in one loop body the register batches
-    //  paid for the LDS way's registers - BAM's packed qualities 82 -> 120 ms of model)
 #define GZ_WAVE_BATCH_HEAD \
         const uint32_t cnt = j1 - j < 64 ? j1 - j : 64; \
         const bool occ = (uint32_t)lane < cnt; \
@@ -1005,57 +906,16 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
         if (p_on) d_record_store (recs + p_pos, d_model_record (p_cum, p_freq, p_inv)); \
         p_on = occ; p_pos = b_pos; p_cum = out_cum; p_freq = out_freq; \
         if (occ) p_inv = inv_tab[out_tot];
-    // wide alphabets (two and four register planes) always go in rounds: measured against the register batches + clock-picked serial LDS
-    // batches they replace - binned FASTQ 44.7 -> 27.5 ms per step, BAM 53.4 -> 37.8, one VCF VBlock 1981 -> 1050
-#ifndef GZ_ROUNDS_MINJ
-#define GZ_ROUNDS_MINJ 2
-#endif
-    constexpr bool kRounds = J >= GZ_ROUNDS_MINJ;
-    for (uint32_t j = j0; j < j1; ) {
-        if constexpr (!kRounds)
-        for (; j < j1 && !through_lds; j += 64) {
-            GZ_WAVE_BATCH_HEAD
-            MPH_T (0);
-            d_model_batch<J> (M, tot, lane, cnt, occ ? b_rk : 0u, nsym, n_absent, out_cum, out_freq, out_tot, n_ev);
-            if constexpr (LDSM) {
-                const uint32_t now = (uint32_t)wall_clock64 ();
-                if (n_ev >= GZ_MODEL_EVENTS_IN) {
-                    reg_cost = now - stamp;
-                    through_lds = !lds_cost || lds_cost <= reg_cost || ++probe >= GZ_MODEL_REPROBE;
-                    if (through_lds) probe = 0;
-                }
-                stamp = now;
-            }
-            MPH_T (1);
-            GZ_WAVE_BATCH_TAIL
-            MPH_T (3);
+    for (uint32_t j = j0; j < j1; j += 64) {
+        GZ_WAVE_BATCH_HEAD
+        MPH_T (0);
+        if constexpr (kRounds) { d_model_batch_rounds<J> (tot, lane, cnt, occ ? b_rk : 0u, nsym, n_absent, out_cum, out_freq, out_tot, n_ev); MPH_T (2); }
+        else                   { d_model_batch<J> (M, tot, lane, cnt, occ ? b_rk : 0u, nsym, n_absent, out_cum, out_freq, out_tot, n_ev); MPH_T (1); }
+        GZ_WAVE_BATCH_TAIL
+        MPH_T (3);
 #ifdef GZ_MODEL_PHASES
-            mph_[4]++; mph_[6] += n_ev;
+        mph_[4]++; mph_[5] += kRounds ? 1 : 0; mph_[6] += n_ev;
 #endif
-        }
-        if constexpr (LDSM || kRounds) {
-            for (; j < j1 && (kRounds || through_lds); j += 64) {
-                GZ_WAVE_BATCH_HEAD
-                MPH_T (0);
-#ifdef GZ_MODEL_SERIAL_LDS
-                d_model_batch_lds<J> (M, tot, lane, cnt, occ ? b_rk : 0u, nsym, n_absent, symlist, out_cum, out_freq, out_tot, n_ev);
-#else
-                d_model_batch_rounds<J> (M, tot, lane, cnt, occ ? b_rk : 0u, nsym, n_absent, symlist, out_cum, out_freq, out_tot, n_ev);
-#endif
-                if constexpr (!kRounds) {
-                    const uint32_t now = (uint32_t)wall_clock64 ();
-                    lds_cost = now - stamp; stamp = now;
-                    through_lds = force_lds || (n_ev >= GZ_MODEL_EVENTS_OUT && (lds_cost <= reg_cost || !reg_cost) && ++probe < GZ_MODEL_REPROBE);
-                    if (!through_lds) probe = 0;
-                }
-                MPH_T (2);
-                GZ_WAVE_BATCH_TAIL
-                MPH_T (3);
-#ifdef GZ_MODEL_PHASES
-                mph_[4]++; mph_[5]++; mph_[6] += n_ev;
-#endif
-            }
-        }
     }
 #undef GZ_WAVE_BATCH_HEAD
 #undef GZ_WAVE_BATCH_TAIL
@@ -1064,6 +924,7 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
     if (!lane && j1 - j0 >= GZ_MODEL_HOT) { for (int k = 0; k < 7; k++) atomicAdd (&g_mph[k], mph_[k]); atomicAdd (&g_mph[7], 1ull); }
 #endif
     if (save) {
+        if constexpr (kRounds) d_rounds_tables_out<J> (M, lane, nsym, symlist);
         #pragma unroll
         for (int j = 0; j < J; j++) {
             uint32_t *s6 = st + (6 * j) * 64 + lane;
@@ -1099,7 +960,7 @@ __device__ unsigned long long g_model_slowest;     // (10 ns ticks << 40) | (lis
 #define GZ_MODEL_T0 do {} while (0)
 #define GZ_MODEL_T1(ctx, occ) do {} while (0)
 #endif
-__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const GzDivInv *inv_tab, uint32_t p0, uint32_t chunk, uint32_t force_rounds)
+__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const GzDivInv *inv_tab, uint32_t p0, uint32_t chunk)
 {
     GZ_XCD_GRID (li, by, n_list);
     GzdLeaf &L = leaves[list[li]];
@@ -1193,8 +1054,8 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
                 continue;
             }
         }
-        if (nsym_u <= 128) d_arith_model_wave<2, true> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, nullptr, force_rounds != 0);
-        else               d_arith_model_wave<4, true> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, nullptr, force_rounds != 0);
+        if (nsym_u <= 128) d_arith_model_wave<2> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        else               d_arith_model_wave<4> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
         GZ_MODEL_T1 (ctx, j1 - j0);
     }
 }
