@@ -456,6 +456,10 @@ __device__ static __forceinline__ void d_model_batch_rounds (uint32_t &tot, int 
     uint64_t todo = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
     const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0, self = 1ull << lane;
     uint32_t t = d_uniform (tot), changes = 0;
+    // (the masks are all zero between rounds: whoever sets a bit clears its word again)
+    #pragma unroll
+    for (int j = 0; j < J; j++) s_mask[1 + j * 64 + lane] = 0;
+    if (lane < 2) s_mask[lane ? 1 + 64 * J : 0] = 0;
     while (todo) {
         if (t + GZ_MODEL_STEP > GZ_MODEL_LIMIT) {
             // ---- the occurrence that halves the model, on its own (c_simple_model.h:124-146): bump, halve, rebuild, one bubble step
@@ -495,9 +499,7 @@ __device__ static __forceinline__ void d_model_batch_rounds (uint32_t &tot, int 
         const bool pend = (todo >> lane) & 1;
         const uint32_t p = t_pos[rk], q = p ? p - 1 : 0;
         const uint32_t f = t_freq[p], fl = t_freq[q], g = t_gap[p], c = t_cum[p], rb = t_rank[q];
-        #pragma unroll
-        for (int j = 0; j < J; j++) s_mask[1 + j * 64 + lane] = 0;
-        if (lane < 2) s_mask[lane ? 1 + 64 * J : 0] = 0;
+        const uint32_t g_nx = t_gap[p + 1 < nsym ? p + 1 : p];
         gz_wave_sync ();
         if (pend) atomicOr (&s_mask[1 + p], (unsigned long long)self);
         gz_wave_sync ();
@@ -513,6 +515,8 @@ __device__ static __forceinline__ void d_model_batch_rounds (uint32_t &tot, int 
         }
         gz_wave_sync ();
         const unsigned long long me = s_mask[1 + p], lf = s_mask[p], rt = s_mask[2 + p], lo = s_low[p];
+        gz_wave_sync ();
+        if (pend) s_mask[1 + p] = 0;
         const uint32_t fj = f + GZ_MODEL_STEP * (uint32_t)__popcll (me & below), flj = fl + GZ_MODEL_STEP * (uint32_t)__popcll (lf & below);
         const uint32_t cj = c + GZ_MODEL_STEP * (uint32_t)__popcll (lo & below), tj = t + GZ_MODEL_STEP * gz_mbcnt (todo);
         const bool bad = pend && (g != 0 || (p > 0 && fj + GZ_MODEL_STEP > flj));
@@ -531,12 +535,14 @@ __device__ static __forceinline__ void d_model_batch_rounds (uint32_t &tot, int 
         }
         gz_wave_sync ();
         // ... then their order changes, every one by its own lane: none of them touches what another one does
+        // (nothing is read back: entry p's cumulative after the additions above is c + 16 x the committed occurrences below p)
         if (com && bad) {
-            if (g) { t_gap[p] = (uint16_t)(g - 1); if (p + 1 < nsym) t_gap[p + 1] = (uint16_t)(t_gap[p + 1] + 1); t_cum[p] -= 1; }
+            const uint32_t c_now = c + GZ_MODEL_STEP * (uint32_t)__popcll (lo & C);
+            if (g) { t_gap[p] = (uint16_t)(g - 1); if (p + 1 < nsym) t_gap[p + 1] = (uint16_t)(g_nx + 1); t_cum[p] = c_now - 1; }
             else {
                 t_freq[q] = fj + GZ_MODEL_STEP; t_freq[p] = flj;
                 t_rank[q] = (uint8_t)rk; t_rank[p] = (uint8_t)rb; t_pos[rk] = (uint8_t)q; t_pos[rb] = (uint8_t)p;
-                t_cum[p] = t_cum[p] - flj + fj + GZ_MODEL_STEP;
+                t_cum[p] = c_now - flj + fj + GZ_MODEL_STEP;
             }
         }
         changes += (uint32_t)__popcll (badm & C);
