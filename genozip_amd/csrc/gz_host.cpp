@@ -986,11 +986,11 @@ static int gz_sync_do (GzHandle *h)
 #endif
 #ifdef GZ_MODEL_PHASES
     if (!h->pending.empty ()) {
-        unsigned long long v[8], z[8] = { 0 };
+        unsigned long long v[9], z[9] = { 0 };
         (void)hipMemcpyFromSymbol (v, HIP_SYMBOL (g_mph), sizeof (v));
         (void)hipMemcpyToSymbol (HIP_SYMBOL (g_mph), z, sizeof (z));
-        if (v[7]) fprintf (stderr, "[phases] bg %d: %llu hot waves, %llu batches (%llu through LDS), %.2f events per batch; us per batch: head %.3f register batches %.3f LDS batches %.3f tail %.3f\n",
-                           (int)h->background, v[7], v[4], v[5], (double)v[6] / (double)v[4], (double)v[0] / 100.0 / (double)v[4],
+        if (v[7]) fprintf (stderr, "[phases] bg %d: %llu hot waves, %llu batches (%llu in rounds, %.2f rounds each), %.2f events per batch; us per batch: head %.3f register batches %.3f batches in rounds %.3f tail %.3f\n",
+                           (int)h->background, v[7], v[4], v[5], v[5] ? (double)v[8] / (double)v[5] : 0.0, (double)v[6] / (double)v[4], (double)v[0] / 100.0 / (double)v[4],
                            v[4] > v[5] ? (double)v[1] / 100.0 / (double)(v[4] - v[5]) : 0.0, v[5] ? (double)v[2] / 100.0 / (double)v[5] : 0.0, (double)v[3] / 100.0 / (double)v[4]);
     }
 #endif

@@ -531,7 +531,8 @@ __device__ static __forceinline__ void d_model_batch_rounds (uint32_t &tot, int 
         #pragma unroll
         for (int j = 0; j < J; j++) {
             const uint32_t e = (uint32_t)(j * 64 + lane);
-            if (e < nsym) t_cum[e] += GZ_MODEL_STEP * ((uint32_t)__popc (x_lo[j] & (uint32_t)C) + (uint32_t)__popc (x_hi[j] & (uint32_t)(C >> 32)));
+            // (an LDS add, not a read and a write: nothing to wait for; entries past the alphabet's end are never looked at)
+            atomicAdd (&t_cum[e], GZ_MODEL_STEP * ((uint32_t)__popc (x_lo[j] & (uint32_t)C) + (uint32_t)__popc (x_hi[j] & (uint32_t)(C >> 32))));
         }
         gz_wave_sync ();
         // ... then their order changes, every one by its own lane: none of them touches what another one does
@@ -549,6 +550,9 @@ __device__ static __forceinline__ void d_model_batch_rounds (uint32_t &tot, int 
         gz_wave_sync ();
         t += GZ_MODEL_STEP * (uint32_t)__popcll (C);
         todo &= ~C;
+#ifdef GZ_MODEL_PHASES
+        changes += 1u << 16;                                       // (rounds, for the phase report)
+#endif
     }
     tot = t; n_changes = changes;
 }
@@ -815,7 +819,7 @@ __global__ void __launch_bounds__(256) k_ctx_succ (GzdLeaf *leaves, const uint32
 #ifndef GZ_MODEL_HOT
 #define GZ_MODEL_HOT 1000000u
 #endif
-__device__ unsigned long long g_mph[8];
+__device__ unsigned long long g_mph[9];
 #define MPH_T(k) do { const unsigned long long now_ = wall_clock64 (); mph_[k] += now_ - mt_; mt_ = now_; } while (0)
 #else
 #define MPH_T(k) do { } while (0)
@@ -857,7 +861,7 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
     const uint32_t n_absent = ms - nsym;
     if constexpr (kRounds) d_rounds_tables_in<J> (M, lane, nsym);
 #ifdef GZ_MODEL_PHASES
-    unsigned long long mph_[7] = { 0, 0, 0, 0, 0, 0, 0 }, mt_ = wall_clock64 ();
+    unsigned long long mph_[7] = { 0, 0, 0, 0, 0, 0, 0 }, mt_ = wall_clock64 (), mph_r_ = 0;
 #endif
 
     // the records of a batch are stored while the next batch is being worked on: the division constants they need come
@@ -920,14 +924,14 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
         GZ_WAVE_BATCH_TAIL
         MPH_T (3);
 #ifdef GZ_MODEL_PHASES
-        mph_[4]++; mph_[5] += kRounds ? 1 : 0; mph_[6] += n_ev;
+        mph_[4]++; mph_[5] += kRounds ? 1 : 0; mph_[6] += n_ev & 0xffff; mph_r_ += n_ev >> 16;
 #endif
     }
 #undef GZ_WAVE_BATCH_HEAD
 #undef GZ_WAVE_BATCH_TAIL
     if (p_on) d_record_store (recs + p_pos, d_model_record (p_cum, p_freq, p_inv));
 #ifdef GZ_MODEL_PHASES
-    if (!lane && j1 - j0 >= GZ_MODEL_HOT) { for (int k = 0; k < 7; k++) atomicAdd (&g_mph[k], mph_[k]); atomicAdd (&g_mph[7], 1ull); }
+    if (!lane && j1 - j0 >= GZ_MODEL_HOT) { for (int k = 0; k < 7; k++) atomicAdd (&g_mph[k], mph_[k]); atomicAdd (&g_mph[7], 1ull); atomicAdd (&g_mph[8], mph_r_); }
 #endif
     if (save) {
         if constexpr (kRounds) d_rounds_tables_out<J> (M, lane, nsym, symlist);
