@@ -52,6 +52,46 @@ def chain_block_boundaries(E, oracle, big=True):
     return len(items)
 
 
+def wide_models(E, oracle, big=True):
+    """the models of alphabets of more than 64 symbols (two or four planes: kept in LDS tables, their batches taken in rounds): sizes of the
+    alphabet around the plane boundaries (65, 128, 129, 192, 193, 256), near-uniform / two-level / geometric frequencies (39 / 30 / 16 order
+    changes per batch of 64), the worst cases for what a round can commit (every occurrence next to the previous one's list position: a
+    sawtooth over neighbouring symbols; one symbol over and over with a rare other one), lengths beyond several halvings of a model
+    (every ~4 000 occurrences) and - big - beyond a position chunk (65 536), orders 0 and 1, plain and run-length variants"""
+    import numpy as np
+    def two_level(seed, n, nsym):
+        r = synth.u32(seed, 2 * n)
+        hot = r[:n] % 100 < 70
+        return np.where(hot, r[n:] % 16, 16 + r[n:] % (nsym - 16)).astype(np.uint8)
+    def geometric(seed, n, nsym):
+        u = (synth.u32(seed, n).astype(np.float64) + 1.0) / 4294967297.0
+        return np.minimum(np.floor(np.log(u) / np.log(0.95)), nsym - 1).astype(np.uint8)
+    def sawtooth(seed, n, nsym):
+        return ((np.arange(n, dtype=np.int64) + (synth.u32(seed, n) % 3)) % nsym).astype(np.uint8)
+    def one_hot(seed, n, nsym):
+        r = synth.u32(seed, n)
+        return np.where(r % 50 == 0, r // 50 % nsym, 7).astype(np.uint8)
+    kinds = (("uniform", lambda sd, n, k: np.frombuffer(synth.uniform_bytes(sd, n, k).tobytes(), dtype=np.uint8)), ("two-level", two_level), ("geometric", geometric),
+             ("sawtooth", sawtooth), ("one-hot", one_hot))
+    ns = [700, 9000] + ([70000, 140000] if big else [])
+    items, names, seed = [], [], 7700
+    for nsym in ((65, 128, 129, 192, 193, 256) if big else (65, 129, 256)):
+        for kind, fn in kinds:
+            for n in ns:
+                if not big and n > 700 and kind in ("sawtooth", "one-hot") and nsym != 129:
+                    continue
+                seed += 1
+                d = fn(seed, n, nsym).tobytes()
+                for codec in ((16, 17, 18, 19) if big or n <= 700 else (16, 17)):
+                    if n > 9000 and codec in (18, 19) and kind != "two-level":
+                        continue
+                    items.append((codec, d)); names.append((codec, kind, nsym, n))
+    got = E.compress_many(items)
+    for (codec, d), g, nm in zip(items, got, names):
+        assert g == oracle.codec_compress(codec, d), nm
+    return len(items)
+
+
 def host_call_surface(E, oracle):
     """the COMPRESS()/UNCOMPRESS() shaped single calls incl. the soft-fail convention (compressor.c:89-110)"""
     data = synth.markov_bytes(9, 3000, 40, 33).tobytes()

@@ -143,6 +143,10 @@ def test_emul_chain_block_boundaries(emul_engine, oracle):
     parity.chain_block_boundaries(emul_engine, oracle, big=False)
 
 
+def test_emul_wide_models(emul_engine, oracle):
+    assert parity.wide_models(emul_engine, oracle, big=False) > 60
+
+
 def test_emul_assign_sort(emul_engine, oracle):
     parity.assign_sort(emul_engine, oracle, rounds=1500)
 

@@ -458,3 +458,7 @@ def test_rans_tables(gpu_engine, oracle):
 
 def test_vcf_retest(gpu_engine, oracle):
     parity.vcf_retest(gpu_engine, oracle, 40, 100)
+
+
+def test_wide_models(gpu_engine, oracle):
+    assert parity.wide_models(gpu_engine, oracle, big=True) > 300
