@@ -912,9 +912,18 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
             nx_pos = rp; nx_rk = (j + 64 + lane < j1) ? to_rank (rr) : 0u; \
         } \
         uint32_t out_cum = 0, out_freq = 0, out_tot = 0, n_ev = 0;
+// (-DGZ_EXP_SORTED_RECORDS: an EXPERIMENT that gives wrong files - the records stored in sorted (context-major) order, 64 consecutive
+//  ones per batch, to see what the scattered stores cost: the streamed form's model launches 1.39 -> 1.18 ms, its call 92 -> 85 ms.
+//  That is the most a coalescing scheme could win BEFORE paying for the pass that puts the records into stream order - round 3's
+//  k_rec_unsort lost more than that - so the records stay scattered.)
+#ifdef GZ_EXP_SORTED_RECORDS
+#define GZ_EXP_RECORD_POS(stream_pos, sorted_pos) (sorted_pos)
+#else
+#define GZ_EXP_RECORD_POS(stream_pos, sorted_pos) (stream_pos)
+#endif
 #define GZ_WAVE_BATCH_TAIL \
         if (p_on) d_record_store (recs + p_pos, d_model_record (p_cum, p_freq, p_inv)); \
-        p_on = occ; p_pos = b_pos; p_cum = out_cum; p_freq = out_freq; \
+        p_on = occ; p_pos = GZ_EXP_RECORD_POS (b_pos, j + lane); p_cum = out_cum; p_freq = out_freq; \
         if (occ) p_inv = inv_tab[out_tot];
     for (uint32_t j = j0; j < j1; j += 64) {
         GZ_WAVE_BATCH_HEAD
