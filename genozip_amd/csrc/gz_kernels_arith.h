@@ -1288,12 +1288,29 @@ __global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const Gzd
         const uint32_t *ck = (const uint32_t *)L.ckpt + 2 * (size_t)slice;
         uint32_t rlo = ck[0], rhi = ck[1], kb[4] = { 0, 0, 0, 0 }, ksum = 0;
         const uint32_t m = i0 >= n ? 0u : (i0 + 64 <= n ? 64u : n - i0);      // (an empty leaf has one empty slice)
-        for (uint32_t j = 0; j < m; j++) {
-            const uint4 c = rec[i0 + j];
-            uint32_t k;
-            const uint32_t r = d_chain_step (rlo, rhi, c.x, c.y, c.z, &k);
-            tile[lane * 65 + j] = c.w * r;
-            kb[j >> 4] |= k << (2 * (j & 15)); ksum += k;
+        // (eight records requested at a time, through GLOBAL loads: as `rec[i0 + j]` in the loop this was a flat load waited for on the
+        //  spot - one trip to memory per symbol, 64 in a row per lane: 1.3 ms per launch of the streamed form where 1 GB at the
+        //  device's rate is 0.3)
+        #pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            uint32_t kw = 0;
+            #pragma unroll
+            for (uint32_t h = 0; h < 2; h++) {
+                const uint32_t j0 = q * 16 + h * 8;
+                if (j0 < m) {
+                    uint4 c[8];
+                    #pragma unroll
+                    for (uint32_t u = 0; u < 8; u++) c[u] = gz_ldg_u32x4 (rec + i0 + (j0 + u < m ? j0 + u : m - 1));
+                    #pragma unroll
+                    for (uint32_t u = 0; u < 8; u++) if (j0 + u < m) {
+                        uint32_t k;
+                        const uint32_t r = d_chain_step (rlo, rhi, c[u].x, c[u].y, c[u].z, &k);
+                        tile[lane * 65 + j0 + u] = c[u].w * r;
+                        kw |= k << (2 * (h * 8 + u)); ksum += k;
+                    }
+                }
+            }
+            kb[q] = kw;
         }
         if (m && (rlo != ck[2] || rhi != ck[3])) L.overflow = 2;
         ((uint32_t *)L.kpos)[slice] = ksum;

@@ -1,6 +1,6 @@
-cp genozip_amd/libgenozip_amd.so /tmp/real.so
-bash tools/prof_timeline4.sh s_real --stream-reads 8000000 > /dev/null 2>&1
-cp genozip_amd/variants/sortedrec.so genozip_amd/libgenozip_amd.so
-bash tools/prof_timeline4.sh s_sorted --stream-reads 8000000 > /dev/null 2>&1
-cp /tmp/real.so genozip_amd/libgenozip_amd.so
-for t in s_real s_sorted; do echo == $t; head -c 300 gpurun_out/tl4_$t/bench.json; echo; tail -2 gpurun_out/tl4_$t/trace.err; grep -E "k_arith_model|k_arith_chain|k_ctx_scatter|k_chain_expand" gpurun_out/tl4_$t/kernel_stats.csv | cut -d, -f1-4 | cut -c1-40,100-; done
+run() { echo "$@"; python bench.py "$@" --no-cpu 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'], d['ms_per_step'], {k: v for k, v in d['roofline']['kernel_ms_per_step_summed_over_concurrent_launches'].items() if k in ('k_chain_expand','k_low_scatter','k_low_scan','k_ctx_scatter','k_arith_model','k_arith_chain','k_ctx_count','k_ctx_scan')})"; }
+python -m pytest tests/test_gpu.py -x -q -k "codec or golden or arith or chain or wide" 2>&1 | tail -2
+run --steps 6 --warmup 2
+run --stream-reads 8000000 --steps 3 --warmup 1
+run --stream-reads 8000000 --steps 3 --warmup 1
+run --config bam --steps 4 --warmup 1
