@@ -92,6 +92,45 @@ def wide_models(E, oracle, big=True):
     return len(items)
 
 
+def wide_models_random(E, oracle, n_cases, seed0=8800, max_n=30000):
+    """randomly drawn streams over wide alphabets (65 - 256 symbols; Zipf / geometric / uniform / hot-and-rare mixtures with drawn
+    parameters; a drawn share of the stream as runs of one symbol; lengths 100 - max_n) through all four arithmetic coders"""
+    import numpy as np
+    items, names = [], []
+    for case in range(n_cases):
+        r = synth.u32(seed0 + case, 8)
+        nsym = 65 + int(r[0] % 192)
+        n = 100 + int(r[1] % (max_n - 100))
+        kind = int(r[2] % 4)
+        u = (synth.u32(seed0 + 100000 + case, n).astype(np.float64) + 0.5) / 4294967296.0
+        if kind == 0:                                              # Zipf with exponent 0.6 .. 2.0
+            w = 1.0 / (1.0 + np.arange(nsym)) ** (0.6 + (r[3] % 15) / 10.0)
+            d = np.searchsorted(np.cumsum(w / w.sum()), u).clip(0, nsym - 1)
+        elif kind == 1:                                            # geometric, ratio 0.90 .. 0.99
+            q = 0.90 + (r[3] % 10) / 100.0
+            d = np.minimum(np.floor(np.log(u) / np.log(q)), nsym - 1)
+        elif kind == 2:                                            # uniform
+            d = np.floor(u * nsym)
+        else:                                                      # h hot symbols with 50 - 90 % of the stream, the rest uniform
+            h = 1 + int(r[3] % 20); share = 0.5 + (r[4] % 5) / 10.0
+            v = (synth.u32(seed0 + 200000 + case, n).astype(np.float64) + 0.5) / 4294967296.0
+            d = np.where(u < share, np.floor(v * h), h + np.floor(v * (nsym - h)))
+        d = d.astype(np.uint8)
+        if r[5] % 3 == 0:                                          # runs: every position copies its predecessor with probability 0.3 .. 0.8
+            keep = (synth.u32(seed0 + 300000 + case, n) % 10) < (3 + r[6] % 6)
+            idx = np.where(~keep, np.arange(n), 0)
+            idx[0] = 0
+            d = d[np.maximum.accumulate(idx)]
+        perm = synth.u32(seed0 + 400000 + case, 256).argsort(kind="stable").astype(np.uint8)     # (the symbols' byte values: any)
+        data = perm[d].tobytes()
+        codec = (16, 17, 18, 19)[int(r[7] % 4)]
+        items.append((codec, data)); names.append((case, codec, kind, nsym, n))
+    got = E.compress_many(items)
+    for (codec, d), g, nm in zip(items, got, names):
+        assert g == oracle.codec_compress(codec, d), nm
+    return len(items)
+
+
 def host_call_surface(E, oracle):
     """the COMPRESS()/UNCOMPRESS() shaped single calls incl. the soft-fail convention (compressor.c:89-110)"""
     data = synth.markov_bytes(9, 3000, 40, 33).tobytes()

@@ -145,6 +145,7 @@ def test_emul_chain_block_boundaries(emul_engine, oracle):
 
 def test_emul_wide_models(emul_engine, oracle):
     assert parity.wide_models(emul_engine, oracle, big=False) > 60
+    assert parity.wide_models_random(emul_engine, oracle, 24, max_n=6000) == 24
 
 
 def test_emul_assign_sort(emul_engine, oracle):

@@ -462,3 +462,4 @@ def test_vcf_retest(gpu_engine, oracle):
 
 def test_wide_models(gpu_engine, oracle):
     assert parity.wide_models(gpu_engine, oracle, big=True) > 300
+    assert parity.wide_models_random(gpu_engine, oracle, 400) == 400
