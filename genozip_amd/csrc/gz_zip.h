@@ -911,7 +911,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     if (!d_staging) return GZ_ERR_HIP;
     if (NCJ) {
         HIPCHK (h, hipMemcpyAsync (d_pack, pack.data (), NCJ * sizeof (GzdPackJob), hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL (k_pack_sizes, dim3 (1), dim3 (1), 0, h->stream, d_pack, (uint32_t)NCJ, pack_cap_used, d_pack_total);
+        hipLaunchKernelGGL (k_pack_sizes, dim3 (1), dim3 (256), 257 * 8, h->stream, d_pack, (uint32_t)NCJ, pack_cap_used, d_pack_total);
         hipLaunchKernelGGL (k_pack_copy, dim3 ((uint32_t)NCJ), dim3 (256), 0, h->stream, (const GzdPackJob *)d_pack, d_staging, (const uint64_t *)d_pack_total);
     }
     T.mark ("queue");
