@@ -32,7 +32,7 @@ import subprocess
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")    # (genozip_amd/lib.py: must be set before the process's first HIP call)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")    # (genozip_amd/lib.py: must be set before the process's first HIP call)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -47,7 +47,7 @@ struct ArenaBlock { uint8_t *base; size_t size, used; };
 
 // More hardware queues than the HIP runtime's default of 4 (see genozip_amd/lib.py): only effective when this library is
 // loaded before the process's first HIP call; never overrides what the host has set.
-__attribute__((constructor)) static void gz_runtime_env (void) { setenv ("GPU_MAX_HW_QUEUES", "12", 0); }
+__attribute__((constructor)) static void gz_runtime_env (void) { setenv ("GPU_MAX_HW_QUEUES", "8", 0); }
 
 // workgroups of persistent chain kernels in flight in this process / those of them that hold a whole compute unit
 static std::atomic<int> g_chain_wgs (0), g_chain_cus (0);

@@ -11,7 +11,7 @@ import os
 # coder's long chains. The HIP runtime maps all streams onto 4 hardware queues by default, and whatever shares a queue with a gate waits
 # with it (configs[2] 61.3 -> 58.0 ms per step, binned FASTQ 57.2 -> 52.5, the default step 92.9 -> 91.8 with 12 queues; 6, 8, 16 measured too). The variable is read when the HIP runtime starts: it
 # has to be in the environment before the first HIP call of the process (the library's own constructor sets it too, for C hosts).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libgenozip_amd.so")
