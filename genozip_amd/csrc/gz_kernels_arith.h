@@ -9,9 +9,11 @@
 //   k_rle_events   (run-length variant only) bytes -> coding events (model id, symbol): a segmented scan
 //   k_ctx_*        a stable counting sort of the positions by context, so that a context's wave reads only its own
 //   k_arith_model  the triple (cum, freq, tot) fed to the coder depends only on MODEL history, and the models never
-//                  interact: one wave per (leaf, context), the model in registers (1, 2 or 4 planes of one entry per
-//                  lane), 64 occurrences at a time, order changes (swaps, hops) patched in as events. Writes a 16-byte
-//                  record per position: the reciprocal of tot as a double, freq, cum.
+//                  interact: one wave per (leaf, context), 64 occurrences at a time through closed formulas (prefix
+//                  counts inside the batch: LDS masks + a DPP scan); order changes (swaps, hops) are events - up to 64
+//                  symbols: the model in registers, events patched in one by one; wider alphabets: the model in LDS
+//                  tables, the batch in ROUNDS (everything that no earlier event can reach commits at once). Writes a
+//                  16-byte record per position: the reciprocal of tot as a double, freq, cum.
 //   k_arith_chain  what is truly serial: range -> range / tot * freq -> renormalise. One wave per leaf, four vector
 //                  instructions per symbol in double precision, the state hopping a lane per symbol (gz_chain_asm.h);
 //                  persistent, following the models position chunk by chunk.
@@ -67,7 +69,8 @@ __device__ static inline uint32_t d_writelane (uint32_t val, int lane, uint32_t 
 
 // ---- the adaptive models ----------------------------------------------------------------------------------------------
 // Only the symbols that occur in the leaf are kept (nsym <= 256 of them), in list order, entry e in register plane
-// e / 64 of lane e % 64 (J = 1, 2 or 4 planes; every quality / token stream has J = 1). The max_sym - nsym entries of
+// e / 64 of lane e % 64 (J = 1, 2 or 4 planes; every quality / token stream has J = 1; with J > 1 the registers only carry
+// the model between position chunks - its wave keeps it in LDS tables of the same content, see ROUNDS below). The max_sym - nsym entries of
 // symbols that never occur all have frequency 1 for ever (halving leaves 1 alone) and never start a swap, so they are
 // interchangeable: each present symbol just remembers how many of them sit directly in front of it (`gap`). Coding a
 // symbol whose gap is > 0 swaps it with such an entry (its frequency, >= 17, always beats 1): gap--, and the next present
@@ -81,9 +84,9 @@ __device__ static inline uint32_t d_writelane (uint32_t val, int lane, uint32_t 
 //        freq_j = F[p_j] + 16 * #{i < j : p_i == p_j}      cum_j = C[p_j] + 16 * #{i < j : p_i < p_j}
 //        tot_j  = tot + 16 * j                              (p = list position of the occurrence's symbol)
 //    and whether occurrence j would swap needs only the left neighbour's frequency at that time,
-//    FL[p_j] + 16 * #{i < j : p_i == p_j - 1}. The lanes fetch F, C, gap, FL with cross-lane reads; one round per
-//    DISTINCT list position in the batch accumulates the counts (and, speculatively, the model update); events (below)
-//    are patched in place.
+//    FL[p_j] + 16 * #{i < j : p_i == p_j - 1}. The lanes fetch F, C, gap, FL with cross-lane reads (J = 1) or from the
+//    LDS tables (J > 1); the counts come through LDS masks (d_batch_counts_lds); events (below) are patched in place
+//    (J = 1) or end a round (J > 1).
 template <int J> struct GzModel { uint32_t sym[J], srank[J], freq[J], cum[J], gap[J], where[J]; };
 
 // R[idx / 64] of lane idx % 64, idx per lane
@@ -161,49 +164,14 @@ __device__ static __forceinline__ void d_model_serial_step (GzModel<J> &M, uint3
 
 // What a batch's occurrences add, from the list positions p of the pending ones (lanes of T): as an occurrence I need the number of
 // EARLIER pending occurrences at my position (eq), at a lower one (lt) and at my left neighbour's (eql); as list entries lane + 64 j I
-// need the number of ALL pending occurrences at my position (ceq[j]) and below it (clt[j]). One ballot per BIT of the position,
-// most significant first: the lanes that agree with a value on all higher bits and have a 0 where it has a 1 are the smaller ones;
-// the lanes left at the end are the equal ones. (The first version took one round per DISTINCT position of the batch - 20 in a
-// quality stream, 35 with a wide alphabet - at about the cost of one bit here.)
-template <int J>
-__device__ static __forceinline__ void d_batch_counts (uint32_t p, uint64_t T, uint32_t nbits, int lane, uint64_t below,
-                                                       uint32_t &eq, uint32_t &lt, uint32_t &eql, uint32_t (&ceq)[J], uint32_t (&clt)[J])
-{
-    const uint32_t q = p - 1;                                   // (p == 0: no left neighbour, the result is dropped)
-    uint64_t P = T, Q = T, Pe[J];
-    uint32_t l = 0;
-    #pragma unroll
-    for (int j = 0; j < J; j++) { Pe[j] = T; clt[j] = 0; }
-    for (int b = (int)nbits - 1; b >= 0; b--) {
-        const bool mine = (p >> b) & 1;
-        const uint64_t B = __ballot (mine), nB = ~B;
-        l += mine ? (uint32_t)__popcll (P & nB & below) : 0u;
-        P &= mine ? B : nB;
-        Q &= ((q >> b) & 1) ? B : nB;
-        #pragma unroll
-        for (int j = 0; j < J; j++) {
-            const bool em = ((uint32_t)(j * 64 + lane) >> b) & 1;
-            clt[j] += em ? (uint32_t)__popcll (Pe[j] & nB) : 0u;
-            Pe[j] &= em ? B : nB;
-        }
-    }
-    eq = (uint32_t)__popcll (P & below); lt = l; eql = p ? (uint32_t)__popcll (Q & below) : 0u;
-    #pragma unroll
-    for (int j = 0; j < J; j++) {
-        // (entries beyond the highest position a batch can hold agree with nobody only if their upper bits are looked at too)
-        const uint32_t e = (uint32_t)(j * 64 + lane);
-        const bool in_range = nbits >= 32 || (e >> nbits) == 0;
-        ceq[j] = in_range ? (uint32_t)__popcll (Pe[j]) : 0u;
-        clt[j] = in_range ? clt[j] : (uint32_t)__popcll (T);
-    }
-}
-
-// The same counts through the LDS: 35 vector instructions per bit of the position went into the ballots above (the per-lane sets P, Q, Pe
-// are 64-bit values: every and / select / popcount is two instructions) - 210 of the ~560 a batch of a quality context costs. Here every
-// pending occurrence ORs its lane bit into the word of its position (one ds_or_b64); a list entry then reads the set of ITS occurrences,
-// an OR-scan over the entries (DPP, gz_wave_or_scan) makes the set of occurrences BELOW every entry, and an occurrence reads the sets of
-// its position, of its left neighbour's and of everything below: the counts are popcounts of those under the mask of the earlier
-// lanes. ~45 vector instructions and three trips to the LDS whatever the alphabet.
+// need the number of ALL pending occurrences at my position (ceq[j]) and below it (clt[j]). Through the LDS: every pending occurrence
+// ORs its lane bit into the word of its position (one ds_or_b64); a list entry then reads the set of ITS occurrences, an OR-scan over
+// the entries (DPP, gz_wave_or_scan) makes the set of occurrences BELOW every entry, and an occurrence reads the sets of its position,
+// of its left neighbour's and of everything below: the counts are popcounts of those under the mask of the earlier lanes. ~45 vector
+// instructions and three trips to the LDS whatever the alphabet. (Round 1 took one ballot round per DISTINCT position of the batch - 20
+// in a quality stream; rounds 2-3 one ballot per BIT of the position, most significant first, narrowing per-lane sets of "lanes that
+// agree with me so far" - 35 vector instructions per bit, because those sets are 64-bit values: 210 of the ~560 instructions a batch
+// of a quality context cost.)
 // LDS: s_mask [2 + 64 J] (word 0 stands for "the position left of position 0": nobody; the last one for the position behind the last), s_low [64 J]
 #define GZ_MLDS_OFF 512                   // (the model's tables: d_model_batch_rounds, below)
 #define GZ_MLDS_BYTES 3072
@@ -259,7 +227,6 @@ __device__ static __forceinline__ void d_model_batch (GzModel<J> &M, uint32_t &t
                                                       uint32_t n_absent, uint32_t &out_cum, uint32_t &out_freq, uint32_t &out_tot, uint32_t &n_events)
 {
     uint64_t todo = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
-    const uint32_t nbits = nsym > 1 ? 32u - (uint32_t)__builtin_clz (nsym - 1) : 0u;   // list positions are < nsym
     const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0;
     // (a model that has seen fewer than two occurrences per symbol is all ties: nearly every occurrence is an event, and
     //  one at a time is the cheaper way through them)
@@ -274,32 +241,7 @@ __device__ static __forceinline__ void d_model_batch (GzModel<J> &M, uint32_t &t
             // as an occurrence I count the earlier occurrences at my position / below it / at my left neighbour; as
             // list entries lane + 64 j I count what the whole batch adds to my frequency and cumulative
             uint32_t eq = 0, lt = 0, eql = 0, ceq[J], clt[J];
-#ifndef GZ_COUNTS_LDS_MAXJ
-#define GZ_COUNTS_LDS_MAXJ 2
-#endif
-            if (J <= GZ_COUNTS_LDS_MAXJ) d_batch_counts_lds<J> (p, todo, lane, below, eq, lt, eql, ceq, clt);
-            else if (J <= 2) d_batch_counts<J> (p, todo, nbits, lane, below, eq, lt, eql, ceq, clt);
-            else {
-                // (four planes: 8 bits x 62 operations cost more than a round per distinct position - measured on BAM's packed
-                //  qualities, whose batches hold ~10 distinct positions: 124 -> 134 ms per step with the ballots per bit)
-                #pragma unroll
-                for (int j = 0; j < J; j++) ceq[j] = clt[j] = 0;
-                for (uint64_t rem = todo; rem; ) {
-                    const uint32_t q = d_readlane (p, __ffsll ((unsigned long long)rem) - 1);
-                    const uint64_t mb = __ballot (p == q) & todo;
-                    rem &= ~mb;
-                    const uint32_t before = gz_mbcnt (mb), c = (uint32_t)__popcll (mb);
-                    eq  += (q == p) ? before : 0u;
-                    lt  += (q < p) ? before : 0u;
-                    eql += (q + 1 == p) ? before : 0u;
-                    #pragma unroll
-                    for (int j = 0; j < J; j++) {
-                        const uint32_t e = (uint32_t)(j * 64 + lane);
-                        ceq[j] += (q == e) ? c : 0u;
-                        clt[j] += (q < e) ? c : 0u;
-                    }
-                }
-            }
+            d_batch_counts_lds<J> (p, todo, lane, below, eq, lt, eql, ceq, clt);
             const uint32_t f = F + GZ_MODEL_STEP * eq, tj = tot + GZ_MODEL_STEP * gz_mbcnt (todo);
             uint32_t cu = Cm + GZ_MODEL_STEP * lt, fl = FL + GZ_MODEL_STEP * eql;
             // the first occurrence that would push the total over the limit ends the attempt
