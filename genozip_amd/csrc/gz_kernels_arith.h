@@ -1321,36 +1321,48 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_scatter (GzdLeaf *leaves, con
     // goes through memory (resid, added by k_low_resid once every digit is stored: 1 slice in 16 instead of every one - that kernel was
     // 0.6 ms at the tail of the step).
     uint32_t carry_in = 0;
+    // (the run's 16 x 64 values and shift counts are requested up front through global loads - one trip to memory per wave instead of
+    //  one per slice - and the accumulators are a wave's own: wave-level syncs, no workgroup barrier)
+    uint32_t a_all[GZ_LOW_RUN], k_all[GZ_LOW_RUN];
+    const uint32_t slice0 = B.first_slice + wave * GZ_LOW_RUN;
+    const uint32_t kp_all = gz_ldg_u32 (kpos + (lane < (int)GZ_LOW_RUN && slice0 + lane < ns ? slice0 + lane : 0));   // lane q: where slice q's digits start
+    #pragma unroll
+    for (uint32_t q = 0; q < GZ_LOW_RUN; q++) {
+        const uint32_t slice = B.first_slice + wave * GZ_LOW_RUN + q, i = slice * GZ_LOW_SLICE + lane;
+        const bool in = slice < ns && i < n;
+        a_all[q] = gz_ldg_u32 (av + (in ? i : 0));
+        k_all[q] = gz_ldg_u32 (kbits + (in ? slice * 4 + (lane >> 4) : 0));
+        if (!in) { a_all[q] = 0; k_all[q] = 0; }
+    }
+    #pragma unroll
     for (uint32_t q = 0; q < GZ_LOW_RUN; q++) {
         const uint32_t slice = B.first_slice + wave * GZ_LOW_RUN + q;
-        const bool on = slice < ns;                            // (all waves keep hitting the barriers)
-        const uint32_t i = slice * GZ_LOW_SLICE + lane;
-        uint32_t k = 0, a = 0;
-        if (on && i < n) { a = av[i]; k = (kbits[slice * 4 + (lane >> 4)] >> (2 * (lane & 15))) & 3u; }
+        const bool on = slice < ns;
+        const uint32_t a = a_all[q], k = (k_all[q] >> (2 * (lane & 15))) & 3u;
         const uint64_t m1 = __ballot (k >= 1), m2 = __ballot (k == 2);
         const uint32_t P = (uint32_t)__popcll (m1 & below) + (uint32_t)__popcll (m2 & below);   // shifts before me in the slice
         const uint32_t K = (uint32_t)__popcll (m1) + (uint32_t)__popcll (m2);
         const bool last = on && slice == ns - 1;
         const uint32_t own = last ? K + 5 : K;                 // digits this slice owns: one per shift (+ the closing 5)
         for (uint32_t j = lane; j < 144; j += 64) acc[j] = j < 4 ? carry_in : 0u;
-        __syncthreads ();
+        gz_wave_sync ();
         if (on && a) {
             atomicAdd (&acc[P],     a >> 24);
             atomicAdd (&acc[P + 1], (a >> 16) & 0xff);
             atomicAdd (&acc[P + 2], (a >> 8) & 0xff);
             atomicAdd (&acc[P + 3], a & 0xff);
         }
-        __syncthreads ();
+        gz_wave_sync ();
         carry_in = 0;
         if (on) {
-            const uint32_t base = kpos[slice] + 1;             // output byte of this slice's first shift
+            const uint32_t base = (uint32_t)__shfl ((int)kp_all, (int)q) + 1;     // output byte of this slice's first shift
             for (uint32_t j = lane; j < own; j += 64) dig[base + j] = acc[j];
             if (lane < 4) {
                 const uint32_t left = last ? 0u : acc[own + lane];
                 if (q == GZ_LOW_RUN - 1) resid[(slice / GZ_LOW_RUN) * 4 + lane] = left; else carry_in = left;
             }
         }
-        __syncthreads ();
+        gz_wave_sync ();
     }
 }
 
