@@ -1212,7 +1212,9 @@ __device__ static inline GzdLowBlock d_low_block (const GzdLowBlock *blocks, con
 // them are 16 bytes written by its lane, and their sum is the slice's entry in the prefix sum of output positions (k_low_scan).
 // (Until round 4 this kernel wrote r, and k_low_count / k_low_scatter each read every symbol's 16-byte record again for freq and cum:
 // 60 bytes of traffic per symbol between the three, now 25.)
-// Same grid as the low kernels that follow it (one workgroup = 64 slices), 64 threads, 64 * 65 * 4 bytes of LDS.
+// Same grid as the low kernels that follow it (one workgroup = 64 slices), 64 threads, GZ_EXPAND_LDS bytes of LDS.
+#define GZ_EXPAND_TILE_BYTES (64 * 65 * 4)          // 16 640: the tile of a = cum * r values, [64 slices][65]
+#define GZ_EXPAND_LDS (GZ_EXPAND_TILE_BYTES + 64 * 9 * 16)
 __global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const GzdLowBlock *blocks, const uint32_t *list, uint32_t p0)
 {
     const GzdLowBlock B = d_low_block (blocks, list, p0);
@@ -1226,34 +1228,50 @@ __global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const Gzd
     uint32_t *av = (uint32_t *)L.rvals;
     uint32_t *tile = (uint32_t *)gz_lds;                        // [64 slices][65]
     const uint32_t slice = B.first_slice + lane, i0 = slice * GZ_LOW_SLICE;
-    if (slice < ns) {
-        const uint32_t *ck = (const uint32_t *)L.ckpt + 2 * (size_t)slice;
-        uint32_t rlo = ck[0], rhi = ck[1], kb[4] = { 0, 0, 0, 0 }, ksum = 0;
-        const uint32_t m = i0 >= n ? 0u : (i0 + 64 <= n ? 64u : n - i0);      // (an empty leaf has one empty slice)
-        // (eight records requested at a time, through GLOBAL loads: as `rec[i0 + j]` in the loop this was a flat load waited for on the
-        //  spot - one trip to memory per symbol, 64 in a row per lane: 1.3 ms per launch of the streamed form where 1 GB at the
-        //  device's rate is 0.3)
+    const bool mine = slice < ns;
+    const uint32_t *ck = (const uint32_t *)L.ckpt + 2 * (size_t)(mine ? slice : 0);
+    uint32_t rlo = ck[0], rhi = ck[1], kb[4] = { 0, 0, 0, 0 }, ksum = 0;
+    const uint32_t m = !mine || i0 >= n ? 0u : (i0 + 64 <= n ? 64u : n - i0);      // (an empty leaf has one empty slice)
+    // The records of 64 slices x 8 symbols at a time, loaded COALESCED - eight lanes take the eight records (one 128-byte line) of a
+    // slice, eight slices per load instruction - and handed to the slices' lanes through the LDS. (As `rec[i0 + j]` per lane this was
+    // one flat load per symbol waited for on the spot; eight global loads per trip, still one line per lane, made 6.4 -> 4.7 ms of it
+    // per default step: every line then came from the L2 eight times.) The next eight are in flight while these are worked on.
+    uint4 *stage = (uint4 *)(gz_lds + GZ_EXPAND_TILE_BYTES);       // [64 slices][8 + 1]
+    const uint32_t ld_s = (uint32_t)lane >> 3, ld_j = (uint32_t)lane & 7;
+    uint4 nx[8];
+    auto load8 = [&] (uint32_t jbase) {
         #pragma unroll
-        for (uint32_t q = 0; q < 4; q++) {
-            uint32_t kw = 0;
-            #pragma unroll
-            for (uint32_t h = 0; h < 2; h++) {
-                const uint32_t j0 = q * 16 + h * 8;
-                if (j0 < m) {
-                    uint4 c[8];
-                    #pragma unroll
-                    for (uint32_t u = 0; u < 8; u++) c[u] = gz_ldg_u32x4 (rec + i0 + (j0 + u < m ? j0 + u : m - 1));
-                    #pragma unroll
-                    for (uint32_t u = 0; u < 8; u++) if (j0 + u < m) {
-                        uint32_t k;
-                        const uint32_t r = d_chain_step (rlo, rhi, c[u].x, c[u].y, c[u].z, &k);
-                        tile[lane * 65 + j0 + u] = c[u].w * r;
-                        kw |= k << (2 * (h * 8 + u)); ksum += k;
-                    }
-                }
-            }
-            kb[q] = kw;
+        for (uint32_t it = 0; it < 8; it++) {
+            const uint32_t sl = B.first_slice + it * 8 + ld_s, idx = sl * GZ_LOW_SLICE + jbase + ld_j;
+            nx[it] = gz_ldg_u32x4 (rec + (sl < ns && idx < n ? idx : 0));
         }
+    };
+    load8 (0);
+    #pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+        uint32_t kw = 0;
+        #pragma unroll
+        for (uint32_t h = 0; h < 2; h++) {
+            const uint32_t j0 = q * 16 + h * 8;
+            #pragma unroll
+            for (uint32_t it = 0; it < 8; it++) stage[(it * 8 + ld_s) * 9 + ld_j] = nx[it];
+            gz_wave_sync ();
+            if (j0 + 8 < 64) load8 (j0 + 8);
+            uint4 c[8];
+            #pragma unroll
+            for (uint32_t u = 0; u < 8; u++) c[u] = stage[lane * 9 + u];
+            gz_wave_sync ();
+            #pragma unroll
+            for (uint32_t u = 0; u < 8; u++) if (j0 + u < m) {
+                uint32_t k;
+                const uint32_t r = d_chain_step (rlo, rhi, c[u].x, c[u].y, c[u].z, &k);
+                tile[lane * 65 + j0 + u] = c[u].w * r;
+                kw |= k << (2 * (h * 8 + u)); ksum += k;
+            }
+        }
+        kb[q] = kw;
+    }
+    if (mine) {
         if (m && (rlo != ck[2] || rhi != ck[3])) L.overflow = 2;
         ((uint32_t *)L.kpos)[slice] = ksum;
         ((uint4 *)L.kbits)[slice] = make_uint4 (kb[0], kb[1], kb[2], kb[3]);
