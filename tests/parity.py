@@ -92,14 +92,14 @@ def wide_models(E, oracle, big=True):
     return len(items)
 
 
-def wide_models_random(E, oracle, n_cases, seed0=8800, max_n=30000):
+def wide_models_random(E, oracle, n_cases, seed0=8800, max_n=30000, min_sym=65):
     """randomly drawn streams over wide alphabets (65 - 256 symbols; Zipf / geometric / uniform / hot-and-rare mixtures with drawn
     parameters; a drawn share of the stream as runs of one symbol; lengths 100 - max_n) through all four arithmetic coders"""
     import numpy as np
     items, names = [], []
     for case in range(n_cases):
         r = synth.u32(seed0 + case, 8)
-        nsym = 65 + int(r[0] % 192)
+        nsym = min_sym + int(r[0] % (257 - min_sym))
         n = 100 + int(r[1] % (max_n - 100))
         kind = int(r[2] % 4)
         u = (synth.u32(seed0 + 100000 + case, n).astype(np.float64) + 0.5) / 4294967296.0
@@ -112,7 +112,7 @@ def wide_models_random(E, oracle, n_cases, seed0=8800, max_n=30000):
         elif kind == 2:                                            # uniform
             d = np.floor(u * nsym)
         else:                                                      # h hot symbols with 50 - 90 % of the stream, the rest uniform
-            h = 1 + int(r[3] % 20); share = 0.5 + (r[4] % 5) / 10.0
+            h = 1 + int(r[3] % min(20, nsym - 1)); share = 0.5 + (r[4] % 5) / 10.0
             v = (synth.u32(seed0 + 200000 + case, n).astype(np.float64) + 0.5) / 4294967296.0
             d = np.where(u < share, np.floor(v * h), h + np.floor(v * (nsym - h)))
         d = d.astype(np.uint8)
