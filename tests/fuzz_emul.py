@@ -5,9 +5,11 @@ Round 1: 4 224 codec cases (8 codecs x random structure x sizes around every thr
 b250 columns (both generation paths, dictionary sizes around every VARL boundary, ONE_UP runs) - no mismatch.
 Round 2: `wide` - 608 streams of 5 000 - 70 000 bytes over alphabets of 66 - 256 byte values with holes, uniform / few successors /
 mixed / skewed, also as the bytes of 16-bit integers, through the arithmetic coders: the eventful batches of the models' LDS way
-(d_model_batch_lds) incl. halvings and position chunks - no mismatch. `driver` - 164 runs of the whole VBlock driver (tests/parity.py::
+(round 3's serial LDS batches) incl. halvings and position chunks - no mismatch. `driver` - 164 runs of the whole VBlock driver (tests/parity.py::
 fastq_zip: 9 - 120 reads per mate, 1 - 2 calls, uniform / binned scores, the three DOMQ modes, small VBlocks first, speculation forced or
-not) against the oracle's composition - no mismatch."""
+not) against the oracle's composition - no mismatch.
+Round 4 (the wide models in LDS tables, their batches in rounds - d_model_batch_rounds; LDS-mask counts): `wide` 388 streams, `driver` 48 runs
+- no mismatch; on the GPU tools/fuzz_wide_models.py: 92 500 randomly drawn streams (alphabets of 2 - 256 symbols, up to 3 MB) - no mismatch."""
 import os
 import sys
 import time
