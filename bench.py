@@ -639,20 +639,24 @@ def main():
     other = None
     if world == 1 and not a.stream_reads and a.qual == "div" and not a.no_cpu:
         import copy
-        b = copy.copy(a); b.qual = "bin"
-        wl2 = Workload(E, b, rank, world, device)
-        os.environ["GZ_ZIP_PRIOR_ONLY"] = "1"
-        wl2.step(None)
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        for _ in range(3):
+        try:                                                      # (a side figure: it must never cost the run its headline)
+            b = copy.copy(a); b.qual = "bin"
+            wl2 = Workload(E, b, rank, world, device)
+            os.environ["GZ_ZIP_PRIOR_ONLY"] = "1"
             wl2.step(None)
-        torch.cuda.synchronize()
-        ms2 = (time.perf_counter() - t1) / 3 * 1e3
-        del os.environ["GZ_ZIP_PRIOR_ONLY"]
-        val2 = (wl2.text_len - wl2.n_reads_own * (L + 1)) / 1e6 / (ms2 / 1e3)
-        other = {"qual_profile": "bin", "ms_per_step": round(ms2, 3), "value": round(val2, 1), "unit": "MB/s", "steps": 3,
-                 "note": "the same file with SURVEY 8d's binned quality profile (cold, as the headline); its bit-exactness is what tests/test_gpu.py checks"}
-        del wl2
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(3):
+                wl2.step(None)
+            torch.cuda.synchronize()
+            ms2 = (time.perf_counter() - t1) / 3 * 1e3
+            val2 = (wl2.text_len - wl2.n_reads_own * (L + 1)) / 1e6 / (ms2 / 1e3)
+            other = {"qual_profile": "bin", "ms_per_step": round(ms2, 3), "value": round(val2, 1), "unit": "MB/s", "steps": 3,
+                     "note": "the same file with SURVEY 8d's binned quality profile (cold, as the headline); its bit-exactness is what tests/test_gpu.py checks"}
+            del wl2
+        except Exception as e:                                    # noqa: BLE001
+            other = {"qual_profile": "bin", "error": repr(e)}
+        finally:
+            os.environ.pop("GZ_ZIP_PRIOR_ONLY", None)
 
     # per-rank byte counts -> whole-job sums
     z_total = wl.offs[-1]
