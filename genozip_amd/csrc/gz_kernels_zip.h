@@ -430,6 +430,42 @@ __global__ void __launch_bounds__(256) k_seq_snips (GzdSeqSnip S)
     if (S.l3_len[r]) atomicAdd (S.n_line3, 1u);
 }
 
+// ---- QUAL: the snip of every read (fastq_seg_QUAL, src/fastq_qual.c:24-47) --------------------------------------------------------------
+// A line that is one score repeated (str_is_monochar, src/strings.h:176-184: an empty line and a single score count) segs
+// { SNIP_SPECIAL, FASTQ_SPECIAL_monochar_QUAL, score } and takes no part in QUAL.local (dl->dont_compress_QUAL: fastq_zip_qual hands the
+// codecs 0 bytes for it, :74); every other line segs { SNIP_LOOKUP } (seg_simple_lookup, src/seg.c:134-137). One thread per read: a 4-byte
+// slot of snip text, its (offset, length) for the column kernels, and the length the QUAL gather / CODEC_DOMQ are to take (0 for a repeated
+// score). Like k_seq_snips the scores are compared with the first 8 at a time; a line that is not one score is left after its first bytes.
+struct GzdQualSnip {
+    const uint8_t *text; const uint32_t *qual_off, *qual_len; uint32_t n;
+    uint8_t prefix[4]; uint32_t prefix_len;      // { SNIP_SPECIAL, code }: the score follows
+    uint8_t *slots; uint32_t *snip_off, *snip_len, *eff_len;
+};
+
+__global__ void __launch_bounds__(256) k_qual_snips (GzdQualSnip S)
+{
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= S.n) return;
+    const uint32_t len = S.qual_len[r];
+    const uint8_t *p = S.text + S.qual_off[r];
+    const uint8_t c = p[0];                              // (an empty line: the byte behind it - what the reference's qual[0] reads)
+    bool mono = true;
+    {
+        const uint64_t pat = 0x0101010101010101ull * c;
+        uint32_t i = 0;
+        for (; mono && i < len && ((uintptr_t)(p + i) & 7); i++) mono = p[i] == c;
+        for (; mono && i + 8 <= len; i += 8) mono = *(const uint64_t *)(p + i) == pat;
+        for (; mono && i < len; i++) mono = p[i] == c;
+    }
+    uint8_t *s = S.slots + (size_t)r * 4;
+    uint32_t k = 0;
+    if (mono) { for (; k < S.prefix_len; k++) s[k] = S.prefix[k]; s[k++] = c; }
+    else s[k++] = 1;                                     // SNIP_LOOKUP (src/context.h:33)
+    for (uint32_t z = k; z < 4; z++) s[z] = 0;
+    S.snip_off[r] = r * 4; S.snip_len[r] = k;
+    S.eff_len[r] = mono ? 0 : len;
+}
+
 // GZ_FQ_ITEM_EXPECT: the item of every record must be exactly `want` (<= 16 bytes) - grid (tiles of 256 records)
 struct GzdExpect { const uint8_t *text; const uint32_t *off, *len; uint32_t n; uint8_t want[16]; uint32_t want_len; uint32_t *n_bad; };
 __global__ void __launch_bounds__(256) k_item_expect (GzdExpect X)

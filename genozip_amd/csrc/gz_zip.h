@@ -52,6 +52,8 @@ struct ZipCol {                    // one (VBlock, context) of this process
     uint8_t lcodec = 0, bcodec = 0;
     int early = -1;                            // index of this local's stream in the batch coded ahead on the second handle
     bool host_len = false;                     // a dyn-int local whose final byte length the host knows (transposed here, not by the batch of local jobs)
+    bool pre_node = false;                     // an R2 VBlock whose context's r2_node is new to the file: the VBlock's first new node (fastq.c:664-665)
+    bool host_local = false;                   // the local was put together on the host (ston_local holds it): uploaded with the small payloads
 };
 
 // One (VBlock, context) as the merge sees it - what a process has to tell the others when the VBlocks of a file are dealt out
@@ -120,7 +122,7 @@ struct GzZipFile {
     GzHandle *h2 = NULL;                   // the long streams (QUAL) are coded here, ahead of and beside everything else
     GzFastqPlan plan;
     std::vector<GzFastqCtx> ctxs;
-    std::vector<std::vector<uint8_t>> snips;
+    std::vector<std::vector<uint8_t>> snips, r2_nodes;
     std::vector<GzZctx *> zctx;
     std::vector<ArenaBlock> ws;            // device workspace of one call (bump allocated, reused by the next call)
     std::vector<uint8_t> stage;            // host staging
@@ -223,18 +225,24 @@ extern "C" GzZipFile *gz_zip_open (GzHandle *h, const GzFastqPlan *plan)
     GzZipFile *f = new GzZipFile ();
     f->h = h; f->h_user = h; f->plan = *plan;
     f->ctxs.assign (plan->ctxs, plan->ctxs + plan->n_ctxs);
-    f->snips.resize (plan->n_ctxs);
+    f->snips.resize (plan->n_ctxs); f->r2_nodes.resize (plan->n_ctxs);
     for (uint32_t i = 0; i < plan->n_ctxs; i++) {
         GzFastqCtx &c = f->ctxs[i];
         if (c.snip && c.snip_len) f->snips[i].assign (c.snip, c.snip + c.snip_len);
         c.snip = f->snips[i].data ();
+        if (c.r2_node && c.r2_node_len) {
+            if (c.r2_node_len > 16 || (c.kind != GZ_FQ_SEQ_SNIP && c.kind != GZ_FQ_ITEM_TEXT) || memchr (c.r2_node, 0, c.r2_node_len)) return zip_open_failed (f);
+            f->r2_nodes[i].assign (c.r2_node, c.r2_node + c.r2_node_len);
+        }
+        else c.r2_node_len = 0;
+        c.r2_node = f->r2_nodes[i].data ();
         if ((c.kind == GZ_FQ_ITEM_TEXT || c.kind == GZ_FQ_ITEM_INT || c.kind == GZ_FQ_ITEM_DELTA) && c.item > plan->n_seps) return zip_open_failed (f);
         if ((c.kind == GZ_FQ_CONST || c.kind == GZ_FQ_ITEM_DELTA) && !c.snip_len) return zip_open_failed (f);
         if (c.kind == GZ_FQ_ITEM_TEXT && c.snip_len > 4) return zip_open_failed (f);
         if (c.kind == GZ_FQ_ITEM_EXPECT && (c.snip_len > 16 || c.item > plan->n_seps)) return zip_open_failed (f);                 // (a lead-in of every snip: at most 4 bytes)
         if (c.kind == GZ_FQ_TOPLEVEL && (c.con_len < 8 || c.con_len > c.snip_len || (c.con_len - 8) % 12)) return zip_open_failed (f);   // Container_0 + n ContainerItem
         if (c.kind == GZ_FQ_SEQ_SNIP) { if (!c.snip_len || c.snip_len > 4 || f->seq_snip_ctx >= 0) return zip_open_failed (f); f->seq_snip_ctx = (int)i; }
-        if (c.kind == GZ_FQ_QUAL) { if (f->qual_ctx >= 0) return zip_open_failed (f); f->qual_ctx = (int)i; }     // (one QUAL per plan)
+        if (c.kind == GZ_FQ_QUAL) { if (f->qual_ctx >= 0 || c.snip_len > 3) return zip_open_failed (f); f->qual_ctx = (int)i; }     // (one QUAL per plan; its snip: the lead-in of a monochar line's)
         if (c.kind == GZ_FQ_QUAL_AUX) { if (c.item > 2 || f->aux[c.item] >= 0) return zip_open_failed (f); f->aux[c.item] = (int)i; }
         f->zctx.push_back (gz_zctx_create (plan->estimated_entries));
         if (c.lcodec) gz_zctx_commit_codec (f->zctx.back (), 1, c.lcodec);
@@ -649,23 +657,60 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         if (R) KLAUNCH (h, k_seq_snips, dim3 ((R + 255) / 256), dim3 (256), 0, S);
         if (f->seq_snip_ctx < 0) nonref_len = NULL;                        // (only the line-3 check was wanted: SEQ as the plan without SQBITMAP has it)
     }
+    // QUAL's snip of every read (fastq_seg_QUAL, src/fastq_qual.c:24-47), and what QUAL.local and CODEC_DOMQ take of the line: a line of one
+    // repeated score segs the special snip and is left out (the callback's 0 bytes, :74) - from here on qual_len is that length
+    uint8_t *q_slots = NULL; uint32_t *q_off = NULL, *q_len = NULL;
+    const bool qual_col = f->qual_ctx >= 0 && f->ctxs[f->qual_ctx].snip_len != 0;
+    if (qual_col) {
+        const GzFastqCtx &X = f->ctxs[f->qual_ctx];
+        uint32_t *qual_eff = NULL;
+        if (!(q_slots = (uint8_t *)ws_alloc (f, (size_t)R * 4 + 64)) || !(q_off = (uint32_t *)ws_alloc (f, ((size_t)R + 8) * 4)) ||
+            !(q_len = (uint32_t *)ws_alloc (f, ((size_t)R + 8) * 4)) || !(qual_eff = (uint32_t *)ws_alloc (f, ((size_t)R + 8) * 4))) return GZ_ERR_HIP;
+        GzdQualSnip S; memset (&S, 0, sizeof (S));
+        S.text = text; S.qual_off = qual_off; S.qual_len = qual_len; S.n = R;
+        S.prefix_len = X.snip_len; memcpy (S.prefix, X.snip, X.snip_len);
+        S.slots = q_slots; S.snip_off = q_off; S.snip_len = q_len; S.eff_len = qual_eff;
+        if (R) KLAUNCH (h, k_qual_snips, dim3 ((R + 255) / 256), dim3 (256), 0, S);
+        qual_len = qual_eff;
+    }
     WS (d_vbstat, uint32_t, 2 * (size_t)NV + 2);
 
     // the dictionaries as every VBlock of this call clones them (ctx_clone)
     struct OlDev { const uint8_t *dict = NULL; const uint64_t *ci = NULL; const uint32_t *sl = NULL; uint32_t n = 0; };
-    std::vector<OlDev> ol (NC);
+    std::vector<OlDev> ol (NC), ol_r2 (NC);
+    std::vector<uint8_t> has_pre (NC, 0);                  // the context's r2_node is not a word of the file yet: an R2 VBlock's first new node
+    std::vector<std::vector<uint8_t>> pre_stage (NC);      // (host side of the uploads below: lives until the stream has taken them)
     for (uint32_t c = 0; c < NC; c++) {
         const uint8_t k = f->ctxs[c].kind;
-        if (k != GZ_FQ_ITEM_TEXT && k != GZ_FQ_ITEM_INT && k != GZ_FQ_SEQ_SNIP) continue;
+        if (k != GZ_FQ_ITEM_TEXT && k != GZ_FQ_ITEM_INT && k != GZ_FQ_SEQ_SNIP && !(k == GZ_FQ_QUAL && qual_col)) continue;
         GzZctxView zv; gz_zctx_view (f->zctx[c], &zv);
         ol[c].n = zv.n_words;
-        if (!zv.n_words) continue;
-        uint8_t *d = (uint8_t *)ws_alloc (f, zv.dict_len + 16); uint64_t *ci = (uint64_t *)ws_alloc (f, (size_t)zv.n_words * 8); uint32_t *sl = (uint32_t *)ws_alloc (f, (size_t)zv.n_words * 4);
-        if (!d || !ci || !sl) return GZ_ERR_HIP;
-        HIPCHK (h, hipMemcpyAsync (d, zv.dict, zv.dict_len, hipMemcpyHostToDevice, h->stream));
-        HIPCHK (h, hipMemcpyAsync (ci, zv.char_index, (size_t)zv.n_words * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHK (h, hipMemcpyAsync (sl, zv.snip_len, (size_t)zv.n_words * 4, hipMemcpyHostToDevice, h->stream));
-        ol[c].dict = d; ol[c].ci = ci; ol[c].sl = sl;
+        const GzFastqCtx &X = f->ctxs[c];
+        has_pre[c] = X.r2_node_len && zctx_find (f->zctx[c], gz_snip_mix (X.r2_node, X.r2_node_len), X.r2_node, X.r2_node_len) == GZ_NO_WORD;
+        if (zv.n_words) {
+            uint8_t *d = (uint8_t *)ws_alloc (f, zv.dict_len + 16); uint64_t *ci = (uint64_t *)ws_alloc (f, (size_t)zv.n_words * 8); uint32_t *sl = (uint32_t *)ws_alloc (f, (size_t)zv.n_words * 4);
+            if (!d || !ci || !sl) return GZ_ERR_HIP;
+            HIPCHK (h, hipMemcpyAsync (d, zv.dict, zv.dict_len, hipMemcpyHostToDevice, h->stream));
+            HIPCHK (h, hipMemcpyAsync (ci, zv.char_index, (size_t)zv.n_words * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK (h, hipMemcpyAsync (sl, zv.snip_len, (size_t)zv.n_words * 4, hipMemcpyHostToDevice, h->stream));
+            ol[c].dict = d; ol[c].ci = ci; ol[c].sl = sl;
+        }
+        if (!has_pre[c]) continue;
+        // ctx_create_node in front of everything an R2 VBlock segs (fastq.c:664-665): the node is the VBlock's first new one, ol_nodes.len, and
+        // every snip new to the VBlock comes behind it. The column kernels number new nodes from the cloned words on, so R2 VBlocks are
+        // given the cloned dictionary with that snip as one more word at its end: the same node indices, a count of 0 for it
+        const uint32_t nw = zv.n_words + 1;
+        std::vector<uint8_t> &st = pre_stage[c];
+        st.resize ((size_t)zv.dict_len + X.r2_node_len + 1 + 8 + (size_t)nw * 12 + 16);
+        uint8_t *sd = st.data (); uint64_t *sci = (uint64_t *)(sd + ((zv.dict_len + X.r2_node_len + 1 + 7) & ~(uint64_t)7)); uint32_t *ssl = (uint32_t *)(sci + nw);
+        if (zv.dict_len) memcpy (sd, zv.dict, zv.dict_len);
+        memcpy (sd + zv.dict_len, X.r2_node, X.r2_node_len); sd[zv.dict_len + X.r2_node_len] = 0;
+        if (zv.n_words) { memcpy (sci, zv.char_index, (size_t)zv.n_words * 8); memcpy (ssl, zv.snip_len, (size_t)zv.n_words * 4); }
+        sci[zv.n_words] = zv.dict_len; ssl[zv.n_words] = X.r2_node_len;
+        uint8_t *dd = (uint8_t *)ws_alloc (f, st.size ());
+        if (!dd) return GZ_ERR_HIP;
+        HIPCHK (h, hipMemcpyAsync (dd, sd, st.size (), hipMemcpyHostToDevice, h->stream));
+        ol_r2[c].dict = dd; ol_r2[c].ci = (const uint64_t *)(dd + ((uint8_t *)sci - sd)); ol_r2[c].sl = (const uint32_t *)(dd + ((uint8_t *)ssl - sd)); ol_r2[c].n = nw;
     }
 
     K.col.assign ((size_t)NV * NC, ZipCol ());
@@ -731,10 +776,11 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
                 dj.out = Z.local; Z.dyn_job = (int)dyn_jobs.size (); dj.result_dev = d_dynres + Z.dyn_job;
                 dyn_jobs.push_back (dj);
             }
-            if (X.kind == GZ_FQ_ITEM_TEXT || X.kind == GZ_FQ_ITEM_INT || X.kind == GZ_FQ_SEQ_SNIP) {
+            if (X.kind == GZ_FQ_ITEM_TEXT || X.kind == GZ_FQ_ITEM_INT || X.kind == GZ_FQ_SEQ_SNIP || (X.kind == GZ_FQ_QUAL && qual_col)) {
                 GzColumnJob j; memset (&j, 0, sizeof (j));
                 j.text = text; j.off = coff; j.len = clen; j.n = nn;
                 if (X.kind == GZ_FQ_SEQ_SNIP) { j.text = sq_slots; j.off = sq_off + rr; j.len = sq_len + rr; }   // (generated text: 16-byte slots)
+                if (X.kind == GZ_FQ_QUAL) { j.text = q_slots; j.off = q_off + rr; j.len = q_len + rr; }           // (generated text: 4-byte slots)
                 uint64_t lead_bytes = 0;
                 if (X.kind == GZ_FQ_ITEM_TEXT && X.snip_len) {
                     // every snip is `snip` + the item (sam_seg_CIGAR, src/sam_cigar.c:717-720): the column is gathered into a text of its own
@@ -748,12 +794,15 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
                     pre_jobs.push_back (pj);
                     j.text = pj.out; j.off = pj.item_off; j.len = pj.item_len;
                 }
-                j.ol_dict = ol[c].dict; j.ol_char_index = ol[c].ci; j.ol_snip_len = ol[c].sl; j.n_ol = ol[c].n;
+                Z.pre_node = vbs[v].r1 >= 0 && has_pre[c];
+                const OlDev &O = Z.pre_node ? ol_r2[c] : ol[c];
+                j.ol_dict = O.dict; j.ol_char_index = O.ci; j.ol_snip_len = O.sl; j.n_ol = O.n;
                 // the dictionary of a column cannot exceed its snips + a NUL each; an item is at most the line
-                const uint64_t dict_cap = X.kind == GZ_FQ_ITEM_INT ? (uint64_t)nn * 24 + 64 : X.kind == GZ_FQ_SEQ_SNIP ? (uint64_t)nn * 17 + 64 : vbs[v].text_len + nn + lead_bytes + 64;
+                const uint64_t dict_cap = X.kind == GZ_FQ_ITEM_INT ? (uint64_t)nn * 24 + 64 : X.kind == GZ_FQ_SEQ_SNIP ? (uint64_t)nn * 17 + 64 : X.kind == GZ_FQ_QUAL ? (uint64_t)nn * 5 + 64 :
+                                          vbs[v].text_len + nn + lead_bytes + 64;
                 j.node_index = (int32_t *)ws_alloc (f, ((size_t)nn + 1) * 4); j.dict = (uint8_t *)ws_alloc (f, dict_cap); j.dict_cap = dict_cap;
                 j.node_char_index = (uint64_t *)ws_alloc (f, ((size_t)nn + 1) * 8); j.node_snip_len = (uint32_t *)ws_alloc (f, ((size_t)nn + 1) * 4);
-                j.counts = (uint32_t *)ws_alloc (f, ((size_t)nn + ol[c].n + 1) * 4); j.b250 = (uint8_t *)ws_alloc (f, (size_t)nn * 4 + 16);
+                j.counts = (uint32_t *)ws_alloc (f, ((size_t)nn + O.n + 1) * 4); j.b250 = (uint8_t *)ws_alloc (f, (size_t)nn * 4 + 16);
                 if (!j.node_index || !j.dict || !j.node_char_index || !j.node_snip_len || !j.counts || !j.b250) return GZ_ERR_HIP;
                 Z.col_job = (int)col_jobs.size (); j.result_dev = d_colres + Z.col_job;
                 Z.b250_seg = j.b250; Z.n_ol = ol[c].n;
@@ -1086,7 +1135,9 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
                 vbs[v].n_bases = Z.local_len; vbs[v].seq_packed_len = K.acgtres[2 * aj + 1]; vbs[v].seq_has_x = (uint32_t)K.acgtres[2 * aj] != 0;
                 Z.has_local = vbs[v].seq_has_x != 0; Z.ltype = GZ_LT_SUPP;   // NONREF_X.ltype (codec_acgt.c:36-41)
             }
-            r.n = Z.n; r.local_len = X.kind == GZ_FQ_QUAL ? (Z.blob_job >= 0 ? K.blobres[Z.blob_job] : 0) : Z.local_len; r.ats_node = -1;
+            // (QUAL: ctx->local.len as the segmenter leaves it - the scores of the lines that are not one repeated score; under CODEC_DOMQ alone
+            //  nothing is gathered: QUALMPLX's byte per such line stands in, only its being zero is looked at)
+            r.n = Z.n; r.local_len = X.kind == GZ_FQ_QUAL ? (Z.blob_job >= 0 ? K.blobres[Z.blob_job] : qmode0 && Z.n ? K.domq[v].res.mplx_len : 0) : Z.local_len; r.ats_node = -1;
             if (qmode0 && Z.n && (X.kind == GZ_FQ_QUAL || X.kind == GZ_FQ_QUAL_AUX)) {
                 const ZipDomq &D = K.domq[v];
                 r.domq_local_len = X.kind == GZ_FQ_QUAL ? D.res.qual_len : X.item == 0 ? D.res.runs_len : X.item == 1 ? D.res.mplx_len : D.res.divr_len;
@@ -1096,7 +1147,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
                     continue;
                 }
             }
-            if (X.kind == GZ_FQ_SEQ || X.kind == GZ_FQ_QUAL || X.kind == GZ_FQ_QUAL_AUX || !Z.n) { blob_put (K.blob, &r, sizeof (r)); continue; }
+            if (X.kind == GZ_FQ_SEQ || (X.kind == GZ_FQ_QUAL && Z.col_job < 0) || X.kind == GZ_FQ_QUAL_AUX || !Z.n) { blob_put (K.blob, &r, sizeof (r)); continue; }
             if (X.kind == GZ_FQ_TOPLEVEL) {
                 // container_seg of the VBlock's TOPLEVEL (fastq.c:845-943): repeats = the VBlock's reads (Container.repeats: bits 8-31 of the
                 // first little-endian word, container.h:74-80; written little endian since 15.0.84, container.c:48-55), then
@@ -1115,18 +1166,30 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
             const GzColumnResult &cr = K.colres[Z.col_job];
             const GzdPackJob &p = pack[Z.col_job];
             const uint32_t *counts = (const uint32_t *)(f->stage.data () + p.at[3]);
-            r.state = 1; r.n_ol = Z.n_ol; r.n_new = cr.n_new; r.dict_len = cr.dict_len; r.seg_b250_len = cr.b250_len; r.b250_count = cr.b250_count;
+            // an R2 VBlock's pre-created node (fastq.c:664-665): node ol_nodes.len of the VBlock, in front of the column's own new nodes
+            const uint32_t pre = Z.pre_node ? 1 : 0, pre_len = pre ? X.r2_node_len : 0;
+            r.state = 1; r.n_ol = Z.n_ol; r.n_new = cr.n_new + pre; r.dict_len = cr.dict_len + (pre ? pre_len + 1 : 0); r.seg_b250_len = cr.b250_len; r.b250_count = cr.b250_count;
             r.all_the_same = cr.all_the_same != 0;
             if (r.all_the_same) {
-                // the one node of the column: an ol word (the index with a count) or the VBlock's first new node
+                // the one node of the column: an ol word (the index with a count) or the first new node of the column
                 for (uint32_t k = 0; k < Z.n_ol && r.ats_node < 0; k++) if (counts[k]) r.ats_node = (int32_t)k;
-                if (r.ats_node < 0 && cr.n_new) r.ats_node = (int32_t)Z.n_ol;    // (-1: every snip was empty / missing: not droppable)
+                if (r.ats_node < 0 && cr.n_new) r.ats_node = (int32_t)(Z.n_ol + pre);    // (-1: every snip was empty / missing: not droppable)
             }
             blob_put (K.blob, &r, sizeof (r));
-            blob_put (K.blob, f->stage.data () + p.at[0], cr.dict_len);
-            blob_put (K.blob, f->stage.data () + p.at[1], 8 * (size_t)cr.n_new);
-            blob_put (K.blob, f->stage.data () + p.at[2], 4 * (size_t)cr.n_new);
-            blob_put (K.blob, counts, 4 * ((size_t)Z.n_ol + cr.n_new));
+            if (!pre) {
+                blob_put (K.blob, f->stage.data () + p.at[0], cr.dict_len);
+                blob_put (K.blob, f->stage.data () + p.at[1], 8 * (size_t)cr.n_new);
+                blob_put (K.blob, f->stage.data () + p.at[2], 4 * (size_t)cr.n_new);
+            }
+            else {
+                std::vector<uint8_t> d (r.dict_len); std::vector<uint64_t> ci (r.n_new); std::vector<uint32_t> sl (r.n_new);
+                memcpy (d.data (), X.r2_node, pre_len); d[pre_len] = 0; if (cr.dict_len) memcpy (d.data () + pre_len + 1, f->stage.data () + p.at[0], cr.dict_len);
+                ci[0] = 0; sl[0] = pre_len;
+                const uint64_t *ci0 = (const uint64_t *)(f->stage.data () + p.at[1]); const uint32_t *sl0 = (const uint32_t *)(f->stage.data () + p.at[2]);
+                for (uint32_t k = 0; k < cr.n_new; k++) { ci[k + 1] = ci0[k] + pre_len + 1; sl[k + 1] = sl0[k]; }
+                blob_put (K.blob, d.data (), d.size ()); blob_put (K.blob, ci.data (), 8 * ci.size ()); blob_put (K.blob, sl.data (), 4 * sl.size ());
+            }
+            blob_put (K.blob, counts, 4 * ((size_t)Z.n_ol + r.n_new));                // (the pre-created node's count, 0, sits between the cloned words' and the new nodes')
         }
     }
     *blob_out = K.blob.data (); *blob_len_out = K.blob.size ();
@@ -1248,7 +1311,7 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
             if (r->state == 0 || (r->state == 3 && X.kind == GZ_FQ_QUAL_AUX && qmode != GZ_CODEC_DOMQ)) continue;
             GzMergeJob m; memset (&m, 0, sizeof (m));
             m.vblock_i = hv->vblock_i;
-            m.local_len = local_len;
+            m.local_len = X.kind == GZ_FQ_QUAL ? r->local_len : local_len;          // (QUAL with a b250: ctx->local.len as the segmenter left it)
             m.pair2_identical = is_r2 && X.pair_identical;
             if (is_r2) { m.b250_r1_len = R1->has_b250[c]; m.local_r1_len = R1->has_local[c]; }
             if (r->state == 2 || r->state == 3) {
@@ -1291,6 +1354,7 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
                 if (mine) {
                     Z.has_b250 = false; Z.has_local = true; Z.ltype = GZ_LT_SINGLETON;
                     Z.local = K.col_jobs[Z.col_job].dict; Z.local_len = r->dict_len; Z.local_cap = Z.local_len;
+                    if (Z.pre_node) { Z.ston_local.assign (dict, dict + r->dict_len); Z.host_local = true; }   // (the dictionary with the pre-created node's snip in front: from the blob)
                     GzZctxView zv; gz_zctx_view (z, &zv);
                     Z.lcodec = zv.lcodec; Z.bcodec = zv.bcodec;
                 }
@@ -1343,7 +1407,7 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
     std::vector<uint8_t> small; std::vector<std::pair<ZipCol *, std::pair<int, size_t>>> small_ref;
     for (auto &Z : K.col) {
         if (Z.has_b250 && !Z.host_b250.empty ()) { small_ref.push_back ({ &Z, { 0, small.size () } }); small.insert (small.end (), Z.host_b250.begin (), Z.host_b250.end ()); small.resize ((small.size () + 15) & ~(size_t)15); }
-        if (Z.ston_only_local && !Z.ston_local.empty ()) { small_ref.push_back ({ &Z, { 1, small.size () } }); small.insert (small.end (), Z.ston_local.begin (), Z.ston_local.end ()); small.resize ((small.size () + 15) & ~(size_t)15); }
+        if ((Z.ston_only_local || Z.host_local) && !Z.ston_local.empty ()) { small_ref.push_back ({ &Z, { 1, small.size () } }); small.insert (small.end (), Z.ston_local.begin (), Z.ston_local.end ()); small.resize ((small.size () + 15) & ~(size_t)15); }
     }
     uint8_t *d_small = (uint8_t *)ws_alloc (f, small.size () + 16);
     if (!d_small) return GZ_ERR_HIP;

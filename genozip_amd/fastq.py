@@ -77,10 +77,11 @@ def illumina_plan(paired=True, qual_codec=0, estimated_entries=0, domq=0, vb_siz
     P = []
 
     def ctx(tag, did_i, kind, dtype=DTYPE_FIELD, item=0, flags=0, snip=b"", pair_identical=False, no_stons=False, lcodec=0, bcodec=0,
-            pair_assisted_b250=False, local_dep=0, nothing_char=0, con_len=0, segs_per_line=0):
+            pair_assisted_b250=False, local_dep=0, nothing_char=0, con_len=0, segs_per_line=0, r2_node=b""):
         P.append(dict(tag=tag, dict_id=dict_id(tag, dtype), did_i=did_i, kind=kind, item=item, flags=flags, snip=snip,
                       pair_identical=pair_identical, no_stons=no_stons or (paired and tag[0] in "Qq" and tag != "QUAL"), lcodec=lcodec, bcodec=bcodec,
-                      pair_assisted_b250=pair_assisted_b250, local_dep=local_dep, nothing_char=nothing_char, con_len=con_len, segs_per_line=segs_per_line))
+                      pair_assisted_b250=pair_assisted_b250, local_dep=local_dep, nothing_char=nothing_char, con_len=con_len, segs_per_line=segs_per_line,
+                      r2_node=r2_node))
 
     pi = True                          # fastq_zip_use_pair_identical: QNAME subfields, QNAME2, LINE3, E1L, E2L, TOPLEVEL (fastq.c:238-243)
     q1 = container([(dict_id("Q0NAME", DTYPE_1), bytes([CI0_COLONn, 3])), (dict_id("Q1NAME", DTYPE_1), b":"), (dict_id("Q2NAME", DTYPE_1), b":"),
@@ -96,9 +97,13 @@ def illumina_plan(paired=True, qual_codec=0, estimated_entries=0, domq=0, vb_siz
     ctx("q0NAME", 19, GZ_FQ_ITEM_TEXT, DTYPE_1, item=5, pair_identical=pi)
     ctx("q1NAME", 20, GZ_FQ_ITEM_TEXT, DTYPE_1, item=6, pair_identical=pi)
     ctx("q2NAME", 21, GZ_FQ_ITEM_TEXT, DTYPE_1, item=7, pair_identical=pi)
-    ctx("SQBITMAP", 54, GZ_FQ_SEQ_SNIP, snip=bytes([SNIP_SPECIAL, FASTQ_SPECIAL_unaligned_SEQ]) + b" ", pair_assisted_b250=True)
+    # every R2 VBlock creates the mate_lookup node in SQBITMAP before it segs a read (fastq_seg_initialize, fastq.c:664-665)
+    ctx("SQBITMAP", 54, GZ_FQ_SEQ_SNIP, snip=bytes([SNIP_SPECIAL, FASTQ_SPECIAL_unaligned_SEQ]) + b" ", pair_assisted_b250=True,
+        r2_node=bytes([SNIP_SPECIAL, FASTQ_SPECIAL_mate_lookup]) if paired else b"")
     ctx("NONREF_X", 56, GZ_FQ_SEQ, local_dep=1)                        # (NONREF itself: did_i 55, sam.h:77-79)
-    ctx("QUAL", 80, GZ_FQ_QUAL, lcodec=qual_codec)
+    # a line of one repeated score segs { SNIP_SPECIAL, FASTQ_SPECIAL_monochar_QUAL, score } and stays out of QUAL.local, all others
+    # { SNIP_LOOKUP } (fastq_seg_QUAL, fastq_qual.c:24-47)
+    ctx("QUAL", 80, GZ_FQ_QUAL, lcodec=qual_codec, snip=bytes([SNIP_SPECIAL, FASTQ_SPECIAL_monochar_QUAL]))
     for k, tag in enumerate(("DOMQRUNS", "QUALMPLX", "DIVRQUAL")):     # "these 3 must be right after SAM_QUAL" (src/sam.h:108-110)
         ctx(tag, 81 + k, GZ_FQ_QUAL_AUX, item=k, local_dep=2)
     top, top_px = fastq_toplevel(has_qname2=True)
@@ -123,7 +128,9 @@ def c_plan(plan):
         a.snip, a.snip_len = c["snip"], len(c["snip"])
         a.con_len, a.segs_per_line = c.get("con_len", 0), c.get("segs_per_line", 0)
         a.per_sample, a.transposed = int(c.get("per_sample", 0)), int(c.get("transposed", 0))
+        a.r2_node, a.r2_node_len = c.get("r2_node") or None, len(c.get("r2_node") or b"")
         keep.append(c["snip"])
+        keep.append(c.get("r2_node"))
     p = GzFastqPlan()
     p.ctxs, p.n_ctxs = arr, n
     p.seps = plan["seps"]

@@ -123,7 +123,8 @@ class GzFastqCtx(C.Structure):
     _fields_ = [("dict_id", C.c_uint8 * 8), ("did_i", C.c_uint16), ("kind", C.c_uint8), ("item", C.c_uint8), ("local_dep", C.c_uint8),
                 ("flags", C.c_uint8), ("no_stons", C.c_uint8), ("lcodec", C.c_uint8), ("bcodec", C.c_uint8), ("pair_identical", C.c_uint8),
                 ("pair_assisted_b250", C.c_uint8), ("nothing_char", C.c_uint8), ("snip", C.c_char_p), ("snip_len", C.c_uint32),
-                ("con_len", C.c_uint32), ("per_sample", C.c_uint8), ("transposed", C.c_uint8), ("segs_per_line", C.c_uint8)]
+                ("con_len", C.c_uint32), ("per_sample", C.c_uint8), ("transposed", C.c_uint8), ("segs_per_line", C.c_uint8),
+                ("r2_node", C.c_char_p), ("r2_node_len", C.c_uint32)]
 
 
 class GzFastqPlan(C.Structure):

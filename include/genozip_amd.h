@@ -484,7 +484,13 @@ enum {
     GZ_FQ_QUAL       = 6,  /* QUAL of every read -> QUAL.local (fastq_qual.c:24-60 through the get_line callback). When the plan
                               also holds its three GZ_FQ_QUAL_AUX contexts, codec_assign_best_qual_codec (src/codec.c:391-450) is
                               followed as far as FASTQ can go: the file's first VBlock decides between CODEC_DOMQ (N3: its QUAL
-                              lines pass codec_domq_qual_data_is_a_fit_for_domq) and a plain LT_BLOB local, for the whole file     */
+                              lines pass codec_domq_qual_data_is_a_fit_for_domq) and a plain LT_BLOB local, for the whole file.
+                              With a `snip` (FASTQ: { SNIP_SPECIAL, FASTQ_SPECIAL_monochar_QUAL }, 2 bytes) the context also gets
+                              fastq_seg_QUAL's b250 (src/fastq_qual.c:24-47): a line that is one score repeated (str_is_monochar) segs
+                              `snip` + that score and is left out of QUAL.local (dl->dont_compress_QUAL: the callback hands the codecs
+                              0 bytes for it, :74), every other line segs { SNIP_LOOKUP } (seg_simple_lookup) - a file without such
+                              lines ends up with neither b250 nor dictionary (ctx_drop_all_the_same, src/context.c:795-871). Without a
+                              `snip` the context has its local only (the SAM plan)                                               */
     GZ_FQ_QUAL_AUX   = 7,  /* DOMQRUNS / QUALMPLX / DIVRQUAL (item 0 / 1 / 2) of the plan's QUAL context: LT_SUPP locals at DEP_L2
                               (codec_domq.c:308-313); DOMQRUNS' dictionary takes the denormalisation table (:240-244)              */
     GZ_FQ_TOPLEVEL   = 8,  /* the TOPLEVEL container, segged ONCE per VBlock with repeats = the VBlock's reads (fastq_seg_finalize,
@@ -523,6 +529,11 @@ typedef struct {
                                      file has samples" (dyn_int_transpose, src/dyn_int.c:45-132)                              */
     uint8_t  segs_per_line;       /* GZ_FQ_CONST: how many times a read segs the snip (E2L: 3, src/fastq.c:1300-1304); 0 = once.
                                      Only the word's count depends on it                                                    */
+    const uint8_t *r2_node; uint32_t r2_node_len;   /* GZ_FQ_SEQ_SNIP / GZ_FQ_ITEM_TEXT: a node every R2 VBlock (GzFastqVB.r1 >= 0) creates in
+                                     this context BEFORE it segs anything - fastq_seg_initialize's ctx_create_node (VB, FASTQ_SQBITMAP,
+                                     { SNIP_SPECIAL, FASTQ_SPECIAL_mate_lookup }) (src/fastq.c:664-665; ctx_create_node_is_new,
+                                     src/context.c:402-409: the node's count stays 0). Unless the file's dictionary has the word already it
+                                     is the VBlock's first new node and the merge makes it a dictionary word. Host pointer, <= 16 bytes; NULL: none */
 } GzFastqCtx;
 typedef struct {
     const GzFastqCtx *ctxs; uint32_t n_ctxs;

@@ -1513,19 +1513,43 @@ int gzo_ctx_seg_column (const uint8_t *text, const uint32_t *off, const uint32_t
                         const uint8_t *ol_dict, const uint64_t *ol_char_index, const uint32_t *ol_snip_len, uint32_t n_ol,
                         GzoColumn *out)
 {
+    return gzo_ctx_seg_column_pre (text, off, len, n, ol_dict, ol_char_index, ol_snip_len, n_ol, NULL, 0, out);
+}
+
+/* the same for a context in which a node is created before anything is segged: fastq_seg_initialize's
+ * ctx_create_node (VB, FASTQ_SQBITMAP, { SNIP_SPECIAL, FASTQ_SPECIAL_mate_lookup }, 2) in R2 VBlocks (fastq.c:664-665) -
+ * ctx_create_node_is_new (context.c:402-409): ctx_create_node_do, then the count it gave taken back. A snip the cloned dictionary
+ * has changes nothing; otherwise it is the VBlock's first new node, with a count of 0 and no b250 entry.
+ * (capacities: out->dict needs pre_len + 1 more bytes, node_char_index / node_snip_len / counts one more entry) */
+int gzo_ctx_seg_column_pre (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n,
+                            const uint8_t *ol_dict, const uint64_t *ol_char_index, const uint32_t *ol_snip_len, uint32_t n_ol,
+                            const uint8_t *pre_snip, uint32_t pre_len, GzoColumn *out)
+{
     /* one chained table for both node arrays (the reference keeps two, hash.c:530-576: ol_nodes are looked up first
      * and a snip found there is never added to the VBlock's own nodes - the same thing) */
     uint32_t hash_len = 65521;
     while (hash_len < 2 * (n + n_ol) && hash_len < 0x7fffffffu / 2) hash_len = hash_len * 2 + 1;
-    uint32_t *head = malloc ((size_t)hash_len * 4), *next = malloc ((size_t)(n_ol + n + 1) * 4);
+    uint32_t *head = malloc ((size_t)hash_len * 4), *next = malloc ((size_t)(n_ol + n + 2) * 4);
     if (!head || !next) { free (head); free (next); return -1; }
     memset (head, 0xff, (size_t)hash_len * 4);
     for (uint32_t i = 0; i < n_ol; i++) {
         const uint32_t hv = o_hash_do (hash_len, ol_dict + ol_char_index[i], ol_snip_len[i]);
         next[i] = head[hv]; head[hv] = i;
     }
-    memset (out->counts, 0, (size_t)(n_ol + n) * 4);
+    memset (out->counts, 0, (size_t)(n_ol + n + (pre_len ? 1 : 0)) * 4);
     out->dict_len = 0; out->n_new = 0; out->b250_len = 0; out->b250_count = 0; out->all_the_same = 0;
+    if (pre_len) {                                                          /* ctx_create_node: context.c:354-384, then :406 */
+        const uint32_t hv = o_hash_do (hash_len, pre_snip, pre_len);
+        uint32_t e = head[hv];
+        for (; e != 0xffffffffu; e = next[e]) if (ol_snip_len[e] == pre_len && !memcmp (ol_dict + ol_char_index[e], pre_snip, pre_len)) break;
+        if (e == 0xffffffffu) {
+            e = n_ol;
+            out->node_char_index[0] = 0; out->node_snip_len[0] = pre_len;
+            memcpy (out->dict, pre_snip, pre_len); out->dict[pre_len] = 0;
+            out->dict_len = (uint64_t)pre_len + 1; out->n_new = 1;
+            next[e] = head[hv]; head[hv] = e;
+        }
+    }
     int32_t first_ni = 0;
     for (uint64_t k = 0; k < n; k++) {
         int32_t ni;

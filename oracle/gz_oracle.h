@@ -153,6 +153,10 @@ typedef struct {
 int gzo_ctx_seg_column (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n,
                         const uint8_t *ol_dict, const uint64_t *ol_char_index, const uint32_t *ol_snip_len, uint32_t n_ol,
                         GzoColumn *out);
+/* ... with a node created before anything is segged (R2 VBlocks' mate_lookup node in SQBITMAP, fastq.c:664-665) */
+int gzo_ctx_seg_column_pre (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n,
+                            const uint8_t *ol_dict, const uint64_t *ol_char_index, const uint32_t *ol_snip_len, uint32_t n_ol,
+                            const uint8_t *pre_snip, uint32_t pre_len, GzoColumn *out);
 
 /* dyn_int_append over a whole column (dyn_int.c:17,232-320, dyn_int_get_ltype :27-43): the final local type is the
  * first of UINT8, INT8, UINT16, INT16, UINT32, INT32, INT64 that holds every value (one less at the top when the

@@ -197,8 +197,9 @@ class Oracle:
         return out.raw[:n]
 
     # ---- seg-side appends, a column at a time (rows a1-a3)
-    def ctx_seg_column(self, text, off, length, ol_snips=()):
-        """-> dict(node_index, dict, node_char_index, node_snip_len, counts, b250, b250_count, all_the_same)"""
+    def ctx_seg_column(self, text, off, length, ol_snips=(), pre=b""):
+        """-> dict(node_index, dict, node_char_index, node_snip_len, counts, b250, b250_count, all_the_same)
+        pre: a snip whose node is created before anything is segged (R2 VBlocks' mate_lookup node, fastq.c:664-665)"""
         import numpy as np
         text = bytes(text)
         off = np.ascontiguousarray(off, dtype=np.uint32); length = np.ascontiguousarray(length, dtype=np.uint32)
@@ -216,14 +217,14 @@ class Oracle:
                         ("counts", ctypes.c_void_p), ("b250", ctypes.c_void_p), ("b250_len", ctypes.c_uint64),
                         ("b250_count", ctypes.c_uint64), ("all_the_same", ctypes.c_int)]
         ni = np.zeros(max(1, n), dtype=np.int32)
-        dic = np.zeros(int(length.astype(np.uint64).sum()) + n + 1, dtype=np.uint8)
-        nci = np.zeros(max(1, n), dtype=np.uint64); nsl = np.zeros(max(1, n), dtype=np.uint32)
-        counts = np.zeros(n_ol + n + 1, dtype=np.uint32)
+        dic = np.zeros(int(length.astype(np.uint64).sum()) + n + 1 + len(pre) + 1, dtype=np.uint8)
+        nci = np.zeros(n + 2, dtype=np.uint64); nsl = np.zeros(n + 2, dtype=np.uint32)
+        counts = np.zeros(n_ol + n + 2, dtype=np.uint32)
         b250 = np.zeros(4 * n + 4, dtype=np.uint8)
         c = Col(ni.ctypes.data, dic.ctypes.data, 0, nci.ctypes.data, nsl.ctypes.data, 0, counts.ctypes.data, b250.ctypes.data, 0, 0, 0)
-        rc = self.L.gzo_ctx_seg_column(text, off.ctypes.data_as(ctypes.c_void_p), length.ctypes.data_as(ctypes.c_void_p),
-                                       ctypes.c_uint64(n), ol_dict, ol_ci.ctypes.data_as(ctypes.c_void_p),
-                                       ol_len.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(n_ol), ctypes.byref(c))
+        rc = self.L.gzo_ctx_seg_column_pre(text, off.ctypes.data_as(ctypes.c_void_p), length.ctypes.data_as(ctypes.c_void_p),
+                                           ctypes.c_uint64(n), ol_dict, ol_ci.ctypes.data_as(ctypes.c_void_p),
+                                           ol_len.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(n_ol), bytes(pre), ctypes.c_uint32(len(pre)), ctypes.byref(c))
         assert rc == 0
         return dict(node_index=ni[:n].copy(), dict=dic[:c.dict_len].tobytes(), node_char_index=nci[:c.n_new].copy(),
                     node_snip_len=nsl[:c.n_new].copy(), counts=counts[:n_ol + c.n_new].copy(),

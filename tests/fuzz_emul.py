@@ -137,9 +137,11 @@ def fuzz_driver(seed, seconds):
         if rnd.random() < 0.5: os.environ["GZ_ZIP_SPECULATION"] = "always"
         else: os.environ.pop("GZ_ZIP_SPECULATION", None)
         try:
-            parity.fastq_zip(E, O, nr, n_calls=rnd.choice([1, 2]), qual=q, domq=domq, small_first=sf)
+        mono = tuple(rnd.choice([0, 0, 2, 3, 7, -1]) for _ in range(2))
+        try:
+            parity.fastq_zip(E, O, nr, n_calls=rnd.choice([1, 2]), qual=q, domq=domq, small_first=sf, mono=mono)
         except Exception as e:                      # noqa: BLE001
-            bad += 1; print("FAIL", nr, q, domq, sf, os.environ.get("GZ_ZIP_SPECULATION"), repr(e)[:300])
+            bad += 1; print("FAIL", nr, q, domq, sf, mono, os.environ.get("GZ_ZIP_SPECULATION"), repr(e)[:300])
         runs += 1
     os.environ.pop("GZ_ZIP_SPECULATION", None)
     print("runs", runs, "bad", bad)

@@ -541,9 +541,11 @@ def merge_chain(E, oracle, n):
     assert E.L.gz_hash_next_size_up(3000) == 65521 and E.L.gz_hash_next_size_up(65521) == 92681 and E.L.gz_hash_next_size_up(10 ** 9) == 16777213
 
 
-def fastq_text(n_reads, seed=11, crlf_every=0, read_len=150, mate=None, qual_seed=None, dirty_seq=False, qual="uniform"):
+def fastq_text(n_reads, seed=11, crlf_every=0, read_len=150, mate=None, qual_seed=None, dirty_seq=False, qual="uniform", mono=0):
     """a small FASTQ text in the shape of SURVEY 8d config 1 (Illumina-7 names, 40-level qualities). mate = 1 / 2: the
-    paired form - plain '+' third lines, names that differ between the mates in the read number only (own SEQ / QUAL)"""
+    paired form - plain '+' third lines, names that differ between the mates in the read number only (own SEQ / QUAL).
+    mono = m > 0: every m-th read's QUAL line is ONE score repeated (fastq_qual.c:33-36; 'F', ',' or '#' in turn - the 'F' lines most
+    often: a snip that repeats, one that is a singleton of its VBlock); mono = -1: every line is (all 'F': the context's local stays empty)"""
     r = synth.u32(seed, 4 * n_reads + 8).astype(np.int64)
     sq = seed + 1 if mate in (None, 1) else seed + 1000
     seqs = np.frombuffer(b"ACGT", dtype=np.uint8)[synth.uniform_bytes(sq, n_reads * read_len, 4)].reshape(n_reads, read_len).copy()
@@ -554,6 +556,10 @@ def fastq_text(n_reads, seed=11, crlf_every=0, read_len=150, mate=None, qual_see
         qb = synth.quality_binned(seed + 2 if qual_seed is None else qual_seed, n_reads, read_len)
         keep = np.arange(n_reads) % 9 == 4
         quals = np.where(keep[:, None], quals, qb).astype(np.uint8)
+    if mono:
+        for i in range(n_reads):
+            if mono < 0 or i % mono == mono - 1:
+                quals[i, :] = ord("F") if mono < 0 else b"FF,F#F"[(i // mono) % 6]
     out = []
     for i in range(n_reads):
         eol = b"\r\n" if crlf_every and i % crlf_every == 0 else b"\n"
@@ -779,6 +785,20 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None, host=None):
             if mono:
                 sl_nonref[r] = 0
         sq_text, sq_off = bytes(slots) + b"\0" * 64, (16 * np.arange(len(sl))).astype(np.uint32)
+    # QUAL's snip of every read and what QUAL.local / CODEC_DOMQ take of the line (fastq_seg_QUAL, src/fastq_qual.c:24-47; the callback's
+    # 0 bytes for a dont_compress_QUAL line, :74): stated here in plain Python
+    qx = next((X for X in C if X["kind"] == GZ_FQ_QUAL and X["snip"]), None)
+    if qx is not None:
+        qslots, q_len, ql = bytearray(4 * len(ql)), np.zeros(len(ql), dtype=np.uint32), ql.copy()
+        for r in range(len(ql)):
+            q = text[int(qo[r]):int(qo[r]) + int(ql[r])]
+            if q == text[int(qo[r]):int(qo[r]) + 1] * len(q):           # str_is_monochar (strings.h:176-184): also an empty line
+                snip = qx["snip"] + text[int(qo[r]):int(qo[r]) + 1]
+                ql[r] = 0
+            else:
+                snip = b"\x01"                                          # seg_simple_lookup
+            qslots[4 * r:4 * r + len(snip)] = snip; q_len[r] = len(snip)
+        q_text, q_off = bytes(qslots) + b"\0" * 64, (4 * np.arange(len(ql))).astype(np.uint32)
     lo_list = lo.tolist()
     ol_words = [z.words() for z in zstate["z"]]                    # cloned when the call starts
     n_vb = len(vbs)
@@ -832,8 +852,10 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None, host=None):
                 lt, raw = oracle.dyn_int_column(d, None, 0)
                 st.update(local=oracle.local_generate(lt, raw)[1], ltype=lt, has_local=len(raw) > 0)
             elif k == GZ_FQ_SEQ_SNIP:
-                st["col"] = oracle.ctx_seg_column(sq_text, sq_off[a:b], sq_len[a:b], ol_words[c])
+                # (an R2 VBlock creates the mate_lookup node first: fastq_seg_initialize, fastq.c:664-665)
+                st["col"] = oracle.ctx_seg_column(sq_text, sq_off[a:b], sq_len[a:b], ol_words[c], pre=X.get("r2_node", b"") if r1 >= 0 else b"")
                 st["n_ol"] = len(ol_words[c])
+                st["pre"] = int(r1 >= 0 and bool(X.get("r2_node")) and X["r2_node"] not in ol_words[c])
             elif k == GZ_FQ_TOPLEVEL and n:                              # container_seg with repeats = the VBlock's reads (fastq.c:845-943, container.c:35-64)
                 con = bytearray(X["snip"][:X["con_len"]]); con[1:4] = n.to_bytes(3, "little")
                 st["own_snip"] = b"\x04" + base64.b64encode(bytes(con)) + X["snip"][X["con_len"]:]
@@ -847,6 +869,10 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None, host=None):
             elif k == GZ_FQ_QUAL:
                 q = oracle.local_blob_column(text, qo[a:b], ql[a:b], False)
                 st.update(local=q, ltype=11, has_local=len(q) > 0)
+            if k == GZ_FQ_QUAL and qx is not None and n:                 # the context's b250 (fastq_seg_QUAL); ctx->local.len as the segmenter leaves it
+                st["col"] = oracle.ctx_seg_column(q_text, q_off[a:b], q_len[a:b], ol_words[c])
+                st["n_ol"] = len(ol_words[c])
+                st["seg_local_len"] = int(ql[a:b].astype(np.uint64).sum())
         if zstate["qual_mode"] == 13 and n:                           # codec_domq.c:308-313,240-244
             dq = next(S[v][c] for c, X in enumerate(C) if X["kind"] == GZ_FQ_QUAL)["domq"]
             for item, key in enumerate(("runs", "mplx", "divr")):
@@ -857,10 +883,11 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None, host=None):
         OZ = zstate["z"][c]
         for v, (off, ln, vi, r1) in enumerate(vbs):
             st = S[v][c]
-            if X["kind"] in (GZ_FQ_SEQ, GZ_FQ_QUAL) or not st["n"] or (X["kind"] == GZ_FQ_QUAL_AUX and "own_snip" not in st):
+            if X["kind"] == GZ_FQ_SEQ or (X["kind"] == GZ_FQ_QUAL and st["col"] is None) or not st["n"] or (X["kind"] == GZ_FQ_QUAL_AUX and "own_snip" not in st):
                 continue
             is_r2 = r1 >= 0
-            kw = dict(flags=X["flags"], local_len=len(st["local"]), pair2_identical=is_r2 and X["pair_identical"])
+            seg_local_len = st.get("seg_local_len", len(st["local"]))
+            kw = dict(flags=X["flags"], local_len=seg_local_len, pair2_identical=is_r2 and X["pair_identical"])
             if is_r2:
                 kw.update(b250_r1_len=int(S[r1][c]["has_b250"]), local_r1_len=int(S[r1][c]["has_local"]))
             if st["col"] is None:                                     # constant snip
@@ -880,13 +907,14 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None, host=None):
             col = st["col"]
             n_new, ats = len(col["node_snip_len"]), col["all_the_same"]
             st["ats"] = ats
-            can_ston = (not st["local"]) and (not X["no_stons"]) and (X["flags"] & 3) != 3 and not ats
+            can_ston = (not seg_local_len) and (not X["no_stons"]) and (X["flags"] & 3) != 3 and not ats
             if can_ston and n_new and n_new == col["b250_count"] and n_new >= st["n"] // 5 and col["b250_count"] != 1:
                 st.update(local=col["dict"], ltype=0, has_local=True)      # zip_handle_unique_words_ctxs: the dictionary becomes local
                 continue
             if ats:
+                pre = st.get("pre", 0)                                     # (the pre-created node of an R2 VBlock sits in front of the column's own new nodes)
                 nz = np.nonzero(col["counts"][:st["n_ol"]])[0]
-                node = int(nz[0]) if len(nz) else (st["n_ol"] if n_new else -1)
+                node = int(nz[0]) if len(nz) else (st["n_ol"] + pre if n_new - pre else -1)
                 col = dict(col, node_index=np.array([node], dtype=np.int32))
                 if node < 0:
                     kw["no_drop_b250"] = True
@@ -1015,7 +1043,7 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None, host=None):
     return out, zstate
 
 
-def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0, small_first=False, host=None):
+def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0, small_first=False, host=None, mono=(0, 0)):
     """the whole a1-a16 path from FASTQ text: gz_fastq_zip_vblocks over paired VBlocks (R1/R2 of a file pair in one call,
     dictionaries carried from call to call) == the oracle's step-by-step composition, byte for byte; every VBlock's z_data
     decodes again on the device (adler32 of every section, payloads) and the packed SEQ unpacks to the reads' bases.
@@ -1040,8 +1068,8 @@ def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0
         return oracle.codec_uncompress(codec, pay, ulen)
     for call in range(n_calls):
         nr = n_reads if call == 0 else max(8, n_reads // 3)
-        r1 = fastq_text(nr, seed=100 + call, dirty_seq=(call == 1), mate=1, qual=qual[call])
-        r2 = fastq_text(nr, seed=100 + call, dirty_seq=(call == 1), mate=2, qual_seed=300 + call, qual=qual[call])
+        r1 = fastq_text(nr, seed=100 + call, dirty_seq=(call == 1), mate=1, qual=qual[call], mono=mono[call])
+        r2 = fastq_text(nr, seed=100 + call, dirty_seq=(call == 1), mate=2, qual_seed=300 + call, qual=qual[call], mono=mono[call] + (mono[call] > 0))
         # two VBlocks per mate (the second shorter), R2's name their R1 counterparts
         cut = nr // 3 if small_first else (2 * nr) // 3
 

@@ -80,12 +80,14 @@ def _cut(text, n_parts):
     return [(a, b - a) for a, b in zip(cuts, cuts[1:])]
 
 
-@pytest.mark.parametrize("qual,dirty", [pytest.param("uniform", False, marks=pytest.mark.thorough), ("uniform", True), ("bin", False)])
-def test_single_file_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, qual, dirty):
+@pytest.mark.parametrize("qual,dirty,mono", [pytest.param("uniform", False, 0, marks=pytest.mark.thorough), ("uniform", True, 0), ("bin", False, 0),
+                                             ("uniform", False, 7), ("bin", True, 5), pytest.param("uniform", False, -1, marks=pytest.mark.thorough)])
+def test_single_file_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, qual, dirty, mono):
     """one FASTQ file, 3 VBlocks in 2 calls (the second clones the first's dictionaries): reads of different lengths, N bases
-    (NONREF_X), binned scores (the file goes through CODEC_DOMQ)"""
+    (NONREF_X), binned scores (the file goes through CODEC_DOMQ); mono: QUAL lines of one repeated score - FASTQ_SPECIAL_monochar_QUAL snips
+    in QUAL's b250, the lines left out of QUAL.local and of CODEC_DOMQ's streams (fastq_qual.c:33-36,74)"""
     from genozip_amd import fastq as fq
-    text = parity.fastq_text(450, seed=41, mate=1, qual=qual, dirty_seq=dirty)
+    text = parity.fastq_text(450, seed=41, mate=1, qual=qual, dirty_seq=dirty, mono=mono)
     parts = _cut(text, 3)
     plan = fq.illumina_plan(paired=False)
     F, vbs = _zip(emul_engine, plan, [(text, [(parts[0][0], parts[0][1], 1, -1)]), (text, [(parts[1][0], parts[1][1], 2, -1), (parts[2][0], parts[2][1], 3, -1)])], lzma_sub)
@@ -97,13 +99,14 @@ def test_single_file_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, qual
     assert out == text, log[:3000]
 
 
-@pytest.mark.parametrize("qual", ["uniform", "bin"])
-def test_paired_files_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, qual):
+@pytest.mark.parametrize("qual,mono", [("uniform", 0), ("bin", 0), ("uniform", 6), pytest.param("bin", 4, marks=pytest.mark.thorough)])
+def test_paired_files_round_trip(emul_engine, genounzip, lzma_sub, tmp_path, qual, mono):
     """--pair: R1 and R2 as two components of one file (R1's VBlocks 1..n, R2's n+1..2n: the reader pairs vblock_i with vblock_i - n,
-    src/writer.c:318-322); R2 sections identical to R1's are left out, R1's carry flags.paired (zfile.c:292-294,323-325)"""
+    src/writer.c:318-322); R2 sections identical to R1's are left out, R1's carry flags.paired (zfile.c:292-294,323-325); every R2 VBlock's
+    SQBITMAP starts with the mate_lookup node (fastq.c:664-665: one more dictionary word); mono: monochar QUAL lines in both mates"""
     from genozip_amd import fastq as fq
-    r1 = parity.fastq_text(360, seed=51, mate=1, qual=qual)
-    r2 = parity.fastq_text(360, seed=51, mate=2, qual_seed=333, qual=qual, dirty_seq=True)
+    r1 = parity.fastq_text(360, seed=51, mate=1, qual=qual, mono=mono)
+    r2 = parity.fastq_text(360, seed=51, mate=2, qual_seed=333, qual=qual, dirty_seq=True, mono=mono + (mono > 0))
     p1, p2 = _cut(r1, 2), _cut(r2, 2)
     text = r1 + r2
     vbs = [(p1[0][0], p1[0][1], 1, -1), (p1[1][0], p1[1][1], 2, -1), (len(r1) + p2[0][0], p2[0][1], 3, 0), (len(r1) + p2[1][0], p2[1][1], 4, 1)]

@@ -125,6 +125,15 @@ def test_emul_fastq_zip(emul_engine, oracle):
     parity.fastq_zip(emul_engine, oracle, 54, small_first=True)                         # VBlocks too small to set the file's codecs
 
 
+def test_emul_fastq_zip_monochar(emul_engine, oracle):
+    """QUAL lines of one repeated score (fastq_qual.c:33-36: FASTQ_SPECIAL_monochar_QUAL snips in QUAL's b250, the lines left out of the
+    local and of CODEC_DOMQ's streams) in both mates of a pair, whose R2 VBlocks start SQBITMAP with the mate_lookup node (fastq.c:664-665);
+    a call in which EVERY line is one (QUAL.local stays empty: its b250 is all-the-same with a special snip)"""
+    parity.fastq_zip(emul_engine, oracle, 60, mono=(7, 5))
+    parity.fastq_zip(emul_engine, oracle, 60, qual=("bin", "bin"), mono=(7, 5))
+    parity.fastq_zip(emul_engine, oracle, 40, mono=(0, -1))
+
+
 def test_emul_fastq_zip_early_path(emul_engine, oracle, monkeypatch):
     """the QUAL streams coded ahead of the merge (what the driver does for LONG streams, >= GZ_ZIP_EARLY_MIN scores: their trial is waited for in
     the seg phase, the streams start on the second handle) - forced here for streams of test size: the same bytes as the ordinary way"""

@@ -115,6 +115,18 @@ def test_fastq_zip_driver(gpu_engine, oracle):
 
 
 @pytest.mark.gpu
+def test_fastq_zip_monochar(gpu_engine, oracle):
+    """QUAL lines of one repeated score (fastq_qual.c:33-36: FASTQ_SPECIAL_monochar_QUAL snips in QUAL's b250, the lines left out of the
+    local and of CODEC_DOMQ's streams) in both mates of a pair, whose R2 VBlocks start SQBITMAP with the mate_lookup node (fastq.c:664-665);
+    calls in which EVERY line is one (QUAL.local stays empty)"""
+    parity.fastq_zip(gpu_engine, oracle, 3000, mono=(7, 5))
+    parity.fastq_zip(gpu_engine, oracle, 3000, qual=("bin", "bin"), mono=(7, 5))
+    parity.fastq_zip(gpu_engine, oracle, 1200, qual=("bin", "uniform"), mono=(3, 11), small_first=True)
+    parity.fastq_zip(gpu_engine, oracle, 600, mono=(0, -1))
+    parity.fastq_zip(gpu_engine, oracle, 600, mono=(-1, 4))
+
+
+@pytest.mark.gpu
 def test_fastq_zip_early_path(gpu_engine, oracle, monkeypatch):
     """the QUAL streams coded ahead of the merge on the second handle (the driver's way for long streams, >= GZ_ZIP_EARLY_MIN scores),
     forced for streams of test size: the same bytes as when QUAL is coded with the rest"""
