@@ -127,6 +127,16 @@ def test_fastq_zip_monochar(gpu_engine, oracle):
 
 
 @pytest.mark.gpu
+def test_e2e_files_sha256(gpu_engine):
+    """whole .genozip files (FASTQ pair and single file with monochar QUAL lines, plain and through CODEC_DOMQ; SAM with a context per tag;
+    multi-sample VCF) written by the HIP library are, byte for byte, the files the REFERENCE'S OWN genounzip has decoded back into the
+    original text in the build container (tests/golden/e2e_sha256.json, made by tests/golden/make_e2e_golden.py with the same recipe on
+    the CPU stand-in): reference-decoder evidence for HIP-made files in every GPU run"""
+    import e2e_files
+    assert e2e_files.check_against_golden(gpu_engine) == len(e2e_files.CASES)
+
+
+@pytest.mark.gpu
 def test_fastq_zip_early_path(gpu_engine, oracle, monkeypatch):
     """the QUAL streams coded ahead of the merge on the second handle (the driver's way for long streams, >= GZ_ZIP_EARLY_MIN scores),
     forced for streams of test size: the same bytes as when QUAL is coded with the rest"""
