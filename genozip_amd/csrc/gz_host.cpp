@@ -96,6 +96,7 @@ struct GzHandle {
     // (plain / through CODEC_DOMQ) - gz_zip.h, "speculation". Starts as a built-in prior - an order-1 adaptive coder is what
     // codec_assign_best_codec's size rule gives quality strings - and follows what the handle's files actually got
     int zip_qual_guess[2] = { GZ_CODEC_ARTB, 0 };
+    uint32_t debug_chain_fault = 0;        // GZ_DEBUG_CHAIN_FAULT=k (tests): k_chain_expand treats slice k - 1 of every arithmetic leaf as a checkpoint mismatch
     std::vector<ProfAcc> prof_view;        // gz_profile_get: this handle's totals + its helpers'
 };
 
@@ -222,6 +223,7 @@ static GzHandle *gz_create_do (int device, void *hip_stream, int *err, bool back
     }
     if (hipMalloc ((void **)&h->d_fail, 64) != hipSuccess || hipMemset (h->d_fail, 0, 64) != hipSuccess) { if (err) *err = GZ_ERR_HIP; gz_destroy (h); return NULL; }
     { const char *e = getenv ("GZ_NO_PIPELINE"); h->no_pipeline = e && *e && *e != '0'; }
+    { const char *e = getenv ("GZ_DEBUG_CHAIN_FAULT"); h->debug_chain_fault = e ? (uint32_t)strtoul (e, NULL, 10) : 0; }   // (tests: a forced checkpoint mismatch must fail the stream)
     // the largest LDS class of the arithmetic coder needs more than the default 64 KB of dynamic LDS
     if (hipFuncSetAttribute ((const void *)k_arith_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
         hipFuncSetAttribute ((const void *)k_arith_decode, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
@@ -734,7 +736,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                     KLAUNCH_ON (h, h->stream5, k_arith_chain, dim3 ((A.nsmall + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), GZ_KEEP_OFF_LDS,
                                 d_leaves, A.d_small, A.nsmall, (const uint32_t *)NULL, 0u, h->d_fail, (uint32_t *)NULL, 0u);
                     if (A.nlb_small) {
-                        KLAUNCH_ON (h, h->stream5, k_chain_expand, dim3 (A.nlb_small), dim3 (64), GZ_EXPAND_LDS, d_leaves, A.d_lb_small, (const uint32_t *)NULL, 0u);
+                        KLAUNCH_ON (h, h->stream5, k_chain_expand, dim3 (A.nlb_small), dim3 (64), GZ_EXPAND_LDS, d_leaves, A.d_lb_small, (const uint32_t *)NULL, 0u, h->debug_chain_fault);
                         KLAUNCH_ON (h, h->stream5, k_low_scan, dim3 (A.nsmall), dim3 (1024), 8192, d_leaves, A.d_small, 0u, 0xffffffffu);
                         KLAUNCH_ON (h, h->stream5, k_low_scatter, dim3 (A.nlb_small), dim3 (GZ_LOW_WG), GZ_KEEP_OFF_LDS, d_leaves, A.d_lb_small, (const uint32_t *)NULL, 0u);
                     }
@@ -748,7 +750,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                     const uint32_t p0 = k * A.chunk, span = P.max_arith_n - p0 < A.chunk ? P.max_arith_n - p0 : A.chunk;
                     const uint32_t wgs = (span + GZ_LOW_SLICE * GZ_LOW_SLICES_PER_WG - 1) / (GZ_LOW_SLICE * GZ_LOW_SLICES_PER_WG);
                     hipLaunchKernelGGL (k_low_gate, dim3 (1), dim3 (1), 0, h->stream6, (const uint32_t *)(A.d_progress + 16 + k), A.nbig, h->d_fail);
-                    KLAUNCH_ON (h, h->stream6, k_chain_expand, dim3 (A.nbig, wgs), dim3 (64), GZ_EXPAND_LDS, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0);
+                    KLAUNCH_ON (h, h->stream6, k_chain_expand, dim3 (A.nbig, wgs), dim3 (64), GZ_EXPAND_LDS, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0, h->debug_chain_fault);
                     KLAUNCH_ON (h, h->stream6, k_low_scan, dim3 (A.nbig), dim3 (1024), 8192, d_leaves, A.d_big, p0, A.chunk);
                     KLAUNCH_ON (h, h->stream6, k_low_scatter, dim3 (A.nbig, wgs), dim3 (GZ_LOW_WG), GZ_KEEP_OFF_LDS, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0);
                 }
@@ -757,7 +759,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_low, 0));
             }
             if (!A.pipelined) {
-                KLAUNCH (h, k_chain_expand, dim3 (A.nlb), dim3 (64), GZ_EXPAND_LDS, d_leaves, A.d_lb, (const uint32_t *)NULL, 0u);
+                KLAUNCH (h, k_chain_expand, dim3 (A.nlb), dim3 (64), GZ_EXPAND_LDS, d_leaves, A.d_lb, (const uint32_t *)NULL, 0u, h->debug_chain_fault);
                 KLAUNCH (h, k_low_scan, dim3 (A.np), dim3 (1024), 8192, d_leaves, A.d_plain, 0u, 0xffffffffu);
                 KLAUNCH (h, k_low_scatter, dim3 (A.nlb), dim3 (GZ_LOW_WG), 4 * 144 * 4, d_leaves, A.d_lb, (const uint32_t *)NULL, 0u);
             }

@@ -105,6 +105,13 @@ __device__ static inline void gz_stg_u16 (uint8_t *p, uint32_t v)     // 2 bytes
 }
 
 // ---- double precision with truncation: the range coder chain (gz_kernels_arith.h) ----------------------------------------
+// INVARIANT (k_arith_chain, k_chain_expand and whatever they call): the rounding mode below is switched behind the compiler's back, so
+// these kernels must hold NO other double- or half-precision arithmetic - none that the compiler could fold at compile time (it folds with
+// round-to-nearest), move across the s_setreg, or that needs the default mode; gz_fma_rtz's operands must never be compile-time constants
+// together. The mode ends with the wave (both kernels are leaf kernels: nothing runs after them in the same wave). The generated loop
+// (gz_chain_asm.h) names its registers itself (v50-v199, s36-s47: the clobber list keeps the compiler off them). What guards all of this at
+// run time: k_chain_expand replays every 64-symbol slice in the other formulation and fails the stream (GZ_ST_FAILED) when it does not
+// arrive at the chain's next checkpoint - tests/test_gpu.py::test_chain_checkpoint_guard forces such a mismatch and asserts the failure.
 // MODE.FP_ROUND[3:2] = 3: double precision rounds toward zero in this wave from here on. (Inline asm: a mode change the
 // compiler knows about is undone by it in front of the next floating point instruction.)
 __device__ static inline void gz_f64_round_toward_zero (void) { asm volatile ("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3" : : : "memory"); }

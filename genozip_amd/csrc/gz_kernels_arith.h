@@ -1215,7 +1215,8 @@ __device__ static inline GzdLowBlock d_low_block (const GzdLowBlock *blocks, con
 // Same grid as the low kernels that follow it (one workgroup = 64 slices), 64 threads, GZ_EXPAND_LDS bytes of LDS.
 #define GZ_EXPAND_TILE_BYTES (64 * 65 * 4)          // 16 640: the tile of a = cum * r values, [64 slices][65]
 #define GZ_EXPAND_LDS (GZ_EXPAND_TILE_BYTES + 64 * 9 * 16)
-__global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const GzdLowBlock *blocks, const uint32_t *list, uint32_t p0)
+// fault: 0, or (GZ_DEBUG_CHAIN_FAULT, tests only) 1 + the index of a slice that is treated as if it had missed the chain's checkpoint
+__global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const GzdLowBlock *blocks, const uint32_t *list, uint32_t p0, uint32_t fault)
 {
     const GzdLowBlock B = d_low_block (blocks, list, p0);
     GzdLeaf &L = leaves[B.leaf];
@@ -1272,7 +1273,7 @@ __global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const Gzd
         kb[q] = kw;
     }
     if (mine) {
-        if (m && (rlo != ck[2] || rhi != ck[3])) L.overflow = 2;
+        if (m && (rlo != ck[2] || rhi != ck[3] || slice + 1 == fault)) L.overflow = 2;
         ((uint32_t *)L.kpos)[slice] = ksum;
         ((uint4 *)L.kbits)[slice] = make_uint4 (kb[0], kb[1], kb[2], kb[3]);
     }

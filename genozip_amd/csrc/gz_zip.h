@@ -867,7 +867,8 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     //  as the first file on a fresh handle does: the "cold" figure of bench.py)
     static const int prior_guess[2] = { GZ_CODEC_ARTB, 0 };
     const char *prior_env = getenv ("GZ_ZIP_PRIOR_ONLY");
-    const int *guess = (prior_env && *prior_env && *prior_env != '0') ? prior_guess : f->h_user->zip_qual_guess;
+    const int *guess0 = (prior_env && *prior_env && *prior_env != '0') ? prior_guess : f->h_user->zip_qual_guess;
+    const int guess[2] = { zip_is_host_codec (guess0[0]) ? 0 : guess0[0], zip_is_host_codec (guess0[1]) ? 0 : guess0[1] };
     uint64_t longest_text = 0;
     for (uint32_t v = 0; v < NV; v++) longest_text = std::max<uint64_t> (longest_text, vbs[v].text_len);
     const char *spec_env = getenv ("GZ_ZIP_SPECULATION");                  // "always": whatever the sizes (tests)
@@ -1023,7 +1024,8 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     const char *early_env = getenv ("GZ_ZIP_EARLY_MIN");
     const uint64_t early_min = early_env ? strtoull (early_env, NULL, 10) : 1500000ull;
     bool early_worth = longest >= early_min || spec_always;
-    { GzZctxView zq; if (f->qual_ctx >= 0) { gz_zctx_view (f->zctx[f->qual_ctx], &zq); if (f->hostc.trial && (!zq.lcodec || zip_is_host_codec (zq.lcodec))) early_worth = false; } }   // (nothing to code ahead on the device)
+    // (nothing to code ahead on the device: the host's candidates are in the race and the file has no codec yet, or the file's codec is one of the host's)
+    { GzZctxView zq; if (f->qual_ctx >= 0) { gz_zctx_view (f->zctx[f->qual_ctx], &zq); if ((f->hostc.trial && !zq.lcodec) || zip_is_host_codec (zq.lcodec)) early_worth = false; } }
     if (!early_worth && f->h2 && NV && qmode >= 0 && f->qual_ctx >= 0) {
         GzZctxView zv; gz_zctx_view (f->zctx[f->qual_ctx], &zv);
         if (zv.lcodec && !zip_is_host_codec (zv.lcodec)) early_worth = true;                 // (the file knows its codec: nothing to wait for, the streams may as well start now)
@@ -1599,7 +1601,8 @@ static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint
             GzZctxView zv; gz_zctx_view (f->zctx[w.first.first], &zv);
             if (w.first.second ? zv.lcodec : zv.bcodec) continue;
             gz_zctx_commit_codec (f->zctx[w.first.first], (int)w.first.second, (int)w.second.codec);
-            if ((int)w.first.first == f->qual_ctx && w.first.second) f->h_user->zip_qual_guess[f->qual_mode == GZ_CODEC_DOMQ] = (int)w.second.codec;   // (next file: speculation)
+            // (next file: speculation - only a coder the device can run ahead: a host codec's win, BZ2 / LZMA / BSC, is no guess for a file without them)
+            if ((int)w.first.first == f->qual_ctx && w.first.second && !zip_is_host_codec ((int)w.second.codec)) f->h_user->zip_qual_guess[f->qual_mode == GZ_CODEC_DOMQ] = (int)w.second.codec;
             // (a VBlock in front of the one that assigned finds nothing in the file, as in a serial run: it had < 50 bytes, or is small)
             for (uint32_t v = 0; v < NV; v++) if (vbs[v].vblock_i >= w.second.vblock_i) {
                 ZipCol &Z = COL (v, w.first.first); if (w.first.second) { if (!Z.lcodec) Z.lcodec = (uint8_t)w.second.codec; } else if (!Z.bcodec) Z.bcodec = (uint8_t)w.second.codec; }

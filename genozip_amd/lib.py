@@ -9,8 +9,10 @@ import os
 
 # The library runs its kernels on ~14 HIP streams per pair of handles, some of which hold one-thread gate kernels that wait for the range
 # coder's long chains. The HIP runtime maps all streams onto 4 hardware queues by default, and whatever shares a queue with a gate waits
-# with it (configs[2] 61.3 -> 58.0 ms per step, binned FASTQ 57.2 -> 52.5, the default step 92.9 -> 91.8 with 12 queues; 6, 8, 16 measured too). The variable is read when the HIP runtime starts: it
-# has to be in the environment before the first HIP call of the process (the library's own constructor sets it too, for C hosts).
+# with it. 8 queues: measured 4 / 6 / 8 / 12 / 16 / 24 - with one call in flight 8 and 12 are the same (default step 46.2 vs 46.5 ms, streamed
+# 167 vs 167 ms per two calls), with two calls in flight 12 is much slower (214 vs 177 ms: beyond 8 the runtime time-slices the queues,
+# whole queues stand still for ~11 ms at a time) - DESIGN.md section 0. The variable is read when the HIP runtime starts: it has to be in the
+# environment before the first HIP call of the process (the library's own constructor sets it too, for C hosts); a value the host set wins.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -145,7 +145,11 @@ int gz_codec_assign_best (GzHandle *h, const uint8_t *in, uint32_t in_len, uint3
  * come from the caller (GzCodecTest rows it fills from its own codec_bz2_compress / codec_bsc_compress / codec_lzma_compress,
  * sizes framed), the nine others run here. */
 typedef struct { int32_t codec; float size; float clock_us; } GzCodecTest;         /* CodecTest, src/codec.c:122-126 */
-enum { GZ_ASSIGN_NORMAL = 0, GZ_ASSIGN_BEST = 1, GZ_ASSIGN_FAST = 2 };              /* flag.best / flag.fast                  */
+/* GZ_ASSIGN_BEST / _FAST select the SORTER's branch for flag.best / flag.fast (src/codec.c:133-143) and nothing else: --best's "keep the
+ * previously selected codec when it comes second with the same size" (:342-343) and its BEST_LOCK_IN_THREASHOLD re-test / lock-in counters
+ * (:20,267-274), the dropping of BSC / LZMA for evb buffers and flag.no_lzma (:292-295) are the caller's (which rows it hands in, which codec it
+ * keeps): a file made with mode 1 is this sorter's choice per trial, not everything `genozip --best` does around it. */
+enum { GZ_ASSIGN_NORMAL = 0, GZ_ASSIGN_BEST = 1, GZ_ASSIGN_FAST = 2 };
 enum { GZ_CODEC_BZ2 = 3, GZ_CODEC_LZMA = 4, GZ_CODEC_BSC = 5 };                      /* src/genozip.h:325-360                  */
 /* The sorter: tests[0..n) in the order the reference tries them (:286-289) -> sorted in place, returns tests[0].codec. The
  * reference's comparator is not a strict order, so what qsort makes of it depends on the C library: this is glibc's top-down

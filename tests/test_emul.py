@@ -167,6 +167,12 @@ def test_emul_fastq_zip_host_codecs(emul_engine, oracle):
     parity.fastq_zip(emul_engine, oracle, 60, host=parity.host_codecs_for_tests(clock_bz2=100.0, clock_lzma=20000.0))
 
 
+def test_emul_fastq_zip_two_in_flight_small(emul_engine, oracle):
+    """two calls in flight (gz_fastq_zip_begin / _end), the smallest form that still has a call begun while the one before it is unfinished -
+    in every default run; the longer sequence is the thorough variant below"""
+    parity.fastq_zip_two_in_flight(emul_engine, oracle, 12, n_calls=3)
+
+
 @pytest.mark.thorough
 def test_emul_fastq_zip_two_in_flight(emul_engine, oracle):
     parity.fastq_zip_two_in_flight(emul_engine, oracle, 30, n_calls=4)
@@ -180,6 +186,12 @@ def test_emul_fastq_zip_domq(emul_engine, oracle):
     """QUAL through CODEC_DOMQ inside the driver: the file's first VBlock decides (binned scores: a fit), later calls follow even
     with scores that would not fit"""
     parity.fastq_zip(emul_engine, oracle, 72, qual=("bin", "uniform"))
+
+
+def test_emul_fastq_zip_domq_modes_small(emul_engine, oracle):
+    """--force-domq on scores that do not fit and --no-domqual on scores that do, at the smallest size, in every default run"""
+    parity.fastq_zip(emul_engine, oracle, 16, n_calls=1, qual=("uniform",), domq=13)
+    parity.fastq_zip(emul_engine, oracle, 16, n_calls=1, qual=("bin",), domq=1)
 
 
 @pytest.mark.thorough
@@ -236,6 +248,10 @@ def test_emul_sam_zip(emul_engine, oracle):
     """N1 for SAM: configs[2] from text - 4 VBlocks over 2 calls through the one-line-record plan == the oracle's composition"""
     assert parity.sam_zip(emul_engine, oracle, 200) == 4
     assert parity.sam_zip(emul_engine, oracle, 120, n_calls=1, qual="uniform", aux=False, via_bam=True) == 2      # (from BAM records)
+
+
+def test_emul_sam_zip_tags_small(emul_engine, oracle):
+    assert parity.sam_zip(emul_engine, oracle, 90, tags=True) == 4                                                       # (a context per optional field, in every default run)
 
 
 @pytest.mark.thorough

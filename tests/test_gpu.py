@@ -127,6 +127,32 @@ def test_fastq_zip_monochar(gpu_engine, oracle):
 
 
 @pytest.mark.gpu
+def test_chain_checkpoint_guard(oracle, monkeypatch):
+    """the range coder chain runs in double precision under a rounding mode switched by inline asm, in a generated loop that only the GPU
+    executes (gz_intrin.h): what guards it is k_chain_expand's replay of every 64-symbol slice against the chain's next checkpoint. A forced
+    mismatch (GZ_DEBUG_CHAIN_FAULT: slice k - 1 of every arithmetic leaf counts as missed) must fail the stream - no bytes, an error - and a
+    handle made without it codes the same data to the oracle's bytes"""
+    from genozip_amd.codec import Engine, GenozipAMDError
+    from genozip_amd import synth
+    data = synth.quality_diverse(5, 3000).tobytes()
+    monkeypatch.setenv("GZ_DEBUG_CHAIN_FAULT", "3")
+    E = Engine(device=0)
+    try:
+        for codec in (16, 17, 18, 19):
+            with pytest.raises(GenozipAMDError):
+                E.compress_many([(codec, data)])
+        assert E.compress_many([(6, data)])[0] == oracle.codec_compress(6, data)      # (rANS has no chain: untouched)
+    finally:
+        E.close()
+    monkeypatch.delenv("GZ_DEBUG_CHAIN_FAULT")
+    E2 = Engine(device=0)
+    try:
+        assert E2.compress_many([(16, data)])[0] == oracle.codec_compress(16, data)
+    finally:
+        E2.close()
+
+
+@pytest.mark.gpu
 def test_e2e_files_sha256(gpu_engine):
     """whole .genozip files (FASTQ pair and single file with monochar QUAL lines, plain and through CODEC_DOMQ; SAM with a context per tag;
     multi-sample VCF) written by the HIP library are, byte for byte, the files the REFERENCE'S OWN genounzip has decoded back into the
