@@ -211,11 +211,49 @@ class Workload:
         return self.offs[-1]
 
 
-def cpu_leg(wl, z_all, n_threads):
-    """the reference's own rANS / arith code (oracle/_ref: src/htscodecs compiled in place) - or, where that was not built,
-    this repo's C restatement - over the SAME section payloads on the host cores: (a) decodes every section the GPU wrote with
-    the reference's decoder, (b) re-encodes with the reference's encoder on a C pthread pool (timed) and compares with the
-    GPU's payload byte for byte, (c) checks the decoded QUAL against the text's quality lines"""
+# nominal cost of the reference's coders on one core, ns per input byte, from BASELINE.md section 2 (the reference's own htscodecs objects, 16 MiB
+# streams): [quality-like row, big-endian u32 row] - the fastest and the slowest data of that table - by codec id
+REF_CLOCK_NS_PER_BYTE = {6: (1e3 / 232, 1e3 / 168), 7: (1e3 / 124, 1e3 / 99), 8: (1e3 / 330, 1e3 / 129), 9: (1e3 / 104, 1e3 / 52),
+                         16: (1e3 / 89, 1e3 / 14.5), 17: (1e3 / 32, 1e3 / 10), 18: (1e3 / 87, 1e3 / 14), 19: (1e3 / 33, 1e3 / 11)}
+
+
+def clocked_selection(E, wl, z_all, R, kind):
+    """codec_assign_best_codec's trials carry clock() (src/codec.c:322-334) and above 5 ms per trial the sorter trades size for time
+    (:149-165); the device trials carry no clock and count as "under 5 ms". Outside the timed region: the file's deciding samples (the first
+    VBlock's streams of >= 50 bytes, first 99 999 bytes each) through gz_codec_assign_best_ex again with nominal per-codec costs from
+    BASELINE.md section 2 - the table's fastest data (quality-like) and its slowest (big-endian u32) - and which contexts would get another codec"""
+    from genozip_amd.lib import CODEC_NAMES
+    out = {"tables": "ns per byte by codec, BASELINE.md section 2: quality-like row / big-endian u32 row", "samples": 0, "changed_fast_row": {}, "changed_slow_row": {}}
+    try:
+        for st, codec, did, ulen, pay, domq in walk_sections(z_all[0]):
+            if ulen < 50:
+                continue
+            data = bytes(pay) if codec == 1 else (R.codec_uncompress(codec, pay, ulen) if kind == "port" else R.hts_uncompress("rans" if codec < 16 else "arith", pay, ulen))
+            tag = next((c["tag"] for c in wl.plan["ctxs"] if c["dict_id"] == did), did.hex())
+            name = ("b250:" if st == 11 else "local:") + tag
+            base = E.assign_best_ex(data)[0]
+            out["samples"] += 1
+            for row, key in ((0, "changed_fast_row"), (1, "changed_slow_row")):
+                clk = [0.0] * 32
+                for c, v in REF_CLOCK_NS_PER_BYTE.items():
+                    clk[c] = v[row]
+                w = E.assign_best_ex(data, clock_ns_per_byte=clk)[0]
+                if w != base:
+                    out[key][name] = "%s -> %s" % (CODEC_NAMES.get(base, base), CODEC_NAMES.get(w, w))
+    except Exception as e:                                        # noqa: BLE001 (a side figure)
+        out["error"] = repr(e)
+    return out
+
+
+def cpu_leg(wl, z_all, n_threads, E=None):
+    """The host's cores on the same file, two legs (both on a C pthread pool, tasks >= 4 x threads so that no thread idles at the end):
+    (1) WHOLE PATH (cpu_baseline.value): oracle/gz_oracle_path.c - this repo's C restatement of the path (lines, reads, items, seg columns with
+        their hash tables, merge, b250 / local generation, CODEC_DOMQ's transform, codec calls through the reference's own htscodecs where
+        oracle/_ref is built, framing), one VBlock per task as the reference's dispatcher runs them (src/dispatcher.c:544-618): the same work as
+        the GPU step. FASTQ plans only.
+    (2) CODEC CALLS ONLY (cpu_baseline.codec_only): the reference's own rANS / arith code over the SAME section payloads: decodes every section
+        the GPU wrote with the reference's decoder, re-encodes with the reference's encoder (timed) and compares with the GPU's payload byte for
+        byte (`bit_exact`), checks the decoded QUAL against the text's quality lines."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
@@ -226,10 +264,15 @@ def cpu_leg(wl, z_all, n_threads):
     text = wl.text[:wl.text_len].cpu().numpy()
     L = wl.W.READ_LEN
     qual_id = next((c["dict_id"] for c in wl.plan["ctxs"] if c["tag"] == "QUAL" and c["kind"] == 6), None)     # (GZ_FQ_QUAL; a VCF plan has none)
+    file_codecs, is_domq = {}, False
     for v, ((off, ln, vi, r1), z) in enumerate(zip(wl.vb, z_all)):
         for st, codec, did, ulen, pay, domq in walk_sections(z):
             data = bytes(pay) if codec == 1 else (R.codec_uncompress(codec, pay, ulen) if kind == "port" else R.hts_uncompress("rans" if codec < 16 else "arith", pay, ulen))
+            tag = next((c["tag"] for c in wl.plan["ctxs"] if c["dict_id"] == did), None)
+            if tag and codec != 1:
+                file_codecs[("b250" if st == 11 else "local", tag)] = codec
             if did == qual_id and st == 12:
+                is_domq |= bool(domq)
                 tv = text[off:off + ln]
                 qo = wl.qual_offsets(tv)                                                   # where every record's QUAL (L scores) starts in the VBlock's text
                 if domq:                       # the stream CODEC_DOMQ leaves of these quality lines, by the CPU restatement of codec_domq.c
@@ -243,16 +286,16 @@ def cpu_leg(wl, z_all, n_threads):
     codecs, datas = [t[0] for t in tasks], [t[1] for t in tasks]
     nbytes = sum(len(d) for d in datas)
 
-    def pool(nt, idx=None):
+    def pool(nt, idx=None, replicas=1):
         cs = codecs if idx is None else [codecs[i] for i in idx]
         ds = datas if idx is None else [datas[i] for i in idx]
         if kind == "reference":
-            outs, dt = R.codec_compress_many(cs, ds, nt)
+            outs, dt = R.codec_compress_many(cs, ds, nt, replicas)
         else:
-            t0 = time.time(); outs = O.codec_compress_many(cs, ds, nt); dt = time.time() - t0
-        return outs, dt, sum(len(d) for d in ds)
+            t0 = time.time(); outs = O.codec_compress_many(cs, ds, nt, replicas); dt = time.time() - t0
+        return outs, dt, sum(len(d) for d in ds) * replicas
     pool(8, list(range(min(8, len(tasks)))))                                    # warm up
-    outs, dt_all, _ = pool(n_threads)
+    outs, dt_all, _ = pool(n_threads)                                           # the file as it is: 150 tasks on 256 threads
     n_diff = sum(o != p for o, p in zip(outs, payloads))
     exact = n_diff == 0 and qual_ok
     if not exact:
@@ -260,23 +303,68 @@ def cpu_leg(wl, z_all, n_threads):
         sys.stderr.write("bit_exact: %d of %d payloads differ from the reference coder's, decoded QUAL %s%s\n" % (n_diff, len(payloads), "matches" if qual_ok else "DIFFERS from the text",
                          "" if bad is None else "; first: task %d of VBlock %d, codec %d, %d bytes in%s" % (bad, task_vb[bad] + 1, codecs[bad], len(datas[bad]),
                          (": data %s library %s reference %s" % (datas[bad].hex(), payloads[bad].hex(), outs[bad].hex())) if len(datas[bad]) <= 256 else "")))
-    # steady state: as many threads as keep every one of them busy with >= 4 of the long streams
-    long_ix = [i for i, d in enumerate(datas) if len(d) >= max(len(x) for x in datas) // 2]
-    nt_ss = max(1, min(n_threads, len(long_ix) // 4))
-    _, dt_ss, nb_ss = pool(nt_ss)
-    per_thread = nb_ss / dt_ss / nt_ss
+    # tasks >= 4 x threads: the same sections again and again (a file with more VBlocks of the same kind) until no thread idles at the end -
+    # bounded to ~10 s of pool time by the rate just measured
+    reps = max(1, -(-4 * n_threads // len(tasks)))
+    reps = max(1, min(reps, int(10.0 / max(dt_all, 1e-3)) or 1))
+    _, dt_rep, nb_rep = pool(n_threads, None, reps)
     # one thread (BASELINE configs[0]) on a bounded sample: the sections of the first VBlock pair
     first = [i for i, v in enumerate(task_vb) if v in (0, len(wl.vb) // 2)]
     _, dt_1, nb_1 = pool(1, first)
     scale = wl.value_bytes / nbytes                                             # same unit as `value`: text without SEQ per second
-    return {"value": round(nbytes / dt_all / 1e6 * scale, 1), "unit": "MB/s", "cores": n_threads, "kind": kind,
-            "sample": "codec calls only (no seg / merge / generate on the CPU side): all %d coded sections of rank 0's %d VBlocks (%.0f MB of streams), %d threads on %d logical CPUs; "
-                      "in the unit of `value` (text without SEQ lines: x %.3f)" % (len(tasks), len(wl.vb), nbytes / 1e6, n_threads, os.cpu_count(), scale),
-            "stream_mb_s": round(nbytes / dt_all / 1e6, 1),
-            "steady_state": {"threads": nt_ss, "stream_mb_s_per_thread": round(per_thread / 1e6, 1),
-                             "stream_mb_s_all_cores_est": round(per_thread * n_threads / 1e6, 1),
-                             "note": "every thread busy with >= 4 long streams; x threads = what a file with tasks >> threads would reach"},
-            "one_thread": {"stream_mb_s": round(nb_1 / dt_1 / 1e6, 1), "sample": "sections of the first VBlock pair (%.1f MB)" % (nb_1 / 1e6)}}, bool(exact)
+    codec_only = {"value": round(nb_rep / dt_rep / 1e6 * scale, 1), "unit": "MB/s", "cores": n_threads, "kind": kind,
+                  "sample": "codec calls only (no seg / merge / generate on the CPU side): the %d coded sections of rank 0's %d VBlocks (%.0f MB of streams) x %d = %d tasks on %d threads "
+                            "(%d logical CPUs); in the unit of `value` (text without SEQ lines: x %.3f)" % (len(tasks), len(wl.vb), nbytes / 1e6, reps, reps * len(tasks), n_threads, os.cpu_count(), scale),
+                  "stream_mb_s": round(nb_rep / dt_rep / 1e6, 1),
+                  "this_file_alone": {"value": round(nbytes / dt_all / 1e6 * scale, 1), "stream_mb_s": round(nbytes / dt_all / 1e6, 1), "tasks": len(tasks),
+                                      "note": "the file's own sections once: fewer tasks than threads, the longest streams set the time (what round 3 reported as cpu_baseline)"},
+                  "one_thread": {"stream_mb_s": round(nb_1 / dt_1 / 1e6, 1), "sample": "sections of the first VBlock pair (%.1f MB)" % (nb_1 / 1e6)}}
+    out = dict(codec_only)
+    out["codec_only"] = codec_only
+    # (1) the whole path, FASTQ plans (the SAM / VCF plans have no C composition: their cpu_baseline stays the codec leg)
+    if getattr(wl, "plan", None) is not None and not wl.plan.get("record_lines") and not wl.plan.get("n_samples"):
+        try:
+            vbs = [(off, ln) for (off, ln, vi, r1) in wl.vb]
+            ref = R if kind == "reference" else None
+            pyoracle.fastq_path_many(O, text, vbs[:2], wl.plan, file_codecs, is_domq, 2, 1, ref)          # warm up
+            dt1, _, _ = pyoracle.fastq_path_many(O, text, vbs, wl.plan, file_codecs, is_domq, n_threads, 1, ref)
+            reps_w = max(1, -(-4 * n_threads // len(vbs)))
+            reps_w = max(1, min(reps_w, int(15.0 / max(dt1, 1e-3)) or 1))
+            dtw, zl, stb = pyoracle.fastq_path_many(O, text, vbs, wl.plan, file_codecs, is_domq, n_threads, reps_w, ref)
+            dt_one, _, _ = pyoracle.fastq_path_many(O, text, vbs[:1], wl.plan, file_codecs, is_domq, 1, 1, ref)
+            per_vb_value = wl.value_bytes / max(1, getattr(wl, "calls_per_step", 1))
+            whole = {"value": round(per_vb_value * reps_w / dtw / 1e6, 1), "unit": "MB/s", "cores": n_threads, "kind": "port",
+                     "codecs": "the reference's htscodecs (oracle/_ref)" if ref is not None else "this repo's C restatement",
+                     "sample": "the WHOLE path of the file's %d VBlocks x %d = %d tasks, one VBlock per task on %d threads (%d logical CPUs): text -> lines -> reads -> items -> seg columns "
+                               "(hash tables, dictionaries, b250) -> merge -> generate -> %scodec calls (the file's codecs, no trials) -> framed sections "
+                               "(oracle/gz_oracle_path.c; every VBlock with file-level contexts of its own: no merge mutex, which favours the CPU); %.1f s"
+                               % (len(vbs), reps_w, reps_w * len(vbs), n_threads, os.cpu_count(), "CODEC_DOMQ's transform -> " if is_domq else "", dtw),
+                     "z_bytes": int(sum(zl)), "stream_bytes": int(sum(stb)),
+                     "this_file_alone": {"value": round(per_vb_value / dt1 / 1e6, 1), "tasks": len(vbs)},
+                     "one_thread": {"value": round(per_vb_value / len(vbs) / dt_one / 1e6, 1), "sample": "the first VBlock"}}
+            out = dict(whole)
+            out["whole_path"] = whole
+            out["codec_only"] = codec_only
+        except Exception as e:                                    # noqa: BLE001 (the codec leg still stands)
+            out["whole_path"] = {"error": repr(e)}
+    if E is not None:
+        out["codec_selection_with_clock"] = clocked_selection(E, wl, z_all, R, kind)
+    return out, bool(exact)
+
+
+def gpu_over_cpu(out, cb):
+    """the honest ratios, at top level: this GPU against this host's cores on the same file, every CPU thread kept busy"""
+    if not cb:
+        return None
+    g = {"note": "value / cpu_baseline figures of the same unit; tasks >= 4 x threads on the CPU side (a file with enough VBlocks to keep every core busy)"}
+    if isinstance(cb.get("whole_path"), dict) and cb["whole_path"].get("value"):
+        g["whole_path"] = round(out["value"] / cb["whole_path"]["value"], 2)
+    co = cb.get("codec_only") or cb
+    if co.get("value"):
+        g["codec_calls_only"] = round(out["value"] / co["value"], 2)
+        if co.get("this_file_alone", {}).get("value"):
+            g["codec_calls_only_this_file_alone"] = round(out["value"] / co["this_file_alone"]["value"], 2)
+    return g
 
 
 def pmc_traffic(kernel, a):
@@ -484,9 +572,10 @@ def text_leg(a, WL):
                         "long_streams": len(long_secs), "symbols_of_longest_stream": max([s_[3] for s_ in long_secs] + [0]),
                         "kernel_ms_per_step_summed_over_concurrent_launches": {k: round(v[0] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]}}}
     if not a.no_cpu:
-        cb, exact = cpu_leg(wl, z_all, min(os.cpu_count() or 1, 256))
+        cb, exact = cpu_leg(wl, z_all, min(os.cpu_count() or 1, 256), E)
         out["cpu_baseline"] = cb
         out["bit_exact"] = exact
+        out["gpu_over_cpu"] = gpu_over_cpu(out, cb)
     print(json.dumps(out))
 
 
@@ -751,9 +840,10 @@ def main():
     if other:
         out["other_profile"] = other
     if not a.no_cpu and world == 1:                # (the CPU pool is timed on rank 0 of the 1-GPU run only)
-        cb, exact = cpu_leg(wl, z_all, min(os.cpu_count() or 1, 256))
+        cb, exact = cpu_leg(wl, z_all, min(os.cpu_count() or 1, 256), E)
         out["cpu_baseline"] = cb
         out["bit_exact"] = exact
+        out["gpu_over_cpu"] = gpu_over_cpu(out, cb)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

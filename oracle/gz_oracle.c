@@ -1102,25 +1102,37 @@ int gzo_codec_uncompress (int codec, const uint8_t *in, uint32_t in_len, uint8_t
 
 typedef struct {
     int n; const int *codecs; const uint8_t *const *ins; const uint32_t *in_lens; uint8_t *const *outs; uint32_t *out_lens;
-    int next, failed; pthread_mutex_t mu;
+    int next, failed; pthread_mutex_t mu; int replicas;
 } ManyJob;
 
 static void *many_worker (void *arg)
 {
     ManyJob *j = arg;
+    uint8_t *scratch = NULL; uint32_t scratch_cap = 0;              /* (replicas beyond the first write here: same work, the output is not kept) */
     for (;;) {
         pthread_mutex_lock (&j->mu);
-        int i = j->next++;
+        int t = j->next++;
         pthread_mutex_unlock (&j->mu);
-        if (i >= j->n) return NULL;
-        if (gzo_codec_compress (j->codecs[i], j->ins[i], j->in_lens[i], j->outs[i], &j->out_lens[i], 0) != 1) j->failed = 1;
+        if (t >= j->n * j->replicas) { free (scratch); return NULL; }
+        const int i = t % j->n;
+        if (t < j->n) { if (gzo_codec_compress (j->codecs[i], j->ins[i], j->in_lens[i], j->outs[i], &j->out_lens[i], 0) != 1) j->failed = 1; continue; }
+        uint32_t cap = gzo_codec_est_size (j->codecs[i], j->in_lens[i]);
+        if (scratch_cap < cap) { free (scratch); scratch = malloc (cap); scratch_cap = scratch ? cap : 0; }
+        if (!scratch || gzo_codec_compress (j->codecs[i], j->ins[i], j->in_lens[i], scratch, &cap, 0) != 1) j->failed = 1;
     }
 }
 
 int gzo_codec_compress_many (int n, const int *codecs, const uint8_t *const *ins, const uint32_t *in_lens,
                              uint8_t *const *outs, uint32_t *out_lens, int n_threads)
 {
-    ManyJob j = { n, codecs, ins, in_lens, outs, out_lens, 0, 0, PTHREAD_MUTEX_INITIALIZER };
+    return gzo_codec_compress_many_rep (n, codecs, ins, in_lens, outs, out_lens, n_threads, 1);
+}
+
+/* every task `replicas` times: a file with more VBlocks of the same kind (tasks >= 4 x threads keep every thread busy to the end) */
+int gzo_codec_compress_many_rep (int n, const int *codecs, const uint8_t *const *ins, const uint32_t *in_lens,
+                                 uint8_t *const *outs, uint32_t *out_lens, int n_threads, int replicas)
+{
+    ManyJob j = { n, codecs, ins, in_lens, outs, out_lens, 0, 0, PTHREAD_MUTEX_INITIALIZER, replicas < 1 ? 1 : replicas };
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 1024) n_threads = 1024;
     pthread_t th[1024];

@@ -56,6 +56,8 @@ int gzo_codec_uncompress (int codec, const uint8_t *in, uint32_t in_len, uint8_t
 /* many independent streams on a pthread pool (the CPU baseline of bench.py): returns 0 if all succeeded */
 int gzo_codec_compress_many (int n, const int *codecs, const uint8_t *const *ins, const uint32_t *in_lens,
                              uint8_t *const *outs, uint32_t *out_lens /* in: capacity, out: length */, int n_threads);
+int gzo_codec_compress_many_rep (int n, const int *codecs, const uint8_t *const *ins, const uint32_t *in_lens,
+                                 uint8_t *const *outs, uint32_t *out_lens, int n_threads, int replicas);
 
 /* deterministic stand-in for codec_assign_best_codec (src/codec.c:234-363): smallest framed size on
  * the first min(len,99999) bytes, ties -> lower codec id; returns GZO_CODEC_UNKNOWN when len < 50 */

@@ -108,7 +108,7 @@ class Oracle:
             raise RuntimeError("oracle codec_uncompress failed")
         return out.raw[:out_len]
 
-    def codec_compress_many(self, codecs, datas, n_threads):
+    def codec_compress_many(self, codecs, datas, n_threads, replicas=1):
         n = len(datas)
         ins = [bytes(d) for d in datas]
         caps = [self.est_size(c, len(d)) for c, d in zip(codecs, ins)]
@@ -118,7 +118,7 @@ class Oracle:
         a_lens = (ctypes.c_uint32 * n)(*[len(d) for d in ins])
         a_outs = (ctypes.c_void_p * n)(*[ctypes.addressof(o) for o in outs])
         a_olens = (ctypes.c_uint32 * n)(*caps)
-        if self.L.gzo_codec_compress_many(n, a_codecs, a_ins, a_lens, a_outs, a_olens, n_threads) != 0:
+        if self.L.gzo_codec_compress_many_rep(n, a_codecs, a_ins, a_lens, a_outs, a_olens, n_threads, int(replicas)) != 0:
             raise RuntimeError("oracle compress_many failed")
         return [o.raw[:l] for o, l in zip(outs, a_olens)]
 
@@ -482,6 +482,52 @@ class OracleZctx:
         return d[:-1].split(b"\0") if d else []
 
 
+class GzoPathPlan(ctypes.Structure):
+    _fields_ = [("n_items", ctypes.c_uint32), ("item_kind", ctypes.c_uint8 * 16), ("seps", ctypes.c_uint8 * 32), ("sep_counts", ctypes.c_uint8 * 32),
+                ("n_seps", ctypes.c_uint32), ("lcodec", ctypes.c_uint8 * 16), ("bcodec", ctypes.c_uint8 * 16), ("qual_codec", ctypes.c_uint8),
+                ("aux_codec", ctypes.c_uint8 * 3), ("x_codec", ctypes.c_uint8), ("domq", ctypes.c_uint8)]
+
+
+def fastq_path_many(oracle, text, vbs, plan, codecs, domq, n_threads, replicas=1, ref=None):
+    """bench.py's cpu_baseline.whole_path (oracle/gz_oracle_path.c): the whole path of every VBlock (text -> lines -> reads -> items -> seg
+    columns -> merge -> b250 / local generation -> codecs -> framed sections) on a pthread pool, one VBlock per task, every VBlock
+    `replicas` times. text: bytes / numpy uint8 (host); vbs: [(offset, length)]; plan: the dict of genozip_amd.fastq.illumina_plan;
+    codecs: {("local" | "b250", tag): codec id} as the GPU run's file ended up with (missing: the VBlock runs the trial itself);
+    ref: a pyoracle.Ref - the codec calls then go through the reference's own htscodecs. -> (seconds, z bytes per VBlock, stream bytes per VBlock)"""
+    import numpy as np
+    L = oracle.L
+    P = GzoPathPlan()
+    items = sorted([c for c in plan["ctxs"] if c["kind"] in (2, 3, 4)], key=lambda c: c["item"])       # GZ_FQ_ITEM_TEXT / _INT / _DELTA
+    P.n_items = len(items)
+    for i, c in enumerate(items):
+        assert c["item"] == i
+        P.item_kind[i] = {2: 0, 3: 1, 4: 2}[c["kind"]]
+        P.lcodec[i] = codecs.get(("local", c["tag"]), 0); P.bcodec[i] = codecs.get(("b250", c["tag"]), 0)
+    seps = bytes(plan["seps"])
+    P.n_seps = len(seps)
+    for i, b in enumerate(seps):
+        P.seps[i] = b; P.sep_counts[i] = plan["sep_counts"][i]
+    P.qual_codec = codecs.get(("local", "QUAL"), 0)
+    for k, t in enumerate(("DOMQRUNS", "QUALMPLX", "DIVRQUAL")):
+        P.aux_codec[k] = codecs.get(("local", t), 0)
+    P.x_codec = codecs.get(("local", "NONREF_X"), 0) or 1
+    P.domq = int(bool(domq))
+    if ref is not None:
+        L.gzo_path_use_codecs(ctypes.cast(ref.L.htsref_rans_compress, ctypes.c_void_p), ctypes.cast(ref.L.htsref_arith_compress, ctypes.c_void_p))
+    else:
+        L.gzo_path_use_codecs(None, None)
+    t = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else text)
+    n = len(vbs)
+    off = np.array([v[0] for v in vbs], dtype=np.uint64); ln = np.array([v[1] for v in vbs], dtype=np.uint64)
+    zl = (ctypes.c_long * n)(); st = (ctypes.c_uint64 * n)()
+    L.gzo_fastq_path_many.restype = ctypes.c_double
+    dt = L.gzo_fastq_path_many(t.ctypes.data_as(ctypes.c_void_p), off.ctypes.data_as(ctypes.c_void_p), ln.ctypes.data_as(ctypes.c_void_p), n, int(replicas),
+                               ctypes.byref(P), zl, st, int(n_threads))
+    if dt < 0:
+        raise RuntimeError("oracle whole-path leg failed")
+    return dt, list(zl), list(st)
+
+
 class Ref:
     """the reference's vendored htscodecs, compiled in place (only where oracle/_ref was built)"""
 
@@ -519,8 +565,9 @@ class Ref:
         kind = "rans" if codec < 16 else "arith"
         return self.hts_compress(kind, data, CODEC_ORDER[codec])
 
-    def codec_compress_many(self, codecs, datas, n_threads):
-        """C pthread pool over independent codec calls (bench.py's multithreaded CPU baseline); returns (payloads, seconds)"""
+    def codec_compress_many(self, codecs, datas, n_threads, replicas=1):
+        """C pthread pool over independent codec calls (bench.py's multithreaded CPU baseline), every call `replicas` times; returns
+        (payloads, seconds)"""
         import time
         n = len(datas)
         ins = [bytes(d) for d in datas]
@@ -534,7 +581,7 @@ class Ref:
         a_cap = (ctypes.c_uint * n)(*caps)
         a_ol = (ctypes.c_long * n)()
         t0 = time.perf_counter()
-        rc = self.L.htsref_compress_many(n, a_ar, a_or, a_in, a_il, a_out, a_cap, a_ol, n_threads)
+        rc = self.L.htsref_compress_many_rep(n, a_ar, a_or, a_in, a_il, a_out, a_cap, a_ol, n_threads, int(replicas))
         dt = time.perf_counter() - t0
         if rc != 0:
             raise RuntimeError("ref compress_many failed")

@@ -105,26 +105,45 @@ unsigned htsref_arith_bound (unsigned size, int order) { return arith_compress_b
 
 typedef struct {
     int n; const int *is_arith; const int *orders; const unsigned char *const *ins; const unsigned *in_lens;
-    unsigned char *const *outs; const unsigned *out_caps; long *out_lens; int next; pthread_mutex_t mu;
+    unsigned char *const *outs; const unsigned *out_caps; long *out_lens; int next; pthread_mutex_t mu; int replicas;
 } HtsRefMany;
 
 static void *htsref_many_worker (void *arg)
 {
     HtsRefMany *j = arg;
+    unsigned char *scratch = NULL; unsigned scratch_cap = 0;       /* (replicas beyond the first write here: same work, the output is not kept) */
     for (;;) {
         pthread_mutex_lock (&j->mu);
-        int i = j->next++;
+        int t = j->next++;
         pthread_mutex_unlock (&j->mu);
-        if (i >= j->n) return NULL;
-        j->out_lens[i] = j->is_arith[i] ? htsref_arith_compress (j->ins[i], j->in_lens[i], j->outs[i], j->out_caps[i], j->orders[i])
-                                             : htsref_rans_compress  (j->ins[i], j->in_lens[i], j->outs[i], j->out_caps[i], j->orders[i]);
+        if (t >= j->n * j->replicas) { free (scratch); return NULL; }
+        const int i = t % j->n;
+        unsigned char *out = j->outs[i];
+        if (t >= j->n) {
+            if (scratch_cap < j->out_caps[i]) { free (scratch); scratch = malloc (j->out_caps[i]); scratch_cap = scratch ? j->out_caps[i] : 0; }
+            if (!scratch) { j->out_lens[i] = -1; continue; }
+            out = scratch;
+        }
+        const long l = j->is_arith[i] ? htsref_arith_compress (j->ins[i], j->in_lens[i], out, j->out_caps[i], j->orders[i])
+                                      : htsref_rans_compress  (j->ins[i], j->in_lens[i], out, j->out_caps[i], j->orders[i]);
+        if (t < j->n || l < 0) j->out_lens[i] = l;
     }
 }
 
+int htsref_compress_many_rep (int n, const int *is_arith, const int *orders, const unsigned char *const *ins, const unsigned *in_lens,
+                              unsigned char *const *outs, const unsigned *out_caps, long *out_lens, int n_threads, int replicas);
 int htsref_compress_many (int n, const int *is_arith, const int *orders, const unsigned char *const *ins, const unsigned *in_lens,
                           unsigned char *const *outs, const unsigned *out_caps, long *out_lens, int n_threads)
 {
-    HtsRefMany j = { n, is_arith, orders, ins, in_lens, outs, out_caps, out_lens, 0, PTHREAD_MUTEX_INITIALIZER };
+    return htsref_compress_many_rep (n, is_arith, orders, ins, in_lens, outs, out_caps, out_lens, n_threads, 1);
+}
+
+/* every task `replicas` times (the task list replica after replica): a file with more VBlocks of the same kind - tasks >= 4 x threads keep
+ * every thread busy until the end, which 150 sections on 256 threads do not */
+int htsref_compress_many_rep (int n, const int *is_arith, const int *orders, const unsigned char *const *ins, const unsigned *in_lens,
+                              unsigned char *const *outs, const unsigned *out_caps, long *out_lens, int n_threads, int replicas)
+{
+    HtsRefMany j = { n, is_arith, orders, ins, in_lens, outs, out_caps, out_lens, 0, PTHREAD_MUTEX_INITIALIZER, replicas < 1 ? 1 : replicas };
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 1024) n_threads = 1024;
     pthread_t th[1024];
