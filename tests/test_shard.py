@@ -198,3 +198,24 @@ def test_strong_scaling_at_one_rank_equals_weak(emul_engine):
     p.join(120)
     assert p.exitcode == 0 and len(allres) == 1
     assert allres[0][0] == one
+
+
+def test_bench_gpus_2_under_gloo(emul_engine):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per "GPU"), on CPU ranks: GZ_BENCH_EMUL=1 runs the same
+    script over the product's sources on the CPU stand-in (tests/emul) with the gloo backend - the strong-scaling path (merge blobs and votes
+    as byte tensors, the point-to-point gather of z_data), the `rccl` record and the streamed share beside the headline all execute; the
+    numbers mean nothing here, the plumbing does"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, GZ_BENCH_EMUL="1", GZ_BENCH_STREAM_SHARE_READS="300")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--pairs", "600", "--vb-mb", "0.05", "--steps", "1", "--warmup", "0", "--no-cpu", "--warm-steps", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    d = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["rccl"]["world"] == 2 and d["rccl"]["backend"] == "gloo"
+    assert d["rccl"]["bytes_gathered_per_step"] > 0 and d["rccl"]["exchanges_per_step"] == 2 and d["rccl"]["exchange_bytes_per_step"] > 0
+    assert "error" not in d["streamed_share"] and d["streamed_share"]["scaling"] == "weak" and "expectation" in d
