@@ -276,10 +276,13 @@ def cpu_leg(wl, z_all, n_threads, E=None):
                 is_domq |= bool(domq)
                 tv = text[off:off + ln]
                 qo = wl.qual_offsets(tv)                                                   # where every record's QUAL (L scores) starts in the VBlock's text
+                lines = tv[qo[:, None] + np.arange(L)]
+                # (FASTQ: a line of one repeated score is a special snip in QUAL's b250 and no part of the local / of CODEC_DOMQ's streams, fastq_qual.c:33-36,74)
+                keep = ~(lines == lines[:, :1]).all(axis=1) if not wl.plan.get("record_lines") else np.ones(len(qo), dtype=bool)
                 if domq:                       # the stream CODEC_DOMQ leaves of these quality lines, by the CPU restatement of codec_domq.c
-                    qual_ok &= data == pyoracle.oracle_domq(O, tv.tobytes(), qo.astype(np.uint32), np.full(len(qo), L, dtype=np.uint32))["qual"]
+                    qual_ok &= data == pyoracle.oracle_domq(O, tv.tobytes(), qo.astype(np.uint32), np.where(keep, L, 0).astype(np.uint32))["qual"]
                 else:
-                    qual_ok &= data == tv[qo[:, None] + np.arange(L)].tobytes()
+                    qual_ok &= data == lines[keep].tobytes()
             if codec != 1:
                 tasks.append((codec, data)); payloads.append(bytes(pay)); task_vb.append(v)
     if not tasks:

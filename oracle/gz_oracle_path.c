@@ -180,7 +180,25 @@ long gzo_fastq_vb_path (const uint8_t *text, uint64_t text_len, uint32_t vblock_
         }
         free (blob); blob = NULL;
     }
-    /* QUAL */
+    /* QUAL (fastq_seg_QUAL, fastq_qual.c:24-47): a line of one repeated score segs a special snip and stays out of the local / of CODEC_DOMQ's
+       streams, every other line segs SNIP_LOOKUP; the context's b250 like any other column */
+    {
+        uint8_t *slots = malloc (4 * n + 16);
+        if (!slots) goto done;
+        for (uint64_t r = 0; r < n; r++) {
+            const uint8_t *q = text + qo[r]; const uint8_t c = q[0];
+            uint32_t i = 1; while (i < ql[r] && q[i] == c) i++;
+            if (i >= ql[r]) { slots[4 * r] = 8; slots[4 * r + 1] = 41; slots[4 * r + 2] = c; so[r] = (uint32_t)(4 * r); sl[r] = 3; ql[r] = 0; }
+            else { slots[4 * r] = 1; so[r] = (uint32_t)(4 * r); sl[r] = 1; }
+        }
+        uint64_t nq = 0; for (uint64_t r = 0; r < n; r++) nq += ql[r];
+        long r6 = -1;
+        if (col_alloc (&col, n, 3 * n) && gzo_ctx_seg_column (slots, so, sl, n, NULL, NULL, NULL, 0, &col) == 0)
+            r6 = path_b250 (&col, (uint32_t)n, nq, 0, vblock_i, z + zl, z_cap - zl, streams);
+        col_free (&col); memset (&col, 0, sizeof (col)); free (slots);
+        if (r6 < 0) goto done;
+        zl += (uint64_t)r6;
+    }
     if (P->domq) {
         GzoDomq dq; memset (&dq, 0, sizeof (dq));
         if (gzo_domq_encode (text, qo, ql, n, &dq) != 0) goto done;
