@@ -318,7 +318,7 @@ def cpu_leg(wl, z_all, n_threads, E=None):
     scale = wl.value_bytes / nbytes                                             # same unit as `value`: text without SEQ per second
     codec_only = {"value": round(nb_rep / dt_rep / 1e6 * scale, 1), "unit": "MB/s", "cores": n_threads, "kind": kind,
                   "sample": "codec calls only (no seg / merge / generate on the CPU side): the %d coded sections of rank 0's %d VBlocks (%.0f MB of streams) x %d = %d tasks on %d threads "
-                            "(%d logical CPUs); in the unit of `value` (text without SEQ lines: x %.3f)" % (len(tasks), len(wl.vb), nbytes / 1e6, reps, reps * len(tasks), n_threads, os.cpu_count(), scale),
+                            "(%s); in the unit of `value` (text without SEQ lines: x %.3f)" % (len(tasks), len(wl.vb), nbytes / 1e6, reps, reps * len(tasks), n_threads, usable_cpus()[1], scale),
                   "stream_mb_s": round(nb_rep / dt_rep / 1e6, 1),
                   "this_file_alone": {"value": round(nbytes / dt_all / 1e6 * scale, 1), "stream_mb_s": round(nbytes / dt_all / 1e6, 1), "tasks": len(tasks),
                                       "note": "the file's own sections once: fewer tasks than threads, the longest streams set the time (what round 3 reported as cpu_baseline)"},
@@ -339,10 +339,10 @@ def cpu_leg(wl, z_all, n_threads, E=None):
             per_vb_value = wl.value_bytes / max(1, getattr(wl, "calls_per_step", 1))
             whole = {"value": round(per_vb_value * reps_w / dtw / 1e6, 1), "unit": "MB/s", "cores": n_threads, "kind": "port",
                      "codecs": "the reference's htscodecs (oracle/_ref)" if ref is not None else "this repo's C restatement",
-                     "sample": "the WHOLE path of the file's %d VBlocks x %d = %d tasks, one VBlock per task on %d threads (%d logical CPUs): text -> lines -> reads -> items -> seg columns "
+                     "sample": "the WHOLE path of the file's %d VBlocks x %d = %d tasks, one VBlock per task on %d threads (%s): text -> lines -> reads -> items -> seg columns "
                                "(hash tables, dictionaries, b250) -> merge -> generate -> %scodec calls (the file's codecs, no trials) -> framed sections "
                                "(oracle/gz_oracle_path.c; every VBlock with file-level contexts of its own: no merge mutex, which favours the CPU); %.1f s"
-                               % (len(vbs), reps_w, reps_w * len(vbs), n_threads, os.cpu_count(), "CODEC_DOMQ's transform -> " if is_domq else "", dtw),
+                               % (len(vbs), reps_w, reps_w * len(vbs), n_threads, usable_cpus()[1], "CODEC_DOMQ's transform -> " if is_domq else "", dtw),
                      "z_bytes": int(sum(zl)), "stream_bytes": int(sum(stb)),
                      "this_file_alone": {"value": round(per_vb_value / dt1 / 1e6, 1), "tasks": len(vbs)},
                      "one_thread": {"value": round(per_vb_value / len(vbs) / dt_one / 1e6, 1), "sample": "the first VBlock"}}
@@ -351,9 +351,39 @@ def cpu_leg(wl, z_all, n_threads, E=None):
             out["codec_only"] = codec_only
         except Exception as e:                                    # noqa: BLE001 (the codec leg still stands)
             out["whole_path"] = {"error": repr(e)}
+    out["host"] = usable_cpus()[1]
     if E is not None:
         out["codec_selection_with_clock"] = clocked_selection(E, wl, z_all, R, kind)
     return out, bool(exact)
+
+
+def usable_cpus():
+    """the CPUs this process may really use: logical CPUs, its affinity mask and the container's CFS quota (cgroup v2 cpu.max / v1 cfs_quota_us) -
+    more threads than that only buy throttling. Returns (threads to use, a sentence for the record). The MI355X boxes of this pool: 256 logical
+    CPUs (2 x EPYC 9575F), cpu.max = 1600000 100000 -> 16."""
+    n = os.cpu_count() or 1
+    note = "%d logical CPUs" % n
+    try:
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n, note = a, note + ", affinity mask of %d" % a
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        n, note = max(1, int(quota + 0.5)), note + ", cgroup CPU quota of %.1f CPUs (cpu.max): threads beyond it are throttled, not run" % quota
+    return min(n, 256), note
 
 
 def gpu_over_cpu(out, cb):
@@ -576,7 +606,7 @@ def text_leg(a, WL):
                         "long_streams": len(long_secs), "symbols_of_longest_stream": max([s_[3] for s_ in long_secs] + [0]),
                         "kernel_ms_per_step_summed_over_concurrent_launches": {k: round(v[0] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]}}}
     if not a.no_cpu:
-        cb, exact = cpu_leg(wl, z_all, min(os.cpu_count() or 1, 256), E)
+        cb, exact = cpu_leg(wl, z_all, usable_cpus()[0], E)
         out["cpu_baseline"] = cb
         out["bit_exact"] = exact
         out["gpu_over_cpu"] = gpu_over_cpu(out, cb)
@@ -630,7 +660,7 @@ def config_leg(a):
                         "avg_launch_ms": round(dom_ms / dom_n, 4), "launches_per_step": dom_n / a.steps, "longest_launch_ms": round(prof_max.get(dom, 0), 3),
                         "kernel_ms_per_step_summed_over_concurrent_launches": {k: round(v[0] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]}}}
     if not a.no_cpu:
-        c, exact = cb.cpu_baseline(z_list, min(os.cpu_count() or 1, 256))
+        c, exact = cb.cpu_baseline(z_list, usable_cpus()[0])
         c["unit"] = "MB/s"
         out["cpu_baseline"] = c
         out["bit_exact"] = exact
@@ -914,7 +944,7 @@ def main():
     if other:
         out["other_profile"] = other
     if not a.no_cpu and world == 1:                # (the CPU pool is timed on rank 0 of the 1-GPU run only)
-        cb, exact = cpu_leg(wl, z_all, min(os.cpu_count() or 1, 256), E)
+        cb, exact = cpu_leg(wl, z_all, usable_cpus()[0], E)
         out["cpu_baseline"] = cb
         out["bit_exact"] = exact
         out["gpu_over_cpu"] = gpu_over_cpu(out, cb)
