@@ -568,6 +568,20 @@ def text_leg(a, WL):
     prof = E.profile_results()
     prof_max = dict(E.profile_max)
     ms = dt / a.steps * 1e3
+    # warm: a handle that has seen a file of the kind codes every stream ahead of its context's trial with the codec that file got (gz_zip_prediction)
+    warm = None
+    if a.warm_steps:
+        os.environ.pop("GZ_ZIP_PRIOR_ONLY", None)
+        wl.step(None)
+        h0, m0 = wl.F.prediction()
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(a.warm_steps):
+            wl.step(None)
+        torch.cuda.synchronize()
+        wms = (time.perf_counter() - t1) / a.warm_steps * 1e3
+        h1, m1 = wl.F.prediction()
+        warm = {"ms_per_step": round(wms, 3), "steps": a.warm_steps, "prediction_hits": h1 - h0, "prediction_misses": m1 - m0,
+                "note": "the handle remembers the codecs of the previous file of the kind: every stream is coded ahead of its context's trial compressions, which still run and decide"}
     z_total = wl.offs[-1]
     zhost = wl.zbuf[:z_total].cpu().numpy().tobytes()
     z_all = [zhost[wl.offs[i]:wl.offs[i + 1]] for i in range(len(wl.vb))]
@@ -599,12 +613,16 @@ def text_leg(a, WL):
                                    "step from text in HBM through the per-sample plan of genozip_amd/vcf.py (N1 for VCF: fixed fields by tab, FORMAT subfields of every sample -> GT / PL b250 columns "
                                    "of lines x samples entries, DP a dyn-int matrix written transposed, a1-a16); a new file every step. MB counted in `value` = the text"
                                    % (wl.n_samples, len(wl.vb), wl.lines_per_vb, wl.n_samples, wl.text_len / 1e6)),
-                      "text_mb_per_step": round(wl.text_len / 1e6, 1), "stream_mb_per_step": round(stream_bytes / 1e6, 1), "compressed_mb_per_step": round(z_total / 1e6, 2), "codecs": codecs},
+                      "text_mb_per_step": round(wl.text_len / 1e6, 1), "stream_mb_per_step": round(stream_bytes / 1e6, 1), "compressed_mb_per_step": round(z_total / 1e6, 2), "codecs": codecs,
+                      "codec_prediction": "hits %d, misses %d (sections coded ahead of their context's trial with a predicted codec - cold: the built-in prior -, kept / coded again)" % wl.F.prediction()},
            "text_mb_s": round(wl.text_len / 1e6 / (ms / 1e3), 1), "stream_mb_s": round(stream_bytes / 1e6 / (ms / 1e3), 1),
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
                         "avg_launch_ms": round(dom_ms / dom_n, 4), "launches_per_step": dom_n / a.steps, "longest_launch_ms": round(prof_max.get(dom, 0), 3),
                         "long_streams": len(long_secs), "symbols_of_longest_stream": max([s_[3] for s_ in long_secs] + [0]),
                         "kernel_ms_per_step_summed_over_concurrent_launches": {k: round(v[0] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]}}}
+    if warm:
+        warm["value"] = round(wl.value_bytes / 1e6 / (warm["ms_per_step"] / 1e3), 1)
+        out["warm"] = warm
     if not a.no_cpu:
         cb, exact = cpu_leg(wl, z_all, usable_cpus()[0], E)
         out["cpu_baseline"] = cb
@@ -917,6 +935,8 @@ def main():
                       "qual_profile": a.qual, "vb_bytes": vb_bytes(a), "codecs": codecs,
                       "qual_codec_speculation": "hits %d, misses %d since the handle was made (warm-up included): the long QUAL streams of a new file start with the codec "
                                                 "the handle's previous file got; the file's own trial compressions still run in the step and decide (gz_zip_speculation)" % wl.F.speculation(),
+                      "codec_prediction": "hits %d, misses %d since the handle was made: sections coded ahead of their context's trial compressions with a predicted codec (cold: the built-in prior by "
+                                          "kind of stream), kept / coded again once the trials had decided (gz_zip_prediction)" % wl.F.prediction(),
                       "text_mb_per_step": round(text_b / 1e6, 1), "stream_mb_per_step": round(stream_b / 1e6, 1), "compressed_mb_per_step": round(z_b / 1e6, 2),
                       "parallelism": "vblocks sharded over %d GPU(s), no data-path collective; host exchange of new dictionary words (strong scaling only); RCCL gather of z_data" % world},
            "text_mb_s": round(text_b / 1e6 / (ms_per_step / 1e3), 1), "stream_mb_s": round(stream_b / 1e6 / (ms_per_step / 1e3), 1),

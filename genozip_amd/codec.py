@@ -193,6 +193,12 @@ class ZipFile:
         self.E.L.gz_zip_speculation(self.f, C.byref(h), C.byref(m))
         return h.value, m.value
 
+    def prediction(self):
+        """-> (hits, misses) of the handle: sections coded ahead of their context's trial with a predicted codec, kept / coded again"""
+        h, m = C.c_uint32(0), C.c_uint32(0)
+        self.E.L.gz_zip_prediction(self.f, C.byref(h), C.byref(m))
+        return h.value, m.value
+
     def reset(self):
         self.E._check(self.E.L.gz_zip_reset(self.f), "gz_zip_reset")
 

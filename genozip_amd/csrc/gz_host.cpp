@@ -92,6 +92,10 @@ struct GzHandle {
     bool background = false;               // gz_create_background
     std::vector<GzHandle *> helpers;       // handles that work for this one (the VBlock driver's second handle): profiled with it
     uint32_t zip_spec_hits = 0, zip_spec_misses = 0;
+    // predicted coding (gz_zip.h): sections coded ahead of their context's trial with a predicted codec - kept / coded again; the codec every
+    // (dict_id, local | b250) of the handle's previous files ended up with (the prediction of a warm handle)
+    uint32_t zip_pred_hits = 0, zip_pred_misses = 0;
+    std::map<std::pair<uint64_t, int>, int> zip_codec_memory;
     // the VBlock driver: the coder the long QUAL streams are started with before the file's own trial compressions are through
     // (plain / through CODEC_DOMQ) - gz_zip.h, "speculation". Starts as a built-in prior - an order-1 adaptive coder is what
     // codec_assign_best_codec's size rule gives quality strings - and follows what the handle's files actually got

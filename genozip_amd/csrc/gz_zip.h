@@ -51,6 +51,7 @@ struct ZipCol {                    // one (VBlock, context) of this process
     size_t n2w_at = 0;
     uint8_t lcodec = 0, bcodec = 0;
     int early = -1;                            // index of this local's stream in the batch coded ahead on the second handle
+    int early_b = -1;                          // the same for its b250 (predicted coding)
     bool host_len = false;                     // a dyn-int local whose final byte length the host knows (transposed here, not by the batch of local jobs)
     bool pre_node = false;                     // an R2 VBlock whose context's r2_node is new to the file: the VBlock's first new node (fastq.c:664-665)
     bool host_local = false;                   // the local was put together on the host (ston_local holds it): uploaded with the small payloads
@@ -106,6 +107,7 @@ struct ZipCall {                   // what lives between the phases of one call
     int qual_mode_applied = -1;
     std::vector<std::vector<uint8_t>> own_snip; // per (VBlock, context): the snip a GZ_FQ_TOPLEVEL context segs in this VBlock
     std::vector<GzStream> early;               // the streams coded ahead (results arrive when the second handle is synchronised)
+    bool predicted = false;                    // ... with predicted codecs, beside their contexts' trials (the merge phase)
     uint32_t *d_early_len = NULL;
     // speculation: the long streams were handed to the coders with the codec the handle's previous file ended up with, before this
     // file's own trial (a8) was through; the trial (queued on the main handle once the seg phase has its results) confirms or refutes
@@ -1219,6 +1221,34 @@ static void zip_apply_qual_mode (GzZipFile *f, int mode)
     }
 }
 
+// Predicted coding (no counterpart in the reference; results are the same with and without). A file's first call finds no codec for most
+// contexts: the trial compressions of codec_assign_best_codec (a8) - eight candidates on a 100 KB sample each, every one of them a strictly
+// serial model + chain - sit between generation and the coding of the sections, 6 - 11 ms in which the device does little else. So every
+// stream that is waiting for a codec is handed to the coders right away with a PREDICTED codec, on the second handle, beside the trials;
+// the trials decide as always, and a section whose prediction they confirm is only framed afterwards (like the QUAL streams coded ahead),
+// the others are coded again with the rest. The prediction: what the handle's previous file ended up with for the same (dict_id, local |
+// b250); a cold handle (or GZ_ZIP_PRIOR_ONLY=1) predicts nothing unless GZ_ZIP_PREDICTION=prior asks for the built-in prior by kind of stream.
+static inline uint64_t zip_dict_key (const uint8_t id[8]) { uint64_t k; memcpy (&k, id, 8); return k; }
+static int zip_predict_codec (const GzZipFile *f, const GzFastqCtx &X, const ZipCol &Z, bool is_local, uint32_t dyn_width, bool prior_only)
+{
+    if (!prior_only) {
+        const auto it = f->h_user->zip_codec_memory.find (std::make_pair (zip_dict_key (X.dict_id), (int)is_local));
+        if (it != f->h_user->zip_codec_memory.end ()) return zip_is_host_codec (it->second) ? 0 : it->second;
+    }
+    // (the built-in prior is off unless asked for, GZ_ZIP_PREDICTION=prior. Measured on the MI355X, ms per step without / with it: binned FASTQ
+    //  - every prediction right - 26.9 / 24.8; BAM from text - 19 % of the sections wrong - 27.7 / 32.8: the coders working ahead slow the trials
+    //  down, 9.2 -> 12.8 ms, and a batch that codes the wrong ones again takes as long as one that codes them all, the time of its slowest stream.
+    //  Prediction pays when it is right: a handle that has seen a file of the kind)
+    const char *pm = getenv ("GZ_ZIP_PREDICTION");
+    const bool use_prior = pm && !strcmp (pm, "prior");
+    if (!use_prior) return 0;
+    if (!is_local) return GZ_CODEC_ARTB;                                   // word indices: an order-1 adaptive coder
+    if (X.kind == GZ_FQ_QUAL) return Z.ltype == GZ_LT_CODEC ? GZ_CODEC_ARTb : GZ_CODEC_ARTB;       // what CODEC_DOMQ leaves: few symbols, packed
+    if (X.kind == GZ_FQ_QUAL_AUX) return X.item == 0 ? GZ_CODEC_ARTW : X.item == 1 ? GZ_CODEC_RANB : GZ_CODEC_ARTb;
+    if (Z.dyn_job >= 0) return dyn_width <= 1 ? GZ_CODEC_RANb : GZ_CODEC_ARTW;                    // integers: by byte planes when wider than one
+    return GZ_CODEC_ARTB;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // phase 2: the merge over ALL VBlocks of the call in vblock_i order (this process' and, when the file is dealt out over
 // several processes, everybody else's), then b250 generation, locals into file order, R2 == R1 drops, and the trial
@@ -1548,8 +1578,47 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
                             if (L < 50) continue;                                                        // (too short to test: :309-312, the file's codec stays)
                             ptr.push_back (p); len.push_back (L); who.push_back ({ c, is_local | 4u | (zip_vb_commits (f->plan, vbs[v]) ? 0u : 2u), vbs[v].vblock_i, 0 });
                         }
+            // predicted coding: every stream that waits for one of these trials goes to the coders now, on the second handle (idle: no long
+            // streams were coded ahead in this call), with a predicted codec - see zip_predict_codec
+            if (f->h2 && K.early.empty () && !f->hostc.trial && !who.empty () && !getenv ("GZ_ZIP_NO_PREDICTION")) {
+                const char *pe = getenv ("GZ_ZIP_PRIOR_ONLY");
+                const bool prior_only = pe && *pe && *pe != '0';
+                std::vector<std::pair<ZipCol *, int>> owner;           // (column, is_local) of every stream
+                for (uint32_t c = 0; c < NC; c++) {
+                    const GzFastqCtx &X = f->ctxs[c];
+                    if (X.kind == GZ_FQ_SEQ || X.kind == GZ_FQ_ITEM_EXPECT) continue;
+                    for (uint32_t is_local = 0; is_local < 2; is_local++) {
+                        bool waiting = false;
+                        for (const ZipVote &w : who) if (w.ctx == c && (w.is_local & 1) == is_local) waiting = true;
+                        if (!waiting) continue;
+                        for (uint32_t v = 0; v < NV; v++) {
+                            ZipCol &Z = COL (v, c);
+                            if (is_local ? (Z.lcodec != 0 || Z.early >= 0) : Z.bcodec != 0) continue;
+                            uint32_t L = 0; const uint8_t *p = NULL;
+                            if (is_local && Z.has_local) { p = Z.local; L = Z.dyn_job >= 0 && !Z.host_len ? seclen[2 * ((size_t)v * NC + c)] : (uint32_t)Z.local_len; }
+                            if (!is_local && Z.has_b250) { p = Z.sec_b250; L = Z.col_job >= 0 ? seclen[2 * ((size_t)v * NC + c) + 1] : Z.sec_b250_len; }
+                            if (L < 50 || !p) continue;                   // (stored, or dropped on the device)
+                            const int codec = zip_predict_codec (f, X, Z, is_local != 0, Z.dyn_job >= 0 ? K.dynres[Z.dyn_job].width : 0, prior_only);
+                            if (!codec) continue;
+                            GzStream st; memset (&st, 0, sizeof (st));
+                            st.in = p; st.in_len = L; st.codec = codec; st.out_cap = gz_codec_est_size (codec, L);
+                            if (!(st.out = (uint8_t *)ws_alloc (f, (size_t)st.out_cap + 64))) return GZ_ERR_HIP;
+                            K.early.push_back (st); owner.push_back ({ &Z, (int)is_local });
+                        }
+                    }
+                }
+                if (!K.early.empty ()) {
+                    if (!(K.d_early_len = (uint32_t *)ws_alloc (f, K.early.size () * 4))) return GZ_ERR_HIP;
+                    for (size_t k = 0; k < K.early.size (); k++) { K.early[k].out_len_dev = K.d_early_len + k; (owner[k].second ? owner[k].first->early : owner[k].first->early_b) = (int)k; }
+                    // (their inputs are complete: this handle was synchronised above, behind the generation kernels; the second handle may still hold
+                    //  the seg phase's QUAL trial that nobody waited for: one batch at a time per handle)
+                    if ((rc = gz_sync (f->h2)) < 0) { h->err = f->h2->err; return rc; }
+                    if ((rc = gz_codec_compress_batch (f->h2, K.early.data (), (int)K.early.size ())) != GZ_OK) { h->err = f->h2->err; (void)gz_sync (f->h2); return rc; }
+                    K.predicted = true;
+                }
+            }
             std::vector<int> best;
-            if ((rc = zip_assign_best_many (h, f, ptr, len, who, best)) != GZ_OK) return rc;
+            if ((rc = zip_assign_best_many (h, f, ptr, len, who, best)) != GZ_OK) { if (K.predicted) (void)gz_sync (f->h2); return rc; }
             for (size_t k = 0; k < who.size (); k++) if (best[k]) { who[k].codec = (uint32_t)best[k]; K.votes.push_back (who[k]); }
         }
     }
@@ -1601,6 +1670,7 @@ static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint
             GzZctxView zv; gz_zctx_view (f->zctx[w.first.first], &zv);
             if (w.first.second ? zv.lcodec : zv.bcodec) continue;
             gz_zctx_commit_codec (f->zctx[w.first.first], (int)w.first.second, (int)w.second.codec);
+            f->h_user->zip_codec_memory[std::make_pair (zip_dict_key (f->ctxs[w.first.first].dict_id), (int)w.first.second)] = (int)w.second.codec;   // (the next file's prediction)
             // (next file: speculation - only a coder the device can run ahead: a host codec's win, BZ2 / LZMA / BSC, is no guess for a file without them)
             if ((int)w.first.first == f->qual_ctx && w.first.second && !zip_is_host_codec ((int)w.second.codec)) f->h_user->zip_qual_guess[f->qual_mode == GZ_CODEC_DOMQ] = (int)w.second.codec;
             // (a VBlock in front of the one that assigned finds nothing in the file, as in a serial run: it had < 50 bytes, or is small)
@@ -1655,14 +1725,15 @@ static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint
                 if (Z.col_job >= 0) s.data_len_dev = Z.sec_len_dev + 1;
                 s.codec = Z.bcodec; s.b250_size_or_nothing_char = 4;                                   // B250_VARL
                 if ((is_r1 && X.pair_identical) || (is_r2 && X.pair_assisted_b250)) s.flags |= PAIRED;    // zfile.c:292-294
+                if (Z.early_b >= 0) {                                                                  // coded ahead with a predicted codec: confirmed?
+                    const GzStream &es = K.early[Z.early_b];
+                    if (es.codec == (s.codec ? s.codec : GZ_CODEC_RANB)) { s.precompressed = 1; s.raw_len = es.in_len; s.data = es.out; s.data_len = es.out_cap; s.data_len_dev = es.out_len_dev; f->h_user->zip_pred_hits++; }
+                    else f->h_user->zip_pred_misses++;
+                }
             }
             else {
                 s.section_type = GZ_SEC_LOCAL; s.data = Z.local; s.data_len = (uint32_t)Z.local_len;
                 if (Z.dyn_job >= 0 && !Z.host_len) { s.data_len = (uint32_t)Z.local_cap; s.data_len_dev = Z.sec_len_dev; }
-                if (Z.early >= 0) {                                                                    // coded ahead on the second handle: only framed here
-                    const GzStream &es = K.early[Z.early];
-                    s.precompressed = 1; s.raw_len = es.in_len; s.data = es.out; s.data_len = es.out_cap; s.data_len_dev = es.out_len_dev;
-                }
                 s.codec = Z.lcodec; s.ltype = (uint8_t)Z.ltype;
                 if (Z.ltype == GZ_LT_CODEC) {                                                          // QUAL through CODEC_DOMQ (codec_domq.c:221,308-309,487-500)
                     // the stream's coder: the file's, as VBlock v would find it in a serial run (codec.c:280-281) - however short the
@@ -1679,6 +1750,16 @@ static int zip_finish_launch (GzZipFile *f, const void *const *votes, const uint
                 const bool int_lt = (Z.ltype >= GZ_LT_INT8 && Z.ltype <= GZ_LT_UINT64) || (Z.ltype >= GZ_LT_UINT8_TR && Z.ltype <= GZ_LT_UINT32_TR);   // lt_max (ltype) != 0
                 if (int_lt) s.b250_size_or_nothing_char = X.nothing_char ? X.nothing_char : 0xff;    // zfile.c:344-345
                 if (is_r1 && X.pair_identical) s.flags |= PAIRED;                                     // zfile.c:323-325
+                if (Z.early >= 0) {                                                                    // coded ahead on the second handle: only framed here
+                    const GzStream &es = K.early[Z.early];
+                    // (predicted coding: only if the trials ended up with the codec the stream was coded with; the QUAL streams coded ahead in the
+                    //  seg phase were given the codec that is theirs by then)
+                    if (!K.predicted || es.codec == (s.codec ? s.codec : GZ_CODEC_RANB)) {
+                        s.precompressed = 1; s.raw_len = es.in_len; s.data = es.out; s.data_len = es.out_cap; s.data_len_dev = es.out_len_dev;
+                        if (K.predicted) f->h_user->zip_pred_hits++;
+                    }
+                    else f->h_user->zip_pred_misses++;
+                }
             }
             if (zip_is_host_codec (s.codec) && !s.precompressed) {
                 // a codec of the host's (a8: its candidate won the context): the stream goes to the host, its coder's payload comes back
@@ -1815,6 +1896,12 @@ extern "C" int gz_fastq_zip_end (GzZipFile *f)
     f->busy = false;
     if (rc != GZ_OK && f->h != f->h_user) f->h_user->err = f->h->err;
     return rc;
+}
+
+extern "C" void gz_zip_prediction (const GzZipFile *f, uint32_t *hits, uint32_t *misses)
+{
+    if (hits)   *hits   = f ? f->h_user->zip_pred_hits : 0;
+    if (misses) *misses = f ? f->h_user->zip_pred_misses : 0;
 }
 
 extern "C" void gz_zip_speculation (const GzZipFile *f, uint32_t *hits, uint32_t *misses)

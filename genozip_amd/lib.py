@@ -178,7 +178,7 @@ ABI_SYMBOLS = (
     "gz_zctx_create", "gz_zctx_destroy", "gz_hash_next_size_up", "gz_ctx_merge", "gz_zctx_view", "gz_zctx_commit_codec",
     "gz_zip_open", "gz_zip_close", "gz_fastq_zip_vblocks", "gz_fastq_zip_seg", "gz_fastq_zip_merge", "gz_fastq_zip_finish", "gz_zip_zctx", "gz_section_order",
     "gz_zip_reset", "gz_fastq_zip_collect",
-    "gz_domq_columns", "gz_domq_fit", "gz_codec_compress_lines_host", "gz_byte_index", "gz_vcf_sample_columns", "gz_fastq_zip_begin", "gz_fastq_zip_end", "gz_zip_speculation",
+    "gz_domq_columns", "gz_domq_fit", "gz_codec_compress_lines_host", "gz_byte_index", "gz_vcf_sample_columns", "gz_fastq_zip_begin", "gz_fastq_zip_end", "gz_zip_speculation", "gz_zip_prediction",
     "gz_zfile_create", "gz_zfile_destroy", "gz_zfile_add_vblock", "gz_zfile_write_global_area", "gz_codec_assign_best_host",
     "gz_zfile_add_txt_header", "gz_zfile_add_txt_header_text", "gz_zfile_set_fastq", "gz_vb_insert_section",
     "gz_tokenize_column_n", "gz_int_columns", "gz_local_generate_batch", "gz_acgt_pack_batch",
@@ -274,6 +274,8 @@ def load(path=None):
     L.gz_fastq_zip_end.argtypes = [C.c_void_p]
     L.gz_zip_speculation.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.gz_zip_speculation.restype = None
+    L.gz_zip_prediction.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.gz_zip_prediction.restype = None
     L.gz_byte_index.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint8, C.c_void_p, C.c_uint32, C.c_void_p]
     L.gz_vcf_sample_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -631,6 +631,15 @@ int gz_fastq_zip_end (GzZipFile *f);
  * scores (the long pole of such a call). hits / misses of the handle the file was opened on; environment: GZ_ZIP_NO_SPECULATION=1 never,
  * GZ_ZIP_SPECULATION=always whatever the sizes. */
 void gz_zip_speculation (const GzZipFile *f, uint32_t *hits, uint32_t *misses);
+/* Predicted coding (no counterpart in the reference either; same bytes with and without): in a call whose contexts still wait for their
+ * trial compressions (a file's first call), every such stream is handed to the coders at once with a PREDICTED codec, on the second handle,
+ * beside the trials - the codec the handle's previous file gave the same (dict_id, local | b250): a handle that has seen a file of the kind
+ * (GZ_ZIP_PRIOR_ONLY=1 forgets it; GZ_ZIP_PREDICTION=prior: a cold handle uses a built-in prior by kind of stream - b250: ARTB; integers: RANb
+ * for one byte, ARTW for more; QUAL: ARTB, through CODEC_DOMQ ARTb - which pays only where it is right: gz_zip.h has the measurements). The
+ * trials decide as always; a section they confirm is only framed afterwards, the others are coded again with the rest. hits / misses:
+ * sections kept / coded again, of the handle the file was opened on. GZ_ZIP_NO_PREDICTION=1: never. Not done while the long QUAL streams of
+ * the call are being coded ahead (the second handle is theirs) or with the host's candidates in the race. */
+void gz_zip_prediction (const GzZipFile *f, uint32_t *hits, uint32_t *misses);
 /* a new file with the same plan (fresh dictionaries and codecs; the device workspace is kept) */
 int gz_zip_reset (GzZipFile *f);
 /* the z_data of the last call's VBlocks one after the other into dst (device) - what is handed to the writer

@@ -2056,3 +2056,38 @@ def bam_front(E, oracle, n, seed=31):
             E.bam_to_sam(broken, off, refs)
         assert E.last_bam.status == -5 and E.last_bam.first_bad == ev.value.args[0] == j, (E.last_bam.first_bad, ev.value.args[0], j)
     return len(got_off)
+
+
+def fastq_zip_prediction(E, oracle, n_reads):
+    """predicted coding (gz_zip_prediction): streams coded ahead of their contexts' trials - with the built-in prior (GZ_ZIP_PREDICTION=prior: some
+    right, some wrong) and from what the handle remembers of its previous file (right, unless the next file is of another kind) - give the bytes of
+    the oracle's composition either way (every run below is compared inside fastq_zip); the counters move"""
+    import os
+    from genozip_amd import fastq as fq
+    F = E.zip_open(fq.illumina_plan(paired=True))
+    h0, m0 = F.prediction()
+    F.close()
+    os.environ["GZ_ZIP_PREDICTION"] = "prior"
+    os.environ["GZ_ZIP_PRIOR_ONLY"] = "1"
+    try:
+        fastq_zip(E, oracle, n_reads, n_calls=1, qual=("uniform",))
+        fastq_zip(E, oracle, n_reads, n_calls=2, qual=("bin", "uniform"), mono=(5, 0))
+    finally:
+        del os.environ["GZ_ZIP_PREDICTION"], os.environ["GZ_ZIP_PRIOR_ONLY"]
+    F = E.zip_open(fq.illumina_plan(paired=True))
+    h1, m1 = F.prediction()
+    F.close()
+    assert h1 + m1 > h0 + m0, "the prior predicted nothing"
+    fastq_zip(E, oracle, n_reads, n_calls=1, qual=("uniform",))        # the handle learns ...
+    fastq_zip(E, oracle, n_reads, n_calls=1, qual=("uniform",))        # ... and predicts right
+    F = E.zip_open(fq.illumina_plan(paired=True))
+    h2, m2 = F.prediction()
+    F.close()
+    assert h2 > h1, "a warm handle predicted nothing"
+    fastq_zip(E, oracle, n_reads, n_calls=1, qual=("bin",))            # another kind of file: what it remembers is partly wrong
+    os.environ["GZ_ZIP_NO_PREDICTION"] = "1"
+    try:
+        fastq_zip(E, oracle, n_reads, n_calls=1, qual=("uniform",))
+    finally:
+        del os.environ["GZ_ZIP_NO_PREDICTION"]
+    return h2 - h0, m2 - m0

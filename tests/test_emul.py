@@ -148,6 +148,10 @@ def test_emul_fastq_zip_speculation(emul_engine, oracle):
     parity.fastq_zip_speculation(emul_engine, oracle, 42)
 
 
+def test_emul_fastq_zip_prediction(emul_engine, oracle):
+    parity.fastq_zip_prediction(emul_engine, oracle, 60)
+
+
 def test_emul_chain_block_boundaries(emul_engine, oracle):
     parity.chain_block_boundaries(emul_engine, oracle, big=False)
 

@@ -163,6 +163,14 @@ def test_e2e_files_sha256(gpu_engine):
 
 
 @pytest.mark.gpu
+def test_fastq_zip_prediction(gpu_engine, oracle):
+    """streams coded ahead of their contexts' trial compressions with a predicted codec (the built-in prior; what the handle remembers): the
+    oracle's bytes whether the prediction was right or wrong"""
+    hits, misses = parity.fastq_zip_prediction(gpu_engine, oracle, 3000)
+    assert hits > 0
+
+
+@pytest.mark.gpu
 def test_fastq_zip_early_path(gpu_engine, oracle, monkeypatch):
     """the QUAL streams coded ahead of the merge on the second handle (the driver's way for long streams, >= GZ_ZIP_EARLY_MIN scores),
     forced for streams of test size: the same bytes as when QUAL is coded with the rest"""
