@@ -2109,9 +2109,13 @@ static void dq_add_runs (uint8_t *runs, uint64_t *n, uint32_t runlen)           
 
 int gzo_domq_encode (const uint8_t *text, const uint32_t *off, const uint32_t *len, uint64_t n_lines, GzoDomq *o)
 {
-    static uint32_t hist[DQ_N][DQ_N];
+    /* (per call, not static: bench.py runs one VBlock per thread) */
+    typedef struct { uint32_t hist[DQ_N][DQ_N], ch[DQ_N][DQ_N]; uint8_t normalize[DQ_N][DQ_N], denorm[DQ_N][DQ_N]; } DomqTabs;
+    DomqTabs *tabs = calloc (1, sizeof (DomqTabs));
+    if (!tabs) return -1;
+    uint32_t (*hist)[DQ_N] = tabs->hist, (*ch)[DQ_N] = tabs->ch;
+    uint8_t (*normalize)[DQ_N] = tabs->normalize, (*denorm)[DQ_N] = tabs->denorm;
     uint32_t lines_with_dom[DQ_N] = { 0 };
-    memset (hist, 0, sizeof (hist));
     uint8_t *dom = malloc (n_lines + 1), *diverse = calloc (n_lines + 1, 1);
     uint64_t total = 0;
     o->has_diverse = 0;
@@ -2120,7 +2124,7 @@ int gzo_domq_encode (const uint8_t *text, const uint32_t *off, const uint32_t *l
         uint32_t h[DQ_N] = { 0 }, best = 0;
         for (uint32_t k = 0; k < len[i]; k++) {
             const uint8_t c = text[off[i] + k];
-            if (c < DQ_FIRST || c > 126) { free (dom); free (diverse); return -1; }
+            if (c < DQ_FIRST || c > 126) { free (dom); free (diverse); free (tabs); return -1; }
             h[c - DQ_FIRST]++;
         }
         for (int q = 0; q < DQ_N; q++) if (h[q] >= best) { best = h[q]; dom[i] = (uint8_t)q; }   /* equal: the higher score */
@@ -2130,10 +2134,7 @@ int gzo_domq_encode (const uint8_t *text, const uint32_t *off, const uint32_t *l
         total += len[i];
     }
     uint8_t dom_to_cdom[DQ_N] = { 0 }, ndom = 0;                                          /* :178-196 */
-    static uint32_t ch[DQ_N][DQ_N];
     for (int q = 0; q < DQ_N; q++) if (lines_with_dom[q]) { dom_to_cdom[q] = ndom; memcpy (ch[ndom], hist[q], sizeof (ch[0])); ndom++; }
-    static uint8_t normalize[DQ_N][DQ_N], denorm[DQ_N][DQ_N];
-    memset (denorm, 0, sizeof (denorm)); memset (normalize, 0, sizeof (normalize));
     uint32_t num_norm = 0;
     for (int c = 0; c < ndom; c++) {                                                      /* :198-249: rank by count, descending, stable */
         uint32_t rank = 0;
@@ -2175,7 +2176,7 @@ int gzo_domq_encode (const uint8_t *text, const uint32_t *off, const uint32_t *l
     if (runlen && (o->runs_len || runlen < last_len)) { dq_add_runs (o->runs, &o->runs_len, runlen); o->qual[o->qual_len++] = no_doms; }
     o->all_diverse = 0;
     if (!o->qual_len) { o->qual[o->qual_len++] = 'X'; o->all_diverse = 1; }             /* :490-494 */
-    free (dom); free (diverse);
+    free (dom); free (diverse); free (tabs);
     return 0;
 }
 

@@ -35,7 +35,7 @@ typedef struct {
     uint8_t  item_kind[16];        /* 0: seg_by_ctx (text), 1: seg_integer_or_not, 2: seg_self_delta */
     uint8_t  seps[32], sep_counts[32]; uint32_t n_seps;   /* item i ends at the sep_counts[i]-th seps[i] (CI0_COLONn) */
     uint8_t  lcodec[16], bcodec[16];   /* per item; 0: codec_assign_best_codec on this VBlock's stream */
-    uint8_t  qual_codec, aux_codec[3], x_codec;
+    uint8_t  qual_codec, aux_codec[3], x_codec, qual_bcodec;
     uint8_t  domq;                 /* QUAL through CODEC_DOMQ */
 } GzoPathPlan;
 
@@ -194,7 +194,7 @@ long gzo_fastq_vb_path (const uint8_t *text, uint64_t text_len, uint32_t vblock_
         uint64_t nq = 0; for (uint64_t r = 0; r < n; r++) nq += ql[r];
         long r6 = -1;
         if (col_alloc (&col, n, 3 * n) && gzo_ctx_seg_column (slots, so, sl, n, NULL, NULL, NULL, 0, &col) == 0)
-            r6 = path_b250 (&col, (uint32_t)n, nq, 0, vblock_i, z + zl, z_cap - zl, streams);
+            r6 = path_b250 (&col, (uint32_t)n, nq, P->qual_bcodec, vblock_i, z + zl, z_cap - zl, streams);
         col_free (&col); memset (&col, 0, sizeof (col)); free (slots);
         if (r6 < 0) goto done;
         zl += (uint64_t)r6;

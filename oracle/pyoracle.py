@@ -485,7 +485,7 @@ class OracleZctx:
 class GzoPathPlan(ctypes.Structure):
     _fields_ = [("n_items", ctypes.c_uint32), ("item_kind", ctypes.c_uint8 * 16), ("seps", ctypes.c_uint8 * 32), ("sep_counts", ctypes.c_uint8 * 32),
                 ("n_seps", ctypes.c_uint32), ("lcodec", ctypes.c_uint8 * 16), ("bcodec", ctypes.c_uint8 * 16), ("qual_codec", ctypes.c_uint8),
-                ("aux_codec", ctypes.c_uint8 * 3), ("x_codec", ctypes.c_uint8), ("domq", ctypes.c_uint8)]
+                ("aux_codec", ctypes.c_uint8 * 3), ("x_codec", ctypes.c_uint8), ("qual_bcodec", ctypes.c_uint8), ("domq", ctypes.c_uint8)]
 
 
 def fastq_path_many(oracle, text, vbs, plan, codecs, domq, n_threads, replicas=1, ref=None):
@@ -511,6 +511,7 @@ def fastq_path_many(oracle, text, vbs, plan, codecs, domq, n_threads, replicas=1
     for k, t in enumerate(("DOMQRUNS", "QUALMPLX", "DIVRQUAL")):
         P.aux_codec[k] = codecs.get(("local", t), 0)
     P.x_codec = codecs.get(("local", "NONREF_X"), 0) or 1
+    P.qual_bcodec = codecs.get(("b250", "QUAL"), 0)
     P.domq = int(bool(domq))
     if ref is not None:
         L.gzo_path_use_codecs(ctypes.cast(ref.L.htsref_rans_compress, ctypes.c_void_p), ctypes.cast(ref.L.htsref_arith_compress, ctypes.c_void_p))
