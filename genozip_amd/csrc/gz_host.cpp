@@ -467,8 +467,8 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
             if (!(L.spos   = (uint32_t *)arena_alloc (h, ((size_t)nb + 64) * 4))) return false;
             if (!(L.srk    = (uint8_t *)arena_alloc (h, (size_t)nb + 64))) return false;
             if (!(L.ctxoff = (uint32_t *)arena_alloc (h, (nt + 1) * nctx * 4))) return false;
-            // one row per position chunk (no chunk is smaller than GZ_CHUNK_MIN: a short leaf has few)
-            const size_t rows = std::min<size_t> (GZ_MAX_CHUNKS, (size_t)nb / GZ_CHUNK_MIN + 2);
+            // one row per position chunk (no chunk is smaller than GZ_CHUNK_MIN - but for the first one, which goes in up to four pieces: a short leaf has few)
+            const size_t rows = std::min<size_t> (GZ_MAX_CHUNKS, (size_t)nb / GZ_CHUNK_MIN + 6);
             if (!(L.ctxend = (uint32_t *)arena_alloc (h, rows * nctx * 4))) return false;
             P.any_arith_o1 = true;
             P.o1_list.push_back ((uint32_t)P.leaves.size ());
@@ -564,6 +564,8 @@ struct ArithPipe {
     const uint32_t *d_plain = NULL, *d_o1 = NULL, *d_big = NULL, *d_small = NULL, *d_rle = NULL;
     const GzdLowBlock *d_lb = NULL, *d_lb_small = NULL;
     uint32_t *d_progress = NULL;      // [0] model chunks announced  [16 + k] leaves whose chain is through chunk k
+    uint32_t *d_bounds = NULL;        // [n_chunks + 1] where the position chunks start (device copy of bounds)
+    std::vector<uint32_t> bounds;     // the first chunk of `chunk` positions goes in pieces: 1/8, 1/8, 1/4, 1/2 of it (whole sort tiles)
     bool pipelined = false, reserve_cu = false;
 };
 
@@ -577,6 +579,22 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
     A.chunk = ((P.max_arith_n + want_chunks - 1) / want_chunks + GZ_CTX_TILE - 1) & ~(GZ_CTX_TILE - 1);
     if (A.chunk < GZ_CHUNK_MIN) A.chunk = GZ_CHUNK_MIN;
     A.n_chunks = P.max_arith_n ? (P.max_arith_n + A.chunk - 1) / A.chunk : 1;
+    // The chain of a long leaf can only start once the sort and the models of its first position chunk are through: the lead-in of the
+    // whole step (0.9 ms of the default FASTQ step's 4.4 before the chain has its first records). So the first chunk goes in pieces of
+    // 1/8, 1/8, 1/4 and 1/2 of a chunk - the models run ahead of the chain (0.9 ms per chunk against the chain's 1.3), so they are
+    // through each piece before the chain asks for it. (GZ_ARITH_FIRST_SPLIT=0: one piece, as until round 5.)
+    A.bounds.clear ();
+    {
+        static const bool split = !(getenv ("GZ_ARITH_FIRST_SPLIT") && getenv ("GZ_ARITH_FIRST_SPLIT")[0] == '0');
+        const uint32_t tiles = A.chunk / GZ_CTX_TILE;
+        A.bounds.push_back (0);
+        if (split && A.n_chunks > 1 && tiles >= 8) {
+            const uint32_t cut[3] = { (tiles + 7) / 8, (tiles + 3) / 4, (tiles + 1) / 2 };
+            for (int c = 0; c < 3; c++) if (cut[c] * GZ_CTX_TILE > A.bounds.back () && cut[c] < tiles) A.bounds.push_back (cut[c] * GZ_CTX_TILE);
+        }
+        for (uint32_t k = 1; k <= A.n_chunks; k++) A.bounds.push_back (k * A.chunk);
+        A.n_chunks = (uint32_t)A.bounds.size () - 1;
+    }
     // leaves that fit one chunk go through model and chain in one piece on a stream of their own; only the long ones
     // take the pipeline (their first model chunk is the lead-in of the whole step: keep it free of other work)
     std::vector<uint32_t> big, small;
@@ -632,6 +650,7 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
         if (A.n_chunks > GZ_MAX_CHUNKS) return GZ_ERR;            // (cannot happen: at most 16 / GZ_ARITH_CHUNKS chunks)
         if (!(A.d_progress = (uint32_t *)arena_alloc (h, 1024))) return GZ_ERR_HIP;
         HIPCHK (h, hipMemsetAsync (A.d_progress, 0, 1024, h->stream));
+        { void *db; if ((rc = upload (h, A.bounds.data (), A.bounds.size () * 4, &db)) != GZ_OK) return rc; A.d_bounds = (uint32_t *)db; }
         if (A.nsmall) {                                           // the slices of the short leaves only
             std::vector<uint8_t> is_small (P.leaves.size (), 0);
             for (uint32_t l : small) is_small[l] = 1;
@@ -651,7 +670,7 @@ static int arith_launch_chain (GzHandle *h, const ArithPipe &A, GzdLeaf *d_leave
     HIPCHK (h, hipEventRecord (h->ev_chain_go, h->stream));                     // (behind the uploads and the memset)
     HIPCHK (h, hipStreamWaitEvent (h->stream3, h->ev_chain_go, 0));
     KLAUNCH_ON (h, h->stream3, k_arith_chain, dim3 ((A.nbig + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), A.reserve_cu ? GZ_CHAIN_LDS : 64,
-                d_leaves, A.d_big, A.nbig, (const uint32_t *)A.d_progress, A.chunk, h->d_fail, A.d_progress + 16, A.n_chunks);
+                d_leaves, A.d_big, A.nbig, (const uint32_t *)A.d_progress, (const uint32_t *)A.d_bounds, h->d_fail, A.d_progress + 16, A.n_chunks);
     HIPCHK (h, hipEventRecord (h->ev_chain, h->stream3));
     return GZ_OK;
 }
@@ -692,19 +711,19 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
             if (!P.rle_list.empty ())                              // the run-length variant's coding events (before anything looks at arith_n)
                 KLAUNCH (h, k_rle_events, dim3 ((uint32_t)P.rle_list.size ()), dim3 (1024), 256, d_leaves, A.d_rle);
             // sort (group the positions of the order-1 leaves by context), models, chain
-            auto sort_chunk = [&] (hipStream_t st, const uint32_t *list, uint32_t n_list, uint32_t p0, uint32_t chunk, uint32_t span) -> int {
+            auto sort_chunk = [&] (hipStream_t st, const uint32_t *list, uint32_t n_list, uint32_t p0, uint32_t chunk, uint32_t span, uint32_t row) -> int {
                 if (!A.no1 || !span) return GZ_OK;
                 const uint32_t tiles = (span + GZ_CTX_TILE - 1) / GZ_CTX_TILE;
                 KLAUNCH_ON (h, st, k_ctx_count, GZ_XCD_DIM (n_list, tiles), dim3 (64), GZ_CTX_MAX * 4, d_leaves, list, n_list, p0, chunk);
-                KLAUNCH_ON (h, st, k_ctx_scan, dim3 (n_list), dim3 (256), GZ_CTX_MAX * 8, d_leaves, list, p0, chunk);
+                KLAUNCH_ON (h, st, k_ctx_scan, dim3 (n_list), dim3 (256), GZ_CTX_MAX * 8, d_leaves, list, p0, chunk, row);
                 KLAUNCH_ON (h, st, k_ctx_scatter, GZ_XCD_DIM (n_list, tiles), dim3 (64), GZ_CTX_MAX * 4 + 256, d_leaves, list, n_list, p0, chunk);
                 return GZ_OK;
             };
             if (!A.pipelined) {
-                if ((rc = sort_chunk (h->stream, A.d_plain, A.np, 0u, 0xffffffffu, P.max_arith_n)) != GZ_OK) return rc;
-                KLAUNCH (h, k_arith_model, GZ_XCD_DIM (A.np, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_plain, A.np, inv_tab, 0u, 0xffffffffu);
+                if ((rc = sort_chunk (h->stream, A.d_plain, A.np, 0u, 0xffffffffu, P.max_arith_n, 0u)) != GZ_OK) return rc;
+                KLAUNCH (h, k_arith_model, GZ_XCD_DIM (A.np, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_plain, A.np, inv_tab, 0u, 0xffffffffu, 0u);
                 KLAUNCH (h, k_arith_chain, dim3 ((A.np + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), 64,
-                         d_leaves, A.d_plain, A.np, (const uint32_t *)NULL, 0u, h->d_fail, (uint32_t *)NULL, 0u);
+                         d_leaves, A.d_plain, A.np, (const uint32_t *)NULL, (const uint32_t *)NULL, h->d_fail, (uint32_t *)NULL, 0u);
             }
             else {
                 HIPCHK (h, hipEventRecord (h->ev_model_fork, h->stream));        // (after k_leaf_prep)
@@ -720,11 +739,13 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 hipStream_t sort_stream = A.nbig > sort_ahead_min ? h->stream7 : h->stream4;   // (measured: 702 leaves 84.0 -> 80.6 ms; 176 leaves 33.9 -> 34.2: the sort then only takes compute units from the models)
                 if (A.no1) KLAUNCH_ON (h, sort_stream, k_ctx_succ, dim3 (A.nbig, (P.max_arith_n + GZ_SUCC_SPAN - 1) / GZ_SUCC_SPAN), dim3 (256), 8192, d_leaves, A.d_big);
                 for (uint32_t k = 0; k < A.n_chunks; k++) {
-                    const uint32_t p0 = k * A.chunk, span = P.max_arith_n - p0 < A.chunk ? P.max_arith_n - p0 : A.chunk;
-                    if ((rc = sort_chunk (sort_stream, A.d_big, A.nbig, p0, A.chunk, span)) != GZ_OK) return rc;
+                    const uint32_t p0 = A.bounds[k], len = A.bounds[k + 1] - p0;
+                    if (p0 >= P.max_arith_n) break;
+                    const uint32_t span = P.max_arith_n - p0 < len ? P.max_arith_n - p0 : len;
+                    if ((rc = sort_chunk (sort_stream, A.d_big, A.nbig, p0, len, span, k)) != GZ_OK) return rc;
                     HIPCHK (h, hipEventRecord (h->ev_sort[k], sort_stream));
                     HIPCHK (h, hipStreamWaitEvent (h->stream4, h->ev_sort[k], 0));
-                    KLAUNCH_ON (h, h->stream4, k_arith_model, GZ_XCD_DIM (A.nbig, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_big, A.nbig, inv_tab, p0, A.chunk);
+                    KLAUNCH_ON (h, h->stream4, k_arith_model, GZ_XCD_DIM (A.nbig, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_big, A.nbig, inv_tab, p0, len, k);
                     hipLaunchKernelGGL (k_arith_progress, dim3 (1), dim3 (1), 0, h->stream4, A.d_progress, k + 1);
                 }
 #ifdef GZ_SEQUENTIAL_STREAMS
@@ -735,10 +756,10 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 //  stripe planes, "short" next to a 30 M-entry b250, started 2.8 s late, after the long chain had finished)
                 if (A.nsmall) {
                     HIPCHK (h, hipStreamWaitEvent (h->stream5, h->ev_model_fork, 0));
-                    if ((rc = sort_chunk (h->stream5, A.d_small, A.nsmall, 0u, 0xffffffffu, A.chunk)) != GZ_OK) return rc;
-                    KLAUNCH_ON (h, h->stream5, k_arith_model, GZ_XCD_DIM (A.nsmall, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_small, A.nsmall, inv_tab, 0u, 0xffffffffu);
+                    if ((rc = sort_chunk (h->stream5, A.d_small, A.nsmall, 0u, 0xffffffffu, A.chunk, 0u)) != GZ_OK) return rc;
+                    KLAUNCH_ON (h, h->stream5, k_arith_model, GZ_XCD_DIM (A.nsmall, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_small, A.nsmall, inv_tab, 0u, 0xffffffffu, 0u);
                     KLAUNCH_ON (h, h->stream5, k_arith_chain, dim3 ((A.nsmall + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), GZ_KEEP_OFF_LDS,
-                                d_leaves, A.d_small, A.nsmall, (const uint32_t *)NULL, 0u, h->d_fail, (uint32_t *)NULL, 0u);
+                                d_leaves, A.d_small, A.nsmall, (const uint32_t *)NULL, (const uint32_t *)NULL, h->d_fail, (uint32_t *)NULL, 0u);
                     if (A.nlb_small) {
                         KLAUNCH_ON (h, h->stream5, k_chain_expand, dim3 (A.nlb_small), dim3 (64), GZ_EXPAND_LDS, d_leaves, A.d_lb_small, (const uint32_t *)NULL, 0u, h->debug_chain_fault);
                         KLAUNCH_ON (h, h->stream5, k_low_scan, dim3 (A.nsmall), dim3 (1024), 8192, d_leaves, A.d_small, 0u, 0xffffffffu);
@@ -751,11 +772,13 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 // leaf is through chunk k; count / scan / scatter of that chunk then run beside the chain's next chunk
                 HIPCHK (h, hipStreamWaitEvent (h->stream6, h->ev_model_fork, 0));
                 for (uint32_t k = 0; k < A.n_chunks; k++) {
-                    const uint32_t p0 = k * A.chunk, span = P.max_arith_n - p0 < A.chunk ? P.max_arith_n - p0 : A.chunk;
+                    const uint32_t p0 = A.bounds[k], len = A.bounds[k + 1] - p0;
+                    if (p0 >= P.max_arith_n) break;
+                    const uint32_t span = P.max_arith_n - p0 < len ? P.max_arith_n - p0 : len;
                     const uint32_t wgs = (span + GZ_LOW_SLICE * GZ_LOW_SLICES_PER_WG - 1) / (GZ_LOW_SLICE * GZ_LOW_SLICES_PER_WG);
                     hipLaunchKernelGGL (k_low_gate, dim3 (1), dim3 (1), 0, h->stream6, (const uint32_t *)(A.d_progress + 16 + k), A.nbig, h->d_fail);
                     KLAUNCH_ON (h, h->stream6, k_chain_expand, dim3 (A.nbig, wgs), dim3 (64), GZ_EXPAND_LDS, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0, h->debug_chain_fault);
-                    KLAUNCH_ON (h, h->stream6, k_low_scan, dim3 (A.nbig), dim3 (1024), 8192, d_leaves, A.d_big, p0, A.chunk);
+                    KLAUNCH_ON (h, h->stream6, k_low_scan, dim3 (A.nbig), dim3 (1024), 8192, d_leaves, A.d_big, p0, len);
                     KLAUNCH_ON (h, h->stream6, k_low_scatter, dim3 (A.nbig, wgs), dim3 (GZ_LOW_WG), GZ_KEEP_OFF_LDS, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0);
                 }
                 HIPCHK (h, hipEventRecord (h->ev_low, h->stream6));

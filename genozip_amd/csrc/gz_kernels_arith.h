@@ -555,7 +555,8 @@ __global__ void __launch_bounds__(64) k_ctx_count (GzdLeaf *leaves, const uint32
 // one 256-thread workgroup per leaf: thread c owns contexts c, c + 256, c + 512. The occurrences of positions
 // [p0, p0 + chunk) take entries [p0, p1) of the sorted lists, grouped by context: every position chunk is sorted on
 // its own, just before its models run (ctxend = where each context's run of this chunk ends).
-__global__ void __launch_bounds__(256) k_ctx_scan (GzdLeaf *leaves, const uint32_t *list, uint32_t p0, uint32_t chunk)
+// row: which row of ctxend this chunk's run ends go to (the sort runs ahead of the models: a row per chunk in flight)
+__global__ void __launch_bounds__(256) k_ctx_scan (GzdLeaf *leaves, const uint32_t *list, uint32_t p0, uint32_t chunk, uint32_t row)
 {
     GzdLeaf &L = leaves[list[blockIdx.x]];
     if (!d_ctx_sorted (L) || L.arith_n <= p0) return;
@@ -573,7 +574,7 @@ __global__ void __launch_bounds__(256) k_ctx_scan (GzdLeaf *leaves, const uint32
     for (uint32_t c = threadIdx.x; c < nctx; c += 256) {
         const uint32_t base = sh[c];
         for (uint32_t t = t0; t < t1; t++) off[(size_t)t * nctx + c] += base;
-        L.ctxend[(size_t)(chunk == 0xffffffffu ? 0 : p0 / chunk) * nctx + c] = base + sh[GZ_CTX_MAX + c];   // (a row per chunk: the sort runs ahead of the models)
+        L.ctxend[(size_t)row * nctx + c] = base + sh[GZ_CTX_MAX + c];   // (a row per chunk: the sort runs ahead of the models)
     }
 }
 
@@ -921,7 +922,7 @@ __device__ unsigned long long g_model_slowest;     // (10 ns ticks << 40) | (lis
 #define GZ_MODEL_T0 do {} while (0)
 #define GZ_MODEL_T1(ctx, occ) do {} while (0)
 #endif
-__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const GzDivInv *inv_tab, uint32_t p0, uint32_t chunk)
+__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const GzDivInv *inv_tab, uint32_t p0, uint32_t chunk, uint32_t row)
 {
     GZ_XCD_GRID (li, by, n_list);
     GzdLeaf &L = leaves[list[li]];
@@ -940,7 +941,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
     const uint32_t p1 = (n_u - p0 > chunk) ? p0 + chunk : n_u;
     const uint32_t *off = d_uniform_ptr (L.ctxoff), *spos = d_uniform_ptr (L.spos);
     const uint8_t *srk = d_uniform_ptr (L.srk);
-    const uint32_t *cend = d_uniform_ptr (L.ctxend + (size_t)(chunk == 0xffffffffu ? 0 : p0 / chunk) * L.nctx);
+    const uint32_t *cend = d_uniform_ptr (L.ctxend + (size_t)row * L.nctx);
     const uint32_t t0 = p0 / GZ_CTX_TILE;                      // (chunks are whole tiles)
     uint32_t *mstate = d_uniform_ptr (L.mstate);
     const uint64_t *succ = d_uniform_ptr (L.succ);
@@ -1121,8 +1122,9 @@ __device__ static __forceinline__ void d_chain_chunk (uint32_t &rlo, uint32_t &r
     gz_scalar_store2 (ck + 2 * ((p1 + 63) >> 6), rlo, rhi);
 }
 
-// progress == NULL: everything is there already, one piece (chunk is ignored)
-__device__ static __forceinline__ void d_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress, uint32_t chunk,
+// progress == NULL: everything is there already, one piece (bounds is ignored). bounds [0 .. n_chunks]: where the position chunks start (the
+// first ones are shorter than the rest: the first chunk's sort + models are the lead-in of the long streams - gz_host.cpp, arith_pipe_setup)
+__device__ static __forceinline__ void d_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress, const uint32_t *bounds,
                                                       uint32_t *fail, uint32_t *done, uint32_t n_chunks)
 {
     const uint32_t li = blockIdx.x * GZ_CHAIN_WAVES + (threadIdx.x >> 6);
@@ -1142,25 +1144,27 @@ __device__ static __forceinline__ void d_arith_chain (GzdLeaf *leaves, const uin
     uint32_t rlo = GZ_CHAIN_R0_LO, rhi = GZ_CHAIN_R0_HI;
     if (!progress) d_chain_chunk (rlo, rhi, lane, 0, n, triples, ck);
     else
-        for (uint32_t k = 0, p0 = 0; p0 < n; k++, p0 += chunk) {
+        for (uint32_t k = 0; k < n_chunks; k++) {
+            const uint32_t p0 = d_uniform (bounds[k]), pe = d_uniform (bounds[k + 1]);
+            if (p0 >= n) break;
             if (k && !d_wait_progress (progress, k + 1)) { if (!lane) { L.overflow = 2; *fail = 1; } break; }
-            d_chain_chunk (rlo, rhi, lane, p0, (n - p0 > chunk) ? p0 + chunk : n, triples, ck);
+            d_chain_chunk (rlo, rhi, lane, p0, pe < n ? pe : n, triples, ck);
             if (done) {                                        // this leaf's checkpoints of chunk k are final: tell the low kernels
                 gz_scalar_store_flush ();
                 __threadfence ();
                 if (!lane) {
                     atomicAdd (&done[k], 1u);
-                    if (n - p0 <= chunk) for (uint32_t k2 = k + 1; k2 < n_chunks; k2++) atomicAdd (&done[k2], 1u);   // (a short leaf has no later chunks)
+                    if (n <= pe) for (uint32_t k2 = k + 1; k2 < n_chunks; k2++) atomicAdd (&done[k2], 1u);   // (a short leaf has no later chunks)
                 }
             }
         }
     gz_scalar_store_flush ();
 }
 
-__global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress, uint32_t chunk,
+__global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress, const uint32_t *bounds,
                                                                       uint32_t *fail, uint32_t *done, uint32_t n_chunks)
 {
-    d_arith_chain (leaves, list, n_list, progress, chunk, fail, done, n_chunks);
+    d_arith_chain (leaves, list, n_list, progress, bounds, fail, done, n_chunks);
 }
 
 // One thread: holds its stream until all `want` leaves of the persistent chain have finished a position chunk (the low
