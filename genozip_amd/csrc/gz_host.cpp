@@ -580,12 +580,14 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
     if (A.chunk < GZ_CHUNK_MIN) A.chunk = GZ_CHUNK_MIN;
     A.n_chunks = P.max_arith_n ? (P.max_arith_n + A.chunk - 1) / A.chunk : 1;
     // The chain of a long leaf can only start once the sort and the models of its first position chunk are through: the lead-in of the
-    // whole step (0.9 ms of the default FASTQ step's 4.4 before the chain has its first records). So the first chunk goes in pieces of
-    // 1/8, 1/8, 1/4 and 1/2 of a chunk - the models run ahead of the chain (0.9 ms per chunk against the chain's 1.3), so they are
-    // through each piece before the chain asks for it. (GZ_ARITH_FIRST_SPLIT=0: one piece, as until round 5.)
+    // whole step (0.9 ms of the default FASTQ step's 4.4 before the chain has its first records). GZ_ARITH_FIRST_SPLIT=1 lets the first
+    // chunk go in pieces of 1/8, 1/8, 1/4 and 1/2 of a chunk. MEASURED WITHOUT EFFECT on the MI355X (round 5; ms per step without / with:
+    // default FASTQ 46.1-46.4 / 46.2, the chain's launch 42.2-42.5 / 42.4; binned FASTQ 26.9 / 28.8; streamed 169.5 / 171.6): a chunk costs
+    // ~0.2 ms of event hand-overs between the sort's and the models' streams whatever its size, so three more chunks cost what the earlier
+    // start buys, and the chain catches up with the small pieces' models at once. Off by default; the chunk bounds stay explicit.
     A.bounds.clear ();
     {
-        static const bool split = !(getenv ("GZ_ARITH_FIRST_SPLIT") && getenv ("GZ_ARITH_FIRST_SPLIT")[0] == '0');
+        static const bool split = getenv ("GZ_ARITH_FIRST_SPLIT") && getenv ("GZ_ARITH_FIRST_SPLIT")[0] == '1';
         const uint32_t tiles = A.chunk / GZ_CTX_TILE;
         A.bounds.push_back (0);
         if (split && A.n_chunks > 1 && tiles >= 8) {
