@@ -403,10 +403,10 @@ def gpu_over_cpu(out, cb):
 
 def pmc_traffic(kernel, a):
     """HBM bytes per STEP of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/round4_pmc.json, made by tools/summarize_prof.py: counter collection serialises kernels, so it cannot happen inside a timed
+    (profiles/round5_pmc.json, made by tools/summarize_prof.py: counter collection serialises kernels, so it cannot happen inside a timed
     run); null when there is no such file for this workload"""
-    p = os.path.join(ROOT, "profiles", "round4_pmc.json")
-    if not os.path.exists(p):
+    p = next((q for q in (os.path.join(ROOT, "profiles", "round%d_pmc.json" % r) for r in (5, 4)) if os.path.exists(q)), None)
+    if p is None:
         return None
     d = json.load(open(p))
     if d.get("workload") != {"pairs": a.pairs, "vb_bytes": vb_bytes(a), "qual": a.qual}:
