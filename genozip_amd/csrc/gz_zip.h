@@ -622,6 +622,17 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         seq_off = item_off + (size_t)f->plan.seq_item * R; seq_len = item_len + (size_t)f->plan.seq_item * R;
         qual_off = item_off + (size_t)f->plan.qual_item * R; qual_len = item_len + (size_t)f->plan.qual_item * R;
     }
+    // (FASTQ: line 1 of every read, gathered - see where the tokenizer is queued. Items are (offset, length) into `itext`; the SNIP_LOOKUP
+    //  byte integer items point at is parked behind it, at ilookup)
+    uint8_t *names = NULL; uint32_t *names_off = NULL, *names_len = NULL;
+    const uint8_t *itext = text; uint32_t ilookup = lookup_off;
+    if (RL == 4 && R && !getenv ("GZ_ZIP_NO_NAMES")) {
+        const uint32_t names_cap = (uint32_t)text_len;          // (line 1 of every read: less than the text)
+        if (!(names = (uint8_t *)ws_alloc (f, (size_t)names_cap + 64)) || !(names_off = (uint32_t *)ws_alloc (f, ((size_t)R + 8) * 4)) ||
+            !(names_len = (uint32_t *)ws_alloc (f, ((size_t)R + 8) * 4))) return GZ_ERR_HIP;
+        HIPCHK (h, hipMemcpyAsync (names + names_cap, lookup_byte, 16, hipMemcpyHostToDevice, h->stream));
+        itext = names; ilookup = names_cap;
+    }
     // VCF: the FORMAT subfields of every sample of every line as columns of lines x samples entries (vcf_seg_samples' split)
     const uint32_t NS = f->plan.n_samples, NSUB = f->plan.n_subfields;
     uint32_t *s_off = NULL, *s_len = NULL;
@@ -759,7 +770,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
             const uint32_t *coff = io, *clen = il;
             if (X.kind == GZ_FQ_ITEM_INT || X.kind == GZ_FQ_ITEM_DELTA) {
                 GzIntColJob j; memset (&j, 0, sizeof (j));
-                j.text = text; j.off = io; j.len = il; j.n = nn; j.nothing_char = X.nothing_char; j.lookup_off = lookup_off; j.mode = X.kind == GZ_FQ_ITEM_DELTA;
+                j.text = ps ? text : itext; j.off = io; j.len = il; j.n = nn; j.nothing_char = X.nothing_char; j.lookup_off = ps ? lookup_off : ilookup; j.mode = X.kind == GZ_FQ_ITEM_DELTA;
                 int64_t *vals = (int64_t *)ws_alloc (f, ((size_t)nn + 1) * 8); uint8_t *isn = (uint8_t *)ws_alloc (f, (size_t)nn + 16);
                 if (!vals || !isn) return GZ_ERR_HIP;
                 j.values = vals; j.is_nothing = isn;
@@ -780,14 +791,14 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
             }
             if (X.kind == GZ_FQ_ITEM_TEXT || X.kind == GZ_FQ_ITEM_INT || X.kind == GZ_FQ_SEQ_SNIP || (X.kind == GZ_FQ_QUAL && qual_col)) {
                 GzColumnJob j; memset (&j, 0, sizeof (j));
-                j.text = text; j.off = coff; j.len = clen; j.n = nn;
+                j.text = ps ? text : itext; j.off = coff; j.len = clen; j.n = nn;
                 if (X.kind == GZ_FQ_SEQ_SNIP) { j.text = sq_slots; j.off = sq_off + rr; j.len = sq_len + rr; }   // (generated text: 16-byte slots)
                 if (X.kind == GZ_FQ_QUAL) { j.text = q_slots; j.off = q_off + rr; j.len = q_len + rr; }           // (generated text: 4-byte slots)
                 uint64_t lead_bytes = 0;
                 if (X.kind == GZ_FQ_ITEM_TEXT && X.snip_len) {
                     // every snip is `snip` + the item (sam_seg_CIGAR, src/sam_cigar.c:717-720): the column is gathered into a text of its own
                     GzBlobJob pj; memset (&pj, 0, sizeof (pj));
-                    pj.text = text; pj.off = coff; pj.len = clen; pj.n = nn; pj.pre_len = X.snip_len; memcpy (pj.pre, X.snip, X.snip_len);
+                    pj.text = ps ? text : itext; pj.off = coff; pj.len = clen; pj.n = nn; pj.pre_len = X.snip_len; memcpy (pj.pre, X.snip, X.snip_len);
                     lead_bytes = (uint64_t)nn * X.snip_len;
                     pj.out = (uint8_t *)ws_alloc (f, vbs[v].text_len + lead_bytes + 64);
                     pj.item_off = (uint32_t *)ws_alloc (f, ((size_t)nn + 1) * 4); pj.item_len = (uint32_t *)ws_alloc (f, ((size_t)nn + 1) * 4);
@@ -928,7 +939,21 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     // (not decided yet whether QUAL goes through DOMQ: both forms are tried, the read-back says which one counts)
     if (want_trial && qmode0) ZCHK (add_trials (K.domq[0].out[0], (const uint32_t *)&d_domqres[0].qual_len, 1));
     // (the items of line 1 and the VBlock statistics are only needed from here on: queued behind the QUAL gather, which the long pole waits for)
-    if (!tokenized) ZCHK (gz_tokenize_column_n (h, text, l1_off, l1_len, R, f->plan.seps, f->plan.sep_counts, f->plan.n_seps, item_off, item_len, &d_a->n_bad_items));
+    if (!tokenized) {
+        // FASTQ: line 1 of every read is gathered into a text of its own first (`names`, allocated above: one coalesced pass over a third of the
+        // text's cache lines), and the tokenizer and every item kernel behind it - each a pass of its own with a thread per 2 - 8 byte snip -
+        // read THAT: 63 bytes per read side by side instead of a 128-byte line of the original text per snip and pass, 368 bytes apart
+        // (profiles/round4_pmc.json: 9.4 GB of the step's 50 were k_tokenize_n / k_icol_* / k_col_insert fetching such lines)
+        if (names) {
+            GzBlobJob nj; memset (&nj, 0, sizeof (nj));
+            nj.text = text; nj.off = l1_off; nj.len = l1_len; nj.n = R; nj.out = names; nj.item_off = names_off; nj.item_len = names_len;
+            WS (d_names_len, uint64_t, 2);
+            nj.out_len_dev = d_names_len;
+            ZCHK (gz_local_blob_columns (h, &nj, 1));
+            ZCHK (gz_tokenize_column_n (h, names, names_off, l1_len, R, f->plan.seps, f->plan.sep_counts, f->plan.n_seps, item_off, item_len, &d_a->n_bad_items));
+        }
+        else ZCHK (gz_tokenize_column_n (h, text, l1_off, l1_len, R, f->plan.seps, f->plan.sep_counts, f->plan.n_seps, item_off, item_len, &d_a->n_bad_items));
+    }
     hipLaunchKernelGGL (k_vb_stats, dim3 (NV), dim3 (256), 2048, h->stream, (const uint32_t *)line_off, (const uint32_t *)seq_len, (const uint32_t *)d_first_line,
                         (const uint64_t *)(d_vb_off + NV), NV, RL, d_vbstat);
     ZCHK (gz_int_columns (h, icol_jobs.data (), (int)icol_jobs.size ()));
@@ -937,7 +962,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         const GzFastqCtx &X = f->ctxs[c];
         if (X.kind != GZ_FQ_ITEM_EXPECT) continue;
         GzdExpect E; memset (&E, 0, sizeof (E));
-        E.text = text; E.off = item_off + (size_t)X.item * R; E.len = item_len + (size_t)X.item * R; E.n = R; E.want_len = X.snip_len; memcpy (E.want, X.snip, X.snip_len);
+        E.text = itext; E.off = item_off + (size_t)X.item * R; E.len = item_len + (size_t)X.item * R; E.n = R; E.want_len = X.snip_len; memcpy (E.want, X.snip, X.snip_len);
         E.n_bad = &d_a->n_unexpected;
         KLAUNCH (h, k_item_expect, dim3 ((R + 255) / 256), dim3 (256), 0, E);
     }
