@@ -938,78 +938,90 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
     HIPCHK (h, hipEventRecord (f->ev_early, h->stream));
     // (not decided yet whether QUAL goes through DOMQ: both forms are tried, the read-back says which one counts)
     if (want_trial && qmode0) ZCHK (add_trials (K.domq[0].out[0], (const uint32_t *)&d_domqres[0].qual_len, 1));
-    // (the items of line 1 and the VBlock statistics are only needed from here on: queued behind the QUAL gather, which the long pole waits for)
-    if (!tokenized) {
-        // FASTQ: line 1 of every read is gathered into a text of its own first (`names`, allocated above: one coalesced pass over a third of the
-        // text's cache lines), and the tokenizer and every item kernel behind it - each a pass of its own with a thread per 2 - 8 byte snip -
-        // read THAT: 63 bytes per read side by side instead of a 128-byte line of the original text per snip and pass, 368 bytes apart
-        // (profiles/round4_pmc.json: 9.4 GB of the step's 50 were k_tokenize_n / k_icol_* / k_col_insert fetching such lines)
-        if (names) {
-            GzBlobJob nj; memset (&nj, 0, sizeof (nj));
-            nj.text = text; nj.off = l1_off; nj.len = l1_len; nj.n = R; nj.out = names; nj.item_off = names_off; nj.item_len = names_len;
-            WS (d_names_len, uint64_t, 2);
-            nj.out_len_dev = d_names_len;
-            ZCHK (gz_local_blob_columns (h, &nj, 1));
-            ZCHK (gz_tokenize_column_n (h, names, names_off, l1_len, R, f->plan.seps, f->plan.sep_counts, f->plan.n_seps, item_off, item_len, &d_a->n_bad_items));
-        }
-        else ZCHK (gz_tokenize_column_n (h, text, l1_off, l1_len, R, f->plan.seps, f->plan.sep_counts, f->plan.n_seps, item_off, item_len, &d_a->n_bad_items));
-    }
-    hipLaunchKernelGGL (k_vb_stats, dim3 (NV), dim3 (256), 2048, h->stream, (const uint32_t *)line_off, (const uint32_t *)seq_len, (const uint32_t *)d_first_line,
-                        (const uint64_t *)(d_vb_off + NV), NV, RL, d_vbstat);
-    ZCHK (gz_int_columns (h, icol_jobs.data (), (int)icol_jobs.size ()));
-    // (column tables hold at most 65 535 rows per call)
-    for (uint32_t c = 0; c < NC && R; c++) {                                     // text the plan's containers carry as prefixes must be there, in every record
-        const GzFastqCtx &X = f->ctxs[c];
-        if (X.kind != GZ_FQ_ITEM_EXPECT) continue;
-        GzdExpect E; memset (&E, 0, sizeof (E));
-        E.text = itext; E.off = item_off + (size_t)X.item * R; E.len = item_len + (size_t)X.item * R; E.n = R; E.want_len = X.snip_len; memcpy (E.want, X.snip, X.snip_len);
-        E.n_bad = &d_a->n_unexpected;
-        KLAUNCH (h, k_item_expect, dim3 ((R + 255) / 256), dim3 (256), 0, E);
-    }
-    for (size_t at = 0; at < pre_jobs.size (); at += 32768) ZCHK (gz_local_blob_columns (h, pre_jobs.data () + at, (int)std::min<size_t> (32768, pre_jobs.size () - at)));
-    for (size_t at = 0; at < col_jobs.size (); at += 32768) ZCHK (gz_ctx_seg_columns (h, col_jobs.data () + at, (int)std::min<size_t> (32768, col_jobs.size () - at)));
-    for (size_t at = 0; at < dyn_jobs.size (); at += 32768) ZCHK (gz_dyn_int_columns (h, dyn_jobs.data () + at, (int)std::min<size_t> (32768, dyn_jobs.size () - at)));
-    ZCHK (gz_acgt_pack_batch (h, acgt_jobs.data (), (int)acgt_jobs.size ()));
-
-    // what the merge needs from every column, packed into one stretch
+    // The columns' kernels (line 1 -> items -> contexts) fill the device for ~2.5 ms of a 1 M-pair file. Queued HERE - behind the gathers, in front of
+    // the launch of the long streams - they are what the persistent chain's workgroups (a whole compute unit each) wait for before they can start at
+    // all: measured, the chain kernel started executing ~3.3 ms into the default step although it was launched at ~1.6. With few VBlocks, whose step is
+    // the latency of the long chains, they are therefore queued AFTER the long streams' launch (defer_columns): the main path that needs them has 20 ms
+    // of slack there. With many VBlocks (the streamed form) the device's time is what counts and they go first, as they always did.
     const size_t NCJ = col_jobs.size ();
     std::vector<GzdPackJob> pack (NCJ);
-    uint64_t pack_cap = 64;
-    for (size_t k = 0; k < NCJ; k++) {
-        const GzColumnJob &j = col_jobs[k];
-        pack[k].dict = j.dict; pack[k].nci = j.node_char_index; pack[k].nsl = j.node_snip_len; pack[k].counts = j.counts; pack[k].n_ol = j.n_ol; pack[k].res = j.result_dev;
-        pack_cap += j.dict_cap + 16ull * j.n + 4ull * j.n_ol + 64;
-    }
-    // (worst case = every snip a new word; the usual case is a few hundred bytes per column)
-    const uint64_t pack_cap_used = std::min<uint64_t> (pack_cap, (uint64_t)256 << 20);
-    WS (d_pack, GzdPackJob, NCJ + 1);
-    WS (d_pack_total, uint64_t, 2);
-    uint8_t *d_staging = (uint8_t *)ws_alloc (f, pack_cap_used);
-    if (!d_staging) return GZ_ERR_HIP;
-    if (NCJ) {
-        HIPCHK (h, hipMemcpyAsync (d_pack, pack.data (), NCJ * sizeof (GzdPackJob), hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL (k_pack_sizes, dim3 (1), dim3 (256), 257 * 8, h->stream, d_pack, (uint32_t)NCJ, pack_cap_used, d_pack_total);
-        hipLaunchKernelGGL (k_pack_copy, dim3 ((uint32_t)NCJ), dim3 (256), 0, h->stream, (const GzdPackJob *)d_pack, d_staging, (const uint64_t *)d_pack_total);
-    }
-    T.mark ("queue");
-    K.blobres.resize (blob_jobs.size () + 1);
-    // ---- read back (second wait): queued behind the seg kernels now, into page-locked memory - a copy into pageable memory would
-    // hold the host until the stream gets there, and the host has the long streams to launch in the meantime
-    K.colres.resize (NCJ + 1); K.dynres.resize (dyn_jobs.size () + 1);
-    std::vector<uint64_t> icolres (2 * icol_jobs.size () + 2);
-    K.acgtres.resize (2 * acgt_jobs.size () + 2); K.vbstat.resize (2 * (size_t)NV + 2);
+    uint8_t *d_staging = NULL;
+    std::vector<uint64_t> icolres;
     uint64_t pack_total[2] = { 0, 1 };
     uint8_t *rb = eb;                                      // (one page-locked stretch for both read-backs)
-    if (NCJ) {
-        HIPCHK (h, hipMemcpyAsync (rb + rb_col, d_colres, NCJ * sizeof (GzColumnResult), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK (h, hipMemcpyAsync (rb + rb_pack, d_pack, NCJ * sizeof (GzdPackJob), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK (h, hipMemcpyAsync (rb + rb_tot, d_pack_total, 16, hipMemcpyDeviceToHost, h->stream));
-    }
-    if (!dyn_jobs.empty ())  HIPCHK (h, hipMemcpyAsync (rb + rb_dyn, d_dynres, dyn_jobs.size () * sizeof (GzDynIntResult), hipMemcpyDeviceToHost, h->stream));
-    if (!icol_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (rb + rb_icol, d_icolres, icol_jobs.size () * 16, hipMemcpyDeviceToHost, h->stream));
-    if (!acgt_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (rb + rb_acgt, d_acgtres, acgt_jobs.size () * 16, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK (h, hipMemcpyAsync (rb + rb_stat, d_vbstat, 2 * (size_t)NV * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK (h, hipMemcpyAsync (rb + rb_a, d_a, sizeof (a), hipMemcpyDeviceToHost, h->stream));
+    K.blobres.resize (blob_jobs.size () + 1);
+    auto queue_columns = [&] () -> int {
+        // (the items of line 1 and the VBlock statistics are only needed from here on: queued behind the QUAL gather, which the long pole waits for)
+        if (!tokenized) {
+            // FASTQ: line 1 of every read is gathered into a text of its own first (`names`, allocated above: one coalesced pass over a third of the
+            // text's cache lines), and the tokenizer and every item kernel behind it - each a pass of its own with a thread per 2 - 8 byte snip -
+            // read THAT: 63 bytes per read side by side instead of a 128-byte line of the original text per snip and pass, 368 bytes apart
+            // (profiles/round4_pmc.json: 9.4 GB of the step's 50 were k_tokenize_n / k_icol_* / k_col_insert fetching such lines)
+            if (names) {
+                GzBlobJob nj; memset (&nj, 0, sizeof (nj));
+                nj.text = text; nj.off = l1_off; nj.len = l1_len; nj.n = R; nj.out = names; nj.item_off = names_off; nj.item_len = names_len;
+                WS (d_names_len, uint64_t, 2);
+                nj.out_len_dev = d_names_len;
+                ZCHK (gz_local_blob_columns (h, &nj, 1));
+                ZCHK (gz_tokenize_column_n (h, names, names_off, l1_len, R, f->plan.seps, f->plan.sep_counts, f->plan.n_seps, item_off, item_len, &d_a->n_bad_items));
+            }
+            else ZCHK (gz_tokenize_column_n (h, text, l1_off, l1_len, R, f->plan.seps, f->plan.sep_counts, f->plan.n_seps, item_off, item_len, &d_a->n_bad_items));
+        }
+        hipLaunchKernelGGL (k_vb_stats, dim3 (NV), dim3 (256), 2048, h->stream, (const uint32_t *)line_off, (const uint32_t *)seq_len, (const uint32_t *)d_first_line,
+                            (const uint64_t *)(d_vb_off + NV), NV, RL, d_vbstat);
+        ZCHK (gz_int_columns (h, icol_jobs.data (), (int)icol_jobs.size ()));
+        // (column tables hold at most 65 535 rows per call)
+        for (uint32_t c = 0; c < NC && R; c++) {                                     // text the plan's containers carry as prefixes must be there, in every record
+            const GzFastqCtx &X = f->ctxs[c];
+            if (X.kind != GZ_FQ_ITEM_EXPECT) continue;
+            GzdExpect E; memset (&E, 0, sizeof (E));
+            E.text = itext; E.off = item_off + (size_t)X.item * R; E.len = item_len + (size_t)X.item * R; E.n = R; E.want_len = X.snip_len; memcpy (E.want, X.snip, X.snip_len);
+            E.n_bad = &d_a->n_unexpected;
+            KLAUNCH (h, k_item_expect, dim3 ((R + 255) / 256), dim3 (256), 0, E);
+        }
+        for (size_t at = 0; at < pre_jobs.size (); at += 32768) ZCHK (gz_local_blob_columns (h, pre_jobs.data () + at, (int)std::min<size_t> (32768, pre_jobs.size () - at)));
+        for (size_t at = 0; at < col_jobs.size (); at += 32768) ZCHK (gz_ctx_seg_columns (h, col_jobs.data () + at, (int)std::min<size_t> (32768, col_jobs.size () - at)));
+        for (size_t at = 0; at < dyn_jobs.size (); at += 32768) ZCHK (gz_dyn_int_columns (h, dyn_jobs.data () + at, (int)std::min<size_t> (32768, dyn_jobs.size () - at)));
+        ZCHK (gz_acgt_pack_batch (h, acgt_jobs.data (), (int)acgt_jobs.size ()));
+
+        // what the merge needs from every column, packed into one stretch
+        uint64_t pack_cap = 64;
+        for (size_t k = 0; k < NCJ; k++) {
+            const GzColumnJob &j = col_jobs[k];
+            pack[k].dict = j.dict; pack[k].nci = j.node_char_index; pack[k].nsl = j.node_snip_len; pack[k].counts = j.counts; pack[k].n_ol = j.n_ol; pack[k].res = j.result_dev;
+            pack_cap += j.dict_cap + 16ull * j.n + 4ull * j.n_ol + 64;
+        }
+        // (worst case = every snip a new word; the usual case is a few hundred bytes per column)
+        const uint64_t pack_cap_used = std::min<uint64_t> (pack_cap, (uint64_t)256 << 20);
+        WS (d_pack, GzdPackJob, NCJ + 1);
+        WS (d_pack_total, uint64_t, 2);
+        if (!(d_staging = (uint8_t *)ws_alloc (f, pack_cap_used))) return GZ_ERR_HIP;
+        if (NCJ) {
+            HIPCHK (h, hipMemcpyAsync (d_pack, pack.data (), NCJ * sizeof (GzdPackJob), hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL (k_pack_sizes, dim3 (1), dim3 (256), 257 * 8, h->stream, d_pack, (uint32_t)NCJ, pack_cap_used, d_pack_total);
+            hipLaunchKernelGGL (k_pack_copy, dim3 ((uint32_t)NCJ), dim3 (256), 0, h->stream, (const GzdPackJob *)d_pack, d_staging, (const uint64_t *)d_pack_total);
+        }
+        // ---- read back (second wait): queued behind the seg kernels now, into page-locked memory - a copy into pageable memory would
+        // hold the host until the stream gets there, and the host has the long streams to launch in the meantime
+        K.colres.resize (NCJ + 1); K.dynres.resize (dyn_jobs.size () + 1);
+        icolres.assign (2 * icol_jobs.size () + 2, 0);
+        K.acgtres.resize (2 * acgt_jobs.size () + 2); K.vbstat.resize (2 * (size_t)NV + 2);
+        if (NCJ) {
+            HIPCHK (h, hipMemcpyAsync (rb + rb_col, d_colres, NCJ * sizeof (GzColumnResult), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK (h, hipMemcpyAsync (rb + rb_pack, d_pack, NCJ * sizeof (GzdPackJob), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK (h, hipMemcpyAsync (rb + rb_tot, d_pack_total, 16, hipMemcpyDeviceToHost, h->stream));
+        }
+        if (!dyn_jobs.empty ())  HIPCHK (h, hipMemcpyAsync (rb + rb_dyn, d_dynres, dyn_jobs.size () * sizeof (GzDynIntResult), hipMemcpyDeviceToHost, h->stream));
+        if (!icol_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (rb + rb_icol, d_icolres, icol_jobs.size () * 16, hipMemcpyDeviceToHost, h->stream));
+        if (!acgt_jobs.empty ()) HIPCHK (h, hipMemcpyAsync (rb + rb_acgt, d_acgtres, acgt_jobs.size () * 16, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK (h, hipMemcpyAsync (rb + rb_stat, d_vbstat, 2 * (size_t)NV * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK (h, hipMemcpyAsync (rb + rb_a, d_a, sizeof (a), hipMemcpyDeviceToHost, h->stream));
+        return GZ_OK;
+    };
+    const char *defer_env = getenv ("GZ_ZIP_DEFER");                      // "always": whatever the sizes (tests); "never"
+    const bool defer_columns = f->h2 && !(defer_env && !strcmp (defer_env, "never")) && ((defer_env && !strcmp (defer_env, "always")) || (NV <= 64 && longest_text >= 10000000));
+    if (!defer_columns) ZCHK (queue_columns ());
+    T.mark ("queue");
     // ---- as soon as the gathered QUAL (and what CODEC_DOMQ makes of it) is there - the columns are still being evaluated:
     HIPCHK (h, hipEventSynchronize (f->ev_early));
     T.mark ("early-wait");
@@ -1111,6 +1123,7 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
         }
     }
     T.mark ("early");
+    if (defer_columns) { ZCHK (queue_columns ()); T.mark ("queue-columns"); }
     rc = gz_sync (h);
     // (the results of the seg kernels were copied to page-locked memory behind them, see above: into their places)
     if (NCJ) { memcpy (K.colres.data (), rb + rb_col, NCJ * sizeof (GzColumnResult)); memcpy (pack.data (), rb + rb_pack, NCJ * sizeof (GzdPackJob)); memcpy (pack_total, rb + rb_tot, 16); }

@@ -136,14 +136,15 @@ def fuzz_driver(seed, seconds):
         domq, sf = rnd.choice([0, 0, 0, 1, 13]), rnd.random() < 0.4
         if rnd.random() < 0.5: os.environ["GZ_ZIP_SPECULATION"] = "always"
         else: os.environ.pop("GZ_ZIP_SPECULATION", None)
-        try:
         mono = tuple(rnd.choice([0, 0, 2, 3, 7, -1]) for _ in range(2))
+        if rnd.random() < 0.3: os.environ["GZ_ZIP_PREDICTION"] = "prior"
+        else: os.environ.pop("GZ_ZIP_PREDICTION", None)
         try:
             parity.fastq_zip(E, O, nr, n_calls=rnd.choice([1, 2]), qual=q, domq=domq, small_first=sf, mono=mono)
         except Exception as e:                      # noqa: BLE001
             bad += 1; print("FAIL", nr, q, domq, sf, mono, os.environ.get("GZ_ZIP_SPECULATION"), repr(e)[:300])
         runs += 1
-    os.environ.pop("GZ_ZIP_SPECULATION", None)
+    os.environ.pop("GZ_ZIP_SPECULATION", None); os.environ.pop("GZ_ZIP_PREDICTION", None)
     print("runs", runs, "bad", bad)
 
 

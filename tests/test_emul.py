@@ -144,6 +144,17 @@ def test_emul_fastq_zip_early_path(emul_engine, oracle, monkeypatch):
     assert parity.sam_zip(emul_engine, oracle, 300, n_calls=1) == 2
 
 
+def test_emul_fastq_zip_deferred_columns(emul_engine, oracle, monkeypatch):
+    """the columns' kernels queued behind the launch of the long streams (what the driver does for few, large VBlocks - the persistent chain's
+    workgroups then find free compute units at once), forced for files of test size, with the long streams coded ahead: the same bytes"""
+    monkeypatch.setenv("GZ_ZIP_DEFER", "always")
+    monkeypatch.setenv("GZ_ZIP_EARLY_MIN", "0")
+    parity.fastq_zip(emul_engine, oracle, 72, qual=("uniform", "bin"), mono=(0, 5))
+    monkeypatch.delenv("GZ_ZIP_EARLY_MIN")
+    parity.fastq_zip(emul_engine, oracle, 54, small_first=True)
+    assert parity.sam_zip(emul_engine, oracle, 200, n_calls=1) == 2
+
+
 def test_emul_fastq_zip_speculation(emul_engine, oracle):
     parity.fastq_zip_speculation(emul_engine, oracle, 42)
 

@@ -163,6 +163,17 @@ def test_e2e_files_sha256(gpu_engine):
 
 
 @pytest.mark.gpu
+def test_fastq_zip_deferred_columns(gpu_engine, oracle, monkeypatch):
+    """the columns' kernels queued behind the launch of the long streams (the driver's way for few, large VBlocks), forced for files of test size"""
+    monkeypatch.setenv("GZ_ZIP_DEFER", "always")
+    monkeypatch.setenv("GZ_ZIP_EARLY_MIN", "0")
+    parity.fastq_zip(gpu_engine, oracle, 3000, qual=("uniform", "bin"), mono=(0, 5))
+    monkeypatch.delenv("GZ_ZIP_EARLY_MIN")
+    parity.fastq_zip(gpu_engine, oracle, 1500, small_first=True)
+    assert parity.sam_zip(gpu_engine, oracle, 3000, n_calls=1) == 2
+
+
+@pytest.mark.gpu
 def test_fastq_zip_prediction(gpu_engine, oracle):
     """streams coded ahead of their contexts' trial compressions with a predicted codec (the built-in prior; what the handle remembers): the
     oracle's bytes whether the prediction was right or wrong"""
