@@ -53,6 +53,7 @@ struct GzdStream {
     uint32_t raw_len;         // precompressed section: data_uncompressed_len of the header
     uint8_t  pre;             // precompressed section: `in` already is the payload of codec hdr[25] (hdr[26] when hdr_codec)
     uint8_t  hdr_codec;       // a complex codec (DOMQ) names the section: the coder of the stream goes to sub_codec
+    uint32_t emit_a, emit_w, emit_done;   // k_emit over several workgroups: the slices' adler32 sums (mod 65521) and how many are through
 };
 
 struct GzdLeaf {

@@ -85,6 +85,41 @@ typedef uint32_t gz_u32x4_unaligned __attribute__((vector_size (16), aligned (1)
 
 // adler32 = (b << 16 | a) with a = 1 + sum d_i, b = len + sum (len - i) d_i, both mod 65521: a weighted sum, so any
 // thread can take any bytes. Thread t takes bytes [4096 k + 16 t, + 16) for k = 0, 1, ... (coalesced 16-byte loads).
+// the same sums over bytes [lo, hi) of a buffer of len bytes only (lo a multiple of 16), without the constant terms: *a_out = sum d_i,
+// *w_out = sum (len - i) d_i, both mod 65521, valid in every thread - several workgroups take a section's bytes between them (k_emit)
+__device__ static inline void gz_adler32_part (const uint8_t *data, uint32_t len, uint32_t lo, uint32_t hi, int tid, uint32_t *a_out, uint32_t *w_out)
+{
+    uint32_t *sA = (uint32_t *)gz_lds, *sB = sA + 256, *res = sA + 512;
+    uint64_t A = 0, W = 0;
+    const uint32_t body = lo + ((hi - lo) & ~15u);
+    uint32_t rounds = 0;
+    const uint32_t step = 256 * 16;
+    for (uint32_t i = lo + (uint32_t)tid * 16; i < body; i += step) {
+        const gz_u32x4_unaligned v = *(const gz_u32x4_unaligned *)(data + i);
+        uint32_t S = 0, T = 0;
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t w = v[k], b0 = w & 0xff, b1 = (w >> 8) & 0xff, b2 = (w >> 16) & 0xff, b3 = w >> 24;
+            S += b0 + b1 + b2 + b3;
+            T += (4 * k) * b0 + (4 * k + 1) * b1 + (4 * k + 2) * b2 + (4 * k + 3) * b3;
+        }
+        A += S; W += (uint64_t)(len - i) * S - T;
+        if (++rounds == 65536) { W %= 65521u; rounds = 0; }
+    }
+    for (uint32_t i = body + tid; i < hi; i += 256) { const uint32_t d = data[i]; A += d; W += (uint64_t)(len - i) * d; }
+    __syncthreads ();
+    sA[tid] = (uint32_t)(A % 65521u);
+    sB[tid] = (uint32_t)(W % 65521u);
+    __syncthreads ();
+    if (!tid) {
+        uint64_t a = 0, b = 0;
+        for (int t = 0; t < 256; t++) { a += sA[t]; b += sB[t]; }
+        res[0] = (uint32_t)(a % 65521u); res[1] = (uint32_t)(b % 65521u);
+    }
+    __syncthreads ();
+    *a_out = res[0]; *w_out = res[1];
+}
+
 __device__ static inline uint32_t gz_adler32_wg (const uint8_t *data, uint32_t len, int tid)
 {
     uint32_t *sA = (uint32_t *)gz_lds, *sB = sA + 256, *res = sA + 512;

@@ -810,7 +810,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
     }
     KLAUNCH (h, k_select, dim3 ((ns + 255) / 256), dim3 (256), 0, d_streams, d_leaves, ns);
     if (n_vbs) KLAUNCH (h, k_vb_layout, dim3 ((n_vbs + 63) / 64), dim3 (64), 0, d_vbs, d_streams, n_vbs);
-    KLAUNCH (h, k_emit, dim3 (ns), dim3 (256), 4096, d_streams, d_leaves, d_vbs);
+    KLAUNCH (h, k_emit, dim3 (ns, n_vbs ? GZ_EMIT_SLICES : 1), dim3 (256), 4096, d_streams, d_leaves, d_vbs);
     HIPCHK (h, hipGetLastError ());
     return GZ_OK;
 }

@@ -958,33 +958,51 @@ __device__ static inline void d_copy (uint8_t *dst, const uint8_t *src, uint32_t
     for (uint32_t j = body + tid; j < n; j += 256) dst[j] = src[j];
 }
 
-__device__ static void d_emit_unit (uint8_t *dst, const GzdLeaf &L, int tid)
+// bytes [lo, hi) of the payload only (a long section's bytes go out by several workgroups): piece = n bytes of src that belong at dst + at
+__device__ static inline void d_copy_part (uint8_t *dst, uint32_t at, const uint8_t *src, uint32_t n, uint32_t lo, uint32_t hi, int tid)
 {
-    d_copy (dst, L.prefix, L.prefix_len, tid);
-    dst += L.prefix_len;
-    if (L.cat) { d_copy (dst, L.coded, L.coded_n, tid); return; }
-    d_copy (dst, L.tab, L.tab_len, tid);
-    const uint8_t *pay = L.engine == GZ_ENG_RANS ? L.pay + L.pay_cap - L.pay_len : L.pay;
-    d_copy (dst + L.tab_len, pay, L.pay_len, tid);
+    const uint32_t a = at > lo ? at : lo, b = at + n < hi ? at + n : hi;
+    if (a < b) d_copy (dst + a, src + (a - at), b - a, tid);
 }
 
+__device__ static void d_emit_unit (uint8_t *dst, uint32_t at, const GzdLeaf &L, uint32_t lo, uint32_t hi, int tid)
+{
+    d_copy_part (dst, at, L.prefix, L.prefix_len, lo, hi, tid);
+    at += L.prefix_len;
+    if (L.cat) { d_copy_part (dst, at, L.coded, L.coded_n, lo, hi, tid); return; }
+    d_copy_part (dst, at, L.tab, L.tab_len, lo, hi, tid);
+    const uint8_t *pay = L.engine == GZ_ENG_RANS ? L.pay + L.pay_cap - L.pay_len : L.pay;
+    d_copy_part (dst, at + L.tab_len, pay, L.pay_len, lo, hi, tid);
+}
+
+// grid (streams, GZ_EMIT_SLICES). A section of GZ_EMIT_LONG bytes or more (the 3 MB QUAL sections at the very end of a step: one workgroup
+// took 0.5 ms over each) is written by all GZ_EMIT_SLICES workgroups of its column, a stretch of the payload each: the adler32 sums of the
+// stretches add up (gz_adler32_part), the last one through writes the header. Everything else is slice 0's alone.
+#define GZ_EMIT_SLICES 8
+#define GZ_EMIT_LONG   (256u * 1024u)
 __global__ void __launch_bounds__(256) k_emit (GzdStream *streams, GzdLeaf *leaves, GzdVB *vbs)
 {
     GzdStream &S = streams[blockIdx.x];
     const int tid = threadIdx.x;
     if (S.status != GZ_ST_PENDING) return;
+    const uint32_t slices = (S.vb >= 0 && S.out_len >= GZ_EMIT_LONG) ? GZ_EMIT_SLICES : 1, slice = blockIdx.y;
+    if (slice >= slices) return;
 
     uint8_t *dst = S.out;
     if (S.vb >= 0) {
         GzdVB &V = vbs[S.vb];
-        if (V.status != GZ_ST_OK) { if (!tid) S.status = GZ_ST_TOO_SMALL; return; }
+        if (V.status != GZ_ST_OK) { if (!tid && !slice) S.status = GZ_ST_TOO_SMALL; return; }
         if (!S.n && S.in_len_dev) { if (!tid) S.status = GZ_ST_OK; return; }     // dropped: k_vb_layout left no room for it
         dst = V.z_data + S.z_off + 40;
     }
     else if (S.out_len > S.out_cap) { if (!tid) S.status = GZ_ST_TOO_SMALL; return; }
 
-    if (S.engine == GZ_ENG_NONE) d_copy (dst, S.in, S.n, tid);
-    else if (!S.striped) d_emit_unit (dst, leaves[S.first_leaf + S.whole_leaf], tid);
+    // this workgroup's stretch of the payload (whole 16-byte groups; the last slice takes the rest)
+    const uint32_t per = slices > 1 ? ((S.out_len / slices + 15) & ~15u) : 0xffffffffu;
+    const uint32_t lo = slices > 1 ? slice * per : 0, hi = slices > 1 ? (slice + 1 == slices ? S.out_len : (lo + per < S.out_len ? lo + per : S.out_len)) : 0xffffffffu;
+
+    if (S.engine == GZ_ENG_NONE) d_copy_part (dst, 0, S.in, S.n, lo, hi, tid);
+    else if (!S.striped) d_emit_unit (dst, 0, leaves[S.first_leaf + S.whole_leaf], lo, hi, tid);
     else {
         // [order & ~NOSZ][varint n][4][varint unit length x4][unit x4]   (rANS_static4x16pr.c:1194-1225)
         uint8_t meta[32]; uint32_t p = 0;
@@ -992,21 +1010,37 @@ __global__ void __launch_bounds__(256) k_emit (GzdStream *streams, GzdLeaf *leav
         p += gz_vi_put (meta + p, S.n);
         meta[p++] = 4;
         for (int k = 0; k < 4; k++) p += gz_vi_put (meta + p, S.plane_unit_len[k]);
-        if (tid < (int)p) dst[tid] = meta[tid];
+        if (tid < (int)p && (uint32_t)tid >= lo && (uint32_t)tid < hi) dst[tid] = meta[tid];
         uint32_t o = p;
         for (int k = 0; k < 4; k++) {
-            d_emit_unit (dst + o, leaves[S.first_leaf + S.best_leaf[k]], tid);
+            d_emit_unit (dst, o, leaves[S.first_leaf + S.best_leaf[k]], lo, hi, tid);
             o += S.plane_unit_len[k];
         }
     }
 
-    // NB: status doubles as the entry test of this kernel: every thread must be past it before it changes
+    // NB: status doubles as the entry test of this kernel: every thread (of every slice) must be past it before it changes
     if (S.vb < 0) { __syncthreads (); if (!tid) { if (S.out_len_dev) *S.out_len_dev = S.out_len; S.status = GZ_ST_OK; } return; }
 
     // ---- section header (comp_compress, compressor.c:114-161): adler32 of the payload by the whole workgroup
     __threadfence_block ();
     __syncthreads ();
-    uint32_t adler = gz_adler32_wg (dst, S.out_len, tid);
+    uint32_t adler;
+    if (slices == 1) adler = gz_adler32_wg (dst, S.out_len, tid);
+    else {
+        uint32_t a, w;
+        gz_adler32_part (dst, S.out_len, lo, hi < S.out_len ? hi : S.out_len, tid, &a, &w);
+        uint32_t *last = (uint32_t *)gz_lds + 520;                  // (behind what gz_adler32_part uses of the LDS)
+        if (!tid) {
+            atomicAdd (&S.emit_a, a); atomicAdd (&S.emit_w, w);
+            __threadfence ();
+            *last = atomicAdd (&S.emit_done, 1u) + 1 == slices;
+        }
+        __syncthreads ();
+        if (!*last) return;
+        __threadfence ();
+        const uint32_t ta = *(volatile uint32_t *)&S.emit_a, tw = *(volatile uint32_t *)&S.emit_w;
+        adler = (((S.out_len % 65521u + tw) % 65521u) << 16) | ((1u + ta) % 65521u);
+    }
     if (!tid) {
         uint8_t *h = vbs[S.vb].z_data + S.z_off;
         for (int k = 0; k < 40; k++) h[k] = S.hdr[k];
