@@ -594,7 +594,20 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
             const uint32_t cut[3] = { (tiles + 7) / 8, (tiles + 3) / 4, (tiles + 1) / 2 };
             for (int c = 0; c < 3; c++) if (cut[c] * GZ_CTX_TILE > A.bounds.back () && cut[c] < tiles) A.bounds.push_back (cut[c] * GZ_CTX_TILE);
         }
-        for (uint32_t k = 1; k <= A.n_chunks; k++) A.bounds.push_back (k * A.chunk);
+        for (uint32_t k = 1; k < A.n_chunks; k++) A.bounds.push_back (k * A.chunk);
+        // The END of the longest leaves is the other way round: what follows the chain's last position chunk - that chunk's k_chain_expand /
+        // k_low_scan / k_low_scatter, then resid / norm / carry and the section writer - is the tail of the whole step, and the first three are
+        // proportional to the last chunk. The models are far ahead of the chain by then, so the last chunk goes in pieces of 1/2, 1/4, 1/8,
+        // 1/8 (whole sort tiles): the low kernels of all but the last piece run beside the chain. (GZ_ARITH_LAST_SPLIT=0: one piece.)
+        {
+            static const bool last_split = !(getenv ("GZ_ARITH_LAST_SPLIT") && getenv ("GZ_ARITH_LAST_SPLIT")[0] == '0');
+            const uint32_t s0 = (A.n_chunks - 1) * A.chunk, span_tiles = P.max_arith_n > s0 ? (P.max_arith_n - s0) / GZ_CTX_TILE : 0;
+            if (last_split && A.n_chunks > 1 && span_tiles >= 8) {
+                const uint32_t cut[3] = { span_tiles / 2, span_tiles / 2 + span_tiles / 4, span_tiles / 2 + span_tiles / 4 + span_tiles / 8 };
+                for (int c = 0; c < 3; c++) if (s0 + cut[c] * GZ_CTX_TILE > A.bounds.back ()) A.bounds.push_back (s0 + cut[c] * GZ_CTX_TILE);
+            }
+        }
+        A.bounds.push_back (A.n_chunks * A.chunk);
         A.n_chunks = (uint32_t)A.bounds.size () - 1;
     }
     // leaves that fit one chunk go through model and chain in one piece on a stream of their own; only the long ones
