@@ -587,20 +587,22 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
     // start buys, and the chain catches up with the small pieces' models at once. Off by default; the chunk bounds stay explicit.
     A.bounds.clear ();
     {
-        static const bool split = getenv ("GZ_ARITH_FIRST_SPLIT") && getenv ("GZ_ARITH_FIRST_SPLIT")[0] == '1';
+        // (1: eighths; 2: two halves; 4: 1/4, 1/4, 1/2 - a piece must not be coded faster than the next one's sort + models take, ~0.3 ms)
+        static const int split = getenv ("GZ_ARITH_FIRST_SPLIT") ? atoi (getenv ("GZ_ARITH_FIRST_SPLIT")) : 0;
         const uint32_t tiles = A.chunk / GZ_CTX_TILE;
         A.bounds.push_back (0);
         if (split && A.n_chunks > 1 && tiles >= 8) {
-            const uint32_t cut[3] = { (tiles + 7) / 8, (tiles + 3) / 4, (tiles + 1) / 2 };
+            const uint32_t cut[3] = { split == 1 ? (tiles + 7) / 8 : split == 4 ? (tiles + 3) / 4 : 0, split == 1 ? (tiles + 3) / 4 : 0, (tiles + 1) / 2 };
             for (int c = 0; c < 3; c++) if (cut[c] * GZ_CTX_TILE > A.bounds.back () && cut[c] < tiles) A.bounds.push_back (cut[c] * GZ_CTX_TILE);
         }
         for (uint32_t k = 1; k < A.n_chunks; k++) A.bounds.push_back (k * A.chunk);
-        // The END of the longest leaves is the other way round: what follows the chain's last position chunk - that chunk's k_chain_expand /
-        // k_low_scan / k_low_scatter, then resid / norm / carry and the section writer - is the tail of the whole step, and the first three are
-        // proportional to the last chunk. The models are far ahead of the chain by then, so the last chunk goes in pieces of 1/2, 1/4, 1/8,
-        // 1/8 (whole sort tiles): the low kernels of all but the last piece run beside the chain. (GZ_ARITH_LAST_SPLIT=0: one piece.)
+        // The END of the longest leaves, the other way round: what follows the chain's last position chunk - that chunk's k_chain_expand /
+        // k_low_scan / k_low_scatter, then resid / norm / carry and the section writer - is the tail of the step, and the first three are
+        // proportional to the last chunk. GZ_ARITH_LAST_SPLIT=1 lets the last chunk go in pieces of 1/2, 1/4, 1/8, 1/8. MEASURED WITHOUT EFFECT
+        // (round 5; ms per step without / with: default FASTQ 44.15-44.17 / 44.21-44.25, binned 26.3 / 26.0, streamed 157.4 / 161.8, VCF 903 /
+        // 903): those kernels are not what the tail consists of. Off by default.
         {
-            static const bool last_split = !(getenv ("GZ_ARITH_LAST_SPLIT") && getenv ("GZ_ARITH_LAST_SPLIT")[0] == '0');
+            static const bool last_split = getenv ("GZ_ARITH_LAST_SPLIT") && getenv ("GZ_ARITH_LAST_SPLIT")[0] == '1';
             const uint32_t s0 = (A.n_chunks - 1) * A.chunk, span_tiles = P.max_arith_n > s0 ? (P.max_arith_n - s0) / GZ_CTX_TILE : 0;
             if (last_split && A.n_chunks > 1 && span_tiles >= 8) {
                 const uint32_t cut[3] = { span_tiles / 2, span_tiles / 2 + span_tiles / 4, span_tiles / 2 + span_tiles / 4 + span_tiles / 8 };
