@@ -1182,8 +1182,11 @@ extern "C" int gz_fastq_zip_seg (GzZipFile *f, uint8_t *text, uint64_t text_len,
             r.n = Z.n; r.local_len = X.kind == GZ_FQ_QUAL ? (Z.blob_job >= 0 ? K.blobres[Z.blob_job] : qmode0 && Z.n ? K.domq[v].res.mplx_len : 0) : Z.local_len; r.ats_node = -1;
             if (qmode0 && Z.n && (X.kind == GZ_FQ_QUAL || X.kind == GZ_FQ_QUAL_AUX)) {
                 const ZipDomq &D = K.domq[v];
-                r.domq_local_len = X.kind == GZ_FQ_QUAL ? D.res.qual_len : X.item == 0 ? D.res.runs_len : X.item == 1 ? D.res.mplx_len : D.res.divr_len;
-                if (X.kind == GZ_FQ_QUAL_AUX && X.item == 0 && !D.snip.empty ()) {          // seg_by_ctx (denorm_snip) (codec_domq.c:244): one b250 entry
+                r.domq_local_len = !D.res.mplx_len ? 0 : X.kind == GZ_FQ_QUAL ? D.res.qual_len : X.item == 0 ? D.res.runs_len : X.item == 1 ? D.res.mplx_len : D.res.divr_len;
+                // seg_by_ctx (denorm_snip) (codec_domq.c:244): one b250 entry. A VBlock whose every line is one repeated score hands CODEC_DOMQ no
+                // line at all: no dom, an EMPTY table, and seg_by_ctx of a snip of length 0 is WORD_INDEX_EMPTY (context.c:331-335) - state 3 with
+                // dict_len 0
+                if (X.kind == GZ_FQ_QUAL_AUX && X.item == 0 && D.res.status == 1) {
                     r.state = 3; r.n = 1; r.dict_len = D.snip.size ();
                     blob_put (K.blob, &r, sizeof (r)); blob_put (K.blob, D.snip.data (), D.snip.size ());
                     continue;
@@ -1250,7 +1253,10 @@ static void zip_apply_qual_mode (GzZipFile *f, int mode)
     for (uint32_t v = 0; v < K.NV; v++) {
         if (mode != GZ_CODEC_DOMQ || !K.vbs[v].n_reads) continue;          // (a plain local: as gathered; the three stay empty)
         const ZipDomq &D = K.domq[v];
-        const uint64_t len[4] = { D.res.qual_len, D.res.runs_len, D.res.mplx_len, D.res.divr_len };
+        // (a VBlock whose every line is one repeated score: ctx->local.len is 0, QUAL is never compressed and codec_domq_compress - whose
+        //  "no scores at all" output is the single byte 'X', codec_domq.c:490-494 - never runs: QUALMPLX has a byte per line that took part)
+        const bool any = D.res.mplx_len != 0;
+        const uint64_t len[4] = { any ? D.res.qual_len : 0, any ? D.res.runs_len : 0, D.res.mplx_len, any ? D.res.divr_len : 0 };
         for (int k = 0; k < 4; k++) {
             ZipCol &Z = K.col[(size_t)v * NC + (k ? f->aux[k - 1] : f->qual_ctx)];
             Z.local = D.out[k]; Z.local_len = len[k]; Z.local_cap = len[k]; Z.has_local = len[k] != 0;
@@ -1384,6 +1390,20 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
             m.local_len = X.kind == GZ_FQ_QUAL ? r->local_len : local_len;          // (QUAL with a b250: ctx->local.len as the segmenter left it)
             m.pair2_identical = is_r2 && X.pair_identical;
             if (is_r2) { m.b250_r1_len = R1->has_b250[c]; m.local_r1_len = R1->has_local[c]; }
+            if (r->state == 3 && !r->dict_len) {
+                // a snip of length 0: WORD_INDEX_EMPTY - no node, a b250 of the one entry BF FE that is all-the-same and cannot be dropped
+                // (ctx_drop_all_the_same: "word_index is negative", context.c:826)
+                const uint32_t n_words = (uint32_t)z->snip_len.size ();
+                std::vector<uint32_t> cnt ((size_t)n_words + 1, 0);
+                int32_t w1 = -1; uint8_t no_ston[8]; const uint64_t one_ci = 0; const uint32_t one_sl = 0;
+                m.n_ol = n_words; m.n_new = 0; m.dict = no_ston; m.node_char_index = &one_ci; m.node_snip_len = &one_sl; m.counts = cnt.data ();
+                m.b250_len = 2; m.flags = X.flags | ATS; m.ats_node_index = -1; m.no_drop_b250 = 1;
+                m.node2word = &w1; m.ston_local = no_ston; m.ston_cap = 0;
+                if ((rc = gz_ctx_merge (z, &m)) != GZ_OK) { h->err = "gz_ctx_merge (empty snip)"; return rc < 0 ? rc : GZ_ERR; }
+                VS.has_b250[c] = 1; VS.host_b250[c].assign ({ 0xBF, 0xFE });                    // WORD_INDEX_EMPTY (b250.c:29-43)
+                if (mine) { Z.n_ol = n_words; Z.all_the_same = true; Z.b250_count = 1; Z.seg_b250_len = 2; Z.n_new = 0; Z.lcodec = m.lcodec; Z.bcodec = m.bcodec; Z.has_b250 = true; Z.host_b250 = VS.host_b250[c]; }
+                continue;
+            }
             if (r->state == 2 || r->state == 3) {
                 const uint8_t *snip = r->state == 3 ? payload3 : X.snip; const uint32_t snip_len = r->state == 3 ? (uint32_t)r->dict_len : X.snip_len;
                 // GZ_FQ_CONST / GZ_FQ_ITEM_DELTA: every line segs `snip` - one node, count = lines (b250_seg_append's

@@ -83,6 +83,21 @@ def fastq_single(E, lzma, qual="bin", mono=5, n=360):
     return blob, {"out.fq": text}, ["-o", "out.fq"]
 
 
+def fastq_single_domq_gap(E, lzma):
+    """binned scores (the file goes through CODEC_DOMQ) with a VBlock in the middle whose EVERY line is one repeated score: CODEC_DOMQ gets no line
+    at all there - no QUAL / DOMQRUNS / QUALMPLX / DIVRQUAL locals, and DOMQRUNS' b250 is the one entry WORD_INDEX_EMPTY (the base64 of an empty
+    denormalisation table is a snip of length 0, codec_domq.c:240-244, context.c:331-335)"""
+    from genozip_amd import fastq as fq
+    a = parity.fastq_text(150, seed=71, mate=1, qual="bin", mono=9)
+    b = parity.fastq_text(60, seed=72, mate=1, qual="bin", mono=-1)
+    c = parity.fastq_text(120, seed=73, mate=1, qual="bin")
+    text = a + b + c
+    F, vbs = _zip(E, fq.illumina_plan(paired=False), [(text, [(0, len(a), 1, -1)]), (text, [(len(a), len(b), 2, -1), (len(a) + len(b), len(c), 3, -1)])], lzma)
+    blob = F.write_file([dict(name=b"reads.fq", pair=0, vbs=vbs)], std_seq_len=150)
+    F.close()
+    return blob, {"out.fq": text}, ["-o", "out.fq"]
+
+
 SAM_HEADER = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:248956422\n@PG\tID:bwa\tPN:bwa\tVN:0.7.17\n"
 
 
@@ -136,6 +151,7 @@ CASES = {
     "fastq_pair_domq_monochar": lambda E, lz: fastq_pair(E, lz, "bin", 4, n=240),
     "fastq_single_domq_monochar": lambda E, lz: fastq_single(E, lz, "bin", 5),
     "fastq_single_all_monochar": lambda E, lz: fastq_single(E, lz, "uniform", -1, n=150),
+    "fastq_single_domq_vb_all_monochar": fastq_single_domq_gap,
     "sam_tags": sam_tags,
     "vcf": vcf,
 }

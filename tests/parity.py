@@ -865,6 +865,8 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None, host=None):
                 st.update(seq_packed=packed, n_bases=len(seq), seq_has_x=has_x, local=x, ltype=27, has_local=has_x)
             elif k == GZ_FQ_QUAL and zstate["qual_mode"] == 13 and n:
                 dq = po.oracle_domq(oracle, text, qo[a:b], ql[a:b])
+                if not ql[a:b].any():      # (every line one repeated score: ctx->local.len is 0, the context is never compressed, codec_domq_compress never runs)
+                    dq = dict(dq, qual=b"", runs=b"", mplx=b"", divr=b"")
                 st.update(local=dq["qual"], ltype=13, has_local=len(dq["qual"]) > 0, param=dq["num_norm_qs"] | 0x80, domq=dq)
             elif k == GZ_FQ_QUAL:
                 q = oracle.local_blob_column(text, qo[a:b], ql[a:b], False)
@@ -890,6 +892,14 @@ def fastq_zip_expected(oracle, plan, text, vbs, zstate=None, host=None):
             kw = dict(flags=X["flags"], local_len=seg_local_len, pair2_identical=is_r2 and X["pair_identical"])
             if is_r2:
                 kw.update(b250_r1_len=int(S[r1][c]["has_b250"]), local_r1_len=int(S[r1][c]["has_local"]))
+            if st["col"] is None and st.get("own_snip") == b"":       # a snip of length 0 (CODEC_DOMQ's table of a VBlock without lines): WORD_INDEX_EMPTY
+                words = OZ.words()
+                col = dict(node_index=np.array([-3], dtype=np.int32), dict=b"", node_char_index=np.zeros(0, dtype=np.uint64), node_snip_len=np.zeros(0, dtype=np.uint32),
+                           counts=np.zeros(len(words), dtype=np.uint32), b250=oracle.b250_seg([-3], len(words)), b250_count=1, all_the_same=True)
+                m = OZ.merge(vi, len(words), col, can_have_singletons=False, no_drop_b250=True, **kw)
+                assert not m["dropped_b250"]
+                st.update(ats=True, has_b250=True, b250=oracle.b250_piz([-3]))
+                continue
             if st["col"] is None:                                     # constant snip
                 words = OZ.words()
                 snip, n_seg = (st["own_snip"], 1) if "own_snip" in st else (X["snip"], st["n"] * (X.get("segs_per_line") or 1))

@@ -132,6 +132,10 @@ def test_emul_fastq_zip_monochar(emul_engine, oracle):
     parity.fastq_zip(emul_engine, oracle, 60, mono=(7, 5))
     parity.fastq_zip(emul_engine, oracle, 60, qual=("bin", "bin"), mono=(7, 5))
     parity.fastq_zip(emul_engine, oracle, 40, mono=(0, -1))
+    # a file that goes through CODEC_DOMQ with VBlocks in which EVERY line is one: CODEC_DOMQ gets no line there (no streams, DOMQRUNS' b250 the one
+    # entry WORD_INDEX_EMPTY) - found by tests/fuzz_emul.py driver in round 5
+    parity.fastq_zip(emul_engine, oracle, 33, qual=("bin", "uniform"), small_first=True, mono=(0, -1))
+    parity.fastq_zip(emul_engine, oracle, 20, qual=("uniform", "bin"), domq=13, mono=(-1, 2))
 
 
 def test_emul_fastq_zip_early_path(emul_engine, oracle, monkeypatch):

@@ -124,6 +124,9 @@ def test_fastq_zip_monochar(gpu_engine, oracle):
     parity.fastq_zip(gpu_engine, oracle, 1200, qual=("bin", "uniform"), mono=(3, 11), small_first=True)
     parity.fastq_zip(gpu_engine, oracle, 600, mono=(0, -1))
     parity.fastq_zip(gpu_engine, oracle, 600, mono=(-1, 4))
+    # through CODEC_DOMQ with VBlocks in which every line is one (no line reaches CODEC_DOMQ: no streams, DOMQRUNS' b250 = WORD_INDEX_EMPTY)
+    parity.fastq_zip(gpu_engine, oracle, 900, qual=("bin", "uniform"), small_first=True, mono=(0, -1))
+    parity.fastq_zip(gpu_engine, oracle, 600, qual=("uniform", "bin"), domq=13, mono=(-1, 2))
 
 
 @pytest.mark.gpu
