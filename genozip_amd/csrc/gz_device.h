@@ -87,7 +87,7 @@ struct GzdLeaf {
     uint32_t  *models;        // arith (run-length variant): global-memory models when they do not fit the LDS
     uint8_t   *triples;       // arith: 16 bytes per coded byte: 2^7 / tot as a double, freq, cum  (k_arith_model -> k_arith_chain, k_chain_expand)
     uint32_t  *spos;          // arith order-1: positions grouped by context (the byte before), stream order inside a context
-    uint8_t   *srk;           // arith order-1: static rank of the symbol at spos[j]
+    uint8_t   *srk;           // arith order-1: static rank of the symbol at spos[j]; NULL (leaves under 2^24 positions): spos[j] = position << 8 | rank
     uint32_t  *ctxoff;        // arith order-1: [tile][context] -> index into spos/srk of the first occurrence at or after the tile
     uint32_t  *ctxend;        // arith order-1: [position chunk][context] -> end of the context's run in that chunk's part of the sorted lists
     uint16_t  *ev_ctx;        // arith run-length variant: model id of every coding event (0..255 literal models, 256 + 0..257 run models)

@@ -465,7 +465,9 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
         if (o1 || rle) {
             const size_t nt = ((size_t)nb + GZ_CTX_TILE - 1) / GZ_CTX_TILE;
             if (!(L.spos   = (uint32_t *)arena_alloc (h, ((size_t)nb + 64) * 4))) return false;
-            if (!(L.srk    = (uint8_t *)arena_alloc (h, (size_t)nb + 64))) return false;
+            // (a leaf of fewer than 2^24 positions keeps a position's symbol rank in the low byte of its spos entry: no srk, one scattered store)
+            L.srk = NULL;
+            if (nb >= (1u << 24) && !(L.srk = (uint8_t *)arena_alloc (h, (size_t)nb + 64))) return false;
             if (!(L.ctxoff = (uint32_t *)arena_alloc (h, (nt + 1) * nctx * 4))) return false;
             // one row per position chunk (no chunk is smaller than GZ_CHUNK_MIN - but for the first one, which goes in up to four pieces: a short leaf has few)
             const size_t rows = std::min<size_t> (GZ_MAX_CHUNKS, (size_t)nb / GZ_CHUNK_MIN + 6);

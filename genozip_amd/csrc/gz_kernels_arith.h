@@ -617,7 +617,11 @@ __global__ void __launch_bounds__(64) k_ctx_scatter (GzdLeaf *leaves, const uint
         }
         const uint32_t within = (uint32_t)__popcll (same & below);
         if (valid) {
-            spos[base + within] = pos; srk[base + within] = ev_sym ? (uint8_t)s : rank_of[s];
+            // (one scattered 4-byte store per position instead of a 4- and a 1-byte one: a leaf of fewer than 2^24 positions - srk == NULL -
+            //  keeps the symbol's rank in the low byte of its entry)
+            const uint32_t rk = ev_sym ? (s & 0xff) : rank_of[s];
+            if (srk) { spos[base + within] = pos; srk[base + within] = (uint8_t)rk; }
+            else spos[base + within] = (pos << 8) | rk;
             atomicAdd (&cnt[c], 1u);
         }
         __syncthreads ();                                  // (one wave: the next group's gather sees this group's counts)
@@ -704,13 +708,13 @@ __device__ static inline uint32_t d_local_rank (const GzLocalAlpha &A, uint32_t 
 
 // Returns the number of distinct symbols among the context's occurrences [j0, j1) and, if there are at most 64, leaves
 // their byte values (ascending) in lds_list[0..]. lds_flags: 256 bytes of LDS; one wave.
-__device__ static inline uint32_t d_local_alphabet (GzLocalAlpha &A, const uint8_t *in, bool o1, const uint8_t *srk, const uint16_t *symrank,
+__device__ static inline uint32_t d_local_alphabet (GzLocalAlpha &A, const uint8_t *in, bool o1, const uint32_t *spos, const uint8_t *srk, const uint16_t *symrank,
                                                     const uint8_t *symlist, uint32_t j0, uint32_t j1, uint8_t *lds_flags, uint8_t *lds_list)
 {
     const int lane = threadIdx.x & 63;
     ((uint32_t *)lds_flags)[lane] = 0;
     __syncthreads ();
-    for (uint32_t j = j0 + lane; j < j1; j += 64) lds_flags[o1 ? srk[j] : symrank[in[j]]] = 1;
+    for (uint32_t j = j0 + lane; j < j1; j += 64) lds_flags[o1 ? (srk ? srk[j] : (spos[j] & 0xff)) : symrank[in[j]]] = 1;
     __syncthreads ();
     uint32_t nd = 0;
     #pragma unroll
@@ -826,7 +830,10 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
     //  a quiet batch were that wait, once every four batches for the whole trip to memory)
     auto fetch_raw = [&] (uint32_t at, uint32_t &pos, uint32_t &raw) {
         const uint32_t a = at < j1 ? at : (j1 ? j1 - 1 : 0u);
-        if (o1) { pos = gz_ldg_u32 (spos + a); raw = gz_ldg_u8 (srk + a); }
+        if (o1) {
+            if (srk) { pos = gz_ldg_u32 (spos + a); raw = gz_ldg_u8 (srk + a); }
+            else { const uint32_t w = gz_ldg_u32 (spos + a); pos = w >> 8; raw = w & 0xff; }       // (position and rank in one entry: k_ctx_scatter)
+        }
         else    { pos = a; raw = gz_ldg_u8 (in + a); }
     };
     auto to_rank = [&] (uint32_t raw) -> uint32_t {
@@ -990,7 +997,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
         if (p0 == 0 && p1 == n_u && j1 > j0) {                  // a leaf in one piece: try the context's own alphabet
             GzLocalAlpha la;
             uint8_t *lds_flags = gz_lds, *lds_list = gz_lds + 256;
-            const uint32_t nd = d_local_alphabet (la, coded, sorted, srk, L.symrank, L.symlist, j0, j1, lds_flags, lds_list);
+            const uint32_t nd = d_local_alphabet (la, coded, sorted, spos, srk, L.symrank, L.symlist, j0, j1, lds_flags, lds_list);
             if (nd <= 64) {
                 d_arith_model_wave<1> (coded, ms_u, sorted, tr, inv_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, true, false, st, &la);
                 GZ_MODEL_T1 (ctx, j1 - j0);
