@@ -558,7 +558,10 @@ static int upload (GzHandle *h, const void *host, size_t bytes, void **dev)
 
 // kernels that run beside the pipelined chain ask for this much LDS so that they never fit on a chain's compute unit
 #define GZ_KEEP_OFF_LDS 4608                  // (the chain leaves 4096 bytes of a compute unit free)
-static const uint32_t ARITH_CLASS_WORDS[4] = { 0, 4096, 16384, 40000 };   // 16 KB, 64 KB, 156 KB of LDS
+// the decoder's models by LDS need (gz_kernels_dec.h: a literal row is 128 words per 64 entries): order 0 - 16 KB; order 1 up to 64 symbols
+// - 42.5 KB, three to a compute unit; up to 80 symbols (quality scores) - 80 KB, two to a compute unit; up to 128 - 140 KB; beyond: global memory
+#define GZ_ARITH_CLASSES 4
+static const uint32_t ARITH_CLASS_WORDS[GZ_ARITH_CLASSES + 1] = { 0, 4096, 10880, 20480, 35840 };
 
 // The arithmetic coder's pipeline of one batch (see gz_kernels_arith.h): which leaves, in how many position chunks
 struct ArithPipe {
@@ -984,10 +987,10 @@ extern "C" int gz_codec_uncompress_batch (GzHandle *h, GzStream *streams, int n_
         hipLaunchKernelGGL (k_dec_parse, dim3 ((ns + 63) / 64), dim3 (64), 0, h->stream, (GzdDecStream *)d_streams, (GzdDecLeaf *)d_leaves, ns);
         hipLaunchKernelGGL (k_dec_table, dim3 (ns * 4), dim3 (256), 20480, h->stream, (GzdDecLeaf *)d_leaves);
         hipLaunchKernelGGL (k_rans_decode, dim3 (ns * 4), dim3 (64), 0, h->stream, (GzdDecLeaf *)d_leaves);
-        for (int c = 0; c < 3; c++)
+        for (int c = 0; c < GZ_ARITH_CLASSES; c++)
             hipLaunchKernelGGL (k_arith_decode, dim3 (ns * 4), dim3 (64), ARITH_CLASS_WORDS[c + 1] * 4, h->stream,
                                 (GzdDecLeaf *)d_leaves, ARITH_CLASS_WORDS[c], ARITH_CLASS_WORDS[c + 1], 0);
-        hipLaunchKernelGGL (k_arith_decode, dim3 (ns * 4), dim3 (64), 0, h->stream, (GzdDecLeaf *)d_leaves, ARITH_CLASS_WORDS[3], 0xffffffffu, 1);
+        hipLaunchKernelGGL (k_arith_decode, dim3 (ns * 4), dim3 (64), 0, h->stream, (GzdDecLeaf *)d_leaves, ARITH_CLASS_WORDS[GZ_ARITH_CLASSES], 0xffffffffu, 1);
         hipLaunchKernelGGL (k_dec_finish, dim3 (ns), dim3 (256), 0, h->stream, (GzdDecStream *)d_streams, (GzdDecLeaf *)d_leaves);
         HIPCHK (h, hipGetLastError ());
     }

@@ -84,6 +84,22 @@ __device__ static inline void gz_wave_sync (void) { __builtin_amdgcn_fence (__AT
 
 // v_rcp_f64: the reciprocal to about one ulp (not the IEEE division sequence)
 __device__ static inline double gz_rcp_f64 (double x) { return __builtin_amdgcn_rcp (x); }
+__device__ static inline uint32_t gz_mul_u24 (uint32_t a, uint32_t b) { uint32_t d; asm ("v_mul_u32_u24 %0, %1, %2" : "=v" (d) : "v" (a), "v" (b)); return d; }   // a, b < 2^24: v_mul_u32_u24, full rate
+// ---- the arithmetic decoder's hand-over of the entry that is hit (gz_kernels_dec.h) ----
+// lane l's x as seen by lane l + 1 (lane 0 keeps `fill`): v_mov_b32_dpp wave_shr:1
+__device__ static inline uint32_t gz_wave_shr1 (uint32_t x, uint32_t fill) { return (uint32_t)__builtin_amdgcn_update_dpp ((int)fill, (int)x, 0x138, 0xf, 0xf, false); }
+// the values x, d, q, xl of the FIRST lane with d < q, as wave-uniform values (no lane with d < q: lane 0's): exec is narrowed to those lanes
+// by the compare itself, v_readfirstlane reads the first of them, exec comes back on. Only where every lane is active.
+__device__ static inline void gz_hit_window (uint32_t d, uint32_t q, uint32_t x, uint32_t xl, uint32_t &ex, uint32_t &ed, uint32_t &eq, uint32_t &exl)
+{
+    asm volatile ("v_cmpx_lt_u32_e32 vcc, %4, %5\n\t"
+                  "s_nop 4\n\t"              // (v_readfirstlane straight after a VALU write of exec still reads under the OLD mask: measured, tools/probes/lat_probe.hip - 4 wait states do)
+                  "v_readfirstlane_b32 %0, %6\n\tv_readfirstlane_b32 %1, %4\n\tv_readfirstlane_b32 %2, %5\n\tv_readfirstlane_b32 %3, %7\n\t"
+                  "s_mov_b64 exec, -1"
+                  : "=&s" (ex), "=&s" (ed), "=&s" (eq), "=&s" (exl) : "v" (d), "v" (q), "v" (x), "v" (xl) : "vcc");
+}
+__device__ static inline void gz_opaque (uint32_t &v) { asm ("" : "+s" (v)); }      // a wave-uniform value the optimiser shall not look through
+__device__ static inline uint32_t gz_first_lane (uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane ((int)v); }   // a wave-uniform value into an SGPR
 
 // loads through a GLOBAL pointer: a load through a generic one is a flat load, which also counts as an LDS operation -
 // every wait for an LDS read would then wait for its trip to memory as well

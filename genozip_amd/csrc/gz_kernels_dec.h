@@ -176,9 +176,15 @@ __device__ static bool d_rans_decode_wave (const uint8_t *pay, uint32_t pay_len,
 }
 
 // one 256-thread workgroup per decode leaf; 20 KB dynamic LDS
+// Workgroup -> leaf, for the kernels with one workgroup per leaf (four leaves per stream, of which an unstriped stream uses the first): the
+// workgroups of a grid go round the 8 XCDs, so with leaf = blockIdx the working leaves 0, 4, 8 ... of a batch of unstriped streams would
+// all land on XCDs 0 and 4 - a quarter of the chip (measured: 1024 quality streams decoded 114 at a time instead of 512). Leaf k of stream
+// s is workgroup k * n_streams + s instead.
+#define GZ_DEC_LEAF_OF_BLOCK ((blockIdx.x % (gridDim.x / 4)) * 4 + blockIdx.x / (gridDim.x / 4))
+
 __global__ void __launch_bounds__(256) k_dec_table (GzdDecLeaf *leaves)
 {
-    GzdDecLeaf &L = leaves[blockIdx.x];
+    GzdDecLeaf &L = leaves[GZ_DEC_LEAF_OF_BLOCK];
     if (!L.active || L.engine != GZ_ENG_RANS || L.cat || !L.coded_n) return;
     const int tid = threadIdx.x;
     uint32_t *lds = (uint32_t *)gz_lds;
@@ -299,7 +305,7 @@ __global__ void __launch_bounds__(256) k_dec_table (GzdDecLeaf *leaves)
 
 __global__ void __launch_bounds__(64) k_rans_decode (GzdDecLeaf *leaves)
 {
-    GzdDecLeaf &L = leaves[blockIdx.x];
+    GzdDecLeaf &L = leaves[GZ_DEC_LEAF_OF_BLOCK];
     if (!L.active || L.engine != GZ_ENG_RANS || L.cat || !L.coded_n || L.status != GZ_ST_PENDING) return;
     const int lane = threadIdx.x;
     const uint32_t n = L.coded_n;
@@ -343,12 +349,47 @@ __global__ void __launch_bounds__(64) k_rans_decode (GzdDecLeaf *leaves)
 // to 140 symbols: 156 KB) or, beyond that, in global memory. The coded bytes are read 64 at a time (one per lane) and handed out by
 // v_readlane. Measured ... see DESIGN.md (decode).
 #define GZ_DEC_BAD 0xffffffffu
-struct GzRcDec { uint32_t code, range; const uint8_t *in; uint32_t pos, len; uint32_t win, base; };   // win: byte base + lane of the coded stream
+// The coded bytes: a window of 256 of them in a register (lane l: the big-endian word at wbase + 4 l, zeros beyond the stream), from which
+// W - the next wvalid (a multiple of 8, >= 16 whenever a symbol starts) bits of the stream, at the top of 64 - is topped up a word at a time;
+// the coder's normalisation (c_range_coder.h:121-126: while range < 2^24 take a byte) is then ONE shift of { code, W } by 0, 8 or 16 bits.
+// (Beyond the end of the stream the reference stops shifting and flags an error; zeros come in here - only a malformed stream gets there.)
+struct GzRcDec { uint32_t code, range; uint64_t W; uint32_t wvalid; const uint8_t *in; uint32_t len, fill, wbase, win; };
+
+__device__ static __forceinline__ void d_rc_window (GzRcDec &rc, int lane)
+{
+    const uint32_t off = rc.wbase + 4 * (uint32_t)lane;
+    uint32_t w = 0;
+    if (off + 4 <= rc.len) w = __builtin_bswap32 (gz_ldg_u32 ((const uint32_t *)(rc.in + off)));     // (any alignment: a global load)
+    else for (uint32_t k = 0; k < 4; k++) w = (w << 8) | (off + k < rc.len ? gz_ldg_u8 (rc.in + off + k) : 0u);
+    rc.win = w;
+}
+
+__device__ static __forceinline__ void d_rc_refill (GzRcDec &rc, int lane)
+{
+    if ((int32_t)rc.wvalid < 0) rc.wvalid = 0;                   // (a malformed stream took more than it was entitled to)
+    while (rc.wvalid <= 32) {
+        if (rc.fill - rc.wbase >= 256) { rc.wbase = rc.fill; d_rc_window (rc, lane); }
+        const uint32_t w = d_readlane (rc.win, (int)((rc.fill - rc.wbase) >> 2));
+        rc.W |= ((uint64_t)w << 32) >> rc.wvalid;
+        rc.wvalid += 32; rc.fill += 4;
+    }
+}
+
+__device__ static __forceinline__ void d_rc_start (GzRcDec &rc, const uint8_t *in, uint32_t len, int lane)   // RC_StartDecode, c_range_coder.h:55-68
+{
+    rc.code = 0; rc.range = 0xffffffffu; rc.W = 0; rc.wvalid = 0; rc.in = in; rc.len = len; rc.fill = 0; rc.wbase = 0;
+    d_rc_window (rc, lane);
+    d_rc_refill (rc, lane);
+    rc.code = (uint32_t)(rc.W >> 24); rc.W <<= 40; rc.wvalid -= 40;      // five bytes, the first of which falls out of the 32 bits
+    d_rc_refill (rc, lane);
+}
 
 __device__ static __forceinline__ uint32_t d_dec_byte (GzRcDec &rc, int lane)
 {
-    if (rc.pos - rc.base >= 64) { rc.base = rc.pos & ~63u; rc.win = rc.base + lane < rc.len ? rc.in[rc.base + lane] : 0u; }
-    return d_readlane (rc.win, (int)(rc.pos++ - rc.base));
+    const uint32_t b = (uint32_t)(rc.W >> 56);
+    rc.W <<= 8; rc.wvalid -= 8;
+    if (rc.wvalid < 16) d_rc_refill (rc, lane);
+    return b;
 }
 
 // a / b for a < 2^32, 0 < b < 2^32: the hardware's reciprocal seed (v_rcp_f64) + one Newton step is good to ~2^-46, so the truncated
@@ -394,8 +435,7 @@ __device__ static inline uint32_t d_model_decode (MP m, uint32_t max_sym, GzRcDe
     const uint32_t at = plane * 64 + l, ex = d_readlane (x, l), ec = d_readlane (c, l);
     rc.code  -= ec * rc.range;
     rc.range *= ex & 0xffff;
-    while (rc.range < (1u << 24)) {
-        if (rc.pos >= rc.len) break;
+    for (int k = 0; k < 3 && rc.range < (1u << 24); k++) {
         rc.code = (rc.code << 8) + d_dec_byte (rc, lane);
         rc.range <<= 8;
     }
@@ -447,17 +487,261 @@ __device__ static inline uint32_t d_model_decode (MP m, uint32_t max_sym, GzRcDe
 
 #define GZ_DEC_ROW(ms) (2 * (ms) + 2)
 #define GZ_DEC_RUN_ROW 10
+#define GZ_DEC_LIT_ROW(ms) ((ms) <= 64 ? 128u : (ms) <= 128 ? 256u : 512u)   // words of a literal row: 64 entries per register plane, zeros beyond the alphabet - no lane needs a bounds check
 
-template <typename MP>
+// ---- the literal models ---------------------------------------------------------------------------------------------------------------
+// ONE wave decodes a stream, and one wave is given an instruction every 4 - 5 clocks whatever the instruction (tools/probes/lat_probe.hip:
+// dependent or not, VALU or SALU), a taken branch costs ~26, one not taken ~13, a value written by the VALU into an SGPR can be read by
+// the SALU ~20 clocks later, the LDS answers after ~48, a global load after 200+. So a symbol costs what its instructions, its branches and
+// its VALU -> SALU hand-overs add up to - d_model_decode above: ~1300 clocks (556 ns) - and the decoder of the literals is built to keep all
+// three small:
+//   * the current context's row lives in REGISTERS (NP entries per lane: list positions lane, lane + 64 ...): freq | sym << 16 and the
+//     cumulative frequency of every entry; it is updated there, goes back to the LDS after every symbol and the next context's row is asked
+//     for BEFORE that (a lane only reads and writes its own entries of a row, the LDS serves a wave in order; if the context stays, the
+//     registers are kept and what was fetched is dropped): no branch, and the LDS latency lies under the update's instructions;
+//   * ONE division, without a correction step: range / total = trunc ((range + 0.5) * rcp) with rcp = v_rcp_f64 and one Newton step
+//     (relative error 2^-48.8 measured over every total a model can have, needed: below 2^-33); the total is the last entry's cumulative +
+//     frequency (a v_readlane at a fixed lane);
+//   * the second division is gone: "cum <= code / r < cum + freq" is "code - cum * r < freq * r" in wrapping 32-bit arithmetic
+//     ((cum + freq) * r <= total * r <= range < 2^32: the products do not wrap, a code below cum * r wraps to something larger than
+//     any freq * r), and the two products ARE the coder's new code and range (c_range_coder.h:118-119);
+//   * the entry that is hit hands over its values through an exec window (v_cmpx, four v_readfirstlane, exec back on: gz_hit_window) -
+//     no ballot / s_ff1 / v_readlane chain; its left neighbour's entry (for the bubble step) comes along, fetched beforehand with a
+//     wave_shr:1 DPP move;
+//   * the model's update is selects on per-lane predicates that need no lane number: "behind the hit" = the subtraction's borrow, "the
+//     hit's left neighbour" = code - (cum + freq) * r equals the new code;
+//   * the rare cases - a hit beyond list position 63, the halving of the frequencies, a window that runs low - leave the fast loop BEFORE
+//     anything is changed and take d_lit_slow, the general routine.
+// Measured: see DESIGN.md (decode).
+#ifdef GZ_DEC_PROFILE
+// (probe builds only, tools/dec_bench.py with GZ_LIB: s_memtime stamps along one symbol of the fast loop, each waited for - ~40 clocks a stamp)
+#define GZ_NSTAMP 8
+struct GzDecProf { uint64_t t[GZ_NSTAMP], sum[GZ_NSTAMP], n, fast_calls, slow, refills; };
+#define GZ_STAMP(k) asm volatile ("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s" (st.P.t[k]) : : "memory")
+#define GZ_PROF(x) x
+#else
+#define GZ_STAMP(k)
+#define GZ_PROF(x)
+#endif
+
+template <int NP>
+struct GzLitState {
+    uint32_t x[NP], c[NP];            // the row of context `ctx`: entries lane + 64 j (freq | sym << 16, cumulative); 0 beyond the alphabet
+    uint32_t ctx;
+#ifdef GZ_DEC_PROFILE
+    GzDecProf P;
+#endif
+};
+
+template <int NP> __device__ static __forceinline__ uint32_t d_pick (const uint32_t (&v)[NP], uint32_t p)   // v[p], p uniform
+{
+    uint32_t r = 0;                                              // (masks, not selects: a chain of selects between array elements ends up as an indexed load from a copy of the array in scratch memory)
+    for (int j = 0; j < NP; j++) r |= v[j] & (0u - (uint32_t)(p == (uint32_t)j));
+    return r;
+}
+
+// floor (a / t) for a < 2^32, 0 < t < 2^16, as trunc (a * rcp) with a reciprocal that is too LARGE by a relative 2^-40 (+- the 2^-48.8 that
+// v_rcp_f64 and one Newton step leave, measured over every t: tools/probes/lat_probe.hip): a / t is an integer k or at least 1 / t away
+// from the next one, and the excess is below 2^32 / t * 2^-39.9 < 1 / t - the product never reaches k + 1 and never falls below k. The bias
+// rides in the Newton step's constant (1 + 2^-40 instead of 1): no instruction of its own, and no correction step.
+__device__ static __forceinline__ uint32_t d_div_exact (uint32_t a, uint32_t t)
+{
+    const double d = (double)t;
+    double r = gz_rcp_f64 (d);
+    r = __builtin_fma (__builtin_fma (-d, r, 1.0 + 0x1p-40), r, r);
+    return (uint32_t)((double)a * r);
+}
+
+template <int NP, typename MP>
+__device__ static __forceinline__ void d_lit_init (MP rows, uint32_t ms, bool o1, GzLitState<NP> &st, int lane)
+{
+    if (o1) for (uint32_t i = lane; i < ms * GZ_DEC_LIT_ROW (ms); i += 64) {
+        const uint32_t k = i % GZ_DEC_LIT_ROW (ms), e = k / 2;
+        rows[i] = e >= ms ? 0u : (k & 1) ? e /* cum: every frequency is 1 */ : (1u | (e << 16));
+    }
+    for (int j = 0; j < NP; j++) {
+        const uint32_t e = (uint32_t)lane + 64 * j;
+        st.x[j] = e < ms ? (1u | (e << 16)) : 0u; st.c[j] = e < ms ? e : 0u;
+    }
+    st.ctx = 0;
+#ifdef GZ_DEC_PROFILE
+    for (int k = 0; k < GZ_NSTAMP; k++) { st.P.t[k] = 0; st.P.sum[k] = 0; }
+    st.P.n = st.P.fast_calls = st.P.slow = st.P.refills = 0;
+#endif
+}
+
+template <int NP, typename MP>
+__device__ static __forceinline__ void d_lit_switch (MP rows, uint32_t ms, GzLitState<NP> &st, uint32_t ctx, int lane)
+{
+    MP nw = rows + ctx * GZ_DEC_LIT_ROW (ms), old = rows + st.ctx * GZ_DEC_LIT_ROW (ms);
+    uint32_t nx[NP], nc[NP];
+    for (int j = 0; j < NP; j++) { const uint32_t e = (uint32_t)lane + 64 * j; nx[j] = nw[2 * e]; nc[j] = nw[2 * e + 1]; }
+    for (int j = 0; j < NP; j++) { const uint32_t e = (uint32_t)lane + 64 * j; old[2 * e] = st.x[j]; old[2 * e + 1] = st.c[j]; }
+    for (int j = 0; j < NP; j++) { st.x[j] = nx[j]; st.c[j] = nc[j]; }
+    st.ctx = ctx;
+}
+
+// one literal in context ctx (uniform; < ms), the general way -> the symbol; 0 and no update when the code lies beyond the model (a
+// malformed stream)
+template <int NP, typename MP>
+__device__ static inline uint32_t d_lit_slow (MP rows, uint32_t ms, GzLitState<NP> &st, uint32_t ctx, GzRcDec &rc, int lane)
+{
+    uint32_t e[NP];
+    for (int j = 0; j < NP; j++) e[j] = (uint32_t)lane + 64 * j;
+    if (ctx != st.ctx) d_lit_switch<NP, MP> (rows, ms, st, ctx, lane);
+    if (rc.wvalid < 16) d_rc_refill (rc, lane);
+    const uint32_t lp = (ms - 1) >> 6, ll = (ms - 1) & 63;
+    const uint32_t tot = d_readlane (d_pick<NP> (st.c, lp) + (d_pick<NP> (st.x, lp) & 0xffff), (int)ll);
+    const uint32_t r = rc.range >= tot ? d_div_exact (rc.range, tot) : 0;
+    uint32_t d[NP], q[NP];
+    for (int j = 0; j < NP; j++) { d[j] = rc.code - st.c[j] * r; q[j] = (st.x[j] & 0xffff) * r; }
+    uint32_t plane = 0;
+    uint64_t hit = __ballot (d[0] < q[0]);
+    uint32_t hx = st.x[0], hc = st.c[0], hd = d[0], hq = q[0];
+    for (int j = 1; j < NP; j++) if (!hit) {
+        hit = __ballot (d[j] < q[j]);
+        plane = j; hx = st.x[j]; hc = st.c[j]; hd = d[j]; hq = q[j];
+    }
+    if (!hit) return 0;
+    const int l = __ffsll ((unsigned long long)hit) - 1;
+    const uint32_t ex = d_readlane (hx, l);
+    rc.code = d_readlane (hd, l);
+    rc.range = d_readlane (hq, l);
+    for (int k = 0; k < 3 && rc.range < (1u << 24); k++) {
+        rc.code = (rc.code << 8) + d_dec_byte (rc, lane);
+        rc.range <<= 8;
+    }
+    // ---- the model's update (c_simple_model.h:127-146), in the registers ----
+    const uint32_t at = plane * 64 + l, ec = d_readlane (hc, l), e_new = ex + 16, f_new = e_new & 0xffff;
+    if (tot + 16 <= 65519) {
+        uint32_t left = 0xffffu;
+        if (l > 0) left = d_readlane (hx, l - 1);
+        else if (plane) left = d_readlane (d_pick<NP> (st.x, plane - 1), 63);
+        const bool swap = at && f_new > (left & 0xffff);             // one bubble step to the left
+        for (int j = 0; j < NP; j++) {
+            st.c[j] += e[j] > at ? 16u : 0u;
+            if (e[j] == at) { st.x[j] = swap ? left : e_new; st.c[j] = swap ? ec - (left & 0xffff) + f_new : ec; }
+            if (swap && e[j] + 1 == at) st.x[j] = e_new;             // (keeps its cumulative)
+        }
+    }
+    else {                                                       // halve every frequency, rebuild the cumulatives
+        uint32_t run = 0;
+        for (int j = 0; j < NP; j++) {
+            if (e[j] == at) st.x[j] = e_new;
+            uint32_t f = st.x[j] & 0xffff;
+            f -= f >> 1;
+            st.x[j] = (st.x[j] & 0xffff0000u) | f;
+            const uint32_t inc = d_wave_incl_scan (f, lane);
+            st.c[j] = run + inc - f;
+            run += d_readlane (inc, 63);
+        }
+        if (at) {
+            const uint32_t lp2 = (at - 1) >> 6, ll2 = (at - 1) & 63;
+            const uint32_t mine = d_readlane (d_pick<NP> (st.x, plane), l), left = d_readlane (d_pick<NP> (st.x, lp2), (int)ll2);
+            const uint32_t lc = d_readlane (d_pick<NP> (st.c, lp2), (int)ll2);
+            if ((mine & 0xffff) > (left & 0xffff))
+                for (int j = 0; j < NP; j++) {
+                    if (e[j] + 1 == at) st.x[j] = mine;
+                    if (e[j] == at) { st.x[j] = left; st.c[j] = lc + (mine & 0xffff); }
+                }
+        }
+    }
+    return ex >> 16;
+}
+
+// literals i .. of a stream without run lengths, the fast way, for as long as nothing rare comes up -> the index of the first literal NOT
+// decoded (n: all done). `last`: the symbol before literal i. The output is buffered in obuf (symbol k of the current 64 in lane k % 64)
+// and stored 64 at a time.
+template <int NP, bool O1, typename MP>
+__device__ static __forceinline__ uint32_t d_lit_fast (MP rows, uint32_t ms, GzLitState<NP> &st, GzRcDec &rc, uint32_t i, uint32_t n, uint32_t &last,
+                                                      uint32_t &obuf, uint8_t *out, int lane)
+{
+    const uint32_t ll = (ms - 1) & 63, e0 = (uint32_t)lane, stride = GZ_DEC_LIT_ROW (ms), first = i;
+    const bool top = ((ms - 1) >> 6) == 3;                       // (NP == 4: the last entry lies in plane 2 or 3)
+    if (O1 && last != st.ctx) d_lit_switch<NP, MP> (rows, ms, st, last, lane);
+    uint32_t code = rc.code, range = rc.range, wvalid = rc.wvalid;
+    uint64_t W = rc.W;
+    uint32_t cnt = n - i < 64 - (i & 63) ? n - i : 64 - (i & 63);          // to the end of the block of 64 / of the stream; the caller saw to wvalid >= 16
+    GZ_PROF (st.P.fast_calls++);
+    for (;;) {
+        GZ_STAMP (0);
+        const uint32_t f0 = st.x[0] & 0xffff;
+        uint32_t tsum;
+        if constexpr (NP == 1) tsum = st.c[0] + f0;
+        else if constexpr (NP == 2) tsum = st.c[1] + (st.x[1] & 0xffff);
+        else tsum = top ? st.c[3] + (st.x[3] & 0xffff) : st.c[2] + (st.x[2] & 0xffff);
+        const uint32_t tot = d_readlane (tsum, (int)ll);
+        const uint32_t r = d_div_exact (range, tot);
+        const uint32_t p = st.c[0] * r, q = f0 * r, d = code - p, old_code = code;
+        const uint32_t xl = gz_wave_shr1 (st.x[0], 0);           // lane l: the entry to the left of lane l's (lane 0: none, reads 0)
+        uint32_t ex, nd, nq, exl;
+        GZ_STAMP (1);
+        gz_hit_window (d, q, st.x[0], xl, ex, nd, nq, exl);
+        GZ_STAMP (2);
+        if ((tot > 65519 - 16 ? 0xffffffffu : nd) >= nq) break;  // no hit among the first 64 entries (lane 0's values come back) / halving due
+        // ---- the coder: code -= cum * r, range = freq * r, normalise (c_range_coder.h:118-126) ----
+        const uint32_t sh = (uint32_t)__builtin_clz (nq) & 0x18;
+        code = (uint32_t)(((((uint64_t)nd << 32) | (W >> 32)) << sh) >> 32);
+        range = nq << sh;
+        W <<= sh; wvalid -= sh;
+        GZ_STAMP (3);
+        // ---- the next context's row is asked for ----
+        const uint32_t sym = ex >> 16;
+        uint32_t nx[NP], nc[NP];
+        if (O1) {
+            MP nw = rows + sym * stride;
+            for (int j = 0; j < NP; j++) { const uint32_t e = e0 + 64 * j; nx[j] = nw[2 * e]; nc[j] = nw[2 * e + 1]; }
+        }
+        GZ_STAMP (4);
+        // ---- the model's update (c_simple_model.h:127-146): freq += 16, one bubble step to the left if that beats the neighbour ----
+        // (f_new > f_left written as f_new - 1 > f_left - 1: no left neighbour reads 0, 0 - 1 is 0xffff - no swap, and the entries beyond
+        // the alphabet, which pass for "left neighbours" when the hit is entry 0, are rewritten with that 0)
+        const uint32_t e_new = ex + 16;
+        const bool swap = ((ex + 15) & 0xffff) > ((exl - 1) & 0xffff);
+        const uint32_t x_hit = swap ? exl : e_new, x_left = swap ? e_new : exl;
+        uint32_t delta = swap ? (e_new & 0xffff) - (exl & 0xffff) : 0u;
+        gz_opaque (delta);                                       // (or the compiler ANDs `swap` into the lanes' hit mask on the SALU: a wait for the VALU)
+        const bool hit = d < q, behind = p > old_code, left = d - q == nd;
+        uint32_t x0 = hit ? x_hit : st.x[0];
+        x0 = left ? x_left : x0;
+        uint32_t inc = hit ? delta : 0u;
+        inc = behind ? 16u : inc;
+        st.x[0] = x0; st.c[0] += inc;
+        for (int j = 1; j < NP; j++) st.c[j] += 16;
+        GZ_STAMP (5);
+        // ---- the old row goes back, the new one takes its place unless the context stays ----
+        if (O1) {
+            MP old = rows + st.ctx * stride;
+            for (int j = 0; j < NP; j++) { const uint32_t e = e0 + 64 * j; old[2 * e] = st.x[j]; old[2 * e + 1] = st.c[j]; }
+            const bool stay = sym == st.ctx;
+            for (int j = 0; j < NP; j++) { st.x[j] = stay ? st.x[j] : nx[j]; st.c[j] = stay ? st.c[j] : nc[j]; }
+            st.ctx = sym;
+        }
+        obuf = (uint32_t)lane == (i & 63) ? sym : obuf;
+        last = sym;
+        i++;
+#ifdef GZ_DEC_PROFILE
+        GZ_STAMP (6);
+        for (int k = 1; k <= 6; k++) st.P.sum[k] += st.P.t[k] - st.P.t[k - 1];
+        if (st.P.t[7]) st.P.sum[0] += st.P.t[0] - st.P.t[7];
+        st.P.t[7] = st.P.t[6]; st.P.n++;
+#endif
+        const uint32_t go = --cnt ? wvalid : 0u;
+        if (go < 16) break;
+    }
+    GZ_PROF (st.P.t[7] = 0);
+    if (i > first && !(i & 63)) gz_stg_u8 (out + (i - 64) + lane, obuf);
+    rc.code = code; rc.range = range; rc.wvalid = wvalid; rc.W = W;
+    return i;
+}
+
+template <int NP, typename MP>
 __device__ static __forceinline__ void d_arith_decode_leaf (GzdDecLeaf &L, MP models, uint32_t ms, uint32_t n, int lane)
 {
-    const bool o1 = L.o1, rle = L.rle;
-    const uint32_t nlit = o1 ? ms : 1, lit_stride = GZ_DEC_ROW (ms);
-    for (uint32_t i = lane; i < nlit * lit_stride; i += 64) {
-        const uint32_t k = i % lit_stride;
-        models[i] = k == 0 ? ms : k == 1 ? 0u : (k & 1) ? (k - 2) / 2 /* cum: every frequency is 1 */ : (1u | (((k - 2) / 2) << 16));
-    }
-    MP runm = models + nlit * lit_stride;
+    const bool o1 = gz_first_lane (L.o1), rle = gz_first_lane (L.rle);
+    GzLitState<NP> st;
+    d_lit_init<NP, MP> (models, ms, o1, st, lane);
+    MP runm = models + (o1 ? ms * GZ_DEC_LIT_ROW (ms) : 0);
     if (rle) for (uint32_t i = lane; i < 258 * GZ_DEC_RUN_ROW; i += 64) {
         const uint32_t k = i % GZ_DEC_RUN_ROW;
         runm[i] = k == 0 ? 4u : k == 1 ? 0u : (k & 1) ? (k - 2) / 2 : (1u | (((k - 2) / 2) << 16));
@@ -465,16 +749,24 @@ __device__ static __forceinline__ void d_arith_decode_leaf (GzdDecLeaf &L, MP mo
     __syncthreads ();
 
     GzRcDec rc;
-    rc.code = 0; rc.range = 0xffffffffu; rc.in = L.body + 1; rc.pos = 0; rc.len = L.body_len - 1; rc.base = 0xffffff00u; rc.win = 0;
-    if (rc.len >= 5) for (int k = 0; k < 5; k++) rc.code = (rc.code << 8) | d_dec_byte (rc, lane);
-    else rc.pos = rc.len;
+    d_rc_start (rc, L.body + 1, gz_first_lane (L.body_len - 1), lane);
     uint8_t *out = L.dst;
     uint32_t last = 0, obuf = 0;                                 // obuf: symbol i of the current 64 in lane i % 64, stored 64 at a time
     for (uint32_t i = 0; i < n; i++) {
-        uint32_t s = d_model_decode<MP> (models + (o1 ? last * lit_stride : 0), ms, rc, lane);
+        if (!rle) {                                              // the fast loop takes what it can, the general routine the literal it stopped at
+            for (;;) {
+                if (rc.wvalid < 16) { d_rc_refill (rc, lane); GZ_PROF (st.P.refills++); }
+                i = o1 ? d_lit_fast<NP, true, MP> (models, ms, st, rc, i, n, last, obuf, out, lane)
+                       : d_lit_fast<NP, false, MP> (models, ms, st, rc, i, n, last, obuf, out, lane);
+                if (i >= n || rc.wvalid >= 16) break;
+            }
+            if (i >= n) break;
+        }
+        uint32_t s = d_lit_slow<NP, MP> (models, ms, st, o1 ? last : 0, rc, lane);
+        GZ_PROF (st.P.slow++);
         if (s >= ms) s = 0;
         obuf = (uint32_t)lane == (i & 63) ? s : obuf;
-        if ((i & 63) == 63) out[(i & ~63u) + lane] = (uint8_t)obuf;
+        if ((i & 63) == 63) gz_stg_u8 (out + (i & ~63u) + lane, obuf);
         last = s;
         if (!rle) continue;
         uint32_t run = 0, d, ctx = s;                            // arith_dynamic.c:476-487
@@ -486,31 +778,46 @@ __device__ static __forceinline__ void d_arith_decode_leaf (GzdDecLeaf &L, MP mo
         // (a run: flush what is buffered, then the wave writes the run 64 bytes at a time)
         const uint32_t r = run < n - 1 - i ? run : n - 1 - i;
         if (r) {
-            if ((i & 63) != 63 && (uint32_t)lane <= (i & 63)) out[(i & ~63u) + lane] = (uint8_t)obuf;
-            for (uint32_t k = lane; k < r; k += 64) out[i + 1 + k] = (uint8_t)s;
+            if ((i & 63) != 63 && (uint32_t)lane <= (i & 63)) gz_stg_u8 (out + (i & ~63u) + lane, obuf);
+            for (uint32_t k = lane; k < r; k += 64) gz_stg_u8 (out + i + 1 + k, s);
             const uint32_t first = i + 1;
             i += r;
             // (the buffer mirrors the 64-block the run ends in: its positions first .. i hold the run's symbol)
             const uint32_t pos = (i & ~63u) + lane;
             obuf = pos >= first && pos <= i ? s : obuf;
-            if ((i & 63) == 63) out[(i & ~63u) + lane] = (uint8_t)obuf;
+            if ((i & 63) == 63) gz_stg_u8 (out + (i & ~63u) + lane, obuf);
         }
     }
-    if ((n & 63) && (uint32_t)lane < (n & 63)) out[(n & ~63u) + lane] = (uint8_t)obuf;
+    if ((n & 63) && (uint32_t)lane < (n & 63)) gz_stg_u8 (out + (n & ~63u) + lane, obuf);
     if (!lane) L.status = GZ_ST_OK;
+#ifdef GZ_DEC_PROFILE
+    if (!lane && n > 100000 && st.P.n) printf ("[dec profile NP %d ms %u o1 %d] %u symbols: %llu fast (in %llu calls of the fast loop), %llu slow, %llu refills; clocks per fast symbol: loop %.1f | r, products %.1f | window %.1f | rare check %.1f | normalise, next row asked for %.1f | update %.1f | rows, out %.1f\n",
+        NP, ms, (int)o1, n, (unsigned long long)st.P.n, (unsigned long long)st.P.fast_calls, (unsigned long long)st.P.slow, (unsigned long long)st.P.refills,
+        (double)st.P.sum[0] / st.P.n, (double)st.P.sum[1] / st.P.n, (double)st.P.sum[2] / st.P.n, (double)st.P.sum[3] / st.P.n, (double)st.P.sum[4] / st.P.n, (double)st.P.sum[5] / st.P.n, (double)st.P.sum[6] / st.P.n);
+#endif
+}
+
+template <typename MP>
+__device__ static __forceinline__ void d_arith_decode_planes (GzdDecLeaf &L, MP models, uint32_t ms, uint32_t n, int lane)
+{
+    if (ms <= 64) d_arith_decode_leaf<1, MP> (L, models, ms, n, lane);
+    else if (ms <= 128) d_arith_decode_leaf<2, MP> (L, models, ms, n, lane);
+    else d_arith_decode_leaf<4, MP> (L, models, ms, n, lane);
 }
 
 __global__ void __launch_bounds__(64) k_arith_decode (GzdDecLeaf *leaves, uint32_t lds_words_lo, uint32_t lds_words_hi, int use_global)
 {
-    GzdDecLeaf &L = leaves[blockIdx.x];
+    GzdDecLeaf &L = leaves[GZ_DEC_LEAF_OF_BLOCK];
     if (!L.active || L.engine != GZ_ENG_ARITH || L.cat || !L.coded_n) return;
     if (!L.body_len) return;
-    const uint32_t n = L.coded_n;
-    const uint32_t ms = L.body[0] ? L.body[0] : 256;
-    const uint32_t words = (L.o1 ? ms : 1) * GZ_DEC_ROW (ms) + (L.rle ? 258 * GZ_DEC_RUN_ROW : 0);
+    // (what comes through a generic pointer is a divergent value to the compiler - and with it every branch and every loop that depends on
+    // it, executed under exec masks with its variables in VGPRs: say that these are the same in every lane)
+    const uint32_t n = gz_first_lane (L.coded_n);
+    const uint32_t ms = gz_first_lane (L.body[0] ? L.body[0] : 256);
+    const uint32_t words = 2 + (L.o1 ? ms * GZ_DEC_LIT_ROW (ms) : 0) + (L.rle ? 258 * GZ_DEC_RUN_ROW : 0);
     if (words <= lds_words_lo || words > lds_words_hi) return;
-    if (use_global) d_arith_decode_leaf<uint32_t *> (L, L.models, ms, n, (int)threadIdx.x);
-    else d_arith_decode_leaf<GzLdsU32P> (L, (GzLdsU32P)gz_lds, ms, n, (int)threadIdx.x);
+    if (use_global) d_arith_decode_planes<uint32_t *> (L, L.models, ms, n, (int)threadIdx.x);
+    else d_arith_decode_planes<GzLdsU32P> (L, (GzLdsU32P)gz_lds, ms, n, (int)threadIdx.x);
 }
 
 // one 256-thread workgroup per stream

@@ -30,6 +30,21 @@ static inline uint4 gz_ldg_u32x4 (const void *p) { return *(const uint4 *)p; }
 static inline void gz_stg_u8 (uint8_t *p, uint32_t v) { *p = (uint8_t)v; }
 static inline void gz_stg_u32 (uint32_t *p, uint32_t v) { *p = v; }
 static inline void gz_stg_u16 (uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
+static inline uint32_t gz_mul_u24 (uint32_t a, uint32_t b) { return (a & 0xffffff) * (b & 0xffffff); }
+static inline uint32_t gz_wave_shr1 (uint32_t x, uint32_t fill)
+{
+    const int lane = (int)(emu.cur % 64);
+    const uint32_t o = (uint32_t)emu_shfl ((int)x, lane ? lane - 1 : 0);
+    return lane ? o : fill;
+}
+static inline void gz_hit_window (uint32_t d, uint32_t q, uint32_t x, uint32_t xl, uint32_t &ex, uint32_t &ed, uint32_t &eq, uint32_t &exl)
+{
+    const unsigned long long m = __ballot (d < q);
+    const int l = m ? __builtin_ctzll (m) : 0;
+    ex = (uint32_t)emu_shfl ((int)x, l); ed = (uint32_t)emu_shfl ((int)d, l); eq = (uint32_t)emu_shfl ((int)q, l); exl = (uint32_t)emu_shfl ((int)xl, l);
+}
+static inline void gz_opaque (uint32_t &) {}
+static inline uint32_t gz_first_lane (uint32_t v) { return (uint32_t)emu_shfl ((int)v, 0); }
 static inline double gz_rcp_f64 (double x) { return (double)(1.0f / (float)x) * (1.0 - 3e-8); }   // (a SEED of single precision, like v_rcp_f64: the caller's refinement and correction must hold)
 // ---- the range coder chain in double precision (product: rounding mode register + an inline-asm loop over 64-symbol blocks) ----
 #include <fenv.h>

@@ -259,6 +259,7 @@ static inline int __popcll (unsigned long long v) { return __builtin_popcountll 
 static inline int __popc (unsigned v) { return __builtin_popcount (v); }
 static inline unsigned __umulhi (unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline long long __double_as_longlong (double d) { long long v; memcpy (&v, &d, 8); return v; }
+static inline double __longlong_as_double (long long v) { double d; memcpy (&d, &v, 8); return d; }
 static inline unsigned atomicAdd (unsigned *p, unsigned v) { return __atomic_fetch_add (p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicOr (unsigned *p, unsigned v) { return __atomic_fetch_or (p, v, __ATOMIC_RELAXED); }
 static inline unsigned long long atomicOr (unsigned long long *p, unsigned long long v) { return __atomic_fetch_or (p, v, __ATOMIC_RELAXED); }

@@ -2101,3 +2101,16 @@ def fastq_zip_prediction(E, oracle, n_reads):
     finally:
         del os.environ["GZ_ZIP_NO_PREDICTION"]
     return h2 - h0, m2 - m0
+
+
+def decode_foreign_arith(E, ref, sizes=(4, 40, 75, 130, 200, 256), n=40000, seed=9):
+    """a14 beyond what Genozip itself writes: arithmetic streams made by the reference's own encoder (oracle/_ref: htscodecs compiled in
+    place) with every order byte arith_dynamic.c accepts - run-length models (0x40: arith_dynamic.c:476-487), PACK, STRIPE, order 0 / 1 -
+    over alphabets that need one, two and four register planes of the decoder (gz_kernels_dec.h) and models in LDS and in global memory"""
+    rng = np.random.default_rng(seed)
+    for ms in sizes:
+        a = rng.choice(ms, size=max(64, n // 13), p=rng.dirichlet(np.ones(ms) * 0.3)).astype(np.uint8)
+        data = np.repeat(a, rng.integers(1, 40, size=len(a)))[:n].tobytes()
+        for order in (0x40, 0x41, 0xc0, 0xc1, 0x48, 0x49, 0x00, 0x01, 0x80, 0x81, 0x08, 0x09):
+            comp = ref.hts_compress("arith", data, order)
+            assert E.uncompress(16, comp, len(data)) == data, "alphabet %d, order byte %02x (stream's own: %02x)" % (ms, order, comp[0])

@@ -116,6 +116,10 @@ def test_emul_decode_malformed(emul_engine, oracle):
     parity.decode_malformed(emul_engine, oracle)
 
 
+def test_emul_decode_foreign_arith(emul_engine, ref):
+    parity.decode_foreign_arith(emul_engine, ref, sizes=(4, 75, 130, 256), n=12000)
+
+
 def test_emul_merge_chain(emul_engine, oracle):
     parity.merge_chain(emul_engine, oracle, 900)
 

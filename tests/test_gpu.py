@@ -250,6 +250,10 @@ def test_decode_malformed(gpu_engine, oracle):
     parity.decode_malformed(gpu_engine, oracle)
 
 
+def test_decode_foreign_arith(gpu_engine, ref):
+    parity.decode_foreign_arith(gpu_engine, ref, n=400000)
+
+
 def test_b250_pair_identical(gpu_engine, oracle):
     parity.b250_pair_identical(gpu_engine, oracle, 300000)
 
