@@ -266,9 +266,11 @@ def cpu_leg(wl, z_all, n_threads, E=None):
     L = wl.W.READ_LEN
     qual_id = next((c["dict_id"] for c in wl.plan["ctxs"] if c["tag"] == "QUAL" and c["kind"] == 6), None)     # (GZ_FQ_QUAL; a VCF plan has none)
     file_codecs, is_domq = {}, False
+    wl.ref_decoded = [[] for _ in z_all]                        # every section as the reference's decoder gives it back (decode_leg compares with it)
     for v, ((off, ln, vi, r1), z) in enumerate(zip(wl.vb, z_all)):
         for st, codec, did, ulen, pay, domq in walk_sections(z):
             data = bytes(pay) if codec == 1 else (R.codec_uncompress(codec, pay, ulen) if kind == "port" else R.hts_uncompress("rans" if codec < 16 else "arith", pay, ulen))
+            wl.ref_decoded[v].append(data)
             tag = next((c["tag"] for c in wl.plan["ctxs"] if c["dict_id"] == did), None)
             if tag and codec != 1:
                 file_codecs[("b250" if st == 11 else "local", tag)] = codec
@@ -628,7 +630,35 @@ def text_leg(a, WL):
         out["cpu_baseline"] = cb
         out["bit_exact"] = exact
         out["gpu_over_cpu"] = gpu_over_cpu(out, cb)
+        out["decode"] = decode_leg(E, wl, z_all)
+        if out["decode"]["equals_reference_decoder"] is False:
+            out["bit_exact"] = False
     print(json.dumps(out))
+
+
+def decode_leg(E, wl, z_all, reps=3):
+    """row a14 at full size: every section of every VBlock the step wrote, decoded again on the GPU in ONE call (gz_vb_uncompress_many: section
+    walk + adler32 check by two kernels, all payloads as one batch of streams) and compared with what the reference's own decoder made of the
+    same payloads (cpu_leg). Timed with the compressed VBlocks resident in HBM; a side figure, never `value`."""
+    totals = [sum(ulen for _st, _c, _d, ulen, _p, _q in walk_sections(z)) for z in z_all]
+    items = [((E.mem.upload(bytes(z)), len(z)), t) for z, t in zip(z_all, totals)]
+    E.sync()
+    best, res = None, None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        res = E.vb_uncompress_many(items, download=False)
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    same = None
+    if getattr(wl, "ref_decoded", None):
+        same = True
+        for (ob, offs), total, want in zip(res, totals, wl.ref_decoded):
+            raw = E.mem.download(ob, total)
+            same &= len(want) == len(offs) - 1 and all(raw[offs[k]:offs[k + 1]] == want[k] for k in range(len(want)))
+    nsec = sum(len(o) - 1 for _ob, o in res)
+    return {"ms": round(best * 1e3, 2), "vblocks": len(z_all), "sections": nsec, "uncompressed_mb": round(sum(totals) / 1e6, 1), "compressed_mb": round(sum(len(z) for z in z_all) / 1e6, 1),
+            "uncompressed_mb_s": round(sum(totals) / 1e6 / best, 1), "equals_reference_decoder": same,
+            "note": "gz_vb_uncompress_many over the step's own output, compressed VBlocks in HBM, best of %d; one wave per stream (a serial adaptive coder), the longest stream sets the time" % reps}
 
 
 def config_leg(a):
@@ -968,6 +998,9 @@ def main():
         out["cpu_baseline"] = cb
         out["bit_exact"] = exact
         out["gpu_over_cpu"] = gpu_over_cpu(out, cb)
+        out["decode"] = decode_leg(E, wl, z_all)
+        if out["decode"]["equals_reference_decoder"] is False:
+            out["bit_exact"] = False
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

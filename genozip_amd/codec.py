@@ -1012,3 +1012,31 @@ class Engine:
         self._check(self.L.gz_vb_uncompress(self.h, self.mem.ptr(zb), len(z_bytes), self.mem.ptr(ob), total_uncompressed, offs, max_sections, C.byref(ns)), "gz_vb_uncompress")
         raw = self.mem.download(ob, total_uncompressed)
         return [raw[offs[i]:offs[i + 1]] for i in range(ns.value)]
+
+    def vb_uncompress_many(self, items, max_sections=4096, download=True):
+        """items: [(z bytes or a device buffer of self.mem with its length, total_uncompressed)] -> per VBlock the list of decoded section
+        payloads (download=False: (device buffer, offsets) per VBlock). One gz_vb_uncompress_many call: every section of every VBlock in
+        one batch."""
+        n = len(items)
+        zbs, obs = [], []
+        zp, zl, op, oc = (C.c_void_p * max(1, n))(), (C.c_uint64 * max(1, n))(), (C.c_void_p * max(1, n))(), (C.c_uint64 * max(1, n))()
+        for i, (z, total) in enumerate(items):
+            if isinstance(z, (bytes, bytearray, memoryview)):
+                zb, ln = self.mem.upload(bytes(z)), len(z)
+            else:
+                zb, ln = z
+            ob = self.mem.alloc(total + 16)
+            zbs.append(zb); obs.append(ob)
+            zp[i], zl[i], op[i], oc[i] = self.mem.ptr(zb), ln, self.mem.ptr(ob), total
+        offs = (C.c_uint64 * (max(1, n) * (max_sections + 1)))()
+        ns = (C.c_uint32 * max(1, n))()
+        self._check(self.L.gz_vb_uncompress_many(self.h, n, zp, zl, op, oc, offs, max_sections, ns), "gz_vb_uncompress_many")
+        res = []
+        for i, (_z, total) in enumerate(items):
+            o = [offs[i * (max_sections + 1) + k] for k in range(ns[i] + 1)]
+            if not download:
+                res.append((obs[i], o))
+                continue
+            raw = self.mem.download(obs[i], total)
+            res.append([raw[o[k]:o[k + 1]] for k in range(ns[i])])
+        return res

@@ -1850,48 +1850,64 @@ extern "C" int gz_seg_integer_or_not (GzHandle *h, const uint8_t *text, const ui
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// VBlock decode (round trip proof): walk the sections on the host, decode payloads on the device
+// VBlock decode: the sections of many VBlocks found and checked by two kernels, their payloads decoded in ONE batch
 // ---------------------------------------------------------------------------------------------------------
-extern "C" int gz_vb_uncompress (GzHandle *h, const uint8_t *z_data, uint64_t z_len, uint8_t *out, uint64_t out_cap,
-                                 uint64_t *section_offsets_host, uint32_t max_sections, uint32_t *n_sections_out)
+extern "C" int gz_vb_uncompress_many (GzHandle *h, int n_vbs, const uint8_t *const *z_data, const uint64_t *z_len, uint8_t *const *out,
+                                      const uint64_t *out_cap, uint64_t *section_offsets_host, uint32_t max_sections, uint32_t *n_sections_out)
 {
-    if (!h || !z_data || !n_sections_out || z_len < 84) return GZ_ERR_ARG;
+    if (!h || n_vbs < 0 || !max_sections || (n_vbs && (!z_data || !z_len || !out || !out_cap || !n_sections_out))) return GZ_ERR_ARG;
     int rc;
     if ((rc = gz_sync (h)) < 0) return rc;
-    std::vector<uint8_t> z (z_len);
-    HIPCHK (h, hipMemcpy (z.data (), z_data, z_len, hipMemcpyDeviceToHost));
-    if (gz_rd_be32 (&z[0]) != 0x27052012u || z[24] != GZ_SEC_VB_HEADER) { h->err = "bad VB header"; return GZ_ERR_CORRUPT; }
-    if (gz_rd_be32 (&z[40]) != z_len) { h->err = "z_data_bytes mismatch"; return GZ_ERR_CORRUPT; }
-    std::vector<GzStream> S;
-    uint64_t at = 84, o = 0;
-    std::vector<uint32_t> want_adler;
-    while (at < z_len) {
-        if (at + 40 > z_len || gz_rd_be32 (&z[at]) != 0x27052012u) { h->err = "bad section magic"; return GZ_ERR_CORRUPT; }
-        uint32_t clen = gz_rd_be32 (&z[at + 12]), ulen = gz_rd_be32 (&z[at + 16]);
-        if (at + 40 + clen > z_len || o + ulen > out_cap || S.size () >= max_sections) { h->err = "section overflow"; return GZ_ERR_CORRUPT; }
-        GzStream s; memset (&s, 0, sizeof (s));
-        s.in = z_data + at + 40; s.in_len = clen; s.out = out + o; s.out_cap = ulen; s.codec = z[at + 25];
-        if (s.codec == GZ_CODEC_DOMQ || s.codec == GZ_CODEC_XCGT) s.codec = z[at + 26];            // USE_SUBCODEC (compressor.c:60-61, codec.c codec_args[CODEC_DOMQ])
-        S.push_back (s);
-        want_adler.push_back (gz_rd_be32 (&z[at + 4]));
-        if (section_offsets_host) section_offsets_host[S.size () - 1] = o;
-        o += ulen; at += 40 + clen;
+    if (!n_vbs) return GZ_OK;
+    std::vector<GzdVbWalk> W ((size_t)n_vbs);
+    for (int v = 0; v < n_vbs; v++) {
+        if (!z_data[v] || z_len[v] < 84) return GZ_ERR_ARG;
+        W[v].z = z_data[v]; W[v].z_len = z_len[v]; W[v].out_cap = out_cap[v]; W[v].n_sections = 0; W[v].status = GZ_ST_CORRUPT;
     }
-    if (section_offsets_host) section_offsets_host[S.size ()] = o;
-    *n_sections_out = (uint32_t)S.size ();
-    for (size_t i = 0; i < S.size (); i++) {                // z_digest check (zfile.c:212-218)
-        uint32_t a;
-        if ((rc = gz_adler32 (h, S[i].in, S[i].in_len, &a)) != GZ_OK) return rc;
-        if (a != want_adler[i]) { h->err = "section adler32 mismatch"; return GZ_ERR_CORRUPT; }
-    }
+    void *d_w;
+    if ((rc = upload (h, W.data (), W.size () * sizeof (GzdVbWalk), &d_w)) != GZ_OK) return rc;
+    const size_t n_secs = (size_t)n_vbs * max_sections;
+    GzdVbSec *d_s = (GzdVbSec *)arena_alloc (h, n_secs * sizeof (GzdVbSec));
+    if (!d_s) return GZ_ERR_HIP;
+    KLAUNCH (h, k_vb_walk, dim3 (((uint32_t)n_vbs + 63) / 64), dim3 (64), 0, (GzdVbWalk *)d_w, d_s, (uint32_t)n_vbs, max_sections);
+    KLAUNCH (h, k_vb_digests, dim3 (max_sections, (uint32_t)n_vbs), dim3 (256), 4096, (const GzdVbWalk *)d_w, d_s, max_sections);
+    HIPCHK (h, hipGetLastError ());
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    std::vector<GzdVbSec> S (n_secs);
+    HIPCHK (h, hipMemcpy (W.data (), d_w, W.size () * sizeof (GzdVbWalk), hipMemcpyDeviceToHost));
+    HIPCHK (h, hipMemcpy (S.data (), d_s, n_secs * sizeof (GzdVbSec), hipMemcpyDeviceToHost));
     std::vector<GzStream> work;
-    for (auto &s : S) if (s.out_cap) work.push_back (s);
+    for (int v = 0; v < n_vbs; v++) {
+        if (W[v].status != GZ_ST_OK) { h->err = "bad VB header / section magic / section overflow"; return GZ_ERR_CORRUPT; }
+        n_sections_out[v] = W[v].n_sections;
+        uint64_t o = 0;
+        uint64_t *offs = section_offsets_host ? section_offsets_host + (size_t)v * (max_sections + 1) : NULL;
+        for (uint32_t i = 0; i < W[v].n_sections; i++) {
+            const GzdVbSec &sec = S[(size_t)v * max_sections + i];
+            if (!sec.ok) { h->err = "section adler32 mismatch"; return GZ_ERR_CORRUPT; }
+            if (offs) offs[i] = o;
+            if (sec.ulen) {
+                GzStream s; memset (&s, 0, sizeof (s));
+                s.in = z_data[v] + sec.at; s.in_len = sec.clen; s.out = out[v] + o; s.out_cap = sec.ulen; s.codec = (int)sec.codec;
+                work.push_back (s);
+            }
+            o += sec.ulen;
+        }
+        if (offs) offs[W[v].n_sections] = o;
+    }
     if (!work.empty ()) {
         if ((rc = gz_codec_uncompress_batch (h, work.data (), (int)work.size ())) != GZ_OK) return rc;
         if ((rc = gz_sync (h)) < 0) return rc;
         for (auto &s : work) if (s.status != GZ_OK) { h->err = "section payload corrupt"; return GZ_ERR_CORRUPT; }
     }
     return GZ_OK;
+}
+
+extern "C" int gz_vb_uncompress (GzHandle *h, const uint8_t *z_data, uint64_t z_len, uint8_t *out, uint64_t out_cap,
+                                 uint64_t *section_offsets_host, uint32_t max_sections, uint32_t *n_sections_out)
+{
+    if (!h || !z_data || !n_sections_out || z_len < 84) return GZ_ERR_ARG;
+    return gz_vb_uncompress_many (h, 1, &z_data, &z_len, &out, &out_cap, section_offsets_host, max_sections, n_sections_out);
 }
 
 #include "gz_zip.h"

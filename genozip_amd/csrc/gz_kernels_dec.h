@@ -867,3 +867,41 @@ __global__ void __launch_bounds__(256) k_dec_finish (GzdDecStream *streams, GzdD
     __syncthreads ();
     if (!tid) S.status = ok ? GZ_ST_OK : GZ_ST_CORRUPT;
 }
+
+// ---- the sections of many VBlocks: found and checked on the device (zfile.c:212-218: magic, lengths, z_digest) -------------------------
+struct GzdVbSec { uint64_t at; uint32_t clen, ulen, adler, codec, ok; uint32_t pad; };      // at: offset of the payload in the VBlock's z_data
+struct GzdVbWalk { const uint8_t *z; uint64_t z_len, out_cap; uint32_t n_sections, status; }; // status: GZ_ST_OK / GZ_ST_CORRUPT
+
+// one thread per VBlock: its section headers one after the other (40 bytes each, behind the 84 of the VBlock header)
+__global__ void k_vb_walk (GzdVbWalk *vbs, GzdVbSec *secs, uint32_t n_vbs, uint32_t max_sections)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_vbs) return;
+    GzdVbWalk &V = vbs[v];
+    GzdVbSec *S = secs + (size_t)v * max_sections;
+    V.n_sections = 0; V.status = GZ_ST_CORRUPT;
+    const uint8_t *z = V.z;
+    if (V.z_len < 84 || gz_rd_be32 (z) != 0x27052012u || z[24] != GZ_SEC_VB_HEADER || gz_rd_be32 (z + 40) != V.z_len) return;
+    uint64_t at = 84, o = 0;
+    uint32_t n = 0;
+    while (at < V.z_len) {
+        if (at + 40 > V.z_len || gz_rd_be32 (z + at) != 0x27052012u) return;
+        const uint32_t clen = gz_rd_be32 (z + at + 12), ulen = gz_rd_be32 (z + at + 16);
+        if (at + 40 + clen > V.z_len || o + ulen > V.out_cap || n >= max_sections) return;
+        uint32_t codec = z[at + 25];
+        if (codec == GZ_CODEC_DOMQ || codec == GZ_CODEC_XCGT) codec = z[at + 26];                 // USE_SUBCODEC (compressor.c:60-61)
+        S[n].at = at + 40; S[n].clen = clen; S[n].ulen = ulen; S[n].adler = gz_rd_be32 (z + at + 4); S[n].codec = codec; S[n].ok = 0;
+        n++; o += ulen; at += 40 + clen;
+    }
+    V.n_sections = n; V.status = GZ_ST_OK;
+}
+
+// grid (max_sections, n_vbs), 256 threads: a section's adler32 against its header's
+__global__ void __launch_bounds__(256) k_vb_digests (const GzdVbWalk *vbs, GzdVbSec *secs, uint32_t max_sections)
+{
+    const GzdVbWalk &V = vbs[blockIdx.y];
+    if (V.status != GZ_ST_OK || blockIdx.x >= V.n_sections) return;
+    GzdVbSec &S = secs[(size_t)blockIdx.y * max_sections + blockIdx.x];
+    const uint32_t a = gz_adler32_wg (V.z + S.at, S.clen, threadIdx.x);
+    if (!threadIdx.x) S.ok = a == S.adler;
+}

@@ -170,7 +170,7 @@ ABI_SYMBOLS = (
     "gz_codec_est_size", "gz_codec_compress_host", "gz_codec_uncompress_host",
     "gz_codec_compress_batch", "gz_codec_uncompress_batch", "gz_codec_assign_best",
     "gz_b250_generate", "gz_b250_generate_batch", "gz_local_generate", "gz_local_to_native",
-    "gz_vb_z_bound", "gz_vb_compress_batch", "gz_vb_uncompress", "gz_adler32",
+    "gz_vb_z_bound", "gz_vb_compress_batch", "gz_vb_uncompress", "gz_vb_uncompress_many", "gz_adler32",
     "gz_acgt_packed_len", "gz_acgt_pack", "gz_acgt_unpack",
     "gz_ctx_seg_columns", "gz_dyn_int_columns", "gz_local_blob_columns",
     "gz_text_lines", "gz_fastq_records", "gz_tokenize_column", "gz_seg_integer_or_not",
@@ -230,6 +230,8 @@ def load(path=None):
     L.gz_vb_z_bound.argtypes = [C.POINTER(GzSection), C.c_uint32]
     L.gz_vb_compress_batch.argtypes = [C.c_void_p, C.POINTER(GzVBlock), C.c_int]
     L.gz_vb_uncompress.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32)]
+    L.gz_vb_uncompress_many.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                        C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32)]
     L.gz_adler32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32)]
     L.gz_acgt_packed_len.restype = C.c_uint64
     L.gz_acgt_packed_len.argtypes = [C.c_uint64]

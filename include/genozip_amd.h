@@ -255,6 +255,14 @@ int gz_vb_compress_batch (GzHandle *h, GzVBlock *vbs, int n_vbs);
 int gz_vb_uncompress (GzHandle *h, const uint8_t *z_data, uint64_t z_len, uint8_t *out, uint64_t out_cap,
                       uint64_t *section_offsets_host, uint32_t max_sections, uint32_t *n_sections_out);
 
+/* the same for n_vbs VBlocks at once (what piz does per VBlock in zfile_read_section_do / comp_uncompress, src/zfile.c:212-218,
+ * src/compressor.c:196-246, here for a whole batch): the section headers of every VBlock are walked and every payload's adler32 is
+ * checked by two kernels, then ALL payloads of ALL VBlocks are decoded as one batch (gz_codec_uncompress_batch) - a wave per stream,
+ * hundreds of streams at a time. z_data[v] / out[v]: device; section_offsets_host: n_vbs rows of max_sections + 1 entries (or NULL);
+ * n_sections_out: n_vbs entries. Synchronous. */
+int gz_vb_uncompress_many (GzHandle *h, int n_vbs, const uint8_t *const *z_data, const uint64_t *z_len, uint8_t *const *out,
+                           const uint64_t *out_cap, uint64_t *section_offsets_host, uint32_t max_sections, uint32_t *n_sections_out);
+
 /* adler32 of a device buffer (libdeflate_adler32 as used by src/compressor.c:161). Synchronous. */
 int gz_adler32 (GzHandle *h, const uint8_t *data, uint64_t len, uint32_t *adler_out);
 

@@ -49,6 +49,9 @@ def chain_block_boundaries(E, oracle, big=True):
     got = E.compress_many(items)
     for (codec, d), g, nm in zip(items, got, names):
         assert g == oracle.codec_compress(codec, d), nm
+    back = E.uncompress_many([(codec, g, len(d)) for (codec, d), g in zip(items, got)])     # ... and a14: all of them decoded as one batch
+    for (codec, d), b, nm in zip(items, back, names):
+        assert b == d, ("decode", nm)
     return len(items)
 
 
@@ -89,6 +92,9 @@ def wide_models(E, oracle, big=True):
     got = E.compress_many(items)
     for (codec, d), g, nm in zip(items, got, names):
         assert g == oracle.codec_compress(codec, d), nm
+    back = E.uncompress_many([(codec, g, len(d)) for (codec, d), g in zip(items, got)])     # ... and a14: all of them decoded as one batch
+    for (codec, d), b, nm in zip(items, back, names):
+        assert b == d, ("decode", nm)
     return len(items)
 
 
@@ -128,6 +134,9 @@ def wide_models_random(E, oracle, n_cases, seed0=8800, max_n=30000, min_sym=65):
     got = E.compress_many(items)
     for (codec, d), g, nm in zip(items, got, names):
         assert g == oracle.codec_compress(codec, d), nm
+    back = E.uncompress_many([(codec, g, len(d)) for (codec, d), g in zip(items, got)])     # ... and a14: all of them decoded as one batch
+    for (codec, d), b, nm in zip(items, back, names):
+        assert b == d, ("decode", nm)
     return len(items)
 
 
@@ -336,6 +345,18 @@ def vblocks(E, oracle, n_vb, qual_len):
         total = sum(len(s.data) for s in vbs[v].sections)
         secs = E.vb_uncompress(g, total)
         assert secs == [bytes(s.data) for s in vbs[v].sections]
+    # ... and all VBlocks in one call: every section of every VBlock in one batch (gz_vb_uncompress_many)
+    totals = [sum(len(s.data) for s in vb.sections) for vb in vbs]
+    many = E.vb_uncompress_many(list(zip(got, totals)))
+    assert many == [[bytes(s.data) for s in vb.sections] for vb in vbs]
+    if len(got) > 1 and len(got[-1]) > 200:
+        import pytest
+        bad = bytearray(got[-1]); bad[150] ^= 0x40              # a payload byte of the last VBlock's first section: its adler32 no longer fits
+        with pytest.raises(RuntimeError):
+            E.vb_uncompress_many(list(zip(got[:-1] + [bytes(bad)], totals)))
+        cut = got[0][:len(got[0]) - 7]                           # a VBlock that ends in the middle of a section
+        with pytest.raises(RuntimeError):
+            E.vb_uncompress_many([(cut, totals[0])] + list(zip(got[1:], totals[1:])))
 
 
 def acgt(E, oracle, n):
