@@ -1886,7 +1886,7 @@ extern "C" int gz_vb_uncompress_many (GzHandle *h, int n_vbs, const uint8_t *con
             const GzdVbSec &sec = S[(size_t)v * max_sections + i];
             if (!sec.ok) { h->err = "section adler32 mismatch"; return GZ_ERR_CORRUPT; }
             if (offs) offs[i] = o;
-            if (sec.ulen) {
+            if (sec.ulen && codec_ok ((int)sec.codec)) {          // (a host coder's section - BZ2 / LZMA / BSC - is left to the caller's own uncompress: its bytes of `out` stay as they are)
                 GzStream s; memset (&s, 0, sizeof (s));
                 s.in = z_data[v] + sec.at; s.in_len = sec.clen; s.out = out[v] + o; s.out_cap = sec.ulen; s.codec = (int)sec.codec;
                 work.push_back (s);

@@ -259,7 +259,8 @@ int gz_vb_uncompress (GzHandle *h, const uint8_t *z_data, uint64_t z_len, uint8_
  * src/compressor.c:196-246, here for a whole batch): the section headers of every VBlock are walked and every payload's adler32 is
  * checked by two kernels, then ALL payloads of ALL VBlocks are decoded as one batch (gz_codec_uncompress_batch) - a wave per stream,
  * hundreds of streams at a time. z_data[v] / out[v]: device; section_offsets_host: n_vbs rows of max_sections + 1 entries (or NULL);
- * n_sections_out: n_vbs entries. Synchronous. */
+ * n_sections_out: n_vbs entries. A section coded by one of the host's coders (BZ2 / LZMA / BSC: gz_zip_set_host_codecs) is checked but not
+ * decoded: its stretch of out[v] is left untouched for the caller's own codec_args[codec].uncompress. Synchronous. */
 int gz_vb_uncompress_many (GzHandle *h, int n_vbs, const uint8_t *const *z_data, const uint64_t *z_len, uint8_t *const *out,
                            const uint64_t *out_cap, uint64_t *section_offsets_host, uint32_t max_sections, uint32_t *n_sections_out);
 
