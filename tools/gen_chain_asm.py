@@ -23,7 +23,18 @@ seven-instruction integer form on the scalar unit (rounds 1-3): 30.5 + the waits
 Everything between the labels is written here, loop control included: the compiler schedules nothing in it. The rest of a leaf that
 does not fill a block is the caller's.
 """
+import os
 import sys
+
+# (experiments only, tools/probes/chain_variants.sh: what each part of the loop costs - the product's header is made with none of these set)
+X_CKPT = int(os.environ.get("GZ_GEN_CKPT", "64"))            # a checkpoint every so many symbols (0: none)
+X_HOP = os.environ.get("GZ_GEN_HOP", "1") == "1"             # 0: no wait states and no DPP move at a lane's last symbol (WRONG results, timing only)
+X_PREP = os.environ.get("GZ_GEN_PREP", "1") == "1"           # 0: F and G are not made from the records (WRONG results)
+X_NOROT = os.environ.get("GZ_GEN_NOROT", "0")                # 1: every symbol reads the FIRST symbol's operand registers; inv / fg: only those do (WRONG results)
+X_SPREAD = int(os.environ.get("GZ_GEN_SPREAD", "0"))          # n > 0: the next block's loads are issued one at a time, n symbols into every 64, instead of eight in a row at the block's start
+X_X3 = os.environ.get("GZ_GEN_X3", "0") == "1"               # 1: 12 of a record's 16 bytes are loaded (the chain never looks at cum)
+X_ONE = os.environ.get("GZ_GEN_ONE", "0") == "1"             # 1: T = 1 + r * 2^-52 (the constant is the inline 1.0, inv is scaled by 2^-52, F by 2^52): one operand less from the register file
+X_CKPT_FORM = os.environ.get("GZ_GEN_CKPT_FORM", "sstore")   # sstore: v_readlane x 2 + s_store_dwordx2 (the product's); none-wait: the same without the s_nops
 
 PER = 8                         # symbols a lane takes in a row
 BLOCK = 64 * PER
@@ -49,43 +60,65 @@ def regset(base):
 
 SETS = [regset(FIRST), regset(FIRST + 8 * PER + 4)]
 CLOB_V = [50, 52, 53, 56, 57, 58, 59, 60, 61, 62, 63] + [r for s in SETS for r in range(s["first"], s["last"] + 1)]
-CLOB_S = [36, 37, 40, 41, 42, 44, 45, 46, 47]
+CLOB_S = [36, 37, 40, 41, 42, 44, 45, 46, 47] + ([38, 39] if X_SPREAD else [])
 BASE, NEXT, CK, TMP = "s[40:41]", "s[36:37]", "s[44:45]", "s[46:47]"     # NEXT = BASE + a block (beyond the 13-bit offset of a load)
 DPP = "wave_ror:1 row_mask:0xf bank_mask:0xf"
 
 
 def loads(a, s, base):
     for k in range(PER):
-        a(f"global_load_dwordx4 {s['rec'][k]}, {OFF}, {base} offset:{16 * k}")
+        if X_X3:
+            b = s['first'] + 8 * k
+            a(f"global_load_dwordx3 v[{b}:{b + 2}], {OFF}, {base} offset:{16 * k}")
+        else:
+            a(f"global_load_dwordx4 {s['rec'][k]}, {OFF}, {base} offset:{16 * k}")
 
 
 def block(a, cur, nxt, tag):
     """BLOCK symbols with the operand set `cur` (its loads were issued a block ago)"""
     a("s_waitcnt vmcnt(0)")
     a("s_cmp_lt_u32 s42, 2")                                 # the block after this one, if the call has one
-    a(f"s_cbranch_scc1 2{tag}f")
-    loads(a, nxt, NEXT)
-    a(f"2{tag}:")
-    for k in range(PER):                                     # F = freq * 2^-7, G = -2^52 * F (the low words are and stay 0)
+    if X_SPREAD:                                             # (no next block: the loads read this block's records again - nobody looks at them)
+        a("s_cselect_b32 s38, s40, s36")
+        a("s_cselect_b32 s39, s41, s37")
+    else:
+        a(f"s_cbranch_scc1 2{tag}f")
+        loads(a, nxt, NEXT)
+        a(f"2{tag}:")
+    for k in range(PER if X_PREP else 0):                    # F = freq * 2^-7, G = -2^52 * F (the low words are and stay 0)
         a(f"v_cvt_f64_u32 {cur['F'][k]}, {cur['fq'][k]}")
-    for k in range(PER):
-        a(f"v_add_u32 {cur['Fhi'][k]}, 0xff900000, {cur['Fhi'][k]}")       # exponent - 7
-    for k in range(PER):
-        a(f"v_add_u32 {cur['Ghi'][k]}, 0x83400000, {cur['Fhi'][k]}")       # exponent + 52, sign
+    if X_ONE:
+        for k in range(PER if X_PREP else 0):
+            a(f"v_add_u32 {cur['Fhi'][k]}, 0x02d00000, {cur['Fhi'][k]}")   # exponent - 7 + 52
+        for k in range(PER if X_PREP else 0):
+            a(f"v_xor_b32 {cur['Ghi'][k]}, 0x80000000, {cur['Fhi'][k]}")   # G = -F
+        for k in range(PER if X_PREP else 0):
+            a(f"v_add_u32 v{cur['first'] + 8 * k + 1}, 0xfcc00000, v{cur['first'] + 8 * k + 1}")   # inv * 2^-52
+    else:
+        for k in range(PER if X_PREP else 0):
+            a(f"v_add_u32 {cur['Fhi'][k]}, 0xff900000, {cur['Fhi'][k]}")       # exponent - 7
+        for k in range(PER if X_PREP else 0):
+            a(f"v_add_u32 {cur['Ghi'][k]}, 0x83400000, {cur['Fhi'][k]}")       # exponent + 52, sign
     a("s_nop 1")
     a(f"v_mov_b32_dpp {cur['Fphi']}, {cur['Fhi'][PER - 1]} {DPP}")          # the F and G before mine: the last of the lane before
     a(f"v_mov_b32_dpp {cur['Gphi']}, {cur['Ghi'][PER - 1]} {DPP}")
     for j in range(BLOCK):
         lane, k = divmod(j, PER)
-        if j % 64 == 0:                                      # the state before every 64th symbol goes out: it sits in lane j / PER
+        if j % 64 == 0 and X_CKPT and j % X_CKPT == 0:       # the state before every 64th symbol goes out: it sits in lane j / PER
             a("s_nop 0")
             a(f"v_readlane_b32 s46, {RLO}, {lane}")
             a(f"v_readlane_b32 s47, {RHI}, {lane}")
             a("s_nop 2")
             a(f"s_store_dwordx2 {TMP}, {CK}, 0x{8 * (j // 64):x}")
-        a(f"v_fma_f64 {T}, {R}, {cur['inv'][k]}, {C52}")
+        if X_SPREAD and j % 64 == X_SPREAD:
+            a(f"global_load_dwordx4 {nxt['rec'][j // 64]}, {OFF}, s[38:39] offset:{16 * (j // 64)}")
+        ki = 0 if X_NOROT in ("1", "inv") else k
+        kf = 0 if X_NOROT in ("1", "fg") else k
+        a(f"v_fma_f64 {T}, {R}, {cur['inv'][ki]}, {'1.0' if X_ONE else C52}")
         if k < PER - 1:                                      # the lane's next symbol: in place
-            a(f"v_fma_f64 {R}, {T}, {cur['F'][k]}, {cur['G'][k]}")
+            a(f"v_fma_f64 {R}, {T}, {cur['F'][kf]}, {cur['G'][kf]}")
+        elif not X_HOP:
+            a(f"v_fma_f64 {R}, {T}, {cur['Fp']}, {cur['Gp']}")
         else:                                                # the next lane's first symbol (lane 0: the next block's)
             a("s_nop 1")
             a(f"v_mov_b32_dpp {T2LO}, {TLO} {DPP}")
@@ -117,7 +150,7 @@ def body():
     a("v_mbcnt_lo_u32_b32 v50, -1, 0")
     a("v_mbcnt_hi_u32_b32 v50, -1, v50")
     a(f"v_mul_u32_u24 v50, {16 * PER}, v50")                 # lane * 16 * PER: my records
-    a("v_mov_b32 v53, 0x43300000")                           # the high word of 2^52 + r
+    a(f"v_mov_b32 v53, {'0x3ff00000' if X_ONE else '0x43300000'}")       # the high word of 2^52 + r (of 1 + r * 2^-52)
     a("v_mov_b32 v56, 0")
     a("v_mov_b32 v57, 0x43300000")
     a("v_mov_b32 v58, 0x7fffff")

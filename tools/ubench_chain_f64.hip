@@ -97,7 +97,11 @@ __global__ void __launch_bounds__(64) k_chain_int (const uint8_t *recs, uint32_t
     if (threadIdx.x == 0) out[blockIdx.x] = range;
 }
 
+#ifdef GZ_CHAIN_HDR
+#include GZ_CHAIN_HDR            // (tools/probes/chain_variants.sh: the loop with parts left out)
+#else
 #include "../genozip_amd/csrc/gz_chain_asm.h"
+#endif
 // records of the hop kernel: { inv (double), freq, cum }
 // one symbol, any total (the fast loop leaves blocks with a total below 256 to this)
 __device__ static inline void d_step_slow (uint32_t &rlo, uint32_t &rhi, const uint32_t *rec)
