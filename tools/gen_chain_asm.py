@@ -36,30 +36,40 @@ X_X3 = os.environ.get("GZ_GEN_X3", "0") == "1"               # 1: 12 of a record
 X_ONE = os.environ.get("GZ_GEN_ONE", "0") == "1"             # 1: T = 1 + r * 2^-52 (the constant is the inline 1.0, inv is scaled by 2^-52, F by 2^52): one operand less from the register file
 X_CKPT_FORM = os.environ.get("GZ_GEN_CKPT_FORM", "sstore")   # sstore: v_readlane x 2 + s_store_dwordx2 (the product's); none-wait: the same without the s_nops
 
-PER = 8                         # symbols a lane takes in a row
+PER = int(os.environ.get("GZ_GEN_PER", "8"))     # symbols a lane takes in a row
+RPS = 6 if PER > 8 else 8       # registers per symbol: beyond 8 symbols a lane F takes the place of freq and cum (6 x 16 x 2 sets + 8 = 200 registers)
 BLOCK = 64 * PER
 
 # registers
-R, T, T2 = "v[60:61]", "v[62:63]", "v[52:53]"      # T2 = { r read from the lane before, 0x43300000 }
-RLO, RHI, TLO, T2LO = "v60", "v61", "v62", "v52"
-C52 = "v[56:57]"                # 2^52
-MASK, EXPO, OFF = "v58", "v59", "v50"
-FIRST = 64
+LOWREGS = PER * RPS * 2 + 8 + 64 > 256          # 16 symbols a lane: the record registers are v56 .. v255, everything else moves below them
+_b = 40 if LOWREGS else 50
+OFF = f"v{_b}"
+T2, T2LO, T2HI = f"v[{_b + 2}:{_b + 3}]", f"v{_b + 2}", f"v{_b + 3}"      # T2 = { r read from the lane before, 0x43300000 }
+_c = _b + 4 if LOWREGS else 56
+C52, C52LO, C52HI = f"v[{_c}:{_c + 1}]", f"v{_c}", f"v{_c + 1}"          # 2^52
+MASK, EXPO = f"v{_c + 2}", f"v{_c + 3}"
+R, RLO, RHI = f"v[{_c + 4}:{_c + 5}]", f"v{_c + 4}", f"v{_c + 5}"
+T, TLO = f"v[{_c + 6}:{_c + 7}]", f"v{_c + 6}"
+FIXED_V = [_b, _b + 2, _b + 3] + list(range(_c, _c + 8))
+FIRST = _c + 8
 
 
 def regset(base):
-    """per symbol 8 registers: inv.lo inv.hi freq cum | F.lo (0) F.hi | G.lo (0) G.hi; then the F and G before mine (2 pairs)"""
-    sym = [base + 8 * k for k in range(PER)]
-    tail = base + 8 * PER
+    """per symbol 8 registers: inv.lo inv.hi freq cum | F.lo (0) F.hi | G.lo (0) G.hi; then the F and G before mine (2 pairs).
+    RPS == 6: inv.lo inv.hi freq cum | G.lo (0) G.hi, and F is made IN PLACE of freq and cum (v_cvt_f64_u32 of freq: low word 0)"""
+    sym = [base + RPS * k for k in range(PER)]
+    tail = base + RPS * PER
+    fo, go = (4, 6) if RPS == 8 else (2, 4)
     return dict(rec=[f"v[{b}:{b + 3}]" for b in sym], inv=[f"v[{b}:{b + 1}]" for b in sym], fq=[f"v{b + 2}" for b in sym],
-                F=[f"v[{b + 4}:{b + 5}]" for b in sym], Flo=[f"v{b + 4}" for b in sym], Fhi=[f"v{b + 5}" for b in sym],
-                G=[f"v[{b + 6}:{b + 7}]" for b in sym], Glo=[f"v{b + 6}" for b in sym], Ghi=[f"v{b + 7}" for b in sym],
+                F=[f"v[{b + fo}:{b + fo + 1}]" for b in sym], Flo=[f"v{b + fo}" for b in sym], Fhi=[f"v{b + fo + 1}" for b in sym],
+                G=[f"v[{b + go}:{b + go + 1}]" for b in sym], Glo=[f"v{b + go}" for b in sym], Ghi=[f"v{b + go + 1}" for b in sym],
                 Fp=f"v[{tail}:{tail + 1}]", Fplo=f"v{tail}", Fphi=f"v{tail + 1}", Gp=f"v[{tail + 2}:{tail + 3}]", Gplo=f"v{tail + 2}", Gphi=f"v{tail + 3}",
-                first=base, last=tail + 3)
+                first=base, last=tail + 3, invhi=[f"v{b + 1}" for b in sym])
 
 
-SETS = [regset(FIRST), regset(FIRST + 8 * PER + 4)]
-CLOB_V = [50, 52, 53, 56, 57, 58, 59, 60, 61, 62, 63] + [r for s in SETS for r in range(s["first"], s["last"] + 1)]
+SETS = [regset(FIRST), regset(FIRST + RPS * PER + 4)]
+assert SETS[1]['last'] <= 255, 'out of vector registers'
+CLOB_V = FIXED_V + [r for s in SETS for r in range(s["first"], s["last"] + 1)]
 CLOB_S = [36, 37, 40, 41, 42, 44, 45, 46, 47] + ([38, 39] if X_SPREAD else [])
 BASE, NEXT, CK, TMP = "s[40:41]", "s[36:37]", "s[44:45]", "s[46:47]"     # NEXT = BASE + a block (beyond the 13-bit offset of a load)
 DPP = "wave_ror:1 row_mask:0xf bank_mask:0xf"
@@ -68,7 +78,7 @@ DPP = "wave_ror:1 row_mask:0xf bank_mask:0xf"
 def loads(a, s, base):
     for k in range(PER):
         if X_X3:
-            b = s['first'] + 8 * k
+            b = s['first'] + RPS * k
             a(f"global_load_dwordx3 v[{b}:{b + 2}], {OFF}, {base} offset:{16 * k}")
         else:
             a(f"global_load_dwordx4 {s['rec'][k]}, {OFF}, {base} offset:{16 * k}")
@@ -93,7 +103,7 @@ def block(a, cur, nxt, tag):
         for k in range(PER if X_PREP else 0):
             a(f"v_xor_b32 {cur['Ghi'][k]}, 0x80000000, {cur['Fhi'][k]}")   # G = -F
         for k in range(PER if X_PREP else 0):
-            a(f"v_add_u32 v{cur['first'] + 8 * k + 1}, 0xfcc00000, v{cur['first'] + 8 * k + 1}")   # inv * 2^-52
+            a(f"v_add_u32 {cur['invhi'][k]}, 0xfcc00000, {cur['invhi'][k]}")   # inv * 2^-52
     else:
         for k in range(PER if X_PREP else 0):
             a(f"v_add_u32 {cur['Fhi'][k]}, 0xff900000, {cur['Fhi'][k]}")       # exponent - 7
@@ -138,8 +148,8 @@ def body():
     a = L.append
     # operands: [rlo] [rhi] (v, in/out): the state - in: the same in every lane; out: valid in lane 0
     #           [blo] [bhi] (s): the records of the first block; [nblk] (s): blocks, >= 1; [clo] [chi] (s): where the first checkpoint goes
-    a("v_mov_b32 v60, %[rlo]")
-    a("v_mov_b32 v61, %[rhi]")
+    a(f"v_mov_b32 {RLO}, %[rlo]")
+    a(f"v_mov_b32 {RHI}, %[rhi]")
     a("s_mov_b32 s40, %[blo]")
     a("s_mov_b32 s41, %[bhi]")
     a(f"s_add_u32 s36, s40, {16 * BLOCK}")
@@ -147,14 +157,14 @@ def body():
     a("s_mov_b32 s42, %[nblk]")
     a("s_mov_b32 s44, %[clo]")
     a("s_mov_b32 s45, %[chi]")
-    a("v_mbcnt_lo_u32_b32 v50, -1, 0")
-    a("v_mbcnt_hi_u32_b32 v50, -1, v50")
-    a(f"v_mul_u32_u24 v50, {16 * PER}, v50")                 # lane * 16 * PER: my records
-    a(f"v_mov_b32 v53, {'0x3ff00000' if X_ONE else '0x43300000'}")       # the high word of 2^52 + r (of 1 + r * 2^-52)
-    a("v_mov_b32 v56, 0")
-    a("v_mov_b32 v57, 0x43300000")
-    a("v_mov_b32 v58, 0x7fffff")
-    a("v_mov_b32 v59, 0x41000000")
+    a(f"v_mbcnt_lo_u32_b32 {OFF}, -1, 0")
+    a(f"v_mbcnt_hi_u32_b32 {OFF}, -1, {OFF}")
+    a(f"v_mul_u32_u24 {OFF}, {16 * PER}, {OFF}")                 # lane * 16 * PER: my records
+    a(f"v_mov_b32 {T2HI}, {'0x3ff00000' if X_ONE else '0x43300000'}")       # the high word of 2^52 + r (of 1 + r * 2^-52)
+    a(f"v_mov_b32 {C52LO}, 0")
+    a(f"v_mov_b32 {C52HI}, 0x43300000")
+    a(f"v_mov_b32 {MASK}, 0x7fffff")
+    a(f"v_mov_b32 {EXPO}, 0x41000000")
     for s in SETS:                                           # the low words of every F and G: 0, never written again (v_cvt_f64_u32 rewrites F's with 0)
         for k in range(PER):
             a(f"v_mov_b32 {s['Glo'][k]}, 0")
@@ -172,8 +182,8 @@ def body():
     a("9:")
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")
     a("s_nop 1")
-    a("v_mov_b32 %[rlo], v60")
-    a("v_mov_b32 %[rhi], v61")
+    a(f"v_mov_b32 %[rlo], {RLO}")
+    a(f"v_mov_b32 %[rhi], {RHI}")
     return L
 
 

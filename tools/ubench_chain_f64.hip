@@ -182,7 +182,7 @@ static uint32_t rnd () { rng_s ^= rng_s << 13; rng_s ^= rng_s >> 7; rng_s ^= rng
 
 int main (int argc, char **argv)
 {
-    const uint32_t n = 1u << 20;            // symbols per chain
+    const uint32_t n = 21504u * 48;         // symbols per chain: a multiple of every block size the generator can make (64 x 8 .. 16)
     const int max_blocks = 256;
     // records: a model-like sequence of (tot, freq): tot walks 32760..65519 in steps of 16 most of the time, sometimes small
     std::vector<uint32_t> ri ((size_t)n * 4), rf ((size_t)n * 4);
