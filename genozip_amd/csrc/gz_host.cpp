@@ -280,8 +280,10 @@ static void prof_collect (GzHandle *h)
         float ms = 0;
         if (hipEventElapsedTime (&ms, pr.a, pr.b) == hipSuccess) {
             bool found = false;
-            for (auto &acc : h->prof) if (acc.name == pr.name) { acc.ms += ms; acc.launches++; if (ms > acc.max_ms) acc.max_ms = ms; found = true; break; }
-            if (!found) { GzHandle::ProfAcc acc; acc.name = pr.name; acc.ms = ms; acc.launches = 1; acc.max_ms = ms; h->prof.push_back (acc); }
+            std::string nm (pr.name);                                  // ("k_arith_model<true>": one kernel under one name)
+            const size_t lt = nm.find ('<'); if (lt != std::string::npos) nm.resize (lt);
+            for (auto &acc : h->prof) if (acc.name == nm) { acc.ms += ms; acc.launches++; if (ms > acc.max_ms) acc.max_ms = ms; found = true; break; }
+            if (!found) { GzHandle::ProfAcc acc; acc.name = nm; acc.ms = ms; acc.launches = 1; acc.max_ms = ms; h->prof.push_back (acc); }
         }
         h->event_pool.push_back (pr.a); h->event_pool.push_back (pr.b);
     }
@@ -427,6 +429,7 @@ struct Plan {
     uint32_t max_in = 0;
     uint32_t max_arith_n = 0;              // largest plain (model/chain) arith leaf
     bool any_arith_o1 = false;
+    bool unpacked = false;                 // a stream of 2^24 bytes or more in the batch: the sorted lists keep ranks in an array of their own (positions need all 32 bits); else position << 8 | rank
     std::vector<uint32_t> plain_list, plain_nb, o1_list, rle_list;   // plain (model/chain) arith leaves and their size bounds; those of them that are order-1
 };
 
@@ -466,8 +469,8 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
             const size_t nt = ((size_t)nb + GZ_CTX_TILE - 1) / GZ_CTX_TILE;
             if (!(L.spos   = (uint32_t *)arena_alloc (h, ((size_t)nb + 64) * 4))) return false;
             // (a leaf of fewer than 2^24 positions keeps a position's symbol rank in the low byte of its spos entry: no srk, one scattered store)
-            L.srk = NULL;
-            if (nb >= (1u << 24) && !(L.srk = (uint8_t *)arena_alloc (h, (size_t)nb + 64))) return false;
+            L.srk = NULL;                                          // (one format for the whole batch: the model kernel is compiled for either, Plan::unpacked)
+            if (P.unpacked && !(L.srk = (uint8_t *)arena_alloc (h, (size_t)nb + 64))) return false;
             if (!(L.ctxoff = (uint32_t *)arena_alloc (h, (nt + 1) * nctx * 4))) return false;
             // one row per position chunk (no chunk is smaller than GZ_CHUNK_MIN - but for the first one, which goes in up to four pieces: a short leaf has few)
             const size_t rows = std::min<size_t> (GZ_MAX_CHUNKS, (size_t)nb / GZ_CHUNK_MIN + 6);
@@ -743,7 +746,8 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
             };
             if (!A.pipelined) {
                 if ((rc = sort_chunk (h->stream, A.d_plain, A.np, 0u, 0xffffffffu, P.max_arith_n, 0u)) != GZ_OK) return rc;
-                KLAUNCH (h, k_arith_model, GZ_XCD_DIM (A.np, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_plain, A.np, inv_tab, 0u, 0xffffffffu, 0u);
+                if (P.unpacked) KLAUNCH (h, k_arith_model<false>, GZ_XCD_DIM (A.np, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_plain, A.np, inv_tab, 0u, 0xffffffffu, 0u);
+                else            KLAUNCH (h, k_arith_model<true>,  GZ_XCD_DIM (A.np, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_plain, A.np, inv_tab, 0u, 0xffffffffu, 0u);
                 KLAUNCH (h, k_arith_chain, dim3 ((A.np + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), 64,
                          d_leaves, A.d_plain, A.np, (const uint32_t *)NULL, (const uint32_t *)NULL, h->d_fail, (uint32_t *)NULL, 0u);
             }
@@ -767,7 +771,8 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                     if ((rc = sort_chunk (sort_stream, A.d_big, A.nbig, p0, len, span, k)) != GZ_OK) return rc;
                     HIPCHK (h, hipEventRecord (h->ev_sort[k], sort_stream));
                     HIPCHK (h, hipStreamWaitEvent (h->stream4, h->ev_sort[k], 0));
-                    KLAUNCH_ON (h, h->stream4, k_arith_model, GZ_XCD_DIM (A.nbig, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_big, A.nbig, inv_tab, p0, len, k);
+                    if (P.unpacked) KLAUNCH_ON (h, h->stream4, k_arith_model<false>, GZ_XCD_DIM (A.nbig, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_big, A.nbig, inv_tab, p0, len, k);
+                    else            KLAUNCH_ON (h, h->stream4, k_arith_model<true>,  GZ_XCD_DIM (A.nbig, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_big, A.nbig, inv_tab, p0, len, k);
                     hipLaunchKernelGGL (k_arith_progress, dim3 (1), dim3 (1), 0, h->stream4, A.d_progress, k + 1);
                 }
 #ifdef GZ_SEQUENTIAL_STREAMS
@@ -779,7 +784,8 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 if (A.nsmall) {
                     HIPCHK (h, hipStreamWaitEvent (h->stream5, h->ev_model_fork, 0));
                     if ((rc = sort_chunk (h->stream5, A.d_small, A.nsmall, 0u, 0xffffffffu, A.chunk, 0u)) != GZ_OK) return rc;
-                    KLAUNCH_ON (h, h->stream5, k_arith_model, GZ_XCD_DIM (A.nsmall, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_small, A.nsmall, inv_tab, 0u, 0xffffffffu, 0u);
+                    if (P.unpacked) KLAUNCH_ON (h, h->stream5, k_arith_model<false>, GZ_XCD_DIM (A.nsmall, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_small, A.nsmall, inv_tab, 0u, 0xffffffffu, 0u);
+                    else            KLAUNCH_ON (h, h->stream5, k_arith_model<true>,  GZ_XCD_DIM (A.nsmall, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_small, A.nsmall, inv_tab, 0u, 0xffffffffu, 0u);
                     KLAUNCH_ON (h, h->stream5, k_arith_chain, dim3 ((A.nsmall + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), GZ_KEEP_OFF_LDS,
                                 d_leaves, A.d_small, A.nsmall, (const uint32_t *)NULL, (const uint32_t *)NULL, h->d_fail, (uint32_t *)NULL, 0u);
                     if (A.nlb_small) {
@@ -841,6 +847,7 @@ extern "C" int gz_codec_compress_batch (GzHandle *h, GzStream *streams, int n_st
     HIPCHK (h, hipSetDevice (h->device));
     Plan P;
     P.streams.resize (n_streams);
+    for (int i = 0; i < n_streams; i++) if (streams[i].in_len >= (1u << 24)) P.unpacked = true;
     for (int i = 0; i < n_streams; i++) {
         GzStream &u = streams[i];
         GzdStream &S = P.streams[i];
@@ -891,6 +898,7 @@ extern "C" int gz_vb_compress_batch (GzHandle *h, GzVBlock *vbs, int n_vbs)
     const auto tm0 = std::chrono::steady_clock::now ();
     Plan P;
     std::vector<GzdVB> V (n_vbs);
+    for (int v = 0; v < n_vbs; v++) for (uint32_t k = 0; k < vbs[v].n_sections; k++) if (vbs[v].sections[k].data_len >= (1u << 24)) P.unpacked = true;
     for (int v = 0; v < n_vbs; v++) {
         GzVBlock &u = vbs[v];
         GzdVB &D = V[v];

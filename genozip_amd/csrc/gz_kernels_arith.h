@@ -774,7 +774,7 @@ __device__ unsigned long long g_mph[9];
 #ifndef GZ_ROUNDS_MINJ
 #define GZ_ROUNDS_MINJ 2                   // (-DGZ_ROUNDS_MINJ=1: the one-plane models in rounds as well)
 #endif
-template <int J>
+template <int J, bool PK>                   // PK: the sorted lists of this batch carry position << 8 | rank (no srk array): k_ctx_scatter
 __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, uint32_t ms, bool o1, uint4 *recs,
                                                    const GzDivInv *inv_tab, const uint8_t *symlist, const uint16_t *symrank, uint32_t nsym,
                                                    const uint32_t *spos, const uint8_t *srk, uint32_t j0, uint32_t j1, bool first, bool save, uint32_t *st,
@@ -828,11 +828,15 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
     //  under a condition leaves the compiler merging old and new value through a copy that has to wait for the load on the spot, and a
     //  load through a generic pointer is a FLAT one, for which it waits with vmcnt (0): measured inside the kernel, 0.5 of the 1.5 us of
     //  a quiet batch were that wait, once every four batches for the whole trip to memory)
+    //  (Round 5: the same holds for a CHOICE between loads at run time - with "if (srk) two loads else one" inside the sorted case the hot
+    //  context's wave of the VCF configuration, an UNSORTED one, took 10 % longer: 784 -> 864 ms of k_arith_model per step, found by
+    //  bisecting; selected addresses or always-the-same-loads variants: 815 - 868. So which of the two list formats a batch has is a
+    //  template parameter of the kernel, and the host keeps a batch to one format.)
     auto fetch_raw = [&] (uint32_t at, uint32_t &pos, uint32_t &raw) {
         const uint32_t a = at < j1 ? at : (j1 ? j1 - 1 : 0u);
         if (o1) {
-            if (srk) { pos = gz_ldg_u32 (spos + a); raw = gz_ldg_u8 (srk + a); }
-            else { const uint32_t w = gz_ldg_u32 (spos + a); pos = w >> 8; raw = w & 0xff; }       // (position and rank in one entry: k_ctx_scatter)
+            if constexpr (PK) { const uint32_t w = gz_ldg_u32 (spos + a); pos = w >> 8; raw = w & 0xff; }
+            else { pos = gz_ldg_u32 (spos + a); raw = gz_ldg_u8 (srk + a); }
         }
         else    { pos = a; raw = gz_ldg_u8 (in + a); }
     };
@@ -929,6 +933,7 @@ __device__ unsigned long long g_model_slowest;     // (10 ns ticks << 40) | (lis
 #define GZ_MODEL_T0 do {} while (0)
 #define GZ_MODEL_T1(ctx, occ) do {} while (0)
 #endif
+template <bool PK>
 __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const GzDivInv *inv_tab, uint32_t p0, uint32_t chunk, uint32_t row)
 {
     GZ_XCD_GRID (li, by, n_list);
@@ -964,7 +969,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
             const uint32_t ctx = 256 + k;
             const uint32_t j0 = d_uniform (off[(size_t)t0 * nctx + ctx]), j1 = d_uniform (cend[ctx]);
             if (j0 == j1 && p0) continue;
-            d_arith_model_wave<1> (coded, 4u, true, tr, inv_tab, digits, L.symrank, 4u, spos, srk, j0, j1, p0 == 0, p1 < n_u,
+            d_arith_model_wave<1, PK> (coded, 4u, true, tr, inv_tab, digits, L.symrank, 4u, spos, srk, j0, j1, p0 == 0, p1 < n_u,
                                    mstate + (size_t)ctx * (GZ_MSTATE_WORDS * 64));
         }
         return;
@@ -982,7 +987,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
         uint32_t j0 = p0, j1 = p1;
         if (sorted) { j0 = d_uniform (off[(size_t)t0 * nctx + ctx]); j1 = d_uniform (cend[ctx]); }   // my run of the sorted lists
         GZ_MODEL_T0;
-        d_arith_model_wave<1> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        d_arith_model_wave<1, PK> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
         GZ_MODEL_T1 (ctx, j1 - j0);
         return;
     }
@@ -999,7 +1004,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
             uint8_t *lds_flags = gz_lds, *lds_list = gz_lds + 256;
             const uint32_t nd = d_local_alphabet (la, coded, sorted, spos, srk, L.symrank, L.symlist, j0, j1, lds_flags, lds_list);
             if (nd <= 64) {
-                d_arith_model_wave<1> (coded, ms_u, sorted, tr, inv_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, true, false, st, &la);
+                d_arith_model_wave<1, PK> (coded, ms_u, sorted, tr, inv_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, true, false, st, &la);
                 GZ_MODEL_T1 (ctx, j1 - j0);
                 continue;
             }
@@ -1017,14 +1022,14 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
                 #pragma unroll
                 for (int k = 0; k < 4; k++) if ((la.m[k] >> (threadIdx.x & 63)) & 1) lds_list[d_local_rank (la, (uint32_t)(k * 64 + (threadIdx.x & 63)))] = L.symlist[k * 64 + (threadIdx.x & 63)];
                 __syncthreads ();
-                if (nd <= 64) d_arith_model_wave<1> (coded, ms_u, sorted, tr, inv_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, &la);
-                else          d_arith_model_wave<2> (coded, ms_u, sorted, tr, inv_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, &la);
+                if (nd <= 64) d_arith_model_wave<1, PK> (coded, ms_u, sorted, tr, inv_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, &la);
+                else          d_arith_model_wave<2, PK> (coded, ms_u, sorted, tr, inv_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, &la);
                 GZ_MODEL_T1 (ctx, j1 - j0);
                 continue;
             }
         }
-        if (nsym_u <= 128) d_arith_model_wave<2> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
-        else               d_arith_model_wave<4> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        if (nsym_u <= 128) d_arith_model_wave<2, PK> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        else               d_arith_model_wave<4, PK> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
         GZ_MODEL_T1 (ctx, j1 - j0);
     }
 }
