@@ -23,8 +23,13 @@ for f in ("bench_stats.json", "bench_fetch.json", "bench_write.json"):
 def agg(path, cname):
     out = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == cname and r["Kernel_Name"].startswith("k_"):
-            out[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        name = r["Kernel_Name"]
+        if name.startswith("void "):                                  # (a kernel template: "void k_arith_model<true>(...)" - one kernel under one name)
+            name = name[5:]
+        if "<" in name.split("(")[0]:
+            name = name.split("<")[0] + "(" + name.split("(", 1)[1] if "(" in name else name.split("<")[0]
+        if r["Counter_Name"] == cname and name.startswith("k_"):
+            out[name].append(float(r["Counter_Value"]))
     return out
 
 
