@@ -84,7 +84,6 @@ __device__ static inline void gz_wave_sync (void) { __builtin_amdgcn_fence (__AT
 
 // v_rcp_f64: the reciprocal to about one ulp (not the IEEE division sequence)
 __device__ static inline double gz_rcp_f64 (double x) { return __builtin_amdgcn_rcp (x); }
-__device__ static inline uint32_t gz_mul_u24 (uint32_t a, uint32_t b) { uint32_t d; asm ("v_mul_u32_u24 %0, %1, %2" : "=v" (d) : "v" (a), "v" (b)); return d; }   // a, b < 2^24: v_mul_u32_u24, full rate
 // ---- the arithmetic decoder's hand-over of the entry that is hit (gz_kernels_dec.h) ----
 // lane l's x as seen by lane l + 1 (lane 0 keeps `fill`): v_mov_b32_dpp wave_shr:1
 __device__ static inline uint32_t gz_wave_shr1 (uint32_t x, uint32_t fill) { return (uint32_t)__builtin_amdgcn_update_dpp ((int)fill, (int)x, 0x138, 0xf, 0xf, false); }

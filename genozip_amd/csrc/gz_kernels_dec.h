@@ -341,13 +341,10 @@ __global__ void __launch_bounds__(64) k_rans_decode (GzdDecLeaf *leaves)
 
 // ---- adaptive arithmetic decoder (c_range_coder.h:55-68,111-127, c_simple_model.h:148-179) --------------------
 // The decoder cannot be taken apart the way the encoder is (models / chain / low): which symbol comes next depends on the coder's
-// state. What CAN be spread over the wave is the model: every lane holds list entries (lane, lane + 64, ...) and a symbol is found
-// by all lanes at once - entry e carries its frequency AND its cumulative frequency, so "cum <= target < cum + freq" is one compare
-// per lane and a ballot, where the reference (and this kernel's first form, one lane walking the list in LDS) searches linearly.
-// Coding a symbol then costs every lane one LDS read and one LDS write of its entry (cum += 16 behind the symbol), the halving every
-// ~2000 symbols of a context rebuilds the cumulatives. A model = [tot, -, (freq | sym << 16, cum) x max_sym] in LDS (order 1 with up
-// to 140 symbols: 156 KB) or, beyond that, in global memory. The coded bytes are read 64 at a time (one per lane) and handed out by
-// v_readlane. Measured ... see DESIGN.md (decode).
+// state - one wave decodes a stream. Two routines share the range decoder below: d_model_decode, round 3's general one (a model row
+// [tot, -, (freq | sym << 16, cum) x max_sym] in the LDS or in global memory, read and written back around every symbol, two divisions,
+// ballot + v_readlane) - it still serves the run-length models of arith_dynamic.c:476-487, which Genozip never writes - and the literal
+// models' d_lit_fast / d_lit_slow further down (round 5), built on measured instruction costs. Measured: DESIGN.md section 3 (Decode).
 #define GZ_DEC_BAD 0xffffffffu
 // The coded bytes: a window of 256 of them in a register (lane l: the big-endian word at wbase + 4 l, zeros beyond the stream), from which
 // W - the next wvalid (a multiple of 8, >= 16 whenever a symbol starts) bits of the stream, at the top of 64 - is topped up a word at a time;
