@@ -33,24 +33,28 @@ X_PREP = os.environ.get("GZ_GEN_PREP", "1") == "1"           # 0: F and G are no
 X_NOROT = os.environ.get("GZ_GEN_NOROT", "0")                # 1: every symbol reads the FIRST symbol's operand registers; inv / fg: only those do (WRONG results)
 X_SPREAD = int(os.environ.get("GZ_GEN_SPREAD", "0"))          # n > 0: the next block's loads are issued one at a time, n symbols into every 64, instead of eight in a row at the block's start
 X_X3 = os.environ.get("GZ_GEN_X3", "0") == "1"               # 1: 12 of a record's 16 bytes are loaded (the chain never looks at cum)
+X_COAL = os.environ.get("GZ_GEN_COALESCED", "0") == "1"      # 1: load k of a block reads 1 KB in a row (lane l: record 64 k + l) - what a block-transposed record layout would give (WRONG results with today's layout)
+X_TOUCH = os.environ.get("GZ_GEN_TOUCH", "0") == "1"          # 1: two one-dword loads per block touch every line of the block AFTER the next one (its records, and the page, are then near when the real loads ask)
 X_ONE = os.environ.get("GZ_GEN_ONE", "0") == "1"             # 1: T = 1 + r * 2^-52 (the constant is the inline 1.0, inv is scaled by 2^-52, F by 2^52): one operand less from the register file
 X_CKPT_FORM = os.environ.get("GZ_GEN_CKPT_FORM", "sstore")   # sstore: v_readlane x 2 + s_store_dwordx2 (the product's); none-wait: the same without the s_nops
 
 PER = int(os.environ.get("GZ_GEN_PER", "8"))     # symbols a lane takes in a row
-RPS = 6 if PER > 8 else 8       # registers per symbol: beyond 8 symbols a lane F takes the place of freq and cum (6 x 16 x 2 sets + 8 = 200 registers)
+RPS = int(os.environ.get("GZ_GEN_RPS", "6" if PER > 8 else "8"))   # registers per symbol: beyond 8 symbols a lane F takes the place of freq and cum (6 x 16 x 2 sets + 8 = 200 registers)
 BLOCK = 64 * PER
 
 # registers
-LOWREGS = PER * RPS * 2 + 8 + 64 > 256          # 16 symbols a lane: the record registers are v56 .. v255, everything else moves below them
+LOWREGS = PER * RPS * 2 + 8 + 64 > 256 or os.environ.get("GZ_GEN_LOW", "0") == "1"          # 16 symbols a lane: the record registers are v56 .. v255, everything else moves below them
 _b = 40 if LOWREGS else 50
 OFF = f"v{_b}"
+OFF2 = f"v{_b + 1}"
+OFFT, TCH0, TCH1 = f"v{_b - 3}", f"v{_b - 2}", f"v{_b - 1}"      # (GZ_GEN_TOUCH: lane * 128, two registers nobody reads)
 T2, T2LO, T2HI = f"v[{_b + 2}:{_b + 3}]", f"v{_b + 2}", f"v{_b + 3}"      # T2 = { r read from the lane before, 0x43300000 }
 _c = _b + 4 if LOWREGS else 56
 C52, C52LO, C52HI = f"v[{_c}:{_c + 1}]", f"v{_c}", f"v{_c + 1}"          # 2^52
 MASK, EXPO = f"v{_c + 2}", f"v{_c + 3}"
 R, RLO, RHI = f"v[{_c + 4}:{_c + 5}]", f"v{_c + 4}", f"v{_c + 5}"
 T, TLO = f"v[{_c + 6}:{_c + 7}]", f"v{_c + 6}"
-FIXED_V = [_b, _b + 2, _b + 3] + list(range(_c, _c + 8))
+FIXED_V = [_b, _b + 2, _b + 3] + ([_b + 1] if X_COAL else []) + ([_b - 3, _b - 2, _b - 1] if X_TOUCH else []) + list(range(_c, _c + 8))
 FIRST = _c + 8
 
 
@@ -70,7 +74,7 @@ def regset(base):
 SETS = [regset(FIRST), regset(FIRST + RPS * PER + 4)]
 assert SETS[1]['last'] <= 255, 'out of vector registers'
 CLOB_V = FIXED_V + [r for s in SETS for r in range(s["first"], s["last"] + 1)]
-CLOB_S = [36, 37, 40, 41, 42, 44, 45, 46, 47] + ([38, 39] if X_SPREAD else [])
+CLOB_S = [36, 37, 40, 41, 42, 44, 45, 46, 47] + ([38, 39] if X_SPREAD or X_TOUCH else [])
 BASE, NEXT, CK, TMP = "s[40:41]", "s[36:37]", "s[44:45]", "s[46:47]"     # NEXT = BASE + a block (beyond the 13-bit offset of a load)
 DPP = "wave_ror:1 row_mask:0xf bank_mask:0xf"
 
@@ -80,13 +84,15 @@ def loads(a, s, base):
         if X_X3:
             b = s['first'] + RPS * k
             a(f"global_load_dwordx3 v[{b}:{b + 2}], {OFF}, {base} offset:{16 * k}")
+        elif X_COAL:                                         # (a load's offset field takes up to 4095: the second half of the block through a second address register)
+            a(f"global_load_dwordx4 {s['rec'][k]}, {OFF if k < 4 else OFF2}, {base} offset:{1024 * (k % 4)}")
         else:
             a(f"global_load_dwordx4 {s['rec'][k]}, {OFF}, {base} offset:{16 * k}")
 
 
 def block(a, cur, nxt, tag):
     """BLOCK symbols with the operand set `cur` (its loads were issued a block ago)"""
-    a("s_waitcnt vmcnt(0)")
+    a("s_waitcnt vmcnt(2)" if X_TOUCH else "s_waitcnt vmcnt(0)")     # (the two touches were asked for after this block's records: they may still be on their way)
     a("s_cmp_lt_u32 s42, 2")                                 # the block after this one, if the call has one
     if X_SPREAD:                                             # (no next block: the loads read this block's records again - nobody looks at them)
         a("s_cselect_b32 s38, s40, s36")
@@ -95,6 +101,14 @@ def block(a, cur, nxt, tag):
         a(f"s_cbranch_scc1 2{tag}f")
         loads(a, nxt, NEXT)
         a(f"2{tag}:")
+    if X_TOUCH:                                              # (fewer than three blocks left: this block's records again)
+        a("s_cmp_lt_u32 s42, 3")
+        a(f"s_add_u32 s38, s36, {16 * BLOCK}")
+        a("s_addc_u32 s39, s37, 0")
+        a("s_cselect_b32 s38, s40, s38")
+        a("s_cselect_b32 s39, s41, s39")
+        a(f"global_load_dword {TCH0}, {OFFT}, s[38:39] offset:0")
+        a(f"global_load_dword {TCH1}, {OFFT}, s[38:39] offset:64")
     for k in range(PER if X_PREP else 0):                    # F = freq * 2^-7, G = -2^52 * F (the low words are and stay 0)
         a(f"v_cvt_f64_u32 {cur['F'][k]}, {cur['fq'][k]}")
     if X_ONE:
@@ -159,7 +173,13 @@ def body():
     a("s_mov_b32 s45, %[chi]")
     a(f"v_mbcnt_lo_u32_b32 {OFF}, -1, 0")
     a(f"v_mbcnt_hi_u32_b32 {OFF}, -1, {OFF}")
-    a(f"v_mul_u32_u24 {OFF}, {16 * PER}, {OFF}")                 # lane * 16 * PER: my records
+    a(f"v_mul_u32_u24 {OFF}, {16 if X_COAL else 16 * PER}, {OFF}")
+    if X_COAL:
+        a(f"v_add_u32 {OFF2}, 0x1000, {OFF}")
+    if X_TOUCH:
+        a(f"v_mbcnt_lo_u32_b32 {OFFT}, -1, 0")
+        a(f"v_mbcnt_hi_u32_b32 {OFFT}, -1, {OFFT}")
+        a(f"v_mul_u32_u24 {OFFT}, {BLOCK * 16 // 64}, {OFFT}")                 # lane * 16 * PER: my records
     a(f"v_mov_b32 {T2HI}, {'0x3ff00000' if X_ONE else '0x43300000'}")       # the high word of 2^52 + r (of 1 + r * 2^-52)
     a(f"v_mov_b32 {C52LO}, 0")
     a(f"v_mov_b32 {C52HI}, 0x43300000")
