@@ -38,7 +38,7 @@ X_TOUCH = os.environ.get("GZ_GEN_TOUCH", "0") == "1"          # 1: two one-dword
 X_ONE = os.environ.get("GZ_GEN_ONE", "0") == "1"             # 1: T = 1 + r * 2^-52 (the constant is the inline 1.0, inv is scaled by 2^-52, F by 2^52): one operand less from the register file
 X_CKPT_FORM = os.environ.get("GZ_GEN_CKPT_FORM", "sstore")   # sstore: v_readlane x 2 + s_store_dwordx2 (the product's); none-wait: the same without the s_nops
 
-PER = int(os.environ.get("GZ_GEN_PER", "8"))     # symbols a lane takes in a row
+PER = int(os.environ.get("GZ_GEN_PER", "12"))    # symbols a lane takes in a row (8 until round 5: 12 - 14 are ~0.6 ms faster on the default step, 16 slower: DESIGN.md section 3)
 RPS = int(os.environ.get("GZ_GEN_RPS", "6" if PER > 8 else "8"))   # registers per symbol: beyond 8 symbols a lane F takes the place of freq and cum (6 x 16 x 2 sets + 8 = 200 registers)
 BLOCK = 64 * PER
 
