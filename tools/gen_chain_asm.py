@@ -34,7 +34,7 @@ X_NOROT = os.environ.get("GZ_GEN_NOROT", "0")                # 1: every symbol r
 X_SPREAD = int(os.environ.get("GZ_GEN_SPREAD", "0"))          # n > 0: the next block's loads are issued one at a time, n symbols into every 64, instead of eight in a row at the block's start
 X_X3 = os.environ.get("GZ_GEN_X3", "0") == "1"               # 1: 12 of a record's 16 bytes are loaded (the chain never looks at cum)
 X_COAL = os.environ.get("GZ_GEN_COALESCED", "0") == "1"      # 1: load k of a block reads 1 KB in a row (lane l: record 64 k + l) - what a block-transposed record layout would give (WRONG results with today's layout)
-X_TOUCH = os.environ.get("GZ_GEN_TOUCH", "0") == "1"          # 1: two one-dword loads per block touch every line of the block AFTER the next one (its records, and the page, are then near when the real loads ask)
+X_TOUCH = os.environ.get("GZ_GEN_TOUCH", "0") == "1"          # (micro-benchmark only - the step faulted with it) 1: two one-dword loads per block touch every line of the block AFTER the next one (its records, and the page, are then near when the real loads ask)
 X_ONE = os.environ.get("GZ_GEN_ONE", "0") == "1"             # 1: T = 1 + r * 2^-52 (the constant is the inline 1.0, inv is scaled by 2^-52, F by 2^52): one operand less from the register file
 X_CKPT_FORM = os.environ.get("GZ_GEN_CKPT_FORM", "sstore")   # sstore: v_readlane x 2 + s_store_dwordx2 (the product's); none-wait: the same without the s_nops
 
