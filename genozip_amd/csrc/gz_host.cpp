@@ -205,16 +205,17 @@ static GzHandle *gz_create_do (int device, void *hip_stream, int *err, bool back
         if (h->own_stream) (void)hipStreamDestroy (h->stream);
         delete h; if (err) *err = GZ_ERR_HIP; return NULL;
     }
-    // range / tot of the range coder (c_range_coder.h:100) as the low word of fma (range * 2^-7, inv, 2^52) rounded toward zero
+    // range / tot of the range coder (c_range_coder.h:100) as the low word of fma (range * 2^-7, inv, 1.0) rounded toward zero
     // (gz_kernels_arith.h): inv = 2^7 / tot rounded UP to a double - the quotient of the two doubles rounded to nearest, one step up
-    // if that fell below (the fma gives the sign of inv * tot - 2^7 exactly). tot <= 65519 + 16
+    // if that fell below (the fma gives the sign of inv * tot - 2^7 exactly) - times 2^-52 (exact). tot <= 65519 + 16
     {
         const uint32_t N = 65536 + 32;
         std::vector<GzDivInv> mt (N);
-        mt[0].lo = 0; mt[0].hi = 0x40600000u;                   // (128.0: never used)
+        mt[0].lo = 0; mt[0].hi = 0x40600000u - (52u << 20);    // (128.0 * 2^-52: never used)
         for (uint32_t dv = 1; dv < N; dv++) {
             double inv = 128.0 / (double)dv;
             if (fma (inv, (double)dv, -128.0) < 0.0) inv = nextafter (inv, 1e300);
+            inv = ldexp (inv, -52);
             uint64_t bits; memcpy (&bits, &inv, 8);
             mt[dv].lo = (uint32_t)bits; mt[dv].hi = (uint32_t)(bits >> 32);
         }
@@ -456,7 +457,7 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
         // what the coder sees: the bytes, or (run-length variant) up to 2 coding events per byte
         const uint32_t nb = rle ? 2 * n_bound : n_bound;
         const uint32_t nctx = rle ? 768 : 256;
-        if (!(L.triples = (uint8_t *)arena_alloc (h, ((size_t)nb + 64) * 16 + 16384))) return false;
+        if (!(L.triples = (uint8_t *)arena_alloc (h, ((size_t)nb + 64) * GZ_CHAIN_REC + 16384))) return false;
         if (!(L.events  = (uint8_t *)arena_alloc (h, ((size_t)L.pay_cap + 128) * 4))) return false;
         if (!(L.rvals   = (uint8_t *)arena_alloc (h, ((size_t)nb + 64) * 4))) return false;
         const uint32_t ns = nb ? (nb + GZ_LOW_SLICE - 1) / GZ_LOW_SLICE : 1;
@@ -584,8 +585,13 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
     // position chunks: at most 32 per leaf (4 MB VBlocks - 8: 38.0 ms, 12: 37.7, 16: 37.6), none smaller than GZ_CHUNK_MIN, whole sort tiles
     uint32_t want_chunks = 32;                                  // (16 -> 32: the first chunk's models are the lead-in of the long streams; default step 96.2 -> 95.1 ms, streamed 280.8 -> 277.1)
     if (const char *e = getenv ("GZ_ARITH_CHUNKS")) { const int v = atoi (e); if (v >= 1 && v <= GZ_MAX_CHUNKS - 1) want_chunks = (uint32_t)v; }   // (experiments)
-    A.chunk = ((P.max_arith_n + want_chunks - 1) / want_chunks + GZ_CTX_TILE - 1) & ~(GZ_CTX_TILE - 1);
+    // (whole sort tiles AND whole blocks of the chain's loop: what a chunk leaves over goes one symbol at a time, d_chain_slow - with blocks
+    //  of 768 symbols and chunks of whole tiles only, 256 symbols of every chunk did)
+    uint32_t unit = GZ_CTX_TILE;
+    while (unit % GZ_CHAIN_BLOCK) unit += GZ_CTX_TILE;
+    A.chunk = (P.max_arith_n + want_chunks - 1) / want_chunks;
     if (A.chunk < GZ_CHUNK_MIN) A.chunk = GZ_CHUNK_MIN;
+    A.chunk = (A.chunk + unit - 1) / unit * unit;
     A.n_chunks = P.max_arith_n ? (P.max_arith_n + A.chunk - 1) / A.chunk : 1;
     // The chain of a long leaf can only start once the sort and the models of its first position chunk are through: the lead-in of the
     // whole step (0.9 ms of the default FASTQ step's 4.4 before the chain has its first records). GZ_ARITH_FIRST_SPLIT=1 lets the first
@@ -695,7 +701,7 @@ static int arith_launch_chain (GzHandle *h, const ArithPipe &A, GzdLeaf *d_leave
     HIPCHK (h, hipEventRecord (h->ev_chain_go, h->stream));                     // (behind the uploads and the memset)
     HIPCHK (h, hipStreamWaitEvent (h->stream3, h->ev_chain_go, 0));
     KLAUNCH_ON (h, h->stream3, k_arith_chain, dim3 ((A.nbig + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), A.reserve_cu ? GZ_CHAIN_LDS : 64,
-                d_leaves, A.d_big, A.nbig, (const uint32_t *)A.d_progress, (const uint32_t *)A.d_bounds, h->d_fail, A.d_progress + 16, A.n_chunks);
+                d_leaves, A.d_big, A.nbig, (const GzDivInv *)h->d_inv_tab, (const uint32_t *)A.d_progress, (const uint32_t *)A.d_bounds, h->d_fail, A.d_progress + 16, A.n_chunks);
     HIPCHK (h, hipEventRecord (h->ev_chain, h->stream3));
     return GZ_OK;
 }
@@ -746,10 +752,10 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
             };
             if (!A.pipelined) {
                 if ((rc = sort_chunk (h->stream, A.d_plain, A.np, 0u, 0xffffffffu, P.max_arith_n, 0u)) != GZ_OK) return rc;
-                if (P.unpacked) KLAUNCH (h, k_arith_model<false>, GZ_XCD_DIM (A.np, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_plain, A.np, inv_tab, 0u, 0xffffffffu, 0u);
-                else            KLAUNCH (h, k_arith_model<true>,  GZ_XCD_DIM (A.np, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_plain, A.np, inv_tab, 0u, 0xffffffffu, 0u);
+                if (P.unpacked) KLAUNCH (h, k_arith_model<false>, GZ_XCD_DIM (A.np, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_plain, A.np, 0u, 0xffffffffu, 0u);
+                else            KLAUNCH (h, k_arith_model<true>,  GZ_XCD_DIM (A.np, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_plain, A.np, 0u, 0xffffffffu, 0u);
                 KLAUNCH (h, k_arith_chain, dim3 ((A.np + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), 64,
-                         d_leaves, A.d_plain, A.np, (const uint32_t *)NULL, (const uint32_t *)NULL, h->d_fail, (uint32_t *)NULL, 0u);
+                         d_leaves, A.d_plain, A.np, inv_tab, (const uint32_t *)NULL, (const uint32_t *)NULL, h->d_fail, (uint32_t *)NULL, 0u);
             }
             else {
                 HIPCHK (h, hipEventRecord (h->ev_model_fork, h->stream));        // (after k_leaf_prep)
@@ -771,8 +777,8 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                     if ((rc = sort_chunk (sort_stream, A.d_big, A.nbig, p0, len, span, k)) != GZ_OK) return rc;
                     HIPCHK (h, hipEventRecord (h->ev_sort[k], sort_stream));
                     HIPCHK (h, hipStreamWaitEvent (h->stream4, h->ev_sort[k], 0));
-                    if (P.unpacked) KLAUNCH_ON (h, h->stream4, k_arith_model<false>, GZ_XCD_DIM (A.nbig, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_big, A.nbig, inv_tab, p0, len, k);
-                    else            KLAUNCH_ON (h, h->stream4, k_arith_model<true>,  GZ_XCD_DIM (A.nbig, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_big, A.nbig, inv_tab, p0, len, k);
+                    if (P.unpacked) KLAUNCH_ON (h, h->stream4, k_arith_model<false>, GZ_XCD_DIM (A.nbig, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_big, A.nbig, p0, len, k);
+                    else            KLAUNCH_ON (h, h->stream4, k_arith_model<true>,  GZ_XCD_DIM (A.nbig, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_big, A.nbig, p0, len, k);
                     hipLaunchKernelGGL (k_arith_progress, dim3 (1), dim3 (1), 0, h->stream4, A.d_progress, k + 1);
                 }
 #ifdef GZ_SEQUENTIAL_STREAMS
@@ -784,12 +790,12 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 if (A.nsmall) {
                     HIPCHK (h, hipStreamWaitEvent (h->stream5, h->ev_model_fork, 0));
                     if ((rc = sort_chunk (h->stream5, A.d_small, A.nsmall, 0u, 0xffffffffu, A.chunk, 0u)) != GZ_OK) return rc;
-                    if (P.unpacked) KLAUNCH_ON (h, h->stream5, k_arith_model<false>, GZ_XCD_DIM (A.nsmall, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_small, A.nsmall, inv_tab, 0u, 0xffffffffu, 0u);
-                    else            KLAUNCH_ON (h, h->stream5, k_arith_model<true>,  GZ_XCD_DIM (A.nsmall, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_small, A.nsmall, inv_tab, 0u, 0xffffffffu, 0u);
+                    if (P.unpacked) KLAUNCH_ON (h, h->stream5, k_arith_model<false>, GZ_XCD_DIM (A.nsmall, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_small, A.nsmall, 0u, 0xffffffffu, 0u);
+                    else            KLAUNCH_ON (h, h->stream5, k_arith_model<true>,  GZ_XCD_DIM (A.nsmall, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_small, A.nsmall, 0u, 0xffffffffu, 0u);
                     KLAUNCH_ON (h, h->stream5, k_arith_chain, dim3 ((A.nsmall + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), GZ_KEEP_OFF_LDS,
-                                d_leaves, A.d_small, A.nsmall, (const uint32_t *)NULL, (const uint32_t *)NULL, h->d_fail, (uint32_t *)NULL, 0u);
+                                d_leaves, A.d_small, A.nsmall, inv_tab, (const uint32_t *)NULL, (const uint32_t *)NULL, h->d_fail, (uint32_t *)NULL, 0u);
                     if (A.nlb_small) {
-                        KLAUNCH_ON (h, h->stream5, k_chain_expand, dim3 (A.nlb_small), dim3 (64), GZ_EXPAND_LDS, d_leaves, A.d_lb_small, (const uint32_t *)NULL, 0u, h->debug_chain_fault);
+                        KLAUNCH_ON (h, h->stream5, k_chain_expand, dim3 (A.nlb_small), dim3 (64), GZ_EXPAND_LDS, d_leaves, A.d_lb_small, (const uint32_t *)NULL, inv_tab, 0u, h->debug_chain_fault);
                         KLAUNCH_ON (h, h->stream5, k_low_scan, dim3 (A.nsmall), dim3 (1024), 8192, d_leaves, A.d_small, 0u, 0xffffffffu);
                         KLAUNCH_ON (h, h->stream5, k_low_scatter, dim3 (A.nlb_small), dim3 (GZ_LOW_WG), GZ_KEEP_OFF_LDS, d_leaves, A.d_lb_small, (const uint32_t *)NULL, 0u);
                     }
@@ -805,7 +811,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                     const uint32_t span = P.max_arith_n - p0 < len ? P.max_arith_n - p0 : len;
                     const uint32_t wgs = (span + GZ_LOW_SLICE * GZ_LOW_SLICES_PER_WG - 1) / (GZ_LOW_SLICE * GZ_LOW_SLICES_PER_WG);
                     hipLaunchKernelGGL (k_low_gate, dim3 (1), dim3 (1), 0, h->stream6, (const uint32_t *)(A.d_progress + 16 + k), A.nbig, h->d_fail);
-                    KLAUNCH_ON (h, h->stream6, k_chain_expand, dim3 (A.nbig, wgs), dim3 (64), GZ_EXPAND_LDS, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0, h->debug_chain_fault);
+                    KLAUNCH_ON (h, h->stream6, k_chain_expand, dim3 (A.nbig, wgs), dim3 (64), GZ_EXPAND_LDS, d_leaves, (const GzdLowBlock *)NULL, A.d_big, inv_tab, p0, h->debug_chain_fault);
                     KLAUNCH_ON (h, h->stream6, k_low_scan, dim3 (A.nbig), dim3 (1024), 8192, d_leaves, A.d_big, p0, len);
                     KLAUNCH_ON (h, h->stream6, k_low_scatter, dim3 (A.nbig, wgs), dim3 (GZ_LOW_WG), GZ_KEEP_OFF_LDS, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0);
                 }
@@ -814,7 +820,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_low, 0));
             }
             if (!A.pipelined) {
-                KLAUNCH (h, k_chain_expand, dim3 (A.nlb), dim3 (64), GZ_EXPAND_LDS, d_leaves, A.d_lb, (const uint32_t *)NULL, 0u, h->debug_chain_fault);
+                KLAUNCH (h, k_chain_expand, dim3 (A.nlb), dim3 (64), GZ_EXPAND_LDS, d_leaves, A.d_lb, (const uint32_t *)NULL, inv_tab, 0u, h->debug_chain_fault);
                 KLAUNCH (h, k_low_scan, dim3 (A.np), dim3 (1024), 8192, d_leaves, A.d_plain, 0u, 0xffffffffu);
                 KLAUNCH (h, k_low_scatter, dim3 (A.nlb), dim3 (GZ_LOW_WG), 4 * 144 * 4, d_leaves, A.d_lb, (const uint32_t *)NULL, 0u);
             }

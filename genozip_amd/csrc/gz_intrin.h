@@ -105,6 +105,12 @@ __device__ static inline uint32_t gz_first_lane (uint32_t v) { return (uint32_t)
 __device__ static inline uint32_t gz_ldg_u8 (const uint8_t *p) { return *(const __attribute__((address_space(1))) uint8_t *)(uintptr_t)p; }
 __device__ static inline uint32_t gz_ldg_u16 (const uint16_t *p) { return *(const __attribute__((address_space(1))) uint16_t *)(uintptr_t)p; }
 __device__ static inline uint32_t gz_ldg_u32 (const uint32_t *p) { return *(const __attribute__((address_space(1))) uint32_t *)(uintptr_t)p; }
+__device__ static inline uint2 gz_ldg_u32x2 (const void *p)
+{
+    typedef uint32_t gz_v2 __attribute__((ext_vector_type(2)));
+    const gz_v2 v = *(const __attribute__((address_space(1))) gz_v2 *)(uintptr_t)p;
+    return make_uint2 (v.x, v.y);
+}
 __device__ static inline uint4 gz_ldg_u32x4 (const void *p)
 {
     typedef uint32_t gz_v4 __attribute__((ext_vector_type(4)));
@@ -124,7 +130,7 @@ __device__ static inline void gz_stg_u16 (uint8_t *p, uint32_t v)     // 2 bytes
 // these kernels must hold NO other double- or half-precision arithmetic - none that the compiler could fold at compile time (it folds with
 // round-to-nearest), move across the s_setreg, or that needs the default mode; gz_fma_rtz's operands must never be compile-time constants
 // together. The mode ends with the wave (both kernels are leaf kernels: nothing runs after them in the same wave). The generated loop
-// (gz_chain_asm.h) names its registers itself (v50-v199, s36-s47: the clobber list keeps the compiler off them). What guards all of this at
+// (gz_chain_asm.h) names its registers itself (GZ_CHAIN_VREGS of the generated header, s36-s47: the clobber list keeps the compiler off them). What guards all of this at
 // run time: k_chain_expand replays every 64-symbol slice in the other formulation and fails the stream (GZ_ST_FAILED) when it does not
 // arrive at the chain's next checkpoint - tests/test_gpu.py::test_chain_checkpoint_guard forces such a mismatch and asserts the failure.
 // MODE.FP_ROUND[3:2] = 3: double precision rounds toward zero in this wave from here on. (Inline asm: a mode change the
@@ -133,18 +139,23 @@ __device__ static inline void gz_f64_round_toward_zero (void) { asm volatile ("s
 // a * b + c in a wave that has called gz_f64_round_toward_zero
 __device__ static inline double gz_fma_rtz (double a, double b, double c) { return __builtin_fma (a, b, c); }
 
+#ifdef GZ_CHAIN_ASM_HDR
+#include GZ_CHAIN_ASM_HDR               // (experiments: another build of the generated loop, tools/build_variant.sh)
+#else
 #include "gz_chain_asm.h"
+#endif
 // Whole blocks of GZ_CHAIN_BLOCK symbols of one leaf's chain (tools/gen_chain_asm.py explains the loop). (rlo, rhi) = the state,
-// a double (range * 2^-7), wave-uniform in and out; recs = the records of the first block; ck = where the first block's first
-// checkpoint goes (8 bytes per 64 symbols, scalar stores).
-__device__ static inline void gz_chain_blocks (uint32_t &rlo, uint32_t &rhi, const uint8_t *recs, uint32_t nblk, uint32_t *ck)
+// a double (range * 2^-7), wave-uniform in and out; recs = the 8-byte records of the first block; inv_tab = the reciprocals of every
+// total (8 bytes each); ck = where the first block's first checkpoint goes (8 bytes per 64 symbols, scalar stores).
+__device__ static inline void gz_chain_blocks (uint32_t &rlo, uint32_t &rhi, const uint8_t *recs, const void *inv_tab, uint32_t nblk, uint32_t *ck)
 {
-    const uint64_t b = (uint64_t)(uintptr_t)recs, c = (uint64_t)(uintptr_t)ck;
+    const uint64_t b = (uint64_t)(uintptr_t)recs, c = (uint64_t)(uintptr_t)ck, t = (uint64_t)(uintptr_t)inv_tab;
     const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)b), b_hi = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)(b >> 32));
     const uint32_t c_lo = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)c), c_hi = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)(c >> 32));
+    const uint32_t t_lo = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)t), t_hi = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)(t >> 32));
     const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane ((int)nblk);
     asm volatile (GZ_CHAIN_F64_ASM : [rlo] "+v"(rlo), [rhi] "+v"(rhi)
-                                   : [blo] "s"(b_lo), [bhi] "s"(b_hi), [nblk] "s"(nb), [clo] "s"(c_lo), [chi] "s"(c_hi) : GZ_CHAIN_F64_CLOBBERS);
+                                   : [blo] "s"(b_lo), [bhi] "s"(b_hi), [nblk] "s"(nb), [clo] "s"(c_lo), [chi] "s"(c_hi), [tlo] "s"(t_lo), [thi] "s"(t_hi) : GZ_CHAIN_F64_CLOBBERS);
     rlo = (uint32_t)__builtin_amdgcn_readfirstlane ((int)rlo); rhi = (uint32_t)__builtin_amdgcn_readfirstlane ((int)rhi);   // (the state ends in lane 0)
 }
 // one 8-byte checkpoint through the scalar unit

@@ -12,9 +12,9 @@
 //                  interact: one wave per (leaf, context), 64 occurrences at a time through closed formulas (prefix
 //                  counts inside the batch: LDS masks + a DPP scan); order changes (swaps, hops) are events - up to 64
 //                  symbols: the model in registers, events patched in one by one; wider alphabets: the model in LDS
-//                  tables, the batch in ROUNDS (everything that no earlier event can reach commits at once). Writes a
-//                  16-byte record per position: the reciprocal of tot as a double, freq, cum.
-//   k_arith_chain  what is truly serial: range -> range / tot * freq -> renormalise. One wave per leaf, four vector
+//                  tables, the batch in ROUNDS (everything that no earlier event can reach commits at once). Writes an
+//                  8-byte record per position: tot | cum << 16, freq as the high word of a double.
+//   k_arith_chain  what is truly serial: range -> range / tot * freq -> renormalise. One wave per leaf, three vector
 //                  instructions per symbol in double precision, the state hopping a lane per symbol (gz_chain_asm.h);
 //                  persistent, following the models position chunk by chunk.
 //   k_low_*        low += cum * r is a big-number addition and addition is associative: one thread per symbol adds its
@@ -28,29 +28,27 @@
 #define GZ_MODEL_STEP  16u
 
 // range / tot without dividing and without the integer unit: in double precision, rounding toward zero,
-//      fma (range * 2^-7, inv, 2^52) = 2^52 + floor (range / tot)        with inv = 2^7 / tot rounded UP to a double
-// (the product inside the fma is exact; inv errs by < 2^-52 relative, range / tot < 2^32, so the product errs by < 2^-20 - far less
+//      fma (range * 2^-7, inv, 1.0) = 1 + floor (range / tot) * 2^-52        with inv = 2^(7 - 52) / tot rounded UP to a double
+// (the product inside the fma is exact; inv errs by < 2^-52 relative, range / tot < 2^32, so the quotient errs by < 2^-20 - far less
 // than the 1 / tot by which a quotient that is not an integer stays below the next one - and never falls below an exact quotient).
 // The low half of the result IS the quotient as an integer. The table of inv for every model total is built by the host (gz_create).
 struct GzDivInv { uint32_t lo, hi; };
 
-// record of one symbol, written by the model for the chain and the low kernels: { inv (a double, two words), freq, cum }
-__device__ static inline uint4 d_model_record (uint32_t cum, uint32_t freq, GzDivInv iv)
+// record of one symbol, written by the model for the chain and the low kernels: 8 bytes (rounds 1-5: 16 - { inv as a double, freq, cum }:
+// every record was written once and read twice, 48 bytes of traffic a symbol before write amplification)
+//      x = tot | cum << 16          (tot <= 65519 at the time a symbol is coded: c_simple_model.h:63,131-137; cum < tot)
+//      y = the high word of the double freq * 2^45 (its low word is 0: freq < 2^16) - the chain's operand F as it is
+// The reciprocal of tot comes from the table, looked up by whoever reads the record (the chain: a block ahead, outside the serial hops).
+#define GZ_REC_F_EXP (1023u + 45u)
+__device__ static inline uint2 d_model_record (uint32_t cum, uint32_t freq, uint32_t tot)
 {
-    return make_uint4 (iv.lo, iv.hi, freq, cum);
+    return make_uint2 (tot | cum << 16, (uint32_t)__double2hiint ((double)freq) + (45u << 20));      // (the conversion is exact in any rounding mode)
 }
+__device__ static inline uint32_t d_record_tot (uint2 r) { return r.x & 0xffffu; }
+__device__ static inline uint32_t d_record_cum (uint2 r) { return r.x >> 16; }
+__device__ static inline uint32_t d_record_freq (uint2 r) { return ((r.y & 0xfffffu) | 0x100000u) >> (20u - ((r.y >> 20) - GZ_REC_F_EXP)); }
 
-// (-DGZ_NT_RECORDS: the records leave as non-temporal stores - an experiment)
-typedef uint32_t gz_rec_u32x4 __attribute__((ext_vector_type (4)));
-__device__ static __forceinline__ void d_record_store (uint4 *at, uint4 v)
-{
-#ifdef GZ_NT_RECORDS
-    gz_rec_u32x4 x = { v.x, v.y, v.z, v.w };
-    __builtin_nontemporal_store (x, (gz_rec_u32x4 *)at);
-#else
-    *at = v;
-#endif
-}
+__device__ static __forceinline__ void d_record_store (uint2 *at, uint2 v) { *at = v; }
 
 // Values loaded from the leaf table arrive through vector loads, so the compiler must assume they differ per lane and
 // turns every loop / branch on them into exec-mask code. They are wave-uniform: say so.
@@ -775,8 +773,8 @@ __device__ unsigned long long g_mph[9];
 #define GZ_ROUNDS_MINJ 2                   // (-DGZ_ROUNDS_MINJ=1: the one-plane models in rounds as well)
 #endif
 template <int J, bool PK, bool O1, bool LA>
-__device__ static __forceinline__ void d_arith_model_wave_ (const uint8_t *in, uint32_t ms, uint4 *recs,
-                                                   const GzDivInv *inv_tab, const uint8_t *symlist, const uint16_t *symrank, uint32_t nsym,
+__device__ static __forceinline__ void d_arith_model_wave_ (const uint8_t *in, uint32_t ms, uint2 *recs,
+                                                   const uint8_t *symlist, const uint16_t *symrank, uint32_t nsym,
                                                    const uint32_t *spos, const uint8_t *srk, uint32_t j0, uint32_t j1, bool first, bool save, uint32_t *st,
                                                    const GzLocalAlpha *la = nullptr)
 {
@@ -812,10 +810,9 @@ __device__ static __forceinline__ void d_arith_model_wave_ (const uint8_t *in, u
     unsigned long long mph_[7] = { 0, 0, 0, 0, 0, 0, 0 }, mt_ = wall_clock64 (), mph_r_ = 0;
 #endif
 
-    // the records of a batch are stored while the next batch is being worked on: the division constants they need come
-    // from a table in memory, and waiting for that load at the end of every batch would cost more than the batch
-    uint32_t p_pos = 0, p_cum = 0, p_freq = 0; GzDivInv p_inv = { 0, 0 }; bool p_on = false;
-    // ... and the occurrences of the following batches are fetched while this one is being worked on. The raw loads (sorted position +
+    // (a batch's records leave as soon as the batch is done: 8 bytes an occurrence, nothing to look up - until round 5 they carried the
+    //  reciprocal of the total, fetched from the table while the NEXT batch was worked on)
+    // The occurrences of the following batches are fetched while this one is being worked on. The raw loads (sorted position +
     // rank byte, or the input byte of an order-0 leaf) run FOUR TO EIGHT batches ahead: a batch without events is ~300 ns of work, a trip
     // to memory 1-2 us, so one batch ahead (as it was) left a context whose order is stable waiting for its next occurrences most of the
     // time (1.2 us per batch measured on a 25 M-occurrence genotype context). Two groups of four batches: A is being used up (picked by
@@ -867,19 +864,11 @@ __device__ static __forceinline__ void d_arith_model_wave_ (const uint8_t *in, u
             nx_pos = rp; nx_rk = (j + 64 + lane < j1) ? to_rank (rr) : 0u; \
         } \
         uint32_t out_cum = 0, out_freq = 0, out_tot = 0, n_ev = 0;
-// (-DGZ_EXP_SORTED_RECORDS: an EXPERIMENT that gives wrong files - the records stored in sorted (context-major) order, 64 consecutive
-//  ones per batch, to see what the scattered stores cost: the streamed form's model launches 1.39 -> 1.18 ms, its call 92 -> 85 ms.
-//  That is the most a coalescing scheme could win BEFORE paying for the pass that puts the records into stream order - round 3's
-//  k_rec_unsort lost more than that - so the records stay scattered.)
-#ifdef GZ_EXP_SORTED_RECORDS
-#define GZ_EXP_RECORD_POS(stream_pos, sorted_pos) (sorted_pos)
-#else
-#define GZ_EXP_RECORD_POS(stream_pos, sorted_pos) (stream_pos)
-#endif
+// (an EXPERIMENT of round 4 - the records stored in sorted (context-major) order, 64 consecutive ones per batch, to see what the
+//  scattered stores cost: the streamed form's model launches 1.39 -> 1.18 ms. That is the most a coalescing scheme could win BEFORE
+//  paying for the pass that puts the records into stream order - round 3's k_rec_unsort lost more than that - so they stay scattered.)
 #define GZ_WAVE_BATCH_TAIL \
-        if (p_on) d_record_store (recs + p_pos, d_model_record (p_cum, p_freq, p_inv)); \
-        p_on = occ; p_pos = GZ_EXP_RECORD_POS (b_pos, j + lane); p_cum = out_cum; p_freq = out_freq; \
-        if (occ) p_inv = inv_tab[out_tot];
+        if (occ) d_record_store (recs + b_pos, d_model_record (out_cum, out_freq, out_tot));
     for (uint32_t j = j0; j < j1; j += 64) {
         GZ_WAVE_BATCH_HEAD
         MPH_T (0);
@@ -893,7 +882,6 @@ __device__ static __forceinline__ void d_arith_model_wave_ (const uint8_t *in, u
     }
 #undef GZ_WAVE_BATCH_HEAD
 #undef GZ_WAVE_BATCH_TAIL
-    if (p_on) d_record_store (recs + p_pos, d_model_record (p_cum, p_freq, p_inv));
 #ifdef GZ_MODEL_PHASES
     if (!lane && j1 - j0 >= GZ_MODEL_HOT) { for (int k = 0; k < 7; k++) atomicAdd (&g_mph[k], mph_[k]); atomicAdd (&g_mph[7], 1ull); atomicAdd (&g_mph[8], mph_r_); }
 #endif
@@ -935,8 +923,8 @@ __device__ unsigned long long g_model_slowest;     // (10 ns ticks << 40) | (lis
 #define GZ_MODEL_T1(ctx, occ) do {} while (0)
 #endif
 template <int J, bool PK>                   // PK: the sorted lists of this batch carry position << 8 | rank (no srk array): k_ctx_scatter
-__device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, uint32_t ms, bool o1, uint4 *recs,
-                                                   const GzDivInv *inv_tab, const uint8_t *symlist, const uint16_t *symrank, uint32_t nsym,
+__device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, uint32_t ms, bool o1, uint2 *recs,
+                                                   const uint8_t *symlist, const uint16_t *symrank, uint32_t nsym,
                                                    const uint32_t *spos, const uint8_t *srk, uint32_t j0, uint32_t j1, bool first, bool save, uint32_t *st,
                                                    const GzLocalAlpha *la = nullptr)
 {
@@ -944,17 +932,17 @@ __device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, ui
     //  the same instructions every time; with `o1` and `la` tested at run time the VCF step took 902 instead of 876 ms, the default step's
     //  model launches 27.8 instead of 24.8 ms)
     if (la) {
-        if (o1) d_arith_model_wave_<J, PK, true, true>  (in, ms, recs, inv_tab, symlist, symrank, nsym, spos, srk, j0, j1, first, save, st, la);
-        else    d_arith_model_wave_<J, PK, false, true> (in, ms, recs, inv_tab, symlist, symrank, nsym, spos, srk, j0, j1, first, save, st, la);
+        if (o1) d_arith_model_wave_<J, PK, true, true>  (in, ms, recs, symlist, symrank, nsym, spos, srk, j0, j1, first, save, st, la);
+        else    d_arith_model_wave_<J, PK, false, true> (in, ms, recs, symlist, symrank, nsym, spos, srk, j0, j1, first, save, st, la);
     }
     else {
-        if (o1) d_arith_model_wave_<J, PK, true, false>  (in, ms, recs, inv_tab, symlist, symrank, nsym, spos, srk, j0, j1, first, save, st, la);
-        else    d_arith_model_wave_<J, PK, false, false> (in, ms, recs, inv_tab, symlist, symrank, nsym, spos, srk, j0, j1, first, save, st, la);
+        if (o1) d_arith_model_wave_<J, PK, true, false>  (in, ms, recs, symlist, symrank, nsym, spos, srk, j0, j1, first, save, st, la);
+        else    d_arith_model_wave_<J, PK, false, false> (in, ms, recs, symlist, symrank, nsym, spos, srk, j0, j1, first, save, st, la);
     }
 }
 
 template <bool PK>
-__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const GzDivInv *inv_tab, uint32_t p0, uint32_t chunk, uint32_t row)
+__global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, uint32_t p0, uint32_t chunk, uint32_t row)
 {
     GZ_XCD_GRID (li, by, n_list);
     GzdLeaf &L = leaves[list[li]];
@@ -965,7 +953,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
     else if (L.nsym <= 64 && by && (!L.o1 || by > L.nsym)) return;
     const uint32_t ms = L.max_sym;
     const bool o1 = L.o1, rle = L.rle;
-    uint4 *tr = d_uniform_ptr ((uint4 *)L.triples);
+    uint2 *tr = d_uniform_ptr ((uint2 *)L.triples);
     const uint8_t *coded = d_uniform_ptr (L.coded);
     const uint32_t n_u = d_uniform (L.arith_n), ms_u = d_uniform (ms), nsym_u = d_uniform (L.nsym), nctx = d_uniform (L.nctx);
     const bool o1_u = d_uniform (o1 ? 1u : 0u) != 0, rle_u = d_uniform (rle ? 1u : 0u) != 0;
@@ -989,7 +977,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
             const uint32_t ctx = 256 + k;
             const uint32_t j0 = d_uniform (off[(size_t)t0 * nctx + ctx]), j1 = d_uniform (cend[ctx]);
             if (j0 == j1 && p0) continue;
-            d_arith_model_wave<1, PK> (coded, 4u, true, tr, inv_tab, digits, L.symrank, 4u, spos, srk, j0, j1, p0 == 0, p1 < n_u,
+            d_arith_model_wave<1, PK> (coded, 4u, true, tr, digits, L.symrank, 4u, spos, srk, j0, j1, p0 == 0, p1 < n_u,
                                    mstate + (size_t)ctx * (GZ_MSTATE_WORDS * 64));
         }
         return;
@@ -1007,7 +995,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
         uint32_t j0 = p0, j1 = p1;
         if (sorted) { j0 = d_uniform (off[(size_t)t0 * nctx + ctx]); j1 = d_uniform (cend[ctx]); }   // my run of the sorted lists
         GZ_MODEL_T0;
-        d_arith_model_wave<1, PK> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        d_arith_model_wave<1, PK> (coded, ms_u, sorted, tr, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
         GZ_MODEL_T1 (ctx, j1 - j0);
         return;
     }
@@ -1024,7 +1012,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
             uint8_t *lds_flags = gz_lds, *lds_list = gz_lds + 256;
             const uint32_t nd = d_local_alphabet (la, coded, sorted, spos, srk, L.symrank, L.symlist, j0, j1, lds_flags, lds_list);
             if (nd <= 64) {
-                d_arith_model_wave<1, PK> (coded, ms_u, sorted, tr, inv_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, true, false, st, &la);
+                d_arith_model_wave<1, PK> (coded, ms_u, sorted, tr, lds_list, L.symrank, nd, spos, srk, j0, j1, true, false, st, &la);
                 GZ_MODEL_T1 (ctx, j1 - j0);
                 continue;
             }
@@ -1042,14 +1030,14 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
                 #pragma unroll
                 for (int k = 0; k < 4; k++) if ((la.m[k] >> (threadIdx.x & 63)) & 1) lds_list[d_local_rank (la, (uint32_t)(k * 64 + (threadIdx.x & 63)))] = L.symlist[k * 64 + (threadIdx.x & 63)];
                 __syncthreads ();
-                if (nd <= 64) d_arith_model_wave<1, PK> (coded, ms_u, sorted, tr, inv_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, &la);
-                else          d_arith_model_wave<2, PK> (coded, ms_u, sorted, tr, inv_tab, lds_list, L.symrank, nd, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, &la);
+                if (nd <= 64) d_arith_model_wave<1, PK> (coded, ms_u, sorted, tr, lds_list, L.symrank, nd, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, &la);
+                else          d_arith_model_wave<2, PK> (coded, ms_u, sorted, tr, lds_list, L.symrank, nd, spos, srk, j0, j1, p0 == 0, p1 < n_u, st, &la);
                 GZ_MODEL_T1 (ctx, j1 - j0);
                 continue;
             }
         }
-        if (nsym_u <= 128) d_arith_model_wave<2, PK> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
-        else               d_arith_model_wave<4, PK> (coded, ms_u, sorted, tr, inv_tab, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        if (nsym_u <= 128) d_arith_model_wave<2, PK> (coded, ms_u, sorted, tr, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
+        else               d_arith_model_wave<4, PK> (coded, ms_u, sorted, tr, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
         GZ_MODEL_T1 (ctx, j1 - j0);
     }
 }
@@ -1065,15 +1053,15 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
 //                  (+ inc, mulhi by a magic number, >> shift, * freq, clz, & 0x18, <<) fed by scalar loads: 30.5 clocks per
 //                  symbol + the waits for those loads (13.6 ns alone on the device, 14.9 beside the other kernels of a step).
 //                  Now THREE vector instructions in double precision (the state R is range * 2^-7 as a double):
-//                      T = fma (R, 2^7 / tot, 2^52)      rounding toward zero: 2^52 + floor (range / tot) - the low word IS r
-//                      R = fma (T, F, G)                 F = freq * 2^-7, G = -2^52 * F: r * freq * 2^-7, exact
+//                      T = fma (R, 2^-45 / tot, 1.0)     rounding toward zero: 1 + floor (range / tot) * 2^-52 - the low word IS r
+//                      R = fma (T, F, -F)                F = freq * 2^45: r * freq * 2^-7, exact
 //                      R.hi = R.hi & 0x7fffff | 0x41000000     the exponent's low three bits stay, the others become those of
 //                                                        [2^24, 2^32): exactly "shift left by whole bytes until >= 2^24"
-//                  and NO operand fetch in the loop: lane j holds the records of symbols base + 8 j .. + 7 (coalesced loads, a
-//                  block of 512 symbols ahead; F and G made from freq by all lanes at once), all lanes execute every step, the
-//                  state hops to the next lane through a DPP read of r - after the 8 symbols a lane holds, because a DPP read of
-//                  a fresh result costs two wait states (gz_chain_asm.h, written by tools/gen_chain_asm.py): 15.8 clocks = 6.6 ns
-//                  per symbol, the same with 1 or 64 chains on the device. It never looks at cum or low, and stores only the state
+//                  and NO operand fetch in the loop: lane j holds the operands of symbols base + 12 j .. + 11 (8-byte records
+//                  loaded coalesced two blocks of 768 symbols ahead, the reciprocals of their totals from the table one block
+//                  ahead), all lanes execute every step, the state hops to the next lane through a DPP read of r - after the 12
+//                  symbols a lane holds, because a DPP read of a fresh result costs two wait states (gz_chain_asm.h, written by
+//                  tools/gen_chain_asm.py): ~15.8 clocks = 6.6 ns per symbol, the same with 1 or 64 chains on the device. It never looks at cum or low, and stores only the state
 //                  before every 64th symbol: k_chain_expand recomputes r = range / tot of every symbol from those for the low
 //                  kernels - with the plain formulation of the same arithmetic (an integer multiply), and checks that it arrives
 //                  at the chain's next checkpoint: the two check each other on every 64 symbols of every stream.
@@ -1093,8 +1081,8 @@ typedef uint32_t gz_u32x4 __attribute__((vector_size (16)));
 // One symbol - the plain formulation (k_chain_expand; in the chain: the rest of a leaf that does not fill a block of the loop). The wave must have called gz_f64_round_toward_zero. Returns r = range / tot.
 __device__ static inline uint32_t d_chain_step (uint32_t &rlo, uint32_t &rhi, uint32_t inv_lo, uint32_t inv_hi, uint32_t freq, uint32_t *shift_bytes = NULL)
 {
-    const double t = gz_fma_rtz (__hiloint2double ((int)rhi, (int)rlo), __hiloint2double ((int)inv_hi, (int)inv_lo), 4503599627370496.0);
-    const uint32_t r = (uint32_t)__double2loint (t);             // 2^52 + r: the integer sits in the low word
+    const double t = gz_fma_rtz (__hiloint2double ((int)rhi, (int)rlo), __hiloint2double ((int)inv_hi, (int)inv_lo), 1.0);
+    const uint32_t r = (uint32_t)__double2loint (t);             // 1 + r * 2^-52: the integer sits in the low word
     const uint32_t rf = r * freq;                                // <= range < 2^32 (>= 256: r >= 2^24 / 65535)
     const double x = (double)rf * 0.0078125;                     // * 2^-7: exact
     rlo = (uint32_t)__double2loint (x);
@@ -1130,33 +1118,35 @@ __device__ static inline bool d_wait_progress (const uint32_t *progress, uint32_
 }
 
 // positions [i0, i1) one symbol at a time in the plain formulation (the end of a leaf that does not fill a block of the loop; i0 a
-// multiple of 64): 64 records per trip to memory, fetched by the lanes and handed out by readlane; the state before every 64th
-// symbol goes out as in the loop
-__device__ static inline void d_chain_slow (uint32_t &rlo, uint32_t &rhi, int lane, uint32_t i0, uint32_t i1, const uint8_t *triples, uint32_t *ck)
+// multiple of 64): 64 records per trip to memory, fetched by the lanes - each with the reciprocal of its total - and handed out by
+// readlane; the state before every 64th symbol goes out as in the loop
+__device__ static inline void d_chain_slow (uint32_t &rlo, uint32_t &rhi, int lane, uint32_t i0, uint32_t i1, const uint8_t *triples, const GzDivInv *inv_tab, uint32_t *ck)
 {
     for (uint32_t g = i0; g < i1; g += 64) {
         gz_scalar_store2 (ck + 2 * (g >> 6), rlo, rhi);
-        const uint4 mine = ((const uint4 *)triples)[g + lane];  // (beyond i1: inside the padded area, not looked at)
+        const uint2 mine = ((const uint2 *)triples)[g + lane];  // (beyond i1: inside the padded area, not looked at - but it picks a table entry: any)
+        const GzDivInv iv = inv_tab[d_record_tot (mine)];
+        const uint32_t fq = g + lane < i1 ? d_record_freq (mine) : 1u;
         const int m = i1 - g < 64 ? (int)(i1 - g) : 64;
-        for (int j = 0; j < m; j++) (void)d_chain_step (rlo, rhi, d_readlane (mine.x, j), d_readlane (mine.y, j), d_readlane (mine.z, j));
+        for (int j = 0; j < m; j++) (void)d_chain_step (rlo, rhi, d_readlane (iv.lo, j), d_readlane (iv.hi, j), d_readlane (fq, j));
     }
 }
 
 // positions [p0, p1) of one leaf (p0 a multiple of 64; p1 - p0 one of GZ_CHAIN_BLOCK unless p1 is the leaf's end)
 // What leaves the chain is the state BEFORE every 64th symbol (8 bytes at ck + 2 * (i / 64)) and the state after the last symbol
 // of the call (the next call's first checkpoint, or the leaf's closing one): one scalar store per 64 symbols.
-__device__ static __forceinline__ void d_chain_chunk (uint32_t &rlo, uint32_t &rhi, int lane, uint32_t p0, uint32_t p1, const uint8_t *triples, uint32_t *ck)
+__device__ static __forceinline__ void d_chain_chunk (uint32_t &rlo, uint32_t &rhi, int lane, uint32_t p0, uint32_t p1, const uint8_t *triples, const GzDivInv *inv_tab, uint32_t *ck)
 {
     const uint32_t whole = p0 + (p1 - p0) / GZ_CHAIN_BLOCK * GZ_CHAIN_BLOCK;
     uint32_t i = p0;
-    if (whole > p0) { gz_chain_blocks (rlo, rhi, triples + (size_t)p0 * 16, (whole - p0) / GZ_CHAIN_BLOCK, ck + 2 * (p0 >> 6)); i = whole; }
-    if (i < p1) d_chain_slow (rlo, rhi, lane, i, p1, triples, ck);     // the end of the leaf
+    if (whole > p0) { gz_chain_blocks (rlo, rhi, triples + (size_t)p0 * GZ_CHAIN_REC, inv_tab, (whole - p0) / GZ_CHAIN_BLOCK, ck + 2 * (p0 >> 6)); i = whole; }
+    if (i < p1) d_chain_slow (rlo, rhi, lane, i, p1, triples, inv_tab, ck);     // the end of the leaf
     gz_scalar_store2 (ck + 2 * ((p1 + 63) >> 6), rlo, rhi);
 }
 
 // progress == NULL: everything is there already, one piece (bounds is ignored). bounds [0 .. n_chunks]: where the position chunks start (the
 // first ones are shorter than the rest: the first chunk's sort + models are the lead-in of the long streams - gz_host.cpp, arith_pipe_setup)
-__device__ static __forceinline__ void d_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress, const uint32_t *bounds,
+__device__ static __forceinline__ void d_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const GzDivInv *inv_tab, const uint32_t *progress, const uint32_t *bounds,
                                                       uint32_t *fail, uint32_t *done, uint32_t n_chunks)
 {
     const uint32_t li = blockIdx.x * GZ_CHAIN_WAVES + (threadIdx.x >> 6);
@@ -1174,13 +1164,13 @@ __device__ static __forceinline__ void d_arith_chain (GzdLeaf *leaves, const uin
     const uint8_t *triples = d_uniform_ptr (L.triples);        // (wave-uniform: keep them in scalar registers)
     uint32_t *ck = d_uniform_ptr ((uint32_t *)L.ckpt);          // (checkpoints: the state before every 64th symbol, 8 bytes each)
     uint32_t rlo = GZ_CHAIN_R0_LO, rhi = GZ_CHAIN_R0_HI;
-    if (!progress) d_chain_chunk (rlo, rhi, lane, 0, n, triples, ck);
+    if (!progress) d_chain_chunk (rlo, rhi, lane, 0, n, triples, inv_tab, ck);
     else
         for (uint32_t k = 0; k < n_chunks; k++) {
             const uint32_t p0 = d_uniform (bounds[k]), pe = d_uniform (bounds[k + 1]);
             if (p0 >= n) break;
             if (k && !d_wait_progress (progress, k + 1)) { if (!lane) { L.overflow = 2; *fail = 1; } break; }
-            d_chain_chunk (rlo, rhi, lane, p0, pe < n ? pe : n, triples, ck);
+            d_chain_chunk (rlo, rhi, lane, p0, pe < n ? pe : n, triples, inv_tab, ck);
             if (done) {                                        // this leaf's checkpoints of chunk k are final: tell the low kernels
                 gz_scalar_store_flush ();
                 __threadfence ();
@@ -1193,10 +1183,10 @@ __device__ static __forceinline__ void d_arith_chain (GzdLeaf *leaves, const uin
     gz_scalar_store_flush ();
 }
 
-__global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress, const uint32_t *bounds,
-                                                                      uint32_t *fail, uint32_t *done, uint32_t n_chunks)
+__global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const GzDivInv *inv_tab, const uint32_t *progress,
+                                                                      const uint32_t *bounds, uint32_t *fail, uint32_t *done, uint32_t n_chunks)
 {
-    d_arith_chain (leaves, list, n_list, progress, bounds, fail, done, n_chunks);
+    d_arith_chain (leaves, list, n_list, inv_tab, progress, bounds, fail, done, n_chunks);
 }
 
 // One thread: holds its stream until all `want` leaves of the persistent chain have finished a position chunk (the low
@@ -1242,17 +1232,17 @@ __device__ static inline GzdLowBlock d_low_block (const GzdLowBlock *blocks, con
 
 // What the low kernels need of every symbol, from the chain's checkpoints: a lane per 64-symbol slice replays the recurrence over its
 // slice in the plain formulation (d_chain_step: any total, an ordinary multiply) and must arrive at the chain's NEXT checkpoint -
-// the chain got there through its 24-bit multiply and 64 hops from lane to lane; a slice that does not fails the stream (it never
+// the chain got there through its fused multiply-adds and 64 hops from lane to lane; a slice that does not fails the stream (it never
 // has; the check costs one comparison per 64 symbols). Per symbol: a = cum * r, what it adds to low (the wave's 64 x 64 values go
 // through LDS so that they are written row by row), and k = the bytes low and range move up after it - two bits, the slice's 64 of
 // them are 16 bytes written by its lane, and their sum is the slice's entry in the prefix sum of output positions (k_low_scan).
 // (Until round 4 this kernel wrote r, and k_low_count / k_low_scatter each read every symbol's 16-byte record again for freq and cum:
-// 60 bytes of traffic per symbol between the three, now 25.)
+// 60 bytes of traffic per symbol between the three; round 4: 25; with the 8-byte record: 17.)
 // Same grid as the low kernels that follow it (one workgroup = 64 slices), 64 threads, GZ_EXPAND_LDS bytes of LDS.
 #define GZ_EXPAND_TILE_BYTES (64 * 65 * 4)          // 16 640: the tile of a = cum * r values, [64 slices][65]
-#define GZ_EXPAND_LDS (GZ_EXPAND_TILE_BYTES + 64 * 9 * 16)
+#define GZ_EXPAND_LDS (GZ_EXPAND_TILE_BYTES + 64 * 17 * 8)
 // fault: 0, or (GZ_DEBUG_CHAIN_FAULT, tests only) 1 + the index of a slice that is treated as if it had missed the chain's checkpoint
-__global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const GzdLowBlock *blocks, const uint32_t *list, uint32_t p0, uint32_t fault)
+__global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const GzdLowBlock *blocks, const uint32_t *list, const GzDivInv *inv_tab, uint32_t p0, uint32_t fault)
 {
     const GzdLowBlock B = d_low_block (blocks, list, p0);
     GzdLeaf &L = leaves[B.leaf];
@@ -1261,7 +1251,7 @@ __global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const Gzd
     if (B.first_slice >= ns) return;
     gz_f64_round_toward_zero ();
     const int lane = threadIdx.x;
-    const uint4 *rec = (const uint4 *)L.triples;
+    const uint2 *rec = (const uint2 *)L.triples;
     uint32_t *av = (uint32_t *)L.rvals;
     uint32_t *tile = (uint32_t *)gz_lds;                        // [64 slices][65]
     const uint32_t slice = B.first_slice + lane, i0 = slice * GZ_LOW_SLICE;
@@ -1269,42 +1259,52 @@ __global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const Gzd
     const uint32_t *ck = (const uint32_t *)L.ckpt + 2 * (size_t)(mine ? slice : 0);
     uint32_t rlo = ck[0], rhi = ck[1], kb[4] = { 0, 0, 0, 0 }, ksum = 0;
     const uint32_t m = !mine || i0 >= n ? 0u : (i0 + 64 <= n ? 64u : n - i0);      // (an empty leaf has one empty slice)
-    // The records of 64 slices x 8 symbols at a time, loaded COALESCED - eight lanes take the eight records (one 128-byte line) of a
-    // slice, eight slices per load instruction - and handed to the slices' lanes through the LDS. (As `rec[i0 + j]` per lane this was
-    // one flat load per symbol waited for on the spot; eight global loads per trip, still one line per lane, made 6.4 -> 4.7 ms of it
-    // per default step: every line then came from the L2 eight times.) The next eight are in flight while these are worked on.
-    uint4 *stage = (uint4 *)(gz_lds + GZ_EXPAND_TILE_BYTES);       // [64 slices][8 + 1]
+    // The records of 64 slices x 16 symbols at a time, loaded COALESCED - eight lanes take the sixteen records (one 128-byte line) of a
+    // slice, two each, eight slices per load instruction - and handed to the slices' lanes through the LDS. (As `rec[i0 + j]` per lane
+    // this was one flat load per symbol waited for on the spot.) The next sixteen are in flight while these are worked on; a lane then
+    // asks the table for the reciprocals of its sixteen totals at once (the table is 512 KB and lives in the L2).
+    uint2 *stage = (uint2 *)(gz_lds + GZ_EXPAND_TILE_BYTES);       // [64 slices][16 + 1]
     const uint32_t ld_s = (uint32_t)lane >> 3, ld_j = (uint32_t)lane & 7;
     uint4 nx[8];
-    auto load8 = [&] (uint32_t jbase) {
+    auto load16 = [&] (uint32_t jbase) {
         #pragma unroll
         for (uint32_t it = 0; it < 8; it++) {
-            const uint32_t sl = B.first_slice + it * 8 + ld_s, idx = sl * GZ_LOW_SLICE + jbase + ld_j;
-            nx[it] = gz_ldg_u32x4 (rec + (sl < ns && idx < n ? idx : 0));
+            const uint32_t sl = B.first_slice + it * 8 + ld_s, idx = sl * GZ_LOW_SLICE + jbase + 2 * ld_j;
+            nx[it] = gz_ldg_u32x4 (rec + (sl < ns && idx < n ? idx : 0));        // (a leaf's records are padded to whole lines)
         }
     };
-    load8 (0);
+    // sixteen symbols at a time; the records and reciprocals of the NEXT sixteen are fetched while these are worked on
+    uint2 c[2][16]; uint32_t ivl[2][16], ivh[2][16];
+    auto fetch16 = [&] (uint32_t q, uint2 (&cq)[16], uint32_t (&il)[16], uint32_t (&ih)[16]) {      // nx holds the records of symbols 16 q .. of every slice
+        #pragma unroll
+        for (uint32_t it = 0; it < 8; it++) {
+            stage[(it * 8 + ld_s) * 17 + 2 * ld_j]     = make_uint2 (nx[it].x, nx[it].y);
+            stage[(it * 8 + ld_s) * 17 + 2 * ld_j + 1] = make_uint2 (nx[it].z, nx[it].w);
+        }
+        gz_wave_sync ();
+        if (q + 1 < 4) load16 (16 * (q + 1));
+        #pragma unroll
+        for (uint32_t u = 0; u < 16; u++) cq[u] = stage[lane * 17 + u];
+        gz_wave_sync ();
+        #pragma unroll
+        for (uint32_t u = 0; u < 16; u++) {
+            const uint2 e = gz_ldg_u32x2 (inv_tab + (16 * q + u < m ? d_record_tot (cq[u]) : 1u));
+            il[u] = e.x; ih[u] = e.y;
+        }
+    };
+    load16 (0);
+    fetch16 (0, c[0], ivl[0], ivh[0]);
     #pragma unroll
     for (uint32_t q = 0; q < 4; q++) {
         uint32_t kw = 0;
+        const uint32_t j0 = q * 16;
+        if (q + 1 < 4) fetch16 (q + 1, c[(q + 1) & 1], ivl[(q + 1) & 1], ivh[(q + 1) & 1]);
         #pragma unroll
-        for (uint32_t h = 0; h < 2; h++) {
-            const uint32_t j0 = q * 16 + h * 8;
-            #pragma unroll
-            for (uint32_t it = 0; it < 8; it++) stage[(it * 8 + ld_s) * 9 + ld_j] = nx[it];
-            gz_wave_sync ();
-            if (j0 + 8 < 64) load8 (j0 + 8);
-            uint4 c[8];
-            #pragma unroll
-            for (uint32_t u = 0; u < 8; u++) c[u] = stage[lane * 9 + u];
-            gz_wave_sync ();
-            #pragma unroll
-            for (uint32_t u = 0; u < 8; u++) if (j0 + u < m) {
-                uint32_t k;
-                const uint32_t r = d_chain_step (rlo, rhi, c[u].x, c[u].y, c[u].z, &k);
-                tile[lane * 65 + j0 + u] = c[u].w * r;
-                kw |= k << (2 * (h * 8 + u)); ksum += k;
-            }
+        for (uint32_t u = 0; u < 16; u++) if (j0 + u < m) {
+            uint32_t k;
+            const uint32_t r = d_chain_step (rlo, rhi, ivl[q & 1][u], ivh[q & 1][u], d_record_freq (c[q & 1][u]), &k);
+            tile[lane * 65 + j0 + u] = d_record_cum (c[q & 1][u]) * r;
+            kw |= k << (2 * u); ksum += k;
         }
         kb[q] = kw;
     }

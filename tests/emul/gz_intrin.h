@@ -26,6 +26,7 @@ static inline void gz_wait_vector_mem (void) {}
 static inline uint32_t gz_ldg_u8 (const uint8_t *p) { return *p; }
 static inline uint32_t gz_ldg_u16 (const uint16_t *p) { return *p; }
 static inline uint32_t gz_ldg_u32 (const uint32_t *p) { return *p; }
+static inline uint2 gz_ldg_u32x2 (const void *p) { return *(const uint2 *)p; }
 static inline uint4 gz_ldg_u32x4 (const void *p) { return *(const uint4 *)p; }
 static inline void gz_stg_u8 (uint8_t *p, uint32_t v) { *p = (uint8_t)v; }
 static inline void gz_stg_u32 (uint32_t *p, uint32_t v) { *p = v; }
@@ -58,19 +59,21 @@ static inline double gz_fma_rtz (double a, double b, double c)
 }
 static inline void gz_scalar_store2 (uint32_t *dst, uint32_t a, uint32_t b) { if (emu.cur % 64 == 0) { dst[0] = a; dst[1] = b; } }
 #include "gz_chain_asm.h"                                       // (GZ_CHAIN_BLOCK; the loop itself is not for this compiler)
-// the same contract as the product's loop, one symbol at a time, in the loop's own arithmetic: records { inv (double), freq, cum },
-// T = fma (R, inv, 2^52) truncated, R' = fma (T, F, G) with F = freq * 2^-7, G = -2^52 * F, then the exponent bits
-static inline void gz_chain_blocks (uint32_t &rlo, uint32_t &rhi, const uint8_t *recs, uint32_t nblk, uint32_t *ck)
+// the same contract as the product's loop, one symbol at a time, in the loop's own arithmetic: records { tot | cum << 16, F.hi },
+// T = fma (R, inv, 1.0) truncated (inv from the table), R' = fma (T, F, -F) with F = freq * 2^45, then the exponent bits
+static inline void gz_chain_blocks (uint32_t &rlo, uint32_t &rhi, const uint8_t *recs, const void *inv_tab, uint32_t nblk, uint32_t *ck)
 {
     for (uint32_t b = 0; b < nblk; b++) {
-        const uint32_t *rec = (const uint32_t *)(recs + (size_t)b * GZ_CHAIN_BLOCK * 16);
+        const uint32_t *rec = (const uint32_t *)(recs + (size_t)b * GZ_CHAIN_BLOCK * GZ_CHAIN_REC);
         for (int j = 0; j < GZ_CHAIN_BLOCK; j++) {
             if (!(j & 63)) gz_scalar_store2 (ck + 2 * (b * (GZ_CHAIN_BLOCK / 64) + j / 64), rlo, rhi);
-            double inv, R; memcpy (&inv, rec + 4 * j, 8);
+            double inv, R, F; memcpy (&inv, (const uint8_t *)inv_tab + 8 * (size_t)(rec[2 * j] & 0xffffu), 8);
             uint64_t rb = (uint64_t)rlo | (uint64_t)rhi << 32; memcpy (&R, &rb, 8);
-            const double t = gz_fma_rtz (R, inv, 4503599627370496.0);
-            const double F = (double)rec[4 * j + 2] * 0.0078125, G = -4503599627370496.0 * F;
-            const double Pd = gz_fma_rtz (t, F, G);
+            const uint64_t fb = (uint64_t)rec[2 * j + 1] << 32; memcpy (&F, &fb, 8);
+            const double t = gz_fma_rtz (R, inv, 1.0);
+            uint64_t tb; memcpy (&tb, &t, 8); tb = (tb & 0xffffffffull) | 0x3ff0000000000000ull;     // (what the lane hop passes on: r under the constant high word)
+            double t2; memcpy (&t2, &tb, 8);
+            const double Pd = gz_fma_rtz (t2, F, -F);
             uint64_t pb; memcpy (&pb, &Pd, 8);
             rlo = (uint32_t)pb; rhi = ((uint32_t)(pb >> 32) & 0x007fffffu) | 0x41000000u;
         }
