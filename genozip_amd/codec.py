@@ -388,6 +388,13 @@ class Engine:
     def version(self):
         return self.L.gz_version().decode()
 
+    def debug_record_inv(self, tot0, n):
+        """(tests) the reciprocals the model kernel puts into the records of totals tot0 .. tot0 + n - 1, as numpy float64"""
+        import numpy as np
+        out = self.mem.alloc(8 * n)
+        self._check(self.L.gz_debug_record_inv(self.h, tot0, n, self.mem.ptr(out)), "gz_debug_record_inv")
+        return np.frombuffer(self.mem.download(out, 8 * n), dtype=np.float64).copy()
+
     def sync(self):
         return self._check(self.L.gz_sync(self.h), "gz_sync")
 

@@ -85,7 +85,7 @@ struct GzdLeaf {
     uint8_t   *tab;           // serialised frequency table
     uint8_t   *pay;           // entropy-coded payload area (rANS fills it from the end)
     uint32_t  *models;        // arith (run-length variant): global-memory models when they do not fit the LDS
-    uint8_t   *triples;       // arith: 8 bytes per coded byte: tot | cum << 16, freq as the high word of the double freq * 2^45  (k_arith_model -> k_arith_chain, k_chain_expand)
+    uint8_t   *triples;       // arith: 12 bytes per coded byte: 2^-45 / tot as a double with cum in its low 16 bits, freq as the high word of the double freq * 2^45  (k_arith_model -> k_arith_chain, k_chain_expand)
     uint32_t  *spos;          // arith order-1: positions grouped by context (the byte before), stream order inside a context
     uint8_t   *srk;           // arith order-1: static rank of the symbol at spos[j]; NULL (leaves under 2^24 positions): spos[j] = position << 8 | rank
     uint32_t  *ctxoff;        // arith order-1: [tile][context] -> index into spos/srk of the first occurrence at or after the tile

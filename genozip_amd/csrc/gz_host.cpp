@@ -79,7 +79,6 @@ struct GzHandle {
     std::vector<Pending> pending;
     std::vector<void *> host_tmp;      // host staging to free at sync
     GzLogTable *d_logs;
-    GzDivInv *d_inv_tab;        // the reciprocal of every possible model total (division by multiplication in the chain)
     std::string err;
     size_t arena_block_size;
     // optional per-kernel timing with HIP events on this handle's stream (bench.py's roofline object)
@@ -166,7 +165,7 @@ static GzHandle *gz_create_do (int device, void *hip_stream, int *err, bool back
     }
     if (hipSetDevice (device) != hipSuccess) { if (err) *err = GZ_ERR_HIP; return NULL; }
     GzHandle *h = new GzHandle ();
-    h->device = device; h->d_logs = NULL; h->d_inv_tab = NULL; h->background = background;
+    h->device = device; h->d_logs = NULL; h->background = background;
     h->arena_block_size = (size_t)256 << 20;
     int prio_lo0 = 0, prio_hi0 = 0;
     if (hipDeviceGetStreamPriorityRange (&prio_lo0, &prio_hi0) != hipSuccess) prio_lo0 = prio_hi0 = 0;
@@ -205,27 +204,6 @@ static GzHandle *gz_create_do (int device, void *hip_stream, int *err, bool back
         if (h->own_stream) (void)hipStreamDestroy (h->stream);
         delete h; if (err) *err = GZ_ERR_HIP; return NULL;
     }
-    // range / tot of the range coder (c_range_coder.h:100) as the low word of fma (range * 2^-7, inv, 1.0) rounded toward zero
-    // (gz_kernels_arith.h): inv = 2^7 / tot rounded UP to a double - the quotient of the two doubles rounded to nearest, one step up
-    // if that fell below (the fma gives the sign of inv * tot - 2^7 exactly) - times 2^-52 (exact). tot <= 65519 + 16
-    {
-        const uint32_t N = 65536 + 32;
-        std::vector<GzDivInv> mt (N);
-        mt[0].lo = 0; mt[0].hi = 0x40600000u - (52u << 20);    // (128.0 * 2^-52: never used)
-        for (uint32_t dv = 1; dv < N; dv++) {
-            double inv = 128.0 / (double)dv;
-            if (fma (inv, (double)dv, -128.0) < 0.0) inv = nextafter (inv, 1e300);
-            inv = ldexp (inv, -52);
-            uint64_t bits; memcpy (&bits, &inv, 8);
-            mt[dv].lo = (uint32_t)bits; mt[dv].hi = (uint32_t)(bits >> 32);
-        }
-        if (hipMalloc ((void **)&h->d_inv_tab, N * sizeof (GzDivInv)) != hipSuccess ||
-            hipMemcpy (h->d_inv_tab, mt.data (), N * sizeof (GzDivInv), hipMemcpyHostToDevice) != hipSuccess) {
-            if (err) *err = GZ_ERR_HIP;
-            gz_destroy (h);
-            return NULL;
-        }
-    }
     if (hipMalloc ((void **)&h->d_fail, 64) != hipSuccess || hipMemset (h->d_fail, 0, 64) != hipSuccess) { if (err) *err = GZ_ERR_HIP; gz_destroy (h); return NULL; }
     { const char *e = getenv ("GZ_NO_PIPELINE"); h->no_pipeline = e && *e && *e != '0'; }
     { const char *e = getenv ("GZ_DEBUG_CHAIN_FAULT"); h->debug_chain_fault = e ? (uint32_t)strtoul (e, NULL, 10) : 0; }   // (tests: a forced checkpoint mismatch must fail the stream)
@@ -253,7 +231,6 @@ extern "C" void gz_destroy (GzHandle *h)
     for (auto &b : h->blocks) (void)hipFree (b.base);
     for (auto p : h->host_tmp) free (p);
     (void)hipFree (h->d_logs);
-    (void)hipFree (h->d_inv_tab);
     (void)hipFree (h->d_fail);
     if (h->own_stream) (void)hipStreamDestroy (h->stream);
     (void)hipStreamDestroy (h->stream2);
@@ -701,7 +678,7 @@ static int arith_launch_chain (GzHandle *h, const ArithPipe &A, GzdLeaf *d_leave
     HIPCHK (h, hipEventRecord (h->ev_chain_go, h->stream));                     // (behind the uploads and the memset)
     HIPCHK (h, hipStreamWaitEvent (h->stream3, h->ev_chain_go, 0));
     KLAUNCH_ON (h, h->stream3, k_arith_chain, dim3 ((A.nbig + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), A.reserve_cu ? GZ_CHAIN_LDS : 64,
-                d_leaves, A.d_big, A.nbig, (const GzDivInv *)h->d_inv_tab, (const uint32_t *)A.d_progress, (const uint32_t *)A.d_bounds, h->d_fail, A.d_progress + 16, A.n_chunks);
+                d_leaves, A.d_big, A.nbig, (const uint32_t *)A.d_progress, (const uint32_t *)A.d_bounds, h->d_fail, A.d_progress + 16, A.n_chunks);
     HIPCHK (h, hipEventRecord (h->ev_chain, h->stream3));
     return GZ_OK;
 }
@@ -737,7 +714,6 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
             KLAUNCH_ON (h, side, k_rans_encode, dim3 (nl), dim3 (64), GZ_RANS_ENC_LDS, d_leaves);
         }
         if (A.np) {
-            const GzDivInv *inv_tab = (const GzDivInv *)h->d_inv_tab;
             const uint32_t grid_y = GZ_MODEL_GRID_Y + (P.rle_list.empty () ? 0 : GZ_MODEL_GRID_RUN);
             if (!P.rle_list.empty ())                              // the run-length variant's coding events (before anything looks at arith_n)
                 KLAUNCH (h, k_rle_events, dim3 ((uint32_t)P.rle_list.size ()), dim3 (1024), 256, d_leaves, A.d_rle);
@@ -755,7 +731,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 if (P.unpacked) KLAUNCH (h, k_arith_model<false>, GZ_XCD_DIM (A.np, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_plain, A.np, 0u, 0xffffffffu, 0u);
                 else            KLAUNCH (h, k_arith_model<true>,  GZ_XCD_DIM (A.np, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_plain, A.np, 0u, 0xffffffffu, 0u);
                 KLAUNCH (h, k_arith_chain, dim3 ((A.np + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), 64,
-                         d_leaves, A.d_plain, A.np, inv_tab, (const uint32_t *)NULL, (const uint32_t *)NULL, h->d_fail, (uint32_t *)NULL, 0u);
+                         d_leaves, A.d_plain, A.np, (const uint32_t *)NULL, (const uint32_t *)NULL, h->d_fail, (uint32_t *)NULL, 0u);
             }
             else {
                 HIPCHK (h, hipEventRecord (h->ev_model_fork, h->stream));        // (after k_leaf_prep)
@@ -793,9 +769,9 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                     if (P.unpacked) KLAUNCH_ON (h, h->stream5, k_arith_model<false>, GZ_XCD_DIM (A.nsmall, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_small, A.nsmall, 0u, 0xffffffffu, 0u);
                     else            KLAUNCH_ON (h, h->stream5, k_arith_model<true>,  GZ_XCD_DIM (A.nsmall, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_small, A.nsmall, 0u, 0xffffffffu, 0u);
                     KLAUNCH_ON (h, h->stream5, k_arith_chain, dim3 ((A.nsmall + GZ_CHAIN_WAVES - 1) / GZ_CHAIN_WAVES), dim3 (64 * GZ_CHAIN_WAVES), GZ_KEEP_OFF_LDS,
-                                d_leaves, A.d_small, A.nsmall, inv_tab, (const uint32_t *)NULL, (const uint32_t *)NULL, h->d_fail, (uint32_t *)NULL, 0u);
+                                d_leaves, A.d_small, A.nsmall, (const uint32_t *)NULL, (const uint32_t *)NULL, h->d_fail, (uint32_t *)NULL, 0u);
                     if (A.nlb_small) {
-                        KLAUNCH_ON (h, h->stream5, k_chain_expand, dim3 (A.nlb_small), dim3 (64), GZ_EXPAND_LDS, d_leaves, A.d_lb_small, (const uint32_t *)NULL, inv_tab, 0u, h->debug_chain_fault);
+                        KLAUNCH_ON (h, h->stream5, k_chain_expand, dim3 (A.nlb_small), dim3 (64), GZ_EXPAND_LDS, d_leaves, A.d_lb_small, (const uint32_t *)NULL, 0u, h->debug_chain_fault);
                         KLAUNCH_ON (h, h->stream5, k_low_scan, dim3 (A.nsmall), dim3 (1024), 8192, d_leaves, A.d_small, 0u, 0xffffffffu);
                         KLAUNCH_ON (h, h->stream5, k_low_scatter, dim3 (A.nlb_small), dim3 (GZ_LOW_WG), GZ_KEEP_OFF_LDS, d_leaves, A.d_lb_small, (const uint32_t *)NULL, 0u);
                     }
@@ -811,7 +787,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                     const uint32_t span = P.max_arith_n - p0 < len ? P.max_arith_n - p0 : len;
                     const uint32_t wgs = (span + GZ_LOW_SLICE * GZ_LOW_SLICES_PER_WG - 1) / (GZ_LOW_SLICE * GZ_LOW_SLICES_PER_WG);
                     hipLaunchKernelGGL (k_low_gate, dim3 (1), dim3 (1), 0, h->stream6, (const uint32_t *)(A.d_progress + 16 + k), A.nbig, h->d_fail);
-                    KLAUNCH_ON (h, h->stream6, k_chain_expand, dim3 (A.nbig, wgs), dim3 (64), GZ_EXPAND_LDS, d_leaves, (const GzdLowBlock *)NULL, A.d_big, inv_tab, p0, h->debug_chain_fault);
+                    KLAUNCH_ON (h, h->stream6, k_chain_expand, dim3 (A.nbig, wgs), dim3 (64), GZ_EXPAND_LDS, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0, h->debug_chain_fault);
                     KLAUNCH_ON (h, h->stream6, k_low_scan, dim3 (A.nbig), dim3 (1024), 8192, d_leaves, A.d_big, p0, len);
                     KLAUNCH_ON (h, h->stream6, k_low_scatter, dim3 (A.nbig, wgs), dim3 (GZ_LOW_WG), GZ_KEEP_OFF_LDS, d_leaves, (const GzdLowBlock *)NULL, A.d_big, p0);
                 }
@@ -820,7 +796,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_low, 0));
             }
             if (!A.pipelined) {
-                KLAUNCH (h, k_chain_expand, dim3 (A.nlb), dim3 (64), GZ_EXPAND_LDS, d_leaves, A.d_lb, (const uint32_t *)NULL, inv_tab, 0u, h->debug_chain_fault);
+                KLAUNCH (h, k_chain_expand, dim3 (A.nlb), dim3 (64), GZ_EXPAND_LDS, d_leaves, A.d_lb, (const uint32_t *)NULL, 0u, h->debug_chain_fault);
                 KLAUNCH (h, k_low_scan, dim3 (A.np), dim3 (1024), 8192, d_leaves, A.d_plain, 0u, 0xffffffffu);
                 KLAUNCH (h, k_low_scatter, dim3 (A.nlb), dim3 (GZ_LOW_WG), 4 * 144 * 4, d_leaves, A.d_lb, (const uint32_t *)NULL, 0u);
             }
@@ -1017,6 +993,15 @@ extern "C" int gz_codec_uncompress_batch (GzHandle *h, GzStream *streams, int n_
 // sync: wait, fetch results, recycle the arena
 // ---------------------------------------------------------------------------------------------------------
 static int gz_sync_do (GzHandle *h);
+
+extern "C" int gz_debug_record_inv (GzHandle *h, uint32_t tot0, uint32_t n, uint32_t *out_dev)
+{
+    if (!h || !out_dev) return GZ_ERR_ARG;
+    if (!n) return GZ_OK;
+    KLAUNCH (h, k_debug_record_inv, dim3 ((n + 255) / 256), dim3 (256), 0, tot0, n, out_dev);
+    HIPCHK (h, hipStreamSynchronize (h->stream));
+    return GZ_OK;
+}
 
 extern "C" int gz_sync (GzHandle *h)
 {

@@ -145,17 +145,16 @@ __device__ static inline double gz_fma_rtz (double a, double b, double c) { retu
 #include "gz_chain_asm.h"
 #endif
 // Whole blocks of GZ_CHAIN_BLOCK symbols of one leaf's chain (tools/gen_chain_asm.py explains the loop). (rlo, rhi) = the state,
-// a double (range * 2^-7), wave-uniform in and out; recs = the 8-byte records of the first block; inv_tab = the reciprocals of every
-// total (8 bytes each); ck = where the first block's first checkpoint goes (8 bytes per 64 symbols, scalar stores).
-__device__ static inline void gz_chain_blocks (uint32_t &rlo, uint32_t &rhi, const uint8_t *recs, const void *inv_tab, uint32_t nblk, uint32_t *ck)
+// a double (range * 2^-7), wave-uniform in and out; recs = the 12-byte records of the first block; ck = where the first block's first
+// checkpoint goes (8 bytes per 64 symbols, scalar stores).
+__device__ static inline void gz_chain_blocks (uint32_t &rlo, uint32_t &rhi, const uint8_t *recs, uint32_t nblk, uint32_t *ck)
 {
-    const uint64_t b = (uint64_t)(uintptr_t)recs, c = (uint64_t)(uintptr_t)ck, t = (uint64_t)(uintptr_t)inv_tab;
+    const uint64_t b = (uint64_t)(uintptr_t)recs, c = (uint64_t)(uintptr_t)ck;
     const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)b), b_hi = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)(b >> 32));
     const uint32_t c_lo = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)c), c_hi = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)(c >> 32));
-    const uint32_t t_lo = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)t), t_hi = (uint32_t)__builtin_amdgcn_readfirstlane ((int)(uint32_t)(t >> 32));
     const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane ((int)nblk);
     asm volatile (GZ_CHAIN_F64_ASM : [rlo] "+v"(rlo), [rhi] "+v"(rhi)
-                                   : [blo] "s"(b_lo), [bhi] "s"(b_hi), [nblk] "s"(nb), [clo] "s"(c_lo), [chi] "s"(c_hi), [tlo] "s"(t_lo), [thi] "s"(t_hi) : GZ_CHAIN_F64_CLOBBERS);
+                                   : [blo] "s"(b_lo), [bhi] "s"(b_hi), [nblk] "s"(nb), [clo] "s"(c_lo), [chi] "s"(c_hi) : GZ_CHAIN_F64_CLOBBERS);
     rlo = (uint32_t)__builtin_amdgcn_readfirstlane ((int)rlo); rhi = (uint32_t)__builtin_amdgcn_readfirstlane ((int)rhi);   // (the state ends in lane 0)
 }
 // one 8-byte checkpoint through the scalar unit

@@ -12,8 +12,9 @@
 //                  interact: one wave per (leaf, context), 64 occurrences at a time through closed formulas (prefix
 //                  counts inside the batch: LDS masks + a DPP scan); order changes (swaps, hops) are events - up to 64
 //                  symbols: the model in registers, events patched in one by one; wider alphabets: the model in LDS
-//                  tables, the batch in ROUNDS (everything that no earlier event can reach commits at once). Writes an
-//                  8-byte record per position: tot | cum << 16, freq as the high word of a double.
+//                  tables, the batch in ROUNDS (everything that no earlier event can reach commits at once). Writes a
+//                  12-byte record per position: the reciprocal of tot as a double with cum in its low 16 bits, freq as
+//                  the high word of a double.
 //   k_arith_chain  what is truly serial: range -> range / tot * freq -> renormalise. One wave per leaf, three vector
 //                  instructions per symbol in double precision, the state hopping a lane per symbol (gz_chain_asm.h);
 //                  persistent, following the models position chunk by chunk.
@@ -28,27 +29,47 @@
 #define GZ_MODEL_STEP  16u
 
 // range / tot without dividing and without the integer unit: in double precision, rounding toward zero,
-//      fma (range * 2^-7, inv, 1.0) = 1 + floor (range / tot) * 2^-52        with inv = 2^(7 - 52) / tot rounded UP to a double
-// (the product inside the fma is exact; inv errs by < 2^-52 relative, range / tot < 2^32, so the quotient errs by < 2^-20 - far less
-// than the 1 / tot by which a quotient that is not an integer stays below the next one - and never falls below an exact quotient).
-// The low half of the result IS the quotient as an integer. The table of inv for every model total is built by the host (gz_create).
-struct GzDivInv { uint32_t lo, hi; };
-
-// record of one symbol, written by the model for the chain and the low kernels: 8 bytes (rounds 1-5: 16 - { inv as a double, freq, cum }:
-// every record was written once and read twice, 48 bytes of traffic a symbol before write amplification)
-//      x = tot | cum << 16          (tot <= 65519 at the time a symbol is coded: c_simple_model.h:63,131-137; cum < tot)
-//      y = the high word of the double freq * 2^45 (its low word is 0: freq < 2^16) - the chain's operand F as it is
-// The reciprocal of tot comes from the table, looked up by whoever reads the record (the chain: a block ahead, outside the serial hops).
+//      fma (range * 2^-7, inv, 1.0) = 1 + floor (range / tot) * 2^-52        with inv >= 2^(7 - 52) / tot, too large by < 2^-32 of itself
+// (the product inside the fma is exact; a quotient that is not an integer stays 1 / tot below the next one, so range / tot * error <
+// 1 / tot - range * error < 1 - keeps the floor, and an inv that is never too small never falls below an exact quotient:
+// tests/test_magic.py, in integer arithmetic for every total). The low half of the result IS the quotient as an integer.
+//
+// record of one symbol, written by the model for the chain and the low kernels: 12 bytes (rounds 1-4: 16 - { inv as a double, freq, cum })
+//      lo = the low word of inv, the symbol's cum in its low 16 bits (cum < tot <= 65519) - chain and expand use the SAME double, cum and all
+//      hi = the high word of inv
+//      f  = the high word of the double freq * 2^45 (its low word is 0: freq < 2^16) - the chain's operand F as it is
+// inv is made by the lane that writes the record, not looked up (rounds 1-4 fetched it from a 512 KB table: a 64-address gather per
+// batch of every context's wave, a fifth of k_arith_model's time in the streamed form): the hardware's reciprocal seed and one Newton
+// step with the constant 1 + 2^-34 give 1 / tot * (1 + 2^-34 +- 2^-40) whatever the seed's last bits are (v_rcp_f64 is good to ~2^-27;
+// a seed of 2^-20 would do), clearing the 16 low bits for cum takes off < 2^-36, and 2^-34 + 2^-35 (cum) < 2^-32.
+// (gz_debug_record_inv + tests/test_gpu.py::test_record_reciprocals: every total on the device against the admissible interval.)
+struct __attribute__((packed, aligned (4))) GzRec { uint32_t lo, hi, f; };
 #define GZ_REC_F_EXP (1023u + 45u)
-__device__ static inline uint2 d_model_record (uint32_t cum, uint32_t freq, uint32_t tot)
+__device__ static __forceinline__ void d_record_inv (uint32_t tot, uint32_t &lo, uint32_t &hi)
 {
-    return make_uint2 (tot | cum << 16, (uint32_t)__double2hiint ((double)freq) + (45u << 20));      // (the conversion is exact in any rounding mode)
+    const double d = (double)tot;
+    double r = gz_rcp_f64 (d);
+    r = __builtin_fma (__builtin_fma (-d, r, 1.0 + 0x1p-34), r, r);
+    lo = (uint32_t)__double2loint (r) & 0xffff0000u; hi = (uint32_t)__double2hiint (r) - (45u << 20);      // * 2^-45
 }
-__device__ static inline uint32_t d_record_tot (uint2 r) { return r.x & 0xffffu; }
-__device__ static inline uint32_t d_record_cum (uint2 r) { return r.x >> 16; }
-__device__ static inline uint32_t d_record_freq (uint2 r) { return ((r.y & 0xfffffu) | 0x100000u) >> (20u - ((r.y >> 20) - GZ_REC_F_EXP)); }
+__device__ static __forceinline__ GzRec d_model_record (uint32_t cum, uint32_t freq, uint32_t tot)
+{
+    uint32_t lo, hi; d_record_inv (tot, lo, hi);
+    GzRec r; r.lo = lo | cum; r.hi = hi;
+    r.f = (uint32_t)__double2hiint ((double)freq) + (45u << 20);      // (the conversion is exact in any rounding mode)
+    return r;
+}
+__device__ static inline uint32_t d_record_cum (uint32_t lo) { return lo & 0xffffu; }
+__device__ static inline uint32_t d_record_freq (uint32_t f) { return ((f & 0xfffffu) | 0x100000u) >> (20u - ((f >> 20) - GZ_REC_F_EXP)); }
 
-__device__ static __forceinline__ void d_record_store (uint2 *at, uint2 v) { *at = v; }
+__device__ static __forceinline__ void d_record_store (GzRec *at, GzRec v) { *at = v; }
+
+// (tests) the reciprocal a record of total tot0 + thread would carry
+__global__ void k_debug_record_inv (uint32_t tot0, uint32_t n, uint32_t *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { uint32_t lo, hi; d_record_inv (tot0 + i, lo, hi); out[2 * i] = lo; out[2 * i + 1] = hi; }
+}
 
 // Values loaded from the leaf table arrive through vector loads, so the compiler must assume they differ per lane and
 // turns every loop / branch on them into exec-mask code. They are wave-uniform: say so.
@@ -773,7 +794,7 @@ __device__ unsigned long long g_mph[9];
 #define GZ_ROUNDS_MINJ 2                   // (-DGZ_ROUNDS_MINJ=1: the one-plane models in rounds as well)
 #endif
 template <int J, bool PK, bool O1, bool LA>
-__device__ static __forceinline__ void d_arith_model_wave_ (const uint8_t *in, uint32_t ms, uint2 *recs,
+__device__ static __forceinline__ void d_arith_model_wave_ (const uint8_t *in, uint32_t ms, GzRec *recs,
                                                    const uint8_t *symlist, const uint16_t *symrank, uint32_t nsym,
                                                    const uint32_t *spos, const uint8_t *srk, uint32_t j0, uint32_t j1, bool first, bool save, uint32_t *st,
                                                    const GzLocalAlpha *la = nullptr)
@@ -810,8 +831,8 @@ __device__ static __forceinline__ void d_arith_model_wave_ (const uint8_t *in, u
     unsigned long long mph_[7] = { 0, 0, 0, 0, 0, 0, 0 }, mt_ = wall_clock64 (), mph_r_ = 0;
 #endif
 
-    // (a batch's records leave as soon as the batch is done: 8 bytes an occurrence, nothing to look up - until round 5 they carried the
-    //  reciprocal of the total, fetched from the table while the NEXT batch was worked on)
+    // (a batch's records leave as soon as the batch is done: 12 bytes an occurrence, nothing to look up - until round 4 they carried the
+    //  reciprocal of the total from a table, fetched while the NEXT batch was worked on)
     // The occurrences of the following batches are fetched while this one is being worked on. The raw loads (sorted position +
     // rank byte, or the input byte of an order-0 leaf) run FOUR TO EIGHT batches ahead: a batch without events is ~300 ns of work, a trip
     // to memory 1-2 us, so one batch ahead (as it was) left a context whose order is stable waiting for its next occurrences most of the
@@ -923,7 +944,7 @@ __device__ unsigned long long g_model_slowest;     // (10 ns ticks << 40) | (lis
 #define GZ_MODEL_T1(ctx, occ) do {} while (0)
 #endif
 template <int J, bool PK>                   // PK: the sorted lists of this batch carry position << 8 | rank (no srk array): k_ctx_scatter
-__device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, uint32_t ms, bool o1, uint2 *recs,
+__device__ static __forceinline__ void d_arith_model_wave (const uint8_t *in, uint32_t ms, bool o1, GzRec *recs,
                                                    const uint8_t *symlist, const uint16_t *symrank, uint32_t nsym,
                                                    const uint32_t *spos, const uint8_t *srk, uint32_t j0, uint32_t j1, bool first, bool save, uint32_t *st,
                                                    const GzLocalAlpha *la = nullptr)
@@ -953,7 +974,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
     else if (L.nsym <= 64 && by && (!L.o1 || by > L.nsym)) return;
     const uint32_t ms = L.max_sym;
     const bool o1 = L.o1, rle = L.rle;
-    uint2 *tr = d_uniform_ptr ((uint2 *)L.triples);
+    GzRec *tr = d_uniform_ptr ((GzRec *)L.triples);
     const uint8_t *coded = d_uniform_ptr (L.coded);
     const uint32_t n_u = d_uniform (L.arith_n), ms_u = d_uniform (ms), nsym_u = d_uniform (L.nsym), nctx = d_uniform (L.nctx);
     const bool o1_u = d_uniform (o1 ? 1u : 0u) != 0, rle_u = d_uniform (rle ? 1u : 0u) != 0;
@@ -1057,9 +1078,9 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
 //                      R = fma (T, F, -F)                F = freq * 2^45: r * freq * 2^-7, exact
 //                      R.hi = R.hi & 0x7fffff | 0x41000000     the exponent's low three bits stay, the others become those of
 //                                                        [2^24, 2^32): exactly "shift left by whole bytes until >= 2^24"
-//                  and NO operand fetch in the loop: lane j holds the operands of symbols base + 12 j .. + 11 (8-byte records
-//                  loaded coalesced two blocks of 768 symbols ahead, the reciprocals of their totals from the table one block
-//                  ahead), all lanes execute every step, the state hops to the next lane through a DPP read of r - after the 12
+//                  and NO operand fetch in the loop: lane j holds the operands of symbols base + 12 j .. + 11 (12-byte records
+//                  loaded coalesced a block of 768 symbols ahead, straight into the registers the loop reads), all lanes
+//                  execute every step, the state hops to the next lane through a DPP read of r - after the 12
 //                  symbols a lane holds, because a DPP read of a fresh result costs two wait states (gz_chain_asm.h, written by
 //                  tools/gen_chain_asm.py): ~15.8 clocks = 6.6 ns per symbol, the same with 1 or 64 chains on the device. It never looks at cum or low, and stores only the state
 //                  before every 64th symbol: k_chain_expand recomputes r = range / tot of every symbol from those for the low
@@ -1118,35 +1139,34 @@ __device__ static inline bool d_wait_progress (const uint32_t *progress, uint32_
 }
 
 // positions [i0, i1) one symbol at a time in the plain formulation (the end of a leaf that does not fill a block of the loop; i0 a
-// multiple of 64): 64 records per trip to memory, fetched by the lanes - each with the reciprocal of its total - and handed out by
-// readlane; the state before every 64th symbol goes out as in the loop
-__device__ static inline void d_chain_slow (uint32_t &rlo, uint32_t &rhi, int lane, uint32_t i0, uint32_t i1, const uint8_t *triples, const GzDivInv *inv_tab, uint32_t *ck)
+// multiple of 64): 64 records per trip to memory, fetched by the lanes and handed out by readlane; the state before every 64th
+// symbol goes out as in the loop
+__device__ static inline void d_chain_slow (uint32_t &rlo, uint32_t &rhi, int lane, uint32_t i0, uint32_t i1, const uint8_t *triples, uint32_t *ck)
 {
     for (uint32_t g = i0; g < i1; g += 64) {
         gz_scalar_store2 (ck + 2 * (g >> 6), rlo, rhi);
-        const uint2 mine = ((const uint2 *)triples)[g + lane];  // (beyond i1: inside the padded area, not looked at - but it picks a table entry: any)
-        const GzDivInv iv = inv_tab[d_record_tot (mine)];
-        const uint32_t fq = g + lane < i1 ? d_record_freq (mine) : 1u;
+        const GzRec mine = ((const GzRec *)triples)[g + lane];  // (beyond i1: inside the padded area, not looked at)
+        const uint32_t fq = g + lane < i1 ? d_record_freq (mine.f) : 1u;
         const int m = i1 - g < 64 ? (int)(i1 - g) : 64;
-        for (int j = 0; j < m; j++) (void)d_chain_step (rlo, rhi, d_readlane (iv.lo, j), d_readlane (iv.hi, j), d_readlane (fq, j));
+        for (int j = 0; j < m; j++) (void)d_chain_step (rlo, rhi, d_readlane (mine.lo, j), d_readlane (mine.hi, j), d_readlane (fq, j));
     }
 }
 
 // positions [p0, p1) of one leaf (p0 a multiple of 64; p1 - p0 one of GZ_CHAIN_BLOCK unless p1 is the leaf's end)
 // What leaves the chain is the state BEFORE every 64th symbol (8 bytes at ck + 2 * (i / 64)) and the state after the last symbol
 // of the call (the next call's first checkpoint, or the leaf's closing one): one scalar store per 64 symbols.
-__device__ static __forceinline__ void d_chain_chunk (uint32_t &rlo, uint32_t &rhi, int lane, uint32_t p0, uint32_t p1, const uint8_t *triples, const GzDivInv *inv_tab, uint32_t *ck)
+__device__ static __forceinline__ void d_chain_chunk (uint32_t &rlo, uint32_t &rhi, int lane, uint32_t p0, uint32_t p1, const uint8_t *triples, uint32_t *ck)
 {
     const uint32_t whole = p0 + (p1 - p0) / GZ_CHAIN_BLOCK * GZ_CHAIN_BLOCK;
     uint32_t i = p0;
-    if (whole > p0) { gz_chain_blocks (rlo, rhi, triples + (size_t)p0 * GZ_CHAIN_REC, inv_tab, (whole - p0) / GZ_CHAIN_BLOCK, ck + 2 * (p0 >> 6)); i = whole; }
-    if (i < p1) d_chain_slow (rlo, rhi, lane, i, p1, triples, inv_tab, ck);     // the end of the leaf
+    if (whole > p0) { gz_chain_blocks (rlo, rhi, triples + (size_t)p0 * GZ_CHAIN_REC, (whole - p0) / GZ_CHAIN_BLOCK, ck + 2 * (p0 >> 6)); i = whole; }
+    if (i < p1) d_chain_slow (rlo, rhi, lane, i, p1, triples, ck);     // the end of the leaf
     gz_scalar_store2 (ck + 2 * ((p1 + 63) >> 6), rlo, rhi);
 }
 
 // progress == NULL: everything is there already, one piece (bounds is ignored). bounds [0 .. n_chunks]: where the position chunks start (the
 // first ones are shorter than the rest: the first chunk's sort + models are the lead-in of the long streams - gz_host.cpp, arith_pipe_setup)
-__device__ static __forceinline__ void d_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const GzDivInv *inv_tab, const uint32_t *progress, const uint32_t *bounds,
+__device__ static __forceinline__ void d_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress, const uint32_t *bounds,
                                                       uint32_t *fail, uint32_t *done, uint32_t n_chunks)
 {
     const uint32_t li = blockIdx.x * GZ_CHAIN_WAVES + (threadIdx.x >> 6);
@@ -1164,13 +1184,13 @@ __device__ static __forceinline__ void d_arith_chain (GzdLeaf *leaves, const uin
     const uint8_t *triples = d_uniform_ptr (L.triples);        // (wave-uniform: keep them in scalar registers)
     uint32_t *ck = d_uniform_ptr ((uint32_t *)L.ckpt);          // (checkpoints: the state before every 64th symbol, 8 bytes each)
     uint32_t rlo = GZ_CHAIN_R0_LO, rhi = GZ_CHAIN_R0_HI;
-    if (!progress) d_chain_chunk (rlo, rhi, lane, 0, n, triples, inv_tab, ck);
+    if (!progress) d_chain_chunk (rlo, rhi, lane, 0, n, triples, ck);
     else
         for (uint32_t k = 0; k < n_chunks; k++) {
             const uint32_t p0 = d_uniform (bounds[k]), pe = d_uniform (bounds[k + 1]);
             if (p0 >= n) break;
             if (k && !d_wait_progress (progress, k + 1)) { if (!lane) { L.overflow = 2; *fail = 1; } break; }
-            d_chain_chunk (rlo, rhi, lane, p0, pe < n ? pe : n, triples, inv_tab, ck);
+            d_chain_chunk (rlo, rhi, lane, p0, pe < n ? pe : n, triples, ck);
             if (done) {                                        // this leaf's checkpoints of chunk k are final: tell the low kernels
                 gz_scalar_store_flush ();
                 __threadfence ();
@@ -1183,10 +1203,10 @@ __device__ static __forceinline__ void d_arith_chain (GzdLeaf *leaves, const uin
     gz_scalar_store_flush ();
 }
 
-__global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const GzDivInv *inv_tab, const uint32_t *progress,
+__global__ void __launch_bounds__(64 * GZ_CHAIN_WAVES) k_arith_chain (GzdLeaf *leaves, const uint32_t *list, uint32_t n_list, const uint32_t *progress,
                                                                       const uint32_t *bounds, uint32_t *fail, uint32_t *done, uint32_t n_chunks)
 {
-    d_arith_chain (leaves, list, n_list, inv_tab, progress, bounds, fail, done, n_chunks);
+    d_arith_chain (leaves, list, n_list, progress, bounds, fail, done, n_chunks);
 }
 
 // One thread: holds its stream until all `want` leaves of the persistent chain have finished a position chunk (the low
@@ -1237,12 +1257,13 @@ __device__ static inline GzdLowBlock d_low_block (const GzdLowBlock *blocks, con
 // through LDS so that they are written row by row), and k = the bytes low and range move up after it - two bits, the slice's 64 of
 // them are 16 bytes written by its lane, and their sum is the slice's entry in the prefix sum of output positions (k_low_scan).
 // (Until round 4 this kernel wrote r, and k_low_count / k_low_scatter each read every symbol's 16-byte record again for freq and cum:
-// 60 bytes of traffic per symbol between the three; round 4: 25; with the 8-byte record: 17.)
+// 60 bytes of traffic per symbol between the three; round 4: 25; with the 12-byte record: 21.)
 // Same grid as the low kernels that follow it (one workgroup = 64 slices), 64 threads, GZ_EXPAND_LDS bytes of LDS.
 #define GZ_EXPAND_TILE_BYTES (64 * 65 * 4)          // 16 640: the tile of a = cum * r values, [64 slices][65]
-#define GZ_EXPAND_LDS (GZ_EXPAND_TILE_BYTES + 64 * 17 * 8)
+#define GZ_EXPAND_ROW 28                            // dwords of a slice's row in the staging area: 8 records x 3 + 4 (rows stay 16-byte aligned)
+#define GZ_EXPAND_LDS (GZ_EXPAND_TILE_BYTES + 64 * GZ_EXPAND_ROW * 4)
 // fault: 0, or (GZ_DEBUG_CHAIN_FAULT, tests only) 1 + the index of a slice that is treated as if it had missed the chain's checkpoint
-__global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const GzdLowBlock *blocks, const uint32_t *list, const GzDivInv *inv_tab, uint32_t p0, uint32_t fault)
+__global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const GzdLowBlock *blocks, const uint32_t *list, uint32_t p0, uint32_t fault)
 {
     const GzdLowBlock B = d_low_block (blocks, list, p0);
     GzdLeaf &L = leaves[B.leaf];
@@ -1251,7 +1272,7 @@ __global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const Gzd
     if (B.first_slice >= ns) return;
     gz_f64_round_toward_zero ();
     const int lane = threadIdx.x;
-    const uint2 *rec = (const uint2 *)L.triples;
+    const uint8_t *rec = L.triples;
     uint32_t *av = (uint32_t *)L.rvals;
     uint32_t *tile = (uint32_t *)gz_lds;                        // [64 slices][65]
     const uint32_t slice = B.first_slice + lane, i0 = slice * GZ_LOW_SLICE;
@@ -1259,52 +1280,44 @@ __global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const Gzd
     const uint32_t *ck = (const uint32_t *)L.ckpt + 2 * (size_t)(mine ? slice : 0);
     uint32_t rlo = ck[0], rhi = ck[1], kb[4] = { 0, 0, 0, 0 }, ksum = 0;
     const uint32_t m = !mine || i0 >= n ? 0u : (i0 + 64 <= n ? 64u : n - i0);      // (an empty leaf has one empty slice)
-    // The records of 64 slices x 16 symbols at a time, loaded COALESCED - eight lanes take the sixteen records (one 128-byte line) of a
-    // slice, two each, eight slices per load instruction - and handed to the slices' lanes through the LDS. (As `rec[i0 + j]` per lane
-    // this was one flat load per symbol waited for on the spot.) The next sixteen are in flight while these are worked on; a lane then
-    // asks the table for the reciprocals of its sixteen totals at once (the table is 512 KB and lives in the L2).
-    uint2 *stage = (uint2 *)(gz_lds + GZ_EXPAND_TILE_BYTES);       // [64 slices][16 + 1]
-    const uint32_t ld_s = (uint32_t)lane >> 3, ld_j = (uint32_t)lane & 7;
-    uint4 nx[8];
-    auto load16 = [&] (uint32_t jbase) {
+    // The records of 64 slices x 8 symbols at a time (96 bytes a slice), loaded COALESCED - six lanes take a slice's six 16-byte pieces,
+    // 384 pieces in six load instructions - and handed to the slices' lanes through the LDS. (As `rec[i0 + j]` per lane this was one flat
+    // load per symbol waited for on the spot; eight global loads per trip, still one line per lane, made 6.4 -> 4.7 ms of it per default
+    // step: every line then came from the L2 eight times.) The next eight are in flight while these are worked on.
+    uint32_t *stage = (uint32_t *)(gz_lds + GZ_EXPAND_TILE_BYTES);     // [64 slices][GZ_EXPAND_ROW]
+    uint4 nx[6];
+    auto load8 = [&] (uint32_t jbase) {
         #pragma unroll
-        for (uint32_t it = 0; it < 8; it++) {
-            const uint32_t sl = B.first_slice + it * 8 + ld_s, idx = sl * GZ_LOW_SLICE + jbase + 2 * ld_j;
-            nx[it] = gz_ldg_u32x4 (rec + (sl < ns && idx < n ? idx : 0));        // (a leaf's records are padded to whole lines)
+        for (uint32_t it = 0; it < 6; it++) {
+            const uint32_t g = it * 64 + (uint32_t)lane, s = g / 6, c = g % 6, sl = B.first_slice + s;
+            const bool in = sl < ns && sl * GZ_LOW_SLICE + jbase < n;          // (a leaf's records are padded beyond n: whole pieces)
+            nx[it] = gz_ldg_u32x4 (rec + (in ? ((size_t)sl * GZ_LOW_SLICE + jbase) * GZ_CHAIN_REC + c * 16 : 0));
         }
     };
-    // sixteen symbols at a time; the records and reciprocals of the NEXT sixteen are fetched while these are worked on
-    uint2 c[2][16]; uint32_t ivl[2][16], ivh[2][16];
-    auto fetch16 = [&] (uint32_t q, uint2 (&cq)[16], uint32_t (&il)[16], uint32_t (&ih)[16]) {      // nx holds the records of symbols 16 q .. of every slice
-        #pragma unroll
-        for (uint32_t it = 0; it < 8; it++) {
-            stage[(it * 8 + ld_s) * 17 + 2 * ld_j]     = make_uint2 (nx[it].x, nx[it].y);
-            stage[(it * 8 + ld_s) * 17 + 2 * ld_j + 1] = make_uint2 (nx[it].z, nx[it].w);
-        }
-        gz_wave_sync ();
-        if (q + 1 < 4) load16 (16 * (q + 1));
-        #pragma unroll
-        for (uint32_t u = 0; u < 16; u++) cq[u] = stage[lane * 17 + u];
-        gz_wave_sync ();
-        #pragma unroll
-        for (uint32_t u = 0; u < 16; u++) {
-            const uint2 e = gz_ldg_u32x2 (inv_tab + (16 * q + u < m ? d_record_tot (cq[u]) : 1u));
-            il[u] = e.x; ih[u] = e.y;
-        }
-    };
-    load16 (0);
-    fetch16 (0, c[0], ivl[0], ivh[0]);
+    load8 (0);
     #pragma unroll
     for (uint32_t q = 0; q < 4; q++) {
         uint32_t kw = 0;
-        const uint32_t j0 = q * 16;
-        if (q + 1 < 4) fetch16 (q + 1, c[(q + 1) & 1], ivl[(q + 1) & 1], ivh[(q + 1) & 1]);
         #pragma unroll
-        for (uint32_t u = 0; u < 16; u++) if (j0 + u < m) {
-            uint32_t k;
-            const uint32_t r = d_chain_step (rlo, rhi, ivl[q & 1][u], ivh[q & 1][u], d_record_freq (c[q & 1][u]), &k);
-            tile[lane * 65 + j0 + u] = d_record_cum (c[q & 1][u]) * r;
-            kw |= k << (2 * u); ksum += k;
+        for (uint32_t h = 0; h < 2; h++) {
+            const uint32_t j0 = q * 16 + h * 8;
+            #pragma unroll
+            for (uint32_t it = 0; it < 6; it++) { const uint32_t g = it * 64 + (uint32_t)lane; *(uint4 *)(stage + (g / 6) * GZ_EXPAND_ROW + (g % 6) * 4) = nx[it]; }
+            gz_wave_sync ();
+            if (j0 + 8 < 64) load8 (j0 + 8);
+            uint4 c4[6];
+            #pragma unroll
+            for (uint32_t u = 0; u < 6; u++) c4[u] = *(const uint4 *)(stage + lane * GZ_EXPAND_ROW + u * 4);
+            gz_wave_sync ();
+            const uint32_t w[24] = { c4[0].x, c4[0].y, c4[0].z, c4[0].w, c4[1].x, c4[1].y, c4[1].z, c4[1].w, c4[2].x, c4[2].y, c4[2].z, c4[2].w,
+                                     c4[3].x, c4[3].y, c4[3].z, c4[3].w, c4[4].x, c4[4].y, c4[4].z, c4[4].w, c4[5].x, c4[5].y, c4[5].z, c4[5].w };
+            #pragma unroll
+            for (uint32_t u = 0; u < 8; u++) if (j0 + u < m) {
+                uint32_t k;
+                const uint32_t r = d_chain_step (rlo, rhi, w[3 * u], w[3 * u + 1], d_record_freq (w[3 * u + 2]), &k);
+                tile[lane * 65 + j0 + u] = d_record_cum (w[3 * u]) * r;
+                kw |= k << (2 * (h * 8 + u)); ksum += k;
+            }
         }
         kb[q] = kw;
     }

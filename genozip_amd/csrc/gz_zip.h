@@ -88,6 +88,24 @@ static inline bool zip_not_representative (const GzFastqPlan &plan, const GzFast
 }
 #define ZIP_RETEST_VB_I 10u            // src/codec.c:22
 
+// What ONE call of codec_assign_best_codec does with a context section whose codec the segmenter left open (normal mode: neither --best
+// nor --fast; src/codec.c:259-283, 309-312, 352-363) - the decisions in front of the trials and behind them, as one rule:
+//   bit 0  the trials run (else: the section takes the file's codec z_codec - or none: < 50 bytes and the file has none)
+//   bit 1  their result is committed to the file's context - not from a VBlock of at most MIN (4 MB, vb_size / 2) of text (:352), and a
+//          LOCAL codec not from VBlock 1 of a context whose beginning may not be representative unless it is the file's last (:358-362)
+//   bit 2  it is VBlock 10's second look (RETEST_VB_I, :274-277): the trials run although the file has a codec
+// pinned to the reference's own function: tests/golden/assign_golden.json (oracle/ref_assign_shim.c)
+extern "C" int gz_codec_assign_rule (uint32_t vblock_i, uint64_t text_len, uint64_t vb_size, int last_of_file, int is_local,
+                                     int not_representative, int hard_coded, int z_codec, uint32_t data_len)
+{
+    const bool retest = vblock_i == ZIP_RETEST_VB_I && !(is_local && hard_coded) && not_representative;
+    if (!retest && z_codec) return 0;                                    // inherited (:280-281)
+    if (data_len < 50) return 0;                                         // MIN_LEN_FOR_COMPRESSION (:311-312)
+    const bool big = !vb_size || text_len > std::min<uint64_t> ((uint64_t)4 << 20, vb_size / 2);
+    const bool commits = big && (!is_local || vblock_i > (not_representative ? 1u : 0u) || last_of_file);
+    return 1 | (commits ? 2 : 0) | (retest && z_codec ? 4 : 0);
+}
+
 struct ZipVBState { std::vector<uint8_t> has_b250, has_local; std::vector<std::vector<uint8_t>> host_b250; };
 struct ZipDomq { uint8_t *out[4] = { NULL, NULL, NULL, NULL }; GzDomqResult res; uint32_t fit = 0; std::vector<uint8_t> snip; };   // one VBlock's QUAL through k_domq
 
@@ -1609,11 +1627,12 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
                         uint32_t L = 0; const uint8_t *p = NULL;
                         if (is_local && Z.has_local) { p = Z.local; L = Z.dyn_job >= 0 && !Z.host_len ? seclen[2 * ((size_t)v * NC + c)] : (uint32_t)Z.local_len; }
                         if (!is_local && Z.has_b250) { p = Z.sec_b250; L = Z.col_job >= 0 ? seclen[2 * ((size_t)v * NC + c) + 1] : Z.sec_b250_len; }
-                        if (L < 50) continue;
                         // a VBlock too small to speak for the file keeps its choice to itself, and the next one tests again (codec.c:352); so
                         // does VBlock 1 for the local of a context whose beginning may not be representative (:358-362)
-                        const bool commits = zip_vb_commits (f->plan, vbs[v]) &&
-                                             (!is_local || !zip_not_representative (f->plan, f->ctxs[c]) || vbs[v].vblock_i > 1 || (vbs[v].flags & GZ_VB_LAST_OF_FILE));
+                        const int rule = gz_codec_assign_rule (vbs[v].vblock_i, vbs[v].text_len, f->plan.vb_size, (vbs[v].flags & GZ_VB_LAST_OF_FILE) != 0, (int)is_local,
+                                                               zip_not_representative (f->plan, f->ctxs[c]), 0, 0, L);
+                        if (!(rule & 1)) continue;
+                        const bool commits = (rule & 2) != 0;
                         ptr.push_back (p); len.push_back (L); who.push_back ({ c, is_local | (commits ? 0u : 2u), vbs[v].vblock_i, 0 });
                         if (commits) break;
                     }
@@ -1633,8 +1652,10 @@ extern "C" int gz_fastq_zip_merge (GzZipFile *f, const void *const *blobs, const
                             uint32_t L = 0; const uint8_t *p = NULL;
                             if (is_local && Z.has_local) { p = Z.local; L = Z.dyn_job >= 0 && !Z.host_len ? seclen[2 * ((size_t)v * NC + c)] : (uint32_t)Z.local_len; }
                             if (!is_local && Z.has_b250) { p = Z.sec_b250; L = Z.col_job >= 0 ? seclen[2 * ((size_t)v * NC + c) + 1] : Z.sec_b250_len; }
-                            if (L < 50) continue;                                                        // (too short to test: :309-312, the file's codec stays)
-                            ptr.push_back (p); len.push_back (L); who.push_back ({ c, is_local | 4u | (zip_vb_commits (f->plan, vbs[v]) ? 0u : 2u), vbs[v].vblock_i, 0 });
+                            const int rule = gz_codec_assign_rule (vbs[v].vblock_i, vbs[v].text_len, f->plan.vb_size, (vbs[v].flags & GZ_VB_LAST_OF_FILE) != 0, (int)is_local,
+                                                                   1, 0, GZ_CODEC_RANB /* whatever the file has */, L);
+                            if (!(rule & 1)) continue;                                                   // (too short to test: :309-312, the file's codec stays)
+                            ptr.push_back (p); len.push_back (L); who.push_back ({ c, is_local | 4u | ((rule & 2) ? 0u : 2u), vbs[v].vblock_i, 0 });
                         }
             // predicted coding: every stream that waits for one of these trials goes to the coders now, on the second handle (idle: no long
             // streams were coded ahead in this call), with a predicted codec - see zip_predict_codec

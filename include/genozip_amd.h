@@ -70,6 +70,11 @@ int  gz_profile_get (GzHandle *h, int idx, char *name, int name_cap, double *tot
 int  gz_profile_get_max (GzHandle *h, int idx, double *max_ms);
 /* the HIP stream work is queued on (a hipStream_t) - for timing with HIP events on the right stream */
 void     *gz_stream (GzHandle *h);
+/* (tests) The reciprocal the arithmetic coder's model kernel puts into a symbol's record for the model totals tot0 .. tot0 + n - 1 (a double
+ * with 16 zero low bits, two words each into out_dev): RC_Encode's range / tot (c_range_coder.h:100) is exact with it as long as it lies in
+ * [2^-45 / tot, 2^-45 / tot * (1 + 2^-33)] - tests/test_magic.py shows that for the interval, tests/test_gpu.py::test_record_reciprocals that
+ * every total's value made on the device is inside. Synchronous. */
+int gz_debug_record_inv (GzHandle *h, uint32_t tot0, uint32_t n, uint32_t *out_dev);
 /* The section-writing kernels of h's NEXT gz_vb_compress_batch (layout, emit, adler32) wait until everything queued on `other`
  * so far has completed - for sections precompressed on another handle while this one's own coders run (no host wait). */
 int gz_emit_after (GzHandle *h, GzHandle *other);
@@ -155,6 +160,13 @@ enum { GZ_CODEC_BZ2 = 3, GZ_CODEC_LZMA = 4, GZ_CODEC_BSC = 5 };                 
  * reference's comparator is not a strict order, so what qsort makes of it depends on the C library: this is glibc's top-down
  * merge sort, what the reference's Linux builds run. */
 int gz_codec_assign_sort (GzCodecTest *tests, int n, int mode);
+/* What ONE call of codec_assign_best_codec does with a context section whose codec the segmenter left open, normal mode (src/codec.c:259-283,
+ * 309-312, 352-363): bit 0 the trials run (else the section takes the file's codec z_codec, or none), bit 1 their result is committed to the
+ * file's context (not from a VBlock of at most MIN (4 MB, vb_size / 2) of text; a local codec not from VBlock 1 of a context whose beginning
+ * may not be representative - dt_props.vb_1_not_representative by kind of dict_id, :199-209 - unless it is the file's last), bit 2 it is
+ * VBlock 10's second look (RETEST_VB_I). The VBlock compute driver decides with this function; host only. vb_size 0: no VBlock is small. */
+int gz_codec_assign_rule (uint32_t vblock_i, uint64_t text_len, uint64_t vb_size, int last_of_file, int is_local,
+                          int not_representative, int hard_coded, int z_codec, uint32_t data_len);
 /* The nine device candidates on the first min (in_len, 99 999) bytes of `in` (device) + the caller's `extra` rows, sorted.
  * clock_ns_per_byte (32 entries, by codec id): NULL - every device trial counts as "fast enough" (<= 5 ms: what the reference sees for samples of 100 KB on
  * any current CPU except with ARTW / ARTw on wide alphabets), so that among the device candidates the smaller size wins and the

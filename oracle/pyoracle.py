@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(_HERE, "liboracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libhtsref.so")
 CTXREF_SO = os.path.join(_HERE, "_ref", "libctxref.so")
+ASSIGNREF_SO = os.path.join(_HERE, "_ref", "libassignref.so")
 COMPREF_SO = os.path.join(_HERE, "_ref", "libcompref.so")
 
 CODEC_NONE, CODEC_RANB, CODEC_RANW, CODEC_RANb, CODEC_RANw = 1, 6, 7, 8, 9
@@ -754,6 +755,40 @@ class CompRef:
         if n < 0:
             raise RuntimeError("compref_section failed")
         return out.raw[:n]
+
+
+class AssignRef:
+    """the reference's OWN src/codec.c - codec_assign_sorter under the C library's qsort, and codec_assign_best_codec with its own
+    compressor.c / zfile.c / codec_htscodecs.c / htscodecs underneath - compiled in place (oracle/Makefile target `ref`,
+    oracle/ref_assign_shim.c: the clock and the sizes of BZ2 / BSC / LZMA are scripted). Row a8. Exists only where /root/reference does."""
+    NAMES = {"NONE": 1, "BZ2": 3, "LZMA": 4, "BSC": 5, "RANB": 6, "RANW": 7, "RANb": 8, "RANw": 9, "ARTB": 16, "ARTW": 17, "ARTb": 18, "ARTw": 19}
+
+    def __init__(self, path=ASSIGNREF_SO):
+        self.L = ctypes.CDLL(path)
+        self.L.assignref_sort.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        self.L.assignref_run.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p]
+
+    @staticmethod
+    def available():
+        return os.path.exists(ASSIGNREF_SO)
+
+    def sort(self, tests, mode=0):
+        """[(codec, size, clock)] in trial order -> the same rows as qsort (.., codec_assign_sorter) leaves them (src/codec.c:334)"""
+        import numpy as np
+        c = np.array([t[0] for t in tests], dtype=np.int32); s = np.array([t[1] for t in tests], dtype=np.float32); k = np.array([t[2] for t in tests], dtype=np.float32)
+        self.L.assignref_sort(c.ctypes.data, s.ctypes.data, k.ctypes.data, len(tests), mode)
+        return [(int(a), float(b), float(d)) for a, b, d in zip(c, s, k)]
+
+    def run(self, inp, dict_id, txt_len, vb_size, data, ticks):
+        """codec_assign_best_codec (src/codec.c:234): inp = the 14 integers of assignref_run. -> (out[5], [(name, size, clock)] the four
+        best rows --show-codec printed, or [] when no trial ran)"""
+        import numpy as np
+        import re
+        i = np.array(inp, dtype=np.int32); t = np.array(ticks, dtype=np.int32); o = np.zeros(8, dtype=np.int32)
+        shown = ctypes.create_string_buffer(512)
+        self.L.assignref_run(i.ctypes.data, bytes(dict_id).ljust(8, b"\0"), txt_len, vb_size, bytes(data), len(data), t.ctypes.data, o.ctypes.data, shown)
+        rows = [(self.NAMES[m.group(1)], int(m.group(2)), int(m.group(3))) for m in re.finditer(r"\[(\w+)\s+(\d+) B\s+(\d+) ", shown.value.decode("utf8", "replace"))]
+        return [int(x) for x in o[:5]], rows
 
 
 def vcf_sample_items(text, line_off, line_len, n_samples, n_sub):

@@ -191,3 +191,64 @@ def check_enc(got, want, what):
         assert got.hex() == want["hex"], what
     else:
         assert len(got) == want["len"] and hashlib.sha1(got).hexdigest() == want["sha1"], what
+
+
+# ---- row a8: codec_assign_best_codec, pinned to the reference's own src/codec.c (tests/golden/make_assign_golden.py) ----------------------
+ASSIGN_CAND = [1, 6, 7, 8, 9, 16, 17, 18, 19, 3, 5, 4]      # the trial order of src/codec.c:286-290: NONE, RAN x 4, ART x 4, BZ2, BSC, LZMA
+
+
+def assign_sort_tables(rounds=260, seed=5):
+    """tables of (codec, size, clock) around every threshold of codec_assign_sorter, 2 .. 12 rows"""
+    rnd = np.random.default_rng(seed)
+    out = []
+    for r in range(rounds):
+        n = int(rnd.integers(2, 13))
+        base = float(rnd.choice([60, 90, 5000, 40000]))
+        tests = []
+        for c in ASSIGN_CAND[:n]:
+            size = float(int(base * rnd.choice([1.0, 0.995, 0.99, 0.985, 0.975, 0.965, 0.95, 0.7, 1.3, 1.31])))
+            clock = float(int(rnd.choice([0, 100, 900, 4999, 5000, 5001, 8000, 20000, 100000]) * rnd.choice([1.0, 0.19, 0.34, 0.66, 0.8, 0.86])))
+            tests.append((c, size, clock))
+        out.append(tests)
+    return out
+
+
+ASSIGN_NS = [[0] * 32,                                                                      # every device trial "under 5 ms"
+             [0, 0, 0, 0, 0, 0, 4, 6, 5, 7] + [0] * 6 + [30, 45, 36, 50] + [0] * 12,       # a fast host: all under 5 ms at 50 KB
+             [0, 0, 0, 0, 0, 0, 20, 30, 24, 36] + [0] * 6 + [80, 120, 90, 140] + [0] * 12]  # a slow one: the arithmetic coders over 5 ms
+
+
+def assign_run_cases(n_random=420, seed=77):
+    """inputs of assignref_run (oracle/ref_assign_shim.c): in[14], dict_id, txt_len, vb_size, the data's recipe, ns table -> ticks"""
+    rnd = np.random.default_rng(seed)
+    kinds = [("markov", 40), ("uniform", 4), ("u32be", 256), ("skew", 5), ("runs", 6), ("uniform", 200)]
+    dids = {0: [0x11, 0x55, 0x41, 0x4c, 0, 0, 0, 0], 2: [0x51, 0x55, 0x41, 0x4c, 0, 0, 0, 0], 1: [0xd1, 0x55, 0x41, 0x4c, 0, 0, 0, 0]}   # field / DTYPE_2 / DTYPE_1 (dict_id.h:15-17)
+    out = []
+    for r in range(n_random):
+        structured = r < 200
+        mode = 0 if structured else int(rnd.choice([0, 0, 1, 2]))
+        kind, nsym = kinds[int(rnd.integers(len(kinds)))]
+        n = int(rnd.choice([30, 49, 50, 20000, 50000, 50000, 120000]))
+        ns_i = int(rnd.integers(3)) if n in (20000, 50000) else 0
+        sample = min(n, 99999)
+        host_pay = [int(sample * f) for f in rnd.choice([0.2, 0.35, 0.5, 0.8, 1.1], 3)]
+        host_clk = [int(x) for x in rnd.choice([300, 2000, 4900, 6000, 30000], 3)]
+        ticks = [0] + [sample * ASSIGN_NS[ns_i][c] // 1000 for c in ASSIGN_CAND[1:9]] + host_clk
+        dt = int(rnd.choice([0, 1, 2]))
+        v_codec = int(rnd.choice([0, 0, 0, 0, 6, 13]))                       # UNKNOWN / a simple codec from the segmenter / a complex one (DOMQ)
+        z_codec = int(rnd.choice([0, 0, 2]))                                 # nothing / a codec no trial can produce (so that a commit shows)
+        inp = [mode, int(rnd.integers(2)), int(rnd.choice([1, 1, 2, 10, 10, 11])), v_codec, z_codec, int(rnd.choice([0, 3, 4, 5])) if mode == 1 else 0,
+               int(rnd.random() < 0.15), int(rnd.choice([0, 0b100, 0b001, 0b010, 0b111])), int(rnd.random() < 0.2), int(rnd.random() < 0.15), int(rnd.random() < 0.1)] + host_pay
+        out.append({"in": inp, "dict_id": dids[dt], "txt_len": int(rnd.choice([1000, 3 << 20, 5 << 20, 10 << 20])), "vb_size": int(rnd.choice([16 << 20, 6 << 20, 256 << 20])),
+                    "data": [kind, 9000 + r, n, nsym], "ns": ns_i, "ticks": [int(t) for t in ticks]})
+    return out
+
+
+def assign_run_data(c):
+    kind, seed, n, nsym = c["data"]
+    return synth.stream(kind, seed, n, nsym).tobytes()
+
+
+def assign_golden():
+    with open(os.path.join(HERE, "golden", "assign_golden.json")) as f:
+        return json.load(f)

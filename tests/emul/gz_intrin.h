@@ -59,17 +59,17 @@ static inline double gz_fma_rtz (double a, double b, double c)
 }
 static inline void gz_scalar_store2 (uint32_t *dst, uint32_t a, uint32_t b) { if (emu.cur % 64 == 0) { dst[0] = a; dst[1] = b; } }
 #include "gz_chain_asm.h"                                       // (GZ_CHAIN_BLOCK; the loop itself is not for this compiler)
-// the same contract as the product's loop, one symbol at a time, in the loop's own arithmetic: records { tot | cum << 16, F.hi },
-// T = fma (R, inv, 1.0) truncated (inv from the table), R' = fma (T, F, -F) with F = freq * 2^45, then the exponent bits
-static inline void gz_chain_blocks (uint32_t &rlo, uint32_t &rhi, const uint8_t *recs, const void *inv_tab, uint32_t nblk, uint32_t *ck)
+// the same contract as the product's loop, one symbol at a time, in the loop's own arithmetic: records { inv.lo | cum, inv.hi, F.hi },
+// T = fma (R, inv, 1.0) truncated (inv as it stands in the record, cum in its low bits), R' = fma (T, F, -F) with F = freq * 2^45, then the exponent bits
+static inline void gz_chain_blocks (uint32_t &rlo, uint32_t &rhi, const uint8_t *recs, uint32_t nblk, uint32_t *ck)
 {
     for (uint32_t b = 0; b < nblk; b++) {
         const uint32_t *rec = (const uint32_t *)(recs + (size_t)b * GZ_CHAIN_BLOCK * GZ_CHAIN_REC);
         for (int j = 0; j < GZ_CHAIN_BLOCK; j++) {
             if (!(j & 63)) gz_scalar_store2 (ck + 2 * (b * (GZ_CHAIN_BLOCK / 64) + j / 64), rlo, rhi);
-            double inv, R, F; memcpy (&inv, (const uint8_t *)inv_tab + 8 * (size_t)(rec[2 * j] & 0xffffu), 8);
+            double inv, R, F; memcpy (&inv, rec + 3 * j, 8);
             uint64_t rb = (uint64_t)rlo | (uint64_t)rhi << 32; memcpy (&R, &rb, 8);
-            const uint64_t fb = (uint64_t)rec[2 * j + 1] << 32; memcpy (&F, &fb, 8);
+            const uint64_t fb = (uint64_t)rec[3 * j + 2] << 32; memcpy (&F, &fb, 8);
             const double t = gz_fma_rtz (R, inv, 1.0);
             uint64_t tb; memcpy (&tb, &t, 8); tb = (tb & 0xffffffffull) | 0x3ff0000000000000ull;     // (what the lane hop passes on: r under the constant high word)
             double t2; memcpy (&t2, &tb, 8);

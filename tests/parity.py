@@ -1,4 +1,5 @@
 """the parity checks proper, parametrised by an Engine (GPU or CPU-emulated) -- compared with the oracle"""
+import hashlib
 import struct
 import zlib
 
@@ -2135,3 +2136,68 @@ def decode_foreign_arith(E, ref, sizes=(4, 40, 75, 130, 200, 256), n=40000, seed
         for order in (0x40, 0x41, 0xc0, 0xc1, 0x48, 0x49, 0x00, 0x01, 0x80, 0x81, 0x08, 0x09):
             comp = ref.hts_compress("arith", data, order)
             assert E.uncompress(16, comp, len(data)) == data, "alphabet %d, order byte %02x (stream's own: %02x)" % (ms, order, comp[0])
+
+
+# ---- row a8 against the reference's own src/codec.c (tests/golden/assign_golden.json, made by tests/golden/make_assign_golden.py) ----------
+def assign_golden_sort(sorter):
+    """sorter (tests, mode) -> (winner, sorted rows): every table of the fixture must come out in the order the reference's
+    codec_assign_sorter under the C library's qsort left it in"""
+    g = cases.assign_golden()
+    for k, c in enumerate(g["sort"]):
+        w, rows = sorter([tuple(r) for r in c["rows"]], c["mode"])
+        assert [int(r[0]) for r in rows] == c["order"] and w == c["order"][0], (k, c["mode"], c["rows"])
+    return len(g["sort"])
+
+
+def _assign_host_rows(c, trials):
+    """the rows of BZ2 / BSC / LZMA that took part in the reference's run: payload sizes and clocks as scripted"""
+    names = (3, 5, 4)
+    return [(names[i], c["in"][11 + i], c["ticks"][9 + i]) for i in range(trials - 9)]
+
+
+def assign_golden_run(best_table):
+    """best_table (data, host rows [(codec, payload size, clock_us)], ns table or None, mode) -> (codec, sorted table [(codec, size, clock)]):
+    the winner and the four best rows of every run of the reference's codec_assign_best_codec in which trials ran"""
+    g = cases.assign_golden()
+    n = 0
+    for k, r in enumerate(g["run"]):
+        c, out = r["case"], r["out"]
+        trials = out[4] // 2
+        if not trials:
+            continue
+        data = cases.assign_run_data(c)
+        assert hashlib.sha1(data).hexdigest() == r["sha1"]
+        mode = c["in"][0]
+        codec, table = best_table(data, _assign_host_rows(c, trials), cases.ASSIGN_NS[c["ns"]], mode)
+        assert [(int(t[0]), int(t[1]), int(t[2])) for t in table[:4]] == [tuple(x) for x in r["top4"]], (k, c, table[:4], r["top4"])
+        if mode != 1:                 # (--best may keep the file's previous codec when it comes second with the same size, :342-343: the caller's)
+            assert codec == out[0], (k, c, codec, out)
+        n += 1
+    return n
+
+
+def assign_golden_rule(rule):
+    """rule = gz_codec_assign_rule: what the reference's codec_assign_best_codec did in normal mode with a context the segmenter left open -
+    whether the trials ran, whether the file's context took the result, what the section got when they did not"""
+    g = cases.assign_golden()
+    n = 0
+    for k, r in enumerate(g["run"]):
+        c, out = r["case"], r["out"]
+        i = c["in"]
+        if i[0] != 0 or i[3] != 0:
+            continue
+        t = c["dict_id"][0] >> 6
+        nr = (i[7] >> (0 if t == 0 else 2 if t == 1 else 1)) & 1            # codec.c:199-209 / dict_id.h:15-17
+        bits = rule(i[2], c["txt_len"], c["vb_size"], i[8], i[1], nr, i[6], i[4], c["data"][2])
+        tested = out[4] > 0
+        assert bool(bits & 1) == tested, (k, c, out, bits)
+        if tested:
+            assert bool(bits & 2) == (out[2] != i[4]), (k, c, out, bits)     # (z_codec of the cases is one no trial produces)
+            assert bool(bits & 4) == (i[4] != 0), (k, c, out, bits)          # trials although the file has a codec: only VBlock 10's second look
+        else:
+            # inherited; or nothing - the file has none, or VBlock 10's second look found < 50 bytes (:274-277 then :311-312: the section is
+            # stored as it is whatever codec it carries, compressor.c:56-58); the file's context is left alone
+            second_look_too_short = i[2] == 10 and nr and not (i[1] and i[6]) and c["data"][2] < 50
+            assert out[2] == i[4] and out[0] == (0 if second_look_too_short else i[4]), (k, c, out)
+        n += 1
+    return n

@@ -100,3 +100,18 @@ def test_c_host_program_against_the_header(emul_engine, tmp_path):
     exe = _build_c_program(os.path.join(ROOT, "tests", "emul"), "libgenozip_amd_emul.so", str(tmp_path / "zip_fastq_emul"))
     r = subprocess.run([exe, "600"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
+def test_assign_golden_vectors_of_the_real_library(real_lib):
+    """row a8 PINNED, host side of the real build (no GPU involved): gz_codec_assign_sort against the order the reference's own
+    codec_assign_sorter + qsort produced, gz_codec_assign_rule - what the VBlock compute driver decides with - against what the
+    reference's own codec_assign_best_codec did (tests/golden/assign_golden.json)"""
+    import parity
+    from genozip_amd.lib import GzCodecTest
+
+    def sorter(tests, mode):
+        tab = (GzCodecTest * len(tests))(*[GzCodecTest(int(c), float(s), float(k)) for c, s, k in tests])
+        w = real_lib.gz_codec_assign_sort(tab, len(tests), mode)
+        return w, [(t.codec, t.size, t.clock_us) for t in tab]
+    assert parity.assign_golden_sort(sorter) == 780
+    assert parity.assign_golden_rule(real_lib.gz_codec_assign_rule) > 100

@@ -537,3 +537,32 @@ def test_vcf_retest(gpu_engine, oracle):
 def test_wide_models(gpu_engine, oracle):
     assert parity.wide_models(gpu_engine, oracle, big=True) > 300
     assert parity.wide_models_random(gpu_engine, oracle, 400) == 400
+
+
+def test_record_reciprocals(gpu_engine):
+    """the reciprocal the model kernel computes for a symbol's record (d_record_inv: reciprocal seed + one Newton step, 16 zero low bits),
+    for EVERY total a model can have, lies in the interval for which tests/test_magic.py shows range / tot to be exact - with the 16 low
+    bits a record's cum can set on top"""
+    from fractions import Fraction
+    import struct
+    n = 65536 + 32
+    inv = gpu_engine.debug_record_inv(1, n - 1)
+    bits = inv.view(np.uint64)
+    assert not (bits & np.uint64(0xffff)).any()
+    hi = (bits | np.uint64(0xffff)).view(np.float64)
+    worst = 0.0
+    for d in range(1, n):
+        exact = Fraction(1, d << 45)
+        lo_f, hi_f = Fraction(float(inv[d - 1])), Fraction(float(hi[d - 1]))
+        assert exact <= lo_f and hi_f <= exact * (1 + Fraction(1, 1 << 33)), d
+        worst = max(worst, float(hi_f / exact - 1))
+    assert worst < 2.0 ** -33
+
+
+def test_assign_golden_vectors(gpu_engine):
+    """row a8 PINNED on the device: gz_codec_assign_best_ex - the nine trial compressions on the GPU, the host's rows, the sorter - picks the
+    codec and builds the table the reference's own codec_assign_best_codec did on the same samples with the same clock
+    (tests/golden/assign_golden.json, oracle/ref_assign_shim.c)"""
+    def best_table(data, rows, ns, mode):
+        return gpu_engine.assign_best_ex(data, [(c, sz + 28, ck) for c, sz, ck in rows], [float(x) for x in ns], mode)
+    assert parity.assign_golden_run(best_table) > 100

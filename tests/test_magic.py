@@ -1,44 +1,57 @@
-"""The arithmetic coder's chain divides by multiplying, in double precision with truncation (gz_host.cpp builds the table,
-gz_kernels_arith.h:d_chain_step and the loop of gz_chain_asm.h use it):
-    range / tot == low word of fma (range * 2^-7, inv, 2^52) rounded toward zero,   inv = 2^7 / tot rounded UP to a double
-The fma forms range * 2^-7 * inv exactly, adds 2^52 and truncates to the 53 bits of a double, i.e. to an integer: the result is
-2^52 + floor (range * inv / 2^7) computed without error. This restates the table construction and checks the identity in exact
-integer arithmetic for every divisor the model total can take, on the numerators where a reciprocal scheme breaks first (multiples
-of the divisor and the numbers just below them, up to the top of the 32-bit range). The product's own table and kernels are
-exercised end to end by the parity tests; the renormalisation by exponent bits is checked here as well."""
+"""The arithmetic coder's chain divides by multiplying, in double precision with truncation (gz_kernels_arith.h: d_record_inv makes the
+reciprocal, d_chain_step and the loop of gz_chain_asm.h use it):
+    range / tot == low word of fma (range * 2^-7, inv, 1.0) rounded toward zero        for ANY double inv in
+    [2^-45 / tot, 2^-45 / tot * (1 + 2^-33)]
+The fma forms range * 2^-7 * inv exactly, adds 1 and truncates to the 53 bits of a double, i.e. to a multiple of 2^-52: the result
+is 1 + floor (range * inv * 2^45) * 2^-52 computed without error. The model kernel's inv is the hardware's reciprocal seed and one
+Newton step with the constant 1 + 2^-34 (about 2^-34 above 1 / tot), its 16 low bits replaced by the symbol's cum: inside that
+interval with room to spare (tests/test_gpu.py::test_record_reciprocals checks every total's value made on the device). This checks
+the identity in exact integer arithmetic for every divisor the model total can take, at both ends of the interval, on the
+numerators where a reciprocal scheme breaks first (multiples of the divisor and the numbers just below them, up to the top of the
+32-bit range); the renormalisation by exponent bits is checked here as well."""
 import math
 import random
 import struct
 from fractions import Fraction
 
 
-def inv_of(d):
-    inv = 128.0 / d
-    if Fraction(inv) * d < 128:                                  # (the host asks fma (inv, d, -128) for the sign)
-        inv = math.nextafter(inv, math.inf)
-    return inv
+def interval_ends(d):
+    """the smallest double >= 2^-45 / d and the largest one <= 2^-45 / d * (1 + 2^-33)"""
+    exact = Fraction(1, d << 45)
+    lo = float(exact)
+    while Fraction(lo) < exact:
+        lo = math.nextafter(lo, math.inf)
+    top = exact * (1 + Fraction(1, 1 << 33))
+    hi = float(top)
+    while Fraction(hi) > top:
+        hi = math.nextafter(hi, 0.0)
+    return lo, hi
 
 
 def quotient(n, inv):
     m, e = math.frexp(inv)                                       # inv = m * 2^e exactly, m * 2^53 an integer
     M = int(m * (1 << 53))
-    s = 53 - e + 7                                               # n * 2^-7 * inv = n * M / 2^s
+    s = 53 - e + 7 - 52                                          # n * 2^-7 * inv * 2^52 = n * M / 2^s
     return (n * M) >> s if s >= 0 else (n * M) << -s
+
+
+def admissible(d, inv):
+    return Fraction(1, d << 45) <= Fraction(inv) <= Fraction(1, d << 45) * (1 + Fraction(1, 1 << 33))
 
 
 def test_reciprocal_is_exact_for_every_model_total():
     rnd = random.Random(1)
     top = 0xffffffff
     for d in range(1, 65536 + 32):
-        inv = inv_of(d)
-        assert Fraction(inv) * d >= 128 and Fraction(math.nextafter(inv, 0.0)) * d < 128 or Fraction(inv) * d == 128
-        q = top // d
-        ns = [top, q * d, q * d - 1, (q - 1) * d, (q - 1) * d + d - 1, 1 << 24, ((1 << 24) // d + 1) * d - 1, ((1 << 24) // d + 1) * d]
-        for _ in range(12):
-            k = rnd.randrange((1 << 24) // d + 1, q + 1)
-            ns += [k * d, k * d - 1, min(top, k * d + rnd.randrange(d))]
-        for n in ns:
-            assert quotient(n, inv) == n // d, (d, n)
+        for inv in interval_ends(d):
+            assert admissible(d, inv)
+            q = top // d
+            ns = [top, q * d, q * d - 1, (q - 1) * d, (q - 1) * d + d - 1, 1 << 24, ((1 << 24) // d + 1) * d - 1, ((1 << 24) // d + 1) * d]
+            for _ in range(6):
+                k = rnd.randrange((1 << 24) // d + 1, q + 1)
+                ns += [k * d, k * d - 1, min(top, k * d + rnd.randrange(d))]
+            for n in ns:
+                assert quotient(n, inv) == n // d, (d, n, inv)
 
 
 def test_renormalisation_by_exponent_bits():

@@ -222,3 +222,19 @@ def test_against_ctx_reference_build(oracle):
         isn = (r[k * 400 + 1:k * 400 + 1 + n] % 5 == 0).astype(np.uint8) if k % 3 == 0 else None
         nc = 46 if k % 3 == 0 else 0
         assert R.dyn_int_column(v, isn, nc) == oracle.dyn_int_column(v, isn, nc), k
+
+
+def test_assign_golden_vectors(oracle):
+    """row a8 PINNED: the oracle's sorter and its composition of the candidate table == what the reference's own src/codec.c did
+    (tests/golden/assign_golden.json: codec_assign_sorter under qsort on 780 tables; codec_assign_best_codec's winner and four best rows
+    with the reference's coders underneath and a scripted clock)"""
+    import parity
+    assert parity.assign_golden_sort(oracle.assign_sort) == 780
+
+    def best_table(data, rows, ns, mode):
+        c0, sizes = oracle.assign_best(data)
+        cand = (1, 6, 7, 8, 9, 16, 17, 18, 19)
+        sample = min(len(data), 99999)
+        tests = [(cd, sizes[i], (sample * ns[cd] / 1000.0) if i else 0.0) for i, cd in enumerate(cand)] + [(c, sz + 28, ck) for c, sz, ck in rows]
+        return oracle.assign_sort(tests, mode)
+    assert parity.assign_golden_run(best_table) > 100

@@ -9,21 +9,22 @@ dependent vector instructions in double precision (the state R is range * 2^-7 a
     v_and_or_b32   R.hi, R.hi, mask, exp      the exponent's low 3 bits stay, the others become "2^24 <= range < 2^32": that IS
                                               "shift left by whole bytes until >= 2^24" (r * freq >= 2^8 always)
 
-The record of a symbol is EIGHT bytes (16 until round 5: { inv as a double, freq, cum }):  { tot | cum << 16,  the high word of F }
-- F has no low word (freq < 2^16) - and the reciprocal comes from the 512 KB table of every total (L2-resident, gz_create), looked
-up by the lanes a block ahead. No operand goes through a scalar register and no load is waited for in the loop: lane L of the wave
-holds the operands of the PER symbols base + PER * L .. + PER - 1, in three stages a block of 64 * PER symbols apart:
-    two blocks ahead   PER coalesced 8-byte loads of the records (RAW)
-    one block ahead    per record: v_mad_u32_u16 (tot * 8: the table offset), the 8-byte load of inv from the table straight into
-                       the operand set, v_mov of F's high word into its pair (the low words are 0 and stay 0)
-    the block          three instructions per symbol
-which is per record 2 loads + 2 vector instructions = what the 16-byte record cost (1 load + 3 instructions to make F and G from freq).
+The record of a symbol is TWELVE bytes (16 in rounds 1-4: { inv as a double, freq, cum }):  { inv.lo | cum,  inv.hi,  the high word of F }
+- F has no low word (freq < 2^16), and the reciprocal needs no more than 36 of its 52 mantissa bits (range * error < 1 is all the
+quotient asks for: tests/test_magic.py), so the table's entries are rounded up to a multiple of 2^16 units and the record carries the
+symbol's cum in those 16 bits: the chain uses the double as it is. No operand goes through a scalar register and no load is waited
+for in the loop: lane L of the wave holds the operands of the PER symbols base + PER * L .. + PER - 1; per record ONE 12-byte load a
+block of 64 * PER symbols ahead, straight into the registers the loop reads ([inv.lo inv.hi | F.hi x]), and one v_lshlrev_b64 that
+turns [F.hi x] into the pair [0 F.hi] when the block starts (tuples are 64-bit aligned: a 12-byte load cannot end on a pair's high
+word). (An 8-byte record { tot | cum << 16, F.hi } with the reciprocal looked up by the lanes was built first - round 5,
+profiles/round5b_*: the same 6.6 ns per symbol alone on the device, 0.4 ns slower inside a step, where the bursts of 64-address
+look-ups of 50 chains meet the other kernels' traffic.)
 Every lane executes every step, and the state walks through a lane's PER symbols and then HOPS to the next lane: the low word of T -
 r, the only word of T that is not a constant - is read from the lane before through DPP (wave_ror:1), and multiplied by that lane's
 last F, which the lane holds as "the F before mine". A DPP read of a register a vector instruction has just written needs two wait
 states (s_nop 1: measured - without them the result is wrong), which is why a lane takes PER symbols in a row and not one. Only the
 diagonal carries meaning; what the other lanes compute is never looked at.
-Clocks per symbol, alone on the device (tools/ubench_chain_f64.hip; profiles/round5_ubench_chain_rec8.txt): see there.
+Clocks per symbol, alone on the device (tools/ubench_chain_f64.hip; profiles/round5b_ubench_chain_rec12.txt): see there.
 
 Everything between the labels is written here, loop control included: the compiler schedules nothing in it. The rest of a leaf that
 does not fill a block is the caller's.
@@ -39,7 +40,7 @@ X_CKPT_FORM = os.environ.get("GZ_GEN_CKPT_FORM", "sstore")   # sstore: v_readlan
 
 PER = int(os.environ.get("GZ_GEN_PER", "12"))    # symbols a lane takes in a row
 BLOCK = 64 * PER
-REC = 8                                          # bytes per record
+REC = 12                                         # bytes per record
 
 # registers: everything the loop touches is named here (the clobber list keeps the compiler off it)
 _b = 40
@@ -50,17 +51,15 @@ R, RLO, RHI = f"v[{_b + 6}:{_b + 7}]", f"v{_b + 6}", f"v{_b + 7}"
 T, TLO = f"v[{_b + 8}:{_b + 9}]", f"v{_b + 8}"
 CKOFF = f"v{_b + 1}"                                                       # (vsave) where my saved state goes: my checkpoint's slot, or the dump
 FIXED_V = list(range(_b, _b + 10))
-RAW0 = _b + 10                                                             # the records of the block after the next: { tot | cum << 16, F.hi } x PER
-RAW = [(f"v[{RAW0 + 2 * k}:{RAW0 + 2 * k + 1}]", f"v{RAW0 + 2 * k}", f"v{RAW0 + 2 * k + 1}") for k in range(PER)]
-FIRST = RAW0 + 2 * PER
+FIRST = _b + 10
 NSAVE = (PER + 3) // 4 if X_CKPT_FORM == "vsave" else 0                    # (vsave) a row of 16 lanes holds at most so many of a block's checkpoints
 
 
 def regset(base):
-    """per symbol 4 registers: inv.lo inv.hi | F.lo (0) F.hi; then the F before mine (a pair)"""
+    """per symbol 4 registers: inv.lo inv.hi | F.lo (the load puts F.hi here; 0 after the shift) F.hi; then the F before mine (a pair)"""
     sym = [base + 4 * k for k in range(PER)]
     tail = base + 4 * PER
-    return dict(inv=[f"v[{b}:{b + 1}]" for b in sym], invlo=[f"v{b}" for b in sym],
+    return dict(rec=[f"v[{b}:{b + 2}]" for b in sym], inv=[f"v[{b}:{b + 1}]" for b in sym],
                 F=[f"v[{b + 2}:{b + 3}]" for b in sym], Flo=[f"v{b + 2}" for b in sym], Fhi=[f"v{b + 3}" for b in sym],
                 Fp=f"v[{tail}:{tail + 1}]", Fplo=f"v{tail}", Fphi=f"v{tail + 1}", first=base, last=tail + 1)
 
@@ -70,27 +69,23 @@ SAVE0 = SETS[1]['last'] + 1
 SAVE = [(f"v[{SAVE0 + 2 * k}:{SAVE0 + 2 * k + 1}]", f"v{SAVE0 + 2 * k}", f"v{SAVE0 + 2 * k + 1}") for k in range(NSAVE)]
 LAST_V = SAVE0 + 2 * NSAVE - 1
 assert LAST_V <= 255, 'out of vector registers'
-CLOB_V = FIXED_V + list(range(RAW0, LAST_V + 1))
-CLOB_S = [36, 37, 38, 39, 40, 41, 42, 44, 45, 46, 47]
-NEXT2, TAB, CK, TMP = "s[40:41]", "s[38:39]", "s[44:45]", "s[46:47]"      # NEXT2 = the records of the block after the next
+CLOB_V = FIXED_V + list(range(FIRST, LAST_V + 1))
+CLOB_S = [36, 37, 40, 41, 42, 44, 45, 46, 47]
+NEXT, CK, TMP = "s[40:41]", "s[44:45]", "s[46:47]"      # NEXT = the records of the next block
 DPP = "wave_ror:1 row_mask:0xf bank_mask:0xf"
 
 
-def load_raw(a, base):
+def loads(a, s, base):
     for k in range(PER):
-        a(f"global_load_dwordx2 {RAW[k][0]}, {OFF}, {base} offset:{REC * k}")
+        a(f"global_load_dwordx3 {s['rec'][k]}, {OFF}, {base} offset:{REC * k}")
 
 
 def make_operands(a, s):
-    """the operand set s from RAW (which has arrived): table offsets, the loads of inv, F's high words"""
+    """the records of set s have arrived: [F.hi x] -> [0 F.hi]"""
     if not X_PREP:
         return
     for k in range(PER):
-        a(f"v_mad_u32_u16 {s['invlo'][k]}, {RAW[k][1]}, 8, 0")           # (tot: the low half) * 8
-    for k in range(PER):
-        a(f"global_load_dwordx2 {s['inv'][k]}, {s['invlo'][k]}, {TAB}")
-    for k in range(PER):
-        a(f"v_mov_b32 {s['Fhi'][k]}, {RAW[k][2]}")
+        a(f"v_lshlrev_b64 {s['F'][k]}, 32, {s['F'][k]}")
 
 
 # (vsave) the checkpoints of a block: checkpoint c = the state before symbol 64 c sits in lane 64 c // PER, when that lane starts its
@@ -107,15 +102,14 @@ def ckpt_lanes():
 
 def block(a, cur, nxt, tag):
     """BLOCK symbols with the operand set `cur` (its loads were issued a block ago)"""
-    a("s_waitcnt vmcnt(0)")                                  # my operands (asked for a block ago) and the next block's records (two blocks ago)
-    a("s_cmp_lt_u32 s42, 2")                                 # the block after this one, if the call has one: its operands
+    a("s_waitcnt vmcnt(0)")                                  # my records (asked for a block ago)
+    a("s_cmp_lt_u32 s42, 2")                                 # the block after this one, if the call has one
     a(f"s_cbranch_scc1 2{tag}f")
-    make_operands(a, nxt)
-    a("s_cmp_lt_u32 s42, 3")                                 # the one after that: its records
-    a(f"s_cbranch_scc1 2{tag}f")
-    load_raw(a, NEXT2)
+    loads(a, nxt, NEXT)
     a(f"2{tag}:")
-    a(f"v_mov_b32_dpp {cur['Fphi']}, {cur['Fhi'][PER - 1]} {DPP}")          # the F before mine: the last of the lane before (written a block ago: no wait states)
+    make_operands(a, cur)
+    a("s_nop 1")
+    a(f"v_mov_b32_dpp {cur['Fphi']}, {cur['Fhi'][PER - 1]} {DPP}")          # the F before mine: the last of the lane before
     row_used = {}
     for j in range(BLOCK):
         lane, k = divmod(j, PER)
@@ -156,15 +150,12 @@ def body():
     a = L.append
     # operands: [rlo] [rhi] (v, in/out): the state - in: the same in every lane; out: valid in lane 0
     #           [blo] [bhi] (s): the records of the first block; [nblk] (s): blocks, >= 1; [clo] [chi] (s): where the first checkpoint goes
-    #           [tlo] [thi] (s): the table of reciprocals (8 bytes per total)
     a(f"v_mov_b32 {RLO}, %[rlo]")
     a(f"v_mov_b32 {RHI}, %[rhi]")
     a("s_mov_b32 s36, %[blo]")
     a("s_mov_b32 s37, %[bhi]")
     a(f"s_add_u32 s40, s36, {REC * BLOCK}")
     a("s_addc_u32 s41, s37, 0")
-    a("s_mov_b32 s38, %[tlo]")
-    a("s_mov_b32 s39, %[thi]")
     a("s_mov_b32 s42, %[nblk]")
     a("s_mov_b32 s44, %[clo]")
     a("s_mov_b32 s45, %[chi]")
@@ -176,20 +167,10 @@ def body():
     a(f"v_mov_b32 {T2HI}, 0x3ff00000")                       # the high word of 1 + r * 2^-52
     a(f"v_mov_b32 {MASK}, 0x7fffff")
     a(f"v_mov_b32 {EXPO}, 0x41000000")
-    for s in SETS:                                           # the low words of every F: 0, never written again
-        for k in range(PER):
-            a(f"v_mov_b32 {s['Flo'][k]}, 0")
-        a(f"v_mov_b32 {s['Fplo']}, 0")
+    for s in SETS:
+        a(f"v_mov_b32 {s['Fplo']}, 0")                       # the low word of the F before mine: 0, never written again
     a("s_nop 4")
-    load_raw(a, "s[36:37]")                                  # the first block's records ...
-    a("s_waitcnt vmcnt(0)")
-    make_operands(a, SETS[0])                                # ... its operands ...
-    a("s_cmp_lt_u32 s42, 2")
-    a("s_cbranch_scc1 1f")
-    load_raw(a, NEXT2)                                       # ... and the second block's records
-    a("1:")
-    a(f"s_add_u32 s40, s40, {REC * BLOCK}")                  # from here on: the block after the next
-    a("s_addc_u32 s41, s41, 0")
+    loads(a, SETS[0], "s[36:37]")                            # the first block's records
     a("3:")
     block(a, SETS[0], SETS[1], "0")
     a("s_cmp_eq_u32 s42, 0")
@@ -211,7 +192,7 @@ def main():
     with open(out, "w") as f:
         f.write("// gz_chain_asm.h -- generated by tools/gen_chain_asm.py (the comments are there) - do not edit\n#pragma once\n")
         f.write(f"#define GZ_CHAIN_BLOCK {BLOCK}        // symbols per block of the loop: 64 lanes x {PER} in a row\n")
-        f.write(f"#define GZ_CHAIN_REC {REC}            // bytes per record: {{ tot | cum << 16, the high word of freq * 2^45 as a double }}\n")
+        f.write(f"#define GZ_CHAIN_REC {REC}           // bytes per record: {{ inv.lo | cum, inv.hi, the high word of freq * 2^45 as a double }}\n")
         f.write(f"#define GZ_CHAIN_VREGS \"v{min(CLOB_V)}-v{max(CLOB_V)}\"   // the vector registers the loop names itself\n")
         f.write("#define GZ_CHAIN_F64_ASM \\\n")
         for ln in body():

@@ -111,7 +111,7 @@ __device__ static inline void d_step_slow (uint32_t &rlo, uint32_t &rhi, const u
     const double Pd = (double)P * 0.0078125;
     rlo = (uint32_t)__double2loint (Pd); rhi = ((uint32_t)__double2hiint (Pd) & 0x007fffffu) | 0x41000000u;
 }
-template <int NOPS> __global__ void __launch_bounds__(64) k_chain_hop (const uint8_t *recs, const uint8_t *inv_tab, uint32_t n, double *out, uint32_t *ck, size_t stride, uint64_t *cyc)
+template <int NOPS> __global__ void __launch_bounds__(64) k_chain_hop (const uint8_t *recs, uint32_t n, double *out, uint32_t *ck, size_t stride, uint64_t *cyc)
 {
     asm volatile ("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3");
     const double R0 = 4294967295.0 / 128.0;
@@ -121,11 +121,10 @@ template <int NOPS> __global__ void __launch_bounds__(64) k_chain_hop (const uin
     uint32_t nblk = __builtin_amdgcn_readfirstlane (n / GZ_CHAIN_BLOCK), done = 0, slow = 0;
     const uint64_t t0 = __builtin_readcyclecounter (), w0 = wall_clock64 ();
     {
-        const uint64_t b = (uint64_t)(uintptr_t)base, cc = (uint64_t)(uintptr_t)c, tt = (uint64_t)(uintptr_t)inv_tab;
-        const uint32_t t_lo = __builtin_amdgcn_readfirstlane ((uint32_t)tt), t_hi = __builtin_amdgcn_readfirstlane ((uint32_t)(tt >> 32));
+        const uint64_t b = (uint64_t)(uintptr_t)base, cc = (uint64_t)(uintptr_t)c;
         const uint32_t b_lo = __builtin_amdgcn_readfirstlane ((uint32_t)b), b_hi = __builtin_amdgcn_readfirstlane ((uint32_t)(b >> 32));
         const uint32_t c_lo = __builtin_amdgcn_readfirstlane ((uint32_t)cc), c_hi = __builtin_amdgcn_readfirstlane ((uint32_t)(cc >> 32));
-        asm volatile (GZ_CHAIN_F64_ASM : [rlo] "+v"(rlo), [rhi] "+v"(rhi) : [blo] "s"(b_lo), [bhi] "s"(b_hi), [nblk] "s"(nblk), [clo] "s"(c_lo), [chi] "s"(c_hi), [tlo] "s"(t_lo), [thi] "s"(t_hi) : GZ_CHAIN_F64_CLOBBERS);
+        asm volatile (GZ_CHAIN_F64_ASM : [rlo] "+v"(rlo), [rhi] "+v"(rhi) : [blo] "s"(b_lo), [bhi] "s"(b_hi), [nblk] "s"(nblk), [clo] "s"(c_lo), [chi] "s"(c_hi) : GZ_CHAIN_F64_CLOBBERS);
         rlo = __builtin_amdgcn_readfirstlane (rlo); rhi = __builtin_amdgcn_readfirstlane (rhi);
         (void)done; (void)slow;
     }
@@ -214,12 +213,13 @@ int main (int argc, char **argv)
     // every block reads the same records (blockIdx * n * 16 would need 256 copies: give blocks > 0 the same data by using n_eff = 0 stride)
     CHK (hipMemcpy (d_ri, ri.data (), (size_t)n * 16, hipMemcpyHostToDevice)); CHK (hipMemcpy (d_rf, rf.data (), (size_t)n * 16, hipMemcpyHostToDevice));
 
-    // records of the hop kernel { tot | cum << 16, the high word of freq * 2^45 } + the table of 2^-45 / tot rounded up: data set A = the
-    // random sequence above (2 % of the totals below 256), data set B = totals of a busy context (32760 .. 65519) after a short start
+    // records of the hop kernel { inv.lo | cum, inv.hi, the high word of freq * 2^45 }, inv = 2^-45 / tot rounded up to a multiple of 2^16
+    // units of the last place: data set A = the random sequence above (2 % of the totals below 256), data set B = totals of a busy
+    // context (32760 .. 65519) after a short start
     auto fhi = [] (uint32_t freq) { double F = ldexp ((double)freq, 45); uint64_t b; memcpy (&b, &F, 8); return (uint32_t)(b >> 32); };
-    std::vector<uint32_t> ra ((size_t)n * 2), rb ((size_t)n * 2), ranges_b (n + 1);
+    std::vector<uint32_t> ra ((size_t)n * 3), rb ((size_t)n * 3), ranges_b (n + 1);
     std::vector<uint64_t> tab (65536 + 32);
-    for (uint32_t dv = 1; dv < tab.size (); dv++) { double inv = 128.0 / dv; if (fma (inv, (double)dv, -128.0) < 0) inv = nextafter (inv, 1e300); inv = ldexp (inv, -52); memcpy (&tab[dv], &inv, 8); }
+    for (uint32_t dv = 1; dv < tab.size (); dv++) { double inv = 128.0 / dv; if (fma (inv, (double)dv, -128.0) < 0) inv = nextafter (inv, 1e300); inv = ldexp (inv, -52); memcpy (&tab[dv], &inv, 8); tab[dv] = (tab[dv] + 0xffffull) & ~0xffffull; }
     {
         uint32_t range = 0xffffffffu, tot = 40;
         for (uint32_t i = 0; i < n; i++) {
@@ -230,25 +230,23 @@ int main (int argc, char **argv)
             ranges_b[i] = range;
             const uint32_t r = range / tot, x = r * freq;
             range = x << (__builtin_clz (x) & 0x18);
-            rb[(size_t)i * 2 + 0] = tot | (rnd () & 0xffff) << 16; rb[(size_t)i * 2 + 1] = fhi (freq);
+            const uint64_t iv = tab[tot] | ((i & 7) == 0 ? 0xffffu : (rnd () & 0xffff));
+            rb[(size_t)i * 3 + 0] = (uint32_t)iv; rb[(size_t)i * 3 + 1] = (uint32_t)(iv >> 32); rb[(size_t)i * 3 + 2] = fhi (freq);
         }
         ranges_b[n] = range;
-        uint32_t tot_a = 7;
-        rng_s = 88172645463325252ull;                // data set A: the same (tot, freq) as rf / ri - replay the generator
-        for (uint32_t i = 0; i < n; i++) {
+        for (uint32_t i = 0; i < n; i++) {          // data set A: the same (tot, freq) as rf / ri
             const uint32_t freq = ri[(size_t)i * 4 + 0];
-            // the total of symbol i: from its record of the f64 form (inv = 128 / tot rounded up): recover by rounding
             double inv; uint64_t ib = (uint64_t)rf[(size_t)i * 4 + 0] | (uint64_t)rf[(size_t)i * 4 + 1] << 32; memcpy (&inv, &ib, 8);
-            tot_a = (uint32_t)floor (128.0 / inv + 0.5);
-            ra[(size_t)i * 2 + 0] = tot_a | (rnd () & 0xffff) << 16; ra[(size_t)i * 2 + 1] = fhi (freq);
+            const uint32_t tot_a = (uint32_t)floor (128.0 / inv + 0.5);
+            const uint64_t iv = tab[tot_a] | ((i & 7) == 0 ? 0xffffu : (rnd () & 0xffff));
+            ra[(size_t)i * 3 + 0] = (uint32_t)iv; ra[(size_t)i * 3 + 1] = (uint32_t)(iv >> 32); ra[(size_t)i * 3 + 2] = fhi (freq);
         }
     }
     const int copies = 64;
-    uint8_t *d_ra, *d_rbc, *d_tab; uint64_t *d_cyc; CHK (hipMalloc (&d_ra, (size_t)n * 8 + 65536)); CHK (hipMalloc (&d_rbc, (size_t)copies * n * 8 + 131072)); CHK (hipMalloc (&d_cyc, 4096 * 24));
-    CHK (hipMalloc (&d_tab, tab.size () * 8)); CHK (hipMemcpy (d_tab, tab.data (), tab.size () * 8, hipMemcpyHostToDevice));
+    uint8_t *d_ra, *d_rbc; uint64_t *d_cyc; CHK (hipMalloc (&d_ra, (size_t)n * 12 + 65536)); CHK (hipMalloc (&d_rbc, (size_t)copies * n * 12 + 131072)); CHK (hipMalloc (&d_cyc, 4096 * 24));
     d_ra += 4096; d_rbc += 4096;
-    CHK (hipMemcpy (d_ra, ra.data (), (size_t)n * 8, hipMemcpyHostToDevice));
-    for (int k = 0; k < copies; k++) CHK (hipMemcpy (d_rbc + (size_t)k * n * 8, rb.data (), (size_t)n * 8, hipMemcpyHostToDevice));
+    CHK (hipMemcpy (d_ra, ra.data (), (size_t)n * 12, hipMemcpyHostToDevice));
+    for (int k = 0; k < copies; k++) CHK (hipMemcpy (d_rbc + (size_t)k * n * 12, rb.data (), (size_t)n * 12, hipMemcpyHostToDevice));
     for (int k = 0; k < 20; k++) hipLaunchKernelGGL (k_probe_fma, dim3 (1024), dim3 (64), 0, 0, d_out, 0.999, 0.001, 100000);   // warm the clocks up
     CHK (hipDeviceSynchronize ());
 
@@ -263,10 +261,10 @@ int main (int argc, char **argv)
         printf ("exactness [%s]: %u of %u checkpoints differ; end range %.0f want %u; %llu blocks the slow way\n", what, bad, n / 64, floor (Rend * 128.0), want_r[n], (unsigned long long)cy[2]);
     };
 #define HOPTEST(NOPS, what) do { \
-        CHK (hipMemset (d_ck, 0, (size_t)(n / 32) * 4)); hipLaunchKernelGGL (k_chain_hop<NOPS>, dim3 (1), dim3 (64), 0, 0, d_ra, d_tab, n, d_out, d_ck, (size_t)0, d_cyc); CHK (hipDeviceSynchronize ()); check (what ", data A", ranges); \
-        CHK (hipMemset (d_ck, 0, (size_t)(n / 32) * 4)); hipLaunchKernelGGL (k_chain_hop<NOPS>, dim3 (1), dim3 (64), 0, 0, d_rbc, d_tab, n, d_out, d_ck, (size_t)0, d_cyc); CHK (hipDeviceSynchronize ()); check (what ", data B", ranges_b); \
+        CHK (hipMemset (d_ck, 0, (size_t)(n / 32) * 4)); hipLaunchKernelGGL (k_chain_hop<NOPS>, dim3 (1), dim3 (64), 0, 0, d_ra, n, d_out, d_ck, (size_t)0, d_cyc); CHK (hipDeviceSynchronize ()); check (what ", data A", ranges); \
+        CHK (hipMemset (d_ck, 0, (size_t)(n / 32) * 4)); hipLaunchKernelGGL (k_chain_hop<NOPS>, dim3 (1), dim3 (64), 0, 0, d_rbc, n, d_out, d_ck, (size_t)0, d_cyc); CHK (hipDeviceSynchronize ()); check (what ", data B", ranges_b); \
         for (int blocks : { 1, 50, 64 }) { uint64_t cy[3]; \
-            float a = time_it ([&] { hipLaunchKernelGGL (k_chain_hop<NOPS>, dim3 (blocks), dim3 (64), 0, 0, d_rbc, d_tab, n, d_out, d_ck, (size_t)n * 8, d_cyc); }); \
+            float a = time_it ([&] { hipLaunchKernelGGL (k_chain_hop<NOPS>, dim3 (blocks), dim3 (64), 0, 0, d_rbc, n, d_out, d_ck, (size_t)n * 12, d_cyc); }); \
             CHK (hipMemcpy (cy, d_cyc, 24, hipMemcpyDeviceToHost)); \
             printf ("  %s: %2d chains at once: %.2f ns/symbol, %.2f shader cycles/symbol, %.3f GHz\n", what, blocks, a * 1e6 / n, (double)cy[0] / n, (double)cy[0] / cy[1] * 0.1); } } while (0)
     HOPTEST (2, "hop");
