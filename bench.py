@@ -37,7 +37,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")    # (genozip_amd/lib.py: must b
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CHAIN_FLOOR_NS = 6.6            # k_arith_chain's loop alone on the device: 15.8 clocks per symbol at 2.4 GHz (profiles/round4_ubench_chain_f64.txt)
+CHAIN_FLOOR_NS = 6.3            # k_arith_chain's loop alone on the device: 15.1 clocks per symbol at 2.4 GHz (profiles/r05_ubench_chain_rec12.txt; 6.6 with the 16-byte records of round 4)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 METRIC = "input MB/s compressed (bit-exact .genozip) at 1/2/4/8 GPUs vs CPU ref"
 
@@ -405,9 +405,9 @@ def gpu_over_cpu(out, cb):
 
 def pmc_traffic(kernel, a):
     """HBM bytes per STEP of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/round5_pmc.json, made by tools/summarize_prof.py: counter collection serialises kernels, so it cannot happen inside a timed
+    (profiles/r05_pmc.json, made by tools/summarize_prof.py: counter collection serialises kernels, so it cannot happen inside a timed
     run); null when there is no such file for this workload"""
-    p = next((q for q in (os.path.join(ROOT, "profiles", "round%d_pmc.json" % r) for r in (5, 4)) if os.path.exists(q)), None)
+    p = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc.json", "round5_pmc.json")) if os.path.exists(q)), None)
     if p is None:
         return None
     d = json.load(open(p))

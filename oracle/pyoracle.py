@@ -14,6 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(_HERE, "liboracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libhtsref.so")
 CTXREF_SO = os.path.join(_HERE, "_ref", "libctxref.so")
+ORDERREF_SO = os.path.join(_HERE, "_ref", "liborderref.so")
+MERGEREF_SO = os.path.join(_HERE, "_ref", "libmergeref.so")
 ASSIGNREF_SO = os.path.join(_HERE, "_ref", "libassignref.so")
 COMPREF_SO = os.path.join(_HERE, "_ref", "libcompref.so")
 
@@ -789,6 +791,82 @@ class AssignRef:
         self.L.assignref_run(i.ctypes.data, bytes(dict_id).ljust(8, b"\0"), txt_len, vb_size, bytes(data), len(data), t.ctypes.data, o.ctypes.data, shown)
         rows = [(self.NAMES[m.group(1)], int(m.group(2)), int(m.group(3))) for m in re.finditer(r"\[(\w+)\s+(\d+) B\s+(\d+) ", shown.value.decode("utf8", "replace"))]
         return [int(x) for x in o[:5]], rows
+
+
+class OrderRef:
+    """the reference's OWN src/zip.c - zip_compress_all_contexts_local / _b250 in the sequence of zip_compress_one_vb, one compute thread -
+    compiled in place (oracle/Makefile target `ref`, oracle/ref_order_shim.c): the order in which a VBlock's context sections reach z_data.
+    Row a15. Exists only where /root/reference does."""
+
+    def __init__(self, path=ORDERREF_SO):
+        self.L = ctypes.CDLL(path)
+        self.L.orderref_run.argtypes = [ctypes.c_uint32] + [ctypes.c_void_p] * 5 + [ctypes.c_uint32, ctypes.c_void_p]
+
+    @staticmethod
+    def available():
+        return os.path.exists(ORDERREF_SO)
+
+    def order(self, ctxs, vblock_i):
+        """ctxs = [(did_i, local_dep, has_local, ston_only, has_b250)] -> [(index into ctxs, 'L' | 'B')]"""
+        import numpy as np
+        n = len(ctxs)
+        did = np.array([c[0] for c in ctxs], dtype=np.uint16); dep = np.array([c[1] for c in ctxs], dtype=np.uint8)
+        hl = np.array([c[2] for c in ctxs], dtype=np.uint8); so = np.array([c[3] for c in ctxs], dtype=np.uint8); hb = np.array([c[4] for c in ctxs], dtype=np.uint8)
+        out = np.zeros(2 * n + 2, dtype=np.uint32)
+        k = self.L.orderref_run(n, did.ctypes.data, dep.ctypes.data, hl.ctypes.data, so.ctypes.data, hb.ctypes.data, vblock_i, out.ctypes.data)
+        at = {int(d): i for i, d in enumerate(did)}
+        return [(at[int(x) // 2], "B" if x & 1 else "L") for x in out[:k]]
+
+
+class MergeRef:
+    """the reference's OWN src/context.c - ctx_merge_in_one_vctx with ctx_commit_node, ctx_insert_to_dict and ctx_drop_all_the_same - over its
+    own hash.c / seg.c / b250.c, compiled in place (oracle/Makefile target `ref`, oracle/ref_merge_shim.c). The loop of row a4. ONE file context
+    at a time (the library keeps it). Same call shape as OracleZctx / genozip_amd.codec.Zctx. Exists only where /root/reference does."""
+
+    def __init__(self, estimated_entries=0, path=MERGEREF_SO):
+        self.L = ctypes.CDLL(path)
+        self.L.mergeref_merge.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_uint64] + [ctypes.c_void_p] * 6
+        self.L.mergeref_view.restype = ctypes.c_uint64
+        self.L.mergeref_view.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+        self.L.mergeref_open(ctypes.c_uint32(estimated_entries))
+
+    @staticmethod
+    def available():
+        return os.path.exists(MERGEREF_SO)
+
+    def merge(self, vblock_i, n_ol, col, can_have_singletons=False, flags=0, local_len=0, no_drop_b250=False,
+              pair2_identical=False, b250_r1_len=0, local_r1_len=0, lcodec=0, bcodec=0):
+        import numpy as np
+        n_new = len(col["node_snip_len"])
+        d = np.frombuffer(bytes(col["dict"]) + b"\0", dtype=np.uint8).copy()
+        nci = np.ascontiguousarray(col["node_char_index"], dtype=np.uint64); nsl = np.ascontiguousarray(col["node_snip_len"], dtype=np.uint32)
+        cnt = np.ascontiguousarray(list(col["counts"]) + [0], dtype=np.uint32)
+        ats = bool(col["all_the_same"])
+        inp = np.array([vblock_i, n_ol, n_new, int(can_have_singletons and not ats), flags | (0x20 if ats else 0), int(no_drop_b250), int(pair2_identical), lcodec, bcodec,
+                        int(col["node_index"][0]) if ats and len(col["node_index"]) else -1], dtype=np.int32)
+        lens = np.array([len(col["b250"]), local_len, b250_r1_len, local_r1_len], dtype=np.uint64)
+        n2w = np.zeros(max(1, n_new), dtype=np.int32); ston = np.zeros(len(d) + 8, dtype=np.uint8); out = np.zeros(8, dtype=np.int32)
+        self.L.mergeref_merge(inp.ctypes.data, lens.ctypes.data, d.ctypes.data, len(col["dict"]), nci.ctypes.data, nsl.ctypes.data, cnt.ctypes.data,
+                              n2w.ctypes.data, ston.ctypes.data, out.ctypes.data)
+        assert out[0] == 1
+        text = ston[:out[4]].tobytes()
+        return dict(node2word=n2w[:n_new].copy(), ston_local=text, n_stons=text.count(b"\0"), dropped_b250=bool(out[1]), lcodec=int(out[2]), bcodec=int(out[3]))
+
+    def view(self):
+        import numpy as np
+        o = np.zeros(12, dtype=np.int64)
+        n = self.L.mergeref_view(None, 0, None, 0, o.ctypes.data)
+        d = np.zeros(max(1, n), dtype=np.uint8); c = np.zeros(max(1, int(o[0])), dtype=np.uint64)
+        self.L.mergeref_view(d.ctypes.data, n, c.ctypes.data, int(o[0]), o.ctypes.data)
+        return dict(dict=d[:n].tobytes(), n_words=int(o[0]), counts=c[:int(o[0])].copy(), n_failed_singletons=int(o[1]), rm_dict=bool(o[2] and not o[3]),
+                    all_the_same_wi=int(o[5]) if o[4] else -1, hash_len=int(o[6]), flags=int(o[7]), lcodec=int(o[8]), bcodec=int(o[9]))
+
+    def words(self):
+        d = self.view()["dict"]
+        return d[:-1].split(b"\0") if d else []
+
+    def commit_codec(self, is_local, codec):
+        self.L.mergeref_commit_codec(int(is_local), int(codec))
 
 
 def vcf_sample_items(text, line_off, line_len, n_samples, n_sub):

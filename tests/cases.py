@@ -252,3 +252,64 @@ def assign_run_data(c):
 def assign_golden():
     with open(os.path.join(HERE, "golden", "assign_golden.json")) as f:
         return json.load(f)
+
+
+# ---- row a4's loop: ctx_merge_in_one_vctx, pinned to the reference's own src/context.c (tests/golden/make_merge_golden.py) ------------------
+def merge_loop_scenarios(n=600):
+    """name -> (estimated_entries, [VBlock: dict(clone=k (the dictionary as it was after k VBlocks had merged), snips=[...], + keyword
+    arguments of Zctx.merge)]). Multi-VBlock word streams with singletons that stay / fail, clones taken before earlier VBlocks merged (a
+    batch), all-the-same contexts that can and cannot drop their b250 (flags, local data, pair rules, a different word), codecs inherited."""
+    r = synth.u32(4242, 8 * n + 64).astype(np.int64)
+
+    def ids(lo, hi):
+        return [b"id%07d" % (i if r[i] % 9 else i - 1) for i in range(lo, hi)]
+
+    def V(clone, snips, **kw):
+        d = dict(clone=clone, snips=snips)
+        d.update(kw)
+        return d
+    S = True
+    return {
+        "ids":    (0, [V(0, ids(0, n), can_have_singletons=S), V(1, ids(n // 2, n + n // 2), can_have_singletons=S), V(2, ids(0, 2 * n), can_have_singletons=S), V(3, ids(0, n // 3), can_have_singletons=S)]),
+        "ids_batch": (5000, [V(0, ids(0, n), can_have_singletons=S), V(0, ids(n // 2, n + n // 2), can_have_singletons=S), V(0, ids(0, 2 * n), can_have_singletons=S),
+                             V(3, ids(n, 3 * n), can_have_singletons=S), V(3, ids(0, n // 3), can_have_singletons=S)]),
+        "tiles":  (0, [V(0, [b"%d" % (1101 + (i * 7 // n)) for i in range(n)]), V(1, [b"%d" % (1104 + (i * 9 // n)) for i in range(n)]),
+                       V(1, [b"%d" % (1101 + (r[i] % 40)) for i in range(n)]), V(3, [b"%d" % (1090 + (r[i] % 80)) for i in range(n)])]),
+        "big":    (0, [V(0, [b"w%d" % (r[i] % 3000) for i in range(n)]), V(1, [b"w%d" % (r[n + i] % 5000) for i in range(n)]), V(2, [b"w%d" % (i % 4000) for i in range(n)])]),
+        "same":   (0, [V(0, [b"+"] * n), V(1, [b"+"] * n), V(2, [b"+"] * (n - 1) + [b"x"]), V(3, [b"+"] * n)]),
+        "same_other_word": (0, [V(0, [b"a", b"b"] * 3), V(1, [b"b"] * 9), V(2, [b"a"] * 9), V(3, [b"b"] * 4)]),         # all-the-same on word 1: not droppable; then on word 0
+        "same_flags": (0, [V(0, [b"+"] * 5, flags=0x01), V(1, [b"+"] * 5, flags=0x01), V(2, [b"+"] * 5, flags=0x02), V(3, [b"+"] * 5)]),   # store bits differ from VBlock 1's
+        "same_local": (0, [V(0, [b"+"] * 5, local_len=40), V(1, [b"\x01"] * 5, local_len=40), V(2, [b"\x01"] * 5)]),    # local data: droppable only for a plain SNIP_LOOKUP
+        "lookup_first": (0, [V(0, [b"\x01"] * 7, local_len=12), V(1, [b"\x01"] * 3, local_len=5), V(2, [b"\x01", b"z"], local_len=5)]),   # rm_dict_all_the_same, then overridden
+        "same_pair": (0, [V(0, [b"="] * 6), V(1, [b"="] * 6, pair2_identical=True, b250_r1_len=3), V(2, [b"="] * 6, pair2_identical=True, local_r1_len=9),
+                          V(3, [b"="] * 6, pair2_identical=True, local_r1_len=9, local_len=4), V(4, [b"="] * 6, no_drop_b250=True)]),
+        "self_delta": (0, [V(0, [b"\x09" + b"1"] * 5), V(1, [b"\x09" + b"1"] * 5)]),                                    # SNIP_SELF_DELTA: never dropped
+        "ston1":  (0, [V(0, [b"only-once"] + [b"rep"] * 5, can_have_singletons=S), V(1, [b"only-once", b"rep", b"new2", b"new2"], can_have_singletons=S),
+                       V(2, [b"only-once", b"new3"], can_have_singletons=S), V(2, [b"new3", b"", None, b"rep"], can_have_singletons=S), V(4, [b"new3", b"new4"], can_have_singletons=S)]),
+        "ston_mixed": (0, [V(0, [b"u%d" % i for i in range(40)] + [b"c"] * 9, can_have_singletons=S), V(1, [b"u%d" % i for i in range(20, 60)] + [b"c"], can_have_singletons=False),
+                           V(2, [b"u%d" % i for i in range(70)], can_have_singletons=S), V(3, [b"v%d" % (i // 2) for i in range(50)], can_have_singletons=S)]),
+    }
+
+
+def merge_golden():
+    with open(os.path.join(HERE, "golden", "merge_golden.json")) as f:
+        return json.load(f)
+
+
+# ---- row a15: the order of a VBlock's sections, pinned to the reference's own src/zip.c (tests/golden/make_order_golden.py) -----------------
+def section_order_tables(n_tables=120):
+    """[(ctxs = [(did_i, local_dep, has_local, ston_only, has_b250)] in shuffled table order, vblock_i)]"""
+    out = []
+    for seed in range(n_tables):
+        r = synth.u32(7000 + seed, 200)
+        n = 1 + int(r[0] % 30)
+        dids = np.argsort(r[1:1 + n], kind="stable")
+        ctxs = [(int(dids[i]) * 3 + 1, int(r[40 + i] % 3), bool(r[80 + i] % 4), bool(r[120 + i] % 5 == 0), bool(r[160 + i] % 3)) for i in range(n)]
+        for vb_i in (1, 2, 7):
+            out.append((ctxs, vb_i))
+    return out
+
+
+def order_golden():
+    with open(os.path.join(HERE, "golden", "order_golden.json")) as f:
+        return json.load(f)

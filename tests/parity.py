@@ -2201,3 +2201,67 @@ def assign_golden_rule(rule):
             assert out[2] == i[4] and out[0] == (0 if second_look_too_short else i[4]), (k, c, out)
         n += 1
     return n
+
+
+# ---- row a4's loop against the reference's own src/context.c (tests/golden/merge_golden.json, made by tests/golden/make_merge_golden.py) ----
+def merge_loop_run(make_zctx, seg_column, n=600):
+    """every scenario of cases.merge_loop_scenarios through a file context made by make_zctx (estimated_entries): what each merge returned and
+    what the file context held afterwards, in the fixture's form"""
+    out = {}
+    for name, (est, vbs) in cases.merge_loop_scenarios(n).items():
+        Z = make_zctx(est)
+        words_after, steps = [[]], []
+        for k, vb in enumerate(vbs):
+            kw = {x: y for x, y in vb.items() if x not in ("clone", "snips", "commit", "lcodec", "bcodec")}
+            ol = words_after[vb["clone"]]
+            t, o, l = _snip_column(vb["snips"])
+            col = seg_column(t, o, l, ol)
+            m = Z.merge(k + 1, len(ol), col, **kw)
+            v = Z.view()
+            words_after.append(Z.words())
+            steps.append({"node2word": hashlib.sha1(np.asarray(m["node2word"], dtype=np.int32).tobytes()).hexdigest(), "n_new": len(m["node2word"]),
+                          "ston_local": hashlib.sha1(m["ston_local"]).hexdigest(), "n_stons": m["n_stons"], "dropped_b250": bool(m["dropped_b250"]),
+                          "dict": hashlib.sha1(v["dict"]).hexdigest(), "n_words": v["n_words"], "counts": hashlib.sha1(np.asarray(v["counts"], dtype=np.uint64).tobytes()).hexdigest(),
+                          "n_failed_singletons": int(v["n_failed_singletons"]), "rm_dict": bool(v["rm_dict"])})
+        out[name] = steps
+        if hasattr(Z, "close"):
+            Z.close()
+    return out
+
+
+def merge_loop_golden(make_zctx, seg_column):
+    g = cases.merge_golden()
+    got = merge_loop_run(make_zctx, seg_column, g["n"])
+    assert set(got) == set(g["scenarios"])
+    for name, steps in g["scenarios"].items():
+        for k, (a, b) in enumerate(zip(got[name], steps)):
+            assert a == {x: b[x] for x in a}, (name, k, a, b)
+    return sum(len(s) for s in got.values())
+
+
+# ---- row a15 against the reference's own src/zip.c (tests/golden/order_golden.json, made by tests/golden/make_order_golden.py) -------------
+def section_order_golden(order):
+    """order (ctxs, vblock_i) -> [(index, 'L' | 'B')] must be the order in which the reference's own zip_compress_all_contexts_local / _b250
+    handed the sections of every table of the fixture to the section writer"""
+    g = cases.order_golden()
+    tabs = cases.section_order_tables(g["n_tables"])
+    assert len(tabs) == len(g["orders"])
+    for k, ((ctxs, vb_i), want) in enumerate(zip(tabs, g["orders"])):
+        assert [[i, t] for i, t in order(ctxs, vb_i)] == want, (k, vb_i, ctxs)
+    return len(tabs)
+
+
+def lib_section_order(L):
+    """gz_section_order of a loaded library as order (ctxs, vblock_i)"""
+    import ctypes as C
+    from genozip_amd.lib import GzSecOrderIn
+
+    def order(ctxs, vb_i):
+        n = len(ctxs)
+        arr = (GzSecOrderIn * n)()
+        for i, (did, dep, hl, so, hb) in enumerate(ctxs):
+            arr[i].did_i, arr[i].local_dep, arr[i].has_local, arr[i].ston_only_local, arr[i].has_b250 = did, dep, int(hl), int(so), int(hb)
+        out = (C.c_uint32 * (2 * n))()
+        k = L.gz_section_order(arr, n, vb_i, out)
+        return [(out[j] // 2, "B" if out[j] & 1 else "L") for j in range(k)]
+    return order

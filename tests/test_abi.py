@@ -115,3 +115,18 @@ def test_assign_golden_vectors_of_the_real_library(real_lib):
         return w, [(t.codec, t.size, t.clock_us) for t in tab]
     assert parity.assign_golden_sort(sorter) == 780
     assert parity.assign_golden_rule(real_lib.gz_codec_assign_rule) > 100
+
+
+def test_merge_golden_vectors_of_the_real_library(real_lib, oracle):
+    """the LOOP of row a4 PINNED, host code of the real build (no GPU involved): gz_ctx_merge against what the reference's own
+    ctx_merge_in_one_vctx did (tests/golden/merge_golden.json, oracle/ref_merge_shim.c)"""
+    import parity
+    from genozip_amd.codec import Zctx
+    assert parity.merge_loop_golden(lambda est: Zctx(real_lib, est), oracle.ctx_seg_column) >= 50
+
+
+def test_order_golden_vectors_of_the_real_library(real_lib):
+    """row a15 PINNED, host code of the real build: gz_section_order - what the VBlock compute driver orders its sections with - against
+    the order the reference's own zip_compress_all_contexts_local / _b250 produced (tests/golden/order_golden.json, oracle/ref_order_shim.c)"""
+    import parity
+    assert parity.section_order_golden(parity.lib_section_order(real_lib)) == 360

@@ -238,3 +238,18 @@ def test_assign_golden_vectors(oracle):
         tests = [(cd, sizes[i], (sample * ns[cd] / 1000.0) if i else 0.0) for i, cd in enumerate(cand)] + [(c, sz + 28, ck) for c, sz, ck in rows]
         return oracle.assign_sort(tests, mode)
     assert parity.assign_golden_run(best_table) > 100
+
+
+def test_merge_golden_vectors(oracle):
+    """the LOOP of row a4 PINNED: the oracle's ctx_merge == what the reference's own ctx_merge_in_one_vctx / ctx_commit_node /
+    ctx_drop_all_the_same (src/context.c compiled in place) did on the multi-VBlock scenarios of tests/golden/merge_golden.json"""
+    import parity
+    import pyoracle
+    assert parity.merge_loop_golden(lambda est: pyoracle.OracleZctx(oracle, est), oracle.ctx_seg_column) >= 50
+
+
+def test_order_golden_vectors():
+    """row a15 PINNED: the tests' own statement of the section order (parity._section_order_ref, what the composition of every driver test
+    uses) == the order the reference's own zip_compress_all_contexts_local / _b250 produced (tests/golden/order_golden.json)"""
+    import parity
+    assert parity.section_order_golden(parity._section_order_ref) == 360

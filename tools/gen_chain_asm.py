@@ -17,14 +17,14 @@ for in the loop: lane L of the wave holds the operands of the PER symbols base +
 block of 64 * PER symbols ahead, straight into the registers the loop reads ([inv.lo inv.hi | F.hi x]), and one v_lshlrev_b64 that
 turns [F.hi x] into the pair [0 F.hi] when the block starts (tuples are 64-bit aligned: a 12-byte load cannot end on a pair's high
 word). (An 8-byte record { tot | cum << 16, F.hi } with the reciprocal looked up by the lanes was built first - round 5,
-profiles/round5b_*: the same 6.6 ns per symbol alone on the device, 0.4 ns slower inside a step, where the bursts of 64-address
+profiles/r05_*: the same 6.6 ns per symbol alone on the device, 0.4 ns slower inside a step, where the bursts of 64-address
 look-ups of 50 chains meet the other kernels' traffic.)
 Every lane executes every step, and the state walks through a lane's PER symbols and then HOPS to the next lane: the low word of T -
 r, the only word of T that is not a constant - is read from the lane before through DPP (wave_ror:1), and multiplied by that lane's
 last F, which the lane holds as "the F before mine". A DPP read of a register a vector instruction has just written needs two wait
 states (s_nop 1: measured - without them the result is wrong), which is why a lane takes PER symbols in a row and not one. Only the
 diagonal carries meaning; what the other lanes compute is never looked at.
-Clocks per symbol, alone on the device (tools/ubench_chain_f64.hip; profiles/round5b_ubench_chain_rec12.txt): see there.
+Clocks per symbol, alone on the device (tools/ubench_chain_f64.hip; profiles/r05_ubench_chain_rec12.txt): see there.
 
 Everything between the labels is written here, loop control included: the compiler schedules nothing in it. The rest of a leaf that
 does not fill a block is the caller's.
