@@ -121,7 +121,7 @@ class Workload:
         from genozip_amd import fastq as fq
         from genozip_amd.shard import pairs_of_rank
         self.E, self.a, self.W = E, a, W
-        strong = a.scaling == "strong" and world > 1
+        strong = a.scaling == "strong" and (world > 1 or bool(os.environ.get("GZ_BENCH_FORCE_DIST")))
         seed = 1 if strong else 1 + 2 * rank                     # strong: the one file; weak: a file pair of its own per rank
         n_reads = a.stream_reads or a.pairs
         ranges = W.vb_ranges(n_reads, vb_bytes(a))
@@ -327,17 +327,22 @@ def cpu_leg(wl, z_all, n_threads, E=None):
                   "one_thread": {"stream_mb_s": round(nb_1 / dt_1 / 1e6, 1), "sample": "sections of the first VBlock pair (%.1f MB)" % (nb_1 / 1e6)}}
     out = dict(codec_only)
     out["codec_only"] = codec_only
-    # (1) the whole path, FASTQ plans (the SAM / VCF plans have no C composition: their cpu_baseline stays the codec leg)
-    if getattr(wl, "plan", None) is not None and not wl.plan.get("record_lines") and not wl.plan.get("n_samples"):
+    # (1) the whole path: the FASTQ plans (gzo_fastq_vb_path) and the one-line-record plans of SAM / VCF text (gzo_text_vb_path)
+    if getattr(wl, "plan", None) is not None:
         try:
             vbs = [(off, ln) for (off, ln, vi, r1) in wl.vb]
             ref = R if kind == "reference" else None
-            pyoracle.fastq_path_many(O, text, vbs[:2], wl.plan, file_codecs, is_domq, 2, 1, ref)          # warm up
-            dt1, _, _ = pyoracle.fastq_path_many(O, text, vbs, wl.plan, file_codecs, is_domq, n_threads, 1, ref)
+            path_many = pyoracle.text_path_many if wl.plan.get("record_lines") else pyoracle.fastq_path_many
+            big = sum(ln for _o, ln in vbs) > (1 << 30)                                          # (a few VBlocks of hundreds of MB: every pass costs seconds - one pass is the sample)
+            if not big:
+                path_many(O, text, vbs[:2], wl.plan, file_codecs, is_domq, 2, 1, ref)          # warm up
+            dt1, zl, stb = path_many(O, text, vbs, wl.plan, file_codecs, is_domq, n_threads, 1, ref)
             reps_w = max(1, -(-4 * n_threads // len(vbs)))
-            reps_w = max(1, min(reps_w, int(15.0 / max(dt1, 1e-3)) or 1))
-            dtw, zl, stb = pyoracle.fastq_path_many(O, text, vbs, wl.plan, file_codecs, is_domq, n_threads, reps_w, ref)
-            dt_one, _, _ = pyoracle.fastq_path_many(O, text, vbs[:1], wl.plan, file_codecs, is_domq, 1, 1, ref)
+            reps_w = 1 if big else max(1, min(reps_w, int(15.0 / max(dt1, 1e-3)) or 1))
+            dtw = dt1
+            if reps_w > 1:
+                dtw, zl, stb = path_many(O, text, vbs, wl.plan, file_codecs, is_domq, n_threads, reps_w, ref)
+            dt_one = dt1 * min(n_threads, len(vbs)) / len(vbs) if big else path_many(O, text, vbs[:1], wl.plan, file_codecs, is_domq, 1, 1, ref)[0]
             per_vb_value = wl.value_bytes / max(1, getattr(wl, "calls_per_step", 1))
             whole = {"value": round(per_vb_value * reps_w / dtw / 1e6, 1), "unit": "MB/s", "cores": n_threads, "kind": "port",
                      "codecs": "the reference's htscodecs (oracle/_ref)" if ref is not None else "this repo's C restatement",
@@ -347,7 +352,7 @@ def cpu_leg(wl, z_all, n_threads, E=None):
                                % (len(vbs), reps_w, reps_w * len(vbs), n_threads, usable_cpus()[1], "CODEC_DOMQ's transform -> " if is_domq else "", dtw),
                      "z_bytes": int(sum(zl)), "stream_bytes": int(sum(stb)),
                      "this_file_alone": {"value": round(per_vb_value / dt1 / 1e6, 1), "tasks": len(vbs)},
-                     "one_thread": {"value": round(per_vb_value / len(vbs) / dt_one / 1e6, 1), "sample": "the first VBlock"}}
+                     "one_thread": {"value": round(per_vb_value / len(vbs) / dt_one / 1e6, 1), "sample": "the first VBlock" if not big else "estimated from the pass above (a VBlock per thread)"}}
             out = dict(whole)
             out["whole_path"] = whole
             out["codec_only"] = codec_only
@@ -633,13 +638,79 @@ def text_leg(a, WL):
         out["decode"] = decode_leg(E, wl, z_all)
         if out["decode"]["equals_reference_decoder"] is False:
             out["bit_exact"] = False
+        out["bit_exact_payloads"] = out["bit_exact"]
+        out["file_exact"] = file_exact_leg(wl, z_all)
+        if out["file_exact"].get("checked"):
+            out["bit_exact"] = bool(out["bit_exact"] and out["file_exact"]["identical"] == out["file_exact"]["vblocks"])
     print(json.dumps(out))
+
+
+def file_exact_leg(wl, z_all):
+    """bit_exact as a statement about the FILE: every VBlock's z_data of the last timed step against the oracle's composition of the whole path -
+    tests/parity.py::fastq_zip_expected, what every driver test compares with: the reference's per-context functions restated (oracle/gz_oracle.c),
+    chained VBlock by VBlock with the real merged dictionaries, codecs found by the reference's trial rule - run once over the same text, outside
+    the timed region, on one host thread. (The payload-level check of cpu_leg - every section's payload is what the reference's own coder makes of
+    the bytes its own decoder gives back - says nothing about WHICH bytes a section holds: a wrong word index would pass it.) A streamed workload's
+    step holds several calls on one file: the VBlocks compared are the last call's, and the composition cannot know the dictionaries the earlier
+    calls left - such lines say so and keep the payload-level check alone."""
+    t0 = time.perf_counter()
+    try:
+        for p_ in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+            if p_ not in sys.path:
+                sys.path.insert(0, p_)
+        import parity
+        import pyoracle
+        if getattr(wl, "calls_per_step", 1) > 1:
+            return {"checked": False, "why": "several calls per step on one file: the last call's VBlocks depend on dictionaries of the calls before"}
+        O = pyoracle.Oracle()
+        text = wl.text[:wl.text_len].cpu().numpy().tobytes()
+        vbs = [tuple(int(x) for x in v[:4]) for v in wl.vb]
+        if wl.plan.get("n_samples"):
+            return {"checked": False, "why": "VCF plan: the composition for per-sample columns lives in tests/parity.py::vcf_zip (small sizes)"}
+        want, _ = parity.fastq_zip_expected(O, wl.plan, text, vbs)
+        bad = [v for v, (w, z) in enumerate(zip(want, z_all)) if bytes(w["z"]) != bytes(z)]
+        return {"checked": True, "vblocks": len(z_all), "identical": len(z_all) - len(bad), "first_difference": None if not bad else {"vblock": bad[0] + 1, "at": parity._first_diff(bytes(z_all[bad[0]]), bytes(want[bad[0]]["z"]))},
+                "oracle_z_bytes": int(sum(len(w["z"]) for w in want)), "seconds": round(time.perf_counter() - t0, 1)}
+    except Exception as e:                                        # noqa: BLE001
+        return {"checked": False, "error": repr(e)[:300], "seconds": round(time.perf_counter() - t0, 1)}
+
+
+SIDE_LEGS = (("bam_text", "BASELINE configs[2], from SAM text", ["--config", "bam"]),
+             ("bam_records", "BASELINE configs[2], from the records of an uncompressed BAM stream", ["--config", "bam", "--bam-binary"]),
+             ("vcf_share", "BASELINE configs[3], one GPU's share at 8 GPUs", ["--config", "vcf"]),
+             ("streamed", "BASELINE configs[4] at reduced scale: 8 M read pairs streamed through one file in calls of 112 VBlock pairs", ["--stream-reads", "8000000"]))
+
+
+def side_legs():
+    """every other BASELINE configuration beside the headline, so that the driver's ONE default run carries all five: each is this same script
+    run on its configuration (a process of its own, 3 timed steps, its CPU leg and its decode leg once), reduced here to its key figures.
+    A leg that fails leaves its error text; the headline never depends on them. GZ_BENCH_NO_SIDE_LEGS=1 leaves them out."""
+    out = {}
+    for name, what, args in SIDE_LEGS:
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__)] + args + ["--steps", "3", "--warmup", "1", "--warm-steps", "0"],
+                               env=dict(os.environ, GZ_BENCH_SIDE_LEG="1", GZ_BENCH_NO_SIDE_LEGS="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            d = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+            r = d.get("roofline", {}); cb = d.get("cpu_baseline", {}); dec = d.get("decode") or {}
+            out[name] = {"what": what, "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "bit_exact": d.get("bit_exact"),
+                         "dominant_kernel": r.get("kernel"), "roofline_frac": r.get("frac"), "chain_ns_per_symbol": (r.get("critical_path") or {}).get("ns_per_symbol"),
+                         "gpu_over_cpu": {k: v for k, v in (d.get("gpu_over_cpu") or {}).items() if k != "note"},
+                         "cpu_baseline": {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind")},
+                         "decode": {"ms": dec.get("ms"), "uncompressed_mb_s": dec.get("uncompressed_mb_s"), "equals_reference_decoder": dec.get("equals_reference_decoder"),
+                                    "cpu_decode_mb_s": dec.get("cpu_decode_mb_s")},
+                         "text_mb_per_step": d["config"].get("text_mb_per_step"), "wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as e:                                    # noqa: BLE001
+            out[name] = {"what": what, "error": repr(e)[:300], "wall_s": round(time.perf_counter() - t0, 1)}
+    return out
 
 
 def decode_leg(E, wl, z_all, reps=3):
     """row a14 at full size: every section of every VBlock the step wrote, decoded again on the GPU in ONE call (gz_vb_uncompress_many: section
     walk + adler32 check by two kernels, all payloads as one batch of streams) and compared with what the reference's own decoder made of the
     same payloads (cpu_leg). Timed with the compressed VBlocks resident in HBM; a side figure, never `value`."""
+    if os.environ.get("GZ_BENCH_SIDE_LEG"):
+        reps = 1
     totals = [sum(ulen for _st, _c, _d, ulen, _p, _q in walk_sections(z)) for z in z_all]
     items = [((E.mem.upload(bytes(z)), len(z)), t) for z, t in zip(z_all, totals)]
     E.sync()
@@ -656,9 +727,50 @@ def decode_leg(E, wl, z_all, reps=3):
             raw = E.mem.download(ob, total)
             same &= len(want) == len(offs) - 1 and all(raw[offs[k]:offs[k + 1]] == want[k] for k in range(len(want)))
     nsec = sum(len(o) - 1 for _ob, o in res)
-    return {"ms": round(best * 1e3, 2), "vblocks": len(z_all), "sections": nsec, "uncompressed_mb": round(sum(totals) / 1e6, 1), "compressed_mb": round(sum(len(z) for z in z_all) / 1e6, 1),
-            "uncompressed_mb_s": round(sum(totals) / 1e6 / best, 1), "equals_reference_decoder": same,
-            "note": "gz_vb_uncompress_many over the step's own output, compressed VBlocks in HBM, best of %d; one wave per stream (a serial adaptive coder), the longest stream sets the time" % reps}
+    out = {"ms": round(best * 1e3, 2), "vblocks": len(z_all), "sections": nsec, "uncompressed_mb": round(sum(totals) / 1e6, 1), "compressed_mb": round(sum(len(z) for z in z_all) / 1e6, 1),
+           "uncompressed_mb_s": round(sum(totals) / 1e6 / best, 1), "equals_reference_decoder": same,
+           "note": "gz_vb_uncompress_many over the step's own output, compressed VBlocks in HBM, best of %d; one wave per stream (a serial adaptive coder), the longest stream sets the time" % reps}
+    out.update(cpu_decode_leg(z_all))
+    if out.get("cpu_decode_mb_s"):
+        out["gpu_over_cpu_decode"] = round(out["uncompressed_mb_s"] / out["cpu_decode_mb_s"], 3)
+    return out
+
+
+def cpu_decode_leg(z_all):
+    """the same sections through the reference's own decoders (htscodecs' rans_uncompress_to_4x16 / arith_uncompress_to, src/codec_htscodecs.c:100-123,
+    compiled in place: oracle/_ref) on the host's usable cores, a section per task - the file's sections as often as it takes to give every thread
+    four tasks, a bounded sample of them when the file is large. What codec_uncompress costs on the CPU side, beside the device's figure."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle
+        from concurrent.futures import ThreadPoolExecutor
+        if not pyoracle.Ref.available():
+            return {"cpu_decode_mb_s": None, "cpu_decode_note": "oracle/_ref not built"}
+        R = pyoracle.Ref()
+        n_threads = usable_cpus()[0]
+        secs = [(codec, bytes(pay), ulen) for z in z_all for _st, codec, _did, ulen, pay, _dq in walk_sections(z) if codec != 1 and ulen]
+        secs.sort(key=lambda t: -t[2])
+        budget, pick, total = 600 << 20, [], 0                     # at most ~600 MB of output per pass: a few seconds on 16 threads
+        for t in secs:
+            if total + t[2] > budget and pick:
+                continue
+            pick.append(t); total += t[2]
+        reps = max(1, -(-4 * n_threads // max(1, len(pick))))
+        tasks = pick * reps
+
+        def one(t):
+            R.hts_uncompress("rans" if t[0] < 16 else "arith", t[1], t[2])
+            return t[2]
+        with ThreadPoolExecutor(max_workers=n_threads) as ex:
+            list(ex.map(one, tasks[:n_threads]))                    # (threads up, pages touched)
+            t0 = time.perf_counter()
+            done = sum(ex.map(one, tasks))
+            dt = time.perf_counter() - t0
+        return {"cpu_decode_mb_s": round(done / 1e6 / dt, 1), "cpu_decode_cores": n_threads,
+                "cpu_decode_note": "the reference's own decoders (oracle/_ref: htscodecs compiled in place) on %d threads: %d of the output's %d coded sections x %d = %d tasks, %.0f MB decoded in %.2f s"
+                                   % (n_threads, len(pick), len(secs), reps, len(tasks), done / 1e6, dt)}
+    except Exception as e:                                        # noqa: BLE001
+        return {"cpu_decode_mb_s": None, "cpu_decode_note": repr(e)[:200]}
 
 
 def config_leg(a):
@@ -739,12 +851,25 @@ def main():
     # (tests/emul), torch tensors in host memory, the gloo backend. It exercises the N > 1 plumbing of this file, not a measurement.
     emul = bool(os.environ.get("GZ_BENCH_EMUL"))
     dist = None
-    if world > 1:
+    # GZ_BENCH_FORCE_DIST=1 (tests/test_gpu.py, launched under torch.distributed.run with ONE rank): the process group is made and every
+    # exchange of the N-GPU path is taken although there is nobody to exchange with (genozip_amd/shard.py::FORCE_AT_WORLD_1) - RCCL sees the
+    # code on the one GPU a test box has
+    force_dist = bool(os.environ.get("GZ_BENCH_FORCE_DIST")) and "WORLD_SIZE" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if emul:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+        if force_dist and world == 1:
+            from genozip_amd import shard as _sh
+            _sh.FORCE_AT_WORLD_1 = True
+        try:                                                      # (RCCL announces its version through C stdio: out with it now, so that the JSON line stays the LAST line of stdout)
+            import ctypes
+            dist.barrier()
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                                         # noqa: BLE001
+            pass
     if emul:
         sys.path.insert(0, os.path.join(ROOT, "tests", "emul"))
         from hostmem import TorchCpuMem
@@ -772,7 +897,7 @@ def main():
     def gather_to_rank0(total):
         # the final exchange of the path: compressed VBlocks go to the writer rank. The gather is only STARTED:
         # the transfer over xGMI runs beside the next step's kernels; every gather is complete before the timed region ends
-        if world == 1:
+        if dist is None:
             return
         from genozip_amd.shard import gather_blobs
         gather_wait()
@@ -783,7 +908,7 @@ def main():
             pending[0] = gather_blobs(dist, blobs, rank, world, device, async_op=True)
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -895,14 +1020,14 @@ def main():
     z_all = [zhost[wl.offs[i]:wl.offs[i + 1]] for i in range(len(wl.vb))]
     stream_bytes = sum(s[3] for z in z_all for s in walk_sections(z)) * wl.calls_per_step
     sums = torch.tensor([dt, wl.text_bytes, wl.value_bytes, stream_bytes, z_total * wl.calls_per_step, warm_ms or 0.0], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist is not None:
         mx = torch.stack([sums[0], sums[5]])
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         sums[0] = mx[0]; sums[5] = mx[1]
     dt, text_b, value_b, stream_b, z_b, warm_ms_all = [float(x) for x in sums.cpu()]
     if rank != 0:
-        if world > 1:
+        if dist is not None:
             dist.destroy_process_group()
         return
 
@@ -974,7 +1099,7 @@ def main():
            "warm": None if not warm_ms_all else {"ms_per_step": round(warm_ms_all, 3), "value": round(value_b / 1e6 / (warm_ms_all / 1e3), 1), "steps": a.warm_steps,
                                                  "note": "the handle remembers the previous file's QUAL coder and starts the long streams with it (gz_zip_speculation)"},
            "roofline": roofline}
-    if world > 1:
+    if dist is not None:
         steps = max(1, a.steps)
         out["rccl"] = {"world": world, "backend": dist.get_backend(), "rank": 0,
                        "bytes_gathered_per_step": int(coll.get("gather_bytes", 0) / steps), "gather_host_ms_per_step": round(coll.get("gather_ms", 0.0) / steps, 3),
@@ -1001,9 +1126,25 @@ def main():
         out["decode"] = decode_leg(E, wl, z_all)
         if out["decode"]["equals_reference_decoder"] is False:
             out["bit_exact"] = False
-    print(json.dumps(out))
-    if world > 1:
+        out["bit_exact_payloads"] = out["bit_exact"]
+        out["file_exact"] = file_exact_leg(wl, z_all)
+        if out["file_exact"].get("checked"):
+            out["bit_exact"] = bool(out["bit_exact"] and out["file_exact"]["identical"] == out["file_exact"]["vblocks"])
+        if not a.stream_reads and a.qual == "div" and a.pairs == 1000000 and not a.vb_mb and not os.environ.get("GZ_BENCH_NO_SIDE_LEGS"):
+            del wl                                                 # (the legs are processes of their own: give the device's memory back first)
+            E.close()
+            torch.cuda.empty_cache()
+            out["configs"] = side_legs()
+    if dist is not None:
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                                         # noqa: BLE001
+            pass
+    print(json.dumps(out), flush=True)
+    if dist is not None:
         dist.destroy_process_group()
+        os._exit(0)                                               # (nothing behind the JSON line: libraries' exit-time chatter stays in their buffers)
 
 
 if __name__ == "__main__":

@@ -1018,7 +1018,8 @@ class Engine:
         ns = C.c_uint32(0)
         self._check(self.L.gz_vb_uncompress(self.h, self.mem.ptr(zb), len(z_bytes), self.mem.ptr(ob), total_uncompressed, offs, max_sections, C.byref(ns)), "gz_vb_uncompress")
         raw = self.mem.download(ob, total_uncompressed)
-        return [raw[offs[i]:offs[i + 1]] for i in range(ns.value)]
+        M = (1 << 63) - 1                            # (GZ_SECTION_NOT_DECODED: a host coder's section - None)
+        return [None if offs[i] >> 63 else raw[offs[i] & M:offs[i + 1] & M] for i in range(ns.value)]
 
     def vb_uncompress_many(self, items, max_sections=4096, download=True):
         """items: [(z bytes or a device buffer of self.mem with its length, total_uncompressed)] -> per VBlock the list of decoded section
@@ -1041,9 +1042,10 @@ class Engine:
         res = []
         for i, (_z, total) in enumerate(items):
             o = [offs[i * (max_sections + 1) + k] for k in range(ns[i] + 1)]
+            M = (1 << 63) - 1                        # (GZ_SECTION_NOT_DECODED: a host coder's section - zeros on the device, None here)
             if not download:
-                res.append((obs[i], o))
+                res.append((obs[i], [x & M for x in o]))
                 continue
             raw = self.mem.download(obs[i], total)
-            res.append([raw[o[k]:o[k + 1]] for k in range(ns[i])])
+            res.append([None if o[k] >> 63 else raw[o[k] & M:o[k + 1] & M] for k in range(ns[i])])
         return res

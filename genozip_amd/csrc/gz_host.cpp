@@ -74,6 +74,9 @@ struct GzHandle {
     GzHandle *emit_after = NULL;   // the next VBlock batch's section writer waits for this handle's queued work (gz_emit_after)
     hipEvent_t ev_other = NULL;
     bool no_pipeline = false; // GZ_NO_PIPELINE=1: no persistent kernel (needed under tools that serialise kernels, e.g. rocprofv3 --pmc)
+    bool in_fallback = false; // gz_sync is running a batch again, unpipelined, after its persistent chain never heard from the models
+    uint32_t chain_fallbacks = 0;           // how often that has happened on this handle (gz_chain_fallbacks)
+    bool debug_starve_chain = false;        // GZ_DEBUG_STARVE_CHAIN=1 (tests): the models' progress is never announced - the chain must time out, the batch must still come out right
     bool own_stream;
     std::vector<ArenaBlock> blocks;
     std::vector<Pending> pending;
@@ -206,6 +209,7 @@ static GzHandle *gz_create_do (int device, void *hip_stream, int *err, bool back
     }
     if (hipMalloc ((void **)&h->d_fail, 64) != hipSuccess || hipMemset (h->d_fail, 0, 64) != hipSuccess) { if (err) *err = GZ_ERR_HIP; gz_destroy (h); return NULL; }
     { const char *e = getenv ("GZ_NO_PIPELINE"); h->no_pipeline = e && *e && *e != '0'; }
+    { const char *e = getenv ("GZ_DEBUG_STARVE_CHAIN"); h->debug_starve_chain = e && *e && *e != '0'; }
     { const char *e = getenv ("GZ_DEBUG_CHAIN_FAULT"); h->debug_chain_fault = e ? (uint32_t)strtoul (e, NULL, 10) : 0; }   // (tests: a forced checkpoint mismatch must fail the stream)
     // the largest LDS class of the arithmetic coder needs more than the default 64 KB of dynamic LDS
     if (hipFuncSetAttribute ((const void *)k_arith_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
@@ -617,7 +621,7 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
     // (on a background handle a batch whose longest leaf is under two chunks - the 99 999-byte sample of the QUAL trial, which sits in
     //  front of the long pole - goes in one piece: 6.5 -> 4.5 ms, it gains nothing from the pipeline and pays for its gates. The same
     //  rule on the main handle made the step 9 ms SLOWER: its trial batches then hold up the sections that run beside the long pole)
-    if (A.nbig && !h->no_pipeline && (!h->background || P.max_arith_n > 2 * GZ_CHUNK_MIN)) {
+    if (A.nbig && !h->no_pipeline && !h->in_fallback && (!h->background || P.max_arith_n > 2 * GZ_CHUNK_MIN)) {
         const int wgs = (int)chain_wgs;
         if (g_chain_wgs.fetch_add (wgs) + wgs <= h->n_cu * 4) {
             A.pipelined = true; h->chain_wgs_held += wgs;
@@ -755,7 +759,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                     HIPCHK (h, hipStreamWaitEvent (h->stream4, h->ev_sort[k], 0));
                     if (P.unpacked) KLAUNCH_ON (h, h->stream4, k_arith_model<false>, GZ_XCD_DIM (A.nbig, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_big, A.nbig, p0, len, k);
                     else            KLAUNCH_ON (h, h->stream4, k_arith_model<true>,  GZ_XCD_DIM (A.nbig, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_big, A.nbig, p0, len, k);
-                    hipLaunchKernelGGL (k_arith_progress, dim3 (1), dim3 (1), 0, h->stream4, A.d_progress, k + 1);
+                    if (!h->debug_starve_chain) hipLaunchKernelGGL (k_arith_progress, dim3 (1), dim3 (1), 0, h->stream4, A.d_progress, k + 1);
                 }
 #ifdef GZ_SEQUENTIAL_STREAMS
                 if ((rc = arith_launch_chain (h, A, d_leaves)) != GZ_OK) return rc;
@@ -1098,18 +1102,40 @@ static int gz_sync_do (GzHandle *h)
         }
     }
     if (!h->profiling || h->prof_open.size () > 4096) prof_collect (h);
+    std::vector<Pending> again;
+    if (device_failed && !h->in_fallback) again = h->pending;
     h->pending.clear ();
     for (auto p : h->host_tmp) free (p);
     h->host_tmp.clear ();
     arena_reset (h);
+    if (device_failed && !h->in_fallback) {
+        // The persistent chain kernel gave up waiting for the model kernels (kernels serialised by a tool, another tenant holding the hardware
+        // queues, a host that initialised HIP before this library could ask for more queues): every stream / VBlock of this sync is suspect.
+        // The reference's contract is "false only for too small, otherwise it works" (src/compressor.c:89-110): the batches run AGAIN, in the
+        // unpipelined order of the same kernels - inputs and outputs are the caller's and still there, the tables too (they are pending) -
+        // and the caller gets the result of that run, a warning in gz_last_error and a count in gz_chain_fallbacks.
+        h->in_fallback = true;
+        int rc2 = GZ_OK;
+        for (auto &pd : again) {
+            if (pd.kind == 0) rc2 = gz_codec_compress_batch (h, (GzStream *)pd.user, pd.n);
+            else if (pd.kind == 2) rc2 = gz_vb_compress_batch (h, (GzVBlock *)pd.user, pd.n);
+            if (rc2 < 0) break;                                           // (kind 1, decoding, has no chain: its results above stand)
+        }
+        if (rc2 >= 0) rc2 = gz_sync_do (h); else (void)gz_sync_do (h);
+        h->in_fallback = false;
+        h->chain_fallbacks++;
+        if (rc2 >= 0) h->err = "warning: the arithmetic coder's persistent chain kernel never heard from the model kernels (kernels serialised by a tool? "
+                               "too few hardware queues?); the batch was run again unpipelined (GZ_NO_PIPELINE=1 selects that order from the start)";
+        return rc2;
+    }
     if (device_failed) {
-        // (every stream / VBlock of this sync is suspect: their statuses say OK where the chain's leaf was not involved)
-        h->err = "the arithmetic coder's persistent chain kernel never heard from the model kernels (are kernels being "
-                 "serialised by a tool? set GZ_NO_PIPELINE=1)";
+        h->err = "the arithmetic coder failed in the unpipelined order as well";
         return GZ_ERR;
     }
     return rc;
 }
+
+extern "C" uint32_t gz_chain_fallbacks (GzHandle *h) { return h ? h->chain_fallbacks : 0; }
 
 // ---------------------------------------------------------------------------------------------------------
 // host-pointer single-call forms == the reference's COMPRESS()/UNCOMPRESS() signatures
@@ -1885,11 +1911,20 @@ extern "C" int gz_vb_uncompress_many (GzHandle *h, int n_vbs, const uint8_t *con
             const GzdVbSec &sec = S[(size_t)v * max_sections + i];
             if (!sec.ok) { h->err = "section adler32 mismatch"; return GZ_ERR_CORRUPT; }
             if (offs) offs[i] = o;
-            if (sec.ulen && codec_ok ((int)sec.codec)) {          // (a host coder's section - BZ2 / LZMA / BSC - is left to the caller's own uncompress: its bytes of `out` stay as they are)
+            const int sc = (int)sec.codec;
+            if (sec.ulen && codec_ok (sc)) {
                 GzStream s; memset (&s, 0, sizeof (s));
-                s.in = z_data[v] + sec.at; s.in_len = sec.clen; s.out = out[v] + o; s.out_cap = sec.ulen; s.codec = (int)sec.codec;
+                s.in = z_data[v] + sec.at; s.in_len = sec.clen; s.out = out[v] + o; s.out_cap = sec.ulen; s.codec = sc;
                 work.push_back (s);
             }
+            else if (sec.ulen && (sc == GZ_CODEC_BZ2 || sc == GZ_CODEC_LZMA || sc == GZ_CODEC_BSC)) {
+                // a host coder's section (sequential LZ / BWT coders stay on the host) is left to the caller's own uncompress: its
+                // stretch of `out` is zeroed and its offset carries GZ_SECTION_NOT_DECODED
+                if (o + sec.ulen > out_cap[v]) { h->err = "output too small"; return GZ_ERR_CORRUPT; }
+                HIPCHK (h, hipMemsetAsync (out[v] + o, 0, sec.ulen, h->stream));
+                if (offs) offs[i] |= GZ_SECTION_NOT_DECODED;
+            }
+            else if (sec.ulen) { h->err = "section with an unknown codec"; return GZ_ERR_CORRUPT; }
             o += sec.ulen;
         }
         if (offs) offs[W[v].n_sections] = o;

@@ -1900,9 +1900,16 @@ static int zip_finish_wait (GzZipFile *f)
     if (K.b250st_pinned && !b250st.empty ()) memcpy (b250st.data (), K.b250st_pinned, b250st.size () * 4);
     K.phase = 0;
     if (!K.early.empty ()) {
+        const uint32_t fb = f->h2->chain_fallbacks;
         const int rc2 = gz_sync (f->h2);
         if (rc2 < 0) { h->err = f->h2->err; return rc2; }
         for (const GzStream &es : K.early) if (es.status != GZ_OK) { h->err = "a stream coded ahead failed"; return GZ_ERR; }
+        if (f->h2->chain_fallbacks != fb) {
+            // the streams coded ahead came out right only at the second attempt (gz_sync's fallback), AFTER the section writer of this handle
+            // had framed what the first one left: the sections are written again from the payloads as they are now
+            if ((rc = gz_vb_compress_batch (h, V.data (), (int)NV)) == GZ_OK) rc = gz_sync (h);
+            h->err = f->h2->err;                                         // (the warning)
+        }
     }
     T.mark ("compress-sync"); T.done ("finish");
     if (rc < 0) return rc;

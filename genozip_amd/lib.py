@@ -183,7 +183,7 @@ ABI_SYMBOLS = (
     "gz_zfile_add_txt_header", "gz_zfile_add_txt_header_text", "gz_zfile_set_fastq", "gz_vb_insert_section",
     "gz_tokenize_column_n", "gz_int_columns", "gz_local_generate_batch", "gz_acgt_pack_batch",
     "gz_bam_records", "gz_bam_to_sam",
-    "gz_codec_assign_sort", "gz_codec_assign_best_ex", "gz_zip_set_host_codecs", "gz_debug_record_inv", "gz_codec_assign_rule",
+    "gz_codec_assign_sort", "gz_codec_assign_best_ex", "gz_zip_set_host_codecs", "gz_debug_record_inv", "gz_codec_assign_rule", "gz_chain_fallbacks",
 )
 
 
@@ -210,6 +210,8 @@ def load(path=None):
     L.gz_last_error.argtypes = [C.c_void_p]
     L.gz_version.restype = C.c_char_p
     L.gz_stream.restype = C.c_void_p
+    L.gz_chain_fallbacks.argtypes = [C.c_void_p]
+    L.gz_chain_fallbacks.restype = C.c_uint32
     L.gz_debug_record_inv.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     L.gz_codec_assign_rule.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]
     L.gz_stream.argtypes = [C.c_void_p]

@@ -28,6 +28,12 @@ class PendingGather:
         return out
 
 
+# GZ_BENCH_FORCE_DIST / tests: take the exchange paths even in a group of ONE rank - the all_gathers of the merge blobs and votes run as
+# collectives of the backend (nccl == RCCL on HBM tensors), and the gather to the writer rank sends the payload to ITSELF point-to-point
+# (a loop-back ncclSend / ncclRecv pair, checked against what was sent): the one GPU a test box has then sees every call of the N-GPU path
+FORCE_AT_WORLD_1 = False
+
+
 # what the collectives of this module moved and how long the host waited for them, since reset_stats (): bench.py's "rccl" record
 STATS = {}
 
@@ -87,11 +93,19 @@ def gather_blobs(dist, blobs, rank, world, device, dst=0, async_op=False):
         ops.append(dist.P2POp(dist.isend, lens, dst))
         if sum(lens_host):
             ops.append(dist.P2POp(dist.isend, pay[:sum(lens_host)], dst))
+    loop = None
+    if FORCE_AT_WORLD_1 and world == 1 and sum(lens_host):          # the loop-back pair: the payload to this same rank through the backend's send / recv
+        loop = torch.empty_like(pay)
+        ops += [dist.P2POp(dist.isend, pay[:sum(lens_host)], rank), dist.P2POp(dist.irecv, loop[:sum(lens_host)], rank)]
     works = dist.batch_isend_irecv(ops) if ops else []
     moved = int(counts_host[:, 1].sum() - counts_host[dst, 1]) if rank == dst else sum(lens_host)
+    if loop is not None:
+        moved += sum(lens_host)
 
     def finish():
         STATS["gathers"] += 1; STATS["gather_bytes"] += moved
+        if loop is not None:
+            assert torch.equal(loop[:sum(lens_host)], pay[:sum(lens_host)]), "loop-back send / recv returned other bytes"
         if rank != dst:
             return None
         out = []
@@ -104,7 +118,7 @@ def gather_blobs(dist, blobs, rank, world, device, dst=0, async_op=False):
 
     if async_op:
         STATS["gather_ms"] += (_now() - t0) * 1e3
-        return PendingGather(works, (lens, pay, len_bufs, pay_bufs), finish)
+        return PendingGather(works, (lens, pay, len_bufs, pay_bufs, loop), finish)
     for w in works:
         w.wait()
     if pay.is_cuda:
@@ -152,7 +166,7 @@ def zip_vblocks_sharded(zf, dist, text_buf, text_len, tab, n, device=None):
     t0 = _now()
     blob = zf.seg(text_buf, text_len, tab, n)
     t1 = _now(); STATS["seg_phase_ms"] += (t1 - t0) * 1e3
-    if dist is None or dist.get_world_size() == 1:
+    if dist is None or (dist.get_world_size() == 1 and not FORCE_AT_WORLD_1):
         votes = zf.merge([blob])
         t2 = _now(); STATS["merge_phase_ms"] += (t2 - t1) * 1e3
         zf.finish([votes])

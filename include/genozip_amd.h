@@ -70,6 +70,10 @@ int  gz_profile_get (GzHandle *h, int idx, char *name, int name_cap, double *tot
 int  gz_profile_get_max (GzHandle *h, int idx, double *max_ms);
 /* the HIP stream work is queued on (a hipStream_t) - for timing with HIP events on the right stream */
 void     *gz_stream (GzHandle *h);
+/* How often gz_sync ran a batch a second time, unpipelined, because the arithmetic coder's persistent chain kernel never heard from the
+ * model kernels it follows (kernels serialised by a profiling tool, too few hardware queues, another tenant). The results are those of the
+ * second run - the reference's COMPRESS contract: false only for "too small" (src/compressor.c:89-110) -, gz_last_error holds a warning. */
+uint32_t gz_chain_fallbacks (GzHandle *h);
 /* (tests) The reciprocal the arithmetic coder's model kernel puts into a symbol's record for the model totals tot0 .. tot0 + n - 1 (a double
  * with 16 zero low bits, two words each into out_dev): RC_Encode's range / tot (c_range_coder.h:100) is exact with it as long as it lies in
  * [2^-45 / tot, 2^-45 / tot * (1 + 2^-33)] - tests/test_magic.py shows that for the interval, tests/test_gpu.py::test_record_reciprocals that
@@ -272,7 +276,9 @@ int gz_vb_uncompress (GzHandle *h, const uint8_t *z_data, uint64_t z_len, uint8_
  * checked by two kernels, then ALL payloads of ALL VBlocks are decoded as one batch (gz_codec_uncompress_batch) - a wave per stream,
  * hundreds of streams at a time. z_data[v] / out[v]: device; section_offsets_host: n_vbs rows of max_sections + 1 entries (or NULL);
  * n_sections_out: n_vbs entries. A section coded by one of the host's coders (BZ2 / LZMA / BSC: gz_zip_set_host_codecs) is checked but not
- * decoded: its stretch of out[v] is left untouched for the caller's own codec_args[codec].uncompress. Synchronous. */
+ * decoded: its stretch of out[v] is zeroed and its entry of section_offsets_host carries GZ_SECTION_NOT_DECODED on top of the offset - the
+ * caller's own codec_args[codec].uncompress fills it. Any other codec byte the device has no decoder for: GZ_ERR_CORRUPT. Synchronous. */
+#define GZ_SECTION_NOT_DECODED (1ull << 63)
 int gz_vb_uncompress_many (GzHandle *h, int n_vbs, const uint8_t *const *z_data, const uint64_t *z_len, uint8_t *const *out,
                            const uint64_t *out_cap, uint64_t *section_offsets_host, uint32_t max_sections, uint32_t *n_sections_out);
 

@@ -230,10 +230,171 @@ done:
     return rc;
 }
 
+/* ---- the same for the one-line-record plans of genozip_amd/sam.py (BASELINE configs[2]: sam_seg_txt_line / bam_seg_txt_line's chain, src/sam_seg.c,
+ * src/bam_seg.c:425-520) and genozip_amd/vcf.py (configs[3]: vcf_seg_txt_line + vcf_seg_samples, src/vcf_samples.c:1601): a record is one line, its
+ * items come from the plan's separators; an item is a snip column, an integer column (seg_integer_or_not: dyn-int local + SNIP_LOOKUP), a delta against
+ * the previous line, SEQ (bases to NONREF.local, padded per read, 2-bit packed) or QUAL (QUAL.local or CODEC_DOMQ's streams); a VCF line's last item
+ * holds n_samples samples of n_sub ':'-separated subfields, each a snip column of lines x samples entries or an integer matrix written transposed
+ * (dyn_int_transpose, src/dyn_int.c:45-132). Same rules as gzo_fastq_vb_path: contexts of the VBlock's own, codecs given by the caller. ---- */
+typedef struct {
+    uint32_t n_items;              /* items of a line: n_seps + 1 */
+    uint8_t  item_kind[64];        /* 0 snips, 1 seg_integer_or_not, 2 delta against the previous line, 3 SEQ, 4 QUAL, 5 not a context (a tag name the plan expects), 6 the samples */
+    uint8_t  seps[64], sep_counts[64]; uint32_t n_seps;
+    uint8_t  lcodec[64], bcodec[64];
+    uint8_t  qual_codec, aux_codec[3], x_codec, domq, seq_pad, reserved;
+    uint32_t n_samples, n_sub;
+    uint8_t  sub_kind[8], sub_lcodec[8], sub_bcodec[8];      /* per FORMAT subfield: 0 snips, 1 integers in a matrix written transposed */
+} GzoTextPlan;
+
+static long path_int_column (const uint8_t *text, const uint32_t *io, const uint32_t *il, uint64_t n, uint32_t transpose_cols, int lcodec, int bcodec, uint32_t vblock_i,
+                             uint8_t *z, uint64_t z_cap, uint64_t *streams)
+{
+    /* seg_integer_or_not: the numbers into a dyn-int local (written transposed for a samples matrix), SNIP_LOOKUP into the b250; other snips stay snips */
+    uint32_t *so = malloc ((n + 8) * 4), *sl = malloc ((n + 8) * 4); int64_t *vals = malloc ((n + 8) * 8); uint8_t *isn = malloc (n + 8), *dyn = malloc ((n + 8) * 8), *scr = malloc ((n + 8) * 8);
+    uint8_t *ctext = NULL;
+    GzoColumn col; memset (&col, 0, sizeof (col));
+    long rc = -1, zl = 0;
+    if (!so || !sl || !vals || !isn || !dyn || !scr) goto out;
+    uint64_t tlen = 0; for (uint64_t r = 0; r < n; r++) if (io[r] + il[r] > tlen) tlen = (uint64_t)io[r] + il[r];
+    /* (the lookup byte must live in the text the column points into: a private copy with one more byte, as the caller of seg_integer_or_not has it) */
+    ctext = malloc (tlen + 16); if (!ctext) goto out;
+    memcpy (ctext, text, tlen); ctext[tlen] = 1;
+    const uint64_t nv = gzo_seg_integer_or_not (ctext, io, il, n, 0, (uint32_t)tlen, so, sl, vals, isn);
+    if (nv) {
+        const int lt = gzo_dyn_int_column (vals, isn, nv, 0, dyn);
+        const uint32_t w = gzo_lt_width (lt);
+        gzo_local_generate (lt, dyn, nv, transpose_cols && nv == n ? transpose_cols : 0, scr);
+        const long r1 = path_section (12, lcodec, 0, (uint8_t)lt, vblock_i, dyn, (uint32_t)(nv * w), z, z_cap, streams);
+        if (r1 < 0) goto out;
+        zl = r1;
+    }
+    uint64_t bytes = 0; for (uint64_t r = 0; r < n; r++) bytes += sl[r];
+    if (!col_alloc (&col, n, bytes) || gzo_ctx_seg_column (ctext, so, sl, n, NULL, NULL, NULL, 0, &col) != 0) goto out;
+    const long r2 = path_b250 (&col, (uint32_t)n, nv ? nv : 0, bcodec, vblock_i, z + zl, z_cap - (uint64_t)zl, streams);
+    if (r2 < 0) goto out;
+    rc = zl + r2;
+out:
+    col_free (&col); free (so); free (sl); free (vals); free (isn); free (dyn); free (scr); free (ctext);
+    return rc;
+}
+
+long gzo_text_vb_path (const uint8_t *text, uint64_t text_len, uint32_t vblock_i, const GzoTextPlan *P, uint8_t *z, uint64_t z_cap, uint64_t *streams)
+{
+    long rc = -1; uint64_t zl = GZO_VB_HEADER_LEN; *streams = 0;
+    if (z_cap < GZO_VB_HEADER_LEN || text_len > 0xfffffff0ull) return -1;
+    uint64_t cap = text_len / 32 + 1024;
+    uint32_t *lo = malloc (cap * 4), *ll = malloc (cap * 4);
+    if (!lo || !ll) { free (lo); free (ll); return -1; }
+    uint64_t n = gzo_text_lines (text, text_len, lo, ll, cap);
+    if (n > cap) { free (lo); free (ll); cap = n + 8; lo = malloc (cap * 4); ll = malloc (cap * 4); if (!lo || !ll) { free (lo); free (ll); return -1; } n = gzo_text_lines (text, text_len, lo, ll, cap); }
+    uint32_t n_flat = 0; uint8_t flat[256];
+    for (uint32_t i = 0; i < P->n_seps; i++) for (uint32_t k = 0; k < P->sep_counts[i] && n_flat < 255; k++) flat[n_flat++] = P->seps[i];
+    uint32_t *fo = malloc (((uint64_t)(n_flat + 1) * n + 8) * 4), *fl = malloc (((uint64_t)(n_flat + 1) * n + 8) * 4);
+    uint32_t *io = malloc ((n + 8) * 4), *il = malloc ((n + 8) * 4);
+    int64_t *vals = malloc ((n + 8) * 8); uint8_t *dyn = malloc ((n + 8) * 8), *blob = NULL, *packed = NULL;
+    uint32_t *so = NULL, *sl = NULL;
+    GzoColumn col; memset (&col, 0, sizeof (col));
+    if (!fo || !fl || !io || !il || !vals || !dyn) goto done;
+    if (gzo_tokenize_column (text, lo, ll, n, flat, n_flat, fo, fl) != 0) goto done;
+    uint32_t at_flat = 0;
+    for (uint32_t it = 0; it < P->n_items; it++) {
+        const uint32_t k = it < P->n_seps ? P->sep_counts[it] : 1;
+        for (uint64_t r = 0; r < n; r++) { io[r] = fo[(uint64_t)at_flat * n + r]; il[r] = fo[(uint64_t)(at_flat + k - 1) * n + r] + fl[(uint64_t)(at_flat + k - 1) * n + r] - io[r]; }
+        at_flat += k;
+        const int kind = P->item_kind[it];
+        long r1 = 0;
+        if (kind == 5) continue;
+        if (kind == 0) {
+            uint64_t bytes = 0; for (uint64_t r = 0; r < n; r++) bytes += il[r];
+            if (!col_alloc (&col, n, bytes) || gzo_ctx_seg_column (text, io, il, n, NULL, NULL, NULL, 0, &col) != 0) goto done;
+            r1 = path_b250 (&col, (uint32_t)n, 0, P->bcodec[it], vblock_i, z + zl, z_cap - zl, streams);
+            col_free (&col); memset (&col, 0, sizeof (col));
+        }
+        else if (kind == 1) r1 = path_int_column (text, io, il, n, 0, P->lcodec[it], P->bcodec[it], vblock_i, z + zl, z_cap - zl, streams);
+        else if (kind == 2) {
+            int64_t prev = 0;
+            for (uint64_t r = 0; r < n; r++) { int64_t v = 0; for (uint32_t c = 0; c < il[r]; c++) v = v * 10 + (text[io[r] + c] - '0'); vals[r] = v - prev; prev = v; }
+            const int lt = gzo_dyn_int_column (vals, NULL, n, 0, dyn);
+            gzo_local_generate (lt, dyn, n, 0, NULL);
+            r1 = n ? path_section (12, P->lcodec[it], 0, (uint8_t)lt, vblock_i, dyn, (uint32_t)(n * gzo_lt_width (lt)), z + zl, z_cap - zl, streams) : 0;
+        }
+        else if (kind == 3) {                                          /* SEQ: the bases, every read padded with 'A' to a multiple of seq_pad (sam_seg_SEQ_pad_nonref, sam_seq.c:224-229) */
+            uint64_t nb = 0; for (uint64_t r = 0; r < n; r++) nb += il[r] + P->seq_pad;
+            blob = malloc (nb + 64); packed = malloc (gzo_acgt_packed_len (nb) + 64);
+            if (!blob || !packed) goto done;
+            const uint64_t L = gzo_local_blob_column_ex (text, io, il, n, 0, NULL, 0, P->seq_pad, 'A', blob, NULL);
+            if (gzo_acgt_pack (blob, L, packed, blob)) r1 = path_section (12, P->x_codec, 11 /* CODEC_XCGT */, 27, vblock_i, blob, (uint32_t)L, z + zl, z_cap - zl, streams);
+            free (blob); blob = NULL; free (packed); packed = NULL;
+        }
+        else if (kind == 4) {                                          /* QUAL */
+            if (P->domq) {
+                GzoDomq dq; memset (&dq, 0, sizeof (dq));
+                if (gzo_domq_encode (text, io, il, n, &dq) != 0) goto done;
+                const uint8_t *s[4] = { dq.qual, dq.runs, dq.mplx, dq.divr }; const uint64_t sn[4] = { dq.qual_len, dq.runs_len, dq.mplx_len, dq.divr_len };
+                for (int q = 0; q < 4 && r1 >= 0; q++) if (sn[q]) {
+                    const long r4 = q ? path_section (12, P->aux_codec[q - 1], 0, 27, vblock_i, s[q], (uint32_t)sn[q], z + zl + r1, z_cap - zl - (uint64_t)r1, streams)
+                                      : path_section (12, P->qual_codec, 13 /* CODEC_DOMQ */, 13, vblock_i, s[q], (uint32_t)sn[q], z + zl + r1, z_cap - zl - (uint64_t)r1, streams);
+                    r1 = r4 < 0 ? -1 : r1 + r4;
+                }
+                gzo_domq_free (&dq);
+            }
+            else {
+                uint64_t nq = 0; for (uint64_t r = 0; r < n; r++) nq += il[r];
+                blob = malloc (nq + 64);
+                if (!blob) goto done;
+                const uint64_t L = gzo_local_blob_column (text, io, il, n, 0, blob);
+                r1 = L ? path_section (12, P->qual_codec, 0, GZO_LT_BLOB, vblock_i, blob, (uint32_t)L, z + zl, z_cap - zl, streams) : 0;
+                free (blob); blob = NULL;
+            }
+        }
+        else if (kind == 6 && P->n_samples && P->n_sub) {              /* vcf_seg_samples: samples by tab, subfields by ':' (trailing ones may be left out: empty) */
+            const uint64_t ns = P->n_samples, k2 = n * ns;
+            so = malloc (((uint64_t)P->n_sub * k2 + 8) * 4); sl = malloc (((uint64_t)P->n_sub * k2 + 8) * 4);
+            if (!so || !sl) goto done;
+            memset (sl, 0, ((uint64_t)P->n_sub * k2 + 8) * 4);
+            for (uint64_t r = 0; r < n; r++) {
+                uint32_t a = io[r]; const uint32_t e = io[r] + il[r];
+                for (uint64_t s_ = 0; s_ < ns && a <= e; s_++) {
+                    uint32_t b = a; while (b < e && text[b] != '\t') b++;
+                    uint32_t c0 = a;
+                    for (uint32_t j = 0; j < P->n_sub && c0 <= b; j++) {
+                        uint32_t c1 = c0; while (c1 < b && text[c1] != ':') c1++;
+                        so[(uint64_t)j * k2 + r * ns + s_] = c0; sl[(uint64_t)j * k2 + r * ns + s_] = c1 - c0;
+                        c0 = c1 + 1;
+                    }
+                    a = b + 1;
+                }
+            }
+            for (uint32_t j = 0; j < P->n_sub && r1 >= 0; j++) {
+                long rj;
+                if (P->sub_kind[j] == 1) rj = path_int_column (text, so + (uint64_t)j * k2, sl + (uint64_t)j * k2, k2, (uint32_t)ns, P->sub_lcodec[j], P->sub_bcodec[j], vblock_i, z + zl + r1, z_cap - zl - (uint64_t)r1, streams);
+                else {
+                    uint64_t bytes = 0; for (uint64_t q = 0; q < k2; q++) bytes += sl[(uint64_t)j * k2 + q];
+                    rj = -1;
+                    if (col_alloc (&col, k2, bytes) && gzo_ctx_seg_column (text, so + (uint64_t)j * k2, sl + (uint64_t)j * k2, k2, NULL, NULL, NULL, 0, &col) == 0)
+                        rj = path_b250 (&col, (uint32_t)k2, 1 /* no_stons: a per-sample context keeps its words */, P->sub_bcodec[j], vblock_i, z + zl + r1, z_cap - zl - (uint64_t)r1, streams);
+                    col_free (&col); memset (&col, 0, sizeof (col));
+                }
+                r1 = rj < 0 ? -1 : r1 + rj;
+            }
+            free (so); free (sl); so = sl = NULL;
+        }
+        if (r1 < 0) goto done;
+        zl += (uint64_t)r1;
+    }
+    gzo_vb_header_write (z, vblock_i, (uint32_t)text_len, 0, 0, NULL, 0);
+    gzo_vb_header_patch (z, (uint32_t)zl);
+    rc = (long)zl;
+done:
+    col_free (&col);
+    free (lo); free (ll); free (fo); free (fl); free (io); free (il); free (vals); free (dyn); free (blob); free (packed); free (so); free (sl);
+    return rc;
+}
+
 /* ---- one VBlock per task on a pthread pool (src/dispatcher.c:544-618) ---- */
 typedef struct {
     const uint8_t *text; const uint64_t *off, *len; int n; int replicas; const GzoPathPlan *plan; uint64_t z_cap;
-    long *z_len; uint64_t *streams; int next, failed; pthread_mutex_t mu;
+    long *z_len; uint64_t *streams; int next, failed; pthread_mutex_t mu; const GzoTextPlan *tplan;
 } PathJob;
 
 static void *path_worker (void *arg)
@@ -248,7 +409,8 @@ static void *path_worker (void *arg)
         if (t >= j->n * j->replicas) break;
         const int i = t % j->n;
         uint64_t st = 0;
-        const long l = gzo_fastq_vb_path (j->text + j->off[i], j->len[i], (uint32_t)t + 1, j->plan, z, j->z_cap, &st);
+        const long l = j->tplan ? gzo_text_vb_path (j->text + j->off[i], j->len[i], (uint32_t)t + 1, j->tplan, z, j->z_cap, &st)
+                                : gzo_fastq_vb_path (j->text + j->off[i], j->len[i], (uint32_t)t + 1, j->plan, z, j->z_cap, &st);
         if (l < 0) j->failed = 1;
         if (t < j->n) { j->z_len[i] = l; j->streams[i] = st; }
     }
@@ -257,15 +419,28 @@ static void *path_worker (void *arg)
 }
 
 /* every VBlock `replicas` times (tasks >= 4 x threads keep every thread busy to the end); returns seconds, < 0 on failure */
+static double path_many (const uint8_t *text, const uint64_t *off, const uint64_t *len, int n, int replicas, const GzoPathPlan *plan, const GzoTextPlan *tplan,
+                         long *z_len, uint64_t *streams, int n_threads);
 double gzo_fastq_path_many (const uint8_t *text, const uint64_t *off, const uint64_t *len, int n, int replicas, const GzoPathPlan *plan,
                             long *z_len, uint64_t *streams, int n_threads)
+{
+    return path_many (text, off, len, n, replicas, plan, NULL, z_len, streams, n_threads);
+}
+/* the one-line-record plans (SAM / VCF) */
+double gzo_text_path_many (const uint8_t *text, const uint64_t *off, const uint64_t *len, int n, int replicas, const GzoTextPlan *plan,
+                           long *z_len, uint64_t *streams, int n_threads)
+{
+    return path_many (text, off, len, n, replicas, NULL, plan, z_len, streams, n_threads);
+}
+static double path_many (const uint8_t *text, const uint64_t *off, const uint64_t *len, int n, int replicas, const GzoPathPlan *plan, const GzoTextPlan *tplan,
+                         long *z_len, uint64_t *streams, int n_threads)
 {
     uint64_t longest = 0;
     for (int i = 0; i < n; i++) if (len[i] > longest) longest = len[i];
     /* (a compute thread of the reference recycles its VBlock's buffers, src/vblock.c:253: keep freed blocks in the threads' heaps instead of
         handing 100 MB per VBlock back to the kernel and faulting it in again - with 256 threads that is what would be measured otherwise) */
     mallopt (M_MMAP_THRESHOLD, 1 << 30); mallopt (M_TRIM_THRESHOLD, 1 << 30); mallopt (M_TOP_PAD, 64 << 20);
-    PathJob j = { text, off, len, n, replicas < 1 ? 1 : replicas, plan, longest + longest / 8 + (1 << 20), z_len, streams, 0, 0, PTHREAD_MUTEX_INITIALIZER };
+    PathJob j = { text, off, len, n, replicas < 1 ? 1 : replicas, plan, longest + longest / 8 + (1 << 20), z_len, streams, 0, 0, PTHREAD_MUTEX_INITIALIZER, tplan };
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 1024) n_threads = 1024;
     pthread_t th[1024];

@@ -532,6 +532,62 @@ def fastq_path_many(oracle, text, vbs, plan, codecs, domq, n_threads, replicas=1
     return dt, list(zl), list(st)
 
 
+class GzoTextPlan(ctypes.Structure):
+    _fields_ = [("n_items", ctypes.c_uint32), ("item_kind", ctypes.c_uint8 * 64), ("seps", ctypes.c_uint8 * 64), ("sep_counts", ctypes.c_uint8 * 64), ("n_seps", ctypes.c_uint32),
+                ("lcodec", ctypes.c_uint8 * 64), ("bcodec", ctypes.c_uint8 * 64), ("qual_codec", ctypes.c_uint8), ("aux_codec", ctypes.c_uint8 * 3), ("x_codec", ctypes.c_uint8),
+                ("domq", ctypes.c_uint8), ("seq_pad", ctypes.c_uint8), ("reserved", ctypes.c_uint8), ("n_samples", ctypes.c_uint32), ("n_sub", ctypes.c_uint32),
+                ("sub_kind", ctypes.c_uint8 * 8), ("sub_lcodec", ctypes.c_uint8 * 8), ("sub_bcodec", ctypes.c_uint8 * 8)]
+
+
+def text_path_many(oracle, text, vbs, plan, codecs, domq, n_threads, replicas=1, ref=None):
+    """fastq_path_many for the one-line-record plans (genozip_amd/sam.py, vcf.py: oracle/gz_oracle_path.c::gzo_text_vb_path): the whole path of every VBlock
+    of SAM / VCF text on a pthread pool. Same arguments and result."""
+    import numpy as np
+    L = oracle.L
+    P = GzoTextPlan()
+    seps = bytes(plan["seps"])
+    P.n_seps = len(seps); P.n_items = len(seps) + 1
+    for i, b in enumerate(seps):
+        P.seps[i] = b; P.sep_counts[i] = plan["sep_counts"][i]
+    for i in range(P.n_items):
+        P.item_kind[i] = 5
+    ns = plan.get("n_samples", 0)
+    for c in plan["ctxs"]:
+        if c.get("per_sample"):
+            j = c["item"]
+            P.sub_kind[j] = 1 if c["kind"] == 3 else 0
+            P.sub_lcodec[j] = codecs.get(("local", c["tag"]), 0); P.sub_bcodec[j] = codecs.get(("b250", c["tag"]), 0)
+        elif c["kind"] in (2, 3, 4):                               # GZ_FQ_ITEM_TEXT / _INT / _DELTA
+            i = c["item"]
+            P.item_kind[i] = {2: 0, 3: 1, 4: 2}[c["kind"]]
+            P.lcodec[i] = codecs.get(("local", c["tag"]), 0); P.bcodec[i] = codecs.get(("b250", c["tag"]), 0)
+    if ns:
+        P.n_samples, P.n_sub = ns, plan["n_subfields"]
+        P.item_kind[P.n_items - 1] = 6
+    else:
+        P.item_kind[plan["seq_item"]] = 3; P.item_kind[plan["qual_item"]] = 4
+        P.seq_pad = plan.get("seq_pad", 0)
+    P.qual_codec = codecs.get(("local", "QUAL"), 0)
+    for k, t in enumerate(("DOMQRUNS", "QUALMPLX", "DIVRQUAL")):
+        P.aux_codec[k] = codecs.get(("local", t), 0)
+    P.x_codec = codecs.get(("local", "NONREF_X"), 0) or 1
+    P.domq = int(bool(domq))
+    if ref is not None:
+        L.gzo_path_use_codecs(ctypes.cast(ref.L.htsref_rans_compress, ctypes.c_void_p), ctypes.cast(ref.L.htsref_arith_compress, ctypes.c_void_p))
+    else:
+        L.gzo_path_use_codecs(None, None)
+    t = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else text)
+    n = len(vbs)
+    off = np.array([v[0] for v in vbs], dtype=np.uint64); ln = np.array([v[1] for v in vbs], dtype=np.uint64)
+    zl = (ctypes.c_long * n)(); st = (ctypes.c_uint64 * n)()
+    L.gzo_text_path_many.restype = ctypes.c_double
+    dt = L.gzo_text_path_many(t.ctypes.data_as(ctypes.c_void_p), off.ctypes.data_as(ctypes.c_void_p), ln.ctypes.data_as(ctypes.c_void_p), n, int(replicas),
+                              ctypes.byref(P), zl, st, int(n_threads))
+    if dt < 0:
+        raise RuntimeError("oracle whole-path leg (text plans) failed")
+    return dt, list(zl), list(st)
+
+
 class Ref:
     """the reference's vendored htscodecs, compiled in place (only where oracle/_ref was built)"""
 

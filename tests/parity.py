@@ -1244,9 +1244,12 @@ def fastq_zip_host_codecs(E, oracle, n_reads=900):
         want, zstate = fastq_zip_expected(oracle, plan, text, vbs, zstate, host=host)
         for v, (g, w) in enumerate(zip(got, want)):
             assert g["z"] == w["z"], (call, v, len(g["z"]), len(w["z"]), _first_diff(g["z"], w["z"]))
-            z, p = g["z"], 84
+            z, p, codecs, total = g["z"], 84, [], 0
             while p < len(z):
-                used.add(z[p + 25]); p += 40 + int.from_bytes(z[p + 12:p + 16], "big")
+                used.add(z[p + 25]); codecs.append(z[p + 25]); total += int.from_bytes(z[p + 16:p + 20], "big"); p += 40 + int.from_bytes(z[p + 12:p + 16], "big")
+            # the device decodes what it has decoders for; a host coder's section comes back as None (GZ_SECTION_NOT_DECODED), never as stale bytes
+            secs = E.vb_uncompress(z, total)
+            assert [s is None for s in secs] == [c in (3, 4, 5) for c in codecs], (call, v, codecs)
     F.set_host_codecs(None)
     F.close()
     assert used & {3, 4}, used                                   # a host coder did win something

@@ -566,3 +566,49 @@ def test_assign_golden_vectors(gpu_engine):
     def best_table(data, rows, ns, mode):
         return gpu_engine.assign_best_ex(data, [(c, sz + 28, ck) for c, sz, ck in rows], [float(x) for x in ns], mode)
     assert parity.assign_golden_run(best_table) > 100
+
+
+def test_chain_timeout_falls_back(oracle, monkeypatch):
+    """the persistent range-coder chain follows the model kernels chunk by chunk; when it never hears from them (GZ_DEBUG_STARVE_CHAIN: the
+    progress announcements are left out, as under a tool that serialises kernels) it gives up after a bounded wait - and gz_sync must then run
+    the batch again unpipelined and hand out the reference's bytes (COMPRESS: false only for "too small", src/compressor.c:89-110), with a
+    warning and a count; the VBlock compute driver, whose long QUAL streams are coded ahead on a second handle, must write its sections again"""
+    from genozip_amd.codec import Engine
+    monkeypatch.setenv("GZ_DEBUG_STARVE_CHAIN", "1")
+    E = Engine(device=0)
+    monkeypatch.delenv("GZ_DEBUG_STARVE_CHAIN")
+    qual = synth.quality_diverse(7, 2000).tobytes()                       # 300 KB: several position chunks, the pipelined path
+    for codec in (16, 17):
+        got = E.compress_many([(codec, qual)])[0]
+        assert got == oracle.codec_compress(codec, qual)
+    assert E.L.gz_chain_fallbacks(E.h) == 2 and b"warning" in E.L.gz_last_error(E.h)
+    assert E.uncompress_many([(16, E.compress_many([(16, qual)])[0], len(qual))])[0] == qual
+    parity.fastq_zip(E, oracle, 2500, n_calls=1)                          # whole path, QUAL coded ahead on the background handle
+    E.close()
+
+
+def test_rccl_sees_the_sharding_code():
+    """the N-GPU path on the ONE GPU of the test box, over RCCL: (1) genozip_amd/shard.py's exchanges on HBM tensors in an nccl group of one
+    rank (all_gather of byte strings, the gather to the writer rank with a loop-back ncclSend / ncclRecv pair); (2) `bench.py --gpus 1
+    --scaling strong` launched the way the driver launches N ranks (torch.distributed.run), with GZ_BENCH_FORCE_DIST=1: the file's merge
+    blobs and codec votes go through all_gather, the z_data through the gather, and the line carries an `rccl` record with backend nccl"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def port():
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+        return p
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_world1.py"), str(port())], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0 and "OK" in p.stdout.decode().split(), p.stderr.decode()[-3000:]      # (RCCL prints its version banner behind it)
+    env = dict(os.environ, GZ_BENCH_FORCE_DIST="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port()),
+                        os.path.join(root, "bench.py"), "--gpus", "1", "--scaling", "strong", "--pairs", "60000", "--steps", "2", "--warmup", "1", "--no-cpu", "--warm-steps", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    d = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["rccl"]["world"] == 1 and d["rccl"]["backend"] == "nccl", d.get("rccl")
+    assert d["rccl"]["exchanges_per_step"] == 2 and d["rccl"]["exchange_bytes_per_step"] == 0 and d["rccl"]["bytes_gathered_per_step"] > 0, d["rccl"]

@@ -215,6 +215,7 @@ def test_bench_gpus_2_under_gloo(emul_engine):
                         os.path.join(root, "bench.py"), "--gpus", "2", "--pairs", "600", "--vb-mb", "0.05", "--steps", "1", "--warmup", "0", "--no-cpu", "--warm-steps", "0"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert p.stdout.decode().strip().splitlines()[-1].startswith("{")          # (the JSON line is the LAST line of stdout: the driver reads it there)
     d = json.loads(p.stdout.decode().strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["rccl"]["world"] == 2 and d["rccl"]["backend"] == "gloo"
     assert d["rccl"]["bytes_gathered_per_step"] > 0 and d["rccl"]["exchanges_per_step"] == 2 and d["rccl"]["exchange_bytes_per_step"] > 0
