@@ -312,7 +312,7 @@ def cpu_leg(wl, z_all, n_threads, E=None):
     # tasks >= 4 x threads: the same sections again and again (a file with more VBlocks of the same kind) until no thread idles at the end -
     # bounded to ~10 s of pool time by the rate just measured
     reps = max(1, -(-4 * n_threads // len(tasks)))
-    reps = max(1, min(reps, int(10.0 / max(dt_all, 1e-3)) or 1))
+    reps = max(1, min(reps, int((4.0 if os.environ.get("GZ_BENCH_SIDE_LEG") else 10.0) / max(dt_all, 1e-3)) or 1))
     _, dt_rep, nb_rep = pool(n_threads, None, reps)
     # one thread (BASELINE configs[0]) on a bounded sample: the sections of the first VBlock pair
     first = [i for i, v in enumerate(task_vb) if v in (0, len(wl.vb) // 2)]
@@ -338,7 +338,7 @@ def cpu_leg(wl, z_all, n_threads, E=None):
                 path_many(O, text, vbs[:2], wl.plan, file_codecs, is_domq, 2, 1, ref)          # warm up
             dt1, zl, stb = path_many(O, text, vbs, wl.plan, file_codecs, is_domq, n_threads, 1, ref)
             reps_w = max(1, -(-4 * n_threads // len(vbs)))
-            reps_w = 1 if big else max(1, min(reps_w, int(15.0 / max(dt1, 1e-3)) or 1))
+            reps_w = 1 if big else max(1, min(reps_w, int((5.0 if os.environ.get("GZ_BENCH_SIDE_LEG") else 15.0) / max(dt1, 1e-3)) or 1))
             dtw = dt1
             if reps_w > 1:
                 dtw, zl, stb = path_many(O, text, vbs, wl.plan, file_codecs, is_domq, n_threads, reps_w, ref)
@@ -698,7 +698,7 @@ def side_legs():
                          "gpu_over_cpu": {k: v for k, v in (d.get("gpu_over_cpu") or {}).items() if k != "note"},
                          "cpu_baseline": {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind")},
                          "decode": {"ms": dec.get("ms"), "uncompressed_mb_s": dec.get("uncompressed_mb_s"), "equals_reference_decoder": dec.get("equals_reference_decoder"),
-                                    "cpu_decode_mb_s": dec.get("cpu_decode_mb_s")},
+                                    "cpu_decode_mb_s": dec.get("cpu_decode_mb_s"), "device_full_mb_s": (dec.get("throughput") or {}).get("uncompressed_mb_s")},
                          "text_mb_per_step": d["config"].get("text_mb_per_step"), "wall_s": round(time.perf_counter() - t0, 1)}
         except Exception as e:                                    # noqa: BLE001
             out[name] = {"what": what, "error": repr(e)[:300], "wall_s": round(time.perf_counter() - t0, 1)}
@@ -733,6 +733,26 @@ def decode_leg(E, wl, z_all, reps=3):
     out.update(cpu_decode_leg(z_all))
     if out.get("cpu_decode_mb_s"):
         out["gpu_over_cpu_decode"] = round(out["uncompressed_mb_s"] / out["cpu_decode_mb_s"], 3)
+    # The figure above is a LATENCY: one wave per stream, the longest stream sets the time, and a file's few hundred streams leave most of the
+    # device idle. What the device decodes per second when it is full - a read-ahead holding many files' VBlocks, as piz would have them - is
+    # measured here: the same output several times over in ONE call (separate outputs), as many copies as bring the call to ~2000 long streams
+    # or 16 GB of output, whichever comes first.
+    try:
+        long_streams = sum(1 for z in z_all for _st, codec, _did, ulen, _p, _q in walk_sections(z) if codec != 1 and ulen >= (1 << 20))
+        copies = max(2, min(16, -(-2000 // max(1, long_streams)), int((16 << 30) // max(1, sum(totals)))))
+        if os.environ.get("GZ_BENCH_SIDE_LEG") and sum(totals) * copies > (6 << 30):
+            copies = max(2, int((6 << 30) // max(1, sum(totals))))
+        many = items * copies
+        E.vb_uncompress_many(many[:len(items)], download=False)
+        t0 = time.perf_counter()
+        E.vb_uncompress_many(many, download=False)
+        dt = time.perf_counter() - t0
+        out["throughput"] = {"copies_in_one_call": copies, "long_streams_in_flight": long_streams * copies, "ms": round(dt * 1e3, 1),
+                             "uncompressed_mb_s": round(sum(totals) * copies / 1e6 / dt, 1),
+                             "gpu_over_cpu_decode": round(sum(totals) * copies / 1e6 / dt / out["cpu_decode_mb_s"], 3) if out.get("cpu_decode_mb_s") else None,
+                             "note": "the device full: the step's output %d times over in one gz_vb_uncompress_many call" % copies}
+    except Exception as e:                                        # noqa: BLE001
+        out["throughput"] = {"error": repr(e)[:200]}
     return out
 
 
@@ -774,9 +794,10 @@ def cpu_decode_leg(z_all):
 
 
 def config_leg(a):
-    """BASELINE configs[2] (BAM-1M) / configs[3] (VCF 10 k samples, one GPU's share) on ONE GPU in this record's layout. Their segmenters
-    (SURVEY 8f N1 for SAM / BAM / VCF) are not built: the context streams of SURVEY 8(0) enter generated, at the sizes the reference would
-    give them; a step = b250 generation + local byte order / transposes + codecs + section framing of every VBlock (tools/config_bench.py)"""
+    """--stream-level: BASELINE configs[2] (BAM-1M) / configs[3] (VCF 10 k samples, one GPU's share) entered at the CONTEXT-STREAM level - the
+    context streams of SURVEY 8(0) generated at the sizes the reference would give them; a step = b250 generation + local byte order /
+    transposes + codecs + section framing of every VBlock (tools/config_bench.py). The default legs of these configurations start from text /
+    BAM records through the one-line-record plans (sam_leg / vcf_leg); this entry stays for the streams alone."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import torch
     import config_bench as cb
@@ -813,7 +834,7 @@ def config_leg(a):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
            "config": {"workload": ("BAM-1M (BASELINE configs[2]): 22 VBlocks of 46 000 aligned reads - CIGAR / FLAG / MAPQ b250, binned QUAL local, POS u32 local" if a.config == "bam" else
                                    "VCF 10 k samples (BASELINE configs[3]), one GPU's share at 8 GPUs: 4 VBlocks of 3 000 lines x 10 000 samples - FORMAT/DP u8 matrix (transposed), FORMAT/PL b250")
-                                  + "; entered at the CONTEXT-STREAM level (the SAM / BAM / VCF segmenters are not built): MB counted = bytes of context streams",
+                                  + "; entered at the CONTEXT-STREAM level (--stream-level; the default legs start from text): MB counted = bytes of context streams",
                       "n_vblocks": wl.n_vb, "stream_mb_per_step": round(wl.stream_bytes / 1e6, 1), "text_mb_approx": round(text_bytes / 1e6), "compressed_mb_per_step": round(z_total / 1e6, 2),
                       "codecs": {k: CODEC_NAMES[v] for k, v in codecs.items()}},
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,

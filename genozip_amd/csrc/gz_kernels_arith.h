@@ -1259,7 +1259,8 @@ __device__ static inline GzdLowBlock d_low_block (const GzdLowBlock *blocks, con
 // (Until round 4 this kernel wrote r, and k_low_count / k_low_scatter each read every symbol's 16-byte record again for freq and cum:
 // 60 bytes of traffic per symbol between the three; round 4: 25; with the 12-byte record: 21.)
 // Same grid as the low kernels that follow it (one workgroup = 64 slices), 64 threads, GZ_EXPAND_LDS bytes of LDS.
-#define GZ_EXPAND_TILE_BYTES (64 * 65 * 4)          // 16 640: the tile of a = cum * r values, [64 slices][65]
+#define GZ_EXPAND_TILE_BYTES (64 * 33 * 4)          // 8 448: the tile of a = cum * r values, [64 slices][32 symbols + 1] - a slice's 64 symbols go out in two halves
+                                                    // (a tile of all 64 made it 23.8 KB of LDS a workgroup of ONE wave: six waves a compute unit; now ten)
 #define GZ_EXPAND_ROW 28                            // dwords of a slice's row in the staging area: 8 records x 3 + 4 (rows stay 16-byte aligned)
 #define GZ_EXPAND_LDS (GZ_EXPAND_TILE_BYTES + 64 * GZ_EXPAND_ROW * 4)
 // fault: 0, or (GZ_DEBUG_CHAIN_FAULT, tests only) 1 + the index of a slice that is treated as if it had missed the chain's checkpoint
@@ -1274,7 +1275,7 @@ __global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const Gzd
     const int lane = threadIdx.x;
     const uint8_t *rec = L.triples;
     uint32_t *av = (uint32_t *)L.rvals;
-    uint32_t *tile = (uint32_t *)gz_lds;                        // [64 slices][65]
+    uint32_t *tile = (uint32_t *)gz_lds;                        // [64 slices][33]
     const uint32_t slice = B.first_slice + lane, i0 = slice * GZ_LOW_SLICE;
     const bool mine = slice < ns;
     const uint32_t *ck = (const uint32_t *)L.ckpt + 2 * (size_t)(mine ? slice : 0);
@@ -1315,21 +1316,25 @@ __global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const Gzd
             for (uint32_t u = 0; u < 8; u++) if (j0 + u < m) {
                 uint32_t k;
                 const uint32_t r = d_chain_step (rlo, rhi, w[3 * u], w[3 * u + 1], d_record_freq (w[3 * u + 2]), &k);
-                tile[lane * 65 + j0 + u] = d_record_cum (w[3 * u]) * r;
+                tile[lane * 33 + ((j0 + u) & 31)] = d_record_cum (w[3 * u]) * r;
                 kw |= k << (2 * (h * 8 + u)); ksum += k;
             }
         }
         kb[q] = kw;
+        if (q & 1) {                                            // 32 symbols of every slice are in the tile: out with them, two slices (2 x 128 bytes) a store
+            gz_wave_sync ();
+            const uint32_t half = q >> 1, hs = (uint32_t)lane >> 5, hl = (uint32_t)lane & 31;
+            for (uint32_t s = 0; s < 64; s += 2) {
+                const uint32_t sl = B.first_slice + s + hs, i = sl * GZ_LOW_SLICE + half * 32 + hl;
+                if (sl < ns && i < n) av[i] = tile[(s + hs) * 33 + hl];
+            }
+            gz_wave_sync ();
+        }
     }
     if (mine) {
         if (m && (rlo != ck[2] || rhi != ck[3] || slice + 1 == fault)) L.overflow = 2;
         ((uint32_t *)L.kpos)[slice] = ksum;
         ((uint4 *)L.kbits)[slice] = make_uint4 (kb[0], kb[1], kb[2], kb[3]);
-    }
-    gz_wave_sync ();
-    for (uint32_t s = 0; s < 64; s++) {
-        const uint32_t i = (B.first_slice + s) * GZ_LOW_SLICE + lane;
-        if (B.first_slice + s < ns && i < n) av[i] = tile[s * 65 + lane];
     }
 }
 

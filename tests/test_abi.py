@@ -130,3 +130,14 @@ def test_order_golden_vectors_of_the_real_library(real_lib):
     the order the reference's own zip_compress_all_contexts_local / _b250 produced (tests/golden/order_golden.json, oracle/ref_order_shim.c)"""
     import parity
     assert parity.section_order_golden(parity.lib_section_order(real_lib)) == 360
+
+
+def test_c_multi_gpu_route_compiles_against_the_headers():
+    """tests/c/zip_fastq_rccl.c - the N-GPU route for a host written in C: gz_fastq_zip_seg / _merge / _finish / _collect with the merge blobs,
+    the votes and the finished z_data carried by RCCL's own C API (ncclAllGather, ncclSend / ncclRecv) - type-checks against
+    include/genozip_amd.h and <rccl/rccl.h>: the exchange format is the C-ABI's, the transport the host's"""
+    import subprocess
+    if not os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        pytest.skip("no RCCL headers here")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                    "-fsyntax-only", os.path.join(ROOT, "tests", "c", "zip_fastq_rccl.c")], check=True)

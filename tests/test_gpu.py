@@ -612,3 +612,13 @@ def test_rccl_sees_the_sharding_code():
     d = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["rccl"]["world"] == 1 and d["rccl"]["backend"] == "nccl", d.get("rccl")
     assert d["rccl"]["exchanges_per_step"] == 2 and d["rccl"]["exchange_bytes_per_step"] == 0 and d["rccl"]["bytes_gathered_per_step"] > 0, d["rccl"]
+
+
+def test_sam_and_vcf_drivers_at_size(gpu_engine, oracle):
+    """the SAM and VCF plans through the driver at sizes where the long-stream machinery works (position chunks, the persistent chain, streams
+    coded ahead on the background handle, multi-workgroup b250 generation): 2 x 60 000 alignment lines a call (9 MB of QUAL a VBlock), with
+    optional fields; 2 x 400 data lines x 2 000 samples (0.8 M entries a per-sample column) - each VBlock's z_data == the oracle's
+    composition. (The full-size configurations are compared with the same composition in every bench line: `file_exact`.)"""
+    assert parity.sam_zip(gpu_engine, oracle, 120000, n_calls=1, tags=True) == 2
+    assert parity.sam_zip(gpu_engine, oracle, 120000, n_calls=1, qual="uniform", aux=False) == 2
+    assert parity.vcf_zip(gpu_engine, oracle, 400, 2000, n_calls=1) == 2
