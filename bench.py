@@ -868,6 +868,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # the other BASELINE configurations, each a process of its own, BEFORE this process touches the device: a process that merely holds a HIP
+    # context (streams, hardware queues) beside them costs them 2 - 10 % (measured: the streamed leg 141 -> 155 ms behind the headline's process)
+    legs = None
+    if (world == 1 and not a.no_cpu and not a.stream_reads and a.qual == "div" and a.pairs == 1000000 and not a.vb_mb and "WORLD_SIZE" not in os.environ
+            and not os.environ.get("GZ_BENCH_NO_SIDE_LEGS") and not os.environ.get("GZ_BENCH_EMUL")):
+        legs = side_legs()
     # GZ_BENCH_EMUL=1 (tests/test_shard.py, no GPU): the same script on CPU ranks - the product's sources on the CPU stand-in of the HIP runtime
     # (tests/emul), torch tensors in host memory, the gloo backend. It exercises the N > 1 plumbing of this file, not a measurement.
     emul = bool(os.environ.get("GZ_BENCH_EMUL"))
@@ -1151,11 +1157,8 @@ def main():
         out["file_exact"] = file_exact_leg(wl, z_all)
         if out["file_exact"].get("checked"):
             out["bit_exact"] = bool(out["bit_exact"] and out["file_exact"]["identical"] == out["file_exact"]["vblocks"])
-        if not a.stream_reads and a.qual == "div" and a.pairs == 1000000 and not a.vb_mb and not os.environ.get("GZ_BENCH_NO_SIDE_LEGS"):
-            del wl                                                 # (the legs are processes of their own: give the device's memory back first)
-            E.close()
-            torch.cuda.empty_cache()
-            out["configs"] = side_legs()
+        if legs is not None:
+            out["configs"] = legs
     if dist is not None:
         try:
             import ctypes

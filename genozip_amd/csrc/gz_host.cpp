@@ -455,7 +455,7 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
             if (P.unpacked && !(L.srk = (uint8_t *)arena_alloc (h, (size_t)nb + 64))) return false;
             if (!(L.ctxoff = (uint32_t *)arena_alloc (h, (nt + 1) * nctx * 4))) return false;
             // one row per position chunk (no chunk is smaller than GZ_CHUNK_MIN - but for the first one, which goes in up to four pieces: a short leaf has few)
-            const size_t rows = std::min<size_t> (GZ_MAX_CHUNKS, (size_t)nb / GZ_CHUNK_MIN + 6);
+            const size_t rows = std::min<size_t> (GZ_MAX_CHUNKS, (size_t)nb / GZ_CHUNK_MIN + 8);
             if (!(L.ctxend = (uint32_t *)arena_alloc (h, rows * nctx * 4))) return false;
             P.any_arith_o1 = true;
             P.o1_list.push_back ((uint32_t)P.leaves.size ());
@@ -969,7 +969,7 @@ extern "C" int gz_codec_uncompress_batch (GzHandle *h, GzStream *streams, int n_
                 if (!(L.fc  = (uint32_t *)arena_alloc (h, 256 * 256 * 4))) return GZ_ERR_HIP;
                 if (!(L.tabtmp = (uint8_t *)arena_alloc (h, GZ_TAB_CAP))) return GZ_ERR_HIP;
             }
-            else if (!(L.models = (uint32_t *)arena_alloc (h, ((size_t)256 * GZ_DEC_ROW (256) + 258 * GZ_DEC_RUN_ROW) * 4))) return GZ_ERR_HIP;   // (models beyond the LDS classes live here)
+            else if (!(L.models = (uint32_t *)arena_alloc (h, ((size_t)256 * GZ_DEC_LIT_ROW (256) + 258 * GZ_DEC_RUN_ROW) * 4))) return GZ_ERR_HIP;   // (models beyond the LDS classes live here)
         }
     }
     void *d_streams, *d_leaves;

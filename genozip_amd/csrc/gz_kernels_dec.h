@@ -811,7 +811,7 @@ __global__ void __launch_bounds__(64) k_arith_decode (GzdDecLeaf *leaves, uint32
     // it, executed under exec masks with its variables in VGPRs: say that these are the same in every lane)
     const uint32_t n = gz_first_lane (L.coded_n);
     const uint32_t ms = gz_first_lane (L.body[0] ? L.body[0] : 256);
-    const uint32_t words = 2 + (L.o1 ? ms * GZ_DEC_LIT_ROW (ms) : 0) + (L.rle ? 258 * GZ_DEC_RUN_ROW : 0);
+    const uint32_t words = (L.o1 ? ms * GZ_DEC_LIT_ROW (ms) : 1) + (L.rle ? 258 * GZ_DEC_RUN_ROW : 0);      // (an order-0 model lives in registers: class 1)
     if (words <= lds_words_lo || words > lds_words_hi) return;
     if (use_global) d_arith_decode_planes<uint32_t *> (L, L.models, ms, n, (int)threadIdx.x);
     else d_arith_decode_planes<GzLdsU32P> (L, (GzLdsU32P)gz_lds, ms, n, (int)threadIdx.x);

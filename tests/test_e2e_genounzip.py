@@ -8,9 +8,11 @@ FASTQ segmenter's snips and containers) and N4 (SEC_TXT_HEADER, SEC_DICT, sectio
 itself reads all of them back into the original text. NONREF's payload (CODEC_ACGT's sub-codec, LZMA: host work outside the path,
 SURVEY F8) is made by the reference's vendored LZMA SDK compiled in place (oracle/_ref/liblzmaref.so).
 
-The decoder ends every run in this container with a segmentation fault AFTER the output is complete ("Done"): its exit path walks the
-System V shared memory segments of the machine (ref_cache_iterator, src/ref_cache.c:337-347) and the sandbox has a foreign one. The
-tests compare the output files; the exit code is not asserted.
+The decoder ends every run in this container with a segmentation fault AFTER the output is complete: its exit path walks the System V
+shared memory segments of the machine (ref_cache_iterator, src/ref_cache.c:337-347) and the sandbox has a foreign one (`ipcs -m`: key
+0xa3e3ccca, 56 bytes). The binary prints its own call stack when that happens - str_trim <- ref_cache_iterator <- main - and `_run`
+accepts exactly that: exit code 0, or a crash whose call stack names ref_cache_iterator under main and nothing of the reading path;
+anything else fails the test. The output files are compared in either case.
 """
 import ctypes as C
 import os
@@ -54,9 +56,19 @@ def lzma_sub():
     return compress
 
 
+def exit_is_clean_or_the_known_exit_path_crash(returncode, log):
+    """0, or the segmentation fault in the exit path's walk over the machine's shared memory segments (the call stack the binary prints)"""
+    if returncode == 0:
+        return True
+    stack = log[log.find("Call stack"):] if "Call stack" in log else ""
+    return "ref_cache_iterator" in stack and "main+" in stack and not any(w in stack for w in ("piz_", "zfile_", "reconstruct", "sections_", "dict_io", "ctx_"))
+
+
 def _run(exe, args, cwd):
     p = subprocess.run([exe] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
-    return p.stdout.decode(errors="replace")
+    log = p.stdout.decode(errors="replace")
+    assert exit_is_clean_or_the_known_exit_path_crash(p.returncode, log), (p.returncode, log[-2500:])
+    return log
 
 
 def _zip(E, plan, calls, lzma_sub):

@@ -36,7 +36,8 @@ import sys
 X_CKPT = int(os.environ.get("GZ_GEN_CKPT", "64"))            # a checkpoint every so many symbols (0: none - WRONG results, timing only)
 X_HOP = os.environ.get("GZ_GEN_HOP", "1") == "1"             # 0: no wait states and no DPP move at a lane's last symbol (WRONG results, timing only)
 X_PREP = os.environ.get("GZ_GEN_PREP", "1") == "1"           # 0: the operands are not made from the records (WRONG results)
-X_CKPT_FORM = os.environ.get("GZ_GEN_CKPT_FORM", "sstore")   # sstore: v_readlane x 2 + s_store_dwordx2; vsave: the lane that holds the state keeps it (DPP row mask), PER / 4 vector stores a block
+X_CKPT_FORM = os.environ.get("GZ_GEN_CKPT_FORM", "sstore")   # sstore: s_nop, v_readlane x 2, s_nop, s_store_dwordx2 per checkpoint (5 instructions); vsave: the lane that holds the
+                                                             # state keeps it - two v_cndmask under a one-lane mask -, the block's checkpoints leave in ONE vector store (2 + 1 / 12)
 
 PER = int(os.environ.get("GZ_GEN_PER", "12"))    # symbols a lane takes in a row
 BLOCK = 64 * PER
@@ -52,7 +53,10 @@ T, TLO = f"v[{_b + 8}:{_b + 9}]", f"v{_b + 8}"
 CKOFF = f"v{_b + 1}"                                                       # (vsave) where my saved state goes: my checkpoint's slot, or the dump
 FIXED_V = list(range(_b, _b + 10))
 FIRST = _b + 10
-NSAVE = (PER + 3) // 4 if X_CKPT_FORM == "vsave" else 0                    # (vsave) a row of 16 lanes holds at most so many of a block's checkpoints
+CK_LANES = [(64 * c) // PER for c in range(BLOCK // 64)]                   # checkpoint c = the state before symbol 64 c of a block: it sits in this lane when that lane starts its symbol 64 c % PER
+NSAVE = 1 if X_CKPT_FORM == "vsave" else 0                                 # (vsave) a lane holds at most one of a block's checkpoints: one pair
+assert X_CKPT_FORM != "vsave" or len(set(CK_LANES)) == len(CK_LANES), "two checkpoints of a block in one lane"
+CKM0 = 48                                                                  # (vsave) s[48 + 2 c : 49 + 2 c] = the mask of checkpoint c's lane; the pair behind them: all of them
 
 
 def regset(base):
@@ -70,7 +74,7 @@ SAVE = [(f"v[{SAVE0 + 2 * k}:{SAVE0 + 2 * k + 1}]", f"v{SAVE0 + 2 * k}", f"v{SAV
 LAST_V = SAVE0 + 2 * NSAVE - 1
 assert LAST_V <= 255, 'out of vector registers'
 CLOB_V = FIXED_V + list(range(FIRST, LAST_V + 1))
-CLOB_S = [36, 37, 40, 41, 42, 44, 45, 46, 47]
+CLOB_S = [36, 37, 40, 41, 42, 44, 45, 46, 47] + (list(range(CKM0, CKM0 + 2 * len(CK_LANES) + 2)) if X_CKPT_FORM == "vsave" else [])
 NEXT, CK, TMP = "s[40:41]", "s[44:45]", "s[46:47]"      # NEXT = the records of the next block
 DPP = "wave_ror:1 row_mask:0xf bank_mask:0xf"
 
@@ -88,18 +92,6 @@ def make_operands(a, s):
         a(f"v_lshlrev_b64 {s['F'][k]}, 32, {s['F'][k]}")
 
 
-# (vsave) the checkpoints of a block: checkpoint c = the state before symbol 64 c sits in lane 64 c // PER, when that lane starts its
-# symbol 64 c % PER. With PER = 12: lanes 0 5 10 16 21 26 32 37 42 48 53 58 - three per row of 16 lanes, so three save pairs, each
-# written under a DPP row mask (all lanes of the row write, only the diagonal lane's value means anything) and stored once a block by
-# the lanes that hold a checkpoint (the others store to a dump slot behind the leaf's checkpoints... their own offset says where).
-def ckpt_lanes():
-    out = []
-    for c in range(BLOCK // 64):
-        lane, k = divmod(64 * c, PER)
-        out.append((c, lane, k))
-    return out
-
-
 def block(a, cur, nxt, tag):
     """BLOCK symbols with the operand set `cur` (its loads were issued a block ago)"""
     a("s_waitcnt vmcnt(0)")                                  # my records (asked for a block ago)
@@ -110,15 +102,13 @@ def block(a, cur, nxt, tag):
     make_operands(a, cur)
     a("s_nop 1")
     a(f"v_mov_b32_dpp {cur['Fphi']}, {cur['Fhi'][PER - 1]} {DPP}")          # the F before mine: the last of the lane before
-    row_used = {}
     for j in range(BLOCK):
         lane, k = divmod(j, PER)
         if j % 64 == 0 and X_CKPT and j % X_CKPT == 0:       # the state before every 64th symbol goes out: it sits in lane j / PER
-            if X_CKPT_FORM == "vsave":
-                row = lane // 16
-                n = row_used.get(row, 0); row_used[row] = n + 1
-                a(f"v_mov_b32_dpp {SAVE[n][1]}, {RLO} quad_perm:[0,1,2,3] row_mask:0x{1 << row:x} bank_mask:0xf")
-                a(f"v_mov_b32_dpp {SAVE[n][2]}, {RHI} quad_perm:[0,1,2,3] row_mask:0x{1 << row:x} bank_mask:0xf")
+            if X_CKPT_FORM == "vsave":                       # every lane executes it, the mask keeps it to the lane that holds the state
+                c = j // 64
+                a(f"v_cndmask_b32 {SAVE[0][1]}, {SAVE[0][1]}, {RLO}, s[{CKM0 + 2 * c}:{CKM0 + 2 * c + 1}]")
+                a(f"v_cndmask_b32 {SAVE[0][2]}, {SAVE[0][2]}, {RHI}, s[{CKM0 + 2 * c}:{CKM0 + 2 * c + 1}]")
             else:
                 a("s_nop 0")
                 a(f"v_readlane_b32 s46, {RLO}, {lane}")
@@ -135,9 +125,11 @@ def block(a, cur, nxt, tag):
             a(f"v_mov_b32_dpp {T2LO}, {TLO} {DPP}")
             a(f"v_fma_f64 {R}, {T2}, {cur['Fp']}, -{cur['Fp']}")
         a(f"v_and_or_b32 {RHI}, {RHI}, {MASK}, {EXPO}")
-    if X_CKPT_FORM == "vsave" and X_CKPT:
-        for n in range(NSAVE):
-            a(f"global_store_dwordx2 {CKOFF}, {SAVE[n][0]}, {CK} offset:{8 * n * 16}")     # (the n-th checkpoint of my row: see the offsets' setup)
+    if X_CKPT_FORM == "vsave" and X_CKPT:                    # the block's checkpoints: one store by the lanes that hold one
+        n = len(CK_LANES)
+        a(f"s_mov_b64 exec, s[{CKM0 + 2 * n}:{CKM0 + 2 * n + 1}]")
+        a(f"global_store_dwordx2 {CKOFF}, {SAVE[0][0]}, {CK}")
+        a("s_mov_b64 exec, -1")
     a(f"s_add_u32 s44, s44, {8 * (BLOCK // 64)}")
     a("s_addc_u32 s45, s45, 0")
     a(f"s_add_u32 s40, s40, {REC * BLOCK}")
@@ -161,8 +153,17 @@ def body():
     a("s_mov_b32 s45, %[chi]")
     a(f"v_mbcnt_lo_u32_b32 {OFF}, -1, 0")
     a(f"v_mbcnt_hi_u32_b32 {OFF}, -1, {OFF}")
-    if X_CKPT_FORM == "vsave":
-        raise SystemExit("vsave: not built")
+    if X_CKPT_FORM == "vsave":                               # lane L's checkpoint, if it holds one, is number ceil (PER L / 64): its slot
+        a(f"v_mad_u32_u24 {CKOFF}, {PER}, {OFF}, 63")
+        a(f"v_lshrrev_b32 {CKOFF}, 6, {CKOFF}")
+        a(f"v_lshlrev_b32 {CKOFF}, 3, {CKOFF}")
+        allm = 0
+        for c, ln in enumerate(CK_LANES):
+            m = 1 << ln; allm |= m
+            a(f"s_mov_b32 s{CKM0 + 2 * c}, 0x{m & 0xffffffff:x}")
+            a(f"s_mov_b32 s{CKM0 + 2 * c + 1}, 0x{m >> 32:x}")
+        a(f"s_mov_b32 s{CKM0 + 2 * len(CK_LANES)}, 0x{allm & 0xffffffff:x}")
+        a(f"s_mov_b32 s{CKM0 + 2 * len(CK_LANES) + 1}, 0x{allm >> 32:x}")
     a(f"v_mul_u32_u24 {OFF}, {REC * PER}, {OFF}")
     a(f"v_mov_b32 {T2HI}, 0x3ff00000")                       # the high word of 1 + r * 2^-52
     a(f"v_mov_b32 {MASK}, 0x7fffff")
