@@ -67,6 +67,7 @@ struct GzdLeaf {
     uint8_t  o1, rle, packed_on, cat;
     uint8_t  prefix_len;
     uint8_t  shift_bits;      // rANS order-1: 10 or 12
+    uint8_t  tile_models;     // arith: the host allows k_arith_model_tiled for this leaf (the device decides by alphabet and order: d_leaf_tiled)
     uint8_t  prefix[GZ_PREFIX_CAP];    // flag [varint n] [pack meta] [varint packed n]
     const uint8_t *src;  uint32_t n;
     const uint8_t *coded; uint32_t coded_n;   // bytes the entropy coder sees (== packed or src)

@@ -73,6 +73,8 @@ struct GzHandle {
     uint32_t *d_fail = NULL;  // set by a kernel that gave up (the persistent chain when the models never report)
     GzHandle *emit_after = NULL;   // the next VBlock batch's section writer waits for this handle's queued work (gz_emit_after)
     hipEvent_t ev_other = NULL;
+    uint32_t tm_dbg = 0;
+    bool tile_models = false; // GZ_MODEL_TILED=1: the leaves of small alphabets through k_arith_model_tiled (one workgroup per leaf, records leave coalesced) - exact, less traffic, SLOWER: off
     bool no_pipeline = false; // GZ_NO_PIPELINE=1: no persistent kernel (needed under tools that serialise kernels, e.g. rocprofv3 --pmc)
     bool in_fallback = false; // gz_sync is running a batch again, unpipelined, after its persistent chain never heard from the models
     uint32_t chain_fallbacks = 0;           // how often that has happened on this handle (gz_chain_fallbacks)
@@ -209,10 +211,13 @@ static GzHandle *gz_create_do (int device, void *hip_stream, int *err, bool back
     }
     if (hipMalloc ((void **)&h->d_fail, 64) != hipSuccess || hipMemset (h->d_fail, 0, 64) != hipSuccess) { if (err) *err = GZ_ERR_HIP; gz_destroy (h); return NULL; }
     { const char *e = getenv ("GZ_NO_PIPELINE"); h->no_pipeline = e && *e && *e != '0'; }
+    { const char *e = getenv ("GZ_MODEL_TILED"); h->tile_models = e && *e && *e != '0'; }
+    { const char *e = getenv ("GZ_TM_DEBUG"); h->tm_dbg = e ? (uint32_t)atoi (e) : 0u; }
     { const char *e = getenv ("GZ_DEBUG_STARVE_CHAIN"); h->debug_starve_chain = e && *e && *e != '0'; }
     { const char *e = getenv ("GZ_DEBUG_CHAIN_FAULT"); h->debug_chain_fault = e ? (uint32_t)strtoul (e, NULL, 10) : 0; }   // (tests: a forced checkpoint mismatch must fail the stream)
     // the largest LDS class of the arithmetic coder needs more than the default 64 KB of dynamic LDS
     if (hipFuncSetAttribute ((const void *)k_arith_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
+        hipFuncSetAttribute ((const void *)k_arith_model_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
         hipFuncSetAttribute ((const void *)k_arith_decode, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
         if (err) *err = GZ_ERR_HIP;
         gz_destroy (h);
@@ -420,6 +425,7 @@ static bool add_leaf (GzHandle *h, Plan &P, uint32_t stream, int engine, int pla
     GzdLeaf L;
     memset (&L, 0, sizeof (L));
     L.stream = stream; L.plane = (uint8_t)plane; L.method = (uint8_t)method; L.engine = (uint8_t)engine;
+    L.tile_models = h->tile_models ? 1 : 0;
     const bool o1 = method & 1, pack = method & GZ_X_PACK;
     if (pack) { if (!(L.packed = (uint8_t *)arena_alloc (h, (size_t)n_bound + 16))) return false; }
     // rANS stops (-> CAT) once the payload exceeds the input; the arithmetic coder's scalar chain carries no capacity
@@ -731,6 +737,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 return GZ_OK;
             };
             if (!A.pipelined) {
+                if (h->tile_models) KLAUNCH (h, k_arith_model_tiled, dim3 (A.np), dim3 (64 * GZ_TM_WAVES), GZ_TM_LDS, d_leaves, A.d_plain, 0u, 0xffffffffu, h->tm_dbg);
                 if ((rc = sort_chunk (h->stream, A.d_plain, A.np, 0u, 0xffffffffu, P.max_arith_n, 0u)) != GZ_OK) return rc;
                 if (P.unpacked) KLAUNCH (h, k_arith_model<false>, GZ_XCD_DIM (A.np, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_plain, A.np, 0u, 0xffffffffu, 0u);
                 else            KLAUNCH (h, k_arith_model<true>,  GZ_XCD_DIM (A.np, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_plain, A.np, 0u, 0xffffffffu, 0u);
@@ -754,6 +761,8 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                     const uint32_t p0 = A.bounds[k], len = A.bounds[k + 1] - p0;
                     if (p0 >= P.max_arith_n) break;
                     const uint32_t span = P.max_arith_n - p0 < len ? P.max_arith_n - p0 : len;
+                    // (the leaves of small alphabets: sort, models and records of the chunk in one kernel, in front of the others' sort)
+                    if (h->tile_models) KLAUNCH_ON (h, h->stream4, k_arith_model_tiled, dim3 (A.nbig), dim3 (64 * GZ_TM_WAVES), GZ_TM_LDS, d_leaves, A.d_big, p0, len, h->tm_dbg);
                     if ((rc = sort_chunk (sort_stream, A.d_big, A.nbig, p0, len, span, k)) != GZ_OK) return rc;
                     HIPCHK (h, hipEventRecord (h->ev_sort[k], sort_stream));
                     HIPCHK (h, hipStreamWaitEvent (h->stream4, h->ev_sort[k], 0));
@@ -769,6 +778,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
                 //  stripe planes, "short" next to a 30 M-entry b250, started 2.8 s late, after the long chain had finished)
                 if (A.nsmall) {
                     HIPCHK (h, hipStreamWaitEvent (h->stream5, h->ev_model_fork, 0));
+                    if (h->tile_models) KLAUNCH_ON (h, h->stream5, k_arith_model_tiled, dim3 (A.nsmall), dim3 (64 * GZ_TM_WAVES), GZ_TM_LDS, d_leaves, A.d_small, 0u, 0xffffffffu, h->tm_dbg);
                     if ((rc = sort_chunk (h->stream5, A.d_small, A.nsmall, 0u, 0xffffffffu, A.chunk, 0u)) != GZ_OK) return rc;
                     if (P.unpacked) KLAUNCH_ON (h, h->stream5, k_arith_model<false>, GZ_XCD_DIM (A.nsmall, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_small, A.nsmall, 0u, 0xffffffffu, 0u);
                     else            KLAUNCH_ON (h, h->stream5, k_arith_model<true>,  GZ_XCD_DIM (A.nsmall, grid_y), dim3 (64), GZ_MODEL_LDS, d_leaves, A.d_small, A.nsmall, 0u, 0xffffffffu, 0u);

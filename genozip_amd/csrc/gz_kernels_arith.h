@@ -197,11 +197,13 @@ __device__ static __forceinline__ void d_model_serial_step (GzModel<J> &M, uint3
 #define GZ_CNT_OFF   (GZ_MLDS_OFF + GZ_MLDS_BYTES)
 #define GZ_CNT_BYTES (258 * 8 + 256 * 8)
 #define GZ_MODEL_LDS (GZ_CNT_OFF + GZ_CNT_BYTES)
+// (s_mask [2 + 64 J], s_low [64 J]: where - a one-wave workgroup's fixed place by default; the tiled kernel's waves have one each)
 template <int J>
 __device__ static __forceinline__ void d_batch_counts_lds (uint32_t p, uint64_t T, int lane, uint64_t below,
-                                                           uint32_t &eq, uint32_t &lt, uint32_t &eql, uint32_t (&ceq)[J], uint32_t (&clt)[J])
+                                                           uint32_t &eq, uint32_t &lt, uint32_t &eql, uint32_t (&ceq)[J], uint32_t (&clt)[J],
+                                                           unsigned long long *s_mask = (unsigned long long *)(gz_lds + GZ_CNT_OFF),
+                                                           unsigned long long *s_low = (unsigned long long *)(gz_lds + GZ_CNT_OFF) + 258)
 {
-    unsigned long long *s_mask = (unsigned long long *)(gz_lds + GZ_CNT_OFF), *s_low = s_mask + 258;
     #pragma unroll
     for (int j = 0; j < J; j++) s_mask[1 + j * 64 + lane] = 0;
     if (!lane) s_mask[0] = 0;
@@ -243,7 +245,9 @@ __device__ static __forceinline__ void d_batch_counts_lds (uint32_t p, uint64_t 
 // that one occurrence goes through d_model_serial_step, and the rest starts a new attempt.
 template <int J>
 __device__ static __forceinline__ void d_model_batch (GzModel<J> &M, uint32_t &tot, int lane, uint32_t cnt, uint32_t rk, uint32_t nsym,
-                                                      uint32_t n_absent, uint32_t &out_cum, uint32_t &out_freq, uint32_t &out_tot, uint32_t &n_events)
+                                                      uint32_t n_absent, uint32_t &out_cum, uint32_t &out_freq, uint32_t &out_tot, uint32_t &n_events,
+                                                      unsigned long long *s_mask = (unsigned long long *)(gz_lds + GZ_CNT_OFF),
+                                                      unsigned long long *s_low = (unsigned long long *)(gz_lds + GZ_CNT_OFF) + 258)
 {
     uint64_t todo = cnt >= 64 ? ~0ull : (1ull << cnt) - 1;
     const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0;
@@ -260,7 +264,7 @@ __device__ static __forceinline__ void d_model_batch (GzModel<J> &M, uint32_t &t
             // as an occurrence I count the earlier occurrences at my position / below it / at my left neighbour; as
             // list entries lane + 64 j I count what the whole batch adds to my frequency and cumulative
             uint32_t eq = 0, lt = 0, eql = 0, ceq[J], clt[J];
-            d_batch_counts_lds<J> (p, todo, lane, below, eq, lt, eql, ceq, clt);
+            d_batch_counts_lds<J> (p, todo, lane, below, eq, lt, eql, ceq, clt, s_mask, s_low);
             const uint32_t f = F + GZ_MODEL_STEP * eq, tj = tot + GZ_MODEL_STEP * gz_mbcnt (todo);
             uint32_t cu = Cm + GZ_MODEL_STEP * lt, fl = FL + GZ_MODEL_STEP * eql;
             // the first occurrence that would push the total over the limit ends the attempt
@@ -321,7 +325,7 @@ __device__ static __forceinline__ void d_model_batch (GzModel<J> &M, uint32_t &t
             }
             if (halve_m) {                                                  // commit the prefix only: recount it
                 uint32_t d0, d1, d2;
-                d_batch_counts_lds<J> (p, acc, lane, below, d0, d1, d2, ceq, clt);
+                d_batch_counts_lds<J> (p, acc, lane, below, d0, d1, d2, ceq, clt, s_mask, s_low);
             }
             if ((acc >> lane) & 1) { out_cum = cu; out_freq = f; out_tot = tj; }
             #pragma unroll
@@ -541,7 +545,12 @@ __device__ static __forceinline__ void d_model_batch_rounds (uint32_t &tot, int 
 #define GZ_XCD_GRID(li, by, n_list) const uint32_t li = blockIdx.x, by = blockIdx.y; if (li >= (n_list)) return
 #define GZ_XCD_DIM(n_list, Y) dim3 ((((uint32_t)(n_list) + 7u) / 8u) * 8u, (uint32_t)(Y))
 
-__device__ static inline bool d_ctx_sorted (const GzdLeaf &L) { return L.active && L.engine == GZ_ENG_ARITH && (L.o1 || L.rle) && L.arith_n; }
+// (order 1, at most 64 distinct bytes: k_arith_model_tiled sorts inside its tiles and runs every context of the leaf itself)
+__device__ static inline bool d_leaf_tiled (const GzdLeaf &L)
+{
+    return L.tile_models && L.active && L.engine == GZ_ENG_ARITH && L.o1 && !L.rle && L.nsym <= 64 && L.arith_n;
+}
+__device__ static inline bool d_ctx_sorted (const GzdLeaf &L) { return L.active && L.engine == GZ_ENG_ARITH && (L.o1 || L.rle) && L.arith_n && !d_leaf_tiled (L); }
 __device__ static inline uint32_t d_ctx_ntiles (uint32_t n) { return (n + GZ_CTX_TILE - 1) / GZ_CTX_TILE; }
 // context (model id) of coding event `pos`: the byte before it, or what k_rle_events wrote down
 __device__ static inline uint32_t d_ctx_of (const GzdLeaf &L, const uint8_t *in, const uint16_t *ev_ctx, uint32_t pos)
@@ -967,7 +976,7 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
 {
     GZ_XCD_GRID (li, by, n_list);
     GzdLeaf &L = leaves[list[li]];
-    if (!L.active || L.engine != GZ_ENG_ARITH || L.arith_n <= p0) return;
+    if (!L.active || L.engine != GZ_ENG_ARITH || L.arith_n <= p0 || d_leaf_tiled (L)) return;
     // (the blocks of the column that have no model to run - most of them, for a leaf of order 0 or with a small alphabet - leave before
     //  anything is made wave-uniform: the same tests as below)
     if (by >= GZ_MODEL_GRID_Y) { if (!L.rle) return; }
@@ -1061,6 +1070,244 @@ __global__ void __launch_bounds__(64) k_arith_model (GzdLeaf *leaves, const uint
         else               d_arith_model_wave<4, PK> (coded, ms_u, sorted, tr, L.symlist, L.symrank, nsym_u, spos, srk, j0, j1, p0 == 0, p1 < n_u, st);
         GZ_MODEL_T1 (ctx, j1 - j0);
     }
+}
+
+// ---- the models of a small alphabet, a TILE of positions at a time (GZ_MODEL_TILED=1; OFF by default: exact, a third less traffic, slower) ----
+// One wave per (leaf, context) stores the records of ITS occurrences: 12 bytes here, 12 bytes there, between the records of the other
+// contexts' waves, which pass the same lines hundreds of microseconds earlier or later - every such store leaves the L2 as a 32-byte
+// sector of its own (profiles/r05_pmc.json: 10.7 GB of WRITE_SIZE for 308 M records of 12 bytes), and the sort that groups the positions
+// by context in front of it moves another 3.3 GB. This kernel is the other way to cut the loop: for the leaves that carry nearly all
+// symbols of a FASTQ / BAM file - order 1, at most 64 distinct bytes: quality scores - ONE workgroup takes all contexts of a leaf through
+// the position chunk tile by tile, and nothing but the tile's input bytes and its finished records crosses the LDS boundary:
+//   1. the tile's bytes -> LDS; a stable counting sort by context inside the LDS (a wave per stretch of the tile, 64 positions at a
+//      time: rank among the lanes with the same context through 64-bit LDS masks, like d_batch_counts_lds; counts per wave and context,
+//      a scan, the scatter): per context the tile positions of its occurrences, in stream order;
+//   2. the contexts, busiest first, are dealt out to the waves back and forth: a wave takes a model's registers from the LDS (2 words
+//      per lane and context), runs the context's occurrences through d_model_batch 64 at a time as k_arith_model does, leaves (cum, freq,
+//      tot) of each in the tile's slot of its position, and puts the registers back;
+//   3. the tile's records leave in stream order, coalesced: the lane that stores a record makes it (d_model_record: the reciprocal).
+// The models' state stays in the LDS from tile to tile and travels through mstate from one position chunk's launch to the next.
+// MEASURED (round 5, profiles/r05b_tiled_*.txt; every output byte equal, tests/test_gpu.py::test_tiled_models_exact):
+//   * HBM traffic of the default step 39.2 -> 27.4 GB (k_arith_model 12.0 + k_ctx_scatter 3.3 -> 4.0: 12 bytes written and 1 read per symbol);
+//   * but ONE workgroup per leaf is 4 - 16 waves where the contexts' own waves are 34 spread over the device: with 4 waves and tiles of
+//     4096 a leaf's models advance at 12.7 ns per position (clocks per tile, alone on the device: load 9 600, sort 7 100, scan + scatter
+//     8 900, models 69 000 = 19 batches a wave at 3 600 - a context's few occurrences per tile make part-empty batches and every batch
+//     waits for its list entries -, waiting for the slowest wave 11 600, records out 3 200), and the range coder's chain wants a position
+//     every 6.3: default step 42.9 -> 76.6 ms, streamed 139 -> 226 ms. With 16 waves and tiles of 8192 (130 KB of LDS and every vector
+//     register of a compute unit: one workgroup per compute unit) a workgroup only ever starts on a compute unit that is completely
+//     empty, and beside the other streams' small workgroups that is rare: 358 ms per default step, 203 ms streamed.
+//   So the records stay scattered (k_arith_model), and this kernel stays in the library as the measured alternative.
+// (A first version dealt the contexts out through an LDS counter bumped by lane 0 of the free wave; the compiler built that loop around
+//  exec masks and the kernel never came back from the device - with GZ_TM_DEBUG's early exits compiled in it did: found by bisecting
+//  builds on the device. Inside the loop over contexts every statement is now executed by every lane.)
+// k_ctx_count / _scan / _scatter and k_arith_model leave such leaves alone when the handle asks for this kernel (d_leaf_tiled).
+#ifdef GZ_TM_NODBG
+#define GZ_TM_STOP(k) do { } while (0)
+#define GZ_TM_STOP_BREAK(k) do { } while (0)
+#else
+#define GZ_TM_STOP(k) do { if (dbg == (k)) return; } while (0)             // (GZ_TM_DEBUG: the kernel leaves after stage k - wrong results, for bisecting on the device)
+#define GZ_TM_STOP_BREAK(k) if (dbg == (k)) break
+#endif
+#ifdef GZ_TM_PROFILE                    // (probe builds: where a workgroup's clocks go, printed by workgroup 0 of a launch with >= 8 tiles)
+#define GZ_TM_T(k) do { const unsigned long long now_ = clock64 (); tmp_[k] += now_ - tmt_; tmt_ = now_; } while (0)
+#else
+#define GZ_TM_T(k) do { } while (0)
+#endif
+#ifndef GZ_TM_TILE
+#define GZ_TM_TILE   4096u
+#endif
+#ifndef GZ_TM_WAVES
+#define GZ_TM_WAVES  4
+#endif
+#define GZ_TM_SLOTS  65                     // context 0 + one per present symbol
+#define GZ_TM_PER    (GZ_TM_TILE / (64 * GZ_TM_WAVES))        // rounds of 64 positions per wave and tile
+#define GZ_TM_REC_CF 0                                          // uint32_t [TILE]: cum | freq << 16 of the position's symbol
+#define GZ_TM_REC_T  (GZ_TM_REC_CF + GZ_TM_TILE * 4)            // uint16_t [TILE]: the total it was coded with
+#define GZ_TM_IN     (GZ_TM_REC_T + GZ_TM_TILE * 2)             // uint8_t  [16 + TILE]: byte 15 + i = the stream's byte t0 + i - 1 (the context of position t0 + i)
+#define GZ_TM_LIST   (GZ_TM_IN + GZ_TM_TILE + 32)               // uint16_t [TILE]: tile positions grouped by context
+#define GZ_TM_STATE  (GZ_TM_LIST + GZ_TM_TILE * 2)              // uint32_t [SLOTS][2][64]: freq | cum << 16, sym | srank << 8 | where << 16 | gap << 24
+#define GZ_TM_TOT    (GZ_TM_STATE + GZ_TM_SLOTS * 512)          // uint32_t [SLOTS + 3] the models' totals
+#define GZ_TM_CNTW   (GZ_TM_TOT + 272)                          // uint32_t [WAVES][SLOTS + 3]: occurrences per wave and context, then their exclusive sum over the waves
+#define GZ_TM_TOTAL  (GZ_TM_CNTW + GZ_TM_WAVES * 272)           // uint32_t [SLOTS + 3] per context in the tile
+#define GZ_TM_START  (GZ_TM_TOTAL + 272)                        // uint32_t [SLOTS + 3] where its list starts
+#define GZ_TM_ORDER  (GZ_TM_START + 272)                        // uint8_t  [80] contexts, busiest first
+#define GZ_TM_MISC   (GZ_TM_ORDER + 80)                         // uint32_t [4]: the queue's counter, contexts with occurrences
+#define GZ_TM_SLOTOF (GZ_TM_MISC + 16)                          // uint8_t  [256] byte -> context slot
+#define GZ_TM_RANKOF (GZ_TM_SLOTOF + 256)                       // uint8_t  [256] byte -> rank in the leaf's alphabet
+#define GZ_TM_SCR    (GZ_TM_RANKOF + 256)                       // per wave: uint64_t [66] masks, [64] d_batch_counts_lds' s_low
+#define GZ_TM_SCR_BYTES 1088
+#define GZ_TM_LDS    (GZ_TM_SCR + GZ_TM_WAVES * GZ_TM_SCR_BYTES)
+// grid (listed leaves), 1024 threads, GZ_TM_LDS bytes of LDS; positions [p0, p0 + chunk) of every listed leaf that d_leaf_tiled
+__global__ void __launch_bounds__(64 * GZ_TM_WAVES) k_arith_model_tiled (GzdLeaf *leaves, const uint32_t *list, uint32_t p0, uint32_t chunk, uint32_t dbg)
+{
+    GzdLeaf &L = leaves[list[blockIdx.x]];
+    if (!d_leaf_tiled (L) || L.arith_n <= p0) return;
+    const uint32_t tid = threadIdx.x, wave = d_uniform (tid >> 6);
+    const int lane = (int)(tid & 63);
+    const uint32_t n = d_uniform (L.arith_n), ms = d_uniform (L.max_sym), nsym = d_uniform (L.nsym), n_absent = ms - nsym;
+    const uint32_t p1 = (n - p0 > chunk) ? p0 + chunk : n;
+    const uint8_t *in = d_uniform_ptr (L.coded);
+    GzRec *recs = d_uniform_ptr ((GzRec *)L.triples);
+    uint32_t *mstate = d_uniform_ptr (L.mstate);
+    uint32_t *rec_cf = (uint32_t *)(gz_lds + GZ_TM_REC_CF);
+    uint16_t *rec_t = (uint16_t *)(gz_lds + GZ_TM_REC_T), *lst = (uint16_t *)(gz_lds + GZ_TM_LIST);
+    uint8_t *tin = gz_lds + GZ_TM_IN + 15, *order = gz_lds + GZ_TM_ORDER, *slot_of = gz_lds + GZ_TM_SLOTOF, *rank_of = gz_lds + GZ_TM_RANKOF;
+    uint32_t *state = (uint32_t *)(gz_lds + GZ_TM_STATE), *s_tot = (uint32_t *)(gz_lds + GZ_TM_TOT), *cntw = (uint32_t *)(gz_lds + GZ_TM_CNTW);
+    uint32_t *total = (uint32_t *)(gz_lds + GZ_TM_TOTAL), *start = (uint32_t *)(gz_lds + GZ_TM_START), *misc = (uint32_t *)(gz_lds + GZ_TM_MISC);
+    unsigned long long *scr = (unsigned long long *)(gz_lds + GZ_TM_SCR + wave * GZ_TM_SCR_BYTES);
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0;
+
+    // ---- once per launch: the byte -> context slot / rank tables, the models' state (fresh, or as the previous chunk's launch left it)
+    for (uint32_t b = tid; b < 256; b += 64 * GZ_TM_WAVES) {
+        const uint32_t rk = L.symrank[b];
+        rank_of[b] = (uint8_t)rk;
+        slot_of[b] = (uint8_t)((b && rk != 0xffffu) ? rk + 1 : 0u);              // (byte 0 is slot 0's whether it occurs or not; a byte that never occurs is never a context)
+    }
+    for (uint32_t c = wave; c < GZ_TM_SLOTS; c += GZ_TM_WAVES) {
+        uint32_t x, y, t;
+        if (p0 == 0) {                                                  // d_arith_model_wave_'s `first`: every symbol once, the absent entries as gaps
+            const uint32_t e = (uint32_t)lane;
+            const bool live = e < nsym;
+            const uint32_t sym = live ? L.symlist[e] : 0xffu, prev = (live && e) ? L.symlist[e - 1] : 0u;
+            const uint32_t gap = live ? (e ? sym - prev - 1 : sym) : 0u;
+            x = live ? (1u | (sym << 16)) : (ms << 16);
+            y = sym | (e << 8) | (e << 16) | (gap << 24);
+            t = ms;
+        }
+        else {
+            const uint32_t *g = mstate + (size_t)c * (GZ_MSTATE_WORDS * 64);
+            x = g[lane]; y = g[64 + lane]; t = d_uniform (g[128]);
+        }
+        state[c * 128 + lane] = x; state[c * 128 + 64 + lane] = y;
+        s_tot[c] = t;
+    }
+    __syncthreads ();
+    GZ_TM_STOP (1);
+
+#ifdef GZ_TM_PROFILE
+    unsigned long long tmp_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tmt_ = clock64 (), tm_batches = 0, tm_ctx = 0;
+#endif
+    for (uint32_t t0 = p0; t0 < p1; t0 += GZ_TM_TILE) {
+        const uint32_t nt = p1 - t0 < GZ_TM_TILE ? p1 - t0 : GZ_TM_TILE;
+        GZ_TM_T (7);
+        // ---- 1. the tile's bytes; per wave: no occurrences yet, no mask set
+        #pragma unroll
+        for (uint32_t r = 0; r < GZ_TM_TILE / (64 * GZ_TM_WAVES); r++) {
+            const uint32_t i = r * (64 * GZ_TM_WAVES) + tid;
+            if (i < nt) tin[1 + i] = (uint8_t)gz_ldg_u8 (in + t0 + i);
+        }
+        if (!tid) tin[0] = t0 ? (uint8_t)gz_ldg_u8 (in + t0 - 1) : 0;
+        for (uint32_t c = (uint32_t)lane; c < GZ_TM_SLOTS + 3; c += 64) cntw[wave * (GZ_TM_SLOTS + 3) + c] = 0;
+        scr[lane] = 0; if (lane < 2) scr[64 + lane] = 0;
+        __syncthreads ();
+        GZ_TM_T (0);
+        // ---- the sort: this wave's 512 positions, 64 at a time - where each one goes inside its (wave, context) run
+        uint32_t co[GZ_TM_PER];                                         // context slot | place inside the wave's run of it << 8
+        #pragma unroll
+        for (uint32_t r = 0; r < GZ_TM_PER; r++) {
+            const uint32_t i = wave * (64 * GZ_TM_PER) + r * 64 + (uint32_t)lane;
+            const bool valid = i < nt;
+            const uint32_t c = valid ? slot_of[tin[i]] : GZ_TM_SLOTS;            // (the byte before position t0 + i; beyond the tile: a slot of nobody's)
+            if (valid) atomicOr (&scr[c], 1ull << lane);
+            gz_wave_sync ();
+            const unsigned long long mm = scr[c];
+            const uint32_t old = cntw[wave * (GZ_TM_SLOTS + 3) + c];
+            gz_wave_sync ();
+            if (valid && (mm >> lane) == 1ull) { cntw[wave * (GZ_TM_SLOTS + 3) + c] = old + (uint32_t)__popcll (mm); scr[c] = 0; }   // (the context's last lane of this round)
+            gz_wave_sync ();
+            co[r] = c | ((old + (uint32_t)__popcll (mm & below)) << 8);
+        }
+        __syncthreads ();
+        GZ_TM_T (1);
+        GZ_TM_STOP (2);
+        if (tid < GZ_TM_SLOTS) {                                        // per context: the waves' counts -> where each wave's run starts inside the context's list
+            uint32_t run = 0;
+            for (uint32_t w = 0; w < GZ_TM_WAVES; w++) { const uint32_t v = cntw[w * (GZ_TM_SLOTS + 3) + tid]; cntw[w * (GZ_TM_SLOTS + 3) + tid] = run; run += v; }
+            total[tid] = run;
+        }
+        __syncthreads ();
+        if (!wave) {                                                    // where the contexts' lists start; the contexts by occurrences, most first
+            const uint32_t v = total[lane], v64 = total[64];
+            const uint32_t inc = d_wave_incl_scan (v, lane);
+            start[lane] = inc - v;
+            if (lane == 63) start[64] = inc;
+            uint32_t rank = 0, rank64 = 0;
+            for (uint32_t k = 0; k < GZ_TM_SLOTS; k++) {
+                const uint32_t tk = total[k];
+                rank   += (tk > v   || (tk == v   && k < (uint32_t)lane)) ? 1u : 0u;
+                rank64 += (tk > v64 || (tk == v64 && k < 64u)) ? 1u : 0u;
+            }
+            order[rank] = (uint8_t)lane;
+            if (!lane) order[rank64] = 64;
+            const uint64_t live = __ballot (v != 0);
+            if (!lane) misc[1] = (uint32_t)__popcll (live) + (v64 ? 1u : 0u);
+        }
+        __syncthreads ();
+        GZ_TM_STOP (3);
+        #pragma unroll
+        for (uint32_t r = 0; r < GZ_TM_PER; r++) {
+            const uint32_t i = wave * (64 * GZ_TM_PER) + r * 64 + (uint32_t)lane;
+            const uint32_t c = co[r] & 0xffu;
+            if (i < nt) lst[start[c] + cntw[wave * (GZ_TM_SLOTS + 3) + c] + (co[r] >> 8)] = (uint16_t)i;
+        }
+        __syncthreads ();
+        GZ_TM_STOP (4);
+        GZ_TM_T (2);
+        // ---- 2. the models: the contexts, busiest first, are dealt out to the waves back and forth (wave 0 .. 15, 15 .. 0, 0 .. 15 ...): the
+        // busiest sixteen start at once and the small ones fill up behind them. (Everything in this loop is wave-uniform and every lane takes
+        // part in every statement - no "lane 0 only" inside it: a counter in the LDS that the free wave's lane 0 bumped made the compiler build
+        // the loop around exec masks, and that build never came back from the device.)
+        const uint32_t n_live = d_uniform (misc[1]);
+        for (uint32_t turn = 0; turn * GZ_TM_WAVES < n_live; turn++) {
+            const uint32_t k = turn * GZ_TM_WAVES + ((turn & 1) ? GZ_TM_WAVES - 1 - wave : wave);
+            if (k >= n_live) break;
+            const uint32_t c = d_uniform (order[k]), nc = d_uniform (total[c]), s0 = d_uniform (start[c]);
+            GzModel<1> M;
+            { const uint32_t x = state[c * 128 + lane], y = state[c * 128 + 64 + lane];
+              M.freq[0] = x & 0xffffu; M.cum[0] = x >> 16; M.sym[0] = y & 0xffu; M.srank[0] = (y >> 8) & 0xffu; M.where[0] = (y >> 16) & 0xffu; M.gap[0] = y >> 24; }
+            uint32_t tot = d_uniform (s_tot[c]);
+            for (uint32_t j = 0; j < nc; j += 64) {
+                const uint32_t cnt = nc - j < 64 ? nc - j : 64;
+                const bool occ = (uint32_t)lane < cnt;
+                const uint32_t pos = lst[s0 + j + (occ ? (uint32_t)lane : 0u)];
+                const uint32_t rk = occ ? rank_of[tin[1 + pos]] : 0u;
+                uint32_t out_cum = 0, out_freq = 0, out_tot = 0, n_ev = 0;
+                d_model_batch<1> (M, tot, lane, cnt, rk, nsym, n_absent, out_cum, out_freq, out_tot, n_ev, scr, scr + 66);
+                if (occ) { rec_cf[pos] = out_cum | (out_freq << 16); rec_t[pos] = (uint16_t)out_tot; }
+            }
+            state[c * 128 + lane] = (M.freq[0] & 0xffffu) | (M.cum[0] << 16);
+            state[c * 128 + 64 + lane] = (M.sym[0] & 0xffu) | ((M.srank[0] & 0xffu) << 8) | ((M.where[0] & 0xffu) << 16) | (M.gap[0] << 24);
+            s_tot[c] = d_uniform (tot);                                 // (every lane the same word)
+#ifdef GZ_TM_PROFILE
+            tm_batches += (nc + 63) / 64; tm_ctx++;
+#endif
+            GZ_TM_STOP_BREAK (5);
+        }
+        GZ_TM_T (3);
+        __syncthreads ();
+        GZ_TM_T (4);
+        GZ_TM_STOP (6);
+        // ---- 3. the tile's records, in stream order
+        #pragma unroll
+        for (uint32_t r = 0; r < GZ_TM_TILE / (64 * GZ_TM_WAVES); r++) {
+            const uint32_t i = r * (64 * GZ_TM_WAVES) + tid;
+            if (i < nt) { const uint32_t cf = rec_cf[i]; d_record_store (recs + t0 + i, d_model_record (cf & 0xffffu, cf >> 16, rec_t[i])); }
+        }
+        __syncthreads ();
+        GZ_TM_T (5);
+    }
+#ifdef GZ_TM_PROFILE
+    if (!blockIdx.x && !lane && p1 - p0 >= 8 * GZ_TM_TILE)
+        printf ("[tm] wave %u: %u tiles; clocks per tile: load %llu  sort rounds %llu  scan + scatter %llu  models %llu (%llu contexts, %llu batches per tile)  wait for the others %llu  records out %llu  loop %llu\n", wave,
+                (p1 - p0) / GZ_TM_TILE, tmp_[0] / ((p1 - p0) / GZ_TM_TILE), tmp_[1] / ((p1 - p0) / GZ_TM_TILE), tmp_[2] / ((p1 - p0) / GZ_TM_TILE), tmp_[3] / ((p1 - p0) / GZ_TM_TILE),
+                tm_ctx / ((p1 - p0) / GZ_TM_TILE), tm_batches / ((p1 - p0) / GZ_TM_TILE), tmp_[4] / ((p1 - p0) / GZ_TM_TILE), tmp_[5] / ((p1 - p0) / GZ_TM_TILE), tmp_[7] / ((p1 - p0) / GZ_TM_TILE));
+#endif
+    if (p1 < n)                                                         // the next position chunk's launch goes on from here
+        for (uint32_t c = wave; c < GZ_TM_SLOTS; c += GZ_TM_WAVES) {
+            uint32_t *g = mstate + (size_t)c * (GZ_MSTATE_WORDS * 64);
+            g[lane] = state[c * 128 + lane]; g[64 + lane] = state[c * 128 + 64 + lane];
+            if (!lane) g[128] = s_tot[c];
+        }
 }
 
 // ---- range coder chain ------------------------------------------------------------------------------------------

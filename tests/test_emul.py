@@ -304,3 +304,21 @@ def test_emul_e2e_files_sha256(emul_engine):
     if not os.path.exists(os.path.join(e2e_files.ROOT, "oracle", "_ref", "liblzmaref.so")) and not os.path.isdir("/root/reference/src"):
         pytest.skip("oracle/_ref/liblzmaref.so is not built and the reference's sources are not here")
     assert e2e_files.check_against_golden(emul_engine, ["fastq_pair_monochar", "fastq_single_domq_monochar", "vcf"]) == 3
+
+
+def test_emul_tiled_models(emul_engine, oracle, monkeypatch):
+    """GZ_MODEL_TILED=1 (opt-in): k_arith_model_tiled - a workgroup per leaf, contexts sorted inside LDS tiles, records out in
+    stream order - gives the oracle's bytes: one piece, position chunks (the models' state through mstate), byte 0 as a symbol, a tile's end
+    inside a stream, 64 symbols, and a wide alphabet beside them (the other kernels' leaf)"""
+    from hostmem import HostMem
+    from genozip_amd.codec import Engine
+    from genozip_amd import synth
+    monkeypatch.setenv("GZ_MODEL_TILED", "1")
+    E = Engine(lib_path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "emul", "libgenozip_amd_emul.so"), mem=HostMem())   # (emul_engine has built it)
+    monkeypatch.delenv("GZ_MODEL_TILED")
+    items = [(16, synth.markov_bytes(3, 160000, 40, 33).tobytes()), (16, synth.markov_bytes(5, 100, 10, 60).tobytes()), (16, synth.markov_bytes(6, 9000, 64, 0).tobytes()),
+             (17, synth.quality_diverse(4, 60).tobytes()), (18, synth.quality_binned(5, 40).tobytes()), (16, bytes(5000)), (16, synth.uniform_bytes(8, 20000, 200).tobytes())]
+    got = E.compress_many(items)
+    for (c, d), g in zip(items, got):
+        assert g == oracle.codec_compress(c, d), (c, len(d))
+    E.close()

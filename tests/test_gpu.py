@@ -587,6 +587,25 @@ def test_chain_timeout_falls_back(oracle, monkeypatch):
     E.close()
 
 
+def test_tiled_models_exact(oracle, monkeypatch):
+    """GZ_MODEL_TILED=1 (an experiment of round 5 that is exact and moves a third less through HBM, but slower - DESIGN section 3 - and therefore
+    off): order-1 leaves of at most 64 distinct bytes go through k_arith_model_tiled - one workgroup per leaf, the sort inside LDS tiles, the
+    records out coalesced - instead of k_ctx_* + k_arith_model. Same bytes: single streams in one piece and in position chunks behind the
+    persistent chain, every arithmetic codec, and a whole FASTQ call"""
+    from genozip_amd.codec import Engine
+    monkeypatch.setenv("GZ_MODEL_TILED", "1")
+    E = Engine(device=0)
+    monkeypatch.delenv("GZ_MODEL_TILED")
+    items = [(16, synth.quality_diverse(3, 30000).tobytes()), (16, synth.markov_bytes(3, 70000, 40, 33).tobytes()), (16, synth.markov_bytes(5, 100, 10, 60).tobytes()),
+             (17, synth.quality_diverse(4, 4000).tobytes()), (18, synth.quality_binned(5, 6000).tobytes()), (19, synth.markov_bytes(6, 300000, 64, 0).tobytes()),
+             (16, bytes(70000)), (16, synth.uniform_bytes(8, 100000, 200).tobytes())]        # (the last one: a wide alphabet - the other kernels' leaf)
+    got = E.compress_many(items)
+    for (c, d), g in zip(items, got):
+        assert g == oracle.codec_compress(c, d), (c, len(d))
+    parity.fastq_zip(E, oracle, 2500, n_calls=2)
+    E.close()
+
+
 def test_rccl_sees_the_sharding_code():
     """the N-GPU path on the ONE GPU of the test box, over RCCL: (1) genozip_amd/shard.py's exchanges on HBM tensors in an nccl group of one
     rank (all_gather of byte strings, the gather to the writer rank with a loop-back ncclSend / ncclRecv pair); (2) `bench.py --gpus 1
