@@ -119,6 +119,13 @@ __device__ static inline uint4 gz_ldg_u32x4 (const void *p)
 }
 __device__ static inline void gz_stg_u8 (uint8_t *p, uint32_t v) { *(__attribute__((address_space(1))) uint8_t *)(uintptr_t)p = (uint8_t)v; }
 __device__ static inline void gz_stg_u32 (uint32_t *p, uint32_t v) { *(__attribute__((address_space(1))) uint32_t *)(uintptr_t)p = v; }
+__device__ static inline void gz_stg_rec (void *p, uint32_t a, uint32_t b, uint32_t c)     // 12 bytes, 4-byte aligned, through a GLOBAL pointer (global_store_dwordx3)
+{
+    typedef uint32_t gz_v3 __attribute__((ext_vector_type(3)));
+    typedef gz_v3 __attribute__((aligned(4))) gz_v3_a4;
+    const gz_v3 v = { a, b, c };
+    *(__attribute__((address_space(1))) gz_v3_a4 *)(uintptr_t)p = v;
+}
 __device__ static inline void gz_stg_u16 (uint8_t *p, uint32_t v)     // 2 bytes, any alignment, through a GLOBAL pointer
 {
     typedef uint16_t __attribute__((aligned(1))) gz_u16_unaligned;

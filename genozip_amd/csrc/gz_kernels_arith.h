@@ -62,7 +62,9 @@ __device__ static __forceinline__ GzRec d_model_record (uint32_t cum, uint32_t f
 __device__ static inline uint32_t d_record_cum (uint32_t lo) { return lo & 0xffffu; }
 __device__ static inline uint32_t d_record_freq (uint32_t f) { return ((f & 0xfffffu) | 0x100000u) >> (20u - ((f >> 20) - GZ_REC_F_EXP)); }
 
-__device__ static __forceinline__ void d_record_store (GzRec *at, GzRec v) { *at = v; }
+// (through a GLOBAL pointer, like the loads of gz_intrin.h: a store through a generic pointer is a FLAT one, which is also counted as an LDS operation
+//  - the wait for the next batch's LDS reads then waits for the scattered store of the last one to be accepted as well)
+__device__ static __forceinline__ void d_record_store (GzRec *at, GzRec v) { gz_stg_rec (at, v.lo, v.hi, v.f); }
 
 // (tests) the reciprocal a record of total tot0 + thread would carry
 __global__ void k_debug_record_inv (uint32_t tot0, uint32_t n, uint32_t *out)
@@ -648,8 +650,8 @@ __global__ void __launch_bounds__(64) k_ctx_scatter (GzdLeaf *leaves, const uint
             // (one scattered 4-byte store per position instead of a 4- and a 1-byte one: a leaf of fewer than 2^24 positions - srk == NULL -
             //  keeps the symbol's rank in the low byte of its entry)
             const uint32_t rk = ev_sym ? (s & 0xff) : rank_of[s];
-            if (srk) { spos[base + within] = pos; srk[base + within] = (uint8_t)rk; }
-            else spos[base + within] = (pos << 8) | rk;
+            if (srk) { gz_stg_u32 (spos + base + within, pos); gz_stg_u8 (srk + base + within, rk); }
+            else gz_stg_u32 (spos + base + within, (pos << 8) | rk);
             atomicAdd (&cnt[c], 1u);
         }
         __syncthreads ();                                  // (one wave: the next group's gather sees this group's counts)
@@ -1573,7 +1575,7 @@ __global__ void __launch_bounds__(64) k_chain_expand (GzdLeaf *leaves, const Gzd
             const uint32_t half = q >> 1, hs = (uint32_t)lane >> 5, hl = (uint32_t)lane & 31;
             for (uint32_t s = 0; s < 64; s += 2) {
                 const uint32_t sl = B.first_slice + s + hs, i = sl * GZ_LOW_SLICE + half * 32 + hl;
-                if (sl < ns && i < n) av[i] = tile[(s + hs) * 33 + hl];
+                if (sl < ns && i < n) gz_stg_u32 (av + i, tile[(s + hs) * 33 + hl]);
             }
             gz_wave_sync ();
         }
@@ -1676,10 +1678,10 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_scatter (GzdLeaf *leaves, con
         carry_in = 0;
         if (on) {
             const uint32_t base = (uint32_t)__shfl ((int)kp_all, (int)q) + 1;     // output byte of this slice's first shift
-            for (uint32_t j = lane; j < own; j += 64) dig[base + j] = acc[j];
+            for (uint32_t j = lane; j < own; j += 64) gz_stg_u32 (dig + base + j, acc[j]);      // (global, not flat: see d_record_store)
             if (lane < 4) {
                 const uint32_t left = last ? 0u : acc[own + lane];
-                if (q == GZ_LOW_RUN - 1) resid[(slice / GZ_LOW_RUN) * 4 + lane] = left; else carry_in = left;
+                if (q == GZ_LOW_RUN - 1) gz_stg_u32 (resid + (slice / GZ_LOW_RUN) * 4 + lane, left); else carry_in = left;
             }
         }
         gz_wave_sync ();

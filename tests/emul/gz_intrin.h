@@ -31,6 +31,7 @@ static inline uint4 gz_ldg_u32x4 (const void *p) { return *(const uint4 *)p; }
 static inline void gz_stg_u8 (uint8_t *p, uint32_t v) { *p = (uint8_t)v; }
 static inline void gz_stg_u32 (uint32_t *p, uint32_t v) { *p = v; }
 static inline void gz_stg_u16 (uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
+static inline void gz_stg_rec (void *p, uint32_t a, uint32_t b, uint32_t c) { uint32_t *q = (uint32_t *)p; q[0] = a; q[1] = b; q[2] = c; }
 static inline uint32_t gz_wave_shr1 (uint32_t x, uint32_t fill)
 {
     const int lane = (int)(emu.cur % 64);
