@@ -1636,7 +1636,6 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_scatter (GzdLeaf *leaves, con
     const uint32_t *kpos = (const uint32_t *)L.kpos;
     uint32_t *dig = (uint32_t *)L.events;
     uint32_t *acc = (uint32_t *)gz_lds + wave * 144;          // up to 128 own digits + 5 closing / 4 spilling
-    const uint64_t below = (1ull << lane) - 1;
     uint32_t *resid = (uint32_t *)L.resid;
     // What a slice adds beyond the digits it owns (up to 4) belongs to the following slices' digits. A wave walks GZ_LOW_RUN consecutive
     // slices, so it carries them into its next slice's accumulator itself (lanes 0..3 hold them); only what the last slice of a run leaves
@@ -1662,11 +1661,15 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_scatter (GzdLeaf *leaves, con
         const bool on = slice < ns;
         const uint32_t a = a_all[q], k = (k_all[q] >> (2 * (lane & 15))) & 3u;
         const uint64_t m1 = __ballot (k >= 1), m2 = __ballot (k == 2);
-        const uint32_t P = (uint32_t)__popcll (m1 & below) + (uint32_t)__popcll (m2 & below);   // shifts before me in the slice
+        const uint32_t P = gz_mbcnt (m1) + gz_mbcnt (m2);     // shifts before me in the slice (the masks are scalars: v_mbcnt, no 64-bit and)
         const uint32_t K = (uint32_t)__popcll (m1) + (uint32_t)__popcll (m2);
         const bool last = on && slice == ns - 1;
         const uint32_t own = last ? K + 5 : K;                 // digits this slice owns: one per shift (+ the closing 5)
-        for (uint32_t j = lane; j < 144; j += 64) acc[j] = j < 4 ? carry_in : 0u;
+        // (this kernel runs at the device's vector issue rate - profiles/r05b_sq_*.txt -: only the words this slice can touch are cleared - its own
+        //  digits and the four behind them; a quality stream's slice has ~25 shifts, one store instead of three)
+        acc[lane] = lane < 4 ? carry_in : 0u;
+        if (own + 4 > 64)  acc[64 + lane] = 0u;
+        if (own + 4 > 128 && lane < 16) acc[128 + lane] = 0u;
         gz_wave_sync ();
         if (on && a) {
             atomicAdd (&acc[P],     a >> 24);
@@ -1677,7 +1680,7 @@ __global__ void __launch_bounds__(GZ_LOW_WG) k_low_scatter (GzdLeaf *leaves, con
         gz_wave_sync ();
         carry_in = 0;
         if (on) {
-            const uint32_t base = (uint32_t)__shfl ((int)kp_all, (int)q) + 1;     // output byte of this slice's first shift
+            const uint32_t base = d_readlane (kp_all, (int)q) + 1;               // output byte of this slice's first shift (q is a constant of the unrolled loop: v_readlane, no trip to the LDS)
             for (uint32_t j = lane; j < own; j += 64) gz_stg_u32 (dig + base + j, acc[j]);      // (global, not flat: see d_record_store)
             if (lane < 4) {
                 const uint32_t left = last ? 0u : acc[own + lane];
