@@ -1369,7 +1369,9 @@ __device__ static inline uint32_t d_chain_step (uint32_t &rlo, uint32_t &rhi, ui
 // number of position chunks whose records are complete (written by k_arith_progress, which the host queues behind every
 // model launch). Records are only ever read after their chunk was announced, and never before by this kernel (the
 // block requested ahead stays inside the announced chunks), so no stale copy of them can sit in a cache on the way.
+#ifndef GZ_CHAIN_WAVES                   // (-DGZ_CHAIN_WAVES=1 / 2: a leaf or two per workgroup - measured, round 5: 42.7 - 42.9 ms per default step with 1, 2 or 4)
 #define GZ_CHAIN_WAVES 4
+#endif
 #define GZ_CHAIN_LDS   (156 * 1024)
 
 __global__ void k_arith_progress (uint32_t *progress, uint32_t chunks_done) { *progress = chunks_done; }
