@@ -62,6 +62,51 @@ def test_chain_loop_header_is_what_its_generator_writes(tmp_path):
     assert out.read_text() == open(os.path.join(ROOT, "genozip_amd", "csrc", "gz_chain_asm.h")).read()
 
 
+def test_chain_loop_instructions_are_aligned(tmp_path):
+    """Round 6 (tools/probes/chain_regs_probe.py): on gfx950 an 8-byte instruction whose address is not a multiple of 8 costs a clock more,
+    and the chain's loop is made of 8-byte instructions. The generator keeps 4-byte instructions in pairs behind a .p2align 3: assemble
+    the committed loop (one word behind an 8-byte boundary, as an inline-asm statement may start) and look at every instruction's address;
+    its own idea of the encodings' sizes is held against the assembler's on the way."""
+    import re
+    import shutil
+    import subprocess
+    import sys
+    mc, dump = "/opt/rocm/lib/llvm/bin/llvm-mc", "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(mc) and os.path.exists(dump)):
+        mc, dump = shutil.which("llvm-mc"), shutil.which("llvm-objdump")
+    if not (mc and dump):
+        pytest.skip("no llvm-mc / llvm-objdump")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_chain_asm
+    src = open(os.path.join(ROOT, "genozip_amd", "csrc", "gz_chain_asm.h")).read()
+    lines = re.findall(r'^\s+"(.*)\\n\\t" \\$', src, re.M)
+    assert len(lines) > 2000
+    for k, v in {"%[rlo]": "v0", "%[rhi]": "v1", "%[blo]": "s0", "%[bhi]": "s1", "%[nblk]": "s2", "%[clo]": "s3", "%[chi]": "s4"}.items():
+        lines = [ln.replace(k, v) for ln in lines]
+    s, o = tmp_path / "chain.s", tmp_path / "chain.o"
+    s.write_text(".text\n.p2align 8\nchain:\n s_nop 0\n" + "\n".join(lines) + "\n")
+    subprocess.run([mc, "-triple=amdgcn-amd-amdhsa", "-mcpu=gfx950", "-filetype=obj", str(s), "-o", str(o)], check=True)
+    dis = subprocess.run([dump, "-d", str(o)], check=True, capture_output=True, text=True).stdout
+    ins = [ln for ln in lines if not ln.endswith(":") and not ln.startswith(".")]
+    got = []
+    for ln in dis.splitlines():
+        m = re.match(r"\s+(\S+).*//\s*([0-9A-F]+):((?: [0-9A-F]{8})+)\s*(<.*>)?\s*$", ln)
+        if m:
+            got.append((m.group(1), int(m.group(2), 16), 4 * len(m.group(3).split())))
+    body = [g for g in got if g[1] >= 4]                      # (behind the word put in front)
+    pads = len(body) - len(ins)                               # what .p2align put in
+    assert 0 <= pads <= 8
+    assert [g for g in body if g[2] == 8 and g[1] % 8] == []
+    i = 0
+    for mnem, addr, n in body:                                # the generator's size() against the assembler, instruction by instruction
+        if i < len(ins) and ins[i].split()[0].replace("_e64", "").replace("_e32", "").startswith(mnem.replace("_e64", "").replace("_e32", "").replace("_dpp", "")):
+            assert gen_chain_asm.size(ins[i]) == n, (ins[i], n)
+            i += 1
+        else:
+            assert mnem == "s_nop", (mnem, ins[i] if i < len(ins) else None)
+    assert i == len(ins)
+
+
 def test_no_cpu_fallback(real_lib):
     import torch
     if torch.cuda.is_available():
