@@ -1023,8 +1023,8 @@ class Engine:
 
     def vb_uncompress_many(self, items, max_sections=4096, download=True):
         """items: [(z bytes or a device buffer of self.mem with its length, total_uncompressed)] -> per VBlock the list of decoded section
-        payloads (download=False: (device buffer, offsets) per VBlock). One gz_vb_uncompress_many call: every section of every VBlock in
-        one batch."""
+        payloads, None for a section the device leaves to the host's coders (download=False: (device buffer, offsets, [decoded? per section])
+        per VBlock - a host coder's stretch is zeros on the device). One gz_vb_uncompress_many call: every section of every VBlock in one batch."""
         n = len(items)
         zbs, obs = [], []
         zp, zl, op, oc = (C.c_void_p * max(1, n))(), (C.c_uint64 * max(1, n))(), (C.c_void_p * max(1, n))(), (C.c_uint64 * max(1, n))()
@@ -1044,7 +1044,7 @@ class Engine:
             o = [offs[i * (max_sections + 1) + k] for k in range(ns[i] + 1)]
             M = (1 << 63) - 1                        # (GZ_SECTION_NOT_DECODED: a host coder's section - zeros on the device, None here)
             if not download:
-                res.append((obs[i], [x & M for x in o]))
+                res.append((obs[i], [x & M for x in o], [not (x >> 63) for x in o[:-1]]))
                 continue
             raw = self.mem.download(obs[i], total)
             res.append([None if o[k] >> 63 else raw[o[k] & M:o[k + 1] & M] for k in range(ns[i])])

@@ -41,6 +41,7 @@ struct Pending {          // results to hand back at gz_sync()
     void *dev_streams;    // GzdStream* / GzdDecStream*
     void *dev_vbs;        // GzdVB*
     size_t n_dev_streams;
+    struct GzHandle *emit_after = NULL;   // (kind 2) the handle whose queued work this batch's section writer waited for: a replay waits for it again
 };
 
 struct ArenaBlock { uint8_t *base; size_t size, used; };
@@ -72,7 +73,9 @@ struct GzHandle {
     int chain_wgs_held = 0, chain_cus_held = 0;   // this handle's share of g_chain_wgs / g_chain_cus, returned at gz_sync
     uint32_t *d_fail = NULL;  // set by a kernel that gave up (the persistent chain when the models never report)
     GzHandle *emit_after = NULL;   // the next VBlock batch's section writer waits for this handle's queued work (gz_emit_after)
+    GzHandle *emit_after_used = NULL;   // what the batch being queued right now has consumed of it
     hipEvent_t ev_other = NULL;
+    std::string warn;         // gz_last_warning: a call that succeeded has something to say (the chain fallback)
     uint32_t tm_dbg = 0;
     bool tile_models = false; // GZ_MODEL_TILED=1: the leaves of small alphabets through k_arith_model_tiled (one workgroup per leaf, records leave coalesced) - exact, less traffic, SLOWER: off
     bool no_pipeline = false; // GZ_NO_PIPELINE=1: no persistent kernel (needed under tools that serialise kernels, e.g. rocprofv3 --pmc)
@@ -364,6 +367,7 @@ extern "C" void *gz_dev_alloc (GzHandle *h, uint64_t n)
 extern "C" void gz_dev_free (GzHandle *h, void *p) { if (h && p && hipSetDevice (h->device) == hipSuccess) (void)hipFree (p); }
 
 extern "C" const char *gz_last_error (GzHandle *h) { return h ? h->err.c_str () : "no handle"; }
+extern "C" const char *gz_last_warning (GzHandle *h) { return h ? h->warn.c_str () : ""; }
 extern "C" void *gz_stream (GzHandle *h) { return h ? (void *)h->stream : NULL; }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -571,7 +575,7 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
     if (!A.np) return GZ_OK;
     // position chunks: at most 32 per leaf (4 MB VBlocks - 8: 38.0 ms, 12: 37.7, 16: 37.6), none smaller than GZ_CHUNK_MIN, whole sort tiles
     uint32_t want_chunks = 32;                                  // (16 -> 32: the first chunk's models are the lead-in of the long streams; default step 96.2 -> 95.1 ms, streamed 280.8 -> 277.1)
-    if (const char *e = getenv ("GZ_ARITH_CHUNKS")) { const int v = atoi (e); if (v >= 1 && v <= GZ_MAX_CHUNKS - 1) want_chunks = (uint32_t)v; }   // (experiments)
+    if (const char *e = getenv ("GZ_ARITH_CHUNKS")) { const int v = atoi (e); if (v >= 1) want_chunks = (uint32_t)std::min (v, GZ_MAX_CHUNKS - 1 - 6); }   // (experiments; the first- / last-chunk splits below add up to 3 bounds each: n_chunks stays within GZ_MAX_CHUNKS - ev_sort[], the ctxend rows)
     // (whole sort tiles AND whole blocks of the chain's loop: what a chunk leaves over goes one symbol at a time, d_chain_slow - with blocks
     //  of 768 symbols and chunks of whole tiles only, 256 symbols of every chunk did)
     uint32_t unit = GZ_CTX_TILE;
@@ -828,6 +832,7 @@ static int launch_encode (GzHandle *h, Plan &P, GzdStream *d_streams, GzdLeaf *d
         if (!h->ev_other) HIPCHK (h, hipEventCreateWithFlags (&h->ev_other, hipEventDisableTiming));
         HIPCHK (h, hipEventRecord (h->ev_other, h->emit_after->stream));
         HIPCHK (h, hipStreamWaitEvent (h->stream, h->ev_other, 0));
+        h->emit_after_used = h->emit_after;          // (one-shot for the caller; the batch's Pending record keeps it for a replay)
         h->emit_after = NULL;
     }
     KLAUNCH (h, k_select, dim3 ((ns + 255) / 256), dim3 (256), 0, d_streams, d_leaves, ns);
@@ -941,6 +946,7 @@ extern "C" int gz_vb_compress_batch (GzHandle *h, GzVBlock *vbs, int n_vbs)
                          sizeof (GzdLeaf), std::chrono::duration<double, std::milli> (tm1 - tm0).count (), std::chrono::duration<double, std::milli> (tm2 - tm1).count (),
                          std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - tm2).count ());
     Pending pd; pd.kind = 2; pd.user = vbs; pd.n = n_vbs; pd.dev_streams = d_streams; pd.dev_vbs = d_vbs; pd.n_dev_streams = P.streams.size ();
+    pd.emit_after = h->emit_after_used; h->emit_after_used = NULL;
     h->pending.push_back (pd);
     return GZ_OK;
 }
@@ -1128,14 +1134,14 @@ static int gz_sync_do (GzHandle *h)
         int rc2 = GZ_OK;
         for (auto &pd : again) {
             if (pd.kind == 0) rc2 = gz_codec_compress_batch (h, (GzStream *)pd.user, pd.n);
-            else if (pd.kind == 2) rc2 = gz_vb_compress_batch (h, (GzVBlock *)pd.user, pd.n);
+            else if (pd.kind == 2) { h->emit_after = pd.emit_after; rc2 = gz_vb_compress_batch (h, (GzVBlock *)pd.user, pd.n); }   // (the writer waits for the other handle again)
             if (rc2 < 0) break;                                           // (kind 1, decoding, has no chain: its results above stand)
         }
         if (rc2 >= 0) rc2 = gz_sync_do (h); else (void)gz_sync_do (h);
         h->in_fallback = false;
         h->chain_fallbacks++;
-        if (rc2 >= 0) h->err = "warning: the arithmetic coder's persistent chain kernel never heard from the model kernels (kernels serialised by a tool? "
-                               "too few hardware queues?); the batch was run again unpipelined (GZ_NO_PIPELINE=1 selects that order from the start)";
+        if (rc2 >= 0) h->warn = "warning: the arithmetic coder's persistent chain kernel never heard from the model kernels (kernels serialised by a tool? "
+                                "too few hardware queues?); the batch was run again unpipelined (GZ_NO_PIPELINE=1 selects that order from the start)";
         return rc2;
     }
     if (device_failed) {
@@ -1927,14 +1933,16 @@ extern "C" int gz_vb_uncompress_many (GzHandle *h, int n_vbs, const uint8_t *con
                 s.in = z_data[v] + sec.at; s.in_len = sec.clen; s.out = out[v] + o; s.out_cap = sec.ulen; s.codec = sc;
                 work.push_back (s);
             }
-            else if (sec.ulen && (sc == GZ_CODEC_BZ2 || sc == GZ_CODEC_LZMA || sc == GZ_CODEC_BSC)) {
-                // a host coder's section (sequential LZ / BWT coders stay on the host) is left to the caller's own uncompress: its
-                // stretch of `out` is zeroed and its offset carries GZ_SECTION_NOT_DECODED
+            else if (sec.ulen && sc > 0 && sc < GZ_NUM_CODECS) {
+                // a codec of the file format the device has no decoder for - the host's sequential coders (BZ2 / LZMA / BSC: SURVEY 2.1), a complex
+                // codec with an uncompress of its own (CODEC_ACGT: this library's own NONREF section, codec_acgt_uncompress runs the LZMA sub-codec
+                // and then unpacks - src/codec.h:108, compressor.c:210-236), anything else of src/genozip.h:326-360 - is left to the caller's
+                // codec_args[codec].uncompress: its stretch of `out` is zeroed and its offset carries GZ_SECTION_NOT_DECODED
                 if (o + sec.ulen > out_cap[v]) { h->err = "output too small"; return GZ_ERR_CORRUPT; }
                 HIPCHK (h, hipMemsetAsync (out[v] + o, 0, sec.ulen, h->stream));
                 if (offs) offs[i] |= GZ_SECTION_NOT_DECODED;
             }
-            else if (sec.ulen) { h->err = "section with an unknown codec"; return GZ_ERR_CORRUPT; }
+            else if (sec.ulen) { h->err = "section with a codec byte the file format does not have"; return GZ_ERR_CORRUPT; }
             o += sec.ulen;
         }
         if (offs) offs[W[v].n_sections] = o;

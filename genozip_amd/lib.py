@@ -165,7 +165,7 @@ class GzHostCodecs(C.Structure):
 
 
 ABI_SYMBOLS = (
-    "gz_create", "gz_create_background", "gz_destroy", "gz_sync", "gz_last_error", "gz_version", "gz_stream", "gz_profile", "gz_profile_get", "gz_profile_get_max",
+    "gz_create", "gz_create_background", "gz_destroy", "gz_sync", "gz_last_error", "gz_last_warning", "gz_version", "gz_stream", "gz_profile", "gz_profile_get", "gz_profile_get_max",
     "gz_download", "gz_upload", "gz_dev_alloc", "gz_dev_free", "gz_emit_after", "gz_wait_for",
     "gz_codec_est_size", "gz_codec_compress_host", "gz_codec_uncompress_host",
     "gz_codec_compress_batch", "gz_codec_uncompress_batch", "gz_codec_assign_best",
@@ -208,6 +208,8 @@ def load(path=None):
     L.gz_sync.argtypes = [C.c_void_p]
     L.gz_last_error.restype = C.c_char_p
     L.gz_last_error.argtypes = [C.c_void_p]
+    L.gz_last_warning.restype = C.c_char_p
+    L.gz_last_warning.argtypes = [C.c_void_p]
     L.gz_version.restype = C.c_char_p
     L.gz_stream.restype = C.c_void_p
     L.gz_chain_fallbacks.argtypes = [C.c_void_p]

@@ -72,8 +72,15 @@ int  gz_profile_get_max (GzHandle *h, int idx, double *max_ms);
 void     *gz_stream (GzHandle *h);
 /* How often gz_sync ran a batch a second time, unpipelined, because the arithmetic coder's persistent chain kernel never heard from the
  * model kernels it follows (kernels serialised by a profiling tool, too few hardware queues, another tenant). The results are those of the
- * second run - the reference's COMPRESS contract: false only for "too small" (src/compressor.c:89-110) -, gz_last_error holds a warning. */
+ * second run - the reference's COMPRESS contract: false only for "too small" (src/compressor.c:89-110). The return code is that of the second
+ * run and gz_last_error is left alone; gz_last_warning says what happened (a string that stays until the next fallback).
+ * CONTRACT for the asynchronous batch calls (gz_codec_compress_batch, gz_vb_compress_batch): the second run reads the caller's tables and INPUT
+ * buffers again, so everything a queued batch reads must stay as it was until the gz_sync that hands its results out has returned - not
+ * overwritten, not freed, not overlapping any of the batch's outputs (the host-pointer forms and the VBlock compute driver keep to this by
+ * themselves: staging buffers / the per-file workspace). A gz_emit_after in front of a VBlock batch is remembered with the batch: the second
+ * run's section writer waits for the other handle again. */
 uint32_t gz_chain_fallbacks (GzHandle *h);
+const char *gz_last_warning (GzHandle *h);
 /* (tests) The reciprocal the arithmetic coder's model kernel puts into a symbol's record for the model totals tot0 .. tot0 + n - 1 (a double
  * with 16 zero low bits, two words each into out_dev): RC_Encode's range / tot (c_range_coder.h:100) is exact with it as long as it lies in
  * [2^-45 / tot, 2^-45 / tot * (1 + 2^-33)] - tests/test_magic.py shows that for the interval, tests/test_gpu.py::test_record_reciprocals that
@@ -275,10 +282,13 @@ int gz_vb_uncompress (GzHandle *h, const uint8_t *z_data, uint64_t z_len, uint8_
  * src/compressor.c:196-246, here for a whole batch): the section headers of every VBlock are walked and every payload's adler32 is
  * checked by two kernels, then ALL payloads of ALL VBlocks are decoded as one batch (gz_codec_uncompress_batch) - a wave per stream,
  * hundreds of streams at a time. z_data[v] / out[v]: device; section_offsets_host: n_vbs rows of max_sections + 1 entries (or NULL);
- * n_sections_out: n_vbs entries. A section coded by one of the host's coders (BZ2 / LZMA / BSC: gz_zip_set_host_codecs) is checked but not
+ * n_sections_out: n_vbs entries. A section whose codec the device has no decoder for - one of the host's coders (BZ2 / LZMA / BSC:
+ * gz_zip_set_host_codecs), CODEC_ACGT (this library's own NONREF section: gz_vb_insert_section, codec = ACGT, sub_codec = LZMA - the reference's
+ * codec_acgt_uncompress runs the sub-codec and unpacks), any other codec of src/genozip.h:326-360 - is checked (magic, adler32) but not
  * decoded: its stretch of out[v] is zeroed and its entry of section_offsets_host carries GZ_SECTION_NOT_DECODED on top of the offset - the
- * caller's own codec_args[codec].uncompress fills it. Any other codec byte the device has no decoder for: GZ_ERR_CORRUPT. Synchronous. */
+ * caller's own codec_args[codec].uncompress fills it. A codec byte the format does not have (0, >= GZ_NUM_CODECS): GZ_ERR_CORRUPT. Synchronous. */
 #define GZ_SECTION_NOT_DECODED (1ull << 63)
+#define GZ_NUM_CODECS 42            /* NUM_CODECS, src/genozip.h:360 */
 int gz_vb_uncompress_many (GzHandle *h, int n_vbs, const uint8_t *const *z_data, const uint64_t *z_len, uint8_t *const *out,
                            const uint64_t *out_cap, uint64_t *section_offsets_host, uint32_t max_sections, uint32_t *n_sections_out);
 

@@ -1133,6 +1133,17 @@ def fastq_zip(E, oracle, n_reads, n_calls=2, qual=("uniform", "uniform"), domq=0
                 total += int.from_bytes(z[at + 16:at + 20], "big"); at += 40 + int.from_bytes(z[at + 12:at + 16], "big")
             secs = E.vb_uncompress(z, total)
             assert len(secs) == g["n_sections"] or True
+            # ... and of the COMPLETE VBlock, the host-made NONREF section (codec ACGT, sub-codec LZMA: gz_vb_insert_section) spliced in where it
+            # belongs: the device's decoder leaves that one section to the host (None here; codec_acgt_uncompress, src/codec.h:108) and decodes
+            # the others as before (it used to call the ACGT byte corrupt)
+            if g["n_bases"] and v == 0:
+                fake = bytes(range(7, 7 + 61))                     # (any payload: the section is checked, not decoded, by the device)
+                z2 = F.insert_section(z, g["seq_section_index"], fq.dict_id("NONREF"), 10, 4, 0 if g["seq_has_x"] else 0x40, 11, 0, fake, g["n_bases"])
+                secs2 = E.vb_uncompress(z2, total + g["n_bases"])
+                k = g["seq_section_index"]
+                assert len(secs2) == len(secs) + 1 and secs2[k] is None and secs2[:k] == secs[:k] and secs2[k + 1:] == secs[k:], (call, v, k)
+                (buf, offs, decoded), = E.vb_uncompress_many([(z2, total + g["n_bases"])], download=False)
+                assert decoded == [i != k for i in range(len(secs2))] and offs[k + 1] - offs[k] == g["n_bases"]
     # the dictionaries the file ends up with: tiles in order of first appearance
     tiles = F.zctx_words(3)
     assert tiles and tiles == zstate["z"][3].words()
