@@ -33,6 +33,14 @@ Round 6 - what the loop paid for beyond its three instructions, measured (tools/
     the scalar stores of the checkpoints all go THERE instead of s_nop; a hop costs 12 clocks in all (1.0 a symbol at 12 a lane).
   * the next block's operand shifts happen late in the current block (its loads were issued in the first hops and are waited for in
     hop 40: long there); nothing is left at a block's head.
+  * A HOP INSIDE A ROW OF 16 LANES IS THE SECOND FMA ITSELF: gfx950 has one double-precision instruction with a DPP operand,
+    `v_fmac_f64_dpp D, S0, S1 row_newbcast:n` (D = S0 * S1 + D, S0 read from lane n of the reader's row). Lane L + 1 holds "the F before
+    mine" (Fp) and its negative (NFp); `v_mov_b64 R, NFp` - one of the two wait states the DPP read of T needs anyway - then
+    `v_fmac_f64_dpp R, T, Fp row_newbcast:(L % 16)` is R = T(lane L) * Fp - Fp in lane L + 1: the move of r and the second fma in one
+    instruction, 8 clocks a hop instead of 12. The four hops of a block that cross into the next row (and the wave's wrap-around) keep
+    the old form (v_mov_b32_dpp wave_ror:1, then the fma). 13.35 -> 13.07 clocks a symbol alone, default step 39.7 -> 38.7 ms
+    (profiles/r06_ubench_chain_fused.txt, r06_ab_chain_fused.txt; 8 / 10 / 16 symbols a lane: 13.45 / - / 12.85 alone, no better in the
+    step - the 52 KB of the 16-symbol loop do not stay in the instruction cache beside the other kernels: 43.5 ms).
 
 Everything between the labels is written here, loop control included: the compiler schedules nothing in it. The rest of a leaf that
 does not fill a block is the caller's.
@@ -44,6 +52,7 @@ import sys
 # (experiments only: the product's header is made with none of these set)
 X_CKPT = int(os.environ.get("GZ_GEN_CKPT", "64"))            # a checkpoint every so many symbols (0: none - WRONG results, timing only)
 X_FILL = os.environ.get("GZ_GEN_FILL", "1") == "1"           # 0: the hops' wait states are s_nop, loads and shifts at the head of a block (aligned all the same)
+X_FUSE = os.environ.get("GZ_GEN_FUSE", "1") == "1"           # 1: a hop inside a row of 16 lanes is the second fma itself (v_fmac_f64_dpp row_newbcast), 0: every hop moves r first
 X_ALIGN = os.environ.get("GZ_GEN_ALIGN", "1") == "1"         # 0: no .p2align, a single s_nop 1 in the hops (round 5's parity flips: for A / B)
 
 PER = int(os.environ.get("GZ_GEN_PER", "12"))    # symbols a lane takes in a row
@@ -67,10 +76,11 @@ def regset(base):
     tail = base + 4 * PER
     return dict(rec=[f"v[{b}:{b + 2}]" for b in sym], inv=[f"v[{b}:{b + 1}]" for b in sym],
                 F=[f"v[{b + 2}:{b + 3}]" for b in sym], Flo=[f"v{b + 2}" for b in sym], Fhi=[f"v{b + 3}" for b in sym],
-                Fp=f"v[{tail}:{tail + 1}]", Fplo=f"v{tail}", Fphi=f"v{tail + 1}", first=base, last=tail + 1)
+                Fp=f"v[{tail}:{tail + 1}]", Fplo=f"v{tail}", Fphi=f"v{tail + 1}",
+                NFp=f"v[{tail + 2}:{tail + 3}]", NFplo=f"v{tail + 2}", NFphi=f"v{tail + 3}", first=base, last=tail + 3)
 
 
-SETS = [regset(FIRST), regset(FIRST + 4 * PER + 2)]
+SETS = [regset(FIRST), regset(FIRST + 4 * PER + 4)]
 LAST_V = SETS[1]['last']
 assert LAST_V <= 255, 'out of vector registers'
 CLOB_V = FIXED_V + list(range(FIRST, LAST_V + 1))
@@ -80,14 +90,14 @@ DPP = "wave_ror:1 row_mask:0xf bank_mask:0xf"
 NOP2 = ["s_nop 0", "s_nop 0"]                           # two wait states in eight bytes
 
 _INLINE_F = {"0.5", "-0.5", "1.0", "-1.0", "2.0", "-2.0", "4.0", "-4.0"}
-_FOUR = ("s_nop", "s_waitcnt", "s_cbranch", "s_cmp", "s_mov_b32", "s_add_u32", "s_addc_u32", "s_sub_u32", "s_cselect_b32", "v_mov_b32", "v_mul_u32_u24")
+_FOUR = ("s_nop", "s_waitcnt", "s_cbranch", "s_cmp", "s_mov_b32", "s_add_u32", "s_addc_u32", "s_sub_u32", "s_cselect_b32", "v_mov_b32", "v_mul_u32_u24", "v_xor_b32", "v_mov_b64")
 _EIGHT = ("v_fma_f64", "v_and_or_b32", "v_lshlrev_b64", "global_load", "global_store", "s_store", "v_readlane_b32", "v_mbcnt")
 
 
 def size(ins):
     """bytes of the encoding (gfx9: VOP3 / DPP / memory = 8; SOP / VOP1 / VOP2 = 4, + 4 with a literal constant) - tests/test_abi.py holds this against the assembler"""
     m = ins.split()[0]
-    if m.endswith("_dpp") or m.startswith(_EIGHT):
+    if m.endswith("_dpp") or m.endswith("_e64") or m.startswith(_EIGHT):
         return 8
     assert m.startswith(_FOUR), ins
     n = 4
@@ -145,6 +155,10 @@ def fp_mov(s):
     return f"v_mov_b32_dpp {s['Fphi']}, {s['Fhi'][PER - 1]} {DPP}"          # the F before mine: the last of the lane before
 
 
+def nfp_make(s):
+    return f"v_xor_b32 {s['NFphi']}, 0x80000000, {s['Fphi']}"               # ... and its negative, the addend a fused hop starts from
+
+
 def hop_fillers(cur, nxt):
     """what stands in the wait states of each of a block's 64 hops: the next block's loads, its operand shifts, the checkpoints' stores"""
     H = [[] for _ in range(64)]
@@ -160,18 +174,25 @@ def hop_fillers(cur, nxt):
         hf = h + 1 + (PER + 1) // 2 + 1
         assert hf < 64
         H[hf].append(fp_mov(nxt))
+        if X_FUSE:
+            H[hf + 1].append(nfp_make(nxt))
     if X_CKPT:
         for c in range(BLOCK // 64):
             if (64 * c) % X_CKPT == 0:
                 H[(64 * c) // PER].append(f"s_store_dwordx2 {TMP}, {CK}, 0x{8 * c:x}")        # what the two v_readlane in front of symbol 64 c have read
     for h in range(64):
+        if X_FUSE and (h + 1) % 16:                          # a hop inside a row: R = -Fp (one of the two wait states), then the fused second fma
+            H[h].insert(0, f"v_mov_b64 {R}, {cur['NFp']}")
         if not X_ALIGN:
             H[h] = ["s_nop 1"] if not H[h] else H[h] + ([] if len(H[h]) >= 2 else ["s_nop 0"])
             continue
-        if len(H[h]) < 2:
-            H[h] += NOP2
-        if sum(size(i) == 4 for i in H[h]) % 2:
+        while len(H[h]) < 2:
             H[h].append("s_nop 0")
+        if sum(size(i) == 4 for i in H[h]) % 2:              # 4-byte instructions in pairs: the move in its 8-byte encoding, or one more s_nop
+            if H[h][0].startswith("v_mov_b64 "):
+                H[h][0] = H[h][0].replace("v_mov_b64 ", "v_mov_b64_e64 ")
+            else:
+                H[h].append("s_nop 0")
     return H
 
 
@@ -186,6 +207,8 @@ def block(a, cur, nxt, tag):
         a("s_nop 0")
         a("s_nop 0")
         a(fp_mov(cur))
+        if X_FUSE:
+            a(nfp_make(cur))
     H = hop_fillers(cur, nxt)
     for j in range(BLOCK):
         lane, k = divmod(j, PER)
@@ -198,8 +221,11 @@ def block(a, cur, nxt, tag):
         else:                                                # the next lane's first symbol (lane 0: the next block's)
             for ins in H[lane]:
                 a(ins)
-            a(f"v_mov_b32_dpp {T2LO}, {TLO} {DPP}")
-            a(f"v_fma_f64 {R}, {T2}, {cur['Fp']}, -{cur['Fp']}")
+            if X_FUSE and (lane + 1) % 16:                   # lane + 1 reads T from lane `lane` of its row and multiplies by its own "F before mine": R = T * Fp + (-Fp)
+                a(f"v_fmac_f64_dpp {R}, {T}, {cur['Fp']} row_newbcast:{lane % 16} row_mask:0xf bank_mask:0xf")
+            else:
+                a(f"v_mov_b32_dpp {T2LO}, {TLO} {DPP}")
+                a(f"v_fma_f64 {R}, {T2}, {cur['Fp']}, -{cur['Fp']}")
         a(f"v_and_or_b32 {RHI}, {RHI}, {MASK}, {EXPO}")
     a(f"s_add_u32 s44, s44, {8 * (BLOCK // 64)}")
     a("s_addc_u32 s45, s45, 0")
@@ -235,6 +261,7 @@ def body():
     a(f"v_mov_b32 {EXPO}, 0x41000000")
     for s in SETS:
         a(f"v_mov_b32 {s['Fplo']}, 0")                       # the low word of the F before mine: 0, never written again
+        a(f"v_mov_b32 {s['NFplo']}, 0")                      # (and of its negative)
     a("s_nop 4")
     loads(a, SETS[0], "s[36:37]")                            # the first block's records
     if X_FILL:
@@ -243,6 +270,8 @@ def body():
             a(ins)
         a("s_nop 1")
         a(fp_mov(SETS[0]))
+        if X_FUSE:
+            a(nfp_make(SETS[0]))
     a.label("3")
     block(a, SETS[0], SETS[1], "0")
     a("s_cmp_eq_u32 s42, 0")
