@@ -37,7 +37,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")    # (genozip_amd/lib.py: must b
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CHAIN_FLOOR_NS = 6.3            # k_arith_chain's loop alone on the device: 15.1 clocks per symbol at 2.4 GHz (profiles/r05_ubench_chain_rec12.txt; 6.6 with the 16-byte records of round 4)
+CHAIN_FLOOR_NS = 5.03           # three dependent vector instructions per symbol at the one-instruction-per-4-clocks issue rate of a wave: 12.07 clocks at 2.4 GHz - what no
+                                # arrangement of this formulation can beat (tools/probes/chain_regs_probe.py: `p_pad0`, profiles/r06_chain_regs_probe_aligned.txt)
+CHAIN_ALONE_NS = 5.46           # k_arith_chain's loop as it is, alone on the device: 13.07 clocks per symbol (profiles/r06_ubench_chain_fused.txt; round 5: 6.3, round 4: 6.6)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 METRIC = "input MB/s compressed (bit-exact .genozip) at 1/2/4/8 GPUs vs CPU ref"
 
@@ -411,9 +413,9 @@ def gpu_over_cpu(out, cb):
 
 def pmc_traffic(kernel, a):
     """HBM bytes per STEP of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r05_pmc.json, made by tools/summarize_prof.py: counter collection serialises kernels, so it cannot happen inside a timed
+    (profiles/r06_pmc.json, made by tools/summarize_prof.py: counter collection serialises kernels, so it cannot happen inside a timed
     run); null when there is no such file for this workload"""
-    p = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc.json", "round5_pmc.json")) if os.path.exists(q)), None)
+    p = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r06_pmc.json", "r05_pmc.json", "round5_pmc.json")) if os.path.exists(q)), None)
     if p is None:
         return None
     d = json.load(open(p))
@@ -1074,9 +1076,10 @@ def main():
     # The critical path. The dominant kernel is launched several times per step on different streams (the persistent launch over the long
     # QUAL streams + the short-leaf launches of trials and section writer): its launches overlap, their sum is NOT time on the step's
     # critical path - the LONGEST launch is. That launch codes the long streams (sections of >= 1 MB); what bounds it is the issue rate
-    # of one wave per stream, not HBM: three dependent vector instructions per symbol + a lane hop every 8 symbols = 15.8 clocks at
-    # 2.4 GHz = 6.6 ns, measured with the loop alone on the device (tools/ubench_chain_f64.hip; rounds 1-3: seven scalar integer
-    # instructions, 12.7 ns).
+    # of one wave per stream, not HBM: three dependent vector instructions per symbol (12.07 clocks = 5.03 ns at 2.4 GHz: the floor) + a
+    # lane hop every 12 symbols, the checkpoints and the operand loads in the hops' wait states = 13.07 clocks = 5.46 ns with the loop alone
+    # on the device (tools/ubench_chain_f64.hip; round 5: 15.1, round 4: 15.8, rounds 1-3: seven scalar integer instructions, 12.7 ns).
+    # ns_per_symbol below is the whole launch / the symbols of its longest stream: it includes the wait for the first chunk's models.
     secs_all = [s for z in z_all for s in walk_sections(z)]
     long_secs = [s for s in secs_all if s[3] >= (1 << 20) and s[1] in (16, 17, 18, 19)]
     longest_ms = prof_max.get(dom, avg_launch_ms)
@@ -1085,7 +1088,7 @@ def main():
         sym = max(s[3] for s in long_secs)
         bytes_long = sum(s[3] + len(s[4]) for s in long_secs) * wl.calls_per_step
         crit = {"kernel": dom, "longest_launch_ms": round(longest_ms, 3), "streams_in_it": len(long_secs), "symbols_of_longest_stream": sym,
-                "ns_per_symbol": round(longest_ms * 1e6 / sym, 2), "issue_rate_floor_ns_per_symbol": CHAIN_FLOOR_NS,
+                "ns_per_symbol": round(longest_ms * 1e6 / sym, 2), "issue_rate_floor_ns_per_symbol": CHAIN_FLOOR_NS, "loop_alone_ns_per_symbol": CHAIN_ALONE_NS,
                 "issue_rate_frac": round(CHAIN_FLOOR_NS / (longest_ms * 1e6 / sym), 3),
                 "alg_bytes_in_it": bytes_long, "hbm_achieved_gbs": round(bytes_long / (longest_ms / 1e3) / 1e9, 3),
                 "hbm_frac": round(bytes_long / (longest_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 6),
