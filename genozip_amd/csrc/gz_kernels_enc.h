@@ -978,7 +978,9 @@ __device__ static void d_emit_unit (uint8_t *dst, uint32_t at, const GzdLeaf &L,
 // grid (streams, GZ_EMIT_SLICES). A section of GZ_EMIT_LONG bytes or more (the 3 MB QUAL sections at the very end of a step: one workgroup
 // took 0.5 ms over each) is written by all GZ_EMIT_SLICES workgroups of its column, a stretch of the payload each: the adler32 sums of the
 // stretches add up (gz_adler32_part), the last one through writes the header. Everything else is slice 0's alone.
+#ifndef GZ_EMIT_SLICES
 #define GZ_EMIT_SLICES 8
+#endif
 #define GZ_EMIT_LONG   (256u * 1024u)
 __global__ void __launch_bounds__(256) k_emit (GzdStream *streams, GzdLeaf *leaves, GzdVB *vbs)
 {
