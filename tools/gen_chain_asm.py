@@ -23,9 +23,11 @@ states (measured - without them the result is wrong), which is why a lane takes 
 carries meaning; what the other lanes compute is never looked at.
 
 Round 6 - what the loop paid for beyond its three instructions, measured (tools/probes/chain_regs_probe.py, profiles/r06_chain_regs_probe*.txt):
-  * AN 8-BYTE INSTRUCTION WHOSE ADDRESS IS NOT A MULTIPLE OF 8 COSTS ONE CLOCK MORE (5 instead of 4; the three instructions of a symbol
-    are all 8-byte encodings: 15.07 instead of 12.07 clocks a symbol, whatever registers they name). The hop's `s_nop 1` - the loop's only
-    4-byte instruction - flipped that parity at every lane, so every other lane's 12 symbols ran misaligned (13.8 clocks a symbol "bare").
+  * A RUN OF 8-BYTE INSTRUCTIONS WHOSE ADDRESSES ARE NOT MULTIPLES OF 8 ISSUES ONE PER 5 CLOCKS INSTEAD OF ONE PER 4 (the three instructions
+    of a symbol are all 8-byte encodings: 15.07 instead of 12.07 clocks a symbol, whatever registers they name; tools/probes/issue_probe.py:
+    every instruction costs a wave 4.07 clocks - 4 or 8 bytes, vector or scalar, dependent or not - and the fetch keeps up with 8 bytes a slot
+    only as aligned words; a 4-byte instruction in between pays the deficit back). The hop's `s_nop 1` - the loop's only 4-byte
+    instruction - flipped the parity at every lane, so every other lane's 36 instructions ran misaligned (13.8 clocks a symbol "bare").
     Now: `.p2align 3` in front of the loop, and 4-byte instructions only ever in pairs; the emitter below keeps count and
     tests/test_abi.py checks every 8-byte instruction's address in the assembled loop.
   * an instruction that has nothing to do with the chain costs 4 clocks wherever it stands (a load 13) - except in the two wait states
