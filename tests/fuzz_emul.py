@@ -24,6 +24,8 @@ import pyoracle              # noqa: E402
 
 
 def engine():
+    if os.environ.get("GZ_FUZZ_GPU"):                         # the real library on cuda:0 instead of the CPU stand-in (GPU box; round 6: the driver fuzz at sizes that fill many blocks of the chain's loop)
+        return Engine(device=0), pyoracle.Oracle()
     so = os.path.join(ROOT, "tests", "emul", "libgenozip_amd_emul.so")
     if not os.path.exists(so):
         import subprocess
@@ -131,7 +133,7 @@ def fuzz_driver(seed, seconds):
     rnd = random.Random(seed)
     t0 = time.time(); runs = bad = 0
     while time.time() - t0 < seconds:
-        nr = rnd.choice([9, 17, 33, 50, 77, 120])
+        nr = rnd.choice([9, 17, 33, 50, 77, 120]) if not os.environ.get("GZ_FUZZ_GPU") else rnd.choice([9, 50, 120, 333, 777, 1500, 2600, 4100, 5200 + rnd.randrange(0, 900)])
         q = tuple(rnd.choice(["uniform", "bin"]) for _ in range(2))
         domq, sf = rnd.choice([0, 0, 0, 1, 13]), rnd.random() < 0.4
         if rnd.random() < 0.5: os.environ["GZ_ZIP_SPECULATION"] = "always"
