@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 
 CHAIN_FLOOR_NS = 5.03           # three dependent vector instructions per symbol at the one-instruction-per-4-clocks issue rate of a wave: 12.07 clocks at 2.4 GHz - what no
                                 # arrangement of this formulation can beat (tools/probes/chain_regs_probe.py: `p_pad0`, profiles/r06_chain_regs_probe_aligned.txt)
-CHAIN_ALONE_NS = 5.46           # k_arith_chain's loop as it is, alone on the device: 13.07 clocks per symbol (profiles/r06_ubench_chain_fused.txt; round 5: 6.3, round 4: 6.6)
+CHAIN_ALONE_NS = 5.41           # k_arith_chain's loop as it is, alone on the device: 13.00 clocks per symbol (profiles/r06_ubench_chain_single.txt; round 5: 6.3, round 4: 6.6)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 METRIC = "input MB/s compressed (bit-exact .genozip) at 1/2/4/8 GPUs vs CPU ref"
 
@@ -1077,7 +1077,7 @@ def main():
     # QUAL streams + the short-leaf launches of trials and section writer): its launches overlap, their sum is NOT time on the step's
     # critical path - the LONGEST launch is. That launch codes the long streams (sections of >= 1 MB); what bounds it is the issue rate
     # of one wave per stream, not HBM: three dependent vector instructions per symbol (12.07 clocks = 5.03 ns at 2.4 GHz: the floor) + a
-    # lane hop every 12 symbols, the checkpoints and the operand loads in the hops' wait states = 13.07 clocks = 5.46 ns with the loop alone
+    # lane hop every 16 symbols, the checkpoints and the operand loads in the hops' wait states = 13.00 clocks = 5.41 ns with the loop alone
     # on the device (tools/ubench_chain_f64.hip; round 5: 15.1, round 4: 15.8, rounds 1-3: seven scalar integer instructions, 12.7 ns).
     # ns_per_symbol below is the whole launch / the symbols of its longest stream: it includes the wait for the first chunk's models.
     secs_all = [s for z in z_all for s in walk_sections(z)]

@@ -31,12 +31,13 @@ def codec_edge_cases(E, oracle, max_n, decode=True, thin_from=None):
 
 
 def chain_block_boundaries(E, oracle, big=True):
-    """the arithmetic coders around the sizes the range coder chain branches on: its loop takes blocks of 512 symbols (the rest of a
-    leaf goes symbol by symbol), position chunks are multiples of 4096 and at least 65536, striped codecs cut a stream into four
+    """the arithmetic coders around the sizes the range coder chain branches on: its loop takes blocks of 1024 symbols (round 6; 768 in
+    round 5, 512 before: the rest of a leaf goes symbol by symbol), position chunks are multiples of 4096 and at least 65536, striped codecs cut a stream into four
     planes, PACK into a quarter or half of the bytes; small totals (a context's first occurrences) anywhere"""
     ns = [511, 512, 513, 1024, 1025, 4095, 4096, 4097, 8703]                  # (the emulated build is slow: the GPU run takes more)
     if big:
-        ns += [1023, 1536, 2047, 2048, 2049, 8191, 8192, 65535, 65536, 65537, 66048, 131071, 131072, 131073, 131584, 196608 + 511, 262144 + 512 * 3 + 1, (1 << 20) + 300]
+        ns += [1023, 1536, 2047, 2048, 2049, 3071, 3072, 3073, 5121, 8191, 8192, 65535, 65536, 65537, 66048, 66559, 66560, 66561, 131071, 131072, 131073, 131584, 196608 + 511,
+               197632, 197633, 262144 + 512 * 3 + 1, (1 << 20) + 300]
     items, names = [], []
     seed = 9100
     for n in ns:

@@ -43,6 +43,12 @@ Round 6 - what the loop paid for beyond its three instructions, measured (tools/
     the old form (v_mov_b32_dpp wave_ror:1, then the fma). 13.35 -> 13.07 clocks a symbol alone, default step 39.7 -> 38.7 ms
     (profiles/r06_ubench_chain_fused.txt, r06_ab_chain_fused.txt; 8 / 10 / 16 symbols a lane: 13.45 / - / 12.85 alone, no better in the
     step - the 52 KB of the 16-symbol loop do not stay in the instruction cache beside the other kernels: 43.5 ms).
+  * ONE COPY OF THE BLOCK'S CODE, 16 SYMBOLS A LANE. The loop used to be two copies of the block (the register sets taking turns): 39 KB at 12
+    symbols a lane, and the instruction cache is shared with a compute unit that runs the model kernels (+ 4.6 % in the step against alone).
+    Now the one block always reads set 0; the next block's operands are loaded and made in set 1 as before and moved over at the block's end
+    (2 PER + 2 `v_mov_b64`, 4 bytes each, an even number: 0.13 clocks a symbol at 16 a lane). 26 KB at 16 symbols a lane (1024-symbol blocks,
+    a checkpoint always at a lane's first symbol): 13.00 clocks a symbol alone, the chain's launch 35.3 -> 34.35 ms in the step (12 / 24 a lane in
+    one copy: 13.23 / 12.82 alone, 34.7 / 35.1 in the step). profiles/r06_ubench_chain_single.txt, r06_ab_chain_single.txt.
 
 Everything between the labels is written here, loop control included: the compiler schedules nothing in it. The rest of a leaf that
 does not fill a block is the caller's.
@@ -55,9 +61,11 @@ import sys
 X_CKPT = int(os.environ.get("GZ_GEN_CKPT", "64"))            # a checkpoint every so many symbols (0: none - WRONG results, timing only)
 X_FILL = os.environ.get("GZ_GEN_FILL", "1") == "1"           # 0: the hops' wait states are s_nop, loads and shifts at the head of a block (aligned all the same)
 X_FUSE = os.environ.get("GZ_GEN_FUSE", "1") == "1"           # 1: a hop inside a row of 16 lanes is the second fma itself (v_fmac_f64_dpp row_newbcast), 0: every hop moves r first
+X_SINGLE = os.environ.get("GZ_GEN_SINGLE", "1") == "1"       # 1: ONE copy of a block's code - the next block's operands are made in the second register set as before and
+                                                             #    moved into the first at the block's end (half the code for PER + 2 v_mov_b64 per block)
 X_ALIGN = os.environ.get("GZ_GEN_ALIGN", "1") == "1"         # 0: no .p2align, a single s_nop 1 in the hops (round 5's parity flips: for A / B)
 
-PER = int(os.environ.get("GZ_GEN_PER", "12"))    # symbols a lane takes in a row
+PER = int(os.environ.get("GZ_GEN_PER", "16"))    # symbols a lane takes in a row
 BLOCK = 64 * PER
 REC = 12                                         # bytes per record
 
@@ -92,7 +100,7 @@ DPP = "wave_ror:1 row_mask:0xf bank_mask:0xf"
 NOP2 = ["s_nop 0", "s_nop 0"]                           # two wait states in eight bytes
 
 _INLINE_F = {"0.5", "-0.5", "1.0", "-1.0", "2.0", "-2.0", "4.0", "-4.0"}
-_FOUR = ("s_nop", "s_waitcnt", "s_cbranch", "s_cmp", "s_mov_b32", "s_add_u32", "s_addc_u32", "s_sub_u32", "s_cselect_b32", "v_mov_b32", "v_mul_u32_u24", "v_xor_b32", "v_mov_b64")
+_FOUR = ("s_nop", "s_waitcnt", "s_cbranch", "s_branch", "s_cmp", "s_mov_b32", "s_add_u32", "s_addc_u32", "s_sub_u32", "s_cselect_b32", "v_mov_b32", "v_mul_u32_u24", "v_xor_b32", "v_mov_b64")
 _EIGHT = ("v_fma_f64", "v_and_or_b32", "v_lshlrev_b64", "global_load", "global_store", "s_store", "v_readlane_b32", "v_mbcnt")
 
 
@@ -278,10 +286,19 @@ def body():
     block(a, SETS[0], SETS[1], "0")
     a("s_cmp_eq_u32 s42, 0")
     a("s_cbranch_scc1 9f")
-    a.label("4")
-    block(a, SETS[1], SETS[0], "1")
-    a("s_cmp_lg_u32 s42, 0")
-    a("s_cbranch_scc1 3b")
+    if X_SINGLE:                                             # the next block's operands into the registers the (one) block reads
+        for k in range(PER):
+            a(f"v_mov_b64 {SETS[0]['inv'][k]}, {SETS[1]['inv'][k]}")
+            a(f"v_mov_b64 {SETS[0]['F'][k]}, {SETS[1]['F'][k]}")
+        a(f"v_mov_b64 {SETS[0]['Fp']}, {SETS[1]['Fp']}")
+        a(f"v_mov_b64 {SETS[0]['NFp']}, {SETS[1]['NFp']}")
+        a("s_branch 3b")
+        a("s_nop 0")
+    else:
+        a.label("4")
+        block(a, SETS[1], SETS[0], "1")
+        a("s_cmp_lg_u32 s42, 0")
+        a("s_cbranch_scc1 3b")
     a.label("9")
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")
     a("s_nop 1")
