@@ -577,7 +577,7 @@ static int arith_pipe_setup (GzHandle *h, Plan &P, ArithPipe &A)
     uint32_t want_chunks = 32;                                  // (16 -> 32: the first chunk's models are the lead-in of the long streams; default step 96.2 -> 95.1 ms, streamed 280.8 -> 277.1)
     if (const char *e = getenv ("GZ_ARITH_CHUNKS")) { const int v = atoi (e); if (v >= 1) want_chunks = (uint32_t)std::min (v, GZ_MAX_CHUNKS - 1 - 6); }   // (experiments; the first- / last-chunk splits below add up to 3 bounds each: n_chunks stays within GZ_MAX_CHUNKS - ev_sort[], the ctxend rows)
     // (whole sort tiles AND whole blocks of the chain's loop: what a chunk leaves over goes one symbol at a time, d_chain_slow - with blocks
-    //  of 768 symbols and chunks of whole tiles only, 256 symbols of every chunk did)
+    //  of 768 symbols - round 5 - and chunks of whole tiles only, 256 symbols of every chunk did; round 6's blocks of 1024 divide the tiles)
     uint32_t unit = GZ_CTX_TILE;
     while (unit % GZ_CHAIN_BLOCK) unit += GZ_CTX_TILE;
     A.chunk = (P.max_arith_n + want_chunks - 1) / want_chunks;

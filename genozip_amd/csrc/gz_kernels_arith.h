@@ -1327,11 +1327,13 @@ __global__ void __launch_bounds__(64 * GZ_TM_WAVES) k_arith_model_tiled (GzdLeaf
 //                      R = fma (T, F, -F)                F = freq * 2^45: r * freq * 2^-7, exact
 //                      R.hi = R.hi & 0x7fffff | 0x41000000     the exponent's low three bits stay, the others become those of
 //                                                        [2^24, 2^32): exactly "shift left by whole bytes until >= 2^24"
-//                  and NO operand fetch in the loop: lane j holds the operands of symbols base + 12 j .. + 11 (12-byte records
-//                  loaded coalesced a block of 768 symbols ahead, straight into the registers the loop reads), all lanes
-//                  execute every step, the state hops to the next lane through a DPP read of r - after the 12
-//                  symbols a lane holds, because a DPP read of a fresh result costs two wait states (gz_chain_asm.h, written by
-//                  tools/gen_chain_asm.py): ~15.8 clocks = 6.6 ns per symbol, the same with 1 or 64 chains on the device. It never looks at cum or low, and stores only the state
+//                  and NO operand fetch in the loop: lane j holds the operands of symbols base + 16 j .. + 15 (12-byte records
+//                  loaded coalesced a block of 1024 symbols ahead, in the wait states of the lane hops), all lanes
+//                  execute every step, the state hops to the next lane through a DPP read - inside a row of 16 lanes the second
+//                  fma itself (v_fmac_f64_dpp row_newbcast) - after the 16 symbols a lane holds, because a DPP read of a fresh
+//                  result costs two wait states (gz_chain_asm.h, written by tools/gen_chain_asm.py: one copy of a block's code, every
+//                  8-byte instruction on an 8-byte boundary): 13.0 clocks = 5.4 ns per symbol, the same with 1 or 64 chains on the
+//                  device (round 5: 15.1, round 4: 15.8). It never looks at cum or low, and stores only the state
 //                  before every 64th symbol: k_chain_expand recomputes r = range / tot of every symbol from those for the low
 //                  kernels - with the plain formulation of the same arithmetic (an integer multiply), and checks that it arrives
 //                  at the chain's next checkpoint: the two check each other on every 64 symbols of every stream.
