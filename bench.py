@@ -567,16 +567,7 @@ def text_leg(a, WL):
     os.environ["GZ_ZIP_PRIOR_ONLY"] = "1"
     for _ in range(max(1, a.warmup)):
         wl.step(None)
-    E.profile(True, reset=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        wl.step(None)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    E.profile(False)
-    prof = E.profile_results()
-    prof_max = dict(E.profile_max)
+    dt, prof, prof_max, prof_table = profiled_steps(E, lambda: wl.step(None), a.steps, torch.cuda.synchronize)
     ms = dt / a.steps * 1e3
     # warm: a handle that has seen a file of the kind codes every stream ahead of its context's trial with the codec that file got (gz_zip_prediction)
     warm = None
@@ -629,7 +620,7 @@ def text_leg(a, WL):
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
                         "avg_launch_ms": round(dom_ms / dom_n, 4), "launches_per_step": dom_n / a.steps, "longest_launch_ms": round(prof_max.get(dom, 0), 3),
                         "long_streams": len(long_secs), "symbols_of_longest_stream": max([s_[3] for s_ in long_secs] + [0]),
-                        "kernel_ms_per_step_summed_over_concurrent_launches": {k: round(v[0] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]}}}
+                        "kernel_ms_per_step_summed_over_concurrent_launches": kernel_table(prof, prof_table, a.steps, 12)}}
     if warm:
         warm["value"] = round(wl.value_bytes / 1e6 / (warm["ms_per_step"] / 1e3), 1)
         out["warm"] = warm
@@ -796,6 +787,38 @@ def cpu_decode_leg(z_all):
         return {"cpu_decode_mb_s": None, "cpu_decode_note": repr(e)[:200]}
 
 
+def kernel_table(prof, table, n_steps, top):
+    """ms per step by kernel: the timed steps' figures where a kernel was timed there, the untimed step's otherwise"""
+    t = dict(table)
+    t.update({k: v[0] / n_steps for k, v in prof.items()})
+    return {k: round(v, 3) for k, v in sorted(t.items(), key=lambda kv: -kv[1])[:top]}
+
+
+def profiled_steps(E, step, n_steps, sync):
+    """The timed region. Every kernel launch between two HIP events costs the host as much as the launch itself (~700 launches a step): the
+    table of all kernels comes from ONE untimed step in front (gz_profile mode 1), the timed steps carry events only on the launches of the two
+    kernels a step can be as long as (mode 2: k_arith_chain, k_arith_model - the dominant kernel of every configuration is one of them; its
+    launches are timed live, over the timed region, on the streams they run on). -> (seconds, {kernel: (ms, launches)} of the timed steps,
+    {kernel: longest launch}, {kernel: ms per step} of the untimed step)"""
+    mode = int(os.environ.get("GZ_BENCH_PROF_MODE", "2"))          # (1: every launch in the timed region as well, as rounds 1 - 5 did)
+    E.profile(True, reset=True)
+    step()
+    sync()
+    E.profile(False)
+    table = {k: v[0] for k, v in E.profile_results().items()}
+    E.profile(mode, reset=True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    E.profile(False)
+    prof = E.profile_results()
+    return dt, prof, dict(E.profile_max), table
+
+
+
 def config_leg(a):
     """--stream-level: BASELINE configs[2] (BAM-1M) / configs[3] (VCF 10 k samples, one GPU's share) entered at the CONTEXT-STREAM level - the
     context streams of SURVEY 8(0) generated at the sizes the reference would give them; a step = b250 generation + local byte order /
@@ -952,19 +975,20 @@ def main():
     for _ in range(a.warmup):
         gather_to_rank0(wl.step(dist))
     gather_wait()
-    E.profile(True, reset=True)
-    shard_mod.reset_stats()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
+    def one_step():
         gather_to_rank0(wl.step(dist))
-    gather_wait()
-    barrier()
-    dt = time.perf_counter() - t0
-    E.profile(False)
+
+    def drain():
+        gather_wait()
+        barrier()
+
+    def timed_sync():                                          # (the statistics of the exchange count the timed steps only)
+        drain()
+        if not timed_sync.armed:
+            shard_mod.reset_stats(); timed_sync.armed = True
+    timed_sync.armed = False
+    dt, prof, prof_max, prof_table = profiled_steps(E, one_step, a.steps, timed_sync)
     coll = dict(shard_mod.STATS)
-    prof = E.profile_results()
-    prof_max = dict(E.profile_max)
     warm_ms = None
     del os.environ["GZ_ZIP_PRIOR_ONLY"]
     if prior_user is not None and not a.warm_steps:
@@ -1100,8 +1124,10 @@ def main():
                 "critical_path": crit,
                 "whole_step": {"alg_bytes": int(text_b / world + z_total * wl.calls_per_step), "achieved_gbs": round((text_b / world + z_total * wl.calls_per_step) / (ms_per_step / 1e3) / 1e9, 2),
                                "frac": round((text_b / world + z_total * wl.calls_per_step) / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS, 6), "note": "T + Z of one step / step time (SURVEY 8d, per pipeline unit)"},
-                "kernel_ms_per_step_summed_over_concurrent_launches": {k: round(v[0] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:24]},
-                "note": "kernel_ms_per_step_summed_over_concurrent_launches adds up launches that run side by side on different streams: a sum of device time, not a critical path"}
+                "kernel_ms_per_step_summed_over_concurrent_launches": kernel_table(prof, prof_table, a.steps, 24),
+                "note": "kernel_ms_per_step_summed_over_concurrent_launches adds up launches that run side by side on different streams: a sum of device time, not a critical path; "
+                        "k_arith_chain / k_arith_model: HIP events over the timed steps, the other kernels: one untimed step in front of them (events on every launch cost the host "
+                        "as much as the launches do: GZ_BENCH_PROF_MODE=1 times everything inside the timed region, as rounds 1 - 5 did)"}
 
     codecs = {}
     for z in z_all[:1] + z_all[len(z_all) // 2:len(z_all) // 2 + 1]:

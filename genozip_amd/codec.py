@@ -399,6 +399,7 @@ class Engine:
         return self._check(self.L.gz_sync(self.h), "gz_sync")
 
     def profile(self, enable=True, reset=False):
+        """enable: False / True / 2 (only k_arith_chain and k_arith_model: gz_profile)"""
         self.L.gz_profile(self.h, int(enable), int(reset))
 
     def compress_lines(self, codec, lines, capacity=None, soft_fail=False):

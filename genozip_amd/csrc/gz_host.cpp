@@ -90,7 +90,7 @@ struct GzHandle {
     std::string err;
     size_t arena_block_size;
     // optional per-kernel timing with HIP events on this handle's stream (bench.py's roofline object)
-    bool profiling = false;
+    int profiling = 0;        // gz_profile: 0 off, 1 every kernel launch between two events, 2 only the two kernels a step can be as long as (k_arith_chain, k_arith_model)
     struct ProfRec { const char *name; hipEvent_t a, b; };
     std::vector<ProfRec> prof_open;
     std::vector<hipEvent_t> event_pool;            // (creating and destroying two events per launch costs more than the launch)
@@ -120,11 +120,14 @@ static inline hipEvent_t gz_event_get (GzHandle *h)
 }
 
 // KLAUNCH: hipLaunchKernelGGL bracketed by two events when profiling is on
+// (mode 2: two events per launch are 4 - 5 us of host time, ~700 launches a step - as much as the launches themselves; the heavy kernels are a few dozen)
+#define GZ_PROF_HEAVY(name) (!__builtin_strcmp (name, "k_arith_chain") || !__builtin_strncmp (name, "k_arith_model", 13))
 #define KLAUNCH_ON(h, strm, kern, grid, block, shmem, ...) do { \
     GzHandle::ProfRec pr_; pr_.name = #kern; \
-    if ((h)->profiling) { pr_.a = gz_event_get (h); pr_.b = gz_event_get (h); (void)hipEventRecord (pr_.a, (strm)); } \
+    const bool prof_ = (h)->profiling == 1 || ((h)->profiling == 2 && GZ_PROF_HEAVY (#kern)); \
+    if (prof_) { pr_.a = gz_event_get (h); pr_.b = gz_event_get (h); (void)hipEventRecord (pr_.a, (strm)); } \
     hipLaunchKernelGGL (kern, grid, block, shmem, (strm), __VA_ARGS__); \
-    if ((h)->profiling) { (void)hipEventRecord (pr_.b, (strm)); (h)->prof_open.push_back (pr_); } } while (0)
+    if (prof_) { (void)hipEventRecord (pr_.b, (strm)); (h)->prof_open.push_back (pr_); } } while (0)
 #define KLAUNCH(h, kern, grid, block, shmem, ...) KLAUNCH_ON (h, (h)->stream, kern, grid, block, shmem, __VA_ARGS__)
 
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
@@ -284,7 +287,7 @@ extern "C" void gz_profile (GzHandle *h, int enable, int reset)
 {
     if (!h) return;
     if (h->pending.empty ()) prof_collect (h);          // (everything recorded so far has been synchronised)
-    h->profiling = enable != 0;
+    h->profiling = enable == 2 ? 2 : enable != 0;
     if (reset) h->prof.clear ();
     for (GzHandle *o : h->helpers) gz_profile (o, enable, reset);
 }

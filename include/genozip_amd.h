@@ -63,7 +63,8 @@ const char *gz_version (void);
 /* Per-kernel timing: when enabled, every kernel launch of the compression pipeline is bracketed by two HIP events on
  * the handle's stream; gz_sync() folds them into per-kernel totals (this is the reference's --show-time /
  * START_TIMER..COPY_TIMER instrumentation, src/profiler.h:96-166, re-expressed for a GPU stream).
- * gz_profile_get(idx) enumerates the accumulated entries until it returns 0. */
+ * gz_profile_get(idx) enumerates the accumulated entries until it returns 0. enable = 2: only the launches of the two kernels a step can
+ * be as long as (k_arith_chain, k_arith_model) - the events of ALL launches cost the host as much as the launches do (~700 a step). */
 void gz_profile (GzHandle *h, int enable, int reset);
 int  gz_profile_get (GzHandle *h, int idx, char *name, int name_cap, double *total_ms, int *launches);
 /* the longest single launch of entry idx of the walk begun with gz_profile_get (h, 0, ...) */
