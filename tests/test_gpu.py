@@ -641,3 +641,24 @@ def test_sam_and_vcf_drivers_at_size(gpu_engine, oracle):
     assert parity.sam_zip(gpu_engine, oracle, 120000, n_calls=1, tags=True) == 2
     assert parity.sam_zip(gpu_engine, oracle, 120000, n_calls=1, qual="uniform", aux=False) == 2
     assert parity.vcf_zip(gpu_engine, oracle, 400, 2000, n_calls=1) == 2
+
+
+def test_profile_modes(gpu_engine, oracle):
+    """gz_profile: 1 = every kernel launch between two HIP events, 2 = only the two kernels a step can be as long as (k_arith_chain,
+    k_arith_model) - bench.py times its steps in mode 2 (events on ~700 launches a step cost the host as much as the launches) and takes the
+    per-kernel table from one untimed step in mode 1. The coded bytes do not depend on the mode."""
+    E = gpu_engine
+    data = synth.quality_diverse(1, 3000).tobytes()
+    want = oracle.codec_compress(16, data)
+    E.profile(True, reset=True)
+    assert E.compress_many([(16, data), (6, data)])[0] == want
+    E.profile(False)
+    full = E.profile_results()
+    assert "k_arith_chain" in full and any(k.startswith("k_arith_model") for k in full) and len(full) > 6, sorted(full)
+    E.profile(2, reset=True)
+    assert E.compress_many([(16, data), (6, data)])[0] == want
+    E.profile(False)
+    heavy = E.profile_results()
+    assert heavy and all(k == "k_arith_chain" or k.startswith("k_arith_model") for k in heavy), sorted(heavy)
+    assert heavy["k_arith_chain"][1] == full["k_arith_chain"][1]                      # the same launches, the same count
+    E.profile(False, reset=True)
