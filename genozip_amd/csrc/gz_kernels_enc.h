@@ -433,7 +433,9 @@ __device__ static uint32_t d_rans_encode_wave (uint32_t len_k, uint32_t rounds, 
             //  reaches any x_max - the smallest is 8 << 16 -, records past the end of a list are `idle`)
             uint32_t used_v = used;
             const uint32_t len_eff = lane < 4 ? len_k : 0u, hi_bits = lane < 4 ? 0xfu >> lane : 0u;
-            for (uint32_t j = 0; j < nb; j++) {
+            // (a full batch of 16 rounds is unrolled - round 6: the rolled loop was 38 instructions and a taken branch per round, a third of
+            //  them loop control and the copy of the prefetched record; with j a constant the record's LDS address is an immediate)
+            auto one_round = [&] (uint32_t j) __attribute__((always_inline)) {
                 const uint32_t r = r_hi - 1 - j;
                 GzRansSym s;
                 s.x_max = cur.x; s.rcp = cur.y; s.bias = cur.z; s.cmpl_rsh = cur.w;
@@ -443,11 +445,16 @@ __device__ static uint32_t d_rans_encode_wave (uint32_t len_k, uint32_t rounds, 
                 const uint32_t below = gz_mbcnt ((uint64_t)mlo);
                 used_v += 2 * (below + (uint32_t)__popcll ((unsigned long long)((mlo >> (lane & 31)) & hi_bits)));   // every lane 0..3: the whole count
                 const uint32_t off = emit ? cap - used_v + 2 * below : 2u * (uint32_t)(lane & 3);
-                if (lane < 4) gz_stg_u16 (buf + off, x);
+                gz_stg_u16 (buf + off, x);                               // (every lane: lanes 4.. never emit, they hit the dump slots too - no exec window, no branch)
                 x = emit ? x >> 16 : x;
                 const uint32_t xn = d_rans_advance (x, s);
                 x = r < len_eff ? xn : x;
+            };
+            if (nb == 16) {
+                #pragma unroll
+                for (uint32_t j = 0; j < 16; j++) one_round (j);
             }
+            else for (uint32_t j = 0; j < nb; j++) one_round (j);
             used = d_uniform_u32 (used_v);
             r_hi -= nb;
             continue;
